@@ -1,0 +1,181 @@
+/* lps_abi.h — C-ABI of liblps_hip.so: the MI355X-native (gfx950) implementation of LongPhase-S's
+ * read->variant allele scoring + haplotype-graph phasing hot path.
+ *
+ * The reference has no FFI layer: the path is reached by direct C++ calls from its per-chromosome OpenMP
+ * loops.  This header is the seam a maintainer binds instead (INTEGRATION.md shows the call-site patch):
+ *
+ *   phase     src/phase/PhasingProcess.cpp:128-158   BamParser::direct_detect_alleles -> SnpParser::filterSNP
+ *                                                    -> Clip -> VairiantGraph::addEdge/phasingProcess/exportResult
+ *   haplotag  src/haplotag/HaplotagParsingBam.cpp:482 ChromosomeProcessor::processRead
+ *                                                    -> GermlineHaplotagChrProcessor::judgeHaplotype
+ *                                                       (src/haplotag/HaplotagProcess.cpp:363)
+ *
+ * Conventions: plain pointers + sizes, no C++/torch types.  All input pointers are HOST pointers unless a
+ * function name ends in _device.  The caller owns every buffer it passes for the duration of the call; the
+ * library owns device memory inside lps_ctx.  Functions return 0 on success, <0 on error
+ * (lps_last_error(ctx) gives the message; the reference prints to stderr and exit(1)s in the same places).
+ * A ctx is single-threaded and bound to one GPU; one ctx processes one chromosome at a time.
+ */
+#ifndef LPS_ABI_H
+#define LPS_ABI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPS_ABI_VERSION 1
+#define LPS_MAX_ADJACENT 64 /* upper bound for lps_params.connect_adjacent (reference default 35) */
+
+typedef struct lps_ctx lps_ctx;
+
+/* PhasingParameters (src/phase/PhasingProcess.h:7-41) + haplotag thresholds (src/haplotag/Haplotag.cpp:60-72).
+ * Defaults in comments are the reference's (src/phase/Phasing.cpp:88-116). */
+typedef struct lps_params {
+    int32_t is_ont;            /* --ont=1 / --pb=0 : ONT enables SnpParser::filterSNP               */
+    int32_t phase_indel;       /* --indels (informational: indel rows simply appear in the table)   */
+    int32_t distance;          /* -d 300000                                                          */
+    int32_t connect_adjacent;  /* -a 35                                                              */
+    int32_t mapping_quality;   /* -q 1                                                               */
+    int32_t base_quality;      /* -p 12                                                              */
+    double edge_weight;        /* -e 0.1                                                             */
+    double snp_confidence;     /* -n 0.75                                                            */
+    double read_confidence;    /* -m 0.65                                                            */
+    double edge_threshold;     /* -1 0.7                                                             */
+    double overlap_threshold;  /* -L 0.2                                                             */
+    /* haplotag */
+    double percentage_threshold; /* -p 0.6                                                           */
+    int32_t tag_supplementary;   /* --tagSupplementary                                               */
+    int32_t reserved;
+} lps_params;
+
+void lps_default_params(lps_params *p);
+
+/* Per-chromosome variant table = std::map<int,RefAlt> (src/phase/ParsingBam.h:16-23,58), position-sorted.
+ * ref0/alt0 are the first characters of REF/ALT exactly as they stand in the VCF; ref_len/alt_len the allele
+ * string lengths (1/1 = SNP, 1/>1 = insertion, >1/1 = deletion).
+ * haplotag only (src/haplotag/HaplotagType.h:110-144 VarData): hp1_is_alt = 1 when HP1 carries ALT ("1|0"),
+ * phase_set = PS value.  Pass NULL for both in `phase`. */
+typedef struct lps_variant_table {
+    int64_t n;
+    const int32_t *pos;      /* 0-based, strictly increasing */
+    const uint8_t *ref0;
+    const uint8_t *alt0;
+    const uint16_t *ref_len;
+    const uint16_t *alt_len;
+    const uint8_t *hp1_is_alt; /* haplotag */
+    const int32_t *phase_set;  /* haplotag */
+} lps_variant_table;
+
+/* Decoded alignments of ONE chromosome in BAM (coordinate) order = what sam_itr_multi_next hands to
+ * BamParser::get_snp (src/phase/ParsingBam.cpp:1279-1293).  SoA; variable-length parts are the BAM record's
+ * own encodings so packing is a memcpy of bam_get_cigar/bam_get_seq/bam_get_qual:
+ *   cigar  uint32 words, oplen<<4|op            (cigar_off[i]..cigar_off[i+1])
+ *   seq    4-bit packed, (l_qseq+1)/2 bytes/read (seq_off[i].. byte offsets)
+ *   qual   l_qseq bytes/read                     (qual_off[i]..)
+ * name_id: rank of the read name among all names of the batch set under byte-wise std::string ordering
+ * (equal names <=> equal id).  The reference iterates merged reads in std::map<std::string,...> order
+ * (src/phase/PhasingGraph.cpp:697,848) and float edge sums depend on that order.
+ * Any order-preserving integer works (ids need not be dense). */
+typedef struct lps_read_batch {
+    int64_t n_reads;
+    const int32_t *ref_start;  /* core.pos */
+    const uint16_t *flag;      /* core.flag */
+    const uint8_t *mapq;       /* core.qual */
+    const int32_t *l_qseq;     /* core.l_qseq */
+    const uint32_t *name_id;
+    const uint64_t *cigar_off; /* n_reads+1 */
+    const uint32_t *cigar;
+    const uint64_t *seq_off;   /* n_reads+1 */
+    const uint8_t *seq;
+    const uint64_t *qual_off;  /* n_reads+1 */
+    const uint8_t *qual;
+} lps_read_batch;
+
+/* Result of one chromosome = PhasingResult entries (src/shared/Util.h:18-24) indexed like the variant
+ * table: phase_set[i] = PS (block start position + 1) or 0 when variant i is not phased;
+ * gt[i] = 0 for "0|1", 1 for "1|0" (only meaningful where phase_set[i] != 0).  Caller allocates n entries. */
+typedef struct lps_phase_result {
+    int64_t n;
+    int32_t *phase_set;
+    uint8_t *gt;
+} lps_phase_result;
+
+/* Per-read haplotag scores (inputs of GermlineHaplotagStrategy::judgeReadHap,
+ * src/haplotag/HaplotagStrategy.cpp:243-300).  Caller allocates n_reads entries of each.
+ *  status: 0 scored; 1 low MAPQ; 2 unmapped; 3 secondary; 4 supplementary (untagged); 5 empty table;
+ *          6 start beyond last variant   (the filter cascade of HaplotagParsingBam.cpp:453-486)
+ *  hp1/hp2: hpCount[GERMLINE_H1/H2]; n_ps: number of distinct PS seen (saturating at 255); ps_min: smallest.
+ *  hp/pq/ps: the decision of judgeReadHap (hp 0 = untagged, 1, 2).  pq uses the host's libm log10
+ *   and is filled by the host side of the library from the integer counts. */
+typedef struct lps_haplotag_result {
+    int64_t n_reads;
+    uint8_t *status;
+    int32_t *hp1;
+    int32_t *hp2;
+    uint8_t *n_ps;
+    int32_t *ps_min;
+    uint8_t *hp;
+    int32_t *pq;
+    int32_t *ps;
+} lps_haplotag_result;
+
+/* Stage timings of the last lps_phase_chromosome / lps_haplotag call, measured with hipEvents on the
+ * library's stream.  ms_kernel[i] pairs with lps_stage_name(i). */
+#define LPS_MAX_STAGES 24
+typedef struct lps_timings {
+    int32_t n_stages;
+    float ms_kernel[LPS_MAX_STAGES];
+    float ms_total;            /* first launch -> last result byte in host memory */
+    int64_t n_obs;             /* read x variant observations after filters */
+    int64_t n_nodes;           /* graph nodes */
+    int64_t n_pairs;           /* edge increments applied */
+    int64_t n_reads_used;      /* alignments with >=1 observation */
+    int64_t algorithmic_bytes[LPS_MAX_STAGES]; /* SURVEY.md §8d closed forms evaluated on this input */
+} lps_timings;
+
+int lps_abi_version(void);
+int lps_device_count(void);
+
+lps_ctx *lps_create(int device, const lps_params *params);
+void lps_destroy(lps_ctx *ctx);
+const char *lps_last_error(lps_ctx *ctx);
+
+/* Start a new chromosome: drops reads/variants/reference held by the ctx (device buffers are reused). */
+int lps_begin_chromosome(lps_ctx *ctx);
+/* getVariants_markindel + getLastSNP (src/phase/ParsingBam.cpp:378-417,426-441). */
+int lps_set_variants(lps_ctx *ctx, const lps_variant_table *table);
+/* Reference bases of the chromosome; the library applies FastaParser's truncation to [0,lastVariant+5]
+ * (src/phase/ParsingBam.cpp:47) itself.  May be shorter than the contig as long as it covers that prefix. */
+int lps_set_reference(lps_ctx *ctx, const char *seq, int64_t len);
+/* Append decoded alignments (H2D copy).  May be called repeatedly (batches / several BAM files). */
+int lps_push_reads(lps_ctx *ctx, const lps_read_batch *batch);
+
+/* phase: everything between direct_detect_alleles and exportResult for the reads pushed so far.
+ * Recomputes from the resident raw reads on every call (nothing is cached between calls). */
+int lps_phase_chromosome(lps_ctx *ctx, lps_phase_result *out);
+/* haplotag: per-read scoring of the reads pushed so far against the phased table. */
+int lps_haplotag_chromosome(lps_ctx *ctx, lps_haplotag_result *out);
+
+int lps_get_timings(lps_ctx *ctx, lps_timings *t);
+const char *lps_stage_name(int stage);
+/* The hipStream_t (as void*) all kernels of this ctx are launched on. */
+void *lps_stream(lps_ctx *ctx);
+
+/* ---- stage dumps for parity tests (valid after lps_phase_chromosome; host buffers, caller-allocated) ---- */
+/* Observations in canonical order (alignment index, then position): per kept alignment
+ * obs_count[read] entries.  Returns total or <0.  Pass NULL arrays to query the total only. */
+int64_t lps_dump_observations(lps_ctx *ctx, int32_t *obs_count /*n_reads*/, int32_t *var_index, int8_t *allele,
+                              int8_t *quality, int64_t capacity);
+/* Graph nodes (variant indices, ascending) and the dense edge matrix [n_nodes][connect_adjacent][4]
+ * (cell order rr, ra, ar, aa = (allele_i<<1)|allele_j).  Returns n_nodes. */
+int64_t lps_dump_graph(lps_ctx *ctx, int32_t *node_var_index, float *edge, int64_t node_capacity);
+/* Vote scan output per node: hp (0 none,1,2) and block start node (-1 none). */
+int64_t lps_dump_votes(lps_ctx *ctx, int8_t *hp, int32_t *block_node, int64_t node_capacity);
+/* Clip events counted by getClip (src/phase/ParsingBam.cpp:1636-1645): (ref_pos, 0 FRONT / 1 BACK). */
+int64_t lps_dump_clips(lps_ctx *ctx, int32_t *pos, uint8_t *front_back, int64_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

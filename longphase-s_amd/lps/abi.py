@@ -1,0 +1,142 @@
+"""ctypes mirror of include/lps_abi.h (structs + array packing helpers).
+
+Used by the test harness, bench.py and __graft_entry__ to drive liblps_hip.so through its C-ABI, and by the
+tests to drive the CPU oracle (oracle/liblps_oracle.so) with the very same structs.
+"""
+import ctypes as C
+import numpy as np
+
+LPS_MAX_STAGES = 24
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("is_ont", C.c_int32), ("phase_indel", C.c_int32), ("distance", C.c_int32),
+        ("connect_adjacent", C.c_int32), ("mapping_quality", C.c_int32), ("base_quality", C.c_int32),
+        ("edge_weight", C.c_double), ("snp_confidence", C.c_double), ("read_confidence", C.c_double),
+        ("edge_threshold", C.c_double), ("overlap_threshold", C.c_double),
+        ("percentage_threshold", C.c_double), ("tag_supplementary", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+def default_params(**kw):
+    """Reference defaults: src/phase/Phasing.cpp:88-116, src/haplotag/Haplotag.cpp:60-72."""
+    p = Params(is_ont=1, phase_indel=0, distance=300000, connect_adjacent=35, mapping_quality=1,
+               base_quality=12, edge_weight=0.1, snp_confidence=0.75, read_confidence=0.65,
+               edge_threshold=0.7, overlap_threshold=0.2, percentage_threshold=0.6, tag_supplementary=0,
+               reserved=0)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class VariantTable(C.Structure):
+    _fields_ = [("n", C.c_int64), ("pos", C.c_void_p), ("ref0", C.c_void_p), ("alt0", C.c_void_p),
+                ("ref_len", C.c_void_p), ("alt_len", C.c_void_p), ("hp1_is_alt", C.c_void_p),
+                ("phase_set", C.c_void_p)]
+
+
+class ReadBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("ref_start", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p),
+                ("l_qseq", C.c_void_p), ("name_id", C.c_void_p), ("cigar_off", C.c_void_p),
+                ("cigar", C.c_void_p), ("seq_off", C.c_void_p), ("seq", C.c_void_p), ("qual_off", C.c_void_p),
+                ("qual", C.c_void_p)]
+
+
+class PhaseResult(C.Structure):
+    _fields_ = [("n", C.c_int64), ("phase_set", C.c_void_p), ("gt", C.c_void_p)]
+
+
+class HaplotagResult(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("status", C.c_void_p), ("hp1", C.c_void_p), ("hp2", C.c_void_p),
+                ("n_ps", C.c_void_p), ("ps_min", C.c_void_p), ("hp", C.c_void_p), ("pq", C.c_void_p),
+                ("ps", C.c_void_p)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("n_stages", C.c_int32), ("ms_kernel", C.c_float * LPS_MAX_STAGES), ("ms_total", C.c_float),
+                ("n_obs", C.c_int64), ("n_nodes", C.c_int64), ("n_pairs", C.c_int64), ("n_reads_used", C.c_int64),
+                ("algorithmic_bytes", C.c_int64 * LPS_MAX_STAGES)]
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Variants:
+    """Host-side variant table (keeps the numpy arrays alive next to the ctypes struct)."""
+
+    def __init__(self, pos, ref, alt, hp1_is_alt=None, phase_set=None):
+        self.pos = np.ascontiguousarray(pos, dtype=np.int32)
+        n = self.pos.size
+        self.ref_str = [r if isinstance(r, bytes) else r.encode() for r in ref]
+        self.alt_str = [a if isinstance(a, bytes) else a.encode() for a in alt]
+        self.ref0 = np.frombuffer(b"".join(r[:1] for r in self.ref_str), dtype=np.uint8).copy() if n else np.zeros(0, np.uint8)
+        self.alt0 = np.frombuffer(b"".join(a[:1] for a in self.alt_str), dtype=np.uint8).copy() if n else np.zeros(0, np.uint8)
+        self.ref_len = np.array([len(r) for r in self.ref_str], dtype=np.uint16)
+        self.alt_len = np.array([len(a) for a in self.alt_str], dtype=np.uint16)
+        self.hp1_is_alt = None if hp1_is_alt is None else np.ascontiguousarray(hp1_is_alt, dtype=np.uint8)
+        self.phase_set = None if phase_set is None else np.ascontiguousarray(phase_set, dtype=np.int32)
+        self.n = n
+        self.c = VariantTable(n, _ptr(self.pos), _ptr(self.ref0), _ptr(self.alt0), _ptr(self.ref_len),
+                              _ptr(self.alt_len), _ptr(self.hp1_is_alt), _ptr(self.phase_set))
+
+
+class Reads:
+    """Host-side SoA read batch."""
+
+    FIELDS = (("ref_start", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("l_qseq", np.int32),
+              ("name_id", np.uint32), ("cigar_off", np.uint64), ("cigar", np.uint32), ("seq_off", np.uint64),
+              ("seq", np.uint8), ("qual_off", np.uint64), ("qual", np.uint8))
+
+    def __init__(self, **arrays):
+        for name, dt in self.FIELDS:
+            setattr(self, name, np.ascontiguousarray(arrays[name], dtype=dt))
+        self.n_reads = int(self.ref_start.size)
+        assert self.cigar_off.size == self.n_reads + 1
+        self.c = ReadBatch(self.n_reads, *[_ptr(getattr(self, n)) for n, _ in self.FIELDS])
+
+    @classmethod
+    def from_synth(cls, s):
+        return cls(**{n: getattr(s, n) for n, _ in cls.FIELDS})
+
+    def subset(self, idx):
+        """New batch holding reads idx (in that order)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        out = {}
+        for n in ("ref_start", "flag", "mapq", "l_qseq", "name_id"):
+            out[n] = getattr(self, n)[idx]
+        for base, off in (("cigar", "cigar_off"), ("seq", "seq_off"), ("qual", "qual_off")):
+            o = getattr(self, off)
+            lens = (o[idx + 1] - o[idx]).astype(np.int64)
+            new_off = np.zeros(idx.size + 1, dtype=np.uint64)
+            np.cumsum(lens, out=new_off[1:])
+            src = getattr(self, base)
+            if idx.size:
+                gather = np.concatenate([np.arange(int(o[i]), int(o[i + 1]), dtype=np.int64) for i in idx]) if lens.sum() else np.zeros(0, np.int64)
+                out[base] = src[gather]
+            else:
+                out[base] = src[:0]
+            out[off] = new_off
+        return Reads(**out)
+
+
+class PhaseOut:
+    def __init__(self, n):
+        self.phase_set = np.zeros(n, dtype=np.int32)
+        self.gt = np.zeros(n, dtype=np.uint8)
+        self.c = PhaseResult(n, _ptr(self.phase_set), _ptr(self.gt))
+
+
+class HaplotagOut:
+    def __init__(self, n):
+        self.status = np.zeros(n, np.uint8)
+        self.hp1 = np.zeros(n, np.int32)
+        self.hp2 = np.zeros(n, np.int32)
+        self.n_ps = np.zeros(n, np.uint8)
+        self.ps_min = np.zeros(n, np.int32)
+        self.hp = np.zeros(n, np.uint8)
+        self.pq = np.zeros(n, np.int32)
+        self.ps = np.zeros(n, np.int32)
+        self.c = HaplotagResult(n, *[_ptr(getattr(self, k)) for k in
+                                     ("status", "hp1", "hp2", "n_ps", "ps_min", "hp", "pq", "ps")])

@@ -1,0 +1,120 @@
+"""ctypes binding of tools/liblps_synth.so — seeded synthetic contig / variants / alignments.
+
+Test + bench infrastructure only (SURVEY.md §8d "Concrete synthetic inputs").  The arrays returned are
+views on memory owned by the generator handle; keep the `Synth` object alive while they are in use.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "..", "tools", "liblps_synth.so")
+
+
+class SynthParams(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64), ("contig_len", C.c_int64), ("n_snp", C.c_int32), ("coverage", C.c_double),
+        ("len_median", C.c_double), ("len_sigma", C.c_double), ("len_min", C.c_int32), ("len_max", C.c_int32),
+        ("sub_rate", C.c_double), ("ins_rate", C.c_double), ("del_rate", C.c_double),
+        ("indel_var_frac", C.c_double), ("lowq_frac", C.c_double), ("mapq0_frac", C.c_double),
+        ("secondary_frac", C.c_double), ("dup_frac", C.c_double), ("clip_every", C.c_int32),
+        ("supp_frac", C.c_double), ("supp_overlap_frac", C.c_double), ("hpoly_every", C.c_double),
+        ("snp_in_hpoly_frac", C.c_double), ("snp_pair_frac", C.c_double), ("tandem_frac", C.c_double),
+        ("n_threads", C.c_int32), ("clip_pileups", C.c_int32), ("gap_start", C.c_int64), ("gap_len", C.c_int64),
+    ]
+
+
+DEFAULTS = dict(
+    seed=1, contig_len=5_000_000, n_snp=5000, coverage=10.0, len_median=15000.0, len_sigma=0.7585,
+    len_min=1000, len_max=200000, sub_rate=0.01, ins_rate=0.01, del_rate=0.01, indel_var_frac=0.0,
+    lowq_frac=0.10, mapq0_frac=0.01, secondary_frac=0.003, dup_frac=0.002, clip_every=7, supp_frac=0.02,
+    supp_overlap_frac=0.5, hpoly_every=2000.0, snp_in_hpoly_frac=0.05, snp_pair_frac=0.01, tandem_frac=0.3,
+    n_threads=8, clip_pileups=0, gap_start=0, gap_len=0,
+)
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise RuntimeError(f"{_LIB} missing - run __graft_entry__.build()")
+        L = C.CDLL(_LIB)
+        L.synth_create.restype = C.c_void_p
+        L.synth_create.argtypes = [C.POINTER(SynthParams)]
+        L.synth_destroy.argtypes = [C.c_void_p]
+        for n in ("synth_n_reads", "synth_n_variants"):
+            getattr(L, n).restype = C.c_int64
+            getattr(L, n).argtypes = [C.c_void_p]
+        for n in ("synth_ref", "synth_var_pos", "synth_var_hap", "synth_ref_start", "synth_l_qseq", "synth_flag",
+                  "synth_mapq", "synth_name_id", "synth_read_hap", "synth_cigar_off", "synth_seq_off",
+                  "synth_qual_off", "synth_cigar", "synth_seq", "synth_qual"):
+            getattr(L, n).restype = C.c_void_p
+            getattr(L, n).argtypes = [C.c_void_p]
+        for n in ("synth_var_ref", "synth_var_alt"):
+            getattr(L, n).restype = C.c_char_p
+            getattr(L, n).argtypes = [C.c_void_p, C.c_int64]
+        L.synth_write_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.synth_write_sam.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.synth_write_vcf.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _view(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class Synth:
+    def __init__(self, **kw):
+        L = _load()
+        p = dict(DEFAULTS)
+        p.update(kw)
+        self.params = p
+        sp = SynthParams(**p)
+        self._h = L.synth_create(C.byref(sp))
+        h = self._h
+        n = self.n_reads = L.synth_n_reads(h)
+        nv = self.n_variants = L.synth_n_variants(h)
+        self.contig_len = p["contig_len"]
+        self.ref = _view(L.synth_ref(h), self.contig_len, np.uint8)
+        self.var_pos = _view(L.synth_var_pos(h), nv, np.int32)
+        self.var_hap = _view(L.synth_var_hap(h), nv, np.uint8)
+        self.var_ref = [L.synth_var_ref(h, i) for i in range(nv)]
+        self.var_alt = [L.synth_var_alt(h, i) for i in range(nv)]
+        self.ref_start = _view(L.synth_ref_start(h), n, np.int32)
+        self.l_qseq = _view(L.synth_l_qseq(h), n, np.int32)
+        self.flag = _view(L.synth_flag(h), n, np.uint16)
+        self.mapq = _view(L.synth_mapq(h), n, np.uint8)
+        self.name_id = _view(L.synth_name_id(h), n, np.uint32)
+        self.read_hap = _view(L.synth_read_hap(h), n, np.uint8)
+        self.cigar_off = _view(L.synth_cigar_off(h), n + 1, np.uint64)
+        self.seq_off = _view(L.synth_seq_off(h), n + 1, np.uint64)
+        self.qual_off = _view(L.synth_qual_off(h), n + 1, np.uint64)
+        self.cigar = _view(L.synth_cigar(h), int(self.cigar_off[-1]) if n else 0, np.uint32)
+        self.seq = _view(L.synth_seq(h), int(self.seq_off[-1]) if n else 0, np.uint8)
+        self.qual = _view(L.synth_qual(h), int(self.qual_off[-1]) if n else 0, np.uint8)
+
+    def write_fasta(self, path, chrom="chrS"):
+        assert _load().synth_write_fasta(self._h, path.encode(), chrom.encode()) == 0
+
+    def write_sam(self, path, chrom="chrS"):
+        assert _load().synth_write_sam(self._h, path.encode(), chrom.encode()) == 0
+
+    def write_vcf(self, path, chrom="chrS", phased=False):
+        assert _load().synth_write_vcf(self._h, path.encode(), chrom.encode(), int(phased)) == 0
+
+    def close(self):
+        if self._h:
+            _load().synth_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

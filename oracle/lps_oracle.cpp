@@ -1,0 +1,526 @@
+// lps_oracle — TEST INFRASTRUCTURE ONLY.  CPU restatement of LongPhase-S's hot path on the
+// SoA inputs of include/lps_abi.h.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// load this library, and only as the checker; the product (liblps_hip.so) never links or calls it.
+//
+// Parity is PINNED: tests/test_oracle_vs_reference.py checks this restatement against outputs of the real
+// reference binary (oracle/_ref/longphase-s-ref, built by oracle/build_ref.sh from /root/reference) on
+// generated inputs, and against the golden vectors committed under tests/golden/ (made by
+// tests/golden/make_golden.py from that binary).
+//
+// Every function cites the reference lines (relative to /root/reference/) whose behaviour it restates.
+// It is a restatement on index space (variant index instead of std::map<int,...> position keys), not a copy.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../include/lps_abi.h"
+
+namespace {
+
+struct Obs { int32_t var; int32_t allele; int32_t quality; };  // quality: base quality or sentinel -4/-5
+struct Aln { int64_t read; std::vector<Obs> obs; bool emptied_by_filter = false; };
+
+struct Table {
+    const lps_variant_table *t;
+    std::vector<uint8_t> danger;
+    int64_t ref_len;          // FastaParser truncation: [0, lastVariant+5]
+    const char *ref;
+};
+
+// src/shared/Util.cpp:21-54 homopolymerLength
+int homopolymer_length(int64_t p, const char *ref, int64_t ref_len) {
+    int len = 1;
+    if (p + 1 >= ref_len) return len;
+    char e = ref[p];
+    int64_t q = p - 1;                       // reference .at(p-1) throws for p==0; generator avoids p==0
+    while (q >= 0 && ref[q] == e) { --q; ++len; if (len >= 10 || q < 0) break; }
+    q = p + 1;
+    if (q < ref_len) {
+        while (ref[q] == e) { ++q; ++len; if (q >= ref_len) break; if (len >= 10) break; }
+    }
+    return len;
+}
+
+// src/phase/ParsingBam.cpp:378-417 getVariants_markindel: an indel is "danger" when the 2-mer right after the
+// site repeats five times (positions p+1..p+10).
+void mark_danger(Table &T) {
+    const lps_variant_table &t = *T.t;
+    T.danger.assign(t.n, 0);
+    auto at = [&](int64_t i) -> char { return (i >= 0 && i < T.ref_len) ? T.ref[i] : '\0'; };
+    for (int64_t v = 0; v < t.n; ++v) {
+        if (t.ref_len[v] <= 1 && t.alt_len[v] <= 1) continue;
+        int64_t p = t.pos[v]; char a = at(p + 1), b = at(p + 2); int i = 0;
+        while (i < 5) { if (a != at(p + 1) || b != at(p + 2)) break; p += 2; ++i; }
+        T.danger[v] = (i == 5);
+    }
+}
+
+inline char seq_base(const uint8_t *seq, int64_t i) {
+    static const char nt[] = "=ACMGRSVTWYHKDBN";     // htslib seq_nt16_str
+    return nt[(seq[i >> 1] >> ((~i & 1) << 2)) & 15];
+}
+
+struct ClipEvent { int32_t pos; uint8_t fb; };
+
+// src/phase/ParsingBam.cpp:1303-1634 get_snp (SNP/indel rows; SV and MOD inputs are out of scope)
+// returns false when the reference would have hit an unsupported CIGAR op (exit(1)).
+bool extract_read(const Table &T, const lps_read_batch &b, int64_t r, std::vector<Obs> &out,
+                  std::vector<ClipEvent> &clips) {
+    const lps_variant_table &t = *T.t;
+    out.clear();
+    const uint32_t *cig = b.cigar + b.cigar_off[r];
+    const int n_cig = (int)(b.cigar_off[r + 1] - b.cigar_off[r]);
+    const uint8_t *seq = b.seq + b.seq_off[r];
+    const uint8_t *qual = b.qual + b.qual_off[r];
+    const int64_t l_qseq = b.l_qseq[r];
+    int64_t ref_pos = b.ref_start[r], query_pos = 0;
+    // :1318 monotone cursor == lower_bound because alignments arrive coordinate-sorted
+    int64_t cur = std::lower_bound(t.pos, t.pos + t.n, (int32_t)ref_pos) - t.pos;
+    for (int i = 0; i < n_cig; ++i) {
+        const int op = cig[i] & 15; const int64_t len = cig[i] >> 4;
+        while (cur < t.n && t.pos[cur] < ref_pos) ++cur;                                  // :1361-1364
+        while (cur < t.n && t.pos[cur] < ref_pos + len) {                                 // :1368-1370
+            if (!(op == 0 || op == 7 || op == 8)) break;                                  // :1521
+            const int64_t vp = t.pos[cur], off = vp - ref_pos;
+            if (query_pos + off + 1 > l_qseq) { out.clear(); return true; }               // :1453-1455 drop read
+            int allele = -1, q = 0;
+            const int rl = t.ref_len[cur], al = t.alt_len[cur];
+            if (rl == 1 && al == 1) {                                                     // :1458-1466
+                char base = seq_base(seq, query_pos + off);
+                if (base == (char)t.ref0[cur]) allele = 0; else if (base == (char)t.alt0[cur]) allele = 1;
+                q = qual[query_pos + off];
+            }
+            if (rl == 1 && al != 1 && i + 1 < n_cig) {                                    // :1470-1491 insertion
+                allele = (ref_pos + len - 1 == vp && (cig[i + 1] & 15) == 1) ? 1 : 0;
+                q = T.danger[cur] ? -5 : -4;
+            }
+            if (rl != 1 && al == 1 && i + 1 < n_cig) {                                    // :1495-1510 deletion
+                allele = (ref_pos + len - 1 == vp && (cig[i + 1] & 15) == 2) ? 1 : 0;
+                q = T.danger[cur] ? -5 : -4;
+            }
+            if (allele != -1) out.push_back({(int32_t)cur, allele, q});
+            ++cur;
+        }
+        if (op == 0 || op == 7 || op == 8) { query_pos += len; ref_pos += len; }
+        else if (op == 1) query_pos += len;
+        else if (op == 2) {                                                               // :1539-1607
+            // cur at end(): reference dereferences end() (UB) -> defined here as "no variant"
+            if (cur < t.n && !(ref_pos + len + 1 == t.pos[cur]) && t.pos[cur] >= ref_pos && t.pos[cur] < ref_pos + len) {
+                if (homopolymer_length(t.pos[cur], T.ref, T.ref_len) >= 3) {
+                    if (query_pos + 1 > l_qseq) { out.clear(); return true; }             // :1559-1561
+                    const int rl = t.ref_len[cur], al = t.alt_len[cur];
+                    int allele = -1, q = 0;
+                    if (rl == 1 && al == 1) {
+                        char base = seq_base(seq, query_pos);
+                        if (base == (char)t.ref0[cur]) allele = 0; else if (base == (char)t.alt0[cur]) allele = 1;
+                        q = qual[query_pos];
+                    } else if (rl != 1 && al == 1) { allele = 1; q = -4; }
+                    if (allele != -1) { out.push_back({(int32_t)cur, allele, q}); ++cur; }
+                }
+            }
+            ref_pos += len;
+        }
+        else if (op == 3) ref_pos += len;
+        else if (op == 4) { query_pos += len; if (len > 5) clips.push_back({(int32_t)ref_pos, (uint8_t)(i == 0 ? 0 : 1)}); }  // :1613-1616,1636-1645
+        else if (op == 5) { if (len > 5) clips.push_back({(int32_t)ref_pos, (uint8_t)(i == 0 ? 0 : 1)}); }
+        else if (op == 6) {}
+        else return false;                                                               // :1625-1628
+    }
+    return true;
+}
+
+// src/phase/ParsingBam.cpp:837-912 filterSNP (variant-table half): which variants are erased
+void filter_snp(const Table &T, std::vector<uint8_t> &erased) {
+    const lps_variant_table &t = *T.t;
+    erased.assign(t.n, 0);
+    std::vector<int> hp(t.n);
+    for (int64_t v = 0; v < t.n; ++v) hp[v] = homopolymer_length(t.pos[v], T.ref, T.ref_len);
+    int64_t cur = 0, nxt = 1;
+    while (cur < t.n && nxt < t.n) {
+        if (hp[cur] >= 3 && hp[nxt] >= 3 && std::abs(t.pos[cur] - t.pos[nxt]) <= 2) { erased[nxt] = 1; ++nxt; continue; }
+        // advance both to the next surviving entries
+        ++cur; while (cur < t.n && erased[cur]) ++cur;
+        nxt = cur + 1; while (nxt < t.n && erased[nxt]) ++nxt;
+    }
+}
+
+// src/phase/PhasingGraph.cpp:1103-1227 Clip::Clip + getCNVInterval + updateThreshold.  The reference runs
+// getCNVInterval twice (ctor + PhasingProcess.cpp:148) so every interval is appended twice.
+struct CnvState {
+    bool push = false, slowUp = false, slowDown = false;
+    int curr = 0, reject = 0, pullDown = 0, slowDownCount = 0, candStart = -1, candEnd = -1;
+    void reset() { *this = CnvState(); }
+    void threshold(int up) {
+        reject = up;
+        if (up >= 20) { pullDown = up / 2; slowDownCount = 5; }
+        else if (up >= 10) { pullDown = up / 2; slowDownCount = up / 4; }
+        else { pullDown = 5; slowDownCount = 2; }
+    }
+};
+
+void cnv_pass(std::map<int, std::pair<int, int>> clip /*copy: sentinel is appended then removed*/,
+              std::vector<std::pair<int, int>> &cnv) {
+    const int Area = 30000;
+    if (clip.empty()) return;   // reference: UB/segfault
+    { auto last = *clip.rbegin(); clip[last.first + Area] = last.second; }
+    CnvState s;
+    for (auto &kv : clip) {
+        const int pos = kv.first, up = kv.second.first, down = kv.second.second;
+        if (!s.push && !s.slowDown && !s.slowUp) {
+            if (up >= 5 && s.curr == 0) { s.push = true; s.slowUp = false; s.slowDown = true; s.curr = up - down; s.candStart = pos; s.candEnd = pos + Area; s.threshold(up); }
+            else if (up > down && s.curr == 0) { s.push = false; s.slowUp = true; s.slowDown = false; s.curr = up - down; s.candStart = pos; s.candEnd = pos + Area; }
+        } else if (s.push && s.slowDown) {
+            if (up > s.reject) { s.threshold(up); s.candStart = pos; s.candEnd = pos + Area; }
+            s.curr = s.curr + up - down;
+            if (s.curr > 30) s.candEnd = pos + Area;
+            if (down >= s.pullDown) { cnv.emplace_back(s.candStart, pos); s.reset(); }
+            else if (s.curr <= s.slowDownCount && pos <= s.candEnd) { cnv.emplace_back(s.candStart, pos); s.reset(); }
+            if (pos > s.candEnd || s.curr <= 0 || pos - s.candStart >= 200000) s.reset();
+        } else if (s.slowUp) {
+            if (s.curr > 20 ? down >= s.curr / 4 : down >= 5) { cnv.emplace_back(s.candStart, pos); s.reset(); }
+            else if (up >= 5) { s.push = true; s.slowUp = false; s.slowDown = true; s.curr = up - down; s.candStart = pos; s.candEnd = pos + Area; s.threshold(up); }
+            else {
+                s.curr = s.curr + up - down;
+                if (s.curr > 30) s.candEnd = pos + Area;
+                if (pos > s.candEnd || s.curr <= 0 || pos - s.candStart >= 200000) s.reset();
+            }
+        }
+    }
+}
+
+// src/phase/PhasingGraph.cpp:707-781 overlap filter of several alignments of one read name
+void overlap_filter(const lps_params &P, const lps_read_batch &b, const lps_variant_table &t,
+                    std::vector<Aln> &alns, int *ub_hazard) {
+    struct NameState { int second = 0; std::vector<int> kept; };
+    std::map<uint32_t, NameState> st;
+    std::vector<char> del(alns.size(), 0);
+    auto first_pos = [&](const Aln &a) { return t.pos[a.obs.front().var]; };
+    auto last_pos = [&](const Aln &a) { return t.pos[a.obs.back().var]; };
+    std::map<uint32_t, int> name_count;
+    for (auto &a : alns) name_count[b.name_id[a.read]]++;
+    for (int ri = 0; ri < (int)alns.size(); ++ri) {
+        Aln &a = alns[ri];
+        if (a.obs.empty()) {
+            // reference reads variantVec.front()/back() of an EMPTY vector (UB); only observable when the name
+            // has other alignments.  Defined here: the alignment does not take part.
+            if (name_count[b.name_id[a.read]] > 1 && ub_hazard) (*ub_hazard)++;
+            continue;
+        }
+        NameState &s = st[b.name_id[a.read]];
+        const int fp = first_pos(a), lp = last_pos(a);
+        bool to_del = false;
+        // alignRange[readName] is default-constructed {0,0} before the find() (:712,716): first stays 0
+        while (0 <= fp && fp <= s.second) {
+            if (lp < s.second) { to_del = true; del[ri] = 1; break; }
+            int pre = (int)s.kept.size() - 1;
+            if (pre < 0) break;
+            const Aln &pa = alns[s.kept[pre]];
+            const int ps = first_pos(pa), pe = last_pos(pa);
+            double ovS = std::max(ps, fp), ovE = std::min(pe, lp);
+            if (ovS > ovE) break;
+            double ovLen = ovE - ovS + 1;
+            double alS = std::max(pe, lp), alE = std::min(ps, fp);
+            double span = alS - alE + 1;
+            double ratio = ovLen / span;
+            if (ratio >= P.overlap_threshold) {
+                int len1 = pe - ps + 1, len2 = lp - fp + 1;
+                if (len2 <= len1) { to_del = true; del[ri] = 1; break; }
+                del[s.kept[pre]] = 1; s.kept.pop_back();
+                s.second = (pre > 0) ? last_pos(alns[s.kept[pre - 1]]) : fp;
+            } else break;
+        }
+        s.second = lp;
+        if (!to_del) s.kept.push_back(ri);
+    }
+    std::vector<Aln> keep;
+    for (size_t i = 0; i < alns.size(); ++i) if (!del[i]) keep.push_back(std::move(alns[i]));
+    alns.swap(keep);
+}
+
+// src/phase/PhasingGraph.cpp:520-692 the four CNV mismatch-rate passes (called :785-791)
+void cnv_filter(const lps_variant_table &t, const std::vector<std::pair<int, int>> &cnv, std::vector<Aln> &alns) {
+    if (alns.empty() || cnv.empty()) return;
+    auto in = [](int p, int s, int e) { return p >= s && p <= e; };
+    std::vector<std::map<int, int>> mm(alns.size());
+    size_t ci = 0;
+    for (size_t r = 0; r < alns.size(); ++r) {                                            // calculateCnvMismatchRate
+        auto &o = alns[r].obs; if (o.empty()) continue;
+        int rs = t.pos[o.front().var], re = t.pos[o.back().var];
+        while (ci > 0 && cnv[ci].first > rs) --ci;
+        size_t i = ci;
+        while (i < cnv.size() && cnv[i].first <= re) {
+            for (auto &v : o) { int p = t.pos[v.var]; if (p > cnv[i].second) break; if (in(p, cnv[i].first, cnv[i].second) && v.allele == 1) mm[r][cnv[i].first]++; }
+            ++i;
+        }
+        ci = i > 0 ? i - 1 : 0;
+    }
+    std::map<int, std::map<int, std::vector<int>>> agg;                                    // aggregateCnvReadMismatchRate
+    ci = 0;
+    for (size_t r = 0; r < alns.size(); ++r) {
+        auto &o = alns[r].obs; if (o.empty()) continue;
+        int rs = t.pos[o.front().var], re = t.pos[o.back().var];
+        while (ci > 0 && cnv[ci].first > rs) --ci;
+        size_t i = ci;
+        while (i < cnv.size() && cnv[i].first <= re) {
+            for (auto &v : o) {
+                int p = t.pos[v.var]; if (p > cnv[i].second) break;
+                auto it = mm[r].find(cnv[i].first);
+                if (in(p, cnv[i].first, cnv[i].second) && it != mm[r].end()) agg[p][v.allele].push_back(it->second);
+            }
+            ++i;
+        }
+        ci = i > 0 ? i - 1 : 0;
+    }
+    std::map<int, double> miss;                                                            // calculateAverageMismatchRate
+    if (!agg.empty()) {
+        ci = 0;
+        auto mean = [](const std::vector<int> &d) { double s = 0; for (int x : d) s += x; return d.empty() ? 0.0 : s / d.size(); };
+        for (auto &kv : agg) {
+            while (ci > 0 && cnv[ci].first > kv.first) --ci;
+            size_t i = ci;
+            while (i < cnv.size()) {
+                if (cnv[i].first > kv.first) break;
+                if (in(kv.first, cnv[i].first, cnv[i].second)) {
+                    auto r0 = kv.second.find(0), r1 = kv.second.find(1);
+                    if (r0 != kv.second.end() && r1 != kv.second.end()) {
+                        double a = mean(r0->second), c = mean(r1->second);
+                        if (a != 0 && c != 0) miss[kv.first] = c / (a + c);
+                    }
+                }
+                ++i;
+            }
+            // reference leaves cnvIndex untouched in this pass (no write-back)
+        }
+    }
+    if (miss.empty()) return;                                                             // filterHighMismatchVariants
+    ci = 0;
+    for (auto &a : alns) {
+        auto &o = a.obs; if (o.empty()) continue;
+        int rs = t.pos[o.front().var];
+        while (ci > 0 && cnv[ci].first > rs) --ci;
+        size_t k = 0;
+        while (k < o.size()) {
+            bool erase = false; int p = t.pos[o[k].var];
+            size_t i = ci;
+            while (i < cnv.size() && cnv[i].first <= p) {
+                if (in(p, cnv[i].first, cnv[i].second)) {
+                    auto m = miss.find(p);
+                    if (m != miss.end() && m->second >= 0.7) { erase = true; o.erase(o.begin() + k); break; }
+                }
+                ++i;
+            }
+            if (!erase) ++k;
+            ci = i > 0 ? i - 1 : 0;
+        }
+    }
+}
+
+struct SortKey { int pos; int var; int allele; int quality; };
+
+}  // namespace
+
+extern "C" {
+
+// Dumps are optional (NULL) stage outputs used by the parity tests.
+typedef struct oracle_dumps {
+    int64_t obs_capacity;
+    int32_t *obs_count;      /* n_reads, 0 for dropped alignments; BEFORE the overlap/CNV filters, AFTER filterSNP */
+    int32_t *obs_var; int8_t *obs_allele; int8_t *obs_quality;
+    int64_t n_obs;
+    int64_t clip_capacity; int32_t *clip_pos; uint8_t *clip_fb; int64_t n_clips;
+    int64_t node_capacity; int32_t *node_var; float *edge; int8_t *node_hp; int32_t *node_block; int64_t n_nodes;
+    uint8_t *aln_deleted;    /* n_reads: 1 when removed by the overlap filter */
+    int32_t n_cnv; int32_t cnv_start[64]; int32_t cnv_end[64];
+    int32_t ub_hazard;       /* >0: input touched behaviour that is UB in the reference */
+    int64_t n_pairs;
+} oracle_dumps;
+
+int oracle_phase(const lps_params *Pp, const lps_variant_table *tp, const char *ref, int64_t ref_len_in,
+                 const lps_read_batch *bp, lps_phase_result *out, oracle_dumps *D) {
+    const lps_params &P = *Pp; const lps_variant_table &t = *tp; const lps_read_batch &b = *bp;
+    for (int64_t i = 0; i < out->n; ++i) { out->phase_set[i] = 0; out->gt[i] = 0; }
+    if (D) { D->n_obs = 0; D->n_clips = 0; D->n_nodes = 0; D->n_cnv = 0; D->ub_hazard = 0; D->n_pairs = 0; }
+    if (t.n == 0) return 0;
+    Table T; T.t = &t; T.ref = ref;
+    const int32_t last_pos = t.pos[t.n - 1];
+    T.ref_len = std::min<int64_t>(ref_len_in, (int64_t)last_pos + 6);   // ParsingBam.cpp:47 faidx_fetch_seq(0,last+5)
+    mark_danger(T);
+    const int A = P.connect_adjacent;
+
+    // ---- a1/a2/a3: direct_detect_alleles + get_snp + getClip  (ParsingBam.cpp:1243-1645)
+    std::vector<Aln> alns; std::vector<ClipEvent> clips; std::vector<Obs> tmp;
+    for (int64_t r = 0; r < b.n_reads; ++r) {
+        if (b.ref_start[r] >= last_pos) continue;                  // region "chr:1-<lastSNPPos>" (:1273)
+        const int fl = b.flag[r];
+        if (b.mapq[r] < P.mapping_quality || (fl & 0x4) || (fl & 0x100) || (fl & 0x400)) continue;   // :1282-1291
+        size_t nclip0 = clips.size();
+        if (!extract_read(T, b, r, tmp, clips)) return -2;
+        (void)nclip0;
+        if (!tmp.empty()) { Aln a; a.read = r; a.obs = tmp; alns.push_back(std::move(a)); }
+    }
+    // ---- a5: filterSNP (ONT only)  (PhasingProcess.cpp:138-140)
+    std::vector<uint8_t> erased(t.n, 0);
+    if (P.is_ont) {
+        filter_snp(T, erased);
+        for (auto &a : alns) {
+            size_t k = 0; for (auto &o : a.obs) if (!erased[o.var]) a.obs[k++] = o;
+            if (k == 0) a.emptied_by_filter = true;
+            a.obs.resize(k);
+        }
+    }
+    if (D) {
+        if (D->obs_count) for (int64_t r = 0; r < b.n_reads; ++r) D->obs_count[r] = 0;
+        int64_t n = 0;
+        for (auto &a : alns) {
+            if (D->obs_count) D->obs_count[a.read] = (int32_t)a.obs.size();
+            for (auto &o : a.obs) { if (D->obs_var && n < D->obs_capacity) { D->obs_var[n] = o.var; D->obs_allele[n] = (int8_t)o.allele; D->obs_quality[n] = (int8_t)o.quality; } ++n; }
+        }
+        D->n_obs = n;
+        int64_t c = 0;
+        for (auto &e : clips) { if (D->clip_pos && c < D->clip_capacity) { D->clip_pos[c] = e.pos; D->clip_fb[c] = e.fb; } ++c; }
+        D->n_clips = c;
+        if (D->aln_deleted) for (int64_t r = 0; r < b.n_reads; ++r) D->aln_deleted[r] = 0;
+    }
+    if (alns.empty()) return 0;                                     // PhasingProcess.cpp:143-145
+    // ---- a7: Clip / CNV intervals (twice)
+    std::map<int, std::pair<int, int>> clipCount;
+    for (auto &e : clips) { auto &c = clipCount[e.pos]; if (e.fb == 0) c.first++; else c.second++; }
+    std::vector<std::pair<int, int>> cnv;
+    if (clipCount.empty()) { if (D) D->ub_hazard++; }
+    else { cnv_pass(clipCount, cnv); cnv_pass(clipCount, cnv); }
+    if (D) { D->n_cnv = (int32_t)cnv.size(); for (size_t i = 0; i < cnv.size() && i < 64; ++i) { D->cnv_start[i] = cnv[i].first; D->cnv_end[i] = cnv[i].second; } }
+    // ---- a8: overlap filter; a9: CNV mismatch filter
+    {
+        std::vector<int64_t> before; for (auto &a : alns) before.push_back(a.read);
+        overlap_filter(P, b, t, alns, D ? &D->ub_hazard : nullptr);
+        if (D && D->aln_deleted) { size_t k = 0; for (int64_t r : before) { if (k < alns.size() && alns[k].read == r) ++k; else D->aln_deleted[r] = 1; } }
+    }
+    cnv_filter(t, cnv, alns);
+    // ---- a10: type tagging + node set  (PhasingGraph.cpp:793-846)
+    std::vector<int8_t> vtype(t.n, -1);                            // 0 SNP, 3 indel, 4 danger indel (last writer wins)
+    std::vector<uint8_t> is_node(t.n, 0);
+    std::map<uint32_t, std::vector<SortKey>> merged;               // keyed by name order
+    for (auto &a : alns) for (auto o : a.obs) {
+        if (o.quality == -4) { vtype[o.var] = 3; o.quality = 60; }
+        else if (o.quality == -5) { vtype[o.var] = 4; o.quality = 60; }
+        else vtype[o.var] = 0;
+        merged[b.name_id[a.read]].push_back({t.pos[o.var], o.var, o.allele, o.quality});
+        is_node[o.var] = 1;
+    }
+    std::vector<int32_t> node_of(t.n, -1), nodes;
+    for (int64_t v = 0; v < t.n; ++v) if (is_node[v]) { node_of[v] = (int32_t)nodes.size(); nodes.push_back((int32_t)v); }
+    const int64_t N = (int64_t)nodes.size();
+    // ---- a11: pair loop + addSubEdge  (PhasingGraph.cpp:848-888, :25-70) -> dense [N][A][4]
+    std::vector<float> edge((size_t)N * A * 4, 0.0f);
+    int64_t n_pairs = 0;
+    for (auto &kv : merged) {
+        auto &v = kv.second;
+        std::sort(v.begin(), v.end(), [](const SortKey &x, const SortKey &y) { return x.pos < y.pos; });   // Util.cpp:3-5
+        for (size_t i = 0; i + 1 < v.size(); ++i) {
+            for (size_t j = i + 1; j < v.size() && j <= i + (size_t)A; ++j) {
+                ++n_pairs;
+                const int d = node_of[v[j].var] - node_of[v[i].var];
+                if (d < 1 || d > A) continue;                      // never queried by edgeConnectResult
+                float &cell = edge[((size_t)node_of[v[i].var] * A + (d - 1)) * 4 + (v[i].allele << 1 | v[j].allele)];
+                if (v[i].quality >= P.base_quality && v[j].quality >= P.base_quality) cell++;
+                else cell = cell + P.edge_weight;                  // float = float + double -> rounded once
+            }
+        }
+    }
+    if (D) D->n_pairs = n_pairs;
+    // ---- a12/a13: edgeConnectResult + findBestEdgePair + Onelongcase  (PhasingGraph.cpp:166-228,251-283,286-474)
+    struct Vote { int src; float para, cross, weight; int hap; double esr; };
+    std::vector<float> h1(N, 0.f), h2(N, 0.f);
+    std::vector<std::vector<Vote>> votes(N);
+    std::vector<int8_t> hp(N, 0); std::vector<int32_t> block(N, -1);
+    int blockStart = -1; int64_t lastConnect = -1;
+    std::map<int, std::vector<int>> blocks;
+    for (int64_t i = 0; i + 1 < N; ++i) {                           // last node never processed (:308-311)
+        const int cp = t.pos[nodes[i]], np = t.pos[nodes[i + 1]];
+        if (std::abs(np - cp) > P.distance) continue;
+        float a1 = h1[i], a2 = h2[i];
+        {   // Onelongcase
+            int counter = 0; float s1 = 0, s2 = 0;
+            for (auto &vt : votes[i]) {
+                if ((vt.para + vt.cross) <= 1) counter++;
+                else if (vt.esr < 0.2 && vt.weight >= 1 && vtype[nodes[vt.src]] != 3) { if (vt.hap == 1) s1 += vt.weight; else if (vt.hap == 2) s2 += vt.weight; }
+            }
+            if (!(counter <= 3 || (s1 == 0 && s2 == 0))) { a1 = s1; a2 = s2; }
+        }
+        if (a1 == a2) {
+            if (i < lastConnect) continue;
+            blockStart = (int)i; blocks[blockStart].push_back((int)i); hp[i] = 1;
+        } else { hp[i] = (a1 > a2) ? 1 : 2; blocks[blockStart].push_back((int)i); }
+        block[i] = blockStart;
+        for (int k = 0; k < A && i + 1 + k < N; ++k) {
+            const int64_t j = i + 1 + k;
+            const float *c = &edge[((size_t)i * A + k) * 4];
+            const float rr = c[0], ra = c[1], ar = c[2], aa = c[3];
+            Vote vt; vt.src = (int)i; vt.weight = 1; vt.hap = 0;
+            int dir = -1;
+            double esr = (double)std::min(rr + aa, ar + ra) / (double)std::max(rr + aa, ar + ra);
+            if (rr + aa > ra + ar) dir = 1; else if (rr + aa < ra + ar) dir = 2;
+            double thr = P.edge_threshold;     // SNP<->MOD special threshold (:197-202) needs MOD input: out of scope
+            if (esr > thr) dir = -1;
+            // the reference's `else if` hangs off `if(debug)` (:210-217, debug is always false): independent of esr>thr
+            if ((esr <= 0.1 && (rr + aa + ra + ar) >= 1) || ((rr + aa) < 1 && (ra + ar) >= 1) || ((rr + aa) >= 1 && (ra + ar) < 1)) vt.weight = 20;
+            vt.para = rr + aa; vt.cross = ra + ar; vt.esr = esr;
+            if (vtype[nodes[i]] == 4) vt.weight = 0.1;
+            if (dir != -1) {
+                int th = (hp[i] == 1) ? dir : (dir == 1 ? 2 : 1);
+                if (th == 1) h1[j] += vt.weight; else h2[j] += vt.weight;
+                vt.hap = th; votes[j].push_back(vt);
+                lastConnect = j;
+            }
+        }
+    }
+    std::vector<int32_t> ps(N, 0); std::vector<int8_t> refhap(N, -1);
+    for (auto &kv : blocks) {
+        if (kv.second.size() <= 1) continue;
+        for (int m : kv.second) { ps[m] = t.pos[nodes[kv.first]] + 1; refhap[m] = (hp[m] == hp[kv.second.front()]) ? 0 : 1; }
+    }
+    if (D) {
+        D->n_nodes = N;
+        for (int64_t i = 0; i < N && i < D->node_capacity; ++i) {
+            if (D->node_var) D->node_var[i] = nodes[i];
+            if (D->node_hp) D->node_hp[i] = hp[i];
+            if (D->node_block) D->node_block[i] = block[i];
+        }
+        if (D->edge && N <= D->node_capacity) std::memcpy(D->edge, edge.data(), edge.size() * sizeof(float));
+    }
+    // ---- a14: readCorrection  (PhasingGraph.cpp:891-1029)
+    std::vector<double> cnt((size_t)N * 4, 0.0);                   // [node][hp][allele]
+    for (auto &a : alns) {
+        double rc = 0, ac = 0;
+        for (auto &o : a.obs) {
+            int nd = node_of[o.var];
+            if (ps[nd] != 0) {
+                int h = (o.allele == 0) ? refhap[nd] : 1 - refhap[nd];
+                int ty = vtype[o.var];
+                if (ty == 0 || ty == 1) { if (h == 0) rc++; else ac++; }
+                else if (ty == 3 || ty == 4) { if (h == 0) rc += 0.1; else ac += 0.1; }
+            }
+        }
+        if (std::max(rc, ac) / (rc + ac) > P.read_confidence && (rc + ac) > 1) {
+            int bh = (rc > ac) ? 0 : 1;
+            for (auto &o : a.obs) cnt[(size_t)node_of[o.var] * 4 + bh * 2 + o.allele]++;
+        }
+    }
+    // ---- a15: final genotype + exportResult  (PhasingGraph.cpp:983-1026,1049-1077)
+    for (int64_t i = 0; i < N; ++i) {
+        const double *c = &cnt[(size_t)i * 4];
+        double r1 = c[0] + c[3], r2 = c[2] + c[1];
+        double conf = std::max(r1, r2) / (r1 + r2);
+        int g = -1;
+        if (conf > P.snp_confidence) { if (r1 > r2) g = 0; else if (r1 < r2) g = 1; }
+        if (g != -1 && ps[i] != 0) { out->phase_set[nodes[i]] = ps[i]; out->gt[nodes[i]] = (uint8_t)g; }
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+"""TEST INFRASTRUCTURE ONLY - ctypes binding of oracle/liblps_oracle.so (the CPU restatement, the checker).
+
+Import only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import sys
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(_HERE, "..", "longphase-s_amd"))
+from lps import abi  # noqa: E402
+
+
+class Dumps(C.Structure):
+    _fields_ = [
+        ("obs_capacity", C.c_int64), ("obs_count", C.c_void_p), ("obs_var", C.c_void_p),
+        ("obs_allele", C.c_void_p), ("obs_quality", C.c_void_p), ("n_obs", C.c_int64),
+        ("clip_capacity", C.c_int64), ("clip_pos", C.c_void_p), ("clip_fb", C.c_void_p), ("n_clips", C.c_int64),
+        ("node_capacity", C.c_int64), ("node_var", C.c_void_p), ("edge", C.c_void_p), ("node_hp", C.c_void_p),
+        ("node_block", C.c_void_p), ("n_nodes", C.c_int64), ("aln_deleted", C.c_void_p),
+        ("n_cnv", C.c_int32), ("cnv_start", C.c_int32 * 64), ("cnv_end", C.c_int32 * 64),
+        ("ub_hazard", C.c_int32), ("n_pairs", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liblps_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/liblps_oracle.so missing - run `make -C oracle` (or __graft_entry__.build())")
+        _lib = C.CDLL(path)
+        _lib.oracle_phase.restype = C.c_int
+        _lib.oracle_phase.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.c_void_p, C.c_int64,
+                                      C.POINTER(abi.ReadBatch), C.POINTER(abi.PhaseResult), C.POINTER(Dumps)]
+    return _lib
+
+
+class PhaseDump:
+    def __init__(self, n_reads, n_var, adj, obs_cap=None, with_edges=True):
+        obs_cap = obs_cap or max(1, n_reads) * 64 + 1024
+        self.obs_count = np.zeros(n_reads, np.int32)
+        self.obs_var = np.zeros(obs_cap, np.int32)
+        self.obs_allele = np.zeros(obs_cap, np.int8)
+        self.obs_quality = np.zeros(obs_cap, np.int8)
+        ccap = 2 * n_reads + 16
+        self.clip_pos = np.zeros(ccap, np.int32)
+        self.clip_fb = np.zeros(ccap, np.uint8)
+        self.node_var = np.zeros(n_var, np.int32)
+        self.edge = np.zeros((n_var, adj, 4), np.float32) if with_edges else None
+        self.node_hp = np.zeros(n_var, np.int8)
+        self.node_block = np.zeros(n_var, np.int32)
+        self.aln_deleted = np.zeros(n_reads, np.uint8)
+        p = lambda a: None if a is None else a.ctypes.data
+        self.c = Dumps(obs_cap, p(self.obs_count), p(self.obs_var), p(self.obs_allele), p(self.obs_quality), 0,
+                       ccap, p(self.clip_pos), p(self.clip_fb), 0,
+                       n_var, p(self.node_var), p(self.edge), p(self.node_hp), p(self.node_block), 0,
+                       p(self.aln_deleted))
+
+
+def phase(params, variants, ref, reads, dump=False, with_edges=True):
+    """Run the CPU restatement.  ref: numpy uint8 array of the contig.  Returns (PhaseOut, PhaseDump|None)."""
+    out = abi.PhaseOut(variants.n)
+    d = PhaseDump(reads.n_reads, variants.n, params.connect_adjacent, with_edges=with_edges) if dump else None
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    rc = lib().oracle_phase(C.byref(params), C.byref(variants.c), ref.ctypes.data, ref.size, C.byref(reads.c),
+                            C.byref(out.c), C.byref(d.c) if d else None)
+    if rc != 0:
+        raise RuntimeError(f"oracle_phase rc={rc}")
+    return out, d
