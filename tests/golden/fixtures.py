@@ -1,0 +1,49 @@
+"""Fixture matrix shared by make_golden.py (generator of the golden vectors) and the parity tests.
+
+Each fixture = generator arguments (longphase-s_amd/lps/synth.py), the reference CLI flags used when the golden
+output was produced, and the matching lps_params overrides.  Matrix follows SURVEY.md §8c.
+"""
+import hashlib
+import numpy as np
+
+SMALL = dict(contig_len=400_000, n_snp=500, coverage=15.0, n_threads=4)
+
+PHASE_FIXTURES = {
+    # name: (synth kwargs, reference CLI flags, lps_params overrides)
+    "snp_ont": (dict(SMALL, seed=1), ["--ont"], {}),
+    "snp_ont_seed2": (dict(SMALL, seed=2, coverage=30.0), ["--ont"], {}),
+    "snp_pb": (dict(SMALL, seed=3), ["--pb"], dict(is_ont=0)),
+    "indels": (dict(SMALL, seed=4, indel_var_frac=0.25), ["--ont", "--indels"], dict(phase_indel=1)),
+    "indels_pb": (dict(SMALL, seed=5, indel_var_frac=0.4, tandem_frac=0.6), ["--pb", "--indels"], dict(is_ont=0, phase_indel=1)),
+    "two_blocks": (dict(SMALL, seed=6, contig_len=900_000, n_snp=900, gap_start=300_000, gap_len=320_000), ["--ont"], {}),
+    "lowq_heavy": (dict(SMALL, seed=7, lowq_frac=0.5), ["--ont"], {}),
+    "supp_overlap": (dict(SMALL, seed=8, supp_frac=0.35, supp_overlap_frac=0.8), ["--ont"], {}),
+    "cnv_pileup": (dict(SMALL, seed=9, contig_len=800_000, n_snp=1000, coverage=40.0, clip_pileups=2), ["--ont"], {}),
+    "sparse_cov": (dict(SMALL, seed=10, coverage=3.0), ["--ont"], {}),
+    "dense_snps": (dict(SMALL, seed=11, n_snp=4000, snp_pair_frac=0.08, snp_in_hpoly_frac=0.3, hpoly_every=300.0), ["--ont"], {}),
+    "params_a": (dict(SMALL, seed=12), ["--ont", "-a", "20", "-d", "50000", "-q", "20", "-p", "20", "-e", "0.3"],
+                 dict(connect_adjacent=20, distance=50000, mapping_quality=20, base_quality=20, edge_weight=0.3)),
+    "params_b": (dict(SMALL, seed=13, indel_var_frac=0.2), ["--ont", "--indels", "-m", "0.8", "-n", "0.9", "-1", "0.5", "-L", "0.05"],
+                 dict(phase_indel=1, read_confidence=0.8, snp_confidence=0.9, edge_threshold=0.5, overlap_threshold=0.05)),
+    "high_error": (dict(SMALL, seed=14, sub_rate=0.06, ins_rate=0.04, del_rate=0.04), ["--ont"], {}),
+    "short_reads": (dict(SMALL, seed=15, len_median=3000.0, len_min=500, coverage=25.0), ["--ont"], {}),
+}
+
+# fixtures whose full inputs (FASTA/VCF/SAM) are committed as data files under tests/golden/data/
+TINY = dict(contig_len=60_000, n_snp=120, coverage=12.0, n_threads=2)
+DATA_FIXTURES = {
+    "tiny_snp": (dict(TINY, seed=21), ["--ont"], {}),
+    "tiny_indel": (dict(TINY, seed=22, indel_var_frac=0.3), ["--ont", "--indels"], dict(phase_indel=1)),
+}
+
+
+def input_digest(s):
+    """sha256 over the generated inputs: detects generator drift between the machine that made the golden
+    vectors and the one that replays them."""
+    h = hashlib.sha256()
+    for a in (s.var_pos, s.ref_start, s.flag, s.mapq, s.l_qseq, s.name_id, s.cigar_off, s.cigar, s.seq, s.qual):
+        h.update(np.ascontiguousarray(a).tobytes())
+    h.update(b"|".join(s.var_ref))
+    h.update(b"|".join(s.var_alt))
+    h.update(np.ascontiguousarray(s.ref).tobytes())
+    return h.hexdigest()

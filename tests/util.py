@@ -1,0 +1,95 @@
+"""Shared helpers of the parity tests."""
+import gzip
+import json
+import os
+
+import numpy as np
+
+import fixtures
+from lps import abi
+from lps.synth import Synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+INDEX = json.load(open(os.path.join(GOLDEN, "index.json")))
+
+
+def make_case(kw):
+    s = Synth(**kw)
+    V = abi.Variants(s.var_pos, s.var_ref, s.var_alt)
+    R = abi.Reads.from_synth(s)
+    return s, V, R
+
+
+def load_golden_phase(name):
+    z = np.load(os.path.join(GOLDEN, f"phase_{name}.npz"))
+    return z["var_pos"], z["phase_set"], z["gt"]
+
+
+def assert_phase_equal(ps_a, gt_a, ps_b, gt_b, what=""):
+    """Bit-exact comparison of phased genotypes and block ids (gt only where phased)."""
+    ps_a = np.asarray(ps_a); ps_b = np.asarray(ps_b)
+    bad = np.nonzero(ps_a != ps_b)[0]
+    assert bad.size == 0, f"{what}: {bad.size} PS mismatches, first at variant {bad[:5]}: {ps_a[bad[:5]]} vs {ps_b[bad[:5]]}"
+    m = ps_a != 0
+    badg = np.nonzero(np.asarray(gt_a)[m] != np.asarray(gt_b)[m])[0]
+    assert badg.size == 0, f"{what}: {badg.size} GT mismatches"
+
+
+_NT16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+_OPS = {c: i for i, c in enumerate("MIDNSHP=XB")}
+
+
+def parse_sam(path):
+    """SAM text -> abi.Reads (+ names).  name_id = rank of the name under byte-wise ordering."""
+    import re
+    op = gzip.open if path.endswith(".gz") else open
+    rs, fl, mq, lq, names, cig, seq, qual = [], [], [], [], [], [], [], []
+    cig_off, seq_off, qual_off = [0], [0], [0]
+    for line in op(path, "rt"):
+        if line.startswith("@"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        names.append(f[0].encode()); fl.append(int(f[1])); rs.append(int(f[3]) - 1); mq.append(int(f[4]))
+        for ln, o in re.findall(r"(\d+)([MIDNSHP=XB])", f[5]):
+            cig.append(int(ln) << 4 | _OPS[o])
+        cig_off.append(len(cig))
+        s = "" if f[9] == "*" else f[9]
+        lq.append(len(s))
+        packed = bytearray((len(s) + 1) // 2)
+        for j, c in enumerate(s):
+            packed[j >> 1] |= _NT16.get(c, 15) << (4 if (j & 1) == 0 else 0)
+        seq.append(bytes(packed)); seq_off.append(seq_off[-1] + len(packed))
+        q = bytes((ord(c) - 33) for c in f[10]) if f[10] != "*" else bytes([255]) * len(s)
+        qual.append(q); qual_off.append(qual_off[-1] + len(q))
+    uniq = sorted(set(names))
+    rank = {n: i for i, n in enumerate(uniq)}
+    R = abi.Reads(ref_start=rs, flag=fl, mapq=mq, l_qseq=lq, name_id=[rank[n] for n in names],
+                  cigar_off=cig_off, cigar=np.array(cig, dtype=np.uint32), seq_off=seq_off,
+                  seq=np.frombuffer(b"".join(seq), dtype=np.uint8), qual_off=qual_off,
+                  qual=np.frombuffer(b"".join(qual), dtype=np.uint8))
+    return R, names
+
+
+def parse_vcf_variants(path, indels=False):
+    """SnpParser::SnpParser (src/phase/ParsingBam.cpp:222-359) row selection: het, bi-allelic, SNP (+indels)."""
+    pos, ref, alt = [], [], []
+    for line in open(path):
+        if line.startswith("#"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        gt = f[9].split(":")[f[8].split(":").index("GT")]
+        if gt not in ("0/1", "1/0", "0|1", "1|0") or "," in f[4] or f[4].startswith("<"):
+            continue
+        is_snp = len(f[3]) == 1 and len(f[4]) == 1
+        if not is_snp and not indels:
+            continue
+        pos.append(int(f[1]) - 1); ref.append(f[3]); alt.append(f[4])
+    return abi.Variants(pos, ref, alt)
+
+
+def parse_fasta(path):
+    seq = []
+    for line in open(path):
+        if not line.startswith(">"):
+            seq.append(line.strip())
+    return np.frombuffer("".join(seq).encode(), dtype=np.uint8)
