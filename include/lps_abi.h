@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define LPS_ABI_VERSION 1
-#define LPS_MAX_ADJACENT 64 /* upper bound for lps_params.connect_adjacent (reference default 35) */
+#define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
 
@@ -135,6 +135,9 @@ typedef struct lps_timings {
 } lps_timings;
 
 int lps_abi_version(void);
+/* sizeof() of the ABI structs as compiled into the library: 0 lps_params, 1 lps_variant_table, 2 lps_read_batch,
+ * 3 lps_phase_result, 4 lps_haplotag_result, 5 lps_timings (binding self-check). */
+int lps_struct_size(int which);
 int lps_device_count(void);
 
 lps_ctx *lps_create(int device, const lps_params *params);
@@ -166,7 +169,7 @@ void *lps_stream(lps_ctx *ctx);
 /* Observations in canonical order (alignment index, then position): per kept alignment
  * obs_count[read] entries.  Returns total or <0.  Pass NULL arrays to query the total only. */
 int64_t lps_dump_observations(lps_ctx *ctx, int32_t *obs_count /*n_reads*/, int32_t *var_index, int8_t *allele,
-                              int8_t *quality, int64_t capacity);
+                              int16_t *quality, int64_t capacity);
 /* Graph nodes (variant indices, ascending) and the dense edge matrix [n_nodes][connect_adjacent][4]
  * (cell order rr, ra, ar, aa = (allele_i<<1)|allele_j).  Returns n_nodes. */
 int64_t lps_dump_graph(lps_ctx *ctx, int32_t *node_var_index, float *edge, int64_t node_capacity);
@@ -174,6 +177,9 @@ int64_t lps_dump_graph(lps_ctx *ctx, int32_t *node_var_index, float *edge, int64
 int64_t lps_dump_votes(lps_ctx *ctx, int8_t *hp, int32_t *block_node, int64_t node_capacity);
 /* Clip events counted by getClip (src/phase/ParsingBam.cpp:1636-1645): (ref_pos, 0 FRONT / 1 BACK). */
 int64_t lps_dump_clips(lps_ctx *ctx, int32_t *pos, uint8_t *front_back, int64_t capacity);
+/* CNV intervals of Clip::getCNVInterval (each interval appears twice, as in the reference) and, optionally,
+ * the per-alignment "removed by the overlap filter" flags (n_reads bytes).  start/end need 64 entries. */
+int lps_dump_cnv(lps_ctx *ctx, int32_t *start, int32_t *end, uint8_t *aln_deleted);
 
 #ifdef __cplusplus
 }

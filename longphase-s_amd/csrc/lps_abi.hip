@@ -1,0 +1,442 @@
+// lps_abi.hip — the C-ABI of liblps_hip.so (include/lps_abi.h): context, device residency, stage orchestration.
+//
+// HBM layout (one chromosome resident per ctx; all SoA, sized for 288 GB: a 50x human chr1 batch is ~25 GB):
+//   variants   pos i32 | ref0,alt0 u8 | ref_len,alt_len u16 | danger,hpoly,erased u8          (<= 16 B / variant)
+//   reference  chars [0, lastVariant+5]
+//   reads      ref_start,l_qseq i32 | flag u16 | mapq u8 | name_id u32 | 3 x u64 offsets | cigar u32[] | seq 4-bit | qual u8
+//   obs rows   var i32 + aq u16 per observation, rows placed by atomic reservation; g_node i32 + g_flag u8 mirror them
+//   graph      node-major sorted (key u64, slot u32) list | edge f32[N][A][4] | einfo u8[N][A] | hp i8[N] | block i32[N]
+// Every lps_phase_chromosome() recomputes all stages from the resident raw reads.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "lps_graph.h"
+
+static const char *kStageNames[LPS_MAX_STAGES] = {
+    "variant_prep", "extract", "name_groups", "clip_cnv", "overlap_filter", "cnv_filter", "nodes", "merge_rows",
+    "node_lists", "edges", "vote_scan", "read_correction", "d2h", nullptr};
+// recorded in this order on the stream
+enum { ST_PREP, ST_EXTRACT, ST_GROUPS, ST_CLIP, ST_OVERLAP, ST_CNV, ST_NODES, ST_MERGE, ST_NODELISTS, ST_EDGES, ST_SCAN, ST_CORR, ST_D2H, ST_COUNT };
+
+struct lps_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    lps_params P{};
+    std::string err;
+    // variants
+    int nV = 0; int last_pos = -1; long long ref_len = 0, ref_len_eff = 0;
+    std::vector<int32_t> h_vpos;
+    DevBuf<int32_t> v_pos; DevBuf<uint8_t> v_ref0, v_alt0, v_danger, v_hpoly, v_erased, v_hp1; DevBuf<uint16_t> v_rl, v_al;
+    DevBuf<int32_t> v_ps; bool has_hap = false;
+    DevBuf<char> ref;
+    // reads
+    int nR = 0; uint64_t n_cig = 0, n_seq = 0, n_qual = 0;
+    DevBuf<int32_t> r_start, r_lq; DevBuf<uint16_t> r_flag; DevBuf<uint8_t> r_mapq; DevBuf<uint32_t> r_name;
+    DevBuf<uint64_t> r_coff, r_soff, r_qoff; DevBuf<uint32_t> cigar; DevBuf<uint8_t> seq, qual;
+    // observations
+    DevBuf<uint32_t> row_off; DevBuf<int32_t> row_cnt, row_fail, g_cnt; DevBuf<uint8_t> row_flags, deleted;
+    DevBuf<int32_t> obs_var, g_node; DevBuf<uint16_t> obs_aq; DevBuf<uint8_t> g_flag;
+    unsigned long long obs_capacity = 0;
+    // clips / cnv
+    DevBuf<int32_t> clip_pos, clip_read, clip_op; unsigned clip_capacity = 0;
+    DevBuf<unsigned long long> clip_keys, clip_keys_s;
+    DevBuf<int32_t> cnv_start, cnv_end;
+    DevBuf<long long> agg_sum; DevBuf<int32_t> agg_cnt; DevBuf<double> miss;
+    // groups
+    DevBuf<unsigned long long> name_keys, name_keys_s;
+    DevBuf<uint32_t> head, gidx, gstart, read_group, stack, mrow_off, koff; DevBuf<int32_t> mrow_cnt;
+    // nodes / graph
+    DevBuf<uint32_t> is_node, vtype_key, node_of, node_off, node_end, bsize, cnt4;
+    DevBuf<int32_t> nodes, block; DevBuf<uint8_t> ntype, einfo; DevBuf<int8_t> hp;
+    DevBuf<unsigned long long> nkeys, nkeys_s; DevBuf<uint32_t> nvals, nvals_s;
+    DevBuf<float> edge;
+    DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
+    DevBuf<char> temp; size_t temp_bytes = 0;
+    LpsCounters *d_cnt = nullptr; LpsCounters h_cnt{};
+    // timing
+    hipEvent_t ev[ST_COUNT + 1]{}; bool ev_used[ST_COUNT + 1]{};
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    lps_timings tm{};
+    bool phase_valid = false;
+    int m_bits = 0, a_bits = 16, n_bits = 0;
+};
+
+static int fail(lps_ctx *c, const std::string &m, int code = -1) { if (c) c->err = m; return code; }
+
+template <class T>
+static void upload(lps_ctx *c, DevBuf<T> &b, const T *src, size_t n, size_t at = 0, bool keep = false) {
+    b.reserve(at + n, c->stream, keep, at);
+    if (n) HIP_TRY(hipMemcpyAsync(b.p + at, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+}
+
+template <class T>
+static std::vector<T> download(lps_ctx *c, const T *p, size_t n) {
+    std::vector<T> h(n);
+    if (n) HIP_TRY(hipMemcpyAsync(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return h;
+}
+
+extern "C" {
+
+int lps_abi_version(void) { return LPS_ABI_VERSION; }
+
+int lps_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(lps_params); case 1: return (int)sizeof(lps_variant_table); case 2: return (int)sizeof(lps_read_batch);
+        case 3: return (int)sizeof(lps_phase_result); case 4: return (int)sizeof(lps_haplotag_result); case 5: return (int)sizeof(lps_timings);
+    }
+    return -1;
+}
+
+int lps_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+void lps_default_params(lps_params *p) {
+    memset(p, 0, sizeof *p);
+    p->is_ont = 1; p->phase_indel = 0; p->distance = 300000; p->connect_adjacent = 35; p->mapping_quality = 1;
+    p->base_quality = 12; p->edge_weight = 0.1; p->snp_confidence = 0.75; p->read_confidence = 0.65;
+    p->edge_threshold = 0.7; p->overlap_threshold = 0.2; p->percentage_threshold = 0.6; p->tag_supplementary = 0;
+}
+
+const char *lps_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : nullptr; }
+
+lps_ctx *lps_create(int device, const lps_params *params) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { fprintf(stderr, "lps_create: no HIP device available (the product path has no CPU fallback)\n"); return nullptr; }
+    if (device < 0 || device >= n) { fprintf(stderr, "lps_create: device %d out of range (%d devices)\n", device, n); return nullptr; }
+    if (params->connect_adjacent < 1 || params->connect_adjacent > LPS_MAX_ADJACENT) { fprintf(stderr, "lps_create: connect_adjacent must be in [1,%d]\n", LPS_MAX_ADJACENT); return nullptr; }
+    lps_ctx *c = new lps_ctx();
+    try {
+        c->device = device; c->P = *params;
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc((void **)&c->d_cnt, sizeof(LpsCounters)));
+        for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventCreate(&c->ev_begin)); HIP_TRY(hipEventCreate(&c->ev_end));
+    } catch (std::string &e) { fprintf(stderr, "lps_create: %s\n", e.c_str()); delete c; return nullptr; }
+    return c;
+}
+
+void lps_destroy(lps_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->d_cnt) (void)hipFree(c->d_cnt);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *lps_last_error(lps_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
+void *lps_stream(lps_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int lps_begin_chromosome(lps_ctx *c) {
+    if (!c) return -1;
+    c->nV = 0; c->last_pos = -1; c->ref_len = c->ref_len_eff = 0; c->nR = 0; c->n_cig = c->n_seq = c->n_qual = 0;
+    c->phase_valid = false; c->has_hap = false; c->h_vpos.clear();
+    return 0;
+}
+
+int lps_set_variants(lps_ctx *c, const lps_variant_table *t) {
+    if (!c || !t) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        if (t->n > 0x3fffff) return fail(c, "variant table larger than 2^22 rows per chromosome");
+        for (int64_t i = 1; i < t->n; ++i) if (t->pos[i] <= t->pos[i - 1]) return fail(c, "variant positions must be strictly increasing");
+        c->nV = (int)t->n; c->last_pos = t->n ? t->pos[t->n - 1] : -1;
+        c->h_vpos.assign(t->pos, t->pos + t->n);
+        upload(c, c->v_pos, t->pos, t->n); upload(c, c->v_ref0, t->ref0, t->n); upload(c, c->v_alt0, t->alt0, t->n);
+        upload(c, c->v_rl, t->ref_len, t->n); upload(c, c->v_al, t->alt_len, t->n);
+        c->v_danger.reserve(t->n + 1); c->v_hpoly.reserve(t->n + 1); c->v_erased.reserve(t->n + 1);
+        c->has_hap = t->hp1_is_alt && t->phase_set;
+        if (c->has_hap) { upload(c, c->v_hp1, t->hp1_is_alt, t->n); upload(c, c->v_ps, t->phase_set, t->n); }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->phase_valid = false;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_set_reference(lps_ctx *c, const char *seq, int64_t len) {
+    if (!c || !seq) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        if (c->nV == 0) return fail(c, "lps_set_variants must be called before lps_set_reference");
+        const long long eff = std::min<long long>(len, (long long)c->last_pos + 6);    // ParsingBam.cpp:47
+        if (eff <= c->last_pos) return fail(c, "reference shorter than the last variant position");
+        c->ref_len = len; c->ref_len_eff = eff;
+        upload(c, c->ref, seq, (size_t)eff);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->phase_valid = false;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_push_reads(lps_ctx *c, const lps_read_batch *b) {
+    if (!c || !b) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        const size_t n = (size_t)b->n_reads; if (n == 0) return 0;
+        if ((uint64_t)c->nR + n > 0x1fffffffull) return fail(c, "more than 2^29 alignments per chromosome");
+        const uint64_t nc = b->cigar_off[n] - b->cigar_off[0], ns = b->seq_off[n] - b->seq_off[0], nq = b->qual_off[n] - b->qual_off[0];
+        // operand shapes the kernels rely on
+        for (size_t i = 0; i < n; ++i) {
+            if (b->cigar_off[i + 1] < b->cigar_off[i] || b->seq_off[i + 1] < b->seq_off[i] || b->qual_off[i + 1] < b->qual_off[i]) return fail(c, "offsets must be non-decreasing");
+            if (b->l_qseq[i] < 0 || (uint64_t)((b->l_qseq[i] + 1) / 2) > b->seq_off[i + 1] - b->seq_off[i] || (uint64_t)b->l_qseq[i] > b->qual_off[i + 1] - b->qual_off[i]) return fail(c, "seq/qual shorter than l_qseq");
+            if (i && b->ref_start[i] < b->ref_start[i - 1]) return fail(c, "alignments must be coordinate-sorted");
+        }
+        const size_t at = (size_t)c->nR;
+        upload(c, c->r_start, b->ref_start, n, at, true); upload(c, c->r_lq, b->l_qseq, n, at, true);
+        upload(c, c->r_flag, b->flag, n, at, true); upload(c, c->r_mapq, b->mapq, n, at, true);
+        upload(c, c->r_name, b->name_id, n, at, true);
+        std::vector<uint64_t> co(n + 1), so(n + 1), qo(n + 1);
+        for (size_t i = 0; i <= n; ++i) { co[i] = b->cigar_off[i] - b->cigar_off[0] + c->n_cig; so[i] = b->seq_off[i] - b->seq_off[0] + c->n_seq; qo[i] = b->qual_off[i] - b->qual_off[0] + c->n_qual; }
+        upload(c, c->r_coff, co.data(), n + 1, at, true); upload(c, c->r_soff, so.data(), n + 1, at, true); upload(c, c->r_qoff, qo.data(), n + 1, at, true);
+        upload(c, c->cigar, b->cigar + b->cigar_off[0], (size_t)nc, (size_t)c->n_cig, true);
+        upload(c, c->seq, b->seq + b->seq_off[0], (size_t)ns, (size_t)c->n_seq, true);
+        upload(c, c->qual, b->qual + b->qual_off[0], (size_t)nq, (size_t)c->n_qual, true);
+        HIP_TRY(hipStreamSynchronize(c->stream));          // co/so/qo are stack-owned
+        c->nR += (int)n; c->n_cig += nc; c->n_seq += ns; c->n_qual += nq;
+        c->phase_valid = false;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+static int bits_for(unsigned long long n) { int b = 1; while ((1ull << b) < n) ++b; return b; }
+
+static void mark(lps_ctx *c, int st) { HIP_TRY(hipEventRecord(c->ev[st], c->stream)); c->ev_used[st] = true; }
+
+static VarView var_view(lps_ctx *c) {
+    VarView V{};
+    V.n = c->nV; V.pos = c->v_pos.p; V.ref0 = c->v_ref0.p; V.alt0 = c->v_alt0.p; V.ref_len = c->v_rl.p; V.alt_len = c->v_al.p;
+    V.danger = c->v_danger.p; V.hpoly = c->v_hpoly.p; V.erased = c->v_erased.p; V.hp1_is_alt = c->v_hp1.p; V.phase_set = c->v_ps.p;
+    V.ref = c->ref.p; V.ref_len_eff = c->ref_len_eff; V.last_pos = c->last_pos;
+    return V;
+}
+static ReadView read_view(lps_ctx *c) {
+    ReadView R{};
+    R.n = c->nR; R.ref_start = c->r_start.p; R.l_qseq = c->r_lq.p; R.flag = c->r_flag.p; R.mapq = c->r_mapq.p; R.name_id = c->r_name.p;
+    R.cigar_off = c->r_coff.p; R.seq_off = c->r_soff.p; R.qual_off = c->r_qoff.p; R.cigar = c->cigar.p; R.seq = c->seq.p; R.qual = c->qual.p;
+    return R;
+}
+
+static int run_phase(lps_ctx *c) {
+    const lps_params &P = c->P; hipStream_t s = c->stream;
+    const int nR = c->nR, nV = c->nV, A = P.connect_adjacent;
+    // ---- capacities
+    if (c->obs_capacity == 0) c->obs_capacity = std::max<unsigned long long>(1024, (unsigned long long)nR * 48);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        const unsigned long long cap = c->obs_capacity;
+        c->row_off.reserve(nR + 1); c->row_cnt.reserve(nR + 1); c->row_fail.reserve(nR + 1); c->row_flags.reserve(nR + 1);
+        c->g_cnt.reserve(nR + 1); c->deleted.reserve(nR + 1);
+        c->obs_var.reserve(cap); c->obs_aq.reserve(cap); c->g_node.reserve(cap); c->g_flag.reserve(cap);
+        c->clip_capacity = (unsigned)std::min<unsigned long long>(0x7fffffff, 4ull * nR + 64);
+        c->clip_pos.reserve(c->clip_capacity); c->clip_read.reserve(c->clip_capacity); c->clip_op.reserve(c->clip_capacity);
+        c->clip_keys.reserve(c->clip_capacity); c->clip_keys_s.reserve(c->clip_capacity);
+        c->cnv_start.reserve(LPS_MAX_CNV); c->cnv_end.reserve(LPS_MAX_CNV);
+        c->name_keys.reserve(nR + 1); c->name_keys_s.reserve(nR + 1);
+        c->head.reserve(nR + 1); c->gidx.reserve(nR + 1); c->gstart.reserve(nR + 2); c->read_group.reserve(nR + 1); c->stack.reserve(nR + 1);
+        c->mrow_off.reserve(nR + 1); c->mrow_cnt.reserve(nR + 1); c->koff.reserve(nR + 1);
+        c->is_node.reserve(nV + 1); c->vtype_key.reserve(nV + 1); c->node_of.reserve(nV + 1); c->node_off.reserve(nV + 1); c->node_end.reserve(nV + 1);
+        c->bsize.reserve(nV + 1); c->cnt4.reserve((size_t)nV * 4 + 4); c->nodes.reserve(nV + 1); c->block.reserve(nV + 1);
+        c->ntype.reserve(nV + 1); c->hp.reserve(nV + 1);
+        c->einfo.reserve((size_t)nV * A + 64); c->edge.reserve((size_t)nV * A * 4 + 16);
+        c->out_ps.reserve(nV + 1); c->out_gt.reserve(nV + 1);
+        const size_t need = GraphTemp::need((size_t)std::max<unsigned long long>(cap, (unsigned long long)std::max(nR, nV) + 1));
+        if (need > c->temp_bytes) { c->temp.reserve(need); c->temp_bytes = need; }
+
+        for (auto &u : c->ev_used) u = false;
+        HIP_TRY(hipEventRecord(c->ev_begin, s));
+        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
+        HIP_TRY(hipMemsetAsync(c->out_ps.p, 0, (size_t)nV * sizeof(int32_t), s));
+        HIP_TRY(hipMemsetAsync(c->out_gt.p, 0, (size_t)nV, s));
+        // ---- a4/a5/a6 variant table prep
+        VarView V = var_view(c); ReadView R = read_view(c);
+        mark(c, ST_PREP);
+        launch_variant_prep(V, P.is_ont, s);
+        // ---- a1/a2/a3 extraction
+        ObsView O{c->row_off.p, c->row_cnt.p, c->row_fail.p, c->row_flags.p, c->obs_var.p, c->obs_aq.p, cap};
+        ClipView C{c->clip_pos.p, c->clip_read.p, c->clip_op.p, c->clip_capacity};
+        mark(c, ST_EXTRACT);
+        launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, s);
+        // ---- name keys (needs only row_cnt); S1: counters to host (sizes of the sorts)
+        mark(c, ST_GROUPS);
+        launch_name_keys(nR, c->r_name.p, c->row_cnt.p, c->name_keys.p, c->d_cnt, s);
+        HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) { c->err = "alignment find unsupported CIGAR operation"; return -2; }
+        if (c->h_cnt.err & LPS_ERR_CLIP_OVERFLOW) { c->err = "clip event buffer overflow"; return -3; }
+        if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = c->h_cnt.obs_total + c->h_cnt.obs_total / 2 + 1024; continue; }
+        const unsigned long long n_keys = c->h_cnt.obs_total;
+        if (n_keys + n_keys / 2 > cap) { /* leave room for merged tails */ }
+        sort_keys64(c->temp.p, c->temp_bytes, c->name_keys.p, c->name_keys_s.p, nR, 64, s);
+        launch_groups(c->name_keys_s.p, nR, c->d_cnt, c->head.p, c->gidx.p, c->gstart.p, c->read_group.p, c->temp.p, c->temp_bytes, s);
+        // ---- a7 clips -> CNV intervals
+        mark(c, ST_CLIP);
+        launch_clip_cnv(C, c->row_fail.p, c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, c->cnv_start.p, c->cnv_end.p, c->d_cnt, s);
+        // ---- a8 overlap filter
+        mark(c, ST_OVERLAP);
+        HIP_TRY(hipMemsetAsync(c->deleted.p, 0, nR, s));
+        launch_overlap_filter(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->row_cnt.p, c->obs_var.p, c->v_pos.p, P.overlap_threshold, c->stack.p, c->deleted.p, s);
+        // ---- a9 CNV mismatch filter (device-side no-op when there are no intervals)
+        mark(c, ST_CNV);
+        c->agg_sum.reserve((size_t)nV * 2 + 2); c->agg_cnt.reserve((size_t)nV * 2 + 2); c->miss.reserve(nV + 1);
+        launch_cnv_filter(c->d_cnt, nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->v_pos.p, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, s);
+        // ---- a10 nodes + graph observations
+        mark(c, ST_NODES);
+        HIP_TRY(hipMemsetAsync(c->is_node.p, 0, (size_t)(nV + 1) * 4, s));
+        HIP_TRY(hipMemsetAsync(c->vtype_key.p, 0, (size_t)(nV + 1) * 4, s));
+        launch_nodes(nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->is_node.p, c->vtype_key.p, c->node_of.p, c->nodes.p, c->ntype.p, P.base_quality, c->g_node.p, c->g_flag.p, c->g_cnt.p, c->d_cnt, c->temp.p, c->temp_bytes, s);
+        // ---- merged rows
+        mark(c, ST_MERGE);
+        HIP_TRY(hipMemsetAsync(c->mrow_cnt.p, 0, (size_t)(nR + 1) * 4, s));
+        launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, cap, c->mrow_off.p, c->mrow_cnt.p, s);
+        // ---- node-major sorted lists
+        mark(c, ST_NODELISTS);
+        c->m_bits = bits_for((unsigned long long)nR + 1); c->n_bits = bits_for((unsigned long long)nV + 2); c->a_bits = 16;
+        if (c->m_bits + c->n_bits + c->a_bits > 63) { c->err = "sort key overflow"; return -4; }
+        c->nkeys.reserve(n_keys + 1); c->nkeys_s.reserve(n_keys + 1); c->nvals.reserve(n_keys + 1); c->nvals_s.reserve(n_keys + 1);
+        HIP_TRY(hipMemsetAsync(c->node_off.p, 0, (size_t)(nV + 1) * 4, s));
+        HIP_TRY(hipMemsetAsync(c->node_end.p, 0, (size_t)(nV + 1) * 4, s));
+        launch_node_lists(c->d_cnt, nR, nV, c->mrow_off.p, c->mrow_cnt.p, c->koff.p, c->g_node.p, c->m_bits, c->a_bits, c->n_bits, c->nkeys.p, c->nkeys_s.p, c->nvals.p, c->nvals_s.p, n_keys, c->node_off.p, c->node_end.p, c->temp.p, c->temp_bytes, s);
+        // ---- a11/a12 edges
+        mark(c, ST_EDGES);
+        launch_edges(c->d_cnt, nV, c->node_off.p, c->node_end.p, c->nkeys_s.p, c->nvals_s.p, c->mrow_off.p, c->mrow_cnt.p, c->m_bits, c->a_bits, c->g_node.p, c->g_flag.p, A, P.edge_weight, P.edge_threshold, c->edge.p, c->einfo.p, s);
+        // ---- a13 vote scan
+        mark(c, ST_SCAN);
+        launch_vote_scan(c->d_cnt, c->nodes.p, c->v_pos.p, c->ntype.p, c->einfo.p, A, P.distance, c->hp.p, c->block.p, s);
+        // ---- a14/a15 read correction + export
+        mark(c, ST_CORR);
+        HIP_TRY(hipMemsetAsync(c->bsize.p, 0, (size_t)(nV + 1) * 4, s));
+        HIP_TRY(hipMemsetAsync(c->cnt4.p, 0, ((size_t)nV * 4 + 4) * 4, s));
+        launch_correction(c->d_cnt, nR, nV, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->v_pos.p, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
+        mark(c, ST_D2H);
+        HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
+        return 0;
+    }
+    c->err = "observation buffer kept overflowing";
+    return -5;
+}
+
+int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
+    if (!c || !out) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        if (out->n != c->nV) return fail(c, "lps_phase_result.n must equal the variant table size");
+        memset(out->phase_set, 0, (size_t)out->n * sizeof(int32_t)); memset(out->gt, 0, (size_t)out->n);
+        c->phase_valid = false;
+        if (c->nV == 0 || c->nR == 0) return 0;
+        if (c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
+        int rc = run_phase(c);
+        if (rc != 0) return rc;
+        HIP_TRY(hipMemcpyAsync(out->phase_set, c->out_ps.p, (size_t)c->nV * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(out->gt, c->out_gt.p, (size_t)c->nV, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_end, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = c->h_cnt.obs_total * 2 + 1024; return lps_phase_chromosome(c, out); }
+        if (c->h_cnt.err & LPS_ERR_KEY_RANGE) return fail(c, "a merged read has more than 65536 observations", -6);
+        if (c->h_cnt.err & LPS_ERR_CNV_CAP) return fail(c, "more than 64 CNV intervals on one chromosome", -7);
+        // timings
+        lps_timings &t = c->tm; memset(&t, 0, sizeof t);
+        t.n_stages = ST_COUNT;
+        int prev = -1;
+        for (int i = 0; i <= ST_COUNT; ++i) {
+            const bool last = (i == ST_COUNT);
+            if (!last && !c->ev_used[i]) continue;
+            if (prev >= 0) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[prev], last ? c->ev_end : c->ev[i])); t.ms_kernel[prev] = ms; }
+            prev = i;
+        }
+        HIP_TRY(hipEventElapsedTime(&t.ms_total, c->ev_begin, c->ev_end));
+        t.n_obs = (int64_t)c->h_cnt.n_obs_final; t.n_nodes = c->h_cnt.n_nodes; t.n_pairs = (int64_t)c->h_cnt.n_pairs; t.n_reads_used = c->h_cnt.n_kept;
+        // algorithmic bytes (SURVEY.md §8d closed forms)
+        t.algorithmic_bytes[ST_EXTRACT] = 36ll * c->nR + 4ll * (int64_t)c->n_cig + (int64_t)c->h_cnt.n_obs_final * (1 + 1 + 12 + 8);
+        t.algorithmic_bytes[ST_EDGES] = 8ll * (int64_t)c->h_cnt.n_pairs + 8ll * (int64_t)c->h_cnt.n_obs_final + 16ll * c->P.connect_adjacent * (int64_t)c->h_cnt.n_nodes;
+        t.algorithmic_bytes[ST_SCAN] = (16ll * c->P.connect_adjacent + 64) * (int64_t)c->h_cnt.n_nodes;
+        t.algorithmic_bytes[ST_CORR] = 16ll * (int64_t)c->h_cnt.n_obs_final + 32ll * (int64_t)c->h_cnt.n_nodes;
+        c->phase_valid = true;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
+    (void)out;
+    return fail(c, "lps_haplotag_chromosome: not built yet", -100);
+}
+
+int lps_get_timings(lps_ctx *c, lps_timings *t) { if (!c || !t) return -1; *t = c->tm; return 0; }
+
+// ------------------------------------------------------------------------------------------------ dumps
+int64_t lps_dump_observations(lps_ctx *c, int32_t *obs_count, int32_t *var_index, int8_t *allele, int16_t *quality, int64_t capacity) {
+    if (!c || !c->phase_valid) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        auto off = download(c, c->row_off.p, c->nR); auto cntv = download(c, c->row_cnt.p, c->nR);
+        const size_t tot = (size_t)std::min<unsigned long long>(c->h_cnt.obs_total, c->obs_capacity);
+        auto var = download(c, c->obs_var.p, tot); auto aq = download(c, c->obs_aq.p, tot);
+        int64_t n = 0;
+        for (int r = 0; r < c->nR; ++r) {
+            if (obs_count) obs_count[r] = cntv[r];
+            for (int k = 0; k < cntv[r]; ++k, ++n) {
+                if (var_index && n < capacity) {
+                    int v = var[off[r] + k]; if (v < 0) v = -1 - v;       // erased later by the CNV filter
+                    var_index[n] = v; allele[n] = (int8_t)aq_allele(aq[off[r] + k]); quality[n] = (int16_t)aq_quality(aq[off[r] + k]);
+                }
+            }
+        }
+        return n;
+    } catch (std::string &e) { fail(c, e); return -1; }
+}
+
+int64_t lps_dump_graph(lps_ctx *c, int32_t *node_var_index, float *edge, int64_t node_capacity) {
+    if (!c || !c->phase_valid) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        const int64_t N = c->h_cnt.n_nodes;
+        if (node_var_index && N <= node_capacity) {
+            auto nd = download(c, c->nodes.p, (size_t)N); memcpy(node_var_index, nd.data(), (size_t)N * 4);
+            if (edge) { auto e = download(c, c->edge.p, (size_t)N * c->P.connect_adjacent * 4); memcpy(edge, e.data(), e.size() * 4); }
+        }
+        return N;
+    } catch (std::string &e) { fail(c, e); return -1; }
+}
+
+int64_t lps_dump_votes(lps_ctx *c, int8_t *hp, int32_t *block_node, int64_t node_capacity) {
+    if (!c || !c->phase_valid) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        const int64_t N = c->h_cnt.n_nodes;
+        if (hp && N <= node_capacity) {
+            auto h = download(c, c->hp.p, (size_t)N); memcpy(hp, h.data(), (size_t)N);
+            auto b = download(c, c->block.p, (size_t)N); memcpy(block_node, b.data(), (size_t)N * 4);
+        }
+        return N;
+    } catch (std::string &e) { fail(c, e); return -1; }
+}
+
+int64_t lps_dump_clips(lps_ctx *c, int32_t *pos, uint8_t *front_back, int64_t capacity) {
+    if (!c || !c->phase_valid) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        const size_t n = c->h_cnt.n_clips;
+        auto k = download(c, c->clip_keys_s.p, n);
+        int64_t m = 0;
+        for (size_t i = 0; i < n; ++i) { if (k[i] == ~0ull) break; if (pos && m < capacity) { pos[m] = (int32_t)(k[i] >> 1); front_back[m] = (uint8_t)(k[i] & 1); } ++m; }
+        return m;
+    } catch (std::string &e) { fail(c, e); return -1; }
+}
+
+int lps_dump_cnv(lps_ctx *c, int32_t *start, int32_t *end, uint8_t *aln_deleted) {
+    if (!c || !c->phase_valid) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        const int n = (int)c->h_cnt.n_cnv;
+        auto s = download(c, c->cnv_start.p, (size_t)n); auto e = download(c, c->cnv_end.p, (size_t)n);
+        for (int i = 0; i < n; ++i) { start[i] = s[i]; end[i] = e[i]; }
+        if (aln_deleted) { auto d = download(c, c->deleted.p, (size_t)c->nR); memcpy(aln_deleted, d.data(), (size_t)c->nR); }
+        return n;
+    } catch (std::string &e) { fail(c, e); return -1; }
+}
+
+}  // extern "C"

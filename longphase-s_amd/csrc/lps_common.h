@@ -1,0 +1,164 @@
+// lps_common.h — shared device/host helpers of liblps_hip.so (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/lps_abi.h"
+
+#define LPS_WAVE 64
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            char _b[512];                                                                               \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            throw std::string(_b);                                                                      \
+        }                                                                                               \
+    } while (0)
+
+// ---------------------------------------------------------------- device memory
+// Growable device buffer.  grow() keeps contents only when keep=true (append buffers).
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    void reserve(size_t n, hipStream_t s = nullptr, bool keep = false, size_t used = 0) {
+        if (n <= cap) return;
+        size_t nc = cap ? cap : 256;
+        while (nc < n) nc = nc + nc / 2 + 256;
+        T *q = nullptr;
+        HIP_TRY(hipMalloc((void **)&q, nc * sizeof(T)));
+        if (keep && p && used) HIP_TRY(hipMemcpyAsync(q, p, used * sizeof(T), hipMemcpyDeviceToDevice, s));
+        if (p) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(p)); }
+        p = q; cap = nc;
+    }
+};
+
+// ---------------------------------------------------------------- error / status words written by kernels
+enum {
+    LPS_ERR_BAD_CIGAR = 1,      // unsupported CIGAR op (reference: exit(1), ParsingBam.cpp:1625-1628)
+    LPS_ERR_OBS_OVERFLOW = 2,   // observation buffer too small -> host grows and reruns
+    LPS_ERR_KEY_RANGE = 4,      // sort-key field overflow (row longer than 2^18 or >2^22 nodes)
+    LPS_ERR_CNV_CAP = 8,        // more than LPS_MAX_CNV CNV intervals
+    LPS_ERR_CLIP_OVERFLOW = 16,
+};
+
+// device-side counters block (one per ctx), zeroed at the start of every run
+struct LpsCounters {
+    unsigned long long obs_total;   // reserved observation slots (rows + merged tails)
+    unsigned int n_clips;
+    unsigned int err;
+    unsigned int n_kept;            // alignments with >=1 observation
+    unsigned int n_groups;          // distinct read names among kept alignments
+    unsigned int n_nodes;
+    unsigned int n_cnv;
+    unsigned int ub_hazard;
+    unsigned long long n_pairs;
+    unsigned long long n_obs_final; // observations of kept alignments after all filters
+    unsigned int n_multi;           // merged rows built from >=2 alignments
+    unsigned int pad;
+};
+
+// ---------------------------------------------------------------- wave-level primitives (wave64)
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <class T>
+__device__ __forceinline__ T wave_incl_scan(T v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T o = __shfl_up(v, d);
+        if (lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+template <class T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
+    return v;
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    return (1ull << lane_id()) - 1ull;
+}
+
+// Wave-cooperative lower_bound over a sorted global int array: first index in [lo,hi) with a[idx] >= key.
+// 64-ary search: ~3 rounds for 3e5 elements instead of 18 dependent loads.  All lanes must call with equal args.
+__device__ __forceinline__ int wave_lower_bound(const int32_t *__restrict__ a, int lo, int hi, int key) {
+    const int l = lane_id();
+    while (hi - lo > 64) {
+        const int step = (hi - lo + 63) >> 6;            // probes at lo + (l+1)*step - 1
+        long long pi = (long long)lo + (long long)(l + 1) * step - 1;
+        bool lt = (pi < hi) ? (a[pi] < key) : false;
+        const int c = __popcll(__ballot(lt));            // number of probe points < key (prefix property)
+        const int nlo = lo + c * step;                   // everything before is < key
+        const int nhi = min(hi, lo + (c + 1) * step);    // probe c is >= key (or out of range)
+        lo = nlo; hi = nhi;
+        if (lo >= hi) return lo;
+    }
+    bool lt = (lo + l < hi) ? (a[lo + l] < key) : false;
+    return lo + __popcll(__ballot(lt));
+}
+
+// homopolymerLength (src/shared/Util.cpp:21-54) on the truncated reference prefix
+__device__ __forceinline__ int homopolymer_length(const char *__restrict__ ref, long long ref_len, long long p) {
+    int len = 1;
+    if (p + 1 >= ref_len) return len;
+    const char e = ref[p];
+    long long q = p - 1;
+    while (q >= 0 && ref[q] == e) { --q; ++len; if (len >= 10 || q < 0) break; }
+    q = p + 1;
+    if (q < ref_len) {
+        while (ref[q] == e) { ++q; ++len; if (q >= ref_len) break; if (len >= 10) break; }
+    }
+    return len;
+}
+
+__device__ __forceinline__ char nt16_char(int code) {
+    // htslib seq_nt16_str "=ACMGRSVTWYHKDBN" packed little-endian into two 64-bit words
+    const unsigned long long lo = 0x565352474d43413dull, hi = 0x4e42444b48595754ull;
+    code &= 15;
+    return (char)(((code < 8 ? lo : hi) >> ((code & 7) * 8)) & 0xff);
+}
+
+// observation quality/allele packing: bits 0..8 = quality+8 (sentinels -4/-5 .. 255), bit 9 = allele
+__host__ __device__ __forceinline__ uint16_t pack_aq(int allele, int quality) { return (uint16_t)((allele << 9) | ((quality + 8) & 0x1ff)); }
+__host__ __device__ __forceinline__ int aq_allele(uint16_t aq) { return (aq >> 9) & 1; }
+__host__ __device__ __forceinline__ int aq_quality(uint16_t aq) { return (int)(aq & 0x1ff) - 8; }
+
+#define LPS_MAX_CNV 64
+#define LPS_SEG 1024          // CIGAR ops staged in LDS per wave and segment
+
+// edge info byte written by the edge kernel and consumed by the vote scan
+//  bits 0-1: direction (0 none, 1 same haplotype, 2 different)   bit 2: weight 20   bit 3: single-read vote
+//  bit 4: ESR < 0.2
+#define EI_DIR(x) ((x) & 3)
+#define EI_W20 4
+#define EI_SINGLE 8
+#define EI_LOWESR 16

@@ -1,0 +1,173 @@
+"""ctypes binding of csrc/liblps_hip.so — the product path (hand-written HIP kernels behind include/lps_abi.h).
+
+There is NO CPU fallback: load() raises when the shared library (or any declared symbol) is missing, and
+Context() raises when no GPU is visible.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.abspath(os.path.join(_HERE, "..", "csrc", "liblps_hip.so"))
+HEADER = os.path.abspath(os.path.join(_HERE, "..", "..", "include", "lps_abi.h"))
+
+_lib = None
+
+
+def declared_symbols():
+    """Every function include/lps_abi.h declares."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lps_[a-z_0-9]+)\s*\(", txt)))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+                           "The product path has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for sym in declared_symbols():
+        if not hasattr(L, sym):
+            raise RuntimeError(f"liblps_hip.so does not export {sym} declared in include/lps_abi.h")
+    L.lps_create.restype = C.c_void_p
+    L.lps_create.argtypes = [C.c_int, C.POINTER(abi.Params)]
+    L.lps_destroy.argtypes = [C.c_void_p]
+    L.lps_last_error.restype = C.c_char_p
+    L.lps_last_error.argtypes = [C.c_void_p]
+    L.lps_begin_chromosome.argtypes = [C.c_void_p]
+    L.lps_set_variants.argtypes = [C.c_void_p, C.POINTER(abi.VariantTable)]
+    L.lps_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.lps_push_reads.argtypes = [C.c_void_p, C.POINTER(abi.ReadBatch)]
+    L.lps_phase_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.PhaseResult)]
+    L.lps_haplotag_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.HaplotagResult)]
+    L.lps_get_timings.argtypes = [C.c_void_p, C.POINTER(abi.Timings)]
+    L.lps_stage_name.restype = C.c_char_p
+    L.lps_stage_name.argtypes = [C.c_int]
+    L.lps_stream.restype = C.c_void_p
+    L.lps_stream.argtypes = [C.c_void_p]
+    L.lps_dump_observations.restype = C.c_int64
+    L.lps_dump_observations.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int64]
+    L.lps_dump_graph.restype = C.c_int64
+    L.lps_dump_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.lps_dump_votes.restype = C.c_int64
+    L.lps_dump_votes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.lps_dump_clips.restype = C.c_int64
+    L.lps_dump_clips.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.lps_dump_cnv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+class LpsError(RuntimeError):
+    pass
+
+
+class Context:
+    """One lps_ctx = one GPU, one chromosome at a time."""
+
+    def __init__(self, device=0, params=None):
+        self.L = load()
+        self.params = params or abi.default_params()
+        self.h = self.L.lps_create(device, C.byref(self.params))
+        if not self.h:
+            raise LpsError("lps_create failed (no GPU visible?) - the product path has no CPU fallback")
+        self.n_var = 0
+        self.n_reads = 0
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise LpsError(f"{what} rc={rc}: {self.L.lps_last_error(self.h).decode()}")
+
+    def load_chromosome(self, variants, ref, reads_list):
+        """begin_chromosome + set_variants + set_reference + push_reads (H2D, untimed part of the benchmark)."""
+        self._check(self.L.lps_begin_chromosome(self.h), "lps_begin_chromosome")
+        self._check(self.L.lps_set_variants(self.h, C.byref(variants.c)), "lps_set_variants")
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        self._check(self.L.lps_set_reference(self.h, ref.ctypes.data, ref.size), "lps_set_reference")
+        self.n_reads = 0
+        for r in (reads_list if isinstance(reads_list, (list, tuple)) else [reads_list]):
+            self._check(self.L.lps_push_reads(self.h, C.byref(r.c)), "lps_push_reads")
+            self.n_reads += r.n_reads
+        self.n_var = variants.n
+
+    def run_phase(self, out=None):
+        out = out or abi.PhaseOut(self.n_var)
+        self._check(self.L.lps_phase_chromosome(self.h, C.byref(out.c)), "lps_phase_chromosome")
+        return out
+
+    def phase(self, variants, ref, reads):
+        self.load_chromosome(variants, ref, reads)
+        return self.run_phase()
+
+    def timings(self):
+        t = abi.Timings()
+        self._check(self.L.lps_get_timings(self.h, C.byref(t)), "lps_get_timings")
+        names = [self.L.lps_stage_name(i).decode() for i in range(t.n_stages)]
+        return dict(stages={n: t.ms_kernel[i] for i, n in enumerate(names)}, ms_total=t.ms_total, n_obs=t.n_obs,
+                    n_nodes=t.n_nodes, n_pairs=t.n_pairs, n_reads_used=t.n_reads_used,
+                    algorithmic_bytes={n: t.algorithmic_bytes[i] for i, n in enumerate(names)})
+
+    # ---- stage dumps (parity tests)
+    def dump_observations(self):
+        n = self.L.lps_dump_observations(self.h, None, None, None, None, 0)
+        if n < 0:
+            raise LpsError("lps_dump_observations failed")
+        cnt = np.zeros(self.n_reads, np.int32)
+        var = np.zeros(max(n, 1), np.int32)
+        al = np.zeros(max(n, 1), np.int8)
+        q = np.zeros(max(n, 1), np.int16)
+        self.L.lps_dump_observations(self.h, cnt.ctypes.data, var.ctypes.data, al.ctypes.data, q.ctypes.data, n)
+        return cnt, var[:n], al[:n], q[:n]
+
+    def dump_graph(self, with_edges=True):
+        n = self.L.lps_dump_graph(self.h, None, None, 0)
+        nodes = np.zeros(max(n, 1), np.int32)
+        A = self.params.connect_adjacent
+        edge = np.zeros((max(n, 1), A, 4), np.float32) if with_edges else None
+        self.L.lps_dump_graph(self.h, nodes.ctypes.data, edge.ctypes.data if with_edges else None, n)
+        return nodes[:n], (edge[:n] if with_edges else None)
+
+    def dump_votes(self):
+        n = self.L.lps_dump_votes(self.h, None, None, 0)
+        hp = np.zeros(max(n, 1), np.int8)
+        blk = np.zeros(max(n, 1), np.int32)
+        self.L.lps_dump_votes(self.h, hp.ctypes.data, blk.ctypes.data, n)
+        return hp[:n], blk[:n]
+
+    def dump_clips(self):
+        n = self.L.lps_dump_clips(self.h, None, None, 0)
+        pos = np.zeros(max(n, 1), np.int32)
+        fb = np.zeros(max(n, 1), np.uint8)
+        self.L.lps_dump_clips(self.h, pos.ctypes.data, fb.ctypes.data, n)
+        return pos[:n], fb[:n]
+
+    def dump_cnv(self):
+        s = np.zeros(64, np.int32)
+        e = np.zeros(64, np.int32)
+        d = np.zeros(max(self.n_reads, 1), np.uint8)
+        n = self.L.lps_dump_cnv(self.h, s.ctypes.data, e.ctypes.data, d.ctypes.data)
+        return s[:n], e[:n], d[:self.n_reads]
+
+    def close(self):
+        if self.h:
+            self.L.lps_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

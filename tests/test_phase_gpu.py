@@ -1,0 +1,108 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle and the reference's golden vectors.
+Bit-exact for genotypes, phase sets, observations, nodes, votes; the fp32 edge matrix is compared exactly too
+(the kernels replay the reference's accumulation order)."""
+import numpy as np
+import pytest
+
+import fixtures
+import lps_oracle
+import util
+from lps import abi, hip
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(kw, over):
+    s, V, R = util.make_case(kw)
+    P = abi.default_params(**over)
+    ref_out, d = lps_oracle.phase(P, V, s.ref, R, dump=True)
+    ctx = hip.Context(0, P)
+    out = ctx.phase(V, s.ref, R)
+    return s, V, R, P, ref_out, d, ctx, out
+
+
+@pytest.mark.parametrize("name", sorted(fixtures.PHASE_FIXTURES))
+def test_phase_matches_oracle_and_golden(name):
+    kw, cli, over = fixtures.PHASE_FIXTURES[name]
+    s, V, R, P, ref_out, d, ctx, out = run_both(kw, over)
+    try:
+        # stage: observations (per alignment, in position order)
+        cnt, var, al, q = ctx.dump_observations()
+        n = d.c.n_obs
+        assert np.array_equal(cnt, d.obs_count), "per-read observation counts differ"
+        assert np.array_equal(var, d.obs_var[:n]) and np.array_equal(al, d.obs_allele[:n])
+        assert np.array_equal(q.astype(np.int32), d.obs_quality[:n].astype(np.int32))
+        # stage: clips + CNV intervals + overlap filter
+        cp, cf = ctx.dump_clips()
+        o = np.lexsort((d.clip_fb[:d.c.n_clips], d.clip_pos[:d.c.n_clips]))
+        assert np.array_equal(cp, d.clip_pos[:d.c.n_clips][o]) and np.array_equal(cf, d.clip_fb[:d.c.n_clips][o])
+        cs, ce, dele = ctx.dump_cnv()
+        assert list(cs) == list(d.c.cnv_start[:d.c.n_cnv]) and list(ce) == list(d.c.cnv_end[:d.c.n_cnv])
+        assert np.array_equal(dele, d.aln_deleted)
+        # stage: graph nodes + fp32 edge matrix (exact: same accumulation order)
+        nodes, edge = ctx.dump_graph()
+        N = d.c.n_nodes
+        assert np.array_equal(nodes, d.node_var[:N])
+        assert np.array_equal(edge.view(np.uint32), d.edge[:N].view(np.uint32)), "edge matrix differs bitwise"
+        # stage: vote scan
+        hp, blk = ctx.dump_votes()
+        assert np.array_equal(hp, d.node_hp[:N]) and np.array_equal(blk, d.node_block[:N])
+        # final result vs oracle and vs the reference binary's golden output
+        util.assert_phase_equal(out.phase_set, out.gt, ref_out.phase_set, ref_out.gt, name + " vs oracle")
+        gpos, gps, ggt = util.load_golden_phase(name)
+        util.assert_phase_equal(out.phase_set, out.gt, gps, ggt, name + " vs reference golden")
+    finally:
+        ctx.close()
+
+
+def test_repeat_runs_are_identical_and_recomputed():
+    kw, cli, over = fixtures.PHASE_FIXTURES["snp_ont_seed2"]
+    s, V, R = util.make_case(kw)
+    with hip.Context(0, abi.default_params()) as ctx:
+        ctx.load_chromosome(V, s.ref, R)
+        a = ctx.run_phase()
+        b = ctx.run_phase()
+        assert np.array_equal(a.phase_set, b.phase_set) and np.array_equal(a.gt, b.gt)
+        t = ctx.timings()
+        assert t["n_obs"] > 0 and t["stages"]["extract"] > 0
+
+
+def test_batched_push_equals_single_push():
+    kw, cli, over = fixtures.PHASE_FIXTURES["snp_ont"]
+    s, V, R = util.make_case(kw)
+    n = R.n_reads
+    parts = [R.subset(np.arange(0, n // 3)), R.subset(np.arange(n // 3, n // 2)), R.subset(np.arange(n // 2, n))]
+    with hip.Context(0, abi.default_params()) as ctx:
+        a = ctx.phase(V, s.ref, R)
+        b = ctx.phase(V, s.ref, parts)
+        assert np.array_equal(a.phase_set, b.phase_set) and np.array_equal(a.gt, b.gt)
+
+
+def test_empty_and_degenerate_inputs():
+    kw, cli, over = fixtures.PHASE_FIXTURES["snp_ont"]
+    s, V, R = util.make_case(kw)
+    with hip.Context(0, abi.default_params()) as ctx:
+        # no reads at all
+        out = ctx.phase(V, s.ref, R.subset(np.zeros(0, np.int64)))
+        assert (out.phase_set == 0).all()
+        # all reads filtered by MAPQ
+        ctx2 = hip.Context(0, abi.default_params(mapping_quality=61))
+        out = ctx2.phase(V, s.ref, R)
+        assert (out.phase_set == 0).all()
+        ctx2.close()
+        # a single read cannot phase anything but must not crash
+        one = R.subset(np.array([np.argmax(R.l_qseq)]))
+        ref_out, _ = lps_oracle.phase(abi.default_params(), V, s.ref, one)
+        out = ctx.phase(V, s.ref, one)
+        util.assert_phase_equal(out.phase_set, out.gt, ref_out.phase_set, ref_out.gt, "single read")
+
+
+def test_config1_scale_matches_oracle():
+    """BASELINE.json configs[0]: 5 Mb, 10x, ~5k het SNPs."""
+    s, V, R = util.make_case(dict(seed=1, contig_len=5_000_000, n_snp=5000, coverage=10.0))
+    P = abi.default_params()
+    ref_out, _ = lps_oracle.phase(P, V, s.ref, R)
+    with hip.Context(0, P) as ctx:
+        out = ctx.phase(V, s.ref, R)
+    util.assert_phase_equal(out.phase_set, out.gt, ref_out.phase_set, ref_out.gt, "config1")
+    assert (out.phase_set != 0).sum() > 4900
