@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the `phase` hot path on MI355X (BASELINE.json metric: het SNPs phased / s).
+
+A step = one lps_phase_chromosome() over the resident decoded reads of one synthetic chr20-sized contig at 30x
+(BASELINE.json configs[1]): everything from allele extraction to phased genotypes is recomputed from the raw
+reads in HBM and the result is copied back to host memory.  Inputs are uploaded before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W
+N>1 (launched by torch.distributed.run, one rank per GPU): every rank owns an independent contig shard (weak
+scaling, no data-path collective - phasing never crosses contigs); torch.distributed only provides
+the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "longphase-s_amd"))
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: germline phase chr20, 30x ONT synthetic, ~60k het SNPs
+    "chr20_30x": dict(contig_len=64_444_167, n_snp=60_000, coverage=30.0),
+    # BASELINE.json configs[0] (plumbing size)
+    "5mb_10x": dict(contig_len=5_000_000, n_snp=5_000, coverage=10.0),
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(seed, threads, sample_mb=8):
+    """Reference CPU path on a bounded sample of the same workload (same generator, same density/coverage).
+    kind 'reference' = the real LongPhase-S binary (oracle/_ref, BAM+VCF+FASTA in, incl. BGZF/BAM decode);
+    falls back to kind 'port' (the oracle restatement on decoded arrays, 1 thread) when the binary is absent."""
+    from lps.synth import Synth
+    from lps import abi
+    kw = dict(WORKLOADS["chr20_30x"])
+    frac = sample_mb * 1e6 / kw["contig_len"]
+    kw.update(contig_len=int(sample_mb * 1e6), n_snp=int(kw["n_snp"] * frac), seed=seed + 7000, n_threads=threads)
+    s = Synth(**kw)
+    sample = f"{sample_mb} Mb contig at 30x from the same generator ({s.n_reads} alignments, {s.n_variants} het SNPs)"
+    out = {}
+    # port: oracle restatement on decoded SoA, single thread
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lps_oracle
+    V = abi.Variants(s.var_pos, s.var_ref, s.var_alt)
+    R = abi.Reads.from_synth(s)
+    t0 = time.time()
+    o, _ = lps_oracle.phase(abi.default_params(), V, s.ref, R)
+    tp = time.time() - t0
+    port = dict(value=float((o.phase_set != 0).sum() / tp), unit="SNPs/s", cores=1, kind="port", sample=sample,
+                note="decoded arrays in memory, no BAM/BGZF decode")
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "longphase-s-ref")
+    tv = os.path.join(ROOT, "oracle", "_ref", "test_view")
+    if os.path.exists(ref_bin) and os.path.exists(tv):
+        try:
+            with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
+                s.write_fasta(d + "/ref.fa"); s.write_vcf(d + "/in.vcf"); s.write_sam(d + "/reads.sam")
+                subprocess.check_call([tv, "-b", "-x", "reads.bam.bai", "-p", "reads.bam", "reads.sam"], cwd=d, stdout=subprocess.DEVNULL)
+                os.remove(d + "/reads.sam")
+                cmd = [ref_bin, "phase", "-s", "in.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(threads), "-o", "out", "--ont"]
+                subprocess.run(cmd, cwd=d, capture_output=True)                     # warm the page cache
+                ts = []
+                for _ in range(3):
+                    t0 = time.time(); r = subprocess.run(cmd, cwd=d, capture_output=True); ts.append(time.time() - t0)
+                    assert r.returncode == 0, r.stderr[-500:]
+                ts.sort()
+                n_ph = sum(1 for ln in open(d + "/out.vcf") if not ln.startswith("#") and not ln.rstrip().endswith(":."))
+            out = dict(value=float(n_ph / ts[1]), unit="SNPs/s", cores=threads, kind="reference",
+                       sample=sample + f"; median of 3 runs of `longphase-s phase -t {threads}` end to end (one contig => one compute thread, the rest feed BGZF)",
+                       port_value=port["value"], port_note=port["note"])
+        except Exception as e:  # noqa: BLE001
+            log("cpu_baseline: reference run failed, using the port:", repr(e)[:300])
+    if not out:
+        out = port
+    s.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="chr20_30x", choices=sorted(WORKLOADS))
+    ap.add_argument("--seed", type=int, default=101)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gen-threads", type=int, default=0)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        log(f"warning: WORLD_SIZE={world} != --gpus {a.gpus}; using WORLD_SIZE")
+    n_gpus = max(world, 1)
+
+    # product library first (binds the ROCm runtime it was built against); torch only for the multi-rank barrier
+    from lps import abi, hip
+    from lps.synth import Synth
+    hip.load()
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only (barrier / max)
+
+    ncpu = os.cpu_count() or 8
+    threads = a.gen_threads or max(2, min(16, ncpu // max(1, min(world, 8))))
+    kw = dict(WORKLOADS[a.workload]); kw.update(seed=a.seed + rank, n_threads=threads)
+    t0 = time.time()
+    s = Synth(**kw)
+    V = abi.Variants(s.var_pos, s.var_ref, s.var_alt)
+    R = abi.Reads.from_synth(s)
+    if rank == 0:
+        log(f"generated {a.workload}: {s.n_reads} alignments, {s.n_variants} het SNPs, {s.qual.size/1e9:.2f} Gbases in {time.time()-t0:.1f}s")
+    P = abi.default_params()
+    ctx = hip.Context(local_rank, P)
+    t0 = time.time()
+    ctx.load_chromosome(V, s.ref, R)
+    h2d_s = time.time() - t0
+    out = abi.PhaseOut(V.n)
+    for _ in range(a.warmup):
+        ctx.run_phase(out)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    stage_ms = {}
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(a.steps):
+        ctx.run_phase(out)                      # synchronous: returns with results in host memory (stream drained)
+        for k, v in ctx.timings()["stages"].items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + v
+    elapsed = time.perf_counter() - t_start
+    barrier()
+    n_phased = int((out.phase_set != 0).sum())
+    tm = ctx.timings()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([n_phased], dtype=torch.float64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_phased = float(c.item())
+    else:
+        total_phased = float(n_phased)
+
+    if rank == 0:
+        stage_avg = {k: v / a.steps for k, v in stage_ms.items()}
+        dom = max((k for k in stage_avg if k != "d2h"), key=lambda k: stage_avg[k])
+        alg = tm["algorithmic_bytes"]
+        # roofline of the dominant kernel (by time), algorithmic bytes / measured duration (hipEvents on the lib's stream)
+        dom_bytes = alg.get(dom, 0)
+        achieved = dom_bytes / (stage_avg[dom] * 1e-3) / 1e9 if stage_avg[dom] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(a.workload, {}).get(dom)
+            except Exception:  # noqa: BLE001
+                traffic = None
+        stages = {}
+        for k, v in stage_avg.items():
+            b = alg.get(k, 0)
+            stages[k] = dict(ms=round(v, 4), alg_bytes=int(b), gbs=round(b / (v * 1e-3) / 1e9, 2) if v > 0 and b else None)
+        res = {
+            "metric": "het SNPs phased/sec", "value": total_phased * a.steps / elapsed, "unit": "SNPs/s",
+            "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32/f32", "data": "synthetic",
+            "config": {"workload": f"germline phase, {a.workload} synthetic ONT ({s.n_reads} alignments, {s.n_variants} het SNPs, "
+                                   f"{s.qual.size/1e9:.2f} Gbases) per GPU; decoded reads resident in HBM", "seed": a.seed,
+                       "phased_per_step_per_gpu": n_phased, "obs": tm["n_obs"], "pairs": tm["n_pairs"], "nodes": tm["n_nodes"],
+                       "h2d_seconds_untimed": round(h2d_s, 2)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "dominant stage by time; per-stage algorithmic GB/s in `stages`"},
+            "stages": stages,
+        }
+        if not a.no_cpu_baseline:
+            t0 = time.time()
+            res["cpu_baseline"] = cpu_baseline(a.seed, min(16, ncpu))
+            log(f"cpu baseline took {time.time()-t0:.1f}s")
+        print(json.dumps(res), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,4 +71,9 @@ def phase(params, variants, ref, reads, dump=False, with_edges=True):
                             C.byref(out.c), C.byref(d.c) if d else None)
     if rc != 0:
         raise RuntimeError(f"oracle_phase rc={rc}")
+    if d is not None and d.c.n_obs > d.c.obs_capacity:      # observation dump did not fit: rerun with the exact size
+        d = PhaseDump(reads.n_reads, variants.n, params.connect_adjacent, obs_cap=int(d.c.n_obs) + 16, with_edges=with_edges)
+        rc = lib().oracle_phase(C.byref(params), C.byref(variants.c), ref.ctypes.data, ref.size, C.byref(reads.c),
+                                C.byref(out.c), C.byref(d.c))
+        assert rc == 0
     return out, d
