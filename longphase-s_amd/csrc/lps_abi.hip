@@ -5,7 +5,7 @@
 //   reference  chars [0, lastVariant+5]
 //   reads      ref_start,l_qseq i32 | flag u16 | mapq u8 | name_id u32 | 3 x u64 offsets | cigar u32[] | seq 4-bit | qual u8
 //   obs rows   var i32 + aq u16 per observation, rows placed by atomic reservation; g_node i32 + g_flag u8 mirror them
-//   graph      node-major sorted (key u64, slot u32) list | edge f32[N][A][4] | einfo u8[N][A] | hp i8[N] | block i32[N]
+//   graph      node-major sorted (key u64, slot u32) list | edge f32[N][A][4] | vote records {f32 w,u32 flags}[N][A] | hp i8[N] | block i32[N]
 // Every lps_phase_chromosome() recomputes all stages from the resident raw reads.
 #include <algorithm>
 #include <cmath>
@@ -48,7 +48,7 @@ struct lps_ctx {
     DevBuf<uint32_t> head, gidx, gstart, read_group, stack, mrow_off, koff; DevBuf<int32_t> mrow_cnt;
     // nodes / graph
     DevBuf<uint32_t> is_node, vtype_key, node_of, node_off, node_end, bsize, cnt4;
-    DevBuf<int32_t> nodes, block; DevBuf<uint8_t> ntype, einfo; DevBuf<int8_t> hp;
+    DevBuf<int32_t> nodes, block; DevBuf<uint8_t> ntype; DevBuf<unsigned long long> erec; DevBuf<unsigned> clip_stats; DevBuf<int8_t> hp, hp_v; DevBuf<int32_t> blk_v, seg_i32; DevBuf<char> st_b, st_e; DevBuf<uint32_t> node_pairs; DevBuf<uint8_t> nstate;
     DevBuf<unsigned long long> nkeys, nkeys_s; DevBuf<uint32_t> nvals, nvals_s;
     DevBuf<float> edge;
     DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
@@ -242,7 +242,9 @@ static int run_phase(lps_ctx *c) {
         c->is_node.reserve(nV + 1); c->vtype_key.reserve(nV + 1); c->node_of.reserve(nV + 1); c->node_off.reserve(nV + 1); c->node_end.reserve(nV + 1);
         c->bsize.reserve(nV + 1); c->cnt4.reserve((size_t)nV * 4 + 4); c->nodes.reserve(nV + 1); c->block.reserve(nV + 1);
         c->ntype.reserve(nV + 1); c->hp.reserve(nV + 1);
-        c->einfo.reserve((size_t)nV * A + 64); c->edge.reserve((size_t)nV * A * 4 + 16);
+        c->erec.reserve((size_t)nV * A + 64); c->clip_stats.reserve(4);
+        c->hp_v.reserve(2 * ((size_t)nV + 64)); c->blk_v.reserve(2 * ((size_t)nV + 64)); c->seg_i32.reserve(4 * (size_t)scan_segments(nV) + 4); c->node_pairs.reserve(nV + 1); c->nstate.reserve(nV + 1);
+        c->st_b.reserve(scan_state_bytes(nV)); c->st_e.reserve(scan_state_bytes(nV)); c->edge.reserve((size_t)nV * A * 4 + 16);
         c->out_ps.reserve(nV + 1); c->out_gt.reserve(nV + 1);
         const size_t need = GraphTemp::need((size_t)std::max<unsigned long long>(cap, (unsigned long long)std::max(nR, nV) + 1));
         if (need > c->temp_bytes) { c->temp.reserve(need); c->temp_bytes = need; }
@@ -275,7 +277,7 @@ static int run_phase(lps_ctx *c) {
         launch_groups(c->name_keys_s.p, nR, c->d_cnt, c->head.p, c->gidx.p, c->gstart.p, c->read_group.p, c->temp.p, c->temp_bytes, s);
         // ---- a7 clips -> CNV intervals
         mark(c, ST_CLIP);
-        launch_clip_cnv(C, c->row_fail.p, c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, c->cnv_start.p, c->cnv_end.p, c->d_cnt, s);
+        launch_clip_cnv(C, c->row_fail.p, c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, c->cnv_start.p, c->cnv_end.p, c->clip_stats.p, c->d_cnt, s);
         // ---- a8 overlap filter
         mark(c, ST_OVERLAP);
         HIP_TRY(hipMemsetAsync(c->deleted.p, 0, nR, s));
@@ -303,15 +305,15 @@ static int run_phase(lps_ctx *c) {
         launch_node_lists(c->d_cnt, nR, nV, c->mrow_off.p, c->mrow_cnt.p, c->koff.p, c->g_node.p, c->m_bits, c->a_bits, c->n_bits, c->nkeys.p, c->nkeys_s.p, c->nvals.p, c->nvals_s.p, n_keys, c->node_off.p, c->node_end.p, c->temp.p, c->temp_bytes, s);
         // ---- a11/a12 edges
         mark(c, ST_EDGES);
-        launch_edges(c->d_cnt, nV, c->node_off.p, c->node_end.p, c->nkeys_s.p, c->nvals_s.p, c->mrow_off.p, c->mrow_cnt.p, c->m_bits, c->a_bits, c->g_node.p, c->g_flag.p, A, P.edge_weight, P.edge_threshold, c->edge.p, c->einfo.p, s);
+        launch_edges(c->d_cnt, nV, c->node_off.p, c->node_end.p, c->nkeys_s.p, c->nvals_s.p, c->mrow_off.p, c->mrow_cnt.p, c->m_bits, c->a_bits, c->g_node.p, c->g_flag.p, A, P.edge_weight, P.edge_threshold, c->ntype.p, c->edge.p, c->erec.p, c->node_pairs.p, s);
         // ---- a13 vote scan
         mark(c, ST_SCAN);
-        launch_vote_scan(c->d_cnt, c->nodes.p, c->v_pos.p, c->ntype.p, c->einfo.p, A, P.distance, c->hp.p, c->block.p, s);
+        launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->v_pos.p, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2, c->hp.p, c->block.p, s);
         // ---- a14/a15 read correction + export
         mark(c, ST_CORR);
         HIP_TRY(hipMemsetAsync(c->bsize.p, 0, (size_t)(nV + 1) * 4, s));
         HIP_TRY(hipMemsetAsync(c->cnt4.p, 0, ((size_t)nV * 4 + 4) * 4, s));
-        launch_correction(c->d_cnt, nR, nV, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->v_pos.p, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
+        launch_correction(c->d_cnt, nR, nV, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->v_pos.p, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, c->node_pairs.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
         mark(c, ST_D2H);
         HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
         return 0;

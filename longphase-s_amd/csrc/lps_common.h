@@ -154,11 +154,3 @@ __host__ __device__ __forceinline__ int aq_quality(uint16_t aq) { return (int)(a
 
 #define LPS_MAX_CNV 64
 #define LPS_SEG 1024          // CIGAR ops staged in LDS per wave and segment
-
-// edge info byte written by the edge kernel and consumed by the vote scan
-//  bits 0-1: direction (0 none, 1 same haplotype, 2 different)   bit 2: weight 20   bit 3: single-read vote
-//  bit 4: ESR < 0.2
-#define EI_DIR(x) ((x) & 3)
-#define EI_W20 4
-#define EI_SINGLE 8
-#define EI_LOWESR 16

@@ -10,7 +10,7 @@ void exscan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out
 
 void launch_clip_cnv(const ClipView &C, const int32_t *row_fail, unsigned n_clips, unsigned long long *keys,
                      unsigned long long *keys_sorted, void *temp, size_t temp_bytes, int32_t *cnv_start, int32_t *cnv_end,
-                     LpsCounters *cnt, hipStream_t s);
+                     unsigned *stats, LpsCounters *cnt, hipStream_t s);
 void launch_name_keys(int n_reads, const uint32_t *name_id, const int32_t *row_cnt, unsigned long long *keys, LpsCounters *cnt, hipStream_t s);
 void launch_groups(const unsigned long long *skeys, int n_reads, LpsCounters *cnt, uint32_t *head, uint32_t *gidx,
                    uint32_t *gstart, uint32_t *read_group, void *temp, size_t temp_bytes, hipStream_t s);
@@ -35,10 +35,13 @@ void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t 
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
                   const unsigned long long *skeys, const uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                   int m_bits, int a_bits, const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
-                  double edge_threshold, float *edge, uint8_t *einfo, hipStream_t s);
-void launch_vote_scan(const LpsCounters *cnt, const int32_t *nodes, const int32_t *vpos, const uint8_t *ntype,
-                      const uint8_t *einfo, int A, int distance, int8_t *hp, int32_t *block, hipStream_t s);
-void launch_correction(const LpsCounters *cnt, int n_reads, int n_var, const uint32_t *row_off, const int32_t *g_cnt,
+                  double edge_threshold, const uint8_t *ntype, float *edge, unsigned long long *erec, uint32_t *node_pairs, hipStream_t s);
+size_t scan_state_bytes(int n_var);
+int scan_segments(int n_var);
+void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, const int32_t *vpos, const unsigned long long *erec,
+                      int A, int distance, int8_t *hp_v, int32_t *blk_v, void *st_b, void *st_e, int32_t *seg_i32,
+                      unsigned *n_replayed, int8_t *hp, int32_t *block, hipStream_t s);
+void launch_correction(LpsCounters *cnt, int n_reads, int n_var, const uint32_t *row_off, const int32_t *g_cnt,
                        const int32_t *g_node, const uint8_t *g_flag, const int32_t *nodes, const int32_t *vpos,
-                       const int32_t *block, uint32_t *bsize, const int8_t *hp, const uint8_t *ntype, double read_conf,
-                       double snp_conf, uint32_t *cnt4, int32_t *out_ps, uint8_t *out_gt, hipStream_t s);
+                       const int32_t *block, uint32_t *bsize, const int8_t *hp, const uint8_t *ntype, const uint32_t *node_pairs,
+                       uint8_t *nstate, double read_conf, double snp_conf, uint32_t *cnt4, int32_t *out_ps, uint8_t *out_gt, hipStream_t s);

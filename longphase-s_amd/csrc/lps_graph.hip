@@ -41,16 +41,34 @@ struct CnvState {
     }
 };
 
-// One thread: run-length the sorted clip keys into (pos, up, down) and replay the CNV state machine, twice
-// (Clip ctor + PhasingProcess.cpp:148), appending [start,end] pairs.  Sequential by nature, O(#clipped reads).
-__global__ void k_cnv_state(const unsigned long long *keys, unsigned n_clips, int32_t *cnv_start, int32_t *cnv_end,
-                            LpsCounters *cnt) {
+// Parallel pre-pass over the sorted clip keys: number of valid keys and the largest per-position FRONT / BACK count.
+// Every transition of the state machine that can emit an interval needs a position with >=5 front or >=5 back clips
+// (push needs up>=5; slowUp emits on down>=5 or down>=curr/4 with curr>20), so when the maximum is below 5 the
+// (sequential) state machine cannot produce anything and is skipped.
+__global__ void k_clip_stats(const unsigned long long *keys, unsigned n_clips, unsigned *stats /*[0]=n_valid,[1]=max run*/) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_clips) return;
+    const unsigned long long k = keys[i];
+    if (k == ~0ull) return;
+    if (i + 1 == n_clips || keys[i + 1] == ~0ull) stats[0] = i + 1;
+    if (i == 0 || keys[i - 1] != k) {                        // head of a run of equal (pos, front/back) keys
+        unsigned j = i + 1; while (j < n_clips && keys[j] == k && j - i < 5) ++j;
+        if (j - i >= 5) atomicMax(&stats[1], j - i);
+    }
+}
+
+// One thread: run-length the sorted clip keys into (pos, up, down) and replay the CNV state machine.  The reference
+// runs it twice on the same counts (Clip ctor + PhasingProcess.cpp:148) which appends the same intervals twice;
+// here it runs once and the result is duplicated.  Sequential by nature, O(#clipped positions).
+__global__ void k_cnv_state(const unsigned long long *keys, unsigned n_clips, const unsigned *stats, int32_t *cnv_start,
+                            int32_t *cnv_end, LpsCounters *cnt) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    unsigned n = 0; while (n < n_clips && keys[n] != ~0ull) ++n;    // invalid keys sort last
+    const unsigned n = stats[0];
     int n_cnv = 0;
     if (n == 0) { cnt->n_cnv = 0; cnt->ub_hazard += 1; return; }   // reference: UB on empty ClipCount
+    if (stats[1] < 5) { cnt->n_cnv = 0; return; }
     const int Area = 30000;
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < 1; ++rep) {
         CnvState s; s.reset();
         unsigned i = 0; bool sentinel_done = false; int last_up = 0, last_down = 0, last_pos = 0;
         while (true) {
@@ -84,8 +102,9 @@ __global__ void k_cnv_state(const unsigned long long *keys, unsigned n_clips, in
             }
         }
     }
-    if (n_cnv > LPS_MAX_CNV) { atomicOr(&cnt->err, (unsigned)LPS_ERR_CNV_CAP); n_cnv = LPS_MAX_CNV; }
-    cnt->n_cnv = n_cnv;
+    if (2 * n_cnv > LPS_MAX_CNV) { atomicOr(&cnt->err, (unsigned)LPS_ERR_CNV_CAP); n_cnv = LPS_MAX_CNV / 2; }
+    for (int q = 0; q < n_cnv; ++q) { cnv_start[n_cnv + q] = cnv_start[q]; cnv_end[n_cnv + q] = cnv_end[q]; }   // second run
+    cnt->n_cnv = 2 * n_cnv;
 }
 
 // ================================================================================================ name groups
@@ -295,7 +314,7 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const uint32_t *
         }
         w += __popcll(m);
     }
-    if (l == 0) { g_cnt[r] = w; atomicAdd(&cnt->n_obs_final, (unsigned long long)w); }
+    if (l == 0) g_cnt[r] = w;
 }
 
 // ================================================================================================ merged rows
@@ -315,11 +334,13 @@ __global__ void k_merge_rows(const unsigned long long *skeys, const uint32_t *gs
     const unsigned long long base = atomicAdd(&cnt->obs_total, (unsigned long long)total);
     if (base + total > capacity) { atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); mrow_off[g] = 0; mrow_cnt[g] = 0; return; }
     atomicAdd(&cnt->n_multi, 1u);
-    int w = 0;
+    int w = 0, last_nd = -1;
     for (uint32_t s = s0; s < s1; ++s) {
         const uint32_t r = (uint32_t)skeys[s];
-        for (int k = 0; k < g_cnt[r]; ++k) {
-            const int nd = g_node[row_off[r] + k]; const uint8_t fl = g_flag[row_off[r] + k];
+        const int n = g_cnt[r]; const uint32_t ro = row_off[r];
+        for (int k = 0; k < n; ++k) {
+            const int nd = g_node[ro + k]; const uint8_t fl = g_flag[ro + k];
+            if (nd >= last_nd) { g_node[base + w] = nd; g_flag[base + w] = fl; last_nd = nd; ++w; continue; }   // already in order
             int j = w;                                       // stable insertion
             while (j > 0 && g_node[base + j - 1] > nd) { g_node[base + j] = g_node[base + j - 1]; g_flag[base + j] = g_flag[base + j - 1]; --j; }
             g_node[base + j] = nd; g_flag[base + j] = fl; ++w;
@@ -335,6 +356,7 @@ __global__ __launch_bounds__(256) void k_node_keys(const LpsCounters *cnt, const
     const unsigned g = blockIdx.x * 4 + (threadIdx.x >> 6); const int l = lane_id();
     if (g >= cnt->n_groups) return;
     const int n = mrow_cnt[g];
+    if (g + 1 == cnt->n_groups && l == 0) cntw->n_obs_final = (unsigned long long)koff[g] + (unsigned)n;   // = sum of merged rows
     if (n > (1 << a_bits)) { if (l == 0) atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); return; }
     const uint32_t off = mrow_off[g], ko = koff[g];
     for (int a = l; a < n; a += 64) {
@@ -367,9 +389,10 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
                                                const unsigned long long *skeys, const uint32_t *svals,
                                                const uint32_t *mrow_off, const int32_t *mrow_cnt, int m_bits, int a_bits,
                                                const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
-                                               double edge_threshold, float *edge, uint8_t *einfo, LpsCounters *cntw) {
+                                               double edge_threshold, const uint8_t *ntype, float *edge, unsigned long long *erec, uint32_t *node_pairs) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
-    if (i >= (int)cnt->n_nodes) return;
+    const int n_nodes = (int)cnt->n_nodes;
+    if (i >= n_nodes) return;
     const uint32_t off = node_off[i], end = node_end[i];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     unsigned long long pairs = 0;
@@ -421,10 +444,13 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
             }
         }
     }
-    if (l == 0 && pairs) atomicAdd(&cntw->n_pairs, pairs);
+    if (l == 0) node_pairs[i] = (uint32_t)pairs;   // summed later (no single-address atomics in the hot kernel)
     if (l < A) {
         reinterpret_cast<float4 *>(edge)[(size_t)i * A + l] = make_float4(a0, a1, a2, a3);
-        // findBestEdgePair (:166-228): everything that does not depend on the scan state
+        // findBestEdgePair (:166-228) + the weight rules of edgeConnectResult (:216,:367) and Onelongcase (:261-265):
+        // everything that does not depend on the scan state is folded into one 8-byte vote record per (i,k):
+        //   .x = weight as float (0 = not connected / no such node), .y = flags: bit0 different haplotype,
+        //   bit1 single-read vote (para+cross <= 1), bit2 counts towards the Onelongcase sums
         const float rr = a0, ra = a1, ar = a2, aa = a3;
         const float para = rr + aa, cross = ra + ar;
         const double esr = (double)fminf(para, cross) / (double)fmaxf(para, cross);
@@ -434,128 +460,301 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
         const bool w20 = (esr <= 0.1 && (rr + aa + ra + ar) >= 1) || (para < 1 && cross >= 1) || (para >= 1 && cross < 1);
         const bool single = (para + cross) <= 1;
         const bool lowesr = esr < 0.2;
-        einfo[(size_t)i * A + l] = (uint8_t)(dir | (w20 ? EI_W20 : 0) | (single ? EI_SINGLE : 0) | (lowesr ? EI_LOWESR : 0));
+        const int typ = ntype[i];
+        float w = (typ == 4) ? 0.1f : (w20 ? 20.f : 1.f);
+        const bool osum = !single && lowesr && w >= 1.f && typ != 3;
+        if (dir == 0 || i + 1 + l >= n_nodes) w = 0.f;
+        const unsigned fl = (dir == 2 ? 1u : 0u) | (single ? 2u : 0u) | (osum ? 4u : 0u);
+        reinterpret_cast<uint2 *>(erec)[(size_t)i * A + l] = make_uint2(__float_as_uint(w), w != 0.f ? fl : 0u);
     }
 }
 
 // ================================================================================================ vote scan
-// ONE wavefront walks the nodes in position order (the reference's loop is a genuine serial dependence chain:
-// a node's haplotype depends on the votes of the <=A nodes before it).  Lane (n & 63) owns the vote accumulators
-// of node n; per node the owner lane decides, the decision is broadcast with v_readlane, and the A lanes of the
-// next A nodes add their votes.  Edge info (1 byte per pair) streams through LDS tiles of 64 nodes.
+// The reference's edgeConnectResult is a serial dependence chain: a node's haplotype depends on the votes of the
+// <=A nodes before it.  A single wavefront is instruction-issue bound (~6 cycles per instruction), so walking a
+// whole chromosome in one wave costs ~0.3 us per node.  Instead the chain is cut into segments of SCAN_SEG nodes
+// that are walked CONCURRENTLY, one wavefront each, from a speculative start SCAN_WARM nodes before the segment:
+//   * the speculative walk starts with the fresh state (no votes, no block) - after >=A consistently voted nodes
+//     the vote accumulators no longer depend on anything before the start, only the haplotype LABELS may be
+//     globally swapped; each wave therefore walks two variants (first block labelled 1 / labelled 2) interleaved
+//     in one instruction stream (two independent chains also hide each other's issue stalls);
+//   * k_scan_stitch then goes over the segments in order and accepts a variant only if its complete state at the
+//     segment boundary (five accumulators of all 64 pending nodes, pending-connection marker) is BIT-IDENTICAL to
+//     the true state handed over by the previous segment; block ids of the block that is open at the boundary are
+//     remapped.  If neither variant matches, that segment is replayed serially from the true state.
+// The result is therefore exactly the reference's, whatever the data; speculation only decides the speed.
+// Per node: lane (n & 63) owns the five vote accumulators of node n; the owner's decision is one v_readlane; the
+// A lanes of the following nodes add their votes with branch-free selects on the 8-byte vote records.
 #define SCAN_TILE 64
-__global__ __launch_bounds__(64) void k_vote_scan(const LpsCounters *cnt, const int32_t *nodes, const int32_t *vpos,
-                                                  const uint8_t *ntype, const uint8_t *einfo, int A, int distance,
-                                                  int8_t *hp_out, int32_t *block_out) {
-    __shared__ uint8_t s_info[2][SCAN_TILE * LPS_MAX_ADJACENT];
-    const int l = lane_id();
-    const int N = (int)cnt->n_nodes;
-    float h1 = 0.f, h2 = 0.f, o1 = 0.f, o2 = 0.f; int vc = 0;
-    int block_start = -1, last_connect = -1;
-    const int tile_bytes = SCAN_TILE * A;
-    constexpr int PRE = (SCAN_TILE * LPS_MAX_ADJACENT + 255) / 256;   // u32 words per lane covering one tile
-    uint32_t pre[PRE];
-    // global -> registers (issued at the start of a tile, consumed at its end: the latency hides under the tile)
-    auto fetch_tile = [&](int t0) {
-        const long long base = (long long)t0 * A, lim = (long long)N * A;
-#pragma unroll
-        for (int q = 0; q < PRE; ++q) {
-            const int b = q * 256 + l * 4;
-            uint32_t w = 0;
-            if (b < tile_bytes) {
-                if (base + b + 3 < lim) w = *reinterpret_cast<const uint32_t *>(einfo + base + b);   // 4-byte aligned: 64*A*t0
-                else for (int k = 0; k < 4; ++k) if (base + b + k < lim) w |= (uint32_t)einfo[base + b + k] << (8 * k);
-            }
-            pre[q] = w;
+#define SCAN_SEG 256
+#define SCAN_WARM 128
+
+struct Chain {
+    float h1, h2, o1, o2; int vc;      // per lane: accumulators of the node this lane owns
+    int lc, bs, force2;                // wave-uniform: lastConnectPos (node index), blockStart, pending label override
+    int my_hp, my_blk;                 // per lane: result of the node this lane owns in the current tile
+};
+
+__device__ __forceinline__ void chain_init(Chain &c, int force2) {
+    c.h1 = c.h2 = c.o1 = c.o2 = 0.f; c.vc = 0; c.lc = -1; c.bs = -1; c.force2 = force2; c.my_hp = 0; c.my_blk = -1;
+}
+
+// one node of edgeConnectResult (:306-418) for one chain.  s = owner lane of node i, rec = this lane's vote record.
+__device__ __forceinline__ void chain_step(Chain &c, int i, int s, int l, bool gap, unsigned long long rec) {
+    // Onelongcase override (:276), tie -> new block (:338), else argmax (:349)
+    const bool use_sp = (c.vc > 3) && !(c.o1 == 0.f && c.o2 == 0.f);
+    const float c1 = use_sp ? c.o1 : c.h1, c2 = use_sp ? c.o2 : c.h2;
+    const int code = (c1 == c2) ? 0 : (c1 > c2 ? 1 : 2);
+    const int code_s = __builtin_amdgcn_readlane(code, s);
+    const bool skip = gap || (code_s == 0 && i < c.lc);                                     // :318, :340
+    int hp_i = code_s;
+    if (skip) hp_i = 0;
+    else if (code_s == 0) { c.bs = i; hp_i = c.force2 ? 2 : 1; c.force2 = 0; }
+    if (l == s) { c.my_hp = hp_i; c.my_blk = skip ? -1 : c.bs; c.h1 = c.h2 = c.o1 = c.o2 = 0.f; c.vc = 0; }
+    if (!skip) {
+        const float w = __uint_as_float((unsigned)rec);
+        const unsigned fl = (unsigned)(rec >> 32);
+        const bool to2 = ((fl & 1u) != 0) != (hp_i == 2);                                   // target haplotype 2
+        const float wo = (fl & 4u) ? w : 0.f;
+        c.h1 += to2 ? 0.f : w; c.h2 += to2 ? w : 0.f;
+        c.o1 += to2 ? 0.f : wo; c.o2 += to2 ? wo : 0.f;
+        c.vc += (fl >> 1) & 1u;
+        const unsigned long long cm = __ballot(w != 0.f);
+        if (cm) {                                                                           // lastConnectPos = last connected target (:411)
+            const int sh = (s + 1) & 63;
+            const unsigned long long rot = sh ? ((cm >> sh) | (cm << (64 - sh))) : cm;
+            c.lc = i + 1 + (63 - __clzll(rot));
         }
-    };
-    auto stash_tile = [&](uint8_t *dst) {
-#pragma unroll
-        for (int q = 0; q < PRE; ++q) { const int b = q * 256 + l * 4; if (b < tile_bytes) *reinterpret_cast<uint32_t *>(dst + b) = pre[q]; }
-    };
-    if (l == 0 && N > 0) { hp_out[N - 1] = 0; block_out[N - 1] = -1; }   // the last node is never processed (:308-311)
-    if (N > 0) { fetch_tile(0); stash_tile(s_info[0]); }
-    wave_sync();
-    for (int t0 = 0, buf = 0; t0 < N; t0 += SCAN_TILE, buf ^= 1) {
-        const bool more = t0 + SCAN_TILE < N;
-        if (more) fetch_tile(t0 + SCAN_TILE);
-        // per-tile node attributes, one node per lane
-        const int n_me = t0 + l;
-        int my_pos = 0, my_next = 0, my_type = 0;
-        if (n_me < N) { my_pos = vpos[nodes[n_me]]; my_type = ntype[n_me]; }
-        if (n_me + 1 < N) my_next = vpos[nodes[n_me + 1]];
-        const int my_gap = (n_me + 1 < N) ? (abs(my_next - my_pos) > distance) : 1;
-        const unsigned long long gapmask = __ballot(my_gap != 0);
-        const uint8_t *info = s_info[buf];
-        const int tend = min(SCAN_TILE, N - 1 - t0);
-        for (int j = 0; j < tend; ++j) {
-            const int i = t0 + j, s = i & 63;
-            const bool use_sp = (vc > 3) && !(o1 == 0.f && o2 == 0.f);                    // Onelongcase (:276)
-            const float c1 = use_sp ? o1 : h1, c2 = use_sp ? o2 : h2;
-            const int code = (c1 == c2) ? 0 : (c1 > c2 ? 1 : 2);
-            const int code_s = __builtin_amdgcn_readlane(code, s);
-            const int typ = __builtin_amdgcn_readlane(my_type, j);
-            const bool gap = (gapmask >> j) & 1ull;
-            const bool skip = gap || (code_s == 0 && i < last_connect);                    // :318,:340
-            if (!skip && code_s == 0) block_start = i;
-            const int hp_i = skip ? 0 : (code_s == 0 ? 1 : code_s);
-            if (l == s) { hp_out[i] = (int8_t)hp_i; block_out[i] = skip ? -1 : block_start; h1 = h2 = o1 = o2 = 0.f; vc = 0; }
-            const int k = (l - s - 1) & 63;
-            const bool act = !skip && k < A && (i + 1 + k) < N;
-            const int inf = act ? info[j * A + k] : 0;
-            const int dir = inf & 3;
-            const bool conn = act && dir != 0;
-            const bool th1 = (hp_i == 1) == (dir == 1);
-            const float w = (typ == 4) ? 0.1f : ((inf & EI_W20) ? 20.f : 1.f);           // :216,:367
-            if (conn) {
-                if (th1) h1 += w; else h2 += w;
-                if (inf & EI_SINGLE) vc++;
-                else if ((inf & EI_LOWESR) && w >= 1.f && typ != 3) { if (th1) o1 += w; else o2 += w; }
-            }
-            const unsigned long long cm = __ballot(conn);
-            if (cm) {
-                const int sh = (s + 1) & 63;
-                const unsigned long long rot = sh ? ((cm >> sh) | (cm << (64 - sh))) : cm;
-                last_connect = max(last_connect, i + 1 + (63 - __clzll(rot)));
-            }
-        }
-        if (more) stash_tile(s_info[buf ^ 1]);
-        wave_sync();
     }
 }
 
-// ================================================================================================ read correction
-__global__ void k_block_size(const LpsCounters *cnt, const int32_t *block, uint32_t *bsize) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int)cnt->n_nodes) return;
-    if (block[i] >= 0) atomicAdd(&bsize[block[i]], 1u);
+// state hand-over record of one chain at a node boundary (before processing node `at`)
+struct ScanState { float h1[64], h2[64], o1[64], o2[64]; int vc[64]; int lc, bs, force2, pad; };
+
+__device__ __forceinline__ void state_save(const Chain &c, ScanState *st, int l, int at) {
+    st->h1[l] = c.h1; st->h2[l] = c.h2; st->o1[l] = c.o1; st->o2[l] = c.o2; st->vc[l] = c.vc;
+    if (l == 0) { st->lc = max(c.lc, at); st->bs = c.bs; st->force2 = c.force2; }          // lc <= at never compares true again
+}
+__device__ __forceinline__ void state_load(Chain &c, const ScanState *st, int l) {
+    c.h1 = st->h1[l]; c.h2 = st->h2[l]; c.o1 = st->o1[l]; c.o2 = st->o2[l]; c.vc = st->vc[l];
+    c.lc = st->lc; c.bs = st->bs; c.force2 = st->force2; c.my_hp = 0; c.my_blk = -1;
+}
+__device__ __forceinline__ bool state_equal(const Chain &c, int at, const ScanState *st, int l) {
+    const bool same = __float_as_uint(c.h1) == __float_as_uint(st->h1[l]) && __float_as_uint(c.h2) == __float_as_uint(st->h2[l]) &&
+                      __float_as_uint(c.o1) == __float_as_uint(st->o1[l]) && __float_as_uint(c.o2) == __float_as_uint(st->o2[l]) && c.vc == st->vc[l];
+    return __ballot(!same) == 0 && max(c.lc, at) == st->lc && c.force2 == 0 && st->force2 == 0;
 }
 
-// thread per alignment: readCorrection's per-read vote (:904-959).  Sequential in the read so that the 0.1
-// contributions of indel sites are summed in the reference's order (doubles).
-__global__ void k_read_correction(int n_reads, const uint32_t *row_off, const int32_t *g_cnt, const int32_t *g_node,
-                                  const uint8_t *g_flag, const int32_t *block, const uint32_t *bsize, const int8_t *hp,
-                                  const uint8_t *ntype, double read_confidence, uint32_t *cnt4) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+// gap flags (:318) of the 64 nodes of a tile as a scalar mask (bit j: node t0+j must be skipped)
+__device__ __forceinline__ unsigned long long tile_gapmask(const int32_t *nodes, const int32_t *vpos, int t0, int N, int distance, int l) {
+    const int n_me = t0 + l;
+    int my_pos = 0, my_next = 0;
+    if (n_me < N) my_pos = vpos[nodes[n_me]];
+    if (n_me + 1 < N) my_next = vpos[nodes[n_me + 1]];
+    return __ballot((n_me + 1 < N) ? (abs(my_next - my_pos) > distance) : true);
+}
+
+// speculative walk of segment blockIdx.x: two label variants interleaved; wave 1 of the workgroup streams the vote
+// records of the next 64-node tile global->LDS while wave 0 walks the current one.
+__global__ __launch_bounds__(128) void k_scan_spec(const LpsCounters *cnt, const int32_t *nodes, const int32_t *vpos,
+                                                   const unsigned long long *erec, int A, int distance,
+                                                   int8_t *hp_v /*[2][N]*/, int32_t *blk_v /*[2][N]*/, size_t vstride,
+                                                   ScanState *st_b /*[seg][2]*/, ScanState *st_e /*[seg][2]*/) {
+    __shared__ unsigned long long s_rec[2][SCAN_TILE * LPS_MAX_ADJACENT];
+    const int l = lane_id(), wv = threadIdx.x >> 6;
+    const int N = (int)cnt->n_nodes;
+    const int seg = blockIdx.x;
+    const int b = seg * SCAN_SEG;
+    if (b >= N) return;                                             // whole workgroup leaves together
+    const int a = max(0, b - SCAN_WARM), e = b + SCAN_SEG;          // walk [a, e); results for [b, e)
+    const int last = min(e, N - 1);                                 // the last node of a contig is never processed (:308-311)
+    const int tile_recs = SCAN_TILE * A;
+    auto load_tile = [&](int t0, unsigned long long *dst) {
+        const long long base = (long long)t0 * A, lim = (long long)N * A;
+        for (int q = l; q < tile_recs; q += 64) dst[q] = (base + q < lim) ? erec[base + q] : 0ull;
+    };
+    if (wv == 1) load_tile(a, s_rec[0]);
+    __syncthreads();
+    Chain c0, c1; chain_init(c0, 0); chain_init(c1, 1);
+    for (int t0 = a, buf = 0; t0 < e; t0 += SCAN_TILE, buf ^= 1) {
+        if (wv == 1) {
+            if (t0 + SCAN_TILE < e && t0 + SCAN_TILE < N) load_tile(t0 + SCAN_TILE, s_rec[buf ^ 1]);
+        } else {
+            if (t0 == b) { state_save(c0, &st_b[seg * 2 + 0], l, b); state_save(c1, &st_b[seg * 2 + 1], l, b); }
+            const unsigned long long gapmask = tile_gapmask(nodes, vpos, t0, N, distance, l);
+            const unsigned long long *rec = s_rec[buf];
+            const int tend = min(SCAN_TILE, last - t0);
+            int s = 0, k = (l - 1) & 63;                             // tiles are 64-aligned: owner lane of node t0+j is j
+            unsigned long long cur = (tend > 0 && k < A) ? rec[k] : 0ull;
+            c0.my_hp = c1.my_hp = 0; c0.my_blk = c1.my_blk = -1;
+            for (int j = 0; j < tend; ++j) {
+                const int kn = (k - 1) & 63;                         // prefetch the record of node i+1
+                const unsigned long long nxt = (j + 1 < tend && kn < A) ? rec[(j + 1) * A + kn] : 0ull;
+                const bool gap = (gapmask >> j) & 1ull;
+                chain_step(c0, t0 + j, s, l, gap, cur);
+                chain_step(c1, t0 + j, s, l, gap, cur);
+                cur = nxt; k = kn; s = (s + 1) & 63;
+            }
+            if (t0 >= b && t0 + l < N) {                             // coalesced result store of the tile (both variants)
+                hp_v[t0 + l] = (int8_t)c0.my_hp; blk_v[t0 + l] = c0.my_blk;
+                hp_v[vstride + t0 + l] = (int8_t)c1.my_hp; blk_v[vstride + t0 + l] = c1.my_blk;
+            }
+        }
+        __syncthreads();
+    }
+    if (wv == 0) { state_save(c0, &st_e[seg * 2 + 0], l, e); state_save(c1, &st_e[seg * 2 + 1], l, e); }
+}
+
+// wave per segment boundary: is the state a variant of segment seg-1 ends with bit-identical to the state a variant of
+// segment seg starts its segment proper with?  bit (v_prev*2 + v) of match[seg].
+__global__ __launch_bounds__(256) void k_scan_match(const LpsCounters *cnt, const ScanState *st_b, const ScanState *st_e, int32_t *match) {
+    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
+    const int N = (int)cnt->n_nodes;
+    const int n_seg = (N + SCAN_SEG - 1) / SCAN_SEG;
+    if (seg < 1 || seg >= n_seg) return;
+    int bits = 0;
+#pragma unroll
+    for (int vp = 0; vp < 2; ++vp)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const ScanState *x = &st_e[(seg - 1) * 2 + vp], *y = &st_b[seg * 2 + v];
+            const bool same = __float_as_uint(x->h1[l]) == __float_as_uint(y->h1[l]) && __float_as_uint(x->h2[l]) == __float_as_uint(y->h2[l]) &&
+                              __float_as_uint(x->o1[l]) == __float_as_uint(y->o1[l]) && __float_as_uint(x->o2[l]) == __float_as_uint(y->o2[l]) && x->vc[l] == y->vc[l];
+            if (__ballot(!same) == 0 && x->lc == y->lc && x->force2 == 0 && y->force2 == 0) bits |= 1 << (vp * 2 + v);
+        }
+    if (l == 0) match[seg] = bits;
+}
+
+// one wave: walk the segments in order.  With the boundary matches precomputed the chain is a handful of LDS reads per
+// segment; only a segment none of whose variants matches is replayed serially from the true state (records straight
+// from global memory), after which states are compared live until the walk is back on stored states.
+__global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, const int32_t *nodes, const int32_t *vpos,
+                                                    const unsigned long long *erec, int A, int distance,
+                                                    int8_t *hp_v, int32_t *blk_v, size_t vstride,
+                                                    const ScanState *st_b, const ScanState *st_e, const int32_t *match,
+                                                    int32_t *chosen /*[seg]*/, int32_t *remap_from, int32_t *remap_to, unsigned *n_replayed) {
+    extern __shared__ int s_seg[];                                  // [n_seg][5]: match, bs_b[2], bs_e[2]
+    const int l = lane_id();
+    const int N = (int)cnt->n_nodes;
+    const int n_seg = (N + SCAN_SEG - 1) / SCAN_SEG;
+    if (n_seg == 0) return;
+    for (int q = l; q < n_seg; q += 64) {
+        s_seg[q * 5 + 0] = q ? match[q] : 0;
+        s_seg[q * 5 + 1] = st_b[q * 2 + 0].bs; s_seg[q * 5 + 2] = st_b[q * 2 + 1].bs;
+        s_seg[q * 5 + 3] = st_e[q * 2 + 0].bs; s_seg[q * 5 + 4] = st_e[q * 2 + 1].bs;
+    }
+    wave_sync();
+    int prev_v = 0, cur_bs = s_seg[3];                              // segment 0 starts at node 0: its variant 0 IS the true walk
+    bool live = false; Chain t; chain_init(t, 0);
+    if (l == 0) { chosen[0] = 0; remap_from[0] = -2; remap_to[0] = -2; }
+    for (int seg = 1; seg < n_seg; ++seg) {
+        const int b = seg * SCAN_SEG, e = b + SCAN_SEG;
+        int mv = -1;
+        if (!live) { const int m = s_seg[seg * 5]; mv = (m >> (prev_v * 2)) & 1 ? 0 : ((m >> (prev_v * 2 + 1)) & 1 ? 1 : -1); }
+        else { if (state_equal(t, b, &st_b[seg * 2 + 0], l)) mv = 0; else if (state_equal(t, b, &st_b[seg * 2 + 1], l)) mv = 1; }
+        if (mv >= 0) {
+            const int open_spec = s_seg[seg * 5 + 1 + mv], open_true = cur_bs, end_bs = s_seg[seg * 5 + 3 + mv];
+            if (l == 0) { chosen[seg] = mv; remap_from[seg] = open_spec >= 0 ? open_spec : -2; remap_to[seg] = open_true; }
+            cur_bs = (end_bs == open_spec) ? open_true : end_bs;     // the block open at b is still open at e
+            prev_v = mv; live = false;
+        } else {
+            if (!live) { state_load(t, &st_e[(seg - 1) * 2 + prev_v], l); t.bs = cur_bs; live = true; }
+            if (l == 0) { chosen[seg] = 0; remap_from[seg] = -2; remap_to[seg] = -2; atomicAdd(n_replayed, 1u); }
+            const int last = min(e, N - 1);
+            for (int t0 = b; t0 < e && t0 < N; t0 += SCAN_TILE) {
+                const unsigned long long gapmask = tile_gapmask(nodes, vpos, t0, N, distance, l);
+                const int tend = min(SCAN_TILE, last - t0);
+                t.my_hp = 0; t.my_blk = -1;
+                for (int j = 0; j < tend; ++j) {
+                    const int i = t0 + j, k = (l - j - 1) & 63;
+                    const unsigned long long rec = (k < A) ? erec[(size_t)i * A + k] : 0ull;
+                    chain_step(t, i, j, l, (gapmask >> j) & 1ull, rec);
+                }
+                if (t0 + l < N) { hp_v[t0 + l] = (int8_t)t.my_hp; blk_v[t0 + l] = t.my_blk; }
+            }
+            cur_bs = t.bs;
+        }
+    }
+}
+
+__global__ void k_scan_finalize(const LpsCounters *cnt, const int8_t *hp_v, const int32_t *blk_v, size_t vstride,
+                                const int32_t *chosen, const int32_t *remap_from, const int32_t *remap_to,
+                                int8_t *hp_out, int32_t *block_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = (int)cnt->n_nodes;
+    if (i >= N) return;
+    if (i == N - 1) { hp_out[i] = 0; block_out[i] = -1; return; }
+    const int seg = i / SCAN_SEG, v = chosen[seg];
+    int blk = blk_v[(size_t)v * vstride + i];
+    if (blk >= 0 && blk == remap_from[seg]) blk = remap_to[seg];
+    hp_out[i] = hp_v[(size_t)v * vstride + i]; block_out[i] = blk;
+}
+
+// ================================================================================================ read correction
+__global__ void k_block_size(LpsCounters *cnt, const int32_t *block, const uint32_t *node_pairs, uint32_t *bsize, uint8_t *nstate,
+                             const int8_t *hp, const uint8_t *ntype) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < (int)cnt->n_nodes;
+    int b = in ? block[i] : -1;
+    unsigned long long pr = in ? node_pairs[i] : 0;
+    pr = wave_sum(pr);
+    if (lane_id() == 0 && pr) atomicAdd(&cnt->n_pairs, pr);
+    // per-node byte for the read-correction kernels: bit0 refhap (hp==2), bits1-3 type; "in a block" is added by k_node_state
+    if (in) nstate[i] = (uint8_t)((hp[i] == 1 ? 0 : 1) | (ntype[i] << 1));
+    // neighbouring nodes nearly always share their block: one atomic per distinct block per wave
+    unsigned long long todo = __ballot(b >= 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lb = __shfl(b, leader);
+        const unsigned long long same = __ballot(b == lb) & todo;
+        if (lane_id() == leader) atomicAdd(&bsize[lb], (unsigned)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+__global__ void k_node_state(const LpsCounters *cnt, const int32_t *block, const uint32_t *bsize, uint8_t *nstate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int)cnt->n_nodes) return;
+    const int b = block[i];
+    if (b >= 0 && bsize[b] > 1) nstate[i] |= 16;            // node carries a PS (block of size > 1)
+}
+
+// wave per alignment: readCorrection's per-read vote (:904-959).  SNP sites contribute integers (order-free, ballot +
+// popcount); as soon as the read touches an indel site the 0.1 contributions are summed by one lane in the reference's
+// order (doubles), so the result is bit-identical either way.
+__global__ __launch_bounds__(256) void k_read_correction(int n_reads, const uint32_t *row_off, const int32_t *g_cnt, const int32_t *g_node,
+                                                         const uint8_t *g_flag, const uint8_t *nstate, double read_confidence, uint32_t *cnt4) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
     if (r >= n_reads) return;
     const int n = g_cnt[r];
     if (n <= 0) return;
     const uint32_t off = row_off[r];
-    double rc = 0, ac = 0;
-    for (int k = 0; k < n; ++k) {
-        const int nd = g_node[off + k]; const int al = g_flag[off + k] & 1;
-        const int b = block[nd];
-        if (b >= 0 && bsize[b] > 1) {
-            const int refhap = (hp[nd] == 1) ? 0 : 1;
-            const int h = al == 0 ? refhap : 1 - refhap;
-            const int ty = ntype[nd];
-            if (ty == 0 || ty == 1) { if (h == 0) rc++; else ac++; }
+    int irc = 0, iac = 0; bool indel = false;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + l;
+        int st = 0, al = 0;
+        if (k < n) { st = nstate[g_node[off + k]]; al = g_flag[off + k] & 1; }
+        const bool live = (st & 16) != 0;
+        const int ty = (st >> 1) & 7;
+        const int h = al ^ (st & 1);                          // 0: haplotype 1, 1: haplotype 2
+        irc += __popcll(__ballot(live && ty <= 1 && h == 0));
+        iac += __popcll(__ballot(live && ty <= 1 && h == 1));
+        indel |= __ballot(live && ty >= 3) != 0;
+    }
+    double rc = irc, ac = iac;
+    if (indel) {                                              // exact order of the reference's double sums
+        rc = 0; ac = 0;
+        for (int k = 0; k < n; ++k) {
+            const int st = nstate[g_node[off + k]]; const int al = g_flag[off + k] & 1;
+            if (!(st & 16)) continue;
+            const int ty = (st >> 1) & 7, h = al ^ (st & 1);
+            if (ty <= 1) { if (h == 0) rc++; else ac++; }
             else if (ty == 3 || ty == 4) { if (h == 0) rc += 0.1; else ac += 0.1; }
         }
     }
     if (fmax(rc, ac) / (rc + ac) > read_confidence && (rc + ac) > 1) {
         const int bh = (rc > ac) ? 0 : 1;
-        for (int k = 0; k < n; ++k) atomicAdd(&cnt4[(size_t)g_node[off + k] * 4 + bh * 2 + (g_flag[off + k] & 1)], 1u);
+        for (int k = l; k < n; k += 64) atomicAdd(&cnt4[(size_t)g_node[off + k] * 4 + bh * 2 + (g_flag[off + k] & 1)], 1u);
     }
 }
 
@@ -611,12 +810,14 @@ void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const uin
 
 void launch_clip_cnv(const ClipView &C, const int32_t *row_fail, unsigned n_clips, unsigned long long *keys,
                      unsigned long long *keys_sorted, void *temp, size_t temp_bytes, int32_t *cnv_start, int32_t *cnv_end,
-                     LpsCounters *cnt, hipStream_t s) {
+                     unsigned *stats, LpsCounters *cnt, hipStream_t s) {
+    HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(unsigned), s));
     if (n_clips) {
         hipLaunchKernelGGL(k_clip_keys, GRID(n_clips, 256), 0, s, C, row_fail, n_clips, keys);
         sort_keys64(temp, temp_bytes, keys, keys_sorted, n_clips, 64, s);
+        hipLaunchKernelGGL(k_clip_stats, GRID(n_clips, 256), 0, s, keys_sorted, n_clips, stats);
     }
-    hipLaunchKernelGGL(k_cnv_state, dim3(1), dim3(64), 0, s, keys_sorted, n_clips, cnv_start, cnv_end, cnt);
+    hipLaunchKernelGGL(k_cnv_state, dim3(1), dim3(64), 0, s, keys_sorted, n_clips, stats, cnv_start, cnv_end, cnt);
 }
 
 void launch_name_keys(int n_reads, const uint32_t *name_id, const int32_t *row_cnt, unsigned long long *keys,
@@ -669,20 +870,30 @@ void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t 
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
                   const unsigned long long *skeys, const uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                   int m_bits, int a_bits, const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
-                  double edge_threshold, float *edge, uint8_t *einfo, hipStream_t s) {
-    hipLaunchKernelGGL(k_edges, dim3((n_var + 3) / 4), dim3(256), 0, s, cnt, node_off, node_end, skeys, svals, mrow_off, mrow_cnt, m_bits, a_bits, g_node, g_flag, A, edge_weight, edge_threshold, edge, einfo, cnt);
+                  double edge_threshold, const uint8_t *ntype, float *edge, unsigned long long *erec, uint32_t *node_pairs, hipStream_t s) {
+    hipLaunchKernelGGL(k_edges, dim3((n_var + 3) / 4), dim3(256), 0, s, cnt, node_off, node_end, skeys, svals, mrow_off, mrow_cnt, m_bits, a_bits, g_node, g_flag, A, edge_weight, edge_threshold, ntype, edge, erec, node_pairs);
 }
 
-void launch_vote_scan(const LpsCounters *cnt, const int32_t *nodes, const int32_t *vpos, const uint8_t *ntype,
-                      const uint8_t *einfo, int A, int distance, int8_t *hp, int32_t *block, hipStream_t s) {
-    hipLaunchKernelGGL(k_vote_scan, dim3(1), dim3(64), 0, s, cnt, nodes, vpos, ntype, einfo, A, distance, hp, block);
+size_t scan_state_bytes(int n_var) { return (size_t)((n_var + SCAN_SEG - 1) / SCAN_SEG + 1) * 2 * sizeof(ScanState); }
+int scan_segments(int n_var) { return (n_var + SCAN_SEG - 1) / SCAN_SEG + 1; }
+
+void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, const int32_t *vpos, const unsigned long long *erec,
+                      int A, int distance, int8_t *hp_v, int32_t *blk_v, void *st_b, void *st_e, int32_t *seg_i32 /*4*segs*/,
+                      unsigned *n_replayed, int8_t *hp, int32_t *block, hipStream_t s) {
+    const int segs = scan_segments(n_var);
+    const size_t vstride = (size_t)n_var + 64;
+    hipLaunchKernelGGL(k_scan_spec, dim3(segs), dim3(128), 0, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (ScanState *)st_b, (ScanState *)st_e);
+    hipLaunchKernelGGL(k_scan_match, dim3((segs + 3) / 4), dim3(256), 0, s, cnt, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs);
+    hipLaunchKernelGGL(k_scan_stitch, dim3(1), dim3(64), (size_t)segs * 5 * sizeof(int), s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, n_replayed);
+    hipLaunchKernelGGL(k_scan_finalize, GRID(n_var, 256), 0, s, cnt, hp_v, blk_v, vstride, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, hp, block);
 }
 
-void launch_correction(const LpsCounters *cnt, int n_reads, int n_var, const uint32_t *row_off, const int32_t *g_cnt,
+void launch_correction(LpsCounters *cnt, int n_reads, int n_var, const uint32_t *row_off, const int32_t *g_cnt,
                        const int32_t *g_node, const uint8_t *g_flag, const int32_t *nodes, const int32_t *vpos,
-                       const int32_t *block, uint32_t *bsize, const int8_t *hp, const uint8_t *ntype, double read_conf,
-                       double snp_conf, uint32_t *cnt4, int32_t *out_ps, uint8_t *out_gt, hipStream_t s) {
-    hipLaunchKernelGGL(k_block_size, GRID(n_var, 256), 0, s, cnt, block, bsize);
-    hipLaunchKernelGGL(k_read_correction, GRID(n_reads, 128), 0, s, n_reads, row_off, g_cnt, g_node, g_flag, block, bsize, hp, ntype, read_conf, cnt4);
+                       const int32_t *block, uint32_t *bsize, const int8_t *hp, const uint8_t *ntype, const uint32_t *node_pairs,
+                       uint8_t *nstate, double read_conf, double snp_conf, uint32_t *cnt4, int32_t *out_ps, uint8_t *out_gt, hipStream_t s) {
+    hipLaunchKernelGGL(k_block_size, GRID(n_var, 256), 0, s, cnt, block, node_pairs, bsize, nstate, hp, ntype);
+    hipLaunchKernelGGL(k_node_state, GRID(n_var, 256), 0, s, cnt, block, bsize, nstate);
+    hipLaunchKernelGGL(k_read_correction, dim3((n_reads + 3) / 4), dim3(256), 0, s, n_reads, row_off, g_cnt, g_node, g_flag, nstate, read_conf, cnt4);
     hipLaunchKernelGGL(k_final, GRID(n_var, 256), 0, s, cnt, nodes, vpos, block, bsize, cnt4, snp_conf, out_ps, out_gt);
 }
