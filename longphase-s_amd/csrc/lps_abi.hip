@@ -28,7 +28,7 @@ struct lps_ctx {
     int nV = 0; int last_pos = -1; long long ref_len = 0, ref_len_eff = 0;
     std::vector<int32_t> h_vpos;
     DevBuf<int32_t> v_pos; DevBuf<uint8_t> v_ref0, v_alt0, v_danger, v_hpoly, v_erased, v_hp1; DevBuf<uint16_t> v_rl, v_al;
-    DevBuf<int32_t> v_ps; bool has_hap = false;
+    DevBuf<int32_t> v_ps, v_bucket; DevBuf<uint2> v_rec; bool has_hap = false;
     DevBuf<char> ref;
     // reads
     int nR = 0; uint64_t n_cig = 0, n_seq = 0, n_qual = 0;
@@ -39,7 +39,7 @@ struct lps_ctx {
     DevBuf<int32_t> obs_var, g_node; DevBuf<uint16_t> obs_aq; DevBuf<uint8_t> g_flag;
     unsigned long long obs_capacity = 0;
     // clips / cnv
-    DevBuf<int32_t> clip_pos, clip_read, clip_op; unsigned clip_capacity = 0;
+    DevBuf<int32_t> clip_pos, clip_op; size_t clip_capacity = 0;
     DevBuf<unsigned long long> clip_keys, clip_keys_s;
     DevBuf<int32_t> cnv_start, cnv_end;
     DevBuf<long long> agg_sum; DevBuf<int32_t> agg_cnt; DevBuf<double> miss;
@@ -213,6 +213,7 @@ static VarView var_view(lps_ctx *c) {
     V.n = c->nV; V.pos = c->v_pos.p; V.ref0 = c->v_ref0.p; V.alt0 = c->v_alt0.p; V.ref_len = c->v_rl.p; V.alt_len = c->v_al.p;
     V.danger = c->v_danger.p; V.hpoly = c->v_hpoly.p; V.erased = c->v_erased.p; V.hp1_is_alt = c->v_hp1.p; V.phase_set = c->v_ps.p;
     V.ref = c->ref.p; V.ref_len_eff = c->ref_len_eff; V.last_pos = c->last_pos;
+    V.n_bucket = (int)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 1; V.bucket = c->v_bucket.p; V.rec = c->v_rec.p;
     return V;
 }
 static ReadView read_view(lps_ctx *c) {
@@ -232,8 +233,8 @@ static int run_phase(lps_ctx *c) {
         c->row_off.reserve(nR + 1); c->row_cnt.reserve(nR + 1); c->row_fail.reserve(nR + 1); c->row_flags.reserve(nR + 1);
         c->g_cnt.reserve(nR + 1); c->deleted.reserve(nR + 1);
         c->obs_var.reserve(cap); c->obs_aq.reserve(cap); c->g_node.reserve(cap); c->g_flag.reserve(cap);
-        c->clip_capacity = (unsigned)std::min<unsigned long long>(0x7fffffff, 4ull * nR + 64);
-        c->clip_pos.reserve(c->clip_capacity); c->clip_read.reserve(c->clip_capacity); c->clip_op.reserve(c->clip_capacity);
+        c->clip_capacity = (size_t)LPS_CLIP_SLOTS * nR + 64;
+        c->clip_pos.reserve(c->clip_capacity); c->clip_op.reserve(c->clip_capacity);
         c->clip_keys.reserve(c->clip_capacity); c->clip_keys_s.reserve(c->clip_capacity);
         c->cnv_start.reserve(LPS_MAX_CNV); c->cnv_end.reserve(LPS_MAX_CNV);
         c->name_keys.reserve(nR + 1); c->name_keys_s.reserve(nR + 1);
@@ -255,17 +256,20 @@ static int run_phase(lps_ctx *c) {
         HIP_TRY(hipMemsetAsync(c->out_ps.p, 0, (size_t)nV * sizeof(int32_t), s));
         HIP_TRY(hipMemsetAsync(c->out_gt.p, 0, (size_t)nV, s));
         // ---- a4/a5/a6 variant table prep
+        c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8);
+        c->v_rec.reserve((size_t)nV + 1);
         VarView V = var_view(c); ReadView R = read_view(c);
         mark(c, ST_PREP);
-        launch_variant_prep(V, P.is_ont, s);
+        launch_variant_prep(V, P.is_ont, c->v_bucket.p, c->v_rec.p, s);
         // ---- a1/a2/a3 extraction
         ObsView O{c->row_off.p, c->row_cnt.p, c->row_fail.p, c->row_flags.p, c->obs_var.p, c->obs_aq.p, cap};
-        ClipView C{c->clip_pos.p, c->clip_read.p, c->clip_op.p, c->clip_capacity};
+        ClipView C{c->clip_pos.p, c->clip_op.p};
         mark(c, ST_EXTRACT);
         launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, s);
         // ---- name keys (needs only row_cnt); S1: counters to host (sizes of the sorts)
         mark(c, ST_GROUPS);
         launch_name_keys(nR, c->r_name.p, c->row_cnt.p, c->name_keys.p, c->d_cnt, s);
+        launch_clip_keys(C, c->row_fail.p, nR, c->clip_keys.p, c->d_cnt, s);
         HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) { c->err = "alignment find unsupported CIGAR operation"; return -2; }
@@ -277,7 +281,7 @@ static int run_phase(lps_ctx *c) {
         launch_groups(c->name_keys_s.p, nR, c->d_cnt, c->head.p, c->gidx.p, c->gstart.p, c->read_group.p, c->temp.p, c->temp_bytes, s);
         // ---- a7 clips -> CNV intervals
         mark(c, ST_CLIP);
-        launch_clip_cnv(C, c->row_fail.p, c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, c->cnv_start.p, c->cnv_end.p, c->clip_stats.p, c->d_cnt, s);
+        launch_clip_cnv(c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, c->cnv_start.p, c->cnv_end.p, c->clip_stats.p, c->d_cnt, s);
         // ---- a8 overlap filter
         mark(c, ST_OVERLAP);
         HIP_TRY(hipMemsetAsync(c->deleted.p, 0, nR, s));

@@ -85,6 +85,18 @@ __device__ __forceinline__ T wave_incl_scan(T v) {
     return v;
 }
 
+// Inclusive wave64 scan of a 32-bit int with DPP row shifts / row broadcasts (gfx9 family: row_shr:n = 0x110+n,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143).  6 VALU instructions, no LDS crossbar traffic (vs 6 ds_bpermute).
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 template <class T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
@@ -153,4 +165,6 @@ __host__ __device__ __forceinline__ int aq_allele(uint16_t aq) { return (aq >> 9
 __host__ __device__ __forceinline__ int aq_quality(uint16_t aq) { return (int)(aq & 0x1ff) - 8; }
 
 #define LPS_MAX_CNV 64
-#define LPS_SEG 1024          // CIGAR ops staged in LDS per wave and segment
+#define LPS_CLIP_SLOTS 4        // clip ops per alignment (H S ... S H); more is reported as an error
+#define LPS_SEG 512           // CIGAR ops staged in LDS per wave and segment (4 KB/wave)
+#define LPS_BUCKET_SHIFT 10    // coarse position index: bucket b = first variant with pos >= b << shift

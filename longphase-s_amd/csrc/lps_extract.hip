@@ -49,11 +49,43 @@ __global__ void k_filter_snp(VarView V) {
     }
 }
 
-void launch_variant_prep(const VarView &V, int is_ont, hipStream_t s) {
+// coarse position index over the variant table (thread per bucket, plain binary search)
+__global__ void k_bucket_index(VarView V, int32_t *bucket) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > V.n_bucket) return;
+    const long long key = (long long)b << LPS_BUCKET_SHIFT;
+    int lo = 0, hi = V.n;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if ((long long)V.pos[m] < key) lo = m + 1; else hi = m; }
+    bucket[b] = lo;
+}
+
+// one 8-byte record per variant so that a candidate costs ONE gather in the extraction kernel
+__global__ void k_variant_pack(VarView V, uint2 *rec) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V.n) return;
+    const int rl = V.ref_len[v], al = V.alt_len[v];
+    const unsigned kind = (rl == 1 && al == 1) ? 0u : ((rl == 1 && al != 1) ? 1u : ((rl != 1 && al == 1) ? 2u : 3u));
+    const unsigned attr = (unsigned)V.ref0[v] | ((unsigned)V.alt0[v] << 8) | (kind << 16) | (V.danger[v] ? VREC_DANGER : 0u) |
+                          (V.erased[v] ? VREC_ERASED : 0u) | (V.hpoly[v] >= 3 ? VREC_HPOLY3 : 0u);
+    rec[v] = make_uint2((unsigned)V.pos[v], attr);
+}
+
+void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *rec, hipStream_t s) {
     if (V.n == 0) return;
     const int b = 256, g = (V.n + b - 1) / b;
     hipLaunchKernelGGL(k_variant_prep, dim3(g), dim3(b), 0, s, V);
     if (is_ont) hipLaunchKernelGGL(k_filter_snp, dim3(g), dim3(b), 0, s, V);
+    hipLaunchKernelGGL(k_variant_pack, dim3(g), dim3(b), 0, s, V, rec);
+    hipLaunchKernelGGL(k_bucket_index, dim3((V.n_bucket + 1 + b) / b), dim3(b), 0, s, V, bucket);
+}
+
+// first variant with pos >= key: one bucket lookup narrows the range to the variants of a 1-kb window, then one
+// 64-wide probe round (falls back to the 64-ary search for very dense windows).  Wave-uniform.
+__device__ __forceinline__ int var_lower_bound(const VarView &V, int key) {
+    if (key < 0) return 0;
+    const int b = key >> LPS_BUCKET_SHIFT;
+    if (b >= V.n_bucket) return wave_lower_bound(V.pos, V.bucket[V.n_bucket], V.n, key);
+    return wave_lower_bound(V.pos, V.bucket[b], V.bucket[b + 1], key);
 }
 
 // ------------------------------------------------------------------------------------------------ extraction
@@ -80,35 +112,42 @@ __device__ __forceinline__ ReadPlan plan_read(const VarView &V, const ReadView &
     const int n_cig = (int)(R.cigar_off[r + 1] - coff);
     const uint32_t *cig = R.cigar + coff;
     long long span = 0; bool bad = false;
-    for (int c = l; c < n_cig; c += 64) {
-        const uint32_t wd = cig[c]; const int op = wd & 15;
-        if (op_consumes_ref(op)) span += wd >> 4;
-        if (op > 8) bad = true;
+    for (int c0 = 0; c0 < n_cig; c0 += 512) {               // 8 independent 256-B loads in flight per trip
+        uint32_t wd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int c = c0 + u * 64 + l; wd[u] = c < n_cig ? cig[c] : 6u; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int op = wd[u] & 15;
+            if (op_consumes_ref(op)) span += wd[u] >> 4;
+            if (op > 8) bad = true;
+        }
     }
     span = wave_sum(span);
     if (__ballot(bad)) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR); }
     long long endll = (long long)start + span; if (endll > 0x7fffffff) endll = 0x7fffffff;
-    p.v0 = wave_lower_bound(V.pos, 0, V.n, start);
-    p.v1 = wave_lower_bound(V.pos, p.v0, V.n, (int)endll);
+    p.v0 = var_lower_bound(V, start);
+    p.v1 = var_lower_bound(V, (int)endll);
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
-                                                       LpsCounters *cnt) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
+                                                          LpsCounters *cnt) {
     __shared__ int s_ref[4][LPS_SEG];
     __shared__ int s_qry[4][LPS_SEG];
+    __shared__ uint32_t s_cig[4][LPS_SEG + 1];
     __shared__ unsigned long long s_cand[4][EXT_RPW];
     __shared__ unsigned long long s_base;
+    __shared__ int s_plan[4][EXT_RPW][3];
     const int w = threadIdx.x >> 6, l = lane_id();
-    int *sref = s_ref[w], *sqry = s_qry[w];
+    int *sref = s_ref[w], *sqry = s_qry[w]; uint32_t *scig = s_cig[w];
     const int r0 = (blockIdx.x * 4 + w) * EXT_RPW;
 
     // ---- pass 1 for the wave's EXT_RPW alignments, then ONE reservation per workgroup
-    ReadPlan plan[EXT_RPW];
-#pragma unroll
+#pragma unroll 1
     for (int q = 0; q < EXT_RPW; ++q) {
-        plan[q] = plan_read(V, R, r0 + q, mapping_quality, cnt);
-        if (l == 0) s_cand[w][q] = (unsigned long long)(plan[q].v1 - plan[q].v0);
+        const ReadPlan pl = plan_read(V, R, r0 + q, mapping_quality, cnt);
+        if (l == 0) { s_cand[w][q] = (unsigned long long)(pl.v1 - pl.v0); s_plan[w][q][0] = pl.v0; s_plan[w][q][1] = pl.v1; s_plan[w][q][2] = pl.live; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -124,9 +163,11 @@ __global__ __launch_bounds__(256) void k_extract_phase(VarView V, ReadView R, Ob
     for (int q = 0; q < EXT_RPW; ++q) {
         const int r = r0 + q;
         if (r >= R.n) break;
-        const int v0 = plan[q].v0, v1 = plan[q].v1, cand = v1 - v0;
+        const int v0 = s_plan[w][q][0], v1 = s_plan[w][q][1], cand = v1 - v0;
+        const bool live_q = s_plan[w][q][2] != 0;
         const unsigned long long my_base = base; base += (unsigned long long)cand;
-        if (!plan[q].live) { if (l == 0) { O.row_off[r] = 0; O.row_cnt[r] = 0; O.row_fail[r] = 0x7fffffff; O.row_flags[r] = 0; } continue; }
+        if (l < LPS_CLIP_SLOTS && (!live_q || my_base + (unsigned long long)cand > O.capacity)) C.opidx_fb[(size_t)r * LPS_CLIP_SLOTS + l] = -1;
+        if (!live_q) { if (l == 0) { O.row_off[r] = 0; O.row_cnt[r] = 0; O.row_fail[r] = 0x7fffffff; O.row_flags[r] = 0; } continue; }
         if (my_base + (unsigned long long)cand > O.capacity) {
             if (l == 0) { atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); O.row_off[r] = 0; O.row_cnt[r] = 0; O.row_fail[r] = 0x7fffffff; O.row_flags[r] = 0; }
             continue;
@@ -139,100 +180,113 @@ __global__ __launch_bounds__(256) void k_extract_phase(VarView V, ReadView R, Ob
         const uint8_t *qual = R.qual + R.qual_off[r];
         const int lq = R.l_qseq[r];
 
-        // ---- pass 2: segments of LPS_SEG ops -> LDS prefix arrays; candidate variants search them
-        int ref_pos = start, q_pos = 0, n_emit = 0, fail_op = 0x7fffffff, vcur = v0;
+        // ---- pass 2: segments of LPS_SEG ops -> LDS (ref prefix, query prefix, raw op word); the candidate variants
+        //      (one packed record per lane, loaded BEFORE the prefix build so both latencies overlap) search them
+        int ref_pos = start, q_pos = 0, n_emit = 0, fail_op = 0x7fffffff, vcur = v0, n_clip = 0;
         bool had_any = false;
         for (int seg0 = 0; seg0 < n_cig; seg0 += LPS_SEG) {
             const int nseg = min(LPS_SEG, n_cig - seg0);
-            for (int c0 = 0; c0 < nseg; c0 += 64) {
+            uint2 vr = make_uint2(0x7fffffffu, 0u);
+            if (vcur + l < v1) vr = V.rec[vcur + l];
+            const uint32_t nextw = (seg0 + nseg < n_cig) ? cig[seg0 + nseg] : 0xfu;      // op after the segment (0xf = none)
+            uint32_t wds[LPS_SEG / 64];                          // the whole segment's CIGAR words: LPS_SEG/64 loads in flight
+#pragma unroll
+            for (int u = 0; u < LPS_SEG / 64; ++u) { const int idx = u * 64 + l; wds[u] = idx < nseg ? cig[seg0 + idx] : 6u; }
+#pragma unroll
+            for (int u = 0; u < LPS_SEG / 64; ++u) {
+                const int c0 = u * 64;
+                if (c0 >= nseg) break;
                 const int idx = c0 + l;
-                const uint32_t wd = idx < nseg ? cig[seg0 + idx] : 0u;
+                const uint32_t wd = wds[u];
                 const int op = idx < nseg ? (int)(wd & 15) : 6, len = (int)(wd >> 4);
                 const int radv = op_consumes_ref(op) ? len : 0, qadv = op_consumes_query(op) ? len : 0;
-                const int ir = wave_incl_scan(radv), iq = wave_incl_scan(qadv);
+                const int ir = wave_incl_scan_dpp(radv), iq = wave_incl_scan_dpp(qadv);
                 const int my_ref = ref_pos + ir - radv, my_q = q_pos + iq - qadv;
-                if (idx < nseg) { sref[idx] = my_ref; sqry[idx] = my_q; }
-                // getClip (:1613-1620,1636-1645): soft/hard clips longer than 5; FRONT iff CIGAR index 0
+                if (idx < nseg) { sref[idx] = my_ref; sqry[idx] = my_q; scig[idx] = wd; }
+                // getClip (:1613-1620,1636-1645): soft/hard clips longer than 5; FRONT iff CIGAR index 0.
+                // Events go to the read's own LPS_CLIP_SLOTS slots (no atomics here); compaction happens later.
                 const bool clip = (op == 4 || op == 5) && len > 5;
                 const unsigned long long cm = __ballot(clip);
                 if (cm) {
-                    unsigned cb = 0;
-                    if (l == 0) cb = atomicAdd(&cnt->n_clips, (unsigned)__popcll(cm));
-                    cb = __shfl(cb, 0);
                     if (clip) {
-                        const unsigned slot = cb + __popcll(cm & lanemask_lt());
-                        if (slot < C.capacity) { C.pos[slot] = my_ref; C.read[slot] = r; C.opidx_fb[slot] = ((seg0 + idx) << 1) | ((seg0 + idx) != 0); }
+                        const int slot = n_clip + __popcll(cm & lanemask_lt());
+                        if (slot < LPS_CLIP_SLOTS) { C.pos[(size_t)r * LPS_CLIP_SLOTS + slot] = my_ref; C.opidx_fb[(size_t)r * LPS_CLIP_SLOTS + slot] = ((seg0 + idx) << 1) | ((seg0 + idx) != 0); }
                         else atomicOr(&cnt->err, (unsigned)LPS_ERR_CLIP_OVERFLOW);
                     }
+                    n_clip += __popcll(cm);
                 }
                 ref_pos += __shfl(ir, 63); q_pos += __shfl(iq, 63);
             }
+            if (l == 0) scig[nseg] = nextw;
             wave_sync();
-            // variants whose position falls inside this segment's reference interval
-            const int vend = (seg0 + nseg >= n_cig) ? v1 : wave_lower_bound(V.pos, vcur, v1, ref_pos);
-            for (int vb = vcur; vb < vend; vb += 64) {
-                const int v = vb + l;
+            // candidates are position-sorted: those inside this segment's reference interval form a prefix of the chunk
+            const bool last_seg = seg0 + nseg >= n_cig;
+            while (true) {
+                const int v = vcur + l;
+                const int p = (int)vr.x;
+                const bool mine = v < v1 && (last_seg || p < ref_pos);
+                const int n_in = __popcll(__ballot(mine));
+                int pprev = __shfl_up(p, 1);                     // position of the previous variant (all lanes take part)
+                if (l == 0) pprev = (v > 0 && v < v1) ? V.pos[v - 1] : -1;
                 bool emit = false, fail = false; int allele = -1, qv = 0, opi = 0;
-                if (v < vend) {
-                    const int p = V.pos[v];
+                if (mine) {
+                    const unsigned at = vr.y;
                     int lo = 0, hi = nseg;                       // first j with sref[j] > p
                     while (lo < hi) { const int m = (lo + hi) >> 1; if (sref[m] > p) hi = m; else lo = m + 1; }
                     const int j = lo - 1;
                     if (j >= 0) {
-                        const uint32_t wd = cig[seg0 + j];
+                        const uint32_t wd = scig[j];
                         const int op = wd & 15, len = (int)(wd >> 4);
                         const int rs = sref[j], qs = sqry[j];
                         opi = seg0 + j;
                         if (p < rs + len) {
-                            const int rl = V.ref_len[v], al = V.alt_len[v];
+                            const unsigned kind = VREC_KIND(at);
+                            const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
                             if (op_is_match(op)) {                                            // :1445-1520
                                 const int off = p - rs;
                                 if (qs + off + 1 > lq) fail = true;                           // :1453-1455
-                                else {
-                                    if (rl == 1 && al == 1) {
-                                        const int qi = qs + off;
-                                        const char base_c = nt16_char(seq[qi >> 1] >> ((~qi & 1) << 2));
-                                        if (base_c == (char)V.ref0[v]) allele = 0; else if (base_c == (char)V.alt0[v]) allele = 1;
-                                        qv = qual[qi];
-                                    }
-                                    const bool has_next = opi + 1 < n_cig;
-                                    if (rl == 1 && al != 1 && has_next) {                     // insertion variant :1470-1491
-                                        allele = (rs + len - 1 == p && (cig[seg0 + j + 1] & 15) == 1) ? 1 : 0;
-                                        qv = V.danger[v] ? -5 : -4;
-                                    }
-                                    if (rl != 1 && al == 1 && has_next) {                     // deletion variant :1495-1510
-                                        allele = (rs + len - 1 == p && (cig[seg0 + j + 1] & 15) == 2) ? 1 : 0;
-                                        qv = V.danger[v] ? -5 : -4;
-                                    }
+                                else if (kind == 0) {
+                                    const int qi = qs + off;
+                                    const char base_c = nt16_char(seq[qi >> 1] >> ((~qi & 1) << 2));
+                                    if (base_c == ref_c) allele = 0; else if (base_c == alt_c) allele = 1;
+                                    qv = qual[qi];
                                     emit = allele != -1;
+                                } else if ((kind == 1 || kind == 2) && opi + 1 < n_cig) {     // indel variant :1470-1510
+                                    const int want = (kind == 1) ? 1 : 2;                      // next op must be I resp. D
+                                    allele = (rs + len - 1 == p && (int)(scig[j + 1] & 15) == want) ? 1 : 0;
+                                    qv = (at & VREC_DANGER) ? -5 : -4;
+                                    emit = true;
                                 }
                             } else if (op == 2) {                                             // :1539-1607
                                 // only the first variant at/after the deletion start is examined by the reference
-                                const bool first_in = (v == 0) || V.pos[v - 1] < rs;
-                                if (first_in && V.hpoly[v] >= 3) {
+                                const bool first_in = (v == 0) || pprev < rs;
+                                if (first_in && (at & VREC_HPOLY3)) {
                                     if (qs + 1 > lq) fail = true;                             // :1559-1561
-                                    else if (rl == 1 && al == 1) {
+                                    else if (kind == 0) {
                                         const char base_c = nt16_char(seq[qs >> 1] >> ((~qs & 1) << 2));
-                                        if (base_c == (char)V.ref0[v]) allele = 0; else if (base_c == (char)V.alt0[v]) allele = 1;
+                                        if (base_c == ref_c) allele = 0; else if (base_c == alt_c) allele = 1;
                                         qv = qual[qs];
                                         emit = allele != -1;
-                                    } else if (rl != 1 && al == 1) { allele = 1; qv = -4; emit = true; }
+                                    } else if (kind == 2) { allele = 1; qv = -4; emit = true; }
                                 }
                             }
                         }
                     }
+                    if (fail) fail_op = min(fail_op, opi);
+                    had_any |= emit;
+                    if (emit && (at & VREC_ERASED)) emit = false;                              // filterSNP (:895-911)
                 }
-                if (fail) fail_op = min(fail_op, opi);
-                had_any |= emit;
-                if (emit && V.erased[v]) emit = false;                                         // filterSNP (:895-911)
                 const unsigned long long em = __ballot(emit);
                 if (emit) {
                     const unsigned long long slot = my_base + n_emit + __popcll(em & lanemask_lt());
                     O.var[slot] = v; O.aq[slot] = pack_aq(allele, qv);
                 }
                 n_emit += __popcll(em);
+                vcur += n_in;
+                if (n_in < 64 || vcur >= v1) break;
+                vr = make_uint2(0x7fffffffu, 0u);
+                if (vcur + l < v1) vr = V.rec[vcur + l];
             }
-            vcur = vend;
             wave_sync();
         }
         fail_op = wave_min(fail_op);
@@ -244,6 +298,7 @@ __global__ __launch_bounds__(256) void k_extract_phase(VarView V, ReadView R, Ob
             O.row_fail[r] = fail_op;
             O.row_flags[r] = (!dropped && any && n_emit == 0) ? 1 : 0;
         }
+        if (l >= n_clip && l < LPS_CLIP_SLOTS) C.opidx_fb[(size_t)r * LPS_CLIP_SLOTS + l] = -1;   // unused slots
     }
 }
 

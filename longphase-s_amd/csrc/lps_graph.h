@@ -8,7 +8,8 @@ void sort_keys64(void *temp, size_t temp_bytes, const unsigned long long *in, un
 void sort_pairs64(void *temp, size_t temp_bytes, const unsigned long long *kin, unsigned long long *kout, const uint32_t *vin, uint32_t *vout, size_t n, int bits, hipStream_t s);
 void exscan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s);
 
-void launch_clip_cnv(const ClipView &C, const int32_t *row_fail, unsigned n_clips, unsigned long long *keys,
+void launch_clip_keys(const ClipView &C, const int32_t *row_fail, int n_reads, unsigned long long *keys, LpsCounters *cnt, hipStream_t s);
+void launch_clip_cnv(unsigned n_clips, unsigned long long *keys,
                      unsigned long long *keys_sorted, void *temp, size_t temp_bytes, int32_t *cnv_start, int32_t *cnv_end,
                      unsigned *stats, LpsCounters *cnt, hipStream_t s);
 void launch_name_keys(int n_reads, const uint32_t *name_id, const int32_t *row_cnt, unsigned long long *keys, LpsCounters *cnt, hipStream_t s);

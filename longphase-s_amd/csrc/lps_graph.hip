@@ -21,13 +21,27 @@
 #include "lps_graph.h"
 
 // ================================================================================================ clips / CNV
-__global__ void k_clip_keys(ClipView C, const int32_t *row_fail, unsigned n_clips, unsigned long long *keys) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_clips) return;
-    const int opidx = C.opidx_fb[i] >> 1, fb = C.opidx_fb[i] & 1;
-    // get_snp returning early (:1453-1455,1559-1561) keeps only clips of ops before the failing op
-    const bool ok = opidx < row_fail[C.read[i]];
-    keys[i] = ok ? (((unsigned long long)(unsigned)C.pos[i] << 1) | (unsigned)fb) : ~0ull;
+// thread per clip slot: keep events of ops before the op at which get_snp returned early (:1453-1455,1559-1561),
+// compact them (one atomic per workgroup) into sort keys (pos << 1 | front/back).
+__global__ __launch_bounds__(256) void k_clip_keys(ClipView C, const int32_t *row_fail, int n_reads, unsigned long long *keys,
+                                                   LpsCounters *cnt) {
+    __shared__ unsigned s_wcnt[4], s_base;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = threadIdx.x >> 6;
+    bool ok = false; unsigned long long key = 0;
+    if (i < (long long)n_reads * LPS_CLIP_SLOTS) {
+        const int of = C.opidx_fb[i];
+        if (of >= 0 && (of >> 1) < row_fail[i / LPS_CLIP_SLOTS]) { ok = true; key = ((unsigned long long)(unsigned)C.pos[i] << 1) | (unsigned)(of & 1); }
+    }
+    const unsigned long long m = __ballot(ok);
+    if (lane_id() == 0) s_wcnt[w] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { const unsigned tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]; s_base = tot ? atomicAdd(&cnt->n_clips, tot) : 0u; }
+    __syncthreads();
+    if (ok) {
+        unsigned off = s_base; for (int q = 0; q < w; ++q) off += s_wcnt[q];
+        keys[off + __popcll(m & lanemask_lt())] = key;
+    }
 }
 
 struct CnvState {
@@ -808,12 +822,15 @@ void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const uin
     hipLaunchKernelGGL(k_cnv_filter_serial, dim3(1), dim3(64), 0, s, cnt, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, vpos, cnv_start, cnv_end, agg_sum, agg_cnt, miss, n_var);
 }
 
-void launch_clip_cnv(const ClipView &C, const int32_t *row_fail, unsigned n_clips, unsigned long long *keys,
+void launch_clip_keys(const ClipView &C, const int32_t *row_fail, int n_reads, unsigned long long *keys, LpsCounters *cnt, hipStream_t s) {
+    if (n_reads) hipLaunchKernelGGL(k_clip_keys, GRID((size_t)n_reads * LPS_CLIP_SLOTS, 256), 0, s, C, row_fail, n_reads, keys, cnt);
+}
+
+void launch_clip_cnv(unsigned n_clips, unsigned long long *keys,
                      unsigned long long *keys_sorted, void *temp, size_t temp_bytes, int32_t *cnv_start, int32_t *cnv_end,
                      unsigned *stats, LpsCounters *cnt, hipStream_t s) {
     HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(unsigned), s));
     if (n_clips) {
-        hipLaunchKernelGGL(k_clip_keys, GRID(n_clips, 256), 0, s, C, row_fail, n_clips, keys);
         sort_keys64(temp, temp_bytes, keys, keys_sorted, n_clips, 64, s);
         hipLaunchKernelGGL(k_clip_stats, GRID(n_clips, 256), 0, s, keys_sorted, n_clips, stats);
     }

@@ -13,6 +13,9 @@ struct VarView {           // variant table, position-sorted (Appendix B of SURV
     uint8_t *erased;       // filterSNP
     const uint8_t *hp1_is_alt;   // haplotag
     const int32_t *phase_set;    // haplotag
+    const uint2 *rec;      // packed per-variant record {pos, attr} used by the extraction kernels (see VREC_*)
+    const int32_t *bucket; // coarse index: bucket[b] = first variant with pos >= (b << LPS_BUCKET_SHIFT); n_bucket+1 entries
+    int n_bucket;
     const char *ref;       // reference bases
     long long ref_len_eff; // FastaParser truncation [0,last+5]
     int last_pos;
@@ -39,11 +42,17 @@ struct ObsView {           // CSR rows placed by atomic reservation: row r = [ro
     unsigned long long capacity;
 };
 
-struct ClipView {          // raw clip events; filtered by row_fail afterwards
-    int32_t *pos; int32_t *read; int32_t *opidx_fb;   // opidx<<1 | (opidx!=0)
-    unsigned int capacity;
+struct ClipView {          // clip events in LPS_CLIP_SLOTS fixed slots per alignment; filtered by row_fail afterwards
+    int32_t *pos; int32_t *opidx_fb;   // opidx<<1 | (opidx!=0), -1 = unused slot
 };
 
-void launch_variant_prep(const VarView &V, int is_ont, hipStream_t s);
+void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *rec, hipStream_t s);
+
+// attr word of a packed variant record: bits 0-7 REF[0], 8-15 ALT[0], 16-17 kind (0 SNP, 1 insertion, 2 deletion,
+// 3 other), 18 danger, 19 erased by filterSNP, 20 homopolymerLength >= 3
+#define VREC_KIND(a) (((a) >> 16) & 3u)
+#define VREC_DANGER (1u << 18)
+#define VREC_ERASED (1u << 19)
+#define VREC_HPOLY3 (1u << 20)
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,
                           int mapping_quality, LpsCounters *cnt, hipStream_t s);
