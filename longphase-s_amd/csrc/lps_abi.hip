@@ -52,6 +52,7 @@ struct lps_ctx {
     DevBuf<unsigned long long> nkeys, nkeys_s; DevBuf<uint32_t> nvals, nvals_s;
     DevBuf<float> edge;
     DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
+    DevBuf<uint8_t> hap_status, hap_nps; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin;
     DevBuf<char> temp; size_t temp_bytes = 0;
     LpsCounters *d_cnt = nullptr; LpsCounters h_cnt{};
     // timing
@@ -367,8 +368,63 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
 }
 
 int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
-    (void)out;
-    return fail(c, "lps_haplotag_chromosome: not built yet", -100);
+    if (!c || !out) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        const int nR = c->nR, nV = c->nV;
+        if (out->n_reads != nR) return fail(c, "lps_haplotag_result.n_reads must equal the number of pushed alignments");
+        if (nR == 0) return 0;
+        if (nV > 0 && !c->has_hap) return fail(c, "haplotag needs hp1_is_alt and phase_set in the variant table");
+        if (nV > 0 && c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
+        hipStream_t s = c->stream;
+        c->hap_status.reserve(nR); c->hap_h1.reserve(nR); c->hap_h2.reserve(nR); c->hap_nps.reserve(nR); c->hap_psmin.reserve(nR);
+        c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1);
+        HIP_TRY(hipEventRecord(c->ev_begin, s));
+        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
+        VarView V = var_view(c); ReadView R = read_view(c);
+        for (auto &u : c->ev_used) u = false;
+        mark(c, ST_PREP);
+        launch_variant_prep(V, /*is_ont (filterSNP is a `phase` step)*/ 0, c->v_bucket.p, c->v_rec.p, s);
+        mark(c, ST_EXTRACT);
+        HapOut H{c->hap_status.p, c->hap_h1.p, c->hap_h2.p, c->hap_nps.p, c->hap_psmin.p};
+        launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, c->d_cnt, s);
+        mark(c, ST_D2H);
+        HIP_TRY(hipMemcpyAsync(out->status, H.status, (size_t)nR, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->hp1, H.hp1, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->hp2, H.hp2, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->n_ps, H.n_ps, (size_t)nR, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->ps_min, H.ps_min, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(c->ev_end, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) return fail(c, "Alignment find unsupported CIGAR operation", -2);
+        // judgeReadHap (src/haplotag/HaplotagStrategy.cpp:243-300) on the host: needs libm's log10
+        const double thr = c->P.percentage_threshold;
+        int64_t tagged = 0;
+        for (int r = 0; r < nR; ++r) {
+            int hp = 0, pq = 0;
+            if (out->status[r] == 0) {
+                const int a = out->hp1[r], b = out->hp2[r];
+                double mn, mx;
+                if (a > b) { mn = b; mx = a; } else { mn = a; mx = b; }
+                if (mx / (mx + mn) < thr) pq = 0;
+                else { if (a > b) hp = 1; if (a < b) hp = 2; }
+                if (mx == 0) pq = 0; else if (mx == mx + mn) pq = 40; else pq = -10 * (std::log10((double)mn / double(mx + mn)));
+                if (out->n_ps[r] > 1) hp = 0;
+            }
+            out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = hp ? out->ps_min[r] : 0;
+            tagged += hp != 0;
+        }
+        lps_timings &t = c->tm; memset(&t, 0, sizeof t);
+        t.n_stages = ST_COUNT;
+        HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_PREP], c->ev[ST_PREP], c->ev[ST_EXTRACT]));
+        HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_EXTRACT], c->ev[ST_EXTRACT], c->ev[ST_D2H]));
+        HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_D2H], c->ev[ST_D2H], c->ev_end));
+        HIP_TRY(hipEventElapsedTime(&t.ms_total, c->ev_begin, c->ev_end));
+        t.n_reads_used = tagged;
+        t.algorithmic_bytes[ST_EXTRACT] = 36ll * nR + 4ll * (int64_t)c->n_cig + 10ll * nR;   // + observations (unknown here)
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
 }
 
 int lps_get_timings(lps_ctx *c, lps_timings *t) { if (!c || !t) return -1; *t = c->tm; return 0; }

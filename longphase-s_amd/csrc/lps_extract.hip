@@ -66,7 +66,8 @@ __global__ void k_variant_pack(VarView V, uint2 *rec) {
     const int rl = V.ref_len[v], al = V.alt_len[v];
     const unsigned kind = (rl == 1 && al == 1) ? 0u : ((rl == 1 && al != 1) ? 1u : ((rl != 1 && al == 1) ? 2u : 3u));
     const unsigned attr = (unsigned)V.ref0[v] | ((unsigned)V.alt0[v] << 8) | (kind << 16) | (V.danger[v] ? VREC_DANGER : 0u) |
-                          (V.erased[v] ? VREC_ERASED : 0u) | (V.hpoly[v] >= 3 ? VREC_HPOLY3 : 0u);
+                          (V.erased[v] ? VREC_ERASED : 0u) | (V.hpoly[v] >= 3 ? VREC_HPOLY3 : 0u) |
+                          ((V.hp1_is_alt && V.hp1_is_alt[v]) ? VREC_HP1ALT : 0u);
     rec[v] = make_uint2((unsigned)V.pos[v], attr);
 }
 
@@ -79,20 +80,7 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
     hipLaunchKernelGGL(k_bucket_index, dim3((V.n_bucket + 1 + b) / b), dim3(b), 0, s, V, bucket);
 }
 
-// first variant with pos >= key: one bucket lookup narrows the range to the variants of a 1-kb window, then one
-// 64-wide probe round (falls back to the 64-ary search for very dense windows).  Wave-uniform.
-__device__ __forceinline__ int var_lower_bound(const VarView &V, int key) {
-    if (key < 0) return 0;
-    const int b = key >> LPS_BUCKET_SHIFT;
-    if (b >= V.n_bucket) return wave_lower_bound(V.pos, V.bucket[V.n_bucket], V.n, key);
-    return wave_lower_bound(V.pos, V.bucket[b], V.bucket[b + 1], key);
-}
-
 // ------------------------------------------------------------------------------------------------ extraction
-__device__ __forceinline__ bool op_consumes_ref(int op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
-__device__ __forceinline__ bool op_consumes_query(int op) { return op == 0 || op == 1 || op == 4 || op == 7 || op == 8; }
-__device__ __forceinline__ bool op_is_match(int op) { return op == 0 || op == 7 || op == 8; }
-
 #define EXT_RPW 4   // alignments per wave: one output reservation (atomic) per workgroup covers 4 waves x 4 reads
 
 struct ReadPlan { int v0, v1; bool live; };

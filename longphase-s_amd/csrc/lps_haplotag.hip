@@ -1,0 +1,137 @@
+// lps_haplotag.hip — per-read haplotype scoring of `haplotag` (germline), gfx950.
+//
+// Replaces (reference file:line, relative to /root/reference/):
+//   ChromosomeProcessor::processSingleChrom filter cascade   src/haplotag/HaplotagParsingBam.cpp:453-486
+//   CigarParser::parsingCigar + IsAltIndel                    src/haplotag/HaplotagParsingBam.cpp:541-670
+//   GermlineHaplotagStrategy::judgeSnpHap / judgeDeletionHap  src/haplotag/HaplotagStrategy.cpp:20-209
+// The read-level decision (judgeReadHap :243-300, PQ = int(-10*log10(..))) is taken on the host from the integer
+// counts this kernel returns, because it needs the host libm's log10.
+//
+// Same wave-per-alignment design as k_extract_phase (LDS-staged CIGAR prefixes, variants search the ops, one packed
+// record per candidate), but there is no output reservation: a read reduces to two vote counts and its PS range.
+#include "lps_kernels.h"
+
+__global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary,
+                                                        LpsCounters *cnt) {
+    __shared__ int s_ref[4][LPS_SEG];
+    __shared__ int s_qry[4][LPS_SEG];
+    __shared__ uint32_t s_cig[4][LPS_SEG + 1];
+    const int w = threadIdx.x >> 6, l = lane_id();
+    const int r = blockIdx.x * 4 + w;
+    if (r >= R.n) return;
+    int *sref = s_ref[w], *sqry = s_qry[w]; uint32_t *scig = s_cig[w];
+    const int start = R.ref_start[r];
+    const int flag = R.flag[r];
+    int status = 0;                                                   // filter cascade (:453-486)
+    if (R.mapq[r] < mapping_quality) status = 1;
+    else if (flag & 0x4) status = 2;
+    else if (flag & 0x100) status = 3;
+    else if ((flag & 0x800) && !tag_supplementary) status = 4;
+    else if (V.n == 0) status = 5;
+    else if (!(start <= V.last_pos)) status = 6;
+    int h1 = 0, h2 = 0, ps_lo = 0x7fffffff, ps_hi = (int)0x80000000;
+    if (status == 0) {
+        const uint64_t coff = R.cigar_off[r];
+        const int n_cig = (int)(R.cigar_off[r + 1] - coff);
+        const uint32_t *cig = R.cigar + coff;
+        const uint8_t *seq = R.seq + R.seq_off[r];
+        const int lq = R.l_qseq[r];
+        int vcur = var_lower_bound(V, start);
+        int ref_pos = start, q_pos = 0;
+        for (int seg0 = 0; seg0 < n_cig && vcur < V.n; seg0 += LPS_SEG) {
+            const int nseg = min(LPS_SEG, n_cig - seg0);
+            uint2 vr = make_uint2(0x7fffffffu, 0u);
+            if (vcur + l < V.n) vr = V.rec[vcur + l];
+            const uint32_t nextw = (seg0 + nseg < n_cig) ? cig[seg0 + nseg] : 0xfu;
+            uint32_t wds[LPS_SEG / 64];
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < LPS_SEG / 64; ++u) { const int idx = u * 64 + l; wds[u] = idx < nseg ? cig[seg0 + idx] : 6u; }
+#pragma unroll
+            for (int u = 0; u < LPS_SEG / 64; ++u) {
+                const int c0 = u * 64;
+                if (c0 >= nseg) break;
+                const int idx = c0 + l;
+                const uint32_t wd = wds[u];
+                const int op = idx < nseg ? (int)(wd & 15) : 6, len = (int)(wd >> 4);
+                if (op > 8) bad = true;
+                const int radv = op_consumes_ref(op) ? len : 0, qadv = op_consumes_query(op) ? len : 0;
+                const int ir = wave_incl_scan_dpp(radv), iq = wave_incl_scan_dpp(qadv);
+                if (idx < nseg) { sref[idx] = ref_pos + ir - radv; sqry[idx] = q_pos + iq - qadv; scig[idx] = wd; }
+                ref_pos += __shfl(ir, 63); q_pos += __shfl(iq, 63);
+            }
+            if (__ballot(bad) && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
+            if (l == 0) scig[nseg] = nextw;
+            wave_sync();
+            while (true) {
+                const int v = vcur + l;
+                const int p = (int)vr.x;
+                const bool mine = v < V.n && p < ref_pos;               // inside the reference interval walked so far
+                const int n_in = __popcll(__ballot(mine));
+                int pprev = __shfl_up(p, 1);
+                if (l == 0) pprev = (v > 0 && v < V.n) ? V.pos[v - 1] : -1;
+                if (mine) {
+                    const unsigned at = vr.y;
+                    int lo = 0, hi = nseg;
+                    while (lo < hi) { const int m = (lo + hi) >> 1; if (sref[m] > p) hi = m; else lo = m + 1; }
+                    const int j = lo - 1;
+                    if (j >= 0) {
+                        const uint32_t wd = scig[j];
+                        const int op = wd & 15, len = (int)(wd >> 4);
+                        const int rs = sref[j], qs = sqry[j];
+                        if (p < rs + len) {
+                            const unsigned kind = VREC_KIND(at);
+                            const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
+                            const bool hp1alt = (at & VREC_HP1ALT) != 0;
+                            int vote = -1;                              // 0: haplotype carrying REF, 1: haplotype carrying ALT
+                            bool count_ps = false;
+                            if (op_is_match(op)) {                                            // judgeSnpHap (:20-130)
+                                if (kind == 0) {
+                                    const int qi = qs + (p - rs);
+                                    const char base_c = qi < lq ? nt16_char(seq[qi >> 1] >> ((~qi & 1) << 2)) : 'N';
+                                    if (base_c == ref_c) vote = 0; else if (base_c == alt_c) vote = 1;
+                                    count_ps = vote >= 0;
+                                } else if ((kind == 1 || kind == 2) && seg0 + j + 1 < n_cig) {
+                                    const int want = (kind == 1) ? 1 : 2;
+                                    const bool has = (rs + len - 1 == p) && (int)(scig[j + 1] & 15) == want;
+                                    // insertion: the read's allele; deletion: the reference votes for the LONG allele (:98-129)
+                                    vote = (kind == 1) ? (has ? 1 : 0) : (has ? 0 : 1);
+                                    count_ps = true;
+                                }
+                            } else if (op == 2) {                                             // judgeDeletionHap (:147-209), once per D op
+                                const bool first_in = (v == 0) || pprev < rs;
+                                if (first_in && (at & VREC_HPOLY3)) {
+                                    if (kind == 0) {
+                                        const char base_c = qs < lq ? nt16_char(seq[qs >> 1] >> ((~qs & 1) << 2)) : 'N';
+                                        if (base_c == ref_c) vote = 0; else if (base_c == alt_c) vote = 1;
+                                        count_ps = true;
+                                    } else if (kind == 2) { vote = 0; count_ps = true; }
+                                }
+                            }
+                            if (vote >= 0) { if ((vote == 1) == hp1alt) ++h1; else ++h2; }
+                            if (count_ps) { const int ps = V.phase_set[v]; ps_lo = min(ps_lo, ps); ps_hi = max(ps_hi, ps); }
+                        }
+                    }
+                }
+                vcur += n_in;
+                if (n_in < 64 || vcur >= V.n) break;
+                vr = make_uint2(0x7fffffffu, 0u);
+                if (vcur + l < V.n) vr = V.rec[vcur + l];
+            }
+            wave_sync();
+        }
+        h1 = wave_sum(h1); h2 = wave_sum(h2); ps_lo = wave_min(ps_lo); ps_hi = wave_max(ps_hi);
+    }
+    if (l == 0) {
+        H.status[r] = (uint8_t)status; H.hp1[r] = h1; H.hp2[r] = h2;
+        const bool any = ps_lo <= ps_hi;
+        H.n_ps[r] = any ? (ps_lo == ps_hi ? 1 : 2) : 0;               // only "more than one" matters to judgeReadHap
+        H.ps_min[r] = any ? ps_lo : 0;
+    }
+}
+
+void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
+                     LpsCounters *cnt, hipStream_t s) {
+    if (R.n == 0) return;
+    hipLaunchKernelGGL(k_haplotag_score, dim3((R.n + 3) / 4), dim3(256), 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
+}

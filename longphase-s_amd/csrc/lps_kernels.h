@@ -54,5 +54,28 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 #define VREC_DANGER (1u << 18)
 #define VREC_ERASED (1u << 19)
 #define VREC_HPOLY3 (1u << 20)
+#define VREC_HP1ALT (1u << 21)   /* haplotag: haplotype 1 carries ALT */
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,
                           int mapping_quality, LpsCounters *cnt, hipStream_t s);
+
+// ---- device helpers shared by the extraction (phase) and scoring (haplotag) kernels
+#ifdef __HIPCC__
+__device__ __forceinline__ bool op_consumes_ref(int op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+__device__ __forceinline__ bool op_consumes_query(int op) { return op == 0 || op == 1 || op == 4 || op == 7 || op == 8; }
+__device__ __forceinline__ bool op_is_match(int op) { return op == 0 || op == 7 || op == 8; }
+
+
+// first variant with pos >= key: one bucket lookup narrows the range to the variants of a 1-kb window, then one
+// 64-wide probe round (falls back to the 64-ary search for very dense windows).  Wave-uniform.
+__device__ __forceinline__ int var_lower_bound(const VarView &V, int key) {
+    if (key < 0) return 0;
+    const int b = key >> LPS_BUCKET_SHIFT;
+    if (b >= V.n_bucket) return wave_lower_bound(V.pos, V.bucket[V.n_bucket], V.n, key);
+    return wave_lower_bound(V.pos, V.bucket[b], V.bucket[b + 1], key);
+}
+
+#endif
+
+struct HapOut { uint8_t *status; int32_t *hp1, *hp2; uint8_t *n_ps; int32_t *ps_min; };
+void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
+                     LpsCounters *cnt, hipStream_t s);

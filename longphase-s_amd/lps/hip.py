@@ -106,6 +106,15 @@ class Context:
         self.load_chromosome(variants, ref, reads)
         return self.run_phase()
 
+    def run_haplotag(self, out=None):
+        out = out or abi.HaplotagOut(self.n_reads)
+        self._check(self.L.lps_haplotag_chromosome(self.h, C.byref(out.c)), "lps_haplotag_chromosome")
+        return out
+
+    def haplotag(self, variants, ref, reads):
+        self.load_chromosome(variants, ref, reads)
+        return self.run_haplotag()
+
     def timings(self):
         t = abi.Timings()
         self._check(self.L.lps_get_timings(self.h, C.byref(t)), "lps_get_timings")

@@ -523,4 +523,92 @@ int oracle_phase(const lps_params *Pp, const lps_variant_table *tp, const char *
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ haplotag
+// Per-read scoring loop of `haplotag` (germline): filter cascade of ChromosomeProcessor::processSingleChrom
+// (src/haplotag/HaplotagParsingBam.cpp:453-486), CigarParser::parsingCigar (:541-647), judgeSnpHap /
+// judgeDeletionHap (src/haplotag/HaplotagStrategy.cpp:20-209) and judgeReadHap (:243-300).
+// The table holds the phased-het rows of the normal VCF (HaplotagVcfParser.cpp:304-400): HP1 = ALT when hp1_is_alt.
+int oracle_haplotag(const lps_params *Pp, const lps_variant_table *tp, const char *ref, int64_t ref_len_in,
+                    const lps_read_batch *bp, lps_haplotag_result *out) {
+    const lps_params &P = *Pp; const lps_variant_table &t = *tp; const lps_read_batch &b = *bp;
+    Table T; T.t = &t; T.ref = ref;
+    const int32_t last_pos = t.n ? t.pos[t.n - 1] : -1;
+    T.ref_len = std::min<int64_t>(ref_len_in, (int64_t)last_pos + 6);
+    for (int64_t r = 0; r < b.n_reads; ++r) {
+        out->status[r] = 0; out->hp1[r] = 0; out->hp2[r] = 0; out->n_ps[r] = 0; out->ps_min[r] = 0; out->hp[r] = 0; out->pq[r] = 0; out->ps[r] = 0;
+        const int fl = b.flag[r];
+        if (b.mapq[r] < P.mapping_quality) { out->status[r] = 1; continue; }
+        if (fl & 0x4) { out->status[r] = 2; continue; }
+        if (fl & 0x100) { out->status[r] = 3; continue; }
+        if ((fl & 0x800) && !P.tag_supplementary) { out->status[r] = 4; continue; }
+        if (t.n == 0) { out->status[r] = 5; continue; }
+        if (!(b.ref_start[r] <= last_pos)) { out->status[r] = 6; continue; }
+        // ---- parsingCigar
+        const uint32_t *cig = b.cigar + b.cigar_off[r];
+        const int n_cig = (int)(b.cigar_off[r + 1] - b.cigar_off[r]);
+        const uint8_t *seq = b.seq + b.seq_off[r];
+        const int64_t lq = b.l_qseq[r];
+        int64_t ref_pos = b.ref_start[r], query_pos = 0;
+        int64_t cur = std::lower_bound(t.pos, t.pos + t.n, (int32_t)ref_pos) - t.pos;
+        int h1 = 0, h2 = 0; std::map<int, int> countPS;
+        auto vote_allele = [&](int64_t v, bool alt) { if ((t.hp1_is_alt[v] != 0) == alt) h1++; else h2++; };
+        if (cur < t.n) for (int i = 0; i < n_cig; ++i) {
+            const int op = cig[i] & 15; const int64_t len = cig[i] >> 4;
+            while (cur < t.n && t.pos[cur] < ref_pos) ++cur;
+            if (op == 0 || op == 7 || op == 8) {
+                while (cur < t.n && t.pos[cur] < ref_pos + len) {
+                    const int64_t off = t.pos[cur] - ref_pos, qi = query_pos + off;
+                    const int rl = t.ref_len[cur], al = t.alt_len[cur];
+                    if (rl == 1 && al == 1) {                                          // judgeSnpHap SNP (:36-65)
+                        const char base = qi < lq ? seq_base(seq, qi) : 'N';           // reference reads out of bounds here
+                        if (base == (char)t.ref0[cur] || base == (char)t.alt0[cur]) { vote_allele(cur, base == (char)t.alt0[cur]); countPS[t.phase_set[cur]]++; }
+                    } else if (rl == 1 && al > 1 && i + 1 < n_cig) {                   // insertion (:68-96)
+                        const bool has = (ref_pos + len - 1 == t.pos[cur]) && (cig[i + 1] & 15) == 1;
+                        vote_allele(cur, has); countPS[t.phase_set[cur]]++;
+                    } else if (rl > 1 && al == 1 && i + 1 < n_cig) {                   // deletion (:98-129): votes for the LONG allele
+                        const bool has = (ref_pos + len - 1 == t.pos[cur]) && (cig[i + 1] & 15) == 2;
+                        vote_allele(cur, !has); countPS[t.phase_set[cur]]++;
+                    }
+                    ++cur;
+                }
+                query_pos += len; ref_pos += len;
+            } else if (op == 1) query_pos += len;
+            else if (op == 2) {
+                bool judged = false;
+                while (cur < t.n && t.pos[cur] < ref_pos + len) {
+                    if (!judged) {                                                     // processDeletionOperation: once per D op
+                        judged = true;
+                        const int64_t p = t.pos[cur];
+                        if (!(ref_pos + len + 1 == p) && p >= ref_pos && p < ref_pos + len && homopolymer_length(p, T.ref, T.ref_len) >= 3) {
+                            const int rl = t.ref_len[cur], al = t.alt_len[cur];
+                            if (rl == 1 && al == 1) {                                  // judgeDeletionHap SNP (:175-189)
+                                const char base = query_pos < lq ? seq_base(seq, query_pos) : 'N';
+                                if (base == (char)t.ref0[cur] || base == (char)t.alt0[cur]) vote_allele(cur, base == (char)t.alt0[cur]);
+                                countPS[t.phase_set[cur]]++;
+                            } else if (rl > 1 && al == 1) { vote_allele(cur, false); countPS[t.phase_set[cur]]++; }   // (:192-206)
+                        }
+                    }
+                    ++cur;
+                }
+                ref_pos += len;
+            } else if (op == 3) ref_pos += len;
+            else if (op == 4) query_pos += len;
+            else if (op == 5 || op == 6) {}
+            else return -2;
+        }
+        out->hp1[r] = h1; out->hp2[r] = h2;
+        out->n_ps[r] = (uint8_t)std::min<size_t>(countPS.size(), 255); out->ps_min[r] = countPS.empty() ? 0 : countPS.begin()->first;
+        // ---- judgeReadHap
+        double mn, mx; int hp = 0, pq = 0;
+        if (h1 > h2) { mn = h2; mx = h1; } else { mn = h1; mx = h2; }
+        if (mx / (mx + mn) < P.percentage_threshold) pq = 0;
+        else { if (h1 > h2) hp = 1; if (h1 < h2) hp = 2; }
+        if (mx == 0) pq = 0; else if (mx == mx + mn) pq = 40; else pq = -10 * (std::log10((double)mn / double(mx + mn)));
+        if (countPS.size() > 1) hp = 0;
+        out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = hp ? countPS.begin()->first : 0;
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -37,6 +37,9 @@ def lib():
         _lib.oracle_phase.restype = C.c_int
         _lib.oracle_phase.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.c_void_p, C.c_int64,
                                       C.POINTER(abi.ReadBatch), C.POINTER(abi.PhaseResult), C.POINTER(Dumps)]
+        _lib.oracle_haplotag.restype = C.c_int
+        _lib.oracle_haplotag.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.c_void_p, C.c_int64,
+                                         C.POINTER(abi.ReadBatch), C.POINTER(abi.HaplotagResult)]
     return _lib
 
 
@@ -77,3 +80,13 @@ def phase(params, variants, ref, reads, dump=False, with_edges=True):
                                 C.byref(out.c), C.byref(d.c))
         assert rc == 0
     return out, d
+
+
+def haplotag(params, variants, ref, reads):
+    """CPU restatement of the germline haplotag per-read scoring loop.  Returns abi.HaplotagOut."""
+    out = abi.HaplotagOut(reads.n_reads)
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    rc = lib().oracle_haplotag(C.byref(params), C.byref(variants.c), ref.ctypes.data, ref.size, C.byref(reads.c), C.byref(out.c))
+    if rc != 0:
+        raise RuntimeError(f"oracle_haplotag rc={rc}")
+    return out

@@ -29,6 +29,18 @@ PHASE_FIXTURES = {
     "short_reads": (dict(SMALL, seed=15, len_median=3000.0, len_min=500, coverage=25.0), ["--ont"], {}),
 }
 
+# haplotag fixtures: (phase fixture providing reads + the reference's own phased VCF, haplotag CLI flags, params overrides)
+HAPLOTAG_FIXTURES = {
+    "snp_ont": ("snp_ont", [], {}),
+    "indels": ("indels", [], {}),
+    "two_blocks": ("two_blocks", [], {}),
+    "sparse_cov": ("sparse_cov", [], {}),
+    "supp_tagged": ("supp_overlap", ["--tagSupplementary"], dict(tag_supplementary=1)),
+    "dense_snps": ("dense_snps", [], {}),
+    "strict": ("lowq_heavy", ["-q", "20", "-p", "0.8"], dict(mapping_quality=20, percentage_threshold=0.8)),
+    "high_error": ("high_error", [], {}),
+}
+
 # fixtures whose full inputs (FASTA/VCF/SAM) are committed as data files under tests/golden/data/
 TINY = dict(contig_len=60_000, n_snp=120, coverage=12.0, n_threads=2)
 DATA_FIXTURES = {

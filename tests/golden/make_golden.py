@@ -65,9 +65,55 @@ def run_reference_phase(s, cli, workdir, chrom="chrS"):
     return parse_phased_vcf(os.path.join(workdir, "out.vcf"), s.var_pos)
 
 
+def parse_phased_table(path):
+    """Phased-het rows of a phased VCF = the haplotag variant table (HaplotagVcfParser.cpp:304-400)."""
+    pos, ref, alt, hp1_alt, ps = [], [], [], [], []
+    for line in open(path):
+        if line.startswith("#"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        fmt = f[8].split(":"); smp = f[9].split(":")
+        gt = smp[fmt.index("GT")]
+        if gt not in ("0|1", "1|0"):
+            continue
+        pos.append(int(f[1]) - 1); ref.append(f[3]); alt.append(f[4]); hp1_alt.append(1 if gt == "1|0" else 0)
+        ps.append(int(smp[fmt.index("PS")]))
+    return np.array(pos, np.int32), ref, alt, np.array(hp1_alt, np.uint8), np.array(ps, np.int32)
+
+
+def run_reference_haplotag(s, phase_cli, tag_cli, workdir, chrom="chrS"):
+    """phase (reference) -> haplotag (reference) -> per-read (HP, PS, PQ) from the tagged BAM."""
+    run_reference_phase(s, phase_cli, workdir, chrom)
+    cmd = [REF_BIN, "haplotag", "-s", "out.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", "1", "-o", "tagged"] + tag_cli
+    r = subprocess.run(cmd, cwd=workdir, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"reference haplotag failed rc={r.returncode}: {r.stderr[-2000:]}")
+    sam = subprocess.run([TEST_VIEW, "tagged.bam"], cwd=workdir, capture_output=True, text=True).stdout
+    hp, ps, pq = [], [], []
+    for line in sam.splitlines():
+        if line.startswith("@"):
+            continue
+        tags = dict((t[:2], t[5:]) for t in line.split("\t")[11:])
+        hp.append(int(tags.get("HP", 0))); ps.append(int(tags.get("PS", 0))); pq.append(int(tags.get("PQ", -1)))
+    assert len(hp) == s.n_reads, (len(hp), s.n_reads)
+    table = parse_phased_table(os.path.join(workdir, "out.vcf"))
+    return table, np.array(hp, np.uint8), np.array(ps, np.int32), np.array(pq, np.int32)
+
+
 def main():
     assert os.path.exists(REF_BIN), "build the reference first: oracle/build_ref.sh"
     index = {}
+    for name, (src, tag_cli, over) in fixtures.HAPLOTAG_FIXTURES.items():
+        kw, phase_cli, _ = fixtures.PHASE_FIXTURES[src]
+        s = Synth(**kw)
+        with tempfile.TemporaryDirectory() as d:
+            (tpos, tref, talt, thp1, tps), hp, ps, pq = run_reference_haplotag(s, phase_cli, tag_cli, d)
+        np.savez_compressed(os.path.join(HERE, f"haplotag_{name}.npz"), pos=tpos, ref=np.array(tref), alt=np.array(talt),
+                            hp1_is_alt=thp1, phase_set=tps, hp=hp, ps=ps, pq=pq)
+        index["haplotag:" + name] = dict(digest=fixtures.input_digest(s), n_reads=int(s.n_reads), n_table=int(tpos.size),
+                                         n_tagged=int((hp != 0).sum()), n_ps=int(len(set(tps.tolist()))), cli=tag_cli)
+        print("haplotag", name, index["haplotag:" + name])
+        s.close()
     for name, (kw, cli, over) in fixtures.PHASE_FIXTURES.items():
         s = Synth(**kw)
         with tempfile.TemporaryDirectory() as d:

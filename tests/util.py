@@ -93,3 +93,19 @@ def parse_fasta(path):
         if not line.startswith(">"):
             seq.append(line.strip())
     return np.frombuffer("".join(seq).encode(), dtype=np.uint8)
+
+
+def load_golden_haplotag(name):
+    z = np.load(os.path.join(GOLDEN, f"haplotag_{name}.npz"))
+    V = abi.Variants(z["pos"], [str(x) for x in z["ref"]], [str(x) for x in z["alt"]], hp1_is_alt=z["hp1_is_alt"],
+                     phase_set=z["phase_set"])
+    return V, z["hp"], z["ps"], z["pq"]
+
+
+def assert_tags_equal(out, hp, ps, pq, what=""):
+    """HP/PS/PQ as written to the BAM: PS and PQ only exist on tagged reads."""
+    bad = np.nonzero(out.hp != hp)[0]
+    assert bad.size == 0, f"{what}: {bad.size} HP mismatches, first reads {bad[:5]}: {out.hp[bad[:5]]} vs {hp[bad[:5]]}"
+    m = hp != 0
+    assert np.array_equal(out.ps[m], ps[m]), f"{what}: PS mismatch"
+    assert np.array_equal(out.pq[m], pq[m]), f"{what}: PQ mismatch"
