@@ -132,6 +132,8 @@ typedef struct lps_timings {
     int64_t n_pairs;           /* edge increments applied */
     int64_t n_reads_used;      /* alignments with >=1 observation */
     int64_t algorithmic_bytes[LPS_MAX_STAGES]; /* SURVEY.md §8d closed forms evaluated on this input */
+    int64_t n_scan_segments;   /* vote scan: speculative segments of the last phase call ...          */
+    int64_t n_scan_replayed;   /* ... and how many had to be replayed serially (exactness fallback)   */
 } lps_timings;
 
 int lps_abi_version(void);

@@ -54,7 +54,7 @@ struct lps_ctx {
     DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
     DevBuf<uint8_t> hap_status, hap_nps; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin;
     DevBuf<char> temp; size_t temp_bytes = 0;
-    LpsCounters *d_cnt = nullptr; LpsCounters h_cnt{};
+    LpsCounters *d_cnt = nullptr; LpsCounters h_cnt{}; unsigned h_stats[4]{};
     // timing
     hipEvent_t ev[ST_COUNT + 1]{}; bool ev_used[ST_COUNT + 1]{};
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -321,6 +321,7 @@ static int run_phase(lps_ctx *c) {
         launch_correction(c->d_cnt, nR, nV, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->v_pos.p, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, c->node_pairs.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
         mark(c, ST_D2H);
         HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(c->h_stats, c->clip_stats.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
         return 0;
     }
     c->err = "observation buffer kept overflowing";
@@ -362,6 +363,7 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         t.algorithmic_bytes[ST_EDGES] = 8ll * (int64_t)c->h_cnt.n_pairs + 8ll * (int64_t)c->h_cnt.n_obs_final + 16ll * c->P.connect_adjacent * (int64_t)c->h_cnt.n_nodes;
         t.algorithmic_bytes[ST_SCAN] = (16ll * c->P.connect_adjacent + 64) * (int64_t)c->h_cnt.n_nodes;
         t.algorithmic_bytes[ST_CORR] = 16ll * (int64_t)c->h_cnt.n_obs_final + 32ll * (int64_t)c->h_cnt.n_nodes;
+        t.n_scan_segments = (c->h_cnt.n_nodes + 255) / 256; t.n_scan_replayed = c->h_stats[2];
         c->phase_valid = true;
     } catch (std::string &e) { return fail(c, e); }
     return 0;

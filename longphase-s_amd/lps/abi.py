@@ -56,7 +56,7 @@ class HaplotagResult(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("ms_kernel", C.c_float * LPS_MAX_STAGES), ("ms_total", C.c_float),
                 ("n_obs", C.c_int64), ("n_nodes", C.c_int64), ("n_pairs", C.c_int64), ("n_reads_used", C.c_int64),
-                ("algorithmic_bytes", C.c_int64 * LPS_MAX_STAGES)]
+                ("algorithmic_bytes", C.c_int64 * LPS_MAX_STAGES), ("n_scan_segments", C.c_int64), ("n_scan_replayed", C.c_int64)]
 
 
 def _ptr(a):

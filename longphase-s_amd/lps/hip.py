@@ -121,6 +121,7 @@ class Context:
         names = [self.L.lps_stage_name(i).decode() for i in range(t.n_stages)]
         return dict(stages={n: t.ms_kernel[i] for i, n in enumerate(names)}, ms_total=t.ms_total, n_obs=t.n_obs,
                     n_nodes=t.n_nodes, n_pairs=t.n_pairs, n_reads_used=t.n_reads_used,
+                    n_scan_segments=t.n_scan_segments, n_scan_replayed=t.n_scan_replayed,
                     algorithmic_bytes={n: t.algorithmic_bytes[i] for i, n in enumerate(names)})
 
     # ---- stage dumps (parity tests)
