@@ -37,7 +37,8 @@ struct lps_ctx {
     // observations
     DevBuf<uint32_t> row_off; DevBuf<int32_t> row_cnt, row_fail, g_cnt; DevBuf<uint8_t> row_flags, deleted;
     DevBuf<int32_t> obs_var, g_node; DevBuf<uint16_t> obs_aq; DevBuf<uint8_t> g_flag;
-    unsigned long long obs_capacity = 0;
+    unsigned long long obs_capacity = 0;   // main arenas (LPS_ARENAS equal parts); a tail arena of obs_capacity/4 follows
+    DevBuf<unsigned long long> arena_ctr;
     // clips / cnv
     DevBuf<int32_t> clip_pos, clip_op; size_t clip_capacity = 0;
     DevBuf<unsigned long long> clip_keys, clip_keys_s;
@@ -228,9 +229,15 @@ static int run_phase(lps_ctx *c) {
     const lps_params &P = c->P; hipStream_t s = c->stream;
     const int nR = c->nR, nV = c->nV, A = P.connect_adjacent;
     // ---- capacities
-    if (c->obs_capacity == 0) c->obs_capacity = std::max<unsigned long long>(1024, (unsigned long long)nR * 48);
+    if (c->obs_capacity == 0) c->obs_capacity = std::max<unsigned long long>(64 * 1024, (unsigned long long)nR * 64);
     for (int attempt = 0; attempt < 3; ++attempt) {
-        const unsigned long long cap = c->obs_capacity;
+        const int n_blocks = (nR + 15) / 16;                                  // k_extract_phase: 4 waves x 4 alignments per workgroup
+        const int n_arenas = std::max(1, std::min(LPS_ARENAS, n_blocks));
+        c->obs_capacity = (c->obs_capacity + n_arenas - 1) / n_arenas * n_arenas;
+        const unsigned long long cap_main = c->obs_capacity, arena_size = cap_main / n_arenas, tail_size = cap_main / 4 + 4096;
+        const unsigned long long cap = cap_main + tail_size;
+        if (cap > 0xffffffffull) { c->err = "observation arena exceeds 2^32 slots"; return -8; }
+        c->arena_ctr.reserve(LPS_ARENAS * 8);
         c->row_off.reserve(nR + 1); c->row_cnt.reserve(nR + 1); c->row_fail.reserve(nR + 1); c->row_flags.reserve(nR + 1);
         c->g_cnt.reserve(nR + 1); c->deleted.reserve(nR + 1);
         c->obs_var.reserve(cap); c->obs_aq.reserve(cap); c->g_node.reserve(cap); c->g_flag.reserve(cap);
@@ -254,6 +261,7 @@ static int run_phase(lps_ctx *c) {
         for (auto &u : c->ev_used) u = false;
         HIP_TRY(hipEventRecord(c->ev_begin, s));
         HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
+        HIP_TRY(hipMemsetAsync(c->arena_ctr.p, 0, LPS_ARENAS * 8 * sizeof(unsigned long long), s));
         HIP_TRY(hipMemsetAsync(c->out_ps.p, 0, (size_t)nV * sizeof(int32_t), s));
         HIP_TRY(hipMemsetAsync(c->out_gt.p, 0, (size_t)nV, s));
         // ---- a4/a5/a6 variant table prep
@@ -263,10 +271,11 @@ static int run_phase(lps_ctx *c) {
         mark(c, ST_PREP);
         launch_variant_prep(V, P.is_ont, c->v_bucket.p, c->v_rec.p, s);
         // ---- a1/a2/a3 extraction
-        ObsView O{c->row_off.p, c->row_cnt.p, c->row_fail.p, c->row_flags.p, c->obs_var.p, c->obs_aq.p, cap};
+        ObsView O{c->row_off.p, c->row_cnt.p, c->row_fail.p, c->row_flags.p, c->obs_var.p, c->obs_aq.p, arena_size, c->arena_ctr.p, n_arenas};
         ClipView C{c->clip_pos.p, c->clip_op.p};
         mark(c, ST_EXTRACT);
         launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, s);
+        launch_arena_sum(c->arena_ctr.p, arena_size, c->d_cnt, s);
         // ---- name keys (needs only row_cnt); S1: counters to host (sizes of the sorts)
         mark(c, ST_GROUPS);
         launch_name_keys(nR, c->r_name.p, c->row_cnt.p, c->name_keys.p, c->d_cnt, s);
@@ -275,7 +284,7 @@ static int run_phase(lps_ctx *c) {
         HIP_TRY(hipStreamSynchronize(s));
         if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) { c->err = "alignment find unsupported CIGAR operation"; return -2; }
         if (c->h_cnt.err & LPS_ERR_CLIP_OVERFLOW) { c->err = "clip event buffer overflow"; return -3; }
-        if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = c->h_cnt.obs_total + c->h_cnt.obs_total / 2 + 1024; continue; }
+        if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = (unsigned long long)n_arenas * (c->h_cnt.arena_max + c->h_cnt.arena_max / 4 + 1024); continue; }
         const unsigned long long n_keys = c->h_cnt.obs_total;
         if (n_keys + n_keys / 2 > cap) { /* leave room for merged tails */ }
         sort_keys64(c->temp.p, c->temp_bytes, c->name_keys.p, c->name_keys_s.p, nR, 64, s);
@@ -299,7 +308,7 @@ static int run_phase(lps_ctx *c) {
         // ---- merged rows
         mark(c, ST_MERGE);
         HIP_TRY(hipMemsetAsync(c->mrow_cnt.p, 0, (size_t)(nR + 1) * 4, s));
-        launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, cap, c->mrow_off.p, c->mrow_cnt.p, s);
+        launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, cap_main, tail_size, c->mrow_off.p, c->mrow_cnt.p, s);
         // ---- node-major sorted lists
         mark(c, ST_NODELISTS);
         c->m_bits = bits_for((unsigned long long)nR + 1); c->n_bits = bits_for((unsigned long long)nV + 2); c->a_bits = 16;
@@ -343,7 +352,7 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         HIP_TRY(hipMemcpyAsync(out->gt, c->out_gt.p, (size_t)c->nV, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipEventRecord(c->ev_end, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = c->h_cnt.obs_total * 2 + 1024; return lps_phase_chromosome(c, out); }
+        if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = c->obs_capacity * 2 + 64 * 1024; return lps_phase_chromosome(c, out); }
         if (c->h_cnt.err & LPS_ERR_KEY_RANGE) return fail(c, "a merged read has more than 65536 observations", -6);
         if (c->h_cnt.err & LPS_ERR_CNV_CAP) return fail(c, "more than 64 CNV intervals on one chromosome", -7);
         // timings
@@ -437,7 +446,7 @@ int64_t lps_dump_observations(lps_ctx *c, int32_t *obs_count, int32_t *var_index
     try {
         HIP_TRY(hipSetDevice(c->device));
         auto off = download(c, c->row_off.p, c->nR); auto cntv = download(c, c->row_cnt.p, c->nR);
-        const size_t tot = (size_t)std::min<unsigned long long>(c->h_cnt.obs_total, c->obs_capacity);
+        const size_t tot = (size_t)(c->obs_capacity + c->obs_capacity / 4 + 4096);   // rows are scattered over the arenas
         auto var = download(c, c->obs_var.p, tot); auto aq = download(c, c->obs_aq.p, tot);
         int64_t n = 0;
         for (int r = 0; r < c->nR; ++r) {

@@ -53,7 +53,7 @@ enum {
 
 // device-side counters block (one per ctx), zeroed at the start of every run
 struct LpsCounters {
-    unsigned long long obs_total;   // reserved observation slots (rows + merged tails)
+    unsigned long long obs_total;   // reserved observation slots summed over the arenas (filled by k_arena_sum)
     unsigned int n_clips;
     unsigned int err;
     unsigned int n_kept;            // alignments with >=1 observation
@@ -65,7 +65,11 @@ struct LpsCounters {
     unsigned long long n_obs_final; // observations of kept alignments after all filters
     unsigned int n_multi;           // merged rows built from >=2 alignments
     unsigned int pad;
+    unsigned long long tail_total;  // slots reserved in the tail arena (merged rows of multi-alignment reads)
+    unsigned long long arena_max;   // largest per-arena reservation (capacity planning on overflow)
 };
+
+#define LPS_ARENAS 64              // observation arenas, each with its own reservation counter on its own 64-B line
 
 // ---------------------------------------------------------------- wave-level primitives (wave64)
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

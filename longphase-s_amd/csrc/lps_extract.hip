@@ -81,7 +81,7 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 }
 
 // ------------------------------------------------------------------------------------------------ extraction
-#define EXT_RPW 4   // alignments per wave: one output reservation (atomic) per workgroup covers 4 waves x 4 reads
+#define EXT_RPW 4   // alignments per wave (processed one after the other)
 
 struct ReadPlan { int v0, v1; bool live; };
 
@@ -119,44 +119,36 @@ __device__ __forceinline__ ReadPlan plan_read(const VarView &V, const ReadView &
     return p;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
-                                                          LpsCounters *cnt) {
+__global__ __launch_bounds__(256) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
+                                                       LpsCounters *cnt) {
     __shared__ int s_ref[4][LPS_SEG];
     __shared__ int s_qry[4][LPS_SEG];
     __shared__ uint32_t s_cig[4][LPS_SEG + 1];
-    __shared__ unsigned long long s_cand[4][EXT_RPW];
-    __shared__ unsigned long long s_base;
-    __shared__ int s_plan[4][EXT_RPW][3];
     const int w = threadIdx.x >> 6, l = lane_id();
     int *sref = s_ref[w], *sqry = s_qry[w]; uint32_t *scig = s_cig[w];
-    const int r0 = (blockIdx.x * 4 + w) * EXT_RPW;
-
-    // ---- pass 1 for the wave's EXT_RPW alignments, then ONE reservation per workgroup
+    // Output rows are reserved per alignment on one of LPS_ARENAS counters (own cache line each).  Workgroups are
+    // dealt round-robin over the 8 XCDs, so arena = blockIdx % 64 keeps each counter inside ONE XCD's L2, and pass 2
+    // follows pass 1 of the same alignment immediately: its CIGAR re-read is an L2 hit instead of a second HBM sweep.
+    const int arena = blockIdx.x % O.n_arenas;
+    const unsigned long long arena_lo = (unsigned long long)arena * O.arena_size;
 #pragma unroll 1
     for (int q = 0; q < EXT_RPW; ++q) {
-        const ReadPlan pl = plan_read(V, R, r0 + q, mapping_quality, cnt);
-        if (l == 0) { s_cand[w][q] = (unsigned long long)(pl.v1 - pl.v0); s_plan[w][q][0] = pl.v0; s_plan[w][q][1] = pl.v1; s_plan[w][q][2] = pl.live; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long tot = 0;
-        for (int i = 0; i < 4 * EXT_RPW; ++i) tot += (&s_cand[0][0])[i];
-        s_base = tot ? atomicAdd(&cnt->obs_total, tot) : 0ull;
-    }
-    __syncthreads();
-    unsigned long long base = s_base;
-    for (int i = 0; i < w * EXT_RPW; ++i) base += (&s_cand[0][0])[i];
-
-#pragma unroll 1
-    for (int q = 0; q < EXT_RPW; ++q) {
-        const int r = r0 + q;
+        const int r = (blockIdx.x * 4 + w) * EXT_RPW + q;
         if (r >= R.n) break;
-        const int v0 = s_plan[w][q][0], v1 = s_plan[w][q][1], cand = v1 - v0;
-        const bool live_q = s_plan[w][q][2] != 0;
-        const unsigned long long my_base = base; base += (unsigned long long)cand;
-        if (l < LPS_CLIP_SLOTS && (!live_q || my_base + (unsigned long long)cand > O.capacity)) C.opidx_fb[(size_t)r * LPS_CLIP_SLOTS + l] = -1;
+        const ReadPlan pl = plan_read(V, R, r, mapping_quality, cnt);
+        const int v0 = pl.v0, v1 = pl.v1, cand = v1 - v0;
+        const bool live_q = pl.live;
+        unsigned long long my_base = 0; bool overflow = false;
+        if (live_q && cand > 0) {
+            unsigned long long off = 0;
+            if (l == 0) off = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)cand);
+            off = __shfl(off, 0);
+            overflow = off + (unsigned long long)cand > O.arena_size;
+            my_base = arena_lo + off;
+        }
+        if (l < LPS_CLIP_SLOTS && (!live_q || overflow)) C.opidx_fb[(size_t)r * LPS_CLIP_SLOTS + l] = -1;
         if (!live_q) { if (l == 0) { O.row_off[r] = 0; O.row_cnt[r] = 0; O.row_fail[r] = 0x7fffffff; O.row_flags[r] = 0; } continue; }
-        if (my_base + (unsigned long long)cand > O.capacity) {
+        if (overflow) {
             if (l == 0) { atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); O.row_off[r] = 0; O.row_cnt[r] = 0; O.row_fail[r] = 0x7fffffff; O.row_flags[r] = 0; }
             continue;
         }

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const uint32_t *
 // differs from it only in the relative order of equal positions beyond that.
 __global__ void k_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt,
                              const uint32_t *row_off, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
-                             unsigned long long capacity, uint32_t *mrow_off, int32_t *mrow_cnt) {
+                             unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt) {
     const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= cnt->n_groups) return;
     const uint32_t s0 = gstart[g], s1 = gstart[g + 1];
@@ -345,8 +345,9 @@ __global__ void k_merge_rows(const unsigned long long *skeys, const uint32_t *gs
     for (uint32_t s = s0; s < s1; ++s) { const uint32_t r = (uint32_t)skeys[s]; if (g_cnt[r] > 0) { ++alive; total += g_cnt[r]; one = r; } }
     if (alive == 0) { mrow_off[g] = 0; mrow_cnt[g] = 0; return; }
     if (alive == 1) { mrow_off[g] = row_off[one]; mrow_cnt[g] = total; return; }
-    const unsigned long long base = atomicAdd(&cnt->obs_total, (unsigned long long)total);
-    if (base + total > capacity) { atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); mrow_off[g] = 0; mrow_cnt[g] = 0; return; }
+    const unsigned long long toff = atomicAdd(&cnt->tail_total, (unsigned long long)total);
+    const unsigned long long base = tail_lo + toff;
+    if (toff + total > tail_size) { atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); mrow_off[g] = 0; mrow_cnt[g] = 0; return; }
     atomicAdd(&cnt->n_multi, 1u);
     int w = 0, last_nd = -1;
     for (uint32_t s = s0; s < s1; ++s) {
@@ -867,8 +868,22 @@ void launch_nodes(int n_reads, int n_var, const uint32_t *row_off, const int32_t
 
 void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
                        const uint32_t *row_off, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
-                       unsigned long long capacity, uint32_t *mrow_off, int32_t *mrow_cnt, hipStream_t s) {
-    hipLaunchKernelGGL(k_merge_rows, GRID(n_reads, 128), 0, s, skeys, gstart, cnt, row_off, g_cnt, g_node, g_flag, capacity, mrow_off, mrow_cnt);
+                       unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_rows, GRID(n_reads, 128), 0, s, skeys, gstart, cnt, row_off, g_cnt, g_node, g_flag, tail_lo, tail_size, mrow_off, mrow_cnt);
+}
+
+__global__ void k_arena_sum(const unsigned long long *arena_ctr, unsigned long long arena_size, LpsCounters *cnt) {
+    const int l = threadIdx.x;
+    unsigned long long v = l < LPS_ARENAS ? arena_ctr[l * 8] : 0ull;
+    if (v > arena_size) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW);
+    unsigned long long mx = v;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+    v = wave_sum(v);
+    if (l == 0) { cnt->obs_total = v; cnt->arena_max = mx; }
+}
+void launch_arena_sum(const unsigned long long *arena_ctr, unsigned long long arena_size, LpsCounters *cnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_arena_sum, dim3(1), dim3(64), 0, s, arena_ctr, arena_size, cnt);
 }
 
 void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t *mrow_off, const int32_t *mrow_cnt, uint32_t *koff,

@@ -39,7 +39,9 @@ struct ObsView {           // CSR rows placed by atomic reservation: row r = [ro
     uint8_t *row_flags;    // bit0: had observations before filterSNP erased them
     int32_t *var;          // variant index
     uint16_t *aq;          // pack_aq(allele, quality)
-    unsigned long long capacity;
+    unsigned long long arena_size;      // slots per arena; arena a covers [a*arena_size, (a+1)*arena_size)
+    unsigned long long *arena_ctr;      // LPS_ARENAS counters, 8 u64 apart (one cache line each)
+    int n_arenas;                       // arenas in use: min(LPS_ARENAS, workgroups)
 };
 
 struct ClipView {          // clip events in LPS_CLIP_SLOTS fixed slots per alignment; filtered by row_fail afterwards
