@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 1
+#define LPS_ABI_VERSION 2
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -65,6 +65,14 @@ typedef struct lps_variant_table {
     const uint16_t *alt_len;
     const uint8_t *hp1_is_alt; /* haplotag */
     const int32_t *phase_set;  /* haplotag */
+    /* somatic tagging only (merged normal+tumor map, src/haplotag/HaplotagType.h:146-162 MultiGenomeVar), else NULL:
+     *  somatic_role[i]: 0 = row of the NORMAL phased-het VCF (alleles/hp1_is_alt/phase_set are the normal ones; a tumor row
+     *                       at the same position is shadowed exactly as in judgeSomaticSnpHap, HaplotagStrategy.cpp:315-389)
+     *                   1 = tumor-only row flagged isSomaticVariant by the caller (SomaticVarCaller::getSomaticFlag :2397-2412)
+     *                   2 = tumor-only row that is not a somatic call (kept: it still defines the last variant position)
+     *  derive_hp[i]   : MultiGenomeVar::somaticReadDeriveByHP of role-1 rows (0 none, 1 H1, 2 H2) */
+    const uint8_t *somatic_role;
+    const uint8_t *derive_hp;
 } lps_variant_table;
 
 /* Decoded alignments of ONE chromosome in BAM (coordinate) order = what sam_itr_multi_next hands to
@@ -120,6 +128,26 @@ typedef struct lps_haplotag_result {
     int32_t *ps;
 } lps_haplotag_result;
 
+/* Per-read result of the somatic tagging pass (SomaticHaplotagChrProcessor::judgeHaplotype,
+ * src/somatic_haplotag/SomaticHaplotagProcess.cpp:310-459 + inheritHaplotype :461-527).  Caller allocates n_reads entries.
+ *  status as in lps_haplotag_result; hp1/hp2/hp3 = hpCount[1..3]; derive_h1/h2 = H3 bases whose variant derives from H1/H2;
+ *  hp = ReadHP code (0 untagged, 1 H1, 2 H2, 3 H3, 4 H4, 5 "1-1", 6 "1-2", 7 "2-1", 8 "2-2", HaplotagType.h:97-108);
+ *  ps = PS value or -1 when no PS tag is written (:416-434); pq as written to the PQ tag. */
+typedef struct lps_somatic_tag_result {
+    int64_t n_reads;
+    uint8_t *status;
+    int32_t *hp1;
+    int32_t *hp2;
+    int32_t *hp3;
+    int32_t *derive_h1;
+    int32_t *derive_h2;
+    uint8_t *n_ps;
+    int32_t *ps_min;
+    uint8_t *hp;
+    int32_t *pq;
+    int32_t *ps;
+} lps_somatic_tag_result;
+
 /* Stage timings of the last lps_phase_chromosome / lps_haplotag call, measured with hipEvents on the
  * library's stream.  ms_kernel[i] pairs with lps_stage_name(i). */
 #define LPS_MAX_STAGES 24
@@ -138,7 +166,7 @@ typedef struct lps_timings {
 
 int lps_abi_version(void);
 /* sizeof() of the ABI structs as compiled into the library: 0 lps_params, 1 lps_variant_table, 2 lps_read_batch,
- * 3 lps_phase_result, 4 lps_haplotag_result, 5 lps_timings (binding self-check). */
+ * 3 lps_phase_result, 4 lps_haplotag_result, 5 lps_timings, 6 lps_somatic_tag_result (binding self-check). */
 int lps_struct_size(int which);
 int lps_device_count(void);
 
@@ -161,6 +189,8 @@ int lps_push_reads(lps_ctx *ctx, const lps_read_batch *batch);
 int lps_phase_chromosome(lps_ctx *ctx, lps_phase_result *out);
 /* haplotag: per-read scoring of the reads pushed so far against the phased table. */
 int lps_haplotag_chromosome(lps_ctx *ctx, lps_haplotag_result *out);
+/* somatic_haplotag tagging pass over the (tumor) reads pushed so far against the merged normal+tumor table. */
+int lps_somatic_tag_chromosome(lps_ctx *ctx, lps_somatic_tag_result *out);
 
 int lps_get_timings(lps_ctx *ctx, lps_timings *t);
 const char *lps_stage_name(int stage);

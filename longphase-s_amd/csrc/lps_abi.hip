@@ -53,7 +53,7 @@ struct lps_ctx {
     DevBuf<unsigned long long> nkeys, nkeys_s; DevBuf<uint32_t> nvals, nvals_s;
     DevBuf<float> edge;
     DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
-    DevBuf<uint8_t> hap_status, hap_nps; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin;
+    DevBuf<uint8_t> hap_status, hap_nps, v_role, v_derive; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1, hap_d2; bool has_somatic = false;
     DevBuf<char> temp; size_t temp_bytes = 0;
     LpsCounters *d_cnt = nullptr; LpsCounters h_cnt{}; unsigned h_stats[4]{};
     // timing
@@ -87,7 +87,7 @@ int lps_abi_version(void) { return LPS_ABI_VERSION; }
 int lps_struct_size(int which) {
     switch (which) {
         case 0: return (int)sizeof(lps_params); case 1: return (int)sizeof(lps_variant_table); case 2: return (int)sizeof(lps_read_batch);
-        case 3: return (int)sizeof(lps_phase_result); case 4: return (int)sizeof(lps_haplotag_result); case 5: return (int)sizeof(lps_timings);
+        case 3: return (int)sizeof(lps_phase_result); case 4: return (int)sizeof(lps_haplotag_result); case 5: return (int)sizeof(lps_timings); case 6: return (int)sizeof(lps_somatic_tag_result);
     }
     return -1;
 }
@@ -155,6 +155,8 @@ int lps_set_variants(lps_ctx *c, const lps_variant_table *t) {
         c->v_danger.reserve(t->n + 1); c->v_hpoly.reserve(t->n + 1); c->v_erased.reserve(t->n + 1);
         c->has_hap = t->hp1_is_alt && t->phase_set;
         if (c->has_hap) { upload(c, c->v_hp1, t->hp1_is_alt, t->n); upload(c, c->v_ps, t->phase_set, t->n); }
+        c->has_somatic = c->has_hap && t->somatic_role && t->derive_hp;
+        if (c->has_somatic) { upload(c, c->v_role, t->somatic_role, t->n); upload(c, c->v_derive, t->derive_hp, t->n); }
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->phase_valid = false;
     } catch (std::string &e) { return fail(c, e); }
@@ -213,7 +215,8 @@ static void mark(lps_ctx *c, int st) { HIP_TRY(hipEventRecord(c->ev[st], c->stre
 static VarView var_view(lps_ctx *c) {
     VarView V{};
     V.n = c->nV; V.pos = c->v_pos.p; V.ref0 = c->v_ref0.p; V.alt0 = c->v_alt0.p; V.ref_len = c->v_rl.p; V.alt_len = c->v_al.p;
-    V.danger = c->v_danger.p; V.hpoly = c->v_hpoly.p; V.erased = c->v_erased.p; V.hp1_is_alt = c->v_hp1.p; V.phase_set = c->v_ps.p;
+    V.danger = c->v_danger.p; V.hpoly = c->v_hpoly.p; V.erased = c->v_erased.p; V.hp1_is_alt = c->has_hap ? c->v_hp1.p : nullptr; V.phase_set = c->v_ps.p;
+    V.somatic_role = c->has_somatic ? c->v_role.p : nullptr; V.derive_hp = c->has_somatic ? c->v_derive.p : nullptr;
     V.ref = c->ref.p; V.ref_len_eff = c->ref_len_eff; V.last_pos = c->last_pos;
     V.n_bucket = (int)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 1; V.bucket = c->v_bucket.p; V.rec = c->v_rec.p;
     return V;
@@ -378,6 +381,48 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
     return 0;
 }
 
+// shared by haplotag and the somatic tagging pass: variant prep + scoring kernel + D2H of the integer counts
+static int run_scorer(lps_ctx *c, bool somatic, uint8_t *status, int32_t *hp1, int32_t *hp2, uint8_t *n_ps, int32_t *ps_min,
+                      int32_t *hp3, int32_t *d1, int32_t *d2) {
+    const int nR = c->nR, nV = c->nV;
+    hipStream_t s = c->stream;
+    c->hap_status.reserve(nR); c->hap_h1.reserve(nR); c->hap_h2.reserve(nR); c->hap_nps.reserve(nR); c->hap_psmin.reserve(nR);
+    c->hap_h3.reserve(nR); c->hap_d1.reserve(nR); c->hap_d2.reserve(nR);
+    c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1);
+    HIP_TRY(hipEventRecord(c->ev_begin, s));
+    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
+    VarView V = var_view(c); ReadView R = read_view(c);
+    for (auto &u : c->ev_used) u = false;
+    mark(c, ST_PREP);
+    launch_variant_prep(V, /*is_ont (filterSNP is a `phase` step)*/ 0, c->v_bucket.p, c->v_rec.p, s);
+    mark(c, ST_EXTRACT);
+    HapOut H{c->hap_status.p, c->hap_h1.p, c->hap_h2.p, c->hap_nps.p, c->hap_psmin.p, c->hap_h3.p, c->hap_d1.p, c->hap_d2.p};
+    launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, somatic, c->d_cnt, s);
+    mark(c, ST_D2H);
+    HIP_TRY(hipMemcpyAsync(status, H.status, (size_t)nR, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hp1, H.hp1, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hp2, H.hp2, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(n_ps, H.n_ps, (size_t)nR, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ps_min, H.ps_min, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+    if (somatic) {
+        HIP_TRY(hipMemcpyAsync(hp3, H.hp3, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(d1, H.d1, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(d2, H.d2, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(c->ev_end, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) return fail(c, "Alignment find unsupported CIGAR operation", -2);
+    lps_timings &t = c->tm; memset(&t, 0, sizeof t);
+    t.n_stages = ST_COUNT;
+    HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_PREP], c->ev[ST_PREP], c->ev[ST_EXTRACT]));
+    HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_EXTRACT], c->ev[ST_EXTRACT], c->ev[ST_D2H]));
+    HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_D2H], c->ev[ST_D2H], c->ev_end));
+    HIP_TRY(hipEventElapsedTime(&t.ms_total, c->ev_begin, c->ev_end));
+    t.algorithmic_bytes[ST_EXTRACT] = 36ll * nR + 4ll * (int64_t)c->n_cig + 10ll * nR;   // + observations (unknown here)
+    return 0;
+}
+
 int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
     if (!c || !out) return -1;
     try {
@@ -387,28 +432,8 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
         if (nR == 0) return 0;
         if (nV > 0 && !c->has_hap) return fail(c, "haplotag needs hp1_is_alt and phase_set in the variant table");
         if (nV > 0 && c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
-        hipStream_t s = c->stream;
-        c->hap_status.reserve(nR); c->hap_h1.reserve(nR); c->hap_h2.reserve(nR); c->hap_nps.reserve(nR); c->hap_psmin.reserve(nR);
-        c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1);
-        HIP_TRY(hipEventRecord(c->ev_begin, s));
-        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
-        VarView V = var_view(c); ReadView R = read_view(c);
-        for (auto &u : c->ev_used) u = false;
-        mark(c, ST_PREP);
-        launch_variant_prep(V, /*is_ont (filterSNP is a `phase` step)*/ 0, c->v_bucket.p, c->v_rec.p, s);
-        mark(c, ST_EXTRACT);
-        HapOut H{c->hap_status.p, c->hap_h1.p, c->hap_h2.p, c->hap_nps.p, c->hap_psmin.p};
-        launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, c->d_cnt, s);
-        mark(c, ST_D2H);
-        HIP_TRY(hipMemcpyAsync(out->status, H.status, (size_t)nR, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(out->hp1, H.hp1, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(out->hp2, H.hp2, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(out->n_ps, H.n_ps, (size_t)nR, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(out->ps_min, H.ps_min, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(c->ev_end, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) return fail(c, "Alignment find unsupported CIGAR operation", -2);
+        int rc = run_scorer(c, false, out->status, out->hp1, out->hp2, out->n_ps, out->ps_min, nullptr, nullptr, nullptr);
+        if (rc) return rc;
         // judgeReadHap (src/haplotag/HaplotagStrategy.cpp:243-300) on the host: needs libm's log10
         const double thr = c->P.percentage_threshold;
         int64_t tagged = 0;
@@ -426,14 +451,57 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
             out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = hp ? out->ps_min[r] : 0;
             tagged += hp != 0;
         }
-        lps_timings &t = c->tm; memset(&t, 0, sizeof t);
-        t.n_stages = ST_COUNT;
-        HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_PREP], c->ev[ST_PREP], c->ev[ST_EXTRACT]));
-        HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_EXTRACT], c->ev[ST_EXTRACT], c->ev[ST_D2H]));
-        HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_D2H], c->ev[ST_D2H], c->ev_end));
-        HIP_TRY(hipEventElapsedTime(&t.ms_total, c->ev_begin, c->ev_end));
-        t.n_reads_used = tagged;
-        t.algorithmic_bytes[ST_EXTRACT] = 36ll * nR + 4ll * (int64_t)c->n_cig + 10ll * nR;   // + observations (unknown here)
+        c->tm.n_reads_used = tagged;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_somatic_tag_chromosome(lps_ctx *c, lps_somatic_tag_result *out) {
+    if (!c || !out) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        const int nR = c->nR, nV = c->nV;
+        if (out->n_reads != nR) return fail(c, "lps_somatic_tag_result.n_reads must equal the number of pushed alignments");
+        if (nR == 0) return 0;
+        if (nV > 0 && !c->has_somatic) return fail(c, "somatic tagging needs hp1_is_alt, phase_set, somatic_role and derive_hp in the variant table");
+        if (nV > 0 && c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
+        int rc = run_scorer(c, true, out->status, out->hp1, out->hp2, out->n_ps, out->ps_min, out->hp3, out->derive_h1, out->derive_h2);
+        if (rc) return rc;
+        // judgeSomaticReadHap (HaplotagStrategy.cpp:452-602) + inheritHaplotype (SomaticHaplotagProcess.cpp:461-527) + PS rule (:416-434)
+        const double thr = c->P.percentage_threshold;
+        int64_t tagged = 0;
+        for (int r = 0; r < nR; ++r) {
+            int hp = 0, pq = 0, ps = -1;
+            if (out->status[r] == 0) {
+                const int h1 = out->hp1[r], h2 = out->hp2[r], h3 = out->hp3[r], h4 = 0;
+                double tMin, tMax, nMin, nMax; int maxT, maxN;
+                if (h3 > h4) { tMin = h4; tMax = h3; maxT = 3; } else { tMin = h3; tMax = h4; maxT = 4; }
+                if (h1 > h2) { nMin = h2; nMax = h1; maxN = 1; } else { nMin = h1; nMax = h2; maxN = 2; }
+                const double tumSim = (tMax == 0) ? 0.0 : tMax / (tMax + tMin);
+                const double norSim = (nMax == 0) ? 0.0 : nMax / (nMax + nMin);
+                if (tMax != 0) {
+                    if (tumSim >= thr) {
+                        if (norSim >= thr) hp = (maxT == 3) ? (maxN == 1 ? 5 : 7) : (maxN == 1 ? 6 : 8);
+                        else hp = (maxT == 3) ? 3 : 4;
+                    }
+                } else if (nMax != 0) { if (norSim >= thr) hp = maxN; }
+                if (out->n_ps[r] > 1) hp = 0;
+                if (nMax == 0 && tMax == 0) pq = 0;
+                else if (tMax != 0) { if (tMax == tMax + tMin) pq = 40; else pq = -10 * (std::log10((double)tMin / double(tMax + tMin))); }
+                else if (nMax != 0) { if (nMax == nMax + nMin) pq = 40; else pq = -10 * (std::log10((double)nMin / double(nMax + nMin))); }
+                if (hp == 3) {
+                    const int d1 = out->derive_h1[r], d2 = out->derive_h2[r];
+                    int mx, mn, mh;
+                    if (d1 > d2) { mx = d1; mn = d2; mh = 1; } else { mx = d2; mn = d1; mh = 2; }
+                    const float sim = (mx == 0) ? 0.0f : ((float)mx / ((float)mx + (float)mn));
+                    if (sim >= thr) hp = (mh == 1) ? 5 : 7;
+                }
+                if (hp != 0 && out->n_ps[r] > 0) ps = out->ps_min[r];
+            }
+            out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = ps;
+            tagged += hp != 0;
+        }
+        c->tm.n_reads_used = tagged;
     } catch (std::string &e) { return fail(c, e); }
     return 0;
 }

@@ -11,6 +11,11 @@
 // record per candidate), but there is no output reservation: a read reduces to two vote counts and its PS range.
 #include "lps_kernels.h"
 
+// SOMATIC = false: germline `haplotag`.  SOMATIC = true: tagging pass of `somatic_haplotag` over the merged normal+tumor table
+// (SomaticHaplotagCigarParser, src/somatic_haplotag/SomaticHaplotagProcess.cpp:557-579; judgeSomaticSnpHap / judgeNormalSnpHap /
+// SomaticHaplotagStrategy::judgeTumorOnlySnpHap, src/haplotag/HaplotagStrategy.cpp:315-435,653-668): deletions cast no vote,
+// indel rows vote with the read's own allele, somatic calls count H3 bases and which germline haplotype they derive from.
+template <bool SOMATIC>
 __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary,
                                                         LpsCounters *cnt) {
     __shared__ int s_ref[4][LPS_SEG];
@@ -29,7 +34,7 @@ __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, H
     else if ((flag & 0x800) && !tag_supplementary) status = 4;
     else if (V.n == 0) status = 5;
     else if (!(start <= V.last_pos)) status = 6;
-    int h1 = 0, h2 = 0, ps_lo = 0x7fffffff, ps_hi = (int)0x80000000;
+    int h1 = 0, h2 = 0, h3 = 0, d1 = 0, d2 = 0, ps_lo = 0x7fffffff, ps_hi = (int)0x80000000;
     if (status == 0) {
         const uint64_t coff = R.cigar_off[r];
         const int n_cig = (int)(R.cigar_off[r + 1] - coff);
@@ -85,6 +90,23 @@ __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, H
                             const bool hp1alt = (at & VREC_HP1ALT) != 0;
                             int vote = -1;                              // 0: haplotype carrying REF, 1: haplotype carrying ALT
                             bool count_ps = false;
+                            if (SOMATIC) {
+                                if (op_is_match(op)) {
+                                    const int qi = qs + (p - rs);
+                                    const char base_c = qi < lq ? nt16_char(seq[qi >> 1] >> ((~qi & 1) << 2)) : 'N';
+                                    bool is_alt = false;                                      // IsAltIndel (HaplotagParsingBam.cpp:650-670)
+                                    if (kind == 0) is_alt = base_c == alt_c;
+                                    else if ((kind == 1 || kind == 2) && seg0 + j + 1 < n_cig)
+                                        is_alt = (rs + len - 1 == p) && (int)(scig[j + 1] & 15) == ((kind == 1) ? 1 : 2);
+                                    const unsigned role = VREC_ROLE(at);
+                                    if (role == 0) {                                          // judgeNormalSnpHap (:403-435)
+                                        if (kind == 0) { if (base_c == ref_c || base_c == alt_c) { vote = is_alt; count_ps = true; } }
+                                        else if (kind == 1 || kind == 2) { vote = is_alt; count_ps = true; }
+                                    } else if (role == 1) {                                   // somatic call: H3 when the read shows ALT (:653-668)
+                                        if ((kind == 0 || kind == 1 || kind == 2) && is_alt) { ++h3; const unsigned dv = VREC_DERIVE(at); if (dv == 1) ++d1; else if (dv == 2) ++d2; }
+                                    }
+                                }
+                            } else
                             if (op_is_match(op)) {                                            // judgeSnpHap (:20-130)
                                 if (kind == 0) {
                                     const int qi = qs + (p - rs);
@@ -121,17 +143,20 @@ __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, H
             wave_sync();
         }
         h1 = wave_sum(h1); h2 = wave_sum(h2); ps_lo = wave_min(ps_lo); ps_hi = wave_max(ps_hi);
+        if (SOMATIC) { h3 = wave_sum(h3); d1 = wave_sum(d1); d2 = wave_sum(d2); }
     }
     if (l == 0) {
         H.status[r] = (uint8_t)status; H.hp1[r] = h1; H.hp2[r] = h2;
         const bool any = ps_lo <= ps_hi;
         H.n_ps[r] = any ? (ps_lo == ps_hi ? 1 : 2) : 0;               // only "more than one" matters to judgeReadHap
         H.ps_min[r] = any ? ps_lo : 0;
+        if (SOMATIC) { H.hp3[r] = h3; H.d1[r] = d1; H.d2[r] = d2; }
     }
 }
 
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
-                     LpsCounters *cnt, hipStream_t s) {
+                     bool somatic, LpsCounters *cnt, hipStream_t s) {
     if (R.n == 0) return;
-    hipLaunchKernelGGL(k_haplotag_score, dim3((R.n + 3) / 4), dim3(256), 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
+    if (somatic) hipLaunchKernelGGL(k_haplotag_score<true>, dim3((R.n + 3) / 4), dim3(256), 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
+    else hipLaunchKernelGGL(k_haplotag_score<false>, dim3((R.n + 3) / 4), dim3(256), 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
 }

@@ -13,6 +13,7 @@ struct VarView {           // variant table, position-sorted (Appendix B of SURV
     uint8_t *erased;       // filterSNP
     const uint8_t *hp1_is_alt;   // haplotag
     const int32_t *phase_set;    // haplotag
+    const uint8_t *somatic_role, *derive_hp;   // somatic tagging
     const uint2 *rec;      // packed per-variant record {pos, attr} used by the extraction kernels (see VREC_*)
     const int32_t *bucket; // coarse index: bucket[b] = first variant with pos >= (b << LPS_BUCKET_SHIFT); n_bucket+1 entries
     int n_bucket;
@@ -57,6 +58,8 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 #define VREC_ERASED (1u << 19)
 #define VREC_HPOLY3 (1u << 20)
 #define VREC_HP1ALT (1u << 21)   /* haplotag: haplotype 1 carries ALT */
+#define VREC_ROLE(a) (((a) >> 22) & 3u)   /* somatic tagging: 0 normal phased-het row, 1 somatic call, 2 inert tumor row */
+#define VREC_DERIVE(a) (((a) >> 24) & 3u) /* somaticReadDeriveByHP of role-1 rows */
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,
                           int mapping_quality, LpsCounters *cnt, hipStream_t s);
 
@@ -78,6 +81,6 @@ __device__ __forceinline__ int var_lower_bound(const VarView &V, int key) {
 
 #endif
 
-struct HapOut { uint8_t *status; int32_t *hp1, *hp2; uint8_t *n_ps; int32_t *ps_min; };
+struct HapOut { uint8_t *status; int32_t *hp1, *hp2; uint8_t *n_ps; int32_t *ps_min; int32_t *hp3, *d1, *d2; };
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
-                     LpsCounters *cnt, hipStream_t s);
+                     bool somatic, LpsCounters *cnt, hipStream_t s);

@@ -33,7 +33,7 @@ def default_params(**kw):
 class VariantTable(C.Structure):
     _fields_ = [("n", C.c_int64), ("pos", C.c_void_p), ("ref0", C.c_void_p), ("alt0", C.c_void_p),
                 ("ref_len", C.c_void_p), ("alt_len", C.c_void_p), ("hp1_is_alt", C.c_void_p),
-                ("phase_set", C.c_void_p)]
+                ("phase_set", C.c_void_p), ("somatic_role", C.c_void_p), ("derive_hp", C.c_void_p)]
 
 
 class ReadBatch(C.Structure):
@@ -53,6 +53,15 @@ class HaplotagResult(C.Structure):
                 ("ps", C.c_void_p)]
 
 
+class SomaticTagResult(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("status", C.c_void_p), ("hp1", C.c_void_p), ("hp2", C.c_void_p), ("hp3", C.c_void_p),
+                ("derive_h1", C.c_void_p), ("derive_h2", C.c_void_p), ("n_ps", C.c_void_p), ("ps_min", C.c_void_p),
+                ("hp", C.c_void_p), ("pq", C.c_void_p), ("ps", C.c_void_p)]
+
+
+READ_HP_STR = [".", "1", "2", "3", "4", "1-1", "1-2", "2-1", "2-2"]   # ReadHapUtil::readHapIntToString (HaplotagType.h:327-342)
+
+
 class Timings(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("ms_kernel", C.c_float * LPS_MAX_STAGES), ("ms_total", C.c_float),
                 ("n_obs", C.c_int64), ("n_nodes", C.c_int64), ("n_pairs", C.c_int64), ("n_reads_used", C.c_int64),
@@ -66,7 +75,7 @@ def _ptr(a):
 class Variants:
     """Host-side variant table (keeps the numpy arrays alive next to the ctypes struct)."""
 
-    def __init__(self, pos, ref, alt, hp1_is_alt=None, phase_set=None):
+    def __init__(self, pos, ref, alt, hp1_is_alt=None, phase_set=None, somatic_role=None, derive_hp=None):
         self.pos = np.ascontiguousarray(pos, dtype=np.int32)
         n = self.pos.size
         self.ref_str = [r if isinstance(r, bytes) else r.encode() for r in ref]
@@ -77,9 +86,12 @@ class Variants:
         self.alt_len = np.array([len(a) for a in self.alt_str], dtype=np.uint16)
         self.hp1_is_alt = None if hp1_is_alt is None else np.ascontiguousarray(hp1_is_alt, dtype=np.uint8)
         self.phase_set = None if phase_set is None else np.ascontiguousarray(phase_set, dtype=np.int32)
+        self.somatic_role = None if somatic_role is None else np.ascontiguousarray(somatic_role, dtype=np.uint8)
+        self.derive_hp = None if derive_hp is None else np.ascontiguousarray(derive_hp, dtype=np.uint8)
         self.n = n
         self.c = VariantTable(n, _ptr(self.pos), _ptr(self.ref0), _ptr(self.alt0), _ptr(self.ref_len),
-                              _ptr(self.alt_len), _ptr(self.hp1_is_alt), _ptr(self.phase_set))
+                              _ptr(self.alt_len), _ptr(self.hp1_is_alt), _ptr(self.phase_set), _ptr(self.somatic_role),
+                              _ptr(self.derive_hp))
 
 
 class Reads:
@@ -140,3 +152,16 @@ class HaplotagOut:
         self.ps = np.zeros(n, np.int32)
         self.c = HaplotagResult(n, *[_ptr(getattr(self, k)) for k in
                                      ("status", "hp1", "hp2", "n_ps", "ps_min", "hp", "pq", "ps")])
+
+
+class SomaticTagOut:
+    I32 = ("hp1", "hp2", "hp3", "derive_h1", "derive_h2", "ps_min", "pq", "ps")
+    U8 = ("status", "n_ps", "hp")
+
+    def __init__(self, n):
+        for k in self.I32:
+            setattr(self, k, np.zeros(n, np.int32))
+        for k in self.U8:
+            setattr(self, k, np.zeros(n, np.uint8))
+        self.c = SomaticTagResult(n, *[_ptr(getattr(self, k)) for k in
+                                       ("status", "hp1", "hp2", "hp3", "derive_h1", "derive_h2", "n_ps", "ps_min", "hp", "pq", "ps")])

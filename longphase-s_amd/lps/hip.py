@@ -47,6 +47,7 @@ def load():
     L.lps_push_reads.argtypes = [C.c_void_p, C.POINTER(abi.ReadBatch)]
     L.lps_phase_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.PhaseResult)]
     L.lps_haplotag_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.HaplotagResult)]
+    L.lps_somatic_tag_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.SomaticTagResult)]
     L.lps_get_timings.argtypes = [C.c_void_p, C.POINTER(abi.Timings)]
     L.lps_stage_name.restype = C.c_char_p
     L.lps_stage_name.argtypes = [C.c_int]
@@ -114,6 +115,15 @@ class Context:
     def haplotag(self, variants, ref, reads):
         self.load_chromosome(variants, ref, reads)
         return self.run_haplotag()
+
+    def run_somatic_tag(self, out=None):
+        out = out or abi.SomaticTagOut(self.n_reads)
+        self._check(self.L.lps_somatic_tag_chromosome(self.h, C.byref(out.c)), "lps_somatic_tag_chromosome")
+        return out
+
+    def somatic_tag(self, variants, ref, reads):
+        self.load_chromosome(variants, ref, reads)
+        return self.run_somatic_tag()
 
     def timings(self):
         t = abi.Timings()

@@ -20,7 +20,7 @@ class SynthParams(C.Structure):
         ("secondary_frac", C.c_double), ("dup_frac", C.c_double), ("clip_every", C.c_int32),
         ("supp_frac", C.c_double), ("supp_overlap_frac", C.c_double), ("hpoly_every", C.c_double),
         ("snp_in_hpoly_frac", C.c_double), ("snp_pair_frac", C.c_double), ("tandem_frac", C.c_double),
-        ("n_threads", C.c_int32), ("clip_pileups", C.c_int32), ("gap_start", C.c_int64), ("gap_len", C.c_int64),
+        ("n_threads", C.c_int32), ("clip_pileups", C.c_int32), ("gap_start", C.c_int64), ("gap_len", C.c_int64), ("read_seed", C.c_uint64), ("somatic_every", C.c_double), ("tumor_purity", C.c_double),
     ]
 
 
@@ -29,7 +29,7 @@ DEFAULTS = dict(
     len_min=1000, len_max=200000, sub_rate=0.01, ins_rate=0.01, del_rate=0.01, indel_var_frac=0.0,
     lowq_frac=0.10, mapq0_frac=0.01, secondary_frac=0.003, dup_frac=0.002, clip_every=7, supp_frac=0.02,
     supp_overlap_frac=0.5, hpoly_every=2000.0, snp_in_hpoly_frac=0.05, snp_pair_frac=0.01, tandem_frac=0.3,
-    n_threads=8, clip_pileups=0, gap_start=0, gap_len=0,
+    n_threads=8, clip_pileups=0, gap_start=0, gap_len=0, read_seed=0, somatic_every=0.0, tumor_purity=0.6,
 )
 
 _lib = None
@@ -44,12 +44,12 @@ def _load():
         L.synth_create.restype = C.c_void_p
         L.synth_create.argtypes = [C.POINTER(SynthParams)]
         L.synth_destroy.argtypes = [C.c_void_p]
-        for n in ("synth_n_reads", "synth_n_variants"):
+        for n in ("synth_n_reads", "synth_n_variants", "synth_n_somatic"):
             getattr(L, n).restype = C.c_int64
             getattr(L, n).argtypes = [C.c_void_p]
         for n in ("synth_ref", "synth_var_pos", "synth_var_hap", "synth_ref_start", "synth_l_qseq", "synth_flag",
                   "synth_mapq", "synth_name_id", "synth_read_hap", "synth_cigar_off", "synth_seq_off",
-                  "synth_qual_off", "synth_cigar", "synth_seq", "synth_qual"):
+                  "synth_qual_off", "synth_cigar", "synth_seq", "synth_qual", "synth_som_pos", "synth_som_ref", "synth_som_alt", "synth_som_hap"):
             getattr(L, n).restype = C.c_void_p
             getattr(L, n).argtypes = [C.c_void_p]
         for n in ("synth_var_ref", "synth_var_alt"):
@@ -58,6 +58,7 @@ def _load():
         L.synth_write_fasta.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         L.synth_write_sam.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         L.synth_write_vcf.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.synth_write_vcf_tumor.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
         _lib = L
     return _lib
 
@@ -86,6 +87,11 @@ class Synth:
         self.var_hap = _view(L.synth_var_hap(h), nv, np.uint8)
         self.var_ref = [L.synth_var_ref(h, i) for i in range(nv)]
         self.var_alt = [L.synth_var_alt(h, i) for i in range(nv)]
+        ns = self.n_somatic = L.synth_n_somatic(h)
+        self.som_pos = _view(L.synth_som_pos(h), ns, np.int32)
+        self.som_ref = _view(L.synth_som_ref(h), ns, np.uint8)
+        self.som_alt = _view(L.synth_som_alt(h), ns, np.uint8)
+        self.som_hap = _view(L.synth_som_hap(h), ns, np.uint8)
         self.ref_start = _view(L.synth_ref_start(h), n, np.int32)
         self.l_qseq = _view(L.synth_l_qseq(h), n, np.int32)
         self.flag = _view(L.synth_flag(h), n, np.uint16)
@@ -107,6 +113,9 @@ class Synth:
 
     def write_vcf(self, path, chrom="chrS", phased=False):
         assert _load().synth_write_vcf(self._h, path.encode(), chrom.encode(), int(phased)) == 0
+
+    def write_vcf_tumor(self, path, chrom="chrS", with_germline=False):
+        assert _load().synth_write_vcf_tumor(self._h, path.encode(), chrom.encode(), int(with_germline)) == 0
 
     def close(self):
         if self._h:

@@ -82,6 +82,9 @@ struct synth_params {
     int32_t clip_pileups;     // number of simulated CNV break-point clip pile-ups (0 = none)
     int64_t gap_start;        // no variants inside [gap_start, gap_start+gap_len)  (two-block fixtures)
     int64_t gap_len;
+    uint64_t read_seed;       // 0 = derive reads from `seed`; otherwise same genome/variants, different reads (tumor/normal pairs)
+    double somatic_every;     // mean spacing of somatic SNVs (0 = none); they exist only in tumor-clone molecules
+    double tumor_purity;      // fraction of molecules drawn from the tumor clone (carry the somatic SNVs of their haplotype)
 };
 
 struct Synth {
@@ -91,6 +94,8 @@ struct Synth {
     std::vector<int32_t> vpos;
     std::vector<std::string> vref, valt;
     std::vector<uint8_t> vhap;   // haplotype (0/1) that carries ALT
+    // somatic SNVs (tumor clone only)
+    std::vector<int32_t> spos; std::vector<char> sref, salt; std::vector<uint8_t> shap;
     // reads SoA
     std::vector<int32_t> ref_start, l_qseq;
     std::vector<uint16_t> flag;
@@ -118,11 +123,12 @@ static void push_op(std::vector<uint32_t> &c, uint32_t op, uint32_t len) {
 }
 
 // simulate one molecule from haplotype `hap` over reference [start, start+span)
-static void simulate(const Synth &S, Rng &g, int hap, int64_t start, int64_t span,
+static void simulate(const Synth &S, Rng &g, int hap, bool clone, int64_t start, int64_t span,
                      std::vector<uint32_t> &cig, std::string &q, std::vector<uint8_t> &ql,
                      std::vector<int64_t> &q2r /* ref coordinate of every M base, -1 for I */) {
     const synth_params &P = S.p;
     size_t vi = std::lower_bound(S.vpos.begin(), S.vpos.end(), (int32_t)start) - S.vpos.begin();
+    size_t si = std::lower_bound(S.spos.begin(), S.spos.end(), (int32_t)start) - S.spos.begin();
     int64_t end = std::min<int64_t>(start + span, P.contig_len);
     auto put = [&](char b, int64_t r) {
         q.push_back(b);
@@ -146,6 +152,8 @@ static void simulate(const Synth &S, Rng &g, int hap, int64_t start, int64_t spa
                 else skip = (int)r.size() - 1;
             }
         }
+        while (si < S.spos.size() && S.spos[si] < p) ++si;
+        if (clone && si < S.spos.size() && S.spos[si] == p && S.shap[si] == hap) b = S.salt[si];
         if (!edge && g.uni() < P.sub_rate) { char nb; do nb = kBases[g.below(4)]; while (nb == b); b = nb; }
         push_op(cig, 0, 1); put(b, p); ++p;
         if (insn) { push_op(cig, 1, insn); for (char c : insb) put(c, -1); }
@@ -258,7 +266,20 @@ Synth *synth_create(const synth_params *pp) {
             S->vpos.push_back((int32_t)p); S->vref.push_back(r); S->valt.push_back(a); S->vhap.push_back((uint8_t)g.below(2));
         }
     }
-    // ---- reads
+    // ---- somatic SNVs: away from germline variants, one haplotype each
+    if (P.somatic_every > 0) {
+        Rng gs(P.seed * 77 + 5);
+        for (double x = 500 + (-std::log(1 - gs.uni())) * P.somatic_every; x < L - 500; x += 50 + (-std::log(1 - gs.uni())) * P.somatic_every) {
+            int64_t p = (int64_t)x;
+            auto it = std::lower_bound(S->vpos.begin(), S->vpos.end(), (int32_t)p - 20);
+            if (it != S->vpos.end() && *it <= p + 20) continue;
+            char r = S->ref[p], a; do a = kBases[gs.below(4)]; while (a == r);
+            S->spos.push_back((int32_t)p); S->sref.push_back(r); S->salt.push_back(a); S->shap.push_back((uint8_t)gs.below(2));
+        }
+    }
+    // ---- reads (own seed when read_seed != 0: tumor / normal samples of one genome)
+    if (P.read_seed) g = Rng(P.read_seed * 0x9E3779B97F4A7C15ull + 999);
+    const uint64_t rseed = P.read_seed ? P.read_seed : P.seed;
     const double mean_len = P.len_median * std::exp(P.len_sigma * P.len_sigma / 2);
     int64_t n_mol = (int64_t)(P.coverage * (double)L / mean_len);
     struct Mol { int64_t start, span; uint32_t id; };
@@ -282,8 +303,9 @@ Synth *synth_create(const synth_params *pp) {
         for (int t = 0; t < nt; ++t) th.emplace_back([&, t] {
             std::vector<int64_t> q2r;
             for (int64_t i = t; i < n_mol; i += nt) {
-                const Mol &m = mols[i]; Rng r(P.seed * 1000003ull + 0x51ED270B1ull * (m.id + 1));
+                const Mol &m = mols[i]; Rng r(rseed * 1000003ull + 0x51ED270B1ull * (m.id + 1));
                 int hap = (int)r.below(2);
+                const bool clone = P.somatic_every > 0 && r.uni() < P.tumor_purity;
                 int64_t mstart = m.start, mspan = m.span;
                 int force_front = -1, force_back = -1;
                 for (size_t k = 0; k < pile.size(); ++k) {   // snap molecules crossing a break point
@@ -291,7 +313,7 @@ Synth *synth_create(const synth_params *pp) {
                     else if (mstart < pile[k].second - 2000 && mstart + mspan > pile[k].second && r.uni() < 0.5) { mspan = pile[k].second - mstart; force_back = 1; }
                 }
                 std::vector<uint32_t> cig; std::string q; std::vector<uint8_t> ql; q2r.clear();
-                simulate(*S, r, hap, mstart, mspan, cig, q, ql, q2r);
+                simulate(*S, r, hap, clone, mstart, mspan, cig, q, ql, q2r);
                 if (cig.empty()) continue;
                 uint16_t fl = r.below(2) ? 16 : 0;
                 double u = r.uni();
@@ -360,6 +382,11 @@ Synth *synth_create(const synth_params *pp) {
 void synth_destroy(Synth *S) { delete S; }
 int64_t synth_n_reads(Synth *S) { return (int64_t)S->ref_start.size(); }
 int64_t synth_n_variants(Synth *S) { return (int64_t)S->vpos.size(); }
+int64_t synth_n_somatic(Synth *S) { return (int64_t)S->spos.size(); }
+const int32_t *synth_som_pos(Synth *S) { return S->spos.data(); }
+const char *synth_som_ref(Synth *S) { return S->sref.data(); }
+const char *synth_som_alt(Synth *S) { return S->salt.data(); }
+const uint8_t *synth_som_hap(Synth *S) { return S->shap.data(); }
 const char *synth_ref(Synth *S) { return S->ref.data(); }
 const int32_t *synth_var_pos(Synth *S) { return S->vpos.data(); }
 const uint8_t *synth_var_hap(Synth *S) { return S->vhap.data(); }
@@ -399,6 +426,21 @@ int synth_write_vcf(Synth *S, const char *path, const char *chr, int phased) {
     for (size_t i = 0; i < S->vpos.size(); ++i) {
         if (!phased) fprintf(f, "%s\t%d\t.\t%s\t%s\t30\tPASS\t.\tGT:GQ\t0/1:30\n", chr, S->vpos[i] + 1, S->vref[i].c_str(), S->valt[i].c_str());
         else fprintf(f, "%s\t%d\t.\t%s\t%s\t30\tPASS\t.\tGT:GQ:PS\t%s:30:%d\n", chr, S->vpos[i] + 1, S->vref[i].c_str(), S->valt[i].c_str(), S->vhap[i] ? "0|1" : "1|0", S->vpos[0] + 1);
+    }
+    fclose(f); return 0;
+}
+
+// tumor VCF for somatic_haplotag: somatic SNVs as 0/1 (plus, optionally, the germline hets as a caller would report them)
+int synth_write_vcf_tumor(Synth *S, const char *path, const char *chr, int with_germline) {
+    FILE *f = fopen(path, "w"); if (!f) return -1;
+    fprintf(f, "##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n##contig=<ID=%s,length=%lld>\n", chr, (long long)S->p.contig_len);
+    fprintf(f, "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Genotype Quality\">\n");
+    fprintf(f, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n");
+    size_t i = 0, j = 0;
+    while (i < S->spos.size() || (with_germline && j < S->vpos.size())) {
+        bool som = i < S->spos.size() && (!with_germline || j >= S->vpos.size() || S->spos[i] < S->vpos[j]);
+        if (som) { fprintf(f, "%s\t%d\t.\t%c\t%c\t30\tPASS\t.\tGT:GQ\t0/1:30\n", chr, S->spos[i] + 1, S->sref[i], S->salt[i]); ++i; }
+        else { fprintf(f, "%s\t%d\t.\t%s\t%s\t30\tPASS\t.\tGT:GQ\t0/1:30\n", chr, S->vpos[j] + 1, S->vref[j].c_str(), S->valt[j].c_str()); ++j; }
     }
     fclose(f); return 0;
 }

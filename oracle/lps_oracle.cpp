@@ -611,4 +611,103 @@ int oracle_haplotag(const lps_params *Pp, const lps_variant_table *tp, const cha
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ somatic tagging (a22)
+// SomaticHaplotagChrProcessor::judgeHaplotype (src/somatic_haplotag/SomaticHaplotagProcess.cpp:310-459),
+// SomaticHaplotagCigarParser (:557-579), SomaticJudgeHapStrategy::judgeSomaticSnpHap / judgeNormalSnpHap
+// (src/haplotag/HaplotagStrategy.cpp:315-435), SomaticHaplotagStrategy::judgeTumorOnlySnpHap (:653-668),
+// judgeSomaticReadHap (:452-602), inheritHaplotype (SomaticHaplotagProcess.cpp:461-527).
+int oracle_somatic_tag(const lps_params *Pp, const lps_variant_table *tp, const lps_read_batch *bp, lps_somatic_tag_result *out) {
+    const lps_params &P = *Pp; const lps_variant_table &t = *tp; const lps_read_batch &b = *bp;
+    const int32_t last_pos = t.n ? t.pos[t.n - 1] : -1;
+    for (int64_t r = 0; r < b.n_reads; ++r) {
+        out->status[r] = 0; out->hp1[r] = out->hp2[r] = out->hp3[r] = 0; out->derive_h1[r] = out->derive_h2[r] = 0;
+        out->n_ps[r] = 0; out->ps_min[r] = 0; out->hp[r] = 0; out->pq[r] = 0; out->ps[r] = -1;
+        const int fl = b.flag[r];
+        if (b.mapq[r] < P.mapping_quality) { out->status[r] = 1; continue; }
+        if (fl & 0x4) { out->status[r] = 2; continue; }
+        if (fl & 0x100) { out->status[r] = 3; continue; }
+        if ((fl & 0x800) && !P.tag_supplementary) { out->status[r] = 4; continue; }
+        if (t.n == 0) { out->status[r] = 5; continue; }
+        if (!(b.ref_start[r] <= last_pos)) { out->status[r] = 6; continue; }
+        const uint32_t *cig = b.cigar + b.cigar_off[r];
+        const int n_cig = (int)(b.cigar_off[r + 1] - b.cigar_off[r]);
+        const uint8_t *seq = b.seq + b.seq_off[r];
+        const int64_t lq = b.l_qseq[r];
+        int64_t ref_pos = b.ref_start[r], query_pos = 0;
+        int64_t cur = std::lower_bound(t.pos, t.pos + t.n, (int32_t)ref_pos) - t.pos;
+        int h1 = 0, h2 = 0, h3 = 0, d1 = 0, d2 = 0; std::map<int, int> norPS;
+        if (cur < t.n) for (int i = 0; i < n_cig; ++i) {
+            const int op = cig[i] & 15; const int64_t len = cig[i] >> 4;
+            while (cur < t.n && t.pos[cur] < ref_pos) ++cur;
+            if (op == 0 || op == 7 || op == 8) {
+                while (cur < t.n && t.pos[cur] < ref_pos + len) {
+                    const int64_t qi = query_pos + (t.pos[cur] - ref_pos);
+                    const char base = qi < lq ? seq_base(seq, qi) : 'N';
+                    const int rl = t.ref_len[cur], al = t.alt_len[cur];
+                    const bool snp = rl == 1 && al == 1, ins = rl == 1 && al > 1, del = rl > 1 && al == 1;
+                    bool isAlt = false;                                               // IsAltIndel (HaplotagParsingBam.cpp:650-670)
+                    if (snp) isAlt = base == (char)t.alt0[cur];
+                    else if (ins && i + 1 < n_cig) isAlt = (ref_pos + len - 1 == t.pos[cur]) && (cig[i + 1] & 15) == 1;
+                    else if (del && i + 1 < n_cig) isAlt = (ref_pos + len - 1 == t.pos[cur]) && (cig[i + 1] & 15) == 2;
+                    const int role = t.somatic_role[cur];
+                    if (role == 0) {                                                  // judgeNormalSnpHap
+                        bool counted = false, alt = false;
+                        if (snp) { if (base == (char)t.ref0[cur] || base == (char)t.alt0[cur]) { counted = true; alt = base == (char)t.alt0[cur]; } }
+                        else if (ins || del) { counted = true; alt = isAlt; }         // base := isAlt ? Alt : Ref (:330-337)
+                        if (counted) { if ((t.hp1_is_alt[cur] != 0) == alt) h1++; else h2++; norPS[t.phase_set[cur]]++; }
+                    } else if (role == 1) {                                           // SomaticHaplotagStrategy::judgeTumorOnlySnpHap
+                        bool h3v = false;
+                        if (snp) h3v = base == (char)t.alt0[cur];                     // guarded by Ref==base||Alt==base (:360-361)
+                        else if (ins || del) h3v = isAlt;
+                        if (h3v) { h3++; if (t.derive_hp[cur] == 1) d1++; else if (t.derive_hp[cur] == 2) d2++; }
+                    }
+                    ++cur;
+                }
+                query_pos += len; ref_pos += len;
+            } else if (op == 1) query_pos += len;
+            else if (op == 2) { while (cur < t.n && t.pos[cur] < ref_pos + len) ++cur; ref_pos += len; }   // only statistics in the reference
+            else if (op == 3) ref_pos += len;
+            else if (op == 4) query_pos += len;
+            else if (op == 5 || op == 6) {}
+            else return -2;
+        }
+        out->hp1[r] = h1; out->hp2[r] = h2; out->hp3[r] = h3; out->derive_h1[r] = d1; out->derive_h2[r] = d2;
+        out->n_ps[r] = (uint8_t)std::min<size_t>(norPS.size(), 255); out->ps_min[r] = norPS.empty() ? 0 : norPS.begin()->first;
+        // ---- judgeSomaticReadHap (hpCount[4] is never incremented by the tagging pass)
+        double tMin, tMax, nMin, nMax; int maxT, maxN;
+        const int h4 = 0;
+        if (h3 > h4) { tMin = h4; tMax = h3; maxT = 3; } else { tMin = h3; tMax = h4; maxT = 4; }
+        if (h1 > h2) { nMin = h2; nMax = h1; maxN = 1; } else { nMin = h1; nMax = h2; maxN = 2; }
+        const double tumSim = (tMax == 0) ? 0.0 : tMax / (tMax + tMin);
+        const double norSim = (nMax == 0) ? 0.0 : nMax / (nMax + nMin);
+        int hp = 0, pq = 0;
+        const double thr = P.percentage_threshold;
+        if (tMax != 0) {
+            if (tumSim >= thr) {
+                if (norSim >= thr) hp = (maxT == 3) ? (maxN == 1 ? 5 : 7) : (maxN == 1 ? 6 : 8);
+                else hp = (maxT == 3) ? 3 : 4;
+            } else pq = 0;
+        } else if (nMax != 0) { if (norSim >= thr) hp = maxN; else pq = 0; }
+        if (norPS.size() > 1) hp = 0;
+        if (nMax == 0 && tMax == 0) pq = 0;
+        else if (tMax != 0) { if (tMax == tMax + tMin) pq = 40; else pq = -10 * (std::log10((double)tMin / double(tMax + tMin))); }
+        else if (nMax != 0) { if (nMax == nMax + nMin) pq = 40; else pq = -10 * (std::log10((double)nMin / double(nMax + nMin))); }
+        // ---- inheritHaplotype
+        if (hp == 3) {
+            int mx, mn, mh;
+            if (d1 > d2) { mx = d1; mn = d2; mh = 1; } else { mx = d2; mn = d1; mh = 2; }
+            const float sim = (mx == 0) ? 0.0f : ((float)mx / ((float)mx + (float)mn));
+            if (sim >= P.percentage_threshold) hp = (mh == 1) ? 5 : 7;
+        }
+        int ps = -1;
+        if (hp != 0) {
+            if (hp != 1 && hp != 2) { if (!norPS.empty()) ps = norPS.begin()->first; }
+            else ps = norPS.begin()->first;
+        }
+        out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = ps;
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -40,6 +40,8 @@ def lib():
         _lib.oracle_haplotag.restype = C.c_int
         _lib.oracle_haplotag.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.c_void_p, C.c_int64,
                                          C.POINTER(abi.ReadBatch), C.POINTER(abi.HaplotagResult)]
+        _lib.oracle_somatic_tag.restype = C.c_int
+        _lib.oracle_somatic_tag.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.POINTER(abi.ReadBatch), C.POINTER(abi.SomaticTagResult)]
     return _lib
 
 
@@ -89,4 +91,13 @@ def haplotag(params, variants, ref, reads):
     rc = lib().oracle_haplotag(C.byref(params), C.byref(variants.c), ref.ctypes.data, ref.size, C.byref(reads.c), C.byref(out.c))
     if rc != 0:
         raise RuntimeError(f"oracle_haplotag rc={rc}")
+    return out
+
+
+def somatic_tag(params, variants, reads):
+    """CPU restatement of the somatic_haplotag tagging pass (merged normal+tumor table).  Returns abi.SomaticTagOut."""
+    out = abi.SomaticTagOut(reads.n_reads)
+    rc = lib().oracle_somatic_tag(C.byref(params), C.byref(variants.c), C.byref(reads.c), C.byref(out.c))
+    if rc != 0:
+        raise RuntimeError(f"oracle_somatic_tag rc={rc}")
     return out

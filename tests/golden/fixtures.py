@@ -41,6 +41,16 @@ HAPLOTAG_FIXTURES = {
     "high_error": ("high_error", [], {}),
 }
 
+# tumor/normal fixtures for the somatic rows: (genome kwargs, normal reads kwargs, tumor reads kwargs, somatic_haplotag CLI, params)
+TN_BASE = dict(contig_len=600_000, n_snp=700, n_threads=4, somatic_every=8000.0)
+SOMATIC_FIXTURES = {
+    "tn60": (dict(TN_BASE, seed=31), dict(coverage=25.0, read_seed=311, tumor_purity=0.0), dict(coverage=50.0, read_seed=312, tumor_purity=0.6), [], {}),
+    "tn30_indel": (dict(TN_BASE, seed=32, indel_var_frac=0.2), dict(coverage=20.0, read_seed=321, tumor_purity=0.0),
+                   dict(coverage=40.0, read_seed=322, tumor_purity=0.3), ["--tagSupplementary"], dict(tag_supplementary=1)),
+    "tn90_blocks": (dict(TN_BASE, seed=33, contig_len=900_000, n_snp=900, gap_start=300_000, gap_len=320_000, somatic_every=5000.0),
+                    dict(coverage=25.0, read_seed=331, tumor_purity=0.0), dict(coverage=45.0, read_seed=332, tumor_purity=0.9, supp_frac=0.2), ["-p", "0.7"], dict(percentage_threshold=0.7)),
+}
+
 # fixtures whose full inputs (FASTA/VCF/SAM) are committed as data files under tests/golden/data/
 TINY = dict(contig_len=60_000, n_snp=120, coverage=12.0, n_threads=2)
 DATA_FIXTURES = {

@@ -100,9 +100,88 @@ def run_reference_haplotag(s, phase_cli, tag_cli, workdir, chrom="chrS"):
     return table, np.array(hp, np.uint8), np.array(ps, np.int32), np.array(pq, np.int32)
 
 
+def parse_tumor_rows(path):
+    """Tumor VCF rows kept by VcfParser for the TUMOR sample (HaplotagVcfParser.cpp:470-530): 0/1, 1/1 (and phased hets)."""
+    rows = {}
+    for line in open(path):
+        if line.startswith("#"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        gt = f[9].split(":")[f[8].split(":").index("GT")]
+        if gt in ("0/1", "1/1", "0|1", "1|0"):
+            rows[int(f[1]) - 1] = (f[3], f[4].split(",")[0])
+    return rows
+
+
+def run_reference_somatic(N, T, tag_cli, workdir, chrom="chrS"):
+    """reference phase on the normal sample -> reference somatic_haplotag -> merged table + flags + per-read tags."""
+    N.write_fasta(os.path.join(workdir, "ref.fa"), chrom)
+    N.write_vcf(os.path.join(workdir, "normal_in.vcf"), chrom)
+    N.write_sam(os.path.join(workdir, "normal.sam"), chrom)
+    T.write_sam(os.path.join(workdir, "tumor.sam"), chrom)
+    T.write_vcf_tumor(os.path.join(workdir, "tumor.vcf"), chrom, with_germline=True)
+    for smp in ("normal", "tumor"):
+        subprocess.check_call([TEST_VIEW, "-b", "-x", smp + ".bam.bai", "-p", smp + ".bam", smp + ".sam"], cwd=workdir, stdout=subprocess.DEVNULL)
+    flags = ["--indels"] if N.params["indel_var_frac"] > 0 else []
+    r = subprocess.run([REF_BIN, "phase", "-s", "normal_in.vcf", "-b", "normal.bam", "-r", "ref.fa", "-t", "1", "-o", "normal_phased", "--ont"] + flags,
+                       cwd=workdir, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1000:]
+    cmd = [REF_BIN, "somatic_haplotag", "-s", "normal_phased.vcf", "-b", "normal.bam", "--tumor-snv-file", "tumor.vcf", "--tumor-bam-file", "tumor.bam",
+           "-r", "ref.fa", "-t", "1", "-o", "som", "--somatic-calling-log", "--output-somatic-vcf", "--log"] + tag_cli
+    r = subprocess.run(cmd, cwd=workdir, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"reference somatic_haplotag failed rc={r.returncode}: {r.stderr[-2000:]}")
+    npos, nref, nalt, nhp1, nps = parse_phased_table(os.path.join(workdir, "normal_phased.vcf"))
+    tum = parse_tumor_rows(os.path.join(workdir, "tumor.vcf"))
+    somatic = set()
+    for line in open(os.path.join(workdir, "som_sc.vcf")):
+        if not line.startswith("#"):
+            f = line.split("\t")
+            if f[6] == "PASS":
+                somatic.add(int(f[1]) - 1)
+    derive = {}
+    for line in open(os.path.join(workdir, "som_read_distri_after_inheritance.out")):
+        if line.startswith("#") or not line.strip():
+            continue
+        f = line.split("\t")
+        derive[int(f[1]) - 1] = {"H1": 1, "H2": 2}.get(f[2], 0)
+    assert set(derive) == somatic, (len(derive), len(somatic))
+    normal = {int(p): i for i, p in enumerate(npos)}
+    pos, ref, alt, hp1, ps, role, dhp = [], [], [], [], [], [], []
+    for p in sorted(set(normal) | set(tum)):
+        if p in normal:
+            i = normal[p]
+            pos.append(p); ref.append(nref[i]); alt.append(nalt[i]); hp1.append(int(nhp1[i])); ps.append(int(nps[i])); role.append(0); dhp.append(0)
+        else:
+            pos.append(p); ref.append(tum[p][0]); alt.append(tum[p][1]); hp1.append(0); ps.append(0)
+            role.append(1 if p in somatic else 2); dhp.append(derive.get(p, 0))
+    sam = subprocess.run([TEST_VIEW, "som.bam"], cwd=workdir, capture_output=True, text=True).stdout
+    codes = {".": 0, "1": 1, "2": 2, "3": 3, "4": 4, "1-1": 5, "1-2": 6, "2-1": 7, "2-2": 8}
+    hp, rps, pq = [], [], []
+    for line in sam.splitlines():
+        if line.startswith("@"):
+            continue
+        tags = dict((t[:2], t[5:]) for t in line.split("\t")[11:])
+        hp.append(codes[tags.get("HP", ".")]); rps.append(int(tags.get("PS", -1))); pq.append(int(tags.get("PQ", -1)))
+    assert len(hp) == T.n_reads
+    table = dict(pos=np.array(pos, np.int32), ref=np.array(ref), alt=np.array(alt), hp1_is_alt=np.array(hp1, np.uint8),
+                 phase_set=np.array(ps, np.int32), somatic_role=np.array(role, np.uint8), derive_hp=np.array(dhp, np.uint8))
+    return table, np.array(hp, np.uint8), np.array(rps, np.int32), np.array(pq, np.int32)
+
+
 def main():
     assert os.path.exists(REF_BIN), "build the reference first: oracle/build_ref.sh"
     index = {}
+    for name, (genome, nkw, tkw, tag_cli, over) in fixtures.SOMATIC_FIXTURES.items():
+        N = Synth(**dict(genome, **nkw)); T = Synth(**dict(genome, **tkw))
+        with tempfile.TemporaryDirectory() as d:
+            table, hp, ps, pq = run_reference_somatic(N, T, tag_cli, d)
+        np.savez_compressed(os.path.join(HERE, f"somatic_tag_{name}.npz"), hp=hp, ps=ps, pq=pq, **table)
+        index["somatic:" + name] = dict(digest=fixtures.input_digest(T), n_reads=int(T.n_reads), n_table=int(table["pos"].size),
+                                        n_somatic=int((table["somatic_role"] == 1).sum()), n_tagged=int((hp != 0).sum()),
+                                        hp_hist=np.bincount(hp, minlength=9).tolist(), cli=tag_cli)
+        print("somatic", name, index["somatic:" + name])
+        N.close(); T.close()
     for name, (src, tag_cli, over) in fixtures.HAPLOTAG_FIXTURES.items():
         kw, phase_cli, _ = fixtures.PHASE_FIXTURES[src]
         s = Synth(**kw)

@@ -1,0 +1,27 @@
+"""GPU parity tests of the somatic_haplotag tagging pass (row a22) through the C-ABI: integer counts == CPU oracle,
+HP:Z / PS / PQ == the tags the reference binary wrote to the tagged tumor BAM."""
+import numpy as np
+import pytest
+
+import fixtures
+import lps_oracle
+import util
+from lps import abi, hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", sorted(fixtures.SOMATIC_FIXTURES))
+def test_somatic_tag_matches_oracle_and_reference(name):
+    genome, nkw, tkw, cli, over = fixtures.SOMATIC_FIXTURES[name]
+    T, R = util.make_tumor_reads(name)
+    V, hp, ps, pq = util.load_golden_somatic(name)
+    P = abi.default_params(**over)
+    ref = lps_oracle.somatic_tag(P, V, R)
+    with hip.Context(0, P) as ctx:
+        out = ctx.somatic_tag(V, T.ref, R)
+    for k in ("status", "hp1", "hp2", "hp3", "derive_h1", "derive_h2", "ps_min", "hp", "pq", "ps"):
+        assert np.array_equal(getattr(out, k), getattr(ref, k)), k
+    assert np.array_equal(np.minimum(out.n_ps, 2), np.minimum(ref.n_ps, 2))
+    util.assert_somatic_tags_equal(out, hp, ps, pq, name + " vs reference BAM tags")
+    assert (out.hp >= 5).sum() > 0, "fixture should contain somatic (H1-1 / H2-1) reads"

@@ -109,3 +109,25 @@ def assert_tags_equal(out, hp, ps, pq, what=""):
     m = hp != 0
     assert np.array_equal(out.ps[m], ps[m]), f"{what}: PS mismatch"
     assert np.array_equal(out.pq[m], pq[m]), f"{what}: PQ mismatch"
+
+
+def load_golden_somatic(name):
+    z = np.load(os.path.join(GOLDEN, f"somatic_tag_{name}.npz"))
+    V = abi.Variants(z["pos"], [str(x) for x in z["ref"]], [str(x) for x in z["alt"]], hp1_is_alt=z["hp1_is_alt"],
+                     phase_set=z["phase_set"], somatic_role=z["somatic_role"], derive_hp=z["derive_hp"])
+    return V, z["hp"], z["ps"], z["pq"]
+
+
+def make_tumor_reads(name):
+    genome, nkw, tkw, cli, over = fixtures.SOMATIC_FIXTURES[name]
+    T = Synth(**dict(genome, **tkw))
+    return T, abi.Reads.from_synth(T)
+
+
+def assert_somatic_tags_equal(out, hp, ps, pq, what=""):
+    """HP:Z code, PS (absent = -1) and PQ as written to the tagged tumor BAM."""
+    bad = np.nonzero(out.hp != hp)[0]
+    assert bad.size == 0, f"{what}: {bad.size} HP mismatches, first reads {bad[:5]}: {out.hp[bad[:5]]} vs {hp[bad[:5]]}"
+    m = hp != 0
+    assert np.array_equal(out.ps[m], ps[m]), f"{what}: PS mismatch"
+    assert np.array_equal(out.pq[m], pq[m]), f"{what}: PQ mismatch"
