@@ -73,6 +73,10 @@ typedef struct lps_variant_table {
      *  derive_hp[i]   : MultiGenomeVar::somaticReadDeriveByHP of role-1 rows (0 none, 1 H1, 2 H2) */
     const uint8_t *somatic_role;
     const uint8_t *derive_hp;
+    /* somatic extraction (a20/a21): tumor_kind[i] = 0 no TUMOR row at this position, 1 SNP, 2 insertion, 3 deletion, 4 other.
+     * Rows with somatic_role 0 additionally carry a NORMAL phased-het row (main alleles); tumor-only rows use the tumor
+     * alleles as main alleles. */
+    const uint8_t *tumor_kind;
 } lps_variant_table;
 
 /* Decoded alignments of ONE chromosome in BAM (coordinate) order = what sam_itr_multi_next hands to
@@ -148,6 +152,21 @@ typedef struct lps_somatic_tag_result {
     int32_t *ps;
 } lps_somatic_tag_result;
 
+/* Per-site counters of the normal-BAM extraction pass (ExtractNorDataChrProcessor + ExtractNorDataCigarParser,
+ * src/somatic_haplotag/SomaticVarCaller.cpp:123-293; PosBase, src/haplotag/HaplotagType.h:165-224), one row of
+ * LPS_SITE_COUNTERS int32 per table row (zero where tumor_kind == 0).  The derived ratios of calculateBaseCommonInfo
+ * (:13-40) are plain host arithmetic on these integers. */
+#define LPS_SITE_COUNTERS 18
+enum { LPS_SC_ALT = 0, LPS_SC_A, LPS_SC_C, LPS_SC_G, LPS_SC_T, LPS_SC_UNKNOWN, LPS_SC_DEPTH, LPS_SC_DEL,
+       LPS_SC_MPQ_ALT, LPS_SC_MPQ_A, LPS_SC_MPQ_C, LPS_SC_MPQ_G, LPS_SC_MPQ_T, LPS_SC_MPQ_UNKNOWN, LPS_SC_MPQ_DEPTH,
+       LPS_SC_READHP_UNTAG, LPS_SC_READHP_H1, LPS_SC_READHP_H2 };
+typedef struct lps_site_counters {
+    int64_t n;          /* = variant table size */
+    int32_t *counters;  /* [n][LPS_SITE_COUNTERS] */
+    int64_t n_reads;    /* optional per-read germline haplotype of the pass (0 untag, 1, 2); read_hp may be NULL */
+    uint8_t *read_hp;
+} lps_site_counters;
+
 /* Stage timings of the last lps_phase_chromosome / lps_haplotag call, measured with hipEvents on the
  * library's stream.  ms_kernel[i] pairs with lps_stage_name(i). */
 #define LPS_MAX_STAGES 24
@@ -166,7 +185,7 @@ typedef struct lps_timings {
 
 int lps_abi_version(void);
 /* sizeof() of the ABI structs as compiled into the library: 0 lps_params, 1 lps_variant_table, 2 lps_read_batch,
- * 3 lps_phase_result, 4 lps_haplotag_result, 5 lps_timings, 6 lps_somatic_tag_result (binding self-check). */
+ * 3 lps_phase_result, 4 lps_haplotag_result, 5 lps_timings, 6 lps_somatic_tag_result, 7 lps_site_counters (binding self-check). */
 int lps_struct_size(int which);
 int lps_device_count(void);
 
@@ -191,6 +210,8 @@ int lps_phase_chromosome(lps_ctx *ctx, lps_phase_result *out);
 int lps_haplotag_chromosome(lps_ctx *ctx, lps_haplotag_result *out);
 /* somatic_haplotag tagging pass over the (tumor) reads pushed so far against the merged normal+tumor table. */
 int lps_somatic_tag_chromosome(lps_ctx *ctx, lps_somatic_tag_result *out);
+/* somatic_haplotag pass 1: the NORMAL sample's reads (pushed so far) counted at the tumor-VCF positions. */
+int lps_somatic_extract_normal(lps_ctx *ctx, lps_site_counters *out);
 
 int lps_get_timings(lps_ctx *ctx, lps_timings *t);
 const char *lps_stage_name(int stage);

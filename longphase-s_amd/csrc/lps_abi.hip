@@ -53,7 +53,7 @@ struct lps_ctx {
     DevBuf<unsigned long long> nkeys, nkeys_s; DevBuf<uint32_t> nvals, nvals_s;
     DevBuf<float> edge;
     DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
-    DevBuf<uint8_t> hap_status, hap_nps, v_role, v_derive; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1, hap_d2; bool has_somatic = false;
+    DevBuf<uint8_t> hap_status, hap_nps, v_role, v_derive, v_tkind, read_hp; DevBuf<int32_t> site; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1, hap_d2; bool has_somatic = false;
     DevBuf<char> temp; size_t temp_bytes = 0;
     LpsCounters *d_cnt = nullptr; LpsCounters h_cnt{}; unsigned h_stats[4]{};
     // timing
@@ -87,7 +87,7 @@ int lps_abi_version(void) { return LPS_ABI_VERSION; }
 int lps_struct_size(int which) {
     switch (which) {
         case 0: return (int)sizeof(lps_params); case 1: return (int)sizeof(lps_variant_table); case 2: return (int)sizeof(lps_read_batch);
-        case 3: return (int)sizeof(lps_phase_result); case 4: return (int)sizeof(lps_haplotag_result); case 5: return (int)sizeof(lps_timings); case 6: return (int)sizeof(lps_somatic_tag_result);
+        case 3: return (int)sizeof(lps_phase_result); case 4: return (int)sizeof(lps_haplotag_result); case 5: return (int)sizeof(lps_timings); case 6: return (int)sizeof(lps_somatic_tag_result); case 7: return (int)sizeof(lps_site_counters);
     }
     return -1;
 }
@@ -157,6 +157,8 @@ int lps_set_variants(lps_ctx *c, const lps_variant_table *t) {
         if (c->has_hap) { upload(c, c->v_hp1, t->hp1_is_alt, t->n); upload(c, c->v_ps, t->phase_set, t->n); }
         c->has_somatic = c->has_hap && t->somatic_role && t->derive_hp;
         if (c->has_somatic) { upload(c, c->v_role, t->somatic_role, t->n); upload(c, c->v_derive, t->derive_hp, t->n); }
+        c->has_tkind = c->has_hap && t->somatic_role && t->tumor_kind;
+        if (c->has_tkind) { upload(c, c->v_role, t->somatic_role, t->n); upload(c, c->v_tkind, t->tumor_kind, t->n); }
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->phase_valid = false;
     } catch (std::string &e) { return fail(c, e); }
@@ -216,7 +218,8 @@ static VarView var_view(lps_ctx *c) {
     VarView V{};
     V.n = c->nV; V.pos = c->v_pos.p; V.ref0 = c->v_ref0.p; V.alt0 = c->v_alt0.p; V.ref_len = c->v_rl.p; V.alt_len = c->v_al.p;
     V.danger = c->v_danger.p; V.hpoly = c->v_hpoly.p; V.erased = c->v_erased.p; V.hp1_is_alt = c->has_hap ? c->v_hp1.p : nullptr; V.phase_set = c->v_ps.p;
-    V.somatic_role = c->has_somatic ? c->v_role.p : nullptr; V.derive_hp = c->has_somatic ? c->v_derive.p : nullptr;
+    V.somatic_role = (c->has_somatic || c->has_tkind) ? c->v_role.p : nullptr; V.derive_hp = c->has_somatic ? c->v_derive.p : nullptr;
+    V.tumor_kind = c->has_tkind ? c->v_tkind.p : nullptr;
     V.ref = c->ref.p; V.ref_len_eff = c->ref_len_eff; V.last_pos = c->last_pos;
     V.n_bucket = (int)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 1; V.bucket = c->v_bucket.p; V.rec = c->v_rec.p;
     return V;
@@ -396,8 +399,8 @@ static int run_scorer(lps_ctx *c, bool somatic, uint8_t *status, int32_t *hp1, i
     mark(c, ST_PREP);
     launch_variant_prep(V, /*is_ont (filterSNP is a `phase` step)*/ 0, c->v_bucket.p, c->v_rec.p, s);
     mark(c, ST_EXTRACT);
-    HapOut H{c->hap_status.p, c->hap_h1.p, c->hap_h2.p, c->hap_nps.p, c->hap_psmin.p, c->hap_h3.p, c->hap_d1.p, c->hap_d2.p};
-    launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, somatic, c->d_cnt, s);
+    HapOut H{c->hap_status.p, c->hap_h1.p, c->hap_h2.p, c->hap_nps.p, c->hap_psmin.p, c->hap_h3.p, c->hap_d1.p, c->hap_d2.p, nullptr, nullptr, 0.0};
+    launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, somatic ? 1 : 0, c->d_cnt, s);
     mark(c, ST_D2H);
     HIP_TRY(hipMemcpyAsync(status, H.status, (size_t)nR, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(hp1, H.hp1, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
@@ -502,6 +505,47 @@ int lps_somatic_tag_chromosome(lps_ctx *c, lps_somatic_tag_result *out) {
             tagged += hp != 0;
         }
         c->tm.n_reads_used = tagged;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_somatic_extract_normal(lps_ctx *c, lps_site_counters *out) {
+    if (!c || !out) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        const int nR = c->nR, nV = c->nV;
+        if (out->n != nV) return fail(c, "lps_site_counters.n must equal the variant table size");
+        if (out->read_hp && out->n_reads != nR) return fail(c, "lps_site_counters.n_reads must equal the number of pushed alignments");
+        memset(out->counters, 0, (size_t)nV * LPS_SITE_COUNTERS * sizeof(int32_t));
+        if (nR == 0 || nV == 0) return 0;
+        if (!c->has_tkind) return fail(c, "somatic extraction needs hp1_is_alt, phase_set, somatic_role and tumor_kind in the variant table");
+        if (c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
+        hipStream_t s = c->stream;
+        c->site.reserve((size_t)nV * LPS_SITE_COUNTERS); c->read_hp.reserve(nR);
+        c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1);
+        HIP_TRY(hipEventRecord(c->ev_begin, s));
+        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
+        HIP_TRY(hipMemsetAsync(c->site.p, 0, (size_t)nV * LPS_SITE_COUNTERS * sizeof(int32_t), s));
+        VarView V = var_view(c); ReadView R = read_view(c);
+        for (auto &u : c->ev_used) u = false;
+        mark(c, ST_PREP);
+        launch_variant_prep(V, 0, c->v_bucket.p, c->v_rec.p, s);
+        mark(c, ST_EXTRACT);
+        HapOut H{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c->site.p, c->read_hp.p, c->P.percentage_threshold};
+        launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 2, c->d_cnt, s);   // votes + base counters + read haplotype
+        launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 3, c->d_cnt, s);   // ReadHpCount of the touched sites
+        mark(c, ST_D2H);
+        HIP_TRY(hipMemcpyAsync(out->counters, c->site.p, (size_t)nV * LPS_SITE_COUNTERS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (out->read_hp) HIP_TRY(hipMemcpyAsync(out->read_hp, c->read_hp.p, (size_t)nR, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(c->ev_end, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) return fail(c, "Alignment find unsupported CIGAR operation", -2);
+        if (out->read_hp) for (int r = 0; r < nR; ++r) if (out->read_hp[r] == 255) out->read_hp[r] = 0;
+        lps_timings &t = c->tm; memset(&t, 0, sizeof t);
+        t.n_stages = ST_COUNT;
+        HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_EXTRACT], c->ev[ST_EXTRACT], c->ev[ST_D2H]));
+        HIP_TRY(hipEventElapsedTime(&t.ms_total, c->ev_begin, c->ev_end));
     } catch (std::string &e) { return fail(c, e); }
     return 0;
 }

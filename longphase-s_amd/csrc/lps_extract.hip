@@ -68,7 +68,8 @@ __global__ void k_variant_pack(VarView V, uint2 *rec) {
     const unsigned attr = (unsigned)V.ref0[v] | ((unsigned)V.alt0[v] << 8) | (kind << 16) | (V.danger[v] ? VREC_DANGER : 0u) |
                           (V.erased[v] ? VREC_ERASED : 0u) | (V.hpoly[v] >= 3 ? VREC_HPOLY3 : 0u) |
                           ((V.hp1_is_alt && V.hp1_is_alt[v]) ? VREC_HP1ALT : 0u) |
-                          (V.somatic_role ? ((unsigned)(V.somatic_role[v] & 3) << 22) | ((unsigned)(V.derive_hp[v] & 3) << 24) : 0u);
+                          (V.somatic_role ? ((unsigned)(V.somatic_role[v] & 3) << 22) | ((unsigned)((V.derive_hp ? V.derive_hp[v] : 0) & 3) << 24) : 0u) |
+                          (V.tumor_kind ? ((unsigned)(V.tumor_kind[v] & 7) << 26) : 0u);
     rec[v] = make_uint2((unsigned)V.pos[v], attr);
 }
 

@@ -15,7 +15,10 @@
 // (SomaticHaplotagCigarParser, src/somatic_haplotag/SomaticHaplotagProcess.cpp:557-579; judgeSomaticSnpHap / judgeNormalSnpHap /
 // SomaticHaplotagStrategy::judgeTumorOnlySnpHap, src/haplotag/HaplotagStrategy.cpp:315-435,653-668): deletions cast no vote,
 // indel rows vote with the read's own allele, somatic calls count H3 bases and which germline haplotype they derive from.
-template <bool SOMATIC>
+// MODE 2/3: normal-BAM extraction pass of somatic_haplotag (ExtractNorDataCigarParser, src/somatic_haplotag/SomaticVarCaller.cpp:227-293):
+//   2 = germline votes gated by MAPQ (low-MAPQ reads are NOT skipped in this pass) + per-site base counters by atomics + the read's
+//       haplotype; 3 = re-walk that adds the read's haplotype to ReadHpCount of every tumor site it touched (:171-173).
+template <int MODE>
 __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary,
                                                         LpsCounters *cnt) {
     __shared__ int s_ref[4][LPS_SEG];
@@ -27,8 +30,11 @@ __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, H
     int *sref = s_ref[w], *sqry = s_qry[w]; uint32_t *scig = s_cig[w];
     const int start = R.ref_start[r];
     const int flag = R.flag[r];
+    constexpr bool SOMATIC = MODE == 1;
+    constexpr bool EXTRACT = MODE == 2 || MODE == 3;
+    const bool mq_ok = R.mapq[r] >= mapping_quality;
     int status = 0;                                                   // filter cascade (:453-486)
-    if (R.mapq[r] < mapping_quality) status = 1;
+    if (!EXTRACT && !mq_ok) status = 1;                               // extraction passes run with mappingQualityFilter == false
     else if (flag & 0x4) status = 2;
     else if (flag & 0x100) status = 3;
     else if ((flag & 0x800) && !tag_supplementary) status = 4;
@@ -43,6 +49,8 @@ __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, H
         const int lq = R.l_qseq[r];
         int vcur = var_lower_bound(V, start);
         int ref_pos = start, q_pos = 0;
+        int judged_op = -1;                                              // EXTRACT: last D op whose germline vote has been cast
+        const int my_hp = (MODE == 3) ? (int)H.read_hp[r] : 0;
         for (int seg0 = 0; seg0 < n_cig && vcur < V.n; seg0 += LPS_SEG) {
             const int nseg = min(LPS_SEG, n_cig - seg0);
             uint2 vr = make_uint2(0x7fffffffu, 0u);
@@ -75,6 +83,7 @@ __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, H
                 const int n_in = __popcll(__ballot(mine));
                 int pprev = __shfl_up(p, 1);
                 if (l == 0) pprev = (v > 0 && v < V.n) ? V.pos[v - 1] : -1;
+                int del_key = -1;                                        // EXTRACT: D op index of a NORMAL row waiting for its once-per-op vote
                 if (mine) {
                     const unsigned at = vr.y;
                     int lo = 0, hi = nseg;
@@ -90,6 +99,40 @@ __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, H
                             const bool hp1alt = (at & VREC_HP1ALT) != 0;
                             int vote = -1;                              // 0: haplotype carrying REF, 1: haplotype carrying ALT
                             bool count_ps = false;
+                            if (EXTRACT) {
+                                const unsigned tk = VREC_TKIND(at);
+                                int32_t *sc = H.site + (size_t)v * LPS_SITE_COUNTERS;
+                                if (op_is_match(op)) {
+                                    const int qi = qs + (p - rs);
+                                    const char base_c = qi < lq ? nt16_char(seq[qi >> 1] >> ((~qi & 1) << 2)) : 'N';
+                                    bool is_alt = false;
+                                    const bool has_next = seg0 + j + 1 < n_cig;
+                                    if (kind == 0) is_alt = base_c == alt_c;
+                                    else if ((kind == 1 || kind == 2) && has_next)
+                                        is_alt = (rs + len - 1 == p) && (int)(scig[j + 1] & 15) == ((kind == 1) ? 1 : 2);
+                                    if (tk >= 1 && tk <= 3) {                                 // countBaseNucleotide (HaplotagParsingBam.cpp:682-719)
+                                        if (MODE == 3) atomicAdd(&sc[LPS_SC_READHP_UNTAG + my_hp], 1);
+                                        else {
+                                            const int bi = base_c == 'A' ? LPS_SC_A : base_c == 'C' ? LPS_SC_C : base_c == 'G' ? LPS_SC_G : base_c == 'T' ? LPS_SC_T : LPS_SC_UNKNOWN;
+                                            if (mq_ok) { atomicAdd(&sc[bi + (LPS_SC_MPQ_A - LPS_SC_A)], 1); if (is_alt) atomicAdd(&sc[LPS_SC_MPQ_ALT], 1); atomicAdd(&sc[LPS_SC_MPQ_DEPTH], 1); }
+                                            atomicAdd(&sc[bi], 1);
+                                            if (is_alt) { if (tk == 3) atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_ALT], 1); }
+                                            atomicAdd(&sc[LPS_SC_DEPTH], 1);
+                                        }
+                                    }
+                                    if (MODE == 2 && mq_ok && VREC_ROLE(at) == 0) {           // germline judgeSnpHap on the NORMAL row
+                                        if (kind == 0) { if (base_c == ref_c) vote = 0; else if (base_c == alt_c) vote = 1; count_ps = vote >= 0; }
+                                        else if ((kind == 1 || kind == 2) && has_next) { vote = (kind == 1) ? (is_alt ? 1 : 0) : (is_alt ? 0 : 1); count_ps = true; }
+                                    }
+                                } else if (op == 2) {
+                                    if (tk != 0) {                                            // processDeletionOperation (:265-282)
+                                        if (MODE == 3) atomicAdd(&sc[LPS_SC_READHP_UNTAG + my_hp], 1);
+                                        else if (tk == 1) { atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_DEPTH], 1); }
+                                        else if (tk == 3) { atomicAdd(&sc[LPS_SC_ALT], 1); atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_DEPTH], 1); }
+                                    }
+                                    if (MODE == 2 && mq_ok && VREC_ROLE(at) == 0) del_key = seg0 + j;   // vote resolved below, once per D op
+                                }
+                            } else
                             if (SOMATIC) {
                                 if (op_is_match(op)) {
                                     const int qi = qs + (p - rs);
@@ -135,6 +178,33 @@ __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, H
                         }
                     }
                 }
+                if (MODE == 2) {
+                    // once per D op: the FIRST NORMAL row inside the deletion casts the judgeDeletionHap vote (:285-291)
+                    unsigned long long todo = __ballot(del_key >= 0);
+                    while (todo) {
+                        const int leader = __ffsll((long long)todo) - 1;
+                        const int k0 = __shfl(del_key, leader);
+                        const unsigned long long same = __ballot(del_key == k0);
+                        if (l == leader && k0 != judged_op) {
+                            const unsigned at = vr.y;
+                            if (at & VREC_HPOLY3) {
+                                const unsigned kind = VREC_KIND(at);
+                                const int qs = sqry[k0 - seg0];
+                                const bool hp1alt = (at & VREC_HP1ALT) != 0;
+                                int vote = -1; bool cps = false;
+                                if (kind == 0) {
+                                    const char base_c = qs < lq ? nt16_char(seq[qs >> 1] >> ((~qs & 1) << 2)) : 'N';
+                                    if (base_c == (char)(at & 0xff)) vote = 0; else if (base_c == (char)((at >> 8) & 0xff)) vote = 1;
+                                    cps = true;
+                                } else if (kind == 2) { vote = 0; cps = true; }
+                                if (vote >= 0) { if ((vote == 1) == hp1alt) ++h1; else ++h2; }
+                                if (cps) { const int ps = V.phase_set[v]; ps_lo = min(ps_lo, ps); ps_hi = max(ps_hi, ps); }
+                            }
+                        }
+                        judged_op = k0;
+                        todo &= ~same;
+                    }
+                }
                 vcur += n_in;
                 if (n_in < 64 || vcur >= V.n) break;
                 vr = make_uint2(0x7fffffffu, 0u);
@@ -144,6 +214,17 @@ __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, H
         }
         h1 = wave_sum(h1); h2 = wave_sum(h2); ps_lo = wave_min(ps_lo); ps_hi = wave_max(ps_hi);
         if (SOMATIC) { h3 = wave_sum(h3); d1 = wave_sum(d1); d2 = wave_sum(d2); }
+    }
+    if (MODE == 3) return;
+    if (MODE == 2) {
+        if (l == 0) {                                                 // judgeReadHap (HaplotagStrategy.cpp:243-300) without the PQ
+            double mn, mx; int hp = 0;
+            if (h1 > h2) { mn = h2; mx = h1; } else { mn = h1; mx = h2; }
+            if (!(mx / (mx + mn) < H.pct_thr)) { if (h1 > h2) hp = 1; if (h1 < h2) hp = 2; }
+            if (ps_lo <= ps_hi && ps_lo != ps_hi) hp = 0;
+            H.read_hp[r] = (uint8_t)(status == 0 ? hp : 255);        // 255: read not processed by the pass
+        }
+        return;
     }
     if (l == 0) {
         H.status[r] = (uint8_t)status; H.hp1[r] = h1; H.hp2[r] = h2;
@@ -155,8 +236,11 @@ __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, H
 }
 
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
-                     bool somatic, LpsCounters *cnt, hipStream_t s) {
+                     int mode, LpsCounters *cnt, hipStream_t s) {
     if (R.n == 0) return;
-    if (somatic) hipLaunchKernelGGL(k_haplotag_score<true>, dim3((R.n + 3) / 4), dim3(256), 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
-    else hipLaunchKernelGGL(k_haplotag_score<false>, dim3((R.n + 3) / 4), dim3(256), 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
+    const dim3 g((R.n + 3) / 4), b(256);
+    if (mode == 1) hipLaunchKernelGGL(k_haplotag_score<1>, g, b, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
+    else if (mode == 2) hipLaunchKernelGGL(k_haplotag_score<2>, g, b, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
+    else if (mode == 3) hipLaunchKernelGGL(k_haplotag_score<3>, g, b, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
+    else hipLaunchKernelGGL(k_haplotag_score<0>, g, b, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
 }

@@ -14,6 +14,7 @@ struct VarView {           // variant table, position-sorted (Appendix B of SURV
     const uint8_t *hp1_is_alt;   // haplotag
     const int32_t *phase_set;    // haplotag
     const uint8_t *somatic_role, *derive_hp;   // somatic tagging
+    const uint8_t *tumor_kind;                 // somatic extraction
     const uint2 *rec;      // packed per-variant record {pos, attr} used by the extraction kernels (see VREC_*)
     const int32_t *bucket; // coarse index: bucket[b] = first variant with pos >= (b << LPS_BUCKET_SHIFT); n_bucket+1 entries
     int n_bucket;
@@ -60,6 +61,7 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 #define VREC_HP1ALT (1u << 21)   /* haplotag: haplotype 1 carries ALT */
 #define VREC_ROLE(a) (((a) >> 22) & 3u)   /* somatic tagging: 0 normal phased-het row, 1 somatic call, 2 inert tumor row */
 #define VREC_DERIVE(a) (((a) >> 24) & 3u) /* somaticReadDeriveByHP of role-1 rows */
+#define VREC_TKIND(a) (((a) >> 26) & 7u)  /* somatic extraction: TUMOR row kind at this position (0 none, 1 SNP, 2 INS, 3 DEL, 4 other) */
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,
                           int mapping_quality, LpsCounters *cnt, hipStream_t s);
 
@@ -81,6 +83,7 @@ __device__ __forceinline__ int var_lower_bound(const VarView &V, int key) {
 
 #endif
 
-struct HapOut { uint8_t *status; int32_t *hp1, *hp2; uint8_t *n_ps; int32_t *ps_min; int32_t *hp3, *d1, *d2; };
+struct HapOut { uint8_t *status; int32_t *hp1, *hp2; uint8_t *n_ps; int32_t *ps_min; int32_t *hp3, *d1, *d2;
+                int32_t *site; uint8_t *read_hp; double pct_thr; };   // site counters [nV][LPS_SITE_COUNTERS], per-read hp of the pass
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
-                     bool somatic, LpsCounters *cnt, hipStream_t s);
+                     int mode, LpsCounters *cnt, hipStream_t s);   // mode 0 haplotag, 1 somatic tag, 2 normal extraction, 3 its read-HP pass

@@ -33,7 +33,7 @@ def default_params(**kw):
 class VariantTable(C.Structure):
     _fields_ = [("n", C.c_int64), ("pos", C.c_void_p), ("ref0", C.c_void_p), ("alt0", C.c_void_p),
                 ("ref_len", C.c_void_p), ("alt_len", C.c_void_p), ("hp1_is_alt", C.c_void_p),
-                ("phase_set", C.c_void_p), ("somatic_role", C.c_void_p), ("derive_hp", C.c_void_p)]
+                ("phase_set", C.c_void_p), ("somatic_role", C.c_void_p), ("derive_hp", C.c_void_p), ("tumor_kind", C.c_void_p)]
 
 
 class ReadBatch(C.Structure):
@@ -59,6 +59,15 @@ class SomaticTagResult(C.Structure):
                 ("hp", C.c_void_p), ("pq", C.c_void_p), ("ps", C.c_void_p)]
 
 
+LPS_SITE_COUNTERS = 18
+SC = dict(ALT=0, A=1, C=2, G=3, T=4, UNKNOWN=5, DEPTH=6, DEL=7, MPQ_ALT=8, MPQ_A=9, MPQ_C=10, MPQ_G=11, MPQ_T=12, MPQ_UNKNOWN=13,
+          MPQ_DEPTH=14, READHP_UNTAG=15, READHP_H1=16, READHP_H2=17)
+
+
+class SiteCounters(C.Structure):
+    _fields_ = [("n", C.c_int64), ("counters", C.c_void_p), ("n_reads", C.c_int64), ("read_hp", C.c_void_p)]
+
+
 READ_HP_STR = [".", "1", "2", "3", "4", "1-1", "1-2", "2-1", "2-2"]   # ReadHapUtil::readHapIntToString (HaplotagType.h:327-342)
 
 
@@ -75,7 +84,7 @@ def _ptr(a):
 class Variants:
     """Host-side variant table (keeps the numpy arrays alive next to the ctypes struct)."""
 
-    def __init__(self, pos, ref, alt, hp1_is_alt=None, phase_set=None, somatic_role=None, derive_hp=None):
+    def __init__(self, pos, ref, alt, hp1_is_alt=None, phase_set=None, somatic_role=None, derive_hp=None, tumor_kind=None):
         self.pos = np.ascontiguousarray(pos, dtype=np.int32)
         n = self.pos.size
         self.ref_str = [r if isinstance(r, bytes) else r.encode() for r in ref]
@@ -88,10 +97,11 @@ class Variants:
         self.phase_set = None if phase_set is None else np.ascontiguousarray(phase_set, dtype=np.int32)
         self.somatic_role = None if somatic_role is None else np.ascontiguousarray(somatic_role, dtype=np.uint8)
         self.derive_hp = None if derive_hp is None else np.ascontiguousarray(derive_hp, dtype=np.uint8)
+        self.tumor_kind = None if tumor_kind is None else np.ascontiguousarray(tumor_kind, dtype=np.uint8)
         self.n = n
         self.c = VariantTable(n, _ptr(self.pos), _ptr(self.ref0), _ptr(self.alt0), _ptr(self.ref_len),
                               _ptr(self.alt_len), _ptr(self.hp1_is_alt), _ptr(self.phase_set), _ptr(self.somatic_role),
-                              _ptr(self.derive_hp))
+                              _ptr(self.derive_hp), _ptr(self.tumor_kind))
 
 
 class Reads:
@@ -165,3 +175,10 @@ class SomaticTagOut:
             setattr(self, k, np.zeros(n, np.uint8))
         self.c = SomaticTagResult(n, *[_ptr(getattr(self, k)) for k in
                                        ("status", "hp1", "hp2", "hp3", "derive_h1", "derive_h2", "n_ps", "ps_min", "hp", "pq", "ps")])
+
+
+class SiteCountersOut:
+    def __init__(self, n_var, n_reads):
+        self.counters = np.zeros((n_var, LPS_SITE_COUNTERS), np.int32)
+        self.read_hp = np.zeros(n_reads, np.uint8)
+        self.c = SiteCounters(n_var, _ptr(self.counters), n_reads, _ptr(self.read_hp))

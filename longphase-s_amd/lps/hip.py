@@ -48,6 +48,7 @@ def load():
     L.lps_phase_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.PhaseResult)]
     L.lps_haplotag_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.HaplotagResult)]
     L.lps_somatic_tag_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.SomaticTagResult)]
+    L.lps_somatic_extract_normal.argtypes = [C.c_void_p, C.POINTER(abi.SiteCounters)]
     L.lps_get_timings.argtypes = [C.c_void_p, C.POINTER(abi.Timings)]
     L.lps_stage_name.restype = C.c_char_p
     L.lps_stage_name.argtypes = [C.c_int]
@@ -124,6 +125,12 @@ class Context:
     def somatic_tag(self, variants, ref, reads):
         self.load_chromosome(variants, ref, reads)
         return self.run_somatic_tag()
+
+    def somatic_extract_normal(self, variants, ref, reads):
+        self.load_chromosome(variants, ref, reads)
+        out = abi.SiteCountersOut(self.n_var, self.n_reads)
+        self._check(self.L.lps_somatic_extract_normal(self.h, C.byref(out.c)), "lps_somatic_extract_normal")
+        return out
 
     def timings(self):
         t = abi.Timings()

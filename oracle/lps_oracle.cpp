@@ -710,4 +710,101 @@ int oracle_somatic_tag(const lps_params *Pp, const lps_variant_table *tp, const 
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ somatic extraction, normal BAM (a20)
+// ExtractNorDataChrProcessor::processRead (src/somatic_haplotag/SomaticVarCaller.cpp:123-174), ExtractNorDataCigarParser
+// (:227-293), CigarParser::countBaseNucleotide / countDeletionBase (src/haplotag/HaplotagParsingBam.cpp:682-729), germline votes by
+// GermlineHaplotagStrategy (HaplotagStrategy.cpp:20-209) gated by MAPQ, judgeReadHap (:243-300).  The extraction passes run
+// with ParsingBamControl::mappingQualityFilter == false (HaplotagParsingBam.h:57): low-MAPQ reads are NOT skipped.
+int oracle_somatic_extract_normal(const lps_params *Pp, const lps_variant_table *tp, const char *ref, int64_t ref_len_in,
+                                  const lps_read_batch *bp, lps_site_counters *out) {
+    const lps_params &P = *Pp; const lps_variant_table &t = *tp; const lps_read_batch &b = *bp;
+    Table T; T.t = &t; T.ref = ref;
+    const int32_t last_pos = t.n ? t.pos[t.n - 1] : -1;
+    T.ref_len = std::min<int64_t>(ref_len_in, (int64_t)last_pos + 6);
+    std::memset(out->counters, 0, (size_t)t.n * LPS_SITE_COUNTERS * sizeof(int32_t));
+    auto C = [&](int64_t v, int k) -> int32_t & { return out->counters[v * LPS_SITE_COUNTERS + k]; };
+    for (int64_t r = 0; r < b.n_reads; ++r) {
+        if (out->read_hp) out->read_hp[r] = 0;
+        const int fl = b.flag[r];
+        if ((fl & 0x4) || (fl & 0x100) || ((fl & 0x800) && !P.tag_supplementary) || t.n == 0 || !(b.ref_start[r] <= last_pos)) continue;
+        const bool mq_ok = b.mapq[r] >= P.mapping_quality;
+        const uint32_t *cig = b.cigar + b.cigar_off[r];
+        const int n_cig = (int)(b.cigar_off[r + 1] - b.cigar_off[r]);
+        const uint8_t *seq = b.seq + b.seq_off[r];
+        const int64_t lq = b.l_qseq[r];
+        int64_t ref_pos = b.ref_start[r], query_pos = 0;
+        int64_t cur = std::lower_bound(t.pos, t.pos + t.n, (int32_t)ref_pos) - t.pos;
+        int h1 = 0, h2 = 0; std::map<int, int> countPS; std::vector<int64_t> touched;
+        auto vote_allele = [&](int64_t v, bool alt) { if ((t.hp1_is_alt[v] != 0) == alt) h1++; else h2++; };
+        if (cur < t.n) for (int i = 0; i < n_cig; ++i) {
+            const int op = cig[i] & 15; const int64_t len = cig[i] >> 4;
+            while (cur < t.n && t.pos[cur] < ref_pos) ++cur;
+            if (op == 0 || op == 7 || op == 8) {
+                while (cur < t.n && t.pos[cur] < ref_pos + len) {
+                    const int64_t qi = query_pos + (t.pos[cur] - ref_pos);
+                    const char base = qi < lq ? seq_base(seq, qi) : 'N';
+                    const int rl = t.ref_len[cur], al = t.alt_len[cur];
+                    const bool snp = rl == 1 && al == 1, ins = rl == 1 && al > 1, del = rl > 1 && al == 1;
+                    bool isAlt = false;
+                    if (snp) isAlt = base == (char)t.alt0[cur];
+                    else if (ins && i + 1 < n_cig) isAlt = (ref_pos + len - 1 == t.pos[cur]) && (cig[i + 1] & 15) == 1;
+                    else if (del && i + 1 < n_cig) isAlt = (ref_pos + len - 1 == t.pos[cur]) && (cig[i + 1] & 15) == 2;
+                    const int tk = t.tumor_kind[cur];
+                    if (tk >= 1 && tk <= 3) {                                          // processMatchOperation :232-243 + countBaseNucleotide
+                        touched.push_back(cur);
+                        const int bi = base == 'A' ? LPS_SC_A : base == 'C' ? LPS_SC_C : base == 'G' ? LPS_SC_G : base == 'T' ? LPS_SC_T : LPS_SC_UNKNOWN;
+                        if (mq_ok) { C(cur, bi + (LPS_SC_MPQ_A - LPS_SC_A))++; if (isAlt) C(cur, LPS_SC_MPQ_ALT)++; C(cur, LPS_SC_MPQ_DEPTH)++; }
+                        C(cur, bi)++;
+                        if (isAlt) { if (tk == 3) C(cur, LPS_SC_DEL)++; C(cur, LPS_SC_ALT)++; }
+                        C(cur, LPS_SC_DEPTH)++;
+                    }
+                    if (mq_ok && t.somatic_role[cur] == 0) {                           // germline judgeSnpHap on the NORMAL row (:255-261)
+                        if (snp) { if (base == (char)t.ref0[cur] || base == (char)t.alt0[cur]) { vote_allele(cur, base == (char)t.alt0[cur]); countPS[t.phase_set[cur]]++; } }
+                        else if (ins && i + 1 < n_cig) { vote_allele(cur, isAlt); countPS[t.phase_set[cur]]++; }
+                        else if (del && i + 1 < n_cig) { vote_allele(cur, !isAlt); countPS[t.phase_set[cur]]++; }
+                    }
+                    ++cur;
+                }
+                query_pos += len; ref_pos += len;
+            } else if (op == 1) query_pos += len;
+            else if (op == 2) {
+                bool judged = false;
+                while (cur < t.n && t.pos[cur] < ref_pos + len) {
+                    const int tk = t.tumor_kind[cur];
+                    if (tk != 0) {                                                     // processDeletionOperation :265-282
+                        touched.push_back(cur);
+                        if (tk == 1) { C(cur, LPS_SC_DEL)++; C(cur, LPS_SC_DEPTH)++; }
+                        else if (tk == 3) { C(cur, LPS_SC_ALT)++; C(cur, LPS_SC_DEL)++; C(cur, LPS_SC_DEPTH)++; }
+                    }
+                    if (mq_ok && t.somatic_role[cur] == 0 && !judged) {                // :285-291, then judgeDeletionHap
+                        judged = true;
+                        const int64_t p = t.pos[cur];
+                        if (homopolymer_length(p, T.ref, T.ref_len) >= 3) {
+                            const int rl = t.ref_len[cur], al = t.alt_len[cur];
+                            if (rl == 1 && al == 1) {
+                                const char base = query_pos < lq ? seq_base(seq, query_pos) : 'N';
+                                if (base == (char)t.ref0[cur] || base == (char)t.alt0[cur]) vote_allele(cur, base == (char)t.alt0[cur]);
+                                countPS[t.phase_set[cur]]++;
+                            } else if (rl > 1 && al == 1) { vote_allele(cur, false); countPS[t.phase_set[cur]]++; }
+                        }
+                    }
+                    ++cur;
+                }
+                ref_pos += len;
+            } else if (op == 3) ref_pos += len;
+            else if (op == 4) query_pos += len;
+            else if (op == 5 || op == 6) {}
+            else return -2;
+        }
+        double mn, mx; int hp = 0;
+        if (h1 > h2) { mn = h2; mx = h1; } else { mn = h1; mx = h2; }
+        if (!(mx / (mx + mn) < P.percentage_threshold)) { if (h1 > h2) hp = 1; if (h1 < h2) hp = 2; }
+        if (countPS.size() > 1) hp = 0;
+        if (out->read_hp) out->read_hp[r] = (uint8_t)hp;
+        for (int64_t v : touched) C(v, LPS_SC_READHP_UNTAG + hp)++;
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -42,6 +42,8 @@ def lib():
                                          C.POINTER(abi.ReadBatch), C.POINTER(abi.HaplotagResult)]
         _lib.oracle_somatic_tag.restype = C.c_int
         _lib.oracle_somatic_tag.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.POINTER(abi.ReadBatch), C.POINTER(abi.SomaticTagResult)]
+        _lib.oracle_somatic_extract_normal.restype = C.c_int
+        _lib.oracle_somatic_extract_normal.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.c_void_p, C.c_int64, C.POINTER(abi.ReadBatch), C.POINTER(abi.SiteCounters)]
     return _lib
 
 
@@ -100,4 +102,14 @@ def somatic_tag(params, variants, reads):
     rc = lib().oracle_somatic_tag(C.byref(params), C.byref(variants.c), C.byref(reads.c), C.byref(out.c))
     if rc != 0:
         raise RuntimeError(f"oracle_somatic_tag rc={rc}")
+    return out
+
+
+def somatic_extract_normal(params, variants, ref, reads):
+    """CPU restatement of the normal-BAM extraction pass of somatic_haplotag.  Returns abi.SiteCountersOut."""
+    out = abi.SiteCountersOut(variants.n, reads.n_reads)
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    rc = lib().oracle_somatic_extract_normal(C.byref(params), C.byref(variants.c), ref.ctypes.data, ref.size, C.byref(reads.c), C.byref(out.c))
+    if rc != 0:
+        raise RuntimeError(f"oracle_somatic_extract_normal rc={rc}")
     return out

@@ -147,14 +147,35 @@ def run_reference_somatic(N, T, tag_cli, workdir, chrom="chrS"):
         derive[int(f[1]) - 1] = {"H1": 1, "H2": 2}.get(f[2], 0)
     assert set(derive) == somatic, (len(derive), len(somatic))
     normal = {int(p): i for i, p in enumerate(npos)}
-    pos, ref, alt, hp1, ps, role, dhp = [], [], [], [], [], [], []
+    pos, ref, alt, hp1, ps, role, dhp, tkind = [], [], [], [], [], [], [], []
+
+    def kind_of(r, a):
+        return 1 if len(r) == 1 and len(a) == 1 else (2 if len(r) == 1 else (3 if len(a) == 1 else 4))
     for p in sorted(set(normal) | set(tum)):
+        tkind.append(kind_of(*tum[p]) if p in tum else 0)
         if p in normal:
             i = normal[p]
+            if p in tum:
+                assert (nref[i], nalt[i]) == tum[p], "normal and tumor VCF disagree on alleles at an overlapping position"
             pos.append(p); ref.append(nref[i]); alt.append(nalt[i]); hp1.append(int(nhp1[i])); ps.append(int(nps[i])); role.append(0); dhp.append(0)
         else:
             pos.append(p); ref.append(tum[p][0]); alt.append(tum[p][1]); hp1.append(0); ps.append(0)
             role.append(1 if p in somatic else 2); dhp.append(derive.get(p, 0))
+    # per-site intermediates the reference logs for its somatic calls (65 numbered fields, SomaticVarCaller.cpp:1852-1917)
+    log_pos, log_val = [], []
+    for line in open(os.path.join(workdir, "som_somatic_var.out")):
+        if line.startswith("#") or not line.strip():
+            continue
+        f = [x for x in line.rstrip("\n").split("\t") if x != ""]
+        assert len(f) == 65, len(f)
+        log_pos.append(int(f[1]) - 1)
+        row = []
+        for x in f:
+            try:
+                row.append(float(x))
+            except ValueError:
+                row.append(np.nan)
+        log_val.append(row)
     sam = subprocess.run([TEST_VIEW, "som.bam"], cwd=workdir, capture_output=True, text=True).stdout
     codes = {".": 0, "1": 1, "2": 2, "3": 3, "4": 4, "1-1": 5, "1-2": 6, "2-1": 7, "2-2": 8}
     hp, rps, pq = [], [], []
@@ -165,7 +186,8 @@ def run_reference_somatic(N, T, tag_cli, workdir, chrom="chrS"):
         hp.append(codes[tags.get("HP", ".")]); rps.append(int(tags.get("PS", -1))); pq.append(int(tags.get("PQ", -1)))
     assert len(hp) == T.n_reads
     table = dict(pos=np.array(pos, np.int32), ref=np.array(ref), alt=np.array(alt), hp1_is_alt=np.array(hp1, np.uint8),
-                 phase_set=np.array(ps, np.int32), somatic_role=np.array(role, np.uint8), derive_hp=np.array(dhp, np.uint8))
+                 phase_set=np.array(ps, np.int32), somatic_role=np.array(role, np.uint8), derive_hp=np.array(dhp, np.uint8),
+                 tumor_kind=np.array(tkind, np.uint8), log_pos=np.array(log_pos, np.int32), log_val=np.array(log_val, np.float64))
     return table, np.array(hp, np.uint8), np.array(rps, np.int32), np.array(pq, np.int32)
 
 
@@ -177,7 +199,7 @@ def main():
         with tempfile.TemporaryDirectory() as d:
             table, hp, ps, pq = run_reference_somatic(N, T, tag_cli, d)
         np.savez_compressed(os.path.join(HERE, f"somatic_tag_{name}.npz"), hp=hp, ps=ps, pq=pq, **table)
-        index["somatic:" + name] = dict(digest=fixtures.input_digest(T), n_reads=int(T.n_reads), n_table=int(table["pos"].size),
+        index["somatic:" + name] = dict(digest=fixtures.input_digest(T), normal_digest=fixtures.input_digest(N), n_reads=int(T.n_reads), n_table=int(table["pos"].size),
                                         n_somatic=int((table["somatic_role"] == 1).sum()), n_tagged=int((hp != 0).sum()),
                                         hp_hist=np.bincount(hp, minlength=9).tolist(), cli=tag_cli)
         print("somatic", name, index["somatic:" + name])

@@ -25,3 +25,20 @@ def test_somatic_tag_matches_oracle_and_reference(name):
     assert np.array_equal(np.minimum(out.n_ps, 2), np.minimum(ref.n_ps, 2))
     util.assert_somatic_tags_equal(out, hp, ps, pq, name + " vs reference BAM tags")
     assert (out.hp >= 5).sum() > 0, "fixture should contain somatic (H1-1 / H2-1) reads"
+
+
+@pytest.mark.parametrize("name", sorted(fixtures.SOMATIC_FIXTURES))
+def test_normal_extraction_matches_oracle_and_reference_log(name):
+    """Row a20: per-site counters of the normal-BAM pass == oracle for EVERY table row, and == the reference's log at its calls."""
+    from test_oracle_somatic_extract_golden import check_normal_sites
+    genome, nkw, tkw, cli, over = fixtures.SOMATIC_FIXTURES[name]
+    N, R = util.make_normal_reads(name)
+    V, _, _, _ = util.load_golden_somatic(name)
+    P = abi.default_params(**over)
+    ref = lps_oracle.somatic_extract_normal(P, V, N.ref, R)
+    with hip.Context(0, P) as ctx:
+        out = ctx.somatic_extract_normal(V, N.ref, R)
+    assert np.array_equal(out.read_hp, ref.read_hp), "per-read germline haplotype of the pass differs"
+    bad = np.nonzero((out.counters != ref.counters).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} sites differ, first {bad[:5]}: {out.counters[bad[:3]]} vs {ref.counters[bad[:3]]}"
+    check_normal_sites(V, out.counters, name + " vs reference log")

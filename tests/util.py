@@ -114,8 +114,20 @@ def assert_tags_equal(out, hp, ps, pq, what=""):
 def load_golden_somatic(name):
     z = np.load(os.path.join(GOLDEN, f"somatic_tag_{name}.npz"))
     V = abi.Variants(z["pos"], [str(x) for x in z["ref"]], [str(x) for x in z["alt"]], hp1_is_alt=z["hp1_is_alt"],
-                     phase_set=z["phase_set"], somatic_role=z["somatic_role"], derive_hp=z["derive_hp"])
+                     phase_set=z["phase_set"], somatic_role=z["somatic_role"], derive_hp=z["derive_hp"], tumor_kind=z["tumor_kind"])
+    V.log_pos, V.log_val = z["log_pos"], z["log_val"]
     return V, z["hp"], z["ps"], z["pq"]
+
+
+def make_normal_reads(name):
+    genome, nkw, tkw, cli, over = fixtures.SOMATIC_FIXTURES[name]
+    N = Synth(**dict(genome, **nkw))
+    return N, abi.Reads.from_synth(N)
+
+
+# 1-based field numbers of the reference's _somatic_var.out rows (SomaticVarCaller.cpp:1852-1917)
+LOG = dict(tumAltCount=6, readCount=7, norAltCount=8, norVAF=18, tumVAF=19, norMpqVAF=20, norDepth=24, tumDepth=25, norDel=27, tumDel=28,
+           norMpqReadRatio=31, H1=35, H2=36, H1_1=37, H2_1=38, H3=39, norH1=45, norH2=46, norNonDelAF=63)
 
 
 def make_tumor_reads(name):
