@@ -167,6 +167,30 @@ typedef struct lps_site_counters {
     uint8_t *read_hp;
 } lps_site_counters;
 
+/* Tumor-BAM extraction pass (ExtractTumDataChrProcessor + ExtractTumDataCigarParser, src/somatic_haplotag/SomaticVarCaller.cpp:334-518,
+ * 627-759; SomaticData, src/haplotag/HaplotagType.h:226-294).  Per table row LPS_TSITE_COUNTERS int32:
+ *   [0..14]  PosBase integers in LPS_SC_* order          [15..23] base.ReadHpCount[ReadHP 0..8]
+ *   [24] unTag [25] totalCleanHP3Read [26] pure_H1_1_read [27] pure_H2_1_read [28] pure_H3_read [29] Mixed_HP_read   (classifyReadsByCase)
+ *   [30..38] somaticReadHpCount[ReadHP 0..8]              [39] alleleCount[REF] [40] alleleCount[ALT]
+ * Per read (n_reads entries each): status (as lps_haplotag_result, never 1: low-MAPQ reads are not skipped by this pass), hp1..hp3 =
+ * hpCount[1..3], hp = judgeSomaticReadHap code, n_ps/ps_min of the NORMAL phase sets, end_pos = reference position after the last
+ * CIGAR op, read_len = query bases walked, has_site = the read is in readHpResultSet (covers >=1 TUMOR row with MAPQ >= q).
+ * Variable-length lists (caller-allocated capacities; the call fails with -9 and sets n_* to the needed size when they do not fit):
+ *   pairs   (site row, read index, base HP) = tumorPosReadCorrBaseHP (:448-456)
+ *   windows (site row, allele 0/1, offset -100..100, read base char) = PosSomaticOffsetBase (:654-710, 729-737) */
+#define LPS_TSITE_COUNTERS 41
+typedef struct lps_tumor_extract_result {
+    int64_t n;               /* variant table size */
+    int32_t *site;           /* [n][LPS_TSITE_COUNTERS] */
+    int64_t n_reads;
+    uint8_t *status; int32_t *hp1; int32_t *hp2; int32_t *hp3; uint8_t *hp; uint8_t *n_ps; int32_t *ps_min;
+    int32_t *end_pos; int32_t *read_len; uint8_t *has_site;
+    int64_t pair_capacity, n_pairs;
+    int32_t *pair_site; int32_t *pair_read; uint8_t *pair_base_hp;
+    int64_t win_capacity, n_windows;
+    int32_t *win_site; uint8_t *win_allele; int16_t *win_offset; uint8_t *win_base;
+} lps_tumor_extract_result;
+
 /* Stage timings of the last lps_phase_chromosome / lps_haplotag call, measured with hipEvents on the
  * library's stream.  ms_kernel[i] pairs with lps_stage_name(i). */
 #define LPS_MAX_STAGES 24
@@ -185,7 +209,7 @@ typedef struct lps_timings {
 
 int lps_abi_version(void);
 /* sizeof() of the ABI structs as compiled into the library: 0 lps_params, 1 lps_variant_table, 2 lps_read_batch,
- * 3 lps_phase_result, 4 lps_haplotag_result, 5 lps_timings, 6 lps_somatic_tag_result, 7 lps_site_counters (binding self-check). */
+ * 3 lps_phase_result, 4 lps_haplotag_result, 5 lps_timings, 6 lps_somatic_tag_result, 7 lps_site_counters, 8 lps_tumor_extract_result (binding self-check). */
 int lps_struct_size(int which);
 int lps_device_count(void);
 
@@ -212,6 +236,8 @@ int lps_haplotag_chromosome(lps_ctx *ctx, lps_haplotag_result *out);
 int lps_somatic_tag_chromosome(lps_ctx *ctx, lps_somatic_tag_result *out);
 /* somatic_haplotag pass 1: the NORMAL sample's reads (pushed so far) counted at the tumor-VCF positions. */
 int lps_somatic_extract_normal(lps_ctx *ctx, lps_site_counters *out);
+/* somatic_haplotag pass 2: the TUMOR sample's reads (pushed so far) at the merged table. */
+int lps_somatic_extract_tumor(lps_ctx *ctx, lps_tumor_extract_result *out);
 
 int lps_get_timings(lps_ctx *ctx, lps_timings *t);
 const char *lps_stage_name(int stage);

@@ -68,6 +68,18 @@ class SiteCounters(C.Structure):
     _fields_ = [("n", C.c_int64), ("counters", C.c_void_p), ("n_reads", C.c_int64), ("read_hp", C.c_void_p)]
 
 
+LPS_TSITE_COUNTERS = 41
+
+
+class TumorExtractResult(C.Structure):
+    _fields_ = [("n", C.c_int64), ("site", C.c_void_p), ("n_reads", C.c_int64), ("status", C.c_void_p), ("hp1", C.c_void_p),
+                ("hp2", C.c_void_p), ("hp3", C.c_void_p), ("hp", C.c_void_p), ("n_ps", C.c_void_p), ("ps_min", C.c_void_p),
+                ("end_pos", C.c_void_p), ("read_len", C.c_void_p), ("has_site", C.c_void_p),
+                ("pair_capacity", C.c_int64), ("n_pairs", C.c_int64), ("pair_site", C.c_void_p), ("pair_read", C.c_void_p),
+                ("pair_base_hp", C.c_void_p), ("win_capacity", C.c_int64), ("n_windows", C.c_int64), ("win_site", C.c_void_p),
+                ("win_allele", C.c_void_p), ("win_offset", C.c_void_p), ("win_base", C.c_void_p)]
+
+
 READ_HP_STR = [".", "1", "2", "3", "4", "1-1", "1-2", "2-1", "2-2"]   # ReadHapUtil::readHapIntToString (HaplotagType.h:327-342)
 
 
@@ -182,3 +194,29 @@ class SiteCountersOut:
         self.counters = np.zeros((n_var, LPS_SITE_COUNTERS), np.int32)
         self.read_hp = np.zeros(n_reads, np.uint8)
         self.c = SiteCounters(n_var, _ptr(self.counters), n_reads, _ptr(self.read_hp))
+
+
+class TumorExtractOut:
+    def __init__(self, n_var, n_reads, pair_cap, win_cap):
+        self.site = np.zeros((n_var, LPS_TSITE_COUNTERS), np.int32)
+        for k in ("hp1", "hp2", "hp3", "ps_min", "end_pos", "read_len"):
+            setattr(self, k, np.zeros(n_reads, np.int32))
+        for k in ("status", "hp", "n_ps", "has_site"):
+            setattr(self, k, np.zeros(n_reads, np.uint8))
+        self.pair_site = np.zeros(pair_cap, np.int32); self.pair_read = np.zeros(pair_cap, np.int32); self.pair_base_hp = np.zeros(pair_cap, np.uint8)
+        self.win_site = np.zeros(win_cap, np.int32); self.win_allele = np.zeros(win_cap, np.uint8)
+        self.win_offset = np.zeros(win_cap, np.int16); self.win_base = np.zeros(win_cap, np.uint8)
+        self.c = TumorExtractResult(n_var, _ptr(self.site), n_reads, _ptr(self.status), _ptr(self.hp1), _ptr(self.hp2), _ptr(self.hp3),
+                                    _ptr(self.hp), _ptr(self.n_ps), _ptr(self.ps_min), _ptr(self.end_pos), _ptr(self.read_len), _ptr(self.has_site),
+                                    pair_cap, 0, _ptr(self.pair_site), _ptr(self.pair_read), _ptr(self.pair_base_hp),
+                                    win_cap, 0, _ptr(self.win_site), _ptr(self.win_allele), _ptr(self.win_offset), _ptr(self.win_base))
+
+    def pairs(self):
+        n = self.c.n_pairs
+        o = np.lexsort((self.pair_read[:n], self.pair_site[:n]))
+        return self.pair_site[:n][o], self.pair_read[:n][o], self.pair_base_hp[:n][o]
+
+    def windows(self):
+        n = self.c.n_windows
+        o = np.lexsort((self.win_base[:n], self.win_offset[:n], self.win_allele[:n], self.win_site[:n]))
+        return self.win_site[:n][o], self.win_allele[:n][o], self.win_offset[:n][o], self.win_base[:n][o]

@@ -807,4 +807,167 @@ int oracle_somatic_extract_normal(const lps_params *Pp, const lps_variant_table 
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ somatic extraction, tumor BAM (a21)
+namespace {
+// processCigarOperation (src/somatic_haplotag/SomaticVarCaller.cpp:627-652).  NB the reference's enum has CIGAR_N == 6 (HaplotagType.h:29).
+bool win_next_op(const uint32_t *cig, int &idx, int end, int dir, int &remaining, int &readPos, int &refPos, int &op) {
+    idx += dir;
+    while (idx < end && idx >= 0) {
+        op = cig[idx] & 15; const int len = cig[idx] >> 4;
+        if (op == 0 || op == 3 || op == 6 || op == 7 || op == 8) { remaining += len; return true; }
+        else if (op == 1) readPos += len * dir;
+        else if (op == 2) refPos += len * dir;
+        else return false;
+        idx += dir;
+    }
+    return false;
+}
+// getOrderWindowsDiffRef (:654-685)
+void win_dir(const uint32_t *cig, int idx, int n_cig, const uint8_t *seq, int readLen, const char *ref, int refLen, int readPos, int remaining,
+             int refPos, int dir, std::vector<std::pair<int, char>> &out) {
+    int op = cig[idx] & 15;
+    for (int i = 1; i <= 100; ++i) {
+        remaining--;
+        if (remaining == 0 || remaining == -1) { if (!win_next_op(cig, idx, n_cig, dir, remaining, readPos, refPos, op)) return; }
+        if (op == 2 || op == 1 || op == 3 || op == 6 || op == 8) continue;
+        readPos += dir; refPos += dir;
+        if (readPos > readLen || refPos > refLen || readPos < 0 || refPos < 0) return;
+        const char rb = readPos < readLen ? seq_base(seq, readPos) : '\0';     // reference reads one past the end here
+        const char fb = refPos < refLen ? ref[refPos] : '\0';
+        if (rb != fb) out.emplace_back(i * dir, rb);
+    }
+}
+}  // namespace
+
+int oracle_somatic_extract_tumor(const lps_params *Pp, const lps_variant_table *tp, const char *ref, int64_t ref_len_in,
+                                 const lps_read_batch *bp, lps_tumor_extract_result *out) {
+    const lps_params &P = *Pp; const lps_variant_table &t = *tp; const lps_read_batch &b = *bp;
+    const int32_t last_pos = t.n ? t.pos[t.n - 1] : -1;
+    const int refLen = (int)std::min<int64_t>(ref_len_in, (int64_t)last_pos + 6);
+    std::memset(out->site, 0, (size_t)t.n * LPS_TSITE_COUNTERS * sizeof(int32_t));
+    auto C = [&](int64_t v, int k) -> int32_t & { return out->site[v * LPS_TSITE_COUNTERS + k]; };
+    int64_t n_pairs = 0, n_win = 0;
+    for (int64_t r = 0; r < b.n_reads; ++r) {
+        out->status[r] = 0; out->hp1[r] = out->hp2[r] = out->hp3[r] = 0; out->hp[r] = 0; out->n_ps[r] = 0; out->ps_min[r] = 0;
+        out->end_pos[r] = 0; out->read_len[r] = 0; out->has_site[r] = 0;
+        const int fl = b.flag[r];
+        if (fl & 0x4) { out->status[r] = 2; continue; }
+        if (fl & 0x100) { out->status[r] = 3; continue; }
+        if ((fl & 0x800) && !P.tag_supplementary) { out->status[r] = 4; continue; }
+        if (t.n == 0) { out->status[r] = 5; continue; }
+        if (!(b.ref_start[r] <= last_pos)) { out->status[r] = 6; continue; }
+        const bool mq_ok = b.mapq[r] >= P.mapping_quality;
+        const uint32_t *cig = b.cigar + b.cigar_off[r];
+        const int n_cig = (int)(b.cigar_off[r + 1] - b.cigar_off[r]);
+        const uint8_t *seq = b.seq + b.seq_off[r];
+        const int lq = b.l_qseq[r];
+        int ref_pos = b.ref_start[r], query_pos = 0;
+        int64_t cur = std::lower_bound(t.pos, t.pos + t.n, (int32_t)ref_pos) - t.pos;
+        int h1 = 0, h2 = 0, h3 = 0; std::map<int, int> norPS;
+        std::vector<int64_t> h3_sites; std::vector<std::pair<int64_t, int>> tum_sites;   // (row, baseHP)
+        std::vector<std::pair<int, char>> win;
+        bool walked = cur < t.n;
+        if (walked) for (int i = 0; i < n_cig; ++i) {
+            const int op = cig[i] & 15; const int len = cig[i] >> 4;
+            while (cur < t.n && t.pos[cur] < ref_pos) ++cur;
+            if (op == 0 || op == 7 || op == 8) {
+                while (cur < t.n && t.pos[cur] < ref_pos + len) {
+                    const int off = t.pos[cur] - ref_pos, qi = query_pos + off;
+                    const char base = qi < lq ? seq_base(seq, qi) : 'N';
+                    const int rl = t.ref_len[cur], al = t.alt_len[cur];
+                    const bool snp = rl == 1 && al == 1, ins = rl == 1 && al > 1, del = rl > 1 && al == 1;
+                    bool isAlt = false;
+                    if (snp) isAlt = base == (char)t.alt0[cur];
+                    else if (ins && i + 1 < n_cig) isAlt = (ref_pos + len - 1 == t.pos[cur]) && (cig[i + 1] & 15) == 1;
+                    else if (del && i + 1 < n_cig) isAlt = (ref_pos + len - 1 == t.pos[cur]) && (cig[i + 1] & 15) == 2;
+                    const int tk = t.tumor_kind[cur]; const int role = t.somatic_role[cur];
+                    // getWindowsDiffRef (:687-710) - computed for every variant, used only below
+                    win.clear();
+                    {
+                        const int fwd = (len - off > 0) ? len - off : 0, rev = off > 0 ? off : 0;
+                        win_dir(cig, i, n_cig, seq, lq, ref, refLen, query_pos + off, rev, t.pos[cur], -1, win);
+                        win_dir(cig, i, n_cig, seq, lq, ref, refLen, query_pos + off, fwd, t.pos[cur], +1, win);
+                    }
+                    int baseHP = 0;
+                    if (mq_ok) {                                                        // judgeSomaticSnpHap (HaplotagStrategy.cpp:315-389)
+                        if (role == 0) {
+                            bool counted = false, alt = false;
+                            if (snp) { if (base == (char)t.ref0[cur] || base == (char)t.alt0[cur]) { counted = true; alt = base == (char)t.alt0[cur]; } }
+                            else if (ins || del) { counted = true; alt = isAlt; }
+                            if (counted) { if ((t.hp1_is_alt[cur] != 0) == alt) { h1++; baseHP = 1; } else { h2++; baseHP = 2; } norPS[t.phase_set[cur]]++; }
+                        } else if (tk != 0) {                                           // tumor-only row: H3 when the read shows the tumor ALT (:617-638)
+                            bool h3v = false;
+                            if (snp) h3v = base == (char)t.alt0[cur]; else if (ins || del) h3v = isAlt;
+                            if (h3v) { h3++; baseHP = 3; h3_sites.push_back(cur); }
+                        }
+                        if (tk != 0) tum_sites.emplace_back(cur, baseHP);               // tumorSnpPosVec (:722-724)
+                    }
+                    if (tk >= 1 && tk <= 3) {                                           // :728-741
+                        if (tk != 1 || base == (char)t.ref0[cur] || base == (char)t.alt0[cur]) {
+                            C(cur, 39 + (isAlt ? 1 : 0))++;
+                            for (auto &w : win) {
+                                if (n_win < out->win_capacity) { out->win_site[n_win] = (int32_t)cur; out->win_allele[n_win] = isAlt; out->win_offset[n_win] = (int16_t)w.first; out->win_base[n_win] = (uint8_t)w.second; }
+                                ++n_win;
+                            }
+                        }
+                        const int bi = base == 'A' ? LPS_SC_A : base == 'C' ? LPS_SC_C : base == 'G' ? LPS_SC_G : base == 'T' ? LPS_SC_T : LPS_SC_UNKNOWN;
+                        if (mq_ok) { C(cur, bi + (LPS_SC_MPQ_A - LPS_SC_A))++; if (isAlt) C(cur, LPS_SC_MPQ_ALT)++; C(cur, LPS_SC_MPQ_DEPTH)++; }
+                        C(cur, bi)++;
+                        if (isAlt) { if (tk == 3) C(cur, LPS_SC_DEL)++; C(cur, LPS_SC_ALT)++; }
+                        C(cur, LPS_SC_DEPTH)++;
+                    }
+                    ++cur;
+                }
+                query_pos += len; ref_pos += len;
+            } else if (op == 1) query_pos += len;
+            else if (op == 2) {
+                while (cur < t.n && t.pos[cur] < ref_pos + len) {                       // processDeletionOperation :743-759
+                    const int tk = t.tumor_kind[cur];
+                    if (tk == 1) { C(cur, LPS_SC_DEL)++; C(cur, LPS_SC_DEPTH)++; }
+                    else if (tk == 3) { C(cur, LPS_SC_ALT)++; C(cur, LPS_SC_DEL)++; C(cur, LPS_SC_DEPTH)++; }
+                    ++cur;
+                }
+                ref_pos += len;
+            } else if (op == 3) ref_pos += len;
+            else if (op == 4) query_pos += len;
+            else if (op == 5 || op == 6) {}
+            else return -2;
+        }
+        // judgeSomaticReadHap without PQ (the extraction pass does not use it)
+        double tMin, tMax, nMin, nMax; int maxT, maxN;
+        const int h4 = 0;
+        if (h3 > h4) { tMin = h4; tMax = h3; maxT = 3; } else { tMin = h3; tMax = h4; maxT = 4; }
+        if (h1 > h2) { nMin = h2; nMax = h1; maxN = 1; } else { nMin = h1; nMax = h2; maxN = 2; }
+        const double tumSim = (tMax == 0) ? 0.0 : tMax / (tMax + tMin), norSim = (nMax == 0) ? 0.0 : nMax / (nMax + nMin);
+        int hp = 0; const double thr = P.percentage_threshold;
+        if (tMax != 0) { if (tumSim >= thr) { if (norSim >= thr) hp = (maxT == 3) ? (maxN == 1 ? 5 : 7) : (maxN == 1 ? 6 : 8); else hp = (maxT == 3) ? 3 : 4; } }
+        else if (nMax != 0) { if (norSim >= thr) hp = maxN; }
+        if (norPS.size() > 1) hp = 0;
+        out->hp1[r] = h1; out->hp2[r] = h2; out->hp3[r] = h3; out->hp[r] = (uint8_t)hp;
+        out->n_ps[r] = (uint8_t)std::min<size_t>(norPS.size(), 255); out->ps_min[r] = norPS.empty() ? 0 : norPS.begin()->first;
+        out->end_pos[r] = walked ? ref_pos : b.ref_start[r]; out->read_len[r] = walked ? query_pos : 0;
+        if (!h3_sites.empty()) {                                                        // classifyReadsByCase (:462-518) + somaticReadHpCount (:386-404)
+            const bool record = norPS.size() <= 1;
+            const bool clean = (h1 == 0 || h2 == 0) && h3 != 0;
+            for (int64_t v : h3_sites) {
+                if (!record) C(v, 24)++;
+                else if (clean) { C(v, 25)++; if (h1 == 0 && h2 == 0) C(v, 28)++; else if (h1 != 0 && h2 == 0) C(v, 26)++; else if (h1 == 0 && h2 != 0) C(v, 27)++; }
+                else C(v, 29)++;
+                C(v, 30 + hp)++;
+            }
+        }
+        if (!tum_sites.empty()) {                                                       // :407-458
+            out->has_site[r] = 1;
+            for (auto &sv : tum_sites) {
+                if (n_pairs < out->pair_capacity) { out->pair_site[n_pairs] = (int32_t)sv.first; out->pair_read[n_pairs] = (int32_t)r; out->pair_base_hp[n_pairs] = (uint8_t)sv.second; }
+                ++n_pairs;
+                C(sv.first, 15 + hp)++;
+            }
+        }
+    }
+    out->n_pairs = n_pairs; out->n_windows = n_win;
+    return (n_pairs > out->pair_capacity || n_win > out->win_capacity) ? -9 : 0;
+}
+
 }  // extern "C"

@@ -44,6 +44,8 @@ def lib():
         _lib.oracle_somatic_tag.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.POINTER(abi.ReadBatch), C.POINTER(abi.SomaticTagResult)]
         _lib.oracle_somatic_extract_normal.restype = C.c_int
         _lib.oracle_somatic_extract_normal.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.c_void_p, C.c_int64, C.POINTER(abi.ReadBatch), C.POINTER(abi.SiteCounters)]
+        _lib.oracle_somatic_extract_tumor.restype = C.c_int
+        _lib.oracle_somatic_extract_tumor.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.c_void_p, C.c_int64, C.POINTER(abi.ReadBatch), C.POINTER(abi.TumorExtractResult)]
     return _lib
 
 
@@ -112,4 +114,18 @@ def somatic_extract_normal(params, variants, ref, reads):
     rc = lib().oracle_somatic_extract_normal(C.byref(params), C.byref(variants.c), ref.ctypes.data, ref.size, C.byref(reads.c), C.byref(out.c))
     if rc != 0:
         raise RuntimeError(f"oracle_somatic_extract_normal rc={rc}")
+    return out
+
+
+def somatic_extract_tumor(params, variants, ref, reads, pair_cap=None, win_cap=None):
+    """CPU restatement of the tumor-BAM extraction pass of somatic_haplotag.  Returns abi.TumorExtractOut."""
+    pair_cap = pair_cap or 64 * reads.n_reads + 1024
+    win_cap = win_cap or 1024 * reads.n_reads + 1024
+    out = abi.TumorExtractOut(variants.n, reads.n_reads, pair_cap, win_cap)
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    rc = lib().oracle_somatic_extract_tumor(C.byref(params), C.byref(variants.c), ref.ctypes.data, ref.size, C.byref(reads.c), C.byref(out.c))
+    if rc == -9:
+        return somatic_extract_tumor(params, variants, ref, reads, int(out.c.n_pairs) + 16, int(out.c.n_windows) + 16)
+    if rc != 0:
+        raise RuntimeError(f"oracle_somatic_extract_tumor rc={rc}")
     return out

@@ -176,6 +176,25 @@ def run_reference_somatic(N, T, tag_cli, workdir, chrom="chrS"):
             except ValueError:
                 row.append(np.nan)
         log_val.append(row)
+    # DenseAlt filter: thresholds (log header) and the per-site sameCount it derived from the +-100 bp difference windows
+    dense_thr = [0.0, 0.0, 0.0]
+    for line in open(os.path.join(workdir, "som_somatic_var.out")):
+        if line.startswith("##DenseAlt filter condition1"): dense_thr[0] = float(line.split(":")[1])
+        if line.startswith("##DenseAlt filter condition2"): dense_thr[1] = float(line.split(":")[1])
+        if line.startswith("##DenseAlt filter minimum same count"): dense_thr[2] = float(line.split(":")[1])
+    dense_pos, dense_cnt = [], []
+    for line in open(os.path.join(workdir, "som_densealt_filter.log")):
+        f = line.split("\t")
+        if len(f) == 3 and f[0] == chrom:
+            dense_pos.append(int(f[1])); dense_cnt.append(int(f[2]))
+    # per-read haplotype of the caller's read set (after calibrateReadHP / calculateReadSetHP)
+    rd_name, rd_hp = [], []
+    rcodes = {"unTag": 0, "H1": 1, "H2": 2, "H3": 3, "H4": 4, "H1_1": 5, "H1_2": 6, "H2_1": 7, "H2_2": 8}
+    for line in open(os.path.join(workdir, "som_read_hp_detail.log")):
+        if line.startswith("#") or not line.strip():
+            continue
+        f = line.split("\t")
+        rd_name.append(f[1]); rd_hp.append(rcodes.get(f[2], 255))
     sam = subprocess.run([TEST_VIEW, "som.bam"], cwd=workdir, capture_output=True, text=True).stdout
     codes = {".": 0, "1": 1, "2": 2, "3": 3, "4": 4, "1-1": 5, "1-2": 6, "2-1": 7, "2-2": 8}
     hp, rps, pq = [], [], []
@@ -187,7 +206,9 @@ def run_reference_somatic(N, T, tag_cli, workdir, chrom="chrS"):
     assert len(hp) == T.n_reads
     table = dict(pos=np.array(pos, np.int32), ref=np.array(ref), alt=np.array(alt), hp1_is_alt=np.array(hp1, np.uint8),
                  phase_set=np.array(ps, np.int32), somatic_role=np.array(role, np.uint8), derive_hp=np.array(dhp, np.uint8),
-                 tumor_kind=np.array(tkind, np.uint8), log_pos=np.array(log_pos, np.int32), log_val=np.array(log_val, np.float64))
+                 tumor_kind=np.array(tkind, np.uint8), log_pos=np.array(log_pos, np.int32), log_val=np.array(log_val, np.float64),
+                 dense_thr=np.array(dense_thr), dense_pos=np.array(dense_pos, np.int32), dense_cnt=np.array(dense_cnt, np.int32),
+                 rd_name=np.array(rd_name), rd_hp=np.array(rd_hp, np.uint8))
     return table, np.array(hp, np.uint8), np.array(rps, np.int32), np.array(pq, np.int32)
 
 

@@ -116,6 +116,7 @@ def load_golden_somatic(name):
     V = abi.Variants(z["pos"], [str(x) for x in z["ref"]], [str(x) for x in z["alt"]], hp1_is_alt=z["hp1_is_alt"],
                      phase_set=z["phase_set"], somatic_role=z["somatic_role"], derive_hp=z["derive_hp"], tumor_kind=z["tumor_kind"])
     V.log_pos, V.log_val = z["log_pos"], z["log_val"]
+    V.dense_thr, V.dense_pos, V.dense_cnt, V.rd_name, V.rd_hp = z["dense_thr"], z["dense_pos"], z["dense_cnt"], z["rd_name"], z["rd_hp"]
     return V, z["hp"], z["ps"], z["pq"]
 
 
