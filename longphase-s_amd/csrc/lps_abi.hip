@@ -53,7 +53,7 @@ struct lps_ctx {
     DevBuf<unsigned long long> nkeys, nkeys_s; DevBuf<uint32_t> nvals, nvals_s;
     DevBuf<float> edge;
     DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
-    DevBuf<uint8_t> hap_status, hap_nps, v_role, v_derive, v_tkind, read_hp; DevBuf<int32_t> site; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1, hap_d2; bool has_somatic = false;
+    DevBuf<uint8_t> hap_status, hap_nps, v_role, v_derive, v_tkind, read_hp; DevBuf<int32_t> site, t_end, t_len, t_pair_site, t_pair_read, t_win_site; DevBuf<uint8_t> t_hp, t_has, t_pair_hp, t_win_allele, t_win_base; DevBuf<int16_t> t_win_off; DevBuf<unsigned long long> t_ctr; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1, hap_d2; bool has_somatic = false;
     DevBuf<char> temp; size_t temp_bytes = 0;
     LpsCounters *d_cnt = nullptr; LpsCounters h_cnt{}; unsigned h_stats[4]{};
     // timing
@@ -87,7 +87,7 @@ int lps_abi_version(void) { return LPS_ABI_VERSION; }
 int lps_struct_size(int which) {
     switch (which) {
         case 0: return (int)sizeof(lps_params); case 1: return (int)sizeof(lps_variant_table); case 2: return (int)sizeof(lps_read_batch);
-        case 3: return (int)sizeof(lps_phase_result); case 4: return (int)sizeof(lps_haplotag_result); case 5: return (int)sizeof(lps_timings); case 6: return (int)sizeof(lps_somatic_tag_result); case 7: return (int)sizeof(lps_site_counters);
+        case 3: return (int)sizeof(lps_phase_result); case 4: return (int)sizeof(lps_haplotag_result); case 5: return (int)sizeof(lps_timings); case 6: return (int)sizeof(lps_somatic_tag_result); case 7: return (int)sizeof(lps_site_counters); case 8: return (int)sizeof(lps_tumor_extract_result);
     }
     return -1;
 }
@@ -546,6 +546,73 @@ int lps_somatic_extract_normal(lps_ctx *c, lps_site_counters *out) {
         t.n_stages = ST_COUNT;
         HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_EXTRACT], c->ev[ST_EXTRACT], c->ev[ST_D2H]));
         HIP_TRY(hipEventElapsedTime(&t.ms_total, c->ev_begin, c->ev_end));
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_somatic_extract_tumor(lps_ctx *c, lps_tumor_extract_result *out) {
+    if (!c || !out) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        const int nR = c->nR, nV = c->nV;
+        if (out->n != nV) return fail(c, "lps_tumor_extract_result.n must equal the variant table size");
+        if (out->n_reads != nR) return fail(c, "lps_tumor_extract_result.n_reads must equal the number of pushed alignments");
+        memset(out->site, 0, (size_t)nV * LPS_TSITE_COUNTERS * sizeof(int32_t));
+        out->n_pairs = 0; out->n_windows = 0;
+        if (nR == 0) return 0;
+        if (nV > 0 && !c->has_tkind) return fail(c, "somatic extraction needs hp1_is_alt, phase_set, somatic_role and tumor_kind in the variant table");
+        if (nV > 0 && c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
+        hipStream_t s = c->stream;
+        const size_t pc = (size_t)std::max<int64_t>(out->pair_capacity, 1), wc = (size_t)std::max<int64_t>(out->win_capacity, 1);
+        c->site.reserve((size_t)nV * LPS_TSITE_COUNTERS + 1);
+        c->hap_status.reserve(nR); c->hap_h1.reserve(nR); c->hap_h2.reserve(nR); c->hap_h3.reserve(nR); c->hap_nps.reserve(nR); c->hap_psmin.reserve(nR);
+        c->t_hp.reserve(nR); c->t_has.reserve(nR); c->t_end.reserve(nR); c->t_len.reserve(nR); c->t_ctr.reserve(2);
+        c->t_pair_site.reserve(pc); c->t_pair_read.reserve(pc); c->t_pair_hp.reserve(pc);
+        c->t_win_site.reserve(wc); c->t_win_allele.reserve(wc); c->t_win_off.reserve(wc); c->t_win_base.reserve(wc);
+        c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1);
+        HIP_TRY(hipEventRecord(c->ev_begin, s));
+        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
+        HIP_TRY(hipMemsetAsync(c->site.p, 0, ((size_t)nV * LPS_TSITE_COUNTERS + 1) * sizeof(int32_t), s));
+        HIP_TRY(hipMemsetAsync(c->t_ctr.p, 0, 2 * sizeof(unsigned long long), s));
+        VarView V = var_view(c); ReadView R = read_view(c);
+        for (auto &u : c->ev_used) u = false;
+        mark(c, ST_PREP);
+        if (nV) launch_variant_prep(V, 0, c->v_bucket.p, c->v_rec.p, s);
+        mark(c, ST_EXTRACT);
+        TumOut T{c->site.p, c->hap_status.p, c->hap_h1.p, c->hap_h2.p, c->hap_h3.p, c->t_hp.p, c->hap_nps.p, c->hap_psmin.p, c->t_end.p, c->t_len.p, c->t_has.p,
+                 c->t_ctr.p, (long long)out->pair_capacity, (long long)out->win_capacity, c->t_pair_site.p, c->t_pair_read.p, c->t_pair_hp.p,
+                 c->t_win_site.p, c->t_win_allele.p, c->t_win_off.p, c->t_win_base.p, c->P.percentage_threshold};
+        launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 0, c->d_cnt, s);
+        launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 1, c->d_cnt, s);
+        mark(c, ST_D2H);
+        unsigned long long ctr[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(ctr, c->t_ctr.p, sizeof ctr, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->site, c->site.p, (size_t)nV * LPS_TSITE_COUNTERS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->status, T.status, (size_t)nR, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->hp1, T.hp1, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->hp2, T.hp2, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->hp3, T.hp3, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->hp, T.hp, (size_t)nR, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->n_ps, T.n_ps, (size_t)nR, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->ps_min, T.ps_min, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->end_pos, T.end_pos, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->read_len, T.read_len, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->has_site, T.has_site, (size_t)nR, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) return fail(c, "Alignment find unsupported CIGAR operation", -2);
+        out->n_pairs = (int64_t)ctr[0]; out->n_windows = (int64_t)ctr[1];
+        const size_t np_ = (size_t)std::min<int64_t>(out->n_pairs, out->pair_capacity), nw_ = (size_t)std::min<int64_t>(out->n_windows, out->win_capacity);
+        if (np_) { HIP_TRY(hipMemcpyAsync(out->pair_site, T.pair_site, np_ * 4, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->pair_read, T.pair_read, np_ * 4, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->pair_base_hp, T.pair_hp, np_, hipMemcpyDeviceToHost, s)); }
+        if (nw_) { HIP_TRY(hipMemcpyAsync(out->win_site, T.win_site, nw_ * 4, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->win_allele, T.win_allele, nw_, hipMemcpyDeviceToHost, s));
+                   HIP_TRY(hipMemcpyAsync(out->win_offset, T.win_offset, nw_ * 2, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->win_base, T.win_base, nw_, hipMemcpyDeviceToHost, s)); }
+        HIP_TRY(hipEventRecord(c->ev_end, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        lps_timings &t = c->tm; memset(&t, 0, sizeof t);
+        t.n_stages = ST_COUNT;
+        HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_EXTRACT], c->ev[ST_EXTRACT], c->ev[ST_D2H]));
+        HIP_TRY(hipEventElapsedTime(&t.ms_total, c->ev_begin, c->ev_end));
+        if (out->n_pairs > out->pair_capacity || out->n_windows > out->win_capacity) return fail(c, "pair/window list capacity too small (needed sizes are in n_pairs / n_windows)", -9);
     } catch (std::string &e) { return fail(c, e); }
     return 0;
 }

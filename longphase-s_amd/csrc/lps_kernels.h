@@ -87,3 +87,16 @@ struct HapOut { uint8_t *status; int32_t *hp1, *hp2; uint8_t *n_ps; int32_t *ps_
                 int32_t *site; uint8_t *read_hp; double pct_thr; };   // site counters [nV][LPS_SITE_COUNTERS], per-read hp of the pass
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
                      int mode, LpsCounters *cnt, hipStream_t s);   // mode 0 haplotag, 1 somatic tag, 2 normal extraction, 3 its read-HP pass
+
+// tumor-BAM extraction (lps_somatic.hip)
+struct TumOut {
+    int32_t *site;                 // [nV][LPS_TSITE_COUNTERS]
+    uint8_t *status; int32_t *hp1, *hp2, *hp3; uint8_t *hp; uint8_t *n_ps; int32_t *ps_min; int32_t *end_pos, *read_len; uint8_t *has_site;
+    unsigned long long *list_ctr;  // [0] pairs, [1] windows
+    long long pair_cap, win_cap;
+    int32_t *pair_site, *pair_read; uint8_t *pair_hp;
+    int32_t *win_site; uint8_t *win_allele; int16_t *win_offset; uint8_t *win_base;
+    double pct_thr;
+};
+void launch_tumor_extract(const VarView &V, const ReadView &R, const TumOut &T, int mapping_quality, int tag_supplementary, int pass,
+                          LpsCounters *cnt, hipStream_t s);

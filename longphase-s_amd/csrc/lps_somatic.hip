@@ -1,0 +1,255 @@
+// lps_somatic.hip — tumor-BAM extraction pass of `somatic_haplotag` (row a21), gfx950.
+//
+// Replaces (reference file:line, relative to /root/reference/):
+//   ExtractTumDataChrProcessor::processRead / classifyReadsByCase    src/somatic_haplotag/SomaticVarCaller.cpp:334-518
+//   ExtractTumDataCigarParser::processMatchOperation / ...Deletion   :712-759
+//   getWindowsDiffRef / getOrderWindowsDiffRef / processCigarOperation :627-710
+//   SomaticJudgeHapStrategy::judgeSomaticSnpHap / judgeNormalSnpHap  src/haplotag/HaplotagStrategy.cpp:315-435
+//   ExtractSomaticDataStragtegy::judgeTumorOnlySnpHap                :617-638
+//   SomaticJudgeHapStrategy::judgeSomaticReadHap (without PQ)        :452-602
+//
+// Two passes of the same wave-per-alignment walker (LDS-staged CIGAR prefixes, packed variant records):
+//   PASS 0  votes (H1/H2 at NORMAL rows, H3 at tumor-only rows), per-site base counters + alleleCount by atomics, the +-100 bp
+//           difference windows (count -> one reservation per wave chunk -> write), the read's haplotype and its per-read record;
+//   PASS 1  everything that needs the read's haplotype: base.ReadHpCount, classifyReadsByCase counters, somaticReadHpCount and the
+//           (site, read, base HP) pairs of tumorPosReadCorrBaseHP.
+// All per-site quantities are order-free integer counts, so atomics reproduce the reference exactly.
+#include "lps_kernels.h"
+
+
+// processCigarOperation (:627-652).  The reference's own enum has CIGAR_N == 6 (HaplotagType.h:29).
+__device__ __forceinline__ bool win_next_op(const uint32_t *cig, int &idx, int end, int dir, int &remaining, int &readPos, int &refPos, int &op) {
+    idx += dir;
+    while (idx < end && idx >= 0) {
+        op = cig[idx] & 15; const int len = (int)(cig[idx] >> 4);
+        if (op == 0 || op == 3 || op == 6 || op == 7 || op == 8) { remaining += len; return true; }
+        else if (op == 1) readPos += len * dir;
+        else if (op == 2) refPos += len * dir;
+        else return false;
+        idx += dir;
+    }
+    return false;
+}
+
+// getOrderWindowsDiffRef (:654-685): WRITE=false counts the differences, WRITE=true stores them from slot `base`.
+template <bool WRITE>
+__device__ __forceinline__ int win_dir(const uint32_t *cig, int idx, int n_cig, const uint8_t *seq, int readLen, const char *ref, int refLen,
+                                       int readPos, int remaining, int refPos, int dir, const TumOut &T, long long base, int site, int allele) {
+    int op = cig[idx] & 15, n = 0;
+    for (int i = 1; i <= 100; ++i) {
+        remaining--;
+        if (remaining == 0 || remaining == -1) { if (!win_next_op(cig, idx, n_cig, dir, remaining, readPos, refPos, op)) return n; }
+        if (op == 2 || op == 1 || op == 3 || op == 6 || op == 8) continue;
+        readPos += dir; refPos += dir;
+        if (readPos > readLen || refPos > refLen || readPos < 0 || refPos < 0) return n;
+        const char rb = readPos < readLen ? nt16_char(seq[readPos >> 1] >> ((~readPos & 1) << 2)) : '\0';
+        const char fb = refPos < refLen ? ref[refPos] : '\0';
+        if (rb != fb) {
+            if (WRITE && base + n < T.win_cap) { T.win_site[base + n] = site; T.win_allele[base + n] = (uint8_t)allele; T.win_offset[base + n] = (int16_t)(i * dir); T.win_base[base + n] = (uint8_t)rb; }
+            ++n;
+        }
+    }
+    return n;
+}
+
+// judgeSomaticReadHap (HaplotagStrategy.cpp:452-602) restricted to the haplotype decision (hpCount[4] is never incremented here)
+__device__ __forceinline__ int somatic_read_hp(int h1, int h2, int h3, bool multi_ps, double thr) {
+    const int h4 = 0;
+    double tMin, tMax, nMin, nMax; int maxT, maxN;
+    if (h3 > h4) { tMin = h4; tMax = h3; maxT = 3; } else { tMin = h3; tMax = h4; maxT = 4; }
+    if (h1 > h2) { nMin = h2; nMax = h1; maxN = 1; } else { nMin = h1; nMax = h2; maxN = 2; }
+    const double tumSim = (tMax == 0) ? 0.0 : tMax / (tMax + tMin), norSim = (nMax == 0) ? 0.0 : nMax / (nMax + nMin);
+    int hp = 0;
+    if (tMax != 0) { if (tumSim >= thr) { if (norSim >= thr) hp = (maxT == 3) ? (maxN == 1 ? 5 : 7) : (maxN == 1 ? 6 : 8); else hp = (maxT == 3) ? 3 : 4; } }
+    else if (nMax != 0) { if (norSim >= thr) hp = maxN; }
+    if (multi_ps) hp = 0;
+    return hp;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void k_tumor_extract(VarView V, ReadView R, TumOut T, int mapping_quality, int tag_supplementary, LpsCounters *cnt) {
+    __shared__ int s_ref[4][LPS_SEG];
+    __shared__ int s_qry[4][LPS_SEG];
+    __shared__ uint32_t s_cig[4][LPS_SEG + 1];
+    const int w = threadIdx.x >> 6, l = lane_id();
+    const int r = blockIdx.x * 4 + w;
+    if (r >= R.n) return;
+    int *sref = s_ref[w], *sqry = s_qry[w]; uint32_t *scig = s_cig[w];
+    const int start = R.ref_start[r];
+    const int flag = R.flag[r];
+    const bool mq_ok = R.mapq[r] >= mapping_quality;
+    int status = 0;                                                    // mappingQualityFilter == false in the extraction passes
+    if (flag & 0x4) status = 2;
+    else if (flag & 0x100) status = 3;
+    else if ((flag & 0x800) && !tag_supplementary) status = 4;
+    else if (V.n == 0) status = 5;
+    else if (!(start <= V.last_pos)) status = 6;
+    int h1 = 0, h2 = 0, h3 = 0, ps_lo = 0x7fffffff, ps_hi = (int)0x80000000, n_site = 0;
+    int ref_pos = start, q_pos = 0;
+    bool walked = false;
+    if (status == 0) {
+        const uint64_t coff = R.cigar_off[r];
+        const int n_cig = (int)(R.cigar_off[r + 1] - coff);
+        const uint32_t *cig = R.cigar + coff;
+        const uint8_t *seq = R.seq + R.seq_off[r];
+        const int lq = R.l_qseq[r];
+        int vcur = var_lower_bound(V, start);
+        walked = vcur < V.n;                                           // parsingCigar returns at once when no variant is left (:555-557)
+        // read-level facts of PASS 0 that PASS 1 needs
+        int r_hp = 0; bool r_record = true, r_clean = false; int r_h1 = 0, r_h2 = 0;
+        if (PASS == 1) { r_hp = T.hp[r]; r_h1 = T.hp1[r]; r_h2 = T.hp2[r]; r_record = T.n_ps[r] <= 1; r_clean = (r_h1 == 0 || r_h2 == 0) && T.hp3[r] != 0; }
+        for (int seg0 = 0; seg0 < n_cig && walked; seg0 += LPS_SEG) {
+            const int nseg = min(LPS_SEG, n_cig - seg0);
+            uint2 vr = make_uint2(0x7fffffffu, 0u);
+            if (vcur + l < V.n) vr = V.rec[vcur + l];
+            const uint32_t nextw = (seg0 + nseg < n_cig) ? cig[seg0 + nseg] : 0xfu;
+            uint32_t wds[LPS_SEG / 64];
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < LPS_SEG / 64; ++u) { const int idx = u * 64 + l; wds[u] = idx < nseg ? cig[seg0 + idx] : 6u; }
+#pragma unroll
+            for (int u = 0; u < LPS_SEG / 64; ++u) {
+                const int c0 = u * 64;
+                if (c0 >= nseg) break;
+                const int idx = c0 + l;
+                const uint32_t wd = wds[u];
+                const int op = idx < nseg ? (int)(wd & 15) : 6, len = (int)(wd >> 4);
+                if (op > 8) bad = true;
+                const int radv = op_consumes_ref(op) ? len : 0, qadv = op_consumes_query(op) ? len : 0;
+                const int ir = wave_incl_scan_dpp(radv), iq = wave_incl_scan_dpp(qadv);
+                if (idx < nseg) { sref[idx] = ref_pos + ir - radv; sqry[idx] = q_pos + iq - qadv; scig[idx] = wd; }
+                ref_pos += __shfl(ir, 63); q_pos += __shfl(iq, 63);
+            }
+            if (__ballot(bad) && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
+            if (l == 0) scig[nseg] = nextw;
+            wave_sync();
+            while (vcur < V.n) {
+                const int v = vcur + l;
+                const int p = (int)vr.x;
+                const bool mine = v < V.n && p < ref_pos;
+                const int n_in = __popcll(__ballot(mine));
+                bool want_win = false, pair = false; int win_allele = 0, opj = 0, win_off = 0, base_hp = 0;
+                if (mine) {
+                    const unsigned at = vr.y;
+                    int lo = 0, hi = nseg;
+                    while (lo < hi) { const int m = (lo + hi) >> 1; if (sref[m] > p) hi = m; else lo = m + 1; }
+                    const int j = lo - 1;
+                    if (j >= 0) {
+                        const uint32_t wd = scig[j];
+                        const int op = wd & 15, len = (int)(wd >> 4);
+                        const int rs = sref[j], qs = sqry[j];
+                        if (p < rs + len) {
+                            const unsigned kind = VREC_KIND(at), tk = VREC_TKIND(at), role = VREC_ROLE(at);
+                            const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
+                            const bool hp1alt = (at & VREC_HP1ALT) != 0;
+                            int32_t *sc = T.site + (size_t)v * LPS_TSITE_COUNTERS;
+                            if (op_is_match(op)) {
+                                const int qi = qs + (p - rs);
+                                const char base_c = qi < lq ? nt16_char(seq[qi >> 1] >> ((~qi & 1) << 2)) : 'N';
+                                bool is_alt = false;
+                                if (kind == 0) is_alt = base_c == alt_c;
+                                else if ((kind == 1 || kind == 2) && seg0 + j + 1 < n_cig)
+                                    is_alt = (rs + len - 1 == p) && (int)(scig[j + 1] & 15) == ((kind == 1) ? 1 : 2);
+                                if (mq_ok) {                                                  // judgeSomaticSnpHap (:315-389)
+                                    if (role == 0) {
+                                        bool counted = false;
+                                        if (kind == 0) counted = base_c == ref_c || base_c == alt_c;
+                                        else if (kind == 1 || kind == 2) counted = true;         // base := isAlt ? Alt : Ref
+                                        if (counted) {
+                                            if (hp1alt == is_alt) { ++h1; base_hp = 1; } else { ++h2; base_hp = 2; }
+                                            const int ps = V.phase_set[v]; ps_lo = min(ps_lo, ps); ps_hi = max(ps_hi, ps);
+                                        }
+                                    } else if (tk != 0) {                                     // tumor-only row: H3 when the read shows the tumor ALT
+                                        if ((kind == 0 || kind == 1 || kind == 2) && is_alt) { ++h3; base_hp = 3; }
+                                    }
+                                    if (tk != 0) { pair = true; ++n_site; }                   // tumorSnpPosVec (:722-724)
+                                }
+                                if (PASS == 0 && tk >= 1 && tk <= 3) {                        // :728-741
+                                    if (tk != 1 || base_c == ref_c || base_c == alt_c) {
+                                        atomicAdd(&sc[39 + (is_alt ? 1 : 0)], 1);
+                                        want_win = true; win_allele = is_alt; opj = seg0 + j; win_off = p - rs;
+                                    }
+                                    const int bi = base_c == 'A' ? LPS_SC_A : base_c == 'C' ? LPS_SC_C : base_c == 'G' ? LPS_SC_G : base_c == 'T' ? LPS_SC_T : LPS_SC_UNKNOWN;
+                                    if (mq_ok) { atomicAdd(&sc[bi + (LPS_SC_MPQ_A - LPS_SC_A)], 1); if (is_alt) atomicAdd(&sc[LPS_SC_MPQ_ALT], 1); atomicAdd(&sc[LPS_SC_MPQ_DEPTH], 1); }
+                                    atomicAdd(&sc[bi], 1);
+                                    if (is_alt) { if (tk == 3) atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_ALT], 1); }
+                                    atomicAdd(&sc[LPS_SC_DEPTH], 1);
+                                }
+                                if (PASS == 1 && pair) {
+                                    atomicAdd(&sc[15 + r_hp], 1);                             // base.ReadHpCount[hpResult] (:457)
+                                    if (base_hp == 3) {                                       // classifyReadsByCase (:462-518) + somaticReadHpCount (:386-404)
+                                        if (!r_record) atomicAdd(&sc[24], 1);
+                                        else if (r_clean) {
+                                            atomicAdd(&sc[25], 1);
+                                            if (r_h1 == 0 && r_h2 == 0) atomicAdd(&sc[28], 1); else if (r_h1 != 0 && r_h2 == 0) atomicAdd(&sc[26], 1); else if (r_h1 == 0 && r_h2 != 0) atomicAdd(&sc[27], 1);
+                                        } else atomicAdd(&sc[29], 1);
+                                        atomicAdd(&sc[30 + r_hp], 1);
+                                    }
+                                }
+                            } else if (op == 2 && PASS == 0) {                                // processDeletionOperation (:743-759)
+                                if (tk == 1) { atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_DEPTH], 1); }
+                                else if (tk == 3) { atomicAdd(&sc[LPS_SC_ALT], 1); atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_DEPTH], 1); }
+                            }
+                        }
+                    }
+                }
+                if (PASS == 0) {
+                    // getWindowsDiffRef (:687-710): count, reserve once per wave chunk, write
+                    if (__ballot(want_win)) {
+                        int nw = 0, fwd = 0, rev = 0, len = 0, rp = 0;
+                        if (want_win) {
+                            len = (int)(cig[opj] >> 4); fwd = (len - win_off > 0) ? len - win_off : 0; rev = win_off > 0 ? win_off : 0;
+                            rp = sqry[opj - seg0] + win_off;
+                            nw = win_dir<false>(cig, opj, n_cig, seq, lq, V.ref, (int)V.ref_len_eff, rp, rev, p, -1, T, 0, 0, 0)
+                               + win_dir<false>(cig, opj, n_cig, seq, lq, V.ref, (int)V.ref_len_eff, rp, fwd, p, +1, T, 0, 0, 0);
+                        }
+                        const int incl = wave_incl_scan_dpp(nw);
+                        const int tot = __shfl(incl, 63);
+                        unsigned long long wb = 0;
+                        if (l == 0 && tot) wb = atomicAdd(&T.list_ctr[1], (unsigned long long)tot);
+                        wb = __shfl(wb, 0);
+                        if (want_win && nw) {
+                            const long long b0 = (long long)wb + incl - nw;
+                            const int k1 = win_dir<true>(cig, opj, n_cig, seq, lq, V.ref, (int)V.ref_len_eff, rp, rev, p, -1, T, b0, v, win_allele);
+                            win_dir<true>(cig, opj, n_cig, seq, lq, V.ref, (int)V.ref_len_eff, rp, fwd, p, +1, T, b0 + k1, v, win_allele);
+                        }
+                    }
+                } else {
+                    const unsigned long long pm = __ballot(pair);
+                    if (pm) {
+                        unsigned long long pb = 0;
+                        if (l == 0) pb = atomicAdd(&T.list_ctr[0], (unsigned long long)__popcll(pm));
+                        pb = __shfl(pb, 0);
+                        if (pair) {
+                            const long long slot = (long long)pb + __popcll(pm & lanemask_lt());
+                            if (slot < T.pair_cap) { T.pair_site[slot] = v; T.pair_read[slot] = r; T.pair_hp[slot] = (uint8_t)base_hp; }
+                        }
+                    }
+                }
+                vcur += n_in;
+                if (n_in < 64 || vcur >= V.n) break;
+                vr = make_uint2(0x7fffffffu, 0u);
+                if (vcur + l < V.n) vr = V.rec[vcur + l];
+            }
+            wave_sync();
+        }
+        if (PASS == 0) { h1 = wave_sum(h1); h2 = wave_sum(h2); h3 = wave_sum(h3); ps_lo = wave_min(ps_lo); ps_hi = wave_max(ps_hi); n_site = wave_sum(n_site); }
+    }
+    if (PASS == 0 && l == 0) {
+        const bool any = ps_lo <= ps_hi;
+        T.status[r] = (uint8_t)status; T.hp1[r] = h1; T.hp2[r] = h2; T.hp3[r] = h3;
+        T.n_ps[r] = any ? (ps_lo == ps_hi ? 1 : 2) : 0; T.ps_min[r] = any ? ps_lo : 0;
+        T.hp[r] = (uint8_t)(status == 0 ? somatic_read_hp(h1, h2, h3, any && ps_lo != ps_hi, T.pct_thr) : 0);
+        T.end_pos[r] = (status == 0 && walked) ? ref_pos : (status == 0 ? start : 0);
+        T.read_len[r] = (status == 0 && walked) ? q_pos : 0;
+        T.has_site[r] = n_site > 0;
+    }
+}
+
+void launch_tumor_extract(const VarView &V, const ReadView &R, const TumOut &T, int mapping_quality, int tag_supplementary, int pass,
+                          LpsCounters *cnt, hipStream_t s) {
+    if (R.n == 0) return;
+    const dim3 g((R.n + 3) / 4), b(256);
+    if (pass == 0) hipLaunchKernelGGL(k_tumor_extract<0>, g, b, 0, s, V, R, T, mapping_quality, tag_supplementary, cnt);
+    else hipLaunchKernelGGL(k_tumor_extract<1>, g, b, 0, s, V, R, T, mapping_quality, tag_supplementary, cnt);
+}

@@ -49,6 +49,7 @@ def load():
     L.lps_haplotag_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.HaplotagResult)]
     L.lps_somatic_tag_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.SomaticTagResult)]
     L.lps_somatic_extract_normal.argtypes = [C.c_void_p, C.POINTER(abi.SiteCounters)]
+    L.lps_somatic_extract_tumor.argtypes = [C.c_void_p, C.POINTER(abi.TumorExtractResult)]
     L.lps_get_timings.argtypes = [C.c_void_p, C.POINTER(abi.Timings)]
     L.lps_stage_name.restype = C.c_char_p
     L.lps_stage_name.argtypes = [C.c_int]
@@ -131,6 +132,20 @@ class Context:
         out = abi.SiteCountersOut(self.n_var, self.n_reads)
         self._check(self.L.lps_somatic_extract_normal(self.h, C.byref(out.c)), "lps_somatic_extract_normal")
         return out
+
+    def somatic_extract_tumor(self, variants, ref, reads, pair_cap=None, win_cap=None):
+        self.load_chromosome(variants, ref, reads)
+        pair_cap = pair_cap or 64 * self.n_reads + 1024
+        win_cap = win_cap or 256 * self.n_reads + 1024
+        for _ in range(2):
+            out = abi.TumorExtractOut(self.n_var, self.n_reads, pair_cap, win_cap)
+            rc = self.L.lps_somatic_extract_tumor(self.h, C.byref(out.c))
+            if rc == -9:      # lists did not fit: retry with the sizes the library reported
+                pair_cap, win_cap = int(out.c.n_pairs) + 16, int(out.c.n_windows) + 16
+                continue
+            self._check(rc, "lps_somatic_extract_tumor")
+            return out
+        self._check(rc, "lps_somatic_extract_tumor")
 
     def timings(self):
         t = abi.Timings()

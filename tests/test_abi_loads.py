@@ -26,5 +26,5 @@ def test_default_params_match_reference_defaults():
 def test_struct_sizes_match_header():
     """ctypes mirrors must have the sizes the C side was compiled with."""
     L = hip.load()
-    for which, st in enumerate((abi.Params, abi.VariantTable, abi.ReadBatch, abi.PhaseResult, abi.HaplotagResult, abi.Timings, abi.SomaticTagResult, abi.SiteCounters)):
+    for which, st in enumerate((abi.Params, abi.VariantTable, abi.ReadBatch, abi.PhaseResult, abi.HaplotagResult, abi.Timings, abi.SomaticTagResult, abi.SiteCounters, abi.TumorExtractResult)):
         assert L.lps_struct_size(which) == C.sizeof(st), st.__name__

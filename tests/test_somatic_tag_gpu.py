@@ -42,3 +42,31 @@ def test_normal_extraction_matches_oracle_and_reference_log(name):
     bad = np.nonzero((out.counters != ref.counters).any(axis=1))[0]
     assert bad.size == 0, f"{bad.size} sites differ, first {bad[:5]}: {out.counters[bad[:3]]} vs {ref.counters[bad[:3]]}"
     check_normal_sites(V, out.counters, name + " vs reference log")
+
+
+@pytest.mark.parametrize("name", sorted(fixtures.SOMATIC_FIXTURES))
+def test_tumor_extraction_matches_oracle_and_reference_logs(name):
+    """Row a21: every per-site counter, per-read record, (site, read, base HP) pair and +-100 bp difference-window entry == oracle
+    (lists compared as sorted multisets: their order is not defined), and the reference's logged fields / DenseAlt counts."""
+    from test_oracle_somatic_tumor_golden import check_tumor_sites, dense_alt_same_count
+    genome, nkw, tkw, cli, over = fixtures.SOMATIC_FIXTURES[name]
+    T, R = util.make_tumor_reads(name)
+    V, _, _, _ = util.load_golden_somatic(name)
+    P = abi.default_params(**over)
+    ref = lps_oracle.somatic_extract_tumor(P, V, T.ref, R)
+    with hip.Context(0, P) as ctx:
+        out = ctx.somatic_extract_tumor(V, T.ref, R, pair_cap=16, win_cap=16)     # forces the capacity-retry path once
+    for k in ("status", "hp1", "hp2", "hp3", "hp", "ps_min", "end_pos", "read_len", "has_site"):
+        assert np.array_equal(getattr(out, k), getattr(ref, k)), k
+    assert np.array_equal(np.minimum(out.n_ps, 2), np.minimum(ref.n_ps, 2))
+    bad = np.nonzero((out.site != ref.site).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} sites differ, first {bad[:3]}: {out.site[bad[:2]]} vs {ref.site[bad[:2]]}"
+    assert out.c.n_pairs == ref.c.n_pairs and out.c.n_windows == ref.c.n_windows
+    for a, b in zip(out.pairs(), ref.pairs()):
+        assert np.array_equal(a, b), "pairs differ"
+    for a, b in zip(out.windows(), ref.windows()):
+        assert np.array_equal(a, b), "difference windows differ"
+    check_tumor_sites(V, out, name + " vs reference log")
+    same = dense_alt_same_count(V, out)
+    didx = np.searchsorted(V.pos, V.dense_pos)
+    assert np.array_equal(same[didx], V.dense_cnt), "DenseAlt sameCount vs reference log"
