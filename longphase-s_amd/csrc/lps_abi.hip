@@ -14,10 +14,10 @@
 #include "lps_graph.h"
 
 static const char *kStageNames[LPS_MAX_STAGES] = {
-    "variant_prep", "extract", "name_groups", "clip_cnv", "overlap_filter", "cnv_filter", "nodes", "merge_rows",
+    "variant_prep", "extract", "name_keys", "clip_cnv", "name_groups", "overlap_filter", "cnv_filter", "nodes", "merge_rows",
     "node_lists", "edges", "vote_scan", "read_correction", "d2h", nullptr};
 // recorded in this order on the stream
-enum { ST_PREP, ST_EXTRACT, ST_GROUPS, ST_CLIP, ST_OVERLAP, ST_CNV, ST_NODES, ST_MERGE, ST_NODELISTS, ST_EDGES, ST_SCAN, ST_CORR, ST_D2H, ST_COUNT };
+enum { ST_PREP, ST_EXTRACT, ST_GROUPS, ST_CLIP, ST_GROUPS2, ST_OVERLAP, ST_CNV, ST_NODES, ST_MERGE, ST_NODELISTS, ST_EDGES, ST_SCAN, ST_CORR, ST_D2H, ST_COUNT };
 
 struct lps_ctx {
     int device = 0;
@@ -44,6 +44,8 @@ struct lps_ctx {
     DevBuf<unsigned long long> clip_keys, clip_keys_s;
     DevBuf<int32_t> cnv_start, cnv_end;
     DevBuf<long long> agg_sum; DevBuf<int32_t> agg_cnt; DevBuf<double> miss;
+    DevBuf<uint32_t> cnv_flag, cnv_idx, cnv_list, cnv_nlist; DevBuf<uint8_t> cnv_tab, cnv_btab, cnv_bstart, cnv_entry;
+    unsigned *h_ncnv = nullptr; hipEvent_t ev_cnv = nullptr;   // pinned word + event: n_cnv reaches the host while the GPU keeps working
     // groups
     DevBuf<unsigned long long> name_keys, name_keys_s;
     DevBuf<uint32_t> head, gidx, gstart, read_group, stack, mrow_off, koff; DevBuf<int32_t> mrow_cnt;
@@ -115,7 +117,8 @@ lps_ctx *lps_create(int device, const lps_params *params) {
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_TRY(hipMalloc((void **)&c->d_cnt, sizeof(LpsCounters)));
         for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(hipEventCreate(&c->ev_begin)); HIP_TRY(hipEventCreate(&c->ev_end));
+        HIP_TRY(hipEventCreate(&c->ev_begin)); HIP_TRY(hipEventCreate(&c->ev_end)); HIP_TRY(hipEventCreate(&c->ev_cnv));
+        HIP_TRY(hipHostMalloc((void **)&c->h_ncnv, 64));
     } catch (std::string &e) { fprintf(stderr, "lps_create: %s\n", e.c_str()); delete c; return nullptr; }
     return c;
 }
@@ -127,6 +130,8 @@ void lps_destroy(lps_ctx *c) {
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->ev_cnv) (void)hipEventDestroy(c->ev_cnv);
+    if (c->h_ncnv) (void)hipHostFree(c->h_ncnv);
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -293,19 +298,28 @@ static int run_phase(lps_ctx *c) {
         if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = (unsigned long long)n_arenas * (c->h_cnt.arena_max + c->h_cnt.arena_max / 4 + 1024); continue; }
         const unsigned long long n_keys = c->h_cnt.obs_total;
         if (n_keys + n_keys / 2 > cap) { /* leave room for merged tails */ }
-        sort_keys64(c->temp.p, c->temp_bytes, c->name_keys.p, c->name_keys_s.p, nR, 64, s);
-        launch_groups(c->name_keys_s.p, nR, c->d_cnt, c->head.p, c->gidx.p, c->gstart.p, c->read_group.p, c->temp.p, c->temp_bytes, s);
-        // ---- a7 clips -> CNV intervals
+        // ---- a7 clips -> CNV intervals first, so that n_cnv travels to the host while the GPU works on the name groups
         mark(c, ST_CLIP);
         launch_clip_cnv(c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, c->cnv_start.p, c->cnv_end.p, c->clip_stats.p, c->d_cnt, s);
+        HIP_TRY(hipMemcpyAsync(c->h_ncnv, &c->d_cnt->n_cnv, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(c->ev_cnv, s));
+        mark(c, ST_GROUPS2);
+        sort_keys64(c->temp.p, c->temp_bytes, c->name_keys.p, c->name_keys_s.p, nR, 64, s);
+        launch_groups(c->name_keys_s.p, nR, c->d_cnt, c->head.p, c->gidx.p, c->gstart.p, c->read_group.p, c->temp.p, c->temp_bytes, s);
         // ---- a8 overlap filter
         mark(c, ST_OVERLAP);
         HIP_TRY(hipMemsetAsync(c->deleted.p, 0, nR, s));
         launch_overlap_filter(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->row_cnt.p, c->obs_var.p, c->v_pos.p, P.overlap_threshold, c->stack.p, c->deleted.p, s);
-        // ---- a9 CNV mismatch filter (device-side no-op when there are no intervals)
+        // ---- a9 CNV mismatch filter: only when intervals exist (the count arrived while the kernels above were running)
         mark(c, ST_CNV);
-        c->agg_sum.reserve((size_t)nV * 2 + 2); c->agg_cnt.reserve((size_t)nV * 2 + 2); c->miss.reserve(nV + 1);
-        launch_cnv_filter(c->d_cnt, nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->v_pos.p, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, s);
+        HIP_TRY(hipEventSynchronize(c->ev_cnv));
+        if (*c->h_ncnv) {
+            c->agg_sum.reserve((size_t)nV * 2 + 2); c->agg_cnt.reserve((size_t)nV * 2 + 2); c->miss.reserve(nV + 1);
+            c->cnv_flag.reserve(nR + 1); c->cnv_idx.reserve(nR + 1); c->cnv_list.reserve(nR + 1); c->cnv_nlist.reserve(4);
+            c->cnv_tab.reserve((size_t)nR * 64 + 64); c->cnv_btab.reserve(((size_t)nR / 256 + 2) * 64); c->cnv_bstart.reserve((size_t)nR / 256 + 2); c->cnv_entry.reserve(nR + 1);
+            CnvScratch W{c->cnv_flag.p, c->cnv_idx.p, c->cnv_list.p, c->cnv_nlist.p, c->cnv_tab.p, c->cnv_btab.p, c->cnv_bstart.p, c->cnv_entry.p};
+            launch_cnv_filter(c->d_cnt, nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->v_pos.p, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, W, c->temp.p, c->temp_bytes, s);
+        }
         // ---- a10 nodes + graph observations
         mark(c, ST_NODES);
         HIP_TRY(hipMemsetAsync(c->is_node.p, 0, (size_t)(nV + 1) * 4, s));

@@ -18,10 +18,11 @@ void launch_groups(const unsigned long long *skeys, int n_reads, LpsCounters *cn
 void launch_overlap_filter(const unsigned long long *skeys, const uint32_t *gstart, const LpsCounters *cnt, int n_reads,
                            const uint32_t *row_off, const int32_t *row_cnt, const int32_t *obs_var, const int32_t *vpos,
                            double thr, uint32_t *stack, uint8_t *deleted, hipStream_t s);
+struct CnvScratch { uint32_t *flag, *idx, *list, *n_list; uint8_t *tab, *btab, *bstart, *entry; };
 void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const uint32_t *row_off, const int32_t *row_cnt,
                        const uint8_t *deleted, int32_t *obs_var, const uint16_t *obs_aq, const int32_t *vpos,
                        const int32_t *cnv_start, const int32_t *cnv_end, long long *agg_sum, int32_t *agg_cnt, double *miss,
-                       hipStream_t s);
+                       CnvScratch &W, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_nodes(int n_reads, int n_var, const uint32_t *row_off, const int32_t *row_cnt, const uint8_t *deleted,
                   const int32_t *obs_var, const uint16_t *obs_aq, uint32_t *is_node, uint32_t *vtype_key, uint32_t *node_of,
                   int32_t *nodes, uint8_t *ntype, int base_quality, int32_t *g_node, uint8_t *g_flag, int32_t *g_cnt,

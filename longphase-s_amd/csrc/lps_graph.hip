@@ -192,85 +192,157 @@ __global__ void k_overlap_filter(const unsigned long long *skeys, const uint32_t
 }
 
 // ================================================================================================ CNV filter
-// The four CNV mismatch-rate passes (PhasingGraph.cpp:520-692).  The reference carries ONE interval cursor from
-// read to read (and, in the last pass, from variant to variant) over the interval list that holds every interval
-// twice (getCNVInterval runs twice), so which intervals a read "visits" depends on all reads before it.
-// Round-1 implementation: a single thread replays the cursor exactly (only launched when intervals exist);
-// the counting itself is order-free integer arithmetic.  TODO(next round): function-composition scan of the cursor.
-__global__ void k_cnv_filter_serial(const LpsCounters *cnt, int n_reads, const uint32_t *row_off, const int32_t *row_cnt,
-                                    const uint8_t *deleted, int32_t *obs_var, const uint16_t *obs_aq, const int32_t *vpos,
-                                    const int32_t *cnv_start, const int32_t *cnv_end, long long *agg_sum /*[nV][2]*/,
-                                    int32_t *agg_cnt /*[nV][2]*/, double *miss /*[nV], <0 = undefined*/, int n_var) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// The four CNV mismatch-rate passes (PhasingGraph.cpp:520-692).  The reference carries ONE interval cursor from read to read
+// (and, in the last pass, from variant to variant) over the interval list that holds every interval twice (getCNVInterval runs
+// twice), so which intervals a read "visits" depends on all reads before it.  Parallel formulation: the cursor lives in
+// [0, n_cnv) with n_cnv <= 64, so every read is a transfer function f_r: cursor_in -> cursor_out, i.e. a 64-entry byte table
+// computed by one wave (lane c simulates cursor_in = c).  Tables are composed per block of CNV_BLOCK reads (lane c follows the
+// chain), the few block tables are chained by one lane, and the per-read entry cursors are then known, which makes the counting
+// passes embarrassingly parallel (order-free integer sums).  Launched only behind a device-side n_cnv check.
+#define CNV_BLOCK 256
+
+__device__ __forceinline__ int cnv_cursor12(int ci, int rs, int re, int nc, const int32_t *cs, int *i_end) {
+    while (ci > 0 && cs[ci] > rs) --ci;
+    int i = ci;
+    while (i < nc && cs[i] <= re) ++i;
+    *i_end = i;
+    return ci;                                               // entry index actually used; cursor_out = i > 0 ? i - 1 : 0
+}
+
+// kept alignments in BAM order -> dense list (reads with observations that survived the overlap filter)
+__global__ void k_cnv_list(const LpsCounters *cnt, int n_reads, const int32_t *row_cnt, const uint8_t *deleted, uint32_t *flag) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    flag[r] = (cnt->n_cnv != 0 && row_cnt[r] > 0 && !deleted[r]) ? 1u : 0u;
+}
+__global__ void k_cnv_compact(const LpsCounters *cnt, int n_reads, const uint32_t *flag, const uint32_t *idx, uint32_t *list, uint32_t *n_list) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    if (flag[r]) list[idx[r]] = r;
+    if (r == n_reads - 1) *n_list = idx[r] + flag[r];
+}
+
+// wave per kept alignment: transfer tables of the pass-1/2 cursor (PASS4=false) or of the pass-4 cursor (PASS4=true)
+template <bool PASS4>
+__global__ __launch_bounds__(256) void k_cnv_tables(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint32_t *row_off,
+                                                    const int32_t *row_cnt, const int32_t *obs_var, const int32_t *vpos, const int32_t *cs,
+                                                    const int32_t *ce, const double *miss, uint8_t *tab) {
+    const unsigned k = blockIdx.x * 4 + (threadIdx.x >> 6); const int l = lane_id();
+    if (k >= *n_list) return;
     const int nc = (int)cnt->n_cnv;
-    if (nc == 0) return;
-    const int K = nc / 2;                                    // unique intervals; list = L ++ L
-    int mm[LPS_MAX_CNV]; bool has[LPS_MAX_CNV];
-    auto inr = [](int p, int s, int e) { return p >= s && p <= e; };
-    // passes 1+2 share the cursor evolution, so they are fused per read
-    int ci = 0;
-    for (int r = 0; r < n_reads; ++r) {
-        const int n = row_cnt[r];
-        if (n <= 0 || deleted[r]) continue;
-        const uint32_t off = row_off[r];
+    const uint32_t r = list[k]; const uint32_t off = row_off[r]; const int n = row_cnt[r];
+    int ci = min(l, nc - 1);
+    if (!PASS4) {
         const int rs = vpos[obs_var[off]], re = vpos[obs_var[off + n - 1]];
-        while (ci > 0 && cnv_start[ci] > rs) --ci;
-        for (int j = 0; j < K; ++j) { mm[j] = 0; has[j] = false; }
-        int i = ci;
-        while (i < nc && cnv_start[i] <= re) {                               // calculateCnvMismatchRate
-            for (int k = 0; k < n; ++k) {
-                const int p = vpos[obs_var[off + k]];
-                if (p > cnv_end[i]) break;
-                if (inr(p, cnv_start[i], cnv_end[i]) && aq_allele(obs_aq[off + k]) == 1) { mm[i % K]++; has[i % K] = true; }
-            }
-            ++i;
-        }
-        i = ci;
-        while (i < nc && cnv_start[i] <= re) {                               // aggregateCnvReadMismatchRate
-            for (int k = 0; k < n; ++k) {
-                const int v = obs_var[off + k]; const int p = vpos[v];
-                if (p > cnv_end[i]) break;
-                if (inr(p, cnv_start[i], cnv_end[i]) && has[i % K]) {
-                    const int al = aq_allele(obs_aq[off + k]);
-                    agg_sum[(size_t)v * 2 + al] += mm[i % K]; agg_cnt[(size_t)v * 2 + al] += 1;
-                }
-            }
-            ++i;
-        }
-        ci = i > 0 ? i - 1 : 0;
-    }
-    // calculateAverageMismatchRate: cursor never moves in the reference (no write-back), scan from 0
-    bool any = false;
-    for (int v = 0; v < n_var; ++v) {
-        miss[v] = -1.0;
-        if (agg_cnt[(size_t)v * 2] == 0 && agg_cnt[(size_t)v * 2 + 1] == 0) continue;
-        const int p = vpos[v];
-        for (int i = 0; i < nc; ++i) {
-            if (cnv_start[i] > p) break;
-            if (inr(p, cnv_start[i], cnv_end[i]) && agg_cnt[(size_t)v * 2] > 0 && agg_cnt[(size_t)v * 2 + 1] > 0) {
-                const double a = (double)agg_sum[(size_t)v * 2] / (double)agg_cnt[(size_t)v * 2];
-                const double c = (double)agg_sum[(size_t)v * 2 + 1] / (double)agg_cnt[(size_t)v * 2 + 1];
-                if (a != 0 && c != 0) { miss[v] = c / (a + c); any = true; }
-            }
-        }
-    }
-    if (!any) return;
-    ci = 0;                                                                  // filterHighMismatchVariants
-    for (int r = 0; r < n_reads; ++r) {
-        const int n = row_cnt[r];
-        if (n <= 0 || deleted[r]) continue;
-        const uint32_t off = row_off[r];
+        int i_end; cnv_cursor12(ci, rs, re, nc, cs, &i_end);
+        ci = i_end > 0 ? i_end - 1 : 0;
+    } else {
         const int rs = vpos[obs_var[off]];
-        while (ci > 0 && cnv_start[ci] > rs) --ci;
-        for (int k = 0; k < n; ++k) {
-            const int v = obs_var[off + k]; const int p = vpos[v];
+        while (ci > 0 && cs[ci] > rs) --ci;
+        for (int q = 0; q < n; ++q) {
+            const int v = obs_var[off + q]; const int p = vpos[v];
             int i = ci;
-            while (i < nc && cnv_start[i] <= p) {
-                if (inr(p, cnv_start[i], cnv_end[i]) && miss[v] >= 0.7) { obs_var[off + k] = -1 - v; break; }
-                ++i;
-            }
+            while (i < nc && cs[i] <= p) { if (p >= cs[i] && p <= ce[i] && miss[v] >= 0.7) break; ++i; }
             ci = i > 0 ? i - 1 : 0;
         }
+    }
+    if (l < nc) tab[(size_t)k * 64 + l] = (uint8_t)ci;
+}
+
+// wave per block of CNV_BLOCK alignments: compose the tables of the block (lane c follows cursor_in = c through the block)
+__global__ __launch_bounds__(64) void k_cnv_block_compose(const LpsCounters *cnt, const uint32_t *n_list, const uint8_t *tab, uint8_t *btab) {
+    const unsigned b = blockIdx.x; const int l = lane_id();
+    const unsigned n = *n_list;
+    if (b * CNV_BLOCK >= n) return;
+    const int nc = (int)cnt->n_cnv;
+    int c = min(l, nc - 1);
+    const unsigned e = min(n, (b + 1) * CNV_BLOCK);
+    for (unsigned k = b * CNV_BLOCK; k < e; ++k) c = tab[(size_t)k * 64 + c];
+    if (l < nc) btab[(size_t)b * 64 + l] = (uint8_t)c;
+}
+// one lane chains the block tables from cursor 0; then wave per block: entry cursor of every alignment of the block
+__global__ void k_cnv_block_chain(const uint32_t *n_list, const uint8_t *btab, uint8_t *bstart) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned nb = (*n_list + CNV_BLOCK - 1) / CNV_BLOCK;
+    int c = 0;
+    for (unsigned b = 0; b < nb; ++b) { bstart[b] = (uint8_t)c; c = btab[(size_t)b * 64 + c]; }
+}
+__global__ void k_cnv_entry(const uint32_t *n_list, const uint8_t *tab, const uint8_t *bstart, uint8_t *entry) {
+    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned n = *n_list;
+    if (b * CNV_BLOCK >= n) return;
+    int c = bstart[b];
+    const unsigned e = min(n, (b + 1) * CNV_BLOCK);
+    for (unsigned k = b * CNV_BLOCK; k < e; ++k) { entry[k] = (uint8_t)c; c = tab[(size_t)k * 64 + c]; }
+}
+
+// thread per kept alignment: calculateCnvMismatchRate + aggregateCnvReadMismatchRate with the known entry cursor
+__global__ void k_cnv_count(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *entry, const uint32_t *row_off,
+                            const int32_t *row_cnt, const int32_t *obs_var, const uint16_t *obs_aq, const int32_t *vpos, const int32_t *cs,
+                            const int32_t *ce, unsigned long long *agg_sum, int32_t *agg_cnt) {
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *n_list) return;
+    const int nc = (int)cnt->n_cnv, K = nc / 2;
+    const uint32_t r = list[k]; const uint32_t off = row_off[r]; const int n = row_cnt[r];
+    const int rs = vpos[obs_var[off]], re = vpos[obs_var[off + n - 1]];
+    int i_end; const int ci = cnv_cursor12(entry[k], rs, re, nc, cs, &i_end);
+    int mm[LPS_MAX_CNV / 2]; unsigned long long has = 0;
+    for (int j = 0; j < K; ++j) mm[j] = 0;
+    for (int i = ci; i < i_end; ++i)
+        for (int q = 0; q < n; ++q) {
+            const int p = vpos[obs_var[off + q]];
+            if (p > ce[i]) break;
+            if (p >= cs[i] && p <= ce[i] && aq_allele(obs_aq[off + q]) == 1) { mm[i % K]++; has |= 1ull << (i % K); }
+        }
+    for (int i = ci; i < i_end; ++i) {
+        if (!((has >> (i % K)) & 1ull)) continue;
+        for (int q = 0; q < n; ++q) {
+            const int v = obs_var[off + q]; const int p = vpos[v];
+            if (p > ce[i]) break;
+            if (p >= cs[i] && p <= ce[i]) {
+                const int al = aq_allele(obs_aq[off + q]);
+                atomicAdd(&agg_sum[(size_t)v * 2 + al], (unsigned long long)mm[i % K]); atomicAdd(&agg_cnt[(size_t)v * 2 + al], 1);
+            }
+        }
+    }
+}
+
+// thread per variant: calculateAverageMismatchRate (the reference never moves the cursor in this pass: scan from 0)
+__global__ void k_cnv_miss(const LpsCounters *cnt, int n_var, const int32_t *vpos, const int32_t *cs, const int32_t *ce,
+                           const unsigned long long *agg_sum, const int32_t *agg_cnt, double *miss) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_var) return;
+    const int nc = (int)cnt->n_cnv;
+    double m = -1.0;
+    if (nc && agg_cnt[(size_t)v * 2] > 0 && agg_cnt[(size_t)v * 2 + 1] > 0) {
+        const int p = vpos[v];
+        for (int i = 0; i < nc; ++i) {
+            if (cs[i] > p) break;
+            if (p >= cs[i] && p <= ce[i]) {
+                const double a = (double)agg_sum[(size_t)v * 2] / (double)agg_cnt[(size_t)v * 2];
+                const double c = (double)agg_sum[(size_t)v * 2 + 1] / (double)agg_cnt[(size_t)v * 2 + 1];
+                if (a != 0 && c != 0) m = c / (a + c);
+            }
+        }
+    }
+    miss[v] = m;
+}
+
+// thread per kept alignment: filterHighMismatchVariants with the known entry cursor
+__global__ void k_cnv_erase(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *entry, const uint32_t *row_off,
+                            const int32_t *row_cnt, int32_t *obs_var, const int32_t *vpos, const int32_t *cs, const int32_t *ce, const double *miss) {
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *n_list) return;
+    const int nc = (int)cnt->n_cnv;
+    const uint32_t r = list[k]; const uint32_t off = row_off[r]; const int n = row_cnt[r];
+    int ci = entry[k];
+    const int rs = vpos[obs_var[off]];
+    while (ci > 0 && cs[ci] > rs) --ci;
+    for (int q = 0; q < n; ++q) {
+        const int v = obs_var[off + q]; const int p = vpos[v];
+        int i = ci;
+        while (i < nc && cs[i] <= p) { if (p >= cs[i] && p <= ce[i] && miss[v] >= 0.7) { obs_var[off + q] = -1 - v; break; } ++i; }
+        ci = i > 0 ? i - 1 : 0;
     }
 }
 
@@ -817,10 +889,28 @@ void exscan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out
 void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const uint32_t *row_off, const int32_t *row_cnt,
                        const uint8_t *deleted, int32_t *obs_var, const uint16_t *obs_aq, const int32_t *vpos,
                        const int32_t *cnv_start, const int32_t *cnv_end, long long *agg_sum, int32_t *agg_cnt, double *miss,
-                       hipStream_t s) {
+                       CnvScratch &W, void *temp, size_t temp_bytes, hipStream_t s) {
+    // Everything below is launched unconditionally (no host round trip); with n_cnv == 0 the kept list is empty and every
+    // kernel returns at once.  Callers that know n_cnv == 0 on the host skip the whole block (see lps_abi.hip).
     HIP_TRY(hipMemsetAsync(agg_sum, 0, (size_t)n_var * 2 * sizeof(long long), s));
     HIP_TRY(hipMemsetAsync(agg_cnt, 0, (size_t)n_var * 2 * sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_cnv_filter_serial, dim3(1), dim3(64), 0, s, cnt, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, vpos, cnv_start, cnv_end, agg_sum, agg_cnt, miss, n_var);
+    const int nb = (n_reads + CNV_BLOCK - 1) / CNV_BLOCK;
+    hipLaunchKernelGGL(k_cnv_list, GRID(n_reads, 256), 0, s, cnt, n_reads, row_cnt, deleted, W.flag);
+    exscan_u32(temp, temp_bytes, W.flag, W.idx, n_reads, s);
+    hipLaunchKernelGGL(k_cnv_compact, GRID(n_reads, 256), 0, s, cnt, n_reads, W.flag, W.idx, W.list, W.n_list);
+    for (int pass4 = 0; pass4 < 2; ++pass4) {
+        if (pass4) hipLaunchKernelGGL(k_cnv_tables<true>, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, W.list, W.n_list, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss, W.tab);
+        else hipLaunchKernelGGL(k_cnv_tables<false>, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, W.list, W.n_list, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss, W.tab);
+        hipLaunchKernelGGL(k_cnv_block_compose, dim3(nb), dim3(64), 0, s, cnt, W.n_list, W.tab, W.btab);
+        hipLaunchKernelGGL(k_cnv_block_chain, dim3(1), dim3(64), 0, s, W.n_list, W.btab, W.bstart);
+        hipLaunchKernelGGL(k_cnv_entry, GRID(nb, 64), 0, s, W.n_list, W.tab, W.bstart, W.entry);
+        if (!pass4) {
+            hipLaunchKernelGGL(k_cnv_count, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, W.entry, row_off, row_cnt, obs_var, obs_aq, vpos, cnv_start, cnv_end, (unsigned long long *)agg_sum, agg_cnt);
+            hipLaunchKernelGGL(k_cnv_miss, GRID(n_var, 256), 0, s, cnt, n_var, vpos, cnv_start, cnv_end, (const unsigned long long *)agg_sum, agg_cnt, miss);
+        } else {
+            hipLaunchKernelGGL(k_cnv_erase, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, W.entry, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss);
+        }
+    }
 }
 
 void launch_clip_keys(const ClipView &C, const int32_t *row_fail, int n_reads, unsigned long long *keys, LpsCounters *cnt, hipStream_t s) {
