@@ -50,7 +50,7 @@ struct lps_ctx {
     DevBuf<unsigned long long> name_keys, name_keys_s;
     DevBuf<uint32_t> head, gidx, gstart, read_group, stack, mrow_off, koff; DevBuf<int32_t> mrow_cnt;
     // nodes / graph
-    DevBuf<uint32_t> is_node, vtype_key, node_of, node_off, node_end, bsize, cnt4;
+    DevBuf<uint32_t> is_node, vtype_key, node_of, node_off, node_end, node_cur, multi_list, bsize, cnt4;
     DevBuf<int32_t> nodes, block; DevBuf<uint8_t> ntype; DevBuf<unsigned long long> erec; DevBuf<unsigned> clip_stats; DevBuf<int8_t> hp, hp_v; DevBuf<int32_t> blk_v, seg_i32; DevBuf<char> st_b, st_e; DevBuf<uint32_t> node_pairs; DevBuf<uint8_t> nstate;
     DevBuf<unsigned long long> nkeys, nkeys_s; DevBuf<uint32_t> nvals, nvals_s;
     DevBuf<float> edge;
@@ -259,7 +259,7 @@ static int run_phase(lps_ctx *c) {
         c->name_keys.reserve(nR + 1); c->name_keys_s.reserve(nR + 1);
         c->head.reserve(nR + 1); c->gidx.reserve(nR + 1); c->gstart.reserve(nR + 2); c->read_group.reserve(nR + 1); c->stack.reserve(nR + 1);
         c->mrow_off.reserve(nR + 1); c->mrow_cnt.reserve(nR + 1); c->koff.reserve(nR + 1);
-        c->is_node.reserve(nV + 1); c->vtype_key.reserve(nV + 1); c->node_of.reserve(nV + 1); c->node_off.reserve(nV + 1); c->node_end.reserve(nV + 1);
+        c->is_node.reserve(nV + 1); c->vtype_key.reserve(nV + 1); c->node_of.reserve(nV + 1); c->node_off.reserve(nV + 2); c->node_end.reserve(nV + 2); c->node_cur.reserve(nV + 2); c->multi_list.reserve(nR + 1);
         c->bsize.reserve(nV + 1); c->cnt4.reserve((size_t)nV * 4 + 4); c->nodes.reserve(nV + 1); c->block.reserve(nV + 1);
         c->ntype.reserve(nV + 1); c->hp.reserve(nV + 1);
         c->erec.reserve((size_t)nV * A + 64); c->clip_stats.reserve(4);
@@ -328,15 +328,15 @@ static int run_phase(lps_ctx *c) {
         // ---- merged rows
         mark(c, ST_MERGE);
         HIP_TRY(hipMemsetAsync(c->mrow_cnt.p, 0, (size_t)(nR + 1) * 4, s));
-        launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, cap_main, tail_size, c->mrow_off.p, c->mrow_cnt.p, s);
+        launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, cap_main, tail_size, c->mrow_off.p, c->mrow_cnt.p, c->multi_list.p, s);
         // ---- node-major sorted lists
         mark(c, ST_NODELISTS);
         c->m_bits = bits_for((unsigned long long)nR + 1); c->n_bits = bits_for((unsigned long long)nV + 2); c->a_bits = 16;
         if (c->m_bits + c->n_bits + c->a_bits > 63) { c->err = "sort key overflow"; return -4; }
         c->nkeys.reserve(n_keys + 1); c->nkeys_s.reserve(n_keys + 1); c->nvals.reserve(n_keys + 1); c->nvals_s.reserve(n_keys + 1);
-        HIP_TRY(hipMemsetAsync(c->node_off.p, 0, (size_t)(nV + 1) * 4, s));
-        HIP_TRY(hipMemsetAsync(c->node_end.p, 0, (size_t)(nV + 1) * 4, s));
-        launch_node_lists(c->d_cnt, nR, nV, c->mrow_off.p, c->mrow_cnt.p, c->koff.p, c->g_node.p, c->m_bits, c->a_bits, c->n_bits, c->nkeys.p, c->nkeys_s.p, c->nvals.p, c->nvals_s.p, n_keys, c->node_off.p, c->node_end.p, c->temp.p, c->temp_bytes, s);
+        HIP_TRY(hipMemsetAsync(c->node_end.p, 0, (size_t)(nV + 2) * 4, s));      // per-node entry counts
+        HIP_TRY(hipMemsetAsync(c->node_cur.p, 0, (size_t)(nV + 2) * 4, s));      // scatter cursors
+        launch_node_lists(c->d_cnt, nR, nV, c->mrow_off.p, c->mrow_cnt.p, c->koff.p, c->g_node.p, c->m_bits, c->a_bits, c->n_bits, c->nkeys.p, c->nkeys_s.p, c->nvals.p, c->nvals_s.p, n_keys, c->node_off.p, c->node_end.p, c->node_cur.p, c->temp.p, c->temp_bytes, s);
         // ---- a11/a12 edges
         mark(c, ST_EDGES);
         launch_edges(c->d_cnt, nV, c->node_off.p, c->node_end.p, c->nkeys_s.p, c->nvals_s.p, c->mrow_off.p, c->mrow_cnt.p, c->m_bits, c->a_bits, c->g_node.p, c->g_flag.p, A, P.edge_weight, P.edge_threshold, c->ntype.p, c->edge.p, c->erec.p, c->node_pairs.p, s);

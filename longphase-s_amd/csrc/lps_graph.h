@@ -29,12 +29,12 @@ void launch_nodes(int n_reads, int n_var, const uint32_t *row_off, const int32_t
                   LpsCounters *cnt, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
                        const uint32_t *row_off, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
-                       unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, hipStream_t s);
+                       unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list, hipStream_t s);
 void launch_arena_sum(const unsigned long long *arena_ctr, unsigned long long arena_size, LpsCounters *cnt, hipStream_t s);
 void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t *mrow_off, const int32_t *mrow_cnt, uint32_t *koff,
                        const int32_t *g_node, int m_bits, int a_bits, int n_bits, unsigned long long *keys,
                        unsigned long long *keys_sorted, uint32_t *vals, uint32_t *vals_sorted, unsigned long long n_keys,
-                       uint32_t *node_off, uint32_t *node_end, void *temp, size_t temp_bytes, hipStream_t s);
+                       uint32_t *node_off, uint32_t *node_cnt, uint32_t *node_cur, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
                   const unsigned long long *skeys, const uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                   int m_bits, int a_bits, const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,

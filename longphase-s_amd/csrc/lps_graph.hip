@@ -4,7 +4,7 @@
 //   Clip::getCNVInterval (x2)            src/phase/PhasingGraph.cpp:1103-1227  -> k_clip_keys + sort + k_cnv_state
 //   VairiantGraph::addEdge overlap filter src/phase/PhasingGraph.cpp:707-781   -> k_name_keys + sort + k_group_* + k_overlap_filter
 //   addEdge type tagging / node set       :793-846                             -> k_mark_nodes + scan + k_graph_obs
-//   addEdge pair loop + addSubEdge        :848-888, :25-70                     -> k_merge_rows + k_node_keys + sort + k_edges
+//   addEdge pair loop + addSubEdge        :848-888, :25-70                     -> k_merge_plan/k_merge_multi + k_node_count/scatter/sort + k_edges
 //   findBestEdgePair                      :166-228                             -> epilogue of k_edges (edge-info byte)
 //   edgeConnectResult + Onelongcase       :286-474, :251-283                   -> k_vote_scan
 //   readCorrection + exportResult         :891-1029, :1049-1077                -> k_block_size + k_read_correction + k_final
@@ -404,64 +404,106 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const uint32_t *
 }
 
 // ================================================================================================ merged rows
-// thread per name group: one surviving alignment -> its own row; several -> concatenate in BAM order and sort by
-// position (== node index) into a freshly reserved tail row.  Insertion sort == libstdc++ std::sort for n<=16 and
-// differs from it only in the relative order of equal positions beyond that.
-__global__ void k_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt,
-                             const uint32_t *row_off, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
-                             unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt) {
+// Reads with ONE surviving alignment (the vast majority) use that alignment's row as their merged row.  Reads with several
+// (supplementary alignments kept by the overlap filter) get a freshly reserved tail row that holds the concatenation of their
+// rows in BAM order sorted by position (== node index): k_merge_plan (thread per name group) reserves it and queues the group,
+// k_merge_multi (wave per queued group) places every element by rank: own index + elements of the other rows that sort before it
+// (ties: earlier alignment first).  That is the stable order == libstdc++ std::sort for n <= 16 and differs from it only in the
+// relative order of equal positions beyond that.
+__global__ void k_merge_plan(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt,
+                             const uint32_t *row_off, const int32_t *g_cnt, unsigned long long tail_lo, unsigned long long tail_size,
+                             uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list) {
     const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= cnt->n_groups) return;
     const uint32_t s0 = gstart[g], s1 = gstart[g + 1];
+    if (s1 - s0 == 1) { const uint32_t r = (uint32_t)skeys[s0]; mrow_off[g] = row_off[r]; mrow_cnt[g] = g_cnt[r]; return; }
     int alive = 0, total = 0; uint32_t one = 0;
     for (uint32_t s = s0; s < s1; ++s) { const uint32_t r = (uint32_t)skeys[s]; if (g_cnt[r] > 0) { ++alive; total += g_cnt[r]; one = r; } }
     if (alive == 0) { mrow_off[g] = 0; mrow_cnt[g] = 0; return; }
     if (alive == 1) { mrow_off[g] = row_off[one]; mrow_cnt[g] = total; return; }
     const unsigned long long toff = atomicAdd(&cnt->tail_total, (unsigned long long)total);
-    const unsigned long long base = tail_lo + toff;
     if (toff + total > tail_size) { atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); mrow_off[g] = 0; mrow_cnt[g] = 0; return; }
-    atomicAdd(&cnt->n_multi, 1u);
-    int w = 0, last_nd = -1;
-    for (uint32_t s = s0; s < s1; ++s) {
-        const uint32_t r = (uint32_t)skeys[s];
-        const int n = g_cnt[r]; const uint32_t ro = row_off[r];
-        for (int k = 0; k < n; ++k) {
-            const int nd = g_node[ro + k]; const uint8_t fl = g_flag[ro + k];
-            if (nd >= last_nd) { g_node[base + w] = nd; g_flag[base + w] = fl; last_nd = nd; ++w; continue; }   // already in order
-            int j = w;                                       // stable insertion
-            while (j > 0 && g_node[base + j - 1] > nd) { g_node[base + j] = g_node[base + j - 1]; g_flag[base + j] = g_flag[base + j - 1]; --j; }
-            g_node[base + j] = nd; g_flag[base + j] = fl; ++w;
-        }
-    }
-    mrow_off[g] = (uint32_t)base; mrow_cnt[g] = total;
+    mrow_off[g] = (uint32_t)(tail_lo + toff); mrow_cnt[g] = total;
+    multi_list[atomicAdd(&cnt->n_multi, 1u)] = g;
 }
 
-// wave per merged row: sort keys (node | name rank | index in row) -> value = slot of the entry
-__global__ __launch_bounds__(256) void k_node_keys(const LpsCounters *cnt, const uint32_t *mrow_off, const int32_t *mrow_cnt,
-                                                   const uint32_t *koff, const int32_t *g_node, int m_bits, int a_bits,
-                                                   unsigned long long *keys, uint32_t *vals, unsigned long long n_keys, LpsCounters *cntw) {
+__global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *skeys, const uint32_t *gstart, const LpsCounters *cnt,
+                                                     const uint32_t *row_off, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
+                                                     const uint32_t *mrow_off, const uint32_t *multi_list) {
+    const int l = lane_id();
+    const unsigned n_waves = gridDim.x * 4;
+    for (unsigned q = blockIdx.x * 4 + (threadIdx.x >> 6); q < cnt->n_multi; q += n_waves) {
+        const unsigned g = multi_list[q];
+        const uint32_t s0 = gstart[g], s1 = gstart[g + 1];
+        const uint32_t base = mrow_off[g];
+        for (uint32_t sa = s0; sa < s1; ++sa) {                      // source alignment (BAM order inside the group)
+            const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = row_off[ra];
+            for (int k = l; k < na; k += 64) {
+                const int nd = g_node[oa + k]; const uint8_t fl = g_flag[oa + k];
+                int rank = k;
+                for (uint32_t sb = s0; sb < s1; ++sb) {
+                    if (sb == sa) continue;
+                    const uint32_t rb = (uint32_t)skeys[sb]; const int nb = g_cnt[rb]; const uint32_t ob = row_off[rb];
+                    // earlier alignment: its equal positions go first (count <= nd); later alignment: only smaller ones
+                    int lo = 0, hi = nb;
+                    if (sb < sa) { while (lo < hi) { const int m = (lo + hi) >> 1; if (g_node[ob + m] <= nd) lo = m + 1; else hi = m; } }
+                    else { while (lo < hi) { const int m = (lo + hi) >> 1; if (g_node[ob + m] < nd) lo = m + 1; else hi = m; } }
+                    rank += lo;
+                }
+                g_node[base + rank] = nd; g_flag[base + rank] = fl;
+            }
+        }
+    }
+}
+
+// ---- node-major lists: entries of node n = observations of n in merged rows, ordered by (name rank, index in merged row).
+// No global sort: count per node (atomics), exclusive scan, scatter in arbitrary order, then every node's short list is put in
+// order by rank counting inside one wave (n^2/64 compares for n entries; n ~ coverage).
+__global__ __launch_bounds__(256) void k_node_count(const LpsCounters *cnt, const uint32_t *mrow_off, const int32_t *mrow_cnt,
+                                                    const int32_t *g_node, uint32_t *node_cnt, LpsCounters *cntw, const uint32_t *koff) {
     const unsigned g = blockIdx.x * 4 + (threadIdx.x >> 6); const int l = lane_id();
     if (g >= cnt->n_groups) return;
     const int n = mrow_cnt[g];
     if (g + 1 == cnt->n_groups && l == 0) cntw->n_obs_final = (unsigned long long)koff[g] + (unsigned)n;   // = sum of merged rows
+    const uint32_t off = mrow_off[g];
+    for (int a = l; a < n; a += 64) atomicAdd(&node_cnt[g_node[off + a]], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_node_scatter(const LpsCounters *cnt, const uint32_t *mrow_off, const int32_t *mrow_cnt,
+                                                      const int32_t *g_node, const uint32_t *node_off, uint32_t *node_cur, int a_bits,
+                                                      unsigned long long *keys, uint32_t *vals, LpsCounters *cntw) {
+    const unsigned g = blockIdx.x * 4 + (threadIdx.x >> 6); const int l = lane_id();
+    if (g >= cnt->n_groups) return;
+    const int n = mrow_cnt[g];
     if (n > (1 << a_bits)) { if (l == 0) atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); return; }
-    const uint32_t off = mrow_off[g], ko = koff[g];
+    const uint32_t off = mrow_off[g];
     for (int a = l; a < n; a += 64) {
-        if ((unsigned long long)ko + a >= n_keys) continue;
-        keys[ko + a] = ((unsigned long long)(unsigned)g_node[off + a] << (m_bits + a_bits)) | ((unsigned long long)g << a_bits) | (unsigned)a;
-        vals[ko + a] = off + a;
+        const int nd = g_node[off + a];
+        const uint32_t slot = node_off[nd] + atomicAdd(&node_cur[nd], 1u);
+        keys[slot] = ((unsigned long long)g << a_bits) | (unsigned)a;      // (name rank, index in row)
+        vals[slot] = off + a;
     }
 }
 
-__global__ void k_node_offsets(const unsigned long long *skeys, unsigned long long n_keys, int shift, uint32_t *node_off,
-                               uint32_t *node_end) {
-    const unsigned long long s = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_keys) return;
-    const unsigned long long k = skeys[s];
-    if (k == ~0ull) return;
-    const uint32_t nd = (uint32_t)(k >> shift);
-    if (s == 0 || (uint32_t)(skeys[s - 1] >> shift) != nd) node_off[nd] = (uint32_t)s;
-    if (s + 1 == n_keys || skeys[s + 1] == ~0ull || (uint32_t)(skeys[s + 1] >> shift) != nd) node_end[nd] = (uint32_t)s + 1;
+// wave per node: order the node's entries by key (rank = number of smaller keys; keys are unique)
+__global__ __launch_bounds__(256) void k_node_sort(const LpsCounters *cnt, const uint32_t *node_off, const uint32_t *node_cnt,
+                                                   const unsigned long long *keys, const uint32_t *vals, unsigned long long *skeys, uint32_t *svals) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
+    if (i >= (int)cnt->n_nodes) return;
+    const uint32_t off = node_off[i]; const int n = (int)node_cnt[i];
+    if (n <= 64) {
+        const unsigned long long k = l < n ? keys[off + l] : ~0ull;
+        int rank = 0;
+        for (int t = 0; t < n; ++t) { const unsigned long long o = __shfl(k, t); rank += o < k; }
+        if (l < n) { skeys[off + rank] = k; svals[off + rank] = vals[off + l]; }
+    } else {
+        for (int a = l; a < n; a += 64) {
+            const unsigned long long k = keys[off + a];
+            int rank = 0;
+            for (int t = 0; t < n; ++t) rank += keys[off + t] < k;           // wave-uniform address: one broadcast load per step
+            skeys[off + rank] = k; svals[off + rank] = vals[off + a];
+        }
+    }
 }
 
 // ================================================================================================ edges
@@ -480,7 +522,7 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
     const int n_nodes = (int)cnt->n_nodes;
     if (i >= n_nodes) return;
-    const uint32_t off = node_off[i], end = node_end[i];
+    const uint32_t off = node_off[i], end = off + node_end[i];      // node_end holds the entry COUNT of the node
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     unsigned long long pairs = 0;
     const unsigned long long m_mask = (1ull << m_bits) - 1ull;
@@ -958,8 +1000,9 @@ void launch_nodes(int n_reads, int n_var, const uint32_t *row_off, const int32_t
 
 void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
                        const uint32_t *row_off, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
-                       unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, hipStream_t s) {
-    hipLaunchKernelGGL(k_merge_rows, GRID(n_reads, 128), 0, s, skeys, gstart, cnt, row_off, g_cnt, g_node, g_flag, tail_lo, tail_size, mrow_off, mrow_cnt);
+                       unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_plan, GRID(n_reads, 256), 0, s, skeys, gstart, cnt, row_off, g_cnt, tail_lo, tail_size, mrow_off, mrow_cnt, multi_list);
+    hipLaunchKernelGGL(k_merge_multi, dim3(256), dim3(256), 0, s, skeys, gstart, cnt, row_off, g_cnt, g_node, g_flag, mrow_off, multi_list);
 }
 
 __global__ void k_arena_sum(const unsigned long long *arena_ctr, unsigned long long arena_size, LpsCounters *cnt) {
@@ -979,14 +1022,14 @@ void launch_arena_sum(const unsigned long long *arena_ctr, unsigned long long ar
 void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t *mrow_off, const int32_t *mrow_cnt, uint32_t *koff,
                        const int32_t *g_node, int m_bits, int a_bits, int n_bits, unsigned long long *keys,
                        unsigned long long *keys_sorted, uint32_t *vals, uint32_t *vals_sorted, unsigned long long n_keys,
-                       uint32_t *node_off, uint32_t *node_end, void *temp, size_t temp_bytes, hipStream_t s) {
-    // koff = exclusive scan of mrow_cnt over groups (unused groups have mrow_cnt = 0 by memset)
+                       uint32_t *node_off, uint32_t *node_cnt, uint32_t *node_cur, void *temp, size_t temp_bytes, hipStream_t s) {
+    // koff = exclusive scan of mrow_cnt over groups (only used for the observation total)
     exscan_u32(temp, temp_bytes, reinterpret_cast<const uint32_t *>(mrow_cnt), koff, n_reads, s);
-    HIP_TRY(hipMemsetAsync(keys, 0xff, n_keys * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(k_node_keys, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, mrow_off, mrow_cnt, koff, g_node, m_bits, a_bits, keys, vals, n_keys, cnt);
-    sort_pairs64(temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, n_keys, n_bits + m_bits + a_bits, s);
-    if (n_keys) hipLaunchKernelGGL(k_node_offsets, GRID(n_keys, 256), 0, s, keys_sorted, n_keys, m_bits + a_bits, node_off, node_end);
-    (void)n_var;
+    hipLaunchKernelGGL(k_node_count, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, mrow_off, mrow_cnt, g_node, node_cnt, cnt, koff);
+    exscan_u32(temp, temp_bytes, node_cnt, node_off, (size_t)n_var + 1, s);
+    hipLaunchKernelGGL(k_node_scatter, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, mrow_off, mrow_cnt, g_node, node_off, node_cur, a_bits, keys, vals, cnt);
+    hipLaunchKernelGGL(k_node_sort, dim3((n_var + 3) / 4), dim3(256), 0, s, cnt, node_off, node_cnt, keys, vals, keys_sorted, vals_sorted);
+    (void)m_bits; (void)n_bits; (void)n_keys;
 }
 
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
