@@ -1,0 +1,56 @@
+"""CPU-side checks of the host CLI: its BGZF/BAM decoder against the SAM text the BAM was made from,
+and that `phase` refuses to run without the HIP device instead of falling back to anything."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from util import write_bam
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "golden", "data")
+CLI = os.path.join(HERE, "..", "longphase-s_amd", "cli", "longphase_amd")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CLI), reason="CLI not built (make -C longphase-s_amd cli)")
+
+
+@pytest.mark.parametrize("name,threads,block", [("tiny_snp", 1, 60000), ("tiny_indel", 3, 4096)])
+def test_bam_reader_round_trip(name, threads, block, tmp_path):
+    bam = str(tmp_path / "x.bam")
+    n = write_bam(os.path.join(DATA, name + ".sam.gz"), bam, block=block)   # small blocks: records straddle BGZF blocks
+    r = subprocess.run([CLI, "view", bam, "chrS", str(threads)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = [l.split("\t") for l in r.stdout.splitlines()]
+    want = [l.rstrip("\n").split("\t") for l in gzip.open(os.path.join(DATA, name + ".sam.gz"), "rt") if not l.startswith("@")]
+    assert len(got) == len(want) == n
+    for g, w in zip(got, want):
+        assert [g[i] for i in (0, 1, 3, 4, 5, 9, 10)] == [w[i] for i in (0, 1, 3, 4, 5, 9, 10)]
+
+
+def test_bam_reader_rejects_garbage(tmp_path):
+    p = tmp_path / "bad.bam"
+    p.write_bytes(b"this is not a bam file at all........")
+    r = subprocess.run([CLI, "view", str(p), "chrS"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "not a BGZF" in r.stderr
+
+
+def test_phase_argument_errors():
+    r = subprocess.run([CLI, "phase", "-s", "x.vcf"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "missing arguments" in r.stderr
+    r = subprocess.run([CLI, "phase", "-s", "x.vcf", "-b", "x.bam", "-r", "x.fa"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "--ont or --pb" in r.stderr          # src/phase/Phasing.cpp:175-183
+    r = subprocess.run([CLI, "phase", "-s", "x.vcf", "-b", "x.bam", "-r", "x.fa", "--ont", "--sv-file", "y.vcf"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "not supported" in r.stderr
+
+
+def test_phase_without_gpu_fails_loudly(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    bam = str(tmp_path / "x.bam")
+    write_bam(os.path.join(DATA, "tiny_snp.sam.gz"), bam)
+    r = subprocess.run([CLI, "phase", "-s", os.path.join(DATA, "tiny_snp.vcf"), "-b", bam, "-r", os.path.join(DATA, "tiny_snp.fa"),
+                        "-o", str(tmp_path / "o"), "--ont"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
+    assert not os.path.exists(str(tmp_path / "o.vcf"))

@@ -144,3 +144,47 @@ def assert_somatic_tags_equal(out, hp, ps, pq, what=""):
     m = hp != 0
     assert np.array_equal(out.ps[m], ps[m]), f"{what}: PS mismatch"
     assert np.array_equal(out.pq[m], pq[m]), f"{what}: PQ mismatch"
+
+
+def write_bam(sam_path, bam_path, block=60000):
+    """SAM(.gz) text -> BAM (BGZF, SAM spec §4): test-side writer so the CLI's own BGZF/BAM reader is exercised
+    on files that never passed through htslib.  No index; aux fields are dropped."""
+    import re, struct, zlib
+    op = gzip.open if sam_path.endswith(".gz") else open
+    header, recs, refs = [], [], []
+    for line in op(sam_path, "rt"):
+        if line.startswith("@"):
+            header.append(line)
+            if line.startswith("@SQ"):
+                d = dict(x.split(":", 1) for x in line.rstrip("\n").split("\t")[1:])
+                refs.append((d["SN"], int(d["LN"])))
+            continue
+        recs.append(line.rstrip("\n").split("\t"))
+    tid = {n: i for i, (n, _) in enumerate(refs)}
+    text = "".join(header).encode()
+    out = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs)))
+    for n, ln in refs:
+        out += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", ln)
+    for f in recs:
+        name = f[0].encode() + b"\0"
+        cig = [(int(ln) << 4) | _OPS[o] for ln, o in re.findall(r"(\d+)([MIDNSHP=XB])", f[5])]
+        s = "" if f[9] == "*" else f[9]
+        packed = bytearray((len(s) + 1) // 2)
+        for j, c in enumerate(s):
+            packed[j >> 1] |= _NT16.get(c, 15) << (4 if (j & 1) == 0 else 0)
+        q = bytes((ord(c) - 33) for c in f[10]) if f[10] != "*" else bytes([255]) * len(s)
+        pos = int(f[3]) - 1
+        body = struct.pack("<iiBBHHHiiii", tid.get(f[2], -1), pos, len(name), int(f[4]), 4680, len(cig), int(f[1]), len(s),
+                           tid.get(f[6] if f[6] != "=" else f[2], -1), int(f[7]) - 1, int(f[8]))
+        body += name + struct.pack("<%dI" % len(cig), *cig) + bytes(packed) + q
+        out += struct.pack("<i", len(body)) + body
+    with open(bam_path, "wb") as fo:
+        def put(chunk):
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            comp = c.compress(bytes(chunk)) + c.flush()
+            fo.write(struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25))
+            fo.write(comp + struct.pack("<II", zlib.crc32(bytes(chunk)) & 0xFFFFFFFF, len(chunk)))
+        for a in range(0, len(out), block):
+            put(out[a:a + block])
+        put(b"")
+    return len(recs)
