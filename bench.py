@@ -76,15 +76,37 @@ def cpu_baseline(seed, threads, sample_mb=8):
                     assert r.returncode == 0, r.stderr[-500:]
                 ts.sort()
                 n_ph = sum(1 for ln in open(d + "/out.vcf") if not ln.startswith("#") and not ln.rstrip().endswith(":."))
+                e2e = cli_e2e(d, threads, ts[1], n_ph)
             out = dict(value=float(n_ph / ts[1]), unit="SNPs/s", cores=threads, kind="reference",
                        sample=sample + f"; median of 3 runs of `longphase-s phase -t {threads}` end to end (one contig => one compute thread, the rest feed BGZF)",
-                       port_value=port["value"], port_note=port["note"])
+                       port_value=port["value"], port_note=port["note"], e2e=e2e)
         except Exception as e:  # noqa: BLE001
             log("cpu_baseline: reference run failed, using the port:", repr(e)[:300])
     if not out:
         out = port
     s.close()
     return out
+
+
+def cli_e2e(d, threads, ref_wall, n_ph):
+    """Clock E of SURVEY.md §8d: the drop-in CLI (longphase-s_amd/cli/longphase_amd: BGZF inflate + BAM decode + GPU path +
+    VCF rewrite, process start to exit) on the very files the reference binary was just timed on, and a byte
+    comparison of the two output VCFs (minus the version / command-line header lines)."""
+    cli = os.path.join(ROOT, "longphase-s_amd", "cli", "longphase_amd")
+    if not os.path.exists(cli):
+        return None
+    cmd = [cli, "phase", "-s", "in.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(threads), "-o", "gpu", "--ont"]
+    ts = []
+    for _ in range(3):
+        t0 = time.time(); r = subprocess.run(cmd, cwd=d, capture_output=True); ts.append(time.time() - t0)
+        if r.returncode != 0:
+            return {"error": r.stderr.decode()[-300:]}
+    ts.sort()
+    body = lambda p: [l for l in open(p) if not l.startswith("##commandline=") and not l.startswith("##longphaseVersion=")]  # noqa: E731
+    stages = r.stderr.decode().strip().splitlines()[-1] if r.stderr else ""
+    return {"cli_wall_s": round(ts[1], 3), "cli_stages": stages, "reference_wall_s": round(ref_wall, 3), "speedup": round(ref_wall / ts[1], 2),
+            "cli_snps_per_s": float(n_ph / ts[1]), "identical_vcf": body(d + "/gpu.vcf") == body(d + "/out.vcf"),
+            "note": "same BAM/VCF/FASTA files, process start to exit, median of 3; CLI wall includes HIP runtime start-up"}
 
 
 def main():
@@ -96,6 +118,7 @@ def main():
     ap.add_argument("--seed", type=int, default=101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--cpu-sample-mb", type=int, default=8, help="contig length of the bounded cpu_baseline / CLI end-to-end sample")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -215,7 +238,7 @@ def main():
         }
         if not a.no_cpu_baseline:
             t0 = time.time()
-            res["cpu_baseline"] = cpu_baseline(a.seed, min(16, ncpu))
+            res["cpu_baseline"] = cpu_baseline(a.seed, min(16, ncpu), a.cpu_sample_mb)
             log(f"cpu baseline took {time.time()-t0:.1f}s")
         print(json.dumps(res), flush=True)
     ctx.close()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 2
+#define LPS_ABI_VERSION 3
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -226,6 +226,14 @@ int lps_set_variants(lps_ctx *ctx, const lps_variant_table *table);
 int lps_set_reference(lps_ctx *ctx, const char *seq, int64_t len);
 /* Append decoded alignments (H2D copy).  May be called repeatedly (batches / several BAM files). */
 int lps_push_reads(lps_ctx *ctx, const lps_read_batch *batch);
+/* Append alignments as RAW (inflated) BAM records - what `sam_itr_multi_next` fills into bam1_t in the loop of
+ * direct_detect_alleles (src/phase/ParsingBam.cpp:1279) / processSingleChrom (src/haplotag/HaplotagParsingBam.cpp:453),
+ * before any field is decoded.  `records` = n_bytes of the uncompressed BAM stream covering the records (anything
+ * between records is ignored); rec_off[i] = byte offset, inside `records`, of record i's refID field (its 4-byte
+ * block_size sits just before).  The record core, the CIGAR re-alignment and the seq/qual addressing are decoded on the GPU;
+ * seq and qual are used in place.  name_id as in lps_read_batch.  Records must be coordinate-sorted and of one contig.
+ * Cannot be mixed with lps_push_reads inside one chromosome.  CIGARs moved to a CG tag (>65535 ops) are rejected. */
+int lps_push_bam_records(lps_ctx *ctx, const uint8_t *records, int64_t n_bytes, const uint64_t *rec_off, int64_t n_records, const uint32_t *name_id);
 
 /* phase: everything between direct_detect_alleles and exportResult for the reads pushed so far.
  * Recomputes from the resident raw reads on every call (nothing is cached between calls). */

@@ -7,14 +7,22 @@
 //   per-chromosome driver                     src/phase/PhasingProcess.cpp:113-173   (the hot path is one lps_phase_chromosome call)
 //   SnpParser::writeLine (VCF rewrite rules)  src/phase/ParsingBam.cpp:460-635
 // Not supported (the reference path must be used): --sv-file, --mod-file, --dot, --deepsomatic_output, CRAM, CIGARs in CG tags.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <iterator>
 #include <map>
@@ -30,90 +38,130 @@ static const char *kVersion = "1.0.0-mi355x";
 
 [[noreturn]] static void die(const std::string &m) { std::cerr << m << "\n"; exit(1); }
 
+// ------------------------------------------------------------------------------------------------ the library, loaded at run time
+// liblps_hip.so (and with it the ROCm runtime) is dlopen'ed from a helper thread so that loading it and creating the GPU context
+// overlap with reading the inputs; the CLI binary itself has no GPU dependency (its `view` subcommand runs anywhere).
+struct Lps {
+    void *so = nullptr;
+    decltype(&lps_default_params) default_params = nullptr; decltype(&lps_create) create = nullptr; decltype(&lps_destroy) destroy = nullptr;
+    decltype(&lps_last_error) last_error = nullptr; decltype(&lps_begin_chromosome) begin_chromosome = nullptr; decltype(&lps_set_variants) set_variants = nullptr;
+    decltype(&lps_set_reference) set_reference = nullptr; decltype(&lps_push_bam_records) push_bam_records = nullptr; decltype(&lps_phase_chromosome) phase_chromosome = nullptr;
+    decltype(&lps_haplotag_chromosome) haplotag_chromosome = nullptr; decltype(&lps_abi_version) abi_version = nullptr;
+    std::string error;
+    bool load() {
+        char exe[4096]; const ssize_t k = readlink("/proc/self/exe", exe, sizeof exe - 1);
+        std::string dir = "."; if (k > 0) { exe[k] = 0; dir = exe; dir = dir.substr(0, dir.find_last_of('/')); }
+        const char *env = getenv("LPS_HIP_LIBRARY");
+        const std::string path = env ? env : dir + "/../csrc/liblps_hip.so";
+        so = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!so) { error = std::string("cannot load ") + path + ": " + dlerror() + " (the GPU library is required; there is no CPU fallback)"; return false; }
+#define LPS_SYM(field, name) field = (decltype(field))dlsym(so, #name); if (!field) { error = "liblps_hip.so does not export " #name; return false; }
+        LPS_SYM(default_params, lps_default_params) LPS_SYM(create, lps_create) LPS_SYM(destroy, lps_destroy) LPS_SYM(last_error, lps_last_error)
+        LPS_SYM(begin_chromosome, lps_begin_chromosome) LPS_SYM(set_variants, lps_set_variants) LPS_SYM(set_reference, lps_set_reference)
+        LPS_SYM(push_bam_records, lps_push_bam_records) LPS_SYM(phase_chromosome, lps_phase_chromosome) LPS_SYM(haplotag_chromosome, lps_haplotag_chromosome)
+        LPS_SYM(abi_version, lps_abi_version)
+#undef LPS_SYM
+        if (abi_version() != LPS_ABI_VERSION) { error = "liblps_hip.so has a different ABI version than this binary was built for"; return false; }
+        return true;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ BGZF / BAM
 struct Bgzf {
-    // whole-file reader: locate the BGZF blocks, inflate them with a thread pool, expose one contiguous byte stream
-    std::vector<uint8_t> data;
+    // whole-file reader: mmap the file, locate the BGZF blocks (18-byte headers), inflate them with a thread pool into one
+    // contiguous byte stream (not zero-initialised: every byte is written by exactly one inflate call)
+    uint8_t *data = nullptr; size_t size = 0;
+    ~Bgzf() { free(data); }
     void load(const std::string &path, int threads) {
-        std::ifstream f(path, std::ios::binary);
-        if (!f) die("ERROR: Cannot open bam file " + path);
-        std::vector<uint8_t> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) die("ERROR: Cannot open bam file " + path);
+        struct stat st; if (fstat(fd, &st) != 0) die("ERROR: Cannot stat " + path);
+        const size_t fsz = (size_t)st.st_size;
+        const uint8_t *raw = fsz ? (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+        if (fsz && raw == (const uint8_t *)MAP_FAILED) die("ERROR: Cannot map " + path);
+        if (fsz) madvise((void *)raw, fsz, MADV_SEQUENTIAL | MADV_WILLNEED);
         struct Blk { size_t off, clen, uoff, ulen; };
         std::vector<Blk> blks; size_t p = 0, utot = 0;
-        while (p + 18 <= raw.size()) {
+        while (p + 18 <= fsz) {
             if (raw[p] != 31 || raw[p + 1] != 139) die("ERROR: " + path + " is not a BGZF/BAM file");
             const unsigned xlen = raw[p + 10] | (raw[p + 11] << 8);
             size_t q = p + 12, bsize = 0;
-            while (q + 4 <= p + 12 + xlen) {                             // BC subfield carries BSIZE
+            while (q + 4 <= p + 12 + xlen && q + 4 <= fsz) {                // BC subfield carries BSIZE
                 const unsigned slen = raw[q + 2] | (raw[q + 3] << 8);
                 if (raw[q] == 'B' && raw[q + 1] == 'C' && slen == 2) bsize = (raw[q + 4] | (raw[q + 5] << 8)) + 1;
                 q += 4 + slen;
             }
-            if (!bsize || p + bsize > raw.size()) die("ERROR: truncated BGZF block in " + path);
+            if (!bsize || bsize < 12 + xlen + 8 || p + bsize > fsz) die("ERROR: truncated BGZF block in " + path);
             const size_t isize = raw[p + bsize - 4] | (raw[p + bsize - 3] << 8) | (raw[p + bsize - 2] << 16) | ((size_t)raw[p + bsize - 1] << 24);
             blks.push_back({p + 12 + xlen, bsize - 12 - xlen - 8, utot, isize});
             utot += isize; p += bsize;
         }
-        data.resize(utot);
+        if (p != fsz || blks.empty()) die("ERROR: " + path + " is not a BGZF/BAM file");
+        data = (uint8_t *)malloc(utot + 64); size = utot;
+        if (!data) die("ERROR: out of memory inflating " + path);
         const int nt = std::max(1, threads);
-        std::vector<std::thread> th; std::vector<int> bad(nt, 0);
+        std::vector<std::thread> th; std::vector<int> bad(nt, 0); std::atomic<size_t> next{0};
         for (int t = 0; t < nt; ++t) th.emplace_back([&, t] {
-            for (size_t b = t; b < blks.size(); b += nt) {
-                if (!blks[b].ulen) continue;
-                z_stream zs{}; zs.next_in = raw.data() + blks[b].off; zs.avail_in = (uInt)blks[b].clen;
-                zs.next_out = data.data() + blks[b].uoff; zs.avail_out = (uInt)blks[b].ulen;
-                if (inflateInit2(&zs, -15) != Z_OK || inflate(&zs, Z_FINISH) != Z_STREAM_END) bad[t] = 1;
-                inflateEnd(&zs);
+            z_stream zs{}; if (inflateInit2(&zs, -15) != Z_OK) { bad[t] = 1; return; }
+            for (;;) {
+                const size_t b0 = next.fetch_add(16); if (b0 >= blks.size()) break;
+                for (size_t b = b0; b < std::min(blks.size(), b0 + 16); ++b) {
+                    if (!blks[b].ulen) continue;
+                    inflateReset(&zs);
+                    zs.next_in = const_cast<uint8_t *>(raw) + blks[b].off; zs.avail_in = (uInt)blks[b].clen;
+                    zs.next_out = data + blks[b].uoff; zs.avail_out = (uInt)blks[b].ulen;
+                    if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) bad[t] = 1;
+                }
             }
+            inflateEnd(&zs);
         });
         for (auto &x : th) x.join();
+        if (fsz) munmap((void *)raw, fsz);
+        close(fd);
         for (int x : bad) if (x) die("ERROR: inflate failed in " + path);
-    }
-};
-
-struct ReadPack {   // SoA of one chromosome, laid out as lps_read_batch wants it
-    std::vector<int32_t> ref_start, l_qseq; std::vector<uint16_t> flag; std::vector<uint8_t> mapq; std::vector<uint32_t> name_id;
-    std::vector<uint64_t> cigar_off{0}, seq_off{0}, qual_off{0}; std::vector<uint32_t> cigar; std::vector<uint8_t> seq, qual;
-    std::vector<std::string> names;
-    void assign_name_ids() {                                         // equal names <=> equal id, order = std::string operator<
-        std::vector<uint32_t> idx(names.size()); std::iota(idx.begin(), idx.end(), 0u);
-        std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return names[a] < names[b]; });
-        name_id.resize(names.size()); uint32_t id = 0;
-        for (size_t k = 0; k < idx.size(); ++k) { if (k && names[idx[k]] != names[idx[k - 1]]) ++id; name_id[idx[k]] = id; }
-    }
-    lps_read_batch view() const {
-        return lps_read_batch{(int64_t)ref_start.size(), ref_start.data(), flag.data(), mapq.data(), l_qseq.data(), name_id.data(),
-                              cigar_off.data(), cigar.data(), seq_off.data(), seq.data(), qual_off.data(), qual.data()};
     }
 };
 
 static uint32_t rd32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-// decode every record of a BAM into per-contig packs (only contigs in `want`)
-static void read_bam(const std::string &path, int threads, const std::map<std::string, int> &want, std::map<std::string, ReadPack> &packs) {
-    Bgzf z; z.load(path, threads);
-    const uint8_t *d = z.data.data(); const size_t n = z.data.size();
-    if (n < 12 || memcmp(d, "BAM\1", 4)) die("ERROR: " + path + " is not a BAM file");
-    size_t p = 4; const uint32_t l_text = rd32(d + p); p += 4 + l_text;
-    const uint32_t n_ref = rd32(d + p); p += 4;
-    std::vector<std::string> ref_names(n_ref);
-    for (uint32_t i = 0; i < n_ref; ++i) { const uint32_t l = rd32(d + p); p += 4; ref_names[i] = std::string((const char *)d + p, l - 1); p += l + 4; }
-    std::vector<ReadPack *> dst(n_ref, nullptr);
-    for (uint32_t i = 0; i < n_ref; ++i) if (want.count(ref_names[i])) dst[i] = &packs[ref_names[i]];
-    while (p + 4 <= n) {
-        const uint32_t bs = rd32(d + p); const uint8_t *r = d + p + 4; p += 4 + bs;
-        if (p > n) die("ERROR: truncated BAM record in " + path);
-        const int32_t tid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
-        const uint32_t l_name = r[8], mq = r[9], n_cig = r[12] | (r[13] << 8), fl = r[14] | (r[15] << 8), l_seq = rd32(r + 16);
-        if (tid < 0 || tid >= (int32_t)n_ref || !dst[tid]) continue;
-        ReadPack &k = *dst[tid];
-        const uint8_t *q = r + 32;
-        k.names.emplace_back((const char *)q, l_name ? l_name - 1 : 0); q += l_name;
-        k.ref_start.push_back(pos); k.flag.push_back((uint16_t)fl); k.mapq.push_back((uint8_t)mq); k.l_qseq.push_back((int32_t)l_seq);
-        const size_t c0 = k.cigar.size(); k.cigar.resize(c0 + n_cig); memcpy(k.cigar.data() + c0, q, 4ull * n_cig); q += 4ull * n_cig; k.cigar_off.push_back(k.cigar.size());
-        k.seq.insert(k.seq.end(), q, q + (l_seq + 1) / 2); q += (l_seq + 1) / 2; k.seq_off.push_back(k.seq.size());
-        k.qual.insert(k.qual.end(), q, q + l_seq); k.qual_off.push_back(k.qual.size());
+// One BAM file, inflated, plus where every record of every wanted contig sits in it.  Nothing is decoded on the host except
+// refID (to route the record) and the read name (to rank it); the rest is lps_push_bam_records' job on the GPU.
+struct ContigRecords { std::vector<uint64_t> rec_off; uint64_t lo = 0, hi = 0; };   // offsets relative to `lo`
+struct BamFile {
+    Bgzf z; std::vector<std::string> ref_names; std::map<std::string, ContigRecords> contigs;
+    void load(const std::string &path, int threads, const std::map<std::string, int> &want) {
+        z.load(path, threads);
+        const uint8_t *d = z.data; const size_t n = z.size;
+        if (n < 12 || memcmp(d, "BAM\1", 4)) die("ERROR: " + path + " is not a BAM file");
+        size_t p = 4; const uint32_t l_text = rd32(d + p); p += 4 + (size_t)l_text;
+        if (p + 4 > n) die("ERROR: truncated BAM header in " + path);
+        const uint32_t n_ref = rd32(d + p); p += 4;
+        ref_names.resize(n_ref);
+        for (uint32_t i = 0; i < n_ref; ++i) { if (p + 4 > n) die("ERROR: truncated BAM header in " + path); const uint32_t l = rd32(d + p); p += 4; if (!l || p + l + 4 > n) die("ERROR: truncated BAM header in " + path); ref_names[i] = std::string((const char *)d + p, l - 1); p += l + 4; }
+        std::vector<ContigRecords *> dst(n_ref, nullptr);
+        for (uint32_t i = 0; i < n_ref; ++i) if (want.count(ref_names[i])) dst[i] = &contigs[ref_names[i]];
+        while (p + 4 <= n) {
+            const uint32_t bs = rd32(d + p);
+            if (bs < 32 || p + 4 + bs > n) die("ERROR: truncated BAM record in " + path);
+            const int32_t tid = (int32_t)rd32(d + p + 4);
+            if (tid >= 0 && tid < (int32_t)n_ref && dst[tid]) {
+                ContigRecords &c = *dst[tid];
+                if (c.rec_off.empty()) c.lo = p;
+                c.rec_off.push_back(p + 4 - c.lo); c.hi = p + 4 + bs;
+            }
+            p += 4 + (size_t)bs;
+        }
     }
+    const char *name_of(const ContigRecords &c, size_t i, size_t &len) const { const uint8_t *r = z.data + c.lo + c.rec_off[i]; len = r[8] ? r[8] - 1u : 0u; return (const char *)r + 32; }
+};
+
+// equal names <=> equal id, order = std::string operator< (the std::map<std::string,...> order of PhasingGraph.cpp:833,848)
+static void rank_names(const std::vector<std::pair<const char *, size_t>> &names, std::vector<uint32_t> &id) {
+    std::vector<uint32_t> idx(names.size()); std::iota(idx.begin(), idx.end(), 0u);
+    auto less = [&](uint32_t a, uint32_t b) { const size_t m = std::min(names[a].second, names[b].second); const int c = memcmp(names[a].first, names[b].first, m); return c ? c < 0 : names[a].second < names[b].second; };
+    std::sort(idx.begin(), idx.end(), less);
+    id.resize(names.size()); uint32_t cur = 0;
+    for (size_t k = 0; k < idx.size(); ++k) { if (k && (less(idx[k - 1], idx[k]) || less(idx[k], idx[k - 1]))) ++cur; id[idx[k]] = cur; }
 }
 
 // ------------------------------------------------------------------------------------------------ text inputs
@@ -234,7 +282,7 @@ static const char *kUsage =
     "   -1 edgeThreshold(0.7)  -L overlapThreshold(0.2)  -m readConfidence(0.65)  -n snpConfidence(0.75)  --gpu=ID (0)\n";
 
 static int phase_main(int argc, char **argv, const std::string &command) {
-    lps_params P; lps_default_params(&P);
+    std::vector<std::function<void(lps_params &)>> over; bool indels = false;
     std::string snp, ref, prefix = "result"; std::vector<std::string> bams; int threads = 1, gpu = 0; bool ont = false, pb = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
@@ -247,16 +295,16 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "-o" || a == "--out-prefix") prefix = val();
         else if (a == "-t" || a == "--threads") threads = std::stoi(val());
         else if (a == "--ont") ont = true; else if (a == "--pb") pb = true;
-        else if (a == "--indels") P.phase_indel = 1;
-        else if (a == "-q" || a == "--mappingQuality") P.mapping_quality = std::stoi(val());
-        else if (a == "-p" || a == "--baseQuality") P.base_quality = std::stoi(val());
-        else if (a == "-e" || a == "--edgeWeight") P.edge_weight = std::stod(val());
-        else if (a == "-a" || a == "--connectAdjacent") P.connect_adjacent = std::stoi(val());
-        else if (a == "-d" || a == "--distance") P.distance = std::stoi(val());
-        else if (a == "-1" || a == "--edgeThreshold") P.edge_threshold = std::stod(val());
-        else if (a == "-L" || a == "--overlapThreshold") P.overlap_threshold = std::stod(val());
-        else if (a == "-m" || a == "--readConfidence") P.read_confidence = std::stod(val());
-        else if (a == "-n" || a == "--snpConfidence") P.snp_confidence = std::stod(val());
+        else if (a == "--indels") { indels = true; over.push_back([](lps_params &P) { P.phase_indel = 1; }); }
+        else if (a == "-q" || a == "--mappingQuality") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.mapping_quality = x; }); }
+        else if (a == "-p" || a == "--baseQuality") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.base_quality = x; }); }
+        else if (a == "-e" || a == "--edgeWeight") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.edge_weight = x; }); }
+        else if (a == "-a" || a == "--connectAdjacent") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.connect_adjacent = x; }); }
+        else if (a == "-d" || a == "--distance") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.distance = x; }); }
+        else if (a == "-1" || a == "--edgeThreshold") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.edge_threshold = x; }); }
+        else if (a == "-L" || a == "--overlapThreshold") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.overlap_threshold = x; }); }
+        else if (a == "-m" || a == "--readConfidence") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.read_confidence = x; }); }
+        else if (a == "-n" || a == "--snpConfidence") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.snp_confidence = x; }); }
         else if (a == "-x" || a == "--mismatchRate") (void)val();
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--help") { std::cout << kUsage; return 0; }
@@ -265,60 +313,295 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     }
     if (snp.empty() || bams.empty() || ref.empty()) { std::cerr << "longphase_amd phase: missing arguments\n" << kUsage; return 1; }
     if (ont == pb) { std::cerr << "longphase_amd phase: missing arguments. --ont or --pb\n" << kUsage; return 1; }   // Phasing.cpp:175-183
-    P.is_ont = ont;
+    over.push_back([ont](lps_params &P) { P.is_ont = ont; });
 
+    Lps L; lps_ctx *ctx = nullptr;
+    std::thread gpu_init([&] { if (!L.load()) return; lps_params P; L.default_params(&P); for (auto &f : over) f(P); ctx = L.create(gpu, &P); if (!ctx) L.error = "cannot create a GPU context (no CPU fallback)"; });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{gpu_init};
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     std::vector<std::string> vcf_lines;
     if (!read_lines(snp, vcf_lines)) die("ERROR: Cannot open vcf file " + snp);
     std::vector<std::string> chr_order; std::map<std::string, ChrVariants> vars;
-    parse_vcf(vcf_lines, P.phase_indel != 0, chr_order, vars);
+    parse_vcf(vcf_lines, indels, chr_order, vars);
     std::map<std::string, int> want; for (auto &kv : vars) if (!kv.second.pos.empty()) want[kv.first] = 1;
     std::map<std::string, std::string> seqs; read_fasta(ref, vars, seqs);
-    std::map<std::string, ReadPack> packs;
-    for (const std::string &b : bams) read_bam(b, threads, want, packs);
+    const double t_text = now();
+    std::vector<BamFile> files(bams.size());
+    for (size_t b = 0; b < bams.size(); ++b) files[b].load(bams[b], threads, want);
+    const double t_bam = now();
 
-    lps_ctx *ctx = lps_create(gpu, &P);
-    if (!ctx) die("longphase_amd: cannot create a GPU context (no CPU fallback)");
+    gpu_init.join();
+    if (!ctx) die("longphase_amd: " + L.error);
+    const double t_ctx = now();
     std::map<std::string, std::map<int32_t, Phased>> res;
     for (const std::string &chr : chr_order) {                       // PhasingProcess.cpp:113-173
         ChrVariants &cv = vars[chr];
-        if (cv.pos.empty() || !packs.count(chr) || !seqs.count(chr)) continue;
-        ReadPack &pk = packs[chr];
-        if (pk.ref_start.empty()) continue;
-        pk.assign_name_ids();
+        if (cv.pos.empty() || !seqs.count(chr)) continue;
+        // names of all files of this contig ranked together (one read name = one merged row, whatever file it came from)
+        std::vector<std::pair<const char *, size_t>> names; std::vector<const ContigRecords *> parts;
+        for (BamFile &f : files) { auto it = f.contigs.find(chr); if (it == f.contigs.end() || it->second.rec_off.empty()) { parts.push_back(nullptr); continue; }
+            parts.push_back(&it->second); for (size_t i = 0; i < it->second.rec_off.size(); ++i) { size_t l; const char *nm = f.name_of(it->second, i, l); names.emplace_back(nm, l); } }
+        if (names.empty()) continue;
+        std::vector<uint32_t> name_id; rank_names(names, name_id);
         std::vector<uint8_t> r0(cv.pos.size()), a0(cv.pos.size()); std::vector<uint16_t> rl(cv.pos.size()), al(cv.pos.size());
         for (size_t i = 0; i < cv.pos.size(); ++i) { r0[i] = (uint8_t)cv.ref[i][0]; a0[i] = (uint8_t)cv.alt[i][0]; rl[i] = (uint16_t)cv.ref[i].size(); al[i] = (uint16_t)cv.alt[i].size(); }
         lps_variant_table vt{}; vt.n = (int64_t)cv.pos.size(); vt.pos = cv.pos.data(); vt.ref0 = r0.data(); vt.alt0 = a0.data(); vt.ref_len = rl.data(); vt.alt_len = al.data();
         const std::string &sq = seqs[chr];
-        lps_read_batch rb = pk.view();
+        if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size())) die(std::string("longphase_amd: ") + L.last_error(ctx));
+        size_t at = 0;
+        for (size_t b = 0; b < files.size(); ++b) {                  // BAM files in -b order (ParsingBam.cpp:1252)
+            if (!parts[b]) continue;
+            const ContigRecords &c = *parts[b];
+            if (L.push_bam_records(ctx, files[b].z.data + c.lo, (int64_t)(c.hi - c.lo), c.rec_off.data(), (int64_t)c.rec_off.size(), name_id.data() + at))
+                die(std::string("longphase_amd: ") + L.last_error(ctx));
+            at += c.rec_off.size();
+        }
         std::vector<int32_t> ps(cv.pos.size()); std::vector<uint8_t> gt(cv.pos.size());
         lps_phase_result pr{(int64_t)cv.pos.size(), ps.data(), gt.data()};
-        if (lps_begin_chromosome(ctx) || lps_set_variants(ctx, &vt) || lps_set_reference(ctx, sq.data(), (int64_t)sq.size()) || lps_push_reads(ctx, &rb) ||
-            lps_phase_chromosome(ctx, &pr)) die(std::string("longphase_amd: ") + lps_last_error(ctx));
+        if (L.phase_chromosome(ctx, &pr)) die(std::string("longphase_amd: ") + L.last_error(ctx));
         auto &rc = res[chr];
         for (size_t i = 0; i < cv.pos.size(); ++i) if (ps[i]) rc[cv.pos[i]] = Phased{ps[i], gt[i] ? '1' : '0', gt[i] ? '0' : '1'};
         std::cerr << "(" << chr << ")";
     }
     std::cerr << "\n";
-    lps_destroy(ctx);
+    L.destroy(ctx);
+    const double t_gpu = now();
     write_vcf(vcf_lines, prefix + ".vcf", res, vars, command);
-    return 0;
+    fprintf(stderr, "vcf+fasta read %.3fs | bam inflate+walk %.3fs | wait for gpu context %.3fs | upload+phase %.3fs | write vcf %.3fs | total %.3fs\n", t_text - t_begin,
+            t_bam - t_text, t_ctx - t_bam, t_gpu - t_ctx, now() - t_gpu, now() - t_begin);
+    fflush(stderr);
+    _exit(0);   // outputs are closed and flushed; skip the ROCm runtime's static teardown (~0.1 s)
 }
 
-// `longphase_amd view BAM CONTIG` — decoded records as SAM columns 1-11 (CPU-only check of the BGZF/BAM reader)
+// ------------------------------------------------------------------------------------------------ haplotag
+// Phased-het rows of the SNP VCF = the haplotag table: VcfParser::parserProcess (src/haplotag/HaplotagVcfParser.cpp:234-400).
+struct PhasedRow { std::string ref, alt; int32_t ps; uint8_t hp1_is_alt; };
+static void parse_phased_vcf(const std::vector<std::string> &lines, std::vector<std::string> &chr_vec, std::map<std::string, int> &chr_len,
+                             std::map<std::string, std::map<int32_t, PhasedRow>> &rows) {
+    for (const std::string &in : lines) {
+        if (in.compare(0, 2, "##") == 0) {
+            if (in.find("contig=") != std::string::npos) {                                   // :236-248 (needs ",length=")
+                const size_t a = in.find("ID=") + 3, b = in.find(",length="), e = in.find(">");
+                if (b == std::string::npos) die("[ERROR] contig header line without length: " + in);
+                const std::string chr = in.substr(a, b - a);
+                chr_vec.push_back(chr); chr_len[chr] = std::stoi(in.substr(b + 8, e - b - 8));
+            }
+            if (in.compare(0, 16, "##FORMAT=<ID=PS,") == 0 && in.find("Type=Integer") == std::string::npos) die("longphase_amd: only an Integer PS field is supported");
+            continue;
+        }
+        if (in.empty() || in[0] == '#') continue;
+        std::istringstream iss(in);
+        std::vector<std::string> f((std::istream_iterator<std::string>(iss)), std::istream_iterator<std::string>());
+        if (f.empty()) continue;
+        if (f.size() < 10) die("[ERROR](VcfParser::parserProcess) => VCF file format not supported: " + in);
+        auto start_of = [&](const char *key) { const size_t kp = f[8].find(key); int colons = 0; for (size_t i = 0; i < kp && i < f[8].size(); ++i) if (f[8][i] == ':') ++colons;
+            int cur = 0; size_t st = 0; for (size_t i = 0; i < f[9].size(); ++i) { if (cur >= colons) break; if (f[9][i] == ':') ++cur; ++st; } return st; };
+        const size_t g = start_of("GT");
+        if (g + 2 >= f[9].size() + 0 && g + 2 > f[9].size() - 1) continue;
+        if (!(f[9][g] != f[9][g + 2] && f[9][g + 1] == '|')) continue;                      // phased hetero GT only (:296)
+        const size_t ps0 = start_of("PS");
+        const size_t pe = f[9].find(':', ps0 + 1);
+        const std::string psv = pe != std::string::npos ? f[9].substr(ps0, pe - ps0) : f[9].substr(ps0);
+        PhasedRow r; r.ref = f[3];
+        if (f[4].find(',') != std::string::npos) { if (f[9].find('2') != std::string::npos) continue; r.alt = f[4].substr(0, f[4].find(',')); }   // :333-347
+        else r.alt = f[4];
+        try { r.ps = std::stoi(psv); } catch (...) { die("longphase_amd: phased record without an integer PS value: " + in); }
+        if (f[9][g] == '0' && f[9][g + 2] == '1') r.hp1_is_alt = 0;
+        else if (f[9][g] == '1' && f[9][g + 2] == '0') r.hp1_is_alt = 1;
+        else die("longphase_amd: phased genotype other than 0|1 / 1|0 is not supported: " + in);
+        rows[f[0]][std::stoi(f[1]) - 1] = r;
+    }
+}
+
+// BGZF writer: the byte stream is cut into 0xff00-byte blocks (htslib's BGZF_BLOCK_SIZE) that are deflated by a thread pool and
+// written in order; ends with the 28-byte EOF block.
+struct BgzfWriter {
+    FILE *f = nullptr; int threads = 1, level = 6; std::vector<uint8_t> pend;
+    void open(const std::string &path, int t, int lvl) { f = fopen(path.c_str(), "wb"); if (!f) die("Fail to open write file: " + path); threads = std::max(1, t); level = lvl; }
+    void append(const uint8_t *p, size_t n) { pend.insert(pend.end(), p, p + n); if (pend.size() >= (256u << 20)) flush(false); }
+    void flush(bool final) {
+        const size_t B = 0xff00; const size_t nblk = final ? (pend.size() + B - 1) / B : pend.size() / B;
+        std::vector<std::vector<uint8_t>> out(nblk); std::atomic<size_t> next{0}; std::vector<std::thread> th; std::atomic<int> bad{0};
+        for (int t = 0; t < threads; ++t) th.emplace_back([&] {
+            z_stream zs{}; if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; return; }
+            for (;;) { const size_t b = next.fetch_add(1); if (b >= nblk) break;
+                const size_t off = b * B, len = std::min(B, pend.size() - off);
+                std::vector<uint8_t> &o = out[b]; o.resize(18 + deflateBound(&zs, (uLong)len) + 8);
+                deflateReset(&zs); zs.next_in = pend.data() + off; zs.avail_in = (uInt)len; zs.next_out = o.data() + 18; zs.avail_out = (uInt)(o.size() - 26);
+                if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { bad = 1; break; }
+                const size_t clen = zs.total_out, bsize = 18 + clen + 8;
+                if (bsize > 65536) { bad = 1; break; }
+                const uint8_t hdr[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1) & 255), (uint8_t)((bsize - 1) >> 8)};
+                memcpy(o.data(), hdr, 18);
+                const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), pend.data() + off, (uInt)len), isz = (uint32_t)len;
+                for (int k = 0; k < 4; ++k) { o[18 + clen + k] = (uint8_t)(crc >> (8 * k)); o[22 + clen + k] = (uint8_t)(isz >> (8 * k)); }
+                o.resize(bsize);
+            }
+            deflateEnd(&zs);
+        });
+        for (auto &x : th) x.join();
+        if (bad) die("ERROR: deflate failed");
+        for (auto &o : out) if (fwrite(o.data(), 1, o.size(), f) != o.size()) die("ERROR: write output bam file failed");
+        pend.erase(pend.begin(), pend.begin() + std::min(pend.size(), nblk * B));
+        if (final) { static const uint8_t eof[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (fwrite(eof, 1, 28, f) != 28 || fclose(f) != 0) die("ERROR: write output bam file failed"); f = nullptr; }
+    }
+};
+
+// byte length of one aux field starting at p (tag[2] type value), 0 when malformed
+static size_t aux_field_len(const uint8_t *p, const uint8_t *end) {
+    if (p + 3 > end) return 0;
+    const uint8_t t = p[2]; size_t v = 0;
+    switch (t) {
+        case 'A': case 'c': case 'C': v = 1; break; case 's': case 'S': v = 2; break; case 'i': case 'I': case 'f': v = 4; break; case 'd': v = 8; break;
+        case 'Z': case 'H': { const uint8_t *q = p + 3; while (q < end && *q) ++q; if (q >= end) return 0; v = (size_t)(q - (p + 3)) + 1; break; }
+        case 'B': { if (p + 8 > end) return 0; const uint8_t st = p[3]; const size_t cnt = rd32(p + 4); size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0; if (!es) return 0; v = 5 + cnt * es; break; }
+        default: return 0;
+    }
+    return p + 3 + v <= end ? 3 + v : 0;
+}
+
+static const char *kTagUsage =
+    "Usage: longphase_amd haplotag [OPTION] ... READSFILE\n"
+    "   -s, --snp-file=NAME   -b, --bam-file=NAME   -r, --reference=NAME   -o, --out-prefix=NAME (result)   -t, --threads=Num (1)\n"
+    "   --tagSupplementary   -q qualityThreshold(1)   -p percentageThreshold(0.6)   --gpu=ID (0)   --compress-level=N (6)\n";
+
+static int haplotag_main(int argc, char **argv, const std::string &command) {
+    std::vector<std::function<void(lps_params &)>> over;
+    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, level = 6;
+    auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kTagUsage; exit(1); } return argv[++i]; };
+    for (int i = 2; i < argc; ++i) {
+        std::string a = argv[i], v; size_t eq = a.find('=');
+        if (a.rfind("--", 0) == 0 && eq != std::string::npos) { v = a.substr(eq + 1); a = a.substr(0, eq); }
+        auto val = [&]() { return v.empty() ? need(i) : v; };
+        if (a == "-s" || a == "--snp-file") snp = val();
+        else if (a == "-b" || a == "--bam-file") bam = val();
+        else if (a == "-r" || a == "--reference") ref = val();
+        else if (a == "-o" || a == "--out-prefix") prefix = val();
+        else if (a == "-t" || a == "--threads") threads = std::stoi(val());
+        else if (a == "--tagSupplementary") over.push_back([](lps_params &P) { P.tag_supplementary = 1; });
+        else if (a == "-q" || a == "--qualityThreshold") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.mapping_quality = x; }); }
+        else if (a == "-p" || a == "--percentageThreshold") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.percentage_threshold = x; }); }
+        else if (a == "--gpu") gpu = std::stoi(val());
+        else if (a == "--compress-level") level = std::stoi(val());
+        else if (a == "--help") { std::cout << kTagUsage; return 0; }
+        else if (a == "--sv-file" || a == "--mod-file" || a == "--cram" || a == "--region" || a == "--log") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
+        else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kTagUsage; return 1; }
+    }
+    if (snp.empty() || bam.empty() || ref.empty()) { std::cerr << "longphase_amd haplotag: missing arguments\n" << kTagUsage; return 1; }
+
+    Lps L; lps_ctx *ctx = nullptr;
+    std::thread gpu_init([&] { if (!L.load()) return; lps_params P; L.default_params(&P); for (auto &f : over) f(P); ctx = L.create(gpu, &P); if (!ctx) L.error = "cannot create a GPU context (no CPU fallback)"; });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{gpu_init};
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    std::vector<std::string> vcf_lines;
+    if (!read_lines(snp, vcf_lines)) die("Fail to open vcf: " + snp);
+    std::vector<std::string> chr_vec; std::map<std::string, int> chr_len; std::map<std::string, std::map<int32_t, PhasedRow>> rows;
+    parse_phased_vcf(vcf_lines, chr_vec, chr_len, rows);
+    std::map<std::string, ChrVariants> want_seq; std::map<std::string, int> want;
+    for (const std::string &c : chr_vec) { want[c] = 1; want_seq[c]; }
+    std::map<std::string, std::string> seqs; read_fasta(ref, want_seq, seqs);
+    const double t_text = now();
+    BamFile in; in.load(bam, threads, want);
+    const double t_bam = now();
+    gpu_init.join();
+    if (!ctx) die("longphase_amd: " + L.error);
+    const double t_ctx = now();
+
+    BgzfWriter w; w.open(prefix + ".bam", threads, level);
+    {   // header: the input's text + one @PG line (BamFileRAII, src/haplotag/HaplotagParsingBam.cpp:45), then the reference table unchanged
+        const uint8_t *d = in.z.data; const uint32_t l_text = rd32(d + 4);
+        std::string text((const char *)d + 8, l_text); while (!text.empty() && text.back() == '\0') text.pop_back();
+        if (!text.empty() && text.back() != '\n') text += '\n';
+        std::string last_pg; for (size_t p = 0; p < text.size();) { const size_t e = text.find('\n', p); const std::string ln = text.substr(p, e - p);
+            if (ln.compare(0, 3, "@PG") == 0) { const size_t i = ln.find("\tID:"); if (i != std::string::npos) last_pg = ln.substr(i + 4, ln.find('\t', i + 4) - i - 4); } p = e == std::string::npos ? text.size() : e + 1; }
+        text += "@PG\tID:longphase_amd\tPN:longphase_amd" + (last_pg.empty() ? std::string() : "\tPP:" + last_pg) + "\tVN:" + kVersion + "\tCL:" + command + "\n";
+        std::vector<uint8_t> h; h.insert(h.end(), d, d + 4); const uint32_t lt = (uint32_t)text.size(); for (int k = 0; k < 4; ++k) h.push_back((uint8_t)(lt >> (8 * k)));
+        h.insert(h.end(), text.begin(), text.end());
+        size_t p = 8 + (size_t)l_text; const size_t ref_begin = p; const uint32_t n_ref = rd32(d + p); p += 4; for (uint32_t i = 0; i < n_ref; ++i) p += 4 + (size_t)rd32(d + p) + 4;
+        h.insert(h.end(), d + ref_begin, d + p);
+        w.append(h.data(), h.size());
+    }
+    unsigned long long st_count[8] = {0}, hp_count[3] = {0};
+    std::vector<uint8_t> rec;
+    for (const std::string &chr : chr_vec) {                          // contigs in VCF-header order (HaplotagProcess.cpp:94-97)
+        auto ci = in.contigs.find(chr);
+        if (ci == in.contigs.end() || ci->second.rec_off.empty()) continue;
+        const ContigRecords &c = ci->second; const size_t n = c.rec_off.size(); const uint8_t *base = in.z.data + c.lo;
+        auto ri = rows.find(chr);
+        std::vector<uint8_t> status(n, 5), hp(n, 0); std::vector<int32_t> h1(n), h2(n), psmin(n), pq(n), psv(n); std::vector<uint8_t> nps(n);
+        if (ri != rows.end() && !ri->second.empty()) {
+            if (!seqs.count(chr)) die("ERROR: contig " + chr + " is missing from the reference FASTA");
+            const size_t m = ri->second.size();
+            std::vector<int32_t> pos(m), ps(m); std::vector<uint8_t> r0(m), a0(m), hpa(m); std::vector<uint16_t> rl(m), al(m); size_t k = 0;
+            for (auto &kv : ri->second) { pos[k] = kv.first; r0[k] = (uint8_t)kv.second.ref[0]; a0[k] = (uint8_t)kv.second.alt[0]; rl[k] = (uint16_t)kv.second.ref.size(); al[k] = (uint16_t)kv.second.alt.size(); hpa[k] = kv.second.hp1_is_alt; ps[k] = kv.second.ps; ++k; }
+            lps_variant_table vt{}; vt.n = (int64_t)m; vt.pos = pos.data(); vt.ref0 = r0.data(); vt.alt0 = a0.data(); vt.ref_len = rl.data(); vt.alt_len = al.data(); vt.hp1_is_alt = hpa.data(); vt.phase_set = ps.data();
+            const std::string &sq = seqs[chr];
+            std::vector<uint32_t> name_id(n, 0);                        // haplotag does not group by read name
+            lps_haplotag_result hr{(int64_t)n, status.data(), h1.data(), h2.data(), nps.data(), psmin.data(), hp.data(), pq.data(), psv.data()};
+            if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) ||
+                L.push_bam_records(ctx, base, (int64_t)(c.hi - c.lo), c.rec_off.data(), (int64_t)n, name_id.data()) || L.haplotag_chromosome(ctx, &hr))
+                die(std::string("longphase_amd: ") + L.last_error(ctx));
+        }
+        // second pass in input order (tagRead is single-threaded by design, HaplotagProcess.cpp:138): strip + append tags, write EVERY record
+        for (size_t i = 0; i < n; ++i) {
+            const uint8_t *r = base + c.rec_off[i]; const uint32_t bs = rd32(r - 4);
+            ++st_count[status[i] & 7];
+            if (status[i] != 0) { w.append(r - 4, 4 + (size_t)bs); continue; }
+            ++hp_count[hp[i] < 3 ? hp[i] : 0];
+            const uint32_t l_name = r[8], n_cig = r[12] | (r[13] << 8), l_seq = rd32(r + 16);
+            const uint8_t *aux = r + 32 + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq, *end = r + bs;
+            rec.assign(4, 0); rec.insert(rec.end(), r, aux);
+            bool seen[3] = {false, false, false};                       // initFlag: the first HP, PS and PQ field each (:337-339)
+            for (const uint8_t *p = aux; p < end;) {
+                const size_t l = aux_field_len(p, end); if (!l) die("ERROR: malformed auxiliary field in record " + std::string((const char *)r + 32));
+                const int which = (p[0] == 'H' && p[1] == 'P') ? 0 : (p[0] == 'P' && p[1] == 'S') ? 1 : (p[0] == 'P' && p[1] == 'Q') ? 2 : -1;
+                if (which >= 0 && !seen[which]) seen[which] = true; else rec.insert(rec.end(), p, p + l);
+                p += l;
+            }
+            if (hp[i]) {                                                // addAuxiliaryTags (:357-361)
+                const int32_t vals[3] = {(int32_t)hp[i], psv[i], pq[i]}; const char *tags[3] = {"HP", "PS", "PQ"};
+                for (int k = 0; k < 3; ++k) { rec.push_back((uint8_t)tags[k][0]); rec.push_back((uint8_t)tags[k][1]); rec.push_back('i'); for (int b = 0; b < 4; ++b) rec.push_back((uint8_t)((uint32_t)vals[k] >> (8 * b))); }
+            }
+            const uint32_t nbs = (uint32_t)rec.size() - 4; for (int b = 0; b < 4; ++b) rec[b] = (uint8_t)(nbs >> (8 * b));
+            w.append(rec.data(), rec.size());
+        }
+        std::cerr << "(" << chr << ")";
+    }
+    std::cerr << "\n";
+    const double t_gpu = now();
+    w.flush(true);
+    L.destroy(ctx);
+    unsigned long long total = 0; for (int k = 0; k < 8; ++k) total += st_count[k];
+    fprintf(stderr, "total alignment %llu | tagged %llu (HP1 %llu, HP2 %llu) | untagged: low mapq %llu, unmapped %llu, secondary %llu, supplementary %llu, no variant %llu, beyond last variant %llu, judged %llu\n",
+            total, hp_count[1] + hp_count[2], hp_count[1], hp_count[2], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6], hp_count[0]);
+    fprintf(stderr, "vcf+fasta read %.3fs | bam inflate+walk %.3fs | wait for gpu context %.3fs | upload+score+tag splice %.3fs | deflate+write %.3fs | total %.3fs\n",
+            t_text - t_begin, t_bam - t_text, t_ctx - t_bam, t_gpu - t_ctx, now() - t_gpu, now() - t_begin);
+    fflush(stderr);
+    _exit(0);
+}
+
+// `longphase_amd view BAM CONTIG` — decoded records as SAM columns 1-11 (CPU-only check of the BGZF reader and the record walk)
 static int view_main(int argc, char **argv) {
     if (argc < 4) die("Usage: longphase_amd view <in.bam> <contig> [threads]");
-    std::map<std::string, int> want{{argv[3], 1}}; std::map<std::string, ReadPack> packs;
-    read_bam(argv[2], argc > 4 ? atoi(argv[4]) : 1, want, packs);
-    const ReadPack &k = packs[argv[3]];
+    std::map<std::string, int> want{{argv[3], 1}}; BamFile f;
+    f.load(argv[2], argc > 4 ? atoi(argv[4]) : 1, want);
+    const ContigRecords &k = f.contigs[argv[3]];
     std::string line;
-    for (size_t i = 0; i < k.ref_start.size(); ++i) {
-        line = k.names[i] + "\t" + std::to_string(k.flag[i]) + "\t" + argv[3] + "\t" + std::to_string(k.ref_start[i] + 1) + "\t" + std::to_string(k.mapq[i]) + "\t";
-        for (uint64_t c = k.cigar_off[i]; c < k.cigar_off[i + 1]; ++c) line += std::to_string(k.cigar[c] >> 4) + "MIDNSHP=XB"[k.cigar[c] & 15];
-        if (k.cigar_off[i] == k.cigar_off[i + 1]) line += "*";
+    for (size_t i = 0; i < k.rec_off.size(); ++i) {
+        const uint8_t *r = f.z.data + k.lo + k.rec_off[i];
+        const uint32_t l_name = r[8], n_cig = r[12] | (r[13] << 8), l_seq = rd32(r + 16);
+        size_t nl; const char *nm = f.name_of(k, i, nl);
+        line = std::string(nm, nl) + "\t" + std::to_string(r[14] | (r[15] << 8)) + "\t" + argv[3] + "\t" + std::to_string((int32_t)rd32(r + 4) + 1) + "\t" + std::to_string(r[9]) + "\t";
+        const uint8_t *cg = r + 32 + l_name, *sq = cg + 4ull * n_cig, *ql = sq + (l_seq + 1) / 2;
+        for (uint32_t c = 0; c < n_cig; ++c) { const uint32_t w = rd32(cg + 4ull * c); line += std::to_string(w >> 4) + "MIDNSHP=XB"[w & 15]; }
+        if (!n_cig) line += "*";
         line += "\t*\t0\t0\t";
-        for (int32_t j = 0; j < k.l_qseq[i]; ++j) line += "=ACMGRSVTWYHKDBN"[(k.seq[k.seq_off[i] + (j >> 1)] >> ((j & 1) ? 0 : 4)) & 15];
+        for (uint32_t j = 0; j < l_seq; ++j) line += "=ACMGRSVTWYHKDBN"[(sq[j >> 1] >> ((j & 1) ? 0 : 4)) & 15];
         line += "\t";
-        for (int32_t j = 0; j < k.l_qseq[i]; ++j) line += (char)(k.qual[k.qual_off[i] + j] + 33);
+        for (uint32_t j = 0; j < l_seq; ++j) line += (char)(ql[j] + 33);
         std::cout << line << "\n";
     }
     return 0;
@@ -326,10 +609,11 @@ static int view_main(int argc, char **argv) {
 
 int main(int argc, char **argv) {
     std::string command; for (int i = 0; i < argc; ++i) { if (i) command += " "; command += argv[i]; }
-    if (argc < 2) { std::cout << "Version: " << kVersion << "\nUsage: longphase_amd <command> [options]\n    phase    run phasing algorithm on the GPU.\n"; return 0; }
+    if (argc < 2) { std::cout << "Version: " << kVersion << "\nUsage: longphase_amd <command> [options]\n    phase    run phasing algorithm on the GPU.\n    haplotag tag reads by haplotype on the GPU.\n"; return 0; }
     const std::string cmd = argv[1];
     if (cmd == "phase") return phase_main(argc, argv, command);
     if (cmd == "view") return view_main(argc, argv);
-    if (cmd == "haplotag" || cmd == "somatic_haplotag") die("longphase_amd: the " + cmd + " scoring passes are available through the C-ABI (include/lps_abi.h); the BAM writer is not built yet");
+    if (cmd == "haplotag") return haplotag_main(argc, argv, command);
+    if (cmd == "somatic_haplotag") die("longphase_amd: the somatic_haplotag passes are available through the C-ABI (include/lps_abi.h); its host stages are not part of the CLI yet");
     std::cerr << "Unrecognized command: " << cmd << "\n"; return 1;
 }

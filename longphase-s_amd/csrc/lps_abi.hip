@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "lps_graph.h"
+#include "lps_bam.h"
 
 static const char *kStageNames[LPS_MAX_STAGES] = {
     "variant_prep", "extract", "name_keys", "clip_cnv", "name_groups", "overlap_filter", "cnv_filter", "nodes", "merge_rows",
@@ -34,6 +35,9 @@ struct lps_ctx {
     int nR = 0; uint64_t n_cig = 0, n_seq = 0, n_qual = 0;
     DevBuf<int32_t> r_start, r_lq; DevBuf<uint16_t> r_flag; DevBuf<uint8_t> r_mapq; DevBuf<uint32_t> r_name;
     DevBuf<uint64_t> r_coff, r_soff, r_qoff; DevBuf<uint32_t> cigar; DevBuf<uint8_t> seq, qual;
+    // raw BAM records (lps_push_bam_records): seq/qual are read in place from the blob
+    DevBuf<uint8_t> blob; uint64_t n_blob = 0; int read_mode = 0;   // 0 none yet, 1 SoA batches, 2 BAM records
+    DevBuf<uint64_t> rec_off; DevBuf<unsigned long long> cig_cnt; DevBuf<unsigned> bam_err;
     // observations
     DevBuf<uint32_t> row_off; DevBuf<int32_t> row_cnt, row_fail, g_cnt; DevBuf<uint8_t> row_flags, deleted;
     DevBuf<int32_t> obs_var, g_node; DevBuf<uint16_t> obs_aq; DevBuf<uint8_t> g_flag;
@@ -142,7 +146,7 @@ void *lps_stream(lps_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int lps_begin_chromosome(lps_ctx *c) {
     if (!c) return -1;
-    c->nV = 0; c->last_pos = -1; c->ref_len = c->ref_len_eff = 0; c->nR = 0; c->n_cig = c->n_seq = c->n_qual = 0;
+    c->nV = 0; c->last_pos = -1; c->ref_len = c->ref_len_eff = 0; c->nR = 0; c->n_cig = c->n_seq = c->n_qual = 0; c->n_blob = 0; c->read_mode = 0;
     c->phase_valid = false; c->has_hap = false; c->h_vpos.clear();
     return 0;
 }
@@ -190,6 +194,8 @@ int lps_push_reads(lps_ctx *c, const lps_read_batch *b) {
     try {
         HIP_TRY(hipSetDevice(c->device));
         const size_t n = (size_t)b->n_reads; if (n == 0) return 0;
+        if (c->read_mode == 2) return fail(c, "lps_push_reads after lps_push_bam_records in the same chromosome");
+        c->read_mode = 1;
         if ((uint64_t)c->nR + n > 0x1fffffffull) return fail(c, "more than 2^29 alignments per chromosome");
         const uint64_t nc = b->cigar_off[n] - b->cigar_off[0], ns = b->seq_off[n] - b->seq_off[0], nq = b->qual_off[n] - b->qual_off[0];
         // operand shapes the kernels rely on
@@ -215,6 +221,44 @@ int lps_push_reads(lps_ctx *c, const lps_read_batch *b) {
     return 0;
 }
 
+int lps_push_bam_records(lps_ctx *c, const uint8_t *records, int64_t n_bytes, const uint64_t *rec_off, int64_t n_records, const uint32_t *name_id) {
+    if (!c || (n_records > 0 && (!records || !rec_off || !name_id))) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        const size_t n = (size_t)n_records; if (n == 0) return 0;
+        if (c->read_mode == 1) return fail(c, "lps_push_bam_records after lps_push_reads in the same chromosome");
+        if ((uint64_t)c->nR + n > 0x1fffffffull) return fail(c, "more than 2^29 alignments per chromosome");
+        if (n_bytes < 36) return fail(c, "BAM record bytes too short");
+        c->read_mode = 2;
+        const size_t at = (size_t)c->nR; hipStream_t s = c->stream;
+        const uint64_t base = c->n_blob;                               // 16-byte aligned
+        c->blob.reserve(base + (uint64_t)n_bytes + 32, s, true, base);
+        HIP_TRY(hipMemcpyAsync(c->blob.p + base, records, (size_t)n_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(c->blob.p + base + n_bytes, 0, 32, s));
+        upload(c, c->rec_off, rec_off, n); upload(c, c->r_name, name_id, n, at, true);
+        c->r_start.reserve(at + n, s, true, at); c->r_lq.reserve(at + n, s, true, at); c->r_flag.reserve(at + n, s, true, at); c->r_mapq.reserve(at + n, s, true, at);
+        c->r_soff.reserve(at + n + 1, s, true, at); c->r_qoff.reserve(at + n + 1, s, true, at); c->r_coff.reserve(at + n + 1, s, true, at);
+        c->cig_cnt.reserve(n + 1); c->bam_err.reserve(1);
+        HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s));
+        BamView B{c->blob.p, base, (uint64_t)n_bytes, c->rec_off.p};
+        launch_bam_core(B, (int)n, (int)at, c->r_start.p, c->r_lq.p, c->r_flag.p, c->r_mapq.p, c->r_soff.p, c->r_qoff.p, c->cig_cnt.p, c->bam_err.p, s);
+        bam_cigar_offsets(c->temp, c->temp_bytes, c->cig_cnt.p, c->r_coff.p + at, (int)n, c->n_cig, s);
+        uint64_t total = 0; unsigned err = 0;
+        HIP_TRY(hipMemcpyAsync(&total, c->r_coff.p + at + n, sizeof total, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&err, c->bam_err.p, sizeof err, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (err & LPS_BAM_ERR_BOUNDS) return fail(c, "BAM record does not fit the bytes handed over (truncated or corrupt record)");
+        if (err & LPS_BAM_ERR_UNSORTED) return fail(c, "alignments must be coordinate-sorted");
+        if (err & LPS_BAM_ERR_CG_TAG) return fail(c, "CIGAR stored in a CG tag (more than 65535 operations) is not supported");
+        c->cigar.reserve(total + 1, s, true, c->n_cig);
+        launch_bam_cigar(B, (int)n, c->r_coff.p + at, c->cigar.p, s);
+        HIP_TRY(hipStreamSynchronize(s));
+        c->nR += (int)n; c->n_cig = total; c->n_blob = (base + (uint64_t)n_bytes + 15) & ~15ull;
+        c->phase_valid = false;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
 static int bits_for(unsigned long long n) { int b = 1; while ((1ull << b) < n) ++b; return b; }
 
 static void mark(lps_ctx *c, int st) { HIP_TRY(hipEventRecord(c->ev[st], c->stream)); c->ev_used[st] = true; }
@@ -232,7 +276,8 @@ static VarView var_view(lps_ctx *c) {
 static ReadView read_view(lps_ctx *c) {
     ReadView R{};
     R.n = c->nR; R.ref_start = c->r_start.p; R.l_qseq = c->r_lq.p; R.flag = c->r_flag.p; R.mapq = c->r_mapq.p; R.name_id = c->r_name.p;
-    R.cigar_off = c->r_coff.p; R.seq_off = c->r_soff.p; R.qual_off = c->r_qoff.p; R.cigar = c->cigar.p; R.seq = c->seq.p; R.qual = c->qual.p;
+    R.cigar_off = c->r_coff.p; R.seq_off = c->r_soff.p; R.qual_off = c->r_qoff.p; R.cigar = c->cigar.p;
+    if (c->read_mode == 2) R.seq = R.qual = c->blob.p; else { R.seq = c->seq.p; R.qual = c->qual.p; }
     return R;
 }
 

@@ -1,0 +1,21 @@
+// Device-side BAM record decode (lps_bam.hip): views + launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "lps_common.h"
+
+enum { LPS_BAM_ERR_BOUNDS = 1, LPS_BAM_ERR_UNSORTED = 2, LPS_BAM_ERR_CG_TAG = 4 };
+
+struct BamView {
+    const uint8_t *blob;        // device copy of the inflated BAM bytes pushed so far (+16 bytes of slack)
+    uint64_t push_base;         // where this push's bytes start inside blob
+    uint64_t push_bytes;        // bytes of this push
+    const uint64_t *rec_off;    // per record of this push: offset of its refID field (block_size sits 4 bytes before)
+};
+
+void launch_bam_core(const BamView &B, int n, int at, int32_t *ref_start, int32_t *l_qseq, uint16_t *flag, uint8_t *mapq, uint64_t *seq_off,
+                     uint64_t *qual_off, unsigned long long *cig_cnt, unsigned *err, hipStream_t s);
+void launch_bam_cigar(const BamView &B, int n, const uint64_t *cigar_off, uint32_t *cigar, hipStream_t s);
+void bam_cigar_offsets(DevBuf<char> &temp, size_t &temp_bytes, const unsigned long long *cig_cnt, uint64_t *cigar_off, int n, uint64_t init, hipStream_t s);

@@ -220,3 +220,35 @@ class TumorExtractOut:
         n = self.c.n_windows
         o = np.lexsort((self.win_base[:n], self.win_offset[:n], self.win_allele[:n], self.win_site[:n]))
         return self.win_site[:n][o], self.win_allele[:n][o], self.win_offset[:n][o], self.win_base[:n][o]
+
+
+class BamRecords:
+    """Raw (inflated) BAM records of one contig for lps_push_bam_records: byte blob + offset of each record's refID field."""
+
+    def __init__(self, blob, rec_off, name_id):
+        self.blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self.rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        self.name_id = np.ascontiguousarray(name_id, dtype=np.uint32)
+        self.n_reads = int(self.rec_off.size)
+
+    @classmethod
+    def from_reads(cls, R, names=None, seed=0, lead=0):
+        """Serialise an abi.Reads batch as BAM records (SAM spec 4.2) with variable-length names and a random aux tail,
+        so that CIGAR/seq/qual land on every byte alignment.  `lead` = junk bytes before the first record."""
+        import struct
+        rng = np.random.default_rng(seed)
+        out = bytearray(rng.integers(0, 256, lead, dtype=np.uint8).tobytes())
+        off = []
+        for i in range(R.n_reads):
+            nm = (names[i] if names is not None else b"r%09d" % int(R.name_id[i])) + b"x" * int(rng.integers(0, 4)) + b"\0"
+            cg = R.cigar[int(R.cigar_off[i]):int(R.cigar_off[i + 1])]
+            lq = int(R.l_qseq[i])
+            sq = R.seq[int(R.seq_off[i]):int(R.seq_off[i]) + (lq + 1) // 2]
+            ql = R.qual[int(R.qual_off[i]):int(R.qual_off[i]) + lq]
+            aux = rng.integers(0, 256, int(rng.integers(0, 9)), dtype=np.uint8).tobytes()
+            body = struct.pack("<iiBBHHHiiii", 0, int(R.ref_start[i]), len(nm), int(R.mapq[i]), 4680, cg.size, int(R.flag[i]), lq, -1, -1, 0)
+            body += nm + cg.astype("<u4").tobytes() + sq.tobytes() + ql.tobytes() + aux
+            out += struct.pack("<i", len(body))
+            off.append(len(out))
+            out += body
+        return cls(np.frombuffer(bytes(out), dtype=np.uint8), off, R.name_id)

@@ -45,6 +45,7 @@ def load():
     L.lps_set_variants.argtypes = [C.c_void_p, C.POINTER(abi.VariantTable)]
     L.lps_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.lps_push_reads.argtypes = [C.c_void_p, C.POINTER(abi.ReadBatch)]
+    L.lps_push_bam_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.lps_phase_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.PhaseResult)]
     L.lps_haplotag_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.HaplotagResult)]
     L.lps_somatic_tag_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.SomaticTagResult)]
@@ -96,7 +97,11 @@ class Context:
         self._check(self.L.lps_set_reference(self.h, ref.ctypes.data, ref.size), "lps_set_reference")
         self.n_reads = 0
         for r in (reads_list if isinstance(reads_list, (list, tuple)) else [reads_list]):
-            self._check(self.L.lps_push_reads(self.h, C.byref(r.c)), "lps_push_reads")
+            if isinstance(r, abi.BamRecords):
+                self._check(self.L.lps_push_bam_records(self.h, r.blob.ctypes.data, r.blob.size, r.rec_off.ctypes.data, r.n_reads,
+                                                        r.name_id.ctypes.data), "lps_push_bam_records")
+            else:
+                self._check(self.L.lps_push_reads(self.h, C.byref(r.c)), "lps_push_reads")
             self.n_reads += r.n_reads
         self.n_var = variants.n
 

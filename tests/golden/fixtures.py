@@ -42,6 +42,10 @@ HAPLOTAG_FIXTURES = {
     "high_error": ("high_error", [], {}),
 }
 
+# end-to-end fixtures of the haplotag CLI (reads regenerated from the seed, stale HP/PS/PQ + other optional fields added by
+# util.add_stale_tags, phased VCF written from the haplotag fixture's table): name -> haplotag fixture
+CLI_HAPLOTAG_FIXTURES = ["snp_ont", "indels", "supp_tagged", "strict", "two_blocks"]
+
 # tumor/normal fixtures for the somatic rows: (genome kwargs, normal reads kwargs, tumor reads kwargs, somatic_haplotag CLI, params)
 TN_BASE = dict(contig_len=600_000, n_snp=700, n_threads=4, somatic_every=8000.0)
 SOMATIC_FIXTURES = {

@@ -212,8 +212,41 @@ def run_reference_somatic(N, T, tag_cli, workdir, chrom="chrS"):
     return table, np.array(hp, np.uint8), np.array(rps, np.int32), np.array(pq, np.int32)
 
 
+def make_cli_haplotag(name):
+    """Reference `haplotag` run whose OUTPUT BAM (inflated record stream) pins the CLI's tag splice + record copy."""
+    import hashlib
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import util
+    src, tag_cli, over = fixtures.HAPLOTAG_FIXTURES[name]
+    kw, _, _ = fixtures.PHASE_FIXTURES[src]
+    s = Synth(**kw)
+    V, _, _, _ = util.load_golden_haplotag(name)
+    with tempfile.TemporaryDirectory() as d:
+        s.write_fasta(d + "/ref.fa"); s.write_sam(d + "/plain.sam")
+        util.add_stale_tags(d + "/plain.sam", d + "/reads.sam")
+        util.write_table_vcf(d + "/table.vcf", V, "chrS", kw["contig_len"])
+        subprocess.check_call([TEST_VIEW, "-b", "-x", "reads.bam.bai", "-p", "reads.bam", "reads.sam"], cwd=d, stdout=subprocess.DEVNULL)
+        cmd = [REF_BIN, "haplotag", "-s", "table.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", "1", "-o", "tagged"] + tag_cli
+        r = subprocess.run(cmd, cwd=d, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"reference haplotag failed rc={r.returncode}: {r.stderr[-2000:]}")
+        text, refs, recs = util.bam_sections(d + "/tagged.bam")
+    tags = util.bam_record_tags(recs)
+    out = dict(digest=fixtures.input_digest(s), records_sha256=hashlib.sha256(recs).hexdigest(), n_records=len(tags), record_bytes=len(recs),
+               header_without_pg=[l for l in text.split("\n") if l and not l.startswith("@PG")],
+               tags=[[q, f, p, [list(t) for t in tg]] for q, f, p, tg in tags], cli=tag_cli)
+    s.close()
+    with open(os.path.join(HERE, f"cli_haplotag_{name}.json"), "w") as f:
+        json.dump(out, f)
+    print("cli_haplotag", name, out["n_records"], out["records_sha256"][:16])
+
+
 def main():
     assert os.path.exists(REF_BIN), "build the reference first: oracle/build_ref.sh"
+    if "--cli-haplotag" in sys.argv:            # only the CLI end-to-end vectors (the others are untouched)
+        for name in fixtures.CLI_HAPLOTAG_FIXTURES:
+            make_cli_haplotag(name)
+        return
     index = {}
     for name, (genome, nkw, tkw, tag_cli, over) in fixtures.SOMATIC_FIXTURES.items():
         N = Synth(**dict(genome, **nkw)); T = Synth(**dict(genome, **tkw))
@@ -260,6 +293,8 @@ def main():
         s.close()
     with open(os.path.join(HERE, "index.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)
+    for name in fixtures.CLI_HAPLOTAG_FIXTURES:
+        make_cli_haplotag(name)
 
 
 if __name__ == "__main__":

@@ -146,9 +146,66 @@ def assert_somatic_tags_equal(out, hp, ps, pq, what=""):
     assert np.array_equal(out.pq[m], pq[m]), f"{what}: PQ mismatch"
 
 
+def _reg2bin(beg, end):
+    """SAM spec 5.3 (UCSC binning, min_shift 14, depth 5)."""
+    end -= 1
+    for sh, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> sh == end >> sh:
+            return off + (beg >> sh)
+    return 0
+
+
+def _aux_bytes(tok):
+    """One SAM optional field -> BAM bytes, integers in the smallest type (what htslib's SAM parser picks)."""
+    import struct
+    tag, typ, val = tok.split(":", 2)
+    t = tag.encode()
+    if typ == "i":
+        v = int(val)
+        if v < 0:
+            code, fmt = ("c", "<b") if v >= -128 else ("s", "<h") if v >= -32768 else ("i", "<i")
+        else:
+            code, fmt = ("C", "<B") if v <= 255 else ("S", "<H") if v <= 65535 else ("I", "<I")
+        return t + code.encode() + struct.pack(fmt, v)
+    if typ == "A":
+        return t + b"A" + val.encode()
+    if typ == "f":
+        return t + b"f" + struct.pack("<f", float(val))
+    if typ in "ZH":
+        return t + typ.encode() + val.encode() + b"\0"
+    if typ == "B":
+        sub, *xs = val.split(",")
+        fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub]
+        conv = float if sub == "f" else int
+        return t + b"B" + sub.encode() + struct.pack("<i", len(xs)) + struct.pack("<%d%s" % (len(xs), fmt), *[conv(x) for x in xs])
+    raise ValueError(tok)
+
+
+def add_stale_tags(sam_in, sam_out):
+    """Copy a SAM, giving the records optional fields (other tags, and HP/PS/PQ left over from an earlier run) in a fixed
+    pattern, so that the tag strip/append rules of HaplotagProcess.cpp:337-361 are exercised."""
+    op = gzip.open if sam_in.endswith(".gz") else open
+    extra = [
+        ["NM:i:17", "HP:i:2", "PS:i:123456", "PQ:i:7"],
+        ["XA:Z:keep me", "PQ:i:300", "ZB:B:s,1,-2,3", "HP:i:1"],
+        [],
+        ["PS:i:70000", "tp:A:P", "de:f:0.0125", "PS:i:5"],
+        ["HP:i:-3", "s1:i:-40000", "HP:i:1"],
+    ]
+    with op(sam_in, "rt") as fi, open(sam_out, "w") as fo:
+        i = 0
+        for line in fi:
+            if line.startswith("@"):
+                fo.write(line); continue
+            f = line.rstrip("\n").split("\t")[:11] + extra[i % len(extra)]
+            fo.write("\t".join(f) + "\n"); i += 1
+    return i
+
+
 def write_bam(sam_path, bam_path, block=60000):
     """SAM(.gz) text -> BAM (BGZF, SAM spec §4): test-side writer so the CLI's own BGZF/BAM reader is exercised
-    on files that never passed through htslib.  No index; aux fields are dropped."""
+    on files that never passed through htslib.  No index.  Bin and optional-field encodings follow htslib's SAM parser, so the
+    inflated byte stream equals what `test_view -b` makes from the same text."""
     import re, struct, zlib
     op = gzip.open if sam_path.endswith(".gz") else open
     header, recs, refs = [], [], []
@@ -167,16 +224,19 @@ def write_bam(sam_path, bam_path, block=60000):
         out += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", ln)
     for f in recs:
         name = f[0].encode() + b"\0"
-        cig = [(int(ln) << 4) | _OPS[o] for ln, o in re.findall(r"(\d+)([MIDNSHP=XB])", f[5])]
+        ops = re.findall(r"(\d+)([MIDNSHP=XB])", f[5])
+        cig = [(int(ln) << 4) | _OPS[o] for ln, o in ops]
         s = "" if f[9] == "*" else f[9]
         packed = bytearray((len(s) + 1) // 2)
         for j, c in enumerate(s):
             packed[j >> 1] |= _NT16.get(c, 15) << (4 if (j & 1) == 0 else 0)
         q = bytes((ord(c) - 33) for c in f[10]) if f[10] != "*" else bytes([255]) * len(s)
         pos = int(f[3]) - 1
-        body = struct.pack("<iiBBHHHiiii", tid.get(f[2], -1), pos, len(name), int(f[4]), 4680, len(cig), int(f[1]), len(s),
+        rlen = sum(int(ln) for ln, o in ops if o in "MDN=X")
+        end = pos + rlen if (rlen and not int(f[1]) & 4) else pos + 1
+        body = struct.pack("<iiBBHHHiiii", tid.get(f[2], -1), pos, len(name), int(f[4]), _reg2bin(pos, end), len(cig), int(f[1]), len(s),
                            tid.get(f[6] if f[6] != "=" else f[2], -1), int(f[7]) - 1, int(f[8]))
-        body += name + struct.pack("<%dI" % len(cig), *cig) + bytes(packed) + q
+        body += name + struct.pack("<%dI" % len(cig), *cig) + bytes(packed) + q + b"".join(_aux_bytes(t) for t in f[11:])
         out += struct.pack("<i", len(body)) + body
     with open(bam_path, "wb") as fo:
         def put(chunk):
@@ -188,3 +248,56 @@ def write_bam(sam_path, bam_path, block=60000):
             put(out[a:a + block])
         put(b"")
     return len(recs)
+
+
+def bam_sections(path):
+    """Inflate a BAM -> (header text, reference table bytes, record stream bytes)."""
+    import struct
+    d = gzip.open(path, "rb").read()
+    assert d[:4] == b"BAM\1"
+    lt = struct.unpack_from("<i", d, 4)[0]
+    text = d[8:8 + lt].rstrip(b"\0").decode()
+    p = 8 + lt
+    r0 = p
+    n_ref = struct.unpack_from("<i", d, p)[0]; p += 4
+    for _ in range(n_ref):
+        p += 4 + struct.unpack_from("<i", d, p)[0] + 4
+    return text, d[r0:p], d[p:]
+
+
+def bam_record_tags(records):
+    """Record stream -> [(qname, flag, pos, {tag: value})] for integer tags HP/PS/PQ (diagnostics of the CLI haplotag test)."""
+    import struct
+    out, p = [], 0
+    size = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4, "d": 8}
+    fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I"}
+    while p < len(records):
+        bs = struct.unpack_from("<i", records, p)[0]
+        r = records[p + 4:p + 4 + bs]; p += 4 + bs
+        _, pos, l_name, _, _, n_cig, flag, l_seq = struct.unpack_from("<iiBBHHHi", r, 0)
+        a = 32 + l_name + 4 * n_cig + (l_seq + 1) // 2 + l_seq
+        tags = []
+        while a < len(r):
+            tag, t = r[a:a + 2].decode(), chr(r[a + 2]); a += 3
+            if t in "ZH":
+                e = r.index(b"\0", a); a = e + 1
+            elif t == "B":
+                sub = chr(r[a]); cnt = struct.unpack_from("<i", r, a + 1)[0]; a += 5 + cnt * size[sub]
+            else:
+                if t in fmt and tag in ("HP", "PS", "PQ"):
+                    tags.append((tag, struct.unpack_from(fmt[t], r, a)[0]))
+                a += size[t]
+        out.append((r[32:32 + l_name - 1].decode(), flag, pos, tags))
+    return out
+
+
+def write_table_vcf(path, V, chrom, length):
+    """Phased table (abi.Variants with hp1_is_alt / phase_set) -> minimal phased VCF, the haplotag CLI's -s input."""
+    with open(path, "w") as fo:
+        fo.write("##fileformat=VCFv4.2\n##contig=<ID=%s,length=%d>\n" % (chrom, length))
+        fo.write('##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n##FORMAT=<ID=PS,Number=1,Type=Integer,Description="Phase set identifier">\n')
+        fo.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n")
+        for i in range(V.n):
+            gt = "1|0" if V.hp1_is_alt[i] else "0|1"
+            r, a = (x.decode() if isinstance(x, bytes) else str(x) for x in (V.ref_str[i], V.alt_str[i]))
+            fo.write("%s\t%d\t.\t%s\t%s\t30\tPASS\t.\tGT:PS\t%s:%d\n" % (chrom, int(V.pos[i]) + 1, r, a, gt, int(V.phase_set[i])))
