@@ -139,7 +139,27 @@ def cli_e2e(d, threads, ref_wall, n_ph):
                        "the reference with the default strategy - see output_bytes"}
     except Exception as e:  # noqa: BLE001
         tag = {"error": repr(e)[:300]}
-    return {"cli_wall_s": round(ts[1], 3), "cli_stages": stages, "haplotag": tag, "reference_wall_s": round(ref_wall, 3), "speedup": round(ref_wall / ts[1], 2),
+    gz = None
+    try:                                                            # GPU BGZF inflate of the same (htslib-written) BAM, checked against zlib
+        import gzip
+        import numpy as np
+        from lps import abi, hip
+        raw = np.fromfile(d + "/reads.bam", dtype=np.uint8)
+        with hip.Context(int(os.environ.get("LOCAL_RANK", "0")), abi.default_params()) as c2:
+            c2.bgzf_load(raw)
+            t0 = time.time(); n_inf = c2.bgzf_load(raw); wall = time.time() - t0
+            tm = c2.bgzf_timings()
+            t0 = time.time(); want = gzip.decompress(raw.tobytes()); zt = time.time() - t0
+            same = len(want) == n_inf
+            for a in range(0, n_inf, 64 << 20):
+                k = min(64 << 20, n_inf - a)
+                same = same and c2.bgzf_read(a, k).tobytes() == want[a:a + k]
+        gz = {"compressed_bytes": int(raw.size), "inflated_bytes": n_inf, "h2d_ms": round(tm["h2d_ms"], 2), "inflate_kernel_ms": round(tm["inflate_ms"], 2),
+              "inflate_GBps_out": round(n_inf / tm["inflate_ms"] / 1e6, 1), "call_wall_s": round(wall, 3), "identical_to_zlib": bool(same),
+              "zlib_1thread_s": round(zt, 2)}
+    except Exception as e:  # noqa: BLE001
+        gz = {"error": repr(e)[:300]}
+    return {"cli_wall_s": round(ts[1], 3), "cli_stages": stages, "haplotag": tag, "gpu_bgzf": gz, "reference_wall_s": round(ref_wall, 3), "speedup": round(ref_wall / ts[1], 2),
             "cli_snps_per_s": float(n_ph / ts[1]), "identical_vcf": body(d + "/gpu.vcf") == body(d + "/out.vcf"),
             "note": "same BAM/VCF/FASTA files, process start to exit, median of 3; CLI wall includes HIP runtime start-up"}
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 3
+#define LPS_ABI_VERSION 5
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -234,6 +234,26 @@ int lps_push_reads(lps_ctx *ctx, const lps_read_batch *batch);
  * seq and qual are used in place.  name_id as in lps_read_batch.  Records must be coordinate-sorted and of one contig.
  * Cannot be mixed with lps_push_reads inside one chromosome.  CIGARs moved to a CG tag (>65535 ops) are rejected. */
 int lps_push_bam_records(lps_ctx *ctx, const uint8_t *records, int64_t n_bytes, const uint64_t *rec_off, int64_t n_records, const uint32_t *name_id);
+
+/* --- whole BAM file on the GPU (replaces htslib's BGZF layer behind sam_itr_multi_next, src/phase/ParsingBam.cpp:1279).
+ * lps_bgzf_load: `bgzf` = the complete .bam file bytes (e.g. an mmap).  Block headers are walked on the host, every block is
+ * inflated on the GPU (lps_inflate.hip), the inflated stream stays resident in the ctx until the next lps_bgzf_load / lps_destroy
+ * (lps_begin_chromosome does not drop it).  Fails on a corrupt block or an ISIZE mismatch.  CRC32 fields are not checked.
+ * lps_bgzf_read: copy a piece of the inflated stream to the host (BAM header text and reference table). */
+int lps_bgzf_load(lps_ctx *ctx, const uint8_t *bgzf, int64_t n_bytes, int64_t *inflated_bytes);
+int lps_bgzf_read(lps_ctx *ctx, int64_t offset, int64_t n, uint8_t *dst);
+int lps_bgzf_timings(lps_ctx *ctx, double *h2d_ms, double *inflate_ms);
+/* Find every BAM record of the resident stream on the GPU, starting at first_record_offset (= the byte after the BAM header's reference
+ * table; the caller parses the header with lps_bgzf_read).  Every byte position is tested against the necessary conditions of a record
+ * start and the candidate list is verified to be exactly the record chain (serial fallback otherwise), so the result is exact.
+ * Records are numbered in file order.  lps_bam_record_tids: refID of every record (n_records entries) - a coordinate-sorted BAM holds each
+ * contig as one contiguous range.  lps_bam_names: read names of records [first, first+count) packed back to back INCLUDING their NUL,
+ * name_off[count+1] relative offsets; call with names == NULL to get the byte count.
+ * lps_push_bam_resident: like lps_push_bam_records for records [first, first+count) of the resident stream - nothing is uploaded. */
+int lps_bam_scan(lps_ctx *ctx, int64_t first_record_offset, int32_t n_ref, int64_t *n_records);
+int lps_bam_record_tids(lps_ctx *ctx, int32_t *tid);
+int lps_bam_names(lps_ctx *ctx, int64_t first, int64_t count, uint32_t *name_off, char *names, int64_t names_cap, int64_t *names_bytes);
+int lps_push_bam_resident(lps_ctx *ctx, int64_t first, int64_t count, const uint32_t *name_id);
 
 /* phase: everything between direct_detect_alleles and exportResult for the reads pushed so far.
  * Recomputes from the resident raw reads on every call (nothing is cached between calls). */

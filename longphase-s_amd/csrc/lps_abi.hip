@@ -13,6 +13,7 @@
 
 #include "lps_graph.h"
 #include "lps_bam.h"
+#include "lps_inflate.h"
 
 static const char *kStageNames[LPS_MAX_STAGES] = {
     "variant_prep", "extract", "name_keys", "clip_cnv", "name_groups", "overlap_filter", "cnv_filter", "nodes", "merge_rows",
@@ -38,6 +39,9 @@ struct lps_ctx {
     // raw BAM records (lps_push_bam_records): seq/qual are read in place from the blob
     DevBuf<uint8_t> blob; uint64_t n_blob = 0; int read_mode = 0;   // 0 none yet, 1 SoA batches, 2 BAM records
     DevBuf<uint64_t> rec_off; DevBuf<unsigned long long> cig_cnt; DevBuf<unsigned> bam_err;
+    // whole BAM file resident on the device (lps_bgzf_load): compressed bytes, block table, inflated stream; survives lps_begin_chromosome
+    DevBuf<uint8_t> zfile, file; DevBuf<InflateBlock> zblk; uint64_t file_bytes = 0; float bgzf_h2d_ms = 0, bgzf_inflate_ms = 0;
+    DevBuf<uint64_t> rcand; uint64_t n_rec_all = 0; DevBuf<int32_t> r_tid_all; DevBuf<uint32_t> r_lname, r_nameoff, wg_cnt, wg_off, scan_nout; DevBuf<uint8_t> names_d; bool names_ready = false;
     // observations
     DevBuf<uint32_t> row_off; DevBuf<int32_t> row_cnt, row_fail, g_cnt; DevBuf<uint8_t> row_flags, deleted;
     DevBuf<int32_t> obs_var, g_node; DevBuf<uint16_t> obs_aq; DevBuf<uint8_t> g_flag;
@@ -194,7 +198,7 @@ int lps_push_reads(lps_ctx *c, const lps_read_batch *b) {
     try {
         HIP_TRY(hipSetDevice(c->device));
         const size_t n = (size_t)b->n_reads; if (n == 0) return 0;
-        if (c->read_mode == 2) return fail(c, "lps_push_reads after lps_push_bam_records in the same chromosome");
+        if (c->read_mode >= 2) return fail(c, "lps_push_reads mixed with a BAM-record push in the same chromosome");
         c->read_mode = 1;
         if ((uint64_t)c->nR + n > 0x1fffffffull) return fail(c, "more than 2^29 alignments per chromosome");
         const uint64_t nc = b->cigar_off[n] - b->cigar_off[0], ns = b->seq_off[n] - b->seq_off[0], nq = b->qual_off[n] - b->qual_off[0];
@@ -221,41 +225,191 @@ int lps_push_reads(lps_ctx *c, const lps_read_batch *b) {
     return 0;
 }
 
+// core decode + CIGAR re-alignment of n records described by B (blob already on the device), appended to the ctx's read arrays
+static int push_record_view(lps_ctx *c, const BamView &B, size_t n, const uint32_t *name_id) {
+    const size_t at = (size_t)c->nR; hipStream_t s = c->stream;
+    upload(c, c->r_name, name_id, n, at, true);
+    c->r_start.reserve(at + n, s, true, at); c->r_lq.reserve(at + n, s, true, at); c->r_flag.reserve(at + n, s, true, at); c->r_mapq.reserve(at + n, s, true, at);
+    c->r_soff.reserve(at + n + 1, s, true, at); c->r_qoff.reserve(at + n + 1, s, true, at); c->r_coff.reserve(at + n + 1, s, true, at);
+    c->cig_cnt.reserve(n + 1); c->bam_err.reserve(1);
+    HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s));
+    launch_bam_core(B, (int)n, (int)at, c->r_start.p, c->r_lq.p, c->r_flag.p, c->r_mapq.p, c->r_soff.p, c->r_qoff.p, c->cig_cnt.p, c->bam_err.p, s);
+    bam_cigar_offsets(c->temp, c->temp_bytes, c->cig_cnt.p, c->r_coff.p + at, (int)n, c->n_cig, s);
+    uint64_t total = 0; unsigned err = 0;
+    HIP_TRY(hipMemcpyAsync(&total, c->r_coff.p + at + n, sizeof total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&err, c->bam_err.p, sizeof err, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (err & LPS_BAM_ERR_BOUNDS) return fail(c, "BAM record does not fit the bytes handed over (truncated or corrupt record)");
+    if (err & LPS_BAM_ERR_UNSORTED) return fail(c, "alignments must be coordinate-sorted");
+    if (err & LPS_BAM_ERR_CG_TAG) return fail(c, "CIGAR stored in a CG tag (more than 65535 operations) is not supported");
+    c->cigar.reserve(total + 1, s, true, c->n_cig);
+    launch_bam_cigar(B, (int)n, c->r_coff.p + at, c->cigar.p, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    c->nR += (int)n; c->n_cig = total;
+    c->phase_valid = false;
+    return 0;
+}
+
 int lps_push_bam_records(lps_ctx *c, const uint8_t *records, int64_t n_bytes, const uint64_t *rec_off, int64_t n_records, const uint32_t *name_id) {
     if (!c || (n_records > 0 && (!records || !rec_off || !name_id))) return -1;
     try {
         HIP_TRY(hipSetDevice(c->device));
         const size_t n = (size_t)n_records; if (n == 0) return 0;
-        if (c->read_mode == 1) return fail(c, "lps_push_bam_records after lps_push_reads in the same chromosome");
+        if (c->read_mode == 1 || c->read_mode == 3) return fail(c, "lps_push_bam_records mixed with another kind of push in the same chromosome");
         if ((uint64_t)c->nR + n > 0x1fffffffull) return fail(c, "more than 2^29 alignments per chromosome");
         if (n_bytes < 36) return fail(c, "BAM record bytes too short");
         c->read_mode = 2;
-        const size_t at = (size_t)c->nR; hipStream_t s = c->stream;
+        hipStream_t s = c->stream;
         const uint64_t base = c->n_blob;                               // 16-byte aligned
         c->blob.reserve(base + (uint64_t)n_bytes + 32, s, true, base);
         HIP_TRY(hipMemcpyAsync(c->blob.p + base, records, (size_t)n_bytes, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(c->blob.p + base + n_bytes, 0, 32, s));
-        upload(c, c->rec_off, rec_off, n); upload(c, c->r_name, name_id, n, at, true);
-        c->r_start.reserve(at + n, s, true, at); c->r_lq.reserve(at + n, s, true, at); c->r_flag.reserve(at + n, s, true, at); c->r_mapq.reserve(at + n, s, true, at);
-        c->r_soff.reserve(at + n + 1, s, true, at); c->r_qoff.reserve(at + n + 1, s, true, at); c->r_coff.reserve(at + n + 1, s, true, at);
-        c->cig_cnt.reserve(n + 1); c->bam_err.reserve(1);
-        HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s));
+        upload(c, c->rec_off, rec_off, n);
         BamView B{c->blob.p, base, (uint64_t)n_bytes, c->rec_off.p};
-        launch_bam_core(B, (int)n, (int)at, c->r_start.p, c->r_lq.p, c->r_flag.p, c->r_mapq.p, c->r_soff.p, c->r_qoff.p, c->cig_cnt.p, c->bam_err.p, s);
-        bam_cigar_offsets(c->temp, c->temp_bytes, c->cig_cnt.p, c->r_coff.p + at, (int)n, c->n_cig, s);
-        uint64_t total = 0; unsigned err = 0;
-        HIP_TRY(hipMemcpyAsync(&total, c->r_coff.p + at + n, sizeof total, hipMemcpyDeviceToHost, s));
+        const int rc = push_record_view(c, B, n, name_id);
+        if (rc) return rc;
+        c->n_blob = (base + (uint64_t)n_bytes + 15) & ~15ull;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_bam_scan(lps_ctx *c, int64_t first_record_offset, int32_t n_ref, int64_t *n_records) {
+    if (!c || !n_records) return -1;
+    if (!c->file_bytes || first_record_offset < 12 || (uint64_t)first_record_offset > c->file_bytes) return fail(c, "lps_bam_scan: no inflated BAM resident (lps_bgzf_load) or bad offset");
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        hipStream_t s = c->stream; c->bam_err.reserve(1); c->scan_nout.reserve(1);
+        uint64_t n = 0;
+        const int rc = bam_scan_records(c->file.p, (uint64_t)first_record_offset, c->file_bytes, n_ref, c->rcand, c->wg_cnt, c->wg_off, c->temp, c->temp_bytes, c->bam_err.p, c->scan_nout.p, &n, s);
+        c->n_rec_all = 0;
+        if (rc == -3) { *n_records = 0; return 0; }
+        if (rc) return fail(c, rc == -4 ? "lps_bam_scan: the BAM record chain is broken (corrupt file)" : "lps_bam_scan: stream too large");
+        if (n > 0x7fffffffull) return fail(c, "lps_bam_scan: more than 2^31 records");
+        c->r_tid_all.reserve(n, s); c->r_lname.reserve(n + 1, s); c->r_nameoff.reserve(n + 1, s);
+        launch_bam_tid_lname(c->file.p, c->rcand.p, (uint32_t)n, c->r_tid_all.p, c->r_lname.p, s);
+        HIP_TRY(hipMemsetAsync(c->r_lname.p + n, 0, sizeof(uint32_t), s));
+        { const size_t need = GraphTemp::need((size_t)n + 1); if (need > c->temp_bytes) { c->temp.reserve(need, s); c->temp_bytes = need; } }
+        exscan_u32(c->temp.p, c->temp_bytes, c->r_lname.p, c->r_nameoff.p, (size_t)n + 1, s);
+        HIP_TRY(hipStreamSynchronize(s));
+        c->n_rec_all = n; *n_records = (int64_t)n;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_bam_record_tids(lps_ctx *c, int32_t *tid) {
+    if (!c || !tid) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        if (c->n_rec_all) HIP_TRY(hipMemcpyAsync(tid, c->r_tid_all.p, c->n_rec_all * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_bam_names(lps_ctx *c, int64_t first, int64_t count, uint32_t *name_off, char *names, int64_t names_cap, int64_t *names_bytes) {
+    if (!c || first < 0 || count < 0 || (uint64_t)(first + count) > c->n_rec_all || !names_bytes) return fail(c, "lps_bam_names: range outside the scanned records");
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        uint32_t lo = 0, hi = 0;
+        HIP_TRY(hipMemcpyAsync(&lo, c->r_nameoff.p + first, sizeof lo, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&hi, c->r_nameoff.p + first + count, sizeof hi, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *names_bytes = (int64_t)(hi - lo);
+        if (!names || !name_off) return 0;                              // size query
+        if (names_cap < (int64_t)(hi - lo)) return fail(c, "lps_bam_names: buffer too small");
+        if (!c->names_ready) {                                          // gather all names once
+            uint32_t tot = 0;
+            HIP_TRY(hipMemcpyAsync(&tot, c->r_nameoff.p + c->n_rec_all, sizeof tot, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            c->names_d.reserve((size_t)tot + 1, s);
+            launch_bam_names(c->file.p, c->rcand.p, (uint32_t)c->n_rec_all, c->r_nameoff.p, c->names_d.p, s);
+            c->names_ready = true;
+        }
+        HIP_TRY(hipMemcpyAsync(name_off, c->r_nameoff.p + first, (size_t)(count + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (hi > lo) HIP_TRY(hipMemcpyAsync(names, c->names_d.p + lo, (size_t)(hi - lo), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int64_t i = 0; i <= count; ++i) name_off[i] -= lo;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_push_bam_resident(lps_ctx *c, int64_t first, int64_t count, const uint32_t *name_id) {
+    if (!c || first < 0 || count < 0 || (uint64_t)(first + count) > c->n_rec_all || (count > 0 && !name_id)) return fail(c, "lps_push_bam_resident: range outside the scanned records");
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        if (count == 0) return 0;
+        if (c->read_mode == 1 || c->read_mode == 2) return fail(c, "lps_push_bam_resident mixed with another kind of push in the same chromosome");
+        if ((uint64_t)c->nR + (uint64_t)count > 0x1fffffffull) return fail(c, "more than 2^29 alignments per chromosome");
+        c->read_mode = 3;
+        BamView B{c->file.p, 0, c->file_bytes, c->rcand.p + first};
+        return push_record_view(c, B, (size_t)count, name_id);
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_bgzf_load(lps_ctx *c, const uint8_t *bgzf, int64_t n_bytes, int64_t *inflated_bytes) {
+    if (!c || !bgzf || n_bytes < 28) return fail(c, "lps_bgzf_load: not a BGZF file");
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        // host: walk the block headers (18 bytes + BSIZE each; RFC 1952 member with the BC extra subfield, SAM spec 4.1)
+        std::vector<InflateBlock> blks; uint64_t p = 0, utot = 0; const uint64_t n = (uint64_t)n_bytes;
+        while (p + 18 <= n) {
+            if (bgzf[p] != 31 || bgzf[p + 1] != 139 || bgzf[p + 2] != 8 || !(bgzf[p + 3] & 4)) return fail(c, "lps_bgzf_load: not a BGZF block header");
+            const unsigned xlen = bgzf[p + 10] | (bgzf[p + 11] << 8);
+            uint64_t q = p + 12, bsize = 0;
+            while (q + 4 <= p + 12 + xlen && q + 4 <= n) {
+                const unsigned slen = bgzf[q + 2] | (bgzf[q + 3] << 8);
+                if (bgzf[q] == 'B' && bgzf[q + 1] == 'C' && slen == 2 && q + 6 <= n) bsize = (uint64_t)(bgzf[q + 4] | (bgzf[q + 5] << 8)) + 1;
+                q += 4 + slen;
+            }
+            if (!bsize || bsize < 12ull + xlen + 8 || p + bsize > n) return fail(c, "lps_bgzf_load: truncated BGZF block");
+            const uint64_t isize = (uint64_t)bgzf[p + bsize - 4] | ((uint64_t)bgzf[p + bsize - 3] << 8) | ((uint64_t)bgzf[p + bsize - 2] << 16) | ((uint64_t)bgzf[p + bsize - 1] << 24);
+            if (isize > 65536) return fail(c, "lps_bgzf_load: BGZF block larger than 64 KiB");
+            blks.push_back(InflateBlock{p + 12 + xlen, utot, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize});
+            utot += isize; p += bsize;
+        }
+        if (p != n || blks.empty()) return fail(c, "lps_bgzf_load: trailing bytes after the last BGZF block");
+        if (blks.size() > 0x7fffffffull) return fail(c, "lps_bgzf_load: too many blocks");
+        hipStream_t s = c->stream; hipEvent_t e0, e1, e2;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
+        c->zfile.reserve(n + 64, s); c->file.reserve(utot + 64, s); c->zblk.reserve(blks.size(), s); c->bam_err.reserve(1);
+        HIP_TRY(hipEventRecord(e0, s));
+        HIP_TRY(hipMemcpyAsync(c->zfile.p, bgzf, n, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(c->zfile.p + n, 0, 64, s));
+        HIP_TRY(hipMemcpyAsync(c->zblk.p, blks.data(), blks.size() * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s));
+        HIP_TRY(hipEventRecord(e1, s));
+        launch_bgzf_inflate(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, s);
+        HIP_TRY(hipMemsetAsync(c->file.p + utot, 0, 64, s));
+        HIP_TRY(hipEventRecord(e2, s));
+        unsigned err = 0;
         HIP_TRY(hipMemcpyAsync(&err, c->bam_err.p, sizeof err, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (err & LPS_BAM_ERR_BOUNDS) return fail(c, "BAM record does not fit the bytes handed over (truncated or corrupt record)");
-        if (err & LPS_BAM_ERR_UNSORTED) return fail(c, "alignments must be coordinate-sorted");
-        if (err & LPS_BAM_ERR_CG_TAG) return fail(c, "CIGAR stored in a CG tag (more than 65535 operations) is not supported");
-        c->cigar.reserve(total + 1, s, true, c->n_cig);
-        launch_bam_cigar(B, (int)n, c->r_coff.p + at, c->cigar.p, s);
-        HIP_TRY(hipStreamSynchronize(s));
-        c->nR += (int)n; c->n_cig = total; c->n_blob = (base + (uint64_t)n_bytes + 15) & ~15ull;
-        c->phase_valid = false;
+        HIP_TRY(hipEventElapsedTime(&c->bgzf_h2d_ms, e0, e1)); HIP_TRY(hipEventElapsedTime(&c->bgzf_inflate_ms, e1, e2));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+        c->file_bytes = 0; c->n_rec_all = 0; c->names_ready = false;
+        if (err) return fail(c, err & LPS_INF_ERR_DATA ? "lps_bgzf_load: corrupt deflate stream" : "lps_bgzf_load: a block does not inflate to its ISIZE");
+        c->file_bytes = utot;
+        if (inflated_bytes) *inflated_bytes = (int64_t)utot;
     } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_bgzf_read(lps_ctx *c, int64_t offset, int64_t n, uint8_t *dst) {
+    if (!c || !dst || offset < 0 || n < 0 || (uint64_t)(offset + n) > c->file_bytes) return fail(c, "lps_bgzf_read: range outside the inflated stream");
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        if (n) HIP_TRY(hipMemcpyAsync(dst, c->file.p + offset, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_bgzf_timings(lps_ctx *c, double *h2d_ms, double *inflate_ms) {
+    if (!c) return -1;
+    if (h2d_ms) *h2d_ms = c->bgzf_h2d_ms;
+    if (inflate_ms) *inflate_ms = c->bgzf_inflate_ms;
     return 0;
 }
 
@@ -277,7 +431,7 @@ static ReadView read_view(lps_ctx *c) {
     ReadView R{};
     R.n = c->nR; R.ref_start = c->r_start.p; R.l_qseq = c->r_lq.p; R.flag = c->r_flag.p; R.mapq = c->r_mapq.p; R.name_id = c->r_name.p;
     R.cigar_off = c->r_coff.p; R.seq_off = c->r_soff.p; R.qual_off = c->r_qoff.p; R.cigar = c->cigar.p;
-    if (c->read_mode == 2) R.seq = R.qual = c->blob.p; else { R.seq = c->seq.p; R.qual = c->qual.p; }
+    if (c->read_mode == 2) R.seq = R.qual = c->blob.p; else if (c->read_mode == 3) R.seq = R.qual = c->file.p; else { R.seq = c->seq.p; R.qual = c->qual.p; }
     return R;
 }
 

@@ -19,3 +19,8 @@ void launch_bam_core(const BamView &B, int n, int at, int32_t *ref_start, int32_
                      uint64_t *qual_off, unsigned long long *cig_cnt, unsigned *err, hipStream_t s);
 void launch_bam_cigar(const BamView &B, int n, const uint64_t *cigar_off, uint32_t *cigar, hipStream_t s);
 void bam_cigar_offsets(DevBuf<char> &temp, size_t &temp_bytes, const unsigned long long *cig_cnt, uint64_t *cigar_off, int n, uint64_t init, hipStream_t s);
+// record discovery in a resident (GPU-inflated) BAM stream; returns 0, or <0: -2 stream too large, -3 no record found, -4 broken record chain
+int bam_scan_records(const uint8_t *d, uint64_t first_rec, uint64_t total, int32_t n_ref, DevBuf<uint64_t> &cand, DevBuf<uint32_t> &wg_cnt, DevBuf<uint32_t> &wg_off,
+                     DevBuf<char> &temp, size_t &temp_bytes, unsigned *flag, uint32_t *n_out_d, uint64_t *n_records, hipStream_t s);
+void launch_bam_tid_lname(const uint8_t *d, const uint64_t *cand, uint32_t n, int32_t *tid, uint32_t *l_name, hipStream_t s);
+void launch_bam_names(const uint8_t *d, const uint64_t *cand, uint32_t n, const uint32_t *name_off, uint8_t *names, hipStream_t s);

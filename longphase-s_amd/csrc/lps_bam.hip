@@ -80,3 +80,122 @@ void bam_cigar_offsets(DevBuf<char> &temp, size_t &temp_bytes, const unsigned lo
     if (need + 256 > temp_bytes) { temp.reserve(need + 256, s); temp_bytes = need + 256; }
     HIP_TRY(rocprim::exclusive_scan(temp.p, need, cig_cnt, out, (unsigned long long)init, (size_t)n + 1, rocprim::plus<unsigned long long>(), s));
 }
+
+// ================================================================================================ record discovery in a resident BAM stream
+// A BAM stream is a chain of records (block_size + body) that can only be walked serially.  On the GPU every byte position is tested against
+// the NECESSARY conditions of a record start (fields in range, sizes consistent, name NUL-terminated), which true starts always pass and random
+// payload bytes pass with negligible probability; the ordered candidate list is then VERIFIED to be exactly the chain (candidate i ends where
+// candidate i+1 begins, the first is the known first record, the last ends at the end of the stream).  If the verification fails the chain is
+// walked serially over the candidate list (k_bam_chain_serial), so the result is exact for any input.
+__device__ __forceinline__ bool bam_candidate(const uint8_t *d, uint64_t p, uint64_t total, int32_t n_ref) {
+    if (p + 36 > total) return false;
+    const int32_t tid = (int32_t)ld_u32_unaligned(d + p + 4);
+    if (tid < -1 || tid >= n_ref) return false;
+    const uint32_t bs = ld_u32_unaligned(d + p);
+    if (bs < 34 || bs > (1u << 29) || p + 4 + bs > total) return false;
+    const int32_t mtid = (int32_t)ld_u32_unaligned(d + p + 24);
+    if (mtid < -1 || mtid >= n_ref) return false;
+    if ((int32_t)ld_u32_unaligned(d + p + 8) < -1) return false;
+    const uint32_t l_name = d[p + 12], n_cig = ld_u16(d + p + 16), l_seq = ld_u32_unaligned(d + p + 20);
+    if (l_name < 1 || (int32_t)l_seq < 0) return false;
+    if (32ull + l_name + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq > bs) return false;
+    return d[p + 36 + l_name - 1] == 0;
+}
+
+// 256 threads x 16 consecutive positions; PASS 0 counts per workgroup, PASS 1 writes the ordered candidates (value = offset of the refID field)
+template <int PASS>
+__global__ void __launch_bounds__(256) k_bam_candidates(const uint8_t *d, uint64_t begin, uint64_t total, int32_t n_ref, uint32_t *wg_count,
+                                                        const uint32_t *wg_off, uint64_t *cand) {
+    __shared__ uint32_t s_cnt[256];
+    const uint64_t p0 = begin + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    uint32_t mask = 0;
+    for (int k = 0; k < 16; ++k) if (p0 + k < total && bam_candidate(d, p0 + k, total, n_ref)) mask |= 1u << k;
+    s_cnt[threadIdx.x] = __popc(mask);
+    __syncthreads();
+    for (int s = 1; s < 256; s <<= 1) { const uint32_t v = threadIdx.x >= (unsigned)s ? s_cnt[threadIdx.x - s] : 0; __syncthreads(); s_cnt[threadIdx.x] += v; __syncthreads(); }
+    if (PASS == 0) { if (threadIdx.x == 255) wg_count[blockIdx.x] = s_cnt[255]; return; }
+    uint32_t at = wg_off[blockIdx.x] + s_cnt[threadIdx.x] - __popc(mask);
+    for (int k = 0; k < 16; ++k) if (mask >> k & 1) cand[at++] = p0 + k + 4;
+}
+
+// flag[0] |= 1 when the candidates are not exactly the record chain
+__global__ void __launch_bounds__(256) k_bam_chain_check(const uint8_t *d, const uint64_t *cand, uint32_t n, uint64_t first_ref_off, uint64_t total, unsigned *flag) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t r = cand[i]; const uint64_t next = r + ld_u32_unaligned(d + r - 4) + 4;   // refID offset of the following record
+    bool ok = (i + 1 < n) ? cand[i + 1] == next : next - 4 == total;
+    if (i == 0 && r != first_ref_off) ok = false;
+    if (!ok) atomicOr(flag, 1u);
+}
+
+// exact fallback: walk the chain serially, keeping the candidates that are on it (binary search per hop); flag |= 2 when the chain leaves the list
+__global__ void k_bam_chain_serial(const uint8_t *d, uint64_t *cand, uint32_t n, uint64_t first_ref_off, uint64_t total, uint32_t *n_out, unsigned *flag) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint64_t r = first_ref_off; uint32_t out = 0, lo = 0;
+    while (r - 4 < total) {
+        uint32_t a = lo, b = n;
+        while (a < b) { const uint32_t m = (a + b) >> 1; if (cand[m] < r) a = m + 1; else b = m; }
+        if (a >= n || cand[a] != r) { atomicOr(flag, 2u); break; }
+        cand[out++] = r; lo = a + 1;                                    // out <= a: in place
+        r = r + ld_u32_unaligned(d + r - 4) + 4;
+    }
+    if (r - 4 != total) atomicOr(flag, 2u);
+    *n_out = out;
+}
+
+// per record: contig id and name length (for the host's per-contig ranges and name ranking)
+__global__ void __launch_bounds__(256) k_bam_tid_lname(const uint8_t *d, const uint64_t *cand, uint32_t n, int32_t *tid, uint32_t *l_name) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t r = cand[i];
+    tid[i] = (int32_t)ld_u32_unaligned(d + r); l_name[i] = d[r + 8];
+}
+__global__ void __launch_bounds__(256) k_bam_names(const uint8_t *d, const uint64_t *cand, uint32_t n, const uint32_t *name_off, uint8_t *names) {
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const uint64_t r = cand[i]; const uint32_t l = d[r + 8], o = name_off[i];
+    for (uint32_t k = lane; k < l; k += 64) names[o + k] = d[r + 32 + k];
+}
+
+int bam_scan_records(const uint8_t *d, uint64_t first_rec, uint64_t total, int32_t n_ref, DevBuf<uint64_t> &cand, DevBuf<uint32_t> &wg_cnt, DevBuf<uint32_t> &wg_off,
+                     DevBuf<char> &temp, size_t &temp_bytes, unsigned *flag, uint32_t *n_out_d, uint64_t *n_records, hipStream_t s) {
+    *n_records = 0;
+    if (first_rec >= total) return 0;
+    const uint64_t span = total - first_rec; const uint64_t n_wg64 = (span + 4095) / 4096;
+    if (n_wg64 > 0x7fffffffull) return -2;
+    const uint32_t n_wg = (uint32_t)n_wg64;
+    wg_cnt.reserve(n_wg + 1, s); wg_off.reserve(n_wg + 1, s);
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned), s));
+    HIP_TRY(hipMemsetAsync(wg_cnt.p + n_wg, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_bam_candidates<0>, dim3(n_wg), dim3(256), 0, s, d, first_rec, total, n_ref, wg_cnt.p, (const uint32_t *)nullptr, (uint64_t *)nullptr);
+    size_t need = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, need, wg_cnt.p, wg_off.p, 0u, (size_t)n_wg + 1, rocprim::plus<uint32_t>(), s));
+    if (need + 256 > temp_bytes) { temp.reserve(need + 256, s); temp_bytes = need + 256; }
+    HIP_TRY(rocprim::exclusive_scan(temp.p, need, wg_cnt.p, wg_off.p, 0u, (size_t)n_wg + 1, rocprim::plus<uint32_t>(), s));
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, wg_off.p + n_wg, sizeof n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (n == 0) return -3;
+    cand.reserve((size_t)n + 1, s);
+    hipLaunchKernelGGL(k_bam_candidates<1>, dim3(n_wg), dim3(256), 0, s, d, first_rec, total, n_ref, wg_cnt.p, (const uint32_t *)wg_off.p, cand.p);
+    hipLaunchKernelGGL(k_bam_chain_check, dim3((n + 255) / 256), dim3(256), 0, s, d, (const uint64_t *)cand.p, n, first_rec + 4, total, flag);
+    unsigned f = 0;
+    HIP_TRY(hipMemcpyAsync(&f, flag, sizeof f, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (f) {                                                            // some candidate is not a record: exact serial walk
+        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned), s));
+        hipLaunchKernelGGL(k_bam_chain_serial, dim3(1), dim3(64), 0, s, d, cand.p, n, first_rec + 4, total, n_out_d, flag);
+        HIP_TRY(hipMemcpyAsync(&f, flag, sizeof f, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&n, n_out_d, sizeof n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (f) return -4;
+    }
+    *n_records = n;
+    return 0;
+}
+void launch_bam_tid_lname(const uint8_t *d, const uint64_t *cand, uint32_t n, int32_t *tid, uint32_t *l_name, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_bam_tid_lname, dim3((n + 255) / 256), dim3(256), 0, s, d, cand, n, tid, l_name);
+}
+void launch_bam_names(const uint8_t *d, const uint64_t *cand, uint32_t n, const uint32_t *name_off, uint8_t *names, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_bam_names, dim3((n + 3) / 4), dim3(256), 0, s, d, cand, n, name_off, names);
+}

@@ -46,6 +46,13 @@ def load():
     L.lps_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.lps_push_reads.argtypes = [C.c_void_p, C.POINTER(abi.ReadBatch)]
     L.lps_push_bam_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    L.lps_bgzf_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.lps_bgzf_read.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    L.lps_bgzf_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.lps_bam_scan.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
+    L.lps_bam_record_tids.argtypes = [C.c_void_p, C.c_void_p]
+    L.lps_bam_names.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.lps_push_bam_resident.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     L.lps_phase_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.PhaseResult)]
     L.lps_haplotag_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.HaplotagResult)]
     L.lps_somatic_tag_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.SomaticTagResult)]
@@ -104,6 +111,48 @@ class Context:
                 self._check(self.L.lps_push_reads(self.h, C.byref(r.c)), "lps_push_reads")
             self.n_reads += r.n_reads
         self.n_var = variants.n
+
+    def bgzf_load(self, data):
+        """Upload a whole .bam file (bytes / uint8 array) and inflate it on the GPU; returns the inflated size."""
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        n = C.c_int64(0)
+        self._check(self.L.lps_bgzf_load(self.h, a.ctypes.data, a.size, C.byref(n)), "lps_bgzf_load")
+        return int(n.value)
+
+    def bam_scan(self, first_record_offset, n_ref):
+        n = C.c_int64(0)
+        self._check(self.L.lps_bam_scan(self.h, first_record_offset, n_ref, C.byref(n)), "lps_bam_scan")
+        tid = np.empty(n.value, dtype=np.int32)
+        self._check(self.L.lps_bam_record_tids(self.h, tid.ctypes.data), "lps_bam_record_tids")
+        return tid
+
+    def bam_names(self, first, count):
+        nb = C.c_int64(0)
+        self._check(self.L.lps_bam_names(self.h, first, count, None, None, 0, C.byref(nb)), "lps_bam_names")
+        off = np.empty(count + 1, dtype=np.uint32); buf = np.empty(max(1, nb.value), dtype=np.uint8)
+        self._check(self.L.lps_bam_names(self.h, first, count, off.ctypes.data, buf.ctypes.data, buf.size, C.byref(nb)), "lps_bam_names")
+        raw = buf.tobytes()
+        return [raw[off[i]:off[i + 1] - 1] for i in range(count)]
+
+    def load_resident(self, variants, ref, first, count, name_id):
+        """begin_chromosome + set_variants + set_reference + lps_push_bam_resident (records of a BAM inflated on the GPU)."""
+        self._check(self.L.lps_begin_chromosome(self.h), "lps_begin_chromosome")
+        self._check(self.L.lps_set_variants(self.h, C.byref(variants.c)), "lps_set_variants")
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        self._check(self.L.lps_set_reference(self.h, ref.ctypes.data, ref.size), "lps_set_reference")
+        nid = np.ascontiguousarray(name_id, dtype=np.uint32)
+        self._check(self.L.lps_push_bam_resident(self.h, first, count, nid.ctypes.data), "lps_push_bam_resident")
+        self.n_reads = count; self.n_var = variants.n
+
+    def bgzf_read(self, offset, n):
+        out = np.empty(n, dtype=np.uint8)
+        self._check(self.L.lps_bgzf_read(self.h, offset, n, out.ctypes.data), "lps_bgzf_read")
+        return out
+
+    def bgzf_timings(self):
+        a, b = C.c_double(0), C.c_double(0)
+        self.L.lps_bgzf_timings(self.h, C.byref(a), C.byref(b))
+        return dict(h2d_ms=a.value, inflate_ms=b.value)
 
     def run_phase(self, out=None):
         out = out or abi.PhaseOut(self.n_var)

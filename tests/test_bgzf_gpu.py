@@ -1,0 +1,132 @@
+"""GPU BGZF inflate (lps_bgzf_load) against zlib: every deflate block type (stored, fixed, dynamic),
+several levels/strategies, empty and short blocks, the EOF block, and corrupt input."""
+import gzip
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import util
+from lps import abi, hip
+
+pytestmark = pytest.mark.gpu
+DATA = util.os.path.join(util.os.path.dirname(util.os.path.abspath(__file__)), "golden", "data")
+
+
+def bgzf(payload, block, level, strategy=zlib.Z_DEFAULT_STRATEGY, eof=True):
+    out = bytearray()
+    def put(chunk):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        comp = c.compress(bytes(chunk)) + c.flush()
+        out.extend(struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25))
+        out.extend(comp + struct.pack("<II", zlib.crc32(bytes(chunk)) & 0xFFFFFFFF, len(chunk)))
+    for a in range(0, len(payload), block):
+        put(payload[a:a + block])
+    if eof:
+        put(b"")
+    return bytes(out)
+
+
+def payloads():
+    rng = np.random.default_rng(5)
+    _, _, rec = util.bam_sections(_bam())
+    yield "bam_records", bytes(rec)
+    yield "random", rng.integers(0, 256, 300_000, dtype=np.uint8).tobytes()
+    yield "zeros", bytes(200_000)
+    yield "text", (b"ACGTTGCA" * 7 + b"the quick brown fox\n") * 3000
+    yield "long_matches", bytes(rng.integers(0, 4, 70_000, dtype=np.uint8)) * 3
+
+
+_cache = {}
+
+
+def _bam():
+    if "p" not in _cache:
+        import tempfile
+        d = tempfile.mkdtemp()
+        util.write_bam(util.os.path.join(DATA, "tiny_indel.sam.gz"), d + "/t.bam")
+        _cache["p"] = d + "/t.bam"
+    return _cache["p"]
+
+
+@pytest.mark.parametrize("level,strategy,block", [(6, zlib.Z_DEFAULT_STRATEGY, 0xff00), (1, zlib.Z_DEFAULT_STRATEGY, 0xff00), (9, zlib.Z_DEFAULT_STRATEGY, 65280),
+                                                    (0, zlib.Z_DEFAULT_STRATEGY, 40000), (6, zlib.Z_FIXED, 30000), (6, zlib.Z_RLE, 0xff00), (6, zlib.Z_HUFFMAN_ONLY, 0xff00),
+                                                    (6, zlib.Z_DEFAULT_STRATEGY, 7), (6, zlib.Z_DEFAULT_STRATEGY, 1000)])
+def test_inflate_matches_zlib(level, strategy, block):
+    with hip.Context(0, abi.default_params()) as ctx:
+        for name, data in payloads():
+            if block < 100:
+                data = data[:5000]
+            z = bgzf(data, block, level, strategy)
+            assert gzip.decompress(z) == data
+            n = ctx.bgzf_load(z)
+            assert n == len(data), name
+            got = ctx.bgzf_read(0, n).tobytes()
+            assert got == data, (name, level, strategy, block)
+
+
+def test_corrupt_streams_are_rejected_and_ctx_survives():
+    data = bytes(np.random.default_rng(1).integers(0, 64, 150_000, dtype=np.uint8))
+    z = bytearray(bgzf(data, 0xff00, 6))
+    with hip.Context(0, abi.default_params()) as ctx:
+        bad = bytearray(z); bad[40] ^= 0x5a; bad[41] ^= 0xa5; bad[300] ^= 0xff
+        with pytest.raises(hip.LpsError):
+            ctx.bgzf_load(bytes(bad))
+        isz = bytearray(z); isz[-28 - 4] ^= 1                       # ISIZE of the last data block off by one
+        with pytest.raises(hip.LpsError):
+            ctx.bgzf_load(bytes(isz))
+        with pytest.raises(hip.LpsError):
+            ctx.bgzf_load(bytes(z[:-5]))                            # truncated file
+        with pytest.raises(hip.LpsError):
+            ctx.bgzf_load(b"not a bgzf file, just some text that is long enough")
+        assert ctx.bgzf_load(bytes(z)) == len(data)                 # still usable
+        assert ctx.bgzf_read(1000, 5000).tobytes() == data[1000:6000]
+        print("timings", ctx.bgzf_timings())
+
+
+def _bam_header_end(ctx, n_inflated):
+    head = ctx.bgzf_read(0, min(n_inflated, 1 << 20)).tobytes()
+    assert head[:4] == b"BAM\1"
+    lt = struct.unpack_from("<i", head, 4)[0]
+    p = 8 + lt
+    n_ref = struct.unpack_from("<i", head, p)[0]; p += 4
+    names = []
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", head, p)[0]; names.append(head[p + 4:p + 4 + ln - 1].decode()); p += 4 + ln + 4
+    return p, names
+
+
+@pytest.mark.parametrize("name", ["snp_ont", "indels", "supp_overlap"])
+def test_phase_from_gpu_inflated_bam(name, tmp_path):
+    """whole input side on the GPU: BGZF inflate -> record discovery -> core decode -> phase; equals the host-decoded path and the reference golden"""
+    import fixtures
+    kw, cli, over = fixtures.PHASE_FIXTURES[name]
+    s, V, R = util.make_case(kw)
+    d = str(tmp_path)
+    s.write_sam(d + "/r.sam")
+    util.add_stale_tags(d + "/r.sam", d + "/t.sam")                  # optional fields after the qualities
+    n_rec = util.write_bam(d + "/t.sam", d + "/t.bam", block=0xff00)
+    assert n_rec == R.n_reads
+    raw = np.fromfile(d + "/t.bam", dtype=np.uint8)
+    with hip.Context(0, abi.default_params(**over)) as ctx:
+        want = ctx.phase(V, s.ref, R)
+        n = ctx.bgzf_load(raw)
+        first, refs = _bam_header_end(ctx, n)
+        tid = ctx.bam_scan(first, len(refs))
+        assert tid.size == n_rec and (tid == 0).all()
+        names = ctx.bam_names(0, n_rec)
+        text = [l.split("\t")[0].encode() for l in open(d + "/t.sam") if not l.startswith("@")]
+        assert names == text
+        rank = {nm: i for i, nm in enumerate(sorted(set(names)))}
+        ctx.load_resident(V, s.ref, 0, n_rec, [rank[x] for x in names])
+        got = ctx.run_phase()
+        assert np.array_equal(got.phase_set, want.phase_set) and np.array_equal(got.gt, want.gt)
+        gpos, gps, ggt = util.load_golden_phase(name)
+        util.assert_phase_equal(got.phase_set, got.gt, gps, ggt, name + " GPU-inflated BAM vs reference golden")
+        # a sub-range push (second half of the records) also works and mixing with another push kind is refused
+        ctx.load_resident(V, s.ref, n_rec // 2, n_rec - n_rec // 2, [rank[x] for x in names[n_rec // 2:]])
+        ctx.run_phase()
+        with pytest.raises(hip.LpsError, match="mixed"):
+            ctx._check(ctx.L.lps_push_reads(ctx.h, hip.C.byref(R.c)), "lps_push_reads")
+    s.close()
