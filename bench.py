@@ -104,6 +104,10 @@ def cli_e2e(d, threads, ref_wall, n_ph):
     ts.sort()
     body = lambda p: [l for l in open(p) if not l.startswith("##commandline=") and not l.startswith("##longphaseVersion=")]  # noqa: E731
     stages = r.stderr.decode().strip().splitlines()[-1] if r.stderr else ""
+    th = []
+    for _ in range(2):                                              # same CLI with zlib on the host threads instead of the GPU inflate
+        t0 = time.time(); rh = subprocess.run(cmd + ["--host-inflate"], cwd=d, capture_output=True); th.append(time.time() - t0)
+    host_stages = rh.stderr.decode().strip().splitlines()[-1] if rh.stderr else ""
     tag = None
     try:                                                            # same comparison for `haplotag` (reads tagged / s, end to end)
         import gzip
@@ -159,7 +163,8 @@ def cli_e2e(d, threads, ref_wall, n_ph):
               "zlib_1thread_s": round(zt, 2)}
     except Exception as e:  # noqa: BLE001
         gz = {"error": repr(e)[:300]}
-    return {"cli_wall_s": round(ts[1], 3), "cli_stages": stages, "haplotag": tag, "gpu_bgzf": gz, "reference_wall_s": round(ref_wall, 3), "speedup": round(ref_wall / ts[1], 2),
+    return {"cli_wall_s": round(ts[1], 3), "cli_stages": stages, "cli_host_inflate_wall_s": round(min(th), 3), "cli_host_inflate_stages": host_stages,
+            "haplotag": tag, "gpu_bgzf": gz, "reference_wall_s": round(ref_wall, 3), "speedup": round(ref_wall / ts[1], 2),
             "cli_snps_per_s": float(n_ph / ts[1]), "identical_vcf": body(d + "/gpu.vcf") == body(d + "/out.vcf"),
             "note": "same BAM/VCF/FASTA files, process start to exit, median of 3; CLI wall includes HIP runtime start-up"}
 

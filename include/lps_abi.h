@@ -252,6 +252,8 @@ int lps_bgzf_timings(lps_ctx *ctx, double *h2d_ms, double *inflate_ms);
  * lps_push_bam_resident: like lps_push_bam_records for records [first, first+count) of the resident stream - nothing is uploaded. */
 int lps_bam_scan(lps_ctx *ctx, int64_t first_record_offset, int32_t n_ref, int64_t *n_records);
 int lps_bam_record_tids(lps_ctx *ctx, int32_t *tid);
+/* offsets (inside the inflated stream) of the refID field of records [first, first+count) - for hosts that also need the bytes (lps_bgzf_read) */
+int lps_bam_record_offsets(lps_ctx *ctx, int64_t first, int64_t count, uint64_t *rec_off);
 int lps_bam_names(lps_ctx *ctx, int64_t first, int64_t count, uint32_t *name_off, char *names, int64_t names_cap, int64_t *names_bytes);
 int lps_push_bam_resident(lps_ctx *ctx, int64_t first, int64_t count, const uint32_t *name_id);
 

@@ -47,6 +47,9 @@ struct Lps {
     decltype(&lps_last_error) last_error = nullptr; decltype(&lps_begin_chromosome) begin_chromosome = nullptr; decltype(&lps_set_variants) set_variants = nullptr;
     decltype(&lps_set_reference) set_reference = nullptr; decltype(&lps_push_bam_records) push_bam_records = nullptr; decltype(&lps_phase_chromosome) phase_chromosome = nullptr;
     decltype(&lps_haplotag_chromosome) haplotag_chromosome = nullptr; decltype(&lps_abi_version) abi_version = nullptr;
+    decltype(&lps_bgzf_load) bgzf_load = nullptr; decltype(&lps_bgzf_read) bgzf_read = nullptr; decltype(&lps_bam_scan) bam_scan = nullptr;
+    decltype(&lps_bam_record_tids) bam_record_tids = nullptr; decltype(&lps_bam_names) bam_names = nullptr; decltype(&lps_push_bam_resident) push_bam_resident = nullptr;
+    decltype(&lps_bam_record_offsets) bam_record_offsets = nullptr;
     std::string error;
     bool load() {
         char exe[4096]; const ssize_t k = readlink("/proc/self/exe", exe, sizeof exe - 1);
@@ -59,7 +62,8 @@ struct Lps {
         LPS_SYM(default_params, lps_default_params) LPS_SYM(create, lps_create) LPS_SYM(destroy, lps_destroy) LPS_SYM(last_error, lps_last_error)
         LPS_SYM(begin_chromosome, lps_begin_chromosome) LPS_SYM(set_variants, lps_set_variants) LPS_SYM(set_reference, lps_set_reference)
         LPS_SYM(push_bam_records, lps_push_bam_records) LPS_SYM(phase_chromosome, lps_phase_chromosome) LPS_SYM(haplotag_chromosome, lps_haplotag_chromosome)
-        LPS_SYM(abi_version, lps_abi_version)
+        LPS_SYM(abi_version, lps_abi_version) LPS_SYM(bgzf_load, lps_bgzf_load) LPS_SYM(bgzf_read, lps_bgzf_read) LPS_SYM(bam_scan, lps_bam_scan)
+        LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets)
 #undef LPS_SYM
         if (abi_version() != LPS_ABI_VERSION) { error = "liblps_hip.so has a different ABI version than this binary was built for"; return false; }
         return true;
@@ -165,6 +169,60 @@ static void rank_names(const std::vector<std::pair<const char *, size_t>> &names
     id.resize(names.size()); uint32_t cur = 0;
     for (size_t k = 0; k < idx.size(); ++k) { if (k && (less(idx[k - 1], idx[k]) || less(idx[k], idx[k - 1]))) ++cur; id[idx[k]] = cur; }
 }
+
+// One BAM file inflated and indexed ON THE GPU (lps_bgzf_load + lps_bam_scan): the host only maps the compressed file, parses the BAM header
+// and ranks the read names of each contig.
+struct GpuBam {
+    std::vector<std::string> ref_names; std::vector<int32_t> tid; std::map<std::string, std::pair<int64_t, int64_t>> range;   // contig -> (first record, count)
+    double t_map = 0, t_inflate = 0, t_scan = 0; int64_t total = 0;
+    void load(Lps &L, lps_ctx *ctx, const std::string &path) {
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now();
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) die("ERROR: Cannot open bam file " + path);
+        struct stat st; if (fstat(fd, &st) != 0 || st.st_size < 28) die("ERROR: " + path + " is not a BGZF/BAM file");
+        const size_t fsz = (size_t)st.st_size;
+        const uint8_t *raw = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        if (raw == (const uint8_t *)MAP_FAILED) die("ERROR: Cannot map " + path);
+        const double t1 = now(); t_map = t1 - t0;
+        if (L.bgzf_load(ctx, raw, (int64_t)fsz, &total)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
+        munmap((void *)raw, fsz); close(fd);
+        const double t2 = now(); t_inflate = t2 - t1;
+        std::vector<uint8_t> head((size_t)std::min<int64_t>(total, 1 << 16));
+        auto fetch = [&](size_t need) { if (need > (size_t)total) die("ERROR: truncated BAM header in " + path); if (need > head.size()) head.resize(need); if (L.bgzf_read(ctx, 0, (int64_t)head.size(), head.data())) die(std::string("ERROR: ") + L.last_error(ctx)); };
+        fetch(head.size());
+        if (head.size() < 12 || memcmp(head.data(), "BAM\1", 4)) die("ERROR: " + path + " is not a BAM file");
+        size_t p = 8 + (size_t)rd32(head.data() + 4);
+        if (p + 4 > head.size()) fetch(p + 4);
+        const uint32_t n_ref = rd32(head.data() + p); p += 4;
+        ref_names.resize(n_ref);
+        for (uint32_t i = 0; i < n_ref; ++i) {
+            if (p + 4 > head.size()) fetch(std::min<size_t>((size_t)total, p + (1 << 16)));
+            const uint32_t l = rd32(head.data() + p); if (!l) die("ERROR: truncated BAM header in " + path);
+            if (p + 4 + l + 4 > head.size()) fetch(std::min<size_t>((size_t)total, p + 4 + l + 4 + (1 << 16)));
+            if (p + 4 + l + 4 > head.size()) die("ERROR: truncated BAM header in " + path);
+            ref_names[i] = std::string((const char *)head.data() + p + 4, l - 1); p += 4 + (size_t)l + 4;
+        }
+        int64_t n = 0;
+        if (L.bam_scan(ctx, (int64_t)p, (int32_t)n_ref, &n)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
+        tid.resize((size_t)n);
+        if (n && L.bam_record_tids(ctx, tid.data())) die(std::string("ERROR: ") + L.last_error(ctx));
+        for (int64_t i = 0; i < n;) {                                  // a coordinate-sorted BAM holds every contig as ONE run of records
+            int64_t j = i; while (j < n && tid[(size_t)j] == tid[(size_t)i]) ++j;
+            if (tid[(size_t)i] >= 0) { const std::string &nm = ref_names[(size_t)tid[(size_t)i]]; if (range.count(nm)) die("ERROR: " + path + " is not coordinate-sorted"); range[nm] = {i, j - i}; }
+            i = j;
+        }
+        t_scan = now() - t2;
+    }
+    // names of records [first, first+count) -> (pointer, length) pairs into `store`
+    void names(Lps &L, lps_ctx *ctx, int64_t first, int64_t count, std::vector<char> &store, std::vector<uint32_t> &off, std::vector<std::pair<const char *, size_t>> &out) {
+        int64_t nb = 0;
+        if (L.bam_names(ctx, first, count, nullptr, nullptr, 0, &nb)) die(std::string("ERROR: ") + L.last_error(ctx));
+        store.resize((size_t)nb + 1); off.resize((size_t)count + 1);
+        if (L.bam_names(ctx, first, count, off.data(), store.data(), (int64_t)store.size(), &nb)) die(std::string("ERROR: ") + L.last_error(ctx));
+        for (int64_t i = 0; i < count; ++i) out.emplace_back(store.data() + off[(size_t)i], (size_t)(off[(size_t)i + 1] - off[(size_t)i]) - 1);
+    }
+};
 
 // ------------------------------------------------------------------------------------------------ text inputs
 static bool read_lines(const std::string &path, std::vector<std::string> &lines) {   // plain or gzip text
@@ -281,11 +339,12 @@ static const char *kUsage =
     "Usage: longphase_amd phase [OPTION] ... READSFILE\n"
     "   -s, --snp-file=NAME   -b, --bam-file=NAME (repeatable)   -r, --reference=NAME   -o, --out-prefix=NAME (result)   -t, --threads=Num (1)\n"
     "   --ont | --pb   --indels   -q MAPQ(1)  -p baseQuality(12)  -e edgeWeight(0.1)  -a connectAdjacent(35)  -d distance(300000)\n"
-    "   -1 edgeThreshold(0.7)  -L overlapThreshold(0.2)  -m readConfidence(0.65)  -n snpConfidence(0.75)  --gpu=ID (0)\n";
+    "   -1 edgeThreshold(0.7)  -L overlapThreshold(0.2)  -m readConfidence(0.65)  -n snpConfidence(0.75)  --gpu=ID (0)\n"
+    "   --host-inflate   inflate BGZF with zlib on the -t host threads instead of on the GPU (always used when several -b files are given)\n";
 
 static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over; bool indels = false;
-    std::string snp, ref, prefix = "result"; std::vector<std::string> bams; int threads = 1, gpu = 0; bool ont = false, pb = false;
+    std::string snp, ref, prefix = "result"; std::vector<std::string> bams; int threads = 1, gpu = 0; bool ont = false, pb = false, host_inflate = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -309,6 +368,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "-n" || a == "--snpConfidence") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.snp_confidence = x; }); }
         else if (a == "-x" || a == "--mismatchRate") (void)val();
         else if (a == "--gpu") gpu = std::stoi(val());
+        else if (a == "--host-inflate") host_inflate = true;
         else if (a == "--help") { std::cout << kUsage; return 0; }
         else if (a == "--sv-file" || a == "--mod-file" || a == "--dot" || a == "--deepsomatic_output" || a == "--indelQuality") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kUsage; return 1; }
@@ -329,19 +389,25 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::map<std::string, int> want; for (auto &kv : vars) if (!kv.second.pos.empty()) want[kv.first] = 1;
     std::map<std::string, std::string> seqs; read_fasta(ref, vars, seqs);
     const double t_text = now();
-    std::vector<BamFile> files(bams.size());
-    for (size_t b = 0; b < bams.size(); ++b) files[b].load(bams[b], threads, want);
+    // one BAM: BGZF inflate, record discovery and record decode all run on the GPU; several BAMs (or --host-inflate): zlib on `-t` host threads
+    const bool gpu_input = bams.size() == 1 && !host_inflate;
+    std::vector<BamFile> files(gpu_input ? 0 : bams.size());
+    for (size_t b = 0; b < files.size(); ++b) files[b].load(bams[b], threads, want);
     const double t_bam = now();
 
     gpu_init.join();
     if (!ctx) die("longphase_amd: " + L.error);
     const double t_ctx = now();
+    GpuBam gb; if (gpu_input) gb.load(L, ctx, bams[0]);
+    const double t_gin = now();
     std::map<std::string, std::map<int32_t, Phased>> res;
     for (const std::string &chr : chr_order) {                       // PhasingProcess.cpp:113-173
         ChrVariants &cv = vars[chr];
         if (cv.pos.empty() || !seqs.count(chr)) continue;
         // names of all files of this contig ranked together (one read name = one merged row, whatever file it came from)
-        std::vector<std::pair<const char *, size_t>> names; std::vector<const ContigRecords *> parts;
+        std::vector<std::pair<const char *, size_t>> names; std::vector<const ContigRecords *> parts; std::vector<char> name_store; std::vector<uint32_t> name_off;
+        std::pair<int64_t, int64_t> gr{0, 0};
+        if (gpu_input) { auto it = gb.range.find(chr); if (it == gb.range.end()) continue; gr = it->second; gb.names(L, ctx, gr.first, gr.second, name_store, name_off, names); }
         for (BamFile &f : files) { auto it = f.contigs.find(chr); if (it == f.contigs.end() || it->second.rec_off.empty()) { parts.push_back(nullptr); continue; }
             parts.push_back(&it->second); for (size_t i = 0; i < it->second.rec_off.size(); ++i) { size_t l; const char *nm = f.name_of(it->second, i, l); names.emplace_back(nm, l); } }
         if (names.empty()) continue;
@@ -352,6 +418,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         const std::string &sq = seqs[chr];
         if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size())) die(std::string("longphase_amd: ") + L.last_error(ctx));
         size_t at = 0;
+        if (gpu_input && L.push_bam_resident(ctx, gr.first, gr.second, name_id.data())) die(std::string("longphase_amd: ") + L.last_error(ctx));
         for (size_t b = 0; b < files.size(); ++b) {                  // BAM files in -b order (ParsingBam.cpp:1252)
             if (!parts[b]) continue;
             const ContigRecords &c = *parts[b];
@@ -370,8 +437,10 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     L.destroy(ctx);
     const double t_gpu = now();
     write_vcf(vcf_lines, prefix + ".vcf", res, vars, command);
-    fprintf(stderr, "vcf+fasta read %.3fs | bam inflate+walk %.3fs | wait for gpu context %.3fs | upload+phase %.3fs | write vcf %.3fs | total %.3fs\n", t_text - t_begin,
-            t_bam - t_text, t_ctx - t_bam, t_gpu - t_ctx, now() - t_gpu, now() - t_begin);
+    if (gpu_input) fprintf(stderr, "vcf+fasta read %.3fs | wait for gpu context %.3fs | map bam %.3fs | upload+gpu inflate %.3fs | gpu record scan %.3fs | names+decode+phase %.3fs | write vcf %.3fs | total %.3fs\n",
+                           t_text - t_begin, t_ctx - t_bam, gb.t_map, gb.t_inflate, gb.t_scan, t_gpu - t_gin, now() - t_gpu, now() - t_begin);
+    else fprintf(stderr, "vcf+fasta read %.3fs | bam inflate+walk %.3fs | wait for gpu context %.3fs | upload+phase %.3fs | write vcf %.3fs | total %.3fs\n", t_text - t_begin,
+                 t_bam - t_text, t_ctx - t_bam, t_gpu - t_ctx, now() - t_gpu, now() - t_begin);
     fflush(stderr);
     _exit(0);   // outputs are closed and flushed; skip the ROCm runtime's static teardown (~0.1 s)
 }
@@ -422,33 +491,42 @@ struct BgzfWriter {
     FILE *f = nullptr; int threads = 1, level = 6, strategy = Z_RLE; unsigned long long bytes_out = 0; std::vector<uint8_t> pend;   // pend: < one block of bytes not yet written
     static constexpr size_t B = 0xff00;
     void open(const std::string &path, int t, int lvl, int strat) { f = fopen(path.c_str(), "wb"); if (!f) die("Fail to open write file: " + path); threads = std::max(1, t); level = lvl; strategy = strat; }
-    // deflate n_blk blocks of B bytes (the last one may be shorter) starting at p and write them in order
+    // deflate the blocks of B bytes (the last one may be shorter) starting at p and write them in order; batches of 1024 blocks, the finished
+    // batch is written by a helper thread while the pool deflates the next one
+    std::thread writer; std::vector<std::vector<uint8_t>> inflight; std::atomic<int> write_bad{0};
+    void wait_writer() { if (writer.joinable()) writer.join(); if (write_bad) die("ERROR: write output bam file failed"); }
     void emit(const uint8_t *p, size_t n) {
-        const size_t nblk = (n + B - 1) / B; if (!nblk) return;
-        std::vector<std::vector<uint8_t>> out(nblk); std::atomic<size_t> next{0}; std::vector<std::thread> th; std::atomic<int> bad{0};
-        auto work = [&] {
-            z_stream zs{}; if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, strategy) != Z_OK) { bad = 1; return; }
-            for (;;) { const size_t b = next.fetch_add(1); if (b >= nblk) break;
-                const size_t off = b * B, len = std::min(B, n - off);
-                std::vector<uint8_t> &o = out[b]; o.resize(18 + deflateBound(&zs, (uLong)len) + 8);
-                deflateReset(&zs); zs.next_in = const_cast<uint8_t *>(p) + off; zs.avail_in = (uInt)len; zs.next_out = o.data() + 18; zs.avail_out = (uInt)(o.size() - 26);
-                if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { bad = 1; break; }
-                const size_t clen = zs.total_out, bsize = 18 + clen + 8;
-                if (bsize > 65536) { bad = 1; break; }
-                const uint8_t hdr[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1) & 255), (uint8_t)((bsize - 1) >> 8)};
-                memcpy(o.data(), hdr, 18);
-                const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), p + off, (uInt)len), isz = (uint32_t)len;
-                for (int k = 0; k < 4; ++k) { o[18 + clen + k] = (uint8_t)(crc >> (8 * k)); o[22 + clen + k] = (uint8_t)(isz >> (8 * k)); }
-                o.resize(bsize);
-            }
-            deflateEnd(&zs);
-        };
-        const int nt = (int)std::min<size_t>(threads, nblk);
-        for (int t = 1; t < nt; ++t) th.emplace_back(work);
-        work();
-        for (auto &x : th) x.join();
-        if (bad) die("ERROR: deflate failed");
-        for (auto &o : out) { if (fwrite(o.data(), 1, o.size(), f) != o.size()) die("ERROR: write output bam file failed"); bytes_out += o.size(); }
+        const size_t total_blk = (n + B - 1) / B, batch = 1024;
+        for (size_t b0 = 0; b0 < total_blk; b0 += batch) {
+            const size_t nblk = std::min(batch, total_blk - b0); const uint8_t *q = p + b0 * B; const size_t qn = std::min(n - b0 * B, nblk * B);
+            std::vector<std::vector<uint8_t>> out(nblk); std::atomic<size_t> next{0}; std::vector<std::thread> th; std::atomic<int> bad{0};
+            auto work = [&] {
+                z_stream zs{}; if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, strategy) != Z_OK) { bad = 1; return; }
+                for (;;) { const size_t b = next.fetch_add(1); if (b >= nblk) break;
+                    const size_t off = b * B, len = std::min(B, qn - off);
+                    std::vector<uint8_t> &o = out[b]; o.resize(18 + deflateBound(&zs, (uLong)len) + 8);
+                    deflateReset(&zs); zs.next_in = const_cast<uint8_t *>(q) + off; zs.avail_in = (uInt)len; zs.next_out = o.data() + 18; zs.avail_out = (uInt)(o.size() - 26);
+                    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { bad = 1; break; }
+                    const size_t clen = zs.total_out, bsize = 18 + clen + 8;
+                    if (bsize > 65536) { bad = 1; break; }
+                    const uint8_t hdr[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1) & 255), (uint8_t)((bsize - 1) >> 8)};
+                    memcpy(o.data(), hdr, 18);
+                    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), q + off, (uInt)len), isz = (uint32_t)len;
+                    for (int k = 0; k < 4; ++k) { o[18 + clen + k] = (uint8_t)(crc >> (8 * k)); o[22 + clen + k] = (uint8_t)(isz >> (8 * k)); }
+                    o.resize(bsize);
+                }
+                deflateEnd(&zs);
+            };
+            const int nt = (int)std::min<size_t>(threads, nblk);
+            for (int t = 1; t < nt; ++t) th.emplace_back(work);
+            work();
+            for (auto &x : th) x.join();
+            if (bad) die("ERROR: deflate failed");
+            wait_writer();
+            inflight.swap(out);
+            for (auto &o : inflight) bytes_out += o.size();
+            writer = std::thread([this] { for (auto &o : inflight) if (fwrite(o.data(), 1, o.size(), f) != o.size()) { write_bad = 1; break; } });
+        }
     }
     void append(const uint8_t *p, size_t n) {
         if (!pend.empty()) {                                            // top up the open block first
@@ -461,7 +539,7 @@ struct BgzfWriter {
         pend.assign(p + whole, p + n);
     }
     void finish() {
-        emit(pend.data(), pend.size()); pend.clear();
+        emit(pend.data(), pend.size()); pend.clear(); wait_writer();
         static const uint8_t eof[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (fwrite(eof, 1, 28, f) != 28 || fclose(f) != 0) die("ERROR: write output bam file failed");
         f = nullptr;
@@ -485,12 +563,13 @@ static const char *kTagUsage =
     "Usage: longphase_amd haplotag [OPTION] ... READSFILE\n"
     "   -s, --snp-file=NAME   -b, --bam-file=NAME   -r, --reference=NAME   -o, --out-prefix=NAME (result)   -t, --threads=Num (1)\n"
     "   --tagSupplementary   -q qualityThreshold(1)   -p percentageThreshold(0.6)   --gpu=ID (0)\n"
+    "   --host-inflate (zlib on the -t threads instead of the GPU inflate)\n"
     "   --compress-level=N (6)   --compress-strategy=rle|default|huffman (rle: packed bases and qualities hold few LZ77 matches; about 2 % larger\n"
     "                             output than zlib's default strategy at several times the speed; `default` = what htslib writes)\n";
 
 static int haplotag_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
-    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, level = 6, strategy = Z_RLE;
+    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, level = 6, strategy = Z_RLE; bool host_inflate = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kTagUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -505,6 +584,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         else if (a == "-q" || a == "--qualityThreshold") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.mapping_quality = x; }); }
         else if (a == "-p" || a == "--percentageThreshold") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.percentage_threshold = x; }); }
         else if (a == "--gpu") gpu = std::stoi(val());
+        else if (a == "--host-inflate") host_inflate = true;
         else if (a == "--compress-level") level = std::stoi(val());
         else if (a == "--compress-strategy") { const std::string x = val(); strategy = x == "default" ? Z_DEFAULT_STRATEGY : x == "rle" ? Z_RLE : x == "huffman" ? Z_HUFFMAN_ONLY : -1; if (strategy < 0) die("longphase_amd: --compress-strategy is one of default, rle, huffman"); }
         else if (a == "--help") { std::cout << kTagUsage; return 0; }
@@ -526,11 +606,35 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     for (const std::string &c : chr_vec) { want[c] = 1; want_seq[c]; }
     std::map<std::string, std::string> seqs; read_fasta(ref, want_seq, seqs);
     const double t_text = now();
-    BamFile in; in.load(bam, threads, want);
+    // default: BGZF inflate + record discovery on the GPU, the inflated stream is copied back once for the writer; --host-inflate: zlib on -t threads
+    BamFile in; GpuBam gb;
+    if (host_inflate) in.load(bam, threads, want);
     const double t_bam = now();
     gpu_init.join();
     if (!ctx) die("longphase_amd: " + L.error);
     const double t_ctx = now();
+    if (!host_inflate) {
+        gb.load(L, ctx, bam);
+        const int64_t total = gb.total;
+        const size_t huge = 2u << 20, cap = ((size_t)total + 64 + huge - 1) / huge * huge;
+        in.z.data = (uint8_t *)aligned_alloc(huge, cap); in.z.size = (size_t)total;
+        if (!in.z.data) die("ERROR: out of memory");
+        madvise(in.z.data, cap, MADV_HUGEPAGE);
+        std::vector<std::thread> th; const int nt = std::max(1, std::min(threads, 8)); std::atomic<int> bad{0};   // touch pages in parallel, then one D2H per slice
+        const size_t slice = ((size_t)total + nt - 1) / nt;
+        for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { const size_t a = std::min((size_t)total, slice * t), b = std::min((size_t)total, a + slice); for (size_t p = a; p < b; p += 4096) in.z.data[p] = 0; });
+        for (auto &x : th) x.join();
+        if (L.bgzf_read(ctx, 0, total, in.z.data)) die(std::string("ERROR: ") + L.last_error(ctx));
+        in.ref_names = gb.ref_names;
+        for (auto &kv : gb.range) {
+            if (!want.count(kv.first)) continue;
+            ContigRecords &c = in.contigs[kv.first]; c.rec_off.resize((size_t)kv.second.second);
+            if (L.bam_record_offsets(ctx, kv.second.first, kv.second.second, c.rec_off.data())) die(std::string("ERROR: ") + L.last_error(ctx));
+            c.lo = 0; c.hi = (uint64_t)total;                          // offsets stay absolute (lo = 0)
+        }
+        (void)bad;
+    }
+    const double t_gin = now();
 
     BgzfWriter w; w.open(prefix + ".bam", threads, level, strategy);
     {   // header: the input's text + one @PG line (BamFileRAII, src/haplotag/HaplotagParsingBam.cpp:45), then the reference table unchanged
@@ -548,6 +652,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     }
     unsigned long long st_count[8] = {0}, hp_count[3] = {0};
     double t_score = 0, t_splice = 0, t_deflate = 0, t_mark = now();
+    (void)t_gin;
     for (const std::string &chr : chr_vec) {                          // contigs in VCF-header order (HaplotagProcess.cpp:94-97)
         auto ci = in.contigs.find(chr);
         if (ci == in.contigs.end() || ci->second.rec_off.empty()) continue;
@@ -564,7 +669,8 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
             std::vector<uint32_t> name_id(n, 0);                        // haplotag does not group by read name
             lps_haplotag_result hr{(int64_t)n, status.data(), h1.data(), h2.data(), nps.data(), psmin.data(), hp.data(), pq.data(), psv.data()};
             if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) ||
-                L.push_bam_records(ctx, base, (int64_t)(c.hi - c.lo), c.rec_off.data(), (int64_t)n, name_id.data()) || L.haplotag_chromosome(ctx, &hr))
+                (host_inflate ? L.push_bam_records(ctx, base, (int64_t)(c.hi - c.lo), c.rec_off.data(), (int64_t)n, name_id.data())
+                              : L.push_bam_resident(ctx, gb.range[chr].first, (int64_t)n, name_id.data())) || L.haplotag_chromosome(ctx, &hr))
                 die(std::string("longphase_amd: ") + L.last_error(ctx));
         }
         t_score += now() - t_mark; t_mark = now();
@@ -631,8 +737,8 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     unsigned long long total = 0; for (int k = 0; k < 8; ++k) total += st_count[k];
     fprintf(stderr, "total alignment %llu | tagged %llu (HP1 %llu, HP2 %llu) | untagged: low mapq %llu, unmapped %llu, secondary %llu, supplementary %llu, no variant %llu, beyond last variant %llu, judged %llu\n",
             total, hp_count[1] + hp_count[2], hp_count[1], hp_count[2], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6], hp_count[0]);
-    fprintf(stderr, "vcf+fasta read %.3fs | bam inflate+walk %.3fs | wait for gpu context %.3fs | upload+score %.3fs | tag splice %.3fs | deflate+write %.3fs (%llu bytes) | total %.3fs\n",
-            t_text - t_begin, t_bam - t_text, t_ctx - t_bam, t_score, t_splice, t_deflate, w.bytes_out, now() - t_begin);
+    fprintf(stderr, "vcf+fasta read %.3fs | %s %.3fs | wait for gpu context %.3fs | score %.3fs | tag splice %.3fs | deflate+write %.3fs (%llu bytes) | total %.3fs\n",
+            t_text - t_begin, host_inflate ? "host inflate+walk" : "gpu inflate+scan+copy back", host_inflate ? t_bam - t_text : t_gin - t_ctx, t_ctx - t_bam, t_score, t_splice, t_deflate, w.bytes_out, now() - t_begin);
     fflush(stderr);
     _exit(0);
 }

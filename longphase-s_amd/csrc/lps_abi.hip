@@ -306,6 +306,16 @@ int lps_bam_record_tids(lps_ctx *c, int32_t *tid) {
     return 0;
 }
 
+int lps_bam_record_offsets(lps_ctx *c, int64_t first, int64_t count, uint64_t *rec_off) {
+    if (!c || first < 0 || count < 0 || (uint64_t)(first + count) > c->n_rec_all || (count > 0 && !rec_off)) return fail(c, "lps_bam_record_offsets: range outside the scanned records");
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        if (count) HIP_TRY(hipMemcpyAsync(rec_off, c->rcand.p + first, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
 int lps_bam_names(lps_ctx *c, int64_t first, int64_t count, uint32_t *name_off, char *names, int64_t names_cap, int64_t *names_bytes) {
     if (!c || first < 0 || count < 0 || (uint64_t)(first + count) > c->n_rec_all || !names_bytes) return fail(c, "lps_bam_names: range outside the scanned records");
     try {

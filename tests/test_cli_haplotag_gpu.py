@@ -19,8 +19,8 @@ CLI = os.path.join(HERE, "..", "longphase-s_amd", "cli", "longphase_amd")
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", fixtures.CLI_HAPLOTAG_FIXTURES)
-def test_cli_haplotag_output_bam_matches_reference(name, tmp_path):
+@pytest.mark.parametrize("name,inflate", [(n, "gpu") for n in fixtures.CLI_HAPLOTAG_FIXTURES] + [("supp_tagged", "host"), ("indels", "host")])
+def test_cli_haplotag_output_bam_matches_reference(name, inflate, tmp_path):
     gold = json.load(open(os.path.join(HERE, "golden", f"cli_haplotag_{name}.json")))
     src, tag_cli, over = fixtures.HAPLOTAG_FIXTURES[name]
     kw, _, _ = fixtures.PHASE_FIXTURES[src]
@@ -33,7 +33,7 @@ def test_cli_haplotag_output_bam_matches_reference(name, tmp_path):
     util.write_table_vcf(d + "/table.vcf", V, "chrS", kw["contig_len"])
     util.write_bam(d + "/reads.sam", d + "/reads.bam", block=20000)
     s.close()
-    r = subprocess.run([CLI, "haplotag", "-s", "table.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", "4", "-o", "tagged"] + tag_cli,
+    r = subprocess.run([CLI, "haplotag", "-s", "table.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", "4", "-o", "tagged"] + tag_cli + (["--host-inflate"] if inflate == "host" else []),
                        cwd=d, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     text, refs, recs = util.bam_sections(d + "/tagged.bam")

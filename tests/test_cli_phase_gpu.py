@@ -19,12 +19,13 @@ def _body(path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("inflate", ["gpu", "host"])
 @pytest.mark.parametrize("name", sorted(DATA_FIXTURES))
-def test_cli_phase_matches_reference_vcf(name, tmp_path):
+def test_cli_phase_matches_reference_vcf(name, inflate, tmp_path):
     assert os.path.exists(CLI), "build the CLI first: make -C longphase-s_amd cli"
     bam = str(tmp_path / (name + ".bam"))
     assert write_bam(os.path.join(DATA, name + ".sam.gz"), bam) > 0
-    flags = DATA_FIXTURES[name][1]
+    flags = DATA_FIXTURES[name][1] + (["--host-inflate"] if inflate == "host" else [])
     prefix = str(tmp_path / "out")
     r = subprocess.run([CLI, "phase", "-s", os.path.join(DATA, name + ".vcf"), "-b", bam, "-r", os.path.join(DATA, name + ".fa"),
                         "-o", prefix, "-t", "4"] + flags, capture_output=True, text=True, timeout=300)
@@ -47,3 +48,39 @@ def test_cli_rewrites_previously_phased_vcf(tmp_path):
     got = [l for l in _body(prefix + ".vcf")]
     want = _body(os.path.join(DATA, name + ".ref_phased.vcf"))
     assert got == want
+
+
+@pytest.mark.gpu
+def test_cli_phase_two_bam_files(tmp_path):
+    """-b given twice (reads split over two files, names ranked across both): same VCF as with one file (ParsingBam.cpp:1252)."""
+    import gzip
+    name = "tiny_snp"
+    lines = gzip.open(os.path.join(DATA, name + ".sam.gz"), "rt").read().splitlines(True)
+    head = [l for l in lines if l.startswith("@")]; recs = [l for l in lines if not l.startswith("@")]
+    for k in (0, 1):
+        with open(tmp_path / f"p{k}.sam", "w") as f:
+            f.writelines(head + recs[k::2])
+        write_bam(str(tmp_path / f"p{k}.sam"), str(tmp_path / f"p{k}.bam"))
+    with open(tmp_path / "all.sam", "w") as f:
+        f.writelines(head + recs[0::2] + recs[1::2])
+    prefix = str(tmp_path / "two")
+    r = subprocess.run([CLI, "phase", "-s", os.path.join(DATA, name + ".vcf"), "-b", str(tmp_path / "p0.bam"), "-b", str(tmp_path / "p1.bam"), "-r",
+                        os.path.join(DATA, name + ".fa"), "-o", prefix, "--ont"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    # oracle for the two-file order: the library on the concatenated alignments (p0 then p1), names ranked together
+    import numpy as np
+    import lps_oracle
+    import util
+    from lps import abi
+    R, names = util.parse_sam(str(tmp_path / "all.sam"))
+    V = util.parse_vcf_variants(os.path.join(DATA, name + ".vcf"))
+    # the two files are each coordinate-sorted; the reference processes file 0 completely, then file 1
+    ref = util.parse_fasta(os.path.join(DATA, name + ".fa"))
+    want, _ = lps_oracle.phase(abi.default_params(), V, ref, R)
+    got = {int(l.split("\t")[1]) - 1: l.rstrip("\n").split("\t")[9] for l in open(prefix + ".vcf") if not l.startswith("#")}
+    for i in range(V.n):
+        smp = got[int(V.pos[i])]
+        if want.phase_set[i]:
+            assert smp.endswith(":%d" % want.phase_set[i]) and smp.startswith("1|0" if want.gt[i] else "0|1")
+        else:
+            assert smp.endswith(":.")
