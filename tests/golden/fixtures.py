@@ -46,6 +46,11 @@ HAPLOTAG_FIXTURES = {
 # util.add_stale_tags, phased VCF written from the haplotag fixture's table): name -> haplotag fixture
 CLI_HAPLOTAG_FIXTURES = ["snp_ont", "indels", "supp_tagged", "strict", "two_blocks"]
 
+# multi-contig end-to-end fixture of the CLI: (contig, synth kwargs, has VCF records); the BAM also ends with unplaced reads
+MULTI = dict(contig_len=150_000, n_snp=200, coverage=14.0, n_threads=2)
+MULTI_CONTIG_FIXTURE = [("chrA", dict(MULTI, seed=41), True), ("chrB", dict(MULTI, seed=42, contig_len=90_000, n_snp=110, supp_frac=0.2), True),
+                        ("chrEmpty", dict(MULTI, seed=43, contig_len=50_000, n_snp=60), False), ("chrC", dict(MULTI, seed=44, indel_var_frac=0.2), True)]
+
 # tumor/normal fixtures for the somatic rows: (genome kwargs, normal reads kwargs, tumor reads kwargs, somatic_haplotag CLI, params)
 TN_BASE = dict(contig_len=600_000, n_snp=700, n_threads=4, somatic_every=8000.0)
 SOMATIC_FIXTURES = {

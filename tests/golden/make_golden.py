@@ -241,8 +241,35 @@ def make_cli_haplotag(name):
     print("cli_haplotag", name, out["n_records"], out["records_sha256"][:16])
 
 
+def make_multi_contig_golden():
+    """reference `phase --indels` and `haplotag` on the multi-contig files -> phased VCF (committed as is) + tagged-BAM digest/tags"""
+    import hashlib
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import util
+    with tempfile.TemporaryDirectory() as d:
+        digests = util.make_multi_contig(d, fixtures.MULTI_CONTIG_FIXTURE)
+        util.add_stale_tags(d + "/multi.sam", d + "/tagged_in.sam")
+        subprocess.check_call([TEST_VIEW, "-b", "-x", "reads.bam.bai", "-p", "reads.bam", "tagged_in.sam"], cwd=d, stdout=subprocess.DEVNULL)
+        for cmd in ([REF_BIN, "phase", "-s", "multi.vcf", "-b", "reads.bam", "-r", "multi.fa", "-t", "2", "-o", "phased", "--ont", "--indels"],
+                    [REF_BIN, "haplotag", "-s", "phased.vcf", "-b", "reads.bam", "-r", "multi.fa", "-t", "1", "-o", "tagged"]):
+            r = subprocess.run(cmd, cwd=d, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"reference failed rc={r.returncode}: {r.stderr[-2000:]}")
+        shutil.copy(d + "/phased.vcf", os.path.join(HERE, "data", "multi_contig.ref_phased.vcf"))
+        text, refs, recs = util.bam_sections(d + "/tagged.bam")
+        tags = util.bam_record_tags(recs)
+    out = dict(digests=digests, records_sha256=hashlib.sha256(recs).hexdigest(), n_records=len(tags), record_bytes=len(recs),
+               header_without_pg=[l for l in text.split("\n") if l and not l.startswith("@PG")], tags=[[q, f, p, [list(t) for t in tg]] for q, f, p, tg in tags])
+    with open(os.path.join(HERE, "cli_multi_contig.json"), "w") as f:
+        json.dump(out, f)
+    print("multi_contig", out["n_records"], out["records_sha256"][:16])
+
+
 def main():
     assert os.path.exists(REF_BIN), "build the reference first: oracle/build_ref.sh"
+    if "--multi-contig" in sys.argv:
+        make_multi_contig_golden()
+        return
     if "--cli-haplotag" in sys.argv:            # only the CLI end-to-end vectors (the others are untouched)
         for name in fixtures.CLI_HAPLOTAG_FIXTURES:
             make_cli_haplotag(name)
@@ -295,6 +322,7 @@ def main():
         json.dump(index, f, indent=1, sort_keys=True)
     for name in fixtures.CLI_HAPLOTAG_FIXTURES:
         make_cli_haplotag(name)
+    make_multi_contig_golden()
 
 
 if __name__ == "__main__":

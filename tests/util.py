@@ -301,3 +301,43 @@ def write_table_vcf(path, V, chrom, length):
             gt = "1|0" if V.hp1_is_alt[i] else "0|1"
             r, a = (x.decode() if isinstance(x, bytes) else str(x) for x in (V.ref_str[i], V.alt_str[i]))
             fo.write("%s\t%d\t.\t%s\t%s\t30\tPASS\t.\tGT:PS\t%s:%d\n" % (chrom, int(V.pos[i]) + 1, r, a, gt, int(V.phase_set[i])))
+
+
+def make_multi_contig(d, specs, unmapped=3):
+    """Several generated contigs in ONE set of files (d/multi.fa, multi.vcf, multi.sam): specs = [(contig name, synth kwargs, in_vcf)].
+    A contig with in_vcf False is present in BAM/FASTA (and listed as ##contig) but has no VCF records; `unmapped` unplaced reads (refID -1)
+    end the SAM.  Read names get the contig as a prefix so they stay unique across contigs.  -> list of Synth digests"""
+    digests = []
+    sq, recs, vhead, vrecs = [], [], None, []
+    with open(os.path.join(d, "multi.fa"), "w") as fa:
+        for name, kw, in_vcf in specs:
+            s = Synth(**kw)
+            digests.append(fixtures.input_digest(s))
+            s.write_fasta(os.path.join(d, "one.fa"), name); fa.write(open(os.path.join(d, "one.fa")).read())
+            s.write_sam(os.path.join(d, "one.sam"), name)
+            for line in open(os.path.join(d, "one.sam")):
+                if line.startswith("@SQ"):
+                    sq.append(line)
+                elif not line.startswith("@"):
+                    recs.append(name + "_" + line)
+            s.write_vcf(os.path.join(d, "one.vcf"), name)
+            for line in open(os.path.join(d, "one.vcf")):
+                if line.startswith("##contig"):
+                    sq_v = line
+                    vhead = (vhead or []) + [sq_v]
+                elif not line.startswith("#") and in_vcf:
+                    vrecs.append(line)
+            s.close()
+    with open(os.path.join(d, "multi.sam"), "w") as f:
+        f.write("@HD\tVN:1.6\tSO:coordinate\n" + "".join(sq))
+        f.writelines(recs)
+        for k in range(unmapped):
+            f.write("unplaced%d\t4\t*\t0\t0\t*\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII\n" % k)
+    with open(os.path.join(d, "multi.vcf"), "w") as f:
+        f.write("##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n" + "".join(vhead))
+        f.write('##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="Genotype Quality">\n')
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n")
+        f.writelines(vrecs)
+    for fn in ("one.fa", "one.sam", "one.vcf"):
+        os.remove(os.path.join(d, fn))
+    return digests
