@@ -251,6 +251,9 @@ int lps_bgzf_timings(lps_ctx *ctx, double *h2d_ms, double *inflate_ms);
  * name_off[count+1] relative offsets; call with names == NULL to get the byte count.
  * lps_push_bam_resident: like lps_push_bam_records for records [first, first+count) of the resident stream - nothing is uploaded. */
 int lps_bam_scan(lps_ctx *ctx, int64_t first_record_offset, int32_t n_ref, int64_t *n_records);
+/* same for a piece of a BAM: the resident stream holds some consecutive BGZF blocks (e.g. the virtual-offset range a .bai index gives for
+ * one contig) and the record chain occupies [first_record_offset, end_offset) of their inflated bytes. */
+int lps_bam_scan_range(lps_ctx *ctx, int64_t first_record_offset, int64_t end_offset, int32_t n_ref, int64_t *n_records);
 int lps_bam_record_tids(lps_ctx *ctx, int32_t *tid);
 /* offsets (inside the inflated stream) of the refID field of records [first, first+count) - for hosts that also need the bytes (lps_bgzf_read) */
 int lps_bam_record_offsets(lps_ctx *ctx, int64_t first, int64_t count, uint64_t *rec_off);

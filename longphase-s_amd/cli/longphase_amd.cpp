@@ -49,7 +49,7 @@ struct Lps {
     decltype(&lps_haplotag_chromosome) haplotag_chromosome = nullptr; decltype(&lps_abi_version) abi_version = nullptr;
     decltype(&lps_bgzf_load) bgzf_load = nullptr; decltype(&lps_bgzf_read) bgzf_read = nullptr; decltype(&lps_bam_scan) bam_scan = nullptr;
     decltype(&lps_bam_record_tids) bam_record_tids = nullptr; decltype(&lps_bam_names) bam_names = nullptr; decltype(&lps_push_bam_resident) push_bam_resident = nullptr;
-    decltype(&lps_bam_record_offsets) bam_record_offsets = nullptr;
+    decltype(&lps_bam_record_offsets) bam_record_offsets = nullptr; decltype(&lps_bam_scan_range) bam_scan_range = nullptr;
     std::string error;
     bool load() {
         char exe[4096]; const ssize_t k = readlink("/proc/self/exe", exe, sizeof exe - 1);
@@ -63,7 +63,7 @@ struct Lps {
         LPS_SYM(begin_chromosome, lps_begin_chromosome) LPS_SYM(set_variants, lps_set_variants) LPS_SYM(set_reference, lps_set_reference)
         LPS_SYM(push_bam_records, lps_push_bam_records) LPS_SYM(phase_chromosome, lps_phase_chromosome) LPS_SYM(haplotag_chromosome, lps_haplotag_chromosome)
         LPS_SYM(abi_version, lps_abi_version) LPS_SYM(bgzf_load, lps_bgzf_load) LPS_SYM(bgzf_read, lps_bgzf_read) LPS_SYM(bam_scan, lps_bam_scan)
-        LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets)
+        LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range)
 #undef LPS_SYM
         if (abi_version() != LPS_ABI_VERSION) { error = "liblps_hip.so has a different ABI version than this binary was built for"; return false; }
         return true;
@@ -173,46 +173,109 @@ static void rank_names(const std::vector<std::pair<const char *, size_t>> &names
 // One BAM file inflated and indexed ON THE GPU (lps_bgzf_load + lps_bam_scan): the host only maps the compressed file, parses the BAM header
 // and ranks the read names of each contig.
 struct GpuBam {
-    std::vector<std::string> ref_names; std::vector<int32_t> tid; std::map<std::string, std::pair<int64_t, int64_t>> range;   // contig -> (first record, count)
+    std::vector<std::string> ref_names; std::map<std::string, std::pair<int64_t, int64_t>> range;   // whole-file mode: contig -> (first record, count)
+    std::vector<uint8_t> header;                                      // inflated bytes "BAM\1" .. end of the reference table
+    std::vector<std::pair<uint64_t, uint64_t>> voff; bool indexed = false;   // .bai: virtual-offset range of every contig's records
+    const uint8_t *raw = nullptr; size_t fsz = 0; int fd = -1; std::string path;
     double t_map = 0, t_inflate = 0, t_scan = 0; int64_t total = 0;
-    void load(Lps &L, lps_ctx *ctx, const std::string &path) {
-        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        const double t0 = now();
-        const int fd = open(path.c_str(), O_RDONLY);
-        if (fd < 0) die("ERROR: Cannot open bam file " + path);
-        struct stat st; if (fstat(fd, &st) != 0 || st.st_size < 28) die("ERROR: " + path + " is not a BGZF/BAM file");
-        const size_t fsz = (size_t)st.st_size;
-        const uint8_t *raw = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
-        if (raw == (const uint8_t *)MAP_FAILED) die("ERROR: Cannot map " + path);
-        const double t1 = now(); t_map = t1 - t0;
-        if (L.bgzf_load(ctx, raw, (int64_t)fsz, &total)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
-        munmap((void *)raw, fsz); close(fd);
-        const double t2 = now(); t_inflate = t2 - t1;
-        std::vector<uint8_t> head((size_t)std::min<int64_t>(total, 1 << 16));
-        auto fetch = [&](size_t need) { if (need > (size_t)total) die("ERROR: truncated BAM header in " + path); if (need > head.size()) head.resize(need); if (L.bgzf_read(ctx, 0, (int64_t)head.size(), head.data())) die(std::string("ERROR: ") + L.last_error(ctx)); };
-        fetch(head.size());
-        if (head.size() < 12 || memcmp(head.data(), "BAM\1", 4)) die("ERROR: " + path + " is not a BAM file");
-        size_t p = 8 + (size_t)rd32(head.data() + 4);
-        if (p + 4 > head.size()) fetch(p + 4);
-        const uint32_t n_ref = rd32(head.data() + p); p += 4;
-        ref_names.resize(n_ref);
-        for (uint32_t i = 0; i < n_ref; ++i) {
-            if (p + 4 > head.size()) fetch(std::min<size_t>((size_t)total, p + (1 << 16)));
-            const uint32_t l = rd32(head.data() + p); if (!l) die("ERROR: truncated BAM header in " + path);
-            if (p + 4 + l + 4 > head.size()) fetch(std::min<size_t>((size_t)total, p + 4 + l + 4 + (1 << 16)));
-            if (p + 4 + l + 4 > head.size()) die("ERROR: truncated BAM header in " + path);
-            ref_names[i] = std::string((const char *)head.data() + p + 4, l - 1); p += 4 + (size_t)l + 4;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+    // map the file, inflate the BAM header on the host (a few blocks), read <bam>.bai when there is one
+    void open_file(const std::string &p, bool use_index) {
+        path = p; const double t0 = now();
+        fd = open(p.c_str(), O_RDONLY);
+        if (fd < 0) die("ERROR: Cannot open bam file " + p);
+        struct stat st; if (fstat(fd, &st) != 0 || st.st_size < 28) die("ERROR: " + p + " is not a BGZF/BAM file");
+        fsz = (size_t)st.st_size;
+        raw = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (raw == (const uint8_t *)MAP_FAILED) die("ERROR: Cannot map " + p);
+        size_t q = 0; size_t need = 12;                                 // grows as l_text / names become known
+        auto parsed = [&]() -> bool {
+            if (header.size() < 12) return false;
+            if (memcmp(header.data(), "BAM\1", 4)) die("ERROR: " + p + " is not a BAM file");
+            size_t h = 8 + (size_t)rd32(header.data() + 4); if (h + 4 > header.size()) { need = h + 4; return false; }
+            const uint32_t n_ref = rd32(header.data() + h); h += 4; ref_names.assign(n_ref, std::string());
+            for (uint32_t i = 0; i < n_ref; ++i) {
+                if (h + 4 > header.size()) { need = h + 4; return false; }
+                const uint32_t l = rd32(header.data() + h); if (!l) die("ERROR: truncated BAM header in " + p);
+                if (h + 4 + l + 4 > header.size()) { need = h + 4 + l + 4; return false; }
+                ref_names[i] = std::string((const char *)header.data() + h + 4, l - 1); h += 4 + (size_t)l + 4;
+            }
+            header.resize(h); return true;
+        };
+        while (!parsed()) {
+            if (q + 18 > fsz) die("ERROR: truncated BAM header in " + p);
+            const unsigned xlen = raw[q + 10] | (raw[q + 11] << 8); const size_t bsize = (size_t)(raw[q + 16] | (raw[q + 17] << 8)) + 1;
+            if (raw[q] != 31 || raw[q + 1] != 139 || q + bsize > fsz) die("ERROR: " + p + " is not a BGZF/BAM file");
+            const size_t isize = rd32(raw + q + bsize - 4), at = header.size(); header.resize(at + isize);
+            z_stream zs{}; zs.next_in = const_cast<uint8_t *>(raw) + q + 12 + xlen; zs.avail_in = (uInt)(bsize - 12 - xlen - 8); zs.next_out = header.data() + at; zs.avail_out = (uInt)isize;
+            if (inflateInit2(&zs, -15) != Z_OK || (isize && inflate(&zs, Z_FINISH) != Z_STREAM_END)) die("ERROR: inflate failed in " + p);
+            inflateEnd(&zs); q += bsize; (void)need;
         }
+        if (use_index) read_bai();
+        t_map = now() - t0;
+    }
+    // BAI (SAM spec 5.2): per reference the bins with their chunk lists; the pseudo-bin 37450 holds (first, last) virtual offset of the reference's records
+    void read_bai() {
+        std::string cand[2] = {path + ".bai", path.size() > 4 ? path.substr(0, path.size() - 4) + ".bai" : std::string()};
+        std::vector<uint8_t> b;
+        for (const std::string &c : cand) { if (c.empty()) continue; std::ifstream f(c, std::ios::binary); if (!f) continue; b.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>()); break; }
+        if (b.size() < 8 || memcmp(b.data(), "BAI\1", 4)) return;
+        auto r32 = [&](size_t &p) -> uint32_t { if (p + 4 > b.size()) die("ERROR: truncated index for " + path); const uint32_t v = rd32(b.data() + p); p += 4; return v; };
+        auto r64 = [&](size_t &p) -> uint64_t { const uint64_t lo = r32(p), hi = r32(p); return lo | (hi << 32); };
+        size_t p = 4; const uint32_t n_ref = r32(p);
+        if (n_ref != ref_names.size()) die("ERROR: index and header of " + path + " disagree on the number of references");
+        voff.assign(n_ref, {0, 0});
+        for (uint32_t i = 0; i < n_ref; ++i) {
+            uint64_t lo = ~0ull, hi = 0, mlo = 0, mhi = 0; bool meta = false;
+            const uint32_t n_bin = r32(p);
+            for (uint32_t k = 0; k < n_bin; ++k) {
+                const uint32_t bin = r32(p), n_chunk = r32(p);
+                for (uint32_t c = 0; c < n_chunk; ++c) { const uint64_t beg = r64(p), end = r64(p); if (bin == 37450) { if (c == 0) { mlo = beg; mhi = end; meta = true; } } else { lo = std::min(lo, beg); hi = std::max(hi, end); } }
+            }
+            const uint32_t n_intv = r32(p); p += 8ull * n_intv;
+            if (meta) voff[i] = {mlo, mhi}; else if (hi) voff[i] = {lo, hi};
+        }
+        indexed = true;
+    }
+    void close_file() { if (raw) munmap((void *)raw, fsz); if (fd >= 0) close(fd); raw = nullptr; fd = -1; }
+
+    // whole-file mode: everything resident at once, one contiguous record range per contig
+    void load_all(Lps &L, lps_ctx *ctx) {
+        const double t1 = now();
+        madvise((void *)raw, fsz, MADV_WILLNEED);
+        if (L.bgzf_load(ctx, raw, (int64_t)fsz, &total)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
+        const double t2 = now(); t_inflate += t2 - t1;
         int64_t n = 0;
-        if (L.bam_scan(ctx, (int64_t)p, (int32_t)n_ref, &n)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
-        tid.resize((size_t)n);
+        if (L.bam_scan(ctx, (int64_t)header.size(), (int32_t)ref_names.size(), &n)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
+        std::vector<int32_t> tid((size_t)n);
         if (n && L.bam_record_tids(ctx, tid.data())) die(std::string("ERROR: ") + L.last_error(ctx));
         for (int64_t i = 0; i < n;) {                                  // a coordinate-sorted BAM holds every contig as ONE run of records
             int64_t j = i; while (j < n && tid[(size_t)j] == tid[(size_t)i]) ++j;
             if (tid[(size_t)i] >= 0) { const std::string &nm = ref_names[(size_t)tid[(size_t)i]]; if (range.count(nm)) die("ERROR: " + path + " is not coordinate-sorted"); range[nm] = {i, j - i}; }
             i = j;
         }
-        t_scan = now() - t2;
+        t_scan += now() - t2;
+    }
+    // indexed mode: only the BGZF blocks that hold this contig's records are uploaded and inflated; -> number of records (numbered from 0)
+    int64_t load_contig(Lps &L, lps_ctx *ctx, const std::string &chr) {
+        size_t t = 0; while (t < ref_names.size() && ref_names[t] != chr) ++t;
+        if (t == ref_names.size() || voff[t].second <= voff[t].first) return 0;
+        const double t1 = now();
+        const uint64_t cbeg = voff[t].first >> 16, ubeg = voff[t].first & 0xffff, cend = voff[t].second >> 16, uend = voff[t].second & 0xffff;
+        uint64_t stop = cend; uint64_t last_isize = 0;
+        if (uend) { if (cend + 18 > fsz) die("ERROR: index of " + path + " points past the end of the file"); const uint64_t bsize = (uint64_t)(raw[cend + 16] | (raw[cend + 17] << 8)) + 1; stop = cend + bsize; if (stop > fsz) die("ERROR: truncated BGZF block in " + path); last_isize = rd32(raw + stop - 4); }
+        if (cbeg >= stop || stop > fsz) die("ERROR: index of " + path + " is inconsistent");
+        if (L.bgzf_load(ctx, raw + cbeg, (int64_t)(stop - cbeg), &total)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
+        const int64_t end = uend ? total - (int64_t)last_isize + (int64_t)uend : total;
+        const double t2 = now(); t_inflate += t2 - t1;
+        int64_t n = 0;
+        if (L.bam_scan_range(ctx, (int64_t)ubeg, end, (int32_t)ref_names.size(), &n)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
+        std::vector<int32_t> tid((size_t)n);
+        if (n && L.bam_record_tids(ctx, tid.data())) die(std::string("ERROR: ") + L.last_error(ctx));
+        for (int32_t x : tid) if (x != (int32_t)t) die("ERROR: index of " + path + " does not match its records");
+        t_scan += now() - t2;
+        return n;
     }
     // names of records [first, first+count) -> (pointer, length) pairs into `store`
     void names(Lps &L, lps_ctx *ctx, int64_t first, int64_t count, std::vector<char> &store, std::vector<uint32_t> &off, std::vector<std::pair<const char *, size_t>> &out) {
@@ -340,11 +403,12 @@ static const char *kUsage =
     "   -s, --snp-file=NAME   -b, --bam-file=NAME (repeatable)   -r, --reference=NAME   -o, --out-prefix=NAME (result)   -t, --threads=Num (1)\n"
     "   --ont | --pb   --indels   -q MAPQ(1)  -p baseQuality(12)  -e edgeWeight(0.1)  -a connectAdjacent(35)  -d distance(300000)\n"
     "   -1 edgeThreshold(0.7)  -L overlapThreshold(0.2)  -m readConfidence(0.65)  -n snpConfidence(0.75)  --gpu=ID (0)\n"
-    "   --host-inflate   inflate BGZF with zlib on the -t host threads instead of on the GPU (always used when several -b files are given)\n";
+    "   --host-inflate   inflate BGZF with zlib on the -t host threads instead of on the GPU (always used when several -b files are given)\n"
+    "   --no-index       ignore <bam>.bai: make the whole file resident on the GPU instead of one contig at a time\n";
 
 static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over; bool indels = false;
-    std::string snp, ref, prefix = "result"; std::vector<std::string> bams; int threads = 1, gpu = 0; bool ont = false, pb = false, host_inflate = false;
+    std::string snp, ref, prefix = "result"; std::vector<std::string> bams; int threads = 1, gpu = 0; bool ont = false, pb = false, host_inflate = false, no_index = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -369,6 +433,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "-x" || a == "--mismatchRate") (void)val();
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--host-inflate") host_inflate = true;
+        else if (a == "--no-index") no_index = true;
         else if (a == "--help") { std::cout << kUsage; return 0; }
         else if (a == "--sv-file" || a == "--mod-file" || a == "--dot" || a == "--deepsomatic_output" || a == "--indelQuality") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kUsage; return 1; }
@@ -398,7 +463,8 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     gpu_init.join();
     if (!ctx) die("longphase_amd: " + L.error);
     const double t_ctx = now();
-    GpuBam gb; if (gpu_input) gb.load(L, ctx, bams[0]);
+    // with a .bai next to the BAM only the blocks of one contig are resident at a time (any file size, per-contig sharding); without, the whole file
+    GpuBam gb; if (gpu_input) { gb.open_file(bams[0], !no_index); if (!gb.indexed) gb.load_all(L, ctx); }
     const double t_gin = now();
     std::map<std::string, std::map<int32_t, Phased>> res;
     for (const std::string &chr : chr_order) {                       // PhasingProcess.cpp:113-173
@@ -407,7 +473,11 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         // names of all files of this contig ranked together (one read name = one merged row, whatever file it came from)
         std::vector<std::pair<const char *, size_t>> names; std::vector<const ContigRecords *> parts; std::vector<char> name_store; std::vector<uint32_t> name_off;
         std::pair<int64_t, int64_t> gr{0, 0};
-        if (gpu_input) { auto it = gb.range.find(chr); if (it == gb.range.end()) continue; gr = it->second; gb.names(L, ctx, gr.first, gr.second, name_store, name_off, names); }
+        if (gpu_input) {
+            if (gb.indexed) { gr = {0, gb.load_contig(L, ctx, chr)}; if (!gr.second) continue; }
+            else { auto it = gb.range.find(chr); if (it == gb.range.end()) continue; gr = it->second; }
+            gb.names(L, ctx, gr.first, gr.second, name_store, name_off, names);
+        }
         for (BamFile &f : files) { auto it = f.contigs.find(chr); if (it == f.contigs.end() || it->second.rec_off.empty()) { parts.push_back(nullptr); continue; }
             parts.push_back(&it->second); for (size_t i = 0; i < it->second.rec_off.size(); ++i) { size_t l; const char *nm = f.name_of(it->second, i, l); names.emplace_back(nm, l); } }
         if (names.empty()) continue;
@@ -437,8 +507,9 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     L.destroy(ctx);
     const double t_gpu = now();
     write_vcf(vcf_lines, prefix + ".vcf", res, vars, command);
-    if (gpu_input) fprintf(stderr, "vcf+fasta read %.3fs | wait for gpu context %.3fs | map bam %.3fs | upload+gpu inflate %.3fs | gpu record scan %.3fs | names+decode+phase %.3fs | write vcf %.3fs | total %.3fs\n",
-                           t_text - t_begin, t_ctx - t_bam, gb.t_map, gb.t_inflate, gb.t_scan, t_gpu - t_gin, now() - t_gpu, now() - t_begin);
+    if (gpu_input) fprintf(stderr, "%s | vcf+fasta read %.3fs | wait for gpu context %.3fs | map bam+header%s %.3fs | upload+gpu inflate %.3fs | gpu record scan %.3fs | names+decode+phase %.3fs | write vcf %.3fs | total %.3fs\n",
+                           gb.indexed ? "per-contig (indexed)" : "whole file", t_text - t_begin, t_ctx - t_bam, gb.indexed ? "+index" : "", gb.t_map, gb.t_inflate, gb.t_scan,
+                           t_gpu - t_gin - (gb.indexed ? gb.t_inflate + gb.t_scan : 0.0), now() - t_gpu, now() - t_begin);
     else fprintf(stderr, "vcf+fasta read %.3fs | bam inflate+walk %.3fs | wait for gpu context %.3fs | upload+phase %.3fs | write vcf %.3fs | total %.3fs\n", t_text - t_begin,
                  t_bam - t_text, t_ctx - t_bam, t_gpu - t_ctx, now() - t_gpu, now() - t_begin);
     fflush(stderr);
@@ -563,13 +634,13 @@ static const char *kTagUsage =
     "Usage: longphase_amd haplotag [OPTION] ... READSFILE\n"
     "   -s, --snp-file=NAME   -b, --bam-file=NAME   -r, --reference=NAME   -o, --out-prefix=NAME (result)   -t, --threads=Num (1)\n"
     "   --tagSupplementary   -q qualityThreshold(1)   -p percentageThreshold(0.6)   --gpu=ID (0)\n"
-    "   --host-inflate (zlib on the -t threads instead of the GPU inflate)\n"
+    "   --host-inflate (zlib on the -t threads instead of the GPU inflate)   --no-index (ignore <bam>.bai, keep the whole file on the GPU)\n"
     "   --compress-level=N (6)   --compress-strategy=rle|default|huffman (rle: packed bases and qualities hold few LZ77 matches; about 2 % larger\n"
     "                             output than zlib's default strategy at several times the speed; `default` = what htslib writes)\n";
 
 static int haplotag_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
-    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, level = 6, strategy = Z_RLE; bool host_inflate = false;
+    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, level = 6, strategy = Z_RLE; bool host_inflate = false, no_index = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kTagUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -585,6 +656,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         else if (a == "-p" || a == "--percentageThreshold") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.percentage_threshold = x; }); }
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--host-inflate") host_inflate = true;
+        else if (a == "--no-index") no_index = true;
         else if (a == "--compress-level") level = std::stoi(val());
         else if (a == "--compress-strategy") { const std::string x = val(); strategy = x == "default" ? Z_DEFAULT_STRATEGY : x == "rle" ? Z_RLE : x == "huffman" ? Z_HUFFMAN_ONLY : -1; if (strategy < 0) die("longphase_amd: --compress-strategy is one of default, rle, huffman"); }
         else if (a == "--help") { std::cout << kTagUsage; return 0; }
@@ -607,38 +679,40 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     std::map<std::string, std::string> seqs; read_fasta(ref, want_seq, seqs);
     const double t_text = now();
     // default: BGZF inflate + record discovery on the GPU, the inflated stream is copied back once for the writer; --host-inflate: zlib on -t threads
-    BamFile in; GpuBam gb;
+    BamFile in; GpuBam gb; size_t in_cap = 0;
     if (host_inflate) in.load(bam, threads, want);
     const double t_bam = now();
     gpu_init.join();
     if (!ctx) die("longphase_amd: " + L.error);
     const double t_ctx = now();
-    if (!host_inflate) {
-        gb.load(L, ctx, bam);
-        const int64_t total = gb.total;
-        const size_t huge = 2u << 20, cap = ((size_t)total + 64 + huge - 1) / huge * huge;
-        in.z.data = (uint8_t *)aligned_alloc(huge, cap); in.z.size = (size_t)total;
-        if (!in.z.data) die("ERROR: out of memory");
-        madvise(in.z.data, cap, MADV_HUGEPAGE);
-        std::vector<std::thread> th; const int nt = std::max(1, std::min(threads, 8)); std::atomic<int> bad{0};   // touch pages in parallel, then one D2H per slice
-        const size_t slice = ((size_t)total + nt - 1) / nt;
-        for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { const size_t a = std::min((size_t)total, slice * t), b = std::min((size_t)total, a + slice); for (size_t p = a; p < b; p += 4096) in.z.data[p] = 0; });
-        for (auto &x : th) x.join();
+    // copy [0, total) of the stream resident on the GPU into `in.z` (2 MiB pages, touched by a few threads first so the D2H does not fault serially)
+    auto copy_back = [&](int64_t total) {
+        if ((size_t)total + 64 > in_cap) { free(in.z.data); const size_t huge = 2u << 20; in_cap = ((size_t)total + 64 + huge - 1) / huge * huge + (in_cap >> 1);
+            in.z.data = (uint8_t *)aligned_alloc(huge, in_cap / huge * huge + huge); if (!in.z.data) die("ERROR: out of memory"); madvise(in.z.data, in_cap, MADV_HUGEPAGE);
+            std::vector<std::thread> th; const int nt = std::max(1, std::min(threads, 8)); const size_t slice = (in_cap + nt - 1) / nt;
+            for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { const size_t a = std::min(in_cap, slice * t), e = std::min(in_cap, a + slice); for (size_t p = a; p < e; p += 4096) in.z.data[p] = 0; });
+            for (auto &x : th) x.join(); }
+        in.z.size = (size_t)total;
         if (L.bgzf_read(ctx, 0, total, in.z.data)) die(std::string("ERROR: ") + L.last_error(ctx));
-        in.ref_names = gb.ref_names;
-        for (auto &kv : gb.range) {
-            if (!want.count(kv.first)) continue;
-            ContigRecords &c = in.contigs[kv.first]; c.rec_off.resize((size_t)kv.second.second);
-            if (L.bam_record_offsets(ctx, kv.second.first, kv.second.second, c.rec_off.data())) die(std::string("ERROR: ") + L.last_error(ctx));
-            c.lo = 0; c.hi = (uint64_t)total;                          // offsets stay absolute (lo = 0)
+    };
+    if (!host_inflate) {
+        gb.open_file(bam, !no_index);
+        if (!gb.indexed) {
+            gb.load_all(L, ctx);
+            copy_back(gb.total);
+            for (auto &kv : gb.range) {
+                if (!want.count(kv.first)) continue;
+                ContigRecords &c = in.contigs[kv.first]; c.rec_off.resize((size_t)kv.second.second);
+                if (L.bam_record_offsets(ctx, kv.second.first, kv.second.second, c.rec_off.data())) die(std::string("ERROR: ") + L.last_error(ctx));
+                c.lo = 0; c.hi = (uint64_t)gb.total;                   // offsets stay absolute (lo = 0)
+            }
         }
-        (void)bad;
     }
     const double t_gin = now();
 
     BgzfWriter w; w.open(prefix + ".bam", threads, level, strategy);
     {   // header: the input's text + one @PG line (BamFileRAII, src/haplotag/HaplotagParsingBam.cpp:45), then the reference table unchanged
-        const uint8_t *d = in.z.data; const uint32_t l_text = rd32(d + 4);
+        const uint8_t *d = host_inflate ? in.z.data : gb.header.data(); const uint32_t l_text = rd32(d + 4);
         std::string text((const char *)d + 8, l_text); while (!text.empty() && text.back() == '\0') text.pop_back();
         if (!text.empty() && text.back() != '\n') text += '\n';
         std::string last_pg; for (size_t p = 0; p < text.size();) { const size_t e = text.find('\n', p); const std::string ln = text.substr(p, e - p);
@@ -651,9 +725,15 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         w.append(h.data(), h.size());
     }
     unsigned long long st_count[8] = {0}, hp_count[3] = {0};
-    double t_score = 0, t_splice = 0, t_deflate = 0, t_mark = now();
-    (void)t_gin;
+    double t_score = 0, t_splice = 0, t_deflate = 0, t_load = 0, t_mark = now();
     for (const std::string &chr : chr_vec) {                          // contigs in VCF-header order (HaplotagProcess.cpp:94-97)
+        if (!host_inflate && gb.indexed) {                              // this contig's blocks only: inflate + scan on the GPU, copy its records back
+            const double tl = now();
+            const int64_t cnt = gb.load_contig(L, ctx, chr);
+            ContigRecords &cc = in.contigs[chr]; cc.rec_off.resize((size_t)cnt); cc.lo = 0; cc.hi = (uint64_t)gb.total;
+            if (cnt) { copy_back(gb.total); if (L.bam_record_offsets(ctx, 0, cnt, cc.rec_off.data())) die(std::string("ERROR: ") + L.last_error(ctx)); }
+            t_load += now() - tl; t_mark = now();
+        }
         auto ci = in.contigs.find(chr);
         if (ci == in.contigs.end() || ci->second.rec_off.empty()) continue;
         const ContigRecords &c = ci->second; const size_t n = c.rec_off.size(); const uint8_t *base = in.z.data + c.lo;
@@ -670,7 +750,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
             lps_haplotag_result hr{(int64_t)n, status.data(), h1.data(), h2.data(), nps.data(), psmin.data(), hp.data(), pq.data(), psv.data()};
             if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) ||
                 (host_inflate ? L.push_bam_records(ctx, base, (int64_t)(c.hi - c.lo), c.rec_off.data(), (int64_t)n, name_id.data())
-                              : L.push_bam_resident(ctx, gb.range[chr].first, (int64_t)n, name_id.data())) || L.haplotag_chromosome(ctx, &hr))
+                              : L.push_bam_resident(ctx, gb.indexed ? 0 : gb.range[chr].first, (int64_t)n, name_id.data())) || L.haplotag_chromosome(ctx, &hr))
                 die(std::string("longphase_amd: ") + L.last_error(ctx));
         }
         t_score += now() - t_mark; t_mark = now();
@@ -738,7 +818,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     fprintf(stderr, "total alignment %llu | tagged %llu (HP1 %llu, HP2 %llu) | untagged: low mapq %llu, unmapped %llu, secondary %llu, supplementary %llu, no variant %llu, beyond last variant %llu, judged %llu\n",
             total, hp_count[1] + hp_count[2], hp_count[1], hp_count[2], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6], hp_count[0]);
     fprintf(stderr, "vcf+fasta read %.3fs | %s %.3fs | wait for gpu context %.3fs | score %.3fs | tag splice %.3fs | deflate+write %.3fs (%llu bytes) | total %.3fs\n",
-            t_text - t_begin, host_inflate ? "host inflate+walk" : "gpu inflate+scan+copy back", host_inflate ? t_bam - t_text : t_gin - t_ctx, t_ctx - t_bam, t_score, t_splice, t_deflate, w.bytes_out, now() - t_begin);
+            t_text - t_begin, host_inflate ? "host inflate+walk" : gb.indexed ? "gpu inflate+scan+copy back per contig (indexed)" : "gpu inflate+scan+copy back", host_inflate ? t_bam - t_text : t_gin - t_ctx + t_load, t_ctx - t_bam, t_score, t_splice, t_deflate, w.bytes_out, now() - t_begin);
     fflush(stderr);
     _exit(0);
 }

@@ -273,16 +273,16 @@ int lps_push_bam_records(lps_ctx *c, const uint8_t *records, int64_t n_bytes, co
     return 0;
 }
 
-int lps_bam_scan(lps_ctx *c, int64_t first_record_offset, int32_t n_ref, int64_t *n_records) {
+int lps_bam_scan_range(lps_ctx *c, int64_t first_record_offset, int64_t end_offset, int32_t n_ref, int64_t *n_records) {
     if (!c || !n_records) return -1;
-    if (!c->file_bytes || first_record_offset < 12 || (uint64_t)first_record_offset > c->file_bytes) return fail(c, "lps_bam_scan: no inflated BAM resident (lps_bgzf_load) or bad offset");
+    if (!c->file_bytes || first_record_offset < 0 || end_offset < first_record_offset || (uint64_t)end_offset > c->file_bytes) return fail(c, "lps_bam_scan: no inflated BAM resident (lps_bgzf_load) or bad offsets");
     try {
         HIP_TRY(hipSetDevice(c->device));
         hipStream_t s = c->stream; c->bam_err.reserve(1); c->scan_nout.reserve(1);
         uint64_t n = 0;
-        const int rc = bam_scan_records(c->file.p, (uint64_t)first_record_offset, c->file_bytes, n_ref, c->rcand, c->wg_cnt, c->wg_off, c->temp, c->temp_bytes, c->bam_err.p, c->scan_nout.p, &n, s);
-        c->n_rec_all = 0;
-        if (rc == -3) { *n_records = 0; return 0; }
+        const int rc = bam_scan_records(c->file.p, (uint64_t)first_record_offset, (uint64_t)end_offset, n_ref, c->rcand, c->wg_cnt, c->wg_off, c->temp, c->temp_bytes, c->bam_err.p, c->scan_nout.p, &n, s);
+        c->n_rec_all = 0; c->names_ready = false;
+        if (rc == -3 || first_record_offset == end_offset) { *n_records = 0; if (rc == -3 && first_record_offset != end_offset) return fail(c, "lps_bam_scan: no BAM record found in a non-empty range"); return 0; }
         if (rc) return fail(c, rc == -4 ? "lps_bam_scan: the BAM record chain is broken (corrupt file)" : "lps_bam_scan: stream too large");
         if (n > 0x7fffffffull) return fail(c, "lps_bam_scan: more than 2^31 records");
         c->r_tid_all.reserve(n, s); c->r_lname.reserve(n + 1, s); c->r_nameoff.reserve(n + 1, s);
@@ -294,6 +294,12 @@ int lps_bam_scan(lps_ctx *c, int64_t first_record_offset, int32_t n_ref, int64_t
         c->n_rec_all = n; *n_records = (int64_t)n;
     } catch (std::string &e) { return fail(c, e); }
     return 0;
+}
+
+int lps_bam_scan(lps_ctx *c, int64_t first_record_offset, int32_t n_ref, int64_t *n_records) {
+    if (!c) return -1;
+    if (first_record_offset < 12) return fail(c, "lps_bam_scan: bad offset");
+    return lps_bam_scan_range(c, first_record_offset, (int64_t)c->file_bytes, n_ref, n_records);
 }
 
 int lps_bam_record_tids(lps_ctx *c, int32_t *tid) {

@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) k_bam_names(const uint8_t *d, const uint6
     for (uint32_t k = lane; k < l; k += 64) names[o + k] = d[r + 32 + k];
 }
 
-int bam_scan_records(const uint8_t *d, uint64_t first_rec, uint64_t total, int32_t n_ref, DevBuf<uint64_t> &cand, DevBuf<uint32_t> &wg_cnt, DevBuf<uint32_t> &wg_off,
+int bam_scan_records(const uint8_t *d, uint64_t first_rec, uint64_t total /* end of the record range */, int32_t n_ref, DevBuf<uint64_t> &cand, DevBuf<uint32_t> &wg_cnt, DevBuf<uint32_t> &wg_off,
                      DevBuf<char> &temp, size_t &temp_bytes, unsigned *flag, uint32_t *n_out_d, uint64_t *n_records, hipStream_t s) {
     *n_records = 0;
     if (first_rec >= total) return 0;

@@ -50,6 +50,7 @@ def load():
     L.lps_bgzf_read.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     L.lps_bgzf_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.lps_bam_scan.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
+    L.lps_bam_scan_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
     L.lps_bam_record_tids.argtypes = [C.c_void_p, C.c_void_p]
     L.lps_bam_record_offsets.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     L.lps_bam_names.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]

@@ -341,3 +341,47 @@ def make_multi_contig(d, specs, unmapped=3):
     for fn in ("one.fa", "one.sam", "one.vcf"):
         os.remove(os.path.join(d, fn))
     return digests
+
+
+def write_bai(bam_path, bai_path=None):
+    """Minimal BAI (SAM spec 5.2) for a coordinate-sorted BAM: per reference only the metadata pseudo-bin 37450 with the virtual-offset range of
+    the reference's records (what htslib writes as its first chunk) and the mapped/unmapped counts; no binning/linear index."""
+    import struct, zlib
+    raw = open(bam_path, "rb").read()
+    blocks, p, u = [], 0, 0                     # (compressed offset, inflated offset, inflated size)
+    data = bytearray()
+    while p < len(raw):
+        xlen = struct.unpack_from("<H", raw, p + 10)[0]
+        bsize = struct.unpack_from("<H", raw, p + 16)[0] + 1
+        chunk = zlib.decompress(raw[p + 12 + xlen:p + bsize - 8], -15)
+        blocks.append((p, u, len(chunk))); data += chunk; u += len(chunk); p += bsize
+    starts = [b[1] for b in blocks]
+
+    def voff(off, end=False):
+        import bisect
+        k = bisect.bisect_right(starts, off) - 1
+        while end and k > 0 and off == blocks[k][1] and False:
+            k -= 1
+        while blocks[k][2] == 0 and k + 1 < len(blocks) and not end:
+            k += 1
+        return (blocks[k][0] << 16) | (off - blocks[k][1])
+    lt = struct.unpack_from("<i", data, 4)[0]
+    q = 8 + lt
+    n_ref = struct.unpack_from("<i", data, q)[0]; q += 4
+    for _ in range(n_ref):
+        q += 4 + struct.unpack_from("<i", data, q)[0] + 4
+    span = {}
+    while q < len(data):
+        bs, tid = struct.unpack_from("<ii", data, q)
+        flag = struct.unpack_from("<H", data, q + 18)[0]
+        s = span.setdefault(tid, [q, 0, 0, 0])
+        s[1] = q + 4 + bs; s[2 if not flag & 4 else 3] += 1
+        q += 4 + bs
+    out = bytearray(b"BAI\1" + struct.pack("<i", n_ref))
+    for t in range(n_ref):
+        if t in span:
+            b, e, nm, nu = span[t]
+            out += struct.pack("<i", 1) + struct.pack("<Ii", 37450, 2) + struct.pack("<QQQQ", voff(b), voff(e, True), nm, nu) + struct.pack("<i", 0)
+        else:
+            out += struct.pack("<ii", 0, 0)
+    open(bai_path or bam_path + ".bai", "wb").write(bytes(out))
