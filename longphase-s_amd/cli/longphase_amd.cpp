@@ -26,6 +26,7 @@
 #include <iostream>
 #include <iterator>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <sstream>
 #include <string>
@@ -49,7 +50,7 @@ struct Lps {
     decltype(&lps_haplotag_chromosome) haplotag_chromosome = nullptr; decltype(&lps_abi_version) abi_version = nullptr;
     decltype(&lps_bgzf_load) bgzf_load = nullptr; decltype(&lps_bgzf_read) bgzf_read = nullptr; decltype(&lps_bam_scan) bam_scan = nullptr;
     decltype(&lps_bam_record_tids) bam_record_tids = nullptr; decltype(&lps_bam_names) bam_names = nullptr; decltype(&lps_push_bam_resident) push_bam_resident = nullptr;
-    decltype(&lps_bam_record_offsets) bam_record_offsets = nullptr; decltype(&lps_bam_scan_range) bam_scan_range = nullptr;
+    decltype(&lps_bam_record_offsets) bam_record_offsets = nullptr; decltype(&lps_bam_scan_range) bam_scan_range = nullptr; decltype(&lps_device_count) device_count = nullptr;
     std::string error;
     bool load() {
         char exe[4096]; const ssize_t k = readlink("/proc/self/exe", exe, sizeof exe - 1);
@@ -63,7 +64,7 @@ struct Lps {
         LPS_SYM(begin_chromosome, lps_begin_chromosome) LPS_SYM(set_variants, lps_set_variants) LPS_SYM(set_reference, lps_set_reference)
         LPS_SYM(push_bam_records, lps_push_bam_records) LPS_SYM(phase_chromosome, lps_phase_chromosome) LPS_SYM(haplotag_chromosome, lps_haplotag_chromosome)
         LPS_SYM(abi_version, lps_abi_version) LPS_SYM(bgzf_load, lps_bgzf_load) LPS_SYM(bgzf_read, lps_bgzf_read) LPS_SYM(bam_scan, lps_bam_scan)
-        LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range)
+        LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range) LPS_SYM(device_count, lps_device_count)
 #undef LPS_SYM
         if (abi_version() != LPS_ABI_VERSION) { error = "liblps_hip.so has a different ABI version than this binary was built for"; return false; }
         return true;
@@ -404,11 +405,12 @@ static const char *kUsage =
     "   --ont | --pb   --indels   -q MAPQ(1)  -p baseQuality(12)  -e edgeWeight(0.1)  -a connectAdjacent(35)  -d distance(300000)\n"
     "   -1 edgeThreshold(0.7)  -L overlapThreshold(0.2)  -m readConfidence(0.65)  -n snpConfidence(0.75)  --gpu=ID (0)\n"
     "   --host-inflate   inflate BGZF with zlib on the -t host threads instead of on the GPU (always used when several -b files are given)\n"
-    "   --no-index       ignore <bam>.bai: make the whole file resident on the GPU instead of one contig at a time\n";
+    "   --no-index       ignore <bam>.bai: make the whole file resident on the GPU instead of one contig at a time\n"
+    "   --gpus=N         deal the contigs onto N GPUs (devices --gpu, --gpu+1, ... modulo the number present); needs the .bai index\n";
 
 static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over; bool indels = false;
-    std::string snp, ref, prefix = "result"; std::vector<std::string> bams; int threads = 1, gpu = 0; bool ont = false, pb = false, host_inflate = false, no_index = false;
+    std::string snp, ref, prefix = "result"; std::vector<std::string> bams; int threads = 1, gpu = 0, n_gpus = 1; bool ont = false, pb = false, host_inflate = false, no_index = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -432,6 +434,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "-n" || a == "--snpConfidence") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.snp_confidence = x; }); }
         else if (a == "-x" || a == "--mismatchRate") (void)val();
         else if (a == "--gpu") gpu = std::stoi(val());
+        else if (a == "--gpus") n_gpus = std::max(1, std::stoi(val()));
         else if (a == "--host-inflate") host_inflate = true;
         else if (a == "--no-index") no_index = true;
         else if (a == "--help") { std::cout << kUsage; return 0; }
@@ -466,21 +469,21 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     // with a .bai next to the BAM only the blocks of one contig are resident at a time (any file size, per-contig sharding); without, the whole file
     GpuBam gb; if (gpu_input) { gb.open_file(bams[0], !no_index); if (!gb.indexed) gb.load_all(L, ctx); }
     const double t_gin = now();
-    std::map<std::string, std::map<int32_t, Phased>> res;
-    for (const std::string &chr : chr_order) {                       // PhasingProcess.cpp:113-173
+    std::map<std::string, std::map<int32_t, Phased>> res; std::mutex res_mu;
+    auto run_contig = [&](lps_ctx *ctx, GpuBam &gb, const std::string &chr) {   // PhasingProcess.cpp:113-173, one contig on one GPU
         ChrVariants &cv = vars[chr];
-        if (cv.pos.empty() || !seqs.count(chr)) continue;
+        if (cv.pos.empty() || !seqs.count(chr)) return;
         // names of all files of this contig ranked together (one read name = one merged row, whatever file it came from)
         std::vector<std::pair<const char *, size_t>> names; std::vector<const ContigRecords *> parts; std::vector<char> name_store; std::vector<uint32_t> name_off;
         std::pair<int64_t, int64_t> gr{0, 0};
         if (gpu_input) {
-            if (gb.indexed) { gr = {0, gb.load_contig(L, ctx, chr)}; if (!gr.second) continue; }
-            else { auto it = gb.range.find(chr); if (it == gb.range.end()) continue; gr = it->second; }
+            if (gb.indexed) { gr = {0, gb.load_contig(L, ctx, chr)}; if (!gr.second) return; }
+            else { auto it = gb.range.find(chr); if (it == gb.range.end()) return; gr = it->second; }
             gb.names(L, ctx, gr.first, gr.second, name_store, name_off, names);
         }
         for (BamFile &f : files) { auto it = f.contigs.find(chr); if (it == f.contigs.end() || it->second.rec_off.empty()) { parts.push_back(nullptr); continue; }
             parts.push_back(&it->second); for (size_t i = 0; i < it->second.rec_off.size(); ++i) { size_t l; const char *nm = f.name_of(it->second, i, l); names.emplace_back(nm, l); } }
-        if (names.empty()) continue;
+        if (names.empty()) return;
         std::vector<uint32_t> name_id; rank_names(names, name_id);
         std::vector<uint8_t> r0(cv.pos.size()), a0(cv.pos.size()); std::vector<uint16_t> rl(cv.pos.size()), al(cv.pos.size());
         for (size_t i = 0; i < cv.pos.size(); ++i) { r0[i] = (uint8_t)cv.ref[i][0]; a0[i] = (uint8_t)cv.alt[i][0]; rl[i] = (uint16_t)cv.ref[i].size(); al[i] = (uint16_t)cv.alt[i].size(); }
@@ -499,10 +502,32 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         std::vector<int32_t> ps(cv.pos.size()); std::vector<uint8_t> gt(cv.pos.size());
         lps_phase_result pr{(int64_t)cv.pos.size(), ps.data(), gt.data()};
         if (L.phase_chromosome(ctx, &pr)) die(std::string("longphase_amd: ") + L.last_error(ctx));
-        auto &rc = res[chr];
+        std::map<int32_t, Phased> rc;
         for (size_t i = 0; i < cv.pos.size(); ++i) if (ps[i]) rc[cv.pos[i]] = Phased{ps[i], gt[i] ? '1' : '0', gt[i] ? '0' : '1'};
-        std::cerr << "(" << chr << ")";
+        { std::lock_guard<std::mutex> lk(res_mu); res[chr].swap(rc); std::cerr << "(" << chr << ")"; }
+    };
+    // contigs never interact: with --gpus N and an indexed BAM they are dealt longest-first onto N contexts, one host thread + one
+    // GPU each, every worker uploading only the BGZF blocks of its own contigs.  No data-path collective; results meet in the VCF writer.
+    int n_workers = 1;
+    if (n_gpus > 1) { if (gpu_input && gb.indexed) n_workers = n_gpus; else std::cerr << "longphase_amd: --gpus needs one BAM with its .bai index; running on one GPU\n"; }
+    std::vector<std::vector<std::string>> share((size_t)n_workers);
+    {
+        std::vector<std::string> by_size(chr_order); std::stable_sort(by_size.begin(), by_size.end(), [&](const std::string &a, const std::string &b) { return vars[a].pos.size() > vars[b].pos.size(); });
+        std::vector<size_t> load((size_t)n_workers, 0);
+        if (n_workers == 1) share[0] = chr_order;
+        else for (const std::string &c : by_size) { const size_t g = (size_t)(std::min_element(load.begin(), load.end()) - load.begin()); share[g].push_back(c); load[g] += vars[c].pos.size() + 1; }
     }
+    std::vector<std::thread> workers;
+    const int n_dev = std::max(1, L.device_count());
+    for (int g = 1; g < n_workers; ++g) workers.emplace_back([&, g] {
+        lps_params P; L.default_params(&P); for (auto &f : over) f(P);
+        lps_ctx *cx = L.create((gpu + g) % n_dev, &P); if (!cx) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
+        GpuBam gg; gg.open_file(bams[0], true);
+        for (const std::string &c : share[(size_t)g]) run_contig(cx, gg, c);
+        L.destroy(cx); gg.close_file();
+    });
+    for (const std::string &c : share[0]) run_contig(ctx, gb, c);
+    for (auto &w : workers) w.join();
     std::cerr << "\n";
     L.destroy(ctx);
     const double t_gpu = now();

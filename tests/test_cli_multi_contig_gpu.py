@@ -20,7 +20,7 @@ def _body(path):
     return [l for l in open(path).read().split("\n") if not l.startswith("##commandline=") and not l.startswith("##longphaseVersion=")]
 
 
-@pytest.mark.parametrize("inflate", ["gpu", "host", "gpu_indexed"])
+@pytest.mark.parametrize("inflate", ["gpu", "host", "gpu_indexed", "gpu_indexed_3workers"])
 def test_multi_contig_phase_then_haplotag(inflate, tmp_path):
     gold = json.load(open(os.path.join(HERE, "golden", "cli_multi_contig.json")))
     d = str(tmp_path)
@@ -28,18 +28,19 @@ def test_multi_contig_phase_then_haplotag(inflate, tmp_path):
     util.add_stale_tags(d + "/multi.sam", d + "/tagged_in.sam")
     util.write_bam(d + "/tagged_in.sam", d + "/reads.bam", block=30000)
     extra = ["--host-inflate"] if inflate == "host" else []
-    if inflate == "gpu_indexed":
+    if inflate.startswith("gpu_indexed"):
         util.write_bai(d + "/reads.bam")                              # only one contig's blocks are resident at a time
-    r = subprocess.run([CLI, "phase", "-s", "multi.vcf", "-b", "reads.bam", "-r", "multi.fa", "-t", "3", "-o", "phased", "--ont", "--indels"] + extra,
+    workers = ["--gpus", "3"] if inflate.endswith("3workers") else []   # three contexts (on the one GPU of the test box), contigs dealt longest-first
+    r = subprocess.run([CLI, "phase", "-s", "multi.vcf", "-b", "reads.bam", "-r", "multi.fa", "-t", "3", "-o", "phased", "--ont", "--indels"] + extra + workers,
                        cwd=d, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert ("per-contig (indexed)" in r.stderr) == (inflate == "gpu_indexed")
+    assert ("per-contig (indexed)" in r.stderr) == inflate.startswith("gpu_indexed")
     ref_vcf = os.path.join(HERE, "golden", "data", "multi_contig.ref_phased.vcf")
     assert _body(d + "/phased.vcf") == _body(ref_vcf)
     r = subprocess.run([CLI, "haplotag", "-s", ref_vcf, "-b", "reads.bam", "-r", "multi.fa", "-t", "3", "-o", "tagged"] + extra,
                        cwd=d, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert ("(indexed)" in r.stderr) == (inflate == "gpu_indexed")
+    assert ("(indexed)" in r.stderr) == inflate.startswith("gpu_indexed")
     text, refs, recs = util.bam_sections(d + "/tagged.bam")
     assert [l for l in text.split("\n") if l and not l.startswith("@PG")] == gold["header_without_pg"]
     got = util.bam_record_tags(recs)
