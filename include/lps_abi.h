@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 5
+#define LPS_ABI_VERSION 6
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -243,6 +243,12 @@ int lps_push_bam_records(lps_ctx *ctx, const uint8_t *records, int64_t n_bytes, 
 int lps_bgzf_load(lps_ctx *ctx, const uint8_t *bgzf, int64_t n_bytes, int64_t *inflated_bytes);
 int lps_bgzf_read(lps_ctx *ctx, int64_t offset, int64_t n, uint8_t *dst);
 int lps_bgzf_timings(lps_ctx *ctx, double *h2d_ms, double *inflate_ms);
+/* GPU BGZF writer (replaces bgzf_write/deflate behind sam_write1, src/haplotag/HaplotagParsingBam.cpp:124-134): bytes [offset, offset+n_bytes)
+ * of the resident stream are cut into 0xff00-byte blocks, each deflated with a per-block dynamic Huffman code (no LZ77) and wrapped as a BGZF
+ * member with CRC32/ISIZE; lps_bgzf_deflate leaves the blocks on the device and returns their total size, lps_bgzf_deflate_fetch copies them
+ * to the host.  No EOF block is appended. */
+int lps_bgzf_deflate(lps_ctx *ctx, int64_t offset, int64_t n_bytes, int64_t *out_bytes);
+int lps_bgzf_deflate_fetch(lps_ctx *ctx, uint8_t *dst, int64_t cap, double *kernel_ms);
 /* Find every BAM record of the resident stream on the GPU, starting at first_record_offset (= the byte after the BAM header's reference
  * table; the caller parses the header with lps_bgzf_read).  Every byte position is tested against the necessary conditions of a record
  * start and the candidate list is verified to be exactly the record chain (serial fallback otherwise), so the result is exact.

@@ -14,6 +14,7 @@
 #include "lps_graph.h"
 #include "lps_bam.h"
 #include "lps_inflate.h"
+#include "lps_deflate.h"
 
 static const char *kStageNames[LPS_MAX_STAGES] = {
     "variant_prep", "extract", "name_keys", "clip_cnv", "name_groups", "overlap_filter", "cnv_filter", "nodes", "merge_rows",
@@ -41,6 +42,7 @@ struct lps_ctx {
     DevBuf<uint64_t> rec_off; DevBuf<unsigned long long> cig_cnt; DevBuf<unsigned> bam_err;
     // whole BAM file resident on the device (lps_bgzf_load): compressed bytes, block table, inflated stream; survives lps_begin_chromosome
     DevBuf<uint8_t> zfile, file; DevBuf<InflateBlock> zblk; uint64_t file_bytes = 0; float bgzf_h2d_ms = 0, bgzf_inflate_ms = 0;
+    DevBuf<uint8_t> dz_slots, dz_packed; DevBuf<uint32_t> dz_bytes; DevBuf<unsigned long long> dz_tmp; DevBuf<uint64_t> dz_off; uint64_t dz_total = 0; float dz_ms = 0;
     DevBuf<uint64_t> rcand; uint64_t n_rec_all = 0; DevBuf<int32_t> r_tid_all; DevBuf<uint32_t> r_lname, r_nameoff, wg_cnt, wg_off, scan_nout; DevBuf<uint8_t> names_d; bool names_ready = false;
     // observations
     DevBuf<uint32_t> row_off; DevBuf<int32_t> row_cnt, row_fail, g_cnt; DevBuf<uint8_t> row_flags, deleted;
@@ -418,6 +420,31 @@ int lps_bgzf_read(lps_ctx *c, int64_t offset, int64_t n, uint8_t *dst) {
         HIP_TRY(hipSetDevice(c->device));
         if (n) HIP_TRY(hipMemcpyAsync(dst, c->file.p + offset, (size_t)n, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_bgzf_deflate(lps_ctx *c, int64_t offset, int64_t n_bytes, int64_t *out_bytes) {
+    if (!c || !out_bytes || offset < 0 || n_bytes < 0 || (uint64_t)(offset + n_bytes) > c->file_bytes) return fail(c, "lps_bgzf_deflate: range outside the resident stream");
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        hipStream_t s = c->stream; hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, s));
+        c->dz_total = bgzf_deflate_device(c->file.p + offset, (uint64_t)n_bytes, c->dz_slots, c->dz_bytes, c->dz_tmp, c->dz_off, c->dz_packed, c->temp, c->temp_bytes, s);
+        HIP_TRY(hipEventRecord(e1, s)); HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipEventElapsedTime(&c->dz_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *out_bytes = (int64_t)c->dz_total;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_bgzf_deflate_fetch(lps_ctx *c, uint8_t *dst, int64_t cap, double *kernel_ms) {
+    if (!c || (c->dz_total && !dst) || cap < (int64_t)c->dz_total) return fail(c, "lps_bgzf_deflate_fetch: buffer too small");
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        if (c->dz_total) HIP_TRY(hipMemcpyAsync(dst, c->dz_packed.p, (size_t)c->dz_total, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (kernel_ms) *kernel_ms = c->dz_ms;
     } catch (std::string &e) { return fail(c, e); }
     return 0;
 }

@@ -48,6 +48,8 @@ def load():
     L.lps_push_bam_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.lps_bgzf_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.lps_bgzf_read.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    L.lps_bgzf_deflate.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
+    L.lps_bgzf_deflate_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]
     L.lps_bgzf_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.lps_bam_scan.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
     L.lps_bam_scan_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
@@ -150,6 +152,14 @@ class Context:
         out = np.empty(n, dtype=np.uint8)
         self._check(self.L.lps_bgzf_read(self.h, offset, n, out.ctypes.data), "lps_bgzf_read")
         return out
+
+    def bgzf_deflate(self, offset, n_bytes):
+        """Deflate a piece of the resident stream into BGZF blocks on the GPU -> (bytes, kernel ms)."""
+        nb = C.c_int64(0)
+        self._check(self.L.lps_bgzf_deflate(self.h, offset, n_bytes, C.byref(nb)), "lps_bgzf_deflate")
+        out = np.empty(max(1, nb.value), dtype=np.uint8); ms = C.c_double(0)
+        self._check(self.L.lps_bgzf_deflate_fetch(self.h, out.ctypes.data, out.size, C.byref(ms)), "lps_bgzf_deflate_fetch")
+        return out[:nb.value].tobytes(), ms.value
 
     def bgzf_timings(self):
         a, b = C.c_double(0), C.c_double(0)

@@ -130,3 +130,37 @@ def test_phase_from_gpu_inflated_bam(name, tmp_path):
         with pytest.raises(hip.LpsError, match="mixed"):
             ctx._check(ctx.L.lps_push_reads(ctx.h, hip.C.byref(R.c)), "lps_push_reads")
     s.close()
+
+
+def _check_blocks(z):
+    """structural checks of a BGZF byte string: member headers, BSIZE chain, ISIZE <= 0xff00"""
+    p, n = 0, 0
+    while p < len(z):
+        assert z[p:p + 4] == b"\x1f\x8b\x08\x04" and z[p + 12:p + 16] == b"BC\x02\x00"
+        bsize = struct.unpack_from("<H", z, p + 16)[0] + 1
+        isize = struct.unpack_from("<I", z, p + bsize - 4)[0]
+        assert isize <= 0xff00 and bsize <= 65536
+        p += bsize; n += 1
+    assert p == len(z)
+    return n
+
+
+@pytest.mark.parametrize("size", [1, 2, 300, 0xff00 - 1, 0xff00, 0xff00 + 1, 200_000])
+def test_gpu_deflate_round_trips(size):
+    """lps_bgzf_deflate: GPU-written BGZF blocks inflate (zlib, incl. its CRC32/ISIZE checks) to the resident bytes; ratio close to zlib's Huffman-only"""
+    with hip.Context(0, abi.default_params()) as ctx:
+        for name, data in payloads():
+            data = (data * (size // len(data) + 1))[:size]
+            assert ctx.bgzf_load(bgzf(data, 0xff00, 1)) == len(data)
+            z, ms = ctx.bgzf_deflate(0, len(data))
+            assert _check_blocks(z) == (len(data) + 0xff00 - 1) // 0xff00
+            assert gzip.decompress(z) == data, (name, size)            # gzip verifies CRC32 and ISIZE of every member
+            if size >= 0xff00:
+                want = len(bgzf(data, 0xff00, 6, zlib.Z_HUFFMAN_ONLY, eof=False))
+                assert len(z) <= want * 1.03 + 64, (name, len(z), want)
+                print(name, size, "gpu", len(z), "zlib huffman-only", want, "zlib level 6", len(bgzf(data, 0xff00, 6, eof=False)), "kernel ms", round(ms, 3))
+            # a sub-range of the stream, and the GPU inflate reads what the GPU deflate wrote
+            if size > 5000:
+                z2, _ = ctx.bgzf_deflate(1234, size - 2345)
+                assert gzip.decompress(z2) == data[1234:size - 1111]
+                assert ctx.bgzf_load(z) == len(data) and ctx.bgzf_read(0, len(data)).tobytes() == data
