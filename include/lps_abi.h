@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 6
+#define LPS_ABI_VERSION 7
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -249,6 +249,13 @@ int lps_bgzf_timings(lps_ctx *ctx, double *h2d_ms, double *inflate_ms);
  * to the host.  No EOF block is appended. */
 int lps_bgzf_deflate(lps_ctx *ctx, int64_t offset, int64_t n_bytes, int64_t *out_bytes);
 int lps_bgzf_deflate_fetch(lps_ctx *ctx, uint8_t *dst, int64_t cap, double *kernel_ms);
+/* haplotag output on the GPU (tag rules of src/haplotag/HaplotagProcess.cpp:337-361 + the BGZF writer above): the records of the ONE
+ * lps_push_bam_resident of this chromosome are re-emitted in order - a record with status 0 loses its first HP, PS and PQ optional field and,
+ * when hp != 0, gains HP:i PS:i PQ:i; every other record is copied untouched - behind `prefix` (e.g. the BAM header for the first contig),
+ * cut into BGZF blocks and deflated.  status/hp/ps/pq: the arrays lps_haplotag_chromosome filled (cur count entries).  Result stays on the
+ * device (lps_bgzf_deflate_fetch copies it out); no EOF block is appended. */
+int lps_haplotag_write_bgzf(lps_ctx *ctx, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, const uint8_t *prefix, int64_t prefix_bytes,
+                            int64_t *out_bytes);
 /* Find every BAM record of the resident stream on the GPU, starting at first_record_offset (= the byte after the BAM header's reference
  * table; the caller parses the header with lps_bgzf_read).  Every byte position is tested against the necessary conditions of a record
  * start and the candidate list is verified to be exactly the record chain (serial fallback otherwise), so the result is exact.

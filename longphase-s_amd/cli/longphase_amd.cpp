@@ -51,6 +51,7 @@ struct Lps {
     decltype(&lps_bgzf_load) bgzf_load = nullptr; decltype(&lps_bgzf_read) bgzf_read = nullptr; decltype(&lps_bam_scan) bam_scan = nullptr;
     decltype(&lps_bam_record_tids) bam_record_tids = nullptr; decltype(&lps_bam_names) bam_names = nullptr; decltype(&lps_push_bam_resident) push_bam_resident = nullptr;
     decltype(&lps_bam_record_offsets) bam_record_offsets = nullptr; decltype(&lps_bam_scan_range) bam_scan_range = nullptr; decltype(&lps_device_count) device_count = nullptr;
+    decltype(&lps_haplotag_write_bgzf) haplotag_write_bgzf = nullptr; decltype(&lps_bgzf_deflate_fetch) bgzf_deflate_fetch = nullptr;
     std::string error;
     bool load() {
         char exe[4096]; const ssize_t k = readlink("/proc/self/exe", exe, sizeof exe - 1);
@@ -64,7 +65,7 @@ struct Lps {
         LPS_SYM(begin_chromosome, lps_begin_chromosome) LPS_SYM(set_variants, lps_set_variants) LPS_SYM(set_reference, lps_set_reference)
         LPS_SYM(push_bam_records, lps_push_bam_records) LPS_SYM(phase_chromosome, lps_phase_chromosome) LPS_SYM(haplotag_chromosome, lps_haplotag_chromosome)
         LPS_SYM(abi_version, lps_abi_version) LPS_SYM(bgzf_load, lps_bgzf_load) LPS_SYM(bgzf_read, lps_bgzf_read) LPS_SYM(bam_scan, lps_bam_scan)
-        LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range) LPS_SYM(device_count, lps_device_count)
+        LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range) LPS_SYM(device_count, lps_device_count) LPS_SYM(haplotag_write_bgzf, lps_haplotag_write_bgzf) LPS_SYM(bgzf_deflate_fetch, lps_bgzf_deflate_fetch)
 #undef LPS_SYM
         if (abi_version() != LPS_ABI_VERSION) { error = "liblps_hip.so has a different ABI version than this binary was built for"; return false; }
         return true;
@@ -634,6 +635,8 @@ struct BgzfWriter {
         emit(p, whole);
         pend.assign(p + whole, p + n);
     }
+    void flush_partial() { emit(pend.data(), pend.size()); pend.clear(); wait_writer(); }
+    void write_raw(const uint8_t *p, size_t n) { wait_writer(); if (n && fwrite(p, 1, n, f) != n) die("ERROR: write output bam file failed"); bytes_out += n; }
     void finish() {
         emit(pend.data(), pend.size()); pend.clear(); wait_writer();
         static const uint8_t eof[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -660,12 +663,13 @@ static const char *kTagUsage =
     "   -s, --snp-file=NAME   -b, --bam-file=NAME   -r, --reference=NAME   -o, --out-prefix=NAME (result)   -t, --threads=Num (1)\n"
     "   --tagSupplementary   -q qualityThreshold(1)   -p percentageThreshold(0.6)   --gpu=ID (0)\n"
     "   --host-inflate (zlib on the -t threads instead of the GPU inflate)   --no-index (ignore <bam>.bai, keep the whole file on the GPU)\n"
+    "   --host-deflate (tag splice + zlib deflate on the -t threads instead of the GPU writer; implied by --host-inflate)\n"
     "   --compress-level=N (6)   --compress-strategy=rle|default|huffman (rle: packed bases and qualities hold few LZ77 matches; about 2 % larger\n"
     "                             output than zlib's default strategy at several times the speed; `default` = what htslib writes)\n";
 
 static int haplotag_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
-    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, level = 6, strategy = Z_RLE; bool host_inflate = false, no_index = false;
+    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, level = 6, strategy = Z_RLE; bool host_inflate = false, no_index = false, host_deflate = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kTagUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -682,6 +686,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--host-inflate") host_inflate = true;
         else if (a == "--no-index") no_index = true;
+        else if (a == "--host-deflate") host_deflate = true;
         else if (a == "--compress-level") level = std::stoi(val());
         else if (a == "--compress-strategy") { const std::string x = val(); strategy = x == "default" ? Z_DEFAULT_STRATEGY : x == "rle" ? Z_RLE : x == "huffman" ? Z_HUFFMAN_ONLY : -1; if (strategy < 0) die("longphase_amd: --compress-strategy is one of default, rle, huffman"); }
         else if (a == "--help") { std::cout << kTagUsage; return 0; }
@@ -705,6 +710,8 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     const double t_text = now();
     // default: BGZF inflate + record discovery on the GPU, the inflated stream is copied back once for the writer; --host-inflate: zlib on -t threads
     BamFile in; GpuBam gb; size_t in_cap = 0;
+    if (host_inflate) host_deflate = true;                             // the GPU writer works on the stream the GPU inflated
+    const bool gpu_writer = !host_deflate;
     if (host_inflate) in.load(bam, threads, want);
     const double t_bam = now();
     gpu_init.join();
@@ -724,11 +731,11 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         gb.open_file(bam, !no_index);
         if (!gb.indexed) {
             gb.load_all(L, ctx);
-            copy_back(gb.total);
+            if (!gpu_writer) copy_back(gb.total);
             for (auto &kv : gb.range) {
                 if (!want.count(kv.first)) continue;
                 ContigRecords &c = in.contigs[kv.first]; c.rec_off.resize((size_t)kv.second.second);
-                if (L.bam_record_offsets(ctx, kv.second.first, kv.second.second, c.rec_off.data())) die(std::string("ERROR: ") + L.last_error(ctx));
+                if (!gpu_writer && L.bam_record_offsets(ctx, kv.second.first, kv.second.second, c.rec_off.data())) die(std::string("ERROR: ") + L.last_error(ctx));
                 c.lo = 0; c.hi = (uint64_t)gb.total;                   // offsets stay absolute (lo = 0)
             }
         }
@@ -748,15 +755,16 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         size_t p = 8 + (size_t)l_text; const size_t ref_begin = p; const uint32_t n_ref = rd32(d + p); p += 4; for (uint32_t i = 0; i < n_ref; ++i) p += 4 + (size_t)rd32(d + p) + 4;
         h.insert(h.end(), d + ref_begin, d + p);
         w.append(h.data(), h.size());
+        if (gpu_writer) w.flush_partial();                             // the header becomes its own BGZF block(s); the GPU writes whole blocks per contig
     }
     unsigned long long st_count[8] = {0}, hp_count[3] = {0};
-    double t_score = 0, t_splice = 0, t_deflate = 0, t_load = 0, t_mark = now();
+    double t_score = 0, t_splice = 0, t_deflate = 0, t_load = 0, t_mark = now(); std::vector<uint8_t> zbuf;
     for (const std::string &chr : chr_vec) {                          // contigs in VCF-header order (HaplotagProcess.cpp:94-97)
         if (!host_inflate && gb.indexed) {                              // this contig's blocks only: inflate + scan on the GPU, copy its records back
             const double tl = now();
             const int64_t cnt = gb.load_contig(L, ctx, chr);
             ContigRecords &cc = in.contigs[chr]; cc.rec_off.resize((size_t)cnt); cc.lo = 0; cc.hi = (uint64_t)gb.total;
-            if (cnt) { copy_back(gb.total); if (L.bam_record_offsets(ctx, 0, cnt, cc.rec_off.data())) die(std::string("ERROR: ") + L.last_error(ctx)); }
+            if (cnt && !gpu_writer) { copy_back(gb.total); if (L.bam_record_offsets(ctx, 0, cnt, cc.rec_off.data())) die(std::string("ERROR: ") + L.last_error(ctx)); }
             t_load += now() - tl; t_mark = now();
         }
         auto ci = in.contigs.find(chr);
@@ -777,8 +785,23 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
                 (host_inflate ? L.push_bam_records(ctx, base, (int64_t)(c.hi - c.lo), c.rec_off.data(), (int64_t)n, name_id.data())
                               : L.push_bam_resident(ctx, gb.indexed ? 0 : gb.range[chr].first, (int64_t)n, name_id.data())) || L.haplotag_chromosome(ctx, &hr))
                 die(std::string("longphase_amd: ") + L.last_error(ctx));
+        } else if (gpu_writer) {                                          // no variants on this contig: its records are still written (untouched)
+            std::vector<uint32_t> name_id(n, 0);
+            if (L.begin_chromosome(ctx) || L.push_bam_resident(ctx, gb.indexed ? 0 : gb.range[chr].first, (int64_t)n, name_id.data())) die(std::string("longphase_amd: ") + L.last_error(ctx));
         }
         t_score += now() - t_mark; t_mark = now();
+        if (gpu_writer) {                                                 // tag splice + BGZF deflate on the GPU; the host only writes the finished blocks
+            int64_t nb = 0;
+            if (L.haplotag_write_bgzf(ctx, status.data(), hp.data(), psv.data(), pq.data(), nullptr, 0, &nb)) die(std::string("longphase_amd: ") + L.last_error(ctx));
+            if ((size_t)nb > zbuf.size()) zbuf.resize((size_t)nb + (zbuf.size() >> 1));
+            if (L.bgzf_deflate_fetch(ctx, zbuf.data(), (int64_t)zbuf.size(), nullptr)) die(std::string("longphase_amd: ") + L.last_error(ctx));
+            t_splice += now() - t_mark; t_mark = now();
+            w.write_raw(zbuf.data(), (size_t)nb);
+            for (size_t i = 0; i < n; ++i) { ++st_count[status[i] & 7]; if (status[i] == 0) ++hp_count[hp[i] < 3 ? hp[i] : 0]; }
+            t_deflate += now() - t_mark; t_mark = now();
+            std::cerr << "(" << chr << ")";
+            continue;
+        }
         // second pass, records stay in input order (the reference's tagRead is single-threaded for that reason, HaplotagProcess.cpp:138):
         // (1) output length of every record, (2) prefix sum, (3) records written into place by a thread pool, (4) block-parallel deflate
         std::vector<uint64_t> out_off(n + 1, 0);
@@ -842,8 +865,8 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     unsigned long long total = 0; for (int k = 0; k < 8; ++k) total += st_count[k];
     fprintf(stderr, "total alignment %llu | tagged %llu (HP1 %llu, HP2 %llu) | untagged: low mapq %llu, unmapped %llu, secondary %llu, supplementary %llu, no variant %llu, beyond last variant %llu, judged %llu\n",
             total, hp_count[1] + hp_count[2], hp_count[1], hp_count[2], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6], hp_count[0]);
-    fprintf(stderr, "vcf+fasta read %.3fs | %s %.3fs | wait for gpu context %.3fs | score %.3fs | tag splice %.3fs | deflate+write %.3fs (%llu bytes) | total %.3fs\n",
-            t_text - t_begin, host_inflate ? "host inflate+walk" : gb.indexed ? "gpu inflate+scan+copy back per contig (indexed)" : "gpu inflate+scan+copy back", host_inflate ? t_bam - t_text : t_gin - t_ctx + t_load, t_ctx - t_bam, t_score, t_splice, t_deflate, w.bytes_out, now() - t_begin);
+    fprintf(stderr, "vcf+fasta read %.3fs | %s %.3fs | wait for gpu context %.3fs | score %.3fs | %s %.3fs | %s %.3fs (%llu bytes) | total %.3fs\n",
+            t_text - t_begin, host_inflate ? "host inflate+walk" : gb.indexed ? "gpu inflate+scan+copy back per contig (indexed)" : "gpu inflate+scan+copy back", host_inflate ? t_bam - t_text : t_gin - t_ctx + t_load, t_ctx - t_bam, t_score, gpu_writer ? "gpu tag splice+deflate+copy out" : "tag splice", t_splice, gpu_writer ? "write" : "deflate+write", t_deflate, w.bytes_out, now() - t_begin);
     fflush(stderr);
     _exit(0);
 }

@@ -42,6 +42,7 @@ struct lps_ctx {
     DevBuf<uint64_t> rec_off; DevBuf<unsigned long long> cig_cnt; DevBuf<unsigned> bam_err;
     // whole BAM file resident on the device (lps_bgzf_load): compressed bytes, block table, inflated stream; survives lps_begin_chromosome
     DevBuf<uint8_t> zfile, file; DevBuf<InflateBlock> zblk; uint64_t file_bytes = 0; float bgzf_h2d_ms = 0, bgzf_inflate_ms = 0;
+    DevBuf<unsigned long long> tg_len, tg_off; DevBuf<uint2> tg_spans; DevBuf<uint8_t> tg_stream, tg_status, tg_hp; DevBuf<int32_t> tg_ps, tg_pq; int64_t cur_first = -1, cur_count = 0;
     DevBuf<uint8_t> dz_slots, dz_packed; DevBuf<uint32_t> dz_bytes; DevBuf<unsigned long long> dz_tmp; DevBuf<uint64_t> dz_off; uint64_t dz_total = 0; float dz_ms = 0;
     DevBuf<uint64_t> rcand; uint64_t n_rec_all = 0; DevBuf<int32_t> r_tid_all; DevBuf<uint32_t> r_lname, r_nameoff, wg_cnt, wg_off, scan_nout; DevBuf<uint8_t> names_d; bool names_ready = false;
     // observations
@@ -152,7 +153,7 @@ void *lps_stream(lps_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int lps_begin_chromosome(lps_ctx *c) {
     if (!c) return -1;
-    c->nV = 0; c->last_pos = -1; c->ref_len = c->ref_len_eff = 0; c->nR = 0; c->n_cig = c->n_seq = c->n_qual = 0; c->n_blob = 0; c->read_mode = 0;
+    c->nV = 0; c->last_pos = -1; c->ref_len = c->ref_len_eff = 0; c->nR = 0; c->n_cig = c->n_seq = c->n_qual = 0; c->n_blob = 0; c->read_mode = 0; c->cur_first = -1; c->cur_count = 0;
     c->phase_valid = false; c->has_hap = false; c->h_vpos.clear();
     return 0;
 }
@@ -359,6 +360,7 @@ int lps_push_bam_resident(lps_ctx *c, int64_t first, int64_t count, const uint32
         if (count == 0) return 0;
         if (c->read_mode == 1 || c->read_mode == 2) return fail(c, "lps_push_bam_resident mixed with another kind of push in the same chromosome");
         if ((uint64_t)c->nR + (uint64_t)count > 0x1fffffffull) return fail(c, "more than 2^29 alignments per chromosome");
+        c->cur_first = c->read_mode == 3 ? -2 : first; c->cur_count = count;   // -2: more than one resident push in this chromosome
         c->read_mode = 3;
         BamView B{c->file.p, 0, c->file_bytes, c->rcand.p + first};
         return push_record_view(c, B, (size_t)count, name_id);
@@ -431,6 +433,29 @@ int lps_bgzf_deflate(lps_ctx *c, int64_t offset, int64_t n_bytes, int64_t *out_b
         hipStream_t s = c->stream; hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, s));
         c->dz_total = bgzf_deflate_device(c->file.p + offset, (uint64_t)n_bytes, c->dz_slots, c->dz_bytes, c->dz_tmp, c->dz_off, c->dz_packed, c->temp, c->temp_bytes, s);
+        HIP_TRY(hipEventRecord(e1, s)); HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipEventElapsedTime(&c->dz_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *out_bytes = (int64_t)c->dz_total;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_haplotag_write_bgzf(lps_ctx *c, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, const uint8_t *prefix, int64_t prefix_bytes, int64_t *out_bytes) {
+    if (!c || !out_bytes || prefix_bytes < 0 || (prefix_bytes && !prefix)) return -1;
+    if (c->read_mode != 3 || c->cur_first < 0) return fail(c, "lps_haplotag_write_bgzf: needs exactly one lps_push_bam_resident in this chromosome");
+    const size_t n = (size_t)c->cur_count;
+    if (n && (!status || !hp || !ps || !pq)) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        hipStream_t s = c->stream; hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        upload(c, c->tg_status, status, n); upload(c, c->tg_hp, hp, n); upload(c, c->tg_ps, ps, n); upload(c, c->tg_pq, pq, n);
+        c->tg_stream.reserve((size_t)prefix_bytes + 64, s); c->bam_err.reserve(1);
+        if (prefix_bytes) HIP_TRY(hipMemcpyAsync(c->tg_stream.p, prefix, (size_t)prefix_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(e0, s));
+        const int64_t total = bam_tag_stream(c->file.p, c->rcand.p + c->cur_first, (uint32_t)n, c->tg_status.p, c->tg_hp.p, c->tg_ps.p, c->tg_pq.p, (uint64_t)prefix_bytes,
+                                             c->tg_len, c->tg_off, c->tg_spans, c->tg_stream, c->temp, c->temp_bytes, c->bam_err.p, s);
+        if (total < 0) return fail(c, "malformed auxiliary field in a BAM record");
+        c->dz_total = bgzf_deflate_device(c->tg_stream.p, (uint64_t)total, c->dz_slots, c->dz_bytes, c->dz_tmp, c->dz_off, c->dz_packed, c->temp, c->temp_bytes, s);
         HIP_TRY(hipEventRecord(e1, s)); HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipEventElapsedTime(&c->dz_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         *out_bytes = (int64_t)c->dz_total;

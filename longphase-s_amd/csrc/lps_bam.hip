@@ -199,3 +199,82 @@ void launch_bam_tid_lname(const uint8_t *d, const uint64_t *cand, uint32_t n, in
 void launch_bam_names(const uint8_t *d, const uint64_t *cand, uint32_t n, const uint32_t *name_off, uint8_t *names, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_bam_names, dim3((n + 3) / 4), dim3(256), 0, s, d, cand, n, name_off, names);
 }
+
+// ================================================================================================ tagged-record stream (haplotag writer)
+// HaplotagProcess.cpp:337-361 on the device: a scored record loses its first HP, PS and PQ optional field and, when tagged, gains HP:i PS:i PQ:i;
+// every other record is copied untouched.  k_tag_sizes walks the optional fields (thread per record), k_tag_write copies bytes (wave per record).
+__device__ __forceinline__ uint32_t aux_len_dev(const uint8_t *p, const uint8_t *end) {       // bytes of one optional field, 0 = malformed
+    if (p + 3 > end) return 0;
+    const uint8_t t = p[2]; uint64_t v;
+    if (t == 'A' || t == 'c' || t == 'C') v = 1; else if (t == 's' || t == 'S') v = 2; else if (t == 'i' || t == 'I' || t == 'f') v = 4; else if (t == 'd') v = 8;
+    else if (t == 'Z' || t == 'H') { const uint8_t *q = p + 3; while (q < end && *q) ++q; if (q >= end) return 0; v = (uint64_t)(q - (p + 3)) + 1; }
+    else if (t == 'B') { if (p + 8 > end) return 0; const uint8_t st = p[3]; const uint64_t cnt = ld_u32_unaligned(p + 4);
+        const uint64_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0; if (!es) return 0; v = 5 + cnt * es; }
+    else return 0;
+    return (p + 3 + v <= end) ? (uint32_t)(3 + v) : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_tag_sizes(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, unsigned long long *new_len,
+                                                   uint2 *spans /* [n][3] (offset from refID, length), sorted by offset, length 0 = none */, unsigned *err) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { new_len[n] = 0; return; }
+    const uint64_t r = rec[i]; const uint32_t bs = ld_u32_unaligned(d + r - 4);
+    uint2 sp[3] = {{0, 0}, {0, 0}, {0, 0}}; uint32_t removed = 0;
+    if (status[i] == 0) {
+        const uint32_t l_name = d[r + 8], n_cig = ld_u16(d + r + 12), l_seq = ld_u32_unaligned(d + r + 16);
+        const uint8_t *p = d + r + 32 + l_name + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq, *end = d + r + bs; int k = 0; bool seen[3] = {false, false, false};
+        while (p < end) {
+            const uint32_t l = aux_len_dev(p, end); if (!l) { atomicOr(err, 1u); break; }
+            const int which = (p[0] == 'H' && p[1] == 'P') ? 0 : (p[0] == 'P' && p[1] == 'S') ? 1 : (p[0] == 'P' && p[1] == 'Q') ? 2 : -1;
+            if (which >= 0 && !seen[which]) { seen[which] = true; sp[k].x = (uint32_t)(p - (d + r)); sp[k].y = l; ++k; removed += l; }   // encountered in offset order
+            p += l;
+        }
+    }
+    spans[(size_t)i * 3 + 0] = sp[0]; spans[(size_t)i * 3 + 1] = sp[1]; spans[(size_t)i * 3 + 2] = sp[2];
+    new_len[i] = 4ull + bs - removed + ((status[i] == 0 && hp[i]) ? 21u : 0u);
+}
+
+__global__ void __launch_bounds__(256) k_tag_write(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq,
+                                                   const unsigned long long *out_off, const uint2 *spans, uint8_t *out) {
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const uint64_t r = rec[i]; const uint32_t bs = ld_u32_unaligned(d + r - 4);
+    const uint2 s0 = spans[(size_t)i * 3], s1 = spans[(size_t)i * 3 + 1], s2 = spans[(size_t)i * 3 + 2];
+    const uint32_t kept = bs - s0.y - s1.y - s2.y; const bool tag = status[i] == 0 && hp[i] != 0; const uint32_t nbs = kept + (tag ? 21u : 0u);
+    uint8_t *o = out + out_off[i];
+    if (lane < 4) o[lane] = (uint8_t)(nbs >> (8 * lane));
+    for (uint32_t j = lane; j < kept; j += 64) {
+        uint32_t src = j;
+        if (s0.y && src >= s0.x) src += s0.y;
+        if (s1.y && src >= s1.x) src += s1.y;
+        if (s2.y && src >= s2.x) src += s2.y;
+        o[4 + j] = d[r + src];
+    }
+    if (tag && lane < 21) {                                               // addAuxiliaryTags: HP:i PS:i PQ:i, 7 bytes each
+        const uint32_t f = lane / 7, b = lane % 7; const uint32_t val = f == 0 ? (uint32_t)hp[i] : f == 1 ? (uint32_t)ps[i] : (uint32_t)pq[i];
+        const char *nm = f == 0 ? "HP" : f == 1 ? "PS" : "PQ";
+        o[4 + kept + lane] = b < 2 ? (uint8_t)nm[b] : b == 2 ? (uint8_t)'i' : (uint8_t)(val >> (8 * (b - 3)));
+    }
+}
+
+// -> total bytes of prefix + re-tagged records in `stream`; -1 when an optional field is malformed
+int64_t bam_tag_stream(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, uint64_t prefix_bytes,
+                       DevBuf<unsigned long long> &new_len, DevBuf<unsigned long long> &out_off, DevBuf<uint2> &spans, DevBuf<uint8_t> &stream, DevBuf<char> &temp, size_t &temp_bytes,
+                       unsigned *err, hipStream_t s) {
+    new_len.reserve((size_t)n + 1, s); out_off.reserve((size_t)n + 1, s); spans.reserve((size_t)n * 3 + 3, s);
+    HIP_TRY(hipMemsetAsync(err, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_tag_sizes, dim3((n + 256) / 256), dim3(256), 0, s, d, rec, n, status, hp, new_len.p, spans.p, err);
+    size_t need = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, need, new_len.p, out_off.p, (unsigned long long)prefix_bytes, (size_t)n + 1, rocprim::plus<unsigned long long>(), s));
+    if (need + 256 > temp_bytes) { temp.reserve(need + 256, s); temp_bytes = need + 256; }
+    HIP_TRY(rocprim::exclusive_scan(temp.p, need, new_len.p, out_off.p, (unsigned long long)prefix_bytes, (size_t)n + 1, rocprim::plus<unsigned long long>(), s));
+    unsigned long long total = 0; unsigned e = 0;
+    HIP_TRY(hipMemcpyAsync(&total, out_off.p + n, sizeof total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&e, err, sizeof e, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (e) return -1;
+    stream.reserve((size_t)total + 64, s, true, prefix_bytes);
+    if (n) hipLaunchKernelGGL(k_tag_write, dim3((n + 3) / 4), dim3(256), 0, s, d, rec, n, status, hp, ps, pq, (const unsigned long long *)out_off.p, (const uint2 *)spans.p, stream.p);
+    return (int64_t)total;
+}

@@ -19,7 +19,7 @@ CLI = os.path.join(HERE, "..", "longphase-s_amd", "cli", "longphase_amd")
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,inflate", [(n, "gpu") for n in fixtures.CLI_HAPLOTAG_FIXTURES] + [("supp_tagged", "host"), ("indels", "host")])
+@pytest.mark.parametrize("name,inflate", [(n, "gpu") for n in fixtures.CLI_HAPLOTAG_FIXTURES] + [("supp_tagged", "host"), ("indels", "host"), ("strict", "hostdeflate"), ("two_blocks", "hostdeflate")])
 def test_cli_haplotag_output_bam_matches_reference(name, inflate, tmp_path):
     gold = json.load(open(os.path.join(HERE, "golden", f"cli_haplotag_{name}.json")))
     src, tag_cli, over = fixtures.HAPLOTAG_FIXTURES[name]
@@ -33,7 +33,7 @@ def test_cli_haplotag_output_bam_matches_reference(name, inflate, tmp_path):
     util.write_table_vcf(d + "/table.vcf", V, "chrS", kw["contig_len"])
     util.write_bam(d + "/reads.sam", d + "/reads.bam", block=20000)
     s.close()
-    r = subprocess.run([CLI, "haplotag", "-s", "table.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", "4", "-o", "tagged"] + tag_cli + (["--host-inflate"] if inflate == "host" else []),
+    r = subprocess.run([CLI, "haplotag", "-s", "table.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", "4", "-o", "tagged"] + tag_cli + (["--host-inflate"] if inflate == "host" else ["--host-deflate"] if inflate == "hostdeflate" else []),
                        cwd=d, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     text, refs, recs = util.bam_sections(d + "/tagged.bam")
@@ -48,6 +48,7 @@ def test_cli_haplotag_output_bam_matches_reference(name, inflate, tmp_path):
         assert g == w
     assert len(recs) == gold["record_bytes"]
     assert hashlib.sha256(recs).hexdigest() == gold["records_sha256"]
+    assert ("gpu tag splice+deflate" in r.stderr) == (inflate == "gpu")
     # the output is a valid BGZF file: ends with the 28-byte EOF block, every block <= 64 KiB
     raw = open(d + "/tagged.bam", "rb").read()
     assert raw[-28:] == bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
