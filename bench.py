@@ -139,8 +139,8 @@ def cli_e2e(d, threads, ref_wall, n_ph):
         tag = {"cli_wall_s": round(min(tc), 3), "reference_wall_s": round(min(tr), 3), "speedup": round(min(tr) / min(tc), 2),
                "cli_reads_per_s": n_aln / min(tc), "reference_reads_per_s": n_aln / min(tr), "identical_record_stream": a == b, "record_bytes": b[1],
                "cli_stages": r2.stderr.decode().strip().splitlines()[-1], "output_bytes": {"cli": os.path.getsize(d + "/gpu_tagged.bam"), "reference": os.path.getsize(d + "/ref_tagged.bam")},
-               "note": "best of 2; both write every record as BGZF level 6; the CLI deflates with zlib strategy Z_RLE (packed bases/qualities have few LZ77 matches), "
-                       "the reference with the default strategy - see output_bytes"}
+               "note": "best of 2; both write every record; the CLI inflates, scores, re-tags and deflates on the GPU (per-4-KiB Huffman codes, no LZ77), "
+                       "the reference uses htslib/zlib level 6 on its thread pool - see output_bytes"}
     except Exception as e:  # noqa: BLE001
         tag = {"error": repr(e)[:300]}
     gz = None
