@@ -238,7 +238,7 @@ int lps_push_bam_records(lps_ctx *ctx, const uint8_t *records, int64_t n_bytes, 
 /* --- whole BAM file on the GPU (replaces htslib's BGZF layer behind sam_itr_multi_next, src/phase/ParsingBam.cpp:1279).
  * lps_bgzf_load: `bgzf` = the complete .bam file bytes (e.g. an mmap).  Block headers are walked on the host, every block is
  * inflated on the GPU (lps_inflate.hip), the inflated stream stays resident in the ctx until the next lps_bgzf_load / lps_destroy
- * (lps_begin_chromosome does not drop it).  Fails on a corrupt block or an ISIZE mismatch.  CRC32 fields are not checked.
+ * (lps_begin_chromosome does not drop it).  Fails on a corrupt block, an ISIZE mismatch or a CRC32 mismatch (checked on the GPU).
  * lps_bgzf_read: copy a piece of the inflated stream to the host (BAM header text and reference table). */
 int lps_bgzf_load(lps_ctx *ctx, const uint8_t *bgzf, int64_t n_bytes, int64_t *inflated_bytes);
 int lps_bgzf_read(lps_ctx *ctx, int64_t offset, int64_t n, uint8_t *dst);

@@ -401,6 +401,7 @@ int lps_bgzf_load(lps_ctx *c, const uint8_t *bgzf, int64_t n_bytes, int64_t *inf
         HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s));
         HIP_TRY(hipEventRecord(e1, s));
         launch_bgzf_inflate(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, s);
+        launch_bgzf_crc(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, s);
         HIP_TRY(hipMemsetAsync(c->file.p + utot, 0, 64, s));
         HIP_TRY(hipEventRecord(e2, s));
         unsigned err = 0;
@@ -409,7 +410,8 @@ int lps_bgzf_load(lps_ctx *c, const uint8_t *bgzf, int64_t n_bytes, int64_t *inf
         HIP_TRY(hipEventElapsedTime(&c->bgzf_h2d_ms, e0, e1)); HIP_TRY(hipEventElapsedTime(&c->bgzf_inflate_ms, e1, e2));
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
         c->file_bytes = 0; c->n_rec_all = 0; c->names_ready = false;
-        if (err) return fail(c, err & LPS_INF_ERR_DATA ? "lps_bgzf_load: corrupt deflate stream" : "lps_bgzf_load: a block does not inflate to its ISIZE");
+        if (err) return fail(c, err & LPS_INF_ERR_DATA ? "lps_bgzf_load: corrupt deflate stream" : err & (LPS_INF_ERR_SIZE | LPS_INF_ERR_OVERRUN) ? "lps_bgzf_load: a block does not inflate to its ISIZE"
+                                                                : "lps_bgzf_load: CRC32 mismatch in a BGZF block");
         c->file_bytes = utot;
         if (inflated_bytes) *inflated_bytes = (int64_t)utot;
     } catch (std::string &e) { return fail(c, e); }

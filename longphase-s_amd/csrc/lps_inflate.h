@@ -4,7 +4,7 @@
 
 #include <cstdint>
 
-enum { LPS_INF_ERR_DATA = 1, LPS_INF_ERR_OVERRUN = 2, LPS_INF_ERR_SIZE = 4 };
+enum { LPS_INF_ERR_DATA = 1, LPS_INF_ERR_OVERRUN = 2, LPS_INF_ERR_SIZE = 4, LPS_INF_ERR_CRC = 8 };
 
 struct InflateBlock {       // one BGZF block: raw deflate bytes [in_off, in_off+in_len) -> [out_off, out_off+out_len)
     uint64_t in_off, out_off;
@@ -12,3 +12,4 @@ struct InflateBlock {       // one BGZF block: raw deflate bytes [in_off, in_off
 };
 
 void launch_bgzf_inflate(const uint8_t *in, const InflateBlock *blk, int n_blk, uint8_t *out, unsigned *err, hipStream_t s);
+void launch_bgzf_crc(const uint8_t *in, const InflateBlock *blk, int n_blk, const uint8_t *out, unsigned *err, hipStream_t s);

@@ -35,8 +35,8 @@ __device__ __forceinline__ void refill(BitIn &b) {
     if (b.cnt <= 32) { b.buf |= (uint64_t)b.a0 << b.cnt; b.cnt += 32; b.shift = true; }
 }
 // header-path refill: may run many times inside one iteration, so it loads (and waits) on the spot; rare
-__device__ __forceinline__ void refill_now(BitIn &b) {
-    if (b.cnt <= 32) { b.buf |= (uint64_t)b.a0 << b.cnt; b.cnt += 32; b.a0 = b.a1; b.a1 = b.a2; ++b.w2; b.a2 = *b.w2; }
+__device__ __forceinline__ void refill_now(BitIn &b, const uint32_t *w_end) {
+    if (b.cnt <= 32) { b.buf |= (uint64_t)b.a0 << b.cnt; b.cnt += 32; b.a0 = b.a1; b.a1 = b.a2; if (b.w2 < w_end) ++b.w2; b.a2 = *b.w2; }
 }
 __device__ __forceinline__ uint32_t take(BitIn &b, int n) { const uint32_t v = (uint32_t)b.buf & ((1u << n) - 1u); b.buf >>= n; b.cnt -= n; return v; }
 __device__ __forceinline__ uint32_t peek15(const BitIn &b) { return __brev((uint32_t)b.buf) >> 17; }   // next 15 stream bits, first bit = MSB
@@ -147,7 +147,11 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
     // whose source words were REQUESTED at the end of the previous iteration, (3) every lane requests what it needs next: the following input dword
     // and, for a pending match, the next source words.  All loads of (3) are consumed only after phase (1) of the next iteration, so the one wait per
     // iteration finds them complete; the lockstep keeps a lane in a long match or a header from stalling the other 63 for more than its own branch.
+    // a valid stream never looks further than its own bytes (+ the 3 dwords fetched ahead); a crafted one (e.g. an endless run of empty
+    // blocks) must not walk off the buffer
+    const uint32_t *w_end = reinterpret_cast<const uint32_t *>(in) + ((B.in_off + B.in_len + 3) >> 2) + 4;
     while (state != ST_DONE) {
+        if (b.w2 > w_end) { e = LPS_INF_ERR_DATA; break; }
         const bool copying = mlen != 0;
         if (!copying) {
             if (state == ST_SYM) {
@@ -181,11 +185,11 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
                 if (slen == 0) { state = last ? ST_DONE : ST_HDR; }
                 else { refill(b); ring_at(op) = (uint8_t)take(b, 8); ++op; --slen; }
             } else {                                                       // ST_HDR: block header (+ Huffman tables)
-                refill_now(b);
+                refill_now(b, w_end);
                 last = take(b, 1); const uint32_t type = take(b, 2);
                 if (type == 0) {
-                    take(b, b.cnt & 7); refill_now(b);
-                    const uint32_t len = take(b, 16); refill_now(b); const uint32_t nlen = take(b, 16);
+                    take(b, b.cnt & 7); refill_now(b, w_end);
+                    const uint32_t len = take(b, 16); refill_now(b, w_end); const uint32_t nlen = take(b, 16);
                     if ((len ^ 0xffffu) != nlen || op + len > on) { e = LPS_INF_ERR_DATA; state = ST_DONE; }
                     else { slen = len; state = ST_STORED; }
                 } else if (type == 3) { e = LPS_INF_ERR_DATA; state = ST_DONE; }
@@ -202,14 +206,14 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
                         if (nlen > 286 || ndist > 30) bad = true;
                         for (int s = 0; s < 19; ++s) LENS(s) = 0;
                         for (int k = 0; k < ncode && !bad; ++k) {
-                            refill_now(b);
+                            refill_now(b, w_end);
                             const int pos = k < 3 ? 16 + k : k == 3 ? 0 : (k & 1) ? 8 - ((k - 3) >> 1) : 7 + ((k - 2) >> 1);   // 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
                             LENS(pos) = (uint8_t)take(b, 3);
                         }
                         if (!bad && !build_canon<1, uint8_t>(lens, 0, 19, s_dsym, s_dlim, s_dbase, t_cnt, t_offs, lane, nullptr)) bad = true;
                         int idx = 0;
                         while (!bad && idx < nlen + ndist) {
-                            refill_now(b);
+                            refill_now(b, w_end);
                             uint32_t si; const int l = decode_limit<1>(peek15(b), s_dlim, s_dbase, lane, si);
                             if (!l || l > 7 || si >= 19) { bad = true; break; }
                             const int sym = L(s_dsym, si); b.buf >>= l; b.cnt -= l;
@@ -265,6 +269,38 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
         while (fl < op) { const uint32_t before = fl; flush_segment(); if (fl == before) { for (uint32_t k = fl; k < op; ++k) o[k] = ring_at(k); fl = op; } }
         if (e) atomicOr(err, e);
     }
+}
+
+// CRC32 of every inflated block against the value stored in its gzip trailer (htslib verifies it on every read): wave per block, per-lane
+// slices combined as state_i * x^(8 * bytes after slice i) mod P.
+__device__ __forceinline__ uint32_t crc_multmodp(uint32_t a, uint32_t b) {
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) { if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; } m >>= 1; b = (b & 1) ? (b >> 1) ^ 0xedb88320u : b >> 1; }
+    return p;
+}
+__global__ void __launch_bounds__(256) k_bgzf_crc(const uint8_t *in, const InflateBlock *blk, int n_blk, const uint8_t *out, unsigned *err) {
+    __shared__ uint32_t tab[256], x2n[32];
+    for (int k = threadIdx.x; k < 256; k += 256) { uint32_t c = (uint32_t)k; for (int j = 0; j < 8; ++j) c = (c & 1) ? (c >> 1) ^ 0xedb88320u : c >> 1; tab[k] = c; }
+    if (threadIdx.x < 32) { uint32_t p = 1u << 30; for (int k = 0; k < (int)threadIdx.x; ++k) p = crc_multmodp(p, p); x2n[threadIdx.x] = p; }
+    __syncthreads();
+    const int bi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (bi >= n_blk) return;
+    const InflateBlock B = blk[bi]; const uint8_t *o = out + B.out_off; const uint32_t len = B.out_len;
+    const uint32_t per = (len + 63) / 64, s0 = min(len, per * lane), s1 = min(len, s0 + per);
+    uint32_t c = lane == 0 ? 0xffffffffu : 0u;
+    for (uint32_t k = s0; k < s1; ++k) c = tab[(c ^ o[k]) & 255u] ^ (c >> 8);
+    { uint32_t p = 1u << 31, n = len - s1; int k = 3; while (n) { if (n & 1) p = crc_multmodp(x2n[k & 31], p); n >>= 1; ++k; } c = crc_multmodp(p, c); }
+    for (int s = 32; s; s >>= 1) c ^= __shfl_xor(c, s);
+    c ^= 0xffffffffu;
+    if (lane == 0) {
+        const uint8_t *t = in + B.in_off + B.in_len;                     // trailer: CRC32, ISIZE
+        const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (want != c) atomicOr(err, LPS_INF_ERR_CRC);
+    }
+}
+
+void launch_bgzf_crc(const uint8_t *in, const InflateBlock *blk, int n_blk, const uint8_t *out, unsigned *err, hipStream_t s) {
+    if (n_blk > 0) hipLaunchKernelGGL(k_bgzf_crc, dim3((n_blk + 3) / 4), dim3(256), 0, s, in, blk, n_blk, out, err);
 }
 
 void launch_bgzf_inflate(const uint8_t *in, const InflateBlock *blk, int n_blk, uint8_t *out, unsigned *err, hipStream_t s) {

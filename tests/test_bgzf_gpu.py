@@ -164,3 +164,36 @@ def test_gpu_deflate_round_trips(size):
                 z2, _ = ctx.bgzf_deflate(1234, size - 2345)
                 assert gzip.decompress(z2) == data[1234:size - 1111]
                 assert ctx.bgzf_load(z) == len(data) and ctx.bgzf_read(0, len(data)).tobytes() == data
+
+
+def test_fuzzed_files_never_hang_or_pass_silently():
+    """random byte flips / garbage inside a valid BGZF file: the loader must return (error or - if the flip hit nothing checked - identical data),
+    never hang, crash or hand back bytes that differ from what zlib makes of the same file"""
+    rng = np.random.default_rng(77)
+    _, _, rec = util.bam_sections(_bam())
+    base = bgzf(bytes(rec[:400_000]), 0xff00, 6)
+    with hip.Context(0, abi.default_params()) as ctx:
+        n_err = 0
+        for trial in range(60):
+            z = bytearray(base)
+            kind = trial % 3
+            if kind == 0:                                           # a few random byte flips
+                for _ in range(int(rng.integers(1, 6))):
+                    z[int(rng.integers(0, len(z) - 28))] ^= int(rng.integers(1, 256))
+            elif kind == 1:                                         # a run of zeros / ones inside a block body
+                p = int(rng.integers(30, len(z) - 4000)); z[p:p + int(rng.integers(8, 2000))] = bytes([0x00 if trial % 2 else 0xff]) * 1
+            else:                                                   # endless-empty-block pattern: BFINAL=0 BTYPE=01 EOB repeated
+                p = int(rng.integers(30, len(z) - 6000)); z[p:p + 4000] = bytes([0x02, 0x08, 0x20, 0x80, 0x00]) * 800
+            try:
+                want = gzip.decompress(bytes(z))
+            except Exception:
+                want = None
+            try:
+                n = ctx.bgzf_load(bytes(z))
+                got = ctx.bgzf_read(0, n).tobytes()
+            except hip.LpsError:
+                n_err += 1
+                continue
+            assert want is not None and got == want, trial
+        assert n_err >= 40
+        assert ctx.bgzf_load(base) == 400_000                       # the context survived all of it
