@@ -38,6 +38,8 @@
 static const char *kVersion = "1.0.0-mi355x";
 
 [[noreturn]] static void die(const std::string &m) { std::cerr << m << "\n"; exit(1); }
+static const size_t kGpuInflateMinBytes = 256u << 20;
+static size_t file_bytes(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 ? (size_t)st.st_size : 0; }
 
 // ------------------------------------------------------------------------------------------------ the library, loaded at run time
 // liblps_hip.so (and with it the ROCm runtime) is dlopen'ed from a helper thread so that loading it and creating the GPU context
@@ -405,13 +407,13 @@ static const char *kUsage =
     "   -s, --snp-file=NAME   -b, --bam-file=NAME (repeatable)   -r, --reference=NAME   -o, --out-prefix=NAME (result)   -t, --threads=Num (1)\n"
     "   --ont | --pb   --indels   -q MAPQ(1)  -p baseQuality(12)  -e edgeWeight(0.1)  -a connectAdjacent(35)  -d distance(300000)\n"
     "   -1 edgeThreshold(0.7)  -L overlapThreshold(0.2)  -m readConfidence(0.65)  -n snpConfidence(0.75)  --gpu=ID (0)\n"
-    "   --host-inflate   inflate BGZF with zlib on the -t host threads instead of on the GPU (always used when several -b files are given)\n"
+    "   --host-inflate | --gpu-inflate   BGZF inflate with zlib on the -t host threads / on the GPU (default: GPU for one BAM of 256 MiB or more)\n"
     "   --no-index       ignore <bam>.bai: make the whole file resident on the GPU instead of one contig at a time\n"
     "   --gpus=N         deal the contigs onto N GPUs (devices --gpu, --gpu+1, ... modulo the number present); needs the .bai index\n";
 
 static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over; bool indels = false;
-    std::string snp, ref, prefix = "result"; std::vector<std::string> bams; int threads = 1, gpu = 0, n_gpus = 1; bool ont = false, pb = false, host_inflate = false, no_index = false;
+    std::string snp, ref, prefix = "result"; std::vector<std::string> bams; int threads = 1, gpu = 0, n_gpus = 1; bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -437,6 +439,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--gpus") n_gpus = std::max(1, std::stoi(val()));
         else if (a == "--host-inflate") host_inflate = true;
+        else if (a == "--gpu-inflate") gpu_inflate = true;
         else if (a == "--no-index") no_index = true;
         else if (a == "--help") { std::cout << kUsage; return 0; }
         else if (a == "--sv-file" || a == "--mod-file" || a == "--dot" || a == "--deepsomatic_output" || a == "--indelQuality") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
@@ -459,6 +462,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::map<std::string, std::string> seqs; read_fasta(ref, vars, seqs);
     const double t_text = now();
     // one BAM: BGZF inflate, record discovery and record decode all run on the GPU; several BAMs (or --host-inflate): zlib on `-t` host threads
+    if (!host_inflate && !gpu_inflate && bams.size() == 1) host_inflate = file_bytes(bams[0]) < kGpuInflateMinBytes;   // small file: zlib on the host overlaps the GPU start-up
     const bool gpu_input = bams.size() == 1 && !host_inflate;
     std::vector<BamFile> files(gpu_input ? 0 : bams.size());
     for (size_t b = 0; b < files.size(); ++b) files[b].load(bams[b], threads, want);
@@ -662,14 +666,14 @@ static const char *kTagUsage =
     "Usage: longphase_amd haplotag [OPTION] ... READSFILE\n"
     "   -s, --snp-file=NAME   -b, --bam-file=NAME   -r, --reference=NAME   -o, --out-prefix=NAME (result)   -t, --threads=Num (1)\n"
     "   --tagSupplementary   -q qualityThreshold(1)   -p percentageThreshold(0.6)   --gpu=ID (0)\n"
-    "   --host-inflate (zlib on the -t threads instead of the GPU inflate)   --no-index (ignore <bam>.bai, keep the whole file on the GPU)\n"
+    "   --host-inflate | --gpu-inflate (zlib on the -t threads / GPU inflate + GPU writer; default: GPU for a BAM of 256 MiB or more)   --no-index (ignore <bam>.bai, keep the whole file on the GPU)\n"
     "   --host-deflate (tag splice + zlib deflate on the -t threads instead of the GPU writer; implied by --host-inflate)\n"
     "   --compress-level=N (6)   --compress-strategy=rle|default|huffman (rle: packed bases and qualities hold few LZ77 matches; about 2 % larger\n"
     "                             output than zlib's default strategy at several times the speed; `default` = what htslib writes)\n";
 
 static int haplotag_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
-    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, level = 6, strategy = Z_RLE; bool host_inflate = false, no_index = false, host_deflate = false;
+    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, level = 6, strategy = Z_RLE; bool host_inflate = false, gpu_inflate = false, no_index = false, host_deflate = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kTagUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -685,6 +689,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         else if (a == "-p" || a == "--percentageThreshold") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.percentage_threshold = x; }); }
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--host-inflate") host_inflate = true;
+        else if (a == "--gpu-inflate") gpu_inflate = true;
         else if (a == "--no-index") no_index = true;
         else if (a == "--host-deflate") host_deflate = true;
         else if (a == "--compress-level") level = std::stoi(val());
@@ -710,6 +715,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     const double t_text = now();
     // default: BGZF inflate + record discovery on the GPU, the inflated stream is copied back once for the writer; --host-inflate: zlib on -t threads
     BamFile in; GpuBam gb; size_t in_cap = 0;
+    if (!host_inflate && !gpu_inflate) host_inflate = file_bytes(bam) < kGpuInflateMinBytes;   // small file: the host path overlaps the GPU start-up
     if (host_inflate) host_deflate = true;                             // the GPU writer works on the stream the GPU inflated
     const bool gpu_writer = !host_deflate;
     if (host_inflate) in.load(bam, threads, want);

@@ -33,7 +33,7 @@ def test_cli_haplotag_output_bam_matches_reference(name, inflate, tmp_path):
     util.write_table_vcf(d + "/table.vcf", V, "chrS", kw["contig_len"])
     util.write_bam(d + "/reads.sam", d + "/reads.bam", block=20000)
     s.close()
-    r = subprocess.run([CLI, "haplotag", "-s", "table.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", "4", "-o", "tagged"] + tag_cli + (["--host-inflate"] if inflate == "host" else ["--host-deflate"] if inflate == "hostdeflate" else []),
+    r = subprocess.run([CLI, "haplotag", "-s", "table.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", "4", "-o", "tagged"] + tag_cli + (["--host-inflate"] if inflate == "host" else ["--gpu-inflate", "--host-deflate"] if inflate == "hostdeflate" else ["--gpu-inflate"]),
                        cwd=d, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     text, refs, recs = util.bam_sections(d + "/tagged.bam")

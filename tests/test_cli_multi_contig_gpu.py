@@ -27,7 +27,7 @@ def test_multi_contig_phase_then_haplotag(inflate, tmp_path):
     assert util.make_multi_contig(d, fixtures.MULTI_CONTIG_FIXTURE) == gold["digests"], "generator drift"
     util.add_stale_tags(d + "/multi.sam", d + "/tagged_in.sam")
     util.write_bam(d + "/tagged_in.sam", d + "/reads.bam", block=30000)
-    extra = ["--host-inflate"] if inflate == "host" else []
+    extra = ["--host-inflate"] if inflate == "host" else ["--gpu-inflate"]
     tag_extra = ["--host-deflate"] if inflate == "gpu_hostdeflate" else []
     if inflate.startswith("gpu_indexed"):
         util.write_bai(d + "/reads.bam")                              # only one contig's blocks are resident at a time

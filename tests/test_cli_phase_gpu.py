@@ -25,7 +25,7 @@ def test_cli_phase_matches_reference_vcf(name, inflate, tmp_path):
     assert os.path.exists(CLI), "build the CLI first: make -C longphase-s_amd cli"
     bam = str(tmp_path / (name + ".bam"))
     assert write_bam(os.path.join(DATA, name + ".sam.gz"), bam) > 0
-    flags = DATA_FIXTURES[name][1] + (["--host-inflate"] if inflate == "host" else [])
+    flags = DATA_FIXTURES[name][1] + (["--host-inflate"] if inflate == "host" else ["--gpu-inflate"])
     prefix = str(tmp_path / "out")
     r = subprocess.run([CLI, "phase", "-s", os.path.join(DATA, name + ".vcf"), "-b", bam, "-r", os.path.join(DATA, name + ".fa"),
                         "-o", prefix, "-t", "4"] + flags, capture_output=True, text=True, timeout=300)
