@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -54,6 +55,8 @@ struct Lps {
     decltype(&lps_bam_record_tids) bam_record_tids = nullptr; decltype(&lps_bam_names) bam_names = nullptr; decltype(&lps_push_bam_resident) push_bam_resident = nullptr;
     decltype(&lps_bam_record_offsets) bam_record_offsets = nullptr; decltype(&lps_bam_scan_range) bam_scan_range = nullptr; decltype(&lps_device_count) device_count = nullptr;
     decltype(&lps_haplotag_write_bgzf) haplotag_write_bgzf = nullptr; decltype(&lps_bgzf_deflate_fetch) bgzf_deflate_fetch = nullptr;
+    decltype(&lps_somatic_extract_normal) somatic_extract_normal = nullptr; decltype(&lps_somatic_extract_tumor) somatic_extract_tumor = nullptr;
+    decltype(&lps_somatic_tag_chromosome) somatic_tag_chromosome = nullptr;
     std::string error;
     bool load() {
         char exe[4096]; const ssize_t k = readlink("/proc/self/exe", exe, sizeof exe - 1);
@@ -68,6 +71,7 @@ struct Lps {
         LPS_SYM(push_bam_records, lps_push_bam_records) LPS_SYM(phase_chromosome, lps_phase_chromosome) LPS_SYM(haplotag_chromosome, lps_haplotag_chromosome)
         LPS_SYM(abi_version, lps_abi_version) LPS_SYM(bgzf_load, lps_bgzf_load) LPS_SYM(bgzf_read, lps_bgzf_read) LPS_SYM(bam_scan, lps_bam_scan)
         LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range) LPS_SYM(device_count, lps_device_count) LPS_SYM(haplotag_write_bgzf, lps_haplotag_write_bgzf) LPS_SYM(bgzf_deflate_fetch, lps_bgzf_deflate_fetch)
+        LPS_SYM(somatic_extract_normal, lps_somatic_extract_normal) LPS_SYM(somatic_extract_tumor, lps_somatic_extract_tumor) LPS_SYM(somatic_tag_chromosome, lps_somatic_tag_chromosome)
 #undef LPS_SYM
         if (abi_version() != LPS_ABI_VERSION) { error = "liblps_hip.so has a different ABI version than this binary was built for"; return false; }
         return true;
@@ -877,6 +881,313 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     _exit(0);
 }
 
+// ------------------------------------------------------------------------------------------------ somatic_haplotag
+// The three BAM passes run on the GPU (rows a20-a22 of SURVEY.md §8: lps_somatic_extract_normal / _tumor, lps_somatic_tag_chromosome); between them the
+// caller's per-site statistics are restated here: SomaticVarCaller::setFilterParamsWithPurity :951-1060, getDenseTumorSnpInterval :1243-1355,
+// somaticFeatureFilter :1062-1230, calibrateReadHP :1366-1404, calculateReadSetHP :1418-1439, statisticSomaticPosReadHP :1441-1518, getSomaticFlag :2397-2412
+// (src/somatic_haplotag/SomaticVarCaller.cpp).  The automatic purity estimator (TumorPurityEstimator.cpp) is not built: --tumor-purity is required.
+struct TumorRow { std::string ref, alt; int kind; };                    // kind: 1 SNP, 2 insertion, 3 deletion, 4 MNP (VarData::setVariantType)
+static void parse_tumor_vcf(const std::vector<std::string> &lines, std::vector<std::string> &chr_vec, std::map<std::string, int> &chr_len,
+                            std::map<std::string, std::map<int32_t, TumorRow>> &rows) {
+    for (const std::string &in : lines) {
+        if (in.compare(0, 2, "##") == 0) {
+            if (in.find("contig=") != std::string::npos) {
+                const size_t a = in.find("ID=") + 3, b = in.find(",length="), e = in.find(">");
+                if (b == std::string::npos) die("[ERROR] contig header line without length: " + in);
+                const std::string chr = in.substr(a, b - a); chr_vec.push_back(chr); chr_len[chr] = std::stoi(in.substr(b + 8, e - b - 8));
+            }
+            continue;
+        }
+        if (in.empty() || in[0] == '#') continue;
+        std::istringstream iss(in);
+        std::vector<std::string> f((std::istream_iterator<std::string>(iss)), std::istream_iterator<std::string>());
+        if (f.empty()) continue;
+        if (f.size() < 10) die("[ERROR](VcfParser::parserProcess) => VCF file format not supported: " + in);
+        const size_t kp = f[8].find("GT"); int colons = 0; for (size_t i = 0; i < kp && i < f[8].size(); ++i) if (f[8][i] == ':') ++colons;
+        int cur = 0; size_t g = 0; for (size_t i = 0; i < f[9].size(); ++i) { if (cur >= colons) break; if (f[9][i] == ':') ++cur; ++g; }
+        if (g + 2 >= f[9].size() + 1) continue;
+        const char a = f[9][g], m = f[9][g + 1], b = g + 2 < f[9].size() ? f[9][g + 2] : '\0';
+        if (a != b && m == '|') die("longphase_amd: phased records in the tumor VCF are not supported: " + in);   // HaplotagVcfParser.cpp:296-400 would need PS handling
+        if (!((a == '1' && m == '/' && b == '1') || (a == '0' && m == '/' && b == '1'))) continue;               // :470-520: 1/1 and 0/1 only
+        TumorRow r; r.ref = f[3]; r.alt = f[4].find(',') != std::string::npos ? f[4].substr(0, f[4].find(',')) : f[4];
+        if (r.ref.size() == 1 && r.alt.size() == 1) r.kind = 1; else if (r.ref.size() == 1 && r.alt.size() > 1) r.kind = 2; else if (r.ref.size() > 1 && r.alt.size() == 1) r.kind = 3;
+        else if (r.ref.size() > 1 && r.ref.size() == r.alt.size()) r.kind = 4; else die("(loadVariantType)Invalid allele: " + r.ref + " " + r.alt);
+        if ((r.kind == 2 || r.kind == 3) && std::abs((int)r.alt.size() - (int)r.ref.size()) > 100) continue;       // tumor INDELs longer than 100 bp are skipped
+        rows[f[0]][std::stoi(f[1]) - 1] = r;
+    }
+}
+
+struct SomaticThr { float norVAF_max; int norDepth_min; float messy; int readCount_min; float hap_VAF_max; int hap_readCount_max, hap_somaticRead_min; float ivl_VAF_max; int ivl_readCount_max, ivl_count_min; float z_max; const char *tier; };
+static SomaticThr somatic_thresholds(double purity) {                  // setFilterParamsWithPurity: the float members are assigned from double literals, the int locals truncate them
+    if (purity >= 0.9 && purity <= 1.0) return {0.13f, 1, 1.0f, 3, 0.144f, 12, 0, 0.189f, 12, 4, 5.233f, "1.0"};
+    if (purity >= 0.7 && purity < 0.9) return {0.13f, 1, 1.0f, 3, 0.130f, 10, 1, 0.133f, 10, 4, 2.676f, "0.8"};
+    if (purity >= 0.5 && purity < 0.7) return {0.105f, 1, 1.0f, 1, 0.071f, 10, 0, 0.105f, 10, 4, 5.683f, "0.6"};
+    if (purity >= 0.3 && purity < 0.5) return {0.117f, 1, 1.0f, 1, 0.035f, 8, 1, 0.049f, 8, 4, 3.043f, "0.4"};
+    return {0.130f, 1, 1.0f, 1, 0.020f, 8, 1, 0.025f, 8, 8, 1.953f, "0.2"};
+}
+static int judge_somatic_read_hap(int h1, int h2, int h3, int n_ps, double thr) {   // judgeSomaticReadHap (src/haplotag/HaplotagStrategy.cpp:452-602), hpCount[4] is always 0 here
+    double tMin, tMax, nMin, nMax; int maxN;
+    if (h3 > 0) { tMin = 0; tMax = h3; } else { tMin = h3; tMax = 0; }
+    if (h1 > h2) { nMin = h2; nMax = h1; maxN = 1; } else { nMin = h1; nMax = h2; maxN = 2; }
+    const double tumSim = (tMax == 0) ? 0.0 : tMax / (tMax + tMin), norSim = (nMax == 0) ? 0.0 : nMax / (nMax + nMin);
+    int hp = 0;
+    if (tMax != 0) { if (tumSim >= thr) hp = norSim >= thr ? (maxN == 1 ? 5 : 7) : 3; }
+    else if (nMax != 0) { if (norSim >= thr) hp = maxN; }
+    if (n_ps > 1) hp = 0;
+    return hp;
+}
+
+static const char *kSomUsage =
+    "Usage: longphase_amd somatic_haplotag [OPTION] ... READSFILE\n"
+    "   -s, --snp-file=NAME (phased normal VCF)   -b, --bam-file=NAME (normal BAM)   --tumor-snv-file=NAME   --tumor-bam-file=NAME   -r, --reference=NAME\n"
+    "   --tumor-purity=Num (REQUIRED: the automatic estimator is not built)   --disableFilter   --somatic-calling-log (writes <prefix>_somatic_filter.log)\n"
+    "   --tagSupplementary   -q qualityThreshold(1)   -p percentageThreshold(0.6)   -t threads(1)   -o out-prefix(result)   --gpu=ID (0)\n";
+
+static int somatic_main(int argc, char **argv, const std::string &command) {
+    std::vector<std::function<void(lps_params &)>> over;
+    std::string snp, ref, nbam, tvcf, tbam, prefix = "result"; int threads = 1, gpu = 0; double purity = -1, pct = 0.6; bool enable_filter = true, write_log = false;
+    auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kSomUsage; exit(1); } return argv[++i]; };
+    for (int i = 2; i < argc; ++i) {
+        std::string a = argv[i], v; size_t eq = a.find('=');
+        if (a.rfind("--", 0) == 0 && eq != std::string::npos) { v = a.substr(eq + 1); a = a.substr(0, eq); }
+        auto val = [&]() { return v.empty() ? need(i) : v; };
+        if (a == "-s" || a == "--snp-file") snp = val();
+        else if (a == "-b" || a == "--bam-file") nbam = val();
+        else if (a == "--tumor-snv-file") tvcf = val();
+        else if (a == "--tumor-bam-file") tbam = val();
+        else if (a == "-r" || a == "--reference") ref = val();
+        else if (a == "-o" || a == "--out-prefix") prefix = val();
+        else if (a == "-t" || a == "--threads") threads = std::stoi(val());
+        else if (a == "--tagSupplementary") over.push_back([](lps_params &P) { P.tag_supplementary = 1; });
+        else if (a == "-q" || a == "--qualityThreshold") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.mapping_quality = x; }); }
+        else if (a == "-p" || a == "--percentageThreshold") { pct = std::stod(val()); const double x = pct; over.push_back([x](lps_params &P) { P.percentage_threshold = x; }); }
+        else if (a == "--tumor-purity") purity = std::stod(val());
+        else if (a == "--disableFilter") enable_filter = false;
+        else if (a == "--somatic-calling-log") write_log = true;
+        else if (a == "--gpu") gpu = std::stoi(val());
+        else if (a == "--help") { std::cout << kSomUsage; return 0; }
+        else if (a == "--cram" || a == "--region" || a == "--log" || a == "--output-somatic-vcf" || a == "--truth-vcf" || a == "--truth-bed" || a == "--benchmark-log") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
+        else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kSomUsage; return 1; }
+    }
+    if (snp.empty() || nbam.empty() || tvcf.empty() || tbam.empty() || ref.empty()) { std::cerr << "longphase_amd somatic_haplotag: missing arguments\n" << kSomUsage; return 1; }
+    if (purity < 0) die("longphase_amd somatic_haplotag: --tumor-purity is required (automatic purity estimation is not part of the GPU path)");
+
+    Lps L; lps_ctx *ctx = nullptr;
+    std::thread gpu_init([&] { if (!L.load()) return; lps_params P; L.default_params(&P); for (auto &f : over) f(P); ctx = L.create(gpu, &P); if (!ctx) L.error = "cannot create a GPU context (no CPU fallback)"; });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{gpu_init};
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    std::vector<std::string> nlines, tlines;
+    if (!read_lines(snp, nlines)) die("Fail to open vcf: " + snp);
+    if (!read_lines(tvcf, tlines)) die("Fail to open vcf: " + tvcf);
+    std::vector<std::string> nchr, tchr; std::map<std::string, int> nlen, tlen; std::map<std::string, std::map<int32_t, PhasedRow>> nrows; std::map<std::string, std::map<int32_t, TumorRow>> trows;
+    parse_phased_vcf(nlines, nchr, nlen, nrows); parse_tumor_vcf(tlines, tchr, tlen, trows);
+    if (const char *dump = getenv("LPS_CLI_DUMP_TABLE")) {                // debugging aid: the parsed rows, before any GPU work
+        std::ofstream o(dump); for (auto &c : trows) for (auto &r : c.second) o << "T\t" << c.first << "\t" << r.first << "\t" << r.second.ref << "\t" << r.second.alt << "\t" << r.second.kind << "\n";
+        for (auto &c : nrows) for (auto &r : c.second) o << "N\t" << c.first << "\t" << r.first << "\t" << r.second.ref << "\t" << r.second.alt << "\t" << r.second.ps << "\t" << (int)r.second.hp1_is_alt << "\n";
+    }
+    for (auto &kv : tlen) { auto it = nlen.find(kv.first); if (it == nlen.end()) die("[ERROR] (setChrVecAndChrLength) :tumor & normal VCFs chromosome count are not the same"); if (it->second != kv.second) die("[ERROR] (setChrVecAndChrLength) :tumor & normal VCFs chromosome length are not the same => chr: " + kv.first); }
+    const std::vector<std::string> &chr_vec = tchr.empty() ? nchr : tchr;   // SomaticHaplotagProcess.cpp:161-174
+    if (chr_vec.empty()) die("[ERROR] (setChrVecAndChrLength) :tumor & normal VCFs chromosome count are empty");
+    std::map<std::string, ChrVariants> want_seq; std::map<std::string, int> want;
+    for (const std::string &c : chr_vec) { want[c] = 1; want_seq[c]; }
+    std::map<std::string, std::string> seqs; read_fasta(ref, want_seq, seqs);
+    BamFile nin, tin; nin.load(nbam, threads, want); tin.load(tbam, threads, want);
+    gpu_init.join();
+    if (!ctx) die("longphase_amd: " + L.error);
+    const double t_in = now();
+    const SomaticThr T = somatic_thresholds(purity);
+    if (purity <= 0 || purity > 1.0) std::cerr << "[WARNING] tumor purity is not in the range of 0.0 to 1.0: " << purity << "\n[WARNING] setting default parameters (tier " << T.tier << ")\n";
+    else std::cerr << "setting filter params (tier " << T.tier << ") with tumor purity: " << purity << "\n";
+    std::ofstream flog; if (write_log) { flog.open(prefix + "_somatic_filter.log"); if (!flog) die("Fail to open write file: " + prefix + "_somatic_filter.log");
+        flog << "######################################\n# Somatic Filter Evaluation Per-Pos   #\n######################################\n"
+             << "#CHROM\tPOS\tNorVAF\tNorDepth\tMixedHpReadRatio\tCaseReadCount\tTumVAF\tIntervalSnpCount\tzScore\tDenseAltSameCount\tFilteredByTINC\tFilteredByMessyRead\tFilteredByReadCount\tFilteredByHapConsistency\tFilteredByVariantCluster\tFilteredByDenseAlt\tisFilterOut\n"; }
+
+    BgzfWriter w; w.open(prefix + ".bam", threads, 6, Z_RLE);
+    {   // header of the TUMOR BAM + one @PG line
+        const uint8_t *d = tin.z.data; const uint32_t l_text = rd32(d + 4);
+        std::string text((const char *)d + 8, l_text); while (!text.empty() && text.back() == '\0') text.pop_back();
+        if (!text.empty() && text.back() != '\n') text += '\n';
+        std::string last_pg; for (size_t p = 0; p < text.size();) { const size_t e = text.find('\n', p); const std::string ln = text.substr(p, e - p);
+            if (ln.compare(0, 3, "@PG") == 0) { const size_t i = ln.find("\tID:"); if (i != std::string::npos) last_pg = ln.substr(i + 4, ln.find('\t', i + 4) - i - 4); } p = e == std::string::npos ? text.size() : e + 1; }
+        text += "@PG\tID:longphase_amd\tPN:longphase_amd" + (last_pg.empty() ? std::string() : "\tPP:" + last_pg) + "\tVN:" + kVersion + "\tCL:" + command + "\n";
+        std::vector<uint8_t> h; h.insert(h.end(), d, d + 4); const uint32_t lt = (uint32_t)text.size(); for (int k = 0; k < 4; ++k) h.push_back((uint8_t)(lt >> (8 * k)));
+        h.insert(h.end(), text.begin(), text.end());
+        size_t p = 8 + (size_t)l_text; const size_t ref_begin = p; const uint32_t n_ref = rd32(d + p); p += 4; for (uint32_t i = 0; i < n_ref; ++i) p += 4 + (size_t)rd32(d + p) + 4;
+        h.insert(h.end(), d + ref_begin, d + p);
+        w.append(h.data(), h.size());
+    }
+    auto fail = [&]() { die(std::string("longphase_amd: ") + L.last_error(ctx)); };
+    unsigned long long n_somatic_flag = 0, hp_hist[9] = {0}, st_count[8] = {0};
+    for (const std::string &chr : chr_vec) {
+        auto ti = tin.contigs.find(chr);
+        const bool have_t = ti != tin.contigs.end() && !ti->second.rec_off.empty();
+        // ---- merged table (MultiGenomeVar map): normal phased-het rows + tumor rows
+        std::map<int32_t, PhasedRow> none_n; std::map<int32_t, TumorRow> none_t;
+        const std::map<int32_t, PhasedRow> &nr = nrows.count(chr) ? nrows[chr] : none_n; const std::map<int32_t, TumorRow> &tr = trows.count(chr) ? trows[chr] : none_t;
+        std::vector<int32_t> pos, ps; std::vector<uint8_t> r0, a0, hpa, role, derive, tkind; std::vector<uint16_t> rl, al;
+        { auto a = nr.begin(); auto b = tr.begin();
+          while (a != nr.end() || b != tr.end()) {
+              const bool take_n = a != nr.end() && (b == tr.end() || a->first <= b->first), both = take_n && b != tr.end() && a->first == b->first;
+              if (take_n) { pos.push_back(a->first); r0.push_back((uint8_t)a->second.ref[0]); a0.push_back((uint8_t)a->second.alt[0]); rl.push_back((uint16_t)a->second.ref.size()); al.push_back((uint16_t)a->second.alt.size());
+                  hpa.push_back(a->second.hp1_is_alt); ps.push_back(a->second.ps); role.push_back(0); derive.push_back(0); tkind.push_back(both ? (uint8_t)b->second.kind : 0);
+                  if (both) { if (a->second.ref != b->second.ref || a->second.alt != b->second.alt) die("longphase_amd: normal and tumor VCF disagree on the alleles at " + chr + ":" + std::to_string(a->first + 1)); ++b; } ++a; }
+              else { pos.push_back(b->first); r0.push_back((uint8_t)b->second.ref[0]); a0.push_back((uint8_t)b->second.alt[0]); rl.push_back((uint16_t)b->second.ref.size()); al.push_back((uint16_t)b->second.alt.size());
+                  hpa.push_back(0); ps.push_back(0); role.push_back(2); derive.push_back(0); tkind.push_back((uint8_t)b->second.kind); ++b; }
+          } }
+        const size_t nv = pos.size();
+        if (!have_t) continue;
+        const ContigRecords &tc = ti->second; const size_t nt = tc.rec_off.size(); const uint8_t *tbase = tin.z.data + tc.lo;
+        std::vector<uint8_t> status(nt, 5), hp(nt, 0); std::vector<int32_t> psv(nt, -1), pq(nt, 0);
+        if (nv) {
+            if (!seqs.count(chr)) die("ERROR: contig " + chr + " is missing from the reference FASTA");
+            const std::string &sq = seqs[chr];
+            lps_variant_table vt{}; vt.n = (int64_t)nv; vt.pos = pos.data(); vt.ref0 = r0.data(); vt.alt0 = a0.data(); vt.ref_len = rl.data(); vt.alt_len = al.data(); vt.hp1_is_alt = hpa.data(); vt.phase_set = ps.data();
+            vt.somatic_role = role.data(); vt.derive_hp = derive.data(); vt.tumor_kind = tkind.data();
+            // ---- pass 1: normal BAM (ExtractNorDataBamParser)
+            std::vector<int32_t> nsite(nv * LPS_SITE_COUNTERS, 0);
+            auto ni = nin.contigs.find(chr);
+            if (ni != nin.contigs.end() && !ni->second.rec_off.empty()) {
+                const ContigRecords &nc = ni->second; std::vector<uint32_t> nid(nc.rec_off.size(), 0);
+                lps_site_counters sc{(int64_t)nv, nsite.data(), 0, nullptr};
+                if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) ||
+                    L.push_bam_records(ctx, nin.z.data + nc.lo, (int64_t)(nc.hi - nc.lo), nc.rec_off.data(), (int64_t)nc.rec_off.size(), nid.data()) || L.somatic_extract_normal(ctx, &sc)) fail();
+            }
+            // ---- pass 2: tumor BAM (ExtractTumDataBamParser)
+            std::vector<int32_t> tsite(nv * LPS_TSITE_COUNTERS, 0), h1(nt), h2(nt), h3(nt), psmin(nt), endp(nt), rlen(nt); std::vector<uint8_t> tstat(nt), thp(nt), tnps(nt), has(nt);
+            std::vector<int32_t> pr_site, pr_read, wn_site; std::vector<uint8_t> pr_hp, wn_al, wn_base; std::vector<int16_t> wn_off;
+            lps_tumor_extract_result te{}; te.n = (int64_t)nv; te.site = tsite.data(); te.n_reads = (int64_t)nt; te.status = tstat.data(); te.hp1 = h1.data(); te.hp2 = h2.data(); te.hp3 = h3.data(); te.hp = thp.data();
+            te.n_ps = tnps.data(); te.ps_min = psmin.data(); te.end_pos = endp.data(); te.read_len = rlen.data(); te.has_site = has.data();
+            { std::vector<uint32_t> tid(nt, 0);
+              if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) || L.push_bam_records(ctx, tbase, (int64_t)(tc.hi - tc.lo), tc.rec_off.data(), (int64_t)nt, tid.data())) fail(); }
+            size_t pcap = nt * 4 + 1024, wcap = nt * 64 + 4096;
+            for (int attempt = 0;; ++attempt) {
+                pr_site.resize(pcap); pr_read.resize(pcap); pr_hp.resize(pcap); wn_site.resize(wcap); wn_al.resize(wcap); wn_off.resize(wcap); wn_base.resize(wcap);
+                te.pair_capacity = (int64_t)pcap; te.pair_site = pr_site.data(); te.pair_read = pr_read.data(); te.pair_base_hp = pr_hp.data();
+                te.win_capacity = (int64_t)wcap; te.win_site = wn_site.data(); te.win_allele = wn_al.data(); te.win_offset = wn_off.data(); te.win_base = wn_base.data();
+                const int rc = L.somatic_extract_tumor(ctx, &te);
+                if (rc == 0) break;
+                if (rc != -9 || attempt > 2) fail();
+                pcap = (size_t)te.n_pairs + 16; wcap = (size_t)te.n_windows + 16;
+            }
+            // ---- host stages.  "exists": the site was touched by a tumor read (std::map entries of somaticPosInfo)
+            std::vector<int> sites; std::vector<int> site_of(nv, -1);
+            for (size_t v = 0; v < nv; ++v) { if (!tkind[v]) continue; const int32_t *c = &tsite[v * LPS_TSITE_COUNTERS]; long rh = 0; for (int k = 15; k < 24; ++k) rh += c[k]; if (c[6] > 0 || rh > 0) { site_of[v] = (int)sites.size(); sites.push_back((int)v); } }
+            const size_t ns = sites.size();
+            if (getenv("LPS_CLI_DEBUG")) { int byk[5] = {0}, tab[5] = {0}; for (size_t v = 0; v < nv; ++v) ++tab[tkind[v] < 5 ? tkind[v] : 0]; for (int v : sites) ++byk[tkind[(size_t)v]];
+                fprintf(stderr, "[debug] %s: table %zu rows (tumor kinds %d/%d/%d/%d), touched sites %zu (%d/%d/%d/%d), pairs %lld, windows %lld, tumor reads %zu\n", chr.c_str(), nv, tab[1], tab[2], tab[3], tab[4], ns, byk[1], byk[2], byk[3], byk[4], (long long)te.n_pairs, (long long)te.n_windows, nt); }
+            std::vector<std::vector<std::pair<int, int>>> pairs(ns);       // site -> (read, baseHP): tumorPosReadCorrBaseHP
+            for (int64_t k = 0; k < te.n_pairs; ++k) { const int sidx = site_of[(size_t)pr_site[(size_t)k]]; if (sidx < 0) die("[ERROR] pair at a site that does not exist"); pairs[(size_t)sidx].push_back({pr_read[(size_t)k], pr_hp[(size_t)k]}); }
+            std::vector<float> meanAlt(ns, 0.0f), zScore(ns, 0.0f), tumVAF(ns, 0.0f), norVAF(ns, 0.0f), mixedRatio(ns, 0.0f); std::vector<int> ivlCount(ns, 0), caseCount(ns, 0), norDepth(ns, 0), sameCount(ns, 0); std::vector<uint8_t> highCon(ns, 0), filt(ns, 0);
+            std::vector<int> hp3(h3.begin(), h3.end());
+            for (size_t i = 0; i < ns; ++i) {                                // getDenseTumorSnpInterval, first loop: mean HP3 count of the reads that carry the ALT here
+                if (pairs[i].empty()) continue;
+                float readCount = 0.0f, altMean = 0.0f;
+                for (auto &pr : pairs[i]) { if (pr.second != 3) continue; readCount++; if (!has[(size_t)pr.first]) die("[ERROR](getDenseTumorSnpInterval) => readID not found in readHpResultSet"); altMean += (float)hp3[(size_t)pr.first]; }
+                if (altMean != 0) altMean /= readCount;
+                meanAlt[i] = altMean;
+            }
+            {   // intervals of sites at most 5000 bp apart (INTERVAL_SNP_MAX_DISTANCE), z-score of meanAlt inside each
+                struct Ivl { std::map<int, double> mean, z; int count = 0; };
+                std::vector<Ivl> ivls; Ivl cur; bool rec = false; int startPos = 0;
+                auto close_ivl = [&]() { const double sz = (double)cur.mean.size(); double sum = 0; for (auto &m : cur.mean) sum += m.second; const double mean = sz == 0 ? 0.0 : sum / sz;
+                    double var = 0; for (auto &m : cur.mean) var += (m.second - mean) * (m.second - mean); const double sd = std::sqrt(var / cur.mean.size());
+                    for (auto &m : cur.mean) cur.z[m.first] = sd == 0 ? 0.0 : (m.second - mean) / sd; ivls.push_back(cur); };
+                for (size_t i = 0; i < ns; ++i) {
+                    if (i + 1 < ns) {
+                        const int curPos = pos[(size_t)sites[i]], nextPos = pos[(size_t)sites[i + 1]], dist = nextPos - curPos;
+                        if (dist <= 5000) { if (!rec) { rec = true; startPos = curPos; cur.mean[(int)i] = meanAlt[i]; cur.count++; } cur.mean[(int)(i + 1)] = meanAlt[i + 1]; cur.count++; }
+                        else if (rec) { close_ivl(); rec = false; startPos = 0; cur = Ivl(); }
+                    }
+                }
+                if (rec && ns && pos[(size_t)sites[ns - 1]] - startPos <= 5000) close_ivl();
+                for (const Ivl &iv : ivls) if (iv.count > 1) for (auto &z : iv.z) { zScore[(size_t)z.first] = (float)std::abs(z.second); ivlCount[(size_t)z.first] = iv.count; }
+            }
+            std::vector<std::map<int, int>> winRef(ns), winAlt(ns);          // offset -> count per allele (PosSomaticOffsetBase)
+            for (int64_t k = 0; k < te.n_windows; ++k) { const int sidx = site_of[(size_t)wn_site[(size_t)k]]; if (sidx < 0) continue; (wn_al[(size_t)k] ? winAlt : winRef)[(size_t)sidx][wn_off[(size_t)k]]++; }
+            for (size_t i = 0; i < ns; ++i) {                                // somaticFeatureFilter
+                const size_t v = (size_t)sites[i]; const int32_t *c = &tsite[v * LPS_TSITE_COUNTERS], *n = &nsite[v * LPS_SITE_COUNTERS]; const int kind = tkind[v];
+                if (kind == 4) continue;                                     // MNP rows never become high-confidence calls
+                auto base_count = [&](const int32_t *cc, uint8_t b) { return b == 'A' ? cc[1] : b == 'C' ? cc[2] : b == 'G' ? cc[3] : b == 'T' ? cc[4] : 0; };
+                auto vaf = [](int alt, int depth) { return (depth == 0 || alt == 0) ? 0.0f : (float)alt / (float)depth; };
+                const int tAlt = kind == 1 ? base_count(c, a0[v]) : c[0], nAlt = kind == 1 ? base_count(n, a0[v]) : n[0];
+                tumVAF[i] = vaf(tAlt, c[6]); norVAF[i] = vaf(nAlt, n[6]); norDepth[i] = n[6];
+                const int clean = c[25], messy = c[29]; caseCount[i] = clean + messy;
+                mixedRatio[i] = caseCount[i] != 0 ? (float)messy / ((float)clean + (float)messy) : 0.0f;
+                const bool f_tinc = !(norVAF[i] <= T.norVAF_max && (float)norDepth[i] > (float)T.norDepth_min);
+                const bool f_messy = mixedRatio[i] >= T.messy, f_count = caseCount[i] <= T.readCount_min;
+                bool f_hap = false; if (caseCount[i] <= T.hap_readCount_max && tumVAF[i] <= T.hap_VAF_max) { if (c[35] > T.hap_somaticRead_min && c[37] > T.hap_somaticRead_min) f_hap = true; }
+                bool f_z = false; if (caseCount[i] <= T.ivl_readCount_max && tumVAF[i] <= T.ivl_VAF_max) { if (ivlCount[i] > T.ivl_count_min && zScore[i] <= T.z_max && zScore[i] >= 0.0f) f_z = true; }
+                int same = 0; { const float c1 = 0.5f, c2 = 0.6f; const int target = c[0];                                  // DenseAlt: base.altCount
+                    for (auto &ao : winAlt[i]) { const auto ro = winRef[i].find(ao.first); const int ra = ro == winRef[i].end() ? 0 : ro->second, aa = ao.second;
+                        const double k1 = (double)aa / target, k2 = (double)aa / (ra + aa); if (k1 >= c1 && k2 >= c2) { if (++same == 3) break; } } }
+                sameCount[i] = same; const bool f_dense = same >= 3;
+                filt[i] = f_tinc || f_messy || f_count || f_hap || f_z || f_dense;
+                if (write_log) flog << chr << "\t" << pos[v] + 1 << "\t" << norVAF[i] << "\t" << norDepth[i] << "\t" << mixedRatio[i] << "\t" << caseCount[i] << "\t" << tumVAF[i] << "\t" << ivlCount[i] << "\t"
+                                    << zScore[i] << "\t" << sameCount[i] << "\t" << f_tinc << "\t" << f_messy << "\t" << f_count << "\t" << f_hap << "\t" << f_z << "\t" << f_dense << "\t" << (int)filt[i] << "\n";
+                if (!(enable_filter && filt[i])) highCon[i] = 1;
+            }
+            for (size_t i = 0; i < ns; ++i) {                                // calibrateReadHP: reads lose the H3 votes of rejected sites
+                if (highCon[i]) continue;
+                if (pairs[i].empty()) die("[ERROR](calibrate read HP) => can't find pos in tumorPosReadCorrBaseHP : chr: " + chr + " pos: " + std::to_string(pos[(size_t)sites[i]] + 1));
+                for (auto &pr : pairs[i]) if (pr.second == 3) { if (--hp3[(size_t)pr.first] < 0) die("[ERROR](calibrate read HP) => read HP3 or HP4 SNP count < 0 :"); }
+            }
+            std::vector<uint8_t> setHp(nt, 0);                               // calculateReadSetHP
+            for (size_t r = 0; r < nt; ++r) if (has[r]) setHp[r] = (uint8_t)judge_somatic_read_hap(h1[r], h2[r], hp3[r], tnps[r], pct);
+            for (size_t i = 0; i < ns; ++i) {                                // statisticSomaticPosReadHP + getSomaticFlag
+                if (!highCon[i]) continue;
+                if (pairs[i].empty()) die("[ERROR](statistic all read HP) => can't find pos in tumorPosReadCorrBaseHP : chr: " + chr + " pos: " + std::to_string(pos[(size_t)sites[i]] + 1));
+                int d1 = 0, d2 = 0; for (auto &pr : pairs[i]) if (pr.second == 3) { if (setHp[(size_t)pr.first] == 5) ++d1; else if (setHp[(size_t)pr.first] == 7) ++d2; }
+                const int tot = d1 + d2; float r1 = 0.0f, r2 = 0.0f; if (tot > 0) { if (d1 > 0) r1 = (float)d1 / (float)tot; if (d2 > 0) r2 = (float)d2 / (float)tot; }
+                const size_t v = (size_t)sites[i]; ++n_somatic_flag;
+                if (role[v] != 0) { role[v] = 1; derive[v] = r1 >= 1.0f ? 1 : r2 >= 1.0f ? 2 : 0; }   // a position that also has a normal row keeps its germline role in the tagging pass
+            }
+            // ---- pass 3: tagging (SomaticHaplotagChrProcessor::judgeHaplotype); the tumor reads are still resident
+            std::vector<int32_t> g1(nt), g2(nt), g3(nt), dh1(nt), dh2(nt), gmin(nt); std::vector<uint8_t> gnps(nt);
+            lps_somatic_tag_result tg{(int64_t)nt, status.data(), g1.data(), g2.data(), g3.data(), dh1.data(), dh2.data(), gnps.data(), gmin.data(), hp.data(), pq.data(), psv.data()};
+            if (L.set_variants(ctx, &vt) || L.somatic_tag_chromosome(ctx, &tg)) fail();
+        }
+        // ---- writer: HP:Z / PS:i (when the read saw a normal phase set) / PQ:i  (SomaticHaplotagProcess.cpp:529-536), records in input order
+        std::vector<uint64_t> out_off(nt + 1, 0);
+        auto aux_of = [&](const uint8_t *r) { const uint32_t l_name = r[8], n_cig = r[12] | (r[13] << 8), l_seq = rd32(r + 16); return r + 32 + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq; };
+        static const char *hp_str[9] = {".", "1", "2", "3", "4", "1-1", "1-2", "2-1", "2-2"};
+        auto tag_bytes = [&](size_t i) -> size_t { if (status[i] != 0 || !hp[i]) return 0; return 3 + strlen(hp_str[hp[i] < 9 ? hp[i] : 0]) + 1 + (psv[i] != -1 ? 7 : 0) + 7; };
+        for (size_t i = 0; i < nt; ++i) {
+            const uint8_t *r = tbase + tc.rec_off[i]; const uint32_t bs = rd32(r - 4); uint64_t len = 4ull + bs;
+            if (status[i] == 0) { bool seen[3] = {false, false, false};
+                for (const uint8_t *p = aux_of(r), *end = r + bs; p < end;) { const size_t l = aux_field_len(p, end); if (!l) die("ERROR: malformed auxiliary field in " + tbam);
+                    const int which = (p[0] == 'H' && p[1] == 'P') ? 0 : (p[0] == 'P' && p[1] == 'S') ? 1 : (p[0] == 'P' && p[1] == 'Q') ? 2 : -1; if (which >= 0 && !seen[which]) { seen[which] = true; len -= l; } p += l; }
+                len += tag_bytes(i); }
+            out_off[i + 1] = out_off[i] + len; ++st_count[status[i] & 7]; if (status[i] == 0) ++hp_hist[hp[i] < 9 ? hp[i] : 0];
+        }
+        std::vector<uint8_t> ob(out_off[nt] + 64);
+        for (size_t i = 0; i < nt; ++i) {
+            const uint8_t *r = tbase + tc.rec_off[i]; const uint32_t bs = rd32(r - 4); uint8_t *o = ob.data() + out_off[i];
+            if (status[i] != 0) { memcpy(o, r - 4, 4 + (size_t)bs); continue; }
+            const uint8_t *aux = aux_of(r), *end = r + bs; uint8_t *q = o + 4; memcpy(q, r, (size_t)(aux - r)); q += aux - r; bool seen[3] = {false, false, false};
+            for (const uint8_t *p = aux; p < end;) { const size_t l = aux_field_len(p, end); const int which = (p[0] == 'H' && p[1] == 'P') ? 0 : (p[0] == 'P' && p[1] == 'S') ? 1 : (p[0] == 'P' && p[1] == 'Q') ? 2 : -1;
+                if (which >= 0 && !seen[which]) seen[which] = true; else { memcpy(q, p, l); q += l; } p += l; }
+            if (hp[i]) { const char *hs = hp_str[hp[i] < 9 ? hp[i] : 0]; *q++ = 'H'; *q++ = 'P'; *q++ = 'Z'; const size_t hl = strlen(hs) + 1; memcpy(q, hs, hl); q += hl;
+                auto put_i = [&](char a, char b, int32_t v) { *q++ = (uint8_t)a; *q++ = (uint8_t)b; *q++ = 'i'; for (int k = 0; k < 4; ++k) *q++ = (uint8_t)((uint32_t)v >> (8 * k)); };
+                if (psv[i] != -1) put_i('P', 'S', psv[i]); put_i('P', 'Q', pq[i]); }
+            const uint32_t nbs = (uint32_t)(q - o) - 4; for (int k = 0; k < 4; ++k) o[k] = (uint8_t)(nbs >> (8 * k));
+        }
+        w.append(ob.data(), out_off[nt]);
+        std::cerr << "(" << chr << ")";
+    }
+    std::cerr << "\n";
+    w.finish();
+    if (write_log) flog.close();                                       // the process leaves through _exit: nothing is flushed implicitly
+    L.destroy(ctx);
+    unsigned long long total = 0; for (int k = 0; k < 8; ++k) total += st_count[k];
+    fprintf(stderr, "somatic variant count(Flag): %llu\n", n_somatic_flag);
+    fprintf(stderr, "total alignment %llu | HP1 %llu HP2 %llu HP1-1 %llu HP2-1 %llu HP3 %llu | judged untagged %llu | low mapq %llu unmapped %llu secondary %llu supplementary %llu no variant %llu beyond last variant %llu\n",
+            total, hp_hist[1], hp_hist[2], hp_hist[5], hp_hist[7], hp_hist[3], hp_hist[0], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6]);
+    fprintf(stderr, "inputs %.3fs | passes + caller + writer %.3fs | total %.3fs\n", t_in - t_begin, now() - t_in, now() - t_begin);
+    fflush(stderr);
+    _exit(0);
+}
+
 // `longphase_amd view BAM CONTIG` — decoded records as SAM columns 1-11 (CPU-only check of the BGZF reader and the record walk)
 static int view_main(int argc, char **argv) {
     if (argc < 4) die("Usage: longphase_amd view <in.bam> <contig> [threads]");
@@ -903,11 +1214,11 @@ static int view_main(int argc, char **argv) {
 
 int main(int argc, char **argv) {
     std::string command; for (int i = 0; i < argc; ++i) { if (i) command += " "; command += argv[i]; }
-    if (argc < 2) { std::cout << "Version: " << kVersion << "\nUsage: longphase_amd <command> [options]\n    phase    run phasing algorithm on the GPU.\n    haplotag tag reads by haplotype on the GPU.\n"; return 0; }
+    if (argc < 2) { std::cout << "Version: " << kVersion << "\nUsage: longphase_amd <command> [options]\n    phase    run phasing algorithm on the GPU.\n    haplotag tag reads by haplotype on the GPU.\n    somatic_haplotag tag tumor reads (somatic + germline haplotypes) on the GPU; needs --tumor-purity.\n"; return 0; }
     const std::string cmd = argv[1];
     if (cmd == "phase") return phase_main(argc, argv, command);
     if (cmd == "view") return view_main(argc, argv);
     if (cmd == "haplotag") return haplotag_main(argc, argv, command);
-    if (cmd == "somatic_haplotag") die("longphase_amd: the somatic_haplotag passes are available through the C-ABI (include/lps_abi.h); its host stages are not part of the CLI yet");
+    if (cmd == "somatic_haplotag") return somatic_main(argc, argv, command);
     std::cerr << "Unrecognized command: " << cmd << "\n"; return 1;
 }

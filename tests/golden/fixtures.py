@@ -61,6 +61,11 @@ SOMATIC_FIXTURES = {
                     dict(coverage=25.0, read_seed=331, tumor_purity=0.0), dict(coverage=45.0, read_seed=332, tumor_purity=0.9, supp_frac=0.2), ["-p", "0.7"], dict(percentage_threshold=0.7)),
 }
 
+# end-to-end fixtures of the somatic_haplotag CLI: name -> (tumor/normal fixture (or its own spec), --tumor-purity, extra CLI flags)
+SOMATIC_FIXTURES["tn_dense"] = (dict(TN_BASE, seed=34, somatic_every=1200.0), dict(coverage=25.0, read_seed=341, tumor_purity=0.0), dict(coverage=50.0, read_seed=342, tumor_purity=0.8), [], {})
+CLI_SOMATIC_FIXTURES = {"tn60_p06": ("tn60", "0.6", []), "tn30_indel_p03": ("tn30_indel", "0.3", []), "tn90_blocks_p095": ("tn90_blocks", "0.95", []),
+                        "tn_dense_p08": ("tn_dense", "0.8", []), "tn_dense_p015": ("tn_dense", "0.15", []), "tn60_nofilter": ("tn60", "0.6", ["--disableFilter"])}
+
 # fixtures whose full inputs (FASTA/VCF/SAM) are committed as data files under tests/golden/data/
 TINY = dict(contig_len=60_000, n_snp=120, coverage=12.0, n_threads=2)
 DATA_FIXTURES = {

@@ -241,6 +241,43 @@ def make_cli_haplotag(name):
     print("cli_haplotag", name, out["n_records"], out["records_sha256"][:16])
 
 
+def make_cli_somatic(key):
+    """reference `phase` on the normal sample (its VCF is committed) + `somatic_haplotag --tumor-purity P`: tagged tumor BAM digest/tags + the per-site filter log"""
+    import hashlib
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import util
+    name, purity, extra = fixtures.CLI_SOMATIC_FIXTURES[key]
+    _, _, _, tag_cli, _ = fixtures.SOMATIC_FIXTURES[name]
+    with tempfile.TemporaryDirectory() as d:
+        digests, indel = util.make_somatic_inputs(d, name)
+        for smp in ("normal", "tumor"):
+            subprocess.check_call([TEST_VIEW, "-b", "-x", smp + ".bam.bai", "-p", smp + ".bam", smp + ".sam"], cwd=d, stdout=subprocess.DEVNULL)
+        r = subprocess.run([REF_BIN, "phase", "-s", "normal_in.vcf", "-b", "normal.bam", "-r", "ref.fa", "-t", "1", "-o", "normal_phased", "--ont"] + (["--indels"] if indel else []),
+                           cwd=d, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1000:]
+        cmd = [REF_BIN, "somatic_haplotag", "-s", "normal_phased.vcf", "-b", "normal.bam", "--tumor-snv-file", "tumor.vcf", "--tumor-bam-file", "tumor.bam", "-r", "ref.fa", "-t", "1",
+               "-o", "som", "--somatic-calling-log", "--tumor-purity", purity] + tag_cli + extra
+        r = subprocess.run(cmd, cwd=d, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"reference somatic_haplotag failed rc={r.returncode}: {r.stderr[-2000:]}")
+        flag_count = int([l for l in r.stderr.splitlines() if l.startswith("somatic variant count(Flag)")][0].split(":")[1])
+        text, refs, recs = util.bam_sections(d + "/som.bam")
+        tags = util.bam_record_tags(recs)
+        filter_log = open(d + "/som_somatic_filter.log").read()
+        shutil.copy(d + "/normal_phased.vcf", os.path.join(HERE, "data", f"somatic_{name}.normal_phased.vcf"))
+    out = dict(digests=list(digests), records_sha256=hashlib.sha256(recs).hexdigest(), n_records=len(tags), record_bytes=len(recs), flag_count=flag_count,
+               header_without_pg=[l for l in text.split("\n") if l and not l.startswith("@PG")], tags=[[q, f, p, [list(t) for t in tg]] for q, f, p, tg in tags],
+               filter_log=filter_log, cli=tag_cli + extra, purity=purity)
+    with open(os.path.join(HERE, f"cli_somatic_{key}.json"), "w") as f:
+        json.dump(out, f)
+    hist = {}
+    for t in tags:
+        for k, v in t[3]:
+            if k == "HP":
+                hist[v] = hist.get(v, 0) + 1
+    print("cli_somatic", key, out["n_records"], "flags", flag_count, "filtered", sum(1 for l in filter_log.splitlines() if l.endswith("\t1")), hist)
+
+
 def make_multi_contig_golden():
     """reference `phase --indels` and `haplotag` on the multi-contig files -> phased VCF (committed as is) + tagged-BAM digest/tags"""
     import hashlib
@@ -267,8 +304,14 @@ def make_multi_contig_golden():
 
 def main():
     assert os.path.exists(REF_BIN), "build the reference first: oracle/build_ref.sh"
+    if "--cli-somatic" in sys.argv:
+        for key in fixtures.CLI_SOMATIC_FIXTURES:
+            make_cli_somatic(key)
+        return
     if "--multi-contig" in sys.argv:
         make_multi_contig_golden()
+    for key in fixtures.CLI_SOMATIC_FIXTURES:
+        make_cli_somatic(key)
         return
     if "--cli-haplotag" in sys.argv:            # only the CLI end-to-end vectors (the others are untouched)
         for name in fixtures.CLI_HAPLOTAG_FIXTURES:
@@ -323,6 +366,8 @@ def main():
     for name in fixtures.CLI_HAPLOTAG_FIXTURES:
         make_cli_haplotag(name)
     make_multi_contig_golden()
+    for key in fixtures.CLI_SOMATIC_FIXTURES:
+        make_cli_somatic(key)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,50 @@
+"""End-to-end check of `longphase_amd somatic_haplotag --tumor-purity P` (reduced to an explicit purity): the three BAM
+passes run on the GPU (rows a20-a22), the caller's per-site statistics and filters are restated on the host.  Against the reference binary on the
+same files: the per-site filter log (every intermediate value and all six filter decisions) must be identical text, the number of flagged somatic
+variants equal, and the inflated record stream of the tagged tumor BAM (HP:Z / PS:i / PQ:i) byte-identical."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+import fixtures
+import util
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CLI = os.path.join(HERE, "..", "longphase-s_amd", "cli", "longphase_amd")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("key", sorted(fixtures.CLI_SOMATIC_FIXTURES))
+def test_cli_somatic_matches_reference(key, tmp_path):
+    gold = json.load(open(os.path.join(HERE, "golden", f"cli_somatic_{key}.json")))
+    name, purity, extra = fixtures.CLI_SOMATIC_FIXTURES[key]
+    d = str(tmp_path)
+    digests, _ = util.make_somatic_inputs(d, name)
+    assert list(digests) == gold["digests"], "generator drift"
+    util.write_bam(d + "/normal.sam", d + "/normal.bam"); util.write_bam(d + "/tumor.sam", d + "/tumor.bam", block=40000)
+    phased = os.path.join(HERE, "golden", "data", f"somatic_{name}.normal_phased.vcf")
+    r = subprocess.run([CLI, "somatic_haplotag", "-s", phased, "-b", "normal.bam", "--tumor-snv-file", "tumor.vcf", "--tumor-bam-file", "tumor.bam", "-r", "ref.fa", "-t", "4",
+                        "-o", "som", "--somatic-calling-log", "--tumor-purity", purity] + gold["cli"], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, LPS_CLI_DEBUG="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    print(r.stderr[-700:])
+    got_log = open(d + "/som_somatic_filter.log").read().splitlines(); want_log = gold["filter_log"].splitlines()
+    assert len(got_log) == len(want_log)
+    for g, w in zip(got_log, want_log):
+        assert g == w
+    assert int([l for l in r.stderr.splitlines() if l.startswith("somatic variant count(Flag)")][0].split(":")[1]) == gold["flag_count"]
+    text, refs, recs = util.bam_sections(d + "/som.bam")
+    assert [l for l in text.split("\n") if l and not l.startswith("@PG")] == gold["header_without_pg"]
+    got = util.bam_record_tags(recs)
+    want = [(q, f, p, [tuple(t) for t in tg]) for q, f, p, tg in gold["tags"]]
+    assert len(got) == gold["n_records"]
+    for g, w in zip(got, want):
+        assert g == w
+    assert hashlib.sha256(recs).hexdigest() == gold["records_sha256"]
+
+
+def test_cli_somatic_requires_purity(tmp_path):
+    r = subprocess.run([CLI, "somatic_haplotag", "-s", "a.vcf", "-b", "a.bam", "--tumor-snv-file", "t.vcf", "--tumor-bam-file", "t.bam", "-r", "r.fa"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "--tumor-purity is required" in r.stderr

@@ -280,13 +280,16 @@ def bam_record_tags(records):
         while a < len(r):
             tag, t = r[a:a + 2].decode(), chr(r[a + 2]); a += 3
             if t in "ZH":
-                e = r.index(b"\0", a); a = e + 1
+                a0 = a; e = r.index(b"\0", a); a = e + 1
             elif t == "B":
                 sub = chr(r[a]); cnt = struct.unpack_from("<i", r, a + 1)[0]; a += 5 + cnt * size[sub]
             else:
                 if t in fmt and tag in ("HP", "PS", "PQ"):
                     tags.append((tag, struct.unpack_from(fmt[t], r, a)[0]))
                 a += size[t]
+                continue
+            if t == "Z" and tag == "HP":
+                tags.append((tag, r[a0:a - 1].decode()))
         out.append((r[32:32 + l_name - 1].decode(), flag, pos, tags))
     return out
 
@@ -385,3 +388,15 @@ def write_bai(bam_path, bai_path=None):
         else:
             out += struct.pack("<ii", 0, 0)
     open(bai_path or bam_path + ".bai", "wb").write(bytes(out))
+
+
+def make_somatic_inputs(d, name, chrom="chrS"):
+    """files of a tumor/normal fixture: ref.fa, normal_in.vcf, normal.sam, tumor.sam, tumor.vcf -> (normal digest, tumor digest)"""
+    genome, nkw, tkw, cli, over = fixtures.SOMATIC_FIXTURES[name]
+    N = Synth(**dict(genome, **nkw)); T = Synth(**dict(genome, **tkw))
+    N.write_fasta(os.path.join(d, "ref.fa"), chrom); N.write_vcf(os.path.join(d, "normal_in.vcf"), chrom); N.write_sam(os.path.join(d, "normal.sam"), chrom)
+    T.write_sam(os.path.join(d, "tumor_plain.sam"), chrom); T.write_vcf_tumor(os.path.join(d, "tumor.vcf"), chrom, with_germline=True)
+    add_stale_tags(os.path.join(d, "tumor_plain.sam"), os.path.join(d, "tumor.sam"))
+    dg = (fixtures.input_digest(N), fixtures.input_digest(T)); indel = N.params["indel_var_frac"] > 0
+    N.close(); T.close()
+    return dg, indel
