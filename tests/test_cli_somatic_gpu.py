@@ -1,5 +1,5 @@
-"""End-to-end check of `longphase_amd somatic_haplotag --tumor-purity P` (reduced to an explicit purity): the three BAM
-passes run on the GPU (rows a20-a22), the caller's per-site statistics and filters are restated on the host.  Against the reference binary on the
+"""End-to-end check of `longphase_amd somatic_haplotag`, with an explicit --tumor-purity and with the automatic estimator: the three
+BAM passes run on the GPU (rows a20-a22), the caller's per-site statistics, filters and the purity estimator are restated on the host.  Against the reference binary on the
 same files: the per-site filter log (every intermediate value and all six filter decisions) must be identical text, the number of flagged somatic
 variants equal, and the inflated record stream of the tagged tumor BAM (HP:Z / PS:i / PQ:i) byte-identical."""
 import hashlib
@@ -27,9 +27,11 @@ def test_cli_somatic_matches_reference(key, tmp_path):
     util.write_bam(d + "/normal.sam", d + "/normal.bam"); util.write_bam(d + "/tumor.sam", d + "/tumor.bam", block=40000)
     phased = os.path.join(HERE, "golden", "data", f"somatic_{name}.normal_phased.vcf")
     r = subprocess.run([CLI, "somatic_haplotag", "-s", phased, "-b", "normal.bam", "--tumor-snv-file", "tumor.vcf", "--tumor-bam-file", "tumor.bam", "-r", "ref.fa", "-t", "4",
-                        "-o", "som", "--somatic-calling-log", "--tumor-purity", purity] + gold["cli"], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, LPS_CLI_DEBUG="1"))
+                        "-o", "som", "--somatic-calling-log"] + (["--tumor-purity", purity] if purity != "auto" else []) + gold["cli"], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, LPS_CLI_DEBUG="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     print(r.stderr[-700:])
+    if purity == "auto":                                              # the estimator's report: every count, the box-plot statistics and the purity itself
+        assert open(d + "/som_purity.out").read() == gold["purity_out"]
     got_log = open(d + "/som_somatic_filter.log").read().splitlines(); want_log = gold["filter_log"].splitlines()
     assert len(got_log) == len(want_log)
     for g, w in zip(got_log, want_log):
@@ -45,6 +47,8 @@ def test_cli_somatic_matches_reference(key, tmp_path):
     assert hashlib.sha256(recs).hexdigest() == gold["records_sha256"]
 
 
-def test_cli_somatic_requires_purity(tmp_path):
-    r = subprocess.run([CLI, "somatic_haplotag", "-s", "a.vcf", "-b", "a.bam", "--tumor-snv-file", "t.vcf", "--tumor-bam-file", "t.bam", "-r", "r.fa"], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 1 and "--tumor-purity is required" in r.stderr
+def test_cli_somatic_argument_errors(tmp_path):
+    r = subprocess.run([CLI, "somatic_haplotag", "-s", "a.vcf", "-b", "a.bam", "--tumor-snv-file", "t.vcf"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "missing arguments" in r.stderr
+    r = subprocess.run([CLI, "somatic_haplotag", "-s", "a.vcf", "-b", "a.bam", "--tumor-snv-file", "t.vcf", "--tumor-bam-file", "t.bam", "-r", "r.fa", "--cram"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "not supported" in r.stderr
