@@ -62,7 +62,9 @@ SOMATIC_FIXTURES = {
 }
 
 # end-to-end fixtures of the somatic_haplotag CLI: name -> (tumor/normal fixture (or its own spec), --tumor-purity, extra CLI flags)
-SOMATIC_FIXTURES["tn_dense"] = (dict(TN_BASE, seed=34, somatic_every=1200.0), dict(coverage=25.0, read_seed=341, tumor_purity=0.0), dict(coverage=50.0, read_seed=342, tumor_purity=0.8), [], {})
+SOMATIC_CLI_ONLY = {}
+SOMATIC_CLI_ONLY["tn_dense"] = (dict(TN_BASE, seed=34, somatic_every=1200.0), dict(coverage=25.0, read_seed=341, tumor_purity=0.0), dict(coverage=50.0, read_seed=342, tumor_purity=0.8), [], {})
+ALL_SOMATIC = dict(SOMATIC_FIXTURES, **SOMATIC_CLI_ONLY)
 CLI_SOMATIC_FIXTURES = {"tn60_p06": ("tn60", "0.6", []), "tn30_indel_p03": ("tn30_indel", "0.3", []), "tn90_blocks_p095": ("tn90_blocks", "0.95", []),
                         "tn_dense_p08": ("tn_dense", "0.8", []), "tn_dense_p015": ("tn_dense", "0.15", []), "tn60_nofilter": ("tn60", "0.6", ["--disableFilter"]),
                         "tn60_auto": ("tn60", "auto", []), "tn30_indel_auto": ("tn30_indel", "auto", []), "tn90_blocks_auto": ("tn90_blocks", "auto", []), "tn_dense_auto": ("tn_dense", "auto", [])}

@@ -247,7 +247,7 @@ def make_cli_somatic(key):
     sys.path.insert(0, os.path.join(HERE, ".."))
     import util
     name, purity, extra = fixtures.CLI_SOMATIC_FIXTURES[key]
-    _, _, _, tag_cli, _ = fixtures.SOMATIC_FIXTURES[name]
+    _, _, _, tag_cli, _ = fixtures.ALL_SOMATIC[name]
     with tempfile.TemporaryDirectory() as d:
         digests, indel = util.make_somatic_inputs(d, name)
         for smp in ("normal", "tumor"):

@@ -392,7 +392,7 @@ def write_bai(bam_path, bai_path=None):
 
 def make_somatic_inputs(d, name, chrom="chrS"):
     """files of a tumor/normal fixture: ref.fa, normal_in.vcf, normal.sam, tumor.sam, tumor.vcf -> (normal digest, tumor digest)"""
-    genome, nkw, tkw, cli, over = fixtures.SOMATIC_FIXTURES[name]
+    genome, nkw, tkw, cli, over = fixtures.ALL_SOMATIC[name]
     N = Synth(**dict(genome, **nkw)); T = Synth(**dict(genome, **tkw))
     N.write_fasta(os.path.join(d, "ref.fa"), chrom); N.write_vcf(os.path.join(d, "normal_in.vcf"), chrom); N.write_sam(os.path.join(d, "normal.sam"), chrom)
     T.write_sam(os.path.join(d, "tumor_plain.sam"), chrom); T.write_vcf_tumor(os.path.join(d, "tumor.vcf"), chrom, with_germline=True)
