@@ -163,8 +163,43 @@ def cli_e2e(d, threads, ref_wall, n_ph):
               "zlib_1thread_s": round(zt, 2)}
     except Exception as e:  # noqa: BLE001
         gz = {"error": repr(e)[:300]}
+    som = None
+    try:                                                            # BASELINE.json configs[4] in miniature: tumor/normal pair, somatic_haplotag end to end
+        import hashlib
+        from lps.synth import Synth
+        genome = dict(contig_len=4_000_000, n_snp=3700, n_threads=threads, somatic_every=8000.0, seed=5101)
+        N = Synth(**dict(genome, coverage=25.0, read_seed=5111, tumor_purity=0.0)); T = Synth(**dict(genome, coverage=50.0, read_seed=5112, tumor_purity=0.6))
+        N.write_fasta(d + "/tn_ref.fa"); N.write_vcf(d + "/tn_normal_in.vcf"); N.write_sam(d + "/tn_normal.sam"); T.write_sam(d + "/tn_tumor.sam"); T.write_vcf_tumor(d + "/tn_tumor.vcf", "chrS", with_germline=True)
+        n_t = int(T.n_reads); N.close(); T.close()
+        tv = os.path.join(ROOT, "oracle", "_ref", "test_view"); ref_bin = os.path.join(ROOT, "oracle", "_ref", "longphase-s-ref")
+        for smp in ("tn_normal", "tn_tumor"):
+            subprocess.check_call([tv, "-b", "-x", smp + ".bam.bai", "-p", smp + ".bam", smp + ".sam"], cwd=d, stdout=subprocess.DEVNULL); os.remove(d + "/" + smp + ".sam")
+        r0 = subprocess.run([ref_bin, "phase", "-s", "tn_normal_in.vcf", "-b", "tn_normal.bam", "-r", "tn_ref.fa", "-t", str(threads), "-o", "tn_normal_phased", "--ont"], cwd=d, capture_output=True)
+        assert r0.returncode == 0, r0.stderr[-300:]
+        common = ["somatic_haplotag", "-s", "tn_normal_phased.vcf", "-b", "tn_normal.bam", "--tumor-snv-file", "tn_tumor.vcf", "--tumor-bam-file", "tn_tumor.bam", "-r", "tn_ref.fa", "-t", str(threads)]
+        tr, tc = [], []
+        for _ in range(2):
+            t0 = time.time(); r1 = subprocess.run([ref_bin] + common + ["-o", "tn_ref_out"], cwd=d, capture_output=True); tr.append(time.time() - t0)
+            t0 = time.time(); r2 = subprocess.run([cli] + common + ["-o", "tn_gpu_out"], cwd=d, capture_output=True); tc.append(time.time() - t0)
+            assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr[-300:], r2.stderr[-300:])
+
+        def digest(path):
+            import gzip
+            h = hashlib.sha256()
+            with gzip.open(path, "rb") as f:
+                head = f.read(8); f.read(int.from_bytes(head[4:8], "little")); nref = int.from_bytes(f.read(4), "little")
+                for _ in range(nref):
+                    ln = int.from_bytes(f.read(4), "little"); f.read(ln + 4)
+                for b in iter(lambda: f.read(1 << 24), b""):
+                    h.update(b)
+            return h.hexdigest()
+        som = {"cli_wall_s": round(min(tc), 3), "reference_wall_s": round(min(tr), 3), "speedup": round(min(tr) / min(tc), 2), "tumor_reads_per_s_cli": n_t / min(tc), "tumor_reads_per_s_reference": n_t / min(tr),
+               "identical_record_stream": digest(d + "/tn_ref_out.bam") == digest(d + "/tn_gpu_out.bam"), "identical_purity_report": open(d + "/tn_ref_out_purity.out").read() == open(d + "/tn_gpu_out_purity.out").read(),
+               "sample": "4 Mb contig, normal 25x + tumor 50x at 60 % purity, automatic purity estimation, best of 2", "cli_stages": r2.stderr.decode().strip().splitlines()[-1]}
+    except Exception as e:  # noqa: BLE001
+        som = {"error": repr(e)[:300]}
     return {"cli_wall_s": round(ts[1], 3), "cli_stages": stages, "cli_host_inflate_wall_s": round(min(th), 3), "cli_host_inflate_stages": host_stages,
-            "haplotag": tag, "gpu_bgzf": gz, "reference_wall_s": round(ref_wall, 3), "speedup": round(ref_wall / ts[1], 2),
+            "haplotag": tag, "somatic_haplotag": som, "gpu_bgzf": gz, "reference_wall_s": round(ref_wall, 3), "speedup": round(ref_wall / ts[1], 2),
             "cli_snps_per_s": float(n_ph / ts[1]), "identical_vcf": body(d + "/gpu.vcf") == body(d + "/out.vcf"),
             "note": "same BAM/VCF/FASTA files, process start to exit, median of 3; CLI wall includes HIP runtime start-up"}
 
