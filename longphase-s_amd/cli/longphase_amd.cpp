@@ -265,12 +265,28 @@ struct GpuBam {
         }
         t_scan += now() - t2;
     }
-    // indexed mode: only the BGZF blocks that hold this contig's records are uploaded and inflated; -> number of records (numbered from 0)
-    int64_t load_contig(Lps &L, lps_ctx *ctx, const std::string &chr) {
-        size_t t = 0; while (t < ref_names.size() && ref_names[t] != chr) ++t;
-        if (t == ref_names.size() || voff[t].second <= voff[t].first) return 0;
+    // indexed mode.  Consecutive contigs are taken in GROUPS of up to `budget` compressed bytes: one upload + one inflate launch per group (a launch
+    // over a single small contig cannot fill the GPU: the inflate kernel's latency is that of one 64 KiB block however few blocks there are).
+    int tid_of(const std::string &chr) const { for (size_t t = 0; t < ref_names.size(); ++t) if (ref_names[t] == chr) return (int)t; return -1; }
+    std::vector<std::vector<std::string>> plan_groups(const std::vector<std::string> &chrs, uint64_t budget) const {
+        std::vector<std::vector<std::string>> groups; int last_tid = -2; uint64_t bytes = 0;
+        for (const std::string &c : chrs) {
+            const int t = tid_of(c); if (t < 0 || voff[(size_t)t].second <= voff[(size_t)t].first) continue;       // not in this BAM / no records
+            const uint64_t sz = (voff[(size_t)t].second >> 16) - (voff[(size_t)t].first >> 16) + 65536;
+            bool gap_free = t > last_tid && !groups.empty();
+            if (gap_free) for (int k = last_tid + 1; k < t; ++k) if (voff[(size_t)k].second > voff[(size_t)k].first) gap_free = false;   // a contig in between is not wanted: keep groups tight
+            if (!gap_free || bytes + sz > budget) { groups.emplace_back(); bytes = 0; }
+            groups.back().push_back(c); bytes += sz; last_tid = t;
+        }
+        return groups;
+    }
+    // upload + inflate + scan the records of a group of consecutive contigs; fills `range` for its members
+    void load_group(Lps &L, lps_ctx *ctx, const std::vector<std::string> &chrs) {
+        range.clear();
+        if (chrs.empty()) return;
+        const size_t t0 = (size_t)tid_of(chrs.front()), t9 = (size_t)tid_of(chrs.back());
         const double t1 = now();
-        const uint64_t cbeg = voff[t].first >> 16, ubeg = voff[t].first & 0xffff, cend = voff[t].second >> 16, uend = voff[t].second & 0xffff;
+        const uint64_t cbeg = voff[t0].first >> 16, ubeg = voff[t0].first & 0xffff, cend = voff[t9].second >> 16, uend = voff[t9].second & 0xffff;
         uint64_t stop = cend; uint64_t last_isize = 0;
         if (uend) { if (cend + 18 > fsz) die("ERROR: index of " + path + " points past the end of the file"); const uint64_t bsize = (uint64_t)(raw[cend + 16] | (raw[cend + 17] << 8)) + 1; stop = cend + bsize; if (stop > fsz) die("ERROR: truncated BGZF block in " + path); last_isize = rd32(raw + stop - 4); }
         if (cbeg >= stop || stop > fsz) die("ERROR: index of " + path + " is inconsistent");
@@ -281,9 +297,13 @@ struct GpuBam {
         if (L.bam_scan_range(ctx, (int64_t)ubeg, end, (int32_t)ref_names.size(), &n)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
         std::vector<int32_t> tid((size_t)n);
         if (n && L.bam_record_tids(ctx, tid.data())) die(std::string("ERROR: ") + L.last_error(ctx));
-        for (int32_t x : tid) if (x != (int32_t)t) die("ERROR: index of " + path + " does not match its records");
+        for (int64_t i = 0; i < n;) {
+            int64_t j = i; while (j < n && tid[(size_t)j] == tid[(size_t)i]) ++j;
+            if (tid[(size_t)i] < (int32_t)t0 || tid[(size_t)i] > (int32_t)t9) die("ERROR: index of " + path + " does not match its records");
+            const std::string &nm = ref_names[(size_t)tid[(size_t)i]]; if (range.count(nm)) die("ERROR: " + path + " is not coordinate-sorted"); range[nm] = {i, j - i};
+            i = j;
+        }
         t_scan += now() - t2;
-        return n;
     }
     // names of records [first, first+count) -> (pointer, length) pairs into `store`
     void names(Lps &L, lps_ctx *ctx, int64_t first, int64_t count, std::vector<char> &store, std::vector<uint32_t> &off, std::vector<std::pair<const char *, size_t>> &out) {
@@ -413,11 +433,12 @@ static const char *kUsage =
     "   -1 edgeThreshold(0.7)  -L overlapThreshold(0.2)  -m readConfidence(0.65)  -n snpConfidence(0.75)  --gpu=ID (0)\n"
     "   --host-inflate | --gpu-inflate   BGZF inflate with zlib on the -t host threads / on the GPU (default: GPU for one BAM of 256 MiB or more)\n"
     "   --no-index       ignore <bam>.bai: make the whole file resident on the GPU instead of one contig at a time\n"
+    "   --group-bytes=N  indexed input: consecutive contigs are uploaded and inflated together up to N compressed bytes (8 GiB)\n"
     "   --gpus=N         deal the contigs onto N GPUs (devices --gpu, --gpu+1, ... modulo the number present); needs the .bai index\n";
 
 static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over; bool indels = false;
-    std::string snp, ref, prefix = "result"; std::vector<std::string> bams; int threads = 1, gpu = 0, n_gpus = 1; bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false;
+    std::string snp, ref, prefix = "result"; std::vector<std::string> bams; int threads = 1, gpu = 0, n_gpus = 1; uint64_t group_bytes = 8ull << 30; bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -442,6 +463,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "-x" || a == "--mismatchRate") (void)val();
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--gpus") n_gpus = std::max(1, std::stoi(val()));
+        else if (a == "--group-bytes") group_bytes = (uint64_t)std::stoull(val());
         else if (a == "--host-inflate") host_inflate = true;
         else if (a == "--gpu-inflate") gpu_inflate = true;
         else if (a == "--no-index") no_index = true;
@@ -486,8 +508,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         std::vector<std::pair<const char *, size_t>> names; std::vector<const ContigRecords *> parts; std::vector<char> name_store; std::vector<uint32_t> name_off;
         std::pair<int64_t, int64_t> gr{0, 0};
         if (gpu_input) {
-            if (gb.indexed) { gr = {0, gb.load_contig(L, ctx, chr)}; if (!gr.second) return; }
-            else { auto it = gb.range.find(chr); if (it == gb.range.end()) return; gr = it->second; }
+            { auto it = gb.range.find(chr); if (it == gb.range.end()) return; gr = it->second; }   // whole file, or the group loaded by the caller
             gb.names(L, ctx, gr.first, gr.second, name_store, name_off, names);
         }
         for (BamFile &f : files) { auto it = f.contigs.find(chr); if (it == f.contigs.end() || it->second.rec_off.empty()) { parts.push_back(nullptr); continue; }
@@ -528,21 +549,26 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     }
     std::vector<std::thread> workers;
     const int n_dev = std::max(1, L.device_count());
+    auto run_share = [&](lps_ctx *cx, GpuBam &g, std::vector<std::string> list) {
+        if (!gpu_input || !g.indexed) { for (const std::string &c : list) run_contig(cx, g, c); return; }
+        std::sort(list.begin(), list.end(), [&](const std::string &a, const std::string &b) { return g.tid_of(a) < g.tid_of(b); });   // file order, so that neighbours share an upload
+        for (auto &grp : g.plan_groups(list, group_bytes)) { g.load_group(L, cx, grp); for (const std::string &c : grp) run_contig(cx, g, c); }
+    };
     for (int g = 1; g < n_workers; ++g) workers.emplace_back([&, g] {
         lps_params P; L.default_params(&P); for (auto &f : over) f(P);
         lps_ctx *cx = L.create((gpu + g) % n_dev, &P); if (!cx) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
         GpuBam gg; gg.open_file(bams[0], true);
-        for (const std::string &c : share[(size_t)g]) run_contig(cx, gg, c);
+        run_share(cx, gg, share[(size_t)g]);
         L.destroy(cx); gg.close_file();
     });
-    for (const std::string &c : share[0]) run_contig(ctx, gb, c);
+    run_share(ctx, gb, share[0]);
     for (auto &w : workers) w.join();
     std::cerr << "\n";
     L.destroy(ctx);
     const double t_gpu = now();
     write_vcf(vcf_lines, prefix + ".vcf", res, vars, command);
     if (gpu_input) fprintf(stderr, "%s | vcf+fasta read %.3fs | wait for gpu context %.3fs | map bam+header%s %.3fs | upload+gpu inflate %.3fs | gpu record scan %.3fs | names+decode+phase %.3fs | write vcf %.3fs | total %.3fs\n",
-                           gb.indexed ? "per-contig (indexed)" : "whole file", t_text - t_begin, t_ctx - t_bam, gb.indexed ? "+index" : "", gb.t_map, gb.t_inflate, gb.t_scan,
+                           gb.indexed ? "contig groups (indexed)" : "whole file", t_text - t_begin, t_ctx - t_bam, gb.indexed ? "+index" : "", gb.t_map, gb.t_inflate, gb.t_scan,
                            t_gpu - t_gin - (gb.indexed ? gb.t_inflate + gb.t_scan : 0.0), now() - t_gpu, now() - t_begin);
     else fprintf(stderr, "vcf+fasta read %.3fs | bam inflate+walk %.3fs | wait for gpu context %.3fs | upload+phase %.3fs | write vcf %.3fs | total %.3fs\n", t_text - t_begin,
                  t_bam - t_text, t_ctx - t_bam, t_gpu - t_ctx, now() - t_gpu, now() - t_begin);
@@ -677,7 +703,7 @@ static const char *kTagUsage =
 
 static int haplotag_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
-    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, level = 6, strategy = Z_RLE; bool host_inflate = false, gpu_inflate = false, no_index = false, host_deflate = false;
+    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, level = 6, strategy = Z_RLE; bool host_inflate = false, gpu_inflate = false, no_index = false, host_deflate = false; uint64_t group_bytes = 8ull << 30;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kTagUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -696,6 +722,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         else if (a == "--gpu-inflate") gpu_inflate = true;
         else if (a == "--no-index") no_index = true;
         else if (a == "--host-deflate") host_deflate = true;
+        else if (a == "--group-bytes") group_bytes = (uint64_t)std::stoull(val());
         else if (a == "--compress-level") level = std::stoi(val());
         else if (a == "--compress-strategy") { const std::string x = val(); strategy = x == "default" ? Z_DEFAULT_STRATEGY : x == "rle" ? Z_RLE : x == "huffman" ? Z_HUFFMAN_ONLY : -1; if (strategy < 0) die("longphase_amd: --compress-strategy is one of default, rle, huffman"); }
         else if (a == "--help") { std::cout << kTagUsage; return 0; }
@@ -769,12 +796,18 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     }
     unsigned long long st_count[8] = {0}, hp_count[3] = {0};
     double t_score = 0, t_splice = 0, t_deflate = 0, t_load = 0, t_mark = now(); std::vector<uint8_t> zbuf;
+    std::vector<std::vector<std::string>> groups; if (!host_inflate && gb.indexed) groups = gb.plan_groups(chr_vec, group_bytes);   // output order = chr_vec order; a group = a run of consecutive contigs in it
     for (const std::string &chr : chr_vec) {                          // contigs in VCF-header order (HaplotagProcess.cpp:94-97)
-        if (!host_inflate && gb.indexed) {                              // this contig's blocks only: inflate + scan on the GPU, copy its records back
+        if (!host_inflate && gb.indexed) {                              // indexed input: the group of consecutive contigs this one belongs to is loaded when its first member comes up
             const double tl = now();
-            const int64_t cnt = gb.load_contig(L, ctx, chr);
-            ContigRecords &cc = in.contigs[chr]; cc.rec_off.resize((size_t)cnt); cc.lo = 0; cc.hi = (uint64_t)gb.total;
-            if (cnt && !gpu_writer) { copy_back(gb.total); if (L.bam_record_offsets(ctx, 0, cnt, cc.rec_off.data())) die(std::string("ERROR: ") + L.last_error(ctx)); }
+            if (!gb.range.count(chr)) {
+                for (auto &grp : groups) if (!grp.empty() && grp.front() == chr) {
+                    gb.load_group(L, ctx, grp);
+                    if (!gpu_writer) copy_back(gb.total);
+                    for (const std::string &m : grp) { auto it = gb.range.find(m); if (it == gb.range.end()) continue; ContigRecords &cc = in.contigs[m]; cc.rec_off.resize((size_t)it->second.second); cc.lo = 0; cc.hi = (uint64_t)gb.total;
+                        if (!gpu_writer && L.bam_record_offsets(ctx, it->second.first, it->second.second, cc.rec_off.data())) die(std::string("ERROR: ") + L.last_error(ctx)); }
+                }
+            }
             t_load += now() - tl; t_mark = now();
         }
         auto ci = in.contigs.find(chr);
@@ -793,11 +826,11 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
             lps_haplotag_result hr{(int64_t)n, status.data(), h1.data(), h2.data(), nps.data(), psmin.data(), hp.data(), pq.data(), psv.data()};
             if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) ||
                 (host_inflate ? L.push_bam_records(ctx, base, (int64_t)(c.hi - c.lo), c.rec_off.data(), (int64_t)n, name_id.data())
-                              : L.push_bam_resident(ctx, gb.indexed ? 0 : gb.range[chr].first, (int64_t)n, name_id.data())) || L.haplotag_chromosome(ctx, &hr))
+                              : L.push_bam_resident(ctx, gb.range[chr].first, (int64_t)n, name_id.data())) || L.haplotag_chromosome(ctx, &hr))
                 die(std::string("longphase_amd: ") + L.last_error(ctx));
         } else if (gpu_writer) {                                          // no variants on this contig: its records are still written (untouched)
             std::vector<uint32_t> name_id(n, 0);
-            if (L.begin_chromosome(ctx) || L.push_bam_resident(ctx, gb.indexed ? 0 : gb.range[chr].first, (int64_t)n, name_id.data())) die(std::string("longphase_amd: ") + L.last_error(ctx));
+            if (L.begin_chromosome(ctx) || L.push_bam_resident(ctx, gb.range[chr].first, (int64_t)n, name_id.data())) die(std::string("longphase_amd: ") + L.last_error(ctx));
         }
         t_score += now() - t_mark; t_mark = now();
         if (gpu_writer) {                                                 // tag splice + BGZF deflate on the GPU; the host only writes the finished blocks
@@ -876,7 +909,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     fprintf(stderr, "total alignment %llu | tagged %llu (HP1 %llu, HP2 %llu) | untagged: low mapq %llu, unmapped %llu, secondary %llu, supplementary %llu, no variant %llu, beyond last variant %llu, judged %llu\n",
             total, hp_count[1] + hp_count[2], hp_count[1], hp_count[2], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6], hp_count[0]);
     fprintf(stderr, "vcf+fasta read %.3fs | %s %.3fs | wait for gpu context %.3fs | score %.3fs | %s %.3fs | %s %.3fs (%llu bytes) | total %.3fs\n",
-            t_text - t_begin, host_inflate ? "host inflate+walk" : gb.indexed ? "gpu inflate+scan+copy back per contig (indexed)" : "gpu inflate+scan+copy back", host_inflate ? t_bam - t_text : t_gin - t_ctx + t_load, t_ctx - t_bam, t_score, gpu_writer ? "gpu tag splice+deflate+copy out" : "tag splice", t_splice, gpu_writer ? "write" : "deflate+write", t_deflate, w.bytes_out, now() - t_begin);
+            t_text - t_begin, host_inflate ? "host inflate+walk" : gb.indexed ? "gpu inflate+scan per contig group (indexed)" : "gpu inflate+scan+copy back", host_inflate ? t_bam - t_text : t_gin - t_ctx + t_load, t_ctx - t_bam, t_score, gpu_writer ? "gpu tag splice+deflate+copy out" : "tag splice", t_splice, gpu_writer ? "write" : "deflate+write", t_deflate, w.bytes_out, now() - t_begin);
     fflush(stderr);
     _exit(0);
 }

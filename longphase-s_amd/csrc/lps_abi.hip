@@ -8,6 +8,8 @@
 //   graph      node-major sorted (key u64, slot u32) list | edge f32[N][A][4] | vote records {f32 w,u32 flags}[N][A] | hp i8[N] | block i32[N]
 // Every lps_phase_chromosome() recomputes all stages from the resident raw reads.
 #include <algorithm>
+#include <thread>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -43,6 +45,7 @@ struct lps_ctx {
     // whole BAM file resident on the device (lps_bgzf_load): compressed bytes, block table, inflated stream; survives lps_begin_chromosome
     DevBuf<uint8_t> zfile, file; DevBuf<InflateBlock> zblk; uint64_t file_bytes = 0; float bgzf_h2d_ms = 0, bgzf_inflate_ms = 0;
     DevBuf<unsigned long long> tg_len, tg_off; DevBuf<uint2> tg_spans; DevBuf<uint8_t> tg_stream, tg_status, tg_hp; DevBuf<int32_t> tg_ps, tg_pq; int64_t cur_first = -1, cur_count = 0;
+    uint8_t *stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; size_t stage_bytes = 0;   // pinned staging ring for large pageable uploads
     DevBuf<uint8_t> dz_slots, dz_packed; DevBuf<uint32_t> dz_bytes; DevBuf<unsigned long long> dz_tmp; DevBuf<uint64_t> dz_off; uint64_t dz_total = 0; float dz_ms = 0;
     DevBuf<uint64_t> rcand; uint64_t n_rec_all = 0; DevBuf<int32_t> r_tid_all; DevBuf<uint32_t> r_lname, r_nameoff, wg_cnt, wg_off, scan_nout; DevBuf<uint8_t> names_d; bool names_ready = false;
     // observations
@@ -78,6 +81,24 @@ struct lps_ctx {
 };
 
 static int fail(lps_ctx *c, const std::string &m, int code = -1) { if (c) c->err = m; return code; }
+
+// Large upload from pageable memory (an mmap of the BAM file): the runtime's own path stages through ONE host thread's memcpy; here four threads fill a
+// pinned 2 x 64 MiB ring while the DMA engine drains the other half.
+static void h2d_staged(lps_ctx *c, uint8_t *dst, const uint8_t *src, size_t n) {
+    const size_t CH = 64u << 20;
+    if (n < (16u << 20)) { HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->stream)); return; }
+    if (!c->stage[0]) { for (int k = 0; k < 2; ++k) { HIP_TRY(hipHostMalloc((void **)&c->stage[k], CH, hipHostMallocDefault)); HIP_TRY(hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming)); } c->stage_bytes = CH; }
+    int k = 0; bool used[2] = {false, false};
+    for (size_t off = 0; off < n; off += CH, k ^= 1) {
+        const size_t len = std::min(CH, n - off);
+        if (used[k]) HIP_TRY(hipEventSynchronize(c->stage_ev[k]));
+        const int nt = 4; std::thread th[nt]; const size_t part = (len + nt - 1) / nt;
+        for (int t = 0; t < nt; ++t) th[t] = std::thread([=] { const size_t a = std::min(len, part * t), b = std::min(len, a + part); if (b > a) memcpy(c->stage[k] + a, src + off + a, b - a); });
+        for (int t = 0; t < nt; ++t) th[t].join();
+        HIP_TRY(hipMemcpyAsync(dst + off, c->stage[k], len, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->stage_ev[k], c->stream)); used[k] = true;
+    }
+}
 
 template <class T>
 static void upload(lps_ctx *c, DevBuf<T> &b, const T *src, size_t n, size_t at = 0, bool keep = false) {
@@ -143,6 +164,7 @@ void lps_destroy(lps_ctx *c) {
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     if (c->ev_cnv) (void)hipEventDestroy(c->ev_cnv);
     if (c->h_ncnv) (void)hipHostFree(c->h_ncnv);
+    for (int k = 0; k < 2; ++k) { if (c->stage[k]) (void)hipHostFree(c->stage[k]); if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]); }
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -265,7 +287,7 @@ int lps_push_bam_records(lps_ctx *c, const uint8_t *records, int64_t n_bytes, co
         hipStream_t s = c->stream;
         const uint64_t base = c->n_blob;                               // 16-byte aligned
         c->blob.reserve(base + (uint64_t)n_bytes + 32, s, true, base);
-        HIP_TRY(hipMemcpyAsync(c->blob.p + base, records, (size_t)n_bytes, hipMemcpyHostToDevice, s));
+        h2d_staged(c, c->blob.p + base, records, (size_t)n_bytes);
         HIP_TRY(hipMemsetAsync(c->blob.p + base + n_bytes, 0, 32, s));
         upload(c, c->rec_off, rec_off, n);
         BamView B{c->blob.p, base, (uint64_t)n_bytes, c->rec_off.p};
@@ -373,6 +395,15 @@ int lps_bgzf_load(lps_ctx *c, const uint8_t *bgzf, int64_t n_bytes, int64_t *inf
     try {
         HIP_TRY(hipSetDevice(c->device));
         // host: walk the block headers (18 bytes + BSIZE each; RFC 1952 member with the BC extra subfield, SAM spec 4.1)
+        auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double th0 = tnow();
+        // the upload needs nothing but the byte count, so it starts now and the header walk below runs beside it
+        hipStream_t s = c->stream; hipEvent_t e0, e1, e2;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
+        c->zfile.reserve((uint64_t)n_bytes + 64, s);
+        HIP_TRY(hipEventRecord(e0, s));
+        std::string up_err; std::thread uploader([&] { try { (void)hipSetDevice(c->device); h2d_staged(c, c->zfile.p, bgzf, (size_t)n_bytes); HIP_TRY(hipMemsetAsync(c->zfile.p + n_bytes, 0, 64, s)); } catch (std::string &e) { up_err = e; } });
+        struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_up{uploader};
         std::vector<InflateBlock> blks; uint64_t p = 0, utot = 0; const uint64_t n = (uint64_t)n_bytes;
         while (p + 18 <= n) {
             if (bgzf[p] != 31 || bgzf[p + 1] != 139 || bgzf[p + 2] != 8 || !(bgzf[p + 3] & 4)) return fail(c, "lps_bgzf_load: not a BGZF block header");
@@ -391,12 +422,11 @@ int lps_bgzf_load(lps_ctx *c, const uint8_t *bgzf, int64_t n_bytes, int64_t *inf
         }
         if (p != n || blks.empty()) return fail(c, "lps_bgzf_load: trailing bytes after the last BGZF block");
         if (blks.size() > 0x7fffffffull) return fail(c, "lps_bgzf_load: too many blocks");
-        hipStream_t s = c->stream; hipEvent_t e0, e1, e2;
-        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
-        c->zfile.reserve(n + 64, s); c->file.reserve(utot + 64, s); c->zblk.reserve(blks.size(), s); c->bam_err.reserve(1);
-        HIP_TRY(hipEventRecord(e0, s));
-        HIP_TRY(hipMemcpyAsync(c->zfile.p, bgzf, n, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemsetAsync(c->zfile.p + n, 0, 64, s));
+        const double th1 = tnow();
+        uploader.join();
+        if (!up_err.empty()) return fail(c, up_err);
+        c->file.reserve(utot + 64, s); c->zblk.reserve(blks.size(), s); c->bam_err.reserve(1);
+        const double th2 = tnow();
         HIP_TRY(hipMemcpyAsync(c->zblk.p, blks.data(), blks.size() * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s));
         HIP_TRY(hipEventRecord(e1, s));
@@ -408,6 +438,7 @@ int lps_bgzf_load(lps_ctx *c, const uint8_t *bgzf, int64_t n_bytes, int64_t *inf
         HIP_TRY(hipMemcpyAsync(&err, c->bam_err.p, sizeof err, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipEventElapsedTime(&c->bgzf_h2d_ms, e0, e1)); HIP_TRY(hipEventElapsedTime(&c->bgzf_inflate_ms, e1, e2));
+        if (getenv("LPS_DEBUG")) fprintf(stderr, "[lps_bgzf_load] %zu blocks: header walk beside the upload %.1f ms | wait for upload + device alloc %.1f ms | inflate + crc (host wall) %.1f ms (kernels %.1f)\n", blks.size(), th1 - th0, th2 - th1, tnow() - th2, c->bgzf_inflate_ms);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
         c->file_bytes = 0; c->n_rec_all = 0; c->names_ready = false;
         if (err) return fail(c, err & LPS_INF_ERR_DATA ? "lps_bgzf_load: corrupt deflate stream" : err & (LPS_INF_ERR_SIZE | LPS_INF_ERR_OVERRUN) ? "lps_bgzf_load: a block does not inflate to its ISIZE"

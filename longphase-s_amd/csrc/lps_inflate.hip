@@ -278,18 +278,32 @@ __device__ __forceinline__ uint32_t crc_multmodp(uint32_t a, uint32_t b) {
     for (;;) { if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; } m >>= 1; b = (b & 1) ? (b >> 1) ^ 0xedb88320u : b >> 1; }
     return p;
 }
+// slicing-by-4: four tables, one dependent step per 4 bytes; two independent halves of the lane's slice are interleaved so that the LDS latency of one
+// overlaps the other.  Slices are 16-byte multiples from the block start; the words are fetched with two aligned loads + v_alignbyte.
 __global__ void __launch_bounds__(256) k_bgzf_crc(const uint8_t *in, const InflateBlock *blk, int n_blk, const uint8_t *out, unsigned *err) {
-    __shared__ uint32_t tab[256], x2n[32];
-    for (int k = threadIdx.x; k < 256; k += 256) { uint32_t c = (uint32_t)k; for (int j = 0; j < 8; ++j) c = (c & 1) ? (c >> 1) ^ 0xedb88320u : c >> 1; tab[k] = c; }
+    __shared__ uint32_t tab[4][256], x2n[32];
+    for (int k = threadIdx.x; k < 256; k += 256) { uint32_t c = (uint32_t)k; for (int j = 0; j < 8; ++j) c = (c & 1) ? (c >> 1) ^ 0xedb88320u : c >> 1; tab[0][k] = c; }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 256; k += 256) { uint32_t c = tab[0][k]; for (int t = 1; t < 4; ++t) { c = tab[0][c & 255u] ^ (c >> 8); tab[t][k] = c; } }
     if (threadIdx.x < 32) { uint32_t p = 1u << 30; for (int k = 0; k < (int)threadIdx.x; ++k) p = crc_multmodp(p, p); x2n[threadIdx.x] = p; }
     __syncthreads();
     const int bi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (bi >= n_blk) return;
-    const InflateBlock B = blk[bi]; const uint8_t *o = out + B.out_off; const uint32_t len = B.out_len;
-    const uint32_t per = (len + 63) / 64, s0 = min(len, per * lane), s1 = min(len, s0 + per);
-    uint32_t c = lane == 0 ? 0xffffffffu : 0u;
-    for (uint32_t k = s0; k < s1; ++k) c = tab[(c ^ o[k]) & 255u] ^ (c >> 8);
-    { uint32_t p = 1u << 31, n = len - s1; int k = 3; while (n) { if (n & 1) p = crc_multmodp(x2n[k & 31], p); n >>= 1; ++k; } c = crc_multmodp(p, c); }
+    const InflateBlock B = blk[bi]; const uint32_t len = B.out_len;
+    const uint32_t per = (((len + 63) / 64) + 31) & ~31u, s0 = min(len, per * lane), s1 = min(len, s0 + per), half = per / 2;   // per: multiple of 32 -> two 16-byte-multiple halves
+    const uint32_t a0 = s0, a1 = min(s1, s0 + half), b0 = a1, b1 = s1;
+    const uint32_t *o32 = reinterpret_cast<const uint32_t *>(out); const uint64_t base = B.out_off;
+    auto word = [&](uint32_t pos) -> uint32_t { const uint64_t a = base + pos; const uint32_t lo = o32[a >> 2], hi = o32[(a >> 2) + 1]; return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3)); };
+    auto step4 = [&](uint32_t c, uint32_t w) -> uint32_t { c ^= w; return tab[3][c & 255u] ^ tab[2][(c >> 8) & 255u] ^ tab[1][(c >> 16) & 255u] ^ tab[0][c >> 24]; };
+    uint32_t ca = lane == 0 ? 0xffffffffu : 0u, cb = 0u; uint32_t pa = a0, pb = b0;
+    while (pa + 4 <= a1 && pb + 4 <= b1) { const uint32_t wa = word(pa), wb = word(pb); ca = step4(ca, wa); cb = step4(cb, wb); pa += 4; pb += 4; }
+    while (pa + 4 <= a1) { ca = step4(ca, word(pa)); pa += 4; }
+    while (pb + 4 <= b1) { cb = step4(cb, word(pb)); pb += 4; }
+    const uint8_t *o = out + base;
+    for (; pa < a1; ++pa) ca = tab[0][(ca ^ o[pa]) & 255u] ^ (ca >> 8);
+    for (; pb < b1; ++pb) cb = tab[0][(cb ^ o[pb]) & 255u] ^ (cb >> 8);
+    auto shift = [&](uint32_t c, uint32_t n) { uint32_t p = 1u << 31; int k = 3; while (n) { if (n & 1) p = crc_multmodp(x2n[k & 31], p); n >>= 1; ++k; } return crc_multmodp(p, c); };
+    uint32_t c = shift(ca, len - a1) ^ shift(cb, len - b1);                // state_i * x^(8 * bytes after the half)
     for (int s = 32; s; s >>= 1) c ^= __shfl_xor(c, s);
     c ^= 0xffffffffu;
     if (lane == 0) {

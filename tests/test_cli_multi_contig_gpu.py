@@ -20,7 +20,7 @@ def _body(path):
     return [l for l in open(path).read().split("\n") if not l.startswith("##commandline=") and not l.startswith("##longphaseVersion=")]
 
 
-@pytest.mark.parametrize("inflate", ["gpu", "host", "gpu_indexed", "gpu_indexed_3workers", "gpu_hostdeflate"])
+@pytest.mark.parametrize("inflate", ["gpu", "host", "gpu_indexed", "gpu_indexed_3workers", "gpu_hostdeflate", "gpu_indexed_1pergroup"])
 def test_multi_contig_phase_then_haplotag(inflate, tmp_path):
     gold = json.load(open(os.path.join(HERE, "golden", "cli_multi_contig.json")))
     d = str(tmp_path)
@@ -31,11 +31,13 @@ def test_multi_contig_phase_then_haplotag(inflate, tmp_path):
     tag_extra = ["--host-deflate"] if inflate == "gpu_hostdeflate" else []
     if inflate.startswith("gpu_indexed"):
         util.write_bai(d + "/reads.bam")                              # only one contig's blocks are resident at a time
-    workers = ["--gpus", "3"] if inflate.endswith("3workers") else []   # three contexts (on the one GPU of the test box), contigs dealt longest-first
+    workers = ["--gpus", "3"] if inflate.endswith("3workers") else []
+    if inflate.endswith("1pergroup"):
+        extra = extra + ["--group-bytes", "1"]                        # every contig is uploaded and inflated on its own   # three contexts (on the one GPU of the test box), contigs dealt longest-first
     r = subprocess.run([CLI, "phase", "-s", "multi.vcf", "-b", "reads.bam", "-r", "multi.fa", "-t", "3", "-o", "phased", "--ont", "--indels"] + extra + workers,
                        cwd=d, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert ("per-contig (indexed)" in r.stderr) == inflate.startswith("gpu_indexed")
+    assert ("(indexed)" in r.stderr) == inflate.startswith("gpu_indexed")
     ref_vcf = os.path.join(HERE, "golden", "data", "multi_contig.ref_phased.vcf")
     assert _body(d + "/phased.vcf") == _body(ref_vcf)
     r = subprocess.run([CLI, "haplotag", "-s", ref_vcf, "-b", "reads.bam", "-r", "multi.fa", "-t", "3", "-o", "tagged"] + extra + tag_extra,
