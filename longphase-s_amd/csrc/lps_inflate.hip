@@ -159,7 +159,15 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
                 int sym; const uint32_t fe = L(s_fast, (uint32_t)b.buf & 255u);
                 if (fe) { const int l = fe & 15; sym = (int)(fe >> 4); b.buf >>= l; b.cnt -= l; }
                 else { uint32_t idx; const int l = decode_limit<9>(peek15(b), s_llim, s_lbase, lane, idx); if (!l || idx >= 288) { e = LPS_INF_ERR_DATA; sym = 256; last = true; } else { sym = L(s_lsym, idx); b.buf >>= l; b.cnt -= l; } }
-                if (sym < 256) { if (op >= on) { e = LPS_INF_ERR_OVERRUN; state = ST_DONE; } else { ring_at(op) = (uint8_t)sym; ++op; } }
+                if (sym < 256) {
+                    if (op >= on) { e = LPS_INF_ERR_OVERRUN; state = ST_DONE; }
+                    else {
+                        ring_at(op) = (uint8_t)sym; ++op;
+                        // a second literal in the same iteration when the next code is a short one (<= 8 bits; at least 18 bits are still buffered)
+                        const uint32_t f2 = L(s_fast, (uint32_t)b.buf & 255u);
+                        if (f2 && (f2 >> 4) < 256u && op < on) { const int l2 = f2 & 15; b.buf >>= l2; b.cnt -= l2; ring_at(op) = (uint8_t)(f2 >> 4); ++op; }
+                    }
+                }
                 else if (sym == 256) { state = last ? ST_DONE : ST_HDR; }
                 else {
                     sym -= 257;
