@@ -573,6 +573,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     else fprintf(stderr, "vcf+fasta read %.3fs | bam inflate+walk %.3fs | wait for gpu context %.3fs | upload+phase %.3fs | write vcf %.3fs | total %.3fs\n", t_text - t_begin,
                  t_bam - t_text, t_ctx - t_bam, t_gpu - t_ctx, now() - t_gpu, now() - t_begin);
     fflush(stderr);
+    if (getenv("LPS_CLI_NO_FAST_EXIT")) return 0;                       // e.g. under a profiler that writes its report from an exit handler
     _exit(0);   // outputs are closed and flushed; skip the ROCm runtime's static teardown (~0.1 s)
 }
 
@@ -911,6 +912,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     fprintf(stderr, "vcf+fasta read %.3fs | %s %.3fs | wait for gpu context %.3fs | score %.3fs | %s %.3fs | %s %.3fs (%llu bytes) | total %.3fs\n",
             t_text - t_begin, host_inflate ? "host inflate+walk" : gb.indexed ? "gpu inflate+scan per contig group (indexed)" : "gpu inflate+scan+copy back", host_inflate ? t_bam - t_text : t_gin - t_ctx + t_load, t_ctx - t_bam, t_score, gpu_writer ? "gpu tag splice+deflate+copy out" : "tag splice", t_splice, gpu_writer ? "write" : "deflate+write", t_deflate, w.bytes_out, now() - t_begin);
     fflush(stderr);
+    if (getenv("LPS_CLI_NO_FAST_EXIT")) return 0;                       // e.g. under a profiler that writes its report from an exit handler
     _exit(0);
 }
 
@@ -1327,6 +1329,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             total, hp_hist[1], hp_hist[2], hp_hist[5], hp_hist[7], hp_hist[3], hp_hist[0], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6]);
     fprintf(stderr, "inputs %.3fs | passes + caller + writer %.3fs | total %.3fs\n", t_in - t_begin, now() - t_in, now() - t_begin);
     fflush(stderr);
+    if (getenv("LPS_CLI_NO_FAST_EXIT")) return 0;                       // e.g. under a profiler that writes its report from an exit handler
     _exit(0);
 }
 

@@ -70,4 +70,11 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
     tc, st = timed([CLI, "haplotag", "-s", "ref.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(T), "-o", "gpu_tag"], 2)
     out["haplotag"] = {"reference_wall_s": round(tr, 3), "cli_wall_s": round(tc, 3), "speedup": round(tr / tc, 2), "identical_record_stream": digest(d + "/ref_tag.bam") == digest(d + "/gpu_tag.bam"),
                        "output_bytes": {"cli": os.path.getsize(d + "/gpu_tag.bam"), "reference": os.path.getsize(d + "/ref_tag.bam")}, "cli_stages": st}
+    prof = os.environ.get("LPS_ROCPROF_DIR")                          # optional: kernel trace of the two CLI runs (the CLI must leave through exit handlers for the report)
+    if prof:
+        env = dict(os.environ, LPS_CLI_NO_FAST_EXIT="1", TMPDIR="/tmp")
+        for what, cmd in (("phase", [CLI, "phase", "-s", "in.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(T), "-o", "gpu", "--ont"]),
+                          ("haplotag", [CLI, "haplotag", "-s", "ref.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(T), "-o", "gpu_tag"])):
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(prof, what), "-o", what, "--"] + cmd, cwd=d, env=env, capture_output=True)
+            out[what]["rocprof_rc"] = r.returncode
     print(json.dumps(out, indent=1))
