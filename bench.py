@@ -244,7 +244,8 @@ def main():
     if rank == 0:
         log(f"generated {a.workload}: {s.n_reads} alignments, {s.n_variants} het SNPs, {s.qual.size/1e9:.2f} Gbases in {time.time()-t0:.1f}s")
     P = abi.default_params()
-    ctx = hip.Context(local_rank, P)
+    n_dev = max(1, int(hip.load().lps_device_count()))
+    ctx = hip.Context(local_rank % n_dev, P)        # one rank per GPU on the node the driver uses; a rehearsal with fewer GPUs than ranks shares them
     t0 = time.time()
     ctx.load_chromosome(V, s.ref, R)
     h2d_s = time.time() - t0
