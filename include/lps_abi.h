@@ -208,6 +208,9 @@ typedef struct lps_timings {
 } lps_timings;
 
 int lps_abi_version(void);
+/* test hook: the library's step-by-step restatement of libstdc++'s std::sort (by key only) applied on the HOST to (keys, payload) pairs -
+ * the routine the GPU runs on merged reads that hold a position twice (src/phase/PhasingGraph.cpp:854; csrc/lps_stdsort.h) */
+void lps_debug_std_sort(int32_t *keys, uint8_t *payload, int64_t n);
 /* sizeof() of the ABI structs as compiled into the library: 0 lps_params, 1 lps_variant_table, 2 lps_read_batch,
  * 3 lps_phase_result, 4 lps_haplotag_result, 5 lps_timings, 6 lps_somatic_tag_result, 7 lps_site_counters, 8 lps_tumor_extract_result (binding self-check). */
 int lps_struct_size(int which);

@@ -17,6 +17,7 @@
 #include "lps_bam.h"
 #include "lps_inflate.h"
 #include "lps_deflate.h"
+#include "lps_stdsort.h"
 
 static const char *kStageNames[LPS_MAX_STAGES] = {
     "variant_prep", "extract", "name_keys", "clip_cnv", "name_groups", "overlap_filter", "cnv_filter", "nodes", "merge_rows",
@@ -117,6 +118,8 @@ static std::vector<T> download(lps_ctx *c, const T *p, size_t n) {
 extern "C" {
 
 int lps_abi_version(void) { return LPS_ABI_VERSION; }
+
+void lps_debug_std_sort(int32_t *keys, uint8_t *payload, int64_t n) { stdsort_pairs(keys, payload, (int)n); }
 
 int lps_struct_size(int which) {
     switch (which) {

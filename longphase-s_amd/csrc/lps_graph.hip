@@ -19,6 +19,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "lps_graph.h"
+#include "lps_stdsort.h"
 
 // ================================================================================================ clips / CNV
 // thread per clip slot: keep events of ops before the op at which get_snp returned early (:1453-1455,1559-1561),
@@ -453,6 +454,24 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
                 g_node[base + rank] = nd; g_flag[base + rank] = fl;
             }
         }
+        // The placement above is the STABLE order.  libstdc++'s std::sort leaves equal positions in another order once a row has more than 16
+        // elements, and the reference's float sums see that order: when the row holds a position twice, rebuild it as the reference does -
+        // alignments concatenated in BAM order, then std::sort restated step by step (lps_stdsort.h).  Rare (overlapping supplementary alignments).
+        int total = 0; for (uint32_t sa = s0; sa < s1; ++sa) total += g_cnt[(uint32_t)skeys[sa]];
+#ifndef LPS_NO_STDSORT_FIX
+        if (total > 16) {
+            __threadfence_block();
+            bool dup = false;
+            for (int k = l; k + 1 < total; k += 64) dup |= g_node[base + k] == g_node[base + k + 1];
+            if (__ballot(dup)) {
+                int at = 0;
+                for (uint32_t sa = s0; sa < s1; ++sa) { const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = row_off[ra];
+                    for (int k = l; k < na; k += 64) { g_node[base + at + k] = g_node[oa + k]; g_flag[base + at + k] = g_flag[oa + k]; } at += na; }
+                __threadfence_block();
+                if (l == 0) stdsort_pairs(g_node + base, g_flag + base, total);
+            }
+        }
+#endif
     }
 }
 

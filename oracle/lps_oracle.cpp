@@ -971,3 +971,13 @@ int oracle_somatic_extract_tumor(const lps_params *Pp, const lps_variant_table *
 }
 
 }  // extern "C"
+
+// test helper: the REAL libstdc++ std::sort on (key, payload) pairs compared by key only - what the reference does to a merged read's variants
+// (src/phase/PhasingGraph.cpp:854 with src/shared/Util.cpp:3-5).  Pins the library's restatement (csrc/lps_stdsort.h).
+extern "C" void oracle_std_sort(int32_t *keys, uint8_t *payload, int64_t n) {
+    struct E { int32_t k; uint8_t p; };
+    std::vector<E> v((size_t)n);
+    for (int64_t i = 0; i < n; ++i) v[(size_t)i] = E{keys[i], payload[i]};
+    std::sort(v.begin(), v.end(), [](const E &a, const E &b) { return a.k < b.k; });
+    for (int64_t i = 0; i < n; ++i) { keys[i] = v[(size_t)i].k; payload[i] = v[(size_t)i].p; }
+}

@@ -28,6 +28,9 @@ PHASE_FIXTURES = {
                  dict(phase_indel=1, read_confidence=0.8, snp_confidence=0.9, edge_threshold=0.5, overlap_threshold=0.05)),
     "high_error": (dict(SMALL, seed=14, sub_rate=0.06, ins_rate=0.04, del_rate=0.04), ["--ont"], {}),
     "short_reads": (dict(SMALL, seed=15, len_median=3000.0, len_min=500, coverage=25.0), ["--ont"], {}),
+    # half of the reads split into overlapping primary + supplementary pieces, dense SNPs, many low-quality bases: merged reads hold positions
+    # twice, where the order std::sort leaves among equal positions reaches the fp32 edge sums
+    "supp_light_dups": (dict(SMALL, seed=17, n_snp=1500, coverage=25.0, supp_frac=0.5, supp_overlap_frac=1.0, lowq_frac=0.4), ["--ont"], {}),
 }
 
 # haplotag fixtures: (phase fixture providing reads + the reference's own phased VCF, haplotag CLI flags, params overrides)

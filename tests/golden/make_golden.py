@@ -305,6 +305,18 @@ def make_multi_contig_golden():
 
 def main():
     assert os.path.exists(REF_BIN), "build the reference first: oracle/build_ref.sh"
+    if "--only-phase" in sys.argv:                 # one phase fixture, index.json updated in place
+        name = sys.argv[sys.argv.index("--only-phase") + 1]
+        kw, cli, over = fixtures.PHASE_FIXTURES[name]
+        s = Synth(**kw)
+        with tempfile.TemporaryDirectory() as d:
+            ps, gt = run_reference_phase(s, cli, d)
+        np.savez_compressed(os.path.join(HERE, f"phase_{name}.npz"), var_pos=np.array(s.var_pos), phase_set=ps, gt=gt)
+        index = json.load(open(os.path.join(HERE, "index.json")))
+        index[name] = dict(digest=fixtures.input_digest(s), n_var=int(s.n_variants), n_reads=int(s.n_reads), n_phased=int((ps != 0).sum()), n_blocks=int(len(set(ps[ps != 0].tolist()))), cli=cli)
+        json.dump(index, open(os.path.join(HERE, "index.json"), "w"), indent=1, sort_keys=True)
+        print(name, index[name]); s.close()
+        return
     if "--cli-somatic" in sys.argv:
         for key in fixtures.CLI_SOMATIC_FIXTURES:
             if "--only-auto" not in sys.argv or key.endswith("_auto"):
