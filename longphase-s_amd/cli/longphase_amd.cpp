@@ -27,6 +27,7 @@
 #include <iostream>
 #include <iterator>
 #include <map>
+#include <set>
 #include <mutex>
 #include <numeric>
 #include <sstream>
@@ -1066,11 +1067,12 @@ static const char *kSomUsage =
     "Usage: longphase_amd somatic_haplotag [OPTION] ... READSFILE\n"
     "   -s, --snp-file=NAME (phased normal VCF)   -b, --bam-file=NAME (normal BAM)   --tumor-snv-file=NAME   --tumor-bam-file=NAME   -r, --reference=NAME\n"
     "   --tumor-purity=Num (default: automatic estimation, written to <prefix>_purity.out)   --disableFilter   --somatic-calling-log (writes <prefix>_somatic_filter.log)\n"
+    "   --output-somatic-vcf (writes <prefix>_sc.vcf: the tumor VCF with FILTER = PASS for the somatic calls, LowQual otherwise)\n"
     "   --tagSupplementary   -q qualityThreshold(1)   -p percentageThreshold(0.6)   -t threads(1)   -o out-prefix(result)   --gpu=ID (0)\n";
 
 static int somatic_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
-    std::string snp, ref, nbam, tvcf, tbam, prefix = "result"; int threads = 1, gpu = 0; double purity = -1, pct = 0.6; bool enable_filter = true, write_log = false;
+    std::string snp, ref, nbam, tvcf, tbam, prefix = "result"; int threads = 1, gpu = 0; double purity = -1, pct = 0.6; bool enable_filter = true, write_log = false, write_sc_vcf = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kSomUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -1089,9 +1091,10 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         else if (a == "--tumor-purity") purity = std::stod(val());
         else if (a == "--disableFilter") enable_filter = false;
         else if (a == "--somatic-calling-log") write_log = true;
+        else if (a == "--output-somatic-vcf") write_sc_vcf = true;
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--help") { std::cout << kSomUsage; return 0; }
-        else if (a == "--cram" || a == "--region" || a == "--log" || a == "--output-somatic-vcf" || a == "--truth-vcf" || a == "--truth-bed" || a == "--benchmark-log") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
+        else if (a == "--cram" || a == "--region" || a == "--log" || a == "--truth-vcf" || a == "--truth-bed" || a == "--benchmark-log") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kSomUsage; return 1; }
     }
     if (snp.empty() || nbam.empty() || tvcf.empty() || tbam.empty() || ref.empty()) { std::cerr << "longphase_amd somatic_haplotag: missing arguments\n" << kSomUsage; return 1; }
@@ -1146,6 +1149,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     }
     auto fail = [&]() { die(std::string("longphase_amd: ") + L.last_error(ctx)); };
     unsigned long long n_somatic_flag = 0, hp_hist[9] = {0}, st_count[8] = {0};
+    std::map<std::string, std::set<int32_t>> somatic_pos;               // isSomaticVariant (getSomaticFlag), for --output-somatic-vcf
     // phase 0 (only when the purity has to be estimated): passes 1 and 2 over every contig feed the estimator, which needs all contigs at once;
     // phase 1: passes 1 and 2 again (milliseconds on the GPU), the caller's statistics and filters, pass 3, the writer.
     for (int phase = estimate ? 0 : 1; phase < 2; ++phase) {
@@ -1282,7 +1286,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                 if (pairs[i].empty()) die("[ERROR](statistic all read HP) => can't find pos in tumorPosReadCorrBaseHP : chr: " + chr + " pos: " + std::to_string(pos[(size_t)sites[i]] + 1));
                 int d1 = 0, d2 = 0; for (auto &pr : pairs[i]) if (pr.second == 3) { if (setHp[(size_t)pr.first] == 5) ++d1; else if (setHp[(size_t)pr.first] == 7) ++d2; }
                 const int tot = d1 + d2; float r1 = 0.0f, r2 = 0.0f; if (tot > 0) { if (d1 > 0) r1 = (float)d1 / (float)tot; if (d2 > 0) r2 = (float)d2 / (float)tot; }
-                const size_t v = (size_t)sites[i]; ++n_somatic_flag;
+                const size_t v = (size_t)sites[i]; ++n_somatic_flag; if (write_sc_vcf) somatic_pos[chr].insert(pos[v]);
                 if (role[v] != 0) { role[v] = 1; derive[v] = r1 >= 1.0f ? 1 : r2 >= 1.0f ? 2 : 0; }   // a position that also has a normal row keeps its germline role in the tagging pass
             }
             // ---- pass 3: tagging (SomaticHaplotagChrProcessor::judgeHaplotype); the tumor reads are still resident
@@ -1322,6 +1326,23 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     std::cerr << "\n";
     w.finish();
     if (write_log) flog.close();                                       // the process leaves through _exit: nothing is flushed implicitly
+    if (write_sc_vcf) {                                                // VcfParser::writeProcess (src/haplotag/HaplotagVcfParser.cpp:548-614): the tumor VCF with FILTER rewritten
+        std::ofstream o(prefix + "_sc.vcf"); if (!o) die("Fail to open output file: " + prefix + "_sc.vcf");
+        bool cmd_done = false; std::set<std::string> in_vec(chr_vec.begin(), chr_vec.end());
+        for (const std::string &in : tlines) {
+            if (in.size() >= 2 && in.compare(0, 2, "##") == 0) { o << in << std::endl; continue; }
+            if (in.size() >= 6 && (in.compare(0, 6, "#CHROM") == 0 || in.compare(0, 6, "#chrom") == 0)) { if (!cmd_done) { o << "##longphase_s_version=" << kVersion << std::endl << "##commandline=" << command << std::endl; cmd_done = true; } o << in << std::endl; continue; }
+            std::istringstream iss(in); std::vector<std::string> f((std::istream_iterator<std::string>(iss)), std::istream_iterator<std::string>());
+            if (f.empty()) continue;
+            if (f.size() < 7) die("[ERROR](VcfParser::writeProcess) => VCF file format error: " + in);
+            if (!in_vec.count(f[0])) continue;
+            const int32_t p0 = std::stoi(f[1]) - 1; auto ct = trows.find(f[0]); if (ct == trows.end()) continue; auto rt = ct->second.find(p0); if (rt == ct->second.end() || rt->second.kind == 4) continue;
+            const bool som = somatic_pos.count(f[0]) && somatic_pos[f[0]].count(p0);
+            if (som) { if (f[6] != "PASS") f[6] = "PASS"; } else if (f[6] == "PASS") f[6] = "LowQual";
+            std::string line = f[0]; for (size_t i = 1; i < f.size(); ++i) line += "\t" + f[i];
+            o << line << std::endl;
+        }
+    }
     L.destroy(ctx);
     unsigned long long total = 0; for (int k = 0; k < 8; ++k) total += st_count[k];
     fprintf(stderr, "somatic variant count(Flag): %llu\n", n_somatic_flag);

@@ -256,7 +256,7 @@ def make_cli_somatic(key):
                            cwd=d, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-1000:]
         cmd = [REF_BIN, "somatic_haplotag", "-s", "normal_phased.vcf", "-b", "normal.bam", "--tumor-snv-file", "tumor.vcf", "--tumor-bam-file", "tumor.bam", "-r", "ref.fa", "-t", "1",
-               "-o", "som", "--somatic-calling-log"] + (["--tumor-purity", purity] if purity != "auto" else []) + tag_cli + extra
+               "-o", "som", "--somatic-calling-log", "--output-somatic-vcf"] + (["--tumor-purity", purity] if purity != "auto" else []) + tag_cli + extra
         r = subprocess.run(cmd, cwd=d, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"reference somatic_haplotag failed rc={r.returncode}: {r.stderr[-2000:]}")
@@ -265,10 +265,12 @@ def make_cli_somatic(key):
         tags = util.bam_record_tags(recs)
         filter_log = open(d + "/som_somatic_filter.log").read()
         purity_out = open(d + "/som_purity.out").read() if purity == "auto" else None
+        sc = [l for l in open(d + "/som_sc.vcf").read().split("\n") if not l.startswith("##commandline=") and not l.startswith("##longphase_s_version=")]
         shutil.copy(d + "/normal_phased.vcf", os.path.join(HERE, "data", f"somatic_{name}.normal_phased.vcf"))
     out = dict(digests=list(digests), records_sha256=hashlib.sha256(recs).hexdigest(), n_records=len(tags), record_bytes=len(recs), flag_count=flag_count,
                header_without_pg=[l for l in text.split("\n") if l and not l.startswith("@PG")], tags=[[q, f, p, [list(t) for t in tg]] for q, f, p, tg in tags],
-               filter_log=filter_log, cli=tag_cli + extra, purity=purity, purity_out=purity_out)
+               filter_log=filter_log, cli=tag_cli + extra, purity=purity, purity_out=purity_out,
+               sc_vcf_sha256=hashlib.sha256("\n".join(sc).encode()).hexdigest(), sc_vcf_pass=sum(1 for l in sc if l and not l.startswith("#") and l.split("\t")[6] == "PASS"))
     with open(os.path.join(HERE, f"cli_somatic_{key}.json"), "w") as f:
         json.dump(out, f)
     hist = {}

@@ -27,7 +27,7 @@ def test_cli_somatic_matches_reference(key, tmp_path):
     util.write_bam(d + "/normal.sam", d + "/normal.bam"); util.write_bam(d + "/tumor.sam", d + "/tumor.bam", block=40000)
     phased = os.path.join(HERE, "golden", "data", f"somatic_{name}.normal_phased.vcf")
     r = subprocess.run([CLI, "somatic_haplotag", "-s", phased, "-b", "normal.bam", "--tumor-snv-file", "tumor.vcf", "--tumor-bam-file", "tumor.bam", "-r", "ref.fa", "-t", "4",
-                        "-o", "som", "--somatic-calling-log"] + (["--tumor-purity", purity] if purity != "auto" else []) + gold["cli"], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, LPS_CLI_DEBUG="1"))
+                        "-o", "som", "--somatic-calling-log", "--output-somatic-vcf"] + (["--tumor-purity", purity] if purity != "auto" else []) + gold["cli"], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, LPS_CLI_DEBUG="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     print(r.stderr[-700:])
     if purity == "auto":                                              # the estimator's report: every count, the box-plot statistics and the purity itself
@@ -37,6 +37,9 @@ def test_cli_somatic_matches_reference(key, tmp_path):
     for g, w in zip(got_log, want_log):
         assert g == w
     assert int([l for l in r.stderr.splitlines() if l.startswith("somatic variant count(Flag)")][0].split(":")[1]) == gold["flag_count"]
+    sc = [l for l in open(d + "/som_sc.vcf").read().split("\n") if not l.startswith("##commandline=") and not l.startswith("##longphase_s_version=")]
+    assert sum(1 for l in sc if l and not l.startswith("#") and l.split("\t")[6] == "PASS") == gold["sc_vcf_pass"]
+    assert hashlib.sha256("\n".join(sc).encode()).hexdigest() == gold["sc_vcf_sha256"]
     text, refs, recs = util.bam_sections(d + "/som.bam")
     assert [l for l in text.split("\n") if l and not l.startswith("@PG")] == gold["header_without_pg"]
     got = util.bam_record_tags(recs)
