@@ -121,7 +121,7 @@ __device__ __forceinline__ ReadPlan plan_read(const VarView &V, const ReadView &
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
+__global__ __launch_bounds__(256, 6) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
                                                        LpsCounters *cnt) {
     __shared__ int s_ref[4][LPS_SEG];
     __shared__ int s_qry[4][LPS_SEG];
