@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 7
+#define LPS_ABI_VERSION 8
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -211,6 +211,9 @@ int lps_abi_version(void);
 /* test hook: the library's step-by-step restatement of libstdc++'s std::sort (by key only) applied on the HOST to (keys, payload) pairs -
  * the routine the GPU runs on merged reads that hold a position twice (src/phase/PhasingGraph.cpp:854; csrc/lps_stdsort.h) */
 void lps_debug_std_sort(int32_t *keys, uint8_t *payload, int64_t n);
+/* test hook: the same sort as the GPU runs it (a wavefront per row, csrc/lps_graph.hip wave_std_sort) on rows [row_start[r], row_start[r+1]) of
+ * host arrays (keys, payload), in place.  Returns 0, or -1 when the device call fails. */
+int lps_debug_std_sort_gpu(int device, int32_t *keys, uint8_t *payload, const int64_t *row_start, int64_t n_rows);
 /* sizeof() of the ABI structs as compiled into the library: 0 lps_params, 1 lps_variant_table, 2 lps_read_batch,
  * 3 lps_phase_result, 4 lps_haplotag_result, 5 lps_timings, 6 lps_somatic_tag_result, 7 lps_site_counters, 8 lps_tumor_extract_result (binding self-check). */
 int lps_struct_size(int which);

@@ -120,6 +120,19 @@ extern "C" {
 int lps_abi_version(void) { return LPS_ABI_VERSION; }
 
 void lps_debug_std_sort(int32_t *keys, uint8_t *payload, int64_t n) { stdsort_pairs(keys, payload, (int)n); }
+int lps_debug_std_sort_gpu(int device, int32_t *keys, uint8_t *payload, const int64_t *row_start, int64_t n_rows) {
+    if (n_rows <= 0) return 0;
+    if (hipSetDevice(device) != hipSuccess) return -1;
+    const size_t n = (size_t)row_start[n_rows]; int32_t *dk = nullptr; uint8_t *dp = nullptr; long long *dr = nullptr; int rc = -1;
+    if (hipMalloc(&dk, n * 4 + 4) == hipSuccess && hipMalloc(&dp, n + 4) == hipSuccess && hipMalloc(&dr, (size_t)(n_rows + 1) * 8) == hipSuccess &&
+        hipMemcpy(dk, keys, n * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dp, payload, n, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(dr, row_start, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice) == hipSuccess) {
+        launch_debug_std_sort(dk, dp, dr, (int)n_rows, 0);
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(keys, dk, n * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(payload, dp, n, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+    }
+    (void)hipFree(dk); (void)hipFree(dp); (void)hipFree(dr);
+    return rc;
+}
 
 int lps_struct_size(int which) {
     switch (which) {

@@ -428,15 +428,96 @@ __global__ void k_merge_plan(const unsigned long long *skeys, const uint32_t *gs
     multi_list[atomicAdd(&cnt->n_multi, 1u)] = g;
 }
 
+// ---- std::sort of one row by one wavefront (rows that hold a position twice; see k_merge_multi).  The row sits in LDS in its unsorted order.
+// __introsort_loop is walked as libstdc++ does (explicit stack for the right-hand parts), but each __unguarded_partition is done by all 64 lanes:
+// with pivot v, A = positions holding >= v in ascending order and B = positions holding <= v in descending order, the serial loop swaps A_j with
+// B_j for j = 1..m where m = #{j : A_j < B_j} (the pointers never look at a swapped position again, so both lists can be taken from the array
+// as it was before the first swap), and returns cut = min(A_(m+1), B_m).  __final_insertion_sort is a stable sort, i.e. a rank count.
+// Heapsort (depth limit hit) stays serial on lane 0.  k/p: n <= STDSORT_LDS elements in LDS; pa/pb: STDSORT_LDS uint16 each; stk: 192 ints.
+constexpr int STDSORT_LDS = 1024;
+__device__ inline void wave_std_sort(int32_t *k, uint8_t *p, int n, int *stk, uint16_t *pa, uint16_t *pb, int32_t *out_k, uint8_t *out_p, int l) {
+    const unsigned long long lt = (1ull << l) - 1ull;
+    if (n > 16) {
+        int lg = 0; for (int m = n; m > 1; m >>= 1) ++lg;
+        int *sf = stk, *sl = stk + 64, *sd = stk + 128; int sp = 1;
+        if (l == 0) { sf[0] = 0; sl[0] = n; sd[0] = 2 * lg; }
+        __threadfence_block();
+        while (sp) {
+            --sp; const int first = sf[sp]; int last = sl[sp], depth = sd[sp];
+            while (last - first > 16) {
+                if (depth == 0) { if (l == 0) { StdSortArrays a{k, p}; stdsort_heapsort(a, first, last); } __threadfence_block(); break; }
+                --depth;
+                if (l == 0) { StdSortArrays a{k, p}; stdsort_move_median_to_first(a, first, first + 1, first + (last - first) / 2, last - 1); }
+                __threadfence_block();
+                const int32_t pv = k[first];
+                int nA = 0, nB = 0;
+                for (int b0 = first + 1; b0 < last; b0 += 64) {
+                    const int i = b0 + l; const bool f = i < last && k[i] >= pv; const unsigned long long m = __ballot(f);
+                    if (f) pa[nA + __popcll(m & lt)] = (uint16_t)i;
+                    nA += __popcll(m);
+                }
+                for (int b0 = last - 1; b0 > first; b0 -= 64) {
+                    const int i = b0 - l; const bool f = i > first && k[i] <= pv; const unsigned long long m = __ballot(f);
+                    if (f) pb[nB + __popcll(m & lt)] = (uint16_t)i;
+                    nB += __popcll(m);
+                }
+                __threadfence_block();
+                const int mn = nA < nB ? nA : nB; int m = 0;
+                for (int j0 = 0; j0 < mn; j0 += 64) {
+                    const int j = j0 + l; const int c = __popcll(__ballot(j < mn && pa[j] < pb[j])); m += c;
+                    if (c < 64) break;
+                }
+                for (int j = l; j < m; j += 64) {
+                    const int a = pa[j], b = pb[j]; const int32_t ka = k[a], kb = k[b]; const uint8_t qa = p[a], qb = p[b];
+                    k[a] = kb; p[a] = qb; k[b] = ka; p[b] = qa;
+                }
+                int cut = 0x7fffffff; if (m < nA) cut = pa[m]; if (m > 0 && (int)pb[m - 1] < cut) cut = pb[m - 1];
+                __threadfence_block();
+                if (l == 0 && sp < 64) { sf[sp] = cut; sl[sp] = last; sd[sp] = depth; }
+                if (sp < 64) ++sp;
+                __threadfence_block();
+                last = cut;
+            }
+        }
+    }
+    // what the loop leaves: runs of <= 16 elements, each run's keys between those of its neighbours - an element's final place is decided inside
+    // the 16 positions either side of it
+    for (int i = l; i < n; i += 64) {
+        const int32_t ki = k[i]; const int lo = i > 16 ? i - 16 : 0, hi = i + 17 < n ? i + 17 : n; int rank = lo;
+        for (int j = lo; j < hi; ++j) { const int32_t kj = k[j]; rank += (kj < ki) || (kj == ki && j < i); }
+        out_k[rank] = ki; out_p[rank] = p[i];
+    }
+}
+
+// test hook (lps_debug_std_sort_gpu): rows [row_start[r], row_start[r+1]) of (keys, payload) sorted in place, a wave per row, same path as k_merge_multi
+__global__ __launch_bounds__(256) void k_debug_std_sort(int32_t *keys, uint8_t *payload, const long long *row_start, int n_rows) {
+    __shared__ int s_stk[4][192]; __shared__ int32_t s_k[4][STDSORT_LDS]; __shared__ uint8_t s_p[4][STDSORT_LDS]; __shared__ uint16_t s_a[4][STDSORT_LDS], s_b[4][STDSORT_LDS];
+    const int l = lane_id(), w = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + w; r < n_rows; r += gridDim.x * 4) {
+        const long long o = row_start[r]; const int n = (int)(row_start[r + 1] - o);
+        if (n <= STDSORT_LDS) {
+            for (int i = l; i < n; i += 64) { s_k[w][i] = keys[o + i]; s_p[w][i] = payload[o + i]; }
+            __threadfence_block();
+            wave_std_sort(s_k[w], s_p[w], n, s_stk[w], s_a[w], s_b[w], keys + o, payload + o, l);
+            __threadfence_block();
+        } else if (l == 0) { StdSortArrays a{keys + o, payload + o}; stdsort_run(a, n, s_stk[w]); }
+    }
+}
+void launch_debug_std_sort(int32_t *keys, uint8_t *payload, const long long *row_start, int n_rows, hipStream_t s) {
+    hipLaunchKernelGGL(k_debug_std_sort, dim3(256), dim3(256), 0, s, keys, payload, row_start, n_rows);
+}
+
 __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *skeys, const uint32_t *gstart, const LpsCounters *cnt,
                                                      const uint32_t *row_off, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
                                                      const uint32_t *mrow_off, const uint32_t *multi_list) {
+    __shared__ int s_stk[4][192]; __shared__ int32_t s_k[4][STDSORT_LDS]; __shared__ uint8_t s_p[4][STDSORT_LDS]; __shared__ uint16_t s_a[4][STDSORT_LDS], s_b[4][STDSORT_LDS];
     const int l = lane_id();
     const unsigned n_waves = gridDim.x * 4;
     for (unsigned q = blockIdx.x * 4 + (threadIdx.x >> 6); q < cnt->n_multi; q += n_waves) {
         const unsigned g = multi_list[q];
         const uint32_t s0 = gstart[g], s1 = gstart[g + 1];
         const uint32_t base = mrow_off[g];
+        bool dup = false;
         for (uint32_t sa = s0; sa < s1; ++sa) {                      // source alignment (BAM order inside the group)
             const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = row_off[ra];
             for (int k = l; k < na; k += 64) {
@@ -448,7 +529,8 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
                     // earlier alignment: its equal positions go first (count <= nd); later alignment: only smaller ones
                     int lo = 0, hi = nb;
                     if (sb < sa) { while (lo < hi) { const int m = (lo + hi) >> 1; if (g_node[ob + m] <= nd) lo = m + 1; else hi = m; } }
-                    else { while (lo < hi) { const int m = (lo + hi) >> 1; if (g_node[ob + m] < nd) lo = m + 1; else hi = m; } }
+                    else { while (lo < hi) { const int m = (lo + hi) >> 1; if (g_node[ob + m] < nd) lo = m + 1; else hi = m; }
+                           dup |= lo < nb && g_node[ob + lo] == nd; }                                // the same position in a later alignment
                     rank += lo;
                 }
                 g_node[base + rank] = nd; g_flag[base + rank] = fl;
@@ -460,15 +542,18 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
         int total = 0; for (uint32_t sa = s0; sa < s1; ++sa) total += g_cnt[(uint32_t)skeys[sa]];
 #ifndef LPS_NO_STDSORT_FIX
         if (total > 16) {
-            __threadfence_block();
-            bool dup = false;
-            for (int k = l; k + 1 < total; k += 64) dup |= g_node[base + k] == g_node[base + k + 1];
             if (__ballot(dup)) {
+                // concatenation in BAM order: into LDS and sorted by the whole wave (wave_std_sort) for rows of up to STDSORT_LDS elements, else in
+                // place in HBM by lane 0 (a chain of dependent accesses at ~1 us each; such rows do not occur with real read lengths)
+                const int w = threadIdx.x >> 6; const bool in_lds = total <= STDSORT_LDS;
+                int32_t *kk = in_lds ? s_k[w] : g_node + base; uint8_t *pp = in_lds ? s_p[w] : g_flag + base;
                 int at = 0;
                 for (uint32_t sa = s0; sa < s1; ++sa) { const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = row_off[ra];
-                    for (int k = l; k < na; k += 64) { g_node[base + at + k] = g_node[oa + k]; g_flag[base + at + k] = g_flag[oa + k]; } at += na; }
+                    for (int k = l; k < na; k += 64) { kk[at + k] = g_node[oa + k]; pp[at + k] = g_flag[oa + k]; } at += na; }
                 __threadfence_block();
-                if (l == 0) stdsort_pairs(g_node + base, g_flag + base, total);
+                if (in_lds) wave_std_sort(kk, pp, total, s_stk[w], s_a[w], s_b[w], g_node + base, g_flag + base, l);
+                else if (l == 0) { StdSortArrays a{kk, pp}; stdsort_run(a, total, s_stk[w]); }
+                __threadfence_block();
             }
         }
 #endif

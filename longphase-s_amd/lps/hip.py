@@ -48,6 +48,8 @@ def load():
     L.lps_push_bam_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.lps_debug_std_sort.restype = None
     L.lps_debug_std_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.lps_debug_std_sort_gpu.restype = C.c_int
+    L.lps_debug_std_sort_gpu.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.lps_bgzf_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.lps_bgzf_read.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     L.lps_bgzf_deflate.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
