@@ -35,7 +35,7 @@ struct DevBuf {
         size_t nc = cap ? cap : 256;
         while (nc < n) nc = nc + nc / 2 + 256;
         T *q = nullptr;
-        HIP_TRY(hipMalloc((void **)&q, nc * sizeof(T)));
+        HIP_TRY(hipMalloc((void **)&q, nc * sizeof(T) + 64));      // 64 B of slack: kernels read whole 16-B vectors at the tail (CIGAR words)
         if (keep && p && used) HIP_TRY(hipMemcpyAsync(q, p, used * sizeof(T), hipMemcpyDeviceToDevice, s));
         if (p) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(p)); }
         p = q; cap = nc;

@@ -83,133 +83,194 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 }
 
 // ------------------------------------------------------------------------------------------------ extraction
-#define EXT_RPW 4   // alignments per wave (processed one after the other)
+#define EXT_RPW 4   // alignments per wave: planned together (one chain of dependent loads for the four), then walked one after the other
 
-struct ReadPlan { int v0, v1; bool live; };
-
-// pass 1 of one alignment: filters, reference span (one coalesced sweep of the CIGAR, wave reduction) and the slice
-// [v0,v1) of candidate variants.  Wave-uniform result.
-__device__ __forceinline__ ReadPlan plan_read(const VarView &V, const ReadView &R, int r, int mapping_quality, LpsCounters *cnt) {
-    ReadPlan p{0, 0, false};
-    if (r >= R.n) return p;
-    const int l = lane_id();
-    const int start = R.ref_start[r];
-    const int flag = R.flag[r];
-    // direct_detect_alleles filters (:1282-1291) + region "chr:1-<lastSNPPos>" (:1273)
-    if (R.mapq[r] < mapping_quality || (flag & 0x4) || (flag & 0x100) || (flag & 0x400) || start >= V.last_pos) return p;
-    p.live = true;
-    const uint64_t coff = R.cigar_off[r];
-    const int n_cig = (int)(R.cigar_off[r + 1] - coff);
-    const uint32_t *cig = R.cigar + coff;
-    long long span = 0; bool bad = false;
-    for (int c0 = 0; c0 < n_cig; c0 += 512) {               // 8 independent 256-B loads in flight per trip
-        uint32_t wd[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int c = c0 + u * 64 + l; wd[u] = c < n_cig ? cig[c] : 6u; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int op = wd[u] & 15;
-            if (op_consumes_ref(op)) span += wd[u] >> 4;
-            if (op > 8) bad = true;
-        }
-    }
-    span = wave_sum(span);
-    if (__ballot(bad)) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR); }
-    long long endll = (long long)start + span; if (endll > 0x7fffffff) endll = 0x7fffffff;
-    p.v0 = var_lower_bound(V, start);
-    p.v1 = var_lower_bound(V, (int)endll);
-    return p;
+// first variant with pos >= key, searched by ONE lane (the planning step runs eight of these side by side); == var_lower_bound
+__device__ __forceinline__ int lane_var_lower_bound(const VarView &V, int key) {
+    if (key < 0) return 0;
+    const int b = key >> LPS_BUCKET_SHIFT;
+    int lo, hi;
+    if (b >= V.n_bucket) { lo = V.bucket[V.n_bucket]; hi = V.n; } else { lo = V.bucket[b]; hi = V.bucket[b + 1]; }
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (V.pos[m] < key) lo = m + 1; else hi = m; }
+    return lo;
 }
 
-__global__ __launch_bounds__(256, 6) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
+// One pass over each CIGAR.  The kernel is bound by the length of its chains of dependent loads and by instruction issue, not by bytes, so
+//  * the wave's EXT_RPW alignments are planned together: headers one per lane, the four start bounds searched by four lanes at once;
+//  * nothing is computed ahead from the CIGAR (no sweep for the reference end): observations are collected in an LDS buffer and the output rows
+//    of all four alignments are reserved with ONE atomicAdd of their exact size when the wave is done, then written with coalesced stores.
+//    A wave whose buffer fills up (long reads over dense variants) reserves an upper bound for the row it is in - remaining reference span
+//    -> remaining candidates -, empties the buffer and writes the rest of that row directly;
+//  * the CIGAR words, candidate records and predecessor position of the NEXT segment (of this or the next alignment) are requested before the
+//    current segment gathers its bases, so one wait covers both;
+//  * CIGAR ops are staged 8 per lane (stage_ops8): a handful of VALU instructions per op and one wave scan per 512 ops.
+#define EXT_CAP 512     // observations buffered per wave
+__global__ __launch_bounds__(256, 4) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
                                                        LpsCounters *cnt) {
-    __shared__ int s_ref[4][LPS_SEG];
-    __shared__ int s_qry[4][LPS_SEG];
-    __shared__ uint32_t s_cig[4][LPS_SEG + 1];
+    __shared__ __attribute__((aligned(16))) int s_ref[4][LPS_SEG];
+    __shared__ __attribute__((aligned(16))) int s_qry[4][LPS_SEG];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cig[4][LPS_SEG + 4];
+    __shared__ int s_bvar[4][EXT_CAP];
+    __shared__ uint16_t s_baq[4][EXT_CAP];
+    enum { H_START, H_LQ, H_REL, H_V0, H_SOFF, H_QOFF = H_SOFF + 2, H_KIND = H_QOFF + 2, H_ROFF, H_RCNT, H_RFAIL, H_RFLAGS, H_WORDS };
+    enum { ROW_DEAD = 0, ROW_BUFFERED = 1, ROW_GLOBAL = 2 };
+    __shared__ int s_hdr[4][EXT_RPW + 1][H_WORDS];
     const int w = threadIdx.x >> 6, l = lane_id();
     int *sref = s_ref[w], *sqry = s_qry[w]; uint32_t *scig = s_cig[w];
-    // Output rows are reserved per alignment on one of LPS_ARENAS counters (own cache line each).  Workgroups are
-    // dealt round-robin over the 8 XCDs, so arena = blockIdx % 64 keeps each counter inside ONE XCD's L2, and pass 2
-    // follows pass 1 of the same alignment immediately: its CIGAR re-read is an L2 hit instead of a second HBM sweep.
+    int *bvar = s_bvar[w]; uint16_t *baq = s_baq[w];
+    int *hdr = s_hdr[w][0];
+    // Output rows are reserved on one of LPS_ARENAS counters (own cache line each).  Workgroups are dealt round-robin over the 8 XCDs, so
+    // arena = blockIdx % 64 keeps each counter inside ONE XCD's L2.
     const int arena = blockIdx.x % O.n_arenas;
     const unsigned long long arena_lo = (unsigned long long)arena * O.arena_size;
-#pragma unroll 1
-    for (int q = 0; q < EXT_RPW; ++q) {
-        const int r = (blockIdx.x * 4 + w) * EXT_RPW + q;
-        if (r >= R.n) break;
-        const ReadPlan pl = plan_read(V, R, r, mapping_quality, cnt);
-        const int v0 = pl.v0, v1 = pl.v1, cand = v1 - v0;
-        const bool live_q = pl.live;
-        unsigned long long my_base = 0; bool overflow = false;
-        if (live_q && cand > 0) {
-            unsigned long long off = 0;
-            if (l == 0) off = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)cand);
-            off = __shfl(off, 0);
-            overflow = off + (unsigned long long)cand > O.arena_size;
-            my_base = arena_lo + off;
-        }
-        if (l < LPS_CLIP_SLOTS && (!live_q || overflow)) C.opidx_fb[(size_t)r * LPS_CLIP_SLOTS + l] = -1;
-        if (!live_q) { if (l == 0) { O.row_off[r] = 0; O.row_cnt[r] = 0; O.row_fail[r] = 0x7fffffff; O.row_flags[r] = 0; } continue; }
-        if (overflow) {
-            if (l == 0) { atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); O.row_off[r] = 0; O.row_cnt[r] = 0; O.row_fail[r] = 0x7fffffff; O.row_flags[r] = 0; }
-            continue;
-        }
-        const int start = R.ref_start[r];
-        const uint64_t coff = R.cigar_off[r];
-        const int n_cig = (int)(R.cigar_off[r + 1] - coff);
-        const uint32_t *cig = R.cigar + coff;
-        const uint8_t *seq = R.seq + R.seq_off[r];
-        const uint8_t *qual = R.qual + R.qual_off[r];
-        const int lq = R.l_qseq[r];
+    const int r0 = (blockIdx.x * 4 + w) * EXT_RPW;
+    if (r0 >= R.n) return;
+    const int nq = min(EXT_RPW, R.n - r0);
+    static_assert(LPS_CLIP_SLOTS == 4 && EXT_RPW == 4 && LPS_SEG == 512, "lane layout of the planning step");
 
-        // ---- pass 2: segments of LPS_SEG ops -> LDS (ref prefix, query prefix, raw op word); the candidate variants
-        //      (one packed record per lane, loaded BEFORE the prefix build so both latencies overlap) search them
-        int ref_pos = start, q_pos = 0, n_emit = 0, fail_op = 0x7fffffff, vcur = v0, n_clip = 0;
-        bool had_any = false;
+    // ---- plan: headers, alignment q in lane q.  direct_detect_alleles filters (:1282-1291) + region "chr:1-<lastSNPPos>" (:1273)
+    int h_start = 0, h_lq = 0, h_rel = 0; bool h_live = false; unsigned long long h_coff = 0, h_soff = 0, h_qoff = 0;
+    if (l <= nq) h_coff = R.cigar_off[r0 + l];
+    if (l < nq) {
+        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r]; h_qoff = R.qual_off[r];
+        const int flag = R.flag[r];
+        h_live = !(R.mapq[r] < mapping_quality || (flag & 0x4) || (flag & 0x100) || (flag & 0x400) || h_start >= V.last_pos);
+    }
+    const unsigned live_mask = (unsigned)__ballot(h_live) & 15u;
+    const unsigned long long c_lo = __shfl(h_coff, 0);
+    if (l <= nq) h_rel = (int)(h_coff - c_lo);                         // op index of alignment q's first op inside the wave's CIGAR range
+    const uint32_t *cg = R.cigar + c_lo;
+
+    // what was requested ahead for segment (pf_q, pf_seg): CIGAR words, op after the segment, candidate records, predecessor position
+    uint32_t pw[8]; uint32_t pnext = 0xfu; uint2 pvr = make_uint2(0x7fffffffu, 0u); int ppv = -1;
+    int pf_q = -1, pf_seg = 0; bool pf_vr_ok = false;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pw[u] = 6u;
+    int q = live_mask ? __builtin_ctz(live_mask) : nq;
+    if (q < nq) {                                                      // first segment of the first alignment: on its way while the bounds are searched
+        const int crel = __shfl(h_rel, q), ncq = __shfl(h_rel, q + 1) - crel;
+        if (ncq > 0) {
+            const int nsegn = min(LPS_SEG, ncq);
+            pnext = (nsegn < ncq) ? cg[crel + nsegn] : 0xfu;
+            load_ops8(cg + crel, 8 * l, nsegn, pw);
+            pf_q = q; pf_seg = 0;
+        }
+    }
+    // first candidate of each alignment: four lanes search the position-sorted table side by side
+    int h_v0 = 0;
+    if (l < 4 && h_live) h_v0 = lane_var_lower_bound(V, h_start);
+    if (l <= 4) {
+        int *h = s_hdr[w][l];
+        h[H_REL] = h_rel;
+        if (l < 4) {
+            h[H_START] = h_start; h[H_LQ] = h_lq; h[H_V0] = h_v0;
+            h[H_SOFF] = (int)(unsigned)h_soff; h[H_SOFF + 1] = (int)(unsigned)(h_soff >> 32);
+            h[H_QOFF] = (int)(unsigned)h_qoff; h[H_QOFF + 1] = (int)(unsigned)(h_qoff >> 32);
+            h[H_KIND] = ROW_DEAD; h[H_ROFF] = 0; h[H_RCNT] = 0; h[H_RFAIL] = 0x7fffffff; h[H_RFLAGS] = 0;
+        }
+    }
+    // alignments that are filtered out: no clips (their rows are written with the others at the end)
+    if (l < 4 * nq && !((live_mask >> (l >> 2)) & 1u)) C.opidx_fb[(size_t)(r0 + (l >> 2)) * LPS_CLIP_SLOTS + (l & 3)] = -1;
+    wave_sync();
+
+    // ---- walk: segments of LPS_SEG ops -> LDS (ref prefix, query prefix, raw op word); the candidate variants (one packed record per lane)
+    //      search them
+    int n_buf = 0;                     // observations in the LDS buffer (rows of this wave not yet in HBM)
+    bool arena_full = false;
+#pragma unroll 1
+    while (q < nq) {
+        const int r = r0 + q;
+        int *h = hdr + q * H_WORDS;
+#define HU(i) __builtin_amdgcn_readfirstlane(h[i])
+        const int start = HU(H_START), lq = HU(H_LQ), crel = HU(H_REL), n_cig = HU(H_WORDS + H_REL) - crel;
+        const uint32_t *cig = cg + crel;
+        const uint8_t *seq = R.seq + ((unsigned long long)(unsigned)HU(H_SOFF) | ((unsigned long long)(unsigned)HU(H_SOFF + 1) << 32));
+        const uint8_t *qual = R.qual + ((unsigned long long)(unsigned)HU(H_QOFF) | ((unsigned long long)(unsigned)HU(H_QOFF + 1) << 32));
+        int vcur = HU(H_V0);
+#undef HU
+        const unsigned rest = live_mask >> (q + 1);
+        const int qn = rest ? q + 1 + __builtin_ctz(rest) : nq;                 // next alignment to walk
+        const int *hn = hdr + qn * H_WORDS;                                     // (row nq exists: only its H_REL is meaningful)
+        const int n_cig_n = qn < nq ? hn[H_WORDS + H_REL] - hn[H_REL] : 0;
+
+        int ref_pos = start, q_pos = 0, n_emit = 0, fail_op = 0x7fffffff, n_clip = 0;
+        bool had_any = false, direct = false;
+        const int row_start = n_buf;                                            // of this row inside the buffer
+        unsigned long long direct_base = 0;
         for (int seg0 = 0; seg0 < n_cig; seg0 += LPS_SEG) {
             const int nseg = min(LPS_SEG, n_cig - seg0);
-            uint2 vr = make_uint2(0x7fffffffu, 0u);
-            if (vcur + l < v1) vr = V.rec[vcur + l];
-            const uint32_t nextw = (seg0 + nseg < n_cig) ? cig[seg0 + nseg] : 0xfu;      // op after the segment (0xf = none)
-            uint32_t wds[LPS_SEG / 64];                          // the whole segment's CIGAR words: LPS_SEG/64 loads in flight
+            uint32_t wds[8]; uint32_t nextw; uint2 vr; int pv0;
+            const bool have = pf_q == q && pf_seg == seg0;
+            if (have) {
 #pragma unroll
-            for (int u = 0; u < LPS_SEG / 64; ++u) { const int idx = u * 64 + l; wds[u] = idx < nseg ? cig[seg0 + idx] : 6u; }
-#pragma unroll
-            for (int u = 0; u < LPS_SEG / 64; ++u) {
-                const int c0 = u * 64;
-                if (c0 >= nseg) break;
-                const int idx = c0 + l;
-                const uint32_t wd = wds[u];
-                const int op = idx < nseg ? (int)(wd & 15) : 6, len = (int)(wd >> 4);
-                const int radv = op_consumes_ref(op) ? len : 0, qadv = op_consumes_query(op) ? len : 0;
-                const int ir = wave_incl_scan_dpp(radv), iq = wave_incl_scan_dpp(qadv);
-                const int my_ref = ref_pos + ir - radv, my_q = q_pos + iq - qadv;
-                if (idx < nseg) { sref[idx] = my_ref; sqry[idx] = my_q; scig[idx] = wd; }
-                // getClip (:1613-1620,1636-1645): soft/hard clips longer than 5; FRONT iff CIGAR index 0.
-                // Events go to the read's own LPS_CLIP_SLOTS slots (no atomics here); compaction happens later.
-                const bool clip = (op == 4 || op == 5) && len > 5;
-                const unsigned long long cm = __ballot(clip);
-                if (cm) {
-                    if (clip) {
-                        const int slot = n_clip + __popcll(cm & lanemask_lt());
-                        if (slot < LPS_CLIP_SLOTS) { C.pos[(size_t)r * LPS_CLIP_SLOTS + slot] = my_ref; C.opidx_fb[(size_t)r * LPS_CLIP_SLOTS + slot] = ((seg0 + idx) << 1) | ((seg0 + idx) != 0); }
-                        else atomicOr(&cnt->err, (unsigned)LPS_ERR_CLIP_OVERFLOW);
+                for (int u = 0; u < 8; ++u) wds[u] = pw[u];
+                nextw = pnext;
+            } else {
+                nextw = (seg0 + nseg < n_cig) ? cig[seg0 + nseg] : 0xfu;      // op after the segment (0xf = none)
+                load_ops8(cig + seg0, 8 * l, nseg, wds);
+            }
+            if (have && pf_vr_ok) { vr = pvr; pv0 = ppv; }
+            else {
+                vr = make_uint2(0x7fffffffu, 0u);
+                if (vcur + l < V.n) vr = V.rec[vcur + l];
+                pv0 = (vcur > 0 && vcur < V.n) ? V.pos[vcur - 1] : -1;
+            }
+            int my_ref;
+            const unsigned cm = stage_ops8(wds, l, ref_pos, q_pos, sref, sqry, scig, my_ref);
+            (void)my_ref;
+            // getClip (:1613-1620,1636-1645): soft/hard clips longer than 5; FRONT iff CIGAR index 0.
+            // Events go to the read's own LPS_CLIP_SLOTS slots (no atomics here); compaction happens later.
+            if (__ballot(cm == 0u)) {                            // rare (first / last segment of a clipped alignment): words re-read from LDS
+                int mine_n = 0;
+#pragma unroll 1
+                for (int k = 0; k < 8; ++k) { const uint32_t wd = scig[8 * l + k]; const unsigned op = wd & 15u; mine_n += ((op == 4u || op == 5u) && (wd >> 4) > 5u) ? 1 : 0; }
+                const int incl = wave_incl_scan_dpp(mine_n);
+                int slot = n_clip + incl - mine_n;
+                if (mine_n) {
+#pragma unroll 1
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t wd = scig[8 * l + k]; const unsigned op = wd & 15u;
+                        if ((op == 4u || op == 5u) && (wd >> 4) > 5u) {
+                            const int oi = seg0 + 8 * l + k;
+                            if (slot < LPS_CLIP_SLOTS) { C.pos[(size_t)r * LPS_CLIP_SLOTS + slot] = sref[8 * l + k]; C.opidx_fb[(size_t)r * LPS_CLIP_SLOTS + slot] = (oi << 1) | (oi != 0); }
+                            else atomicOr(&cnt->err, (unsigned)LPS_ERR_CLIP_OVERFLOW);
+                            ++slot;
+                        }
                     }
-                    n_clip += __popcll(cm);
                 }
-                ref_pos += __shfl(ir, 63); q_pos += __shfl(iq, 63);
+                n_clip += __shfl(incl, 63);
             }
             if (l == 0) scig[nseg] = nextw;
             wave_sync();
-            // candidates are position-sorted: those inside this segment's reference interval form a prefix of the chunk
-            const bool last_seg = seg0 + nseg >= n_cig;
+            // ---- request the next segment's CIGAR words: same alignment, or the first segment of the next one
+            const bool same = seg0 + LPS_SEG < n_cig;
+            const bool has_next = same || (qn < nq && n_cig_n > 0);
+            if (has_next) {
+                const uint32_t *cign = same ? cig : cg + hn[H_REL];
+                const int segn = same ? seg0 + LPS_SEG : 0, ncn = same ? n_cig : n_cig_n, nsegn = min(LPS_SEG, ncn - segn);
+                pnext = (segn + nsegn < ncn) ? cign[segn + nsegn] : 0xfu;
+                load_ops8(cign + segn, 8 * l, nsegn, pw);
+                pf_q = same ? q : qn; pf_seg = segn;
+            } else pf_q = -1;
+            pf_vr_ok = false;
+            // candidates are position-sorted: those before the end of this segment's reference interval form a prefix of the chunk
+            bool first_round = true;
             while (true) {
                 const int v = vcur + l;
                 const int p = (int)vr.x;
-                const bool mine = v < v1 && (last_seg || p < ref_pos);
+                const bool mine = v < V.n && p < ref_pos;
                 const int n_in = __popcll(__ballot(mine));
+                const bool more = n_in == 64;
+                if (first_round && has_next && !more) {          // ... and its candidate records + predecessor position
+                    const int nv = same ? vcur + n_in : hn[H_V0];
+                    pvr = make_uint2(0x7fffffffu, 0u);
+                    if (nv + l < V.n) pvr = V.rec[nv + l];
+                    ppv = (nv > 0 && nv < V.n) ? V.pos[nv - 1] : -1;
+                    pf_vr_ok = true;
+                }
                 int pprev = __shfl_up(p, 1);                     // position of the previous variant (all lanes take part)
-                if (l == 0) pprev = (v > 0 && v < v1) ? V.pos[v - 1] : -1;
+                if (l == 0) pprev = first_round ? pv0 : ((v > 0 && v < V.n) ? V.pos[v - 1] : -1);
+                first_round = false;
                 bool emit = false, fail = false; int allele = -1, qv = 0, opi = 0;
                 if (mine) {
                     const unsigned at = vr.y;
@@ -259,15 +320,40 @@ __global__ __launch_bounds__(256, 6) void k_extract_phase(VarView V, ReadView R,
                     if (emit && (at & VREC_ERASED)) emit = false;                              // filterSNP (:895-911)
                 }
                 const unsigned long long em = __ballot(emit);
-                if (emit) {
-                    const unsigned long long slot = my_base + n_emit + __popcll(em & lanemask_lt());
-                    O.var[slot] = v; O.aq[slot] = pack_aq(allele, qv);
+                const int n_em = __popcll(em);
+                if (!direct && n_buf + n_em > EXT_CAP) {
+                    // ---- buffer full: reserve what is buffered + an upper bound for the rest of this row (every candidate up to the reference end
+                    //      of the alignment emits at most once), move the buffer out, write the rest of the row directly
+                    long long rem = 0;
+                    for (int c = seg0 + nseg + l; c < n_cig; c += 64) { const uint32_t wd = cig[c]; if (op_consumes_ref(wd & 15)) rem += wd >> 4; }
+                    rem = wave_sum(rem);
+                    long long endll = (long long)ref_pos + rem; if (endll > 0x7fffffff) endll = 0x7fffffff;
+                    const int v1 = var_lower_bound(V, (int)endll);
+                    const unsigned long long need = (unsigned long long)n_buf + (unsigned long long)max(0, v1 - vcur);
+                    unsigned long long off = 0;
+                    if (l == 0) off = atomicAdd(&O.arena_ctr[arena * 8], need);
+                    off = __shfl(off, 0);
+                    if (off + need > O.arena_size) arena_full = true;
+                    else {
+                        const unsigned long long g0 = arena_lo + off;
+                        for (int i = l; i < n_buf; i += 64) { O.var[g0 + i] = bvar[i]; O.aq[g0 + i] = baq[i]; }
+                        if (l < q) { int *hp = hdr + l * H_WORDS; if (hp[H_KIND] == ROW_BUFFERED) { hp[H_KIND] = ROW_GLOBAL; hp[H_ROFF] = (int)(uint32_t)(g0 + (unsigned)hp[H_ROFF]); } }
+                        direct_base = g0 + row_start;
+                    }
+                    wave_sync();
+                    direct = true; n_buf = 0;
                 }
-                n_emit += __popcll(em);
+                if (emit) {
+                    const int rank = n_emit + __popcll(em & lanemask_lt());
+                    if (direct) { if (!arena_full) { O.var[direct_base + rank] = v; O.aq[direct_base + rank] = pack_aq(allele, qv); } }
+                    else { bvar[row_start + rank] = v; baq[row_start + rank] = pack_aq(allele, qv); }
+                }
+                n_emit += n_em;
+                if (!direct) n_buf += n_em;
                 vcur += n_in;
-                if (n_in < 64 || vcur >= v1) break;
+                if (!more) break;
                 vr = make_uint2(0x7fffffffu, 0u);
-                if (vcur + l < v1) vr = V.rec[vcur + l];
+                if (vcur + l < V.n) vr = V.rec[vcur + l];
             }
             wave_sync();
         }
@@ -275,13 +361,35 @@ __global__ __launch_bounds__(256, 6) void k_extract_phase(VarView V, ReadView R,
         const bool any = __ballot(had_any) != 0;
         if (l == 0) {
             const bool dropped = fail_op != 0x7fffffff;
-            O.row_off[r] = (uint32_t)my_base;
-            O.row_cnt[r] = dropped ? 0 : n_emit;
-            O.row_fail[r] = fail_op;
-            O.row_flags[r] = (!dropped && any && n_emit == 0) ? 1 : 0;
+            h[H_KIND] = direct ? ROW_GLOBAL : ROW_BUFFERED;
+            h[H_ROFF] = direct ? (int)(uint32_t)direct_base : row_start;
+            h[H_RCNT] = dropped ? 0 : n_emit;
+            h[H_RFAIL] = fail_op;
+            h[H_RFLAGS] = (!dropped && any && n_emit == 0) ? 1 : 0;
         }
         if (l >= n_clip && l < LPS_CLIP_SLOTS) C.opidx_fb[(size_t)r * LPS_CLIP_SLOTS + l] = -1;   // unused slots
+        q = qn;
     }
+    wave_sync();
+    // ---- one reservation for the buffered rows of the wave, coalesced copy-out, row descriptors
+    unsigned long long off = 0;
+    if (n_buf > 0) {
+        if (l == 0) off = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)n_buf);
+        off = __shfl(off, 0);
+        if (off + (unsigned long long)n_buf > O.arena_size) arena_full = true;
+    }
+    const unsigned long long g0 = arena_lo + off;
+    if (!arena_full) for (int i = l; i < n_buf; i += 64) { O.var[g0 + i] = bvar[i]; O.aq[g0 + i] = baq[i]; }
+    if (arena_full && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW);          // the host grows the arenas and reruns
+    if (l < nq) {
+        const int *hp = hdr + l * H_WORDS; const int r = r0 + l; const int kind = hp[H_KIND];
+        const bool ok = kind != ROW_DEAD && !arena_full;
+        O.row_off[r] = !ok ? 0u : (kind == ROW_BUFFERED ? (uint32_t)(g0 + (unsigned)hp[H_ROFF]) : (uint32_t)hp[H_ROFF]);
+        O.row_cnt[r] = ok ? hp[H_RCNT] : 0;
+        O.row_fail[r] = ok ? hp[H_RFAIL] : 0x7fffffff;
+        O.row_flags[r] = ok ? (uint8_t)hp[H_RFLAGS] : (uint8_t)0;
+    }
+    if (arena_full && l < 4 * nq) C.opidx_fb[(size_t)(r0 + (l >> 2)) * LPS_CLIP_SLOTS + (l & 3)] = -1;
 }
 
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,

@@ -72,6 +72,58 @@ __device__ __forceinline__ bool op_consumes_query(int op) { return op == 0 || op
 __device__ __forceinline__ bool op_is_match(int op) { return op == 0 || op == 7 || op == 8; }
 
 
+// ---- CIGAR staging, 8 consecutive ops per lane (a 512-op segment per wave): per-op work is a handful of VALU instructions and the wave-wide
+//      prefix scan runs once per segment instead of once per 64 ops.
+struct __attribute__((packed, aligned(4))) LpsU4 { uint32_t x, y, z, w; };
+// ops [i0, i0+8) of a CIGAR of n ops; 6u (op P, length 0: consumes nothing) beyond its end.  May read up to 7 words past the end of the
+// CIGAR array: DevBuf allocations carry 64 B of slack.
+__device__ __forceinline__ void load_ops8(const uint32_t *cig, int i0, int n, uint32_t (&w)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = 6u;
+    if (i0 < n) {
+        const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cig + i0), b = *reinterpret_cast<const LpsU4 *>(cig + i0 + 4);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        if (i0 + 8 > n) {
+#pragma unroll
+            for (int k = 1; k < 8; ++k) if (i0 + k >= n) w[k] = 6u;
+        }
+    }
+}
+// bit 0: the op consumes the reference (M D N = X: 0x18D), bit 16: it consumes the query (M I S = X: 0x193); ops 9..15 consume nothing
+__device__ __forceinline__ unsigned op_consume_bits(unsigned op) { return ((0x193u << 16) | 0x18Du) >> op; }
+__device__ __forceinline__ int bit_mask(unsigned x, int bit) { return (int)(x << (31 - bit)) >> 31; }      // 0 or -1 (v_bfe_i32)
+
+// Stages the segment whose words are in w (lane l owns ops 8l..8l+7 of it) in LDS: sref/sqry = reference / query position at which the op
+// starts, scig = the raw word.  ref_pos / q_pos (wave-uniform) advance over the segment.  Returns, per lane, 0 iff one of its ops is a
+// soft / hard clip (the caller then looks closer); my_ref = reference position of the lane's first op.
+__device__ __forceinline__ unsigned stage_ops8(const uint32_t (&w)[8], int l, int &ref_pos, int &q_pos, int *sref, int *sqry, uint32_t *scig, int &my_ref) {
+    // lane totals first, positions in a second sweep over the same 8 words: holding 16 prefix values across the wave scan would cost the
+    // kernels a wave of occupancy, recomputing them costs 40 instructions per segment
+    int rt = 0, qt = 0; unsigned cm = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned t = op_consume_bits(w[k] & 15u); const int len = (int)(w[k] >> 4);
+        rt += len & bit_mask(t, 0); qt += len & bit_mask(t, 16);
+        cm = min(cm, (w[k] & 14u) ^ 4u);
+    }
+    const int ir = wave_incl_scan_dpp(rt), iq = wave_incl_scan_dpp(qt);
+    my_ref = ref_pos + ir - rt; int rr = my_ref, qq = q_pos + iq - qt;
+    int4 *dr = reinterpret_cast<int4 *>(sref + 8 * l), *dq = reinterpret_cast<int4 *>(sqry + 8 * l); uint4 *dc = reinterpret_cast<uint4 *>(scig + 8 * l);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int pr[4], pq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned t = op_consume_bits(w[4 * h + k] & 15u); const int len = (int)(w[4 * h + k] >> 4);
+            pr[k] = rr; pq[k] = qq; rr += len & bit_mask(t, 0); qq += len & bit_mask(t, 16);
+        }
+        dr[h] = make_int4(pr[0], pr[1], pr[2], pr[3]); dq[h] = make_int4(pq[0], pq[1], pq[2], pq[3]);
+        dc[h] = make_uint4(w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]);
+    }
+    ref_pos += __shfl(ir, 63); q_pos += __shfl(iq, 63);
+    return cm;
+}
+
 // first variant with pos >= key: one bucket lookup narrows the range to the variants of a 1-kb window, then one
 // 64-wide probe round (falls back to the 64-ary search for very dense windows).  Wave-uniform.
 __device__ __forceinline__ int var_lower_bound(const VarView &V, int key) {
