@@ -54,6 +54,7 @@ struct lps_ctx {
     DevBuf<int32_t> obs_var, g_node; DevBuf<uint16_t> obs_aq; DevBuf<uint8_t> g_flag;
     unsigned long long obs_capacity = 0;   // main arenas (LPS_ARENAS equal parts); a tail arena of obs_capacity/4 follows
     DevBuf<unsigned long long> arena_ctr;
+    DevBuf<uint8_t> zpool;        // the zero-initialised arrays of a phase run (arena_ctr, out_ps/gt, deleted, is_node, vtype_key, mrow_cnt, node_end/cur, bsize, cnt4) are carved from it
     // clips / cnv
     DevBuf<int32_t> clip_pos, clip_op; size_t clip_capacity = 0;
     DevBuf<unsigned long long> clip_keys, clip_keys_s;
@@ -564,9 +565,8 @@ static int run_phase(lps_ctx *c) {
         const unsigned long long cap_main = c->obs_capacity, arena_size = cap_main / n_arenas, tail_size = cap_main / 4 + 4096;
         const unsigned long long cap = cap_main + tail_size;
         if (cap > 0xffffffffull) { c->err = "observation arena exceeds 2^32 slots"; return -8; }
-        c->arena_ctr.reserve(LPS_ARENAS * 8);
         c->row_off.reserve(nR + 1); c->row_cnt.reserve(nR + 1); c->row_fail.reserve(nR + 1); c->row_flags.reserve(nR + 1);
-        c->g_cnt.reserve(nR + 1); c->deleted.reserve(nR + 1);
+        c->g_cnt.reserve(nR + 1);
         c->obs_var.reserve(cap); c->obs_aq.reserve(cap); c->g_node.reserve(cap); c->g_flag.reserve(cap);
         c->clip_capacity = (size_t)LPS_CLIP_SLOTS * nR + 64;
         c->clip_pos.reserve(c->clip_capacity); c->clip_op.reserve(c->clip_capacity);
@@ -574,23 +574,31 @@ static int run_phase(lps_ctx *c) {
         c->cnv_start.reserve(LPS_MAX_CNV); c->cnv_end.reserve(LPS_MAX_CNV);
         c->name_keys.reserve(nR + 1); c->name_keys_s.reserve(nR + 1);
         c->head.reserve(nR + 1); c->gidx.reserve(nR + 1); c->gstart.reserve(nR + 2); c->read_group.reserve(nR + 1); c->stack.reserve(nR + 1);
-        c->mrow_off.reserve(nR + 1); c->mrow_cnt.reserve(nR + 1); c->koff.reserve(nR + 1);
-        c->is_node.reserve(nV + 1); c->vtype_key.reserve(nV + 1); c->node_of.reserve(nV + 1); c->node_off.reserve(nV + 2); c->node_end.reserve(nV + 2); c->node_cur.reserve(nV + 2); c->multi_list.reserve(nR + 1);
-        c->bsize.reserve(nV + 1); c->cnt4.reserve((size_t)nV * 4 + 4); c->nodes.reserve(nV + 1); c->block.reserve(nV + 1);
+        c->mrow_off.reserve(nR + 1); c->koff.reserve(nR + 1);
+        c->node_of.reserve(nV + 1); c->node_off.reserve(nV + 2); c->multi_list.reserve(nR + 1);
+        c->nodes.reserve(nV + 1); c->block.reserve(nV + 1);
         c->ntype.reserve(nV + 1); c->hp.reserve(nV + 1);
         c->erec.reserve((size_t)nV * A + 64); c->clip_stats.reserve(4);
         c->hp_v.reserve(2 * ((size_t)nV + 64)); c->blk_v.reserve(2 * ((size_t)nV + 64)); c->seg_i32.reserve(4 * (size_t)scan_segments(nV) + 4); c->node_pairs.reserve(nV + 1); c->nstate.reserve(nV + 1);
         c->st_b.reserve(scan_state_bytes(nV)); c->st_e.reserve(scan_state_bytes(nV)); c->edge.reserve((size_t)nV * A * 4 + 16);
-        c->out_ps.reserve(nV + 1); c->out_gt.reserve(nV + 1);
+        // everything that has to start a run as zeros sits in ONE allocation cleared by one fill (a dozen separate fills cost ~4 us each)
+        size_t zbytes = 0;
+        auto zslot = [&](size_t bytes) { const size_t at = zbytes; zbytes += (bytes + 255) & ~(size_t)255; return at; };
+        const size_t z_arena = zslot(LPS_ARENAS * 8 * sizeof(unsigned long long)), z_ps = zslot(((size_t)nV + 1) * 4), z_gt = zslot((size_t)nV + 1),
+                     z_del = zslot((size_t)nR + 1), z_isn = zslot(((size_t)nV + 1) * 4), z_vtk = zslot(((size_t)nV + 1) * 4), z_mrc = zslot(((size_t)nR + 1) * 4),
+                     z_nend = zslot(((size_t)nV + 2) * 4), z_ncur = zslot(((size_t)nV + 2) * 4), z_bs = zslot(((size_t)nV + 1) * 4), z_c4 = zslot(((size_t)nV * 4 + 4) * 4);
+        c->zpool.reserve(zbytes);
+        c->arena_ctr.carve(c->zpool.p + z_arena, LPS_ARENAS * 8); c->out_ps.carve(c->zpool.p + z_ps, (size_t)nV + 1); c->out_gt.carve(c->zpool.p + z_gt, (size_t)nV + 1);
+        c->deleted.carve(c->zpool.p + z_del, (size_t)nR + 1); c->is_node.carve(c->zpool.p + z_isn, (size_t)nV + 1); c->vtype_key.carve(c->zpool.p + z_vtk, (size_t)nV + 1);
+        c->mrow_cnt.carve(c->zpool.p + z_mrc, (size_t)nR + 1); c->node_end.carve(c->zpool.p + z_nend, (size_t)nV + 2); c->node_cur.carve(c->zpool.p + z_ncur, (size_t)nV + 2);
+        c->bsize.carve(c->zpool.p + z_bs, (size_t)nV + 1); c->cnt4.carve(c->zpool.p + z_c4, (size_t)nV * 4 + 4);
         const size_t need = GraphTemp::need((size_t)std::max<unsigned long long>(cap, (unsigned long long)std::max(nR, nV) + 1));
         if (need > c->temp_bytes) { c->temp.reserve(need); c->temp_bytes = need; }
 
         for (auto &u : c->ev_used) u = false;
         HIP_TRY(hipEventRecord(c->ev_begin, s));
         HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
-        HIP_TRY(hipMemsetAsync(c->arena_ctr.p, 0, LPS_ARENAS * 8 * sizeof(unsigned long long), s));
-        HIP_TRY(hipMemsetAsync(c->out_ps.p, 0, (size_t)nV * sizeof(int32_t), s));
-        HIP_TRY(hipMemsetAsync(c->out_gt.p, 0, (size_t)nV, s));
+        HIP_TRY(hipMemsetAsync(c->zpool.p, 0, zbytes, s));
         // ---- a4/a5/a6 variant table prep
         c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8);
         c->v_rec.reserve((size_t)nV + 1);
@@ -624,7 +632,6 @@ static int run_phase(lps_ctx *c) {
         launch_groups(c->name_keys_s.p, nR, c->d_cnt, c->head.p, c->gidx.p, c->gstart.p, c->read_group.p, c->temp.p, c->temp_bytes, s);
         // ---- a8 overlap filter
         mark(c, ST_OVERLAP);
-        HIP_TRY(hipMemsetAsync(c->deleted.p, 0, nR, s));
         launch_overlap_filter(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->row_cnt.p, c->obs_var.p, c->v_pos.p, P.overlap_threshold, c->stack.p, c->deleted.p, s);
         // ---- a9 CNV mismatch filter: only when intervals exist (the count arrived while the kernels above were running)
         mark(c, ST_CNV);
@@ -638,20 +645,15 @@ static int run_phase(lps_ctx *c) {
         }
         // ---- a10 nodes + graph observations
         mark(c, ST_NODES);
-        HIP_TRY(hipMemsetAsync(c->is_node.p, 0, (size_t)(nV + 1) * 4, s));
-        HIP_TRY(hipMemsetAsync(c->vtype_key.p, 0, (size_t)(nV + 1) * 4, s));
         launch_nodes(nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->is_node.p, c->vtype_key.p, c->node_of.p, c->nodes.p, c->ntype.p, P.base_quality, c->g_node.p, c->g_flag.p, c->g_cnt.p, c->d_cnt, c->temp.p, c->temp_bytes, s);
         // ---- merged rows
         mark(c, ST_MERGE);
-        HIP_TRY(hipMemsetAsync(c->mrow_cnt.p, 0, (size_t)(nR + 1) * 4, s));
         launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, cap_main, tail_size, c->mrow_off.p, c->mrow_cnt.p, c->multi_list.p, s);
         // ---- node-major sorted lists
         mark(c, ST_NODELISTS);
         c->m_bits = bits_for((unsigned long long)nR + 1); c->n_bits = bits_for((unsigned long long)nV + 2); c->a_bits = 16;
         if (c->m_bits + c->n_bits + c->a_bits > 63) { c->err = "sort key overflow"; return -4; }
         c->nkeys.reserve(n_keys + 1); c->nkeys_s.reserve(n_keys + 1); c->nvals.reserve(n_keys + 1); c->nvals_s.reserve(n_keys + 1);
-        HIP_TRY(hipMemsetAsync(c->node_end.p, 0, (size_t)(nV + 2) * 4, s));      // per-node entry counts
-        HIP_TRY(hipMemsetAsync(c->node_cur.p, 0, (size_t)(nV + 2) * 4, s));      // scatter cursors
         launch_node_lists(c->d_cnt, nR, nV, c->mrow_off.p, c->mrow_cnt.p, c->koff.p, c->g_node.p, c->m_bits, c->a_bits, c->n_bits, c->nkeys.p, c->nkeys_s.p, c->nvals.p, c->nvals_s.p, n_keys, c->node_off.p, c->node_end.p, c->node_cur.p, c->temp.p, c->temp_bytes, s);
         // ---- a11/a12 edges
         mark(c, ST_EDGES);
@@ -661,8 +663,6 @@ static int run_phase(lps_ctx *c) {
         launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->v_pos.p, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2, c->hp.p, c->block.p, s);
         // ---- a14/a15 read correction + export
         mark(c, ST_CORR);
-        HIP_TRY(hipMemsetAsync(c->bsize.p, 0, (size_t)(nV + 1) * 4, s));
-        HIP_TRY(hipMemsetAsync(c->cnt4.p, 0, ((size_t)nV * 4 + 4) * 4, s));
         launch_correction(c->d_cnt, nR, nV, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->v_pos.p, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, c->node_pairs.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
         mark(c, ST_D2H);
         HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));

@@ -26,12 +26,15 @@ template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool carved = false;       // p points into another allocation (see ZeroPool in lps_abi.hip): not owned
+    ~DevBuf() { if (p && !carved) (void)hipFree(p); }
+    void carve(void *q, size_t n) { if (p && !carved) (void)hipFree(p); p = (T *)q; cap = n; carved = true; }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     void reserve(size_t n, hipStream_t s = nullptr, bool keep = false, size_t used = 0) {
         if (n <= cap) return;
+        if (carved) { p = nullptr; cap = 0; carved = false; }
         size_t nc = cap ? cap : 256;
         while (nc < n) nc = nc + nc / 2 + 256;
         T *q = nullptr;

@@ -21,9 +21,9 @@
 template <int MODE>
 __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary,
                                                         LpsCounters *cnt) {
-    __shared__ int s_ref[4][LPS_SEG];
-    __shared__ int s_qry[4][LPS_SEG];
-    __shared__ uint32_t s_cig[4][LPS_SEG + 1];
+    __shared__ __attribute__((aligned(16))) int s_ref[4][LPS_SEG];
+    __shared__ __attribute__((aligned(16))) int s_qry[4][LPS_SEG];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cig[4][LPS_SEG + 4];
     const int w = threadIdx.x >> 6, l = lane_id();
     const int r = blockIdx.x * 4 + w;
     if (r >= R.n) return;
@@ -56,23 +56,14 @@ __global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, H
             uint2 vr = make_uint2(0x7fffffffu, 0u);
             if (vcur + l < V.n) vr = V.rec[vcur + l];
             const uint32_t nextw = (seg0 + nseg < n_cig) ? cig[seg0 + nseg] : 0xfu;
-            uint32_t wds[LPS_SEG / 64];
-            bool bad = false;
+            uint32_t wds[8];                                         // 8 consecutive ops per lane (lps_kernels.h)
+            load_ops8(cig + seg0, 8 * l, nseg, wds);
+            unsigned mxop = 0;
 #pragma unroll
-            for (int u = 0; u < LPS_SEG / 64; ++u) { const int idx = u * 64 + l; wds[u] = idx < nseg ? cig[seg0 + idx] : 6u; }
-#pragma unroll
-            for (int u = 0; u < LPS_SEG / 64; ++u) {
-                const int c0 = u * 64;
-                if (c0 >= nseg) break;
-                const int idx = c0 + l;
-                const uint32_t wd = wds[u];
-                const int op = idx < nseg ? (int)(wd & 15) : 6, len = (int)(wd >> 4);
-                if (op > 8) bad = true;
-                const int radv = op_consumes_ref(op) ? len : 0, qadv = op_consumes_query(op) ? len : 0;
-                const int ir = wave_incl_scan_dpp(radv), iq = wave_incl_scan_dpp(qadv);
-                if (idx < nseg) { sref[idx] = ref_pos + ir - radv; sqry[idx] = q_pos + iq - qadv; scig[idx] = wd; }
-                ref_pos += __shfl(ir, 63); q_pos += __shfl(iq, 63);
-            }
+            for (int u = 0; u < 8; ++u) mxop = max(mxop, wds[u] & 15u);
+            const bool bad = mxop > 8u;
+            int my_ref;
+            (void)stage_ops8(wds, l, ref_pos, q_pos, sref, sqry, scig, my_ref);
             if (__ballot(bad) && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
             if (l == 0) scig[nseg] = nextw;
             wave_sync();
