@@ -20,10 +20,10 @@
 #include "lps_stdsort.h"
 
 static const char *kStageNames[LPS_MAX_STAGES] = {
-    "variant_prep", "extract", "name_keys", "clip_cnv", "name_groups", "overlap_filter", "cnv_filter", "nodes", "merge_rows",
+    "variant_prep", "extract", "name_keys", "name_groups", "overlap_filter", "clip_cnv", "cnv_filter", "nodes", "merge_rows",
     "node_lists", "edges", "vote_scan", "read_correction", "d2h", nullptr};
 // recorded in this order on the stream
-enum { ST_PREP, ST_EXTRACT, ST_GROUPS, ST_CLIP, ST_GROUPS2, ST_OVERLAP, ST_CNV, ST_NODES, ST_MERGE, ST_NODELISTS, ST_EDGES, ST_SCAN, ST_CORR, ST_D2H, ST_COUNT };
+enum { ST_PREP, ST_EXTRACT, ST_GROUPS, ST_GROUPS2, ST_OVERLAP, ST_CLIP, ST_CNV, ST_NODES, ST_MERGE, ST_NODELISTS, ST_EDGES, ST_SCAN, ST_CORR, ST_D2H, ST_COUNT };
 
 struct lps_ctx {
     int device = 0;
@@ -54,6 +54,7 @@ struct lps_ctx {
     DevBuf<int32_t> obs_var, g_node; DevBuf<uint16_t> obs_aq; DevBuf<uint8_t> g_flag;
     unsigned long long obs_capacity = 0;   // main arenas (LPS_ARENAS equal parts); a tail arena of obs_capacity/4 follows
     DevBuf<unsigned long long> arena_ctr;
+    size_t z_late_off = 0, z_late_bytes = 0; unsigned long long late_n_keys = 0, late_cap_main = 0, late_tail = 0; bool cnv_skipped = false;
     DevBuf<uint8_t> zpool;        // the zero-initialised arrays of a phase run (arena_ctr, out_ps/gt, deleted, is_node, vtype_key, mrow_cnt, node_end/cur, bsize, cnt4) are carved from it
     // clips / cnv
     DevBuf<int32_t> clip_pos, clip_op; size_t clip_capacity = 0;
@@ -61,7 +62,7 @@ struct lps_ctx {
     DevBuf<int32_t> cnv_start, cnv_end;
     DevBuf<long long> agg_sum; DevBuf<int32_t> agg_cnt; DevBuf<double> miss;
     DevBuf<uint32_t> cnv_flag, cnv_idx, cnv_list, cnv_nlist; DevBuf<uint8_t> cnv_tab, cnv_btab, cnv_bstart, cnv_entry;
-    unsigned *h_ncnv = nullptr; hipEvent_t ev_cnv = nullptr;   // pinned word + event: n_cnv reaches the host while the GPU keeps working
+    unsigned *h_ncnv = nullptr; LpsCounters *h_cnt_pin = nullptr; unsigned *h_stats_pin = nullptr; hipEvent_t ev_cnv = nullptr;   // pinned word + event: n_cnv reaches the host while the GPU keeps working
     // groups
     DevBuf<unsigned long long> name_keys, name_keys_s;
     DevBuf<uint32_t> head, gidx, gstart, read_group, stack, mrow_off, koff; DevBuf<int32_t> mrow_cnt;
@@ -167,7 +168,9 @@ lps_ctx *lps_create(int device, const lps_params *params) {
         HIP_TRY(hipMalloc((void **)&c->d_cnt, sizeof(LpsCounters)));
         for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventCreate(&c->ev_begin)); HIP_TRY(hipEventCreate(&c->ev_end)); HIP_TRY(hipEventCreate(&c->ev_cnv));
-        HIP_TRY(hipHostMalloc((void **)&c->h_ncnv, 64));
+        HIP_TRY(hipHostMalloc((void **)&c->h_ncnv, 1024));          // pinned: copies into it do not block the host
+        c->h_cnt_pin = (LpsCounters *)(c->h_ncnv + 16); c->h_stats_pin = c->h_ncnv + 192;
+        static_assert(sizeof(LpsCounters) <= 512, "pinned block layout");
     } catch (std::string &e) { fprintf(stderr, "lps_create: %s\n", e.c_str()); delete c; return nullptr; }
     return c;
 }
@@ -553,6 +556,54 @@ static ReadView read_view(lps_ctx *c) {
     return R;
 }
 
+// Stages after the overlap filter and the clip statistics.  with_cnv = false is the first, speculative run (no CNV interval assumed); with_cnv =
+// true runs them again with the CNV mismatch filter after clearing what they accumulate (tail of the zero pool, late counters).
+static int run_late(lps_ctx *c, bool with_cnv) {
+    hipStream_t s = c->stream; const lps_params &P = c->P; const int nR = c->nR, nV = c->nV, A = P.connect_adjacent;
+    {
+        if (with_cnv) {
+            HIP_TRY(hipMemsetAsync(c->zpool.p + c->z_late_off, 0, c->z_late_bytes, s));
+            HIP_TRY(hipMemsetAsync(&c->d_cnt->n_pairs, 0, offsetof(LpsCounters, arena_max) - offsetof(LpsCounters, n_pairs), s));
+            HIP_TRY(hipMemsetAsync(c->clip_stats.p + 2, 0, 2 * sizeof(unsigned), s));
+        }
+        // ---- a9 CNV mismatch filter: only when intervals exist (the count arrived while the kernels above were running)
+        mark(c, ST_CNV);
+        c->cnv_skipped = !with_cnv;
+        if (with_cnv) {
+            c->agg_sum.reserve((size_t)nV * 2 + 2); c->agg_cnt.reserve((size_t)nV * 2 + 2); c->miss.reserve(nV + 1);
+            c->cnv_flag.reserve(nR + 1); c->cnv_idx.reserve(nR + 1); c->cnv_list.reserve(nR + 1); c->cnv_nlist.reserve(4);
+            c->cnv_tab.reserve((size_t)nR * 64 + 64); c->cnv_btab.reserve(((size_t)nR / 256 + 2) * 64); c->cnv_bstart.reserve((size_t)nR / 256 + 2); c->cnv_entry.reserve(nR + 1);
+            CnvScratch W{c->cnv_flag.p, c->cnv_idx.p, c->cnv_list.p, c->cnv_nlist.p, c->cnv_tab.p, c->cnv_btab.p, c->cnv_bstart.p, c->cnv_entry.p};
+            launch_cnv_filter(c->d_cnt, nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->v_pos.p, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, W, c->temp.p, c->temp_bytes, s);
+        }
+        // ---- a10 nodes + graph observations
+        mark(c, ST_NODES);
+        launch_nodes(nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->is_node.p, c->vtype_key.p, c->node_of.p, c->nodes.p, c->ntype.p, P.base_quality, c->g_node.p, c->g_flag.p, c->g_cnt.p, c->d_cnt, c->temp.p, c->temp_bytes, s);
+        // ---- merged rows
+        mark(c, ST_MERGE);
+        launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->late_cap_main, c->late_tail, c->mrow_off.p, c->mrow_cnt.p, c->multi_list.p, s);
+        // ---- node-major sorted lists
+        mark(c, ST_NODELISTS);
+        c->m_bits = bits_for((unsigned long long)nR + 1); c->n_bits = bits_for((unsigned long long)nV + 2); c->a_bits = 16;
+        if (c->m_bits + c->n_bits + c->a_bits > 63) { c->err = "sort key overflow"; return -4; }
+        c->nkeys.reserve(c->late_n_keys + 1); c->nkeys_s.reserve(c->late_n_keys + 1); c->nvals.reserve(c->late_n_keys + 1); c->nvals_s.reserve(c->late_n_keys + 1);
+        launch_node_lists(c->d_cnt, nR, nV, c->mrow_off.p, c->mrow_cnt.p, c->koff.p, c->g_node.p, c->m_bits, c->a_bits, c->n_bits, c->nkeys.p, c->nkeys_s.p, c->nvals.p, c->nvals_s.p, c->late_n_keys, c->node_off.p, c->node_end.p, c->node_cur.p, c->temp.p, c->temp_bytes, s);
+        // ---- a11/a12 edges
+        mark(c, ST_EDGES);
+        launch_edges(c->d_cnt, nV, c->node_off.p, c->node_end.p, c->nkeys_s.p, c->nvals_s.p, c->mrow_off.p, c->mrow_cnt.p, c->m_bits, c->a_bits, c->g_node.p, c->g_flag.p, A, P.edge_weight, P.edge_threshold, c->ntype.p, c->edge.p, c->erec.p, c->node_pairs.p, s);
+        // ---- a13 vote scan
+        mark(c, ST_SCAN);
+        launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->v_pos.p, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2, c->hp.p, c->block.p, s);
+        // ---- a14/a15 read correction + export
+        mark(c, ST_CORR);
+        launch_correction(c->d_cnt, nR, nV, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->v_pos.p, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, c->node_pairs.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
+        mark(c, ST_D2H);
+        HIP_TRY(hipMemcpyAsync(c->h_cnt_pin, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));      // read by lps_phase_chromosome after its sync
+        HIP_TRY(hipMemcpyAsync(c->h_stats_pin, c->clip_stats.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        return 0;
+    }
+}
+
 static int run_phase(lps_ctx *c) {
     const lps_params &P = c->P; hipStream_t s = c->stream;
     const int nR = c->nR, nV = c->nV, A = P.connect_adjacent;
@@ -584,10 +635,11 @@ static int run_phase(lps_ctx *c) {
         // everything that has to start a run as zeros sits in ONE allocation cleared by one fill (a dozen separate fills cost ~4 us each)
         size_t zbytes = 0;
         auto zslot = [&](size_t bytes) { const size_t at = zbytes; zbytes += (bytes + 255) & ~(size_t)255; return at; };
-        const size_t z_arena = zslot(LPS_ARENAS * 8 * sizeof(unsigned long long)), z_ps = zslot(((size_t)nV + 1) * 4), z_gt = zslot((size_t)nV + 1),
-                     z_del = zslot((size_t)nR + 1), z_isn = zslot(((size_t)nV + 1) * 4), z_vtk = zslot(((size_t)nV + 1) * 4), z_mrc = zslot(((size_t)nR + 1) * 4),
+        const size_t z_arena = zslot(LPS_ARENAS * 8 * sizeof(unsigned long long)), z_del = zslot((size_t)nR + 1),
+                     z_ps = zslot(((size_t)nV + 1) * 4), z_gt = zslot((size_t)nV + 1), z_isn = zslot(((size_t)nV + 1) * 4), z_vtk = zslot(((size_t)nV + 1) * 4), z_mrc = zslot(((size_t)nR + 1) * 4),
                      z_nend = zslot(((size_t)nV + 2) * 4), z_ncur = zslot(((size_t)nV + 2) * 4), z_bs = zslot(((size_t)nV + 1) * 4), z_c4 = zslot(((size_t)nV * 4 + 4) * 4);
         c->zpool.reserve(zbytes);
+        c->z_late_off = z_ps; c->z_late_bytes = zbytes - z_ps;       // what the stages after the overlap filter need zeroed (see run_late)
         c->arena_ctr.carve(c->zpool.p + z_arena, LPS_ARENAS * 8); c->out_ps.carve(c->zpool.p + z_ps, (size_t)nV + 1); c->out_gt.carve(c->zpool.p + z_gt, (size_t)nV + 1);
         c->deleted.carve(c->zpool.p + z_del, (size_t)nR + 1); c->is_node.carve(c->zpool.p + z_isn, (size_t)nV + 1); c->vtype_key.carve(c->zpool.p + z_vtk, (size_t)nV + 1);
         c->mrow_cnt.carve(c->zpool.p + z_mrc, (size_t)nR + 1); c->node_end.carve(c->zpool.p + z_nend, (size_t)nV + 2); c->node_cur.carve(c->zpool.p + z_ncur, (size_t)nV + 2);
@@ -611,63 +663,30 @@ static int run_phase(lps_ctx *c) {
         mark(c, ST_EXTRACT);
         launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, s);
         launch_arena_sum(c->arena_ctr.p, arena_size, c->d_cnt, s);
-        // ---- name keys (needs only row_cnt); S1: counters to host (sizes of the sorts)
+        // ---- name keys (needs only row_cnt) and clip keys; the counters (sizes of the sorts, errors) start their way to the host ...
         mark(c, ST_GROUPS);
         launch_name_keys(nR, c->r_name.p, c->row_cnt.p, c->name_keys.p, c->d_cnt, s);
         launch_clip_keys(C, c->row_fail.p, nR, c->clip_keys.p, c->d_cnt, s);
-        HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) { c->err = "alignment find unsupported CIGAR operation"; return -2; }
-        if (c->h_cnt.err & LPS_ERR_CLIP_OVERFLOW) { c->err = "clip event buffer overflow"; return -3; }
-        if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = (unsigned long long)n_arenas * (c->h_cnt.arena_max + c->h_cnt.arena_max / 4 + 1024); continue; }
-        const unsigned long long n_keys = c->h_cnt.obs_total;
-        if (n_keys + n_keys / 2 > cap) { /* leave room for merged tails */ }
-        // ---- a7 clips -> CNV intervals first, so that n_cnv travels to the host while the GPU works on the name groups
-        mark(c, ST_CLIP);
-        launch_clip_cnv(c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, c->cnv_start.p, c->cnv_end.p, c->clip_stats.p, c->d_cnt, s);
-        HIP_TRY(hipMemcpyAsync(c->h_ncnv, &c->d_cnt->n_cnv, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(c->h_cnt_pin, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(c->ev_cnv, s));
+        // ---- ... while the GPU sorts the names into groups and runs the overlap filter (a8): no bubble when the host looks at them
         mark(c, ST_GROUPS2);
         sort_keys64(c->temp.p, c->temp_bytes, c->name_keys.p, c->name_keys_s.p, nR, 64, s);
         launch_groups(c->name_keys_s.p, nR, c->d_cnt, c->head.p, c->gidx.p, c->gstart.p, c->read_group.p, c->temp.p, c->temp_bytes, s);
-        // ---- a8 overlap filter
         mark(c, ST_OVERLAP);
         launch_overlap_filter(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->row_cnt.p, c->obs_var.p, c->v_pos.p, P.overlap_threshold, c->stack.p, c->deleted.p, s);
-        // ---- a9 CNV mismatch filter: only when intervals exist (the count arrived while the kernels above were running)
-        mark(c, ST_CNV);
         HIP_TRY(hipEventSynchronize(c->ev_cnv));
-        if (*c->h_ncnv) {
-            c->agg_sum.reserve((size_t)nV * 2 + 2); c->agg_cnt.reserve((size_t)nV * 2 + 2); c->miss.reserve(nV + 1);
-            c->cnv_flag.reserve(nR + 1); c->cnv_idx.reserve(nR + 1); c->cnv_list.reserve(nR + 1); c->cnv_nlist.reserve(4);
-            c->cnv_tab.reserve((size_t)nR * 64 + 64); c->cnv_btab.reserve(((size_t)nR / 256 + 2) * 64); c->cnv_bstart.reserve((size_t)nR / 256 + 2); c->cnv_entry.reserve(nR + 1);
-            CnvScratch W{c->cnv_flag.p, c->cnv_idx.p, c->cnv_list.p, c->cnv_nlist.p, c->cnv_tab.p, c->cnv_btab.p, c->cnv_bstart.p, c->cnv_entry.p};
-            launch_cnv_filter(c->d_cnt, nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->v_pos.p, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, W, c->temp.p, c->temp_bytes, s);
-        }
-        // ---- a10 nodes + graph observations
-        mark(c, ST_NODES);
-        launch_nodes(nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->is_node.p, c->vtype_key.p, c->node_of.p, c->nodes.p, c->ntype.p, P.base_quality, c->g_node.p, c->g_flag.p, c->g_cnt.p, c->d_cnt, c->temp.p, c->temp_bytes, s);
-        // ---- merged rows
-        mark(c, ST_MERGE);
-        launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, cap_main, tail_size, c->mrow_off.p, c->mrow_cnt.p, c->multi_list.p, s);
-        // ---- node-major sorted lists
-        mark(c, ST_NODELISTS);
-        c->m_bits = bits_for((unsigned long long)nR + 1); c->n_bits = bits_for((unsigned long long)nV + 2); c->a_bits = 16;
-        if (c->m_bits + c->n_bits + c->a_bits > 63) { c->err = "sort key overflow"; return -4; }
-        c->nkeys.reserve(n_keys + 1); c->nkeys_s.reserve(n_keys + 1); c->nvals.reserve(n_keys + 1); c->nvals_s.reserve(n_keys + 1);
-        launch_node_lists(c->d_cnt, nR, nV, c->mrow_off.p, c->mrow_cnt.p, c->koff.p, c->g_node.p, c->m_bits, c->a_bits, c->n_bits, c->nkeys.p, c->nkeys_s.p, c->nvals.p, c->nvals_s.p, n_keys, c->node_off.p, c->node_end.p, c->node_cur.p, c->temp.p, c->temp_bytes, s);
-        // ---- a11/a12 edges
-        mark(c, ST_EDGES);
-        launch_edges(c->d_cnt, nV, c->node_off.p, c->node_end.p, c->nkeys_s.p, c->nvals_s.p, c->mrow_off.p, c->mrow_cnt.p, c->m_bits, c->a_bits, c->g_node.p, c->g_flag.p, A, P.edge_weight, P.edge_threshold, c->ntype.p, c->edge.p, c->erec.p, c->node_pairs.p, s);
-        // ---- a13 vote scan
-        mark(c, ST_SCAN);
-        launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->v_pos.p, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2, c->hp.p, c->block.p, s);
-        // ---- a14/a15 read correction + export
-        mark(c, ST_CORR);
-        launch_correction(c->d_cnt, nR, nV, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->v_pos.p, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, c->node_pairs.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
-        mark(c, ST_D2H);
-        HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(c->h_stats, c->clip_stats.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-        return 0;
+        c->h_cnt = *c->h_cnt_pin;
+        if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) { c->err = "alignment find unsupported CIGAR operation"; return -2; }
+        if (c->h_cnt.err & LPS_ERR_CLIP_OVERFLOW) { c->err = "clip event buffer overflow"; return -3; }
+        if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = (unsigned long long)n_arenas * (c->h_cnt.arena_max + c->h_cnt.arena_max / 4 + 1024); continue; }
+        // ---- a7 clips -> CNV intervals
+        mark(c, ST_CLIP);
+        launch_clip_cnv(c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, c->cnv_start.p, c->cnv_end.p, c->clip_stats.p, c->d_cnt, s);
+        c->late_n_keys = c->h_cnt.obs_total; c->late_cap_main = cap_main; c->late_tail = tail_size;
+        // ---- everything after: run on the assumption that the clips gave no CNV interval (the common case), so that the host never waits for
+        //      that count; lps_phase_chromosome looks at it when the results are back and runs the late stages again if the guess was wrong
+        return run_late(c, false);
     }
     c->err = "observation buffer kept overflowing";
     return -5;
@@ -688,6 +707,16 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         HIP_TRY(hipMemcpyAsync(out->gt, c->out_gt.p, (size_t)c->nV, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipEventRecord(c->ev_end, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        c->h_cnt = *c->h_cnt_pin; memcpy(c->h_stats, c->h_stats_pin, sizeof c->h_stats);
+        if (c->cnv_skipped && c->h_cnt.n_cnv != 0 && !(c->h_cnt.err & LPS_ERR_OBS_OVERFLOW)) {     // CNV intervals exist after all: late stages again, with the filter
+            rc = run_late(c, true);
+            if (rc != 0) return rc;
+            HIP_TRY(hipMemcpyAsync(out->phase_set, c->out_ps.p, (size_t)c->nV * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(out->gt, c->out_gt.p, (size_t)c->nV, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipEventRecord(c->ev_end, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->h_cnt = *c->h_cnt_pin; memcpy(c->h_stats, c->h_stats_pin, sizeof c->h_stats);
+        }
         if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = c->obs_capacity * 2 + 64 * 1024; return lps_phase_chromosome(c, out); }
         if (c->h_cnt.err & LPS_ERR_KEY_RANGE) return fail(c, "a merged read has more than 65536 observations", -6);
         if (c->h_cnt.err & LPS_ERR_CNV_CAP) return fail(c, "more than 64 CNV intervals on one chromosome", -7);
