@@ -62,6 +62,7 @@ struct lps_ctx {
     DevBuf<int32_t> cnv_start, cnv_end;
     DevBuf<long long> agg_sum; DevBuf<int32_t> agg_cnt; DevBuf<double> miss;
     DevBuf<uint32_t> cnv_flag, cnv_idx, cnv_list, cnv_nlist; DevBuf<uint8_t> cnv_tab, cnv_btab, cnv_bstart, cnv_entry;
+    uint8_t *h_res = nullptr; size_t h_res_bytes = 0;   // pinned landing zone of (phase_set, gt): one copy, then memcpy into the caller's arrays
     unsigned *h_ncnv = nullptr; LpsCounters *h_cnt_pin = nullptr; unsigned *h_stats_pin = nullptr; hipEvent_t ev_cnv = nullptr;   // pinned word + event: n_cnv reaches the host while the GPU keeps working
     // groups
     DevBuf<unsigned long long> name_keys, name_keys_s;
@@ -184,6 +185,7 @@ void lps_destroy(lps_ctx *c) {
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     if (c->ev_cnv) (void)hipEventDestroy(c->ev_cnv);
     if (c->h_ncnv) (void)hipHostFree(c->h_ncnv);
+    if (c->h_res) (void)hipHostFree(c->h_res);
     for (int k = 0; k < 2; ++k) { if (c->stage[k]) (void)hipHostFree(c->stage[k]); if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]); }
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -692,6 +694,19 @@ static int run_phase(lps_ctx *c) {
     return -5;
 }
 
+// out_ps and out_gt are neighbours in the zero pool: both leave in one copy into pinned memory (a copy into the caller's pageable arrays would be
+// staged by the runtime, twice, and block the host meanwhile)
+static size_t enqueue_result_copy(lps_ctx *c) {
+    const size_t span = (size_t)((uint8_t *)c->out_gt.p - (uint8_t *)c->out_ps.p) + (size_t)c->nV;
+    if (span > c->h_res_bytes) { if (c->h_res) HIP_TRY(hipHostFree(c->h_res)); c->h_res = nullptr; c->h_res_bytes = span + span / 4 + 4096; HIP_TRY(hipHostMalloc((void **)&c->h_res, c->h_res_bytes)); }
+    HIP_TRY(hipMemcpyAsync(c->h_res, c->out_ps.p, span, hipMemcpyDeviceToHost, c->stream));
+    return span;
+}
+static void deliver_result(lps_ctx *c, lps_phase_result *out) {
+    memcpy(out->phase_set, c->h_res, (size_t)c->nV * sizeof(int32_t));
+    memcpy(out->gt, c->h_res + ((uint8_t *)c->out_gt.p - (uint8_t *)c->out_ps.p), (size_t)c->nV);
+}
+
 int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
     if (!c || !out) return -1;
     try {
@@ -703,16 +718,14 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         if (c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
         int rc = run_phase(c);
         if (rc != 0) return rc;
-        HIP_TRY(hipMemcpyAsync(out->phase_set, c->out_ps.p, (size_t)c->nV * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(out->gt, c->out_gt.p, (size_t)c->nV, hipMemcpyDeviceToHost, c->stream));
+        (void)enqueue_result_copy(c);
         HIP_TRY(hipEventRecord(c->ev_end, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->h_cnt = *c->h_cnt_pin; memcpy(c->h_stats, c->h_stats_pin, sizeof c->h_stats);
         if (c->cnv_skipped && c->h_cnt.n_cnv != 0 && !(c->h_cnt.err & LPS_ERR_OBS_OVERFLOW)) {     // CNV intervals exist after all: late stages again, with the filter
             rc = run_late(c, true);
             if (rc != 0) return rc;
-            HIP_TRY(hipMemcpyAsync(out->phase_set, c->out_ps.p, (size_t)c->nV * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipMemcpyAsync(out->gt, c->out_gt.p, (size_t)c->nV, hipMemcpyDeviceToHost, c->stream));
+            (void)enqueue_result_copy(c);
             HIP_TRY(hipEventRecord(c->ev_end, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             c->h_cnt = *c->h_cnt_pin; memcpy(c->h_stats, c->h_stats_pin, sizeof c->h_stats);
@@ -720,6 +733,7 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = c->obs_capacity * 2 + 64 * 1024; return lps_phase_chromosome(c, out); }
         if (c->h_cnt.err & LPS_ERR_KEY_RANGE) return fail(c, "a merged read has more than 65536 observations", -6);
         if (c->h_cnt.err & LPS_ERR_CNV_CAP) return fail(c, "more than 64 CNV intervals on one chromosome", -7);
+        deliver_result(c, out);
         // timings
         lps_timings &t = c->tm; memset(&t, 0, sizeof t);
         t.n_stages = ST_COUNT;
