@@ -719,8 +719,12 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
 // Per node: lane (n & 63) owns the five vote accumulators of node n; the owner's decision is one v_readlane; the
 // A lanes of the following nodes add their votes with branch-free selects on the 8-byte vote records.
 #define SCAN_TILE 64
-#define SCAN_SEG 256
-#define SCAN_WARM 128
+#ifndef SCAN_SEG
+#define SCAN_SEG 64
+#endif
+#ifndef SCAN_WARM
+#define SCAN_WARM 64
+#endif
 
 struct Chain {
     float h1, h2, o1, o2; int vc;      // per lane: accumulators of the node this lane owns
@@ -858,35 +862,67 @@ __global__ __launch_bounds__(256) void k_scan_match(const LpsCounters *cnt, cons
     if (l == 0) match[seg] = bits;
 }
 
-// one wave: walk the segments in order.  With the boundary matches precomputed the chain is a handful of LDS reads per
-// segment; only a segment none of whose variants matches is replayed serially from the true state (records straight
-// from global memory), after which states are compared live until the walk is back on stored states.
+// One wave decides, for every segment, which of its two variants is the true walk and how the id of the block that is open at its start has to
+// be renamed.  With the boundary matches precomputed both are compositions of tiny functions - variant: {0,1} -> {0,1,none matches}, open
+// block: "keep" or "becomes b" - so each lane composes the functions of its own run of segments, the 64 lane results are chained with
+// v_readlane, and each lane replays its run with the true inputs: a few microseconds whatever the number of segments.  Only when a segment
+// has no matching variant on the true path does the wave fall back to walking the segments in order, replaying that segment serially from
+// the true state (records straight from global memory) and comparing states live until the walk is back on stored states.
 __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, const int32_t *nodes, const int32_t *vpos,
                                                     const unsigned long long *erec, int A, int distance,
                                                     int8_t *hp_v, int32_t *blk_v, size_t vstride,
                                                     const ScanState *st_b, const ScanState *st_e, const int32_t *match,
                                                     int32_t *chosen /*[seg]*/, int32_t *remap_from, int32_t *remap_to, unsigned *n_replayed) {
-    extern __shared__ int s_seg[];                                  // [n_seg][5]: match, bs_b[2], bs_e[2]
     const int l = lane_id();
     const int N = (int)cnt->n_nodes;
     const int n_seg = (N + SCAN_SEG - 1) / SCAN_SEG;
     if (n_seg == 0) return;
-    for (int q = l; q < n_seg; q += 64) {
-        s_seg[q * 5 + 0] = q ? match[q] : 0;
-        s_seg[q * 5 + 1] = st_b[q * 2 + 0].bs; s_seg[q * 5 + 2] = st_b[q * 2 + 1].bs;
-        s_seg[q * 5 + 3] = st_e[q * 2 + 0].bs; s_seg[q * 5 + 4] = st_e[q * 2 + 1].bs;
+    // variant of segment seg that continues variant p of segment seg-1 (2: neither)
+    auto next_variant = [](int m, int p) { return ((m >> (p * 2)) & 1) ? 0 : (((m >> (p * 2 + 1)) & 1) ? 1 : 2); };
+    {
+        const int chunk = (n_seg + 63) / 64, s0 = max(1, l * chunk), s1 = min(n_seg, (l + 1) * chunk);
+        int f0 = 0, f1 = 1;                                          // this lane's run of segments as a function of the incoming variant
+        for (int seg = s0; seg < s1; ++seg) { const int m = match[seg]; f0 = f0 == 2 ? 2 : next_variant(m, f0); f1 = f1 == 2 ? 2 : next_variant(m, f1); }
+        int vin = 0, v = 0;                                          // segment 0 starts at node 0: its variant 0 IS the true walk
+        for (int j = 0; j < 64; ++j) {
+            if (l == j) vin = v;
+            const int a0 = __builtin_amdgcn_readlane(f0, j), a1 = __builtin_amdgcn_readlane(f1, j);
+            v = v == 2 ? 2 : (v ? a1 : a0);
+        }
+        if (v != 2) {                                                // every boundary on the true path has a matching variant
+            int pv = vin, has_set = 0, last_val = 0;                 // open block after this lane's run: kept, or becomes last_val
+            for (int seg = s0; seg < s1; ++seg) {
+                const int mv = next_variant(match[seg], pv), open_spec = st_b[seg * 2 + mv].bs, end_bs = st_e[seg * 2 + mv].bs;
+                if (end_bs != open_spec) { has_set = 1; last_val = end_bs; }
+                pv = mv;
+            }
+            int cin = 0, cb = st_e[0].bs;
+            for (int j = 0; j < 64; ++j) {
+                if (l == j) cin = cb;
+                const int hs = __builtin_amdgcn_readlane(has_set, j), lv = __builtin_amdgcn_readlane(last_val, j);
+                cb = hs ? lv : cb;
+            }
+            pv = vin; int cur = cin;
+            for (int seg = s0; seg < s1; ++seg) {
+                const int mv = next_variant(match[seg], pv), open_spec = st_b[seg * 2 + mv].bs, end_bs = st_e[seg * 2 + mv].bs;
+                chosen[seg] = mv; remap_from[seg] = open_spec >= 0 ? open_spec : -2; remap_to[seg] = cur;
+                cur = (end_bs == open_spec) ? cur : end_bs;          // the block open at b is still open at e
+                pv = mv;
+            }
+            if (l == 0) { chosen[0] = 0; remap_from[0] = -2; remap_to[0] = -2; }
+            return;
+        }
     }
-    wave_sync();
-    int prev_v = 0, cur_bs = s_seg[3];                              // segment 0 starts at node 0: its variant 0 IS the true walk
+    int prev_v = 0, cur_bs = st_e[0].bs;
     bool live = false; Chain t; chain_init(t, 0);
     if (l == 0) { chosen[0] = 0; remap_from[0] = -2; remap_to[0] = -2; }
     for (int seg = 1; seg < n_seg; ++seg) {
         const int b = seg * SCAN_SEG, e = b + SCAN_SEG;
         int mv = -1;
-        if (!live) { const int m = s_seg[seg * 5]; mv = (m >> (prev_v * 2)) & 1 ? 0 : ((m >> (prev_v * 2 + 1)) & 1 ? 1 : -1); }
+        if (!live) { mv = next_variant(match[seg], prev_v); if (mv == 2) mv = -1; }
         else { if (state_equal(t, b, &st_b[seg * 2 + 0], l)) mv = 0; else if (state_equal(t, b, &st_b[seg * 2 + 1], l)) mv = 1; }
         if (mv >= 0) {
-            const int open_spec = s_seg[seg * 5 + 1 + mv], open_true = cur_bs, end_bs = s_seg[seg * 5 + 3 + mv];
+            const int open_spec = st_b[seg * 2 + mv].bs, open_true = cur_bs, end_bs = st_e[seg * 2 + mv].bs;
             if (l == 0) { chosen[seg] = mv; remap_from[seg] = open_spec >= 0 ? open_spec : -2; remap_to[seg] = open_true; }
             cur_bs = (end_bs == open_spec) ? open_true : end_bs;     // the block open at b is still open at e
             prev_v = mv; live = false;
@@ -1153,7 +1189,7 @@ void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, c
     const size_t vstride = (size_t)n_var + 64;
     hipLaunchKernelGGL(k_scan_spec, dim3(segs), dim3(128), 0, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (ScanState *)st_b, (ScanState *)st_e);
     hipLaunchKernelGGL(k_scan_match, dim3((segs + 3) / 4), dim3(256), 0, s, cnt, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs);
-    hipLaunchKernelGGL(k_scan_stitch, dim3(1), dim3(64), (size_t)segs * 5 * sizeof(int), s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, n_replayed);
+    hipLaunchKernelGGL(k_scan_stitch, dim3(1), dim3(64), 0, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, n_replayed);
     hipLaunchKernelGGL(k_scan_finalize, GRID(n_var, 256), 0, s, cnt, hp_v, blk_v, vstride, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, hp, block);
 }
 
