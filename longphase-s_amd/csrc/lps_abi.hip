@@ -751,7 +751,7 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         t.algorithmic_bytes[ST_EDGES] = 8ll * (int64_t)c->h_cnt.n_pairs + 8ll * (int64_t)c->h_cnt.n_obs_final + 16ll * c->P.connect_adjacent * (int64_t)c->h_cnt.n_nodes;
         t.algorithmic_bytes[ST_SCAN] = (16ll * c->P.connect_adjacent + 64) * (int64_t)c->h_cnt.n_nodes;
         t.algorithmic_bytes[ST_CORR] = 16ll * (int64_t)c->h_cnt.n_obs_final + 32ll * (int64_t)c->h_cnt.n_nodes;
-        t.n_scan_segments = (c->h_cnt.n_nodes + 255) / 256; t.n_scan_replayed = c->h_stats[2];
+        t.n_scan_segments = c->h_cnt.n_nodes ? scan_segments((int)c->h_cnt.n_nodes) - 1 : 0; t.n_scan_replayed = c->h_stats[2];
         c->phase_valid = true;
     } catch (std::string &e) { return fail(c, e); }
     return 0;

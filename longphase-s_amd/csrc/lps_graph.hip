@@ -20,6 +20,7 @@
 
 #include "lps_graph.h"
 #include "lps_stdsort.h"
+#include <cstdlib>
 
 // ================================================================================================ clips / CNV
 // thread per clip slot: keep events of ops before the op at which get_snp returned early (:1453-1455,1559-1561),
@@ -797,7 +798,8 @@ __global__ __launch_bounds__(128) void k_scan_spec(const LpsCounters *cnt, const
                                                    const unsigned long long *erec, int A, int distance,
                                                    int8_t *hp_v /*[2][N]*/, int32_t *blk_v /*[2][N]*/, size_t vstride,
                                                    ScanState *st_b /*[seg][2]*/, ScanState *st_e /*[seg][2]*/) {
-    __shared__ unsigned long long s_rec[2][SCAN_TILE * LPS_MAX_ADJACENT];
+    extern __shared__ unsigned long long s_rec_dyn[];              // [2][SCAN_TILE * A]: sized by the A in use, so that all segments are resident at once
+    unsigned long long *s_rec[2] = {s_rec_dyn, s_rec_dyn + SCAN_TILE * A};
     const int l = lane_id(), wv = threadIdx.x >> 6;
     const int N = (int)cnt->n_nodes;
     const int seg = blockIdx.x;
@@ -1182,13 +1184,20 @@ void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const u
 size_t scan_state_bytes(int n_var) { return (size_t)((n_var + SCAN_SEG - 1) / SCAN_SEG + 1) * 2 * sizeof(ScanState); }
 int scan_segments(int n_var) { return (n_var + SCAN_SEG - 1) / SCAN_SEG + 1; }
 
+// test hook (LPS_SCAN_FORCE_REPLAY=k): pretend that every k-th boundary has no matching variant, so that the serial replay path of k_scan_stitch runs
+__global__ void k_scan_break_matches(int32_t *match, int segs, int every) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > 0 && i < segs && i % every == 1 % every) match[i] = 0;
+}
+
 void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, const int32_t *vpos, const unsigned long long *erec,
                       int A, int distance, int8_t *hp_v, int32_t *blk_v, void *st_b, void *st_e, int32_t *seg_i32 /*4*segs*/,
                       unsigned *n_replayed, int8_t *hp, int32_t *block, hipStream_t s) {
     const int segs = scan_segments(n_var);
     const size_t vstride = (size_t)n_var + 64;
-    hipLaunchKernelGGL(k_scan_spec, dim3(segs), dim3(128), 0, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (ScanState *)st_b, (ScanState *)st_e);
+    hipLaunchKernelGGL(k_scan_spec, dim3(segs), dim3(128), (size_t)2 * SCAN_TILE * A * sizeof(unsigned long long), s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (ScanState *)st_b, (ScanState *)st_e);
     hipLaunchKernelGGL(k_scan_match, dim3((segs + 3) / 4), dim3(256), 0, s, cnt, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs);
+    if (const char *e = getenv("LPS_SCAN_FORCE_REPLAY")) { const int every = atoi(e); if (every > 0) hipLaunchKernelGGL(k_scan_break_matches, GRID(segs, 256), 0, s, seg_i32 + 3 * segs, segs, every); }
     hipLaunchKernelGGL(k_scan_stitch, dim3(1), dim3(64), 0, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, n_replayed);
     hipLaunchKernelGGL(k_scan_finalize, GRID(n_var, 256), 0, s, cnt, hp_v, blk_v, vstride, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, hp, block);
 }

@@ -55,6 +55,27 @@ def test_phase_matches_oracle_and_golden(name):
         ctx.close()
 
 
+@pytest.mark.parametrize("every", [1, 3])
+@pytest.mark.parametrize("name", ["snp_ont_seed2", "cnv_many"])
+def test_vote_scan_serial_replay_path(name, every, monkeypatch):
+    """k_scan_stitch's fallback: boundaries declared unmatched (LPS_SCAN_FORCE_REPLAY) are replayed serially from the true state -
+    the votes and the result must not change."""
+    kw, cli, over = fixtures.PHASE_FIXTURES[name]
+    s, V, R, P, ref_out, d, ctx, out = run_both(kw, over)
+    try:
+        hp0, blk0 = ctx.dump_votes()
+        monkeypatch.setenv("LPS_SCAN_FORCE_REPLAY", str(every))
+        out2 = ctx.phase(V, s.ref, R)
+        assert ctx.timings()["n_scan_replayed"] > 0
+        hp1, blk1 = ctx.dump_votes()
+        N = d.c.n_nodes
+        assert np.array_equal(hp1, d.node_hp[:N]) and np.array_equal(blk1, d.node_block[:N])
+        assert np.array_equal(hp0, hp1) and np.array_equal(blk0, blk1)
+        util.assert_phase_equal(out2.phase_set, out2.gt, ref_out.phase_set, ref_out.gt, name + " replayed vs oracle")
+    finally:
+        ctx.close()
+
+
 def test_repeat_runs_are_identical_and_recomputed():
     kw, cli, over = fixtures.PHASE_FIXTURES["snp_ont_seed2"]
     s, V, R = util.make_case(kw)
