@@ -76,6 +76,25 @@ def test_vote_scan_serial_replay_path(name, every, monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize("seed,len_median", [(71, 15000.0), (72, 3000.0)])
+def test_rows_longer_than_the_extraction_buffer(seed, len_median):
+    """k_extract_phase collects a wave's observations (four alignments) in a 512-entry LDS buffer; a SNP every ~10 bp makes single rows far
+    longer than that, so the buffer-full path (reserve an upper bound, flush, write the rest of the row directly) runs, also twice per wave."""
+    kw = dict(seed=seed, contig_len=150_000, n_snp=15_000, coverage=12.0, len_median=len_median, len_min=500, sub_rate=0.03,
+              lowq_frac=0.1, supp_frac=0.1, n_threads=2, snp_pair_frac=0.05, snp_in_hpoly_frac=0.1, hpoly_every=400.0)
+    s, V, R, P, ref_out, d, ctx, out = run_both(kw, {})
+    try:
+        cnt, var, al, q = ctx.dump_observations()
+        assert cnt.max() > 512
+        n = d.c.n_obs
+        assert np.array_equal(cnt, d.obs_count), "per-read observation counts differ"
+        assert np.array_equal(var, d.obs_var[:n]) and np.array_equal(al, d.obs_allele[:n])
+        assert np.array_equal(q.astype(np.int32), d.obs_quality[:n].astype(np.int32))
+        util.assert_phase_equal(out.phase_set, out.gt, ref_out.phase_set, ref_out.gt, "dense rows vs oracle")
+    finally:
+        ctx.close()
+
+
 def test_repeat_runs_are_identical_and_recomputed():
     kw, cli, over = fixtures.PHASE_FIXTURES["snp_ont_seed2"]
     s, V, R = util.make_case(kw)
