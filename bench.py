@@ -257,16 +257,26 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    stage_ms = {}
+    # Timed region: events only around the extraction kernel (the dominant one) - every event recorded on the stream idles the GPU for a few
+    # microseconds, the full per-stage set costs ~4 % of a step.  The per-stage table comes from a separate, untimed pass below.
+    ctx.set_stage_timing(1)
+    ctx.run_phase(out)
+    extract_ms = 0.0
     barrier()
     t_start = time.perf_counter()
     for _ in range(a.steps):
         ctx.run_phase(out)                      # synchronous: returns with results in host memory (stream drained)
-        for k, v in ctx.timings()["stages"].items():
-            stage_ms[k] = stage_ms.get(k, 0.0) + v
+        extract_ms += ctx.timings()["stages"]["extract"]
     elapsed = time.perf_counter() - t_start
     barrier()
     n_phased = int((out.phase_set != 0).sum())
+    stage_ms = {}
+    ctx.set_stage_timing(2)
+    n_prof = max(1, min(10, a.steps))
+    for _ in range(n_prof):
+        ctx.run_phase(out)
+        for k, v in ctx.timings()["stages"].items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + v
     tm = ctx.timings()
     if dist is not None:
         import torch
@@ -297,8 +307,10 @@ def main():
     n_scored = int((hout.status == 0).sum())
 
     if rank == 0:
-        stage_avg = {k: v / a.steps for k, v in stage_ms.items()}
+        stage_avg = {k: v / n_prof for k, v in stage_ms.items()}
         dom = max((k for k in stage_avg if k != "d2h"), key=lambda k: stage_avg[k])
+        if dom == "extract":
+            stage_avg["extract"] = extract_ms / a.steps     # measured live in the timed region (hipEvents on the library's stream)
         alg = tm["algorithmic_bytes"]
         # roofline of the dominant kernel (by time), algorithmic bytes / measured duration (hipEvents on the lib's stream)
         dom_bytes = alg.get(dom, 0)
@@ -324,8 +336,9 @@ def main():
                        "h2d_seconds_untimed": round(h2d_s, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "dominant stage by time; per-stage algorithmic GB/s in `stages`"},
+                         "note": "dominant stage by time, its duration from hipEvents inside the timed region; per-stage algorithmic GB/s in `stages`"},
             "stages": stages,
+            "stages_note": f"all stages but the dominant one: separate untimed pass of {n_prof} steps with every stage event recorded",
             "scan": {"segments": tm["n_scan_segments"], "replayed_serially": tm["n_scan_replayed"]},
             "secondary": {"metric": "reads haplotagged/sec", "value": R.n_reads * a.steps / hap_elapsed * n_gpus, "unit": "reads/s",
                           "ms_per_step": hap_elapsed / a.steps * 1e3, "kernel_ms": hap_tm["stages"]["extract"],

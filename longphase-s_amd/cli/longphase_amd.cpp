@@ -54,7 +54,7 @@ struct Lps {
     decltype(&lps_haplotag_chromosome) haplotag_chromosome = nullptr; decltype(&lps_abi_version) abi_version = nullptr;
     decltype(&lps_bgzf_load) bgzf_load = nullptr; decltype(&lps_bgzf_read) bgzf_read = nullptr; decltype(&lps_bam_scan) bam_scan = nullptr;
     decltype(&lps_bam_record_tids) bam_record_tids = nullptr; decltype(&lps_bam_names) bam_names = nullptr; decltype(&lps_push_bam_resident) push_bam_resident = nullptr;
-    decltype(&lps_bam_record_offsets) bam_record_offsets = nullptr; decltype(&lps_bam_scan_range) bam_scan_range = nullptr; decltype(&lps_device_count) device_count = nullptr;
+    decltype(&lps_bam_record_offsets) bam_record_offsets = nullptr; decltype(&lps_bam_scan_range) bam_scan_range = nullptr; decltype(&lps_device_count) device_count = nullptr; decltype(&lps_set_stage_timing) set_stage_timing = nullptr;
     decltype(&lps_haplotag_write_bgzf) haplotag_write_bgzf = nullptr; decltype(&lps_bgzf_deflate_fetch) bgzf_deflate_fetch = nullptr;
     decltype(&lps_somatic_extract_normal) somatic_extract_normal = nullptr; decltype(&lps_somatic_extract_tumor) somatic_extract_tumor = nullptr;
     decltype(&lps_somatic_tag_chromosome) somatic_tag_chromosome = nullptr;
@@ -71,7 +71,7 @@ struct Lps {
         LPS_SYM(begin_chromosome, lps_begin_chromosome) LPS_SYM(set_variants, lps_set_variants) LPS_SYM(set_reference, lps_set_reference)
         LPS_SYM(push_bam_records, lps_push_bam_records) LPS_SYM(phase_chromosome, lps_phase_chromosome) LPS_SYM(haplotag_chromosome, lps_haplotag_chromosome)
         LPS_SYM(abi_version, lps_abi_version) LPS_SYM(bgzf_load, lps_bgzf_load) LPS_SYM(bgzf_read, lps_bgzf_read) LPS_SYM(bam_scan, lps_bam_scan)
-        LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range) LPS_SYM(device_count, lps_device_count) LPS_SYM(haplotag_write_bgzf, lps_haplotag_write_bgzf) LPS_SYM(bgzf_deflate_fetch, lps_bgzf_deflate_fetch)
+        LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range) LPS_SYM(device_count, lps_device_count) LPS_SYM(set_stage_timing, lps_set_stage_timing) LPS_SYM(haplotag_write_bgzf, lps_haplotag_write_bgzf) LPS_SYM(bgzf_deflate_fetch, lps_bgzf_deflate_fetch)
         LPS_SYM(somatic_extract_normal, lps_somatic_extract_normal) LPS_SYM(somatic_extract_tumor, lps_somatic_extract_tumor) LPS_SYM(somatic_tag_chromosome, lps_somatic_tag_chromosome)
 #undef LPS_SYM
         if (abi_version() != LPS_ABI_VERSION) { error = "liblps_hip.so has a different ABI version than this binary was built for"; return false; }
@@ -477,7 +477,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     over.push_back([ont](lps_params &P) { P.is_ont = ont; });
 
     Lps L; lps_ctx *ctx = nullptr;
-    std::thread gpu_init([&] { if (!L.load()) return; lps_params P; L.default_params(&P); for (auto &f : over) f(P); ctx = L.create(gpu, &P); if (!ctx) L.error = "cannot create a GPU context (no CPU fallback)"; });
+    std::thread gpu_init([&] { if (!L.load()) return; lps_params P; L.default_params(&P); for (auto &f : over) f(P); ctx = L.create(gpu, &P); if (!ctx) L.error = "cannot create a GPU context (no CPU fallback)"; else L.set_stage_timing(ctx, 0); });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{gpu_init};
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
@@ -558,6 +558,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     for (int g = 1; g < n_workers; ++g) workers.emplace_back([&, g] {
         lps_params P; L.default_params(&P); for (auto &f : over) f(P);
         lps_ctx *cx = L.create((gpu + g) % n_dev, &P); if (!cx) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
+        L.set_stage_timing(cx, 0);
         GpuBam gg; gg.open_file(bams[0], true);
         run_share(cx, gg, share[(size_t)g]);
         L.destroy(cx); gg.close_file();
@@ -734,7 +735,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     if (snp.empty() || bam.empty() || ref.empty()) { std::cerr << "longphase_amd haplotag: missing arguments\n" << kTagUsage; return 1; }
 
     Lps L; lps_ctx *ctx = nullptr;
-    std::thread gpu_init([&] { if (!L.load()) return; lps_params P; L.default_params(&P); for (auto &f : over) f(P); ctx = L.create(gpu, &P); if (!ctx) L.error = "cannot create a GPU context (no CPU fallback)"; });
+    std::thread gpu_init([&] { if (!L.load()) return; lps_params P; L.default_params(&P); for (auto &f : over) f(P); ctx = L.create(gpu, &P); if (!ctx) L.error = "cannot create a GPU context (no CPU fallback)"; else L.set_stage_timing(ctx, 0); });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{gpu_init};
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
@@ -1101,7 +1102,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     const bool estimate = purity < 0;                                  // default: automatic estimation, as in the reference
 
     Lps L; lps_ctx *ctx = nullptr;
-    std::thread gpu_init([&] { if (!L.load()) return; lps_params P; L.default_params(&P); for (auto &f : over) f(P); ctx = L.create(gpu, &P); if (!ctx) L.error = "cannot create a GPU context (no CPU fallback)"; });
+    std::thread gpu_init([&] { if (!L.load()) return; lps_params P; L.default_params(&P); for (auto &f : over) f(P); ctx = L.create(gpu, &P); if (!ctx) L.error = "cannot create a GPU context (no CPU fallback)"; else L.set_stage_timing(ctx, 0); });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{gpu_init};
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();

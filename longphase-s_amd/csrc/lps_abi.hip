@@ -54,6 +54,7 @@ struct lps_ctx {
     DevBuf<int32_t> obs_var, g_node; DevBuf<uint16_t> obs_aq; DevBuf<uint8_t> g_flag;
     unsigned long long obs_capacity = 0;   // main arenas (LPS_ARENAS equal parts); a tail arena of obs_capacity/4 follows
     DevBuf<unsigned long long> arena_ctr;
+    bool in_phase = false; int timing_level = 2;
     size_t z_late_off = 0, z_late_bytes = 0; unsigned long long late_n_keys = 0, late_cap_main = 0, late_tail = 0; bool cnv_skipped = false;
     DevBuf<uint8_t> zpool;        // the zero-initialised arrays of a phase run (arena_ctr, out_ps/gt, deleted, is_node, vtype_key, mrow_cnt, node_end/cur, bsize, cnt4) are carved from it
     // clips / cnv
@@ -538,7 +539,12 @@ int lps_bgzf_timings(lps_ctx *c, double *h2d_ms, double *inflate_ms) {
 
 static int bits_for(unsigned long long n) { int b = 1; while ((1ull << b) < n) ++b; return b; }
 
-static void mark(lps_ctx *c, int st) { HIP_TRY(hipEventRecord(c->ev[st], c->stream)); c->ev_used[st] = true; }
+// stage boundaries on the stream.  Every recorded event drains the queue for a moment (~3.5 us): a phase run records them all only when the
+// caller asked for the per-stage breakdown (lps_set_stage_timing level 2), else just the two around the extraction kernel (level 1) or none.
+static void mark(lps_ctx *c, int st) {
+    if (c->in_phase && (c->timing_level == 0 || (c->timing_level == 1 && st != ST_EXTRACT && st != ST_GROUPS))) return;
+    HIP_TRY(hipEventRecord(c->ev[st], c->stream)); c->ev_used[st] = true;
+}
 
 static VarView var_view(lps_ctx *c) {
     VarView V{};
@@ -707,6 +713,12 @@ static void deliver_result(lps_ctx *c, lps_phase_result *out) {
     memcpy(out->gt, c->h_res + ((uint8_t *)c->out_gt.p - (uint8_t *)c->out_ps.p), (size_t)c->nV);
 }
 
+int lps_set_stage_timing(lps_ctx *c, int level) {
+    if (!c || level < 0 || level > 2) return -1;
+    c->timing_level = level;
+    return 0;
+}
+
 int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
     if (!c || !out) return -1;
     try {
@@ -716,7 +728,9 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         c->phase_valid = false;
         if (c->nV == 0 || c->nR == 0) return 0;
         if (c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
+        c->in_phase = true;
         int rc = run_phase(c);
+        c->in_phase = false;
         if (rc != 0) return rc;
         (void)enqueue_result_copy(c);
         HIP_TRY(hipEventRecord(c->ev_end, c->stream));
@@ -738,7 +752,8 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         lps_timings &t = c->tm; memset(&t, 0, sizeof t);
         t.n_stages = ST_COUNT;
         int prev = -1;
-        for (int i = 0; i <= ST_COUNT; ++i) {
+        if (c->timing_level == 1) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[ST_EXTRACT], c->ev[ST_GROUPS])); t.ms_kernel[ST_EXTRACT] = ms; }
+        for (int i = 0; i <= ST_COUNT && c->timing_level == 2; ++i) {
             const bool last = (i == ST_COUNT);
             if (!last && !c->ev_used[i]) continue;
             if (prev >= 0) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[prev], last ? c->ev_end : c->ev[i])); t.ms_kernel[prev] = ms; }

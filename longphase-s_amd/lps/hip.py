@@ -68,6 +68,7 @@ def load():
     L.lps_somatic_extract_normal.argtypes = [C.c_void_p, C.POINTER(abi.SiteCounters)]
     L.lps_somatic_extract_tumor.argtypes = [C.c_void_p, C.POINTER(abi.TumorExtractResult)]
     L.lps_get_timings.argtypes = [C.c_void_p, C.POINTER(abi.Timings)]
+    L.lps_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
     L.lps_stage_name.restype = C.c_char_p
     L.lps_stage_name.argtypes = [C.c_int]
     L.lps_stream.restype = C.c_void_p
@@ -217,6 +218,9 @@ class Context:
             self._check(rc, "lps_somatic_extract_tumor")
             return out
         self._check(rc, "lps_somatic_extract_tumor")
+
+    def set_stage_timing(self, level):
+        self._check(self.L.lps_set_stage_timing(self.h, int(level)), "lps_set_stage_timing")
 
     def timings(self):
         t = abi.Timings()
