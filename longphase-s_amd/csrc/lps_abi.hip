@@ -598,7 +598,7 @@ static int run_late(lps_ctx *c, bool with_cnv) {
         launch_node_lists(c->d_cnt, nR, nV, c->mrow_off.p, c->mrow_cnt.p, c->koff.p, c->g_node.p, c->m_bits, c->a_bits, c->n_bits, c->nkeys.p, c->nkeys_s.p, c->nvals.p, c->nvals_s.p, c->late_n_keys, c->node_off.p, c->node_end.p, c->node_cur.p, c->temp.p, c->temp_bytes, s);
         // ---- a11/a12 edges
         mark(c, ST_EDGES);
-        launch_edges(c->d_cnt, nV, c->node_off.p, c->node_end.p, c->nkeys_s.p, c->nvals_s.p, c->mrow_off.p, c->mrow_cnt.p, c->m_bits, c->a_bits, c->g_node.p, c->g_flag.p, A, P.edge_weight, P.edge_threshold, c->ntype.p, c->edge.p, c->erec.p, c->node_pairs.p, s);
+        launch_edges(c->d_cnt, nV, c->node_off.p, c->node_end.p, c->nkeys.p, c->nvals.p, c->nkeys_s.p, c->nvals_s.p, c->mrow_off.p, c->mrow_cnt.p, c->m_bits, c->a_bits, c->g_node.p, c->g_flag.p, A, P.edge_weight, P.edge_threshold, c->ntype.p, c->edge.p, c->erec.p, c->node_pairs.p, s);
         // ---- a13 vote scan
         mark(c, ST_SCAN);
         launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->v_pos.p, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2, c->hp.p, c->block.p, s);

@@ -37,7 +37,7 @@ void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t 
                        unsigned long long *keys_sorted, uint32_t *vals, uint32_t *vals_sorted, unsigned long long n_keys,
                        uint32_t *node_off, uint32_t *node_cnt, uint32_t *node_cur, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
-                  const unsigned long long *skeys, const uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
+                  const unsigned long long *ukeys, const uint32_t *uvals, const unsigned long long *skeys, const uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                   int m_bits, int a_bits, const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
                   double edge_threshold, const uint8_t *ntype, float *edge, unsigned long long *erec, uint32_t *node_pairs, hipStream_t s);
 size_t scan_state_bytes(int n_var);

@@ -569,15 +569,15 @@ __global__ __launch_bounds__(256) void k_node_count(const LpsCounters *cnt, cons
     const unsigned g = blockIdx.x * 4 + (threadIdx.x >> 6); const int l = lane_id();
     if (g >= cnt->n_groups) return;
     const int n = mrow_cnt[g];
-    if (g + 1 == cnt->n_groups && l == 0) cntw->n_obs_final = (unsigned long long)koff[g] + (unsigned)n;   // = sum of merged rows
     const uint32_t off = mrow_off[g];
     for (int a = l; a < n; a += 64) atomicAdd(&node_cnt[g_node[off + a]], 1u);
 }
 
 __global__ __launch_bounds__(256) void k_node_scatter(const LpsCounters *cnt, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                                                       const int32_t *g_node, const uint32_t *node_off, uint32_t *node_cur, int a_bits,
-                                                      unsigned long long *keys, uint32_t *vals, LpsCounters *cntw) {
+                                                      unsigned long long *keys, uint32_t *vals, LpsCounters *cntw, int n_var) {
     const unsigned g = blockIdx.x * 4 + (threadIdx.x >> 6); const int l = lane_id();
+    if (g == 0 && l == 0) cntw->n_obs_final = node_off[n_var];         // sum of merged rows = end of the last node's list
     if (g >= cnt->n_groups) return;
     const int n = mrow_cnt[g];
     if (n > (1 << a_bits)) { if (l == 0) atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); return; }
@@ -590,18 +590,14 @@ __global__ __launch_bounds__(256) void k_node_scatter(const LpsCounters *cnt, co
     }
 }
 
-// wave per node: order the node's entries by key (rank = number of smaller keys; keys are unique)
+// wave per node with MORE than 64 entries (coverage above 64): order the node's entries by key (rank = number of smaller keys; keys are unique)
 __global__ __launch_bounds__(256) void k_node_sort(const LpsCounters *cnt, const uint32_t *node_off, const uint32_t *node_cnt,
                                                    const unsigned long long *keys, const uint32_t *vals, unsigned long long *skeys, uint32_t *svals) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
     if (i >= (int)cnt->n_nodes) return;
     const uint32_t off = node_off[i]; const int n = (int)node_cnt[i];
-    if (n <= 64) {
-        const unsigned long long k = l < n ? keys[off + l] : ~0ull;
-        int rank = 0;
-        for (int t = 0; t < n; ++t) { const unsigned long long o = __shfl(k, t); rank += o < k; }
-        if (l < n) { skeys[off + rank] = k; svals[off + rank] = vals[off + l]; }
-    } else {
+    if (n <= 64) return;                                               // k_edges orders lists of up to 64 entries itself, in registers
+    {
         for (int a = l; a < n; a += 64) {
             const unsigned long long k = keys[off + a];
             int rank = 0;
@@ -620,6 +616,7 @@ __device__ __forceinline__ float edge_upd(float x, bool hi, double w) {
 // For each read observing node i (in name-rank order) lane t loads the read's t-th following observation;
 // its node distance d selects the owning lane, the (allele pair, quality class) travels there by ds_permute.
 __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uint32_t *node_off, const uint32_t *node_end,
+                                               const unsigned long long *ukeys, const uint32_t *uvals,
                                                const unsigned long long *skeys, const uint32_t *svals,
                                                const uint32_t *mrow_off, const int32_t *mrow_cnt, int m_bits, int a_bits,
                                                const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
@@ -631,10 +628,28 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     unsigned long long pairs = 0;
     const unsigned long long m_mask = (1ull << m_bits) - 1ull;
+    const bool short_list = end - off <= 64;                           // unsorted entries (ukeys/uvals): ordered here; longer lists come sorted (k_node_sort)
     for (uint32_t e0 = off; e0 < end; e0 += 64) {
         const int nb = (int)min(64u, end - e0);
         uint32_t my_val = 0, my_end = 0;
-        if (l < nb) {
+        if (short_list) {
+            unsigned long long key = ~0ull; uint32_t v0 = 0, x0 = 0;
+            if (l < nb) {
+                key = ukeys[e0 + l];
+                const uint32_t m = (uint32_t)((key >> a_bits) & m_mask);
+                v0 = uvals[e0 + l]; x0 = mrow_off[m] + (uint32_t)mrow_cnt[m];
+            }
+            // rank = number of smaller keys (keys are unique): the read order of the reference (name rank, index in the merged read)
+            const int klo = (int)(unsigned)key, khi = (int)(unsigned)(key >> 32);
+            int rank = 0;
+            for (int t = 0; t < nb; ++t) {
+                const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(khi, t) << 32) | (unsigned)__builtin_amdgcn_readlane(klo, t);
+                rank += o < key;
+            }
+            const int dst = (l < nb ? rank : l) << 2;                   // lanes past the list keep to themselves (ranks are a permutation of 0..nb-1)
+            my_val = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)v0);
+            my_end = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)x0);
+        } else if (l < nb) {
             const unsigned long long key = skeys[e0 + l];
             const uint32_t m = (uint32_t)((key >> a_bits) & m_mask);
             my_val = svals[e0 + l]; my_end = mrow_off[m] + (uint32_t)mrow_cnt[m];
@@ -1165,20 +1180,18 @@ void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t 
                        const int32_t *g_node, int m_bits, int a_bits, int n_bits, unsigned long long *keys,
                        unsigned long long *keys_sorted, uint32_t *vals, uint32_t *vals_sorted, unsigned long long n_keys,
                        uint32_t *node_off, uint32_t *node_cnt, uint32_t *node_cur, void *temp, size_t temp_bytes, hipStream_t s) {
-    // koff = exclusive scan of mrow_cnt over groups (only used for the observation total)
-    exscan_u32(temp, temp_bytes, reinterpret_cast<const uint32_t *>(mrow_cnt), koff, n_reads, s);
     hipLaunchKernelGGL(k_node_count, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, mrow_off, mrow_cnt, g_node, node_cnt, cnt, koff);
     exscan_u32(temp, temp_bytes, node_cnt, node_off, (size_t)n_var + 1, s);
-    hipLaunchKernelGGL(k_node_scatter, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, mrow_off, mrow_cnt, g_node, node_off, node_cur, a_bits, keys, vals, cnt);
+    hipLaunchKernelGGL(k_node_scatter, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, mrow_off, mrow_cnt, g_node, node_off, node_cur, a_bits, keys, vals, cnt, n_var);
     hipLaunchKernelGGL(k_node_sort, dim3((n_var + 3) / 4), dim3(256), 0, s, cnt, node_off, node_cnt, keys, vals, keys_sorted, vals_sorted);
     (void)m_bits; (void)n_bits; (void)n_keys;
 }
 
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
-                  const unsigned long long *skeys, const uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
+                  const unsigned long long *ukeys, const uint32_t *uvals, const unsigned long long *skeys, const uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                   int m_bits, int a_bits, const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
                   double edge_threshold, const uint8_t *ntype, float *edge, unsigned long long *erec, uint32_t *node_pairs, hipStream_t s) {
-    hipLaunchKernelGGL(k_edges, dim3((n_var + 3) / 4), dim3(256), 0, s, cnt, node_off, node_end, skeys, svals, mrow_off, mrow_cnt, m_bits, a_bits, g_node, g_flag, A, edge_weight, edge_threshold, ntype, edge, erec, node_pairs);
+    hipLaunchKernelGGL(k_edges, dim3((n_var + 3) / 4), dim3(256), 0, s, cnt, node_off, node_end, ukeys, uvals, skeys, svals, mrow_off, mrow_cnt, m_bits, a_bits, g_node, g_flag, A, edge_weight, edge_threshold, ntype, edge, erec, node_pairs);
 }
 
 size_t scan_state_bytes(int n_var) { return (size_t)((n_var + SCAN_SEG - 1) / SCAN_SEG + 1) * 2 * sizeof(ScanState); }
