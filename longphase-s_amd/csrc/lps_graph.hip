@@ -1121,7 +1121,7 @@ void launch_clip_cnv(unsigned n_clips, unsigned long long *keys,
                      unsigned *stats, LpsCounters *cnt, hipStream_t s) {
     HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(unsigned), s));
     if (n_clips) {
-        sort_keys64(temp, temp_bytes, keys, keys_sorted, n_clips, 64, s);
+        sort_keys64(temp, temp_bytes, keys, keys_sorted, n_clips, 33, s);          // key = pos << 1 | front/back: 33 bits, 5 digit passes instead of 8
         hipLaunchKernelGGL(k_clip_stats, GRID(n_clips, 256), 0, s, keys_sorted, n_clips, stats);
     }
     hipLaunchKernelGGL(k_cnv_state, dim3(1), dim3(64), 0, s, keys_sorted, n_clips, stats, cnv_start, cnv_end, cnt);
