@@ -56,6 +56,7 @@ struct lps_ctx {
     DevBuf<unsigned long long> arena_ctr;
     bool in_phase = false; int timing_level = 2;
     size_t z_late_off = 0, z_late_bytes = 0; unsigned long long late_n_keys = 0, late_cap_main = 0, late_tail = 0; bool cnv_skipped = false;
+    DevBuf<uint8_t> hap_pool;     // per-read outputs of the scoring kernels, carved like zpool
     DevBuf<uint8_t> zpool;        // the zero-initialised arrays of a phase run (arena_ctr, out_ps/gt, deleted, is_node, vtype_key, mrow_cnt, node_end/cur, bsize, cnt4) are carved from it
     // clips / cnv
     DevBuf<int32_t> clip_pos, clip_op; size_t clip_capacity = 0;
@@ -777,8 +778,17 @@ static int run_scorer(lps_ctx *c, bool somatic, uint8_t *status, int32_t *hp1, i
                       int32_t *hp3, int32_t *d1, int32_t *d2) {
     const int nR = c->nR, nV = c->nV;
     hipStream_t s = c->stream;
-    c->hap_status.reserve(nR); c->hap_h1.reserve(nR); c->hap_h2.reserve(nR); c->hap_nps.reserve(nR); c->hap_psmin.reserve(nR);
-    c->hap_h3.reserve(nR); c->hap_d1.reserve(nR); c->hap_d2.reserve(nR);
+    // per-read outputs side by side in one allocation: they leave in ONE copy into pinned memory (five to eight copies into the caller's pageable
+    // arrays are staged by the runtime one after the other and block the host meanwhile)
+    size_t hbytes = 0;
+    auto hslot = [&](size_t bytes) { const size_t at = hbytes; hbytes += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_st = hslot(nR), o_h1 = hslot((size_t)nR * 4), o_h2 = hslot((size_t)nR * 4), o_np = hslot(nR), o_pm = hslot((size_t)nR * 4), o_h3 = hslot((size_t)nR * 4),
+                 o_d1 = hslot((size_t)nR * 4), o_d2 = hslot((size_t)nR * 4);
+    c->hap_pool.reserve(hbytes);
+    c->hap_status.carve(c->hap_pool.p + o_st, nR); c->hap_h1.carve(c->hap_pool.p + o_h1, nR); c->hap_h2.carve(c->hap_pool.p + o_h2, nR); c->hap_nps.carve(c->hap_pool.p + o_np, nR);
+    c->hap_psmin.carve(c->hap_pool.p + o_pm, nR); c->hap_h3.carve(c->hap_pool.p + o_h3, nR); c->hap_d1.carve(c->hap_pool.p + o_d1, nR); c->hap_d2.carve(c->hap_pool.p + o_d2, nR);
+    const size_t span = somatic ? hbytes : o_h3;
+    if (span + 1024 > c->h_res_bytes) { if (c->h_res) HIP_TRY(hipHostFree(c->h_res)); c->h_res = nullptr; c->h_res_bytes = span + span / 4 + 4096; HIP_TRY(hipHostMalloc((void **)&c->h_res, c->h_res_bytes)); }
     c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1);
     HIP_TRY(hipEventRecord(c->ev_begin, s));
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
@@ -790,19 +800,14 @@ static int run_scorer(lps_ctx *c, bool somatic, uint8_t *status, int32_t *hp1, i
     HapOut H{c->hap_status.p, c->hap_h1.p, c->hap_h2.p, c->hap_nps.p, c->hap_psmin.p, c->hap_h3.p, c->hap_d1.p, c->hap_d2.p, nullptr, nullptr, 0.0};
     launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, somatic ? 1 : 0, c->d_cnt, s);
     mark(c, ST_D2H);
-    HIP_TRY(hipMemcpyAsync(status, H.status, (size_t)nR, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(hp1, H.hp1, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(hp2, H.hp2, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(n_ps, H.n_ps, (size_t)nR, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(ps_min, H.ps_min, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
-    if (somatic) {
-        HIP_TRY(hipMemcpyAsync(hp3, H.hp3, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(d1, H.d1, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(d2, H.d2, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
-    }
-    HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c->h_res, c->hap_pool.p, span, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c->h_cnt_pin, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(c->ev_end, s));
     HIP_TRY(hipStreamSynchronize(s));
+    c->h_cnt = *c->h_cnt_pin;
+    memcpy(status, c->h_res + o_st, (size_t)nR); memcpy(hp1, c->h_res + o_h1, (size_t)nR * 4); memcpy(hp2, c->h_res + o_h2, (size_t)nR * 4);
+    memcpy(n_ps, c->h_res + o_np, (size_t)nR); memcpy(ps_min, c->h_res + o_pm, (size_t)nR * 4);
+    if (somatic) { memcpy(hp3, c->h_res + o_h3, (size_t)nR * 4); memcpy(d1, c->h_res + o_d1, (size_t)nR * 4); memcpy(d2, c->h_res + o_d2, (size_t)nR * 4); }
     if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) return fail(c, "Alignment find unsupported CIGAR operation", -2);
     lps_timings &t = c->tm; memset(&t, 0, sizeof t);
     t.n_stages = ST_COUNT;
