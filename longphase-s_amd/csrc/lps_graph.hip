@@ -27,23 +27,27 @@
 // compact them (one atomic per workgroup) into sort keys (pos << 1 | front/back).
 __global__ __launch_bounds__(256) void k_clip_keys(ClipView C, const int32_t *row_fail, int n_reads, unsigned long long *keys,
                                                    LpsCounters *cnt) {
+    // thread per alignment (its LPS_CLIP_SLOTS slots), ONE atomic per workgroup: same-word atomics are served one after the other
     __shared__ unsigned s_wcnt[4], s_base;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int w = threadIdx.x >> 6;
-    bool ok = false; unsigned long long key = 0;
-    if (i < (long long)n_reads * LPS_CLIP_SLOTS) {
-        const int of = C.opidx_fb[i];
-        if (of >= 0 && (of >> 1) < row_fail[i / LPS_CLIP_SLOTS]) { ok = true; key = ((unsigned long long)(unsigned)C.pos[i] << 1) | (unsigned)(of & 1); }
+    unsigned long long key[LPS_CLIP_SLOTS]; int n = 0;
+    if (r < n_reads) {
+        const int4 of4 = reinterpret_cast<const int4 *>(C.opidx_fb)[r], ps4 = reinterpret_cast<const int4 *>(C.pos)[r];
+        const int of[4] = {of4.x, of4.y, of4.z, of4.w}, ps[4] = {ps4.x, ps4.y, ps4.z, ps4.w};
+        const int rf = row_fail[r];
+#pragma unroll
+        for (int k = 0; k < LPS_CLIP_SLOTS; ++k)
+            if (of[k] >= 0 && (of[k] >> 1) < rf) { key[n] = ((unsigned long long)(unsigned)ps[k] << 1) | (unsigned)(of[k] & 1); ++n; }
     }
-    const unsigned long long m = __ballot(ok);
-    if (lane_id() == 0) s_wcnt[w] = (unsigned)__popcll(m);
+    const int incl = wave_incl_scan_dpp(n);
+    if (lane_id() == 63) s_wcnt[w] = (unsigned)incl;
     __syncthreads();
     if (threadIdx.x == 0) { const unsigned tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]; s_base = tot ? atomicAdd(&cnt->n_clips, tot) : 0u; }
     __syncthreads();
-    if (ok) {
-        unsigned off = s_base; for (int q = 0; q < w; ++q) off += s_wcnt[q];
-        keys[off + __popcll(m & lanemask_lt())] = key;
-    }
+    unsigned off = s_base + (unsigned)(incl - n); for (int q = 0; q < w; ++q) off += s_wcnt[q];
+#pragma unroll
+    for (int k = 0; k < LPS_CLIP_SLOTS; ++k) if (k < n) keys[off + k] = key[k];
 }
 
 struct CnvState {
@@ -124,13 +128,17 @@ __global__ void k_cnv_state(const unsigned long long *keys, unsigned n_clips, co
 }
 
 // ================================================================================================ name groups
-__global__ void k_name_keys(int n_reads, const uint32_t *name_id, const int32_t *row_cnt, unsigned long long *keys,
-                            LpsCounters *cnt) {
+__global__ __launch_bounds__(256) void k_name_keys(int n_reads, const uint32_t *name_id, const int32_t *row_cnt, unsigned long long *keys,
+                                                   LpsCounters *cnt) {
+    __shared__ unsigned s_cnt[4];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    const bool kept = row_cnt[r] > 0;
-    keys[r] = kept ? ((unsigned long long)name_id[r] << 32 | (unsigned)r) : ~0ull;
-    if (kept) atomicAdd(&cnt->n_kept, 1u);
+    const bool kept = r < n_reads && row_cnt[r] > 0;
+    if (r < n_reads) keys[r] = kept ? ((unsigned long long)name_id[r] << 32 | (unsigned)r) : ~0ull;
+    // one atomic per workgroup: atomics on ONE word are served one after the other (~11 ns each), 1 500 wave atomics were the kernel's whole duration
+    const unsigned long long m = __ballot(kept);
+    if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]; if (tot) atomicAdd(&cnt->n_kept, tot); }
 }
 
 __global__ void k_group_heads(const unsigned long long *skeys, int n_reads, const LpsCounters *cnt, uint32_t *head) {
@@ -984,7 +992,10 @@ __global__ void k_block_size(LpsCounters *cnt, const int32_t *block, const uint3
     int b = in ? block[i] : -1;
     unsigned long long pr = in ? node_pairs[i] : 0;
     pr = wave_sum(pr);
-    if (lane_id() == 0 && pr) atomicAdd(&cnt->n_pairs, pr);
+    __shared__ unsigned long long s_pr[16];
+    if (lane_id() == 0) s_pr[threadIdx.x >> 6] = pr;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long tot = 0; for (unsigned q = 0; q < (blockDim.x + 63) / 64; ++q) tot += s_pr[q]; if (tot) atomicAdd(&cnt->n_pairs, tot); }
     // per-node byte for the read-correction kernels: bit0 refhap (hp==2), bits1-3 type; "in a block" is added by k_node_state
     if (in) nstate[i] = (uint8_t)((hp[i] == 1 ? 0 : 1) | (ntype[i] << 1));
     // neighbouring nodes nearly always share their block: one atomic per distinct block per wave
@@ -1113,7 +1124,7 @@ void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const uin
 }
 
 void launch_clip_keys(const ClipView &C, const int32_t *row_fail, int n_reads, unsigned long long *keys, LpsCounters *cnt, hipStream_t s) {
-    if (n_reads) hipLaunchKernelGGL(k_clip_keys, GRID((size_t)n_reads * LPS_CLIP_SLOTS, 256), 0, s, C, row_fail, n_reads, keys, cnt);
+    if (n_reads) hipLaunchKernelGGL(k_clip_keys, GRID(n_reads, 256), 0, s, C, row_fail, n_reads, keys, cnt);
 }
 
 void launch_clip_cnv(unsigned n_clips, unsigned long long *keys,
