@@ -420,21 +420,42 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const uint32_t *
 // k_merge_multi (wave per queued group) places every element by rank: own index + elements of the other rows that sort before it
 // (ties: earlier alignment first).  That is the stable order == libstdc++ std::sort for n <= 16 and differs from it only in the
 // relative order of equal positions beyond that.
-__global__ void k_merge_plan(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt,
+__global__ __launch_bounds__(256) void k_merge_plan(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt,
                              const uint32_t *row_off, const int32_t *g_cnt, unsigned long long tail_lo, unsigned long long tail_size,
                              uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list) {
+    __shared__ unsigned s_tot[4], s_n[4]; __shared__ unsigned long long s_base_t; __shared__ unsigned s_base_n;
     const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= cnt->n_groups) return;
-    const uint32_t s0 = gstart[g], s1 = gstart[g + 1];
-    if (s1 - s0 == 1) { const uint32_t r = (uint32_t)skeys[s0]; mrow_off[g] = row_off[r]; mrow_cnt[g] = g_cnt[r]; return; }
-    int alive = 0, total = 0; uint32_t one = 0;
-    for (uint32_t s = s0; s < s1; ++s) { const uint32_t r = (uint32_t)skeys[s]; if (g_cnt[r] > 0) { ++alive; total += g_cnt[r]; one = r; } }
-    if (alive == 0) { mrow_off[g] = 0; mrow_cnt[g] = 0; return; }
-    if (alive == 1) { mrow_off[g] = row_off[one]; mrow_cnt[g] = total; return; }
-    const unsigned long long toff = atomicAdd(&cnt->tail_total, (unsigned long long)total);
-    if (toff + total > tail_size) { atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); mrow_off[g] = 0; mrow_cnt[g] = 0; return; }
-    mrow_off[g] = (uint32_t)(tail_lo + toff); mrow_cnt[g] = total;
-    multi_list[atomicAdd(&cnt->n_multi, 1u)] = g;
+    const int w = threadIdx.x >> 6;
+    bool multi = false; int total = 0;
+    if (g < cnt->n_groups) {
+        const uint32_t s0 = gstart[g], s1 = gstart[g + 1];
+        if (s1 - s0 == 1) { const uint32_t r = (uint32_t)skeys[s0]; mrow_off[g] = row_off[r]; mrow_cnt[g] = g_cnt[r]; }
+        else {
+            int alive = 0; uint32_t one = 0;
+            for (uint32_t s = s0; s < s1; ++s) { const uint32_t r = (uint32_t)skeys[s]; if (g_cnt[r] > 0) { ++alive; total += g_cnt[r]; one = r; } }
+            if (alive == 0) { mrow_off[g] = 0; mrow_cnt[g] = 0; }
+            else if (alive == 1) { mrow_off[g] = row_off[one]; mrow_cnt[g] = total; }
+            else multi = true;
+        }
+    }
+    // tail slots and queue entries: ONE atomic each per workgroup (same-word atomics are served one after the other)
+    const int mine = multi ? total : 0;
+    const int incl = wave_incl_scan_dpp(mine);
+    const unsigned long long mm = __ballot(multi);
+    if (lane_id() == 63) s_tot[w] = (unsigned)incl;
+    if (lane_id() == 0) s_n[w] = (unsigned)__popcll(mm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long T = (unsigned long long)s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3]; const unsigned N = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+        s_base_t = T ? atomicAdd(&cnt->tail_total, T) : 0ull; s_base_n = N ? atomicAdd(&cnt->n_multi, N) : 0u;
+    }
+    __syncthreads();
+    if (multi) {
+        unsigned long long toff = s_base_t + (unsigned long long)(incl - mine); unsigned qi = s_base_n + (unsigned)__popcll(mm & lanemask_lt());
+        for (int q = 0; q < w; ++q) { toff += s_tot[q]; qi += s_n[q]; }
+        if (toff + (unsigned long long)total > tail_size) { atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); mrow_off[g] = 0; mrow_cnt[g] = 0; multi_list[qi] = 0xffffffffu; }
+        else { mrow_off[g] = (uint32_t)(tail_lo + toff); mrow_cnt[g] = total; multi_list[qi] = g; }
+    }
 }
 
 // ---- std::sort of one row by one wavefront (rows that hold a position twice; see k_merge_multi).  The row sits in LDS in its unsorted order.
@@ -524,6 +545,7 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
     const unsigned n_waves = gridDim.x * 4;
     for (unsigned q = blockIdx.x * 4 + (threadIdx.x >> 6); q < cnt->n_multi; q += n_waves) {
         const unsigned g = multi_list[q];
+        if (g == 0xffffffffu) continue;                                   // its tail reservation failed (the host grows the buffers and reruns)
         const uint32_t s0 = gstart[g], s1 = gstart[g + 1];
         const uint32_t base = mrow_off[g];
         bool dup = false;
