@@ -372,7 +372,9 @@ __global__ __launch_bounds__(256) void k_mark_nodes(int n_reads, const uint32_t 
         if (v < 0) continue;                                  // erased by the CNV filter
         const unsigned ty = (q == -4) ? 3u : (q == -5 ? 4u : 0u);
         is_node[v] = 1u;
-        atomicMax(&vtype_key[v], ((unsigned)r << 3) | ty);
+        // type of the LAST alignment that saw the variant.  Base qualities are never negative, so ty == 0 means a SNP row, all of whose
+        // observations are of type 0: the word stays 0 without 1.7 M atomics
+        if (ty) atomicMax(&vtype_key[v], ((unsigned)r << 3) | ty);
     }
 }
 
