@@ -638,19 +638,19 @@ static int run_phase(lps_ctx *c) {
         c->node_of.reserve(nV + 1); c->node_off.reserve(nV + 2); c->multi_list.reserve(nR + 1);
         c->nodes.reserve(nV + 1); c->block.reserve(nV + 1);
         c->ntype.reserve(nV + 1); c->hp.reserve(nV + 1);
-        c->erec.reserve((size_t)nV * A + 64); c->clip_stats.reserve(4);
+        c->erec.reserve((size_t)nV * A + 64);
         c->hp_v.reserve(2 * ((size_t)nV + 64)); c->blk_v.reserve(2 * ((size_t)nV + 64)); c->seg_i32.reserve(4 * (size_t)scan_segments(nV) + 4); c->node_pairs.reserve(nV + 1); c->nstate.reserve(nV + 1);
         c->st_b.reserve(scan_state_bytes(nV)); c->st_e.reserve(scan_state_bytes(nV)); c->edge.reserve((size_t)nV * A * 4 + 16);
         // everything that has to start a run as zeros sits in ONE allocation cleared by one fill (a dozen separate fills cost ~4 us each)
         size_t zbytes = 0;
         auto zslot = [&](size_t bytes) { const size_t at = zbytes; zbytes += (bytes + 255) & ~(size_t)255; return at; };
-        const size_t z_arena = zslot(LPS_ARENAS * 8 * sizeof(unsigned long long)), z_del = zslot((size_t)nR + 1),
+        const size_t z_arena = zslot(LPS_ARENAS * 8 * sizeof(unsigned long long)), z_del = zslot((size_t)nR + 1), z_stats = zslot(4 * sizeof(unsigned)),
                      z_ps = zslot(((size_t)nV + 1) * 4), z_gt = zslot((size_t)nV + 1), z_isn = zslot(((size_t)nV + 1) * 4), z_vtk = zslot(((size_t)nV + 1) * 4), z_mrc = zslot(((size_t)nR + 1) * 4),
                      z_nend = zslot(((size_t)nV + 2) * 4), z_ncur = zslot(((size_t)nV + 2) * 4), z_bs = zslot(((size_t)nV + 1) * 4), z_c4 = zslot(((size_t)nV * 4 + 4) * 4);
         c->zpool.reserve(zbytes);
         c->z_late_off = z_ps; c->z_late_bytes = zbytes - z_ps;       // what the stages after the overlap filter need zeroed (see run_late)
         c->arena_ctr.carve(c->zpool.p + z_arena, LPS_ARENAS * 8); c->out_ps.carve(c->zpool.p + z_ps, (size_t)nV + 1); c->out_gt.carve(c->zpool.p + z_gt, (size_t)nV + 1);
-        c->deleted.carve(c->zpool.p + z_del, (size_t)nR + 1); c->is_node.carve(c->zpool.p + z_isn, (size_t)nV + 1); c->vtype_key.carve(c->zpool.p + z_vtk, (size_t)nV + 1);
+        c->deleted.carve(c->zpool.p + z_del, (size_t)nR + 1); c->clip_stats.carve(c->zpool.p + z_stats, 4); c->is_node.carve(c->zpool.p + z_isn, (size_t)nV + 1); c->vtype_key.carve(c->zpool.p + z_vtk, (size_t)nV + 1);
         c->mrow_cnt.carve(c->zpool.p + z_mrc, (size_t)nR + 1); c->node_end.carve(c->zpool.p + z_nend, (size_t)nV + 2); c->node_cur.carve(c->zpool.p + z_ncur, (size_t)nV + 2);
         c->bsize.carve(c->zpool.p + z_bs, (size_t)nV + 1); c->cnt4.carve(c->zpool.p + z_c4, (size_t)nV * 4 + 4);
         const size_t need = GraphTemp::need((size_t)std::max<unsigned long long>(cap, (unsigned long long)std::max(nR, nV) + 1));
@@ -671,10 +671,9 @@ static int run_phase(lps_ctx *c) {
         ClipView C{c->clip_pos.p, c->clip_op.p};
         mark(c, ST_EXTRACT);
         launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, s);
-        launch_arena_sum(c->arena_ctr.p, arena_size, c->d_cnt, s);
         // ---- name keys (needs only row_cnt) and clip keys; the counters (sizes of the sorts, errors) start their way to the host ...
         mark(c, ST_GROUPS);
-        launch_name_keys(nR, c->r_name.p, c->row_cnt.p, c->name_keys.p, c->d_cnt, s);
+        launch_name_keys(nR, c->r_name.p, c->row_cnt.p, c->name_keys.p, c->d_cnt, c->arena_ctr.p, arena_size, s);
         launch_clip_keys(C, c->row_fail.p, nR, c->clip_keys.p, c->d_cnt, s);
         HIP_TRY(hipMemcpyAsync(c->h_cnt_pin, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(c->ev_cnv, s));

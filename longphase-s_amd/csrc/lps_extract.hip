@@ -49,18 +49,18 @@ __global__ void k_filter_snp(VarView V) {
     }
 }
 
-// coarse position index over the variant table (thread per bucket, plain binary search)
-__global__ void k_bucket_index(VarView V, int32_t *bucket) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > V.n_bucket) return;
-    const long long key = (long long)b << LPS_BUCKET_SHIFT;
-    int lo = 0, hi = V.n;
-    while (lo < hi) { const int m = (lo + hi) >> 1; if ((long long)V.pos[m] < key) lo = m + 1; else hi = m; }
-    bucket[b] = lo;
-}
-
 // one 8-byte record per variant so that a candidate costs ONE gather in the extraction kernel
-__global__ void k_variant_pack(VarView V, uint2 *rec) {
+// + (the workgroups after the variants') the coarse position index over the table: thread per bucket, plain binary search
+__global__ void k_variant_pack(VarView V, uint2 *rec, int32_t *bucket, int nb_pack) {
+    if ((int)blockIdx.x >= nb_pack) {
+        const int b = ((int)blockIdx.x - nb_pack) * blockDim.x + threadIdx.x;
+        if (b > V.n_bucket) return;
+        const long long key = (long long)b << LPS_BUCKET_SHIFT;
+        int lo = 0, hi = V.n;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if ((long long)V.pos[m] < key) lo = m + 1; else hi = m; }
+        bucket[b] = lo;
+        return;
+    }
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V.n) return;
     const int rl = V.ref_len[v], al = V.alt_len[v];
@@ -78,8 +78,7 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
     const int b = 256, g = (V.n + b - 1) / b;
     hipLaunchKernelGGL(k_variant_prep, dim3(g), dim3(b), 0, s, V);
     if (is_ont) hipLaunchKernelGGL(k_filter_snp, dim3(g), dim3(b), 0, s, V);
-    hipLaunchKernelGGL(k_variant_pack, dim3(g), dim3(b), 0, s, V, rec);
-    hipLaunchKernelGGL(k_bucket_index, dim3((V.n_bucket + 1 + b) / b), dim3(b), 0, s, V, bucket);
+    hipLaunchKernelGGL(k_variant_pack, dim3(g + (V.n_bucket + 1 + b) / b), dim3(b), 0, s, V, rec, bucket, g);
 }
 
 // ------------------------------------------------------------------------------------------------ extraction

@@ -12,7 +12,8 @@ void launch_clip_keys(const ClipView &C, const int32_t *row_fail, int n_reads, u
 void launch_clip_cnv(unsigned n_clips, unsigned long long *keys,
                      unsigned long long *keys_sorted, void *temp, size_t temp_bytes, int32_t *cnv_start, int32_t *cnv_end,
                      unsigned *stats, LpsCounters *cnt, hipStream_t s);
-void launch_name_keys(int n_reads, const uint32_t *name_id, const int32_t *row_cnt, unsigned long long *keys, LpsCounters *cnt, hipStream_t s);
+void launch_name_keys(int n_reads, const uint32_t *name_id, const int32_t *row_cnt, unsigned long long *keys, LpsCounters *cnt,
+                      const unsigned long long *arena_ctr, unsigned long long arena_size, hipStream_t s);
 void launch_groups(const unsigned long long *skeys, int n_reads, LpsCounters *cnt, uint32_t *head, uint32_t *gidx,
                    uint32_t *gstart, uint32_t *read_group, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_overlap_filter(const unsigned long long *skeys, const uint32_t *gstart, const LpsCounters *cnt, int n_reads,
@@ -31,13 +32,12 @@ void launch_debug_std_sort(int32_t *keys, uint8_t *payload, const long long *row
 void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
                        const uint32_t *row_off, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
                        unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list, hipStream_t s);
-void launch_arena_sum(const unsigned long long *arena_ctr, unsigned long long arena_size, LpsCounters *cnt, hipStream_t s);
 void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t *mrow_off, const int32_t *mrow_cnt, uint32_t *koff,
                        const int32_t *g_node, int m_bits, int a_bits, int n_bits, unsigned long long *keys,
                        unsigned long long *keys_sorted, uint32_t *vals, uint32_t *vals_sorted, unsigned long long n_keys,
                        uint32_t *node_off, uint32_t *node_cnt, uint32_t *node_cur, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
-                  const unsigned long long *ukeys, const uint32_t *uvals, const unsigned long long *skeys, const uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
+                  const unsigned long long *ukeys, const uint32_t *uvals, unsigned long long *skeys, uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                   int m_bits, int a_bits, const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
                   double edge_threshold, const uint8_t *ntype, float *edge, unsigned long long *erec, uint32_t *node_pairs, hipStream_t s);
 size_t scan_state_bytes(int n_var);

@@ -129,8 +129,21 @@ __global__ void k_cnv_state(const unsigned long long *keys, unsigned n_clips, co
 
 // ================================================================================================ name groups
 __global__ __launch_bounds__(256) void k_name_keys(int n_reads, const uint32_t *name_id, const int32_t *row_cnt, unsigned long long *keys,
-                                                   LpsCounters *cnt) {
+                                                   LpsCounters *cnt, const unsigned long long *arena_ctr, unsigned long long arena_size) {
     __shared__ unsigned s_cnt[4];
+    if (blockIdx.x == gridDim.x - 1) {                                  // one extra workgroup: observation slots reserved by the extraction, over the arenas
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            unsigned long long v = l < LPS_ARENAS ? arena_ctr[l * 8] : 0ull;
+            if (v > arena_size) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW);
+            unsigned long long mx = v;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+            v = wave_sum(v);
+            if (l == 0) { cnt->obs_total = v; cnt->arena_max = mx; }
+        }
+        return;
+    }
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool kept = r < n_reads && row_cnt[r] > 0;
     if (r < n_reads) keys[r] = kept ? ((unsigned long long)name_id[r] << 32 | (unsigned)r) : ~0ull;
@@ -378,19 +391,21 @@ __global__ __launch_bounds__(256) void k_mark_nodes(int n_reads, const uint32_t 
     }
 }
 
-__global__ void k_node_list(int n_var, const uint32_t *is_node, const uint32_t *node_of, const uint32_t *vtype_key,
-                            int32_t *nodes, uint8_t *ntype, LpsCounters *cnt) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_var) return;
-    if (is_node[v]) { nodes[node_of[v]] = v; ntype[node_of[v]] = (uint8_t)(vtype_key[v] & 7u); }
-    if (v == n_var - 1) cnt->n_nodes = node_of[v] + is_node[v];
-}
-
 // wave per alignment: graph view of the observations (node index, allele, hi-quality flag) in the same slots
 __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const uint32_t *row_off, const int32_t *row_cnt,
                                                    const uint8_t *deleted, const int32_t *obs_var, const uint16_t *obs_aq,
                                                    const uint32_t *node_of, int base_quality, int32_t *g_node, uint8_t *g_flag,
-                                                   int32_t *g_cnt, LpsCounters *cnt) {
+                                                   int32_t *g_cnt, LpsCounters *cnt, int n_var, const uint32_t *is_node, const uint32_t *vtype_key,
+                                                   int32_t *nodes, uint8_t *ntype) {
+    const int nb_reads = (n_reads + 3) / 4;
+    if ((int)blockIdx.x >= nb_reads) {                                  // the workgroups after the alignments': node list (variant index, type) and node count
+        const int v = ((int)blockIdx.x - nb_reads) * blockDim.x + threadIdx.x;
+        if (v < n_var) {
+            if (is_node[v]) { nodes[node_of[v]] = v; ntype[node_of[v]] = (uint8_t)(vtype_key[v] & 7u); }
+            if (v == n_var - 1) cnt->n_nodes = node_of[v] + is_node[v];
+        }
+        return;
+    }
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
     if (r >= n_reads) return;
     const int n = row_cnt[r];
@@ -622,23 +637,6 @@ __global__ __launch_bounds__(256) void k_node_scatter(const LpsCounters *cnt, co
     }
 }
 
-// wave per node with MORE than 64 entries (coverage above 64): order the node's entries by key (rank = number of smaller keys; keys are unique)
-__global__ __launch_bounds__(256) void k_node_sort(const LpsCounters *cnt, const uint32_t *node_off, const uint32_t *node_cnt,
-                                                   const unsigned long long *keys, const uint32_t *vals, unsigned long long *skeys, uint32_t *svals) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
-    if (i >= (int)cnt->n_nodes) return;
-    const uint32_t off = node_off[i]; const int n = (int)node_cnt[i];
-    if (n <= 64) return;                                               // k_edges orders lists of up to 64 entries itself, in registers
-    {
-        for (int a = l; a < n; a += 64) {
-            const unsigned long long k = keys[off + a];
-            int rank = 0;
-            for (int t = 0; t < n; ++t) rank += keys[off + t] < k;           // wave-uniform address: one broadcast load per step
-            skeys[off + rank] = k; svals[off + rank] = vals[off + a];
-        }
-    }
-}
-
 // ================================================================================================ edges
 __device__ __forceinline__ float edge_upd(float x, bool hi, double w) {
     return hi ? x + 1.0f : (float)((double)x + w);           // SubEdge::addSubEdge (:40-43,62-65)
@@ -649,7 +647,7 @@ __device__ __forceinline__ float edge_upd(float x, bool hi, double w) {
 // its node distance d selects the owning lane, the (allele pair, quality class) travels there by ds_permute.
 __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uint32_t *node_off, const uint32_t *node_end,
                                                const unsigned long long *ukeys, const uint32_t *uvals,
-                                               const unsigned long long *skeys, const uint32_t *svals,
+                                               unsigned long long *skeys, uint32_t *svals,
                                                const uint32_t *mrow_off, const int32_t *mrow_cnt, int m_bits, int a_bits,
                                                const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
                                                double edge_threshold, const uint8_t *ntype, float *edge, unsigned long long *erec, uint32_t *node_pairs) {
@@ -660,7 +658,17 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     unsigned long long pairs = 0;
     const unsigned long long m_mask = (1ull << m_bits) - 1ull;
-    const bool short_list = end - off <= 64;                           // unsorted entries (ukeys/uvals): ordered here; longer lists come sorted (k_node_sort)
+    const bool short_list = end - off <= 64;                           // unsorted entries (ukeys/uvals): up to 64 are ordered in registers below
+    if (!short_list) {                                                  // coverage above 64: rank sort through memory (rank = number of smaller keys; keys are unique)
+        const int n = (int)(end - off);
+        for (int a = l; a < n; a += 64) {
+            const unsigned long long k = ukeys[off + a];
+            int rank = 0;
+            for (int t = 0; t < n; ++t) rank += ukeys[off + t] < k;    // wave-uniform address: one broadcast load per step
+            skeys[off + rank] = k; svals[off + rank] = uvals[off + a];
+        }
+        __threadfence_block(); wave_sync();
+    }
     for (uint32_t e0 = off; e0 < end; e0 += 64) {
         const int nb = (int)min(64u, end - e0);
         uint32_t my_val = 0, my_end = 0;
@@ -1154,8 +1162,7 @@ void launch_clip_keys(const ClipView &C, const int32_t *row_fail, int n_reads, u
 void launch_clip_cnv(unsigned n_clips, unsigned long long *keys,
                      unsigned long long *keys_sorted, void *temp, size_t temp_bytes, int32_t *cnv_start, int32_t *cnv_end,
                      unsigned *stats, LpsCounters *cnt, hipStream_t s) {
-    HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(unsigned), s));
-    if (n_clips) {
+    if (n_clips) {                                                      // stats: zero from the zero pool
         sort_keys64(temp, temp_bytes, keys, keys_sorted, n_clips, 33, s);          // key = pos << 1 | front/back: 33 bits, 5 digit passes instead of 8
         hipLaunchKernelGGL(k_clip_stats, GRID(n_clips, 256), 0, s, keys_sorted, n_clips, stats);
     }
@@ -1163,8 +1170,8 @@ void launch_clip_cnv(unsigned n_clips, unsigned long long *keys,
 }
 
 void launch_name_keys(int n_reads, const uint32_t *name_id, const int32_t *row_cnt, unsigned long long *keys,
-                      LpsCounters *cnt, hipStream_t s) {
-    hipLaunchKernelGGL(k_name_keys, GRID(n_reads, 256), 0, s, n_reads, name_id, row_cnt, keys, cnt);
+                      LpsCounters *cnt, const unsigned long long *arena_ctr, unsigned long long arena_size, hipStream_t s) {
+    hipLaunchKernelGGL(k_name_keys, dim3((n_reads + 255) / 256 + 1), dim3(256), 0, s, n_reads, name_id, row_cnt, keys, cnt, arena_ctr, arena_size);
 }
 
 void launch_groups(const unsigned long long *skeys, int n_reads, LpsCounters *cnt, uint32_t *head, uint32_t *gidx,
@@ -1186,8 +1193,7 @@ void launch_nodes(int n_reads, int n_var, const uint32_t *row_off, const int32_t
                   LpsCounters *cnt, void *temp, size_t temp_bytes, hipStream_t s) {
     hipLaunchKernelGGL(k_mark_nodes, dim3((n_reads + 3) / 4), dim3(256), 0, s, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, is_node, vtype_key);
     exscan_u32(temp, temp_bytes, is_node, node_of, n_var, s);
-    hipLaunchKernelGGL(k_node_list, GRID(n_var, 256), 0, s, n_var, is_node, node_of, vtype_key, nodes, ntype, cnt);
-    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + 3) / 4), dim3(256), 0, s, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, node_of, base_quality, g_node, g_flag, g_cnt, cnt);
+    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + 3) / 4 + (n_var + 255) / 256), dim3(256), 0, s, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, node_of, base_quality, g_node, g_flag, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype);
 }
 
 void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
@@ -1197,20 +1203,6 @@ void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, 
     hipLaunchKernelGGL(k_merge_multi, dim3(256), dim3(256), 0, s, skeys, gstart, cnt, row_off, g_cnt, g_node, g_flag, mrow_off, multi_list);
 }
 
-__global__ void k_arena_sum(const unsigned long long *arena_ctr, unsigned long long arena_size, LpsCounters *cnt) {
-    const int l = threadIdx.x;
-    unsigned long long v = l < LPS_ARENAS ? arena_ctr[l * 8] : 0ull;
-    if (v > arena_size) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW);
-    unsigned long long mx = v;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
-    v = wave_sum(v);
-    if (l == 0) { cnt->obs_total = v; cnt->arena_max = mx; }
-}
-void launch_arena_sum(const unsigned long long *arena_ctr, unsigned long long arena_size, LpsCounters *cnt, hipStream_t s) {
-    hipLaunchKernelGGL(k_arena_sum, dim3(1), dim3(64), 0, s, arena_ctr, arena_size, cnt);
-}
-
 void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t *mrow_off, const int32_t *mrow_cnt, uint32_t *koff,
                        const int32_t *g_node, int m_bits, int a_bits, int n_bits, unsigned long long *keys,
                        unsigned long long *keys_sorted, uint32_t *vals, uint32_t *vals_sorted, unsigned long long n_keys,
@@ -1218,12 +1210,12 @@ void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t 
     hipLaunchKernelGGL(k_node_count, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, mrow_off, mrow_cnt, g_node, node_cnt, cnt, koff);
     exscan_u32(temp, temp_bytes, node_cnt, node_off, (size_t)n_var + 1, s);
     hipLaunchKernelGGL(k_node_scatter, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, mrow_off, mrow_cnt, g_node, node_off, node_cur, a_bits, keys, vals, cnt, n_var);
-    hipLaunchKernelGGL(k_node_sort, dim3((n_var + 3) / 4), dim3(256), 0, s, cnt, node_off, node_cnt, keys, vals, keys_sorted, vals_sorted);
+    (void)keys_sorted; (void)vals_sorted;
     (void)m_bits; (void)n_bits; (void)n_keys;
 }
 
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
-                  const unsigned long long *ukeys, const uint32_t *uvals, const unsigned long long *skeys, const uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
+                  const unsigned long long *ukeys, const uint32_t *uvals, unsigned long long *skeys, uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                   int m_bits, int a_bits, const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
                   double edge_threshold, const uint8_t *ntype, float *edge, unsigned long long *erec, uint32_t *node_pairs, hipStream_t s) {
     hipLaunchKernelGGL(k_edges, dim3((n_var + 3) / 4), dim3(256), 0, s, cnt, node_off, node_end, ukeys, uvals, skeys, svals, mrow_off, mrow_cnt, m_bits, a_bits, g_node, g_flag, A, edge_weight, edge_threshold, ntype, edge, erec, node_pairs);

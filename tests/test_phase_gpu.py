@@ -95,6 +95,24 @@ def test_rows_longer_than_the_extraction_buffer(seed, len_median):
         ctx.close()
 
 
+def test_nodes_with_more_than_64_reads():
+    """Coverage ~90: every node's entry list is longer than a wavefront, so k_edges orders it through memory (rank sort) instead of in registers;
+    the fp32 edge sums must still be the reference's bit for bit."""
+    kw = dict(seed=81, contig_len=80_000, n_snp=90, coverage=90.0, len_median=9000.0, len_min=1000, sub_rate=0.03, lowq_frac=0.1, supp_frac=0.05,
+              n_threads=2, snp_pair_frac=0.02, snp_in_hpoly_frac=0.1, hpoly_every=400.0)
+    s, V, R, P, ref_out, d, ctx, out = run_both(kw, {})
+    try:
+        nodes, edge = ctx.dump_graph()
+        N = d.c.n_nodes
+        assert np.array_equal(nodes, d.node_var[:N])
+        assert np.array_equal(edge.view(np.uint32), d.edge[:N].view(np.uint32)), "edge matrix differs bitwise"
+        cnt, var, al, q = ctx.dump_observations()
+        assert np.bincount(var).max() > 64
+        util.assert_phase_equal(out.phase_set, out.gt, ref_out.phase_set, ref_out.gt, "coverage 90 vs oracle")
+    finally:
+        ctx.close()
+
+
 def test_repeat_runs_are_identical_and_recomputed():
     kw, cli, over = fixtures.PHASE_FIXTURES["snp_ont_seed2"]
     s, V, R = util.make_case(kw)
