@@ -55,6 +55,7 @@ struct lps_ctx {
     unsigned long long obs_capacity = 0;   // main arenas (LPS_ARENAS equal parts); a tail arena of obs_capacity/4 follows
     DevBuf<unsigned long long> arena_ctr;
     bool in_phase = false; int timing_level = 2;
+    uint32_t name_max = 0;        // largest name_id pushed for this chromosome: bounds the digits of the name sort
     size_t z_late_off = 0, z_late_bytes = 0; unsigned long long late_n_keys = 0, late_cap_main = 0, late_tail = 0; bool cnv_skipped = false;
     DevBuf<uint8_t> hap_pool;     // per-read outputs of the scoring kernels, carved like zpool
     DevBuf<uint8_t> zpool;        // the zero-initialised arrays of a phase run (arena_ctr, out_ps/gt, deleted, is_node, vtype_key, mrow_cnt, node_end/cur, bsize, cnt4) are carved from it
@@ -200,7 +201,7 @@ void *lps_stream(lps_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int lps_begin_chromosome(lps_ctx *c) {
     if (!c) return -1;
     c->nV = 0; c->last_pos = -1; c->ref_len = c->ref_len_eff = 0; c->nR = 0; c->n_cig = c->n_seq = c->n_qual = 0; c->n_blob = 0; c->read_mode = 0; c->cur_first = -1; c->cur_count = 0;
-    c->phase_valid = false; c->has_hap = false; c->h_vpos.clear();
+    c->phase_valid = false; c->has_hap = false; c->h_vpos.clear(); c->name_max = 0;
     return 0;
 }
 
@@ -261,6 +262,7 @@ int lps_push_reads(lps_ctx *c, const lps_read_batch *b) {
         upload(c, c->r_start, b->ref_start, n, at, true); upload(c, c->r_lq, b->l_qseq, n, at, true);
         upload(c, c->r_flag, b->flag, n, at, true); upload(c, c->r_mapq, b->mapq, n, at, true);
         upload(c, c->r_name, b->name_id, n, at, true);
+        for (size_t i = 0; i < n; ++i) c->name_max = std::max(c->name_max, b->name_id[i]);
         std::vector<uint64_t> co(n + 1), so(n + 1), qo(n + 1);
         for (size_t i = 0; i <= n; ++i) { co[i] = b->cigar_off[i] - b->cigar_off[0] + c->n_cig; so[i] = b->seq_off[i] - b->seq_off[0] + c->n_seq; qo[i] = b->qual_off[i] - b->qual_off[0] + c->n_qual; }
         upload(c, c->r_coff, co.data(), n + 1, at, true); upload(c, c->r_soff, so.data(), n + 1, at, true); upload(c, c->r_qoff, qo.data(), n + 1, at, true);
@@ -278,6 +280,7 @@ int lps_push_reads(lps_ctx *c, const lps_read_batch *b) {
 static int push_record_view(lps_ctx *c, const BamView &B, size_t n, const uint32_t *name_id) {
     const size_t at = (size_t)c->nR; hipStream_t s = c->stream;
     upload(c, c->r_name, name_id, n, at, true);
+    for (size_t i = 0; i < n; ++i) c->name_max = std::max(c->name_max, name_id[i]);
     c->r_start.reserve(at + n, s, true, at); c->r_lq.reserve(at + n, s, true, at); c->r_flag.reserve(at + n, s, true, at); c->r_mapq.reserve(at + n, s, true, at);
     c->r_soff.reserve(at + n + 1, s, true, at); c->r_qoff.reserve(at + n + 1, s, true, at); c->r_coff.reserve(at + n + 1, s, true, at);
     c->cig_cnt.reserve(n + 1); c->bam_err.reserve(1);
@@ -679,7 +682,10 @@ static int run_phase(lps_ctx *c) {
         HIP_TRY(hipEventRecord(c->ev_cnv, s));
         // ---- ... while the GPU sorts the names into groups and runs the overlap filter (a8): no bubble when the host looks at them
         mark(c, ST_GROUPS2);
-        sort_keys64(c->temp.p, c->temp_bytes, c->name_keys.p, c->name_keys_s.p, nR, 64, s);
+        // keys are (name rank << 32 | alignment index), written in index order: a STABLE sort by the name digits alone leaves equal names in index
+        // order, so only the bits of the largest rank are sorted (3 digit passes for chr20 instead of 8); one more value than name_max so that the
+        // all-ones sentinel of alignments without observations stays above every name
+        sort_keys64_range(c->temp.p, c->temp_bytes, c->name_keys.p, c->name_keys_s.p, nR, 32, 32 + bits_for((unsigned long long)c->name_max + 2), s);
         launch_groups(c->name_keys_s.p, nR, c->d_cnt, c->head.p, c->gidx.p, c->gstart.p, c->read_group.p, c->temp.p, c->temp_bytes, s);
         mark(c, ST_OVERLAP);
         launch_overlap_filter(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->row_cnt.p, c->obs_var.p, c->v_pos.p, P.overlap_threshold, c->stack.p, c->deleted.p, s);

@@ -4,6 +4,7 @@
 
 struct GraphTemp { static size_t need(size_t n_sort); };
 
+void sort_keys64_range(void *temp, size_t temp_bytes, const unsigned long long *in, unsigned long long *out, size_t n, int begin_bit, int end_bit, hipStream_t s);
 void sort_keys64(void *temp, size_t temp_bytes, const unsigned long long *in, unsigned long long *out, size_t n, int bits, hipStream_t s);
 void sort_pairs64(void *temp, size_t temp_bytes, const unsigned long long *kin, unsigned long long *kout, const uint32_t *vin, uint32_t *vout, size_t n, int bits, hipStream_t s);
 void exscan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s);

@@ -1116,6 +1116,11 @@ void sort_keys64(void *temp, size_t temp_bytes, const unsigned long long *in, un
     if (n == 0) return;
     HIP_TRY(rocprim::radix_sort_keys(temp, temp_bytes, in, out, n, 0, bits, s));
 }
+void sort_keys64_range(void *temp, size_t temp_bytes, const unsigned long long *in, unsigned long long *out, size_t n, int begin_bit, int end_bit,
+                       hipStream_t s) {
+    if (n == 0) return;
+    HIP_TRY(rocprim::radix_sort_keys(temp, temp_bytes, in, out, n, (unsigned)begin_bit, (unsigned)std::min(end_bit, 64), s));
+}
 void sort_pairs64(void *temp, size_t temp_bytes, const unsigned long long *kin, unsigned long long *kout, const uint32_t *vin,
                   uint32_t *vout, size_t n, int bits, hipStream_t s) {
     if (n == 0) return;
