@@ -56,7 +56,7 @@ enum {
 
 // device-side counters block (one per ctx), zeroed at the start of every run
 struct LpsCounters {
-    unsigned long long obs_total;   // reserved observation slots summed over the arenas (filled by k_arena_sum)
+    unsigned long long obs_total;   // reserved observation slots summed over the arenas (filled by the last workgroup of k_name_keys)
     unsigned int n_clips;
     unsigned int err;
     unsigned int n_kept;            // alignments with >=1 observation

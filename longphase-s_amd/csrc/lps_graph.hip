@@ -4,7 +4,7 @@
 //   Clip::getCNVInterval (x2)            src/phase/PhasingGraph.cpp:1103-1227  -> k_clip_keys + sort + k_cnv_state
 //   VairiantGraph::addEdge overlap filter src/phase/PhasingGraph.cpp:707-781   -> k_name_keys + sort + k_group_* + k_overlap_filter
 //   addEdge type tagging / node set       :793-846                             -> k_mark_nodes + scan + k_graph_obs
-//   addEdge pair loop + addSubEdge        :848-888, :25-70                     -> k_merge_plan/k_merge_multi + k_node_count/scatter/sort + k_edges
+//   addEdge pair loop + addSubEdge        :848-888, :25-70                     -> k_merge_plan/k_merge_multi + k_node_count/scatter + k_edges (orders the node lists)
 //   findBestEdgePair                      :166-228                             -> epilogue of k_edges (edge-info byte)
 //   edgeConnectResult + Onelongcase       :286-474, :251-283                   -> k_vote_scan
 //   readCorrection + exportResult         :891-1029, :1049-1077                -> k_block_size + k_read_correction + k_final
@@ -609,8 +609,8 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
 }
 
 // ---- node-major lists: entries of node n = observations of n in merged rows, ordered by (name rank, index in merged row).
-// No global sort: count per node (atomics), exclusive scan, scatter in arbitrary order, then every node's short list is put in
-// order by rank counting inside one wave (n^2/64 compares for n entries; n ~ coverage).
+// No global sort: count per node (atomics), exclusive scan, scatter in arbitrary order; every node's short list is put in order by rank
+// counting by the wave of k_edges that consumes it (n^2/64 compares for n entries; n ~ coverage).
 __global__ __launch_bounds__(256) void k_node_count(const LpsCounters *cnt, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                                                     const int32_t *g_node, uint32_t *node_cnt, LpsCounters *cntw, const uint32_t *koff) {
     const unsigned g = blockIdx.x * 4 + (threadIdx.x >> 6); const int l = lane_id();
