@@ -565,46 +565,62 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
         if (g == 0xffffffffu) continue;                                   // its tail reservation failed (the host grows the buffers and reruns)
         const uint32_t s0 = gstart[g], s1 = gstart[g + 1];
         const uint32_t base = mrow_off[g];
+        const int w = threadIdx.x >> 6;
+        int total = 0; for (uint32_t sa = s0; sa < s1; ++sa) total += g_cnt[(uint32_t)skeys[sa]];
+        const bool in_lds = total <= STDSORT_LDS;
+        // the alignments' rows concatenated in BAM order, in LDS when they fit (they do for real read lengths): the rank searches below are chains
+        // of dependent probes - tens of cycles each in LDS, a microsecond each in HBM - and the std::sort path wants this copy anyway
+        if (in_lds) {
+            int at = 0;
+            for (uint32_t sa = s0; sa < s1; ++sa) { const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = row_off[ra];
+                for (int k = l; k < na; k += 64) { s_k[w][at + k] = g_node[oa + k]; s_p[w][at + k] = g_flag[oa + k]; } at += na; }
+            wave_sync();
+        }
         bool dup = false;
+        int aa = 0;                                                      // offset of alignment sa's row inside the concatenation
         for (uint32_t sa = s0; sa < s1; ++sa) {                      // source alignment (BAM order inside the group)
             const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = row_off[ra];
             for (int k = l; k < na; k += 64) {
-                const int nd = g_node[oa + k]; const uint8_t fl = g_flag[oa + k];
-                int rank = k;
+                const int nd = in_lds ? s_k[w][aa + k] : g_node[oa + k]; const uint8_t fl = in_lds ? s_p[w][aa + k] : g_flag[oa + k];
+                int rank = k, ab = 0;
                 for (uint32_t sb = s0; sb < s1; ++sb) {
-                    if (sb == sa) continue;
-                    const uint32_t rb = (uint32_t)skeys[sb]; const int nb = g_cnt[rb]; const uint32_t ob = row_off[rb];
-                    // earlier alignment: its equal positions go first (count <= nd); later alignment: only smaller ones
-                    int lo = 0, hi = nb;
-                    if (sb < sa) { while (lo < hi) { const int m = (lo + hi) >> 1; if (g_node[ob + m] <= nd) lo = m + 1; else hi = m; } }
-                    else { while (lo < hi) { const int m = (lo + hi) >> 1; if (g_node[ob + m] < nd) lo = m + 1; else hi = m; }
-                           dup |= lo < nb && g_node[ob + lo] == nd; }                                // the same position in a later alignment
-                    rank += lo;
+                    const uint32_t rb = (uint32_t)skeys[sb]; const int nb = g_cnt[rb];
+                    if (sb != sa) {
+                        const int32_t *row = in_lds ? s_k[w] + ab : g_node + row_off[rb];
+                        // earlier alignment: its equal positions go first (count <= nd); later alignment: only smaller ones
+                        int lo = 0, hi = nb;
+                        if (sb < sa) { while (lo < hi) { const int m = (lo + hi) >> 1; if (row[m] <= nd) lo = m + 1; else hi = m; } }
+                        else { while (lo < hi) { const int m = (lo + hi) >> 1; if (row[m] < nd) lo = m + 1; else hi = m; }
+                               dup |= lo < nb && row[lo] == nd; }                                    // the same position in a later alignment
+                        rank += lo;
+                    }
+                    ab += nb;
                 }
                 g_node[base + rank] = nd; g_flag[base + rank] = fl;
             }
+            aa += na;
         }
         // The placement above is the STABLE order.  libstdc++'s std::sort leaves equal positions in another order once a row has more than 16
         // elements, and the reference's float sums see that order: when the row holds a position twice, rebuild it as the reference does -
         // alignments concatenated in BAM order, then std::sort restated step by step (lps_stdsort.h).  Rare (overlapping supplementary alignments).
-        int total = 0; for (uint32_t sa = s0; sa < s1; ++sa) total += g_cnt[(uint32_t)skeys[sa]];
 #ifndef LPS_NO_STDSORT_FIX
         if (total > 16) {
             if (__ballot(dup)) {
-                // concatenation in BAM order: into LDS and sorted by the whole wave (wave_std_sort) for rows of up to STDSORT_LDS elements, else in
-                // place in HBM by lane 0 (a chain of dependent accesses at ~1 us each; such rows do not occur with real read lengths)
-                const int w = threadIdx.x >> 6; const bool in_lds = total <= STDSORT_LDS;
-                int32_t *kk = in_lds ? s_k[w] : g_node + base; uint8_t *pp = in_lds ? s_p[w] : g_flag + base;
-                int at = 0;
-                for (uint32_t sa = s0; sa < s1; ++sa) { const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = row_off[ra];
-                    for (int k = l; k < na; k += 64) { kk[at + k] = g_node[oa + k]; pp[at + k] = g_flag[oa + k]; } at += na; }
-                __threadfence_block();
-                if (in_lds) wave_std_sort(kk, pp, total, s_stk[w], s_a[w], s_b[w], g_node + base, g_flag + base, l);
-                else if (l == 0) { StdSortArrays a{kk, pp}; stdsort_run(a, total, s_stk[w]); }
+                // sorted by the whole wave (wave_std_sort) from the LDS copy for rows of up to STDSORT_LDS elements, else in place in HBM by lane 0
+                // (a chain of dependent accesses at ~1 us each; such rows do not occur with real read lengths)
+                if (in_lds) { wave_sync(); wave_std_sort(s_k[w], s_p[w], total, s_stk[w], s_a[w], s_b[w], g_node + base, g_flag + base, l); }
+                else {
+                    int at = 0;
+                    for (uint32_t sa = s0; sa < s1; ++sa) { const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = row_off[ra];
+                        for (int k = l; k < na; k += 64) { g_node[base + at + k] = g_node[oa + k]; g_flag[base + at + k] = g_flag[oa + k]; } at += na; }
+                    __threadfence_block();
+                    if (l == 0) { StdSortArrays a{g_node + base, g_flag + base}; stdsort_run(a, total, s_stk[w]); }
+                }
                 __threadfence_block();
             }
         }
 #endif
+        wave_sync();                                                     // the LDS copy is reused by the wave's next group
     }
 }
 
