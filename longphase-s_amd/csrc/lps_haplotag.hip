@@ -19,7 +19,7 @@
 //   2 = germline votes gated by MAPQ (low-MAPQ reads are NOT skipped in this pass) + per-site base counters by atomics + the read's
 //       haplotype; 3 = re-walk that adds the read's haplotype to ReadHpCount of every tumor site it touched (:171-173).
 template <int MODE>
-__global__ __launch_bounds__(256) void k_haplotag_score(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary,
+__global__ __launch_bounds__(256, 6) void k_haplotag_score(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary,
                                                         LpsCounters *cnt) {
     __shared__ __attribute__((aligned(16))) int s_ref[4][LPS_SEG];
     __shared__ __attribute__((aligned(16))) int s_qry[4][LPS_SEG];
