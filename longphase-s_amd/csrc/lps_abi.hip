@@ -838,6 +838,9 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
         // judgeReadHap (src/haplotag/HaplotagStrategy.cpp:243-300) on the host: needs libm's log10
         const double thr = c->P.percentage_threshold;
         int64_t tagged = 0;
+        struct PqSmall { int v[64][64]; };                                       // PQ of (min votes, max votes) for small counts: libm's log10 once per pair
+        static const PqSmall pq_tab = [] { PqSmall t{}; for (int mn = 1; mn < 64; ++mn) for (int mx = mn; mx < 64; ++mx) t.v[mn][mx] = -10 * (std::log10((double)mn / double((double)mx + (double)mn))); return t; }();
+        const auto &pq_small = pq_tab.v;
         for (int r = 0; r < nR; ++r) {
             int hp = 0, pq = 0;
             if (out->status[r] == 0) {
@@ -846,7 +849,9 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
                 if (a > b) { mn = b; mx = a; } else { mn = a; mx = b; }
                 if (mx / (mx + mn) < thr) pq = 0;
                 else { if (a > b) hp = 1; if (a < b) hp = 2; }
-                if (mx == 0) pq = 0; else if (mx == mx + mn) pq = 40; else pq = -10 * (std::log10((double)mn / double(mx + mn)));
+                if (mx == 0) pq = 0; else if (mx == mx + mn) pq = 40;
+                else if (a < 64 && b < 64) pq = pq_small[a < b ? a : b][a < b ? b : a];    // the same expression, evaluated once per (min, max) pair
+                else pq = -10 * (std::log10((double)mn / double(mx + mn)));
                 if (out->n_ps[r] > 1) hp = 0;
             }
             out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = hp ? out->ps_min[r] : 0;
