@@ -273,8 +273,12 @@ __global__ __launch_bounds__(256, 4) void k_extract_phase(VarView V, ReadView R,
                 bool emit = false, fail = false; int allele = -1, qv = 0, opi = 0;
                 if (mine) {
                     const unsigned at = vr.y;
-                    int lo = 0, hi = nseg;                       // first j with sref[j] > p
-                    while (lo < hi) { const int m = (lo + hi) >> 1; if (sref[m] > p) hi = m; else lo = m + 1; }
+                    // number of staged ops that start at or before p, by a fixed-trip search without branches: all LPS_SEG entries are valid numbers
+                    // (the entries past the segment's ops hold its end position, which is beyond every candidate)
+                    int lo = 0;
+#pragma unroll
+                    for (int step = LPS_SEG / 2; step >= 1; step >>= 1) lo += (sref[lo + step - 1] <= p) ? step : 0;
+                    lo += (sref[lo] <= p) ? 1 : 0;               // lo <= LPS_SEG - 1 before this probe
                     const int j = lo - 1;
                     if (j >= 0) {
                         const uint32_t wd = scig[j];
