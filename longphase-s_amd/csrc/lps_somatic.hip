@@ -122,8 +122,11 @@ __global__ __launch_bounds__(256) void k_tumor_extract(VarView V, ReadView R, Tu
                 bool want_win = false, pair = false; int win_allele = 0, opj = 0, win_off = 0, base_hp = 0;
                 if (mine) {
                     const unsigned at = vr.y;
-                    int lo = 0, hi = nseg;
-                    while (lo < hi) { const int m = (lo + hi) >> 1; if (sref[m] > p) hi = m; else lo = m + 1; }
+                    // ops starting at or before p: fixed-trip search without branches (entries past the segment's ops hold its end position)
+                    int lo = 0;
+#pragma unroll
+                    for (int step = LPS_SEG / 2; step >= 1; step >>= 1) lo += (sref[lo + step - 1] <= p) ? step : 0;
+                    lo += (sref[lo] <= p) ? 1 : 0;
                     const int j = lo - 1;
                     if (j >= 0) {
                         const uint32_t wd = scig[j];
