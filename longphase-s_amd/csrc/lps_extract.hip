@@ -215,11 +215,12 @@ __global__ __launch_bounds__(256, 4) void k_extract_phase(VarView V, ReadView R,
                 pv0 = (vcur > 0 && vcur < V.n) ? V.pos[vcur - 1] : -1;
             }
             int my_ref;
-            const unsigned cm = stage_ops8(wds, l, ref_pos, q_pos, sref, sqry, scig, my_ref);
+            const unsigned seen = stage_ops8(wds, l, ref_pos, q_pos, sref, sqry, scig, my_ref);
+            if (__ballot((seen & LPS_OPS_BAD) != 0u) && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);   // the reference exits (:1625-1628)
             (void)my_ref;
             // getClip (:1613-1620,1636-1645): soft/hard clips longer than 5; FRONT iff CIGAR index 0.
             // Events go to the read's own LPS_CLIP_SLOTS slots (no atomics here); compaction happens later.
-            if (__ballot(cm == 0u)) {                            // rare (first / last segment of a clipped alignment): words re-read from LDS
+            if (__ballot((seen & LPS_OPS_CLIP) != 0u)) {                            // rare (first / last segment of a clipped alignment): words re-read from LDS
                 int mine_n = 0;
 #pragma unroll 1
                 for (int k = 0; k < 8; ++k) { const uint32_t wd = scig[8 * l + k]; const unsigned op = wd & 15u; mine_n += ((op == 4u || op == 5u) && (wd >> 4) > 5u) ? 1 : 0; }

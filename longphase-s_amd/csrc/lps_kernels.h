@@ -94,17 +94,21 @@ __device__ __forceinline__ unsigned op_consume_bits(unsigned op) { return ((0x19
 __device__ __forceinline__ int bit_mask(unsigned x, int bit) { return (int)(x << (31 - bit)) >> 31; }      // 0 or -1 (v_bfe_i32)
 
 // Stages the segment whose words are in w (lane l owns ops 8l..8l+7 of it) in LDS: sref/sqry = reference / query position at which the op
-// starts, scig = the raw word.  ref_pos / q_pos (wave-uniform) advance over the segment.  Returns, per lane, 0 iff one of its ops is a
-// soft / hard clip (the caller then looks closer); my_ref = reference position of the lane's first op.
+// starts, scig = the raw word.  ref_pos / q_pos (wave-uniform) advance over the segment.  Returns, per lane, the set of op codes its 8 words
+// hold (bit op; the padding past the segment sets bit 6): LPS_OPS_CLIP = a soft / hard clip is among them (the caller then looks closer),
+// LPS_OPS_BAD = an op code the reference rejects (ParsingBam.cpp:1625-1628).  my_ref = reference position of the lane's first op.
+#define LPS_OPS_CLIP 0x30u
+#define LPS_OPS_BAD 0xfe00u
 __device__ __forceinline__ unsigned stage_ops8(const uint32_t (&w)[8], int l, int &ref_pos, int &q_pos, int *sref, int *sqry, uint32_t *scig, int &my_ref) {
     // lane totals first, positions in a second sweep over the same 8 words: holding 16 prefix values across the wave scan would cost the
     // kernels a wave of occupancy, recomputing them costs 40 instructions per segment
-    int rt = 0, qt = 0; unsigned cm = 0xffffffffu;
+    int rt = 0, qt = 0; unsigned seen = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const unsigned t = op_consume_bits(w[k] & 15u); const int len = (int)(w[k] >> 4);
+        const unsigned op = w[k] & 15u;
+        const unsigned t = op_consume_bits(op); const int len = (int)(w[k] >> 4);
         rt += len & bit_mask(t, 0); qt += len & bit_mask(t, 16);
-        cm = min(cm, (w[k] & 14u) ^ 4u);
+        seen |= 1u << op;
     }
     const int ir = wave_incl_scan_dpp(rt), iq = wave_incl_scan_dpp(qt);
     my_ref = ref_pos + ir - rt; int rr = my_ref, qq = q_pos + iq - qt;
@@ -121,7 +125,7 @@ __device__ __forceinline__ unsigned stage_ops8(const uint32_t (&w)[8], int l, in
         dc[h] = make_uint4(w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]);
     }
     ref_pos += __shfl(ir, 63); q_pos += __shfl(iq, 63);
-    return cm;
+    return seen;
 }
 
 // first variant with pos >= key: one bucket lookup narrows the range to the variants of a 1-kb window, then one

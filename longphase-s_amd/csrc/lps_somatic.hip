@@ -105,12 +105,8 @@ __global__ __launch_bounds__(256) void k_tumor_extract(VarView V, ReadView R, Tu
             const uint32_t nextw = (seg0 + nseg < n_cig) ? cig[seg0 + nseg] : 0xfu;
             uint32_t wds[8];                                         // 8 consecutive ops per lane (lps_kernels.h)
             load_ops8(cig + seg0, 8 * l, nseg, wds);
-            unsigned mxop = 0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) mxop = max(mxop, wds[u] & 15u);
-            const bool bad = mxop > 8u;
             int my_ref;
-            (void)stage_ops8(wds, l, ref_pos, q_pos, sref, sqry, scig, my_ref);
+            const bool bad = (stage_ops8(wds, l, ref_pos, q_pos, sref, sqry, scig, my_ref) & LPS_OPS_BAD) != 0u;
             if (__ballot(bad) && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
             if (l == 0) scig[nseg] = nextw;
             wave_sync();

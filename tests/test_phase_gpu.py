@@ -113,6 +113,30 @@ def test_nodes_with_more_than_64_reads():
         ctx.close()
 
 
+def test_unsupported_cigar_op_is_an_error():
+    """The reference prints "alignment find unsupported CIGAR operation" and exits (ParsingBam.cpp:1625-1628); the library returns an error
+    with that message.  An op code above 8 in an alignment that is filtered out (MAPQ 0) is never looked at, as in the reference."""
+    kw, cli, over = fixtures.PHASE_FIXTURES["snp_ont_seed2"]
+    s, V, R = util.make_case(kw)
+    P = abi.default_params(**over)
+    r = R.n_reads // 2
+    o = int(R.cigar_off[r]) + (int(R.cigar_off[r + 1]) - int(R.cigar_off[r])) // 2
+    arrays = {n: getattr(R, n).copy() for n, _ in abi.Reads.FIELDS}
+    arrays["cigar"][o] = (arrays["cigar"][o] & ~np.uint32(15)) | np.uint32(9)          # op code 9 ('B')
+    bad = abi.Reads(**arrays)
+    ctx = hip.Context(0, P)
+    try:
+        with pytest.raises(hip.LpsError, match="unsupported CIGAR"):
+            ctx.phase(V, s.ref, bad)
+        arrays["mapq"][r] = 0                                                          # filtered out: its CIGAR is not walked
+        skipped = abi.Reads(**arrays)
+        out = ctx.phase(V, s.ref, skipped)
+        ref_out, _ = lps_oracle.phase(P, V, s.ref, R.subset(np.delete(np.arange(R.n_reads), r)))
+        util.assert_phase_equal(out.phase_set, out.gt, ref_out.phase_set, ref_out.gt, "bad op in a filtered alignment")
+    finally:
+        ctx.close()
+
+
 def test_repeat_runs_are_identical_and_recomputed():
     kw, cli, over = fixtures.PHASE_FIXTURES["snp_ont_seed2"]
     s, V, R = util.make_case(kw)
