@@ -590,7 +590,7 @@ static int run_late(lps_ctx *c, bool with_cnv) {
         }
         // ---- a10 nodes + graph observations
         mark(c, ST_NODES);
-        launch_nodes(nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->is_node.p, c->vtype_key.p, c->node_of.p, c->nodes.p, c->ntype.p, P.base_quality, c->g_node.p, c->g_flag.p, c->g_cnt.p, c->d_cnt, c->temp.p, c->temp_bytes, s);
+        launch_nodes(nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->is_node.p, c->vtype_key.p, c->node_of.p, c->nodes.p, c->ntype.p, P.base_quality, c->g_node.p, c->g_flag.p, c->g_cnt.p, c->d_cnt, c->node_end.p, c->temp.p, c->temp_bytes, s);
         // ---- merged rows
         mark(c, ST_MERGE);
         launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->late_cap_main, c->late_tail, c->mrow_off.p, c->mrow_cnt.p, c->multi_list.p, s);

@@ -28,7 +28,7 @@ void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const uin
 void launch_nodes(int n_reads, int n_var, const uint32_t *row_off, const int32_t *row_cnt, const uint8_t *deleted,
                   const int32_t *obs_var, const uint16_t *obs_aq, uint32_t *is_node, uint32_t *vtype_key, uint32_t *node_of,
                   int32_t *nodes, uint8_t *ntype, int base_quality, int32_t *g_node, uint8_t *g_flag, int32_t *g_cnt,
-                  LpsCounters *cnt, void *temp, size_t temp_bytes, hipStream_t s);
+                  LpsCounters *cnt, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_debug_std_sort(int32_t *keys, uint8_t *payload, const long long *row_start, int n_rows, hipStream_t s);
 void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
                        const uint32_t *row_off, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const uint32_t *
                                                    const uint8_t *deleted, const int32_t *obs_var, const uint16_t *obs_aq,
                                                    const uint32_t *node_of, int base_quality, int32_t *g_node, uint8_t *g_flag,
                                                    int32_t *g_cnt, LpsCounters *cnt, int n_var, const uint32_t *is_node, const uint32_t *vtype_key,
-                                                   int32_t *nodes, uint8_t *ntype) {
+                                                   int32_t *nodes, uint8_t *ntype, uint32_t *node_cnt) {
     const int nb_reads = (n_reads + 3) / 4;
     if ((int)blockIdx.x >= nb_reads) {                                  // the workgroups after the alignments': node list (variant index, type) and node count
         const int v = ((int)blockIdx.x - nb_reads) * blockDim.x + threadIdx.x;
@@ -422,8 +422,10 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const uint32_t *
         if (ok) {
             int q = aq_quality(aq); if (q < 0) q = 60;          // indel sentinels -> quality 60 (:820-828)
             const uint32_t slot = off + w + __popcll(m & lanemask_lt());
-            g_node[slot] = (int32_t)node_of[v];
+            const uint32_t nd = node_of[v];
+            g_node[slot] = (int32_t)nd;
             g_flag[slot] = (uint8_t)(aq_allele(aq) | ((q >= base_quality) ? 2 : 0));
+            atomicAdd(&node_cnt[nd], 1u);                        // entries of the node's list: the merged rows hold exactly these observations
         }
         w += __popcll(m);
     }
@@ -625,17 +627,8 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
 }
 
 // ---- node-major lists: entries of node n = observations of n in merged rows, ordered by (name rank, index in merged row).
-// No global sort: count per node (atomics), exclusive scan, scatter in arbitrary order; every node's short list is put in order by rank
+// No global sort: count per node (atomics, in k_graph_obs), exclusive scan, scatter in arbitrary order; every node's short list is put in order by rank
 // counting by the wave of k_edges that consumes it (n^2/64 compares for n entries; n ~ coverage).
-__global__ __launch_bounds__(256) void k_node_count(const LpsCounters *cnt, const uint32_t *mrow_off, const int32_t *mrow_cnt,
-                                                    const int32_t *g_node, uint32_t *node_cnt, LpsCounters *cntw, const uint32_t *koff) {
-    const unsigned g = blockIdx.x * 4 + (threadIdx.x >> 6); const int l = lane_id();
-    if (g >= cnt->n_groups) return;
-    const int n = mrow_cnt[g];
-    const uint32_t off = mrow_off[g];
-    for (int a = l; a < n; a += 64) atomicAdd(&node_cnt[g_node[off + a]], 1u);
-}
-
 __global__ __launch_bounds__(256) void k_node_scatter(const LpsCounters *cnt, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                                                       const int32_t *g_node, const uint32_t *node_off, uint32_t *node_cur, int a_bits,
                                                       unsigned long long *keys, uint32_t *vals, LpsCounters *cntw, int n_var) {
@@ -1211,10 +1204,10 @@ void launch_overlap_filter(const unsigned long long *skeys, const uint32_t *gsta
 void launch_nodes(int n_reads, int n_var, const uint32_t *row_off, const int32_t *row_cnt, const uint8_t *deleted,
                   const int32_t *obs_var, const uint16_t *obs_aq, uint32_t *is_node, uint32_t *vtype_key, uint32_t *node_of,
                   int32_t *nodes, uint8_t *ntype, int base_quality, int32_t *g_node, uint8_t *g_flag, int32_t *g_cnt,
-                  LpsCounters *cnt, void *temp, size_t temp_bytes, hipStream_t s) {
+                  LpsCounters *cnt, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s) {
     hipLaunchKernelGGL(k_mark_nodes, dim3((n_reads + 3) / 4), dim3(256), 0, s, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, is_node, vtype_key);
     exscan_u32(temp, temp_bytes, is_node, node_of, n_var, s);
-    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + 3) / 4 + (n_var + 255) / 256), dim3(256), 0, s, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, node_of, base_quality, g_node, g_flag, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype);
+    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + 3) / 4 + (n_var + 255) / 256), dim3(256), 0, s, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, node_of, base_quality, g_node, g_flag, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype, node_cnt);
 }
 
 void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
@@ -1228,7 +1221,7 @@ void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t 
                        const int32_t *g_node, int m_bits, int a_bits, int n_bits, unsigned long long *keys,
                        unsigned long long *keys_sorted, uint32_t *vals, uint32_t *vals_sorted, unsigned long long n_keys,
                        uint32_t *node_off, uint32_t *node_cnt, uint32_t *node_cur, void *temp, size_t temp_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(k_node_count, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, mrow_off, mrow_cnt, g_node, node_cnt, cnt, koff);
+    (void)koff;                                                         // node_cnt was filled by k_graph_obs
     exscan_u32(temp, temp_bytes, node_cnt, node_off, (size_t)n_var + 1, s);
     hipLaunchKernelGGL(k_node_scatter, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, mrow_off, mrow_cnt, g_node, node_off, node_cur, a_bits, keys, vals, cnt, n_var);
     (void)keys_sorted; (void)vals_sorted;
