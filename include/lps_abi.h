@@ -279,9 +279,9 @@ int lps_bam_record_offsets(lps_ctx *ctx, int64_t first, int64_t count, uint64_t 
 int lps_bam_names(lps_ctx *ctx, int64_t first, int64_t count, uint32_t *name_off, char *names, int64_t names_cap, int64_t *names_bytes);
 int lps_push_bam_resident(lps_ctx *ctx, int64_t first, int64_t count, const uint32_t *name_id);
 
-/* How much of a phase run is timed with events on the stream (lps_get_timings): 2 = every stage (default), 1 = only the extraction kernel
- * (ms_kernel of the other stages reads 0), 0 = nothing but ms_total.  Each recorded event idles the GPU for ~3.5 us, 14 of them ~4 % of a
- * chr20 step: production callers and the timed region of bench.py use 1. */
+/* How much of a phase run is timed with events on the stream (lps_get_timings): 2 = every stage, 1 = only the extraction kernel (default;
+ * ms_kernel of the other stages reads 0), 0 = nothing but ms_total.  Each recorded event idles the GPU for ~3.5 us, 14 of them ~4 % of a
+ * chr20 step: the timed region of bench.py uses 1, its per-stage table comes from a separate pass at 2, the CLI uses 0. */
 int lps_set_stage_timing(lps_ctx *ctx, int level);
 
 /* phase: everything between direct_detect_alleles and exportResult for the reads pushed so far.

@@ -54,7 +54,7 @@ struct lps_ctx {
     DevBuf<int32_t> obs_var, g_node; DevBuf<uint16_t> obs_aq; DevBuf<uint8_t> g_flag;
     unsigned long long obs_capacity = 0;   // main arenas (LPS_ARENAS equal parts); a tail arena of obs_capacity/4 follows
     DevBuf<unsigned long long> arena_ctr;
-    bool in_phase = false; int timing_level = 2;
+    bool in_phase = false; int timing_level = 1;
     uint32_t name_max = 0;        // largest name_id pushed for this chromosome: bounds the digits of the name sort
     size_t z_late_off = 0, z_late_bytes = 0; unsigned long long late_n_keys = 0, late_cap_main = 0, late_tail = 0; bool cnv_skipped = false;
     DevBuf<uint8_t> hap_pool;     // per-read outputs of the scoring kernels, carved like zpool
