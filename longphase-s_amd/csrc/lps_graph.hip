@@ -863,7 +863,7 @@ __global__ __launch_bounds__(128) void k_scan_spec(const LpsCounters *cnt, const
                                                    int8_t *hp_v /*[2][N]*/, int32_t *blk_v /*[2][N]*/, size_t vstride,
                                                    ScanState *st_b /*[seg][2]*/, ScanState *st_e /*[seg][2]*/) {
     extern __shared__ unsigned long long s_rec_dyn[];              // [2][SCAN_TILE * A]: sized by the A in use, so that all segments are resident at once
-    unsigned long long *s_rec[2] = {s_rec_dyn, s_rec_dyn + SCAN_TILE * A};
+    const int rec_stride = SCAN_TILE * A;                           // (pointers derived by arithmetic from the LDS array: an array of pointers would make the reads flat loads)
     const int l = lane_id(), wv = threadIdx.x >> 6;
     const int N = (int)cnt->n_nodes;
     const int seg = blockIdx.x;
@@ -876,16 +876,16 @@ __global__ __launch_bounds__(128) void k_scan_spec(const LpsCounters *cnt, const
         const long long base = (long long)t0 * A, lim = (long long)N * A;
         for (int q = l; q < tile_recs; q += 64) dst[q] = (base + q < lim) ? erec[base + q] : 0ull;
     };
-    if (wv == 1) load_tile(a, s_rec[0]);
+    if (wv == 1) load_tile(a, s_rec_dyn);
     __syncthreads();
     Chain c0, c1; chain_init(c0, 0); chain_init(c1, 1);
     for (int t0 = a, buf = 0; t0 < e; t0 += SCAN_TILE, buf ^= 1) {
         if (wv == 1) {
-            if (t0 + SCAN_TILE < e && t0 + SCAN_TILE < N) load_tile(t0 + SCAN_TILE, s_rec[buf ^ 1]);
+            if (t0 + SCAN_TILE < e && t0 + SCAN_TILE < N) load_tile(t0 + SCAN_TILE, s_rec_dyn + (buf ^ 1) * rec_stride);
         } else {
             if (t0 == b) { state_save(c0, &st_b[seg * 2 + 0], l, b); state_save(c1, &st_b[seg * 2 + 1], l, b); }
             const unsigned long long gapmask = tile_gapmask(nodes, vpos, t0, N, distance, l);
-            const unsigned long long *rec = s_rec[buf];
+            const unsigned long long *rec = s_rec_dyn + buf * rec_stride;
             const int tend = min(SCAN_TILE, last - t0);
             int s = 0, k = (l - 1) & 63;                             // tiles are 64-aligned: owner lane of node t0+j is j
             unsigned long long cur = (tend > 0 && k < A) ? rec[k] : 0ull;
