@@ -830,6 +830,37 @@ __device__ __forceinline__ void chain_step(Chain &c, int i, int s, int l, bool g
     }
 }
 
+// chain_step without branches: the speculative walk steps TWO chains per node, and only straight-line code lets their instructions interleave
+// (a lone wave is bound by the latency of each dependent instruction, not by issue slots).  Same arithmetic: a skipped node adds +0.f / 0,
+// which leaves sums of non-negative weights bit-identical.
+__device__ __forceinline__ void chain_step_flat(Chain &c, int i, int s, int l, bool gap, unsigned long long rec) {
+    const bool use_sp = (c.vc > 3) && !(c.o1 == 0.f && c.o2 == 0.f);
+    const float c1 = use_sp ? c.o1 : c.h1, c2 = use_sp ? c.o2 : c.h2;
+    const int code = (c1 == c2) ? 0 : (c1 > c2 ? 1 : 2);
+    const int code_s = __builtin_amdgcn_readlane(code, s);
+    const bool tie_skip = code_s == 0 && i < c.lc;
+    const bool skip = gap || tie_skip;                                                      // :318, :340
+    const bool newblk = !skip && code_s == 0;                                               // tie -> new block (:338)
+    c.bs = newblk ? i : c.bs;
+    const int hp_i = skip ? 0 : (code_s == 0 ? (c.force2 ? 2 : 1) : code_s);
+    c.force2 = newblk ? 0 : c.force2;
+    const bool own = l == s;
+    c.my_hp = own ? hp_i : c.my_hp; c.my_blk = own ? (skip ? -1 : c.bs) : c.my_blk;
+    c.h1 = own ? 0.f : c.h1; c.h2 = own ? 0.f : c.h2; c.o1 = own ? 0.f : c.o1; c.o2 = own ? 0.f : c.o2; c.vc = own ? 0 : c.vc;
+    const float w = skip ? 0.f : __uint_as_float((unsigned)rec);
+    const unsigned fl = skip ? 0u : (unsigned)(rec >> 32);
+    const bool to2 = ((fl & 1u) != 0) != (hp_i == 2);                                       // target haplotype 2
+    const float wo = (fl & 4u) ? w : 0.f;
+    c.h1 += to2 ? 0.f : w; c.h2 += to2 ? w : 0.f;
+    c.o1 += to2 ? 0.f : wo; c.o2 += to2 ? wo : 0.f;
+    c.vc += (fl >> 1) & 1u;
+    const unsigned long long cm = __ballot(w != 0.f);
+    const int sh = (s + 1) & 63;
+    const unsigned long long rot = (cm >> sh) | (cm << ((64 - sh) & 63));
+    const int lc_new = i + 1 + (63 - __clzll(rot | 1ull));                                  // lastConnectPos = last connected target (:411)
+    c.lc = cm ? lc_new : c.lc;
+}
+
 // state hand-over record of one chain at a node boundary (before processing node `at`)
 struct ScanState { float h1[64], h2[64], o1[64], o2[64]; int vc[64]; int lc, bs, force2, pad; };
 
@@ -894,8 +925,8 @@ __global__ __launch_bounds__(128) void k_scan_spec(const LpsCounters *cnt, const
                 const int kn = (k - 1) & 63;                         // prefetch the record of node i+1
                 const unsigned long long nxt = (j + 1 < tend && kn < A) ? rec[(j + 1) * A + kn] : 0ull;
                 const bool gap = (gapmask >> j) & 1ull;
-                chain_step(c0, t0 + j, s, l, gap, cur);
-                chain_step(c1, t0 + j, s, l, gap, cur);
+                chain_step_flat(c0, t0 + j, s, l, gap, cur);
+                chain_step_flat(c1, t0 + j, s, l, gap, cur);
                 cur = nxt; k = kn; s = (s + 1) & 63;
             }
             if (t0 >= b && t0 + l < N) {                             // coalesced result store of the tile (both variants)
