@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 9
+#define LPS_ABI_VERSION 10
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -214,6 +214,9 @@ void lps_debug_std_sort(int32_t *keys, uint8_t *payload, int64_t n);
 /* test hook: the same sort as the GPU runs it (a wavefront per row, csrc/lps_graph.hip wave_std_sort) on rows [row_start[r], row_start[r+1]) of
  * host arrays (keys, payload), in place.  Returns 0, or -1 when the device call fails. */
 int lps_debug_std_sort_gpu(int device, int32_t *keys, uint8_t *payload, const int64_t *row_start, int64_t n_rows);
+/* test hook: size of the observation arenas (slots) of the next phase run; 0 = the library's own estimate.  A value that is too small makes
+ * the extraction overflow, which the library answers by growing the arenas and running again (tests/test_scale_gpu.py). */
+int lps_debug_set_obs_capacity(lps_ctx *ctx, int64_t slots);
 /* sizeof() of the ABI structs as compiled into the library: 0 lps_params, 1 lps_variant_table, 2 lps_read_batch,
  * 3 lps_phase_result, 4 lps_haplotag_result, 5 lps_timings, 6 lps_somatic_tag_result, 7 lps_site_counters, 8 lps_tumor_extract_result (binding self-check). */
 int lps_struct_size(int which);
@@ -232,6 +235,10 @@ int lps_set_variants(lps_ctx *ctx, const lps_variant_table *table);
 int lps_set_reference(lps_ctx *ctx, const char *seq, int64_t len);
 /* Append decoded alignments (H2D copy).  May be called repeatedly (batches / several BAM files). */
 int lps_push_reads(lps_ctx *ctx, const lps_read_batch *batch);
+/* Same as lps_push_reads for a batch that is already resident on the ctx's GPU: every pointer of `batch` is a DEVICE pointer
+ * (e.g. the output of a GPU-side BAM decoder or generator).  The arrays are copied device-to-device; the caller may free them when the
+ * call returns.  The operand checks of lps_push_reads (offsets, seq/qual lengths, coordinate order) run as a kernel. */
+int lps_push_reads_device(lps_ctx *ctx, const lps_read_batch *batch);
 /* Append alignments as RAW (inflated) BAM records - what `sam_itr_multi_next` fills into bam1_t in the loop of
  * direct_detect_alleles (src/phase/ParsingBam.cpp:1279) / processSingleChrom (src/haplotag/HaplotagParsingBam.cpp:453),
  * before any field is decoded.  `records` = n_bytes of the uncompressed BAM stream covering the records (anything

@@ -276,6 +276,28 @@ int lps_push_reads(lps_ctx *c, const lps_read_batch *b) {
     return 0;
 }
 
+// ---- device-resident batches (lps_push_reads_device): the operand checks of lps_push_reads run as a kernel
+// flags[0]: bit0 offsets not non-decreasing, bit1 seq/qual shorter than l_qseq, bit2 not coordinate-sorted; flags[1]: largest name_id
+__global__ void k_batch_check(long long n, const int32_t *ref_start, const int32_t *l_qseq, const uint32_t *name_id, const uint64_t *coff, const uint64_t *soff,
+                              const uint64_t *qoff, unsigned *flags) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned f = 0;
+    if (coff[i + 1] < coff[i] || soff[i + 1] < soff[i] || qoff[i + 1] < qoff[i]) f |= 1u;
+    const int lq = l_qseq[i];
+    if (lq < 0 || (uint64_t)((lq + 1) / 2) > soff[i + 1] - soff[i] || (uint64_t)lq > qoff[i + 1] - qoff[i]) f |= 2u;
+    if (i && ref_start[i] < ref_start[i - 1]) f |= 4u;
+    if (f) atomicOr(&flags[0], f);
+    unsigned m = name_id[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
+    if (lane_id() == 0) atomicMax(&flags[1], m);
+}
+__global__ void k_rebase_offsets(long long n1, const uint64_t *in, uint64_t add, uint64_t *out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n1) out[i] = in[i] - in[0] + add;
+}
+
 // core decode + CIGAR re-alignment of n records described by B (blob already on the device), appended to the ctx's read arrays
 static int push_record_view(lps_ctx *c, const BamView &B, size_t n, const uint32_t *name_id) {
     const size_t at = (size_t)c->nR; hipStream_t s = c->stream;
@@ -321,6 +343,51 @@ int lps_push_bam_records(lps_ctx *c, const uint8_t *records, int64_t n_bytes, co
         const int rc = push_record_view(c, B, n, name_id);
         if (rc) return rc;
         c->n_blob = (base + (uint64_t)n_bytes + 15) & ~15ull;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_push_reads_device(lps_ctx *c, const lps_read_batch *b) {
+    if (!c || !b) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        const size_t n = (size_t)b->n_reads; if (n == 0) return 0;
+        if (c->read_mode >= 2) return fail(c, "lps_push_reads_device mixed with a BAM-record push in the same chromosome");
+        if ((uint64_t)c->nR + n > 0x1fffffffull) return fail(c, "more than 2^29 alignments per chromosome");
+        hipStream_t s = c->stream;
+        uint64_t ends[6];                                                // first and last entry of the three offset arrays
+        const uint64_t *offs[3] = {b->cigar_off, b->seq_off, b->qual_off};
+        for (int k = 0; k < 3; ++k) { HIP_TRY(hipMemcpyAsync(&ends[2 * k], offs[k], 8, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(&ends[2 * k + 1], offs[k] + n, 8, hipMemcpyDeviceToHost, s)); }
+        c->bam_err.reserve(2);
+        HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, 2 * sizeof(unsigned), s));
+        hipLaunchKernelGGL(k_batch_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (long long)n, b->ref_start, b->l_qseq, b->name_id, b->cigar_off, b->seq_off, b->qual_off, c->bam_err.p);
+        unsigned flags[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(flags, c->bam_err.p, sizeof flags, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (flags[0] & 1u) return fail(c, "offsets must be non-decreasing");
+        if (flags[0] & 2u) return fail(c, "seq/qual shorter than l_qseq");
+        if (flags[0] & 4u) return fail(c, "alignments must be coordinate-sorted");
+        if (ends[1] < ends[0] || ends[3] < ends[2] || ends[5] < ends[4]) return fail(c, "offsets must be non-decreasing");
+        const uint64_t nc = ends[1] - ends[0], ns = ends[3] - ends[2], nq = ends[5] - ends[4];
+        c->read_mode = 1;
+        const size_t at = (size_t)c->nR;
+        auto d2d = [&](auto &buf, const auto *src, size_t cnt, size_t where) {
+            buf.reserve(where + cnt, s, true, where);
+            if (cnt) HIP_TRY(hipMemcpyAsync(buf.p + where, src, cnt * sizeof(*src), hipMemcpyDeviceToDevice, s));
+        };
+        d2d(c->r_start, b->ref_start, n, at); d2d(c->r_lq, b->l_qseq, n, at); d2d(c->r_flag, b->flag, n, at); d2d(c->r_mapq, b->mapq, n, at); d2d(c->r_name, b->name_id, n, at);
+        c->r_coff.reserve(at + n + 1, s, true, at); c->r_soff.reserve(at + n + 1, s, true, at); c->r_qoff.reserve(at + n + 1, s, true, at);
+        const dim3 g((unsigned)((n + 1 + 255) / 256)), bl(256);
+        hipLaunchKernelGGL(k_rebase_offsets, g, bl, 0, s, (long long)n + 1, b->cigar_off, c->n_cig, c->r_coff.p + at);
+        hipLaunchKernelGGL(k_rebase_offsets, g, bl, 0, s, (long long)n + 1, b->seq_off, c->n_seq, c->r_soff.p + at);
+        hipLaunchKernelGGL(k_rebase_offsets, g, bl, 0, s, (long long)n + 1, b->qual_off, c->n_qual, c->r_qoff.p + at);
+        d2d(c->cigar, b->cigar + ends[0], (size_t)nc, (size_t)c->n_cig);
+        d2d(c->seq, b->seq + ends[2], (size_t)ns, (size_t)c->n_seq);
+        d2d(c->qual, b->qual + ends[4], (size_t)nq, (size_t)c->n_qual);
+        HIP_TRY(hipStreamSynchronize(s));
+        c->name_max = std::max(c->name_max, flags[1]);
+        c->nR += (int)n; c->n_cig += nc; c->n_seq += ns; c->n_qual += nq;
+        c->phase_valid = false;
     } catch (std::string &e) { return fail(c, e); }
     return 0;
 }
@@ -717,6 +784,12 @@ static size_t enqueue_result_copy(lps_ctx *c) {
 static void deliver_result(lps_ctx *c, lps_phase_result *out) {
     memcpy(out->phase_set, c->h_res, (size_t)c->nV * sizeof(int32_t));
     memcpy(out->gt, c->h_res + ((uint8_t *)c->out_gt.p - (uint8_t *)c->out_ps.p), (size_t)c->nV);
+}
+
+int lps_debug_set_obs_capacity(lps_ctx *c, int64_t slots) {
+    if (!c || slots < 0) return -1;
+    c->obs_capacity = (unsigned long long)slots;
+    return 0;
 }
 
 int lps_set_stage_timing(lps_ctx *c, int level) {

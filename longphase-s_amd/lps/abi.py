@@ -116,6 +116,23 @@ class Variants:
                               _ptr(self.derive_hp), _ptr(self.tumor_kind))
 
 
+    @classmethod
+    def from_snps(cls, pos, ref0, alt0, hp1_is_alt=None, phase_set=None):
+        """SNP-only table straight from arrays (no per-row Python objects: whole-genome tables have millions of rows)."""
+        self = cls.__new__(cls)
+        self.pos = np.ascontiguousarray(pos, dtype=np.int32)
+        n = self.n = int(self.pos.size)
+        self.ref0 = np.ascontiguousarray(ref0, dtype=np.uint8); self.alt0 = np.ascontiguousarray(alt0, dtype=np.uint8)
+        self.ref_len = np.ones(n, np.uint16); self.alt_len = np.ones(n, np.uint16)
+        self.ref_str = self.alt_str = None
+        self.hp1_is_alt = None if hp1_is_alt is None else np.ascontiguousarray(hp1_is_alt, dtype=np.uint8)
+        self.phase_set = None if phase_set is None else np.ascontiguousarray(phase_set, dtype=np.int32)
+        self.somatic_role = self.derive_hp = self.tumor_kind = None
+        self.c = VariantTable(n, _ptr(self.pos), _ptr(self.ref0), _ptr(self.alt0), _ptr(self.ref_len), _ptr(self.alt_len),
+                              _ptr(self.hp1_is_alt), _ptr(self.phase_set), None, None, None)
+        return self
+
+
 class Reads:
     """Host-side SoA read batch."""
 

@@ -45,6 +45,7 @@ def load():
     L.lps_set_variants.argtypes = [C.c_void_p, C.POINTER(abi.VariantTable)]
     L.lps_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.lps_push_reads.argtypes = [C.c_void_p, C.POINTER(abi.ReadBatch)]
+    L.lps_push_reads_device.argtypes = [C.c_void_p, C.POINTER(abi.ReadBatch)]
     L.lps_push_bam_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.lps_debug_std_sort.restype = None
     L.lps_debug_std_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -69,6 +70,7 @@ def load():
     L.lps_somatic_extract_tumor.argtypes = [C.c_void_p, C.POINTER(abi.TumorExtractResult)]
     L.lps_get_timings.argtypes = [C.c_void_p, C.POINTER(abi.Timings)]
     L.lps_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
+    L.lps_debug_set_obs_capacity.argtypes = [C.c_void_p, C.c_int64]
     L.lps_stage_name.restype = C.c_char_p
     L.lps_stage_name.argtypes = [C.c_int]
     L.lps_stream.restype = C.c_void_p
@@ -120,6 +122,23 @@ class Context:
             else:
                 self._check(self.L.lps_push_reads(self.h, C.byref(r.c)), "lps_push_reads")
             self.n_reads += r.n_reads
+        self.n_var = variants.n
+
+    def load_chromosome_device(self, variants, ref, batch, n_reads):
+        """As load_chromosome for a batch whose arrays already sit on this GPU (abi.ReadBatch of DEVICE pointers)."""
+        self._check(self.L.lps_begin_chromosome(self.h), "lps_begin_chromosome")
+        self._check(self.L.lps_set_variants(self.h, C.byref(variants.c)), "lps_set_variants")
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        self._check(self.L.lps_set_reference(self.h, ref.ctypes.data, ref.size), "lps_set_reference")
+        self._check(self.L.lps_push_reads_device(self.h, C.byref(batch)), "lps_push_reads_device")
+        self.n_reads = n_reads
+        self.n_var = variants.n
+
+    def set_table(self, variants, ref):
+        """Replace the variant table (e.g. by the phased one) while the pushed reads stay resident."""
+        self._check(self.L.lps_set_variants(self.h, C.byref(variants.c)), "lps_set_variants")
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        self._check(self.L.lps_set_reference(self.h, ref.ctypes.data, ref.size), "lps_set_reference")
         self.n_var = variants.n
 
     def bgzf_load(self, data):

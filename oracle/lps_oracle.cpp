@@ -2,10 +2,11 @@
 // SoA inputs of include/lps_abi.h.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 // load this library, and only as the checker; the product (liblps_hip.so) never links or calls it.
 //
-// Parity is PINNED: tests/test_oracle_vs_reference.py checks this restatement against outputs of the real
-// reference binary (oracle/_ref/longphase-s-ref, built by oracle/build_ref.sh from /root/reference) on
-// generated inputs, and against the golden vectors committed under tests/golden/ (made by
-// tests/golden/make_golden.py from that binary).
+// Pinning: tests/test_oracle_golden.py, tests/test_oracle_haplotag_golden.py and tests/test_oracle_somatic_*_golden.py check this
+// restatement against the golden vectors committed under tests/golden/, which tests/golden/make_golden.py made by running the real
+// reference binary (oracle/_ref/longphase-s-ref, built by oracle/build_ref.sh from /root/reference) on generated inputs.  That build
+// is zlib-only htslib with generated headers written by the script and without jemalloc (DESIGN.md §5 lists the stand-ins), so by the
+// rule for reference builds the parity status reads "parity unpinned" although none of the stand-ins touches scoring arithmetic.
 //
 // Every function cites the reference lines (relative to /root/reference/) whose behaviour it restates.
 // It is a restatement on index space (variant index instead of std::map<int,...> position keys), not a copy.
@@ -335,7 +336,7 @@ typedef struct oracle_dumps {
     int64_t clip_capacity; int32_t *clip_pos; uint8_t *clip_fb; int64_t n_clips;
     int64_t node_capacity; int32_t *node_var; float *edge; int8_t *node_hp; int32_t *node_block; int64_t n_nodes;
     uint8_t *aln_deleted;    /* n_reads: 1 when removed by the overlap filter */
-    int32_t n_cnv; int32_t cnv_start[64]; int32_t cnv_end[64];
+    int32_t n_cnv; int32_t cnv_capacity; int32_t *cnv_start; int32_t *cnv_end;   /* every interval twice, as in the reference; unbounded there (std::vector) */
     int32_t ub_hazard;       /* >0: input touched behaviour that is UB in the reference */
     int64_t n_pairs;
 } oracle_dumps;
@@ -393,7 +394,7 @@ int oracle_phase(const lps_params *Pp, const lps_variant_table *tp, const char *
     std::vector<std::pair<int, int>> cnv;
     if (clipCount.empty()) { if (D) D->ub_hazard++; }
     else { cnv_pass(clipCount, cnv); cnv_pass(clipCount, cnv); }
-    if (D) { D->n_cnv = (int32_t)cnv.size(); for (size_t i = 0; i < cnv.size() && i < 64; ++i) { D->cnv_start[i] = cnv[i].first; D->cnv_end[i] = cnv[i].second; } }
+    if (D) { D->n_cnv = (int32_t)cnv.size(); for (size_t i = 0; i < cnv.size() && (int64_t)i < D->cnv_capacity && D->cnv_start; ++i) { D->cnv_start[i] = cnv[i].first; D->cnv_end[i] = cnv[i].second; } }
     // ---- a8: overlap filter; a9: CNV mismatch filter
     {
         std::vector<int64_t> before; for (auto &a : alns) before.push_back(a.read);

@@ -19,7 +19,7 @@ class Dumps(C.Structure):
         ("clip_capacity", C.c_int64), ("clip_pos", C.c_void_p), ("clip_fb", C.c_void_p), ("n_clips", C.c_int64),
         ("node_capacity", C.c_int64), ("node_var", C.c_void_p), ("edge", C.c_void_p), ("node_hp", C.c_void_p),
         ("node_block", C.c_void_p), ("n_nodes", C.c_int64), ("aln_deleted", C.c_void_p),
-        ("n_cnv", C.c_int32), ("cnv_start", C.c_int32 * 64), ("cnv_end", C.c_int32 * 64),
+        ("n_cnv", C.c_int32), ("cnv_capacity", C.c_int32), ("cnv_start", C.c_void_p), ("cnv_end", C.c_void_p),
         ("ub_hazard", C.c_int32), ("n_pairs", C.c_int64),
     ]
 
@@ -64,11 +64,19 @@ class PhaseDump:
         self.node_hp = np.zeros(n_var, np.int8)
         self.node_block = np.zeros(n_var, np.int32)
         self.aln_deleted = np.zeros(n_reads, np.uint8)
+        self._cnv_start = np.zeros(4096, np.int32)
+        self._cnv_end = np.zeros(4096, np.int32)
         p = lambda a: None if a is None else a.ctypes.data
         self.c = Dumps(obs_cap, p(self.obs_count), p(self.obs_var), p(self.obs_allele), p(self.obs_quality), 0,
                        ccap, p(self.clip_pos), p(self.clip_fb), 0,
                        n_var, p(self.node_var), p(self.edge), p(self.node_hp), p(self.node_block), 0,
-                       p(self.aln_deleted))
+                       p(self.aln_deleted), 0, 4096, p(self._cnv_start), p(self._cnv_end))
+
+    def cnv_start(self):
+        return self._cnv_start[:self.c.n_cnv]
+
+    def cnv_end(self):
+        return self._cnv_end[:self.c.n_cnv]
 
 
 def phase(params, variants, ref, reads, dump=False, with_edges=True):

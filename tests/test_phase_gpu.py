@@ -37,7 +37,7 @@ def test_phase_matches_oracle_and_golden(name):
         o = np.lexsort((d.clip_fb[:d.c.n_clips], d.clip_pos[:d.c.n_clips]))
         assert np.array_equal(cp, d.clip_pos[:d.c.n_clips][o]) and np.array_equal(cf, d.clip_fb[:d.c.n_clips][o])
         cs, ce, dele = ctx.dump_cnv()
-        assert list(cs) == list(d.c.cnv_start[:d.c.n_cnv]) and list(ce) == list(d.c.cnv_end[:d.c.n_cnv])
+        assert list(cs) == list(d.cnv_start()) and list(ce) == list(d.cnv_end())
         assert np.array_equal(dele, d.aln_deleted)
         # stage: graph nodes + fp32 edge matrix (exact: same accumulation order)
         nodes, edge = ctx.dump_graph()

@@ -1,0 +1,88 @@
+"""Parity at the sizes BASELINE.json's configs name: the HIP path through the C-ABI against the CPU oracle, bit for bit,
+on chr20-30x (configs[1]) and on one 50x contig of 160 Mb (the per-contig unit of configs[2]/[3]) - observations, clips, nodes, the fp32
+edge matrix as uint32, vote-scan hp/block, PS/GT, and the haplotag counts/tags on the table the phase run produced.  The inputs come from
+the GPU generator (tools/lps_synth_gpu.hip): the host generator needs minutes for these sizes.  Scale-only paths covered here: arena
+overflow re-run, ~5 000 speculative scan segments, the sort-key packing with 19/20-bit fields, 64 observation arenas in use."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import lps_oracle
+import util
+from lps import abi, hip
+from lps.synth_gpu import SynthGpu
+
+pytestmark = pytest.mark.gpu
+
+CHR20_30X = dict(seed=101, contig_len=64_444_167, n_snp=60_000, coverage=30.0)
+CONTIG_50X = dict(seed=201, contig_len=160_000_000, n_snp=206_000, coverage=50.0)          # ~ GRCh38 chr7 at the WGS density of 4 M SNPs / 3.1 Gb
+
+
+def check_haplotag(ctx, P, V, ph, ref, R, what):
+    idx = np.nonzero(ph.phase_set != 0)[0]
+    VT = abi.Variants.from_snps(V.pos[idx], V.ref0[idx], V.alt0[idx], hp1_is_alt=ph.gt[idx], phase_set=ph.phase_set[idx])
+    ctx.set_table(VT, ref)
+    out = ctx.run_haplotag()
+    want = lps_oracle.haplotag(P, VT, ref, R)
+    for k in ("status", "hp1", "hp2", "ps_min", "hp", "pq", "ps"):
+        assert np.array_equal(getattr(out, k), getattr(want, k)), f"{what}: haplotag {k} differs"
+    assert np.array_equal(np.minimum(out.n_ps, 2), np.minimum(want.n_ps, 2))
+    assert (out.hp != 0).sum() > 0.5 * R.n_reads
+
+
+def test_chr20_30x_every_stage_host_push():
+    """configs[1] through lps_push_reads (host arrays), every stage dump compared."""
+    g = SynthGpu(0, **CHR20_30X)
+    h = g.to_host(); g.close()
+    V = abi.Variants.from_snps(h.var_pos, h.var_ref0, h.var_alt0); R = abi.Reads.from_synth(h)
+    assert R.n_reads > 90_000 and V.n > 59_000
+    P = abi.default_params()
+    want, d = lps_oracle.phase(P, V, h.ref, R, dump=True)
+    assert d.c.ub_hazard == 0
+    with hip.Context(0, P) as ctx:
+        out = ctx.phase(V, h.ref, R)
+        util.assert_stages_equal(ctx, d, "chr20_30x")
+        util.assert_phase_equal(out.phase_set, out.gt, want.phase_set, want.gt, "chr20_30x vs oracle")
+        assert (out.phase_set != 0).sum() > 0.95 * V.n
+        # the same run from arenas that are far too small: the library must notice, grow them and come to the same result
+        ctx._check(ctx.L.lps_debug_set_obs_capacity(ctx.h, 70_000), "lps_debug_set_obs_capacity")
+        out2 = ctx.run_phase()
+        util.assert_stages_equal(ctx, d, "chr20_30x after the arena overflow")
+        util.assert_phase_equal(out2.phase_set, out2.gt, want.phase_set, want.gt, "chr20_30x after the arena overflow")
+        check_haplotag(ctx, P, V, out, h.ref, R, "chr20_30x")
+
+
+def test_contig_160mb_50x_every_stage_device_push():
+    """One 50x contig of the whole-genome configs through lps_push_reads_device (arrays generated in HBM), every stage dump compared."""
+    g = SynthGpu(0, **CONTIG_50X)
+    h = g.to_host()
+    V = abi.Variants.from_snps(h.var_pos, h.var_ref0, h.var_alt0); R = abi.Reads.from_synth(h)
+    assert h.contig_len >= 150_000_000 and R.n_reads > 350_000
+    P = abi.default_params()
+    with hip.Context(0, P) as ctx:
+        ctx.load_chromosome_device(V, h.ref, g.device_batch(), g.n_reads)
+        g.close()
+        out = ctx.run_phase()
+        tm = ctx.timings()
+        want, d = lps_oracle.phase(P, V, h.ref, R, dump=True)
+        assert d.c.ub_hazard == 0
+        util.assert_stages_equal(ctx, d, "160 Mb 50x")
+        util.assert_phase_equal(out.phase_set, out.gt, want.phase_set, want.gt, "160 Mb 50x vs oracle")
+        assert tm["n_scan_segments"] > 3000 and tm["n_obs"] > 8_000_000
+        check_haplotag(ctx, P, V, out, h.ref, R, "160 Mb 50x")
+
+
+def test_device_push_rejects_bad_operands():
+    """lps_push_reads_device runs the operand checks of lps_push_reads as a kernel."""
+    g = SynthGpu(0, seed=5, contig_len=400_000, n_snp=400, coverage=8.0)
+    h = g.to_host()
+    V = abi.Variants.from_snps(h.var_pos, h.var_ref0, h.var_alt0)
+    with hip.Context(0, abi.default_params()) as ctx:
+        ctx.load_chromosome_device(V, h.ref, g.device_batch(), g.n_reads)           # fine as generated
+        b = g.device_batch()
+        b.qual_off, b.seq_off = b.seq_off, b.qual_off                                # qual rows now half as long as l_qseq needs
+        ctx.L.lps_begin_chromosome(ctx.h)
+        assert ctx.L.lps_push_reads_device(ctx.h, C.byref(b)) != 0
+        assert b"l_qseq" in ctx.L.lps_last_error(ctx.h)
+    g.close()

@@ -35,6 +35,27 @@ def assert_phase_equal(ps_a, gt_a, ps_b, gt_b, what=""):
     assert badg.size == 0, f"{what}: {badg.size} GT mismatches"
 
 
+def assert_stages_equal(ctx, d, what=""):
+    """Every stage dump of the last lps_phase_chromosome against the oracle's dumps `d` (bit-exact, the fp32 edge matrix as uint32)."""
+    cnt, var, al, q = ctx.dump_observations()
+    n = d.c.n_obs
+    assert np.array_equal(cnt, d.obs_count), what + ": per-read observation counts differ"
+    assert np.array_equal(var, d.obs_var[:n]) and np.array_equal(al, d.obs_allele[:n]), what + ": observations differ"
+    assert np.array_equal(q.astype(np.int32), d.obs_quality[:n].astype(np.int32)), what + ": observation qualities differ"
+    cp, cf = ctx.dump_clips()
+    o = np.lexsort((d.clip_fb[:d.c.n_clips], d.clip_pos[:d.c.n_clips]))
+    assert np.array_equal(cp, d.clip_pos[:d.c.n_clips][o]) and np.array_equal(cf, d.clip_fb[:d.c.n_clips][o]), what + ": clips differ"
+    cs, ce, dele = ctx.dump_cnv()
+    assert list(cs) == list(d.cnv_start()) and list(ce) == list(d.cnv_end()), what + ": CNV intervals differ"
+    assert np.array_equal(dele, d.aln_deleted), what + ": overlap-filter deletions differ"
+    nodes, edge = ctx.dump_graph()
+    N = d.c.n_nodes
+    assert np.array_equal(nodes, d.node_var[:N]), what + ": graph nodes differ"
+    assert np.array_equal(edge.view(np.uint32), d.edge[:N].view(np.uint32)), what + ": edge matrix differs bitwise"
+    hp, blk = ctx.dump_votes()
+    assert np.array_equal(hp, d.node_hp[:N]) and np.array_equal(blk, d.node_block[:N]), what + ": vote scan differs"
+
+
 _NT16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
 _OPS = {c: i for i, c in enumerate("MIDNSHP=XB")}
 
