@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the `phase` hot path on MI355X (BASELINE.json metric: het SNPs phased / s).
+"""bench.py — throughput of the `phase` hot path on MI355X (BASELINE.json metric: het SNPs phased / s, 50x ONT whole genome).
 
-A step = one lps_phase_chromosome() over the resident decoded reads of one synthetic chr20-sized contig at 30x
-(BASELINE.json configs[1]): everything from allele extraction to phased genotypes is recomputed from the raw
-reads in HBM and the result is copied back to host memory.  Inputs are uploaded before the timed region.
+Default workload `wgs_50x` = BASELINE.json's headline configuration (configs[2]/[3]): germline `phase` over 24 contigs of GRCh38 length,
+50x synthetic ONT reads, ~4 M het SNPs, ~155 Gbases.  The genome is streamed contig by contig, as the reference does (one chromosome per
+worker, src/phase/PhasingProcess.cpp:113-173): a contig's decoded alignments are generated in HBM (tools/lps_synth_gpu.hip), handed to the
+library (lps_push_reads_device), and then
+
+    a STEP = one pass of the hot path over the whole genome = one lps_phase_chromosome() per contig,
+
+everything from allele extraction to phased genotypes recomputed from the raw reads in HBM, results back in host memory.  K steps are run as K
+consecutive calls per contig while that contig is resident (inputs in HBM when its timed region starts); `value` = phased SNPs of all
+contigs x K / sum of the per-contig timed regions.  Nothing is cached between calls.
 
   python bench.py --gpus N --steps K --warmup W
-N>1 (launched by torch.distributed.run, one rank per GPU): every rank owns an independent contig shard (weak
-scaling, no data-path collective - phasing never crosses contigs); torch.distributed only provides
-the barrier and the max-over-ranks of the elapsed time.
+N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling - the 24 contigs are dealt longest-first onto the ranks
+(SURVEY.md §8e), rank 0 broadcasts the packed SNP table to the other GPUs with RCCL (lps_comm_bcast_device -> ncclBroadcast over xGMI),
+then no data-path collective; time = max over ranks of their summed timed regions, value = all phased SNPs x K / that.
+torch.distributed (gloo) is the control plane only (unique id, barrier, max/sum of scalars).
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects.
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel at the largest contig), `cpu_baseline` (the reference binary on one whole 50x
+contig) and `parity_checked` (step-0 output of every benched contig compared with the oracle, outside the timed regions).
 """
 import argparse
+import concurrent.futures as cf
 import ctypes as C
 import json
 import os
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,334 +37,388 @@ sys.path.insert(0, os.path.join(ROOT, "longphase-s_amd"))
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
-WORKLOADS = {
-    # BASELINE.json configs[1]: germline phase chr20, 30x ONT synthetic, ~60k het SNPs
-    "chr20_30x": dict(contig_len=64_444_167, n_snp=60_000, coverage=30.0),
-    # BASELINE.json configs[0] (plumbing size)
-    "5mb_10x": dict(contig_len=5_000_000, n_snp=5_000, coverage=10.0),
-}
+GRCH38 = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555), ("chr5", 181538259), ("chr6", 170805979),
+          ("chr7", 159345973), ("chr8", 145138636), ("chr9", 138394717), ("chr10", 133797422), ("chr11", 135086622), ("chr12", 133275309),
+          ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189), ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285),
+          ("chr19", 58617616), ("chr20", 64444167), ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
+WGS_SNPS = 4_000_000
+
+
+def wgs_contigs(seed, coverage=50.0):
+    total = sum(n for _, n in GRCH38)
+    return [dict(name=c, contig_len=n, n_snp=int(round(WGS_SNPS * n / total)), coverage=coverage, seed=seed + i) for i, (c, n) in enumerate(GRCH38)]
+
+
+def workload_contigs(name, seed):
+    if name == "wgs_50x":          # BASELINE.json configs[2]/[3] (the configuration the metric is quoted on)
+        return wgs_contigs(seed)
+    if name == "chr1_50x":         # the largest contig of it alone (profiling runs)
+        return wgs_contigs(seed)[:1]
+    if name == "chr20_30x":        # BASELINE.json configs[1]
+        return [dict(name="chr20", contig_len=64_444_167, n_snp=60_000, coverage=30.0, seed=seed)]
+    if name == "chr20_30x_pileups":   # configs[1] with simulated CNV break points: clip pile-ups, so that the CNV interval stage and filter run
+        return [dict(name="chr20", contig_len=64_444_167, n_snp=60_000, coverage=30.0, seed=seed, clip_pileups=50)]
+    if name == "5mb_10x":          # BASELINE.json configs[0] (plumbing size)
+        return [dict(name="ctg5mb", contig_len=5_000_000, n_snp=5_000, coverage=10.0, seed=seed)]
+    raise SystemExit(f"unknown workload {name}")
+
+
+def lpt(contigs, world):
+    """Longest-processing-time-first deal of the contigs onto `world` ranks (lps/shard.py does the same for the CLI)."""
+    from lps import shard
+    return shard.lpt_schedule([c["contig_len"] for c in contigs], world)
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(seed, threads, sample_mb=8):
-    """Reference CPU path on a bounded sample of the same workload (same generator, same density/coverage).
-    kind 'reference' = the real LongPhase-S binary (oracle/_ref, BAM+VCF+FASTA in, incl. BGZF/BAM decode);
-    falls back to kind 'port' (the oracle restatement on decoded arrays, 1 thread) when the binary is absent."""
-    from lps.synth import Synth
-    from lps import abi
-    kw = dict(WORKLOADS["chr20_30x"])
-    frac = sample_mb * 1e6 / kw["contig_len"]
-    kw.update(contig_len=int(sample_mb * 1e6), n_snp=int(kw["n_snp"] * frac), seed=seed + 7000, n_threads=threads)
-    s = Synth(**kw)
-    sample = f"{sample_mb} Mb contig at 30x from the same generator ({s.n_reads} alignments, {s.n_variants} het SNPs)"
-    out = {}
-    # port: oracle restatement on decoded SoA, single thread
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import lps_oracle
-    V = abi.Variants(s.var_pos, s.var_ref, s.var_alt)
-    R = abi.Reads.from_synth(s)
-    t0 = time.time()
-    o, _ = lps_oracle.phase(abi.default_params(), V, s.ref, R)
-    tp = time.time() - t0
-    port = dict(value=float((o.phase_set != 0).sum() / tp), unit="SNPs/s", cores=1, kind="port", sample=sample,
-                note="decoded arrays in memory, no BAM/BGZF decode")
+class ParityPool:
+    """Oracle (CPU restatement) runs on host threads beside the GPU work; bounded by the host bytes in flight."""
+
+    def __init__(self, workers, max_bytes=96 << 30):
+        self.ex = cf.ThreadPoolExecutor(max_workers=workers)
+        self.futs = []
+        self.bytes = 0
+        self.max_bytes = max_bytes
+        self.cv = threading.Condition()
+
+    def submit(self, name, P, V, host, out_ps, out_gt):
+        from lps import abi
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import lps_oracle
+        import numpy as np
+        nb = int(host.qual.nbytes + host.seq.nbytes + host.cigar.nbytes)
+        with self.cv:
+            while self.bytes and self.bytes + nb > self.max_bytes:
+                self.cv.wait()
+            self.bytes += nb
+
+        def job():
+            try:
+                R = abi.Reads.from_synth(host)
+                t0 = time.time()
+                want, _ = lps_oracle.phase(P, V, host.ref, R)
+                dt = time.time() - t0
+                same_ps = bool(np.array_equal(want.phase_set, out_ps))
+                m = want.phase_set != 0
+                same_gt = bool(np.array_equal(want.gt[m], out_gt[m]))
+                return dict(contig=name, identical=same_ps and same_gt, oracle_s=dt, n_phased=int(m.sum()))
+            finally:
+                with self.cv:
+                    self.bytes -= nb
+                    self.cv.notify_all()
+        self.futs.append(self.ex.submit(job))
+
+    def results(self):
+        return [f.result() for f in self.futs]
+
+
+def pin(arr):
+    """hipHostRegister a numpy array (P clock: decoded batches in pinned host memory)."""
+    hiprt = C.CDLL("libamdhip64.so")
+    hiprt.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+    return hiprt.hipHostRegister(arr.ctypes.data, arr.nbytes, 0) == 0
+
+
+def cpu_baseline(g, spec, threads, port):
+    """The reference binary (oracle/_ref/longphase-s-ref: BAM + VCF + FASTA in, phased VCF out, incl. BGZF/BAM decode) on ONE WHOLE contig
+    of the benched workload; kind 'port' (the oracle restatement on decoded arrays, 1 thread) when the binary is not there."""
+    sample = f"whole contig {spec['name']} of the benched workload ({spec['contig_len']} bp, {spec['coverage']:.0f}x, {g.n_reads} alignments, {g.n_variants} het SNPs)"
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "longphase-s-ref")
     tv = os.path.join(ROOT, "oracle", "_ref", "test_view")
-    if os.path.exists(ref_bin) and os.path.exists(tv):
-        try:
-            with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
-                s.write_fasta(d + "/ref.fa"); s.write_vcf(d + "/in.vcf"); s.write_sam(d + "/reads.sam")
-                subprocess.check_call([tv, "-b", "-x", "reads.bam.bai", "-p", "reads.bam", "reads.sam"], cwd=d, stdout=subprocess.DEVNULL)
-                os.remove(d + "/reads.sam")
-                cmd = [ref_bin, "phase", "-s", "in.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(threads), "-o", "out", "--ont"]
-                subprocess.run(cmd, cwd=d, capture_output=True)                     # warm the page cache
-                ts = []
-                for _ in range(3):
-                    t0 = time.time(); r = subprocess.run(cmd, cwd=d, capture_output=True); ts.append(time.time() - t0)
-                    assert r.returncode == 0, r.stderr[-500:]
-                ts.sort()
-                n_ph = sum(1 for ln in open(d + "/out.vcf") if not ln.startswith("#") and not ln.rstrip().endswith(":."))
-                e2e = cli_e2e(d, threads, ts[1], n_ph)
-            out = dict(value=float(n_ph / ts[1]), unit="SNPs/s", cores=threads, kind="reference",
-                       sample=sample + f"; median of 3 runs of `longphase-s phase -t {threads}` end to end (one contig => one compute thread, the rest feed BGZF)",
-                       port_value=port["value"], port_note=port["note"], e2e=e2e)
-        except Exception as e:  # noqa: BLE001
-            log("cpu_baseline: reference run failed, using the port:", repr(e)[:300])
-    if not out:
-        out = port
-    s.close()
-    return out
-
-
-def cli_e2e(d, threads, ref_wall, n_ph):
-    """Clock E of SURVEY.md §8d: the drop-in CLI (longphase-s_amd/cli/longphase_amd: BGZF inflate + BAM decode + GPU path +
-    VCF rewrite, process start to exit) on the very files the reference binary was just timed on, and a byte
-    comparison of the two output VCFs (minus the version / command-line header lines)."""
-    cli = os.path.join(ROOT, "longphase-s_amd", "cli", "longphase_amd")
-    if not os.path.exists(cli):
-        return None
-    cmd = [cli, "phase", "-s", "in.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(threads), "-o", "gpu", "--ont"]
-    ts = []
-    for _ in range(3):
-        t0 = time.time(); r = subprocess.run(cmd, cwd=d, capture_output=True); ts.append(time.time() - t0)
-        if r.returncode != 0:
-            return {"error": r.stderr.decode()[-300:]}
-    ts.sort()
-    body = lambda p: [l for l in open(p) if not l.startswith("##commandline=") and not l.startswith("##longphaseVersion=")]  # noqa: E731
-    stages = r.stderr.decode().strip().splitlines()[-1] if r.stderr else ""
-    th = []
-    for _ in range(2):                                              # same CLI with zlib on the host threads instead of the GPU inflate
-        t0 = time.time(); rh = subprocess.run(cmd + ["--host-inflate"], cwd=d, capture_output=True); th.append(time.time() - t0)
-    host_stages = rh.stderr.decode().strip().splitlines()[-1] if rh.stderr else ""
-    tag = None
-    try:                                                            # same comparison for `haplotag` (reads tagged / s, end to end)
-        import gzip
-        import hashlib
-        ref_bin = os.path.join(ROOT, "oracle", "_ref", "longphase-s-ref")
-        rcmd = [ref_bin, "haplotag", "-s", "out.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(threads), "-o", "ref_tagged"]
-        ccmd = [cli, "haplotag", "-s", "out.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(threads), "-o", "gpu_tagged"]
-        tr, tc = [], []
-        for _ in range(2):
-            t0 = time.time(); r1 = subprocess.run(rcmd, cwd=d, capture_output=True); tr.append(time.time() - t0)
-            t0 = time.time(); r2 = subprocess.run(ccmd, cwd=d, capture_output=True); tc.append(time.time() - t0)
-            assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr[-300:], r2.stderr[-300:])
-
-        def records_digest(path):
-            h = hashlib.sha256(); n = 0
-            with gzip.open(path, "rb") as f:
-                head = f.read(8); lt = int.from_bytes(head[4:8], "little"); f.read(lt)
-                nref = int.from_bytes(f.read(4), "little")
-                for _ in range(nref):
-                    ln = int.from_bytes(f.read(4), "little"); f.read(ln + 4)
-                while True:
-                    b = f.read(1 << 24)
-                    if not b:
-                        break
-                    h.update(b); n += len(b)
-            return h.hexdigest(), n
-        a, b = records_digest(d + "/ref_tagged.bam"), records_digest(d + "/gpu_tagged.bam")
-        n_aln = int([l for l in r2.stderr.decode().splitlines() if l.startswith("total alignment")][0].split()[2])
-        tag = {"cli_wall_s": round(min(tc), 3), "reference_wall_s": round(min(tr), 3), "speedup": round(min(tr) / min(tc), 2),
-               "cli_reads_per_s": n_aln / min(tc), "reference_reads_per_s": n_aln / min(tr), "identical_record_stream": a == b, "record_bytes": b[1],
-               "cli_stages": r2.stderr.decode().strip().splitlines()[-1], "output_bytes": {"cli": os.path.getsize(d + "/gpu_tagged.bam"), "reference": os.path.getsize(d + "/ref_tagged.bam")},
-               "note": "best of 2; both write every record; the CLI inflates, scores, re-tags and deflates on the GPU (per-4-KiB Huffman codes, no LZ77), "
-                       "the reference uses htslib/zlib level 6 on its thread pool - see output_bytes"}
+    out = dict(port) if port else {}
+    out.update(kind="port", cores=1, sample=sample + "; oracle restatement on decoded arrays in memory (no BAM/BGZF decode), one thread")
+    if not (os.path.exists(ref_bin) and os.path.exists(tv)):
+        return out
+    try:
+        with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
+            t0 = time.time()
+            g.write_fasta(d + "/ref.fa", spec["name"]); g.write_vcf(d + "/in.vcf", spec["name"]); g.write_sam(d + "/reads.sam", spec["name"], threads)
+            t1 = time.time()
+            subprocess.check_call([tv, "-@", str(threads), "-b", "-x", "reads.bam.bai", "-p", "reads.bam", "reads.sam"], cwd=d, stdout=subprocess.DEVNULL)
+            os.remove(d + "/reads.sam")
+            log(f"cpu_baseline: files written in {t1-t0:.1f}s, BAM + index in {time.time()-t1:.1f}s ({os.path.getsize(d + '/reads.bam')/1e9:.2f} GB)")
+            cmd = [ref_bin, "phase", "-s", "in.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(threads), "-o", "out", "--ont"]
+            ts = []
+            for _ in range(2):                       # first run also warms the page cache
+                t0 = time.time(); r = subprocess.run(cmd, cwd=d, capture_output=True); ts.append(time.time() - t0)
+                assert r.returncode == 0, r.stderr[-500:]
+            n_ph = sum(1 for ln in open(d + "/out.vcf") if not ln.startswith("#") and not ln.rstrip().endswith(":."))
+            stages = [ln.strip() for ln in r.stderr.decode(errors="replace").splitlines() if "total" in ln.lower() or "parsing" in ln.lower()][-4:]
+        return dict(value=float(n_ph / min(ts)), unit="SNPs/s", cores=threads, kind="reference",
+                    sample=sample + f"; best of 2 runs of `longphase-s phase -t {threads} --ont` end to end (one contig => one compute thread, the others feed BGZF)",
+                    wall_s=round(min(ts), 2), n_phased=n_ph, reference_stage_lines=stages,
+                    port_value=port.get("value") if port else None, port_note="oracle restatement, decoded arrays in memory, one thread")
     except Exception as e:  # noqa: BLE001
-        tag = {"error": repr(e)[:300]}
-    gz = None
-    try:                                                            # GPU BGZF inflate of the same (htslib-written) BAM, checked against zlib
-        import gzip
-        import numpy as np
-        from lps import abi, hip
-        raw = np.fromfile(d + "/reads.bam", dtype=np.uint8)
-        with hip.Context(int(os.environ.get("LOCAL_RANK", "0")), abi.default_params()) as c2:
-            c2.bgzf_load(raw)
-            t0 = time.time(); n_inf = c2.bgzf_load(raw); wall = time.time() - t0
-            tm = c2.bgzf_timings()
-            t0 = time.time(); want = gzip.decompress(raw.tobytes()); zt = time.time() - t0
-            same = len(want) == n_inf
-            for a in range(0, n_inf, 64 << 20):
-                k = min(64 << 20, n_inf - a)
-                same = same and c2.bgzf_read(a, k).tobytes() == want[a:a + k]
-        gz = {"compressed_bytes": int(raw.size), "inflated_bytes": n_inf, "h2d_ms": round(tm["h2d_ms"], 2), "inflate_kernel_ms": round(tm["inflate_ms"], 2),
-              "inflate_GBps_out": round(n_inf / tm["inflate_ms"] / 1e6, 1), "call_wall_s": round(wall, 3), "identical_to_zlib": bool(same),
-              "zlib_1thread_s": round(zt, 2)}
-    except Exception as e:  # noqa: BLE001
-        gz = {"error": repr(e)[:300]}
-    som = None
-    try:                                                            # BASELINE.json configs[4] in miniature: tumor/normal pair, somatic_haplotag end to end
-        import hashlib
-        from lps.synth import Synth
-        genome = dict(contig_len=4_000_000, n_snp=3700, n_threads=threads, somatic_every=8000.0, seed=5101)
-        N = Synth(**dict(genome, coverage=25.0, read_seed=5111, tumor_purity=0.0)); T = Synth(**dict(genome, coverage=50.0, read_seed=5112, tumor_purity=0.6))
-        N.write_fasta(d + "/tn_ref.fa"); N.write_vcf(d + "/tn_normal_in.vcf"); N.write_sam(d + "/tn_normal.sam"); T.write_sam(d + "/tn_tumor.sam"); T.write_vcf_tumor(d + "/tn_tumor.vcf", "chrS", with_germline=True)
-        n_t = int(T.n_reads); N.close(); T.close()
-        tv = os.path.join(ROOT, "oracle", "_ref", "test_view"); ref_bin = os.path.join(ROOT, "oracle", "_ref", "longphase-s-ref")
-        for smp in ("tn_normal", "tn_tumor"):
-            subprocess.check_call([tv, "-b", "-x", smp + ".bam.bai", "-p", smp + ".bam", smp + ".sam"], cwd=d, stdout=subprocess.DEVNULL); os.remove(d + "/" + smp + ".sam")
-        r0 = subprocess.run([ref_bin, "phase", "-s", "tn_normal_in.vcf", "-b", "tn_normal.bam", "-r", "tn_ref.fa", "-t", str(threads), "-o", "tn_normal_phased", "--ont"], cwd=d, capture_output=True)
-        assert r0.returncode == 0, r0.stderr[-300:]
-        common = ["somatic_haplotag", "-s", "tn_normal_phased.vcf", "-b", "tn_normal.bam", "--tumor-snv-file", "tn_tumor.vcf", "--tumor-bam-file", "tn_tumor.bam", "-r", "tn_ref.fa", "-t", str(threads)]
-        tr, tc = [], []
-        for _ in range(2):
-            t0 = time.time(); r1 = subprocess.run([ref_bin] + common + ["-o", "tn_ref_out"], cwd=d, capture_output=True); tr.append(time.time() - t0)
-            t0 = time.time(); r2 = subprocess.run([cli] + common + ["-o", "tn_gpu_out"], cwd=d, capture_output=True); tc.append(time.time() - t0)
-            assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr[-300:], r2.stderr[-300:])
-
-        def digest(path):
-            import gzip
-            h = hashlib.sha256()
-            with gzip.open(path, "rb") as f:
-                head = f.read(8); f.read(int.from_bytes(head[4:8], "little")); nref = int.from_bytes(f.read(4), "little")
-                for _ in range(nref):
-                    ln = int.from_bytes(f.read(4), "little"); f.read(ln + 4)
-                for b in iter(lambda: f.read(1 << 24), b""):
-                    h.update(b)
-            return h.hexdigest()
-        som = {"cli_wall_s": round(min(tc), 3), "reference_wall_s": round(min(tr), 3), "speedup": round(min(tr) / min(tc), 2), "tumor_reads_per_s_cli": n_t / min(tc), "tumor_reads_per_s_reference": n_t / min(tr),
-               "identical_record_stream": digest(d + "/tn_ref_out.bam") == digest(d + "/tn_gpu_out.bam"), "identical_purity_report": open(d + "/tn_ref_out_purity.out").read() == open(d + "/tn_gpu_out_purity.out").read(),
-               "sample": "4 Mb contig, normal 25x + tumor 50x at 60 % purity, automatic purity estimation, best of 2", "cli_stages": r2.stderr.decode().strip().splitlines()[-1]}
-    except Exception as e:  # noqa: BLE001
-        som = {"error": repr(e)[:300]}
-    return {"cli_wall_s": round(ts[1], 3), "cli_stages": stages, "cli_host_inflate_wall_s": round(min(th), 3), "cli_host_inflate_stages": host_stages,
-            "haplotag": tag, "somatic_haplotag": som, "gpu_bgzf": gz, "reference_wall_s": round(ref_wall, 3), "speedup": round(ref_wall / ts[1], 2),
-            "cli_snps_per_s": float(n_ph / ts[1]), "identical_vcf": body(d + "/gpu.vcf") == body(d + "/out.vcf"),
-            "note": "same BAM/VCF/FASTA files, process start to exit, median of 3; CLI wall includes HIP runtime start-up"}
+        log("cpu_baseline: reference run failed, reporting the port:", repr(e)[:300])
+        return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="chr20_30x", choices=sorted(WORKLOADS))
-    ap.add_argument("--seed", type=int, default=101)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="wgs_50x", choices=["wgs_50x", "chr1_50x", "chr20_30x", "chr20_30x_pileups", "5mb_10x"])
+    ap.add_argument("--seed", type=int, default=201)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gen-threads", type=int, default=0)
-    ap.add_argument("--cpu-sample-mb", type=int, default=8, help="contig length of the bounded cpu_baseline / CLI end-to-end sample")
+    ap.add_argument("--parity", default="all", help="all | none | comma-separated contig names whose step-0 output is compared with the oracle")
+    ap.add_argument("--cpu-contig", default="", help="contig the reference binary is timed on (default: the smallest of the workload)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = max(1, int(os.environ.get("WORLD_SIZE", "1")))
     if world != a.gpus and world > 1:
         log(f"warning: WORLD_SIZE={world} != --gpus {a.gpus}; using WORLD_SIZE")
-    n_gpus = max(world, 1)
 
-    # product library first (binds the ROCm runtime it was built against); torch only for the multi-rank barrier
+    # product library first (binds the ROCm runtime it was built against); torch only as the control plane of a multi-rank run
+    import numpy as np
     from lps import abi, hip
-    from lps.synth import Synth
-    hip.load()
+    from lps.synth_gpu import SynthGpu
+    L = hip.load()
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only (barrier / max)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
-    ncpu = os.cpu_count() or 8
-    threads = a.gen_threads or max(2, min(16, ncpu // max(1, min(world, 8))))
-    kw = dict(WORKLOADS[a.workload]); kw.update(seed=a.seed + rank, n_threads=threads)
-    t0 = time.time()
-    s = Synth(**kw)
-    V = abi.Variants(s.var_pos, s.var_ref, s.var_alt)
-    R = abi.Reads.from_synth(s)
-    if rank == 0:
-        log(f"generated {a.workload}: {s.n_reads} alignments, {s.n_variants} het SNPs, {s.qual.size/1e9:.2f} Gbases in {time.time()-t0:.1f}s")
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    cpu_share = max(2, min(16, ncpu // world))
+    n_dev = max(1, int(L.lps_device_count()))
+    dev = local_rank % n_dev            # one rank per GPU on the driver's node; a rehearsal with fewer GPUs than ranks shares them
     P = abi.default_params()
-    n_dev = max(1, int(hip.load().lps_device_count()))
-    ctx = hip.Context(local_rank % n_dev, P)        # one rank per GPU on the node the driver uses; a rehearsal with fewer GPUs than ranks shares them
-    t0 = time.time()
-    ctx.load_chromosome(V, s.ref, R)
-    h2d_s = time.time() - t0
-    out = abi.PhaseOut(V.n)
-    for _ in range(a.warmup):
-        ctx.run_phase(out)
+    contigs = workload_contigs(a.workload, a.seed)
+    mine = [contigs[i] for i in lpt(contigs, world)[rank]]
+    parity_set = set(c["name"] for c in contigs) if a.parity == "all" else (set() if a.parity == "none" else set(a.parity.split(",")))
+    pool = ParityPool(workers=max(2, cpu_share // 2)) if parity_set else None
+
+    # ---- SNP table: with several ranks, rank 0's packed table reaches the other GPUs by one RCCL broadcast (north_star, SURVEY.md §8e)
+    bcast = None
+    if world > 1:
+        bcast = snp_table_broadcast(L, dist, dev, rank, world, contigs)
+
+    ctx = hip.Context(dev, P)
+    per_contig = []
+    elapsed = 0.0; hap_elapsed = 0.0; total_phased = 0; total_reads = 0; total_tagged = 0; total_bases = 0
+    largest = None; cpu_pick = None; p_clock = None; port = None
+    cpu_name = a.cpu_contig or min(contigs, key=lambda c: c["contig_len"])["name"]
+    gen_s = 0.0; push_s = 0.0; d2h_s = 0.0
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    # Timed region: events only around the extraction kernel (the dominant one) - every event recorded on the stream idles the GPU for a few
-    # microseconds, the full per-stage set costs ~4 % of a step.  The per-stage table comes from a separate, untimed pass below.
-    ctx.set_stage_timing(1)
-    ctx.run_phase(out)
-    extract_ms = 0.0
     barrier()
-    t_start = time.perf_counter()
-    for _ in range(a.steps):
-        ctx.run_phase(out)                      # synchronous: returns with results in host memory (stream drained)
-        extract_ms += ctx.timings()["stages"]["extract"]
-    elapsed = time.perf_counter() - t_start
+    for spec in mine:
+        kw = {k: v for k, v in spec.items() if k != "name"}
+        t0 = time.time()
+        g = SynthGpu(dev, **kw)
+        gen_s += time.time() - t0
+        V = g.variants()
+        if bcast is not None:
+            assert np.array_equal(bcast[spec["name"]][0], V.pos), "broadcast SNP table differs from the contig's own"
+        ref = g.host("ref")
+        t0 = time.time()
+        ctx.load_chromosome_device(V, ref, g.device_batch(), g.n_reads)
+        push_s += time.time() - t0
+        host = None
+        if spec["name"] in parity_set or (rank == 0 and spec["name"] == cpu_name):
+            t0 = time.time(); host = g.to_host(); d2h_s += time.time() - t0
+        if rank == 0 and spec["name"] == cpu_name and not a.no_cpu_baseline:
+            cpu_pick = (g, spec)            # keeps its device arrays for the SAM writer; everything else is released below
+        else:
+            g.release_reads()
+        out = abi.PhaseOut(V.n)
+        for _ in range(a.warmup):
+            ctx.run_phase(out)
+        # ---- timed region of this contig: events only around the extraction kernel (each recorded event idles the GPU for a few microseconds)
+        ctx.set_stage_timing(1)
+        extract_ms = 0.0
+        t_start = time.perf_counter()
+        for _ in range(a.steps):
+            ctx.run_phase(out)              # synchronous: returns with the results in host memory (stream drained)
+            extract_ms += ctx.timings()["stages"]["extract"]
+        dt = time.perf_counter() - t_start
+        elapsed += dt
+        tm = ctx.timings()
+        n_ph = int((out.phase_set != 0).sum())
+        total_phased += n_ph; total_reads += g.n_reads; total_bases += g.n_bases
+        rec = dict(contig=spec["name"], alignments=g.n_reads, snps=V.n, phased=n_ph, gbases=round(g.n_bases / 1e9, 2), ms_per_step=dt / a.steps * 1e3,
+                   extract_ms=extract_ms / a.steps, obs=tm["n_obs"], pairs=tm["n_pairs"], nodes=tm["n_nodes"], alg=tm["algorithmic_bytes"],
+                   scan_segments=tm["n_scan_segments"], scan_replayed=tm["n_scan_replayed"], gen_ms=g.gen_ms)
+        if host is not None and spec["name"] in parity_set:
+            pool.submit(spec["name"], P, V, host, out.phase_set.copy(), out.gt.copy())
+        if largest is None or spec["contig_len"] > largest[0]["contig_len"]:
+            # per-stage table of the largest contig: separate untimed pass with every stage event recorded
+            ctx.set_stage_timing(2)
+            n_prof = max(1, min(3, a.steps)); st = {}
+            for _ in range(n_prof):
+                ctx.run_phase(out)
+                for k, v in ctx.timings()["stages"].items():
+                    st[k] = st.get(k, 0.0) + v / n_prof
+            largest = (spec, rec, st)
+        # ---- P clock (SURVEY.md §8d): decoded batch in pinned host memory -> results in host memory, H2D included (never `value`)
+        if rank == 0 and host is not None and spec["name"] == cpu_name:
+            R = abi.Reads.from_synth(host)
+            pinned = all(pin(x) for x in (host.qual, host.seq, host.cigar))
+            t0 = time.perf_counter(); ctx.load_chromosome(V, ref, R); h2d = time.perf_counter() - t0
+            t0 = time.perf_counter(); ctx.run_phase(out); one = time.perf_counter() - t0
+            p_clock = dict(contig=spec["name"], h2d_s=round(h2d, 3), step_s=round(one, 4), value=n_ph / (h2d + one), unit="SNPs/s", pinned_host_memory=bool(pinned),
+                           note="lps_set_variants + lps_set_reference + lps_push_reads (H2D of the decoded batch) + one lps_phase_chromosome; PCIe-inclusive, never `value`")
+        # ---- secondary metric: reads haplotagged / s on the same resident alignments, table = this contig's phased SNPs
+        idx = np.nonzero(out.phase_set != 0)[0]
+        VT = abi.Variants.from_snps(V.pos[idx], V.ref0[idx], V.alt0[idx], hp1_is_alt=out.gt[idx], phase_set=out.phase_set[idx])
+        ctx.set_table(VT, ref)
+        hout = abi.HaplotagOut(g.n_reads)
+        ctx.run_haplotag(hout)
+        t_h = time.perf_counter()
+        for _ in range(a.steps):
+            ctx.run_haplotag(hout)
+        hdt = time.perf_counter() - t_h
+        hap_elapsed += hdt
+        rec.update(haplotag_ms_per_step=hdt / a.steps * 1e3, haplotag_kernel_ms=ctx.timings()["stages"]["extract"], tagged=int((hout.hp != 0).sum()))
+        total_tagged += rec["tagged"]
+        per_contig.append(rec)
+        if cpu_pick is None or cpu_pick[0] is not g:
+            g.close()
+        log(f"[rank {rank}] {spec['name']}: {g.n_reads} alignments, {V.n} SNPs, {rec['gbases']} Gbases | phase {rec['ms_per_step']:.3f} ms/step (extract {rec['extract_ms']:.3f}) "
+            f"| haplotag {rec['haplotag_ms_per_step']:.3f} ms/step | phased {n_ph}")
     barrier()
-    n_phased = int((out.phase_set != 0).sum())
-    stage_ms = {}
-    ctx.set_stage_timing(2)
-    n_prof = max(1, min(10, a.steps))
-    for _ in range(n_prof):
-        ctx.run_phase(out)
-        for k, v in ctx.timings()["stages"].items():
-            stage_ms[k] = stage_ms.get(k, 0.0) + v
-    tm = ctx.timings()
+
+    my_elapsed = elapsed
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([n_phased], dtype=torch.float64)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_phased = float(c.item())
+        t = torch.tensor([elapsed, hap_elapsed], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        c = torch.tensor([total_phased, total_reads, total_tagged, total_bases], dtype=torch.float64); dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        loads = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(loads, torch.tensor([my_elapsed, float(sum(s["contig_len"] for s in mine))], dtype=torch.float64))
+        elapsed, hap_elapsed = float(t[0]), float(t[1])
+        total_phased, total_reads, total_tagged, total_bases = (float(x) for x in c)
+        rank_loads = [dict(rank=i, timed_s=round(float(x[0]), 4), bases_of_contigs=int(x[1])) for i, x in enumerate(loads)]
     else:
-        total_phased = float(n_phased)
+        rank_loads = [dict(rank=0, timed_s=round(my_elapsed, 4), bases_of_contigs=int(sum(s["contig_len"] for s in mine)))]
 
-    # secondary metric of BASELINE.json: reads haplotagged / s (same resident reads, table = this run's phased SNPs)
-    import numpy as np
-    idx = np.nonzero(out.phase_set != 0)[0]
-    VT = abi.Variants(V.pos[idx], [V.ref_str[i] for i in idx], [V.alt_str[i] for i in idx], hp1_is_alt=out.gt[idx], phase_set=out.phase_set[idx])
-    import ctypes as _C
-    ctx._check(ctx.L.lps_set_variants(ctx.h, _C.byref(VT.c)), "lps_set_variants")
-    refa = np.ascontiguousarray(s.ref, dtype=np.uint8)
-    ctx._check(ctx.L.lps_set_reference(ctx.h, refa.ctypes.data, refa.size), "lps_set_reference")
-    hout = abi.HaplotagOut(R.n_reads)
-    ctx.run_haplotag(hout)
-    t_h = time.perf_counter()
-    for _ in range(a.steps):
-        ctx.run_haplotag(hout)
-    hap_elapsed = time.perf_counter() - t_h
-    hap_tm = ctx.timings()
-    n_scored = int((hout.status == 0).sum())
+    parity = None
+    if pool is not None:
+        t0 = time.time(); res = pool.results()
+        log(f"[rank {rank}] oracle comparison of {len(res)} contigs done ({time.time()-t0:.1f}s after the GPU work)")
+        ok = all(r["identical"] for r in res) and len(res) > 0
+        if cpu_name in [r["contig"] for r in res]:
+            r = [r for r in res if r["contig"] == cpu_name][0]
+            port = dict(value=r["n_phased"] / r["oracle_s"], unit="SNPs/s")
+        if dist is not None:
+            import torch
+            f = torch.tensor([1.0 if ok else 0.0, float(len(res))], dtype=torch.float64)
+            allf = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]; dist.all_gather(allf, f)
+            ok = all(float(x[0]) == 1.0 for x in allf if float(x[1]) > 0); n_checked = int(sum(float(x[1]) for x in allf))
+        else:
+            n_checked = len(res)
+        parity = dict(checked=ok, contigs_checked=n_checked, contigs_total=len(contigs), oracle_seconds_rank0=round(sum(r["oracle_s"] for r in res), 1),
+                      mismatching=[r["contig"] for r in res if not r["identical"]],
+                      what="phase_set of every variant and gt of every phased variant of the step-0 result == oracle/lps_oracle on the same arrays (copied back from HBM)")
 
     if rank == 0:
-        stage_avg = {k: v / n_prof for k, v in stage_ms.items()}
+        spec, rec, stage_avg = largest
+        stage_avg = dict(stage_avg); stage_avg["extract"] = rec["extract_ms"]          # measured live inside the timed region (hipEvents on the library's stream)
         dom = max((k for k in stage_avg if k != "d2h"), key=lambda k: stage_avg[k])
-        if dom == "extract":
-            stage_avg["extract"] = extract_ms / a.steps     # measured live in the timed region (hipEvents on the library's stream)
-        alg = tm["algorithmic_bytes"]
-        # roofline of the dominant kernel (by time), algorithmic bytes / measured duration (hipEvents on the lib's stream)
-        dom_bytes = alg.get(dom, 0)
-        achieved = dom_bytes / (stage_avg[dom] * 1e-3) / 1e9 if stage_avg[dom] > 0 else 0.0
+        alg = rec["alg"]
+        achieved = alg.get(dom, 0) / (stage_avg[dom] * 1e-3) / 1e9 if stage_avg[dom] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(a.workload, {}).get(dom)
+                traffic = json.load(open(tpath)).get(f"{spec['name']}_{spec['coverage']:.0f}x", {}).get(dom)
             except Exception:  # noqa: BLE001
                 traffic = None
-        stages = {}
-        for k, v in stage_avg.items():
-            b = alg.get(k, 0)
-            stages[k] = dict(ms=round(v, 4), alg_bytes=int(b), gbs=round(b / (v * 1e-3) / 1e9, 2) if v > 0 and b else None)
+        stages = {k: dict(ms=round(v, 4), alg_bytes=int(alg.get(k, 0)), gbs=round(alg.get(k, 0) / (v * 1e-3) / 1e9, 1) if v > 0 and alg.get(k, 0) else None) for k, v in stage_avg.items()}
+        n_all = sum(c["n_snp"] for c in contigs)
         res = {
             "metric": "het SNPs phased/sec", "value": total_phased * a.steps / elapsed, "unit": "SNPs/s",
-            "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32/f32", "data": "synthetic",
-            "config": {"workload": f"germline phase, {a.workload} synthetic ONT ({s.n_reads} alignments, {s.n_variants} het SNPs, "
-                                   f"{s.qual.size/1e9:.2f} Gbases) per GPU; decoded reads resident in HBM", "seed": a.seed,
-                       "phased_per_step_per_gpu": n_phased, "obs": tm["n_obs"], "pairs": tm["n_pairs"], "nodes": tm["n_nodes"],
-                       "h2d_seconds_untimed": round(h2d_s, 2)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "dominant stage by time, its duration from hipEvents inside the timed region; per-stage algorithmic GB/s in `stages`"},
-            "stages": stages,
-            "stages_note": f"all stages but the dominant one: separate untimed pass of {n_prof} steps with every stage event recorded",
-            "scan": {"segments": tm["n_scan_segments"], "replayed_serially": tm["n_scan_replayed"]},
-            "secondary": {"metric": "reads haplotagged/sec", "value": R.n_reads * a.steps / hap_elapsed * n_gpus, "unit": "reads/s",
-                          "ms_per_step": hap_elapsed / a.steps * 1e3, "kernel_ms": hap_tm["stages"]["extract"],
-                          "reads_scored_per_step": n_scored, "reads_tagged_per_step": int((hout.hp != 0).sum()),
-                          "note": "same resident alignments, phased table = this run's phase output; per-GPU rate x n_gpus"},
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong" if a.workload == "wgs_50x" else "weak", "vs_baseline": None, "dtype": "i32/f32", "data": "synthetic",
+            "config": {"workload": f"germline phase, {a.workload}: {len(contigs)} contig(s), {int(total_bases)/1e9:.1f} Gbases of synthetic ONT reads, {int(total_reads)} alignments, "
+                                   f"~{n_all} het SNP strata; streamed per contig, decoded reads resident in HBM during a contig's timed region; a step = one pass over all contigs",
+                       "seed": a.seed, "phased_per_step": int(total_phased), "contigs": len(contigs), "parallelism": f"contigs dealt longest-first onto {world} rank(s)",
+                       "generation_s": round(gen_s, 2), "device_push_s": round(push_s, 2), "d2h_for_oracle_s": round(d2h_s, 2)},
+            "parity_checked": bool(parity and parity["checked"]), "parity": parity,
+            "roofline": {"bound": "hbm", "kernel": dom, "at": f"{spec['name']} {spec['coverage']:.0f}x ({rec['alignments']} alignments, {rec['snps']} SNPs, {rec['obs']} observations)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes": int(alg.get(dom, 0)), "kernel_ms": stage_avg[dom],
+                         "note": "dominant stage by time at the largest contig; duration from hipEvents on the library's stream inside that contig's timed region"},
+            "stages_at_largest_contig": stages,
+            "whole_step_gbs": round(sum(sum(r["alg"].values()) for r in per_contig) * a.steps / my_elapsed / 1e9, 1),
+            "per_contig_rank0": [{k: v for k, v in r.items() if k != "alg"} for r in per_contig],
+            "rank_loads": rank_loads,
+            "secondary": {"metric": "reads haplotagged/sec", "value": total_reads * a.steps / hap_elapsed, "unit": "reads/s", "ms_per_step": hap_elapsed / a.steps * 1e3,
+                          "reads_tagged_per_step": int(total_tagged), "config": "germline haplotag, same resident 50x alignments (BASELINE.json configs[2]), table = this run's phased SNPs"},
+            "p_clock": p_clock,
         }
-        if not a.no_cpu_baseline:
+        if bcast is not None:
+            res["rccl"] = bcast["_info"]
+        if not a.no_cpu_baseline and cpu_pick is not None:
             t0 = time.time()
-            res["cpu_baseline"] = cpu_baseline(a.seed, min(16, ncpu), a.cpu_sample_mb)
+            res["cpu_baseline"] = cpu_baseline(cpu_pick[0], cpu_pick[1], a.cpu_threads or min(16, ncpu), port)
+            cpu_pick[0].close()
             log(f"cpu baseline took {time.time()-t0:.1f}s")
+        elif port:
+            res["cpu_baseline"] = dict(port, kind="port", cores=1, sample=f"contig {cpu_name}, oracle restatement on decoded arrays, one thread")
         print(json.dumps(res), flush=True)
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def snp_table_broadcast(L, dist, dev, rank, world, contigs):
+    """Rank 0 builds the packed SNP table of the whole genome (pos i32 | ref0 u8 | alt0 u8 per row, contig after contig) on its GPU; one
+    ncclBroadcast (RCCL, behind lps_comm_bcast_device) hands it to every other GPU.  Returns {contig: (pos, ref0, alt0)} + '_info'."""
+    import numpy as np
+    import torch
+    from lps.synth_gpu import SynthGpu
+    info = dict(collective="ncclBroadcast", ranks=world)
+    try:
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            assert L.lps_comm_unique_id(uid) == 0
+        t = torch.tensor(list(uid), dtype=torch.uint8); dist.broadcast(t, src=0)
+        uid = (C.c_uint8 * 128)(*t.tolist())
+        comm = L.lps_comm_create(dev, world, rank, uid)
+        if not comm:
+            raise RuntimeError("lps_comm_create failed")
+        counts = torch.zeros(len(contigs), dtype=torch.int64)
+        parts = []
+        if rank == 0:
+            for i, spec in enumerate(contigs):
+                kw = {k: v for k, v in spec.items() if k != "name"}; kw["coverage"] = 0.0          # reference + variants only
+                g = SynthGpu(dev, **kw)
+                parts.append((g.host("var_pos"), g.host("var_ref0"), g.host("var_alt0"))); counts[i] = g.n_variants
+                g.close()
+        dist.broadcast(counts, src=0)
+        n = int(counts.sum())
+        buf = np.zeros(n * 6, dtype=np.uint8)
+        if rank == 0:
+            buf[:4 * n] = np.concatenate([p[0] for p in parts]).view(np.uint8)
+            buf[4 * n:5 * n] = np.concatenate([p[1] for p in parts]); buf[5 * n:] = np.concatenate([p[2] for p in parts])
+        t0 = time.perf_counter()
+        ms = C.c_double(0)
+        rc = L.lps_comm_bcast(comm, buf.ctypes.data, buf.size, 0, C.byref(ms))
+        if rc != 0:
+            raise RuntimeError(f"lps_comm_bcast rc={rc}")
+        info.update(bytes=int(buf.size), wall_ms=round((time.perf_counter() - t0) * 1e3, 2), device_ms=round(ms.value, 3), n_ranks_in_communicator=int(L.lps_comm_size(comm)))
+        L.lps_comm_destroy(comm)
+        out = {}; o = 0
+        pos = buf[:4 * n].view(np.int32)
+        for i, spec in enumerate(contigs):
+            k = int(counts[i]); out[spec["name"]] = (pos[o:o + k].copy(), buf[4 * n + o:4 * n + o + k].copy(), buf[5 * n + o:5 * n + o + k].copy()); o += k
+        out["_info"] = info
+        return out
+    except Exception as e:  # noqa: BLE001
+        log(f"[rank {rank}] RCCL broadcast of the SNP table failed ({e!r}); every rank derives its own contigs' table instead")
+        return None
 
 
 if __name__ == "__main__":

@@ -308,6 +308,26 @@ const char *lps_stage_name(int stage);
 /* The hipStream_t (as void*) all kernels of this ctx are launched on. */
 void *lps_stream(lps_ctx *ctx);
 
+/* ---- multi-GPU (one node): the ONE collective of the path.  Rank 0 parses the VCF; its packed variant table (and, if wanted, reference
+ * slices) reaches the other GPUs by ncclBroadcast - RCCL over xGMI - and from then on every GPU works on its own contigs with no exchange.
+ * Replaces nothing in the reference (its workers share one parsed SnpParser in one address space, src/phase/PhasingProcess.cpp:113-173).
+ *   multi-process (one rank per GPU): rank 0 calls lps_comm_unique_id, hands the 128 bytes to the others over any control channel,
+ *                                     every rank calls lps_comm_create(device, n_ranks, rank, id);
+ *   single process, N GPUs (CLI --gpus N): lps_comm_create_all; each worker thread then uses its own lps_comm.
+ * lps_comm_bcast: `host_buf` is the source on `root` and the destination elsewhere (staged through the communicator's device buffer);
+ * lps_comm_bcast_device: the same on a DEVICE buffer, in place.  Both are collective: every rank of the communicator must call them with the
+ * same n_bytes and root.  ms (optional): duration of the broadcast on the communicator's stream.  Errors: <0, lps_comm_last_error(). */
+typedef struct lps_comm lps_comm;
+int lps_comm_unique_id(uint8_t id[128]);
+lps_comm *lps_comm_create(int device, int n_ranks, int rank, const uint8_t id[128]);
+int lps_comm_create_all(int n_devices, const int *devices, lps_comm **comms);
+int lps_comm_size(lps_comm *comm);
+int lps_comm_rank(lps_comm *comm);
+void lps_comm_destroy(lps_comm *comm);
+int lps_comm_bcast(lps_comm *comm, void *host_buf, int64_t n_bytes, int root, double *ms);
+int lps_comm_bcast_device(lps_comm *comm, void *dev_buf, int64_t n_bytes, int root, double *ms);
+const char *lps_comm_last_error(void);
+
 /* ---- stage dumps for parity tests (valid after lps_phase_chromosome; host buffers, caller-allocated) ---- */
 /* Observations in canonical order (alignment index, then position): per kept alignment
  * obs_count[read] entries.  Returns total or <0.  Pass NULL arrays to query the total only. */

@@ -70,6 +70,17 @@ def load():
     L.lps_somatic_extract_tumor.argtypes = [C.c_void_p, C.POINTER(abi.TumorExtractResult)]
     L.lps_get_timings.argtypes = [C.c_void_p, C.POINTER(abi.Timings)]
     L.lps_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
+    L.lps_comm_unique_id.argtypes = [C.c_void_p]
+    L.lps_comm_create.restype = C.c_void_p
+    L.lps_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.lps_comm_create_all.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    L.lps_comm_size.argtypes = [C.c_void_p]
+    L.lps_comm_rank.argtypes = [C.c_void_p]
+    L.lps_comm_destroy.argtypes = [C.c_void_p]
+    L.lps_comm_destroy.restype = None
+    L.lps_comm_bcast.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]
+    L.lps_comm_bcast_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]
+    L.lps_comm_last_error.restype = C.c_char_p
     L.lps_debug_set_obs_capacity.argtypes = [C.c_void_p, C.c_int64]
     L.lps_stage_name.restype = C.c_char_p
     L.lps_stage_name.argtypes = [C.c_int]

@@ -427,7 +427,7 @@ sg_handle *sg_create(int device, const sg_params *pp) {
         P.clip_every = p.clip_every; P.n_pile = std::min(p.clip_pileups, 64);
         const double mean_len = p.len_median * std::exp(p.len_sigma * p.len_sigma / 2);
         P.n_mol = (long long)(p.coverage * (double)p.contig_len / mean_len);
-        if (P.n_mol < 1 || P.n_mol > 0x3fffffffll) throw std::string("molecule count out of range");
+        if (p.coverage > 0 && (P.n_mol < 1 || P.n_mol > 0x3fffffffll)) throw std::string("molecule count out of range");
         const long long L = P.L;
         Dev<char> tmp;
         // reference + variants
@@ -443,6 +443,11 @@ sg_handle *sg_create(int device, const sg_params *pp) {
         h->n_var = nv;
         h->vpos.alloc(nv); h->vref.alloc(nv); h->valt.alloc(nv); h->vhap.alloc(nv);
         hipLaunchKernelGGL(k_var_fill, dim3((P.n_strata + 255) / 256), dim3(256), 0, nullptr, P, voff.p, h->ref.p, h->code.p, h->vpos.p, h->vref.p, h->valt.p, h->vhap.p);
+        if (p.coverage <= 0) {                                                  // reference + variant table only (the SNP-table broadcast of a multi-rank run)
+            SG_TRY(hipDeviceSynchronize()); h->code.release();
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            return h;
+        }
         // molecules -> alignments sorted by start
         Dev<uint32_t> mcnt, moff; mcnt.alloc((size_t)P.n_mol + 1); moff.alloc((size_t)P.n_mol + 1);
         SG_TRY(hipMemsetAsync(mcnt.p, 0, ((size_t)P.n_mol + 1) * 4, nullptr));
