@@ -340,9 +340,9 @@ int64_t lps_dump_graph(lps_ctx *ctx, int32_t *node_var_index, float *edge, int64
 int64_t lps_dump_votes(lps_ctx *ctx, int8_t *hp, int32_t *block_node, int64_t node_capacity);
 /* Clip events counted by getClip (src/phase/ParsingBam.cpp:1636-1645): (ref_pos, 0 FRONT / 1 BACK). */
 int64_t lps_dump_clips(lps_ctx *ctx, int32_t *pos, uint8_t *front_back, int64_t capacity);
-/* CNV intervals of Clip::getCNVInterval (each interval appears twice, as in the reference) and, optionally,
- * the per-alignment "removed by the overlap filter" flags (n_reads bytes).  start/end need 64 entries. */
-int lps_dump_cnv(lps_ctx *ctx, int32_t *start, int32_t *end, uint8_t *aln_deleted);
+/* CNV intervals of Clip::getCNVInterval (each interval appears twice, as in the reference; their number is unbounded) and, optionally,
+ * the per-alignment "removed by the overlap filter" flags (n_reads bytes).  Returns the number of entries (pass NULL / 0 to query it). */
+int64_t lps_dump_cnv(lps_ctx *ctx, int32_t *start, int32_t *end, int64_t capacity, uint8_t *aln_deleted);
 
 #ifdef __cplusplus
 }

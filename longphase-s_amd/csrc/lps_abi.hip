@@ -64,9 +64,11 @@ struct lps_ctx {
     DevBuf<unsigned long long> clip_keys, clip_keys_s;
     DevBuf<int32_t> cnv_start, cnv_end;
     DevBuf<long long> agg_sum; DevBuf<int32_t> agg_cnt; DevBuf<double> miss;
-    DevBuf<uint32_t> cnv_flag, cnv_idx, cnv_list, cnv_nlist; DevBuf<uint8_t> cnv_tab, cnv_btab, cnv_bstart, cnv_entry;
+    DevBuf<uint32_t> cnv_flag, cnv_idx, cnv_list, cnv_nlist; DevBuf<uint8_t> cnv_fn, cnv_pre;
     uint8_t *h_res = nullptr; size_t h_res_bytes = 0;   // pinned landing zone of (phase_set, gt): one copy, then memcpy into the caller's arrays
-    unsigned *h_ncnv = nullptr; LpsCounters *h_cnt_pin = nullptr; unsigned *h_stats_pin = nullptr; hipEvent_t ev_cnv = nullptr;   // pinned word + event: n_cnv reaches the host while the GPU keeps working
+    unsigned *h_ncnv = nullptr; LpsCounters *h_cnt_pin = nullptr; unsigned *h_stats_pin = nullptr; hipEvent_t ev_cnv = nullptr;   // pinned block + event: the counters reach the host while the GPU keeps working
+    unsigned long long *h_clip_keys = nullptr; size_t h_clip_cap = 0; hipEvent_t ev_clip = nullptr;   // sorted clip keys on their way to the host (pinned): the CNV state machine is replayed there
+    std::vector<int32_t> h_cnv_start, h_cnv_end; bool cnv_expect = false; unsigned h_ub_hazard = 0;   // intervals of the current run (each once); cnv_expect: the previous run had intervals
     // groups
     DevBuf<unsigned long long> name_keys, name_keys_s;
     DevBuf<uint32_t> head, gidx, gstart, read_group, stack, mrow_off, koff; DevBuf<int32_t> mrow_cnt;
@@ -171,7 +173,7 @@ lps_ctx *lps_create(int device, const lps_params *params) {
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_TRY(hipMalloc((void **)&c->d_cnt, sizeof(LpsCounters)));
         for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(hipEventCreate(&c->ev_begin)); HIP_TRY(hipEventCreate(&c->ev_end)); HIP_TRY(hipEventCreate(&c->ev_cnv));
+        HIP_TRY(hipEventCreate(&c->ev_begin)); HIP_TRY(hipEventCreate(&c->ev_end)); HIP_TRY(hipEventCreate(&c->ev_cnv)); HIP_TRY(hipEventCreate(&c->ev_clip));
         HIP_TRY(hipHostMalloc((void **)&c->h_ncnv, 1024));          // pinned: copies into it do not block the host
         c->h_cnt_pin = (LpsCounters *)(c->h_ncnv + 16); c->h_stats_pin = c->h_ncnv + 192;
         static_assert(sizeof(LpsCounters) <= 512, "pinned block layout");
@@ -187,6 +189,8 @@ void lps_destroy(lps_ctx *c) {
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     if (c->ev_cnv) (void)hipEventDestroy(c->ev_cnv);
+    if (c->ev_clip) (void)hipEventDestroy(c->ev_clip);
+    if (c->h_clip_keys) (void)hipHostFree(c->h_clip_keys);
     if (c->h_ncnv) (void)hipHostFree(c->h_ncnv);
     if (c->h_res) (void)hipHostFree(c->h_res);
     for (int k = 0; k < 2; ++k) { if (c->stage[k]) (void)hipHostFree(c->stage[k]); if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]); }
@@ -608,6 +612,57 @@ int lps_bgzf_timings(lps_ctx *c, double *h2d_ms, double *inflate_ms) {
     return 0;
 }
 
+// Clip::getCNVInterval (src/phase/PhasingGraph.cpp:1103-1227) replayed on the HOST from the sorted clip keys (pos << 1 | front/back): a serial state
+// machine over the clipped positions - a lone GPU lane walked it at ~0.4 us per position (5 ms for a chr20 with pile-ups), a host core does it in
+// microseconds while the GPU runs the stages that do not need the intervals.  The reference runs it twice on the same counts (Clip ctor +
+// PhasingProcess.cpp:148), which appends the same intervals twice: here it runs once and the list is doubled by the caller.  Unbounded output.
+// Every transition that can emit needs a position with >= 5 front or >= 5 back clips (push needs up >= 5; slowUp emits on down >= 5, or on
+// down >= curr / 4 with curr > 20, i.e. again down >= 5): without one the walk is skipped.
+static void replay_cnv(const unsigned long long *keys, size_t n, std::vector<int32_t> &start, std::vector<int32_t> &end) {
+    start.clear(); end.clear();
+    if (n == 0) return;
+    {   // largest per-position FRONT / BACK count: below 5 nothing can be emitted
+        unsigned best = 0, run = 0;
+        for (size_t i = 0; i < n; ++i) { run = (i && keys[i] == keys[i - 1]) ? run + 1 : 1; if (run > best) best = run; }
+        if (best < 5) return;
+    }
+    struct St { bool push = false, slowUp = false, slowDown = false; int curr = 0, reject = 0, pullDown = 0, slowDownCount = 0, candStart = -1, candEnd = -1;
+                void reset() { *this = St(); }
+                void threshold(int up) { reject = up; if (up >= 20) { pullDown = up / 2; slowDownCount = 5; } else if (up >= 10) { pullDown = up / 2; slowDownCount = up / 4; } else { pullDown = 5; slowDownCount = 2; } } } s;
+    const int Area = 30000;
+    size_t i = 0; bool sentinel_done = false; int last_up = 0, last_down = 0, last_pos = 0;
+    while (true) {
+        int pos, up = 0, down = 0;
+        if (i < n) {
+            pos = (int)(keys[i] >> 1);
+            while (i < n && (int)(keys[i] >> 1) == pos) { if (keys[i] & 1) ++down; else ++up; ++i; }
+            last_up = up; last_down = down; last_pos = pos;
+        } else if (!sentinel_done) { pos = last_pos + Area; up = last_up; down = last_down; sentinel_done = true; }   // :1134
+        else break;
+        if (!s.push && !s.slowDown && !s.slowUp) {
+            if (up >= 5 && s.curr == 0) { s.push = true; s.slowUp = false; s.slowDown = true; s.curr = up - down; s.candStart = pos; s.candEnd = pos + Area; s.threshold(up); }
+            else if (up > down && s.curr == 0) { s.push = false; s.slowUp = true; s.slowDown = false; s.curr = up - down; s.candStart = pos; s.candEnd = pos + Area; }
+        } else if (s.push && s.slowDown) {
+            if (up > s.reject) { s.threshold(up); s.candStart = pos; s.candEnd = pos + Area; }
+            s.curr = s.curr + up - down;
+            if (s.curr > 30) s.candEnd = pos + Area;
+            bool emitted = false;
+            if (down >= s.pullDown) emitted = true;
+            else if (s.curr <= s.slowDownCount && pos <= s.candEnd) emitted = true;
+            if (emitted) { start.push_back(s.candStart); end.push_back(pos); s.reset(); }
+            if (pos > s.candEnd || s.curr <= 0 || pos - s.candStart >= 200000) s.reset();
+        } else if (s.slowUp) {
+            if (s.curr > 20 ? down >= s.curr / 4 : down >= 5) { start.push_back(s.candStart); end.push_back(pos); s.reset(); }
+            else if (up >= 5) { s.push = true; s.slowUp = false; s.slowDown = true; s.curr = up - down; s.candStart = pos; s.candEnd = pos + Area; s.threshold(up); }
+            else {
+                s.curr = s.curr + up - down;
+                if (s.curr > 30) s.candEnd = pos + Area;
+                if (pos > s.candEnd || s.curr <= 0 || pos - s.candStart >= 200000) s.reset();
+            }
+        }
+    }
+}
+
 static int bits_for(unsigned long long n) { int b = 1; while ((1ull << b) < n) ++b; return b; }
 
 // stage boundaries on the stream.  Every recorded event drains the queue for a moment (~3.5 us): a phase run records them all only when the
@@ -649,10 +704,19 @@ static int run_late(lps_ctx *c, bool with_cnv) {
         mark(c, ST_CNV);
         c->cnv_skipped = !with_cnv;
         if (with_cnv) {
+            const size_t K = c->h_cnv_start.size();
+            c->cnv_start.reserve(2 * K + 2); c->cnv_end.reserve(2 * K + 2);
+            std::vector<int32_t> two(4 * K);                               // [start x2 | end x2]: every interval twice, as the reference's cnvVec holds them
+            for (size_t i = 0; i < K; ++i) { two[i] = two[K + i] = c->h_cnv_start[i]; two[2 * K + i] = two[3 * K + i] = c->h_cnv_end[i]; }
+            HIP_TRY(hipMemcpyAsync(c->cnv_start.p, two.data(), 2 * K * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(c->cnv_end.p, two.data() + 2 * K, 2 * K * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            const unsigned nc = (unsigned)(2 * K);
+            HIP_TRY(hipMemcpyAsync(&c->d_cnt->n_cnv, &nc, sizeof nc, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));                              // `two` and `nc` are stack-owned
             c->agg_sum.reserve((size_t)nV * 2 + 2); c->agg_cnt.reserve((size_t)nV * 2 + 2); c->miss.reserve(nV + 1);
             c->cnv_flag.reserve(nR + 1); c->cnv_idx.reserve(nR + 1); c->cnv_list.reserve(nR + 1); c->cnv_nlist.reserve(4);
-            c->cnv_tab.reserve((size_t)nR * 64 + 64); c->cnv_btab.reserve(((size_t)nR / 256 + 2) * 64); c->cnv_bstart.reserve((size_t)nR / 256 + 2); c->cnv_entry.reserve(nR + 1);
-            CnvScratch W{c->cnv_flag.p, c->cnv_idx.p, c->cnv_list.p, c->cnv_nlist.p, c->cnv_tab.p, c->cnv_btab.p, c->cnv_bstart.p, c->cnv_entry.p};
+            c->cnv_fn.reserve(nR + 1); c->cnv_pre.reserve(nR + 1);
+            CnvScratch W{c->cnv_flag.p, c->cnv_idx.p, c->cnv_list.p, c->cnv_nlist.p, c->cnv_fn.p, c->cnv_pre.p};
             launch_cnv_filter(c->d_cnt, nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->v_pos.p, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, W, c->temp.p, c->temp_bytes, s);
         }
         // ---- a10 nodes + graph observations
@@ -701,7 +765,6 @@ static int run_phase(lps_ctx *c) {
         c->clip_capacity = (size_t)LPS_CLIP_SLOTS * nR + 64;
         c->clip_pos.reserve(c->clip_capacity); c->clip_op.reserve(c->clip_capacity);
         c->clip_keys.reserve(c->clip_capacity); c->clip_keys_s.reserve(c->clip_capacity);
-        c->cnv_start.reserve(LPS_MAX_CNV); c->cnv_end.reserve(LPS_MAX_CNV);
         c->name_keys.reserve(nR + 1); c->name_keys_s.reserve(nR + 1);
         c->head.reserve(nR + 1); c->gidx.reserve(nR + 1); c->gstart.reserve(nR + 2); c->read_group.reserve(nR + 1); c->stack.reserve(nR + 1);
         c->mrow_off.reserve(nR + 1); c->koff.reserve(nR + 1);
@@ -761,13 +824,27 @@ static int run_phase(lps_ctx *c) {
         if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) { c->err = "alignment find unsupported CIGAR operation"; return -2; }
         if (c->h_cnt.err & LPS_ERR_CLIP_OVERFLOW) { c->err = "clip event buffer overflow"; return -3; }
         if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = (unsigned long long)n_arenas * (c->h_cnt.arena_max + c->h_cnt.arena_max / 4 + 1024); continue; }
-        // ---- a7 clips -> CNV intervals
+        // ---- a7 clips -> CNV intervals: the keys are sorted here and travel to the host (pinned), which replays the state machine (replay_cnv)
         mark(c, ST_CLIP);
-        launch_clip_cnv(c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, c->cnv_start.p, c->cnv_end.p, c->clip_stats.p, c->d_cnt, s);
+        launch_clip_sort(c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, s);
+        const size_t nk = c->h_cnt.n_clips;
+        if (nk > c->h_clip_cap) { if (c->h_clip_keys) HIP_TRY(hipHostFree(c->h_clip_keys)); c->h_clip_keys = nullptr; c->h_clip_cap = nk + nk / 2 + 1024; HIP_TRY(hipHostMalloc((void **)&c->h_clip_keys, c->h_clip_cap * sizeof(unsigned long long))); }
+        if (nk) HIP_TRY(hipMemcpyAsync(c->h_clip_keys, c->clip_keys_s.p, nk * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(c->ev_clip, s));
         c->late_n_keys = c->h_cnt.obs_total; c->late_cap_main = cap_main; c->late_tail = tail_size;
-        // ---- everything after: run on the assumption that the clips gave no CNV interval (the common case), so that the host never waits for
-        //      that count; lps_phase_chromosome looks at it when the results are back and runs the late stages again if the guess was wrong
-        return run_late(c, false);
+        c->h_ub_hazard = nk == 0 ? 1u : 0u;                               // reference: UB on an empty ClipCount (PhasingGraph.cpp:1134)
+        // ---- everything after.  Usually the clips give no CNV interval, so the late stages are enqueued on that guess and the host replays the state
+        //      machine meanwhile; lps_phase_chromosome runs them again with the filter if the guess was wrong.  When the previous run of this ctx did
+        //      have intervals the guess is not made: the host waits for the keys (a bubble of one small copy), replays, and the late stages run once.
+        if (c->cnv_expect) {
+            HIP_TRY(hipEventSynchronize(c->ev_clip));
+            replay_cnv(c->h_clip_keys, nk, c->h_cnv_start, c->h_cnv_end);
+            return run_late(c, !c->h_cnv_start.empty());
+        }
+        const int rc = run_late(c, false);
+        HIP_TRY(hipEventSynchronize(c->ev_clip));                          // arrived long ago: the late stages are still running
+        replay_cnv(c->h_clip_keys, nk, c->h_cnv_start, c->h_cnv_end);
+        return rc;
     }
     c->err = "observation buffer kept overflowing";
     return -5;
@@ -815,7 +892,7 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         HIP_TRY(hipEventRecord(c->ev_end, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->h_cnt = *c->h_cnt_pin; memcpy(c->h_stats, c->h_stats_pin, sizeof c->h_stats);
-        if (c->cnv_skipped && c->h_cnt.n_cnv != 0 && !(c->h_cnt.err & LPS_ERR_OBS_OVERFLOW)) {     // CNV intervals exist after all: late stages again, with the filter
+        if (c->cnv_skipped && !c->h_cnv_start.empty() && !(c->h_cnt.err & LPS_ERR_OBS_OVERFLOW)) {     // CNV intervals exist after all: late stages again, with the filter
             rc = run_late(c, true);
             if (rc != 0) return rc;
             (void)enqueue_result_copy(c);
@@ -825,7 +902,7 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         }
         if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = c->obs_capacity * 2 + 64 * 1024; return lps_phase_chromosome(c, out); }
         if (c->h_cnt.err & LPS_ERR_KEY_RANGE) return fail(c, "a merged read has more than 65536 observations", -6);
-        if (c->h_cnt.err & LPS_ERR_CNV_CAP) return fail(c, "more than 64 CNV intervals on one chromosome", -7);
+        c->cnv_expect = !c->h_cnv_start.empty();
         deliver_result(c, out);
         // timings
         lps_timings &t = c->tm; memset(&t, 0, sizeof t);
@@ -1155,15 +1232,14 @@ int64_t lps_dump_clips(lps_ctx *c, int32_t *pos, uint8_t *front_back, int64_t ca
     } catch (std::string &e) { fail(c, e); return -1; }
 }
 
-int lps_dump_cnv(lps_ctx *c, int32_t *start, int32_t *end, uint8_t *aln_deleted) {
+int64_t lps_dump_cnv(lps_ctx *c, int32_t *start, int32_t *end, int64_t capacity, uint8_t *aln_deleted) {
     if (!c || !c->phase_valid) return -1;
     try {
         HIP_TRY(hipSetDevice(c->device));
-        const int n = (int)c->h_cnt.n_cnv;
-        auto s = download(c, c->cnv_start.p, (size_t)n); auto e = download(c, c->cnv_end.p, (size_t)n);
-        for (int i = 0; i < n; ++i) { start[i] = s[i]; end[i] = e[i]; }
+        const int64_t K = (int64_t)c->h_cnv_start.size();
+        for (int64_t i = 0; i < 2 * K && i < capacity && start && end; ++i) { start[i] = c->h_cnv_start[(size_t)(i % K)]; end[i] = c->h_cnv_end[(size_t)(i % K)]; }
         if (aln_deleted) { auto d = download(c, c->deleted.p, (size_t)c->nR); memcpy(aln_deleted, d.data(), (size_t)c->nR); }
-        return n;
+        return 2 * K;
     } catch (std::string &e) { fail(c, e); return -1; }
 }
 

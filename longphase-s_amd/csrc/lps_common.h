@@ -50,7 +50,6 @@ enum {
     LPS_ERR_BAD_CIGAR = 1,      // unsupported CIGAR op (reference: exit(1), ParsingBam.cpp:1625-1628)
     LPS_ERR_OBS_OVERFLOW = 2,   // observation buffer too small -> host grows and reruns
     LPS_ERR_KEY_RANGE = 4,      // sort-key field overflow (row longer than 2^18 or >2^22 nodes)
-    LPS_ERR_CNV_CAP = 8,        // more than LPS_MAX_CNV CNV intervals
     LPS_ERR_CLIP_OVERFLOW = 16,
 };
 
@@ -171,7 +170,6 @@ __host__ __device__ __forceinline__ uint16_t pack_aq(int allele, int quality) { 
 __host__ __device__ __forceinline__ int aq_allele(uint16_t aq) { return (aq >> 9) & 1; }
 __host__ __device__ __forceinline__ int aq_quality(uint16_t aq) { return (int)(aq & 0x1ff) - 8; }
 
-#define LPS_MAX_CNV 64
 #define LPS_CLIP_SLOTS 4        // clip ops per alignment (H S ... S H); more is reported as an error
 #define LPS_SEG 512           // CIGAR ops staged in LDS per wave and segment (4 KB/wave)
 #define LPS_BUCKET_SHIFT 10    // coarse position index: bucket b = first variant with pos >= b << shift

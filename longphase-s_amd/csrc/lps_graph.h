@@ -10,9 +10,7 @@ void sort_pairs64(void *temp, size_t temp_bytes, const unsigned long long *kin, 
 void exscan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s);
 
 void launch_clip_keys(const ClipView &C, const int32_t *row_fail, int n_reads, unsigned long long *keys, LpsCounters *cnt, hipStream_t s);
-void launch_clip_cnv(unsigned n_clips, unsigned long long *keys,
-                     unsigned long long *keys_sorted, void *temp, size_t temp_bytes, int32_t *cnv_start, int32_t *cnv_end,
-                     unsigned *stats, LpsCounters *cnt, hipStream_t s);
+void launch_clip_sort(unsigned n_clips, unsigned long long *keys, unsigned long long *keys_sorted, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_name_keys(int n_reads, const uint32_t *name_id, const int32_t *row_cnt, unsigned long long *keys, LpsCounters *cnt,
                       const unsigned long long *arena_ctr, unsigned long long arena_size, hipStream_t s);
 void launch_groups(const unsigned long long *skeys, int n_reads, LpsCounters *cnt, uint32_t *head, uint32_t *gidx,
@@ -20,7 +18,7 @@ void launch_groups(const unsigned long long *skeys, int n_reads, LpsCounters *cn
 void launch_overlap_filter(const unsigned long long *skeys, const uint32_t *gstart, const LpsCounters *cnt, int n_reads,
                            const uint32_t *row_off, const int32_t *row_cnt, const int32_t *obs_var, const int32_t *vpos,
                            double thr, uint32_t *stack, uint8_t *deleted, hipStream_t s);
-struct CnvScratch { uint32_t *flag, *idx, *list, *n_list; uint8_t *tab, *btab, *bstart, *entry; };
+struct CnvScratch { uint32_t *flag, *idx, *list, *n_list; uint8_t *fn, *pre; };
 void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const uint32_t *row_off, const int32_t *row_cnt,
                        const uint8_t *deleted, int32_t *obs_var, const uint16_t *obs_aq, const int32_t *vpos,
                        const int32_t *cnv_start, const int32_t *cnv_end, long long *agg_sum, int32_t *agg_cnt, double *miss,

@@ -1,7 +1,7 @@
 // lps_graph.hip — haplotype-graph kernels of `phase` (gfx950, wave64).
 //
 // Replaces (reference file:line, relative to /root/reference/):
-//   Clip::getCNVInterval (x2)            src/phase/PhasingGraph.cpp:1103-1227  -> k_clip_keys + sort + k_cnv_state
+//   Clip::getCNVInterval (x2)            src/phase/PhasingGraph.cpp:1103-1227  -> k_clip_keys + sort; the state machine itself is replayed on the host (lps_abi.hip replay_cnv)
 //   VairiantGraph::addEdge overlap filter src/phase/PhasingGraph.cpp:707-781   -> k_name_keys + sort + k_group_* + k_overlap_filter
 //   addEdge type tagging / node set       :793-846                             -> k_mark_nodes + scan + k_graph_obs
 //   addEdge pair loop + addSubEdge        :848-888, :25-70                     -> k_merge_plan/k_merge_multi + k_node_count/scatter + k_edges (orders the node lists)
@@ -48,83 +48,6 @@ __global__ __launch_bounds__(256) void k_clip_keys(ClipView C, const int32_t *ro
     unsigned off = s_base + (unsigned)(incl - n); for (int q = 0; q < w; ++q) off += s_wcnt[q];
 #pragma unroll
     for (int k = 0; k < LPS_CLIP_SLOTS; ++k) if (k < n) keys[off + k] = key[k];
-}
-
-struct CnvState {
-    bool push, slowUp, slowDown; int curr, reject, pullDown, slowDownCount, candStart, candEnd;
-    __device__ void reset() { push = slowUp = slowDown = false; curr = reject = pullDown = slowDownCount = 0; candStart = candEnd = -1; }
-    __device__ void threshold(int up) {
-        reject = up;
-        if (up >= 20) { pullDown = up / 2; slowDownCount = 5; }
-        else if (up >= 10) { pullDown = up / 2; slowDownCount = up / 4; }
-        else { pullDown = 5; slowDownCount = 2; }
-    }
-};
-
-// Parallel pre-pass over the sorted clip keys: number of valid keys and the largest per-position FRONT / BACK count.
-// Every transition of the state machine that can emit an interval needs a position with >=5 front or >=5 back clips
-// (push needs up>=5; slowUp emits on down>=5 or down>=curr/4 with curr>20), so when the maximum is below 5 the
-// (sequential) state machine cannot produce anything and is skipped.
-__global__ void k_clip_stats(const unsigned long long *keys, unsigned n_clips, unsigned *stats /*[0]=n_valid,[1]=max run*/) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_clips) return;
-    const unsigned long long k = keys[i];
-    if (k == ~0ull) return;
-    if (i + 1 == n_clips || keys[i + 1] == ~0ull) stats[0] = i + 1;
-    if (i == 0 || keys[i - 1] != k) {                        // head of a run of equal (pos, front/back) keys
-        unsigned j = i + 1; while (j < n_clips && keys[j] == k && j - i < 5) ++j;
-        if (j - i >= 5) atomicMax(&stats[1], j - i);
-    }
-}
-
-// One thread: run-length the sorted clip keys into (pos, up, down) and replay the CNV state machine.  The reference
-// runs it twice on the same counts (Clip ctor + PhasingProcess.cpp:148) which appends the same intervals twice;
-// here it runs once and the result is duplicated.  Sequential by nature, O(#clipped positions).
-__global__ void k_cnv_state(const unsigned long long *keys, unsigned n_clips, const unsigned *stats, int32_t *cnv_start,
-                            int32_t *cnv_end, LpsCounters *cnt) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const unsigned n = stats[0];
-    int n_cnv = 0;
-    if (n == 0) { cnt->n_cnv = 0; cnt->ub_hazard += 1; return; }   // reference: UB on empty ClipCount
-    if (stats[1] < 5) { cnt->n_cnv = 0; return; }
-    const int Area = 30000;
-    for (int rep = 0; rep < 1; ++rep) {
-        CnvState s; s.reset();
-        unsigned i = 0; bool sentinel_done = false; int last_up = 0, last_down = 0, last_pos = 0;
-        while (true) {
-            int pos, up = 0, down = 0;
-            if (i < n) {
-                pos = (int)(keys[i] >> 1);
-                while (i < n && (int)(keys[i] >> 1) == pos) { if (keys[i] & 1) ++down; else ++up; ++i; }
-                last_up = up; last_down = down; last_pos = pos;
-            } else if (!sentinel_done) { pos = last_pos + Area; up = last_up; down = last_down; sentinel_done = true; }   // :1134
-            else break;
-            if (!s.push && !s.slowDown && !s.slowUp) {
-                if (up >= 5 && s.curr == 0) { s.push = true; s.slowUp = false; s.slowDown = true; s.curr = up - down; s.candStart = pos; s.candEnd = pos + Area; s.threshold(up); }
-                else if (up > down && s.curr == 0) { s.push = false; s.slowUp = true; s.slowDown = false; s.curr = up - down; s.candStart = pos; s.candEnd = pos + Area; }
-            } else if (s.push && s.slowDown) {
-                if (up > s.reject) { s.threshold(up); s.candStart = pos; s.candEnd = pos + Area; }
-                s.curr = s.curr + up - down;
-                if (s.curr > 30) s.candEnd = pos + Area;
-                bool emitted = false;
-                if (down >= s.pullDown) emitted = true;
-                else if (s.curr <= s.slowDownCount && pos <= s.candEnd) emitted = true;
-                if (emitted) { if (n_cnv < LPS_MAX_CNV) { cnv_start[n_cnv] = s.candStart; cnv_end[n_cnv] = pos; } ++n_cnv; s.reset(); }
-                if (pos > s.candEnd || s.curr <= 0 || pos - s.candStart >= 200000) s.reset();
-            } else if (s.slowUp) {
-                if (s.curr > 20 ? down >= s.curr / 4 : down >= 5) { if (n_cnv < LPS_MAX_CNV) { cnv_start[n_cnv] = s.candStart; cnv_end[n_cnv] = pos; } ++n_cnv; s.reset(); }
-                else if (up >= 5) { s.push = true; s.slowUp = false; s.slowDown = true; s.curr = up - down; s.candStart = pos; s.candEnd = pos + Area; s.threshold(up); }
-                else {
-                    s.curr = s.curr + up - down;
-                    if (s.curr > 30) s.candEnd = pos + Area;
-                    if (pos > s.candEnd || s.curr <= 0 || pos - s.candStart >= 200000) s.reset();
-                }
-            }
-        }
-    }
-    if (2 * n_cnv > LPS_MAX_CNV) { atomicOr(&cnt->err, (unsigned)LPS_ERR_CNV_CAP); n_cnv = LPS_MAX_CNV / 2; }
-    for (int q = 0; q < n_cnv; ++q) { cnv_start[n_cnv + q] = cnv_start[q]; cnv_end[n_cnv + q] = cnv_end[q]; }   // second run
-    cnt->n_cnv = 2 * n_cnv;
 }
 
 // ================================================================================================ name groups
@@ -215,21 +138,26 @@ __global__ void k_overlap_filter(const unsigned long long *skeys, const uint32_t
 }
 
 // ================================================================================================ CNV filter
-// The four CNV mismatch-rate passes (PhasingGraph.cpp:520-692).  The reference carries ONE interval cursor from read to read
-// (and, in the last pass, from variant to variant) over the interval list that holds every interval twice (getCNVInterval runs
-// twice), so which intervals a read "visits" depends on all reads before it.  Parallel formulation: the cursor lives in
-// [0, n_cnv) with n_cnv <= 64, so every read is a transfer function f_r: cursor_in -> cursor_out, i.e. a 64-entry byte table
-// computed by one wave (lane c simulates cursor_in = c).  Tables are composed per block of CNV_BLOCK reads (lane c follows the
-// chain), the few block tables are chained by one lane, and the per-read entry cursors are then known, which makes the counting
-// passes embarrassingly parallel (order-free integer sums).  Launched only behind a device-side n_cnv check.
-#define CNV_BLOCK 256
-
-__device__ __forceinline__ int cnv_cursor12(int ci, int rs, int re, int nc, const int32_t *cs, int *i_end) {
-    while (ci > 0 && cs[ci] > rs) --ci;
-    int i = ci;
-    while (i < nc && cs[i] <= re) ++i;
-    *i_end = i;
-    return ci;                                               // entry index actually used; cursor_out = i > 0 ? i - 1 : 0
+// The four CNV mismatch-rate passes (PhasingGraph.cpp:520-692).  The reference carries ONE interval cursor from read to read (and, in the last
+// pass, from observation to observation) over an interval list that holds every interval twice (getCNVInterval runs twice): cs = [s_0..s_(K-1),
+// s_0..s_(K-1)], each half ascending and its intervals disjoint.  Which intervals a read "visits" therefore depends on all reads before it.
+// What it depends on is ONE BIT: the half h the carried cursor sits in.  Inside a half the reference first walks the cursor back to the last
+// interval that starts at or before the read (or to index 0 of the whole list when the read starts before s_0), and intervals that end before
+// the read can neither be hit nor change where the forward scan ends - so for any offset inside the half the visited intervals that can hold an
+// observation, the erasures and the cursor handed on are the same (checked exhaustively against the reference's loops on random interval sets
+// when this was written; tests/test_phase_gpu.py cnv_* fixtures pin it end to end).  A read is therefore a function {0,1} -> {0,1} on the half;
+// functions compose associatively, one device-wide scan gives every read its entry half, and counting / erasing are then embarrassingly
+// parallel: each read replays the reference's own loops from the representative cursor of its half.  No bound on the number of intervals
+// (the reference's cnvVec is an unbounded std::vector).
+__device__ __forceinline__ int cnv_ub(const int32_t *cs, int K, int p) {   // number of interval starts <= p (first half)
+    int lo = 0, hi = K;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (cs[m] <= p) lo = m + 1; else hi = m; }
+    return lo;
+}
+// the cursor the reference's back-up loop (`while (ci > 0 && cs[ci] > rs) --ci`) reaches from anywhere in half h, taken at the representative
+__device__ __forceinline__ int cnv_entry(const int32_t *cs, int K, int h, int rs) {
+    const int A = cnv_ub(cs, K, rs);
+    return A == 0 ? 0 : h * K + A - 1;
 }
 
 // kept alignments in BAM order -> dense list (reads with observations that survived the overlap filter)
@@ -245,62 +173,43 @@ __global__ void k_cnv_compact(const LpsCounters *cnt, int n_reads, const uint32_
     if (r == n_reads - 1) *n_list = idx[r] + flag[r];
 }
 
-// wave per kept alignment: transfer tables of the pass-1/2 cursor (PASS4=false) or of the pass-4 cursor (PASS4=true)
+// thread per kept alignment: its transfer function on the cursor's half, bit h = half of the cursor it hands on when entered in half h.
+// PASS4 = false: calculateCnvMismatchRate / aggregateCnvReadMismatchRate (same cursor walk); PASS4 = true: filterHighMismatchVariants.
 template <bool PASS4>
-__global__ __launch_bounds__(256) void k_cnv_tables(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint32_t *row_off,
-                                                    const int32_t *row_cnt, const int32_t *obs_var, const int32_t *vpos, const int32_t *cs,
-                                                    const int32_t *ce, const double *miss, uint8_t *tab) {
-    const unsigned k = blockIdx.x * 4 + (threadIdx.x >> 6); const int l = lane_id();
+__global__ void k_cnv_fn(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint32_t *row_off, const int32_t *row_cnt,
+                         const int32_t *obs_var, const int32_t *vpos, const int32_t *cs, const int32_t *ce, const double *miss, uint8_t *fn) {
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= *n_list) return;
-    const int nc = (int)cnt->n_cnv;
+    const int nc = (int)cnt->n_cnv, K = nc / 2;
     const uint32_t r = list[k]; const uint32_t off = row_off[r]; const int n = row_cnt[r];
-    int ci = min(l, nc - 1);
-    if (!PASS4) {
-        const int rs = vpos[obs_var[off]], re = vpos[obs_var[off + n - 1]];
-        int i_end; cnv_cursor12(ci, rs, re, nc, cs, &i_end);
-        ci = i_end > 0 ? i_end - 1 : 0;
-    } else {
-        const int rs = vpos[obs_var[off]];
-        while (ci > 0 && cs[ci] > rs) --ci;
-        for (int q = 0; q < n; ++q) {
-            const int v = obs_var[off + q]; const int p = vpos[v];
-            int i = ci;
-            while (i < nc && cs[i] <= p) { if (p >= cs[i] && p <= ce[i] && miss[v] >= 0.7) break; ++i; }
+    const int rs = vpos[obs_var[off]];
+    unsigned f = 0;
+    for (int h = 0; h < 2; ++h) {
+        int ci = cnv_entry(cs, K, h, rs);
+        if (!PASS4) {
+            const int re = vpos[obs_var[off + n - 1]];
+            int i = ci; while (i < nc && cs[i] <= re) ++i;
             ci = i > 0 ? i - 1 : 0;
+        } else {
+            for (int q = 0; q < n; ++q) {
+                const int v = obs_var[off + q]; const int p = vpos[v];
+                int i = ci;
+                while (i < nc && cs[i] <= p) { if (p >= cs[i] && p <= ce[i] && miss[v] >= 0.7) break; ++i; }
+                ci = i > 0 ? i - 1 : 0;
+            }
         }
+        f |= (unsigned)(ci >= K) << h;
     }
-    if (l < nc) tab[(size_t)k * 64 + l] = (uint8_t)ci;
+    fn[k] = (uint8_t)f;
 }
+struct CnvCompose {   // (a then b): bit h of the result = b(a(h)); identity 0b10
+    __host__ __device__ uint8_t operator()(uint8_t a, uint8_t b) const { return (uint8_t)(((b >> (a & 1)) & 1) | (((b >> ((a >> 1) & 1)) & 1) << 1)); }
+};
 
-// wave per block of CNV_BLOCK alignments: compose the tables of the block (lane c follows cursor_in = c through the block)
-__global__ __launch_bounds__(64) void k_cnv_block_compose(const LpsCounters *cnt, const uint32_t *n_list, const uint8_t *tab, uint8_t *btab) {
-    const unsigned b = blockIdx.x; const int l = lane_id();
-    const unsigned n = *n_list;
-    if (b * CNV_BLOCK >= n) return;
-    const int nc = (int)cnt->n_cnv;
-    int c = min(l, nc - 1);
-    const unsigned e = min(n, (b + 1) * CNV_BLOCK);
-    for (unsigned k = b * CNV_BLOCK; k < e; ++k) c = tab[(size_t)k * 64 + c];
-    if (l < nc) btab[(size_t)b * 64 + l] = (uint8_t)c;
-}
-// one lane chains the block tables from cursor 0; then wave per block: entry cursor of every alignment of the block
-__global__ void k_cnv_block_chain(const uint32_t *n_list, const uint8_t *btab, uint8_t *bstart) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const unsigned nb = (*n_list + CNV_BLOCK - 1) / CNV_BLOCK;
-    int c = 0;
-    for (unsigned b = 0; b < nb; ++b) { bstart[b] = (uint8_t)c; c = btab[(size_t)b * 64 + c]; }
-}
-__global__ void k_cnv_entry(const uint32_t *n_list, const uint8_t *tab, const uint8_t *bstart, uint8_t *entry) {
-    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned n = *n_list;
-    if (b * CNV_BLOCK >= n) return;
-    int c = bstart[b];
-    const unsigned e = min(n, (b + 1) * CNV_BLOCK);
-    for (unsigned k = b * CNV_BLOCK; k < e; ++k) { entry[k] = (uint8_t)c; c = tab[(size_t)k * 64 + c]; }
-}
-
-// thread per kept alignment: calculateCnvMismatchRate + aggregateCnvReadMismatchRate with the known entry cursor
-__global__ void k_cnv_count(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *entry, const uint32_t *row_off,
+// thread per kept alignment: calculateCnvMismatchRate + aggregateCnvReadMismatchRate with the known entry half.  mm[read][interval] counts the
+// ALT observations inside the interval once per visit of the interval (an interval is visited in both halves when the scan runs across the
+// middle of the doubled list), and every visit then appends that count to the per-(position, allele) lists.
+__global__ void k_cnv_count(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *pre, const uint32_t *row_off,
                             const int32_t *row_cnt, const int32_t *obs_var, const uint16_t *obs_aq, const int32_t *vpos, const int32_t *cs,
                             const int32_t *ce, unsigned long long *agg_sum, int32_t *agg_cnt) {
     const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -308,59 +217,51 @@ __global__ void k_cnv_count(const LpsCounters *cnt, const uint32_t *list, const 
     const int nc = (int)cnt->n_cnv, K = nc / 2;
     const uint32_t r = list[k]; const uint32_t off = row_off[r]; const int n = row_cnt[r];
     const int rs = vpos[obs_var[off]], re = vpos[obs_var[off + n - 1]];
-    int i_end; const int ci = cnv_cursor12(entry[k], rs, re, nc, cs, &i_end);
-    int mm[LPS_MAX_CNV / 2]; unsigned long long has = 0;
-    for (int j = 0; j < K; ++j) mm[j] = 0;
-    for (int i = ci; i < i_end; ++i)
-        for (int q = 0; q < n; ++q) {
-            const int p = vpos[obs_var[off + q]];
-            if (p > ce[i]) break;
-            if (p >= cs[i] && p <= ce[i] && aq_allele(obs_aq[off + q]) == 1) { mm[i % K]++; has |= 1ull << (i % K); }
-        }
+    const int ci = cnv_entry(cs, K, pre[k] & 1, rs);
+    int i_end = ci; while (i_end < nc && cs[i_end] <= re) ++i_end;
     for (int i = ci; i < i_end; ++i) {
-        if (!((has >> (i % K)) & 1ull)) continue;
+        const int j = i % K; const int s0 = cs[j], e0 = ce[j];
+        if (e0 < rs) continue;
+        int alt = 0;
+        for (int q = 0; q < n; ++q) { const int p = vpos[obs_var[off + q]]; if (p > e0) break; if (p >= s0 && aq_allele(obs_aq[off + q]) == 1) ++alt; }
+        if (!alt) continue;
+        const int visits = (j >= ci && j < min(i_end, K) ? 1 : 0) + (K + j >= max(ci, K) && K + j < i_end ? 1 : 0);
+        const unsigned long long mm = (unsigned long long)alt * (unsigned long long)visits;
         for (int q = 0; q < n; ++q) {
             const int v = obs_var[off + q]; const int p = vpos[v];
-            if (p > ce[i]) break;
-            if (p >= cs[i] && p <= ce[i]) {
-                const int al = aq_allele(obs_aq[off + q]);
-                atomicAdd(&agg_sum[(size_t)v * 2 + al], (unsigned long long)mm[i % K]); atomicAdd(&agg_cnt[(size_t)v * 2 + al], 1);
-            }
+            if (p > e0) break;
+            if (p >= s0) { const int al = aq_allele(obs_aq[off + q]); atomicAdd(&agg_sum[(size_t)v * 2 + al], mm); atomicAdd(&agg_cnt[(size_t)v * 2 + al], 1); }
         }
     }
 }
 
-// thread per variant: calculateAverageMismatchRate (the reference never moves the cursor in this pass: scan from 0)
+// thread per variant: calculateAverageMismatchRate.  The reference scans the list from index 0 for every position (it never moves the cursor in
+// this pass); both halves hold the same disjoint intervals, so "is p inside one of the visited intervals" is one binary search.
 __global__ void k_cnv_miss(const LpsCounters *cnt, int n_var, const int32_t *vpos, const int32_t *cs, const int32_t *ce,
                            const unsigned long long *agg_sum, const int32_t *agg_cnt, double *miss) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_var) return;
-    const int nc = (int)cnt->n_cnv;
+    const int nc = (int)cnt->n_cnv, K = nc / 2;
     double m = -1.0;
     if (nc && agg_cnt[(size_t)v * 2] > 0 && agg_cnt[(size_t)v * 2 + 1] > 0) {
-        const int p = vpos[v];
-        for (int i = 0; i < nc; ++i) {
-            if (cs[i] > p) break;
-            if (p >= cs[i] && p <= ce[i]) {
-                const double a = (double)agg_sum[(size_t)v * 2] / (double)agg_cnt[(size_t)v * 2];
-                const double c = (double)agg_sum[(size_t)v * 2 + 1] / (double)agg_cnt[(size_t)v * 2 + 1];
-                if (a != 0 && c != 0) m = c / (a + c);
-            }
+        const int p = vpos[v]; const int u = cnv_ub(cs, K, p);
+        if (u > 0 && p <= ce[u - 1]) {
+            const double a = (double)agg_sum[(size_t)v * 2] / (double)agg_cnt[(size_t)v * 2];
+            const double c = (double)agg_sum[(size_t)v * 2 + 1] / (double)agg_cnt[(size_t)v * 2 + 1];
+            if (a != 0 && c != 0) m = c / (a + c);
         }
     }
     miss[v] = m;
 }
 
-// thread per kept alignment: filterHighMismatchVariants with the known entry cursor
-__global__ void k_cnv_erase(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *entry, const uint32_t *row_off,
+// thread per kept alignment: filterHighMismatchVariants with the known entry half
+__global__ void k_cnv_erase(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *pre, const uint32_t *row_off,
                             const int32_t *row_cnt, int32_t *obs_var, const int32_t *vpos, const int32_t *cs, const int32_t *ce, const double *miss) {
     const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= *n_list) return;
-    const int nc = (int)cnt->n_cnv;
+    const int nc = (int)cnt->n_cnv, K = nc / 2;
     const uint32_t r = list[k]; const uint32_t off = row_off[r]; const int n = row_cnt[r];
-    int ci = entry[k];
-    const int rs = vpos[obs_var[off]];
-    while (ci > 0 && cs[ci] > rs) --ci;
+    int ci = cnv_entry(cs, K, pre[k] & 1, vpos[obs_var[off]]);
     for (int q = 0; q < n; ++q) {
         const int v = obs_var[off + q]; const int p = vpos[v];
         int i = ci;
@@ -1148,7 +1049,9 @@ size_t GraphTemp::need(size_t n_sort) {
     (void)rocprim::radix_sort_keys(nullptr, a, k, k, n_sort, 0, 64, nullptr);
     (void)rocprim::radix_sort_pairs(nullptr, b, k, k, v, v, n_sort, 0, 64, nullptr);
     (void)rocprim::exclusive_scan(nullptr, c, v, v, 0u, n_sort, rocprim::plus<uint32_t>(), nullptr);
-    return std::max(a, std::max(b, c)) + 256;
+    size_t d = 0; uint8_t *u = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, d, u, u, (uint8_t)2, n_sort, CnvCompose(), nullptr);
+    return std::max(std::max(a, d), std::max(b, c)) + 256;
 }
 
 void sort_keys64(void *temp, size_t temp_bytes, const unsigned long long *in, unsigned long long *out, size_t n, int bits,
@@ -1177,25 +1080,24 @@ void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const uin
                        const uint8_t *deleted, int32_t *obs_var, const uint16_t *obs_aq, const int32_t *vpos,
                        const int32_t *cnv_start, const int32_t *cnv_end, long long *agg_sum, int32_t *agg_cnt, double *miss,
                        CnvScratch &W, void *temp, size_t temp_bytes, hipStream_t s) {
-    // Everything below is launched unconditionally (no host round trip); with n_cnv == 0 the kept list is empty and every
-    // kernel returns at once.  Callers that know n_cnv == 0 on the host skip the whole block (see lps_abi.hip).
     HIP_TRY(hipMemsetAsync(agg_sum, 0, (size_t)n_var * 2 * sizeof(long long), s));
     HIP_TRY(hipMemsetAsync(agg_cnt, 0, (size_t)n_var * 2 * sizeof(int32_t), s));
-    const int nb = (n_reads + CNV_BLOCK - 1) / CNV_BLOCK;
     hipLaunchKernelGGL(k_cnv_list, GRID(n_reads, 256), 0, s, cnt, n_reads, row_cnt, deleted, W.flag);
     exscan_u32(temp, temp_bytes, W.flag, W.idx, n_reads, s);
     hipLaunchKernelGGL(k_cnv_compact, GRID(n_reads, 256), 0, s, cnt, n_reads, W.flag, W.idx, W.list, W.n_list);
+    // entry half of every kept alignment = (composition of the transfer functions of the alignments before it)(half 0); at most n_reads entries are
+    // scanned - the tail beyond n_list holds the identity
     for (int pass4 = 0; pass4 < 2; ++pass4) {
-        if (pass4) hipLaunchKernelGGL(k_cnv_tables<true>, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, W.list, W.n_list, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss, W.tab);
-        else hipLaunchKernelGGL(k_cnv_tables<false>, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, W.list, W.n_list, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss, W.tab);
-        hipLaunchKernelGGL(k_cnv_block_compose, dim3(nb), dim3(64), 0, s, cnt, W.n_list, W.tab, W.btab);
-        hipLaunchKernelGGL(k_cnv_block_chain, dim3(1), dim3(64), 0, s, W.n_list, W.btab, W.bstart);
-        hipLaunchKernelGGL(k_cnv_entry, GRID(nb, 64), 0, s, W.n_list, W.tab, W.bstart, W.entry);
+        HIP_TRY(hipMemsetAsync(W.fn, 2, (size_t)n_reads, s));
+        if (pass4) hipLaunchKernelGGL(k_cnv_fn<true>, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss, W.fn);
+        else hipLaunchKernelGGL(k_cnv_fn<false>, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss, W.fn);
+        size_t need = temp_bytes;
+        HIP_TRY(rocprim::exclusive_scan(temp, need, W.fn, W.pre, (uint8_t)2, (size_t)n_reads, CnvCompose(), s));
         if (!pass4) {
-            hipLaunchKernelGGL(k_cnv_count, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, W.entry, row_off, row_cnt, obs_var, obs_aq, vpos, cnv_start, cnv_end, (unsigned long long *)agg_sum, agg_cnt);
+            hipLaunchKernelGGL(k_cnv_count, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, W.pre, row_off, row_cnt, obs_var, obs_aq, vpos, cnv_start, cnv_end, (unsigned long long *)agg_sum, agg_cnt);
             hipLaunchKernelGGL(k_cnv_miss, GRID(n_var, 256), 0, s, cnt, n_var, vpos, cnv_start, cnv_end, (const unsigned long long *)agg_sum, agg_cnt, miss);
         } else {
-            hipLaunchKernelGGL(k_cnv_erase, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, W.entry, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss);
+            hipLaunchKernelGGL(k_cnv_erase, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, W.pre, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss);
         }
     }
 }
@@ -1204,14 +1106,8 @@ void launch_clip_keys(const ClipView &C, const int32_t *row_fail, int n_reads, u
     if (n_reads) hipLaunchKernelGGL(k_clip_keys, GRID(n_reads, 256), 0, s, C, row_fail, n_reads, keys, cnt);
 }
 
-void launch_clip_cnv(unsigned n_clips, unsigned long long *keys,
-                     unsigned long long *keys_sorted, void *temp, size_t temp_bytes, int32_t *cnv_start, int32_t *cnv_end,
-                     unsigned *stats, LpsCounters *cnt, hipStream_t s) {
-    if (n_clips) {                                                      // stats: zero from the zero pool
-        sort_keys64(temp, temp_bytes, keys, keys_sorted, n_clips, 33, s);          // key = pos << 1 | front/back: 33 bits, 5 digit passes instead of 8
-        hipLaunchKernelGGL(k_clip_stats, GRID(n_clips, 256), 0, s, keys_sorted, n_clips, stats);
-    }
-    hipLaunchKernelGGL(k_cnv_state, dim3(1), dim3(64), 0, s, keys_sorted, n_clips, stats, cnv_start, cnv_end, cnt);
+void launch_clip_sort(unsigned n_clips, unsigned long long *keys, unsigned long long *keys_sorted, void *temp, size_t temp_bytes, hipStream_t s) {
+    if (n_clips) sort_keys64(temp, temp_bytes, keys, keys_sorted, n_clips, 33, s);          // key = pos << 1 | front/back: 33 bits, 5 digit passes instead of 8
 }
 
 void launch_name_keys(int n_reads, const uint32_t *name_id, const int32_t *row_cnt, unsigned long long *keys,

@@ -94,7 +94,8 @@ def load():
     L.lps_dump_votes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.lps_dump_clips.restype = C.c_int64
     L.lps_dump_clips.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
-    L.lps_dump_cnv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lps_dump_cnv.restype = C.c_int64
+    L.lps_dump_cnv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     _lib = L
     return L
 
@@ -296,10 +297,11 @@ class Context:
         return pos[:n], fb[:n]
 
     def dump_cnv(self):
-        s = np.zeros(64, np.int32)
-        e = np.zeros(64, np.int32)
+        n = int(self.L.lps_dump_cnv(self.h, None, None, 0, None))
+        s = np.zeros(max(n, 1), np.int32)
+        e = np.zeros(max(n, 1), np.int32)
         d = np.zeros(max(self.n_reads, 1), np.uint8)
-        n = self.L.lps_dump_cnv(self.h, s.ctypes.data, e.ctypes.data, d.ctypes.data)
+        self.L.lps_dump_cnv(self.h, s.ctypes.data, e.ctypes.data, n, d.ctypes.data)
         return s[:n], e[:n], d[:self.n_reads]
 
     def close(self):

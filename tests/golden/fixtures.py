@@ -20,6 +20,8 @@ PHASE_FIXTURES = {
     "supp_overlap": (dict(SMALL, seed=8, supp_frac=0.35, supp_overlap_frac=0.8), ["--ont"], {}),
     "cnv_pileup": (dict(SMALL, seed=9, contig_len=800_000, n_snp=1000, coverage=40.0, clip_pileups=2), ["--ont"], {}),
     "cnv_many": (dict(SMALL, seed=16, contig_len=2_000_000, n_snp=2400, coverage=45.0, clip_pileups=7, supp_frac=0.05), ["--ont"], {}),
+    # 80 simulated break points -> 64 distinct CNV intervals (128 entries in the reference's cnvVec): beyond the 32 the first GPU version could hold
+    "cnv_64": (dict(SMALL, seed=18, contig_len=5_000_000, n_snp=5000, coverage=35.0, clip_pileups=80, supp_frac=0.03), ["--ont"], {}),
     "sparse_cov": (dict(SMALL, seed=10, coverage=3.0), ["--ont"], {}),
     "dense_snps": (dict(SMALL, seed=11, n_snp=4000, snp_pair_frac=0.08, snp_in_hpoly_frac=0.3, hpoly_every=300.0), ["--ont"], {}),
     "params_a": (dict(SMALL, seed=12), ["--ont", "-a", "20", "-d", "50000", "-q", "20", "-p", "20", "-e", "0.3"],
