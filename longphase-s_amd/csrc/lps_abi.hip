@@ -27,7 +27,8 @@ enum { ST_PREP, ST_EXTRACT, ST_GROUPS, ST_GROUPS2, ST_OVERLAP, ST_CLIP, ST_CNV, 
 
 struct lps_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr;   // copy_stream: the sorted clip keys leave beside the late stages
+    hipEvent_t ev_sorted = nullptr;
     lps_params P{};
     std::string err;
     // variants
@@ -68,13 +69,14 @@ struct lps_ctx {
     uint8_t *h_res = nullptr; size_t h_res_bytes = 0;   // pinned landing zone of (phase_set, gt): one copy, then memcpy into the caller's arrays
     unsigned *h_ncnv = nullptr; LpsCounters *h_cnt_pin = nullptr; unsigned *h_stats_pin = nullptr; hipEvent_t ev_cnv = nullptr;   // pinned block + event: the counters reach the host while the GPU keeps working
     unsigned long long *h_clip_keys = nullptr; size_t h_clip_cap = 0; hipEvent_t ev_clip = nullptr;   // sorted clip keys on their way to the host (pinned): the CNV state machine is replayed there
+    int32_t *h_cnv_pin = nullptr; size_t h_cnv_pin_bytes = 0;
     std::vector<int32_t> h_cnv_start, h_cnv_end; bool cnv_expect = false; unsigned h_ub_hazard = 0;   // intervals of the current run (each once); cnv_expect: the previous run had intervals
     // groups
     DevBuf<unsigned long long> name_keys, name_keys_s;
     DevBuf<uint32_t> head, gidx, gstart, read_group, stack, mrow_off, koff; DevBuf<int32_t> mrow_cnt;
     // nodes / graph
     DevBuf<uint32_t> is_node, vtype_key, node_of, node_off, node_end, node_cur, multi_list, bsize, cnt4;
-    DevBuf<int32_t> nodes, block; DevBuf<uint8_t> ntype; DevBuf<unsigned long long> erec; DevBuf<unsigned> clip_stats; DevBuf<int8_t> hp, hp_v; DevBuf<int32_t> blk_v, seg_i32; DevBuf<char> st_b, st_e; DevBuf<uint32_t> node_pairs; DevBuf<uint8_t> nstate;
+    DevBuf<int32_t> nodes, block; DevBuf<uint8_t> ntype; DevBuf<uint8_t> erec; DevBuf<unsigned> clip_stats; DevBuf<int8_t> hp, hp_v; DevBuf<int32_t> blk_v, seg_i32; DevBuf<char> st_b, st_e; DevBuf<uint32_t> node_pairs; DevBuf<uint8_t> nstate;
     DevBuf<unsigned long long> nkeys, nkeys_s; DevBuf<uint32_t> nvals, nvals_s;
     DevBuf<float> edge;
     DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
@@ -170,7 +172,8 @@ lps_ctx *lps_create(int device, const lps_params *params) {
     try {
         c->device = device; c->P = *params;
         HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
         HIP_TRY(hipMalloc((void **)&c->d_cnt, sizeof(LpsCounters)));
         for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventCreate(&c->ev_begin)); HIP_TRY(hipEventCreate(&c->ev_end)); HIP_TRY(hipEventCreate(&c->ev_cnv)); HIP_TRY(hipEventCreate(&c->ev_clip));
@@ -191,10 +194,13 @@ void lps_destroy(lps_ctx *c) {
     if (c->ev_cnv) (void)hipEventDestroy(c->ev_cnv);
     if (c->ev_clip) (void)hipEventDestroy(c->ev_clip);
     if (c->h_clip_keys) (void)hipHostFree(c->h_clip_keys);
+    if (c->h_cnv_pin) (void)hipHostFree(c->h_cnv_pin);
     if (c->h_ncnv) (void)hipHostFree(c->h_ncnv);
     if (c->h_res) (void)hipHostFree(c->h_res);
     for (int k = 0; k < 2; ++k) { if (c->stage[k]) (void)hipHostFree(c->stage[k]); if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]); }
     if (c->d_cnt) (void)hipFree(c->d_cnt);
+    if (c->ev_sorted) (void)hipEventDestroy(c->ev_sorted);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -705,14 +711,14 @@ static int run_late(lps_ctx *c, bool with_cnv) {
         c->cnv_skipped = !with_cnv;
         if (with_cnv) {
             const size_t K = c->h_cnv_start.size();
-            c->cnv_start.reserve(2 * K + 2); c->cnv_end.reserve(2 * K + 2);
-            std::vector<int32_t> two(4 * K);                               // [start x2 | end x2]: every interval twice, as the reference's cnvVec holds them
+            const size_t need = (4 * K + 4) * sizeof(int32_t);             // pinned staging [n_cnv | start x2 | end x2]: every interval twice, as the reference's cnvVec holds them
+            if (need > c->h_cnv_pin_bytes) { if (c->h_cnv_pin) HIP_TRY(hipHostFree(c->h_cnv_pin)); c->h_cnv_pin = nullptr; c->h_cnv_pin_bytes = need * 2; HIP_TRY(hipHostMalloc((void **)&c->h_cnv_pin, c->h_cnv_pin_bytes)); }
+            int32_t *two = c->h_cnv_pin + 4;
+            c->h_cnv_pin[0] = (int32_t)(2 * K);
             for (size_t i = 0; i < K; ++i) { two[i] = two[K + i] = c->h_cnv_start[i]; two[2 * K + i] = two[3 * K + i] = c->h_cnv_end[i]; }
-            HIP_TRY(hipMemcpyAsync(c->cnv_start.p, two.data(), 2 * K * sizeof(int32_t), hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemcpyAsync(c->cnv_end.p, two.data() + 2 * K, 2 * K * sizeof(int32_t), hipMemcpyHostToDevice, s));
-            const unsigned nc = (unsigned)(2 * K);
-            HIP_TRY(hipMemcpyAsync(&c->d_cnt->n_cnv, &nc, sizeof nc, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));                              // `two` and `nc` are stack-owned
+            c->cnv_start.reserve(4 * K + 4); c->cnv_end.carve(c->cnv_start.p + 2 * K, 2 * K);
+            HIP_TRY(hipMemcpyAsync(c->cnv_start.p, two, 4 * K * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(&c->d_cnt->n_cnv, c->h_cnv_pin, sizeof(unsigned), hipMemcpyHostToDevice, s));
             c->agg_sum.reserve((size_t)nV * 2 + 2); c->agg_cnt.reserve((size_t)nV * 2 + 2); c->miss.reserve(nV + 1);
             c->cnv_flag.reserve(nR + 1); c->cnv_idx.reserve(nR + 1); c->cnv_list.reserve(nR + 1); c->cnv_nlist.reserve(4);
             c->cnv_fn.reserve(nR + 1); c->cnv_pre.reserve(nR + 1);
@@ -741,9 +747,7 @@ static int run_late(lps_ctx *c, bool with_cnv) {
         mark(c, ST_CORR);
         launch_correction(c->d_cnt, nR, nV, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->v_pos.p, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, c->node_pairs.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
         mark(c, ST_D2H);
-        HIP_TRY(hipMemcpyAsync(c->h_cnt_pin, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));      // read by lps_phase_chromosome after its sync
-        HIP_TRY(hipMemcpyAsync(c->h_stats_pin, c->clip_stats.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-        return 0;
+        return 0;                                                          // counters + statistics leave with the result (enqueue_result_copy)
     }
 }
 
@@ -771,7 +775,7 @@ static int run_phase(lps_ctx *c) {
         c->node_of.reserve(nV + 1); c->node_off.reserve(nV + 2); c->multi_list.reserve(nR + 1);
         c->nodes.reserve(nV + 1); c->block.reserve(nV + 1);
         c->ntype.reserve(nV + 1); c->hp.reserve(nV + 1);
-        c->erec.reserve((size_t)nV * A + 64);
+        c->erec.reserve((size_t)nV * A + 256);
         c->hp_v.reserve(2 * ((size_t)nV + 64)); c->blk_v.reserve(2 * ((size_t)nV + 64)); c->seg_i32.reserve(4 * (size_t)scan_segments(nV) + 4); c->node_pairs.reserve(nV + 1); c->nstate.reserve(nV + 1);
         c->st_b.reserve(scan_state_bytes(nV)); c->st_e.reserve(scan_state_bytes(nV)); c->edge.reserve((size_t)nV * A * 4 + 16);
         // everything that has to start a run as zeros sits in ONE allocation cleared by one fill (a dozen separate fills cost ~4 us each)
@@ -829,8 +833,10 @@ static int run_phase(lps_ctx *c) {
         launch_clip_sort(c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, s);
         const size_t nk = c->h_cnt.n_clips;
         if (nk > c->h_clip_cap) { if (c->h_clip_keys) HIP_TRY(hipHostFree(c->h_clip_keys)); c->h_clip_keys = nullptr; c->h_clip_cap = nk + nk / 2 + 1024; HIP_TRY(hipHostMalloc((void **)&c->h_clip_keys, c->h_clip_cap * sizeof(unsigned long long))); }
-        if (nk) HIP_TRY(hipMemcpyAsync(c->h_clip_keys, c->clip_keys_s.p, nk * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(c->ev_clip, s));
+        HIP_TRY(hipEventRecord(c->ev_sorted, s));
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_sorted, 0));      // the copy rides on its own stream: the late stages do not queue behind it
+        if (nk) HIP_TRY(hipMemcpyAsync(c->h_clip_keys, c->clip_keys_s.p, nk * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipEventRecord(c->ev_clip, c->copy_stream));
         c->late_n_keys = c->h_cnt.obs_total; c->late_cap_main = cap_main; c->late_tail = tail_size;
         c->h_ub_hazard = nk == 0 ? 1u : 0u;                               // reference: UB on an empty ClipCount (PhasingGraph.cpp:1134)
         // ---- everything after.  Usually the clips give no CNV interval, so the late stages are enqueued on that guess and the host replays the state
@@ -850,12 +856,18 @@ static int run_phase(lps_ctx *c) {
     return -5;
 }
 
-// out_ps and out_gt are neighbours in the zero pool: both leave in one copy into pinned memory (a copy into the caller's pageable arrays would be
-// staged by the runtime, twice, and block the host meanwhile)
+// out_ps and out_gt are neighbours in the zero pool: ONE kernel writes both, the counters and the scan statistics straight into pinned host memory
+// (coalesced 16-byte stores over PCIe) instead of three copies on the DMA queue, each with its fixed cost.
+__global__ void k_result_out(const uint4 *src, uint4 *dst, size_t n16, const LpsCounters *cnt, LpsCounters *cnt_out, const unsigned *stats, unsigned *stats_out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+    if (i == 0) { *cnt_out = *cnt; stats_out[0] = stats[0]; stats_out[1] = stats[1]; stats_out[2] = stats[2]; stats_out[3] = stats[3]; }
+}
 static size_t enqueue_result_copy(lps_ctx *c) {
     const size_t span = (size_t)((uint8_t *)c->out_gt.p - (uint8_t *)c->out_ps.p) + (size_t)c->nV;
-    if (span > c->h_res_bytes) { if (c->h_res) HIP_TRY(hipHostFree(c->h_res)); c->h_res = nullptr; c->h_res_bytes = span + span / 4 + 4096; HIP_TRY(hipHostMalloc((void **)&c->h_res, c->h_res_bytes)); }
-    HIP_TRY(hipMemcpyAsync(c->h_res, c->out_ps.p, span, hipMemcpyDeviceToHost, c->stream));
+    const size_t n16 = (span + 15) / 16;                                   // the zero pool's slots are padded to 256 bytes: the rounded span stays inside it
+    if (n16 * 16 > c->h_res_bytes) { if (c->h_res) HIP_TRY(hipHostFree(c->h_res)); c->h_res = nullptr; c->h_res_bytes = n16 * 16 + span / 4 + 4096; HIP_TRY(hipHostMalloc((void **)&c->h_res, c->h_res_bytes)); }
+    hipLaunchKernelGGL(k_result_out, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, (const uint4 *)c->out_ps.p, (uint4 *)c->h_res, n16, c->d_cnt, c->h_cnt_pin, c->clip_stats.p, c->h_stats_pin);
     return span;
 }
 static void deliver_result(lps_ctx *c, lps_phase_result *out) {
@@ -920,7 +932,7 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         // algorithmic bytes (SURVEY.md §8d closed forms)
         t.algorithmic_bytes[ST_EXTRACT] = 36ll * c->nR + 4ll * (int64_t)c->n_cig + (int64_t)c->h_cnt.n_obs_final * (1 + 1 + 12 + 8);
         t.algorithmic_bytes[ST_EDGES] = 8ll * (int64_t)c->h_cnt.n_pairs + 8ll * (int64_t)c->h_cnt.n_obs_final + 16ll * c->P.connect_adjacent * (int64_t)c->h_cnt.n_nodes;
-        t.algorithmic_bytes[ST_SCAN] = (16ll * c->P.connect_adjacent + 64) * (int64_t)c->h_cnt.n_nodes;
+        t.algorithmic_bytes[ST_SCAN] = (16ll * c->P.connect_adjacent + 64) * (int64_t)c->h_cnt.n_nodes;   // SURVEY.md 8d closed form (the edge matrix); the kernels read 1 B per cell
         t.algorithmic_bytes[ST_CORR] = 16ll * (int64_t)c->h_cnt.n_obs_final + 32ll * (int64_t)c->h_cnt.n_nodes;
         t.n_scan_segments = c->h_cnt.n_nodes ? scan_segments((int)c->h_cnt.n_nodes) - 1 : 0; t.n_scan_replayed = c->h_stats[2];
         c->phase_valid = true;

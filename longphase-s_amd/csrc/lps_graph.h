@@ -38,10 +38,10 @@ void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t 
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
                   const unsigned long long *ukeys, const uint32_t *uvals, unsigned long long *skeys, uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                   int m_bits, int a_bits, const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
-                  double edge_threshold, const uint8_t *ntype, float *edge, unsigned long long *erec, uint32_t *node_pairs, hipStream_t s);
+                  double edge_threshold, const uint8_t *ntype, float *edge, uint8_t *erec, uint32_t *node_pairs, hipStream_t s);
 size_t scan_state_bytes(int n_var);
 int scan_segments(int n_var);
-void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, const int32_t *vpos, const unsigned long long *erec,
+void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, const int32_t *vpos, const uint8_t *erec,
                       int A, int distance, int8_t *hp_v, int32_t *blk_v, void *st_b, void *st_e, int32_t *seg_i32,
                       unsigned *n_replayed, int8_t *hp, int32_t *block, hipStream_t s);
 void launch_correction(LpsCounters *cnt, int n_reads, int n_var, const uint32_t *row_off, const int32_t *g_cnt,

@@ -137,6 +137,13 @@ __global__ void k_overlap_filter(const unsigned long long *skeys, const uint32_t
     }
 }
 
+// ---- rows by sub-wave groups.  A row holds ~20-30 observations, so a 64-lane wave per row runs with a third of its lanes; the per-row passes below
+// give every row a group of ROW_G lanes instead (two rows per wave): the same instruction stream serves two rows.
+#define ROW_G 32
+#define ROWS_PER_WAVE (64 / ROW_G)
+#define ROWS_PER_BLOCK (4 * ROWS_PER_WAVE)
+__device__ __forceinline__ unsigned long long group_ballot(bool pred, int grp) { return (__ballot(pred) >> (grp * ROW_G)) & ((ROW_G == 64) ? ~0ull : ((1ull << ROW_G) - 1ull)); }
+
 // ================================================================================================ CNV filter
 // The four CNV mismatch-rate passes (PhasingGraph.cpp:520-692).  The reference carries ONE interval cursor from read to read (and, in the last
 // pass, from observation to observation) over an interval list that holds every interval twice (getCNVInterval runs twice): cs = [s_0..s_(K-1),
@@ -160,6 +167,13 @@ __device__ __forceinline__ int cnv_entry(const int32_t *cs, int K, int h, int rs
     return A == 0 ? 0 : h * K + A - 1;
 }
 
+// where the reference's forward scan (`i = ci; while (i < nc && cs[i] <= re) ++i;`) ends, given U = number of first-half starts <= re: inside the
+// first half it stops at the first start beyond re; when every start is <= re it runs on through the whole second half
+__device__ __forceinline__ int cnv_walk_end(int ci, int K, int U) {
+    if (ci < K) return U < K ? max(ci, U) : 2 * K;
+    return max(ci, K + U);
+}
+
 // kept alignments in BAM order -> dense list (reads with observations that survived the overlap filter)
 __global__ void k_cnv_list(const LpsCounters *cnt, int n_reads, const int32_t *row_cnt, const uint8_t *deleted, uint32_t *flag) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -175,33 +189,100 @@ __global__ void k_cnv_compact(const LpsCounters *cnt, int n_reads, const uint32_
 
 // thread per kept alignment: its transfer function on the cursor's half, bit h = half of the cursor it hands on when entered in half h.
 // PASS4 = false: calculateCnvMismatchRate / aggregateCnvReadMismatchRate (same cursor walk); PASS4 = true: filterHighMismatchVariants.
-template <bool PASS4>
-__global__ void k_cnv_fn(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint32_t *row_off, const int32_t *row_cnt,
-                         const int32_t *obs_var, const int32_t *vpos, const int32_t *cs, const int32_t *ce, const double *miss, uint8_t *fn) {
+// thread per kept alignment: transfer function of passes 1/2 (calculateCnvMismatchRate / aggregateCnvReadMismatchRate walk the cursor alike)
+__global__ void k_cnv_fn12(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint32_t *row_off, const int32_t *row_cnt,
+                           const int32_t *obs_var, const int32_t *vpos, const int32_t *cs, uint8_t *fn) {
     const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= *n_list) return;
     const int nc = (int)cnt->n_cnv, K = nc / 2;
     const uint32_t r = list[k]; const uint32_t off = row_off[r]; const int n = row_cnt[r];
-    const int rs = vpos[obs_var[off]];
+    const int rs = vpos[obs_var[off]], re = vpos[obs_var[off + n - 1]];
+    const int A0 = cnv_ub(cs, K, rs), U0 = cnv_ub(cs, K, re);
     unsigned f = 0;
     for (int h = 0; h < 2; ++h) {
-        int ci = cnv_entry(cs, K, h, rs);
-        if (!PASS4) {
-            const int re = vpos[obs_var[off + n - 1]];
-            int i = ci; while (i < nc && cs[i] <= re) ++i;
-            ci = i > 0 ? i - 1 : 0;
-        } else {
-            for (int q = 0; q < n; ++q) {
-                const int v = obs_var[off + q]; const int p = vpos[v];
-                int i = ci;
-                while (i < nc && cs[i] <= p) { if (p >= cs[i] && p <= ce[i] && miss[v] >= 0.7) break; ++i; }
-                ci = i > 0 ? i - 1 : 0;
-            }
-        }
-        f |= (unsigned)(ci >= K) << h;
+        const int ci = A0 == 0 ? 0 : h * K + A0 - 1;         // cnv_entry
+        const int i = cnv_walk_end(ci, K, U0);
+        f |= (unsigned)((i > 0 ? i - 1 : 0) >= K) << h;
     }
     fn[k] = (uint8_t)f;
 }
+
+// One observation of filterHighMismatchVariants' scan (`i = ci; while (i < nc && cs[i] <= p) { if (p in [cs[i], ce[i]] && rate >= 0.7) break; ++i; }
+// ci = i > 0 ? i - 1 : 0`) without touching the interval list: U = number of first-half starts <= p, j = index of the interval that holds p
+// (-1: none), hot = rate >= 0.7.  cs[i] <= p holds exactly for the indices i < U of the first half and K <= i < K + U of the second.
+__device__ __forceinline__ int cnv_obs_step(int ci, int K, int U, int j, bool hot, bool *erased) {
+    const bool can = hot && j >= 0;
+    int i; bool brk = false;
+    if (ci < K) {
+        if (ci >= U) i = ci;
+        else if (can && j >= ci) { i = j; brk = true; }
+        else if (U < K) i = U;
+        else if (can) { i = K + j; brk = true; }             // every start is <= p: the scan runs on into the second half
+        else i = 2 * K;
+    } else {
+        const int a = ci - K;
+        if (a >= U) i = ci;
+        else if (can && j >= a) { i = K + j; brk = true; }
+        else i = K + U;
+    }
+    *erased = brk;
+    return i > 0 ? i - 1 : 0;
+}
+
+// filterHighMismatchVariants, a lane group per kept alignment.  ERASE = false: the alignment's transfer function on the cursor's half (both halves
+// simulated); ERASE = true: the erasures, from the known entry half.  The group's lanes load the row's positions and mismatch rates side by side
+// (a lane walking its row alone is one chain of dependent misses, ~3 per observation); rows without an observation that can stop the scan
+// (rate >= 0.7) - nearly all - move the cursor exactly like passes 1/2 and erase nothing; the others replay the reference's loop on the
+// loaded values.
+template <bool ERASE>
+__global__ __launch_bounds__(256) void k_cnv_rows(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *pre, const uint32_t *row_off,
+                                                  const int32_t *row_cnt, int32_t *obs_var, const int32_t *vpos, const int32_t *cs, const int32_t *ce,
+                                                  const double *miss, uint8_t *fn) {
+    const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
+    const unsigned k = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
+    if (k >= *n_list) return;
+    const int nc = (int)cnt->n_cnv, K = nc / 2;
+    const uint32_t r = list[k]; const uint32_t off = row_off[r]; const int n = row_cnt[r];
+    const int rs = vpos[obs_var[off]], re = vpos[obs_var[off + n - 1]];
+    const int A0 = cnv_ub(cs, K, rs), U0 = cnv_ub(cs, K, re);
+    const bool touch = U0 > A0 || (A0 > 0 && ce[A0 - 1] >= rs);          // an interval intersects the row
+    int c0 = A0 == 0 ? 0 : A0 - 1, c1 = A0 == 0 ? 0 : K + A0 - 1;        // cnv_entry of half 0 / half 1
+    if (ERASE) { c0 = (pre[k] & 1) ? c1 : c0; }
+    bool any_hot = false;
+    if (touch) {
+        for (int q0 = 0; q0 < n; q0 += ROW_G) {
+            const int q = q0 + sl;
+            int v = -1, p = 0; bool hot = false;
+            if (q < n) { v = obs_var[off + q]; p = vpos[v]; hot = miss[v] >= 0.7; }
+            const unsigned long long hm = group_ballot(hot, grp);
+            if (hm == 0ull && !any_hot) continue;                        // nothing can stop the scan yet: the cursor is brought up when it first matters (below)
+            if (!any_hot && q0 > 0) {                                    // first hot chunk: bring the cursor(s) up to the end of the chunk before it
+                const int pp = vpos[obs_var[off + q0 - 1]]; const int Up = cnv_ub(cs, K, pp);
+                int i = cnv_walk_end(c0, K, Up); c0 = i > 0 ? i - 1 : 0;
+                if (!ERASE) { i = cnv_walk_end(c1, K, Up); c1 = i > 0 ? i - 1 : 0; }
+            }
+            any_hot = true;
+            // per observation, side by side: how many intervals start at or before it, and which one holds it
+            int Uq = 0, jq = -1;
+            if (q < n) { Uq = cnv_ub(cs, K, p); if (Uq > 0 && p <= ce[Uq - 1]) jq = Uq - 1; }
+            const int m = min(ROW_G, n - q0);
+            bool mine = false;                                           // this lane's observation is erased
+            for (int t = 0; t < m; ++t) {                                // the reference's scan, one observation after the other, on the loaded values
+                const int src = grp * ROW_G + t;
+                const int Ut = __shfl(Uq, src), jt = __shfl(jq, src); const bool ht = (hm >> t) & 1ull;
+                bool e0, e1;
+                c0 = cnv_obs_step(c0, K, Ut, jt, ht, &e0);
+                if (!ERASE) c1 = cnv_obs_step(c1, K, Ut, jt, ht, &e1);
+                if (ERASE && e0 && sl == t) mine = true;
+            }
+            if (ERASE && mine) obs_var[off + q] = -1 - v;
+        }
+    }
+    if (ERASE) return;
+    if (!any_hot) { int i = cnv_walk_end(c0, K, U0); c0 = i > 0 ? i - 1 : 0; i = cnv_walk_end(c1, K, U0); c1 = i > 0 ? i - 1 : 0; }   // (from the first hot chunk on every observation was replayed)
+    if (sl == 0) fn[k] = (uint8_t)((unsigned)(c0 >= K) | ((unsigned)(c1 >= K) << 1));
+}
+
 struct CnvCompose {   // (a then b): bit h of the result = b(a(h)); identity 0b10
     __host__ __device__ uint8_t operator()(uint8_t a, uint8_t b) const { return (uint8_t)(((b >> (a & 1)) & 1) | (((b >> ((a >> 1) & 1)) & 1) << 1)); }
 };
@@ -217,20 +298,27 @@ __global__ void k_cnv_count(const LpsCounters *cnt, const uint32_t *list, const 
     const int nc = (int)cnt->n_cnv, K = nc / 2;
     const uint32_t r = list[k]; const uint32_t off = row_off[r]; const int n = row_cnt[r];
     const int rs = vpos[obs_var[off]], re = vpos[obs_var[off + n - 1]];
-    const int ci = cnv_entry(cs, K, pre[k] & 1, rs);
-    int i_end = ci; while (i_end < nc && cs[i_end] <= re) ++i_end;
-    for (int i = ci; i < i_end; ++i) {
-        const int j = i % K; const int s0 = cs[j], e0 = ce[j];
+    const int A0 = cnv_ub(cs, K, rs), U0 = cnv_ub(cs, K, re);
+    const int ci = A0 == 0 ? 0 : (pre[k] & 1) * K + A0 - 1;            // cnv_entry
+    const int i_end = cnv_walk_end(ci, K, U0);
+    // intervals that can hold an observation of this read: those that start at or before re and do not end before rs
+    for (int j = max(0, A0 - 1); j < U0; ++j) {
+        const int s0 = cs[j], e0 = ce[j];
         if (e0 < rs) continue;
-        int alt = 0;
-        for (int q = 0; q < n; ++q) { const int p = vpos[obs_var[off + q]]; if (p > e0) break; if (p >= s0 && aq_allele(obs_aq[off + q]) == 1) ++alt; }
-        if (!alt) continue;
         const int visits = (j >= ci && j < min(i_end, K) ? 1 : 0) + (K + j >= max(ci, K) && K + j < i_end ? 1 : 0);
+        if (!visits) continue;
+        // observations inside [s0, e0]: a range of the position-sorted row, found by two searches; the loops over it have no data-dependent exit,
+        // so their loads overlap (a row walked with an early exit is one chain of dependent misses)
+        int qa = 0, qb = n;
+        { int lo = 0, hi = n; while (lo < hi) { const int m = (lo + hi) >> 1; if (vpos[obs_var[off + m]] < s0) lo = m + 1; else hi = m; } qa = lo; }
+        { int lo = qa, hi = n; while (lo < hi) { const int m = (lo + hi) >> 1; if (vpos[obs_var[off + m]] <= e0) lo = m + 1; else hi = m; } qb = lo; }
+        int alt = 0;
+        for (int q = qa; q < qb; ++q) alt += aq_allele(obs_aq[off + q]);
+        if (!alt) continue;
         const unsigned long long mm = (unsigned long long)alt * (unsigned long long)visits;
-        for (int q = 0; q < n; ++q) {
-            const int v = obs_var[off + q]; const int p = vpos[v];
-            if (p > e0) break;
-            if (p >= s0) { const int al = aq_allele(obs_aq[off + q]); atomicAdd(&agg_sum[(size_t)v * 2 + al], mm); atomicAdd(&agg_cnt[(size_t)v * 2 + al], 1); }
+        for (int q = qa; q < qb; ++q) {
+            const int v = obs_var[off + q]; const int al = aq_allele(obs_aq[off + q]);
+            atomicAdd(&agg_sum[(size_t)v * 2 + al], mm * (unsigned long long)visits); atomicAdd(&agg_cnt[(size_t)v * 2 + al], visits);
         }
     }
 }
@@ -254,34 +342,19 @@ __global__ void k_cnv_miss(const LpsCounters *cnt, int n_var, const int32_t *vpo
     miss[v] = m;
 }
 
-// thread per kept alignment: filterHighMismatchVariants with the known entry half
-__global__ void k_cnv_erase(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *pre, const uint32_t *row_off,
-                            const int32_t *row_cnt, int32_t *obs_var, const int32_t *vpos, const int32_t *cs, const int32_t *ce, const double *miss) {
-    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= *n_list) return;
-    const int nc = (int)cnt->n_cnv, K = nc / 2;
-    const uint32_t r = list[k]; const uint32_t off = row_off[r]; const int n = row_cnt[r];
-    int ci = cnv_entry(cs, K, pre[k] & 1, vpos[obs_var[off]]);
-    for (int q = 0; q < n; ++q) {
-        const int v = obs_var[off + q]; const int p = vpos[v];
-        int i = ci;
-        while (i < nc && cs[i] <= p) { if (p >= cs[i] && p <= ce[i] && miss[v] >= 0.7) { obs_var[off + q] = -1 - v; break; } ++i; }
-        ci = i > 0 ? i - 1 : 0;
-    }
-}
-
 // ================================================================================================ nodes
 // wave per alignment: mark observed variants as graph nodes, record the type written by the LAST alignment
 // (BAM order) that observes the position - the reference's (*variantType)[pos] = ... is last-writer-wins.
 __global__ __launch_bounds__(256) void k_mark_nodes(int n_reads, const uint32_t *row_off, const int32_t *row_cnt,
                                                     const uint8_t *deleted, const int32_t *obs_var, const uint16_t *obs_aq,
                                                     uint32_t *is_node, uint32_t *vtype_key) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
+    const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
+    const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
     if (r >= n_reads) return;
     const int n = row_cnt[r];
     if (n <= 0 || deleted[r]) return;
     const uint32_t off = row_off[r];
-    for (int k = l; k < n; k += 64) {
+    for (int k = sl; k < n; k += ROW_G) {
         const int v = obs_var[off + k]; const int q = aq_quality(obs_aq[off + k]);
         if (v < 0) continue;                                  // erased by the CNV filter
         const unsigned ty = (q == -4) ? 3u : (q == -5 ? 4u : 0u);
@@ -298,7 +371,7 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const uint32_t *
                                                    const uint32_t *node_of, int base_quality, int32_t *g_node, uint8_t *g_flag,
                                                    int32_t *g_cnt, LpsCounters *cnt, int n_var, const uint32_t *is_node, const uint32_t *vtype_key,
                                                    int32_t *nodes, uint8_t *ntype, uint32_t *node_cnt) {
-    const int nb_reads = (n_reads + 3) / 4;
+    const int nb_reads = (n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     if ((int)blockIdx.x >= nb_reads) {                                  // the workgroups after the alignments': node list (variant index, type) and node count
         const int v = ((int)blockIdx.x - nb_reads) * blockDim.x + threadIdx.x;
         if (v < n_var) {
@@ -307,22 +380,23 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const uint32_t *
         }
         return;
     }
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
+    const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
+    const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
     if (r >= n_reads) return;
     const int n = row_cnt[r];
-    if (n <= 0 || deleted[r]) { if (l == 0) g_cnt[r] = 0; return; }
+    if (n <= 0 || deleted[r]) { if (sl == 0) g_cnt[r] = 0; return; }
     const uint32_t off = row_off[r];
-    // compact in place (CNV-erased entries have var = -1); rows are wave-private so a running count suffices
+    // compact in place (CNV-erased entries have var = -1); rows are private to their lane group so a running count suffices
     int w = 0;
-    for (int k0 = 0; k0 < n; k0 += 64) {
-        const int k = k0 + l;
+    for (int k0 = 0; k0 < n; k0 += ROW_G) {
+        const int k = k0 + sl;
         int v = -1; uint16_t aq = 0;
         if (k < n) { v = obs_var[off + k]; aq = obs_aq[off + k]; }
         const bool ok = v >= 0;
-        const unsigned long long m = __ballot(ok);
+        const unsigned long long m = group_ballot(ok, grp);
         if (ok) {
             int q = aq_quality(aq); if (q < 0) q = 60;          // indel sentinels -> quality 60 (:820-828)
-            const uint32_t slot = off + w + __popcll(m & lanemask_lt());
+            const uint32_t slot = off + w + __popcll(m & ((1ull << sl) - 1ull));
             const uint32_t nd = node_of[v];
             g_node[slot] = (int32_t)nd;
             g_flag[slot] = (uint8_t)(aq_allele(aq) | ((q >= base_quality) ? 2 : 0));
@@ -330,7 +404,7 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const uint32_t *
         }
         w += __popcll(m);
     }
-    if (l == 0) g_cnt[r] = w;
+    if (sl == 0) g_cnt[r] = w;
 }
 
 // ================================================================================================ merged rows
@@ -533,13 +607,14 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
 __global__ __launch_bounds__(256) void k_node_scatter(const LpsCounters *cnt, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                                                       const int32_t *g_node, const uint32_t *node_off, uint32_t *node_cur, int a_bits,
                                                       unsigned long long *keys, uint32_t *vals, LpsCounters *cntw, int n_var) {
-    const unsigned g = blockIdx.x * 4 + (threadIdx.x >> 6); const int l = lane_id();
-    if (g == 0 && l == 0) cntw->n_obs_final = node_off[n_var];         // sum of merged rows = end of the last node's list
+    const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
+    const unsigned g = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
+    if (g == 0 && sl == 0) cntw->n_obs_final = node_off[n_var];         // sum of merged rows = end of the last node's list
     if (g >= cnt->n_groups) return;
     const int n = mrow_cnt[g];
-    if (n > (1 << a_bits)) { if (l == 0) atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); return; }
+    if (n > (1 << a_bits)) { if (sl == 0) atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); return; }
     const uint32_t off = mrow_off[g];
-    for (int a = l; a < n; a += 64) {
+    for (int a = sl; a < n; a += ROW_G) {
         const int nd = g_node[off + a];
         const uint32_t slot = node_off[nd] + atomicAdd(&node_cur[nd], 1u);
         keys[slot] = ((unsigned long long)g << a_bits) | (unsigned)a;      // (name rank, index in row)
@@ -560,7 +635,7 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
                                                unsigned long long *skeys, uint32_t *svals,
                                                const uint32_t *mrow_off, const int32_t *mrow_cnt, int m_bits, int a_bits,
                                                const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
-                                               double edge_threshold, const uint8_t *ntype, float *edge, unsigned long long *erec, uint32_t *node_pairs) {
+                                               double edge_threshold, const uint8_t *ntype, float *edge, uint8_t *erec, uint32_t *node_pairs) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
     const int n_nodes = (int)cnt->n_nodes;
     if (i >= n_nodes) return;
@@ -647,8 +722,8 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
     if (l < A) {
         reinterpret_cast<float4 *>(edge)[(size_t)i * A + l] = make_float4(a0, a1, a2, a3);
         // findBestEdgePair (:166-228) + the weight rules of edgeConnectResult (:216,:367) and Onelongcase (:261-265):
-        // everything that does not depend on the scan state is folded into one 8-byte vote record per (i,k):
-        //   .x = weight as float (0 = not connected / no such node), .y = flags: bit0 different haplotype,
+        // everything that does not depend on the scan state is folded into one vote BYTE per (i,k) (a 64-node tile of the scan is 2.2 KB of LDS):
+        //   bits 3-4 = weight code (0 not connected / no such node, 1: 0.1, 2: 1, 3: 20), bit0 different haplotype,
         //   bit1 single-read vote (para+cross <= 1), bit2 counts towards the Onelongcase sums
         const float rr = a0, ra = a1, ar = a2, aa = a3;
         const float para = rr + aa, cross = ra + ar;
@@ -664,7 +739,8 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
         const bool osum = !single && lowesr && w >= 1.f && typ != 3;
         if (dir == 0 || i + 1 + l >= n_nodes) w = 0.f;
         const unsigned fl = (dir == 2 ? 1u : 0u) | (single ? 2u : 0u) | (osum ? 4u : 0u);
-        reinterpret_cast<uint2 *>(erec)[(size_t)i * A + l] = make_uint2(__float_as_uint(w), w != 0.f ? fl : 0u);
+        const unsigned wc = w == 0.f ? 0u : (typ == 4 ? 1u : (w20 ? 3u : 2u));
+        erec[(size_t)i * A + l] = (uint8_t)(wc ? ((wc << 3) | fl) : 0u);
     }
 }
 
@@ -703,7 +779,9 @@ __device__ __forceinline__ void chain_init(Chain &c, int force2) {
 }
 
 // one node of edgeConnectResult (:306-418) for one chain.  s = owner lane of node i, rec = this lane's vote record.
-__device__ __forceinline__ void chain_step(Chain &c, int i, int s, int l, bool gap, unsigned long long rec) {
+__device__ __forceinline__ float vote_weight(unsigned rec) { const unsigned wc = (rec >> 3) & 3u; return wc == 3u ? 20.f : (wc == 2u ? 1.f : (wc == 1u ? 0.1f : 0.f)); }
+
+__device__ __forceinline__ void chain_step(Chain &c, int i, int s, int l, bool gap, unsigned rec) {
     // Onelongcase override (:276), tie -> new block (:338), else argmax (:349)
     const bool use_sp = (c.vc > 3) && !(c.o1 == 0.f && c.o2 == 0.f);
     const float c1 = use_sp ? c.o1 : c.h1, c2 = use_sp ? c.o2 : c.h2;
@@ -715,8 +793,8 @@ __device__ __forceinline__ void chain_step(Chain &c, int i, int s, int l, bool g
     else if (code_s == 0) { c.bs = i; hp_i = c.force2 ? 2 : 1; c.force2 = 0; }
     if (l == s) { c.my_hp = hp_i; c.my_blk = skip ? -1 : c.bs; c.h1 = c.h2 = c.o1 = c.o2 = 0.f; c.vc = 0; }
     if (!skip) {
-        const float w = __uint_as_float((unsigned)rec);
-        const unsigned fl = (unsigned)(rec >> 32);
+        const float w = vote_weight(rec);
+        const unsigned fl = rec & 7u;
         const bool to2 = ((fl & 1u) != 0) != (hp_i == 2);                                   // target haplotype 2
         const float wo = (fl & 4u) ? w : 0.f;
         c.h1 += to2 ? 0.f : w; c.h2 += to2 ? w : 0.f;
@@ -734,7 +812,7 @@ __device__ __forceinline__ void chain_step(Chain &c, int i, int s, int l, bool g
 // chain_step without branches: the speculative walk steps TWO chains per node, and only straight-line code lets their instructions interleave
 // (a lone wave is bound by the latency of each dependent instruction, not by issue slots).  Same arithmetic: a skipped node adds +0.f / 0,
 // which leaves sums of non-negative weights bit-identical.
-__device__ __forceinline__ void chain_step_flat(Chain &c, int i, int s, int l, bool gap, unsigned long long rec) {
+__device__ __forceinline__ void chain_step_flat(Chain &c, int i, int s, int l, bool gap, unsigned rec) {
     const bool use_sp = (c.vc > 3) && !(c.o1 == 0.f && c.o2 == 0.f);
     const float c1 = use_sp ? c.o1 : c.h1, c2 = use_sp ? c.o2 : c.h2;
     const int code = (c1 == c2) ? 0 : (c1 > c2 ? 1 : 2);
@@ -748,8 +826,8 @@ __device__ __forceinline__ void chain_step_flat(Chain &c, int i, int s, int l, b
     const bool own = l == s;
     c.my_hp = own ? hp_i : c.my_hp; c.my_blk = own ? (skip ? -1 : c.bs) : c.my_blk;
     c.h1 = own ? 0.f : c.h1; c.h2 = own ? 0.f : c.h2; c.o1 = own ? 0.f : c.o1; c.o2 = own ? 0.f : c.o2; c.vc = own ? 0 : c.vc;
-    const float w = skip ? 0.f : __uint_as_float((unsigned)rec);
-    const unsigned fl = skip ? 0u : (unsigned)(rec >> 32);
+    const float w = skip ? 0.f : vote_weight(rec);
+    const unsigned fl = skip ? 0u : (rec & 7u);
     const bool to2 = ((fl & 1u) != 0) != (hp_i == 2);                                       // target haplotype 2
     const float wo = (fl & 4u) ? w : 0.f;
     c.h1 += to2 ? 0.f : w; c.h2 += to2 ? w : 0.f;
@@ -788,56 +866,51 @@ __device__ __forceinline__ unsigned long long tile_gapmask(const int32_t *nodes,
     return __ballot((n_me + 1 < N) ? (abs(my_next - my_pos) > distance) : true);
 }
 
-// speculative walk of segment blockIdx.x: two label variants interleaved; wave 1 of the workgroup streams the vote
-// records of the next 64-node tile global->LDS while wave 0 walks the current one.
-__global__ __launch_bounds__(128) void k_scan_spec(const LpsCounters *cnt, const int32_t *nodes, const int32_t *vpos,
-                                                   const unsigned long long *erec, int A, int distance,
-                                                   int8_t *hp_v /*[2][N]*/, int32_t *blk_v /*[2][N]*/, size_t vstride,
-                                                   ScanState *st_b /*[seg][2]*/, ScanState *st_e /*[seg][2]*/) {
-    extern __shared__ unsigned long long s_rec_dyn[];              // [2][SCAN_TILE * A]: sized by the A in use, so that all segments are resident at once
-    const int rec_stride = SCAN_TILE * A;                           // (pointers derived by arithmetic from the LDS array: an array of pointers would make the reads flat loads)
-    const int l = lane_id(), wv = threadIdx.x >> 6;
+// speculative walk of segment blockIdx.x by ONE wave, two label variants interleaved.  The vote bytes of the whole walk range (warm-up + segment,
+// 2 x 2.2 KB at A = 35) are staged in LDS up front: with one byte per record every segment of a chromosome is resident at once (32 per CU).
+__global__ __launch_bounds__(64) void k_scan_spec(const LpsCounters *cnt, const int32_t *nodes, const int32_t *vpos,
+                                                  const uint8_t *erec, int A, int distance,
+                                                  int8_t *hp_v /*[2][N]*/, int32_t *blk_v /*[2][N]*/, size_t vstride,
+                                                  ScanState *st_b /*[seg][2]*/, ScanState *st_e /*[seg][2]*/) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_rec_dyn[];   // [(SCAN_WARM + SCAN_SEG) * A]
+    const int l = lane_id();
     const int N = (int)cnt->n_nodes;
     const int seg = blockIdx.x;
     const int b = seg * SCAN_SEG;
-    if (b >= N) return;                                             // whole workgroup leaves together
+    if (b >= N) return;
     const int a = max(0, b - SCAN_WARM), e = b + SCAN_SEG;          // walk [a, e); results for [b, e)
     const int last = min(e, N - 1);                                 // the last node of a contig is never processed (:308-311)
-    const int tile_recs = SCAN_TILE * A;
-    auto load_tile = [&](int t0, unsigned long long *dst) {
-        const long long base = (long long)t0 * A, lim = (long long)N * A;
-        for (int q = l; q < tile_recs; q += 64) dst[q] = (base + q < lim) ? erec[base + q] : 0ull;
-    };
-    if (wv == 1) load_tile(a, s_rec_dyn);
-    __syncthreads();
-    Chain c0, c1; chain_init(c0, 0); chain_init(c1, 1);
-    for (int t0 = a, buf = 0; t0 < e; t0 += SCAN_TILE, buf ^= 1) {
-        if (wv == 1) {
-            if (t0 + SCAN_TILE < e && t0 + SCAN_TILE < N) load_tile(t0 + SCAN_TILE, s_rec_dyn + (buf ^ 1) * rec_stride);
-        } else {
-            if (t0 == b) { state_save(c0, &st_b[seg * 2 + 0], l, b); state_save(c1, &st_b[seg * 2 + 1], l, b); }
-            const unsigned long long gapmask = tile_gapmask(nodes, vpos, t0, N, distance, l);
-            const unsigned long long *rec = s_rec_dyn + buf * rec_stride;
-            const int tend = min(SCAN_TILE, last - t0);
-            int s = 0, k = (l - 1) & 63;                             // tiles are 64-aligned: owner lane of node t0+j is j
-            unsigned long long cur = (tend > 0 && k < A) ? rec[k] : 0ull;
-            c0.my_hp = c1.my_hp = 0; c0.my_blk = c1.my_blk = -1;
-            for (int j = 0; j < tend; ++j) {
-                const int kn = (k - 1) & 63;                         // prefetch the record of node i+1
-                const unsigned long long nxt = (j + 1 < tend && kn < A) ? rec[(j + 1) * A + kn] : 0ull;
-                const bool gap = (gapmask >> j) & 1ull;
-                chain_step_flat(c0, t0 + j, s, l, gap, cur);
-                chain_step_flat(c1, t0 + j, s, l, gap, cur);
-                cur = nxt; k = kn; s = (s + 1) & 63;
-            }
-            if (t0 >= b && t0 + l < N) {                             // coalesced result store of the tile (both variants)
-                hp_v[t0 + l] = (int8_t)c0.my_hp; blk_v[t0 + l] = c0.my_blk;
-                hp_v[vstride + t0 + l] = (int8_t)c1.my_hp; blk_v[vstride + t0 + l] = c1.my_blk;
-            }
-        }
-        __syncthreads();
+    {
+        // a and e are multiples of 64, so the byte range [a * A, e * A) starts and ends on a 4-byte boundary
+        const long long base = (long long)a * A, lim = (long long)N * A;
+        const int n_words = (e - a) * A / 4;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(erec + base); uint32_t *dst = reinterpret_cast<uint32_t *>(s_rec_dyn);
+        for (int q = l; q < n_words; q += 64) dst[q] = (base + 4ll * q < lim) ? src[q] : 0u;          // (bytes past N * A lie inside the allocation and belong to no node)
     }
-    if (wv == 0) { state_save(c0, &st_e[seg * 2 + 0], l, e); state_save(c1, &st_e[seg * 2 + 1], l, e); }
+    wave_sync();
+    Chain c0, c1; chain_init(c0, 0); chain_init(c1, 1);
+    for (int t0 = a; t0 < e; t0 += SCAN_TILE) {
+        if (t0 == b) { state_save(c0, &st_b[seg * 2 + 0], l, b); state_save(c1, &st_b[seg * 2 + 1], l, b); }
+        const unsigned long long gapmask = tile_gapmask(nodes, vpos, t0, N, distance, l);
+        const uint8_t *rec = s_rec_dyn + (size_t)(t0 - a) * A;
+        const int tend = min(SCAN_TILE, last - t0);
+        int s = 0, k = (l - 1) & 63;                             // tiles are 64-aligned: owner lane of node t0+j is j
+        unsigned cur = (tend > 0 && k < A) ? rec[k] : 0u;
+        c0.my_hp = c1.my_hp = 0; c0.my_blk = c1.my_blk = -1;
+        for (int j = 0; j < tend; ++j) {
+            const int kn = (k - 1) & 63;                         // prefetch the record of node i+1
+            const unsigned nxt = (j + 1 < tend && kn < A) ? rec[(j + 1) * A + kn] : 0u;
+            const bool gap = (gapmask >> j) & 1ull;
+            chain_step_flat(c0, t0 + j, s, l, gap, cur);
+            chain_step_flat(c1, t0 + j, s, l, gap, cur);
+            cur = nxt; k = kn; s = (s + 1) & 63;
+        }
+        if (t0 >= b && t0 + l < N) {                             // coalesced result store of the tile (both variants)
+            hp_v[t0 + l] = (int8_t)c0.my_hp; blk_v[t0 + l] = c0.my_blk;
+            hp_v[vstride + t0 + l] = (int8_t)c1.my_hp; blk_v[vstride + t0 + l] = c1.my_blk;
+        }
+    }
+    state_save(c0, &st_e[seg * 2 + 0], l, e); state_save(c1, &st_e[seg * 2 + 1], l, e);
 }
 
 // wave per segment boundary: is the state a variant of segment seg-1 ends with bit-identical to the state a variant of
@@ -867,7 +940,7 @@ __global__ __launch_bounds__(256) void k_scan_match(const LpsCounters *cnt, cons
 // has no matching variant on the true path does the wave fall back to walking the segments in order, replaying that segment serially from
 // the true state (records straight from global memory) and comparing states live until the walk is back on stored states.
 __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, const int32_t *nodes, const int32_t *vpos,
-                                                    const unsigned long long *erec, int A, int distance,
+                                                    const uint8_t *erec, int A, int distance,
                                                     int8_t *hp_v, int32_t *blk_v, size_t vstride,
                                                     const ScanState *st_b, const ScanState *st_e, const int32_t *match,
                                                     int32_t *chosen /*[seg]*/, int32_t *remap_from, int32_t *remap_to, unsigned *n_replayed) {
@@ -934,7 +1007,7 @@ __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, cons
                 t.my_hp = 0; t.my_blk = -1;
                 for (int j = 0; j < tend; ++j) {
                     const int i = t0 + j, k = (l - j - 1) & 63;
-                    const unsigned long long rec = (k < A) ? erec[(size_t)i * A + k] : 0ull;
+                    const unsigned rec = (k < A) ? erec[(size_t)i * A + k] : 0u;
                     chain_step(t, i, j, l, (gapmask >> j) & 1ull, rec);
                 }
                 if (t0 + l < N) { hp_v[t0 + l] = (int8_t)t.my_hp; blk_v[t0 + l] = t.my_blk; }
@@ -994,22 +1067,23 @@ __global__ void k_node_state(const LpsCounters *cnt, const int32_t *block, const
 // order (doubles), so the result is bit-identical either way.
 __global__ __launch_bounds__(256) void k_read_correction(int n_reads, const uint32_t *row_off, const int32_t *g_cnt, const int32_t *g_node,
                                                          const uint8_t *g_flag, const uint8_t *nstate, double read_confidence, uint32_t *cnt4) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
+    const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
+    const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
     if (r >= n_reads) return;
     const int n = g_cnt[r];
     if (n <= 0) return;
     const uint32_t off = row_off[r];
     int irc = 0, iac = 0; bool indel = false;
-    for (int k0 = 0; k0 < n; k0 += 64) {
-        const int k = k0 + l;
+    for (int k0 = 0; k0 < n; k0 += ROW_G) {
+        const int k = k0 + sl;
         int st = 0, al = 0;
         if (k < n) { st = nstate[g_node[off + k]]; al = g_flag[off + k] & 1; }
         const bool live = (st & 16) != 0;
         const int ty = (st >> 1) & 7;
         const int h = al ^ (st & 1);                          // 0: haplotype 1, 1: haplotype 2
-        irc += __popcll(__ballot(live && ty <= 1 && h == 0));
-        iac += __popcll(__ballot(live && ty <= 1 && h == 1));
-        indel |= __ballot(live && ty >= 3) != 0;
+        irc += __popcll(group_ballot(live && ty <= 1 && h == 0, grp));
+        iac += __popcll(group_ballot(live && ty <= 1 && h == 1, grp));
+        indel |= group_ballot(live && ty >= 3, grp) != 0;
     }
     double rc = irc, ac = iac;
     if (indel) {                                              // exact order of the reference's double sums
@@ -1024,7 +1098,7 @@ __global__ __launch_bounds__(256) void k_read_correction(int n_reads, const uint
     }
     if (fmax(rc, ac) / (rc + ac) > read_confidence && (rc + ac) > 1) {
         const int bh = (rc > ac) ? 0 : 1;
-        for (int k = l; k < n; k += 64) atomicAdd(&cnt4[(size_t)g_node[off + k] * 4 + bh * 2 + (g_flag[off + k] & 1)], 1u);
+        for (int k = sl; k < n; k += ROW_G) atomicAdd(&cnt4[(size_t)g_node[off + k] * 4 + bh * 2 + (g_flag[off + k] & 1)], 1u);
     }
 }
 
@@ -1087,17 +1161,18 @@ void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const uin
     hipLaunchKernelGGL(k_cnv_compact, GRID(n_reads, 256), 0, s, cnt, n_reads, W.flag, W.idx, W.list, W.n_list);
     // entry half of every kept alignment = (composition of the transfer functions of the alignments before it)(half 0); at most n_reads entries are
     // scanned - the tail beyond n_list holds the identity
+    const unsigned row_grid = (unsigned)((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     for (int pass4 = 0; pass4 < 2; ++pass4) {
         HIP_TRY(hipMemsetAsync(W.fn, 2, (size_t)n_reads, s));
-        if (pass4) hipLaunchKernelGGL(k_cnv_fn<true>, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss, W.fn);
-        else hipLaunchKernelGGL(k_cnv_fn<false>, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss, W.fn);
+        if (pass4) hipLaunchKernelGGL(k_cnv_rows<false>, dim3(row_grid), dim3(256), 0, s, cnt, W.list, W.n_list, W.pre, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss, W.fn);
+        else hipLaunchKernelGGL(k_cnv_fn12, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, row_off, row_cnt, obs_var, vpos, cnv_start, W.fn);
         size_t need = temp_bytes;
         HIP_TRY(rocprim::exclusive_scan(temp, need, W.fn, W.pre, (uint8_t)2, (size_t)n_reads, CnvCompose(), s));
         if (!pass4) {
             hipLaunchKernelGGL(k_cnv_count, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, W.pre, row_off, row_cnt, obs_var, obs_aq, vpos, cnv_start, cnv_end, (unsigned long long *)agg_sum, agg_cnt);
             hipLaunchKernelGGL(k_cnv_miss, GRID(n_var, 256), 0, s, cnt, n_var, vpos, cnv_start, cnv_end, (const unsigned long long *)agg_sum, agg_cnt, miss);
         } else {
-            hipLaunchKernelGGL(k_cnv_erase, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, W.pre, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss);
+            hipLaunchKernelGGL(k_cnv_rows<true>, dim3(row_grid), dim3(256), 0, s, cnt, W.list, W.n_list, W.pre, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss, W.fn);
         }
     }
 }
@@ -1132,9 +1207,9 @@ void launch_nodes(int n_reads, int n_var, const uint32_t *row_off, const int32_t
                   const int32_t *obs_var, const uint16_t *obs_aq, uint32_t *is_node, uint32_t *vtype_key, uint32_t *node_of,
                   int32_t *nodes, uint8_t *ntype, int base_quality, int32_t *g_node, uint8_t *g_flag, int32_t *g_cnt,
                   LpsCounters *cnt, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(k_mark_nodes, dim3((n_reads + 3) / 4), dim3(256), 0, s, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, is_node, vtype_key);
+    hipLaunchKernelGGL(k_mark_nodes, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, is_node, vtype_key);
     exscan_u32(temp, temp_bytes, is_node, node_of, n_var, s);
-    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + 3) / 4 + (n_var + 255) / 256), dim3(256), 0, s, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, node_of, base_quality, g_node, g_flag, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype, node_cnt);
+    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK + (n_var + 255) / 256), dim3(256), 0, s, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, node_of, base_quality, g_node, g_flag, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype, node_cnt);
 }
 
 void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
@@ -1150,7 +1225,7 @@ void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t 
                        uint32_t *node_off, uint32_t *node_cnt, uint32_t *node_cur, void *temp, size_t temp_bytes, hipStream_t s) {
     (void)koff;                                                         // node_cnt was filled by k_graph_obs
     exscan_u32(temp, temp_bytes, node_cnt, node_off, (size_t)n_var + 1, s);
-    hipLaunchKernelGGL(k_node_scatter, dim3((n_reads + 3) / 4), dim3(256), 0, s, cnt, mrow_off, mrow_cnt, g_node, node_off, node_cur, a_bits, keys, vals, cnt, n_var);
+    hipLaunchKernelGGL(k_node_scatter, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, cnt, mrow_off, mrow_cnt, g_node, node_off, node_cur, a_bits, keys, vals, cnt, n_var);
     (void)keys_sorted; (void)vals_sorted;
     (void)m_bits; (void)n_bits; (void)n_keys;
 }
@@ -1158,7 +1233,7 @@ void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t 
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
                   const unsigned long long *ukeys, const uint32_t *uvals, unsigned long long *skeys, uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                   int m_bits, int a_bits, const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
-                  double edge_threshold, const uint8_t *ntype, float *edge, unsigned long long *erec, uint32_t *node_pairs, hipStream_t s) {
+                  double edge_threshold, const uint8_t *ntype, float *edge, uint8_t *erec, uint32_t *node_pairs, hipStream_t s) {
     hipLaunchKernelGGL(k_edges, dim3((n_var + 3) / 4), dim3(256), 0, s, cnt, node_off, node_end, ukeys, uvals, skeys, svals, mrow_off, mrow_cnt, m_bits, a_bits, g_node, g_flag, A, edge_weight, edge_threshold, ntype, edge, erec, node_pairs);
 }
 
@@ -1171,12 +1246,12 @@ __global__ void k_scan_break_matches(int32_t *match, int segs, int every) {
     if (i > 0 && i < segs && i % every == 1 % every) match[i] = 0;
 }
 
-void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, const int32_t *vpos, const unsigned long long *erec,
+void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, const int32_t *vpos, const uint8_t *erec,
                       int A, int distance, int8_t *hp_v, int32_t *blk_v, void *st_b, void *st_e, int32_t *seg_i32 /*4*segs*/,
                       unsigned *n_replayed, int8_t *hp, int32_t *block, hipStream_t s) {
     const int segs = scan_segments(n_var);
     const size_t vstride = (size_t)n_var + 64;
-    hipLaunchKernelGGL(k_scan_spec, dim3(segs), dim3(128), (size_t)2 * SCAN_TILE * A * sizeof(unsigned long long), s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (ScanState *)st_b, (ScanState *)st_e);
+    hipLaunchKernelGGL(k_scan_spec, dim3(segs), dim3(64), (size_t)(SCAN_WARM + SCAN_SEG) * A, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (ScanState *)st_b, (ScanState *)st_e);
     hipLaunchKernelGGL(k_scan_match, dim3((segs + 3) / 4), dim3(256), 0, s, cnt, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs);
     if (const char *e = getenv("LPS_SCAN_FORCE_REPLAY")) { const int every = atoi(e); if (every > 0) hipLaunchKernelGGL(k_scan_break_matches, GRID(segs, 256), 0, s, seg_i32 + 3 * segs, segs, every); }
     hipLaunchKernelGGL(k_scan_stitch, dim3(1), dim3(64), 0, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, n_replayed);
@@ -1189,6 +1264,6 @@ void launch_correction(LpsCounters *cnt, int n_reads, int n_var, const uint32_t 
                        uint8_t *nstate, double read_conf, double snp_conf, uint32_t *cnt4, int32_t *out_ps, uint8_t *out_gt, hipStream_t s) {
     hipLaunchKernelGGL(k_block_size, GRID(n_var, 256), 0, s, cnt, block, node_pairs, bsize, nstate, hp, ntype);
     hipLaunchKernelGGL(k_node_state, GRID(n_var, 256), 0, s, cnt, block, bsize, nstate);
-    hipLaunchKernelGGL(k_read_correction, dim3((n_reads + 3) / 4), dim3(256), 0, s, n_reads, row_off, g_cnt, g_node, g_flag, nstate, read_conf, cnt4);
+    hipLaunchKernelGGL(k_read_correction, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, n_reads, row_off, g_cnt, g_node, g_flag, nstate, read_conf, cnt4);
     hipLaunchKernelGGL(k_final, GRID(n_var, 256), 0, s, cnt, nodes, vpos, block, bsize, cnt4, snp_conf, out_ps, out_gt);
 }

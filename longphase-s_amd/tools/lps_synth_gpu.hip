@@ -175,12 +175,12 @@ __device__ inline int molecule_alignments(const DevParams &P, long long i, Aln *
     long long span = (long long)len; if (span > P.L - start) span = P.L - start;
     const int hap = (int)(h3 & 1);
     int force_front = 0, force_back = 0;
-    for (int k = 0; k < P.n_pile; ++k) {                                     // snap molecules that cross a simulated break point
-        const long long a = (long long)(((double)k + 0.3) * (double)P.L / (double)P.n_pile), b = a + 60000 + (long long)(hsh(P.s_mol ^ 0x77, (uint64_t)k) % 40000);
+    for (int k = 0; k < P.n_pile; ++k) {                                     // snap molecules that cross a simulated break point: front clips pile up at a, back clips at b
+        const long long a = (long long)(((double)k + 0.3) * (double)P.L / (double)P.n_pile), b = a + 8000 + (long long)(hsh(P.s_mol ^ 0x77, (uint64_t)k) % 12000);
         if (b >= P.L - 1000) continue;
         const double u = u01(hsh(P.s_mol ^ 0x99, (uint64_t)i * 64 + k));
         if (start < a && start + span > a + 2000 && u < 0.5) { span -= a - start; start = a; force_front = 1; }
-        else if (start < b - 2000 && start + span > b && u < 0.5) { span = b - start; force_back = 1; }
+        else if (start < b - 2000 && start + span > b && u < 0.5) { start += (b - start) % BLK; span = b - start; force_back = 1; }   // whole blocks up to b: the clip sits exactly there
     }
     const int nb = (int)(span / BLK);
     if (nb < 4) return 0;

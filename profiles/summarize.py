@@ -25,13 +25,14 @@ def short(name):
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
+    wl = sys.argv[3] if len(sys.argv) > 3 else "chr1_50x"
     os.makedirs(dst, exist_ok=True)
     stats = find(os.path.join(src, "stats"), "*kernel_stats.csv")
     rows = list(csv.DictReader(open(stats)))
     with open(os.path.join(dst, "kernel_stats.csv"), "w") as f:
         f.write(open(stats).read())
     with open(os.path.join(dst, "kernel_stats.md"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline (MI355X)\n\n| kernel | calls | avg us | total % |\n|---|---|---|---|\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --parity none --steps 10 --warmup 2 --no-cpu-baseline (MI355X)" % wl + "\n\n| kernel | calls | avg us | total % |\n|---|---|---|---|\n")
         for r in rows[:40]:
             f.write("| `%s` | %s | %.1f | %s |\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
     per = {}
@@ -47,16 +48,16 @@ def main():
         for k, (tot, n) in acc.items():
             per.setdefault(k, {})[what + "_kb"] = tot / n
             per[k]["launches_" + what] = n
-    out = {"chr20_30x": {}, "_detail": {}, "_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 5 --warmup 1), "
+    out = {wl: {}, "_detail": {}, "_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 5 --warmup 1), "
            "average per launch; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads) - an upper estimate for "
            "gather-heavy kernels, raw values kept in _detail"}
     for k, v in per.items():
         fk, wk = v.get("fetch_kb", 0.0), v.get("write_kb", 0.0)
         v["hbm_bytes_raw"] = int((fk + wk) * 1024); v["hbm_bytes_fetch_x2"] = int((2 * fk + wk) * 1024)
         out["_detail"][k] = v
-        out["chr20_30x"][STAGE_OF[k]] = v["hbm_bytes_fetch_x2"]
+        out[wl][STAGE_OF[k]] = v["hbm_bytes_fetch_x2"]
     json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-    print(json.dumps(out["chr20_30x"]))
+    print(json.dumps(out[wl]))
 
 
 if __name__ == "__main__":

@@ -73,6 +73,22 @@ def test_contig_160mb_50x_every_stage_device_push():
         check_haplotag(ctx, P, V, out, h.ref, R, "160 Mb 50x")
 
 
+def test_chr20_30x_with_clip_pile_ups_cnv_filter_active():
+    """configs[1] with 50 simulated break points: clip pile-ups give CNV intervals (replayed on the host), the late stages run with the CNV
+    mismatch filter; the second call takes the path that waits for the intervals instead of guessing "none"."""
+    g = SynthGpu(0, clip_pileups=50, **CHR20_30X)
+    h = g.to_host(); g.close()
+    V = abi.Variants.from_snps(h.var_pos, h.var_ref0, h.var_alt0); R = abi.Reads.from_synth(h)
+    P = abi.default_params()
+    want, d = lps_oracle.phase(P, V, h.ref, R, dump=True)
+    assert d.c.ub_hazard == 0 and d.c.n_cnv >= 40, d.c.n_cnv
+    with hip.Context(0, P) as ctx:
+        for call in range(2):
+            out = ctx.phase(V, h.ref, R) if call == 0 else ctx.run_phase()
+            util.assert_stages_equal(ctx, d, f"chr20_30x pile-ups, call {call}")
+            util.assert_phase_equal(out.phase_set, out.gt, want.phase_set, want.gt, f"chr20_30x pile-ups, call {call}")
+
+
 def test_device_push_rejects_bad_operands():
     """lps_push_reads_device runs the operand checks of lps_push_reads as a kernel."""
     g = SynthGpu(0, seed=5, contig_len=400_000, n_snp=400, coverage=8.0)
