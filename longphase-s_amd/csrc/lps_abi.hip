@@ -51,8 +51,8 @@ struct lps_ctx {
     DevBuf<uint8_t> dz_slots, dz_packed; DevBuf<uint32_t> dz_bytes; DevBuf<unsigned long long> dz_tmp; DevBuf<uint64_t> dz_off; uint64_t dz_total = 0; float dz_ms = 0;
     DevBuf<uint64_t> rcand; uint64_t n_rec_all = 0; DevBuf<int32_t> r_tid_all; DevBuf<uint32_t> r_lname, r_nameoff, wg_cnt, wg_off, scan_nout; DevBuf<uint8_t> names_d; bool names_ready = false;
     // observations
-    DevBuf<uint32_t> row_off; DevBuf<int32_t> row_cnt, row_fail, g_cnt; DevBuf<uint8_t> row_flags, deleted;
-    DevBuf<int32_t> obs_var, g_node; DevBuf<uint16_t> obs_aq; DevBuf<uint8_t> g_flag;
+    DevBuf<RowDesc> rows; DevBuf<int32_t> g_cnt; DevBuf<uint8_t> deleted;
+    DevBuf<ObsRec> obs; DevBuf<int32_t> g_node; DevBuf<uint8_t> g_flag; DevBuf<uint32_t> redo_list;
     unsigned long long obs_capacity = 0;   // main arenas (LPS_ARENAS equal parts); a tail arena of obs_capacity/4 follows
     DevBuf<unsigned long long> arena_ctr;
     bool in_phase = false; int timing_level = 1;
@@ -61,7 +61,7 @@ struct lps_ctx {
     DevBuf<uint8_t> hap_pool;     // per-read outputs of the scoring kernels, carved like zpool
     DevBuf<uint8_t> zpool;        // the zero-initialised arrays of a phase run (arena_ctr, out_ps/gt, deleted, is_node, vtype_key, mrow_cnt, node_end/cur, bsize, cnt4) are carved from it
     // clips / cnv
-    DevBuf<int32_t> clip_pos, clip_op; size_t clip_capacity = 0;
+    DevBuf<ClipEv> clip_ev; size_t clip_capacity = 0;
     DevBuf<unsigned long long> clip_keys, clip_keys_s;
     DevBuf<int32_t> cnv_start, cnv_end;
     DevBuf<long long> agg_sum; DevBuf<int32_t> agg_cnt; DevBuf<double> miss;
@@ -723,14 +723,14 @@ static int run_late(lps_ctx *c, bool with_cnv) {
             c->cnv_flag.reserve(nR + 1); c->cnv_idx.reserve(nR + 1); c->cnv_list.reserve(nR + 1); c->cnv_nlist.reserve(4);
             c->cnv_fn.reserve(nR + 1); c->cnv_pre.reserve(nR + 1);
             CnvScratch W{c->cnv_flag.p, c->cnv_idx.p, c->cnv_list.p, c->cnv_nlist.p, c->cnv_fn.p, c->cnv_pre.p};
-            launch_cnv_filter(c->d_cnt, nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->v_pos.p, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, W, c->temp.p, c->temp_bytes, s);
+            launch_cnv_filter(c->d_cnt, nR, nV, c->rows.p, c->deleted.p, c->obs.p, c->v_pos.p, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, W, c->temp.p, c->temp_bytes, s);
         }
         // ---- a10 nodes + graph observations
         mark(c, ST_NODES);
-        launch_nodes(nR, nV, c->row_off.p, c->row_cnt.p, c->deleted.p, c->obs_var.p, c->obs_aq.p, c->is_node.p, c->vtype_key.p, c->node_of.p, c->nodes.p, c->ntype.p, P.base_quality, c->g_node.p, c->g_flag.p, c->g_cnt.p, c->d_cnt, c->node_end.p, c->temp.p, c->temp_bytes, s);
+        launch_nodes(nR, nV, c->rows.p, c->deleted.p, c->obs.p, c->is_node.p, c->vtype_key.p, c->node_of.p, c->nodes.p, c->ntype.p, P.base_quality, c->g_node.p, c->g_flag.p, c->g_cnt.p, c->d_cnt, c->node_end.p, c->temp.p, c->temp_bytes, s);
         // ---- merged rows
         mark(c, ST_MERGE);
-        launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->late_cap_main, c->late_tail, c->mrow_off.p, c->mrow_cnt.p, c->multi_list.p, s);
+        launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->rows.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->late_cap_main, c->late_tail, c->mrow_off.p, c->mrow_cnt.p, c->multi_list.p, s);
         // ---- node-major sorted lists
         mark(c, ST_NODELISTS);
         c->m_bits = bits_for((unsigned long long)nR + 1); c->n_bits = bits_for((unsigned long long)nV + 2); c->a_bits = 16;
@@ -745,7 +745,7 @@ static int run_late(lps_ctx *c, bool with_cnv) {
         launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->v_pos.p, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2, c->hp.p, c->block.p, s);
         // ---- a14/a15 read correction + export
         mark(c, ST_CORR);
-        launch_correction(c->d_cnt, nR, nV, c->row_off.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->v_pos.p, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, c->node_pairs.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
+        launch_correction(c->d_cnt, nR, nV, c->rows.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->v_pos.p, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, c->node_pairs.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
         mark(c, ST_D2H);
         return 0;                                                          // counters + statistics leave with the result (enqueue_result_copy)
     }
@@ -763,11 +763,11 @@ static int run_phase(lps_ctx *c) {
         const unsigned long long cap_main = c->obs_capacity, arena_size = cap_main / n_arenas, tail_size = cap_main / 4 + 4096;
         const unsigned long long cap = cap_main + tail_size;
         if (cap > 0xffffffffull) { c->err = "observation arena exceeds 2^32 slots"; return -8; }
-        c->row_off.reserve(nR + 1); c->row_cnt.reserve(nR + 1); c->row_fail.reserve(nR + 1); c->row_flags.reserve(nR + 1);
+        c->rows.reserve(nR + 4); c->redo_list.reserve((size_t)nR / 4 + 4);
         c->g_cnt.reserve(nR + 1);
-        c->obs_var.reserve(cap); c->obs_aq.reserve(cap); c->g_node.reserve(cap); c->g_flag.reserve(cap);
-        c->clip_capacity = (size_t)LPS_CLIP_SLOTS * nR + 64;
-        c->clip_pos.reserve(c->clip_capacity); c->clip_op.reserve(c->clip_capacity);
+        c->obs.reserve(cap); c->g_node.reserve(cap); c->g_flag.reserve(cap);
+        c->clip_capacity = (size_t)4 * nR + 64;                             // clip events (an alignment has two real clips at most; more only with H S ... S H)
+        c->clip_ev.reserve(c->clip_capacity);
         c->clip_keys.reserve(c->clip_capacity); c->clip_keys_s.reserve(c->clip_capacity);
         c->name_keys.reserve(nR + 1); c->name_keys_s.reserve(nR + 1);
         c->head.reserve(nR + 1); c->gidx.reserve(nR + 1); c->gstart.reserve(nR + 2); c->read_group.reserve(nR + 1); c->stack.reserve(nR + 1);
@@ -804,14 +804,14 @@ static int run_phase(lps_ctx *c) {
         mark(c, ST_PREP);
         launch_variant_prep(V, P.is_ont, c->v_bucket.p, c->v_rec.p, s);
         // ---- a1/a2/a3 extraction
-        ObsView O{c->row_off.p, c->row_cnt.p, c->row_fail.p, c->row_flags.p, c->obs_var.p, c->obs_aq.p, arena_size, c->arena_ctr.p, n_arenas};
-        ClipView C{c->clip_pos.p, c->clip_op.p};
+        ObsView O{c->rows.p, c->obs.p, arena_size, c->arena_ctr.p, n_arenas};
+        ClipView C{c->clip_ev.p, c->clip_stats.p, (unsigned)c->clip_capacity};            // clip_stats[0]: events appended, [1]: waves queued for k_extract_redo (zero pool)
         mark(c, ST_EXTRACT);
-        launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, s);
+        launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, c->redo_list.p, c->clip_stats.p + 1, s);
         // ---- name keys (needs only row_cnt) and clip keys; the counters (sizes of the sorts, errors) start their way to the host ...
         mark(c, ST_GROUPS);
-        launch_name_keys(nR, c->r_name.p, c->row_cnt.p, c->name_keys.p, c->d_cnt, c->arena_ctr.p, arena_size, s);
-        launch_clip_keys(C, c->row_fail.p, nR, c->clip_keys.p, c->d_cnt, s);
+        launch_name_keys(nR, c->r_name.p, c->rows.p, c->name_keys.p, c->d_cnt, c->arena_ctr.p, arena_size, s);
+        launch_clip_keys(C, c->rows.p, nR, c->clip_keys.p, c->d_cnt, s);
         HIP_TRY(hipMemcpyAsync(c->h_cnt_pin, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(c->ev_cnv, s));
         // ---- ... while the GPU sorts the names into groups and runs the overlap filter (a8): no bubble when the host looks at them
@@ -822,7 +822,7 @@ static int run_phase(lps_ctx *c) {
         sort_keys64_range(c->temp.p, c->temp_bytes, c->name_keys.p, c->name_keys_s.p, nR, 32, 32 + bits_for((unsigned long long)c->name_max + 2), s);
         launch_groups(c->name_keys_s.p, nR, c->d_cnt, c->head.p, c->gidx.p, c->gstart.p, c->read_group.p, c->temp.p, c->temp_bytes, s);
         mark(c, ST_OVERLAP);
-        launch_overlap_filter(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->row_off.p, c->row_cnt.p, c->obs_var.p, c->v_pos.p, P.overlap_threshold, c->stack.p, c->deleted.p, s);
+        launch_overlap_filter(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->rows.p, c->obs.p, c->v_pos.p, P.overlap_threshold, c->stack.p, c->deleted.p, s);
         HIP_TRY(hipEventSynchronize(c->ev_cnv));
         c->h_cnt = *c->h_cnt_pin;
         if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) { c->err = "alignment find unsupported CIGAR operation"; return -2; }
@@ -1189,16 +1189,17 @@ int64_t lps_dump_observations(lps_ctx *c, int32_t *obs_count, int32_t *var_index
     if (!c || !c->phase_valid) return -1;
     try {
         HIP_TRY(hipSetDevice(c->device));
-        auto off = download(c, c->row_off.p, c->nR); auto cntv = download(c, c->row_cnt.p, c->nR);
+        auto rows = download(c, c->rows.p, c->nR);
         const size_t tot = (size_t)(c->obs_capacity + c->obs_capacity / 4 + 4096);   // rows are scattered over the arenas
-        auto var = download(c, c->obs_var.p, tot); auto aq = download(c, c->obs_aq.p, tot);
+        auto obs = download(c, c->obs.p, tot);
         int64_t n = 0;
         for (int r = 0; r < c->nR; ++r) {
-            if (obs_count) obs_count[r] = cntv[r];
-            for (int k = 0; k < cntv[r]; ++k, ++n) {
+            if (obs_count) obs_count[r] = rows[r].cnt;
+            for (int k = 0; k < rows[r].cnt; ++k, ++n) {
                 if (var_index && n < capacity) {
-                    int v = var[off[r] + k]; if (v < 0) v = -1 - v;       // erased later by the CNV filter
-                    var_index[n] = v; allele[n] = (int8_t)aq_allele(aq[off[r] + k]); quality[n] = (int16_t)aq_quality(aq[off[r] + k]);
+                    const ObsRec &o = obs[rows[r].off + k];
+                    int v = o.var; if (v < 0) v = -1 - v;       // erased later by the CNV filter
+                    var_index[n] = v; allele[n] = (int8_t)aq_allele((uint16_t)o.aq); quality[n] = (int16_t)aq_quality((uint16_t)o.aq);
                 }
             }
         }

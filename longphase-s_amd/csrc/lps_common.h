@@ -170,6 +170,5 @@ __host__ __device__ __forceinline__ uint16_t pack_aq(int allele, int quality) { 
 __host__ __device__ __forceinline__ int aq_allele(uint16_t aq) { return (aq >> 9) & 1; }
 __host__ __device__ __forceinline__ int aq_quality(uint16_t aq) { return (int)(aq & 0x1ff) - 8; }
 
-#define LPS_CLIP_SLOTS 4        // clip ops per alignment (H S ... S H); more is reported as an error
 #define LPS_SEG 512           // CIGAR ops staged in LDS per wave and segment (4 KB/wave)
 #define LPS_BUCKET_SHIFT 10    // coarse position index: bucket b = first variant with pos >= b << shift

@@ -23,35 +23,34 @@
 #include <cstdlib>
 
 // ================================================================================================ clips / CNV
-// thread per clip slot: keep events of ops before the op at which get_snp returned early (:1453-1455,1559-1561),
-// compact them (one atomic per workgroup) into sort keys (pos << 1 | front/back).
-__global__ __launch_bounds__(256) void k_clip_keys(ClipView C, const int32_t *row_fail, int n_reads, unsigned long long *keys,
-                                                   LpsCounters *cnt) {
-    // thread per alignment (its LPS_CLIP_SLOTS slots), ONE atomic per workgroup: same-word atomics are served one after the other
+// thread per clip event (grid-stride over the list the extraction appended): keep events of ops before the op at which get_snp returned early
+// (:1453-1455,1559-1561), compact them (one atomic per workgroup) into sort keys (pos << 1 | front/back).
+__global__ __launch_bounds__(256) void k_clip_keys(ClipView C, const RowDesc *rows, unsigned long long *keys, LpsCounters *cnt) {
     __shared__ unsigned s_wcnt[4], s_base;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned n_ev = min(*C.n_ev, C.capacity);
     const int w = threadIdx.x >> 6;
-    unsigned long long key[LPS_CLIP_SLOTS]; int n = 0;
-    if (r < n_reads) {
-        const int4 of4 = reinterpret_cast<const int4 *>(C.opidx_fb)[r], ps4 = reinterpret_cast<const int4 *>(C.pos)[r];
-        const int of[4] = {of4.x, of4.y, of4.z, of4.w}, ps[4] = {ps4.x, ps4.y, ps4.z, ps4.w};
-        const int rf = row_fail[r];
-#pragma unroll
-        for (int k = 0; k < LPS_CLIP_SLOTS; ++k)
-            if (of[k] >= 0 && (of[k] >> 1) < rf) { key[n] = ((unsigned long long)(unsigned)ps[k] << 1) | (unsigned)(of[k] & 1); ++n; }
+    for (unsigned base = blockIdx.x * blockDim.x; base < n_ev; base += gridDim.x * blockDim.x) {     // uniform per workgroup
+        const unsigned e = base + threadIdx.x;
+        bool keep = false; unsigned long long key = 0;
+        if (e < n_ev) {
+            const ClipEv ev = C.ev[e];
+            keep = (ev.opidx_fb >> 1) < rows[ev.read].fail;
+            key = ((unsigned long long)(unsigned)ev.pos << 1) | (unsigned)(ev.opidx_fb & 1);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane_id() == 0) s_wcnt[w] = (unsigned)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) { const unsigned tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]; s_base = tot ? atomicAdd(&cnt->n_clips, tot) : 0u; }
+        __syncthreads();
+        unsigned off = s_base + (unsigned)__popcll(m & lanemask_lt()); for (int q = 0; q < w; ++q) off += s_wcnt[q];
+        if (keep) keys[off] = key;
+        __syncthreads();
     }
-    const int incl = wave_incl_scan_dpp(n);
-    if (lane_id() == 63) s_wcnt[w] = (unsigned)incl;
-    __syncthreads();
-    if (threadIdx.x == 0) { const unsigned tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]; s_base = tot ? atomicAdd(&cnt->n_clips, tot) : 0u; }
-    __syncthreads();
-    unsigned off = s_base + (unsigned)(incl - n); for (int q = 0; q < w; ++q) off += s_wcnt[q];
-#pragma unroll
-    for (int k = 0; k < LPS_CLIP_SLOTS; ++k) if (k < n) keys[off + k] = key[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *C.n_ev > C.capacity) atomicOr(&cnt->err, (unsigned)LPS_ERR_CLIP_OVERFLOW);
 }
 
 // ================================================================================================ name groups
-__global__ __launch_bounds__(256) void k_name_keys(int n_reads, const uint32_t *name_id, const int32_t *row_cnt, unsigned long long *keys,
+__global__ __launch_bounds__(256) void k_name_keys(int n_reads, const uint32_t *name_id, const RowDesc *rows, unsigned long long *keys,
                                                    LpsCounters *cnt, const unsigned long long *arena_ctr, unsigned long long arena_size) {
     __shared__ unsigned s_cnt[4];
     if (blockIdx.x == gridDim.x - 1) {                                  // one extra workgroup: observation slots reserved by the extraction, over the arenas
@@ -68,7 +67,7 @@ __global__ __launch_bounds__(256) void k_name_keys(int n_reads, const uint32_t *
         return;
     }
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool kept = r < n_reads && row_cnt[r] > 0;
+    const bool kept = r < n_reads && rows[r].cnt > 0;
     if (r < n_reads) keys[r] = kept ? ((unsigned long long)name_id[r] << 32 | (unsigned)r) : ~0ull;
     // one atomic per workgroup: atomics on ONE word are served one after the other (~11 ns each), 1 500 wave atomics were the kernel's whole duration
     const unsigned long long m = __ballot(kept);
@@ -100,15 +99,15 @@ __global__ void k_group_starts(const unsigned long long *skeys, const uint32_t *
 // Overlap filter of several alignments of one read name: one thread replays the reference's sequential rule for
 // its group (groups with one alignment have nothing to do).  `stack` is scratch aligned with the sorted slots.
 __global__ void k_overlap_filter(const unsigned long long *skeys, const uint32_t *gstart, const LpsCounters *cnt,
-                                 const uint32_t *row_off, const int32_t *row_cnt, const int32_t *obs_var,
+                                 const RowDesc *rows, const ObsRec *obs,
                                  const int32_t *vpos, double overlap_threshold, uint32_t *stack, uint8_t *deleted) {
     const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= cnt->n_groups) return;
     const uint32_t s0 = gstart[g], s1 = gstart[g + 1];
     if (s1 - s0 < 2) return;
     uint32_t *kept = stack + s0; int nk = 0; int second = 0;
-    auto fpos = [&](uint32_t r) { return vpos[obs_var[row_off[r]]]; };
-    auto lpos = [&](uint32_t r) { return vpos[obs_var[row_off[r] + row_cnt[r] - 1]]; };
+    auto fpos = [&](uint32_t r) { return vpos[obs[rows[r].off].var]; };
+    auto lpos = [&](uint32_t r) { return vpos[obs[rows[r].off + rows[r].cnt - 1].var]; };
     for (uint32_t s = s0; s < s1; ++s) {
         const uint32_t r = (uint32_t)skeys[s];
         const int fp = fpos(r), lp = lpos(r);
@@ -175,10 +174,10 @@ __device__ __forceinline__ int cnv_walk_end(int ci, int K, int U) {
 }
 
 // kept alignments in BAM order -> dense list (reads with observations that survived the overlap filter)
-__global__ void k_cnv_list(const LpsCounters *cnt, int n_reads, const int32_t *row_cnt, const uint8_t *deleted, uint32_t *flag) {
+__global__ void k_cnv_list(const LpsCounters *cnt, int n_reads, const RowDesc *rows, const uint8_t *deleted, uint32_t *flag) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
-    flag[r] = (cnt->n_cnv != 0 && row_cnt[r] > 0 && !deleted[r]) ? 1u : 0u;
+    flag[r] = (cnt->n_cnv != 0 && rows[r].cnt > 0 && !deleted[r]) ? 1u : 0u;
 }
 __global__ void k_cnv_compact(const LpsCounters *cnt, int n_reads, const uint32_t *flag, const uint32_t *idx, uint32_t *list, uint32_t *n_list) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,13 +189,13 @@ __global__ void k_cnv_compact(const LpsCounters *cnt, int n_reads, const uint32_
 // thread per kept alignment: its transfer function on the cursor's half, bit h = half of the cursor it hands on when entered in half h.
 // PASS4 = false: calculateCnvMismatchRate / aggregateCnvReadMismatchRate (same cursor walk); PASS4 = true: filterHighMismatchVariants.
 // thread per kept alignment: transfer function of passes 1/2 (calculateCnvMismatchRate / aggregateCnvReadMismatchRate walk the cursor alike)
-__global__ void k_cnv_fn12(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint32_t *row_off, const int32_t *row_cnt,
-                           const int32_t *obs_var, const int32_t *vpos, const int32_t *cs, uint8_t *fn) {
+__global__ void k_cnv_fn12(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const RowDesc *rows,
+                           const ObsRec *obs, const int32_t *vpos, const int32_t *cs, uint8_t *fn) {
     const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= *n_list) return;
     const int nc = (int)cnt->n_cnv, K = nc / 2;
-    const uint32_t r = list[k]; const uint32_t off = row_off[r]; const int n = row_cnt[r];
-    const int rs = vpos[obs_var[off]], re = vpos[obs_var[off + n - 1]];
+    const uint32_t r = list[k]; const uint32_t off = rows[r].off; const int n = rows[r].cnt;
+    const int rs = vpos[obs[off].var], re = vpos[obs[off + n - 1].var];
     const int A0 = cnv_ub(cs, K, rs), U0 = cnv_ub(cs, K, re);
     unsigned f = 0;
     for (int h = 0; h < 2; ++h) {
@@ -235,15 +234,14 @@ __device__ __forceinline__ int cnv_obs_step(int ci, int K, int U, int j, bool ho
 // (rate >= 0.7) - nearly all - move the cursor exactly like passes 1/2 and erase nothing; the others replay the reference's loop on the
 // loaded values.
 template <bool ERASE>
-__global__ __launch_bounds__(256) void k_cnv_rows(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *pre, const uint32_t *row_off,
-                                                  const int32_t *row_cnt, int32_t *obs_var, const int32_t *vpos, const int32_t *cs, const int32_t *ce,
+__global__ __launch_bounds__(256) void k_cnv_rows(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *pre, const RowDesc *rows, ObsRec *obs, const int32_t *vpos, const int32_t *cs, const int32_t *ce,
                                                   const double *miss, uint8_t *fn) {
     const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
     const unsigned k = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
     if (k >= *n_list) return;
     const int nc = (int)cnt->n_cnv, K = nc / 2;
-    const uint32_t r = list[k]; const uint32_t off = row_off[r]; const int n = row_cnt[r];
-    const int rs = vpos[obs_var[off]], re = vpos[obs_var[off + n - 1]];
+    const uint32_t r = list[k]; const uint32_t off = rows[r].off; const int n = rows[r].cnt;
+    const int rs = vpos[obs[off].var], re = vpos[obs[off + n - 1].var];
     const int A0 = cnv_ub(cs, K, rs), U0 = cnv_ub(cs, K, re);
     const bool touch = U0 > A0 || (A0 > 0 && ce[A0 - 1] >= rs);          // an interval intersects the row
     int c0 = A0 == 0 ? 0 : A0 - 1, c1 = A0 == 0 ? 0 : K + A0 - 1;        // cnv_entry of half 0 / half 1
@@ -253,11 +251,11 @@ __global__ __launch_bounds__(256) void k_cnv_rows(const LpsCounters *cnt, const 
         for (int q0 = 0; q0 < n; q0 += ROW_G) {
             const int q = q0 + sl;
             int v = -1, p = 0; bool hot = false;
-            if (q < n) { v = obs_var[off + q]; p = vpos[v]; hot = miss[v] >= 0.7; }
+            if (q < n) { v = obs[off + q].var; p = vpos[v]; hot = miss[v] >= 0.7; }
             const unsigned long long hm = group_ballot(hot, grp);
             if (hm == 0ull && !any_hot) continue;                        // nothing can stop the scan yet: the cursor is brought up when it first matters (below)
             if (!any_hot && q0 > 0) {                                    // first hot chunk: bring the cursor(s) up to the end of the chunk before it
-                const int pp = vpos[obs_var[off + q0 - 1]]; const int Up = cnv_ub(cs, K, pp);
+                const int pp = vpos[obs[off + q0 - 1].var]; const int Up = cnv_ub(cs, K, pp);
                 int i = cnv_walk_end(c0, K, Up); c0 = i > 0 ? i - 1 : 0;
                 if (!ERASE) { i = cnv_walk_end(c1, K, Up); c1 = i > 0 ? i - 1 : 0; }
             }
@@ -275,7 +273,7 @@ __global__ __launch_bounds__(256) void k_cnv_rows(const LpsCounters *cnt, const 
                 if (!ERASE) c1 = cnv_obs_step(c1, K, Ut, jt, ht, &e1);
                 if (ERASE && e0 && sl == t) mine = true;
             }
-            if (ERASE && mine) obs_var[off + q] = -1 - v;
+            if (ERASE && mine) obs[off + q].var = -1 - v;
         }
     }
     if (ERASE) return;
@@ -290,14 +288,13 @@ struct CnvCompose {   // (a then b): bit h of the result = b(a(h)); identity 0b1
 // thread per kept alignment: calculateCnvMismatchRate + aggregateCnvReadMismatchRate with the known entry half.  mm[read][interval] counts the
 // ALT observations inside the interval once per visit of the interval (an interval is visited in both halves when the scan runs across the
 // middle of the doubled list), and every visit then appends that count to the per-(position, allele) lists.
-__global__ void k_cnv_count(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *pre, const uint32_t *row_off,
-                            const int32_t *row_cnt, const int32_t *obs_var, const uint16_t *obs_aq, const int32_t *vpos, const int32_t *cs,
+__global__ void k_cnv_count(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *pre, const RowDesc *rows, const ObsRec *obs, const int32_t *vpos, const int32_t *cs,
                             const int32_t *ce, unsigned long long *agg_sum, int32_t *agg_cnt) {
     const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= *n_list) return;
     const int nc = (int)cnt->n_cnv, K = nc / 2;
-    const uint32_t r = list[k]; const uint32_t off = row_off[r]; const int n = row_cnt[r];
-    const int rs = vpos[obs_var[off]], re = vpos[obs_var[off + n - 1]];
+    const uint32_t r = list[k]; const uint32_t off = rows[r].off; const int n = rows[r].cnt;
+    const int rs = vpos[obs[off].var], re = vpos[obs[off + n - 1].var];
     const int A0 = cnv_ub(cs, K, rs), U0 = cnv_ub(cs, K, re);
     const int ci = A0 == 0 ? 0 : (pre[k] & 1) * K + A0 - 1;            // cnv_entry
     const int i_end = cnv_walk_end(ci, K, U0);
@@ -310,14 +307,14 @@ __global__ void k_cnv_count(const LpsCounters *cnt, const uint32_t *list, const 
         // observations inside [s0, e0]: a range of the position-sorted row, found by two searches; the loops over it have no data-dependent exit,
         // so their loads overlap (a row walked with an early exit is one chain of dependent misses)
         int qa = 0, qb = n;
-        { int lo = 0, hi = n; while (lo < hi) { const int m = (lo + hi) >> 1; if (vpos[obs_var[off + m]] < s0) lo = m + 1; else hi = m; } qa = lo; }
-        { int lo = qa, hi = n; while (lo < hi) { const int m = (lo + hi) >> 1; if (vpos[obs_var[off + m]] <= e0) lo = m + 1; else hi = m; } qb = lo; }
+        { int lo = 0, hi = n; while (lo < hi) { const int m = (lo + hi) >> 1; if (vpos[obs[off + m].var] < s0) lo = m + 1; else hi = m; } qa = lo; }
+        { int lo = qa, hi = n; while (lo < hi) { const int m = (lo + hi) >> 1; if (vpos[obs[off + m].var] <= e0) lo = m + 1; else hi = m; } qb = lo; }
         int alt = 0;
-        for (int q = qa; q < qb; ++q) alt += aq_allele(obs_aq[off + q]);
+        for (int q = qa; q < qb; ++q) alt += aq_allele((uint16_t)obs[off + q].aq);
         if (!alt) continue;
         const unsigned long long mm = (unsigned long long)alt * (unsigned long long)visits;
         for (int q = qa; q < qb; ++q) {
-            const int v = obs_var[off + q]; const int al = aq_allele(obs_aq[off + q]);
+            const int v = obs[off + q].var; const int al = aq_allele((uint16_t)obs[off + q].aq);
             atomicAdd(&agg_sum[(size_t)v * 2 + al], mm * (unsigned long long)visits); atomicAdd(&agg_cnt[(size_t)v * 2 + al], visits);
         }
     }
@@ -345,17 +342,17 @@ __global__ void k_cnv_miss(const LpsCounters *cnt, int n_var, const int32_t *vpo
 // ================================================================================================ nodes
 // wave per alignment: mark observed variants as graph nodes, record the type written by the LAST alignment
 // (BAM order) that observes the position - the reference's (*variantType)[pos] = ... is last-writer-wins.
-__global__ __launch_bounds__(256) void k_mark_nodes(int n_reads, const uint32_t *row_off, const int32_t *row_cnt,
-                                                    const uint8_t *deleted, const int32_t *obs_var, const uint16_t *obs_aq,
+__global__ __launch_bounds__(256) void k_mark_nodes(int n_reads, const RowDesc *rows,
+                                                    const uint8_t *deleted, const ObsRec *obs,
                                                     uint32_t *is_node, uint32_t *vtype_key) {
     const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
     const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
     if (r >= n_reads) return;
-    const int n = row_cnt[r];
+    const int n = rows[r].cnt;
     if (n <= 0 || deleted[r]) return;
-    const uint32_t off = row_off[r];
+    const uint32_t off = rows[r].off;
     for (int k = sl; k < n; k += ROW_G) {
-        const int v = obs_var[off + k]; const int q = aq_quality(obs_aq[off + k]);
+        const int v = obs[off + k].var; const int q = aq_quality((uint16_t)obs[off + k].aq);
         if (v < 0) continue;                                  // erased by the CNV filter
         const unsigned ty = (q == -4) ? 3u : (q == -5 ? 4u : 0u);
         is_node[v] = 1u;
@@ -366,8 +363,8 @@ __global__ __launch_bounds__(256) void k_mark_nodes(int n_reads, const uint32_t 
 }
 
 // wave per alignment: graph view of the observations (node index, allele, hi-quality flag) in the same slots
-__global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const uint32_t *row_off, const int32_t *row_cnt,
-                                                   const uint8_t *deleted, const int32_t *obs_var, const uint16_t *obs_aq,
+__global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const RowDesc *rows,
+                                                   const uint8_t *deleted, const ObsRec *obs,
                                                    const uint32_t *node_of, int base_quality, int32_t *g_node, uint8_t *g_flag,
                                                    int32_t *g_cnt, LpsCounters *cnt, int n_var, const uint32_t *is_node, const uint32_t *vtype_key,
                                                    int32_t *nodes, uint8_t *ntype, uint32_t *node_cnt) {
@@ -383,15 +380,15 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const uint32_t *
     const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
     const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
     if (r >= n_reads) return;
-    const int n = row_cnt[r];
+    const int n = rows[r].cnt;
     if (n <= 0 || deleted[r]) { if (sl == 0) g_cnt[r] = 0; return; }
-    const uint32_t off = row_off[r];
+    const uint32_t off = rows[r].off;
     // compact in place (CNV-erased entries have var = -1); rows are private to their lane group so a running count suffices
     int w = 0;
     for (int k0 = 0; k0 < n; k0 += ROW_G) {
         const int k = k0 + sl;
         int v = -1; uint16_t aq = 0;
-        if (k < n) { v = obs_var[off + k]; aq = obs_aq[off + k]; }
+        if (k < n) { v = obs[off + k].var; aq = (uint16_t)obs[off + k].aq; }
         const bool ok = v >= 0;
         const unsigned long long m = group_ballot(ok, grp);
         if (ok) {
@@ -415,7 +412,7 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const uint32_t *
 // (ties: earlier alignment first).  That is the stable order == libstdc++ std::sort for n <= 16 and differs from it only in the
 // relative order of equal positions beyond that.
 __global__ __launch_bounds__(256) void k_merge_plan(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt,
-                             const uint32_t *row_off, const int32_t *g_cnt, unsigned long long tail_lo, unsigned long long tail_size,
+                             const RowDesc *rows, const int32_t *g_cnt, unsigned long long tail_lo, unsigned long long tail_size,
                              uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list) {
     __shared__ unsigned s_tot[4], s_n[4]; __shared__ unsigned long long s_base_t; __shared__ unsigned s_base_n;
     const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -423,12 +420,12 @@ __global__ __launch_bounds__(256) void k_merge_plan(const unsigned long long *sk
     bool multi = false; int total = 0;
     if (g < cnt->n_groups) {
         const uint32_t s0 = gstart[g], s1 = gstart[g + 1];
-        if (s1 - s0 == 1) { const uint32_t r = (uint32_t)skeys[s0]; mrow_off[g] = row_off[r]; mrow_cnt[g] = g_cnt[r]; }
+        if (s1 - s0 == 1) { const uint32_t r = (uint32_t)skeys[s0]; mrow_off[g] = rows[r].off; mrow_cnt[g] = g_cnt[r]; }
         else {
             int alive = 0; uint32_t one = 0;
             for (uint32_t s = s0; s < s1; ++s) { const uint32_t r = (uint32_t)skeys[s]; if (g_cnt[r] > 0) { ++alive; total += g_cnt[r]; one = r; } }
             if (alive == 0) { mrow_off[g] = 0; mrow_cnt[g] = 0; }
-            else if (alive == 1) { mrow_off[g] = row_off[one]; mrow_cnt[g] = total; }
+            else if (alive == 1) { mrow_off[g] = rows[one].off; mrow_cnt[g] = total; }
             else multi = true;
         }
     }
@@ -532,7 +529,7 @@ void launch_debug_std_sort(int32_t *keys, uint8_t *payload, const long long *row
 }
 
 __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *skeys, const uint32_t *gstart, const LpsCounters *cnt,
-                                                     const uint32_t *row_off, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
+                                                     const RowDesc *rows, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
                                                      const uint32_t *mrow_off, const uint32_t *multi_list) {
     __shared__ int s_stk[4][192]; __shared__ int32_t s_k[4][STDSORT_LDS]; __shared__ uint8_t s_p[4][STDSORT_LDS]; __shared__ uint16_t s_a[4][STDSORT_LDS], s_b[4][STDSORT_LDS];
     const int l = lane_id();
@@ -549,21 +546,21 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
         // of dependent probes - tens of cycles each in LDS, a microsecond each in HBM - and the std::sort path wants this copy anyway
         if (in_lds) {
             int at = 0;
-            for (uint32_t sa = s0; sa < s1; ++sa) { const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = row_off[ra];
+            for (uint32_t sa = s0; sa < s1; ++sa) { const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = rows[ra].off;
                 for (int k = l; k < na; k += 64) { s_k[w][at + k] = g_node[oa + k]; s_p[w][at + k] = g_flag[oa + k]; } at += na; }
             wave_sync();
         }
         bool dup = false;
         int aa = 0;                                                      // offset of alignment sa's row inside the concatenation
         for (uint32_t sa = s0; sa < s1; ++sa) {                      // source alignment (BAM order inside the group)
-            const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = row_off[ra];
+            const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = rows[ra].off;
             for (int k = l; k < na; k += 64) {
                 const int nd = in_lds ? s_k[w][aa + k] : g_node[oa + k]; const uint8_t fl = in_lds ? s_p[w][aa + k] : g_flag[oa + k];
                 int rank = k, ab = 0;
                 for (uint32_t sb = s0; sb < s1; ++sb) {
                     const uint32_t rb = (uint32_t)skeys[sb]; const int nb = g_cnt[rb];
                     if (sb != sa) {
-                        const int32_t *row = in_lds ? s_k[w] + ab : g_node + row_off[rb];
+                        const int32_t *row = in_lds ? s_k[w] + ab : g_node + rows[rb].off;
                         // earlier alignment: its equal positions go first (count <= nd); later alignment: only smaller ones
                         int lo = 0, hi = nb;
                         if (sb < sa) { while (lo < hi) { const int m = (lo + hi) >> 1; if (row[m] <= nd) lo = m + 1; else hi = m; } }
@@ -588,7 +585,7 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
                 if (in_lds) { wave_sync(); wave_std_sort(s_k[w], s_p[w], total, s_stk[w], s_a[w], s_b[w], g_node + base, g_flag + base, l); }
                 else {
                     int at = 0;
-                    for (uint32_t sa = s0; sa < s1; ++sa) { const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = row_off[ra];
+                    for (uint32_t sa = s0; sa < s1; ++sa) { const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = rows[ra].off;
                         for (int k = l; k < na; k += 64) { g_node[base + at + k] = g_node[oa + k]; g_flag[base + at + k] = g_flag[oa + k]; } at += na; }
                     __threadfence_block();
                     if (l == 0) { StdSortArrays a{g_node + base, g_flag + base}; stdsort_run(a, total, s_stk[w]); }
@@ -1065,14 +1062,14 @@ __global__ void k_node_state(const LpsCounters *cnt, const int32_t *block, const
 // wave per alignment: readCorrection's per-read vote (:904-959).  SNP sites contribute integers (order-free, ballot +
 // popcount); as soon as the read touches an indel site the 0.1 contributions are summed by one lane in the reference's
 // order (doubles), so the result is bit-identical either way.
-__global__ __launch_bounds__(256) void k_read_correction(int n_reads, const uint32_t *row_off, const int32_t *g_cnt, const int32_t *g_node,
+__global__ __launch_bounds__(256) void k_read_correction(int n_reads, const RowDesc *rows, const int32_t *g_cnt, const int32_t *g_node,
                                                          const uint8_t *g_flag, const uint8_t *nstate, double read_confidence, uint32_t *cnt4) {
     const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
     const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
     if (r >= n_reads) return;
     const int n = g_cnt[r];
     if (n <= 0) return;
-    const uint32_t off = row_off[r];
+    const uint32_t off = rows[r].off;
     int irc = 0, iac = 0; bool indel = false;
     for (int k0 = 0; k0 < n; k0 += ROW_G) {
         const int k = k0 + sl;
@@ -1150,13 +1147,13 @@ void exscan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out
 
 #define GRID(n, b) dim3((unsigned)(((n) + (b) - 1) / (b))), dim3(b)
 
-void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const uint32_t *row_off, const int32_t *row_cnt,
-                       const uint8_t *deleted, int32_t *obs_var, const uint16_t *obs_aq, const int32_t *vpos,
+void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const RowDesc *rows,
+                       const uint8_t *deleted, ObsRec *obs, const int32_t *vpos,
                        const int32_t *cnv_start, const int32_t *cnv_end, long long *agg_sum, int32_t *agg_cnt, double *miss,
                        CnvScratch &W, void *temp, size_t temp_bytes, hipStream_t s) {
     HIP_TRY(hipMemsetAsync(agg_sum, 0, (size_t)n_var * 2 * sizeof(long long), s));
     HIP_TRY(hipMemsetAsync(agg_cnt, 0, (size_t)n_var * 2 * sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_cnv_list, GRID(n_reads, 256), 0, s, cnt, n_reads, row_cnt, deleted, W.flag);
+    hipLaunchKernelGGL(k_cnv_list, GRID(n_reads, 256), 0, s, cnt, n_reads, rows, deleted, W.flag);
     exscan_u32(temp, temp_bytes, W.flag, W.idx, n_reads, s);
     hipLaunchKernelGGL(k_cnv_compact, GRID(n_reads, 256), 0, s, cnt, n_reads, W.flag, W.idx, W.list, W.n_list);
     // entry half of every kept alignment = (composition of the transfer functions of the alignments before it)(half 0); at most n_reads entries are
@@ -1164,30 +1161,30 @@ void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const uin
     const unsigned row_grid = (unsigned)((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     for (int pass4 = 0; pass4 < 2; ++pass4) {
         HIP_TRY(hipMemsetAsync(W.fn, 2, (size_t)n_reads, s));
-        if (pass4) hipLaunchKernelGGL(k_cnv_rows<false>, dim3(row_grid), dim3(256), 0, s, cnt, W.list, W.n_list, W.pre, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss, W.fn);
-        else hipLaunchKernelGGL(k_cnv_fn12, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, row_off, row_cnt, obs_var, vpos, cnv_start, W.fn);
+        if (pass4) hipLaunchKernelGGL(k_cnv_rows<false>, dim3(row_grid), dim3(256), 0, s, cnt, W.list, W.n_list, W.pre, rows, obs, vpos, cnv_start, cnv_end, miss, W.fn);
+        else hipLaunchKernelGGL(k_cnv_fn12, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, rows, obs, vpos, cnv_start, W.fn);
         size_t need = temp_bytes;
         HIP_TRY(rocprim::exclusive_scan(temp, need, W.fn, W.pre, (uint8_t)2, (size_t)n_reads, CnvCompose(), s));
         if (!pass4) {
-            hipLaunchKernelGGL(k_cnv_count, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, W.pre, row_off, row_cnt, obs_var, obs_aq, vpos, cnv_start, cnv_end, (unsigned long long *)agg_sum, agg_cnt);
+            hipLaunchKernelGGL(k_cnv_count, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, W.pre, rows, obs, vpos, cnv_start, cnv_end, (unsigned long long *)agg_sum, agg_cnt);
             hipLaunchKernelGGL(k_cnv_miss, GRID(n_var, 256), 0, s, cnt, n_var, vpos, cnv_start, cnv_end, (const unsigned long long *)agg_sum, agg_cnt, miss);
         } else {
-            hipLaunchKernelGGL(k_cnv_rows<true>, dim3(row_grid), dim3(256), 0, s, cnt, W.list, W.n_list, W.pre, row_off, row_cnt, obs_var, vpos, cnv_start, cnv_end, miss, W.fn);
+            hipLaunchKernelGGL(k_cnv_rows<true>, dim3(row_grid), dim3(256), 0, s, cnt, W.list, W.n_list, W.pre, rows, obs, vpos, cnv_start, cnv_end, miss, W.fn);
         }
     }
 }
 
-void launch_clip_keys(const ClipView &C, const int32_t *row_fail, int n_reads, unsigned long long *keys, LpsCounters *cnt, hipStream_t s) {
-    if (n_reads) hipLaunchKernelGGL(k_clip_keys, GRID(n_reads, 256), 0, s, C, row_fail, n_reads, keys, cnt);
+void launch_clip_keys(const ClipView &C, const RowDesc *rows, int n_reads, unsigned long long *keys, LpsCounters *cnt, hipStream_t s) {
+    if (n_reads) hipLaunchKernelGGL(k_clip_keys, dim3((unsigned)std::min(1024, (n_reads + 255) / 256)), dim3(256), 0, s, C, rows, keys, cnt);
 }
 
 void launch_clip_sort(unsigned n_clips, unsigned long long *keys, unsigned long long *keys_sorted, void *temp, size_t temp_bytes, hipStream_t s) {
     if (n_clips) sort_keys64(temp, temp_bytes, keys, keys_sorted, n_clips, 33, s);          // key = pos << 1 | front/back: 33 bits, 5 digit passes instead of 8
 }
 
-void launch_name_keys(int n_reads, const uint32_t *name_id, const int32_t *row_cnt, unsigned long long *keys,
+void launch_name_keys(int n_reads, const uint32_t *name_id, const RowDesc *rows, unsigned long long *keys,
                       LpsCounters *cnt, const unsigned long long *arena_ctr, unsigned long long arena_size, hipStream_t s) {
-    hipLaunchKernelGGL(k_name_keys, dim3((n_reads + 255) / 256 + 1), dim3(256), 0, s, n_reads, name_id, row_cnt, keys, cnt, arena_ctr, arena_size);
+    hipLaunchKernelGGL(k_name_keys, dim3((n_reads + 255) / 256 + 1), dim3(256), 0, s, n_reads, name_id, rows, keys, cnt, arena_ctr, arena_size);
 }
 
 void launch_groups(const unsigned long long *skeys, int n_reads, LpsCounters *cnt, uint32_t *head, uint32_t *gidx,
@@ -1198,25 +1195,25 @@ void launch_groups(const unsigned long long *skeys, int n_reads, LpsCounters *cn
 }
 
 void launch_overlap_filter(const unsigned long long *skeys, const uint32_t *gstart, const LpsCounters *cnt, int n_reads,
-                           const uint32_t *row_off, const int32_t *row_cnt, const int32_t *obs_var, const int32_t *vpos,
+                           const RowDesc *rows, const ObsRec *obs, const int32_t *vpos,
                            double thr, uint32_t *stack, uint8_t *deleted, hipStream_t s) {
-    hipLaunchKernelGGL(k_overlap_filter, GRID(n_reads, 128), 0, s, skeys, gstart, cnt, row_off, row_cnt, obs_var, vpos, thr, stack, deleted);
+    hipLaunchKernelGGL(k_overlap_filter, GRID(n_reads, 128), 0, s, skeys, gstart, cnt, rows, obs, vpos, thr, stack, deleted);
 }
 
-void launch_nodes(int n_reads, int n_var, const uint32_t *row_off, const int32_t *row_cnt, const uint8_t *deleted,
-                  const int32_t *obs_var, const uint16_t *obs_aq, uint32_t *is_node, uint32_t *vtype_key, uint32_t *node_of,
+void launch_nodes(int n_reads, int n_var, const RowDesc *rows, const uint8_t *deleted,
+                  const ObsRec *obs, uint32_t *is_node, uint32_t *vtype_key, uint32_t *node_of,
                   int32_t *nodes, uint8_t *ntype, int base_quality, int32_t *g_node, uint8_t *g_flag, int32_t *g_cnt,
                   LpsCounters *cnt, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(k_mark_nodes, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, is_node, vtype_key);
+    hipLaunchKernelGGL(k_mark_nodes, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, n_reads, rows, deleted, obs, is_node, vtype_key);
     exscan_u32(temp, temp_bytes, is_node, node_of, n_var, s);
-    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK + (n_var + 255) / 256), dim3(256), 0, s, n_reads, row_off, row_cnt, deleted, obs_var, obs_aq, node_of, base_quality, g_node, g_flag, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype, node_cnt);
+    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK + (n_var + 255) / 256), dim3(256), 0, s, n_reads, rows, deleted, obs, node_of, base_quality, g_node, g_flag, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype, node_cnt);
 }
 
 void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
-                       const uint32_t *row_off, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
+                       const RowDesc *rows, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
                        unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list, hipStream_t s) {
-    hipLaunchKernelGGL(k_merge_plan, GRID(n_reads, 256), 0, s, skeys, gstart, cnt, row_off, g_cnt, tail_lo, tail_size, mrow_off, mrow_cnt, multi_list);
-    hipLaunchKernelGGL(k_merge_multi, dim3(256), dim3(256), 0, s, skeys, gstart, cnt, row_off, g_cnt, g_node, g_flag, mrow_off, multi_list);
+    hipLaunchKernelGGL(k_merge_plan, GRID(n_reads, 256), 0, s, skeys, gstart, cnt, rows, g_cnt, tail_lo, tail_size, mrow_off, mrow_cnt, multi_list);
+    hipLaunchKernelGGL(k_merge_multi, dim3(256), dim3(256), 0, s, skeys, gstart, cnt, rows, g_cnt, g_node, g_flag, mrow_off, multi_list);
 }
 
 void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t *mrow_off, const int32_t *mrow_cnt, uint32_t *koff,
@@ -1258,12 +1255,12 @@ void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, c
     hipLaunchKernelGGL(k_scan_finalize, GRID(n_var, 256), 0, s, cnt, hp_v, blk_v, vstride, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, hp, block);
 }
 
-void launch_correction(LpsCounters *cnt, int n_reads, int n_var, const uint32_t *row_off, const int32_t *g_cnt,
+void launch_correction(LpsCounters *cnt, int n_reads, int n_var, const RowDesc *rows, const int32_t *g_cnt,
                        const int32_t *g_node, const uint8_t *g_flag, const int32_t *nodes, const int32_t *vpos,
                        const int32_t *block, uint32_t *bsize, const int8_t *hp, const uint8_t *ntype, const uint32_t *node_pairs,
                        uint8_t *nstate, double read_conf, double snp_conf, uint32_t *cnt4, int32_t *out_ps, uint8_t *out_gt, hipStream_t s) {
     hipLaunchKernelGGL(k_block_size, GRID(n_var, 256), 0, s, cnt, block, node_pairs, bsize, nstate, hp, ntype);
     hipLaunchKernelGGL(k_node_state, GRID(n_var, 256), 0, s, cnt, block, bsize, nstate);
-    hipLaunchKernelGGL(k_read_correction, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, n_reads, row_off, g_cnt, g_node, g_flag, nstate, read_conf, cnt4);
+    hipLaunchKernelGGL(k_read_correction, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, n_reads, rows, g_cnt, g_node, g_flag, nstate, read_conf, cnt4);
     hipLaunchKernelGGL(k_final, GRID(n_var, 256), 0, s, cnt, nodes, vpos, block, bsize, cnt4, snp_conf, out_ps, out_gt);
 }

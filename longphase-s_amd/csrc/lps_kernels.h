@@ -34,20 +34,28 @@ struct ReadView {
     const uint8_t *seq, *qual;
 };
 
-struct ObsView {           // CSR rows placed by atomic reservation: row r = [row_off[r], row_off[r]+row_cnt[r])
-    uint32_t *row_off;
-    int32_t *row_cnt;
-    int32_t *row_fail;     // CIGAR op index at which get_snp returned early (INT_MAX = none)
-    uint8_t *row_flags;    // bit0: had observations before filterSNP erased them
-    int32_t *var;          // variant index
-    uint16_t *aq;          // pack_aq(allele, quality)
+// one alignment's row of observations: 16 bytes, written by one lane of the extraction wave (four rows = one 64-byte line per wave)
+struct __attribute__((aligned(16))) RowDesc {
+    uint32_t off;          // first slot of the row in the observation arena
+    int32_t cnt;           // observations (0: none, filtered out, or get_snp returned early)
+    int32_t fail;          // CIGAR op index at which get_snp returned early (INT_MAX = none): clips of later ops do not count
+    uint32_t flags;        // bit0: had observations before filterSNP erased them
+};
+// one observation: 8 bytes {variant index (or -1 - index once the CNV filter erased it), pack_aq(allele, quality)}
+struct __attribute__((aligned(8))) ObsRec { int32_t var; uint32_t aq; };
+// a clip event of getClip: position, op index << 1 | (op index != 0), alignment
+struct ClipEv { int32_t pos; int32_t opidx_fb; int32_t read; };
+
+struct ObsView {           // rows placed by atomic reservation: row r = [rows[r].off, rows[r].off + rows[r].cnt)
+    RowDesc *rows;
+    ObsRec *rec;
     unsigned long long arena_size;      // slots per arena; arena a covers [a*arena_size, (a+1)*arena_size)
     unsigned long long *arena_ctr;      // LPS_ARENAS counters, 8 u64 apart (one cache line each)
     int n_arenas;                       // arenas in use: min(LPS_ARENAS, workgroups)
 };
 
-struct ClipView {          // clip events in LPS_CLIP_SLOTS fixed slots per alignment; filtered by row_fail afterwards
-    int32_t *pos; int32_t *opidx_fb;   // opidx<<1 | (opidx!=0), -1 = unused slot
+struct ClipView {          // clip events of the kept alignments, appended (one reservation per wave that has any); filtered by RowDesc.fail afterwards
+    ClipEv *ev; unsigned *n_ev; unsigned capacity;
 };
 
 void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *rec, hipStream_t s);
@@ -63,7 +71,7 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 #define VREC_DERIVE(a) (((a) >> 24) & 3u) /* somaticReadDeriveByHP of role-1 rows */
 #define VREC_TKIND(a) (((a) >> 26) & 7u)  /* somatic extraction: TUMOR row kind at this position (0 none, 1 SNP, 2 INS, 3 DEL, 4 other) */
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,
-                          int mapping_quality, LpsCounters *cnt, hipStream_t s);
+                          int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, hipStream_t s);
 
 // ---- device helpers shared by the extraction (phase) and scoring (haplotag) kernels
 #ifdef __HIPCC__
