@@ -31,6 +31,7 @@
 #include <mutex>
 #include <numeric>
 #include <sstream>
+#include <condition_variable>
 #include <string>
 #include <thread>
 #include <vector>
@@ -58,6 +59,8 @@ struct Lps {
     decltype(&lps_haplotag_write_bgzf) haplotag_write_bgzf = nullptr; decltype(&lps_bgzf_deflate_fetch) bgzf_deflate_fetch = nullptr;
     decltype(&lps_somatic_extract_normal) somatic_extract_normal = nullptr; decltype(&lps_somatic_extract_tumor) somatic_extract_tumor = nullptr;
     decltype(&lps_somatic_tag_chromosome) somatic_tag_chromosome = nullptr;
+    decltype(&lps_comm_create_all) comm_create_all = nullptr; decltype(&lps_comm_bcast) comm_bcast = nullptr; decltype(&lps_comm_destroy) comm_destroy = nullptr;
+    decltype(&lps_comm_size) comm_size = nullptr; decltype(&lps_comm_last_error) comm_last_error = nullptr;
     std::string error;
     bool load() {
         char exe[4096]; const ssize_t k = readlink("/proc/self/exe", exe, sizeof exe - 1);
@@ -73,6 +76,7 @@ struct Lps {
         LPS_SYM(abi_version, lps_abi_version) LPS_SYM(bgzf_load, lps_bgzf_load) LPS_SYM(bgzf_read, lps_bgzf_read) LPS_SYM(bam_scan, lps_bam_scan)
         LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range) LPS_SYM(device_count, lps_device_count) LPS_SYM(set_stage_timing, lps_set_stage_timing) LPS_SYM(haplotag_write_bgzf, lps_haplotag_write_bgzf) LPS_SYM(bgzf_deflate_fetch, lps_bgzf_deflate_fetch)
         LPS_SYM(somatic_extract_normal, lps_somatic_extract_normal) LPS_SYM(somatic_extract_tumor, lps_somatic_extract_tumor) LPS_SYM(somatic_tag_chromosome, lps_somatic_tag_chromosome)
+        LPS_SYM(comm_create_all, lps_comm_create_all) LPS_SYM(comm_bcast, lps_comm_bcast) LPS_SYM(comm_destroy, lps_comm_destroy) LPS_SYM(comm_size, lps_comm_size) LPS_SYM(comm_last_error, lps_comm_last_error)
 #undef LPS_SYM
         if (abi_version() != LPS_ABI_VERSION) { error = "liblps_hip.so has a different ABI version than this binary was built for"; return false; }
         return true;
@@ -502,7 +506,18 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     GpuBam gb; if (gpu_input) { gb.open_file(bams[0], !no_index); if (!gb.indexed) gb.load_all(L, ctx); }
     const double t_gin = now();
     std::map<std::string, std::map<int32_t, Phased>> res; std::mutex res_mu;
-    auto run_contig = [&](lps_ctx *ctx, GpuBam &gb, const std::string &chr) {   // PhasingProcess.cpp:113-173, one contig on one GPU
+    // packed SNP table of the whole genome (pos i32 | ref0 u8 | alt0 u8 | ref_len u16 | alt_len u16, contig after contig): worker 0 builds it from the parsed
+    // VCF; with --gpus N it reaches the other GPUs by one RCCL broadcast (lps_comm_bcast) and every worker reads its contigs' rows from ITS copy
+    struct Packed { std::vector<uint8_t> buf; size_t n = 0; std::map<std::string, std::pair<size_t, size_t>> where;
+        const int32_t *pos() const { return (const int32_t *)buf.data(); } const uint8_t *r0() const { return buf.data() + 4 * n; } const uint8_t *a0() const { return buf.data() + 5 * n; }
+        const uint16_t *rl() const { return (const uint16_t *)(buf.data() + 6 * n); } const uint16_t *al() const { return (const uint16_t *)(buf.data() + 8 * n); } };
+    Packed table0;
+    { size_t n = 0; for (const std::string &c : chr_order) { table0.where[c] = {n, vars[c].pos.size()}; n += vars[c].pos.size(); }
+      table0.n = n; table0.buf.assign(10 * n + 16, 0);
+      int32_t *pp = (int32_t *)table0.buf.data(); uint8_t *r0 = table0.buf.data() + 4 * n, *a0 = table0.buf.data() + 5 * n; uint16_t *rl = (uint16_t *)(table0.buf.data() + 6 * n), *al = (uint16_t *)(table0.buf.data() + 8 * n);
+      for (const std::string &c : chr_order) { const ChrVariants &cv = vars[c]; const size_t o = table0.where[c].first;
+          for (size_t i = 0; i < cv.pos.size(); ++i) { pp[o + i] = cv.pos[i]; r0[o + i] = (uint8_t)cv.ref[i][0]; a0[o + i] = (uint8_t)cv.alt[i][0]; rl[o + i] = (uint16_t)cv.ref[i].size(); al[o + i] = (uint16_t)cv.alt[i].size(); } } }
+    auto run_contig = [&](lps_ctx *ctx, GpuBam &gb, const std::string &chr, const Packed &tab) {   // PhasingProcess.cpp:113-173, one contig on one GPU
         ChrVariants &cv = vars[chr];
         if (cv.pos.empty() || !seqs.count(chr)) return;
         // names of all files of this contig ranked together (one read name = one merged row, whatever file it came from)
@@ -516,9 +531,8 @@ static int phase_main(int argc, char **argv, const std::string &command) {
             parts.push_back(&it->second); for (size_t i = 0; i < it->second.rec_off.size(); ++i) { size_t l; const char *nm = f.name_of(it->second, i, l); names.emplace_back(nm, l); } }
         if (names.empty()) return;
         std::vector<uint32_t> name_id; rank_names(names, name_id);
-        std::vector<uint8_t> r0(cv.pos.size()), a0(cv.pos.size()); std::vector<uint16_t> rl(cv.pos.size()), al(cv.pos.size());
-        for (size_t i = 0; i < cv.pos.size(); ++i) { r0[i] = (uint8_t)cv.ref[i][0]; a0[i] = (uint8_t)cv.alt[i][0]; rl[i] = (uint16_t)cv.ref[i].size(); al[i] = (uint16_t)cv.alt[i].size(); }
-        lps_variant_table vt{}; vt.n = (int64_t)cv.pos.size(); vt.pos = cv.pos.data(); vt.ref0 = r0.data(); vt.alt0 = a0.data(); vt.ref_len = rl.data(); vt.alt_len = al.data();
+        const size_t to = tab.where.at(chr).first;
+        lps_variant_table vt{}; vt.n = (int64_t)cv.pos.size(); vt.pos = tab.pos() + to; vt.ref0 = tab.r0() + to; vt.alt0 = tab.a0() + to; vt.ref_len = tab.rl() + to; vt.alt_len = tab.al() + to;
         const std::string &sq = seqs[chr];
         if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size())) die(std::string("longphase_amd: ") + L.last_error(ctx));
         size_t at = 0;
@@ -550,21 +564,37 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     }
     std::vector<std::thread> workers;
     const int n_dev = std::max(1, L.device_count());
-    auto run_share = [&](lps_ctx *cx, GpuBam &g, std::vector<std::string> list) {
-        if (!gpu_input || !g.indexed) { for (const std::string &c : list) run_contig(cx, g, c); return; }
+    auto run_share = [&](lps_ctx *cx, GpuBam &g, std::vector<std::string> list, const Packed &tab) {
+        if (!gpu_input || !g.indexed) { for (const std::string &c : list) run_contig(cx, g, c, tab); return; }
         std::sort(list.begin(), list.end(), [&](const std::string &a, const std::string &b) { return g.tid_of(a) < g.tid_of(b); });   // file order, so that neighbours share an upload
-        for (auto &grp : g.plan_groups(list, group_bytes)) { g.load_group(L, cx, grp); for (const std::string &c : grp) run_contig(cx, g, c); }
+        for (auto &grp : g.plan_groups(list, group_bytes)) { g.load_group(L, cx, grp); for (const std::string &c : grp) run_contig(cx, g, c, tab); }
+    };
+    // the one collective: a communicator over the workers' GPUs (ncclCommInitAll); fails when two workers share a device (rehearsal on fewer GPUs
+    // than --gpus) - the workers then read the table worker 0 holds, in this one address space
+    std::vector<lps_comm *> comms((size_t)n_workers, nullptr); bool have_comm = false;
+    if (n_workers > 1) { std::vector<int> devs; for (int g = 0; g < n_workers; ++g) devs.push_back((gpu + g) % n_dev);
+        have_comm = std::set<int>(devs.begin(), devs.end()).size() == devs.size() && L.comm_create_all(n_workers, devs.data(), comms.data()) == 0;
+        if (have_comm) std::cerr << "longphase_amd: RCCL communicator over " << L.comm_size(comms[0]) << " GPUs\n";
+        else std::cerr << "longphase_amd: no RCCL communicator (" << (std::set<int>(devs.begin(), devs.end()).size() == devs.size() ? L.comm_last_error() : "workers share a device") << "); workers read the host table\n"; }
+    auto obtain_table = [&](int g, Packed &mine) -> const Packed & {       // every worker calls this once (collective)
+        if (!have_comm) return table0;
+        if (g == 0) { double ms = 0; if (L.comm_bcast(comms[0], table0.buf.data(), (int64_t)table0.buf.size(), 0, &ms)) die(std::string("longphase_amd: ") + L.comm_last_error()); fprintf(stderr, "longphase_amd: SNP table broadcast, %zu bytes, %.3f ms\n", table0.buf.size(), ms); return table0; }
+        mine.n = table0.n; mine.where = table0.where; mine.buf.assign(table0.buf.size(), 0);
+        if (L.comm_bcast(comms[(size_t)g], mine.buf.data(), (int64_t)mine.buf.size(), 0, nullptr)) die(std::string("longphase_amd: ") + L.comm_last_error());
+        return mine;
     };
     for (int g = 1; g < n_workers; ++g) workers.emplace_back([&, g] {
         lps_params P; L.default_params(&P); for (auto &f : over) f(P);
         lps_ctx *cx = L.create((gpu + g) % n_dev, &P); if (!cx) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
         L.set_stage_timing(cx, 0);
         GpuBam gg; gg.open_file(bams[0], true);
-        run_share(cx, gg, share[(size_t)g]);
+        Packed mine; const Packed &tab = obtain_table(g, mine);
+        run_share(cx, gg, share[(size_t)g], tab);
         L.destroy(cx); gg.close_file();
     });
-    run_share(ctx, gb, share[0]);
+    { Packed none; const Packed &tab = obtain_table(0, none); run_share(ctx, gb, share[0], tab); }
     for (auto &w : workers) w.join();
+    for (lps_comm *cm : comms) if (cm) L.comm_destroy(cm);
     std::cerr << "\n";
     L.destroy(ctx);
     const double t_gpu = now();
@@ -699,6 +729,7 @@ static const char *kTagUsage =
     "Usage: longphase_amd haplotag [OPTION] ... READSFILE\n"
     "   -s, --snp-file=NAME   -b, --bam-file=NAME   -r, --reference=NAME   -o, --out-prefix=NAME (result)   -t, --threads=Num (1)\n"
     "   --tagSupplementary   -q qualityThreshold(1)   -p percentageThreshold(0.6)   --gpu=ID (0)\n"
+    "   --gpus=N (deal the contigs onto N GPUs, devices --gpu, --gpu+1, ...; needs <bam>.bai and the GPU writer; output contigs stay in VCF-header order)\n"
     "   --host-inflate | --gpu-inflate (zlib on the -t threads / GPU inflate + GPU writer; default: GPU for a BAM of 256 MiB or more)   --no-index (ignore <bam>.bai, keep the whole file on the GPU)\n"
     "   --host-deflate (tag splice + zlib deflate on the -t threads instead of the GPU writer; implied by --host-inflate)\n"
     "   --compress-level=N (6)   --compress-strategy=rle|default|huffman (rle: packed bases and qualities hold few LZ77 matches; about 2 % larger\n"
@@ -706,7 +737,7 @@ static const char *kTagUsage =
 
 static int haplotag_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
-    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, level = 6, strategy = Z_RLE; bool host_inflate = false, gpu_inflate = false, no_index = false, host_deflate = false; uint64_t group_bytes = 8ull << 30;
+    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, n_gpus = 1, level = 6, strategy = Z_RLE; bool host_inflate = false, gpu_inflate = false, no_index = false, host_deflate = false; uint64_t group_bytes = 8ull << 30;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kTagUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -721,6 +752,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         else if (a == "-q" || a == "--qualityThreshold") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.mapping_quality = x; }); }
         else if (a == "-p" || a == "--percentageThreshold") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.percentage_threshold = x; }); }
         else if (a == "--gpu") gpu = std::stoi(val());
+        else if (a == "--gpus") n_gpus = std::max(1, std::stoi(val()));
         else if (a == "--host-inflate") host_inflate = true;
         else if (a == "--gpu-inflate") gpu_inflate = true;
         else if (a == "--no-index") no_index = true;
@@ -799,6 +831,85 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     }
     unsigned long long st_count[8] = {0}, hp_count[3] = {0};
     double t_score = 0, t_splice = 0, t_deflate = 0, t_load = 0, t_mark = now(); std::vector<uint8_t> zbuf;
+    // ---- --gpus N (indexed BAM, GPU writer): scoring is per read and the output BGZF blocks of a contig depend on nothing but that contig, so the contigs
+    //      are dealt longest-first onto N workers (one host thread + one GPU + its own view of the file each); every worker inflates, scores, re-tags and
+    //      deflates its contigs, the main thread writes the finished contigs in VCF-header order (BGZF members concatenate).  No data-path collective.
+    if (n_gpus > 1 && !(gpu_writer && !host_inflate && gb.indexed)) std::cerr << "longphase_amd: haplotag --gpus needs the indexed BAM and the GPU writer; running on one GPU\n";
+    if (n_gpus > 1 && gpu_writer && !host_inflate && gb.indexed) {
+        struct Done { std::vector<uint8_t> z; bool ready = false; unsigned long long st[8] = {0}, hpc[3] = {0}; };
+        std::vector<Done> done(chr_vec.size()); std::mutex mu; std::condition_variable cv;
+        auto tag_contig = [&](lps_ctx *cx, GpuBam &g, const std::string &chr, Done &d) {
+            auto gi = g.range.find(chr);
+            if (gi == g.range.end() || gi->second.second == 0) return;
+            const size_t n = (size_t)gi->second.second;
+            auto ri = rows.find(chr);
+            std::vector<uint8_t> status(n, 5), hp(n, 0); std::vector<int32_t> h1(n), h2(n), psmin(n), pq(n), psv(n); std::vector<uint8_t> nps(n);
+            std::vector<uint32_t> name_id(n, 0);                        // haplotag does not group by read name
+            if (ri != rows.end() && !ri->second.empty()) {
+                if (!seqs.count(chr)) die("ERROR: contig " + chr + " is missing from the reference FASTA");
+                const size_t m = ri->second.size();
+                std::vector<int32_t> pos(m), ps(m); std::vector<uint8_t> r0(m), a0(m), hpa(m); std::vector<uint16_t> rl(m), al(m); size_t k = 0;
+                for (auto &kv : ri->second) { pos[k] = kv.first; r0[k] = (uint8_t)kv.second.ref[0]; a0[k] = (uint8_t)kv.second.alt[0]; rl[k] = (uint16_t)kv.second.ref.size(); al[k] = (uint16_t)kv.second.alt.size(); hpa[k] = kv.second.hp1_is_alt; ps[k] = kv.second.ps; ++k; }
+                lps_variant_table vt{}; vt.n = (int64_t)m; vt.pos = pos.data(); vt.ref0 = r0.data(); vt.alt0 = a0.data(); vt.ref_len = rl.data(); vt.alt_len = al.data(); vt.hp1_is_alt = hpa.data(); vt.phase_set = ps.data();
+                const std::string &sq = seqs.at(chr);
+                lps_haplotag_result hr{(int64_t)n, status.data(), h1.data(), h2.data(), nps.data(), psmin.data(), hp.data(), pq.data(), psv.data()};
+                if (L.begin_chromosome(cx) || L.set_variants(cx, &vt) || L.set_reference(cx, sq.data(), (int64_t)sq.size()) || L.push_bam_resident(cx, gi->second.first, (int64_t)n, name_id.data()) || L.haplotag_chromosome(cx, &hr))
+                    die(std::string("longphase_amd: ") + L.last_error(cx));
+            } else if (L.begin_chromosome(cx) || L.push_bam_resident(cx, gi->second.first, (int64_t)n, name_id.data())) die(std::string("longphase_amd: ") + L.last_error(cx));
+            int64_t nb = 0;
+            if (L.haplotag_write_bgzf(cx, status.data(), hp.data(), psv.data(), pq.data(), nullptr, 0, &nb)) die(std::string("longphase_amd: ") + L.last_error(cx));
+            d.z.resize((size_t)nb);
+            if (L.bgzf_deflate_fetch(cx, d.z.data(), (int64_t)d.z.size(), nullptr)) die(std::string("longphase_amd: ") + L.last_error(cx));
+            for (size_t i = 0; i < n; ++i) { ++d.st[status[i] & 7]; if (status[i] == 0) ++d.hpc[hp[i] < 3 ? hp[i] : 0]; }
+        };
+        // deal by compressed size of the contig's blocks (what the index knows), longest first
+        std::vector<size_t> order(chr_vec.size()); for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        auto weight = [&](size_t i) -> uint64_t { const int t = gb.tid_of(chr_vec[i]); return (t < 0 || (size_t)t >= gb.voff.size()) ? 0 : ((gb.voff[(size_t)t].second >> 16) - (gb.voff[(size_t)t].first >> 16)) + 1; };
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight(a) > weight(b); });
+        std::vector<std::vector<size_t>> share((size_t)n_gpus); std::vector<uint64_t> load((size_t)n_gpus, 0);
+        for (size_t i : order) { const size_t g = (size_t)(std::min_element(load.begin(), load.end()) - load.begin()); share[g].push_back(i); load[g] += weight(i); }
+        const int n_dev = std::max(1, L.device_count());
+        auto run_worker = [&](int g, lps_ctx *cx, GpuBam &gg) {
+            std::vector<size_t> mine = share[(size_t)g];
+            std::sort(mine.begin(), mine.end(), [&](size_t a, size_t b) { return gg.tid_of(chr_vec[a]) < gg.tid_of(chr_vec[b]); });   // file order: neighbours share an upload
+            std::vector<std::string> names; for (size_t i : mine) names.push_back(chr_vec[i]);
+            std::map<std::string, size_t> idx; for (size_t i : mine) idx[chr_vec[i]] = i;
+            for (auto &grp : gg.plan_groups(names, group_bytes)) {
+                gg.load_group(L, cx, grp);
+                for (const std::string &c : grp) { Done &d = done[idx[c]]; tag_contig(cx, gg, c, d); { std::lock_guard<std::mutex> lk(mu); d.ready = true; } cv.notify_all(); }
+            }
+            for (size_t i : mine) { std::lock_guard<std::mutex> lk(mu); if (!done[i].ready) { done[i].ready = true; cv.notify_all(); } }     // contigs without records in the file
+        };
+        std::vector<std::thread> workers;
+        for (int g = 1; g < n_gpus; ++g) workers.emplace_back([&, g] {
+            lps_params P; L.default_params(&P); for (auto &f : over) f(P);
+            lps_ctx *cx = L.create((gpu + g) % n_dev, &P); if (!cx) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
+            L.set_stage_timing(cx, 0);
+            GpuBam gg; gg.open_file(bam, true);
+            run_worker(g, cx, gg);
+            L.destroy(cx); gg.close_file();
+        });
+        std::thread first([&] { run_worker(0, ctx, gb); });
+        for (size_t i = 0; i < chr_vec.size(); ++i) {                     // the writer: contigs in VCF-header order
+            std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done[i].ready; }); lk.unlock();
+            if (!done[i].z.empty()) w.write_raw(done[i].z.data(), done[i].z.size());
+            for (int k = 0; k < 8; ++k) st_count[k] += done[i].st[k]; for (int k = 0; k < 3; ++k) hp_count[k] += done[i].hpc[k];
+            std::vector<uint8_t>().swap(done[i].z);
+            std::cerr << "(" << chr_vec[i] << ")";
+        }
+        first.join(); for (auto &x : workers) x.join();
+        std::cerr << "\n";
+        w.finish();
+        L.destroy(ctx);
+        unsigned long long total = 0; for (int k = 0; k < 8; ++k) total += st_count[k];
+        fprintf(stderr, "total alignment %llu | tagged %llu (HP1 %llu, HP2 %llu) | untagged: low mapq %llu, unmapped %llu, secondary %llu, supplementary %llu, no variant %llu, beyond last variant %llu, judged %llu\n",
+                total, hp_count[1] + hp_count[2], hp_count[1], hp_count[2], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6], hp_count[0]);
+        fprintf(stderr, "%d workers (one GPU each, contigs dealt by compressed size) | total %.3fs\n", n_gpus, now() - t_begin);
+        fflush(stderr);
+        if (getenv("LPS_CLI_NO_FAST_EXIT")) return 0;
+        _exit(0);
+    }
+
     std::vector<std::vector<std::string>> groups; if (!host_inflate && gb.indexed) groups = gb.plan_groups(chr_vec, group_bytes);   // output order = chr_vec order; a group = a run of consecutive contigs in it
     for (const std::string &chr : chr_vec) {                          // contigs in VCF-header order (HaplotagProcess.cpp:94-97)
         if (!host_inflate && gb.indexed) {                              // indexed input: the group of consecutive contigs this one belongs to is loaded when its first member comes up

@@ -40,10 +40,13 @@ def test_multi_contig_phase_then_haplotag(inflate, tmp_path):
     assert ("(indexed)" in r.stderr) == inflate.startswith("gpu_indexed")
     ref_vcf = os.path.join(HERE, "golden", "data", "multi_contig.ref_phased.vcf")
     assert _body(d + "/phased.vcf") == _body(ref_vcf)
-    r = subprocess.run([CLI, "haplotag", "-s", ref_vcf, "-b", "reads.bam", "-r", "multi.fa", "-t", "3", "-o", "tagged"] + extra + tag_extra,
+    r = subprocess.run([CLI, "haplotag", "-s", ref_vcf, "-b", "reads.bam", "-r", "multi.fa", "-t", "3", "-o", "tagged"] + extra + tag_extra + workers,
                        cwd=d, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert ("(indexed)" in r.stderr) == inflate.startswith("gpu_indexed")
+    if workers:
+        assert "3 workers" in r.stderr                                 # haplotag --gpus: contigs dealt onto three contexts, written in VCF-header order
+    else:
+        assert ("(indexed)" in r.stderr) == inflate.startswith("gpu_indexed")
     text, refs, recs = util.bam_sections(d + "/tagged.bam")
     assert [l for l in text.split("\n") if l and not l.startswith("@PG")] == gold["header_without_pg"]
     got = util.bam_record_tags(recs)
