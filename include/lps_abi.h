@@ -245,7 +245,8 @@ int lps_push_reads_device(lps_ctx *ctx, const lps_read_batch *batch);
  * between records is ignored); rec_off[i] = byte offset, inside `records`, of record i's refID field (its 4-byte
  * block_size sits just before).  The record core, the CIGAR re-alignment and the seq/qual addressing are decoded on the GPU;
  * seq and qual are used in place.  name_id as in lps_read_batch.  Records must be coordinate-sorted and of one contig.
- * Cannot be mixed with lps_push_reads inside one chromosome.  CIGARs moved to a CG tag (>65535 ops) are rejected. */
+ * Cannot be mixed with lps_push_reads inside one chromosome.  A CIGAR of more than 65535 operations is taken from the record's CG:B,I field, as
+ * htslib's bam_tag2cigar does behind sam_itr_multi_next. */
 int lps_push_bam_records(lps_ctx *ctx, const uint8_t *records, int64_t n_bytes, const uint64_t *rec_off, int64_t n_records, const uint32_t *name_id);
 
 /* --- whole BAM file on the GPU (replaces htslib's BGZF layer behind sam_itr_multi_next, src/phase/ParsingBam.cpp:1279).

@@ -43,7 +43,7 @@ struct lps_ctx {
     DevBuf<uint64_t> r_coff, r_soff, r_qoff; DevBuf<uint32_t> cigar; DevBuf<uint8_t> seq, qual;
     // raw BAM records (lps_push_bam_records): seq/qual are read in place from the blob
     DevBuf<uint8_t> blob; uint64_t n_blob = 0; int read_mode = 0;   // 0 none yet, 1 SoA batches, 2 BAM records
-    DevBuf<uint64_t> rec_off; DevBuf<unsigned long long> cig_cnt; DevBuf<unsigned> bam_err;
+    DevBuf<uint64_t> rec_off, cig_src; DevBuf<unsigned long long> cig_cnt; DevBuf<unsigned> bam_err;
     // whole BAM file resident on the device (lps_bgzf_load): compressed bytes, block table, inflated stream; survives lps_begin_chromosome
     DevBuf<uint8_t> zfile, file; DevBuf<InflateBlock> zblk; uint64_t file_bytes = 0; float bgzf_h2d_ms = 0, bgzf_inflate_ms = 0;
     DevBuf<unsigned long long> tg_len, tg_off; DevBuf<uint2> tg_spans; DevBuf<uint8_t> tg_stream, tg_status, tg_hp; DevBuf<int32_t> tg_ps, tg_pq; int64_t cur_first = -1, cur_count = 0;
@@ -315,9 +315,9 @@ static int push_record_view(lps_ctx *c, const BamView &B, size_t n, const uint32
     for (size_t i = 0; i < n; ++i) c->name_max = std::max(c->name_max, name_id[i]);
     c->r_start.reserve(at + n, s, true, at); c->r_lq.reserve(at + n, s, true, at); c->r_flag.reserve(at + n, s, true, at); c->r_mapq.reserve(at + n, s, true, at);
     c->r_soff.reserve(at + n + 1, s, true, at); c->r_qoff.reserve(at + n + 1, s, true, at); c->r_coff.reserve(at + n + 1, s, true, at);
-    c->cig_cnt.reserve(n + 1); c->bam_err.reserve(1);
+    c->cig_cnt.reserve(n + 1); c->cig_src.reserve(n + 1); c->bam_err.reserve(1);
     HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s));
-    launch_bam_core(B, (int)n, (int)at, c->r_start.p, c->r_lq.p, c->r_flag.p, c->r_mapq.p, c->r_soff.p, c->r_qoff.p, c->cig_cnt.p, c->bam_err.p, s);
+    launch_bam_core(B, (int)n, (int)at, c->r_start.p, c->r_lq.p, c->r_flag.p, c->r_mapq.p, c->r_soff.p, c->r_qoff.p, c->cig_cnt.p, c->cig_src.p, c->bam_err.p, s);
     bam_cigar_offsets(c->temp, c->temp_bytes, c->cig_cnt.p, c->r_coff.p + at, (int)n, c->n_cig, s);
     uint64_t total = 0; unsigned err = 0;
     HIP_TRY(hipMemcpyAsync(&total, c->r_coff.p + at + n, sizeof total, hipMemcpyDeviceToHost, s));
@@ -325,9 +325,8 @@ static int push_record_view(lps_ctx *c, const BamView &B, size_t n, const uint32
     HIP_TRY(hipStreamSynchronize(s));
     if (err & LPS_BAM_ERR_BOUNDS) return fail(c, "BAM record does not fit the bytes handed over (truncated or corrupt record)");
     if (err & LPS_BAM_ERR_UNSORTED) return fail(c, "alignments must be coordinate-sorted");
-    if (err & LPS_BAM_ERR_CG_TAG) return fail(c, "CIGAR stored in a CG tag (more than 65535 operations) is not supported");
     c->cigar.reserve(total + 1, s, true, c->n_cig);
-    launch_bam_cigar(B, (int)n, c->r_coff.p + at, c->cigar.p, s);
+    launch_bam_cigar(B, (int)n, c->r_coff.p + at, c->cig_src.p, c->cigar.p, s);
     HIP_TRY(hipStreamSynchronize(s));
     c->nR += (int)n; c->n_cig = total;
     c->phase_valid = false;
@@ -733,7 +732,8 @@ static int run_late(lps_ctx *c, bool with_cnv) {
         launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->rows.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->late_cap_main, c->late_tail, c->mrow_off.p, c->mrow_cnt.p, c->multi_list.p, s);
         // ---- node-major sorted lists
         mark(c, ST_NODELISTS);
-        c->m_bits = bits_for((unsigned long long)nR + 1); c->n_bits = bits_for((unsigned long long)nV + 2); c->a_bits = 16;
+        c->m_bits = bits_for((unsigned long long)nR + 1); c->n_bits = bits_for((unsigned long long)nV + 2);
+        c->a_bits = bits_for(2ull * (unsigned long long)nV + 2);        // index inside a merged row: a row holds every variant once per alignment of the read at most, and overlapping alignments are rare pairs
         if (c->m_bits + c->n_bits + c->a_bits > 63) { c->err = "sort key overflow"; return -4; }
         c->nkeys.reserve(c->late_n_keys + 1); c->nkeys_s.reserve(c->late_n_keys + 1); c->nvals.reserve(c->late_n_keys + 1); c->nvals_s.reserve(c->late_n_keys + 1);
         launch_node_lists(c->d_cnt, nR, nV, c->mrow_off.p, c->mrow_cnt.p, c->koff.p, c->g_node.p, c->m_bits, c->a_bits, c->n_bits, c->nkeys.p, c->nkeys_s.p, c->nvals.p, c->nvals_s.p, c->late_n_keys, c->node_off.p, c->node_end.p, c->node_cur.p, c->temp.p, c->temp_bytes, s);
@@ -913,7 +913,7 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
             c->h_cnt = *c->h_cnt_pin; memcpy(c->h_stats, c->h_stats_pin, sizeof c->h_stats);
         }
         if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = c->obs_capacity * 2 + 64 * 1024; return lps_phase_chromosome(c, out); }
-        if (c->h_cnt.err & LPS_ERR_KEY_RANGE) return fail(c, "a merged read has more than 65536 observations", -6);
+        if (c->h_cnt.err & LPS_ERR_KEY_RANGE) return fail(c, "a merged read holds more than twice as many observations as there are variants", -6);
         c->cnv_expect = !c->h_cnv_start.empty();
         deliver_result(c, out);
         // timings

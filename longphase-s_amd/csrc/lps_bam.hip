@@ -23,14 +23,47 @@ __device__ __forceinline__ uint32_t ld_u32_unaligned(const uint8_t *p) {
 }
 __device__ __forceinline__ uint32_t ld_u16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 
+__device__ __forceinline__ uint32_t aux_len_dev(const uint8_t *p, const uint8_t *end) {       // bytes of one optional field, 0 = malformed
+    if (p + 3 > end) return 0;
+    const uint8_t t = p[2]; uint64_t v;
+    if (t == 'A' || t == 'c' || t == 'C') v = 1; else if (t == 's' || t == 'S') v = 2; else if (t == 'i' || t == 'I' || t == 'f') v = 4; else if (t == 'd') v = 8;
+    else if (t == 'Z' || t == 'H') { const uint8_t *q = p + 3; while (q < end && *q) ++q; if (q >= end) return 0; v = (uint64_t)(q - (p + 3)) + 1; }
+    else if (t == 'B') { if (p + 8 > end) return 0; const uint8_t st = p[3]; const uint64_t cnt = ld_u32_unaligned(p + 4);
+        const uint64_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0; if (!es) return 0; v = 5 + cnt * es; }
+    else return 0;
+    return (p + 3 + v <= end) ? (uint32_t)(3 + v) : 0u;
+}
+
+// CIGARs of more than 65535 operations (ultra-long ONT reads) do not fit the 16-bit n_cigar_op: the record then carries the placeholder
+// <l_seq>S<ref_len>N and the real CIGAR in an optional field CG:B,I (SAM spec 4.2.2).  htslib moves it back when it reads a record (bam_tag2cigar,
+// behind sam_itr_multi_next, src/phase/ParsingBam.cpp:1279) under exactly these conditions; -> offset of the field from the refID field (0: none)
+__device__ __forceinline__ uint32_t find_cg_field(const uint8_t *r, uint32_t block_size, uint32_t l_name, uint32_t n_cig, uint32_t l_seq, int32_t tid, int32_t pos, uint32_t *count) {
+    if (n_cig == 0 || tid < 0 || pos < 0) return 0;
+    const uint32_t c0 = ld_u32_unaligned(r + 32 + l_name);
+    if ((c0 & 15u) != 4u || (c0 >> 4) != l_seq) return 0;
+    const uint8_t *p = r + 32 + l_name + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq, *end = r + block_size;
+    while (p < end) {
+        const uint32_t l = aux_len_dev(p, end); if (!l) return 0;
+        if (p[0] == 'C' && p[1] == 'G') {                                // bam_aux_get: the first field of that name
+            if (p[2] != 'B' || !(p[3] == 'I' || p[3] == 'i')) return 0;
+            const uint32_t cnt = ld_u32_unaligned(p + 4);
+            if (cnt < n_cig || cnt >= (1u << 29)) return 0;
+            *count = cnt; return (uint32_t)(p - r);
+        }
+        p += l;
+    }
+    return 0;
+}
+
+
 __global__ void __launch_bounds__(256) k_bam_core(BamView B, int n, int at, int32_t *ref_start, int32_t *l_qseq, uint16_t *flag, uint8_t *mapq,
-                                                  uint64_t *seq_off, uint64_t *qual_off, unsigned long long *cig_cnt, unsigned *err) {
+                                                  uint64_t *seq_off, uint64_t *qual_off, unsigned long long *cig_cnt, uint64_t *cig_src, unsigned *err) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i > n) return;
     if (i == n) { cig_cnt[n] = 0; return; }
     const uint64_t ro = B.rec_off[i];
     unsigned e = 0;
-    if (ro < 4 || ro + 32 > B.push_bytes) { atomicOr(err, LPS_BAM_ERR_BOUNDS); cig_cnt[i] = 0; ref_start[at + i] = 0; l_qseq[at + i] = 0; flag[at + i] = 4; mapq[at + i] = 0; seq_off[at + i] = qual_off[at + i] = B.push_base; return; }
+    if (ro < 4 || ro + 32 > B.push_bytes) { atomicOr(err, LPS_BAM_ERR_BOUNDS); cig_cnt[i] = 0; cig_src[i] = B.push_base; ref_start[at + i] = 0; l_qseq[at + i] = 0; flag[at + i] = 4; mapq[at + i] = 0; seq_off[at + i] = qual_off[at + i] = B.push_base; return; }
     const uint8_t *r = B.blob + B.push_base + ro;
     const uint32_t block_size = ld_u32_unaligned(r - 4);
     const int32_t pos = (int32_t)ld_u32_unaligned(r + 4);
@@ -42,34 +75,34 @@ __global__ void __launch_bounds__(256) k_bam_core(BamView B, int n, int at, int3
         if (rp >= 4 && rp + 32 <= B.push_bytes && (int32_t)ld_u32_unaligned(B.blob + B.push_base + rp + 4) > pos) e |= LPS_BAM_ERR_UNSORTED;
         if (rp >= ro) e |= LPS_BAM_ERR_BOUNDS;
     }
-    if (!e && n_cig == 2) {                                           // htslib's placeholder for >65535 ops: <l_seq>S<ref_len>N + CG:B,I tag
-        const uint32_t c0 = ld_u32_unaligned(r + 32 + l_name), c1 = ld_u32_unaligned(r + 36 + l_name);
-        if ((c0 & 15u) == 4u && (c0 >> 4) == l_seq && (c1 & 15u) == 3u) e |= LPS_BAM_ERR_CG_TAG;
+    uint32_t n_real = n_cig; uint64_t src = B.push_base + ro + 32 + l_name;
+    if (!e) {                                                         // the real CIGAR of a record with more than 65535 operations sits in its CG:B,I field
+        uint32_t cnt = 0; const uint32_t cg = find_cg_field(r, block_size, l_name, n_cig, l_seq, (int32_t)ld_u32_unaligned(r), pos, &cnt);
+        if (cg) { n_real = cnt; src = B.push_base + ro + cg + 8; }
     }
     if (e) atomicOr(err, e);
     const bool ok = (e & LPS_BAM_ERR_BOUNDS) == 0;
     ref_start[at + i] = pos; l_qseq[at + i] = ok ? (int32_t)l_seq : 0; flag[at + i] = (uint16_t)fl; mapq[at + i] = (uint8_t)mq;
-    cig_cnt[i] = ok ? n_cig : 0;
+    cig_cnt[i] = ok ? n_real : 0; cig_src[i] = src;
     const uint64_t so = B.push_base + ro + 32 + l_name + 4ull * n_cig;
     seq_off[at + i] = ok ? so : B.push_base; qual_off[at + i] = ok ? so + (l_seq + 1ull) / 2 : B.push_base;
 }
 
-__global__ void __launch_bounds__(256) k_bam_cigar(BamView B, int n, const uint64_t *cigar_off /* [n+1], absolute */, uint32_t *cigar) {
+__global__ void __launch_bounds__(256) k_bam_cigar(BamView B, int n, const uint64_t *cigar_off /* [n+1], absolute */, const uint64_t *cig_src, uint32_t *cigar) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const uint64_t c0 = cigar_off[i]; const int n_cig = (int)(cigar_off[i + 1] - c0);
     if (n_cig == 0) return;
-    const uint8_t *r = B.blob + B.push_base + B.rec_off[i];
-    const uint8_t *src = r + 32 + r[8];
+    const uint8_t *src = B.blob + cig_src[i];                            // behind the read name, or inside the CG field
     for (int j = lane; j < n_cig; j += 64) cigar[c0 + j] = ld_u32_unaligned(src + 4ull * j);
 }
 
 void launch_bam_core(const BamView &B, int n, int at, int32_t *ref_start, int32_t *l_qseq, uint16_t *flag, uint8_t *mapq, uint64_t *seq_off,
-                     uint64_t *qual_off, unsigned long long *cig_cnt, unsigned *err, hipStream_t s) {
-    hipLaunchKernelGGL(k_bam_core, dim3((n + 1 + 255) / 256), dim3(256), 0, s, B, n, at, ref_start, l_qseq, flag, mapq, seq_off, qual_off, cig_cnt, err);
+                     uint64_t *qual_off, unsigned long long *cig_cnt, uint64_t *cig_src, unsigned *err, hipStream_t s) {
+    hipLaunchKernelGGL(k_bam_core, dim3((n + 1 + 255) / 256), dim3(256), 0, s, B, n, at, ref_start, l_qseq, flag, mapq, seq_off, qual_off, cig_cnt, cig_src, err);
 }
-void launch_bam_cigar(const BamView &B, int n, const uint64_t *cigar_off, uint32_t *cigar, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_bam_cigar, dim3((n + 3) / 4), dim3(256), 0, s, B, n, cigar_off, cigar);
+void launch_bam_cigar(const BamView &B, int n, const uint64_t *cigar_off, const uint64_t *cig_src, uint32_t *cigar, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_bam_cigar, dim3((n + 3) / 4), dim3(256), 0, s, B, n, cigar_off, cig_src, cigar);
 }
 
 // cigar_off[at + i] = init + sum_{k<i} cig_cnt[k], i = 0..n  (cig_cnt[n] == 0)
@@ -203,26 +236,19 @@ void launch_bam_names(const uint8_t *d, const uint64_t *cand, uint32_t n, const 
 // ================================================================================================ tagged-record stream (haplotag writer)
 // HaplotagProcess.cpp:337-361 on the device: a scored record loses its first HP, PS and PQ optional field and, when tagged, gains HP:i PS:i PQ:i;
 // every other record is copied untouched.  k_tag_sizes walks the optional fields (thread per record), k_tag_write copies bytes (wave per record).
-__device__ __forceinline__ uint32_t aux_len_dev(const uint8_t *p, const uint8_t *end) {       // bytes of one optional field, 0 = malformed
-    if (p + 3 > end) return 0;
-    const uint8_t t = p[2]; uint64_t v;
-    if (t == 'A' || t == 'c' || t == 'C') v = 1; else if (t == 's' || t == 'S') v = 2; else if (t == 'i' || t == 'I' || t == 'f') v = 4; else if (t == 'd') v = 8;
-    else if (t == 'Z' || t == 'H') { const uint8_t *q = p + 3; while (q < end && *q) ++q; if (q >= end) return 0; v = (uint64_t)(q - (p + 3)) + 1; }
-    else if (t == 'B') { if (p + 8 > end) return 0; const uint8_t st = p[3]; const uint64_t cnt = ld_u32_unaligned(p + 4);
-        const uint64_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0; if (!es) return 0; v = 5 + cnt * es; }
-    else return 0;
-    return (p + 3 + v <= end) ? (uint32_t)(3 + v) : 0u;
-}
-
 __global__ void __launch_bounds__(256) k_tag_sizes(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, unsigned long long *new_len,
-                                                   uint2 *spans /* [n][3] (offset from refID, length), sorted by offset, length 0 = none */, unsigned *err) {
+                                                   uint2 *spans /* [n][4] (offset from refID, length), sorted by offset, length 0 = none; [3] = the CG field, re-appended at the end */, unsigned *err) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i > n) return;
     if (i == n) { new_len[n] = 0; return; }
     const uint64_t r = rec[i]; const uint32_t bs = ld_u32_unaligned(d + r - 4);
-    uint2 sp[3] = {{0, 0}, {0, 0}, {0, 0}}; uint32_t removed = 0;
+    uint2 sp[3] = {{0, 0}, {0, 0}, {0, 0}}; uint2 cgs = {0, 0}; uint32_t removed = 0;
+    const uint32_t l_name = d[r + 8], n_cig = ld_u16(d + r + 12), l_seq = ld_u32_unaligned(d + r + 16);
+    {   // a record htslib would have read through bam_tag2cigar is written with its CG field LAST (bam_write1 re-creates placeholder + field), scored or not
+        uint32_t cnt = 0; const uint32_t cg = find_cg_field(d + r, bs, l_name, n_cig, l_seq, (int32_t)ld_u32_unaligned(d + r), (int32_t)ld_u32_unaligned(d + r + 4), &cnt);
+        if (cg) { cgs.x = cg; cgs.y = 8u + 4u * cnt; }
+    }
     if (status[i] == 0) {
-        const uint32_t l_name = d[r + 8], n_cig = ld_u16(d + r + 12), l_seq = ld_u32_unaligned(d + r + 16);
         const uint8_t *p = d + r + 32 + l_name + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq, *end = d + r + bs; int k = 0; bool seen[3] = {false, false, false};
         while (p < end) {
             const uint32_t l = aux_len_dev(p, end); if (!l) { atomicOr(err, 1u); break; }
@@ -231,7 +257,7 @@ __global__ void __launch_bounds__(256) k_tag_sizes(const uint8_t *d, const uint6
             p += l;
         }
     }
-    spans[(size_t)i * 3 + 0] = sp[0]; spans[(size_t)i * 3 + 1] = sp[1]; spans[(size_t)i * 3 + 2] = sp[2];
+    spans[(size_t)i * 4 + 0] = sp[0]; spans[(size_t)i * 4 + 1] = sp[1]; spans[(size_t)i * 4 + 2] = sp[2]; spans[(size_t)i * 4 + 3] = cgs;
     new_len[i] = 4ull + bs - removed + ((status[i] == 0 && hp[i]) ? 21u : 0u);
 }
 
@@ -240,15 +266,21 @@ __global__ void __launch_bounds__(256) k_tag_write(const uint8_t *d, const uint6
     const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const uint64_t r = rec[i]; const uint32_t bs = ld_u32_unaligned(d + r - 4);
-    const uint2 s0 = spans[(size_t)i * 3], s1 = spans[(size_t)i * 3 + 1], s2 = spans[(size_t)i * 3 + 2];
-    const uint32_t kept = bs - s0.y - s1.y - s2.y; const bool tag = status[i] == 0 && hp[i] != 0; const uint32_t nbs = kept + (tag ? 21u : 0u);
+    const uint2 s0 = spans[(size_t)i * 4], s1 = spans[(size_t)i * 4 + 1], s2 = spans[(size_t)i * 4 + 2], cg = spans[(size_t)i * 4 + 3];
+    const uint32_t kept = bs - s0.y - s1.y - s2.y - cg.y; const bool tag = status[i] == 0 && hp[i] != 0; const uint32_t nbs = kept + (tag ? 21u : 0u) + cg.y;
     uint8_t *o = out + out_off[i];
     if (lane < 4) o[lane] = (uint8_t)(nbs >> (8 * lane));
     for (uint32_t j = lane; j < kept; j += 64) {
+        // the dropped spans in offset order (the CG field can sit anywhere among them)
         uint32_t src = j;
-        if (s0.y && src >= s0.x) src += s0.y;
-        if (s1.y && src >= s1.x) src += s1.y;
-        if (s2.y && src >= s2.x) src += s2.y;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            uint2 lo = {0xffffffffu, 0};                                  // the pass-th smallest offset among the spans in use
+            const uint2 all[4] = {s0, s1, s2, cg};
+            int taken = 0;
+            for (int a = 0; a < 4; ++a) if (all[a].y) { int before = 0; for (int b2 = 0; b2 < 4; ++b2) if (all[b2].y && (all[b2].x < all[a].x)) ++before; if (before == pass) { lo = all[a]; taken = 1; } }
+            if (taken && src >= lo.x) src += lo.y;
+        }
         o[4 + j] = d[r + src];
     }
     if (tag && lane < 21) {                                               // addAuxiliaryTags: HP:i PS:i PQ:i, 7 bytes each
@@ -256,13 +288,14 @@ __global__ void __launch_bounds__(256) k_tag_write(const uint8_t *d, const uint6
         const char *nm = f == 0 ? "HP" : f == 1 ? "PS" : "PQ";
         o[4 + kept + lane] = b < 2 ? (uint8_t)nm[b] : b == 2 ? (uint8_t)'i' : (uint8_t)(val >> (8 * (b - 3)));
     }
+    for (uint32_t j = lane; j < cg.y; j += 64) o[4 + kept + (tag ? 21u : 0u) + j] = d[r + cg.x + j];   // ... and the CG field behind everything else
 }
 
 // -> total bytes of prefix + re-tagged records in `stream`; -1 when an optional field is malformed
 int64_t bam_tag_stream(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, uint64_t prefix_bytes,
                        DevBuf<unsigned long long> &new_len, DevBuf<unsigned long long> &out_off, DevBuf<uint2> &spans, DevBuf<uint8_t> &stream, DevBuf<char> &temp, size_t &temp_bytes,
                        unsigned *err, hipStream_t s) {
-    new_len.reserve((size_t)n + 1, s); out_off.reserve((size_t)n + 1, s); spans.reserve((size_t)n * 3 + 3, s);
+    new_len.reserve((size_t)n + 1, s); out_off.reserve((size_t)n + 1, s); spans.reserve((size_t)n * 4 + 4, s);
     HIP_TRY(hipMemsetAsync(err, 0, sizeof(unsigned), s));
     hipLaunchKernelGGL(k_tag_sizes, dim3((n + 256) / 256), dim3(256), 0, s, d, rec, n, status, hp, new_len.p, spans.p, err);
     size_t need = 0;

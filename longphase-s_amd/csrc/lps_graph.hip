@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void k_node_scatter(const LpsCounters *cnt, co
     if (g == 0 && sl == 0) cntw->n_obs_final = node_off[n_var];         // sum of merged rows = end of the last node's list
     if (g >= cnt->n_groups) return;
     const int n = mrow_cnt[g];
-    if (n > (1 << a_bits)) { if (sl == 0) atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); return; }
+    if ((unsigned long long)n > (1ull << a_bits)) { if (sl == 0) atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); return; }
     const uint32_t off = mrow_off[g];
     for (int a = sl; a < n; a += ROW_G) {
         const int nd = g_node[off + a];

@@ -263,8 +263,15 @@ class BamRecords:
             sq = R.seq[int(R.seq_off[i]):int(R.seq_off[i]) + (lq + 1) // 2]
             ql = R.qual[int(R.qual_off[i]):int(R.qual_off[i]) + lq]
             aux = rng.integers(0, 256, int(rng.integers(0, 9)), dtype=np.uint8).tobytes()
-            body = struct.pack("<iiBBHHHiiii", 0, int(R.ref_start[i]), len(nm), int(R.mapq[i]), 4680, cg.size, int(R.flag[i]), lq, -1, -1, 0)
-            body += nm + cg.astype("<u4").tobytes() + sq.tobytes() + ql.tobytes() + aux
+            cgw = cg
+            if cg.size > 65535:
+                # more operations than the 16-bit n_cigar_op holds: placeholder <l_seq>S<ref_len>N + the real CIGAR in a CG:B,I field (SAM spec 4.2.2),
+                # here between two ordinary fields
+                rlen = int(sum(int(w) >> 4 for w in cg if (int(w) & 15) in (0, 2, 3, 7, 8)))
+                cgw = np.array([(lq << 4) | 4, (rlen << 4) | 3], dtype=np.uint32)
+                aux = b"NMi" + struct.pack("<i", 5) + b"CGBI" + struct.pack("<I", cg.size) + cg.astype("<u4").tobytes() + b"XSZabc\0"
+            body = struct.pack("<iiBBHHHiiii", 0, int(R.ref_start[i]), len(nm), int(R.mapq[i]), 4680, cgw.size, int(R.flag[i]), lq, -1, -1, 0)
+            body += nm + cgw.astype("<u4").tobytes() + sq.tobytes() + ql.tobytes() + aux
             out += struct.pack("<i", len(body))
             off.append(len(out))
             out += body

@@ -89,6 +89,48 @@ def test_chr20_30x_with_clip_pile_ups_cnv_filter_active():
             util.assert_phase_equal(out.phase_set, out.gt, want.phase_set, want.gt, f"chr20_30x pile-ups, call {call}")
 
 
+def test_ultra_long_read_cg_tag_cigar_and_row_longer_than_65536():
+    """One read of 70 000 CIGAR operations over 77 000 dense variants: as a BAM record its CIGAR sits in a CG:B,I field (more than 65 535
+    operations, htslib expands it behind sam_itr_multi_next), its row of observations is longer than 2^16 (the old sort-key field), and the
+    extraction sends it through k_extract_redo's direct-to-memory path."""
+    g = SynthGpu(0, seed=77, contig_len=400_000, n_snp=79_000, coverage=3.0, hpoly_every=400)
+    h = g.to_host(); g.close()
+    R0 = abi.Reads.from_synth(h)
+    # the long read: (10M 1I) x 35 000 from position 1 000, bases copied from the reference (ALT at every 3rd variant), inserted bases 'A'
+    start, n_blk = 1000, 35_000
+    code = {65: 1, 67: 2, 71: 4, 84: 8}
+    ref = h.ref.copy()
+    alt_at = {int(p): int(a) for p, a in zip(h.var_pos[::3], h.var_alt0[::3])}
+    span = ref[start:start + 10 * n_blk].copy()
+    for p, a in alt_at.items():
+        if start <= p < start + 10 * n_blk:
+            span[p - start] = a
+    q = np.empty(11 * n_blk, np.uint8)
+    q.reshape(n_blk, 11)[:, :10] = span.reshape(n_blk, 10); q.reshape(n_blk, 11)[:, 10] = 65
+    nib = np.vectorize(code.get)(q).astype(np.uint8)
+    seq = (nib[0::2] << 4) | np.append(nib[1::2], 0)[:(q.size + 1) // 2]
+    qual = np.full(q.size, 30, np.uint8)
+    cig = np.tile(np.array([(10 << 4) | 0, (1 << 4) | 1], np.uint32), n_blk)
+    at = int(np.searchsorted(R0.ref_start, start, side="right"))
+    def ins(a, v): return np.concatenate([a[:at], np.asarray(v, a.dtype), a[at:]])
+    def ins_rows(off, data, row):
+        o = off.astype(np.int64); cut = int(o[at])
+        return np.concatenate([o[:at + 1], o[at:] + len(row)]).astype(np.uint64), np.concatenate([data[:cut], row, data[cut:]])
+    co, cg = ins_rows(R0.cigar_off, R0.cigar, cig); so, sq = ins_rows(R0.seq_off, R0.seq, seq); qo, ql = ins_rows(R0.qual_off, R0.qual, qual)
+    R = abi.Reads(ref_start=ins(R0.ref_start, [start]), flag=ins(R0.flag, [0]), mapq=ins(R0.mapq, [60]), l_qseq=ins(R0.l_qseq, [q.size]),
+                  name_id=ins(R0.name_id, [int(R0.name_id.max()) + 7]), cigar_off=co, cigar=cg, seq_off=so, seq=sq, qual_off=qo, qual=ql)
+    V = abi.Variants.from_snps(h.var_pos, h.var_ref0, h.var_alt0)
+    P = abi.default_params()
+    want, d = lps_oracle.phase(P, V, h.ref, R, dump=True)
+    assert d.obs_count.max() > 65536
+    B = abi.BamRecords.from_reads(R, seed=3)
+    for reads, what in ((R, "decoded arrays"), (B, "BAM records with a CG field")):
+        with hip.Context(0, P) as ctx:
+            out = ctx.phase(V, h.ref, [reads])
+            util.assert_stages_equal(ctx, d, "ultra-long read, " + what)
+            util.assert_phase_equal(out.phase_set, out.gt, want.phase_set, want.gt, "ultra-long read, " + what)
+
+
 def test_device_push_rejects_bad_operands():
     """lps_push_reads_device runs the operand checks of lps_push_reads as a kernel."""
     g = SynthGpu(0, seed=5, contig_len=400_000, n_snp=400, coverage=8.0)
