@@ -121,7 +121,7 @@ def pin(arr):
     return hiprt.hipHostRegister(arr.ctypes.data, arr.nbytes, 0) == 0
 
 
-def cpu_baseline(g, spec, threads, port):
+def cpu_baseline(g, spec, threads, port, gpu_result=None):
     """The reference binary (oracle/_ref/longphase-s-ref: BAM + VCF + FASTA in, phased VCF out, incl. BGZF/BAM decode) on ONE WHOLE contig
     of the benched workload; kind 'port' (the oracle restatement on decoded arrays, 1 thread) when the binary is not there."""
     sample = f"whole contig {spec['name']} of the benched workload ({spec['contig_len']} bp, {spec['coverage']:.0f}x, {g.n_reads} alignments, {g.n_variants} het SNPs)"
@@ -144,11 +144,21 @@ def cpu_baseline(g, spec, threads, port):
             for _ in range(2):                       # first run also warms the page cache
                 t0 = time.time(); r = subprocess.run(cmd, cwd=d, capture_output=True); ts.append(time.time() - t0)
                 assert r.returncode == 0, r.stderr[-500:]
-            n_ph = sum(1 for ln in open(d + "/out.vcf") if not ln.startswith("#") and not ln.rstrip().endswith(":."))
+            n_ph = 0; same = True; vi = 0
+            for ln in open(d + "/out.vcf"):                      # the reference's phased VCF against the GPU result of the same contig, row by row
+                if ln.startswith("#"):
+                    continue
+                f = ln.rstrip("\n").split("\t"); smp = f[9].split(":")
+                ps = 0 if smp[-1] == "." else int(smp[-1])
+                n_ph += ps != 0
+                if gpu_result is not None:
+                    same = same and int(f[1]) - 1 == int(gpu_result[0][vi]) and ps == int(gpu_result[1][vi]) and (ps == 0 or smp[0] == ("1|0" if gpu_result[2][vi] else "0|1"))
+                vi += 1
+            same = same and (gpu_result is None or vi == len(gpu_result[0]))
             stages = [ln.strip() for ln in r.stderr.decode(errors="replace").splitlines() if "total" in ln.lower() or "parsing" in ln.lower()][-4:]
         return dict(value=float(n_ph / min(ts)), unit="SNPs/s", cores=threads, kind="reference",
                     sample=sample + f"; best of 2 runs of `longphase-s phase -t {threads} --ont` end to end (one contig => one compute thread, the others feed BGZF)",
-                    wall_s=round(min(ts), 2), n_phased=n_ph, reference_stage_lines=stages,
+                    wall_s=round(min(ts), 2), n_phased=n_ph, identical_to_gpu_result=(bool(same) if gpu_result is not None else None), reference_stage_lines=stages,
                     port_value=port.get("value") if port else None, port_note="oracle restatement, decoded arrays in memory, one thread")
     except Exception as e:  # noqa: BLE001
         log("cpu_baseline: reference run failed, reporting the port:", repr(e)[:300])
@@ -229,7 +239,7 @@ def main():
         if spec["name"] in parity_set or (rank == 0 and spec["name"] == cpu_name):
             t0 = time.time(); host = g.to_host(); d2h_s += time.time() - t0
         if rank == 0 and spec["name"] == cpu_name and not a.no_cpu_baseline:
-            cpu_pick = (g, spec)            # keeps its device arrays for the SAM writer; everything else is released below
+            cpu_pick = [g, spec, None]      # keeps its device arrays for the SAM writer; everything else is released below
         else:
             g.release_reads()
         out = abi.PhaseOut(V.n)
@@ -246,6 +256,8 @@ def main():
         elapsed += dt
         tm = ctx.timings()
         n_ph = int((out.phase_set != 0).sum())
+        if cpu_pick is not None and cpu_pick[0] is g:
+            cpu_pick[2] = (V.pos.copy(), out.phase_set.copy(), out.gt.copy())
         total_phased += n_ph; total_reads += g.n_reads; total_bases += g.n_bases
         rec = dict(contig=spec["name"], alignments=g.n_reads, snps=V.n, phased=n_ph, gbases=round(g.n_bases / 1e9, 2), ms_per_step=dt / a.steps * 1e3,
                    extract_ms=extract_ms / a.steps, obs=tm["n_obs"], pairs=tm["n_pairs"], nodes=tm["n_nodes"], alg=tm["algorithmic_bytes"],
@@ -361,7 +373,7 @@ def main():
             res["rccl"] = bcast["_info"]
         if not a.no_cpu_baseline and cpu_pick is not None:
             t0 = time.time()
-            res["cpu_baseline"] = cpu_baseline(cpu_pick[0], cpu_pick[1], a.cpu_threads or min(16, ncpu), port)
+            res["cpu_baseline"] = cpu_baseline(cpu_pick[0], cpu_pick[1], a.cpu_threads or min(16, ncpu), port, cpu_pick[2])
             cpu_pick[0].close()
             log(f"cpu baseline took {time.time()-t0:.1f}s")
         elif port:

@@ -40,7 +40,9 @@
 
 static const char *kVersion = "1.0.0-mi355x";
 
-[[noreturn]] static void die(const std::string &m) { std::cerr << m << "\n"; exit(1); }
+// Errors end the process at once, from whatever thread: _exit skips the static destructors and the ROCm runtime's teardown, which would otherwise race
+// with the streams of worker threads that are still running (--gpus N) - exit(1) from a worker could hang or crash on the way out.
+[[noreturn]] static void die(const std::string &m) { std::cerr << m << "\n"; std::cerr.flush(); fflush(nullptr); _exit(1); }
 static const size_t kGpuInflateMinBytes = 256u << 20;
 static size_t file_bytes(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 ? (size_t)st.st_size : 0; }
 

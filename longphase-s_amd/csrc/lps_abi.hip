@@ -52,7 +52,7 @@ struct lps_ctx {
     DevBuf<uint64_t> rcand; uint64_t n_rec_all = 0; DevBuf<int32_t> r_tid_all; DevBuf<uint32_t> r_lname, r_nameoff, wg_cnt, wg_off, scan_nout; DevBuf<uint8_t> names_d; bool names_ready = false;
     // observations
     DevBuf<RowDesc> rows; DevBuf<int32_t> g_cnt; DevBuf<uint8_t> deleted;
-    DevBuf<ObsRec> obs; DevBuf<int32_t> g_node; DevBuf<uint8_t> g_flag; DevBuf<uint32_t> redo_list;
+    DevBuf<ObsRec> obs; DevBuf<int32_t> g_node; DevBuf<uint8_t> g_flag; DevBuf<uint32_t> redo_list; DevBuf<uint2> hit_ovf; unsigned ovf_chunks = 0;
     unsigned long long obs_capacity = 0;   // main arenas (LPS_ARENAS equal parts); a tail arena of obs_capacity/4 follows
     DevBuf<unsigned long long> arena_ctr;
     bool in_phase = false; int timing_level = 1;
@@ -501,7 +501,8 @@ int lps_bgzf_load(lps_ctx *c, const uint8_t *bgzf, int64_t n_bytes, int64_t *inf
         auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double th0 = tnow();
         // the upload needs nothing but the byte count, so it starts now and the header walk below runs beside it
-        hipStream_t s = c->stream; hipEvent_t e0, e1, e2;
+        hipStream_t s = c->stream; hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+        struct Events { hipEvent_t &a, &b, &c; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); if (c) (void)hipEventDestroy(c); } } ev_guard{e0, e1, e2};   // every early return below releases them
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
         c->zfile.reserve((uint64_t)n_bytes + 64, s);
         HIP_TRY(hipEventRecord(e0, s));
@@ -542,7 +543,6 @@ int lps_bgzf_load(lps_ctx *c, const uint8_t *bgzf, int64_t n_bytes, int64_t *inf
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipEventElapsedTime(&c->bgzf_h2d_ms, e0, e1)); HIP_TRY(hipEventElapsedTime(&c->bgzf_inflate_ms, e1, e2));
         if (getenv("LPS_DEBUG")) fprintf(stderr, "[lps_bgzf_load] %zu blocks: header walk beside the upload %.1f ms | wait for upload + device alloc %.1f ms | inflate + crc (host wall) %.1f ms (kernels %.1f)\n", blks.size(), th1 - th0, th2 - th1, tnow() - th2, c->bgzf_inflate_ms);
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
         c->file_bytes = 0; c->n_rec_all = 0; c->names_ready = false;
         if (err) return fail(c, err & LPS_INF_ERR_DATA ? "lps_bgzf_load: corrupt deflate stream" : err & (LPS_INF_ERR_SIZE | LPS_INF_ERR_OVERRUN) ? "lps_bgzf_load: a block does not inflate to its ISIZE"
                                                                 : "lps_bgzf_load: CRC32 mismatch in a BGZF block");
@@ -764,6 +764,8 @@ static int run_phase(lps_ctx *c) {
         const unsigned long long cap = cap_main + tail_size;
         if (cap > 0xffffffffull) { c->err = "observation arena exceeds 2^32 slots"; return -8; }
         c->rows.reserve(nR + 4); c->redo_list.reserve((size_t)nR / 4 + 4);
+        c->ovf_chunks = (unsigned)((size_t)nR / 4 / 8 + 256);              // chunks of the global hit list: an eighth of the waves may take one
+        c->hit_ovf.reserve((size_t)c->ovf_chunks * LPS_EXT_OVF_HITS);
         c->g_cnt.reserve(nR + 1);
         c->obs.reserve(cap); c->g_node.reserve(cap); c->g_flag.reserve(cap);
         c->clip_capacity = (size_t)4 * nR + 64;                             // clip events (an alignment has two real clips at most; more only with H S ... S H)
@@ -805,9 +807,9 @@ static int run_phase(lps_ctx *c) {
         launch_variant_prep(V, P.is_ont, c->v_bucket.p, c->v_rec.p, s);
         // ---- a1/a2/a3 extraction
         ObsView O{c->rows.p, c->obs.p, arena_size, c->arena_ctr.p, n_arenas};
-        ClipView C{c->clip_ev.p, c->clip_stats.p, (unsigned)c->clip_capacity};            // clip_stats[0]: events appended, [1]: waves queued for k_extract_redo (zero pool)
+        ClipView C{c->clip_ev.p, c->clip_stats.p, (unsigned)c->clip_capacity};            // clip_stats[0]: events appended, [1]: waves queued for k_extract_redo, [3]: chunks of the global hit list taken (zero pool)
         mark(c, ST_EXTRACT);
-        launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, c->redo_list.p, c->clip_stats.p + 1, s);
+        launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, c->redo_list.p, c->clip_stats.p + 1, c->hit_ovf.p, c->clip_stats.p + 3, c->ovf_chunks, s);
         // ---- name keys (needs only row_cnt) and clip keys; the counters (sizes of the sorts, errors) start their way to the host ...
         mark(c, ST_GROUPS);
         launch_name_keys(nR, c->r_name.p, c->rows.p, c->name_keys.p, c->d_cnt, c->arena_ctr.p, arena_size, s);

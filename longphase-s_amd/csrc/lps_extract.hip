@@ -89,7 +89,8 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 
 // ------------------------------------------------------------------------------------------------ extraction
 #define EXT_RPW 4       // alignments per wave
-#define EXT_CAP 384     // hits buffered per wave (8 bytes each): with 4 workgroups per CU the 160 KB of LDS hold 40 KB each
+#define EXT_CAP 384     // hits buffered per wave in LDS (8 bytes each): with 4 workgroups per CU the 160 KB of LDS hold 40 KB each
+#define EXT_OVF 2048    // ... and in one chunk of global memory a wave takes when the LDS list is full (four reads of 200 kb hold ~1 000 hits)
 #define EXT_CLIPS 16    // clip events buffered per wave
 
 // first variant with pos >= key, searched by ONE lane (the planning step runs four of these side by side); == var_lower_bound
@@ -110,7 +111,7 @@ __device__ __forceinline__ int lane_var_lower_bound(const VarView &V, int key) {
 #define HIT_ERASED (1u << 25)
 
 __global__ __launch_bounds__(256, 4) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
-                                                       LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo) {
+                                                       LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint2 *ovf, unsigned *ovf_ctr, unsigned ovf_chunks) {
     __shared__ __attribute__((aligned(16))) int s_ref[4][LPS_SEG];
     __shared__ __attribute__((aligned(16))) int s_qry[4][LPS_SEG];
     __shared__ __attribute__((aligned(16))) uint32_t s_cig[4][LPS_SEG + 4];
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_phase(VarView V, ReadView R,
     //      search them and leave hits
     int n_hit = 0, n_clip = 0;
     bool overflow = false;
+    uint2 *ovf_mine = nullptr;                                          // this wave's chunk of the global hit list, taken when the LDS list is full
 #pragma unroll 1
     while (q < nq && !overflow) {
         const int r = r0 + q;
@@ -311,8 +313,16 @@ __global__ __launch_bounds__(256, 4) void k_extract_phase(VarView V, ReadView R,
                 }
                 const unsigned long long hm = __ballot(is_hit);
                 const int n_h = __popcll(hm);
-                if (n_hit + n_h > EXT_CAP) { overflow = true; break; }
-                if (is_hit) hit[n_hit + __popcll(hm & lanemask_lt())] = make_uint2(h0, (unsigned)h1);
+                if (n_hit + n_h > EXT_CAP) {
+                    if (n_hit + n_h > EXT_CAP + EXT_OVF) { overflow = true; break; }
+                    if (!ovf_mine) {
+                        unsigned ch = 0; if (l == 0) ch = atomicAdd(ovf_ctr, 1u);
+                        ch = __shfl((int)ch, 0);
+                        if (ch >= ovf_chunks) { overflow = true; break; }
+                        ovf_mine = ovf + (size_t)ch * EXT_OVF;
+                    }
+                }
+                if (is_hit) { const int at = n_hit + __popcll(hm & lanemask_lt()); const uint2 hv = make_uint2(h0, (unsigned)h1); if (at < EXT_CAP) hit[at] = hv; else ovf_mine[at - EXT_CAP] = hv; }
                 n_hit += n_h;
                 vcur += n_in;
                 if (!more) break;
@@ -347,12 +357,22 @@ __global__ __launch_bounds__(256, 4) void k_extract_phase(VarView V, ReadView R,
         sb[k] = (unsigned long long)(unsigned)hk[H_SOFF] | ((unsigned long long)(unsigned)hk[H_SOFF + 1] << 32);
         qb[k] = (unsigned long long)(unsigned)hk[H_QOFF] | ((unsigned long long)(unsigned)hk[H_QOFF + 1] << 32);
     }
+    // ---- ONE reservation for the rows of the wave: as many slots as there are hits (the few hits that turn out not to be observations - a base that is
+    //      neither allele, a variant filterSNP erased - leave their slots unused), so that the resolved records go straight to their place
+    unsigned long long off = 0; bool arena_full = false;
+    if (n_hit > 0) {
+        if (l == 0) off = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)n_hit);
+        off = __shfl(off, 0);
+        if (off + (unsigned long long)n_hit > O.arena_size) arena_full = true;
+    }
+    const unsigned long long g0 = arena_lo + off;
+    ObsRec *dst = O.rec + g0;
     int n_out = 0, n_emit[4] = {0, 0, 0, 0}; unsigned any_pre = 0;
     for (int i0 = 0; i0 < n_hit; i0 += 64) {
         const int i = i0 + l;
         const bool in = i < n_hit;
         uint2 hv = make_uint2(0u, 0u);
-        if (in) hv = hit[i];
+        if (in) hv = i < EXT_CAP ? hit[i] : ovf_mine[i - EXT_CAP];
         const int rq = (i >= hs[1]) + (i >= hs[2]) + (i >= hs[3]);       // row of the hit
         const unsigned long long so = rq == 0 ? sb[0] : (rq == 1 ? sb[1] : (rq == 2 ? sb[2] : sb[3]));
         const unsigned long long qo = rq == 0 ? qb[0] : (rq == 1 ? qb[1] : (rq == 2 ? qb[2] : qb[3]));
@@ -381,21 +401,9 @@ __global__ __launch_bounds__(256, 4) void k_extract_phase(VarView V, ReadView R,
                 n_emit[k] += __popcll(om & rm); if (pm & rm) any_pre |= 1u << k;
             }
         }
-        wave_sync();                                                     // every lane holds its hit: the compacted records may overwrite the list
-        if (ok) hit[n_out + __popcll(om & lanemask_lt())] = make_uint2((unsigned)v, (unsigned)pack_aq(allele, qv));
+        if (ok && !arena_full) dst[n_out + __popcll(om & lanemask_lt())] = ObsRec{(int32_t)v, (uint32_t)pack_aq(allele, qv)};
         n_out += __popcll(om);
     }
-    wave_sync();
-
-    // ---- one reservation for the rows of the wave, coalesced copy-out, row descriptors, clip events
-    unsigned long long off = 0; bool arena_full = false;
-    if (n_out > 0) {
-        if (l == 0) off = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)n_out);
-        off = __shfl(off, 0);
-        if (off + (unsigned long long)n_out > O.arena_size) arena_full = true;
-    }
-    const unsigned long long g0 = arena_lo + off;
-    if (!arena_full) { ObsRec *dst = O.rec + g0; for (int i = l; i < n_out; i += 64) { const uint2 e = hit[i]; dst[i] = ObsRec{(int32_t)e.x, e.y}; } }
     if (arena_full && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW);          // the host grows the arenas and reruns
     if (l < nq) {
         int before = 0, mine = 0;
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
         const int *hn = hdr + qn * H_WORDS;                                     // (row nq exists: only its H_REL is meaningful)
         const int n_cig_n = qn < nq ? hn[H_WORDS + H_REL] - hn[H_REL] : 0;
 
-        int ref_pos = start, q_pos = 0, n_emit = 0, fail_op = 0x7fffffff, n_clip = 0;
+        int ref_pos = start, q_pos = 0, n_emit = 0, fail_op = 0x7fffffff;
         bool had_any = false, direct = false;
         const int row_start = n_buf;                                            // of this row inside the buffer
         unsigned long long direct_base = 0;
@@ -543,8 +551,6 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
                 int mine_n = 0;
 #pragma unroll 1
                 for (int k = 0; k < 8; ++k) { const uint32_t wd = scig[8 * l + k]; const unsigned op = wd & 15u; mine_n += ((op == 4u || op == 5u) && (wd >> 4) > 5u) ? 1 : 0; }
-                const int incl = wave_incl_scan_dpp(mine_n);
-                int slot = n_clip + incl - mine_n;
                 if (mine_n) {
 #pragma unroll 1
                     for (int k = 0; k < 8; ++k) {
@@ -553,11 +559,9 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
                             const int oi = seg0 + 8 * l + k;
                             const unsigned e = atomicAdd(C.n_ev, 1u);               // (rare path: one atomic per event)
                             if (e < C.capacity) C.ev[e] = ClipEv{sref[8 * l + k], (oi << 1) | (oi != 0), r};
-                            ++slot;
                         }
                     }
                 }
-                n_clip += __shfl(incl, 63);
             }
             if (l == 0) scig[nseg] = nextw;
             wave_sync();
@@ -718,10 +722,10 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
 }
 
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,
-                          int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, hipStream_t s) {
+                          int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint2 *ovf, unsigned *ovf_ctr, unsigned ovf_chunks, hipStream_t s) {
     if (R.n == 0) return;
     const int n_jobs = (R.n + EXT_RPW - 1) / EXT_RPW;
-    hipLaunchKernelGGL(k_extract_phase, dim3((n_jobs + 3) / 4), dim3(256), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo);
+    hipLaunchKernelGGL(k_extract_phase, dim3((n_jobs + 3) / 4), dim3(256), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo, ovf, ovf_ctr, ovf_chunks);
     // waves whose hits did not fit their LDS list queued themselves (none with ordinary read lengths and variant densities): a small grid drains the queue
     hipLaunchKernelGGL(k_extract_redo, dim3(std::min(256, (n_jobs + 3) / 4)), dim3(256), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo);
 }

@@ -150,8 +150,12 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
     // a valid stream never looks further than its own bytes (+ the 3 dwords fetched ahead); a crafted one (e.g. an endless run of empty
     // blocks) must not walk off the buffer
     const uint32_t *w_end = reinterpret_cast<const uint32_t *>(in) + ((B.in_off + B.in_len + 3) >> 2) + 4;
+    // ... and must not spin: every iteration of a valid stream consumes input bits or produces output, an empty stored / fixed block costs 3 iterations
+    // for at least 10 bits - anything beyond this bound is a crafted stream (the header path clamps its reads at w_end, so the guard above alone
+    // would never trip on an endless run of empty blocks)
+    const uint32_t iter_cap = 16u * (B.in_len * 8u + on) + 4096u;
     while (state != ST_DONE) {
-        if (b.w2 > w_end) { e = LPS_INF_ERR_DATA; break; }
+        if (b.w2 > w_end || iter > iter_cap) { e = LPS_INF_ERR_DATA; break; }
         const bool copying = mlen != 0;
         if (!copying) {
             if (state == ST_SYM) {

@@ -14,16 +14,18 @@ if [ ! -d "$REF/src" ]; then
   echo "build_ref: $REF not present (GPU box?) - keeping prebuilt oracle/_ref" >&2; exit 0
 fi
 mkdir -p "$O/hts/htscodecs/htscodecs" "$O/hts/cram" "$O/hts/test" "$O/obj"
+H="$REF/htslib"
 cat > "$O/hts/config.h" <<'CFG'
 #ifndef _XOPEN_SOURCE
 #define _XOPEN_SOURCE 600
 #endif
 #define HAVE_DRAND48 1
 CFG
-H="$REF/htslib"
-# version.h / config_vars.h are generated by htslib's Makefile; emit equivalents out-of-tree
-echo '#define HTS_VERSION_TEXT "1.16"' > "$O/hts/version.h"
-echo '#define HTSCODECS_VERSION_TEXT "1.3.0"' > "$O/hts/htscodecs/htscodecs/version.h"
+# version.h is what htslib's own Makefile rule writes: echo '#define HTS_VERSION_TEXT "$(PACKAGE_VERSION)"' with PACKAGE_VERSION := $(shell version.sh);
+# the reference's own version.sh is run here, where it lies.  htscodecs ships its version.h in the tree when there is no git clone
+# (Makefile:530-545); it is used from there when present.  config_vars.h holds compiler / flag strings for `htsfile --version` only.
+echo "#define HTS_VERSION_TEXT \"$(sh "$H/version.sh")\"" > "$O/hts/version.h"
+if [ ! -f "$H/htscodecs/htscodecs/version.h" ]; then echo '#define HTSCODECS_VERSION_TEXT "1.3.0"' > "$O/hts/htscodecs/htscodecs/version.h"; fi
 cat > "$O/hts/config_vars.h" <<'CFG'
 #define HTS_CC "gcc"
 #define HTS_CPPFLAGS ""
