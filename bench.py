@@ -273,14 +273,6 @@ def main():
                 for k, v in ctx.timings()["stages"].items():
                     st[k] = st.get(k, 0.0) + v / n_prof
             largest = (spec, rec, st)
-        # ---- P clock (SURVEY.md §8d): decoded batch in pinned host memory -> results in host memory, H2D included (never `value`)
-        if rank == 0 and host is not None and spec["name"] == cpu_name:
-            R = abi.Reads.from_synth(host)
-            pinned = all(pin(x) for x in (host.qual, host.seq, host.cigar))
-            t0 = time.perf_counter(); ctx.load_chromosome(V, ref, R); h2d = time.perf_counter() - t0
-            t0 = time.perf_counter(); ctx.run_phase(out); one = time.perf_counter() - t0
-            p_clock = dict(contig=spec["name"], h2d_s=round(h2d, 3), step_s=round(one, 4), value=n_ph / (h2d + one), unit="SNPs/s", pinned_host_memory=bool(pinned),
-                           note="lps_set_variants + lps_set_reference + lps_push_reads (H2D of the decoded batch) + one lps_phase_chromosome; PCIe-inclusive, never `value`")
         # ---- secondary metric: reads haplotagged / s on the same resident alignments, table = this contig's phased SNPs
         idx = np.nonzero(out.phase_set != 0)[0]
         VT = abi.Variants.from_snps(V.pos[idx], V.ref0[idx], V.alt0[idx], hp1_is_alt=out.gt[idx], phase_set=out.phase_set[idx])
@@ -294,6 +286,14 @@ def main():
         hap_elapsed += hdt
         rec.update(haplotag_ms_per_step=hdt / a.steps * 1e3, haplotag_kernel_ms=ctx.timings()["stages"]["extract"], tagged=int((hout.hp != 0).sum()))
         total_tagged += rec["tagged"]
+        # ---- P clock (SURVEY.md §8d): decoded batch in pinned host memory -> results in host memory, H2D included (never `value`)
+        if rank == 0 and host is not None and spec["name"] == cpu_name:
+            R = abi.Reads.from_synth(host)
+            pinned = all(pin(x) for x in (host.qual, host.seq, host.cigar))
+            t0 = time.perf_counter(); ctx.load_chromosome(V, ref, R); h2d = time.perf_counter() - t0
+            t0 = time.perf_counter(); ctx.run_phase(out); one = time.perf_counter() - t0
+            p_clock = dict(contig=spec["name"], h2d_s=round(h2d, 3), step_s=round(one, 4), value=n_ph / (h2d + one), unit="SNPs/s", pinned_host_memory=bool(pinned),
+                           note="lps_set_variants + lps_set_reference + lps_push_reads (H2D of the decoded batch) + one lps_phase_chromosome; PCIe-inclusive, never `value`")
         per_contig.append(rec)
         if cpu_pick is None or cpu_pick[0] is not g:
             g.close()

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_mark_nodes(int n_reads, const RowDesc *
 // wave per alignment: graph view of the observations (node index, allele, hi-quality flag) in the same slots
 __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const RowDesc *rows,
                                                    const uint8_t *deleted, const ObsRec *obs,
-                                                   const uint32_t *node_of, int base_quality, int32_t *g_node, uint8_t *g_flag,
+                                                   const uint32_t *node_of, int base_quality, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack,
                                                    int32_t *g_cnt, LpsCounters *cnt, int n_var, const uint32_t *is_node, const uint32_t *vtype_key,
                                                    int32_t *nodes, uint8_t *ntype, uint32_t *node_cnt) {
     const int nb_reads = (n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
@@ -395,8 +395,10 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const RowDesc *r
             int q = aq_quality(aq); if (q < 0) q = 60;          // indel sentinels -> quality 60 (:820-828)
             const uint32_t slot = off + w + __popcll(m & ((1ull << sl) - 1ull));
             const uint32_t nd = node_of[v];
+            const unsigned fl = (unsigned)aq_allele(aq) | ((q >= base_quality) ? 2u : 0u);
             g_node[slot] = (int32_t)nd;
-            g_flag[slot] = (uint8_t)(aq_allele(aq) | ((q >= base_quality) ? 2 : 0));
+            g_flag[slot] = (uint8_t)fl;
+            g_pack[slot] = nd | (fl << 30);                       // node (< 2^22) and flag in one word: what k_edges reads per pair
             atomicAdd(&node_cnt[nd], 1u);                        // entries of the node's list: the merged rows hold exactly these observations
         }
         w += __popcll(m);
@@ -529,7 +531,7 @@ void launch_debug_std_sort(int32_t *keys, uint8_t *payload, const long long *row
 }
 
 __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *skeys, const uint32_t *gstart, const LpsCounters *cnt,
-                                                     const RowDesc *rows, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
+                                                     const RowDesc *rows, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack,
                                                      const uint32_t *mrow_off, const uint32_t *multi_list) {
     __shared__ int s_stk[4][192]; __shared__ int32_t s_k[4][STDSORT_LDS]; __shared__ uint8_t s_p[4][STDSORT_LDS]; __shared__ uint16_t s_a[4][STDSORT_LDS], s_b[4][STDSORT_LDS];
     const int l = lane_id();
@@ -594,6 +596,8 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
             }
         }
 #endif
+        __threadfence_block(); wave_sync();
+        for (int k = l; k < total; k += 64) g_pack[base + k] = (uint32_t)g_node[base + k] | ((uint32_t)g_flag[base + k] << 30);   // the merged row as k_edges reads it
         wave_sync();                                                     // the LDS copy is reused by the wave's next group
     }
 }
@@ -631,7 +635,7 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
                                                const unsigned long long *ukeys, const uint32_t *uvals,
                                                unsigned long long *skeys, uint32_t *svals,
                                                const uint32_t *mrow_off, const int32_t *mrow_cnt, int m_bits, int a_bits,
-                                               const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
+                                               const uint32_t *g_pack, uint32_t tail_lo, int A, double edge_weight,
                                                double edge_threshold, const uint8_t *ntype, float *edge, uint8_t *erec, uint32_t *node_pairs) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
     const int n_nodes = (int)cnt->n_nodes;
@@ -676,23 +680,32 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
             const uint32_t m = (uint32_t)((key >> a_bits) & m_mask);
             my_val = svals[e0 + l]; my_end = mrow_off[m] + (uint32_t)mrow_cnt[m];
         }
+        // every lane's own observation (flag of the source side) and its share of the pair count, loaded side by side
+        const int my_sf = l < nb ? (int)(g_pack[my_val] >> 30) : 0;
+        if (l < nb) pairs += (unsigned long long)min((uint32_t)A, my_end - my_val - 1u);
+        // merged rows of several alignments (tail arena) are the only ones that can hold a node twice inside the window
+        const bool any_multi = __ballot(l < nb && my_val >= tail_lo) != 0ull;
+        // the t-th read's following observations: requested one read ahead, so that the loads of read t+1 are in flight while read t is applied
+        uint32_t cur;
+        { const uint32_t idx = __shfl(my_val, 0), rend = __shfl(my_end, 0); const uint32_t e2 = idx + 1 + l; cur = (l < A && e2 < rend) ? g_pack[e2] : 0xffffffffu; }
         for (int t = 0; t < nb; ++t) {
-            const uint32_t idx = __shfl(my_val, t), rend = __shfl(my_end, t);
-            const int sf = g_flag[idx];                       // wave-uniform address
-            const uint32_t e2 = idx + 1 + l;
-            const bool in_row = l < A && e2 < rend;
-            const int n2 = in_row ? g_node[e2] : -1;
-            const int f2 = in_row ? g_flag[e2] : 0;
+            uint32_t nxt = 0xffffffffu;
+            if (t + 1 < nb) { const uint32_t idx = __shfl(my_val, t + 1), rend = __shfl(my_end, t + 1); const uint32_t e2 = idx + 1 + l; if (l < A && e2 < rend) nxt = g_pack[e2]; }
+            const int sf = __shfl(my_sf, t);
+            const bool in_row = cur != 0xffffffffu;
+            const int n2 = (int)(cur & 0x3fffffffu), f2 = (int)(cur >> 30);
             const int d = n2 - i;
             const bool ok = in_row && d >= 1 && d <= A;
-            pairs += __popcll(__ballot(in_row));
-            const int dprev = __shfl_up(d, 1);
-            const bool okprev = __shfl_up((int)ok, 1) != 0;
-            const bool dup = ok && l > 0 && okprev && dprev == d;
             const int cell = ((sf & 1) << 1) | (f2 & 1);
             const bool hi = (sf & 2) && (f2 & 2);
             const int payload = ok ? (1 | (cell << 1) | ((int)hi << 3)) : 0;
-            if (__ballot(dup) == 0) {
+            bool dups = false;
+            if (any_multi) {
+                const int dprev = __shfl_up(d, 1);
+                const bool okprev = __shfl_up((int)ok, 1) != 0;
+                dups = __ballot(ok && l > 0 && okprev && dprev == d) != 0ull;
+            }
+            if (!dups) {
                 // lanes without a contribution push to lane 63, which owns no target (A <= 63)
                 const int recv = __builtin_amdgcn_ds_permute((ok ? (d - 1) : 63) << 2, payload);
                 if (l < A && (recv & 1)) {
@@ -713,8 +726,10 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
                     }
                 }
             }
+            cur = nxt;
         }
     }
+    pairs = wave_sum(pairs);
     if (l == 0) node_pairs[i] = (uint32_t)pairs;   // summed later (no single-address atomics in the hot kernel)
     if (l < A) {
         reinterpret_cast<float4 *>(edge)[(size_t)i * A + l] = make_float4(a0, a1, a2, a3);
@@ -1202,18 +1217,18 @@ void launch_overlap_filter(const unsigned long long *skeys, const uint32_t *gsta
 
 void launch_nodes(int n_reads, int n_var, const RowDesc *rows, const uint8_t *deleted,
                   const ObsRec *obs, uint32_t *is_node, uint32_t *vtype_key, uint32_t *node_of,
-                  int32_t *nodes, uint8_t *ntype, int base_quality, int32_t *g_node, uint8_t *g_flag, int32_t *g_cnt,
+                  int32_t *nodes, uint8_t *ntype, int base_quality, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack, int32_t *g_cnt,
                   LpsCounters *cnt, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s) {
     hipLaunchKernelGGL(k_mark_nodes, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, n_reads, rows, deleted, obs, is_node, vtype_key);
     exscan_u32(temp, temp_bytes, is_node, node_of, n_var, s);
-    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK + (n_var + 255) / 256), dim3(256), 0, s, n_reads, rows, deleted, obs, node_of, base_quality, g_node, g_flag, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype, node_cnt);
+    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK + (n_var + 255) / 256), dim3(256), 0, s, n_reads, rows, deleted, obs, node_of, base_quality, g_node, g_flag, g_pack, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype, node_cnt);
 }
 
 void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
                        const RowDesc *rows, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
-                       unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list, hipStream_t s) {
+                       unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list, uint32_t *g_pack, hipStream_t s) {
     hipLaunchKernelGGL(k_merge_plan, GRID(n_reads, 256), 0, s, skeys, gstart, cnt, rows, g_cnt, tail_lo, tail_size, mrow_off, mrow_cnt, multi_list);
-    hipLaunchKernelGGL(k_merge_multi, dim3(256), dim3(256), 0, s, skeys, gstart, cnt, rows, g_cnt, g_node, g_flag, mrow_off, multi_list);
+    hipLaunchKernelGGL(k_merge_multi, dim3(256), dim3(256), 0, s, skeys, gstart, cnt, rows, g_cnt, g_node, g_flag, g_pack, mrow_off, multi_list);
 }
 
 void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t *mrow_off, const int32_t *mrow_cnt, uint32_t *koff,
@@ -1229,9 +1244,9 @@ void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t 
 
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
                   const unsigned long long *ukeys, const uint32_t *uvals, unsigned long long *skeys, uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
-                  int m_bits, int a_bits, const int32_t *g_node, const uint8_t *g_flag, int A, double edge_weight,
+                  int m_bits, int a_bits, const uint32_t *g_pack, uint32_t tail_lo, int A, double edge_weight,
                   double edge_threshold, const uint8_t *ntype, float *edge, uint8_t *erec, uint32_t *node_pairs, hipStream_t s) {
-    hipLaunchKernelGGL(k_edges, dim3((n_var + 3) / 4), dim3(256), 0, s, cnt, node_off, node_end, ukeys, uvals, skeys, svals, mrow_off, mrow_cnt, m_bits, a_bits, g_node, g_flag, A, edge_weight, edge_threshold, ntype, edge, erec, node_pairs);
+    hipLaunchKernelGGL(k_edges, dim3((n_var + 3) / 4), dim3(256), 0, s, cnt, node_off, node_end, ukeys, uvals, skeys, svals, mrow_off, mrow_cnt, m_bits, a_bits, g_pack, tail_lo, A, edge_weight, edge_threshold, ntype, edge, erec, node_pairs);
 }
 
 size_t scan_state_bytes(int n_var) { return (size_t)((n_var + SCAN_SEG - 1) / SCAN_SEG + 1) * 2 * sizeof(ScanState); }
