@@ -191,6 +191,8 @@ def main():
     L = hip.load()
     dist = None
     if world > 1:
+        _uid = (C.c_uint8 * 128)()
+        L.lps_comm_unique_id(_uid)      # opens the system librccl now, before torch brings its own copy of that soname into the process
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -204,7 +206,7 @@ def main():
     contigs = workload_contigs(a.workload, a.seed)
     mine = [contigs[i] for i in lpt(contigs, world)[rank]]
     parity_set = set(c["name"] for c in contigs) if a.parity == "all" else (set() if a.parity == "none" else set(a.parity.split(",")))
-    pool = ParityPool(workers=max(2, cpu_share // 2)) if parity_set else None
+    pool = ParityPool(workers=max(2, cpu_share // 2), max_bytes=(24 << 30) + (72 << 30) // world) if parity_set else None
 
     # ---- SNP table: with several ranks, rank 0's packed table reaches the other GPUs by one RCCL broadcast (north_star)
     bcast = None
@@ -393,6 +395,16 @@ def snp_table_broadcast(L, dist, dev, rank, world, contigs):
     from lps.synth_gpu import SynthGpu
     info = dict(collective="ncclBroadcast", ranks=world)
     try:
+        # RCCL refuses two ranks on one GPU - and a refused ncclCommInitRank leaves the process without a usable HIP runtime - so the ranks first
+        # compare the PCI bus ids of their devices over the control plane; a rehearsal with fewer GPUs than ranks skips the collective
+        bus = C.create_string_buffer(64)
+        if L.lps_device_bus_id(dev, bus, 64) != 0:
+            raise RuntimeError("lps_device_bus_id failed")
+        ids = [None] * world
+        dist.all_gather_object(ids, bus.value.decode())
+        if len(set(ids)) != world:
+            log(f"[rank {rank}] ranks share a GPU ({ids}): no RCCL communicator; every rank derives its own contigs' table")
+            return None
         uid = (C.c_uint8 * 128)()
         if rank == 0:
             assert L.lps_comm_unique_id(uid) == 0

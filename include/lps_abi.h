@@ -221,6 +221,8 @@ int lps_debug_set_obs_capacity(lps_ctx *ctx, int64_t slots);
  * 3 lps_phase_result, 4 lps_haplotag_result, 5 lps_timings, 6 lps_somatic_tag_result, 7 lps_site_counters, 8 lps_tumor_extract_result (binding self-check). */
 int lps_struct_size(int which);
 int lps_device_count(void);
+/* PCI bus id ("0000:c1:00.0") of a device: ranks that share a GPU must not form an RCCL communicator (lps_comm_create) */
+int lps_device_bus_id(int device, char *buf, int len);
 
 lps_ctx *lps_create(int device, const lps_params *params);
 void lps_destroy(lps_ctx *ctx);

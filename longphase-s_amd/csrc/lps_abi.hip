@@ -153,6 +153,7 @@ int lps_struct_size(int which) {
 }
 
 int lps_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+int lps_device_bus_id(int device, char *buf, int len) { if (!buf || len < 16) return -1; return hipDeviceGetPCIBusId(buf, len, device) == hipSuccess ? 0 : -1; }
 
 void lps_default_params(lps_params *p) {
     memset(p, 0, sizeof *p);

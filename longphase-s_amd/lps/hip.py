@@ -70,6 +70,7 @@ def load():
     L.lps_somatic_extract_tumor.argtypes = [C.c_void_p, C.POINTER(abi.TumorExtractResult)]
     L.lps_get_timings.argtypes = [C.c_void_p, C.POINTER(abi.Timings)]
     L.lps_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
+    L.lps_device_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     L.lps_comm_unique_id.argtypes = [C.c_void_p]
     L.lps_comm_create.restype = C.c_void_p
     L.lps_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
