@@ -1,0 +1,235 @@
+// cli_vcf.h — text inputs of longphase_amd: VCF row selection (SnpParser / VcfParser restatements), FASTA, and the phased-VCF rewriter.
+#pragma once
+#include "cli_common.h"
+
+// ------------------------------------------------------------------------------------------------ text inputs
+static bool read_lines(const std::string &path, std::vector<std::string> &lines) {   // plain or gzip text
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::string cur; char buf[1 << 16]; int k;
+    while ((k = gzread(f, buf, sizeof buf)) > 0) {
+        for (int i = 0; i < k; ++i) { if (buf[i] == '\n') { lines.push_back(cur); cur.clear(); } else cur.push_back(buf[i]); }
+    }
+    if (!cur.empty()) lines.push_back(cur);
+    gzclose(f);
+    return true;
+}
+
+struct ChrVariants { std::map<int32_t, std::pair<std::string, std::string>> rows; std::vector<int32_t> pos; std::vector<std::string> ref, alt; };
+
+static std::vector<std::string> split_tab(const std::string &s) {
+    std::vector<std::string> f; size_t a = 0;
+    while (true) { size_t b = s.find('\t', a);
+        if (b == std::string::npos) { f.push_back(s.substr(a));
+            break;
+            } f.push_back(s.substr(a, b - a));
+        a = b + 1;
+        }
+    return f;
+}
+
+// SnpParser::SnpParser (ParsingBam.cpp:222-359): het bi-allelic SNPs (bcf_is_snp: every allele one base), with --indels every other
+// het bi-allelic record.  GT of the first sample must be 0/1, 1/0, 0|1 or 1|0.
+static void parse_vcf(const std::vector<std::string> &lines, bool indels, std::vector<std::string> &chr_order, std::map<std::string, ChrVariants> &out) {
+    for (const std::string &ln : lines) {
+        if (ln.empty()) continue;
+        if (ln[0] == '#') {
+            if (ln.compare(0, 13, "##contig=<ID=") == 0) { size_t e = ln.find_first_of(",>", 13);
+                std::string c = ln.substr(13, e - 13);
+                if (!out.count(c)) { out[c];
+                    chr_order.push_back(c);
+                    } }
+            continue;
+        }
+        std::vector<std::string> f = split_tab(ln);
+        if (f.size() < 10) continue;
+        const std::string &ref = f[3], &alt = f[4];
+        if (alt.find(',') != std::string::npos || alt.empty() || alt[0] == '<' || alt == "." || alt == "*") continue;
+        const bool is_snp = ref.size() == 1 && alt.size() == 1;
+        if (!is_snp && !indels) continue;
+        // GT position inside FORMAT
+        std::vector<std::string> fmt, smp;
+        { std::stringstream a(f[8]), b(f[9]);
+            std::string x;
+            while (std::getline(a, x, ':')) fmt.push_back(x);
+            while (std::getline(b, x, ':')) smp.push_back(x);
+            }
+        size_t gi = std::find(fmt.begin(), fmt.end(), "GT") - fmt.begin();
+        if (gi >= fmt.size() || gi >= smp.size()) die("pos " + f[1] + " missing GT value");
+        const std::string &gt = smp[gi];
+        if (!(gt == "0/1" || gt == "1/0" || gt == "0|1" || gt == "1|0")) continue;
+        if (!out.count(f[0])) { out[f[0]]; chr_order.push_back(f[0]); }
+        out[f[0]].rows[std::stoi(f[1]) - 1] = {ref, alt};           // map semantics: the later record at one position wins
+    }
+    for (auto &kv : out) for (auto &r : kv.second.rows) { kv.second.pos.push_back(r.first);
+        kv.second.ref.push_back(r.second.first);
+        kv.second.alt.push_back(r.second.second);
+        }
+}
+
+static void read_fasta(const std::string &path, const std::map<std::string, ChrVariants> &want, std::map<std::string, std::string> &seqs) {
+    std::ifstream f(path); if (!f) die("ERROR: Cannot open reference " + path);
+    std::string ln, cur; std::string *dst = nullptr;
+    while (std::getline(f, ln)) {
+        if (!ln.empty() && ln[0] == '>') { std::string name = ln.substr(1, ln.find_first_of(" \t", 1) - 1);
+            dst = want.count(name) ? &seqs[name] : nullptr;
+            continue;
+            }
+        if (dst) { if (!ln.empty() && ln.back() == '\r') ln.pop_back(); dst->append(ln); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ VCF rewriter
+struct Phased { int32_t ps; char a, b; };
+// SnpParser::writeLine (ParsingBam.cpp:460-635) restated
+static void write_vcf(const std::vector<std::string> &lines, const std::string &out_path, const std::map<std::string, std::map<int32_t, Phased>> &res,
+                      const std::map<std::string, ChrVariants> &vars, const std::string &command) {
+    std::ofstream o(out_path); if (!o) die("Fail to open write file: " + out_path);
+    bool ps_def = false, cmd_done = false;
+    for (const std::string &in : lines) {
+        if (in.compare(0, 2, "##") == 0) { if (in.compare(0, 16, "##FORMAT=<ID=PS,") == 0) ps_def = true; o << in << "\n"; continue; }
+        if (in.compare(0, 6, "#CHROM") == 0 || in.compare(0, 6, "#chrom") == 0) {
+            if (!cmd_done) {
+                if (!ps_def) { o << "##FORMAT=<ID=PS,Number=1,Type=Integer,Description=\"Phase set identifier\">\n"; ps_def = true; }
+                o << "##longphaseVersion=" << kVersion << "\n" << "##commandline=\"" << command << "\"\n"; cmd_done = true;
+            }
+            o << in << "\n"; continue;
+        }
+        std::istringstream iss(in);
+        std::vector<std::string> f((std::istream_iterator<std::string>(iss)), std::istream_iterator<std::string>());
+        if (f.empty()) continue;
+        if (f.size() < 10) { o << in << "\n"; continue; }
+        const int32_t pidx = std::stoi(f[1]) - 1;
+        auto colon_index = [](const std::string &fmt, size_t upto) { int c = 0;
+            for (size_t i = 0; i < upto; ++i) if (fmt[i] == ':') ++c;
+            return c;
+            };
+        auto value_start = [](const std::string &v, int colons) { int cur = 0;
+            size_t st = 0;
+            for (size_t i = 0; i < v.size(); ++i) { if (cur >= colons) break;
+                if (v[i] == ':') ++cur;
+                ++st;
+                } return st;
+            };
+        if (f[8].find("PS") != std::string::npos) {                  // strip an existing PS key and value
+            const size_t pp = f[8].find("PS"); const int cp = colon_index(f[8], pp);
+            if (f[8].find(":", pp + 1) != std::string::npos) f[8].erase(pp, 3); else f[8].erase(pp - 1, 3);
+            const size_t st = value_start(f[9], cp);
+            if (f[9].find(":", st + 1) != std::string::npos) { const size_t e = f[9].find(":", st + 1); f[9].erase(st, e - st + 1); }
+            else f[9].erase(st - 1, f[9].length() - st + 1);
+        }
+        if (f[8].find("GT") != std::string::npos) {                  // un-phase an existing phased GT
+            const size_t gp = f[8].find("GT"); const size_t st = value_start(f[9], colon_index(f[8], gp));
+            if (st + 2 < f[9].size() + 1 && f[9][st + 1] == '|') {
+                if (f[9][st] > f[9][st + 2]) { f[9][st + 1] = f[9][st]; f[9][st] = f[9][st + 2]; f[9][st + 2] = f[9][st + 1]; }
+                f[9][st + 1] = '/';
+            }
+        }
+        const Phased *ph = nullptr;
+        auto rc = res.find(f[0]);
+        if (rc != res.end()) { auto it = rc->second.find(pidx); if (it != rc->second.end()) ph = &it->second; }
+        bool extracted = false;
+        auto vc = vars.find(f[0]);
+        if (vc != vars.end()) extracted = std::binary_search(vc->second.pos.begin(), vc->second.pos.end(), pidx);
+        if (ph && extracted) {
+            f[8] += ":PS"; f[9] += ":" + std::to_string(ph->ps);
+            const size_t gp = f[8].find("GT"); const size_t st = value_start(f[9], colon_index(f[8], gp));
+            f[9][st] = ph->a; f[9][st + 1] = '|'; f[9][st + 2] = ph->b;
+        } else { f[8] += ":PS"; f[9] += ":."; }
+        for (size_t i = 0; i < f.size(); ++i) { if (i) o << "\t"; o << f[i]; }
+        o << "\n";
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ haplotag
+// Phased-het rows of the SNP VCF = the haplotag table: VcfParser::parserProcess (src/haplotag/HaplotagVcfParser.cpp:234-400).
+struct PhasedRow { std::string ref, alt; int32_t ps; uint8_t hp1_is_alt; };
+static void parse_phased_vcf(const std::vector<std::string> &lines, std::vector<std::string> &chr_vec, std::map<std::string, int> &chr_len,
+                             std::map<std::string, std::map<int32_t, PhasedRow>> &rows) {
+    for (const std::string &in : lines) {
+        if (in.compare(0, 2, "##") == 0) {
+            if (in.find("contig=") != std::string::npos) {                                   // :236-248 (needs ",length=")
+                const size_t a = in.find("ID=") + 3, b = in.find(",length="), e = in.find(">");
+                if (b == std::string::npos) die("[ERROR] contig header line without length: " + in);
+                const std::string chr = in.substr(a, b - a);
+                chr_vec.push_back(chr); chr_len[chr] = std::stoi(in.substr(b + 8, e - b - 8));
+            }
+            if (in.compare(0, 16, "##FORMAT=<ID=PS,") == 0 && in.find("Type=Integer") == std::string::npos) die("longphase_amd: only an Integer PS field is supported");
+            continue;
+        }
+        if (in.empty() || in[0] == '#') continue;
+        std::istringstream iss(in);
+        std::vector<std::string> f((std::istream_iterator<std::string>(iss)), std::istream_iterator<std::string>());
+        if (f.empty()) continue;
+        if (f.size() < 10) die("[ERROR](VcfParser::parserProcess) => VCF file format not supported: " + in);
+        auto start_of = [&](const char *key) { const size_t kp = f[8].find(key);
+            int colons = 0;
+            for (size_t i = 0; i < kp && i < f[8].size(); ++i) if (f[8][i] == ':') ++colons;
+            int cur = 0;
+            size_t st = 0;
+            for (size_t i = 0; i < f[9].size(); ++i) { if (cur >= colons) break;
+                if (f[9][i] == ':') ++cur;
+                ++st;
+                } return st;
+            };
+        const size_t g = start_of("GT");
+        if (g + 2 >= f[9].size() + 0 && g + 2 > f[9].size() - 1) continue;
+        if (!(f[9][g] != f[9][g + 2] && f[9][g + 1] == '|')) continue;                      // phased hetero GT only (:296)
+        const size_t ps0 = start_of("PS");
+        const size_t pe = f[9].find(':', ps0 + 1);
+        const std::string psv = pe != std::string::npos ? f[9].substr(ps0, pe - ps0) : f[9].substr(ps0);
+        PhasedRow r; r.ref = f[3];
+        if (f[4].find(',') != std::string::npos) { if (f[9].find('2') != std::string::npos) continue;
+            r.alt = f[4].substr(0, f[4].find(','));
+            }   // :333-347
+        else r.alt = f[4];
+        try { r.ps = std::stoi(psv); } catch (...) { die("longphase_amd: phased record without an integer PS value: " + in); }
+        if (f[9][g] == '0' && f[9][g + 2] == '1') r.hp1_is_alt = 0;
+        else if (f[9][g] == '1' && f[9][g + 2] == '0') r.hp1_is_alt = 1;
+        else die("longphase_amd: phased genotype other than 0|1 / 1|0 is not supported: " + in);
+        rows[f[0]][std::stoi(f[1]) - 1] = r;
+    }
+}
+
+// BGZF writer: the byte stream is cut into 0xff00-byte blocks (htslib's BGZF_BLOCK_SIZE) that are deflated by a thread pool and
+// written in order; ends with the 28-byte EOF block.
+
+struct TumorRow { std::string ref, alt; int kind; };                    // kind: 1 SNP, 2 insertion, 3 deletion, 4 MNP (VarData::setVariantType)
+static void parse_tumor_vcf(const std::vector<std::string> &lines, std::vector<std::string> &chr_vec, std::map<std::string, int> &chr_len,
+                            std::map<std::string, std::map<int32_t, TumorRow>> &rows) {
+    for (const std::string &in : lines) {
+        if (in.compare(0, 2, "##") == 0) {
+            if (in.find("contig=") != std::string::npos) {
+                const size_t a = in.find("ID=") + 3, b = in.find(",length="), e = in.find(">");
+                if (b == std::string::npos) die("[ERROR] contig header line without length: " + in);
+                const std::string chr = in.substr(a, b - a); chr_vec.push_back(chr); chr_len[chr] = std::stoi(in.substr(b + 8, e - b - 8));
+            }
+            continue;
+        }
+        if (in.empty() || in[0] == '#') continue;
+        std::istringstream iss(in);
+        std::vector<std::string> f((std::istream_iterator<std::string>(iss)), std::istream_iterator<std::string>());
+        if (f.empty()) continue;
+        if (f.size() < 10) die("[ERROR](VcfParser::parserProcess) => VCF file format not supported: " + in);
+        const size_t kp = f[8].find("GT"); int colons = 0; for (size_t i = 0; i < kp && i < f[8].size(); ++i) if (f[8][i] == ':') ++colons;
+        int cur = 0; size_t g = 0; for (size_t i = 0; i < f[9].size(); ++i) { if (cur >= colons) break; if (f[9][i] == ':') ++cur; ++g; }
+        if (g + 2 >= f[9].size() + 1) continue;
+        const char a = f[9][g], m = f[9][g + 1], b = g + 2 < f[9].size() ? f[9][g + 2] : '\0';
+        if (a != b && m == '|') die("longphase_amd: phased records in the tumor VCF are not supported: " + in);
+        // HaplotagVcfParser.cpp:296-400 would need PS handling
+        if (!((a == '1' && m == '/' && b == '1') || (a == '0' && m == '/' && b == '1'))) continue;               // :470-520: 1/1 and 0/1 only
+        TumorRow r; r.ref = f[3]; r.alt = f[4].find(',') != std::string::npos ? f[4].substr(0, f[4].find(',')) : f[4];
+        if (r.ref.size() == 1 && r.alt.size() == 1) r.kind = 1;
+        else if (r.ref.size() == 1 && r.alt.size() > 1) r.kind = 2;
+        else if (r.ref.size() > 1 && r.alt.size() == 1) r.kind = 3;
+        else if (r.ref.size() > 1 && r.ref.size() == r.alt.size()) r.kind = 4; else die("(loadVariantType)Invalid allele: " + r.ref + " " + r.alt);
+        if ((r.kind == 2 || r.kind == 3) && std::abs((int)r.alt.size() - (int)r.ref.size()) > 100) continue;
+        // tumor INDELs longer than 100 bp are skipped
+        rows[f[0]][std::stoi(f[1]) - 1] = r;
+    }
+}
+
+// TumorPurityEstimator (src/somatic_haplotag/TumorPurityEstimator.cpp) restated: LCVF filters :92-150, histogram of the normal germline read
+// counts smoothed with a sigma-0.5 Gaussian :443-600, peak / valley analysis for the dynamic count threshold :649-1060, box-plot statistics with
+// linear-interpolation percentiles :281-344, one outlier-removal round, and the quadratic model in (median, IQR) :66.  Writes <prefix>_purity.out.

@@ -6,431 +6,12 @@
 //   SnpParser row selection                   src/phase/ParsingBam.cpp:222-359
 //   per-chromosome driver                     src/phase/PhasingProcess.cpp:113-173   (the hot path is one lps_phase_chromosome call)
 //   SnpParser::writeLine (VCF rewrite rules)  src/phase/ParsingBam.cpp:460-635
-// Not supported (the reference path must be used): --sv-file, --mod-file, --dot, --deepsomatic_output, CRAM, CIGARs in CG tags.
-#include <dlfcn.h>
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
-#include <zlib.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <fstream>
-#include <functional>
-#include <iostream>
-#include <iterator>
-#include <map>
-#include <set>
-#include <mutex>
-#include <numeric>
-#include <sstream>
-#include <condition_variable>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "../../include/lps_abi.h"
-
-static const char *kVersion = "1.0.0-mi355x";
-
-// Errors end the process at once, from whatever thread: _exit skips the static destructors and the ROCm runtime's teardown, which would otherwise race
-// with the streams of worker threads that are still running (--gpus N) - exit(1) from a worker could hang or crash on the way out.
-[[noreturn]] static void die(const std::string &m) { std::cerr << m << "\n"; std::cerr.flush(); fflush(nullptr); _exit(1); }
-static const size_t kGpuInflateMinBytes = 256u << 20;
-static size_t file_bytes(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 ? (size_t)st.st_size : 0; }
-
-// ------------------------------------------------------------------------------------------------ the library, loaded at run time
-// liblps_hip.so (and with it the ROCm runtime) is dlopen'ed from a helper thread so that loading it and creating the GPU context
-// overlap with reading the inputs; the CLI binary itself has no GPU dependency (its `view` subcommand runs anywhere).
-struct Lps {
-    void *so = nullptr;
-    decltype(&lps_default_params) default_params = nullptr; decltype(&lps_create) create = nullptr; decltype(&lps_destroy) destroy = nullptr;
-    decltype(&lps_last_error) last_error = nullptr; decltype(&lps_begin_chromosome) begin_chromosome = nullptr; decltype(&lps_set_variants) set_variants = nullptr;
-    decltype(&lps_set_reference) set_reference = nullptr; decltype(&lps_push_bam_records) push_bam_records = nullptr; decltype(&lps_phase_chromosome) phase_chromosome = nullptr;
-    decltype(&lps_haplotag_chromosome) haplotag_chromosome = nullptr; decltype(&lps_abi_version) abi_version = nullptr;
-    decltype(&lps_bgzf_load) bgzf_load = nullptr; decltype(&lps_bgzf_read) bgzf_read = nullptr; decltype(&lps_bam_scan) bam_scan = nullptr;
-    decltype(&lps_bam_record_tids) bam_record_tids = nullptr; decltype(&lps_bam_names) bam_names = nullptr; decltype(&lps_push_bam_resident) push_bam_resident = nullptr;
-    decltype(&lps_bam_record_offsets) bam_record_offsets = nullptr; decltype(&lps_bam_scan_range) bam_scan_range = nullptr; decltype(&lps_device_count) device_count = nullptr; decltype(&lps_set_stage_timing) set_stage_timing = nullptr;
-    decltype(&lps_haplotag_write_bgzf) haplotag_write_bgzf = nullptr; decltype(&lps_bgzf_deflate_fetch) bgzf_deflate_fetch = nullptr;
-    decltype(&lps_somatic_extract_normal) somatic_extract_normal = nullptr; decltype(&lps_somatic_extract_tumor) somatic_extract_tumor = nullptr;
-    decltype(&lps_somatic_tag_chromosome) somatic_tag_chromosome = nullptr;
-    decltype(&lps_comm_create_all) comm_create_all = nullptr; decltype(&lps_comm_bcast) comm_bcast = nullptr; decltype(&lps_comm_destroy) comm_destroy = nullptr;
-    decltype(&lps_comm_size) comm_size = nullptr; decltype(&lps_comm_last_error) comm_last_error = nullptr;
-    std::string error;
-    bool load() {
-        char exe[4096]; const ssize_t k = readlink("/proc/self/exe", exe, sizeof exe - 1);
-        std::string dir = "."; if (k > 0) { exe[k] = 0; dir = exe; dir = dir.substr(0, dir.find_last_of('/')); }
-        const char *env = getenv("LPS_HIP_LIBRARY");
-        const std::string path = env ? env : dir + "/../csrc/liblps_hip.so";
-        so = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (!so) { error = std::string("cannot load ") + path + ": " + dlerror() + " (the GPU library is required; there is no CPU fallback)"; return false; }
-#define LPS_SYM(field, name) field = (decltype(field))dlsym(so, #name); if (!field) { error = "liblps_hip.so does not export " #name; return false; }
-        LPS_SYM(default_params, lps_default_params) LPS_SYM(create, lps_create) LPS_SYM(destroy, lps_destroy) LPS_SYM(last_error, lps_last_error)
-        LPS_SYM(begin_chromosome, lps_begin_chromosome) LPS_SYM(set_variants, lps_set_variants) LPS_SYM(set_reference, lps_set_reference)
-        LPS_SYM(push_bam_records, lps_push_bam_records) LPS_SYM(phase_chromosome, lps_phase_chromosome) LPS_SYM(haplotag_chromosome, lps_haplotag_chromosome)
-        LPS_SYM(abi_version, lps_abi_version) LPS_SYM(bgzf_load, lps_bgzf_load) LPS_SYM(bgzf_read, lps_bgzf_read) LPS_SYM(bam_scan, lps_bam_scan)
-        LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range) LPS_SYM(device_count, lps_device_count) LPS_SYM(set_stage_timing, lps_set_stage_timing) LPS_SYM(haplotag_write_bgzf, lps_haplotag_write_bgzf) LPS_SYM(bgzf_deflate_fetch, lps_bgzf_deflate_fetch)
-        LPS_SYM(somatic_extract_normal, lps_somatic_extract_normal) LPS_SYM(somatic_extract_tumor, lps_somatic_extract_tumor) LPS_SYM(somatic_tag_chromosome, lps_somatic_tag_chromosome)
-        LPS_SYM(comm_create_all, lps_comm_create_all) LPS_SYM(comm_bcast, lps_comm_bcast) LPS_SYM(comm_destroy, lps_comm_destroy) LPS_SYM(comm_size, lps_comm_size) LPS_SYM(comm_last_error, lps_comm_last_error)
-#undef LPS_SYM
-        if (abi_version() != LPS_ABI_VERSION) { error = "liblps_hip.so has a different ABI version than this binary was built for"; return false; }
-        return true;
-    }
-};
-
-// ------------------------------------------------------------------------------------------------ BGZF / BAM
-struct Bgzf {
-    // whole-file reader: mmap the file, locate the BGZF blocks (18-byte headers), inflate them with a thread pool into one
-    // contiguous byte stream (not zero-initialised: every byte is written by exactly one inflate call)
-    uint8_t *data = nullptr; size_t size = 0;
-    ~Bgzf() { free(data); }
-    void load(const std::string &path, int threads) {
-        const int fd = open(path.c_str(), O_RDONLY);
-        if (fd < 0) die("ERROR: Cannot open bam file " + path);
-        struct stat st; if (fstat(fd, &st) != 0) die("ERROR: Cannot stat " + path);
-        const size_t fsz = (size_t)st.st_size;
-        const uint8_t *raw = fsz ? (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
-        if (fsz && raw == (const uint8_t *)MAP_FAILED) die("ERROR: Cannot map " + path);
-        if (fsz) madvise((void *)raw, fsz, MADV_SEQUENTIAL | MADV_WILLNEED);
-        struct Blk { size_t off, clen, uoff, ulen; };
-        std::vector<Blk> blks; size_t p = 0, utot = 0;
-        while (p + 18 <= fsz) {
-            if (raw[p] != 31 || raw[p + 1] != 139) die("ERROR: " + path + " is not a BGZF/BAM file");
-            const unsigned xlen = raw[p + 10] | (raw[p + 11] << 8);
-            size_t q = p + 12, bsize = 0;
-            while (q + 4 <= p + 12 + xlen && q + 4 <= fsz) {                // BC subfield carries BSIZE
-                const unsigned slen = raw[q + 2] | (raw[q + 3] << 8);
-                if (raw[q] == 'B' && raw[q + 1] == 'C' && slen == 2) bsize = (raw[q + 4] | (raw[q + 5] << 8)) + 1;
-                q += 4 + slen;
-            }
-            if (!bsize || bsize < 12 + xlen + 8 || p + bsize > fsz) die("ERROR: truncated BGZF block in " + path);
-            const size_t isize = raw[p + bsize - 4] | (raw[p + bsize - 3] << 8) | (raw[p + bsize - 2] << 16) | ((size_t)raw[p + bsize - 1] << 24);
-            blks.push_back({p + 12 + xlen, bsize - 12 - xlen - 8, utot, isize});
-            utot += isize; p += bsize;
-        }
-        if (p != fsz || blks.empty()) die("ERROR: " + path + " is not a BGZF/BAM file");
-        const size_t huge = 2u << 20, cap = (utot + 64 + huge - 1) / huge * huge;
-        data = (uint8_t *)aligned_alloc(huge, cap); size = utot;
-        if (!data) die("ERROR: out of memory inflating " + path);
-        madvise(data, cap, MADV_HUGEPAGE);                              // 2 MiB pages: fewer faults while 16 threads fill it
-        const int nt = std::max(1, threads);
-        std::vector<std::thread> th; std::vector<int> bad(nt, 0); std::atomic<size_t> next{0};
-        for (int t = 0; t < nt; ++t) th.emplace_back([&, t] {
-            z_stream zs{}; if (inflateInit2(&zs, -15) != Z_OK) { bad[t] = 1; return; }
-            for (;;) {
-                const size_t b0 = next.fetch_add(16); if (b0 >= blks.size()) break;
-                for (size_t b = b0; b < std::min(blks.size(), b0 + 16); ++b) {
-                    if (!blks[b].ulen) continue;
-                    inflateReset(&zs);
-                    zs.next_in = const_cast<uint8_t *>(raw) + blks[b].off; zs.avail_in = (uInt)blks[b].clen;
-                    zs.next_out = data + blks[b].uoff; zs.avail_out = (uInt)blks[b].ulen;
-                    if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) bad[t] = 1;
-                }
-            }
-            inflateEnd(&zs);
-        });
-        for (auto &x : th) x.join();
-        if (fsz) munmap((void *)raw, fsz);
-        close(fd);
-        for (int x : bad) if (x) die("ERROR: inflate failed in " + path);
-    }
-};
-
-static uint32_t rd32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
-
-// One BAM file, inflated, plus where every record of every wanted contig sits in it.  Nothing is decoded on the host except
-// refID (to route the record) and the read name (to rank it); the rest is lps_push_bam_records' job on the GPU.
-struct ContigRecords { std::vector<uint64_t> rec_off; uint64_t lo = 0, hi = 0; };   // offsets relative to `lo`
-struct BamFile {
-    Bgzf z; std::vector<std::string> ref_names; std::map<std::string, ContigRecords> contigs;
-    void load(const std::string &path, int threads, const std::map<std::string, int> &want) {
-        z.load(path, threads);
-        const uint8_t *d = z.data; const size_t n = z.size;
-        if (n < 12 || memcmp(d, "BAM\1", 4)) die("ERROR: " + path + " is not a BAM file");
-        size_t p = 4; const uint32_t l_text = rd32(d + p); p += 4 + (size_t)l_text;
-        if (p + 4 > n) die("ERROR: truncated BAM header in " + path);
-        const uint32_t n_ref = rd32(d + p); p += 4;
-        ref_names.resize(n_ref);
-        for (uint32_t i = 0; i < n_ref; ++i) { if (p + 4 > n) die("ERROR: truncated BAM header in " + path); const uint32_t l = rd32(d + p); p += 4; if (!l || p + l + 4 > n) die("ERROR: truncated BAM header in " + path); ref_names[i] = std::string((const char *)d + p, l - 1); p += l + 4; }
-        std::vector<ContigRecords *> dst(n_ref, nullptr);
-        for (uint32_t i = 0; i < n_ref; ++i) if (want.count(ref_names[i])) dst[i] = &contigs[ref_names[i]];
-        while (p + 4 <= n) {
-            const uint32_t bs = rd32(d + p);
-            if (bs < 32 || p + 4 + bs > n) die("ERROR: truncated BAM record in " + path);
-            const int32_t tid = (int32_t)rd32(d + p + 4);
-            if (tid >= 0 && tid < (int32_t)n_ref && dst[tid]) {
-                ContigRecords &c = *dst[tid];
-                if (c.rec_off.empty()) c.lo = p;
-                c.rec_off.push_back(p + 4 - c.lo); c.hi = p + 4 + bs;
-            }
-            p += 4 + (size_t)bs;
-        }
-    }
-    const char *name_of(const ContigRecords &c, size_t i, size_t &len) const { const uint8_t *r = z.data + c.lo + c.rec_off[i]; len = r[8] ? r[8] - 1u : 0u; return (const char *)r + 32; }
-};
-
-// equal names <=> equal id, order = std::string operator< (the std::map<std::string,...> order of PhasingGraph.cpp:833,848)
-static void rank_names(const std::vector<std::pair<const char *, size_t>> &names, std::vector<uint32_t> &id) {
-    std::vector<uint32_t> idx(names.size()); std::iota(idx.begin(), idx.end(), 0u);
-    auto less = [&](uint32_t a, uint32_t b) { const size_t m = std::min(names[a].second, names[b].second); const int c = memcmp(names[a].first, names[b].first, m); return c ? c < 0 : names[a].second < names[b].second; };
-    std::sort(idx.begin(), idx.end(), less);
-    id.resize(names.size()); uint32_t cur = 0;
-    for (size_t k = 0; k < idx.size(); ++k) { if (k && (less(idx[k - 1], idx[k]) || less(idx[k], idx[k - 1]))) ++cur; id[idx[k]] = cur; }
-}
-
-// One BAM file inflated and indexed ON THE GPU (lps_bgzf_load + lps_bam_scan): the host only maps the compressed file, parses the BAM header
-// and ranks the read names of each contig.
-struct GpuBam {
-    std::vector<std::string> ref_names; std::map<std::string, std::pair<int64_t, int64_t>> range;   // whole-file mode: contig -> (first record, count)
-    std::vector<uint8_t> header;                                      // inflated bytes "BAM\1" .. end of the reference table
-    std::vector<std::pair<uint64_t, uint64_t>> voff; bool indexed = false;   // .bai: virtual-offset range of every contig's records
-    const uint8_t *raw = nullptr; size_t fsz = 0; int fd = -1; std::string path;
-    double t_map = 0, t_inflate = 0, t_scan = 0; int64_t total = 0;
-    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-    // map the file, inflate the BAM header on the host (a few blocks), read <bam>.bai when there is one
-    void open_file(const std::string &p, bool use_index) {
-        path = p; const double t0 = now();
-        fd = open(p.c_str(), O_RDONLY);
-        if (fd < 0) die("ERROR: Cannot open bam file " + p);
-        struct stat st; if (fstat(fd, &st) != 0 || st.st_size < 28) die("ERROR: " + p + " is not a BGZF/BAM file");
-        fsz = (size_t)st.st_size;
-        raw = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (raw == (const uint8_t *)MAP_FAILED) die("ERROR: Cannot map " + p);
-        size_t q = 0; size_t need = 12;                                 // grows as l_text / names become known
-        auto parsed = [&]() -> bool {
-            if (header.size() < 12) return false;
-            if (memcmp(header.data(), "BAM\1", 4)) die("ERROR: " + p + " is not a BAM file");
-            size_t h = 8 + (size_t)rd32(header.data() + 4); if (h + 4 > header.size()) { need = h + 4; return false; }
-            const uint32_t n_ref = rd32(header.data() + h); h += 4; ref_names.assign(n_ref, std::string());
-            for (uint32_t i = 0; i < n_ref; ++i) {
-                if (h + 4 > header.size()) { need = h + 4; return false; }
-                const uint32_t l = rd32(header.data() + h); if (!l) die("ERROR: truncated BAM header in " + p);
-                if (h + 4 + l + 4 > header.size()) { need = h + 4 + l + 4; return false; }
-                ref_names[i] = std::string((const char *)header.data() + h + 4, l - 1); h += 4 + (size_t)l + 4;
-            }
-            header.resize(h); return true;
-        };
-        while (!parsed()) {
-            if (q + 18 > fsz) die("ERROR: truncated BAM header in " + p);
-            const unsigned xlen = raw[q + 10] | (raw[q + 11] << 8); const size_t bsize = (size_t)(raw[q + 16] | (raw[q + 17] << 8)) + 1;
-            if (raw[q] != 31 || raw[q + 1] != 139 || q + bsize > fsz) die("ERROR: " + p + " is not a BGZF/BAM file");
-            const size_t isize = rd32(raw + q + bsize - 4), at = header.size(); header.resize(at + isize);
-            z_stream zs{}; zs.next_in = const_cast<uint8_t *>(raw) + q + 12 + xlen; zs.avail_in = (uInt)(bsize - 12 - xlen - 8); zs.next_out = header.data() + at; zs.avail_out = (uInt)isize;
-            if (inflateInit2(&zs, -15) != Z_OK || (isize && inflate(&zs, Z_FINISH) != Z_STREAM_END)) die("ERROR: inflate failed in " + p);
-            inflateEnd(&zs); q += bsize; (void)need;
-        }
-        if (use_index) read_bai();
-        t_map = now() - t0;
-    }
-    // BAI (SAM spec 5.2): per reference the bins with their chunk lists; the pseudo-bin 37450 holds (first, last) virtual offset of the reference's records
-    void read_bai() {
-        std::string cand[2] = {path + ".bai", path.size() > 4 ? path.substr(0, path.size() - 4) + ".bai" : std::string()};
-        std::vector<uint8_t> b;
-        for (const std::string &c : cand) { if (c.empty()) continue; std::ifstream f(c, std::ios::binary); if (!f) continue; b.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>()); break; }
-        if (b.size() < 8 || memcmp(b.data(), "BAI\1", 4)) return;
-        auto r32 = [&](size_t &p) -> uint32_t { if (p + 4 > b.size()) die("ERROR: truncated index for " + path); const uint32_t v = rd32(b.data() + p); p += 4; return v; };
-        auto r64 = [&](size_t &p) -> uint64_t { const uint64_t lo = r32(p), hi = r32(p); return lo | (hi << 32); };
-        size_t p = 4; const uint32_t n_ref = r32(p);
-        if (n_ref != ref_names.size()) die("ERROR: index and header of " + path + " disagree on the number of references");
-        voff.assign(n_ref, {0, 0});
-        for (uint32_t i = 0; i < n_ref; ++i) {
-            uint64_t lo = ~0ull, hi = 0, mlo = 0, mhi = 0; bool meta = false;
-            const uint32_t n_bin = r32(p);
-            for (uint32_t k = 0; k < n_bin; ++k) {
-                const uint32_t bin = r32(p), n_chunk = r32(p);
-                for (uint32_t c = 0; c < n_chunk; ++c) { const uint64_t beg = r64(p), end = r64(p); if (bin == 37450) { if (c == 0) { mlo = beg; mhi = end; meta = true; } } else { lo = std::min(lo, beg); hi = std::max(hi, end); } }
-            }
-            const uint32_t n_intv = r32(p); p += 8ull * n_intv;
-            if (meta) voff[i] = {mlo, mhi}; else if (hi) voff[i] = {lo, hi};
-        }
-        indexed = true;
-    }
-    void close_file() { if (raw) munmap((void *)raw, fsz); if (fd >= 0) close(fd); raw = nullptr; fd = -1; }
-
-    // whole-file mode: everything resident at once, one contiguous record range per contig
-    void load_all(Lps &L, lps_ctx *ctx) {
-        const double t1 = now();
-        madvise((void *)raw, fsz, MADV_WILLNEED);
-        if (L.bgzf_load(ctx, raw, (int64_t)fsz, &total)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
-        const double t2 = now(); t_inflate += t2 - t1;
-        int64_t n = 0;
-        if (L.bam_scan(ctx, (int64_t)header.size(), (int32_t)ref_names.size(), &n)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
-        std::vector<int32_t> tid((size_t)n);
-        if (n && L.bam_record_tids(ctx, tid.data())) die(std::string("ERROR: ") + L.last_error(ctx));
-        for (int64_t i = 0; i < n;) {                                  // a coordinate-sorted BAM holds every contig as ONE run of records
-            int64_t j = i; while (j < n && tid[(size_t)j] == tid[(size_t)i]) ++j;
-            if (tid[(size_t)i] >= 0) { const std::string &nm = ref_names[(size_t)tid[(size_t)i]]; if (range.count(nm)) die("ERROR: " + path + " is not coordinate-sorted"); range[nm] = {i, j - i}; }
-            i = j;
-        }
-        t_scan += now() - t2;
-    }
-    // indexed mode.  Consecutive contigs are taken in GROUPS of up to `budget` compressed bytes: one upload + one inflate launch per group (a launch
-    // over a single small contig cannot fill the GPU: the inflate kernel's latency is that of one 64 KiB block however few blocks there are).
-    int tid_of(const std::string &chr) const { for (size_t t = 0; t < ref_names.size(); ++t) if (ref_names[t] == chr) return (int)t; return -1; }
-    std::vector<std::vector<std::string>> plan_groups(const std::vector<std::string> &chrs, uint64_t budget) const {
-        std::vector<std::vector<std::string>> groups; int last_tid = -2; uint64_t bytes = 0;
-        for (const std::string &c : chrs) {
-            const int t = tid_of(c); if (t < 0 || voff[(size_t)t].second <= voff[(size_t)t].first) continue;       // not in this BAM / no records
-            const uint64_t sz = (voff[(size_t)t].second >> 16) - (voff[(size_t)t].first >> 16) + 65536;
-            bool gap_free = t > last_tid && !groups.empty();
-            if (gap_free) for (int k = last_tid + 1; k < t; ++k) if (voff[(size_t)k].second > voff[(size_t)k].first) gap_free = false;   // a contig in between is not wanted: keep groups tight
-            if (!gap_free || bytes + sz > budget) { groups.emplace_back(); bytes = 0; }
-            groups.back().push_back(c); bytes += sz; last_tid = t;
-        }
-        return groups;
-    }
-    // upload + inflate + scan the records of a group of consecutive contigs; fills `range` for its members
-    void load_group(Lps &L, lps_ctx *ctx, const std::vector<std::string> &chrs) {
-        range.clear();
-        if (chrs.empty()) return;
-        const size_t t0 = (size_t)tid_of(chrs.front()), t9 = (size_t)tid_of(chrs.back());
-        const double t1 = now();
-        const uint64_t cbeg = voff[t0].first >> 16, ubeg = voff[t0].first & 0xffff, cend = voff[t9].second >> 16, uend = voff[t9].second & 0xffff;
-        uint64_t stop = cend; uint64_t last_isize = 0;
-        if (uend) { if (cend + 18 > fsz) die("ERROR: index of " + path + " points past the end of the file"); const uint64_t bsize = (uint64_t)(raw[cend + 16] | (raw[cend + 17] << 8)) + 1; stop = cend + bsize; if (stop > fsz) die("ERROR: truncated BGZF block in " + path); last_isize = rd32(raw + stop - 4); }
-        if (cbeg >= stop || stop > fsz) die("ERROR: index of " + path + " is inconsistent");
-        if (L.bgzf_load(ctx, raw + cbeg, (int64_t)(stop - cbeg), &total)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
-        const int64_t end = uend ? total - (int64_t)last_isize + (int64_t)uend : total;
-        const double t2 = now(); t_inflate += t2 - t1;
-        int64_t n = 0;
-        if (L.bam_scan_range(ctx, (int64_t)ubeg, end, (int32_t)ref_names.size(), &n)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
-        std::vector<int32_t> tid((size_t)n);
-        if (n && L.bam_record_tids(ctx, tid.data())) die(std::string("ERROR: ") + L.last_error(ctx));
-        for (int64_t i = 0; i < n;) {
-            int64_t j = i; while (j < n && tid[(size_t)j] == tid[(size_t)i]) ++j;
-            if (tid[(size_t)i] < (int32_t)t0 || tid[(size_t)i] > (int32_t)t9) die("ERROR: index of " + path + " does not match its records");
-            const std::string &nm = ref_names[(size_t)tid[(size_t)i]]; if (range.count(nm)) die("ERROR: " + path + " is not coordinate-sorted"); range[nm] = {i, j - i};
-            i = j;
-        }
-        t_scan += now() - t2;
-    }
-    // names of records [first, first+count) -> (pointer, length) pairs into `store`
-    void names(Lps &L, lps_ctx *ctx, int64_t first, int64_t count, std::vector<char> &store, std::vector<uint32_t> &off, std::vector<std::pair<const char *, size_t>> &out) {
-        int64_t nb = 0;
-        if (L.bam_names(ctx, first, count, nullptr, nullptr, 0, &nb)) die(std::string("ERROR: ") + L.last_error(ctx));
-        store.resize((size_t)nb + 1); off.resize((size_t)count + 1);
-        if (L.bam_names(ctx, first, count, off.data(), store.data(), (int64_t)store.size(), &nb)) die(std::string("ERROR: ") + L.last_error(ctx));
-        for (int64_t i = 0; i < count; ++i) out.emplace_back(store.data() + off[(size_t)i], (size_t)(off[(size_t)i + 1] - off[(size_t)i]) - 1);
-    }
-};
-
-// ------------------------------------------------------------------------------------------------ text inputs
-static bool read_lines(const std::string &path, std::vector<std::string> &lines) {   // plain or gzip text
-    gzFile f = gzopen(path.c_str(), "rb");
-    if (!f) return false;
-    std::string cur; char buf[1 << 16]; int k;
-    while ((k = gzread(f, buf, sizeof buf)) > 0) {
-        for (int i = 0; i < k; ++i) { if (buf[i] == '\n') { lines.push_back(cur); cur.clear(); } else cur.push_back(buf[i]); }
-    }
-    if (!cur.empty()) lines.push_back(cur);
-    gzclose(f);
-    return true;
-}
-
-struct ChrVariants { std::map<int32_t, std::pair<std::string, std::string>> rows; std::vector<int32_t> pos; std::vector<std::string> ref, alt; };
-
-static std::vector<std::string> split_tab(const std::string &s) {
-    std::vector<std::string> f; size_t a = 0;
-    while (true) { size_t b = s.find('\t', a); if (b == std::string::npos) { f.push_back(s.substr(a)); break; } f.push_back(s.substr(a, b - a)); a = b + 1; }
-    return f;
-}
-
-// SnpParser::SnpParser (ParsingBam.cpp:222-359): het bi-allelic SNPs (bcf_is_snp: every allele one base), with --indels every other
-// het bi-allelic record.  GT of the first sample must be 0/1, 1/0, 0|1 or 1|0.
-static void parse_vcf(const std::vector<std::string> &lines, bool indels, std::vector<std::string> &chr_order, std::map<std::string, ChrVariants> &out) {
-    for (const std::string &ln : lines) {
-        if (ln.empty()) continue;
-        if (ln[0] == '#') {
-            if (ln.compare(0, 13, "##contig=<ID=") == 0) { size_t e = ln.find_first_of(",>", 13); std::string c = ln.substr(13, e - 13); if (!out.count(c)) { out[c]; chr_order.push_back(c); } }
-            continue;
-        }
-        std::vector<std::string> f = split_tab(ln);
-        if (f.size() < 10) continue;
-        const std::string &ref = f[3], &alt = f[4];
-        if (alt.find(',') != std::string::npos || alt.empty() || alt[0] == '<' || alt == "." || alt == "*") continue;
-        const bool is_snp = ref.size() == 1 && alt.size() == 1;
-        if (!is_snp && !indels) continue;
-        // GT position inside FORMAT
-        std::vector<std::string> fmt, smp; { std::stringstream a(f[8]), b(f[9]); std::string x; while (std::getline(a, x, ':')) fmt.push_back(x); while (std::getline(b, x, ':')) smp.push_back(x); }
-        size_t gi = std::find(fmt.begin(), fmt.end(), "GT") - fmt.begin();
-        if (gi >= fmt.size() || gi >= smp.size()) die("pos " + f[1] + " missing GT value");
-        const std::string &gt = smp[gi];
-        if (!(gt == "0/1" || gt == "1/0" || gt == "0|1" || gt == "1|0")) continue;
-        if (!out.count(f[0])) { out[f[0]]; chr_order.push_back(f[0]); }
-        out[f[0]].rows[std::stoi(f[1]) - 1] = {ref, alt};           // map semantics: the later record at one position wins
-    }
-    for (auto &kv : out) for (auto &r : kv.second.rows) { kv.second.pos.push_back(r.first); kv.second.ref.push_back(r.second.first); kv.second.alt.push_back(r.second.second); }
-}
-
-static void read_fasta(const std::string &path, const std::map<std::string, ChrVariants> &want, std::map<std::string, std::string> &seqs) {
-    std::ifstream f(path); if (!f) die("ERROR: Cannot open reference " + path);
-    std::string ln, cur; std::string *dst = nullptr;
-    while (std::getline(f, ln)) {
-        if (!ln.empty() && ln[0] == '>') { std::string name = ln.substr(1, ln.find_first_of(" \t", 1) - 1); dst = want.count(name) ? &seqs[name] : nullptr; continue; }
-        if (dst) { if (!ln.empty() && ln.back() == '\r') ln.pop_back(); dst->append(ln); }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ VCF rewriter
-struct Phased { int32_t ps; char a, b; };
-// SnpParser::writeLine (ParsingBam.cpp:460-635) restated
-static void write_vcf(const std::vector<std::string> &lines, const std::string &out_path, const std::map<std::string, std::map<int32_t, Phased>> &res,
-                      const std::map<std::string, ChrVariants> &vars, const std::string &command) {
-    std::ofstream o(out_path); if (!o) die("Fail to open write file: " + out_path);
-    bool ps_def = false, cmd_done = false;
-    for (const std::string &in : lines) {
-        if (in.compare(0, 2, "##") == 0) { if (in.compare(0, 16, "##FORMAT=<ID=PS,") == 0) ps_def = true; o << in << "\n"; continue; }
-        if (in.compare(0, 6, "#CHROM") == 0 || in.compare(0, 6, "#chrom") == 0) {
-            if (!cmd_done) {
-                if (!ps_def) { o << "##FORMAT=<ID=PS,Number=1,Type=Integer,Description=\"Phase set identifier\">\n"; ps_def = true; }
-                o << "##longphaseVersion=" << kVersion << "\n" << "##commandline=\"" << command << "\"\n"; cmd_done = true;
-            }
-            o << in << "\n"; continue;
-        }
-        std::istringstream iss(in);
-        std::vector<std::string> f((std::istream_iterator<std::string>(iss)), std::istream_iterator<std::string>());
-        if (f.empty()) continue;
-        if (f.size() < 10) { o << in << "\n"; continue; }
-        const int32_t pidx = std::stoi(f[1]) - 1;
-        auto colon_index = [](const std::string &fmt, size_t upto) { int c = 0; for (size_t i = 0; i < upto; ++i) if (fmt[i] == ':') ++c; return c; };
-        auto value_start = [](const std::string &v, int colons) { int cur = 0; size_t st = 0; for (size_t i = 0; i < v.size(); ++i) { if (cur >= colons) break; if (v[i] == ':') ++cur; ++st; } return st; };
-        if (f[8].find("PS") != std::string::npos) {                  // strip an existing PS key and value
-            const size_t pp = f[8].find("PS"); const int cp = colon_index(f[8], pp);
-            if (f[8].find(":", pp + 1) != std::string::npos) f[8].erase(pp, 3); else f[8].erase(pp - 1, 3);
-            const size_t st = value_start(f[9], cp);
-            if (f[9].find(":", st + 1) != std::string::npos) { const size_t e = f[9].find(":", st + 1); f[9].erase(st, e - st + 1); }
-            else f[9].erase(st - 1, f[9].length() - st + 1);
-        }
-        if (f[8].find("GT") != std::string::npos) {                  // un-phase an existing phased GT
-            const size_t gp = f[8].find("GT"); const size_t st = value_start(f[9], colon_index(f[8], gp));
-            if (st + 2 < f[9].size() + 1 && f[9][st + 1] == '|') {
-                if (f[9][st] > f[9][st + 2]) { f[9][st + 1] = f[9][st]; f[9][st] = f[9][st + 2]; f[9][st + 2] = f[9][st + 1]; }
-                f[9][st + 1] = '/';
-            }
-        }
-        const Phased *ph = nullptr;
-        auto rc = res.find(f[0]);
-        if (rc != res.end()) { auto it = rc->second.find(pidx); if (it != rc->second.end()) ph = &it->second; }
-        bool extracted = false;
-        auto vc = vars.find(f[0]);
-        if (vc != vars.end()) extracted = std::binary_search(vc->second.pos.begin(), vc->second.pos.end(), pidx);
-        if (ph && extracted) {
-            f[8] += ":PS"; f[9] += ":" + std::to_string(ph->ps);
-            const size_t gp = f[8].find("GT"); const size_t st = value_start(f[9], colon_index(f[8], gp));
-            f[9][st] = ph->a; f[9][st + 1] = '|'; f[9][st + 2] = ph->b;
-        } else { f[8] += ":PS"; f[9] += ":."; }
-        for (size_t i = 0; i < f.size(); ++i) { if (i) o << "\t"; o << f[i]; }
-        o << "\n";
-    }
-}
+// Not supported (the reference path must be used): --sv-file, --mod-file, --dot, --deepsomatic_output, CRAM.
+// Split in round 2: cli_common.h (loader), cli_bam.h (BGZF/BAM in, BGZF out), cli_vcf.h (VCF/FASTA in, phased VCF out), cli_purity.h (purity estimator).
+#include "cli_common.h"
+#include "cli_bam.h"
+#include "cli_vcf.h"
+#include "cli_purity.h"
 
 // ------------------------------------------------------------------------------------------------ phase
 static const char *kUsage =
@@ -445,7 +26,11 @@ static const char *kUsage =
 
 static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over; bool indels = false;
-    std::string snp, ref, prefix = "result"; std::vector<std::string> bams; int threads = 1, gpu = 0, n_gpus = 1; uint64_t group_bytes = 8ull << 30; bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false;
+    std::string snp, ref, prefix = "result";
+    std::vector<std::string> bams;
+    int threads = 1, gpu = 0, n_gpus = 1;
+    uint64_t group_bytes = 8ull << 30;
+    bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -458,15 +43,27 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "-t" || a == "--threads") threads = std::stoi(val());
         else if (a == "--ont") ont = true; else if (a == "--pb") pb = true;
         else if (a == "--indels") { indels = true; over.push_back([](lps_params &P) { P.phase_indel = 1; }); }
-        else if (a == "-q" || a == "--mappingQuality") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.mapping_quality = x; }); }
+        else if (a == "-q" || a == "--mappingQuality") { const auto x = std::stoi(val());
+            over.push_back([x](lps_params &P) { P.mapping_quality = x; });
+            }
         else if (a == "-p" || a == "--baseQuality") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.base_quality = x; }); }
         else if (a == "-e" || a == "--edgeWeight") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.edge_weight = x; }); }
-        else if (a == "-a" || a == "--connectAdjacent") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.connect_adjacent = x; }); }
+        else if (a == "-a" || a == "--connectAdjacent") { const auto x = std::stoi(val());
+            over.push_back([x](lps_params &P) { P.connect_adjacent = x; });
+            }
         else if (a == "-d" || a == "--distance") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.distance = x; }); }
-        else if (a == "-1" || a == "--edgeThreshold") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.edge_threshold = x; }); }
-        else if (a == "-L" || a == "--overlapThreshold") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.overlap_threshold = x; }); }
-        else if (a == "-m" || a == "--readConfidence") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.read_confidence = x; }); }
-        else if (a == "-n" || a == "--snpConfidence") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.snp_confidence = x; }); }
+        else if (a == "-1" || a == "--edgeThreshold") { const auto x = std::stod(val());
+            over.push_back([x](lps_params &P) { P.edge_threshold = x; });
+            }
+        else if (a == "-L" || a == "--overlapThreshold") { const auto x = std::stod(val());
+            over.push_back([x](lps_params &P) { P.overlap_threshold = x; });
+            }
+        else if (a == "-m" || a == "--readConfidence") { const auto x = std::stod(val());
+            over.push_back([x](lps_params &P) { P.read_confidence = x; });
+            }
+        else if (a == "-n" || a == "--snpConfidence") { const auto x = std::stod(val());
+            over.push_back([x](lps_params &P) { P.snp_confidence = x; });
+            }
         else if (a == "-x" || a == "--mismatchRate") (void)val();
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--gpus") n_gpus = std::max(1, std::stoi(val()));
@@ -495,7 +92,8 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::map<std::string, std::string> seqs; read_fasta(ref, vars, seqs);
     const double t_text = now();
     // one BAM: BGZF inflate, record discovery and record decode all run on the GPU; several BAMs (or --host-inflate): zlib on `-t` host threads
-    if (!host_inflate && !gpu_inflate && bams.size() == 1) host_inflate = file_bytes(bams[0]) < kGpuInflateMinBytes;   // small file: zlib on the host overlaps the GPU start-up
+    if (!host_inflate && !gpu_inflate && bams.size() == 1) host_inflate = file_bytes(bams[0]) < kGpuInflateMinBytes;
+    // small file: zlib on the host overlaps the GPU start-up
     const bool gpu_input = bams.size() == 1 && !host_inflate;
     std::vector<BamFile> files(gpu_input ? 0 : bams.size());
     for (size_t b = 0; b < files.size(); ++b) files[b].load(bams[b], threads, want);
@@ -511,30 +109,58 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     // packed SNP table of the whole genome (pos i32 | ref0 u8 | alt0 u8 | ref_len u16 | alt_len u16, contig after contig): worker 0 builds it from the parsed
     // VCF; with --gpus N it reaches the other GPUs by one RCCL broadcast (lps_comm_bcast) and every worker reads its contigs' rows from ITS copy
     struct Packed { std::vector<uint8_t> buf; size_t n = 0; std::map<std::string, std::pair<size_t, size_t>> where;
-        const int32_t *pos() const { return (const int32_t *)buf.data(); } const uint8_t *r0() const { return buf.data() + 4 * n; } const uint8_t *a0() const { return buf.data() + 5 * n; }
-        const uint16_t *rl() const { return (const uint16_t *)(buf.data() + 6 * n); } const uint16_t *al() const { return (const uint16_t *)(buf.data() + 8 * n); } };
+        const int32_t *pos() const { return (const int32_t *)buf.data();
+            } const uint8_t *r0() const { return buf.data() + 4 * n;
+            } const uint8_t *a0() const { return buf.data() + 5 * n;
+            }
+        const uint16_t *rl() const { return (const uint16_t *)(buf.data() + 6 * n);
+            } const uint16_t *al() const { return (const uint16_t *)(buf.data() + 8 * n);
+            } };
     Packed table0;
     { size_t n = 0; for (const std::string &c : chr_order) { table0.where[c] = {n, vars[c].pos.size()}; n += vars[c].pos.size(); }
       table0.n = n; table0.buf.assign(10 * n + 16, 0);
-      int32_t *pp = (int32_t *)table0.buf.data(); uint8_t *r0 = table0.buf.data() + 4 * n, *a0 = table0.buf.data() + 5 * n; uint16_t *rl = (uint16_t *)(table0.buf.data() + 6 * n), *al = (uint16_t *)(table0.buf.data() + 8 * n);
+      int32_t *pp = (int32_t *)table0.buf.data();
+      uint8_t *r0 = table0.buf.data() + 4 * n, *a0 = table0.buf.data() + 5 * n;
+      uint16_t *rl = (uint16_t *)(table0.buf.data() + 6 * n), *al = (uint16_t *)(table0.buf.data() + 8 * n);
       for (const std::string &c : chr_order) { const ChrVariants &cv = vars[c]; const size_t o = table0.where[c].first;
-          for (size_t i = 0; i < cv.pos.size(); ++i) { pp[o + i] = cv.pos[i]; r0[o + i] = (uint8_t)cv.ref[i][0]; a0[o + i] = (uint8_t)cv.alt[i][0]; rl[o + i] = (uint16_t)cv.ref[i].size(); al[o + i] = (uint16_t)cv.alt[i].size(); } } }
+          for (size_t i = 0; i < cv.pos.size(); ++i) { pp[o + i] = cv.pos[i];
+              r0[o + i] = (uint8_t)cv.ref[i][0];
+              a0[o + i] = (uint8_t)cv.alt[i][0];
+              rl[o + i] = (uint16_t)cv.ref[i].size();
+              al[o + i] = (uint16_t)cv.alt[i].size();
+              } } }
     auto run_contig = [&](lps_ctx *ctx, GpuBam &gb, const std::string &chr, const Packed &tab) {   // PhasingProcess.cpp:113-173, one contig on one GPU
         ChrVariants &cv = vars[chr];
         if (cv.pos.empty() || !seqs.count(chr)) return;
         // names of all files of this contig ranked together (one read name = one merged row, whatever file it came from)
-        std::vector<std::pair<const char *, size_t>> names; std::vector<const ContigRecords *> parts; std::vector<char> name_store; std::vector<uint32_t> name_off;
+        std::vector<std::pair<const char *, size_t>> names;
+        std::vector<const ContigRecords *> parts;
+        std::vector<char> name_store;
+        std::vector<uint32_t> name_off;
         std::pair<int64_t, int64_t> gr{0, 0};
         if (gpu_input) {
             { auto it = gb.range.find(chr); if (it == gb.range.end()) return; gr = it->second; }   // whole file, or the group loaded by the caller
             gb.names(L, ctx, gr.first, gr.second, name_store, name_off, names);
         }
-        for (BamFile &f : files) { auto it = f.contigs.find(chr); if (it == f.contigs.end() || it->second.rec_off.empty()) { parts.push_back(nullptr); continue; }
-            parts.push_back(&it->second); for (size_t i = 0; i < it->second.rec_off.size(); ++i) { size_t l; const char *nm = f.name_of(it->second, i, l); names.emplace_back(nm, l); } }
+        for (BamFile &f : files) { auto it = f.contigs.find(chr);
+            if (it == f.contigs.end() || it->second.rec_off.empty()) { parts.push_back(nullptr);
+                continue;
+                }
+            parts.push_back(&it->second);
+            for (size_t i = 0; i < it->second.rec_off.size(); ++i) { size_t l;
+                const char *nm = f.name_of(it->second, i, l);
+                names.emplace_back(nm, l);
+                } }
         if (names.empty()) return;
         std::vector<uint32_t> name_id; rank_names(names, name_id);
         const size_t to = tab.where.at(chr).first;
-        lps_variant_table vt{}; vt.n = (int64_t)cv.pos.size(); vt.pos = tab.pos() + to; vt.ref0 = tab.r0() + to; vt.alt0 = tab.a0() + to; vt.ref_len = tab.rl() + to; vt.alt_len = tab.al() + to;
+        lps_variant_table vt{};
+        vt.n = (int64_t)cv.pos.size();
+        vt.pos = tab.pos() + to;
+        vt.ref0 = tab.r0() + to;
+        vt.alt0 = tab.a0() + to;
+        vt.ref_len = tab.rl() + to;
+        vt.alt_len = tab.al() + to;
         const std::string &sq = seqs[chr];
         if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size())) die(std::string("longphase_amd: ") + L.last_error(ctx));
         size_t at = 0;
@@ -556,19 +182,26 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     // contigs never interact: with --gpus N and an indexed BAM they are dealt longest-first onto N contexts, one host thread + one
     // GPU each, every worker uploading only the BGZF blocks of its own contigs.  No data-path collective; results meet in the VCF writer.
     int n_workers = 1;
-    if (n_gpus > 1) { if (gpu_input && gb.indexed) n_workers = n_gpus; else std::cerr << "longphase_amd: --gpus needs one BAM with its .bai index; running on one GPU\n"; }
+    if (n_gpus > 1) { if (gpu_input && gb.indexed) n_workers = n_gpus;
+        else std::cerr << "longphase_amd: --gpus needs one BAM with its .bai index; running on one GPU\n";
+        }
     std::vector<std::vector<std::string>> share((size_t)n_workers);
     {
-        std::vector<std::string> by_size(chr_order); std::stable_sort(by_size.begin(), by_size.end(), [&](const std::string &a, const std::string &b) { return vars[a].pos.size() > vars[b].pos.size(); });
+        std::vector<std::string> by_size(chr_order);
+        std::stable_sort(by_size.begin(), by_size.end(), [&](const std::string &a, const std::string &b) { return vars[a].pos.size() > vars[b].pos.size(); });
         std::vector<size_t> load((size_t)n_workers, 0);
         if (n_workers == 1) share[0] = chr_order;
-        else for (const std::string &c : by_size) { const size_t g = (size_t)(std::min_element(load.begin(), load.end()) - load.begin()); share[g].push_back(c); load[g] += vars[c].pos.size() + 1; }
+        else for (const std::string &c : by_size) { const size_t g = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+            share[g].push_back(c);
+            load[g] += vars[c].pos.size() + 1;
+            }
     }
     std::vector<std::thread> workers;
     const int n_dev = std::max(1, L.device_count());
     auto run_share = [&](lps_ctx *cx, GpuBam &g, std::vector<std::string> list, const Packed &tab) {
         if (!gpu_input || !g.indexed) { for (const std::string &c : list) run_contig(cx, g, c, tab); return; }
-        std::sort(list.begin(), list.end(), [&](const std::string &a, const std::string &b) { return g.tid_of(a) < g.tid_of(b); });   // file order, so that neighbours share an upload
+        std::sort(list.begin(), list.end(), [&](const std::string &a, const std::string &b) { return g.tid_of(a) < g.tid_of(b); });
+        // file order, so that neighbours share an upload
         for (auto &grp : g.plan_groups(list, group_bytes)) { g.load_group(L, cx, grp); for (const std::string &c : grp) run_contig(cx, g, c, tab); }
     };
     // the one collective: a communicator over the workers' GPUs (ncclCommInitAll); fails when two workers share a device (rehearsal on fewer GPUs
@@ -577,10 +210,15 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     if (n_workers > 1) { std::vector<int> devs; for (int g = 0; g < n_workers; ++g) devs.push_back((gpu + g) % n_dev);
         have_comm = std::set<int>(devs.begin(), devs.end()).size() == devs.size() && L.comm_create_all(n_workers, devs.data(), comms.data()) == 0;
         if (have_comm) std::cerr << "longphase_amd: RCCL communicator over " << L.comm_size(comms[0]) << " GPUs\n";
-        else std::cerr << "longphase_amd: no RCCL communicator (" << (std::set<int>(devs.begin(), devs.end()).size() == devs.size() ? L.comm_last_error() : "workers share a device") << "); workers read the host table\n"; }
+        else std::cerr << "longphase_amd: no RCCL communicator (" << (std::set<int>(devs.begin(), devs.end()).size() == devs.size() ? L.comm_last_error() : "workers share a device") << "); workers read the host table\n";
+        }
     auto obtain_table = [&](int g, Packed &mine) -> const Packed & {       // every worker calls this once (collective)
         if (!have_comm) return table0;
-        if (g == 0) { double ms = 0; if (L.comm_bcast(comms[0], table0.buf.data(), (int64_t)table0.buf.size(), 0, &ms)) die(std::string("longphase_amd: ") + L.comm_last_error()); fprintf(stderr, "longphase_amd: SNP table broadcast, %zu bytes, %.3f ms\n", table0.buf.size(), ms); return table0; }
+        if (g == 0) { double ms = 0;
+            if (L.comm_bcast(comms[0], table0.buf.data(), (int64_t)table0.buf.size(), 0, &ms)) die(std::string("longphase_amd: ") + L.comm_last_error());
+            fprintf(stderr, "longphase_amd: SNP table broadcast, %zu bytes, %.3f ms\n", table0.buf.size(), ms);
+            return table0;
+            }
         mine.n = table0.n; mine.where = table0.where; mine.buf.assign(table0.buf.size(), 0);
         if (L.comm_bcast(comms[(size_t)g], mine.buf.data(), (int64_t)mine.buf.size(), 0, nullptr)) die(std::string("longphase_amd: ") + L.comm_last_error());
         return mine;
@@ -611,122 +249,6 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     _exit(0);   // outputs are closed and flushed; skip the ROCm runtime's static teardown (~0.1 s)
 }
 
-// ------------------------------------------------------------------------------------------------ haplotag
-// Phased-het rows of the SNP VCF = the haplotag table: VcfParser::parserProcess (src/haplotag/HaplotagVcfParser.cpp:234-400).
-struct PhasedRow { std::string ref, alt; int32_t ps; uint8_t hp1_is_alt; };
-static void parse_phased_vcf(const std::vector<std::string> &lines, std::vector<std::string> &chr_vec, std::map<std::string, int> &chr_len,
-                             std::map<std::string, std::map<int32_t, PhasedRow>> &rows) {
-    for (const std::string &in : lines) {
-        if (in.compare(0, 2, "##") == 0) {
-            if (in.find("contig=") != std::string::npos) {                                   // :236-248 (needs ",length=")
-                const size_t a = in.find("ID=") + 3, b = in.find(",length="), e = in.find(">");
-                if (b == std::string::npos) die("[ERROR] contig header line without length: " + in);
-                const std::string chr = in.substr(a, b - a);
-                chr_vec.push_back(chr); chr_len[chr] = std::stoi(in.substr(b + 8, e - b - 8));
-            }
-            if (in.compare(0, 16, "##FORMAT=<ID=PS,") == 0 && in.find("Type=Integer") == std::string::npos) die("longphase_amd: only an Integer PS field is supported");
-            continue;
-        }
-        if (in.empty() || in[0] == '#') continue;
-        std::istringstream iss(in);
-        std::vector<std::string> f((std::istream_iterator<std::string>(iss)), std::istream_iterator<std::string>());
-        if (f.empty()) continue;
-        if (f.size() < 10) die("[ERROR](VcfParser::parserProcess) => VCF file format not supported: " + in);
-        auto start_of = [&](const char *key) { const size_t kp = f[8].find(key); int colons = 0; for (size_t i = 0; i < kp && i < f[8].size(); ++i) if (f[8][i] == ':') ++colons;
-            int cur = 0; size_t st = 0; for (size_t i = 0; i < f[9].size(); ++i) { if (cur >= colons) break; if (f[9][i] == ':') ++cur; ++st; } return st; };
-        const size_t g = start_of("GT");
-        if (g + 2 >= f[9].size() + 0 && g + 2 > f[9].size() - 1) continue;
-        if (!(f[9][g] != f[9][g + 2] && f[9][g + 1] == '|')) continue;                      // phased hetero GT only (:296)
-        const size_t ps0 = start_of("PS");
-        const size_t pe = f[9].find(':', ps0 + 1);
-        const std::string psv = pe != std::string::npos ? f[9].substr(ps0, pe - ps0) : f[9].substr(ps0);
-        PhasedRow r; r.ref = f[3];
-        if (f[4].find(',') != std::string::npos) { if (f[9].find('2') != std::string::npos) continue; r.alt = f[4].substr(0, f[4].find(',')); }   // :333-347
-        else r.alt = f[4];
-        try { r.ps = std::stoi(psv); } catch (...) { die("longphase_amd: phased record without an integer PS value: " + in); }
-        if (f[9][g] == '0' && f[9][g + 2] == '1') r.hp1_is_alt = 0;
-        else if (f[9][g] == '1' && f[9][g + 2] == '0') r.hp1_is_alt = 1;
-        else die("longphase_amd: phased genotype other than 0|1 / 1|0 is not supported: " + in);
-        rows[f[0]][std::stoi(f[1]) - 1] = r;
-    }
-}
-
-// BGZF writer: the byte stream is cut into 0xff00-byte blocks (htslib's BGZF_BLOCK_SIZE) that are deflated by a thread pool and
-// written in order; ends with the 28-byte EOF block.
-struct BgzfWriter {
-    FILE *f = nullptr; int threads = 1, level = 6, strategy = Z_RLE; unsigned long long bytes_out = 0; std::vector<uint8_t> pend;   // pend: < one block of bytes not yet written
-    static constexpr size_t B = 0xff00;
-    void open(const std::string &path, int t, int lvl, int strat) { f = fopen(path.c_str(), "wb"); if (!f) die("Fail to open write file: " + path); threads = std::max(1, t); level = lvl; strategy = strat; }
-    // deflate the blocks of B bytes (the last one may be shorter) starting at p and write them in order; batches of 1024 blocks, the finished
-    // batch is written by a helper thread while the pool deflates the next one
-    std::thread writer; std::vector<std::vector<uint8_t>> inflight; std::atomic<int> write_bad{0};
-    void wait_writer() { if (writer.joinable()) writer.join(); if (write_bad) die("ERROR: write output bam file failed"); }
-    void emit(const uint8_t *p, size_t n) {
-        const size_t total_blk = (n + B - 1) / B, batch = 1024;
-        for (size_t b0 = 0; b0 < total_blk; b0 += batch) {
-            const size_t nblk = std::min(batch, total_blk - b0); const uint8_t *q = p + b0 * B; const size_t qn = std::min(n - b0 * B, nblk * B);
-            std::vector<std::vector<uint8_t>> out(nblk); std::atomic<size_t> next{0}; std::vector<std::thread> th; std::atomic<int> bad{0};
-            auto work = [&] {
-                z_stream zs{}; if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, strategy) != Z_OK) { bad = 1; return; }
-                for (;;) { const size_t b = next.fetch_add(1); if (b >= nblk) break;
-                    const size_t off = b * B, len = std::min(B, qn - off);
-                    std::vector<uint8_t> &o = out[b]; o.resize(18 + deflateBound(&zs, (uLong)len) + 8);
-                    deflateReset(&zs); zs.next_in = const_cast<uint8_t *>(q) + off; zs.avail_in = (uInt)len; zs.next_out = o.data() + 18; zs.avail_out = (uInt)(o.size() - 26);
-                    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { bad = 1; break; }
-                    const size_t clen = zs.total_out, bsize = 18 + clen + 8;
-                    if (bsize > 65536) { bad = 1; break; }
-                    const uint8_t hdr[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1) & 255), (uint8_t)((bsize - 1) >> 8)};
-                    memcpy(o.data(), hdr, 18);
-                    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), q + off, (uInt)len), isz = (uint32_t)len;
-                    for (int k = 0; k < 4; ++k) { o[18 + clen + k] = (uint8_t)(crc >> (8 * k)); o[22 + clen + k] = (uint8_t)(isz >> (8 * k)); }
-                    o.resize(bsize);
-                }
-                deflateEnd(&zs);
-            };
-            const int nt = (int)std::min<size_t>(threads, nblk);
-            for (int t = 1; t < nt; ++t) th.emplace_back(work);
-            work();
-            for (auto &x : th) x.join();
-            if (bad) die("ERROR: deflate failed");
-            wait_writer();
-            inflight.swap(out);
-            for (auto &o : inflight) bytes_out += o.size();
-            writer = std::thread([this] { for (auto &o : inflight) if (fwrite(o.data(), 1, o.size(), f) != o.size()) { write_bad = 1; break; } });
-        }
-    }
-    void append(const uint8_t *p, size_t n) {
-        if (!pend.empty()) {                                            // top up the open block first
-            const size_t k = std::min(n, B - pend.size()); pend.insert(pend.end(), p, p + k); p += k; n -= k;
-            if (pend.size() < B) return;
-            emit(pend.data(), B); pend.clear();
-        }
-        const size_t whole = n / B * B;
-        emit(p, whole);
-        pend.assign(p + whole, p + n);
-    }
-    void flush_partial() { emit(pend.data(), pend.size()); pend.clear(); wait_writer(); }
-    void write_raw(const uint8_t *p, size_t n) { wait_writer(); if (n && fwrite(p, 1, n, f) != n) die("ERROR: write output bam file failed"); bytes_out += n; }
-    void finish() {
-        emit(pend.data(), pend.size()); pend.clear(); wait_writer();
-        static const uint8_t eof[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (fwrite(eof, 1, 28, f) != 28 || fclose(f) != 0) die("ERROR: write output bam file failed");
-        f = nullptr;
-    }
-};
-
-// byte length of one aux field starting at p (tag[2] type value), 0 when malformed
-static size_t aux_field_len(const uint8_t *p, const uint8_t *end) {
-    if (p + 3 > end) return 0;
-    const uint8_t t = p[2]; size_t v = 0;
-    switch (t) {
-        case 'A': case 'c': case 'C': v = 1; break; case 's': case 'S': v = 2; break; case 'i': case 'I': case 'f': v = 4; break; case 'd': v = 8; break;
-        case 'Z': case 'H': { const uint8_t *q = p + 3; while (q < end && *q) ++q; if (q >= end) return 0; v = (size_t)(q - (p + 3)) + 1; break; }
-        case 'B': { if (p + 8 > end) return 0; const uint8_t st = p[3]; const size_t cnt = rd32(p + 4); size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0; if (!es) return 0; v = 5 + cnt * es; break; }
-        default: return 0;
-    }
-    return p + 3 + v <= end ? 3 + v : 0;
-}
-
 static const char *kTagUsage =
     "Usage: longphase_amd haplotag [OPTION] ... READSFILE\n"
     "   -s, --snp-file=NAME   -b, --bam-file=NAME   -r, --reference=NAME   -o, --out-prefix=NAME (result)   -t, --threads=Num (1)\n"
@@ -739,7 +261,10 @@ static const char *kTagUsage =
 
 static int haplotag_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
-    std::string snp, ref, bam, prefix = "result"; int threads = 1, gpu = 0, n_gpus = 1, level = 6, strategy = Z_RLE; bool host_inflate = false, gpu_inflate = false, no_index = false, host_deflate = false; uint64_t group_bytes = 8ull << 30;
+    std::string snp, ref, bam, prefix = "result";
+    int threads = 1, gpu = 0, n_gpus = 1, level = 6, strategy = Z_RLE;
+    bool host_inflate = false, gpu_inflate = false, no_index = false, host_deflate = false;
+    uint64_t group_bytes = 8ull << 30;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kTagUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -751,8 +276,12 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         else if (a == "-o" || a == "--out-prefix") prefix = val();
         else if (a == "-t" || a == "--threads") threads = std::stoi(val());
         else if (a == "--tagSupplementary") over.push_back([](lps_params &P) { P.tag_supplementary = 1; });
-        else if (a == "-q" || a == "--qualityThreshold") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.mapping_quality = x; }); }
-        else if (a == "-p" || a == "--percentageThreshold") { const auto x = std::stod(val()); over.push_back([x](lps_params &P) { P.percentage_threshold = x; }); }
+        else if (a == "-q" || a == "--qualityThreshold") { const auto x = std::stoi(val());
+            over.push_back([x](lps_params &P) { P.mapping_quality = x; });
+            }
+        else if (a == "-p" || a == "--percentageThreshold") { const auto x = std::stod(val());
+            over.push_back([x](lps_params &P) { P.percentage_threshold = x; });
+            }
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--gpus") n_gpus = std::max(1, std::stoi(val()));
         else if (a == "--host-inflate") host_inflate = true;
@@ -761,7 +290,10 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         else if (a == "--host-deflate") host_deflate = true;
         else if (a == "--group-bytes") group_bytes = (uint64_t)std::stoull(val());
         else if (a == "--compress-level") level = std::stoi(val());
-        else if (a == "--compress-strategy") { const std::string x = val(); strategy = x == "default" ? Z_DEFAULT_STRATEGY : x == "rle" ? Z_RLE : x == "huffman" ? Z_HUFFMAN_ONLY : -1; if (strategy < 0) die("longphase_amd: --compress-strategy is one of default, rle, huffman"); }
+        else if (a == "--compress-strategy") { const std::string x = val();
+            strategy = x == "default" ? Z_DEFAULT_STRATEGY : x == "rle" ? Z_RLE : x == "huffman" ? Z_HUFFMAN_ONLY : -1;
+            if (strategy < 0) die("longphase_amd: --compress-strategy is one of default, rle, huffman");
+            }
         else if (a == "--help") { std::cout << kTagUsage; return 0; }
         else if (a == "--sv-file" || a == "--mod-file" || a == "--cram" || a == "--region" || a == "--log") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kTagUsage; return 1; }
@@ -793,8 +325,12 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     const double t_ctx = now();
     // copy [0, total) of the stream resident on the GPU into `in.z` (2 MiB pages, touched by a few threads first so the D2H does not fault serially)
     auto copy_back = [&](int64_t total) {
-        if ((size_t)total + 64 > in_cap) { free(in.z.data); const size_t huge = 2u << 20; in_cap = ((size_t)total + 64 + huge - 1) / huge * huge + (in_cap >> 1);
-            in.z.data = (uint8_t *)aligned_alloc(huge, in_cap / huge * huge + huge); if (!in.z.data) die("ERROR: out of memory"); madvise(in.z.data, in_cap, MADV_HUGEPAGE);
+        if ((size_t)total + 64 > in_cap) { free(in.z.data);
+            const size_t huge = 2u << 20;
+            in_cap = ((size_t)total + 64 + huge - 1) / huge * huge + (in_cap >> 1);
+            in.z.data = (uint8_t *)aligned_alloc(huge, in_cap / huge * huge + huge);
+            if (!in.z.data) die("ERROR: out of memory");
+            madvise(in.z.data, in_cap, MADV_HUGEPAGE);
             std::vector<std::thread> th; const int nt = std::max(1, std::min(threads, 8)); const size_t slice = (in_cap + nt - 1) / nt;
             for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { const size_t a = std::min(in_cap, slice * t), e = std::min(in_cap, a + slice); for (size_t p = a; p < e; p += 4096) in.z.data[p] = 0; });
             for (auto &x : th) x.join(); }
@@ -821,15 +357,28 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         const uint8_t *d = host_inflate ? in.z.data : gb.header.data(); const uint32_t l_text = rd32(d + 4);
         std::string text((const char *)d + 8, l_text); while (!text.empty() && text.back() == '\0') text.pop_back();
         if (!text.empty() && text.back() != '\n') text += '\n';
-        std::string last_pg; for (size_t p = 0; p < text.size();) { const size_t e = text.find('\n', p); const std::string ln = text.substr(p, e - p);
-            if (ln.compare(0, 3, "@PG") == 0) { const size_t i = ln.find("\tID:"); if (i != std::string::npos) last_pg = ln.substr(i + 4, ln.find('\t', i + 4) - i - 4); } p = e == std::string::npos ? text.size() : e + 1; }
+        std::string last_pg;
+        for (size_t p = 0; p < text.size();) { const size_t e = text.find('\n', p);
+            const std::string ln = text.substr(p, e - p);
+            if (ln.compare(0, 3, "@PG") == 0) { const size_t i = ln.find("\tID:");
+                if (i != std::string::npos) last_pg = ln.substr(i + 4, ln.find('\t', i + 4) - i - 4);
+                } p = e == std::string::npos ? text.size() : e + 1;
+            }
         text += "@PG\tID:longphase_amd\tPN:longphase_amd" + (last_pg.empty() ? std::string() : "\tPP:" + last_pg) + "\tVN:" + kVersion + "\tCL:" + command + "\n";
-        std::vector<uint8_t> h; h.insert(h.end(), d, d + 4); const uint32_t lt = (uint32_t)text.size(); for (int k = 0; k < 4; ++k) h.push_back((uint8_t)(lt >> (8 * k)));
+        std::vector<uint8_t> h;
+        h.insert(h.end(), d, d + 4);
+        const uint32_t lt = (uint32_t)text.size();
+        for (int k = 0; k < 4; ++k) h.push_back((uint8_t)(lt >> (8 * k)));
         h.insert(h.end(), text.begin(), text.end());
-        size_t p = 8 + (size_t)l_text; const size_t ref_begin = p; const uint32_t n_ref = rd32(d + p); p += 4; for (uint32_t i = 0; i < n_ref; ++i) p += 4 + (size_t)rd32(d + p) + 4;
+        size_t p = 8 + (size_t)l_text;
+        const size_t ref_begin = p;
+        const uint32_t n_ref = rd32(d + p);
+        p += 4;
+        for (uint32_t i = 0; i < n_ref; ++i) p += 4 + (size_t)rd32(d + p) + 4;
         h.insert(h.end(), d + ref_begin, d + p);
         w.append(h.data(), h.size());
-        if (gpu_writer) w.flush_partial();                             // the header becomes its own BGZF block(s); the GPU writes whole blocks per contig
+        if (gpu_writer) w.flush_partial();
+        // the header becomes its own BGZF block(s); the GPU writes whole blocks per contig
     }
     unsigned long long st_count[8] = {0}, hp_count[3] = {0};
     double t_score = 0, t_splice = 0, t_deflate = 0, t_load = 0, t_mark = now(); std::vector<uint8_t> zbuf;
@@ -851,8 +400,24 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
                 if (!seqs.count(chr)) die("ERROR: contig " + chr + " is missing from the reference FASTA");
                 const size_t m = ri->second.size();
                 std::vector<int32_t> pos(m), ps(m); std::vector<uint8_t> r0(m), a0(m), hpa(m); std::vector<uint16_t> rl(m), al(m); size_t k = 0;
-                for (auto &kv : ri->second) { pos[k] = kv.first; r0[k] = (uint8_t)kv.second.ref[0]; a0[k] = (uint8_t)kv.second.alt[0]; rl[k] = (uint16_t)kv.second.ref.size(); al[k] = (uint16_t)kv.second.alt.size(); hpa[k] = kv.second.hp1_is_alt; ps[k] = kv.second.ps; ++k; }
-                lps_variant_table vt{}; vt.n = (int64_t)m; vt.pos = pos.data(); vt.ref0 = r0.data(); vt.alt0 = a0.data(); vt.ref_len = rl.data(); vt.alt_len = al.data(); vt.hp1_is_alt = hpa.data(); vt.phase_set = ps.data();
+                for (auto &kv : ri->second) { pos[k] = kv.first;
+                    r0[k] = (uint8_t)kv.second.ref[0];
+                    a0[k] = (uint8_t)kv.second.alt[0];
+                    rl[k] = (uint16_t)kv.second.ref.size();
+                    al[k] = (uint16_t)kv.second.alt.size();
+                    hpa[k] = kv.second.hp1_is_alt;
+                    ps[k] = kv.second.ps;
+                    ++k;
+                    }
+                lps_variant_table vt{};
+                vt.n = (int64_t)m;
+                vt.pos = pos.data();
+                vt.ref0 = r0.data();
+                vt.alt0 = a0.data();
+                vt.ref_len = rl.data();
+                vt.alt_len = al.data();
+                vt.hp1_is_alt = hpa.data();
+                vt.phase_set = ps.data();
                 const std::string &sq = seqs.at(chr);
                 lps_haplotag_result hr{(int64_t)n, status.data(), h1.data(), h2.data(), nps.data(), psmin.data(), hp.data(), pq.data(), psv.data()};
                 if (L.begin_chromosome(cx) || L.set_variants(cx, &vt) || L.set_reference(cx, sq.data(), (int64_t)sq.size()) || L.push_bam_resident(cx, gi->second.first, (int64_t)n, name_id.data()) || L.haplotag_chromosome(cx, &hr))
@@ -866,26 +431,41 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         };
         // deal by compressed size of the contig's blocks (what the index knows), longest first
         std::vector<size_t> order(chr_vec.size()); for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-        auto weight = [&](size_t i) -> uint64_t { const int t = gb.tid_of(chr_vec[i]); return (t < 0 || (size_t)t >= gb.voff.size()) ? 0 : ((gb.voff[(size_t)t].second >> 16) - (gb.voff[(size_t)t].first >> 16)) + 1; };
+        auto weight = [&](size_t i) -> uint64_t { const int t = gb.tid_of(chr_vec[i]);
+            return (t < 0 || (size_t)t >= gb.voff.size()) ? 0 : ((gb.voff[(size_t)t].second >> 16) - (gb.voff[(size_t)t].first >> 16)) + 1;
+            };
         std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight(a) > weight(b); });
         std::vector<std::vector<size_t>> share((size_t)n_gpus); std::vector<uint64_t> load((size_t)n_gpus, 0);
-        for (size_t i : order) { const size_t g = (size_t)(std::min_element(load.begin(), load.end()) - load.begin()); share[g].push_back(i); load[g] += weight(i); }
+        for (size_t i : order) { const size_t g = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+            share[g].push_back(i);
+            load[g] += weight(i);
+            }
         const int n_dev = std::max(1, L.device_count());
         auto run_worker = [&](int g, lps_ctx *cx, GpuBam &gg) {
             std::vector<size_t> mine = share[(size_t)g];
-            std::sort(mine.begin(), mine.end(), [&](size_t a, size_t b) { return gg.tid_of(chr_vec[a]) < gg.tid_of(chr_vec[b]); });   // file order: neighbours share an upload
+            std::sort(mine.begin(), mine.end(), [&](size_t a, size_t b) { return gg.tid_of(chr_vec[a]) < gg.tid_of(chr_vec[b]); });
+            // file order: neighbours share an upload
             std::vector<std::string> names; for (size_t i : mine) names.push_back(chr_vec[i]);
             std::map<std::string, size_t> idx; for (size_t i : mine) idx[chr_vec[i]] = i;
             for (auto &grp : gg.plan_groups(names, group_bytes)) {
                 gg.load_group(L, cx, grp);
-                for (const std::string &c : grp) { Done &d = done[idx[c]]; tag_contig(cx, gg, c, d); { std::lock_guard<std::mutex> lk(mu); d.ready = true; } cv.notify_all(); }
+                for (const std::string &c : grp) { Done &d = done[idx[c]];
+                    tag_contig(cx, gg, c, d);
+                    { std::lock_guard<std::mutex> lk(mu);
+                        d.ready = true;
+                        } cv.notify_all();
+                    }
             }
-            for (size_t i : mine) { std::lock_guard<std::mutex> lk(mu); if (!done[i].ready) { done[i].ready = true; cv.notify_all(); } }     // contigs without records in the file
+            for (size_t i : mine) { std::lock_guard<std::mutex> lk(mu);
+                if (!done[i].ready) { done[i].ready = true;
+                    cv.notify_all();
+                    } }     // contigs without records in the file
         };
         std::vector<std::thread> workers;
         for (int g = 1; g < n_gpus; ++g) workers.emplace_back([&, g] {
             lps_params P; L.default_params(&P); for (auto &f : over) f(P);
-            lps_ctx *cx = L.create((gpu + g) % n_dev, &P); if (!cx) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
+            lps_ctx *cx = L.create((gpu + g) % n_dev, &P);
+            if (!cx) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
             L.set_stage_timing(cx, 0);
             GpuBam gg; gg.open_file(bam, true);
             run_worker(g, cx, gg);
@@ -912,7 +492,9 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         _exit(0);
     }
 
-    std::vector<std::vector<std::string>> groups; if (!host_inflate && gb.indexed) groups = gb.plan_groups(chr_vec, group_bytes);   // output order = chr_vec order; a group = a run of consecutive contigs in it
+    std::vector<std::vector<std::string>> groups;
+    if (!host_inflate && gb.indexed) groups = gb.plan_groups(chr_vec, group_bytes);
+    // output order = chr_vec order; a group = a run of consecutive contigs in it
     for (const std::string &chr : chr_vec) {                          // contigs in VCF-header order (HaplotagProcess.cpp:94-97)
         if (!host_inflate && gb.indexed) {                              // indexed input: the group of consecutive contigs this one belongs to is loaded when its first member comes up
             const double tl = now();
@@ -920,8 +502,14 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
                 for (auto &grp : groups) if (!grp.empty() && grp.front() == chr) {
                     gb.load_group(L, ctx, grp);
                     if (!gpu_writer) copy_back(gb.total);
-                    for (const std::string &m : grp) { auto it = gb.range.find(m); if (it == gb.range.end()) continue; ContigRecords &cc = in.contigs[m]; cc.rec_off.resize((size_t)it->second.second); cc.lo = 0; cc.hi = (uint64_t)gb.total;
-                        if (!gpu_writer && L.bam_record_offsets(ctx, it->second.first, it->second.second, cc.rec_off.data())) die(std::string("ERROR: ") + L.last_error(ctx)); }
+                    for (const std::string &m : grp) { auto it = gb.range.find(m);
+                        if (it == gb.range.end()) continue;
+                        ContigRecords &cc = in.contigs[m];
+                        cc.rec_off.resize((size_t)it->second.second);
+                        cc.lo = 0;
+                        cc.hi = (uint64_t)gb.total;
+                        if (!gpu_writer && L.bam_record_offsets(ctx, it->second.first, it->second.second, cc.rec_off.data())) die(std::string("ERROR: ") + L.last_error(ctx));
+                        }
                 }
             }
             t_load += now() - tl; t_mark = now();
@@ -935,8 +523,24 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
             if (!seqs.count(chr)) die("ERROR: contig " + chr + " is missing from the reference FASTA");
             const size_t m = ri->second.size();
             std::vector<int32_t> pos(m), ps(m); std::vector<uint8_t> r0(m), a0(m), hpa(m); std::vector<uint16_t> rl(m), al(m); size_t k = 0;
-            for (auto &kv : ri->second) { pos[k] = kv.first; r0[k] = (uint8_t)kv.second.ref[0]; a0[k] = (uint8_t)kv.second.alt[0]; rl[k] = (uint16_t)kv.second.ref.size(); al[k] = (uint16_t)kv.second.alt.size(); hpa[k] = kv.second.hp1_is_alt; ps[k] = kv.second.ps; ++k; }
-            lps_variant_table vt{}; vt.n = (int64_t)m; vt.pos = pos.data(); vt.ref0 = r0.data(); vt.alt0 = a0.data(); vt.ref_len = rl.data(); vt.alt_len = al.data(); vt.hp1_is_alt = hpa.data(); vt.phase_set = ps.data();
+            for (auto &kv : ri->second) { pos[k] = kv.first;
+                r0[k] = (uint8_t)kv.second.ref[0];
+                a0[k] = (uint8_t)kv.second.alt[0];
+                rl[k] = (uint16_t)kv.second.ref.size();
+                al[k] = (uint16_t)kv.second.alt.size();
+                hpa[k] = kv.second.hp1_is_alt;
+                ps[k] = kv.second.ps;
+                ++k;
+                }
+            lps_variant_table vt{};
+            vt.n = (int64_t)m;
+            vt.pos = pos.data();
+            vt.ref0 = r0.data();
+            vt.alt0 = a0.data();
+            vt.ref_len = rl.data();
+            vt.alt_len = al.data();
+            vt.hp1_is_alt = hpa.data();
+            vt.phase_set = ps.data();
             const std::string &sq = seqs[chr];
             std::vector<uint32_t> name_id(n, 0);                        // haplotag does not group by read name
             lps_haplotag_result hr{(int64_t)n, status.data(), h1.data(), h2.data(), nps.data(), psmin.data(), hp.data(), pq.data(), psv.data()};
@@ -964,7 +568,9 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         // second pass, records stay in input order (the reference's tagRead is single-threaded for that reason, HaplotagProcess.cpp:138):
         // (1) output length of every record, (2) prefix sum, (3) records written into place by a thread pool, (4) block-parallel deflate
         std::vector<uint64_t> out_off(n + 1, 0);
-        auto aux_of = [&](const uint8_t *r) { const uint32_t l_name = r[8], n_cig = r[12] | (r[13] << 8), l_seq = rd32(r + 16); return r + 32 + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq; };
+        auto aux_of = [&](const uint8_t *r) { const uint32_t l_name = r[8], n_cig = r[12] | (r[13] << 8), l_seq = rd32(r + 16);
+            return r + 32 + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq;
+            };
         auto parallel_records = [&](const std::function<void(size_t, size_t)> &fn) {
             const int nt = (int)std::max<size_t>(1, std::min<size_t>(threads, n / 256 + 1)); std::vector<std::thread> th;
             for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt); });
@@ -989,7 +595,10 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
             }
         });
         if (malformed) die("ERROR: malformed auxiliary field in " + bam);
-        for (size_t i = 0; i < n; ++i) { out_off[i + 1] += out_off[i]; ++st_count[status[i] & 7]; if (status[i] == 0) ++hp_count[hp[i] < 3 ? hp[i] : 0]; }
+        for (size_t i = 0; i < n; ++i) { out_off[i + 1] += out_off[i];
+            ++st_count[status[i] & 7];
+            if (status[i] == 0) ++hp_count[hp[i] < 3 ? hp[i] : 0];
+            }
         uint8_t *ob = (uint8_t *)malloc(out_off[n] + 64); if (!ob) die("ERROR: out of memory");
         parallel_records([&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i) {
@@ -997,7 +606,8 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
                 if (status[i] != 0) { memcpy(o, r - 4, 4 + (size_t)bs); continue; }             // not scored: written untouched
                 const uint8_t *aux = aux_of(r), *end = r + bs; uint8_t *q = o + 4;
                 memcpy(q, r, (size_t)(aux - r)); q += aux - r;
-                bool seen[3] = {false, false, false};                                            // initFlag: the first HP, PS and PQ field each (:337-339)
+                bool seen[3] = {false, false, false};
+                // initFlag: the first HP, PS and PQ field each (:337-339)
                 for (const uint8_t *p = aux; p < end;) {
                     const size_t l = aux_field_len(p, end);
                     const int which = (p[0] == 'H' && p[1] == 'P') ? 0 : (p[0] == 'P' && p[1] == 'S') ? 1 : (p[0] == 'P' && p[1] == 'Q') ? 2 : -1;
@@ -1006,7 +616,11 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
                 }
                 if (hp[i]) {                                                                     // addAuxiliaryTags (:357-361)
                     const int32_t vals[3] = {(int32_t)hp[i], psv[i], pq[i]}; const char *tags[3] = {"HP", "PS", "PQ"};
-                    for (int k = 0; k < 3; ++k) { *q++ = (uint8_t)tags[k][0]; *q++ = (uint8_t)tags[k][1]; *q++ = 'i'; for (int b = 0; b < 4; ++b) *q++ = (uint8_t)((uint32_t)vals[k] >> (8 * b)); }
+                    for (int k = 0; k < 3; ++k) { *q++ = (uint8_t)tags[k][0];
+                        *q++ = (uint8_t)tags[k][1];
+                        *q++ = 'i';
+                        for (int b = 0; b < 4; ++b) *q++ = (uint8_t)((uint32_t)vals[k] >> (8 * b));
+                        }
                 }
                 const uint32_t nbs = (uint32_t)(q - o) - 4; for (int b = 0; b < 4; ++b) o[b] = (uint8_t)(nbs >> (8 * b));
             }
@@ -1036,128 +650,17 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
 // caller's per-site statistics are restated here: SomaticVarCaller::setFilterParamsWithPurity :951-1060, getDenseTumorSnpInterval :1243-1355,
 // somaticFeatureFilter :1062-1230, calibrateReadHP :1366-1404, calculateReadSetHP :1418-1439, statisticSomaticPosReadHP :1441-1518, getSomaticFlag :2397-2412
 // (src/somatic_haplotag/SomaticVarCaller.cpp), and TumorPurityEstimator.cpp (estimate_purity below) when no --tumor-purity is given.
-struct TumorRow { std::string ref, alt; int kind; };                    // kind: 1 SNP, 2 insertion, 3 deletion, 4 MNP (VarData::setVariantType)
-static void parse_tumor_vcf(const std::vector<std::string> &lines, std::vector<std::string> &chr_vec, std::map<std::string, int> &chr_len,
-                            std::map<std::string, std::map<int32_t, TumorRow>> &rows) {
-    for (const std::string &in : lines) {
-        if (in.compare(0, 2, "##") == 0) {
-            if (in.find("contig=") != std::string::npos) {
-                const size_t a = in.find("ID=") + 3, b = in.find(",length="), e = in.find(">");
-                if (b == std::string::npos) die("[ERROR] contig header line without length: " + in);
-                const std::string chr = in.substr(a, b - a); chr_vec.push_back(chr); chr_len[chr] = std::stoi(in.substr(b + 8, e - b - 8));
-            }
-            continue;
-        }
-        if (in.empty() || in[0] == '#') continue;
-        std::istringstream iss(in);
-        std::vector<std::string> f((std::istream_iterator<std::string>(iss)), std::istream_iterator<std::string>());
-        if (f.empty()) continue;
-        if (f.size() < 10) die("[ERROR](VcfParser::parserProcess) => VCF file format not supported: " + in);
-        const size_t kp = f[8].find("GT"); int colons = 0; for (size_t i = 0; i < kp && i < f[8].size(); ++i) if (f[8][i] == ':') ++colons;
-        int cur = 0; size_t g = 0; for (size_t i = 0; i < f[9].size(); ++i) { if (cur >= colons) break; if (f[9][i] == ':') ++cur; ++g; }
-        if (g + 2 >= f[9].size() + 1) continue;
-        const char a = f[9][g], m = f[9][g + 1], b = g + 2 < f[9].size() ? f[9][g + 2] : '\0';
-        if (a != b && m == '|') die("longphase_amd: phased records in the tumor VCF are not supported: " + in);   // HaplotagVcfParser.cpp:296-400 would need PS handling
-        if (!((a == '1' && m == '/' && b == '1') || (a == '0' && m == '/' && b == '1'))) continue;               // :470-520: 1/1 and 0/1 only
-        TumorRow r; r.ref = f[3]; r.alt = f[4].find(',') != std::string::npos ? f[4].substr(0, f[4].find(',')) : f[4];
-        if (r.ref.size() == 1 && r.alt.size() == 1) r.kind = 1; else if (r.ref.size() == 1 && r.alt.size() > 1) r.kind = 2; else if (r.ref.size() > 1 && r.alt.size() == 1) r.kind = 3;
-        else if (r.ref.size() > 1 && r.ref.size() == r.alt.size()) r.kind = 4; else die("(loadVariantType)Invalid allele: " + r.ref + " " + r.alt);
-        if ((r.kind == 2 || r.kind == 3) && std::abs((int)r.alt.size() - (int)r.ref.size()) > 100) continue;       // tumor INDELs longer than 100 bp are skipped
-        rows[f[0]][std::stoi(f[1]) - 1] = r;
-    }
-}
-
-// TumorPurityEstimator (src/somatic_haplotag/TumorPurityEstimator.cpp) restated: LCVF filters :92-150, histogram of the normal germline read
-// counts smoothed with a sigma-0.5 Gaussian :443-600, peak / valley analysis for the dynamic count threshold :649-1060, box-plot statistics with
-// linear-interpolation percentiles :281-344, one outlier-removal round, and the quadratic model in (median, IQR) :66.  Writes <prefix>_purity.out.
-struct PurityDatum { double ratio; int nor_count; };
-static double estimate_purity(std::vector<PurityDatum> v, size_t initial_size, const int lcvf[5], const std::string &prefix) {
-    struct H { double count, pct; };
-    int threshold = 0; size_t n_valley = 0, n_out = 0;
-    double purity = 0.0;
-    try {
-        if (v.empty()) throw std::runtime_error("Failed to build purity feature vector: empty vector");
-        try {   // findBimodalValleyThreshold
-            std::vector<H> hist(1000, H{0, 0});
-            for (auto &d : v) { const size_t rc = (size_t)d.nor_count; if (rc >= hist.size()) { const size_t ns = hist.size() * 2; if (ns >= 1000000) throw std::overflow_error("Read count exceeds maximum histogram size"); hist.resize(ns, H{0, 0}); } hist[rc].count++; }
-            const size_t total = v.size(); double max_height = 0; std::pair<size_t, size_t> range{0, 0};
-            auto stats = [&](std::vector<H> &h) { double tot = 0; bool first = false;
-                for (size_t i = 0; i < h.size(); ++i) { tot += h[i].count / (double)total; h[i].pct = tot; if (h[i].count > max_height) max_height = h[i].count; if (!first && h[i].count > 0) { range.first = i; first = true; } if (h[i].count > 0) range.second = i; }
-                if (max_height == 0) throw std::runtime_error("max_height is 0 in histogram");
-                h.resize(range.second + 1); };
-            stats(hist);
-            std::vector<H> sm = hist;
-            {   // Gaussian filter, sigma 0.5: kernel size int(6 * 0.5 + 1) = 4 -> 5
-                const double sigma = 0.5; int ks = (int)(6 * sigma + 1); if (ks % 2 == 0) ks += 1; const int half = ks / 2; std::vector<double> k((size_t)ks); double sum = 0;
-                for (int i = 0; i < ks; ++i) { const double x = i - half; k[(size_t)i] = std::exp(-0.5 * (x / sigma) * (x / sigma)); sum += k[(size_t)i]; }
-                for (double &x : k) x /= sum;
-                const std::vector<H> tmp = sm;
-                for (size_t i = 0; i < sm.size(); ++i) { double c = 0; for (size_t j = 0; j < k.size(); ++j) { size_t idx = 0; if (i + j >= (size_t)half) { idx = i + j - (size_t)half; if (idx >= sm.size()) idx = sm.size() - 1; } c += tmp[idx].count * k[j]; } sm[i].count = c; }
-                stats(sm);                                                // max_height keeps the larger of raw and smoothed, as the copied object does
-            }
-            const double peak_thr = (double)std::max((size_t)(max_height * 0.05), (size_t)1);
-            struct Peak { size_t idx; double h; int lt = 0, rt = 0; bool main = false; };   // trends: 1 UP, 2 DOWN, 3 FLAT
-            std::vector<Peak> pk;
-            for (size_t i = 0; i < sm.size(); ++i) { bool is = false; if (sm[i].count < peak_thr) continue;
-                else if (i == 0 && i != sm.size() - 1) { if (sm[i].count > sm[i + 1].count) is = true; }
-                else if (i == sm.size() - 1 && i != 0) { if (sm[i].count > sm[i - 1].count) is = true; }
-                else if (sm.size() > 1 && sm[i].count > sm[i - 1].count && sm[i].count > sm[i + 1].count) is = true;
-                if (is) pk.push_back(Peak{i, sm[i].count}); }
-            if (pk.empty()) throw std::runtime_error("No peaks found in peaksVec");
-            if (pk.size() >= 2) for (size_t i = 0; i < pk.size() - 1;) { if (pk[i + 1].idx - pk[i].idx < 2) { if (pk[i].h >= pk[i + 1].h) pk.erase(pk.begin() + (long)i + 1); else pk.erase(pk.begin() + (long)i); } else ++i; }
-            if (pk.size() >= 2) for (size_t i = 0; i < pk.size() - 1; ++i) { const int t = pk[i].h < pk[i + 1].h ? 1 : pk[i].h > pk[i + 1].h ? 2 : 3; pk[i].rt = t; pk[i + 1].lt = t; }
-            if (pk.size() == 1) pk[0].main = true;
-            else for (size_t i = 0; i < pk.size(); ++i) { if (i == 0) pk[i].main = pk[i].rt == 2; else if (i == pk.size() - 1) pk[i].main = pk[i].lt == 1; else pk[i].main = pk[i].lt == 1 && pk[i].rt == 2; }
-            std::vector<Peak> mains; for (auto &q : pk) if (q.main) mains.push_back(q);
-            if (mains.empty()) throw std::runtime_error("No main peaks found in peaksVec");
-            size_t main_idx;
-            if (mains.size() == 1) main_idx = mains[0].idx; else { std::sort(mains.begin(), mains.end(), [](const Peak &a, const Peak &b) { return a.h > b.h; }); main_idx = mains[0].idx > mains[1].idx ? mains[0].idx : mains[1].idx; }
-            auto at_peak = [&](size_t idx) -> size_t { for (size_t i = 0; i < pk.size(); ++i) if (pk[i].idx == idx) return i; throw std::runtime_error("Peak not found"); };
-            auto lowest_valley = [&](size_t a, size_t b, size_t &vi, double &vh, double &vp) -> bool { if (a >= b || b > sm.size()) return false; bool found = false; vh = 2147483647.0;
-                for (size_t i = a + 1; i + 1 < b; ++i) if (sm[i].count < sm[i - 1].count && sm[i].count < sm[i + 1].count) { if (!found || sm[i].count < vh) { vi = i; vh = sm[i].count; vp = sm[i].pct; found = true; } }
-                return found; };
-            double valley_h = 0, thr_pct = 0;                                 // Valley() is value-initialised: height 0
-            bool found_sec = false; size_t sec_i = 0;
-            if (pk[0].idx != main_idx) { size_t mi = at_peak(main_idx); size_t j = mi - 1;
-                if (j == 0) { sec_i = 0; found_sec = true; }
-                else { while (j != 0) { if (pk[j].lt == 2 && pk[j].rt == 1) { sec_i = j; found_sec = true; break; } --j; } if (!found_sec) { sec_i = 0; found_sec = true; } } }
-            if (found_sec) {
-                size_t vi = 0; double vh = 0, vp = 0;
-                bool fv = lowest_valley(pk[sec_i].idx, pk[sec_i + 1].idx, vi, vh, vp);
-                if (fv) { thr_pct = vp; threshold = (int)vi; valley_h = vh; } else { valley_h = 2147483647.0; }   // findLowestValley leaves height = INT_MAX when it finds nothing
-                if (thr_pct >= 0.3 || !fv) { valley_h = 0; thr_pct = 0; threshold = 0;
-                    if (sec_i != 0) { fv = lowest_valley(pk[sec_i - 1].idx, pk[sec_i].idx, vi, vh, vp); if (fv) { thr_pct = vp; threshold = (int)vi; valley_h = vh; } else valley_h = 2147483647.0; } }
-            }
-            if (valley_h > max_height * 0.7) { thr_pct = 0; threshold = 0; }
-            if (thr_pct >= 0.3) { thr_pct = 0; threshold = 0; }
-        } catch (const std::exception &e) { std::cerr << "[ERROR] " << e.what() << "\n[ERROR] Failed to find peak valley threshold, set threshold to 0\n"; threshold = 0; }
-        for (auto it = v.begin(); it != v.end();) { if (it->nor_count < threshold) { ++n_valley; it = v.erase(it); } else ++it; }   // bimodalValleyFilter
-        struct Box { size_t n = 0; double q1 = 0, med = 0, q3 = 0, iqr = 0, lo = 0, hi = 0; size_t outliers = 0; };
-        auto box = [&](std::vector<PurityDatum> &d) { Box b; b.n = d.size(); if (!b.n) throw std::runtime_error("Failed to statistic purity data: the data size is 0");
-            std::sort(d.begin(), d.end(), [](const PurityDatum &x, const PurityDatum &y) { return x.ratio < y.ratio; });
-            auto pct = [&](double p) { const double pos = p * (double)(b.n - 1); const size_t idx = (size_t)pos; const double frac = pos - (double)idx; if (idx + 1 >= b.n) return d[b.n - 1].ratio; return d[idx].ratio * (1.0 - frac) + d[idx + 1].ratio * frac; };
-            b.q1 = pct(0.25); b.med = pct(0.5); b.q3 = pct(0.75); b.iqr = b.q3 - b.q1; b.lo = std::max(0.0, b.q1 - 1.5 * b.iqr); b.hi = b.q3 + 1.5 * b.iqr;
-            for (auto &x : d) if (x.ratio < b.lo || x.ratio > b.hi) ++b.outliers; return b; };
-        Box b = box(v);
-        for (auto it = v.begin(); it != v.end();) { if (it->ratio < b.lo || it->ratio > b.hi) { it = v.erase(it); ++n_out; } else ++it; }
-        b = box(v);
-        purity = -3.3454 * b.med + 14.7747 * b.iqr + 4.0344 * b.med * b.med + -13.7777 * b.med * b.iqr + -5.2434 * b.iqr * b.iqr + 0.3058;
-        if (purity > 1.0) purity = 1.0; else if (purity < 0.0) throw std::runtime_error("The value of purity exceeds the model's estimation range: " + std::to_string(purity));
-        std::ofstream o(prefix + "_purity.out");
-        if (o) { o << "#==================================\n# TUMOR PURITY ESTIMATION REPORT\n#==================================\n#Initial data size: " << initial_size << std::endl
-            << "#==========filter parameters==========" << std::endl << "#GERMLINE_HP_IMBALANCE_RATIO_MIN_THR: " << 0.0f << std::endl << "#GERMLINE_HP_IMBALANCE_RATIO_IN_NOR_BAM_MIN_THR: " << 0.0f << std::endl
-            << "#GERMLINE_HP_IMBALANCE_RATIO_IN_NOR_BAM_MAX_THR: " << 0.7f << std::endl << "#GERMLINE_HP_PERCENTAGE_IN_NOR_BAM_MAX_THR: " << 0.7f << std::endl << "#GERMLINE_HP_READ_COUNT_IN_NOR_BAM_MIN_THR: " << 5 << std::endl
-            << "#GERMLINE_HP_READ_COUNT_IN_NOR_BAM_DYNAMIC_THR: " << threshold << std::endl << "#==========Initial filter out data count==========" << std::endl
-            << "#imbalanceRatioInNorBam: " << lcvf[0] << std::endl << "#imbalanceRatio: " << lcvf[1] << std::endl << "#imbalanceRatioInNorBam_over_thr: " << lcvf[2] << std::endl << "#readHpCountInNorBam: " << lcvf[3] << std::endl
-            << "#percentageOfGermlineHpInNorBam: " << lcvf[4] << std::endl << "#==========Second filter out data count==========" << std::endl << "#peakValley count: " << n_valley << std::endl
-            << "#==========Whisker filter out data count==========" << std::endl << "#iteration times: " << 1 << std::endl << "#remove outliers: " << n_out << std::endl << "#==========Statistical analysis===========" << std::endl
-            << "Data size: " << b.n << std::endl << "Median: " << b.med << std::endl << "Q1: " << b.q1 << std::endl << "Q3: " << b.q3 << std::endl << "IQR: " << b.iqr << std::endl << "Whiskers: " << b.lo << " to " << b.hi << std::endl
-            << "Outliers: " << b.outliers << std::endl << "#==========Estimation result===========" << std::endl << "Tumor purity: " << purity << std::endl; }
-    } catch (const std::exception &e) { std::cerr << "[ERROR] " << e.what() << "\n[ERROR] Failed to estimate tumor purity, set purity to 0.0\n"; purity = 0.0; }
-    return purity;
-}
-
-struct SomaticThr { float norVAF_max; int norDepth_min; float messy; int readCount_min; float hap_VAF_max; int hap_readCount_max, hap_somaticRead_min; float ivl_VAF_max; int ivl_readCount_max, ivl_count_min; float z_max; const char *tier; };
+struct SomaticThr { float norVAF_max;
+    int norDepth_min;
+    float messy;
+    int readCount_min;
+    float hap_VAF_max;
+    int hap_readCount_max, hap_somaticRead_min;
+    float ivl_VAF_max;
+    int ivl_readCount_max, ivl_count_min;
+    float z_max;
+    const char *tier;
+    };
 static SomaticThr somatic_thresholds(double purity) {                  // setFilterParamsWithPurity: the float members are assigned from double literals, the int locals truncate them
     if (purity >= 0.9 && purity <= 1.0) return {0.13f, 1, 1.0f, 3, 0.144f, 12, 0, 0.189f, 12, 4, 5.233f, "1.0"};
     if (purity >= 0.7 && purity < 0.9) return {0.13f, 1, 1.0f, 3, 0.130f, 10, 1, 0.133f, 10, 4, 2.676f, "0.8"};
@@ -1186,7 +689,10 @@ static const char *kSomUsage =
 
 static int somatic_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
-    std::string snp, ref, nbam, tvcf, tbam, prefix = "result"; int threads = 1, gpu = 0; double purity = -1, pct = 0.6; bool enable_filter = true, write_log = false, write_sc_vcf = false;
+    std::string snp, ref, nbam, tvcf, tbam, prefix = "result";
+    int threads = 1, gpu = 0;
+    double purity = -1, pct = 0.6;
+    bool enable_filter = true, write_log = false, write_sc_vcf = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kSomUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -1200,8 +706,13 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         else if (a == "-o" || a == "--out-prefix") prefix = val();
         else if (a == "-t" || a == "--threads") threads = std::stoi(val());
         else if (a == "--tagSupplementary") over.push_back([](lps_params &P) { P.tag_supplementary = 1; });
-        else if (a == "-q" || a == "--qualityThreshold") { const auto x = std::stoi(val()); over.push_back([x](lps_params &P) { P.mapping_quality = x; }); }
-        else if (a == "-p" || a == "--percentageThreshold") { pct = std::stod(val()); const double x = pct; over.push_back([x](lps_params &P) { P.percentage_threshold = x; }); }
+        else if (a == "-q" || a == "--qualityThreshold") { const auto x = std::stoi(val());
+            over.push_back([x](lps_params &P) { P.mapping_quality = x; });
+            }
+        else if (a == "-p" || a == "--percentageThreshold") { pct = std::stod(val());
+            const double x = pct;
+            over.push_back([x](lps_params &P) { P.percentage_threshold = x; });
+            }
         else if (a == "--tumor-purity") purity = std::stod(val());
         else if (a == "--disableFilter") enable_filter = false;
         else if (a == "--somatic-calling-log") write_log = true;
@@ -1211,7 +722,9 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         else if (a == "--cram" || a == "--region" || a == "--log" || a == "--truth-vcf" || a == "--truth-bed" || a == "--benchmark-log") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kSomUsage; return 1; }
     }
-    if (snp.empty() || nbam.empty() || tvcf.empty() || tbam.empty() || ref.empty()) { std::cerr << "longphase_amd somatic_haplotag: missing arguments\n" << kSomUsage; return 1; }
+    if (snp.empty() || nbam.empty() || tvcf.empty() || tbam.empty() || ref.empty()) { std::cerr << "longphase_amd somatic_haplotag: missing arguments\n" << kSomUsage;
+        return 1;
+        }
     const bool estimate = purity < 0;                                  // default: automatic estimation, as in the reference
 
     Lps L; lps_ctx *ctx = nullptr;
@@ -1222,13 +735,20 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     std::vector<std::string> nlines, tlines;
     if (!read_lines(snp, nlines)) die("Fail to open vcf: " + snp);
     if (!read_lines(tvcf, tlines)) die("Fail to open vcf: " + tvcf);
-    std::vector<std::string> nchr, tchr; std::map<std::string, int> nlen, tlen; std::map<std::string, std::map<int32_t, PhasedRow>> nrows; std::map<std::string, std::map<int32_t, TumorRow>> trows;
+    std::vector<std::string> nchr, tchr;
+    std::map<std::string, int> nlen, tlen;
+    std::map<std::string, std::map<int32_t, PhasedRow>> nrows;
+    std::map<std::string, std::map<int32_t, TumorRow>> trows;
     parse_phased_vcf(nlines, nchr, nlen, nrows); parse_tumor_vcf(tlines, tchr, tlen, trows);
     if (const char *dump = getenv("LPS_CLI_DUMP_TABLE")) {                // debugging aid: the parsed rows, before any GPU work
-        std::ofstream o(dump); for (auto &c : trows) for (auto &r : c.second) o << "T\t" << c.first << "\t" << r.first << "\t" << r.second.ref << "\t" << r.second.alt << "\t" << r.second.kind << "\n";
+        std::ofstream o(dump);
+        for (auto &c : trows) for (auto &r : c.second) o << "T\t" << c.first << "\t" << r.first << "\t" << r.second.ref << "\t" << r.second.alt << "\t" << r.second.kind << "\n";
         for (auto &c : nrows) for (auto &r : c.second) o << "N\t" << c.first << "\t" << r.first << "\t" << r.second.ref << "\t" << r.second.alt << "\t" << r.second.ps << "\t" << (int)r.second.hp1_is_alt << "\n";
     }
-    for (auto &kv : tlen) { auto it = nlen.find(kv.first); if (it == nlen.end()) die("[ERROR] (setChrVecAndChrLength) :tumor & normal VCFs chromosome count are not the same"); if (it->second != kv.second) die("[ERROR] (setChrVecAndChrLength) :tumor & normal VCFs chromosome length are not the same => chr: " + kv.first); }
+    for (auto &kv : tlen) { auto it = nlen.find(kv.first);
+        if (it == nlen.end()) die("[ERROR] (setChrVecAndChrLength) :tumor & normal VCFs chromosome count are not the same");
+        if (it->second != kv.second) die("[ERROR] (setChrVecAndChrLength) :tumor & normal VCFs chromosome length are not the same => chr: " + kv.first);
+        }
     const std::vector<std::string> &chr_vec = tchr.empty() ? nchr : tchr;   // SomaticHaplotagProcess.cpp:161-174
     if (chr_vec.empty()) die("[ERROR] (setChrVecAndChrLength) :tumor & normal VCFs chromosome count are empty");
     std::map<std::string, ChrVariants> want_seq; std::map<std::string, int> want;
@@ -1243,21 +763,36 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         else std::cerr << "setting filter params (tier " << T.tier << ") with tumor purity: " << purity << "\n"; };
     if (!estimate) announce();
     std::vector<PurityDatum> pdata; size_t p_initial = 0; int lcvf[5] = {0, 0, 0, 0, 0};
-    std::ofstream flog; if (write_log) { flog.open(prefix + "_somatic_filter.log"); if (!flog) die("Fail to open write file: " + prefix + "_somatic_filter.log");
+    std::ofstream flog;
+    if (write_log) { flog.open(prefix + "_somatic_filter.log");
+        if (!flog) die("Fail to open write file: " + prefix + "_somatic_filter.log");
         flog << "######################################\n# Somatic Filter Evaluation Per-Pos   #\n######################################\n"
-             << "#CHROM\tPOS\tNorVAF\tNorDepth\tMixedHpReadRatio\tCaseReadCount\tTumVAF\tIntervalSnpCount\tzScore\tDenseAltSameCount\tFilteredByTINC\tFilteredByMessyRead\tFilteredByReadCount\tFilteredByHapConsistency\tFilteredByVariantCluster\tFilteredByDenseAlt\tisFilterOut\n"; }
+             << "#CHROM\tPOS\tNorVAF\tNorDepth\tMixedHpReadRatio\tCaseReadCount\tTumVAF\tIntervalSnpCount\tzScore\tDenseAltSameCount\tFilteredByTINC\tFilteredByMessyRead\tFilteredByReadCount\tFilteredByHapConsistency\tFilteredByVariantCluster\tFilteredByDenseAlt\tisFilterOut\n";
+             }
 
     BgzfWriter w; w.open(prefix + ".bam", threads, 6, Z_RLE);
     {   // header of the TUMOR BAM + one @PG line
         const uint8_t *d = tin.z.data; const uint32_t l_text = rd32(d + 4);
         std::string text((const char *)d + 8, l_text); while (!text.empty() && text.back() == '\0') text.pop_back();
         if (!text.empty() && text.back() != '\n') text += '\n';
-        std::string last_pg; for (size_t p = 0; p < text.size();) { const size_t e = text.find('\n', p); const std::string ln = text.substr(p, e - p);
-            if (ln.compare(0, 3, "@PG") == 0) { const size_t i = ln.find("\tID:"); if (i != std::string::npos) last_pg = ln.substr(i + 4, ln.find('\t', i + 4) - i - 4); } p = e == std::string::npos ? text.size() : e + 1; }
+        std::string last_pg;
+        for (size_t p = 0; p < text.size();) { const size_t e = text.find('\n', p);
+            const std::string ln = text.substr(p, e - p);
+            if (ln.compare(0, 3, "@PG") == 0) { const size_t i = ln.find("\tID:");
+                if (i != std::string::npos) last_pg = ln.substr(i + 4, ln.find('\t', i + 4) - i - 4);
+                } p = e == std::string::npos ? text.size() : e + 1;
+            }
         text += "@PG\tID:longphase_amd\tPN:longphase_amd" + (last_pg.empty() ? std::string() : "\tPP:" + last_pg) + "\tVN:" + kVersion + "\tCL:" + command + "\n";
-        std::vector<uint8_t> h; h.insert(h.end(), d, d + 4); const uint32_t lt = (uint32_t)text.size(); for (int k = 0; k < 4; ++k) h.push_back((uint8_t)(lt >> (8 * k)));
+        std::vector<uint8_t> h;
+        h.insert(h.end(), d, d + 4);
+        const uint32_t lt = (uint32_t)text.size();
+        for (int k = 0; k < 4; ++k) h.push_back((uint8_t)(lt >> (8 * k)));
         h.insert(h.end(), text.begin(), text.end());
-        size_t p = 8 + (size_t)l_text; const size_t ref_begin = p; const uint32_t n_ref = rd32(d + p); p += 4; for (uint32_t i = 0; i < n_ref; ++i) p += 4 + (size_t)rd32(d + p) + 4;
+        size_t p = 8 + (size_t)l_text;
+        const size_t ref_begin = p;
+        const uint32_t n_ref = rd32(d + p);
+        p += 4;
+        for (uint32_t i = 0; i < n_ref; ++i) p += 4 + (size_t)rd32(d + p) + 4;
         h.insert(h.end(), d + ref_begin, d + p);
         w.append(h.data(), h.size());
     }
@@ -1273,15 +808,31 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         const bool have_t = ti != tin.contigs.end() && !ti->second.rec_off.empty();
         // ---- merged table (MultiGenomeVar map): normal phased-het rows + tumor rows
         std::map<int32_t, PhasedRow> none_n; std::map<int32_t, TumorRow> none_t;
-        const std::map<int32_t, PhasedRow> &nr = nrows.count(chr) ? nrows[chr] : none_n; const std::map<int32_t, TumorRow> &tr = trows.count(chr) ? trows[chr] : none_t;
+        const std::map<int32_t, PhasedRow> &nr = nrows.count(chr) ? nrows[chr] : none_n;
+        const std::map<int32_t, TumorRow> &tr = trows.count(chr) ? trows[chr] : none_t;
         std::vector<int32_t> pos, ps; std::vector<uint8_t> r0, a0, hpa, role, derive, tkind; std::vector<uint16_t> rl, al;
         { auto a = nr.begin(); auto b = tr.begin();
           while (a != nr.end() || b != tr.end()) {
               const bool take_n = a != nr.end() && (b == tr.end() || a->first <= b->first), both = take_n && b != tr.end() && a->first == b->first;
-              if (take_n) { pos.push_back(a->first); r0.push_back((uint8_t)a->second.ref[0]); a0.push_back((uint8_t)a->second.alt[0]); rl.push_back((uint16_t)a->second.ref.size()); al.push_back((uint16_t)a->second.alt.size());
-                  hpa.push_back(a->second.hp1_is_alt); ps.push_back(a->second.ps); role.push_back(0); derive.push_back(0); tkind.push_back(both ? (uint8_t)b->second.kind : 0);
-                  if (both) { if (a->second.ref != b->second.ref || a->second.alt != b->second.alt) die("longphase_amd: normal and tumor VCF disagree on the alleles at " + chr + ":" + std::to_string(a->first + 1)); ++b; } ++a; }
-              else { pos.push_back(b->first); r0.push_back((uint8_t)b->second.ref[0]); a0.push_back((uint8_t)b->second.alt[0]); rl.push_back((uint16_t)b->second.ref.size()); al.push_back((uint16_t)b->second.alt.size());
+              if (take_n) { pos.push_back(a->first);
+                  r0.push_back((uint8_t)a->second.ref[0]);
+                  a0.push_back((uint8_t)a->second.alt[0]);
+                  rl.push_back((uint16_t)a->second.ref.size());
+                  al.push_back((uint16_t)a->second.alt.size());
+                  hpa.push_back(a->second.hp1_is_alt);
+                  ps.push_back(a->second.ps);
+                  role.push_back(0);
+                  derive.push_back(0);
+                  tkind.push_back(both ? (uint8_t)b->second.kind : 0);
+                  if (both) { if (a->second.ref != b->second.ref || a->second.alt != b->second.alt) die("longphase_amd: normal and tumor VCF disagree on the alleles at " + chr + ":" + std::to_string(a->first + 1));
+                      ++b;
+                      } ++a;
+                  }
+              else { pos.push_back(b->first);
+                  r0.push_back((uint8_t)b->second.ref[0]);
+                  a0.push_back((uint8_t)b->second.alt[0]);
+                  rl.push_back((uint16_t)b->second.ref.size());
+                  al.push_back((uint16_t)b->second.alt.size());
                   hpa.push_back(0); ps.push_back(0); role.push_back(2); derive.push_back(0); tkind.push_back((uint8_t)b->second.kind); ++b; }
           } }
         const size_t nv = pos.size();
@@ -1292,7 +843,15 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         if (nv) {
             if (!seqs.count(chr)) die("ERROR: contig " + chr + " is missing from the reference FASTA");
             const std::string &sq = seqs[chr];
-            lps_variant_table vt{}; vt.n = (int64_t)nv; vt.pos = pos.data(); vt.ref0 = r0.data(); vt.alt0 = a0.data(); vt.ref_len = rl.data(); vt.alt_len = al.data(); vt.hp1_is_alt = hpa.data(); vt.phase_set = ps.data();
+            lps_variant_table vt{};
+            vt.n = (int64_t)nv;
+            vt.pos = pos.data();
+            vt.ref0 = r0.data();
+            vt.alt0 = a0.data();
+            vt.ref_len = rl.data();
+            vt.alt_len = al.data();
+            vt.hp1_is_alt = hpa.data();
+            vt.phase_set = ps.data();
             vt.somatic_role = role.data(); vt.derive_hp = derive.data(); vt.tumor_kind = tkind.data();
             // ---- pass 1: normal BAM (ExtractNorDataBamParser)
             std::vector<int32_t> nsite(nv * LPS_SITE_COUNTERS, 0);
@@ -1304,72 +863,141 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                     L.push_bam_records(ctx, nin.z.data + nc.lo, (int64_t)(nc.hi - nc.lo), nc.rec_off.data(), (int64_t)nc.rec_off.size(), nid.data()) || L.somatic_extract_normal(ctx, &sc)) fail();
             }
             // ---- pass 2: tumor BAM (ExtractTumDataBamParser)
-            std::vector<int32_t> tsite(nv * LPS_TSITE_COUNTERS, 0), h1(nt), h2(nt), h3(nt), psmin(nt), endp(nt), rlen(nt); std::vector<uint8_t> tstat(nt), thp(nt), tnps(nt), has(nt);
+            std::vector<int32_t> tsite(nv * LPS_TSITE_COUNTERS, 0), h1(nt), h2(nt), h3(nt), psmin(nt), endp(nt), rlen(nt);
+            std::vector<uint8_t> tstat(nt), thp(nt), tnps(nt), has(nt);
             std::vector<int32_t> pr_site, pr_read, wn_site; std::vector<uint8_t> pr_hp, wn_al, wn_base; std::vector<int16_t> wn_off;
-            lps_tumor_extract_result te{}; te.n = (int64_t)nv; te.site = tsite.data(); te.n_reads = (int64_t)nt; te.status = tstat.data(); te.hp1 = h1.data(); te.hp2 = h2.data(); te.hp3 = h3.data(); te.hp = thp.data();
+            lps_tumor_extract_result te{};
+            te.n = (int64_t)nv;
+            te.site = tsite.data();
+            te.n_reads = (int64_t)nt;
+            te.status = tstat.data();
+            te.hp1 = h1.data();
+            te.hp2 = h2.data();
+            te.hp3 = h3.data();
+            te.hp = thp.data();
             te.n_ps = tnps.data(); te.ps_min = psmin.data(); te.end_pos = endp.data(); te.read_len = rlen.data(); te.has_site = has.data();
             { std::vector<uint32_t> tid(nt, 0);
-              if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) || L.push_bam_records(ctx, tbase, (int64_t)(tc.hi - tc.lo), tc.rec_off.data(), (int64_t)nt, tid.data())) fail(); }
+              if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) || L.push_bam_records(ctx, tbase, (int64_t)(tc.hi - tc.lo), tc.rec_off.data(), (int64_t)nt, tid.data())) fail();
+              }
             size_t pcap = nt * 4 + 1024, wcap = nt * 64 + 4096;
             for (int attempt = 0;; ++attempt) {
-                pr_site.resize(pcap); pr_read.resize(pcap); pr_hp.resize(pcap); wn_site.resize(wcap); wn_al.resize(wcap); wn_off.resize(wcap); wn_base.resize(wcap);
+                pr_site.resize(pcap);
+                pr_read.resize(pcap);
+                pr_hp.resize(pcap);
+                wn_site.resize(wcap);
+                wn_al.resize(wcap);
+                wn_off.resize(wcap);
+                wn_base.resize(wcap);
                 te.pair_capacity = (int64_t)pcap; te.pair_site = pr_site.data(); te.pair_read = pr_read.data(); te.pair_base_hp = pr_hp.data();
-                te.win_capacity = (int64_t)wcap; te.win_site = wn_site.data(); te.win_allele = wn_al.data(); te.win_offset = wn_off.data(); te.win_base = wn_base.data();
+                te.win_capacity = (int64_t)wcap;
+                te.win_site = wn_site.data();
+                te.win_allele = wn_al.data();
+                te.win_offset = wn_off.data();
+                te.win_base = wn_base.data();
                 const int rc = L.somatic_extract_tumor(ctx, &te);
                 if (rc == 0) break;
                 if (rc != -9 || attempt > 2) fail();
                 pcap = (size_t)te.n_pairs + 16; wcap = (size_t)te.n_windows + 16;
             }
             if (phase == 0) {                                                // TumorPurityEstimator::buildPurityFeatureValueVec (LCVF) over the touched sites
-                for (size_t v = 0; v < nv; ++v) { if (!tkind[v]) continue; const int32_t *c = &tsite[v * LPS_TSITE_COUNTERS], *n = &nsite[v * LPS_SITE_COUNTERS]; long rh = 0; for (int k = 15; k < 24; ++k) rh += c[k];
+                for (size_t v = 0; v < nv; ++v) { if (!tkind[v]) continue;
+                    const int32_t *c = &tsite[v * LPS_TSITE_COUNTERS], *n = &nsite[v * LPS_SITE_COUNTERS];
+                    long rh = 0;
+                    for (int k = 15; k < 24; ++k) rh += c[k];
                     if (!(c[6] > 0 || rh > 0)) continue;
                     ++p_initial;
-                    auto imb = [](int a, int b) { const int t = a + b; if (a > 0 && b > 0) return a > b ? (double)a / (double)t : (double)b / (double)t; if (a == 0 && b == 0) return 0.0; return 1.0; };
+                    auto imb = [](int a, int b) { const int t = a + b;
+                        if (a > 0 && b > 0) return a > b ? (double)a / (double)t : (double)b / (double)t;
+                        if (a == 0 && b == 0) return 0.0;
+                        return 1.0;
+                        };
                     const double tr_ratio = tkind[v] == 4 ? 0.0 : imb(c[16], c[17]), nr_ratio = imb(n[LPS_SC_READHP_H1], n[LPS_SC_READHP_H2]);
-                    const int ncount = n[LPS_SC_READHP_H1] + n[LPS_SC_READHP_H2]; const double npct = (n[LPS_SC_DEPTH] == 0 || ncount == 0) ? 0.0 : (double)ncount / (double)n[LPS_SC_DEPTH];
-                    if (nr_ratio == 0.0f) ++lcvf[0]; else if (tr_ratio == 0.0f) ++lcvf[1]; else if (nr_ratio >= 0.7f) ++lcvf[2]; else if (ncount <= 5) ++lcvf[3]; else if (npct <= 0.7f) ++lcvf[4];
+                    const int ncount = n[LPS_SC_READHP_H1] + n[LPS_SC_READHP_H2];
+                    const double npct = (n[LPS_SC_DEPTH] == 0 || ncount == 0) ? 0.0 : (double)ncount / (double)n[LPS_SC_DEPTH];
+                    if (nr_ratio == 0.0f) ++lcvf[0];
+                    else if (tr_ratio == 0.0f) ++lcvf[1];
+                    else if (nr_ratio >= 0.7f) ++lcvf[2];
+                    else if (ncount <= 5) ++lcvf[3];
+                    else if (npct <= 0.7f) ++lcvf[4];
                     else pdata.push_back(PurityDatum{tr_ratio, ncount}); }
                 continue;
             }
             // ---- host stages.  "exists": the site was touched by a tumor read (std::map entries of somaticPosInfo)
             std::vector<int> sites; std::vector<int> site_of(nv, -1);
-            for (size_t v = 0; v < nv; ++v) { if (!tkind[v]) continue; const int32_t *c = &tsite[v * LPS_TSITE_COUNTERS]; long rh = 0; for (int k = 15; k < 24; ++k) rh += c[k]; if (c[6] > 0 || rh > 0) { site_of[v] = (int)sites.size(); sites.push_back((int)v); } }
+            for (size_t v = 0; v < nv; ++v) { if (!tkind[v]) continue;
+                const int32_t *c = &tsite[v * LPS_TSITE_COUNTERS];
+                long rh = 0;
+                for (int k = 15; k < 24; ++k) rh += c[k];
+                if (c[6] > 0 || rh > 0) { site_of[v] = (int)sites.size();
+                    sites.push_back((int)v);
+                    } }
             const size_t ns = sites.size();
-            if (getenv("LPS_CLI_DEBUG")) { int byk[5] = {0}, tab[5] = {0}; for (size_t v = 0; v < nv; ++v) ++tab[tkind[v] < 5 ? tkind[v] : 0]; for (int v : sites) ++byk[tkind[(size_t)v]];
-                fprintf(stderr, "[debug] %s: table %zu rows (tumor kinds %d/%d/%d/%d), touched sites %zu (%d/%d/%d/%d), pairs %lld, windows %lld, tumor reads %zu\n", chr.c_str(), nv, tab[1], tab[2], tab[3], tab[4], ns, byk[1], byk[2], byk[3], byk[4], (long long)te.n_pairs, (long long)te.n_windows, nt); }
+            if (getenv("LPS_CLI_DEBUG")) { int byk[5] = {0}, tab[5] = {0};
+                for (size_t v = 0; v < nv; ++v) ++tab[tkind[v] < 5 ? tkind[v] : 0];
+                for (int v : sites) ++byk[tkind[(size_t)v]];
+                fprintf(stderr, "[debug] %s: table %zu rows (tumor kinds %d/%d/%d/%d), touched sites %zu (%d/%d/%d/%d), pairs %lld, windows %lld, tumor reads %zu\n", chr.c_str(), nv, tab[1], tab[2], tab[3], tab[4], ns, byk[1], byk[2], byk[3], byk[4], (long long)te.n_pairs, (long long)te.n_windows, nt);
+                }
             std::vector<std::vector<std::pair<int, int>>> pairs(ns);       // site -> (read, baseHP): tumorPosReadCorrBaseHP
-            for (int64_t k = 0; k < te.n_pairs; ++k) { const int sidx = site_of[(size_t)pr_site[(size_t)k]]; if (sidx < 0) die("[ERROR] pair at a site that does not exist"); pairs[(size_t)sidx].push_back({pr_read[(size_t)k], pr_hp[(size_t)k]}); }
-            std::vector<float> meanAlt(ns, 0.0f), zScore(ns, 0.0f), tumVAF(ns, 0.0f), norVAF(ns, 0.0f), mixedRatio(ns, 0.0f); std::vector<int> ivlCount(ns, 0), caseCount(ns, 0), norDepth(ns, 0), sameCount(ns, 0); std::vector<uint8_t> highCon(ns, 0), filt(ns, 0);
+            for (int64_t k = 0; k < te.n_pairs; ++k) { const int sidx = site_of[(size_t)pr_site[(size_t)k]];
+                if (sidx < 0) die("[ERROR] pair at a site that does not exist");
+                pairs[(size_t)sidx].push_back({pr_read[(size_t)k], pr_hp[(size_t)k]});
+                }
+            std::vector<float> meanAlt(ns, 0.0f), zScore(ns, 0.0f), tumVAF(ns, 0.0f), norVAF(ns, 0.0f), mixedRatio(ns, 0.0f);
+            std::vector<int> ivlCount(ns, 0), caseCount(ns, 0), norDepth(ns, 0), sameCount(ns, 0);
+            std::vector<uint8_t> highCon(ns, 0), filt(ns, 0);
             std::vector<int> hp3(h3.begin(), h3.end());
             for (size_t i = 0; i < ns; ++i) {                                // getDenseTumorSnpInterval, first loop: mean HP3 count of the reads that carry the ALT here
                 if (pairs[i].empty()) continue;
                 float readCount = 0.0f, altMean = 0.0f;
-                for (auto &pr : pairs[i]) { if (pr.second != 3) continue; readCount++; if (!has[(size_t)pr.first]) die("[ERROR](getDenseTumorSnpInterval) => readID not found in readHpResultSet"); altMean += (float)hp3[(size_t)pr.first]; }
+                for (auto &pr : pairs[i]) { if (pr.second != 3) continue;
+                    readCount++;
+                    if (!has[(size_t)pr.first]) die("[ERROR](getDenseTumorSnpInterval) => readID not found in readHpResultSet");
+                    altMean += (float)hp3[(size_t)pr.first];
+                    }
                 if (altMean != 0) altMean /= readCount;
                 meanAlt[i] = altMean;
             }
             {   // intervals of sites at most 5000 bp apart (INTERVAL_SNP_MAX_DISTANCE), z-score of meanAlt inside each
                 struct Ivl { std::map<int, double> mean, z; int count = 0; };
                 std::vector<Ivl> ivls; Ivl cur; bool rec = false; int startPos = 0;
-                auto close_ivl = [&]() { const double sz = (double)cur.mean.size(); double sum = 0; for (auto &m : cur.mean) sum += m.second; const double mean = sz == 0 ? 0.0 : sum / sz;
-                    double var = 0; for (auto &m : cur.mean) var += (m.second - mean) * (m.second - mean); const double sd = std::sqrt(var / cur.mean.size());
+                auto close_ivl = [&]() { const double sz = (double)cur.mean.size();
+                    double sum = 0;
+                    for (auto &m : cur.mean) sum += m.second;
+                    const double mean = sz == 0 ? 0.0 : sum / sz;
+                    double var = 0;
+                    for (auto &m : cur.mean) var += (m.second - mean) * (m.second - mean);
+                    const double sd = std::sqrt(var / cur.mean.size());
                     for (auto &m : cur.mean) cur.z[m.first] = sd == 0 ? 0.0 : (m.second - mean) / sd; ivls.push_back(cur); };
                 for (size_t i = 0; i < ns; ++i) {
                     if (i + 1 < ns) {
                         const int curPos = pos[(size_t)sites[i]], nextPos = pos[(size_t)sites[i + 1]], dist = nextPos - curPos;
-                        if (dist <= 5000) { if (!rec) { rec = true; startPos = curPos; cur.mean[(int)i] = meanAlt[i]; cur.count++; } cur.mean[(int)(i + 1)] = meanAlt[i + 1]; cur.count++; }
+                        if (dist <= 5000) { if (!rec) { rec = true;
+                                startPos = curPos;
+                                cur.mean[(int)i] = meanAlt[i];
+                                cur.count++;
+                                } cur.mean[(int)(i + 1)] = meanAlt[i + 1];
+                            cur.count++;
+                            }
                         else if (rec) { close_ivl(); rec = false; startPos = 0; cur = Ivl(); }
                     }
                 }
                 if (rec && ns && pos[(size_t)sites[ns - 1]] - startPos <= 5000) close_ivl();
-                for (const Ivl &iv : ivls) if (iv.count > 1) for (auto &z : iv.z) { zScore[(size_t)z.first] = (float)std::abs(z.second); ivlCount[(size_t)z.first] = iv.count; }
+                for (const Ivl &iv : ivls) if (iv.count > 1) for (auto &z : iv.z) { zScore[(size_t)z.first] = (float)std::abs(z.second);
+                    ivlCount[(size_t)z.first] = iv.count;
+                    }
             }
             std::vector<std::map<int, int>> winRef(ns), winAlt(ns);          // offset -> count per allele (PosSomaticOffsetBase)
-            for (int64_t k = 0; k < te.n_windows; ++k) { const int sidx = site_of[(size_t)wn_site[(size_t)k]]; if (sidx < 0) continue; (wn_al[(size_t)k] ? winAlt : winRef)[(size_t)sidx][wn_off[(size_t)k]]++; }
+            for (int64_t k = 0; k < te.n_windows; ++k) { const int sidx = site_of[(size_t)wn_site[(size_t)k]];
+                if (sidx < 0) continue;
+                (wn_al[(size_t)k] ? winAlt : winRef)[(size_t)sidx][wn_off[(size_t)k]]++;
+                }
             for (size_t i = 0; i < ns; ++i) {                                // somaticFeatureFilter
-                const size_t v = (size_t)sites[i]; const int32_t *c = &tsite[v * LPS_TSITE_COUNTERS], *n = &nsite[v * LPS_SITE_COUNTERS]; const int kind = tkind[v];
+                const size_t v = (size_t)sites[i];
+                const int32_t *c = &tsite[v * LPS_TSITE_COUNTERS], *n = &nsite[v * LPS_SITE_COUNTERS];
+                const int kind = tkind[v];
                 if (kind == 4) continue;                                     // MNP rows never become high-confidence calls
-                auto base_count = [&](const int32_t *cc, uint8_t b) { return b == 'A' ? cc[1] : b == 'C' ? cc[2] : b == 'G' ? cc[3] : b == 'T' ? cc[4] : 0; };
+                auto base_count = [&](const int32_t *cc, uint8_t b) { return b == 'A' ? cc[1] : b == 'C' ? cc[2] : b == 'G' ? cc[3] : b == 'T' ? cc[4] : 0;
+                    };
                 auto vaf = [](int alt, int depth) { return (depth == 0 || alt == 0) ? 0.0f : (float)alt / (float)depth; };
                 const int tAlt = kind == 1 ? base_count(c, a0[v]) : c[0], nAlt = kind == 1 ? base_count(n, a0[v]) : n[0];
                 tumVAF[i] = vaf(tAlt, c[6]); norVAF[i] = vaf(nAlt, n[6]); norDepth[i] = n[6];
@@ -1377,10 +1005,18 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                 mixedRatio[i] = caseCount[i] != 0 ? (float)messy / ((float)clean + (float)messy) : 0.0f;
                 const bool f_tinc = !(norVAF[i] <= T.norVAF_max && (float)norDepth[i] > (float)T.norDepth_min);
                 const bool f_messy = mixedRatio[i] >= T.messy, f_count = caseCount[i] <= T.readCount_min;
-                bool f_hap = false; if (caseCount[i] <= T.hap_readCount_max && tumVAF[i] <= T.hap_VAF_max) { if (c[35] > T.hap_somaticRead_min && c[37] > T.hap_somaticRead_min) f_hap = true; }
-                bool f_z = false; if (caseCount[i] <= T.ivl_readCount_max && tumVAF[i] <= T.ivl_VAF_max) { if (ivlCount[i] > T.ivl_count_min && zScore[i] <= T.z_max && zScore[i] >= 0.0f) f_z = true; }
-                int same = 0; { const float c1 = 0.5f, c2 = 0.6f; const int target = c[0];                                  // DenseAlt: base.altCount
-                    for (auto &ao : winAlt[i]) { const auto ro = winRef[i].find(ao.first); const int ra = ro == winRef[i].end() ? 0 : ro->second, aa = ao.second;
+                bool f_hap = false;
+                if (caseCount[i] <= T.hap_readCount_max && tumVAF[i] <= T.hap_VAF_max) { if (c[35] > T.hap_somaticRead_min && c[37] > T.hap_somaticRead_min) f_hap = true;
+                    }
+                bool f_z = false;
+                if (caseCount[i] <= T.ivl_readCount_max && tumVAF[i] <= T.ivl_VAF_max) { if (ivlCount[i] > T.ivl_count_min && zScore[i] <= T.z_max && zScore[i] >= 0.0f) f_z = true;
+                    }
+                int same = 0;
+                { const float c1 = 0.5f, c2 = 0.6f;
+                    const int target = c[0];
+                    // DenseAlt: base.altCount
+                    for (auto &ao : winAlt[i]) { const auto ro = winRef[i].find(ao.first);
+                        const int ra = ro == winRef[i].end() ? 0 : ro->second, aa = ao.second;
                         const double k1 = (double)aa / target, k2 = (double)aa / (ra + aa); if (k1 >= c1 && k2 >= c2) { if (++same == 3) break; } } }
                 sameCount[i] = same; const bool f_dense = same >= 3;
                 filt[i] = f_tinc || f_messy || f_count || f_hap || f_z || f_dense;
@@ -1391,17 +1027,27 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             for (size_t i = 0; i < ns; ++i) {                                // calibrateReadHP: reads lose the H3 votes of rejected sites
                 if (highCon[i]) continue;
                 if (pairs[i].empty()) die("[ERROR](calibrate read HP) => can't find pos in tumorPosReadCorrBaseHP : chr: " + chr + " pos: " + std::to_string(pos[(size_t)sites[i]] + 1));
-                for (auto &pr : pairs[i]) if (pr.second == 3) { if (--hp3[(size_t)pr.first] < 0) die("[ERROR](calibrate read HP) => read HP3 or HP4 SNP count < 0 :"); }
+                for (auto &pr : pairs[i]) if (pr.second == 3) { if (--hp3[(size_t)pr.first] < 0) die("[ERROR](calibrate read HP) => read HP3 or HP4 SNP count < 0 :");
+                    }
             }
             std::vector<uint8_t> setHp(nt, 0);                               // calculateReadSetHP
             for (size_t r = 0; r < nt; ++r) if (has[r]) setHp[r] = (uint8_t)judge_somatic_read_hap(h1[r], h2[r], hp3[r], tnps[r], pct);
             for (size_t i = 0; i < ns; ++i) {                                // statisticSomaticPosReadHP + getSomaticFlag
                 if (!highCon[i]) continue;
                 if (pairs[i].empty()) die("[ERROR](statistic all read HP) => can't find pos in tumorPosReadCorrBaseHP : chr: " + chr + " pos: " + std::to_string(pos[(size_t)sites[i]] + 1));
-                int d1 = 0, d2 = 0; for (auto &pr : pairs[i]) if (pr.second == 3) { if (setHp[(size_t)pr.first] == 5) ++d1; else if (setHp[(size_t)pr.first] == 7) ++d2; }
-                const int tot = d1 + d2; float r1 = 0.0f, r2 = 0.0f; if (tot > 0) { if (d1 > 0) r1 = (float)d1 / (float)tot; if (d2 > 0) r2 = (float)d2 / (float)tot; }
+                int d1 = 0, d2 = 0;
+                for (auto &pr : pairs[i]) if (pr.second == 3) { if (setHp[(size_t)pr.first] == 5) ++d1;
+                    else if (setHp[(size_t)pr.first] == 7) ++d2;
+                    }
+                const int tot = d1 + d2;
+                float r1 = 0.0f, r2 = 0.0f;
+                if (tot > 0) { if (d1 > 0) r1 = (float)d1 / (float)tot;
+                    if (d2 > 0) r2 = (float)d2 / (float)tot;
+                    }
                 const size_t v = (size_t)sites[i]; ++n_somatic_flag; if (write_sc_vcf) somatic_pos[chr].insert(pos[v]);
-                if (role[v] != 0) { role[v] = 1; derive[v] = r1 >= 1.0f ? 1 : r2 >= 1.0f ? 2 : 0; }   // a position that also has a normal row keeps its germline role in the tagging pass
+                if (role[v] != 0) { role[v] = 1;
+                    derive[v] = r1 >= 1.0f ? 1 : r2 >= 1.0f ? 2 : 0;
+                    }   // a position that also has a normal row keeps its germline role in the tagging pass
             }
             // ---- pass 3: tagging (SomaticHaplotagChrProcessor::judgeHaplotype); the tumor reads are still resident
             std::vector<int32_t> g1(nt), g2(nt), g3(nt), dh1(nt), dh2(nt), gmin(nt); std::vector<uint8_t> gnps(nt);
@@ -1410,14 +1056,23 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         }
         // ---- writer: HP:Z / PS:i (when the read saw a normal phase set) / PQ:i  (SomaticHaplotagProcess.cpp:529-536), records in input order
         std::vector<uint64_t> out_off(nt + 1, 0);
-        auto aux_of = [&](const uint8_t *r) { const uint32_t l_name = r[8], n_cig = r[12] | (r[13] << 8), l_seq = rd32(r + 16); return r + 32 + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq; };
+        auto aux_of = [&](const uint8_t *r) { const uint32_t l_name = r[8], n_cig = r[12] | (r[13] << 8), l_seq = rd32(r + 16);
+            return r + 32 + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq;
+            };
         static const char *hp_str[9] = {".", "1", "2", "3", "4", "1-1", "1-2", "2-1", "2-2"};
-        auto tag_bytes = [&](size_t i) -> size_t { if (status[i] != 0 || !hp[i]) return 0; return 3 + strlen(hp_str[hp[i] < 9 ? hp[i] : 0]) + 1 + (psv[i] != -1 ? 7 : 0) + 7; };
+        auto tag_bytes = [&](size_t i) -> size_t { if (status[i] != 0 || !hp[i]) return 0;
+            return 3 + strlen(hp_str[hp[i] < 9 ? hp[i] : 0]) + 1 + (psv[i] != -1 ? 7 : 0) + 7;
+            };
         for (size_t i = 0; i < nt; ++i) {
             const uint8_t *r = tbase + tc.rec_off[i]; const uint32_t bs = rd32(r - 4); uint64_t len = 4ull + bs;
             if (status[i] == 0) { bool seen[3] = {false, false, false};
-                for (const uint8_t *p = aux_of(r), *end = r + bs; p < end;) { const size_t l = aux_field_len(p, end); if (!l) die("ERROR: malformed auxiliary field in " + tbam);
-                    const int which = (p[0] == 'H' && p[1] == 'P') ? 0 : (p[0] == 'P' && p[1] == 'S') ? 1 : (p[0] == 'P' && p[1] == 'Q') ? 2 : -1; if (which >= 0 && !seen[which]) { seen[which] = true; len -= l; } p += l; }
+                for (const uint8_t *p = aux_of(r), *end = r + bs; p < end;) { const size_t l = aux_field_len(p, end);
+                    if (!l) die("ERROR: malformed auxiliary field in " + tbam);
+                    const int which = (p[0] == 'H' && p[1] == 'P') ? 0 : (p[0] == 'P' && p[1] == 'S') ? 1 : (p[0] == 'P' && p[1] == 'Q') ? 2 : -1;
+                    if (which >= 0 && !seen[which]) { seen[which] = true;
+                        len -= l;
+                        } p += l;
+                    }
                 len += tag_bytes(i); }
             out_off[i + 1] = out_off[i] + len; ++st_count[status[i] & 7]; if (status[i] == 0) ++hp_hist[hp[i] < 9 ? hp[i] : 0];
         }
@@ -1425,11 +1080,26 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         for (size_t i = 0; i < nt; ++i) {
             const uint8_t *r = tbase + tc.rec_off[i]; const uint32_t bs = rd32(r - 4); uint8_t *o = ob.data() + out_off[i];
             if (status[i] != 0) { memcpy(o, r - 4, 4 + (size_t)bs); continue; }
-            const uint8_t *aux = aux_of(r), *end = r + bs; uint8_t *q = o + 4; memcpy(q, r, (size_t)(aux - r)); q += aux - r; bool seen[3] = {false, false, false};
-            for (const uint8_t *p = aux; p < end;) { const size_t l = aux_field_len(p, end); const int which = (p[0] == 'H' && p[1] == 'P') ? 0 : (p[0] == 'P' && p[1] == 'S') ? 1 : (p[0] == 'P' && p[1] == 'Q') ? 2 : -1;
+            const uint8_t *aux = aux_of(r), *end = r + bs;
+            uint8_t *q = o + 4;
+            memcpy(q, r, (size_t)(aux - r));
+            q += aux - r;
+            bool seen[3] = {false, false, false};
+            for (const uint8_t *p = aux; p < end;) { const size_t l = aux_field_len(p, end);
+                const int which = (p[0] == 'H' && p[1] == 'P') ? 0 : (p[0] == 'P' && p[1] == 'S') ? 1 : (p[0] == 'P' && p[1] == 'Q') ? 2 : -1;
                 if (which >= 0 && !seen[which]) seen[which] = true; else { memcpy(q, p, l); q += l; } p += l; }
-            if (hp[i]) { const char *hs = hp_str[hp[i] < 9 ? hp[i] : 0]; *q++ = 'H'; *q++ = 'P'; *q++ = 'Z'; const size_t hl = strlen(hs) + 1; memcpy(q, hs, hl); q += hl;
-                auto put_i = [&](char a, char b, int32_t v) { *q++ = (uint8_t)a; *q++ = (uint8_t)b; *q++ = 'i'; for (int k = 0; k < 4; ++k) *q++ = (uint8_t)((uint32_t)v >> (8 * k)); };
+            if (hp[i]) { const char *hs = hp_str[hp[i] < 9 ? hp[i] : 0];
+                *q++ = 'H';
+                *q++ = 'P';
+                *q++ = 'Z';
+                const size_t hl = strlen(hs) + 1;
+                memcpy(q, hs, hl);
+                q += hl;
+                auto put_i = [&](char a, char b, int32_t v) { *q++ = (uint8_t)a;
+                    *q++ = (uint8_t)b;
+                    *q++ = 'i';
+                    for (int k = 0; k < 4; ++k) *q++ = (uint8_t)((uint32_t)v >> (8 * k));
+                    };
                 if (psv[i] != -1) put_i('P', 'S', psv[i]); put_i('P', 'Q', pq[i]); }
             const uint32_t nbs = (uint32_t)(q - o) - 4; for (int k = 0; k < 4; ++k) o[k] = (uint8_t)(nbs >> (8 * k));
         }
@@ -1445,12 +1115,20 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         bool cmd_done = false; std::set<std::string> in_vec(chr_vec.begin(), chr_vec.end());
         for (const std::string &in : tlines) {
             if (in.size() >= 2 && in.compare(0, 2, "##") == 0) { o << in << std::endl; continue; }
-            if (in.size() >= 6 && (in.compare(0, 6, "#CHROM") == 0 || in.compare(0, 6, "#chrom") == 0)) { if (!cmd_done) { o << "##longphase_s_version=" << kVersion << std::endl << "##commandline=" << command << std::endl; cmd_done = true; } o << in << std::endl; continue; }
+            if (in.size() >= 6 && (in.compare(0, 6, "#CHROM") == 0 || in.compare(0, 6, "#chrom") == 0)) { if (!cmd_done) { o << "##longphase_s_version=" << kVersion << std::endl << "##commandline=" << command << std::endl;
+                    cmd_done = true;
+                    } o << in << std::endl;
+                continue;
+                }
             std::istringstream iss(in); std::vector<std::string> f((std::istream_iterator<std::string>(iss)), std::istream_iterator<std::string>());
             if (f.empty()) continue;
             if (f.size() < 7) die("[ERROR](VcfParser::writeProcess) => VCF file format error: " + in);
             if (!in_vec.count(f[0])) continue;
-            const int32_t p0 = std::stoi(f[1]) - 1; auto ct = trows.find(f[0]); if (ct == trows.end()) continue; auto rt = ct->second.find(p0); if (rt == ct->second.end() || rt->second.kind == 4) continue;
+            const int32_t p0 = std::stoi(f[1]) - 1;
+            auto ct = trows.find(f[0]);
+            if (ct == trows.end()) continue;
+            auto rt = ct->second.find(p0);
+            if (rt == ct->second.end() || rt->second.kind == 4) continue;
             const bool som = somatic_pos.count(f[0]) && somatic_pos[f[0]].count(p0);
             if (som) { if (f[6] != "PASS") f[6] = "PASS"; } else if (f[6] == "PASS") f[6] = "LowQual";
             std::string line = f[0]; for (size_t i = 1; i < f.size(); ++i) line += "\t" + f[i];
@@ -1494,7 +1172,9 @@ static int view_main(int argc, char **argv) {
 
 int main(int argc, char **argv) {
     std::string command; for (int i = 0; i < argc; ++i) { if (i) command += " "; command += argv[i]; }
-    if (argc < 2) { std::cout << "Version: " << kVersion << "\nUsage: longphase_amd <command> [options]\n    phase    run phasing algorithm on the GPU.\n    haplotag tag reads by haplotype on the GPU.\n    somatic_haplotag tag tumor reads (somatic + germline haplotypes) on the GPU; needs --tumor-purity.\n"; return 0; }
+    if (argc < 2) { std::cout << "Version: " << kVersion << "\nUsage: longphase_amd <command> [options]\n    phase    run phasing algorithm on the GPU.\n    haplotag tag reads by haplotype on the GPU.\n    somatic_haplotag tag tumor reads (somatic + germline haplotypes) on the GPU; needs --tumor-purity.\n";
+        return 0;
+        }
     const std::string cmd = argv[1];
     if (cmd == "phase") return phase_main(argc, argv, command);
     if (cmd == "view") return view_main(argc, argv);
