@@ -975,8 +975,14 @@ static int run_scorer(lps_ctx *c, bool somatic, uint8_t *status, int32_t *hp1, i
     HIP_TRY(hipEventRecord(c->ev_end, s));
     HIP_TRY(hipStreamSynchronize(s));
     c->h_cnt = *c->h_cnt_pin;
-    memcpy(status, c->h_res + o_st, (size_t)nR); memcpy(hp1, c->h_res + o_h1, (size_t)nR * 4); memcpy(hp2, c->h_res + o_h2, (size_t)nR * 4);
-    memcpy(n_ps, c->h_res + o_np, (size_t)nR); memcpy(ps_min, c->h_res + o_pm, (size_t)nR * 4);
+    if (nR < 200000) {
+        memcpy(status, c->h_res + o_st, (size_t)nR); memcpy(hp1, c->h_res + o_h1, (size_t)nR * 4); memcpy(hp2, c->h_res + o_h2, (size_t)nR * 4);
+        memcpy(n_ps, c->h_res + o_np, (size_t)nR); memcpy(ps_min, c->h_res + o_pm, (size_t)nR * 4);
+    } else {
+        std::thread t1([&] { memcpy(hp1, c->h_res + o_h1, (size_t)nR * 4); }), t2([&] { memcpy(hp2, c->h_res + o_h2, (size_t)nR * 4); }), t3([&] { memcpy(ps_min, c->h_res + o_pm, (size_t)nR * 4); });
+        memcpy(status, c->h_res + o_st, (size_t)nR); memcpy(n_ps, c->h_res + o_np, (size_t)nR);
+        t1.join(); t2.join(); t3.join();
+    }
     if (somatic) { memcpy(hp3, c->h_res + o_h3, (size_t)nR * 4); memcpy(d1, c->h_res + o_d1, (size_t)nR * 4); memcpy(d2, c->h_res + o_d2, (size_t)nR * 4); }
     if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) return fail(c, "Alignment find unsupported CIGAR operation", -2);
     lps_timings &t = c->tm; memset(&t, 0, sizeof t);
@@ -1006,21 +1012,31 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
         struct PqSmall { int v[64][64]; };                                       // PQ of (min votes, max votes) for small counts: libm's log10 once per pair
         static const PqSmall pq_tab = [] { PqSmall t{}; for (int mn = 1; mn < 64; ++mn) for (int mx = mn; mx < 64; ++mx) t.v[mn][mx] = -10 * (std::log10((double)mn / double((double)mx + (double)mn))); return t; }();
         const auto &pq_small = pq_tab.v;
-        for (int r = 0; r < nR; ++r) {
-            int hp = 0, pq = 0;
-            if (out->status[r] == 0) {
-                const int a = out->hp1[r], b = out->hp2[r];
-                double mn, mx;
-                if (a > b) { mn = b; mx = a; } else { mn = a; mx = b; }
-                if (mx / (mx + mn) < thr) pq = 0;
-                else { if (a > b) hp = 1; if (a < b) hp = 2; }
-                if (mx == 0) pq = 0; else if (mx == mx + mn) pq = 40;
-                else if (a < 64 && b < 64) pq = pq_small[a < b ? a : b][a < b ? b : a];    // the same expression, evaluated once per (min, max) pair
-                else pq = -10 * (std::log10((double)mn / double(mx + mn)));
-                if (out->n_ps[r] > 1) hp = 0;
+        auto judge = [&](int r0, int r1) -> int64_t {
+            int64_t n_tagged = 0;
+            for (int r = r0; r < r1; ++r) {
+                int hp = 0, pq = 0;
+                if (out->status[r] == 0) {
+                    const int a = out->hp1[r], b = out->hp2[r];
+                    double mn, mx;
+                    if (a > b) { mn = b; mx = a; } else { mn = a; mx = b; }
+                    if (mx / (mx + mn) < thr) pq = 0;
+                    else { if (a > b) hp = 1; if (a < b) hp = 2; }
+                    if (mx == 0) pq = 0; else if (mx == mx + mn) pq = 40;
+                    else if (a < 64 && b < 64) pq = pq_small[a < b ? a : b][a < b ? b : a];    // the same expression, evaluated once per (min, max) pair
+                    else pq = -10 * (std::log10((double)mn / double(mx + mn)));
+                    if (out->n_ps[r] > 1) hp = 0;
+                }
+                out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = hp ? out->ps_min[r] : 0;
+                n_tagged += hp != 0;
             }
-            out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = hp ? out->ps_min[r] : 0;
-            tagged += hp != 0;
+            return n_tagged;
+        };
+        if (nR < 200000) tagged = judge(0, nR);
+        else {                                                            // a whole 50x chromosome: a few host threads share the per-read decisions
+            const int nt = 4; std::thread th[nt]; int64_t part[nt] = {0, 0, 0, 0};
+            for (int t = 0; t < nt; ++t) th[t] = std::thread([&, t] { part[t] = judge((int)((int64_t)nR * t / nt), (int)((int64_t)nR * (t + 1) / nt)); });
+            for (int t = 0; t < nt; ++t) { th[t].join(); tagged += part[t]; }
         }
         c->tm.n_reads_used = tagged;
     } catch (std::string &e) { return fail(c, e); }
