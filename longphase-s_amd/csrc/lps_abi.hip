@@ -52,7 +52,7 @@ struct lps_ctx {
     DevBuf<uint64_t> rcand; uint64_t n_rec_all = 0; DevBuf<int32_t> r_tid_all; DevBuf<uint32_t> r_lname, r_nameoff, wg_cnt, wg_off, scan_nout; DevBuf<uint8_t> names_d; bool names_ready = false;
     // observations
     DevBuf<RowDesc> rows; DevBuf<int32_t> g_cnt; DevBuf<uint8_t> deleted;
-    DevBuf<ObsRec> obs; DevBuf<int32_t> g_node; DevBuf<uint8_t> g_flag; DevBuf<uint32_t> g_pack; DevBuf<uint32_t> redo_list; DevBuf<uint2> hit_ovf; unsigned ovf_chunks = 0;
+    DevBuf<ObsRec> obs; DevBuf<int32_t> g_node; DevBuf<uint8_t> g_flag; DevBuf<uint32_t> g_pack, t_src; DevBuf<uint16_t> g_rank; DevBuf<uint32_t> redo_list; DevBuf<uint2> hit_ovf; unsigned ovf_chunks = 0;
     unsigned long long obs_capacity = 0;   // main arenas (LPS_ARENAS equal parts); a tail arena of obs_capacity/4 follows
     DevBuf<unsigned long long> arena_ctr;
     bool in_phase = false; int timing_level = 1;
@@ -727,17 +727,18 @@ static int run_late(lps_ctx *c, bool with_cnv) {
         }
         // ---- a10 nodes + graph observations
         mark(c, ST_NODES);
-        launch_nodes(nR, nV, c->rows.p, c->deleted.p, c->obs.p, c->is_node.p, c->vtype_key.p, c->node_of.p, c->nodes.p, c->ntype.p, P.base_quality, c->g_node.p, c->g_flag.p, c->g_pack.p, c->g_cnt.p, c->d_cnt, c->node_end.p, c->temp.p, c->temp_bytes, s);
+        launch_nodes(nR, nV, c->rows.p, c->deleted.p, c->obs.p, c->is_node.p, c->vtype_key.p, c->node_of.p, c->nodes.p, c->ntype.p, P.base_quality, c->g_node.p, c->g_flag.p, c->g_pack.p, c->g_rank.p, c->g_cnt.p, c->d_cnt, c->node_end.p, c->temp.p, c->temp_bytes, s);
         // ---- merged rows
         mark(c, ST_MERGE);
-        launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->rows.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->late_cap_main, c->late_tail, c->mrow_off.p, c->mrow_cnt.p, c->multi_list.p, c->g_pack.p, s);
+        launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->rows.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->late_cap_main, c->late_tail, c->mrow_off.p, c->mrow_cnt.p, c->multi_list.p, c->g_pack.p, c->t_src.p, s);
         // ---- node-major sorted lists
         mark(c, ST_NODELISTS);
         c->m_bits = bits_for((unsigned long long)nR + 1); c->n_bits = bits_for((unsigned long long)nV + 2);
         c->a_bits = bits_for(2ull * (unsigned long long)nV + 2);        // index inside a merged row: a row holds every variant once per alignment of the read at most, and overlapping alignments are rare pairs
         if (c->m_bits + c->n_bits + c->a_bits > 63) { c->err = "sort key overflow"; return -4; }
         c->nkeys.reserve(c->late_n_keys + 1); c->nkeys_s.reserve(c->late_n_keys + 1); c->nvals.reserve(c->late_n_keys + 1); c->nvals_s.reserve(c->late_n_keys + 1);
-        launch_node_lists(c->d_cnt, nR, nV, c->mrow_off.p, c->mrow_cnt.p, c->koff.p, c->g_node.p, c->m_bits, c->a_bits, c->n_bits, c->nkeys.p, c->nkeys_s.p, c->nvals.p, c->nvals_s.p, c->late_n_keys, c->node_off.p, c->node_end.p, c->node_cur.p, c->temp.p, c->temp_bytes, s);
+        launch_node_lists(c->d_cnt, nR, nV, c->rows.p, c->g_cnt.p, c->read_group.p, c->gstart.p, c->mrow_off.p, c->mrow_cnt.p, c->multi_list.p, c->g_node.p, c->g_rank.p, c->t_src.p,
+                          (uint32_t)c->late_cap_main, c->a_bits, c->nkeys.p, c->nvals.p, c->node_off.p, c->node_end.p, c->temp.p, c->temp_bytes, s);
         // ---- a11/a12 edges
         mark(c, ST_EDGES);
         launch_edges(c->d_cnt, nV, c->node_off.p, c->node_end.p, c->nkeys.p, c->nvals.p, c->nkeys_s.p, c->nvals_s.p, c->mrow_off.p, c->mrow_cnt.p, c->m_bits, c->a_bits, c->g_pack.p, (uint32_t)c->late_cap_main, A, P.edge_weight, P.edge_threshold, c->ntype.p, c->edge.p, c->erec.p, c->node_pairs.p, s);
@@ -768,7 +769,7 @@ static int run_phase(lps_ctx *c) {
         c->ovf_chunks = (unsigned)((size_t)nR / 4 / 8 + 256);              // chunks of the global hit list: an eighth of the waves may take one
         c->hit_ovf.reserve((size_t)c->ovf_chunks * LPS_EXT_OVF_HITS);
         c->g_cnt.reserve(nR + 1);
-        c->obs.reserve(cap); c->g_node.reserve(cap); c->g_flag.reserve(cap); c->g_pack.reserve(cap);
+        c->obs.reserve(cap); c->g_node.reserve(cap); c->g_flag.reserve(cap); c->g_pack.reserve(cap); c->g_rank.reserve(cap); c->t_src.reserve(tail_size + 64);
         c->clip_capacity = (size_t)4 * nR + 64;                             // clip events (an alignment has two real clips at most; more only with H S ... S H)
         c->clip_ev.reserve(c->clip_capacity);
         c->clip_keys.reserve(c->clip_capacity); c->clip_keys_s.reserve(c->clip_capacity);

@@ -25,16 +25,16 @@ void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const Row
                        CnvScratch &W, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_nodes(int n_reads, int n_var, const RowDesc *rows, const uint8_t *deleted,
                   const ObsRec *obs, uint32_t *is_node, uint32_t *vtype_key, uint32_t *node_of,
-                  int32_t *nodes, uint8_t *ntype, int base_quality, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack, int32_t *g_cnt,
+                  int32_t *nodes, uint8_t *ntype, int base_quality, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack, uint16_t *g_rank, int32_t *g_cnt,
                   LpsCounters *cnt, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_debug_std_sort(int32_t *keys, uint8_t *payload, const long long *row_start, int n_rows, hipStream_t s);
 void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
                        const RowDesc *rows, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
-                       unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list, uint32_t *g_pack, hipStream_t s);
-void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t *mrow_off, const int32_t *mrow_cnt, uint32_t *koff,
-                       const int32_t *g_node, int m_bits, int a_bits, int n_bits, unsigned long long *keys,
-                       unsigned long long *keys_sorted, uint32_t *vals, uint32_t *vals_sorted, unsigned long long n_keys,
-                       uint32_t *node_off, uint32_t *node_cnt, uint32_t *node_cur, void *temp, size_t temp_bytes, hipStream_t s);
+                       unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list, uint32_t *g_pack, uint32_t *t_src, hipStream_t s);
+void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const RowDesc *rows, const int32_t *g_cnt, const uint32_t *read_group, const uint32_t *gstart,
+                       const uint32_t *mrow_off, const int32_t *mrow_cnt, const uint32_t *multi_list,
+                       const int32_t *g_node, const uint16_t *g_rank, const uint32_t *t_src, uint32_t tail_lo, int a_bits,
+                       unsigned long long *keys, uint32_t *vals, uint32_t *node_off, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
                   const unsigned long long *ukeys, const uint32_t *uvals, unsigned long long *skeys, uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                   int m_bits, int a_bits, const uint32_t *g_pack, uint32_t tail_lo, int A, double edge_weight,

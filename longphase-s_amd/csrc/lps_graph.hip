@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_mark_nodes(int n_reads, const RowDesc *
 // wave per alignment: graph view of the observations (node index, allele, hi-quality flag) in the same slots
 __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const RowDesc *rows,
                                                    const uint8_t *deleted, const ObsRec *obs,
-                                                   const uint32_t *node_of, int base_quality, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack,
+                                                   const uint32_t *node_of, int base_quality, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack, uint16_t *g_rank,
                                                    int32_t *g_cnt, LpsCounters *cnt, int n_var, const uint32_t *is_node, const uint32_t *vtype_key,
                                                    int32_t *nodes, uint8_t *ntype, uint32_t *node_cnt) {
     const int nb_reads = (n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
@@ -399,7 +399,11 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const RowDesc *r
             g_node[slot] = (int32_t)nd;
             g_flag[slot] = (uint8_t)fl;
             g_pack[slot] = nd | (fl << 30);                       // node (< 2^22) and flag in one word: what k_edges reads per pair
-            atomicAdd(&node_cnt[nd], 1u);                        // entries of the node's list: the merged rows hold exactly these observations
+            // entries of the node's list: the merged rows hold exactly these observations.  What the counting atomic returns is a unique rank inside
+            // that list: kept, it places the entry later without a second atomic (k_node_scatter)
+            const unsigned rk = atomicAdd(&node_cnt[nd], 1u);
+            if (rk > 0xffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE);   // more than 65 536 reads over one variant
+            g_rank[slot] = (uint16_t)rk;
         }
         w += __popcll(m);
     }
@@ -531,7 +535,7 @@ void launch_debug_std_sort(int32_t *keys, uint8_t *payload, const long long *row
 }
 
 __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *skeys, const uint32_t *gstart, const LpsCounters *cnt,
-                                                     const RowDesc *rows, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack,
+                                                     const RowDesc *rows, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack, uint32_t *t_src, uint32_t tail_lo,
                                                      const uint32_t *mrow_off, const uint32_t *multi_list) {
     __shared__ int s_stk[4][192]; __shared__ int32_t s_k[4][STDSORT_LDS]; __shared__ uint8_t s_p[4][STDSORT_LDS]; __shared__ uint16_t s_a[4][STDSORT_LDS], s_b[4][STDSORT_LDS];
     const int l = lane_id();
@@ -573,6 +577,9 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
                     ab += nb;
                 }
                 g_node[base + rank] = nd; g_flag[base + rank] = fl;
+                // the observation this element came from: its rank in the node's list places the element (k_node_scatter).  The std::sort path below only
+                // permutes elements of EQUAL node among themselves, so the pairing stays a bijection per node
+                t_src[base - tail_lo + rank] = oa + k;
             }
             aa += na;
         }
@@ -605,19 +612,45 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
 // ---- node-major lists: entries of node n = observations of n in merged rows, ordered by (name rank, index in merged row).
 // No global sort: count per node (atomics, in k_graph_obs), exclusive scan, scatter in arbitrary order; every node's short list is put in order by rank
 // counting by the wave of k_edges that consumes it (n^2/64 compares for n entries; n ~ coverage).
-__global__ __launch_bounds__(256) void k_node_scatter(const LpsCounters *cnt, const uint32_t *mrow_off, const int32_t *mrow_cnt,
-                                                      const int32_t *g_node, const uint32_t *node_off, uint32_t *node_cur, int a_bits,
-                                                      unsigned long long *keys, uint32_t *vals, LpsCounters *cntw, int n_var) {
+__global__ __launch_bounds__(256) void k_node_scatter(const LpsCounters *cnt, const RowDesc *rows, const int32_t *g_cnt, const uint32_t *read_group, const uint32_t *gstart,
+                                                      const uint32_t *mrow_off, const int32_t *mrow_cnt, const uint32_t *multi_list,
+                                                      const int32_t *g_node, const uint16_t *g_rank, const uint32_t *t_src, uint32_t tail_lo,
+                                                      const uint32_t *node_off, int a_bits,
+                                                      unsigned long long *keys, uint32_t *vals, LpsCounters *cntw, int n_var, int n_reads, int nb_reads) {
+    // No atomics: every observation already holds a unique rank inside its node's list (what k_graph_obs's counting atomic returned).  And BAM order: the
+    // entries of a node's list come from reads that overlap the node, i.e. from neighbours in BAM order, so the lists being filled at any moment span a
+    // few megabytes and the 12-byte entries combine in L2 before they reach HBM (walking the merged rows in name order sent every entry to a cold line:
+    // 5.6 bytes written per payload byte).  Reads of one alignment (nearly all) use their row as the merged row; the merged rows of multi-alignment reads
+    // (tail arena; an element takes the rank of the observation it was copied from) follow in the trailing workgroups.
     const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
-    const unsigned g = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
-    if (g == 0 && sl == 0) cntw->n_obs_final = node_off[n_var];         // sum of merged rows = end of the last node's list
-    if (g >= cnt->n_groups) return;
-    const int n = mrow_cnt[g];
+    if ((int)blockIdx.x >= nb_reads) {
+        const unsigned stride = (gridDim.x - nb_reads) * ROWS_PER_BLOCK, n_multi = cnt->n_multi;
+        for (unsigned q = (((int)blockIdx.x - nb_reads) * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp; q < n_multi; q += stride) {
+            const unsigned g = multi_list[q];
+            if (g == 0xffffffffu) continue;                             // its tail reservation failed (the host grows the buffers and reruns)
+            const int n = mrow_cnt[g];
+            if ((unsigned long long)n > (1ull << a_bits)) { if (sl == 0) atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); continue; }
+            const uint32_t off = mrow_off[g];
+            for (int a = sl; a < n; a += ROW_G) {
+                const int nd = g_node[off + a];
+                const uint32_t slot = node_off[nd] + g_rank[t_src[off - tail_lo + a]];
+                keys[slot] = ((unsigned long long)g << a_bits) | (unsigned)a; vals[slot] = off + a;
+            }
+        }
+        return;
+    }
+    const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
+    if (r == 0 && sl == 0) cntw->n_obs_final = node_off[n_var];         // sum of merged rows = end of the last node's list
+    if (r >= n_reads) return;
+    const int n = g_cnt[r];
+    if (n <= 0) return;
+    const unsigned g = read_group[r];
+    const uint32_t off = rows[r].off;
+    if (gstart[g + 1] - gstart[g] != 1 && mrow_off[g] != off) return;   // part of a merged row of several alignments: handled above (a group with ONE surviving alignment uses that row)
     if ((unsigned long long)n > (1ull << a_bits)) { if (sl == 0) atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); return; }
-    const uint32_t off = mrow_off[g];
     for (int a = sl; a < n; a += ROW_G) {
         const int nd = g_node[off + a];
-        const uint32_t slot = node_off[nd] + atomicAdd(&node_cur[nd], 1u);
+        const uint32_t slot = node_off[nd] + g_rank[off + a];
         keys[slot] = ((unsigned long long)g << a_bits) | (unsigned)a;      // (name rank, index in row)
         vals[slot] = off + a;
     }
@@ -1217,29 +1250,27 @@ void launch_overlap_filter(const unsigned long long *skeys, const uint32_t *gsta
 
 void launch_nodes(int n_reads, int n_var, const RowDesc *rows, const uint8_t *deleted,
                   const ObsRec *obs, uint32_t *is_node, uint32_t *vtype_key, uint32_t *node_of,
-                  int32_t *nodes, uint8_t *ntype, int base_quality, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack, int32_t *g_cnt,
+                  int32_t *nodes, uint8_t *ntype, int base_quality, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack, uint16_t *g_rank, int32_t *g_cnt,
                   LpsCounters *cnt, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s) {
     hipLaunchKernelGGL(k_mark_nodes, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, n_reads, rows, deleted, obs, is_node, vtype_key);
     exscan_u32(temp, temp_bytes, is_node, node_of, n_var, s);
-    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK + (n_var + 255) / 256), dim3(256), 0, s, n_reads, rows, deleted, obs, node_of, base_quality, g_node, g_flag, g_pack, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype, node_cnt);
+    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK + (n_var + 255) / 256), dim3(256), 0, s, n_reads, rows, deleted, obs, node_of, base_quality, g_node, g_flag, g_pack, g_rank, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype, node_cnt);
 }
 
 void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
                        const RowDesc *rows, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
-                       unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list, uint32_t *g_pack, hipStream_t s) {
+                       unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list, uint32_t *g_pack, uint32_t *t_src, hipStream_t s) {
     hipLaunchKernelGGL(k_merge_plan, GRID(n_reads, 256), 0, s, skeys, gstart, cnt, rows, g_cnt, tail_lo, tail_size, mrow_off, mrow_cnt, multi_list);
-    hipLaunchKernelGGL(k_merge_multi, dim3(256), dim3(256), 0, s, skeys, gstart, cnt, rows, g_cnt, g_node, g_flag, g_pack, mrow_off, multi_list);
+    hipLaunchKernelGGL(k_merge_multi, dim3(256), dim3(256), 0, s, skeys, gstart, cnt, rows, g_cnt, g_node, g_flag, g_pack, t_src, (uint32_t)tail_lo, mrow_off, multi_list);
 }
 
-void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const uint32_t *mrow_off, const int32_t *mrow_cnt, uint32_t *koff,
-                       const int32_t *g_node, int m_bits, int a_bits, int n_bits, unsigned long long *keys,
-                       unsigned long long *keys_sorted, uint32_t *vals, uint32_t *vals_sorted, unsigned long long n_keys,
-                       uint32_t *node_off, uint32_t *node_cnt, uint32_t *node_cur, void *temp, size_t temp_bytes, hipStream_t s) {
-    (void)koff;                                                         // node_cnt was filled by k_graph_obs
-    exscan_u32(temp, temp_bytes, node_cnt, node_off, (size_t)n_var + 1, s);
-    hipLaunchKernelGGL(k_node_scatter, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, cnt, mrow_off, mrow_cnt, g_node, node_off, node_cur, a_bits, keys, vals, cnt, n_var);
-    (void)keys_sorted; (void)vals_sorted;
-    (void)m_bits; (void)n_bits; (void)n_keys;
+void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const RowDesc *rows, const int32_t *g_cnt, const uint32_t *read_group, const uint32_t *gstart,
+                       const uint32_t *mrow_off, const int32_t *mrow_cnt, const uint32_t *multi_list,
+                       const int32_t *g_node, const uint16_t *g_rank, const uint32_t *t_src, uint32_t tail_lo, int a_bits,
+                       unsigned long long *keys, uint32_t *vals, uint32_t *node_off, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s) {
+    exscan_u32(temp, temp_bytes, node_cnt, node_off, (size_t)n_var + 1, s);      // node_cnt was filled by k_graph_obs
+    const int nb_reads = (n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(k_node_scatter, dim3(nb_reads + 64), dim3(256), 0, s, cnt, rows, g_cnt, read_group, gstart, mrow_off, mrow_cnt, multi_list, g_node, g_rank, t_src, tail_lo, node_off, a_bits, keys, vals, cnt, n_var, n_reads, nb_reads);
 }
 
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
