@@ -685,12 +685,14 @@ static const char *kSomUsage =
     "   -s, --snp-file=NAME (phased normal VCF)   -b, --bam-file=NAME (normal BAM)   --tumor-snv-file=NAME   --tumor-bam-file=NAME   -r, --reference=NAME\n"
     "   --tumor-purity=Num (default: automatic estimation, written to <prefix>_purity.out)   --disableFilter   --somatic-calling-log (writes <prefix>_somatic_filter.log)\n"
     "   --output-somatic-vcf (writes <prefix>_sc.vcf: the tumor VCF with FILTER = PASS for the somatic calls, LowQual otherwise)\n"
-    "   --tagSupplementary   -q qualityThreshold(1)   -p percentageThreshold(0.6)   -t threads(1)   -o out-prefix(result)   --gpu=ID (0)\n";
+    "   --tagSupplementary   -q qualityThreshold(1)   -p percentageThreshold(0.6)   -t threads(1)   -o out-prefix(result)   --gpu=ID (0)\n"
+    "   --gpus=N (deal the contigs onto N GPU contexts, devices --gpu, --gpu+1, ...: the three BAM passes of a contig run on its worker, purity is estimated\n"
+    "             over all contigs, logs and the tagged BAM are merged in contig order)\n";
 
 static int somatic_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
     std::string snp, ref, nbam, tvcf, tbam, prefix = "result";
-    int threads = 1, gpu = 0;
+    int threads = 1, gpu = 0, n_gpus = 1;
     double purity = -1, pct = 0.6;
     bool enable_filter = true, write_log = false, write_sc_vcf = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kSomUsage; exit(1); } return argv[++i]; };
@@ -718,6 +720,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         else if (a == "--somatic-calling-log") write_log = true;
         else if (a == "--output-somatic-vcf") write_sc_vcf = true;
         else if (a == "--gpu") gpu = std::stoi(val());
+        else if (a == "--gpus") n_gpus = std::max(1, std::stoi(val()));
         else if (a == "--help") { std::cout << kSomUsage; return 0; }
         else if (a == "--cram" || a == "--region" || a == "--log" || a == "--truth-vcf" || a == "--truth-bed" || a == "--benchmark-log") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kSomUsage; return 1; }
@@ -796,14 +799,18 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         h.insert(h.end(), d + ref_begin, d + p);
         w.append(h.data(), h.size());
     }
-    auto fail = [&]() { die(std::string("longphase_amd: ") + L.last_error(ctx)); };
     unsigned long long n_somatic_flag = 0, hp_hist[9] = {0}, st_count[8] = {0};
     std::map<std::string, std::set<int32_t>> somatic_pos;               // isSomaticVariant (getSomaticFlag), for --output-somatic-vcf
     // phase 0 (only when the purity has to be estimated): passes 1 and 2 over every contig feed the estimator, which needs all contigs at once;
     // phase 1: passes 1 and 2 again (milliseconds on the GPU), the caller's statistics and filters, pass 3, the writer.
-    for (int phase = estimate ? 0 : 1; phase < 2; ++phase) {
-    if (phase == 1 && estimate) { purity = estimate_purity(pdata, p_initial, lcvf, prefix); T = somatic_thresholds(purity); announce(); }
-    for (const std::string &chr : chr_vec) {
+    // One contig of one phase, on one GPU context.  Everything it adds to run-wide state goes to its own ContigAcc, merged in contig order by the caller - so the
+    // contigs can be dealt onto several workers (--gpus N) and the outputs (filter log, tagged BAM, purity inputs) still come out in the reference's order.
+    struct ContigAcc { std::vector<PurityDatum> pdata; size_t p_initial = 0; int lcvf[5] = {0, 0, 0, 0, 0}; std::ostringstream flog; std::set<int32_t> som;
+                       unsigned long long n_flag = 0, hp_hist[9] = {0}, st_count[8] = {0}; std::vector<uint8_t> out; size_t out_bytes = 0; bool ready = false; };
+    auto do_contig = [&](lps_ctx *ctx, const std::string &chr, int phase, ContigAcc &A) {
+        auto fail = [&]() { die(std::string("longphase_amd: ") + L.last_error(ctx)); };
+        std::vector<PurityDatum> &pdata = A.pdata; size_t &p_initial = A.p_initial; int (&lcvf)[5] = A.lcvf; std::ostringstream &flog = A.flog;
+        unsigned long long &n_somatic_flag = A.n_flag; unsigned long long (&hp_hist)[9] = A.hp_hist; unsigned long long (&st_count)[8] = A.st_count;
         auto ti = tin.contigs.find(chr);
         const bool have_t = ti != tin.contigs.end() && !ti->second.rec_off.empty();
         // ---- merged table (MultiGenomeVar map): normal phased-het rows + tumor rows
@@ -836,10 +843,10 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                   hpa.push_back(0); ps.push_back(0); role.push_back(2); derive.push_back(0); tkind.push_back((uint8_t)b->second.kind); ++b; }
           } }
         const size_t nv = pos.size();
-        if (!have_t) continue;
+        if (!have_t) return;
         const ContigRecords &tc = ti->second; const size_t nt = tc.rec_off.size(); const uint8_t *tbase = tin.z.data + tc.lo;
         std::vector<uint8_t> status(nt, 5), hp(nt, 0); std::vector<int32_t> psv(nt, -1), pq(nt, 0);
-        if (phase == 0 && !nv) continue;
+        if (phase == 0 && !nv) return;
         if (nv) {
             if (!seqs.count(chr)) die("ERROR: contig " + chr + " is missing from the reference FASTA");
             const std::string &sq = seqs[chr];
@@ -920,7 +927,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                     else if (ncount <= 5) ++lcvf[3];
                     else if (npct <= 0.7f) ++lcvf[4];
                     else pdata.push_back(PurityDatum{tr_ratio, ncount}); }
-                continue;
+                return;
             }
             // ---- host stages.  "exists": the site was touched by a tumor read (std::map entries of somaticPosInfo)
             std::vector<int> sites; std::vector<int> site_of(nv, -1);
@@ -1044,7 +1051,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                 if (tot > 0) { if (d1 > 0) r1 = (float)d1 / (float)tot;
                     if (d2 > 0) r2 = (float)d2 / (float)tot;
                     }
-                const size_t v = (size_t)sites[i]; ++n_somatic_flag; if (write_sc_vcf) somatic_pos[chr].insert(pos[v]);
+                const size_t v = (size_t)sites[i]; ++n_somatic_flag; if (write_sc_vcf) A.som.insert(pos[v]);
                 if (role[v] != 0) { role[v] = 1;
                     derive[v] = r1 >= 1.0f ? 1 : r2 >= 1.0f ? 2 : 0;
                     }   // a position that also has a normal row keeps its germline role in the tagging pass
@@ -1103,10 +1110,44 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                 if (psv[i] != -1) put_i('P', 'S', psv[i]); put_i('P', 'Q', pq[i]); }
             const uint32_t nbs = (uint32_t)(q - o) - 4; for (int k = 0; k < 4; ++k) o[k] = (uint8_t)(nbs >> (8 * k));
         }
-        w.append(ob.data(), out_off[nt]);
+        A.out.swap(ob); A.out_bytes = (size_t)out_off[nt];
         std::cerr << "(" << chr << ")";
+    };
+    // contigs dealt longest-first (tumor records) onto the workers; worker 0 is this thread's context, the others create theirs
+    const int n_dev = std::max(1, L.device_count());
+    const int n_workers = std::max(1, std::min<int>(n_gpus, (int)chr_vec.size()));
+    std::vector<std::vector<size_t>> share((size_t)n_workers);
+    { std::vector<size_t> order(chr_vec.size()); for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+      auto weight = [&](size_t i) -> size_t { auto it = tin.contigs.find(chr_vec[i]); return it == tin.contigs.end() ? 0 : it->second.rec_off.size(); };
+      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight(a) > weight(b); });
+      std::vector<size_t> load((size_t)n_workers, 0);
+      for (size_t i : order) { const size_t g = (size_t)(std::min_element(load.begin(), load.end()) - load.begin()); share[g].push_back(i); load[g] += weight(i) + 1; }
+      for (auto &v : share) std::sort(v.begin(), v.end()); }
+    std::vector<lps_ctx *> wctx((size_t)n_workers, nullptr); wctx[0] = ctx;
+    for (int g = 1; g < n_workers; ++g) { lps_params P; L.default_params(&P); for (auto &f : over) f(P);
+        wctx[(size_t)g] = L.create((gpu + g) % n_dev, &P); if (!wctx[(size_t)g]) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
+        L.set_stage_timing(wctx[(size_t)g], 0); }
+    for (int phase = estimate ? 0 : 1; phase < 2; ++phase) {
+        if (phase == 1 && estimate) { purity = estimate_purity(pdata, p_initial, lcvf, prefix); T = somatic_thresholds(purity); announce(); }
+        std::vector<ContigAcc> acc(chr_vec.size()); std::mutex mu; std::condition_variable cv;
+        auto run_share = [&](int g) { for (size_t i : share[(size_t)g]) { do_contig(wctx[(size_t)g], chr_vec[i], phase, acc[i]); { std::lock_guard<std::mutex> lk(mu); acc[i].ready = true; } cv.notify_all(); } };
+        std::vector<std::thread> workers;
+        if (n_workers > 1) for (int g = 0; g < n_workers; ++g) workers.emplace_back(run_share, g);
+        for (size_t i = 0; i < chr_vec.size(); ++i) {                    // merge (and write) in contig order
+            if (n_workers == 1) do_contig(ctx, chr_vec[i], phase, acc[i]);
+            else { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return acc[i].ready; }); }
+            ContigAcc &A = acc[i];
+            pdata.insert(pdata.end(), A.pdata.begin(), A.pdata.end()); p_initial += A.p_initial; for (int k = 0; k < 5; ++k) lcvf[k] += A.lcvf[k];
+            if (write_log) flog << A.flog.str();
+            if (!A.som.empty()) somatic_pos[chr_vec[i]].swap(A.som);
+            n_somatic_flag += A.n_flag; for (int k = 0; k < 9; ++k) hp_hist[k] += A.hp_hist[k]; for (int k = 0; k < 8; ++k) st_count[k] += A.st_count[k];
+            if (A.out_bytes) w.append(A.out.data(), A.out_bytes);
+            std::vector<uint8_t>().swap(A.out); A.flog.str(std::string());
+        }
+        for (auto &x : workers) x.join();
     }
-    }
+    for (int g = 1; g < n_workers; ++g) L.destroy(wctx[(size_t)g]);
+    if (n_workers > 1) std::cerr << "\n" << n_workers << " workers (one GPU context each, contigs dealt by tumor record count)";
     std::cerr << "\n";
     w.finish();
     if (write_log) flog.close();                                       // the process leaves through _exit: nothing is flushed implicitly

@@ -55,3 +55,54 @@ def test_cli_somatic_argument_errors(tmp_path):
     assert r.returncode == 1 and "missing arguments" in r.stderr
     r = subprocess.run([CLI, "somatic_haplotag", "-s", "a.vcf", "-b", "a.bam", "--tumor-snv-file", "t.vcf", "--tumor-bam-file", "t.bam", "-r", "r.fa", "--cram"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "not supported" in r.stderr
+
+
+def _merge_contigs(d, parts):
+    """three single-contig tumor/normal fixtures -> one three-contig input set in d (text merges: headers first, records in contig order)"""
+    def cat(name, is_header):
+        head, body = [], []
+        for sub, _ in parts:
+            for ln in open(os.path.join(d, sub, name)):
+                (head if is_header(ln) else body).append(ln)
+        seen, uniq = set(), []
+        for h in head:
+            if h not in seen:
+                seen.add(h); uniq.append(h)
+        return uniq, body
+    with open(d + "/ref.fa", "w") as f:
+        for sub, _ in parts:
+            f.write(open(os.path.join(d, sub, "ref.fa")).read())
+    for sam in ("normal.sam", "tumor.sam"):
+        head, body = cat(sam, lambda l: l.startswith("@"))
+        hd = [h for h in head if h.startswith("@HD")][:1] + [h for h in head if h.startswith("@SQ")] + [h for h in head if not h.startswith(("@HD", "@SQ"))]
+        open(os.path.join(d, sam), "w").write("".join(hd + body))
+    for vcf in ("tumor.vcf", "normal_phased.vcf"):
+        head, body = cat(vcf, lambda l: l.startswith("#"))
+        cols = [h for h in head if h.startswith("#CHROM")][:1]
+        open(os.path.join(d, vcf), "w").write("".join([h for h in head if h.startswith("##")] + cols + body))
+
+
+def test_cli_somatic_gpus_equals_single_worker(tmp_path):
+    """somatic_haplotag --gpus 3 (three contexts on the one GPU of the box, contigs dealt onto them, purity estimated over all contigs, outputs merged in
+    contig order) must write exactly what the single-worker run writes: filter log, purity report, somatic VCF and the tagged BAM's record stream."""
+    d = str(tmp_path)
+    parts = [("a", "chrA"), ("b", "chrB"), ("c", "chrC")]
+    for (sub, chrom), name in zip(parts, ("tn60", "tn30_indel", "tn_dense")):
+        os.makedirs(os.path.join(d, sub))
+        util.make_somatic_inputs(os.path.join(d, sub), name, chrom=chrom)
+        phased = open(os.path.join(HERE, "golden", "data", f"somatic_{name}.normal_phased.vcf")).read().replace("chrS", chrom)
+        open(os.path.join(d, sub, "normal_phased.vcf"), "w").write(phased)
+    _merge_contigs(d, parts)
+    util.write_bam(d + "/normal.sam", d + "/normal.bam"); util.write_bam(d + "/tumor.sam", d + "/tumor.bam", block=40000)
+    outs = {}
+    for tag, extra in (("one", []), ("three", ["--gpus", "3"])):
+        r = subprocess.run([CLI, "somatic_haplotag", "-s", "normal_phased.vcf", "-b", "normal.bam", "--tumor-snv-file", "tumor.vcf", "--tumor-bam-file", "tumor.bam", "-r", "ref.fa",
+                            "-t", "4", "-o", tag, "--somatic-calling-log", "--output-somatic-vcf", "--tagSupplementary"] + extra, cwd=d, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("3 workers" in r.stderr) == bool(extra)
+        text, refs, recs = util.bam_sections(os.path.join(d, tag + ".bam"))
+        sc = [l for l in open(os.path.join(d, tag + "_sc.vcf")).read().split("\n") if not l.startswith("##commandline=")]
+        outs[tag] = (hashlib.sha256(recs).hexdigest(), len(recs), open(os.path.join(d, tag + "_somatic_filter.log")).read(), open(os.path.join(d, tag + "_purity.out")).read(), sc,
+                     [l for l in r.stderr.splitlines() if l.startswith("somatic variant count(Flag)")])
+    assert outs["one"][1] > 1_000_000 and len(outs["one"][2].splitlines()) > 100
+    assert outs["one"] == outs["three"]
