@@ -9,10 +9,10 @@ WL=${1:-chr1_50x}            # bench.py --workload: chr1_50x = the largest conti
 OUT=$ROOT/gpurun_out/prof_$WL
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --parity none --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_under_trace.json" 2> "$OUT/stats.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --parity none --ctx-per-gpu 1 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_under_trace.json" 2> "$OUT/stats.err"
 echo "stats pass done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 "$ROOT/bench.py" --workload $WL --parity none --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/fetch.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 "$ROOT/bench.py" --workload $WL --parity none --ctx-per-gpu 1 --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/fetch.err"
 echo "FETCH_SIZE pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 "$ROOT/bench.py" --workload $WL --parity none --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/write.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 "$ROOT/bench.py" --workload $WL --parity none --ctx-per-gpu 1 --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/write.err"
 echo "WRITE_SIZE pass done"
 cd "$ROOT" && python3 profiles/summarize.py "$OUT" gpurun_out/prof_summary_$WL $WL

@@ -32,7 +32,7 @@ def main():
     with open(os.path.join(dst, "kernel_stats.csv"), "w") as f:
         f.write(open(stats).read())
     with open(os.path.join(dst, "kernel_stats.md"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --parity none --steps 10 --warmup 2 --no-cpu-baseline (MI355X)" % wl + "\n\n| kernel | calls | avg us | total % |\n|---|---|---|---|\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --parity none --ctx-per-gpu 1 --steps 10 --warmup 2 --no-cpu-baseline (MI355X)" % wl + "\n\n| kernel | calls | avg us | total % |\n|---|---|---|---|\n")
         for r in rows[:40]:
             f.write("| `%s` | %s | %.1f | %s |\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
     per = {}
