@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 10
+#define LPS_ABI_VERSION 11
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -103,6 +103,32 @@ typedef struct lps_read_batch {
     const uint64_t *qual_off;  /* n_reads+1 */
     const uint8_t *qual;
 } lps_read_batch;
+
+/* SV and MOD rows co-phased with the SNPs (`phase --sv-file / --mod-file`): what BamParser holds next to the SNP map
+ * (src/phase/ParsingBam.cpp:1207-1235) - SV_map[chr] = (start, SVLEN) pairs of SVParser (:915-1017), currentMod = per position the reads
+ * METHParser listed (:1685-1786).  Both become graph nodes at their own positions; get_snp's SV branch (:1397-1434) calls a read ALT when an
+ * insertion / deletion of about the SV's length lies within sv_window CIGAR operations of the operation that reaches the row, its MOD branch
+ * (:1373-1395) takes the allele from the read lists.
+ *   sv_pos   0-based = VCF POS - 1 (:1354), strictly increasing; sv_len = SVLEN as written in the VCF (sign kept)
+ *   mod_pos  0-based representative position (:1709-1711), strictly increasing
+ *   mod_off  n_mod+1 offsets into mod_name / mod_flag; mod_name = name_id of the listed reads (same id space as lps_read_batch.name_id;
+ *            names that occur in no alignment can be left out), strictly increasing inside a row; mod_flag bit0 = listed under MR= (modified),
+ *            bit1 = RS=N (reverse strand)
+ * No position may occur in two of the three tables (SNP, SV, MOD): the reference's three-cursor loop does not terminate on such input
+ * (none of its branches takes a row that ties with another cursor), the library refuses it. */
+typedef struct lps_extra_variants {
+    int64_t n_sv;
+    const int32_t *sv_pos;
+    const int32_t *sv_len;
+    int64_t n_mod;
+    const int32_t *mod_pos;
+    const uint64_t *mod_off;
+    const uint32_t *mod_name;
+    const uint8_t *mod_flag;
+    int32_t sv_window;      /* --svWindow 20    (src/phase/Phasing.cpp:113) */
+    int32_t reserved;
+    double sv_threshold;    /* --svThreshold 0.1 (src/phase/Phasing.cpp:114) */
+} lps_extra_variants;
 
 /* Result of one chromosome = PhasingResult entries (src/shared/Util.h:18-24) indexed like the variant
  * table: phase_set[i] = PS (block start position + 1) or 0 when variant i is not phased;
@@ -218,7 +244,8 @@ int lps_debug_std_sort_gpu(int device, int32_t *keys, uint8_t *payload, const in
  * the extraction overflow, which the library answers by growing the arenas and running again (tests/test_scale_gpu.py). */
 int lps_debug_set_obs_capacity(lps_ctx *ctx, int64_t slots);
 /* sizeof() of the ABI structs as compiled into the library: 0 lps_params, 1 lps_variant_table, 2 lps_read_batch,
- * 3 lps_phase_result, 4 lps_haplotag_result, 5 lps_timings, 6 lps_somatic_tag_result, 7 lps_site_counters, 8 lps_tumor_extract_result (binding self-check). */
+ * 3 lps_phase_result, 4 lps_haplotag_result, 5 lps_timings, 6 lps_somatic_tag_result, 7 lps_site_counters, 8 lps_tumor_extract_result,
+ * 9 lps_extra_variants (binding self-check). */
 int lps_struct_size(int which);
 int lps_device_count(void);
 /* PCI bus id ("0000:c1:00.0") of a device: ranks that share a GPU must not form an RCCL communicator (lps_comm_create) */
@@ -232,6 +259,10 @@ const char *lps_last_error(lps_ctx *ctx);
 int lps_begin_chromosome(lps_ctx *ctx);
 /* getVariants_markindel + getLastSNP (src/phase/ParsingBam.cpp:378-417,426-441). */
 int lps_set_variants(lps_ctx *ctx, const lps_variant_table *table);
+/* SV / MOD rows of the chromosome (phase only).  Call after lps_set_variants; NULL or an empty table = none.  The tables are copied. */
+int lps_set_extra_variants(lps_ctx *ctx, const lps_extra_variants *extra);
+/* Results of the SV / MOD rows of the last lps_phase_chromosome (sv->n = n_sv, mod->n = n_mod; either may be NULL). */
+int lps_get_extra_result(lps_ctx *ctx, lps_phase_result *sv, lps_phase_result *mod);
 /* Reference bases of the chromosome; the library applies FastaParser's truncation to [0,lastVariant+5]
  * (src/phase/ParsingBam.cpp:47) itself.  May be shorter than the contig as long as it covers that prefix. */
 int lps_set_reference(lps_ctx *ctx, const char *seq, int64_t len);

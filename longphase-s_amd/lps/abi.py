@@ -133,6 +133,30 @@ class Variants:
         return self
 
 
+class ExtraVariantTable(C.Structure):
+    _fields_ = [("n_sv", C.c_int64), ("sv_pos", C.c_void_p), ("sv_len", C.c_void_p), ("n_mod", C.c_int64), ("mod_pos", C.c_void_p),
+                ("mod_off", C.c_void_p), ("mod_name", C.c_void_p), ("mod_flag", C.c_void_p), ("sv_window", C.c_int32), ("reserved", C.c_int32),
+                ("sv_threshold", C.c_double)]
+
+
+class ExtraVariants:
+    """SV and MOD rows co-phased with the SNPs (lps_extra_variants).  mod_rows: per MOD row a list of (name_id, modified, reverse)."""
+
+    def __init__(self, sv_pos=(), sv_len=(), mod_pos=(), mod_rows=(), sv_window=20, sv_threshold=0.1):
+        self.sv_pos = np.ascontiguousarray(sv_pos, dtype=np.int32); self.sv_len = np.ascontiguousarray(sv_len, dtype=np.int32)
+        self.mod_pos = np.ascontiguousarray(mod_pos, dtype=np.int32)
+        assert self.sv_pos.size == self.sv_len.size and self.mod_pos.size == len(mod_rows)
+        off = [0]; names = []; flags = []
+        for row in mod_rows:
+            row = sorted(row)
+            names += [int(r[0]) for r in row]; flags += [(1 if r[1] else 0) | (2 if r[2] else 0) for r in row]
+            off.append(len(names))
+        self.mod_off = np.array(off, np.uint64); self.mod_name = np.array(names, np.uint32); self.mod_flag = np.array(flags, np.uint8)
+        self.n_sv = int(self.sv_pos.size); self.n_mod = int(self.mod_pos.size)
+        self.c = ExtraVariantTable(self.n_sv, _ptr(self.sv_pos), _ptr(self.sv_len), self.n_mod, _ptr(self.mod_pos), _ptr(self.mod_off),
+                                   _ptr(self.mod_name), _ptr(self.mod_flag), sv_window, 0, sv_threshold)
+
+
 class Reads:
     """Host-side SoA read batch."""
 

@@ -21,6 +21,7 @@ class SynthParams(C.Structure):
         ("supp_frac", C.c_double), ("supp_overlap_frac", C.c_double), ("hpoly_every", C.c_double),
         ("snp_in_hpoly_frac", C.c_double), ("snp_pair_frac", C.c_double), ("tandem_frac", C.c_double),
         ("n_threads", C.c_int32), ("clip_pileups", C.c_int32), ("gap_start", C.c_int64), ("gap_len", C.c_int64), ("read_seed", C.c_uint64), ("somatic_every", C.c_double), ("tumor_purity", C.c_double),
+        ("sv_every", C.c_double),
     ]
 
 
@@ -29,7 +30,7 @@ DEFAULTS = dict(
     len_min=1000, len_max=200000, sub_rate=0.01, ins_rate=0.01, del_rate=0.01, indel_var_frac=0.0,
     lowq_frac=0.10, mapq0_frac=0.01, secondary_frac=0.003, dup_frac=0.002, clip_every=7, supp_frac=0.02,
     supp_overlap_frac=0.5, hpoly_every=2000.0, snp_in_hpoly_frac=0.05, snp_pair_frac=0.01, tandem_frac=0.3,
-    n_threads=8, clip_pileups=0, gap_start=0, gap_len=0, read_seed=0, somatic_every=0.0, tumor_purity=0.6,
+    n_threads=8, clip_pileups=0, gap_start=0, gap_len=0, read_seed=0, somatic_every=0.0, tumor_purity=0.6, sv_every=0.0,
 )
 
 _lib = None
@@ -44,12 +45,13 @@ def _load():
         L.synth_create.restype = C.c_void_p
         L.synth_create.argtypes = [C.POINTER(SynthParams)]
         L.synth_destroy.argtypes = [C.c_void_p]
-        for n in ("synth_n_reads", "synth_n_variants", "synth_n_somatic"):
+        for n in ("synth_n_reads", "synth_n_variants", "synth_n_somatic", "synth_n_sv"):
             getattr(L, n).restype = C.c_int64
             getattr(L, n).argtypes = [C.c_void_p]
         for n in ("synth_ref", "synth_var_pos", "synth_var_hap", "synth_ref_start", "synth_l_qseq", "synth_flag",
                   "synth_mapq", "synth_name_id", "synth_read_hap", "synth_cigar_off", "synth_seq_off",
-                  "synth_qual_off", "synth_cigar", "synth_seq", "synth_qual", "synth_som_pos", "synth_som_ref", "synth_som_alt", "synth_som_hap"):
+                  "synth_qual_off", "synth_cigar", "synth_seq", "synth_qual", "synth_som_pos", "synth_som_ref", "synth_som_alt", "synth_som_hap",
+                  "synth_sv_pos", "synth_sv_len", "synth_sv_hap"):
             getattr(L, n).restype = C.c_void_p
             getattr(L, n).argtypes = [C.c_void_p]
         for n in ("synth_var_ref", "synth_var_alt"):
@@ -92,6 +94,10 @@ class Synth:
         self.som_ref = _view(L.synth_som_ref(h), ns, np.uint8)
         self.som_alt = _view(L.synth_som_alt(h), ns, np.uint8)
         self.som_hap = _view(L.synth_som_hap(h), ns, np.uint8)
+        nx = self.n_sv = L.synth_n_sv(h)
+        self.sv_pos = _view(L.synth_sv_pos(h), nx, np.int32)
+        self.sv_len = _view(L.synth_sv_len(h), nx, np.int32)
+        self.sv_hap = _view(L.synth_sv_hap(h), nx, np.uint8)
         self.ref_start = _view(L.synth_ref_start(h), n, np.int32)
         self.l_qseq = _view(L.synth_l_qseq(h), n, np.int32)
         self.flag = _view(L.synth_flag(h), n, np.uint16)
@@ -127,3 +133,87 @@ class Synth:
             self.close()
         except Exception:
             pass
+
+
+# ---- SV / MOD inputs of `phase` (test infrastructure): what a SV caller and `modcall` would have written for the generated reads
+def read_ref_end(s):
+    """Reference position after the last CIGAR operation of every alignment."""
+    op = s.cigar & 15
+    ln = (s.cigar >> 4).astype(np.int64)
+    cons = np.where((op == 0) | (op == 2) | (op == 3) | (op == 7) | (op == 8), ln, 0)
+    cs = np.concatenate([[0], np.cumsum(cons)])
+    off = s.cigar_off.astype(np.int64)
+    return s.ref_start.astype(np.int64) + cs[off[1:]] - cs[off[:-1]]
+
+
+def make_mod_lines(s, mod_every=2500.0, seed=0, pair_frac=0.5, noise=0.1, wrong_strand=0.05, listed=0.9, taken=()):
+    """-> list of (pos0, reverse, [(name_id, modified)]) = the records of a modcall VCF: one strand per record, consecutive positions are
+    merged by the reader under the first one (METHParser, src/phase/ParsingBam.cpp:1707-1711).  Positions avoid `taken` and the SNP / SV rows."""
+    g = np.random.default_rng(seed)
+    avoid = set(int(p) for p in s.var_pos) | set(int(p) for p in s.sv_pos) | set(int(p) + 1 for p in s.sv_pos) | set(int(p) for p in taken)
+    end = read_ref_end(s)
+    order = np.argsort(s.ref_start, kind="stable")
+    lines = []
+    x = 500.0 + g.exponential(mod_every)
+    hap_of_site = {}
+    while x < s.contig_len - 500:
+        p = int(x)
+        x += 30 + g.exponential(mod_every)
+        positions = [(p, False), (p + 1, True)] if g.random() < pair_frac else [(p, bool(g.random() < 0.5))]
+        if any(q in avoid or q - 1 in avoid or q + 1 in avoid for q, _ in positions):
+            continue
+        mod_hap = int(g.integers(2))
+        for q, rev in positions:
+            cover = np.nonzero((s.ref_start <= q) & (end > q))[0]
+            reads = []
+            for r in cover:
+                r_rev = bool(s.flag[r] & 0x10)
+                if g.random() > listed:
+                    continue
+                if r_rev != rev and g.random() > wrong_strand:
+                    continue
+                modified = (int(s.read_hap[r]) == mod_hap) != (g.random() < noise)
+                reads.append((int(s.name_id[r]), bool(modified)))
+            if reads:
+                lines.append((q, rev, reads))
+    return lines
+
+
+def merge_mod_lines(lines):
+    """The representative rows METHParser builds from well-formed heterozygous records: (positions, per row [(name_id, modified, reverse)])."""
+    rows = {}
+    rep = None
+    prev = None
+    for q, rev, reads in lines:
+        if prev is None or prev + 1 != q:
+            rep = q
+        d = rows.setdefault(rep, {})
+        for name, modified in sorted(reads, key=lambda e: not e[1]):     # the reader takes the MR= list first, then NR= (:1746-1780)
+            d[name] = (modified, rev)          # a name listed twice under one representative: the later entry wins (std::map assignment)
+        prev = q
+    pos = sorted(rows)
+    return pos, [[(n, m, r) for n, (m, r) in sorted(rows[p].items())] for p in pos]
+
+
+def write_sv_vcf(path, chrom, sv_pos, sv_len, contig_len, gt=None):
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.2\n##contig=<ID=%s,length=%d>\n##INFO=<ID=SVTYPE,Number=1,Type=String,Description=\"\">\n" % (chrom, contig_len))
+        f.write("##INFO=<ID=SVLEN,Number=1,Type=Integer,Description=\"\">\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"\">\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n")
+        for i, (p, l) in enumerate(zip(sv_pos, sv_len)):
+            g = "0/1" if gt is None else gt[i]
+            f.write("%s\t%d\tsv%d\tN\t<%s>\t60\tPASS\tSVTYPE=%s;SVLEN=%d;END=%d\tGT:DR:DV\t%s:10:10\n"
+                    % (chrom, int(p) + 1, i, "INS" if l > 0 else "DEL", "INS" if l > 0 else "DEL", int(l), int(p) + 1 + (0 if l > 0 else -int(l)), g))
+
+
+def write_mod_vcf(path, chrom, lines, contig_len, gt=None):
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.2\n##contig=<ID=%s,length=%d>\n##INFO=<ID=RS,Number=1,Type=String,Description=\"\">\n" % (chrom, contig_len))
+        f.write("##INFO=<ID=MR,Number=.,Type=String,Description=\"\">\n##INFO=<ID=NR,Number=.,Type=String,Description=\"\">\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"\">\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n")
+        for i, (q, rev, reads) in enumerate(lines):
+            mr = ",".join("r%09d" % n for n, m in reads if m)
+            nr = ",".join("r%09d" % n for n, m in reads if not m)
+            g = "0/1" if gt is None else gt[i]
+            f.write("%s\t%d\t.\t%s\t<MOD>\t.\tPASS\tRS=%s;MR=%s;NR=%s;\tGT:MD:UD\t%s:%d:%d\n"
+                    % (chrom, q + 1, "G" if rev else "C", "N" if rev else "P", mr, nr, g, sum(1 for _, m in reads if m), sum(1 for _, m in reads if not m)))

@@ -85,6 +85,7 @@ struct synth_params {
     uint64_t read_seed;       // 0 = derive reads from `seed`; otherwise same genome/variants, different reads (tumor/normal pairs)
     double somatic_every;     // mean spacing of somatic SNVs (0 = none); they exist only in tumor-clone molecules
     double tumor_purity;      // fraction of molecules drawn from the tumor clone (carry the somatic SNVs of their haplotype)
+    double sv_every;          // mean spacing of heterozygous structural variants (0 = none): insertions / deletions of 50..800 bp on one haplotype
 };
 
 struct Synth {
@@ -96,6 +97,8 @@ struct Synth {
     std::vector<uint8_t> vhap;   // haplotype (0/1) that carries ALT
     // somatic SNVs (tumor clone only)
     std::vector<int32_t> spos; std::vector<char> sref, salt; std::vector<uint8_t> shap;
+    // structural variants: anchor base (0-based; VCF POS = anchor + 1), signed length (+ insertion, - deletion), haplotype that carries it
+    std::vector<int32_t> xpos, xlen; std::vector<uint8_t> xhap;
     // reads SoA
     std::vector<int32_t> ref_start, l_qseq;
     std::vector<uint16_t> flag;
@@ -129,6 +132,7 @@ static void simulate(const Synth &S, Rng &g, int hap, bool clone, int64_t start,
     const synth_params &P = S.p;
     size_t vi = std::lower_bound(S.vpos.begin(), S.vpos.end(), (int32_t)start) - S.vpos.begin();
     size_t si = std::lower_bound(S.spos.begin(), S.spos.end(), (int32_t)start) - S.spos.begin();
+    size_t xi = std::lower_bound(S.xpos.begin(), S.xpos.end(), (int32_t)start) - S.xpos.begin();
     int64_t end = std::min<int64_t>(start + span, P.contig_len);
     auto put = [&](char b, int64_t r) {
         q.push_back(b);
@@ -158,6 +162,15 @@ static void simulate(const Synth &S, Rng &g, int hap, bool clone, int64_t start,
         push_op(cig, 0, 1); put(b, p); ++p;
         if (insn) { push_op(cig, 1, insn); for (char c : insb) put(c, -1); }
         if (skip) { int k = (int)std::min<int64_t>(skip, end - p); push_op(cig, 2, k); p += k; }
+        while (xi < S.xpos.size() && S.xpos[xi] < p - 1) ++xi;
+        if (xi < S.xpos.size() && S.xpos[xi] == p - 1 && S.xhap[xi] == hap && !edge) {
+            // the molecule carries the SV: usually at its length (a caller's SVLEN is a consensus, reads scatter by a few percent), sometimes far
+            // enough off that get_snp's |region - oplen| / region < threshold test fails, sometimes not at all
+            const double u = g.uni(); const int L0 = std::abs(S.xlen[xi]);
+            int k = u < 0.8 ? (int)(L0 * (0.98 + 0.04 * g.uni())) : (u < 0.9 ? (int)(L0 * (g.uni() < 0.5 ? 0.8 : 1.25)) : 0);
+            if (k > 0 && S.xlen[xi] > 0) { push_op(cig, 1, k); for (int i = 0; i < k; ++i) put(kBases[g.below(4)], -1); }
+            else if (k > 0) { k = (int)std::min<int64_t>(k, end - 8 - p); if (k > 0) { push_op(cig, 2, k); p += k; } }
+        }
         if (!edge && p < end - 8) {
             double u = g.uni();
             if (u < P.ins_rate) { int k = g.geometric(0.6); push_op(cig, 1, k); for (int i = 0; i < k; ++i) put(kBases[g.below(4)], -1); }
@@ -277,6 +290,19 @@ Synth *synth_create(const synth_params *pp) {
             S->spos.push_back((int32_t)p); S->sref.push_back(r); S->salt.push_back(a); S->shap.push_back((uint8_t)gs.below(2));
         }
     }
+    // ---- structural variants: well away from the small variants and from each other
+    if (P.sv_every > 0) {
+        Rng gx(P.seed * 131 + 17);
+        int64_t last = 0;
+        for (double x = 2000 + (-std::log(1 - gx.uni())) * P.sv_every; x < L - 3000; x += 1500 + (-std::log(1 - gx.uni())) * P.sv_every) {
+            int64_t p = (int64_t)x; if (p < last + 1500) continue;
+            auto it = std::lower_bound(S->vpos.begin(), S->vpos.end(), (int32_t)p - 30);
+            if (it != S->vpos.end() && *it <= p + 30) continue;
+            const int len = 50 + (int)gx.below(750);
+            S->xpos.push_back((int32_t)p); S->xlen.push_back(gx.uni() < 0.5 ? len : -len); S->xhap.push_back((uint8_t)gx.below(2));
+            last = p + len;
+        }
+    }
     // ---- reads (own seed when read_seed != 0: tumor / normal samples of one genome)
     if (P.read_seed) g = Rng(P.read_seed * 0x9E3779B97F4A7C15ull + 999);
     const uint64_t rseed = P.read_seed ? P.read_seed : P.seed;
@@ -383,6 +409,10 @@ void synth_destroy(Synth *S) { delete S; }
 int64_t synth_n_reads(Synth *S) { return (int64_t)S->ref_start.size(); }
 int64_t synth_n_variants(Synth *S) { return (int64_t)S->vpos.size(); }
 int64_t synth_n_somatic(Synth *S) { return (int64_t)S->spos.size(); }
+int64_t synth_n_sv(Synth *S) { return (int64_t)S->xpos.size(); }
+const int32_t *synth_sv_pos(Synth *S) { return S->xpos.data(); }
+const int32_t *synth_sv_len(Synth *S) { return S->xlen.data(); }
+const uint8_t *synth_sv_hap(Synth *S) { return S->xhap.data(); }
 const int32_t *synth_som_pos(Synth *S) { return S->spos.data(); }
 const char *synth_som_ref(Synth *S) { return S->sref.data(); }
 const char *synth_som_alt(Synth *S) { return S->salt.data(); }

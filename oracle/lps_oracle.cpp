@@ -11,6 +11,7 @@
 // Every function cites the reference lines (relative to /root/reference/) whose behaviour it restates.
 // It is a restatement on index space (variant index instead of std::map<int,...> position keys), not a copy.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -133,6 +134,107 @@ bool extract_read(const Table &T, const lps_read_batch &b, int64_t r, std::vecto
         else return false;                                                               // :1625-1628
     }
     return true;
+}
+
+// SV / MOD rows next to the SNP table, as BamParser holds them (src/phase/ParsingBam.cpp:1207-1235): SV_map[chr] = (start, svlen) pairs in
+// start order, currentMod = map<pos, map<read name, RefAlt>>.  Index space: sv[k] / mod[k] are rows of lps_extra_variants; u_* give the row's
+// index in the position-sorted union of all three tables (what the graph stages run on).
+struct Extras {
+    const lps_extra_variants *x = nullptr;
+    std::vector<int32_t> u_of_snp, u_of_sv, u_of_mod, snp_of_u, upos;
+};
+
+// src/phase/ParsingBam.cpp:1303-1634 get_snp WITH the SV (:1397-1434) and MOD (:1373-1395) branches: the reference's three-cursor walk, cursor
+// for cursor.  Emits unified indices; quality -1 = SV, -2 / -3 = MOD on the forward / reverse strand.
+// Returns 0 ok, 1 unsupported CIGAR op (exit(1) in the reference), 2 the reference's loop would never end (two of the three cursors stand on
+// the same position: none of its three branches takes the row).
+int extract_read_x(const Table &T, const Extras &E, const lps_read_batch &b, int64_t r, std::vector<Obs> &out,
+                   std::vector<ClipEvent> &clips, int *ub_hazard) {
+    const lps_variant_table &t = *T.t; const lps_extra_variants &x = *E.x;
+    out.clear();
+    const uint32_t *cig = b.cigar + b.cigar_off[r];
+    const int n_cig = (int)(b.cigar_off[r + 1] - b.cigar_off[r]);
+    const uint8_t *seq = b.seq + b.seq_off[r];
+    const uint8_t *qual = b.qual + b.qual_off[r];
+    const int64_t l_qseq = b.l_qseq[r];
+    const bool rev = (b.flag[r] & 0x10) != 0;
+    int64_t ref_pos = b.ref_start[r], query_pos = 0;
+    const int64_t nV = t.n, nS = x.n_sv, nM = x.n_mod;
+    // :1318-1327 the three "first" cursors: alignments arrive coordinate-sorted, so each is a lower bound.  The SV cursor compares the 1-based
+    // VCF start (SV_map holds `start`, :1014,1228) with the 0-based alignment start.
+    int64_t cur = std::lower_bound(t.pos, t.pos + nV, (int32_t)ref_pos) - t.pos;
+    int64_t cs = 0; while (cs < nS && (int64_t)x.sv_pos[cs] + 1 < ref_pos) ++cs;
+    int64_t cm = std::lower_bound(x.mod_pos, x.mod_pos + nM, (int32_t)ref_pos) - x.mod_pos;
+    // what `(*iter).first` reads at end(): for the two std::map cursors libstdc++ keeps _M_node_count right behind the header node, i.e. the
+    // number of entries (UB, but stable with the reference's toolchain); every use of the SV value at end() is guarded.
+    auto vpos = [&](int64_t i) -> int64_t { return i < nV ? t.pos[i] : nV; };
+    auto mpos = [&](int64_t i) -> int64_t { return i < nM ? x.mod_pos[i] : nM; };
+    for (int i = 0; i < n_cig; ++i) {
+        const int op = cig[i] & 15; const int64_t len = cig[i] >> 4;
+        int64_t modPos = mpos(cm), svPos = cs < nS ? x.sv_pos[cs] : 0, variantPos = vpos(cur);                  // :1351-1358
+        while (cur < nV && variantPos < ref_pos) { ++cur; variantPos = vpos(cur); }                             // :1361-1364
+        while ((cm < nM && modPos < ref_pos + len) || (cs < nS && svPos < ref_pos + len) || (cur < nV && variantPos < ref_pos + len)) {
+            if ((cur == nV || modPos < variantPos) && (cs == nS || modPos < svPos) && cm < nM) {                // :1373-1395 MOD row
+                const uint32_t *names = x.mod_name + x.mod_off[cm], *ne = x.mod_name + x.mod_off[cm + 1];
+                const uint32_t *it = std::lower_bound(names, ne, b.name_id[r]);
+                if (cur == nV && ub_hazard) (*ub_hazard)++;                                                      // compares with end()'s garbage
+                if (it != ne && *it == b.name_id[r] && modPos < variantPos) {
+                    const uint8_t f = x.mod_flag[x.mod_off[cm] + (it - names)];
+                    if (((f >> 1) & 1) == (rev ? 1 : 0)) out.push_back({E.u_of_mod[cm], (f & 1) ? 0 : 1, rev ? -3 : -2});
+                }
+                ++cm; modPos = mpos(cm);
+            } else if ((cur == nV || svPos < variantPos) && (cm == nM || svPos < modPos) && cs < nS) {          // :1397-1434 SV row
+                int allele = 0;
+                const int64_t sv_start = (int64_t)x.sv_pos[cs] + 1, sv_end = sv_start + std::abs((int64_t)x.sv_len[cs]);
+                const double sv_region = (double)(sv_end - sv_start + 1);
+                for (int j = std::max(i - x.sv_window, 0); j < std::min(i + x.sv_window, n_cig); ++j) {
+                    const int o2 = cig[j] & 15; const int l2 = (int)(cig[j] >> 4);
+                    if ((o2 == 1 || o2 == 2) && std::abs(sv_region - l2) / std::abs(sv_region) < x.sv_threshold) { allele = 1; break; }
+                }
+                out.push_back({E.u_of_sv[cs], allele, -1});
+                ++cs; svPos = cs < nS ? x.sv_pos[cs] : 0;
+            } else if ((cs == nS || variantPos < svPos) && (cm == nM || variantPos < modPos) && cur < nV) {     // :1437-1522 SNP / indel row
+                if (!(op == 0 || op == 7 || op == 8)) break;
+                const int64_t vp = variantPos, off = vp - ref_pos;
+                if (query_pos + off + 1 > l_qseq) { out.clear(); return 0; }
+                int allele = -1, q = 0;
+                const int rl = t.ref_len[cur], al = t.alt_len[cur];
+                if (rl == 1 && al == 1) {
+                    char base = seq_base(seq, query_pos + off);
+                    if (base == (char)t.ref0[cur]) allele = 0; else if (base == (char)t.alt0[cur]) allele = 1;
+                    q = qual[query_pos + off];
+                }
+                if (rl == 1 && al != 1 && i + 1 < n_cig) { allele = (ref_pos + len - 1 == vp && (cig[i + 1] & 15) == 1) ? 1 : 0; q = T.danger[cur] ? -5 : -4; }
+                if (rl != 1 && al == 1 && i + 1 < n_cig) { allele = (ref_pos + len - 1 == vp && (cig[i + 1] & 15) == 2) ? 1 : 0; q = T.danger[cur] ? -5 : -4; }
+                if (allele != -1) out.push_back({E.u_of_snp[cur], allele, q});
+                ++cur; variantPos = vpos(cur);
+            } else return 2;
+        }
+        if (op == 0 || op == 7 || op == 8) { query_pos += len; ref_pos += len; }
+        else if (op == 1) query_pos += len;
+        else if (op == 2) {                                                                                       // :1539-1607, as in extract_read
+            if (cur < nV && !(ref_pos + len + 1 == t.pos[cur]) && t.pos[cur] >= ref_pos && t.pos[cur] < ref_pos + len) {
+                if (homopolymer_length(t.pos[cur], T.ref, T.ref_len) >= 3) {
+                    if (query_pos + 1 > l_qseq) { out.clear(); return 0; }
+                    const int rl = t.ref_len[cur], al = t.alt_len[cur];
+                    int allele = -1, q = 0;
+                    if (rl == 1 && al == 1) {
+                        char base = seq_base(seq, query_pos);
+                        if (base == (char)t.ref0[cur]) allele = 0; else if (base == (char)t.alt0[cur]) allele = 1;
+                        q = qual[query_pos];
+                    } else if (rl != 1 && al == 1) { allele = 1; q = -4; }
+                    if (allele != -1) { out.push_back({E.u_of_snp[cur], allele, q}); ++cur; }
+                }
+            }
+            ref_pos += len;
+        }
+        else if (op == 3) ref_pos += len;
+        else if (op == 4) { query_pos += len; if (len > 5) clips.push_back({(int32_t)ref_pos, (uint8_t)(i == 0 ? 0 : 1)}); }
+        else if (op == 5) { if (len > 5) clips.push_back({(int32_t)ref_pos, (uint8_t)(i == 0 ? 0 : 1)}); }
+        else if (op == 6) {}
+        else return 1;
+    }
+    return 0;
 }
 
 // src/phase/ParsingBam.cpp:837-912 filterSNP (variant-table half): which variants are erased
@@ -341,14 +443,37 @@ typedef struct oracle_dumps {
     int64_t n_pairs;
 } oracle_dumps;
 
-int oracle_phase(const lps_params *Pp, const lps_variant_table *tp, const char *ref, int64_t ref_len_in,
-                 const lps_read_batch *bp, lps_phase_result *out, oracle_dumps *D) {
-    const lps_params &P = *Pp; const lps_variant_table &t = *tp; const lps_read_batch &b = *bp;
+// xp != NULL: SV / MOD rows are co-phased (`--sv-file` / `--mod-file`).  From the extraction on everything runs on the position-sorted UNION of
+// the three tables (the reference's maps are keyed by position and never ask which file a row came from); the dumps then hold union indices and
+// out_sv / out_mod receive the rows' results.  Returns -2 bad CIGAR op, -3 the reference's extraction loop would not terminate.
+int oracle_phase_x(const lps_params *Pp, const lps_variant_table *tp, const lps_extra_variants *xp, const char *ref, int64_t ref_len_in,
+                   const lps_read_batch *bp, lps_phase_result *out, lps_phase_result *out_sv, lps_phase_result *out_mod, oracle_dumps *D) {
+    const lps_params &P = *Pp; const lps_variant_table &t0 = *tp; const lps_read_batch &b = *bp;
     for (int64_t i = 0; i < out->n; ++i) { out->phase_set[i] = 0; out->gt[i] = 0; }
+    if (out_sv) for (int64_t i = 0; i < out_sv->n; ++i) { out_sv->phase_set[i] = 0; out_sv->gt[i] = 0; }
+    if (out_mod) for (int64_t i = 0; i < out_mod->n; ++i) { out_mod->phase_set[i] = 0; out_mod->gt[i] = 0; }
     if (D) { D->n_obs = 0; D->n_clips = 0; D->n_nodes = 0; D->n_cnv = 0; D->ub_hazard = 0; D->n_pairs = 0; }
-    if (t.n == 0) return 0;
-    Table T; T.t = &t; T.ref = ref;
-    const int32_t last_pos = t.pos[t.n - 1];
+    if (t0.n == 0) return 0;                                        // BamParser exits on an empty SNP map (:1218-1221); PhasingProcess skips the contig (:121)
+    Table T; T.t = &t0; T.ref = ref;
+    const int32_t last_pos = t0.pos[t0.n - 1];
+    Extras E;
+    if (xp && (xp->n_sv > 0 || xp->n_mod > 0)) {
+        E.x = xp;
+        const int64_t nU = t0.n + xp->n_sv + xp->n_mod;
+        E.u_of_snp.resize(t0.n); E.u_of_sv.resize(xp->n_sv); E.u_of_mod.resize(xp->n_mod); E.upos.reserve(nU); E.snp_of_u.reserve(nU);
+        int64_t a = 0, s2 = 0, m = 0;
+        while (a < t0.n || s2 < xp->n_sv || m < xp->n_mod) {
+            const int64_t pa = a < t0.n ? t0.pos[a] : INT64_MAX, ps = s2 < xp->n_sv ? xp->sv_pos[s2] : INT64_MAX, pm = m < xp->n_mod ? xp->mod_pos[m] : INT64_MAX;
+            const int32_t u = (int32_t)E.upos.size();
+            if (pa <= ps && pa <= pm) { E.u_of_snp[a] = u; E.snp_of_u.push_back((int32_t)a); E.upos.push_back((int32_t)pa); ++a; }
+            else if (ps <= pm) { E.u_of_sv[s2] = u; E.snp_of_u.push_back(-1); E.upos.push_back((int32_t)ps); ++s2; }
+            else { E.u_of_mod[m] = u; E.snp_of_u.push_back(-1); E.upos.push_back((int32_t)pm); ++m; }
+        }
+    }
+    // the table the graph stages see: positions of the union (the other columns are not read after the extraction)
+    lps_variant_table tu = t0;
+    if (E.x) { tu.n = (int64_t)E.upos.size(); tu.pos = E.upos.data(); }
+    const lps_variant_table &t = tu;
     T.ref_len = std::min<int64_t>(ref_len_in, (int64_t)last_pos + 6);   // ParsingBam.cpp:47 faidx_fetch_seq(0,last+5)
     mark_danger(T);
     const int A = P.connect_adjacent;
@@ -359,17 +484,16 @@ int oracle_phase(const lps_params *Pp, const lps_variant_table *tp, const char *
         if (b.ref_start[r] >= last_pos) continue;                  // region "chr:1-<lastSNPPos>" (:1273)
         const int fl = b.flag[r];
         if (b.mapq[r] < P.mapping_quality || (fl & 0x4) || (fl & 0x100) || (fl & 0x400)) continue;   // :1282-1291
-        size_t nclip0 = clips.size();
-        if (!extract_read(T, b, r, tmp, clips)) return -2;
-        (void)nclip0;
+        if (E.x) { const int rc = extract_read_x(T, E, b, r, tmp, clips, D ? &D->ub_hazard : nullptr); if (rc) return rc == 1 ? -2 : -3; }
+        else if (!extract_read(T, b, r, tmp, clips)) return -2;
         if (!tmp.empty()) { Aln a; a.read = r; a.obs = tmp; alns.push_back(std::move(a)); }
     }
     // ---- a5: filterSNP (ONT only)  (PhasingProcess.cpp:138-140)
-    std::vector<uint8_t> erased(t.n, 0);
+    std::vector<uint8_t> erased(t0.n, 0);
     if (P.is_ont) {
         filter_snp(T, erased);
         for (auto &a : alns) {
-            size_t k = 0; for (auto &o : a.obs) if (!erased[o.var]) a.obs[k++] = o;
+            size_t k = 0; for (auto &o : a.obs) { const int sv = E.x ? E.snp_of_u[o.var] : o.var; if (sv < 0 || !erased[sv]) a.obs[k++] = o; }
             if (k == 0) a.emptied_by_filter = true;
             a.obs.resize(k);
         }
@@ -403,11 +527,13 @@ int oracle_phase(const lps_params *Pp, const lps_variant_table *tp, const char *
     }
     cnv_filter(t, cnv, alns);
     // ---- a10: type tagging + node set  (PhasingGraph.cpp:793-846)
-    std::vector<int8_t> vtype(t.n, -1);                            // 0 SNP, 3 indel, 4 danger indel (last writer wins)
+    std::vector<int8_t> vtype(t.n, -1);                            // 0 SNP, 1 SV, 2 MOD, 3 indel, 4 danger indel (last writer wins)
     std::vector<uint8_t> is_node(t.n, 0);
     std::map<uint32_t, std::vector<SortKey>> merged;               // keyed by name order
     for (auto &a : alns) for (auto o : a.obs) {
-        if (o.quality == -4) { vtype[o.var] = 3; o.quality = 60; }
+        if (o.quality == -2 || o.quality == -3) { vtype[o.var] = 2; o.quality = 60; }                       // :803-806
+        else if (o.quality == -1) { vtype[o.var] = 1; o.quality = (o.allele == 1) ? 60 : 30; }                // :808-817
+        else if (o.quality == -4) { vtype[o.var] = 3; o.quality = 60; }
         else if (o.quality == -5) { vtype[o.var] = 4; o.quality = 60; }
         else vtype[o.var] = 0;
         merged[b.name_id[a.read]].push_back({t.pos[o.var], o.var, o.allele, o.quality});
@@ -466,7 +592,11 @@ int oracle_phase(const lps_params *Pp, const lps_variant_table *tp, const char *
             int dir = -1;
             double esr = (double)std::min(rr + aa, ar + ra) / (double)std::max(rr + aa, ar + ra);
             if (rr + aa > ra + ar) dir = 1; else if (rr + aa < ra + ar) dir = 2;
-            double thr = P.edge_threshold;     // SNP<->MOD special threshold (:197-202) needs MOD input: out of scope
+            double thr = P.edge_threshold;
+            {   // :197-202 an edge between a SNP and a MOD row: 0.3, and nothing passes when the four cells sum to less than one read
+                const int ti = vtype[nodes[i]], tj = vtype[nodes[j]];
+                if ((ti == 0 && tj == 2) || (ti == 2 && tj == 0)) { thr = 0.3; if ((rr + ra + ar + aa) < 1) thr = -1; }
+            }
             if (esr > thr) dir = -1;
             // the reference's `else if` hangs off `if(debug)` (:210-217, debug is always false): independent of esr>thr
             if ((esr <= 0.1 && (rr + aa + ra + ar) >= 1) || ((rr + aa) < 1 && (ra + ar) >= 1) || ((rr + aa) >= 1 && (ra + ar) < 1)) vt.weight = 20;
@@ -519,9 +649,23 @@ int oracle_phase(const lps_params *Pp, const lps_variant_table *tp, const char *
         double conf = std::max(r1, r2) / (r1 + r2);
         int g = -1;
         if (conf > P.snp_confidence) { if (r1 > r2) g = 0; else if (r1 < r2) g = 1; }
-        if (g != -1 && ps[i] != 0) { out->phase_set[nodes[i]] = ps[i]; out->gt[nodes[i]] = (uint8_t)g; }
+        if (g != -1 && ps[i] != 0) {
+            const int32_t u = nodes[i];
+            if (!E.x) { out->phase_set[u] = ps[i]; out->gt[u] = (uint8_t)g; }
+            else if (E.snp_of_u[u] >= 0) { out->phase_set[E.snp_of_u[u]] = ps[i]; out->gt[E.snp_of_u[u]] = (uint8_t)g; }
+            else {
+                const auto sv = std::lower_bound(E.u_of_sv.begin(), E.u_of_sv.end(), u);
+                if (sv != E.u_of_sv.end() && *sv == u) { if (out_sv) { out_sv->phase_set[sv - E.u_of_sv.begin()] = ps[i]; out_sv->gt[sv - E.u_of_sv.begin()] = (uint8_t)g; } }
+                else { const auto md = std::lower_bound(E.u_of_mod.begin(), E.u_of_mod.end(), u); if (out_mod) { out_mod->phase_set[md - E.u_of_mod.begin()] = ps[i]; out_mod->gt[md - E.u_of_mod.begin()] = (uint8_t)g; } }
+            }
+        }
     }
     return 0;
+}
+
+int oracle_phase(const lps_params *Pp, const lps_variant_table *tp, const char *ref, int64_t ref_len_in,
+                 const lps_read_batch *bp, lps_phase_result *out, oracle_dumps *D) {
+    return oracle_phase_x(Pp, tp, nullptr, ref, ref_len_in, bp, out, nullptr, nullptr, D);
 }
 
 

@@ -37,6 +37,9 @@ def lib():
         _lib.oracle_phase.restype = C.c_int
         _lib.oracle_phase.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.c_void_p, C.c_int64,
                                       C.POINTER(abi.ReadBatch), C.POINTER(abi.PhaseResult), C.POINTER(Dumps)]
+        _lib.oracle_phase_x.restype = C.c_int
+        _lib.oracle_phase_x.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.POINTER(abi.ExtraVariantTable), C.c_void_p, C.c_int64,
+                                        C.POINTER(abi.ReadBatch), C.POINTER(abi.PhaseResult), C.POINTER(abi.PhaseResult), C.POINTER(abi.PhaseResult), C.POINTER(Dumps)]
         _lib.oracle_haplotag.restype = C.c_int
         _lib.oracle_haplotag.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.c_void_p, C.c_int64,
                                          C.POINTER(abi.ReadBatch), C.POINTER(abi.HaplotagResult)]
@@ -94,6 +97,24 @@ def phase(params, variants, ref, reads, dump=False, with_edges=True):
                                 C.byref(out.c), C.byref(d.c))
         assert rc == 0
     return out, d
+
+
+def phase_x(params, variants, extra, ref, reads, dump=False, with_edges=True):
+    """The CPU restatement with SV / MOD rows co-phased.  Returns (snp PhaseOut, sv PhaseOut, mod PhaseOut, PhaseDump|None); the dump holds
+    indices into the position-sorted union of the three tables."""
+    out, osv, omod = abi.PhaseOut(variants.n), abi.PhaseOut(extra.n_sv), abi.PhaseOut(extra.n_mod)
+    n_u = variants.n + extra.n_sv + extra.n_mod
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    d = PhaseDump(reads.n_reads, n_u, params.connect_adjacent, with_edges=with_edges) if dump else None
+    for _ in range(2):
+        rc = lib().oracle_phase_x(C.byref(params), C.byref(variants.c), C.byref(extra.c), ref.ctypes.data, ref.size, C.byref(reads.c),
+                                  C.byref(out.c), C.byref(osv.c), C.byref(omod.c), C.byref(d.c) if d else None)
+        if rc != 0:
+            raise RuntimeError(f"oracle_phase_x rc={rc}")
+        if d is None or d.c.n_obs <= d.c.obs_capacity:
+            break
+        d = PhaseDump(reads.n_reads, n_u, params.connect_adjacent, obs_cap=int(d.c.n_obs) + 16, with_edges=with_edges)
+    return out, osv, omod, d
 
 
 def haplotag(params, variants, ref, reads):
