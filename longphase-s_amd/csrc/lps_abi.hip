@@ -11,6 +11,7 @@
 #include <thread>
 #include <chrono>
 #include <cmath>
+#include <climits>
 #include <cstring>
 
 #include "lps_graph.h"
@@ -37,6 +38,12 @@ struct lps_ctx {
     DevBuf<int32_t> v_pos; DevBuf<uint8_t> v_ref0, v_alt0, v_danger, v_hpoly, v_erased, v_hp1; DevBuf<uint16_t> v_rl, v_al;
     DevBuf<int32_t> v_ps, v_bucket; DevBuf<uint2> v_rec; bool has_hap = false;
     DevBuf<char> ref;
+    // SV / MOD rows (lps_set_extra_variants): merged by position; nG / g_vpos = size and positions of the table the stages after the extraction
+    // run on (the SNP table itself when there are no such rows, else the union of the three)
+    int nX = 0, nSV = 0, nMOD = 0, sv_window = 20; double sv_threshold = 0.1;
+    DevBuf<int32_t> x_pos, x_info, x_u, x_snp_u, u_pos; DevBuf<uint8_t> x_kind, x_mflag; DevBuf<uint32_t> x_moff, x_mname;
+    std::vector<int32_t> h_snp_u, h_sv_u, h_mod_u, h_res_ps_u; std::vector<uint8_t> h_res_gt_u;
+    int nG = 0; const int32_t *g_vpos = nullptr;
     // reads
     int nR = 0; uint64_t n_cig = 0, n_seq = 0, n_qual = 0;
     DevBuf<int32_t> r_start, r_lq; DevBuf<uint16_t> r_flag; DevBuf<uint8_t> r_mapq; DevBuf<uint32_t> r_name;
@@ -147,7 +154,7 @@ int lps_debug_std_sort_gpu(int device, int32_t *keys, uint8_t *payload, const in
 int lps_struct_size(int which) {
     switch (which) {
         case 0: return (int)sizeof(lps_params); case 1: return (int)sizeof(lps_variant_table); case 2: return (int)sizeof(lps_read_batch);
-        case 3: return (int)sizeof(lps_phase_result); case 4: return (int)sizeof(lps_haplotag_result); case 5: return (int)sizeof(lps_timings); case 6: return (int)sizeof(lps_somatic_tag_result); case 7: return (int)sizeof(lps_site_counters); case 8: return (int)sizeof(lps_tumor_extract_result);
+        case 3: return (int)sizeof(lps_phase_result); case 4: return (int)sizeof(lps_haplotag_result); case 5: return (int)sizeof(lps_timings); case 6: return (int)sizeof(lps_somatic_tag_result); case 7: return (int)sizeof(lps_site_counters); case 8: return (int)sizeof(lps_tumor_extract_result); case 9: return (int)sizeof(lps_extra_variants);
     }
     return -1;
 }
@@ -213,6 +220,7 @@ int lps_begin_chromosome(lps_ctx *c) {
     if (!c) return -1;
     c->nV = 0; c->last_pos = -1; c->ref_len = c->ref_len_eff = 0; c->nR = 0; c->n_cig = c->n_seq = c->n_qual = 0; c->n_blob = 0; c->read_mode = 0; c->cur_first = -1; c->cur_count = 0;
     c->phase_valid = false; c->has_hap = false; c->h_vpos.clear(); c->name_max = 0;
+    c->nX = c->nSV = c->nMOD = 0; c->h_snp_u.clear(); c->h_sv_u.clear(); c->h_mod_u.clear();
     return 0;
 }
 
@@ -235,7 +243,67 @@ int lps_set_variants(lps_ctx *c, const lps_variant_table *t) {
         if (c->has_tkind) { upload(c, c->v_role, t->somatic_role, t->n); upload(c, c->v_tkind, t->tumor_kind, t->n); }
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->phase_valid = false;
+        c->nX = c->nSV = c->nMOD = 0; c->h_snp_u.clear(); c->h_sv_u.clear(); c->h_mod_u.clear();      // a new SNP table: extra rows must be set again
     } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+// SV_map / currentMod of BamParser (src/phase/ParsingBam.cpp:1207-1235) as one position-sorted list next to the SNP table
+int lps_set_extra_variants(lps_ctx *c, const lps_extra_variants *x) {
+    if (!c) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        c->nX = c->nSV = c->nMOD = 0; c->h_snp_u.clear(); c->h_sv_u.clear(); c->h_mod_u.clear(); c->phase_valid = false;
+        if (!x || (x->n_sv <= 0 && x->n_mod <= 0)) return 0;
+        if (c->nV == 0) return fail(c, "lps_set_variants must be called before lps_set_extra_variants");
+        const int64_t nS = std::max<int64_t>(x->n_sv, 0), nM = std::max<int64_t>(x->n_mod, 0);
+        if ((int64_t)c->nV + nS + nM > 0x3fffff) return fail(c, "SNP + SV + MOD rows exceed 2^22 per chromosome");
+        if (x->sv_window < 0 || !(x->sv_threshold >= 0 && x->sv_threshold <= 1)) return fail(c, "invalid svWindow / svThreshold");     // Phasing.cpp:304-318
+        for (int64_t i = 1; i < nS; ++i) if (x->sv_pos[i] <= x->sv_pos[i - 1]) return fail(c, "SV positions must be strictly increasing");
+        for (int64_t i = 1; i < nM; ++i) if (x->mod_pos[i] <= x->mod_pos[i - 1]) return fail(c, "MOD positions must be strictly increasing");
+        if (nM && x->mod_off[0] != 0) return fail(c, "mod_off[0] must be 0");
+        if (nM && x->mod_off[nM] > 0xffffffffull) return fail(c, "more than 2^32 MOD read entries");
+        for (int64_t m = 0; m < nM; ++m) {
+            if (x->mod_off[m + 1] < x->mod_off[m]) return fail(c, "mod_off must be non-decreasing");
+            for (uint64_t k = x->mod_off[m] + 1; k < x->mod_off[m + 1]; ++k) if (x->mod_name[k] <= x->mod_name[k - 1]) return fail(c, "mod_name must be strictly increasing inside a row");
+        }
+        // merge the three position lists; a position in two of them would make get_snp's inner loop spin forever (none of its three branches
+        // serves a row that ties with another cursor, ParsingBam.cpp:1373,1397,1437)
+        const size_t nX = (size_t)(nS + nM), nU = nX + (size_t)c->nV;
+        std::vector<int32_t> xpos(nX), xinfo(nX), xu(nX), upos(nU); std::vector<uint8_t> xkind(nX);
+        c->h_snp_u.resize(c->nV); c->h_sv_u.resize(nS); c->h_mod_u.resize(nM);
+        size_t a = 0, sv = 0, md = 0, k = 0, u = 0;
+        while (a < (size_t)c->nV || sv < (size_t)nS || md < (size_t)nM) {
+            const long long pa = a < (size_t)c->nV ? c->h_vpos[a] : LLONG_MAX, ps = sv < (size_t)nS ? x->sv_pos[sv] : LLONG_MAX, pm = md < (size_t)nM ? x->mod_pos[md] : LLONG_MAX;
+            const long long lo = std::min(pa, std::min(ps, pm));
+            if ((pa == lo) + (ps == lo) + (pm == lo) > 1) return fail(c, "position " + std::to_string(lo) + " occurs in more than one of the SNP / SV / MOD tables: the reference does not terminate on such input");
+            upos[u] = (int32_t)lo;
+            if (pa == lo) c->h_snp_u[a++] = (int32_t)u;
+            else if (ps == lo) { xpos[k] = (int32_t)lo; xinfo[k] = x->sv_len[sv]; xkind[k] = 1; xu[k] = (int32_t)u; c->h_sv_u[sv++] = (int32_t)u; ++k; }
+            else { xpos[k] = (int32_t)lo; xinfo[k] = (int32_t)md; xkind[k] = 2; xu[k] = (int32_t)u; c->h_mod_u[md++] = (int32_t)u; ++k; }
+            ++u;
+        }
+        std::vector<uint32_t> moff(nM + 1, 0u);
+        for (int64_t m = 0; m <= nM && nM; ++m) moff[m] = (uint32_t)x->mod_off[m];
+        upload(c, c->x_pos, xpos.data(), nX); upload(c, c->x_info, xinfo.data(), nX); upload(c, c->x_kind, xkind.data(), nX); upload(c, c->x_u, xu.data(), nX);
+        upload(c, c->x_snp_u, c->h_snp_u.data(), (size_t)c->nV); upload(c, c->u_pos, upos.data(), nU);
+        upload(c, c->x_moff, moff.data(), (size_t)nM + 1);
+        const size_t ne = nM ? (size_t)x->mod_off[nM] : 0;
+        c->x_mname.reserve(ne + 1); c->x_mflag.reserve(ne + 1);
+        if (ne) { upload(c, c->x_mname, x->mod_name, ne); upload(c, c->x_mflag, x->mod_flag, ne); }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->nX = (int)nX; c->nSV = (int)nS; c->nMOD = (int)nM; c->sv_window = x->sv_window; c->sv_threshold = x->sv_threshold;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_get_extra_result(lps_ctx *c, lps_phase_result *sv, lps_phase_result *mod) {
+    if (!c) return -1;
+    if (!c->phase_valid) return fail(c, "no phase result");
+    if ((sv && sv->n != c->nSV) || (mod && mod->n != c->nMOD)) return fail(c, "lps_get_extra_result: n must equal the table sizes given to lps_set_extra_variants");
+    const bool have = c->nX > 0 && c->h_res_ps_u.size() == (size_t)c->nG;       // nothing ran (no reads): every row unphased
+    if (sv) for (int i = 0; i < c->nSV; ++i) { sv->phase_set[i] = have ? c->h_res_ps_u[c->h_sv_u[i]] : 0; sv->gt[i] = have ? c->h_res_gt_u[c->h_sv_u[i]] : 0; }
+    if (mod) for (int i = 0; i < c->nMOD; ++i) { mod->phase_set[i] = have ? c->h_res_ps_u[c->h_mod_u[i]] : 0; mod->gt[i] = have ? c->h_res_gt_u[c->h_mod_u[i]] : 0; }
     return 0;
 }
 
@@ -699,7 +767,7 @@ static ReadView read_view(lps_ctx *c) {
 // Stages after the overlap filter and the clip statistics.  with_cnv = false is the first, speculative run (no CNV interval assumed); with_cnv =
 // true runs them again with the CNV mismatch filter after clearing what they accumulate (tail of the zero pool, late counters).
 static int run_late(lps_ctx *c, bool with_cnv) {
-    hipStream_t s = c->stream; const lps_params &P = c->P; const int nR = c->nR, nV = c->nV, A = P.connect_adjacent;
+    hipStream_t s = c->stream; const lps_params &P = c->P; const int nR = c->nR, nV = c->nG, A = P.connect_adjacent;   // nV here: rows of the table the graph runs on (SNP rows, or the union with SV / MOD rows)
     {
         if (with_cnv) {
             HIP_TRY(hipMemsetAsync(c->zpool.p + c->z_late_off, 0, c->z_late_bytes, s));
@@ -723,7 +791,7 @@ static int run_late(lps_ctx *c, bool with_cnv) {
             c->cnv_flag.reserve(nR + 1); c->cnv_idx.reserve(nR + 1); c->cnv_list.reserve(nR + 1); c->cnv_nlist.reserve(4);
             c->cnv_fn.reserve(nR + 1); c->cnv_pre.reserve(nR + 1);
             CnvScratch W{c->cnv_flag.p, c->cnv_idx.p, c->cnv_list.p, c->cnv_nlist.p, c->cnv_fn.p, c->cnv_pre.p};
-            launch_cnv_filter(c->d_cnt, nR, nV, c->rows.p, c->deleted.p, c->obs.p, c->v_pos.p, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, W, c->temp.p, c->temp_bytes, s);
+            launch_cnv_filter(c->d_cnt, nR, nV, c->rows.p, c->deleted.p, c->obs.p, c->g_vpos, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, W, c->temp.p, c->temp_bytes, s);
         }
         // ---- a10 nodes + graph observations
         mark(c, ST_NODES);
@@ -744,10 +812,10 @@ static int run_late(lps_ctx *c, bool with_cnv) {
         launch_edges(c->d_cnt, nV, c->node_off.p, c->node_end.p, c->nkeys.p, c->nvals.p, c->nkeys_s.p, c->nvals_s.p, c->mrow_off.p, c->mrow_cnt.p, c->m_bits, c->a_bits, c->g_pack.p, (uint32_t)c->late_cap_main, A, P.edge_weight, P.edge_threshold, c->ntype.p, c->edge.p, c->erec.p, c->node_pairs.p, s);
         // ---- a13 vote scan
         mark(c, ST_SCAN);
-        launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->v_pos.p, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2, c->hp.p, c->block.p, s);
+        launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->g_vpos, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2, c->hp.p, c->block.p, s);
         // ---- a14/a15 read correction + export
         mark(c, ST_CORR);
-        launch_correction(c->d_cnt, nR, nV, c->rows.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->v_pos.p, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, c->node_pairs.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
+        launch_correction(c->d_cnt, nR, nV, c->rows.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->g_vpos, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, c->node_pairs.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
         mark(c, ST_D2H);
         return 0;                                                          // counters + statistics leave with the result (enqueue_result_copy)
     }
@@ -756,6 +824,8 @@ static int run_late(lps_ctx *c, bool with_cnv) {
 static int run_phase(lps_ctx *c) {
     const lps_params &P = c->P; hipStream_t s = c->stream;
     const int nR = c->nR, nV = c->nV, A = P.connect_adjacent;
+    const int nG = c->nG = c->nV + c->nX;                                      // rows of the table the stages after the extraction run on
+    c->g_vpos = c->nX ? c->u_pos.p : c->v_pos.p;
     // ---- capacities
     if (c->obs_capacity == 0) c->obs_capacity = std::max<unsigned long long>(64 * 1024, (unsigned long long)nR * 64);
     for (int attempt = 0; attempt < 3; ++attempt) {
@@ -776,25 +846,25 @@ static int run_phase(lps_ctx *c) {
         c->name_keys.reserve(nR + 1); c->name_keys_s.reserve(nR + 1);
         c->head.reserve(nR + 1); c->gidx.reserve(nR + 1); c->gstart.reserve(nR + 2); c->read_group.reserve(nR + 1); c->stack.reserve(nR + 1);
         c->mrow_off.reserve(nR + 1); c->koff.reserve(nR + 1);
-        c->node_of.reserve(nV + 1); c->node_off.reserve(nV + 2); c->multi_list.reserve(nR + 1);
-        c->nodes.reserve(nV + 1); c->block.reserve(nV + 1);
-        c->ntype.reserve(nV + 1); c->hp.reserve(nV + 1);
-        c->erec.reserve((size_t)nV * A + 256);
-        c->hp_v.reserve(2 * ((size_t)nV + 64)); c->blk_v.reserve(2 * ((size_t)nV + 64)); c->seg_i32.reserve(4 * (size_t)scan_segments(nV) + 4); c->node_pairs.reserve(nV + 1); c->nstate.reserve(nV + 1);
-        c->st_b.reserve(scan_state_bytes(nV)); c->st_e.reserve(scan_state_bytes(nV)); c->edge.reserve((size_t)nV * A * 4 + 16);
+        c->node_of.reserve(nG + 1); c->node_off.reserve(nG + 2); c->multi_list.reserve(nR + 1);
+        c->nodes.reserve(nG + 1); c->block.reserve(nG + 1);
+        c->ntype.reserve(nG + 1); c->hp.reserve(nG + 1);
+        c->erec.reserve((size_t)nG * A + 256);
+        c->hp_v.reserve(2 * ((size_t)nG + 64)); c->blk_v.reserve(2 * ((size_t)nG + 64)); c->seg_i32.reserve(4 * (size_t)scan_segments(nG) + 4); c->node_pairs.reserve(nG + 1); c->nstate.reserve(nG + 1);
+        c->st_b.reserve(scan_state_bytes(nG)); c->st_e.reserve(scan_state_bytes(nG)); c->edge.reserve((size_t)nG * A * 4 + 16);
         // everything that has to start a run as zeros sits in ONE allocation cleared by one fill (a dozen separate fills cost ~4 us each)
         size_t zbytes = 0;
         auto zslot = [&](size_t bytes) { const size_t at = zbytes; zbytes += (bytes + 255) & ~(size_t)255; return at; };
         const size_t z_arena = zslot(LPS_ARENAS * 8 * sizeof(unsigned long long)), z_del = zslot((size_t)nR + 1), z_stats = zslot(4 * sizeof(unsigned)),
-                     z_ps = zslot(((size_t)nV + 1) * 4), z_gt = zslot((size_t)nV + 1), z_isn = zslot(((size_t)nV + 1) * 4), z_vtk = zslot(((size_t)nV + 1) * 4), z_mrc = zslot(((size_t)nR + 1) * 4),
-                     z_nend = zslot(((size_t)nV + 2) * 4), z_ncur = zslot(((size_t)nV + 2) * 4), z_bs = zslot(((size_t)nV + 1) * 4), z_c4 = zslot(((size_t)nV * 4 + 4) * 4);
+                     z_ps = zslot(((size_t)nG + 1) * 4), z_gt = zslot((size_t)nG + 1), z_isn = zslot(((size_t)nG + 1) * 4), z_vtk = zslot(((size_t)nG + 1) * 4), z_mrc = zslot(((size_t)nR + 1) * 4),
+                     z_nend = zslot(((size_t)nG + 2) * 4), z_ncur = zslot(((size_t)nG + 2) * 4), z_bs = zslot(((size_t)nG + 1) * 4), z_c4 = zslot(((size_t)nG * 4 + 4) * 4);
         c->zpool.reserve(zbytes);
         c->z_late_off = z_ps; c->z_late_bytes = zbytes - z_ps;       // what the stages after the overlap filter need zeroed (see run_late)
-        c->arena_ctr.carve(c->zpool.p + z_arena, LPS_ARENAS * 8); c->out_ps.carve(c->zpool.p + z_ps, (size_t)nV + 1); c->out_gt.carve(c->zpool.p + z_gt, (size_t)nV + 1);
-        c->deleted.carve(c->zpool.p + z_del, (size_t)nR + 1); c->clip_stats.carve(c->zpool.p + z_stats, 4); c->is_node.carve(c->zpool.p + z_isn, (size_t)nV + 1); c->vtype_key.carve(c->zpool.p + z_vtk, (size_t)nV + 1);
-        c->mrow_cnt.carve(c->zpool.p + z_mrc, (size_t)nR + 1); c->node_end.carve(c->zpool.p + z_nend, (size_t)nV + 2); c->node_cur.carve(c->zpool.p + z_ncur, (size_t)nV + 2);
-        c->bsize.carve(c->zpool.p + z_bs, (size_t)nV + 1); c->cnt4.carve(c->zpool.p + z_c4, (size_t)nV * 4 + 4);
-        const size_t need = GraphTemp::need((size_t)std::max<unsigned long long>(cap, (unsigned long long)std::max(nR, nV) + 1));
+        c->arena_ctr.carve(c->zpool.p + z_arena, LPS_ARENAS * 8); c->out_ps.carve(c->zpool.p + z_ps, (size_t)nG + 1); c->out_gt.carve(c->zpool.p + z_gt, (size_t)nG + 1);
+        c->deleted.carve(c->zpool.p + z_del, (size_t)nR + 1); c->clip_stats.carve(c->zpool.p + z_stats, 4); c->is_node.carve(c->zpool.p + z_isn, (size_t)nG + 1); c->vtype_key.carve(c->zpool.p + z_vtk, (size_t)nG + 1);
+        c->mrow_cnt.carve(c->zpool.p + z_mrc, (size_t)nR + 1); c->node_end.carve(c->zpool.p + z_nend, (size_t)nG + 2); c->node_cur.carve(c->zpool.p + z_ncur, (size_t)nG + 2);
+        c->bsize.carve(c->zpool.p + z_bs, (size_t)nG + 1); c->cnt4.carve(c->zpool.p + z_c4, (size_t)nG * 4 + 4);
+        const size_t need = GraphTemp::need((size_t)std::max<unsigned long long>(cap, (unsigned long long)std::max(nR, nG) + 1));
         if (need > c->temp_bytes) { c->temp.reserve(need); c->temp_bytes = need; }
 
         for (auto &u : c->ev_used) u = false;
@@ -812,6 +882,11 @@ static int run_phase(lps_ctx *c) {
         ClipView C{c->clip_ev.p, c->clip_stats.p, (unsigned)c->clip_capacity};            // clip_stats[0]: events appended, [1]: waves queued for k_extract_redo, [3]: chunks of the global hit list taken (zero pool)
         mark(c, ST_EXTRACT);
         launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, c->redo_list.p, c->clip_stats.p + 1, c->hit_ovf.p, c->clip_stats.p + 3, c->ovf_chunks, s);
+        // ---- SV / MOD rows: served against each alignment's CIGAR, merged into its row; every observation leaves in union indices
+        if (c->nX) {
+            ExtraView X{c->nX, c->x_pos.p, c->x_info.p, c->x_kind.p, c->x_u.p, c->x_snp_u.p, c->x_moff.p, c->x_mname.p, c->x_mflag.p, c->sv_window, c->sv_threshold};
+            launch_extra_merge(V, R, O, X, P.mapping_quality, c->d_cnt, s);
+        }
         // ---- name keys (needs only row_cnt) and clip keys; the counters (sizes of the sorts, errors) start their way to the host ...
         mark(c, ST_GROUPS);
         launch_name_keys(nR, c->r_name.p, c->rows.p, c->name_keys.p, c->d_cnt, c->arena_ctr.p, arena_size, s);
@@ -826,7 +901,7 @@ static int run_phase(lps_ctx *c) {
         sort_keys64_range(c->temp.p, c->temp_bytes, c->name_keys.p, c->name_keys_s.p, nR, 32, 32 + bits_for((unsigned long long)c->name_max + 2), s);
         launch_groups(c->name_keys_s.p, nR, c->d_cnt, c->head.p, c->gidx.p, c->gstart.p, c->read_group.p, c->temp.p, c->temp_bytes, s);
         mark(c, ST_OVERLAP);
-        launch_overlap_filter(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->rows.p, c->obs.p, c->v_pos.p, P.overlap_threshold, c->stack.p, c->deleted.p, s);
+        launch_overlap_filter(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->rows.p, c->obs.p, c->g_vpos, P.overlap_threshold, c->stack.p, c->deleted.p, s);
         HIP_TRY(hipEventSynchronize(c->ev_cnv));
         c->h_cnt = *c->h_cnt_pin;
         if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) { c->err = "alignment find unsupported CIGAR operation"; return -2; }
@@ -868,15 +943,18 @@ __global__ void k_result_out(const uint4 *src, uint4 *dst, size_t n16, const Lps
     if (i == 0) { *cnt_out = *cnt; stats_out[0] = stats[0]; stats_out[1] = stats[1]; stats_out[2] = stats[2]; stats_out[3] = stats[3]; }
 }
 static size_t enqueue_result_copy(lps_ctx *c) {
-    const size_t span = (size_t)((uint8_t *)c->out_gt.p - (uint8_t *)c->out_ps.p) + (size_t)c->nV;
+    const size_t span = (size_t)((uint8_t *)c->out_gt.p - (uint8_t *)c->out_ps.p) + (size_t)c->nG;
     const size_t n16 = (span + 15) / 16;                                   // the zero pool's slots are padded to 256 bytes: the rounded span stays inside it
     if (n16 * 16 > c->h_res_bytes) { if (c->h_res) HIP_TRY(hipHostFree(c->h_res)); c->h_res = nullptr; c->h_res_bytes = n16 * 16 + span / 4 + 4096; HIP_TRY(hipHostMalloc((void **)&c->h_res, c->h_res_bytes)); }
     hipLaunchKernelGGL(k_result_out, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, (const uint4 *)c->out_ps.p, (uint4 *)c->h_res, n16, c->d_cnt, c->h_cnt_pin, c->clip_stats.p, c->h_stats_pin);
     return span;
 }
 static void deliver_result(lps_ctx *c, lps_phase_result *out) {
-    memcpy(out->phase_set, c->h_res, (size_t)c->nV * sizeof(int32_t));
-    memcpy(out->gt, c->h_res + ((uint8_t *)c->out_gt.p - (uint8_t *)c->out_ps.p), (size_t)c->nV);
+    const int32_t *ps = (const int32_t *)c->h_res; const uint8_t *gt = c->h_res + ((uint8_t *)c->out_gt.p - (uint8_t *)c->out_ps.p);
+    if (!c->nX) { memcpy(out->phase_set, ps, (size_t)c->nV * sizeof(int32_t)); memcpy(out->gt, gt, (size_t)c->nV); return; }
+    // the result covers the union of the three tables: the SNP rows go to the caller, the whole of it stays for lps_get_extra_result
+    c->h_res_ps_u.assign(ps, ps + c->nG); c->h_res_gt_u.assign(gt, gt + c->nG);
+    for (int i = 0; i < c->nV; ++i) { out->phase_set[i] = ps[c->h_snp_u[i]]; out->gt[i] = gt[c->h_snp_u[i]]; }
 }
 
 int lps_debug_set_obs_capacity(lps_ctx *c, int64_t slots) {
@@ -897,8 +975,8 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         HIP_TRY(hipSetDevice(c->device));
         if (out->n != c->nV) return fail(c, "lps_phase_result.n must equal the variant table size");
         memset(out->phase_set, 0, (size_t)out->n * sizeof(int32_t)); memset(out->gt, 0, (size_t)out->n);
-        c->phase_valid = false;
-        if (c->nV == 0 || c->nR == 0) return 0;
+        c->phase_valid = false; c->h_res_ps_u.clear(); c->h_res_gt_u.clear();
+        if (c->nV == 0 || c->nR == 0) { c->phase_valid = c->nV != 0; return 0; }
         if (c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
         c->in_phase = true;
         int rc = run_phase(c);

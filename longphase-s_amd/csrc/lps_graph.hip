@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_mark_nodes(int n_reads, const RowDesc *
     for (int k = sl; k < n; k += ROW_G) {
         const int v = obs[off + k].var; const int q = aq_quality((uint16_t)obs[off + k].aq);
         if (v < 0) continue;                                  // erased by the CNV filter
-        const unsigned ty = (q == -4) ? 3u : (q == -5 ? 4u : 0u);
+        const unsigned ty = (q >= 0) ? 0u : (q == -4 ? 3u : (q == -5 ? 4u : (q == -1 ? 1u : 2u)));      // :803-832 (-2 / -3: MOD on the forward / reverse strand)
         is_node[v] = 1u;
         // type of the LAST alignment that saw the variant.  Base qualities are never negative, so ty == 0 means a SNP row, all of whose
         // observations are of type 0: the word stays 0 without 1.7 M atomics
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const RowDesc *r
         const bool ok = v >= 0;
         const unsigned long long m = group_ballot(ok, grp);
         if (ok) {
-            int q = aq_quality(aq); if (q < 0) q = 60;          // indel sentinels -> quality 60 (:820-828)
+            int q = aq_quality(aq); if (q < 0) q = (q == -1 && !aq_allele(aq)) ? 30 : 60;   // sentinels -> quality 60; a SV row the read does not carry: 30 (:803-828)
             const uint32_t slot = off + w + __popcll(m & ((1ull << sl) - 1ull));
             const uint32_t nd = node_of[v];
             const unsigned fl = (unsigned)aq_allele(aq) | ((q >= base_quality) ? 2u : 0u);
@@ -775,11 +775,14 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
         const double esr = (double)fminf(para, cross) / (double)fmaxf(para, cross);
         int dir = 0;
         if (para > cross) dir = 1; else if (para < cross) dir = 2;
-        if (esr > edge_threshold) dir = 0;
+        // an edge between a SNP and a MOD row: threshold 0.3, and nothing connects when the four cells sum to less than one read (:197-202)
+        const int typ = ntype[i], typ_t = (i + 1 + l < n_nodes) ? ntype[i + 1 + l] : 0;
+        double thr = edge_threshold;
+        if ((typ == 0 && typ_t == 2) || (typ == 2 && typ_t == 0)) thr = ((rr + ra + ar + aa) < 1) ? -1.0 : 0.3;
+        if (esr > thr) dir = 0;
         const bool w20 = (esr <= 0.1 && (rr + aa + ra + ar) >= 1) || (para < 1 && cross >= 1) || (para >= 1 && cross < 1);
         const bool single = (para + cross) <= 1;
         const bool lowesr = esr < 0.2;
-        const int typ = ntype[i];
         float w = (typ == 4) ? 0.1f : (w20 ? 20.f : 1.f);
         const bool osum = !single && lowesr && w >= 1.f && typ != 3;
         if (dir == 0 || i + 1 + l >= n_nodes) w = 0.f;

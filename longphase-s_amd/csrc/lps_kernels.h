@@ -58,6 +58,22 @@ struct ClipView {          // clip events of the kept alignments, appended (one 
     ClipEv *ev; unsigned *n_ev; unsigned capacity;
 };
 
+// SV / MOD rows of `phase --sv-file / --mod-file` (lps_extra.hip): both tables merged by position; u / snp_u = index of a row / of SNP row i in
+// the position-sorted union of all three tables, the index space of every stage after the extraction when such rows are present
+struct ExtraView {
+    int n;
+    const int32_t *pos;        // ascending, distinct, none equal to a SNP position
+    const int32_t *info;       // SV: SVLEN as in the VCF; MOD: row number (mod_off)
+    const uint8_t *kind;       // 1 SV, 2 MOD
+    const int32_t *u;
+    const int32_t *snp_u;      // [V.n]
+    const uint32_t *mod_off;   // reads listed at MOD row m: [mod_off[m], mod_off[m+1]) of mod_name (ascending name ids) / mod_flag (bit0 modified, bit1 reverse)
+    const uint32_t *mod_name;
+    const uint8_t *mod_flag;
+    int sv_window; double sv_threshold;
+};
+void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int mapping_quality, LpsCounters *cnt, hipStream_t s);
+
 void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *rec, hipStream_t s);
 
 // attr word of a packed variant record: bits 0-7 REF[0], 8-15 ALT[0], 16-17 kind (0 SNP, 1 insertion, 2 deletion,

@@ -44,6 +44,8 @@ def load():
     L.lps_begin_chromosome.argtypes = [C.c_void_p]
     L.lps_set_variants.argtypes = [C.c_void_p, C.POINTER(abi.VariantTable)]
     L.lps_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.lps_set_extra_variants.argtypes = [C.c_void_p, C.POINTER(abi.ExtraVariantTable)]
+    L.lps_get_extra_result.argtypes = [C.c_void_p, C.POINTER(abi.PhaseResult), C.POINTER(abi.PhaseResult)]
     L.lps_push_reads.argtypes = [C.c_void_p, C.POINTER(abi.ReadBatch)]
     L.lps_push_reads_device.argtypes = [C.c_void_p, C.POINTER(abi.ReadBatch)]
     L.lps_push_bam_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
@@ -146,6 +148,17 @@ class Context:
         self._check(self.L.lps_push_reads_device(self.h, C.byref(batch)), "lps_push_reads_device")
         self.n_reads = n_reads
         self.n_var = variants.n
+
+    def set_extra(self, extra):
+        """SV / MOD rows co-phased with the SNPs (after load_chromosome / set_table; None = none)."""
+        self._check(self.L.lps_set_extra_variants(self.h, C.byref(extra.c) if extra is not None else None), "lps_set_extra_variants")
+        self._extra = extra
+
+    def extra_result(self):
+        """(sv PhaseOut, mod PhaseOut) of the last run_phase."""
+        sv, mod = abi.PhaseOut(self._extra.n_sv), abi.PhaseOut(self._extra.n_mod)
+        self._check(self.L.lps_get_extra_result(self.h, C.byref(sv.c), C.byref(mod.c)), "lps_get_extra_result")
+        return sv, mod
 
     def set_table(self, variants, ref):
         """Replace the variant table (e.g. by the phased one) while the pushed reads stay resident."""
