@@ -81,9 +81,10 @@ static void read_fasta(const std::string &path, const std::map<std::string, ChrV
 
 // ------------------------------------------------------------------------------------------------ VCF rewriter
 struct Phased { int32_t ps; char a, b; };
-// SnpParser::writeLine (ParsingBam.cpp:460-635) restated
-static void write_vcf(const std::vector<std::string> &lines, const std::string &out_path, const std::map<std::string, std::map<int32_t, Phased>> &res,
-                      const std::map<std::string, ChrVariants> &vars, const std::string &command) {
+// SnpParser::writeLine (ParsingBam.cpp:460-635) restated; SVParser::writeLine (:1042-1193) and METHParser::writeLine (:1788-1942) differ from it only
+// in how a record finds its result - `lookup(chromosome, 1-based POS)` returns it, or nullptr when the record is not phased or was not a row of the table
+template <class Lookup>
+static void rewrite_vcf(const std::vector<std::string> &lines, const std::string &out_path, const std::string &command, Lookup lookup) {
     std::ofstream o(out_path); if (!o) die("Fail to open write file: " + out_path);
     bool ps_def = false, cmd_done = false;
     for (const std::string &in : lines) {
@@ -125,13 +126,8 @@ static void write_vcf(const std::vector<std::string> &lines, const std::string &
                 f[9][st + 1] = '/';
             }
         }
-        const Phased *ph = nullptr;
-        auto rc = res.find(f[0]);
-        if (rc != res.end()) { auto it = rc->second.find(pidx); if (it != rc->second.end()) ph = &it->second; }
-        bool extracted = false;
-        auto vc = vars.find(f[0]);
-        if (vc != vars.end()) extracted = std::binary_search(vc->second.pos.begin(), vc->second.pos.end(), pidx);
-        if (ph && extracted) {
+        const Phased *ph = lookup(f[0], pidx + 1);
+        if (ph) {
             f[8] += ":PS"; f[9] += ":" + std::to_string(ph->ps);
             const size_t gp = f[8].find("GT"); const size_t st = value_start(f[9], colon_index(f[8], gp));
             f[9][st] = ph->a; f[9][st + 1] = '|'; f[9][st + 2] = ph->b;
@@ -141,6 +137,16 @@ static void write_vcf(const std::vector<std::string> &lines, const std::string &
     }
 }
 
+static void write_vcf(const std::vector<std::string> &lines, const std::string &out_path, const std::map<std::string, std::map<int32_t, Phased>> &res,
+                      const std::map<std::string, ChrVariants> &vars, const std::string &command) {
+    rewrite_vcf(lines, out_path, command, [&](const std::string &chr, int32_t pos1) -> const Phased * {
+        auto rc = res.find(chr); auto vc = vars.find(chr);
+        if (rc == res.end() || vc == vars.end()) return nullptr;
+        auto it = rc->second.find(pos1 - 1);
+        if (it == rc->second.end() || !std::binary_search(vc->second.pos.begin(), vc->second.pos.end(), pos1 - 1)) return nullptr;
+        return &it->second;
+    });
+}
 
 // ------------------------------------------------------------------------------------------------ haplotag
 // Phased-het rows of the SNP VCF = the haplotag table: VcfParser::parserProcess (src/haplotag/HaplotagVcfParser.cpp:234-400).

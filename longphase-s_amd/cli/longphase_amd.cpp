@@ -6,12 +6,14 @@
 //   SnpParser row selection                   src/phase/ParsingBam.cpp:222-359
 //   per-chromosome driver                     src/phase/PhasingProcess.cpp:113-173   (the hot path is one lps_phase_chromosome call)
 //   SnpParser::writeLine (VCF rewrite rules)  src/phase/ParsingBam.cpp:460-635
-// Not supported (the reference path must be used): --sv-file, --mod-file, --dot, --deepsomatic_output, CRAM.
+//   SVParser / METHParser (--sv-file, --mod-file) src/phase/ParsingBam.cpp:915-1206, 1647-1952   (cli_extra.h)
+// Not supported (the reference path must be used): --dot, --deepsomatic_output, CRAM.
 // Split in round 2: cli_common.h (loader), cli_bam.h (BGZF/BAM in, BGZF out), cli_vcf.h (VCF/FASTA in, phased VCF out), cli_purity.h (purity estimator).
 #include "cli_common.h"
 #include "cli_bam.h"
 #include "cli_vcf.h"
 #include "cli_purity.h"
+#include "cli_extra.h"
 
 // ------------------------------------------------------------------------------------------------ phase
 static const char *kUsage =
@@ -19,6 +21,7 @@ static const char *kUsage =
     "   -s, --snp-file=NAME   -b, --bam-file=NAME (repeatable)   -r, --reference=NAME   -o, --out-prefix=NAME (result)   -t, --threads=Num (1)\n"
     "   --ont | --pb   --indels   -q MAPQ(1)  -p baseQuality(12)  -e edgeWeight(0.1)  -a connectAdjacent(35)  -d distance(300000)\n"
     "   -1 edgeThreshold(0.7)  -L overlapThreshold(0.2)  -m readConfidence(0.65)  -n snpConfidence(0.75)  --gpu=ID (0)\n"
+    "   --sv-file=NAME  --mod-file=NAME   co-phase structural variants / modcall records (outputs <prefix>_SV.vcf, <prefix>_mod.vcf)   -w svWindow(20)  -h svThreshold(0.1)\n"
     "   --host-inflate | --gpu-inflate   BGZF inflate with zlib on the -t host threads / on the GPU (default: GPU for one BAM of 256 MiB or more)\n"
     "   --no-index       ignore <bam>.bai: make the whole file resident on the GPU instead of one contig at a time\n"
     "   --group-bytes=N  indexed input: consecutive contigs are uploaded and inflated together up to N compressed bytes (8 GiB)\n"
@@ -26,9 +29,9 @@ static const char *kUsage =
 
 static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over; bool indels = false;
-    std::string snp, ref, prefix = "result";
+    std::string snp, ref, prefix = "result", sv_file, mod_file;
     std::vector<std::string> bams;
-    int threads = 1, gpu = 0, n_gpus = 1;
+    int threads = 1, gpu = 0, n_gpus = 1, sv_window = 20; double sv_threshold = 0.1;
     uint64_t group_bytes = 8ull << 30;
     bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
@@ -65,6 +68,10 @@ static int phase_main(int argc, char **argv, const std::string &command) {
             over.push_back([x](lps_params &P) { P.snp_confidence = x; });
             }
         else if (a == "-x" || a == "--mismatchRate") (void)val();
+        else if (a == "--sv-file") sv_file = val();
+        else if (a == "--mod-file") mod_file = val();
+        else if (a == "-w" || a == "--svWindow") sv_window = std::stoi(val());
+        else if (a == "-h" || a == "--svThreshold") sv_threshold = std::stod(val());
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--gpus") n_gpus = std::max(1, std::stoi(val()));
         else if (a == "--group-bytes") group_bytes = (uint64_t)std::stoull(val());
@@ -72,8 +79,12 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "--gpu-inflate") gpu_inflate = true;
         else if (a == "--no-index") no_index = true;
         else if (a == "--help") { std::cout << kUsage; return 0; }
-        else if (a == "--sv-file" || a == "--mod-file" || a == "--dot" || a == "--deepsomatic_output" || a == "--indelQuality") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
+        else if (a == "--dot" || a == "--deepsomatic_output" || a == "--indelQuality") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kUsage; return 1; }
+    }
+    if (!sv_file.empty()) {                                             // Phasing.cpp:304-318
+        if (sv_window < 0) { std::cerr << "longphase_amd phase: invalid svWindow. value: " << sv_window << "\n please check -w, --svWindow=Num\n"; return 1; }
+        if (sv_threshold < 0 || sv_threshold > 1) { std::cerr << "longphase_amd phase: invalid svThreshold. value: " << sv_threshold << "\n this value need: 0~1, please check -h, --svThreshold=[0~1]\n"; return 1; }
     }
     if (snp.empty() || bams.empty() || ref.empty()) { std::cerr << "longphase_amd phase: missing arguments\n" << kUsage; return 1; }
     if (ont == pb) { std::cerr << "longphase_amd phase: missing arguments. --ont or --pb\n" << kUsage; return 1; }   // Phasing.cpp:175-183
@@ -88,6 +99,11 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     if (!read_lines(snp, vcf_lines)) die("ERROR: Cannot open vcf file " + snp);
     std::vector<std::string> chr_order; std::map<std::string, ChrVariants> vars;
     parse_vcf(vcf_lines, indels, chr_order, vars);
+    // SV rows, then MOD rows: each reader drops what sits on a row of the tables read before it (PhasingProcess.cpp:69-79)
+    std::vector<std::string> sv_lines, mod_lines; SvTable svt; ModTable modt;
+    if (!sv_file.empty()) { if (!read_lines(sv_file, sv_lines)) die("ERROR: Cannot open vcf file " + sv_file); svt.parse(sv_lines, vars); }
+    if (!mod_file.empty()) { if (!read_lines(mod_file, mod_lines)) die("ERROR: Cannot open vcf file " + mod_file); modt.parse(mod_lines, vars, svt); }
+    const bool co_phase = !sv_lines.empty() || !mod_lines.empty();
     std::map<std::string, int> want; for (auto &kv : vars) if (!kv.second.pos.empty()) want[kv.first] = 1;
     std::map<std::string, std::string> seqs; read_fasta(ref, vars, seqs);
     const double t_text = now();
@@ -163,6 +179,8 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         vt.alt_len = tab.al() + to;
         const std::string &sq = seqs[chr];
         if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size())) die(std::string("longphase_amd: ") + L.last_error(ctx));
+        ExtraRows xr;
+        if (co_phase) { xr.build(svt, modt, chr, names, name_id, sv_window, sv_threshold); if (xr.any() && L.set_extra_variants(ctx, &xr.x)) die(std::string("longphase_amd: ") + chr + ": " + L.last_error(ctx)); }
         size_t at = 0;
         if (gpu_input && L.push_bam_resident(ctx, gr.first, gr.second, name_id.data())) die(std::string("longphase_amd: ") + L.last_error(ctx));
         for (size_t b = 0; b < files.size(); ++b) {                  // BAM files in -b order (ParsingBam.cpp:1252)
@@ -177,6 +195,13 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         if (L.phase_chromosome(ctx, &pr)) die(std::string("longphase_amd: ") + L.last_error(ctx));
         std::map<int32_t, Phased> rc;
         for (size_t i = 0; i < cv.pos.size(); ++i) if (ps[i]) rc[cv.pos[i]] = Phased{ps[i], gt[i] ? '1' : '0', gt[i] ? '0' : '1'};
+        if (xr.any()) {                                              // the reference keeps ONE result map keyed by position for all three files
+            std::vector<int32_t> sps(xr.sv_pos.size()), mps(xr.mod_pos.size()); std::vector<uint8_t> sgt(xr.sv_pos.size()), mgt(xr.mod_pos.size());
+            lps_phase_result rs{(int64_t)sps.size(), sps.data(), sgt.data()}, rm{(int64_t)mps.size(), mps.data(), mgt.data()};
+            if (L.get_extra_result(ctx, &rs, &rm)) die(std::string("longphase_amd: ") + L.last_error(ctx));
+            for (size_t i = 0; i < sps.size(); ++i) if (sps[i]) rc[xr.sv_pos[i]] = Phased{sps[i], sgt[i] ? '1' : '0', sgt[i] ? '0' : '1'};
+            for (size_t i = 0; i < mps.size(); ++i) if (mps[i]) rc[xr.mod_pos[i]] = Phased{mps[i], mgt[i] ? '1' : '0', mgt[i] ? '0' : '1'};
+        }
         { std::lock_guard<std::mutex> lk(res_mu); res[chr].swap(rc); std::cerr << "(" << chr << ")"; }
     };
     // contigs never interact: with --gpus N and an indexed BAM they are dealt longest-first onto N contexts, one host thread + one
@@ -239,6 +264,8 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     L.destroy(ctx);
     const double t_gpu = now();
     write_vcf(vcf_lines, prefix + ".vcf", res, vars, command);
+    if (!sv_file.empty()) write_sv_vcf(sv_lines, prefix + "_SV.vcf", res, svt, command);          // PhasingProcess.cpp:191-203
+    if (!mod_file.empty()) write_mod_vcf(mod_lines, prefix + "_mod.vcf", res, modt, command);
     if (gpu_input) fprintf(stderr, "%s | vcf+fasta read %.3fs | wait for gpu context %.3fs | map bam+header%s %.3fs | upload+gpu inflate %.3fs | gpu record scan %.3fs | names+decode+phase %.3fs | write vcf %.3fs | total %.3fs\n",
                            gb.indexed ? "contig groups (indexed)" : "whole file", t_text - t_begin, t_ctx - t_bam, gb.indexed ? "+index" : "", gb.t_map, gb.t_inflate, gb.t_scan,
                            t_gpu - t_gin - (gb.indexed ? gb.t_inflate + gb.t_scan : 0.0), now() - t_gpu, now() - t_begin);

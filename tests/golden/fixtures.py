@@ -35,6 +35,28 @@ PHASE_FIXTURES = {
     "supp_light_dups": (dict(SMALL, seed=17, n_snp=1500, coverage=25.0, supp_frac=0.5, supp_overlap_frac=1.0, lowq_frac=0.4), ["--ont"], {}),
 }
 
+# `phase --sv-file --mod-file` fixtures: name -> (synth kwargs, make_mod_lines kwargs or None (no MOD file), use the generator's SVs,
+# reference CLI flags, lps_params overrides, lps_extra_variants overrides).  The MOD read lists are drawn by numpy and therefore stored in the
+# golden file next to the reference's results.
+XB = dict(contig_len=400_000, n_snp=500, coverage=15.0, n_threads=4)
+EXTRA_FIXTURES = {
+    "sv_and_mod": (dict(XB, seed=21, sv_every=15000.0), dict(), True, ["--ont"], {}, {}),
+    "sv_only": (dict(XB, seed=22, sv_every=15000.0), None, True, ["--ont"], {}, {}),
+    "mod_only": (dict(XB, seed=23), dict(), False, ["--ont"], {}, {}),
+    "pb_indels": (dict(XB, seed=24, sv_every=15000.0, indel_var_frac=0.3), dict(), True, ["--pb", "--indels"], dict(is_ont=0, phase_indel=1), {}),
+    "supp": (dict(XB, seed=25, sv_every=15000.0, coverage=30.0, supp_frac=0.3, clip_pileups=2, contig_len=800_000, n_snp=1000), dict(), True, ["--ont"], {}, {}),
+    # break-point clip pile-ups: CNV intervals, the mismatch filter looks at SV / MOD rows like at any other
+    "cnv": (dict(XB, seed=16, sv_every=20000.0, contig_len=2_000_000, n_snp=2400, coverage=45.0, clip_pileups=7, supp_frac=0.05), dict(mod_every=4000.0), True, ["--ont"], {}, {}),
+    "short_reads_dense_mod": (dict(XB, seed=26, sv_every=5000.0, len_median=3000.0, len_min=500, coverage=25.0), dict(mod_every=300.0), True, ["--ont"], {}, {}),
+    # clips on every second read + overlapping supplementary pieces: rows reached through the forward reach of clips, MOD rows behind the last SNP
+    "clips_sparse_snps": (dict(XB, seed=27, sv_every=15000.0, clip_every=2, supp_frac=0.5, supp_overlap_frac=1.0, n_snp=150), dict(mod_every=500.0), True, ["--ont"], {}, {}),
+    "window_threshold": (dict(XB, seed=28, sv_every=15000.0, indel_var_frac=0.3, sub_rate=0.05, ins_rate=0.04, del_rate=0.04), dict(), True,
+                         ["--ont", "--indels", "-a", "20", "--svWindow", "3", "--svThreshold", "0.3"], dict(phase_indel=1, connect_adjacent=20), dict(sv_window=3, sv_threshold=0.3)),
+    "dense_everything": (dict(XB, seed=29, sv_every=4000.0, n_snp=2000, coverage=8.0), dict(mod_every=200.0), True, ["--pb"], dict(is_ont=0), {}),
+    # more recorded rows per alignment than the kernel keeps in LDS (512): its second walk
+    "mod_every_20": (dict(XB, seed=30, contig_len=200_000, n_snp=200, coverage=6.0, len_median=40000.0), dict(mod_every=20.0, pair_frac=0.0, listed=1.0), False, ["--ont"], {}, {}),
+}
+
 # haplotag fixtures: (phase fixture providing reads + the reference's own phased VCF, haplotag CLI flags, params overrides)
 HAPLOTAG_FIXTURES = {
     "snp_ont": ("snp_ont", [], {}),
@@ -55,6 +77,13 @@ CLI_HAPLOTAG_FIXTURES = ["snp_ont", "indels", "supp_tagged", "strict", "two_bloc
 MULTI = dict(contig_len=150_000, n_snp=200, coverage=14.0, n_threads=2)
 MULTI_CONTIG_FIXTURE = [("chrA", dict(MULTI, seed=41), True), ("chrB", dict(MULTI, seed=42, contig_len=90_000, n_snp=110, supp_frac=0.2), True),
                         ("chrEmpty", dict(MULTI, seed=43, contig_len=50_000, n_snp=60), False), ("chrC", dict(MULTI, seed=44, indel_var_frac=0.2), True)]
+
+# end-to-end fixture of `phase --sv-file --mod-file`: three contigs in one BAM, the last one without SNP records; the SV / MOD VCFs (with the records
+# the reference's readers drop, see make_golden.make_cli_extra) are committed under tests/golden/data next to the three VCFs the reference wrote
+XC = dict(n_threads=2, coverage=14.0)
+CLI_EXTRA_FIXTURE = [("chrA", dict(XC, seed=51, contig_len=120_000, n_snp=160, sv_every=8000.0), True),
+                     ("chrB", dict(XC, seed=52, contig_len=90_000, n_snp=110, sv_every=6000.0, supp_frac=0.2), True),
+                     ("chrC", dict(XC, seed=53, contig_len=50_000, n_snp=60, sv_every=6000.0), False)]
 
 # tumor/normal fixtures for the somatic rows: (genome kwargs, normal reads kwargs, tumor reads kwargs, somatic_haplotag CLI, params)
 TN_BASE = dict(contig_len=600_000, n_snp=700, n_threads=4, somatic_every=8000.0)

@@ -305,8 +305,130 @@ def make_multi_contig_golden():
     print("multi_contig", out["n_records"], out["records_sha256"][:16])
 
 
+def parse_gt_ps(path):
+    """position (0-based) -> (GT, PS) of every record of a phased VCF."""
+    d = {}
+    for line in open(path):
+        if line.startswith("#"):
+            continue
+        f = line.rstrip("\n").split("\t"); fmt = f[8].split(":"); smp = f[9].split(":")
+        d[int(f[1]) - 1] = (smp[fmt.index("GT")], smp[fmt.index("PS")])
+    return d
+
+
+def rows_result(d, positions):
+    ps = np.zeros(len(positions), np.int32); gt = np.zeros(len(positions), np.uint8)
+    for i, p in enumerate(positions):
+        g, v = d[int(p)]
+        if v != ".":
+            assert g in ("0|1", "1|0"), (p, g)
+            ps[i] = int(v); gt[i] = 1 if g == "1|0" else 0
+        else:
+            assert "|" not in g, (p, g)
+    return ps, gt
+
+
+def make_extra(name):
+    """phase with --sv-file / --mod-file through the reference binary: results of the SNP, SV and MOD rows + the MOD read lists that were used."""
+    from lps.synth import make_mod_lines, merge_mod_lines, write_sv_vcf, write_mod_vcf
+    kw, mod_kw, use_sv, cli, over, xover = fixtures.EXTRA_FIXTURES[name]
+    s = Synth(**kw)
+    lines = make_mod_lines(s, seed=kw["seed"], **mod_kw) if mod_kw is not None else []
+    mpos, mrows = merge_mod_lines(lines)
+    with tempfile.TemporaryDirectory() as d:
+        extra = []
+        if use_sv:
+            write_sv_vcf(os.path.join(d, "sv.vcf"), "chrS", s.sv_pos, s.sv_len, s.contig_len); extra += ["--sv-file", "sv.vcf"]
+        if mod_kw is not None:
+            write_mod_vcf(os.path.join(d, "mod.vcf"), "chrS", lines, s.contig_len); extra += ["--mod-file", "mod.vcf"]
+        ps, gt = run_reference_phase(s, cli + extra, d)
+        sv_ps, sv_gt = rows_result(parse_gt_ps(os.path.join(d, "out_SV.vcf")), s.sv_pos) if use_sv else (np.zeros(0, np.int32), np.zeros(0, np.uint8))
+        mod_ps, mod_gt = rows_result(parse_gt_ps(os.path.join(d, "out_mod.vcf")), mpos) if mod_kw is not None else (np.zeros(0, np.int32), np.zeros(0, np.uint8))
+    off = np.concatenate([[0], np.cumsum([len(r) for r in mrows])]).astype(np.uint64)
+    flat = [e for r in mrows for e in r]
+    np.savez_compressed(os.path.join(HERE, f"phase_extra_{name}.npz"), var_pos=np.array(s.var_pos), phase_set=ps, gt=gt,
+                        sv_pos=np.array(s.sv_pos if use_sv else [], np.int32), sv_len=np.array(s.sv_len if use_sv else [], np.int32), sv_ps=sv_ps, sv_gt=sv_gt,
+                        mod_pos=np.array(mpos, np.int32), mod_off=off, mod_name=np.array([e[0] for e in flat], np.uint32),
+                        mod_flag=np.array([(1 if e[1] else 0) | (2 if e[2] else 0) for e in flat], np.uint8), mod_ps=mod_ps, mod_gt=mod_gt)
+    index = json.load(open(os.path.join(HERE, "index.json")))
+    index["extra:" + name] = dict(digest=fixtures.input_digest(s), n_var=int(s.n_variants), n_reads=int(s.n_reads), n_phased=int((ps != 0).sum()),
+                                  n_sv=int(len(sv_ps)), n_sv_phased=int((sv_ps != 0).sum()), n_mod=int(len(mod_ps)), n_mod_phased=int((mod_ps != 0).sum()), cli=cli + extra)
+    json.dump(index, open(os.path.join(HERE, "index.json"), "w"), indent=1, sort_keys=True)
+    print("extra", name, index["extra:" + name]); s.close()
+
+
+def make_cli_extra():
+    """`phase --sv-file --mod-file` of the reference on a three-contig BAM.  The SV / MOD VCFs hold, besides what a caller would write for the
+    generated reads, the records SVParser / METHParser drop or mangle: homozygous records, records on a SNP, a position given twice (and the
+    neighbour the reference erases instead of it), no SVLEN, no RS, a modcall record on an SV's 1-based start, a run of consecutive positions
+    broken by a dropped record, already phased records with a PS value, records of a contig the SNP file does not cover."""
+    from lps.synth import make_mod_lines
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import util
+    with tempfile.TemporaryDirectory() as d:
+        digests = util.make_multi_contig(d, fixtures.CLI_EXTRA_FIXTURE, unmapped=0)
+        sv_recs, mod_recs, contigs = [], [], []
+        for name, kw, in_vcf in fixtures.CLI_EXTRA_FIXTURE:
+            s = Synth(**kw)
+            contigs.append((name, s.contig_len))
+            snp = [int(p) for p in s.var_pos]
+            for i, (p, l) in enumerate(zip(s.sv_pos, s.sv_len)):
+                p = int(p); l = int(l); ty = "INS" if l > 0 else "DEL"
+                gt, fmt = "0/1:10:10", "GT:DR:DV"
+                if i == 1: gt = "1/1:0:20"                                   # homozygous: dropped
+                if i == 2: fmt, gt = "GT:PS:DR:DV", "1|0:777:10:10"          # phased by an earlier run: PS stripped, GT rewritten
+                if i == 4: sv_recs.append((name, p, "%s\t%d\tsvL%d\tN\t<DEL>\t60\tPASS\tSVTYPE=DEL;SVLEN=-120;END=%d\tGT:DR:DV\t0/1:9:9\n" % (name, p, i, p + 120)))   # erased in place of the pair below
+                info = "SVTYPE=%s;SVLEN=%d;END=%d" % (ty, l, p + 1 + (0 if l > 0 else -l))
+                if i == 5: info = "SVTYPE=%s;END=%d" % (ty, p + 1)          # no SVLEN: dropped
+                if i == 6: info = "SVTYPE=%s;END=%d;SVLEN=%d" % (ty, p + 1, l)   # SVLEN last, no ';' behind it
+                sv_recs.append((name, p + 1, "%s\t%d\tsv%d\tN\t<%s>\t60\tPASS\t%s\t%s\t%s\n" % (name, p + 1, i, ty, info, fmt, gt)))
+                if i == 4: sv_recs.append((name, p + 1, "%s\t%d\tsvD%d\tN\t<INS>\t60\tPASS\tSVTYPE=INS;SVLEN=90\tGT:DR:DV\t0/1:9:9\n" % (name, p + 1, i)))   # same POS again: dropped, marks the position
+            sv_recs.append((name, snp[7] + 1, "%s\t%d\tsvS\tN\t<INS>\t60\tPASS\tSVTYPE=INS;SVLEN=200\tGT:DR:DV\t0/1:9:9\n" % (name, snp[7] + 1)))       # on a SNP: dropped
+            lines = make_mod_lines(s, seed=kw["seed"], mod_every=900.0)
+            sv1 = set(int(p) + 1 for p in s.sv_pos)
+            k_run = next(i for i in range(len(lines) - 1) if lines[i][0] + 1 == lines[i + 1][0])      # first two-record run
+            for i, (q, rev, reads) in enumerate(lines):
+                mr = ",".join("%s_r%09d" % (name, n) for n, m in reads if m); nr = ",".join("%s_r%09d" % (name, n) for n, m in reads if not m)
+                rs, gt, fmt = ("RS=N" if rev else "RS=P"), "0/1:%d:%d" % (len(mr.split(",")), len(nr.split(","))), "GT:MD:UD"
+                if i == 3: gt = "1/1:5:0"                                    # homozygous: dropped
+                if i == 5: rs = "XS=1"                                       # no strand: dropped
+                if i == 8: fmt, gt = "GT:PS:MD:UD", "0|1:4242:3:3"           # phased by an earlier run
+                if i == k_run + 4: mod_recs.append((name, q, "%s\t%d\t.\tC\t<MOD>\t.\tPASS\tRS=P;MR=%s;NR=%s;\tGT:MD:UD\t1/1:1:1\n" % (name, q, mr, nr)))   # the record before: homozygous, so the run restarts here
+                mod_recs.append((name, q + 1, "%s\t%d\t.\t%s\t<MOD>\t.\tPASS\t%s;MR=%s;NR=%s;\t%s\t%s\n" % (name, q + 1, "G" if rev else "C", rs, mr, nr, fmt, gt)))
+            some = "%s_r%09d" % (name, int(s.name_id[5]))
+            mod_recs.append((name, snp[11] + 1, "%s\t%d\t.\tC\t<MOD>\t.\tPASS\tRS=P;MR=%s;NR=;\tGT:MD:UD\t0/1:1:0\n" % (name, snp[11] + 1, some)))      # on a SNP: dropped
+            p3 = int(s.sv_pos[3]) + 1                                        # 1-based start of a kept SV: METHParser looks the 0-based position up there -> VCF POS + 1 is dropped
+            mod_recs.append((name, p3 + 1, "%s\t%d\t.\tC\t<MOD>\t.\tPASS\tRS=P;MR=%s;NR=;\tGT:MD:UD\t0/1:1:0\n" % (name, p3 + 1, some)))
+            s.close()
+        order = {n: i for i, (n, _) in enumerate(contigs)}
+        head = "##fileformat=VCFv4.2\n" + "".join("##contig=<ID=%s,length=%d>\n" % c for c in contigs) + "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
+        for fn, recs in (("sv.vcf", sv_recs), ("mod.vcf", mod_recs)):
+            recs.sort(key=lambda r: (order[r[0]], r[1]))                      # stable: records of one position keep the order they were added in
+            with open(os.path.join(d, fn), "w") as f:
+                f.write(head + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n" + "".join(r[2] for r in recs))
+        subprocess.check_call([TEST_VIEW, "-b", "-x", "reads.bam.bai", "-p", "reads.bam", "multi.sam"], cwd=d, stdout=subprocess.DEVNULL)
+        cmd = [REF_BIN, "phase", "-s", "multi.vcf", "-b", "reads.bam", "-r", "multi.fa", "-t", "2", "-o", "out", "--ont", "--sv-file", "sv.vcf", "--mod-file", "mod.vcf"]
+        r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            raise RuntimeError(f"reference failed rc={r.returncode}: {r.stderr[-2000:]}")
+        for fn in ("sv.vcf", "mod.vcf", "out.vcf", "out_SV.vcf", "out_mod.vcf"):
+            with open(os.path.join(d, fn), "rb") as fi, gzip.GzipFile(os.path.join(HERE, "data", "cli_extra." + fn + ".gz"), "wb", mtime=0) as fo:
+                shutil.copyfileobj(fi, fo)
+        n = {fn: sum(1 for l in open(os.path.join(d, fn)) if not l.startswith("#") and ":." not in l.split("\t")[9]) for fn in ("out.vcf", "out_SV.vcf", "out_mod.vcf")}
+    with open(os.path.join(HERE, "cli_extra.json"), "w") as f:
+        json.dump(dict(digests=digests, phased_records=n), f)
+    print("cli_extra", n)
+
+
 def main():
     assert os.path.exists(REF_BIN), "build the reference first: oracle/build_ref.sh"
+    if "--cli-extra" in sys.argv:
+        make_cli_extra()
+        return
+    if "--extra" in sys.argv:                       # only the SV / MOD co-phasing vectors
+        for name in fixtures.EXTRA_FIXTURES:
+            make_extra(name)
+        return
     if "--only-phase" in sys.argv:                 # one phase fixture, index.json updated in place
         name = sys.argv[sys.argv.index("--only-phase") + 1]
         kw, cli, over = fixtures.PHASE_FIXTURES[name]

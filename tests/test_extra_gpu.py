@@ -9,46 +9,16 @@ import pytest
 import lps_oracle
 import util
 from lps import abi, hip
-from lps.synth import Synth, make_mod_lines, merge_mod_lines
 
 pytestmark = pytest.mark.gpu
 
-BASE = dict(contig_len=400_000, n_snp=500, coverage=15.0, n_threads=4)
-
-CASES = {
-    # name: (synth kwargs, mod kwargs or None, use SVs, params, extra kwargs)
-    "sv_and_mod": (dict(BASE, seed=21, sv_every=15000.0), dict(), True, {}, {}),
-    "sv_only": (dict(BASE, seed=22, sv_every=15000.0), None, True, {}, {}),
-    "mod_only": (dict(BASE, seed=23), dict(), False, {}, {}),
-    "pb_indels": (dict(BASE, seed=24, sv_every=15000.0, indel_var_frac=0.3), dict(), True, dict(is_ont=0, phase_indel=1), {}),
-    "supp_cnv": (dict(BASE, seed=25, sv_every=15000.0, coverage=30.0, supp_frac=0.3, clip_pileups=2, contig_len=800_000, n_snp=1000), dict(), True, {}, {}),
-    "short_reads_dense_mod": (dict(BASE, seed=26, sv_every=5000.0, len_median=3000.0, len_min=500, coverage=25.0), dict(mod_every=300.0), True, {}, {}),
-    # clips on every second read + overlapping supplementary pieces: rows reached through the forward reach of clips, MOD rows behind the last SNP
-    "clips_sparse_snps": (dict(BASE, seed=27, sv_every=15000.0, clip_every=2, supp_frac=0.5, supp_overlap_frac=1.0, n_snp=150), dict(mod_every=500.0), True, {}, {}),
-    "window_threshold": (dict(BASE, seed=28, sv_every=15000.0, indel_var_frac=0.3, sub_rate=0.05, ins_rate=0.04, del_rate=0.04), dict(),
-                         True, dict(phase_indel=1, connect_adjacent=20), dict(sv_window=3, sv_threshold=0.3)),
-    "dense_everything": (dict(BASE, seed=29, sv_every=4000.0, n_snp=2000, coverage=8.0), dict(mod_every=200.0), True, dict(is_ont=0), {}),
-    # more recorded rows per alignment than the kernel keeps in LDS (512): the second walk
-    "mod_every_20": (dict(BASE, seed=30, contig_len=200_000, n_snp=200, coverage=6.0, len_median=40000.0), dict(mod_every=20.0, pair_frac=0.0, listed=1.0), False, {}, {}),
-}
+import fixtures
 
 
-def build(name):
-    kw, mod_kw, use_sv, pkw, xkw = CASES[name]
-    s = Synth(**kw)
-    lines = make_mod_lines(s, seed=kw["seed"], **mod_kw) if mod_kw is not None else []
-    mpos, mrows = merge_mod_lines(lines)
-    X = abi.ExtraVariants(s.sv_pos if use_sv else (), s.sv_len if use_sv else (), mpos, mrows, **xkw)
-    V = abi.Variants(s.var_pos, s.var_ref, s.var_alt)
-    R = abi.Reads.from_synth(s)
-    return s, V, X, R, abi.default_params(**pkw)
-
-
-@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("name", sorted(fixtures.EXTRA_FIXTURES))
 def test_extra_rows_every_stage(name):
-    s, V, X, R, P = build(name)
+    s, V, X, R, P, g = util.make_extra_case(name)
     want, wsv, wmod, d = lps_oracle.phase_x(P, V, X, s.ref, R, dump=True)
-    assert (X.n_sv == 0 or (wsv.phase_set != 0).sum() > 0.5 * X.n_sv) and (X.n_mod == 0 or (wmod.phase_set != 0).sum() > 0.5 * X.n_mod)
     with hip.Context(0, P) as ctx:
         ctx.load_chromosome(V, s.ref, R)
         ctx.set_extra(X)
@@ -59,6 +29,10 @@ def test_extra_rows_every_stage(name):
             gsv, gmod = ctx.extra_result()
             util.assert_phase_equal(gsv.phase_set, gsv.gt, wsv.phase_set, wsv.gt, f"{name}: SV rows")
             util.assert_phase_equal(gmod.phase_set, gmod.gt, wmod.phase_set, wmod.gt, f"{name}: MOD rows")
+        # ... and what the reference binary wrote for the same input
+        util.assert_phase_equal(out.phase_set, out.gt, g["phase_set"], g["gt"], f"{name}: SNP rows vs reference")
+        util.assert_phase_equal(gsv.phase_set, gsv.gt, g["sv_ps"], g["sv_gt"], f"{name}: SV rows vs reference")
+        util.assert_phase_equal(gmod.phase_set, gmod.gt, g["mod_ps"], g["mod_gt"], f"{name}: MOD rows vs reference")
         # without the extra rows the same ctx gives the plain result again
         ctx.set_extra(None)
         plain = ctx.run_phase()
@@ -68,7 +42,7 @@ def test_extra_rows_every_stage(name):
 
 def test_extra_rows_as_bam_records_and_small_arenas():
     """The same through raw BAM records, from arenas that are too small for the merged rows (the library grows them and runs again)."""
-    s, V, X, R, P = build("short_reads_dense_mod")
+    s, V, X, R, P, _ = util.make_extra_case("short_reads_dense_mod")
     want, wsv, wmod, d = lps_oracle.phase_x(P, V, X, s.ref, R, dump=True)
     B = abi.BamRecords.from_reads(R, seed=5)
     with hip.Context(0, P) as ctx:
@@ -85,7 +59,7 @@ def test_extra_rows_as_bam_records_and_small_arenas():
 
 def test_extra_rows_refused():
     """A position in two of the three tables, unsorted rows, unsorted read lists: refused (the reference would not terminate / misparse)."""
-    s, V, X, R, P = build("sv_and_mod")
+    s, V, X, R, P, _ = util.make_extra_case("sv_and_mod")
     with hip.Context(0, P) as ctx:
         ctx.load_chromosome(V, s.ref, R)
         for bad, msg in ((abi.ExtraVariants([int(s.var_pos[10])], [300], (), ()), b"more than one"),

@@ -20,6 +20,22 @@ def make_case(kw):
     return s, V, R
 
 
+def make_extra_case(name):
+    """A `phase --sv-file --mod-file` fixture: generator output, tables, lps_extra_variants (MOD read lists as stored with the golden results),
+    params and the golden arrays."""
+    kw, mod_kw, use_sv, cli, over, xover = fixtures.EXTRA_FIXTURES[name]
+    s, V, R = make_case(kw)
+    assert fixtures.input_digest(s) == INDEX["extra:" + name]["digest"], "generator drift: golden inputs differ"
+    g = np.load(os.path.join(GOLDEN, f"phase_extra_{name}.npz"))
+    assert np.array_equal(g["var_pos"], V.pos)
+    if use_sv:
+        assert np.array_equal(g["sv_pos"], s.sv_pos) and np.array_equal(g["sv_len"], s.sv_len)
+    off = g["mod_off"].astype(np.int64)
+    rows = [[(int(n), bool(f & 1), bool(f & 2)) for n, f in zip(g["mod_name"][off[i]:off[i + 1]], g["mod_flag"][off[i]:off[i + 1]])] for i in range(len(g["mod_pos"]))]
+    X = abi.ExtraVariants(g["sv_pos"], g["sv_len"], g["mod_pos"], rows, **xover)
+    return s, V, X, R, abi.default_params(**over), g
+
+
 def load_golden_phase(name):
     z = np.load(os.path.join(GOLDEN, f"phase_{name}.npz"))
     return z["var_pos"], z["phase_set"], z["gt"]
