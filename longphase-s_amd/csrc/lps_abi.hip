@@ -812,7 +812,7 @@ static int run_late(lps_ctx *c, bool with_cnv) {
         launch_edges(c->d_cnt, nV, c->node_off.p, c->node_end.p, c->nkeys.p, c->nvals.p, c->nkeys_s.p, c->nvals_s.p, c->mrow_off.p, c->mrow_cnt.p, c->m_bits, c->a_bits, c->g_pack.p, (uint32_t)c->late_cap_main, A, P.edge_weight, P.edge_threshold, c->ntype.p, c->edge.p, c->erec.p, c->node_pairs.p, s);
         // ---- a13 vote scan
         mark(c, ST_SCAN);
-        launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->g_vpos, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2, c->hp.p, c->block.p, s);
+        launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->g_vpos, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2, c->hp.p, c->block.p, c->nX ? 2 : 1, s);
         // ---- a14/a15 read correction + export
         mark(c, ST_CORR);
         launch_correction(c->d_cnt, nR, nV, c->rows.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->g_vpos, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, c->node_pairs.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);

@@ -64,14 +64,31 @@ __global__ __launch_bounds__(256) void k_extra_merge(VarView V, ReadView R, ObsV
     int xs = wave_lower_bound(X.pos, 0, X.n, start - 1);
     if (xs < X.n && X.pos[xs] == start - 1 && X.kind[xs] == 2) ++xs;
 
+    // how far the alignment can reach at most: E_j <= start + (reference bases consumed by all operations) + (longest operation).  One pass over
+    // the CIGAR words with no staging; with sparse rows (SVs) most alignments have none below that bound and are done after it.  When the next
+    // row lies within a quarter of the read length the alignment almost surely reaches it: no bound is taken, the walk below ends by itself.
+    int xe = xs < X.n ? X.n : xs;
+    if (xs < X.n && X.pos[xs] - start >= R.l_qseq[r] / 4) {
+        long long cons = 0; int longest = 0;
+        for (int i0 = 0; i0 < n_cig; i0 += LPS_SEG) {
+            uint32_t wv[8];
+            load_ops8(cig + i0, 8 * l, min(LPS_SEG, n_cig - i0), wv);                 // 6u (no length) past the end
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int len = (int)(wv[k] >> 4); cons += len & bit_mask(op_consume_bits(wv[k] & 15u), 0); longest = max(longest, len); }
+        }
+        cons = wave_sum(cons); longest = wave_max(longest);
+        const long long bound = (long long)start + cons + longest;
+        if (bound < 0x7fffffffll) xe = wave_lower_bound(X.pos, xs, X.n, (int)bound);
+    }
+
     int n_emit = 0;
     uint32_t new_off = 0;
-    if (xs < X.n) {
+    if (xs < xe) {
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             int xp = xs, ref_pos = start, q_pos = 0, idx = 0;
 #pragma unroll 1
-            for (int i0 = 0; i0 < n_cig && xp < X.n; i0 += LPS_SEG) {
+            for (int i0 = 0; i0 < n_cig && xp < xe; i0 += LPS_SEG) {
                 const int nseg = min(LPS_SEG, n_cig - i0);
                 uint32_t wv[8]; int my_ref;
                 load_ops8(cig + i0, 8 * l, nseg, wv);
@@ -94,9 +111,9 @@ __global__ __launch_bounds__(256) void k_extra_merge(VarView V, ReadView R, ObsV
                 const int segmax = __shfl(inc, 63);
                 // rows this segment can serve, 64 at a time
 #pragma unroll 1
-                while (xp < X.n) {
+                while (xp < xe) {
                     const int row = xp + l;
-                    const int p = row < X.n ? X.pos[row] : 0x7fffffff;
+                    const int p = row < xe ? X.pos[row] : 0x7fffffff;
                     const bool cand = p < segmax;
                     const int nb = __popcll(__ballot(cand));            // positions are sorted: the candidates are the first nb lanes
                     if (nb == 0) break;

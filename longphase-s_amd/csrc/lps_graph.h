@@ -43,7 +43,7 @@ size_t scan_state_bytes(int n_var);
 int scan_segments(int n_var);
 void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, const int32_t *vpos, const uint8_t *erec,
                       int A, int distance, int8_t *hp_v, int32_t *blk_v, void *st_b, void *st_e, int32_t *seg_i32,
-                      unsigned *n_replayed, int8_t *hp, int32_t *block, hipStream_t s);
+                      unsigned *n_replayed, int8_t *hp, int32_t *block, int warm_tiles, hipStream_t s);
 void launch_correction(LpsCounters *cnt, int n_reads, int n_var, const RowDesc *rows, const int32_t *g_cnt,
                        const int32_t *g_node, const uint8_t *g_flag, const int32_t *nodes, const int32_t *vpos,
                        const int32_t *block, uint32_t *bsize, const int8_t *hp, const uint8_t *ntype, const uint32_t *node_pairs,

@@ -919,14 +919,14 @@ __device__ __forceinline__ unsigned long long tile_gapmask(const int32_t *nodes,
 __global__ __launch_bounds__(64) void k_scan_spec(const LpsCounters *cnt, const int32_t *nodes, const int32_t *vpos,
                                                   const uint8_t *erec, int A, int distance,
                                                   int8_t *hp_v /*[2][N]*/, int32_t *blk_v /*[2][N]*/, size_t vstride,
-                                                  ScanState *st_b /*[seg][2]*/, ScanState *st_e /*[seg][2]*/) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_rec_dyn[];   // [(SCAN_WARM + SCAN_SEG) * A]
+                                                  ScanState *st_b /*[seg][2]*/, ScanState *st_e /*[seg][2]*/, int warm /*multiple of 64*/) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_rec_dyn[];   // [(warm + SCAN_SEG) * A]
     const int l = lane_id();
     const int N = (int)cnt->n_nodes;
     const int seg = blockIdx.x;
     const int b = seg * SCAN_SEG;
     if (b >= N) return;
-    const int a = max(0, b - SCAN_WARM), e = b + SCAN_SEG;          // walk [a, e); results for [b, e)
+    const int a = max(0, b - warm), e = b + SCAN_SEG;               // walk [a, e); results for [b, e)
     const int last = min(e, N - 1);                                 // the last node of a contig is never processed (:308-311)
     {
         // a and e are multiples of 64, so the byte range [a * A, e * A) starts and ends on a 4-byte boundary
@@ -984,9 +984,10 @@ __global__ __launch_bounds__(256) void k_scan_match(const LpsCounters *cnt, cons
 // One wave decides, for every segment, which of its two variants is the true walk and how the id of the block that is open at its start has to
 // be renamed.  With the boundary matches precomputed both are compositions of tiny functions - variant: {0,1} -> {0,1,none matches}, open
 // block: "keep" or "becomes b" - so each lane composes the functions of its own run of segments, the 64 lane results are chained with
-// v_readlane, and each lane replays its run with the true inputs: a few microseconds whatever the number of segments.  Only when a segment
-// has no matching variant on the true path does the wave fall back to walking the segments in order, replaying that segment serially from
-// the true state (records straight from global memory) and comparing states live until the walk is back on stored states.
+// v_readlane, and each lane replays its run with the true inputs: a few microseconds whatever the number of segments.  Where a segment has no
+// matching variant on the true path the composition stops there: the wave replays that segment serially from the true state (records straight
+// from global memory), compares states live until the walk is back on a stored state, and composes again from there - a break costs one
+// segment's walk plus one more composition round, not a serial pass over all segments (one break in 5 000 segments used to cost 2.5 ms).
 __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, const int32_t *nodes, const int32_t *vpos,
                                                     const uint8_t *erec, int A, int distance,
                                                     int8_t *hp_v, int32_t *blk_v, size_t vstride,
@@ -998,55 +999,58 @@ __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, cons
     if (n_seg == 0) return;
     // variant of segment seg that continues variant p of segment seg-1 (2: neither)
     auto next_variant = [](int m, int p) { return ((m >> (p * 2)) & 1) ? 0 : (((m >> (p * 2 + 1)) & 1) ? 1 : 2); };
-    {
-        const int chunk = (n_seg + 63) / 64, s0 = max(1, l * chunk), s1 = min(n_seg, (l + 1) * chunk);
-        int f0 = 0, f1 = 1;                                          // this lane's run of segments as a function of the incoming variant
+    if (l == 0) { chosen[0] = 0; remap_from[0] = -2; remap_to[0] = -2; }     // segment 0 starts at node 0: its variant 0 IS the true walk
+    int seg_lo = 1, v_in = 0, cur_bs = st_e[0].bs;                           // first undecided segment, variant chosen before it, block open at its start
+    Chain t; chain_init(t, 0);
+    while (seg_lo < n_seg) {
+        // ---- composition over [seg_lo, n_seg): lane l owns the run [s0, s1)
+        const int chunk = (n_seg - seg_lo + 63) / 64, s0 = min(n_seg, seg_lo + l * chunk), s1 = min(n_seg, s0 + chunk);
+        int f0 = 0, f1 = 1;                                          // this lane's run as a function of the incoming variant
         for (int seg = s0; seg < s1; ++seg) { const int m = match[seg]; f0 = f0 == 2 ? 2 : next_variant(m, f0); f1 = f1 == 2 ? 2 : next_variant(m, f1); }
-        int vin = 0, v = 0;                                          // segment 0 starts at node 0: its variant 0 IS the true walk
+        int vin = 0, v = v_in, J = 64;                               // J: first lane whose run holds a boundary nothing matches
         for (int j = 0; j < 64; ++j) {
             if (l == j) vin = v;
             const int a0 = __builtin_amdgcn_readlane(f0, j), a1 = __builtin_amdgcn_readlane(f1, j);
-            v = v == 2 ? 2 : (v ? a1 : a0);
+            const int nv = v == 2 ? 2 : (v ? a1 : a0);
+            if (nv == 2 && v != 2) J = j;
+            v = nv;
         }
-        if (v != 2) {                                                // every boundary on the true path has a matching variant
-            int pv = vin, has_set = 0, last_val = 0;                 // open block after this lane's run: kept, or becomes last_val
-            for (int seg = s0; seg < s1; ++seg) {
+        // how far this lane's run is on stored states: all of it before lane J, up to the break inside lane J, nothing behind
+        int lim = l < J ? s1 : s0, pv_end = vin;
+        if (l == J) { int pv = vin; lim = s1; for (int seg = s0; seg < s1; ++seg) { const int mv = next_variant(match[seg], pv); if (mv == 2) { lim = seg; break; } pv = mv; } pv_end = pv; }
+        int has_set = 0, last_val = 0;                               // open block after the run: kept, or becomes last_val
+        {
+            int pv = vin;
+            for (int seg = s0; seg < lim; ++seg) {
                 const int mv = next_variant(match[seg], pv), open_spec = st_b[seg * 2 + mv].bs, end_bs = st_e[seg * 2 + mv].bs;
                 if (end_bs != open_spec) { has_set = 1; last_val = end_bs; }
                 pv = mv;
             }
-            int cin = 0, cb = st_e[0].bs;
-            for (int j = 0; j < 64; ++j) {
-                if (l == j) cin = cb;
-                const int hs = __builtin_amdgcn_readlane(has_set, j), lv = __builtin_amdgcn_readlane(last_val, j);
-                cb = hs ? lv : cb;
-            }
-            pv = vin; int cur = cin;
-            for (int seg = s0; seg < s1; ++seg) {
+        }
+        int cin = 0, cb = cur_bs;
+        for (int j = 0; j < 64; ++j) {
+            if (l == j) cin = cb;
+            const int hs = __builtin_amdgcn_readlane(has_set, j), lv = __builtin_amdgcn_readlane(last_val, j);
+            cb = hs ? lv : cb;                                       // (lanes behind J contribute nothing: their runs are empty here)
+        }
+        {
+            int pv = vin, cur = cin;
+            for (int seg = s0; seg < lim; ++seg) {
                 const int mv = next_variant(match[seg], pv), open_spec = st_b[seg * 2 + mv].bs, end_bs = st_e[seg * 2 + mv].bs;
                 chosen[seg] = mv; remap_from[seg] = open_spec >= 0 ? open_spec : -2; remap_to[seg] = cur;
                 cur = (end_bs == open_spec) ? cur : end_bs;          // the block open at b is still open at e
                 pv = mv;
             }
-            if (l == 0) { chosen[0] = 0; remap_from[0] = -2; remap_to[0] = -2; }
-            return;
         }
-    }
-    int prev_v = 0, cur_bs = st_e[0].bs;
-    bool live = false; Chain t; chain_init(t, 0);
-    if (l == 0) { chosen[0] = 0; remap_from[0] = -2; remap_to[0] = -2; }
-    for (int seg = 1; seg < n_seg; ++seg) {
-        const int b = seg * SCAN_SEG, e = b + SCAN_SEG;
-        int mv = -1;
-        if (!live) { mv = next_variant(match[seg], prev_v); if (mv == 2) mv = -1; }
-        else { if (state_equal(t, b, &st_b[seg * 2 + 0], l)) mv = 0; else if (state_equal(t, b, &st_b[seg * 2 + 1], l)) mv = 1; }
-        if (mv >= 0) {
-            const int open_spec = st_b[seg * 2 + mv].bs, open_true = cur_bs, end_bs = st_e[seg * 2 + mv].bs;
-            if (l == 0) { chosen[seg] = mv; remap_from[seg] = open_spec >= 0 ? open_spec : -2; remap_to[seg] = open_true; }
-            cur_bs = (end_bs == open_spec) ? open_true : end_bs;     // the block open at b is still open at e
-            prev_v = mv; live = false;
-        } else {
-            if (!live) { state_load(t, &st_e[(seg - 1) * 2 + prev_v], l); t.bs = cur_bs; live = true; }
+        if (J == 64) break;                                          // every boundary on the true path had a matching variant
+        // ---- the boundary before segment `seg` matches nothing: walk on from the true state until it is a stored state again
+        int seg = __builtin_amdgcn_readlane(lim, J);
+        const int pv_star = __builtin_amdgcn_readlane(pv_end, J);
+        cur_bs = cb;
+        state_load(t, &st_e[(seg - 1) * 2 + pv_star], l); t.bs = cur_bs;
+        bool resynced = false;
+        while (seg < n_seg && !resynced) {
+            const int b = seg * SCAN_SEG, e = b + SCAN_SEG;
             if (l == 0) { chosen[seg] = 0; remap_from[seg] = -2; remap_to[seg] = -2; atomicAdd(n_replayed, 1u); }
             const int last = min(e, N - 1);
             for (int t0 = b; t0 < e && t0 < N; t0 += SCAN_TILE) {
@@ -1061,7 +1065,18 @@ __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, cons
                 if (t0 + l < N) { hp_v[t0 + l] = (int8_t)t.my_hp; blk_v[t0 + l] = t.my_blk; }
             }
             cur_bs = t.bs;
+            ++seg;
+            if (seg >= n_seg) break;
+            int mv = -1;
+            if (state_equal(t, seg * SCAN_SEG, &st_b[seg * 2 + 0], l)) mv = 0; else if (state_equal(t, seg * SCAN_SEG, &st_b[seg * 2 + 1], l)) mv = 1;
+            if (mv >= 0) {                                           // back on a stored state: this segment is its variant mv
+                const int open_spec = st_b[seg * 2 + mv].bs, end_bs = st_e[seg * 2 + mv].bs;
+                if (l == 0) { chosen[seg] = mv; remap_from[seg] = open_spec >= 0 ? open_spec : -2; remap_to[seg] = cur_bs; }
+                cur_bs = (end_bs == open_spec) ? cur_bs : end_bs;
+                v_in = mv; seg_lo = seg + 1; resynced = true;
+            }
         }
+        if (!resynced) break;                                        // walked to the end
     }
 }
 
@@ -1294,10 +1309,13 @@ __global__ void k_scan_break_matches(int32_t *match, int segs, int every) {
 
 void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, const int32_t *vpos, const uint8_t *erec,
                       int A, int distance, int8_t *hp_v, int32_t *blk_v, void *st_b, void *st_e, int32_t *seg_i32 /*4*segs*/,
-                      unsigned *n_replayed, int8_t *hp, int32_t *block, hipStream_t s) {
+                      unsigned *n_replayed, int8_t *hp, int32_t *block, int warm_tiles, hipStream_t s) {
     const int segs = scan_segments(n_var);
+    // warm-up of the speculative walks: SCAN_WARM nodes as a rule.  With SV / MOD rows in the graph (sparser votes across the SNP<->MOD threshold,
+    // more ties) twice that: 41 of 1 454 boundaries of a chr20-sized graph missed with 64 nodes, none with 128, and a miss costs a 37-us replay
+    const int warm = SCAN_WARM * std::max(1, warm_tiles);
     const size_t vstride = (size_t)n_var + 64;
-    hipLaunchKernelGGL(k_scan_spec, dim3(segs), dim3(64), (size_t)(SCAN_WARM + SCAN_SEG) * A, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (ScanState *)st_b, (ScanState *)st_e);
+    hipLaunchKernelGGL(k_scan_spec, dim3(segs), dim3(64), (size_t)(warm + SCAN_SEG) * A, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (ScanState *)st_b, (ScanState *)st_e, warm);
     hipLaunchKernelGGL(k_scan_match, dim3((segs + 3) / 4), dim3(256), 0, s, cnt, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs);
     if (const char *e = getenv("LPS_SCAN_FORCE_REPLAY")) { const int every = atoi(e); if (every > 0) hipLaunchKernelGGL(k_scan_break_matches, GRID(segs, 256), 0, s, seg_i32 + 3 * segs, segs, every); }
     hipLaunchKernelGGL(k_scan_stitch, dim3(1), dim3(64), 0, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, n_replayed);

@@ -157,6 +157,16 @@ class ExtraVariants:
                                    _ptr(self.mod_name), _ptr(self.mod_flag), sv_window, 0, sv_threshold)
 
 
+def extra_from_arrays(sv_pos, sv_len, mod_pos, mod_off, mod_name, mod_flag, sv_window=20, sv_threshold=0.1):
+    """ExtraVariants from flat arrays (large tables: no per-row Python lists)."""
+    x = ExtraVariants.__new__(ExtraVariants)
+    x.sv_pos = np.ascontiguousarray(sv_pos, np.int32); x.sv_len = np.ascontiguousarray(sv_len, np.int32); x.mod_pos = np.ascontiguousarray(mod_pos, np.int32)
+    x.mod_off = np.ascontiguousarray(mod_off, np.uint64); x.mod_name = np.ascontiguousarray(mod_name, np.uint32); x.mod_flag = np.ascontiguousarray(mod_flag, np.uint8)
+    x.n_sv = int(x.sv_pos.size); x.n_mod = int(x.mod_pos.size)
+    x.c = ExtraVariantTable(x.n_sv, _ptr(x.sv_pos), _ptr(x.sv_len), x.n_mod, _ptr(x.mod_pos), _ptr(x.mod_off), _ptr(x.mod_name), _ptr(x.mod_flag), sv_window, 0, sv_threshold)
+    return x
+
+
 class Reads:
     """Host-side SoA read batch."""
 

@@ -217,3 +217,46 @@ def write_mod_vcf(path, chrom, lines, contig_len, gt=None):
             g = "0/1" if gt is None else gt[i]
             f.write("%s\t%d\t.\t%s\t<MOD>\t.\tPASS\tRS=%s;MR=%s;NR=%s;\tGT:MD:UD\t%s:%d:%d\n"
                     % (chrom, q + 1, "G" if rev else "C", "N" if rev else "P", mr, nr, g, sum(1 for _, m in reads if m), sum(1 for _, m in reads if not m)))
+
+
+def make_extras_fast(h, mod_every=2000.0, sv_every=150000.0, seed=0, noise=0.1, listed=0.9):
+    """SV and MOD rows for a large generated contig (host arrays of Synth or SynthGpu.to_host()): -> (sv_pos, sv_len, mod_pos, mod_off, mod_name,
+    mod_flag) ready for lps_extra_variants.  One record per MOD row, reads of the record's strand, modified on one haplotype (with noise); the SV
+    rows are not carried by any read (every spanning read is called REF).  Positions keep 3 bp away from the SNP rows and from each other."""
+    g = np.random.default_rng(seed)
+    end = read_ref_end(h)
+    start = h.ref_start.astype(np.int64)
+    rev = (h.flag & 0x10) != 0
+    taken = np.asarray(h.var_pos, np.int64)
+
+    def free(p):
+        i = np.searchsorted(taken, p - 3)
+        return i >= taken.size or taken[i] > p + 3
+
+    sv_pos, sv_len, x = [], [], 5000.0
+    while x < h.contig_len - 5000:
+        p = int(x); x += 2000 + g.exponential(sv_every)
+        if free(p):
+            sv_pos.append(p); sv_len.append(int(g.integers(50, 800)) * (1 if g.random() < 0.5 else -1))
+    sv_set = set(sv_pos)
+    reach = int((end - start).max()) + 1
+    mod_pos, off, names, flags = [], [0], [], []
+    x = 500.0 + g.exponential(mod_every)
+    while x < h.contig_len - 500:
+        q = int(x); x += 10 + g.exponential(mod_every)
+        if not free(q) or any((q + d) in sv_set for d in (-2, -1, 0, 1, 2)):
+            continue
+        lo, hi = np.searchsorted(start, q - reach, side="left"), np.searchsorted(start, q, side="right")
+        idx = lo + np.nonzero(end[lo:hi] > q)[0]
+        strand = bool(g.random() < 0.5)
+        idx = idx[(rev[idx] == strand) & (g.random(idx.size) < listed)]
+        if idx.size == 0:
+            continue
+        hap = int(g.integers(2))
+        modified = (h.read_hap[idx] == hap) != (g.random(idx.size) < noise)
+        nid, first = np.unique(h.name_id[idx], return_index=True)     # a name once per row
+        mod_pos.append(q)
+        names.append(nid.astype(np.uint32)); flags.append((modified[first].astype(np.uint8)) | (2 if strand else 0))
+        off.append(off[-1] + nid.size)
+    cat = lambda a, t: np.concatenate(a).astype(t) if a else np.zeros(0, t)
+    return (np.array(sv_pos, np.int32), np.array(sv_len, np.int32), np.array(mod_pos, np.int32), np.array(off, np.uint64), cat(names, np.uint32), cat(flags, np.uint8))

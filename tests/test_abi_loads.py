@@ -11,7 +11,7 @@ def test_library_exports_all_declared_symbols():
     assert len(syms) >= 15
     for s in syms:
         assert hasattr(L, s), s
-    assert L.lps_abi_version() == 10
+    assert L.lps_abi_version() == 11
 
 
 def test_default_params_match_reference_defaults():
@@ -26,5 +26,6 @@ def test_default_params_match_reference_defaults():
 def test_struct_sizes_match_header():
     """ctypes mirrors must have the sizes the C side was compiled with."""
     L = hip.load()
-    for which, st in enumerate((abi.Params, abi.VariantTable, abi.ReadBatch, abi.PhaseResult, abi.HaplotagResult, abi.Timings, abi.SomaticTagResult, abi.SiteCounters, abi.TumorExtractResult)):
+    for which, st in enumerate((abi.Params, abi.VariantTable, abi.ReadBatch, abi.PhaseResult, abi.HaplotagResult, abi.Timings, abi.SomaticTagResult, abi.SiteCounters, abi.TumorExtractResult,
+                                abi.ExtraVariantTable)):
         assert L.lps_struct_size(which) == C.sizeof(st), st.__name__

@@ -55,8 +55,8 @@ def test_phase_matches_oracle_and_golden(name):
         ctx.close()
 
 
-@pytest.mark.parametrize("every", [1, 3])
-@pytest.mark.parametrize("name", ["snp_ont_seed2", "cnv_many"])
+@pytest.mark.parametrize("every", [1, 2, 3, 7, 29])
+@pytest.mark.parametrize("name", ["snp_ont_seed2", "cnv_many", "cnv_64"])
 def test_vote_scan_serial_replay_path(name, every, monkeypatch):
     """k_scan_stitch's fallback: boundaries declared unmatched (LPS_SCAN_FORCE_REPLAY) are replayed serially from the true state -
     the votes and the result must not change."""

@@ -53,6 +53,31 @@ def test_chr20_30x_every_stage_host_push():
         check_haplotag(ctx, P, V, out, h.ref, R, "chr20_30x")
 
 
+@pytest.mark.parametrize("every", [2, 13, 97, 400])
+def test_chr20_30x_vote_scan_with_unmatched_boundaries(every, monkeypatch):
+    """~950 speculative scan segments of which every `every`-th boundary is declared unmatched: k_scan_stitch composes up to the break, replays
+    that segment from the true state, composes on - votes, blocks and the result stay those of the oracle; and a handful of breaks must not cost
+    a serial pass over all segments."""
+    g = SynthGpu(0, **CHR20_30X)
+    h = g.to_host(); g.close()
+    V = abi.Variants.from_snps(h.var_pos, h.var_ref0, h.var_alt0); R = abi.Reads.from_synth(h)
+    P = abi.default_params()
+    want, d = lps_oracle.phase(P, V, h.ref, R, dump=True)
+    with hip.Context(0, P) as ctx:
+        monkeypatch.setenv("LPS_SCAN_FORCE_REPLAY", str(every))
+        out = ctx.phase(V, h.ref, R)
+        tm = ctx.timings()
+        assert tm["n_scan_replayed"] >= tm["n_scan_segments"] // every - 1
+        hp, blk = ctx.dump_votes()
+        N = d.c.n_nodes
+        assert np.array_equal(hp, d.node_hp[:N]) and np.array_equal(blk, d.node_block[:N]), "vote scan differs"
+        util.assert_phase_equal(out.phase_set, out.gt, want.phase_set, want.gt, f"every {every}")
+        ctx.L.lps_set_stage_timing(ctx.h, 2); ctx.run_phase(); tm = ctx.timings()
+        print(f"every {every}: {tm['n_scan_replayed']} of {tm['n_scan_segments']} segments replayed, vote_scan {tm['stages']['vote_scan']:.3f} ms")
+        if every >= 97:
+            assert tm["stages"]["vote_scan"] < 0.6
+
+
 def test_contig_160mb_50x_every_stage_device_push():
     """One 50x contig of the whole-genome configs through lps_push_reads_device (arrays generated in HBM), every stage dump compared."""
     g = SynthGpu(0, **CONTIG_50X)
@@ -71,6 +96,38 @@ def test_contig_160mb_50x_every_stage_device_push():
         util.assert_phase_equal(out.phase_set, out.gt, want.phase_set, want.gt, "160 Mb 50x vs oracle")
         assert tm["n_scan_segments"] > 3000 and tm["n_obs"] > 8_000_000
         check_haplotag(ctx, P, V, out, h.ref, R, "160 Mb 50x")
+
+
+def test_chr20_30x_with_sv_and_mod_rows():
+    """configs[1] with ~30 000 modcall rows and ~400 SV rows co-phased (`--sv-file --mod-file`): every stage in indices of the union table, the
+    three results; then the same from arenas that cannot hold the merged rows."""
+    from lps.synth import make_extras_fast
+    g = SynthGpu(0, **CHR20_30X)
+    h = g.to_host(); g.close()
+    V = abi.Variants.from_snps(h.var_pos, h.var_ref0, h.var_alt0); R = abi.Reads.from_synth(h)
+    X = abi.extra_from_arrays(*make_extras_fast(h, seed=7))
+    assert X.n_mod > 25_000 and X.n_sv > 300
+    P = abi.default_params()
+    want, wsv, wmod, d = lps_oracle.phase_x(P, V, X, h.ref, R, dump=True)
+    assert (wmod.phase_set != 0).sum() > 0.8 * X.n_mod             # (no generated read carries the SV rows: they are served, called REF, and stay unphased)
+    with hip.Context(0, P) as ctx:
+        ctx.load_chromosome(V, h.ref, R)
+        ctx.set_extra(X)
+        for call in range(2):
+            if call == 1:
+                ctx._check(ctx.L.lps_debug_set_obs_capacity(ctx.h, int(d.c.n_obs) // 2), "lps_debug_set_obs_capacity")
+            out = ctx.run_phase()
+            util.assert_stages_equal(ctx, d, f"chr20_30x + SV/MOD rows, call {call}")
+            gsv, gmod = ctx.extra_result()
+            util.assert_phase_equal(out.phase_set, out.gt, want.phase_set, want.gt, "SNP rows")
+            util.assert_phase_equal(gsv.phase_set, gsv.gt, wsv.phase_set, wsv.gt, "SV rows")
+            util.assert_phase_equal(gmod.phase_set, gmod.gt, wmod.phase_set, wmod.gt, "MOD rows")
+        ctx.L.lps_set_stage_timing(ctx.h, 2)
+        ctx.run_phase()
+        tm = ctx.timings()
+        with_rows = tm["stages"]["extract"]
+        ctx.set_extra(None); ctx.run_phase()
+        print(f"extract stage: {ctx.timings()['stages']['extract']:.3f} ms without, {with_rows:.3f} ms with {X.n_mod} MOD + {X.n_sv} SV rows served and merged; whole step {tm['ms_total']:.3f} ms")
 
 
 def test_chr20_30x_with_clip_pile_ups_cnv_filter_active():
