@@ -1,6 +1,7 @@
 // cli_vcf.h — text inputs of longphase_amd: VCF row selection (SnpParser / VcfParser restatements), FASTA, and the phased-VCF rewriter.
 #pragma once
 #include "cli_common.h"
+#include <limits>
 
 // ------------------------------------------------------------------------------------------------ text inputs
 static bool read_lines(const std::string &path, std::vector<std::string> &lines) {   // plain or gzip text
@@ -76,6 +77,56 @@ static void read_fasta(const std::string &path, const std::map<std::string, ChrV
             continue;
             }
         if (dst) { if (!ln.empty() && ln.back() == '\r') ln.pop_back(); dst->append(ln); }
+    }
+}
+
+// SnpParser::preprocessDeepsomaticVCF (ParsingBam.cpp:651-835), `phase --deepsomatic_output`: keeps the records whose FILTER holds GERMLINE and
+// rewrites their GT to the unphased diploid genotype whose expected allele fractions (1 / 0.5+0.5) lie closest, in squared error, to the observed
+// ones - AD when it has one count per allele and a positive sum, else 1 - sum(VAF) and the VAF values.  Header lines pass through.
+static void preprocess_deepsomatic(const std::vector<std::string> &in, std::vector<std::string> &out) {
+    for (const std::string &line : in) {
+        if (line.compare(0, 1, "#") == 0) { out.push_back(line); continue; }
+        std::istringstream iss(line);
+        std::vector<std::string> f((std::istream_iterator<std::string>(iss)), std::istream_iterator<std::string>());
+        if (f.size() < 10) continue;
+        if (f[6].find("GERMLINE") == std::string::npos) continue;
+        auto split = [](const std::string &s, char d) { std::vector<std::string> v; std::istringstream ss(s); std::string x; while (std::getline(ss, x, d)) v.push_back(x); return v; };
+        const std::vector<std::string> fmt = split(f[8], ':'); std::vector<std::string> smp = split(f[9], ':');
+        int vaf_i = -1, gt_i = -1, ad_i = -1;
+        for (int i = 0; i < (int)fmt.size(); ++i) { if (fmt[i] == "VAF") vaf_i = i; if (fmt[i] == "GT") gt_i = i; if (fmt[i] == "AD") ad_i = i; }
+        if (gt_i >= 0 && gt_i < (int)smp.size()) {
+            int alt_count = 0;
+            if (!f[4].empty() && f[4] != ".") for (const std::string &t : split(f[4], ',')) if (!t.empty()) ++alt_count;
+            const int n_allele = alt_count + 1;
+            std::vector<double> obs; bool have = false;
+            if (ad_i >= 0 && ad_i < (int)smp.size()) {
+                std::vector<long long> ad; long long sum = 0;
+                for (const std::string &t : split(smp[ad_i], ',')) { long long v = 0; if (!(t == "." || t.empty())) { try { v = std::stoll(t); } catch (...) { v = 0; } } ad.push_back(v); }
+                for (long long v : ad) sum += v;
+                if (sum > 0 && (int)ad.size() == n_allele) { for (long long v : ad) obs.push_back((double)v / (double)sum); have = true; }
+            }
+            if (!have && vaf_i >= 0 && vaf_i < (int)smp.size()) {
+                std::vector<double> vafs;
+                for (const std::string &t : split(smp[vaf_i], ',')) { if (t == "." || t.empty()) continue; try { vafs.push_back(std::stod(t)); } catch (...) {} }
+                if (alt_count == (int)vafs.size() && alt_count >= 1) {
+                    double sum = 0.0; for (double v : vafs) sum += v;
+                    obs.clear(); obs.push_back(std::max(0.0, 1.0 - sum)); for (double v : vafs) obs.push_back(v);
+                    have = true;
+                }
+            }
+            if (have && n_allele >= 1) {
+                int best_a = 0, best_b = 0; double best = std::numeric_limits<double>::infinity();
+                for (int a = 0; a < n_allele; ++a) for (int b = a; b < n_allele; ++b) {
+                    double cost = 0.0;
+                    for (int i = 0; i < n_allele; ++i) { const double e = (a == b) ? (i == a ? 1.0 : 0.0) : ((i == a || i == b) ? 0.5 : 0.0); const double d = obs[(size_t)i] - e; cost += d * d; }
+                    if (cost < best) { best = cost; best_a = a; best_b = b; }
+                }
+                smp[(size_t)gt_i] = std::to_string(best_a) + "/" + std::to_string(best_b);
+                f[9].clear(); for (size_t i = 0; i < smp.size(); ++i) { if (i) f[9] += ":"; f[9] += smp[i]; }
+            }
+        }
+        std::string o; for (size_t i = 0; i < f.size(); ++i) { if (i) o += "\t"; o += f[i]; }
+        out.push_back(o);
     }
 }
 

@@ -7,7 +7,8 @@
 //   per-chromosome driver                     src/phase/PhasingProcess.cpp:113-173   (the hot path is one lps_phase_chromosome call)
 //   SnpParser::writeLine (VCF rewrite rules)  src/phase/ParsingBam.cpp:460-635
 //   SVParser / METHParser (--sv-file, --mod-file) src/phase/ParsingBam.cpp:915-1206, 1647-1952   (cli_extra.h)
-// Not supported (the reference path must be used): --dot, --deepsomatic_output, CRAM.
+//   SnpParser::preprocessDeepsomaticVCF (--deepsomatic_output) src/phase/ParsingBam.cpp:651-835, PhasingProcess.cpp:47-61
+// Not supported (the reference path must be used): --dot, CRAM.
 // Split in round 2: cli_common.h (loader), cli_bam.h (BGZF/BAM in, BGZF out), cli_vcf.h (VCF/FASTA in, phased VCF out), cli_purity.h (purity estimator).
 #include "cli_common.h"
 #include "cli_bam.h"
@@ -21,6 +22,7 @@ static const char *kUsage =
     "   -s, --snp-file=NAME   -b, --bam-file=NAME (repeatable)   -r, --reference=NAME   -o, --out-prefix=NAME (result)   -t, --threads=Num (1)\n"
     "   --ont | --pb   --indels   -q MAPQ(1)  -p baseQuality(12)  -e edgeWeight(0.1)  -a connectAdjacent(35)  -d distance(300000)\n"
     "   -1 edgeThreshold(0.7)  -L overlapThreshold(0.2)  -m readConfidence(0.65)  -n snpConfidence(0.75)  --gpu=ID (0)\n"
+    "   --deepsomatic_output   the SNP file is a DeepSomatic VCF: keep FILTER=GERMLINE records, genotype them from AD / VAF (writes <prefix>_preprocessed.vcf)\n"
     "   --sv-file=NAME  --mod-file=NAME   co-phase structural variants / modcall records (outputs <prefix>_SV.vcf, <prefix>_mod.vcf)   -w svWindow(20)  -h svThreshold(0.1)\n"
     "   --host-inflate | --gpu-inflate   BGZF inflate with zlib on the -t host threads / on the GPU (default: GPU for one BAM of 256 MiB or more)\n"
     "   --no-index       ignore <bam>.bai: make the whole file resident on the GPU instead of one contig at a time\n"
@@ -33,7 +35,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<std::string> bams;
     int threads = 1, gpu = 0, n_gpus = 1, sv_window = 20; double sv_threshold = 0.1;
     uint64_t group_bytes = 8ull << 30;
-    bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false;
+    bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false, deepsomatic = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -79,7 +81,8 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "--gpu-inflate") gpu_inflate = true;
         else if (a == "--no-index") no_index = true;
         else if (a == "--help") { std::cout << kUsage; return 0; }
-        else if (a == "--dot" || a == "--deepsomatic_output" || a == "--indelQuality") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
+        else if (a == "--deepsomatic_output") deepsomatic = true;
+        else if (a == "--dot" || a == "--indelQuality") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kUsage; return 1; }
     }
     if (!sv_file.empty()) {                                             // Phasing.cpp:304-318
@@ -97,6 +100,12 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     const double t_begin = now();
     std::vector<std::string> vcf_lines;
     if (!read_lines(snp, vcf_lines)) die("ERROR: Cannot open vcf file " + snp);
+    if (deepsomatic) {                                                  // PhasingProcess.cpp:47-61: the filtered, re-genotyped copy IS the SNP file from here on
+        std::vector<std::string> pre; preprocess_deepsomatic(vcf_lines, pre);
+        std::ofstream o(prefix + "_preprocessed.vcf"); if (!o) die("Fail to open output VCF: " + prefix + "_preprocessed.vcf");
+        for (const std::string &l : pre) o << l << "\n";
+        vcf_lines.swap(pre);
+    }
     std::vector<std::string> chr_order; std::map<std::string, ChrVariants> vars;
     parse_vcf(vcf_lines, indels, chr_order, vars);
     // SV rows, then MOD rows: each reader drops what sits on a row of the tables read before it (PhasingProcess.cpp:69-79)

@@ -420,8 +420,58 @@ def make_cli_extra():
     print("cli_extra", n)
 
 
+def make_cli_deepsomatic():
+    """`phase --deepsomatic_output` of the reference on a DeepSomatic-style copy of the tiny_snp VCF: FILTER values with and without GERMLINE,
+    GT:GQ:AD:VAF samples whose AD / VAF say something else than the GT, multi-allelic records, AD with the wrong number of counts or missing
+    values (VAF fallback), records with neither.  (Tokens htslib cannot parse are left out: its reader stops at such a record.)"""
+    src = [l.rstrip("\n") for l in open(os.path.join(HERE, "data", "tiny_snp.vcf"))]
+    out = []
+    k = 0
+    for l in src:
+        if l.startswith("##FORMAT=<ID=GQ"):
+            out += [l, '##FORMAT=<ID=AD,Number=R,Type=Integer,Description="Allelic depths">', '##FORMAT=<ID=VAF,Number=A,Type=Float,Description="Variant allele fractions">',
+                    '##FILTER=<ID=GERMLINE,Description="Germline">', '##FILTER=<ID=RefCall,Description="Reference call">']
+            continue
+        if l.startswith("#"):
+            out.append(l); continue
+        f = l.split("\t"); k += 1
+        f[6] = ["GERMLINE", "PASS", "GERMLINE", "RefCall", "GERMLINE;LowQ"][k % 5]
+        f[8] = "GT:GQ:AD:VAF"
+        case = k % 11
+        if case == 0: smp = "1/1:30:14,15:0.52"               # AD says het
+        elif case == 1: smp = "0/1:30:1,29:0.97"              # AD says hom ALT (dropped by the SNP reader afterwards)
+        elif case == 2: smp = "0/1:30:.:0.47"                 # no AD: VAF
+        elif case == 3: smp = "0/0:30:12,.:0.55"              # missing count -> 0; sum > 0, two counts: AD used (12, 0) -> 0/0
+        elif case == 4: smp = "0/1:30:10,9,1:0.45"            # three counts for two alleles: VAF fallback
+        elif case == 5: smp = "1/0:30:16,14:."                # AD het, VAF missing
+        elif case == 6: smp = "0/1:30:0,0:."                  # nothing usable: GT kept
+        elif case == 7: f[4] = f[4] + ",G" if f[4] != "G" else f[4] + ",T"; smp = "0/1:30:2,14,13:0.48,0.45"      # multi-allelic, 1/2
+        elif case == 8: f[4] = f[4] + ",G" if f[4] != "G" else f[4] + ",T"; smp = "1/2:30:.:0.5,0.02"             # multi-allelic by VAF -> 0/1
+        elif case == 9: f[8] = "GT:GQ"; smp = "0/1:30"        # neither AD nor VAF
+        else: smp = "0/1:30:15,15:0.5"
+        f[9] = smp
+        out.append("\t".join(f))
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "ds.vcf"), "w").write("\n".join(out) + "\n")
+        with gzip.open(os.path.join(HERE, "data", "tiny_snp.sam.gz"), "rt") as fi:
+            open(os.path.join(d, "reads.sam"), "w").write(fi.read())
+        shutil.copy(os.path.join(HERE, "data", "tiny_snp.fa"), os.path.join(d, "ref.fa"))
+        subprocess.check_call([TEST_VIEW, "-b", "-x", "reads.bam.bai", "-p", "reads.bam", "reads.sam"], cwd=d, stdout=subprocess.DEVNULL)
+        r = subprocess.run([REF_BIN, "phase", "-s", "ds.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", "1", "-o", "out", "--ont", "--deepsomatic_output"], cwd=d, capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            raise RuntimeError(f"reference failed rc={r.returncode}: {r.stderr[-2000:]}")
+        for fn in ("ds.vcf", "out_preprocessed.vcf", "out.vcf"):
+            with open(os.path.join(d, fn), "rb") as fi, gzip.GzipFile(os.path.join(HERE, "data", "cli_deepsomatic." + fn + ".gz"), "wb", mtime=0) as fo:
+                shutil.copyfileobj(fi, fo)
+        n = sum(1 for l in open(os.path.join(d, "out.vcf")) if not l.startswith("#") and "|" in l.split("\t")[9])
+        print("cli_deepsomatic: records kept", sum(1 for l in open(os.path.join(d, "out_preprocessed.vcf")) if not l.startswith("#")), "phased", n)
+
+
 def main():
     assert os.path.exists(REF_BIN), "build the reference first: oracle/build_ref.sh"
+    if "--cli-deepsomatic" in sys.argv:
+        make_cli_deepsomatic()
+        return
     if "--cli-extra" in sys.argv:
         make_cli_extra()
         return

@@ -56,3 +56,16 @@ def test_phase_without_gpu_fails_loudly(tmp_path):
                         "-o", str(tmp_path / "o"), "--ont"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "no CPU fallback" in r.stderr
     assert not os.path.exists(str(tmp_path / "o.vcf"))
+
+
+def test_deepsomatic_preprocessing_matches_reference(tmp_path):
+    """`phase --deepsomatic_output` (SnpParser::preprocessDeepsomaticVCF, src/phase/ParsingBam.cpp:651-835): the filtered, re-genotyped VCF is
+    written before any GPU work - the reference binary's <prefix>_preprocessed.vcf byte for byte (AD / VAF fallbacks, multi-allelic records,
+    unparsable counts).  tests/test_cli_phase_gpu.py checks the phased VCF that follows from it."""
+    import gzip
+    d = str(tmp_path)
+    open(d + "/ds.vcf", "w").write(gzip.open(os.path.join(DATA, "cli_deepsomatic.ds.vcf.gz"), "rt").read())
+    write_bam(os.path.join(DATA, "tiny_snp.sam.gz"), d + "/r.bam")
+    subprocess.run([CLI, "phase", "-s", "ds.vcf", "-b", "r.bam", "-r", os.path.join(DATA, "tiny_snp.fa"), "-o", "o", "--ont", "--deepsomatic_output"],
+                   cwd=d, capture_output=True, text=True, timeout=120)
+    assert open(d + "/o_preprocessed.vcf").read() == gzip.open(os.path.join(DATA, "cli_deepsomatic.out_preprocessed.vcf.gz"), "rt").read()

@@ -35,6 +35,21 @@ def test_cli_phase_matches_reference_vcf(name, inflate, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_phase_deepsomatic_output(tmp_path):
+    """--deepsomatic_output: <prefix>_preprocessed.vcf and the phased VCF written from it equal the reference's."""
+    import gzip
+    d = str(tmp_path)
+    open(d + "/ds.vcf", "w").write(gzip.open(os.path.join(DATA, "cli_deepsomatic.ds.vcf.gz"), "rt").read())
+    write_bam(os.path.join(DATA, "tiny_snp.sam.gz"), d + "/r.bam")
+    r = subprocess.run([CLI, "phase", "-s", "ds.vcf", "-b", "r.bam", "-r", os.path.join(DATA, "tiny_snp.fa"), "-o", "o", "--ont", "--deepsomatic_output"],
+                       cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert open(d + "/o_preprocessed.vcf").read() == gzip.open(os.path.join(DATA, "cli_deepsomatic.out_preprocessed.vcf.gz"), "rt").read()
+    strip = lambda t: [l for l in t.split("\n") if not l.startswith("##commandline=") and not l.startswith("##longphaseVersion=")]
+    assert strip(open(d + "/o.vcf").read()) == strip(gzip.open(os.path.join(DATA, "cli_deepsomatic.out.vcf.gz"), "rt").read())
+
+
+@pytest.mark.gpu
 def test_cli_rewrites_previously_phased_vcf(tmp_path):
     """Feeding the reference's own phased output back in (old PS keys, phased GTs) must reproduce it: exercises the
     PS strip / GT un-phase rules of SnpParser::writeLine (src/phase/ParsingBam.cpp:505-571)."""
