@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
         __threadfence_block(); wave_sync();
     }
     for (uint32_t e0 = off; e0 < end; e0 += 64) {
-        const int nb = (int)min(64u, end - e0);
+        const int nb = __builtin_amdgcn_readfirstlane((int)min(64u, end - e0));      // wave-uniform: the loops over it run on the scalar unit
         uint32_t my_val = 0, my_end = 0;
         if (short_list) {
             unsigned long long key = ~0ull; uint32_t v0 = 0, x0 = 0;
@@ -718,45 +718,45 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
         if (l < nb) pairs += (unsigned long long)min((uint32_t)A, my_end - my_val - 1u);
         // merged rows of several alignments (tail arena) are the only ones that can hold a node twice inside the window
         const bool any_multi = __ballot(l < nb && my_val >= tail_lo) != 0ull;
-        // the t-th read's following observations: requested one read ahead, so that the loads of read t+1 are in flight while read t is applied
+        // the t-th read's following observations: requested one read ahead, so that the loads of read t+1 are in flight while read t is applied.
+        // Read t's (first slot, end, source flag) come out of their lane by v_readlane (t is uniform): no LDS round trip, no wait
         uint32_t cur;
-        { const uint32_t idx = __shfl(my_val, 0), rend = __shfl(my_end, 0); const uint32_t e2 = idx + 1 + l; cur = (l < A && e2 < rend) ? g_pack[e2] : 0xffffffffu; }
+        { const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_val, 0), rend = (uint32_t)__builtin_amdgcn_readlane((int)my_end, 0);
+          const uint32_t e2 = idx + 1 + l; cur = (l < A && e2 < rend) ? g_pack[e2] : 0xffffffffu; }
         for (int t = 0; t < nb; ++t) {
             uint32_t nxt = 0xffffffffu;
-            if (t + 1 < nb) { const uint32_t idx = __shfl(my_val, t + 1), rend = __shfl(my_end, t + 1); const uint32_t e2 = idx + 1 + l; if (l < A && e2 < rend) nxt = g_pack[e2]; }
-            const int sf = __shfl(my_sf, t);
-            const bool in_row = cur != 0xffffffffu;
+            if (t + 1 < nb) {
+                const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_val, t + 1), rend = (uint32_t)__builtin_amdgcn_readlane((int)my_end, t + 1);
+                const uint32_t e2 = idx + 1 + l; if (l < A && e2 < rend) nxt = g_pack[e2];
+            }
+            const int sf = __builtin_amdgcn_readlane(my_sf, t);
             const int n2 = (int)(cur & 0x3fffffffu), f2 = (int)(cur >> 30);
             const int d = n2 - i;
-            const bool ok = in_row && d >= 1 && d <= A;
+            const bool ok = cur != 0xffffffffu && d >= 1 && d <= A;
             const int cell = ((sf & 1) << 1) | (f2 & 1);
-            const bool hi = (sf & 2) && (f2 & 2);
-            const int payload = ok ? (1 | (cell << 1) | ((int)hi << 3)) : 0;
-            bool dups = false;
+            const int hi = (sf & f2 & 2) << 2;                          // both observations of high quality -> bit 3
+            const int payload = 1 | (cell << 1) | hi;
+            // the same node twice inside the window (overlapping alignments of one read, neighbours in the position-sorted row): the second
+            // occurrence is applied in a second round, after the first - window order, as the reference's pair loop goes
+            int round_of = 0, rounds = 1;
             if (any_multi) {
-                const int dprev = __shfl_up(d, 1);
-                const bool okprev = __shfl_up((int)ok, 1) != 0;
-                dups = __ballot(ok && l > 0 && okprev && dprev == d) != 0ull;
+                for (int s = 1; s < 64; ++s) {
+                    const int dprev = __shfl_up(d, s); const bool okprev = __shfl_up((int)ok, s) != 0;
+                    const bool same = ok && l >= s && okprev && dprev == d && round_of == s - 1;
+                    if (!__ballot(same)) break;
+                    if (same) round_of = s;
+                    rounds = s + 1;
+                }
             }
-            if (!dups) {
-                // lanes without a contribution push to lane 63, which owns no target (A <= 63)
-                const int recv = __builtin_amdgcn_ds_permute((ok ? (d - 1) : 63) << 2, payload);
-                if (l < A && (recv & 1)) {
+            for (int rd = 0; rd < rounds; ++rd) {
+                // lanes without a contribution in this round push to lane 63, which owns no target (A <= 63)
+                const bool mine = ok && round_of == rd;
+                const int recv = __builtin_amdgcn_ds_permute((mine ? (d - 1) : 63) << 2, mine ? payload : 0);
+                if (recv & 1) {
                     const int c = (recv >> 1) & 3; const bool h = (recv >> 3) & 1;
                     const float x = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
                     const float nx = edge_upd(x, h, edge_weight);
                     a0 = c == 0 ? nx : a0; a1 = c == 1 ? nx : a1; a2 = c == 2 ? nx : a2; a3 = c == 3 ? nx : a3;
-                }
-            } else {
-                // the same node twice inside the window (overlapping alignments of one read): apply in window order
-                for (int tt = 0; tt < A; ++tt) {
-                    const int pd = __shfl(d, tt), pp = __shfl(payload, tt);
-                    if ((pp & 1) && l == pd - 1) {
-                        const int c = (pp >> 1) & 3; const bool h = (pp >> 3) & 1;
-                        const float x = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
-                        const float nx = edge_upd(x, h, edge_weight);
-                        a0 = c == 0 ? nx : a0; a1 = c == 1 ? nx : a1; a2 = c == 2 ? nx : a2; a3 = c == 3 ? nx : a3;
-                    }
                 }
             }
             cur = nxt;
