@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 11
+#define LPS_ABI_VERSION 12
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -330,6 +330,11 @@ int lps_set_stage_timing(lps_ctx *ctx, int level);
 int lps_phase_chromosome(lps_ctx *ctx, lps_phase_result *out);
 /* haplotag: per-read scoring of the reads pushed so far against the phased table. */
 int lps_haplotag_chromosome(lps_ctx *ctx, lps_haplotag_result *out);
+/* judgeSVHap (src/haplotag/HaplotagStrategy.cpp:220-226), `haplotag --sv-file --mod-file`: the votes a read brings along from the phased SV / MOD
+ * files - one per record that lists the read's name under RNAMES= / MR= (src/haplotag/HaplotagVcfParser.cpp:403-468), for the haplotype the
+ * record's GT puts ALT on - are added to hpCount[H1] / hpCount[H2] of every scored alignment before judgeReadHap.  h1 / h2: one entry per pushed
+ * alignment, in push order (NULL, NULL = none).  Call after the reads are pushed; the arrays are copied and dropped by lps_begin_chromosome. */
+int lps_set_read_votes(lps_ctx *ctx, const int32_t *h1, const int32_t *h2, int64_t n_reads);
 /* somatic_haplotag tagging pass over the (tumor) reads pushed so far against the merged normal+tumor table. */
 int lps_somatic_tag_chromosome(lps_ctx *ctx, lps_somatic_tag_result *out);
 /* somatic_haplotag pass 1: the NORMAL sample's reads (pushed so far) counted at the tumor-VCF positions. */

@@ -4,6 +4,7 @@
 #pragma once
 #include "cli_common.h"
 #include "cli_vcf.h"
+#include <array>
 
 static std::vector<std::string> split_space(const std::string &s) {      // the reference tokenises on any white space (istream_iterator)
     std::istringstream iss(s);
@@ -124,4 +125,27 @@ static void write_mod_vcf(const std::vector<std::string> &lines, const std::stri
         if (rc == res.end() || mc == mod.chr.end() || !mc->second.count(rep)) return nullptr;
         auto it = rc->second.find(rep); return it == rc->second.end() ? nullptr : &it->second;
     });
+}
+
+// `haplotag --sv-file / --mod-file` (src/haplotag/HaplotagVcfParser.cpp:269-300, 403-468): every phased heterozygous record of the file gives one
+// vote to each read it lists - under RNAMES= in a SV file, under MR= in a modcall file - for the haplotype its GT puts ALT on (0|1: haplotype 2,
+// 1|0: haplotype 1).  One table for all chromosomes, keyed by read name (VCF_Info::readSVHapCount); judgeSVHap adds it to the read's counts.
+typedef std::unordered_map<std::string, std::array<int32_t, 2>> ReadVotes;
+static void parse_read_votes(const std::vector<std::string> &lines, const char *key, ReadVotes &votes) {
+    int hap = -1;                                                       // the reference leaves it unset for a GT other than 0|1 / 1|0: what the previous record left
+    for (const std::string &in : lines) {
+        if (in.empty() || in[0] == '#') continue;
+        const std::vector<std::string> f = split_space(in);
+        if (f.empty()) continue;
+        if (f.size() < 10) die("[ERROR](VcfParser::parserProcess) => VCF file format not supported: " + in);
+        const size_t st = gt_value_start(f[8], f[9]);
+        const char *g = f[9].c_str();
+        if (st + 2 > f[9].size() || !(g[st] != g[st + 2] && g[st + 1] == '|')) continue;           // only phased heterozygous records
+        int rp = (int)f[7].find(key); rp = (int)f[7].find("=", (size_t)rp); rp++;
+        const int nx = (int)f[7].find(";", (size_t)rp);
+        std::stringstream ss(f[7].substr((size_t)rp, (size_t)(nx - rp)));
+        if (g[st] == '0' && g[st + 2] == '1') hap = 1; else if (g[st] == '1' && g[st + 2] == '0') hap = 0;
+        std::string read;
+        while (std::getline(ss, read, ',')) { auto it = votes.find(read); if (it == votes.end()) it = votes.emplace(read, std::array<int32_t, 2>{0, 0}).first; if (hap >= 0) it->second[(size_t)hap]++; }
+    }
 }

@@ -289,6 +289,7 @@ static const char *kTagUsage =
     "Usage: longphase_amd haplotag [OPTION] ... READSFILE\n"
     "   -s, --snp-file=NAME   -b, --bam-file=NAME   -r, --reference=NAME   -o, --out-prefix=NAME (result)   -t, --threads=Num (1)\n"
     "   --tagSupplementary   -q qualityThreshold(1)   -p percentageThreshold(0.6)   --gpu=ID (0)\n"
+    "   --sv-file=NAME  --mod-file=NAME   phased SV / modcall VCFs: every phased record votes for the reads it lists (RNAMES= / MR=)\n"
     "   --gpus=N (deal the contigs onto N GPUs, devices --gpu, --gpu+1, ...; needs <bam>.bai and the GPU writer; output contigs stay in VCF-header order)\n"
     "   --host-inflate | --gpu-inflate (zlib on the -t threads / GPU inflate + GPU writer; default: GPU for a BAM of 256 MiB or more)   --no-index (ignore <bam>.bai, keep the whole file on the GPU)\n"
     "   --host-deflate (tag splice + zlib deflate on the -t threads instead of the GPU writer; implied by --host-inflate)\n"
@@ -297,7 +298,7 @@ static const char *kTagUsage =
 
 static int haplotag_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
-    std::string snp, ref, bam, prefix = "result";
+    std::string snp, ref, bam, prefix = "result", sv_file, mod_file;
     int threads = 1, gpu = 0, n_gpus = 1, level = 6, strategy = Z_RLE;
     bool host_inflate = false, gpu_inflate = false, no_index = false, host_deflate = false;
     uint64_t group_bytes = 8ull << 30;
@@ -312,6 +313,8 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         else if (a == "-o" || a == "--out-prefix") prefix = val();
         else if (a == "-t" || a == "--threads") threads = std::stoi(val());
         else if (a == "--tagSupplementary") over.push_back([](lps_params &P) { P.tag_supplementary = 1; });
+        else if (a == "--sv-file") sv_file = val();
+        else if (a == "--mod-file") mod_file = val();
         else if (a == "-q" || a == "--qualityThreshold") { const auto x = std::stoi(val());
             over.push_back([x](lps_params &P) { P.mapping_quality = x; });
             }
@@ -331,7 +334,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
             if (strategy < 0) die("longphase_amd: --compress-strategy is one of default, rle, huffman");
             }
         else if (a == "--help") { std::cout << kTagUsage; return 0; }
-        else if (a == "--sv-file" || a == "--mod-file" || a == "--cram" || a == "--region" || a == "--log") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
+        else if (a == "--cram" || a == "--region" || a == "--log") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kTagUsage; return 1; }
     }
     if (snp.empty() || bam.empty() || ref.empty()) { std::cerr << "longphase_amd haplotag: missing arguments\n" << kTagUsage; return 1; }
@@ -345,6 +348,18 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     if (!read_lines(snp, vcf_lines)) die("Fail to open vcf: " + snp);
     std::vector<std::string> chr_vec; std::map<std::string, int> chr_len; std::map<std::string, std::map<int32_t, PhasedRow>> rows;
     parse_phased_vcf(vcf_lines, chr_vec, chr_len, rows);
+    // phased SV / MOD files: votes per read NAME, one table for the whole genome (HaplotagProcess.cpp:72-90)
+    ReadVotes votes; bool have_votes = false;
+    for (int k = 0; k < 2; ++k) { const std::string &fn = k ? mod_file : sv_file; if (fn.empty()) continue;
+        std::vector<std::string> ls; if (!read_lines(fn, ls)) die("Fail to open vcf: " + fn);
+        parse_read_votes(ls, k ? "MR=" : "RNAMES=", votes); have_votes = true; }
+    // per alignment of a contig, in record order: looked up by name; handed to the library before the scoring call
+    auto set_votes = [&](lps_ctx *cx, size_t n, const std::function<std::string(size_t)> &name_of) {
+        if (!have_votes) return;
+        std::vector<int32_t> v1(n, 0), v2(n, 0);
+        for (size_t i = 0; i < n; ++i) { auto it = votes.find(name_of(i)); if (it != votes.end()) { v1[i] = it->second[0]; v2[i] = it->second[1]; } }
+        if (L.set_read_votes(cx, v1.data(), v2.data(), (int64_t)n)) die(std::string("longphase_amd: ") + L.last_error(cx));
+    };
     std::map<std::string, ChrVariants> want_seq; std::map<std::string, int> want;
     for (const std::string &c : chr_vec) { want[c] = 1; want_seq[c]; }
     std::map<std::string, std::string> seqs; read_fasta(ref, want_seq, seqs);
@@ -456,8 +471,12 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
                 vt.phase_set = ps.data();
                 const std::string &sq = seqs.at(chr);
                 lps_haplotag_result hr{(int64_t)n, status.data(), h1.data(), h2.data(), nps.data(), psmin.data(), hp.data(), pq.data(), psv.data()};
-                if (L.begin_chromosome(cx) || L.set_variants(cx, &vt) || L.set_reference(cx, sq.data(), (int64_t)sq.size()) || L.push_bam_resident(cx, gi->second.first, (int64_t)n, name_id.data()) || L.haplotag_chromosome(cx, &hr))
+                if (L.begin_chromosome(cx) || L.set_variants(cx, &vt) || L.set_reference(cx, sq.data(), (int64_t)sq.size()) || L.push_bam_resident(cx, gi->second.first, (int64_t)n, name_id.data()))
                     die(std::string("longphase_amd: ") + L.last_error(cx));
+                if (have_votes) { std::vector<char> store; std::vector<uint32_t> noff; std::vector<std::pair<const char *, size_t>> nm;
+                    g.names(L, cx, gi->second.first, gi->second.second, store, noff, nm);
+                    set_votes(cx, n, [&](size_t i) { return std::string(nm[i].first, nm[i].second); }); }
+                if (L.haplotag_chromosome(cx, &hr)) die(std::string("longphase_amd: ") + L.last_error(cx));
             } else if (L.begin_chromosome(cx) || L.push_bam_resident(cx, gi->second.first, (int64_t)n, name_id.data())) die(std::string("longphase_amd: ") + L.last_error(cx));
             int64_t nb = 0;
             if (L.haplotag_write_bgzf(cx, status.data(), hp.data(), psv.data(), pq.data(), nullptr, 0, &nb)) die(std::string("longphase_amd: ") + L.last_error(cx));
@@ -582,8 +601,15 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
             lps_haplotag_result hr{(int64_t)n, status.data(), h1.data(), h2.data(), nps.data(), psmin.data(), hp.data(), pq.data(), psv.data()};
             if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) ||
                 (host_inflate ? L.push_bam_records(ctx, base, (int64_t)(c.hi - c.lo), c.rec_off.data(), (int64_t)n, name_id.data())
-                              : L.push_bam_resident(ctx, gb.range[chr].first, (int64_t)n, name_id.data())) || L.haplotag_chromosome(ctx, &hr))
+                              : L.push_bam_resident(ctx, gb.range[chr].first, (int64_t)n, name_id.data())))
                 die(std::string("longphase_amd: ") + L.last_error(ctx));
+            if (have_votes) {
+                if (host_inflate) set_votes(ctx, n, [&](size_t i) { size_t l; const char *nm = in.name_of(c, i, l); return std::string(nm, l); });
+                else { std::vector<char> store; std::vector<uint32_t> noff; std::vector<std::pair<const char *, size_t>> nm;
+                    gb.names(L, ctx, gb.range[chr].first, gb.range[chr].second, store, noff, nm);
+                    set_votes(ctx, n, [&](size_t i) { return std::string(nm[i].first, nm[i].second); }); }
+            }
+            if (L.haplotag_chromosome(ctx, &hr)) die(std::string("longphase_amd: ") + L.last_error(ctx));
         } else if (gpu_writer) {                                          // no variants on this contig: its records are still written (untouched)
             std::vector<uint32_t> name_id(n, 0);
             if (L.begin_chromosome(ctx) || L.push_bam_resident(ctx, gb.range[chr].first, (int64_t)n, name_id.data())) die(std::string("longphase_amd: ") + L.last_error(ctx));

@@ -44,6 +44,7 @@ struct lps_ctx {
     DevBuf<int32_t> x_pos, x_info, x_u, x_snp_u, u_pos; DevBuf<uint8_t> x_kind, x_mflag; DevBuf<uint32_t> x_moff, x_mname;
     std::vector<int32_t> h_snp_u, h_sv_u, h_mod_u, h_res_ps_u; std::vector<uint8_t> h_res_gt_u;
     int nG = 0; const int32_t *g_vpos = nullptr;
+    std::vector<int32_t> votes_h1, votes_h2;   // lps_set_read_votes
     // reads
     int nR = 0; uint64_t n_cig = 0, n_seq = 0, n_qual = 0;
     DevBuf<int32_t> r_start, r_lq; DevBuf<uint16_t> r_flag; DevBuf<uint8_t> r_mapq; DevBuf<uint32_t> r_name;
@@ -220,7 +221,7 @@ int lps_begin_chromosome(lps_ctx *c) {
     if (!c) return -1;
     c->nV = 0; c->last_pos = -1; c->ref_len = c->ref_len_eff = 0; c->nR = 0; c->n_cig = c->n_seq = c->n_qual = 0; c->n_blob = 0; c->read_mode = 0; c->cur_first = -1; c->cur_count = 0;
     c->phase_valid = false; c->has_hap = false; c->h_vpos.clear(); c->name_max = 0;
-    c->nX = c->nSV = c->nMOD = 0; c->h_snp_u.clear(); c->h_sv_u.clear(); c->h_mod_u.clear();
+    c->nX = c->nSV = c->nMOD = 0; c->h_snp_u.clear(); c->h_sv_u.clear(); c->h_mod_u.clear(); c->votes_h1.clear(); c->votes_h2.clear();
     return 0;
 }
 
@@ -1074,6 +1075,16 @@ static int run_scorer(lps_ctx *c, bool somatic, uint8_t *status, int32_t *hp1, i
     return 0;
 }
 
+int lps_set_read_votes(lps_ctx *c, const int32_t *h1, const int32_t *h2, int64_t n_reads) {
+    if (!c) return -1;
+    c->votes_h1.clear(); c->votes_h2.clear();
+    if (!h1 && !h2) return 0;
+    if (!h1 || !h2) return fail(c, "lps_set_read_votes: both arrays or none");
+    if (n_reads != c->nR) return fail(c, "lps_set_read_votes: n_reads must equal the number of pushed alignments");
+    c->votes_h1.assign(h1, h1 + n_reads); c->votes_h2.assign(h2, h2 + n_reads);
+    return 0;
+}
+
 int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
     if (!c || !out) return -1;
     try {
@@ -1085,6 +1096,10 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
         if (nV > 0 && c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
         int rc = run_scorer(c, false, out->status, out->hp1, out->hp2, out->n_ps, out->ps_min, nullptr, nullptr, nullptr);
         if (rc) return rc;
+        if (!c->votes_h1.empty()) {                                       // judgeSVHap (:220-226): after the CIGAR walk, before the decision
+            if ((int)c->votes_h1.size() != nR) return fail(c, "lps_set_read_votes was called for another set of alignments");
+            for (int r = 0; r < nR; ++r) if (out->status[r] == 0) { out->hp1[r] += c->votes_h1[r]; out->hp2[r] += c->votes_h2[r]; }
+        }
         // judgeReadHap (src/haplotag/HaplotagStrategy.cpp:243-300) on the host: needs libm's log10
         const double thr = c->P.percentage_threshold;
         int64_t tagged = 0;
@@ -1106,7 +1121,7 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
                     else pq = -10 * (std::log10((double)mn / double(mx + mn)));
                     if (out->n_ps[r] > 1) hp = 0;
                 }
-                out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = hp ? out->ps_min[r] : 0;
+                out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = (hp && out->n_ps[r]) ? out->ps_min[r] : 0;   // no PS seen (a read tagged by SV / MOD votes alone): the reference reads begin() of an empty map, 0 with libstdc++
                 n_tagged += hp != 0;
             }
             return n_tagged;

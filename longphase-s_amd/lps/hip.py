@@ -45,6 +45,7 @@ def load():
     L.lps_set_variants.argtypes = [C.c_void_p, C.POINTER(abi.VariantTable)]
     L.lps_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.lps_set_extra_variants.argtypes = [C.c_void_p, C.POINTER(abi.ExtraVariantTable)]
+    L.lps_set_read_votes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.lps_get_extra_result.argtypes = [C.c_void_p, C.POINTER(abi.PhaseResult), C.POINTER(abi.PhaseResult)]
     L.lps_push_reads.argtypes = [C.c_void_p, C.POINTER(abi.ReadBatch)]
     L.lps_push_reads_device.argtypes = [C.c_void_p, C.POINTER(abi.ReadBatch)]
@@ -159,6 +160,13 @@ class Context:
         sv, mod = abi.PhaseOut(self._extra.n_sv), abi.PhaseOut(self._extra.n_mod)
         self._check(self.L.lps_get_extra_result(self.h, C.byref(sv.c), C.byref(mod.c)), "lps_get_extra_result")
         return sv, mod
+
+    def set_read_votes(self, h1, h2):
+        """haplotag: per-alignment votes from the phased SV / MOD files (judgeSVHap); None, None = none."""
+        if h1 is None:
+            self._check(self.L.lps_set_read_votes(self.h, None, None, 0), "lps_set_read_votes"); return
+        a = np.ascontiguousarray(h1, np.int32); b = np.ascontiguousarray(h2, np.int32)
+        self._check(self.L.lps_set_read_votes(self.h, a.ctypes.data, b.ctypes.data, a.size), "lps_set_read_votes")
 
     def set_table(self, variants, ref):
         """Replace the variant table (e.g. by the phased one) while the pushed reads stay resident."""

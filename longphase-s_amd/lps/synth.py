@@ -195,15 +195,26 @@ def merge_mod_lines(lines):
     return pos, [[(n, m, r) for n, (m, r) in sorted(rows[p].items())] for p in pos]
 
 
-def write_sv_vcf(path, chrom, sv_pos, sv_len, contig_len, gt=None):
+def sv_read_names(s, prefix=""):
+    """Per generated SV the names of the alignments that span it and come from the haplotype carrying it (what a SV caller lists under RNAMES=)."""
+    end = read_ref_end(s)
+    out = []
+    for p, h in zip(s.sv_pos, s.sv_hap):
+        idx = np.nonzero((s.ref_start <= p) & (end > p + 1) & (s.read_hap == h))[0]
+        out.append(sorted(set("%sr%09d" % (prefix, int(s.name_id[i])) for i in idx)))
+    return out
+
+
+def write_sv_vcf(path, chrom, sv_pos, sv_len, contig_len, gt=None, rnames=None):
     with open(path, "w") as f:
         f.write("##fileformat=VCFv4.2\n##contig=<ID=%s,length=%d>\n##INFO=<ID=SVTYPE,Number=1,Type=String,Description=\"\">\n" % (chrom, contig_len))
         f.write("##INFO=<ID=SVLEN,Number=1,Type=Integer,Description=\"\">\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"\">\n")
         f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n")
         for i, (p, l) in enumerate(zip(sv_pos, sv_len)):
             g = "0/1" if gt is None else gt[i]
-            f.write("%s\t%d\tsv%d\tN\t<%s>\t60\tPASS\tSVTYPE=%s;SVLEN=%d;END=%d\tGT:DR:DV\t%s:10:10\n"
-                    % (chrom, int(p) + 1, i, "INS" if l > 0 else "DEL", "INS" if l > 0 else "DEL", int(l), int(p) + 1 + (0 if l > 0 else -int(l)), g))
+            rn = "" if rnames is None else ";RNAMES=" + ",".join(rnames[i])
+            f.write("%s\t%d\tsv%d\tN\t<%s>\t60\tPASS\tSVTYPE=%s;SVLEN=%d;END=%d%s\tGT:DR:DV\t%s:10:10\n"
+                    % (chrom, int(p) + 1, i, "INS" if l > 0 else "DEL", "INS" if l > 0 else "DEL", int(l), int(p) + 1 + (0 if l > 0 else -int(l)), rn, g))
 
 
 def write_mod_vcf(path, chrom, lines, contig_len, gt=None):

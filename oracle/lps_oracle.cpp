@@ -674,8 +674,9 @@ int oracle_phase(const lps_params *Pp, const lps_variant_table *tp, const char *
 // (src/haplotag/HaplotagParsingBam.cpp:453-486), CigarParser::parsingCigar (:541-647), judgeSnpHap /
 // judgeDeletionHap (src/haplotag/HaplotagStrategy.cpp:20-209) and judgeReadHap (:243-300).
 // The table holds the phased-het rows of the normal VCF (HaplotagVcfParser.cpp:304-400): HP1 = ALT when hp1_is_alt.
-int oracle_haplotag(const lps_params *Pp, const lps_variant_table *tp, const char *ref, int64_t ref_len_in,
-                    const lps_read_batch *bp, lps_haplotag_result *out) {
+// votes_h1 / votes_h2 (may be NULL): per alignment, what judgeSVHap (src/haplotag/HaplotagStrategy.cpp:220-226) adds from the phased SV / MOD files
+int oracle_haplotag_v(const lps_params *Pp, const lps_variant_table *tp, const char *ref, int64_t ref_len_in,
+                      const lps_read_batch *bp, const int32_t *votes_h1, const int32_t *votes_h2, lps_haplotag_result *out) {
     const lps_params &P = *Pp; const lps_variant_table &t = *tp; const lps_read_batch &b = *bp;
     Table T; T.t = &t; T.ref = ref;
     const int32_t last_pos = t.n ? t.pos[t.n - 1] : -1;
@@ -742,6 +743,7 @@ int oracle_haplotag(const lps_params *Pp, const lps_variant_table *tp, const cha
             else if (op == 5 || op == 6) {}
             else return -2;
         }
+        if (votes_h1 && votes_h2) { h1 += votes_h1[r]; h2 += votes_h2[r]; }                  // judgeSVHap, HaplotagProcess.cpp:401
         out->hp1[r] = h1; out->hp2[r] = h2;
         out->n_ps[r] = (uint8_t)std::min<size_t>(countPS.size(), 255); out->ps_min[r] = countPS.empty() ? 0 : countPS.begin()->first;
         // ---- judgeReadHap
@@ -751,9 +753,15 @@ int oracle_haplotag(const lps_params *Pp, const lps_variant_table *tp, const cha
         else { if (h1 > h2) hp = 1; if (h1 < h2) hp = 2; }
         if (mx == 0) pq = 0; else if (mx == mx + mn) pq = 40; else pq = -10 * (std::log10((double)mn / double(mx + mn)));
         if (countPS.size() > 1) hp = 0;
-        out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = hp ? countPS.begin()->first : 0;
+        // (a read tagged by SV / MOD votes alone has no PS: the reference reads begin() of the empty map - the node count, 0, with libstdc++)
+        out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = (hp && !countPS.empty()) ? countPS.begin()->first : 0;
     }
     return 0;
+}
+
+int oracle_haplotag(const lps_params *Pp, const lps_variant_table *tp, const char *ref, int64_t ref_len_in,
+                    const lps_read_batch *bp, lps_haplotag_result *out) {
+    return oracle_haplotag_v(Pp, tp, ref, ref_len_in, bp, nullptr, nullptr, out);
 }
 
 

@@ -43,6 +43,9 @@ def lib():
         _lib.oracle_haplotag.restype = C.c_int
         _lib.oracle_haplotag.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.c_void_p, C.c_int64,
                                          C.POINTER(abi.ReadBatch), C.POINTER(abi.HaplotagResult)]
+        _lib.oracle_haplotag_v.restype = C.c_int
+        _lib.oracle_haplotag_v.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.c_void_p, C.c_int64,
+                                           C.POINTER(abi.ReadBatch), C.c_void_p, C.c_void_p, C.POINTER(abi.HaplotagResult)]
         _lib.oracle_somatic_tag.restype = C.c_int
         _lib.oracle_somatic_tag.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.VariantTable), C.POINTER(abi.ReadBatch), C.POINTER(abi.SomaticTagResult)]
         _lib.oracle_somatic_extract_normal.restype = C.c_int
@@ -117,11 +120,15 @@ def phase_x(params, variants, extra, ref, reads, dump=False, with_edges=True):
     return out, osv, omod, d
 
 
-def haplotag(params, variants, ref, reads):
-    """CPU restatement of the germline haplotag per-read scoring loop.  Returns abi.HaplotagOut."""
+def haplotag(params, variants, ref, reads, votes=None):
+    """CPU restatement of the germline haplotag per-read scoring loop.  votes = (h1, h2) int32 arrays per alignment (judgeSVHap).  Returns abi.HaplotagOut."""
     out = abi.HaplotagOut(reads.n_reads)
     ref = np.ascontiguousarray(ref, dtype=np.uint8)
-    rc = lib().oracle_haplotag(C.byref(params), C.byref(variants.c), ref.ctypes.data, ref.size, C.byref(reads.c), C.byref(out.c))
+    v1 = v2 = None
+    if votes is not None:
+        v1 = np.ascontiguousarray(votes[0], np.int32); v2 = np.ascontiguousarray(votes[1], np.int32)
+    rc = lib().oracle_haplotag_v(C.byref(params), C.byref(variants.c), ref.ctypes.data, ref.size, C.byref(reads.c),
+                                 None if v1 is None else v1.ctypes.data, None if v2 is None else v2.ctypes.data, C.byref(out.c))
     if rc != 0:
         raise RuntimeError(f"oracle_haplotag rc={rc}")
     return out

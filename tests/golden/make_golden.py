@@ -467,8 +467,49 @@ def make_cli_deepsomatic():
         print("cli_deepsomatic: records kept", sum(1 for l in open(os.path.join(d, "out_preprocessed.vcf")) if not l.startswith("#")), "phased", n)
 
 
+def make_cli_haplotag_extra():
+    """reference `phase --sv-file --mod-file` -> its three phased VCFs (committed) -> reference `haplotag --sv-file --mod-file` on them: the tagged BAM's
+    record stream pins judgeSVHap (votes from RNAMES= / MR= lists) next to the SNP votes."""
+    import hashlib
+    from lps.synth import make_mod_lines, write_sv_vcf, write_mod_vcf, sv_read_names
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import util
+    kw, mod_kw, use_sv, cli, over, xover = fixtures.EXTRA_FIXTURES["sv_and_mod"]
+    s = Synth(**kw)
+    lines = make_mod_lines(s, seed=kw["seed"], **mod_kw)
+    with tempfile.TemporaryDirectory() as d:
+        write_sv_vcf(d + "/sv.vcf", "chrS", s.sv_pos, s.sv_len, s.contig_len, rnames=sv_read_names(s))
+        write_mod_vcf(d + "/mod.vcf", "chrS", lines, s.contig_len)
+        run_reference_phase(s, cli + ["--sv-file", "sv.vcf", "--mod-file", "mod.vcf"], d)
+        s.write_sam(d + "/plain.sam"); util.add_stale_tags(d + "/plain.sam", d + "/tagged_in.sam")
+        subprocess.check_call([TEST_VIEW, "-b", "-x", "tin.bam.bai", "-p", "tin.bam", "tagged_in.sam"], cwd=d, stdout=subprocess.DEVNULL)
+        r = subprocess.run([REF_BIN, "haplotag", "-s", "out.vcf", "-b", "tin.bam", "-r", "ref.fa", "-t", "1", "-o", "tagged", "--sv-file", "out_SV.vcf", "--mod-file", "out_mod.vcf"],
+                           cwd=d, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"reference haplotag failed rc={r.returncode}: {r.stderr[-2000:]}")
+        r0 = subprocess.run([REF_BIN, "haplotag", "-s", "out.vcf", "-b", "tin.bam", "-r", "ref.fa", "-t", "1", "-o", "tagged_snp_only"], cwd=d, capture_output=True, text=True)
+        assert r0.returncode == 0
+        for fn in ("out.vcf", "out_SV.vcf", "out_mod.vcf"):
+            with open(os.path.join(d, fn), "rb") as fi, gzip.GzipFile(os.path.join(HERE, "data", "cli_haplotag_extra." + fn + ".gz"), "wb", mtime=0) as fo:
+                shutil.copyfileobj(fi, fo)
+        text, refs, recs = util.bam_sections(d + "/tagged.bam")
+        _, _, recs0 = util.bam_sections(d + "/tagged_snp_only.bam")
+    tags = util.bam_record_tags(recs); tags0 = util.bam_record_tags(recs0)
+    differ = sum(1 for a, b in zip(tags, tags0) if a != b)
+    out = dict(digest=fixtures.input_digest(s), records_sha256=hashlib.sha256(recs).hexdigest(), n_records=len(tags), record_bytes=len(recs),
+               header_without_pg=[l for l in text.split("\n") if l and not l.startswith("@PG")],
+               tags=[[q, f, p, [list(t) for t in tg]] for q, f, p, tg in tags], records_changed_by_the_votes=differ)
+    s.close()
+    with open(os.path.join(HERE, "cli_haplotag_extra.json"), "w") as f:
+        json.dump(out, f)
+    print("cli_haplotag_extra", out["n_records"], out["records_sha256"][:16], "records whose tags differ from the SNP-only run:", differ)
+
+
 def main():
     assert os.path.exists(REF_BIN), "build the reference first: oracle/build_ref.sh"
+    if "--cli-haplotag-extra" in sys.argv:
+        make_cli_haplotag_extra()
+        return
     if "--cli-deepsomatic" in sys.argv:
         make_cli_deepsomatic()
         return

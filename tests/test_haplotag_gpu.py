@@ -29,6 +29,36 @@ def test_haplotag_matches_oracle_and_reference_tags(name):
     util.assert_tags_equal(out, hp, ps, pq, name + " vs reference BAM tags")
 
 
+@pytest.mark.parametrize("name", ["snp_ont", "sparse_cov"])
+def test_haplotag_with_read_votes(name):
+    """lps_set_read_votes (judgeSVHap): votes from the phased SV / MOD files enter every scored alignment's counts before the decision - also for
+    alignments without any SNP vote (they are tagged with PS 0, as the reference does); votes of a previous contig do not leak."""
+    src, cli, over = fixtures.HAPLOTAG_FIXTURES[name]
+    kw, _, _ = fixtures.PHASE_FIXTURES[src]
+    s, _, R = util.make_case(kw)
+    V, _, _, _ = util.load_golden_haplotag(name)
+    P = abi.default_params(**over)
+    g = np.random.default_rng(3)
+    v1 = (g.integers(0, 30, R.n_reads) * (g.random(R.n_reads) < 0.4)).astype(np.int32)
+    v2 = (g.integers(0, 30, R.n_reads) * (g.random(R.n_reads) < 0.4)).astype(np.int32)
+    plain = lps_oracle.haplotag(P, V, s.ref, R)
+    lone = np.nonzero((plain.status == 0) & (plain.n_ps == 0))[0]        # scored alignments that saw no phased SNP: votes alone tag them
+    v1[lone] = 3; v2[lone] = 0
+    want = lps_oracle.haplotag(P, V, s.ref, R, votes=(v1, v2))
+    assert (want.hp != plain.hp).sum() >= 5 and (want.pq != plain.pq).sum() >= 20
+    assert np.all(want.hp[lone] == 1) and np.all(want.ps[lone] == 0)
+    with hip.Context(0, P) as ctx:
+        ctx.load_chromosome(V, s.ref, R)
+        ctx.set_read_votes(v1, v2)
+        out = ctx.run_haplotag()
+        for k in ("status", "hp1", "hp2", "ps_min", "hp", "pq", "ps"):
+            assert np.array_equal(getattr(out, k), getattr(want, k)), k
+        out2 = ctx.haplotag(V, s.ref, R)                       # a new chromosome: no votes
+        for k in ("status", "hp1", "hp2", "hp", "pq", "ps"):
+            assert np.array_equal(getattr(out2, k), getattr(plain, k)), k
+        assert ctx.L.lps_set_read_votes(ctx.h, v1[:5].ctypes.data, v2[:5].ctypes.data, 5) != 0
+
+
 def test_haplotag_after_own_phase_roundtrip():
     """phase on the GPU, build the phased table from its result, haplotag on the GPU == oracle on the same table."""
     kw, cli, over = fixtures.PHASE_FIXTURES["two_blocks"]
