@@ -201,3 +201,51 @@ def test_device_push_rejects_bad_operands():
         assert ctx.L.lps_push_reads_device(ctx.h, C.byref(b)) != 0
         assert b"l_qseq" in ctx.L.lps_last_error(ctx.h)
     g.close()
+
+
+def test_tumor_normal_pair_50x_25x_every_somatic_pass():
+    """BASELINE configs[4] at one contig: a tumor / normal pair (50x / 25x, SNP + indel variants, 60 % purity) on a 16 Mb contig - the normal
+    sample is phased on the GPU, the merged table (phased germline rows + the tumor-only somatic rows) goes through the three per-read passes
+    of somatic_haplotag (normal extraction a20, tumor extraction a21, tagging a22), each compared with the oracle: every per-site counter,
+    per-read count, list entry and tag."""
+    from lps.synth import Synth
+    genome = dict(seed=61, contig_len=16_000_000, n_snp=16_000, indel_var_frac=0.15, somatic_every=6000.0, n_threads=8)
+    N = Synth(**dict(genome, coverage=25.0, read_seed=611, tumor_purity=0.0))
+    T = Synth(**dict(genome, coverage=50.0, read_seed=612, tumor_purity=0.6))
+    RN, RT = abi.Reads.from_synth(N), abi.Reads.from_synth(T)
+    assert RT.n_reads > 35_000 and RN.n_reads > 17_000 and N.n_somatic > 1500
+    P = abi.default_params(phase_indel=1)
+    V0 = abi.Variants(N.var_pos, N.var_ref, N.var_alt)
+    with hip.Context(0, P) as ctx:
+        ph = ctx.phase(V0, N.ref, RN)
+        util.assert_phase_equal(ph.phase_set, ph.gt, *(lambda o: (o.phase_set, o.gt))(lps_oracle.phase(P, V0, N.ref, RN)[0]), "normal sample")
+        # merged table: phased germline rows (role 0) + somatic SNVs of the tumor VCF (role 1, derived from the haplotype they sit on)
+        keep = np.nonzero(ph.phase_set != 0)[0]
+        rows = [(int(N.var_pos[i]), N.var_ref[i], N.var_alt[i], int(ph.gt[i]), int(ph.phase_set[i]), 0, 0) for i in keep]
+        rows += [(int(p), bytes([r]), bytes([a]), 0, 0, 1, int(h) + 1) for p, r, a, h in zip(N.som_pos, N.som_ref, N.som_alt, N.som_hap)]
+        rows.sort()
+        assert len(set(r[0] for r in rows)) == len(rows)
+        kind = [1 if len(r[1]) == 1 and len(r[2]) == 1 else (2 if len(r[1]) == 1 else 3) for r in rows]
+        V = abi.Variants([r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows], hp1_is_alt=[r[3] for r in rows], phase_set=[r[4] for r in rows],
+                         somatic_role=[r[5] for r in rows], derive_hp=[r[6] for r in rows], tumor_kind=kind)
+        # a20: normal sample at the tumor-VCF positions
+        want = lps_oracle.somatic_extract_normal(P, V, N.ref, RN)
+        out = ctx.somatic_extract_normal(V, N.ref, RN)
+        assert np.array_equal(out.read_hp, want.read_hp) and np.array_equal(out.counters, want.counters), "normal extraction"
+        # a21: tumor sample
+        want = lps_oracle.somatic_extract_tumor(P, V, T.ref, RT)
+        out = ctx.somatic_extract_tumor(V, T.ref, RT)
+        for k in ("status", "hp1", "hp2", "hp3", "hp", "ps_min", "end_pos", "read_len", "has_site"):
+            assert np.array_equal(getattr(out, k), getattr(want, k)), "tumor extraction: " + k
+        assert np.array_equal(out.site, want.site), "tumor extraction: per-site counters"
+        assert out.c.n_pairs == want.c.n_pairs and out.c.n_windows == want.c.n_windows and out.c.n_pairs > 50_000
+        for a, b in zip(out.pairs(), want.pairs()):
+            assert np.array_equal(a, b), "tumor extraction: (site, read, base HP) pairs"
+        for a, b in zip(out.windows(), want.windows()):
+            assert np.array_equal(a, b), "tumor extraction: difference windows"
+        # a22: tagging
+        want = lps_oracle.somatic_tag(P, V, RT)
+        out = ctx.somatic_tag(V, T.ref, RT)
+        for k in ("status", "hp1", "hp2", "hp3", "derive_h1", "derive_h2", "ps_min", "hp", "pq", "ps"):
+            assert np.array_equal(getattr(out, k), getattr(want, k)), "tagging: " + k
+        assert (out.hp >= 5).sum() > 1000 and (out.hp == 1).sum() > 5000
