@@ -40,14 +40,15 @@ __device__ __forceinline__ int last_snp_before(const VarView &V, int p) {
     return lo > 0 ? V.pos[lo - 1] : (int)0x80000000;
 }
 
-__global__ __launch_bounds__(256) void k_extra_merge(VarView V, ReadView R, ObsView O, ExtraView X, int mapping_quality, LpsCounters *cnt) {
-    __shared__ __attribute__((aligned(16))) int s_ref[4][LPS_SEG];
-    __shared__ __attribute__((aligned(16))) int s_qry[4][LPS_SEG];
-    __shared__ __attribute__((aligned(16))) uint32_t s_cig[4][LPS_SEG + 4];
-    __shared__ int s_pm[4][LPS_SEG];
-    __shared__ ObsRec s_ex[4][XM_CAP];
+#define XM_WPB 1        // waves per workgroup (they share nothing)
+__global__ __launch_bounds__(64 * XM_WPB) void k_extra_merge(VarView V, ReadView R, ObsView O, ExtraView X, int mapping_quality, LpsCounters *cnt) {
+    __shared__ __attribute__((aligned(16))) int s_ref[XM_WPB][LPS_SEG];
+    __shared__ __attribute__((aligned(16))) int s_qry[XM_WPB][LPS_SEG];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cig[XM_WPB][LPS_SEG + 4];
+    __shared__ int s_pm[XM_WPB][LPS_SEG];
+    __shared__ ObsRec s_ex[XM_WPB][XM_CAP];
     const int w = threadIdx.x >> 6, l = lane_id();
-    const int r = blockIdx.x * 4 + w;
+    const int r = blockIdx.x * XM_WPB + w;
     if (r >= R.n) return;
     int *sref = s_ref[w], *sqry = s_qry[w], *spm = s_pm[w]; uint32_t *scig = s_cig[w]; ObsRec *sex = s_ex[w];
 
@@ -217,5 +218,5 @@ __global__ __launch_bounds__(256) void k_extra_merge(VarView V, ReadView R, ObsV
 
 void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int mapping_quality, LpsCounters *cnt, hipStream_t s) {
     if (R.n <= 0) return;
-    hipLaunchKernelGGL(k_extra_merge, dim3((R.n + 3) / 4), dim3(256), 0, s, V, R, O, X, mapping_quality, cnt);
+    hipLaunchKernelGGL(k_extra_merge, dim3((R.n + XM_WPB - 1) / XM_WPB), dim3(64 * XM_WPB), 0, s, V, R, O, X, mapping_quality, cnt);
 }

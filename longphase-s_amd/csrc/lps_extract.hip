@@ -110,15 +110,20 @@ __device__ __forceinline__ int lane_var_lower_bound(const VarView &V, int key) {
 #define HIT_Q5 (1u << 24)
 #define HIT_ERASED (1u << 25)
 
-__global__ __launch_bounds__(256, 4) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
+// waves per workgroup of k_extract_phase.  The waves of a workgroup share nothing; one wave per workgroup gives its 9.6 KB of LDS back the moment
+// that wave is done instead of when the slowest of four is (alignments differ tenfold in length)
+#ifndef EXT_WPB
+#define EXT_WPB 1
+#endif
+__global__ __launch_bounds__(64 * EXT_WPB, 4) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
                                                        LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint2 *ovf, unsigned *ovf_ctr, unsigned ovf_chunks) {
-    __shared__ __attribute__((aligned(16))) int s_ref[4][LPS_SEG];
-    __shared__ __attribute__((aligned(16))) int s_qry[4][LPS_SEG];
-    __shared__ __attribute__((aligned(16))) uint32_t s_cig[4][LPS_SEG + 4];
-    __shared__ __attribute__((aligned(16))) uint2 s_hit[4][EXT_CAP];
-    __shared__ ClipEv s_clip[4][EXT_CLIPS];
+    __shared__ __attribute__((aligned(16))) int s_ref[EXT_WPB][LPS_SEG];
+    __shared__ __attribute__((aligned(16))) int s_qry[EXT_WPB][LPS_SEG];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cig[EXT_WPB][LPS_SEG + 4];
+    __shared__ __attribute__((aligned(16))) uint2 s_hit[EXT_WPB][EXT_CAP];
+    __shared__ ClipEv s_clip[EXT_WPB][EXT_CLIPS];
     enum { H_START, H_LQ, H_REL, H_V0, H_SOFF, H_QOFF = H_SOFF + 2, H_HIT0 = H_QOFF + 2, H_FAIL, H_WORDS };
-    __shared__ int s_hdr[4][EXT_RPW + 1][H_WORDS];
+    __shared__ int s_hdr[EXT_WPB][EXT_RPW + 1][H_WORDS];
     const int w = threadIdx.x >> 6, l = lane_id();
     int *sref = s_ref[w], *sqry = s_qry[w]; uint32_t *scig = s_cig[w];
     uint2 *hit = s_hit[w]; ClipEv *clipb = s_clip[w];
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_phase(VarView V, ReadView R,
     // arena = blockIdx % 64 keeps each counter inside ONE XCD's L2.
     const int arena = blockIdx.x % O.n_arenas;
     const unsigned long long arena_lo = (unsigned long long)arena * O.arena_size;
-    const int job = blockIdx.x * 4 + w;
+    const int job = blockIdx.x * EXT_WPB + w;
     const int r0 = job * EXT_RPW;
     if (r0 >= R.n) return;
     const int nq = min(EXT_RPW, R.n - r0);
@@ -725,7 +730,7 @@ void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O,
                           int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint2 *ovf, unsigned *ovf_ctr, unsigned ovf_chunks, hipStream_t s) {
     if (R.n == 0) return;
     const int n_jobs = (R.n + EXT_RPW - 1) / EXT_RPW;
-    hipLaunchKernelGGL(k_extract_phase, dim3((n_jobs + 3) / 4), dim3(256), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo, ovf, ovf_ctr, ovf_chunks);
+    hipLaunchKernelGGL(k_extract_phase, dim3((n_jobs + EXT_WPB - 1) / EXT_WPB), dim3(64 * EXT_WPB), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo, ovf, ovf_ctr, ovf_chunks);
     // waves whose hits did not fit their LDS list queued themselves (none with ordinary read lengths and variant densities): a small grid drains the queue
     hipLaunchKernelGGL(k_extract_redo, dim3(std::min(256, (n_jobs + 3) / 4)), dim3(256), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo);
 }

@@ -18,14 +18,17 @@
 // MODE 2/3: normal-BAM extraction pass of somatic_haplotag (ExtractNorDataCigarParser, src/somatic_haplotag/SomaticVarCaller.cpp:227-293):
 //   2 = germline votes gated by MAPQ (low-MAPQ reads are NOT skipped in this pass) + per-site base counters by atomics + the read's
 //       haplotype; 3 = re-walk that adds the read's haplotype to ReadHpCount of every tumor site it touched (:171-173).
+#ifndef HAP_WPB
+#define HAP_WPB 1      // waves per workgroup: they share nothing, one wave per workgroup frees its LDS as soon as that wave is done
+#endif
 template <int MODE>
-__global__ __launch_bounds__(256, 6) void k_haplotag_score(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary,
+__global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary,
                                                         LpsCounters *cnt) {
-    __shared__ __attribute__((aligned(16))) int s_ref[4][LPS_SEG];
-    __shared__ __attribute__((aligned(16))) int s_qry[4][LPS_SEG];
-    __shared__ __attribute__((aligned(16))) uint32_t s_cig[4][LPS_SEG + 4];
+    __shared__ __attribute__((aligned(16))) int s_ref[HAP_WPB][LPS_SEG];
+    __shared__ __attribute__((aligned(16))) int s_qry[HAP_WPB][LPS_SEG];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cig[HAP_WPB][LPS_SEG + 4];
     const int w = threadIdx.x >> 6, l = lane_id();
-    const int r = blockIdx.x * 4 + w;
+    const int r = blockIdx.x * HAP_WPB + w;
     if (r >= R.n) return;
     int *sref = s_ref[w], *sqry = s_qry[w]; uint32_t *scig = s_cig[w];
     const int start = R.ref_start[r];
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256, 6) void k_haplotag_score(VarView V, ReadView R
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
                      int mode, LpsCounters *cnt, hipStream_t s) {
     if (R.n == 0) return;
-    const dim3 g((R.n + 3) / 4), b(256);
+    const dim3 g((R.n + HAP_WPB - 1) / HAP_WPB), b(64 * HAP_WPB);
     if (mode == 1) hipLaunchKernelGGL(k_haplotag_score<1>, g, b, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
     else if (mode == 2) hipLaunchKernelGGL(k_haplotag_score<2>, g, b, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
     else if (mode == 3) hipLaunchKernelGGL(k_haplotag_score<3>, g, b, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);

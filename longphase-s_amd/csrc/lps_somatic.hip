@@ -67,12 +67,12 @@ __device__ __forceinline__ int somatic_read_hp(int h1, int h2, int h3, bool mult
 }
 
 template <int PASS>
-__global__ __launch_bounds__(256) void k_tumor_extract(VarView V, ReadView R, TumOut T, int mapping_quality, int tag_supplementary, LpsCounters *cnt) {
-    __shared__ __attribute__((aligned(16))) int s_ref[4][LPS_SEG];
-    __shared__ __attribute__((aligned(16))) int s_qry[4][LPS_SEG];
-    __shared__ __attribute__((aligned(16))) uint32_t s_cig[4][LPS_SEG + 4];
+__global__ __launch_bounds__(64) void k_tumor_extract(VarView V, ReadView R, TumOut T, int mapping_quality, int tag_supplementary, LpsCounters *cnt) {
+    __shared__ __attribute__((aligned(16))) int s_ref[1][LPS_SEG];
+    __shared__ __attribute__((aligned(16))) int s_qry[1][LPS_SEG];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cig[1][LPS_SEG + 4];
     const int w = threadIdx.x >> 6, l = lane_id();
-    const int r = blockIdx.x * 4 + w;
+    const int r = blockIdx.x + w;                                     // one wave per workgroup: the waves share nothing, LDS is freed per wave
     if (r >= R.n) return;
     int *sref = s_ref[w], *sqry = s_qry[w]; uint32_t *scig = s_cig[w];
     const int start = R.ref_start[r];
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_tumor_extract(VarView V, ReadView R, Tu
 void launch_tumor_extract(const VarView &V, const ReadView &R, const TumOut &T, int mapping_quality, int tag_supplementary, int pass,
                           LpsCounters *cnt, hipStream_t s) {
     if (R.n == 0) return;
-    const dim3 g((R.n + 3) / 4), b(256);
+    const dim3 g(R.n), b(64);
     if (pass == 0) hipLaunchKernelGGL(k_tumor_extract<0>, g, b, 0, s, V, R, T, mapping_quality, tag_supplementary, cnt);
     else hipLaunchKernelGGL(k_tumor_extract<1>, g, b, 0, s, V, R, T, mapping_quality, tag_supplementary, cnt);
 }
