@@ -138,7 +138,9 @@ __global__ void k_overlap_filter(const unsigned long long *skeys, const uint32_t
 
 // ---- rows by sub-wave groups.  A row holds ~20-30 observations, so a 64-lane wave per row runs with a third of its lanes; the per-row passes below
 // give every row a group of ROW_G lanes instead (two rows per wave): the same instruction stream serves two rows.
+#ifndef ROW_G
 #define ROW_G 32
+#endif
 #define ROWS_PER_WAVE (64 / ROW_G)
 #define ROWS_PER_BLOCK (4 * ROWS_PER_WAVE)
 __device__ __forceinline__ unsigned long long group_ballot(bool pred, int grp) { return (__ballot(pred) >> (grp * ROW_G)) & ((ROW_G == 64) ? ~0ull : ((1ull << ROW_G) - 1ull)); }
