@@ -114,7 +114,10 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     if (!mod_file.empty()) { if (!read_lines(mod_file, mod_lines)) die("ERROR: Cannot open vcf file " + mod_file); modt.parse(mod_lines, vars, svt); }
     const bool co_phase = !sv_lines.empty() || !mod_lines.empty();
     std::map<std::string, int> want; for (auto &kv : vars) if (!kv.second.pos.empty()) want[kv.first] = 1;
-    std::map<std::string, std::string> seqs; read_fasta(ref, vars, seqs);
+    // the reference sequences are first needed when a contig's table goes to the GPU: the FASTA is read beside the GPU start-up and the upload +
+    // inflate of the first BAM blocks (need_fasta joins the reader)
+    std::map<std::string, std::string> seqs; std::thread fasta_thread([&] { read_fasta(ref, vars, seqs); });
+    std::once_flag fasta_once; auto need_fasta = [&] { std::call_once(fasta_once, [&] { fasta_thread.join(); }); };
     const double t_text = now();
     // one BAM: BGZF inflate, record discovery and record decode all run on the GPU; several BAMs (or --host-inflate): zlib on `-t` host threads
     if (!host_inflate && !gpu_inflate && bams.size() == 1) host_inflate = file_bytes(bams[0]) < kGpuInflateMinBytes;
@@ -156,6 +159,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
               } } }
     auto run_contig = [&](lps_ctx *ctx, GpuBam &gb, const std::string &chr, const Packed &tab) {   // PhasingProcess.cpp:113-173, one contig on one GPU
         ChrVariants &cv = vars[chr];
+        need_fasta();
         if (cv.pos.empty() || !seqs.count(chr)) return;
         // names of all files of this contig ranked together (one read name = one merged row, whatever file it came from)
         std::vector<std::pair<const char *, size_t>> names;
@@ -270,12 +274,13 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     for (auto &w : workers) w.join();
     for (lps_comm *cm : comms) if (cm) L.comm_destroy(cm);
     std::cerr << "\n";
+    need_fasta();
     L.destroy(ctx);
     const double t_gpu = now();
     write_vcf(vcf_lines, prefix + ".vcf", res, vars, command);
     if (!sv_file.empty()) write_sv_vcf(sv_lines, prefix + "_SV.vcf", res, svt, command);          // PhasingProcess.cpp:191-203
     if (!mod_file.empty()) write_mod_vcf(mod_lines, prefix + "_mod.vcf", res, modt, command);
-    if (gpu_input) fprintf(stderr, "%s | vcf+fasta read %.3fs | wait for gpu context %.3fs | map bam+header%s %.3fs | upload+gpu inflate %.3fs | gpu record scan %.3fs | names+decode+phase %.3fs | write vcf %.3fs | total %.3fs\n",
+    if (gpu_input) fprintf(stderr, "%s | vcf read (fasta beside the gpu start-up) %.3fs | wait for gpu context %.3fs | map bam+header%s %.3fs | upload+gpu inflate %.3fs | gpu record scan %.3fs | names+decode+phase %.3fs | write vcf %.3fs | total %.3fs\n",
                            gb.indexed ? "contig groups (indexed)" : "whole file", t_text - t_begin, t_ctx - t_bam, gb.indexed ? "+index" : "", gb.t_map, gb.t_inflate, gb.t_scan,
                            t_gpu - t_gin - (gb.indexed ? gb.t_inflate + gb.t_scan : 0.0), now() - t_gpu, now() - t_begin);
     else fprintf(stderr, "vcf+fasta read %.3fs | bam inflate+walk %.3fs | wait for gpu context %.3fs | upload+phase %.3fs | write vcf %.3fs | total %.3fs\n", t_text - t_begin,
@@ -362,7 +367,9 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     };
     std::map<std::string, ChrVariants> want_seq; std::map<std::string, int> want;
     for (const std::string &c : chr_vec) { want[c] = 1; want_seq[c]; }
-    std::map<std::string, std::string> seqs; read_fasta(ref, want_seq, seqs);
+    // (the FASTA is read beside the BAM upload + inflate; need_fasta joins the reader before the first contig's table goes to the GPU)
+    std::map<std::string, std::string> seqs; std::thread fasta_thread([&] { read_fasta(ref, want_seq, seqs); });
+    std::once_flag fasta_once; auto need_fasta = [&] { std::call_once(fasta_once, [&] { fasta_thread.join(); }); };
     const double t_text = now();
     // default: BGZF inflate + record discovery on the GPU, the inflated stream is copied back once for the writer; --host-inflate: zlib on -t threads
     BamFile in; GpuBam gb; size_t in_cap = 0;
@@ -448,6 +455,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
             std::vector<uint8_t> status(n, 5), hp(n, 0); std::vector<int32_t> h1(n), h2(n), psmin(n), pq(n), psv(n); std::vector<uint8_t> nps(n);
             std::vector<uint32_t> name_id(n, 0);                        // haplotag does not group by read name
             if (ri != rows.end() && !ri->second.empty()) {
+                need_fasta();
                 if (!seqs.count(chr)) die("ERROR: contig " + chr + " is missing from the reference FASTA");
                 const size_t m = ri->second.size();
                 std::vector<int32_t> pos(m), ps(m); std::vector<uint8_t> r0(m), a0(m), hpa(m); std::vector<uint16_t> rl(m), al(m); size_t k = 0;
@@ -536,7 +544,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         }
         first.join(); for (auto &x : workers) x.join();
         std::cerr << "\n";
-        w.finish();
+        need_fasta(); w.finish();
         L.destroy(ctx);
         unsigned long long total = 0; for (int k = 0; k < 8; ++k) total += st_count[k];
         fprintf(stderr, "total alignment %llu | tagged %llu (HP1 %llu, HP2 %llu) | untagged: low mapq %llu, unmapped %llu, secondary %llu, supplementary %llu, no variant %llu, beyond last variant %llu, judged %llu\n",
@@ -575,7 +583,8 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         auto ri = rows.find(chr);
         std::vector<uint8_t> status(n, 5), hp(n, 0); std::vector<int32_t> h1(n), h2(n), psmin(n), pq(n), psv(n); std::vector<uint8_t> nps(n);
         if (ri != rows.end() && !ri->second.empty()) {
-            if (!seqs.count(chr)) die("ERROR: contig " + chr + " is missing from the reference FASTA");
+            need_fasta();
+                if (!seqs.count(chr)) die("ERROR: contig " + chr + " is missing from the reference FASTA");
             const size_t m = ri->second.size();
             std::vector<int32_t> pos(m), ps(m); std::vector<uint8_t> r0(m), a0(m), hpa(m); std::vector<uint16_t> rl(m), al(m); size_t k = 0;
             for (auto &kv : ri->second) { pos[k] = kv.first;
@@ -694,7 +703,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         std::cerr << "(" << chr << ")";
     }
     std::cerr << "\n";
-    w.finish();
+    need_fasta(); w.finish();
     t_deflate += now() - t_mark;
     L.destroy(ctx);
     unsigned long long total = 0; for (int k = 0; k < 8; ++k) total += st_count[k];
