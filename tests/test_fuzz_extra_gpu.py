@@ -97,6 +97,15 @@ def test_fuzz_extra_rows_on_random_cigars(block):
             w0, d0 = lps_oracle.phase(P, V, ref, R, dump=True)
             util.assert_stages_equal(ctx, d0, f"seed {seed}, SNP table alone")
             util.assert_phase_equal(plain.phase_set, plain.gt, w0.phase_set, w0.gt, f"seed {seed}: SNP table alone")
+            # ... and the haplotag scorer on the table that phase run produced
+            idx = np.nonzero(plain.phase_set != 0)[0]
+            if idx.size:
+                VT = abi.Variants(V.pos[idx], [V.ref_str[i] for i in idx], [V.alt_str[i] for i in idx], hp1_is_alt=plain.gt[idx], phase_set=plain.phase_set[idx])
+                ctx.set_table(VT, ref)
+                tag = ctx.run_haplotag()
+                wt = lps_oracle.haplotag(P, VT, ref, R)
+                for k in ("status", "hp1", "hp2", "ps_min", "hp", "pq", "ps"):
+                    assert np.array_equal(getattr(tag, k), getattr(wt, k)), f"seed {seed}: haplotag {k}"
         util.assert_phase_equal(out.phase_set, out.gt, want.phase_set, want.gt, f"seed {seed}: SNP rows")
         util.assert_phase_equal(gsv.phase_set, gsv.gt, wsv.phase_set, wsv.gt, f"seed {seed}: SV rows")
         util.assert_phase_equal(gmod.phase_set, gmod.gt, wmod.phase_set, wmod.gt, f"seed {seed}: MOD rows")
