@@ -53,7 +53,7 @@ struct lps_ctx {
     DevBuf<uint8_t> blob; uint64_t n_blob = 0; int read_mode = 0;   // 0 none yet, 1 SoA batches, 2 BAM records
     DevBuf<uint64_t> rec_off, cig_src; DevBuf<unsigned long long> cig_cnt; DevBuf<unsigned> bam_err;
     // whole BAM file resident on the device (lps_bgzf_load): compressed bytes, block table, inflated stream; survives lps_begin_chromosome
-    DevBuf<uint8_t> zfile, file; DevBuf<InflateBlock> zblk; uint64_t file_bytes = 0; float bgzf_h2d_ms = 0, bgzf_inflate_ms = 0;
+    DevBuf<uint8_t> zfile, file, zscratch; DevBuf<InflateBlock> zblk; uint64_t file_bytes = 0; float bgzf_h2d_ms = 0, bgzf_inflate_ms = 0;
     DevBuf<unsigned long long> tg_len, tg_off; DevBuf<uint2> tg_spans; DevBuf<uint8_t> tg_stream, tg_status, tg_hp; DevBuf<int32_t> tg_ps, tg_pq; int64_t cur_first = -1, cur_count = 0;
     uint8_t *stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; size_t stage_bytes = 0;   // pinned staging ring for large pageable uploads
     DevBuf<uint8_t> dz_slots, dz_packed; DevBuf<uint32_t> dz_bytes; DevBuf<unsigned long long> dz_tmp; DevBuf<uint64_t> dz_off; uint64_t dz_total = 0; float dz_ms = 0;
@@ -604,7 +604,8 @@ int lps_bgzf_load(lps_ctx *c, const uint8_t *bgzf, int64_t n_bytes, int64_t *inf
         HIP_TRY(hipMemcpyAsync(c->zblk.p, blks.data(), blks.size() * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s));
         HIP_TRY(hipEventRecord(e1, s));
-        launch_bgzf_inflate(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, s);
+        c->zscratch.reserve(bgzf_inflate_scratch_bytes((int)blks.size()), s);
+        launch_bgzf_inflate(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, c->zscratch.p, s);
         launch_bgzf_crc(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, s);
         HIP_TRY(hipMemsetAsync(c->file.p + utot, 0, 64, s));
         HIP_TRY(hipEventRecord(e2, s));

@@ -11,5 +11,6 @@ struct InflateBlock {       // one BGZF block: raw deflate bytes [in_off, in_off
     uint32_t in_len, out_len;
 };
 
-void launch_bgzf_inflate(const uint8_t *in, const InflateBlock *blk, int n_blk, uint8_t *out, unsigned *err, hipStream_t s);
+size_t bgzf_inflate_scratch_bytes(int n_blk);      // per-lane scratch columns for the code lengths of a header
+void launch_bgzf_inflate(const uint8_t *in, const InflateBlock *blk, int n_blk, uint8_t *out, unsigned *err, uint8_t *scratch, hipStream_t s);
 void launch_bgzf_crc(const uint8_t *in, const InflateBlock *blk, int n_blk, const uint8_t *out, unsigned *err, hipStream_t s);

@@ -3,14 +3,19 @@
 // What it replaces: htslib's bgzf.c block inflate behind sam_itr_multi_next (src/phase/ParsingBam.cpp:1279,
 // src/haplotag/HaplotagParsingBam.cpp:453), the largest share of the reference's wall clock.
 //
-// One LANE per BGZF block (blocks are independent, ≤64 KiB each; a chr20-30x BAM has ~50 k of them): the bit stream is
-// inherently serial inside a block, so the parallelism is across blocks.  Per lane the Huffman tables live in LDS,
-// laid out [entry][lane] so that the 64 lanes of a wave always hit 64 different banks/words whatever entry each one needs:
-//   fast  u16[256]  litlen codes of <=8 bits: (symbol << 4) | length, 0 = take the canonical path
-//   lsym  u16[288]  litlen symbols sorted by (length, symbol); llim/lbase u16[8]: limit + list offset of lengths 9..15 (branch-free canonical decode)
-//   dsym  u8[32], dlim/dbase u16[16]   same for distances (decoded only after a length symbol, so no fast table)
+// One LANE per BGZF block (blocks are independent, <=64 KiB each; a chr20-30x BAM has ~50 k of them): the bit stream is
+// inherently serial inside a block, so the parallelism is across blocks.  What limits the kernel is how many such lanes a CU holds: the
+// Huffman tables of a lane live in LDS, and a lone wavefront per SIMD issues a dependent instruction only every ~6 cycles
+// (profiles/r02_inflate_counters.md).  Round 2 put the tables on a diet - 548 bytes per lane instead of 1 280, FOUR wavefronts per CU, one on
+// every SIMD, instead of two - laid out [entry][lane] so that lanes never share a word:
+//   lsym8 u8[288] + lhi 36 B   litlen symbols sorted by (length, symbol), 9 bits each: low byte + a bit array
+//   llim / lbase u16[16]        limit + list offset per code length 1..15 (branch-free canonical decode; no first-level table any more:
+//                               the 8-bit table cost 512 B per lane, and with 64 lanes in lockstep some lane missed it every iteration anyway)
+//   dsym u8[32], dlim / dbase u16[16]   same for distances; they also hold the code-length code while a dynamic header is read
 //   ring  64 output bytes, written to HBM as aligned 32-byte segments
-// 80 KiB per 64-lane workgroup => 2 workgroups per CU.  The input is read as aligned dwords, two dwords ahead of use.
+// A header's code lengths (<= 316) go to a per-lane scratch column in GLOBAL memory (written once, read once while the sorted lists are built:
+// a few headers per block), the per-length counters and list cursors sit packed in registers.
+// The input is read as aligned dwords, two dwords ahead of use.
 // Errors (corrupt stream, output overrun) set a flag; nothing is written outside [out_off, out_off + out_len).
 #include <hip/hip_runtime.h>
 
@@ -19,9 +24,6 @@
 #include "lps_inflate.h"
 
 #define L(a, i) a[(i) * 64 + lane]
-// header scratch inside the lane's OWN column of the fast table (lanes sit in different states, so a scratch laid out any other way would
-// trample a neighbour's live table): code length i = byte (i & 1) of cell i >> 1 (cells 0..159), cnt[16] = cells 160.., offs[16] = cells 176..
-#define LENS(i) lens[((((i) >> 1) * 64 + lane) << 1) + ((i) & 1)]
 
 struct BitIn {
     const uint32_t *w2;     // address of the dword that a2 holds / is being loaded into a2
@@ -43,54 +45,41 @@ __device__ __forceinline__ uint32_t peek15(const BitIn &b) { return __brev((uint
 
 // Canonical decode by limits: lim[len] = (first_code[len] + count[len]) << (15 - len) is non-decreasing in len, the code's length is the
 // smallest len with peek < lim[len]; its symbol sits at base[len] + (peek >> (15 - len)) in the (length, symbol)-sorted list.
-// Branch-free over the lengths LO..15, so the lanes of a wave never serialise on it.  Returns the length (0 = invalid code).
-template <int LO>
+// Branch-free over the lengths 1..15, so the lanes of a wave never serialise on it.  Returns the length (0 = invalid code).
 __device__ __forceinline__ int decode_limit(uint32_t peek, const uint16_t *lim, const uint16_t *base, int lane, uint32_t &index) {
     int sel = 0;
 #pragma unroll
-    for (int len = 15; len >= LO; --len) sel = peek < (uint32_t)L(lim, len - LO) ? len : sel;
-    const int s = sel ? sel : LO;
-    index = (uint16_t)(L(base, s - LO) + (peek >> (15 - s)));
+    for (int len = 15; len >= 1; --len) sel = peek < (uint32_t)L(lim, len - 1) ? len : sel;
+    const int s = sel ? sel : 1;
+    index = (uint16_t)(L(base, s - 1) + (peek >> (15 - s)));
     return sel;
 }
 
-// lengths (bytes, [i][lane] in `lens`) -> (length, symbol)-sorted symbols + limit/base per length LO..15.  cnt/offs: 16-entry scratch.
-// cnt8[k] receives the number of codes of length k (k = 1..8) for the fast table.  false when over-subscribed.
-template <int LO, class SymT>
-__device__ __forceinline__ bool build_canon(const uint8_t *lens, int first, int n, SymT *sym, uint16_t *lim, uint16_t *base, uint16_t *cnt, uint16_t *offs,
-                                            int lane, int *cnt8) {
-    for (int l = 0; l < 16; ++l) L(cnt, l) = 0;
-    for (int s = 0; s < n; ++s) { const int l = LENS(first + s); L(cnt, l) = L(cnt, l) + 1; }
-    int left = 1;
-    for (int l = 1; l < 16; ++l) { left <<= 1; left -= L(cnt, l); if (left < 0) return false; }
-    L(offs, 1) = 0;
-    for (int l = 1; l < 15; ++l) L(offs, l + 1) = L(offs, l) + L(cnt, l);
-    for (int s = 0; s < n; ++s) { const int l = LENS(first + s); if (l) { const int o = L(offs, l); L(sym, o) = (SymT)s; L(offs, l) = o + 1; } }
-    int code = 0, index = 0;
+// sixteen 16-bit counters in four registers (per-length symbol counts / list cursors of a header): a lane's own, indexed at run time by selects
+struct Pack16 { uint64_t a, b, c, d; };
+__device__ __forceinline__ unsigned p16_get(const Pack16 &p, int k) {
+    const uint64_t w = (k & 8) ? ((k & 4) ? p.d : p.c) : ((k & 4) ? p.b : p.a);
+    return (unsigned)(w >> ((k & 3) * 16)) & 0xffffu;
+}
+__device__ __forceinline__ void p16_add(Pack16 &p, int k, unsigned v) {
+    const uint64_t inc = (uint64_t)v << ((k & 3) * 16); const int q = k >> 2;
+    p.a += q == 0 ? inc : 0ull; p.b += q == 1 ? inc : 0ull; p.c += q == 2 ? inc : 0ull; p.d += q == 3 ? inc : 0ull;
+}
+// counts per length -> limit/base per length 1..15 and the first list slot of every length.  false when over-subscribed; incomplete sets are
+// legal while unused (a code that falls into the gap decodes to "invalid").
+__device__ __forceinline__ bool canon_tables(const Pack16 &cnt, uint16_t *lim, uint16_t *base, int lane, Pack16 &offs) {
+    bool ok = true; int left = 1;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) { left <<= 1; left -= (int)p16_get(cnt, l); if (left < 0) ok = false; }
+    int code = 0, index = 0; offs = Pack16{0, 0, 0, 0};
 #pragma unroll
     for (int l = 1; l <= 15; ++l) {
-        const int c = L(cnt, l);
-        if (l >= LO) { L(lim, l - LO) = (uint16_t)((code + c) << (15 - l)); L(base, l - LO) = (uint16_t)(index - code); }
-        if (cnt8 && l <= 8) cnt8[l] = c;
+        const int c = (int)p16_get(cnt, l);
+        L(lim, l - 1) = (uint16_t)((code + c) << (15 - l)); L(base, l - 1) = (uint16_t)(index - code);
+        p16_add(offs, l, (unsigned)index);
         index += c; code = (code + c) << 1;
     }
-    return true;                                                       // incomplete sets are legal while unused; a bad code decodes to "invalid"
-}
-
-// fast table (codes of length <= 8) from the sorted symbol list and the per-length counts
-__device__ __forceinline__ void build_fast(uint16_t *fast, const uint16_t *sym, const int *cnt8, int lane) {
-    for (int k = 0; k < 256; ++k) L(fast, k) = 0;
-    int code = 0, index = 0;
-#pragma unroll
-    for (int len = 1; len <= 8; ++len) {
-        const int c = cnt8[len];
-        for (int j = 0; j < c; ++j) {
-            const uint32_t rev = __brev((uint32_t)(code + j)) >> (32 - len);
-            const uint16_t e = (uint16_t)((L(sym, index + j) << 4) | len);
-            for (uint32_t k = rev; k < 256; k += 1u << len) L(fast, k) = e;
-        }
-        index += c; code = (code + c) << 1;
-    }
+    return ok;
 }
 
 // The loop below is ONE state machine per lane - header / stored byte / match byte / symbol - iterated in lockstep by the wave, so a lane in
@@ -99,10 +88,12 @@ __device__ __forceinline__ void build_fast(uint16_t *fast, const uint16_t *sym, 
 // behind a whole iteration of the other lanes' work.
 // Output bytes go to a 64-byte LDS ring per lane and reach HBM as aligned 32-byte segments (2 x dwordx4), flushed at a wave-uniform
 // cadence: few stores, so the in-order vmcnt queue does not stall the input prefetch behind them.
-__global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__ in, const InflateBlock *__restrict__ blk, int n_blk, uint8_t *out, unsigned *err) {
-    __shared__ uint16_t s_fast[256 * 64];                                  // 32 KiB; a lane's column doubles as its scratch while it parses a header
-    __shared__ uint16_t s_lsym[288 * 64];
-    __shared__ uint16_t s_llim[8 * 64], s_lbase[8 * 64];                   // litlen lengths 9..15
+#define INF_SCRATCH 320      // code lengths of one header per lane (<= 286 + 30), bytes; column layout [i][lane] per wavefront
+__global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__ in, const InflateBlock *__restrict__ blk, int n_blk, uint8_t *out, unsigned *err,
+                                                      uint8_t *scratch) {
+    __shared__ uint8_t s_lsym8[288 * 64];                                  // low byte of the (length, symbol)-sorted litlen symbols
+    __shared__ uint8_t s_lhi[36 * 64];                                     // their ninth bit, 8 per byte
+    __shared__ uint16_t s_llim[16 * 64], s_lbase[16 * 64];                 // litlen lengths 1..15
     __shared__ uint8_t s_dsym[32 * 64];
     __shared__ uint16_t s_dlim[16 * 64], s_dbase[16 * 64];                 // distance (and code-length code) lengths 1..15
     __shared__ uint32_t s_ring[16 * 64];                                   // 64 output bytes per lane, slot = global address & 63
@@ -112,6 +103,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
     const uint64_t gbase = B.out_off;                                       // global byte offset of this block's output
     uint8_t *o = out + gbase; uint32_t op = 0, fl = 0; const uint32_t on = B.out_len;
     const uint8_t *ip = in + B.in_off;
+    uint8_t *gl = scratch + (size_t)blockIdx.x * INF_SCRATCH * 64 + lane;   // this lane's scratch column: entry i at gl[i * 64]
     BitIn b;
     {   // aligned dword stream (pointer arithmetic on the kernel argument keeps these GLOBAL loads: a flat load would drag lgkmcnt into every
         // wait); `in` is 256-byte aligned.  Bits past the block's end are never consumed by a valid stream (checked at the end).
@@ -120,8 +112,6 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
         const uint32_t w0 = w[0]; b.a0 = w[1]; b.a1 = w[2]; b.a2 = w[3]; b.w2 = w + 3;
         b.buf = (uint64_t)(w0 >> (8 * sh)); b.cnt = 32 - 8 * sh; b.shift = false;
     }
-    uint8_t *lens = reinterpret_cast<uint8_t *>(s_fast);
-    uint16_t *t_cnt = s_fast + 160 * 64, *t_offs = s_fast + 176 * 64;
     uint8_t *ring = reinterpret_cast<uint8_t *>(s_ring);
     const uint32_t gb6 = (uint32_t)gbase & 63u;
     auto ring_at = [&](uint32_t pos) -> uint8_t & { const uint32_t slot = (gb6 + pos) & 63u; return ring[((slot >> 2) * 64 + lane) * 4 + (slot & 3)]; };
@@ -138,6 +128,8 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
         } else { for (uint32_t k = fl; k < nb; ++k) o[k] = ring_at(k); }
         fl = nb;
     };
+    // litlen symbol of sorted slot idx: low byte + ninth bit
+    auto litlen_at = [&](uint32_t idx) -> int { return (int)L(s_lsym8, idx) | ((((int)s_lhi[(idx >> 3) * 64 + lane] >> (idx & 7u)) & 1) << 8); };
     enum { ST_HDR = 0, ST_SYM = 1, ST_STORED = 2, ST_DONE = 3, ST_DIST = 4 };
     int state = (active && on) ? ST_HDR : ST_DONE; bool last = false; unsigned e = 0;
     uint32_t mlen = 0, msrc = 0, slen = 0, iter = 0, mpend = 0;
@@ -160,16 +152,15 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
         if (!copying) {
             if (state == ST_SYM) {
                 refill(b);
-                int sym; const uint32_t fe = L(s_fast, (uint32_t)b.buf & 255u);
-                if (fe) { const int l = fe & 15; sym = (int)(fe >> 4); b.buf >>= l; b.cnt -= l; }
-                else { uint32_t idx; const int l = decode_limit<9>(peek15(b), s_llim, s_lbase, lane, idx); if (!l || idx >= 288) { e = LPS_INF_ERR_DATA; sym = 256; last = true; } else { sym = L(s_lsym, idx); b.buf >>= l; b.cnt -= l; } }
+                int sym; uint32_t idx; const int l = decode_limit(peek15(b), s_llim, s_lbase, lane, idx);
+                if (!l || idx >= 288) { e = LPS_INF_ERR_DATA; sym = 256; last = true; } else { sym = litlen_at(idx); b.buf >>= l; b.cnt -= l; }
                 if (sym < 256) {
                     if (op >= on) { e = LPS_INF_ERR_OVERRUN; state = ST_DONE; }
                     else {
                         ring_at(op) = (uint8_t)sym; ++op;
-                        // a second literal in the same iteration when the next code is a short one (<= 8 bits; at least 18 bits are still buffered)
-                        const uint32_t f2 = L(s_fast, (uint32_t)b.buf & 255u);
-                        if (f2 && (f2 >> 4) < 256u && op < on) { const int l2 = f2 & 15; b.buf >>= l2; b.cnt -= l2; ring_at(op) = (uint8_t)(f2 >> 4); ++op; }
+                        // a second literal in the same iteration when the next code is one (at least 18 bits are still buffered: a code has 15 at most)
+                        uint32_t i2; const int l2 = decode_limit(peek15(b), s_llim, s_lbase, lane, i2);
+                        if (l2 && i2 < 288 && op < on) { const int s2 = litlen_at(i2); if (s2 < 256) { b.buf >>= l2; b.cnt -= l2; ring_at(op) = (uint8_t)s2; ++op; } }
                     }
                 }
                 else if (sym == 256) { state = last ? ST_DONE : ST_HDR; }
@@ -183,7 +174,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
                 }
             } else if (state == ST_DIST) {
                 refill(b);
-                uint32_t idx; const int l = decode_limit<1>(peek15(b), s_dlim, s_dbase, lane, idx);
+                uint32_t idx; const int l = decode_limit(peek15(b), s_dlim, s_dbase, lane, idx);
                 const int ds = (l && idx < 30) ? (int)L(s_dsym, idx) : 30;
                 if (ds >= 30) { e = LPS_INF_ERR_DATA; state = ST_DONE; }
                 else {
@@ -207,43 +198,56 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
                 } else if (type == 3) { e = LPS_INF_ERR_DATA; state = ST_DONE; }
                 else {
                     int nlen = 288, ndist = 30; bool bad = false;
+                    Pack16 cl{0, 0, 0, 0}, cd{0, 0, 0, 0}, offs;          // symbols per code length: litlen, distance
                     if (type == 1) {                                       // fixed codes (RFC 1951 3.2.6)
-                        for (int s = 0; s < 144; ++s) LENS(s) = 8;
-                        for (int s = 144; s < 256; ++s) LENS(s) = 9;
-                        for (int s = 256; s < 280; ++s) LENS(s) = 7;
-                        for (int s = 280; s < 288; ++s) LENS(s) = 8;
-                        for (int s = 288; s < 318; ++s) LENS(s) = 5;
+                        for (int s = 0; s < 144; ++s) gl[s * 64] = 8;
+                        for (int s = 144; s < 256; ++s) gl[s * 64] = 9;
+                        for (int s = 256; s < 280; ++s) gl[s * 64] = 7;
+                        for (int s = 280; s < 288; ++s) gl[s * 64] = 8;
+                        for (int s = 288; s < 318; ++s) gl[s * 64] = 5;
+                        p16_add(cl, 7, 24); p16_add(cl, 8, 152); p16_add(cl, 9, 112); p16_add(cd, 5, 30);
                     } else {                                               // dynamic: code-length code, then the two length vectors
                         nlen = (int)take(b, 5) + 257; ndist = (int)take(b, 5) + 1; const int ncode = (int)take(b, 4) + 4;
                         if (nlen > 286 || ndist > 30) bad = true;
-                        for (int s = 0; s < 19; ++s) LENS(s) = 0;
+                        uint64_t clv = 0;                                  // the 19 lengths of the code-length code, 3 bits each
                         for (int k = 0; k < ncode && !bad; ++k) {
                             refill_now(b, w_end);
                             const int pos = k < 3 ? 16 + k : k == 3 ? 0 : (k & 1) ? 8 - ((k - 3) >> 1) : 7 + ((k - 2) >> 1);   // 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
-                            LENS(pos) = (uint8_t)take(b, 3);
+                            clv |= (uint64_t)take(b, 3) << (3 * pos);
                         }
-                        if (!bad && !build_canon<1, uint8_t>(lens, 0, 19, s_dsym, s_dlim, s_dbase, t_cnt, t_offs, lane, nullptr)) bad = true;
-                        int idx = 0;
+                        Pack16 cc{0, 0, 0, 0};
+                        for (int s = 0; s < 19; ++s) p16_add(cc, (int)((clv >> (3 * s)) & 7u), 1);
+                        if (!bad && !canon_tables(cc, s_dlim, s_dbase, lane, offs)) bad = true;
+                        for (int s = 0; s < 19 && !bad; ++s) { const int l = (int)((clv >> (3 * s)) & 7u); if (l) { L(s_dsym, p16_get(offs, l)) = (uint8_t)s; p16_add(offs, l, 1); } }
+                        int idx = 0, prev = 0; bool eob = false;
+                        auto put_len = [&](int v) { gl[idx * 64] = (uint8_t)v; if (idx < nlen) p16_add(cl, v, 1); else p16_add(cd, v, 1); if (idx == 256 && v) eob = true; prev = v; ++idx; };
                         while (!bad && idx < nlen + ndist) {
                             refill_now(b, w_end);
-                            uint32_t si; const int l = decode_limit<1>(peek15(b), s_dlim, s_dbase, lane, si);
+                            uint32_t si; const int l = decode_limit(peek15(b), s_dlim, s_dbase, lane, si);
                             if (!l || l > 7 || si >= 19) { bad = true; break; }
                             const int sym = L(s_dsym, si); b.buf >>= l; b.cnt -= l;
-                            if (sym < 16) { LENS(idx) = (uint8_t)sym; ++idx; continue; }
+                            if (sym < 16) { put_len(sym); continue; }
                             int rep, val = 0;
-                            if (sym == 16) { if (idx == 0) { bad = true; break; } val = LENS(idx - 1); rep = 3 + (int)take(b, 2); }
+                            if (sym == 16) { if (idx == 0) { bad = true; break; } val = prev; rep = 3 + (int)take(b, 2); }
                             else if (sym == 17) rep = 3 + (int)take(b, 3);
                             else rep = 11 + (int)take(b, 7);
                             if (idx + rep > nlen + ndist) { bad = true; break; }
-                            while (rep--) { LENS(idx) = (uint8_t)val; ++idx; }
+                            while (rep--) put_len(val);
                         }
-                        if (!bad && LENS(256) == 0) bad = true;            // no end-of-block code
+                        if (!bad && !eob) bad = true;                      // no end-of-block code
                     }
-                    int cnt8[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    if (!bad && !build_canon<9, uint16_t>(lens, 0, nlen, s_lsym, s_llim, s_lbase, t_cnt, t_offs, lane, cnt8)) bad = true;
-                    if (!bad && !build_canon<1, uint8_t>(lens, nlen, ndist, s_dsym, s_dlim, s_dbase, t_cnt, t_offs, lane, nullptr)) bad = true;
-                    if (bad) { e = LPS_INF_ERR_DATA; state = ST_DONE; }
-                    else { build_fast(s_fast, s_lsym, cnt8, lane); state = ST_SYM; }   // overwrites the scratch
+                    // litlen list: symbols placed by (length, symbol); the lengths come back from the scratch column
+                    if (!bad && !canon_tables(cl, s_llim, s_lbase, lane, offs)) bad = true;
+                    if (!bad) {
+                        for (int k = 0; k < 36; ++k) L(s_lhi, k) = 0;
+                        for (int s = 0; s < nlen; ++s) {
+                            const int l = gl[s * 64];
+                            if (l) { const unsigned at = p16_get(offs, l); L(s_lsym8, at) = (uint8_t)s; if (s >> 8) s_lhi[(at >> 3) * 64 + lane] |= (uint8_t)(1u << (at & 7u)); p16_add(offs, l, 1); }
+                        }
+                    }
+                    if (!bad && !canon_tables(cd, s_dlim, s_dbase, lane, offs)) bad = true;
+                    if (!bad) for (int s = 0; s < ndist; ++s) { const int l = gl[(nlen + s) * 64]; if (l) { L(s_dsym, p16_get(offs, l)) = (uint8_t)s; p16_add(offs, l, 1); } }
+                    if (bad) { e = LPS_INF_ERR_DATA; state = ST_DONE; } else state = ST_SYM;
                 }
             }
         }
@@ -329,6 +333,7 @@ void launch_bgzf_crc(const uint8_t *in, const InflateBlock *blk, int n_blk, cons
     if (n_blk > 0) hipLaunchKernelGGL(k_bgzf_crc, dim3((n_blk + 3) / 4), dim3(256), 0, s, in, blk, n_blk, out, err);
 }
 
-void launch_bgzf_inflate(const uint8_t *in, const InflateBlock *blk, int n_blk, uint8_t *out, unsigned *err, hipStream_t s) {
-    if (n_blk > 0) hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_blk + 63) / 64), dim3(64), 0, s, in, blk, n_blk, out, err);
+size_t bgzf_inflate_scratch_bytes(int n_blk) { return (size_t)((n_blk + 63) / 64) * INF_SCRATCH * 64; }
+void launch_bgzf_inflate(const uint8_t *in, const InflateBlock *blk, int n_blk, uint8_t *out, unsigned *err, uint8_t *scratch, hipStream_t s) {
+    if (n_blk > 0) hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_blk + 63) / 64), dim3(64), 0, s, in, blk, n_blk, out, err, scratch);
 }
