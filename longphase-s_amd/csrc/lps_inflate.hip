@@ -146,6 +146,16 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
     // for at least 10 bits - anything beyond this bound is a crafted stream (the header path clamps its reads at w_end, so the guard above alone
     // would never trip on an endless run of empty blocks)
     const uint32_t iter_cap = 16u * (B.in_len * 8u + on) + 4096u;
+    auto decode_distance = [&]() {                                          // distance code + extra bits of the match whose length is in mpend
+        uint32_t idx; const int l = decode_limit(peek15(b), s_dlim, s_dbase, lane, idx);
+        const int ds = (l && idx < 30) ? (int)L(s_dsym, idx) : 30;
+        if (ds >= 30) { e = LPS_INF_ERR_DATA; state = ST_DONE; return; }
+        b.buf >>= l; b.cnt -= l;
+        uint32_t dist;
+        if (ds < 4) dist = 1 + ds; else { const int x = (ds >> 1) - 1; dist = ((2u + (ds & 1)) << x) + 1 + take(b, x); }
+        if (dist > op || op + mpend > on) { e = dist > op ? LPS_INF_ERR_DATA : LPS_INF_ERR_OVERRUN; state = ST_DONE; }
+        else { mlen = mpend; msrc = op - dist; state = ST_SYM; }
+    };
     while (state != ST_DONE) {
         if (b.w2 > w_end || iter > iter_cap) { e = LPS_INF_ERR_DATA; break; }
         const bool copying = mlen != 0;
@@ -169,21 +179,14 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
                     if (sym >= 29) { e = LPS_INF_ERR_DATA; state = ST_DONE; }
                     else {
                         if (sym < 8) mpend = 3 + sym; else if (sym == 28) mpend = 258; else { const int x = (sym >> 2) - 1; mpend = ((4u + (sym & 3)) << x) + 3 + take(b, x); }
-                        state = ST_DIST;                                   // the distance code is read next iteration (one refill per iteration)
+                        // the distance code right away when its 28 bits at most (15 + 13 extra) are still buffered - a match then costs one iteration
+                        // less; else next iteration, after its refill (one refill per iteration)
+                        if (b.cnt >= 28) decode_distance(); else state = ST_DIST;
                     }
                 }
             } else if (state == ST_DIST) {
                 refill(b);
-                uint32_t idx; const int l = decode_limit(peek15(b), s_dlim, s_dbase, lane, idx);
-                const int ds = (l && idx < 30) ? (int)L(s_dsym, idx) : 30;
-                if (ds >= 30) { e = LPS_INF_ERR_DATA; state = ST_DONE; }
-                else {
-                    b.buf >>= l; b.cnt -= l;
-                    uint32_t dist;
-                    if (ds < 4) dist = 1 + ds; else { const int x = (ds >> 1) - 1; dist = ((2u + (ds & 1)) << x) + 1 + take(b, x); }
-                    if (dist > op || op + mpend > on) { e = dist > op ? LPS_INF_ERR_DATA : LPS_INF_ERR_OVERRUN; state = ST_DONE; }
-                    else { mlen = mpend; msrc = op - dist; state = ST_SYM; }
-                }
+                decode_distance();
             } else if (state == ST_STORED) {
                 if (slen == 0) { state = last ? ST_DONE : ST_HDR; }
                 else { refill(b); ring_at(op) = (uint8_t)take(b, 8); ++op; --slen; }
