@@ -439,7 +439,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         // the header becomes its own BGZF block(s); the GPU writes whole blocks per contig
     }
     unsigned long long st_count[8] = {0}, hp_count[3] = {0};
-    double t_score = 0, t_splice = 0, t_deflate = 0, t_load = 0, t_mark = now(); std::vector<uint8_t> zbuf;
+    double t_score = 0, t_splice = 0, t_deflate = 0, t_load = 0, t_mark = now(); std::vector<uint8_t> zbuf; uint8_t *pin[2] = {nullptr, nullptr};
     // ---- --gpus N (indexed BAM, GPU writer): scoring is per read and the output BGZF blocks of a contig depend on nothing but that contig, so the contigs
     //      are dealt longest-first onto N workers (one host thread + one GPU + its own view of the file each); every worker inflates, scores, re-tags and
     //      deflates its contigs, the main thread writes the finished contigs in VCF-header order (BGZF members concatenate).  No data-path collective.
@@ -627,10 +627,21 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         if (gpu_writer) {                                                 // tag splice + BGZF deflate on the GPU; the host only writes the finished blocks
             int64_t nb = 0;
             if (L.haplotag_write_bgzf(ctx, status.data(), hp.data(), psv.data(), pq.data(), nullptr, 0, &nb)) die(std::string("longphase_amd: ") + L.last_error(ctx));
-            if ((size_t)nb > zbuf.size()) zbuf.resize((size_t)nb + (zbuf.size() >> 1));
-            if (L.bgzf_deflate_fetch(ctx, zbuf.data(), (int64_t)zbuf.size(), nullptr)) die(std::string("longphase_amd: ") + L.last_error(ctx));
             t_splice += now() - t_mark; t_mark = now();
-            w.write_raw(zbuf.data(), (size_t)nb);
+            {   // the blocks leave the GPU in 64-MiB pieces through two page-locked buffers; a writer thread puts piece k on disk while piece k+1 arrives
+                const int64_t piece = 64ll << 20;
+                if (!pin[0]) { pin[0] = (uint8_t *)L.host_alloc((size_t)piece); pin[1] = (uint8_t *)L.host_alloc((size_t)piece); if (!pin[0] || !pin[1]) die("longphase_amd: cannot allocate page-locked host memory"); }
+                w.wait_writer();
+                std::thread wr; int k = 0;
+                for (int64_t off = 0; off < nb; off += piece, k ^= 1) {
+                    const int64_t len = std::min(piece, nb - off);
+                    if (L.bgzf_deflate_fetch_range(ctx, off, len, pin[k])) die(std::string("longphase_amd: ") + L.last_error(ctx));
+                    if (wr.joinable()) wr.join();                       // piece k-1 is on disk: its buffer is free for piece k+1
+                    uint8_t *src = pin[k];
+                    wr = std::thread([&w, src, len] { w.write_raw(src, (size_t)len); });
+                }
+                if (wr.joinable()) wr.join();
+            }
             for (size_t i = 0; i < n; ++i) { ++st_count[status[i] & 7]; if (status[i] == 0) ++hp_count[hp[i] < 3 ? hp[i] : 0]; }
             t_deflate += now() - t_mark; t_mark = now();
             std::cerr << "(" << chr << ")";
@@ -710,7 +721,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     fprintf(stderr, "total alignment %llu | tagged %llu (HP1 %llu, HP2 %llu) | untagged: low mapq %llu, unmapped %llu, secondary %llu, supplementary %llu, no variant %llu, beyond last variant %llu, judged %llu\n",
             total, hp_count[1] + hp_count[2], hp_count[1], hp_count[2], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6], hp_count[0]);
     fprintf(stderr, "vcf+fasta read %.3fs | %s %.3fs | wait for gpu context %.3fs | score %.3fs | %s %.3fs | %s %.3fs (%llu bytes) | total %.3fs\n",
-            t_text - t_begin, host_inflate ? "host inflate+walk" : gb.indexed ? "gpu inflate+scan per contig group (indexed)" : "gpu inflate+scan+copy back", host_inflate ? t_bam - t_text : t_gin - t_ctx + t_load, t_ctx - t_bam, t_score, gpu_writer ? "gpu tag splice+deflate+copy out" : "tag splice", t_splice, gpu_writer ? "write" : "deflate+write", t_deflate, w.bytes_out, now() - t_begin);
+            t_text - t_begin, host_inflate ? "host inflate+walk" : gb.indexed ? "gpu inflate+scan per contig group (indexed)" : "gpu inflate+scan+copy back", host_inflate ? t_bam - t_text : t_gin - t_ctx + t_load, t_ctx - t_bam, t_score, gpu_writer ? "gpu tag splice+deflate" : "tag splice", t_splice, gpu_writer ? "copy out+write (overlapped)" : "deflate+write", t_deflate, w.bytes_out, now() - t_begin);
     fflush(stderr);
     if (getenv("LPS_CLI_NO_FAST_EXIT")) return 0;                       // e.g. under a profiler that writes its report from an exit handler
     _exit(0);

@@ -681,6 +681,18 @@ int lps_bgzf_deflate_fetch(lps_ctx *c, uint8_t *dst, int64_t cap, double *kernel
     return 0;
 }
 
+int lps_bgzf_deflate_fetch_range(lps_ctx *c, int64_t offset, int64_t n, uint8_t *dst) {
+    if (!c || offset < 0 || n < 0 || (uint64_t)(offset + n) > c->dz_total || (n && !dst)) return fail(c, "lps_bgzf_deflate_fetch_range: range outside the deflated result");
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        if (n) HIP_TRY(hipMemcpyAsync(dst, c->dz_packed.p + offset, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+void *lps_host_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+void lps_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 int lps_bgzf_timings(lps_ctx *c, double *h2d_ms, double *inflate_ms) {
     if (!c) return -1;
     if (h2d_ms) *h2d_ms = c->bgzf_h2d_ms;
