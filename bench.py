@@ -439,6 +439,12 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if _HUNG:                                      # a helper thread is still inside RCCL: do not wait for it at interpreter exit
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
+
+
+_HUNG = []     # collective steps that did not return in time (snp_table_broadcast)
 
 
 def snp_table_broadcast(L, dist, dev, rank, world, contigs):
@@ -464,7 +470,16 @@ def snp_table_broadcast(L, dist, dev, rank, world, contigs):
             assert L.lps_comm_unique_id(uid) == 0
         t = torch.tensor(list(uid), dtype=torch.uint8); dist.broadcast(t, src=0)
         uid = (C.c_uint8 * 128)(*t.tolist())
-        comm = L.lps_comm_create(dev, world, rank, uid)
+        # the communicator comes up in a helper thread under a watchdog: a bootstrap that never completes (this path has only been rehearsed on
+        # one GPU) must cost the run two minutes and the collective, not the whole scaling measurement - the rank then derives its own table
+        box = {}
+        th = threading.Thread(target=lambda: box.update(comm=L.lps_comm_create(dev, world, rank, uid)), daemon=True)
+        th.start(); th.join(120.0)
+        if th.is_alive():
+            _HUNG.append("lps_comm_create")
+            log(f"[rank {rank}] RCCL communicator not up after 120 s; every rank derives its own contigs' table instead")
+            return None
+        comm = box.get("comm")
         if not comm:
             raise RuntimeError("lps_comm_create failed")
         counts = torch.zeros(len(contigs), dtype=torch.int64)
@@ -483,7 +498,13 @@ def snp_table_broadcast(L, dist, dev, rank, world, contigs):
             buf[4 * n:5 * n] = np.concatenate([p[1] for p in parts]); buf[5 * n:] = np.concatenate([p[2] for p in parts])
         t0 = time.perf_counter()
         ms = C.c_double(0)
-        rc = L.lps_comm_bcast(comm, buf.ctypes.data, buf.size, 0, C.byref(ms))
+        th = threading.Thread(target=lambda: box.update(rc=L.lps_comm_bcast(comm, buf.ctypes.data, buf.size, 0, C.byref(ms))), daemon=True)
+        th.start(); th.join(120.0)
+        if th.is_alive():
+            _HUNG.append("lps_comm_bcast")
+            log(f"[rank {rank}] ncclBroadcast not done after 120 s; every rank derives its own contigs' table instead")
+            return None
+        rc = box.get("rc", -1)
         if rc != 0:
             raise RuntimeError(f"lps_comm_bcast rc={rc}")
         info.update(bytes=int(buf.size), wall_ms=round((time.perf_counter() - t0) * 1e3, 2), device_ms=round(ms.value, 3), n_ranks_in_communicator=int(L.lps_comm_size(comm)))
