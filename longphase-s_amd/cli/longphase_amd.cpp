@@ -843,6 +843,9 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     gpu_init.join();
     if (!ctx) die("longphase_amd: " + L.error);
     const double t_in = now();
+    std::atomic<long long> ns_p1{0}, ns_p2{0}, ns_host{0}, ns_p3{0}, ns_splice{0}, ns_append{0}, ns_prep{0}, ns_purity{0}, ns_finish{0};      // where the time goes (summed over workers)
+    auto tick = [] { return std::chrono::steady_clock::now(); };
+    auto tock = [](std::atomic<long long> &acc, std::chrono::steady_clock::time_point t0) { acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
     SomaticThr T = somatic_thresholds(purity);
     auto announce = [&]() { if (purity <= 0 || purity > 1.0) std::cerr << "[WARNING] tumor purity is not in the range of 0.0 to 1.0: " << purity << "\n[WARNING] setting default parameters (tier " << T.tier << ")\n";
         else std::cerr << "setting filter params (tier " << T.tier << ") with tumor purity: " << purity << "\n"; };
@@ -888,8 +891,9 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     // One contig of one phase, on one GPU context.  Everything it adds to run-wide state goes to its own ContigAcc, merged in contig order by the caller - so the
     // contigs can be dealt onto several workers (--gpus N) and the outputs (filter log, tagged BAM, purity inputs) still come out in the reference's order.
     struct ContigAcc { std::vector<PurityDatum> pdata; size_t p_initial = 0; int lcvf[5] = {0, 0, 0, 0, 0}; std::ostringstream flog; std::set<int32_t> som;
-                       unsigned long long n_flag = 0, hp_hist[9] = {0}, st_count[8] = {0}; std::vector<uint8_t> out; size_t out_bytes = 0; bool ready = false; };
+                       unsigned long long n_flag = 0, hp_hist[9] = {0}, st_count[8] = {0}; uint8_t *out = nullptr; size_t out_bytes = 0; bool ready = false; };
     auto do_contig = [&](lps_ctx *ctx, const std::string &chr, int phase, ContigAcc &A) {
+        auto t_prep = tick();
         auto fail = [&]() { die(std::string("longphase_amd: ") + L.last_error(ctx)); };
         std::vector<PurityDatum> &pdata = A.pdata; size_t &p_initial = A.p_initial; int (&lcvf)[5] = A.lcvf; std::ostringstream &flog = A.flog;
         unsigned long long &n_somatic_flag = A.n_flag; unsigned long long (&hp_hist)[9] = A.hp_hist; unsigned long long (&st_count)[8] = A.st_count;
@@ -943,6 +947,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             vt.phase_set = ps.data();
             vt.somatic_role = role.data(); vt.derive_hp = derive.data(); vt.tumor_kind = tkind.data();
             // ---- pass 1: normal BAM (ExtractNorDataBamParser)
+            tock(ns_prep, t_prep);
+            auto t_stage = tick();
             std::vector<int32_t> nsite(nv * LPS_SITE_COUNTERS, 0);
             auto ni = nin.contigs.find(chr);
             if (ni != nin.contigs.end() && !ni->second.rec_off.empty()) {
@@ -951,6 +957,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                 if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) ||
                     L.push_bam_records(ctx, nin.z.data + nc.lo, (int64_t)(nc.hi - nc.lo), nc.rec_off.data(), (int64_t)nc.rec_off.size(), nid.data()) || L.somatic_extract_normal(ctx, &sc)) fail();
             }
+            tock(ns_p1, t_stage); t_stage = tick();
             // ---- pass 2: tumor BAM (ExtractTumDataBamParser)
             std::vector<int32_t> tsite(nv * LPS_TSITE_COUNTERS, 0), h1(nt), h2(nt), h3(nt), psmin(nt), endp(nt), rlen(nt);
             std::vector<uint8_t> tstat(nt), thp(nt), tnps(nt), has(nt);
@@ -1011,6 +1018,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                     else pdata.push_back(PurityDatum{tr_ratio, ncount}); }
                 return;
             }
+            tock(ns_p2, t_stage); t_stage = tick();
             // ---- host stages.  "exists": the site was touched by a tumor read (std::map entries of somaticPosInfo)
             std::vector<int> sites; std::vector<int> site_of(nv, -1);
             for (size_t v = 0; v < nv; ++v) { if (!tkind[v]) continue;
@@ -1075,10 +1083,15 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                     ivlCount[(size_t)z.first] = iv.count;
                     }
             }
-            std::vector<std::map<int, int>> winRef(ns), winAlt(ns);          // offset -> count per allele (PosSomaticOffsetBase)
+            // offset (-100..100) -> count per allele (PosSomaticOffsetBase; std::map<int,int> per site in the reference: flat counters here - the
+            // DenseAlt test below only counts offsets that qualify, up to three, so the order they are visited in does not matter)
+            const int WOFF = 100, WN = 2 * WOFF + 1;
+            std::vector<int32_t> winRef(ns * (size_t)WN, 0), winAlt(ns * (size_t)WN, 0);
             for (int64_t k = 0; k < te.n_windows; ++k) { const int sidx = site_of[(size_t)wn_site[(size_t)k]];
                 if (sidx < 0) continue;
-                (wn_al[(size_t)k] ? winAlt : winRef)[(size_t)sidx][wn_off[(size_t)k]]++;
+                const int off = wn_off[(size_t)k];
+                if (off < -WOFF || off > WOFF) die("[ERROR] difference window offset out of range");
+                (wn_al[(size_t)k] ? winAlt : winRef)[(size_t)sidx * WN + (size_t)(off + WOFF)]++;
                 }
             for (size_t i = 0; i < ns; ++i) {                                // somaticFeatureFilter
                 const size_t v = (size_t)sites[i];
@@ -1104,8 +1117,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                 { const float c1 = 0.5f, c2 = 0.6f;
                     const int target = c[0];
                     // DenseAlt: base.altCount
-                    for (auto &ao : winAlt[i]) { const auto ro = winRef[i].find(ao.first);
-                        const int ra = ro == winRef[i].end() ? 0 : ro->second, aa = ao.second;
+                    for (int w = 0; w < WN; ++w) { const int aa = winAlt[i * WN + (size_t)w]; if (!aa) continue;
+                        const int ra = winRef[i * WN + (size_t)w];
                         const double k1 = (double)aa / target, k2 = (double)aa / (ra + aa); if (k1 >= c1 && k2 >= c2) { if (++same == 3) break; } } }
                 sameCount[i] = same; const bool f_dense = same >= 3;
                 filt[i] = f_tinc || f_messy || f_count || f_hap || f_z || f_dense;
@@ -1138,11 +1151,14 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                     derive[v] = r1 >= 1.0f ? 1 : r2 >= 1.0f ? 2 : 0;
                     }   // a position that also has a normal row keeps its germline role in the tagging pass
             }
+            tock(ns_host, t_stage); t_stage = tick();
             // ---- pass 3: tagging (SomaticHaplotagChrProcessor::judgeHaplotype); the tumor reads are still resident
             std::vector<int32_t> g1(nt), g2(nt), g3(nt), dh1(nt), dh2(nt), gmin(nt); std::vector<uint8_t> gnps(nt);
             lps_somatic_tag_result tg{(int64_t)nt, status.data(), g1.data(), g2.data(), g3.data(), dh1.data(), dh2.data(), gnps.data(), gmin.data(), hp.data(), pq.data(), psv.data()};
             if (L.set_variants(ctx, &vt) || L.somatic_tag_chromosome(ctx, &tg)) fail();
+            tock(ns_p3, t_stage);
         }
+        auto t_splice = tick();
         // ---- writer: HP:Z / PS:i (when the read saw a normal phase set) / PQ:i  (SomaticHaplotagProcess.cpp:529-536), records in input order
         std::vector<uint64_t> out_off(nt + 1, 0);
         auto aux_of = [&](const uint8_t *r) { const uint32_t l_name = r[8], n_cig = r[12] | (r[13] << 8), l_seq = rd32(r + 16);
@@ -1152,22 +1168,32 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         auto tag_bytes = [&](size_t i) -> size_t { if (status[i] != 0 || !hp[i]) return 0;
             return 3 + strlen(hp_str[hp[i] < 9 ? hp[i] : 0]) + 1 + (psv[i] != -1 ? 7 : 0) + 7;
             };
-        for (size_t i = 0; i < nt; ++i) {
+        auto parallel_records = [&](const std::function<void(size_t, size_t)> &fn) {      // records are independent: -t threads share them
+            const int nth = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, nt / 256 + 1)); std::vector<std::thread> th;
+            for (int t = 0; t < nth; ++t) th.emplace_back([&, t] { fn(nt * t / nth, nt * (t + 1) / nth); });
+            for (auto &x : th) x.join();
+        };
+        std::atomic<int> malformed{0};
+        parallel_records([&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
             const uint8_t *r = tbase + tc.rec_off[i]; const uint32_t bs = rd32(r - 4); uint64_t len = 4ull + bs;
             if (status[i] == 0) { bool seen[3] = {false, false, false};
                 for (const uint8_t *p = aux_of(r), *end = r + bs; p < end;) { const size_t l = aux_field_len(p, end);
-                    if (!l) die("ERROR: malformed auxiliary field in " + tbam);
+                    if (!l) { malformed = 1; break; }
                     const int which = (p[0] == 'H' && p[1] == 'P') ? 0 : (p[0] == 'P' && p[1] == 'S') ? 1 : (p[0] == 'P' && p[1] == 'Q') ? 2 : -1;
                     if (which >= 0 && !seen[which]) { seen[which] = true;
                         len -= l;
                         } p += l;
                     }
                 len += tag_bytes(i); }
-            out_off[i + 1] = out_off[i] + len; ++st_count[status[i] & 7]; if (status[i] == 0) ++hp_hist[hp[i] < 9 ? hp[i] : 0];
-        }
-        std::vector<uint8_t> ob(out_off[nt] + 64);
-        for (size_t i = 0; i < nt; ++i) {
-            const uint8_t *r = tbase + tc.rec_off[i]; const uint32_t bs = rd32(r - 4); uint8_t *o = ob.data() + out_off[i];
+            out_off[i + 1] = len;
+        } });
+        if (malformed) die("ERROR: malformed auxiliary field in " + tbam);
+        for (size_t i = 0; i < nt; ++i) { out_off[i + 1] += out_off[i]; ++st_count[status[i] & 7]; if (status[i] == 0) ++hp_hist[hp[i] < 9 ? hp[i] : 0]; }
+        uint8_t *obp = (uint8_t *)malloc(out_off[nt] + 64); if (!obp) die("ERROR: out of memory");      // (not a vector: 2 GB would be zeroed first)
+        parallel_records([&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const uint8_t *r = tbase + tc.rec_off[i]; const uint32_t bs = rd32(r - 4); uint8_t *o = obp + out_off[i];
             if (status[i] != 0) { memcpy(o, r - 4, 4 + (size_t)bs); continue; }
             const uint8_t *aux = aux_of(r), *end = r + bs;
             uint8_t *q = o + 4;
@@ -1191,8 +1217,9 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                     };
                 if (psv[i] != -1) put_i('P', 'S', psv[i]); put_i('P', 'Q', pq[i]); }
             const uint32_t nbs = (uint32_t)(q - o) - 4; for (int k = 0; k < 4; ++k) o[k] = (uint8_t)(nbs >> (8 * k));
-        }
-        A.out.swap(ob); A.out_bytes = (size_t)out_off[nt];
+        } });
+        A.out = obp; A.out_bytes = (size_t)out_off[nt];
+        tock(ns_splice, t_splice);
         std::cerr << "(" << chr << ")";
     };
     // contigs dealt longest-first (tumor records) onto the workers; worker 0 is this thread's context, the others create theirs
@@ -1210,7 +1237,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         wctx[(size_t)g] = L.create((gpu + g) % n_dev, &P); if (!wctx[(size_t)g]) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
         L.set_stage_timing(wctx[(size_t)g], 0); }
     for (int phase = estimate ? 0 : 1; phase < 2; ++phase) {
-        if (phase == 1 && estimate) { purity = estimate_purity(pdata, p_initial, lcvf, prefix); T = somatic_thresholds(purity); announce(); }
+        if (phase == 1 && estimate) { auto tp = tick(); purity = estimate_purity(pdata, p_initial, lcvf, prefix); T = somatic_thresholds(purity); announce(); tock(ns_purity, tp); }
         std::vector<ContigAcc> acc(chr_vec.size()); std::mutex mu; std::condition_variable cv;
         auto run_share = [&](int g) { for (size_t i : share[(size_t)g]) { do_contig(wctx[(size_t)g], chr_vec[i], phase, acc[i]); { std::lock_guard<std::mutex> lk(mu); acc[i].ready = true; } cv.notify_all(); } };
         std::vector<std::thread> workers;
@@ -1223,15 +1250,15 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             if (write_log) flog << A.flog.str();
             if (!A.som.empty()) somatic_pos[chr_vec[i]].swap(A.som);
             n_somatic_flag += A.n_flag; for (int k = 0; k < 9; ++k) hp_hist[k] += A.hp_hist[k]; for (int k = 0; k < 8; ++k) st_count[k] += A.st_count[k];
-            if (A.out_bytes) w.append(A.out.data(), A.out_bytes);
-            std::vector<uint8_t>().swap(A.out); A.flog.str(std::string());
+            { auto ta = tick(); if (A.out_bytes) w.append(A.out, A.out_bytes); tock(ns_append, ta); }
+            free(A.out); A.out = nullptr; A.flog.str(std::string());
         }
         for (auto &x : workers) x.join();
     }
     for (int g = 1; g < n_workers; ++g) L.destroy(wctx[(size_t)g]);
     if (n_workers > 1) std::cerr << "\n" << n_workers << " workers (one GPU context each, contigs dealt by tumor record count)";
     std::cerr << "\n";
-    w.finish();
+    { auto tf = tick(); w.finish(); tock(ns_finish, tf); }
     if (write_log) flog.close();                                       // the process leaves through _exit: nothing is flushed implicitly
     if (write_sc_vcf) {                                                // VcfParser::writeProcess (src/haplotag/HaplotagVcfParser.cpp:548-614): the tumor VCF with FILTER rewritten
         std::ofstream o(prefix + "_sc.vcf"); if (!o) die("Fail to open output file: " + prefix + "_sc.vcf");
@@ -1263,7 +1290,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     fprintf(stderr, "somatic variant count(Flag): %llu\n", n_somatic_flag);
     fprintf(stderr, "total alignment %llu | HP1 %llu HP2 %llu HP1-1 %llu HP2-1 %llu HP3 %llu | judged untagged %llu | low mapq %llu unmapped %llu secondary %llu supplementary %llu no variant %llu beyond last variant %llu\n",
             total, hp_hist[1], hp_hist[2], hp_hist[5], hp_hist[7], hp_hist[3], hp_hist[0], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6]);
-    fprintf(stderr, "inputs %.3fs | passes + caller + writer %.3fs | total %.3fs\n", t_in - t_begin, now() - t_in, now() - t_begin);
+    fprintf(stderr, "inputs %.3fs | passes + caller + writer %.3fs (table %.3f, normal pass %.3f, tumor pass %.3f, host stages %.3f, purity %.3f, tagging pass %.3f, tag splice %.3f, deflate + write %.3f + %.3f) | total %.3fs\n", t_in - t_begin, now() - t_in,
+            ns_prep / 1e9, ns_p1 / 1e9, ns_p2 / 1e9, ns_host / 1e9, ns_purity / 1e9, ns_p3 / 1e9, ns_splice / 1e9, ns_append / 1e9, ns_finish / 1e9, now() - t_begin);
     fflush(stderr);
     if (getenv("LPS_CLI_NO_FAST_EXIT")) return 0;                       // e.g. under a profiler that writes its report from an exit handler
     _exit(0);
