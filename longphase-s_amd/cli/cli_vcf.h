@@ -31,7 +31,10 @@ static std::vector<std::string> split_tab(const std::string &s) {
 
 // SnpParser::SnpParser (ParsingBam.cpp:222-359): het bi-allelic SNPs (bcf_is_snp: every allele one base), with --indels every other
 // het bi-allelic record.  GT of the first sample must be 0/1, 1/0, 0|1 or 1|0.
-static void parse_vcf(const std::vector<std::string> &lines, bool indels, std::vector<std::string> &chr_order, std::map<std::string, ChrVariants> &out) {
+// --indelQuality N (with --indels; :229-235, 325-340): a het record that is not a SNP and whose QUAL is below N is dropped before anything else is
+// looked at, logged to <prefix>_removed_indels.log, and its FILTER reads INDEL_QUAL_FILTERED in the output VCF (IndelQual below).
+struct IndelQual { int threshold = 0; std::ofstream log; std::map<std::string, std::set<int32_t>> filtered; };
+static void parse_vcf(const std::vector<std::string> &lines, bool indels, std::vector<std::string> &chr_order, std::map<std::string, ChrVariants> &out, IndelQual *iq = nullptr) {
     for (const std::string &ln : lines) {
         if (ln.empty()) continue;
         if (ln[0] == '#') {
@@ -45,8 +48,14 @@ static void parse_vcf(const std::vector<std::string> &lines, bool indels, std::v
         std::vector<std::string> f = split_tab(ln);
         if (f.size() < 10) continue;
         const std::string &ref = f[3], &alt = f[4];
-        if (alt.find(',') != std::string::npos || alt.empty() || alt[0] == '<' || alt == "." || alt == "*") continue;
+        const bool unusable = alt.find(',') != std::string::npos || alt.empty() || alt[0] == '<' || alt == "." || alt == "*";
         const bool is_snp = ref.size() == 1 && alt.size() == 1;
+        if (!(iq && iq->threshold > 0 && indels) && (unusable || (!is_snp && !indels))) continue;
+        if (unusable && alt.find(',') != std::string::npos) {              // all-single-base alleles: htslib calls it a SNP, the multi-allele check drops it
+            bool all1 = ref.size() == 1; size_t a = 0;
+            while (all1) { const size_t b = alt.find(',', a); if ((b == std::string::npos ? alt.size() : b) - a != 1) all1 = false; if (b == std::string::npos) break; a = b + 1; }
+            if (all1) continue;
+        }
         if (!is_snp && !indels) continue;
         // GT position inside FORMAT
         std::vector<std::string> fmt, smp;
@@ -59,6 +68,17 @@ static void parse_vcf(const std::vector<std::string> &lines, bool indels, std::v
         if (gi >= fmt.size() || gi >= smp.size()) die("pos " + f[1] + " missing GT value");
         const std::string &gt = smp[gi];
         if (!(gt == "0/1" || gt == "1/0" || gt == "0|1" || gt == "1|0")) continue;
+        if (!is_snp && iq && iq->threshold > 0) {                          // :325-340, before the multi-allele check
+            float qual = 0.0f; bool missing = f[5] == ".";
+            if (!missing) { try { qual = std::stof(f[5]); } catch (...) { qual = 0.0f; missing = true; } }
+            if (qual < (float)iq->threshold) {
+                const std::string alt1 = alt.substr(0, alt.find(','));
+                if (iq->log.is_open()) iq->log << f[0] << "\t" << f[1] << "\t" << ref << "\t" << alt1 << "\t" << (missing ? std::string(".") : std::to_string(qual)) << "\n";
+                iq->filtered[f[0]].insert(std::stoi(f[1]) - 1);
+                continue;
+            }
+        }
+        if (unusable) continue;
         if (!out.count(f[0])) { out[f[0]]; chr_order.push_back(f[0]); }
         out[f[0]].rows[std::stoi(f[1]) - 1] = {ref, alt};           // map semantics: the later record at one position wins
     }
@@ -135,11 +155,14 @@ struct Phased { int32_t ps; char a, b; };
 // SnpParser::writeLine (ParsingBam.cpp:460-635) restated; SVParser::writeLine (:1042-1193) and METHParser::writeLine (:1788-1942) differ from it only
 // in how a record finds its result - `lookup(chromosome, 1-based POS)` returns it, or nullptr when the record is not phased or was not a row of the table
 template <class Lookup>
-static void rewrite_vcf(const std::vector<std::string> &lines, const std::string &out_path, const std::string &command, Lookup lookup) {
+static void rewrite_vcf(const std::vector<std::string> &lines, const std::string &out_path, const std::string &command, Lookup lookup, const IndelQual *iq = nullptr) {
     std::ofstream o(out_path); if (!o) die("Fail to open write file: " + out_path);
     bool ps_def = false, cmd_done = false;
     for (const std::string &in : lines) {
-        if (in.compare(0, 2, "##") == 0) { if (in.compare(0, 16, "##FORMAT=<ID=PS,") == 0) ps_def = true; o << in << "\n"; continue; }
+        if (in.compare(0, 2, "##") == 0) { if (in.compare(0, 16, "##FORMAT=<ID=PS,") == 0) ps_def = true; o << in << "\n";
+            if (iq && iq->threshold > 0 && in.compare(0, 17, "##FILTER=<ID=PASS") == 0)          // :467-473
+                o << "##FILTER=<ID=INDEL_QUAL_FILTERED,Description=\"Indel filtered due to QUAL below threshold (" << iq->threshold << ")\">\n";
+            continue; }
         if (in.compare(0, 6, "#CHROM") == 0 || in.compare(0, 6, "#chrom") == 0) {
             if (!cmd_done) {
                 if (!ps_def) { o << "##FORMAT=<ID=PS,Number=1,Type=Integer,Description=\"Phase set identifier\">\n"; ps_def = true; }
@@ -183,20 +206,21 @@ static void rewrite_vcf(const std::vector<std::string> &lines, const std::string
             const size_t gp = f[8].find("GT"); const size_t st = value_start(f[9], colon_index(f[8], gp));
             f[9][st] = ph->a; f[9][st + 1] = '|'; f[9][st + 2] = ph->b;
         } else { f[8] += ":PS"; f[9] += ":."; }
+        if (iq && iq->threshold > 0) { auto fc = iq->filtered.find(f[0]); if (fc != iq->filtered.end() && fc->second.count(pidx)) f[6] = "INDEL_QUAL_FILTERED"; }   // :619-623
         for (size_t i = 0; i < f.size(); ++i) { if (i) o << "\t"; o << f[i]; }
         o << "\n";
     }
 }
 
 static void write_vcf(const std::vector<std::string> &lines, const std::string &out_path, const std::map<std::string, std::map<int32_t, Phased>> &res,
-                      const std::map<std::string, ChrVariants> &vars, const std::string &command) {
+                      const std::map<std::string, ChrVariants> &vars, const std::string &command, const IndelQual *iq = nullptr) {
     rewrite_vcf(lines, out_path, command, [&](const std::string &chr, int32_t pos1) -> const Phased * {
         auto rc = res.find(chr); auto vc = vars.find(chr);
         if (rc == res.end() || vc == vars.end()) return nullptr;
         auto it = rc->second.find(pos1 - 1);
         if (it == rc->second.end() || !std::binary_search(vc->second.pos.begin(), vc->second.pos.end(), pos1 - 1)) return nullptr;
         return &it->second;
-    });
+    }, iq);
 }
 
 // ------------------------------------------------------------------------------------------------ haplotag

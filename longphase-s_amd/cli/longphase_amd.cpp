@@ -8,7 +8,7 @@
 //   SnpParser::writeLine (VCF rewrite rules)  src/phase/ParsingBam.cpp:460-635
 //   SVParser / METHParser (--sv-file, --mod-file) src/phase/ParsingBam.cpp:915-1206, 1647-1952   (cli_extra.h)
 //   SnpParser::preprocessDeepsomaticVCF (--deepsomatic_output) src/phase/ParsingBam.cpp:651-835, PhasingProcess.cpp:47-61
-// Not supported (the reference path must be used): --dot, CRAM.
+// Not supported (the reference path must be used): --dot, CRAM.   (--indelQuality: cli_vcf.h IndelQual)
 // Split in round 2: cli_common.h (loader), cli_bam.h (BGZF/BAM in, BGZF out), cli_vcf.h (VCF/FASTA in, phased VCF out), cli_purity.h (purity estimator).
 #include "cli_common.h"
 #include "cli_bam.h"
@@ -23,6 +23,7 @@ static const char *kUsage =
     "   --ont | --pb   --indels   -q MAPQ(1)  -p baseQuality(12)  -e edgeWeight(0.1)  -a connectAdjacent(35)  -d distance(300000)\n"
     "   -1 edgeThreshold(0.7)  -L overlapThreshold(0.2)  -m readConfidence(0.65)  -n snpConfidence(0.75)  --gpu=ID (0)\n"
     "   --deepsomatic_output   the SNP file is a DeepSomatic VCF: keep FILTER=GERMLINE records, genotype them from AD / VAF (writes <prefix>_preprocessed.vcf)\n"
+    "   --indelQuality=N       with --indels: indels below this QUAL are left out (logged to <prefix>_removed_indels.log, FILTER INDEL_QUAL_FILTERED)\n"
     "   --sv-file=NAME  --mod-file=NAME   co-phase structural variants / modcall records (outputs <prefix>_SV.vcf, <prefix>_mod.vcf)   -w svWindow(20)  -h svThreshold(0.1)\n"
     "   --host-inflate | --gpu-inflate   BGZF inflate with zlib on the -t host threads / on the GPU (default: GPU for one BAM of 256 MiB or more)\n"
     "   --no-index       ignore <bam>.bai: make the whole file resident on the GPU instead of one contig at a time\n"
@@ -33,7 +34,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over; bool indels = false;
     std::string snp, ref, prefix = "result", sv_file, mod_file;
     std::vector<std::string> bams;
-    int threads = 1, gpu = 0, n_gpus = 1, sv_window = 20; double sv_threshold = 0.1;
+    int threads = 1, gpu = 0, n_gpus = 1, sv_window = 20, indel_quality = 0; double sv_threshold = 0.1;
     uint64_t group_bytes = 8ull << 30;
     bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false, deepsomatic = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
@@ -82,7 +83,8 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "--no-index") no_index = true;
         else if (a == "--help") { std::cout << kUsage; return 0; }
         else if (a == "--deepsomatic_output") deepsomatic = true;
-        else if (a == "--dot" || a == "--indelQuality") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
+        else if (a == "--indelQuality") indel_quality = std::stoi(val());
+        else if (a == "--dot") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kUsage; return 1; }
     }
     if (!sv_file.empty()) {                                             // Phasing.cpp:304-318
@@ -107,7 +109,10 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         vcf_lines.swap(pre);
     }
     std::vector<std::string> chr_order; std::map<std::string, ChrVariants> vars;
-    parse_vcf(vcf_lines, indels, chr_order, vars);
+    IndelQual iq;
+    if (indels && indel_quality > 0) { iq.threshold = indel_quality; iq.log.open(prefix + "_removed_indels.log"); if (iq.log.is_open()) iq.log << "#CHROM\tPOS\tREF\tALT\tQUAL\n"; }
+    parse_vcf(vcf_lines, indels, chr_order, vars, &iq);
+    if (iq.log.is_open()) iq.log.close();
     // SV rows, then MOD rows: each reader drops what sits on a row of the tables read before it (PhasingProcess.cpp:69-79)
     std::vector<std::string> sv_lines, mod_lines; SvTable svt; ModTable modt;
     if (!sv_file.empty()) { if (!read_lines(sv_file, sv_lines)) die("ERROR: Cannot open vcf file " + sv_file); svt.parse(sv_lines, vars); }
@@ -277,7 +282,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     need_fasta();
     L.destroy(ctx);
     const double t_gpu = now();
-    write_vcf(vcf_lines, prefix + ".vcf", res, vars, command);
+    write_vcf(vcf_lines, prefix + ".vcf", res, vars, command, &iq);
     if (!sv_file.empty()) write_sv_vcf(sv_lines, prefix + "_SV.vcf", res, svt, command);          // PhasingProcess.cpp:191-203
     if (!mod_file.empty()) write_mod_vcf(mod_lines, prefix + "_mod.vcf", res, modt, command);
     if (gpu_input) fprintf(stderr, "%s | vcf read (fasta beside the gpu start-up) %.3fs | wait for gpu context %.3fs | map bam+header%s %.3fs | upload+gpu inflate %.3fs | gpu record scan %.3fs | names+decode+phase %.3fs | write vcf %.3fs | total %.3fs\n",

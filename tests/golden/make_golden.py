@@ -505,8 +505,37 @@ def make_cli_haplotag_extra():
     print("cli_haplotag_extra", out["n_records"], out["records_sha256"][:16], "records whose tags differ from the SNP-only run:", differ)
 
 
+def make_cli_indelq():
+    """`phase --indels --indelQuality 25` of the reference on the tiny_indel inputs with QUAL values spread over the records (missing, below, at and
+    above the threshold, fractional; also on SNP records, which the option must not touch)."""
+    src = [l.rstrip("\n") for l in open(os.path.join(HERE, "data", "tiny_indel.vcf"))]
+    quals = [".", "3", "10.5", "24.99", "25", "25.01", "40", "60", "0", "33.3"]
+    out = []; k = 0
+    for l in src:
+        if l.startswith("#"):
+            out.append(l); continue
+        f = l.split("\t"); f[5] = quals[k % len(quals)]; k += 1
+        out.append("\t".join(f))
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "iq.vcf"), "w").write("\n".join(out) + "\n")
+        with gzip.open(os.path.join(HERE, "data", "tiny_indel.sam.gz"), "rt") as fi:
+            open(os.path.join(d, "reads.sam"), "w").write(fi.read())
+        shutil.copy(os.path.join(HERE, "data", "tiny_indel.fa"), os.path.join(d, "ref.fa"))
+        subprocess.check_call([TEST_VIEW, "-b", "-x", "reads.bam.bai", "-p", "reads.bam", "reads.sam"], cwd=d, stdout=subprocess.DEVNULL)
+        r = subprocess.run([REF_BIN, "phase", "-s", "iq.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", "1", "-o", "out", "--ont", "--indels", "--indelQuality", "25"], cwd=d, capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            raise RuntimeError(f"reference failed rc={r.returncode}: {r.stderr[-2000:]}")
+        for fn in ("iq.vcf", "out.vcf", "out_removed_indels.log"):
+            with open(os.path.join(d, fn), "rb") as fi, gzip.GzipFile(os.path.join(HERE, "data", "cli_indelq." + fn + ".gz"), "wb", mtime=0) as fo:
+                shutil.copyfileobj(fi, fo)
+        print("cli_indelq: removed", sum(1 for _ in open(os.path.join(d, "out_removed_indels.log"))) - 1, "filtered tags", sum(1 for l in open(os.path.join(d, "out.vcf")) if "INDEL_QUAL_FILTERED" in l and not l.startswith("#")))
+
+
 def main():
     assert os.path.exists(REF_BIN), "build the reference first: oracle/build_ref.sh"
+    if "--cli-indelq" in sys.argv:
+        make_cli_indelq()
+        return
     if "--cli-haplotag-extra" in sys.argv:
         make_cli_haplotag_extra()
         return

@@ -50,6 +50,24 @@ def test_cli_phase_deepsomatic_output(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_phase_indel_quality(tmp_path):
+    """--indels --indelQuality 25: het indel records below the threshold are dropped (src/phase/ParsingBam.cpp:325-340), listed in
+    <prefix>_removed_indels.log and marked INDEL_QUAL_FILTERED in the output VCF (:467-473, 578-623); SNP records are not touched."""
+    import gzip
+    d = str(tmp_path)
+    gz = lambda n: gzip.open(os.path.join(DATA, "cli_indelq." + n + ".gz"), "rt").read()
+    open(d + "/iq.vcf", "w").write(gz("iq.vcf"))
+    write_bam(os.path.join(DATA, "tiny_indel.sam.gz"), d + "/r.bam")
+    r = subprocess.run([CLI, "phase", "-s", "iq.vcf", "-b", "r.bam", "-r", os.path.join(DATA, "tiny_indel.fa"), "-o", "o", "--ont", "--indels", "--indelQuality", "25"],
+                       cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert open(d + "/o_removed_indels.log").read() == gz("out_removed_indels.log")
+    strip = lambda t: [l for l in t.split("\n") if not l.startswith("##commandline=") and not l.startswith("##longphaseVersion=")]
+    assert strip(open(d + "/o.vcf").read()) == strip(gz("out.vcf"))
+    assert "INDEL_QUAL_FILTERED" in open(d + "/o.vcf").read()
+
+
+@pytest.mark.gpu
 def test_cli_rewrites_previously_phased_vcf(tmp_path):
     """Feeding the reference's own phased output back in (old PS keys, phased GTs) must reproduce it: exercises the
     PS strip / GT un-phase rules of SnpParser::writeLine (src/phase/ParsingBam.cpp:505-571)."""
