@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 13
+#define LPS_ABI_VERSION 14
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -295,6 +295,9 @@ int lps_bgzf_timings(lps_ctx *ctx, double *h2d_ms, double *inflate_ms);
  * member with CRC32/ISIZE; lps_bgzf_deflate leaves the blocks on the device and returns their total size, lps_bgzf_deflate_fetch copies them
  * to the host.  No EOF block is appended. */
 int lps_bgzf_deflate(lps_ctx *ctx, int64_t offset, int64_t n_bytes, int64_t *out_bytes);
+/* the same writer for bytes that sit in HOST memory (e.g. records a host-side splice produced): uploaded through the ctx's pinned ring, cut into
+ * BGZF blocks and deflated on the GPU; the result is fetched like that of lps_bgzf_deflate.  The resident stream of the ctx is not touched. */
+int lps_bgzf_deflate_host(lps_ctx *ctx, const uint8_t *bytes, int64_t n_bytes, int64_t *out_bytes);
 int lps_bgzf_deflate_fetch(lps_ctx *ctx, uint8_t *dst, int64_t cap, double *kernel_ms);
 /* the same in pieces: bytes [offset, offset + n) of the deflated result to `dst`.  With `dst` from lps_host_alloc (pinned memory) the copy runs at
  * PCIe speed and a writer thread can put piece k on disk while piece k+1 arrives (a 1.9 GB result into pageable memory costs 0.3 s). */

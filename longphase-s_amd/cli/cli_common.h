@@ -51,7 +51,7 @@ struct Lps {
     decltype(&lps_set_variants) set_variants = nullptr;
     decltype(&lps_set_reference) set_reference = nullptr;
     decltype(&lps_set_extra_variants) set_extra_variants = nullptr; decltype(&lps_get_extra_result) get_extra_result = nullptr; decltype(&lps_set_read_votes) set_read_votes = nullptr;
-    decltype(&lps_bgzf_deflate_fetch_range) bgzf_deflate_fetch_range = nullptr; decltype(&lps_host_alloc) host_alloc = nullptr; decltype(&lps_host_free) host_free = nullptr;
+    decltype(&lps_bgzf_deflate_fetch_range) bgzf_deflate_fetch_range = nullptr; decltype(&lps_bgzf_deflate_host) bgzf_deflate_host = nullptr; decltype(&lps_host_alloc) host_alloc = nullptr; decltype(&lps_host_free) host_free = nullptr;
     decltype(&lps_push_bam_records) push_bam_records = nullptr;
     decltype(&lps_phase_chromosome) phase_chromosome = nullptr;
     decltype(&lps_haplotag_chromosome) haplotag_chromosome = nullptr; decltype(&lps_abi_version) abi_version = nullptr;
@@ -82,7 +82,7 @@ struct Lps {
             }
 #define LPS_SYM(field, name) field = (decltype(field))dlsym(so, #name); if (!field) { error = "liblps_hip.so does not export " #name; return false; }
         LPS_SYM(default_params, lps_default_params) LPS_SYM(create, lps_create) LPS_SYM(destroy, lps_destroy) LPS_SYM(last_error, lps_last_error)
-        LPS_SYM(begin_chromosome, lps_begin_chromosome) LPS_SYM(set_variants, lps_set_variants) LPS_SYM(set_reference, lps_set_reference) LPS_SYM(set_extra_variants, lps_set_extra_variants) LPS_SYM(get_extra_result, lps_get_extra_result) LPS_SYM(set_read_votes, lps_set_read_votes) LPS_SYM(bgzf_deflate_fetch_range, lps_bgzf_deflate_fetch_range) LPS_SYM(host_alloc, lps_host_alloc) LPS_SYM(host_free, lps_host_free)
+        LPS_SYM(begin_chromosome, lps_begin_chromosome) LPS_SYM(set_variants, lps_set_variants) LPS_SYM(set_reference, lps_set_reference) LPS_SYM(set_extra_variants, lps_set_extra_variants) LPS_SYM(get_extra_result, lps_get_extra_result) LPS_SYM(set_read_votes, lps_set_read_votes) LPS_SYM(bgzf_deflate_fetch_range, lps_bgzf_deflate_fetch_range) LPS_SYM(bgzf_deflate_host, lps_bgzf_deflate_host) LPS_SYM(host_alloc, lps_host_alloc) LPS_SYM(host_free, lps_host_free)
         LPS_SYM(push_bam_records, lps_push_bam_records) LPS_SYM(phase_chromosome, lps_phase_chromosome) LPS_SYM(haplotag_chromosome, lps_haplotag_chromosome)
         LPS_SYM(abi_version, lps_abi_version) LPS_SYM(bgzf_load, lps_bgzf_load) LPS_SYM(bgzf_read, lps_bgzf_read) LPS_SYM(bam_scan, lps_bam_scan)
         LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range) LPS_SYM(device_count, lps_device_count) LPS_SYM(set_stage_timing, lps_set_stage_timing) LPS_SYM(haplotag_write_bgzf, lps_haplotag_write_bgzf) LPS_SYM(bgzf_deflate_fetch, lps_bgzf_deflate_fetch)

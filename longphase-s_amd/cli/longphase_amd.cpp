@@ -773,6 +773,7 @@ static const char *kSomUsage =
     "   --tumor-purity=Num (default: automatic estimation, written to <prefix>_purity.out)   --disableFilter   --somatic-calling-log (writes <prefix>_somatic_filter.log)\n"
     "   --output-somatic-vcf (writes <prefix>_sc.vcf: the tumor VCF with FILTER = PASS for the somatic calls, LowQual otherwise)\n"
     "   --tagSupplementary   -q qualityThreshold(1)   -p percentageThreshold(0.6)   -t threads(1)   -o out-prefix(result)   --gpu=ID (0)\n"
+    "   --host-deflate   zlib (level 6, RLE) on the -t threads for the tagged BAM instead of the GPU's BGZF writer\n"
     "   --gpus=N (deal the contigs onto N GPU contexts, devices --gpu, --gpu+1, ...: the three BAM passes of a contig run on its worker, purity is estimated\n"
     "             over all contigs, logs and the tagged BAM are merged in contig order)\n";
 
@@ -781,7 +782,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     std::string snp, ref, nbam, tvcf, tbam, prefix = "result";
     int threads = 1, gpu = 0, n_gpus = 1;
     double purity = -1, pct = 0.6;
-    bool enable_filter = true, write_log = false, write_sc_vcf = false;
+    bool enable_filter = true, write_log = false, write_sc_vcf = false; bool host_deflate = false, raw_started = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kSomUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -808,6 +809,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         else if (a == "--output-somatic-vcf") write_sc_vcf = true;
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--gpus") n_gpus = std::max(1, std::stoi(val()));
+        else if (a == "--host-deflate") host_deflate = true;
         else if (a == "--help") { std::cout << kSomUsage; return 0; }
         else if (a == "--cram" || a == "--region" || a == "--log" || a == "--truth-vcf" || a == "--truth-bed" || a == "--benchmark-log") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kSomUsage; return 1; }
@@ -848,7 +850,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     gpu_init.join();
     if (!ctx) die("longphase_amd: " + L.error);
     const double t_in = now();
-    std::atomic<long long> ns_p1{0}, ns_p2{0}, ns_host{0}, ns_p3{0}, ns_splice{0}, ns_append{0}, ns_prep{0}, ns_purity{0}, ns_finish{0};      // where the time goes (summed over workers)
+    std::atomic<long long> ns_p1{0}, ns_p2{0}, ns_host{0}, ns_p3{0}, ns_splice{0}, ns_append{0}, ns_prep{0}, ns_purity{0}, ns_finish{0}, ns_gpu_deflate{0};      // where the time goes (summed over workers)
     auto tick = [] { return std::chrono::steady_clock::now(); };
     auto tock = [](std::atomic<long long> &acc, std::chrono::steady_clock::time_point t0) { acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
     SomaticThr T = somatic_thresholds(purity);
@@ -895,8 +897,9 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     // phase 1: passes 1 and 2 again (milliseconds on the GPU), the caller's statistics and filters, pass 3, the writer.
     // One contig of one phase, on one GPU context.  Everything it adds to run-wide state goes to its own ContigAcc, merged in contig order by the caller - so the
     // contigs can be dealt onto several workers (--gpus N) and the outputs (filter log, tagged BAM, purity inputs) still come out in the reference's order.
+    int n_workers_now = 1; uint8_t *pin[2] = {nullptr, nullptr};       // set once the workers are known (below); pin: page-locked pieces of the single-worker writer
     struct ContigAcc { std::vector<PurityDatum> pdata; size_t p_initial = 0; int lcvf[5] = {0, 0, 0, 0, 0}; std::ostringstream flog; std::set<int32_t> som;
-                       unsigned long long n_flag = 0, hp_hist[9] = {0}, st_count[8] = {0}; uint8_t *out = nullptr; size_t out_bytes = 0; bool ready = false; };
+                       unsigned long long n_flag = 0, hp_hist[9] = {0}, st_count[8] = {0}; uint8_t *out = nullptr; size_t out_bytes = 0; bool ready = false, deflated = false; };
     auto do_contig = [&](lps_ctx *ctx, const std::string &chr, int phase, ContigAcc &A) {
         auto t_prep = tick();
         auto fail = [&]() { die(std::string("longphase_amd: ") + L.last_error(ctx)); };
@@ -1223,8 +1226,35 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                 if (psv[i] != -1) put_i('P', 'S', psv[i]); put_i('P', 'Q', pq[i]); }
             const uint32_t nbs = (uint32_t)(q - o) - 4; for (int k = 0; k < 4; ++k) o[k] = (uint8_t)(nbs >> (8 * k));
         } });
-        A.out = obp; A.out_bytes = (size_t)out_off[nt];
         tock(ns_splice, t_splice);
+        if (!host_deflate && out_off[nt]) {                                // BGZF blocks cut and deflated on this worker's GPU (per-block Huffman codes, as the haplotag writer)
+            auto td = tick();
+            int64_t nb = 0;
+            if (L.bgzf_deflate_host(ctx, obp, (int64_t)out_off[nt], &nb)) fail();
+            free(obp);
+            if (n_workers_now == 1) {                                       // this thread is also the writer: pieces go from two page-locked buffers straight to the file
+                if (!pin[0]) { pin[0] = (uint8_t *)L.host_alloc(64u << 20); pin[1] = (uint8_t *)L.host_alloc(64u << 20); if (!pin[0] || !pin[1]) die("longphase_amd: cannot allocate page-locked host memory"); }
+                if (!raw_started) { w.flush_partial(); raw_started = true; }
+                std::thread wr; int k = 0;
+                for (int64_t off = 0; off < nb; off += (64ll << 20), k ^= 1) { const int64_t len = std::min<int64_t>(64ll << 20, nb - off);
+                    if (L.bgzf_deflate_fetch_range(ctx, off, len, pin[k])) fail();
+                    if (wr.joinable()) wr.join();
+                    uint8_t *src = pin[k];
+                    wr = std::thread([&w, src, len] { w.write_raw(src, (size_t)len); }); }
+                if (wr.joinable()) wr.join();
+                tock(ns_gpu_deflate, td);
+                std::cerr << "(" << chr << ")";
+                return;
+            }
+            uint8_t *zb = (uint8_t *)malloc((size_t)nb + 64); if (!zb) die("ERROR: out of memory");
+            uint8_t *bounce = (uint8_t *)L.host_alloc(32u << 20); if (!bounce) die("longphase_amd: cannot allocate page-locked host memory");
+            for (int64_t off = 0; off < nb; off += (32ll << 20)) { const int64_t len = std::min<int64_t>(32ll << 20, nb - off);
+                if (L.bgzf_deflate_fetch_range(ctx, off, len, bounce)) fail();
+                memcpy(zb + off, bounce, (size_t)len); }
+            L.host_free(bounce);
+            A.out = zb; A.out_bytes = (size_t)nb; A.deflated = true;
+            tock(ns_gpu_deflate, td);
+        } else { A.out = obp; A.out_bytes = (size_t)out_off[nt]; }
         std::cerr << "(" << chr << ")";
     };
     // contigs dealt longest-first (tumor records) onto the workers; worker 0 is this thread's context, the others create theirs
@@ -1237,6 +1267,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
       std::vector<size_t> load((size_t)n_workers, 0);
       for (size_t i : order) { const size_t g = (size_t)(std::min_element(load.begin(), load.end()) - load.begin()); share[g].push_back(i); load[g] += weight(i) + 1; }
       for (auto &v : share) std::sort(v.begin(), v.end()); }
+    n_workers_now = n_workers;
     std::vector<lps_ctx *> wctx((size_t)n_workers, nullptr); wctx[0] = ctx;
     for (int g = 1; g < n_workers; ++g) { lps_params P; L.default_params(&P); for (auto &f : over) f(P);
         wctx[(size_t)g] = L.create((gpu + g) % n_dev, &P); if (!wctx[(size_t)g]) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
@@ -1255,7 +1286,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             if (write_log) flog << A.flog.str();
             if (!A.som.empty()) somatic_pos[chr_vec[i]].swap(A.som);
             n_somatic_flag += A.n_flag; for (int k = 0; k < 9; ++k) hp_hist[k] += A.hp_hist[k]; for (int k = 0; k < 8; ++k) st_count[k] += A.st_count[k];
-            { auto ta = tick(); if (A.out_bytes) w.append(A.out, A.out_bytes); tock(ns_append, ta); }
+            { auto ta = tick(); if (A.out_bytes) { if (A.deflated) { if (!raw_started) { w.flush_partial(); raw_started = true; } w.write_raw(A.out, A.out_bytes); } else w.append(A.out, A.out_bytes); } tock(ns_append, ta); }
             free(A.out); A.out = nullptr; A.flog.str(std::string());
         }
         for (auto &x : workers) x.join();
@@ -1295,8 +1326,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     fprintf(stderr, "somatic variant count(Flag): %llu\n", n_somatic_flag);
     fprintf(stderr, "total alignment %llu | HP1 %llu HP2 %llu HP1-1 %llu HP2-1 %llu HP3 %llu | judged untagged %llu | low mapq %llu unmapped %llu secondary %llu supplementary %llu no variant %llu beyond last variant %llu\n",
             total, hp_hist[1], hp_hist[2], hp_hist[5], hp_hist[7], hp_hist[3], hp_hist[0], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6]);
-    fprintf(stderr, "inputs %.3fs | passes + caller + writer %.3fs (table %.3f, normal pass %.3f, tumor pass %.3f, host stages %.3f, purity %.3f, tagging pass %.3f, tag splice %.3f, deflate + write %.3f + %.3f) | total %.3fs\n", t_in - t_begin, now() - t_in,
-            ns_prep / 1e9, ns_p1 / 1e9, ns_p2 / 1e9, ns_host / 1e9, ns_purity / 1e9, ns_p3 / 1e9, ns_splice / 1e9, ns_append / 1e9, ns_finish / 1e9, now() - t_begin);
+    fprintf(stderr, "inputs %.3fs | passes + caller + writer %.3fs (table %.3f, normal pass %.3f, tumor pass %.3f, host stages %.3f, purity %.3f, tagging pass %.3f, tag splice %.3f, gpu deflate + copy out %.3f, %s %.3f + %.3f) | total %.3fs\n", t_in - t_begin, now() - t_in,
+            ns_prep / 1e9, ns_p1 / 1e9, ns_p2 / 1e9, ns_host / 1e9, ns_purity / 1e9, ns_p3 / 1e9, ns_splice / 1e9, ns_gpu_deflate / 1e9, host_deflate ? "deflate + write" : "write", ns_append / 1e9, ns_finish / 1e9, now() - t_begin);
     fflush(stderr);
     if (getenv("LPS_CLI_NO_FAST_EXIT")) return 0;                       // e.g. under a profiler that writes its report from an exit handler
     _exit(0);

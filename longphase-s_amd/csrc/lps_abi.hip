@@ -56,7 +56,7 @@ struct lps_ctx {
     DevBuf<uint8_t> zfile, file, zscratch; DevBuf<InflateBlock> zblk; uint64_t file_bytes = 0; float bgzf_h2d_ms = 0, bgzf_inflate_ms = 0;
     DevBuf<unsigned long long> tg_len, tg_off; DevBuf<uint2> tg_spans; DevBuf<uint8_t> tg_stream, tg_status, tg_hp; DevBuf<int32_t> tg_ps, tg_pq; int64_t cur_first = -1, cur_count = 0;
     uint8_t *stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; size_t stage_bytes = 0;   // pinned staging ring for large pageable uploads
-    DevBuf<uint8_t> dz_slots, dz_packed; DevBuf<uint32_t> dz_bytes; DevBuf<unsigned long long> dz_tmp; DevBuf<uint64_t> dz_off; uint64_t dz_total = 0; float dz_ms = 0;
+    DevBuf<uint8_t> dz_slots, dz_packed, dz_src; DevBuf<uint32_t> dz_bytes; DevBuf<unsigned long long> dz_tmp; DevBuf<uint64_t> dz_off; uint64_t dz_total = 0; float dz_ms = 0;
     DevBuf<uint64_t> rcand; uint64_t n_rec_all = 0; DevBuf<int32_t> r_tid_all; DevBuf<uint32_t> r_lname, r_nameoff, wg_cnt, wg_off, scan_nout; DevBuf<uint8_t> names_d; bool names_ready = false;
     // observations
     DevBuf<RowDesc> rows; DevBuf<int32_t> g_cnt; DevBuf<uint8_t> deleted;
@@ -640,6 +640,22 @@ int lps_bgzf_deflate(lps_ctx *c, int64_t offset, int64_t n_bytes, int64_t *out_b
         hipStream_t s = c->stream; hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, s));
         c->dz_total = bgzf_deflate_device(c->file.p + offset, (uint64_t)n_bytes, c->dz_slots, c->dz_bytes, c->dz_tmp, c->dz_off, c->dz_packed, c->temp, c->temp_bytes, s);
+        HIP_TRY(hipEventRecord(e1, s)); HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipEventElapsedTime(&c->dz_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *out_bytes = (int64_t)c->dz_total;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
+int lps_bgzf_deflate_host(lps_ctx *c, const uint8_t *bytes, int64_t n_bytes, int64_t *out_bytes) {
+    if (!c || !out_bytes || n_bytes < 0 || (n_bytes && !bytes)) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        hipStream_t s = c->stream; hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        c->dz_src.reserve((size_t)n_bytes + 64, s);
+        h2d_staged(c, c->dz_src.p, bytes, (size_t)n_bytes);
+        HIP_TRY(hipEventRecord(e0, s));
+        c->dz_total = bgzf_deflate_device(c->dz_src.p, (uint64_t)n_bytes, c->dz_slots, c->dz_bytes, c->dz_tmp, c->dz_off, c->dz_packed, c->temp, c->temp_bytes, s);
         HIP_TRY(hipEventRecord(e1, s)); HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipEventElapsedTime(&c->dz_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         *out_bytes = (int64_t)c->dz_total;

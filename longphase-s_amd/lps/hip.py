@@ -45,6 +45,7 @@ def load():
     L.lps_set_variants.argtypes = [C.c_void_p, C.POINTER(abi.VariantTable)]
     L.lps_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.lps_set_extra_variants.argtypes = [C.c_void_p, C.POINTER(abi.ExtraVariantTable)]
+    L.lps_bgzf_deflate_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.lps_bgzf_deflate_fetch_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     L.lps_host_alloc.restype = C.c_void_p; L.lps_host_alloc.argtypes = [C.c_size_t]
     L.lps_host_free.restype = None; L.lps_host_free.argtypes = [C.c_void_p]

@@ -11,7 +11,7 @@ def test_library_exports_all_declared_symbols():
     assert len(syms) >= 15
     for s in syms:
         assert hasattr(L, s), s
-    assert L.lps_abi_version() == 13
+    assert L.lps_abi_version() == 14
 
 
 def test_default_params_match_reference_defaults():
