@@ -197,3 +197,29 @@ def test_fuzzed_files_never_hang_or_pass_silently():
             assert want is not None and got == want, trial
         assert n_err >= 40
         assert ctx.bgzf_load(base) == 400_000                       # the context survived all of it
+
+
+def test_deflate_of_host_bytes_fetched_in_pieces():
+    """lps_bgzf_deflate_host (bytes a host-side splice produced) + lps_bgzf_deflate_fetch_range into page-locked memory from lps_host_alloc, in
+    pieces: the concatenated members inflate (zlib) to the input; ranges outside the result are refused."""
+    import ctypes as C
+    rng = np.random.default_rng(9)
+    _, _, rec = util.bam_sections(_bam())
+    data = bytes(rec[:300_000]) + rng.integers(0, 256, 100_001, dtype=np.uint8).tobytes()
+    with hip.Context(0, abi.default_params()) as ctx:
+        L = ctx.L
+        nb = C.c_int64(0)
+        src = np.frombuffer(data, np.uint8)
+        assert L.lps_bgzf_deflate_host(ctx.h, src.ctypes.data, src.size, C.byref(nb)) == 0 and nb.value > 0
+        piece = 70_000
+        pin = L.lps_host_alloc(piece)
+        assert pin
+        out = bytearray()
+        for off in range(0, nb.value, piece):
+            n = min(piece, nb.value - off)
+            assert L.lps_bgzf_deflate_fetch_range(ctx.h, off, n, pin) == 0
+            out += C.string_at(pin, n)
+        assert L.lps_bgzf_deflate_fetch_range(ctx.h, nb.value - 10, 11, pin) != 0
+        L.lps_host_free(pin)
+        assert gzip.decompress(bytes(out)) == data
+        assert L.lps_bgzf_deflate_host(ctx.h, None, 0, C.byref(nb)) == 0 and nb.value == 0
