@@ -82,6 +82,9 @@ class ParityPool:
         self.bytes = 0
         self.max_bytes = max_bytes
         self.cv = threading.Condition()
+        # Held by a checker thread while it hands a contig's host copy (up to 22 GB) back to the OS, and by the main thread for every timed region:
+        # an munmap of that size stops every thread of the process that needs the address-space lock (the HIP runtime's included) for ~0.5 s
+        self.heavy = threading.Lock()
 
     def submit(self, name, P, V, host, out_ps, out_gt):
         from lps import abi
@@ -94,17 +97,22 @@ class ParityPool:
                 self.cv.wait()
             self.bytes += nb
 
+        box = [host]; del host                                           # the checker thread holds the only reference once the caller dropped its own
+
         def job():
+            R = None
             try:
-                R = abi.Reads.from_synth(host)
+                R = abi.Reads.from_synth(box[0])
                 t0 = time.time()
-                want, _ = lps_oracle.phase(P, V, host.ref, R)
+                want, _ = lps_oracle.phase(P, V, box[0].ref, R)
                 dt = time.time() - t0
                 same_ps = bool(np.array_equal(want.phase_set, out_ps))
                 m = want.phase_set != 0
                 same_gt = bool(np.array_equal(want.gt[m], out_gt[m]))
                 return dict(contig=name, identical=same_ps and same_gt, oracle_s=dt, n_phased=int(m.sum()))
             finally:
+                with self.heavy:
+                    R = None; box.clear()                                # the arrays are freed HERE, never while a timed region runs
                 with self.cv:
                     self.bytes -= nb
                     self.cv.notify_all()
@@ -231,6 +239,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    import contextlib
+    quiet = (lambda: pool.heavy) if pool is not None else contextlib.nullcontext   # `with quiet():` = no checker thread frees memory meanwhile
+
     def concurrent(fns):
         """start the callables together, one thread each; -> wall time until the last one is done"""
         if len(fns) == 1:
@@ -286,9 +297,13 @@ def main():
             s["ctx"].set_stage_timing(0)
 
         def k_steps(s):
+            s["step_ms"] = []
             for _ in range(a.steps):
+                t1 = time.perf_counter()
                 s["ctx"].run_phase(s["out"])      # synchronous: returns with the results in host memory (its stream drained)
-        dt = concurrent([(lambda s=s: k_steps(s)) for s in slots])
+                s["step_ms"].append(round((time.perf_counter() - t1) * 1e3, 2))
+        with quiet():
+            dt = concurrent([(lambda s=s: k_steps(s)) for s in slots])
         elapsed += dt
         for s in slots:
             spec, g, V, out, ctx = s["spec"], s["g"], s["V"], s["out"], s["ctx"]
@@ -303,6 +318,8 @@ def main():
                             scan_segments=tm["n_scan_segments"], scan_replayed=tm["n_scan_replayed"], gen_ms=g.gen_ms)
             if s["host"] is not None and spec["name"] in parity_set:
                 pool.submit(spec["name"], P, V, s["host"], out.phase_set.copy(), out.gt.copy())
+                if not (rank == 0 and spec["name"] == cpu_name):
+                    s["host"] = None                                       # (the P clock below still needs the copy of the contig it runs on)
         s = slots[0]
         if largest is None or s["spec"]["contig_len"] > largest[0]["contig_len"]:
             # the largest contig ALONE on the GPU: call time, the dominant kernel's duration (hipEvents on the library's stream around it, live) and the
@@ -333,7 +350,8 @@ def main():
         def k_tags(s):
             for _ in range(a.steps):
                 s["ctx"].run_haplotag(s["hout"])
-        hdt = concurrent([(lambda s=s: k_tags(s)) for s in slots])
+        with quiet():
+            hdt = concurrent([(lambda s=s: k_tags(s)) for s in slots])
         hap_elapsed += hdt
         for s in slots:
             s["rec"].update(group_haplotag_ms_per_step=hdt / a.steps * 1e3, haplotag_kernel_ms=s["ctx"].timings()["stages"]["extract"], tagged=int((s["hout"].hp != 0).sum()))
@@ -352,7 +370,8 @@ def main():
             if cpu_pick is None or cpu_pick[0] is not s["g"]:
                 s["g"].close()
         log(f"[rank {rank}] " + " + ".join(f"{s['spec']['name']} ({s['g'].n_reads} alignments, {s['V'].n} SNPs)" for s in slots) +
-            f": phase {dt / a.steps * 1e3:.3f} ms/step | haplotag {hdt / a.steps * 1e3:.3f} ms/step | phased {sum(s['n_ph'] for s in slots)}")
+            f": phase {dt / a.steps * 1e3:.3f} ms/step | haplotag {hdt / a.steps * 1e3:.3f} ms/step | phased {sum(s['n_ph'] for s in slots)}"
+            f" | calls (ms) {[s['step_ms'] for s in slots]}")
     barrier()
     ctx = ctxs[0]
 

@@ -663,6 +663,16 @@ __device__ __forceinline__ float edge_upd(float x, bool hi, double w) {
     return hi ? x + 1.0f : (float)((double)x + w);           // SubEdge::addSubEdge (:40-43,62-65)
 }
 
+// One read's contribution to the two cells its source allele selects (x0: target REF, x1: target ALT); bit 30 of the packed word is the target's
+// allele, bit 31 its quality class.  SRC_HI: the source observation is of high quality (else the pair never is).
+template <bool SRC_HI>
+__device__ __forceinline__ void cell_upd(float &x0, float &x1, uint32_t word, double w) {
+    const bool alt = (word >> 30) & 1u;
+    const float x = alt ? x1 : x0;
+    const float nx = edge_upd(x, SRC_HI && (word >> 31), w);
+    x0 = alt ? x0 : nx; x1 = alt ? nx : x1;
+}
+
 // wave per source node i.  Lane k (< A) owns the four cells (rr,ra,ar,aa) towards node i+1+k in registers.
 // For each read observing node i (in name-rank order) lane t loads the read's t-th following observation;
 // its node distance d selects the owning lane, the (allele pair, quality class) travels there by ds_permute.
@@ -725,6 +735,28 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
         uint32_t cur;
         { const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_val, 0), rend = (uint32_t)__builtin_amdgcn_readlane((int)my_end, 0);
           const uint32_t e2 = idx + 1 + l; cur = (l < A && e2 < rend) ? g_pack[e2] : 0xffffffffu; }
+        // No node twice in any of these rows (nearly every block): the packed word itself travels to the lane that owns its target - lanes without
+        // one push to a lane >= A, whose cells are never stored - and the receiver, for whom the source flag is wave-uniform, picks between TWO cells
+        // on a scalar branch.  ~25 vector instructions per read instead of ~50 (this kernel runs at its vector-issue floor)
+        if (!any_multi) {
+            for (int t = 0; t < nb; ++t) {
+                uint32_t nxt = 0xffffffffu;
+                if (t + 1 < nb) {
+                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_val, t + 1), rend = (uint32_t)__builtin_amdgcn_readlane((int)my_end, t + 1);
+                    const uint32_t e2 = idx + 1 + l; if (l < A && e2 < rend) nxt = g_pack[e2];
+                }
+                const int sf = __builtin_amdgcn_readlane(my_sf, t);
+                // d - 1 as unsigned: an empty slot (all ones), a node before i+1 or beyond the window all land on lane 63 or on a lane >= A
+                const uint32_t dm1 = (cur & 0x3fffffffu) - (uint32_t)(i + 1);
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute((int)(min(dm1, 63u) << 2), (int)cur);
+                if (recv) {                                             // a target node is >= 1, so its word is never 0
+                    if (sf & 1) { if (sf & 2) cell_upd<true>(a2, a3, recv, edge_weight); else cell_upd<false>(a2, a3, recv, edge_weight); }
+                    else        { if (sf & 2) cell_upd<true>(a0, a1, recv, edge_weight); else cell_upd<false>(a0, a1, recv, edge_weight); }
+                }
+                cur = nxt;
+            }
+            continue;
+        }
         for (int t = 0; t < nb; ++t) {
             uint32_t nxt = 0xffffffffu;
             if (t + 1 < nb) {
