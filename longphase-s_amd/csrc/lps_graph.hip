@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const RowDesc *r
             const unsigned fl = (unsigned)aq_allele(aq) | ((q >= base_quality) ? 2u : 0u);
             g_node[slot] = (int32_t)nd;
             g_flag[slot] = (uint8_t)fl;
-            g_pack[slot] = nd | (fl << 30);                       // node (< 2^22) and flag in one word: what k_edges reads per pair
+            g_pack[slot] = ((uint32_t)nd << 2) | fl;              // node and flag (bit 0 allele, bit 1 quality class) in one word: what k_edges reads per pair
             // entries of the node's list: the merged rows hold exactly these observations.  What the counting atomic returns is a unique rank inside
             // that list: kept, it places the entry later without a second atomic (k_node_scatter)
             const unsigned rk = atomicAdd(&node_cnt[nd], 1u);
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
         }
 #endif
         __threadfence_block(); wave_sync();
-        for (int k = l; k < total; k += 64) g_pack[base + k] = (uint32_t)g_node[base + k] | ((uint32_t)g_flag[base + k] << 30);   // the merged row as k_edges reads it
+        for (int k = l; k < total; k += 64) g_pack[base + k] = ((uint32_t)g_node[base + k] << 2) | (uint32_t)g_flag[base + k];   // the merged row as k_edges reads it
         wave_sync();                                                     // the LDS copy is reused by the wave's next group
     }
 }
@@ -663,13 +663,13 @@ __device__ __forceinline__ float edge_upd(float x, bool hi, double w) {
     return hi ? x + 1.0f : (float)((double)x + w);           // SubEdge::addSubEdge (:40-43,62-65)
 }
 
-// One read's contribution to the two cells its source allele selects (x0: target REF, x1: target ALT); bit 30 of the packed word is the target's
-// allele, bit 31 its quality class.  SRC_HI: the source observation is of high quality (else the pair never is).
+// One read's contribution to the two cells its source allele selects (x0: target REF, x1: target ALT); bit 0 of the packed word is the target's
+// allele, bit 1 its quality class.  SRC_HI: the source observation is of high quality (else the pair never is).
 template <bool SRC_HI>
 __device__ __forceinline__ void cell_upd(float &x0, float &x1, uint32_t word, double w) {
-    const bool alt = (word >> 30) & 1u;
+    const bool alt = word & 1u;
     const float x = alt ? x1 : x0;
-    const float nx = edge_upd(x, SRC_HI && (word >> 31), w);
+    const float nx = edge_upd(x, SRC_HI && (word & 2u), w);
     x0 = alt ? x0 : nx; x1 = alt ? nx : x1;
 }
 
@@ -689,6 +689,7 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     unsigned long long pairs = 0;
     const unsigned long long m_mask = (1ull << m_bits) - 1ull;
+    const uint32_t first4 = (uint32_t)__builtin_amdgcn_readfirstlane((i + 1) << 2);   // packed word of node i+1 with flag 0
     const bool short_list = end - off <= 64;                           // unsorted entries (ukeys/uvals): up to 64 are ordered in registers below
     if (!short_list) {                                                  // coverage above 64: rank sort through memory (rank = number of smaller keys; keys are unique)
         const int n = (int)(end - off);
@@ -713,9 +714,13 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
             // rank = number of smaller keys (keys are unique): the read order of the reference (name rank, index in the merged read)
             const int klo = (int)(unsigned)key, khi = (int)(unsigned)(key >> 32);
             int rank = 0;
-            for (int t = 0; t < nb; ++t) {
-                const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(khi, t) << 32) | (unsigned)__builtin_amdgcn_readlane(klo, t);
-                rank += o < key;
+            if (m_bits + a_bits <= 32) {                                // the whole key in one word (the usual case): one lane read per step
+                for (int t = 0; t < nb; ++t) rank += (unsigned)__builtin_amdgcn_readlane(klo, t) < (unsigned)klo;
+            } else {
+                for (int t = 0; t < nb; ++t) {
+                    const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(khi, t) << 32) | (unsigned)__builtin_amdgcn_readlane(klo, t);
+                    rank += o < key;
+                }
             }
             const int dst = (l < nb ? rank : l) << 2;                   // lanes past the list keep to themselves (ranks are a permutation of 0..nb-1)
             my_val = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)v0);
@@ -726,37 +731,49 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
             my_val = svals[e0 + l]; my_end = mrow_off[m] + (uint32_t)mrow_cnt[m];
         }
         // every lane's own observation (flag of the source side) and its share of the pair count, loaded side by side
-        const int my_sf = l < nb ? (int)(g_pack[my_val] >> 30) : 0;
-        if (l < nb) pairs += (unsigned long long)min((uint32_t)A, my_end - my_val - 1u);
+        const int my_sf = l < nb ? (int)(g_pack[my_val] & 3u) : 0;
+        const int my_lim = l < nb ? (int)min((uint32_t)A, my_end - my_val - 1u) : 0;    // observations of the read inside the window (A <= 63)
+        pairs += (unsigned long long)my_lim;
+        const int my_meta = my_lim | (my_sf << 8);
         // merged rows of several alignments (tail arena) are the only ones that can hold a node twice inside the window
         const bool any_multi = __ballot(l < nb && my_val >= tail_lo) != 0ull;
         // the t-th read's following observations: requested one read ahead, so that the loads of read t+1 are in flight while read t is applied.
         // Read t's (first slot, end, source flag) come out of their lane by v_readlane (t is uniform): no LDS round trip, no wait
-        uint32_t cur;
-        { const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_val, 0), rend = (uint32_t)__builtin_amdgcn_readlane((int)my_end, 0);
-          const uint32_t e2 = idx + 1 + l; cur = (l < A && e2 < rend) ? g_pack[e2] : 0xffffffffu; }
         // No node twice in any of these rows (nearly every block): the packed word itself travels to the lane that owns its target - lanes without
         // one push to a lane >= A, whose cells are never stored - and the receiver, for whom the source flag is wave-uniform, picks between TWO cells
         // on a scalar branch.  ~25 vector instructions per read instead of ~50 (this kernel runs at its vector-issue floor)
         if (!any_multi) {
-            for (int t = 0; t < nb; ++t) {
-                uint32_t nxt = 0xffffffffu;
-                if (t + 1 < nb) {
-                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_val, t + 1), rend = (uint32_t)__builtin_amdgcn_readlane((int)my_end, t + 1);
-                    const uint32_t e2 = idx + 1 + l; if (l < A && e2 < rend) nxt = g_pack[e2];
+            // read t+1 is requested while read t is applied (three in flight were measured no faster: the rows come from L2 and the other waves of
+            // the SIMD cover the rest)
+            // the row's address is wave-uniform (scalar base), the lane adds its own 4*l: no vector address arithmetic
+            auto request = [&](int t, uint32_t &w, int &meta) {
+                w = 0xffffffffu; meta = 0;
+                if (t < nb) {
+                    const uint32_t *rowp = g_pack + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_val, t) + 1;
+                    meta = __builtin_amdgcn_readlane(my_meta, t);
+                    if (l < (meta & 63)) w = rowp[l];
                 }
-                const int sf = __builtin_amdgcn_readlane(my_sf, t);
-                // d - 1 as unsigned: an empty slot (all ones), a node before i+1 or beyond the window all land on lane 63 or on a lane >= A
-                const uint32_t dm1 = (cur & 0x3fffffffu) - (uint32_t)(i + 1);
-                const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute((int)(min(dm1, 63u) << 2), (int)cur);
+            };
+            uint32_t w0; int m0;
+            request(0, w0, m0);
+            for (int t = 0; t < nb; ++t) {
+                uint32_t w1; int m1;
+                request(t + 1, w1, m1);
+                const int sf = m0 >> 8;
+                // 4*(d-1) + flag as unsigned: an empty slot (all ones), a node before i+1 or beyond the window all land on lane 63 or on a lane >= A
+                // (ds_permute takes lane = address / 4 mod 64: the flag bits below do not matter)
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute((int)min(w0 - first4, 255u), (int)w0);
                 if (recv) {                                             // a target node is >= 1, so its word is never 0
                     if (sf & 1) { if (sf & 2) cell_upd<true>(a2, a3, recv, edge_weight); else cell_upd<false>(a2, a3, recv, edge_weight); }
                     else        { if (sf & 2) cell_upd<true>(a0, a1, recv, edge_weight); else cell_upd<false>(a0, a1, recv, edge_weight); }
                 }
-                cur = nxt;
+                w0 = w1; m0 = m1;
             }
             continue;
         }
+        uint32_t cur;
+        { const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_val, 0), rend = (uint32_t)__builtin_amdgcn_readlane((int)my_end, 0);
+          const uint32_t e2 = idx + 1 + l; cur = (l < A && e2 < rend) ? g_pack[e2] : 0xffffffffu; }
         for (int t = 0; t < nb; ++t) {
             uint32_t nxt = 0xffffffffu;
             if (t + 1 < nb) {
@@ -764,7 +781,7 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
                 const uint32_t e2 = idx + 1 + l; if (l < A && e2 < rend) nxt = g_pack[e2];
             }
             const int sf = __builtin_amdgcn_readlane(my_sf, t);
-            const int n2 = (int)(cur & 0x3fffffffu), f2 = (int)(cur >> 30);
+            const int n2 = (int)(cur >> 2), f2 = (int)(cur & 3u);
             const int d = n2 - i;
             const bool ok = cur != 0xffffffffu && d >= 1 && d <= A;
             const int cell = ((sf & 1) << 1) | (f2 & 1);
