@@ -664,12 +664,11 @@ __device__ __forceinline__ float edge_upd(float x, bool hi, double w) {
 }
 
 // One read's contribution to the two cells its source allele selects (x0: target REF, x1: target ALT); bit 0 of the packed word is the target's
-// allele, bit 1 its quality class.  SRC_HI: the source observation is of high quality (else the pair never is).
-template <bool SRC_HI>
-__device__ __forceinline__ void cell_upd(float &x0, float &x1, uint32_t word, double w) {
+// allele, bit 1 its quality class.  hi_mask (wave-uniform): 2 when the source observation is of high quality, else 0 (the pair never is).
+__device__ __forceinline__ void cell_upd(float &x0, float &x1, uint32_t word, uint32_t hi_mask, double w) {
     const bool alt = word & 1u;
     const float x = alt ? x1 : x0;
-    const float nx = edge_upd(x, SRC_HI && (word & 2u), w);
+    const float nx = edge_upd(x, (word & hi_mask) != 0u, w);
     x0 = alt ? x0 : nx; x1 = alt ? nx : x1;
 }
 
@@ -734,63 +733,50 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
         const int my_sf = l < nb ? (int)(g_pack[my_val] & 3u) : 0;
         const int my_lim = l < nb ? (int)min((uint32_t)A, my_end - my_val - 1u) : 0;    // observations of the read inside the window (A <= 63)
         pairs += (unsigned long long)my_lim;
-        const int my_meta = my_lim | (my_sf << 8);
-        // merged rows of several alignments (tail arena) are the only ones that can hold a node twice inside the window
-        const bool any_multi = __ballot(l < nb && my_val >= tail_lo) != 0ull;
-        // the t-th read's following observations: requested one read ahead, so that the loads of read t+1 are in flight while read t is applied.
-        // Read t's (first slot, end, source flag) come out of their lane by v_readlane (t is uniform): no LDS round trip, no wait
-        // No node twice in any of these rows (nearly every block): the packed word itself travels to the lane that owns its target - lanes without
-        // one push to a lane >= A, whose cells are never stored - and the receiver, for whom the source flag is wave-uniform, picks between TWO cells
-        // on a scalar branch.  ~25 vector instructions per read instead of ~50 (this kernel runs at its vector-issue floor)
-        if (!any_multi) {
-            // read t+1 is requested while read t is applied (three in flight were measured no faster: the rows come from L2 and the other waves of
-            // the SIMD cover the rest)
-            // the row's address is wave-uniform (scalar base), the lane adds its own 4*l: no vector address arithmetic
-            auto request = [&](int t, uint32_t &w, int &meta) {
-                w = 0xffffffffu; meta = 0;
-                if (t < nb) {
-                    const uint32_t *rowp = g_pack + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_val, t) + 1;
-                    meta = __builtin_amdgcn_readlane(my_meta, t);
-                    if (l < (meta & 63)) w = rowp[l];
-                }
-            };
-            uint32_t w0; int m0;
-            request(0, w0, m0);
-            for (int t = 0; t < nb; ++t) {
-                uint32_t w1; int m1;
-                request(t + 1, w1, m1);
-                const int sf = m0 >> 8;
-                // 4*(d-1) + flag as unsigned: an empty slot (all ones), a node before i+1 or beyond the window all land on lane 63 or on a lane >= A
-                // (ds_permute takes lane = address / 4 mod 64: the flag bits below do not matter)
-                const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute((int)min(w0 - first4, 255u), (int)w0);
-                if (recv) {                                             // a target node is >= 1, so its word is never 0
-                    if (sf & 1) { if (sf & 2) cell_upd<true>(a2, a3, recv, edge_weight); else cell_upd<false>(a2, a3, recv, edge_weight); }
-                    else        { if (sf & 2) cell_upd<true>(a0, a1, recv, edge_weight); else cell_upd<false>(a0, a1, recv, edge_weight); }
-                }
-                w0 = w1; m0 = m1;
+        // one lane read per step hands out the window length (bits 0-5), the source flag (8-9) and whether the read's row is a merged row of several
+        // alignments (bit 10; tail arena) - the only rows that can hold a node twice inside the window
+        const int my_meta = my_lim | (my_sf << 8) | ((l < nb && my_val >= tail_lo) ? 1 << 10 : 0);
+        // The t-th read's following observations are requested one read ahead, so that the loads of read t+1 are in flight while read t is applied
+        // (three in flight were measured no faster: the rows come from L2 and the other waves of the SIMD cover the rest).  The request is a BUFFER
+        // load whose descriptor is the read's window itself - base = the word after the source observation, size = the observations inside the
+        // window, both wave-uniform and put together on the scalar unit: the lane adds its 4*l, and a lane beyond the window gets 0 from the bounds
+        // check (no compare, no vector address arithmetic, no default).  A word of a following observation is never 0 (its node is >= 1).
+        auto request = [&](int t, uint32_t &w, int &meta) {
+            w = 0u; meta = 0;
+            if (t < nb) {
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)my_val, t);
+                meta = __builtin_amdgcn_readlane(my_meta, t);
+                const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc((void *)(g_pack + (size_t)v + 1), 0, (meta & 63) * 4, 0x00020000);
+                w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(win, 4 * l, 0, 0);
             }
-            continue;
-        }
-        uint32_t cur;
-        { const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_val, 0), rend = (uint32_t)__builtin_amdgcn_readlane((int)my_end, 0);
-          const uint32_t e2 = idx + 1 + l; cur = (l < A && e2 < rend) ? g_pack[e2] : 0xffffffffu; }
+        };
+        uint32_t w0; int m0;
+        request(0, w0, m0);
         for (int t = 0; t < nb; ++t) {
-            uint32_t nxt = 0xffffffffu;
-            if (t + 1 < nb) {
-                const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)my_val, t + 1), rend = (uint32_t)__builtin_amdgcn_readlane((int)my_end, t + 1);
-                const uint32_t e2 = idx + 1 + l; if (l < A && e2 < rend) nxt = g_pack[e2];
-            }
-            const int sf = __builtin_amdgcn_readlane(my_sf, t);
-            const int n2 = (int)(cur >> 2), f2 = (int)(cur & 3u);
-            const int d = n2 - i;
-            const bool ok = cur != 0xffffffffu && d >= 1 && d <= A;
-            const int cell = ((sf & 1) << 1) | (f2 & 1);
-            const int hi = (sf & f2 & 2) << 2;                          // both observations of high quality -> bit 3
-            const int payload = 1 | (cell << 1) | hi;
-            // the same node twice inside the window (overlapping alignments of one read, neighbours in the position-sorted row): the second
-            // occurrence is applied in a second round, after the first - window order, as the reference's pair loop goes
-            int round_of = 0, rounds = 1;
-            if (any_multi) {
+            uint32_t w1; int m1;
+            request(t + 1, w1, m1);
+            const int sf = (m0 >> 8) & 3;
+            if (!(m0 & (1 << 10))) {
+                // No node twice in this row (all but the merged rows, ~2 % of the reads): the packed word itself travels to the lane that owns its
+                // target and the receiver, for whom the source flag is wave-uniform, picks between TWO cells on a scalar branch.  The permute address is
+                // 4*(d-1) + flag as unsigned: an empty slot (0), a node before i+1 or beyond the window all land on lane 63 or on a lane >= A, whose
+                // cells are never stored (ds_permute takes lane = address / 4 mod 64: the flag bits below do not matter).  ~21 vector instructions
+                // per read instead of ~50 (this kernel runs at its vector-issue floor)
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute((int)min(w0 - first4, 255u), (int)w0);
+                if (recv) {
+                    const uint32_t hi_mask = (uint32_t)sf & 2u;         // wave-uniform
+                    if (sf & 1) cell_upd(a2, a3, recv, hi_mask, edge_weight); else cell_upd(a0, a1, recv, hi_mask, edge_weight);
+                }
+            } else {
+                const int n2 = (int)(w0 >> 2), f2 = (int)(w0 & 3u);
+                const int d = n2 - i;
+                const bool ok = w0 != 0u && d >= 1 && d <= A;
+                const int cell = ((sf & 1) << 1) | (f2 & 1);
+                const int hi = (sf & f2 & 2) << 2;                          // both observations of high quality -> bit 3
+                const int payload = 1 | (cell << 1) | hi;
+                // the same node twice inside the window (overlapping alignments of one read, neighbours in the position-sorted row): the second
+                // occurrence is applied in a second round, after the first - window order, as the reference's pair loop goes
+                int round_of = 0, rounds = 1;
                 for (int s = 1; s < 64; ++s) {
                     const int dprev = __shfl_up(d, s); const bool okprev = __shfl_up((int)ok, s) != 0;
                     const bool same = ok && l >= s && okprev && dprev == d && round_of == s - 1;
@@ -798,19 +784,19 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
                     if (same) round_of = s;
                     rounds = s + 1;
                 }
-            }
-            for (int rd = 0; rd < rounds; ++rd) {
-                // lanes without a contribution in this round push to lane 63, which owns no target (A <= 63)
-                const bool mine = ok && round_of == rd;
-                const int recv = __builtin_amdgcn_ds_permute((mine ? (d - 1) : 63) << 2, mine ? payload : 0);
-                if (recv & 1) {
-                    const int c = (recv >> 1) & 3; const bool h = (recv >> 3) & 1;
-                    const float x = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
-                    const float nx = edge_upd(x, h, edge_weight);
-                    a0 = c == 0 ? nx : a0; a1 = c == 1 ? nx : a1; a2 = c == 2 ? nx : a2; a3 = c == 3 ? nx : a3;
+                for (int rd = 0; rd < rounds; ++rd) {
+                    // lanes without a contribution in this round push to lane 63, which owns no target (A <= 63)
+                    const bool mine = ok && round_of == rd;
+                    const int recv = __builtin_amdgcn_ds_permute((mine ? (d - 1) : 63) << 2, mine ? payload : 0);
+                    if (recv & 1) {
+                        const int c = (recv >> 1) & 3; const bool h = (recv >> 3) & 1;
+                        const float x = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
+                        const float nx = edge_upd(x, h, edge_weight);
+                        a0 = c == 0 ? nx : a0; a1 = c == 1 ? nx : a1; a2 = c == 2 ? nx : a2; a3 = c == 3 ? nx : a3;
+                    }
                 }
             }
-            cur = nxt;
+            w0 = w1; m0 = m1;
         }
     }
     pairs = wave_sum(pairs);
