@@ -737,18 +737,19 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
         // alignments (bit 10; tail arena) - the only rows that can hold a node twice inside the window
         const int my_meta = my_lim | (my_sf << 8) | ((l < nb && my_val >= tail_lo) ? 1 << 10 : 0);
         // The t-th read's following observations are requested one read ahead, so that the loads of read t+1 are in flight while read t is applied
-        // (three in flight were measured no faster: the rows come from L2 and the other waves of the SIMD cover the rest).  The request is a BUFFER
+        // (two ahead were measured slower, 1.05 vs 1.02 ms: the rows come from L2 and the other waves of the SIMD cover the rest).  The request is a BUFFER
         // load whose descriptor is the read's window itself - base = the word after the source observation, size = the observations inside the
         // window, both wave-uniform and put together on the scalar unit: the lane adds its 4*l, and a lane beyond the window gets 0 from the bounds
         // check (no compare, no vector address arithmetic, no default).  A word of a following observation is never 0 (its node is >= 1).
+        // The request is UNCONDITIONAL - past the list it reads a lane whose window is empty (lanes >= nb hold 0: no memory access, all lanes get 0):
+        // a load under a branch makes the compiler wait for ALL outstanding loads where the paths join (s_waitcnt vmcnt(0)), i.e. for the request
+        // just made, and the one-ahead scheme hides nothing
         auto request = [&](int t, uint32_t &w, int &meta) {
-            w = 0u; meta = 0;
-            if (t < nb) {
-                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)my_val, t);
-                meta = __builtin_amdgcn_readlane(my_meta, t);
-                const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc((void *)(g_pack + (size_t)v + 1), 0, (meta & 63) * 4, 0x00020000);
-                w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(win, 4 * l, 0, 0);
-            }
+            const int tt = min(t, 63);
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)my_val, tt);
+            meta = __builtin_amdgcn_readlane(my_meta, tt);
+            const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc((void *)(g_pack + (size_t)v + 1), 0, (meta & 63) * 4, 0x00020000);
+            w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(win, 4 * l, 0, 0);
         };
         uint32_t w0; int m0;
         request(0, w0, m0);
