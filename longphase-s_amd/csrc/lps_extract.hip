@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * EXT_WPB, 4) void k_extract_phase(VarView V, Re
         if (ncq > 0) {
             const int nsegn = min(LPS_SEG, ncq);
             pnext = (nsegn < ncq) ? cg[crel + nsegn] : 0xfu;
-            load_ops8(cg + crel, 8 * l, nsegn, pw);
+            request_ops8(cg + crel, 8 * l, nsegn, pw);
             pf_q = q; pf_seg = 0;
         }
     }
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(64 * EXT_WPB, 4) void k_extract_phase(VarView V, Re
             if (have) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) wds[u] = pw[u];
+                finish_ops8(8 * l, nseg, wds);
                 nextw = pnext;
             } else {
                 nextw = (seg0 + nseg < n_cig) ? cig[seg0 + nseg] : 0xfu;      // op after the segment (0xf = none)
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(64 * EXT_WPB, 4) void k_extract_phase(VarView V, Re
                 const uint32_t *cign = same ? cig : cg + hn[H_REL];
                 const int segn = same ? seg0 + LPS_SEG : 0, ncn = same ? n_cig : n_cig_n, nsegn = min(LPS_SEG, ncn - segn);
                 pnext = (segn + nsegn < ncn) ? cign[segn + nsegn] : 0xfu;
-                load_ops8(cign + segn, 8 * l, nsegn, pw);
+                request_ops8(cign + segn, 8 * l, nsegn, pw);
                 pf_q = same ? q : qn; pf_seg = segn;
             } else pf_q = -1;
             pf_vr_ok = false;
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
         if (ncq > 0) {
             const int nsegn = min(LPS_SEG, ncq);
             pnext = (nsegn < ncq) ? cg[crel + nsegn] : 0xfu;
-            load_ops8(cg + crel, 8 * l, nsegn, pw);
+            request_ops8(cg + crel, 8 * l, nsegn, pw);
             pf_q = q; pf_seg = 0;
         }
     }
@@ -536,6 +537,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
             if (have) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) wds[u] = pw[u];
+                finish_ops8(8 * l, nseg, wds);
                 nextw = pnext;
             } else {
                 nextw = (seg0 + nseg < n_cig) ? cig[seg0 + nseg] : 0xfu;      // op after the segment (0xf = none)
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
                 const uint32_t *cign = same ? cig : cg + hn[H_REL];
                 const int segn = same ? seg0 + LPS_SEG : 0, ncn = same ? n_cig : n_cig_n, nsegn = min(LPS_SEG, ncn - segn);
                 pnext = (segn + nsegn < ncn) ? cign[segn + nsegn] : 0xfu;
-                load_ops8(cign + segn, 8 * l, nsegn, pw);
+                request_ops8(cign + segn, 8 * l, nsegn, pw);
                 pf_q = same ? q : qn; pf_seg = segn;
             } else pf_q = -1;
             pf_vr_ok = false;

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
         int judged_op = -1;                                              // EXTRACT: last D op whose germline vote has been cast
         const int my_hp = (MODE == 3) ? (int)H.read_hp[r] : 0;
         uint32_t pw[8];                                              // the NEXT segment's words, requested while the current one is searched
-        load_ops8(cig, 8 * l, min(LPS_SEG, n_cig), pw);
+        request_ops8(cig, 8 * l, min(LPS_SEG, n_cig), pw);
         for (int seg0 = 0; seg0 < n_cig && vcur < V.n; seg0 += LPS_SEG) {
             const int nseg = min(LPS_SEG, n_cig - seg0);
             uint2 vr = make_uint2(0x7fffffffu, 0u);
@@ -64,7 +64,8 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
             uint32_t wds[8];                                         // 8 consecutive ops per lane (lps_kernels.h)
 #pragma unroll
             for (int k = 0; k < 8; ++k) wds[k] = pw[k];
-            if (seg0 + LPS_SEG < n_cig) load_ops8(cig + seg0 + LPS_SEG, 8 * l, min(LPS_SEG, n_cig - seg0 - LPS_SEG), pw);
+            finish_ops8(8 * l, nseg, wds);
+            if (seg0 + LPS_SEG < n_cig) request_ops8(cig + seg0 + LPS_SEG, 8 * l, min(LPS_SEG, n_cig - seg0 - LPS_SEG), pw);
             int my_ref;
             const bool bad = (stage_ops8(wds, l, ref_pos, q_pos, sref, sqry, scig, my_ref) & LPS_OPS_BAD) != 0u;
             if (__ballot(bad) && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);

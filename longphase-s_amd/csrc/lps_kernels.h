@@ -101,19 +101,23 @@ __device__ __forceinline__ bool op_is_match(int op) { return op == 0 || op == 7 
 //      prefix scan runs once per segment instead of once per 64 ops.
 struct __attribute__((packed, aligned(4))) LpsU4 { uint32_t x, y, z, w; };
 // ops [i0, i0+8) of a CIGAR of n ops; 6u (op P, length 0: consumes nothing) beyond its end.  May read up to 7 words past the end of the
-// CIGAR array: DevBuf allocations carry 64 B of slack.
-__device__ __forceinline__ void load_ops8(const uint32_t *cig, int i0, int n, uint32_t (&w)[8]) {
+// CIGAR array: DevBuf allocations carry 64 B of slack.  In two halves, so that a segment requested AHEAD is not waited for where it is requested:
+// request_ops8 only issues the loads; finish_ops8 (same i0, n) blanks the words past the end where the words are consumed.
+__device__ __forceinline__ void request_ops8(const uint32_t *cig, int i0, int n, uint32_t (&w)[8]) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) w[k] = 6u;
     if (i0 < n) {
         const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cig + i0), b = *reinterpret_cast<const LpsU4 *>(cig + i0 + 4);
         w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-        if (i0 + 8 > n) {
-#pragma unroll
-            for (int k = 1; k < 8; ++k) if (i0 + k >= n) w[k] = 6u;
-        }
     }
 }
+__device__ __forceinline__ void finish_ops8(int i0, int n, uint32_t (&w)[8]) {
+    if (i0 < n && i0 + 8 > n) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) if (i0 + k >= n) w[k] = 6u;
+    }
+}
+__device__ __forceinline__ void load_ops8(const uint32_t *cig, int i0, int n, uint32_t (&w)[8]) { request_ops8(cig, i0, n, w); finish_ops8(i0, n, w); }
 // bit 0: the op consumes the reference (M D N = X: 0x18D), bit 16: it consumes the query (M I S = X: 0x193); ops 9..15 consume nothing
 __device__ __forceinline__ unsigned op_consume_bits(unsigned op) { return ((0x193u << 16) | 0x18Du) >> op; }
 __device__ __forceinline__ int bit_mask(unsigned x, int bit) { return (int)(x << (31 - bit)) >> 31; }      // 0 or -1 (v_bfe_i32)
