@@ -114,9 +114,9 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
     }
     uint8_t *ring = reinterpret_cast<uint8_t *>(s_ring);
     const uint32_t gb6 = (uint32_t)gbase & 63u;
-    auto ring_at = [&](uint32_t pos) -> uint8_t & { const uint32_t slot = (gb6 + pos) & 63u; return ring[((slot >> 2) * 64 + lane) * 4 + (slot & 3)]; };
-    auto hist = [&](uint32_t pos) -> uint8_t { return pos >= fl ? ring_at(pos) : __hip_atomic_load(o + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    auto flush_segment = [&]() {                                            // write [fl, next 32-byte boundary) if complete
+    auto ring_at = [&](uint32_t pos) __attribute__((always_inline)) -> uint8_t & { const uint32_t slot = (gb6 + pos) & 63u; return ring[((slot >> 2) * 64 + lane) * 4 + (slot & 3)]; };
+    auto hist = [&](uint32_t pos) __attribute__((always_inline)) -> uint8_t { return pos >= fl ? ring_at(pos) : __hip_atomic_load(o + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto flush_segment = [&]() __attribute__((always_inline)) {                                            // write [fl, next 32-byte boundary) if complete
         const uint32_t nb = (uint32_t)((((gbase + fl) | 31ull) + 1ull) - gbase);
         if (op < nb) return;
         if (nb - fl == 32) {
@@ -129,9 +129,10 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
         fl = nb;
     };
     // litlen symbol of sorted slot idx: low byte + ninth bit
-    auto litlen_at = [&](uint32_t idx) -> int { return (int)L(s_lsym8, idx) | ((((int)s_lhi[(idx >> 3) * 64 + lane] >> (idx & 7u)) & 1) << 8); };
+    auto litlen_at = [&](uint32_t idx) __attribute__((always_inline)) -> int { return (int)L(s_lsym8, idx) | ((((int)s_lhi[(idx >> 3) * 64 + lane] >> (idx & 7u)) & 1) << 8); };
     enum { ST_HDR = 0, ST_SYM = 1, ST_STORED = 2, ST_DONE = 3, ST_DIST = 4 };
-    int state = (active && on) ? ST_HDR : ST_DONE; bool last = false; unsigned e = 0;
+    int state = (active && on) ? ST_HDR : ST_DONE; bool last = false;
+    uint16_t e = 0;   // (16 bits on purpose: as an i32 its stores were merged with those of `op` through a pointer phi, which kept BOTH in scratch memory)
     uint32_t mlen = 0, msrc = 0, slen = 0, iter = 0, mpend = 0;
     uint32_t p_lo = 0, p_hi = 0, p_sh = 0; bool have_pend = false;
     const uint32_t *out32 = reinterpret_cast<const uint32_t *>(out);        // `out` is 256-byte aligned
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
     // for at least 10 bits - anything beyond this bound is a crafted stream (the header path clamps its reads at w_end, so the guard above alone
     // would never trip on an endless run of empty blocks)
     const uint32_t iter_cap = 16u * (B.in_len * 8u + on) + 4096u;
-    auto decode_distance = [&]() {                                          // distance code + extra bits of the match whose length is in mpend
+    auto decode_distance = [&]() __attribute__((always_inline)) {                                          // distance code + extra bits of the match whose length is in mpend
         uint32_t idx; const int l = decode_limit(peek15(b), s_dlim, s_dbase, lane, idx);
         const int ds = (l && idx < 30) ? (int)L(s_dsym, idx) : 30;
         if (ds >= 30) { e = LPS_INF_ERR_DATA; state = ST_DONE; return; }
@@ -203,11 +204,10 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
                     int nlen = 288, ndist = 30; bool bad = false;
                     Pack16 cl{0, 0, 0, 0}, cd{0, 0, 0, 0}, offs;          // symbols per code length: litlen, distance
                     if (type == 1) {                                       // fixed codes (RFC 1951 3.2.6)
-                        for (int s = 0; s < 144; ++s) gl[s * 64] = 8;
-                        for (int s = 144; s < 256; ++s) gl[s * 64] = 9;
-                        for (int s = 256; s < 280; ++s) gl[s * 64] = 7;
-                        for (int s = 280; s < 288; ++s) gl[s * 64] = 8;
-                        for (int s = 288; s < 318; ++s) gl[s * 64] = 5;
+                        // (one rolled loop: unrolled, the 318 store addresses were hoisted out of the main loop and held in registers for the
+                        // whole kernel - 338 registers, the hot path reading its state back from AGPRs)
+#pragma unroll 1
+                        for (int s = 0; s < 318; ++s) gl[s * 64] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
                         p16_add(cl, 7, 24); p16_add(cl, 8, 152); p16_add(cl, 9, 112); p16_add(cd, 5, 30);
                     } else {                                               // dynamic: code-length code, then the two length vectors
                         nlen = (int)take(b, 5) + 257; ndist = (int)take(b, 5) + 1; const int ncode = (int)take(b, 4) + 4;
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
                         if (!bad && !canon_tables(cc, s_dlim, s_dbase, lane, offs)) bad = true;
                         for (int s = 0; s < 19 && !bad; ++s) { const int l = (int)((clv >> (3 * s)) & 7u); if (l) { L(s_dsym, p16_get(offs, l)) = (uint8_t)s; p16_add(offs, l, 1); } }
                         int idx = 0, prev = 0; bool eob = false;
-                        auto put_len = [&](int v) { gl[idx * 64] = (uint8_t)v; if (idx < nlen) p16_add(cl, v, 1); else p16_add(cd, v, 1); if (idx == 256 && v) eob = true; prev = v; ++idx; };
+                        auto put_len = [&](int v) __attribute__((always_inline)) { gl[idx * 64] = (uint8_t)v; if (idx < nlen) p16_add(cl, v, 1); else p16_add(cd, v, 1); if (idx == 256 && v) eob = true; prev = v; ++idx; };
                         while (!bad && idx < nlen + ndist) {
                             refill_now(b, w_end);
                             uint32_t si; const int l = decode_limit(peek15(b), s_dlim, s_dbase, lane, si);
