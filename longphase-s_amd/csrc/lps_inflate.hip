@@ -23,7 +23,13 @@
 
 #include "lps_inflate.h"
 
-#define L(a, i) a[(i) * 64 + lane]
+// members per workgroup = active lanes of its one wavefront (the tables of a lane are columns of stride INF_LANES).  32, not 64: the kernel is bound by
+// the latency of its per-lane dependence chains, not by lanes - half-filled wavefronts need 17.5 KB of LDS each, so TWO fit a SIMD (228 VGPRs allow
+// it) and one runs while the other waits: 29.3 -> 33.2 GB/s sustained; 16 lanes (four per SIMD) make it instruction-bound: 18.6 GB/s
+#ifndef INF_LANES
+#define INF_LANES 32
+#endif
+#define L(a, i) a[(i) * INF_LANES + lane]
 
 struct BitIn {
     const uint32_t *w2;     // address of the dword that a2 holds / is being loaded into a2
@@ -89,21 +95,21 @@ __device__ __forceinline__ bool canon_tables(const Pack16 &cnt, uint16_t *lim, u
 // Output bytes go to a 64-byte LDS ring per lane and reach HBM as aligned 32-byte segments (2 x dwordx4), flushed at a wave-uniform
 // cadence: few stores, so the in-order vmcnt queue does not stall the input prefetch behind them.
 #define INF_SCRATCH 320      // code lengths of one header per lane (<= 286 + 30), bytes; column layout [i][lane] per wavefront
-__global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__ in, const InflateBlock *__restrict__ blk, int n_blk, uint8_t *out, unsigned *err,
+__global__ void __launch_bounds__(INF_LANES) k_bgzf_inflate(const uint8_t *__restrict__ in, const InflateBlock *__restrict__ blk, int n_blk, uint8_t *out, unsigned *err,
                                                       uint8_t *scratch) {
-    __shared__ uint8_t s_lsym8[288 * 64];                                  // low byte of the (length, symbol)-sorted litlen symbols
-    __shared__ uint8_t s_lhi[36 * 64];                                     // their ninth bit, 8 per byte
-    __shared__ uint16_t s_llim[16 * 64], s_lbase[16 * 64];                 // litlen lengths 1..15
-    __shared__ uint8_t s_dsym[32 * 64];
-    __shared__ uint16_t s_dlim[16 * 64], s_dbase[16 * 64];                 // distance (and code-length code) lengths 1..15
-    __shared__ uint32_t s_ring[16 * 64];                                   // 64 output bytes per lane, slot = global address & 63
-    const int lane = threadIdx.x, bi = blockIdx.x * 64 + lane;
+    __shared__ uint8_t s_lsym8[288 * INF_LANES];                                  // low byte of the (length, symbol)-sorted litlen symbols
+    __shared__ uint8_t s_lhi[36 * INF_LANES];                                     // their ninth bit, 8 per byte
+    __shared__ uint16_t s_llim[16 * INF_LANES], s_lbase[16 * INF_LANES];                 // litlen lengths 1..15
+    __shared__ uint8_t s_dsym[32 * INF_LANES];
+    __shared__ uint16_t s_dlim[16 * INF_LANES], s_dbase[16 * INF_LANES];                 // distance (and code-length code) lengths 1..15
+    __shared__ uint32_t s_ring[16 * INF_LANES];                                   // 64 output bytes per lane, slot = global address & 63
+    const int lane = threadIdx.x, bi = blockIdx.x * INF_LANES + lane;
     const bool active = bi < n_blk;
     const InflateBlock B = active ? blk[bi] : InflateBlock{0, 0, 0, 0};
     const uint64_t gbase = B.out_off;                                       // global byte offset of this block's output
     uint8_t *o = out + gbase; uint32_t op = 0, fl = 0; const uint32_t on = B.out_len;
     const uint8_t *ip = in + B.in_off;
-    uint8_t *gl = scratch + (size_t)blockIdx.x * INF_SCRATCH * 64 + lane;   // this lane's scratch column: entry i at gl[i * 64]
+    uint8_t *gl = scratch + (size_t)blockIdx.x * INF_SCRATCH * INF_LANES + lane;   // this lane's scratch column: entry i at gl[i * INF_LANES]
     BitIn b;
     {   // aligned dword stream (pointer arithmetic on the kernel argument keeps these GLOBAL loads: a flat load would drag lgkmcnt into every
         // wait); `in` is 256-byte aligned.  Bits past the block's end are never consumed by a valid stream (checked at the end).
@@ -114,7 +120,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
     }
     uint8_t *ring = reinterpret_cast<uint8_t *>(s_ring);
     const uint32_t gb6 = (uint32_t)gbase & 63u;
-    auto ring_at = [&](uint32_t pos) __attribute__((always_inline)) -> uint8_t & { const uint32_t slot = (gb6 + pos) & 63u; return ring[((slot >> 2) * 64 + lane) * 4 + (slot & 3)]; };
+    auto ring_at = [&](uint32_t pos) __attribute__((always_inline)) -> uint8_t & { const uint32_t slot = (gb6 + pos) & 63u; return ring[((slot >> 2) * INF_LANES + lane) * 4 + (slot & 3)]; };
     auto hist = [&](uint32_t pos) __attribute__((always_inline)) -> uint8_t { return pos >= fl ? ring_at(pos) : __hip_atomic_load(o + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto flush_segment = [&]() __attribute__((always_inline)) {                                            // write [fl, next 32-byte boundary) if complete
         const uint32_t nb = (uint32_t)((((gbase + fl) | 31ull) + 1ull) - gbase);
@@ -122,14 +128,14 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
         if (nb - fl == 32) {
             const uint32_t d0 = ((uint32_t)(gbase + fl) & 63u) >> 2;
             uint4 x, y;
-            x.x = s_ring[(d0 + 0) * 64 + lane]; x.y = s_ring[(d0 + 1) * 64 + lane]; x.z = s_ring[(d0 + 2) * 64 + lane]; x.w = s_ring[(d0 + 3) * 64 + lane];
-            y.x = s_ring[(d0 + 4) * 64 + lane]; y.y = s_ring[(d0 + 5) * 64 + lane]; y.z = s_ring[(d0 + 6) * 64 + lane]; y.w = s_ring[(d0 + 7) * 64 + lane];
+            x.x = s_ring[(d0 + 0) * INF_LANES + lane]; x.y = s_ring[(d0 + 1) * INF_LANES + lane]; x.z = s_ring[(d0 + 2) * INF_LANES + lane]; x.w = s_ring[(d0 + 3) * INF_LANES + lane];
+            y.x = s_ring[(d0 + 4) * INF_LANES + lane]; y.y = s_ring[(d0 + 5) * INF_LANES + lane]; y.z = s_ring[(d0 + 6) * INF_LANES + lane]; y.w = s_ring[(d0 + 7) * INF_LANES + lane];
             uint4 *dst = reinterpret_cast<uint4 *>(o + fl); dst[0] = x; dst[1] = y;
         } else { for (uint32_t k = fl; k < nb; ++k) o[k] = ring_at(k); }
         fl = nb;
     };
     // litlen symbol of sorted slot idx: low byte + ninth bit
-    auto litlen_at = [&](uint32_t idx) __attribute__((always_inline)) -> int { return (int)L(s_lsym8, idx) | ((((int)s_lhi[(idx >> 3) * 64 + lane] >> (idx & 7u)) & 1) << 8); };
+    auto litlen_at = [&](uint32_t idx) __attribute__((always_inline)) -> int { return (int)L(s_lsym8, idx) | ((((int)s_lhi[(idx >> 3) * INF_LANES + lane] >> (idx & 7u)) & 1) << 8); };
     enum { ST_HDR = 0, ST_SYM = 1, ST_STORED = 2, ST_DONE = 3, ST_DIST = 4 };
     int state = (active && on) ? ST_HDR : ST_DONE; bool last = false;
     uint16_t e = 0;   // (16 bits on purpose: as an i32 its stores were merged with those of `op` through a pointer phi, which kept BOTH in scratch memory)
@@ -207,7 +213,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
                         // (one rolled loop: unrolled, the 318 store addresses were hoisted out of the main loop and held in registers for the
                         // whole kernel - 338 registers, the hot path reading its state back from AGPRs)
 #pragma unroll 1
-                        for (int s = 0; s < 318; ++s) gl[s * 64] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+                        for (int s = 0; s < 318; ++s) gl[s * INF_LANES] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
                         p16_add(cl, 7, 24); p16_add(cl, 8, 152); p16_add(cl, 9, 112); p16_add(cd, 5, 30);
                     } else {                                               // dynamic: code-length code, then the two length vectors
                         nlen = (int)take(b, 5) + 257; ndist = (int)take(b, 5) + 1; const int ncode = (int)take(b, 4) + 4;
@@ -223,7 +229,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
                         if (!bad && !canon_tables(cc, s_dlim, s_dbase, lane, offs)) bad = true;
                         for (int s = 0; s < 19 && !bad; ++s) { const int l = (int)((clv >> (3 * s)) & 7u); if (l) { L(s_dsym, p16_get(offs, l)) = (uint8_t)s; p16_add(offs, l, 1); } }
                         int idx = 0, prev = 0; bool eob = false;
-                        auto put_len = [&](int v) __attribute__((always_inline)) { gl[idx * 64] = (uint8_t)v; if (idx < nlen) p16_add(cl, v, 1); else p16_add(cd, v, 1); if (idx == 256 && v) eob = true; prev = v; ++idx; };
+                        auto put_len = [&](int v) __attribute__((always_inline)) { gl[idx * INF_LANES] = (uint8_t)v; if (idx < nlen) p16_add(cl, v, 1); else p16_add(cd, v, 1); if (idx == 256 && v) eob = true; prev = v; ++idx; };
                         while (!bad && idx < nlen + ndist) {
                             refill_now(b, w_end);
                             uint32_t si; const int l = decode_limit(peek15(b), s_dlim, s_dbase, lane, si);
@@ -244,12 +250,12 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
                     if (!bad) {
                         for (int k = 0; k < 36; ++k) L(s_lhi, k) = 0;
                         for (int s = 0; s < nlen; ++s) {
-                            const int l = gl[s * 64];
-                            if (l) { const unsigned at = p16_get(offs, l); L(s_lsym8, at) = (uint8_t)s; if (s >> 8) s_lhi[(at >> 3) * 64 + lane] |= (uint8_t)(1u << (at & 7u)); p16_add(offs, l, 1); }
+                            const int l = gl[s * INF_LANES];
+                            if (l) { const unsigned at = p16_get(offs, l); L(s_lsym8, at) = (uint8_t)s; if (s >> 8) s_lhi[(at >> 3) * INF_LANES + lane] |= (uint8_t)(1u << (at & 7u)); p16_add(offs, l, 1); }
                         }
                     }
                     if (!bad && !canon_tables(cd, s_dlim, s_dbase, lane, offs)) bad = true;
-                    if (!bad) for (int s = 0; s < ndist; ++s) { const int l = gl[(nlen + s) * 64]; if (l) { L(s_dsym, p16_get(offs, l)) = (uint8_t)s; p16_add(offs, l, 1); } }
+                    if (!bad) for (int s = 0; s < ndist; ++s) { const int l = gl[(nlen + s) * INF_LANES]; if (l) { L(s_dsym, p16_get(offs, l)) = (uint8_t)s; p16_add(offs, l, 1); } }
                     if (bad) { e = LPS_INF_ERR_DATA; state = ST_DONE; } else state = ST_SYM;
                 }
             }
@@ -336,7 +342,7 @@ void launch_bgzf_crc(const uint8_t *in, const InflateBlock *blk, int n_blk, cons
     if (n_blk > 0) hipLaunchKernelGGL(k_bgzf_crc, dim3((n_blk + 3) / 4), dim3(256), 0, s, in, blk, n_blk, out, err);
 }
 
-size_t bgzf_inflate_scratch_bytes(int n_blk) { return (size_t)((n_blk + 63) / 64) * INF_SCRATCH * 64; }
+size_t bgzf_inflate_scratch_bytes(int n_blk) { return (size_t)((n_blk + INF_LANES - 1) / INF_LANES) * INF_SCRATCH * INF_LANES; }
 void launch_bgzf_inflate(const uint8_t *in, const InflateBlock *blk, int n_blk, uint8_t *out, unsigned *err, uint8_t *scratch, hipStream_t s) {
-    if (n_blk > 0) hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_blk + 63) / 64), dim3(64), 0, s, in, blk, n_blk, out, err, scratch);
+    if (n_blk > 0) hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_blk + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), 0, s, in, blk, n_blk, out, err, scratch);
 }
