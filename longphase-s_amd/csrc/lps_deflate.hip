@@ -105,7 +105,14 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t *src, uint64_
             // two-queue Huffman: leaves 0..n-1 (sorted), internal nodes n..2n-2 are created in non-decreasing weight order
             for (int i = 0; i < n; ++i) S.weight[i] = S.hist[S.order[i]];
             int leaf = 0, inode = n, next = n;
-            auto pick = [&]() -> int { if (leaf < n && (inode >= next || S.weight[leaf] <= S.weight[inode])) return leaf++; return inode++; };
+            // (both cursors advance by a 0/1 amount: `return leaf++` / `return inode++` on two paths became ONE increment through a selected pointer,
+            // which kept both cursors in scratch memory - three scratch accesses with their waits per pick)
+            auto pick = [&]() -> int {
+                const bool from_leaves = leaf < n && (inode >= next || S.weight[leaf] <= S.weight[inode]);
+                const int r = from_leaves ? leaf : inode;
+                leaf += from_leaves ? 1 : 0; inode += from_leaves ? 0 : 1;
+                return r;
+            };
             for (int m = 0; m < n - 1; ++m) { const int a = pick(), b = pick(); S.weight[next] = S.weight[a] + S.weight[b]; S.parent[a] = next; S.parent[b] = next; ++next; }
             const int root = next - 1; S.depth[root] = 0;
             for (int i = root - 1; i >= 0; --i) { const int d = S.depth[S.parent[i]] + 1; S.depth[i] = (uint8_t)(d > 255 ? 255 : d); }   // parents have larger indices

@@ -22,10 +22,12 @@ __device__ __forceinline__ bool win_next_op(const uint32_t *cig, int &idx, int e
     idx += dir;
     while (idx < end && idx >= 0) {
         op = cig[idx] & 15; const int len = (int)(cig[idx] >> 4);
-        if (op == 0 || op == 3 || op == 6 || op == 7 || op == 8) { remaining += len; return true; }
-        else if (op == 1) readPos += len * dir;
-        else if (op == 2) refPos += len * dir;
-        else return false;
+        // (additions of a possibly-zero amount: an `x += ...` on one path and a `y += ...` on another become one addition through a selected
+        // pointer, and the variables then live in scratch memory)
+        const bool aligned = op == 0 || op == 3 || op == 6 || op == 7 || op == 8;
+        remaining += aligned ? len : 0; readPos += op == 1 ? len * dir : 0; refPos += op == 2 ? len * dir : 0;
+        if (aligned) return true;
+        if (op != 1 && op != 2) return false;
         idx += dir;
     }
     return false;
@@ -146,13 +148,15 @@ __global__ __launch_bounds__(64) void k_tumor_extract(VarView V, ReadView R, Tum
                                         if (kind == 0) counted = base_c == ref_c || base_c == alt_c;
                                         else if (kind == 1 || kind == 2) counted = true;         // base := isAlt ? Alt : Ref
                                         if (counted) {
-                                            if (hp1alt == is_alt) { ++h1; base_hp = 1; } else { ++h2; base_hp = 2; }
+                                            // (0/1 amounts, not `++h1` on one path and `++h2` on the other: the compiler turns that into one increment through a
+                                            // selected pointer and keeps the counters in scratch memory)
+                                            const bool to1 = hp1alt == is_alt; h1 += to1 ? 1 : 0; h2 += to1 ? 0 : 1; base_hp = to1 ? 1 : 2;
                                             const int ps = V.phase_set[v]; ps_lo = min(ps_lo, ps); ps_hi = max(ps_hi, ps);
                                         }
                                     } else if (tk != 0) {                                     // tumor-only row: H3 when the read shows the tumor ALT
-                                        if ((kind == 0 || kind == 1 || kind == 2) && is_alt) { ++h3; base_hp = 3; }
+                                        const bool to3 = (kind == 0 || kind == 1 || kind == 2) && is_alt; h3 += to3 ? 1 : 0; base_hp = to3 ? 3 : base_hp;
                                     }
-                                    if (tk != 0) { pair = true; ++n_site; }                   // tumorSnpPosVec (:722-724)
+                                    pair = pair || tk != 0; n_site += tk != 0 ? 1 : 0;          // tumorSnpPosVec (:722-724)
                                 }
                                 if (PASS == 0 && tk >= 1 && tk <= 3) {                        // :728-741
                                     if (tk != 1 || base_c == ref_c || base_c == alt_c) {
