@@ -344,23 +344,56 @@ __global__ void k_cnv_miss(const LpsCounters *cnt, int n_var, const int32_t *vpo
 // ================================================================================================ nodes
 // wave per alignment: mark observed variants as graph nodes, record the type written by the LAST alignment
 // (BAM order) that observes the position - the reference's (*variantType)[pos] = ... is last-writer-wins.
+// The four rows of an extraction job (k_extract_phase: one reservation per wave) lie back to back in the arena: a wave takes the job's whole span -
+// ~100 observations, two 64-lane rounds whose loads are all in flight together - instead of two rows in two 32-lane groups; these kernels wait on
+// dependent loads, so what counts is observations per resident wave.  Rows that were moved (k_extract_redo, k_extra_merge) break the span: then the
+// rows are walked one after the other.
+struct JobSpan { uint32_t base; int total; int c1, c2, c3; unsigned dead; bool flat; int n[4]; uint32_t off[4]; };
+__device__ __forceinline__ JobSpan job_span(const RowDesc *rows, const uint8_t *deleted, int r0, int n_reads) {
+    const int l = lane_id();
+    int n = 0; uint32_t off = 0; int del = 0;
+    if (l < 4 && r0 + l < n_reads) { const RowDesc d = rows[r0 + l]; n = max(d.cnt, 0); off = d.off; del = deleted ? deleted[r0 + l] : 0; }
+    JobSpan J;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { J.n[j] = __builtin_amdgcn_readlane(n, j); J.off[j] = (uint32_t)__builtin_amdgcn_readlane((int)off, j); }
+    J.dead = (unsigned)__ballot(del != 0 || n == 0) & 15u;
+    J.c1 = J.n[0]; J.c2 = J.c1 + J.n[1]; J.c3 = J.c2 + J.n[2]; J.total = J.c3 + J.n[3];
+    J.base = J.n[0] ? J.off[0] : (J.n[1] ? J.off[1] : (J.n[2] ? J.off[2] : J.off[3]));
+    J.flat = (!J.n[1] || J.off[1] == J.base + (uint32_t)J.c1) && (!J.n[2] || J.off[2] == J.base + (uint32_t)J.c2) && (!J.n[3] || J.off[3] == J.base + (uint32_t)J.c3);
+    return J;
+}
+
 __global__ __launch_bounds__(256) void k_mark_nodes(int n_reads, const RowDesc *rows,
                                                     const uint8_t *deleted, const ObsRec *obs,
                                                     uint32_t *is_node, uint32_t *vtype_key) {
-    const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
-    const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
-    if (r >= n_reads) return;
-    const int n = rows[r].cnt;
-    if (n <= 0 || deleted[r]) return;
-    const uint32_t off = rows[r].off;
-    for (int k = sl; k < n; k += ROW_G) {
-        const int v = obs[off + k].var; const int q = aq_quality((uint16_t)obs[off + k].aq);
-        if (v < 0) continue;                                  // erased by the CNV filter
+    const int l = lane_id();
+    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (r0 >= n_reads) return;
+    const JobSpan J = job_span(rows, deleted, r0, n_reads);
+    auto mark = [&](const ObsRec o, int r) __attribute__((always_inline)) {
+        const int v = o.var; const int q = aq_quality((uint16_t)o.aq);
+        if (v < 0) return;                                    // erased by the CNV filter
         const unsigned ty = (q >= 0) ? 0u : (q == -4 ? 3u : (q == -5 ? 4u : (q == -1 ? 1u : 2u)));      // :803-832 (-2 / -3: MOD on the forward / reverse strand)
         is_node[v] = 1u;
         // type of the LAST alignment that saw the variant.  Base qualities are never negative, so ty == 0 means a SNP row, all of whose
         // observations are of type 0: the word stays 0 without 1.7 M atomics
         if (ty) atomicMax(&vtype_key[v], ((unsigned)r << 3) | ty);
+    };
+    if (J.flat) {
+        for (int s0 = 0; s0 < J.total; s0 += 128) {                      // two rounds per trip: both loads leave before either is used
+            const int sa = s0 + l, sb = s0 + 64 + l;
+            ObsRec oa{-1, 0}, ob{-1, 0};
+            if (sa < J.total) oa = obs[J.base + sa];
+            if (sb < J.total) ob = obs[J.base + sb];
+            const int ja = (sa >= J.c1) + (sa >= J.c2) + (sa >= J.c3), jb = (sb >= J.c1) + (sb >= J.c2) + (sb >= J.c3);
+            if (sa < J.total && !((J.dead >> ja) & 1u)) mark(oa, r0 + ja);
+            if (sb < J.total && !((J.dead >> jb) & 1u)) mark(ob, r0 + jb);
+        }
+    } else {
+        for (int j = 0; j < 4; ++j) {
+            if ((J.dead >> j) & 1u) continue;
+            for (int k = l; k < J.n[j]; k += 64) mark(obs[J.off[j] + k], r0 + j);
+        }
     }
 }
 
@@ -370,7 +403,7 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const RowDesc *r
                                                    const uint32_t *node_of, int base_quality, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack, uint16_t *g_rank,
                                                    int32_t *g_cnt, LpsCounters *cnt, int n_var, const uint32_t *is_node, const uint32_t *vtype_key,
                                                    int32_t *nodes, uint8_t *ntype, uint32_t *node_cnt) {
-    const int nb_reads = (n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    const int nb_reads = (n_reads + 15) / 16;                              // four jobs of four alignments per workgroup
     if ((int)blockIdx.x >= nb_reads) {                                  // the workgroups after the alignments': node list (variant index, type) and node count
         const int v = ((int)blockIdx.x - nb_reads) * blockDim.x + threadIdx.x;
         if (v < n_var) {
@@ -379,37 +412,73 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const RowDesc *r
         }
         return;
     }
-    const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
-    const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
-    if (r >= n_reads) return;
-    const int n = rows[r].cnt;
-    if (n <= 0 || deleted[r]) { if (sl == 0) g_cnt[r] = 0; return; }
-    const uint32_t off = rows[r].off;
-    // compact in place (CNV-erased entries have var = -1); rows are private to their lane group so a running count suffices
-    int w = 0;
-    for (int k0 = 0; k0 < n; k0 += ROW_G) {
-        const int k = k0 + sl;
-        int v = -1; uint16_t aq = 0;
-        if (k < n) { v = obs[off + k].var; aq = (uint16_t)obs[off + k].aq; }
-        const bool ok = v >= 0;
-        const unsigned long long m = group_ballot(ok, grp);
-        if (ok) {
-            int q = aq_quality(aq); if (q < 0) q = (q == -1 && !aq_allele(aq)) ? 30 : 60;   // sentinels -> quality 60; a SV row the read does not carry: 30 (:803-828)
-            const uint32_t slot = off + w + __popcll(m & ((1ull << sl) - 1ull));
-            const uint32_t nd = node_of[v];
-            const unsigned fl = (unsigned)aq_allele(aq) | ((q >= base_quality) ? 2u : 0u);
-            g_node[slot] = (int32_t)nd;
-            g_flag[slot] = (uint8_t)fl;
-            g_pack[slot] = ((uint32_t)nd << 2) | fl;              // node and flag (bit 0 allele, bit 1 quality class) in one word: what k_edges reads per pair
-            // entries of the node's list: the merged rows hold exactly these observations.  What the counting atomic returns is a unique rank inside
-            // that list: kept, it places the entry later without a second atomic (k_node_scatter)
-            const unsigned rk = atomicAdd(&node_cnt[nd], 1u);
-            if (rk > 0xffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE);   // more than 65 536 reads over one variant
-            g_rank[slot] = (uint16_t)rk;
+    // wave per extraction job: the job's four rows as one span (see job_span), two 64-lane rounds per trip with their gathers and atomics in flight together
+    const int l = lane_id();
+    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (r0 >= n_reads) return;
+    const JobSpan J = job_span(rows, deleted, r0, n_reads);
+    // one observation -> its graph view in slot `slot` (compacted: CNV-erased entries have var < 0 and leave no slot)
+    auto emit = [&](int v, uint16_t aq, uint32_t slot) __attribute__((always_inline)) {
+        int q = aq_quality(aq); if (q < 0) q = (q == -1 && !aq_allele(aq)) ? 30 : 60;   // sentinels -> quality 60; a SV row the read does not carry: 30 (:803-828)
+        const uint32_t nd = node_of[v];
+        const unsigned fl = (unsigned)aq_allele(aq) | ((q >= base_quality) ? 2u : 0u);
+        g_node[slot] = (int32_t)nd;
+        g_flag[slot] = (uint8_t)fl;
+        g_pack[slot] = ((uint32_t)nd << 2) | fl;              // node and flag (bit 0 allele, bit 1 quality class) in one word: what k_edges reads per pair
+        // entries of the node's list: the merged rows hold exactly these observations.  What the counting atomic returns is a unique rank inside
+        // that list: kept, it places the entry later without a second atomic (k_node_scatter)
+        const unsigned rk = atomicAdd(&node_cnt[nd], 1u);
+        if (rk > 0xffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE);   // more than 65 536 reads over one variant
+        g_rank[slot] = (uint16_t)rk;
+    };
+    int w0 = 0, w1 = 0, w2 = 0, w3 = 0;                                   // entries placed so far in each row (wave-uniform)
+    if (J.flat) {
+        const unsigned long long lt = lanemask_lt();
+        // slot of a valid entry: its row's first slot + the row's valid entries before it (earlier rounds: w; this round: ballot under the row's lanes)
+        auto place = [&](int s0, int s, bool ok, unsigned long long m) __attribute__((always_inline)) -> uint32_t {
+            const int j = (s >= J.c1) + (s >= J.c2) + (s >= J.c3);
+            auto lanes = [&](int lo, int hi) __attribute__((always_inline)) -> unsigned long long {            // lanes of this round whose position is in [lo, hi)
+                const int a = min(max(lo - s0, 0), 64), b = min(max(hi - s0, 0), 64);
+                return ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((a >= 64) ? ~0ull : ((1ull << a) - 1ull));
+            };
+            const unsigned long long r0m = lanes(0, J.c1), r1m = lanes(J.c1, J.c2), r2m = lanes(J.c2, J.c3), r3m = lanes(J.c3, J.total);
+            const unsigned long long mine = j == 0 ? r0m : (j == 1 ? r1m : (j == 2 ? r2m : r3m));
+            const int wj = j == 0 ? w0 : (j == 1 ? w1 : (j == 2 ? w2 : w3));
+            const uint32_t first = J.base + (uint32_t)(j == 0 ? 0 : (j == 1 ? J.c1 : (j == 2 ? J.c2 : J.c3)));
+            const uint32_t slot = first + (uint32_t)wj + (uint32_t)__popcll(m & mine & lt);
+            w0 += __popcll(m & r0m); w1 += __popcll(m & r1m); w2 += __popcll(m & r2m); w3 += __popcll(m & r3m);
+            (void)ok;
+            return slot;
+        };
+        for (int s0 = 0; s0 < J.total; s0 += 128) {
+            const int sa = s0 + l, sb = s0 + 64 + l;
+            ObsRec oa{-1, 0}, ob{-1, 0};
+            if (sa < J.total) oa = obs[J.base + sa];
+            if (sb < J.total) ob = obs[J.base + sb];
+            const int ja = (sa >= J.c1) + (sa >= J.c2) + (sa >= J.c3), jb = (sb >= J.c1) + (sb >= J.c2) + (sb >= J.c3);
+            const bool oka = sa < J.total && !((J.dead >> ja) & 1u) && oa.var >= 0, okb = sb < J.total && !((J.dead >> jb) & 1u) && ob.var >= 0;
+            const unsigned long long ma = __ballot(oka), mb = __ballot(okb);
+            const uint32_t slot_a = place(s0, sa, oka, ma), slot_b = place(s0 + 64, sb, okb, mb);
+            if (oka) emit(oa.var, (uint16_t)oa.aq, slot_a);
+            if (okb) emit(ob.var, (uint16_t)ob.aq, slot_b);
         }
-        w += __popcll(m);
+    } else {
+        for (int j = 0; j < 4; ++j) {                                   // rows that were moved: one after the other, 64 lanes each
+            if ((J.dead >> j) & 1u) continue;
+            int w = 0;
+            for (int k0 = 0; k0 < J.n[j]; k0 += 64) {
+                const int k = k0 + l;
+                ObsRec o{-1, 0};
+                if (k < J.n[j]) o = obs[J.off[j] + k];
+                const bool ok = o.var >= 0;
+                const unsigned long long m = __ballot(ok);
+                if (ok) emit(o.var, (uint16_t)o.aq, J.off[j] + (uint32_t)w + (uint32_t)__popcll(m & lanemask_lt()));
+                w += __popcll(m);
+            }
+            if (j == 0) w0 = w; else if (j == 1) w1 = w; else if (j == 2) w2 = w; else w3 = w;
+        }
     }
-    if (sl == 0) g_cnt[r] = w;
+    if (l < 4 && r0 + l < n_reads) g_cnt[r0 + l] = ((J.dead >> l) & 1u) ? 0 : (l == 0 ? w0 : (l == 1 ? w1 : (l == 2 ? w2 : w3)));
 }
 
 // ================================================================================================ merged rows
@@ -1308,9 +1377,9 @@ void launch_nodes(int n_reads, int n_var, const RowDesc *rows, const uint8_t *de
                   const ObsRec *obs, uint32_t *is_node, uint32_t *vtype_key, uint32_t *node_of,
                   int32_t *nodes, uint8_t *ntype, int base_quality, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack, uint16_t *g_rank, int32_t *g_cnt,
                   LpsCounters *cnt, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(k_mark_nodes, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, n_reads, rows, deleted, obs, is_node, vtype_key);
+    hipLaunchKernelGGL(k_mark_nodes, dim3((n_reads + 15) / 16), dim3(256), 0, s, n_reads, rows, deleted, obs, is_node, vtype_key);
     exscan_u32(temp, temp_bytes, is_node, node_of, n_var, s);
-    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK + (n_var + 255) / 256), dim3(256), 0, s, n_reads, rows, deleted, obs, node_of, base_quality, g_node, g_flag, g_pack, g_rank, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype, node_cnt);
+    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + 15) / 16 + (n_var + 255) / 256), dim3(256), 0, s, n_reads, rows, deleted, obs, node_of, base_quality, g_node, g_flag, g_pack, g_rank, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype, node_cnt);
 }
 
 void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
