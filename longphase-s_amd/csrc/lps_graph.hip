@@ -1386,7 +1386,7 @@ void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, 
                        const RowDesc *rows, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
                        unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list, uint32_t *g_pack, uint32_t *t_src, hipStream_t s) {
     hipLaunchKernelGGL(k_merge_plan, GRID(n_reads, 256), 0, s, skeys, gstart, cnt, rows, g_cnt, tail_lo, tail_size, mrow_off, mrow_cnt, multi_list);
-    hipLaunchKernelGGL(k_merge_multi, dim3(256), dim3(256), 0, s, skeys, gstart, cnt, rows, g_cnt, g_node, g_flag, g_pack, t_src, (uint32_t)tail_lo, mrow_off, multi_list);
+    hipLaunchKernelGGL(k_merge_multi, dim3(1024), dim3(256), 0, s, skeys, gstart, cnt, rows, g_cnt, g_node, g_flag, g_pack, t_src, (uint32_t)tail_lo, mrow_off, multi_list);
 }
 
 void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const RowDesc *rows, const int32_t *g_cnt, const uint32_t *read_group, const uint32_t *gstart,
