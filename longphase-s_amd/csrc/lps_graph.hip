@@ -1395,7 +1395,7 @@ void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const RowDesc *
                        unsigned long long *keys, uint32_t *vals, uint32_t *node_off, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s) {
     exscan_u32(temp, temp_bytes, node_cnt, node_off, (size_t)n_var + 1, s);      // node_cnt was filled by k_graph_obs
     const int nb_reads = (n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(k_node_scatter, dim3(nb_reads + 64), dim3(256), 0, s, cnt, rows, g_cnt, read_group, gstart, mrow_off, mrow_cnt, multi_list, g_node, g_rank, t_src, tail_lo, node_off, a_bits, keys, vals, cnt, n_var, n_reads, nb_reads);
+    hipLaunchKernelGGL(k_node_scatter, dim3(nb_reads + 512), dim3(256), 0, s, cnt, rows, g_cnt, read_group, gstart, mrow_off, mrow_cnt, multi_list, g_node, g_rank, t_src, tail_lo, node_off, a_bits, keys, vals, cnt, n_var, n_reads, nb_reads);
 }
 
 void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
