@@ -321,6 +321,20 @@ __global__ void __launch_bounds__(256) k_bgzf_crc(const uint8_t *in, const Infla
     auto word = [&](uint32_t pos) -> uint32_t { const uint64_t a = base + pos; const uint32_t lo = o32[a >> 2], hi = o32[(a >> 2) + 1]; return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3)); };
     auto step4 = [&](uint32_t c, uint32_t w) -> uint32_t { c ^= w; return tab[3][c & 255u] ^ tab[2][(c >> 8) & 255u] ^ tab[1][(c >> 16) & 255u] ^ tab[0][c >> 24]; };
     uint32_t ca = lane == 0 ? 0xffffffffu : 0u, cb = 0u; uint32_t pa = a0, pb = b0;
+    // 16 bytes of each half per trip: five dwords per half (one 16-byte load + one dword; `word` alone costs two loads per FOUR bytes, and every lane's
+    // loads go to lines of their own - the load instructions, not the table lookups, were what the kernel waited for)
+    struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };
+    while (pa + 16 <= a1 && pb + 16 <= b1) {
+        const uint64_t ga = base + pa, gb = base + pb;
+        const uint32_t *qa = o32 + (ga >> 2), *qb = o32 + (gb >> 2);
+        const U4 xa = *reinterpret_cast<const U4 *>(qa), xb = *reinterpret_cast<const U4 *>(qb); const uint32_t ya = qa[4], yb = qb[4];
+        const uint32_t sa = (uint32_t)(ga & 3), sb = (uint32_t)(gb & 3);
+        ca = step4(ca, __builtin_amdgcn_alignbyte(xa.y, xa.x, sa)); cb = step4(cb, __builtin_amdgcn_alignbyte(xb.y, xb.x, sb));
+        ca = step4(ca, __builtin_amdgcn_alignbyte(xa.z, xa.y, sa)); cb = step4(cb, __builtin_amdgcn_alignbyte(xb.z, xb.y, sb));
+        ca = step4(ca, __builtin_amdgcn_alignbyte(xa.w, xa.z, sa)); cb = step4(cb, __builtin_amdgcn_alignbyte(xb.w, xb.z, sb));
+        ca = step4(ca, __builtin_amdgcn_alignbyte(ya, xa.w, sa));   cb = step4(cb, __builtin_amdgcn_alignbyte(yb, xb.w, sb));
+        pa += 16; pb += 16;
+    }
     while (pa + 4 <= a1 && pb + 4 <= b1) { const uint32_t wa = word(pa), wb = word(pb); ca = step4(ca, wa); cb = step4(cb, wb); pa += 4; pb += 4; }
     while (pa + 4 <= a1) { ca = step4(ca, word(pa)); pa += 4; }
     while (pb + 4 <= b1) { cb = step4(cb, word(pb)); pb += 4; }
