@@ -135,6 +135,19 @@ __device__ __forceinline__ bool bam_candidate(const uint8_t *d, uint64_t p, uint
     return d[p + 36 + l_name - 1] == 0;
 }
 
+// positions k of 16 consecutive ones whose refID field (4 bytes at +4) is a contig index or -1; w = the six dwords from the aligned address at or
+// before the first position's refID, SH = that refID's byte offset inside w[0]
+template <int SH>
+__device__ __forceinline__ uint32_t refid_mask(const uint32_t (&w)[6], int32_t n_ref) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int32_t tid = (int32_t)__builtin_amdgcn_alignbyte(w[((SH + k) >> 2) + 1], w[(SH + k) >> 2], (SH + k) & 3);
+        if (tid >= -1 && tid < n_ref) m |= 1u << k;
+    }
+    return m;
+}
+
 // 256 threads x 16 consecutive positions; PASS 0 counts per workgroup, PASS 1 writes the ordered candidates (value = offset of the refID field)
 template <int PASS>
 __global__ void __launch_bounds__(256) k_bam_candidates(const uint8_t *d, uint64_t begin, uint64_t total, int32_t n_ref, uint32_t *wg_count,
@@ -142,7 +155,17 @@ __global__ void __launch_bounds__(256) k_bam_candidates(const uint8_t *d, uint64
     __shared__ uint32_t s_cnt[256];
     const uint64_t p0 = begin + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
     uint32_t mask = 0;
-    for (int k = 0; k < 16; ++k) if (p0 + k < total && bam_candidate(d, p0 + k, total, n_ref)) mask |= 1u << k;
+    if (p0 + 64 <= total) {
+        // the refID test alone rejects nearly every position: the 19 bytes it looks at for the thread's 16 positions come in as six aligned dwords
+        // (neighbouring threads: neighbouring 16 bytes), the 16 candidates' refIDs are cut out of them in registers; only survivors see the full test
+        const uint64_t a = (p0 + 4) & ~3ull; const int sh = (int)((p0 + 4) & 3ull);        // sh is the same for every thread of the launch
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(d + a);
+        const uint32_t w[6] = {q[0], q[1], q[2], q[3], q[4], q[5]};
+        uint32_t pre = sh == 0 ? refid_mask<0>(w, n_ref) : sh == 1 ? refid_mask<1>(w, n_ref) : sh == 2 ? refid_mask<2>(w, n_ref) : refid_mask<3>(w, n_ref);
+        while (pre) { const int k = __ffs(pre) - 1; pre &= pre - 1; if (bam_candidate(d, p0 + k, total, n_ref)) mask |= 1u << k; }
+    } else {
+        for (int k = 0; k < 16; ++k) if (p0 + k < total && bam_candidate(d, p0 + k, total, n_ref)) mask |= 1u << k;
+    }
     s_cnt[threadIdx.x] = __popc(mask);
     __syncthreads();
     for (int s = 1; s < 256; s <<= 1) { const uint32_t v = threadIdx.x >= (unsigned)s ? s_cnt[threadIdx.x - s] : 0; __syncthreads(); s_cnt[threadIdx.x] += v; __syncthreads(); }
