@@ -7,5 +7,5 @@ for i in 1 2 3; do for v in "$1" "$2"; do
   python3 -c "
 import json
 d=json.loads(open('/tmp/ab.json').read().strip().splitlines()[-1]); st=d['stages_at_largest_contig']
-print('$v', 'step', round(d['ms_per_step'],3), 'dominant', d['roofline']['kernel'], round(d['roofline']['kernel_ms'],4), 'edges', st['edges']['ms'], 'nodes', st['nodes']['ms'], 'node_lists', st['node_lists']['ms'], 'rc', st['read_correction']['ms'], 'merge', st['merge_rows']['ms'], 'groups', st['name_groups']['ms'], 'scan', st['vote_scan']['ms'], 'extract', st['extract']['ms'], 'haplotag', round(d['secondary']['ms_per_step'],3))"
+print('$v', 'step', round(d['ms_per_step'],3), 'dominant', d['roofline']['kernel'], round(d['roofline']['kernel_ms'],4), 'edges', st['edges']['ms'], 'nodes', st['nodes']['ms'], 'node_lists', st['node_lists']['ms'], 'rc', st['read_correction']['ms'], 'merge', st['merge_rows']['ms'], 'groups', st['name_groups']['ms'], 'scan', st['vote_scan']['ms'], 'extract', st['extract']['ms'], 'haplotag', round(d['secondary']['ms_per_step'],3), 'hap kernel', round(d['per_contig_rank0'][0].get('haplotag_kernel_ms', 0), 4))"
 done; done
