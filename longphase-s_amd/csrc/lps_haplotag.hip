@@ -33,6 +33,9 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
     int *sref = s_ref[w], *sqry = s_qry[w]; uint32_t *scig = s_cig[w];
     const int start = R.ref_start[r];
     const int flag = R.flag[r];
+    // every field of the read's header in one round trip (the filter cascade below needs three of them; the others used to be a second trip)
+    const uint64_t coff = R.cigar_off[r], coff_end = R.cigar_off[r + 1], soff = R.seq_off[r];
+    const int lq = R.l_qseq[r];
     constexpr bool SOMATIC = MODE == 1;
     constexpr bool EXTRACT = MODE == 2 || MODE == 3;
     const bool mq_ok = R.mapq[r] >= mapping_quality;
@@ -45,17 +48,15 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
     else if (!(start <= V.last_pos)) status = 6;
     int h1 = 0, h2 = 0, h3 = 0, d1 = 0, d2 = 0, ps_lo = 0x7fffffff, ps_hi = (int)0x80000000;
     if (status == 0) {
-        const uint64_t coff = R.cigar_off[r];
-        const int n_cig = (int)(R.cigar_off[r + 1] - coff);
+        const int n_cig = (int)(coff_end - coff);
         const uint32_t *cig = R.cigar + coff;
-        const uint8_t *seq = R.seq + R.seq_off[r];
-        const int lq = R.l_qseq[r];
+        const uint8_t *seq = R.seq + soff;
+        uint32_t pw[8];                                              // the NEXT segment's words, requested while the current one is searched
+        request_ops8(cig, 8 * l, min(LPS_SEG, n_cig), pw);            // (the first segment's: on their way while the first candidate is searched)
         int vcur = var_lower_bound(V, start);
         int ref_pos = start, q_pos = 0;
         int judged_op = -1;                                              // EXTRACT: last D op whose germline vote has been cast
         const int my_hp = (MODE == 3) ? (int)H.read_hp[r] : 0;
-        uint32_t pw[8];                                              // the NEXT segment's words, requested while the current one is searched
-        request_ops8(cig, 8 * l, min(LPS_SEG, n_cig), pw);
         for (int seg0 = 0; seg0 < n_cig && vcur < V.n; seg0 += LPS_SEG) {
             const int nseg = min(LPS_SEG, n_cig - seg0);
             uint2 vr = make_uint2(0x7fffffffu, 0u);
