@@ -717,12 +717,18 @@ __global__ __launch_bounds__(256) void k_node_scatter(const LpsCounters *cnt, co
     if (n <= 0) return;
     const unsigned g = read_group[r];
     const uint32_t off = rows[r].off;
+    // the first round's entries (and their nodes' list starts) are requested BEFORE the group is looked at: the two chains of dependent loads -
+    // entry -> node -> list start, and group -> its bounds and merged row - run side by side instead of one after the other
+    int nd0 = 0; uint32_t slot0 = 0;
+    if (sl < n) { nd0 = g_node[off + sl]; slot0 = g_rank[off + sl]; }
+    if (sl < n) slot0 += node_off[nd0];
     if (gstart[g + 1] - gstart[g] != 1 && mrow_off[g] != off) return;   // part of a merged row of several alignments: handled above (a group with ONE surviving alignment uses that row)
     if ((unsigned long long)n > (1ull << a_bits)) { if (sl == 0) atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); return; }
-    for (int a = sl; a < n; a += ROW_G) {
+    if (sl < n) { keys[slot0] = ((unsigned long long)g << a_bits) | (unsigned)sl; vals[slot0] = off + sl; }      // (name rank, index in row)
+    for (int a = sl + ROW_G; a < n; a += ROW_G) {
         const int nd = g_node[off + a];
         const uint32_t slot = node_off[nd] + g_rank[off + a];
-        keys[slot] = ((unsigned long long)g << a_bits) | (unsigned)a;      // (name rank, index in row)
+        keys[slot] = ((unsigned long long)g << a_bits) | (unsigned)a;
         vals[slot] = off + a;
     }
 }
