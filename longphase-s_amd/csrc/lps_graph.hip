@@ -348,6 +348,12 @@ __global__ void k_cnv_miss(const LpsCounters *cnt, int n_var, const int32_t *vpo
 // ~100 observations, two 64-lane rounds whose loads are all in flight together - instead of two rows in two 32-lane groups; these kernels wait on
 // dependent loads, so what counts is observations per resident wave.  Rows that were moved (k_extract_redo, k_extra_merge) break the span: then the
 // rows are walked one after the other.
+// Workgroups are dealt round-robin over the 8 XCDs (one L2 each): workgroup b of a grid of 8k takes unit (b % 8) * k + b / 8, so that an XCD walks ONE
+// contiguous eighth of the units and what neighbouring units share (list entries, rows of packed words) meets in one L2.  Used by k_edges (-2 %) and
+// k_node_scatter (-28 %); the kernels whose neighbouring rows hit the same COUNTERS with atomics (k_graph_obs, k_read_correction) were 20 % slower
+// with it - their atomics do better spread over all eight L2s
+__device__ __forceinline__ int xcd_unit(int b, int n_blocks8) { return (b & 7) * (n_blocks8 >> 3) + (b >> 3); }
+__host__ __device__ inline int round_up8(int x) { return (x + 7) / 8 * 8; }
 struct JobSpan { uint32_t base; int total; int c1, c2, c3; unsigned dead; bool flat; int n[4]; uint32_t off[4]; };
 __device__ __forceinline__ JobSpan job_span(const RowDesc *rows, const uint8_t *deleted, int r0, int n_reads) {
     const int l = lane_id();
@@ -710,7 +716,9 @@ __global__ __launch_bounds__(256) void k_node_scatter(const LpsCounters *cnt, co
         }
         return;
     }
-    const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
+    // (XCD-aware, as in k_edges: the eight XCDs each walk a contiguous eighth of the rows, so that the entries of neighbouring reads - neighbours in
+    // the node lists - are put together in ONE L2 before they reach HBM; nb_reads is a multiple of 8)
+    const int r = (xcd_unit((int)blockIdx.x, nb_reads) * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
     if (r == 0 && sl == 0) cntw->n_obs_final = node_off[n_var];         // sum of merged rows = end of the last node's list
     if (r >= n_reads) return;
     const int n = g_cnt[r];
@@ -756,7 +764,10 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
                                                const uint32_t *mrow_off, const int32_t *mrow_cnt, int m_bits, int a_bits,
                                                const uint32_t *g_pack, uint32_t tail_lo, int A, double edge_weight,
                                                double edge_threshold, const uint8_t *ntype, float *edge, uint8_t *erec, uint32_t *node_pairs) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2, and a row of packed words is wanted by the ~35 source nodes before it:
+    // workgroup b takes node block (b % 8) * (blocks / 8) + b / 8, so that an XCD walks ONE contiguous eighth of the nodes and a row is fetched into
+    // one L2, not into all eight (the grid is a multiple of 8)
+    const int i = xcd_unit((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6), l = lane_id();
     const int n_nodes = (int)cnt->n_nodes;
     if (i >= n_nodes) return;
     const uint32_t off = node_off[i], end = off + node_end[i];      // node_end holds the entry COUNT of the node
@@ -1400,7 +1411,7 @@ void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const RowDesc *
                        const int32_t *g_node, const uint16_t *g_rank, const uint32_t *t_src, uint32_t tail_lo, int a_bits,
                        unsigned long long *keys, uint32_t *vals, uint32_t *node_off, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s) {
     exscan_u32(temp, temp_bytes, node_cnt, node_off, (size_t)n_var + 1, s);      // node_cnt was filled by k_graph_obs
-    const int nb_reads = (n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    const int nb_reads = (((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK + 7) / 8) * 8;
     hipLaunchKernelGGL(k_node_scatter, dim3(nb_reads + 512), dim3(256), 0, s, cnt, rows, g_cnt, read_group, gstart, mrow_off, mrow_cnt, multi_list, g_node, g_rank, t_src, tail_lo, node_off, a_bits, keys, vals, cnt, n_var, n_reads, nb_reads);
 }
 
@@ -1408,7 +1419,7 @@ void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const u
                   const unsigned long long *ukeys, const uint32_t *uvals, unsigned long long *skeys, uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
                   int m_bits, int a_bits, const uint32_t *g_pack, uint32_t tail_lo, int A, double edge_weight,
                   double edge_threshold, const uint8_t *ntype, float *edge, uint8_t *erec, uint32_t *node_pairs, hipStream_t s) {
-    hipLaunchKernelGGL(k_edges, dim3((n_var + 3) / 4), dim3(256), 0, s, cnt, node_off, node_end, ukeys, uvals, skeys, svals, mrow_off, mrow_cnt, m_bits, a_bits, g_pack, tail_lo, A, edge_weight, edge_threshold, ntype, edge, erec, node_pairs);
+    hipLaunchKernelGGL(k_edges, dim3((((n_var + 3) / 4 + 7) / 8) * 8), dim3(256), 0, s, cnt, node_off, node_end, ukeys, uvals, skeys, svals, mrow_off, mrow_cnt, m_bits, a_bits, g_pack, tail_lo, A, edge_weight, edge_threshold, ntype, edge, erec, node_pairs);
 }
 
 size_t scan_state_bytes(int n_var) { return (size_t)((n_var + SCAN_SEG - 1) / SCAN_SEG + 1) * 2 * sizeof(ScanState); }
