@@ -717,27 +717,50 @@ __global__ __launch_bounds__(256) void k_node_scatter(const LpsCounters *cnt, co
         return;
     }
     // (XCD-aware, as in k_edges: the eight XCDs each walk a contiguous eighth of the rows, so that the entries of neighbouring reads - neighbours in
-    // the node lists - are put together in ONE L2 before they reach HBM; nb_reads is a multiple of 8)
-    const int r = (xcd_unit((int)blockIdx.x, nb_reads) * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
-    if (r == 0 && sl == 0) cntw->n_obs_final = node_off[n_var];         // sum of merged rows = end of the last node's list
-    if (r >= n_reads) return;
-    const int n = g_cnt[r];
-    if (n <= 0) return;
-    const unsigned g = read_group[r];
-    const uint32_t off = rows[r].off;
-    // the first round's entries (and their nodes' list starts) are requested BEFORE the group is looked at: the two chains of dependent loads -
-    // entry -> node -> list start, and group -> its bounds and merged row - run side by side instead of one after the other
-    int nd0 = 0; uint32_t slot0 = 0;
-    if (sl < n) { nd0 = g_node[off + sl]; slot0 = g_rank[off + sl]; }
-    if (sl < n) slot0 += node_off[nd0];
-    if (gstart[g + 1] - gstart[g] != 1 && mrow_off[g] != off) return;   // part of a merged row of several alignments: handled above (a group with ONE surviving alignment uses that row)
-    if ((unsigned long long)n > (1ull << a_bits)) { if (sl == 0) atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); return; }
-    if (sl < n) { keys[slot0] = ((unsigned long long)g << a_bits) | (unsigned)sl; vals[slot0] = off + sl; }      // (name rank, index in row)
-    for (int a = sl + ROW_G; a < n; a += ROW_G) {
-        const int nd = g_node[off + a];
-        const uint32_t slot = node_off[nd] + g_rank[off + a];
-        keys[slot] = ((unsigned long long)g << a_bits) | (unsigned)a;
-        vals[slot] = off + a;
+    // the node lists - are put together in ONE L2 before they reach HBM; nb_reads is a multiple of 8.)  A wave takes the span of an extraction job
+    // (job_span: four rows back to back, the compacted entries at the front of each row's part), two 64-lane rounds in flight.
+    const int r0 = (xcd_unit((int)blockIdx.x, nb_reads) * 4 + (threadIdx.x >> 6)) * 4;
+    if (r0 == 0 && l == 0) cntw->n_obs_final = node_off[n_var];         // sum of merged rows = end of the last node's list
+    if (r0 >= n_reads) return;
+    const JobSpan J = job_span(rows, nullptr, r0, n_reads);
+    // per row (lanes 0-3): entries kept, name group, and whether the row IS its read's merged row (a group with ONE surviving alignment uses that
+    // alignment's row; the rows of the others are parts of a merged row in the tail arena, handled above)
+    int gc = 0; unsigned g = 0; bool use = false;
+    if (l < 4 && r0 + l < n_reads) {
+        gc = max(g_cnt[r0 + l], 0); g = read_group[r0 + l];
+        if (gc > 0) {
+            use = !(gstart[g + 1] - gstart[g] != 1 && mrow_off[g] != J.off[l]);
+            if ((unsigned long long)gc > (1ull << a_bits)) { atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); use = false; }
+        }
+    }
+    const unsigned um = (unsigned)__ballot(use) & 15u;
+    if (!um) return;
+    const int k0 = __builtin_amdgcn_readlane(gc, 0), k1 = __builtin_amdgcn_readlane(gc, 1), k2 = __builtin_amdgcn_readlane(gc, 2), k3 = __builtin_amdgcn_readlane(gc, 3);
+    const unsigned q0 = (unsigned)__builtin_amdgcn_readlane((int)g, 0), q1 = (unsigned)__builtin_amdgcn_readlane((int)g, 1), q2 = (unsigned)__builtin_amdgcn_readlane((int)g, 2), q3 = (unsigned)__builtin_amdgcn_readlane((int)g, 3);
+    auto put = [&](uint32_t at, unsigned gj, int a, int nd, unsigned rk) __attribute__((always_inline)) {
+        const uint32_t slot = node_off[nd] + rk;
+        keys[slot] = ((unsigned long long)gj << a_bits) | (unsigned)a;      // (name rank, index in row)
+        vals[slot] = at;
+    };
+    if (J.flat) {
+        for (int s0 = 0; s0 < J.total; s0 += 128) {
+            const int sa = s0 + l, sb = s0 + 64 + l;
+            const int ja = (sa >= J.c1) + (sa >= J.c2) + (sa >= J.c3), jb = (sb >= J.c1) + (sb >= J.c2) + (sb >= J.c3);
+            const int aa = sa - (ja == 0 ? 0 : (ja == 1 ? J.c1 : (ja == 2 ? J.c2 : J.c3))), ab = sb - (jb == 0 ? 0 : (jb == 1 ? J.c1 : (jb == 2 ? J.c2 : J.c3)));
+            const bool ina = sa < J.total && ((um >> ja) & 1u) && aa < (ja == 0 ? k0 : (ja == 1 ? k1 : (ja == 2 ? k2 : k3)));
+            const bool inb = sb < J.total && ((um >> jb) & 1u) && ab < (jb == 0 ? k0 : (jb == 1 ? k1 : (jb == 2 ? k2 : k3)));
+            int nda = 0, ndb = 0; unsigned rka = 0, rkb = 0;
+            if (ina) { nda = g_node[J.base + sa]; rka = g_rank[J.base + sa]; }
+            if (inb) { ndb = g_node[J.base + sb]; rkb = g_rank[J.base + sb]; }
+            if (ina) put(J.base + sa, ja == 0 ? q0 : (ja == 1 ? q1 : (ja == 2 ? q2 : q3)), aa, nda, rka);
+            if (inb) put(J.base + sb, jb == 0 ? q0 : (jb == 1 ? q1 : (jb == 2 ? q2 : q3)), ab, ndb, rkb);
+        }
+    } else {
+        for (int j = 0; j < 4; ++j) {                                   // rows that were moved: one after the other
+            if (!((um >> j) & 1u)) continue;
+            const int n = j == 0 ? k0 : (j == 1 ? k1 : (j == 2 ? k2 : k3)); const unsigned gj = j == 0 ? q0 : (j == 1 ? q1 : (j == 2 ? q2 : q3));
+            for (int a = l; a < n; a += 64) put(J.off[j] + a, gj, a, g_node[J.off[j] + a], g_rank[J.off[j] + a]);
+        }
     }
 }
 
@@ -1411,7 +1434,7 @@ void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const RowDesc *
                        const int32_t *g_node, const uint16_t *g_rank, const uint32_t *t_src, uint32_t tail_lo, int a_bits,
                        unsigned long long *keys, uint32_t *vals, uint32_t *node_off, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s) {
     exscan_u32(temp, temp_bytes, node_cnt, node_off, (size_t)n_var + 1, s);      // node_cnt was filled by k_graph_obs
-    const int nb_reads = (((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK + 7) / 8) * 8;
+    const int nb_reads = round_up8((n_reads + 15) / 16);                  // workgroups of four extraction jobs (16 rows)
     hipLaunchKernelGGL(k_node_scatter, dim3(nb_reads + 512), dim3(256), 0, s, cnt, rows, g_cnt, read_group, gstart, mrow_off, mrow_cnt, multi_list, g_node, g_rank, t_src, tail_lo, node_off, a_bits, keys, vals, cnt, n_var, n_reads, nb_reads);
 }
 
