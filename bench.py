@@ -58,6 +58,8 @@ def workload_contigs(name, seed):
         return [dict(name="chr20", contig_len=64_444_167, n_snp=60_000, coverage=30.0, seed=seed)]
     if name == "chr20_30x_pileups":   # configs[1] with simulated CNV break points: clip pile-ups, so that the CNV interval stage and filter run
         return [dict(name="chr20", contig_len=64_444_167, n_snp=60_000, coverage=30.0, seed=seed, clip_pileups=50)]
+    if name == "mini_wgs":         # eight small contigs: rehearsal of the multi-rank path (tests/test_bench_ranks_gpu.py), not a measurement
+        return [dict(name=f"ctg{i}", contig_len=(6 - i % 3) * 1_000_000, n_snp=(6 - i % 3) * 1_000, coverage=12.0, seed=seed + i) for i in range(8)]
     if name == "5mb_10x":          # BASELINE.json configs[0] (plumbing size)
         return [dict(name="ctg5mb", contig_len=5_000_000, n_snp=5_000, coverage=10.0, seed=seed)]
     raise SystemExit(f"unknown workload {name}")
@@ -86,7 +88,8 @@ class ParityPool:
         # an munmap of that size stops every thread of the process that needs the address-space lock (the HIP runtime's included) for ~0.5 s
         self.heavy = threading.Lock()
 
-    def submit(self, name, P, V, host, out_ps, out_gt):
+    def submit(self, name, P, V, host, out_ps, out_gt, hap=None):
+        """hap = (VT, hp, pq, ps): the haplotag table of the benched run and the tags the GPU gave every alignment, checked against lps_oracle.haplotag"""
         from lps import abi
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import lps_oracle
@@ -109,7 +112,13 @@ class ParityPool:
                 same_ps = bool(np.array_equal(want.phase_set, out_ps))
                 m = want.phase_set != 0
                 same_gt = bool(np.array_equal(want.gt[m], out_gt[m]))
-                return dict(contig=name, identical=same_ps and same_gt, oracle_s=dt, n_phased=int(m.sum()))
+                res = dict(contig=name, identical=same_ps and same_gt, oracle_s=dt, n_phased=int(m.sum()))
+                if hap is not None:                                       # secondary metric: HP / PQ / PS of every alignment (HaplotagStrategy.cpp:243-300)
+                    t0 = time.time()
+                    hw = lps_oracle.haplotag(P, hap[0], box[0].ref, R)
+                    res.update(haplotag_identical=bool(np.array_equal(hw.hp, hap[1]) and np.array_equal(hw.pq, hap[2]) and np.array_equal(hw.ps, hap[3])),
+                               haplotag_oracle_s=time.time() - t0, n_tagged=int((hw.hp != 0).sum()))
+                return res
             finally:
                 with self.heavy:
                     R = None; box.clear()                                # the arrays are freed HERE, never while a timed region runs
@@ -173,12 +182,47 @@ def cpu_baseline(g, spec, threads, port, gpu_result=None):
         return out
 
 
+def gpu_nodes():
+    """GPUs of this machine from the KFD topology in sysfs - no HIP call (the parent of spawn_ranks must not touch the GPU).  None = unknown."""
+    import glob
+    n = 0; seen = False
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(ln.split()[:2] for ln in open(f) if len(ln.split()) >= 2)
+        except OSError:
+            continue
+        seen = True
+        n += int(props.get("simd_count", "0")) > 0
+    return n if seen else None
+
+
+def spawn_ranks(a):
+    """`--gpus N` launched plainly (no torchrun, WORLD_SIZE unset): start the N ranks as CHILD processes - this process has made no GPU call and
+    makes none; a process that has touched the GPU must never exec another program - hand them the rendezvous through the environment torchrun
+    would set, relay rank 0's JSON line and exit with the worst of their codes."""
+    import socket
+    n_dev = gpu_nodes()
+    if n_dev and (a.gpus + n_dev - 1) // n_dev > 6:
+        raise SystemExit(f"--gpus {a.gpus} on {n_dev} GPU(s): more than 6 ranks would share a GPU")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode(errors="replace")); sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    raise SystemExit(bad[0] if bad else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="wgs_50x", choices=["wgs_50x", "chr1_50x", "chr20_30x", "chr20_30x_pileups", "5mb_10x"])
+    ap.add_argument("--workload", default="wgs_50x", choices=["wgs_50x", "chr1_50x", "chr20_30x", "chr20_30x_pileups", "5mb_10x", "mini_wgs"])
     ap.add_argument("--seed", type=int, default=201)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity", default="all", help="all | none | comma-separated contig names whose step-0 output is compared with the oracle")
@@ -187,6 +231,8 @@ def main():
     ap.add_argument("--ctx-per-gpu", type=int, default=4, help="contigs phased concurrently on one GPU, one context (stream, host thread) each")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)                       # never returns: `python3 bench.py --gpus N` without a launcher starts its N ranks itself
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = max(1, int(os.environ.get("WORLD_SIZE", "1")))
@@ -218,9 +264,18 @@ def main():
     pool = ParityPool(workers=max(2, cpu_share // 2), max_bytes=(24 << 30) + (72 << 30) // world) if parity_set else None
 
     # ---- SNP table: with several ranks, rank 0's packed table reaches the other GPUs by one RCCL broadcast (north_star)
-    bcast = None
+    bcast = None; rccl_info = None; comm = None; invalid = None
     if world > 1:
-        bcast = snp_table_broadcast(L, dist, dev, rank, world, contigs)
+        try:
+            bcast, rccl_info, comm = snp_table_broadcast(L, dist, dev, rank, world, contigs)
+        except Invalid as e:
+            # a collective hung on some rank (all ranks know: the verdict was all-reduced): no timings are taken beside a thread stuck in RCCL
+            invalid = str(e)
+            if rank == 0:
+                print(json.dumps({"metric": "het SNPs phased/sec", "value": None, "unit": "SNPs/s", "n_gpus": world, "valid": False,
+                                  "rccl": {"collective": "ncclBroadcast", "ranks": world, "hung": invalid}}), flush=True)
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(3)                       # the stuck helper thread would keep a normal exit waiting
 
     # ---- C contexts on this rank's GPU, each with one contig resident, phase their contigs CONCURRENTLY (one host thread per context; the library
     #      call releases the GIL).  A single stream of ~70 dependent launches per call leaves much of the chip idle - launch gaps, tails of small
@@ -275,12 +330,14 @@ def main():
             t0 = time.time()
             g = SynthGpu(dev, **kw)
             gen_s += time.time() - t0
-            V = g.variants()
-            if bcast is not None:
-                assert np.array_equal(bcast[spec["name"]][0], V.pos), "broadcast SNP table differs from the contig's own"
+            V = g.variants()                   # host copy: what the oracle is given (and the haplotag table is built from)
+            tdev = None
+            if bcast is not None:              # the rows THIS context phases come from the broadcast buffer on the GPU, not from V
+                tdev = bcast[spec["name"]]
+                assert tdev[3] == V.n, "broadcast SNP table: row count differs from the contig's own"
             ref = g.host("ref")
             t0 = time.time()
-            ctx.load_chromosome_device(V, ref, g.device_batch(), g.n_reads)
+            ctx.load_chromosome_device(V, ref, g.device_batch(), g.n_reads, table_dev=tdev[:3] if tdev else None)
             push_s += time.time() - t0
             host = None
             if spec["name"] in parity_set or (rank == 0 and spec["name"] == cpu_name):
@@ -316,10 +373,6 @@ def main():
             s["rec"] = dict(contig=spec["name"], group=[x["spec"]["name"] for x in slots], alignments=g.n_reads, snps=V.n, phased=n_ph, gbases=round(g.n_bases / 1e9, 2),
                             group_ms_per_step=dt / a.steps * 1e3, obs=tm["n_obs"], pairs=tm["n_pairs"], nodes=tm["n_nodes"], alg=tm["algorithmic_bytes"],
                             scan_segments=tm["n_scan_segments"], scan_replayed=tm["n_scan_replayed"], gen_ms=g.gen_ms)
-            if s["host"] is not None and spec["name"] in parity_set:
-                pool.submit(spec["name"], P, V, s["host"], out.phase_set.copy(), out.gt.copy())
-                if not (rank == 0 and spec["name"] == cpu_name):
-                    s["host"] = None                                       # (the P clock below still needs the copy of the contig it runs on)
         s = slots[0]
         if largest is None or s["spec"]["contig_len"] > largest[0]["contig_len"]:
             # the largest contig ALONE on the GPU: call time, the dominant kernel's duration (hipEvents on the library's stream around it, live) and the
@@ -356,6 +409,11 @@ def main():
         for s in slots:
             s["rec"].update(group_haplotag_ms_per_step=hdt / a.steps * 1e3, haplotag_kernel_ms=s["ctx"].timings()["stages"]["extract"], tagged=int((s["hout"].hp != 0).sum()))
             total_tagged += s["rec"]["tagged"]
+            if s["host"] is not None and s["spec"]["name"] in parity_set:      # oracle on host threads, outside every timed region: phase result + tags
+                ho = s["hout"]
+                pool.submit(s["spec"]["name"], P, s["V"], s["host"], s["out"].phase_set.copy(), s["out"].gt.copy(), hap=(s["VT"], ho.hp.copy(), ho.pq.copy(), ho.ps.copy()))
+                if not (rank == 0 and s["spec"]["name"] == cpu_name):
+                    s["host"] = None                                       # (the P clock below still needs the copy of the contig it runs on)
         # ---- P clock: decoded batch in pinned host memory -> results in host memory, H2D included (never `value`); alone on the GPU
         for s in slots:
             if rank == 0 and s["host"] is not None and s["spec"]["name"] == cpu_name:
@@ -392,7 +450,7 @@ def main():
     if pool is not None:
         t0 = time.time(); res = pool.results()
         log(f"[rank {rank}] oracle comparison of {len(res)} contigs done ({time.time()-t0:.1f}s after the GPU work)")
-        ok = all(r["identical"] for r in res) and len(res) > 0
+        ok = all(r["identical"] and r.get("haplotag_identical", True) for r in res) and len(res) > 0
         if cpu_name in [r["contig"] for r in res]:
             r = [r for r in res if r["contig"] == cpu_name][0]
             port = dict(value=r["n_phased"] / r["oracle_s"], unit="SNPs/s")
@@ -405,19 +463,26 @@ def main():
             n_checked = len(res)
         parity = dict(checked=ok, contigs_checked=n_checked, contigs_total=len(contigs), oracle_seconds_rank0=round(sum(r["oracle_s"] for r in res), 1),
                       mismatching=[r["contig"] for r in res if not r["identical"]],
-                      what="phase_set of every variant and gt of every phased variant of the step-0 result == oracle/lps_oracle on the same arrays (copied back from HBM)")
+                      haplotag_mismatching=[r["contig"] for r in res if not r.get("haplotag_identical", True)],
+                      haplotag_oracle_seconds_rank0=round(sum(r.get("haplotag_oracle_s", 0.0) for r in res), 1),
+                      what="phase: phase_set of every variant and gt of every phased variant == oracle/lps_oracle.phase on the same arrays (copied back from HBM); "
+                           "haplotag (secondary metric): hp, pq, ps of every alignment == lps_oracle.haplotag on the table the benched run produced")
 
     if rank == 0:
+        assert largest is not None, "rank 0 holds the largest contig (longest-processing-time-first deal)"
         spec, rec, stage_avg = largest
         stage_avg = dict(stage_avg); stage_avg["extract"] = rec["extract_ms"]          # the two events around the kernel only (hipEvents on the library's stream), contig alone on the GPU
         dom = max((k for k in stage_avg if k != "d2h"), key=lambda k: stage_avg[k])
         alg = rec["alg"]
         achieved = alg.get(dom, 0) / (stage_avg[dom] * 1e-3) / 1e9 if stage_avg[dom] > 0 else 0.0
-        traffic = None
+        traffic = None; traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{spec['name']}_{spec['coverage']:.0f}x", {}).get(dom)
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"{spec['name']}_{spec['coverage']:.0f}x", {}).get(dom)
+                if traffic is not None:
+                    traffic_source = f"profiles/traffic.json ({tj.get('_collected', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/collect.sh')}): a committed counter run of this workload, NOT measured by this invocation"
             except Exception:  # noqa: BLE001
                 traffic = None
         stages = {k: dict(ms=round(v, 4), alg_bytes=int(alg.get(k, 0)), gbs=round(alg.get(k, 0) / (v * 1e-3) / 1e9, 1) if v > 0 and alg.get(k, 0) else None) for k, v in stage_avg.items()}
@@ -432,7 +497,7 @@ def main():
                        "generation_s": round(gen_s, 2), "device_push_s": round(push_s, 2), "d2h_for_oracle_s": round(d2h_s, 2)},
             "parity_checked": bool(parity and parity["checked"]), "parity": parity,
             "roofline": {"bound": "hbm", "kernel": dom, "at": f"{spec['name']} {spec['coverage']:.0f}x ({rec['alignments']} alignments, {rec['snps']} SNPs, {rec['obs']} observations)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes": int(alg.get(dom, 0)), "kernel_ms": stage_avg[dom], "solo_call_ms": rec.get("solo_ms_per_step"),
                          "note": "dominant stage by time at the largest contig, measured with that contig ALONE on the GPU: durations from hipEvents on the library's stream (extract: the two events around the kernel, live; the others: pass with every stage event recorded)"},
             "stages_at_largest_contig": stages,
@@ -443,8 +508,8 @@ def main():
                           "reads_tagged_per_step": int(total_tagged), "config": "germline haplotag, same resident 50x alignments (BASELINE.json configs[2]), table = this run's phased SNPs"},
             "p_clock": p_clock,
         }
-        if bcast is not None:
-            res["rccl"] = bcast["_info"]
+        if rccl_info is not None:
+            res["rccl"] = rccl_info
         if not a.no_cpu_baseline and cpu_pick is not None:
             t0 = time.time()
             res["cpu_baseline"] = cpu_baseline(cpu_pick[0], cpu_pick[1], a.cpu_threads or min(16, ncpu), port, cpu_pick[2])
@@ -455,88 +520,113 @@ def main():
         print(json.dumps(res), flush=True)
     for cx in ctxs:
         cx.close()
+    if comm:
+        L.lps_comm_destroy(comm)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if _HUNG:                                      # a helper thread is still inside RCCL: do not wait for it at interpreter exit
-        sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+    if parity is not None and not parity["checked"]:
+        log(f"[rank {rank}] PARITY FAILED: {parity}")
+        sys.exit(4)                                # the JSON line above carries parity_checked false; the exit code says it too
 
 
-_HUNG = []     # collective steps that did not return in time (snp_table_broadcast)
+class Invalid(Exception):
+    """the run cannot publish a measurement (a collective hung on some rank): every rank prints what it knows and exits non-zero"""
 
 
 def snp_table_broadcast(L, dist, dev, rank, world, contigs):
-    """Rank 0 builds the packed SNP table of the whole genome (pos i32 | ref0 u8 | alt0 u8 per row, contig after contig) on its GPU; one
-    ncclBroadcast (RCCL, behind lps_comm_bcast_device) hands it to every other GPU.  Returns {contig: (pos, ref0, alt0)} + '_info'."""
+    """Rank 0 packs the SNP table of the whole genome (pos i32 | ref0 u8 | alt0 u8 per row, contig after contig); ONE ncclBroadcast (RCCL over xGMI,
+    behind lps_comm_bcast_to_device) puts it into a device buffer on every rank's GPU, where it STAYS: each contig's rows are handed to the library
+    as device pointers (lps_set_variants_device) - no copy back to the host.  Returns ({contig: (dev_pos, dev_ref0, dev_alt0)} or None, info, comm).
+
+    Every decision that only some ranks could take alone - a device without a bus id, a failed ncclGetUniqueId, a communicator that does not come up -
+    is taken TOGETHER: the ranks all-reduce an ok flag over the control plane (gloo) before the next step, so nobody waits in a collective its peers
+    skipped.  A step that HANGS (watchdog, 120 s) leaves a thread stuck inside RCCL on this GPU: nothing measured beside it is published - Invalid."""
     import numpy as np
     import torch
     from lps.synth_gpu import SynthGpu
     info = dict(collective="ncclBroadcast", ranks=world)
-    try:
-        # RCCL refuses two ranks on one GPU - and a refused ncclCommInitRank leaves the process without a usable HIP runtime - so the ranks first
-        # compare the PCI bus ids of their devices over the control plane; a rehearsal with fewer GPUs than ranks skips the collective
-        bus = C.create_string_buffer(64)
-        if L.lps_device_bus_id(dev, bus, 64) != 0:
-            raise RuntimeError("lps_device_bus_id failed")
-        ids = [None] * world
-        dist.all_gather_object(ids, bus.value.decode())
-        if len(set(ids)) != world:
-            log(f"[rank {rank}] ranks share a GPU ({ids}): no RCCL communicator; every rank derives its own contigs' table")
-            return None
-        uid = (C.c_uint8 * 128)()
-        if rank == 0:
-            assert L.lps_comm_unique_id(uid) == 0
-        t = torch.tensor(list(uid), dtype=torch.uint8); dist.broadcast(t, src=0)
-        uid = (C.c_uint8 * 128)(*t.tolist())
-        # the communicator comes up in a helper thread under a watchdog: a bootstrap that never completes (this path has only been rehearsed on
-        # one GPU) must cost the run two minutes and the collective, not the whole scaling measurement - the rank then derives its own table
+
+    def agree(ok):                          # 1 fine, 0 failed here, -1 hung here -> the worst over all ranks
+        t = torch.tensor([int(ok)], dtype=torch.int64); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t[0])
+
+    def guarded(what, fn):                  # run fn under the watchdog; -> (state, value)
         box = {}
-        th = threading.Thread(target=lambda: box.update(comm=L.lps_comm_create(dev, world, rank, uid)), daemon=True)
-        th.start(); th.join(120.0)
+        def run():
+            try:
+                box["v"] = fn()
+            except Exception as e:  # noqa: BLE001
+                box["e"] = e
+        th = threading.Thread(target=run, daemon=True); th.start(); th.join(120.0)
         if th.is_alive():
-            _HUNG.append("lps_comm_create")
-            log(f"[rank {rank}] RCCL communicator not up after 120 s; every rank derives its own contigs' table instead")
-            return None
-        comm = box.get("comm")
-        if not comm:
-            raise RuntimeError("lps_comm_create failed")
-        counts = torch.zeros(len(contigs), dtype=torch.int64)
+            log(f"[rank {rank}] {what} not done after 120 s")
+            return -1, None
+        if "e" in box:
+            log(f"[rank {rank}] {what} failed: {box['e']!r}")
+            return 0, None
+        return 1, box["v"]
+
+    def settle(step, state):
+        worst = agree(state)
+        if worst < 0:
+            info.update(hung=step); raise Invalid(step)
+        if worst == 0:
+            info.update(skipped=f"{step} failed on some rank: every rank derives its own contigs' table")
+        return worst == 1
+
+    # RCCL refuses two ranks on one GPU - and a refused ncclCommInitRank leaves the process without a usable HIP runtime - so the ranks first compare
+    # the PCI bus ids of their devices; a rehearsal with fewer GPUs than ranks has no communicator
+    bus = C.create_string_buffer(64)
+    my_id = bus.value.decode() if L.lps_device_bus_id(dev, bus, 64) == 0 else None
+    ids = [None] * world
+    dist.all_gather_object(ids, my_id)
+    if any(i is None for i in ids):
+        info.update(skipped="lps_device_bus_id failed on some rank"); return None, info, None
+    if len(set(ids)) != world:
+        log(f"[rank {rank}] ranks share a GPU ({ids}): no RCCL communicator; every rank derives its own contigs' table")
+        info.update(skipped=f"{world} ranks on {len(set(ids))} GPU(s): RCCL refuses ranks that share a device"); return None, info, None
+    uid = (C.c_uint8 * 128)()
+    ok = L.lps_comm_unique_id(uid) == 0 if rank == 0 else True
+    if not settle("ncclGetUniqueId", 1 if ok else 0):
+        return None, info, None
+    t = torch.tensor(list(uid), dtype=torch.uint8); dist.broadcast(t, src=0)
+    uid = (C.c_uint8 * 128)(*t.tolist())
+    state, comm = guarded("lps_comm_create", lambda: L.lps_comm_create(dev, world, rank, uid))
+    if state == 1 and not comm:
+        log(f"[rank {rank}] lps_comm_create: {L.lps_comm_last_error().decode()}"); state = 0
+    if not settle("ncclCommInitRank", state):
+        if comm:
+            L.lps_comm_destroy(comm)
+        return None, info, None
+    counts = torch.zeros(len(contigs), dtype=torch.int64)
+    buf = None
+    if rank == 0:
         parts = []
-        if rank == 0:
-            for i, spec in enumerate(contigs):
-                kw = {k: v for k, v in spec.items() if k != "name"}; kw["coverage"] = 0.0          # reference + variants only
-                g = SynthGpu(dev, **kw)
-                parts.append((g.host("var_pos"), g.host("var_ref0"), g.host("var_alt0"))); counts[i] = g.n_variants
-                g.close()
-        dist.broadcast(counts, src=0)
-        n = int(counts.sum())
-        buf = np.zeros(n * 6, dtype=np.uint8)
-        if rank == 0:
-            buf[:4 * n] = np.concatenate([p[0] for p in parts]).view(np.uint8)
-            buf[4 * n:5 * n] = np.concatenate([p[1] for p in parts]); buf[5 * n:] = np.concatenate([p[2] for p in parts])
-        t0 = time.perf_counter()
-        ms = C.c_double(0)
-        th = threading.Thread(target=lambda: box.update(rc=L.lps_comm_bcast(comm, buf.ctypes.data, buf.size, 0, C.byref(ms))), daemon=True)
-        th.start(); th.join(120.0)
-        if th.is_alive():
-            _HUNG.append("lps_comm_bcast")
-            log(f"[rank {rank}] ncclBroadcast not done after 120 s; every rank derives its own contigs' table instead")
-            return None
-        rc = box.get("rc", -1)
-        if rc != 0:
-            raise RuntimeError(f"lps_comm_bcast rc={rc}")
-        info.update(bytes=int(buf.size), wall_ms=round((time.perf_counter() - t0) * 1e3, 2), device_ms=round(ms.value, 3), n_ranks_in_communicator=int(L.lps_comm_size(comm)))
-        L.lps_comm_destroy(comm)
-        out = {}; o = 0
-        pos = buf[:4 * n].view(np.int32)
         for i, spec in enumerate(contigs):
-            k = int(counts[i]); out[spec["name"]] = (pos[o:o + k].copy(), buf[4 * n + o:4 * n + o + k].copy(), buf[5 * n + o:5 * n + o + k].copy()); o += k
-        out["_info"] = info
-        return out
-    except Exception as e:  # noqa: BLE001
-        log(f"[rank {rank}] RCCL broadcast of the SNP table failed ({e!r}); every rank derives its own contigs' table instead")
-        return None
+            kw = {k: v for k, v in spec.items() if k != "name"}; kw["coverage"] = 0.0          # reference + variants only
+            g = SynthGpu(dev, **kw)
+            parts.append((g.host("var_pos"), g.host("var_ref0"), g.host("var_alt0"))); counts[i] = g.n_variants
+            g.close()
+    dist.broadcast(counts, src=0)
+    n = int(counts.sum())
+    if rank == 0:
+        buf = np.zeros(n * 6, dtype=np.uint8)
+        buf[:4 * n] = np.concatenate([p[0] for p in parts]).view(np.uint8)
+        buf[4 * n:5 * n] = np.concatenate([p[1] for p in parts]); buf[5 * n:] = np.concatenate([p[2] for p in parts])
+    ms = C.c_double(0); dptr = C.c_void_p(0)
+    t0 = time.perf_counter()
+    state, rc = guarded("lps_comm_bcast_to_device", lambda: L.lps_comm_bcast_to_device(comm, buf.ctypes.data if rank == 0 else None, 6 * n, 0, C.byref(dptr), C.byref(ms)))
+    if state == 1 and rc != 0:
+        log(f"[rank {rank}] lps_comm_bcast_to_device rc={rc}: {L.lps_comm_last_error().decode()}"); state = 0
+    if not settle("ncclBroadcast", state):
+        return None, info, comm
+    info.update(bytes=6 * n, wall_ms=round((time.perf_counter() - t0) * 1e3, 2), device_ms=round(ms.value, 3), n_ranks_in_communicator=int(L.lps_comm_size(comm)),
+                consumed="every rank loads its contigs' rows from the broadcast buffer on its GPU (lps_set_variants_device)")
+    out = {}; o = 0; base = int(dptr.value)
+    for i, spec in enumerate(contigs):
+        k = int(counts[i]); out[spec["name"]] = (base + 4 * o, base + 4 * n + o, base + 5 * n + o, k); o += k
+    return out, info, comm
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 14
+#define LPS_ABI_VERSION 15
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -259,6 +259,11 @@ const char *lps_last_error(lps_ctx *ctx);
 int lps_begin_chromosome(lps_ctx *ctx);
 /* getVariants_markindel + getLastSNP (src/phase/ParsingBam.cpp:378-417,426-441). */
 int lps_set_variants(lps_ctx *ctx, const lps_variant_table *table);
+/* lps_set_variants for a table that is already on the ctx's GPU: pos / ref0 / alt0 (and ref_len / alt_len, NULL = every row is a SNP) are
+ * DEVICE pointers, the haplotag / somatic columns must be NULL.  The rows are copied device-to-device (the caller's buffer may go away when the
+ * call returns); order and range of the positions are checked by a kernel.  With lps_comm_bcast_to_device the table of a multi-GPU run travels
+ * ncclBroadcast -> context with no host hop (reference analogue: one parsed SnpParser shared by the chromosome loop, PhasingProcess.cpp:113-173). */
+int lps_set_variants_device(lps_ctx *ctx, const lps_variant_table *table);
 /* SV / MOD rows of the chromosome (phase only).  Call after lps_set_variants; NULL or an empty table = none.  The tables are copied. */
 int lps_set_extra_variants(lps_ctx *ctx, const lps_extra_variants *extra);
 /* Results of the SV / MOD rows of the last lps_phase_chromosome (sv->n = n_sv, mod->n = n_mod; either may be NULL). */
@@ -373,6 +378,9 @@ int lps_comm_rank(lps_comm *comm);
 void lps_comm_destroy(lps_comm *comm);
 int lps_comm_bcast(lps_comm *comm, void *host_buf, int64_t n_bytes, int root, double *ms);
 int lps_comm_bcast_device(lps_comm *comm, void *dev_buf, int64_t n_bytes, int root, double *ms);
+/* root's `host_src` (ignored elsewhere) -> a device buffer owned by the communicator on EVERY rank; *dev_out points at it until the next
+ * broadcast on this communicator or lps_comm_destroy.  ms = -1 when the timing events failed. */
+int lps_comm_bcast_to_device(lps_comm *comm, const void *host_src, int64_t n_bytes, int root, void **dev_out, double *ms);
 const char *lps_comm_last_error(void);
 
 /* ---- stage dumps for parity tests (valid after lps_phase_chromosome; host buffers, caller-allocated) ---- */

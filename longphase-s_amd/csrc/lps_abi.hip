@@ -34,7 +34,7 @@ struct lps_ctx {
     std::string err;
     // variants
     int nV = 0; int last_pos = -1; long long ref_len = 0, ref_len_eff = 0;
-    std::vector<int32_t> h_vpos;
+    std::vector<int32_t> h_vpos; bool vpos_on_device_only = false;   // lps_set_variants_device: the host copy is fetched when something asks for it
     DevBuf<int32_t> v_pos; DevBuf<uint8_t> v_ref0, v_alt0, v_danger, v_hpoly, v_erased, v_hp1; DevBuf<uint16_t> v_rl, v_al;
     DevBuf<int32_t> v_ps, v_bucket; DevBuf<uint2> v_rec; bool has_hap = false;
     DevBuf<char> ref;
@@ -60,7 +60,7 @@ struct lps_ctx {
     DevBuf<uint64_t> rcand; uint64_t n_rec_all = 0; DevBuf<int32_t> r_tid_all; DevBuf<uint32_t> r_lname, r_nameoff, wg_cnt, wg_off, scan_nout; DevBuf<uint8_t> names_d; bool names_ready = false;
     // observations
     DevBuf<RowDesc> rows; DevBuf<int32_t> g_cnt; DevBuf<uint8_t> deleted;
-    DevBuf<ObsRec> obs; DevBuf<int32_t> g_node; DevBuf<uint8_t> g_flag; DevBuf<uint32_t> g_pack, t_src; DevBuf<uint16_t> g_rank; DevBuf<uint32_t> redo_list; DevBuf<uint2> hit_ovf; unsigned ovf_chunks = 0;
+    DevBuf<ObsRec> obs; DevBuf<int32_t> g_node; DevBuf<uint8_t> g_flag; DevBuf<uint32_t> g_pack, t_src; DevBuf<uint16_t> g_rank; DevBuf<uint32_t> redo_list;
     unsigned long long obs_capacity = 0;   // main arenas (LPS_ARENAS equal parts); a tail arena of obs_capacity/4 follows
     DevBuf<unsigned long long> arena_ctr;
     bool in_phase = false; int timing_level = 1;
@@ -99,6 +99,7 @@ struct lps_ctx {
     int m_bits = 0, a_bits = 16, n_bits = 0;
 };
 
+#define LPS_MAX_ROWS 0x3fffff   /* rows of the table the graph runs on (SNP + SV + MOD): the packed observation word keeps the row in 22 bits */
 static int fail(lps_ctx *c, const std::string &m, int code = -1) { if (c) c->err = m; return code; }
 
 // Large upload from pageable memory (an mmap of the BAM file): the runtime's own path stages through ONE host thread's memcpy; here four threads fill a
@@ -220,7 +221,7 @@ void *lps_stream(lps_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int lps_begin_chromosome(lps_ctx *c) {
     if (!c) return -1;
     c->nV = 0; c->last_pos = -1; c->ref_len = c->ref_len_eff = 0; c->nR = 0; c->n_cig = c->n_seq = c->n_qual = 0; c->n_blob = 0; c->read_mode = 0; c->cur_first = -1; c->cur_count = 0;
-    c->phase_valid = false; c->has_hap = false; c->h_vpos.clear(); c->name_max = 0;
+    c->phase_valid = false; c->has_hap = false; c->h_vpos.clear(); c->vpos_on_device_only = false; c->name_max = 0;
     c->nX = c->nSV = c->nMOD = 0; c->h_snp_u.clear(); c->h_sv_u.clear(); c->h_mod_u.clear(); c->votes_h1.clear(); c->votes_h2.clear();
     return 0;
 }
@@ -229,10 +230,10 @@ int lps_set_variants(lps_ctx *c, const lps_variant_table *t) {
     if (!c || !t) return -1;
     try {
         HIP_TRY(hipSetDevice(c->device));
-        if (t->n > 0x3fffff) return fail(c, "variant table larger than 2^22 rows per chromosome");
+        if (t->n > LPS_MAX_ROWS) return fail(c, "variant table larger than 2^22 rows per chromosome");
         for (int64_t i = 1; i < t->n; ++i) if (t->pos[i] <= t->pos[i - 1]) return fail(c, "variant positions must be strictly increasing");
         c->nV = (int)t->n; c->last_pos = t->n ? t->pos[t->n - 1] : -1;
-        c->h_vpos.assign(t->pos, t->pos + t->n);
+        c->h_vpos.assign(t->pos, t->pos + t->n); c->vpos_on_device_only = false;
         upload(c, c->v_pos, t->pos, t->n); upload(c, c->v_ref0, t->ref0, t->n); upload(c, c->v_alt0, t->alt0, t->n);
         upload(c, c->v_rl, t->ref_len, t->n); upload(c, c->v_al, t->alt_len, t->n);
         c->v_danger.reserve(t->n + 1); c->v_hpoly.reserve(t->n + 1); c->v_erased.reserve(t->n + 1);
@@ -249,6 +250,50 @@ int lps_set_variants(lps_ctx *c, const lps_variant_table *t) {
     return 0;
 }
 
+// lps_set_variants for a table that is already on the ctx's GPU (e.g. the communicator's buffer after lps_comm_bcast_to_device: the table goes
+// ncclBroadcast -> context without touching the host).  flags[0] bit0: positions not strictly increasing
+__global__ void k_table_check(long long n, const int32_t *pos, unsigned *flags) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if ((i && pos[i] <= pos[i - 1]) || pos[i] < 0) atomicOr(&flags[0], 1u);
+}
+__global__ void k_fill_u16(long long n, uint16_t v, uint16_t *out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+int lps_set_variants_device(lps_ctx *c, const lps_variant_table *t) {
+    if (!c || !t) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        if (t->n > LPS_MAX_ROWS) return fail(c, "variant table larger than 2^22 rows per chromosome");
+        if (t->hp1_is_alt || t->phase_set || t->somatic_role || t->derive_hp || t->tumor_kind) return fail(c, "lps_set_variants_device takes the phase columns only (pos, ref0, alt0, ref_len, alt_len)");
+        if (t->n && (!t->pos || !t->ref0 || !t->alt0)) return fail(c, "lps_set_variants_device: pos / ref0 / alt0 missing");
+        hipStream_t s = c->stream; const size_t n = (size_t)t->n;
+        c->bam_err.reserve(2);
+        HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s));
+        int32_t last = -1; unsigned flags = 0;
+        if (n) {
+            hipLaunchKernelGGL(k_table_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (long long)n, t->pos, c->bam_err.p);
+            HIP_TRY(hipMemcpyAsync(&last, t->pos + n - 1, sizeof last, hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipMemcpyAsync(&flags, c->bam_err.p, sizeof flags, hipMemcpyDeviceToHost, s));
+        auto d2d = [&](auto &buf, const auto *src) { buf.reserve(n + 1); if (n) HIP_TRY(hipMemcpyAsync(buf.p, src, n * sizeof(*src), hipMemcpyDeviceToDevice, s)); };
+        d2d(c->v_pos, t->pos); d2d(c->v_ref0, t->ref0); d2d(c->v_alt0, t->alt0);
+        c->v_rl.reserve(n + 1); c->v_al.reserve(n + 1);
+        const dim3 g((unsigned)((n + 255) / 256)), b(256);
+        if (t->ref_len) d2d(c->v_rl, t->ref_len); else if (n) hipLaunchKernelGGL(k_fill_u16, g, b, 0, s, (long long)n, (uint16_t)1, c->v_rl.p);   // NULL: every row is a SNP
+        if (t->alt_len) d2d(c->v_al, t->alt_len); else if (n) hipLaunchKernelGGL(k_fill_u16, g, b, 0, s, (long long)n, (uint16_t)1, c->v_al.p);
+        c->v_danger.reserve(n + 1); c->v_hpoly.reserve(n + 1); c->v_erased.reserve(n + 1);
+        HIP_TRY(hipStreamSynchronize(s));
+        if (flags & 1u) { c->nV = 0; return fail(c, "variant positions must be strictly increasing"); }
+        c->nV = (int)n; c->last_pos = last; c->h_vpos.clear(); c->vpos_on_device_only = n != 0;
+        c->has_hap = c->has_somatic = c->has_tkind = false;
+        c->phase_valid = false;
+        c->nX = c->nSV = c->nMOD = 0; c->h_snp_u.clear(); c->h_sv_u.clear(); c->h_mod_u.clear();
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
 // SV_map / currentMod of BamParser (src/phase/ParsingBam.cpp:1207-1235) as one position-sorted list next to the SNP table
 int lps_set_extra_variants(lps_ctx *c, const lps_extra_variants *x) {
     if (!c) return -1;
@@ -257,8 +302,9 @@ int lps_set_extra_variants(lps_ctx *c, const lps_extra_variants *x) {
         c->nX = c->nSV = c->nMOD = 0; c->h_snp_u.clear(); c->h_sv_u.clear(); c->h_mod_u.clear(); c->phase_valid = false;
         if (!x || (x->n_sv <= 0 && x->n_mod <= 0)) return 0;
         if (c->nV == 0) return fail(c, "lps_set_variants must be called before lps_set_extra_variants");
+        if (c->vpos_on_device_only) { c->h_vpos = download(c, c->v_pos.p, (size_t)c->nV); c->vpos_on_device_only = false; }   // the merge below runs on the host
         const int64_t nS = std::max<int64_t>(x->n_sv, 0), nM = std::max<int64_t>(x->n_mod, 0);
-        if ((int64_t)c->nV + nS + nM > 0x3fffff) return fail(c, "SNP + SV + MOD rows exceed 2^22 per chromosome");
+        if ((int64_t)c->nV + nS + nM > LPS_MAX_ROWS) return fail(c, "SNP + SV + MOD rows exceed 2^22 per chromosome");
         if (x->sv_window < 0 || !(x->sv_threshold >= 0 && x->sv_threshold <= 1)) return fail(c, "invalid svWindow / svThreshold");     // Phasing.cpp:304-318
         for (int64_t i = 1; i < nS; ++i) if (x->sv_pos[i] <= x->sv_pos[i - 1]) return fail(c, "SV positions must be strictly increasing");
         for (int64_t i = 1; i < nM; ++i) if (x->mod_pos[i] <= x->mod_pos[i - 1]) return fail(c, "MOD positions must be strictly increasing");
@@ -866,8 +912,6 @@ static int run_phase(lps_ctx *c) {
         const unsigned long long cap = cap_main + tail_size;
         if (cap > 0xffffffffull) { c->err = "observation arena exceeds 2^32 slots"; return -8; }
         c->rows.reserve(nR + 4); c->redo_list.reserve((size_t)nR / 4 + 4);
-        c->ovf_chunks = (unsigned)((size_t)nR / 4 / 8 + 256);              // chunks of the global hit list: an eighth of the waves may take one
-        c->hit_ovf.reserve((size_t)c->ovf_chunks * LPS_EXT_OVF_HITS);
         c->g_cnt.reserve(nR + 1);
         c->obs.reserve(cap); c->g_node.reserve(cap); c->g_flag.reserve(cap); c->g_pack.reserve(cap); c->g_rank.reserve(cap); c->t_src.reserve(tail_size + 64);
         c->clip_capacity = (size_t)4 * nR + 64;                             // clip events (an alignment has two real clips at most; more only with H S ... S H)
@@ -909,9 +953,9 @@ static int run_phase(lps_ctx *c) {
         launch_variant_prep(V, P.is_ont, c->v_bucket.p, c->v_rec.p, s);
         // ---- a1/a2/a3 extraction
         ObsView O{c->rows.p, c->obs.p, arena_size, c->arena_ctr.p, n_arenas};
-        ClipView C{c->clip_ev.p, c->clip_stats.p, (unsigned)c->clip_capacity};            // clip_stats[0]: events appended, [1]: waves queued for k_extract_redo, [3]: chunks of the global hit list taken (zero pool)
+        ClipView C{c->clip_ev.p, c->clip_stats.p, (unsigned)c->clip_capacity};            // clip_stats[0]: events appended, [1]: jobs queued for k_extract_redo (zero pool)
         mark(c, ST_EXTRACT);
-        launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, c->redo_list.p, c->clip_stats.p + 1, c->hit_ovf.p, c->clip_stats.p + 3, c->ovf_chunks, s);
+        launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, c->redo_list.p, c->clip_stats.p + 1, s);
         // ---- SV / MOD rows: served against each alignment's CIGAR, merged into its row; every observation leaves in union indices
         if (c->nX) {
             ExtraView X{c->nX, c->x_pos.p, c->x_info.p, c->x_kind.p, c->x_u.p, c->x_snp_u.p, c->x_moff.p, c->x_mname.p, c->x_mflag.p, c->sv_window, c->sv_threshold};

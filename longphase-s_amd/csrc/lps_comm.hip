@@ -53,7 +53,11 @@ int lps_comm_unique_id(uint8_t id[128]) {
 }
 
 static lps_comm *comm_finish(lps_comm *c) {
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_comm_err = "hipStreamCreate failed"; delete c; return nullptr; }
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        g_comm_err = "hipStreamCreate failed";
+        if (c->comm) (void)rccl().CommDestroy(c->comm);
+        delete c; return nullptr;
+    }
     return c;
 }
 
@@ -76,10 +80,15 @@ int lps_comm_create_all(int n_devices, const int *devices, lps_comm **out) {
     ncclComm_t comms[64];
     const ncclResult_t rc = R.CommInitAll(comms, n_devices, devices);
     if (rc != ncclSuccess) { g_comm_err = std::string("ncclCommInitAll: ") + R.GetErrorString(rc); return -1; }
+    for (int i = 0; i < n_devices; ++i) out[i] = nullptr;
     for (int i = 0; i < n_devices; ++i) {
         lps_comm *c = new lps_comm(); c->comm = comms[i]; c->device = devices[i]; c->rank = i; c->n_ranks = n_devices;
         out[i] = comm_finish(c);
-        if (!out[i]) return -1;
+        if (!out[i]) {                                                   // nothing half-built stays behind: the communicators made so far and the handles not yet wrapped
+            for (int k = 0; k < i; ++k) { lps_comm_destroy(out[k]); out[k] = nullptr; }
+            for (int k = i + 1; k < n_devices; ++k) (void)R.CommDestroy(comms[k]);
+            return -1;
+        }
     }
     return 0;
 }
@@ -106,14 +115,32 @@ int lps_comm_bcast_device(lps_comm *c, void *dev_buf, int64_t n_bytes, int root,
     if (!c || n_bytes < 0 || (n_bytes && !dev_buf) || root < 0 || root >= c->n_ranks) { g_comm_err = "lps_comm_bcast_device: bad arguments"; return -1; }
     Rccl &R = rccl();
     if (hipSetDevice(c->device) != hipSuccess) { g_comm_err = "hipSetDevice failed"; return -1; }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ms) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, c->stream); }
+    hipEvent_t e0 = nullptr, e1 = nullptr; bool timed = ms != nullptr;
+    if (timed) timed = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventRecord(e0, c->stream) == hipSuccess;
     const ncclResult_t rc = R.Broadcast(dev_buf, dev_buf, (size_t)n_bytes, ncclUint8, root, c->comm, c->stream);
-    if (ms) (void)hipEventRecord(e1, c->stream);
+    if (timed) timed = hipEventRecord(e1, c->stream) == hipSuccess;
     const hipError_t he = hipStreamSynchronize(c->stream);
-    if (ms) { float f = 0; (void)hipEventElapsedTime(&f, e0, e1); *ms = f; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+    if (ms) { float f = -1.f; if (!timed || hipEventElapsedTime(&f, e0, e1) != hipSuccess) f = -1.f; *ms = f; }   // -1: the events failed, not a measurement
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     if (rc != ncclSuccess) { g_comm_err = std::string("ncclBroadcast: ") + R.GetErrorString(rc); return -2; }
     if (he != hipSuccess) { g_comm_err = std::string("ncclBroadcast stream: ") + hipGetErrorString(he); return -2; }
+    return 0;
+}
+
+// The table stays where the collective put it: root uploads `host_src` into the communicator's device buffer, ncclBroadcast fills the same buffer
+// on the other ranks, and *dev_out is that buffer on every rank (valid until the next broadcast on this communicator or lps_comm_destroy) -
+// what lps_set_variants_device takes.  No copy back to the host anywhere.
+int lps_comm_bcast_to_device(lps_comm *c, const void *host_src, int64_t n_bytes, int root, void **dev_out, double *ms) {
+    if (!c || n_bytes < 0 || !dev_out || root < 0 || root >= c->n_ranks || (c->rank == root && n_bytes && !host_src)) { g_comm_err = "lps_comm_bcast_to_device: bad arguments"; return -1; }
+    *dev_out = nullptr;
+    if (n_bytes == 0) return 0;
+    if (hipSetDevice(c->device) != hipSuccess) { g_comm_err = "hipSetDevice failed"; return -1; }
+    if ((size_t)n_bytes > c->cap) { if (c->buf) (void)hipFree(c->buf); c->buf = nullptr; c->cap = 0; if (hipMalloc((void **)&c->buf, (size_t)n_bytes + 256) != hipSuccess) { g_comm_err = "lps_comm_bcast_to_device: device allocation failed"; return -1; } c->cap = (size_t)n_bytes; }
+    if (c->rank == root && hipMemcpy(c->buf, host_src, (size_t)n_bytes, hipMemcpyHostToDevice) != hipSuccess) { g_comm_err = "lps_comm_bcast_to_device: H2D failed"; return -1; }
+    const int rc = lps_comm_bcast_device(c, c->buf, n_bytes, root, ms);
+    if (rc) return rc;
+    *dev_out = c->buf;
     return 0;
 }
 

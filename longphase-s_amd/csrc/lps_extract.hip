@@ -88,9 +88,10 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 }
 
 // ------------------------------------------------------------------------------------------------ extraction
-#define EXT_RPW 4       // alignments per wave
-#define EXT_CAP 384     // hits buffered per wave in LDS (8 bytes each): with 4 workgroups per CU the 160 KB of LDS hold 40 KB each
-#define EXT_OVF 2048    // ... and in one chunk of global memory a wave takes when the LDS list is full (four reads of 200 kb hold ~1 000 hits)
+#define EXT_RPW 4       // alignments per wave (a "job"; the later per-row kernels walk the four rows of a job as one span)
+#ifndef EXT_TAB
+#define EXT_TAB 1536    // lane-chunks (8 CIGAR ops each) a wave keeps in LDS: 12 KB, i.e. 12 288 ops = ~300 kb of ONT read for the four alignments together
+#endif
 #define EXT_CLIPS 16    // clip events buffered per wave
 
 // first variant with pos >= key, searched by ONE lane (the planning step runs four of these side by side); == var_lower_bound
@@ -103,43 +104,63 @@ __device__ __forceinline__ int lane_var_lower_bound(const VarView &V, int key) {
     return lo;
 }
 
-// hit word 0: bits 0-21 variant index, 22 finished call (else: gather base and quality at query index = word 1), 23 allele of a finished call,
-//             24 quality sentinel -5 (else -4) of a finished call, 25 erased by filterSNP
-#define HIT_FINAL (1u << 22)
-#define HIT_ALLELE (1u << 23)
-#define HIT_Q5 (1u << 24)
-#define HIT_ERASED (1u << 25)
+// what a candidate lane needs to know about its alignment: three 16-byte LDS reads
+struct __attribute__((aligned(16))) ExtHdr {
+    int crel, ncig, c0, nch;               // first CIGAR word (relative to the job's first), CIGAR words, first chunk in the table, chunks it touches
+    int vadj, lq, ds, dq;                  // variant of flattened candidate i = vadj + i; l_qseq; stream - true reference coordinate; stream query coordinate of the read's first base
+    unsigned so_lo, so_hi, qo_lo, qo_hi;   // byte offsets of SEQ / QUAL
+};
 
-// waves per workgroup of k_extract_phase.  The waves of a workgroup share nothing; one wave per workgroup gives its 9.6 KB of LDS back the moment
-// that wave is done instead of when the slowest of four is (alignments differ tenfold in length)
-#ifndef EXT_WPB
-#define EXT_WPB 1
-#endif
-__global__ __launch_bounds__(64 * EXT_WPB, 4) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
-                                                       LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint2 *ovf, unsigned *ovf_ctr, unsigned ovf_chunks) {
-    __shared__ __attribute__((aligned(16))) int s_ref[EXT_WPB][LPS_SEG];
-    __shared__ __attribute__((aligned(16))) int s_qry[EXT_WPB][LPS_SEG];
-    __shared__ __attribute__((aligned(16))) uint32_t s_cig[EXT_WPB][LPS_SEG + 4];
-    __shared__ __attribute__((aligned(16))) uint2 s_hit[EXT_WPB][EXT_CAP];
-    __shared__ ClipEv s_clip[EXT_WPB][EXT_CLIPS];
-    enum { H_START, H_LQ, H_REL, H_V0, H_SOFF, H_QOFF = H_SOFF + 2, H_HIT0 = H_QOFF + 2, H_FAIL, H_WORDS };
-    __shared__ int s_hdr[EXT_WPB][EXT_RPW + 1][H_WORDS];
-    const int w = threadIdx.x >> 6, l = lane_id();
-    int *sref = s_ref[w], *sqry = s_qry[w]; uint32_t *scig = s_cig[w];
-    uint2 *hit = s_hit[w]; ClipEv *clipb = s_clip[w];
-    int *hdr = s_hdr[w][0];
+// the c-th of four wave-uniform scalars, c = index of the first flattened candidate of alignments 1..3 (per-lane compare against thresholds)
+#define SELC(c, t, a) ((c) >= (t)[3] ? (a)[3] : ((c) >= (t)[2] ? (a)[2] : ((c) >= (t)[1] ? (a)[1] : (a)[0])))
+#define SEL4(q, a) ((q) >= 3 ? (a)[3] : ((q) >= 2 ? (a)[2] : ((q) >= 1 ? (a)[1] : (a)[0])))
+// reference / query bases consumed by the first k (wave-uniform, 0..8) of a lane's 8 words
+__device__ __forceinline__ void advance_of(const uint32_t (&w)[8], int k, int &sr, int &sq) {
+    sr = 0; sq = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const unsigned t = op_consume_bits(w[m] & 15u); const int len = (m < k) ? (int)(w[m] >> 4) : 0;
+        sr += len & bit_mask(t, 0); sq += len & bit_mask(t, 16);
+    }
+}
+
+// One wavefront = one job of four consecutive alignments, whose CIGARs lie back to back in memory.
+//   * WALK.  The CIGAR words of the job are ONE stream, taken 512 words per round, 8 consecutive words per lane, every lane busy whatever the
+//     alignments' lengths.  A lane sums the reference / query advance of its 8 words and one pair of DPP scans over the wave turns the sums into
+//     STREAM coordinates: reference and query bases consumed since the job's first word, running on across alignment boundaries.  That pair, 8 bytes
+//     per lane-chunk, is all that goes to LDS - no per-op prefixes, no per-alignment bookkeeping per lane, no barrier inside the loop; the words of
+//     the next round are requested before the current round is summed.  What an alignment needs is three scalars taken where its first and last
+//     word pass by: the stream coordinates of its first op (a variant at reference position p then sits at stream position p - start + that) and
+//     the reference position it ends at.
+//   * CANDIDATES.  With the job's chunks in the table, the candidate variants of the four alignments (position-sorted slices of the variant
+//     table: [first variant at or after the alignment's start, first variant at or beyond its reference end)) are counted, ONE atomicAdd reserves
+//     that many observation slots, and the candidates are taken 64 at a time as one flattened list, every lane busy: binary search of the
+//     alignment's chunks for the last chunk that starts at or before the variant, the chunk's 8 words (+ the one after) re-read from memory
+//     (they went through L2 a moment ago), an 8-step walk in registers to the op that covers the variant, the reference's rules for that op
+//     (ParsingBam.cpp:1445-1607), base and quality gathered right there, allele called, filterSNP's erasures applied, and the record written to
+//     its final, compacted place.  seq / qual are touched at variant sites only.
+// A job whose chunks do not fit the table (EXT_TAB), which holds more clip events than EXT_CLIPS, or in which get_snp's early return fires
+// (:1453-1455, :1559-1561: a record whose SEQ is shorter than its CIGAR) queues itself for k_extract_redo, the general walker, before it has
+// written anything a later stage looks at.
+__global__ __launch_bounds__(64) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
+                                                      LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo) {
+    __shared__ __attribute__((aligned(16))) int2 s_tab[EXT_TAB];
+    __shared__ ExtHdr s_hdr[EXT_RPW];
+    __shared__ ClipEv s_clip[EXT_CLIPS];
+    const int l = lane_id();
     // Output rows are reserved on one of LPS_ARENAS counters (own cache line each).  Workgroups are dealt round-robin over the 8 XCDs, so
     // arena = blockIdx % 64 keeps each counter inside ONE XCD's L2.
     const int arena = blockIdx.x % O.n_arenas;
     const unsigned long long arena_lo = (unsigned long long)arena * O.arena_size;
-    const int job = blockIdx.x * EXT_WPB + w;
+    const int job = blockIdx.x;
     const int r0 = job * EXT_RPW;
     if (r0 >= R.n) return;
     const int nq = min(EXT_RPW, R.n - r0);
-    static_assert(EXT_RPW == 4 && LPS_SEG == 512, "lane layout of the planning step");
+    static_assert(EXT_RPW == 4, "lane layout of the planning step");
+    auto to_redo = [&]() __attribute__((always_inline)) { if (l == 0) redo_list[atomicAdd(n_redo, 1u)] = (uint32_t)job; };
 
     // ---- plan: headers, alignment q in lane q.  direct_detect_alleles filters (:1282-1291) + region "chr:1-<lastSNPPos>" (:1273)
-    int h_start = 0, h_lq = 0, h_rel = 0; bool h_live = false; unsigned long long h_coff = 0, h_soff = 0, h_qoff = 0;
+    int h_start = 0, h_lq = 0; bool h_live = false; unsigned long long h_coff = 0, h_soff = 0, h_qoff = 0;
     if (l <= nq) h_coff = R.cigar_off[r0 + l];
     if (l < nq) {
         const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r]; h_qoff = R.qual_off[r];
@@ -147,289 +168,291 @@ __global__ __launch_bounds__(64 * EXT_WPB, 4) void k_extract_phase(VarView V, Re
         h_live = !(R.mapq[r] < mapping_quality || (flag & 0x4) || (flag & 0x100) || (flag & 0x400) || h_start >= V.last_pos);
     }
     const unsigned live_mask = (unsigned)__ballot(h_live) & 15u;
-    const unsigned long long c_lo = __shfl(h_coff, 0);
-    if (l <= nq) h_rel = (int)(h_coff - c_lo);                         // op index of alignment q's first op inside the wave's CIGAR range
-    const uint32_t *cg = R.cigar + c_lo;
-
-    // what was requested ahead for segment (pf_q, pf_seg): CIGAR words, op after the segment, candidate records, predecessor position
-    uint32_t pw[8]; uint32_t pnext = 0xfu; uint2 pvr = make_uint2(0x7fffffffu, 0u); int ppv = -1;
-    int pf_q = -1, pf_seg = 0; bool pf_vr_ok = false;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) pw[u] = 6u;
-    int q = live_mask ? __builtin_ctz(live_mask) : nq;
-    if (q < nq) {                                                      // first segment of the first alignment: on its way while the bounds are searched
-        const int crel = __shfl(h_rel, q), ncq = __shfl(h_rel, q + 1) - crel;
-        if (ncq > 0) {
-            const int nsegn = min(LPS_SEG, ncq);
-            pnext = (nsegn < ncq) ? cg[crel + nsegn] : 0xfu;
-            request_ops8(cg + crel, 8 * l, nsegn, pw);
-            pf_q = q; pf_seg = 0;
-        }
+    if (!live_mask) {                                                  // nothing to walk: four empty rows
+        if (l < nq) O.rows[r0 + l] = RowDesc{0u, 0, 0x7fffffff, 0u};
+        return;
     }
+    // the stream: from the first word of the first alignment that is walked to the last word of the last one (alignments in between that are
+    // not walked - low MAPQ, secondary - pass by as words that only move the coordinates on)
+    const int q_first = __builtin_ctz(live_mask), q_last = 31 - __builtin_clz(live_mask);
+    const unsigned long long c_lo = __shfl(h_coff, q_first);
+    const int h_rel = (l <= nq) ? (int)(long long)(h_coff - c_lo) : 0;  // word index of alignment q's first word inside the stream
+    const int h_ncig = __shfl_down(h_rel, 1) - h_rel;                  // (lanes < nq)
+    const uint32_t *cg = R.cigar + c_lo;
+    const int total = __builtin_amdgcn_readlane(h_rel + h_ncig, q_last);   // words of the stream
+    const int TC = (total + 7) >> 3;                                    // lane-chunks
+    if (TC > EXT_TAB) { to_redo(); return; }                            // very long alignments: the general walker takes the job
+    // UNCONDITIONAL loads, clamped to the stream (a load under a branch makes the compiler wait for every outstanding load where the paths join,
+    // i.e. for the request just made).  A lane's 8 words may run past the stream's end (DevBuf allocations carry 64 B of slack): the last round
+    // blanks those
+    auto request = [&](int cid, uint32_t (&w)[8]) __attribute__((always_inline)) {
+        const uint32_t *p = cg + 8 * min(cid, max(TC - 1, 0));
+        const LpsU4 a = *reinterpret_cast<const LpsU4 *>(p), b = *reinterpret_cast<const LpsU4 *>(p + 4);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    };
+    uint32_t pw[8];
+    request(l, pw);                                                     // round 0 is on its way while the first candidates are searched
     // first candidate of each alignment: four lanes search the position-sorted table side by side
     int h_v0 = 0;
     if (l < 4 && h_live) h_v0 = lane_var_lower_bound(V, h_start);
-    if (l <= 4) {
-        int *h = s_hdr[w][l];
-        h[H_REL] = h_rel;
-        if (l < 4) {
-            h[H_START] = h_start; h[H_LQ] = h_lq; h[H_V0] = h_v0;
-            h[H_SOFF] = (int)(unsigned)h_soff; h[H_SOFF + 1] = (int)(unsigned)(h_soff >> 32);
-            h[H_QOFF] = (int)(unsigned)h_qoff; h[H_QOFF + 1] = (int)(unsigned)(h_qoff >> 32);
-            h[H_HIT0] = 0; h[H_FAIL] = 0x7fffffff;
+    const bool h_walk = l < 4 && h_live && h_ncig > 0;
+    if (l < 4) {                                                        // (first half of the header: what the rare paths of the walk look at)
+        ExtHdr &h = s_hdr[l];
+        h.crel = h_rel; h.ncig = h_walk ? h_ncig : 0; h.c0 = h_rel >> 3; h.nch = h_walk ? ((h_rel + h_ncig - 1) >> 3) - (h_rel >> 3) + 1 : 0;
+        h.lq = h_lq; h.so_lo = (unsigned)h_soff; h.so_hi = (unsigned)(h_soff >> 32); h.qo_lo = (unsigned)h_qoff; h.qo_hi = (unsigned)(h_qoff >> 32);
+    }
+    wave_sync();
+
+    // ---- walk
+    int carry_r = 0, carry_q = 0, n_clip = 0;
+#pragma unroll 1
+    for (int R0 = 0; R0 < TC; R0 += 64) {
+        const int cid = R0 + l;
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = pw[k];
+        request(cid + 64, pw);
+        if (R0 + 64 >= TC) {                                            // last round: words past the stream's end count for nothing (6u: op P, length 0)
+            const int nv = total - 8 * cid;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = k < nv ? w[k] : 6u;
+        }
+        int rt = 0, qt = 0; unsigned seen = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned op = w[k] & 15u;
+            const unsigned t = op_consume_bits(op); const int len = (int)(w[k] >> 4);
+            rt += len & bit_mask(t, 0); qt += len & bit_mask(t, 16);
+            seen |= 1u << op;
+        }
+        const int ir = wave_incl_scan_dpp(rt), iq = wave_incl_scan_dpp(qt);
+        const int my_s = carry_r + ir - rt, my_q = carry_q + iq - qt;   // stream coordinates of the lane's first word
+        if (cid < TC) s_tab[cid] = make_int2(my_s, my_q);
+        carry_r += __builtin_amdgcn_readlane(ir, 63); carry_q += __builtin_amdgcn_readlane(iq, 63);
+        if ((unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu) { to_redo(); return; }   // stream coordinates are 32-bit: absurd spans go to the general walker
+        // ops the reference rejects (:1625-1628) and clips (getClip :1613-1620,1636-1645: soft/hard clips longer than 5; FRONT iff CIGAR index 0),
+        // both only in alignments that are walked.  Rare: a clipped alignment's first / last lane-chunk.  Events wait in LDS for the wave's one
+        // reservation, their position still in stream coordinates
+        if (__ballot((seen & (LPS_OPS_BAD | LPS_OPS_CLIP)) != 0u)) {
+            int mine_n = 0; bool bad = false; unsigned wq = 0;          // wq: 4 bits per word: its alignment + 1 (0: none that is walked)
+            int hr[4], hn[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { hr[q] = s_hdr[q].crel; hn[q] = s_hdr[q].ncig; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int x = 8 * cid + k;
+                unsigned q1 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (x >= hr[q] && x < hr[q] + hn[q]) q1 = q + 1;
+                wq |= q1 << (4 * k);
+                const unsigned op = w[k] & 15u;
+                if (q1) { bad |= op > 8u; mine_n += ((op == 4u || op == 5u) && (w[k] >> 4) > 5u) ? 1 : 0; }
+            }
+            if (__ballot(bad) && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
+            const int incl = wave_incl_scan_dpp(mine_n);
+            int slot = n_clip + incl - mine_n;
+            if (mine_n) {
+                int rr = my_s;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned op = w[k] & 15u; const int q = (int)((wq >> (4 * k)) & 15u) - 1;
+                    if (q >= 0 && (op == 4u || op == 5u) && (w[k] >> 4) > 5u) {
+                        const int oi = 8 * cid + k - SEL4(q, hr);
+                        if (slot < EXT_CLIPS) s_clip[slot] = ClipEv{rr, (oi << 1) | (oi != 0), q};
+                        ++slot;
+                    }
+                    rr += (int)(w[k] >> 4) & bit_mask(op_consume_bits(op), 0);
+                }
+            }
+            n_clip += __builtin_amdgcn_readlane(incl, 63);
+            if (n_clip > EXT_CLIPS) { to_redo(); return; }              // more clip ops than the buffer holds (H S ... S H chains)
         }
     }
     wave_sync();
 
-    // ---- walk: segments of LPS_SEG ops -> LDS (ref prefix, query prefix, raw op word); the candidate variants (one packed record per lane)
-    //      search them and leave hits
-    int n_hit = 0, n_clip = 0;
-    bool overflow = false;
-    uint2 *ovf_mine = nullptr;                                          // this wave's chunk of the global hit list, taken when the LDS list is full
-#pragma unroll 1
-    while (q < nq && !overflow) {
-        const int r = r0 + q;
-        int *h = hdr + q * H_WORDS;
-#define HU(i) __builtin_amdgcn_readfirstlane(h[i])
-        const int start = HU(H_START), lq = HU(H_LQ), crel = HU(H_REL), n_cig = HU(H_WORDS + H_REL) - crel;
-        const uint32_t *cig = cg + crel;
-        int vcur = HU(H_V0);
-#undef HU
-        const unsigned rest = live_mask >> (q + 1);
-        const int qn = rest ? q + 1 + __builtin_ctz(rest) : nq;                 // next alignment to walk
-        const int *hn = hdr + qn * H_WORDS;                                     // (row nq exists: only its H_REL is meaningful)
-        const int n_cig_n = qn < nq ? hn[H_WORDS + H_REL] - hn[H_REL] : 0;
-
-        int ref_pos = start, q_pos = 0, fail_op = 0x7fffffff;
-        if (l == 0) h[H_HIT0] = n_hit;
-        for (int seg0 = 0; seg0 < n_cig && !overflow; seg0 += LPS_SEG) {
-            const int nseg = min(LPS_SEG, n_cig - seg0);
-            uint32_t wds[8]; uint32_t nextw; uint2 vr; int pv0;
-            const bool have = pf_q == q && pf_seg == seg0;
-            if (have) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) wds[u] = pw[u];
-                finish_ops8(8 * l, nseg, wds);
-                nextw = pnext;
-            } else {
-                nextw = (seg0 + nseg < n_cig) ? cig[seg0 + nseg] : 0xfu;      // op after the segment (0xf = none)
-                load_ops8(cig + seg0, 8 * l, nseg, wds);
-            }
-            if (have && pf_vr_ok) { vr = pvr; pv0 = ppv; }
-            else {
-                vr = make_uint2(0x7fffffffu, 0u);
-                if (vcur + l < V.n) vr = V.rec[vcur + l];
-                pv0 = (vcur > 0 && vcur < V.n) ? V.pos[vcur - 1] : -1;
-            }
-            int my_ref;
-            const unsigned seen = stage_ops8(wds, l, ref_pos, q_pos, sref, sqry, scig, my_ref);
-            if (__ballot((seen & LPS_OPS_BAD) != 0u) && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);   // the reference exits (:1625-1628)
-            (void)my_ref;
-            // getClip (:1613-1620,1636-1645): soft/hard clips longer than 5; FRONT iff CIGAR index 0.  Events wait in LDS for the wave's one reservation.
-            if (__ballot((seen & LPS_OPS_CLIP) != 0u)) {                            // rare (first / last segment of a clipped alignment): words re-read from LDS
-                int mine_n = 0;
-#pragma unroll 1
-                for (int k = 0; k < 8; ++k) { const uint32_t wd = scig[8 * l + k]; const unsigned op = wd & 15u; mine_n += ((op == 4u || op == 5u) && (wd >> 4) > 5u) ? 1 : 0; }
-                const int incl = wave_incl_scan_dpp(mine_n);
-                int slot = n_clip + incl - mine_n;
-                if (mine_n) {
-#pragma unroll 1
-                    for (int k = 0; k < 8; ++k) {
-                        const uint32_t wd = scig[8 * l + k]; const unsigned op = wd & 15u;
-                        if ((op == 4u || op == 5u) && (wd >> 4) > 5u) {
-                            const int oi = seg0 + 8 * l + k;
-                            if (slot < EXT_CLIPS) clipb[slot] = ClipEv{sref[8 * l + k], (oi << 1) | (oi != 0), r};
-                            ++slot;
-                        }
-                    }
-                }
-                n_clip += __shfl(incl, 63);
-                if (n_clip > EXT_CLIPS) overflow = true;                             // more clip ops than the buffer holds: the redo kernel takes the wave
-            }
-            if (l == 0) scig[nseg] = nextw;
-            wave_sync();
-            // ---- request the next segment's CIGAR words: same alignment, or the first segment of the next one
-            const bool same = seg0 + LPS_SEG < n_cig;
-            const bool has_next = same || (qn < nq && n_cig_n > 0);
-            if (has_next) {
-                const uint32_t *cign = same ? cig : cg + hn[H_REL];
-                const int segn = same ? seg0 + LPS_SEG : 0, ncn = same ? n_cig : n_cig_n, nsegn = min(LPS_SEG, ncn - segn);
-                pnext = (segn + nsegn < ncn) ? cign[segn + nsegn] : 0xfu;
-                request_ops8(cign + segn, 8 * l, nsegn, pw);
-                pf_q = same ? q : qn; pf_seg = segn;
-            } else pf_q = -1;
-            pf_vr_ok = false;
-            // candidates are position-sorted: those before the end of this segment's reference interval form a prefix of the chunk
-            bool first_round = true;
-            while (true) {
-                const int v = vcur + l;
-                const int p = (int)vr.x;
-                const bool mine = v < V.n && p < ref_pos;
-                const int n_in = __popcll(__ballot(mine));
-                const bool more = n_in == 64;
-                if (first_round && has_next && !more) {          // ... and its candidate records + predecessor position
-                    const int nv = same ? vcur + n_in : hn[H_V0];
-                    pvr = make_uint2(0x7fffffffu, 0u);
-                    if (nv + l < V.n) pvr = V.rec[nv + l];
-                    ppv = (nv > 0 && nv < V.n) ? V.pos[nv - 1] : -1;
-                    pf_vr_ok = true;
-                }
-                int pprev = __shfl_up(p, 1);                     // position of the previous variant (all lanes take part)
-                if (l == 0) pprev = first_round ? pv0 : ((v > 0 && v < V.n) ? V.pos[v - 1] : -1);
-                first_round = false;
-                bool is_hit = false, fail = false; unsigned h0 = 0; int h1 = 0, opi = 0;
-                if (mine) {
-                    const unsigned at = vr.y;
-                    // number of staged ops that start at or before p, by a fixed-trip search without branches: all LPS_SEG entries are valid numbers
-                    // (the entries past the segment's ops hold its end position, which is beyond every candidate)
-                    int lo = 0;
-#pragma unroll
-                    for (int step = LPS_SEG / 2; step >= 1; step >>= 1) lo += (sref[lo + step - 1] <= p) ? step : 0;
-                    lo += (sref[lo] <= p) ? 1 : 0;               // lo <= LPS_SEG - 1 before this probe
-                    const int j = lo - 1;
-                    if (j >= 0) {
-                        const uint32_t wd = scig[j];
-                        const int op = wd & 15, len = (int)(wd >> 4);
-                        const int rs = sref[j], qs = sqry[j];
-                        opi = seg0 + j;
-                        if (p < rs + len) {
-                            const unsigned kind = VREC_KIND(at);
-                            if (op_is_match(op)) {                                            // :1445-1520
-                                const int off = p - rs;
-                                if (qs + off + 1 > lq) fail = true;                           // :1453-1455
-                                else if (kind == 0) { is_hit = true; h1 = qs + off; }         // base and quality are fetched when the hits are resolved
-                                else if ((kind == 1 || kind == 2) && opi + 1 < n_cig) {       // indel variant :1470-1510
-                                    const int want = (kind == 1) ? 1 : 2;                      // next op must be I resp. D
-                                    const bool alt = rs + len - 1 == p && (int)(scig[j + 1] & 15) == want;
-                                    is_hit = true; h0 = HIT_FINAL | (alt ? HIT_ALLELE : 0u) | ((at & VREC_DANGER) ? HIT_Q5 : 0u);
-                                }
-                            } else if (op == 2) {                                             // :1539-1607
-                                // only the first variant at/after the deletion start is examined by the reference
-                                const bool first_in = (v == 0) || pprev < rs;
-                                if (first_in && (at & VREC_HPOLY3)) {
-                                    if (qs + 1 > lq) fail = true;                             // :1559-1561
-                                    else if (kind == 0) { is_hit = true; h1 = qs; }
-                                    else if (kind == 2) { is_hit = true; h0 = HIT_FINAL | HIT_ALLELE; }
-                                }
-                            }
-                        }
-                    }
-                    if (fail) fail_op = min(fail_op, opi);
-                    if (is_hit) h0 |= (unsigned)v | ((at & VREC_ERASED) ? HIT_ERASED : 0u);
-                }
-                const unsigned long long hm = __ballot(is_hit);
-                const int n_h = __popcll(hm);
-                if (n_hit + n_h > EXT_CAP) {
-                    if (n_hit + n_h > EXT_CAP + EXT_OVF) { overflow = true; break; }
-                    if (!ovf_mine) {
-                        unsigned ch = 0; if (l == 0) ch = atomicAdd(ovf_ctr, 1u);
-                        ch = __shfl((int)ch, 0);
-                        if (ch >= ovf_chunks) { overflow = true; break; }
-                        ovf_mine = ovf + (size_t)ch * EXT_OVF;
-                    }
-                }
-                if (is_hit) { const int at = n_hit + __popcll(hm & lanemask_lt()); const uint2 hv = make_uint2(h0, (unsigned)h1); if (at < EXT_CAP) hit[at] = hv; else ovf_mine[at - EXT_CAP] = hv; }
-                n_hit += n_h;
-                vcur += n_in;
-                if (!more) break;
-                vr = make_uint2(0x7fffffffu, 0u);
-                if (vcur + l < V.n) vr = V.rec[vcur + l];
-            }
-            wave_sync();
-        }
-        fail_op = wave_min(fail_op);
-        if (l == 0) h[H_FAIL] = fail_op;
-        q = qn;
-    }
-    if (overflow) {
-        // the hits (or clip events) of these four alignments do not fit the wave's LDS lists: k_extract_redo walks them with the direct-to-memory path
-        if (l == 0) redo_list[atomicAdd(n_redo, 1u)] = (uint32_t)job;
-        return;
-    }
-    wave_sync();
-
-    // ---- resolve the hits, 64 at a time with every lane busy: gather base + quality, call the allele, drop what filterSNP erased, compact in place
-    int hs[5]; int rfail[4];                                            // first hit of every row (rows that were not walked are empty), early-return op
+    // ---- where each alignment begins and ends in stream coordinates: lane q takes the chunks that hold the first and the last word of
+    //      alignment q and sums the words in front of / up to them
+    int b_sat = 0, b_qat = 0, b_rend = h_start;
     {
-        int nxt = n_hit;
+        const int xe = h_rel + h_ncig - 1;
+        const int cs = h_walk ? h_rel >> 3 : 0, ce = h_walk ? xe >> 3 : 0;
+        const int ks = h_rel & 7, ke = (xe & 7) + 1;
+        uint32_t ws[8], we[8];
+        {
+            const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs), b = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs + 4);
+            const LpsU4 c = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce), d = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce + 4);
+            ws[0] = a.x; ws[1] = a.y; ws[2] = a.z; ws[3] = a.w; ws[4] = b.x; ws[5] = b.y; ws[6] = b.z; ws[7] = b.w;
+            we[0] = c.x; we[1] = c.y; we[2] = c.z; we[3] = c.w; we[4] = d.x; we[5] = d.y; we[6] = d.z; we[7] = d.w;
+        }
+        const int2 ts = s_tab[cs], te = s_tab[ce];
+        int ar = 0, aq = 0, er = 0;
 #pragma unroll
-        for (int k = 3; k >= 0; --k) { const bool walked = k < nq && ((live_mask >> k) & 1u); hs[k] = walked ? hdr[k * H_WORDS + H_HIT0] : nxt; nxt = hs[k]; rfail[k] = walked ? hdr[k * H_WORDS + H_FAIL] : 0x7fffffff; }
-        hs[4] = n_hit;
+        for (int m = 0; m < 8; ++m) {
+            const unsigned t1 = op_consume_bits(ws[m] & 15u), t2 = op_consume_bits(we[m] & 15u);
+            const int l1 = m < ks ? (int)(ws[m] >> 4) : 0, l2 = m < ke ? (int)(we[m] >> 4) : 0;
+            ar += l1 & bit_mask(t1, 0); aq += l1 & bit_mask(t1, 16); er += l2 & bit_mask(t2, 0);
+        }
+        if (h_walk) { b_sat = ts.x + ar; b_qat = ts.y + aq; b_rend = h_start + te.x + er - b_sat; }
     }
-    unsigned long long sb[4], qb[4];
+
+    // ---- candidates of each alignment: variants [v0, first variant at or beyond the alignment's reference end)
+    int v0q[4], ncand[4], rend[4]; bool walkq[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int *hk = hdr + k * H_WORDS;
-        sb[k] = (unsigned long long)(unsigned)hk[H_SOFF] | ((unsigned long long)(unsigned)hk[H_SOFF + 1] << 32);
-        qb[k] = (unsigned long long)(unsigned)hk[H_QOFF] | ((unsigned long long)(unsigned)hk[H_QOFF + 1] << 32);
+    for (int q = 0; q < 4; ++q) { v0q[q] = __builtin_amdgcn_readlane(h_v0, q); rend[q] = __builtin_amdgcn_readlane(b_rend, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; }
+    {
+        int pp[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pp[q] = V.pos[min(v0q[q] + l, V.n - 1)];           // four loads in flight together (unconditional: see `request`)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int n = __popcll(__ballot(walkq[q] && v0q[q] + l < V.n && pp[q] < rend[q]));
+            if (n == 64) {                                              // more than a wave's worth (dense tables): count on
+                for (;;) { int p2 = 0x7fffffff; if (v0q[q] + n + l < V.n) p2 = V.pos[v0q[q] + n + l]; const int m = __popcll(__ballot(p2 < rend[q])); n += m; if (m < 64) break; }
+            }
+            ncand[q] = n;
+        }
     }
-    // ---- ONE reservation for the rows of the wave: as many slots as there are hits (the few hits that turn out not to be observations - a base that is
-    //      neither allele, a variant filterSNP erased - leave their slots unused), so that the resolved records go straight to their place
-    unsigned long long off = 0; bool arena_full = false;
-    if (n_hit > 0) {
-        if (l == 0) off = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)n_hit);
-        off = __shfl(off, 0);
-        if (off + (unsigned long long)n_hit > O.arena_size) arena_full = true;
-    }
-    const unsigned long long g0 = arena_lo + off;
-    ObsRec *dst = O.rec + g0;
+    int cum[5]; cum[0] = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cum[q + 1] = cum[q] + ncand[q];
+    const int T = cum[4];
+    int vadj[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vadj[q] = v0q[q] - cum[q];
+    if (l < 4) { ExtHdr &h = s_hdr[l]; h.vadj = SEL4(l, vadj); h.ds = b_sat - h_start; h.dq = b_qat; }
+    int maxnch = l < 4 ? s_hdr[l].nch : 0;
+    maxnch = max(max(__builtin_amdgcn_readlane(maxnch, 0), __builtin_amdgcn_readlane(maxnch, 1)), max(__builtin_amdgcn_readlane(maxnch, 2), __builtin_amdgcn_readlane(maxnch, 3)));
+    // ---- ONE reservation for the rows of the wave: a slot per candidate (the few candidates that turn out not to be observations - a base that is
+    //      neither allele, a variant inside a deletion, a variant filterSNP erased - leave slots unused at the end), so that records go straight
+    //      to their compacted place
+    unsigned long long off = 0;
+    if (T > 0 && l == 0) off = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)T);
+    wave_sync();
+    const int step0 = maxnch > 1 ? 1 << (31 - __builtin_clz(maxnch - 1)) : 0;    // the steps step0, step0/2, .. 1 sum to >= maxnch - 1
+    bool arena_full = false; unsigned long long g0 = 0; ObsRec *dst = nullptr;
     int n_out = 0, n_emit[4] = {0, 0, 0, 0}; unsigned any_pre = 0;
-    for (int i0 = 0; i0 < n_hit; i0 += 64) {
+    bool fail = false;
+    uint2 pvr = V.rec[min(SELC(l, cum, vadj) + l, V.n - 1)];             // records are requested one round ahead
+#pragma unroll 1
+    for (int i0 = 0; i0 < T; i0 += 64) {
         const int i = i0 + l;
-        const bool in = i < n_hit;
-        uint2 hv = make_uint2(0u, 0u);
-        if (in) hv = i < EXT_CAP ? hit[i] : ovf_mine[i - EXT_CAP];
-        const int rq = (i >= hs[1]) + (i >= hs[2]) + (i >= hs[3]);       // row of the hit
-        const unsigned long long so = rq == 0 ? sb[0] : (rq == 1 ? sb[1] : (rq == 2 ? sb[2] : sb[3]));
-        const unsigned long long qo = rq == 0 ? qb[0] : (rq == 1 ? qb[1] : (rq == 2 ? qb[2] : qb[3]));
-        const int rf = rq == 0 ? rfail[0] : (rq == 1 ? rfail[1] : (rq == 2 ? rfail[2] : rfail[3]));
-        const int v = (int)(hv.x & 0x3fffffu);
-        int allele = -1, qv = 0;
+        const bool in = i < T;
+        int allele = -1, qv = 0, v = 0; bool erased = false;
+        const uint2 vr = pvr;
+        pvr = V.rec[min(SELC(i + 64, cum, vadj) + i + 64, V.n - 1)];
         if (in) {
-            if (hv.x & HIT_FINAL) { allele = (hv.x & HIT_ALLELE) ? 1 : 0; qv = (hv.x & HIT_Q5) ? -5 : -4; }
-            else {
-                const int qi = (int)hv.y;
-                const unsigned at = V.rec[v].y;
-                const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
-                const char base_c = nt16_char(R.seq[so + (unsigned)(qi >> 1)] >> ((~qi & 1) << 2));
-                if (base_c == ref_c) allele = 0; else if (base_c == alt_c) allele = 1;
-                qv = R.qual[qo + (unsigned)qi];
+            const int q = (i >= cum[1]) + (i >= cum[2]) + (i >= cum[3]);
+            const int4 ha = *reinterpret_cast<const int4 *>(&s_hdr[q].crel), hb = *reinterpret_cast<const int4 *>(&s_hdr[q].vadj);
+            const int hcrel = ha.x, hncig = ha.y, hc0 = ha.z, hnch = ha.w, hlq = hb.y;
+            v = hb.x + i;
+            const int p = (int)vr.x; const unsigned at = vr.y;
+            erased = (at & VREC_ERASED) != 0u;
+            const int ps = p + hb.z;                                      // the variant in stream coordinates
+            // last chunk of the alignment that starts at or before it (the alignment's first chunk does: the variant lies at or after its start)
+            int co = 0;
+            for (int step = step0; step >= 1; step >>= 1) { const int t = co + step; const int sv = s_tab[hc0 + min(t, hnch - 1)].x; co = (t < hnch && sv <= ps) ? t : co; }
+            const int2 base = s_tab[hc0 + co];
+            const int x0 = 8 * (hc0 + co);                                // stream index of the chunk's first word
+            const uint32_t *cw = cg + x0;
+            uint32_t w[9];
+            {
+                const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cw), b = *reinterpret_cast<const LpsU4 *>(cw + 4);
+                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = cw[8];
+            }
+            // the op that covers the variant: the last one that starts at or before it.  Starts never decrease, so "starts at or before" holds
+            // for a prefix of the words: words of the alignment before (they end where this one begins) pass the test and are overtaken by this
+            // alignment's first op, words past its end start at its end, beyond every candidate - whatever they hold
+            int rr = base.x, qq = base.y, j = 0, rs = base.x, qs = base.y; uint32_t wj = w[0], wn = w[1];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                const unsigned t = op_consume_bits(w[k - 1] & 15u); const int len = (int)(w[k - 1] >> 4);
+                rr += len & bit_mask(t, 0); qq += len & bit_mask(t, 16);
+                const bool le = rr <= ps;
+                j = le ? k : j; rs = le ? rr : rs; qs = le ? qq : qs; wj = le ? w[k] : wj; wn = le ? w[k + 1] : wn;
+            }
+            const int op = wj & 15, len = (int)(wj >> 4);
+            const int opi = x0 + j - hcrel;                               // op index inside the alignment
+            qs -= hb.w;                                                   // query position inside the alignment
+            if (ps < rs + len) {
+                const unsigned kind = VREC_KIND(at);
+                int qi = -1;
+                if (op_is_match(op)) {                                            // :1445-1520
+                    const int o = ps - rs;
+                    if (qs + o + 1 > hlq) fail = true;                            // :1453-1455
+                    else if (kind == 0) qi = qs + o;
+                    else if ((kind == 1 || kind == 2) && opi + 1 < hncig) {       // indel variant :1470-1510
+                        const int want = (kind == 1) ? 1 : 2;                      // next op must be I resp. D
+                        allele = (rs + len - 1 == ps && (int)(wn & 15u) == want) ? 1 : 0;
+                        qv = (at & VREC_DANGER) ? -5 : -4;
+                    }
+                } else if (op == 2) {                                             // :1539-1607
+                    // only the first variant at/after the deletion start is examined by the reference
+                    const bool first_in = (v == 0) || V.pos[v - 1] + hb.z < rs;
+                    if (first_in && (at & VREC_HPOLY3)) {
+                        if (qs + 1 > hlq) fail = true;                            // :1559-1561
+                        else if (kind == 0) qi = qs;
+                        else if (kind == 2) { allele = 1; qv = -4; }
+                    }
+                }
+                if (qi >= 0) {                                                    // base and quality at the variant site
+                    const int4 hc = *reinterpret_cast<const int4 *>(&s_hdr[q].so_lo);
+                    const unsigned long long so = (unsigned long long)(unsigned)hc.x | ((unsigned long long)(unsigned)hc.y << 32);
+                    const unsigned long long qo = (unsigned long long)(unsigned)hc.z | ((unsigned long long)(unsigned)hc.w << 32);
+                    const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
+                    const char base_c = nt16_char(R.seq[so + (unsigned)(qi >> 1)] >> ((~qi & 1) << 2));
+                    if (base_c == ref_c) allele = 0; else if (base_c == alt_c) allele = 1;
+                    qv = R.qual[qo + (unsigned)qi];
+                }
             }
         }
-        const bool pre = in && allele != -1 && rf == 0x7fffffff;          // an observation before filterSNP (rows that returned early hold none)
-        const bool ok = pre && !(hv.x & HIT_ERASED);
+        const bool pre = in && allele != -1;                              // an observation before filterSNP
+        const bool ok = pre && !erased;
         const unsigned long long pm = __ballot(pre), om = __ballot(ok);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int a = max(hs[k] - i0, 0), b = min(hs[k + 1] - i0, 64);   // lanes of row k in this round
+            const int a = max(cum[k] - i0, 0), b = min(cum[k + 1] - i0, 64);   // lanes of row k in this round
             if (b > a) {
                 const unsigned long long rm = ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << a) - 1ull);
                 n_emit[k] += __popcll(om & rm); if (pm & rm) any_pre |= 1u << k;
             }
         }
+        if (i0 == 0) {                                                    // the reservation has had the first round's searches to arrive
+            off = __shfl(off, 0);
+            arena_full = off + (unsigned long long)T > O.arena_size;
+            g0 = arena_lo + off; dst = O.rec + g0;
+        }
         if (ok && !arena_full) dst[n_out + __popcll(om & lanemask_lt())] = ObsRec{(int32_t)v, (uint32_t)pack_aq(allele, qv)};
         n_out += __popcll(om);
+    }
+    if (__ballot(fail)) {
+        // get_snp returned early somewhere in these four alignments (SEQ shorter than the CIGAR says): the read is dropped but clips of earlier ops
+        // stay - the general walker replays the job; the slots reserved above stay unused (no row points at them)
+        to_redo();
+        return;
     }
     if (arena_full && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW);          // the host grows the arenas and reruns
     if (l < nq) {
         int before = 0, mine = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { if (k < l) before += n_emit[k]; if (k == l) mine = n_emit[k]; }
-        const int rf = l == 0 ? rfail[0] : (l == 1 ? rfail[1] : (l == 2 ? rfail[2] : rfail[3]));
         const bool walked = (live_mask >> l) & 1u;
         const bool ok = walked && !arena_full;
         RowDesc d;
         d.off = ok ? (uint32_t)(g0 + (unsigned)before) : 0u;
         d.cnt = ok ? mine : 0;
-        d.fail = ok ? rf : 0x7fffffff;
-        d.flags = (ok && rf == 0x7fffffff && ((any_pre >> l) & 1u) && mine == 0) ? 1u : 0u;
+        d.fail = 0x7fffffff;
+        d.flags = (ok && ((any_pre >> l) & 1u) && mine == 0) ? 1u : 0u;
         O.rows[r0 + l] = d;
     }
     if (n_clip > 0 && !arena_full) {
         unsigned cb = 0;
         if (l == 0) cb = atomicAdd(C.n_ev, (unsigned)n_clip);
         cb = __shfl(cb, 0);
-        if (l < n_clip && cb + (unsigned)l < C.capacity) C.ev[cb + l] = clipb[l];
+        if (l < n_clip && cb + (unsigned)l < C.capacity) {
+            ClipEv e = s_clip[l]; const int q = e.read;                   // stream coordinate -> reference position, alignment of the job -> alignment index
+            e.pos = e.pos - s_hdr[q].ds; e.read = r0 + q;
+            C.ev[cb + l] = e;
+        }
     }
 }
 
@@ -729,10 +752,10 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
 }
 
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,
-                          int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint2 *ovf, unsigned *ovf_ctr, unsigned ovf_chunks, hipStream_t s) {
+                          int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, hipStream_t s) {
     if (R.n == 0) return;
     const int n_jobs = (R.n + EXT_RPW - 1) / EXT_RPW;
-    hipLaunchKernelGGL(k_extract_phase, dim3((n_jobs + EXT_WPB - 1) / EXT_WPB), dim3(64 * EXT_WPB), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo, ovf, ovf_ctr, ovf_chunks);
-    // waves whose hits did not fit their LDS list queued themselves (none with ordinary read lengths and variant densities): a small grid drains the queue
+    hipLaunchKernelGGL(k_extract_phase, dim3(n_jobs), dim3(64), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo);
+    // jobs the lane-chunk table could not hold queued themselves (very long alignments; none with ordinary read lengths): a small grid drains the queue
     hipLaunchKernelGGL(k_extract_redo, dim3(std::min(256, (n_jobs + 3) / 4)), dim3(256), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo);
 }

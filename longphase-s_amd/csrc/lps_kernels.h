@@ -87,8 +87,7 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 #define VREC_DERIVE(a) (((a) >> 24) & 3u) /* somaticReadDeriveByHP of role-1 rows */
 #define VREC_TKIND(a) (((a) >> 26) & 7u)  /* somatic extraction: TUMOR row kind at this position (0 none, 1 SNP, 2 INS, 3 DEL, 4 other) */
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,
-                          int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint2 *ovf, unsigned *ovf_ctr, unsigned ovf_chunks, hipStream_t s);
-#define LPS_EXT_OVF_HITS 2048   /* = EXT_OVF of lps_extract.hip: hits per chunk of the global hit list */
+                          int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, hipStream_t s);
 
 // ---- device helpers shared by the extraction (phase) and scoring (haplotag) kernels
 #ifdef __HIPCC__

@@ -12,7 +12,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.abspath(os.path.join(_HERE, "..", "csrc", "liblps_hip.so"))
+# LPS_HIP_LIB: another BUILD of the same library (profiles/ab.sh compares two builds on one box without touching the in-tree file)
+LIB_PATH = os.path.abspath(os.environ.get("LPS_HIP_LIB") or os.path.join(_HERE, "..", "csrc", "liblps_hip.so"))
 HEADER = os.path.abspath(os.path.join(_HERE, "..", "..", "include", "lps_abi.h"))
 
 _lib = None
@@ -88,6 +89,8 @@ def load():
     L.lps_comm_destroy.restype = None
     L.lps_comm_bcast.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]
     L.lps_comm_bcast_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]
+    L.lps_comm_bcast_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_double)]
+    L.lps_set_variants_device.argtypes = [C.c_void_p, C.POINTER(abi.VariantTable)]
     L.lps_comm_last_error.restype = C.c_char_p
     L.lps_debug_set_obs_capacity.argtypes = [C.c_void_p, C.c_int64]
     L.lps_stage_name.restype = C.c_char_p
@@ -144,10 +147,18 @@ class Context:
             self.n_reads += r.n_reads
         self.n_var = variants.n
 
-    def load_chromosome_device(self, variants, ref, batch, n_reads):
-        """As load_chromosome for a batch whose arrays already sit on this GPU (abi.ReadBatch of DEVICE pointers)."""
+    def load_chromosome_device(self, variants, ref, batch, n_reads, table_dev=None):
+        """As load_chromosome for a batch whose arrays already sit on this GPU (abi.ReadBatch of DEVICE pointers).  table_dev = (pos, ref0, alt0)
+        device addresses of the contig's `variants.n` rows (e.g. inside the buffer lps_comm_bcast_to_device filled): the table is then taken from
+        there (lps_set_variants_device) and the host arrays of `variants` are not uploaded."""
         self._check(self.L.lps_begin_chromosome(self.h), "lps_begin_chromosome")
-        self._check(self.L.lps_set_variants(self.h, C.byref(variants.c)), "lps_set_variants")
+        if table_dev is None:
+            self._check(self.L.lps_set_variants(self.h, C.byref(variants.c)), "lps_set_variants")
+        else:
+            t = abi.VariantTable()
+            t.n = variants.n
+            t.pos, t.ref0, t.alt0 = int(table_dev[0]), int(table_dev[1]), int(table_dev[2])
+            self._check(self.L.lps_set_variants_device(self.h, C.byref(t)), "lps_set_variants_device")
         ref = np.ascontiguousarray(ref, dtype=np.uint8)
         self._check(self.L.lps_set_reference(self.h, ref.ctypes.data, ref.size), "lps_set_reference")
         self._check(self.L.lps_push_reads_device(self.h, C.byref(batch)), "lps_push_reads_device")

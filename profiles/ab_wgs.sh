@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of two builds on ONE box with the whole-genome workload (four contexts): bash profiles/ab_wgs.sh A.so B.so
-ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-for i in 1 2 3; do for v in "$1" "$2"; do
-  cp "$ROOT/longphase-s_amd/csrc/ab/$v" "$ROOT/longphase-s_amd/csrc/liblps_hip.so"
-  timeout -k 10 300 python3 "$ROOT/bench.py" --no-cpu-baseline --parity none > /tmp/ab.json 2> /tmp/ab.err || { echo "$v failed"; tail -3 /tmp/ab.err; exit 1; }
+# A/B of builds on ONE box with the whole-genome workload (four contexts): bash profiles/ab_wgs.sh [-n rounds] A.so B.so [...]  (builds in csrc/ab/, see ab.sh)
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; N=3
+while getopts "n:" o; do case $o in n) N=$OPTARG;; esac; done; shift $((OPTIND-1))
+for i in $(seq $N); do for v in "$@"; do
+  LPS_HIP_LIB="$ROOT/longphase-s_amd/csrc/ab/$v" timeout -k 10 300 python3 "$ROOT/bench.py" --no-cpu-baseline --parity none > /tmp/ab.json 2> /tmp/ab.err || { echo "$v failed"; tail -3 /tmp/ab.err; exit 1; }
   python3 -c "
 import json
 d=json.loads(open('/tmp/ab.json').read().strip().splitlines()[-1])
