@@ -525,9 +525,17 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    rc = 0
     if parity is not None and not parity["checked"]:
         log(f"[rank {rank}] PARITY FAILED: {parity}")
-        sys.exit(4)                                # the JSON line above carries parity_checked false; the exit code says it too
+        rc = 4                                     # the JSON line above carries parity_checked false; the exit code says it too
+    if dist is not None:
+        # a multi-rank process holds two ROCm stacks (the system's, which liblps_hip.so and librccl were built against, and the one torch ships for
+        # its gloo control plane): everything of ours is closed and flushed above, the interpreter's teardown of both at once is skipped
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(rc)
+    if rc:
+        sys.exit(rc)
 
 
 class Invalid(Exception):

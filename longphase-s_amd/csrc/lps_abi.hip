@@ -21,10 +21,10 @@
 #include "lps_stdsort.h"
 
 static const char *kStageNames[LPS_MAX_STAGES] = {
-    "variant_prep", "extract", "name_keys", "name_groups", "overlap_filter", "clip_cnv", "cnv_filter", "nodes", "merge_rows",
-    "node_lists", "edges", "vote_scan", "read_correction", "d2h", nullptr};
+    "variant_prep", "extract", "names_clips", "overlap_filter", "clip_cnv", "cnv_filter", "graph_rows",
+    "edges", "vote_scan", "read_correction", "d2h", nullptr};
 // recorded in this order on the stream
-enum { ST_PREP, ST_EXTRACT, ST_GROUPS, ST_GROUPS2, ST_OVERLAP, ST_CLIP, ST_CNV, ST_NODES, ST_MERGE, ST_NODELISTS, ST_EDGES, ST_SCAN, ST_CORR, ST_D2H, ST_COUNT };
+enum { ST_PREP, ST_EXTRACT, ST_GROUPS, ST_OVERLAP, ST_CLIP, ST_CNV, ST_NODES, ST_EDGES, ST_SCAN, ST_CORR, ST_D2H, ST_COUNT };
 
 struct lps_ctx {
     int device = 0;
@@ -49,6 +49,7 @@ struct lps_ctx {
     int nR = 0; uint64_t n_cig = 0, n_seq = 0, n_qual = 0;
     DevBuf<int32_t> r_start, r_lq; DevBuf<uint16_t> r_flag; DevBuf<uint8_t> r_mapq; DevBuf<uint32_t> r_name;
     DevBuf<uint64_t> r_coff, r_soff, r_qoff; DevBuf<uint32_t> cigar; DevBuf<uint8_t> seq, qual;
+    DevBuf<uint8_t> sq; DevBuf<uint32_t> r_sqblk, sq_cnt; int sq_reads = -1; float sq_ms = 0;   // bases + qualities interleaved per 128-byte line (lps_reads.hip); sq_reads: alignments it covers (-1: not built)
     // raw BAM records (lps_push_bam_records): seq/qual are read in place from the blob
     DevBuf<uint8_t> blob; uint64_t n_blob = 0; int read_mode = 0;   // 0 none yet, 1 SoA batches, 2 BAM records
     DevBuf<uint64_t> rec_off, cig_src; DevBuf<unsigned long long> cig_cnt; DevBuf<unsigned> bam_err;
@@ -60,7 +61,7 @@ struct lps_ctx {
     DevBuf<uint64_t> rcand; uint64_t n_rec_all = 0; DevBuf<int32_t> r_tid_all; DevBuf<uint32_t> r_lname, r_nameoff, wg_cnt, wg_off, scan_nout; DevBuf<uint8_t> names_d; bool names_ready = false;
     // observations
     DevBuf<RowDesc> rows; DevBuf<int32_t> g_cnt; DevBuf<uint8_t> deleted;
-    DevBuf<ObsRec> obs; DevBuf<int32_t> g_node; DevBuf<uint8_t> g_flag; DevBuf<uint32_t> g_pack, t_src; DevBuf<uint16_t> g_rank; DevBuf<uint32_t> redo_list;
+    DevBuf<ObsRec> obs; DevBuf<uint32_t> g_pack, g_rank, t_src, redo_list; DevBuf<int32_t> t_node; DevBuf<uint8_t> t_flag;
     unsigned long long obs_capacity = 0;   // main arenas (LPS_ARENAS equal parts); a tail arena of obs_capacity/4 follows
     DevBuf<unsigned long long> arena_ctr;
     bool in_phase = false; int timing_level = 1;
@@ -80,12 +81,13 @@ struct lps_ctx {
     int32_t *h_cnv_pin = nullptr; size_t h_cnv_pin_bytes = 0;
     std::vector<int32_t> h_cnv_start, h_cnv_end; bool cnv_expect = false; unsigned h_ub_hazard = 0;   // intervals of the current run (each once); cnv_expect: the previous run had intervals
     // groups
-    DevBuf<unsigned long long> name_keys, name_keys_s;
-    DevBuf<uint32_t> head, gidx, gstart, read_group, stack, mrow_off, koff; DevBuf<int32_t> mrow_cnt;
+    DevBuf<unsigned long long> name_keys, name_keys_s;    // (only when the caller's name ids are not dense: ranks by one sort)
+    DevBuf<uint32_t> head, gidx, name_dense, name_link, mm_r, stack, mg_start, mg_cnt, mg_name, mg_plan, mrow_off; DevBuf<int32_t> mrow_cnt;
+    const uint32_t *name_p = nullptr; size_t name_cap = 0; bool key64 = false, scan_done = false; GraphView G{};
     // nodes / graph
-    DevBuf<uint32_t> is_node, vtype_key, node_of, node_off, node_end, node_cur, multi_list, bsize, cnt4;
-    DevBuf<int32_t> nodes, block; DevBuf<uint8_t> ntype; DevBuf<uint8_t> erec; DevBuf<unsigned> clip_stats; DevBuf<int8_t> hp, hp_v; DevBuf<int32_t> blk_v, seg_i32; DevBuf<char> st_b, st_e; DevBuf<uint32_t> node_pairs; DevBuf<uint8_t> nstate;
-    DevBuf<unsigned long long> nkeys, nkeys_s; DevBuf<uint32_t> nvals, nvals_s;
+    DevBuf<uint32_t> name_head, var_cnt, var_del, var_del2, vtype_key, node_of, var_off, node_off, node_cap, node_end, bsum, cnt4; DevBuf<uint8_t> bmulti;
+    DevBuf<int32_t> nodes, block; DevBuf<uint8_t> erec; DevBuf<unsigned> clip_stats; DevBuf<int8_t> hp, hp_v; DevBuf<int32_t> blk_v, seg_i32; DevBuf<char> st_b, st_e; DevBuf<uint32_t> node_pairs; DevBuf<uint8_t> nstate;
+    DevBuf<unsigned long long> nkeys, nkeys_s; DevBuf<uint32_t> nvals, nvals_s;   // node-major lists (keys: 32 bits each when name rank + row index fit, else 64)
     DevBuf<float> edge;
     DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
     DevBuf<uint8_t> hap_status, hap_nps, v_role, v_derive, v_tkind, read_hp; DevBuf<int32_t> site, t_end, t_len, t_pair_site, t_pair_read, t_win_site; DevBuf<uint8_t> t_hp, t_has, t_pair_hp, t_win_allele, t_win_base; DevBuf<int16_t> t_win_off; DevBuf<unsigned long long> t_ctr; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1, hap_d2; bool has_somatic = false;
@@ -221,7 +223,7 @@ void *lps_stream(lps_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int lps_begin_chromosome(lps_ctx *c) {
     if (!c) return -1;
     c->nV = 0; c->last_pos = -1; c->ref_len = c->ref_len_eff = 0; c->nR = 0; c->n_cig = c->n_seq = c->n_qual = 0; c->n_blob = 0; c->read_mode = 0; c->cur_first = -1; c->cur_count = 0;
-    c->phase_valid = false; c->has_hap = false; c->h_vpos.clear(); c->vpos_on_device_only = false; c->name_max = 0;
+    c->phase_valid = false; c->has_hap = false; c->h_vpos.clear(); c->vpos_on_device_only = false; c->name_max = 0; c->sq_reads = -1;
     c->nX = c->nSV = c->nMOD = 0; c->h_snp_u.clear(); c->h_sv_u.clear(); c->h_mod_u.clear(); c->votes_h1.clear(); c->votes_h2.clear();
     return 0;
 }
@@ -832,11 +834,38 @@ static VarView var_view(lps_ctx *c) {
     V.n_bucket = (int)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 1; V.bucket = c->v_bucket.p; V.rec = c->v_rec.p;
     return V;
 }
+// the interleaved base + quality blocks of the resident alignments (lps_prepare_reads; lps_phase_chromosome builds them itself when the caller did not)
+static int prepare_reads(lps_ctx *c) {
+    if (c->sq_reads == c->nR || c->nR == 0) return 0;
+    hipStream_t s = c->stream; const int n = c->nR;
+    ReadView R{}; R.n = n; R.l_qseq = c->r_lq.p; R.seq_off = c->r_soff.p; R.qual_off = c->r_qoff.p;
+    if (c->read_mode == 2) R.seq = R.qual = c->blob.p; else if (c->read_mode == 3) R.seq = R.qual = c->file.p; else { R.seq = c->seq.p; R.qual = c->qual.p; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    struct Ev { hipEvent_t a, b; ~Ev() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } guard{e0, e1};
+    HIP_TRY(hipEventRecord(e0, s));
+    c->sq_cnt.reserve((size_t)n + 2); c->r_sqblk.reserve((size_t)n + 2);
+    launch_sq_count(n, c->r_lq.p, c->sq_cnt.p, s);
+    const size_t need = GraphTemp::need((size_t)n + 2);
+    if (need > c->temp_bytes) { c->temp.reserve(need); c->temp_bytes = need; }
+    exscan_u32(c->temp.p, c->temp_bytes, c->sq_cnt.p, c->r_sqblk.p, (size_t)n + 1, s);
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, c->r_sqblk.p + n, sizeof total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->sq.reserve((size_t)total * 128 + 128);
+    launch_sq_pack(R, c->r_sqblk.p, c->sq.p, s);
+    HIP_TRY(hipEventRecord(e1, s)); HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipEventElapsedTime(&c->sq_ms, e0, e1));
+    c->sq_reads = n;
+    return 0;
+}
+
 static ReadView read_view(lps_ctx *c) {
     ReadView R{};
     R.n = c->nR; R.ref_start = c->r_start.p; R.l_qseq = c->r_lq.p; R.flag = c->r_flag.p; R.mapq = c->r_mapq.p; R.name_id = c->r_name.p;
     R.cigar_off = c->r_coff.p; R.seq_off = c->r_soff.p; R.qual_off = c->r_qoff.p; R.cigar = c->cigar.p;
     if (c->read_mode == 2) R.seq = R.qual = c->blob.p; else if (c->read_mode == 3) R.seq = R.qual = c->file.p; else { R.seq = c->seq.p; R.qual = c->qual.p; }
+    R.sq = c->sq.p; R.sq_blk = c->r_sqblk.p;
     return R;
 }
 
@@ -844,57 +873,48 @@ static ReadView read_view(lps_ctx *c) {
 // true runs them again with the CNV mismatch filter after clearing what they accumulate (tail of the zero pool, late counters).
 static int run_late(lps_ctx *c, bool with_cnv) {
     hipStream_t s = c->stream; const lps_params &P = c->P; const int nR = c->nR, nV = c->nG, A = P.connect_adjacent;   // nV here: rows of the table the graph runs on (SNP rows, or the union with SV / MOD rows)
-    {
-        if (with_cnv) {
-            HIP_TRY(hipMemsetAsync(c->zpool.p + c->z_late_off, 0, c->z_late_bytes, s));
-            HIP_TRY(hipMemsetAsync(&c->d_cnt->n_pairs, 0, offsetof(LpsCounters, arena_max) - offsetof(LpsCounters, n_pairs), s));
-            HIP_TRY(hipMemsetAsync(c->clip_stats.p + 2, 0, 2 * sizeof(unsigned), s));
-        }
-        // ---- a9 CNV mismatch filter: only when intervals exist (the count arrived while the kernels above were running)
-        mark(c, ST_CNV);
-        c->cnv_skipped = !with_cnv;
-        if (with_cnv) {
-            const size_t K = c->h_cnv_start.size();
-            const size_t need = (4 * K + 4) * sizeof(int32_t);             // pinned staging [n_cnv | start x2 | end x2]: every interval twice, as the reference's cnvVec holds them
-            if (need > c->h_cnv_pin_bytes) { if (c->h_cnv_pin) HIP_TRY(hipHostFree(c->h_cnv_pin)); c->h_cnv_pin = nullptr; c->h_cnv_pin_bytes = need * 2; HIP_TRY(hipHostMalloc((void **)&c->h_cnv_pin, c->h_cnv_pin_bytes)); }
-            int32_t *two = c->h_cnv_pin + 4;
-            c->h_cnv_pin[0] = (int32_t)(2 * K);
-            for (size_t i = 0; i < K; ++i) { two[i] = two[K + i] = c->h_cnv_start[i]; two[2 * K + i] = two[3 * K + i] = c->h_cnv_end[i]; }
-            c->cnv_start.reserve(4 * K + 4); c->cnv_end.carve(c->cnv_start.p + 2 * K, 2 * K);
-            HIP_TRY(hipMemcpyAsync(c->cnv_start.p, two, 4 * K * sizeof(int32_t), hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemcpyAsync(&c->d_cnt->n_cnv, c->h_cnv_pin, sizeof(unsigned), hipMemcpyHostToDevice, s));
-            c->agg_sum.reserve((size_t)nV * 2 + 2); c->agg_cnt.reserve((size_t)nV * 2 + 2); c->miss.reserve(nV + 1);
-            c->cnv_flag.reserve(nR + 1); c->cnv_idx.reserve(nR + 1); c->cnv_list.reserve(nR + 1); c->cnv_nlist.reserve(4);
-            c->cnv_fn.reserve(nR + 1); c->cnv_pre.reserve(nR + 1);
-            CnvScratch W{c->cnv_flag.p, c->cnv_idx.p, c->cnv_list.p, c->cnv_nlist.p, c->cnv_fn.p, c->cnv_pre.p};
-            launch_cnv_filter(c->d_cnt, nR, nV, c->rows.p, c->deleted.p, c->obs.p, c->g_vpos, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, W, c->temp.p, c->temp_bytes, s);
-        }
-        // ---- a10 nodes + graph observations
-        mark(c, ST_NODES);
-        launch_nodes(nR, nV, c->rows.p, c->deleted.p, c->obs.p, c->is_node.p, c->vtype_key.p, c->node_of.p, c->nodes.p, c->ntype.p, P.base_quality, c->g_node.p, c->g_flag.p, c->g_pack.p, c->g_rank.p, c->g_cnt.p, c->d_cnt, c->node_end.p, c->temp.p, c->temp_bytes, s);
-        // ---- merged rows
-        mark(c, ST_MERGE);
-        launch_merge_rows(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->rows.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->late_cap_main, c->late_tail, c->mrow_off.p, c->mrow_cnt.p, c->multi_list.p, c->g_pack.p, c->t_src.p, s);
-        // ---- node-major sorted lists
-        mark(c, ST_NODELISTS);
-        c->m_bits = bits_for((unsigned long long)nR + 1); c->n_bits = bits_for((unsigned long long)nV + 2);
-        c->a_bits = bits_for(2ull * (unsigned long long)nV + 2);        // index inside a merged row: a row holds every variant once per alignment of the read at most, and overlapping alignments are rare pairs
-        if (c->m_bits + c->n_bits + c->a_bits > 63) { c->err = "sort key overflow"; return -4; }
-        c->nkeys.reserve(c->late_n_keys + 1); c->nkeys_s.reserve(c->late_n_keys + 1); c->nvals.reserve(c->late_n_keys + 1); c->nvals_s.reserve(c->late_n_keys + 1);
-        launch_node_lists(c->d_cnt, nR, nV, c->rows.p, c->g_cnt.p, c->read_group.p, c->gstart.p, c->mrow_off.p, c->mrow_cnt.p, c->multi_list.p, c->g_node.p, c->g_rank.p, c->t_src.p,
-                          (uint32_t)c->late_cap_main, c->a_bits, c->nkeys.p, c->nvals.p, c->node_off.p, c->node_end.p, c->temp.p, c->temp_bytes, s);
-        // ---- a11/a12 edges
-        mark(c, ST_EDGES);
-        launch_edges(c->d_cnt, nV, c->node_off.p, c->node_end.p, c->nkeys.p, c->nvals.p, c->nkeys_s.p, c->nvals_s.p, c->mrow_off.p, c->mrow_cnt.p, c->m_bits, c->a_bits, c->g_pack.p, (uint32_t)c->late_cap_main, A, P.edge_weight, P.edge_threshold, c->ntype.p, c->edge.p, c->erec.p, c->node_pairs.p, s);
-        // ---- a13 vote scan
-        mark(c, ST_SCAN);
-        launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->g_vpos, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2, c->hp.p, c->block.p, c->nX ? 2 : 1, s);
-        // ---- a14/a15 read correction + export
-        mark(c, ST_CORR);
-        launch_correction(c->d_cnt, nR, nV, c->rows.p, c->g_cnt.p, c->g_node.p, c->g_flag.p, c->nodes.p, c->g_vpos, c->block.p, c->bsize.p, c->hp.p, c->ntype.p, c->node_pairs.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
-        mark(c, ST_D2H);
-        return 0;                                                          // counters + statistics leave with the result (enqueue_result_copy)
+    const GraphView &G = c->G;
+    if (with_cnv) {
+        HIP_TRY(hipMemsetAsync(c->zpool.p + c->z_late_off, 0, c->z_late_bytes, s));
+        HIP_TRY(hipMemsetAsync(&c->d_cnt->n_pairs, 0, offsetof(LpsCounters, arena_max) - offsetof(LpsCounters, n_pairs), s));
+        HIP_TRY(hipMemsetAsync(c->clip_stats.p + 2, 0, 2 * sizeof(unsigned), s));
     }
+    // ---- a9 CNV mismatch filter: only when intervals exist (the count arrived while the kernels above were running)
+    mark(c, ST_CNV);
+    c->cnv_skipped = !with_cnv;
+    if (with_cnv) {
+        const size_t K = c->h_cnv_start.size();
+        const size_t need = (4 * K + 4) * sizeof(int32_t);             // pinned staging [n_cnv | start x2 | end x2]: every interval twice, as the reference's cnvVec holds them
+        if (need > c->h_cnv_pin_bytes) { if (c->h_cnv_pin) HIP_TRY(hipHostFree(c->h_cnv_pin)); c->h_cnv_pin = nullptr; c->h_cnv_pin_bytes = need * 2; HIP_TRY(hipHostMalloc((void **)&c->h_cnv_pin, c->h_cnv_pin_bytes)); }
+        int32_t *two = c->h_cnv_pin + 4;
+        c->h_cnv_pin[0] = (int32_t)(2 * K);
+        for (size_t i = 0; i < K; ++i) { two[i] = two[K + i] = c->h_cnv_start[i]; two[2 * K + i] = two[3 * K + i] = c->h_cnv_end[i]; }
+        c->cnv_start.reserve(4 * K + 4); c->cnv_end.carve(c->cnv_start.p + 2 * K, 2 * K);
+        HIP_TRY(hipMemcpyAsync(c->cnv_start.p, two, 4 * K * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(&c->d_cnt->n_cnv, c->h_cnv_pin, sizeof(unsigned), hipMemcpyHostToDevice, s));
+        c->agg_sum.reserve((size_t)nV * 2 + 2); c->agg_cnt.reserve((size_t)nV * 2 + 2); c->miss.reserve(nV + 1);
+        c->cnv_flag.reserve(nR + 1); c->cnv_idx.reserve(nR + 1); c->cnv_list.reserve(nR + 1); c->cnv_nlist.reserve(4);
+        c->cnv_fn.reserve(nR + 1); c->cnv_pre.reserve(nR + 1);
+        CnvScratch W{c->cnv_flag.p, c->cnv_idx.p, c->cnv_list.p, c->cnv_nlist.p, c->cnv_fn.p, c->cnv_pre.p};
+        launch_cnv_filter(c->d_cnt, nR, nV, c->rows.p, c->deleted.p, c->obs.p, c->g_vpos, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, W, c->var_del2.p, c->temp.p, c->temp_bytes, s);
+    }
+    // ---- a10 node set (numbered before the host looked at the counters when no CNV filter was expected), graph view of the rows, node-major lists,
+    //      merged rows of reads with several alignments
+    mark(c, ST_NODES);
+    if (!c->scan_done) launch_var_scan(G, s);
+    c->scan_done = false;
+    launch_graph_rows(G, P.base_quality, c->a_bits, c->key64, c->h_cnt.n_multi, s);
+    // ---- a11/a12 edges
+    mark(c, ST_EDGES);
+    launch_edges(G, c->m_bits, c->a_bits, c->key64, P.edge_weight, P.edge_threshold, s);
+    // ---- a13 vote scan
+    mark(c, ST_SCAN);
+    launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->g_vpos, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2, c->hp.p, c->block.p, c->bmulti.p, c->nX ? 2 : 1, s);
+    // ---- a14/a15 read correction + export
+    mark(c, ST_CORR);
+    launch_correction(G, c->block.p, c->bmulti.p, c->hp.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
+    mark(c, ST_D2H);
+    return 0;                                                          // counters + statistics leave with the result (enqueue_result_copy)
 }
 
 static int run_phase(lps_ctx *c) {
@@ -902,10 +922,13 @@ static int run_phase(lps_ctx *c) {
     const int nR = c->nR, nV = c->nV, A = P.connect_adjacent;
     const int nG = c->nG = c->nV + c->nX;                                      // rows of the table the stages after the extraction run on
     c->g_vpos = c->nX ? c->u_pos.p : c->v_pos.p;
+    // read names: the stages below index by name, so the ids must be dense.  The CLI and the bench hand over ranks; anything sparser is ranked here
+    const bool dense = (unsigned long long)c->name_max < 4ull * (unsigned long long)nR + 65536ull;
+    c->name_cap = dense ? (size_t)c->name_max + 1 : (size_t)nR;
     // ---- capacities
     if (c->obs_capacity == 0) c->obs_capacity = std::max<unsigned long long>(64 * 1024, (unsigned long long)nR * 64);
     for (int attempt = 0; attempt < 3; ++attempt) {
-        const int n_blocks = (nR + 15) / 16;                                  // k_extract_phase: 4 waves x 4 alignments per workgroup
+        const int n_blocks = (nR + 3) / 4;                                    // k_extract_phase: a wave of 4 alignments per workgroup
         const int n_arenas = std::max(1, std::min(LPS_ARENAS, n_blocks));
         c->obs_capacity = (c->obs_capacity + n_arenas - 1) / n_arenas * n_arenas;
         const unsigned long long cap_main = c->obs_capacity, arena_size = cap_main / n_arenas, tail_size = cap_main / 4 + 4096;
@@ -913,16 +936,18 @@ static int run_phase(lps_ctx *c) {
         if (cap > 0xffffffffull) { c->err = "observation arena exceeds 2^32 slots"; return -8; }
         c->rows.reserve(nR + 4); c->redo_list.reserve((size_t)nR / 4 + 4);
         c->g_cnt.reserve(nR + 1);
-        c->obs.reserve(cap); c->g_node.reserve(cap); c->g_flag.reserve(cap); c->g_pack.reserve(cap); c->g_rank.reserve(cap); c->t_src.reserve(tail_size + 64);
+        c->obs.reserve(cap); c->g_pack.reserve(cap); c->g_rank.reserve(cap);
+        c->t_node.reserve(tail_size + 64); c->t_flag.reserve(tail_size + 64); c->t_src.reserve(tail_size + 64);
         c->clip_capacity = (size_t)4 * nR + 64;                             // clip events (an alignment has two real clips at most; more only with H S ... S H)
         c->clip_ev.reserve(c->clip_capacity);
         c->clip_keys.reserve(c->clip_capacity); c->clip_keys_s.reserve(c->clip_capacity);
-        c->name_keys.reserve(nR + 1); c->name_keys_s.reserve(nR + 1);
-        c->head.reserve(nR + 1); c->gidx.reserve(nR + 1); c->gstart.reserve(nR + 2); c->read_group.reserve(nR + 1); c->stack.reserve(nR + 1);
-        c->mrow_off.reserve(nR + 1); c->koff.reserve(nR + 1);
-        c->node_of.reserve(nG + 1); c->node_off.reserve(nG + 2); c->multi_list.reserve(nR + 1);
+        c->name_link.reserve(nR + 1); c->mm_r.reserve(nR + 1); c->stack.reserve(nR + 1);
+        c->mg_start.reserve(nR / 2 + 2); c->mg_cnt.reserve(nR / 2 + 2); c->mg_name.reserve(nR / 2 + 2); c->mg_plan.reserve(nR / 2 + 2);
+        c->mrow_off.reserve(c->name_cap + 1); c->mrow_cnt.reserve(c->name_cap + 1);
+        c->node_of.reserve(nG + 1); c->var_off.reserve(nG + 1); c->node_off.reserve(nG + 2); c->node_cap.reserve(nG + 2); c->node_end.reserve(nG + 2);
+        c->bsum.reserve(3 * ((size_t)nG / 1024 + 2));
         c->nodes.reserve(nG + 1); c->block.reserve(nG + 1);
-        c->ntype.reserve(nG + 1); c->hp.reserve(nG + 1);
+        c->hp.reserve(nG + 1);
         c->erec.reserve((size_t)nG * A + 256);
         c->hp_v.reserve(2 * ((size_t)nG + 64)); c->blk_v.reserve(2 * ((size_t)nG + 64)); c->seg_i32.reserve(4 * (size_t)scan_segments(nG) + 4); c->node_pairs.reserve(nG + 1); c->nstate.reserve(nG + 1);
         c->st_b.reserve(scan_state_bytes(nG)); c->st_e.reserve(scan_state_bytes(nG)); c->edge.reserve((size_t)nG * A * 4 + 16);
@@ -930,15 +955,17 @@ static int run_phase(lps_ctx *c) {
         size_t zbytes = 0;
         auto zslot = [&](size_t bytes) { const size_t at = zbytes; zbytes += (bytes + 255) & ~(size_t)255; return at; };
         const size_t z_arena = zslot(LPS_ARENAS * 8 * sizeof(unsigned long long)), z_del = zslot((size_t)nR + 1), z_stats = zslot(4 * sizeof(unsigned)),
-                     z_ps = zslot(((size_t)nG + 1) * 4), z_gt = zslot((size_t)nG + 1), z_isn = zslot(((size_t)nG + 1) * 4), z_vtk = zslot(((size_t)nG + 1) * 4), z_mrc = zslot(((size_t)nR + 1) * 4),
-                     z_nend = zslot(((size_t)nG + 2) * 4), z_ncur = zslot(((size_t)nG + 2) * 4), z_bs = zslot(((size_t)nG + 1) * 4), z_c4 = zslot(((size_t)nG * 4 + 4) * 4);
+                     z_vc = zslot(((size_t)nG + 1) * 4), z_vd = zslot(((size_t)nG + 1) * 4), z_nh = zslot((c->name_cap + 2) * 4),
+                     z_ps = zslot(((size_t)nG + 1) * 4), z_gt = zslot((size_t)nG + 1), z_vd2 = zslot(((size_t)nG + 1) * 4), z_vtk = zslot(((size_t)nG + 1) * 4),
+                     z_bm = zslot((size_t)nG + 1), z_c4 = zslot(((size_t)nG * 4 + 4) * 4);
         c->zpool.reserve(zbytes);
         c->z_late_off = z_ps; c->z_late_bytes = zbytes - z_ps;       // what the stages after the overlap filter need zeroed (see run_late)
         c->arena_ctr.carve(c->zpool.p + z_arena, LPS_ARENAS * 8); c->out_ps.carve(c->zpool.p + z_ps, (size_t)nG + 1); c->out_gt.carve(c->zpool.p + z_gt, (size_t)nG + 1);
-        c->deleted.carve(c->zpool.p + z_del, (size_t)nR + 1); c->clip_stats.carve(c->zpool.p + z_stats, 4); c->is_node.carve(c->zpool.p + z_isn, (size_t)nG + 1); c->vtype_key.carve(c->zpool.p + z_vtk, (size_t)nG + 1);
-        c->mrow_cnt.carve(c->zpool.p + z_mrc, (size_t)nR + 1); c->node_end.carve(c->zpool.p + z_nend, (size_t)nG + 2); c->node_cur.carve(c->zpool.p + z_ncur, (size_t)nG + 2);
-        c->bsize.carve(c->zpool.p + z_bs, (size_t)nG + 1); c->cnt4.carve(c->zpool.p + z_c4, (size_t)nG * 4 + 4);
-        const size_t need = GraphTemp::need((size_t)std::max<unsigned long long>(cap, (unsigned long long)std::max(nR, nG) + 1));
+        c->deleted.carve(c->zpool.p + z_del, (size_t)nR + 1); c->clip_stats.carve(c->zpool.p + z_stats, 4);
+        c->var_cnt.carve(c->zpool.p + z_vc, (size_t)nG + 1); c->var_del.carve(c->zpool.p + z_vd, (size_t)nG + 1); c->name_head.carve(c->zpool.p + z_nh, c->name_cap + 2);
+        c->var_del2.carve(c->zpool.p + z_vd2, (size_t)nG + 1); c->vtype_key.carve(c->zpool.p + z_vtk, (size_t)nG + 1);
+        c->bmulti.carve(c->zpool.p + z_bm, (size_t)nG + 1); c->cnt4.carve(c->zpool.p + z_c4, (size_t)nG * 4 + 4);
+        const size_t need = GraphTemp::need((size_t)std::max(nR, nG) + 1);
         if (need > c->temp_bytes) { c->temp.reserve(need); c->temp_bytes = need; }
 
         for (auto &u : c->ev_used) u = false;
@@ -951,36 +978,59 @@ static int run_phase(lps_ctx *c) {
         VarView V = var_view(c); ReadView R = read_view(c);
         mark(c, ST_PREP);
         launch_variant_prep(V, P.is_ont, c->v_bucket.p, c->v_rec.p, s);
-        // ---- a1/a2/a3 extraction
+        if (!dense) {
+            c->name_keys.reserve(nR + 1); c->name_keys_s.reserve(nR + 1); c->head.reserve(nR + 1); c->gidx.reserve(nR + 1); c->name_dense.reserve(nR + 1);
+            launch_dense_names(nR, c->r_name.p, c->name_max, c->name_keys.p, c->name_keys_s.p, c->head.p, c->gidx.p, c->name_dense.p, c->temp.p, c->temp_bytes, s);
+        }
+        c->name_p = dense ? c->r_name.p : c->name_dense.p;
+        // ---- a1/a2/a3 extraction; with no SV / MOD rows every observation is counted (and ranked inside its variant's list) right there
         ObsView O{c->rows.p, c->obs.p, arena_size, c->arena_ctr.p, n_arenas};
         ClipView C{c->clip_ev.p, c->clip_stats.p, (unsigned)c->clip_capacity};            // clip_stats[0]: events appended, [1]: jobs queued for k_extract_redo (zero pool)
         mark(c, ST_EXTRACT);
-        launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, c->redo_list.p, c->clip_stats.p + 1, s);
+        launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, c->redo_list.p, c->clip_stats.p + 1, c->nX ? nullptr : c->var_cnt.p, c->var_del.p, s);
         // ---- SV / MOD rows: served against each alignment's CIGAR, merged into its row; every observation leaves in union indices
         if (c->nX) {
             ExtraView X{c->nX, c->x_pos.p, c->x_info.p, c->x_kind.p, c->x_u.p, c->x_snp_u.p, c->x_moff.p, c->x_mname.p, c->x_mflag.p, c->sv_window, c->sv_threshold};
             launch_extra_merge(V, R, O, X, P.mapping_quality, c->d_cnt, s);
         }
-        // ---- name keys (needs only row_cnt) and clip keys; the counters (sizes of the sorts, errors) start their way to the host ...
+        GraphView &G = c->G;
+        G = GraphView{};
+        G.n_reads = nR; G.n_var = nG; G.A = A; G.rows = c->rows.p; G.obs = c->obs.p; G.deleted = c->deleted.p; G.vpos = c->g_vpos; G.name = c->name_p;
+        G.name_head = c->name_head.p; G.name_link = c->name_link.p; G.mm_r = c->mm_r.p; G.stack = c->stack.p; G.mg_start = c->mg_start.p; G.mg_cnt = c->mg_cnt.p; G.mg_name = c->mg_name.p; G.mg_plan = c->mg_plan.p;
+        G.var_cnt = c->var_cnt.p; G.var_del = c->var_del.p; G.var_del2 = c->var_del2.p; G.vtype_key = c->vtype_key.p; G.bsum = c->bsum.p;
+        G.node_of = c->node_of.p; G.var_off = c->var_off.p; G.nodes = c->nodes.p; G.node_off = c->node_off.p; G.node_cap = c->node_cap.p; G.node_end = c->node_end.p;
+        G.g_pack = c->g_pack.p; G.g_rank = c->g_rank.p; G.g_cnt = c->g_cnt.p; G.mrow_off = c->mrow_off.p; G.mrow_cnt = c->mrow_cnt.p;
+        G.t_node = c->t_node.p; G.t_flag = c->t_flag.p; G.t_src = c->t_src.p; G.tail_lo = cap_main; G.tail_size = tail_size;
+        G.edge = c->edge.p; G.erec = c->erec.p; G.node_pairs = c->node_pairs.p; G.cnt = c->d_cnt;
+        // ---- read names linked into lists, clip keys, reservation totals: one launch; then the groups of several alignments and their overlap filter (a8)
         mark(c, ST_GROUPS);
-        launch_name_keys(nR, c->r_name.p, c->rows.p, c->name_keys.p, c->d_cnt, c->arena_ctr.p, arena_size, s);
-        launch_clip_keys(C, c->rows.p, nR, c->clip_keys.p, c->d_cnt, s);
+        launch_names(G, C, c->clip_keys.p, c->arena_ctr.p, arena_size, s);
+        mark(c, ST_OVERLAP);
+        launch_groups(G, P.overlap_threshold, /*counted=*/!c->nX, s);
+        if (c->nX) launch_count_ranks(G, s);
+        // ---- the counters (sizes of what follows, errors) go to the host; the node numbering does not need them and keeps the GPU busy meanwhile
+        //      (unless the CNV filter is expected to drop observations first)
         HIP_TRY(hipMemcpyAsync(c->h_cnt_pin, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(c->ev_cnv, s));
-        // ---- ... while the GPU sorts the names into groups and runs the overlap filter (a8): no bubble when the host looks at them
-        mark(c, ST_GROUPS2);
-        // keys are (name rank << 32 | alignment index), written in index order: a STABLE sort by the name digits alone leaves equal names in index
-        // order, so only the bits of the largest rank are sorted (3 digit passes for chr20 instead of 8); one more value than name_max so that the
-        // all-ones sentinel of alignments without observations stays above every name
-        sort_keys64_range(c->temp.p, c->temp_bytes, c->name_keys.p, c->name_keys_s.p, nR, 32, 32 + bits_for((unsigned long long)c->name_max + 2), s);
-        launch_groups(c->name_keys_s.p, nR, c->d_cnt, c->head.p, c->gidx.p, c->gstart.p, c->read_group.p, c->temp.p, c->temp_bytes, s);
-        mark(c, ST_OVERLAP);
-        launch_overlap_filter(c->name_keys_s.p, c->gstart.p, c->d_cnt, nR, c->rows.p, c->obs.p, c->g_vpos, P.overlap_threshold, c->stack.p, c->deleted.p, s);
+        c->scan_done = !c->cnv_expect;
+        if (c->scan_done) launch_var_scan(G, s);
         HIP_TRY(hipEventSynchronize(c->ev_cnv));
         c->h_cnt = *c->h_cnt_pin;
         if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) { c->err = "alignment find unsupported CIGAR operation"; return -2; }
         if (c->h_cnt.err & LPS_ERR_CLIP_OVERFLOW) { c->err = "clip event buffer overflow"; return -3; }
         if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = (unsigned long long)n_arenas * (c->h_cnt.arena_max + c->h_cnt.arena_max / 4 + 1024); continue; }
+        // keys of the node-major lists: (read name, index in the read's merged row).  The index field is sized by what the rows actually hold - the
+        // longest row times the most alignments under one name - so that for real data name rank + index fit ONE 32-bit word (half the entry
+        // bytes, one compare per rank step in k_edges); 64-bit keys otherwise
+        c->m_bits = bits_for((unsigned long long)c->name_cap + 1);
+        c->a_bits = bits_for((unsigned long long)std::max(1u, c->h_cnt.max_row) * (unsigned long long)std::max(1u, c->h_cnt.max_group) + 1);
+        c->key64 = c->m_bits + c->a_bits > 31;
+        if (c->m_bits + c->a_bits > 63) { c->err = "sort key overflow"; return -4; }
+        c->late_n_keys = c->h_cnt.obs_total;
+        c->nkeys.reserve(c->late_n_keys / (c->key64 ? 1 : 2) + 2); c->nkeys_s.reserve(c->late_n_keys / (c->key64 ? 1 : 2) + 2); c->nvals.reserve(c->late_n_keys + 1); c->nvals_s.reserve(c->late_n_keys + 1);
+        G.ukeys = c->nkeys.p; G.skeys = c->nkeys_s.p; G.uvals = c->nvals.p; G.svals = c->nvals_s.p;
+        // places in the lists that no row will ever fill (observations of a job that went to the general walker after they were counted: malformed records)
+        if (c->h_cnt.n_abandoned) HIP_TRY(hipMemsetAsync(c->nkeys.p, 0xff, (size_t)c->late_n_keys * (c->key64 ? 8 : 4), s));
         // ---- a7 clips -> CNV intervals: the keys are sorted here and travel to the host (pinned), which replays the state machine (replay_cnv)
         mark(c, ST_CLIP);
         launch_clip_sort(c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, s);
@@ -990,7 +1040,7 @@ static int run_phase(lps_ctx *c) {
         HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_sorted, 0));      // the copy rides on its own stream: the late stages do not queue behind it
         if (nk) HIP_TRY(hipMemcpyAsync(c->h_clip_keys, c->clip_keys_s.p, nk * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->copy_stream));
         HIP_TRY(hipEventRecord(c->ev_clip, c->copy_stream));
-        c->late_n_keys = c->h_cnt.obs_total; c->late_cap_main = cap_main; c->late_tail = tail_size;
+        c->late_cap_main = cap_main; c->late_tail = tail_size;
         c->h_ub_hazard = nk == 0 ? 1u : 0u;                               // reference: UB on an empty ClipCount (PhasingGraph.cpp:1134)
         // ---- everything after.  Usually the clips give no CNV interval, so the late stages are enqueued on that guess and the host replays the state
         //      machine meanwhile; lps_phase_chromosome runs them again with the filter if the guess was wrong.  When the previous run of this ctx did
@@ -1031,6 +1081,17 @@ static void deliver_result(lps_ctx *c, lps_phase_result *out) {
     for (int i = 0; i < c->nV; ++i) { out->phase_set[i] = ps[c->h_snp_u[i]]; out->gt[i] = gt[c->h_snp_u[i]]; }
 }
 
+int lps_prepare_reads(lps_ctx *c, double *ms) {
+    if (!c) return -1;
+    try {
+        HIP_TRY(hipSetDevice(c->device));
+        const bool had = c->sq_reads == c->nR;
+        if (prepare_reads(c) != 0) return -1;
+        if (ms) *ms = had ? 0.0 : (double)c->sq_ms;
+    } catch (std::string &e) { return fail(c, e); }
+    return 0;
+}
+
 int lps_debug_set_obs_capacity(lps_ctx *c, int64_t slots) {
     if (!c || slots < 0) return -1;
     c->obs_capacity = (unsigned long long)slots;
@@ -1052,6 +1113,7 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         c->phase_valid = false; c->h_res_ps_u.clear(); c->h_res_gt_u.clear();
         if (c->nV == 0 || c->nR == 0) { c->phase_valid = c->nV != 0; return 0; }
         if (c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
+        if (prepare_reads(c) != 0) return -1;
         c->in_phase = true;
         int rc = run_phase(c);
         c->in_phase = false;
@@ -1069,7 +1131,7 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
             c->h_cnt = *c->h_cnt_pin; memcpy(c->h_stats, c->h_stats_pin, sizeof c->h_stats);
         }
         if (c->h_cnt.err & LPS_ERR_OBS_OVERFLOW) { c->obs_capacity = c->obs_capacity * 2 + 64 * 1024; return lps_phase_chromosome(c, out); }
-        if (c->h_cnt.err & LPS_ERR_KEY_RANGE) return fail(c, "a merged read holds more than twice as many observations as there are variants", -6);
+        if (c->h_cnt.err & LPS_ERR_KEY_RANGE) return fail(c, "more than 4 194 304 observations of one variant (the rank inside a variant's list is a 22-bit field)", -6);
         c->cnv_expect = !c->h_cnv_start.empty();
         deliver_result(c, out);
         // timings

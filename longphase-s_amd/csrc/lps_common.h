@@ -49,25 +49,32 @@ struct DevBuf {
 enum {
     LPS_ERR_BAD_CIGAR = 1,      // unsupported CIGAR op (reference: exit(1), ParsingBam.cpp:1625-1628)
     LPS_ERR_OBS_OVERFLOW = 2,   // observation buffer too small -> host grows and reruns
-    LPS_ERR_KEY_RANGE = 4,      // sort-key field overflow (row longer than 2^18 or >2^22 nodes)
+    LPS_ERR_KEY_RANGE = 4,      // more than 2^22 observations of one variant (the rank inside its list is a 22-bit field)
     LPS_ERR_CLIP_OVERFLOW = 16,
 };
 
 // device-side counters block (one per ctx), zeroed at the start of every run
 struct LpsCounters {
-    unsigned long long obs_total;   // reserved observation slots summed over the arenas (filled by the last workgroup of k_name_keys)
+    unsigned long long obs_total;   // reserved observation slots summed over the arenas (k_name_link's extra workgroup)
     unsigned int n_clips;
     unsigned int err;
     unsigned int n_kept;            // alignments with >=1 observation
-    unsigned int n_groups;          // distinct read names among kept alignments
-    unsigned int n_nodes;
+    unsigned int n_multi;           // read names with >= 2 such alignments (k_groups)
+    unsigned int mm_total;          // ... and how many alignments they hold together
+    unsigned int max_row;           // longest row (observations of one alignment)
+    unsigned int max_group;         // most alignments under one read name
     unsigned int n_cnv;
     unsigned int ub_hazard;
+    unsigned int n_nodes;
+    unsigned int n_abandoned;       // observations counted at the extraction whose job then went to the general walker (their list places are holes)
+    unsigned int pad0;
+    // ---- accumulated by the stages after the overlap filter (cleared when they run again with the CNV filter)
     unsigned long long n_pairs;
     unsigned long long n_obs_final; // observations of kept alignments after all filters
-    unsigned int n_multi;           // merged rows built from >=2 alignments
-    unsigned int pad;
     unsigned long long tail_total;  // slots reserved in the tail arena (merged rows of multi-alignment reads)
+    unsigned int n_merged;          // merged rows built from >=2 alignments
+    unsigned int pad;
+    // ----
     unsigned long long arena_max;   // largest per-arena reservation (capacity planning on overflow)
 };
 

@@ -90,7 +90,10 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 // ------------------------------------------------------------------------------------------------ extraction
 #define EXT_RPW 4       // alignments per wave (a "job"; the later per-row kernels walk the four rows of a job as one span)
 #ifndef EXT_TAB
-#define EXT_TAB 1536    // lane-chunks (8 CIGAR ops each) a wave keeps in LDS: 12 KB, i.e. 12 288 ops = ~300 kb of ONT read for the four alignments together
+#define EXT_TAB 1024    // lane-chunks (8 CIGAR words each) a wave keeps in LDS: 8 KB = 8 192 words, ~200 kb of ONT read; a job that holds more is walked in groups
+#endif
+#ifndef EXT_GROUP_MAX
+#define EXT_GROUP_MAX 4 // alignments walked together (their candidates are resolved together once their words are through)
 #endif
 #define EXT_CLIPS 16    // clip events buffered per wave
 
@@ -108,7 +111,7 @@ __device__ __forceinline__ int lane_var_lower_bound(const VarView &V, int key) {
 struct __attribute__((aligned(16))) ExtHdr {
     int crel, ncig, c0, nch;               // first CIGAR word (relative to the job's first), CIGAR words, first chunk in the table, chunks it touches
     int vadj, lq, ds, dq;                  // variant of flattened candidate i = vadj + i; l_qseq; stream - true reference coordinate; stream query coordinate of the read's first base
-    unsigned so_lo, so_hi, qo_lo, qo_hi;   // byte offsets of SEQ / QUAL
+    unsigned blk0, pad0, pad1, pad2;       // first block of the read's interleaved bases + qualities (lps_reads.hip)
 };
 
 // the c-th of four wave-uniform scalars, c = index of the first flattened candidate of alignments 1..3 (per-lane compare against thresholds)
@@ -142,8 +145,8 @@ __device__ __forceinline__ void advance_of(const uint32_t (&w)[8], int k, int &s
 // A job whose chunks do not fit the table (EXT_TAB), which holds more clip events than EXT_CLIPS, or in which get_snp's early return fires
 // (:1453-1455, :1559-1561: a record whose SEQ is shorter than its CIGAR) queues itself for k_extract_redo, the general walker, before it has
 // written anything a later stage looks at.
-__global__ __launch_bounds__(64) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
-                                                      LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo) {
+__global__ __launch_bounds__(64, 4) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
+                                                      LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint32_t *var_cnt, uint32_t *var_del) {
     __shared__ __attribute__((aligned(16))) int2 s_tab[EXT_TAB];
     __shared__ ExtHdr s_hdr[EXT_RPW];
     __shared__ ClipEv s_clip[EXT_CLIPS];
@@ -160,10 +163,10 @@ __global__ __launch_bounds__(64) void k_extract_phase(VarView V, ReadView R, Obs
     auto to_redo = [&]() __attribute__((always_inline)) { if (l == 0) redo_list[atomicAdd(n_redo, 1u)] = (uint32_t)job; };
 
     // ---- plan: headers, alignment q in lane q.  direct_detect_alleles filters (:1282-1291) + region "chr:1-<lastSNPPos>" (:1273)
-    int h_start = 0, h_lq = 0; bool h_live = false; unsigned long long h_coff = 0, h_soff = 0, h_qoff = 0;
+    int h_start = 0, h_lq = 0; bool h_live = false; unsigned long long h_coff = 0; unsigned h_blk = 0;
     if (l <= nq) h_coff = R.cigar_off[r0 + l];
     if (l < nq) {
-        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r]; h_qoff = R.qual_off[r];
+        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_blk = R.sq_blk[r];
         const int flag = R.flag[r];
         h_live = !(R.mapq[r] < mapping_quality || (flag & 0x4) || (flag & 0x100) || (flag & 0x400) || h_start >= V.last_pos);
     }
@@ -172,287 +175,325 @@ __global__ __launch_bounds__(64) void k_extract_phase(VarView V, ReadView R, Obs
         if (l < nq) O.rows[r0 + l] = RowDesc{0u, 0, 0x7fffffff, 0u};
         return;
     }
-    // the stream: from the first word of the first alignment that is walked to the last word of the last one (alignments in between that are
-    // not walked - low MAPQ, secondary - pass by as words that only move the coordinates on)
-    const int q_first = __builtin_ctz(live_mask), q_last = 31 - __builtin_clz(live_mask);
-    const unsigned long long c_lo = __shfl(h_coff, q_first);
-    const int h_rel = (l <= nq) ? (int)(long long)(h_coff - c_lo) : 0;  // word index of alignment q's first word inside the stream
-    const int h_ncig = __shfl_down(h_rel, 1) - h_rel;                  // (lanes < nq)
-    const uint32_t *cg = R.cigar + c_lo;
-    const int total = __builtin_amdgcn_readlane(h_rel + h_ncig, q_last);   // words of the stream
-    const int TC = (total + 7) >> 3;                                    // lane-chunks
-    if (TC > EXT_TAB) { to_redo(); return; }                            // very long alignments: the general walker takes the job
-    // UNCONDITIONAL loads, clamped to the stream (a load under a branch makes the compiler wait for every outstanding load where the paths join,
-    // i.e. for the request just made).  A lane's 8 words may run past the stream's end (DevBuf allocations carry 64 B of slack): the last round
-    // blanks those
-    auto request = [&](int cid, uint32_t (&w)[8]) __attribute__((always_inline)) {
-        const uint32_t *p = cg + 8 * min(cid, max(TC - 1, 0));
-        const LpsU4 a = *reinterpret_cast<const LpsU4 *>(p), b = *reinterpret_cast<const LpsU4 *>(p + 4);
-        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-    };
-    uint32_t pw[8];
-    request(l, pw);                                                     // round 0 is on its way while the first candidates are searched
+    const int h_ncig_all = (int)(long long)(__shfl_down(h_coff, 1) - h_coff);   // (lanes < nq)
+    // an alignment that alone does not fit the table: the general walker takes the job (checked before anything is written)
+    if (__ballot(l < nq && h_live && ((h_ncig_all + 7) >> 3) + 1 > EXT_TAB)) { to_redo(); return; }
     // first candidate of each alignment: four lanes search the position-sorted table side by side
     int h_v0 = 0;
     if (l < 4 && h_live) h_v0 = lane_var_lower_bound(V, h_start);
-    const bool h_walk = l < 4 && h_live && h_ncig > 0;
-    if (l < 4) {                                                        // (first half of the header: what the rare paths of the walk look at)
-        ExtHdr &h = s_hdr[l];
-        h.crel = h_rel; h.ncig = h_walk ? h_ncig : 0; h.c0 = h_rel >> 3; h.nch = h_walk ? ((h_rel + h_ncig - 1) >> 3) - (h_rel >> 3) + 1 : 0;
-        h.lq = h_lq; h.so_lo = (unsigned)h_soff; h.so_hi = (unsigned)(h_soff >> 32); h.qo_lo = (unsigned)h_qoff; h.qo_hi = (unsigned)(h_qoff >> 32);
-    }
-    wave_sync();
+    // what lane q collects for row q; clip events of the job (reference coordinates)
+    unsigned row_off = 0; int row_cnt = 0; unsigned row_flags = 0;
+    int n_clip = 0; bool fail = false, arena_full = false;
 
-    // ---- walk
-    int carry_r = 0, carry_q = 0, n_clip = 0;
+    // ---- the job's alignments in GROUPS whose CIGAR words fit the table together: nearly always one group of four
+    unsigned todo = live_mask;
 #pragma unroll 1
-    for (int R0 = 0; R0 < TC; R0 += 64) {
-        const int cid = R0 + l;
-        uint32_t w[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) w[k] = pw[k];
-        request(cid + 64, pw);
-        if (R0 + 64 >= TC) {                                            // last round: words past the stream's end count for nothing (6u: op P, length 0)
-            const int nv = total - 8 * cid;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) w[k] = k < nv ? w[k] : 6u;
+    while (todo) {
+        const int qa = __builtin_ctz(todo);
+        const unsigned long long c_lo = __shfl(h_coff, qa);
+        int qb = qa; unsigned gm = 1u << qa;
+        for (int q = qa + 1; q < nq; ++q) {
+            if (!((todo >> q) & 1u)) continue;
+            const long long span = (long long)(__shfl(h_coff, q + 1) - c_lo);
+            if (((span + 7) >> 3) > EXT_TAB || __popc(gm) >= EXT_GROUP_MAX) break;
+            gm |= 1u << q; qb = q;
         }
-        int rt = 0, qt = 0; unsigned seen = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const unsigned op = w[k] & 15u;
-            const unsigned t = op_consume_bits(op); const int len = (int)(w[k] >> 4);
-            rt += len & bit_mask(t, 0); qt += len & bit_mask(t, 16);
-            seen |= 1u << op;
-        }
-        const int ir = wave_incl_scan_dpp(rt), iq = wave_incl_scan_dpp(qt);
-        const int my_s = carry_r + ir - rt, my_q = carry_q + iq - qt;   // stream coordinates of the lane's first word
-        if (cid < TC) s_tab[cid] = make_int2(my_s, my_q);
-        carry_r += __builtin_amdgcn_readlane(ir, 63); carry_q += __builtin_amdgcn_readlane(iq, 63);
-        if ((unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu) { to_redo(); return; }   // stream coordinates are 32-bit: absurd spans go to the general walker
-        // ops the reference rejects (:1625-1628) and clips (getClip :1613-1620,1636-1645: soft/hard clips longer than 5; FRONT iff CIGAR index 0),
-        // both only in alignments that are walked.  Rare: a clipped alignment's first / last lane-chunk.  Events wait in LDS for the wave's one
-        // reservation, their position still in stream coordinates
-        if (__ballot((seen & (LPS_OPS_BAD | LPS_OPS_CLIP)) != 0u)) {
-            int mine_n = 0; bool bad = false; unsigned wq = 0;          // wq: 4 bits per word: its alignment + 1 (0: none that is walked)
-            int hr[4], hn[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { hr[q] = s_hdr[q].crel; hn[q] = s_hdr[q].ncig; }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int x = 8 * cid + k;
-                unsigned q1 = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) if (x >= hr[q] && x < hr[q] + hn[q]) q1 = q + 1;
-                wq |= q1 << (4 * k);
-                const unsigned op = w[k] & 15u;
-                if (q1) { bad |= op > 8u; mine_n += ((op == 4u || op == 5u) && (w[k] >> 4) > 5u) ? 1 : 0; }
-            }
-            if (__ballot(bad) && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
-            const int incl = wave_incl_scan_dpp(mine_n);
-            int slot = n_clip + incl - mine_n;
-            if (mine_n) {
-                int rr = my_s;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const unsigned op = w[k] & 15u; const int q = (int)((wq >> (4 * k)) & 15u) - 1;
-                    if (q >= 0 && (op == 4u || op == 5u) && (w[k] >> 4) > 5u) {
-                        const int oi = 8 * cid + k - SEL4(q, hr);
-                        if (slot < EXT_CLIPS) s_clip[slot] = ClipEv{rr, (oi << 1) | (oi != 0), q};
-                        ++slot;
-                    }
-                    rr += (int)(w[k] >> 4) & bit_mask(op_consume_bits(op), 0);
-                }
-            }
-            n_clip += __builtin_amdgcn_readlane(incl, 63);
-            if (n_clip > EXT_CLIPS) { to_redo(); return; }              // more clip ops than the buffer holds (H S ... S H chains)
-        }
-    }
-    wave_sync();
-
-    // ---- where each alignment begins and ends in stream coordinates: lane q takes the chunks that hold the first and the last word of
-    //      alignment q and sums the words in front of / up to them
-    int b_sat = 0, b_qat = 0, b_rend = h_start;
-    {
-        const int xe = h_rel + h_ncig - 1;
-        const int cs = h_walk ? h_rel >> 3 : 0, ce = h_walk ? xe >> 3 : 0;
-        const int ks = h_rel & 7, ke = (xe & 7) + 1;
-        uint32_t ws[8], we[8];
+        todo &= ~gm;
+        // the stream: from the first word of the group's first alignment to the last word of its last one (alignments in between that are not
+        // walked - low MAPQ, secondary - pass by as words that only move the coordinates on)
+        const bool h_in = l < 4 && ((gm >> l) & 1u);
+        const int h_rel = (l <= nq) ? (int)(long long)(h_coff - c_lo) : 0; // word index of alignment q's first word inside the stream
+        const int h_ncig = h_ncig_all;
+        const uint32_t *cg = R.cigar + c_lo;
+        const int total = __builtin_amdgcn_readlane(h_rel + h_ncig, qb);  // words of the stream
+        const int TC = (total + 7) >> 3;                                  // lane-chunks
+        // UNCONDITIONAL loads, clamped to the stream (a load under a branch makes the compiler wait for every outstanding load where the paths join,
+        // i.e. for the request just made).  A lane's 8 words may run past the stream's end (DevBuf allocations carry 64 B of slack): the last round
+        // blanks those
+        auto request = [&](int cid, uint32_t (&w)[8]) __attribute__((always_inline)) {
+            const uint32_t *p = cg + 8 * min(cid, max(TC - 1, 0));
+            const LpsU4 a = *reinterpret_cast<const LpsU4 *>(p), b = *reinterpret_cast<const LpsU4 *>(p + 4);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        };
+        uint32_t pw[8];
+        request(l, pw);                                                   // round 0 is on its way
+        const bool h_walk = h_in && h_ncig > 0;
+        // where an alignment begins and ends INSIDE its first / last lane-chunk: lane q sums the words in front of the first and up to the last
+        // word of alignment q now, while the walk's first round is in flight (the chunks' own coordinates come out of the walk)
+        const int x_end = h_rel + h_ncig - 1;
+        const int cs = h_walk ? h_rel >> 3 : 0, ce = h_walk ? x_end >> 3 : 0;
+        int adv_r = 0, adv_q = 0, end_r = 0;
         {
+            const int ks = h_rel & 7, ke = (x_end & 7) + 1;
             const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs), b = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs + 4);
             const LpsU4 c = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce), d = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce + 4);
-            ws[0] = a.x; ws[1] = a.y; ws[2] = a.z; ws[3] = a.w; ws[4] = b.x; ws[5] = b.y; ws[6] = b.z; ws[7] = b.w;
-            we[0] = c.x; we[1] = c.y; we[2] = c.z; we[3] = c.w; we[4] = d.x; we[5] = d.y; we[6] = d.z; we[7] = d.w;
-        }
-        const int2 ts = s_tab[cs], te = s_tab[ce];
-        int ar = 0, aq = 0, er = 0;
+            const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, we[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const unsigned t1 = op_consume_bits(ws[m] & 15u), t2 = op_consume_bits(we[m] & 15u);
-            const int l1 = m < ks ? (int)(ws[m] >> 4) : 0, l2 = m < ke ? (int)(we[m] >> 4) : 0;
-            ar += l1 & bit_mask(t1, 0); aq += l1 & bit_mask(t1, 16); er += l2 & bit_mask(t2, 0);
+            for (int m = 0; m < 8; ++m) {
+                const unsigned t1 = op_consume_bits(ws[m] & 15u), t2 = op_consume_bits(we[m] & 15u);
+                const int l1 = m < ks ? (int)(ws[m] >> 4) : 0, l2 = m < ke ? (int)(we[m] >> 4) : 0;
+                adv_r += l1 & bit_mask(t1, 0); adv_q += l1 & bit_mask(t1, 16); end_r += l2 & bit_mask(t2, 0);
+            }
         }
-        if (h_walk) { b_sat = ts.x + ar; b_qat = ts.y + aq; b_rend = h_start + te.x + er - b_sat; }
-    }
+        // ... and the positions of each alignment's first 64 candidate variants (counted against its reference end after the walk)
+        int v0q[4], pp[4]; bool walkq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v0q[q] = __builtin_amdgcn_readlane(h_v0, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; pp[q] = V.pos[min(v0q[q] + l, V.n - 1)]; }
+        if (l < 4) {                                                      // (first half of the header: what the rare paths of the walk look at)
+            ExtHdr &h = s_hdr[l];
+            h.crel = h_rel; h.ncig = h_walk ? h_ncig : 0; h.c0 = cs; h.nch = h_walk ? ce - cs + 1 : 0;
+            h.lq = h_lq; h.blk0 = h_blk;
+        }
+        wave_sync();
 
-    // ---- candidates of each alignment: variants [v0, first variant at or beyond the alignment's reference end)
-    int v0q[4], ncand[4], rend[4]; bool walkq[4];
+        // ---- walk
+        int carry_r = 0, carry_q = 0, n_clip0 = n_clip; bool give_up = false;
+#pragma unroll 1
+        for (int R0 = 0; R0 < TC; R0 += 64) {
+            const int cid = R0 + l;
+            uint32_t w[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { v0q[q] = __builtin_amdgcn_readlane(h_v0, q); rend[q] = __builtin_amdgcn_readlane(b_rend, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; }
-    {
-        int pp[4];
+            for (int k = 0; k < 8; ++k) w[k] = pw[k];
+            request(cid + 64, pw);
+            if (R0 + 64 >= TC) {                                          // last round: words past the stream's end count for nothing (6u: op P, length 0)
+                const int nv = total - 8 * cid;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pp[q] = V.pos[min(v0q[q] + l, V.n - 1)];           // four loads in flight together (unconditional: see `request`)
+                for (int k = 0; k < 8; ++k) w[k] = k < nv ? w[k] : 6u;
+            }
+            int rt = 0, qt = 0; unsigned seen = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned op = w[k] & 15u;
+                const unsigned t = op_consume_bits(op); const int len = (int)(w[k] >> 4);
+                rt += len & bit_mask(t, 0); qt += len & bit_mask(t, 16);
+                seen |= 1u << op;
+            }
+            const int ir = wave_incl_scan_dpp(rt), iq = wave_incl_scan_dpp(qt);
+            const int my_s = carry_r + ir - rt, my_q = carry_q + iq - qt; // stream coordinates of the lane's first word
+            if (cid < TC) s_tab[cid] = make_int2(my_s, my_q);
+            carry_r += __builtin_amdgcn_readlane(ir, 63); carry_q += __builtin_amdgcn_readlane(iq, 63);
+            if ((unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu) { give_up = true; break; }   // stream coordinates are 32-bit: absurd spans go to the general walker
+            // ops the reference rejects (:1625-1628) and clips (getClip :1613-1620,1636-1645: soft/hard clips longer than 5; FRONT iff CIGAR index 0),
+            // both only in alignments that are walked.  Rare: a clipped alignment's first / last lane-chunk.  Events wait in LDS for the wave's one
+            // reservation, their position in stream coordinates until the group is through
+            if (__ballot((seen & (LPS_OPS_BAD | LPS_OPS_CLIP)) != 0u)) {
+                int mine_n = 0; bool bad = false; unsigned wq = 0;        // wq: 4 bits per word: its alignment + 1 (0: none that is walked)
+                int hr[4], hn[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { hr[q] = s_hdr[q].crel; hn[q] = s_hdr[q].ncig; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int x = 8 * cid + k;
+                    unsigned q1 = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (x >= hr[q] && x < hr[q] + hn[q]) q1 = q + 1;
+                    wq |= q1 << (4 * k);
+                    const unsigned op = w[k] & 15u;
+                    if (q1) { bad |= op > 8u; mine_n += ((op == 4u || op == 5u) && (w[k] >> 4) > 5u) ? 1 : 0; }
+                }
+                if (__ballot(bad) && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
+                const int incl = wave_incl_scan_dpp(mine_n);
+                int slot = n_clip + incl - mine_n;
+                if (mine_n) {
+                    int rr = my_s;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const unsigned op = w[k] & 15u; const int q = (int)((wq >> (4 * k)) & 15u) - 1;
+                        if (q >= 0 && (op == 4u || op == 5u) && (w[k] >> 4) > 5u) {
+                            const int oi = 8 * cid + k - SEL4(q, hr);
+                            if (slot < EXT_CLIPS) s_clip[slot] = ClipEv{rr, (oi << 1) | (oi != 0), q};
+                            ++slot;
+                        }
+                        rr += (int)(w[k] >> 4) & bit_mask(op_consume_bits(op), 0);
+                    }
+                }
+                n_clip += __builtin_amdgcn_readlane(incl, 63);
+                if (n_clip > EXT_CLIPS) { give_up = true; break; }        // more clip ops than the buffer holds (H S ... S H chains)
+            }
+        }
+        if (give_up) {                                                    // (groups done before this one were counted: taken off as in the early-return case below)
+            if (var_cnt) {
+                unsigned gone = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)row_off, q); const int n = __builtin_amdgcn_readlane(row_cnt, q);
+                    for (int i = l; i < n; i += 64) atomicAdd(&var_del[O.rec[o + i].var], 1u);
+                    gone += (unsigned)n;
+                }
+                if (l == 0 && gone) atomicAdd(&cnt->n_abandoned, gone);
+            }
+            to_redo(); return;
+        }
+        wave_sync();
+
+        // ---- where each alignment begins and ends in stream coordinates, the candidates of each: variants [v0, first variant at or beyond its end)
+        int b_sat = 0, b_qat = 0, b_rend = h_start;
+        if (h_walk) { const int2 ts = s_tab[cs], te = s_tab[ce]; b_sat = ts.x + adv_r; b_qat = ts.y + adv_q; b_rend = h_start + te.x + end_r - b_sat; }
+        int ncand[4], rend[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            rend[q] = __builtin_amdgcn_readlane(b_rend, q);
             int n = __popcll(__ballot(walkq[q] && v0q[q] + l < V.n && pp[q] < rend[q]));
-            if (n == 64) {                                              // more than a wave's worth (dense tables): count on
+            if (n == 64) {                                                // more than a wave's worth (dense tables): count on
                 for (;;) { int p2 = 0x7fffffff; if (v0q[q] + n + l < V.n) p2 = V.pos[v0q[q] + n + l]; const int m = __popcll(__ballot(p2 < rend[q])); n += m; if (m < 64) break; }
             }
             ncand[q] = n;
         }
-    }
-    int cum[5]; cum[0] = 0;
+        int cum[5]; cum[0] = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cum[q + 1] = cum[q] + ncand[q];
-    const int T = cum[4];
-    int vadj[4];
+        for (int q = 0; q < 4; ++q) cum[q + 1] = cum[q] + ncand[q];
+        const int T = cum[4];
+        int vadj[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) vadj[q] = v0q[q] - cum[q];
-    if (l < 4) { ExtHdr &h = s_hdr[l]; h.vadj = SEL4(l, vadj); h.ds = b_sat - h_start; h.dq = b_qat; }
-    int maxnch = l < 4 ? s_hdr[l].nch : 0;
-    maxnch = max(max(__builtin_amdgcn_readlane(maxnch, 0), __builtin_amdgcn_readlane(maxnch, 1)), max(__builtin_amdgcn_readlane(maxnch, 2), __builtin_amdgcn_readlane(maxnch, 3)));
-    // ---- ONE reservation for the rows of the wave: a slot per candidate (the few candidates that turn out not to be observations - a base that is
-    //      neither allele, a variant inside a deletion, a variant filterSNP erased - leave slots unused at the end), so that records go straight
-    //      to their compacted place
-    unsigned long long off = 0;
-    if (T > 0 && l == 0) off = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)T);
-    wave_sync();
-    const int step0 = maxnch > 1 ? 1 << (31 - __builtin_clz(maxnch - 1)) : 0;    // the steps step0, step0/2, .. 1 sum to >= maxnch - 1
-    bool arena_full = false; unsigned long long g0 = 0; ObsRec *dst = nullptr;
-    int n_out = 0, n_emit[4] = {0, 0, 0, 0}; unsigned any_pre = 0;
-    bool fail = false;
-    uint2 pvr = V.rec[min(SELC(l, cum, vadj) + l, V.n - 1)];             // records are requested one round ahead
+        for (int q = 0; q < 4; ++q) vadj[q] = v0q[q] - cum[q];
+        if (l < 4) { ExtHdr &h = s_hdr[l]; h.vadj = SEL4(l, vadj); h.ds = b_sat - h_start; h.dq = b_qat; }
+        int maxnch = h_walk ? ce - cs + 1 : 0;
+        maxnch = max(max(__builtin_amdgcn_readlane(maxnch, 0), __builtin_amdgcn_readlane(maxnch, 1)), max(__builtin_amdgcn_readlane(maxnch, 2), __builtin_amdgcn_readlane(maxnch, 3)));
+        // ---- ONE reservation for the rows of the group: a slot per candidate (the few candidates that turn out not to be observations - a base that
+        //      is neither allele, a variant inside a deletion, a variant filterSNP erased - leave slots unused at the end), so that records go straight
+        //      to their compacted place
+        unsigned long long off = 0;
+        if (T > 0 && l == 0) off = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)T);
+        wave_sync();
+        const int step0 = maxnch > 1 ? 1 << (31 - __builtin_clz(maxnch - 1)) : 0;    // the steps step0, step0/2, .. 1 sum to >= maxnch - 1
+        unsigned long long g0 = 0; ObsRec *dst = nullptr;
+        int n_out = 0, n_emit[4] = {0, 0, 0, 0}; unsigned any_pre = 0;
+        uint2 pvr = V.rec[min(SELC(l, cum, vadj) + l, V.n - 1)];           // records are requested one round ahead
 #pragma unroll 1
-    for (int i0 = 0; i0 < T; i0 += 64) {
-        const int i = i0 + l;
-        const bool in = i < T;
-        int allele = -1, qv = 0, v = 0; bool erased = false;
-        const uint2 vr = pvr;
-        pvr = V.rec[min(SELC(i + 64, cum, vadj) + i + 64, V.n - 1)];
-        if (in) {
-            const int q = (i >= cum[1]) + (i >= cum[2]) + (i >= cum[3]);
-            const int4 ha = *reinterpret_cast<const int4 *>(&s_hdr[q].crel), hb = *reinterpret_cast<const int4 *>(&s_hdr[q].vadj);
-            const int hcrel = ha.x, hncig = ha.y, hc0 = ha.z, hnch = ha.w, hlq = hb.y;
-            v = hb.x + i;
-            const int p = (int)vr.x; const unsigned at = vr.y;
-            erased = (at & VREC_ERASED) != 0u;
-            const int ps = p + hb.z;                                      // the variant in stream coordinates
-            // last chunk of the alignment that starts at or before it (the alignment's first chunk does: the variant lies at or after its start)
-            int co = 0;
-            for (int step = step0; step >= 1; step >>= 1) { const int t = co + step; const int sv = s_tab[hc0 + min(t, hnch - 1)].x; co = (t < hnch && sv <= ps) ? t : co; }
-            const int2 base = s_tab[hc0 + co];
-            const int x0 = 8 * (hc0 + co);                                // stream index of the chunk's first word
-            const uint32_t *cw = cg + x0;
-            uint32_t w[9];
-            {
-                const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cw), b = *reinterpret_cast<const LpsU4 *>(cw + 4);
-                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = cw[8];
-            }
-            // the op that covers the variant: the last one that starts at or before it.  Starts never decrease, so "starts at or before" holds
-            // for a prefix of the words: words of the alignment before (they end where this one begins) pass the test and are overtaken by this
-            // alignment's first op, words past its end start at its end, beyond every candidate - whatever they hold
-            int rr = base.x, qq = base.y, j = 0, rs = base.x, qs = base.y; uint32_t wj = w[0], wn = w[1];
+        for (int i0 = 0; i0 < T; i0 += 64) {
+            const int i = i0 + l;
+            const bool in = i < T;
+            int allele = -1, qv = 0, v = 0; bool erased = false;
+            const uint2 vr = pvr;
+            pvr = V.rec[min(SELC(i + 64, cum, vadj) + i + 64, V.n - 1)];
+            if (in) {
+                const int q = (i >= cum[1]) + (i >= cum[2]) + (i >= cum[3]);
+                const int4 ha = *reinterpret_cast<const int4 *>(&s_hdr[q].crel), hb = *reinterpret_cast<const int4 *>(&s_hdr[q].vadj);
+                const int hcrel = ha.x, hncig = ha.y, hc0 = ha.z, hnch = ha.w, hlq = hb.y;
+                v = hb.x + i;
+                const int p = (int)vr.x; const unsigned at = vr.y;
+                erased = (at & VREC_ERASED) != 0u;
+                const int ps = p + hb.z;                                  // the variant in stream coordinates
+                // last chunk of the alignment that starts at or before it (the alignment's first chunk does: the variant lies at or after its start)
+                int co = 0;
+                for (int step = step0; step >= 1; step >>= 1) { const int t = co + step; const int sv = s_tab[hc0 + min(t, hnch - 1)].x; co = (t < hnch && sv <= ps) ? t : co; }
+                const int2 base = s_tab[hc0 + co];
+                const int x0 = 8 * (hc0 + co);                            // stream index of the chunk's first word
+                const uint32_t *cw = cg + x0;
+                uint32_t w[9];
+                {
+                    const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cw), b = *reinterpret_cast<const LpsU4 *>(cw + 4);
+                    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = cw[8];
+                }
+                // the op that covers the variant: the last one that starts at or before it.  Starts never decrease, so "starts at or before" holds
+                // for a prefix of the words: words of the alignment before (they end where this one begins) pass the test and are overtaken by this
+                // alignment's first op, words past its end start at its end, beyond every candidate - whatever they hold
+                int rr = base.x, qq = base.y, j = 0, rs = base.x, qs = base.y; uint32_t wj = w[0], wn = w[1];
 #pragma unroll
-            for (int k = 1; k < 8; ++k) {
-                const unsigned t = op_consume_bits(w[k - 1] & 15u); const int len = (int)(w[k - 1] >> 4);
-                rr += len & bit_mask(t, 0); qq += len & bit_mask(t, 16);
-                const bool le = rr <= ps;
-                j = le ? k : j; rs = le ? rr : rs; qs = le ? qq : qs; wj = le ? w[k] : wj; wn = le ? w[k + 1] : wn;
-            }
-            const int op = wj & 15, len = (int)(wj >> 4);
-            const int opi = x0 + j - hcrel;                               // op index inside the alignment
-            qs -= hb.w;                                                   // query position inside the alignment
-            if (ps < rs + len) {
-                const unsigned kind = VREC_KIND(at);
-                int qi = -1;
-                if (op_is_match(op)) {                                            // :1445-1520
-                    const int o = ps - rs;
-                    if (qs + o + 1 > hlq) fail = true;                            // :1453-1455
-                    else if (kind == 0) qi = qs + o;
-                    else if ((kind == 1 || kind == 2) && opi + 1 < hncig) {       // indel variant :1470-1510
-                        const int want = (kind == 1) ? 1 : 2;                      // next op must be I resp. D
-                        allele = (rs + len - 1 == ps && (int)(wn & 15u) == want) ? 1 : 0;
-                        qv = (at & VREC_DANGER) ? -5 : -4;
+                for (int k = 1; k < 8; ++k) {
+                    const unsigned t = op_consume_bits(w[k - 1] & 15u); const int len = (int)(w[k - 1] >> 4);
+                    rr += len & bit_mask(t, 0); qq += len & bit_mask(t, 16);
+                    const bool le = rr <= ps;
+                    j = le ? k : j; rs = le ? rr : rs; qs = le ? qq : qs; wj = le ? w[k] : wj; wn = le ? w[k + 1] : wn;
+                }
+                const int op = wj & 15, len = (int)(wj >> 4);
+                const int opi = x0 + j - hcrel;                           // op index inside the alignment
+                qs -= hb.w;                                               // query position inside the alignment
+                if (ps < rs + len) {
+                    const unsigned kind = VREC_KIND(at);
+                    int qi = -1;
+                    if (op_is_match(op)) {                                        // :1445-1520
+                        const int o = ps - rs;
+                        if (qs + o + 1 > hlq) fail = true;                        // :1453-1455
+                        else if (kind == 0) qi = qs + o;
+                        else if ((kind == 1 || kind == 2) && opi + 1 < hncig) {   // indel variant :1470-1510
+                            const int want = (kind == 1) ? 1 : 2;                  // next op must be I resp. D
+                            allele = (rs + len - 1 == ps && (int)(wn & 15u) == want) ? 1 : 0;
+                            qv = (at & VREC_DANGER) ? -5 : -4;
+                        }
+                    } else if (op == 2) {                                         // :1539-1607
+                        // only the first variant at/after the deletion start is examined by the reference
+                        const bool first_in = (v == 0) || V.pos[v - 1] + hb.z < rs;
+                        if (first_in && (at & VREC_HPOLY3)) {
+                            if (qs + 1 > hlq) fail = true;                        // :1559-1561
+                            else if (kind == 0) qi = qs;
+                            else if (kind == 2) { allele = 1; qv = -4; }
+                        }
                     }
-                } else if (op == 2) {                                             // :1539-1607
-                    // only the first variant at/after the deletion start is examined by the reference
-                    const bool first_in = (v == 0) || V.pos[v - 1] + hb.z < rs;
-                    if (first_in && (at & VREC_HPOLY3)) {
-                        if (qs + 1 > hlq) fail = true;                            // :1559-1561
-                        else if (kind == 0) qi = qs;
-                        else if (kind == 2) { allele = 1; qv = -4; }
+                    if (qi >= 0) {                                                // base and quality at the variant site: one 128-byte line holds both
+                        const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
+                        int code; sq_fetch(R.sq, s_hdr[q].blk0, qi, code, qv);
+                        const char base_c = nt16_char(code);
+                        if (base_c == ref_c) allele = 0; else if (base_c == alt_c) allele = 1;
                     }
                 }
-                if (qi >= 0) {                                                    // base and quality at the variant site
-                    const int4 hc = *reinterpret_cast<const int4 *>(&s_hdr[q].so_lo);
-                    const unsigned long long so = (unsigned long long)(unsigned)hc.x | ((unsigned long long)(unsigned)hc.y << 32);
-                    const unsigned long long qo = (unsigned long long)(unsigned)hc.z | ((unsigned long long)(unsigned)hc.w << 32);
-                    const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
-                    const char base_c = nt16_char(R.seq[so + (unsigned)(qi >> 1)] >> ((~qi & 1) << 2));
-                    if (base_c == ref_c) allele = 0; else if (base_c == alt_c) allele = 1;
-                    qv = R.qual[qo + (unsigned)qi];
+            }
+            const bool pre = in && allele != -1;                          // an observation before filterSNP
+            const bool ok = pre && !erased;
+            const unsigned long long pm = __ballot(pre), om = __ballot(ok);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int a = max(cum[k] - i0, 0), b = min(cum[k + 1] - i0, 64);   // lanes of row k in this round
+                if (b > a) {
+                    const unsigned long long rm = ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << a) - 1ull);
+                    n_emit[k] += __popcll(om & rm); if (pm & rm) any_pre |= 1u << k;
                 }
             }
-        }
-        const bool pre = in && allele != -1;                              // an observation before filterSNP
-        const bool ok = pre && !erased;
-        const unsigned long long pm = __ballot(pre), om = __ballot(ok);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int a = max(cum[k] - i0, 0), b = min(cum[k + 1] - i0, 64);   // lanes of row k in this round
-            if (b > a) {
-                const unsigned long long rm = ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << a) - 1ull);
-                n_emit[k] += __popcll(om & rm); if (pm & rm) any_pre |= 1u << k;
+            if (i0 == 0) {                                                // the reservation has had the first round's searches to arrive
+                off = __shfl(off, 0);
+                if (off + (unsigned long long)T > O.arena_size) arena_full = true;
+                g0 = arena_lo + off; dst = O.rec + g0;
             }
+            if (ok && !arena_full) {
+                // the observation is counted where it is made: what the counting atomic returns is its rank inside the variant's list of observations,
+                // kept beside allele and quality - the node-major lists are filled later without a counting pass and without a second atomic
+                unsigned rk = 0;
+                if (var_cnt) { rk = atomicAdd(&var_cnt[v], 1u); if (rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); }
+                dst[n_out + __popcll(om & lanemask_lt())] = ObsRec{(int32_t)v, (uint32_t)pack_aq(allele, qv) | (rk << 10)};
+            }
+            n_out += __popcll(om);
         }
-        if (i0 == 0) {                                                    // the reservation has had the first round's searches to arrive
-            off = __shfl(off, 0);
-            arena_full = off + (unsigned long long)T > O.arena_size;
-            g0 = arena_lo + off; dst = O.rec + g0;
+        if (__ballot(fail)) {
+            // get_snp returned early somewhere in these alignments (SEQ shorter than the CIGAR says: the read is dropped but clips of earlier ops
+            // stay): the general walker replays the whole job.  Nothing a later stage looks at has been written, but the observations made so far
+            // were COUNTED: they are taken off again (var_del), their places in the variants' lists stay holes (the host fills the lists with the
+            // hole key when n_abandoned is not zero); the reserved slots stay unused
+            if (var_cnt) {
+                __threadfence();
+                unsigned gone = (unsigned)n_out;
+                for (int i = l; i < n_out; i += 64) atomicAdd(&var_del[dst[i].var], 1u);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)row_off, q); const int n = __builtin_amdgcn_readlane(row_cnt, q);
+                    for (int i = l; i < n; i += 64) atomicAdd(&var_del[O.rec[o + i].var], 1u);
+                    gone += (unsigned)n;
+                }
+                if (l == 0 && gone) atomicAdd(&cnt->n_abandoned, gone);
+            }
+            to_redo();
+            return;
         }
-        if (ok && !arena_full) dst[n_out + __popcll(om & lanemask_lt())] = ObsRec{(int32_t)v, (uint32_t)pack_aq(allele, qv)};
-        n_out += __popcll(om);
-    }
-    if (__ballot(fail)) {
-        // get_snp returned early somewhere in these four alignments (SEQ shorter than the CIGAR says): the read is dropped but clips of earlier ops
-        // stay - the general walker replays the job; the slots reserved above stay unused (no row points at them)
-        to_redo();
-        return;
+        // rows of the group's alignments: back to back in the group's reservation
+        if (h_in) {
+            int before = 0, mine = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { if (k < l) before += n_emit[k]; if (k == l) mine = n_emit[k]; }
+            row_off = (uint32_t)(g0 + (unsigned)before); row_cnt = mine; row_flags = (((any_pre >> l) & 1u) && mine == 0) ? 1u : 0u;
+        }
+        // the group's clip events: stream coordinate -> reference position, alignment of the job -> alignment index
+        if (l >= n_clip0 && l < n_clip) { ClipEv e = s_clip[l]; const int q = e.read; e.pos -= s_hdr[q].ds; e.read = r0 + q; s_clip[l] = e; }
+        wave_sync();                                                      // the table and the headers are reused by the next group
     }
     if (arena_full && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW);          // the host grows the arenas and reruns
     if (l < nq) {
-        int before = 0, mine = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { if (k < l) before += n_emit[k]; if (k == l) mine = n_emit[k]; }
-        const bool walked = (live_mask >> l) & 1u;
-        const bool ok = walked && !arena_full;
-        RowDesc d;
-        d.off = ok ? (uint32_t)(g0 + (unsigned)before) : 0u;
-        d.cnt = ok ? mine : 0;
-        d.fail = 0x7fffffff;
-        d.flags = (ok && ((any_pre >> l) & 1u) && mine == 0) ? 1u : 0u;
-        O.rows[r0 + l] = d;
+        const bool ok = h_live && !arena_full;
+        O.rows[r0 + l] = RowDesc{ok ? row_off : 0u, ok ? row_cnt : 0, 0x7fffffff, ok ? row_flags : 0u};
     }
     if (n_clip > 0 && !arena_full) {
         unsigned cb = 0;
         if (l == 0) cb = atomicAdd(C.n_ev, (unsigned)n_clip);
         cb = __shfl(cb, 0);
-        if (l < n_clip && cb + (unsigned)l < C.capacity) {
-            ClipEv e = s_clip[l]; const int q = e.read;                   // stream coordinate -> reference position, alignment of the job -> alignment index
-            e.pos = e.pos - s_hdr[q].ds; e.read = r0 + q;
-            C.ev[cb + l] = e;
-        }
+        if (l < n_clip && cb + (unsigned)l < C.capacity) C.ev[cb + l] = s_clip[l];
     }
 }
 
@@ -461,18 +502,18 @@ __global__ __launch_bounds__(64) void k_extract_phase(VarView V, ReadView R, Obs
 // wave: observations are called as their segment is searched and collected in an LDS buffer; when that fills up the wave reserves an upper bound
 // for the row it is in - remaining reference span -> remaining candidates -, empties the buffer and writes the rest of that row directly.
 __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
-                                                      LpsCounters *cnt, const uint32_t *redo_list, const unsigned *n_redo) {
+                                                      LpsCounters *cnt, const uint32_t *redo_list, const unsigned *n_redo, uint32_t *var_cnt, uint32_t *var_del) {
     __shared__ __attribute__((aligned(16))) int s_ref[4][LPS_SEG];
     __shared__ __attribute__((aligned(16))) int s_qry[4][LPS_SEG];
     __shared__ __attribute__((aligned(16))) uint32_t s_cig[4][LPS_SEG + 4];
     __shared__ int s_bvar[4][REDO_CAP];
-    __shared__ uint16_t s_baq[4][REDO_CAP];
+    __shared__ uint32_t s_baq[4][REDO_CAP];
     enum { H_START, H_LQ, H_REL, H_V0, H_SOFF, H_QOFF = H_SOFF + 2, H_KIND = H_QOFF + 2, H_ROFF, H_RCNT, H_RFAIL, H_RFLAGS, H_WORDS };
     enum { ROW_DEAD = 0, ROW_BUFFERED = 1, ROW_GLOBAL = 2 };
     __shared__ int s_hdr[4][EXT_RPW + 1][H_WORDS];
     const int w = threadIdx.x >> 6, l = lane_id();
     int *sref = s_ref[w], *sqry = s_qry[w]; uint32_t *scig = s_cig[w];
-    int *bvar = s_bvar[w]; uint16_t *baq = s_baq[w];
+    int *bvar = s_bvar[w]; uint32_t *baq = s_baq[w];
     int *hdr = s_hdr[w][0];
     // Output rows are reserved on one of LPS_ARENAS counters (own cache line each).  Workgroups are dealt round-robin over the 8 XCDs, so
     // arena = blockIdx % 64 keeps each counter inside ONE XCD's L2.
@@ -487,10 +528,10 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
     const int nq = min(EXT_RPW, R.n - r0);
 
     // ---- plan: headers, alignment q in lane q.  direct_detect_alleles filters (:1282-1291) + region "chr:1-<lastSNPPos>" (:1273)
-    int h_start = 0, h_lq = 0, h_rel = 0; bool h_live = false; unsigned long long h_coff = 0, h_soff = 0, h_qoff = 0;
+    int h_start = 0, h_lq = 0, h_rel = 0; bool h_live = false; unsigned long long h_coff = 0; unsigned h_blk = 0;
     if (l <= nq) h_coff = R.cigar_off[r0 + l];
     if (l < nq) {
-        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r]; h_qoff = R.qual_off[r];
+        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_blk = R.sq_blk[r];
         const int flag = R.flag[r];
         h_live = !(R.mapq[r] < mapping_quality || (flag & 0x4) || (flag & 0x100) || (flag & 0x400) || h_start >= V.last_pos);
     }
@@ -522,8 +563,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
         h[H_REL] = h_rel;
         if (l < 4) {
             h[H_START] = h_start; h[H_LQ] = h_lq; h[H_V0] = h_v0;
-            h[H_SOFF] = (int)(unsigned)h_soff; h[H_SOFF + 1] = (int)(unsigned)(h_soff >> 32);
-            h[H_QOFF] = (int)(unsigned)h_qoff; h[H_QOFF + 1] = (int)(unsigned)(h_qoff >> 32);
+            h[H_SOFF] = (int)h_blk; h[H_SOFF + 1] = 0; h[H_QOFF] = 0; h[H_QOFF + 1] = 0;
             h[H_KIND] = ROW_DEAD; h[H_ROFF] = 0; h[H_RCNT] = 0; h[H_RFAIL] = 0x7fffffff; h[H_RFLAGS] = 0;
         }
     }
@@ -540,8 +580,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
 #define HU(i) __builtin_amdgcn_readfirstlane(h[i])
         const int start = HU(H_START), lq = HU(H_LQ), crel = HU(H_REL), n_cig = HU(H_WORDS + H_REL) - crel;
         const uint32_t *cig = cg + crel;
-        const uint8_t *seq = R.seq + ((unsigned long long)(unsigned)HU(H_SOFF) | ((unsigned long long)(unsigned)HU(H_SOFF + 1) << 32));
-        const uint8_t *qual = R.qual + ((unsigned long long)(unsigned)HU(H_QOFF) | ((unsigned long long)(unsigned)HU(H_QOFF + 1) << 32));
+        const unsigned blk0 = (unsigned)HU(H_SOFF);                      // first block of the read's interleaved bases + qualities
         int vcur = HU(H_V0);
 #undef HU
         const unsigned rest = live_mask >> (q + 1);
@@ -647,9 +686,9 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
                                 if (qs + off + 1 > lq) fail = true;                           // :1453-1455
                                 else if (kind == 0) {
                                     const int qi = qs + off;
-                                    const char base_c = nt16_char(seq[qi >> 1] >> ((~qi & 1) << 2));
+                                    int code; sq_fetch(R.sq, blk0, qi, code, qv);
+                                    const char base_c = nt16_char(code);
                                     if (base_c == ref_c) allele = 0; else if (base_c == alt_c) allele = 1;
-                                    qv = qual[qi];
                                     emit = allele != -1;
                                 } else if ((kind == 1 || kind == 2) && opi + 1 < n_cig) {     // indel variant :1470-1510
                                     const int want = (kind == 1) ? 1 : 2;                      // next op must be I resp. D
@@ -663,9 +702,9 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
                                 if (first_in && (at & VREC_HPOLY3)) {
                                     if (qs + 1 > lq) fail = true;                             // :1559-1561
                                     else if (kind == 0) {
-                                        const char base_c = nt16_char(seq[qs >> 1] >> ((~qs & 1) << 2));
+                                        int code; sq_fetch(R.sq, blk0, qs, code, qv);
+                                        const char base_c = nt16_char(code);
                                         if (base_c == ref_c) allele = 0; else if (base_c == alt_c) allele = 1;
-                                        qv = qual[qs];
                                         emit = allele != -1;
                                     } else if (kind == 2) { allele = 1; qv = -4; emit = true; }
                                 }
@@ -693,7 +732,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
                     if (off + need > O.arena_size) arena_full = true;
                     else {
                         const unsigned long long g0 = arena_lo + off;
-                        for (int i = l; i < n_buf; i += 64) O.rec[g0 + i] = ObsRec{bvar[i], (uint32_t)baq[i]};
+                        for (int i = l; i < n_buf; i += 64) O.rec[g0 + i] = ObsRec{bvar[i], baq[i]};
                         if (l < q) { int *hp = hdr + l * H_WORDS; if (hp[H_KIND] == ROW_BUFFERED) { hp[H_KIND] = ROW_GLOBAL; hp[H_ROFF] = (int)(uint32_t)(g0 + (unsigned)hp[H_ROFF]); } }
                         direct_base = g0 + row_start;
                     }
@@ -702,8 +741,11 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
                 }
                 if (emit) {
                     const int rank = n_emit + __popcll(em & lanemask_lt());
-                    if (direct) { if (!arena_full) O.rec[direct_base + rank] = ObsRec{v, (uint32_t)pack_aq(allele, qv)}; }
-                    else { bvar[row_start + rank] = v; baq[row_start + rank] = pack_aq(allele, qv); }
+                    unsigned rk = 0;                                        // rank inside the variant's list of observations (see k_extract_phase)
+                    if (var_cnt) { rk = atomicAdd(&var_cnt[v], 1u); if (rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); }
+                    const uint32_t aqw = (uint32_t)pack_aq(allele, qv) | (rk << 10);
+                    if (direct) { if (!arena_full) O.rec[direct_base + rank] = ObsRec{v, aqw}; }
+                    else { bvar[row_start + rank] = v; baq[row_start + rank] = aqw; }
                 }
                 n_emit += n_em;
                 if (!direct) n_buf += n_em;
@@ -716,6 +758,11 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
         }
         fail_op = wave_min(fail_op);
         const bool any = __ballot(had_any) != 0;
+        if (var_cnt && fail_op != 0x7fffffff && n_emit > 0) {                    // the read is dropped (:1453-1455) after its observations were counted: taken off again
+            __threadfence();
+            for (int i = l; i < n_emit; i += 64) atomicAdd(&var_del[direct ? O.rec[direct_base + i].var : bvar[row_start + i]], 1u);
+            if (l == 0) atomicAdd(&cnt->n_abandoned, (unsigned)n_emit);
+        }
         if (l == 0) {
             const bool dropped = fail_op != 0x7fffffff;
             h[H_KIND] = direct ? ROW_GLOBAL : ROW_BUFFERED;
@@ -735,7 +782,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
         if (off + (unsigned long long)n_buf > O.arena_size) arena_full = true;
     }
     const unsigned long long g0 = arena_lo + off;
-    if (!arena_full) for (int i = l; i < n_buf; i += 64) O.rec[g0 + i] = ObsRec{bvar[i], (uint32_t)baq[i]};
+    if (!arena_full) for (int i = l; i < n_buf; i += 64) O.rec[g0 + i] = ObsRec{bvar[i], baq[i]};
     if (arena_full && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW);          // the host grows the arenas and reruns
     if (l < nq) {
         const int *hp = hdr + l * H_WORDS; const int r = r0 + l; const int kind = hp[H_KIND];
@@ -752,10 +799,10 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
 }
 
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,
-                          int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, hipStream_t s) {
+                          int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint32_t *var_cnt, uint32_t *var_del, hipStream_t s) {
     if (R.n == 0) return;
     const int n_jobs = (R.n + EXT_RPW - 1) / EXT_RPW;
-    hipLaunchKernelGGL(k_extract_phase, dim3(n_jobs), dim3(64), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo);
-    // jobs the lane-chunk table could not hold queued themselves (very long alignments; none with ordinary read lengths): a small grid drains the queue
-    hipLaunchKernelGGL(k_extract_redo, dim3(std::min(256, (n_jobs + 3) / 4)), dim3(256), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo);
+    hipLaunchKernelGGL(k_extract_phase, dim3(n_jobs), dim3(64), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo, var_cnt, var_del);
+    // jobs the lane-chunk table could not hold queued themselves (an alignment of more than ~200 kb of CIGAR; none with ordinary read lengths): a small grid drains the queue
+    hipLaunchKernelGGL(k_extract_redo, dim3(std::min(256, (n_jobs + 3) / 4)), dim3(256), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo, var_cnt, var_del);
 }

@@ -15,6 +15,7 @@
 // order taken from a radix-sorted node-major list: no atomics, every cell is written exactly once.
 #include <cstring>
 #include <algorithm>
+#include <type_traits>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -22,14 +23,53 @@
 #include "lps_stdsort.h"
 #include <cstdlib>
 
-// ================================================================================================ clips / CNV
-// thread per clip event (grid-stride over the list the extraction appended): keep events of ops before the op at which get_snp returned early
-// (:1453-1455,1559-1561), compact them (one atomic per workgroup) into sort keys (pos << 1 | front/back).
-__global__ __launch_bounds__(256) void k_clip_keys(ClipView C, const RowDesc *rows, unsigned long long *keys, LpsCounters *cnt) {
-    __shared__ unsigned s_wcnt[4], s_base;
-    const unsigned n_ev = min(*C.n_ev, C.capacity);
+// ================================================================================================ clips, read names, overlap filter
+// One launch after the extraction:
+//   * workgroups [0, nb_reads): thread per alignment.  The alignments of one read NAME are linked into a list - name_head[name] holds the last one
+//     that arrived (+1), name_link[alignment] the one before it (+1, 0 = none) - with one atomicExch per alignment that has observations: no sort
+//     of 600 k keys, no head flags, no scan (the reference's mergeReadMap, PhasingGraph.cpp:697, groups by name too; only ~2 % of the names hold
+//     more than one alignment).  `name` is dense: the caller's name ids when they are (CLI and bench hand over ranks), else ranks made by
+//     launch_dense_names.  Also: alignments with observations, the longest row.
+//   * workgroup nb_reads: observation slots reserved by the extraction, over the arenas.
+//   * the workgroups after it: clip events of ops before the op at which get_snp returned early (:1453-1455,1559-1561), compacted (one atomic per
+//     workgroup) into sort keys (pos << 1 | front/back).
+__global__ __launch_bounds__(256) void k_name_link(int n_reads, const uint32_t *name, const RowDesc *rows, uint32_t *name_head, uint32_t *name_link,
+                                                   LpsCounters *cnt, const unsigned long long *arena_ctr, unsigned long long arena_size,
+                                                   ClipView C, unsigned long long *keys, int nb_reads) {
+    __shared__ unsigned s_wcnt[4], s_wmax[4], s_base;
     const int w = threadIdx.x >> 6;
-    for (unsigned base = blockIdx.x * blockDim.x; base < n_ev; base += gridDim.x * blockDim.x) {     // uniform per workgroup
+    if ((int)blockIdx.x < nb_reads) {
+        const int r = blockIdx.x * blockDim.x + threadIdx.x;
+        const int n = r < n_reads ? rows[r].cnt : 0;
+        const bool kept = n > 0;
+        if (r < n_reads) name_link[r] = kept ? atomicExch(&name_head[name[r]], (uint32_t)r + 1u) : 0u;
+        // one atomic per workgroup: atomics on ONE word are served one after the other (~11 ns each)
+        const unsigned long long m = __ballot(kept);
+        const int mx = wave_max(n);
+        if (lane_id() == 0) { s_wcnt[w] = (unsigned)__popcll(m); s_wmax[w] = (unsigned)max(mx, 0); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]; if (tot) atomicAdd(&cnt->n_kept, tot);
+            const unsigned big = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])); if (big) atomicMax(&cnt->max_row, big);
+        }
+        return;
+    }
+    if ((int)blockIdx.x == nb_reads) {
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            unsigned long long v = l < LPS_ARENAS ? arena_ctr[l * 8] : 0ull;
+            if (v > arena_size) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW);
+            unsigned long long mx = v;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+            v = wave_sum(v);
+            if (l == 0) { cnt->obs_total = v; cnt->arena_max = mx; }
+        }
+        return;
+    }
+    const unsigned n_ev = min(*C.n_ev, C.capacity);
+    const unsigned cb = blockIdx.x - nb_reads - 1, n_cb = gridDim.x - nb_reads - 1;
+    for (unsigned base = cb * blockDim.x; base < n_ev; base += n_cb * blockDim.x) {     // uniform per workgroup
         const unsigned e = base + threadIdx.x;
         bool keep = false; unsigned long long key = 0;
         if (e < n_ev) {
@@ -46,71 +86,54 @@ __global__ __launch_bounds__(256) void k_clip_keys(ClipView C, const RowDesc *ro
         if (keep) keys[off] = key;
         __syncthreads();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && *C.n_ev > C.capacity) atomicOr(&cnt->err, (unsigned)LPS_ERR_CLIP_OVERFLOW);
+    if (cb == 0 && threadIdx.x == 0 && *C.n_ev > C.capacity) atomicOr(&cnt->err, (unsigned)LPS_ERR_CLIP_OVERFLOW);
 }
 
-// ================================================================================================ name groups
-__global__ __launch_bounds__(256) void k_name_keys(int n_reads, const uint32_t *name_id, const RowDesc *rows, unsigned long long *keys,
-                                                   LpsCounters *cnt, const unsigned long long *arena_ctr, unsigned long long arena_size) {
-    __shared__ unsigned s_cnt[4];
-    if (blockIdx.x == gridDim.x - 1) {                                  // one extra workgroup: observation slots reserved by the extraction, over the arenas
-        if (threadIdx.x < 64) {
-            const int l = threadIdx.x;
-            unsigned long long v = l < LPS_ARENAS ? arena_ctr[l * 8] : 0ull;
-            if (v > arena_size) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW);
-            unsigned long long mx = v;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
-            v = wave_sum(v);
-            if (l == 0) { cnt->obs_total = v; cnt->arena_max = mx; }
-        }
-        return;
+// Thread per alignment; the thread of the LAST alignment linked under a name that holds several (a few per workgroup) takes the group: its members
+// in BAM order (the list is in arrival order: every member is found by another walk - groups have two or three members) go to mm_r, where the
+// merged-row kernels find them, and the reference's overlap filter of several alignments of one read (:707-781) is replayed on them one after the
+// other.  A deleted alignment's observations leave the per-variant counts the extraction took (var_del).
+__global__ __launch_bounds__(256) void k_groups(int n_reads, const uint32_t *name, const RowDesc *rows, const ObsRec *obs, const int32_t *vpos, double overlap_threshold,
+                                                const uint32_t *name_head, const uint32_t *name_link, LpsCounters *cnt,
+                                                uint32_t *mm_r, uint32_t *stack, uint32_t *mg_start, uint32_t *mg_cnt, uint32_t *mg_name, uint8_t *deleted, uint32_t *var_del) {
+    __shared__ unsigned s_k[4], s_n[4], s_mx[4], s_base_k, s_base_n;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, w = threadIdx.x >> 6;
+    bool owner = false; int k = 0; uint32_t id = 0;
+    if (r < n_reads && rows[r].cnt > 0) {
+        id = name[r];
+        if (name_head[id] == (uint32_t)r + 1u && name_link[r] != 0u) { owner = true; for (uint32_t x = (uint32_t)r + 1u; x; x = name_link[x - 1]) ++k; }
     }
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool kept = r < n_reads && rows[r].cnt > 0;
-    if (r < n_reads) keys[r] = kept ? ((unsigned long long)name_id[r] << 32 | (unsigned)r) : ~0ull;
-    // one atomic per workgroup: atomics on ONE word are served one after the other (~11 ns each), 1 500 wave atomics were the kernel's whole duration
-    const unsigned long long m = __ballot(kept);
-    if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = (unsigned)__popcll(m);
+    const int incl = wave_incl_scan_dpp(k);
+    const unsigned long long om = __ballot(owner);
+    const int kmx = wave_max(k);
+    if (lane_id() == 63) s_k[w] = (unsigned)incl;
+    if (lane_id() == 0) { s_n[w] = (unsigned)__popcll(om); s_mx[w] = (unsigned)kmx; }
     __syncthreads();
-    if (threadIdx.x == 0) { const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]; if (tot) atomicAdd(&cnt->n_kept, tot); }
-}
-
-__global__ void k_group_heads(const unsigned long long *skeys, int n_reads, const LpsCounters *cnt, uint32_t *head) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_reads) return;
-    const unsigned nk = cnt->n_kept;
-    head[s] = ((unsigned)s < nk && (s == 0 || (skeys[s] >> 32) != (skeys[s - 1] >> 32))) ? 1u : 0u;
-}
-
-// gidx = exclusive scan of head; group of sorted slot s is gidx[s] + head[s] - 1
-__global__ void k_group_starts(const unsigned long long *skeys, const uint32_t *head, const uint32_t *gidx, int n_reads,
-                               LpsCounters *cnt, uint32_t *gstart, uint32_t *read_group) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_reads) return;
-    const unsigned nk = cnt->n_kept;
-    if ((unsigned)s >= nk) return;
-    const uint32_t g = gidx[s] + head[s] - 1;
-    if (head[s]) gstart[g] = s;
-    read_group[(uint32_t)skeys[s]] = g;
-    if ((unsigned)s == nk - 1) { gstart[g + 1] = nk; cnt->n_groups = g + 1; }
-}
-
-// Overlap filter of several alignments of one read name: one thread replays the reference's sequential rule for
-// its group (groups with one alignment have nothing to do).  `stack` is scratch aligned with the sorted slots.
-__global__ void k_overlap_filter(const unsigned long long *skeys, const uint32_t *gstart, const LpsCounters *cnt,
-                                 const RowDesc *rows, const ObsRec *obs,
-                                 const int32_t *vpos, double overlap_threshold, uint32_t *stack, uint8_t *deleted) {
-    const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= cnt->n_groups) return;
-    const uint32_t s0 = gstart[g], s1 = gstart[g + 1];
-    if (s1 - s0 < 2) return;
-    uint32_t *kept = stack + s0; int nk = 0; int second = 0;
-    auto fpos = [&](uint32_t r) { return vpos[obs[rows[r].off].var]; };
-    auto lpos = [&](uint32_t r) { return vpos[obs[rows[r].off + rows[r].cnt - 1].var]; };
-    for (uint32_t s = s0; s < s1; ++s) {
-        const uint32_t r = (uint32_t)skeys[s];
-        const int fp = fpos(r), lp = lpos(r);
+    if (threadIdx.x == 0) {
+        const unsigned K = s_k[0] + s_k[1] + s_k[2] + s_k[3], N = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+        s_base_k = K ? atomicAdd(&cnt->mm_total, K) : 0u; s_base_n = N ? atomicAdd(&cnt->n_multi, N) : 0u;
+        const unsigned big = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3])); if (big) atomicMax(&cnt->max_group, big);
+    }
+    __syncthreads();
+    if (!owner) return;
+    unsigned base = s_base_k + (unsigned)(incl - k), qi = s_base_n + (unsigned)__popcll(om & lanemask_lt());
+    for (int q = 0; q < w; ++q) { base += s_k[q]; qi += s_n[q]; }
+    {
+        uint32_t prev = 0;                                      // members in ascending alignment index (+1): the smallest above the last one taken
+        for (int t = 0; t < k; ++t) {
+            uint32_t best = 0xffffffffu;
+            for (uint32_t x = (uint32_t)r + 1u; x; x = name_link[x - 1]) if (x > prev && x < best) best = x;
+            mm_r[base + t] = best - 1u; prev = best;
+        }
+    }
+    mg_start[qi] = base; mg_cnt[qi] = (uint32_t)k; mg_name[qi] = id;
+    // ---- overlap filter (:707-781): the reference's sequential rule over the group's alignments; `stack` is scratch aligned with mm_r
+    uint32_t *kept = stack + base; int nk = 0; int second = 0;
+    auto fpos = [&](uint32_t a) { return vpos[obs[rows[a].off].var]; };
+    auto lpos = [&](uint32_t a) { return vpos[obs[rows[a].off + rows[a].cnt - 1].var]; };
+    for (int t = 0; t < k; ++t) {
+        const uint32_t a = mm_r[base + t];
+        const int fp = fpos(a), lp = lpos(a);
         bool del = false;
         while (0 <= fp && fp <= second) {                    // alignRange starts as {0,0} (:712-716)
             if (lp < second) { del = true; break; }
@@ -132,8 +155,30 @@ __global__ void k_overlap_filter(const unsigned long long *skeys, const uint32_t
             } else break;
         }
         second = lp;
-        if (del) deleted[r] = 1; else kept[nk++] = r;
+        if (del) deleted[a] = 1; else kept[nk++] = a;
     }
+    if (var_del) {
+        for (int t = 0; t < k; ++t) {
+            const uint32_t a = mm_r[base + t];
+            if (!deleted[a]) continue;
+            const uint32_t off = rows[a].off; const int n = rows[a].cnt;
+            for (int j = 0; j < n; ++j) atomicAdd(&var_del[obs[off + j].var], 1u);
+        }
+    }
+}
+
+// ---- name ids that are not dense (the ABI allows any order-preserving integer): ranks by one sort.  keys = (name id << 32 | alignment).
+__global__ void k_dense_keys(int n_reads, const uint32_t *name_id, unsigned long long *keys) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_reads) keys[r] = (unsigned long long)name_id[r] << 32 | (unsigned)r;
+}
+__global__ void k_dense_heads(const unsigned long long *skeys, int n_reads, uint32_t *head) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_reads) head[s] = (s == 0 || (skeys[s] >> 32) != (skeys[s - 1] >> 32)) ? 1u : 0u;
+}
+__global__ void k_dense_ids(const unsigned long long *skeys, const uint32_t *head, const uint32_t *gidx, int n_reads, uint32_t *dense) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_reads) dense[(uint32_t)skeys[s]] = gidx[s] + head[s] - 1;
 }
 
 // ---- rows by sub-wave groups.  A row holds ~20-30 observations, so a 64-lane wave per row runs with a third of its lanes; the per-row passes below
@@ -237,7 +282,7 @@ __device__ __forceinline__ int cnv_obs_step(int ci, int K, int U, int j, bool ho
 // loaded values.
 template <bool ERASE>
 __global__ __launch_bounds__(256) void k_cnv_rows(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *pre, const RowDesc *rows, ObsRec *obs, const int32_t *vpos, const int32_t *cs, const int32_t *ce,
-                                                  const double *miss, uint8_t *fn) {
+                                                  const double *miss, uint8_t *fn, uint32_t *var_del2) {
     const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
     const unsigned k = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
     if (k >= *n_list) return;
@@ -275,7 +320,7 @@ __global__ __launch_bounds__(256) void k_cnv_rows(const LpsCounters *cnt, const 
                 if (!ERASE) c1 = cnv_obs_step(c1, K, Ut, jt, ht, &e1);
                 if (ERASE && e0 && sl == t) mine = true;
             }
-            if (ERASE && mine) obs[off + q].var = -1 - v;
+            if (ERASE && mine) { obs[off + q].var = -1 - v; atomicAdd(&var_del2[v], 1u); }
         }
     }
     if (ERASE) return;
@@ -342,149 +387,164 @@ __global__ void k_cnv_miss(const LpsCounters *cnt, int n_var, const int32_t *vpo
 }
 
 // ================================================================================================ nodes
-// wave per alignment: mark observed variants as graph nodes, record the type written by the LAST alignment
-// (BAM order) that observes the position - the reference's (*variantType)[pos] = ... is last-writer-wins.
-// The four rows of an extraction job (k_extract_phase: one reservation per wave) lie back to back in the arena: a wave takes the job's whole span -
-// ~100 observations, two 64-lane rounds whose loads are all in flight together - instead of two rows in two 32-lane groups; these kernels wait on
-// dependent loads, so what counts is observations per resident wave.  Rows that were moved (k_extract_redo, k_extra_merge) break the span: then the
-// rows are walked one after the other.
 // Workgroups are dealt round-robin over the 8 XCDs (one L2 each): workgroup b of a grid of 8k takes unit (b % 8) * k + b / 8, so that an XCD walks ONE
-// contiguous eighth of the units and what neighbouring units share (list entries, rows of packed words) meets in one L2.  Used by k_edges (-2 %) and
-// k_node_scatter (-28 %); the kernels whose neighbouring rows hit the same COUNTERS with atomics (k_graph_obs, k_read_correction) were 20 % slower
-// with it - their atomics do better spread over all eight L2s
+// contiguous eighth of the units and what neighbouring units share (list entries, rows of packed words) meets in one L2.
 __device__ __forceinline__ int xcd_unit(int b, int n_blocks8) { return (b & 7) * (n_blocks8 >> 3) + (b >> 3); }
 __host__ __device__ inline int round_up8(int x) { return (x + 7) / 8 * 8; }
-struct JobSpan { uint32_t base; int total; int c1, c2, c3; unsigned dead; bool flat; int n[4]; uint32_t off[4]; };
-__device__ __forceinline__ JobSpan job_span(const RowDesc *rows, const uint8_t *deleted, int r0, int n_reads) {
+
+// Every observation was counted where it was made: the extraction's atomicAdd on var_cnt[variant] RETURNED the observation's rank inside the
+// variant's list (kept in bits 10..31 of ObsRec.aq), observations that were dropped afterwards - alignments deleted by the overlap filter, entries
+// erased by the CNV filter - were counted again in var_del / var_del2.  A variant is a graph node when observations are left (the reference's node
+// set, PhasingGraph.cpp:793-846); its list of (read, slot) entries has room for every rank handed out, the dropped ones stay behind as holes.
+// Two small launches instead of a device-wide scan library call each for the node numbers and the list offsets: workgroup sums, then every
+// workgroup adds up the sums before it (a few hundred numbers) and scans its own 1 024 variants.
+#define VSCAN_B 1024
+struct VarSum { uint32_t nodes, cap, valid; };
+__device__ __forceinline__ VarSum var_sum_of(int v, int n_var, const uint32_t *var_cnt, const uint32_t *var_del, const uint32_t *var_del2) {
+    VarSum x{0u, 0u, 0u};
+    if (v < n_var) { x.cap = var_cnt[v]; const uint32_t d = var_del[v] + var_del2[v]; x.valid = x.cap > d ? x.cap - d : 0u; x.nodes = x.valid ? 1u : 0u; }
+    return x;
+}
+__global__ __launch_bounds__(VSCAN_B) void k_var_sums(int n_var, const uint32_t *var_cnt, const uint32_t *var_del, const uint32_t *var_del2, uint32_t *bsum) {
+    __shared__ uint32_t s_a[16], s_b[16], s_c[16];
+    const int v = blockIdx.x * VSCAN_B + threadIdx.x, w = threadIdx.x >> 6;
+    const VarSum x = var_sum_of(v, n_var, var_cnt, var_del, var_del2);
+    const uint32_t a = wave_sum(x.nodes), b = wave_sum(x.cap), c = wave_sum(x.valid);
+    if (lane_id() == 0) { s_a[w] = a; s_b[w] = b; s_c[w] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t A = 0, B = 0, Cc = 0; for (int q = 0; q < VSCAN_B / 64; ++q) { A += s_a[q]; B += s_b[q]; Cc += s_c[q]; } bsum[3 * blockIdx.x] = A; bsum[3 * blockIdx.x + 1] = B; bsum[3 * blockIdx.x + 2] = Cc; }
+}
+__global__ __launch_bounds__(VSCAN_B) void k_var_scan(int n_var, const uint32_t *var_cnt, const uint32_t *var_del, const uint32_t *var_del2, const uint32_t *bsum,
+                                                      uint32_t *node_of, uint32_t *var_off, int32_t *nodes, uint32_t *node_off, uint32_t *node_cap, uint32_t *node_end, LpsCounters *cnt) {
+    __shared__ uint32_t s_a[16], s_b[16], s_c[16], s_base[3];
+    const int l = lane_id(), w = threadIdx.x >> 6;
+    {   // sums of the workgroups before this one
+        uint32_t a = 0, b = 0, c = 0;
+        for (int q = threadIdx.x; q < (int)blockIdx.x; q += VSCAN_B) { a += bsum[3 * q]; b += bsum[3 * q + 1]; c += bsum[3 * q + 2]; }
+        a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+        if (l == 0) { s_a[w] = a; s_b[w] = b; s_c[w] = c; }
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t A = 0, B = 0, Cc = 0; for (int q = 0; q < VSCAN_B / 64; ++q) { A += s_a[q]; B += s_b[q]; Cc += s_c[q]; } s_base[0] = A; s_base[1] = B; s_base[2] = Cc; }
+        __syncthreads();
+    }
+    const int v = blockIdx.x * VSCAN_B + threadIdx.x;
+    const VarSum x = var_sum_of(v, n_var, var_cnt, var_del, var_del2);
+    const uint32_t ia = (uint32_t)wave_incl_scan_dpp((int)x.nodes), ib = (uint32_t)wave_incl_scan_dpp((int)x.cap), ic = (uint32_t)wave_incl_scan_dpp((int)x.valid);
+    __syncthreads();
+    if (l == 63) { s_a[w] = ia; s_b[w] = ib; s_c[w] = ic; }
+    __syncthreads();
+    uint32_t pa = s_base[0], pb = s_base[1], pc = s_base[2];
+    for (int q = 0; q < w; ++q) { pa += s_a[q]; pb += s_b[q]; pc += s_c[q]; }
+    const uint32_t nd = pa + ia - x.nodes, off = pb + ib - x.cap;
+    if (v < n_var) {
+        node_of[v] = nd; var_off[v] = off;
+        if (x.nodes) { nodes[nd] = v; node_off[nd] = off; node_cap[nd] = x.cap; node_end[nd] = x.valid; }
+    }
+    if (v == n_var - 1) { cnt->n_nodes = nd + x.nodes; cnt->n_obs_final = (unsigned long long)(pc + ic); }
+}
+
+// ---- wave per extraction job (four alignments): the graph view of their observations and - for the alignments that are their read's only one,
+// nearly all - the entries of the node-major lists, in ONE pass (the counting pass, the device-wide scans and the scatter pass of the first two
+// rounds are gone: ranks come from the extraction, offsets from k_var_scan).
+//   * a row's valid observations (alignment not deleted, entry not erased by the CNV filter) are compacted to the front of the row's slots:
+//     g_pack[slot] = node << 2 | flags (bit 0 allele, bit 1 quality class): what k_edges reads per pair and k_read_correction per observation;
+//   * entry of the node's list at var_off[variant] + rank: key = (read name, index in row) - the order the reference adds a node's reads in
+//     (PhasingGraph.cpp:848-888: name order) - and the slot; a dropped observation leaves the all-ones key in its place (a hole k_edges sorts last);
+//   * the type of the LAST alignment (BAM order) that saw an indel / SV / MOD row wins (:803-832: (*variantType)[pos] = ... is last-writer-wins);
+//   * rows of reads with several alignments only get their packed words and ranks here: their merged row is built by k_merge_multi, which also
+//     places its entries.
+// The four rows need not be neighbours in the arena.  XCD-aware unit mapping: the entries of neighbouring reads are neighbours in the node lists.
+template <bool KEY64>
+__global__ __launch_bounds__(256) void k_graph_rows(int n_reads, const RowDesc *rows, const uint8_t *deleted, const ObsRec *obs, const uint32_t *name,
+                                                    const uint32_t *name_head, const uint32_t *name_link, const uint32_t *node_of, const uint32_t *var_off,
+                                                    int base_quality, int a_bits, uint32_t *g_pack, uint32_t *g_rank, int32_t *g_cnt,
+                                                    uint32_t *mrow_off, int32_t *mrow_cnt, void *ukeys_v, uint32_t *uvals, uint32_t *vtype_key, int nb_reads) {
     const int l = lane_id();
-    int n = 0; uint32_t off = 0; int del = 0;
-    if (l < 4 && r0 + l < n_reads) { const RowDesc d = rows[r0 + l]; n = max(d.cnt, 0); off = d.off; del = deleted ? deleted[r0 + l] : 0; }
-    JobSpan J;
+    const int r0 = (xcd_unit((int)blockIdx.x, nb_reads) * 4 + (threadIdx.x >> 6)) * 4;
+    if (r0 >= n_reads) return;
+    unsigned long long *ukeys64 = (unsigned long long *)ukeys_v; uint32_t *ukeys32 = (uint32_t *)ukeys_v;
+    int h_n = 0; uint32_t h_off = 0, h_name = 0; bool h_dead = true, h_single = false;
+    if (l < 4 && r0 + l < n_reads) {
+        const int r = r0 + l; const RowDesc d = rows[r]; h_n = max(d.cnt, 0); h_off = d.off;
+        if (h_n > 0) { h_dead = deleted[r] != 0; h_name = name[r]; h_single = name_head[h_name] == (uint32_t)r + 1u && name_link[r] == 0u; }
+    }
+    int n[4]; uint32_t off[4], nm[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { J.n[j] = __builtin_amdgcn_readlane(n, j); J.off[j] = (uint32_t)__builtin_amdgcn_readlane((int)off, j); }
-    J.dead = (unsigned)__ballot(del != 0 || n == 0) & 15u;
-    J.c1 = J.n[0]; J.c2 = J.c1 + J.n[1]; J.c3 = J.c2 + J.n[2]; J.total = J.c3 + J.n[3];
-    J.base = J.n[0] ? J.off[0] : (J.n[1] ? J.off[1] : (J.n[2] ? J.off[2] : J.off[3]));
-    J.flat = (!J.n[1] || J.off[1] == J.base + (uint32_t)J.c1) && (!J.n[2] || J.off[2] == J.base + (uint32_t)J.c2) && (!J.n[3] || J.off[3] == J.base + (uint32_t)J.c3);
-    return J;
-}
-
-__global__ __launch_bounds__(256) void k_mark_nodes(int n_reads, const RowDesc *rows,
-                                                    const uint8_t *deleted, const ObsRec *obs,
-                                                    uint32_t *is_node, uint32_t *vtype_key) {
-    const int l = lane_id();
-    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-    if (r0 >= n_reads) return;
-    const JobSpan J = job_span(rows, deleted, r0, n_reads);
-    auto mark = [&](const ObsRec o, int r) __attribute__((always_inline)) {
-        const int v = o.var; const int q = aq_quality((uint16_t)o.aq);
-        if (v < 0) return;                                    // erased by the CNV filter
-        const unsigned ty = (q >= 0) ? 0u : (q == -4 ? 3u : (q == -5 ? 4u : (q == -1 ? 1u : 2u)));      // :803-832 (-2 / -3: MOD on the forward / reverse strand)
-        is_node[v] = 1u;
-        // type of the LAST alignment that saw the variant.  Base qualities are never negative, so ty == 0 means a SNP row, all of whose
-        // observations are of type 0: the word stays 0 without 1.7 M atomics
-        if (ty) atomicMax(&vtype_key[v], ((unsigned)r << 3) | ty);
-    };
-    if (J.flat) {
-        for (int s0 = 0; s0 < J.total; s0 += 128) {                      // two rounds per trip: both loads leave before either is used
-            const int sa = s0 + l, sb = s0 + 64 + l;
-            ObsRec oa{-1, 0}, ob{-1, 0};
-            if (sa < J.total) oa = obs[J.base + sa];
-            if (sb < J.total) ob = obs[J.base + sb];
-            const int ja = (sa >= J.c1) + (sa >= J.c2) + (sa >= J.c3), jb = (sb >= J.c1) + (sb >= J.c2) + (sb >= J.c3);
-            if (sa < J.total && !((J.dead >> ja) & 1u)) mark(oa, r0 + ja);
-            if (sb < J.total && !((J.dead >> jb) & 1u)) mark(ob, r0 + jb);
-        }
-    } else {
-        for (int j = 0; j < 4; ++j) {
-            if ((J.dead >> j) & 1u) continue;
-            for (int k = l; k < J.n[j]; k += 64) mark(obs[J.off[j] + k], r0 + j);
-        }
-    }
-}
-
-// wave per alignment: graph view of the observations (node index, allele, hi-quality flag) in the same slots
-__global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const RowDesc *rows,
-                                                   const uint8_t *deleted, const ObsRec *obs,
-                                                   const uint32_t *node_of, int base_quality, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack, uint16_t *g_rank,
-                                                   int32_t *g_cnt, LpsCounters *cnt, int n_var, const uint32_t *is_node, const uint32_t *vtype_key,
-                                                   int32_t *nodes, uint8_t *ntype, uint32_t *node_cnt) {
-    const int nb_reads = (n_reads + 15) / 16;                              // four jobs of four alignments per workgroup
-    if ((int)blockIdx.x >= nb_reads) {                                  // the workgroups after the alignments': node list (variant index, type) and node count
-        const int v = ((int)blockIdx.x - nb_reads) * blockDim.x + threadIdx.x;
-        if (v < n_var) {
-            if (is_node[v]) { nodes[node_of[v]] = v; ntype[node_of[v]] = (uint8_t)(vtype_key[v] & 7u); }
-            if (v == n_var - 1) cnt->n_nodes = node_of[v] + is_node[v];
-        }
-        return;
-    }
-    // wave per extraction job: the job's four rows as one span (see job_span), two 64-lane rounds per trip with their gathers and atomics in flight together
-    const int l = lane_id();
-    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-    if (r0 >= n_reads) return;
-    const JobSpan J = job_span(rows, deleted, r0, n_reads);
-    // one observation -> its graph view in slot `slot` (compacted: CNV-erased entries have var < 0 and leave no slot)
-    auto emit = [&](int v, uint16_t aq, uint32_t slot) __attribute__((always_inline)) {
-        int q = aq_quality(aq); if (q < 0) q = (q == -1 && !aq_allele(aq)) ? 30 : 60;   // sentinels -> quality 60; a SV row the read does not carry: 30 (:803-828)
-        const uint32_t nd = node_of[v];
-        const unsigned fl = (unsigned)aq_allele(aq) | ((q >= base_quality) ? 2u : 0u);
-        g_node[slot] = (int32_t)nd;
-        g_flag[slot] = (uint8_t)fl;
-        g_pack[slot] = ((uint32_t)nd << 2) | fl;              // node and flag (bit 0 allele, bit 1 quality class) in one word: what k_edges reads per pair
-        // entries of the node's list: the merged rows hold exactly these observations.  What the counting atomic returns is a unique rank inside
-        // that list: kept, it places the entry later without a second atomic (k_node_scatter)
-        const unsigned rk = atomicAdd(&node_cnt[nd], 1u);
-        if (rk > 0xffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE);   // more than 65 536 reads over one variant
-        g_rank[slot] = (uint16_t)rk;
-    };
-    int w0 = 0, w1 = 0, w2 = 0, w3 = 0;                                   // entries placed so far in each row (wave-uniform)
-    if (J.flat) {
-        const unsigned long long lt = lanemask_lt();
-        // slot of a valid entry: its row's first slot + the row's valid entries before it (earlier rounds: w; this round: ballot under the row's lanes)
-        auto place = [&](int s0, int s, bool ok, unsigned long long m) __attribute__((always_inline)) -> uint32_t {
-            const int j = (s >= J.c1) + (s >= J.c2) + (s >= J.c3);
-            auto lanes = [&](int lo, int hi) __attribute__((always_inline)) -> unsigned long long {            // lanes of this round whose position is in [lo, hi)
-                const int a = min(max(lo - s0, 0), 64), b = min(max(hi - s0, 0), 64);
-                return ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((a >= 64) ? ~0ull : ((1ull << a) - 1ull));
-            };
-            const unsigned long long r0m = lanes(0, J.c1), r1m = lanes(J.c1, J.c2), r2m = lanes(J.c2, J.c3), r3m = lanes(J.c3, J.total);
-            const unsigned long long mine = j == 0 ? r0m : (j == 1 ? r1m : (j == 2 ? r2m : r3m));
-            const int wj = j == 0 ? w0 : (j == 1 ? w1 : (j == 2 ? w2 : w3));
-            const uint32_t first = J.base + (uint32_t)(j == 0 ? 0 : (j == 1 ? J.c1 : (j == 2 ? J.c2 : J.c3)));
-            const uint32_t slot = first + (uint32_t)wj + (uint32_t)__popcll(m & mine & lt);
-            w0 += __popcll(m & r0m); w1 += __popcll(m & r1m); w2 += __popcll(m & r2m); w3 += __popcll(m & r3m);
-            (void)ok;
-            return slot;
+    for (int j = 0; j < 4; ++j) { n[j] = __builtin_amdgcn_readlane(h_n, j); off[j] = (uint32_t)__builtin_amdgcn_readlane((int)h_off, j); nm[j] = (uint32_t)__builtin_amdgcn_readlane((int)h_name, j); }
+    const unsigned dead = (unsigned)__ballot(h_dead) & 15u, single = (unsigned)__ballot(h_single) & 15u;
+    const int c1 = n[0], c2 = c1 + n[1], c3 = c2 + n[2], total = c3 + n[3];
+    int w0 = 0, w1 = 0, w2 = 0, w3 = 0;                                 // valid entries placed so far in each row (wave-uniform)
+    const unsigned long long lt = lanemask_lt();
+    for (int s0 = 0; s0 < total; s0 += 64) {
+        const int s = s0 + l;
+        const bool in = s < total;
+        const int j = (s >= c1) + (s >= c2) + (s >= c3);
+        const int cj = j == 0 ? 0 : (j == 1 ? c1 : (j == 2 ? c2 : c3));
+        const uint32_t oj = j == 0 ? off[0] : (j == 1 ? off[1] : (j == 2 ? off[2] : off[3]));
+        ObsRec o{-1, 0};
+        if (in) o = obs[oj + (uint32_t)(s - cj)];
+        const bool row_dead = (dead >> j) & 1u;
+        const bool valid = in && !row_dead && o.var >= 0;
+        const int v = o.var >= 0 ? o.var : -1 - o.var;                   // (an entry the CNV filter erased keeps its variant as -1 - index)
+        const uint32_t rank = o.aq >> 10;
+        // place among the valid entries of its row: the row's earlier rounds (w) + this round's valid lanes of the row below this one
+        auto lanes = [&](int lo, int hi) __attribute__((always_inline)) -> unsigned long long {
+            const int a = min(max(lo - s0, 0), 64), b = min(max(hi - s0, 0), 64);
+            return ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((a >= 64) ? ~0ull : ((1ull << a) - 1ull));
         };
-        for (int s0 = 0; s0 < J.total; s0 += 128) {
-            const int sa = s0 + l, sb = s0 + 64 + l;
-            ObsRec oa{-1, 0}, ob{-1, 0};
-            if (sa < J.total) oa = obs[J.base + sa];
-            if (sb < J.total) ob = obs[J.base + sb];
-            const int ja = (sa >= J.c1) + (sa >= J.c2) + (sa >= J.c3), jb = (sb >= J.c1) + (sb >= J.c2) + (sb >= J.c3);
-            const bool oka = sa < J.total && !((J.dead >> ja) & 1u) && oa.var >= 0, okb = sb < J.total && !((J.dead >> jb) & 1u) && ob.var >= 0;
-            const unsigned long long ma = __ballot(oka), mb = __ballot(okb);
-            const uint32_t slot_a = place(s0, sa, oka, ma), slot_b = place(s0 + 64, sb, okb, mb);
-            if (oka) emit(oa.var, (uint16_t)oa.aq, slot_a);
-            if (okb) emit(ob.var, (uint16_t)ob.aq, slot_b);
-        }
-    } else {
-        for (int j = 0; j < 4; ++j) {                                   // rows that were moved: one after the other, 64 lanes each
-            if ((J.dead >> j) & 1u) continue;
-            int w = 0;
-            for (int k0 = 0; k0 < J.n[j]; k0 += 64) {
-                const int k = k0 + l;
-                ObsRec o{-1, 0};
-                if (k < J.n[j]) o = obs[J.off[j] + k];
-                const bool ok = o.var >= 0;
-                const unsigned long long m = __ballot(ok);
-                if (ok) emit(o.var, (uint16_t)o.aq, J.off[j] + (uint32_t)w + (uint32_t)__popcll(m & lanemask_lt()));
-                w += __popcll(m);
+        const unsigned long long m = __ballot(valid);
+        const unsigned long long r0m = lanes(0, c1), r1m = lanes(c1, c2), r2m = lanes(c2, c3), r3m = lanes(c3, total);
+        const unsigned long long mine = j == 0 ? r0m : (j == 1 ? r1m : (j == 2 ? r2m : r3m));
+        const int wj = j == 0 ? w0 : (j == 1 ? w1 : (j == 2 ? w2 : w3));
+        const int a = wj + __popcll(m & mine & lt);
+        w0 += __popcll(m & r0m); w1 += __popcll(m & r1m); w2 += __popcll(m & r2m); w3 += __popcll(m & r3m);
+        if (in) {
+            const uint32_t e = var_off[v] + rank;
+            if (valid) {
+                const uint16_t aq = (uint16_t)o.aq;
+                const int q0 = aq_quality(aq);
+                const int q = q0 < 0 ? ((q0 == -1 && !aq_allele(aq)) ? 30 : 60) : q0;   // sentinels -> quality 60; a SV row the read does not carry: 30 (:803-828)
+                const unsigned fl = (unsigned)aq_allele(aq) | ((q >= base_quality) ? 2u : 0u);
+                const uint32_t slot = oj + (uint32_t)a;
+                g_pack[slot] = (node_of[v] << 2) | fl;
+                if (q0 < 0) {                                             // :803-832 (-2 / -3: MOD on the forward / reverse strand)
+                    const unsigned ty = q0 == -4 ? 3u : (q0 == -5 ? 4u : (q0 == -1 ? 1u : 2u));
+                    atomicMax(&vtype_key[v], ((unsigned)(r0 + j) << 3) | ty);
+                }
+                if ((single >> j) & 1u) {
+                    const uint32_t nmj = j == 0 ? nm[0] : (j == 1 ? nm[1] : (j == 2 ? nm[2] : nm[3]));
+                    if (KEY64) ukeys64[e] = ((unsigned long long)nmj << a_bits) | (unsigned)a; else ukeys32[e] = (nmj << a_bits) | (unsigned)a;
+                    uvals[e] = slot;
+                } else g_rank[slot] = rank;
+            } else if (n[0] + n[1] + n[2] + n[3] > 0) {                   // a dropped observation: its place in the list stays a hole
+                if (KEY64) ukeys64[e] = ~0ull; else ukeys32[e] = 0xffffffffu;
             }
-            if (j == 0) w0 = w; else if (j == 1) w1 = w; else if (j == 2) w2 = w; else w3 = w;
         }
     }
-    if (l < 4 && r0 + l < n_reads) g_cnt[r0 + l] = ((J.dead >> l) & 1u) ? 0 : (l == 0 ? w0 : (l == 1 ? w1 : (l == 2 ? w2 : w3)));
+    if (l < 4 && r0 + l < n_reads) {
+        const int wl = l == 0 ? w0 : (l == 1 ? w1 : (l == 2 ? w2 : w3));
+        const int kept = h_dead ? 0 : wl;
+        g_cnt[r0 + l] = kept;
+        if (h_single) { mrow_off[h_name] = h_off; mrow_cnt[h_name] = kept; }
+    }
+}
+
+// SV / MOD co-phasing re-indexes every observation after the extraction (k_extra_merge): the ranks are taken here instead, one pass over the rows.
+// Alignments the overlap filter deleted count like the others and are taken off again in var_del, as k_groups does on the plain path.
+__global__ __launch_bounds__(256) void k_count_ranks(int n_reads, const RowDesc *rows, const uint8_t *deleted, ObsRec *obs, uint32_t *var_cnt, uint32_t *var_del, LpsCounters *cnt) {
+    const int l = lane_id();
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_reads) return;
+    const RowDesc d = rows[r];
+    const bool del = deleted[r] != 0;
+    for (int k = l; k < d.cnt; k += 64) {
+        ObsRec o = obs[d.off + k];
+        const unsigned rk = atomicAdd(&var_cnt[o.var], 1u);
+        if (rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE);
+        o.aq = (o.aq & 0x3ffu) | (rk << 10);
+        obs[d.off + k] = o;
+        if (del) atomicAdd(&var_del[o.var], 1u);
+    }
 }
 
 // ================================================================================================ merged rows
@@ -494,25 +554,22 @@ __global__ __launch_bounds__(256) void k_graph_obs(int n_reads, const RowDesc *r
 // k_merge_multi (wave per queued group) places every element by rank: own index + elements of the other rows that sort before it
 // (ties: earlier alignment first).  That is the stable order == libstdc++ std::sort for n <= 16 and differs from it only in the
 // relative order of equal positions beyond that.
-__global__ __launch_bounds__(256) void k_merge_plan(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt,
+__global__ __launch_bounds__(256) void k_merge_plan(LpsCounters *cnt, const uint32_t *mg_start, const uint32_t *mg_cnt, const uint32_t *mg_name, const uint32_t *mm_r,
                              const RowDesc *rows, const int32_t *g_cnt, unsigned long long tail_lo, unsigned long long tail_size,
-                             uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list) {
+                             uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *mg_plan) {
     __shared__ unsigned s_tot[4], s_n[4]; __shared__ unsigned long long s_base_t; __shared__ unsigned s_base_n;
-    const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
     const int w = threadIdx.x >> 6;
-    bool multi = false; int total = 0;
-    if (g < cnt->n_groups) {
-        const uint32_t s0 = gstart[g], s1 = gstart[g + 1];
-        if (s1 - s0 == 1) { const uint32_t r = (uint32_t)skeys[s0]; mrow_off[g] = rows[r].off; mrow_cnt[g] = g_cnt[r]; }
-        else {
-            int alive = 0; uint32_t one = 0;
-            for (uint32_t s = s0; s < s1; ++s) { const uint32_t r = (uint32_t)skeys[s]; if (g_cnt[r] > 0) { ++alive; total += g_cnt[r]; one = r; } }
-            if (alive == 0) { mrow_off[g] = 0; mrow_cnt[g] = 0; }
-            else if (alive == 1) { mrow_off[g] = rows[one].off; mrow_cnt[g] = total; }
-            else multi = true;
-        }
+    bool multi = false; int total = 0; uint32_t id = 0;
+    if (q < cnt->n_multi) {
+        const uint32_t s0 = mg_start[q], k = mg_cnt[q]; id = mg_name[q];
+        int alive = 0; uint32_t one = 0;
+        for (uint32_t t = 0; t < k; ++t) { const uint32_t r = mm_r[s0 + t]; if (g_cnt[r] > 0) { ++alive; total += g_cnt[r]; one = r; } }
+        if (alive == 0) { mrow_off[id] = 0; mrow_cnt[id] = 0; mg_plan[q] = 0u; }
+        else if (alive == 1) { mrow_off[id] = rows[one].off; mrow_cnt[id] = total; mg_plan[q] = 1u | (one << 2); }   // the one row IS the merged row: only its entries are placed
+        else multi = true;
     }
-    // tail slots and queue entries: ONE atomic each per workgroup (same-word atomics are served one after the other)
+    // tail slots and the count of merged rows: ONE atomic each per workgroup (same-word atomics are served one after the other)
     const int mine = multi ? total : 0;
     const int incl = wave_incl_scan_dpp(mine);
     const unsigned long long mm = __ballot(multi);
@@ -521,14 +578,14 @@ __global__ __launch_bounds__(256) void k_merge_plan(const unsigned long long *sk
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long T = (unsigned long long)s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3]; const unsigned N = s_n[0] + s_n[1] + s_n[2] + s_n[3];
-        s_base_t = T ? atomicAdd(&cnt->tail_total, T) : 0ull; s_base_n = N ? atomicAdd(&cnt->n_multi, N) : 0u;
+        s_base_t = T ? atomicAdd(&cnt->tail_total, T) : 0ull; if (N) atomicAdd(&cnt->n_merged, N);
     }
     __syncthreads();
     if (multi) {
-        unsigned long long toff = s_base_t + (unsigned long long)(incl - mine); unsigned qi = s_base_n + (unsigned)__popcll(mm & lanemask_lt());
-        for (int q = 0; q < w; ++q) { toff += s_tot[q]; qi += s_n[q]; }
-        if (toff + (unsigned long long)total > tail_size) { atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); mrow_off[g] = 0; mrow_cnt[g] = 0; multi_list[qi] = 0xffffffffu; }
-        else { mrow_off[g] = (uint32_t)(tail_lo + toff); mrow_cnt[g] = total; multi_list[qi] = g; }
+        unsigned long long toff = s_base_t + (unsigned long long)(incl - mine);
+        for (int qq = 0; qq < w; ++qq) toff += s_tot[qq];
+        if (toff + (unsigned long long)total > tail_size) { atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); mrow_off[id] = 0; mrow_cnt[id] = 0; mg_plan[q] = 0u; }   // the host grows the buffers and reruns
+        else { mrow_off[id] = (uint32_t)(tail_lo + toff); mrow_cnt[id] = total; mg_plan[q] = 2u; }
     }
 }
 
@@ -611,52 +668,69 @@ void launch_debug_std_sort(int32_t *keys, uint8_t *payload, const long long *row
     hipLaunchKernelGGL(k_debug_std_sort, dim3(256), dim3(256), 0, s, keys, payload, row_start, n_rows);
 }
 
-__global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *skeys, const uint32_t *gstart, const LpsCounters *cnt,
-                                                     const RowDesc *rows, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack, uint32_t *t_src, uint32_t tail_lo,
-                                                     const uint32_t *mrow_off, const uint32_t *multi_list) {
+template <bool KEY64>
+__global__ __launch_bounds__(256) void k_merge_multi(const LpsCounters *cnt, const uint32_t *mg_start, const uint32_t *mg_cnt, const uint32_t *mg_name, const uint32_t *mg_plan, const uint32_t *mm_r,
+                                                     const RowDesc *rows, const int32_t *g_cnt, uint32_t *g_pack, const uint32_t *g_rank, int32_t *t_node, uint8_t *t_flag, uint32_t *t_src, uint32_t tail_lo,
+                                                     const uint32_t *mrow_off, const int32_t *nodes, const uint32_t *var_off, int a_bits, void *ukeys_v, uint32_t *uvals) {
     __shared__ int s_stk[4][192]; __shared__ int32_t s_k[4][STDSORT_LDS]; __shared__ uint8_t s_p[4][STDSORT_LDS]; __shared__ uint16_t s_a[4][STDSORT_LDS], s_b[4][STDSORT_LDS];
     const int l = lane_id();
     const unsigned n_waves = gridDim.x * 4;
+    unsigned long long *ukeys64 = (unsigned long long *)ukeys_v; uint32_t *ukeys32 = (uint32_t *)ukeys_v;
     for (unsigned q = blockIdx.x * 4 + (threadIdx.x >> 6); q < cnt->n_multi; q += n_waves) {
-        const unsigned g = multi_list[q];
-        if (g == 0xffffffffu) continue;                                   // its tail reservation failed (the host grows the buffers and reruns)
-        const uint32_t s0 = gstart[g], s1 = gstart[g + 1];
-        const uint32_t base = mrow_off[g];
+        const uint32_t plan = mg_plan[q];
+        if ((plan & 3u) == 0u) continue;                                  // no observation left, or its tail reservation failed (the host grows the buffers and reruns)
+        const uint32_t id = mg_name[q];
+        // entry of the node's list for element a of the read's merged row: (read name, a) at the rank of the observation it came from
+        auto place = [&](int a, uint32_t slot, int nd, uint32_t src) __attribute__((always_inline)) {
+            const uint32_t e = var_off[nodes[nd]] + g_rank[src];
+            if (KEY64) ukeys64[e] = ((unsigned long long)id << a_bits) | (unsigned)a; else ukeys32[e] = (id << a_bits) | (unsigned)a;
+            uvals[e] = slot;
+        };
+        if ((plan & 3u) == 1u) {                                          // one alignment left: its row is the merged row
+            const uint32_t r = plan >> 2, off = rows[r].off; const int n = g_cnt[r];
+            for (int a = l; a < n; a += 64) place(a, off + (uint32_t)a, (int)(g_pack[off + a] >> 2), off + (uint32_t)a);
+            continue;
+        }
+        const uint32_t s0 = mg_start[q], s1 = s0 + mg_cnt[q];
+        const uint32_t base = mrow_off[id];
+        int32_t *m_node = t_node + (base - tail_lo); uint8_t *m_flag = t_flag + (base - tail_lo); uint32_t *m_src = t_src + (base - tail_lo);
         const int w = threadIdx.x >> 6;
-        int total = 0; for (uint32_t sa = s0; sa < s1; ++sa) total += g_cnt[(uint32_t)skeys[sa]];
+        int total = 0; for (uint32_t sa = s0; sa < s1; ++sa) total += g_cnt[mm_r[sa]];
         const bool in_lds = total <= STDSORT_LDS;
         // the alignments' rows concatenated in BAM order, in LDS when they fit (they do for real read lengths): the rank searches below are chains
         // of dependent probes - tens of cycles each in LDS, a microsecond each in HBM - and the std::sort path wants this copy anyway
         if (in_lds) {
             int at = 0;
-            for (uint32_t sa = s0; sa < s1; ++sa) { const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = rows[ra].off;
-                for (int k = l; k < na; k += 64) { s_k[w][at + k] = g_node[oa + k]; s_p[w][at + k] = g_flag[oa + k]; } at += na; }
+            for (uint32_t sa = s0; sa < s1; ++sa) { const uint32_t ra = mm_r[sa]; const int na = g_cnt[ra]; const uint32_t oa = rows[ra].off;
+                for (int k = l; k < na; k += 64) { const uint32_t wd = g_pack[oa + k]; s_k[w][at + k] = (int32_t)(wd >> 2); s_p[w][at + k] = (uint8_t)(wd & 3u); } at += na; }
             wave_sync();
         }
         bool dup = false;
         int aa = 0;                                                      // offset of alignment sa's row inside the concatenation
         for (uint32_t sa = s0; sa < s1; ++sa) {                      // source alignment (BAM order inside the group)
-            const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = rows[ra].off;
+            const uint32_t ra = mm_r[sa]; const int na = g_cnt[ra]; const uint32_t oa = rows[ra].off;
             for (int k = l; k < na; k += 64) {
-                const int nd = in_lds ? s_k[w][aa + k] : g_node[oa + k]; const uint8_t fl = in_lds ? s_p[w][aa + k] : g_flag[oa + k];
+                const uint32_t wd = in_lds ? 0u : g_pack[oa + k];
+                const int nd = in_lds ? s_k[w][aa + k] : (int)(wd >> 2); const uint8_t fl = in_lds ? s_p[w][aa + k] : (uint8_t)(wd & 3u);
                 int rank = k, ab = 0;
                 for (uint32_t sb = s0; sb < s1; ++sb) {
-                    const uint32_t rb = (uint32_t)skeys[sb]; const int nb = g_cnt[rb];
+                    const uint32_t rb = mm_r[sb]; const int nb = g_cnt[rb];
                     if (sb != sa) {
-                        const int32_t *row = in_lds ? s_k[w] + ab : g_node + rows[rb].off;
+                        const uint32_t ob = rows[rb].off;
+                        auto at_b = [&](int m) __attribute__((always_inline)) -> int { return in_lds ? s_k[w][ab + m] : (int)(g_pack[ob + m] >> 2); };
                         // earlier alignment: its equal positions go first (count <= nd); later alignment: only smaller ones
                         int lo = 0, hi = nb;
-                        if (sb < sa) { while (lo < hi) { const int m = (lo + hi) >> 1; if (row[m] <= nd) lo = m + 1; else hi = m; } }
-                        else { while (lo < hi) { const int m = (lo + hi) >> 1; if (row[m] < nd) lo = m + 1; else hi = m; }
-                               dup |= lo < nb && row[lo] == nd; }                                    // the same position in a later alignment
+                        if (sb < sa) { while (lo < hi) { const int m = (lo + hi) >> 1; if (at_b(m) <= nd) lo = m + 1; else hi = m; } }
+                        else { while (lo < hi) { const int m = (lo + hi) >> 1; if (at_b(m) < nd) lo = m + 1; else hi = m; }
+                               dup |= lo < nb && at_b(lo) == nd; }                                   // the same position in a later alignment
                         rank += lo;
                     }
                     ab += nb;
                 }
-                g_node[base + rank] = nd; g_flag[base + rank] = fl;
-                // the observation this element came from: its rank in the node's list places the element (k_node_scatter).  The std::sort path below only
+                m_node[rank] = nd; m_flag[rank] = fl;
+                // the observation this element came from: its rank in the node's list places the element.  The std::sort path below only
                 // permutes elements of EQUAL node among themselves, so the pairing stays a bijection per node
-                t_src[base - tail_lo + rank] = oa + k;
+                m_src[rank] = oa + k;
             }
             aa += na;
         }
@@ -668,99 +742,25 @@ __global__ __launch_bounds__(256) void k_merge_multi(const unsigned long long *s
             if (__ballot(dup)) {
                 // sorted by the whole wave (wave_std_sort) from the LDS copy for rows of up to STDSORT_LDS elements, else in place in HBM by lane 0
                 // (a chain of dependent accesses at ~1 us each; such rows do not occur with real read lengths)
-                if (in_lds) { wave_sync(); wave_std_sort(s_k[w], s_p[w], total, s_stk[w], s_a[w], s_b[w], g_node + base, g_flag + base, l); }
+                if (in_lds) { wave_sync(); wave_std_sort(s_k[w], s_p[w], total, s_stk[w], s_a[w], s_b[w], m_node, m_flag, l); }
                 else {
                     int at = 0;
-                    for (uint32_t sa = s0; sa < s1; ++sa) { const uint32_t ra = (uint32_t)skeys[sa]; const int na = g_cnt[ra]; const uint32_t oa = rows[ra].off;
-                        for (int k = l; k < na; k += 64) { g_node[base + at + k] = g_node[oa + k]; g_flag[base + at + k] = g_flag[oa + k]; } at += na; }
+                    for (uint32_t sa = s0; sa < s1; ++sa) { const uint32_t ra = mm_r[sa]; const int na = g_cnt[ra]; const uint32_t oa = rows[ra].off;
+                        for (int k = l; k < na; k += 64) { const uint32_t wd = g_pack[oa + k]; m_node[at + k] = (int32_t)(wd >> 2); m_flag[at + k] = (uint8_t)(wd & 3u); } at += na; }
                     __threadfence_block();
-                    if (l == 0) { StdSortArrays a{g_node + base, g_flag + base}; stdsort_run(a, total, s_stk[w]); }
+                    if (l == 0) { StdSortArrays a{m_node, m_flag}; stdsort_run(a, total, s_stk[w]); }
                 }
                 __threadfence_block();
             }
         }
 #endif
         __threadfence_block(); wave_sync();
-        for (int k = l; k < total; k += 64) g_pack[base + k] = ((uint32_t)g_node[base + k] << 2) | (uint32_t)g_flag[base + k];   // the merged row as k_edges reads it
+        for (int k = l; k < total; k += 64) {                             // the merged row as k_edges reads it, and its entries in the node lists
+            const int nd = m_node[k];
+            g_pack[base + k] = ((uint32_t)nd << 2) | (uint32_t)m_flag[k];
+            place(k, base + (uint32_t)k, nd, m_src[k]);
+        }
         wave_sync();                                                     // the LDS copy is reused by the wave's next group
-    }
-}
-
-// ---- node-major lists: entries of node n = observations of n in merged rows, ordered by (name rank, index in merged row).
-// No global sort: count per node (atomics, in k_graph_obs), exclusive scan, scatter in arbitrary order; every node's short list is put in order by rank
-// counting by the wave of k_edges that consumes it (n^2/64 compares for n entries; n ~ coverage).
-__global__ __launch_bounds__(256) void k_node_scatter(const LpsCounters *cnt, const RowDesc *rows, const int32_t *g_cnt, const uint32_t *read_group, const uint32_t *gstart,
-                                                      const uint32_t *mrow_off, const int32_t *mrow_cnt, const uint32_t *multi_list,
-                                                      const int32_t *g_node, const uint16_t *g_rank, const uint32_t *t_src, uint32_t tail_lo,
-                                                      const uint32_t *node_off, int a_bits,
-                                                      unsigned long long *keys, uint32_t *vals, LpsCounters *cntw, int n_var, int n_reads, int nb_reads) {
-    // No atomics: every observation already holds a unique rank inside its node's list (what k_graph_obs's counting atomic returned).  And BAM order: the
-    // entries of a node's list come from reads that overlap the node, i.e. from neighbours in BAM order, so the lists being filled at any moment span a
-    // few megabytes and the 12-byte entries combine in L2 before they reach HBM (walking the merged rows in name order sent every entry to a cold line:
-    // 5.6 bytes written per payload byte).  Reads of one alignment (nearly all) use their row as the merged row; the merged rows of multi-alignment reads
-    // (tail arena; an element takes the rank of the observation it was copied from) follow in the trailing workgroups.
-    const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
-    if ((int)blockIdx.x >= nb_reads) {
-        const unsigned stride = (gridDim.x - nb_reads) * ROWS_PER_BLOCK, n_multi = cnt->n_multi;
-        for (unsigned q = (((int)blockIdx.x - nb_reads) * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp; q < n_multi; q += stride) {
-            const unsigned g = multi_list[q];
-            if (g == 0xffffffffu) continue;                             // its tail reservation failed (the host grows the buffers and reruns)
-            const int n = mrow_cnt[g];
-            if ((unsigned long long)n > (1ull << a_bits)) { if (sl == 0) atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); continue; }
-            const uint32_t off = mrow_off[g];
-            for (int a = sl; a < n; a += ROW_G) {
-                const int nd = g_node[off + a];
-                const uint32_t slot = node_off[nd] + g_rank[t_src[off - tail_lo + a]];
-                keys[slot] = ((unsigned long long)g << a_bits) | (unsigned)a; vals[slot] = off + a;
-            }
-        }
-        return;
-    }
-    // (XCD-aware, as in k_edges: the eight XCDs each walk a contiguous eighth of the rows, so that the entries of neighbouring reads - neighbours in
-    // the node lists - are put together in ONE L2 before they reach HBM; nb_reads is a multiple of 8.)  A wave takes the span of an extraction job
-    // (job_span: four rows back to back, the compacted entries at the front of each row's part), two 64-lane rounds in flight.
-    const int r0 = (xcd_unit((int)blockIdx.x, nb_reads) * 4 + (threadIdx.x >> 6)) * 4;
-    if (r0 == 0 && l == 0) cntw->n_obs_final = node_off[n_var];         // sum of merged rows = end of the last node's list
-    if (r0 >= n_reads) return;
-    const JobSpan J = job_span(rows, nullptr, r0, n_reads);
-    // per row (lanes 0-3): entries kept, name group, and whether the row IS its read's merged row (a group with ONE surviving alignment uses that
-    // alignment's row; the rows of the others are parts of a merged row in the tail arena, handled above)
-    int gc = 0; unsigned g = 0; bool use = false;
-    if (l < 4 && r0 + l < n_reads) {
-        gc = max(g_cnt[r0 + l], 0); g = read_group[r0 + l];
-        if (gc > 0) {
-            use = !(gstart[g + 1] - gstart[g] != 1 && mrow_off[g] != J.off[l]);
-            if ((unsigned long long)gc > (1ull << a_bits)) { atomicOr(&cntw->err, (unsigned)LPS_ERR_KEY_RANGE); use = false; }
-        }
-    }
-    const unsigned um = (unsigned)__ballot(use) & 15u;
-    if (!um) return;
-    const int k0 = __builtin_amdgcn_readlane(gc, 0), k1 = __builtin_amdgcn_readlane(gc, 1), k2 = __builtin_amdgcn_readlane(gc, 2), k3 = __builtin_amdgcn_readlane(gc, 3);
-    const unsigned q0 = (unsigned)__builtin_amdgcn_readlane((int)g, 0), q1 = (unsigned)__builtin_amdgcn_readlane((int)g, 1), q2 = (unsigned)__builtin_amdgcn_readlane((int)g, 2), q3 = (unsigned)__builtin_amdgcn_readlane((int)g, 3);
-    auto put = [&](uint32_t at, unsigned gj, int a, int nd, unsigned rk) __attribute__((always_inline)) {
-        const uint32_t slot = node_off[nd] + rk;
-        keys[slot] = ((unsigned long long)gj << a_bits) | (unsigned)a;      // (name rank, index in row)
-        vals[slot] = at;
-    };
-    if (J.flat) {
-        for (int s0 = 0; s0 < J.total; s0 += 128) {
-            const int sa = s0 + l, sb = s0 + 64 + l;
-            const int ja = (sa >= J.c1) + (sa >= J.c2) + (sa >= J.c3), jb = (sb >= J.c1) + (sb >= J.c2) + (sb >= J.c3);
-            const int aa = sa - (ja == 0 ? 0 : (ja == 1 ? J.c1 : (ja == 2 ? J.c2 : J.c3))), ab = sb - (jb == 0 ? 0 : (jb == 1 ? J.c1 : (jb == 2 ? J.c2 : J.c3)));
-            const bool ina = sa < J.total && ((um >> ja) & 1u) && aa < (ja == 0 ? k0 : (ja == 1 ? k1 : (ja == 2 ? k2 : k3)));
-            const bool inb = sb < J.total && ((um >> jb) & 1u) && ab < (jb == 0 ? k0 : (jb == 1 ? k1 : (jb == 2 ? k2 : k3)));
-            int nda = 0, ndb = 0; unsigned rka = 0, rkb = 0;
-            if (ina) { nda = g_node[J.base + sa]; rka = g_rank[J.base + sa]; }
-            if (inb) { ndb = g_node[J.base + sb]; rkb = g_rank[J.base + sb]; }
-            if (ina) put(J.base + sa, ja == 0 ? q0 : (ja == 1 ? q1 : (ja == 2 ? q2 : q3)), aa, nda, rka);
-            if (inb) put(J.base + sb, jb == 0 ? q0 : (jb == 1 ? q1 : (jb == 2 ? q2 : q3)), ab, ndb, rkb);
-        }
-    } else {
-        for (int j = 0; j < 4; ++j) {                                   // rows that were moved: one after the other
-            if (!((um >> j) & 1u)) continue;
-            const int n = j == 0 ? k0 : (j == 1 ? k1 : (j == 2 ? k2 : k3)); const unsigned gj = j == 0 ? q0 : (j == 1 ? q1 : (j == 2 ? q2 : q3));
-            for (int a = l; a < n; a += 64) put(J.off[j] + a, gj, a, g_node[J.off[j] + a], g_rank[J.off[j] + a]);
-        }
     }
 }
 
@@ -781,61 +781,69 @@ __device__ __forceinline__ void cell_upd(float &x0, float &x1, uint32_t word, ui
 // wave per source node i.  Lane k (< A) owns the four cells (rr,ra,ar,aa) towards node i+1+k in registers.
 // For each read observing node i (in name-rank order) lane t loads the read's t-th following observation;
 // its node distance d selects the owning lane, the (allele pair, quality class) travels there by ds_permute.
-__global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uint32_t *node_off, const uint32_t *node_end,
-                                               const unsigned long long *ukeys, const uint32_t *uvals,
-                                               unsigned long long *skeys, uint32_t *svals,
+template <bool KEY64>
+__global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uint32_t *node_off, const uint32_t *node_cap, const uint32_t *node_end,
+                                               const void *ukeys_v, const uint32_t *uvals,
+                                               void *skeys_v, uint32_t *svals,
                                                const uint32_t *mrow_off, const int32_t *mrow_cnt, int m_bits, int a_bits,
                                                const uint32_t *g_pack, uint32_t tail_lo, int A, double edge_weight,
-                                               double edge_threshold, const uint8_t *ntype, float *edge, uint8_t *erec, uint32_t *node_pairs) {
+                                               double edge_threshold, const int32_t *nodes, const uint32_t *vtype_key, float *edge, uint8_t *erec, uint32_t *node_pairs) {
+    typedef typename std::conditional<KEY64, unsigned long long, uint32_t>::type key_t;
+    const key_t *ukeys = (const key_t *)ukeys_v; key_t *skeys = (key_t *)skeys_v;
+    const key_t HOLE = (key_t)~(key_t)0;                                // a dropped observation's place in the list (k_graph_rows)
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2, and a row of packed words is wanted by the ~35 source nodes before it:
     // workgroup b takes node block (b % 8) * (blocks / 8) + b / 8, so that an XCD walks ONE contiguous eighth of the nodes and a row is fetched into
     // one L2, not into all eight (the grid is a multiple of 8)
     const int i = xcd_unit((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6), l = lane_id();
     const int n_nodes = (int)cnt->n_nodes;
     if (i >= n_nodes) return;
-    const uint32_t off = node_off[i], end = off + node_end[i];      // node_end holds the entry COUNT of the node
+    // the node's list: room for every observation counted at the extraction (cap), of which n_valid are left after the filters; the others are holes
+    const uint32_t off = node_off[i]; const int cap = (int)node_cap[i], n_valid = (int)node_end[i];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     unsigned long long pairs = 0;
-    const unsigned long long m_mask = (1ull << m_bits) - 1ull;
+    const uint32_t m_mask = (uint32_t)((1ull << m_bits) - 1ull);
     const uint32_t first4 = (uint32_t)__builtin_amdgcn_readfirstlane((i + 1) << 2);   // packed word of node i+1 with flag 0
-    const bool short_list = end - off <= 64;                           // unsorted entries (ukeys/uvals): up to 64 are ordered in registers below
-    if (!short_list) {                                                  // coverage above 64: rank sort through memory (rank = number of smaller keys; keys are unique)
-        const int n = (int)(end - off);
-        for (int a = l; a < n; a += 64) {
-            const unsigned long long k = ukeys[off + a];
+    const bool short_list = cap <= 64;                                  // unsorted entries (ukeys/uvals): up to 64 are ordered in registers below
+    if (!short_list) {                                                  // coverage above 64: rank sort through memory (rank = number of smaller keys; keys are unique, holes sort last)
+        for (int a = l; a < cap; a += 64) {
+            const key_t k = ukeys[off + a];
             int rank = 0;
-            for (int t = 0; t < n; ++t) rank += ukeys[off + t] < k;    // wave-uniform address: one broadcast load per step
-            skeys[off + rank] = k; svals[off + rank] = uvals[off + a];
+            for (int t = 0; t < cap; ++t) rank += ukeys[off + t] < k;  // wave-uniform address: one broadcast load per step
+            if (k != HOLE) { skeys[off + rank] = k; svals[off + rank] = uvals[off + a]; }
         }
         __threadfence_block(); wave_sync();
     }
+    const uint32_t end = off + (uint32_t)(short_list ? cap : n_valid);
     for (uint32_t e0 = off; e0 < end; e0 += 64) {
-        const int nb = __builtin_amdgcn_readfirstlane((int)min(64u, end - e0));      // wave-uniform: the loops over it run on the scalar unit
+        int nb = __builtin_amdgcn_readfirstlane((int)min(64u, end - e0));      // wave-uniform: the loops over it run on the scalar unit
         uint32_t my_val = 0, my_end = 0;
         if (short_list) {
-            unsigned long long key = ~0ull; uint32_t v0 = 0, x0 = 0;
-            if (l < nb) {
-                key = ukeys[e0 + l];
-                const uint32_t m = (uint32_t)((key >> a_bits) & m_mask);
+            key_t key = HOLE; uint32_t v0 = 0, x0 = 0;
+            if (l < nb) key = ukeys[e0 + l];
+            if (key != HOLE) {
+                const uint32_t m = (uint32_t)(key >> a_bits) & m_mask;
                 v0 = uvals[e0 + l]; x0 = mrow_off[m] + (uint32_t)mrow_cnt[m];
             }
-            // rank = number of smaller keys (keys are unique): the read order of the reference (name rank, index in the merged read)
-            const int klo = (int)(unsigned)key, khi = (int)(unsigned)(key >> 32);
+            // rank = number of smaller keys (keys are unique): the read order of the reference (name rank, index in the merged read); holes rank last
             int rank = 0;
-            if (m_bits + a_bits <= 32) {                                // the whole key in one word (the usual case): one lane read per step
+            if (!KEY64) {                                               // the whole key in one word (the usual case): one lane read per step
+                const int klo = (int)(uint32_t)key;
                 for (int t = 0; t < nb; ++t) rank += (unsigned)__builtin_amdgcn_readlane(klo, t) < (unsigned)klo;
             } else {
+                const int klo = (int)(unsigned)(unsigned long long)key, khi = (int)(unsigned)((unsigned long long)key >> 32);
                 for (int t = 0; t < nb; ++t) {
                     const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(khi, t) << 32) | (unsigned)__builtin_amdgcn_readlane(klo, t);
-                    rank += o < key;
+                    rank += o < (unsigned long long)key;
                 }
             }
-            const int dst = (l < nb ? rank : l) << 2;                   // lanes past the list keep to themselves (ranks are a permutation of 0..nb-1)
+            const int nbv = __popcll(__ballot(key != HOLE));
+            const int dst = ((l < nb && key != HOLE) ? rank : max(l, nbv)) << 2;   // holes and lanes past the list stay out of the ranks 0..nbv-1 of the valid entries
             my_val = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)v0);
             my_end = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)x0);
+            nb = nbv;
         } else if (l < nb) {
-            const unsigned long long key = skeys[e0 + l];
-            const uint32_t m = (uint32_t)((key >> a_bits) & m_mask);
+            const key_t key = skeys[e0 + l];
+            const uint32_t m = (uint32_t)(key >> a_bits) & m_mask;
             my_val = svals[e0 + l]; my_end = mrow_off[m] + (uint32_t)mrow_cnt[m];
         }
         // every lane's own observation (flag of the source side) and its share of the pair count, loaded side by side
@@ -923,7 +931,7 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
         int dir = 0;
         if (para > cross) dir = 1; else if (para < cross) dir = 2;
         // an edge between a SNP and a MOD row: threshold 0.3, and nothing connects when the four cells sum to less than one read (:197-202)
-        const int typ = ntype[i], typ_t = (i + 1 + l < n_nodes) ? ntype[i + 1 + l] : 0;
+        const int typ = (int)(vtype_key[nodes[i]] & 7u), typ_t = (i + 1 + l < n_nodes) ? (int)(vtype_key[nodes[i + 1 + l]] & 7u) : 0;
         double thr = edge_threshold;
         if ((typ == 0 && typ_t == 2) || (typ == 2 && typ_t == 0)) thr = ((rr + ra + ar + aa) < 1) ? -1.0 : 0.3;
         if (esr > thr) dir = 0;
@@ -1227,9 +1235,11 @@ __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, cons
     }
 }
 
+// + which blocks carry a PS: a block's id is the index of its first node, so a block has a second member (PhasingGraph.cpp:423: size > 1) exactly when
+// some OTHER node names it - a plain store of 1, no counting
 __global__ void k_scan_finalize(const LpsCounters *cnt, const int8_t *hp_v, const int32_t *blk_v, size_t vstride,
                                 const int32_t *chosen, const int32_t *remap_from, const int32_t *remap_to,
-                                int8_t *hp_out, int32_t *block_out) {
+                                int8_t *hp_out, int32_t *block_out, uint8_t *bmulti) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = (int)cnt->n_nodes;
     if (i >= N) return;
@@ -1238,45 +1248,31 @@ __global__ void k_scan_finalize(const LpsCounters *cnt, const int8_t *hp_v, cons
     int blk = blk_v[(size_t)v * vstride + i];
     if (blk >= 0 && blk == remap_from[seg]) blk = remap_to[seg];
     hp_out[i] = hp_v[(size_t)v * vstride + i]; block_out[i] = blk;
+    if (blk >= 0 && blk != i) bmulti[blk] = 1;
 }
 
 // ================================================================================================ read correction
-__global__ void k_block_size(LpsCounters *cnt, const int32_t *block, const uint32_t *node_pairs, uint32_t *bsize, uint8_t *nstate,
-                             const int8_t *hp, const uint8_t *ntype) {
+// per-node byte for the read-correction kernel: bit0 refhap (hp == 2), bits 1-3 type, bit 4 the node carries a PS (block of size > 1); + the pair count
+__global__ void k_node_state(LpsCounters *cnt, const int32_t *nodes, const int32_t *block, const uint8_t *bmulti, const int8_t *hp, const uint32_t *vtype_key,
+                             const uint32_t *node_pairs, uint8_t *nstate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < (int)cnt->n_nodes;
-    int b = in ? block[i] : -1;
     unsigned long long pr = in ? node_pairs[i] : 0;
     pr = wave_sum(pr);
     __shared__ unsigned long long s_pr[16];
     if (lane_id() == 0) s_pr[threadIdx.x >> 6] = pr;
     __syncthreads();
     if (threadIdx.x == 0) { unsigned long long tot = 0; for (unsigned q = 0; q < (blockDim.x + 63) / 64; ++q) tot += s_pr[q]; if (tot) atomicAdd(&cnt->n_pairs, tot); }
-    // per-node byte for the read-correction kernels: bit0 refhap (hp==2), bits1-3 type; "in a block" is added by k_node_state
-    if (in) nstate[i] = (uint8_t)((hp[i] == 1 ? 0 : 1) | (ntype[i] << 1));
-    // neighbouring nodes nearly always share their block: one atomic per distinct block per wave
-    unsigned long long todo = __ballot(b >= 0);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int lb = __shfl(b, leader);
-        const unsigned long long same = __ballot(b == lb) & todo;
-        if (lane_id() == leader) atomicAdd(&bsize[lb], (unsigned)__popcll(same));
-        todo &= ~same;
-    }
-}
-
-__global__ void k_node_state(const LpsCounters *cnt, const int32_t *block, const uint32_t *bsize, uint8_t *nstate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int)cnt->n_nodes) return;
+    if (!in) return;
     const int b = block[i];
-    if (b >= 0 && bsize[b] > 1) nstate[i] |= 16;            // node carries a PS (block of size > 1)
+    nstate[i] = (uint8_t)((hp[i] == 1 ? 0 : 1) | ((vtype_key[nodes[i]] & 7u) << 1) | ((b >= 0 && bmulti[b]) ? 16u : 0u));
 }
 
 // wave per alignment: readCorrection's per-read vote (:904-959).  SNP sites contribute integers (order-free, ballot +
 // popcount); as soon as the read touches an indel site the 0.1 contributions are summed by one lane in the reference's
 // order (doubles), so the result is bit-identical either way.
-__global__ __launch_bounds__(256) void k_read_correction(int n_reads, const RowDesc *rows, const int32_t *g_cnt, const int32_t *g_node,
-                                                         const uint8_t *g_flag, const uint8_t *nstate, double read_confidence, uint32_t *cnt4) {
+__global__ __launch_bounds__(256) void k_read_correction(int n_reads, const RowDesc *rows, const int32_t *g_cnt, const uint32_t *g_pack,
+                                                         const uint8_t *nstate, double read_confidence, uint32_t *cnt4) {
     const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
     const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
     if (r >= n_reads) return;
@@ -1287,7 +1283,7 @@ __global__ __launch_bounds__(256) void k_read_correction(int n_reads, const RowD
     for (int k0 = 0; k0 < n; k0 += ROW_G) {
         const int k = k0 + sl;
         int st = 0, al = 0;
-        if (k < n) { st = nstate[g_node[off + k]]; al = g_flag[off + k] & 1; }
+        if (k < n) { const uint32_t wd = g_pack[off + k]; st = nstate[wd >> 2]; al = (int)(wd & 1u); }
         const bool live = (st & 16) != 0;
         const int ty = (st >> 1) & 7;
         const int h = al ^ (st & 1);                          // 0: haplotype 1, 1: haplotype 2
@@ -1299,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_read_correction(int n_reads, const RowD
     if (indel) {                                              // exact order of the reference's double sums
         rc = 0; ac = 0;
         for (int k = 0; k < n; ++k) {
-            const int st = nstate[g_node[off + k]]; const int al = g_flag[off + k] & 1;
+            const uint32_t wd = g_pack[off + k]; const int st = nstate[wd >> 2]; const int al = (int)(wd & 1u);
             if (!(st & 16)) continue;
             const int ty = (st >> 1) & 7, h = al ^ (st & 1);
             if (ty <= 1) { if (h == 0) rc++; else ac++; }
@@ -1308,16 +1304,16 @@ __global__ __launch_bounds__(256) void k_read_correction(int n_reads, const RowD
     }
     if (fmax(rc, ac) / (rc + ac) > read_confidence && (rc + ac) > 1) {
         const int bh = (rc > ac) ? 0 : 1;
-        for (int k = sl; k < n; k += ROW_G) atomicAdd(&cnt4[(size_t)g_node[off + k] * 4 + bh * 2 + (g_flag[off + k] & 1)], 1u);
+        for (int k = sl; k < n; k += ROW_G) { const uint32_t wd = g_pack[off + k]; atomicAdd(&cnt4[(size_t)(wd >> 2) * 4 + bh * 2 + (wd & 1u)], 1u); }
     }
 }
 
 __global__ void k_final(const LpsCounters *cnt, const int32_t *nodes, const int32_t *vpos, const int32_t *block,
-                        const uint32_t *bsize, const uint32_t *cnt4, double snp_confidence, int32_t *out_ps, uint8_t *out_gt) {
+                        const uint8_t *bmulti, const uint32_t *cnt4, double snp_confidence, int32_t *out_ps, uint8_t *out_gt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int)cnt->n_nodes) return;
     const int b = block[i];
-    if (b < 0 || bsize[b] <= 1) return;
+    if (b < 0 || !bmulti[b]) return;
     const uint32_t *c = cnt4 + (size_t)i * 4;
     const double r1 = (double)c[0] + (double)c[3], r2 = (double)c[2] + (double)c[1];
     const double conf = fmax(r1, r2) / (r1 + r2);
@@ -1363,7 +1359,7 @@ void exscan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out
 void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const RowDesc *rows,
                        const uint8_t *deleted, ObsRec *obs, const int32_t *vpos,
                        const int32_t *cnv_start, const int32_t *cnv_end, long long *agg_sum, int32_t *agg_cnt, double *miss,
-                       CnvScratch &W, void *temp, size_t temp_bytes, hipStream_t s) {
+                       CnvScratch &W, uint32_t *var_del2, void *temp, size_t temp_bytes, hipStream_t s) {
     HIP_TRY(hipMemsetAsync(agg_sum, 0, (size_t)n_var * 2 * sizeof(long long), s));
     HIP_TRY(hipMemsetAsync(agg_cnt, 0, (size_t)n_var * 2 * sizeof(int32_t), s));
     hipLaunchKernelGGL(k_cnv_list, GRID(n_reads, 256), 0, s, cnt, n_reads, rows, deleted, W.flag);
@@ -1374,7 +1370,7 @@ void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const Row
     const unsigned row_grid = (unsigned)((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     for (int pass4 = 0; pass4 < 2; ++pass4) {
         HIP_TRY(hipMemsetAsync(W.fn, 2, (size_t)n_reads, s));
-        if (pass4) hipLaunchKernelGGL(k_cnv_rows<false>, dim3(row_grid), dim3(256), 0, s, cnt, W.list, W.n_list, W.pre, rows, obs, vpos, cnv_start, cnv_end, miss, W.fn);
+        if (pass4) hipLaunchKernelGGL(k_cnv_rows<false>, dim3(row_grid), dim3(256), 0, s, cnt, W.list, W.n_list, W.pre, rows, obs, vpos, cnv_start, cnv_end, miss, W.fn, var_del2);
         else hipLaunchKernelGGL(k_cnv_fn12, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, rows, obs, vpos, cnv_start, W.fn);
         size_t need = temp_bytes;
         HIP_TRY(rocprim::exclusive_scan(temp, need, W.fn, W.pre, (uint8_t)2, (size_t)n_reads, CnvCompose(), s));
@@ -1382,67 +1378,64 @@ void launch_cnv_filter(const LpsCounters *cnt, int n_reads, int n_var, const Row
             hipLaunchKernelGGL(k_cnv_count, GRID(n_reads, 128), 0, s, cnt, W.list, W.n_list, W.pre, rows, obs, vpos, cnv_start, cnv_end, (unsigned long long *)agg_sum, agg_cnt);
             hipLaunchKernelGGL(k_cnv_miss, GRID(n_var, 256), 0, s, cnt, n_var, vpos, cnv_start, cnv_end, (const unsigned long long *)agg_sum, agg_cnt, miss);
         } else {
-            hipLaunchKernelGGL(k_cnv_rows<true>, dim3(row_grid), dim3(256), 0, s, cnt, W.list, W.n_list, W.pre, rows, obs, vpos, cnv_start, cnv_end, miss, W.fn);
+            hipLaunchKernelGGL(k_cnv_rows<true>, dim3(row_grid), dim3(256), 0, s, cnt, W.list, W.n_list, W.pre, rows, obs, vpos, cnv_start, cnv_end, miss, W.fn, var_del2);
         }
     }
-}
-
-void launch_clip_keys(const ClipView &C, const RowDesc *rows, int n_reads, unsigned long long *keys, LpsCounters *cnt, hipStream_t s) {
-    if (n_reads) hipLaunchKernelGGL(k_clip_keys, dim3((unsigned)std::min(1024, (n_reads + 255) / 256)), dim3(256), 0, s, C, rows, keys, cnt);
 }
 
 void launch_clip_sort(unsigned n_clips, unsigned long long *keys, unsigned long long *keys_sorted, void *temp, size_t temp_bytes, hipStream_t s) {
     if (n_clips) sort_keys64(temp, temp_bytes, keys, keys_sorted, n_clips, 33, s);          // key = pos << 1 | front/back: 33 bits, 5 digit passes instead of 8
 }
 
-void launch_name_keys(int n_reads, const uint32_t *name_id, const RowDesc *rows, unsigned long long *keys,
-                      LpsCounters *cnt, const unsigned long long *arena_ctr, unsigned long long arena_size, hipStream_t s) {
-    hipLaunchKernelGGL(k_name_keys, dim3((n_reads + 255) / 256 + 1), dim3(256), 0, s, n_reads, name_id, rows, keys, cnt, arena_ctr, arena_size);
-}
-
-void launch_groups(const unsigned long long *skeys, int n_reads, LpsCounters *cnt, uint32_t *head, uint32_t *gidx,
-                   uint32_t *gstart, uint32_t *read_group, void *temp, size_t temp_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(k_group_heads, GRID(n_reads, 256), 0, s, skeys, n_reads, cnt, head);
+// name ids -> dense ranks (only when the caller's ids are not dense): sort of (id, alignment), heads, scan
+void launch_dense_names(int n_reads, const uint32_t *name_id, uint32_t name_max, unsigned long long *keys, unsigned long long *keys_s, uint32_t *head, uint32_t *gidx,
+                        uint32_t *dense, void *temp, size_t temp_bytes, hipStream_t s) {
+    if (!n_reads) return;
+    int bits = 1; while ((1ull << bits) < (unsigned long long)name_max + 2) ++bits;
+    hipLaunchKernelGGL(k_dense_keys, GRID(n_reads, 256), 0, s, n_reads, name_id, keys);
+    sort_keys64_range(temp, temp_bytes, keys, keys_s, n_reads, 32, 32 + bits, s);   // stable by the name digits alone: equal names stay in alignment order
+    hipLaunchKernelGGL(k_dense_heads, GRID(n_reads, 256), 0, s, keys_s, n_reads, head);
     exscan_u32(temp, temp_bytes, head, gidx, n_reads, s);
-    hipLaunchKernelGGL(k_group_starts, GRID(n_reads, 256), 0, s, skeys, head, gidx, n_reads, cnt, gstart, read_group);
+    hipLaunchKernelGGL(k_dense_ids, GRID(n_reads, 256), 0, s, keys_s, head, gidx, n_reads, dense);
 }
 
-void launch_overlap_filter(const unsigned long long *skeys, const uint32_t *gstart, const LpsCounters *cnt, int n_reads,
-                           const RowDesc *rows, const ObsRec *obs, const int32_t *vpos,
-                           double thr, uint32_t *stack, uint8_t *deleted, hipStream_t s) {
-    hipLaunchKernelGGL(k_overlap_filter, GRID(n_reads, 128), 0, s, skeys, gstart, cnt, rows, obs, vpos, thr, stack, deleted);
+void launch_names(const GraphView &G, const ClipView &C, unsigned long long *clip_keys, const unsigned long long *arena_ctr, unsigned long long arena_size, hipStream_t s) {
+    if (!G.n_reads) return;
+    const int nb_reads = (G.n_reads + 255) / 256;
+    hipLaunchKernelGGL(k_name_link, dim3(nb_reads + 1 + std::min(1024, nb_reads)), dim3(256), 0, s, G.n_reads, G.name, G.rows, G.name_head, G.name_link, G.cnt, arena_ctr, arena_size, C, clip_keys, nb_reads);
 }
 
-void launch_nodes(int n_reads, int n_var, const RowDesc *rows, const uint8_t *deleted,
-                  const ObsRec *obs, uint32_t *is_node, uint32_t *vtype_key, uint32_t *node_of,
-                  int32_t *nodes, uint8_t *ntype, int base_quality, int32_t *g_node, uint8_t *g_flag, uint32_t *g_pack, uint16_t *g_rank, int32_t *g_cnt,
-                  LpsCounters *cnt, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(k_mark_nodes, dim3((n_reads + 15) / 16), dim3(256), 0, s, n_reads, rows, deleted, obs, is_node, vtype_key);
-    exscan_u32(temp, temp_bytes, is_node, node_of, n_var, s);
-    hipLaunchKernelGGL(k_graph_obs, dim3((n_reads + 15) / 16 + (n_var + 255) / 256), dim3(256), 0, s, n_reads, rows, deleted, obs, node_of, base_quality, g_node, g_flag, g_pack, g_rank, g_cnt, cnt, n_var, is_node, vtype_key, nodes, ntype, node_cnt);
+void launch_groups(const GraphView &G, double overlap_threshold, bool counted, hipStream_t s) {
+    if (!G.n_reads) return;
+    hipLaunchKernelGGL(k_groups, GRID(G.n_reads, 256), 0, s, G.n_reads, G.name, G.rows, G.obs, G.vpos, overlap_threshold, G.name_head, G.name_link, G.cnt,
+                       G.mm_r, G.stack, G.mg_start, G.mg_cnt, G.mg_name, G.deleted, counted ? G.var_del : nullptr);
 }
 
-void launch_merge_rows(const unsigned long long *skeys, const uint32_t *gstart, LpsCounters *cnt, int n_reads,
-                       const RowDesc *rows, const int32_t *g_cnt, int32_t *g_node, uint8_t *g_flag,
-                       unsigned long long tail_lo, unsigned long long tail_size, uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *multi_list, uint32_t *g_pack, uint32_t *t_src, hipStream_t s) {
-    hipLaunchKernelGGL(k_merge_plan, GRID(n_reads, 256), 0, s, skeys, gstart, cnt, rows, g_cnt, tail_lo, tail_size, mrow_off, mrow_cnt, multi_list);
-    hipLaunchKernelGGL(k_merge_multi, dim3(1024), dim3(256), 0, s, skeys, gstart, cnt, rows, g_cnt, g_node, g_flag, g_pack, t_src, (uint32_t)tail_lo, mrow_off, multi_list);
+void launch_count_ranks(const GraphView &G, hipStream_t s) {
+    if (G.n_reads) hipLaunchKernelGGL(k_count_ranks, dim3((G.n_reads + 3) / 4), dim3(256), 0, s, G.n_reads, G.rows, G.deleted, G.obs, G.var_cnt, G.var_del, G.cnt);
 }
 
-void launch_node_lists(LpsCounters *cnt, int n_reads, int n_var, const RowDesc *rows, const int32_t *g_cnt, const uint32_t *read_group, const uint32_t *gstart,
-                       const uint32_t *mrow_off, const int32_t *mrow_cnt, const uint32_t *multi_list,
-                       const int32_t *g_node, const uint16_t *g_rank, const uint32_t *t_src, uint32_t tail_lo, int a_bits,
-                       unsigned long long *keys, uint32_t *vals, uint32_t *node_off, uint32_t *node_cnt, void *temp, size_t temp_bytes, hipStream_t s) {
-    exscan_u32(temp, temp_bytes, node_cnt, node_off, (size_t)n_var + 1, s);      // node_cnt was filled by k_graph_obs
-    const int nb_reads = round_up8((n_reads + 15) / 16);                  // workgroups of four extraction jobs (16 rows)
-    hipLaunchKernelGGL(k_node_scatter, dim3(nb_reads + 512), dim3(256), 0, s, cnt, rows, g_cnt, read_group, gstart, mrow_off, mrow_cnt, multi_list, g_node, g_rank, t_src, tail_lo, node_off, a_bits, keys, vals, cnt, n_var, n_reads, nb_reads);
+// node numbers + list offsets, the graph view of the rows with the entries of single-alignment reads, the merged rows of the others with theirs
+void launch_var_scan(const GraphView &G, hipStream_t s) {
+    const int nvb = (G.n_var + VSCAN_B - 1) / VSCAN_B;
+    hipLaunchKernelGGL(k_var_sums, dim3(nvb), dim3(VSCAN_B), 0, s, G.n_var, G.var_cnt, G.var_del, G.var_del2, G.bsum);
+    hipLaunchKernelGGL(k_var_scan, dim3(nvb), dim3(VSCAN_B), 0, s, G.n_var, G.var_cnt, G.var_del, G.var_del2, G.bsum, G.node_of, G.var_off, G.nodes, G.node_off, G.node_cap, G.node_end, G.cnt);
+}
+void launch_graph_rows(const GraphView &G, int base_quality, int a_bits, bool key64, unsigned n_multi, hipStream_t s) {
+    const int nb_reads = round_up8((G.n_reads + 15) / 16);                // workgroups of four extraction jobs (16 rows)
+    if (key64) hipLaunchKernelGGL(k_graph_rows<true>, dim3(nb_reads), dim3(256), 0, s, G.n_reads, G.rows, G.deleted, G.obs, G.name, G.name_head, G.name_link, G.node_of, G.var_off, base_quality, a_bits, G.g_pack, G.g_rank, G.g_cnt, G.mrow_off, G.mrow_cnt, G.ukeys, G.uvals, G.vtype_key, nb_reads);
+    else hipLaunchKernelGGL(k_graph_rows<false>, dim3(nb_reads), dim3(256), 0, s, G.n_reads, G.rows, G.deleted, G.obs, G.name, G.name_head, G.name_link, G.node_of, G.var_off, base_quality, a_bits, G.g_pack, G.g_rank, G.g_cnt, G.mrow_off, G.mrow_cnt, G.ukeys, G.uvals, G.vtype_key, nb_reads);
+    if (!n_multi) return;                                                 // (known on the host since the overlap filter)
+    hipLaunchKernelGGL(k_merge_plan, GRID(n_multi, 256), 0, s, G.cnt, G.mg_start, G.mg_cnt, G.mg_name, G.mm_r, G.rows, G.g_cnt, G.tail_lo, G.tail_size, G.mrow_off, G.mrow_cnt, G.mg_plan);
+    const unsigned mb = std::min(1024u, (n_multi + 3) / 4);
+    if (key64) hipLaunchKernelGGL(k_merge_multi<true>, dim3(mb), dim3(256), 0, s, G.cnt, G.mg_start, G.mg_cnt, G.mg_name, G.mg_plan, G.mm_r, G.rows, G.g_cnt, G.g_pack, G.g_rank, G.t_node, G.t_flag, G.t_src, (uint32_t)G.tail_lo, G.mrow_off, G.nodes, G.var_off, a_bits, G.ukeys, G.uvals);
+    else hipLaunchKernelGGL(k_merge_multi<false>, dim3(mb), dim3(256), 0, s, G.cnt, G.mg_start, G.mg_cnt, G.mg_name, G.mg_plan, G.mm_r, G.rows, G.g_cnt, G.g_pack, G.g_rank, G.t_node, G.t_flag, G.t_src, (uint32_t)G.tail_lo, G.mrow_off, G.nodes, G.var_off, a_bits, G.ukeys, G.uvals);
 }
 
-void launch_edges(LpsCounters *cnt, int n_var, const uint32_t *node_off, const uint32_t *node_end,
-                  const unsigned long long *ukeys, const uint32_t *uvals, unsigned long long *skeys, uint32_t *svals, const uint32_t *mrow_off, const int32_t *mrow_cnt,
-                  int m_bits, int a_bits, const uint32_t *g_pack, uint32_t tail_lo, int A, double edge_weight,
-                  double edge_threshold, const uint8_t *ntype, float *edge, uint8_t *erec, uint32_t *node_pairs, hipStream_t s) {
-    hipLaunchKernelGGL(k_edges, dim3((((n_var + 3) / 4 + 7) / 8) * 8), dim3(256), 0, s, cnt, node_off, node_end, ukeys, uvals, skeys, svals, mrow_off, mrow_cnt, m_bits, a_bits, g_pack, tail_lo, A, edge_weight, edge_threshold, ntype, edge, erec, node_pairs);
+void launch_edges(const GraphView &G, int m_bits, int a_bits, bool key64, double edge_weight, double edge_threshold, hipStream_t s) {
+    const dim3 grid((((G.n_var + 3) / 4 + 7) / 8) * 8);
+    if (key64) hipLaunchKernelGGL(k_edges<true>, grid, dim3(256), 0, s, G.cnt, G.node_off, G.node_cap, G.node_end, G.ukeys, G.uvals, G.skeys, G.svals, G.mrow_off, G.mrow_cnt, m_bits, a_bits, G.g_pack, (uint32_t)G.tail_lo, G.A, edge_weight, edge_threshold, G.nodes, G.vtype_key, G.edge, G.erec, G.node_pairs);
+    else hipLaunchKernelGGL(k_edges<false>, grid, dim3(256), 0, s, G.cnt, G.node_off, G.node_cap, G.node_end, G.ukeys, G.uvals, G.skeys, G.svals, G.mrow_off, G.mrow_cnt, m_bits, a_bits, G.g_pack, (uint32_t)G.tail_lo, G.A, edge_weight, edge_threshold, G.nodes, G.vtype_key, G.edge, G.erec, G.node_pairs);
 }
 
 size_t scan_state_bytes(int n_var) { return (size_t)((n_var + SCAN_SEG - 1) / SCAN_SEG + 1) * 2 * sizeof(ScanState); }
@@ -1456,7 +1449,7 @@ __global__ void k_scan_break_matches(int32_t *match, int segs, int every) {
 
 void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, const int32_t *vpos, const uint8_t *erec,
                       int A, int distance, int8_t *hp_v, int32_t *blk_v, void *st_b, void *st_e, int32_t *seg_i32 /*4*segs*/,
-                      unsigned *n_replayed, int8_t *hp, int32_t *block, int warm_tiles, hipStream_t s) {
+                      unsigned *n_replayed, int8_t *hp, int32_t *block, uint8_t *bmulti, int warm_tiles, hipStream_t s) {
     const int segs = scan_segments(n_var);
     // warm-up of the speculative walks: SCAN_WARM nodes as a rule.  With SV / MOD rows in the graph (sparser votes across the SNP<->MOD threshold,
     // more ties) twice that: 41 of 1 454 boundaries of a chr20-sized graph missed with 64 nodes, none with 128, and a miss costs a 37-us replay
@@ -1466,15 +1459,12 @@ void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, c
     hipLaunchKernelGGL(k_scan_match, dim3((segs + 3) / 4), dim3(256), 0, s, cnt, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs);
     if (const char *e = getenv("LPS_SCAN_FORCE_REPLAY")) { const int every = atoi(e); if (every > 0) hipLaunchKernelGGL(k_scan_break_matches, GRID(segs, 256), 0, s, seg_i32 + 3 * segs, segs, every); }
     hipLaunchKernelGGL(k_scan_stitch, dim3(1), dim3(64), 0, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, n_replayed);
-    hipLaunchKernelGGL(k_scan_finalize, GRID(n_var, 256), 0, s, cnt, hp_v, blk_v, vstride, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, hp, block);
+    hipLaunchKernelGGL(k_scan_finalize, GRID(n_var, 256), 0, s, cnt, hp_v, blk_v, vstride, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, hp, block, bmulti);
 }
 
-void launch_correction(LpsCounters *cnt, int n_reads, int n_var, const RowDesc *rows, const int32_t *g_cnt,
-                       const int32_t *g_node, const uint8_t *g_flag, const int32_t *nodes, const int32_t *vpos,
-                       const int32_t *block, uint32_t *bsize, const int8_t *hp, const uint8_t *ntype, const uint32_t *node_pairs,
-                       uint8_t *nstate, double read_conf, double snp_conf, uint32_t *cnt4, int32_t *out_ps, uint8_t *out_gt, hipStream_t s) {
-    hipLaunchKernelGGL(k_block_size, GRID(n_var, 256), 0, s, cnt, block, node_pairs, bsize, nstate, hp, ntype);
-    hipLaunchKernelGGL(k_node_state, GRID(n_var, 256), 0, s, cnt, block, bsize, nstate);
-    hipLaunchKernelGGL(k_read_correction, dim3((n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, n_reads, rows, g_cnt, g_node, g_flag, nstate, read_conf, cnt4);
-    hipLaunchKernelGGL(k_final, GRID(n_var, 256), 0, s, cnt, nodes, vpos, block, bsize, cnt4, snp_conf, out_ps, out_gt);
+void launch_correction(const GraphView &G, const int32_t *block, const uint8_t *bmulti, const int8_t *hp, uint8_t *nstate, double read_conf, double snp_conf,
+                       uint32_t *cnt4, int32_t *out_ps, uint8_t *out_gt, hipStream_t s) {
+    hipLaunchKernelGGL(k_node_state, GRID(G.n_var, 256), 0, s, G.cnt, G.nodes, block, bmulti, hp, G.vtype_key, G.node_pairs, nstate);
+    hipLaunchKernelGGL(k_read_correction, dim3((G.n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, G.n_reads, G.rows, G.g_cnt, G.g_pack, nstate, read_conf, cnt4);
+    hipLaunchKernelGGL(k_final, GRID(G.n_var, 256), 0, s, G.cnt, G.nodes, G.vpos, block, bmulti, cnt4, snp_conf, out_ps, out_gt);
 }

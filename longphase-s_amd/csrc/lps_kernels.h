@@ -32,7 +32,20 @@ struct ReadView {
     const uint64_t *cigar_off, *seq_off, *qual_off;
     const uint32_t *cigar;
     const uint8_t *seq, *qual;
+    const uint8_t *sq;         // bases + qualities interleaved in 128-byte blocks of LPS_SQ_BASES bases (lps_reads.hip); read r starts at block sq_blk[r]
+    const uint32_t *sq_blk;
 };
+#define LPS_SQ_BASES 84
+void launch_sq_count(int n, const int32_t *l_qseq, uint32_t *nblk, hipStream_t s);
+void launch_sq_pack(const ReadView &R, const uint32_t *blk, uint8_t *sq, hipStream_t s);
+#ifdef __HIPCC__
+// base code (4 bits) and quality of query index qi of a read whose first block is at `blk0`: both from ONE 128-byte line
+__device__ __forceinline__ void sq_fetch(const uint8_t *__restrict__ sq, uint32_t blk0, int qi, int &code, int &qual) {
+    const int b = qi / LPS_SQ_BASES, t = qi - b * LPS_SQ_BASES;
+    const uint8_t *p = sq + ((size_t)blk0 + (unsigned)b) * 128;
+    code = (p[LPS_SQ_BASES + (t >> 1)] >> ((~t & 1) << 2)) & 15; qual = p[t];
+}
+#endif
 
 // one alignment's row of observations: 16 bytes, written by one lane of the extraction wave (four rows = one 64-byte line per wave)
 struct __attribute__((aligned(16))) RowDesc {
@@ -87,7 +100,7 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 #define VREC_DERIVE(a) (((a) >> 24) & 3u) /* somaticReadDeriveByHP of role-1 rows */
 #define VREC_TKIND(a) (((a) >> 26) & 7u)  /* somatic extraction: TUMOR row kind at this position (0 none, 1 SNP, 2 INS, 3 DEL, 4 other) */
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,
-                          int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, hipStream_t s);
+                          int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint32_t *var_cnt /* NULL: observations are counted later */, uint32_t *var_del, hipStream_t s);
 
 // ---- device helpers shared by the extraction (phase) and scoring (haplotag) kernels
 #ifdef __HIPCC__
