@@ -820,6 +820,8 @@ static int bits_for(unsigned long long n) { int b = 1; while ((1ull << b) < n) +
 // stage boundaries on the stream.  Every recorded event drains the queue for a moment (~3.5 us): a phase run records them all only when the
 // caller asked for the per-stage breakdown (lps_set_stage_timing level 2), else just the two around the extraction kernel (level 1) or none.
 static void mark(lps_ctx *c, int st) {
+    static const bool dbg = getenv("LPS_DEBUG_SYNC") != nullptr;        // diagnostic: drain the stream at every stage boundary and say which stage comes next
+    if (dbg) { const hipError_t e = hipStreamSynchronize(c->stream); fprintf(stderr, "[lps] before stage %s: %s\n", kStageNames[st], hipGetErrorString(e)); fflush(stderr); }
     if (c->in_phase && (c->timing_level == 0 || (c->timing_level == 1 && st != ST_EXTRACT && st != ST_GROUPS))) return;
     HIP_TRY(hipEventRecord(c->ev[st], c->stream)); c->ev_used[st] = true;
 }

@@ -458,7 +458,8 @@ template <bool KEY64>
 __global__ __launch_bounds__(256) void k_graph_rows(int n_reads, const RowDesc *rows, const uint8_t *deleted, const ObsRec *obs, const uint32_t *name,
                                                     const uint32_t *name_head, const uint32_t *name_link, const uint32_t *node_of, const uint32_t *var_off,
                                                     int base_quality, int a_bits, uint32_t *g_pack, uint32_t *g_rank, int32_t *g_cnt,
-                                                    uint32_t *mrow_off, int32_t *mrow_cnt, void *ukeys_v, uint32_t *uvals, uint32_t *vtype_key, int nb_reads) {
+                                                    uint32_t *mrow_off, int32_t *mrow_cnt, void *ukeys_v, uint32_t *uvals, uint32_t *vtype_key, int nb_reads
+                                                    ) {
     const int l = lane_id();
     const int r0 = (xcd_unit((int)blockIdx.x, nb_reads) * 4 + (threadIdx.x >> 6)) * 4;
     if (r0 >= n_reads) return;
@@ -582,6 +583,7 @@ __global__ __launch_bounds__(256) void k_merge_plan(LpsCounters *cnt, const uint
     }
     __syncthreads();
     if (multi) {
+        id = mg_name[q];                                                  // (read again: the value carried across the barriers was lost by the compiler - the stores below went to another name's slot)
         unsigned long long toff = s_base_t + (unsigned long long)(incl - mine);
         for (int qq = 0; qq < w; ++qq) toff += s_tot[qq];
         if (toff + (unsigned long long)total > tail_size) { atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); mrow_off[id] = 0; mrow_cnt[id] = 0; mg_plan[q] = 0u; }   // the host grows the buffers and reruns
@@ -671,7 +673,8 @@ void launch_debug_std_sort(int32_t *keys, uint8_t *payload, const long long *row
 template <bool KEY64>
 __global__ __launch_bounds__(256) void k_merge_multi(const LpsCounters *cnt, const uint32_t *mg_start, const uint32_t *mg_cnt, const uint32_t *mg_name, const uint32_t *mg_plan, const uint32_t *mm_r,
                                                      const RowDesc *rows, const int32_t *g_cnt, uint32_t *g_pack, const uint32_t *g_rank, int32_t *t_node, uint8_t *t_flag, uint32_t *t_src, uint32_t tail_lo,
-                                                     const uint32_t *mrow_off, const int32_t *nodes, const uint32_t *var_off, int a_bits, void *ukeys_v, uint32_t *uvals) {
+                                                     const uint32_t *mrow_off, const int32_t *nodes, const uint32_t *var_off, int a_bits, void *ukeys_v, uint32_t *uvals
+                                                     ) {
     __shared__ int s_stk[4][192]; __shared__ int32_t s_k[4][STDSORT_LDS]; __shared__ uint8_t s_p[4][STDSORT_LDS]; __shared__ uint16_t s_a[4][STDSORT_LDS], s_b[4][STDSORT_LDS];
     const int l = lane_id();
     const unsigned n_waves = gridDim.x * 4;
