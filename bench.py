@@ -182,6 +182,100 @@ def cpu_baseline(g, spec, threads, port, gpu_result=None):
         return out
 
 
+def whole_node_baseline(dev, P, threads, seed, n_contigs=16, contig_mb=10):
+    """The reference's only parallelism is its chromosome loop (src/phase/PhasingProcess.cpp:106,113), so a single contig keeps ONE of its threads
+    computing.  Here every thread gets a contig: `n_contigs` contigs of `contig_mb` Mb at 50x with the genome's SNP density in ONE BAM, phased by
+    `longphase-s phase -t threads` (best of 2 runs, the first warms the page cache) - the whole-node CPU rate - and by the GPU from the same
+    decoded alignments in PINNED host memory (clock P: H2D + layout + phase, the load of one contig overlapping the phase of another: two
+    contexts, two host threads), every contig's result compared with the reference's VCF."""
+    import numpy as np
+    from lps import abi, hip
+    from lps.synth_gpu import SynthGpu
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "longphase-s-ref"); tv = os.path.join(ROOT, "oracle", "_ref", "test_view")
+    if not (os.path.exists(ref_bin) and os.path.exists(tv)):
+        return None
+    total = sum(n for _, n in GRCH38)
+    L = contig_mb * 1_000_000; n_snp = int(round(WGS_SNPS * L / total))
+    t_prep = time.time()
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
+        names = ["ctg%02d" % (k + 1) for k in range(n_contigs)]
+        header = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{nm}\tLN:{L}\n" for nm in names)
+        bam = subprocess.Popen([tv, "-@", str(threads), "-b", "-x", "reads.bam.bai", "-p", "reads.bam", "-"], cwd=d, stdin=subprocess.PIPE, stdout=subprocess.DEVNULL)
+        bam.stdin.write(header.encode()); bam.stdin.flush()
+        vhead, contigs = [], []
+        with open(d + "/ref.fa", "wb") as fa, open(d + "/in.vcf.body", "wb") as vb:
+            for k, nm in enumerate(names):
+                g = SynthGpu(dev, contig_len=L, n_snp=n_snp, coverage=50.0, seed=seed + 1000 + k)
+                g.write_fasta(d + "/one.fa", nm); fa.write(open(d + "/one.fa", "rb").read())
+                g.write_vcf(d + "/one.vcf", nm)
+                for line in open(d + "/one.vcf", "rb"):
+                    if line.startswith(b"##contig"):
+                        vhead.append(line)
+                    elif not line.startswith(b"#"):
+                        vb.write(line)
+                g.write_sam(d + "/one.sam", nm, threads)
+                subprocess.check_call(["grep", "-v", "^@", "one.sam"], cwd=d, stdout=bam.stdin)      # the records of this contig behind the common header
+                os.remove(d + "/one.sam")
+                contigs.append(dict(name=nm, V=g.variants(), ref=g.host("ref"), host=g.to_host(), n_reads=g.n_reads, n_bases=g.n_bases))
+                g.close()
+        bam.stdin.close()
+        assert bam.wait() == 0, "test_view failed"
+        with open(d + "/in.vcf", "wb") as f:
+            f.write(b"##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n" + b"".join(vhead) +
+                    b'##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="Genotype Quality">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n')
+            f.write(open(d + "/in.vcf.body", "rb").read())
+        prep_s = time.time() - t_prep
+        log(f"whole-node sample: {n_contigs} x {contig_mb} Mb at 50x, BAM {os.path.getsize(d + '/reads.bam') / 1e9:.2f} GB, prepared in {prep_s:.0f}s")
+        cmd = [ref_bin, "phase", "-s", "in.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(threads), "-o", "out", "--ont"]
+        ts = []
+        for _ in range(2):
+            t0 = time.time(); r = subprocess.run(cmd, cwd=d, capture_output=True); ts.append(time.time() - t0)
+            assert r.returncode == 0, r.stderr[-500:]
+        want = {}                                                         # contig -> {pos0: (ps, "a|b")}
+        for ln in open(d + "/out.vcf"):
+            if ln.startswith("#"):
+                continue
+            f = ln.rstrip("\n").split("\t"); smp = f[9].split(":")
+            want.setdefault(f[0], {})[int(f[1]) - 1] = (0 if smp[-1] == "." else int(smp[-1]), smp[0])
+    # ---- the GPU on the same decoded alignments, from pinned host memory (clock P), loads and phases of different contigs overlapping
+    for c in contigs:
+        c["R"] = abi.Reads.from_synth(c["host"])
+        c["pinned"] = all(pin(x) for x in (c["host"].qual, c["host"].seq, c["host"].cigar))
+        c["out"] = abi.PhaseOut(c["V"].n)
+    ctxs = [hip.Context(dev, P) for _ in range(2)]
+    for cx, c in zip(ctxs, contigs):                                      # warm-up: buffers of both contexts at their working size
+        cx.load_chromosome(c["V"], c["ref"], c["R"]); cx.run_phase(c["out"])
+    def lane(i):
+        for c in contigs[i::2]:
+            ctxs[i].load_chromosome(c["V"], c["ref"], c["R"]); ctxs[i].run_phase(c["out"])
+    th = [threading.Thread(target=lane, args=(i,)) for i in range(2)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    p_wall = time.perf_counter() - t0
+    for cx in ctxs:
+        cx.close()
+    same = True; n_ph = 0; n_ref = 0
+    for c in contigs:
+        w = want.get(c["name"], {})
+        pos = c["V"].pos; ps = c["out"].phase_set; gt = c["out"].gt
+        n_ph += int((ps != 0).sum()); n_ref += sum(1 for v in w.values() if v[0])
+        ok = len(w) == len(pos) and all(w[int(pos[i])][0] == int(ps[i]) and (ps[i] == 0 or w[int(pos[i])][1] == ("1|0" if gt[i] else "0|1")) for i in range(len(pos)))
+        same = same and ok
+    cpu = n_ref / min(ts); gpu_p = n_ph / p_wall
+    return dict(value=float(cpu), unit="SNPs/s", cores=threads, kind="reference",
+                sample=f"{n_contigs} contigs x {contig_mb} Mb at 50x ({sum(c['n_reads'] for c in contigs)} alignments, {sum(c['n_bases'] for c in contigs) / 1e9:.1f} Gbases, {n_ref} phased SNPs) in one BAM: "
+                       f"`longphase-s phase -t {threads} --ont` end to end, every thread with a contig of its own; best of 2 runs",
+                wall_s=round(min(ts), 2), runs_s=[round(x, 2) for x in ts], prepare_s=round(prep_s, 1), identical_to_gpu_result_all_contigs=bool(same),
+                p_clock=dict(value=float(gpu_p), unit="SNPs/s", wall_s=round(p_wall, 3), pinned_host_memory=all(c["pinned"] for c in contigs),
+                             note="decoded alignments in pinned host memory -> results in host memory: lps_set_variants + lps_set_reference + lps_push_reads (H2D) + lps_prepare_reads + "
+                                  "lps_phase_chromosome per contig, two contexts on one GPU so that one contig's load overlaps another's phase; PCIe-inclusive, never `value`"),
+                vs_baseline=dict(p_clock_over_cpu=round(gpu_p / cpu, 2), note="clock P (what SURVEY.md 8d judges the >= 20x target by) over the whole-node reference rate on the same sample; "
+                                 "the top-level vs_baseline stays null: BASELINE.md holds no published number"))
+
+
 def gpu_nodes():
     """GPUs of this machine from the KFD topology in sysfs - no HIP call (the parent of spawn_ranks must not touch the GPU).  None = unknown."""
     import glob
@@ -228,6 +322,7 @@ def main():
     ap.add_argument("--parity", default="all", help="all | none | comma-separated contig names whose step-0 output is compared with the oracle")
     ap.add_argument("--cpu-contig", default="", help="contig the reference binary is timed on (default: the smallest of the workload)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-whole-node", action="store_true", help="skip the 16-contig whole-node CPU baseline / P clock (about 1.5 min)")
     ap.add_argument("--ctx-per-gpu", type=int, default=4, help="contigs phased concurrently on one GPU, one context (stream, host thread) each")
     a = ap.parse_args()
 
@@ -514,7 +609,19 @@ def main():
             t0 = time.time()
             res["cpu_baseline"] = cpu_baseline(cpu_pick[0], cpu_pick[1], a.cpu_threads or min(16, ncpu), port, cpu_pick[2])
             cpu_pick[0].close()
-            log(f"cpu baseline took {time.time()-t0:.1f}s")
+            log(f"cpu baseline (one contig) took {time.time()-t0:.1f}s")
+            if a.workload == "wgs_50x" and not a.no_whole_node:
+                t0 = time.time()
+                for cx in ctxs:                                            # (their buffers are not needed any more: room for the sample's two contexts)
+                    cx.close()
+                try:
+                    wn = whole_node_baseline(dev, P, a.cpu_threads or min(16, ncpu), a.seed)
+                except Exception as e:  # noqa: BLE001
+                    log("whole-node baseline failed:", repr(e)[:300]); wn = None
+                if wn is not None:
+                    wn["k_clock_over_cpu"] = round(res["value"] / wn["value"], 1)
+                    res["cpu_baseline"]["whole_node"] = wn
+                log(f"whole-node baseline took {time.time()-t0:.1f}s")
         elif port:
             res["cpu_baseline"] = dict(port, kind="port", cores=1, sample=f"contig {cpu_name}, oracle restatement on decoded arrays, one thread")
         print(json.dumps(res), flush=True)

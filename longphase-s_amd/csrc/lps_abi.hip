@@ -68,6 +68,7 @@ struct lps_ctx {
     uint32_t name_max = 0;        // largest name_id pushed for this chromosome: bounds the digits of the name sort
     size_t z_late_off = 0, z_late_bytes = 0; unsigned long long late_n_keys = 0, late_cap_main = 0, late_tail = 0; bool cnv_skipped = false;
     DevBuf<uint8_t> hap_pool;     // per-read outputs of the scoring kernels, carved like zpool
+    DevBuf<uint4> hap_rec; DevBuf<int> pq_tab; bool pq_ready = false; DevBuf<int32_t> d_votes1, d_votes2;   // germline haplotag: packed per-read records, PQ table (host libm), SV / MOD votes
     DevBuf<uint8_t> zpool;        // the zero-initialised arrays of a phase run (arena_ctr, out_ps/gt, deleted, is_node, vtype_key, mrow_cnt, node_end/cur, bsize, cnt4) are carved from it
     // clips / cnv
     DevBuf<ClipEv> clip_ev; size_t clip_capacity = 0;
@@ -1222,6 +1223,14 @@ int lps_set_read_votes(lps_ctx *c, const int32_t *h1, const int32_t *h2, int64_t
     return 0;
 }
 
+// PQ = int(-10 log10(min / (max + min))) of (min, max) votes below 64, with the HOST's libm (HaplotagStrategy.cpp:287): what the
+// GPU looks up and the host would compute are the same numbers
+struct PqSmall { int v[64][64]; };
+static const PqSmall &pq_small_table() {
+    static const PqSmall tab = [] { PqSmall t{}; for (int mn = 1; mn < 64; ++mn) for (int mx = mn; mx < 64; ++mx) t.v[mn][mx] = -10 * (std::log10((double)mn / double((double)mx + (double)mn))); return t; }();
+    return tab;
+}
+
 int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
     if (!c || !out) return -1;
     try {
@@ -1231,45 +1240,62 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
         if (nR == 0) return 0;
         if (nV > 0 && !c->has_hap) return fail(c, "haplotag needs hp1_is_alt and phase_set in the variant table");
         if (nV > 0 && c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
-        int rc = run_scorer(c, false, out->status, out->hp1, out->hp2, out->n_ps, out->ps_min, nullptr, nullptr, nullptr);
-        if (rc) return rc;
-        if (!c->votes_h1.empty()) {                                       // judgeSVHap (:220-226): after the CIGAR walk, before the decision
-            if ((int)c->votes_h1.size() != nR) return fail(c, "lps_set_read_votes was called for another set of alignments");
-            for (int r = 0; r < nR; ++r) if (out->status[r] == 0) { out->hp1[r] += c->votes_h1[r]; out->hp2[r] += c->votes_h2[r]; }
-        }
-        // judgeReadHap (src/haplotag/HaplotagStrategy.cpp:243-300) on the host: needs libm's log10
-        const double thr = c->P.percentage_threshold;
-        int64_t tagged = 0;
-        struct PqSmall { int v[64][64]; };                                       // PQ of (min votes, max votes) for small counts: libm's log10 once per pair
-        static const PqSmall pq_tab = [] { PqSmall t{}; for (int mn = 1; mn < 64; ++mn) for (int mx = mn; mx < 64; ++mx) t.v[mn][mx] = -10 * (std::log10((double)mn / double((double)mx + (double)mn))); return t; }();
-        const auto &pq_small = pq_tab.v;
-        auto judge = [&](int r0, int r1) -> int64_t {
+        const bool votes = !c->votes_h1.empty();
+        if (votes && (int)c->votes_h1.size() != nR) return fail(c, "lps_set_read_votes was called for another set of alignments");
+        hipStream_t s = c->stream;
+        // ---- one 16-byte record per read: votes, PS and the read-level decision (judgeReadHap, HaplotagStrategy.cpp:243-300) taken on the GPU
+        c->hap_rec.reserve((size_t)nR + 1);
+        const size_t span = (size_t)nR * sizeof(uint4);
+        if (span + 1024 > c->h_res_bytes) { if (c->h_res) HIP_TRY(hipHostFree(c->h_res)); c->h_res = nullptr; c->h_res_bytes = span + span / 4 + 4096; HIP_TRY(hipHostMalloc((void **)&c->h_res, c->h_res_bytes)); }
+        if (!c->pq_ready) { c->pq_tab.reserve(64 * 64); HIP_TRY(hipMemcpyAsync(c->pq_tab.p, &pq_small_table().v[0][0], 64 * 64 * sizeof(int), hipMemcpyHostToDevice, s)); c->pq_ready = true; }
+        if (votes) { upload(c, c->d_votes1, c->votes_h1.data(), (size_t)nR); upload(c, c->d_votes2, c->votes_h2.data(), (size_t)nR); }
+        c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1);
+        HIP_TRY(hipEventRecord(c->ev_begin, s));
+        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
+        VarView V = var_view(c); ReadView R = read_view(c);
+        for (auto &u : c->ev_used) u = false;
+        mark(c, ST_PREP);
+        launch_variant_prep(V, /*is_ont (filterSNP is a `phase` step)*/ 0, c->v_bucket.p, c->v_rec.p, s);
+        mark(c, ST_EXTRACT);
+        HapOut H{};
+        H.pct_thr = c->P.percentage_threshold; H.rec = c->hap_rec.p; H.pq_tab = c->pq_tab.p; H.votes1 = votes ? c->d_votes1.p : nullptr; H.votes2 = votes ? c->d_votes2.p : nullptr;
+        launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 0, c->d_cnt, s);
+        mark(c, ST_D2H);
+        HIP_TRY(hipMemcpyAsync(c->h_res, c->hap_rec.p, span, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(c->h_cnt_pin, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(c->ev_end, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        c->h_cnt = *c->h_cnt_pin;
+        if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) return fail(c, "Alignment find unsupported CIGAR operation", -2);
+        // ---- the records into the caller's arrays (PQ of reads with 64 votes or more: libm here)
+        const uint4 *rec = (const uint4 *)c->h_res;
+        auto unpack = [&](int r0, int r1) -> int64_t {
             int64_t n_tagged = 0;
             for (int r = r0; r < r1; ++r) {
-                int hp = 0, pq = 0;
-                if (out->status[r] == 0) {
-                    const int a = out->hp1[r], b = out->hp2[r];
-                    double mn, mx;
-                    if (a > b) { mn = b; mx = a; } else { mn = a; mx = b; }
-                    if (mx / (mx + mn) < thr) pq = 0;
-                    else { if (a > b) hp = 1; if (a < b) hp = 2; }
-                    if (mx == 0) pq = 0; else if (mx == mx + mn) pq = 40;
-                    else if (a < 64 && b < 64) pq = pq_small[a < b ? a : b][a < b ? b : a];    // the same expression, evaluated once per (min, max) pair
-                    else pq = -10 * (std::log10((double)mn / double(mx + mn)));
-                    if (out->n_ps[r] > 1) hp = 0;
-                }
-                out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = (hp && out->n_ps[r]) ? out->ps_min[r] : 0;   // no PS seen (a read tagged by SV / MOD votes alone): the reference reads begin() of an empty map, 0 with libstdc++
+                const uint4 w = rec[r];
+                const int a = (int)w.y, b = (int)w.z; const unsigned hp = (w.x >> 16) & 0xffu, nps = (w.x >> 8) & 0xffu; int pq = (int)(w.x >> 24);
+                if (pq == 255) { const double mn = a < b ? a : b, mx = a < b ? b : a; pq = -10 * (std::log10(mn / double(mx + mn))); }
+                out->status[r] = (uint8_t)(w.x & 0xffu); out->hp1[r] = a; out->hp2[r] = b; out->n_ps[r] = (uint8_t)nps; out->ps_min[r] = (int32_t)w.w;
+                out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = (hp && nps) ? (int32_t)w.w : 0;   // no PS seen (a read tagged by SV / MOD votes alone): the reference reads begin() of an empty map, 0 with libstdc++
                 n_tagged += hp != 0;
             }
             return n_tagged;
         };
-        if (nR < 200000) tagged = judge(0, nR);
-        else {                                                            // a whole 50x chromosome: a few host threads share the per-read decisions
+        int64_t tagged = 0;
+        if (nR < 200000) tagged = unpack(0, nR);
+        else {                                                            // a whole 50x chromosome: a few host threads share the copy-out
             const int nt = 4; std::thread th[nt]; int64_t part[nt] = {0, 0, 0, 0};
-            for (int t = 0; t < nt; ++t) th[t] = std::thread([&, t] { part[t] = judge((int)((int64_t)nR * t / nt), (int)((int64_t)nR * (t + 1) / nt)); });
+            for (int t = 0; t < nt; ++t) th[t] = std::thread([&, t] { part[t] = unpack((int)((int64_t)nR * t / nt), (int)((int64_t)nR * (t + 1) / nt)); });
             for (int t = 0; t < nt; ++t) { th[t].join(); tagged += part[t]; }
         }
-        c->tm.n_reads_used = tagged;
+        lps_timings &t = c->tm; memset(&t, 0, sizeof t);
+        t.n_stages = ST_COUNT;
+        HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_PREP], c->ev[ST_PREP], c->ev[ST_EXTRACT]));
+        HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_EXTRACT], c->ev[ST_EXTRACT], c->ev[ST_D2H]));
+        HIP_TRY(hipEventElapsedTime(&t.ms_kernel[ST_D2H], c->ev[ST_D2H], c->ev_end));
+        HIP_TRY(hipEventElapsedTime(&t.ms_total, c->ev_begin, c->ev_end));
+        t.algorithmic_bytes[ST_EXTRACT] = 36ll * nR + 4ll * (int64_t)c->n_cig + 16ll * nR;   // + observations (unknown here)
+        t.n_reads_used = tagged;
     } catch (std::string &e) { return fail(c, e); }
     return 0;
 }

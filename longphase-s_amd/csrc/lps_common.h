@@ -177,5 +177,10 @@ __host__ __device__ __forceinline__ uint16_t pack_aq(int allele, int quality) { 
 __host__ __device__ __forceinline__ int aq_allele(uint16_t aq) { return (aq >> 9) & 1; }
 __host__ __device__ __forceinline__ int aq_quality(uint16_t aq) { return (int)(aq & 0x1ff) - 8; }
 
+// Workgroups are dealt round-robin over the 8 XCDs (one L2 each): workgroup b of a grid of 8k takes unit (b % 8) * k + b / 8, so that an XCD walks ONE
+// contiguous eighth of the units and what neighbouring units share or write side by side meets in one L2.
+__device__ __forceinline__ int xcd_unit(int b, int n_blocks8) { return (b & 7) * (n_blocks8 >> 3) + (b >> 3); }
+__host__ __device__ inline int round_up8(int x) { return (x + 7) / 8 * 8; }
+
 #define LPS_SEG 512           // CIGAR ops staged in LDS per wave and segment (4 KB/wave)
 #define LPS_BUCKET_SHIFT 10    // coarse position index: bucket b = first variant with pos >= b << shift

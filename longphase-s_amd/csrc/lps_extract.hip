@@ -88,9 +88,15 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 }
 
 // ------------------------------------------------------------------------------------------------ extraction
-#define EXT_RPW 4       // alignments per wave (a "job"; the later per-row kernels walk the four rows of a job as one span)
+#define EXT_RPW 4       // alignments per wave (a "job")
 #ifndef EXT_TAB
-#define EXT_TAB 1024    // lane-chunks (8 CIGAR words each) a wave keeps in LDS: 8 KB = 8 192 words, ~200 kb of ONT read; a job that holds more is walked in groups
+#define EXT_TAB 1024    // lane-chunks (8 CIGAR words each) a wave keeps in LDS - words (16 KB) and the chunks' coordinates (4 KB): 4 096 words, ~100 kb of
+#endif                  // ONT read; a job that holds more is walked in groups, an alignment that alone holds more with a coarser table
+#ifndef EXT_WORDS_IN_LDS
+#define EXT_WORDS_IN_LDS 0   // 1: a group's CIGAR words stay in LDS for the candidates (32 B per lane-chunk more); 0: the candidates re-read their chunk's words
+#endif
+#ifndef EXT_WAVES
+#define EXT_WAVES 4     // waves per SIMD the register budget is sized for: 128 VGPRs, no spills; 5 / 6 / 8 waves (spills, smaller tables) were measured slower
 #endif
 #ifndef EXT_GROUP_MAX
 #define EXT_GROUP_MAX 4 // alignments walked together (their candidates are resolved together once their words are through)
@@ -130,24 +136,28 @@ __device__ __forceinline__ void advance_of(const uint32_t (&w)[8], int k, int &s
 // One wavefront = one job of four consecutive alignments, whose CIGARs lie back to back in memory.
 //   * WALK.  The CIGAR words of the job are ONE stream, taken 512 words per round, 8 consecutive words per lane, every lane busy whatever the
 //     alignments' lengths.  A lane sums the reference / query advance of its 8 words and one pair of DPP scans over the wave turns the sums into
-//     STREAM coordinates: reference and query bases consumed since the job's first word, running on across alignment boundaries.  That pair, 8 bytes
-//     per lane-chunk, is all that goes to LDS - no per-op prefixes, no per-alignment bookkeeping per lane, no barrier inside the loop; the words of
-//     the next round are requested before the current round is summed.  What an alignment needs is three scalars taken where its first and last
-//     word pass by: the stream coordinates of its first op (a variant at reference position p then sits at stream position p - start + that) and
-//     the reference position it ends at.
-//   * CANDIDATES.  With the job's chunks in the table, the candidate variants of the four alignments (position-sorted slices of the variant
-//     table: [first variant at or after the alignment's start, first variant at or beyond its reference end)) are counted, ONE atomicAdd reserves
-//     that many observation slots, and the candidates are taken 64 at a time as one flattened list, every lane busy: binary search of the
-//     alignment's chunks for the last chunk that starts at or before the variant, the chunk's 8 words (+ the one after) re-read from memory
-//     (they went through L2 a moment ago), an 8-step walk in registers to the op that covers the variant, the reference's rules for that op
-//     (ParsingBam.cpp:1445-1607), base and quality gathered right there, allele called, filterSNP's erasures applied, and the record written to
-//     its final, compacted place.  seq / qual are touched at variant sites only.
-// A job whose chunks do not fit the table (EXT_TAB), which holds more clip events than EXT_CLIPS, or in which get_snp's early return fires
-// (:1453-1455, :1559-1561: a record whose SEQ is shorter than its CIGAR) queues itself for k_extract_redo, the general walker, before it has
-// written anything a later stage looks at.
-__global__ __launch_bounds__(64, 4) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
+//     STREAM coordinates: reference and query bases consumed since the job's first word, running on across alignment boundaries.  The lane's pair
+//     (8 bytes) and its 8 words (32 bytes) go to LDS - no per-op prefixes, no per-alignment bookkeeping per lane, no barrier inside the loop; the
+//     words of the next round are requested before the current round is summed.  What an alignment needs is three scalars taken where its first
+//     and last word pass by: the stream coordinates of its first op (a variant at reference position p then sits at stream position
+//     p - start + that) and the reference position it ends at.
+//   * CANDIDATES.  With the job's chunks in LDS, the candidate variants of the four alignments (position-sorted slices of the variant table:
+//     [first variant at or after the alignment's start, first variant at or beyond its reference end)) are counted, ONE atomicAdd reserves that
+//     many observation slots, and the candidates are taken 64 at a time as one flattened list, every lane busy: binary search of the alignment's
+//     chunks for the last chunk that starts at or before the variant, the chunk's 8 words (+ the one after) from LDS, an 8-step walk in
+//     registers to the op that covers the variant, the reference's rules for that op (ParsingBam.cpp:1445-1607), base and quality gathered
+//     right there (one 128-byte line for both, lps_reads.hip), allele called, filterSNP's erasures applied, the observation counted (its rank
+//     in the variant's list) and the record written to its final, compacted place.  Every CIGAR word is fetched from memory ONCE and a base /
+//     quality pair costs one line: the kernel is bound by the rate at which L2 misses are served (profiles/r03_gather_calibration.md), so lines
+//     are what it saves.
+// A job whose words do not fit (8 * EXT_TAB) is walked in groups of alignments; an alignment that alone does not fit is walked with one table
+// entry per 8 << shift words and re-reads the words it needs (LONG mode: read lengths beyond ~100 kb).  A job that holds more clip events than
+// EXT_CLIPS, or in which get_snp's early return fires (:1453-1455, :1559-1561: a record whose SEQ is shorter than its CIGAR) queues itself for
+// k_extract_redo, the general walker, before it has written anything a later stage looks at.
+__global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
                                                       LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint32_t *var_cnt, uint32_t *var_del) {
     __shared__ __attribute__((aligned(16))) int2 s_tab[EXT_TAB];
+    __shared__ __attribute__((aligned(16))) uint32_t s_words[EXT_WORDS_IN_LDS ? 8 * EXT_TAB + 16 : 16];
     __shared__ ExtHdr s_hdr[EXT_RPW];
     __shared__ ClipEv s_clip[EXT_CLIPS];
     const int l = lane_id();
@@ -176,11 +186,7 @@ __global__ __launch_bounds__(64, 4) void k_extract_phase(VarView V, ReadView R, 
         return;
     }
     const int h_ncig_all = (int)(long long)(__shfl_down(h_coff, 1) - h_coff);   // (lanes < nq)
-    // an alignment that alone does not fit the table: the general walker takes the job (checked before anything is written)
-    if (__ballot(l < nq && h_live && ((h_ncig_all + 7) >> 3) + 1 > EXT_TAB)) { to_redo(); return; }
-    // first candidate of each alignment: four lanes search the position-sorted table side by side
-    int h_v0 = 0;
-    if (l < 4 && h_live) h_v0 = lane_var_lower_bound(V, h_start);
+    int h_v0 = 0; bool have_v0 = false;
     // what lane q collects for row q; clip events of the job (reference coordinates)
     unsigned row_off = 0; int row_cnt = 0; unsigned row_flags = 0;
     int n_clip = 0; bool fail = false, arena_full = false;
@@ -199,6 +205,12 @@ __global__ __launch_bounds__(64, 4) void k_extract_phase(VarView V, ReadView R, 
             gm |= 1u << q; qb = q;
         }
         todo &= ~gm;
+        // LONG mode: the group's first alignment alone holds more words than LDS takes (then it is the whole group): one table entry per 8 << shift
+        // words, the words themselves are read again where a candidate needs them
+        int shift = 0;
+        { const long long w1 = (long long)(__shfl(h_coff, qa + 1) - c_lo); while ((((w1 + 7) >> 3) + ((1ll << shift) - 1)) >> shift > EXT_TAB) ++shift; }
+        const bool fast = shift == 0;                                     // one table entry per lane-chunk, alignment boundaries inside chunks
+        const bool in_lds = EXT_WORDS_IN_LDS && fast;
         // the stream: from the first word of the group's first alignment to the last word of its last one (alignments in between that are not
         // walked - low MAPQ, secondary - pass by as words that only move the coordinates on)
         const bool h_in = l < 4 && ((gm >> l) & 1u);
@@ -217,11 +229,13 @@ __global__ __launch_bounds__(64, 4) void k_extract_phase(VarView V, ReadView R, 
         };
         uint32_t pw[8];
         request(l, pw);                                                   // round 0 is on its way
+        // first candidate of each alignment: four lanes search the position-sorted table side by side (a chain of dependent loads: behind round 0's request)
+        if (!have_v0) { if (l < 4 && h_live) h_v0 = lane_var_lower_bound(V, h_start); have_v0 = true; }
         const bool h_walk = h_in && h_ncig > 0;
         // where an alignment begins and ends INSIDE its first / last lane-chunk: lane q sums the words in front of the first and up to the last
         // word of alignment q now, while the walk's first round is in flight (the chunks' own coordinates come out of the walk)
         const int x_end = h_rel + h_ncig - 1;
-        const int cs = h_walk ? h_rel >> 3 : 0, ce = h_walk ? x_end >> 3 : 0;
+        const int cs = (h_walk && fast) ? h_rel >> 3 : 0, ce = (h_walk && fast) ? x_end >> 3 : 0;
         int adv_r = 0, adv_q = 0, end_r = 0;
         {
             const int ks = h_rel & 7, ke = (x_end & 7) + 1;
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(64, 4) void k_extract_phase(VarView V, ReadView R, 
         for (int q = 0; q < 4; ++q) { v0q[q] = __builtin_amdgcn_readlane(h_v0, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; pp[q] = V.pos[min(v0q[q] + l, V.n - 1)]; }
         if (l < 4) {                                                      // (first half of the header: what the rare paths of the walk look at)
             ExtHdr &h = s_hdr[l];
-            h.crel = h_rel; h.ncig = h_walk ? h_ncig : 0; h.c0 = cs; h.nch = h_walk ? ce - cs + 1 : 0;
+            h.crel = h_rel; h.ncig = h_walk ? h_ncig : 0; h.c0 = cs; h.nch = h_walk ? (fast ? ce - cs + 1 : (((h_ncig + 7) >> 3) + (1 << shift) - 1) >> shift) : 0;
             h.lq = h_lq; h.blk0 = h_blk;
         }
         wave_sync();
@@ -270,7 +284,12 @@ __global__ __launch_bounds__(64, 4) void k_extract_phase(VarView V, ReadView R, 
             }
             const int ir = wave_incl_scan_dpp(rt), iq = wave_incl_scan_dpp(qt);
             const int my_s = carry_r + ir - rt, my_q = carry_q + iq - qt; // stream coordinates of the lane's first word
-            if (cid < TC) s_tab[cid] = make_int2(my_s, my_q);
+            if (fast) {
+                if (cid < TC) {
+                    s_tab[cid] = make_int2(my_s, my_q);
+                    if (in_lds) { uint4 *wd = reinterpret_cast<uint4 *>(s_words + 8 * cid); wd[0] = make_uint4(w[0], w[1], w[2], w[3]); wd[1] = make_uint4(w[4], w[5], w[6], w[7]); }
+                }
+            } else if (cid < TC && (cid & ((1 << shift) - 1)) == 0) s_tab[cid >> shift] = make_int2(my_s, my_q);
             carry_r += __builtin_amdgcn_readlane(ir, 63); carry_q += __builtin_amdgcn_readlane(iq, 63);
             if ((unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu) { give_up = true; break; }   // stream coordinates are 32-bit: absurd spans go to the general walker
             // ops the reference rejects (:1625-1628) and clips (getClip :1613-1620,1636-1645: soft/hard clips longer than 5; FRONT iff CIGAR index 0),
@@ -328,7 +347,10 @@ __global__ __launch_bounds__(64, 4) void k_extract_phase(VarView V, ReadView R, 
 
         // ---- where each alignment begins and ends in stream coordinates, the candidates of each: variants [v0, first variant at or beyond its end)
         int b_sat = 0, b_qat = 0, b_rend = h_start;
-        if (h_walk) { const int2 ts = s_tab[cs], te = s_tab[ce]; b_sat = ts.x + adv_r; b_qat = ts.y + adv_q; b_rend = h_start + te.x + end_r - b_sat; }
+        if (h_walk) {
+            if (fast) { const int2 ts = s_tab[cs], te = s_tab[ce]; b_sat = ts.x + adv_r; b_qat = ts.y + adv_q; b_rend = h_start + te.x + end_r - b_sat; }
+            else b_rend = h_start + carry_r;                                // LONG mode: the alignment is the whole stream
+        }
         int ncand[4], rend[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -347,7 +369,7 @@ __global__ __launch_bounds__(64, 4) void k_extract_phase(VarView V, ReadView R, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) vadj[q] = v0q[q] - cum[q];
         if (l < 4) { ExtHdr &h = s_hdr[l]; h.vadj = SEL4(l, vadj); h.ds = b_sat - h_start; h.dq = b_qat; }
-        int maxnch = h_walk ? ce - cs + 1 : 0;
+        int maxnch = l < 4 ? s_hdr[l].nch : 0;
         maxnch = max(max(__builtin_amdgcn_readlane(maxnch, 0), __builtin_amdgcn_readlane(maxnch, 1)), max(__builtin_amdgcn_readlane(maxnch, 2), __builtin_amdgcn_readlane(maxnch, 3)));
         // ---- ONE reservation for the rows of the group: a slot per candidate (the few candidates that turn out not to be observations - a base that
         //      is neither allele, a variant inside a deletion, a variant filterSNP erased - leave slots unused at the end), so that records go straight
@@ -359,6 +381,10 @@ __global__ __launch_bounds__(64, 4) void k_extract_phase(VarView V, ReadView R, 
         unsigned long long g0 = 0; ObsRec *dst = nullptr;
         int n_out = 0, n_emit[4] = {0, 0, 0, 0}; unsigned any_pre = 0;
         uint2 pvr = V.rec[min(SELC(l, cum, vadj) + l, V.n - 1)];           // records are requested one round ahead
+        // an observation is counted where it is made: what the counting atomic returns is its rank inside the variant's list of observations, kept
+        // beside allele and quality - the node-major lists are filled later without a counting pass and without a second atomic.  The atomic's
+        // answer is not waited for: the record leaves at once, the rank follows a round later (or after the last round), when it has long arrived
+        bool pend = false; uint32_t pend_slot = 0, pend_aq = 0; unsigned pend_rk = 0;
 #pragma unroll 1
         for (int i0 = 0; i0 < T; i0 += 64) {
             const int i = i0 + l;
@@ -378,24 +404,36 @@ __global__ __launch_bounds__(64, 4) void k_extract_phase(VarView V, ReadView R, 
                 int co = 0;
                 for (int step = step0; step >= 1; step >>= 1) { const int t = co + step; const int sv = s_tab[hc0 + min(t, hnch - 1)].x; co = (t < hnch && sv <= ps) ? t : co; }
                 const int2 base = s_tab[hc0 + co];
-                const int x0 = 8 * (hc0 + co);                            // stream index of the chunk's first word
-                const uint32_t *cw = cg + x0;
-                uint32_t w[9];
-                {
-                    const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cw), b = *reinterpret_cast<const LpsU4 *>(cw + 4);
-                    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = cw[8];
-                }
+                const int x0 = (8 * (hc0 + co)) << shift;                  // stream index of the chunk's first word
                 // the op that covers the variant: the last one that starts at or before it.  Starts never decrease, so "starts at or before" holds
                 // for a prefix of the words: words of the alignment before (they end where this one begins) pass the test and are overtaken by this
                 // alignment's first op, words past its end start at its end, beyond every candidate - whatever they hold
-                int rr = base.x, qq = base.y, j = 0, rs = base.x, qs = base.y; uint32_t wj = w[0], wn = w[1];
+                int rr = base.x, qq = base.y, jx = x0, rs = base.x, qs = base.y; uint32_t wj = 6u, wn = 6u;
+                auto walk8 = [&](const uint32_t (&w)[9], int xb) __attribute__((always_inline)) {
 #pragma unroll
-                for (int k = 1; k < 8; ++k) {
-                    const unsigned t = op_consume_bits(w[k - 1] & 15u); const int len = (int)(w[k - 1] >> 4);
-                    rr += len & bit_mask(t, 0); qq += len & bit_mask(t, 16);
-                    const bool le = rr <= ps;
-                    j = le ? k : j; rs = le ? rr : rs; qs = le ? qq : qs; wj = le ? w[k] : wj; wn = le ? w[k + 1] : wn;
+                    for (int k = 0; k < 8; ++k) {
+                        const bool le = rr <= ps;
+                        jx = le ? xb + k : jx; rs = le ? rr : rs; qs = le ? qq : qs; wj = le ? w[k] : wj; wn = le ? w[k + 1] : wn;
+                        const unsigned t = op_consume_bits(w[k] & 15u); const int len = (int)(w[k] >> 4);
+                        rr += len & bit_mask(t, 0); qq += len & bit_mask(t, 16);
+                    }
+                };
+                if (in_lds) {
+                    uint32_t w[9];
+                    const uint4 a = *reinterpret_cast<const uint4 *>(s_words + x0), b = *reinterpret_cast<const uint4 *>(s_words + x0 + 4);
+                    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = s_words[x0 + 8];
+                    walk8(w, x0);
+                } else {
+                    for (int u = 0; u < (1 << shift); ++u) {                  // the entry's 8 << shift words, 8 at a time, until the walk is past the variant
+                        const uint32_t *cw = cg + x0 + 8 * u;
+                        uint32_t w[9];
+                        const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cw), b = *reinterpret_cast<const LpsU4 *>(cw + 4);
+                        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = cw[8];
+                        walk8(w, x0 + 8 * u);
+                        if (rr > ps || x0 + 8 * u + 8 >= hcrel + hncig) break;
+                    }
                 }
+                const int j = jx - x0;
                 const int op = wj & 15, len = (int)(wj >> 4);
                 const int opi = x0 + j - hcrel;                           // op index inside the alignment
                 qs -= hb.w;                                               // query position inside the alignment
@@ -444,15 +482,15 @@ __global__ __launch_bounds__(64, 4) void k_extract_phase(VarView V, ReadView R, 
                 if (off + (unsigned long long)T > O.arena_size) arena_full = true;
                 g0 = arena_lo + off; dst = O.rec + g0;
             }
-            if (ok && !arena_full) {
-                // the observation is counted where it is made: what the counting atomic returns is its rank inside the variant's list of observations,
-                // kept beside allele and quality - the node-major lists are filled later without a counting pass and without a second atomic
-                unsigned rk = 0;
-                if (var_cnt) { rk = atomicAdd(&var_cnt[v], 1u); if (rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); }
-                dst[n_out + __popcll(om & lanemask_lt())] = ObsRec{(int32_t)v, (uint32_t)pack_aq(allele, qv) | (rk << 10)};
-            }
+            const bool put = ok && !arena_full;
+            const uint32_t slot = (uint32_t)(n_out + __popcll(om & lanemask_lt())), aqw = (uint32_t)pack_aq(allele, qv);
+            unsigned rk = 0;
+            if (put) { dst[slot] = ObsRec{(int32_t)v, aqw}; if (var_cnt) rk = atomicAdd(&var_cnt[v], 1u); }
+            if (pend) { if (pend_rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); dst[pend_slot].aq = pend_aq | (pend_rk << 10); }
+            pend = put && var_cnt != nullptr; pend_slot = slot; pend_aq = aqw; pend_rk = rk;
             n_out += __popcll(om);
         }
+        if (pend) { if (pend_rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); dst[pend_slot].aq = pend_aq | (pend_rk << 10); }
         if (__ballot(fail)) {
             // get_snp returned early somewhere in these alignments (SEQ shorter than the CIGAR says: the read is dropped but clips of earlier ops
             // stay): the general walker replays the whole job.  Nothing a later stage looks at has been written, but the observations made so far

@@ -389,8 +389,6 @@ __global__ void k_cnv_miss(const LpsCounters *cnt, int n_var, const int32_t *vpo
 // ================================================================================================ nodes
 // Workgroups are dealt round-robin over the 8 XCDs (one L2 each): workgroup b of a grid of 8k takes unit (b % 8) * k + b / 8, so that an XCD walks ONE
 // contiguous eighth of the units and what neighbouring units share (list entries, rows of packed words) meets in one L2.
-__device__ __forceinline__ int xcd_unit(int b, int n_blocks8) { return (b & 7) * (n_blocks8 >> 3) + (b >> 3); }
-__host__ __device__ inline int round_up8(int x) { return (x + 7) / 8 * 8; }
 
 // Every observation was counted where it was made: the extraction's atomicAdd on var_cnt[variant] RETURNED the observation's rank inside the
 // variant's list (kept in bits 10..31 of ObsRec.aq), observations that were dropped afterwards - alignments deleted by the overlap filter, entries

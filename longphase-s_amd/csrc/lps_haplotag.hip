@@ -28,7 +28,9 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
     __shared__ __attribute__((aligned(16))) int s_qry[HAP_WPB][LPS_SEG];
     __shared__ __attribute__((aligned(16))) uint32_t s_cig[HAP_WPB][LPS_SEG + 4];
     const int w = threadIdx.x >> 6, l = lane_id();
-    const int r = blockIdx.x * HAP_WPB + w;
+    // XCD-aware: neighbouring reads are scored inside one XCD, so that their 16-byte result records meet in ONE L2 and leave as whole lines (with the
+    // plain mapping every 128-byte line of results was written back as eight partials: 62 bytes written per byte of payload)
+    const int r = xcd_unit((int)blockIdx.x, (int)gridDim.x) * HAP_WPB + w;
     if (r >= R.n) return;
     int *sref = s_ref[w], *sqry = s_qry[w]; uint32_t *scig = s_cig[w];
     const int start = R.ref_start[r];
@@ -225,6 +227,26 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
         }
         return;
     }
+    if (MODE == 0 && H.rec) {
+        // judgeReadHap (HaplotagStrategy.cpp:243-300) here: the threshold is an IEEE double division like the host's; PQ = int(-10 log10(min / (max + min)))
+        // comes from a table the host built with ITS libm for votes below 64, beyond that the host computes it (PQ 255)
+        if (l == 0) {
+            const bool any = ps_lo <= ps_hi; const unsigned nps = any ? (ps_lo == ps_hi ? 1u : 2u) : 0u;
+            int a = h1, b = h2; unsigned hp = 0, pq = 0;
+            if (status == 0) {
+                if (H.votes1) { a += H.votes1[r]; b += H.votes2[r]; }                 // judgeSVHap (:220-226): after the CIGAR walk, before the decision
+                double mn, mx;
+                if (a > b) { mn = b; mx = a; } else { mn = a; mx = b; }
+                if (!(mx / (mx + mn) < H.pct_thr)) { if (a > b) hp = 1; if (a < b) hp = 2; }
+                if (mx == 0) pq = 0; else if (mn == 0) pq = 40;
+                else if (a >= 0 && b >= 0 && a < 64 && b < 64) pq = (unsigned)H.pq_tab[(a < b ? a : b) * 64 + (a < b ? b : a)];
+                else pq = 255;
+                if (nps > 1) hp = 0;
+            }
+            H.rec[r] = make_uint4((unsigned)status | (nps << 8) | (hp << 16) | (pq << 24), (unsigned)a, (unsigned)b, (unsigned)(any ? ps_lo : 0));
+        }
+        return;
+    }
     if (l == 0) {
         H.status[r] = (uint8_t)status; H.hp1[r] = h1; H.hp2[r] = h2;
         const bool any = ps_lo <= ps_hi;
@@ -237,7 +259,7 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
                      int mode, LpsCounters *cnt, hipStream_t s) {
     if (R.n == 0) return;
-    const dim3 g((R.n + HAP_WPB - 1) / HAP_WPB), b(64 * HAP_WPB);
+    const dim3 g(round_up8((R.n + HAP_WPB - 1) / HAP_WPB)), b(64 * HAP_WPB);   // a multiple of 8: the XCD-aware unit mapping
     if (mode == 1) hipLaunchKernelGGL(k_haplotag_score<1>, g, b, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
     else if (mode == 2) hipLaunchKernelGGL(k_haplotag_score<2>, g, b, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
     else if (mode == 3) hipLaunchKernelGGL(k_haplotag_score<3>, g, b, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);

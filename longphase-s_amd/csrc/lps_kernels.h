@@ -181,7 +181,10 @@ __device__ __forceinline__ int var_lower_bound(const VarView &V, int key) {
 #endif
 
 struct HapOut { uint8_t *status; int32_t *hp1, *hp2; uint8_t *n_ps; int32_t *ps_min; int32_t *hp3, *d1, *d2;
-                int32_t *site; uint8_t *read_hp; double pct_thr; };   // site counters [nV][LPS_SITE_COUNTERS], per-read hp of the pass
+                int32_t *site; uint8_t *read_hp; double pct_thr;     // site counters [nV][LPS_SITE_COUNTERS], per-read hp of the pass
+                // germline haplotag (mode 0): ONE 16-byte record per read instead of five arrays, the read-level decision taken on the GPU:
+                //   word 0 = status | n_ps << 8 | HP << 16 | PQ << 24 (PQ 255: votes of 64 or more, the host computes it), hp1, hp2 (votes included), ps_min
+                uint4 *rec; const int *pq_tab /* [64][64]: PQ of (min, max) votes, built by the host's libm */; const int32_t *votes1, *votes2; };
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
                      int mode, LpsCounters *cnt, hipStream_t s);   // mode 0 haplotag, 1 somatic tag, 2 normal extraction, 3 its read-HP pass
 

@@ -531,8 +531,71 @@ def make_cli_indelq():
         print("cli_indelq: removed", sum(1 for _ in open(os.path.join(d, "out_removed_indels.log"))) - 1, "filtered tags", sum(1 for l in open(os.path.join(d, "out.vcf")) if "INDEL_QUAL_FILTERED" in l and not l.startswith("#")))
 
 
+def parse_dot(path):
+    """`phase --dot` (<chr>.dot, PhasingGraph.cpp:402-409,1031-1047): two lines per CONNECTED (source, target) pair of edgeConnectResult,
+    "P.1 -> Q.a" and "P.2 -> Q.b" with 1-based positions; a == 1: the target continues the source's haplotype (direction 1), a == 2: it crosses.
+    -> int32 [n][3] rows (source pos0, target pos0, direction) in the order the reference connected them."""
+    rows = []
+    lines = [ln.strip() for ln in open(path) if "->" in ln]
+    assert len(lines) % 2 == 0
+    for e1, e2 in zip(lines[0::2], lines[1::2]):
+        a, _, b = e1.split("\t"); c, _, d = e2.split("\t")
+        sp, sh = a.split("."); tp, th = b.split("."); sp2, sh2 = c.split("."); tp2, th2 = d.split(".")
+        assert sh == "1" and sh2 == "2" and sp == sp2 and tp == tp2 and {th, th2} == {"1", "2"}, (e1, e2)
+        rows.append((int(sp) - 1, int(tp) - 1, int(th)))
+    return np.array(rows, np.int32).reshape(-1, 3)
+
+
+def parse_tag_log(path):
+    """`haplotag --log` (<prefix>.out, HaplotagProcess.cpp:177-237): one row per alignment that reached judgeHaplotype.
+    -> dict of arrays: qname, read_start (0-based), hp (0 = '.'), ps (0 = '.'), h1, h2 (votes), pq, n_var (entries of the (Variant,HP) list)."""
+    qn, st, hp, ps, h1, h2, pq, nv = [], [], [], [], [], [], [], []
+    for ln in open(path):
+        if ln.startswith("#"):
+            continue
+        f = ln.rstrip("\n").split("\t")
+        qn.append(f[0]); st.append(int(f[2]))
+        h = f[4][1:]; hp.append(0 if h in (".", "") else int(h))
+        ps.append(0 if f[5] in (".", "") else int(f[5]))
+        h1.append(int(f[7])); h2.append(int(f[8])); pq.append(int(f[9]) if f[9] not in (".", "") else -1)
+        nv.append(len(f[10].split()) if len(f) > 10 else 0)
+    return dict(qname=np.array(qn), read_start=np.array(st, np.int32), hp=np.array(hp, np.int8), ps=np.array(ps, np.int32),
+                h1=np.array(h1, np.int32), h2=np.array(h2, np.int32), pq=np.array(pq, np.int32), n_var=np.array(nv, np.int32))
+
+
+STAGE_PHASE = ["snp_ont", "indels", "two_blocks", "supp_light_dups", "params_a"]
+STAGE_HAPLOTAG = ["snp_ont", "indels", "supp_tagged", "strict"]
+
+
+def make_stage_goldens():
+    """Intermediate stages the reference itself exposes: the connected pairs of edgeConnectResult with their direction (`--dot`)
+    and the per-read votes / PQ / PS of judgeHaplotype (`--log`).  tests/test_stage_goldens*.py hold the oracle and the GPU dumps against them."""
+    for name in STAGE_PHASE:
+        kw, cli, over = fixtures.PHASE_FIXTURES[name]
+        s = Synth(**kw)
+        with tempfile.TemporaryDirectory() as d:
+            ps, gt = run_reference_phase(s, cli + ["--dot"], d)
+            dot = parse_dot(os.path.join(d, "chrS.dot"))
+        np.savez_compressed(os.path.join(HERE, f"stage_dot_{name}.npz"), edges=dot, digest=np.array(fixtures.input_digest(s)))
+        print("dot", name, dot.shape, "direction 1:", int((dot[:, 2] == 1).sum()), "direction 2:", int((dot[:, 2] == 2).sum()))
+        s.close()
+    for name in STAGE_HAPLOTAG:
+        src, tag_cli, over = fixtures.HAPLOTAG_FIXTURES[name]
+        kw, phase_cli, _ = fixtures.PHASE_FIXTURES[src]
+        s = Synth(**kw)
+        with tempfile.TemporaryDirectory() as d:
+            run_reference_haplotag(s, phase_cli, tag_cli + ["--log"], d)
+            log = parse_tag_log(os.path.join(d, "tagged.out"))
+        np.savez_compressed(os.path.join(HERE, f"stage_taglog_{name}.npz"), digest=np.array(fixtures.input_digest(s)), **log)
+        print("taglog", name, log["hp"].size, "rows,", int((log["hp"] != 0).sum()), "tagged")
+        s.close()
+
+
 def main():
     assert os.path.exists(REF_BIN), "build the reference first: oracle/build_ref.sh"
+    if "--stages" in sys.argv:
+        make_stage_goldens()
+        return
     if "--cli-indelq" in sys.argv:
         make_cli_indelq()
         return
