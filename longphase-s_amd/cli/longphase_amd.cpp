@@ -141,13 +141,16 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::map<std::string, std::map<int32_t, Phased>> res; std::mutex res_mu;
     // packed SNP table of the whole genome (pos i32 | ref0 u8 | alt0 u8 | ref_len u16 | alt_len u16, contig after contig): worker 0 builds it from the parsed
     // VCF; with --gpus N it reaches the other GPUs by one RCCL broadcast (lps_comm_bcast) and every worker reads its contigs' rows from ITS copy
-    struct Packed { std::vector<uint8_t> buf; size_t n = 0; std::map<std::string, std::pair<size_t, size_t>> where;
-        const int32_t *pos() const { return (const int32_t *)buf.data();
-            } const uint8_t *r0() const { return buf.data() + 4 * n;
-            } const uint8_t *a0() const { return buf.data() + 5 * n;
+    // dev: the table where ncclBroadcast left it on this worker's GPU (lps_comm_bcast_to_device) - the rows then go to the context as device
+    // pointers (lps_set_variants_device), no copy back to the host; else the rows are read from buf (host)
+    struct Packed { std::vector<uint8_t> buf; size_t n = 0; std::map<std::string, std::pair<size_t, size_t>> where; const uint8_t *dev = nullptr;
+        const uint8_t *base() const { return dev ? dev : buf.data(); }
+        const int32_t *pos() const { return (const int32_t *)base();
+            } const uint8_t *r0() const { return base() + 4 * n;
+            } const uint8_t *a0() const { return base() + 5 * n;
             }
-        const uint16_t *rl() const { return (const uint16_t *)(buf.data() + 6 * n);
-            } const uint16_t *al() const { return (const uint16_t *)(buf.data() + 8 * n);
+        const uint16_t *rl() const { return (const uint16_t *)(base() + 6 * n);
+            } const uint16_t *al() const { return (const uint16_t *)(base() + 8 * n);
             } };
     Packed table0;
     { size_t n = 0; for (const std::string &c : chr_order) { table0.where[c] = {n, vars[c].pos.size()}; n += vars[c].pos.size(); }
@@ -196,7 +199,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         vt.ref_len = tab.rl() + to;
         vt.alt_len = tab.al() + to;
         const std::string &sq = seqs[chr];
-        if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size())) die(std::string("longphase_amd: ") + L.last_error(ctx));
+        if (L.begin_chromosome(ctx) || (tab.dev ? L.set_variants_device(ctx, &vt) : L.set_variants(ctx, &vt)) || L.set_reference(ctx, sq.data(), (int64_t)sq.size())) die(std::string("longphase_amd: ") + L.last_error(ctx));
         ExtraRows xr;
         if (co_phase) { xr.build(svt, modt, chr, names, name_id, sv_window, sv_threshold); if (xr.any() && L.set_extra_variants(ctx, &xr.x)) die(std::string("longphase_amd: ") + chr + ": " + L.last_error(ctx)); }
         size_t at = 0;
@@ -250,20 +253,19 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     // the one collective: a communicator over the workers' GPUs (ncclCommInitAll); fails when two workers share a device (rehearsal on fewer GPUs
     // than --gpus) - the workers then read the table worker 0 holds, in this one address space
     std::vector<lps_comm *> comms((size_t)n_workers, nullptr); bool have_comm = false;
-    if (n_workers > 1) { std::vector<int> devs; for (int g = 0; g < n_workers; ++g) devs.push_back((gpu + g) % n_dev);
+    // (LPS_CLI_BCAST_ALWAYS: a communicator even for one worker, so that the broadcast -> lps_set_variants_device path runs on a one-GPU box)
+    if (n_workers > 1 || getenv("LPS_CLI_BCAST_ALWAYS")) { std::vector<int> devs; for (int g = 0; g < n_workers; ++g) devs.push_back((gpu + g) % n_dev);
         have_comm = std::set<int>(devs.begin(), devs.end()).size() == devs.size() && L.comm_create_all(n_workers, devs.data(), comms.data()) == 0;
         if (have_comm) std::cerr << "longphase_amd: RCCL communicator over " << L.comm_size(comms[0]) << " GPUs\n";
         else std::cerr << "longphase_amd: no RCCL communicator (" << (std::set<int>(devs.begin(), devs.end()).size() == devs.size() ? L.comm_last_error() : "workers share a device") << "); workers read the host table\n";
         }
     auto obtain_table = [&](int g, Packed &mine) -> const Packed & {       // every worker calls this once (collective)
         if (!have_comm) return table0;
-        if (g == 0) { double ms = 0;
-            if (L.comm_bcast(comms[0], table0.buf.data(), (int64_t)table0.buf.size(), 0, &ms)) die(std::string("longphase_amd: ") + L.comm_last_error());
-            fprintf(stderr, "longphase_amd: SNP table broadcast, %zu bytes, %.3f ms\n", table0.buf.size(), ms);
-            return table0;
-            }
-        mine.n = table0.n; mine.where = table0.where; mine.buf.assign(table0.buf.size(), 0);
-        if (L.comm_bcast(comms[(size_t)g], mine.buf.data(), (int64_t)mine.buf.size(), 0, nullptr)) die(std::string("longphase_amd: ") + L.comm_last_error());
+        // root's host table -> the communicator's device buffer on every GPU; each worker's contexts take their contigs' rows from there
+        double ms = 0; void *d = nullptr;
+        if (L.comm_bcast_to_device(comms[(size_t)g], g == 0 ? table0.buf.data() : nullptr, (int64_t)table0.buf.size(), 0, &d, g == 0 ? &ms : nullptr)) die(std::string("longphase_amd: ") + L.comm_last_error());
+        if (g == 0) fprintf(stderr, "longphase_amd: SNP table broadcast, %zu bytes, %.3f ms\n", table0.buf.size(), ms);
+        mine.n = table0.n; mine.where = table0.where; mine.dev = (const uint8_t *)d;
         return mine;
     };
     for (int g = 1; g < n_workers; ++g) workers.emplace_back([&, g] {

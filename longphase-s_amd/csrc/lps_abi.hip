@@ -102,7 +102,7 @@ struct lps_ctx {
     int m_bits = 0, a_bits = 16, n_bits = 0;
 };
 
-#define LPS_MAX_ROWS 0x3fffff   /* rows of the table the graph runs on (SNP + SV + MOD): the packed observation word keeps the row in 22 bits */
+#define LPS_MAX_ROWS 0xfffffff   /* rows of the table the graph runs on (SNP + SV + MOD): a packed word holds node << 2 | flags; what really bounds a table is memory (560 B per row for the edge matrix) */
 static int fail(lps_ctx *c, const std::string &m, int code = -1) { if (c) c->err = m; return code; }
 
 // Large upload from pageable memory (an mmap of the BAM file): the runtime's own path stages through ONE host thread's memcpy; here four threads fill a
@@ -233,7 +233,7 @@ int lps_set_variants(lps_ctx *c, const lps_variant_table *t) {
     if (!c || !t) return -1;
     try {
         HIP_TRY(hipSetDevice(c->device));
-        if (t->n > LPS_MAX_ROWS) return fail(c, "variant table larger than 2^22 rows per chromosome");
+        if (t->n > LPS_MAX_ROWS) return fail(c, "variant table larger than 2^28 rows per chromosome");
         for (int64_t i = 1; i < t->n; ++i) if (t->pos[i] <= t->pos[i - 1]) return fail(c, "variant positions must be strictly increasing");
         c->nV = (int)t->n; c->last_pos = t->n ? t->pos[t->n - 1] : -1;
         c->h_vpos.assign(t->pos, t->pos + t->n); c->vpos_on_device_only = false;
@@ -268,7 +268,7 @@ int lps_set_variants_device(lps_ctx *c, const lps_variant_table *t) {
     if (!c || !t) return -1;
     try {
         HIP_TRY(hipSetDevice(c->device));
-        if (t->n > LPS_MAX_ROWS) return fail(c, "variant table larger than 2^22 rows per chromosome");
+        if (t->n > LPS_MAX_ROWS) return fail(c, "variant table larger than 2^28 rows per chromosome");
         if (t->hp1_is_alt || t->phase_set || t->somatic_role || t->derive_hp || t->tumor_kind) return fail(c, "lps_set_variants_device takes the phase columns only (pos, ref0, alt0, ref_len, alt_len)");
         if (t->n && (!t->pos || !t->ref0 || !t->alt0)) return fail(c, "lps_set_variants_device: pos / ref0 / alt0 missing");
         hipStream_t s = c->stream; const size_t n = (size_t)t->n;
@@ -307,7 +307,7 @@ int lps_set_extra_variants(lps_ctx *c, const lps_extra_variants *x) {
         if (c->nV == 0) return fail(c, "lps_set_variants must be called before lps_set_extra_variants");
         if (c->vpos_on_device_only) { c->h_vpos = download(c, c->v_pos.p, (size_t)c->nV); c->vpos_on_device_only = false; }   // the merge below runs on the host
         const int64_t nS = std::max<int64_t>(x->n_sv, 0), nM = std::max<int64_t>(x->n_mod, 0);
-        if ((int64_t)c->nV + nS + nM > LPS_MAX_ROWS) return fail(c, "SNP + SV + MOD rows exceed 2^22 per chromosome");
+        if ((int64_t)c->nV + nS + nM > LPS_MAX_ROWS) return fail(c, "SNP + SV + MOD rows exceed 2^28 per chromosome");
         if (x->sv_window < 0 || !(x->sv_threshold >= 0 && x->sv_threshold <= 1)) return fail(c, "invalid svWindow / svThreshold");     // Phasing.cpp:304-318
         for (int64_t i = 1; i < nS; ++i) if (x->sv_pos[i] <= x->sv_pos[i - 1]) return fail(c, "SV positions must be strictly increasing");
         for (int64_t i = 1; i < nM; ++i) if (x->mod_pos[i] <= x->mod_pos[i - 1]) return fail(c, "MOD positions must be strictly increasing");

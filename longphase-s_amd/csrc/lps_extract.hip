@@ -133,6 +133,12 @@ __device__ __forceinline__ void advance_of(const uint32_t (&w)[8], int k, int &s
     }
 }
 
+#ifdef EXT_PROFILE
+__device__ unsigned long long g_ext_prof[8];     // diagnostic build: s_memtime ticks per phase summed over the waves (plan, walk, bounds + count, passes, tail), jobs
+#define EXT_TICK(k) { const unsigned long long t_now = __builtin_readcyclecounter(); if (l == 0) atomicAdd(&g_ext_prof[k], t_now - t_last); t_last = t_now; }
+#else
+#define EXT_TICK(k)
+#endif
 // One wavefront = one job of four consecutive alignments, whose CIGARs lie back to back in memory.
 //   * WALK.  The CIGAR words of the job are ONE stream, taken 512 words per round, 8 consecutive words per lane, every lane busy whatever the
 //     alignments' lengths.  A lane sums the reference / query advance of its 8 words and one pair of DPP scans over the wave turns the sums into
@@ -161,6 +167,9 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
     __shared__ ExtHdr s_hdr[EXT_RPW];
     __shared__ ClipEv s_clip[EXT_CLIPS];
     const int l = lane_id();
+#ifdef EXT_PROFILE
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
     // Output rows are reserved on one of LPS_ARENAS counters (own cache line each).  Workgroups are dealt round-robin over the 8 XCDs, so
     // arena = blockIdx % 64 keeps each counter inside ONE XCD's L2.
     const int arena = blockIdx.x % O.n_arenas;
@@ -260,6 +269,7 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         }
         wave_sync();
 
+        EXT_TICK(0)
         // ---- walk
         int carry_r = 0, carry_q = 0, n_clip0 = n_clip; bool give_up = false;
 #pragma unroll 1
@@ -345,6 +355,7 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         }
         wave_sync();
 
+        EXT_TICK(1)
         // ---- where each alignment begins and ends in stream coordinates, the candidates of each: variants [v0, first variant at or beyond its end)
         int b_sat = 0, b_qat = 0, b_rend = h_start;
         if (h_walk) {
@@ -380,6 +391,7 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         const int step0 = maxnch > 1 ? 1 << (31 - __builtin_clz(maxnch - 1)) : 0;    // the steps step0, step0/2, .. 1 sum to >= maxnch - 1
         unsigned long long g0 = 0; ObsRec *dst = nullptr;
         int n_out = 0, n_emit[4] = {0, 0, 0, 0}; unsigned any_pre = 0;
+        EXT_TICK(2)
         uint2 pvr = V.rec[min(SELC(l, cum, vadj) + l, V.n - 1)];           // records are requested one round ahead
         // an observation is counted where it is made: what the counting atomic returns is its rank inside the variant's list of observations, kept
         // beside allele and quality - the node-major lists are filled later without a counting pass and without a second atomic.  The atomic's
@@ -511,6 +523,7 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
             to_redo();
             return;
         }
+        EXT_TICK(3)
         // rows of the group's alignments: back to back in the group's reservation
         if (h_in) {
             int before = 0, mine = 0;
@@ -533,6 +546,10 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         cb = __shfl(cb, 0);
         if (l < n_clip && cb + (unsigned)l < C.capacity) C.ev[cb + l] = s_clip[l];
     }
+    EXT_TICK(4)
+#ifdef EXT_PROFILE
+    if (l == 0) atomicAdd(&g_ext_prof[5], 1ull);
+#endif
 }
 
 #define REDO_CAP 512    // observations buffered per wave of the redo kernel
@@ -842,5 +859,10 @@ void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O,
     const int n_jobs = (R.n + EXT_RPW - 1) / EXT_RPW;
     hipLaunchKernelGGL(k_extract_phase, dim3(n_jobs), dim3(64), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo, var_cnt, var_del);
     // jobs the lane-chunk table could not hold queued themselves (an alignment of more than ~200 kb of CIGAR; none with ordinary read lengths): a small grid drains the queue
+#ifdef EXT_PROFILE
+    { static int calls = 0; unsigned long long h[8];
+      if (++calls == 8) { (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ext_prof), sizeof h);
+          fprintf(stderr, "[ext profile] %d calls, %llu jobs: ticks per job: plan %.0f walk %.0f bounds+count %.0f passes %.0f tail %.0f (s_memtime ticks at 100 MHz)\n", calls, h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5]); } }
+#endif
     hipLaunchKernelGGL(k_extract_redo, dim3(std::min(256, (n_jobs + 3) / 4)), dim3(256), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo, var_cnt, var_del);
 }

@@ -35,6 +35,21 @@ def test_cli_phase_matches_reference_vcf(name, inflate, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_phase_table_through_the_collective(tmp_path):
+    """The --gpus path of the table on the one-GPU box: rank 0's packed SNP table goes through lps_comm_bcast_to_device (a one-rank RCCL
+    communicator) and reaches the context as device pointers (lps_set_variants_device) - same VCF as the reference's."""
+    name = "tiny_indel"
+    bam = str(tmp_path / (name + ".bam"))
+    assert write_bam(os.path.join(DATA, name + ".sam.gz"), bam) > 0
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([CLI, "phase", "-s", os.path.join(DATA, name + ".vcf"), "-b", bam, "-r", os.path.join(DATA, name + ".fa"), "-o", prefix, "-t", "4"] + DATA_FIXTURES[name][1],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, LPS_CLI_BCAST_ALWAYS="1"))
+    assert r.returncode == 0, r.stderr
+    assert "SNP table broadcast" in r.stderr
+    assert _body(prefix + ".vcf") == _body(os.path.join(DATA, name + ".ref_phased.vcf"))
+
+
+@pytest.mark.gpu
 def test_cli_phase_deepsomatic_output(tmp_path):
     """--deepsomatic_output: <prefix>_preprocessed.vcf and the phased VCF written from it equal the reference's."""
     import gzip

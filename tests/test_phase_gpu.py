@@ -113,6 +113,45 @@ def test_nodes_with_more_than_64_reads():
         ctx.close()
 
 
+def test_table_of_more_than_2p22_rows():
+    """A variant table beyond the 4 194 303 rows the first versions could address (the hit word kept the row in 22 bits; the reference's std::map
+    has no limit, src/phase/ParsingBam.h:165-185): 4.3 M more rows behind the region the reads cover.  Result == oracle."""
+    import lps_oracle
+    from lps import abi, hip
+    from lps.synth import Synth
+    s = Synth(seed=83, contig_len=300_000, n_snp=350, coverage=14.0, n_threads=2)
+    extra = 4_300_000
+    pos = np.concatenate([np.asarray(s.var_pos, np.int32), (300_010 + 3 * np.arange(extra)).astype(np.int32)])
+    ref = np.concatenate([np.asarray(s.ref, np.uint8), np.full(3 * extra + 64, ord("A"), np.uint8)])
+    V = abi.Variants(pos, list(s.var_ref) + [b"A"] * extra, list(s.var_alt) + [b"C"] * extra)
+    assert V.n > (1 << 22)
+    R = abi.Reads.from_synth(s)
+    P = abi.default_params()
+    with hip.Context(0, P) as ctx:
+        out = ctx.phase(V, ref, R)
+    want, _ = lps_oracle.phase(P, V, ref, R)
+    util.assert_phase_equal(out.phase_set, out.gt, want.phase_set, want.gt, "4.3 M-row table vs oracle")
+    assert int((out.phase_set != 0).sum()) > 300
+
+
+def test_observations_of_one_variant_beyond_the_old_16_bit_rank():
+    """More than 65 536 alignments over one variant (ultra-deep amplicon data): the rank of an observation inside its variant's list was a 16-bit
+    field once (k_graph_obs raised LPS_ERR_KEY_RANGE); it has 22 bits now and the limit has its own message.  84 000 short reads over 7 SNPs."""
+    import lps_oracle
+    from lps import abi, hip
+    from lps.synth import Synth
+    s = Synth(seed=84, contig_len=3_000, n_snp=6, coverage=75000.0, len_median=2000.0, len_min=1800, len_max=2600, n_threads=4, clip_every=7)
+    assert s.n_reads > 80_000
+    V = abi.Variants(s.var_pos, s.var_ref, s.var_alt); R = abi.Reads.from_synth(s)
+    P = abi.default_params()
+    with hip.Context(0, P) as ctx:
+        out = ctx.phase(V, s.ref, R)
+        cnt, var, al, q = ctx.dump_observations()
+        assert np.bincount(var).max() > 65_536
+    want, _ = lps_oracle.phase(P, V, s.ref, R)
+    util.assert_phase_equal(out.phase_set, out.gt, want.phase_set, want.gt, "81 000 observations of one variant vs oracle")
+
+
 def test_unsupported_cigar_op_is_an_error():
     """The reference prints "alignment find unsupported CIGAR operation" and exits (ParsingBam.cpp:1625-1628); the library returns an error
     with that message.  An op code above 8 in an alignment that is filtered out (MAPQ 0) is never looked at, as in the reference."""
