@@ -103,26 +103,6 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 #endif
 #define EXT_CLIPS 16    // clip events buffered per wave
 
-// first variant with pos >= key, searched by ONE lane (the planning step runs four of these side by side); == var_lower_bound
-__device__ __forceinline__ int lane_var_lower_bound(const VarView &V, int key) {
-    if (key < 0) return 0;
-    const int b = key >> LPS_BUCKET_SHIFT;
-    int lo, hi;
-    if (b >= V.n_bucket) { lo = V.bucket[V.n_bucket]; hi = V.n; } else { lo = V.bucket[b]; hi = V.bucket[b + 1]; }
-    while (lo < hi) { const int m = (lo + hi) >> 1; if (V.pos[m] < key) lo = m + 1; else hi = m; }
-    return lo;
-}
-
-// what a candidate lane needs to know about its alignment: three 16-byte LDS reads
-struct __attribute__((aligned(16))) ExtHdr {
-    int crel, ncig, c0, nch;               // first CIGAR word (relative to the job's first), CIGAR words, first chunk in the table, chunks it touches
-    int vadj, lq, ds, dq;                  // variant of flattened candidate i = vadj + i; l_qseq; stream - true reference coordinate; stream query coordinate of the read's first base
-    unsigned blk0, pad0, pad1, pad2;       // first block of the read's interleaved bases + qualities (lps_reads.hip)
-};
-
-// the c-th of four wave-uniform scalars, c = index of the first flattened candidate of alignments 1..3 (per-lane compare against thresholds)
-#define SELC(c, t, a) ((c) >= (t)[3] ? (a)[3] : ((c) >= (t)[2] ? (a)[2] : ((c) >= (t)[1] ? (a)[1] : (a)[0])))
-#define SEL4(q, a) ((q) >= 3 ? (a)[3] : ((q) >= 2 ? (a)[2] : ((q) >= 1 ? (a)[1] : (a)[0])))
 // reference / query bases consumed by the first k (wave-uniform, 0..8) of a lane's 8 words
 __device__ __forceinline__ void advance_of(const uint32_t (&w)[8], int k, int &sr, int &sq) {
     sr = 0; sq = 0;

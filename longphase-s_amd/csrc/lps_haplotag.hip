@@ -256,9 +256,289 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
     }
 }
 
+// ---- germline haplotag as a STREAM walk (the extraction's design, lps_extract.hip): a wave takes FOUR consecutive alignments, their CIGAR words
+// are one stream taken 512 words per round (8 per lane), one pair of DPP scans gives every lane-chunk its stream coordinates (8 bytes to LDS), and
+// when the words are through the phased variants under the four alignments are taken 64 at a time as one flattened list, every lane busy:
+// chunk search, the chunk's words, an 8-step walk to the op that covers the variant, judgeSnpHap / judgeDeletionHap (HaplotagStrategy.cpp:20-209),
+// votes and phase sets reduced per alignment with ballots.  judgeReadHap (:243-300) follows right there and the four 16-byte records of the job
+// leave as ONE 64-byte line.  A third of the vector instructions of k_haplotag_score<0>, which it replaces for the germline pass.
+#ifndef HTG_TAB
+#define HTG_TAB 1024
+#endif
+__global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary, LpsCounters *cnt) {
+    __shared__ __attribute__((aligned(16))) int2 s_tab[HTG_TAB];
+    __shared__ ExtHdr s_hdr[4];
+    const int l = lane_id();
+    const int r0 = xcd_unit((int)blockIdx.x, (int)gridDim.x) * 4;        // XCD-aware: neighbouring jobs write neighbouring result lines into one L2
+    if (r0 >= R.n) return;
+    const int nq = min(4, R.n - r0);
+    // ---- plan: headers, alignment q in lane q; the filter cascade of processSingleChrom (HaplotagParsingBam.cpp:453-486)
+    int h_start = 0, h_lq = 0, h_status = 0; unsigned long long h_coff = 0, h_soff = 0;
+    if (l <= nq) h_coff = R.cigar_off[r0 + l];
+    if (l < nq) {
+        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r];
+        const int flag = R.flag[r];
+        if (R.mapq[r] < mapping_quality) h_status = 1;
+        else if (flag & 0x4) h_status = 2;
+        else if (flag & 0x100) h_status = 3;
+        else if ((flag & 0x800) && !tag_supplementary) h_status = 4;
+        else if (V.n == 0) h_status = 5;
+        else if (!(h_start <= V.last_pos)) h_status = 6;
+    }
+    const bool h_live = l < nq && h_status == 0;
+    const unsigned live_mask = (unsigned)__ballot(h_live) & 15u;
+    const int h_ncig_all = (int)(long long)(__shfl_down(h_coff, 1) - h_coff);   // (lanes < nq)
+    int h_v0 = 0; bool have_v0 = false;
+    int vh1[4] = {0, 0, 0, 0}, vh2[4] = {0, 0, 0, 0}, plo[4], phi[4];      // per alignment: votes, smallest / largest phase set seen (wave-uniform)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { plo[q] = 0x7fffffff; phi[q] = (int)0x80000000; }
+    unsigned todo = live_mask;
+#pragma unroll 1
+    while (todo) {
+        // ---- the job's alignments in groups whose CIGAR words fit the table together (nearly always one group of four); an alignment that alone
+        //      does not fit is walked with one table entry per 8 << shift words (see k_extract_phase)
+        const int qa = __builtin_ctz(todo);
+        const unsigned long long c_lo = __shfl(h_coff, qa);
+        int qb = qa; unsigned gm = 1u << qa;
+        for (int q = qa + 1; q < nq; ++q) {
+            if (!((todo >> q) & 1u)) continue;
+            const long long span = (long long)(__shfl(h_coff, q + 1) - c_lo);
+            if (((span + 7) >> 3) > HTG_TAB) break;
+            gm |= 1u << q; qb = q;
+        }
+        todo &= ~gm;
+        int shift = 0;
+        { const long long w1 = (long long)(__shfl(h_coff, qa + 1) - c_lo); while ((((w1 + 7) >> 3) + ((1ll << shift) - 1)) >> shift > HTG_TAB) ++shift; }
+        const bool fast = shift == 0;
+        const bool h_in = l < 4 && ((gm >> l) & 1u);
+        const int h_rel = (l <= nq) ? (int)(long long)(h_coff - c_lo) : 0;
+        const int h_ncig = h_ncig_all;
+        const uint32_t *cg = R.cigar + c_lo;
+        const int total = __builtin_amdgcn_readlane(h_rel + h_ncig, qb);
+        const int TC = (total + 7) >> 3;
+        auto request = [&](int cid, uint32_t (&w)[8]) __attribute__((always_inline)) {          // unconditional, clamped (see k_extract_phase)
+            const uint32_t *p = cg + 8 * min(cid, max(TC - 1, 0));
+            const LpsU4 a = *reinterpret_cast<const LpsU4 *>(p), b = *reinterpret_cast<const LpsU4 *>(p + 4);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        };
+        uint32_t pw[8];
+        request(l, pw);
+        if (!have_v0) { if (l < 4 && h_live) h_v0 = lane_var_lower_bound(V, h_start); have_v0 = true; }
+        const bool h_walk = h_in && h_ncig > 0;
+        const int x_end = h_rel + h_ncig - 1;
+        const int cs = (h_walk && fast) ? h_rel >> 3 : 0, ce = (h_walk && fast) ? x_end >> 3 : 0;
+        int adv_r = 0, adv_q = 0, end_r = 0;
+        {
+            const int ks = h_rel & 7, ke = (x_end & 7) + 1;
+            const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs), b = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs + 4);
+            const LpsU4 c = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce), d = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce + 4);
+            const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, we[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const unsigned t1 = op_consume_bits(ws[m] & 15u), t2 = op_consume_bits(we[m] & 15u);
+                const int l1 = m < ks ? (int)(ws[m] >> 4) : 0, l2 = m < ke ? (int)(we[m] >> 4) : 0;
+                adv_r += l1 & bit_mask(t1, 0); adv_q += l1 & bit_mask(t1, 16); end_r += l2 & bit_mask(t2, 0);
+            }
+        }
+        int v0q[4], pp[4]; bool walkq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v0q[q] = __builtin_amdgcn_readlane(h_v0, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; pp[q] = V.n ? V.pos[min(v0q[q] + l, V.n - 1)] : 0x7fffffff; }
+        if (l < 4) {
+            ExtHdr &h = s_hdr[l];
+            h.crel = h_rel; h.ncig = h_walk ? h_ncig : 0; h.c0 = cs; h.nch = h_walk ? (fast ? ce - cs + 1 : (((h_ncig + 7) >> 3) + (1 << shift) - 1) >> shift) : 0;
+            h.lq = h_lq; h.blk0 = (unsigned)h_soff; h.pad0 = (unsigned)(h_soff >> 32);
+        }
+        wave_sync();
+        // ---- walk
+        int carry_r = 0, carry_q = 0; bool absurd = false;
+#pragma unroll 1
+        for (int R0 = 0; R0 < TC; R0 += 64) {
+            const int cid = R0 + l;
+            uint32_t w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = pw[k];
+            request(cid + 64, pw);
+            if (R0 + 64 >= TC) {
+                const int nv = total - 8 * cid;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) w[k] = k < nv ? w[k] : 6u;
+            }
+            int rt = 0, qt = 0; unsigned seen = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned op = w[k] & 15u;
+                const unsigned t = op_consume_bits(op); const int len = (int)(w[k] >> 4);
+                rt += len & bit_mask(t, 0); qt += len & bit_mask(t, 16);
+                seen |= 1u << op;
+            }
+            const int ir = wave_incl_scan_dpp(rt), iq = wave_incl_scan_dpp(qt);
+            const int my_s = carry_r + ir - rt, my_q = carry_q + iq - qt;
+            if (fast) { if (cid < TC) s_tab[cid] = make_int2(my_s, my_q); }
+            else if (cid < TC && (cid & ((1 << shift) - 1)) == 0) s_tab[cid >> shift] = make_int2(my_s, my_q);
+            carry_r += __builtin_amdgcn_readlane(ir, 63); carry_q += __builtin_amdgcn_readlane(iq, 63);
+            if ((unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu) { absurd = true; break; }
+            if (__ballot((seen & LPS_OPS_BAD) != 0u)) {                   // an op code the reference rejects, in an alignment that is walked (rare path)
+                bool bad = false;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int x = 8 * cid + k; bool inq = false;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) inq |= x >= s_hdr[q].crel && x < s_hdr[q].crel + s_hdr[q].ncig;
+                    bad |= inq && (w[k] & 15u) > 8u;
+                }
+                if (__ballot(bad) && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
+            }
+        }
+        if (absurd) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); break; }   // stream coordinates beyond 2^30: reference spans no aligner produces
+        wave_sync();
+        // ---- alignment bounds in stream coordinates, candidates of each: phased variants [v0, first variant at or beyond its reference end)
+        int b_sat = 0, b_qat = 0, b_rend = h_start;
+        if (h_walk) {
+            if (fast) { const int2 ts = s_tab[cs], te = s_tab[ce]; b_sat = ts.x + adv_r; b_qat = ts.y + adv_q; b_rend = h_start + te.x + end_r - b_sat; }
+            else b_rend = h_start + carry_r;
+        }
+        int ncand[4], rend[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rend[q] = __builtin_amdgcn_readlane(b_rend, q);
+            int n = __popcll(__ballot(walkq[q] && v0q[q] + l < V.n && pp[q] < rend[q]));
+            if (n == 64) {
+                for (;;) { int p2 = 0x7fffffff; if (v0q[q] + n + l < V.n) p2 = V.pos[v0q[q] + n + l]; const int m = __popcll(__ballot(p2 < rend[q])); n += m; if (m < 64) break; }
+            }
+            ncand[q] = n;
+        }
+        int cum[5]; cum[0] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cum[q + 1] = cum[q] + ncand[q];
+        const int T = cum[4];
+        int vadj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vadj[q] = v0q[q] - cum[q];
+        if (l < 4) { ExtHdr &h = s_hdr[l]; h.vadj = SEL4(l, vadj); h.ds = b_sat - h_start; h.dq = b_qat; }
+        int maxnch = l < 4 ? s_hdr[l].nch : 0;
+        maxnch = max(max(__builtin_amdgcn_readlane(maxnch, 0), __builtin_amdgcn_readlane(maxnch, 1)), max(__builtin_amdgcn_readlane(maxnch, 2), __builtin_amdgcn_readlane(maxnch, 3)));
+        wave_sync();
+        const int step0 = maxnch > 1 ? 1 << (31 - __builtin_clz(maxnch - 1)) : 0;
+        uint2 pvr = V.n ? V.rec[min(SELC(l, cum, vadj) + l, V.n - 1)] : make_uint2(0u, 0u);
+#pragma unroll 1
+        for (int i0 = 0; i0 < T; i0 += 64) {
+            const int i = i0 + l;
+            const bool in = i < T;
+            int vote = -1, ps_v = 0; bool count_ps = false, hp1alt = false;
+            const uint2 vr = pvr;
+            pvr = V.rec[min(SELC(i + 64, cum, vadj) + i + 64, V.n - 1)];
+            if (in) {
+                const int q = (i >= cum[1]) + (i >= cum[2]) + (i >= cum[3]);
+                const int4 ha = *reinterpret_cast<const int4 *>(&s_hdr[q].crel), hb = *reinterpret_cast<const int4 *>(&s_hdr[q].vadj);
+                const int hcrel = ha.x, hncig = ha.y, hc0 = ha.z, hnch = ha.w, hlq = hb.y;
+                const int v = hb.x + i;
+                const int p = (int)vr.x; const unsigned at = vr.y;
+                hp1alt = (at & VREC_HP1ALT) != 0;
+                const int ps = p + hb.z;
+                int co = 0;
+                for (int step = step0; step >= 1; step >>= 1) { const int t = co + step; const int sv = s_tab[hc0 + min(t, hnch - 1)].x; co = (t < hnch && sv <= ps) ? t : co; }
+                const int2 base = s_tab[hc0 + co];
+                const int x0 = (8 * (hc0 + co)) << shift;
+                int rr = base.x, qq = base.y, jx = x0, rs = base.x, qs = base.y; uint32_t wj = 6u, wn = 6u;
+                auto walk8 = [&](const uint32_t (&w)[9], int xb) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool le = rr <= ps;
+                        jx = le ? xb + k : jx; rs = le ? rr : rs; qs = le ? qq : qs; wj = le ? w[k] : wj; wn = le ? w[k + 1] : wn;
+                        const unsigned t = op_consume_bits(w[k] & 15u); const int len = (int)(w[k] >> 4);
+                        rr += len & bit_mask(t, 0); qq += len & bit_mask(t, 16);
+                    }
+                };
+                for (int u = 0; u < (1 << shift); ++u) {                  // (one trip unless the alignment is walked in LONG mode)
+                    const uint32_t *cw = cg + x0 + 8 * u;
+                    uint32_t w[9];
+                    const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cw), b = *reinterpret_cast<const LpsU4 *>(cw + 4);
+                    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = cw[8];
+                    walk8(w, x0 + 8 * u);
+                    if (rr > ps || x0 + 8 * u + 8 >= hcrel + hncig) break;
+                }
+                const int op = wj & 15, len = (int)(wj >> 4);
+                const int opi = jx - hcrel;
+                qs -= hb.w;
+                if (ps < rs + len) {
+                    const unsigned kind = VREC_KIND(at);
+                    const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
+                    const uint8_t *seq = R.seq + ((unsigned long long)s_hdr[q].blk0 | ((unsigned long long)s_hdr[q].pad0 << 32));
+                    if (op_is_match(op)) {                                        // judgeSnpHap (:20-130)
+                        if (kind == 0) {
+                            const int qi = qs + (ps - rs);
+                            const char base_c = qi < hlq ? nt16_char(seq[qi >> 1] >> ((~qi & 1) << 2)) : 'N';
+                            if (base_c == ref_c) vote = 0; else if (base_c == alt_c) vote = 1;
+                            count_ps = vote >= 0;
+                        } else if ((kind == 1 || kind == 2) && opi + 1 < hncig) {
+                            const int want = (kind == 1) ? 1 : 2;
+                            const bool has = (rs + len - 1 == ps) && (int)(wn & 15u) == want;
+                            vote = (kind == 1) ? (has ? 1 : 0) : (has ? 0 : 1);   // insertion: the read's allele; deletion: the reference votes for the LONG allele (:98-129)
+                            count_ps = true;
+                        }
+                    } else if (op == 2) {                                         // judgeDeletionHap (:147-209), once per D op
+                        const bool first_in = (v == 0) || V.pos[v - 1] + hb.z < rs;
+                        if (first_in && (at & VREC_HPOLY3)) {
+                            if (kind == 0) {
+                                const char base_c = qs < hlq ? nt16_char(seq[qs >> 1] >> ((~qs & 1) << 2)) : 'N';
+                                if (base_c == ref_c) vote = 0; else if (base_c == alt_c) vote = 1;
+                                count_ps = true;
+                            } else if (kind == 2) { vote = 0; count_ps = true; }
+                        }
+                    }
+                    if (count_ps) ps_v = V.phase_set[v];
+                }
+            }
+            // ---- per alignment: votes by ballot; the phase-set range by two masked reductions, taken only when the alignment's variants do not all
+            //      carry ONE phase set (they nearly always do: blocks are long)
+            const bool to1 = vote >= 0 && ((vote == 1) == hp1alt), to2 = vote >= 0 && !((vote == 1) == hp1alt);
+            const unsigned long long m1 = __ballot(to1), m2 = __ballot(to2), mp = __ballot(count_ps);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int a = max(cum[k] - i0, 0), b = min(cum[k + 1] - i0, 64);
+                if (b > a) {
+                    const unsigned long long rm = ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << a) - 1ull);
+                    vh1[k] += __popcll(m1 & rm); vh2[k] += __popcll(m2 & rm);
+                    const unsigned long long pk = mp & rm;
+                    if (pk) {
+                        const int first = __builtin_amdgcn_readlane(ps_v, __builtin_ctzll(pk));
+                        if (__ballot(count_ps && ps_v != first) & rm) {
+                            const bool mine = (pk >> l) & 1ull;
+                            plo[k] = min(plo[k], wave_min(mine ? ps_v : 0x7fffffff)); phi[k] = max(phi[k], wave_max(mine ? ps_v : (int)0x80000000));
+                        } else { plo[k] = min(plo[k], first); phi[k] = max(phi[k], first); }
+                    }
+                }
+            }
+        }
+        wave_sync();                                                      // the table and the headers are reused by the next group
+    }
+    // ---- judgeReadHap (:243-300) for the four alignments, one lane each; ONE 64-byte line of results per job
+    if (l < nq) {
+        const int r = r0 + l;
+        const int h1 = SEL4(l, vh1), h2 = SEL4(l, vh2), lo = SEL4(l, plo), hi = SEL4(l, phi);
+        const bool any = lo <= hi; const unsigned nps = any ? (lo == hi ? 1u : 2u) : 0u;
+        int a = h1, b = h2; unsigned hp = 0, pq = 0;
+        if (h_status == 0) {
+            if (H.votes1) { a += H.votes1[r]; b += H.votes2[r]; }                 // judgeSVHap (:220-226): after the CIGAR walk, before the decision
+            double mn, mx;
+            if (a > b) { mn = b; mx = a; } else { mn = a; mx = b; }
+            if (!(mx / (mx + mn) < H.pct_thr)) { if (a > b) hp = 1; if (a < b) hp = 2; }
+            if (mx == 0) pq = 0; else if (mn == 0) pq = 40;
+            else if (a >= 0 && b >= 0 && a < 64 && b < 64) pq = (unsigned)H.pq_tab[(a < b ? a : b) * 64 + (a < b ? b : a)];
+            else pq = 255;
+            if (nps > 1) hp = 0;
+        }
+        H.rec[r] = make_uint4((unsigned)h_status | (nps << 8) | (hp << 16) | (pq << 24), (unsigned)a, (unsigned)b, (unsigned)(any ? lo : 0));
+    }
+}
+
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
                      int mode, LpsCounters *cnt, hipStream_t s) {
     if (R.n == 0) return;
+    if (mode == 0 && H.rec) {                                             // germline haplotag: the stream walk, four alignments per wave
+        hipLaunchKernelGGL(k_haplotag_stream, dim3(round_up8((R.n + 3) / 4)), dim3(64), 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
+        return;
+    }
     const dim3 g(round_up8((R.n + HAP_WPB - 1) / HAP_WPB)), b(64 * HAP_WPB);   // a multiple of 8: the XCD-aware unit mapping
     if (mode == 1) hipLaunchKernelGGL(k_haplotag_score<1>, g, b, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
     else if (mode == 2) hipLaunchKernelGGL(k_haplotag_score<2>, g, b, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
