@@ -49,7 +49,7 @@ struct lps_ctx {
     int nR = 0; uint64_t n_cig = 0, n_seq = 0, n_qual = 0;
     DevBuf<int32_t> r_start, r_lq; DevBuf<uint16_t> r_flag; DevBuf<uint8_t> r_mapq; DevBuf<uint32_t> r_name;
     DevBuf<uint64_t> r_coff, r_soff, r_qoff; DevBuf<uint32_t> cigar; DevBuf<uint8_t> seq, qual;
-    DevBuf<uint8_t> sq; DevBuf<uint32_t> r_sqblk, sq_cnt; int sq_reads = -1; float sq_ms = 0;   // bases + qualities interleaved per 128-byte line (lps_reads.hip); sq_reads: alignments it covers (-1: not built)
+    DevBuf<uint8_t> sq; DevBuf<uint32_t> r_sqblk, sq_cnt; DevBuf<int32_t> r_v0; int sq_reads = -1; float sq_ms = 0;   // bases + qualities interleaved per 128-byte line (lps_reads.hip); sq_reads: alignments it covers (-1: not built)
     // raw BAM records (lps_push_bam_records): seq/qual are read in place from the blob
     DevBuf<uint8_t> blob; uint64_t n_blob = 0; int read_mode = 0;   // 0 none yet, 1 SoA batches, 2 BAM records
     DevBuf<uint64_t> rec_off, cig_src; DevBuf<unsigned long long> cig_cnt; DevBuf<unsigned> bam_err;
@@ -868,7 +868,7 @@ static ReadView read_view(lps_ctx *c) {
     R.n = c->nR; R.ref_start = c->r_start.p; R.l_qseq = c->r_lq.p; R.flag = c->r_flag.p; R.mapq = c->r_mapq.p; R.name_id = c->r_name.p;
     R.cigar_off = c->r_coff.p; R.seq_off = c->r_soff.p; R.qual_off = c->r_qoff.p; R.cigar = c->cigar.p;
     if (c->read_mode == 2) R.seq = R.qual = c->blob.p; else if (c->read_mode == 3) R.seq = R.qual = c->file.p; else { R.seq = c->seq.p; R.qual = c->qual.p; }
-    R.sq = c->sq.p; R.sq_blk = c->r_sqblk.p;
+    R.sq = c->sq.p; R.sq_blk = c->r_sqblk.p; R.v0 = c->r_v0.p;
     return R;
 }
 
@@ -978,6 +978,7 @@ static int run_phase(lps_ctx *c) {
         // ---- a4/a5/a6 variant table prep
         c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8);
         c->v_rec.reserve((size_t)nV + 1);
+        c->r_v0.reserve((size_t)nR + 1);
         VarView V = var_view(c); ReadView R = read_view(c);
         mark(c, ST_PREP);
         launch_variant_prep(V, P.is_ont, c->v_bucket.p, c->v_rec.p, s);
@@ -990,7 +991,16 @@ static int run_phase(lps_ctx *c) {
         ObsView O{c->rows.p, c->obs.p, arena_size, c->arena_ctr.p, n_arenas};
         ClipView C{c->clip_ev.p, c->clip_stats.p, (unsigned)c->clip_capacity};            // clip_stats[0]: events appended, [1]: jobs queued for k_extract_redo (zero pool)
         mark(c, ST_EXTRACT);
+        launch_read_v0(V, R, c->r_v0.p, s);
         launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, c->redo_list.p, c->clip_stats.p + 1, c->nX ? nullptr : c->var_cnt.p, c->var_del.p, s);
+        {   // diagnostic (profiles/extract_only.py: timing experiments on builds whose extraction is incomplete on purpose): stop here, rc 77
+            static const bool extract_only = getenv("LPS_EXTRACT_ONLY") != nullptr;
+            if (extract_only) {
+                HIP_TRY(hipEventRecord(c->ev_end, s)); HIP_TRY(hipStreamSynchronize(s));
+                float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[ST_EXTRACT], c->ev_end)); c->tm.ms_kernel[ST_EXTRACT] = ms;
+                return 77;
+            }
+        }
         // ---- SV / MOD rows: served against each alignment's CIGAR, merged into its row; every observation leaves in union indices
         if (c->nX) {
             ExtraView X{c->nX, c->x_pos.p, c->x_info.p, c->x_kind.p, c->x_u.p, c->x_snp_u.p, c->x_moff.p, c->x_mname.p, c->x_mflag.p, c->sv_window, c->sv_threshold};
@@ -1249,7 +1259,7 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
         if (span + 1024 > c->h_res_bytes) { if (c->h_res) HIP_TRY(hipHostFree(c->h_res)); c->h_res = nullptr; c->h_res_bytes = span + span / 4 + 4096; HIP_TRY(hipHostMalloc((void **)&c->h_res, c->h_res_bytes)); }
         if (!c->pq_ready) { c->pq_tab.reserve(64 * 64); HIP_TRY(hipMemcpyAsync(c->pq_tab.p, &pq_small_table().v[0][0], 64 * 64 * sizeof(int), hipMemcpyHostToDevice, s)); c->pq_ready = true; }
         if (votes) { upload(c, c->d_votes1, c->votes_h1.data(), (size_t)nR); upload(c, c->d_votes2, c->votes_h2.data(), (size_t)nR); }
-        c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1);
+        c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1); c->r_v0.reserve((size_t)nR + 1);
         HIP_TRY(hipEventRecord(c->ev_begin, s));
         HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
         VarView V = var_view(c); ReadView R = read_view(c);
@@ -1257,6 +1267,7 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
         mark(c, ST_PREP);
         launch_variant_prep(V, /*is_ont (filterSNP is a `phase` step)*/ 0, c->v_bucket.p, c->v_rec.p, s);
         mark(c, ST_EXTRACT);
+        launch_read_v0(V, R, c->r_v0.p, s);
         HapOut H{};
         H.pct_thr = c->P.percentage_threshold; H.rec = c->hap_rec.p; H.pq_tab = c->pq_tab.p; H.votes1 = votes ? c->d_votes1.p : nullptr; H.votes2 = votes ? c->d_votes2.p : nullptr;
         launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 0, c->d_cnt, s);

@@ -101,6 +101,12 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 #ifndef EXT_GROUP_MAX
 #define EXT_GROUP_MAX 4 // alignments walked together (their candidates are resolved together once their words are through)
 #endif
+#ifndef EXT_ABL
+#define EXT_ABL 0       // timing experiments: 1 no counting atomic, 2 no base / quality fetch, 3 no record stores, 4 no second (rank) store
+#endif
+#ifndef EXT_NC
+#define EXT_NC 1        // candidates per lane and round of the resolve loop
+#endif
 #define EXT_CLIPS 16    // clip events buffered per wave
 
 // reference / query bases consumed by the first k (wave-uniform, 0..8) of a lane's 8 words
@@ -159,13 +165,14 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
     if (r0 >= R.n) return;
     const int nq = min(EXT_RPW, R.n - r0);
     static_assert(EXT_RPW == 4, "lane layout of the planning step");
-    auto to_redo = [&]() __attribute__((always_inline)) { if (l == 0) redo_list[atomicAdd(n_redo, 1u)] = (uint32_t)job; };
+    bool bad_cigar = false;                                            // an op code the reference rejects was seen in an alignment that is walked
+    auto to_redo = [&]() __attribute__((always_inline)) { if (l == 0) { redo_list[atomicAdd(n_redo, 1u)] = (uint32_t)job; if (bad_cigar) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR); } };
 
     // ---- plan: headers, alignment q in lane q.  direct_detect_alleles filters (:1282-1291) + region "chr:1-<lastSNPPos>" (:1273)
-    int h_start = 0, h_lq = 0; bool h_live = false; unsigned long long h_coff = 0; unsigned h_blk = 0;
+    int h_start = 0, h_lq = 0, h_v0 = 0; bool h_live = false; unsigned long long h_coff = 0; unsigned h_blk = 0;
     if (l <= nq) h_coff = R.cigar_off[r0 + l];
     if (l < nq) {
-        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_blk = R.sq_blk[r];
+        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_blk = R.sq_blk[r]; h_v0 = V.n ? R.v0[r] : 0;
         const int flag = R.flag[r];
         h_live = !(R.mapq[r] < mapping_quality || (flag & 0x4) || (flag & 0x100) || (flag & 0x400) || h_start >= V.last_pos);
     }
@@ -175,7 +182,6 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         return;
     }
     const int h_ncig_all = (int)(long long)(__shfl_down(h_coff, 1) - h_coff);   // (lanes < nq)
-    int h_v0 = 0; bool have_v0 = false;
     // what lane q collects for row q; clip events of the job (reference coordinates)
     unsigned row_off = 0; int row_cnt = 0; unsigned row_flags = 0;
     int n_clip = 0; bool fail = false, arena_full = false;
@@ -207,7 +213,11 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         const int h_ncig = h_ncig_all;
         const uint32_t *cg = R.cigar + c_lo;
         const int total = __builtin_amdgcn_readlane(h_rel + h_ncig, qb);  // words of the stream
+#if EXT_ABL == 6
+        const int TC = 0;
+#else
         const int TC = (total + 7) >> 3;                                  // lane-chunks
+#endif
         // UNCONDITIONAL loads, clamped to the stream (a load under a branch makes the compiler wait for every outstanding load where the paths join,
         // i.e. for the request just made).  A lane's 8 words may run past the stream's end (DevBuf allocations carry 64 B of slack): the last round
         // blanks those
@@ -216,32 +226,14 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
             const LpsU4 a = *reinterpret_cast<const LpsU4 *>(p), b = *reinterpret_cast<const LpsU4 *>(p + 4);
             w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
         };
-        uint32_t pw[8];
-        request(l, pw);                                                   // round 0 is on its way
+        uint32_t wa[8], wb[8];                                            // two buffers taken in turn: the round being summed and the one in flight
+        request(l, wa);                                                   // round 0 is on its way
         // first candidate of each alignment: four lanes search the position-sorted table side by side (a chain of dependent loads: behind round 0's request)
-        if (!have_v0) { if (l < 4 && h_live) h_v0 = lane_var_lower_bound(V, h_start); have_v0 = true; }
         const bool h_walk = h_in && h_ncig > 0;
         // where an alignment begins and ends INSIDE its first / last lane-chunk: lane q sums the words in front of the first and up to the last
         // word of alignment q now, while the walk's first round is in flight (the chunks' own coordinates come out of the walk)
         const int x_end = h_rel + h_ncig - 1;
         const int cs = (h_walk && fast) ? h_rel >> 3 : 0, ce = (h_walk && fast) ? x_end >> 3 : 0;
-        int adv_r = 0, adv_q = 0, end_r = 0;
-        {
-            const int ks = h_rel & 7, ke = (x_end & 7) + 1;
-            const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs), b = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs + 4);
-            const LpsU4 c = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce), d = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce + 4);
-            const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, we[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const unsigned t1 = op_consume_bits(ws[m] & 15u), t2 = op_consume_bits(we[m] & 15u);
-                const int l1 = m < ks ? (int)(ws[m] >> 4) : 0, l2 = m < ke ? (int)(we[m] >> 4) : 0;
-                adv_r += l1 & bit_mask(t1, 0); adv_q += l1 & bit_mask(t1, 16); end_r += l2 & bit_mask(t2, 0);
-            }
-        }
-        // ... and the positions of each alignment's first 64 candidate variants (counted against its reference end after the walk)
-        int v0q[4], pp[4]; bool walkq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v0q[q] = __builtin_amdgcn_readlane(h_v0, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; pp[q] = V.pos[min(v0q[q] + l, V.n - 1)]; }
         if (l < 4) {                                                      // (first half of the header: what the rare paths of the walk look at)
             ExtHdr &h = s_hdr[l];
             h.crel = h_rel; h.ncig = h_walk ? h_ncig : 0; h.c0 = cs; h.nch = h_walk ? (fast ? ce - cs + 1 : (((h_ncig + 7) >> 3) + (1 << shift) - 1) >> shift) : 0;
@@ -252,13 +244,14 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         EXT_TICK(0)
         // ---- walk
         int carry_r = 0, carry_q = 0, n_clip0 = n_clip; bool give_up = false;
-#pragma unroll 1
-        for (int R0 = 0; R0 < TC; R0 += 64) {
+        // one round of the walk over the words in `win`; false: the job gives up (give_up is set).  The loop below hands it the two buffers in turn
+        // and requests into the OTHER one first: a buffer is never copied while its load is in flight (the compiler places such a copy at the end
+        // of the iteration that issued the load and waits for the load there - the prefetch then overlaps nothing; seen in the ISA, cost 2/3 of the kernel)
+        auto walk_round = [&](const uint32_t (&win)[8], const int R0) __attribute__((always_inline)) -> bool {
             const int cid = R0 + l;
             uint32_t w[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) w[k] = pw[k];
-            request(cid + 64, pw);
+            for (int k = 0; k < 8; ++k) w[k] = win[k];
             if (R0 + 64 >= TC) {                                          // last round: words past the stream's end count for nothing (6u: op P, length 0)
                 const int nv = total - 8 * cid;
 #pragma unroll
@@ -272,7 +265,11 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
                 rt += len & bit_mask(t, 0); qt += len & bit_mask(t, 16);
                 seen |= 1u << op;
             }
+#if EXT_ABL == 7
+            const int ir = rt, iq = qt;
+#else
             const int ir = wave_incl_scan_dpp(rt), iq = wave_incl_scan_dpp(qt);
+#endif
             const int my_s = carry_r + ir - rt, my_q = carry_q + iq - qt; // stream coordinates of the lane's first word
             if (fast) {
                 if (cid < TC) {
@@ -281,7 +278,7 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
                 }
             } else if (cid < TC && (cid & ((1 << shift) - 1)) == 0) s_tab[cid >> shift] = make_int2(my_s, my_q);
             carry_r += __builtin_amdgcn_readlane(ir, 63); carry_q += __builtin_amdgcn_readlane(iq, 63);
-            if ((unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu) { give_up = true; break; }   // stream coordinates are 32-bit: absurd spans go to the general walker
+            if ((unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu) { give_up = true; return false; }   // stream coordinates are 32-bit: absurd spans go to the general walker
             // ops the reference rejects (:1625-1628) and clips (getClip :1613-1620,1636-1645: soft/hard clips longer than 5; FRONT iff CIGAR index 0),
             // both only in alignments that are walked.  Rare: a clipped alignment's first / last lane-chunk.  Events wait in LDS for the wave's one
             // reservation, their position in stream coordinates until the group is through
@@ -300,7 +297,7 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
                     const unsigned op = w[k] & 15u;
                     if (q1) { bad |= op > 8u; mine_n += ((op == 4u || op == 5u) && (w[k] >> 4) > 5u) ? 1 : 0; }
                 }
-                if (__ballot(bad) && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
+                bad_cigar |= __ballot(bad) != 0ull;                       // (reported once, at the end: a store inside the loop would make every wait of the loop a full one)
                 const int incl = wave_incl_scan_dpp(mine_n);
                 int slot = n_clip + incl - mine_n;
                 if (mine_n) {
@@ -317,9 +314,23 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
                     }
                 }
                 n_clip += __builtin_amdgcn_readlane(incl, 63);
-                if (n_clip > EXT_CLIPS) { give_up = true; break; }        // more clip ops than the buffer holds (H S ... S H chains)
+                if (n_clip > EXT_CLIPS) { give_up = true; return false; } // more clip ops than the buffer holds (H S ... S H chains)
             }
+            return true;
+        };
+        // Two rounds per trip, ONE way out of the loop, and the same loads in flight whichever way a trip went: where paths meet the compiler waits for
+        // every load that is in flight on ANY of them before it reuses the registers (an early exit after the first half, with the second buffer's
+        // request in flight, made the loop's head wait for everything on every trip).  When the rounds are odd the last half-trip walks nothing:
+        // its words are blanked like all words past the stream's end
+#pragma unroll 1
+        for (int R0 = 0; R0 < TC; R0 += 128) {
+            request(R0 + 64 + l, wb);
+            walk_round(wa, R0);
+            request(R0 + 128 + l, wa);
+            walk_round(wb, R0 + 64);
+            if (give_up) break;
         }
+        drain8(wa);
         if (give_up) {                                                    // (groups done before this one were counted: taken off as in the early-return case below)
             if (var_cnt) {
                 unsigned gone = 0;
@@ -336,6 +347,26 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         wave_sync();
 
         EXT_TICK(1)
+        // where an alignment begins and ends INSIDE its first / last lane-chunk: lane q sums the words in front of the first and up to the last word
+        // of alignment q (the chunks' own coordinates came out of the walk).  Requested only now - the lines have just been streamed, they come from
+        // the caches - so that nothing but the walk's own two buffers is in flight, and held in registers, during the walk
+        int adv_r = 0, adv_q = 0, end_r = 0;
+        {
+            const int ks = h_rel & 7, ke = (x_end & 7) + 1;
+            const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs), b = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs + 4);
+            const LpsU4 c = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce), d = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce + 4);
+            const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, we[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const unsigned t1 = op_consume_bits(ws[m] & 15u), t2 = op_consume_bits(we[m] & 15u);
+                const int l1 = m < ks ? (int)(ws[m] >> 4) : 0, l2 = m < ke ? (int)(we[m] >> 4) : 0;
+                adv_r += l1 & bit_mask(t1, 0); adv_q += l1 & bit_mask(t1, 16); end_r += l2 & bit_mask(t2, 0);
+            }
+        }
+        // ... and the positions of each alignment's first 64 candidate variants
+        int v0q[4], pp[4]; bool walkq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v0q[q] = __builtin_amdgcn_readlane(h_v0, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; pp[q] = V.pos[min(v0q[q] + l, V.n - 1)]; }
         // ---- where each alignment begins and ends in stream coordinates, the candidates of each: variants [v0, first variant at or beyond its end)
         int b_sat = 0, b_qat = 0, b_rend = h_start;
         if (h_walk) {
@@ -355,7 +386,11 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         int cum[5]; cum[0] = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) cum[q + 1] = cum[q] + ncand[q];
+#if EXT_ABL >= 5
+        const int T = 0;
+#else
         const int T = cum[4];
+#endif
         int vadj[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) vadj[q] = v0q[q] - cum[q];
@@ -372,6 +407,142 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         unsigned long long g0 = 0; ObsRec *dst = nullptr;
         int n_out = 0, n_emit[4] = {0, 0, 0, 0}; unsigned any_pre = 0;
         EXT_TICK(2)
+#if EXT_NC > 1
+        // EXT_NC candidates per lane and round, their memory trips side by side: the searches of all, then the word requests of all, the walks, the
+        // base / quality requests of all, the calls.  A job's ~100 candidates are one round instead of two and a round is one chain of dependent
+        // trips (table search -> CIGAR words -> base line -> counting atomic) whoever many candidates ride on it
+        constexpr int NC = EXT_NC;
+        uint2 pvr[NC]; int ppv[NC];                                        // records and the position of the variant before, requested one round ahead
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { const int i = l + 64 * c; const int vv = min(SELC(i, cum, vadj) + i, V.n - 1); pvr[c] = V.rec[vv]; ppv[c] = V.pos[max(vv - 1, 0)]; }
+        bool pend[NC]; uint32_t pend_slot[NC], pend_aq[NC]; unsigned pend_rk[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { pend[c] = false; pend_slot[c] = 0; pend_aq[c] = 0; pend_rk[c] = 0; }
+#pragma unroll 1
+        for (int i0 = 0; i0 < T; i0 += 64 * NC) {
+            int allele[NC], qv[NC], v[NC], qi[NC]; bool erased[NC], in[NC];
+            int ps[NC], hcrel[NC], hncig[NC], hlq[NC], hdq[NC], hds[NC], x0[NC], rr[NC], qq[NC], pprev[NC]; unsigned at[NC], blk[NC];
+            uint32_t w[NC][9];
+            // ---- A: search, words requested
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int i = i0 + 64 * c + l;
+                in[c] = i < T;
+                const uint2 vr = pvr[c]; pprev[c] = ppv[c];
+                { const int i2 = i + 64 * NC; const int vv = min(SELC(i2, cum, vadj) + i2, V.n - 1); pvr[c] = V.rec[vv]; ppv[c] = V.pos[max(vv - 1, 0)]; }
+                const int ic = min(i, T - 1);                             // lanes past the last candidate ride along on it (loads stay unconditional), `in` keeps them out
+                const int q = (ic >= cum[1]) + (ic >= cum[2]) + (ic >= cum[3]);
+                const int4 ha = *reinterpret_cast<const int4 *>(&s_hdr[q].crel), hb = *reinterpret_cast<const int4 *>(&s_hdr[q].vadj);
+                hcrel[c] = ha.x; hncig[c] = ha.y; hlq[c] = hb.y; hds[c] = hb.z; hdq[c] = hb.w; blk[c] = s_hdr[q].blk0;
+                const int hc0 = ha.z, hnch = ha.w;
+                v[c] = hb.x + ic;
+                at[c] = vr.y; erased[c] = (vr.y & VREC_ERASED) != 0u;
+                ps[c] = (int)vr.x + hb.z;
+                int co = 0;
+                for (int step = step0; step >= 1; step >>= 1) { const int t = co + step; const int sv = s_tab[hc0 + min(t, hnch - 1)].x; co = (t < hnch && sv <= ps[c]) ? t : co; }
+                const int2 base = s_tab[hc0 + co];
+                x0[c] = (8 * (hc0 + co)) << shift; rr[c] = base.x; qq[c] = base.y;
+                const uint32_t *cw = cg + x0[c];
+                const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cw), b = *reinterpret_cast<const LpsU4 *>(cw + 4);
+                w[c][0] = a.x; w[c][1] = a.y; w[c][2] = a.z; w[c][3] = a.w; w[c][4] = b.x; w[c][5] = b.y; w[c][6] = b.z; w[c][7] = b.w; w[c][8] = cw[8];
+            }
+            // ---- B: the op that covers the variant (see the comments of the one-candidate loop below), the reference's rules for it
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                allele[c] = -1; qv[c] = 0; qi[c] = -1;
+                int jx = x0[c], rs = rr[c], qs = qq[c]; uint32_t wj = 6u, wn = 6u;
+                int r_ = rr[c], q_ = qq[c];
+                auto walk8 = [&](const uint32_t (&ww)[9], int xb) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool le = r_ <= ps[c];
+                        jx = le ? xb + k : jx; rs = le ? r_ : rs; qs = le ? q_ : qs; wj = le ? ww[k] : wj; wn = le ? ww[k + 1] : wn;
+                        const unsigned t = op_consume_bits(ww[k] & 15u); const int len = (int)(ww[k] >> 4);
+                        r_ += len & bit_mask(t, 0); q_ += len & bit_mask(t, 16);
+                    }
+                };
+                walk8(w[c], x0[c]);
+                if (shift) {                                              // LONG mode: the entry's other words, 8 at a time, until the walk is past the variant
+                    for (int u = 1; u < (1 << shift); ++u) {
+                        if (r_ > ps[c] || x0[c] + 8 * u >= hcrel[c] + hncig[c]) break;
+                        const uint32_t *cw = cg + x0[c] + 8 * u;
+                        uint32_t w2[9];
+                        const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cw), b = *reinterpret_cast<const LpsU4 *>(cw + 4);
+                        w2[0] = a.x; w2[1] = a.y; w2[2] = a.z; w2[3] = a.w; w2[4] = b.x; w2[5] = b.y; w2[6] = b.z; w2[7] = b.w; w2[8] = cw[8];
+                        walk8(w2, x0[c] + 8 * u);
+                    }
+                }
+                if (in[c]) {
+                    const int op = wj & 15, len = (int)(wj >> 4);
+                    const int opi = jx - hcrel[c];
+                    qs -= hdq[c];
+                    if (ps[c] < rs + len) {
+                        const unsigned kind = VREC_KIND(at[c]);
+                        if (op_is_match(op)) {                                        // :1445-1520
+                            const int o = ps[c] - rs;
+                            if (qs + o + 1 > hlq[c]) fail = true;                     // :1453-1455
+                            else if (kind == 0) qi[c] = qs + o;
+                            else if ((kind == 1 || kind == 2) && opi + 1 < hncig[c]) {   // indel variant :1470-1510
+                                const int want = (kind == 1) ? 1 : 2;
+                                allele[c] = (rs + len - 1 == ps[c] && (int)(wn & 15u) == want) ? 1 : 0;
+                                qv[c] = (at[c] & VREC_DANGER) ? -5 : -4;
+                            }
+                        } else if (op == 2) {                                         // :1539-1607: only the first variant at / after the deletion's start
+                            const bool first_in = (v[c] == 0) || pprev[c] + hds[c] < rs;
+                            if (first_in && (at[c] & VREC_HPOLY3)) {
+                                if (qs + 1 > hlq[c]) fail = true;                     // :1559-1561
+                                else if (kind == 0) qi[c] = qs;
+                                else if (kind == 2) { allele[c] = 1; qv[c] = -4; }
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- C: base and quality at the variant site, one 128-byte line for both; all requests before the first is looked at
+            int code[NC], qual[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sq_fetch(R.sq, qi[c] >= 0 ? blk[c] : 0u, max(qi[c], 0), code[c], qual[c]);   // (lanes with nothing to fetch read the array's first line)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (qi[c] >= 0) {
+                    const char ref_c = (char)(at[c] & 0xff), alt_c = (char)((at[c] >> 8) & 0xff);
+                    const char base_c = nt16_char(code[c]);
+                    qv[c] = qual[c];
+                    if (base_c == ref_c) allele[c] = 0; else if (base_c == alt_c) allele[c] = 1;
+                }
+            // ---- D: rows, slots, records, counts
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int ib = i0 + 64 * c;
+                const bool pre = in[c] && allele[c] != -1;                // an observation before filterSNP
+                const bool ok = pre && !erased[c];
+                const unsigned long long pm = __ballot(pre), om = __ballot(ok);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int a = max(cum[k] - ib, 0), b = min(cum[k + 1] - ib, 64);   // lanes of row k in this part of the round
+                    if (b > a) {
+                        const unsigned long long rm = ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << a) - 1ull);
+                        n_emit[k] += __popcll(om & rm); if (pm & rm) any_pre |= 1u << k;
+                    }
+                }
+                if (ib == 0) {                                            // the reservation has had the first round's searches to arrive
+                    off = __shfl(off, 0);
+                    if (off + (unsigned long long)T > O.arena_size) arena_full = true;
+                    g0 = arena_lo + off; dst = O.rec + g0;
+                }
+                const bool put = ok && !arena_full;
+                const uint32_t slot = (uint32_t)(n_out + __popcll(om & lanemask_lt())), aqw = (uint32_t)pack_aq(allele[c], qv[c]);
+                unsigned rk = 0;
+                if (put) { dst[slot] = ObsRec{(int32_t)v[c], aqw}; if (var_cnt) rk = atomicAdd(&var_cnt[v[c]], 1u); }
+                if (pend[c]) { if (pend_rk[c] > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); dst[pend_slot[c]].aq = pend_aq[c] | (pend_rk[c] << 10); }
+                pend[c] = put && var_cnt != nullptr; pend_slot[c] = slot; pend_aq[c] = aqw; pend_rk[c] = rk;
+                n_out += __popcll(om);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (pend[c]) { if (pend_rk[c] > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); dst[pend_slot[c]].aq = pend_aq[c] | (pend_rk[c] << 10); }
+#else
         uint2 pvr = V.rec[min(SELC(l, cum, vadj) + l, V.n - 1)];           // records are requested one round ahead
         // an observation is counted where it is made: what the counting atomic returns is its rank inside the variant's list of observations, kept
         // beside allele and quality - the node-major lists are filled later without a counting pass and without a second atomic.  The atomic's
@@ -452,7 +623,12 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
                     }
                     if (qi >= 0) {                                                // base and quality at the variant site: one 128-byte line holds both
                         const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
-                        int code; sq_fetch(R.sq, s_hdr[q].blk0, qi, code, qv);
+                        int code;
+#if EXT_ABL == 2
+                        code = (qi & 3) ? 1 : 2; qv = 20 + (qi & 7);
+#else
+                        sq_fetch(R.sq, s_hdr[q].blk0, qi, code, qv);
+#endif
                         const char base_c = nt16_char(code);
                         if (base_c == ref_c) allele = 0; else if (base_c == alt_c) allele = 1;
                     }
@@ -477,12 +653,25 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
             const bool put = ok && !arena_full;
             const uint32_t slot = (uint32_t)(n_out + __popcll(om & lanemask_lt())), aqw = (uint32_t)pack_aq(allele, qv);
             unsigned rk = 0;
+#if EXT_ABL == 1
+            if (put) { dst[slot] = ObsRec{(int32_t)v, aqw}; rk = slot; }
+#elif EXT_ABL == 3
+            if (put) { if (var_cnt) rk = atomicAdd(&var_cnt[v], 1u); }
+#else
             if (put) { dst[slot] = ObsRec{(int32_t)v, aqw}; if (var_cnt) rk = atomicAdd(&var_cnt[v], 1u); }
-            if (pend) { if (pend_rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); dst[pend_slot].aq = pend_aq | (pend_rk << 10); }
+#endif
+#if EXT_ABL == 3 || EXT_ABL == 4
+            if (pend && pend_rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE);
+            if (0) {
+#else
+            if (pend) {
+#endif
+                if (pend_rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); dst[pend_slot].aq = pend_aq | (pend_rk << 10); }
             pend = put && var_cnt != nullptr; pend_slot = slot; pend_aq = aqw; pend_rk = rk;
             n_out += __popcll(om);
         }
         if (pend) { if (pend_rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); dst[pend_slot].aq = pend_aq | (pend_rk << 10); }
+#endif
         if (__ballot(fail)) {
             // get_snp returned early somewhere in these alignments (SEQ shorter than the CIGAR says: the read is dropped but clips of earlier ops
             // stay): the general walker replays the whole job.  Nothing a later stage looks at has been written, but the observations made so far
@@ -515,7 +704,7 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         if (l >= n_clip0 && l < n_clip) { ClipEv e = s_clip[l]; const int q = e.read; e.pos -= s_hdr[q].ds; e.read = r0 + q; s_clip[l] = e; }
         wave_sync();                                                      // the table and the headers are reused by the next group
     }
-    if (arena_full && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW);          // the host grows the arenas and reruns
+    if ((arena_full || bad_cigar) && l == 0) atomicOr(&cnt->err, (arena_full ? (unsigned)LPS_ERR_OBS_OVERFLOW : 0u) | (bad_cigar ? (unsigned)LPS_ERR_BAD_CIGAR : 0u));   // (overflow: the host grows the arenas and reruns)
     if (l < nq) {
         const bool ok = h_live && !arena_full;
         O.rows[r0 + l] = RowDesc{ok ? row_off : 0u, ok ? row_cnt : 0, 0x7fffffff, ok ? row_flags : 0u};
@@ -831,6 +1020,17 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
     }
     wave_sync();                                                         // the LDS buffers are reused by the wave's next job
     }
+}
+
+// first candidate of every alignment: the position-sorted table searched by one thread per alignment, all at once - inside the wave-per-job kernels
+// the same search was a chain of dependent loads at the head of every job
+__global__ void k_read_v0(VarView V, const int32_t *ref_start, int n, int32_t *v0) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) v0[r] = lane_var_lower_bound(V, ref_start[r]);
+}
+void launch_read_v0(const VarView &V, const ReadView &R, int32_t *v0, hipStream_t s) {
+    if (R.n == 0 || V.n == 0) return;
+    hipLaunchKernelGGL(k_read_v0, dim3((R.n + 255) / 256), dim3(256), 0, s, V, R.ref_start, R.n, v0);
 }
 
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,

@@ -273,10 +273,10 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
     if (r0 >= R.n) return;
     const int nq = min(4, R.n - r0);
     // ---- plan: headers, alignment q in lane q; the filter cascade of processSingleChrom (HaplotagParsingBam.cpp:453-486)
-    int h_start = 0, h_lq = 0, h_status = 0; unsigned long long h_coff = 0, h_soff = 0;
+    int h_start = 0, h_lq = 0, h_status = 0, h_v0 = 0; unsigned long long h_coff = 0, h_soff = 0;
     if (l <= nq) h_coff = R.cigar_off[r0 + l];
     if (l < nq) {
-        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r];
+        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r]; h_v0 = V.n ? R.v0[r] : 0;
         const int flag = R.flag[r];
         if (R.mapq[r] < mapping_quality) h_status = 1;
         else if (flag & 0x4) h_status = 2;
@@ -286,9 +286,9 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
         else if (!(h_start <= V.last_pos)) h_status = 6;
     }
     const bool h_live = l < nq && h_status == 0;
+    bool bad_cigar = false;
     const unsigned live_mask = (unsigned)__ballot(h_live) & 15u;
     const int h_ncig_all = (int)(long long)(__shfl_down(h_coff, 1) - h_coff);   // (lanes < nq)
-    int h_v0 = 0; bool have_v0 = false;
     int vh1[4] = {0, 0, 0, 0}, vh2[4] = {0, 0, 0, 0}, plo[4], phi[4];      // per alignment: votes, smallest / largest phase set seen (wave-uniform)
 #pragma unroll
     for (int q = 0; q < 4; ++q) { plo[q] = 0x7fffffff; phi[q] = (int)0x80000000; }
@@ -321,28 +321,11 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
             const LpsU4 a = *reinterpret_cast<const LpsU4 *>(p), b = *reinterpret_cast<const LpsU4 *>(p + 4);
             w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
         };
-        uint32_t pw[8];
-        request(l, pw);
-        if (!have_v0) { if (l < 4 && h_live) h_v0 = lane_var_lower_bound(V, h_start); have_v0 = true; }
+        uint32_t wa[8], wb[8];                                            // two buffers taken in turn (see the walk of k_extract_phase)
+        request(l, wa);
         const bool h_walk = h_in && h_ncig > 0;
         const int x_end = h_rel + h_ncig - 1;
         const int cs = (h_walk && fast) ? h_rel >> 3 : 0, ce = (h_walk && fast) ? x_end >> 3 : 0;
-        int adv_r = 0, adv_q = 0, end_r = 0;
-        {
-            const int ks = h_rel & 7, ke = (x_end & 7) + 1;
-            const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs), b = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs + 4);
-            const LpsU4 c = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce), d = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce + 4);
-            const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, we[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const unsigned t1 = op_consume_bits(ws[m] & 15u), t2 = op_consume_bits(we[m] & 15u);
-                const int l1 = m < ks ? (int)(ws[m] >> 4) : 0, l2 = m < ke ? (int)(we[m] >> 4) : 0;
-                adv_r += l1 & bit_mask(t1, 0); adv_q += l1 & bit_mask(t1, 16); end_r += l2 & bit_mask(t2, 0);
-            }
-        }
-        int v0q[4], pp[4]; bool walkq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v0q[q] = __builtin_amdgcn_readlane(h_v0, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; pp[q] = V.n ? V.pos[min(v0q[q] + l, V.n - 1)] : 0x7fffffff; }
         if (l < 4) {
             ExtHdr &h = s_hdr[l];
             h.crel = h_rel; h.ncig = h_walk ? h_ncig : 0; h.c0 = cs; h.nch = h_walk ? (fast ? ce - cs + 1 : (((h_ncig + 7) >> 3) + (1 << shift) - 1) >> shift) : 0;
@@ -351,13 +334,11 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
         wave_sync();
         // ---- walk
         int carry_r = 0, carry_q = 0; bool absurd = false;
-#pragma unroll 1
-        for (int R0 = 0; R0 < TC; R0 += 64) {
+        auto walk_round = [&](const uint32_t (&win)[8], const int R0) __attribute__((always_inline)) {
             const int cid = R0 + l;
             uint32_t w[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) w[k] = pw[k];
-            request(cid + 64, pw);
+            for (int k = 0; k < 8; ++k) w[k] = win[k];
             if (R0 + 64 >= TC) {
                 const int nv = total - 8 * cid;
 #pragma unroll
@@ -376,7 +357,7 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
             if (fast) { if (cid < TC) s_tab[cid] = make_int2(my_s, my_q); }
             else if (cid < TC && (cid & ((1 << shift) - 1)) == 0) s_tab[cid >> shift] = make_int2(my_s, my_q);
             carry_r += __builtin_amdgcn_readlane(ir, 63); carry_q += __builtin_amdgcn_readlane(iq, 63);
-            if ((unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu) { absurd = true; break; }
+            if ((unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu) { absurd = true; return; }
             if (__ballot((seen & LPS_OPS_BAD) != 0u)) {                   // an op code the reference rejects, in an alignment that is walked (rare path)
                 bool bad = false;
 #pragma unroll
@@ -386,11 +367,39 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
                     for (int q = 0; q < 4; ++q) inq |= x >= s_hdr[q].crel && x < s_hdr[q].crel + s_hdr[q].ncig;
                     bad |= inq && (w[k] & 15u) > 8u;
                 }
-                if (__ballot(bad) && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
+                bad_cigar |= __ballot(bad) != 0ull;                       // (reported once, at the end: no store inside the loop)
             }
+        };
+        // two rounds per trip, one way out, the same loads in flight whichever way a trip went (see k_extract_phase)
+#pragma unroll 1
+        for (int R0 = 0; R0 < TC; R0 += 128) {
+            request(R0 + 64 + l, wb);
+            walk_round(wa, R0);
+            request(R0 + 128 + l, wa);
+            walk_round(wb, R0 + 64);
+            if (absurd) break;
         }
+        drain8(wa);
         if (absurd) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); break; }   // stream coordinates beyond 2^30: reference spans no aligner produces
         wave_sync();
+        // the words in front of each alignment's first and up to its last word inside their lane-chunks, the first 64 candidate positions of each:
+        // requested only now (from the caches), so that the walk has nothing in flight but its own two buffers
+        int adv_r = 0, adv_q = 0, end_r = 0;
+        {
+            const int ks = h_rel & 7, ke = (x_end & 7) + 1;
+            const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs), b = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs + 4);
+            const LpsU4 c = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce), d = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce + 4);
+            const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, we[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const unsigned t1 = op_consume_bits(ws[m] & 15u), t2 = op_consume_bits(we[m] & 15u);
+                const int l1 = m < ks ? (int)(ws[m] >> 4) : 0, l2 = m < ke ? (int)(we[m] >> 4) : 0;
+                adv_r += l1 & bit_mask(t1, 0); adv_q += l1 & bit_mask(t1, 16); end_r += l2 & bit_mask(t2, 0);
+            }
+        }
+        int v0q[4], pp[4]; bool walkq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v0q[q] = __builtin_amdgcn_readlane(h_v0, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; pp[q] = V.n ? V.pos[min(v0q[q] + l, V.n - 1)] : 0x7fffffff; }
         // ---- alignment bounds in stream coordinates, candidates of each: phased variants [v0, first variant at or beyond its reference end)
         int b_sat = 0, b_qat = 0, b_rend = h_start;
         if (h_walk) {
@@ -512,6 +521,7 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
         }
         wave_sync();                                                      // the table and the headers are reused by the next group
     }
+    if (bad_cigar && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
     // ---- judgeReadHap (:243-300) for the four alignments, one lane each; ONE 64-byte line of results per job
     if (l < nq) {
         const int r = r0 + l;

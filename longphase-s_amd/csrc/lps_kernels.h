@@ -34,6 +34,7 @@ struct ReadView {
     const uint8_t *seq, *qual;
     const uint8_t *sq;         // bases + qualities interleaved in 128-byte blocks of LPS_SQ_BASES bases (lps_reads.hip); read r starts at block sq_blk[r]
     const uint32_t *sq_blk;
+    const int32_t *v0;         // first variant at or after the alignment's start (k_read_v0: one thread per alignment, before the wave-per-job kernels)
 };
 #define LPS_SQ_BASES 84
 void launch_sq_count(int n, const int32_t *l_qseq, uint32_t *nblk, hipStream_t s);
@@ -195,6 +196,11 @@ struct __attribute__((aligned(16))) ExtHdr {
     unsigned blk0, pad0, pad1, pad2;       // first block of the read's interleaved bases + qualities (lps_reads.hip)
 };
 
+// waits for the loads into w[] (an empty asm that reads the registers): see the walk loop of k_extract_phase
+__device__ __forceinline__ void drain8(const uint32_t (&w)[8]) {
+    asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+}
+
 // the c-th of four wave-uniform scalars, c = index of the first flattened candidate of alignments 1..3 (per-lane compare against thresholds)
 #define SELC(c, t, a) ((c) >= (t)[3] ? (a)[3] : ((c) >= (t)[2] ? (a)[2] : ((c) >= (t)[1] ? (a)[1] : (a)[0])))
 #define SEL4(q, a) ((q) >= 3 ? (a)[3] : ((q) >= 2 ? (a)[2] : ((q) >= 1 ? (a)[1] : (a)[0])))
@@ -205,6 +211,7 @@ struct HapOut { uint8_t *status; int32_t *hp1, *hp2; uint8_t *n_ps; int32_t *ps_
                 // germline haplotag (mode 0): ONE 16-byte record per read instead of five arrays, the read-level decision taken on the GPU:
                 //   word 0 = status | n_ps << 8 | HP << 16 | PQ << 24 (PQ 255: votes of 64 or more, the host computes it), hp1, hp2 (votes included), ps_min
                 uint4 *rec; const int *pq_tab /* [64][64]: PQ of (min, max) votes, built by the host's libm */; const int32_t *votes1, *votes2; };
+void launch_read_v0(const VarView &V, const ReadView &R, int32_t *v0, hipStream_t s);
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
                      int mode, LpsCounters *cnt, hipStream_t s);   // mode 0 haplotag, 1 somatic tag, 2 normal extraction, 3 its read-HP pass
 
