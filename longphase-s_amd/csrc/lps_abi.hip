@@ -49,7 +49,7 @@ struct lps_ctx {
     int nR = 0; uint64_t n_cig = 0, n_seq = 0, n_qual = 0;
     DevBuf<int32_t> r_start, r_lq; DevBuf<uint16_t> r_flag; DevBuf<uint8_t> r_mapq; DevBuf<uint32_t> r_name;
     DevBuf<uint64_t> r_coff, r_soff, r_qoff; DevBuf<uint32_t> cigar; DevBuf<uint8_t> seq, qual;
-    DevBuf<uint8_t> sq; DevBuf<uint32_t> r_sqblk, sq_cnt; DevBuf<int32_t> r_v0; int sq_reads = -1; float sq_ms = 0;   // bases + qualities interleaved per 128-byte line (lps_reads.hip); sq_reads: alignments it covers (-1: not built)
+    DevBuf<uint8_t> sq; DevBuf<uint32_t> r_sqblk, sq_cnt; DevBuf<int32_t> r_v0; DevBuf<uint32_t> cigp, cp_off, cp_cnt; DevBuf<int32_t> cp_n; int cp_reads = -1; int sq_reads = -1; float sq_ms = 0;   // bases + qualities interleaved per 128-byte line (lps_reads.hip); sq_reads: alignments it covers (-1: not built)
     // raw BAM records (lps_push_bam_records): seq/qual are read in place from the blob
     DevBuf<uint8_t> blob; uint64_t n_blob = 0; int read_mode = 0;   // 0 none yet, 1 SoA batches, 2 BAM records
     DevBuf<uint64_t> rec_off, cig_src; DevBuf<unsigned long long> cig_cnt; DevBuf<unsigned> bam_err;
@@ -224,7 +224,7 @@ void *lps_stream(lps_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int lps_begin_chromosome(lps_ctx *c) {
     if (!c) return -1;
     c->nV = 0; c->last_pos = -1; c->ref_len = c->ref_len_eff = 0; c->nR = 0; c->n_cig = c->n_seq = c->n_qual = 0; c->n_blob = 0; c->read_mode = 0; c->cur_first = -1; c->cur_count = 0;
-    c->phase_valid = false; c->has_hap = false; c->h_vpos.clear(); c->vpos_on_device_only = false; c->name_max = 0; c->sq_reads = -1;
+    c->phase_valid = false; c->has_hap = false; c->h_vpos.clear(); c->vpos_on_device_only = false; c->name_max = 0; c->sq_reads = -1; c->cp_reads = -1;
     c->nX = c->nSV = c->nMOD = 0; c->h_snp_u.clear(); c->h_sv_u.clear(); c->h_mod_u.clear(); c->votes_h1.clear(); c->votes_h2.clear();
     return 0;
 }
@@ -863,12 +863,34 @@ static int prepare_reads(lps_ctx *c) {
     return 0;
 }
 
+// the CIGAR words in lane-chunks (lps_reads.hip): what the stream walks of phase and haplotag read
+static int prepare_cigar(lps_ctx *c) {
+    if (c->cp_reads == c->nR || c->nR == 0) return 0;
+    hipStream_t s = c->stream; const int n = c->nR;
+    c->cp_cnt.reserve((size_t)n + 2); c->cp_off.reserve((size_t)n + 2); c->cp_n.reserve((size_t)n + 2);
+    const size_t need = GraphTemp::need((size_t)n + 2);
+    if (need > c->temp_bytes) { c->temp.reserve(need); c->temp_bytes = need; }
+    unsigned *flag = reinterpret_cast<unsigned *>(c->cp_cnt.p + n + 1);
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, s));
+    launch_cp_count(n, c->r_coff.p, c->cp_cnt.p, c->cp_n.p, flag, s);
+    exscan_u32(c->temp.p, c->temp_bytes, c->cp_cnt.p, c->cp_off.p, (size_t)n + 1, s);
+    uint32_t total = 0, bad = 0;
+    HIP_TRY(hipMemcpyAsync(&total, c->cp_off.p + n, sizeof total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof bad, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (bad || (uint64_t)total * 8 < c->n_cig) return fail(c, "CIGAR arrays beyond 2^35 words per chromosome (or 2^31 per alignment) are not supported");
+    c->cigp.reserve((size_t)total * 8 + 64);
+    launch_cp_pack(n, c->r_coff.p, c->cigar.p, c->cp_off.p, c->cigp.p, s);
+    c->cp_reads = n;
+    return 0;
+}
+
 static ReadView read_view(lps_ctx *c) {
     ReadView R{};
     R.n = c->nR; R.ref_start = c->r_start.p; R.l_qseq = c->r_lq.p; R.flag = c->r_flag.p; R.mapq = c->r_mapq.p; R.name_id = c->r_name.p;
     R.cigar_off = c->r_coff.p; R.seq_off = c->r_soff.p; R.qual_off = c->r_qoff.p; R.cigar = c->cigar.p;
     if (c->read_mode == 2) R.seq = R.qual = c->blob.p; else if (c->read_mode == 3) R.seq = R.qual = c->file.p; else { R.seq = c->seq.p; R.qual = c->qual.p; }
-    R.sq = c->sq.p; R.sq_blk = c->r_sqblk.p; R.v0 = c->r_v0.p;
+    R.sq = c->sq.p; R.sq_blk = c->r_sqblk.p; R.v0 = c->r_v0.p; R.cigp = c->cigp.p; R.cp_off = c->cp_off.p; R.cp_n = c->cp_n.p;
     return R;
 }
 
@@ -1099,7 +1121,7 @@ int lps_prepare_reads(lps_ctx *c, double *ms) {
     try {
         HIP_TRY(hipSetDevice(c->device));
         const bool had = c->sq_reads == c->nR;
-        if (prepare_reads(c) != 0) return -1;
+        if (prepare_reads(c) != 0 || prepare_cigar(c) != 0) return -1;
         if (ms) *ms = had ? 0.0 : (double)c->sq_ms;
     } catch (std::string &e) { return fail(c, e); }
     return 0;
@@ -1126,7 +1148,7 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         c->phase_valid = false; c->h_res_ps_u.clear(); c->h_res_gt_u.clear();
         if (c->nV == 0 || c->nR == 0) { c->phase_valid = c->nV != 0; return 0; }
         if (c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
-        if (prepare_reads(c) != 0) return -1;
+        if (prepare_reads(c) != 0 || prepare_cigar(c) != 0) return -1;
         c->in_phase = true;
         int rc = run_phase(c);
         c->in_phase = false;
@@ -1253,6 +1275,7 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
         const bool votes = !c->votes_h1.empty();
         if (votes && (int)c->votes_h1.size() != nR) return fail(c, "lps_set_read_votes was called for another set of alignments");
         hipStream_t s = c->stream;
+        if (prepare_cigar(c) != 0) return -1;
         // ---- one 16-byte record per read: votes, PS and the read-level decision (judgeReadHap, HaplotagStrategy.cpp:243-300) taken on the GPU
         c->hap_rec.reserve((size_t)nR + 1);
         const size_t span = (size_t)nR * sizeof(uint4);

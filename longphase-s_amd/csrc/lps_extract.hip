@@ -92,70 +92,46 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 #ifndef EXT_TAB
 #define EXT_TAB 1024    // lane-chunks (8 CIGAR words each) a wave keeps in LDS - words (16 KB) and the chunks' coordinates (4 KB): 4 096 words, ~100 kb of
 #endif                  // ONT read; a job that holds more is walked in groups, an alignment that alone holds more with a coarser table
-#ifndef EXT_WORDS_IN_LDS
-#define EXT_WORDS_IN_LDS 0   // 1: a group's CIGAR words stay in LDS for the candidates (32 B per lane-chunk more); 0: the candidates re-read their chunk's words
-#endif
 #ifndef EXT_WAVES
 #define EXT_WAVES 4     // waves per SIMD the register budget is sized for: 128 VGPRs, no spills; 5 / 6 / 8 waves (spills, smaller tables) were measured slower
 #endif
 #ifndef EXT_GROUP_MAX
 #define EXT_GROUP_MAX 4 // alignments walked together (their candidates are resolved together once their words are through)
 #endif
-#ifndef EXT_ABL
-#define EXT_ABL 0       // timing experiments: 1 no counting atomic, 2 no base / quality fetch, 3 no record stores, 4 no second (rank) store
-#endif
-#ifndef EXT_NC
-#define EXT_NC 1        // candidates per lane and round of the resolve loop
-#endif
 #define EXT_CLIPS 16    // clip events buffered per wave
 
-// reference / query bases consumed by the first k (wave-uniform, 0..8) of a lane's 8 words
-__device__ __forceinline__ void advance_of(const uint32_t (&w)[8], int k, int &sr, int &sq) {
-    sr = 0; sq = 0;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const unsigned t = op_consume_bits(w[m] & 15u); const int len = (m < k) ? (int)(w[m] >> 4) : 0;
-        sr += len & bit_mask(t, 0); sq += len & bit_mask(t, 16);
-    }
-}
 
-#ifdef EXT_PROFILE
-__device__ unsigned long long g_ext_prof[8];     // diagnostic build: s_memtime ticks per phase summed over the waves (plan, walk, bounds + count, passes, tail), jobs
-#define EXT_TICK(k) { const unsigned long long t_now = __builtin_readcyclecounter(); if (l == 0) atomicAdd(&g_ext_prof[k], t_now - t_last); t_last = t_now; }
-#else
-#define EXT_TICK(k)
-#endif
-// One wavefront = one job of four consecutive alignments, whose CIGARs lie back to back in memory.
-//   * WALK.  The CIGAR words of the job are ONE stream, taken 512 words per round, 8 consecutive words per lane, every lane busy whatever the
-//     alignments' lengths.  A lane sums the reference / query advance of its 8 words and one pair of DPP scans over the wave turns the sums into
-//     STREAM coordinates: reference and query bases consumed since the job's first word, running on across alignment boundaries.  The lane's pair
-//     (8 bytes) and its 8 words (32 bytes) go to LDS - no per-op prefixes, no per-alignment bookkeeping per lane, no barrier inside the loop; the
-//     words of the next round are requested before the current round is summed.  What an alignment needs is three scalars taken where its first
-//     and last word pass by: the stream coordinates of its first op (a variant at reference position p then sits at stream position
-//     p - start + that) and the reference position it ends at.
-//   * CANDIDATES.  With the job's chunks in LDS, the candidate variants of the four alignments (position-sorted slices of the variant table:
+// One wavefront = one job of four consecutive alignments; their CIGAR words lie back to back in lane-chunks of 8, each alignment padded to a whole
+// number of chunks (lps_reads.hip).
+//   * WALK.  The words of the job are ONE stream, taken 512 words per round, 8 consecutive words per lane, every lane busy whatever the alignments'
+//     lengths.  A lane sums the reference / query advance of its 8 words (six vector instructions per word) and one pair of DPP scans over the wave
+//     turns the sums into STREAM coordinates: reference and query bases consumed since the job's first word, running on across alignments.  The
+//     lane's pair goes to LDS (8 bytes per chunk) - no per-op prefixes, no per-alignment bookkeeping, no branch and no store to memory inside the
+//     loop; four rounds are requested together, 8 KB of the stream in flight per wave.  An alignment begins and ends on a chunk: where it starts
+//     in the stream and where it ends on the reference are table entries.
+//   * CLIPS (getClip :1613-1645) are looked for where the SAM format puts them: lane q examines the first two and the last two words of alignment
+//     q, loaded ahead of the walk; their positions follow from the alignment's start and end.  The walk only COUNTS the words whose op is a clip
+//     or one the reference rejects; a count that differs from what the alignments' ends hold - a clip in the middle of a CIGAR, an unknown op -
+//     sends the job to the general walker (k_extract_redo), like a length of 2^24 and more.
+//   * CANDIDATES.  With the job's table in LDS, the candidate variants of the four alignments (position-sorted slices of the variant table:
 //     [first variant at or after the alignment's start, first variant at or beyond its reference end)) are counted, ONE atomicAdd reserves that
 //     many observation slots, and the candidates are taken 64 at a time as one flattened list, every lane busy: binary search of the alignment's
-//     chunks for the last chunk that starts at or before the variant, the chunk's 8 words (+ the one after) from LDS, an 8-step walk in
+//     chunks for the last chunk that starts at or before the variant, the chunk's 8 words (+ the one after) from the caches, an 8-step walk in
 //     registers to the op that covers the variant, the reference's rules for that op (ParsingBam.cpp:1445-1607), base and quality gathered
 //     right there (one 128-byte line for both, lps_reads.hip), allele called, filterSNP's erasures applied, the observation counted (its rank
 //     in the variant's list) and the record written to its final, compacted place.  Every CIGAR word is fetched from memory ONCE and a base /
-//     quality pair costs one line: the kernel is bound by the rate at which L2 misses are served (profiles/r03_gather_calibration.md), so lines
-//     are what it saves.
-// A job whose words do not fit (8 * EXT_TAB) is walked in groups of alignments; an alignment that alone does not fit is walked with one table
-// entry per 8 << shift words and re-reads the words it needs (LONG mode: read lengths beyond ~100 kb).  A job that holds more clip events than
-// EXT_CLIPS, or in which get_snp's early return fires (:1453-1455, :1559-1561: a record whose SEQ is shorter than its CIGAR) queues itself for
-// k_extract_redo, the general walker, before it has written anything a later stage looks at.
+//     quality pair costs one line.
+// A job whose chunks do not fit the table (EXT_TAB) is walked in groups of alignments; an alignment that alone does not fit is walked with one
+// table entry per 1 << shift chunks and re-reads the words it needs (LONG mode: read lengths beyond ~100 kb).  A job in which get_snp's early
+// return fires (:1453-1455, :1559-1561: a record whose SEQ is shorter than its CIGAR) queues itself for k_extract_redo before it has written
+// anything a later stage looks at.
 __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
                                                       LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint32_t *var_cnt, uint32_t *var_del) {
-    __shared__ __attribute__((aligned(16))) int2 s_tab[EXT_TAB];
-    __shared__ __attribute__((aligned(16))) uint32_t s_words[EXT_WORDS_IN_LDS ? 8 * EXT_TAB + 16 : 16];
+    __shared__ __attribute__((aligned(16))) int2 s_tab[EXT_TAB + 1];
     __shared__ ExtHdr s_hdr[EXT_RPW];
     __shared__ ClipEv s_clip[EXT_CLIPS];
+    static_assert(EXT_CLIPS >= 4 * EXT_RPW, "four end words per alignment");
     const int l = lane_id();
-#ifdef EXT_PROFILE
-    unsigned long long t_last = __builtin_readcyclecounter();
-#endif
     // Output rows are reserved on one of LPS_ARENAS counters (own cache line each).  Workgroups are dealt round-robin over the 8 XCDs, so
     // arena = blockIdx % 64 keeps each counter inside ONE XCD's L2.
     const int arena = blockIdx.x % O.n_arenas;
@@ -165,14 +141,13 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
     if (r0 >= R.n) return;
     const int nq = min(EXT_RPW, R.n - r0);
     static_assert(EXT_RPW == 4, "lane layout of the planning step");
-    bool bad_cigar = false;                                            // an op code the reference rejects was seen in an alignment that is walked
-    auto to_redo = [&]() __attribute__((always_inline)) { if (l == 0) { redo_list[atomicAdd(n_redo, 1u)] = (uint32_t)job; if (bad_cigar) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR); } };
+    auto to_redo = [&]() __attribute__((always_inline)) { if (l == 0) redo_list[atomicAdd(n_redo, 1u)] = (uint32_t)job; };
 
     // ---- plan: headers, alignment q in lane q.  direct_detect_alleles filters (:1282-1291) + region "chr:1-<lastSNPPos>" (:1273)
-    int h_start = 0, h_lq = 0, h_v0 = 0; bool h_live = false; unsigned long long h_coff = 0; unsigned h_blk = 0;
-    if (l <= nq) h_coff = R.cigar_off[r0 + l];
+    int h_start = 0, h_lq = 0, h_v0 = 0, h_n = 0; bool h_live = false; unsigned h_cp = 0, h_blk = 0;
+    if (l <= nq) h_cp = R.cp_off[r0 + l];
     if (l < nq) {
-        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_blk = R.sq_blk[r]; h_v0 = V.n ? R.v0[r] : 0;
+        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_blk = R.sq_blk[r]; h_v0 = V.n ? R.v0[r] : 0; h_n = R.cp_n[r];
         const int flag = R.flag[r];
         h_live = !(R.mapq[r] < mapping_quality || (flag & 0x4) || (flag & 0x100) || (flag & 0x400) || h_start >= V.last_pos);
     }
@@ -181,157 +156,82 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         if (l < nq) O.rows[r0 + l] = RowDesc{0u, 0, 0x7fffffff, 0u};
         return;
     }
-    const int h_ncig_all = (int)(long long)(__shfl_down(h_coff, 1) - h_coff);   // (lanes < nq)
-    // what lane q collects for row q; clip events of the job (reference coordinates)
+    const int h_nch = (int)(__shfl_down(h_cp, 1) - h_cp);             // chunks of alignment q (lanes < nq)
+    // what lane q collects for row q; clip events of the job
     unsigned row_off = 0; int row_cnt = 0; unsigned row_flags = 0;
     int n_clip = 0; bool fail = false, arena_full = false;
 
-    // ---- the job's alignments in GROUPS whose CIGAR words fit the table together: nearly always one group of four
+    // ---- the job's alignments in GROUPS whose chunks fit the table together: nearly always one group of four
     unsigned todo = live_mask;
 #pragma unroll 1
     while (todo) {
         const int qa = __builtin_ctz(todo);
-        const unsigned long long c_lo = __shfl(h_coff, qa);
+        const unsigned c_lo = __shfl(h_cp, qa);
         int qb = qa; unsigned gm = 1u << qa;
         for (int q = qa + 1; q < nq; ++q) {
             if (!((todo >> q) & 1u)) continue;
-            const long long span = (long long)(__shfl(h_coff, q + 1) - c_lo);
-            if (((span + 7) >> 3) > EXT_TAB || __popc(gm) >= EXT_GROUP_MAX) break;
+            if (__shfl(h_cp, q + 1) - c_lo > (unsigned)EXT_TAB || __popc(gm) >= EXT_GROUP_MAX) break;
             gm |= 1u << q; qb = q;
         }
         todo &= ~gm;
-        // LONG mode: the group's first alignment alone holds more words than LDS takes (then it is the whole group): one table entry per 8 << shift
-        // words, the words themselves are read again where a candidate needs them
+        // LONG mode: the group's first alignment alone holds more chunks than the table takes (then it is the whole group): one entry per
+        // 1 << shift chunks, the words themselves are read again where a candidate needs them
         int shift = 0;
-        { const long long w1 = (long long)(__shfl(h_coff, qa + 1) - c_lo); while ((((w1 + 7) >> 3) + ((1ll << shift) - 1)) >> shift > EXT_TAB) ++shift; }
-        const bool fast = shift == 0;                                     // one table entry per lane-chunk, alignment boundaries inside chunks
-        const bool in_lds = EXT_WORDS_IN_LDS && fast;
-        // the stream: from the first word of the group's first alignment to the last word of its last one (alignments in between that are not
+        { const unsigned n1 = __shfl(h_cp, qa + 1) - c_lo; while (((n1 + (1u << shift) - 1u) >> shift) > (unsigned)EXT_TAB) ++shift; }
+        const bool fast = shift == 0;
+        // the stream: from the first chunk of the group's first alignment to the last chunk of its last one (alignments in between that are not
         // walked - low MAPQ, secondary - pass by as words that only move the coordinates on)
         const bool h_in = l < 4 && ((gm >> l) & 1u);
-        const int h_rel = (l <= nq) ? (int)(long long)(h_coff - c_lo) : 0; // word index of alignment q's first word inside the stream
-        const int h_ncig = h_ncig_all;
-        const uint32_t *cg = R.cigar + c_lo;
-        const int total = __builtin_amdgcn_readlane(h_rel + h_ncig, qb);  // words of the stream
-#if EXT_ABL == 6
-        const int TC = 0;
-#else
-        const int TC = (total + 7) >> 3;                                  // lane-chunks
-#endif
-        // UNCONDITIONAL loads, clamped to the stream (a load under a branch makes the compiler wait for every outstanding load where the paths join,
-        // i.e. for the request just made).  A lane's 8 words may run past the stream's end (DevBuf allocations carry 64 B of slack): the last round
-        // blanks those
+        const bool h_strm = l < nq && l >= qa && l <= qb && h_n > 0;      // alignment q has words in the stream
+        const bool h_walk = h_in && h_n > 0;
+        const int h_c0 = (l <= nq) ? (int)(h_cp - c_lo) : 0;              // first chunk of alignment q inside the stream
+        const uint32_t *cg = R.cigp + 8ull * c_lo;
+        const int TC = __builtin_amdgcn_readlane(h_c0 + h_nch, qb);       // chunks of the stream
+        // UNCONDITIONAL loads, clamped to the stream (a load under a branch makes the compiler wait for every outstanding load where the paths join)
         auto request = [&](int cid, uint32_t (&w)[8]) __attribute__((always_inline)) {
             const uint32_t *p = cg + 8 * min(cid, max(TC - 1, 0));
-            const LpsU4 a = *reinterpret_cast<const LpsU4 *>(p), b = *reinterpret_cast<const LpsU4 *>(p + 4);
+            const uint4 a = *reinterpret_cast<const uint4 *>(p), b = *reinterpret_cast<const uint4 *>(p + 4);
             w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
         };
-        uint32_t wa[8], wb[8];                                            // two buffers taken in turn: the round being summed and the one in flight
-        request(l, wa);                                                   // round 0 is on its way
-        // first candidate of each alignment: four lanes search the position-sorted table side by side (a chain of dependent loads: behind round 0's request)
-        const bool h_walk = h_in && h_ncig > 0;
-        // where an alignment begins and ends INSIDE its first / last lane-chunk: lane q sums the words in front of the first and up to the last
-        // word of alignment q now, while the walk's first round is in flight (the chunks' own coordinates come out of the walk)
-        const int x_end = h_rel + h_ncig - 1;
-        const int cs = (h_walk && fast) ? h_rel >> 3 : 0, ce = (h_walk && fast) ? x_end >> 3 : 0;
-        if (l < 4) {                                                      // (first half of the header: what the rare paths of the walk look at)
+        // the first two and the last two words of alignment q (lane q: where its clips are), the positions of each alignment's first 64 candidate
+        // variants (counted against its reference end after the walk): requested ahead of the walk, looked at after it
+        uint32_t e_f0, e_f1, e_b1, e_b0;
+        {
+            const uint32_t *e = cg + 8 * (h_strm ? h_c0 : 0); const int n = h_strm ? h_n : 1;
+            e_f0 = e[0]; e_f1 = e[min(1, n - 1)]; e_b1 = e[max(n - 2, 0)]; e_b0 = e[n - 1];
+        }
+        int v0q[4], pp[4]; bool walkq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v0q[q] = __builtin_amdgcn_readlane(h_v0, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; pp[q] = V.pos[min(v0q[q] + l, V.n - 1)]; }
+        if (l < 4) {                                                      // (first half of the header)
             ExtHdr &h = s_hdr[l];
-            h.crel = h_rel; h.ncig = h_walk ? h_ncig : 0; h.c0 = cs; h.nch = h_walk ? (fast ? ce - cs + 1 : (((h_ncig + 7) >> 3) + (1 << shift) - 1) >> shift) : 0;
+            h.crel = fast ? 8 * h_c0 : 0; h.ncig = h_walk ? h_n : 0; h.c0 = fast ? h_c0 : 0; h.nch = h_walk ? (int)(((unsigned)h_nch + (1u << shift) - 1u) >> shift) : 0;
             h.lq = h_lq; h.blk0 = h_blk;
         }
-        wave_sync();
 
-        EXT_TICK(0)
-        // ---- walk
-        int carry_r = 0, carry_q = 0, n_clip0 = n_clip; bool give_up = false;
-        // one round of the walk over the words in `win`; false: the job gives up (give_up is set).  The loop below hands it the two buffers in turn
-        // and requests into the OTHER one first: a buffer is never copied while its load is in flight (the compiler places such a copy at the end
-        // of the iteration that issued the load and waits for the load there - the prefetch then overlaps nothing; seen in the ISA, cost 2/3 of the kernel)
-        auto walk_round = [&](const uint32_t (&win)[8], const int R0) __attribute__((always_inline)) -> bool {
-            const int cid = R0 + l;
-            uint32_t w[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) w[k] = win[k];
-            if (R0 + 64 >= TC) {                                          // last round: words past the stream's end count for nothing (6u: op P, length 0)
-                const int nv = total - 8 * cid;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) w[k] = k < nv ? w[k] : 6u;
-            }
-            int rt = 0, qt = 0; unsigned seen = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const unsigned op = w[k] & 15u;
-                const unsigned t = op_consume_bits(op); const int len = (int)(w[k] >> 4);
-                rt += len & bit_mask(t, 0); qt += len & bit_mask(t, 16);
-                seen |= 1u << op;
-            }
-#if EXT_ABL == 7
-            const int ir = rt, iq = qt;
-#else
-            const int ir = wave_incl_scan_dpp(rt), iq = wave_incl_scan_dpp(qt);
-#endif
-            const int my_s = carry_r + ir - rt, my_q = carry_q + iq - qt; // stream coordinates of the lane's first word
-            if (fast) {
-                if (cid < TC) {
-                    s_tab[cid] = make_int2(my_s, my_q);
-                    if (in_lds) { uint4 *wd = reinterpret_cast<uint4 *>(s_words + 8 * cid); wd[0] = make_uint4(w[0], w[1], w[2], w[3]); wd[1] = make_uint4(w[4], w[5], w[6], w[7]); }
-                }
-            } else if (cid < TC && (cid & ((1 << shift) - 1)) == 0) s_tab[cid >> shift] = make_int2(my_s, my_q);
-            carry_r += __builtin_amdgcn_readlane(ir, 63); carry_q += __builtin_amdgcn_readlane(iq, 63);
-            if ((unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu) { give_up = true; return false; }   // stream coordinates are 32-bit: absurd spans go to the general walker
-            // ops the reference rejects (:1625-1628) and clips (getClip :1613-1620,1636-1645: soft/hard clips longer than 5; FRONT iff CIGAR index 0),
-            // both only in alignments that are walked.  Rare: a clipped alignment's first / last lane-chunk.  Events wait in LDS for the wave's one
-            // reservation, their position in stream coordinates until the group is through
-            if (__ballot((seen & (LPS_OPS_BAD | LPS_OPS_CLIP)) != 0u)) {
-                int mine_n = 0; bool bad = false; unsigned wq = 0;        // wq: 4 bits per word: its alignment + 1 (0: none that is walked)
-                int hr[4], hn[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { hr[q] = s_hdr[q].crel; hn[q] = s_hdr[q].ncig; }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int x = 8 * cid + k;
-                    unsigned q1 = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) if (x >= hr[q] && x < hr[q] + hn[q]) q1 = q + 1;
-                    wq |= q1 << (4 * k);
-                    const unsigned op = w[k] & 15u;
-                    if (q1) { bad |= op > 8u; mine_n += ((op == 4u || op == 5u) && (w[k] >> 4) > 5u) ? 1 : 0; }
-                }
-                bad_cigar |= __ballot(bad) != 0ull;                       // (reported once, at the end: a store inside the loop would make every wait of the loop a full one)
-                const int incl = wave_incl_scan_dpp(mine_n);
-                int slot = n_clip + incl - mine_n;
-                if (mine_n) {
-                    int rr = my_s;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const unsigned op = w[k] & 15u; const int q = (int)((wq >> (4 * k)) & 15u) - 1;
-                        if (q >= 0 && (op == 4u || op == 5u) && (w[k] >> 4) > 5u) {
-                            const int oi = 8 * cid + k - SEL4(q, hr);
-                            if (slot < EXT_CLIPS) s_clip[slot] = ClipEv{rr, (oi << 1) | (oi != 0), q};
-                            ++slot;
-                        }
-                        rr += (int)(w[k] >> 4) & bit_mask(op_consume_bits(op), 0);
-                    }
-                }
-                n_clip += __builtin_amdgcn_readlane(incl, 63);
-                if (n_clip > EXT_CLIPS) { give_up = true; return false; } // more clip ops than the buffer holds (H S ... S H chains)
-            }
-            return true;
-        };
-        // Two rounds per trip, ONE way out of the loop, and the same loads in flight whichever way a trip went: where paths meet the compiler waits for
-        // every load that is in flight on ANY of them before it reuses the registers (an early exit after the first half, with the second buffer's
-        // request in flight, made the loop's head wait for everything on every trip).  When the rounds are odd the last half-trip walks nothing:
-        // its words are blanked like all words past the stream's end
+        // ---- walk.  FOUR rounds per trip, all four requested at its head: 8 KB of the stream in flight per wave, one exposed memory latency per
+        //      trip (an ordinary job is two trips).  Nothing is carried from trip to trip in a buffer: a buffer whose load crosses the loop's back
+        //      edge is copied at the end of the trip that issued the load (the compiler gives the in-loop load other registers than the one before
+        //      the loop), and the copy waits for the load there - a prefetch that overlaps nothing (seen in the ISA with one and with two buffers)
+        int carry_r = 0, carry_q = 0; unsigned special = 0; uint32_t big = 0; bool absurd = false;
 #pragma unroll 1
-        for (int R0 = 0; R0 < TC; R0 += 128) {
-            request(R0 + 64 + l, wb);
-            walk_round(wa, R0);
-            request(R0 + 128 + l, wa);
-            walk_round(wb, R0 + 64);
-            if (give_up) break;
+        for (int R0 = 0; R0 < TC; R0 += 256) {
+            uint32_t w0[8], w1[8], w2[8], w3[8];
+            request(R0 + l, w0); request(R0 + 64 + l, w1); request(R0 + 128 + l, w2); request(R0 + 192 + l, w3);
+            stream_round<LPS_CLIPMASK2 | LPS_BADMASK2>(w0, R0 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
+            stream_round<LPS_CLIPMASK2 | LPS_BADMASK2>(w1, R0 + 64 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
+            stream_round<LPS_CLIPMASK2 | LPS_BADMASK2>(w2, R0 + 128 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
+            stream_round<LPS_CLIPMASK2 | LPS_BADMASK2>(w3, R0 + 192 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
+            absurd |= (unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu;    // stream coordinates are 32-bit: absurd spans go to the general walker
+            if (absurd) break;
         }
-        drain8(wa);
-        if (give_up) {                                                    // (groups done before this one were counted: taken off as in the early-return case below)
+        if (fast && l == 0) s_tab[TC] = make_int2(carry_r, carry_q);      // where the stream ends: the end of its last alignment
+        // what the alignments' ends hold against what the walk counted
+        const unsigned c_f0 = op_bit(LPS_CLIPMASK2, e_f0), c_f1 = h_n >= 2 ? op_bit(LPS_CLIPMASK2, e_f1) : 0u,
+                       c_b1 = h_n >= 4 ? op_bit(LPS_CLIPMASK2, e_b1) : 0u, c_b0 = h_n >= 3 ? op_bit(LPS_CLIPMASK2, e_b0) : 0u;
+        const int expected = wave_sum(h_strm ? (int)(c_f0 + c_f1 + c_b1 + c_b0) : 0), counted = wave_sum((int)special);
+        if (absurd || expected != counted || __ballot(big >= 0x10000000u)) {
+            // (groups done before this one were counted: taken off as in the early-return case below)
             if (var_cnt) {
                 unsigned gone = 0;
 #pragma unroll
@@ -346,32 +246,27 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         }
         wave_sync();
 
-        EXT_TICK(1)
-        // where an alignment begins and ends INSIDE its first / last lane-chunk: lane q sums the words in front of the first and up to the last word
-        // of alignment q (the chunks' own coordinates came out of the walk).  Requested only now - the lines have just been streamed, they come from
-        // the caches - so that nothing but the walk's own two buffers is in flight, and held in registers, during the walk
-        int adv_r = 0, adv_q = 0, end_r = 0;
-        {
-            const int ks = h_rel & 7, ke = (x_end & 7) + 1;
-            const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs), b = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs + 4);
-            const LpsU4 c = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce), d = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce + 4);
-            const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, we[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const unsigned t1 = op_consume_bits(ws[m] & 15u), t2 = op_consume_bits(we[m] & 15u);
-                const int l1 = m < ks ? (int)(ws[m] >> 4) : 0, l2 = m < ke ? (int)(we[m] >> 4) : 0;
-                adv_r += l1 & bit_mask(t1, 0); adv_q += l1 & bit_mask(t1, 16); end_r += l2 & bit_mask(t2, 0);
-            }
-        }
-        // ... and the positions of each alignment's first 64 candidate variants
-        int v0q[4], pp[4]; bool walkq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v0q[q] = __builtin_amdgcn_readlane(h_v0, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; pp[q] = V.pos[min(v0q[q] + l, V.n - 1)]; }
-        // ---- where each alignment begins and ends in stream coordinates, the candidates of each: variants [v0, first variant at or beyond its end)
+        // ---- where each alignment begins in the stream and ends on the reference; its clips; its candidates: variants [v0, first variant at or beyond its end)
         int b_sat = 0, b_qat = 0, b_rend = h_start;
         if (h_walk) {
-            if (fast) { const int2 ts = s_tab[cs], te = s_tab[ce]; b_sat = ts.x + adv_r; b_qat = ts.y + adv_q; b_rend = h_start + te.x + end_r - b_sat; }
+            if (fast) { const int2 ts = s_tab[h_c0], te = s_tab[h_c0 + h_nch]; b_sat = ts.x; b_qat = ts.y; b_rend = h_start + te.x - ts.x; }
             else b_rend = h_start + carry_r;                                // LONG mode: the alignment is the whole stream
+        }
+        {   // getClip (:1613-1620,1636-1645): soft / hard clips longer than 5; FRONT iff CIGAR index 0.  Word i sits at the reference position the
+            // walk has reached before it: the start (+ what word 0 consumes), the end (- what the last words consume)
+            const bool k_f0 = h_walk && c_f0 && (e_f0 >> 4) > 5u, k_f1 = h_walk && c_f1 && (e_f1 >> 4) > 5u,
+                       k_b1 = h_walk && c_b1 && (e_b1 >> 4) > 5u, k_b0 = h_walk && c_b0 && (e_b0 >> 4) > 5u;
+            const int ne = (int)k_f0 + (int)k_f1 + (int)k_b1 + (int)k_b0;
+            const int ne0 = __builtin_amdgcn_readlane(ne, 0), ne1 = __builtin_amdgcn_readlane(ne, 1), ne2 = __builtin_amdgcn_readlane(ne, 2), ne3 = __builtin_amdgcn_readlane(ne, 3);
+            int slot = n_clip + (l > 0 ? ne0 : 0) + (l > 1 ? ne1 : 0) + (l > 2 ? ne2 : 0);
+            if (l < 4 && ne) {
+                const int p_b0 = b_rend - ref_len_of(e_b0), p_b1 = p_b0 - ref_len_of(e_b1), rd = r0 + l;
+                if (k_f0) s_clip[slot++] = ClipEv{h_start, 0, rd};
+                if (k_f1) s_clip[slot++] = ClipEv{h_start + ref_len_of(e_f0), (1 << 1) | 1, rd};
+                if (k_b1) s_clip[slot++] = ClipEv{p_b1, ((h_n - 2) << 1) | 1, rd};
+                if (k_b0) s_clip[slot++] = ClipEv{p_b0, ((h_n - 1) << 1) | 1, rd};
+            }
+            n_clip += ne0 + ne1 + ne2 + ne3;
         }
         int ncand[4], rend[4];
 #pragma unroll
@@ -386,11 +281,7 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         int cum[5]; cum[0] = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) cum[q + 1] = cum[q] + ncand[q];
-#if EXT_ABL >= 5
-        const int T = 0;
-#else
         const int T = cum[4];
-#endif
         int vadj[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) vadj[q] = v0q[q] - cum[q];
@@ -406,143 +297,6 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         const int step0 = maxnch > 1 ? 1 << (31 - __builtin_clz(maxnch - 1)) : 0;    // the steps step0, step0/2, .. 1 sum to >= maxnch - 1
         unsigned long long g0 = 0; ObsRec *dst = nullptr;
         int n_out = 0, n_emit[4] = {0, 0, 0, 0}; unsigned any_pre = 0;
-        EXT_TICK(2)
-#if EXT_NC > 1
-        // EXT_NC candidates per lane and round, their memory trips side by side: the searches of all, then the word requests of all, the walks, the
-        // base / quality requests of all, the calls.  A job's ~100 candidates are one round instead of two and a round is one chain of dependent
-        // trips (table search -> CIGAR words -> base line -> counting atomic) whoever many candidates ride on it
-        constexpr int NC = EXT_NC;
-        uint2 pvr[NC]; int ppv[NC];                                        // records and the position of the variant before, requested one round ahead
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { const int i = l + 64 * c; const int vv = min(SELC(i, cum, vadj) + i, V.n - 1); pvr[c] = V.rec[vv]; ppv[c] = V.pos[max(vv - 1, 0)]; }
-        bool pend[NC]; uint32_t pend_slot[NC], pend_aq[NC]; unsigned pend_rk[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { pend[c] = false; pend_slot[c] = 0; pend_aq[c] = 0; pend_rk[c] = 0; }
-#pragma unroll 1
-        for (int i0 = 0; i0 < T; i0 += 64 * NC) {
-            int allele[NC], qv[NC], v[NC], qi[NC]; bool erased[NC], in[NC];
-            int ps[NC], hcrel[NC], hncig[NC], hlq[NC], hdq[NC], hds[NC], x0[NC], rr[NC], qq[NC], pprev[NC]; unsigned at[NC], blk[NC];
-            uint32_t w[NC][9];
-            // ---- A: search, words requested
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int i = i0 + 64 * c + l;
-                in[c] = i < T;
-                const uint2 vr = pvr[c]; pprev[c] = ppv[c];
-                { const int i2 = i + 64 * NC; const int vv = min(SELC(i2, cum, vadj) + i2, V.n - 1); pvr[c] = V.rec[vv]; ppv[c] = V.pos[max(vv - 1, 0)]; }
-                const int ic = min(i, T - 1);                             // lanes past the last candidate ride along on it (loads stay unconditional), `in` keeps them out
-                const int q = (ic >= cum[1]) + (ic >= cum[2]) + (ic >= cum[3]);
-                const int4 ha = *reinterpret_cast<const int4 *>(&s_hdr[q].crel), hb = *reinterpret_cast<const int4 *>(&s_hdr[q].vadj);
-                hcrel[c] = ha.x; hncig[c] = ha.y; hlq[c] = hb.y; hds[c] = hb.z; hdq[c] = hb.w; blk[c] = s_hdr[q].blk0;
-                const int hc0 = ha.z, hnch = ha.w;
-                v[c] = hb.x + ic;
-                at[c] = vr.y; erased[c] = (vr.y & VREC_ERASED) != 0u;
-                ps[c] = (int)vr.x + hb.z;
-                int co = 0;
-                for (int step = step0; step >= 1; step >>= 1) { const int t = co + step; const int sv = s_tab[hc0 + min(t, hnch - 1)].x; co = (t < hnch && sv <= ps[c]) ? t : co; }
-                const int2 base = s_tab[hc0 + co];
-                x0[c] = (8 * (hc0 + co)) << shift; rr[c] = base.x; qq[c] = base.y;
-                const uint32_t *cw = cg + x0[c];
-                const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cw), b = *reinterpret_cast<const LpsU4 *>(cw + 4);
-                w[c][0] = a.x; w[c][1] = a.y; w[c][2] = a.z; w[c][3] = a.w; w[c][4] = b.x; w[c][5] = b.y; w[c][6] = b.z; w[c][7] = b.w; w[c][8] = cw[8];
-            }
-            // ---- B: the op that covers the variant (see the comments of the one-candidate loop below), the reference's rules for it
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                allele[c] = -1; qv[c] = 0; qi[c] = -1;
-                int jx = x0[c], rs = rr[c], qs = qq[c]; uint32_t wj = 6u, wn = 6u;
-                int r_ = rr[c], q_ = qq[c];
-                auto walk8 = [&](const uint32_t (&ww)[9], int xb) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const bool le = r_ <= ps[c];
-                        jx = le ? xb + k : jx; rs = le ? r_ : rs; qs = le ? q_ : qs; wj = le ? ww[k] : wj; wn = le ? ww[k + 1] : wn;
-                        const unsigned t = op_consume_bits(ww[k] & 15u); const int len = (int)(ww[k] >> 4);
-                        r_ += len & bit_mask(t, 0); q_ += len & bit_mask(t, 16);
-                    }
-                };
-                walk8(w[c], x0[c]);
-                if (shift) {                                              // LONG mode: the entry's other words, 8 at a time, until the walk is past the variant
-                    for (int u = 1; u < (1 << shift); ++u) {
-                        if (r_ > ps[c] || x0[c] + 8 * u >= hcrel[c] + hncig[c]) break;
-                        const uint32_t *cw = cg + x0[c] + 8 * u;
-                        uint32_t w2[9];
-                        const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cw), b = *reinterpret_cast<const LpsU4 *>(cw + 4);
-                        w2[0] = a.x; w2[1] = a.y; w2[2] = a.z; w2[3] = a.w; w2[4] = b.x; w2[5] = b.y; w2[6] = b.z; w2[7] = b.w; w2[8] = cw[8];
-                        walk8(w2, x0[c] + 8 * u);
-                    }
-                }
-                if (in[c]) {
-                    const int op = wj & 15, len = (int)(wj >> 4);
-                    const int opi = jx - hcrel[c];
-                    qs -= hdq[c];
-                    if (ps[c] < rs + len) {
-                        const unsigned kind = VREC_KIND(at[c]);
-                        if (op_is_match(op)) {                                        // :1445-1520
-                            const int o = ps[c] - rs;
-                            if (qs + o + 1 > hlq[c]) fail = true;                     // :1453-1455
-                            else if (kind == 0) qi[c] = qs + o;
-                            else if ((kind == 1 || kind == 2) && opi + 1 < hncig[c]) {   // indel variant :1470-1510
-                                const int want = (kind == 1) ? 1 : 2;
-                                allele[c] = (rs + len - 1 == ps[c] && (int)(wn & 15u) == want) ? 1 : 0;
-                                qv[c] = (at[c] & VREC_DANGER) ? -5 : -4;
-                            }
-                        } else if (op == 2) {                                         // :1539-1607: only the first variant at / after the deletion's start
-                            const bool first_in = (v[c] == 0) || pprev[c] + hds[c] < rs;
-                            if (first_in && (at[c] & VREC_HPOLY3)) {
-                                if (qs + 1 > hlq[c]) fail = true;                     // :1559-1561
-                                else if (kind == 0) qi[c] = qs;
-                                else if (kind == 2) { allele[c] = 1; qv[c] = -4; }
-                            }
-                        }
-                    }
-                }
-            }
-            // ---- C: base and quality at the variant site, one 128-byte line for both; all requests before the first is looked at
-            int code[NC], qual[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) sq_fetch(R.sq, qi[c] >= 0 ? blk[c] : 0u, max(qi[c], 0), code[c], qual[c]);   // (lanes with nothing to fetch read the array's first line)
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-                if (qi[c] >= 0) {
-                    const char ref_c = (char)(at[c] & 0xff), alt_c = (char)((at[c] >> 8) & 0xff);
-                    const char base_c = nt16_char(code[c]);
-                    qv[c] = qual[c];
-                    if (base_c == ref_c) allele[c] = 0; else if (base_c == alt_c) allele[c] = 1;
-                }
-            // ---- D: rows, slots, records, counts
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int ib = i0 + 64 * c;
-                const bool pre = in[c] && allele[c] != -1;                // an observation before filterSNP
-                const bool ok = pre && !erased[c];
-                const unsigned long long pm = __ballot(pre), om = __ballot(ok);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int a = max(cum[k] - ib, 0), b = min(cum[k + 1] - ib, 64);   // lanes of row k in this part of the round
-                    if (b > a) {
-                        const unsigned long long rm = ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << a) - 1ull);
-                        n_emit[k] += __popcll(om & rm); if (pm & rm) any_pre |= 1u << k;
-                    }
-                }
-                if (ib == 0) {                                            // the reservation has had the first round's searches to arrive
-                    off = __shfl(off, 0);
-                    if (off + (unsigned long long)T > O.arena_size) arena_full = true;
-                    g0 = arena_lo + off; dst = O.rec + g0;
-                }
-                const bool put = ok && !arena_full;
-                const uint32_t slot = (uint32_t)(n_out + __popcll(om & lanemask_lt())), aqw = (uint32_t)pack_aq(allele[c], qv[c]);
-                unsigned rk = 0;
-                if (put) { dst[slot] = ObsRec{(int32_t)v[c], aqw}; if (var_cnt) rk = atomicAdd(&var_cnt[v[c]], 1u); }
-                if (pend[c]) { if (pend_rk[c] > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); dst[pend_slot[c]].aq = pend_aq[c] | (pend_rk[c] << 10); }
-                pend[c] = put && var_cnt != nullptr; pend_slot[c] = slot; pend_aq[c] = aqw; pend_rk[c] = rk;
-                n_out += __popcll(om);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-            if (pend[c]) { if (pend_rk[c] > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); dst[pend_slot[c]].aq = pend_aq[c] | (pend_rk[c] << 10); }
-#else
         uint2 pvr = V.rec[min(SELC(l, cum, vadj) + l, V.n - 1)];           // records are requested one round ahead
         // an observation is counted where it is made: what the counting atomic returns is its rank inside the variant's list of observations, kept
         // beside allele and quality - the node-major lists are filled later without a counting pass and without a second atomic.  The atomic's
@@ -569,32 +323,24 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
                 const int2 base = s_tab[hc0 + co];
                 const int x0 = (8 * (hc0 + co)) << shift;                  // stream index of the chunk's first word
                 // the op that covers the variant: the last one that starts at or before it.  Starts never decrease, so "starts at or before" holds
-                // for a prefix of the words: words of the alignment before (they end where this one begins) pass the test and are overtaken by this
-                // alignment's first op, words past its end start at its end, beyond every candidate - whatever they hold
+                // for a prefix of the words; the padding past the alignment's last word starts at its end, beyond every candidate
                 int rr = base.x, qq = base.y, jx = x0, rs = base.x, qs = base.y; uint32_t wj = 6u, wn = 6u;
                 auto walk8 = [&](const uint32_t (&w)[9], int xb) __attribute__((always_inline)) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const bool le = rr <= ps;
                         jx = le ? xb + k : jx; rs = le ? rr : rs; qs = le ? qq : qs; wj = le ? w[k] : wj; wn = le ? w[k + 1] : wn;
-                        const unsigned t = op_consume_bits(w[k] & 15u); const int len = (int)(w[k] >> 4);
-                        rr += len & bit_mask(t, 0); qq += len & bit_mask(t, 16);
+                        const unsigned len = w[k] >> 4;                  // (below 2^24: the walk sent everything else to the general walker)
+                        rr += (int)__umul24(len, op_bit(LPS_RMASK2, w[k])); qq += (int)__umul24(len, op_bit(LPS_QMASK2, w[k]));
                     }
                 };
-                if (in_lds) {
+                for (int u = 0; u < (1 << shift); ++u) {                      // the entry's 8 << shift words, 8 at a time, until the walk is past the variant (one trip unless LONG)
+                    const uint32_t *cw = cg + x0 + 8 * u;
                     uint32_t w[9];
-                    const uint4 a = *reinterpret_cast<const uint4 *>(s_words + x0), b = *reinterpret_cast<const uint4 *>(s_words + x0 + 4);
-                    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = s_words[x0 + 8];
-                    walk8(w, x0);
-                } else {
-                    for (int u = 0; u < (1 << shift); ++u) {                  // the entry's 8 << shift words, 8 at a time, until the walk is past the variant
-                        const uint32_t *cw = cg + x0 + 8 * u;
-                        uint32_t w[9];
-                        const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cw), b = *reinterpret_cast<const LpsU4 *>(cw + 4);
-                        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = cw[8];
-                        walk8(w, x0 + 8 * u);
-                        if (rr > ps || x0 + 8 * u + 8 >= hcrel + hncig) break;
-                    }
+                    const uint4 a = *reinterpret_cast<const uint4 *>(cw), b = *reinterpret_cast<const uint4 *>(cw + 4);
+                    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = cw[8];
+                    walk8(w, x0 + 8 * u);
+                    if (rr > ps || x0 + 8 * u + 8 >= hcrel + hncig) break;
                 }
                 const int j = jx - x0;
                 const int op = wj & 15, len = (int)(wj >> 4);
@@ -624,11 +370,7 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
                     if (qi >= 0) {                                                // base and quality at the variant site: one 128-byte line holds both
                         const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
                         int code;
-#if EXT_ABL == 2
-                        code = (qi & 3) ? 1 : 2; qv = 20 + (qi & 7);
-#else
                         sq_fetch(R.sq, s_hdr[q].blk0, qi, code, qv);
-#endif
                         const char base_c = nt16_char(code);
                         if (base_c == ref_c) allele = 0; else if (base_c == alt_c) allele = 1;
                     }
@@ -653,25 +395,13 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
             const bool put = ok && !arena_full;
             const uint32_t slot = (uint32_t)(n_out + __popcll(om & lanemask_lt())), aqw = (uint32_t)pack_aq(allele, qv);
             unsigned rk = 0;
-#if EXT_ABL == 1
-            if (put) { dst[slot] = ObsRec{(int32_t)v, aqw}; rk = slot; }
-#elif EXT_ABL == 3
-            if (put) { if (var_cnt) rk = atomicAdd(&var_cnt[v], 1u); }
-#else
             if (put) { dst[slot] = ObsRec{(int32_t)v, aqw}; if (var_cnt) rk = atomicAdd(&var_cnt[v], 1u); }
-#endif
-#if EXT_ABL == 3 || EXT_ABL == 4
-            if (pend && pend_rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE);
-            if (0) {
-#else
             if (pend) {
-#endif
                 if (pend_rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); dst[pend_slot].aq = pend_aq | (pend_rk << 10); }
             pend = put && var_cnt != nullptr; pend_slot = slot; pend_aq = aqw; pend_rk = rk;
             n_out += __popcll(om);
         }
         if (pend) { if (pend_rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); dst[pend_slot].aq = pend_aq | (pend_rk << 10); }
-#endif
         if (__ballot(fail)) {
             // get_snp returned early somewhere in these alignments (SEQ shorter than the CIGAR says: the read is dropped but clips of earlier ops
             // stay): the general walker replays the whole job.  Nothing a later stage looks at has been written, but the observations made so far
@@ -692,7 +422,6 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
             to_redo();
             return;
         }
-        EXT_TICK(3)
         // rows of the group's alignments: back to back in the group's reservation
         if (h_in) {
             int before = 0, mine = 0;
@@ -700,11 +429,9 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
             for (int k = 0; k < 4; ++k) { if (k < l) before += n_emit[k]; if (k == l) mine = n_emit[k]; }
             row_off = (uint32_t)(g0 + (unsigned)before); row_cnt = mine; row_flags = (((any_pre >> l) & 1u) && mine == 0) ? 1u : 0u;
         }
-        // the group's clip events: stream coordinate -> reference position, alignment of the job -> alignment index
-        if (l >= n_clip0 && l < n_clip) { ClipEv e = s_clip[l]; const int q = e.read; e.pos -= s_hdr[q].ds; e.read = r0 + q; s_clip[l] = e; }
         wave_sync();                                                      // the table and the headers are reused by the next group
     }
-    if ((arena_full || bad_cigar) && l == 0) atomicOr(&cnt->err, (arena_full ? (unsigned)LPS_ERR_OBS_OVERFLOW : 0u) | (bad_cigar ? (unsigned)LPS_ERR_BAD_CIGAR : 0u));   // (overflow: the host grows the arenas and reruns)
+    if (arena_full && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW);          // the host grows the arenas and reruns
     if (l < nq) {
         const bool ok = h_live && !arena_full;
         O.rows[r0 + l] = RowDesc{ok ? row_off : 0u, ok ? row_cnt : 0, 0x7fffffff, ok ? row_flags : 0u};
@@ -715,10 +442,6 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         cb = __shfl(cb, 0);
         if (l < n_clip && cb + (unsigned)l < C.capacity) C.ev[cb + l] = s_clip[l];
     }
-    EXT_TICK(4)
-#ifdef EXT_PROFILE
-    if (l == 0) atomicAdd(&g_ext_prof[5], 1ull);
-#endif
 }
 
 #define REDO_CAP 512    // observations buffered per wave of the redo kernel
@@ -1039,10 +762,5 @@ void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O,
     const int n_jobs = (R.n + EXT_RPW - 1) / EXT_RPW;
     hipLaunchKernelGGL(k_extract_phase, dim3(n_jobs), dim3(64), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo, var_cnt, var_del);
     // jobs the lane-chunk table could not hold queued themselves (an alignment of more than ~200 kb of CIGAR; none with ordinary read lengths): a small grid drains the queue
-#ifdef EXT_PROFILE
-    { static int calls = 0; unsigned long long h[8];
-      if (++calls == 8) { (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ext_prof), sizeof h);
-          fprintf(stderr, "[ext profile] %d calls, %llu jobs: ticks per job: plan %.0f walk %.0f bounds+count %.0f passes %.0f tail %.0f (s_memtime ticks at 100 MHz)\n", calls, h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5]); } }
-#endif
     hipLaunchKernelGGL(k_extract_redo, dim3(std::min(256, (n_jobs + 3) / 4)), dim3(256), 0, s, V, R, O, C, mapping_quality, cnt, redo_list, n_redo, var_cnt, var_del);
 }

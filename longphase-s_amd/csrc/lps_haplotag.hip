@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
 }
 
 // ---- germline haplotag as a STREAM walk (the extraction's design, lps_extract.hip): a wave takes FOUR consecutive alignments, their CIGAR words
-// are one stream taken 512 words per round (8 per lane), one pair of DPP scans gives every lane-chunk its stream coordinates (8 bytes to LDS), and
+// (in lane-chunks, lps_reads.hip) are one stream taken 512 words per round (8 per lane), one pair of DPP scans gives every lane-chunk its stream coordinates (8 bytes to LDS), and
 // when the words are through the phased variants under the four alignments are taken 64 at a time as one flattened list, every lane busy:
 // chunk search, the chunk's words, an 8-step walk to the op that covers the variant, judgeSnpHap / judgeDeletionHap (HaplotagStrategy.cpp:20-209),
 // votes and phase sets reduced per alignment with ballots.  judgeReadHap (:243-300) follows right there and the four 16-byte records of the job
@@ -266,17 +266,17 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
 #define HTG_TAB 1024
 #endif
 __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary, LpsCounters *cnt) {
-    __shared__ __attribute__((aligned(16))) int2 s_tab[HTG_TAB];
+    __shared__ __attribute__((aligned(16))) int2 s_tab[HTG_TAB + 1];
     __shared__ ExtHdr s_hdr[4];
     const int l = lane_id();
     const int r0 = xcd_unit((int)blockIdx.x, (int)gridDim.x) * 4;        // XCD-aware: neighbouring jobs write neighbouring result lines into one L2
     if (r0 >= R.n) return;
     const int nq = min(4, R.n - r0);
     // ---- plan: headers, alignment q in lane q; the filter cascade of processSingleChrom (HaplotagParsingBam.cpp:453-486)
-    int h_start = 0, h_lq = 0, h_status = 0, h_v0 = 0; unsigned long long h_coff = 0, h_soff = 0;
-    if (l <= nq) h_coff = R.cigar_off[r0 + l];
+    int h_start = 0, h_lq = 0, h_status = 0, h_v0 = 0, h_n = 0; unsigned h_cp = 0; unsigned long long h_soff = 0;
+    if (l <= nq) h_cp = R.cp_off[r0 + l];
     if (l < nq) {
-        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r]; h_v0 = V.n ? R.v0[r] : 0;
+        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r]; h_v0 = V.n ? R.v0[r] : 0; h_n = R.cp_n[r];
         const int flag = R.flag[r];
         if (R.mapq[r] < mapping_quality) h_status = 1;
         else if (flag & 0x4) h_status = 2;
@@ -288,122 +288,77 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
     const bool h_live = l < nq && h_status == 0;
     bool bad_cigar = false;
     const unsigned live_mask = (unsigned)__ballot(h_live) & 15u;
-    const int h_ncig_all = (int)(long long)(__shfl_down(h_coff, 1) - h_coff);   // (lanes < nq)
+    const int h_nch = (int)(__shfl_down(h_cp, 1) - h_cp);                 // chunks of alignment q (lanes < nq)
     int vh1[4] = {0, 0, 0, 0}, vh2[4] = {0, 0, 0, 0}, plo[4], phi[4];      // per alignment: votes, smallest / largest phase set seen (wave-uniform)
 #pragma unroll
     for (int q = 0; q < 4; ++q) { plo[q] = 0x7fffffff; phi[q] = (int)0x80000000; }
     unsigned todo = live_mask;
 #pragma unroll 1
     while (todo) {
-        // ---- the job's alignments in groups whose CIGAR words fit the table together (nearly always one group of four); an alignment that alone
-        //      does not fit is walked with one table entry per 8 << shift words (see k_extract_phase)
+        // ---- the job's alignments in groups whose chunks fit the table together (nearly always one group of four); an alignment that alone does
+        //      not fit is walked with one table entry per 1 << shift chunks (see k_extract_phase)
         const int qa = __builtin_ctz(todo);
-        const unsigned long long c_lo = __shfl(h_coff, qa);
+        const unsigned c_lo = __shfl(h_cp, qa);
         int qb = qa; unsigned gm = 1u << qa;
         for (int q = qa + 1; q < nq; ++q) {
             if (!((todo >> q) & 1u)) continue;
-            const long long span = (long long)(__shfl(h_coff, q + 1) - c_lo);
-            if (((span + 7) >> 3) > HTG_TAB) break;
+            if (__shfl(h_cp, q + 1) - c_lo > (unsigned)HTG_TAB) break;
             gm |= 1u << q; qb = q;
         }
         todo &= ~gm;
         int shift = 0;
-        { const long long w1 = (long long)(__shfl(h_coff, qa + 1) - c_lo); while ((((w1 + 7) >> 3) + ((1ll << shift) - 1)) >> shift > HTG_TAB) ++shift; }
+        { const unsigned n1 = __shfl(h_cp, qa + 1) - c_lo; while (((n1 + (1u << shift) - 1u) >> shift) > (unsigned)HTG_TAB) ++shift; }
         const bool fast = shift == 0;
         const bool h_in = l < 4 && ((gm >> l) & 1u);
-        const int h_rel = (l <= nq) ? (int)(long long)(h_coff - c_lo) : 0;
-        const int h_ncig = h_ncig_all;
-        const uint32_t *cg = R.cigar + c_lo;
-        const int total = __builtin_amdgcn_readlane(h_rel + h_ncig, qb);
-        const int TC = (total + 7) >> 3;
+        const bool h_walk = h_in && h_n > 0;
+        const int h_c0 = (l <= nq) ? (int)(h_cp - c_lo) : 0;              // first chunk of alignment q inside the stream
+        const uint32_t *cg = R.cigp + 8ull * c_lo;
+        const int TC = __builtin_amdgcn_readlane(h_c0 + h_nch, qb);       // chunks of the stream
         auto request = [&](int cid, uint32_t (&w)[8]) __attribute__((always_inline)) {          // unconditional, clamped (see k_extract_phase)
             const uint32_t *p = cg + 8 * min(cid, max(TC - 1, 0));
-            const LpsU4 a = *reinterpret_cast<const LpsU4 *>(p), b = *reinterpret_cast<const LpsU4 *>(p + 4);
+            const uint4 a = *reinterpret_cast<const uint4 *>(p), b = *reinterpret_cast<const uint4 *>(p + 4);
             w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
         };
-        uint32_t wa[8], wb[8];                                            // two buffers taken in turn (see the walk of k_extract_phase)
-        request(l, wa);
-        const bool h_walk = h_in && h_ncig > 0;
-        const int x_end = h_rel + h_ncig - 1;
-        const int cs = (h_walk && fast) ? h_rel >> 3 : 0, ce = (h_walk && fast) ? x_end >> 3 : 0;
-        if (l < 4) {
-            ExtHdr &h = s_hdr[l];
-            h.crel = h_rel; h.ncig = h_walk ? h_ncig : 0; h.c0 = cs; h.nch = h_walk ? (fast ? ce - cs + 1 : (((h_ncig + 7) >> 3) + (1 << shift) - 1) >> shift) : 0;
-            h.lq = h_lq; h.blk0 = (unsigned)h_soff; h.pad0 = (unsigned)(h_soff >> 32);
-        }
-        wave_sync();
-        // ---- walk
-        int carry_r = 0, carry_q = 0; bool absurd = false;
-        auto walk_round = [&](const uint32_t (&win)[8], const int R0) __attribute__((always_inline)) {
-            const int cid = R0 + l;
-            uint32_t w[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) w[k] = win[k];
-            if (R0 + 64 >= TC) {
-                const int nv = total - 8 * cid;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) w[k] = k < nv ? w[k] : 6u;
-            }
-            int rt = 0, qt = 0; unsigned seen = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const unsigned op = w[k] & 15u;
-                const unsigned t = op_consume_bits(op); const int len = (int)(w[k] >> 4);
-                rt += len & bit_mask(t, 0); qt += len & bit_mask(t, 16);
-                seen |= 1u << op;
-            }
-            const int ir = wave_incl_scan_dpp(rt), iq = wave_incl_scan_dpp(qt);
-            const int my_s = carry_r + ir - rt, my_q = carry_q + iq - qt;
-            if (fast) { if (cid < TC) s_tab[cid] = make_int2(my_s, my_q); }
-            else if (cid < TC && (cid & ((1 << shift) - 1)) == 0) s_tab[cid >> shift] = make_int2(my_s, my_q);
-            carry_r += __builtin_amdgcn_readlane(ir, 63); carry_q += __builtin_amdgcn_readlane(iq, 63);
-            if ((unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu) { absurd = true; return; }
-            if (__ballot((seen & LPS_OPS_BAD) != 0u)) {                   // an op code the reference rejects, in an alignment that is walked (rare path)
-                bool bad = false;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int x = 8 * cid + k; bool inq = false;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) inq |= x >= s_hdr[q].crel && x < s_hdr[q].crel + s_hdr[q].ncig;
-                    bad |= inq && (w[k] & 15u) > 8u;
-                }
-                bad_cigar |= __ballot(bad) != 0ull;                       // (reported once, at the end: no store inside the loop)
-            }
-        };
-        // two rounds per trip, one way out, the same loads in flight whichever way a trip went (see k_extract_phase)
-#pragma unroll 1
-        for (int R0 = 0; R0 < TC; R0 += 128) {
-            request(R0 + 64 + l, wb);
-            walk_round(wa, R0);
-            request(R0 + 128 + l, wa);
-            walk_round(wb, R0 + 64);
-            if (absurd) break;
-        }
-        drain8(wa);
-        if (absurd) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); break; }   // stream coordinates beyond 2^30: reference spans no aligner produces
-        wave_sync();
-        // the words in front of each alignment's first and up to its last word inside their lane-chunks, the first 64 candidate positions of each:
-        // requested only now (from the caches), so that the walk has nothing in flight but its own two buffers
-        int adv_r = 0, adv_q = 0, end_r = 0;
-        {
-            const int ks = h_rel & 7, ke = (x_end & 7) + 1;
-            const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs), b = *reinterpret_cast<const LpsU4 *>(cg + 8 * cs + 4);
-            const LpsU4 c = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce), d = *reinterpret_cast<const LpsU4 *>(cg + 8 * ce + 4);
-            const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, we[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const unsigned t1 = op_consume_bits(ws[m] & 15u), t2 = op_consume_bits(we[m] & 15u);
-                const int l1 = m < ks ? (int)(ws[m] >> 4) : 0, l2 = m < ke ? (int)(we[m] >> 4) : 0;
-                adv_r += l1 & bit_mask(t1, 0); adv_q += l1 & bit_mask(t1, 16); end_r += l2 & bit_mask(t2, 0);
-            }
-        }
+        // the first 64 candidate positions of each alignment: requested ahead of the walk, looked at after it
         int v0q[4], pp[4]; bool walkq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { v0q[q] = __builtin_amdgcn_readlane(h_v0, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; pp[q] = V.n ? V.pos[min(v0q[q] + l, V.n - 1)] : 0x7fffffff; }
+        if (l < 4) {
+            ExtHdr &h = s_hdr[l];
+            h.crel = fast ? 8 * h_c0 : 0; h.ncig = h_walk ? h_n : 0; h.c0 = fast ? h_c0 : 0; h.nch = h_walk ? (int)(((unsigned)h_nch + (1u << shift) - 1u) >> shift) : 0;
+            h.lq = h_lq; h.blk0 = (unsigned)h_soff; h.pad0 = (unsigned)(h_soff >> 32);
+        }
+        // ---- walk: four rounds per trip, all four requested at its head (see k_extract_phase); it counts the words whose op the reference rejects
+        int carry_r = 0, carry_q = 0; unsigned special = 0; uint32_t big = 0; bool absurd = false;
+#pragma unroll 1
+        for (int R0 = 0; R0 < TC; R0 += 256) {
+            uint32_t w0[8], w1[8], w2[8], w3[8];
+            request(R0 + l, w0); request(R0 + 64 + l, w1); request(R0 + 128 + l, w2); request(R0 + 192 + l, w3);
+            stream_round<LPS_BADMASK2>(w0, R0 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
+            stream_round<LPS_BADMASK2>(w1, R0 + 64 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
+            stream_round<LPS_BADMASK2>(w2, R0 + 128 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
+            stream_round<LPS_BADMASK2>(w3, R0 + 192 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
+            absurd |= (unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu;
+            if (absurd) break;
+        }
+        if (fast && l == 0) s_tab[TC] = make_int2(carry_r, carry_q);      // where the stream ends: the end of its last alignment
+        // stream coordinates beyond 2^30 or one op of 2^24 bases and more (the sums are 24-bit multiplies): reference spans no aligner produces
+        if (absurd || __ballot(big >= 0x10000000u)) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); break; }
+        if (__ballot(special != 0u)) {                                    // an op code the reference rejects: in an alignment that is walked? (rare path: the stream again)
+            bool bad = false;
+            for (int cid = l; cid < TC; cid += 64) {
+                bool inq = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) inq |= s_hdr[q].ncig > 0 && (!fast || (cid >= s_hdr[q].c0 && 8 * (cid - s_hdr[q].c0) < s_hdr[q].ncig));
+                for (int k = 0; k < 8; ++k) bad |= inq && op_bit(LPS_BADMASK2, cg[8 * cid + k]) != 0u;
+            }
+            bad_cigar |= __ballot(bad) != 0ull;
+        }
+        wave_sync();
         // ---- alignment bounds in stream coordinates, candidates of each: phased variants [v0, first variant at or beyond its reference end)
         int b_sat = 0, b_qat = 0, b_rend = h_start;
         if (h_walk) {
-            if (fast) { const int2 ts = s_tab[cs], te = s_tab[ce]; b_sat = ts.x + adv_r; b_qat = ts.y + adv_q; b_rend = h_start + te.x + end_r - b_sat; }
+            if (fast) { const int2 ts = s_tab[h_c0], te = s_tab[h_c0 + h_nch]; b_sat = ts.x; b_qat = ts.y; b_rend = h_start + te.x - ts.x; }
             else b_rend = h_start + carry_r;
         }
         int ncand[4], rend[4];
@@ -454,14 +409,14 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
                     for (int k = 0; k < 8; ++k) {
                         const bool le = rr <= ps;
                         jx = le ? xb + k : jx; rs = le ? rr : rs; qs = le ? qq : qs; wj = le ? w[k] : wj; wn = le ? w[k + 1] : wn;
-                        const unsigned t = op_consume_bits(w[k] & 15u); const int len = (int)(w[k] >> 4);
-                        rr += len & bit_mask(t, 0); qq += len & bit_mask(t, 16);
+                        const unsigned len = w[k] >> 4;                  // (below 2^24, see the walk)
+                        rr += (int)__umul24(len, op_bit(LPS_RMASK2, w[k])); qq += (int)__umul24(len, op_bit(LPS_QMASK2, w[k]));
                     }
                 };
                 for (int u = 0; u < (1 << shift); ++u) {                  // (one trip unless the alignment is walked in LONG mode)
                     const uint32_t *cw = cg + x0 + 8 * u;
                     uint32_t w[9];
-                    const LpsU4 a = *reinterpret_cast<const LpsU4 *>(cw), b = *reinterpret_cast<const LpsU4 *>(cw + 4);
+                    const uint4 a = *reinterpret_cast<const uint4 *>(cw), b = *reinterpret_cast<const uint4 *>(cw + 4);
                     w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = cw[8];
                     walk8(w, x0 + 8 * u);
                     if (rr > ps || x0 + 8 * u + 8 >= hcrel + hncig) break;

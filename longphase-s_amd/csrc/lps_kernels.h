@@ -34,11 +34,16 @@ struct ReadView {
     const uint8_t *seq, *qual;
     const uint8_t *sq;         // bases + qualities interleaved in 128-byte blocks of LPS_SQ_BASES bases (lps_reads.hip); read r starts at block sq_blk[r]
     const uint32_t *sq_blk;
+    const uint32_t *cigp;      // the CIGAR words in lane-chunks of 8, every alignment padded to a whole number of them (lps_reads.hip): read r = chunks [cp_off[r], cp_off[r + 1]), cp_n[r] words
+    const uint32_t *cp_off;
+    const int32_t *cp_n;
     const int32_t *v0;         // first variant at or after the alignment's start (k_read_v0: one thread per alignment, before the wave-per-job kernels)
 };
 #define LPS_SQ_BASES 84
 void launch_sq_count(int n, const int32_t *l_qseq, uint32_t *nblk, hipStream_t s);
 void launch_sq_pack(const ReadView &R, const uint32_t *blk, uint8_t *sq, hipStream_t s);
+void launch_cp_count(int n, const uint64_t *cigar_off, uint32_t *nch, int32_t *ncig, unsigned *too_long, hipStream_t s);
+void launch_cp_pack(int n, const uint64_t *cigar_off, const uint32_t *cigar, const uint32_t *cp_off, uint32_t *cigp, hipStream_t s);
 #ifdef __HIPCC__
 // base code (4 bits) and quality of query index qi of a read whose first block is at `blk0`: both from ONE 128-byte line
 __device__ __forceinline__ void sq_fetch(const uint8_t *__restrict__ sq, uint32_t blk0, int qi, int &code, int &qual) {
@@ -134,6 +139,36 @@ __device__ __forceinline__ void load_ops8(const uint32_t *cig, int i0, int n, ui
 // bit 0: the op consumes the reference (M D N = X: 0x18D), bit 16: it consumes the query (M I S = X: 0x193); ops 9..15 consume nothing
 __device__ __forceinline__ unsigned op_consume_bits(unsigned op) { return ((0x193u << 16) | 0x18Du) >> op; }
 __device__ __forceinline__ int bit_mask(unsigned x, int bit) { return (int)(x << (31 - bit)) >> 31; }      // 0 or -1 (v_bfe_i32)
+
+// ---- the stream walk of k_extract_phase / k_haplotag_stream over CIGAR words in lane-chunks (lps_reads.hip)
+// Properties of an op as ONE v_bfe_u32 on the raw word: the instruction takes bits [4:0] of the word as bit index - the op code plus 16 x (bit 0 of the
+// length) - into a mask that repeats the 16 per-op bits in both halves.  No `& 15`, no shifted table.
+#define LPS_RMASK2 0x018D018Du      // consumes the reference: M D N = X
+#define LPS_QMASK2 0x01930193u      // consumes the query:     M I S = X
+#define LPS_CLIPMASK2 0x00300030u   // S H
+#define LPS_BADMASK2 0xfe00fe00u    // op codes the reference rejects (ParsingBam.cpp:1625-1628)
+__device__ __forceinline__ unsigned op_bit(unsigned mask2, uint32_t word) { return __builtin_amdgcn_ubfe(mask2, word, 1u); }
+__device__ __forceinline__ int ref_len_of(uint32_t w) { return (int)(w >> 4) & -(int)op_bit(LPS_RMASK2, w); }
+// One round: the lane's 8 words (lane-chunk cid of a stream of TC chunks) -> its reference / query advance, scanned over the wave into the stream
+// coordinates of the chunk's first word (table entry cid >> shift, for chunks that are multiples of 1 << shift), the carries moved on.  `special`
+// counts the words whose op is in SPECIAL2, `big` ORs the words: lengths of 2^24 and more (bit 28 and up) are outside the 24-bit multiply below
+// and send the job to the general walker.  Lanes past the stream's end hold a copy of its last chunk and count for nothing.
+template <unsigned SPECIAL2>
+__device__ __forceinline__ void stream_round(const uint32_t (&w)[8], const int cid, const int TC, const int shift, int2 *s_tab, int &carry_r, int &carry_q,
+                                             unsigned &special, uint32_t &big) {
+    unsigned rt = 0, qt = 0, sp = 0; uint32_t bg = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t x = w[k]; const unsigned len = x >> 4;
+        rt = __umul24(len, op_bit(LPS_RMASK2, x)) + rt; qt = __umul24(len, op_bit(LPS_QMASK2, x)) + qt;
+        sp += op_bit(SPECIAL2, x); bg |= x;
+    }
+    const bool live = cid < TC;
+    rt = live ? rt : 0u; qt = live ? qt : 0u; special += live ? sp : 0u; big |= live ? bg : 0u;
+    const int ir = wave_incl_scan_dpp((int)rt), iq = wave_incl_scan_dpp((int)qt);
+    if (live && (cid & ((1 << shift) - 1)) == 0) s_tab[cid >> shift] = make_int2(carry_r + ir - (int)rt, carry_q + iq - (int)qt);
+    carry_r += __builtin_amdgcn_readlane(ir, 63); carry_q += __builtin_amdgcn_readlane(iq, 63);
+}
 
 // Stages the segment whose words are in w (lane l owns ops 8l..8l+7 of it) in LDS: sref/sqry = reference / query position at which the op
 // starts, scig = the raw word.  ref_pos / q_pos (wave-uniform) advance over the segment.  Returns, per lane, the set of op codes its 8 words

@@ -51,3 +51,32 @@ void launch_sq_pack(const ReadView &R, const uint32_t *blk, uint8_t *sq, hipStre
     if (R.n == 0) return;
     hipLaunchKernelGGL(k_sq_pack, dim3((unsigned)std::min(65536, (R.n + 3) / 4)), dim3(256), 0, s, R.n, R.l_qseq, R.seq_off, R.qual_off, R.seq, R.qual, blk, sq);
 }
+
+// ---- CIGAR words in lane-chunks: every alignment's words start on a multiple of 8 words and are padded to one with op P, length 0 (6u: consumes
+// nothing, neither a clip nor an op the reference rejects).  The stream walk of k_extract_phase / k_haplotag_stream takes 8 words per lane: with
+// this layout an alignment begins and ends ON a lane-chunk - its stream coordinates are table entries, no partial sums, no blanking of a tail, no
+// separate loads for its first and last chunk.  +0.5 % of words at ONT read lengths; built once per chromosome like the blocks above.
+__global__ void k_cp_count(int n, const uint64_t *cigar_off, uint32_t *nch, int32_t *ncig, unsigned *too_long) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { nch[i] = 0u; return; }
+    const uint64_t w = cigar_off[i + 1] - cigar_off[i];
+    if (w > 0x7fffffffull) { atomicOr(too_long, 1u); nch[i] = 0u; ncig[i] = 0; return; }
+    nch[i] = (uint32_t)((w + 7) >> 3); ncig[i] = (int32_t)w;
+}
+__global__ __launch_bounds__(256) void k_cp_pack(int n, const uint64_t *cigar_off, const uint32_t *cigar, const uint32_t *cp_off, uint32_t *cigp) {
+    const int l = lane_id();
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += gridDim.x * 4) {
+        const uint32_t c0 = cp_off[r], nw = (cp_off[r + 1] - c0) * 8u;
+        const uint64_t o = cigar_off[r]; const uint32_t nreal = (uint32_t)(cigar_off[r + 1] - o);
+        uint32_t *dst = cigp + (size_t)c0 * 8;
+        for (uint32_t i = l; i < nw; i += 64u) dst[i] = i < nreal ? cigar[o + i] : 6u;
+    }
+}
+void launch_cp_count(int n, const uint64_t *cigar_off, uint32_t *nch, int32_t *ncig, unsigned *too_long, hipStream_t s) {
+    hipLaunchKernelGGL(k_cp_count, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, n, cigar_off, nch, ncig, too_long);
+}
+void launch_cp_pack(int n, const uint64_t *cigar_off, const uint32_t *cigar, const uint32_t *cp_off, uint32_t *cigp, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_cp_pack, dim3((unsigned)std::min(65536, (n + 3) / 4)), dim3(256), 0, s, n, cigar_off, cigar, cp_off, cigp);
+}
