@@ -963,7 +963,7 @@ static int run_phase(lps_ctx *c) {
         c->g_cnt.reserve(nR + 1);
         c->obs.reserve(cap); c->g_pack.reserve(cap); c->g_rank.reserve(cap);
         c->t_node.reserve(tail_size + 64); c->t_flag.reserve(tail_size + 64); c->t_src.reserve(tail_size + 64);
-        c->clip_capacity = (size_t)4 * nR + 64;                             // clip events (an alignment has two real clips at most; more only with H S ... S H)
+        c->clip_capacity = (size_t)EXT_CLIPS * ((nR + 3) / 4) + (size_t)4 * nR + 64;   // clip events: every extraction job's own slots, then room for what the general walker appends
         c->clip_ev.reserve(c->clip_capacity);
         c->clip_keys.reserve(c->clip_capacity); c->clip_keys_s.reserve(c->clip_capacity);
         c->name_link.reserve(nR + 1); c->mm_r.reserve(nR + 1); c->stack.reserve(nR + 1);
@@ -1011,7 +1011,7 @@ static int run_phase(lps_ctx *c) {
         c->name_p = dense ? c->r_name.p : c->name_dense.p;
         // ---- a1/a2/a3 extraction; with no SV / MOD rows every observation is counted (and ranked inside its variant's list) right there
         ObsView O{c->rows.p, c->obs.p, arena_size, c->arena_ctr.p, n_arenas};
-        ClipView C{c->clip_ev.p, c->clip_stats.p, (unsigned)c->clip_capacity};            // clip_stats[0]: events appended, [1]: jobs queued for k_extract_redo (zero pool)
+        ClipView C{c->clip_ev.p, c->clip_stats.p, (unsigned)c->clip_capacity, (unsigned)(EXT_CLIPS * ((nR + 3) / 4))};            // clip_stats[0]: events appended by the general walker, [1]: jobs queued for it (zero pool)
         mark(c, ST_EXTRACT);
         launch_read_v0(V, R, c->r_v0.p, s);
         launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, c->redo_list.p, c->clip_stats.p + 1, c->nX ? nullptr : c->var_cnt.p, c->var_del.p, s);
@@ -1020,6 +1020,7 @@ static int run_phase(lps_ctx *c) {
             if (extract_only) {
                 HIP_TRY(hipEventRecord(c->ev_end, s)); HIP_TRY(hipStreamSynchronize(s));
                 float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[ST_EXTRACT], c->ev_end)); c->tm.ms_kernel[ST_EXTRACT] = ms;
+                { unsigned st[2] = {0, 0}; HIP_TRY(hipMemcpy(st, c->clip_stats.p, sizeof st, hipMemcpyDeviceToHost)); static int said = 0; if (!said++) fprintf(stderr, "[extract only] clip events %u, jobs sent to the general walker %u of %d\n", st[0], st[1], (nR + 3) / 4); }
                 return 77;
             }
         }

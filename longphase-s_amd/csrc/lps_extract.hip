@@ -98,7 +98,6 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 #ifndef EXT_GROUP_MAX
 #define EXT_GROUP_MAX 4 // alignments walked together (their candidates are resolved together once their words are through)
 #endif
-#define EXT_CLIPS 16    // clip events buffered per wave
 
 
 // One wavefront = one job of four consecutive alignments; their CIGAR words lie back to back in lane-chunks of 8, each alignment padded to a whole
@@ -141,7 +140,8 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
     if (r0 >= R.n) return;
     const int nq = min(EXT_RPW, R.n - r0);
     static_assert(EXT_RPW == 4, "lane layout of the planning step");
-    auto to_redo = [&]() __attribute__((always_inline)) { if (l == 0) redo_list[atomicAdd(n_redo, 1u)] = (uint32_t)job; };
+    auto no_clips = [&]() __attribute__((always_inline)) { if (l < EXT_CLIPS) C.ev[(size_t)EXT_CLIPS * job + l] = ClipEv{0, 0, -1}; };   // the job's slots of the clip list hold nothing
+    auto to_redo = [&]() __attribute__((always_inline)) { no_clips(); if (l == 0) redo_list[atomicAdd(n_redo, 1u)] = (uint32_t)job; };
 
     // ---- plan: headers, alignment q in lane q.  direct_detect_alleles filters (:1282-1291) + region "chr:1-<lastSNPPos>" (:1273)
     int h_start = 0, h_lq = 0, h_v0 = 0, h_n = 0; bool h_live = false; unsigned h_cp = 0, h_blk = 0;
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
     const unsigned live_mask = (unsigned)__ballot(h_live) & 15u;
     if (!live_mask) {                                                  // nothing to walk: four empty rows
         if (l < nq) O.rows[r0 + l] = RowDesc{0u, 0, 0x7fffffff, 0u};
+        no_clips();
         return;
     }
     const int h_nch = (int)(__shfl_down(h_cp, 1) - h_cp);             // chunks of alignment q (lanes < nq)
@@ -436,12 +437,7 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         const bool ok = h_live && !arena_full;
         O.rows[r0 + l] = RowDesc{ok ? row_off : 0u, ok ? row_cnt : 0, 0x7fffffff, ok ? row_flags : 0u};
     }
-    if (n_clip > 0 && !arena_full) {
-        unsigned cb = 0;
-        if (l == 0) cb = atomicAdd(C.n_ev, (unsigned)n_clip);
-        cb = __shfl(cb, 0);
-        if (l < n_clip && cb + (unsigned)l < C.capacity) C.ev[cb + l] = s_clip[l];
-    }
+    if (l < EXT_CLIPS) C.ev[(size_t)EXT_CLIPS * job + l] = (l < n_clip && !arena_full) ? s_clip[l] : ClipEv{0, 0, -1};   // the job's own slots: no counter (ClipView)
 }
 
 #define REDO_CAP 512    // observations buffered per wave of the redo kernel
@@ -573,7 +569,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
                         const uint32_t wd = scig[8 * l + k]; const unsigned op = wd & 15u;
                         if ((op == 4u || op == 5u) && (wd >> 4) > 5u) {
                             const int oi = seg0 + 8 * l + k;
-                            const unsigned e = atomicAdd(C.n_ev, 1u);               // (rare path: one atomic per event)
+                            const unsigned e = C.fixed + atomicAdd(C.n_ev, 1u);     // (rare path: one atomic per event, behind the jobs' own slots)
                             if (e < C.capacity) C.ev[e] = ClipEv{sref[8 * l + k], (oi << 1) | (oi != 0), r};
                         }
                     }

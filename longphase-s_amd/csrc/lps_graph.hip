@@ -67,26 +67,26 @@ __global__ __launch_bounds__(256) void k_name_link(int n_reads, const uint32_t *
         }
         return;
     }
-    const unsigned n_ev = min(*C.n_ev, C.capacity);
+    const unsigned n_ev = C.fixed + min(*C.n_ev, C.capacity - C.fixed);    // the jobs' own slots (unused ones hold read = -1), then what the general walker appended
     const unsigned cb = blockIdx.x - nb_reads - 1, n_cb = gridDim.x - nb_reads - 1;
-    for (unsigned base = cb * blockDim.x; base < n_ev; base += n_cb * blockDim.x) {     // uniform per workgroup
-        const unsigned e = base + threadIdx.x;
-        bool keep = false; unsigned long long key = 0;
-        if (e < n_ev) {
-            const ClipEv ev = C.ev[e];
-            keep = (ev.opidx_fb >> 1) < rows[ev.read].fail;
-            key = ((unsigned long long)(unsigned)ev.pos << 1) | (unsigned)(ev.opidx_fb & 1);
-        }
-        const unsigned long long m = __ballot(keep);
-        if (lane_id() == 0) s_wcnt[w] = (unsigned)__popcll(m);
-        __syncthreads();
-        if (threadIdx.x == 0) { const unsigned tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]; s_base = tot ? atomicAdd(&cnt->n_clips, tot) : 0u; }
-        __syncthreads();
-        unsigned off = s_base + (unsigned)__popcll(m & lanemask_lt()); for (int q = 0; q < w; ++q) off += s_wcnt[q];
-        if (keep) keys[off] = key;
-        __syncthreads();
-    }
-    if (cb == 0 && threadIdx.x == 0 && *C.n_ev > C.capacity) atomicOr(&cnt->err, (unsigned)LPS_ERR_CLIP_OVERFLOW);
+    // a workgroup takes ONE contiguous share of the slots: counts what it keeps, reserves once (atomics on one word are served one after the other:
+    // one per workgroup, not one per 256 slots), then goes over its share again (from the caches) and writes the keys
+    const unsigned per = (n_ev + n_cb - 1) / n_cb, lo = min(n_ev, cb * per), hi = min(n_ev, lo + per);
+    auto key_of = [&](unsigned e, unsigned long long &key) -> bool {
+        const ClipEv ev = C.ev[e];
+        key = ((unsigned long long)(unsigned)ev.pos << 1) | (unsigned)(ev.opidx_fb & 1);
+        return ev.read >= 0 && (ev.opidx_fb >> 1) < rows[max(ev.read, 0)].fail;
+    };
+    unsigned mine = 0; unsigned long long key;
+    for (unsigned e = lo + threadIdx.x; e < hi; e += blockDim.x) mine += key_of(e, key) ? 1u : 0u;
+    const unsigned incl = (unsigned)wave_incl_scan_dpp((int)mine);
+    if (lane_id() == 63) s_wcnt[w] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) { const unsigned tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]; s_base = tot ? atomicAdd(&cnt->n_clips, tot) : 0u; }
+    __syncthreads();
+    unsigned off = s_base + incl - mine; for (int q = 0; q < w; ++q) off += s_wcnt[q];
+    for (unsigned e = lo + threadIdx.x; e < hi; e += blockDim.x) if (key_of(e, key)) keys[off++] = key;
+    if (cb == 0 && threadIdx.x == 0 && *C.n_ev > C.capacity - C.fixed) atomicOr(&cnt->err, (unsigned)LPS_ERR_CLIP_OVERFLOW);
 }
 
 // Thread per alignment; the thread of the LAST alignment linked under a name that holds several (a few per workgroup) takes the group: its members

@@ -73,9 +73,14 @@ struct ObsView {           // rows placed by atomic reservation: row r = [rows[r
     int n_arenas;                       // arenas in use: min(LPS_ARENAS, workgroups)
 };
 
-struct ClipView {          // clip events of the kept alignments, appended (one reservation per wave that has any); filtered by RowDesc.fail afterwards
-    ClipEv *ev; unsigned *n_ev; unsigned capacity;
+// Clip events of the kept alignments (filtered by RowDesc.fail afterwards).  k_extract_phase writes the events of job j into ITS OWN slots
+// [EXT_CLIPS * j, EXT_CLIPS * (j + 1)) - a job holds at most that many - and marks the unused ones (read = -1): no counter.  (An appended list cost
+// one returning atomic per job on ONE word: ~11 ns each, served one after the other - 0.7 ms of a 1.2 ms kernel at chr1-50x, whatever the rest of
+// the kernel did.)  Only the general walker (k_extract_redo, rare) appends, behind the fixed part: slot `fixed` + atomicAdd(n_ev).
+struct ClipView {
+    ClipEv *ev; unsigned *n_ev; unsigned capacity; unsigned fixed;
 };
+#define EXT_CLIPS 16    // clip events a job of four alignments can hold: its alignments' first two and last two CIGAR words
 
 // SV / MOD rows of `phase --sv-file / --mod-file` (lps_extra.hip): both tables merged by position; u / snp_u = index of a row / of SNP row i in
 // the position-sorted union of all three tables, the index space of every stage after the extraction when such rows are present
