@@ -95,6 +95,9 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 #ifndef EXT_WAVES
 #define EXT_WAVES 4     // waves per SIMD the register budget is sized for: 128 VGPRs, no spills; 5 / 6 / 8 waves (spills, smaller tables) were measured slower
 #endif
+#ifndef EXT_TRIP
+#define EXT_TRIP 4      // rounds of the walk requested together (8 VGPRs each)
+#endif
 #ifndef EXT_GROUP_MAX
 #define EXT_GROUP_MAX 4 // alignments walked together (their candidates are resolved together once their words are through)
 #endif
@@ -216,13 +219,12 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         //      the loop), and the copy waits for the load there - a prefetch that overlaps nothing (seen in the ISA with one and with two buffers)
         int carry_r = 0, carry_q = 0; unsigned special = 0; uint32_t big = 0; bool absurd = false;
 #pragma unroll 1
-        for (int R0 = 0; R0 < TC; R0 += 256) {
-            uint32_t w0[8], w1[8], w2[8], w3[8];
-            request(R0 + l, w0); request(R0 + 64 + l, w1); request(R0 + 128 + l, w2); request(R0 + 192 + l, w3);
-            stream_round<LPS_CLIPMASK2 | LPS_BADMASK2>(w0, R0 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
-            stream_round<LPS_CLIPMASK2 | LPS_BADMASK2>(w1, R0 + 64 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
-            stream_round<LPS_CLIPMASK2 | LPS_BADMASK2>(w2, R0 + 128 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
-            stream_round<LPS_CLIPMASK2 | LPS_BADMASK2>(w3, R0 + 192 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
+        for (int R0 = 0; R0 < TC; R0 += 64 * EXT_TRIP) {
+            uint32_t wt[EXT_TRIP][8];
+#pragma unroll
+            for (int t = 0; t < EXT_TRIP; ++t) request(R0 + 64 * t + l, wt[t]);
+#pragma unroll
+            for (int t = 0; t < EXT_TRIP; ++t) stream_round<LPS_CLIPMASK2 | LPS_BADMASK2>(wt[t], R0 + 64 * t + l, TC, shift, s_tab, carry_r, carry_q, special, big);
             absurd |= (unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu;    // stream coordinates are 32-bit: absurd spans go to the general walker
             if (absurd) break;
         }
