@@ -237,6 +237,23 @@ def whole_node_baseline(dev, P, threads, seed, n_contigs=16, contig_mb=10):
                 continue
             f = ln.rstrip("\n").split("\t"); smp = f[9].split(":")
             want.setdefault(f[0], {})[int(f[1]) - 1] = (0 if smp[-1] == "." else int(smp[-1]), smp[0])
+        # ---- clock E: this repository's command line on the SAME files (BGZF blocks uploaded, inflated, scanned, decoded and phased on the GPU,
+        #      the VCF written by the host), against the reference's wall time above; the output must be the reference's, line for line
+        e_clock = None
+        cli = os.path.join(ROOT, "longphase-s_amd", "cli", "longphase_amd")
+        if os.path.exists(cli):
+            try:
+                gcmd = [cli, "phase", "-s", "in.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(threads), "-o", "outg", "--ont", "--gpu", str(dev)]
+                es = []
+                for _ in range(2):
+                    t0 = time.time(); r = subprocess.run(gcmd, cwd=d, capture_output=True); es.append(time.time() - t0)
+                    assert r.returncode == 0, r.stderr[-500:]
+                body = lambda p: [ln for ln in open(p) if not ln.startswith("##commandline=") and not ln.startswith("##longphaseVersion=")]  # noqa: E731
+                e_clock = dict(wall_s=round(min(es), 3), runs_s=[round(x, 3) for x in es], vcf_identical_to_reference=body(d + "/out.vcf") == body(d + "/outg.vcf"),
+                               over_cpu=round(min(ts) / min(es), 2), stage_line=r.stderr.decode(errors="replace").strip().splitlines()[-1][:600],
+                               note="`longphase_amd phase` end to end on the same BAM + VCF + FASTA (page cache warm, like the reference's best run): file -> phased VCF, GPU start-up included")
+            except Exception as e:  # noqa: BLE001
+                log("whole-node sample: the command line run failed:", repr(e)[:300])
     # ---- the GPU on the same decoded alignments, from pinned host memory (clock P), loads and phases of different contigs overlapping
     for c in contigs:
         c["R"] = abi.Reads.from_synth(c["host"])
@@ -272,6 +289,7 @@ def whole_node_baseline(dev, P, threads, seed, n_contigs=16, contig_mb=10):
                 p_clock=dict(value=float(gpu_p), unit="SNPs/s", wall_s=round(p_wall, 3), pinned_host_memory=all(c["pinned"] for c in contigs),
                              note="decoded alignments in pinned host memory -> results in host memory: lps_set_variants + lps_set_reference + lps_push_reads (H2D) + lps_prepare_reads + "
                                   "lps_phase_chromosome per contig, two contexts on one GPU so that one contig's load overlaps another's phase; PCIe-inclusive, never `value`"),
+                e_clock=e_clock,
                 vs_baseline=dict(p_clock_over_cpu=round(gpu_p / cpu, 2), note="clock P (what SURVEY.md 8d judges the >= 20x target by) over the whole-node reference rate on the same sample; "
                                  "the top-level vs_baseline stays null: BASELINE.md holds no published number"))
 

@@ -27,7 +27,8 @@ static const char *kUsage =
     "   --sv-file=NAME  --mod-file=NAME   co-phase structural variants / modcall records (outputs <prefix>_SV.vcf, <prefix>_mod.vcf)   -w svWindow(20)  -h svThreshold(0.1)\n"
     "   --host-inflate | --gpu-inflate   BGZF inflate with zlib on the -t host threads / on the GPU (default: GPU for one BAM of 256 MiB or more)\n"
     "   --no-index       ignore <bam>.bai: make the whole file resident on the GPU instead of one contig at a time\n"
-    "   --group-bytes=N  indexed input: consecutive contigs are uploaded and inflated together up to N compressed bytes (8 GiB)\n"
+    "   --group-bytes=N  indexed input: consecutive contigs are uploaded and inflated together up to N compressed bytes (1 GiB)\n"
+    "   --workers-per-gpu=N  indexed input: contig groups in flight per GPU, each with its own context and stream (3)\n"
     "   --gpus=N         deal the contigs onto N GPUs (devices --gpu, --gpu+1, ... modulo the number present); needs the .bai index\n";
 
 static int phase_main(int argc, char **argv, const std::string &command) {
@@ -35,7 +36,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::string snp, ref, prefix = "result", sv_file, mod_file;
     std::vector<std::string> bams;
     int threads = 1, gpu = 0, n_gpus = 1, sv_window = 20, indel_quality = 0; double sv_threshold = 0.1;
-    uint64_t group_bytes = 8ull << 30;
+    uint64_t group_bytes = 1ull << 30; int workers_per_gpu = 3;        // indexed BAM: contigs are taken in groups of about this many compressed bytes, by this many concurrent workers per GPU
     bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false, deepsomatic = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
@@ -78,6 +79,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--gpus") n_gpus = std::max(1, std::stoi(val()));
         else if (a == "--group-bytes") group_bytes = (uint64_t)std::stoull(val());
+        else if (a == "--workers-per-gpu") workers_per_gpu = std::max(1, std::stoi(val()));
         else if (a == "--host-inflate") host_inflate = true;
         else if (a == "--gpu-inflate") gpu_inflate = true;
         else if (a == "--no-index") no_index = true;
@@ -227,10 +229,15 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     };
     // contigs never interact: with --gpus N and an indexed BAM they are dealt longest-first onto N contexts, one host thread + one
     // GPU each, every worker uploading only the BGZF blocks of its own contigs.  No data-path collective; results meet in the VCF writer.
+    // On ONE GPU, too, several workers (host thread + context + stream each) take contig groups side by side: while one uploads its next group's BGZF
+    // blocks, another's are being inflated and scanned, a third ranks read names on the host and a fourth's kernels phase - the stages of the
+    // reference's chromosome loop (PhasingProcess.cpp:106-176) overlap without any of them knowing about the others.
     int n_workers = 1;
-    if (n_gpus > 1) { if (gpu_input && gb.indexed) n_workers = n_gpus;
-        else std::cerr << "longphase_amd: --gpus needs one BAM with its .bai index; running on one GPU\n";
-        }
+    if (gpu_input && gb.indexed) n_workers = n_gpus * workers_per_gpu;
+    else { workers_per_gpu = 1; if (n_gpus > 1) std::cerr << "longphase_amd: --gpus needs one BAM with its .bai index; running on one GPU\n"; n_gpus = 1; }
+    { size_t with_rows = 0; for (const std::string &c : chr_order) with_rows += !vars[c].pos.empty();
+      while (workers_per_gpu > 1 && (size_t)(n_gpus * workers_per_gpu) > with_rows) --workers_per_gpu;       // no more workers than contigs to deal out
+      n_workers = n_gpus * workers_per_gpu; }
     std::vector<std::vector<std::string>> share((size_t)n_workers);
     {
         std::vector<std::string> by_size(chr_order);
@@ -252,32 +259,40 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     };
     // the one collective: a communicator over the workers' GPUs (ncclCommInitAll); fails when two workers share a device (rehearsal on fewer GPUs
     // than --gpus) - the workers then read the table worker 0 holds, in this one address space
-    std::vector<lps_comm *> comms((size_t)n_workers, nullptr); bool have_comm = false;
-    // (LPS_CLI_BCAST_ALWAYS: a communicator even for one worker, so that the broadcast -> lps_set_variants_device path runs on a one-GPU box)
-    if (n_workers > 1 || getenv("LPS_CLI_BCAST_ALWAYS")) { std::vector<int> devs; for (int g = 0; g < n_workers; ++g) devs.push_back((gpu + g) % n_dev);
-        have_comm = std::set<int>(devs.begin(), devs.end()).size() == devs.size() && L.comm_create_all(n_workers, devs.data(), comms.data()) == 0;
+    // ONE communicator rank per GPU: worker k * workers_per_gpu leads GPU k, the workers beside it read the device buffer it received
+    auto dev_of = [&](int g) { return (gpu + g / workers_per_gpu) % n_dev; };
+    std::vector<lps_comm *> comms((size_t)n_gpus, nullptr); bool have_comm = false;
+    // (LPS_CLI_BCAST_ALWAYS: a communicator even for one GPU, so that the broadcast -> lps_set_variants_device path runs on a one-GPU box)
+    if (n_gpus > 1 || getenv("LPS_CLI_BCAST_ALWAYS")) { std::vector<int> devs; for (int k = 0; k < n_gpus; ++k) devs.push_back(dev_of(k * workers_per_gpu));
+        have_comm = std::set<int>(devs.begin(), devs.end()).size() == devs.size() && L.comm_create_all(n_gpus, devs.data(), comms.data()) == 0;
         if (have_comm) std::cerr << "longphase_amd: RCCL communicator over " << L.comm_size(comms[0]) << " GPUs\n";
         else std::cerr << "longphase_amd: no RCCL communicator (" << (std::set<int>(devs.begin(), devs.end()).size() == devs.size() ? L.comm_last_error() : "workers share a device") << "); workers read the host table\n";
         }
-    auto obtain_table = [&](int g, Packed &mine) -> const Packed & {       // every worker calls this once (collective)
+    std::vector<Packed> gpu_tab((size_t)n_gpus); std::vector<char> gpu_tab_ready((size_t)n_gpus, 0); std::mutex tab_mu; std::condition_variable tab_cv;
+    auto obtain_table = [&](int g) -> const Packed & {                     // every worker calls this once (collective among the GPUs' leaders)
         if (!have_comm) return table0;
-        // root's host table -> the communicator's device buffer on every GPU; each worker's contexts take their contigs' rows from there
-        double ms = 0; void *d = nullptr;
-        if (L.comm_bcast_to_device(comms[(size_t)g], g == 0 ? table0.buf.data() : nullptr, (int64_t)table0.buf.size(), 0, &d, g == 0 ? &ms : nullptr)) die(std::string("longphase_amd: ") + L.comm_last_error());
-        if (g == 0) fprintf(stderr, "longphase_amd: SNP table broadcast, %zu bytes, %.3f ms\n", table0.buf.size(), ms);
-        mine.n = table0.n; mine.where = table0.where; mine.dev = (const uint8_t *)d;
-        return mine;
+        const int k = g / workers_per_gpu;
+        if (g % workers_per_gpu == 0) {
+            // root's host table -> the communicator's device buffer on every GPU; each GPU's contexts take their contigs' rows from there
+            double ms = 0; void *d = nullptr;
+            if (L.comm_bcast_to_device(comms[(size_t)k], k == 0 ? table0.buf.data() : nullptr, (int64_t)table0.buf.size(), 0, &d, k == 0 ? &ms : nullptr)) die(std::string("longphase_amd: ") + L.comm_last_error());
+            if (k == 0) fprintf(stderr, "longphase_amd: SNP table broadcast, %zu bytes, %.3f ms\n", table0.buf.size(), ms);
+            { std::lock_guard<std::mutex> lk(tab_mu); Packed &m = gpu_tab[(size_t)k]; m.n = table0.n; m.where = table0.where; m.dev = (const uint8_t *)d; gpu_tab_ready[(size_t)k] = 1; }
+            tab_cv.notify_all();
+        } else { std::unique_lock<std::mutex> lk(tab_mu); tab_cv.wait(lk, [&] { return gpu_tab_ready[(size_t)k] != 0; }); }
+        return gpu_tab[(size_t)k];
     };
     for (int g = 1; g < n_workers; ++g) workers.emplace_back([&, g] {
         lps_params P; L.default_params(&P); for (auto &f : over) f(P);
-        lps_ctx *cx = L.create((gpu + g) % n_dev, &P); if (!cx) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
+        lps_ctx *cx = L.create(dev_of(g), &P); if (!cx) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
         L.set_stage_timing(cx, 0);
         GpuBam gg; gg.open_file(bams[0], true);
-        Packed mine; const Packed &tab = obtain_table(g, mine);
+        const Packed &tab = obtain_table(g);
         run_share(cx, gg, share[(size_t)g], tab);
+        { std::lock_guard<std::mutex> lk(res_mu); gb.t_inflate += gg.t_inflate; gb.t_scan += gg.t_scan; }     // (summed over the workers: they overlap, the sum can exceed the wall time)
         L.destroy(cx); gg.close_file();
     });
-    { Packed none; const Packed &tab = obtain_table(0, none); run_share(ctx, gb, share[0], tab); }
+    { const Packed &tab = obtain_table(0); run_share(ctx, gb, share[0], tab); }
     for (auto &w : workers) w.join();
     for (lps_comm *cm : comms) if (cm) L.comm_destroy(cm);
     std::cerr << "\n";

@@ -49,7 +49,7 @@ struct lps_ctx {
     int nR = 0; uint64_t n_cig = 0, n_seq = 0, n_qual = 0;
     DevBuf<int32_t> r_start, r_lq; DevBuf<uint16_t> r_flag; DevBuf<uint8_t> r_mapq; DevBuf<uint32_t> r_name;
     DevBuf<uint64_t> r_coff, r_soff, r_qoff; DevBuf<uint32_t> cigar; DevBuf<uint8_t> seq, qual;
-    DevBuf<uint8_t> sq; DevBuf<uint32_t> r_sqblk, sq_cnt; DevBuf<int32_t> r_v0; DevBuf<uint32_t> cigp, cp_off, cp_cnt; DevBuf<int32_t> cp_n; int cp_reads = -1; int sq_reads = -1; float sq_ms = 0;   // bases + qualities interleaved per 128-byte line (lps_reads.hip); sq_reads: alignments it covers (-1: not built)
+    DevBuf<uint8_t> sq; DevBuf<uint32_t> r_sqblk, sq_cnt; DevBuf<int32_t> r_v0; DevBuf<uint32_t> cigp, cp_off, cp_cnt; DevBuf<int32_t> cp_n; int cp_reads = -1; int sq_reads = -1; int32_t last_start = 0;   /* start of the last alignment pushed (order across pushes) */ float sq_ms = 0;   // bases + qualities interleaved per 128-byte line (lps_reads.hip); sq_reads: alignments it covers (-1: not built)
     // raw BAM records (lps_push_bam_records): seq/qual are read in place from the blob
     DevBuf<uint8_t> blob; uint64_t n_blob = 0; int read_mode = 0;   // 0 none yet, 1 SoA batches, 2 BAM records
     DevBuf<uint64_t> rec_off, cig_src; DevBuf<unsigned long long> cig_cnt; DevBuf<unsigned> bam_err;
@@ -387,6 +387,8 @@ int lps_push_reads(lps_ctx *c, const lps_read_batch *b) {
             if (b->l_qseq[i] < 0 || (uint64_t)((b->l_qseq[i] + 1) / 2) > b->seq_off[i + 1] - b->seq_off[i] || (uint64_t)b->l_qseq[i] > b->qual_off[i + 1] - b->qual_off[i]) return fail(c, "seq/qual shorter than l_qseq");
             if (i && b->ref_start[i] < b->ref_start[i - 1]) return fail(c, "alignments must be coordinate-sorted");
         }
+        if (n && c->nR && b->ref_start[0] < c->last_start) return fail(c, "alignments must be coordinate-sorted (a batch starts before the end of the one pushed before it)");
+        if (n) c->last_start = b->ref_start[n - 1];
         const size_t at = (size_t)c->nR;
         upload(c, c->r_start, b->ref_start, n, at, true); upload(c, c->r_lq, b->l_qseq, n, at, true);
         upload(c, c->r_flag, b->flag, n, at, true); upload(c, c->r_mapq, b->mapq, n, at, true);
@@ -486,6 +488,8 @@ int lps_push_reads_device(lps_ctx *c, const lps_read_batch *b) {
         uint64_t ends[6];                                                // first and last entry of the three offset arrays
         const uint64_t *offs[3] = {b->cigar_off, b->seq_off, b->qual_off};
         for (int k = 0; k < 3; ++k) { HIP_TRY(hipMemcpyAsync(&ends[2 * k], offs[k], 8, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(&ends[2 * k + 1], offs[k] + n, 8, hipMemcpyDeviceToHost, s)); }
+        int32_t start_ends[2] = {0, 0};                                  // first and last start of the batch: the order ACROSS pushes is checked here, inside a batch by k_batch_check
+        if (n) { HIP_TRY(hipMemcpyAsync(&start_ends[0], b->ref_start, 4, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(&start_ends[1], b->ref_start + (n - 1), 4, hipMemcpyDeviceToHost, s)); }
         c->bam_err.reserve(2);
         HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, 2 * sizeof(unsigned), s));
         hipLaunchKernelGGL(k_batch_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (long long)n, b->ref_start, b->l_qseq, b->name_id, b->cigar_off, b->seq_off, b->qual_off, c->bam_err.p);
@@ -495,6 +499,8 @@ int lps_push_reads_device(lps_ctx *c, const lps_read_batch *b) {
         if (flags[0] & 1u) return fail(c, "offsets must be non-decreasing");
         if (flags[0] & 2u) return fail(c, "seq/qual shorter than l_qseq");
         if (flags[0] & 4u) return fail(c, "alignments must be coordinate-sorted");
+        if (n && c->nR && start_ends[0] < c->last_start) return fail(c, "alignments must be coordinate-sorted (a batch starts before the end of the one pushed before it)");
+        if (n) c->last_start = start_ends[1];
         if (ends[1] < ends[0] || ends[3] < ends[2] || ends[5] < ends[4]) return fail(c, "offsets must be non-decreasing");
         const uint64_t nc = ends[1] - ends[0], ns = ends[3] - ends[2], nq = ends[5] - ends[4];
         c->read_mode = 1;
@@ -682,15 +688,23 @@ int lps_bgzf_read(lps_ctx *c, int64_t offset, int64_t n, uint8_t *dst) {
     return 0;
 }
 
+// two events for timing a stretch of the stream; destroyed when the scope is left, whichever way
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    EventPair() { HIP_TRY(hipEventCreate(&a)); if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); a = nullptr; throw std::string("hipEventCreate failed"); } }
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    EventPair(const EventPair &) = delete; EventPair &operator=(const EventPair &) = delete;
+};
+
 int lps_bgzf_deflate(lps_ctx *c, int64_t offset, int64_t n_bytes, int64_t *out_bytes) {
     if (!c || !out_bytes || offset < 0 || n_bytes < 0 || (uint64_t)(offset + n_bytes) > c->file_bytes) return fail(c, "lps_bgzf_deflate: range outside the resident stream");
     try {
         HIP_TRY(hipSetDevice(c->device));
-        hipStream_t s = c->stream; hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        hipStream_t s = c->stream; EventPair ev; hipEvent_t &e0 = ev.a, &e1 = ev.b;   // (released on every way out, a throw included)
         HIP_TRY(hipEventRecord(e0, s));
         c->dz_total = bgzf_deflate_device(c->file.p + offset, (uint64_t)n_bytes, c->dz_slots, c->dz_bytes, c->dz_tmp, c->dz_off, c->dz_packed, c->temp, c->temp_bytes, s);
         HIP_TRY(hipEventRecord(e1, s)); HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipEventElapsedTime(&c->dz_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        HIP_TRY(hipEventElapsedTime(&c->dz_ms, e0, e1));
         *out_bytes = (int64_t)c->dz_total;
     } catch (std::string &e) { return fail(c, e); }
     return 0;
@@ -700,13 +714,13 @@ int lps_bgzf_deflate_host(lps_ctx *c, const uint8_t *bytes, int64_t n_bytes, int
     if (!c || !out_bytes || n_bytes < 0 || (n_bytes && !bytes)) return -1;
     try {
         HIP_TRY(hipSetDevice(c->device));
-        hipStream_t s = c->stream; hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        hipStream_t s = c->stream; EventPair ev; hipEvent_t &e0 = ev.a, &e1 = ev.b;   // (released on every way out, a throw included)
         c->dz_src.reserve((size_t)n_bytes + 64, s);
         h2d_staged(c, c->dz_src.p, bytes, (size_t)n_bytes);
         HIP_TRY(hipEventRecord(e0, s));
         c->dz_total = bgzf_deflate_device(c->dz_src.p, (uint64_t)n_bytes, c->dz_slots, c->dz_bytes, c->dz_tmp, c->dz_off, c->dz_packed, c->temp, c->temp_bytes, s);
         HIP_TRY(hipEventRecord(e1, s)); HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipEventElapsedTime(&c->dz_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        HIP_TRY(hipEventElapsedTime(&c->dz_ms, e0, e1));
         *out_bytes = (int64_t)c->dz_total;
     } catch (std::string &e) { return fail(c, e); }
     return 0;
@@ -719,7 +733,7 @@ int lps_haplotag_write_bgzf(lps_ctx *c, const uint8_t *status, const uint8_t *hp
     if (n && (!status || !hp || !ps || !pq)) return -1;
     try {
         HIP_TRY(hipSetDevice(c->device));
-        hipStream_t s = c->stream; hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        hipStream_t s = c->stream; EventPair ev; hipEvent_t &e0 = ev.a, &e1 = ev.b;   // (released on every way out, a throw included)
         upload(c, c->tg_status, status, n); upload(c, c->tg_hp, hp, n); upload(c, c->tg_ps, ps, n); upload(c, c->tg_pq, pq, n);
         c->tg_stream.reserve((size_t)prefix_bytes + 64, s); c->bam_err.reserve(1);
         if (prefix_bytes) HIP_TRY(hipMemcpyAsync(c->tg_stream.p, prefix, (size_t)prefix_bytes, hipMemcpyHostToDevice, s));
@@ -729,7 +743,7 @@ int lps_haplotag_write_bgzf(lps_ctx *c, const uint8_t *status, const uint8_t *hp
         if (total < 0) return fail(c, "malformed auxiliary field in a BAM record");
         c->dz_total = bgzf_deflate_device(c->tg_stream.p, (uint64_t)total, c->dz_slots, c->dz_bytes, c->dz_tmp, c->dz_off, c->dz_packed, c->temp, c->temp_bytes, s);
         HIP_TRY(hipEventRecord(e1, s)); HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipEventElapsedTime(&c->dz_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        HIP_TRY(hipEventElapsedTime(&c->dz_ms, e0, e1));
         *out_bytes = (int64_t)c->dz_total;
     } catch (std::string &e) { return fail(c, e); }
     return 0;

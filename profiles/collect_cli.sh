@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel stats of the CLI (phase + haplotag) on a chr20-30x BAM, from HEAD
 set -e
-ROOT=$GRAFT_REPO_ROOT
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 D=/tmp/cliprof; rm -rf $D; mkdir -p $D; cd $D
 python3 - <<PY
 import sys, os, subprocess

@@ -199,6 +199,21 @@ def test_batched_push_equals_single_push():
         assert np.array_equal(a.phase_set, b.phase_set) and np.array_equal(a.gt, b.gt)
 
 
+def test_batches_pushed_out_of_order_are_refused():
+    """Every kernel assumes coordinate order over ALL resident alignments: a batch that starts before the end of the one pushed before it is an
+    error like an unsorted batch (the order inside a batch is checked by lps_push_reads / k_batch_check)."""
+    kw, cli, over = fixtures.PHASE_FIXTURES["snp_ont"]
+    s, V, R = util.make_case(kw)
+    n = R.n_reads
+    assert R.ref_start[n // 2] > R.ref_start[0]
+    parts = [R.subset(np.arange(n // 2, n)), R.subset(np.arange(0, n // 2))]
+    with hip.Context(0, abi.default_params()) as ctx:
+        with pytest.raises(hip.LpsError, match="coordinate-sorted"):
+            ctx.phase(V, s.ref, parts)
+        a = ctx.phase(V, s.ref, R)                  # the context is usable afterwards
+        assert (a.phase_set != 0).any()
+
+
 def test_empty_and_degenerate_inputs():
     kw, cli, over = fixtures.PHASE_FIXTURES["snp_ont"]
     s, V, R = util.make_case(kw)
