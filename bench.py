@@ -249,7 +249,13 @@ def whole_node_baseline(dev, P, threads, seed, n_contigs=16, contig_mb=10):
                     t0 = time.time(); r = subprocess.run(gcmd, cwd=d, capture_output=True); es.append(time.time() - t0)
                     assert r.returncode == 0, r.stderr[-500:]
                 body = lambda p: [ln for ln in open(p) if not ln.startswith("##commandline=") and not ln.startswith("##longphaseVersion=")]  # noqa: E731
-                e_clock = dict(wall_s=round(min(es), 3), runs_s=[round(x, 3) for x in es], vcf_identical_to_reference=body(d + "/out.vcf") == body(d + "/outg.vcf"),
+                sweep = []                                               # (profiles/e2e_whole_node.py: other settings of the command line on the same files)
+                for extra in json.loads(os.environ.get("LPS_E2E_SWEEP", "[]")):
+                    xs = []
+                    for _ in range(2):
+                        t0 = time.time(); rx = subprocess.run(gcmd + list(extra), cwd=d, capture_output=True); xs.append(time.time() - t0)
+                    sweep.append(dict(args=extra, wall_s=round(min(xs), 3), rc=rx.returncode, stage_line=rx.stderr.decode(errors="replace").strip().splitlines()[-1][:400]))
+                e_clock = dict(sweep=sweep, wall_s=round(min(es), 3), runs_s=[round(x, 3) for x in es], vcf_identical_to_reference=body(d + "/out.vcf") == body(d + "/outg.vcf"),
                                over_cpu=round(min(ts) / min(es), 2), stage_line=r.stderr.decode(errors="replace").strip().splitlines()[-1][:600],
                                note="`longphase_amd phase` end to end on the same BAM + VCF + FASTA (page cache warm, like the reference's best run): file -> phased VCF, GPU start-up included")
             except Exception as e:  # noqa: BLE001

@@ -27,8 +27,8 @@ static const char *kUsage =
     "   --sv-file=NAME  --mod-file=NAME   co-phase structural variants / modcall records (outputs <prefix>_SV.vcf, <prefix>_mod.vcf)   -w svWindow(20)  -h svThreshold(0.1)\n"
     "   --host-inflate | --gpu-inflate   BGZF inflate with zlib on the -t host threads / on the GPU (default: GPU for one BAM of 256 MiB or more)\n"
     "   --no-index       ignore <bam>.bai: make the whole file resident on the GPU instead of one contig at a time\n"
-    "   --group-bytes=N  indexed input: consecutive contigs are uploaded and inflated together up to N compressed bytes (1 GiB)\n"
-    "   --workers-per-gpu=N  indexed input: contig groups in flight per GPU, each with its own context and stream (3)\n"
+    "   --group-bytes=N  indexed input: consecutive contigs are uploaded and inflated together up to N compressed bytes (8 GiB)\n"
+    "   --workers-per-gpu=N  indexed input: contig groups in flight per GPU, each with its own context and stream (1)\n"
     "   --gpus=N         deal the contigs onto N GPUs (devices --gpu, --gpu+1, ... modulo the number present); needs the .bai index\n";
 
 static int phase_main(int argc, char **argv, const std::string &command) {
@@ -36,7 +36,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::string snp, ref, prefix = "result", sv_file, mod_file;
     std::vector<std::string> bams;
     int threads = 1, gpu = 0, n_gpus = 1, sv_window = 20, indel_quality = 0; double sv_threshold = 0.1;
-    uint64_t group_bytes = 1ull << 30; int workers_per_gpu = 3;        // indexed BAM: contigs are taken in groups of about this many compressed bytes, by this many concurrent workers per GPU
+    uint64_t group_bytes = 8ull << 30; int workers_per_gpu = 1;        // indexed BAM: contigs are taken in groups of about this many compressed bytes, by this many concurrent workers per GPU
     bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false, deepsomatic = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
@@ -229,9 +229,10 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     };
     // contigs never interact: with --gpus N and an indexed BAM they are dealt longest-first onto N contexts, one host thread + one
     // GPU each, every worker uploading only the BGZF blocks of its own contigs.  No data-path collective; results meet in the VCF writer.
-    // On ONE GPU, too, several workers (host thread + context + stream each) take contig groups side by side: while one uploads its next group's BGZF
-    // blocks, another's are being inflated and scanned, a third ranks read names on the host and a fourth's kernels phase - the stages of the
-    // reference's chromosome loop (PhasingProcess.cpp:106-176) overlap without any of them knowing about the others.
+    // On ONE GPU, too, several workers (host thread + context + stream each) can take contig groups side by side (--workers-per-gpu): one uploads
+    // its next group's BGZF blocks while another's are inflated and a third's kernels phase.  MEASURED on the 16-contig, 8.3 GB sample of bench.py
+    // (profiles/e2e_whole_node.py): 1 worker with the whole file as one group 1.44 s, 2 - 8 workers with 0.5 - 1 GiB groups 1.61 - 1.74 s - one
+    // large upload and one inflate launch over all blocks beat several small ones that compete for the link and the GPU.  The default stays one.
     int n_workers = 1;
     if (gpu_input && gb.indexed) n_workers = n_gpus * workers_per_gpu;
     else { workers_per_gpu = 1; if (n_gpus > 1) std::cerr << "longphase_amd: --gpus needs one BAM with its .bai index; running on one GPU\n"; n_gpus = 1; }
