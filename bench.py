@@ -254,7 +254,8 @@ def whole_node_baseline(dev, P, threads, seed, n_contigs=16, contig_mb=10):
                     xs = []
                     for _ in range(2):
                         t0 = time.time(); rx = subprocess.run(gcmd + list(extra), cwd=d, capture_output=True); xs.append(time.time() - t0)
-                    sweep.append(dict(args=extra, wall_s=round(min(xs), 3), rc=rx.returncode, stage_line=rx.stderr.decode(errors="replace").strip().splitlines()[-1][:400]))
+                    err_lines = rx.stderr.decode(errors="replace").strip().splitlines()
+                    sweep.append(dict(args=extra, wall_s=round(min(xs), 3), rc=rx.returncode, stage_line=err_lines[-1][:400], debug=[ln[:400] for ln in err_lines if ln.startswith("[lps_")]))
                 e_clock = dict(sweep=sweep, wall_s=round(min(es), 3), runs_s=[round(x, 3) for x in es], vcf_identical_to_reference=body(d + "/out.vcf") == body(d + "/outg.vcf"),
                                over_cpu=round(min(ts) / min(es), 2), stage_line=r.stderr.decode(errors="replace").strip().splitlines()[-1][:600],
                                note="`longphase_amd phase` end to end on the same BAM + VCF + FASTA (page cache warm, like the reference's best run): file -> phased VCF, GPU start-up included")
