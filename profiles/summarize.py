@@ -11,7 +11,7 @@ import os
 import sys
 
 STAGE_OF = {"k_extract_phase": "extract", "k_edges": "edges", "k_scan_spec": "vote_scan", "k_read_correction": "read_correction",
-            "k_merge_multi": "merge_rows", "k_node_scatter": "node_lists", "k_haplotag_score": "haplotag_extract"}
+            "k_merge_multi": "merge_rows", "k_node_scatter": "node_lists", "k_haplotag_score": "haplotag_extract", "k_haplotag_stream": "haplotag_extract", "k_graph_rows": "graph_rows"}
 
 
 def find(d, pat):
