@@ -1308,13 +1308,19 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
         launch_read_v0(V, R, c->r_v0.p, s);
         HapOut H{};
         H.pct_thr = c->P.percentage_threshold; H.rec = c->hap_rec.p; H.pq_tab = c->pq_tab.p; H.votes1 = votes ? c->d_votes1.p : nullptr; H.votes2 = votes ? c->d_votes2.p : nullptr;
-        launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 0, c->d_cnt, s);
-        mark(c, ST_D2H);
-        HIP_TRY(hipMemcpyAsync(c->h_res, c->hap_rec.p, span, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(c->h_cnt_pin, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(c->ev_end, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        c->h_cnt = *c->h_cnt_pin;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 0, c->d_cnt, s, /*general=*/attempt == 1);
+            if (attempt == 0) mark(c, ST_D2H);
+            HIP_TRY(hipMemcpyAsync(c->h_res, c->hap_rec.p, span, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(c->h_cnt_pin, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(c->ev_end, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            c->h_cnt = *c->h_cnt_pin;
+            // one CIGAR operation of 2^24 bases and more, or the alignments of a job spanning more than 2^30 bases: outside the stream walk's arithmetic
+            // (24-bit multiplies, 32-bit stream coordinates).  The chromosome is scored again by the per-op-prefix walker, which takes any BAM record
+            if (!(c->h_cnt.err & LPS_ERR_KEY_RANGE) || attempt == 1) break;
+            HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
+        }
         if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) return fail(c, "Alignment find unsupported CIGAR operation", -2);
         // ---- the records into the caller's arrays (PQ of reads with 64 votes or more: libm here)
         const uint4 *rec = (const uint4 *)c->h_res;

@@ -498,9 +498,9 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
 }
 
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
-                     int mode, LpsCounters *cnt, hipStream_t s) {
+                     int mode, LpsCounters *cnt, hipStream_t s, bool general) {
     if (R.n == 0) return;
-    if (mode == 0 && H.rec) {                                             // germline haplotag: the stream walk, four alignments per wave
+    if (mode == 0 && H.rec && !general) {                                 // germline haplotag: the stream walk, four alignments per wave
         hipLaunchKernelGGL(k_haplotag_stream, dim3(round_up8((R.n + 3) / 4)), dim3(64), 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
         return;
     }

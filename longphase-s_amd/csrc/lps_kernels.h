@@ -253,7 +253,7 @@ struct HapOut { uint8_t *status; int32_t *hp1, *hp2; uint8_t *n_ps; int32_t *ps_
                 uint4 *rec; const int *pq_tab /* [64][64]: PQ of (min, max) votes, built by the host's libm */; const int32_t *votes1, *votes2; };
 void launch_read_v0(const VarView &V, const ReadView &R, int32_t *v0, hipStream_t s);
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
-                     int mode, LpsCounters *cnt, hipStream_t s);   // mode 0 haplotag, 1 somatic tag, 2 normal extraction, 3 its read-HP pass
+                     int mode, LpsCounters *cnt, hipStream_t s, bool general = false);   // general: the per-op-prefix walker also for the germline pass (what the stream walk cannot take);   // mode 0 haplotag, 1 somatic tag, 2 normal extraction, 3 its read-HP pass
 
 // tumor-BAM extraction (lps_somatic.hip)
 struct TumOut {
