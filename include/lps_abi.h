@@ -274,9 +274,11 @@ int lps_set_reference(lps_ctx *ctx, const char *seq, int64_t len);
 /* Append decoded alignments (H2D copy).  May be called repeatedly (batches / several BAM files). */
 int lps_push_reads(lps_ctx *ctx, const lps_read_batch *batch);
 /* After the last push of a chromosome (optional: lps_phase_chromosome does it itself when it has not been done for the resident alignments):
- * builds the layout the phase extraction gathers bases and qualities from - both of a base in ONE 128-byte line (csrc/lps_reads.hip) instead of two,
- * because a random byte costs a whole line of HBM traffic.  One pass over SEQ + QUAL; *ms (optional) = its duration on the GPU, 0 if already built.
- * Part of loading a chromosome (P and E clocks include it); pushing more alignments invalidates it. */
+ * builds the layouts the hot kernels read (csrc/lps_reads.hip): bases and qualities of a base in ONE 128-byte line instead of two, because a random
+ * byte costs a whole line of HBM traffic (one pass over SEQ + QUAL; *ms (optional) = its duration on the GPU, 0 if already built), and the CIGAR
+ * words in lane-chunks - every alignment padded to a multiple of 8 words - which the stream walks of phase and haplotag take 8 words per lane
+ * (lps_haplotag_chromosome builds the latter itself when needed).  Part of loading a chromosome (P and E clocks include it); pushing more
+ * alignments invalidates both. */
 int lps_prepare_reads(lps_ctx *ctx, double *ms);
 /* Same as lps_push_reads for a batch that is already resident on the ctx's GPU: every pointer of `batch` is a DEVICE pointer
  * (e.g. the output of a GPU-side BAM decoder or generator).  The arrays are copied device-to-device; the caller may free them when the
