@@ -41,7 +41,7 @@ struct lps_ctx {
     // SV / MOD rows (lps_set_extra_variants): merged by position; nG / g_vpos = size and positions of the table the stages after the extraction
     // run on (the SNP table itself when there are no such rows, else the union of the three)
     int nX = 0, nSV = 0, nMOD = 0, sv_window = 20; double sv_threshold = 0.1;
-    DevBuf<int32_t> x_pos, x_info, x_u, x_snp_u, u_pos; DevBuf<uint8_t> x_kind, x_mflag; DevBuf<uint32_t> x_moff, x_mname;
+    DevBuf<int32_t> x_pos, x_info, x_u, x_snp_u, u_pos, x_x0; DevBuf<XRow> x_row; DevBuf<uint8_t> x_kind, x_mflag; DevBuf<uint32_t> x_moff, x_mname;
     std::vector<int32_t> h_snp_u, h_sv_u, h_mod_u, h_res_ps_u; std::vector<uint8_t> h_res_gt_u;
     int nG = 0; const int32_t *g_vpos = nullptr;
     std::vector<int32_t> votes_h1, votes_h2;   // lps_set_read_votes
@@ -1024,7 +1024,7 @@ static int run_phase(lps_ctx *c) {
         }
         c->name_p = dense ? c->r_name.p : c->name_dense.p;
         // ---- a1/a2/a3 extraction; with no SV / MOD rows every observation is counted (and ranked inside its variant's list) right there
-        ObsView O{c->rows.p, c->obs.p, arena_size, c->arena_ctr.p, n_arenas};
+        ObsView O{c->rows.p, c->obs.p, arena_size, c->arena_ctr.p, n_arenas, c->nX ? c->x_snp_u.p : nullptr};
         ClipView C{c->clip_ev.p, c->clip_stats.p, (unsigned)c->clip_capacity, (unsigned)(EXT_CLIPS * ((nR + 3) / 4))};            // clip_stats[0]: events appended by the general walker, [1]: jobs queued for it (zero pool)
         mark(c, ST_EXTRACT);
         launch_read_v0(V, R, c->r_v0.p, s);
@@ -1041,7 +1041,8 @@ static int run_phase(lps_ctx *c) {
         // ---- SV / MOD rows: served against each alignment's CIGAR, merged into its row; every observation leaves in union indices
         if (c->nX) {
             ExtraView X{c->nX, c->x_pos.p, c->x_info.p, c->x_kind.p, c->x_u.p, c->x_snp_u.p, c->x_moff.p, c->x_mname.p, c->x_mflag.p, c->sv_window, c->sv_threshold};
-            launch_extra_merge(V, R, O, X, P.mapping_quality, c->d_cnt, s);
+            c->x_x0.reserve((size_t)nR + 1); c->x_row.reserve((size_t)nR + 1);
+            launch_extra_merge(V, R, O, X, c->x_x0.p, c->x_row.p, P.mapping_quality, c->d_cnt, s);
         }
         GraphView &G = c->G;
         G = GraphView{};

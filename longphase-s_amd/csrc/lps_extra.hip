@@ -41,7 +41,9 @@ __device__ __forceinline__ int last_snp_before(const VarView &V, int p) {
 }
 
 #define XM_WPB 1        // waves per workgroup (they share nothing)
-__global__ __launch_bounds__(64 * XM_WPB) void k_extra_merge(VarView V, ReadView R, ObsView O, ExtraView X, int mapping_quality, LpsCounters *cnt) {
+// (since round 3 the general walker behind k_extra_find: it takes the alignments that kernel marked - xrow[r].cnt == -1 - and finds their rows of
+// observations already in union indices, as the extraction writes them)
+__global__ __launch_bounds__(64 * XM_WPB) void k_extra_merge(VarView V, ReadView R, ObsView O, ExtraView X, const XRow *xrow, int mapping_quality, LpsCounters *cnt) {
     __shared__ __attribute__((aligned(16))) int s_ref[XM_WPB][LPS_SEG];
     __shared__ __attribute__((aligned(16))) int s_qry[XM_WPB][LPS_SEG];
     __shared__ __attribute__((aligned(16))) uint32_t s_cig[XM_WPB][LPS_SEG + 4];
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(64 * XM_WPB) void k_extra_merge(VarView V, ReadView
     if (r >= R.n) return;
     int *sref = s_ref[w], *sqry = s_qry[w], *spm = s_pm[w]; uint32_t *scig = s_cig[w]; ObsRec *sex = s_ex[w];
 
+    if (xrow[r].cnt != -1) return;
     const RowDesc rd = O.rows[r];
     const int start = R.ref_start[r], flag = R.flag[r];
     const bool live = !(R.mapq[r] < mapping_quality || (flag & 0x4) || (flag & 0x100) || (flag & 0x400) || start >= V.last_pos) && rd.fail == 0x7fffffff;
@@ -187,10 +190,7 @@ __global__ __launch_bounds__(64 * XM_WPB) void k_extra_merge(VarView V, ReadView
             }
         }
     }
-    if (n_emit == 0) {                                                  // nothing recorded: the row stays where it is, in union indices
-        for (int k = l; k < rd.cnt; k += 64) { ObsRec *o = O.rec + rd.off + k; o->var = X.snp_u[o->var]; }
-        return;
-    }
+    if (n_emit == 0) return;                                            // nothing recorded: the row stays where it is (in union indices already)
     // ---- merge path: A = the alignment's SNP / indel observations (old row), B = the recorded rows (tail of the new row), both ascending and
     //      without common keys.  Output o comes from A[i] or B[o - i]; unread B entries always lie at or behind the outputs being written.
     __threadfence_block();
@@ -202,10 +202,10 @@ __global__ __launch_bounds__(64 * XM_WPB) void k_extra_merge(VarView V, ReadView
         ObsRec v{0, 0};
         if (o < total) {
             int lo = max(0, o - nB), hi = min(o, nA);
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (X.snp_u[A[mid].var] < B[o - mid - 1].var) lo = mid + 1; else hi = mid; }
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid].var < B[o - mid - 1].var) lo = mid + 1; else hi = mid; }
             const int i = lo, j = o - lo;
             ObsRec a{0x7fffffff, 0}, b{0x7fffffff, 0};
-            if (i < nA) { a = A[i]; a.var = X.snp_u[a.var]; }
+            if (i < nA) a = A[i];
             if (j < nB) b = B[j];
             v = (a.var < b.var) ? a : b;
         }
@@ -216,7 +216,279 @@ __global__ __launch_bounds__(64 * XM_WPB) void k_extra_merge(VarView V, ReadView
     if (l == 0) { RowDesc d = rd; d.off = new_off; d.cnt = total; d.flags = 0; O.rows[r] = d; }
 }
 
-void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int mapping_quality, LpsCounters *cnt, hipStream_t s) {
+
+// ================================================================================================ the stream walk for SV / MOD rows
+// k_extra_merge above takes an alignment per wave and stages every op; with dense MOD rows (a row every 2 kb: every alignment holds ten) that is a
+// second, slow walk over every CIGAR.  The same rows are found by the extraction's design: a wave takes a JOB of four alignments, walks their
+// lane-chunks as one stream (lps_reads.hip) and keeps per chunk (reference coordinate at its start, running maximum of E = ref_pos + length over
+// the alignment's ops through the chunk) - the rows of the four alignments' reaches are then one flattened list, a lane each: binary search of the
+// chunk whose running maximum first exceeds the row, its 8 words, the first op with E > p, the scan forward to the op that serves the row (header
+// of this file), the record.  The records of an alignment leave compacted in row order into the wave's arena (k_extra_place merges them into the
+// alignment's row); XRow = where they are.  What this walk cannot take (an alignment of more chunks than the table holds, an op of 2^24 bases,
+// stream coordinates beyond 2^30) is marked cnt = -1 and left to k_extra_merge.
+#define XF_TAB 1024
+
+__global__ void k_read_x0(ExtraView X, const int32_t *ref_start, int n, int32_t *x0) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int key = ref_start[r] - 1;                                   // SV rows from start - 1 on (the SV cursor compares the 1-based VCF position), MOD rows from start on
+    int lo = 0, hi = X.n;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (X.pos[m] < key) lo = m + 1; else hi = m; }
+    if (lo < X.n && X.pos[lo] == key && X.kind[lo] == 2) ++lo;
+    x0[r] = lo;
+}
+
+__global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, ObsView O, ExtraView X, const int32_t *x0, XRow *xrow, int mapping_quality, LpsCounters *cnt) {
+    __shared__ __attribute__((aligned(16))) int2 s_tab[XF_TAB];          // (stream reference coordinate at the chunk's start, running maximum of E through the chunk)
+    __shared__ ExtHdr s_hdr[4];
+    const int l = lane_id();
+    const int job = blockIdx.x, r0 = job * 4;
+    if (r0 >= R.n) return;
+    const int nq = min(4, R.n - r0);
+    const int arena = blockIdx.x % O.n_arenas;
+    const unsigned long long arena_lo = (unsigned long long)arena * O.arena_size;
+    // ---- plan: alignment q in lane q; the filters of the extraction + "get_snp returned early: the alignment has no row"
+    int h_start = 0, h_n = 0, h_x0 = 0, h_flag = 0; unsigned h_cp = 0, h_name = 0; bool h_live = false;
+    if (l <= nq) h_cp = R.cp_off[r0 + l];
+    if (l < nq) {
+        const int r = r0 + l; h_start = R.ref_start[r]; h_n = R.cp_n[r]; h_x0 = x0[r]; h_flag = R.flag[r]; h_name = R.name_id[r];
+        h_live = !(R.mapq[r] < mapping_quality || (h_flag & 0x4) || (h_flag & 0x100) || (h_flag & 0x400) || h_start >= V.last_pos) && O.rows[r].fail == 0x7fffffff && h_x0 < X.n;
+    }
+    const int h_nch = (int)(__shfl_down(h_cp, 1) - h_cp);
+    int x_cnt = 0; uint32_t x_off = 0;                     // what lane q reports for alignment q
+    bool general = l < nq && h_live && h_nch > XF_TAB;                  // more chunks than the table holds: left to k_extra_merge
+    unsigned todo = (unsigned)__ballot(h_live && !general) & 15u;
+#pragma unroll 1
+    while (todo) {
+        const int qa = __builtin_ctz(todo);
+        const unsigned c_lo = __shfl(h_cp, qa);
+        int qb = qa; unsigned gm = 1u << qa;
+        for (int q = qa + 1; q < nq; ++q) {
+            if (__shfl(h_cp, q + 1) - c_lo > (unsigned)XF_TAB) break;     // (alignments in between that are not walked pass by as words)
+            if ((todo >> q) & 1u) { gm |= 1u << q; qb = q; }
+        }
+        todo &= ~gm;
+        const bool h_in = l < 4 && ((gm >> l) & 1u);
+        const bool h_walk = h_in && h_n > 0;
+        const int h_c0 = (l <= nq) ? (int)(h_cp - c_lo) : 0;
+        const uint32_t *cg = R.cigp + 8ull * c_lo;
+        const int TC = __builtin_amdgcn_readlane(h_c0 + h_nch, qb);
+        auto request = [&](int cid, uint32_t (&w)[8]) __attribute__((always_inline)) {
+            const uint32_t *p = cg + 8 * min(cid, max(TC - 1, 0));
+            const uint4 a = *reinterpret_cast<const uint4 *>(p), b = *reinterpret_cast<const uint4 *>(p + 4);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        };
+        // first chunk of an alignment of the job (the running maximum starts again there): chunk index -> bit
+        int hc[4]; 
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hc[q] = q < nq ? __builtin_amdgcn_readlane(h_c0, q) : -1;
+        int xq[4], pp[4]; bool walkq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { xq[q] = __builtin_amdgcn_readlane(h_x0, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; pp[q] = X.pos[min(xq[q] + l, X.n - 1)]; }
+        if (l < 4) {
+            ExtHdr &h = s_hdr[l];
+            h.crel = 8 * h_c0; h.ncig = h_walk ? h_n : 0; h.c0 = h_c0; h.nch = h_walk ? h_nch : 0;
+            h.lq = h_flag; h.blk0 = h_name;
+        }
+        // ---- walk: coordinates like stream_round (lps_kernels.h) + the running maximum of E, a segmented inclusive max-scan (heads = first chunks)
+        int carry_r = 0, carry_e = (int)0x80000000; uint32_t big = 0; bool absurd = false;
+#pragma unroll 1
+        for (int R0 = 0; R0 < TC; R0 += 128) {
+            uint32_t wt[2][8];
+            request(R0 + l, wt[0]); request(R0 + 64 + l, wt[1]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int cid = R0 + 64 * t + l; const bool live = cid < TC;
+                unsigned rt = 0; int emax = (int)0x80000000; uint32_t bg = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t x = wt[t][k]; const unsigned len = x >> 4;
+                    emax = max(emax, (int)(rt + len));                // E of word k relative to the chunk's start: reference consumed before it + its length, whatever its op
+                    rt = __umul24(len, op_bit(LPS_RMASK2, x)) + rt; bg |= x;
+                }
+                rt = live ? rt : 0u; big |= live ? bg : 0u;
+                const int ir = wave_incl_scan_dpp((int)rt);
+                const int my_s = carry_r + ir - (int)rt;
+                int v = live ? my_s + emax : (int)0x80000000;
+                bool f = live && (cid == hc[0] || cid == hc[1] || cid == hc[2] || cid == hc[3]);
+                if (l == 0 && !f) v = max(v, carry_e);
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int vu = __shfl_up(v, d); const int fu = __shfl_up((int)f, d);
+                    if (l >= d && !f) { v = max(v, vu); f = fu != 0; }
+                }
+                if (live) s_tab[cid] = make_int2(my_s, v);
+                carry_r += __builtin_amdgcn_readlane(ir, 63); carry_e = __builtin_amdgcn_readlane(v, 63);
+            }
+            absurd |= (unsigned)carry_r > 0x3fffffffu;
+            if (absurd) break;
+        }
+        if (absurd || __ballot(big >= 0x10000000u)) { general |= h_in; continue; }   // outside this walk's arithmetic: k_extra_merge takes the group's alignments
+        wave_sync();
+        // ---- reach of each alignment, its rows: [x0, first row at or beyond the reach)
+        int b_sat = 0, b_reach = h_start;
+        if (h_walk) { const int2 ts = s_tab[h_c0], te = s_tab[h_c0 + h_nch - 1]; b_sat = ts.x; b_reach = h_start + te.y - ts.x; }
+        int nrow[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int reach = __builtin_amdgcn_readlane(b_reach, q);
+            int n = __popcll(__ballot(walkq[q] && xq[q] + l < X.n && pp[q] < reach));
+            if (n == 64) { for (;;) { int p2 = 0x7fffffff; if (xq[q] + n + l < X.n) p2 = X.pos[xq[q] + n + l]; const int m = __popcll(__ballot(p2 < reach)); n += m; if (m < 64) break; } }
+            nrow[q] = n;
+        }
+        int cum[5]; cum[0] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cum[q + 1] = cum[q] + nrow[q];
+        const int T = cum[4];
+        int xadj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xadj[q] = xq[q] - cum[q];
+        if (l < 4) { ExtHdr &h = s_hdr[l]; h.vadj = SEL4(l, xadj); h.ds = b_sat - h_start; }
+        int maxnch = l < 4 ? s_hdr[l].nch : 0;
+        maxnch = max(max(__builtin_amdgcn_readlane(maxnch, 0), __builtin_amdgcn_readlane(maxnch, 1)), max(__builtin_amdgcn_readlane(maxnch, 2), __builtin_amdgcn_readlane(maxnch, 3)));
+        // ONE reservation for the records of the group (a slot per row of the reaches: most rows are recorded)
+        unsigned long long off = 0;
+        if (T > 0 && l == 0) off = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)T);
+        wave_sync();
+        off = __shfl(off, 0);
+        const bool arena_full = T > 0 && off + (unsigned long long)T > O.arena_size;
+        if (arena_full) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); if (l < nq) xrow[r0 + l] = XRow{0u, 0}; return; }   // the host grows the arenas and runs again (nothing is left for the kernels behind this one)
+        ObsRec *dst = O.rec + arena_lo + off;
+        const int step0 = maxnch > 1 ? 1 << (31 - __builtin_clz(maxnch - 1)) : 0;
+        int n_x[4] = {0, 0, 0, 0}; unsigned blocked = 0;                  // records of alignment k so far; k has a row that no op serves: the cursor stays there
+#pragma unroll 1
+        for (int i0 = 0; i0 < T; i0 += 64) {
+            const int i = i0 + l;
+            const bool in = i < T;
+            bool found = false, emit = false; ObsRec rec{0, 0};
+            const int q = (i >= cum[1]) + (i >= cum[2]) + (i >= cum[3]);
+            if (in) {
+                const int4 ha = *reinterpret_cast<const int4 *>(&s_hdr[q].crel), hb = *reinterpret_cast<const int4 *>(&s_hdr[q].vadj);
+                const int hncig = ha.y, hc0 = ha.z, hnch = ha.w, hflag = hb.y, hds = hb.z;
+                const int row = hb.x + i;
+                const int p = X.pos[row], ps = p + hds;
+                // first chunk of the alignment whose running maximum exceeds the row: the op that first reaches beyond it lies there
+                int co = -1;
+                for (int step = step0; step >= 1; step >>= 1) { const int t = co + step; const int ev = s_tab[hc0 + min(t, hnch - 1)].y; co = (t < hnch && ev <= ps) ? t : co; }
+                ++co;                                                     // (co < hnch: ps < reach = the last chunk's running maximum)
+                if (step0 == 0) co = 0;
+                int q_snp = 0; bool have_q = false; int j = 0, rp = 0;
+                for (int cc = co; cc < hnch && !found; ++cc) {
+                    const uint32_t *cw = cg + 8 * (hc0 + cc);
+                    const uint4 a = *reinterpret_cast<const uint4 *>(cw), b = *reinterpret_cast<const uint4 *>(cw + 4);
+                    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                    int rr = s_tab[hc0 + cc].x;
+                    for (int k = 0; k < 8 && !found; ++k) {
+                        const int opi = 8 * cc + k;
+                        if (opi >= hncig) break;
+                        const int op = w[k] & 15u, len = (int)(w[k] >> 4);
+                        if (rr + len > ps) {                            // (from the first such op on: every later op reaches beyond the row as well or does not matter - the test is the reference's)
+                            if (op_is_match(op)) { found = true; j = opi; rp = rr; }
+                            else {
+                                if (!have_q) { q_snp = last_snp_before(V, p + 1); have_q = true; }   // SNP positions never equal p (lps_set_extra_variants)
+                                if (rr - hds > q_snp) { found = true; j = opi; rp = rr; }
+                            }
+                        }
+                        rr += len & -(int)op_bit(LPS_RMASK2, w[k]);
+                    }
+                }
+                if (found) {
+                    const int kind = X.kind[row], info = X.info[row];
+                    const int rp_true = rp - hds;
+                    if (kind == 1) {                                    // :1403-1429
+                        const double region = (double)(abs(info) + 1);
+                        int allele = 0;
+                        const int a = max(j - X.sv_window, 0), b = min(j + X.sv_window, hncig);
+                        const uint32_t *cig = cg + 8 * hc0;
+                        for (int t = a; t < b; ++t) {
+                            const uint32_t c = cig[t]; const int op = c & 15u; const double len = (double)(int)(c >> 4);
+                            if ((op == 1 || op == 2) && fabs(region - len) / fabs(region) < X.sv_threshold) { allele = 1; break; }
+                        }
+                        emit = true; rec = ObsRec{X.u[row], (uint32_t)pack_aq(allele, -1)};
+                    } else {                                            // :1377-1392
+                        const uint32_t name = s_hdr[q].blk0; const bool rev = (hflag & 0x10) != 0;
+                        uint32_t lo = X.mod_off[info], hi = X.mod_off[info + 1]; const uint32_t end = hi;
+                        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (X.mod_name[mid] < name) lo = mid + 1; else hi = mid; }
+                        if (lo < end && X.mod_name[lo] == name) {
+                            const unsigned f = X.mod_flag[lo];
+                            // the reference compares modPos with *currentVariantIter even when that is end(): the entry count of the SNP map
+                            const bool cursor_ok = V.last_pos >= max(rp_true, p + 1) || p < V.n;
+                            if ((((f >> 1) & 1u) != 0) == rev && cursor_ok) { emit = true; rec = ObsRec{X.u[row], (uint32_t)pack_aq((f & 1u) ? 0 : 1, rev ? -3 : -2)}; }
+                        }
+                    }
+                }
+            }
+            // per alignment: the served rows are a prefix (a row no op serves keeps the reference's cursor: nothing behind it is served); records in row order
+            const unsigned long long fm = __ballot(in && !found), em0 = __ballot(emit);
+            unsigned long long keep = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int a = max(cum[k] - i0, 0), b = min(cum[k + 1] - i0, 64);
+                if (b > a) {
+                    const unsigned long long rm = ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << a) - 1ull);
+                    unsigned long long ok = rm;
+                    if ((blocked >> k) & 1u) ok = 0;
+                    else if (fm & rm) { const int first_bad = __builtin_ctzll(fm & rm); ok = rm & ((1ull << first_bad) - 1ull); blocked |= 1u << k; }
+                    keep |= ok;
+                }
+            }
+            const unsigned long long em = em0 & keep;
+            if ((em >> l) & 1ull) {
+                const int cq = SEL4(q, cum), a = max(cq - i0, 0);
+                const unsigned long long before = em & lanemask_lt() & ~((1ull << a) - 1ull);
+                dst[cq + SEL4(q, n_x) + __popcll(before)] = rec;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int a = max(cum[k] - i0, 0), b = min(cum[k + 1] - i0, 64);
+                if (b > a) { const unsigned long long rm = ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << a) - 1ull); n_x[k] += __popcll(em & rm); }
+            }
+        }
+        if (h_in) { x_cnt = SEL4(l, n_x); x_off = (uint32_t)(arena_lo + off + (unsigned)SEL4(l, cum)); }
+        wave_sync();
+    }
+    if (l < nq) xrow[r0 + l] = XRow{x_off, general ? -1 : x_cnt};
+}
+
+// The records k_extra_find left for an alignment, merged by position into its row (union indices on both sides, no common keys): fresh arena slots,
+// one wave per alignment that has records.  Rows and records of ordinary size meet in LDS; longer ones are merged from memory.
+#define XP_CAP 768
+__global__ __launch_bounds__(64) void k_extra_place(int n_reads, ObsView O, const XRow *xrow, LpsCounters *cnt) {
+    __shared__ int s_a[XP_CAP], s_b[XP_CAP];
+    const int r = blockIdx.x, l = lane_id();
+    if (r >= n_reads) return;
+    const XRow x = xrow[r];
+    if (x.cnt <= 0) return;
+    const RowDesc rd = O.rows[r];
+    const int nA = rd.cnt, nB = x.cnt, total = nA + nB;
+    const int arena = blockIdx.x % O.n_arenas;
+    unsigned long long local = 0;
+    if (l == 0) local = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)total);
+    local = __shfl(local, 0);
+    if (local + (unsigned long long)total > O.arena_size) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); return; }   // the host grows the arenas and runs again
+    const uint32_t new_off = (uint32_t)((unsigned long long)arena * O.arena_size + local);
+    const ObsRec *A = O.rec + rd.off, *B = O.rec + x.off; ObsRec *out = O.rec + new_off;
+    const bool in_lds = nA <= XP_CAP && nB <= XP_CAP;
+    if (in_lds) { for (int k = l; k < nA; k += 64) s_a[k] = A[k].var; for (int k = l; k < nB; k += 64) s_b[k] = B[k].var; wave_sync(); }
+#pragma unroll 1
+    for (int o0 = 0; o0 < total; o0 += 64) {
+        const int o = o0 + l;
+        if (o < total) {
+            int lo = max(0, o - nB), hi = min(o, nA);
+            if (in_lds) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_a[mid] < s_b[o - mid - 1]) lo = mid + 1; else hi = mid; } }
+            else { while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid].var < B[o - mid - 1].var) lo = mid + 1; else hi = mid; } }
+            const int i = lo, j = o - lo;
+            const int ka = i < nA ? (in_lds ? s_a[i] : A[i].var) : 0x7fffffff, kb = j < nB ? (in_lds ? s_b[j] : B[j].var) : 0x7fffffff;
+            out[o] = (ka < kb) ? A[i] : B[j];
+        }
+    }
+    if (l == 0) { RowDesc d = rd; d.off = new_off; d.cnt = total; d.flags = 0; O.rows[r] = d; }
+}
+
+void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int32_t *x0, XRow *xrow, int mapping_quality, LpsCounters *cnt, hipStream_t s) {
     if (R.n <= 0) return;
-    hipLaunchKernelGGL(k_extra_merge, dim3((R.n + XM_WPB - 1) / XM_WPB), dim3(64 * XM_WPB), 0, s, V, R, O, X, mapping_quality, cnt);
+    hipLaunchKernelGGL(k_read_x0, dim3((R.n + 255) / 256), dim3(256), 0, s, X, R.ref_start, R.n, x0);
+    hipLaunchKernelGGL(k_extra_find, dim3((R.n + 3) / 4), dim3(64), 0, s, V, R, O, X, x0, xrow, mapping_quality, cnt);
+    hipLaunchKernelGGL(k_extra_place, dim3(R.n), dim3(64), 0, s, R.n, O, xrow, cnt);
+    hipLaunchKernelGGL(k_extra_merge, dim3((R.n + XM_WPB - 1) / XM_WPB), dim3(64 * XM_WPB), 0, s, V, R, O, X, xrow, mapping_quality, cnt);   // what the stream walk left (none with ordinary reads)
 }

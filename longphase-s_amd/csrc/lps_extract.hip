@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
             const bool put = ok && !arena_full;
             const uint32_t slot = (uint32_t)(n_out + __popcll(om & lanemask_lt())), aqw = (uint32_t)pack_aq(allele, qv);
             unsigned rk = 0;
-            if (put) { dst[slot] = ObsRec{(int32_t)v, aqw}; if (var_cnt) rk = atomicAdd(&var_cnt[v], 1u); }
+            if (put) { dst[slot] = ObsRec{O.snp_u ? O.snp_u[v] : (int32_t)v, aqw}; if (var_cnt) rk = atomicAdd(&var_cnt[v], 1u); }   // (with SV / MOD rows: the index in the union of the tables)
             if (pend) {
                 if (pend_rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); dst[pend_slot].aq = pend_aq | (pend_rk << 10); }
             pend = put && var_cnt != nullptr; pend_slot = slot; pend_aq = aqw; pend_rk = rk;
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
                     if (off + need > O.arena_size) arena_full = true;
                     else {
                         const unsigned long long g0 = arena_lo + off;
-                        for (int i = l; i < n_buf; i += 64) O.rec[g0 + i] = ObsRec{bvar[i], baq[i]};
+                        for (int i = l; i < n_buf; i += 64) O.rec[g0 + i] = ObsRec{O.snp_u ? O.snp_u[bvar[i]] : bvar[i], baq[i]};
                         if (l < q) { int *hp = hdr + l * H_WORDS; if (hp[H_KIND] == ROW_BUFFERED) { hp[H_KIND] = ROW_GLOBAL; hp[H_ROFF] = (int)(uint32_t)(g0 + (unsigned)hp[H_ROFF]); } }
                         direct_base = g0 + row_start;
                     }
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
                     unsigned rk = 0;                                        // rank inside the variant's list of observations (see k_extract_phase)
                     if (var_cnt) { rk = atomicAdd(&var_cnt[v], 1u); if (rk > 0x3fffffu) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); }
                     const uint32_t aqw = (uint32_t)pack_aq(allele, qv) | (rk << 10);
-                    if (direct) { if (!arena_full) O.rec[direct_base + rank] = ObsRec{v, aqw}; }
+                    if (direct) { if (!arena_full) O.rec[direct_base + rank] = ObsRec{O.snp_u ? O.snp_u[v] : v, aqw}; }
                     else { bvar[row_start + rank] = v; baq[row_start + rank] = aqw; }
                 }
                 n_emit += n_em;
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
         if (off + (unsigned long long)n_buf > O.arena_size) arena_full = true;
     }
     const unsigned long long g0 = arena_lo + off;
-    if (!arena_full) for (int i = l; i < n_buf; i += 64) O.rec[g0 + i] = ObsRec{bvar[i], baq[i]};
+    if (!arena_full) for (int i = l; i < n_buf; i += 64) O.rec[g0 + i] = ObsRec{O.snp_u ? O.snp_u[bvar[i]] : bvar[i], baq[i]};
     if (arena_full && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW);          // the host grows the arenas and reruns
     if (l < nq) {
         const int *hp = hdr + l * H_WORDS; const int r = r0 + l; const int kind = hp[H_KIND];

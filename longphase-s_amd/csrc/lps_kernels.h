@@ -71,6 +71,7 @@ struct ObsView {           // rows placed by atomic reservation: row r = [rows[r
     unsigned long long arena_size;      // slots per arena; arena a covers [a*arena_size, (a+1)*arena_size)
     unsigned long long *arena_ctr;      // LPS_ARENAS counters, 8 u64 apart (one cache line each)
     int n_arenas;                       // arenas in use: min(LPS_ARENAS, workgroups)
+    const int32_t *snp_u;               // SV / MOD rows co-phased: index of SNP row v in the union of the three tables - what the extraction then writes as `var` (else nullptr)
 };
 
 // Clip events of the kept alignments (filtered by RowDesc.fail afterwards).  k_extract_phase writes the events of job j into ITS OWN slots
@@ -96,7 +97,8 @@ struct ExtraView {
     const uint8_t *mod_flag;
     int sv_window; double sv_threshold;
 };
-void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int mapping_quality, LpsCounters *cnt, hipStream_t s);
+struct XRow { uint32_t off; int32_t cnt; };   // the SV / MOD records k_extra_find left for an alignment: O.rec[off .. off + cnt); cnt -1: left to k_extra_merge
+void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int32_t *x0, XRow *xrow, int mapping_quality, LpsCounters *cnt, hipStream_t s);
 
 void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *rec, hipStream_t s);
 
