@@ -41,7 +41,7 @@ struct lps_ctx {
     // SV / MOD rows (lps_set_extra_variants): merged by position; nG / g_vpos = size and positions of the table the stages after the extraction
     // run on (the SNP table itself when there are no such rows, else the union of the three)
     int nX = 0, nSV = 0, nMOD = 0, sv_window = 20; double sv_threshold = 0.1;
-    DevBuf<int32_t> x_pos, x_info, x_u, x_snp_u, u_pos, x_x0; DevBuf<XRow> x_row; DevBuf<uint8_t> x_kind, x_mflag; DevBuf<uint32_t> x_moff, x_mname;
+    DevBuf<int32_t> x_pos, x_info, x_u, x_snp_u, u_pos, x_x0; DevBuf<XRow> x_row; DevBuf<int4> x_rec; DevBuf<uint32_t> x_mpack; DevBuf<uint8_t> x_kind, x_mflag; DevBuf<uint32_t> x_moff, x_mname;
     std::vector<int32_t> h_snp_u, h_sv_u, h_mod_u, h_res_ps_u; std::vector<uint8_t> h_res_gt_u;
     int nG = 0; const int32_t *g_vpos = nullptr;
     std::vector<int32_t> votes_h1, votes_h2;   // lps_set_read_votes
@@ -341,6 +341,11 @@ int lps_set_extra_variants(lps_ctx *c, const lps_extra_variants *x) {
         const size_t ne = nM ? (size_t)x->mod_off[nM] : 0;
         c->x_mname.reserve(ne + 1); c->x_mflag.reserve(ne + 1);
         if (ne) { upload(c, c->x_mname, x->mod_name, ne); upload(c, c->x_mflag, x->mod_flag, ne); }
+        // what k_extra_find reads per row / per listed read in ONE load each: {pos, info, union index, kind} and name << 2 | flags
+        std::vector<int4> xrec(nX); for (int64_t i = 0; i < nX; ++i) xrec[i] = make_int4(xpos[i], xinfo[i], xu[i], (int)xkind[i]);
+        std::vector<uint32_t> mpack(ne);
+        for (size_t i = 0; i < ne; ++i) { if (x->mod_name[i] >= (1u << 30)) return fail(c, "lps_set_extra_variants: read name ids must be below 2^30"); mpack[i] = (x->mod_name[i] << 2) | (uint32_t)(x->mod_flag[i] & 3u); }
+        upload(c, c->x_rec, xrec.data(), (size_t)nX); c->x_mpack.reserve(ne + 1); if (ne) upload(c, c->x_mpack, mpack.data(), ne);
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->nX = (int)nX; c->nSV = (int)nS; c->nMOD = (int)nM; c->sv_window = x->sv_window; c->sv_threshold = x->sv_threshold;
     } catch (std::string &e) { return fail(c, e); }
@@ -1040,7 +1045,7 @@ static int run_phase(lps_ctx *c) {
         }
         // ---- SV / MOD rows: served against each alignment's CIGAR, merged into its row; every observation leaves in union indices
         if (c->nX) {
-            ExtraView X{c->nX, c->x_pos.p, c->x_info.p, c->x_kind.p, c->x_u.p, c->x_snp_u.p, c->x_moff.p, c->x_mname.p, c->x_mflag.p, c->sv_window, c->sv_threshold};
+            ExtraView X{c->nX, c->x_pos.p, c->x_info.p, c->x_kind.p, c->x_u.p, c->x_snp_u.p, c->x_moff.p, c->x_mname.p, c->x_mflag.p, c->sv_window, c->sv_threshold, c->x_rec.p, c->x_mpack.p};
             c->x_x0.reserve((size_t)nR + 1); c->x_row.reserve((size_t)nR + 1);
             launch_extra_merge(V, R, O, X, c->x_x0.p, c->x_row.p, P.mapping_quality, c->d_cnt, s);
         }

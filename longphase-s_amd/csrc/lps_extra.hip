@@ -240,6 +240,7 @@ __global__ void k_read_x0(ExtraView X, const int32_t *ref_start, int n, int32_t 
 
 __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, ObsView O, ExtraView X, const int32_t *x0, XRow *xrow, int mapping_quality, LpsCounters *cnt) {
     __shared__ __attribute__((aligned(16))) int2 s_tab[XF_TAB];          // (stream reference coordinate at the chunk's start, running maximum of E through the chunk)
+    __shared__ int s_lm[XF_TAB];                                         // maximum of E over the chunk's own ops: chunks that cannot serve a row are passed over without loading them
     __shared__ ExtHdr s_hdr[4];
     const int l = lane_id();
     const int job = blockIdx.x, r0 = job * 4;
@@ -310,6 +311,7 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                 const int ir = wave_incl_scan_dpp((int)rt);
                 const int my_s = carry_r + ir - (int)rt;
                 int v = live ? my_s + emax : (int)0x80000000;
+                if (live) s_lm[cid] = v;
                 bool f = live && (cid == hc[0] || cid == hc[1] || cid == hc[2] || cid == hc[3]);
                 if (l == 0 && !f) v = max(v, carry_e);
 #pragma unroll
@@ -366,14 +368,18 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                 const int4 ha = *reinterpret_cast<const int4 *>(&s_hdr[q].crel), hb = *reinterpret_cast<const int4 *>(&s_hdr[q].vadj);
                 const int hncig = ha.y, hc0 = ha.z, hnch = ha.w, hflag = hb.y, hds = hb.z;
                 const int row = hb.x + i;
-                const int p = X.pos[row], ps = p + hds;
+                const int4 xr = X.rec[row];                             // {pos, info, union index, kind}
+                const int p = xr.x, ps = p + hds;
                 // first chunk of the alignment whose running maximum exceeds the row: the op that first reaches beyond it lies there
                 int co = -1;
                 for (int step = step0; step >= 1; step >>= 1) { const int t = co + step; const int ev = s_tab[hc0 + min(t, hnch - 1)].y; co = (t < hnch && ev <= ps) ? t : co; }
                 ++co;                                                     // (co < hnch: ps < reach = the last chunk's running maximum)
                 if (step0 == 0) co = 0;
                 int q_snp = 0; bool have_q = false; int j = 0, rp = 0;
+                // (a row in the reach of a long clip or insertion that does not serve it - a SNP lies in between - is served by a much later op: the
+                //  chunks in between whose own ops all end at or before the row are passed over by their table entry, not loaded)
                 for (int cc = co; cc < hnch && !found; ++cc) {
+                    if (cc > co && s_lm[hc0 + cc] <= ps) continue;
                     const uint32_t *cw = cg + 8 * (hc0 + cc);
                     const uint4 a = *reinterpret_cast<const uint4 *>(cw), b = *reinterpret_cast<const uint4 *>(cw + 4);
                     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -393,27 +399,44 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                     }
                 }
                 if (found) {
-                    const int kind = X.kind[row], info = X.info[row];
+                    const int kind = xr.w, info = xr.y;
                     const int rp_true = rp - hds;
                     if (kind == 1) {                                    // :1403-1429
                         const double region = (double)(abs(info) + 1);
                         int allele = 0;
                         const int a = max(j - X.sv_window, 0), b = min(j + X.sv_window, hncig);
                         const uint32_t *cig = cg + 8 * hc0;
-                        for (int t = a; t < b; ++t) {
-                            const uint32_t c = cig[t]; const int op = c & 15u; const double len = (double)(int)(c >> 4);
-                            if ((op == 1 || op == 2) && fabs(region - len) / fabs(region) < X.sv_threshold) { allele = 1; break; }
+                        for (int c8 = a >> 3; c8 <= (b - 1) >> 3 && !allele; ++c8) {        // the window's words a lane-chunk at a time (two 16-byte loads a trip instead of one word)
+                            const uint4 wa = *reinterpret_cast<const uint4 *>(cig + 8 * c8), wb = *reinterpret_cast<const uint4 *>(cig + 8 * c8 + 4);
+                            const uint32_t ww[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const int t = 8 * c8 + k; const int op = ww[k] & 15u; const double len = (double)(int)(ww[k] >> 4);
+                                if (t >= a && t < b && (op == 1 || op == 2) && fabs(region - len) / fabs(region) < X.sv_threshold) allele = 1;
+                            }
                         }
-                        emit = true; rec = ObsRec{X.u[row], (uint32_t)pack_aq(allele, -1)};
+                        emit = true; rec = ObsRec{xr.z, (uint32_t)pack_aq(allele, -1)};
                     } else {                                            // :1377-1392
                         const uint32_t name = s_hdr[q].blk0; const bool rev = (hflag & 0x10) != 0;
                         uint32_t lo = X.mod_off[info], hi = X.mod_off[info + 1]; const uint32_t end = hi;
-                        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (X.mod_name[mid] < name) lo = mid + 1; else hi = mid; }
-                        if (lo < end && X.mod_name[lo] == name) {
-                            const unsigned f = X.mod_flag[lo];
+                        // first listed read with name >= this one: a 4-ary search over name << 2 | flags (three probes a trip: a site lists a read per fold of coverage)
+                        const uint32_t key = name << 2;
+                        while (hi - lo > 3) {
+                            const uint32_t n4 = (hi - lo) >> 2, m1 = lo + n4, m2 = m1 + n4, m3 = m2 + n4;
+                            const uint32_t v1 = X.mod_pack[m1], v2 = X.mod_pack[m2], v3 = X.mod_pack[m3];
+                            if (v1 >= key) hi = m1; else if (v2 >= key) { lo = m1 + 1; hi = m2; } else if (v3 >= key) { lo = m2 + 1; hi = m3; } else lo = m3 + 1;
+                        }
+                        bool have = false; uint32_t hit = 0u;                      // the answer is one of lo, lo + 1, lo + 2 (below hi) or hi itself: four probes, one trip
+                        {
+                            const bool i0 = lo < hi, i1 = lo + 1 < hi, i2 = lo + 2 < hi, ih = hi < end;
+                            const uint32_t v0 = i0 ? X.mod_pack[lo] : 0u, v1 = i1 ? X.mod_pack[lo + 1] : 0u, v2 = i2 ? X.mod_pack[lo + 2] : 0u, vh = ih ? X.mod_pack[hi] : 0u;
+                            if (i0 && v0 >= key) { have = true; hit = v0; } else if (i1 && v1 >= key) { have = true; hit = v1; } else if (i2 && v2 >= key) { have = true; hit = v2; } else if (ih) { have = true; hit = vh; }
+                        }
+                        if (have && (hit >> 2) == name) {
+                            const unsigned f = hit & 3u;
                             // the reference compares modPos with *currentVariantIter even when that is end(): the entry count of the SNP map
                             const bool cursor_ok = V.last_pos >= max(rp_true, p + 1) || p < V.n;
-                            if ((((f >> 1) & 1u) != 0) == rev && cursor_ok) { emit = true; rec = ObsRec{X.u[row], (uint32_t)pack_aq((f & 1u) ? 0 : 1, rev ? -3 : -2)}; }
+                            if ((((f >> 1) & 1u) != 0) == rev && cursor_ok) { emit = true; rec = ObsRec{xr.z, (uint32_t)pack_aq((f & 1u) ? 0 : 1, rev ? -3 : -2)}; }
                         }
                     }
                 }

@@ -96,6 +96,8 @@ struct ExtraView {
     const uint32_t *mod_name;
     const uint8_t *mod_flag;
     int sv_window; double sv_threshold;
+    const int4 *rec;           // per row {pos, info, u, kind}: one load for k_extra_find
+    const uint32_t *mod_pack;  // mod_name << 2 | mod_flag: the search finds the flags with the name
 };
 struct XRow { uint32_t off; int32_t cnt; };   // the SV / MOD records k_extra_find left for an alignment: O.rec[off .. off + cnt); cnt -1: left to k_extra_merge
 void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int32_t *x0, XRow *xrow, int mapping_quality, LpsCounters *cnt, hipStream_t s);

@@ -1,8 +1,9 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-for c in 3 4 5 6 8; do
-  LPS_HIP_LIB=$ROOT/longphase-s_amd/csrc/ab/p4.so timeout -k 10 300 python3 $ROOT/bench.py --no-cpu-baseline --parity none --ctx-per-gpu $c > /tmp/c.json 2>/tmp/c.err || { echo "ctx $c failed"; tail -3 /tmp/c.err; }
-  python3 -c "
-import json
-d=json.loads(open('/tmp/c.json').read().strip().splitlines()[-1])
-print('ctx $c pass ms', round(d['ms_per_step'],2), 'haplotag ms', round(d['secondary']['ms_per_step'],2))"
+cd /tmp && export TMPDIR=/tmp
+for v in xf3 xf4; do
+  export LPS_HIP_LIB=$ROOT/longphase-s_amd/csrc/ab/$v.so
+  rm -rf /tmp/xp_$v
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/xp_$v -o x -- python3 -m pytest $ROOT/tests/test_scale_gpu.py -m gpu -x -q -k sv_and_mod > /tmp/xp_$v.log 2>&1
+  echo "$v: $(grep k_extra_find /tmp/xp_$v/x_kernel_stats.csv | cut -d, -f1,2,4 | cut -c1-40,100-)"
+  grep "k_extra_find" /tmp/xp_$v/x_kernel_stats.csv | awk -F, '{print $(NF-6), $(NF-5), $(NF-4)}'
 done
