@@ -41,7 +41,7 @@ struct lps_ctx {
     // SV / MOD rows (lps_set_extra_variants): merged by position; nG / g_vpos = size and positions of the table the stages after the extraction
     // run on (the SNP table itself when there are no such rows, else the union of the three)
     int nX = 0, nSV = 0, nMOD = 0, sv_window = 20; double sv_threshold = 0.1;
-    DevBuf<int32_t> x_pos, x_info, x_u, x_snp_u, u_pos, x_x0; DevBuf<XRow> x_row; DevBuf<int4> x_rec; DevBuf<uint32_t> x_mpack; DevBuf<uint8_t> x_kind, x_mflag; DevBuf<uint32_t> x_moff, x_mname;
+    DevBuf<int32_t> x_pos, x_info, x_u, x_snp_u, u_pos, x_x0; DevBuf<uint32_t> x_redo; DevBuf<int4> x_rec; DevBuf<uint32_t> x_mpack; DevBuf<uint8_t> x_kind, x_mflag; DevBuf<uint32_t> x_moff, x_mname;
     std::vector<int32_t> h_snp_u, h_sv_u, h_mod_u, h_res_ps_u; std::vector<uint8_t> h_res_gt_u;
     int nG = 0; const int32_t *g_vpos = nullptr;
     std::vector<int32_t> votes_h1, votes_h2;   // lps_set_read_votes
@@ -1046,8 +1046,8 @@ static int run_phase(lps_ctx *c) {
         // ---- SV / MOD rows: served against each alignment's CIGAR, merged into its row; every observation leaves in union indices
         if (c->nX) {
             ExtraView X{c->nX, c->x_pos.p, c->x_info.p, c->x_kind.p, c->x_u.p, c->x_snp_u.p, c->x_moff.p, c->x_mname.p, c->x_mflag.p, c->sv_window, c->sv_threshold, c->x_rec.p, c->x_mpack.p};
-            c->x_x0.reserve((size_t)nR + 1); c->x_row.reserve((size_t)nR + 1);
-            launch_extra_merge(V, R, O, X, c->x_x0.p, c->x_row.p, P.mapping_quality, c->d_cnt, s);
+            c->x_x0.reserve((size_t)nR + 1); c->x_redo.reserve((size_t)nR + 2);
+            launch_extra_merge(V, R, O, X, c->x_x0.p, c->x_redo.p + 1, c->x_redo.p, P.mapping_quality, c->d_cnt, s);   // (x_redo[0]: how many alignments were queued for the general walker)
         }
         GraphView &G = c->G;
         G = GraphView{};

@@ -41,20 +41,11 @@ __device__ __forceinline__ int last_snp_before(const VarView &V, int p) {
 }
 
 #define XM_WPB 1        // waves per workgroup (they share nothing)
-// (since round 3 the general walker behind k_extra_find: it takes the alignments that kernel marked - xrow[r].cnt == -1 - and finds their rows of
-// observations already in union indices, as the extraction writes them)
-__global__ __launch_bounds__(64 * XM_WPB) void k_extra_merge(VarView V, ReadView R, ObsView O, ExtraView X, const XRow *xrow, int mapping_quality, LpsCounters *cnt) {
-    __shared__ __attribute__((aligned(16))) int s_ref[XM_WPB][LPS_SEG];
-    __shared__ __attribute__((aligned(16))) int s_qry[XM_WPB][LPS_SEG];
-    __shared__ __attribute__((aligned(16))) uint32_t s_cig[XM_WPB][LPS_SEG + 4];
-    __shared__ int s_pm[XM_WPB][LPS_SEG];
-    __shared__ ObsRec s_ex[XM_WPB][XM_CAP];
-    const int w = threadIdx.x >> 6, l = lane_id();
-    const int r = blockIdx.x * XM_WPB + w;
-    if (r >= R.n) return;
-    int *sref = s_ref[w], *sqry = s_qry[w], *spm = s_pm[w]; uint32_t *scig = s_cig[w]; ObsRec *sex = s_ex[w];
-
-    if (xrow[r].cnt != -1) return;
+// (since round 3 the general walker behind k_extra_find: it takes the alignments that kernel queued - more chunks than its table holds, an op of 2^24
+// bases, a second reservation that did not fit - and finds their rows of observations already in union indices, as the extraction writes them)
+__device__ void extra_merge_one(const int r, const int arena, const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int mapping_quality, LpsCounters *cnt,
+                                int *sref, int *sqry, uint32_t *scig, int *spm, ObsRec *sex) {
+    const int l = lane_id();
     const RowDesc rd = O.rows[r];
     const int start = R.ref_start[r], flag = R.flag[r];
     const bool live = !(R.mapq[r] < mapping_quality || (flag & 0x4) || (flag & 0x100) || (flag & 0x400) || start >= V.last_pos) && rd.fail == 0x7fffffff;
@@ -175,7 +166,6 @@ __global__ __launch_bounds__(64 * XM_WPB) void k_extra_merge(VarView V, ReadView
             if (pass == 0) {
                 n_emit = idx;
                 if (n_emit == 0) break;
-                const int arena = blockIdx.x % O.n_arenas;
                 const unsigned long long need = (unsigned long long)rd.cnt + (unsigned long long)n_emit;
                 unsigned long long local = 0;
                 if (l == 0) local = atomicAdd(&O.arena_ctr[arena * 8], need);
@@ -215,6 +205,19 @@ __global__ __launch_bounds__(64 * XM_WPB) void k_extra_merge(VarView V, ReadView
     }
     if (l == 0) { RowDesc d = rd; d.off = new_off; d.cnt = total; d.flags = 0; O.rows[r] = d; }
 }
+__global__ __launch_bounds__(64) void k_extra_merge(VarView V, ReadView R, ObsView O, ExtraView X, const uint32_t *list, const unsigned *n_list, int mapping_quality, LpsCounters *cnt) {
+    __shared__ __attribute__((aligned(16))) int s_ref[LPS_SEG];
+    __shared__ __attribute__((aligned(16))) int s_qry[LPS_SEG];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cig[LPS_SEG + 4];
+    __shared__ int s_pm[LPS_SEG];
+    __shared__ ObsRec s_ex[XM_CAP];
+    const unsigned n = *n_list;
+#pragma unroll 1
+    for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+        extra_merge_one((int)list[i], (int)(i % (unsigned)O.n_arenas), V, R, O, X, mapping_quality, cnt, s_ref, s_qry, s_cig, s_pm, s_ex);
+        wave_sync();                                                    // the LDS arrays are reused by the wave's next alignment
+    }
+}
 
 
 // ================================================================================================ the stream walk for SV / MOD rows
@@ -223,9 +226,10 @@ __global__ __launch_bounds__(64 * XM_WPB) void k_extra_merge(VarView V, ReadView
 // lane-chunks as one stream (lps_reads.hip) and keeps per chunk (reference coordinate at its start, running maximum of E = ref_pos + length over
 // the alignment's ops through the chunk) - the rows of the four alignments' reaches are then one flattened list, a lane each: binary search of the
 // chunk whose running maximum first exceeds the row, its 8 words, the first op with E > p, the scan forward to the op that serves the row (header
-// of this file), the record.  The records of an alignment leave compacted in row order into the wave's arena (k_extra_place merges them into the
-// alignment's row); XRow = where they are.  What this walk cannot take (an alignment of more chunks than the table holds, an op of 2^24 bases,
-// stream coordinates beyond 2^30) is marked cnt = -1 and left to k_extra_merge.
+// of this file; chunks whose own ops all end at or before the row are passed over by a third table entry), the record.  The records of an alignment
+// leave compacted in row order into the wave's arena and are merged by position into the alignment's row right there: ONE more reservation for the
+// rows of the job that got records, the outputs of its four merges flattened over the lanes, the keys of rows and records in LDS.  What this walk
+// cannot take (an alignment of more chunks than the table holds, an op of 2^24 bases, stream coordinates beyond 2^30) is queued for k_extra_merge.
 #define XF_TAB 1024
 
 __global__ void k_read_x0(ExtraView X, const int32_t *ref_start, int n, int32_t *x0) {
@@ -238,7 +242,7 @@ __global__ void k_read_x0(ExtraView X, const int32_t *ref_start, int n, int32_t 
     x0[r] = lo;
 }
 
-__global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, ObsView O, ExtraView X, const int32_t *x0, XRow *xrow, int mapping_quality, LpsCounters *cnt) {
+__global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, ObsView O, ExtraView X, const int32_t *x0, uint32_t *redo, unsigned *n_redo, int mapping_quality, LpsCounters *cnt) {
     __shared__ __attribute__((aligned(16))) int2 s_tab[XF_TAB];          // (stream reference coordinate at the chunk's start, running maximum of E through the chunk)
     __shared__ int s_lm[XF_TAB];                                         // maximum of E over the chunk's own ops: chunks that cannot serve a row are passed over without loading them
     __shared__ ExtHdr s_hdr[4];
@@ -249,14 +253,14 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
     const int arena = blockIdx.x % O.n_arenas;
     const unsigned long long arena_lo = (unsigned long long)arena * O.arena_size;
     // ---- plan: alignment q in lane q; the filters of the extraction + "get_snp returned early: the alignment has no row"
-    int h_start = 0, h_n = 0, h_x0 = 0, h_flag = 0; unsigned h_cp = 0, h_name = 0; bool h_live = false;
+    int h_start = 0, h_n = 0, h_x0 = 0, h_flag = 0, h_rcnt = 0; unsigned h_cp = 0, h_name = 0, h_roff = 0; bool h_live = false;
     if (l <= nq) h_cp = R.cp_off[r0 + l];
     if (l < nq) {
         const int r = r0 + l; h_start = R.ref_start[r]; h_n = R.cp_n[r]; h_x0 = x0[r]; h_flag = R.flag[r]; h_name = R.name_id[r];
-        h_live = !(R.mapq[r] < mapping_quality || (h_flag & 0x4) || (h_flag & 0x100) || (h_flag & 0x400) || h_start >= V.last_pos) && O.rows[r].fail == 0x7fffffff && h_x0 < X.n;
+        const RowDesc rd = O.rows[r]; h_roff = rd.off; h_rcnt = rd.cnt;
+        h_live = !(R.mapq[r] < mapping_quality || (h_flag & 0x4) || (h_flag & 0x100) || (h_flag & 0x400) || h_start >= V.last_pos) && rd.fail == 0x7fffffff && h_x0 < X.n;
     }
     const int h_nch = (int)(__shfl_down(h_cp, 1) - h_cp);
-    int x_cnt = 0; uint32_t x_off = 0;                     // what lane q reports for alignment q
     bool general = l < nq && h_live && h_nch > XF_TAB;                  // more chunks than the table holds: left to k_extra_merge
     unsigned todo = (unsigned)__ballot(h_live && !general) & 15u;
 #pragma unroll 1
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
         wave_sync();
         off = __shfl(off, 0);
         const bool arena_full = T > 0 && off + (unsigned long long)T > O.arena_size;
-        if (arena_full) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); if (l < nq) xrow[r0 + l] = XRow{0u, 0}; return; }   // the host grows the arenas and runs again (nothing is left for the kernels behind this one)
+        if (arena_full) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); return; }   // the host grows the arenas and runs again
         ObsRec *dst = O.rec + arena_lo + off;
         const int step0 = maxnch > 1 ? 1 << (31 - __builtin_clz(maxnch - 1)) : 0;
         int n_x[4] = {0, 0, 0, 0}; unsigned blocked = 0;                  // records of alignment k so far; k has a row that no op serves: the cursor stays there
@@ -467,51 +471,62 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                 if (b > a) { const unsigned long long rm = ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << a) - 1ull); n_x[k] += __popcll(em & rm); }
             }
         }
-        if (h_in) { x_cnt = SEL4(l, n_x); x_off = (uint32_t)(arena_lo + off + (unsigned)SEL4(l, cum)); }
+        // ---- the records merged by position into the rows of the group's alignments (union indices on both sides, no common keys): the rows that
+        //      got records move to fresh slots, ONE reservation for all of them, the outputs of the four merges flattened over the lanes; the keys of
+        //      rows and records meet in LDS (the walk's tables are done with)
+        {
+            int nA[4], nB[4], cm[5], ca[5], cb[5]; cm[0] = ca[0] = cb[0] = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                nB[q] = n_x[q]; nA[q] = nB[q] ? __builtin_amdgcn_readlane(h_rcnt, q) : 0;
+                cm[q + 1] = cm[q] + nA[q] + nB[q]; ca[q + 1] = ca[q] + nA[q]; cb[q + 1] = cb[q] + nB[q];
+            }
+            const int TM = cm[4];
+            if (TM > 0) {
+                unsigned roffq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) roffq[q] = (unsigned)__builtin_amdgcn_readlane((int)h_roff, q);
+                unsigned long long off2 = 0;
+                if (l == 0) off2 = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)TM);
+                off2 = __shfl(off2, 0);
+                if (off2 + (unsigned long long)TM > O.arena_size) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); return; }   // the host grows the arenas and runs again
+                ObsRec *out = O.rec + arena_lo + off2;
+                __threadfence_block();                                  // the records this wave wrote above are read back below
+                int *s_ka = s_lm, *s_kb = reinterpret_cast<int *>(s_tab);   // keys of the rows (<= XF_TAB) / of the records (<= 2 * XF_TAB)
+                const bool in_lds = ca[4] <= XF_TAB && cb[4] <= 2 * XF_TAB;
+                wave_sync();
+                if (in_lds) {
+                    for (int i = l; i < ca[4]; i += 64) { const int q = (i >= ca[1]) + (i >= ca[2]) + (i >= ca[3]); s_ka[i] = O.rec[SEL4(q, roffq) + (unsigned)(i - SEL4(q, ca))].var; }
+                    for (int i = l; i < cb[4]; i += 64) { const int q = (i >= cb[1]) + (i >= cb[2]) + (i >= cb[3]); s_kb[i] = dst[SEL4(q, cum) + (i - SEL4(q, cb))].var; }
+                    wave_sync();
+                }
+#pragma unroll 1
+                for (int o0 = 0; o0 < TM; o0 += 64) {
+                    const int og = o0 + l;
+                    if (og < TM) {
+                        const int q = (og >= cm[1]) + (og >= cm[2]) + (og >= cm[3]);
+                        const int o = og - SEL4(q, cm), na = SEL4(q, nA), nb = SEL4(q, nB), a0 = SEL4(q, ca), b0 = SEL4(q, cb);
+                        const ObsRec *A = O.rec + SEL4(q, roffq), *B = dst + SEL4(q, cum);
+                        int lo = max(0, o - nb), hi = min(o, na);
+                        if (in_lds) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_ka[a0 + mid] < s_kb[b0 + o - mid - 1]) lo = mid + 1; else hi = mid; } }
+                        else { while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid].var < B[o - mid - 1].var) lo = mid + 1; else hi = mid; } }
+                        const int i = lo, j = o - lo;
+                        const int ka = i < na ? (in_lds ? s_ka[a0 + i] : A[i].var) : 0x7fffffff, kb = j < nb ? (in_lds ? s_kb[b0 + j] : B[j].var) : 0x7fffffff;
+                        out[og] = (ka < kb) ? A[i] : B[j];
+                    }
+                }
+                if (l < 4 && SEL4(l, nB) > 0) { RowDesc d = O.rows[r0 + l]; d.off = (uint32_t)(arena_lo + off2 + (unsigned)SEL4(l, cm)); d.cnt = SEL4(l, nA) + SEL4(l, nB); d.flags = 0; O.rows[r0 + l] = d; }
+            }
+        }
         wave_sync();
     }
-    if (l < nq) xrow[r0 + l] = XRow{x_off, general ? -1 : x_cnt};
+    if (l < nq && general) redo[atomicAdd(n_redo, 1u)] = (uint32_t)(r0 + l);   // (rare: one atomic per alignment that is left to the general walker)
 }
 
-// The records k_extra_find left for an alignment, merged by position into its row (union indices on both sides, no common keys): fresh arena slots,
-// one wave per alignment that has records.  Rows and records of ordinary size meet in LDS; longer ones are merged from memory.
-#define XP_CAP 768
-__global__ __launch_bounds__(64) void k_extra_place(int n_reads, ObsView O, const XRow *xrow, LpsCounters *cnt) {
-    __shared__ int s_a[XP_CAP], s_b[XP_CAP];
-    const int r = blockIdx.x, l = lane_id();
-    if (r >= n_reads) return;
-    const XRow x = xrow[r];
-    if (x.cnt <= 0) return;
-    const RowDesc rd = O.rows[r];
-    const int nA = rd.cnt, nB = x.cnt, total = nA + nB;
-    const int arena = blockIdx.x % O.n_arenas;
-    unsigned long long local = 0;
-    if (l == 0) local = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)total);
-    local = __shfl(local, 0);
-    if (local + (unsigned long long)total > O.arena_size) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); return; }   // the host grows the arenas and runs again
-    const uint32_t new_off = (uint32_t)((unsigned long long)arena * O.arena_size + local);
-    const ObsRec *A = O.rec + rd.off, *B = O.rec + x.off; ObsRec *out = O.rec + new_off;
-    const bool in_lds = nA <= XP_CAP && nB <= XP_CAP;
-    if (in_lds) { for (int k = l; k < nA; k += 64) s_a[k] = A[k].var; for (int k = l; k < nB; k += 64) s_b[k] = B[k].var; wave_sync(); }
-#pragma unroll 1
-    for (int o0 = 0; o0 < total; o0 += 64) {
-        const int o = o0 + l;
-        if (o < total) {
-            int lo = max(0, o - nB), hi = min(o, nA);
-            if (in_lds) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_a[mid] < s_b[o - mid - 1]) lo = mid + 1; else hi = mid; } }
-            else { while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid].var < B[o - mid - 1].var) lo = mid + 1; else hi = mid; } }
-            const int i = lo, j = o - lo;
-            const int ka = i < nA ? (in_lds ? s_a[i] : A[i].var) : 0x7fffffff, kb = j < nB ? (in_lds ? s_b[j] : B[j].var) : 0x7fffffff;
-            out[o] = (ka < kb) ? A[i] : B[j];
-        }
-    }
-    if (l == 0) { RowDesc d = rd; d.off = new_off; d.cnt = total; d.flags = 0; O.rows[r] = d; }
-}
-
-void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int32_t *x0, XRow *xrow, int mapping_quality, LpsCounters *cnt, hipStream_t s) {
+void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int32_t *x0, uint32_t *redo, unsigned *n_redo, int mapping_quality, LpsCounters *cnt, hipStream_t s) {
     if (R.n <= 0) return;
+    (void)hipMemsetAsync(n_redo, 0, sizeof(unsigned), s);
     hipLaunchKernelGGL(k_read_x0, dim3((R.n + 255) / 256), dim3(256), 0, s, X, R.ref_start, R.n, x0);
-    hipLaunchKernelGGL(k_extra_find, dim3((R.n + 3) / 4), dim3(64), 0, s, V, R, O, X, x0, xrow, mapping_quality, cnt);
-    hipLaunchKernelGGL(k_extra_place, dim3(R.n), dim3(64), 0, s, R.n, O, xrow, cnt);
-    hipLaunchKernelGGL(k_extra_merge, dim3((R.n + XM_WPB - 1) / XM_WPB), dim3(64 * XM_WPB), 0, s, V, R, O, X, xrow, mapping_quality, cnt);   // what the stream walk left (none with ordinary reads)
+    hipLaunchKernelGGL(k_extra_find, dim3((R.n + 3) / 4), dim3(64), 0, s, V, R, O, X, x0, redo, n_redo, mapping_quality, cnt);
+    hipLaunchKernelGGL(k_extra_merge, dim3(std::min(256, R.n)), dim3(64), 0, s, V, R, O, X, redo, n_redo, mapping_quality, cnt);   // what the stream walk queued (nothing with ordinary reads)
 }

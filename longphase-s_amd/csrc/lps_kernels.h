@@ -99,8 +99,7 @@ struct ExtraView {
     const int4 *rec;           // per row {pos, info, u, kind}: one load for k_extra_find
     const uint32_t *mod_pack;  // mod_name << 2 | mod_flag: the search finds the flags with the name
 };
-struct XRow { uint32_t off; int32_t cnt; };   // the SV / MOD records k_extra_find left for an alignment: O.rec[off .. off + cnt); cnt -1: left to k_extra_merge
-void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int32_t *x0, XRow *xrow, int mapping_quality, LpsCounters *cnt, hipStream_t s);
+void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int32_t *x0, uint32_t *redo, unsigned *n_redo, int mapping_quality, LpsCounters *cnt, hipStream_t s);
 
 void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *rec, hipStream_t s);
 
