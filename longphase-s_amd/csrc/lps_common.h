@@ -110,6 +110,18 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
     return v;
 }
 
+// the same for the running maximum (lanes a shift does not reach keep INT_MIN)
+__device__ __forceinline__ int wave_incl_max_dpp(int v) {
+    const int none = (int)0x80000000;
+    v = max(v, __builtin_amdgcn_update_dpp(none, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(none, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(none, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(none, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(none, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(none, v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
 template <class T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

@@ -230,7 +230,9 @@ __global__ __launch_bounds__(64) void k_extra_merge(VarView V, ReadView R, ObsVi
 // leave compacted in row order into the wave's arena and are merged by position into the alignment's row right there: ONE more reservation for the
 // rows of the job that got records, the outputs of its four merges flattened over the lanes, the keys of rows and records in LDS.  What this walk
 // cannot take (an alignment of more chunks than the table holds, an op of 2^24 bases, stream coordinates beyond 2^30) is queued for k_extra_merge.
-#define XF_TAB 1024
+#ifndef XF_TAB
+#define XF_TAB 768     // lane-chunks of a group's stream (6 144 words); LDS 9.2 KB per wave
+#endif
 
 __global__ void k_read_x0(ExtraView X, const int32_t *ref_start, int n, int32_t *x0) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
         // first chunk of an alignment of the job (the running maximum starts again there): chunk index -> bit
         int hc[4]; 
 #pragma unroll
-        for (int q = 0; q < 4; ++q) hc[q] = q < nq ? __builtin_amdgcn_readlane(h_c0, q) : -1;
+        for (int q = 0; q < 4; ++q) hc[q] = q < nq ? __builtin_amdgcn_readlane(h_c0, q) : 0x7fffffff;   // (alignments in front of the stream: negative)
         int xq[4], pp[4]; bool walkq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { xq[q] = __builtin_amdgcn_readlane(h_x0, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; pp[q] = X.pos[min(xq[q] + l, X.n - 1)]; }
@@ -314,26 +316,23 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                 rt = live ? rt : 0u; big |= live ? bg : 0u;
                 const int ir = wave_incl_scan_dpp((int)rt);
                 const int my_s = carry_r + ir - (int)rt;
-                int v = live ? my_s + emax : (int)0x80000000;
+                // E of alignment q of the job is kept as E + (q << 28): every value of an alignment lies above every value of the one before it, so
+                // ONE running maximum over the stream (a DPP scan) is the running maximum of each alignment - no segmented scan
+                const int aq = (cid >= hc[1]) + (cid >= hc[2]) + (cid >= hc[3]);       // the alignment of the job this chunk belongs to
+                int v = live ? my_s + emax + (aq << 28) : (int)0x80000000;
                 if (live) s_lm[cid] = v;
-                bool f = live && (cid == hc[0] || cid == hc[1] || cid == hc[2] || cid == hc[3]);
-                if (l == 0 && !f) v = max(v, carry_e);
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int vu = __shfl_up(v, d); const int fu = __shfl_up((int)f, d);
-                    if (l >= d && !f) { v = max(v, vu); f = fu != 0; }
-                }
+                v = max(wave_incl_max_dpp(v), carry_e);
                 if (live) s_tab[cid] = make_int2(my_s, v);
                 carry_r += __builtin_amdgcn_readlane(ir, 63); carry_e = __builtin_amdgcn_readlane(v, 63);
             }
-            absurd |= (unsigned)carry_r > 0x3fffffffu;
+            absurd |= (unsigned)carry_r > 0x07ffffffu;                     // (E + (q << 28) must stay a positive int)
             if (absurd) break;
         }
         if (absurd || __ballot(big >= 0x10000000u)) { general |= h_in; continue; }   // outside this walk's arithmetic: k_extra_merge takes the group's alignments
         wave_sync();
         // ---- reach of each alignment, its rows: [x0, first row at or beyond the reach)
         int b_sat = 0, b_reach = h_start;
-        if (h_walk) { const int2 ts = s_tab[h_c0], te = s_tab[h_c0 + h_nch - 1]; b_sat = ts.x; b_reach = h_start + te.y - ts.x; }
+        if (h_walk) { const int2 ts = s_tab[h_c0], te = s_tab[h_c0 + h_nch - 1]; b_sat = ts.x; b_reach = h_start + (te.y - (l << 28)) - ts.x; }
         int nrow[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -352,14 +351,16 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
         if (l < 4) { ExtHdr &h = s_hdr[l]; h.vadj = SEL4(l, xadj); h.ds = b_sat - h_start; }
         int maxnch = l < 4 ? s_hdr[l].nch : 0;
         maxnch = max(max(__builtin_amdgcn_readlane(maxnch, 0), __builtin_amdgcn_readlane(maxnch, 1)), max(__builtin_amdgcn_readlane(maxnch, 2), __builtin_amdgcn_readlane(maxnch, 3)));
-        // ONE reservation for the records of the group (a slot per row of the reaches: most rows are recorded)
+        // ONE reservation for the group: a slot per row of the reaches (most rows are recorded), and behind them room for the merged rows of its
+        // alignments (their observations + as many records at most).  Its answer is waited for where the first record is stored
+        int sumA = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sumA += walkq[q] ? __builtin_amdgcn_readlane(h_rcnt, q) : 0;
+        const unsigned long long want = (unsigned long long)(2 * T + sumA);
         unsigned long long off = 0;
-        if (T > 0 && l == 0) off = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)T);
+        if (T > 0 && l == 0) off = atomicAdd(&O.arena_ctr[arena * 8], want);
         wave_sync();
-        off = __shfl(off, 0);
-        const bool arena_full = T > 0 && off + (unsigned long long)T > O.arena_size;
-        if (arena_full) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); return; }   // the host grows the arenas and runs again
-        ObsRec *dst = O.rec + arena_lo + off;
+        ObsRec *dst = nullptr;
         const int step0 = maxnch > 1 ? 1 << (31 - __builtin_clz(maxnch - 1)) : 0;
         int n_x[4] = {0, 0, 0, 0}; unsigned blocked = 0;                  // records of alignment k so far; k has a row that no op serves: the cursor stays there
 #pragma unroll 1
@@ -373,17 +374,17 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                 const int hncig = ha.y, hc0 = ha.z, hnch = ha.w, hflag = hb.y, hds = hb.z;
                 const int row = hb.x + i;
                 const int4 xr = X.rec[row];                             // {pos, info, union index, kind}
-                const int p = xr.x, ps = p + hds;
+                const int p = xr.x, ps = p + hds, pse = ps + (q << 28);       // pse: against the table's E entries (alignment q's values lie at q << 28)
                 // first chunk of the alignment whose running maximum exceeds the row: the op that first reaches beyond it lies there
                 int co = -1;
-                for (int step = step0; step >= 1; step >>= 1) { const int t = co + step; const int ev = s_tab[hc0 + min(t, hnch - 1)].y; co = (t < hnch && ev <= ps) ? t : co; }
+                for (int step = step0; step >= 1; step >>= 1) { const int t = co + step; const int ev = s_tab[hc0 + min(t, hnch - 1)].y; co = (t < hnch && ev <= pse) ? t : co; }
                 ++co;                                                     // (co < hnch: ps < reach = the last chunk's running maximum)
                 if (step0 == 0) co = 0;
                 int q_snp = 0; bool have_q = false; int j = 0, rp = 0;
                 // (a row in the reach of a long clip or insertion that does not serve it - a SNP lies in between - is served by a much later op: the
                 //  chunks in between whose own ops all end at or before the row are passed over by their table entry, not loaded)
                 for (int cc = co; cc < hnch && !found; ++cc) {
-                    if (cc > co && s_lm[hc0 + cc] <= ps) continue;
+                    if (cc > co && s_lm[hc0 + cc] <= pse) continue;
                     const uint32_t *cw = cg + 8 * (hc0 + cc);
                     const uint4 a = *reinterpret_cast<const uint4 *>(cw), b = *reinterpret_cast<const uint4 *>(cw + 4);
                     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -425,6 +426,17 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                         uint32_t lo = X.mod_off[info], hi = X.mod_off[info + 1]; const uint32_t end = hi;
                         // first listed read with name >= this one: a 4-ary search over name << 2 | flags (three probes a trip: a site lists a read per fold of coverage)
                         const uint32_t key = name << 2;
+                        while (hi - lo > 7) {                             // 8-ary: seven probes a trip (a site lists a read per fold of coverage: two trips)
+                            const uint32_t n8 = (hi - lo) >> 3;
+                            uint32_t v[7];
+#pragma unroll
+                            for (int t = 0; t < 7; ++t) v[t] = X.mod_pack[lo + n8 * (t + 1)];
+                            int g = 0;                                      // probes below the key: the answer lies behind the last of them
+#pragma unroll
+                            for (int t = 0; t < 7; ++t) g += v[t] < key ? 1 : 0;
+                            const uint32_t nlo = g ? lo + n8 * g + 1 : lo, nhi = g < 7 ? lo + n8 * (g + 1) : hi;
+                            lo = nlo; hi = nhi;
+                        }
                         while (hi - lo > 3) {
                             const uint32_t n4 = (hi - lo) >> 2, m1 = lo + n4, m2 = m1 + n4, m3 = m2 + n4;
                             const uint32_t v1 = X.mod_pack[m1], v2 = X.mod_pack[m2], v3 = X.mod_pack[m3];
@@ -460,6 +472,11 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                 }
             }
             const unsigned long long em = em0 & keep;
+            if (i0 == 0) {                                                // the reservation has had the searches of the first round to arrive
+                off = __shfl(off, 0);
+                if (off + want > O.arena_size) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); return; }   // the host grows the arenas and runs again
+                dst = O.rec + arena_lo + off;
+            }
             if ((em >> l) & 1ull) {
                 const int cq = SEL4(q, cum), a = max(cq - i0, 0);
                 const unsigned long long before = em & lanemask_lt() & ~((1ull << a) - 1ull);
@@ -486,10 +503,7 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                 unsigned roffq[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) roffq[q] = (unsigned)__builtin_amdgcn_readlane((int)h_roff, q);
-                unsigned long long off2 = 0;
-                if (l == 0) off2 = atomicAdd(&O.arena_ctr[arena * 8], (unsigned long long)TM);
-                off2 = __shfl(off2, 0);
-                if (off2 + (unsigned long long)TM > O.arena_size) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_OBS_OVERFLOW); return; }   // the host grows the arenas and runs again
+                const unsigned long long off2 = off + (unsigned long long)T;       // (TM <= sumA + T: reserved with the records)
                 ObsRec *out = O.rec + arena_lo + off2;
                 __threadfence_block();                                  // the records this wave wrote above are read back below
                 int *s_ka = s_lm, *s_kb = reinterpret_cast<int *>(s_tab);   // keys of the rows (<= XF_TAB) / of the records (<= 2 * XF_TAB)
