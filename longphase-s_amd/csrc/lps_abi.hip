@@ -320,7 +320,8 @@ int lps_set_extra_variants(lps_ctx *c, const lps_extra_variants *x) {
         // merge the three position lists; a position in two of them would make get_snp's inner loop spin forever (none of its three branches
         // serves a row that ties with another cursor, ParsingBam.cpp:1373,1397,1437)
         const size_t nX = (size_t)(nS + nM), nU = nX + (size_t)c->nV;
-        std::vector<int32_t> xpos(nX), xinfo(nX), xu(nX), upos(nU); std::vector<uint8_t> xkind(nX);
+        std::vector<int32_t> xpos(nX), xinfo(nX), xu(nX), upos(nU), xq(nX); std::vector<uint8_t> xkind(nX);   // xq: position of the last SNP row before the row (INT_MIN: none)
+        int32_t last_snp = INT_MIN;
         c->h_snp_u.resize(c->nV); c->h_sv_u.resize(nS); c->h_mod_u.resize(nM);
         size_t a = 0, sv = 0, md = 0, k = 0, u = 0;
         while (a < (size_t)c->nV || sv < (size_t)nS || md < (size_t)nM) {
@@ -328,9 +329,9 @@ int lps_set_extra_variants(lps_ctx *c, const lps_extra_variants *x) {
             const long long lo = std::min(pa, std::min(ps, pm));
             if ((pa == lo) + (ps == lo) + (pm == lo) > 1) return fail(c, "position " + std::to_string(lo) + " occurs in more than one of the SNP / SV / MOD tables: the reference does not terminate on such input");
             upos[u] = (int32_t)lo;
-            if (pa == lo) c->h_snp_u[a++] = (int32_t)u;
-            else if (ps == lo) { xpos[k] = (int32_t)lo; xinfo[k] = x->sv_len[sv]; xkind[k] = 1; xu[k] = (int32_t)u; c->h_sv_u[sv++] = (int32_t)u; ++k; }
-            else { xpos[k] = (int32_t)lo; xinfo[k] = (int32_t)md; xkind[k] = 2; xu[k] = (int32_t)u; c->h_mod_u[md++] = (int32_t)u; ++k; }
+            if (pa == lo) { c->h_snp_u[a++] = (int32_t)u; last_snp = (int32_t)lo; }
+            else if (ps == lo) { xq[k] = last_snp; xpos[k] = (int32_t)lo; xinfo[k] = x->sv_len[sv]; xkind[k] = 1; xu[k] = (int32_t)u; c->h_sv_u[sv++] = (int32_t)u; ++k; }
+            else { xq[k] = last_snp; xpos[k] = (int32_t)lo; xinfo[k] = (int32_t)md; xkind[k] = 2; xu[k] = (int32_t)u; c->h_mod_u[md++] = (int32_t)u; ++k; }
             ++u;
         }
         std::vector<uint32_t> moff(nM + 1, 0u);
@@ -341,8 +342,9 @@ int lps_set_extra_variants(lps_ctx *c, const lps_extra_variants *x) {
         const size_t ne = nM ? (size_t)x->mod_off[nM] : 0;
         c->x_mname.reserve(ne + 1); c->x_mflag.reserve(ne + 1);
         if (ne) { upload(c, c->x_mname, x->mod_name, ne); upload(c, c->x_mflag, x->mod_flag, ne); }
-        // what k_extra_find reads per row / per listed read in ONE load each: {pos, info, union index, kind} and name << 2 | flags
-        std::vector<int4> xrec(nX); for (int64_t i = 0; i < nX; ++i) xrec[i] = make_int4(xpos[i], xinfo[i], xu[i], (int)xkind[i]);
+        // what k_extra_find reads per row / per listed read in ONE load each: {pos, info, union index | kind << 30, last SNP position before it} and name << 2 | flags
+        if (nU >= (1ull << 30)) return fail(c, "lps_set_extra_variants: more than 2^30 rows in the union of the tables");
+        std::vector<int4> xrec(nX); for (size_t i = 0; i < nX; ++i) xrec[i] = make_int4(xpos[i], xinfo[i], xu[i] | ((int)xkind[i] << 30), xq[i]);
         std::vector<uint32_t> mpack(ne);
         for (size_t i = 0; i < ne; ++i) { if (x->mod_name[i] >= (1u << 30)) return fail(c, "lps_set_extra_variants: read name ids must be below 2^30"); mpack[i] = (x->mod_name[i] << 2) | (uint32_t)(x->mod_flag[i] & 3u); }
         upload(c, c->x_rec, xrec.data(), (size_t)nX); c->x_mpack.reserve(ne + 1); if (ne) upload(c, c->x_mpack, mpack.data(), ne);

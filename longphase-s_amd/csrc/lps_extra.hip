@@ -373,14 +373,14 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                 const int4 ha = *reinterpret_cast<const int4 *>(&s_hdr[q].crel), hb = *reinterpret_cast<const int4 *>(&s_hdr[q].vadj);
                 const int hncig = ha.y, hc0 = ha.z, hnch = ha.w, hflag = hb.y, hds = hb.z;
                 const int row = hb.x + i;
-                const int4 xr = X.rec[row];                             // {pos, info, union index, kind}
+                const int4 xr = X.rec[row];                             // {pos, info, union index | kind << 30, last SNP position before the row}
                 const int p = xr.x, ps = p + hds, pse = ps + (q << 28);       // pse: against the table's E entries (alignment q's values lie at q << 28)
                 // first chunk of the alignment whose running maximum exceeds the row: the op that first reaches beyond it lies there
                 int co = -1;
                 for (int step = step0; step >= 1; step >>= 1) { const int t = co + step; const int ev = s_tab[hc0 + min(t, hnch - 1)].y; co = (t < hnch && ev <= pse) ? t : co; }
                 ++co;                                                     // (co < hnch: ps < reach = the last chunk's running maximum)
                 if (step0 == 0) co = 0;
-                int q_snp = 0; bool have_q = false; int j = 0, rp = 0;
+                const int q_snp = xr.w; int j = 0, rp = 0;                // (SNP positions never equal p, lps_set_extra_variants: the last SNP before p + 1 is the last one before p)
                 // (a row in the reach of a long clip or insertion that does not serve it - a SNP lies in between - is served by a much later op: the
                 //  chunks in between whose own ops all end at or before the row are passed over by their table entry, not loaded)
                 for (int cc = co; cc < hnch && !found; ++cc) {
@@ -395,16 +395,13 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                         const int op = w[k] & 15u, len = (int)(w[k] >> 4);
                         if (rr + len > ps) {                            // (from the first such op on: every later op reaches beyond the row as well or does not matter - the test is the reference's)
                             if (op_is_match(op)) { found = true; j = opi; rp = rr; }
-                            else {
-                                if (!have_q) { q_snp = last_snp_before(V, p + 1); have_q = true; }   // SNP positions never equal p (lps_set_extra_variants)
-                                if (rr - hds > q_snp) { found = true; j = opi; rp = rr; }
-                            }
+                            else if (rr - hds > q_snp) { found = true; j = opi; rp = rr; }      // no SNP lies in [ref_pos, p]
                         }
                         rr += len & -(int)op_bit(LPS_RMASK2, w[k]);
                     }
                 }
                 if (found) {
-                    const int kind = xr.w, info = xr.y;
+                    const int kind = (int)((unsigned)xr.z >> 30), info = xr.y, xu = xr.z & 0x3fffffff;
                     const int rp_true = rp - hds;
                     if (kind == 1) {                                    // :1403-1429
                         const double region = (double)(abs(info) + 1);
@@ -420,7 +417,7 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                                 if (t >= a && t < b && (op == 1 || op == 2) && fabs(region - len) / fabs(region) < X.sv_threshold) allele = 1;
                             }
                         }
-                        emit = true; rec = ObsRec{xr.z, (uint32_t)pack_aq(allele, -1)};
+                        emit = true; rec = ObsRec{xu, (uint32_t)pack_aq(allele, -1)};
                     } else {                                            // :1377-1392
                         const uint32_t name = s_hdr[q].blk0; const bool rev = (hflag & 0x10) != 0;
                         uint32_t lo = X.mod_off[info], hi = X.mod_off[info + 1]; const uint32_t end = hi;
@@ -452,7 +449,7 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                             const unsigned f = hit & 3u;
                             // the reference compares modPos with *currentVariantIter even when that is end(): the entry count of the SNP map
                             const bool cursor_ok = V.last_pos >= max(rp_true, p + 1) || p < V.n;
-                            if ((((f >> 1) & 1u) != 0) == rev && cursor_ok) { emit = true; rec = ObsRec{xr.z, (uint32_t)pack_aq((f & 1u) ? 0 : 1, rev ? -3 : -2)}; }
+                            if ((((f >> 1) & 1u) != 0) == rev && cursor_ok) { emit = true; rec = ObsRec{xu, (uint32_t)pack_aq((f & 1u) ? 0 : 1, rev ? -3 : -2)}; }
                         }
                     }
                 }

@@ -96,7 +96,7 @@ struct ExtraView {
     const uint32_t *mod_name;
     const uint8_t *mod_flag;
     int sv_window; double sv_threshold;
-    const int4 *rec;           // per row {pos, info, u, kind}: one load for k_extra_find
+    const int4 *rec;           // per row {pos, info, u | kind << 30, position of the last SNP row before it}: one load for k_extra_find
     const uint32_t *mod_pack;  // mod_name << 2 | mod_flag: the search finds the flags with the name
 };
 void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int32_t *x0, uint32_t *redo, unsigned *n_redo, int mapping_quality, LpsCounters *cnt, hipStream_t s);
