@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void k_extra_merge(VarView V, ReadView R, ObsVi
 // rows of the job that got records, the outputs of its four merges flattened over the lanes, the keys of rows and records in LDS.  What this walk
 // cannot take (an alignment of more chunks than the table holds, an op of 2^24 bases, stream coordinates beyond 2^30) is queued for k_extra_merge.
 #ifndef XF_TAB
-#define XF_TAB 768     // lane-chunks of a group's stream (6 144 words); LDS 9.2 KB per wave
+#define XF_TAB 1024    // lane-chunks of a group's stream (8 192 words); 12.3 KB of LDS per wave (768: more alignments of the test genome left to the general walker, 70 us)
 #endif
 
 __global__ void k_read_x0(ExtraView X, const int32_t *ref_start, int n, int32_t *x0) {
@@ -247,6 +247,7 @@ __global__ void k_read_x0(ExtraView X, const int32_t *ref_start, int n, int32_t 
 __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, ObsView O, ExtraView X, const int32_t *x0, uint32_t *redo, unsigned *n_redo, int mapping_quality, LpsCounters *cnt) {
     __shared__ __attribute__((aligned(16))) int2 s_tab[XF_TAB];          // (stream reference coordinate at the chunk's start, running maximum of E through the chunk)
     __shared__ int s_lm[XF_TAB];                                         // maximum of E over the chunk's own ops: chunks that cannot serve a row are passed over without loading them
+    __shared__ int s_bm[XF_TAB / 16];                                    // ... and the maximum over 16 chunks: sixteen are passed over at a time
     __shared__ ExtHdr s_hdr[4];
     const int l = lane_id();
     const int job = blockIdx.x, r0 = job * 4;
@@ -330,6 +331,9 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
         }
         if (absurd || __ballot(big >= 0x10000000u)) { general |= h_in; continue; }   // outside this walk's arithmetic: k_extra_merge takes the group's alignments
         wave_sync();
+        static_assert(XF_TAB / 16 <= 64, "a lane per block of 16 chunks");
+        if (l < XF_TAB / 16) { int m = (int)0x80000000; for (int t = 0; t < 16; ++t) { const int c = 16 * l + t; if (c < TC) m = max(m, s_lm[c]); } s_bm[l] = m; }
+        wave_sync();
         // ---- reach of each alignment, its rows: [x0, first row at or beyond the reach)
         int b_sat = 0, b_reach = h_start;
         if (h_walk) { const int2 ts = s_tab[h_c0], te = s_tab[h_c0 + h_nch - 1]; b_sat = ts.x; b_reach = h_start + (te.y - (l << 28)) - ts.x; }
@@ -384,7 +388,11 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                 // (a row in the reach of a long clip or insertion that does not serve it - a SNP lies in between - is served by a much later op: the
                 //  chunks in between whose own ops all end at or before the row are passed over by their table entry, not loaded)
                 for (int cc = co; cc < hnch && !found; ++cc) {
-                    if (cc > co && s_lm[hc0 + cc] <= pse) continue;
+                    if (cc > co) {
+                        const int ac = hc0 + cc;
+                        if ((ac & 15) == 0 && cc + 16 <= hnch && s_bm[ac >> 4] <= pse) { cc += 15; continue; }
+                        if (s_lm[ac] <= pse) continue;
+                    }
                     const uint32_t *cw = cg + 8 * (hc0 + cc);
                     const uint4 a = *reinterpret_cast<const uint4 *>(cw), b = *reinterpret_cast<const uint4 *>(cw + 4);
                     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
