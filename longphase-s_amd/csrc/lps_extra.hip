@@ -301,11 +301,12 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
         // ---- walk: coordinates like stream_round (lps_kernels.h) + the running maximum of E, a segmented inclusive max-scan (heads = first chunks)
         int carry_r = 0, carry_e = (int)0x80000000; uint32_t big = 0; bool absurd = false;
 #pragma unroll 1
-        for (int R0 = 0; R0 < TC; R0 += 128) {
-            uint32_t wt[2][8];
-            request(R0 + l, wt[0]); request(R0 + 64 + l, wt[1]);
+        for (int R0 = 0; R0 < TC; R0 += 256) {                            // four rounds requested together, like k_extract_phase
+            uint32_t wt[4][8];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 4; ++t) request(R0 + 64 * t + l, wt[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
                 const int cid = R0 + 64 * t + l; const bool live = cid < TC;
                 unsigned rt = 0; int emax = (int)0x80000000; uint32_t bg = 0;
 #pragma unroll
@@ -378,6 +379,8 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                 const int hncig = ha.y, hc0 = ha.z, hnch = ha.w, hflag = hb.y, hds = hb.z;
                 const int row = hb.x + i;
                 const int4 xr = X.rec[row];                             // {pos, info, union index | kind << 30, last SNP position before the row}
+                const int mrow = ((unsigned)xr.z >> 30) == 2u ? xr.y : 0;      // MOD row: where its listed reads are, requested beside the chunk's words
+                const uint32_t m_lo = X.mod_off[mrow], m_hi = X.mod_off[mrow + 1];
                 const int p = xr.x, ps = p + hds, pse = ps + (q << 28);       // pse: against the table's E entries (alignment q's values lie at q << 28)
                 // first chunk of the alignment whose running maximum exceeds the row: the op that first reaches beyond it lies there
                 int co = -1;
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                         emit = true; rec = ObsRec{xu, (uint32_t)pack_aq(allele, -1)};
                     } else {                                            // :1377-1392
                         const uint32_t name = s_hdr[q].blk0; const bool rev = (hflag & 0x10) != 0;
-                        uint32_t lo = X.mod_off[info], hi = X.mod_off[info + 1]; const uint32_t end = hi;
+                        uint32_t lo = m_lo, hi = m_hi; const uint32_t end = hi;
                         // first listed read with name >= this one: a 4-ary search over name << 2 | flags (three probes a trip: a site lists a read per fold of coverage)
                         const uint32_t key = name << 2;
                         while (hi - lo > 7) {                             // 8-ary: seven probes a trip (a site lists a read per fold of coverage: two trips)
