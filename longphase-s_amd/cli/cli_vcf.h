@@ -154,38 +154,30 @@ static void preprocess_deepsomatic(const std::vector<std::string> &in, std::vect
 struct Phased { int32_t ps; char a, b; };
 // SnpParser::writeLine (ParsingBam.cpp:460-635) restated; SVParser::writeLine (:1042-1193) and METHParser::writeLine (:1788-1942) differ from it only
 // in how a record finds its result - `lookup(chromosome, 1-based POS)` returns it, or nullptr when the record is not phased or was not a row of the table
+// (records are independent of each other: the header goes first, then the records in slices of the line vector, one host thread each, written in order)
+static int g_text_threads = 8;
 template <class Lookup>
 static void rewrite_vcf(const std::vector<std::string> &lines, const std::string &out_path, const std::string &command, Lookup lookup, const IndelQual *iq = nullptr) {
     std::ofstream o(out_path); if (!o) die("Fail to open write file: " + out_path);
     bool ps_def = false, cmd_done = false;
-    for (const std::string &in : lines) {
-        if (in.compare(0, 2, "##") == 0) { if (in.compare(0, 16, "##FORMAT=<ID=PS,") == 0) ps_def = true; o << in << "\n";
-            if (iq && iq->threshold > 0 && in.compare(0, 17, "##FILTER=<ID=PASS") == 0)          // :467-473
-                o << "##FILTER=<ID=INDEL_QUAL_FILTERED,Description=\"Indel filtered due to QUAL below threshold (" << iq->threshold << ")\">\n";
-            continue; }
-        if (in.compare(0, 6, "#CHROM") == 0 || in.compare(0, 6, "#chrom") == 0) {
-            if (!cmd_done) {
-                if (!ps_def) { o << "##FORMAT=<ID=PS,Number=1,Type=Integer,Description=\"Phase set identifier\">\n"; ps_def = true; }
-                o << "##longphaseVersion=" << kVersion << "\n" << "##commandline=\"" << command << "\"\n"; cmd_done = true;
-            }
-            o << in << "\n"; continue;
-        }
+    auto colon_index = [](const std::string &fmt, size_t upto) { int c = 0;
+        for (size_t i = 0; i < upto; ++i) if (fmt[i] == ':') ++c;
+        return c;
+        };
+    auto value_start = [](const std::string &v, int colons) { int cur = 0;
+        size_t st = 0;
+        for (size_t i = 0; i < v.size(); ++i) { if (cur >= colons) break;
+            if (v[i] == ':') ++cur;
+            ++st;
+            } return st;
+        };
+    // one record -> its output line(s), appended to `out`
+    auto record = [&](const std::string &in, std::string &out) {
         std::istringstream iss(in);
         std::vector<std::string> f((std::istream_iterator<std::string>(iss)), std::istream_iterator<std::string>());
-        if (f.empty()) continue;
-        if (f.size() < 10) { o << in << "\n"; continue; }
+        if (f.empty()) return;
+        if (f.size() < 10) { out += in; out += '\n'; return; }
         const int32_t pidx = std::stoi(f[1]) - 1;
-        auto colon_index = [](const std::string &fmt, size_t upto) { int c = 0;
-            for (size_t i = 0; i < upto; ++i) if (fmt[i] == ':') ++c;
-            return c;
-            };
-        auto value_start = [](const std::string &v, int colons) { int cur = 0;
-            size_t st = 0;
-            for (size_t i = 0; i < v.size(); ++i) { if (cur >= colons) break;
-                if (v[i] == ':') ++cur;
-                ++st;
-                } return st;
-            };
         if (f[8].find("PS") != std::string::npos) {                  // strip an existing PS key and value
             const size_t pp = f[8].find("PS"); const int cp = colon_index(f[8], pp);
             if (f[8].find(":", pp + 1) != std::string::npos) f[8].erase(pp, 3); else f[8].erase(pp - 1, 3);
@@ -207,8 +199,32 @@ static void rewrite_vcf(const std::vector<std::string> &lines, const std::string
             f[9][st] = ph->a; f[9][st + 1] = '|'; f[9][st + 2] = ph->b;
         } else { f[8] += ":PS"; f[9] += ":."; }
         if (iq && iq->threshold > 0) { auto fc = iq->filtered.find(f[0]); if (fc != iq->filtered.end() && fc->second.count(pidx)) f[6] = "INDEL_QUAL_FILTERED"; }   // :619-623
-        for (size_t i = 0; i < f.size(); ++i) { if (i) o << "\t"; o << f[i]; }
-        o << "\n";
+        for (size_t i = 0; i < f.size(); ++i) { if (i) out += '\t'; out += f[i]; }
+        out += '\n';
+    };
+    // header lines (and whatever else starts with '#'): in order, they carry state
+    auto header = [&](const std::string &in) {
+        if (in.compare(0, 2, "##") == 0) { if (in.compare(0, 16, "##FORMAT=<ID=PS,") == 0) ps_def = true; o << in << "\n";
+            if (iq && iq->threshold > 0 && in.compare(0, 17, "##FILTER=<ID=PASS") == 0)          // :467-473
+                o << "##FILTER=<ID=INDEL_QUAL_FILTERED,Description=\"Indel filtered due to QUAL below threshold (" << iq->threshold << ")\">\n";
+            return; }
+        if (!cmd_done) {
+            if (!ps_def) { o << "##FORMAT=<ID=PS,Number=1,Type=Integer,Description=\"Phase set identifier\">\n"; ps_def = true; }
+            o << "##longphaseVersion=" << kVersion << "\n" << "##commandline=\"" << command << "\"\n"; cmd_done = true;
+        }
+        o << in << "\n";
+    };
+    auto is_header = [](const std::string &in) { return in.compare(0, 2, "##") == 0 || in.compare(0, 6, "#CHROM") == 0 || in.compare(0, 6, "#chrom") == 0; };
+    size_t i = 0;
+    while (i < lines.size()) {
+        if (is_header(lines[i])) { header(lines[i]); ++i; continue; }
+        size_t j = i; while (j < lines.size() && !is_header(lines[j])) ++j;      // a run of records
+        const size_t n = j - i; const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, g_text_threads), n / 4096 + 1));
+        std::vector<std::string> part((size_t)nt); std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { const size_t a = i + n * (size_t)t / (size_t)nt, b = i + n * (size_t)(t + 1) / (size_t)nt; part[(size_t)t].reserve((b - a) * 96); for (size_t k = a; k < b; ++k) record(lines[k], part[(size_t)t]); });
+        for (auto &x : th) x.join();
+        for (const std::string &x : part) o.write(x.data(), (std::streamsize)x.size());
+        i = j;
     }
 }
 
