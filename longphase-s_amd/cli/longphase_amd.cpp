@@ -8,7 +8,7 @@
 //   SnpParser::writeLine (VCF rewrite rules)  src/phase/ParsingBam.cpp:460-635
 //   SVParser / METHParser (--sv-file, --mod-file) src/phase/ParsingBam.cpp:915-1206, 1647-1952   (cli_extra.h)
 //   SnpParser::preprocessDeepsomaticVCF (--deepsomatic_output) src/phase/ParsingBam.cpp:651-835, PhasingProcess.cpp:47-61
-// Not supported (the reference path must be used): --dot, CRAM.   (--indelQuality: cli_vcf.h IndelQual)
+// --dot: <chr>.dot from the GPU's graph (SNP / indel graphs; with --sv-file / --mod-file the reference path must be used).  Not supported: CRAM.   (--indelQuality: cli_vcf.h IndelQual)
 // Split in round 2: cli_common.h (loader), cli_bam.h (BGZF/BAM in, BGZF out), cli_vcf.h (VCF/FASTA in, phased VCF out), cli_purity.h (purity estimator).
 #include "cli_common.h"
 #include "cli_bam.h"
@@ -24,6 +24,7 @@ static const char *kUsage =
     "   -1 edgeThreshold(0.7)  -L overlapThreshold(0.2)  -m readConfidence(0.65)  -n snpConfidence(0.75)  --gpu=ID (0)\n"
     "   --deepsomatic_output   the SNP file is a DeepSomatic VCF: keep FILTER=GERMLINE records, genotype them from AD / VAF (writes <prefix>_preprocessed.vcf)\n"
     "   --indelQuality=N       with --indels: indels below this QUAL are left out (logged to <prefix>_removed_indels.log, FILTER INDEL_QUAL_FILTERED)\n"
+    "   --dot                  write <chromosome>.dot (the connected pairs of the graph) into the working directory; not with --sv-file / --mod-file\n"
     "   --sv-file=NAME  --mod-file=NAME   co-phase structural variants / modcall records (outputs <prefix>_SV.vcf, <prefix>_mod.vcf)   -w svWindow(20)  -h svThreshold(0.1)\n"
     "   --host-inflate | --gpu-inflate   BGZF inflate with zlib on the -t host threads / on the GPU (default: GPU for one BAM of 256 MiB or more)\n"
     "   --no-index       ignore <bam>.bai: make the whole file resident on the GPU instead of one contig at a time\n"
@@ -37,7 +38,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<std::string> bams;
     int threads = 1, gpu = 0, n_gpus = 1, sv_window = 20, indel_quality = 0; double sv_threshold = 0.1;
     uint64_t group_bytes = 8ull << 30; int workers_per_gpu = 1;        // indexed BAM: contigs are taken in groups of about this many compressed bytes, by this many concurrent workers per GPU
-    bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false, deepsomatic = false;
+    bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false, deepsomatic = false, dot = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -86,9 +87,10 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "--help") { std::cout << kUsage; return 0; }
         else if (a == "--deepsomatic_output") deepsomatic = true;
         else if (a == "--indelQuality") indel_quality = std::stoi(val());
-        else if (a == "--dot") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
+        else if (a == "--dot") dot = true;
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kUsage; return 1; }
     }
+    if (dot && (!sv_file.empty() || !mod_file.empty())) die("longphase_amd: --dot together with --sv-file / --mod-file is not supported by the GPU path; use the reference binary");
     if (!sv_file.empty()) {                                             // Phasing.cpp:304-318
         if (sv_window < 0) { std::cerr << "longphase_amd phase: invalid svWindow. value: " << sv_window << "\n please check -w, --svWindow=Num\n"; return 1; }
         if (sv_threshold < 0 || sv_threshold > 1) { std::cerr << "longphase_amd phase: invalid svThreshold. value: " << sv_threshold << "\n this value need: 0~1, please check -h, --svThreshold=[0~1]\n"; return 1; }
@@ -216,6 +218,39 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         std::vector<int32_t> ps(cv.pos.size()); std::vector<uint8_t> gt(cv.pos.size());
         lps_phase_result pr{(int64_t)cv.pos.size(), ps.data(), gt.data()};
         if (L.phase_chromosome(ctx, &pr)) die(std::string("longphase_amd: ") + L.last_error(ctx));
+        if (dot) {
+            // --dot: <chr>.dot in the working directory, two lines per CONNECTED pair of edgeConnectResult in the order it visits them
+            // (PhasingGraph.cpp:286-418 with findBestEdgePair :166-228; written by writingDotFile :1031-1047).  A node the walk gives no haplotype - a
+            // gap beyond `distance`, a tie behind the last connection - is skipped with all its pairs; a pair is connected when its cells do not tie
+            // and their similarity ratio does not exceed the threshold.  From the graph the GPU built: the edge matrix and the vote scan's haplotypes
+            lps_params P; L.default_params(&P); for (auto &f : over) f(P);
+            const int64_t N = L.dump_graph(ctx, nullptr, nullptr, 0);
+            if (N < 0) die(std::string("longphase_amd: ") + L.last_error(ctx));
+            const int A = P.connect_adjacent;
+            std::vector<int32_t> node((size_t)N + 1), blk((size_t)N + 1); std::vector<float> edge((size_t)N * (size_t)A * 4 + 4); std::vector<int8_t> hp((size_t)N + 1);
+            if (N && (L.dump_graph(ctx, node.data(), edge.data(), N) != N || L.dump_votes(ctx, hp.data(), blk.data(), N) != N)) die(std::string("longphase_amd: ") + L.last_error(ctx));
+            std::ofstream d;
+            if (N > 0) d.open(chr + ".dot");                                   // no read reached a variant: the reference leaves the chromosome before the graph (PhasingProcess.cpp:143-146)
+            if (N <= 0) {}
+            else if (!d) std::cerr << "Fail to open write file: " << chr << ".vcf\n";            // (the reference's message names .vcf)
+            else {
+                d << "digraph G {\n";
+                for (int64_t i = 0; i + 1 < N; ++i) {
+                    if (!hp[(size_t)i]) continue;
+                    for (int k = 0; k < A && i + 1 + k < N; ++k) {
+                        const float *c = &edge[((size_t)i * (size_t)A + (size_t)k) * 4];
+                        const float para = c[0] + c[3], cross = c[1] + c[2];
+                        if (para == cross) continue;
+                        const double esr = (double)std::min(para, cross) / (double)std::max(para, cross);
+                        if (esr > P.edge_threshold) continue;
+                        const int a1 = para > cross ? 1 : 2, a2 = 3 - a1;
+                        const long long sp = (long long)cv.pos[(size_t)node[(size_t)i]] + 1, tp = (long long)cv.pos[(size_t)node[(size_t)(i + 1 + k)]] + 1;
+                        d << sp << ".1\t->\t" << tp << "." << a1 << "\n" << sp << ".2\t->\t" << tp << "." << a2 << "\n";
+                    }
+                }
+                d << "}\n";
+            }
+        }
         std::map<int32_t, Phased> rc;
         for (size_t i = 0; i < cv.pos.size(); ++i) if (ps[i]) rc[cv.pos[i]] = Phased{ps[i], gt[i] ? '1' : '0', gt[i] ? '0' : '1'};
         if (xr.any()) {                                              // the reference keeps ONE result map keyed by position for all three files

@@ -673,11 +673,12 @@ def main():
     for name, (kw, cli, over) in fixtures.DATA_FIXTURES.items():
         s = Synth(**kw)
         with tempfile.TemporaryDirectory() as d:
-            ps, gt = run_reference_phase(s, cli, d)
+            ps, gt = run_reference_phase(s, cli + ["--dot"], d)        # --dot changes nothing in out.vcf; <chr>.dot lands in the working directory
             for fn, dst in (("ref.fa", f"{name}.fa"), ("in.vcf", f"{name}.vcf"), ("out.vcf", f"{name}.ref_phased.vcf")):
                 shutil.copy(os.path.join(d, fn), os.path.join(HERE, "data", dst))
-            with open(os.path.join(d, "reads.sam"), "rb") as fi, gzip.GzipFile(os.path.join(HERE, "data", f"{name}.sam.gz"), "wb", mtime=0) as fo:
-                shutil.copyfileobj(fi, fo)
+            for fn, dst in (("reads.sam", f"{name}.sam.gz"), ("chrS.dot", f"{name}.ref.dot.gz")):
+                with open(os.path.join(d, fn), "rb") as fi, gzip.GzipFile(os.path.join(HERE, "data", dst), "wb", mtime=0) as fo:
+                    shutil.copyfileobj(fi, fo)
         index["data:" + name] = dict(digest=fixtures.input_digest(s), n_var=int(s.n_variants), n_reads=int(s.n_reads),
                                      n_phased=int((ps != 0).sum()), cli=cli)
         print(name, index["data:" + name])

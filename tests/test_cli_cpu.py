@@ -40,8 +40,8 @@ def test_phase_argument_errors():
     assert r.returncode == 1 and "missing arguments" in r.stderr
     r = subprocess.run([CLI, "phase", "-s", "x.vcf", "-b", "x.bam", "-r", "x.fa"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "--ont or --pb" in r.stderr          # src/phase/Phasing.cpp:175-183
-    r = subprocess.run([CLI, "phase", "-s", "x.vcf", "-b", "x.bam", "-r", "x.fa", "--ont", "--dot"], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 1 and "not supported" in r.stderr
+    r = subprocess.run([CLI, "phase", "-s", "x.vcf", "-b", "x.bam", "-r", "x.fa", "--ont", "--dot", "--mod-file", "m.vcf"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "not supported" in r.stderr              # --dot is written for SNP / indel graphs only
     r = subprocess.run([CLI, "phase", "-s", "x.vcf", "-b", "x.bam", "-r", "x.fa", "--ont", "--sv-file", "y.vcf", "--svThreshold", "1.5"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "invalid svThreshold" in r.stderr        # src/phase/Phasing.cpp:312-318
 

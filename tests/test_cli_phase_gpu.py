@@ -35,6 +35,23 @@ def test_cli_phase_matches_reference_vcf(name, inflate, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(DATA_FIXTURES))
+def test_cli_phase_dot_matches_reference(name, tmp_path):
+    """--dot: <chr>.dot in the working directory, byte for byte the file the reference wrote (PhasingGraph.cpp:402-409, 1031-1047): every connected
+    pair of edgeConnectResult in the order it visits them, with its direction."""
+    import gzip
+    d = str(tmp_path)
+    assert write_bam(os.path.join(DATA, name + ".sam.gz"), d + "/r.bam") > 0
+    r = subprocess.run([CLI, "phase", "-s", os.path.join(DATA, name + ".vcf"), "-b", "r.bam", "-r", os.path.join(DATA, name + ".fa"), "-o", "out", "-t", "4", "--dot"]
+                       + DATA_FIXTURES[name][1], cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    want = gzip.open(os.path.join(DATA, name + ".ref.dot.gz"), "rt").read()
+    assert want.count("->") > 1000
+    assert open(d + "/chrS.dot").read() == want
+    assert _body(d + "/out.vcf") == _body(os.path.join(DATA, name + ".ref_phased.vcf"))
+
+
+@pytest.mark.gpu
 def test_cli_phase_table_through_the_collective(tmp_path):
     """The --gpus path of the table on the one-GPU box: rank 0's packed SNP table goes through lps_comm_bcast_to_device (a one-rank RCCL
     communicator) and reaches the context as device pointers (lps_set_variants_device) - same VCF as the reference's."""
