@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 15
+#define LPS_ABI_VERSION 16
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -323,6 +323,11 @@ void lps_host_free(void *p);
  * device (lps_bgzf_deflate_fetch copies it out); no EOF block is appended. */
 int lps_haplotag_write_bgzf(lps_ctx *ctx, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, const uint8_t *prefix, int64_t prefix_bytes,
                             int64_t *out_bytes);
+/* the same writer with somatic_haplotag's tags (addAuxiliaryTags, src/somatic_haplotag/SomaticHaplotagProcess.cpp:529-536): a record with
+ * status 0 loses its first HP, PS and PQ field and, when hp != 0, gains HP:Z with the haplotype's name (1 2 3 4 1-1 1-2 2-1 2-2 for hp 1..8),
+ * PS:i unless ps == -1, and PQ:i.  status/hp/ps/pq: what the caller decided from lps_somatic_tag_chromosome's counts. */
+int lps_somatic_write_bgzf(lps_ctx *ctx, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, const uint8_t *prefix, int64_t prefix_bytes,
+                           int64_t *out_bytes);
 /* Find every BAM record of the resident stream on the GPU, starting at first_record_offset (= the byte after the BAM header's reference
  * table; the caller parses the header with lps_bgzf_read).  Every byte position is tested against the necessary conditions of a record
  * start and the candidate list is verified to be exactly the record chain (serial fallback otherwise), so the result is exact.

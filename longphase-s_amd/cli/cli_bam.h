@@ -283,6 +283,35 @@ struct GpuBam {
     }
 };
 
+// A whole BAM inflated and scanned on the GPU, then copied back ONCE: `out` as BamFile::load leaves it (the records of the wanted contigs; offsets
+// relative to the contig's first record) for callers that splice records on the host.  The stream stays resident in `ctx` until its next lps_bgzf_load.
+static void gpu_load_to_host(Lps &L, lps_ctx *ctx, const std::string &path, const std::map<std::string, int> &want, int threads, BamFile &out, double *t_inflate = nullptr) {
+    GpuBam gb; gb.open_file(path, false); gb.load_all(L, ctx);
+    const size_t huge = 2u << 20, cap = ((size_t)gb.total + 64 + huge - 1) / huge * huge;
+    free(out.z.data);
+    out.z.data = (uint8_t *)aligned_alloc(huge, cap); out.z.size = (size_t)gb.total;
+    if (!out.z.data) die("ERROR: out of memory inflating " + path);
+    madvise(out.z.data, cap, MADV_HUGEPAGE);
+    {   // touched by a few threads first, so that the device-to-host copy does not fault page by page
+        std::vector<std::thread> th; const int nt = std::max(1, std::min(threads, 8)); const size_t slice = (cap + nt - 1) / nt;
+        for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { const size_t a = std::min(cap, slice * t), e = std::min(cap, a + slice); for (size_t q = a; q < e; q += 4096) out.z.data[q] = 0; });
+        for (auto &x : th) x.join();
+    }
+    if (gb.total && L.bgzf_read(ctx, 0, gb.total, out.z.data)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
+    out.ref_names = gb.ref_names;
+    for (auto &kv : gb.range) {
+        if (!want.count(kv.first)) continue;
+        ContigRecords &c = out.contigs[kv.first]; c.rec_off.resize((size_t)kv.second.second);
+        if (kv.second.second && L.bam_record_offsets(ctx, kv.second.first, kv.second.second, c.rec_off.data())) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
+        if (c.rec_off.empty()) continue;
+        c.lo = c.rec_off.front() - 4; c.hi = c.rec_off.back() + rd32(out.z.data + c.rec_off.back() - 4);      // a contig's records are one run of the stream
+        if (c.hi > (uint64_t)gb.total) die("ERROR: truncated BAM record in " + path);
+        for (uint64_t &o : c.rec_off) o -= c.lo;
+    }
+    if (t_inflate) *t_inflate += gb.t_inflate + gb.t_scan;
+    gb.close_file();
+}
+
 
 struct BgzfWriter {
     FILE *f = nullptr;

@@ -827,6 +827,7 @@ static const char *kSomUsage =
     "   --output-somatic-vcf (writes <prefix>_sc.vcf: the tumor VCF with FILTER = PASS for the somatic calls, LowQual otherwise)\n"
     "   --tagSupplementary   -q qualityThreshold(1)   -p percentageThreshold(0.6)   -t threads(1)   -o out-prefix(result)   --gpu=ID (0)\n"
     "   --host-deflate   zlib (level 6, RLE) on the -t threads for the tagged BAM instead of the GPU's BGZF writer\n"
+    "   --host-inflate   zlib on the -t threads for both BAMs instead of the GPU's BGZF inflate (the default for files below 256 MiB); --gpu-inflate forces the GPU\n"
     "   --gpus=N (deal the contigs onto N GPU contexts, devices --gpu, --gpu+1, ...: the three BAM passes of a contig run on its worker, purity is estimated\n"
     "             over all contigs, logs and the tagged BAM are merged in contig order)\n";
 
@@ -835,7 +836,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     std::string snp, ref, nbam, tvcf, tbam, prefix = "result";
     int threads = 1, gpu = 0, n_gpus = 1;
     double purity = -1, pct = 0.6;
-    bool enable_filter = true, write_log = false, write_sc_vcf = false; bool host_deflate = false, raw_started = false;
+    bool enable_filter = true, write_log = false, write_sc_vcf = false; bool host_deflate = false, raw_started = false, host_inflate = false, gpu_inflate = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kSomUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i], v; size_t eq = a.find('=');
@@ -863,6 +864,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--gpus") n_gpus = std::max(1, std::stoi(val()));
         else if (a == "--host-deflate") host_deflate = true;
+        else if (a == "--host-inflate") host_inflate = true;
+        else if (a == "--gpu-inflate") gpu_inflate = true;
         else if (a == "--help") { std::cout << kSomUsage; return 0; }
         else if (a == "--cram" || a == "--region" || a == "--log" || a == "--truth-vcf" || a == "--truth-bed" || a == "--benchmark-log") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kSomUsage; return 1; }
@@ -898,10 +901,33 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     if (chr_vec.empty()) die("[ERROR] (setChrVecAndChrLength) :tumor & normal VCFs chromosome count are empty");
     std::map<std::string, ChrVariants> want_seq; std::map<std::string, int> want;
     for (const std::string &c : chr_vec) { want[c] = 1; want_seq[c]; }
-    std::map<std::string, std::string> seqs; read_fasta(ref, want_seq, seqs);
-    BamFile nin, tin; nin.load(nbam, threads, want); tin.load(tbam, threads, want);
+    // Both BAMs: BGZF inflate + record discovery on the GPU, the inflated stream copied back once (the tag splice below works on host bytes); a small
+    // file (or --host-inflate) goes through zlib on -t threads beside the GPU start-up.  The FASTA is read beside either.
+    std::map<std::string, std::string> seqs; std::thread fasta_thread([&] { read_fasta(ref, want_seq, seqs); });
+    struct FastaJoin { std::thread &t; ~FastaJoin() { if (t.joinable()) t.join(); } } fasta_join{fasta_thread};
+    BamFile nin, tin;
+    const bool n_gpu = !host_inflate && (gpu_inflate || file_bytes(nbam) >= kGpuInflateMinBytes), t_gpu = !host_inflate && (gpu_inflate || file_bytes(tbam) >= kGpuInflateMinBytes);
+    if (!n_gpu) nin.load(nbam, threads, want);
+    if (!t_gpu) tin.load(tbam, threads, want);
     gpu_init.join();
     if (!ctx) die("longphase_amd: " + L.error);
+    // One worker and the GPU writer: both inflated streams STAY on the GPU (the tumor's in this context, the normal's in a second one that runs pass 1):
+    // the passes take their records from there (lps_push_bam_resident), the tagged records are spliced and deflated there (lps_somatic_write_bgzf).
+    // Otherwise (--gpus N, --host-deflate): the stream is copied back once and the contigs' records are pushed from host memory as before.
+    const bool resident = n_gpu && t_gpu && !host_deflate && n_gpus <= 1;
+    double t_gpu_inflate = 0; GpuBam ngb, tgb; lps_ctx *nctx = nullptr;
+    if (resident) {
+        tgb.open_file(tbam, false); tgb.load_all(L, ctx);
+        lps_params P; L.default_params(&P); for (auto &f : over) f(P);
+        nctx = L.create(gpu, &P); if (!nctx) die("longphase_amd: cannot create the GPU context of the normal BAM");
+        L.set_stage_timing(nctx, 0);
+        ngb.open_file(nbam, false); ngb.load_all(L, nctx);
+        t_gpu_inflate = tgb.t_inflate + tgb.t_scan + ngb.t_inflate + ngb.t_scan;
+    } else {
+        if (n_gpu) gpu_load_to_host(L, ctx, nbam, want, threads, nin, &t_gpu_inflate);
+        if (t_gpu) gpu_load_to_host(L, ctx, tbam, want, threads, tin, &t_gpu_inflate);
+    }
+    fasta_thread.join();
     const double t_in = now();
     std::atomic<long long> ns_p1{0}, ns_p2{0}, ns_host{0}, ns_p3{0}, ns_splice{0}, ns_append{0}, ns_prep{0}, ns_purity{0}, ns_finish{0}, ns_gpu_deflate{0};      // where the time goes (summed over workers)
     auto tick = [] { return std::chrono::steady_clock::now(); };
@@ -920,7 +946,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
 
     BgzfWriter w; w.open(prefix + ".bam", threads, 6, Z_RLE);
     {   // header of the TUMOR BAM + one @PG line
-        const uint8_t *d = tin.z.data; const uint32_t l_text = rd32(d + 4);
+        const uint8_t *d = resident ? tgb.header.data() : tin.z.data; const uint32_t l_text = rd32(d + 4);
         std::string text((const char *)d + 8, l_text); while (!text.empty() && text.back() == '\0') text.pop_back();
         if (!text.empty() && text.back() != '\n') text += '\n';
         std::string last_pg;
@@ -959,7 +985,9 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         std::vector<PurityDatum> &pdata = A.pdata; size_t &p_initial = A.p_initial; int (&lcvf)[5] = A.lcvf; std::ostringstream &flog = A.flog;
         unsigned long long &n_somatic_flag = A.n_flag; unsigned long long (&hp_hist)[9] = A.hp_hist; unsigned long long (&st_count)[8] = A.st_count;
         auto ti = tin.contigs.find(chr);
-        const bool have_t = ti != tin.contigs.end() && !ti->second.rec_off.empty();
+        std::pair<int64_t, int64_t> t_range{0, 0}, n_range{0, 0};          // resident streams: (first record, count) of this contig
+        if (resident) { auto a = tgb.range.find(chr); if (a != tgb.range.end()) t_range = a->second; auto b = ngb.range.find(chr); if (b != ngb.range.end()) n_range = b->second; }
+        const bool have_t = resident ? t_range.second > 0 : (ti != tin.contigs.end() && !ti->second.rec_off.empty());
         // ---- merged table (MultiGenomeVar map): normal phased-het rows + tumor rows
         std::map<int32_t, PhasedRow> none_n; std::map<int32_t, TumorRow> none_t;
         const std::map<int32_t, PhasedRow> &nr = nrows.count(chr) ? nrows[chr] : none_n;
@@ -991,7 +1019,9 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
           } }
         const size_t nv = pos.size();
         if (!have_t) return;
-        const ContigRecords &tc = ti->second; const size_t nt = tc.rec_off.size(); const uint8_t *tbase = tin.z.data + tc.lo;
+        static const ContigRecords no_records;
+        const ContigRecords &tc = resident ? no_records : ti->second; const size_t nt = resident ? (size_t)t_range.second : tc.rec_off.size(); const uint8_t *tbase = resident ? nullptr : tin.z.data + tc.lo;
+        bool tumor_pushed = false;
         std::vector<uint8_t> status(nt, 5), hp(nt, 0); std::vector<int32_t> psv(nt, -1), pq(nt, 0);
         if (phase == 0 && !nv) return;
         if (nv) {
@@ -1012,7 +1042,12 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             auto t_stage = tick();
             std::vector<int32_t> nsite(nv * LPS_SITE_COUNTERS, 0);
             auto ni = nin.contigs.find(chr);
-            if (ni != nin.contigs.end() && !ni->second.rec_off.empty()) {
+            if (resident) {
+                if (n_range.second > 0) { std::vector<uint32_t> nid((size_t)n_range.second, 0);
+                    lps_site_counters sc{(int64_t)nv, nsite.data(), 0, nullptr};
+                    if (L.begin_chromosome(nctx) || L.set_variants(nctx, &vt) || L.set_reference(nctx, sq.data(), (int64_t)sq.size()) ||
+                        L.push_bam_resident(nctx, n_range.first, n_range.second, nid.data()) || L.somatic_extract_normal(nctx, &sc)) die(std::string("longphase_amd: ") + L.last_error(nctx)); }
+            } else if (ni != nin.contigs.end() && !ni->second.rec_off.empty()) {
                 const ContigRecords &nc = ni->second; std::vector<uint32_t> nid(nc.rec_off.size(), 0);
                 lps_site_counters sc{(int64_t)nv, nsite.data(), 0, nullptr};
                 if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) ||
@@ -1034,7 +1069,9 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             te.hp = thp.data();
             te.n_ps = tnps.data(); te.ps_min = psmin.data(); te.end_pos = endp.data(); te.read_len = rlen.data(); te.has_site = has.data();
             { std::vector<uint32_t> tid(nt, 0);
-              if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) || L.push_bam_records(ctx, tbase, (int64_t)(tc.hi - tc.lo), tc.rec_off.data(), (int64_t)nt, tid.data())) fail();
+              if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) ||
+                  (resident ? L.push_bam_resident(ctx, t_range.first, t_range.second, tid.data()) : L.push_bam_records(ctx, tbase, (int64_t)(tc.hi - tc.lo), tc.rec_off.data(), (int64_t)nt, tid.data()))) fail();
+              tumor_pushed = true;
               }
             size_t pcap = nt * 4 + 1024, wcap = nt * 64 + 4096;
             for (int attempt = 0;; ++attempt) {
@@ -1221,6 +1258,27 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         }
         auto t_splice = tick();
         // ---- writer: HP:Z / PS:i (when the read saw a normal phase set) / PQ:i  (SomaticHaplotagProcess.cpp:529-536), records in input order
+        if (resident) {                                                     // records spliced, cut into BGZF blocks and deflated where the inflated stream already is
+            for (size_t i = 0; i < nt; ++i) { ++st_count[status[i] & 7]; if (status[i] == 0) ++hp_hist[hp[i] < 9 ? hp[i] : 0]; }
+            if (!tumor_pushed) { std::vector<uint32_t> tid(nt, 0);         // a contig without variants: every record is copied untouched
+                if (L.begin_chromosome(ctx) || L.push_bam_resident(ctx, t_range.first, t_range.second, tid.data())) fail(); }
+            int64_t nb = 0;
+            if (L.somatic_write_bgzf(ctx, status.data(), hp.data(), psv.data(), pq.data(), nullptr, 0, &nb)) fail();
+            tock(ns_splice, t_splice);
+            auto td = tick();
+            if (!pin[0]) { pin[0] = (uint8_t *)L.host_alloc(64u << 20); pin[1] = (uint8_t *)L.host_alloc(64u << 20); if (!pin[0] || !pin[1]) die("longphase_amd: cannot allocate page-locked host memory"); }
+            if (!raw_started) { w.flush_partial(); raw_started = true; }
+            std::thread wr; int k = 0;
+            for (int64_t off = 0; off < nb; off += (64ll << 20), k ^= 1) { const int64_t len = std::min<int64_t>(64ll << 20, nb - off);
+                if (L.bgzf_deflate_fetch_range(ctx, off, len, pin[k])) fail();
+                if (wr.joinable()) wr.join();
+                uint8_t *src = pin[k];
+                wr = std::thread([&w, src, len] { w.write_raw(src, (size_t)len); }); }
+            if (wr.joinable()) wr.join();
+            tock(ns_gpu_deflate, td);
+            std::cerr << "(" << chr << ")";
+            return;
+        }
         std::vector<uint64_t> out_off(nt + 1, 0);
         auto aux_of = [&](const uint8_t *r) { const uint32_t l_name = r[8], n_cig = r[12] | (r[13] << 8), l_seq = rd32(r + 16);
             return r + 32 + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq;
@@ -1315,7 +1373,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     const int n_workers = std::max(1, std::min<int>(n_gpus, (int)chr_vec.size()));
     std::vector<std::vector<size_t>> share((size_t)n_workers);
     { std::vector<size_t> order(chr_vec.size()); for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-      auto weight = [&](size_t i) -> size_t { auto it = tin.contigs.find(chr_vec[i]); return it == tin.contigs.end() ? 0 : it->second.rec_off.size(); };
+      auto weight = [&](size_t i) -> size_t { if (resident) { auto a = tgb.range.find(chr_vec[i]); return a == tgb.range.end() ? 0 : (size_t)a->second.second; }
+          auto it = tin.contigs.find(chr_vec[i]); return it == tin.contigs.end() ? 0 : it->second.rec_off.size(); };
       std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight(a) > weight(b); });
       std::vector<size_t> load((size_t)n_workers, 0);
       for (size_t i : order) { const size_t g = (size_t)(std::min_element(load.begin(), load.end()) - load.begin()); share[g].push_back(i); load[g] += weight(i) + 1; }
@@ -1374,6 +1433,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             o << line << std::endl;
         }
     }
+    if (nctx) L.destroy(nctx);
+    tgb.close_file(); ngb.close_file();
     L.destroy(ctx);
     unsigned long long total = 0; for (int k = 0; k < 8; ++k) total += st_count[k];
     fprintf(stderr, "somatic variant count(Flag): %llu\n", n_somatic_flag);

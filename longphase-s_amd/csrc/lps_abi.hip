@@ -733,9 +733,9 @@ int lps_bgzf_deflate_host(lps_ctx *c, const uint8_t *bytes, int64_t n_bytes, int
     return 0;
 }
 
-int lps_haplotag_write_bgzf(lps_ctx *c, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, const uint8_t *prefix, int64_t prefix_bytes, int64_t *out_bytes) {
+static int write_tagged_bgzf(lps_ctx *c, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, const uint8_t *prefix, int64_t prefix_bytes, int64_t *out_bytes, int somatic_tags) {
     if (!c || !out_bytes || prefix_bytes < 0 || (prefix_bytes && !prefix)) return -1;
-    if (c->read_mode != 3 || c->cur_first < 0) return fail(c, "lps_haplotag_write_bgzf: needs exactly one lps_push_bam_resident in this chromosome");
+    if (c->read_mode != 3 || c->cur_first < 0) return fail(c, "lps_haplotag_write_bgzf / lps_somatic_write_bgzf: needs exactly one lps_push_bam_resident in this chromosome");
     const size_t n = (size_t)c->cur_count;
     if (n && (!status || !hp || !ps || !pq)) return -1;
     try {
@@ -745,7 +745,7 @@ int lps_haplotag_write_bgzf(lps_ctx *c, const uint8_t *status, const uint8_t *hp
         c->tg_stream.reserve((size_t)prefix_bytes + 64, s); c->bam_err.reserve(1);
         if (prefix_bytes) HIP_TRY(hipMemcpyAsync(c->tg_stream.p, prefix, (size_t)prefix_bytes, hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(e0, s));
-        const int64_t total = bam_tag_stream(c->file.p, c->rcand.p + c->cur_first, (uint32_t)n, c->tg_status.p, c->tg_hp.p, c->tg_ps.p, c->tg_pq.p, (uint64_t)prefix_bytes,
+        const int64_t total = bam_tag_stream(c->file.p, c->rcand.p + c->cur_first, (uint32_t)n, c->tg_status.p, c->tg_hp.p, c->tg_ps.p, c->tg_pq.p, somatic_tags, (uint64_t)prefix_bytes,
                                              c->tg_len, c->tg_off, c->tg_spans, c->tg_stream, c->temp, c->temp_bytes, c->bam_err.p, s);
         if (total < 0) return fail(c, "malformed auxiliary field in a BAM record");
         c->dz_total = bgzf_deflate_device(c->tg_stream.p, (uint64_t)total, c->dz_slots, c->dz_bytes, c->dz_tmp, c->dz_off, c->dz_packed, c->temp, c->temp_bytes, s);
@@ -754,6 +754,12 @@ int lps_haplotag_write_bgzf(lps_ctx *c, const uint8_t *status, const uint8_t *hp
         *out_bytes = (int64_t)c->dz_total;
     } catch (std::string &e) { return fail(c, e); }
     return 0;
+}
+int lps_haplotag_write_bgzf(lps_ctx *c, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, const uint8_t *prefix, int64_t prefix_bytes, int64_t *out_bytes) {
+    return write_tagged_bgzf(c, status, hp, ps, pq, prefix, prefix_bytes, out_bytes, 0);
+}
+int lps_somatic_write_bgzf(lps_ctx *c, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, const uint8_t *prefix, int64_t prefix_bytes, int64_t *out_bytes) {
+    return write_tagged_bgzf(c, status, hp, ps, pq, prefix, prefix_bytes, out_bytes, 1);
 }
 
 int lps_bgzf_deflate_fetch(lps_ctx *c, uint8_t *dst, int64_t cap, double *kernel_ms) {

@@ -25,6 +25,6 @@ int bam_scan_records(const uint8_t *d, uint64_t first_rec, uint64_t total, int32
 void launch_bam_tid_lname(const uint8_t *d, const uint64_t *cand, uint32_t n, int32_t *tid, uint32_t *l_name, hipStream_t s);
 void launch_bam_names(const uint8_t *d, const uint64_t *cand, uint32_t n, const uint32_t *name_off, uint8_t *names, hipStream_t s);
 // haplotag writer: prefix + re-tagged records -> `stream` (the caller puts the prefix bytes at stream[0, prefix_bytes) BEFORE the call); -1 = malformed optional field
-int64_t bam_tag_stream(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, uint64_t prefix_bytes,
+int64_t bam_tag_stream(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, int somatic_tags, uint64_t prefix_bytes,
                        DevBuf<unsigned long long> &new_len, DevBuf<unsigned long long> &out_off, DevBuf<uint2> &spans, DevBuf<uint8_t> &stream, DevBuf<char> &temp, size_t &temp_bytes,
                        unsigned *err, hipStream_t s);

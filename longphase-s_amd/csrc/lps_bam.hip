@@ -259,7 +259,19 @@ void launch_bam_names(const uint8_t *d, const uint64_t *cand, uint32_t n, const 
 // ================================================================================================ tagged-record stream (haplotag writer)
 // HaplotagProcess.cpp:337-361 on the device: a scored record loses its first HP, PS and PQ optional field and, when tagged, gains HP:i PS:i PQ:i;
 // every other record is copied untouched.  k_tag_sizes walks the optional fields (thread per record), k_tag_write copies bytes (wave per record).
-__global__ void __launch_bounds__(256) k_tag_sizes(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, unsigned long long *new_len,
+// somatic_haplotag's tags (src/somatic_haplotag/SomaticHaplotagProcess.cpp:529-536: HP:Z with the haplotype's name - 1 2 3 4 1-1 1-2 2-1 2-2 -, PS:i only for a read with a phase set, PQ:i)
+__device__ __forceinline__ uint32_t som_tag_len(uint32_t hp, int32_t ps) { return 3u + ((hp >= 5u && hp <= 8u) ? 3u : 1u) + 1u + (ps != -1 ? 7u : 0u) + 7u; }
+__device__ __forceinline__ uint8_t som_tag_byte(uint32_t b, uint32_t hp, int32_t ps, int32_t pq) {
+    const uint32_t sl = (hp >= 5u && hp <= 8u) ? 3u : 1u;
+    if (b < 3u) return b == 0 ? (uint8_t)'H' : b == 1 ? (uint8_t)'P' : (uint8_t)'Z';
+    b -= 3u;
+    if (b < sl) { if (sl == 1u) return (hp >= 1u && hp <= 4u) ? (uint8_t)('0' + hp) : (uint8_t)'.'; const uint32_t k = hp - 5u; return b == 0 ? (uint8_t)('1' + (k >> 1)) : b == 1 ? (uint8_t)'-' : (uint8_t)('1' + (k & 1u)); }
+    if (b == sl) return 0;
+    b -= sl + 1u;
+    if (ps != -1) { if (b < 7u) return b == 0 ? (uint8_t)'P' : b == 1 ? (uint8_t)'S' : b == 2 ? (uint8_t)'i' : (uint8_t)((uint32_t)ps >> (8 * (b - 3u))); b -= 7u; }
+    return b == 0 ? (uint8_t)'P' : b == 1 ? (uint8_t)'Q' : b == 2 ? (uint8_t)'i' : (uint8_t)((uint32_t)pq >> (8 * (b - 3u)));
+}
+__global__ void __launch_bounds__(256) k_tag_sizes(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, const int32_t *ps, int som, unsigned long long *new_len,
                                                    uint2 *spans /* [n][4] (offset from refID, length), sorted by offset, length 0 = none; [3] = the CG field, re-appended at the end */, unsigned *err) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i > n) return;
@@ -281,16 +293,17 @@ __global__ void __launch_bounds__(256) k_tag_sizes(const uint8_t *d, const uint6
         }
     }
     spans[(size_t)i * 4 + 0] = sp[0]; spans[(size_t)i * 4 + 1] = sp[1]; spans[(size_t)i * 4 + 2] = sp[2]; spans[(size_t)i * 4 + 3] = cgs;
-    new_len[i] = 4ull + bs - removed + ((status[i] == 0 && hp[i]) ? 21u : 0u);
+    new_len[i] = 4ull + bs - removed + ((status[i] == 0 && hp[i]) ? (som ? som_tag_len(hp[i], ps[i]) : 21u) : 0u);
 }
 
 __global__ void __launch_bounds__(256) k_tag_write(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq,
-                                                   const unsigned long long *out_off, const uint2 *spans, uint8_t *out) {
+                                                   int som, const unsigned long long *out_off, const uint2 *spans, uint8_t *out) {
     const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const uint64_t r = rec[i]; const uint32_t bs = ld_u32_unaligned(d + r - 4);
     const uint2 s0 = spans[(size_t)i * 4], s1 = spans[(size_t)i * 4 + 1], s2 = spans[(size_t)i * 4 + 2], cg = spans[(size_t)i * 4 + 3];
-    const uint32_t kept = bs - s0.y - s1.y - s2.y - cg.y; const bool tag = status[i] == 0 && hp[i] != 0; const uint32_t nbs = kept + (tag ? 21u : 0u) + cg.y;
+    const uint32_t kept = bs - s0.y - s1.y - s2.y - cg.y; const bool tag = status[i] == 0 && hp[i] != 0;
+    const uint32_t tlen = !tag ? 0u : som ? som_tag_len(hp[i], ps[i]) : 21u, nbs = kept + tlen + cg.y;
     uint8_t *o = out + out_off[i];
     if (lane < 4) o[lane] = (uint8_t)(nbs >> (8 * lane));
     for (uint32_t j = lane; j < kept; j += 64) {
@@ -306,21 +319,22 @@ __global__ void __launch_bounds__(256) k_tag_write(const uint8_t *d, const uint6
         }
         o[4 + j] = d[r + src];
     }
-    if (tag && lane < 21) {                                               // addAuxiliaryTags: HP:i PS:i PQ:i, 7 bytes each
+    if (tag && som) { if (lane < tlen) o[4 + kept + lane] = som_tag_byte(lane, hp[i], ps[i], pq[i]); }
+    else if (tag && lane < 21) {                                          // addAuxiliaryTags: HP:i PS:i PQ:i, 7 bytes each
         const uint32_t f = lane / 7, b = lane % 7; const uint32_t val = f == 0 ? (uint32_t)hp[i] : f == 1 ? (uint32_t)ps[i] : (uint32_t)pq[i];
         const char *nm = f == 0 ? "HP" : f == 1 ? "PS" : "PQ";
         o[4 + kept + lane] = b < 2 ? (uint8_t)nm[b] : b == 2 ? (uint8_t)'i' : (uint8_t)(val >> (8 * (b - 3)));
     }
-    for (uint32_t j = lane; j < cg.y; j += 64) o[4 + kept + (tag ? 21u : 0u) + j] = d[r + cg.x + j];   // ... and the CG field behind everything else
+    for (uint32_t j = lane; j < cg.y; j += 64) o[4 + kept + tlen + j] = d[r + cg.x + j];   // ... and the CG field behind everything else
 }
 
 // -> total bytes of prefix + re-tagged records in `stream`; -1 when an optional field is malformed
-int64_t bam_tag_stream(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, uint64_t prefix_bytes,
+int64_t bam_tag_stream(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, int somatic_tags, uint64_t prefix_bytes,
                        DevBuf<unsigned long long> &new_len, DevBuf<unsigned long long> &out_off, DevBuf<uint2> &spans, DevBuf<uint8_t> &stream, DevBuf<char> &temp, size_t &temp_bytes,
                        unsigned *err, hipStream_t s) {
     new_len.reserve((size_t)n + 1, s); out_off.reserve((size_t)n + 1, s); spans.reserve((size_t)n * 4 + 4, s);
     HIP_TRY(hipMemsetAsync(err, 0, sizeof(unsigned), s));
-    hipLaunchKernelGGL(k_tag_sizes, dim3((n + 256) / 256), dim3(256), 0, s, d, rec, n, status, hp, new_len.p, spans.p, err);
+    hipLaunchKernelGGL(k_tag_sizes, dim3((n + 256) / 256), dim3(256), 0, s, d, rec, n, status, hp, ps, somatic_tags, new_len.p, spans.p, err);
     size_t need = 0;
     HIP_TRY(rocprim::exclusive_scan(nullptr, need, new_len.p, out_off.p, (unsigned long long)prefix_bytes, (size_t)n + 1, rocprim::plus<unsigned long long>(), s));
     if (need + 256 > temp_bytes) { temp.reserve(need + 256, s); temp_bytes = need + 256; }
@@ -331,6 +345,6 @@ int64_t bam_tag_stream(const uint8_t *d, const uint64_t *rec, uint32_t n, const 
     HIP_TRY(hipStreamSynchronize(s));
     if (e) return -1;
     stream.reserve((size_t)total + 64, s, true, prefix_bytes);
-    if (n) hipLaunchKernelGGL(k_tag_write, dim3((n + 3) / 4), dim3(256), 0, s, d, rec, n, status, hp, ps, pq, (const unsigned long long *)out_off.p, (const uint2 *)spans.p, stream.p);
+    if (n) hipLaunchKernelGGL(k_tag_write, dim3((n + 3) / 4), dim3(256), 0, s, d, rec, n, status, hp, ps, pq, somatic_tags, (const unsigned long long *)out_off.p, (const uint2 *)spans.p, stream.p);
     return (int64_t)total;
 }

@@ -17,8 +17,11 @@ CLI = os.path.join(HERE, "..", "longphase-s_amd", "cli", "longphase_amd")
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("key", sorted(fixtures.CLI_SOMATIC_FIXTURES))
-def test_cli_somatic_matches_reference(key, tmp_path):
+# both BAMs through zlib on the host (the default below 256 MiB), or inflated on the GPU where they stay: records pushed from the resident streams, the
+# tagged BAM spliced and deflated there (lps_somatic_write_bgzf) - for a third of the fixtures, to keep the suite short
+_KEYS = sorted(fixtures.CLI_SOMATIC_FIXTURES)
+@pytest.mark.parametrize("key,inflate", [(k, "host") for k in _KEYS] + [(k, "gpu") for k in _KEYS[::3]])
+def test_cli_somatic_matches_reference(key, inflate, tmp_path):
     gold = json.load(open(os.path.join(HERE, "golden", f"cli_somatic_{key}.json")))
     name, purity, extra = fixtures.CLI_SOMATIC_FIXTURES[key]
     d = str(tmp_path)
@@ -27,7 +30,7 @@ def test_cli_somatic_matches_reference(key, tmp_path):
     util.write_bam(d + "/normal.sam", d + "/normal.bam"); util.write_bam(d + "/tumor.sam", d + "/tumor.bam", block=40000)
     phased = os.path.join(HERE, "golden", "data", f"somatic_{name}.normal_phased.vcf")
     r = subprocess.run([CLI, "somatic_haplotag", "-s", phased, "-b", "normal.bam", "--tumor-snv-file", "tumor.vcf", "--tumor-bam-file", "tumor.bam", "-r", "ref.fa", "-t", "4",
-                        "-o", "som", "--somatic-calling-log", "--output-somatic-vcf"] + (["--tumor-purity", purity] if purity != "auto" else []) + gold["cli"], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, LPS_CLI_DEBUG="1"))
+                        "-o", "som", "--somatic-calling-log", "--output-somatic-vcf"] + (["--tumor-purity", purity] if purity != "auto" else []) + gold["cli"] + ["--" + inflate + "-inflate"], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, LPS_CLI_DEBUG="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     print(r.stderr[-700:])
     if purity == "auto":                                              # the estimator's report: every count, the box-plot statistics and the purity itself
@@ -95,14 +98,16 @@ def test_cli_somatic_gpus_equals_single_worker(tmp_path):
     _merge_contigs(d, parts)
     util.write_bam(d + "/normal.sam", d + "/normal.bam"); util.write_bam(d + "/tumor.sam", d + "/tumor.bam", block=40000)
     outs = {}
-    for tag, extra in (("one", []), ("three", ["--gpus", "3"])):
+    for tag, extra in (("one", []), ("three", ["--gpus", "3"]), ("gpuin", ["--gpu-inflate"]), ("gpuin_hostz", ["--gpu-inflate", "--host-deflate"])):
         r = subprocess.run([CLI, "somatic_haplotag", "-s", "normal_phased.vcf", "-b", "normal.bam", "--tumor-snv-file", "tumor.vcf", "--tumor-bam-file", "tumor.bam", "-r", "ref.fa",
                             "-t", "4", "-o", tag, "--somatic-calling-log", "--output-somatic-vcf", "--tagSupplementary"] + extra, cwd=d, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        assert ("3 workers" in r.stderr) == bool(extra)
+        assert ("3 workers" in r.stderr) == (tag == "three")
         text, refs, recs = util.bam_sections(os.path.join(d, tag + ".bam"))
         sc = [l for l in open(os.path.join(d, tag + "_sc.vcf")).read().split("\n") if not l.startswith("##commandline=")]
         outs[tag] = (hashlib.sha256(recs).hexdigest(), len(recs), open(os.path.join(d, tag + "_somatic_filter.log")).read(), open(os.path.join(d, tag + "_purity.out")).read(), sc,
                      [l for l in r.stderr.splitlines() if l.startswith("somatic variant count(Flag)")])
     assert outs["one"][1] > 1_000_000 and len(outs["one"][2].splitlines()) > 100
     assert outs["one"] == outs["three"]
+    assert outs["one"] == outs["gpuin"]                                 # both streams resident on the GPU, three contigs taken from them, the GPU's tag writer
+    assert outs["one"] == outs["gpuin_hostz"]                           # inflated on the GPU, copied back once, three contigs cut out of the copy
