@@ -64,6 +64,7 @@ def load():
     L.lps_bgzf_deflate.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
     L.lps_bgzf_deflate_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]
     L.lps_haplotag_write_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.lps_somatic_write_bgzf.argtypes = L.lps_haplotag_write_bgzf.argtypes
     L.lps_bgzf_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.lps_bam_scan.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
     L.lps_bam_scan_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
