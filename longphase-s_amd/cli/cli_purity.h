@@ -1,172 +1,284 @@
-// cli_purity.h — restatement of the reference's tumor purity estimator (src/somatic_haplotag/TumorPurityEstimator.cpp) for longphase_amd somatic_haplotag.
+// cli_purity.h — the tumor purity estimator of `somatic_haplotag` (restatement of src/somatic_haplotag/TumorPurityEstimator.cpp) for longphase_amd.
+//
+// Input: one datum per germline het site that survived the caller's first filters - the haplotype imbalance ratio of the tumor reads and the number of
+// haplotype-resolved reads of the normal BAM there.  The estimator
+//   1. drops the sites with few normal reads: the threshold is the valley between the two modes of the read-count histogram, when there is one
+//      (findBimodalValleyThreshold: histogram -> Gaussian smoothing -> peaks -> main peak -> the lowest valley before it);
+//   2. drops the outliers of the imbalance ratio once (box plot, 1.5 IQR whiskers);
+//   3. maps (median, IQR) of what is left to a purity with a fitted quadratic;
+//   4. writes <prefix>_purity.out.
+// Every quirk of the reference that shows in the report is kept on purpose and marked "as the reference".  Pinned by the goldens of
+// tests/test_cli_somatic_gpu.py (the report is compared as text) and by tests/test_purity_cpu.py (hand-made histograms).
 #pragma once
 #include "cli_common.h"
 
 struct PurityDatum { double ratio; int nor_count; };
-static double estimate_purity(std::vector<PurityDatum> v, size_t initial_size, const int lcvf[5], const std::string &prefix) {
-    struct H { double count, pct; };
-    int threshold = 0; size_t n_valley = 0, n_out = 0;
-    double purity = 0.0;
-    try {
-        if (v.empty()) throw std::runtime_error("Failed to build purity feature vector: empty vector");
-        try {   // findBimodalValleyThreshold
-            std::vector<H> hist(1000, H{0, 0});
-            for (auto &d : v) { const size_t rc = (size_t)d.nor_count;
-                if (rc >= hist.size()) { const size_t ns = hist.size() * 2;
-                    if (ns >= 1000000) throw std::overflow_error("Read count exceeds maximum histogram size");
-                    hist.resize(ns, H{0, 0});
-                    } hist[rc].count++;
-                }
-            const size_t total = v.size(); double max_height = 0; std::pair<size_t, size_t> range{0, 0};
-            auto stats = [&](std::vector<H> &h) { double tot = 0; bool first = false;
-                for (size_t i = 0; i < h.size(); ++i) { tot += h[i].count / (double)total;
-                    h[i].pct = tot;
-                    if (h[i].count > max_height) max_height = h[i].count;
-                    if (!first && h[i].count > 0) { range.first = i;
-                        first = true;
-                        } if (h[i].count > 0) range.second = i;
-                    }
-                if (max_height == 0) throw std::runtime_error("max_height is 0 in histogram");
-                h.resize(range.second + 1); };
-            stats(hist);
-            std::vector<H> sm = hist;
-            {   // Gaussian filter, sigma 0.5: kernel size int(6 * 0.5 + 1) = 4 -> 5
-                const double sigma = 0.5;
-                int ks = (int)(6 * sigma + 1);
-                if (ks % 2 == 0) ks += 1;
-                const int half = ks / 2;
-                std::vector<double> k((size_t)ks);
-                double sum = 0;
-                for (int i = 0; i < ks; ++i) { const double x = i - half;
-                    k[(size_t)i] = std::exp(-0.5 * (x / sigma) * (x / sigma));
-                    sum += k[(size_t)i];
-                    }
-                for (double &x : k) x /= sum;
-                const std::vector<H> tmp = sm;
-                for (size_t i = 0; i < sm.size(); ++i) { double c = 0;
-                    for (size_t j = 0; j < k.size(); ++j) { size_t idx = 0;
-                        if (i + j >= (size_t)half) { idx = i + j - (size_t)half;
-                            if (idx >= sm.size()) idx = sm.size() - 1;
-                            } c += tmp[idx].count * k[j];
-                        } sm[i].count = c;
-                    }
-                stats(sm);
-                // max_height keeps the larger of raw and smoothed, as the copied object does
-            }
-            const double peak_thr = (double)std::max((size_t)(max_height * 0.05), (size_t)1);
-            struct Peak { size_t idx; double h; int lt = 0, rt = 0; bool main = false; };   // trends: 1 UP, 2 DOWN, 3 FLAT
-            std::vector<Peak> pk;
-            for (size_t i = 0; i < sm.size(); ++i) { bool is = false; if (sm[i].count < peak_thr) continue;
-                else if (i == 0 && i != sm.size() - 1) { if (sm[i].count > sm[i + 1].count) is = true; }
-                else if (i == sm.size() - 1 && i != 0) { if (sm[i].count > sm[i - 1].count) is = true; }
-                else if (sm.size() > 1 && sm[i].count > sm[i - 1].count && sm[i].count > sm[i + 1].count) is = true;
-                if (is) pk.push_back(Peak{i, sm[i].count}); }
-            if (pk.empty()) throw std::runtime_error("No peaks found in peaksVec");
-            if (pk.size() >= 2) for (size_t i = 0; i < pk.size() - 1;) { if (pk[i + 1].idx - pk[i].idx < 2) { if (pk[i].h >= pk[i + 1].h) pk.erase(pk.begin() + (long)i + 1);
-                    else pk.erase(pk.begin() + (long)i);
-                    } else ++i;
-                }
-            if (pk.size() >= 2) for (size_t i = 0; i < pk.size() - 1; ++i) { const int t = pk[i].h < pk[i + 1].h ? 1 : pk[i].h > pk[i + 1].h ? 2 : 3;
-                pk[i].rt = t;
-                pk[i + 1].lt = t;
-                }
-            if (pk.size() == 1) pk[0].main = true;
-            else for (size_t i = 0; i < pk.size(); ++i) { if (i == 0) pk[i].main = pk[i].rt == 2;
-                else if (i == pk.size() - 1) pk[i].main = pk[i].lt == 1;
-                else pk[i].main = pk[i].lt == 1 && pk[i].rt == 2;
-                }
-            std::vector<Peak> mains; for (auto &q : pk) if (q.main) mains.push_back(q);
-            if (mains.empty()) throw std::runtime_error("No main peaks found in peaksVec");
-            size_t main_idx;
-            if (mains.size() == 1) main_idx = mains[0].idx;
-            else { std::sort(mains.begin(), mains.end(), [](const Peak &a, const Peak &b) { return a.h > b.h; });
-                main_idx = mains[0].idx > mains[1].idx ? mains[0].idx : mains[1].idx;
-                }
-            auto at_peak = [&](size_t idx) -> size_t { for (size_t i = 0; i < pk.size(); ++i) if (pk[i].idx == idx) return i;
-                throw std::runtime_error("Peak not found");
-                };
-            auto lowest_valley = [&](size_t a, size_t b, size_t &vi, double &vh, double &vp) -> bool { if (a >= b || b > sm.size()) return false;
-                bool found = false;
-                vh = 2147483647.0;
-                for (size_t i = a + 1; i + 1 < b; ++i) if (sm[i].count < sm[i - 1].count && sm[i].count < sm[i + 1].count) { if (!found || sm[i].count < vh) { vi = i;
-                        vh = sm[i].count;
-                        vp = sm[i].pct;
-                        found = true;
-                        } }
-                return found; };
-            double valley_h = 0, thr_pct = 0;                                 // Valley() is value-initialised: height 0
-            bool found_sec = false; size_t sec_i = 0;
-            if (pk[0].idx != main_idx) { size_t mi = at_peak(main_idx); size_t j = mi - 1;
-                if (j == 0) { sec_i = 0; found_sec = true; }
-                else { while (j != 0) { if (pk[j].lt == 2 && pk[j].rt == 1) { sec_i = j;
-                            found_sec = true;
-                            break;
-                            } --j;
-                        } if (!found_sec) { sec_i = 0;
-                        found_sec = true;
-                        } } }
-            if (found_sec) {
-                size_t vi = 0; double vh = 0, vp = 0;
-                bool fv = lowest_valley(pk[sec_i].idx, pk[sec_i + 1].idx, vi, vh, vp);
-                if (fv) { thr_pct = vp;
-                    threshold = (int)vi;
-                    valley_h = vh;
-                    } else { valley_h = 2147483647.0;
-                    }   // findLowestValley leaves height = INT_MAX when it finds nothing
-                if (thr_pct >= 0.3 || !fv) { valley_h = 0; thr_pct = 0; threshold = 0;
-                    if (sec_i != 0) { fv = lowest_valley(pk[sec_i - 1].idx, pk[sec_i].idx, vi, vh, vp);
-                        if (fv) { thr_pct = vp;
-                            threshold = (int)vi;
-                            valley_h = vh;
-                            } else valley_h = 2147483647.0;
-                        } }
-            }
-            if (valley_h > max_height * 0.7) { thr_pct = 0; threshold = 0; }
-            if (thr_pct >= 0.3) { thr_pct = 0; threshold = 0; }
-        } catch (const std::exception &e) { std::cerr << "[ERROR] " << e.what() << "\n[ERROR] Failed to find peak valley threshold, set threshold to 0\n";
-        threshold = 0;
+
+namespace purity_detail {
+
+struct Bin { double count = 0, pct = 0; };                    // pct: cumulative share of the data up to and including this bin
+
+// Running facts about the histogram that the reference keeps in ONE object across the raw and the smoothed pass (as the reference: the maximum is
+// the larger of the two passes, the occupied range is that of the pass that ran last).
+struct HistFacts { double max_height = 0; size_t first = 0, last = 0; };
+
+// read count -> number of sites; the histogram doubles until the count fits (at most 2^20 bins)
+static std::vector<Bin> read_count_histogram(const std::vector<PurityDatum> &data) {
+    std::vector<Bin> hist(1000);
+    for (const PurityDatum &d : data) {
+        const size_t rc = (size_t)d.nor_count;
+        while (rc >= hist.size()) {                           // (the reference doubles once per datum and would then store out of bounds: doubled until it fits here)
+            const size_t bigger = hist.size() * 2;
+            if (bigger >= 1000000) throw std::overflow_error("Read count exceeds maximum histogram size");
+            hist.resize(bigger);
         }
-        for (auto it = v.begin(); it != v.end();) { if (it->nor_count < threshold) { ++n_valley;
-                it = v.erase(it);
-                } else ++it;
-            }   // bimodalValleyFilter
-        struct Box { size_t n = 0; double q1 = 0, med = 0, q3 = 0, iqr = 0, lo = 0, hi = 0; size_t outliers = 0; };
-        auto box = [&](std::vector<PurityDatum> &d) { Box b;
-            b.n = d.size();
-            if (!b.n) throw std::runtime_error("Failed to statistic purity data: the data size is 0");
-            std::sort(d.begin(), d.end(), [](const PurityDatum &x, const PurityDatum &y) { return x.ratio < y.ratio; });
-            auto pct = [&](double p) { const double pos = p * (double)(b.n - 1);
-                const size_t idx = (size_t)pos;
-                const double frac = pos - (double)idx;
-                if (idx + 1 >= b.n) return d[b.n - 1].ratio;
-                return d[idx].ratio * (1.0 - frac) + d[idx + 1].ratio * frac;
-                };
-            b.q1 = pct(0.25);
-            b.med = pct(0.5);
-            b.q3 = pct(0.75);
-            b.iqr = b.q3 - b.q1;
-            b.lo = std::max(0.0, b.q1 - 1.5 * b.iqr);
-            b.hi = b.q3 + 1.5 * b.iqr;
-            for (auto &x : d) if (x.ratio < b.lo || x.ratio > b.hi) ++b.outliers; return b; };
-        Box b = box(v);
-        for (auto it = v.begin(); it != v.end();) { if (it->ratio < b.lo || it->ratio > b.hi) { it = v.erase(it); ++n_out; } else ++it; }
-        b = box(v);
-        purity = -3.3454 * b.med + 14.7747 * b.iqr + 4.0344 * b.med * b.med + -13.7777 * b.med * b.iqr + -5.2434 * b.iqr * b.iqr + 0.3058;
-        if (purity > 1.0) purity = 1.0;
-        else if (purity < 0.0) throw std::runtime_error("The value of purity exceeds the model's estimation range: " + std::to_string(purity));
-        std::ofstream o(prefix + "_purity.out");
-        if (o) { o << "#==================================\n# TUMOR PURITY ESTIMATION REPORT\n#==================================\n#Initial data size: " << initial_size << std::endl
-            << "#==========filter parameters==========" << std::endl << "#GERMLINE_HP_IMBALANCE_RATIO_MIN_THR: " << 0.0f << std::endl << "#GERMLINE_HP_IMBALANCE_RATIO_IN_NOR_BAM_MIN_THR: " << 0.0f << std::endl
-            << "#GERMLINE_HP_IMBALANCE_RATIO_IN_NOR_BAM_MAX_THR: " << 0.7f << std::endl << "#GERMLINE_HP_PERCENTAGE_IN_NOR_BAM_MAX_THR: " << 0.7f << std::endl << "#GERMLINE_HP_READ_COUNT_IN_NOR_BAM_MIN_THR: " << 5 << std::endl
-            << "#GERMLINE_HP_READ_COUNT_IN_NOR_BAM_DYNAMIC_THR: " << threshold << std::endl << "#==========Initial filter out data count==========" << std::endl
-            << "#imbalanceRatioInNorBam: " << lcvf[0] << std::endl << "#imbalanceRatio: " << lcvf[1] << std::endl << "#imbalanceRatioInNorBam_over_thr: " << lcvf[2] << std::endl << "#readHpCountInNorBam: " << lcvf[3] << std::endl
-            << "#percentageOfGermlineHpInNorBam: " << lcvf[4] << std::endl << "#==========Second filter out data count==========" << std::endl << "#peakValley count: " << n_valley << std::endl
-            << "#==========Whisker filter out data count==========" << std::endl << "#iteration times: " << 1 << std::endl << "#remove outliers: " << n_out << std::endl << "#==========Statistical analysis===========" << std::endl
-            << "Data size: " << b.n << std::endl << "Median: " << b.med << std::endl << "Q1: " << b.q1 << std::endl << "Q3: " << b.q3 << std::endl << "IQR: " << b.iqr << std::endl << "Whiskers: " << b.lo << " to " << b.hi << std::endl
-            << "Outliers: " << b.outliers << std::endl << "#==========Estimation result===========" << std::endl << "Tumor purity: " << purity << std::endl;
-            }
-    } catch (const std::exception &e) { std::cerr << "[ERROR] " << e.what() << "\n[ERROR] Failed to estimate tumor purity, set purity to 0.0\n";
-    purity = 0.0;
+        hist[rc].count++;
     }
-    return purity;
+    return hist;
+}
+
+// cumulative shares, the tallest bin and the occupied range; bins behind the last occupied one are cut off
+static void histogram_stats(std::vector<Bin> &h, size_t n_data, HistFacts &f) {
+    double cumulative = 0;
+    bool seen_first = false;
+    for (size_t i = 0; i < h.size(); ++i) {
+        cumulative += h[i].count / (double)n_data;
+        h[i].pct = cumulative;
+        if (h[i].count > f.max_height) f.max_height = h[i].count;
+        if (h[i].count > 0) {
+            if (!seen_first) { f.first = i; seen_first = true; }
+            f.last = i;
+        }
+    }
+    if (f.max_height == 0) throw std::runtime_error("max_height is 0 in histogram");
+    h.resize(f.last + 1);
+}
+
+// Gaussian filter with sigma 0.5: kernel size int(6 * 0.5 + 1) = 4, made odd -> 5 taps; the borders repeat the edge bin
+static void gaussian_smooth(std::vector<Bin> &h) {
+    const double sigma = 0.5;
+    int taps = (int)(6 * sigma + 1);
+    if (taps % 2 == 0) taps += 1;
+    const int half = taps / 2;
+    std::vector<double> kernel((size_t)taps);
+    double sum = 0;
+    for (int i = 0; i < taps; ++i) {
+        const double x = i - half;
+        kernel[(size_t)i] = std::exp(-0.5 * (x / sigma) * (x / sigma));
+        sum += kernel[(size_t)i];
+    }
+    for (double &k : kernel) k /= sum;
+    const std::vector<Bin> src = h;
+    for (size_t i = 0; i < h.size(); ++i) {
+        double acc = 0;
+        for (size_t j = 0; j < kernel.size(); ++j) {
+            size_t at = 0;                                     // left of the first bin: the first bin
+            if (i + j >= (size_t)half) at = std::min(i + j - (size_t)half, h.size() - 1);
+            acc += src[at].count * kernel[j];
+        }
+        h[i].count = acc;
+    }
+}
+
+enum Trend { NONE = 0, UP = 1, DOWN = 2, FLAT = 3 };
+struct Peak { size_t idx; double height; int left = NONE, right = NONE; bool main = false; };
+
+// local maxima of at least 5 % of the tallest bin (at least 1); of two peaks less than two bins apart the taller stays (the left one on a tie)
+static std::vector<Peak> find_peaks(const std::vector<Bin> &h, double max_height) {
+    const double min_height = (double)std::max((size_t)(max_height * 0.05), (size_t)1);
+    std::vector<Peak> peaks;
+    const size_t n = h.size();
+    for (size_t i = 0; i < n; ++i) {
+        if (h[i].count < min_height) continue;
+        bool is_peak = false;
+        if (i == 0 && i != n - 1) is_peak = h[i].count > h[i + 1].count;
+        else if (i == n - 1 && i != 0) is_peak = h[i].count > h[i - 1].count;
+        else if (n > 1) is_peak = h[i].count > h[i - 1].count && h[i].count > h[i + 1].count;      // (a histogram of ONE bin has no peak, as the reference)
+        if (is_peak) peaks.push_back(Peak{i, h[i].count});
+    }
+    if (peaks.empty()) throw std::runtime_error("No peaks found in peaksVec");
+    for (size_t i = 0; i + 1 < peaks.size();) {
+        if (peaks[i + 1].idx - peaks[i].idx < 2) peaks.erase(peaks.begin() + (long)(peaks[i].height >= peaks[i + 1].height ? i + 1 : i));
+        else ++i;
+    }
+    return peaks;
+}
+
+// how the heights move from peak to peak; a MAIN peak is one the sequence climbs to and falls from (the ends need only their one side)
+static void mark_main_peaks(std::vector<Peak> &peaks) {
+    for (size_t i = 0; i + 1 < peaks.size(); ++i) {
+        const int t = peaks[i].height < peaks[i + 1].height ? UP : peaks[i].height > peaks[i + 1].height ? DOWN : FLAT;
+        peaks[i].right = t;
+        peaks[i + 1].left = t;
+    }
+    if (peaks.size() == 1) { peaks[0].main = true; return; }
+    for (size_t i = 0; i < peaks.size(); ++i) {
+        if (i == 0) peaks[i].main = peaks[i].right == DOWN;
+        else if (i + 1 == peaks.size()) peaks[i].main = peaks[i].left == UP;
+        else peaks[i].main = peaks[i].left == UP && peaks[i].right == DOWN;
+    }
+}
+
+// histogram index of THE main peak: the only one, or of the two tallest the one further right
+static size_t pick_main_peak(const std::vector<Peak> &peaks) {
+    std::vector<Peak> mains;
+    for (const Peak &p : peaks) if (p.main) mains.push_back(p);
+    if (mains.empty()) throw std::runtime_error("No main peaks found in peaksVec");
+    if (mains.size() == 1) return mains[0].idx;
+    std::sort(mains.begin(), mains.end(), [](const Peak &a, const Peak &b) { return a.height > b.height; });
+    return std::max(mains[0].idx, mains[1].idx);
+}
+
+struct Valley { bool found = false; size_t idx = 0; double height = 0, pct = 0; };
+// the lowest strict local minimum strictly inside (a, b); the first one on a tie
+static Valley lowest_valley(const std::vector<Bin> &h, size_t a, size_t b) {
+    Valley v;
+    if (a >= b || b > h.size()) return v;
+    for (size_t i = a + 1; i + 1 < b; ++i) {
+        if (!(h[i].count < h[i - 1].count && h[i].count < h[i + 1].count)) continue;
+        if (!v.found || h[i].count < v.height) v = Valley{true, i, h[i].count, h[i].pct};
+    }
+    return v;
+}
+
+// The peak whose right-hand valley separates the low-count mode from the main peak: walking left from the main peak, the first peak that sits in a
+// dip of the peak heights (fell to it, climbs after it); the first peak of all when there is none.  false when the main peak IS the first peak.
+static bool peak_before_main(const std::vector<Peak> &peaks, size_t main_idx, size_t &which) {
+    if (peaks[0].idx == main_idx) return false;
+    size_t at_main = peaks.size();
+    for (size_t i = 0; i < peaks.size(); ++i) if (peaks[i].idx == main_idx) { at_main = i; break; }
+    if (at_main == peaks.size()) throw std::runtime_error("Peak not found");
+    which = 0;
+    for (size_t j = at_main - 1; j != 0; --j) if (peaks[j].left == DOWN && peaks[j].right == UP) { which = j; break; }
+    return true;
+}
+
+// findBimodalValleyThreshold: the read count below which a site belongs to the low mode; 0 = no usable valley
+static int bimodal_valley_threshold(const std::vector<PurityDatum> &data) {
+    HistFacts facts;
+    std::vector<Bin> hist = read_count_histogram(data);
+    histogram_stats(hist, data.size(), facts);
+    std::vector<Bin> smooth = hist;
+    gaussian_smooth(smooth);
+    histogram_stats(smooth, data.size(), facts);
+    std::vector<Peak> peaks = find_peaks(smooth, facts.max_height);
+    mark_main_peaks(peaks);
+    const size_t main_idx = pick_main_peak(peaks);
+
+    const double kNothingFound = 2147483647.0;               // findLowestValley leaves height = INT_MAX when it finds nothing (as the reference)
+    double valley_height = 0, valley_pct = 0;                 // a default-constructed Valley: height 0
+    int threshold = 0;
+    auto take = [&](const Valley &v) {
+        if (v.found) { valley_pct = v.pct; threshold = (int)v.idx; valley_height = v.height; }
+        else valley_height = kNothingFound;
+    };
+    size_t before = 0;
+    if (peak_before_main(peaks, main_idx, before)) {
+        Valley v = lowest_valley(smooth, peaks[before].idx, peaks[before + 1].idx);
+        take(v);
+        if (valley_pct >= 0.3 || !v.found) {                  // cuts off too much (or nothing there): try the valley on the other side of that peak
+            valley_height = 0; valley_pct = 0; threshold = 0;
+            if (before != 0) take(lowest_valley(smooth, peaks[before - 1].idx, peaks[before].idx));
+        }
+    }
+    if (valley_height > facts.max_height * 0.7) { valley_pct = 0; threshold = 0; }   // not a valley: nearly as high as the tallest bin
+    if (valley_pct >= 0.3) threshold = 0;
+    return threshold;
+}
+
+struct BoxPlot { size_t n = 0; double q1 = 0, median = 0, q3 = 0, iqr = 0, low = 0, high = 0; size_t outliers = 0; };
+// quartiles by linear interpolation over the sorted ratios (sorts `data`), whiskers at 1.5 IQR (the lower one not below 0)
+static BoxPlot box_plot(std::vector<PurityDatum> &data) {
+    BoxPlot b;
+    b.n = data.size();
+    if (!b.n) throw std::runtime_error("Failed to statistic purity data: the data size is 0");
+    std::sort(data.begin(), data.end(), [](const PurityDatum &x, const PurityDatum &y) { return x.ratio < y.ratio; });
+    auto percentile = [&](double p) {
+        const double pos = p * (double)(b.n - 1);
+        const size_t i = (size_t)pos;
+        const double frac = pos - (double)i;
+        if (i + 1 >= b.n) return data[b.n - 1].ratio;
+        return data[i].ratio * (1.0 - frac) + data[i + 1].ratio * frac;
+    };
+    b.q1 = percentile(0.25);
+    b.median = percentile(0.5);
+    b.q3 = percentile(0.75);
+    b.iqr = b.q3 - b.q1;
+    b.low = std::max(0.0, b.q1 - 1.5 * b.iqr);
+    b.high = b.q3 + 1.5 * b.iqr;
+    for (const PurityDatum &x : data) if (x.ratio < b.low || x.ratio > b.high) ++b.outliers;
+    return b;
+}
+
+struct PurityReport { size_t initial_size = 0; const int *first_filters = nullptr; int threshold = 0; size_t below_valley = 0, outliers_removed = 0; BoxPlot box; double purity = 0; };
+static void write_report(const std::string &path, const PurityReport &r) {
+    std::ofstream o(path);
+    if (!o) return;
+    o << "#==================================\n# TUMOR PURITY ESTIMATION REPORT\n#==================================\n";
+    o << "#Initial data size: " << r.initial_size << std::endl;
+    o << "#==========filter parameters==========" << std::endl;
+    o << "#GERMLINE_HP_IMBALANCE_RATIO_MIN_THR: " << 0.0f << std::endl;
+    o << "#GERMLINE_HP_IMBALANCE_RATIO_IN_NOR_BAM_MIN_THR: " << 0.0f << std::endl;
+    o << "#GERMLINE_HP_IMBALANCE_RATIO_IN_NOR_BAM_MAX_THR: " << 0.7f << std::endl;
+    o << "#GERMLINE_HP_PERCENTAGE_IN_NOR_BAM_MAX_THR: " << 0.7f << std::endl;
+    o << "#GERMLINE_HP_READ_COUNT_IN_NOR_BAM_MIN_THR: " << 5 << std::endl;
+    o << "#GERMLINE_HP_READ_COUNT_IN_NOR_BAM_DYNAMIC_THR: " << r.threshold << std::endl;
+    o << "#==========Initial filter out data count==========" << std::endl;
+    o << "#imbalanceRatioInNorBam: " << r.first_filters[0] << std::endl;
+    o << "#imbalanceRatio: " << r.first_filters[1] << std::endl;
+    o << "#imbalanceRatioInNorBam_over_thr: " << r.first_filters[2] << std::endl;
+    o << "#readHpCountInNorBam: " << r.first_filters[3] << std::endl;
+    o << "#percentageOfGermlineHpInNorBam: " << r.first_filters[4] << std::endl;
+    o << "#==========Second filter out data count==========" << std::endl;
+    o << "#peakValley count: " << r.below_valley << std::endl;
+    o << "#==========Whisker filter out data count==========" << std::endl;
+    o << "#iteration times: " << 1 << std::endl;
+    o << "#remove outliers: " << r.outliers_removed << std::endl;
+    o << "#==========Statistical analysis===========" << std::endl;
+    o << "Data size: " << r.box.n << std::endl;
+    o << "Median: " << r.box.median << std::endl;
+    o << "Q1: " << r.box.q1 << std::endl;
+    o << "Q3: " << r.box.q3 << std::endl;
+    o << "IQR: " << r.box.iqr << std::endl;
+    o << "Whiskers: " << r.box.low << " to " << r.box.high << std::endl;
+    o << "Outliers: " << r.box.outliers << std::endl;
+    o << "#==========Estimation result===========" << std::endl;
+    o << "Tumor purity: " << r.purity << std::endl;
+}
+
+}  // namespace purity_detail
+
+// -> purity in (0, 1]; 0.0 (with the reference's messages on stderr) when the estimate fails.  first_filters[5]: how many sites each of the caller's
+// first filters dropped (only reported).  Writes <prefix>_purity.out on success.
+static double estimate_purity(std::vector<PurityDatum> data, size_t initial_size, const int first_filters[5], const std::string &prefix) {
+    using namespace purity_detail;
+    try {
+        if (data.empty()) throw std::runtime_error("Failed to build purity feature vector: empty vector");
+        PurityReport r; r.initial_size = initial_size; r.first_filters = first_filters;
+        try {
+            r.threshold = bimodal_valley_threshold(data);
+        } catch (const std::exception &e) {
+            std::cerr << "[ERROR] " << e.what() << "\n[ERROR] Failed to find peak valley threshold, set threshold to 0\n";
+            r.threshold = 0;
+        }
+        // bimodalValleyFilter
+        const size_t before_valley = data.size();
+        data.erase(std::remove_if(data.begin(), data.end(), [&](const PurityDatum &d) { return d.nor_count < r.threshold; }), data.end());
+        r.below_valley = before_valley - data.size();
+        // one round of the whisker filter, then the statistics of what is left
+        const BoxPlot first = box_plot(data);
+        const size_t before_whiskers = data.size();
+        data.erase(std::remove_if(data.begin(), data.end(), [&](const PurityDatum &d) { return d.ratio < first.low || d.ratio > first.high; }), data.end());
+        r.outliers_removed = before_whiskers - data.size();
+        r.box = box_plot(data);
+        const double m = r.box.median, q = r.box.iqr;
+        r.purity = -3.3454 * m + 14.7747 * q + 4.0344 * m * m + -13.7777 * m * q + -5.2434 * q * q + 0.3058;      // the reference's fitted model
+        if (r.purity > 1.0) r.purity = 1.0;
+        else if (r.purity < 0.0) throw std::runtime_error("The value of purity exceeds the model's estimation range: " + std::to_string(r.purity));
+        write_report(prefix + "_purity.out", r);
+        return r.purity;
+    } catch (const std::exception &e) {
+        std::cerr << "[ERROR] " << e.what() << "\n[ERROR] Failed to estimate tumor purity, set purity to 0.0\n";
+        return 0.0;
+    }
 }

@@ -32,6 +32,10 @@ static const char *kUsage =
     "   --workers-per-gpu=N  indexed input: contig groups in flight per GPU, each with its own context and stream (1)\n"
     "   --gpus=N         deal the contigs onto N GPUs (devices --gpu, --gpu+1, ... modulo the number present); needs the .bai index\n";
 
+// The commands end with _exit once their outputs are closed (the ROCm runtime's teardown and giving back tens of GB page by page cost 0.1 - 0.2 s; the
+// kernel does both for a process that simply ends); LPS_CLI_NO_FAST_EXIT=1 takes the full way out, e.g. under a profiler that reports from an exit handler.
+static bool full_teardown() { return getenv("LPS_CLI_NO_FAST_EXIT") != nullptr; }
+
 static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over; bool indels = false;
     std::string snp, ref, prefix = "result", sv_file, mod_file;
@@ -333,7 +337,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     for (lps_comm *cm : comms) if (cm) L.comm_destroy(cm);
     std::cerr << "\n";
     need_fasta();
-    L.destroy(ctx);
+    if (full_teardown()) L.destroy(ctx);                                // otherwise the context ends with the process (main)
     const double t_gpu = now();
     write_vcf(vcf_lines, prefix + ".vcf", res, vars, command, &iq);
     if (!sv_file.empty()) write_sv_vcf(sv_lines, prefix + "_SV.vcf", res, svt, command);          // PhasingProcess.cpp:191-203
@@ -774,7 +778,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     std::cerr << "\n";
     need_fasta(); w.finish();
     t_deflate += now() - t_mark;
-    L.destroy(ctx);
+    if (full_teardown()) L.destroy(ctx);
     unsigned long long total = 0; for (int k = 0; k < 8; ++k) total += st_count[k];
     fprintf(stderr, "total alignment %llu | tagged %llu (HP1 %llu, HP2 %llu) | untagged: low mapq %llu, unmapped %llu, secondary %llu, supplementary %llu, no variant %llu, beyond last variant %llu, judged %llu\n",
             total, hp_count[1] + hp_count[2], hp_count[1], hp_count[2], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6], hp_count[0]);
@@ -1433,9 +1437,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             o << line << std::endl;
         }
     }
-    if (nctx) L.destroy(nctx);
-    tgb.close_file(); ngb.close_file();
-    L.destroy(ctx);
+    if (full_teardown()) { if (nctx) L.destroy(nctx); tgb.close_file(); ngb.close_file(); L.destroy(ctx); }
     unsigned long long total = 0; for (int k = 0; k < 8; ++k) total += st_count[k];
     fprintf(stderr, "somatic variant count(Flag): %llu\n", n_somatic_flag);
     fprintf(stderr, "total alignment %llu | HP1 %llu HP2 %llu HP1-1 %llu HP2-1 %llu HP3 %llu | judged untagged %llu | low mapq %llu unmapped %llu secondary %llu supplementary %llu no variant %llu beyond last variant %llu\n",
