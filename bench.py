@@ -182,6 +182,39 @@ def cpu_baseline(g, spec, threads, port, gpu_result=None):
         return out
 
 
+def bam_record_digest(path):
+    """sha256 of the inflated record stream of a BAM (everything behind the header and the reference table)"""
+    import gzip, hashlib
+    h = hashlib.sha256()
+    with gzip.open(path, "rb") as f:
+        head = f.read(8); f.read(int.from_bytes(head[4:8], "little")); nref = int.from_bytes(f.read(4), "little")
+        for _ in range(nref):
+            ln = int.from_bytes(f.read(4), "little"); f.read(ln + 4)
+        for b in iter(lambda: f.read(1 << 24), b""):
+            h.update(b)
+    return h.hexdigest()
+
+
+def e2e_haplotag(d, ref_bin, cli, threads, dev):
+    import shutil
+    need = 2.5 * os.path.getsize(d + "/reads.bam")
+    if shutil.disk_usage(d).free < need:
+        return dict(skipped="less than %.0f GB free in %s" % (need / 1e9, d))
+    rcmd = [ref_bin, "haplotag", "-s", "out.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(threads), "-o", "tag_ref"]
+    t0 = time.time(); r = subprocess.run(rcmd, cwd=d, capture_output=True); t_ref = time.time() - t0
+    assert r.returncode == 0, r.stderr[-500:]
+    want = bam_record_digest(d + "/tag_ref.bam"); os.remove(d + "/tag_ref.bam")
+    gcmd = [cli, "haplotag", "-s", "out.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(threads), "-o", "tag_gpu", "--gpu", str(dev)]
+    gs = []
+    for _ in range(2):
+        t0 = time.time(); g = subprocess.run(gcmd, cwd=d, capture_output=True); gs.append(time.time() - t0)
+        assert g.returncode == 0, g.stderr[-500:]
+    same = want == bam_record_digest(d + "/tag_gpu.bam"); os.remove(d + "/tag_gpu.bam")
+    return dict(reference_wall_s=round(t_ref, 2), wall_s=round(min(gs), 3), runs_s=[round(x, 3) for x in gs], over_cpu=round(t_ref / min(gs), 2), identical_record_stream=same,
+                stage_line=g.stderr.decode(errors="replace").strip().splitlines()[-1][:700],
+                note="`haplotag -t %d` of the reference against `longphase_amd haplotag` on the same BAM + phased VCF: file -> tagged BAM" % threads)
+
+
 def whole_node_baseline(dev, P, threads, seed, n_contigs=16, contig_mb=10):
     """The reference's only parallelism is its chromosome loop (src/phase/PhasingProcess.cpp:106,113), so a single contig keeps ONE of its threads
     computing.  Here every thread gets a contig: `n_contigs` contigs of `contig_mb` Mb at 50x with the genome's SNP density in ONE BAM, phased by
@@ -261,6 +294,13 @@ def whole_node_baseline(dev, P, threads, seed, n_contigs=16, contig_mb=10):
                                note="`longphase_amd phase` end to end on the same BAM + VCF + FASTA (page cache warm, like the reference's best run): file -> phased VCF, GPU start-up included")
             except Exception as e:  # noqa: BLE001
                 log("whole-node sample: the command line run failed:", repr(e)[:300])
+            # ---- the secondary path end to end on the same files (profiles/e2e_whole_node.py only: the reference takes a minute): `haplotag` of the
+            #      8 GB BAM against the VCF the reference just phased, tagged BAM out; the record streams must be identical
+            if e_clock is not None and os.environ.get("LPS_E2E_HAPLOTAG"):
+                try:
+                    e_clock["haplotag"] = e2e_haplotag(d, ref_bin, cli, threads, dev)
+                except Exception as e:  # noqa: BLE001
+                    log("whole-node sample: the haplotag run failed:", repr(e)[:300])
     # ---- the GPU on the same decoded alignments, from pinned host memory (clock P), loads and phases of different contigs overlapping
     for c in contigs:
         c["R"] = abi.Reads.from_synth(c["host"])

@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "longphase-s_amd
 import bench  # noqa: E402
 from lps import abi  # noqa: E402
 
+os.environ.setdefault("LPS_E2E_HAPLOTAG", "1")        # also `haplotag` end to end on the same files (the reference takes about a minute)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 mb = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 out = bench.whole_node_baseline(0, abi.default_params(), min(16, os.cpu_count() or 8), 201, n_contigs=n, contig_mb=mb)
