@@ -799,7 +799,9 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
     const int n_nodes = (int)cnt->n_nodes;
     if (i >= n_nodes) return;
     // the node's list: room for every observation counted at the extraction (cap), of which n_valid are left after the filters; the others are holes
-    const uint32_t off = node_off[i]; const int cap = (int)node_cap[i], n_valid = (int)node_end[i];
+    // (wave-uniform by construction - one node per wave -, but only readfirstlane tells the compiler: the loops over the list then run on the scalar unit
+    // instead of under an exec mask, with the cells copied around every pass)
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)node_off[i]); const int cap = __builtin_amdgcn_readfirstlane((int)node_cap[i]), n_valid = __builtin_amdgcn_readfirstlane((int)node_end[i]);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     unsigned long long pairs = 0;
     const uint32_t m_mask = (uint32_t)((1ull << m_bits) - 1ull);
@@ -841,19 +843,32 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
             const int dst = ((l < nb && key != HOLE) ? rank : max(l, nbv)) << 2;   // holes and lanes past the list stay out of the ranks 0..nbv-1 of the valid entries
             my_val = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)v0);
             my_end = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)x0);
-            nb = nbv;
+            nb = __builtin_amdgcn_readfirstlane(nbv);          // (a popcount of a ballot: uniform, but only this tells the compiler - the loop below then runs on the scalar unit)
         } else if (l < nb) {
             const key_t key = skeys[e0 + l];
             const uint32_t m = (uint32_t)(key >> a_bits) & m_mask;
             my_val = svals[e0 + l]; my_end = mrow_off[m] + (uint32_t)mrow_cnt[m];
         }
         // every lane's own observation (flag of the source side) and its share of the pair count, loaded side by side
-        const int my_sf = l < nb ? (int)(g_pack[my_val] & 3u) : 0;
+        int my_sf = l < nb ? (int)(g_pack[my_val] & 3u) : 0;
         const int my_lim = l < nb ? (int)min((uint32_t)A, my_end - my_val - 1u) : 0;    // observations of the read inside the window (A <= 63)
         pairs += (unsigned long long)my_lim;
         // one lane read per step hands out the window length (bits 0-5), the source flag (8-9) and whether the read's row is a merged row of several
         // alignments (bit 10; tail arena) - the only rows that can hold a node twice inside the window
-        const int my_meta = my_lim | (my_sf << 8) | ((l < nb && my_val >= tail_lo) ? 1 << 10 : 0);
+        int my_meta = my_lim | (my_sf << 8) | ((l < nb && my_val >= tail_lo) ? 1 << 10 : 0);
+        // The reads of the block are taken in TWO runs: first those whose source observation shows REF, then those that show ALT, each run in rank
+        // order.  A cell only ever sees the reads of one source allele (rr, ra: REF; ar, aa: ALT), so every cell still receives its updates in the
+        // reference's order - and inside a run the pair of cells is FIXED: no branch on the source allele per read, and the compiler keeps the
+        // cells in place (with the branch inside one loop it copied all four cells twice per read: 9 moves beside 19 useful instructions).
+        const unsigned long long alt_mask = __ballot(l < nb && (my_sf & 1));
+        const int n_ref = nb - __popcll(alt_mask);
+        {
+            const unsigned long long below = (1ull << l) - 1ull, valid = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+            const int pos = l >= nb ? l : ((my_sf & 1) ? n_ref + __popcll(alt_mask & below) : __popcll(~alt_mask & valid & below));
+            my_val = (uint32_t)__builtin_amdgcn_ds_permute(pos << 2, (int)my_val);
+            my_meta = __builtin_amdgcn_ds_permute(pos << 2, my_meta);
+        }
+        const unsigned long long slow_mask = __ballot((my_meta >> 10) & 1);
         // The t-th read's following observations are requested one read ahead, so that the loads of read t+1 are in flight while read t is applied
         // (two ahead were measured slower, 1.05 vs 1.02 ms: the rows come from L2 and the other waves of the SIMD cover the rest).  The request is a BUFFER
         // load whose descriptor is the read's window itself - base = the word after the source observation, size = the observations inside the
@@ -869,54 +884,68 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
             const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc((void *)(g_pack + (size_t)v + 1), 0, (meta & 63) * 4, 0x00020000);
             w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(win, 4 * l, 0, 0);
         };
-        uint32_t w0; int m0;
-        request(0, w0, m0);
-        for (int t = 0; t < nb; ++t) {
-            uint32_t w1; int m1;
-            request(t + 1, w1, m1);
-            const int sf = (m0 >> 8) & 3;
-            if (!(m0 & (1 << 10))) {
-                // No node twice in this row (all but the merged rows, ~2 % of the reads): the packed word itself travels to the lane that owns its
-                // target and the receiver, for whom the source flag is wave-uniform, picks between TWO cells on a scalar branch.  The permute address is
-                // 4*(d-1) + flag as unsigned: an empty slot (0), a node before i+1 or beyond the window all land on lane 63 or on a lane >= A, whose
-                // cells are never stored (ds_permute takes lane = address / 4 mod 64: the flag bits below do not matter).  ~21 vector instructions
-                // per read instead of ~50 (this kernel runs at its vector-issue floor)
-                const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute((int)min(w0 - first4, 255u), (int)w0);
-                if (recv) {
-                    const uint32_t hi_mask = (uint32_t)sf & 2u;         // wave-uniform
-                    if (sf & 1) cell_upd(a2, a3, recv, hi_mask, edge_weight); else cell_upd(a0, a1, recv, hi_mask, edge_weight);
-                }
-            } else {
-                const int n2 = (int)(w0 >> 2), f2 = (int)(w0 & 3u);
-                const int d = n2 - i;
-                const bool ok = w0 != 0u && d >= 1 && d <= A;
-                const int cell = ((sf & 1) << 1) | (f2 & 1);
-                const int hi = (sf & f2 & 2) << 2;                          // both observations of high quality -> bit 3
-                const int payload = 1 | (cell << 1) | hi;
-                // the same node twice inside the window (overlapping alignments of one read, neighbours in the position-sorted row): the second
-                // occurrence is applied in a second round, after the first - window order, as the reference's pair loop goes
-                int round_of = 0, rounds = 1;
-                for (int s = 1; s < 64; ++s) {
-                    const int dprev = __shfl_up(d, s); const bool okprev = __shfl_up((int)ok, s) != 0;
-                    const bool same = ok && l >= s && okprev && dprev == d && round_of == s - 1;
-                    if (!__ballot(same)) break;
-                    if (same) round_of = s;
-                    rounds = s + 1;
-                }
-                for (int rd = 0; rd < rounds; ++rd) {
-                    // lanes without a contribution in this round push to lane 63, which owns no target (A <= 63)
-                    const bool mine = ok && round_of == rd;
-                    const int recv = __builtin_amdgcn_ds_permute((mine ? (d - 1) : 63) << 2, mine ? payload : 0);
-                    if (recv & 1) {
-                        const int c = (recv >> 1) & 3; const bool h = (recv >> 3) & 1;
-                        const float x = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
-                        const float nx = edge_upd(x, h, edge_weight);
-                        a0 = c == 0 ? nx : a0; a1 = c == 1 ? nx : a1; a2 = c == 2 ? nx : a2; a3 = c == 3 ? nx : a3;
-                    }
+        // No node twice in the row (all but the merged rows, ~2 % of the reads): the packed word itself travels to the lane that owns its target
+        // and the receiver picks between the TWO cells of the run.  The permute address is 4*(d-1) + flag as unsigned: an empty slot (0), a node
+        // before i+1 or beyond the window all land on lane 63 or on a lane >= A, whose cells are never stored (ds_permute takes
+        // lane = address / 4 mod 64: the flag bits below do not matter)
+        auto plain_read = [&](uint32_t w, int meta, float &x0, float &x1) {
+            const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute((int)min(w - first4, 255u), (int)w);
+            if (recv) cell_upd(x0, x1, recv, (uint32_t)(meta >> 8) & 2u, edge_weight);       // hi mask: wave-uniform
+        };
+        // the same node twice inside the window (overlapping alignments of one read, neighbours in the position-sorted row): the second
+        // occurrence is applied in a second round, after the first - window order, as the reference's pair loop goes
+        auto merged_read = [&](uint32_t w, int meta) {
+            const int sf = (meta >> 8) & 3;
+            const int n2 = (int)(w >> 2), f2 = (int)(w & 3u);
+            const int d = n2 - i;
+            const bool ok = w != 0u && d >= 1 && d <= A;
+            const int cell = ((sf & 1) << 1) | (f2 & 1);
+            const int hi = (sf & f2 & 2) << 2;                          // both observations of high quality -> bit 3
+            const int payload = 1 | (cell << 1) | hi;
+            int round_of = 0, rounds = 1;
+            for (int s = 1; s < 64; ++s) {
+                const int dprev = __shfl_up(d, s); const bool okprev = __shfl_up((int)ok, s) != 0;
+                const bool same = ok && l >= s && okprev && dprev == d && round_of == s - 1;
+                if (!__ballot(same)) break;
+                if (same) round_of = s;
+                rounds = s + 1;
+            }
+            for (int rd = 0; rd < rounds; ++rd) {
+                // lanes without a contribution in this round push to lane 63, which owns no target (A <= 63)
+                const bool mine = ok && round_of == rd;
+                const int recv = __builtin_amdgcn_ds_permute((mine ? (d - 1) : 63) << 2, mine ? payload : 0);
+                if (recv & 1) {
+                    const int c = (recv >> 1) & 3; const bool h = (recv >> 3) & 1;
+                    const float x = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
+                    const float nx = edge_upd(x, h, edge_weight);
+                    a0 = c == 0 ? nx : a0; a1 = c == 1 ? nx : a1; a2 = c == 2 ? nx : a2; a3 = c == 3 ? nx : a3;
                 }
             }
-            w0 = w1; m0 = m1;
-        }
+        };
+        uint32_t w0; int m0;
+        request(0, w0, m0);
+        int t = 0;
+        // one run: [t, run_end) in stretches of plain reads (an inner loop that holds nothing but them) with the merged rows between the stretches
+        auto run = [&](const int run_end, float &x0, float &x1) {
+            while (t < run_end) {
+                const unsigned long long rest = slow_mask >> t;
+                const int stop = min(run_end, rest ? t + (int)__builtin_ctzll(rest) : 64);
+                for (; t < stop; ++t) {
+                    uint32_t w1; int m1;
+                    request(t + 1, w1, m1);
+                    plain_read(w0, m0, x0, x1);
+                    w0 = w1; m0 = m1;
+                }
+                if (t < run_end) {
+                    uint32_t w1; int m1;
+                    request(t + 1, w1, m1);
+                    merged_read(w0, m0);
+                    w0 = w1; m0 = m1; ++t;
+                }
+            }
+        };
+        run(n_ref, a0, a1);
+        run(nb, a2, a3);
     }
     pairs = wave_sum(pairs);
     if (l == 0) node_pairs[i] = (uint32_t)pairs;   // summed later (no single-address atomics in the hot kernel)
