@@ -782,7 +782,8 @@ __device__ __forceinline__ void cell_upd(float &x0, float &x1, uint32_t word, ui
 // wave per source node i.  Lane k (< A) owns the four cells (rr,ra,ar,aa) towards node i+1+k in registers.
 // For each read observing node i (in name-rank order) lane t loads the read's t-th following observation;
 // its node distance d selects the owning lane, the (allele pair, quality class) travels there by ds_permute.
-template <bool KEY64>
+// SOFF: every slot of g_pack is below 2^30 words, so a window's byte offset fits the scalar offset of the buffer load
+template <bool KEY64, bool SOFF>
 __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uint32_t *node_off, const uint32_t *node_cap, const uint32_t *node_end,
                                                const void *ukeys_v, const uint32_t *uvals,
                                                void *skeys_v, uint32_t *svals,
@@ -853,9 +854,10 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
         int my_sf = l < nb ? (int)(g_pack[my_val] & 3u) : 0;
         const int my_lim = l < nb ? (int)min((uint32_t)A, my_end - my_val - 1u) : 0;    // observations of the read inside the window (A <= 63)
         pairs += (unsigned long long)my_lim;
-        // one lane read per step hands out the window length (bits 0-5), the source flag (8-9) and whether the read's row is a merged row of several
-        // alignments (bit 10; tail arena) - the only rows that can hold a node twice inside the window
-        int my_meta = my_lim | (my_sf << 8) | ((l < nb && my_val >= tail_lo) ? 1 << 10 : 0);
+        // one lane read per step hands out the source flag (bits 0-1: bit 1 = the quality mask as the receiver needs it), the window length in BYTES
+        // (bits 2-7: the descriptor's size word, no shift) and whether the read's row is a merged row of several alignments (bit 10; tail arena) -
+        // the only rows that can hold a node twice inside the window
+        int my_meta = my_sf | (my_lim << 2) | ((l < nb && my_val >= tail_lo) ? 1 << 10 : 0);
         // The reads of the block are taken in TWO runs: first those whose source observation shows REF, then those that show ALT, each run in rank
         // order.  A cell only ever sees the reads of one source allele (rr, ra: REF; ar, aa: ALT), so every cell still receives its updates in the
         // reference's order - and inside a run the pair of cells is FIXED: no branch on the source allele per read, and the compiler keeps the
@@ -881,8 +883,15 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
             const int tt = min(t, 63);
             const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)my_val, tt);
             meta = __builtin_amdgcn_readlane(my_meta, tt);
-            const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc((void *)(g_pack + (size_t)v + 1), 0, (meta & 63) * 4, 0x00020000);
-            w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(win, 4 * l, 0, 0);
+            if (SOFF) {     // the descriptor's base stays put and the window's place goes into the scalar offset; a raw buffer is out of range from
+                            // num_records - scalar offset on, so the size word is the window's END: one addition instead of a 64-bit base
+                const uint32_t so = v << 2;
+                const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc((void *)(g_pack + 1), 0, (int)(so + ((uint32_t)meta & 0xfcu)), 0x00020000);
+                w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(win, 4 * l, (int)so, 0);
+            } else {
+                const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc((void *)(g_pack + (size_t)v + 1), 0, meta & 0xfc, 0x00020000);
+                w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(win, 4 * l, 0, 0);
+            }
         };
         // No node twice in the row (all but the merged rows, ~2 % of the reads): the packed word itself travels to the lane that owns its target
         // and the receiver picks between the TWO cells of the run.  The permute address is 4*(d-1) + flag as unsigned: an empty slot (0), a node
@@ -890,12 +899,12 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
         // lane = address / 4 mod 64: the flag bits below do not matter)
         auto plain_read = [&](uint32_t w, int meta, float &x0, float &x1) {
             const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute((int)min(w - first4, 255u), (int)w);
-            if (recv) cell_upd(x0, x1, recv, (uint32_t)(meta >> 8) & 2u, edge_weight);       // hi mask: wave-uniform
+            if (recv) cell_upd(x0, x1, recv, (uint32_t)meta & 2u, edge_weight);              // hi mask: wave-uniform
         };
         // the same node twice inside the window (overlapping alignments of one read, neighbours in the position-sorted row): the second
         // occurrence is applied in a second round, after the first - window order, as the reference's pair loop goes
         auto merged_read = [&](uint32_t w, int meta) {
-            const int sf = (meta >> 8) & 3;
+            const int sf = meta & 3;
             const int n2 = (int)(w >> 2), f2 = (int)(w & 3u);
             const int d = n2 - i;
             const bool ok = w != 0u && d >= 1 && d <= A;
@@ -1464,8 +1473,11 @@ void launch_graph_rows(const GraphView &G, int base_quality, int a_bits, bool ke
 
 void launch_edges(const GraphView &G, int m_bits, int a_bits, bool key64, double edge_weight, double edge_threshold, hipStream_t s) {
     const dim3 grid((((G.n_var + 3) / 4 + 7) / 8) * 8);
-    if (key64) hipLaunchKernelGGL(k_edges<true>, grid, dim3(256), 0, s, G.cnt, G.node_off, G.node_cap, G.node_end, G.ukeys, G.uvals, G.skeys, G.svals, G.mrow_off, G.mrow_cnt, m_bits, a_bits, G.g_pack, (uint32_t)G.tail_lo, G.A, edge_weight, edge_threshold, G.nodes, G.vtype_key, G.edge, G.erec, G.node_pairs);
-    else hipLaunchKernelGGL(k_edges<false>, grid, dim3(256), 0, s, G.cnt, G.node_off, G.node_cap, G.node_end, G.ukeys, G.uvals, G.skeys, G.svals, G.mrow_off, G.mrow_cnt, m_bits, a_bits, G.g_pack, (uint32_t)G.tail_lo, G.A, edge_weight, edge_threshold, G.nodes, G.vtype_key, G.edge, G.erec, G.node_pairs);
+    const bool soff = G.tail_lo + G.tail_size < (1ull << 30);
+#define LPS_EDGES(K, S) hipLaunchKernelGGL((k_edges<K, S>), grid, dim3(256), 0, s, G.cnt, G.node_off, G.node_cap, G.node_end, G.ukeys, G.uvals, G.skeys, G.svals, G.mrow_off, G.mrow_cnt, m_bits, a_bits, G.g_pack, (uint32_t)G.tail_lo, G.A, edge_weight, edge_threshold, G.nodes, G.vtype_key, G.edge, G.erec, G.node_pairs)
+    if (key64) { if (soff) LPS_EDGES(true, true); else LPS_EDGES(true, false); }
+    else { if (soff) LPS_EDGES(false, true); else LPS_EDGES(false, false); }
+#undef LPS_EDGES
 }
 
 size_t scan_state_bytes(int n_var) { return (size_t)((n_var + SCAN_SEG - 1) / SCAN_SEG + 1) * 2 * sizeof(ScanState); }
