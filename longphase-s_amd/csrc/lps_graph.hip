@@ -899,7 +899,10 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
         // lane = address / 4 mod 64: the flag bits below do not matter)
         auto plain_read = [&](uint32_t w, int meta, float &x0, float &x1) {
             const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute((int)min(w - first4, 255u), (int)w);
-            if (recv) cell_upd(x0, x1, recv, (uint32_t)meta & 2u, edge_weight);              // hi mask: wave-uniform
+            // no branch around the update (some lane always receives): a lane that received nothing keeps its cells through the select masks
+            const bool alt = recv & 1u, got = recv != 0u;
+            const float nx = edge_upd(alt ? x1 : x0, (recv & (uint32_t)meta & 2u) != 0u, edge_weight);    // quality mask: wave-uniform
+            x0 = (got && !alt) ? nx : x0; x1 = alt ? nx : x1;
         };
         // the same node twice inside the window (overlapping alignments of one read, neighbours in the position-sorted row): the second
         // occurrence is applied in a second round, after the first - window order, as the reference's pair loop goes
