@@ -57,6 +57,7 @@ struct lps_ctx {
     DevBuf<uint8_t> zfile, file, zscratch; DevBuf<InflateBlock> zblk; uint64_t file_bytes = 0; float bgzf_h2d_ms = 0, bgzf_inflate_ms = 0;
     DevBuf<unsigned long long> tg_len, tg_off; DevBuf<uint2> tg_spans; DevBuf<uint8_t> tg_stream, tg_status, tg_hp; DevBuf<int32_t> tg_ps, tg_pq; int64_t cur_first = -1, cur_count = 0;
     uint8_t *stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; size_t stage_bytes = 0;   // pinned staging ring for large pageable uploads
+    unsigned long long *up_mark = nullptr;   // upload watermark of lps_bgzf_load: a page-locked host word the inflate kernel polls
     DevBuf<uint8_t> dz_slots, dz_packed, dz_src; DevBuf<uint32_t> dz_bytes; DevBuf<unsigned long long> dz_tmp; DevBuf<uint64_t> dz_off; uint64_t dz_total = 0; float dz_ms = 0;
     DevBuf<uint64_t> rcand; uint64_t n_rec_all = 0; DevBuf<int32_t> r_tid_all; DevBuf<uint32_t> r_lname, r_nameoff, wg_cnt, wg_off, scan_nout; DevBuf<uint8_t> names_d; bool names_ready = false;
     // observations
@@ -107,20 +108,26 @@ static int fail(lps_ctx *c, const std::string &m, int code = -1) { if (c) c->err
 
 // Large upload from pageable memory (an mmap of the BAM file): the runtime's own path stages through ONE host thread's memcpy; here four threads fill a
 // pinned 2 x 64 MiB ring while the DMA engine drains the other half.
-static void h2d_staged(lps_ctx *c, uint8_t *dst, const uint8_t *src, size_t n) {
+// `mark` (optional): a word in PAGE-LOCKED HOST memory that this (host) thread raises to the number of bytes known to be in place - after the event of
+// a piece has been waited for, i.e. two pieces late, and n at the end.  It is what a kernel launched beside the upload polls (k_bgzf_inflate): host
+// memory, because a word in device memory written by the copy engine would sit stale in the polling XCD's L2 until the next kernel boundary.
+static void h2d_staged(lps_ctx *c, uint8_t *dst, const uint8_t *src, size_t n, hipStream_t st = nullptr, unsigned long long *mark = nullptr) {
     const size_t CH = 64u << 20;
-    if (n < (16u << 20)) { HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->stream)); return; }
+    if (!st) st = c->stream;
+    auto raise = [&](size_t bytes) { if (mark) __atomic_store_n(mark, (unsigned long long)bytes, __ATOMIC_RELEASE); };
+    if (n < (16u << 20)) { HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st)); if (mark) { HIP_TRY(hipStreamSynchronize(st)); raise(n); } return; }
     if (!c->stage[0]) { for (int k = 0; k < 2; ++k) { HIP_TRY(hipHostMalloc((void **)&c->stage[k], CH, hipHostMallocDefault)); HIP_TRY(hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming)); } c->stage_bytes = CH; }
-    int k = 0; bool used[2] = {false, false};
+    int k = 0; bool used[2] = {false, false}; size_t end_of[2] = {0, 0};
     for (size_t off = 0; off < n; off += CH, k ^= 1) {
         const size_t len = std::min(CH, n - off);
-        if (used[k]) HIP_TRY(hipEventSynchronize(c->stage_ev[k]));
+        if (used[k]) { HIP_TRY(hipEventSynchronize(c->stage_ev[k])); raise(end_of[k]); }       // (pieces complete in order: everything before end_of[k] is in place)
         const int nt = 4; std::thread th[nt]; const size_t part = (len + nt - 1) / nt;
         for (int t = 0; t < nt; ++t) th[t] = std::thread([=] { const size_t a = std::min(len, part * t), b = std::min(len, a + part); if (b > a) memcpy(c->stage[k] + a, src + off + a, b - a); });
         for (int t = 0; t < nt; ++t) th[t].join();
-        HIP_TRY(hipMemcpyAsync(dst + off, c->stage[k], len, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipEventRecord(c->stage_ev[k], c->stream)); used[k] = true;
+        HIP_TRY(hipMemcpyAsync(dst + off, c->stage[k], len, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(c->stage_ev[k], st)); used[k] = true; end_of[k] = off + len;
     }
+    if (mark) { for (int q = 0; q < 2; ++q) if (used[q]) HIP_TRY(hipEventSynchronize(c->stage_ev[q])); raise(n); }
 }
 
 template <class T>
@@ -210,6 +217,7 @@ void lps_destroy(lps_ctx *c) {
     if (c->h_cnv_pin) (void)hipHostFree(c->h_cnv_pin);
     if (c->h_ncnv) (void)hipHostFree(c->h_ncnv);
     if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->up_mark) (void)hipHostFree(c->up_mark);
     for (int k = 0; k < 2; ++k) { if (c->stage[k]) (void)hipHostFree(c->stage[k]); if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]); }
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->ev_sorted) (void)hipEventDestroy(c->ev_sorted);
@@ -625,59 +633,123 @@ int lps_push_bam_resident(lps_ctx *c, int64_t first, int64_t count, const uint32
     return 0;
 }
 
+// One BGZF block header at p (18 bytes + extra subfields; RFC 1952 member with the BC subfield, SAM spec 4.1) -> BSIZE, 0 when p holds none
+static inline uint64_t bgzf_block_at(const uint8_t *z, uint64_t p, uint64_t n, unsigned &xlen) {
+    if (p + 18 > n || z[p] != 31 || z[p + 1] != 139 || z[p + 2] != 8 || !(z[p + 3] & 4)) return 0;
+    xlen = z[p + 10] | (z[p + 11] << 8);
+    uint64_t q = p + 12, bsize = 0;
+    while (q + 4 <= p + 12 + xlen && q + 4 <= n) {
+        const unsigned slen = z[q + 2] | (z[q + 3] << 8);
+        if (z[q] == 'B' && z[q + 1] == 'C' && slen == 2 && q + 6 <= n) bsize = (uint64_t)(z[q + 4] | (z[q + 5] << 8)) + 1;
+        q += 4 + slen;
+    }
+    if (!bsize || bsize < 12ull + xlen + 8 || p + bsize > n) return 0;
+    return bsize;
+}
+// The block table of [from, to): false when a header is bad, a block is larger than 64 KiB or the chain does not land on `to` exactly.  out_off is
+// relative to the piece's first block (utot = the piece's inflated size).
+static bool bgzf_walk_piece(const uint8_t *z, uint64_t n, uint64_t from, uint64_t to, std::vector<InflateBlock> &blks, uint64_t &utot) {
+    uint64_t p = from; utot = 0;
+    while (p < to) {
+        unsigned xlen = 0; const uint64_t bsize = bgzf_block_at(z, p, n, xlen);
+        if (!bsize) return false;
+        const uint64_t isize = (uint64_t)z[p + bsize - 4] | ((uint64_t)z[p + bsize - 3] << 8) | ((uint64_t)z[p + bsize - 2] << 16) | ((uint64_t)z[p + bsize - 1] << 24);
+        if (isize > 65536) return false;
+        blks.push_back(InflateBlock{p + 12 + xlen, utot, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize});
+        utot += isize; p += bsize;
+    }
+    return p == to;
+}
+// The header walk touches one page in eight of the file (0.2 s for 8 GB on one thread: page-table work, not bytes): T threads take a piece each.  A
+// piece starts at the first position behind k * n / T where FOUR block headers follow one another; the piece before it must end exactly there,
+// otherwise (and whenever anything else looks wrong) the caller walks the file serially, which also finds the words for the error.
+static bool bgzf_walk_parallel(const uint8_t *z, uint64_t n, std::vector<InflateBlock> &blks, uint64_t &utot) {
+    const int T = 8;
+    if (n < (64ull << 20)) return false;
+    std::vector<uint64_t> seed((size_t)T + 1, 0); seed[(size_t)T] = n;
+    for (int k = 1; k < T; ++k) {
+        uint64_t found = 0;
+        for (uint64_t p = n * (uint64_t)k / T, stop = std::min<uint64_t>(n, p + (1ull << 20)); p < stop && !found; ++p) {
+            if (z[p] != 31 || z[p + 1] != 139) continue;
+            uint64_t q = p; int chain = 0;
+            for (; chain < 4 && q < n; ++chain) { unsigned xl; const uint64_t b = bgzf_block_at(z, q, n, xl); if (!b) break; q += b; }
+            if (chain == 4 || (chain > 0 && q == n)) found = p;
+        }
+        if (!found) return false;
+        seed[(size_t)k] = found;
+    }
+    std::vector<std::vector<InflateBlock>> part((size_t)T); std::vector<uint64_t> ut((size_t)T, 0); std::vector<char> ok((size_t)T, 0); std::vector<std::thread> th;
+    for (int k = 0; k < T; ++k) th.emplace_back([&, k] { part[(size_t)k].reserve((size_t)((seed[(size_t)k + 1] - seed[(size_t)k]) / 16384 + 16)); ok[(size_t)k] = bgzf_walk_piece(z, n, seed[(size_t)k], seed[(size_t)k + 1], part[(size_t)k], ut[(size_t)k]); });
+    for (auto &t : th) t.join();
+    size_t total = 0;
+    for (int k = 0; k < T; ++k) { if (!ok[(size_t)k]) return false; total += part[(size_t)k].size(); }
+    blks.clear(); blks.reserve(total); utot = 0;
+    for (int k = 0; k < T; ++k) { for (InflateBlock b : part[(size_t)k]) { b.out_off += utot; blks.push_back(b); } utot += ut[(size_t)k]; }
+    return true;
+}
+
 int lps_bgzf_load(lps_ctx *c, const uint8_t *bgzf, int64_t n_bytes, int64_t *inflated_bytes) {
     if (!c || !bgzf || n_bytes < 28) return fail(c, "lps_bgzf_load: not a BGZF file");
     try {
         HIP_TRY(hipSetDevice(c->device));
-        // host: walk the block headers (18 bytes + BSIZE each; RFC 1952 member with the BC extra subfield, SAM spec 4.1)
         auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double th0 = tnow();
-        // the upload needs nothing but the byte count, so it starts now and the header walk below runs beside it
-        hipStream_t s = c->stream; hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+        // The upload needs nothing but the byte count: it starts now, on the copy stream, and raises a device word behind every 64-MiB piece.  The
+        // block headers are walked beside it (pieces on 8 threads); as soon as the table is known the inflate kernel is launched on the main stream,
+        // where a wavefront waits for the bytes of its own 32 members only - upload and inflate overlap (LPS_BGZF_SERIAL=1: one after the other).
+        static const bool serial = getenv("LPS_BGZF_SERIAL") != nullptr;
+        hipStream_t s = c->stream, cs = serial ? c->stream : c->copy_stream; hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
         struct Events { hipEvent_t &a, &b, &c; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); if (c) (void)hipEventDestroy(c); } } ev_guard{e0, e1, e2};   // every early return below releases them
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
         c->zfile.reserve((uint64_t)n_bytes + 64, s);
-        HIP_TRY(hipEventRecord(e0, s));
-        std::string up_err; std::thread uploader([&] { try { (void)hipSetDevice(c->device); h2d_staged(c, c->zfile.p, bgzf, (size_t)n_bytes); HIP_TRY(hipMemsetAsync(c->zfile.p + n_bytes, 0, 64, s)); } catch (std::string &e) { up_err = e; } });
+        if (!c->up_mark) HIP_TRY(hipHostMalloc((void **)&c->up_mark, 64, hipHostMallocDefault));
+        __atomic_store_n(c->up_mark, 0ull, __ATOMIC_RELEASE);
+        HIP_TRY(hipStreamSynchronize(s));                                   // (the buffers exist before another stream writes them)
+        HIP_TRY(hipMemsetAsync(c->zfile.p + n_bytes, 0, 64, cs));
+        HIP_TRY(hipEventRecord(e0, cs));
+        std::string up_err;
+        std::thread uploader([&] { try { (void)hipSetDevice(c->device); h2d_staged(c, c->zfile.p, bgzf, (size_t)n_bytes, cs, serial ? nullptr : c->up_mark); HIP_TRY(hipEventRecord(e1, cs)); }
+                                   catch (std::string &e) { up_err = e; __atomic_store_n(c->up_mark, ~0ull, __ATOMIC_RELEASE); } });   // (a failed upload must not leave the kernel waiting)
         struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_up{uploader};
-        std::vector<InflateBlock> blks; uint64_t p = 0, utot = 0; const uint64_t n = (uint64_t)n_bytes;
-        while (p + 18 <= n) {
-            if (bgzf[p] != 31 || bgzf[p + 1] != 139 || bgzf[p + 2] != 8 || !(bgzf[p + 3] & 4)) return fail(c, "lps_bgzf_load: not a BGZF block header");
-            const unsigned xlen = bgzf[p + 10] | (bgzf[p + 11] << 8);
-            uint64_t q = p + 12, bsize = 0;
-            while (q + 4 <= p + 12 + xlen && q + 4 <= n) {
-                const unsigned slen = bgzf[q + 2] | (bgzf[q + 3] << 8);
-                if (bgzf[q] == 'B' && bgzf[q + 1] == 'C' && slen == 2 && q + 6 <= n) bsize = (uint64_t)(bgzf[q + 4] | (bgzf[q + 5] << 8)) + 1;
-                q += 4 + slen;
+        std::vector<InflateBlock> blks; uint64_t utot = 0; const uint64_t n = (uint64_t)n_bytes;
+        if (serial || !bgzf_walk_parallel(bgzf, n, blks, utot)) {
+            blks.clear(); utot = 0; uint64_t p = 0;
+            while (p + 18 <= n) {
+                unsigned xlen = 0;
+                if (bgzf[p] != 31 || bgzf[p + 1] != 139 || bgzf[p + 2] != 8 || !(bgzf[p + 3] & 4)) return fail(c, "lps_bgzf_load: not a BGZF block header");
+                const uint64_t bsize = bgzf_block_at(bgzf, p, n, xlen);
+                if (!bsize) return fail(c, "lps_bgzf_load: truncated BGZF block");
+                const uint64_t isize = (uint64_t)bgzf[p + bsize - 4] | ((uint64_t)bgzf[p + bsize - 3] << 8) | ((uint64_t)bgzf[p + bsize - 2] << 16) | ((uint64_t)bgzf[p + bsize - 1] << 24);
+                if (isize > 65536) return fail(c, "lps_bgzf_load: BGZF block larger than 64 KiB");
+                blks.push_back(InflateBlock{p + 12 + xlen, utot, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize});
+                utot += isize; p += bsize;
             }
-            if (!bsize || bsize < 12ull + xlen + 8 || p + bsize > n) return fail(c, "lps_bgzf_load: truncated BGZF block");
-            const uint64_t isize = (uint64_t)bgzf[p + bsize - 4] | ((uint64_t)bgzf[p + bsize - 3] << 8) | ((uint64_t)bgzf[p + bsize - 2] << 16) | ((uint64_t)bgzf[p + bsize - 1] << 24);
-            if (isize > 65536) return fail(c, "lps_bgzf_load: BGZF block larger than 64 KiB");
-            blks.push_back(InflateBlock{p + 12 + xlen, utot, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize});
-            utot += isize; p += bsize;
+            if (p != n || blks.empty()) return fail(c, "lps_bgzf_load: trailing bytes after the last BGZF block");
         }
-        if (p != n || blks.empty()) return fail(c, "lps_bgzf_load: trailing bytes after the last BGZF block");
         if (blks.size() > 0x7fffffffull) return fail(c, "lps_bgzf_load: too many blocks");
         const double th1 = tnow();
-        uploader.join();
-        if (!up_err.empty()) return fail(c, up_err);
+        if (serial) { uploader.join(); if (!up_err.empty()) return fail(c, up_err); }
         c->file.reserve(utot + 64, s); c->zblk.reserve(blks.size(), s); c->bam_err.reserve(1);
+        c->zscratch.reserve(bgzf_inflate_scratch_bytes((int)blks.size()), s);
         const double th2 = tnow();
         HIP_TRY(hipMemcpyAsync(c->zblk.p, blks.data(), blks.size() * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s));
-        HIP_TRY(hipEventRecord(e1, s));
-        c->zscratch.reserve(bgzf_inflate_scratch_bytes((int)blks.size()), s);
-        launch_bgzf_inflate(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, c->zscratch.p, s);
+        HIP_TRY(hipEventRecord(e2, s));
+        launch_bgzf_inflate(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, c->zscratch.p, s, serial ? nullptr : c->up_mark, n);
         launch_bgzf_crc(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, s);
         HIP_TRY(hipMemsetAsync(c->file.p + utot, 0, 64, s));
-        HIP_TRY(hipEventRecord(e2, s));
+        hipEvent_t e3 = nullptr; HIP_TRY(hipEventCreate(&e3)); struct One { hipEvent_t &a; ~One() { if (a) (void)hipEventDestroy(a); } } e3_guard{e3};
+        HIP_TRY(hipEventRecord(e3, s));
         unsigned err = 0;
         HIP_TRY(hipMemcpyAsync(&err, c->bam_err.p, sizeof err, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipEventElapsedTime(&c->bgzf_h2d_ms, e0, e1)); HIP_TRY(hipEventElapsedTime(&c->bgzf_inflate_ms, e1, e2));
-        if (getenv("LPS_DEBUG")) fprintf(stderr, "[lps_bgzf_load] %zu blocks: header walk beside the upload %.1f ms | wait for upload + device alloc %.1f ms | inflate + crc (host wall) %.1f ms (kernels %.1f)\n", blks.size(), th1 - th0, th2 - th1, tnow() - th2, c->bgzf_inflate_ms);
+        if (uploader.joinable()) uploader.join();
+        HIP_TRY(hipStreamSynchronize(cs)); HIP_TRY(hipStreamSynchronize(s));
+        if (!up_err.empty()) return fail(c, up_err);
+        HIP_TRY(hipEventElapsedTime(&c->bgzf_h2d_ms, e0, e1)); HIP_TRY(hipEventElapsedTime(&c->bgzf_inflate_ms, e2, e3));
+        if (getenv("LPS_DEBUG")) fprintf(stderr, "[lps_bgzf_load] %zu blocks: header walk %.1f ms | device buffers %.1f ms | upload %.1f ms beside inflate + crc %.1f ms (from its launch; it waits for its bytes) | host wall %.1f ms\n", blks.size(), th1 - th0, th2 - th1, c->bgzf_h2d_ms, c->bgzf_inflate_ms, tnow() - th0);
         c->file_bytes = 0; c->n_rec_all = 0; c->names_ready = false;
-        if (err) return fail(c, err & LPS_INF_ERR_DATA ? "lps_bgzf_load: corrupt deflate stream" : err & (LPS_INF_ERR_SIZE | LPS_INF_ERR_OVERRUN) ? "lps_bgzf_load: a block does not inflate to its ISIZE"
+        if (err) return fail(c, err & LPS_INF_ERR_TIMEOUT ? "lps_bgzf_load: the inflate kernel waited for the upload for more than five seconds"
+                               : err & LPS_INF_ERR_DATA ? "lps_bgzf_load: corrupt deflate stream" : err & (LPS_INF_ERR_SIZE | LPS_INF_ERR_OVERRUN) ? "lps_bgzf_load: a block does not inflate to its ISIZE"
                                                                 : "lps_bgzf_load: CRC32 mismatch in a BGZF block");
         c->file_bytes = utot;
         if (inflated_bytes) *inflated_bytes = (int64_t)utot;

@@ -96,7 +96,7 @@ __device__ __forceinline__ bool canon_tables(const Pack16 &cnt, uint16_t *lim, u
 // cadence: few stores, so the in-order vmcnt queue does not stall the input prefetch behind them.
 #define INF_SCRATCH 320      // code lengths of one header per lane (<= 286 + 30), bytes; column layout [i][lane] per wavefront
 __global__ void __launch_bounds__(INF_LANES) k_bgzf_inflate(const uint8_t *__restrict__ in, const InflateBlock *__restrict__ blk, int n_blk, uint8_t *out, unsigned *err,
-                                                      uint8_t *scratch) {
+                                                      uint8_t *scratch, const unsigned long long *uploaded, unsigned long long total_in) {
     __shared__ uint8_t s_lsym8[288 * INF_LANES];                                  // low byte of the (length, symbol)-sorted litlen symbols
     __shared__ uint8_t s_lhi[36 * INF_LANES];                                     // their ninth bit, 8 per byte
     __shared__ uint16_t s_llim[16 * INF_LANES], s_lbase[16 * INF_LANES];                 // litlen lengths 1..15
@@ -105,6 +105,29 @@ __global__ void __launch_bounds__(INF_LANES) k_bgzf_inflate(const uint8_t *__res
     __shared__ uint32_t s_ring[16 * INF_LANES];                                   // 64 output bytes per lane, slot = global address & 63
     const int lane = threadIdx.x, bi = blockIdx.x * INF_LANES + lane;
     const bool active = bi < n_blk;
+    if (uploaded) {
+        // The upload may still be running (lps_bgzf_load launches this kernel beside it): wait until the bytes of this wavefront's members - and the
+        // dwords the bit reader fetches ahead - are in place.  Workgroups are dispatched in member order and the upload runs in file order, faster than
+        // the members are consumed, so the wait is short or none.  Chunk ends are multiples of 128 bytes: no cache line is ever read half-uploaded.
+        // Every wave leaves this loop: the counter reaches total_in, or the wall clock (100 MHz) runs out and the launch reports a timeout.
+        const InflateBlock last_member = blk[min(n_blk - 1, (int)blockIdx.x * INF_LANES + INF_LANES - 1)];
+        unsigned long long need = last_member.in_off + last_member.in_len + 64ull;
+        if (need > total_in) need = total_in;
+        // the word lives in host memory: ONE lane reads it (one PCIe read per poll), and a wave that is far ahead of the upload sleeps for about half
+        // of the time its bytes need at 40 GB/s before it looks again - a few polls per wave, not a stream of reads against the upload's direction
+        const long long t0 = wall_clock64(); bool timed_out = false;
+        for (;;) {
+            unsigned long long have = 0;
+            if (lane == 0) have = __hip_atomic_load(uploaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            have = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(have >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)have);
+            if (have >= need) break;
+            const unsigned long long naps = (need - have) >> 18;            // 3.4 us each (s_sleep 127 = 8 128 cycles): 256 KiB of upload take 6.5 us
+            for (unsigned long long k = 0, n_k = naps < 1 ? 1 : naps > 4096 ? 4096 : naps; k < n_k; ++k) __builtin_amdgcn_s_sleep(127);
+            if (wall_clock64() - t0 > 500000000ll) { timed_out = true; break; }
+        }
+        if (timed_out) { if (lane == 0) atomicOr(err, (unsigned)LPS_INF_ERR_TIMEOUT); return; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     const InflateBlock B = active ? blk[bi] : InflateBlock{0, 0, 0, 0};
     const uint64_t gbase = B.out_off;                                       // global byte offset of this block's output
     uint8_t *o = out + gbase; uint32_t op = 0, fl = 0; const uint32_t on = B.out_len;
@@ -357,6 +380,7 @@ void launch_bgzf_crc(const uint8_t *in, const InflateBlock *blk, int n_blk, cons
 }
 
 size_t bgzf_inflate_scratch_bytes(int n_blk) { return (size_t)((n_blk + INF_LANES - 1) / INF_LANES) * INF_SCRATCH * INF_LANES; }
-void launch_bgzf_inflate(const uint8_t *in, const InflateBlock *blk, int n_blk, uint8_t *out, unsigned *err, uint8_t *scratch, hipStream_t s) {
-    if (n_blk > 0) hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_blk + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), 0, s, in, blk, n_blk, out, err, scratch);
+void launch_bgzf_inflate(const uint8_t *in, const InflateBlock *blk, int n_blk, uint8_t *out, unsigned *err, uint8_t *scratch, hipStream_t s,
+                         const unsigned long long *uploaded, unsigned long long total_in) {
+    if (n_blk > 0) hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_blk + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), 0, s, in, blk, n_blk, out, err, scratch, uploaded, total_in);
 }
