@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 16
+#define LPS_ABI_VERSION 17
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -300,6 +300,9 @@ int lps_push_bam_records(lps_ctx *ctx, const uint8_t *records, int64_t n_bytes, 
  * (lps_begin_chromosome does not drop it).  Fails on a corrupt block, an ISIZE mismatch or a CRC32 mismatch (checked on the GPU).
  * lps_bgzf_read: copy a piece of the inflated stream to the host (BAM header text and reference table). */
 int lps_bgzf_load(lps_ctx *ctx, const uint8_t *bgzf, int64_t n_bytes, int64_t *inflated_bytes);
+/* the same for bytes [offset, offset + n_bytes) of an open FILE: read with pread straight into the page-locked upload pieces, so that a multi-GB file
+ * is never mapped (an 8 GB mapping costs 0.14 s to tear down when the process ends, and as many page-table entries to set up while it is copied) */
+int lps_bgzf_load_fd(lps_ctx *ctx, int fd, int64_t offset, int64_t n_bytes, int64_t *inflated_bytes);
 int lps_bgzf_read(lps_ctx *ctx, int64_t offset, int64_t n, uint8_t *dst);
 int lps_bgzf_timings(lps_ctx *ctx, double *h2d_ms, double *inflate_ms);
 /* GPU BGZF writer (replaces bgzf_write/deflate behind sam_write1, src/haplotag/HaplotagParsingBam.cpp:124-134): bytes [offset, offset+n_bytes)

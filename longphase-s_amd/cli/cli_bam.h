@@ -208,8 +208,8 @@ struct GpuBam {
     // whole-file mode: everything resident at once, one contiguous record range per contig
     void load_all(Lps &L, lps_ctx *ctx) {
         const double t1 = now();
-        madvise((void *)raw, fsz, MADV_WILLNEED);
-        if (L.bgzf_load(ctx, raw, (int64_t)fsz, &total)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
+        posix_fadvise(fd, 0, (off_t)fsz, POSIX_FADV_WILLNEED);
+        if (L.bgzf_load_fd(ctx, fd, 0, (int64_t)fsz, &total)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));      // (pread into the upload pieces: the mapping stays a few header pages)
         const double t2 = now(); t_inflate += t2 - t1;
         int64_t n = 0;
         if (L.bam_scan(ctx, (int64_t)header.size(), (int32_t)ref_names.size(), &n)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
@@ -256,7 +256,7 @@ struct GpuBam {
             last_isize = rd32(raw + stop - 4);
             }
         if (cbeg >= stop || stop > fsz) die("ERROR: index of " + path + " is inconsistent");
-        if (L.bgzf_load(ctx, raw + cbeg, (int64_t)(stop - cbeg), &total)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
+        if (L.bgzf_load_fd(ctx, fd, (int64_t)cbeg, (int64_t)(stop - cbeg), &total)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
         const int64_t end = uend ? total - (int64_t)last_isize + (int64_t)uend : total;
         const double t2 = now(); t_inflate += t2 - t1;
         int64_t n = 0;

@@ -38,6 +38,7 @@ static const char *kVersion = "1.0.0-mi355x";
 // with the streams of worker threads that are still running (--gpus N) - exit(1) from a worker could hang or crash on the way out.
 [[noreturn]] static void die(const std::string &m) { std::cerr << m << "\n"; std::cerr.flush(); fflush(nullptr); _exit(1); }
 static const size_t kGpuInflateMinBytes = 256u << 20;
+static double epoch_now() { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 static size_t file_bytes(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 ? (size_t)st.st_size : 0; }
 
 // ------------------------------------------------------------------------------------------------ the library, loaded at run time
@@ -68,7 +69,7 @@ struct Lps {
     decltype(&lps_somatic_tag_chromosome) somatic_tag_chromosome = nullptr;
     decltype(&lps_comm_create_all) comm_create_all = nullptr;
     decltype(&lps_comm_bcast) comm_bcast = nullptr; decltype(&lps_comm_bcast_to_device) comm_bcast_to_device = nullptr; decltype(&lps_set_variants_device) set_variants_device = nullptr;
-    decltype(&lps_somatic_write_bgzf) somatic_write_bgzf = nullptr; decltype(&lps_dump_graph) dump_graph = nullptr; decltype(&lps_dump_votes) dump_votes = nullptr;
+    decltype(&lps_somatic_write_bgzf) somatic_write_bgzf = nullptr; decltype(&lps_bgzf_load_fd) bgzf_load_fd = nullptr; decltype(&lps_dump_graph) dump_graph = nullptr; decltype(&lps_dump_votes) dump_votes = nullptr;
     decltype(&lps_comm_destroy) comm_destroy = nullptr;
     decltype(&lps_comm_size) comm_size = nullptr; decltype(&lps_comm_last_error) comm_last_error = nullptr;
     std::string error;
@@ -88,7 +89,7 @@ struct Lps {
         LPS_SYM(abi_version, lps_abi_version) LPS_SYM(bgzf_load, lps_bgzf_load) LPS_SYM(bgzf_read, lps_bgzf_read) LPS_SYM(bam_scan, lps_bam_scan)
         LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range) LPS_SYM(device_count, lps_device_count) LPS_SYM(set_stage_timing, lps_set_stage_timing) LPS_SYM(haplotag_write_bgzf, lps_haplotag_write_bgzf) LPS_SYM(bgzf_deflate_fetch, lps_bgzf_deflate_fetch)
         LPS_SYM(somatic_extract_normal, lps_somatic_extract_normal) LPS_SYM(somatic_extract_tumor, lps_somatic_extract_tumor) LPS_SYM(somatic_tag_chromosome, lps_somatic_tag_chromosome)
-        LPS_SYM(somatic_write_bgzf, lps_somatic_write_bgzf) LPS_SYM(dump_graph, lps_dump_graph) LPS_SYM(dump_votes, lps_dump_votes)
+        LPS_SYM(somatic_write_bgzf, lps_somatic_write_bgzf) LPS_SYM(bgzf_load_fd, lps_bgzf_load_fd) LPS_SYM(dump_graph, lps_dump_graph) LPS_SYM(dump_votes, lps_dump_votes)
         LPS_SYM(comm_create_all, lps_comm_create_all) LPS_SYM(comm_bcast, lps_comm_bcast) LPS_SYM(comm_bcast_to_device, lps_comm_bcast_to_device) LPS_SYM(set_variants_device, lps_set_variants_device) LPS_SYM(comm_destroy, lps_comm_destroy) LPS_SYM(comm_size, lps_comm_size) LPS_SYM(comm_last_error, lps_comm_last_error)
 #undef LPS_SYM
         if (abi_version() != LPS_ABI_VERSION) { error = "liblps_hip.so has a different ABI version than this binary was built for"; return false; }

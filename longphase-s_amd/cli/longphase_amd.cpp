@@ -36,6 +36,8 @@ static const char *kUsage =
 // kernel does both for a process that simply ends); LPS_CLI_NO_FAST_EXIT=1 takes the full way out, e.g. under a profiler that reports from an exit handler.
 static bool full_teardown() { return getenv("LPS_CLI_NO_FAST_EXIT") != nullptr; }
 
+static double g_main_entered = 0;
+
 static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over; bool indels = false;
     std::string snp, ref, prefix = "result", sv_file, mod_file;
@@ -347,6 +349,8 @@ static int phase_main(int argc, char **argv, const std::string &command) {
                            t_gpu - t_gin - (gb.indexed ? gb.t_inflate + gb.t_scan : 0.0), now() - t_gpu, now() - t_begin);
     else fprintf(stderr, "vcf+fasta read %.3fs | bam inflate+walk %.3fs | wait for gpu context %.3fs | upload+phase %.3fs | write vcf %.3fs | total %.3fs\n", t_text - t_begin,
                  t_bam - t_text, t_ctx - t_bam, t_gpu - t_ctx, now() - t_gpu, now() - t_begin);
+    if (getenv("LPS_CLI_EXIT_PROBE")) { const double a = now(); gb.close_file(); const double b = now(); L.destroy(ctx); fprintf(stderr, "[cli] exit probe: munmap of the BAM %.3fs, lps_destroy %.3fs\n", b - a, now() - b); }
+    if (getenv("LPS_CLI_DEBUG")) fprintf(stderr, "[cli] main entered at %.3f, left at %.3f (epoch seconds: what the caller's clock shows before and after is start-up and exit)\n", g_main_entered, epoch_now());
     fflush(stderr);
     if (getenv("LPS_CLI_NO_FAST_EXIT")) return 0;                       // e.g. under a profiler that writes its report from an exit handler
     _exit(0);   // outputs are closed and flushed; skip the ROCm runtime's static teardown (~0.1 s)
@@ -1474,6 +1478,7 @@ static int view_main(int argc, char **argv) {
 }
 
 int main(int argc, char **argv) {
+    g_main_entered = epoch_now();
     std::string command; for (int i = 0; i < argc; ++i) { if (i) command += " "; command += argv[i]; }
     if (argc < 2) { std::cout << "Version: " << kVersion << "\nUsage: longphase_amd <command> [options]\n    phase    run phasing algorithm on the GPU.\n    haplotag tag reads by haplotype on the GPU.\n    somatic_haplotag tag tumor reads (somatic + germline haplotypes) on the GPU; needs --tumor-purity.\n";
         return 0;

@@ -13,6 +13,8 @@
 #include <cmath>
 #include <climits>
 #include <cstring>
+#include <cerrno>
+#include <unistd.h>
 
 #include "lps_graph.h"
 #include "lps_bam.h"
@@ -108,27 +110,48 @@ static int fail(lps_ctx *c, const std::string &m, int code = -1) { if (c) c->err
 
 // Large upload from pageable memory (an mmap of the BAM file): the runtime's own path stages through ONE host thread's memcpy; here four threads fill a
 // pinned 2 x 64 MiB ring while the DMA engine drains the other half.
+// Where a large upload takes its bytes from: memory, or a file read with pread straight into the page-locked pieces (no mapping of the file: an 8 GB
+// mapping costs two million page-table entries to set up while it is copied and 0.14 s to tear down when the process ends).
+struct ZSource {
+    const uint8_t *mem = nullptr; int fd = -1; uint64_t base = 0;
+    bool read(uint64_t pos, size_t len, uint8_t *dst) const {
+        if (mem) { memcpy(dst, mem + pos, len); return true; }
+        while (len) {
+            const ssize_t r = pread(fd, dst, len, (off_t)(base + pos));
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) return false;
+            dst += r; pos += (uint64_t)r; len -= (size_t)r;
+        }
+        return true;
+    }
+};
 // `mark` (optional): a word in PAGE-LOCKED HOST memory that this (host) thread raises to the number of bytes known to be in place - after the event of
 // a piece has been waited for, i.e. two pieces late, and n at the end.  It is what a kernel launched beside the upload polls (k_bgzf_inflate): host
 // memory, because a word in device memory written by the copy engine would sit stale in the polling XCD's L2 until the next kernel boundary.
-static void h2d_staged(lps_ctx *c, uint8_t *dst, const uint8_t *src, size_t n, hipStream_t st = nullptr, unsigned long long *mark = nullptr) {
+static void h2d_staged(lps_ctx *c, uint8_t *dst, const ZSource &src, size_t n, hipStream_t st = nullptr, unsigned long long *mark = nullptr) {
     const size_t CH = 64u << 20;
     if (!st) st = c->stream;
     auto raise = [&](size_t bytes) { if (mark) __atomic_store_n(mark, (unsigned long long)bytes, __ATOMIC_RELEASE); };
-    if (n < (16u << 20)) { HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st)); if (mark) { HIP_TRY(hipStreamSynchronize(st)); raise(n); } return; }
+    if (n < (16u << 20)) {
+        if (src.mem) { HIP_TRY(hipMemcpyAsync(dst, src.mem, n, hipMemcpyHostToDevice, st)); if (mark) HIP_TRY(hipStreamSynchronize(st)); }
+        else { std::vector<uint8_t> tmp(n); if (!src.read(0, n, tmp.data())) throw std::string("cannot read the file"); HIP_TRY(hipMemcpyAsync(dst, tmp.data(), n, hipMemcpyHostToDevice, st)); HIP_TRY(hipStreamSynchronize(st)); }
+        raise(n); return;
+    }
     if (!c->stage[0]) { for (int k = 0; k < 2; ++k) { HIP_TRY(hipHostMalloc((void **)&c->stage[k], CH, hipHostMallocDefault)); HIP_TRY(hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming)); } c->stage_bytes = CH; }
     int k = 0; bool used[2] = {false, false}; size_t end_of[2] = {0, 0};
     for (size_t off = 0; off < n; off += CH, k ^= 1) {
         const size_t len = std::min(CH, n - off);
         if (used[k]) { HIP_TRY(hipEventSynchronize(c->stage_ev[k])); raise(end_of[k]); }       // (pieces complete in order: everything before end_of[k] is in place)
-        const int nt = 4; std::thread th[nt]; const size_t part = (len + nt - 1) / nt;
-        for (int t = 0; t < nt; ++t) th[t] = std::thread([=] { const size_t a = std::min(len, part * t), b = std::min(len, a + part); if (b > a) memcpy(c->stage[k] + a, src + off + a, b - a); });
+        const int nt = 4; std::thread th[nt]; const size_t part = (len + nt - 1) / nt; bool ok[nt];
+        for (int t = 0; t < nt; ++t) th[t] = std::thread([&, t] { const size_t a = std::min(len, part * t), b = std::min(len, a + part); ok[t] = b <= a || src.read(off + a, b - a, c->stage[k] + a); });
         for (int t = 0; t < nt; ++t) th[t].join();
+        for (int t = 0; t < nt; ++t) if (!ok[t]) throw std::string("cannot read the file");
         HIP_TRY(hipMemcpyAsync(dst + off, c->stage[k], len, hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(c->stage_ev[k], st)); used[k] = true; end_of[k] = off + len;
     }
     if (mark) { for (int q = 0; q < 2; ++q) if (used[q]) HIP_TRY(hipEventSynchronize(c->stage_ev[q])); raise(n); }
 }
+static void h2d_staged(lps_ctx *c, uint8_t *dst, const uint8_t *src, size_t n, hipStream_t st = nullptr, unsigned long long *mark = nullptr) { h2d_staged(c, dst, ZSource{src, -1, 0}, n, st, mark); }
 
 template <class T>
 static void upload(lps_ctx *c, DevBuf<T> &b, const T *src, size_t n, size_t at = 0, bool keep = false) {
@@ -633,47 +656,66 @@ int lps_push_bam_resident(lps_ctx *c, int64_t first, int64_t count, const uint32
     return 0;
 }
 
-// One BGZF block header at p (18 bytes + extra subfields; RFC 1952 member with the BC subfield, SAM spec 4.1) -> BSIZE, 0 when p holds none
-static inline uint64_t bgzf_block_at(const uint8_t *z, uint64_t p, uint64_t n, unsigned &xlen) {
-    if (p + 18 > n || z[p] != 31 || z[p + 1] != 139 || z[p + 2] != 8 || !(z[p + 3] & 4)) return 0;
-    xlen = z[p + 10] | (z[p + 11] << 8);
-    uint64_t q = p + 12, bsize = 0;
-    while (q + 4 <= p + 12 + xlen && q + 4 <= n) {
-        const unsigned slen = z[q + 2] | (z[q + 3] << 8);
-        if (z[q] == 'B' && z[q + 1] == 'C' && slen == 2 && q + 6 <= n) bsize = (uint64_t)(z[q + 4] | (z[q + 5] << 8)) + 1;
+// One BGZF block header (18 bytes + extra subfields; RFC 1952 member with the BC subfield, SAM spec 4.1) in h[0, avail) = the file's bytes from p on
+// -> BSIZE; 0 when it is none; ~0 when the extra field reaches beyond `avail` (the caller reads more)
+static inline uint64_t bgzf_parse_header(const uint8_t *h, size_t avail, uint64_t p, uint64_t n, unsigned &xlen) {
+    if (avail < 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return 0;
+    xlen = h[10] | (h[11] << 8);
+    if (12ull + xlen > avail) return p + 12ull + xlen > n ? 0 : ~0ull;
+    uint64_t q = 12, bsize = 0;
+    while (q + 4 <= 12ull + xlen) {
+        const unsigned slen = h[q + 2] | (h[q + 3] << 8);
+        if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2 && q + 6 <= 12ull + xlen) bsize = (uint64_t)(h[q + 4] | (h[q + 5] << 8)) + 1;
         q += 4 + slen;
     }
     if (!bsize || bsize < 12ull + xlen + 8 || p + bsize > n) return 0;
     return bsize;
 }
-// The block table of [from, to): false when a header is bad, a block is larger than 64 KiB or the chain does not land on `to` exactly.  out_off is
-// relative to the piece's first block (utot = the piece's inflated size).
-static bool bgzf_walk_piece(const uint8_t *z, uint64_t n, uint64_t from, uint64_t to, std::vector<InflateBlock> &blks, uint64_t &utot) {
-    uint64_t p = from; utot = 0;
+// The block table of [from, to): false when a header is bad, a block is larger than 64 KiB, the source cannot be read or the chain does not land on
+// `to` exactly.  out_off is relative to the piece's first block (utot = the piece's inflated size).  One read per block: the ISIZE at a block's end
+// and the header behind it come together.
+static bool bgzf_walk_piece(const ZSource &z, uint64_t n, uint64_t from, uint64_t to, std::vector<InflateBlock> &blks, uint64_t &utot, uint64_t *bad_at = nullptr) {
+    uint64_t p = from; utot = 0; uint8_t h[64], t[68]; size_t have = 0; std::vector<uint8_t> wide;
     while (p < to) {
-        unsigned xlen = 0; const uint64_t bsize = bgzf_block_at(z, p, n, xlen);
-        if (!bsize) return false;
-        const uint64_t isize = (uint64_t)z[p + bsize - 4] | ((uint64_t)z[p + bsize - 3] << 8) | ((uint64_t)z[p + bsize - 2] << 16) | ((uint64_t)z[p + bsize - 1] << 24);
+        if (bad_at) *bad_at = p;
+        const size_t want = (size_t)std::min<uint64_t>(sizeof h, n - p);
+        if (have < want) { if (!z.read(p + have, want - have, h + have)) return false; have = want; }
+        unsigned xlen = 0; uint64_t bsize = bgzf_parse_header(h, have, p, n, xlen);
+        if (bsize == ~0ull) { wide.resize(12 + (size_t)xlen); if (!z.read(p, wide.size(), wide.data())) return false; bsize = bgzf_parse_header(wide.data(), wide.size(), p, n, xlen); }
+        if (!bsize || bsize == ~0ull) return false;
+        const size_t tl = (size_t)std::min<uint64_t>(sizeof t, n - (p + bsize - 4));
+        if (!z.read(p + bsize - 4, tl, t)) return false;
+        const uint64_t isize = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
         if (isize > 65536) return false;
         blks.push_back(InflateBlock{p + 12 + xlen, utot, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize});
         utot += isize; p += bsize;
+        have = tl - 4; memcpy(h, t + 4, have);
     }
     return p == to;
 }
-// The header walk touches one page in eight of the file (0.2 s for 8 GB on one thread: page-table work, not bytes): T threads take a piece each.  A
-// piece starts at the first position behind k * n / T where FOUR block headers follow one another; the piece before it must end exactly there,
-// otherwise (and whenever anything else looks wrong) the caller walks the file serially, which also finds the words for the error.
-static bool bgzf_walk_parallel(const uint8_t *z, uint64_t n, std::vector<InflateBlock> &blks, uint64_t &utot) {
+// The header walk is latency, not bytes (one small read per 20 - 30 KB block; 0.2 s for 8 GB on one thread): T threads take a piece each.  A piece
+// starts at the first position behind k * n / T where FOUR block headers follow one another; the piece before it must end exactly there, otherwise
+// (and whenever anything else looks wrong) the caller walks the file serially.
+static bool bgzf_walk_parallel(const ZSource &z, uint64_t n, std::vector<InflateBlock> &blks, uint64_t &utot) {
     const int T = 8;
     if (n < (64ull << 20)) return false;
     std::vector<uint64_t> seed((size_t)T + 1, 0); seed[(size_t)T] = n;
+    std::vector<uint8_t> win((1u << 20) + 64);
     for (int k = 1; k < T; ++k) {
+        const uint64_t w0 = n * (uint64_t)k / T; const size_t wl = (size_t)std::min<uint64_t>(win.size(), n - w0);
+        if (!z.read(w0, wl, win.data())) return false;
         uint64_t found = 0;
-        for (uint64_t p = n * (uint64_t)k / T, stop = std::min<uint64_t>(n, p + (1ull << 20)); p < stop && !found; ++p) {
-            if (z[p] != 31 || z[p + 1] != 139) continue;
-            uint64_t q = p; int chain = 0;
-            for (; chain < 4 && q < n; ++chain) { unsigned xl; const uint64_t b = bgzf_block_at(z, q, n, xl); if (!b) break; q += b; }
-            if (chain == 4 || (chain > 0 && q == n)) found = p;
+        for (size_t i = 0; i + 18 <= wl && i < (1u << 20) && !found; ++i) {
+            if (win[i] != 31 || win[i + 1] != 139 || win[i + 2] != 8 || !(win[i + 3] & 4)) continue;
+            uint64_t q = w0 + i; int chain = 0; uint8_t h[64];
+            for (; chain < 4 && q < n; ++chain) {
+                const size_t hl = (size_t)std::min<uint64_t>(sizeof h, n - q); unsigned xl = 0;
+                if (!z.read(q, hl, h)) return false;
+                const uint64_t b = bgzf_parse_header(h, hl, q, n, xl);
+                if (!b || b == ~0ull) break;
+                q += b;
+            }
+            if (chain == 4 || (chain > 0 && q == n)) found = w0 + i;
         }
         if (!found) return false;
         seed[(size_t)k] = found;
@@ -688,8 +730,16 @@ static bool bgzf_walk_parallel(const uint8_t *z, uint64_t n, std::vector<Inflate
     return true;
 }
 
+static int bgzf_load_source(lps_ctx *c, const ZSource &src, int64_t n_bytes, int64_t *inflated_bytes);
 int lps_bgzf_load(lps_ctx *c, const uint8_t *bgzf, int64_t n_bytes, int64_t *inflated_bytes) {
     if (!c || !bgzf || n_bytes < 28) return fail(c, "lps_bgzf_load: not a BGZF file");
+    return bgzf_load_source(c, ZSource{bgzf, -1, 0}, n_bytes, inflated_bytes);
+}
+int lps_bgzf_load_fd(lps_ctx *c, int fd, int64_t offset, int64_t n_bytes, int64_t *inflated_bytes) {
+    if (!c || fd < 0 || offset < 0 || n_bytes < 28) return fail(c, "lps_bgzf_load_fd: not a BGZF file");
+    return bgzf_load_source(c, ZSource{nullptr, fd, (uint64_t)offset}, n_bytes, inflated_bytes);
+}
+static int bgzf_load_source(lps_ctx *c, const ZSource &src, int64_t n_bytes, int64_t *inflated_bytes) {
     try {
         HIP_TRY(hipSetDevice(c->device));
         auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -708,23 +758,22 @@ int lps_bgzf_load(lps_ctx *c, const uint8_t *bgzf, int64_t n_bytes, int64_t *inf
         HIP_TRY(hipMemsetAsync(c->zfile.p + n_bytes, 0, 64, cs));
         HIP_TRY(hipEventRecord(e0, cs));
         std::string up_err;
-        std::thread uploader([&] { try { (void)hipSetDevice(c->device); h2d_staged(c, c->zfile.p, bgzf, (size_t)n_bytes, cs, serial ? nullptr : c->up_mark); HIP_TRY(hipEventRecord(e1, cs)); }
+        std::thread uploader([&] { try { (void)hipSetDevice(c->device); h2d_staged(c, c->zfile.p, src, (size_t)n_bytes, cs, serial ? nullptr : c->up_mark); HIP_TRY(hipEventRecord(e1, cs)); }
                                    catch (std::string &e) { up_err = e; __atomic_store_n(c->up_mark, ~0ull, __ATOMIC_RELEASE); } });   // (a failed upload must not leave the kernel waiting)
         struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_up{uploader};
         std::vector<InflateBlock> blks; uint64_t utot = 0; const uint64_t n = (uint64_t)n_bytes;
-        if (serial || !bgzf_walk_parallel(bgzf, n, blks, utot)) {
-            blks.clear(); utot = 0; uint64_t p = 0;
-            while (p + 18 <= n) {
-                unsigned xlen = 0;
-                if (bgzf[p] != 31 || bgzf[p + 1] != 139 || bgzf[p + 2] != 8 || !(bgzf[p + 3] & 4)) return fail(c, "lps_bgzf_load: not a BGZF block header");
-                const uint64_t bsize = bgzf_block_at(bgzf, p, n, xlen);
+        if (serial || !bgzf_walk_parallel(src, n, blks, utot)) {
+            blks.clear(); utot = 0; uint64_t bad_at = 0;
+            if (!bgzf_walk_piece(src, n, 0, n, blks, utot, &bad_at) || blks.empty()) {
+                // the words for what is wrong at bad_at
+                uint8_t h[64]; const size_t hl = (size_t)std::min<uint64_t>(sizeof h, n - bad_at); unsigned xlen = 0;
+                if (bad_at >= n || !src.read(bad_at, hl, h)) return fail(c, bad_at >= n ? "lps_bgzf_load: trailing bytes after the last BGZF block" : "lps_bgzf_load: cannot read the file");
+                if (hl < 18) return fail(c, "lps_bgzf_load: trailing bytes after the last BGZF block");
+                if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return fail(c, "lps_bgzf_load: not a BGZF block header");
+                const uint64_t bsize = bgzf_parse_header(h, hl, bad_at, n, xlen);
                 if (!bsize) return fail(c, "lps_bgzf_load: truncated BGZF block");
-                const uint64_t isize = (uint64_t)bgzf[p + bsize - 4] | ((uint64_t)bgzf[p + bsize - 3] << 8) | ((uint64_t)bgzf[p + bsize - 2] << 16) | ((uint64_t)bgzf[p + bsize - 1] << 24);
-                if (isize > 65536) return fail(c, "lps_bgzf_load: BGZF block larger than 64 KiB");
-                blks.push_back(InflateBlock{p + 12 + xlen, utot, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize});
-                utot += isize; p += bsize;
+                return fail(c, "lps_bgzf_load: BGZF block larger than 64 KiB");
             }
-            if (p != n || blks.empty()) return fail(c, "lps_bgzf_load: trailing bytes after the last BGZF block");
         }
         if (blks.size() > 0x7fffffffull) return fail(c, "lps_bgzf_load: too many blocks");
         const double th1 = tnow();
