@@ -60,6 +60,7 @@ def load():
     L.lps_debug_std_sort_gpu.restype = C.c_int
     L.lps_debug_std_sort_gpu.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.lps_bgzf_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.lps_bgzf_load_fd.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
     L.lps_bgzf_read.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     L.lps_bgzf_deflate.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
     L.lps_bgzf_deflate_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]
@@ -203,6 +204,12 @@ class Context:
         a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         n = C.c_int64(0)
         self._check(self.L.lps_bgzf_load(self.h, a.ctypes.data, a.size, C.byref(n)), "lps_bgzf_load")
+        return int(n.value)
+
+    def bgzf_load_fd(self, fd, offset, n_bytes):
+        """The same for bytes [offset, offset + n_bytes) of an open file (pread into the upload pieces, no mapping); returns the inflated size."""
+        n = C.c_int64(0)
+        self._check(self.L.lps_bgzf_load_fd(self.h, int(fd), int(offset), int(n_bytes), C.byref(n)), "lps_bgzf_load_fd")
         return int(n.value)
 
     def bam_scan(self, first_record_offset, n_ref):

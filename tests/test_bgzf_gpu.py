@@ -223,3 +223,43 @@ def test_deflate_of_host_bytes_fetched_in_pieces():
         L.lps_host_free(pin)
         assert gzip.decompress(bytes(out)) == data
         assert L.lps_bgzf_deflate_host(ctx.h, None, 0, C.byref(nb)) == 0 and nb.value == 0
+
+
+def test_file_of_several_upload_pieces_read_with_pread(tmp_path):
+    """lps_bgzf_load_fd on a 160 MB file: the header walk runs in eight pieces (seeds found where four headers follow one another), the upload goes in
+    64-MiB pieces beside the inflate kernel, whose wavefronts wait for their own bytes (the watermark); then a sub-range of the same file (what a .bai
+    gives for a contig group), the memory entry point on the same bytes, and a file whose chain breaks in the middle (serial walk, the error names it)."""
+    import os
+    rng = np.random.default_rng(11)
+    parts, blocks, zs, at = [], [], [], 0
+    for k in range(2700):                                             # ~64 KB of packed-base-like bytes per block: barely compressible, 63 KB per block
+        raw = rng.integers(0, 200, int(rng.integers(60_000, 65_280)), dtype=np.uint8).tobytes()
+        z = bgzf(raw, 1 << 20, 1, eof=False)
+        parts.append(raw); blocks.append((at, len(z))); at += len(z); zs.append(z)
+    z = b"".join(zs) + bgzf(b"", 1, 1)[:28]
+    data = b"".join(parts)
+    assert len(z) > 150_000_000                                       # three upload pieces of 64 MiB
+    path = str(tmp_path / "big.bgzf"); open(path, "wb").write(z)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        with hip.Context(0, abi.default_params()) as ctx:
+            assert ctx.bgzf_load_fd(fd, 0, len(z)) == len(data)
+            for a in (0, 70_000_000, len(data) - 9_000):
+                assert ctx.bgzf_read(a, 9_000).tobytes() == data[a:a + 9_000]
+            lo, hi = blocks[400][0], blocks[2100][0]                   # a run of whole blocks from the middle of the file
+            ulo = sum(len(x) for x in parts[:400]); uhi = sum(len(x) for x in parts[:2100])
+            assert ctx.bgzf_load_fd(fd, lo, hi - lo) == uhi - ulo
+            assert ctx.bgzf_read(0, 5_000).tobytes() == data[ulo:ulo + 5_000] and ctx.bgzf_read(uhi - ulo - 5_000, 5_000).tobytes() == data[uhi - 5_000:uhi]
+            assert ctx.bgzf_load(z) == len(data)                       # from memory: same walk, same kernel
+            assert ctx.bgzf_read(123_456_789, 4_096).tobytes() == data[123_456_789:123_456_789 + 4_096]
+            bad = bytearray(z); bad[blocks[1500][0] + 1] ^= 0xff         # the second magic byte of a block in the middle
+            bpath = str(tmp_path / "bad.bgzf"); open(bpath, "wb").write(bytes(bad))
+            bfd = os.open(bpath, os.O_RDONLY)
+            try:
+                with pytest.raises(hip.LpsError, match="not a BGZF block header"):
+                    ctx.bgzf_load_fd(bfd, 0, len(bad))
+            finally:
+                os.close(bfd)
+            assert ctx.bgzf_load_fd(fd, 0, len(z)) == len(data)         # the context is still usable
+    finally:
+        os.close(fd)
