@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256) void k_groups(int n_reads, const uint32_t *nam
         const unsigned big = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3])); if (big) atomicMax(&cnt->max_group, big);
     }
     __syncthreads();
-    if (!owner) return;
     unsigned base = s_base_k + (unsigned)(incl - k), qi = s_base_n + (unsigned)__popcll(om & lanemask_lt());
     for (int q = 0; q < w; ++q) { base += s_k[q]; qi += s_n[q]; }
+    if (owner) {
     {
         uint32_t prev = 0;                                      // members in ascending alignment index (+1): the smallest above the last one taken
         for (int t = 0; t < k; ++t) {
@@ -157,12 +157,22 @@ __global__ __launch_bounds__(256) void k_groups(int n_reads, const uint32_t *nam
         second = lp;
         if (del) deleted[a] = 1; else kept[nk++] = a;
     }
-    if (var_del) {
-        for (int t = 0; t < k; ++t) {
-            const uint32_t a = mm_r[base + t];
-            if (!deleted[a]) continue;
-            const uint32_t off = rows[a].off; const int n = rows[a].cnt;
-            for (int j = 0; j < n; ++j) atomicAdd(&var_del[obs[off + j].var], 1u);
+    }
+    // ---- the observations of the deleted alignments leave their variants' counts.  One lane per group decided; the counts are taken back by the
+    //      WHOLE wave, one deleted alignment after the other (a lane on its own walked its alignments' 20 - 60 observations one dependent load at a
+    //      time: most of this kernel's 0.13 ms at chr1-50x)
+    if (!var_del) return;
+    const int l = lane_id();
+    for (int t_next = 0;;) {
+        uint32_t a = 0xffffffffu;
+        if (owner) { while (t_next < k) { const uint32_t x = mm_r[base + t_next++]; if (deleted[x]) { a = x; break; } } }
+        unsigned long long pending = __ballot(a != 0xffffffffu);
+        if (!pending) break;
+        while (pending) {
+            const int src = (int)__builtin_ctzll(pending); pending &= pending - 1ull;
+            const uint32_t aa = (uint32_t)__builtin_amdgcn_readlane((int)a, src);
+            const uint32_t off = rows[aa].off; const int n = rows[aa].cnt;
+            for (int j = l; j < n; j += 64) atomicAdd(&var_del[obs[off + j].var], 1u);
         }
     }
 }
