@@ -93,10 +93,13 @@ __global__ __launch_bounds__(256) void k_name_link(int n_reads, const uint32_t *
 // in BAM order (the list is in arrival order: every member is found by another walk - groups have two or three members) go to mm_r, where the
 // merged-row kernels find them, and the reference's overlap filter of several alignments of one read (:707-781) is replayed on them one after the
 // other.  A deleted alignment's observations leave the per-variant counts the extraction took (var_del).
-__global__ __launch_bounds__(256) void k_groups(int n_reads, const uint32_t *name, const RowDesc *rows, const ObsRec *obs, const int32_t *vpos, double overlap_threshold,
+// 1 024 alignments per workgroup: its two reservations are RETURNING atomics on single words, which the L2 serves one after the other at ~11 ns each
+//  - with 256 alignments per workgroup they alone were 55 us of this kernel at chr1-50x
+#define GROUPS_B 1024
+__global__ __launch_bounds__(GROUPS_B) void k_groups(int n_reads, const uint32_t *name, const RowDesc *rows, const ObsRec *obs, const int32_t *vpos, double overlap_threshold,
                                                 const uint32_t *name_head, const uint32_t *name_link, LpsCounters *cnt,
                                                 uint32_t *mm_r, uint32_t *stack, uint32_t *mg_start, uint32_t *mg_cnt, uint32_t *mg_name, uint8_t *deleted, uint32_t *var_del) {
-    __shared__ unsigned s_k[4], s_n[4], s_mx[4], s_base_k, s_base_n;
+    __shared__ unsigned s_k[GROUPS_B / 64], s_n[GROUPS_B / 64], s_mx[GROUPS_B / 64], s_base_k, s_base_n;
     const int r = blockIdx.x * blockDim.x + threadIdx.x, w = threadIdx.x >> 6;
     bool owner = false; int k = 0; uint32_t id = 0;
     if (r < n_reads && rows[r].cnt > 0) {
@@ -110,9 +113,10 @@ __global__ __launch_bounds__(256) void k_groups(int n_reads, const uint32_t *nam
     if (lane_id() == 0) { s_n[w] = (unsigned)__popcll(om); s_mx[w] = (unsigned)kmx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned K = s_k[0] + s_k[1] + s_k[2] + s_k[3], N = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+        unsigned K = 0, N = 0, big = 0;
+        for (int q = 0; q < GROUPS_B / 64; ++q) { K += s_k[q]; N += s_n[q]; big = max(big, s_mx[q]); }
         s_base_k = K ? atomicAdd(&cnt->mm_total, K) : 0u; s_base_n = N ? atomicAdd(&cnt->n_multi, N) : 0u;
-        const unsigned big = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3])); if (big) atomicMax(&cnt->max_group, big);
+        if (big) atomicMax(&cnt->max_group, big);
     }
     __syncthreads();
     unsigned base = s_base_k + (unsigned)(incl - k), qi = s_base_n + (unsigned)__popcll(om & lanemask_lt());
@@ -1459,7 +1463,7 @@ void launch_names(const GraphView &G, const ClipView &C, unsigned long long *cli
 
 void launch_groups(const GraphView &G, double overlap_threshold, bool counted, hipStream_t s) {
     if (!G.n_reads) return;
-    hipLaunchKernelGGL(k_groups, GRID(G.n_reads, 256), 0, s, G.n_reads, G.name, G.rows, G.obs, G.vpos, overlap_threshold, G.name_head, G.name_link, G.cnt,
+    hipLaunchKernelGGL(k_groups, GRID(G.n_reads, GROUPS_B), 0, s, G.n_reads, G.name, G.rows, G.obs, G.vpos, overlap_threshold, G.name_head, G.name_link, G.cnt,
                        G.mm_r, G.stack, G.mg_start, G.mg_cnt, G.mg_name, G.deleted, counted ? G.var_del : nullptr);
 }
 
