@@ -33,10 +33,11 @@
 //   * workgroup nb_reads: observation slots reserved by the extraction, over the arenas.
 //   * the workgroups after it: clip events of ops before the op at which get_snp returned early (:1453-1455,1559-1561), compacted (one atomic per
 //     workgroup) into sort keys (pos << 1 | front/back).
-__global__ __launch_bounds__(256) void k_name_link(int n_reads, const uint32_t *name, const RowDesc *rows, uint32_t *name_head, uint32_t *name_link,
+#define NAMES_B 1024      // alignments (and clip slots per pass) of a workgroup: a quarter of the atomics on the counters' single words that 256 would make
+__global__ __launch_bounds__(NAMES_B) void k_name_link(int n_reads, const uint32_t *name, const RowDesc *rows, uint32_t *name_head, uint32_t *name_link,
                                                    LpsCounters *cnt, const unsigned long long *arena_ctr, unsigned long long arena_size,
                                                    ClipView C, unsigned long long *keys, int nb_reads) {
-    __shared__ unsigned s_wcnt[4], s_wmax[4], s_base;
+    __shared__ unsigned s_wcnt[NAMES_B / 64], s_wmax[NAMES_B / 64], s_base;
     const int w = threadIdx.x >> 6;
     if ((int)blockIdx.x < nb_reads) {
         const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -49,8 +50,10 @@ __global__ __launch_bounds__(256) void k_name_link(int n_reads, const uint32_t *
         if (lane_id() == 0) { s_wcnt[w] = (unsigned)__popcll(m); s_wmax[w] = (unsigned)max(mx, 0); }
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]; if (tot) atomicAdd(&cnt->n_kept, tot);
-            const unsigned big = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])); if (big) atomicMax(&cnt->max_row, big);
+            unsigned tot = 0, big = 0;
+            for (int q = 0; q < NAMES_B / 64; ++q) { tot += s_wcnt[q]; big = max(big, s_wmax[q]); }
+            if (tot) atomicAdd(&cnt->n_kept, tot);
+            if (big) atomicMax(&cnt->max_row, big);
         }
         return;
     }
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void k_name_link(int n_reads, const uint32_t *
     const unsigned incl = (unsigned)wave_incl_scan_dpp((int)mine);
     if (lane_id() == 63) s_wcnt[w] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) { const unsigned tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]; s_base = tot ? atomicAdd(&cnt->n_clips, tot) : 0u; }
+    if (threadIdx.x == 0) { unsigned tot = 0; for (int q = 0; q < NAMES_B / 64; ++q) tot += s_wcnt[q]; s_base = tot ? atomicAdd(&cnt->n_clips, tot) : 0u; }
     __syncthreads();
     unsigned off = s_base + incl - mine; for (int q = 0; q < w; ++q) off += s_wcnt[q];
     for (unsigned e = lo + threadIdx.x; e < hi; e += blockDim.x) if (key_of(e, key)) keys[off++] = key;
@@ -1457,8 +1460,8 @@ void launch_dense_names(int n_reads, const uint32_t *name_id, uint32_t name_max,
 
 void launch_names(const GraphView &G, const ClipView &C, unsigned long long *clip_keys, const unsigned long long *arena_ctr, unsigned long long arena_size, hipStream_t s) {
     if (!G.n_reads) return;
-    const int nb_reads = (G.n_reads + 255) / 256;
-    hipLaunchKernelGGL(k_name_link, dim3(nb_reads + 1 + std::min(1024, nb_reads)), dim3(256), 0, s, G.n_reads, G.name, G.rows, G.name_head, G.name_link, G.cnt, arena_ctr, arena_size, C, clip_keys, nb_reads);
+    const int nb_reads = (G.n_reads + NAMES_B - 1) / NAMES_B;
+    hipLaunchKernelGGL(k_name_link, dim3(nb_reads + 1 + std::min(512, nb_reads)), dim3(NAMES_B), 0, s, G.n_reads, G.name, G.rows, G.name_head, G.name_link, G.cnt, arena_ctr, arena_size, C, clip_keys, nb_reads);
 }
 
 void launch_groups(const GraphView &G, double overlap_threshold, bool counted, hipStream_t s) {
