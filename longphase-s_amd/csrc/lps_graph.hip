@@ -1526,7 +1526,7 @@ void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, c
 
 void launch_correction(const GraphView &G, const int32_t *block, const uint8_t *bmulti, const int8_t *hp, uint8_t *nstate, double read_conf, double snp_conf,
                        uint32_t *cnt4, int32_t *out_ps, uint8_t *out_gt, hipStream_t s) {
-    hipLaunchKernelGGL(k_node_state, GRID(G.n_var, 256), 0, s, G.cnt, G.nodes, block, bmulti, hp, G.vtype_key, G.node_pairs, nstate);
+    hipLaunchKernelGGL(k_node_state, GRID(G.n_var, 1024), 0, s, G.cnt, G.nodes, block, bmulti, hp, G.vtype_key, G.node_pairs, nstate);
     hipLaunchKernelGGL(k_read_correction, dim3((G.n_reads + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, G.n_reads, G.rows, G.g_cnt, G.g_pack, nstate, read_conf, cnt4);
     hipLaunchKernelGGL(k_final, GRID(G.n_var, 256), 0, s, G.cnt, G.nodes, G.vpos, block, bmulti, cnt4, snp_conf, out_ps, out_gt);
 }
