@@ -1207,6 +1207,8 @@ __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, cons
                                                     int8_t *hp_v, int32_t *blk_v, size_t vstride,
                                                     const ScanState *st_b, const ScanState *st_e, const int32_t *match,
                                                     int32_t *chosen /*[seg]*/, int32_t *remap_from, int32_t *remap_to, unsigned *n_replayed) {
+    constexpr int SC_CH = 96;                                           // segments per lane whose states fit the LDS copy (6 144 segments = 393 k nodes; beyond: re-read)
+    __shared__ int s_open[SC_CH * 64], s_end[SC_CH * 64]; __shared__ uint8_t s_mv[SC_CH * 64];
     const int l = lane_id();
     const int N = (int)cnt->n_nodes;
     const int n_seg = (N + SCAN_SEG - 1) / SCAN_SEG;
@@ -1220,7 +1222,15 @@ __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, cons
         // ---- composition over [seg_lo, n_seg): lane l owns the run [s0, s1)
         const int chunk = (n_seg - seg_lo + 63) / 64, s0 = min(n_seg, seg_lo + l * chunk), s1 = min(n_seg, s0 + chunk);
         int f0 = 0, f1 = 1;                                          // this lane's run as a function of the incoming variant
-        for (int seg = s0; seg < s1; ++seg) { const int m = match[seg]; f0 = f0 == 2 ? 2 : next_variant(m, f0); f1 = f1 == 2 ? 2 : next_variant(m, f1); }
+        // (the loads of a run do not depend on what the run computes: sixteen are requested together - one at a time, as the plain loop compiles, a
+        // run of 80 segments costs 80 memory latencies, and this single wave is on every contig's critical path)
+        for (int seg = s0; seg < s1; seg += 16) {
+            int m[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) m[q] = match[min(seg + q, s1 - 1)];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) if (seg + q < s1) { f0 = f0 == 2 ? 2 : next_variant(m[q], f0); f1 = f1 == 2 ? 2 : next_variant(m[q], f1); }
+        }
         int vin = 0, v = v_in, J = 64;                               // J: first lane whose run holds a boundary nothing matches
         for (int j = 0; j < 64; ++j) {
             if (l == j) vin = v;
@@ -1233,12 +1243,24 @@ __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, cons
         int lim = l < J ? s1 : s0, pv_end = vin;
         if (l == J) { int pv = vin; lim = s1; for (int seg = s0; seg < s1; ++seg) { const int mv = next_variant(match[seg], pv); if (mv == 2) { lim = seg; break; } pv = mv; } pv_end = pv; }
         int has_set = 0, last_val = 0;                               // open block after the run: kept, or becomes last_val
+        const bool cached = chunk <= SC_CH;                           // the run's (variant, open block, block at the end) stay in LDS for the pass below
         {
             int pv = vin;
-            for (int seg = s0; seg < lim; ++seg) {
-                const int mv = next_variant(match[seg], pv), open_spec = st_b[seg * 2 + mv].bs, end_bs = st_e[seg * 2 + mv].bs;
-                if (end_bs != open_spec) { has_set = 1; last_val = end_bs; }
-                pv = mv;
+            for (int seg = s0; seg < lim; seg += 8) {                 // both variants' states of eight segments requested together, then chosen
+                int m[8], ob[8][2], eb[8][2];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int sg = min(seg + q, lim - 1);
+                    m[q] = match[sg]; ob[q][0] = st_b[sg * 2].bs; ob[q][1] = st_b[sg * 2 + 1].bs; eb[q][0] = st_e[sg * 2].bs; eb[q][1] = st_e[sg * 2 + 1].bs;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (seg + q >= lim) break;
+                    const int mv = next_variant(m[q], pv), open_spec = mv ? ob[q][1] : ob[q][0], end_bs = mv ? eb[q][1] : eb[q][0];
+                    if (end_bs != open_spec) { has_set = 1; last_val = end_bs; }
+                    if (cached) { const int at = (seg + q - s0) * 64 + l; s_mv[at] = (uint8_t)mv; s_open[at] = open_spec; s_end[at] = end_bs; }
+                    pv = mv;
+                }
             }
         }
         int cin = 0, cb = cur_bs;
@@ -1250,7 +1272,9 @@ __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, cons
         {
             int pv = vin, cur = cin;
             for (int seg = s0; seg < lim; ++seg) {
-                const int mv = next_variant(match[seg], pv), open_spec = st_b[seg * 2 + mv].bs, end_bs = st_e[seg * 2 + mv].bs;
+                int mv, open_spec, end_bs;
+                if (cached) { const int at = (seg - s0) * 64 + l; mv = s_mv[at]; open_spec = s_open[at]; end_bs = s_end[at]; }
+                else { mv = next_variant(match[seg], pv); open_spec = st_b[seg * 2 + mv].bs; end_bs = st_e[seg * 2 + mv].bs; }
                 chosen[seg] = mv; remap_from[seg] = open_spec >= 0 ? open_spec : -2; remap_to[seg] = cur;
                 cur = (end_bs == open_spec) ? cur : end_bs;          // the block open at b is still open at e
                 pv = mv;
