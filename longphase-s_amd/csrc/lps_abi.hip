@@ -1122,7 +1122,7 @@ static int run_phase(lps_ctx *c) {
         c->nodes.reserve(nG + 1); c->block.reserve(nG + 1);
         c->hp.reserve(nG + 1);
         c->erec.reserve((size_t)nG * A + 256);
-        c->hp_v.reserve(2 * ((size_t)nG + 64)); c->blk_v.reserve(2 * ((size_t)nG + 64)); c->seg_i32.reserve(4 * (size_t)scan_segments(nG) + 4); c->node_pairs.reserve(nG + 1); c->nstate.reserve(nG + 1);
+        c->hp_v.reserve(2 * ((size_t)nG + 64)); c->blk_v.reserve(2 * ((size_t)nG + 64)); c->seg_i32.reserve(8 * (size_t)scan_segments(nG) + 16); c->node_pairs.reserve(nG + 1); c->nstate.reserve(nG + 1);
         c->st_b.reserve(scan_state_bytes(nG)); c->st_e.reserve(scan_state_bytes(nG)); c->edge.reserve((size_t)nG * A * 4 + 16);
         // everything that has to start a run as zeros sits in ONE allocation cleared by one fill (a dozen separate fills cost ~4 us each)
         size_t zbytes = 0;

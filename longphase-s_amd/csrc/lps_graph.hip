@@ -1177,11 +1177,15 @@ __global__ __launch_bounds__(64) void k_scan_spec(const LpsCounters *cnt, const 
 
 // wave per segment boundary: is the state a variant of segment seg-1 ends with bit-identical to the state a variant of
 // segment seg starts its segment proper with?  bit (v_prev*2 + v) of match[seg].
-__global__ __launch_bounds__(256) void k_scan_match(const LpsCounters *cnt, const ScanState *st_b, const ScanState *st_e, int32_t *match) {
+// Also: the open-block ids of the four states of a segment side by side (bs[seg] = {start v0, start v1, end v0, end v1}) - k_scan_stitch's lone wave
+// reads them for every segment, and out of the 1.3-KB state records every read was a page of its own.
+__global__ __launch_bounds__(256) void k_scan_match(const LpsCounters *cnt, const ScanState *st_b, const ScanState *st_e, int32_t *match, int4 *bs) {
     const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), l = lane_id();
     const int N = (int)cnt->n_nodes;
     const int n_seg = (N + SCAN_SEG - 1) / SCAN_SEG;
-    if (seg < 1 || seg >= n_seg) return;
+    if (seg >= n_seg) return;
+    if (l == 0) bs[seg] = make_int4(st_b[seg * 2].bs, st_b[seg * 2 + 1].bs, st_e[seg * 2].bs, st_e[seg * 2 + 1].bs);
+    if (seg < 1) return;
     int bits = 0;
 #pragma unroll
     for (int vp = 0; vp < 2; ++vp)
@@ -1205,7 +1209,7 @@ __global__ __launch_bounds__(256) void k_scan_match(const LpsCounters *cnt, cons
 __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, const int32_t *nodes, const int32_t *vpos,
                                                     const uint8_t *erec, int A, int distance,
                                                     int8_t *hp_v, int32_t *blk_v, size_t vstride,
-                                                    const ScanState *st_b, const ScanState *st_e, const int32_t *match,
+                                                    const ScanState *st_b, const ScanState *st_e, const int32_t *match, const int4 *bs,
                                                     int32_t *chosen /*[seg]*/, int32_t *remap_from, int32_t *remap_to, unsigned *n_replayed) {
     constexpr int SC_CH = 96;                                           // segments per lane whose states fit the LDS copy (6 144 segments = 393 k nodes; beyond: re-read)
     __shared__ int s_open[SC_CH * 64], s_end[SC_CH * 64]; __shared__ uint8_t s_mv[SC_CH * 64];
@@ -1251,7 +1255,8 @@ __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, cons
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int sg = min(seg + q, lim - 1);
-                    m[q] = match[sg]; ob[q][0] = st_b[sg * 2].bs; ob[q][1] = st_b[sg * 2 + 1].bs; eb[q][0] = st_e[sg * 2].bs; eb[q][1] = st_e[sg * 2 + 1].bs;
+                    const int4 x = bs[sg];
+                    m[q] = match[sg]; ob[q][0] = x.x; ob[q][1] = x.y; eb[q][0] = x.z; eb[q][1] = x.w;
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -1274,7 +1279,7 @@ __global__ __launch_bounds__(64) void k_scan_stitch(const LpsCounters *cnt, cons
             for (int seg = s0; seg < lim; ++seg) {
                 int mv, open_spec, end_bs;
                 if (cached) { const int at = (seg - s0) * 64 + l; mv = s_mv[at]; open_spec = s_open[at]; end_bs = s_end[at]; }
-                else { mv = next_variant(match[seg], pv); open_spec = st_b[seg * 2 + mv].bs; end_bs = st_e[seg * 2 + mv].bs; }
+                else { mv = next_variant(match[seg], pv); const int4 x = bs[seg]; open_spec = mv ? x.y : x.x; end_bs = mv ? x.w : x.z; }
                 chosen[seg] = mv; remap_from[seg] = open_spec >= 0 ? open_spec : -2; remap_to[seg] = cur;
                 cur = (end_bs == open_spec) ? cur : end_bs;          // the block open at b is still open at e
                 pv = mv;
@@ -1534,7 +1539,7 @@ __global__ void k_scan_break_matches(int32_t *match, int segs, int every) {
 }
 
 void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, const int32_t *vpos, const uint8_t *erec,
-                      int A, int distance, int8_t *hp_v, int32_t *blk_v, void *st_b, void *st_e, int32_t *seg_i32 /*4*segs*/,
+                      int A, int distance, int8_t *hp_v, int32_t *blk_v, void *st_b, void *st_e, int32_t *seg_i32 /*8*segs + 16*/,
                       unsigned *n_replayed, int8_t *hp, int32_t *block, uint8_t *bmulti, int warm_tiles, hipStream_t s) {
     const int segs = scan_segments(n_var);
     // warm-up of the speculative walks: SCAN_WARM nodes as a rule.  With SV / MOD rows in the graph (sparser votes across the SNP<->MOD threshold,
@@ -1542,9 +1547,10 @@ void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, c
     const int warm = SCAN_WARM * std::max(1, warm_tiles);
     const size_t vstride = (size_t)n_var + 64;
     hipLaunchKernelGGL(k_scan_spec, dim3(segs), dim3(64), (size_t)(warm + SCAN_SEG) * A, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (ScanState *)st_b, (ScanState *)st_e, warm);
-    hipLaunchKernelGGL(k_scan_match, dim3((segs + 3) / 4), dim3(256), 0, s, cnt, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs);
+    int4 *seg_bs = reinterpret_cast<int4 *>(seg_i32 + 4 * (((size_t)segs + 3) / 4 * 4));     // behind the four int arrays, 16-byte aligned
+    hipLaunchKernelGGL(k_scan_match, dim3((segs + 3) / 4), dim3(256), 0, s, cnt, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs, seg_bs);
     if (const char *e = getenv("LPS_SCAN_FORCE_REPLAY")) { const int every = atoi(e); if (every > 0) hipLaunchKernelGGL(k_scan_break_matches, GRID(segs, 256), 0, s, seg_i32 + 3 * segs, segs, every); }
-    hipLaunchKernelGGL(k_scan_stitch, dim3(1), dim3(64), 0, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, n_replayed);
+    hipLaunchKernelGGL(k_scan_stitch, dim3(1), dim3(64), 0, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs, seg_bs, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, n_replayed);
     hipLaunchKernelGGL(k_scan_finalize, GRID(n_var, 256), 0, s, cnt, hp_v, blk_v, vstride, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, hp, block, bmulti);
 }
 
