@@ -32,9 +32,9 @@ static const char *kUsage =
     "   --workers-per-gpu=N  indexed input: contig groups in flight per GPU, each with its own context and stream (1)\n"
     "   --gpus=N         deal the contigs onto N GPUs (devices --gpu, --gpu+1, ... modulo the number present); needs the .bai index\n";
 
-// The commands end with _exit once their outputs are closed (the ROCm runtime's teardown and giving back tens of GB page by page cost 0.1 - 0.2 s; the
-// kernel does both for a process that simply ends); LPS_CLI_NO_FAST_EXIT=1 takes the full way out, e.g. under a profiler that reports from an exit handler.
-static bool full_teardown() { return getenv("LPS_CLI_NO_FAST_EXIT") != nullptr; }
+// The commands end with _exit once their outputs are closed and the GPU context is destroyed (the ROCm runtime's static teardown costs ~0.1 s;
+// LPS_CLI_NO_FAST_EXIT=1 takes the full way out, e.g. under a profiler that reports from an exit handler).  The context IS destroyed first: device
+// memory left to the process exit is given back by the driver from a work queue after the exit, and the next process on the GPU waits for it.
 
 static double g_main_entered = 0;
 
@@ -369,7 +369,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     for (lps_comm *cm : comms) if (cm) L.comm_destroy(cm);
     std::cerr << "\n";
     need_fasta();
-    if (full_teardown()) L.destroy(ctx);                                // otherwise the context ends with the process (main)
+    L.destroy(ctx);        // (25 ms.  Left to the process exit, the driver gives the device memory back from a work queue AFTER the exit - and the next process on the GPU pays for it)
     const double t_gpu = now();
     write_vcf(vcf_lines, prefix + ".vcf", res, vars, command, &iq);
     if (!sv_file.empty()) write_sv_vcf(sv_lines, prefix + "_SV.vcf", res, svt, command);          // PhasingProcess.cpp:191-203
@@ -380,7 +380,6 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     else fprintf(stderr, "vcf+fasta read %.3fs | bam inflate+walk %.3fs | wait for gpu context %.3fs | upload+phase %.3fs | write vcf %.3fs | total %.3fs\n", t_text - t_begin,
                  t_bam - t_text, t_ctx - t_bam, t_gpu - t_ctx, now() - t_gpu, now() - t_begin);
     if (getenv("LPS_CLI_DEBUG")) fprintf(stderr, "[cli] per-contig host time summed: names %.3fs, ranks %.3fs, table + reference %.3fs, push %.3fs, phase %.3fs\n", ns_names / 1e9, ns_rank / 1e9, ns_setup / 1e9, ns_push / 1e9, ns_phase / 1e9);
-    if (getenv("LPS_CLI_EXIT_PROBE")) { const double a = now(); gb.close_file(); const double b = now(); L.destroy(ctx); fprintf(stderr, "[cli] exit probe: munmap of the BAM %.3fs, lps_destroy %.3fs\n", b - a, now() - b); }
     if (getenv("LPS_CLI_DEBUG")) fprintf(stderr, "[cli] main entered at %.3f, left at %.3f (epoch seconds: what the caller's clock shows before and after is start-up and exit)\n", g_main_entered, epoch_now());
     fflush(stderr);
     if (getenv("LPS_CLI_NO_FAST_EXIT")) return 0;                       // e.g. under a profiler that writes its report from an exit handler
@@ -813,7 +812,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     std::cerr << "\n";
     need_fasta(); w.finish();
     t_deflate += now() - t_mark;
-    if (full_teardown()) L.destroy(ctx);
+    L.destroy(ctx);
     unsigned long long total = 0; for (int k = 0; k < 8; ++k) total += st_count[k];
     fprintf(stderr, "total alignment %llu | tagged %llu (HP1 %llu, HP2 %llu) | untagged: low mapq %llu, unmapped %llu, secondary %llu, supplementary %llu, no variant %llu, beyond last variant %llu, judged %llu\n",
             total, hp_count[1] + hp_count[2], hp_count[1], hp_count[2], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6], hp_count[0]);
@@ -1472,7 +1471,9 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             o << line << std::endl;
         }
     }
-    if (full_teardown()) { if (nctx) L.destroy(nctx); tgb.close_file(); ngb.close_file(); L.destroy(ctx); }
+    if (nctx) L.destroy(nctx);
+    tgb.close_file(); ngb.close_file();
+    L.destroy(ctx);
     unsigned long long total = 0; for (int k = 0; k < 8; ++k) total += st_count[k];
     fprintf(stderr, "somatic variant count(Flag): %llu\n", n_somatic_flag);
     fprintf(stderr, "total alignment %llu | HP1 %llu HP2 %llu HP1-1 %llu HP2-1 %llu HP3 %llu | judged untagged %llu | low mapq %llu unmapped %llu secondary %llu supplementary %llu no variant %llu beyond last variant %llu\n",
