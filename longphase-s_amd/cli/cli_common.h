@@ -85,13 +85,19 @@ struct Lps {
             }
 #define LPS_SYM(field, name) field = (decltype(field))dlsym(so, #name); if (!field) { error = "liblps_hip.so does not export " #name; return false; }
         LPS_SYM(default_params, lps_default_params) LPS_SYM(create, lps_create) LPS_SYM(destroy, lps_destroy) LPS_SYM(last_error, lps_last_error)
-        LPS_SYM(begin_chromosome, lps_begin_chromosome) LPS_SYM(set_variants, lps_set_variants) LPS_SYM(set_reference, lps_set_reference) LPS_SYM(set_extra_variants, lps_set_extra_variants) LPS_SYM(get_extra_result, lps_get_extra_result) LPS_SYM(set_read_votes, lps_set_read_votes) LPS_SYM(bgzf_deflate_fetch_range, lps_bgzf_deflate_fetch_range) LPS_SYM(bgzf_deflate_host, lps_bgzf_deflate_host) LPS_SYM(host_alloc, lps_host_alloc) LPS_SYM(host_free, lps_host_free)
+        LPS_SYM(begin_chromosome, lps_begin_chromosome) LPS_SYM(set_variants, lps_set_variants) LPS_SYM(set_reference, lps_set_reference) LPS_SYM(set_extra_variants,
+                lps_set_extra_variants) LPS_SYM(get_extra_result, lps_get_extra_result) LPS_SYM(set_read_votes, lps_set_read_votes) LPS_SYM(bgzf_deflate_fetch_range,
+                lps_bgzf_deflate_fetch_range) LPS_SYM(bgzf_deflate_host, lps_bgzf_deflate_host) LPS_SYM(host_alloc, lps_host_alloc) LPS_SYM(host_free, lps_host_free)
         LPS_SYM(push_bam_records, lps_push_bam_records) LPS_SYM(phase_chromosome, lps_phase_chromosome) LPS_SYM(haplotag_chromosome, lps_haplotag_chromosome)
         LPS_SYM(abi_version, lps_abi_version) LPS_SYM(bgzf_load, lps_bgzf_load) LPS_SYM(bgzf_read, lps_bgzf_read) LPS_SYM(bam_scan, lps_bam_scan)
-        LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets, lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range) LPS_SYM(device_count, lps_device_count) LPS_SYM(set_stage_timing, lps_set_stage_timing) LPS_SYM(haplotag_write_bgzf, lps_haplotag_write_bgzf) LPS_SYM(bgzf_deflate_fetch, lps_bgzf_deflate_fetch)
+        LPS_SYM(bam_record_tids, lps_bam_record_tids) LPS_SYM(bam_names, lps_bam_names) LPS_SYM(push_bam_resident, lps_push_bam_resident) LPS_SYM(bam_record_offsets,
+                lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range) LPS_SYM(device_count, lps_device_count) LPS_SYM(set_stage_timing,
+                lps_set_stage_timing) LPS_SYM(haplotag_write_bgzf, lps_haplotag_write_bgzf) LPS_SYM(bgzf_deflate_fetch, lps_bgzf_deflate_fetch)
         LPS_SYM(somatic_extract_normal, lps_somatic_extract_normal) LPS_SYM(somatic_extract_tumor, lps_somatic_extract_tumor) LPS_SYM(somatic_tag_chromosome, lps_somatic_tag_chromosome)
         LPS_SYM(somatic_write_bgzf, lps_somatic_write_bgzf) LPS_SYM(bgzf_load_fd, lps_bgzf_load_fd) LPS_SYM(dump_graph, lps_dump_graph) LPS_SYM(dump_votes, lps_dump_votes)
-        LPS_SYM(comm_create_all, lps_comm_create_all) LPS_SYM(comm_bcast, lps_comm_bcast) LPS_SYM(comm_bcast_to_device, lps_comm_bcast_to_device) LPS_SYM(set_variants_device, lps_set_variants_device) LPS_SYM(comm_destroy, lps_comm_destroy) LPS_SYM(comm_size, lps_comm_size) LPS_SYM(comm_last_error, lps_comm_last_error)
+        LPS_SYM(comm_create_all, lps_comm_create_all) LPS_SYM(comm_bcast, lps_comm_bcast) LPS_SYM(comm_bcast_to_device,
+                lps_comm_bcast_to_device) LPS_SYM(set_variants_device, lps_set_variants_device) LPS_SYM(comm_destroy, lps_comm_destroy) LPS_SYM(comm_size,
+                lps_comm_size) LPS_SYM(comm_last_error, lps_comm_last_error)
 #undef LPS_SYM
         if (abi_version() != LPS_ABI_VERSION) { error = "liblps_hip.so has a different ABI version than this binary was built for"; return false; }
         return true;

@@ -221,7 +221,8 @@ static void rewrite_vcf(const std::vector<std::string> &lines, const std::string
         size_t j = i; while (j < lines.size() && !is_header(lines[j])) ++j;      // a run of records
         const size_t n = j - i; const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, g_text_threads), n / 4096 + 1));
         std::vector<std::string> part((size_t)nt); std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { const size_t a = i + n * (size_t)t / (size_t)nt, b = i + n * (size_t)(t + 1) / (size_t)nt; part[(size_t)t].reserve((b - a) * 96); for (size_t k = a; k < b; ++k) record(lines[k], part[(size_t)t]); });
+        for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { const size_t a = i + n * (size_t)t / (size_t)nt,
+                b = i + n * (size_t)(t + 1) / (size_t)nt; part[(size_t)t].reserve((b - a) * 96); for (size_t k = a; k < b; ++k) record(lines[k], part[(size_t)t]); });
         for (auto &x : th) x.join();
         for (const std::string &x : part) o.write(x.data(), (std::streamsize)x.size());
         i = j;

@@ -181,7 +181,8 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::map<lps_ctx *, std::map<std::string, std::unique_ptr<NamesAhead>>> ahead; std::mutex ahead_mu;
     static std::atomic<long long> ns_names{0}, ns_rank{0}, ns_setup{0}, ns_push{0}, ns_phase{0}, ns_merge{0};      // where a contig's host time goes (LPS_CLI_DEBUG)
     auto tick_ns = [] { return std::chrono::steady_clock::now(); };
-    auto tock_ns = [](std::atomic<long long> &acc, std::chrono::steady_clock::time_point t0) { acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
+    auto tock_ns = [](std::atomic<long long> &acc,
+            std::chrono::steady_clock::time_point t0) { acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
     auto run_contig = [&](lps_ctx *ctx, GpuBam &gb, const std::string &chr, const Packed &tab) {   // PhasingProcess.cpp:113-173, one contig on one GPU
         ChrVariants &cv = vars[chr];
         need_fasta();
@@ -486,7 +487,8 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
             if (!in.z.data) die("ERROR: out of memory");
             madvise(in.z.data, in_cap, MADV_HUGEPAGE);
             std::vector<std::thread> th; const int nt = std::max(1, std::min(threads, 8)); const size_t slice = (in_cap + nt - 1) / nt;
-            for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { const size_t a = std::min(in_cap, slice * t), e = std::min(in_cap, a + slice); for (size_t p = a; p < e; p += 4096) in.z.data[p] = 0; });
+            for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { const size_t a = std::min(in_cap, slice * t), e = std::min(in_cap,
+                    a + slice); for (size_t p = a; p < e; p += 4096) in.z.data[p] = 0; });
             for (auto &x : th) x.join(); }
         in.z.size = (size_t)total;
         if (L.bgzf_read(ctx, 0, total, in.z.data)) die(std::string("ERROR: ") + L.last_error(ctx));
@@ -969,7 +971,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     const double t_in = now();
     std::atomic<long long> ns_p1{0}, ns_p2{0}, ns_host{0}, ns_p3{0}, ns_splice{0}, ns_append{0}, ns_prep{0}, ns_purity{0}, ns_finish{0}, ns_gpu_deflate{0};      // where the time goes (summed over workers)
     auto tick = [] { return std::chrono::steady_clock::now(); };
-    auto tock = [](std::atomic<long long> &acc, std::chrono::steady_clock::time_point t0) { acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
+    auto tock = [](std::atomic<long long> &acc,
+            std::chrono::steady_clock::time_point t0) { acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
     SomaticThr T = somatic_thresholds(purity);
     auto announce = [&]() { if (purity <= 0 || purity > 1.0) std::cerr << "[WARNING] tumor purity is not in the range of 0.0 to 1.0: " << purity << "\n[WARNING] setting default parameters (tier " << T.tier << ")\n";
         else std::cerr << "setting filter params (tier " << T.tier << ") with tumor purity: " << purity << "\n"; };
@@ -1108,7 +1111,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             te.n_ps = tnps.data(); te.ps_min = psmin.data(); te.end_pos = endp.data(); te.read_len = rlen.data(); te.has_site = has.data();
             { std::vector<uint32_t> tid(nt, 0);
               if (L.begin_chromosome(ctx) || L.set_variants(ctx, &vt) || L.set_reference(ctx, sq.data(), (int64_t)sq.size()) ||
-                  (resident ? L.push_bam_resident(ctx, t_range.first, t_range.second, tid.data()) : L.push_bam_records(ctx, tbase, (int64_t)(tc.hi - tc.lo), tc.rec_off.data(), (int64_t)nt, tid.data()))) fail();
+                  (resident ? L.push_bam_resident(ctx, t_range.first, t_range.second, tid.data()) : L.push_bam_records(ctx, tbase, (int64_t)(tc.hi - tc.lo),
+                          tc.rec_off.data(), (int64_t)nt, tid.data()))) fail();
               tumor_pushed = true;
               }
             size_t pcap = nt * 4 + 1024, wcap = nt * 64 + 4096;
@@ -1425,7 +1429,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     for (int phase = estimate ? 0 : 1; phase < 2; ++phase) {
         if (phase == 1 && estimate) { auto tp = tick(); purity = estimate_purity(pdata, p_initial, lcvf, prefix); T = somatic_thresholds(purity); announce(); tock(ns_purity, tp); }
         std::vector<ContigAcc> acc(chr_vec.size()); std::mutex mu; std::condition_variable cv;
-        auto run_share = [&](int g) { for (size_t i : share[(size_t)g]) { do_contig(wctx[(size_t)g], chr_vec[i], phase, acc[i]); { std::lock_guard<std::mutex> lk(mu); acc[i].ready = true; } cv.notify_all(); } };
+        auto run_share = [&](int g) { for (size_t i : share[(size_t)g]) { do_contig(wctx[(size_t)g], chr_vec[i], phase,
+                acc[i]); { std::lock_guard<std::mutex> lk(mu); acc[i].ready = true; } cv.notify_all(); } };
         std::vector<std::thread> workers;
         if (n_workers > 1) for (int g = 0; g < n_workers; ++g) workers.emplace_back(run_share, g);
         for (size_t i = 0; i < chr_vec.size(); ++i) {                    // merge (and write) in contig order
@@ -1436,7 +1441,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             if (write_log) flog << A.flog.str();
             if (!A.som.empty()) somatic_pos[chr_vec[i]].swap(A.som);
             n_somatic_flag += A.n_flag; for (int k = 0; k < 9; ++k) hp_hist[k] += A.hp_hist[k]; for (int k = 0; k < 8; ++k) st_count[k] += A.st_count[k];
-            { auto ta = tick(); if (A.out_bytes) { if (A.deflated) { if (!raw_started) { w.flush_partial(); raw_started = true; } w.write_raw(A.out, A.out_bytes); } else w.append(A.out, A.out_bytes); } tock(ns_append, ta); }
+            { auto ta = tick(); if (A.out_bytes) { if (A.deflated) { if (!raw_started) { w.flush_partial(); raw_started = true; } w.write_raw(A.out,
+                    A.out_bytes); } else w.append(A.out, A.out_bytes); } tock(ns_append, ta); }
             free(A.out); A.out = nullptr; A.flog.str(std::string());
         }
         for (auto &x : workers) x.join();

@@ -90,11 +90,15 @@ struct lps_ctx {
     const uint32_t *name_p = nullptr; size_t name_cap = 0; bool key64 = false, scan_done = false; GraphView G{};
     // nodes / graph
     DevBuf<uint32_t> name_head, var_cnt, var_del, var_del2, vtype_key, node_of, var_off, node_off, node_cap, node_end, bsum, cnt4; DevBuf<uint8_t> bmulti;
-    DevBuf<int32_t> nodes, block; DevBuf<uint8_t> erec; DevBuf<unsigned> clip_stats; DevBuf<int8_t> hp, hp_v; DevBuf<int32_t> blk_v, seg_i32; DevBuf<char> st_b, st_e; DevBuf<uint32_t> node_pairs; DevBuf<uint8_t> nstate;
+    DevBuf<int32_t> nodes, block; DevBuf<uint8_t> erec; DevBuf<unsigned> clip_stats; DevBuf<int8_t> hp, hp_v; DevBuf<int32_t> blk_v, seg_i32; DevBuf<char> st_b,
+            st_e; DevBuf<uint32_t> node_pairs; DevBuf<uint8_t> nstate;
     DevBuf<unsigned long long> nkeys, nkeys_s; DevBuf<uint32_t> nvals, nvals_s;   // node-major lists (keys: 32 bits each when name rank + row index fit, else 64)
     DevBuf<float> edge;
     DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
-    DevBuf<uint8_t> hap_status, hap_nps, v_role, v_derive, v_tkind, read_hp; DevBuf<int32_t> site, t_end, t_len, t_pair_site, t_pair_read, t_win_site; DevBuf<uint8_t> t_hp, t_has, t_pair_hp, t_win_allele, t_win_base; DevBuf<int16_t> t_win_off; DevBuf<unsigned long long> t_ctr; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1, hap_d2; bool has_somatic = false;
+    DevBuf<uint8_t> hap_status, hap_nps, v_role, v_derive, v_tkind, read_hp; DevBuf<int32_t> site, t_end, t_len, t_pair_site, t_pair_read,
+            t_win_site; DevBuf<uint8_t> t_hp, t_has, t_pair_hp, t_win_allele,
+            t_win_base; DevBuf<int16_t> t_win_off; DevBuf<unsigned long long> t_ctr; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1,
+            hap_d2; bool has_somatic = false;
     DevBuf<char> temp; size_t temp_bytes = 0;
     LpsCounters *d_cnt = nullptr; LpsCounters h_cnt{}; unsigned h_stats[4]{};
     // timing
@@ -137,13 +141,15 @@ static void h2d_staged(lps_ctx *c, uint8_t *dst, const ZSource &src, size_t n, h
         else { std::vector<uint8_t> tmp(n); if (!src.read(0, n, tmp.data())) throw std::string("cannot read the file"); HIP_TRY(hipMemcpyAsync(dst, tmp.data(), n, hipMemcpyHostToDevice, st)); HIP_TRY(hipStreamSynchronize(st)); }
         raise(n); return;
     }
-    if (!c->stage[0]) { for (int k = 0; k < 2; ++k) { HIP_TRY(hipHostMalloc((void **)&c->stage[k], CH, hipHostMallocDefault)); HIP_TRY(hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming)); } c->stage_bytes = CH; }
+    if (!c->stage[0]) { for (int k = 0; k < 2; ++k) { HIP_TRY(hipHostMalloc((void **)&c->stage[k], CH,
+            hipHostMallocDefault)); HIP_TRY(hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming)); } c->stage_bytes = CH; }
     int k = 0; bool used[2] = {false, false}; size_t end_of[2] = {0, 0};
     for (size_t off = 0; off < n; off += CH, k ^= 1) {
         const size_t len = std::min(CH, n - off);
         if (used[k]) { HIP_TRY(hipEventSynchronize(c->stage_ev[k])); raise(end_of[k]); }       // (pieces complete in order: everything before end_of[k] is in place)
         const int nt = 4; std::thread th[nt]; const size_t part = (len + nt - 1) / nt; bool ok[nt];
-        for (int t = 0; t < nt; ++t) th[t] = std::thread([&, t] { const size_t a = std::min(len, part * t), b = std::min(len, a + part); ok[t] = b <= a || src.read(off + a, b - a, c->stage[k] + a); });
+        for (int t = 0; t < nt; ++t) th[t] = std::thread([&, t] { const size_t a = std::min(len, part * t), b = std::min(len, a + part); ok[t] = b <= a ||
+                src.read(off + a, b - a, c->stage[k] + a); });
         for (int t = 0; t < nt; ++t) th[t].join();
         for (int t = 0; t < nt; ++t) if (!ok[t]) throw std::string("cannot read the file");
         HIP_TRY(hipMemcpyAsync(dst + off, c->stage[k], len, hipMemcpyHostToDevice, st));
@@ -525,7 +531,8 @@ int lps_push_reads_device(lps_ctx *c, const lps_read_batch *b) {
         hipStream_t s = c->stream;
         uint64_t ends[6];                                                // first and last entry of the three offset arrays
         const uint64_t *offs[3] = {b->cigar_off, b->seq_off, b->qual_off};
-        for (int k = 0; k < 3; ++k) { HIP_TRY(hipMemcpyAsync(&ends[2 * k], offs[k], 8, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(&ends[2 * k + 1], offs[k] + n, 8, hipMemcpyDeviceToHost, s)); }
+        for (int k = 0; k < 3; ++k) { HIP_TRY(hipMemcpyAsync(&ends[2 * k], offs[k], 8, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(&ends[2 * k + 1], offs[k] + n,
+                8, hipMemcpyDeviceToHost, s)); }
         int32_t start_ends[2] = {0, 0};                                  // first and last start of the batch: the order ACROSS pushes is checked here, inside a batch by k_batch_check
         if (n) { HIP_TRY(hipMemcpyAsync(&start_ends[0], b->ref_start, 4, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(&start_ends[1], b->ref_start + (n - 1), 4, hipMemcpyDeviceToHost, s)); }
         c->bam_err.reserve(2);
@@ -571,7 +578,8 @@ int lps_bam_scan_range(lps_ctx *c, int64_t first_record_offset, int64_t end_offs
         HIP_TRY(hipSetDevice(c->device));
         hipStream_t s = c->stream; c->bam_err.reserve(1); c->scan_nout.reserve(1);
         uint64_t n = 0;
-        const int rc = bam_scan_records(c->file.p, (uint64_t)first_record_offset, (uint64_t)end_offset, n_ref, c->rcand, c->wg_cnt, c->wg_off, c->temp, c->temp_bytes, c->bam_err.p, c->scan_nout.p, &n, s);
+        const int rc = bam_scan_records(c->file.p, (uint64_t)first_record_offset, (uint64_t)end_offset, n_ref, c->rcand, c->wg_cnt, c->wg_off, c->temp, c->temp_bytes,
+                c->bam_err.p, c->scan_nout.p, &n, s);
         c->n_rec_all = 0; c->names_ready = false;
         if (rc == -3 || first_record_offset == end_offset) { *n_records = 0; if (rc == -3 && first_record_offset != end_offset) return fail(c, "lps_bam_scan: no BAM record found in a non-empty range"); return 0; }
         if (rc) return fail(c, rc == -4 ? "lps_bam_scan: the BAM record chain is broken (corrupt file)" : "lps_bam_scan: stream too large");
@@ -721,7 +729,9 @@ static bool bgzf_walk_parallel(const ZSource &z, uint64_t n, std::vector<Inflate
         seed[(size_t)k] = found;
     }
     std::vector<std::vector<InflateBlock>> part((size_t)T); std::vector<uint64_t> ut((size_t)T, 0); std::vector<char> ok((size_t)T, 0); std::vector<std::thread> th;
-    for (int k = 0; k < T; ++k) th.emplace_back([&, k] { part[(size_t)k].reserve((size_t)((seed[(size_t)k + 1] - seed[(size_t)k]) / 16384 + 16)); ok[(size_t)k] = bgzf_walk_piece(z, n, seed[(size_t)k], seed[(size_t)k + 1], part[(size_t)k], ut[(size_t)k]); });
+    for (int k = 0; k < T; ++k) th.emplace_back([&,
+            k] { part[(size_t)k].reserve((size_t)((seed[(size_t)k + 1] - seed[(size_t)k]) / 16384 + 16)); ok[(size_t)k] = bgzf_walk_piece(z, n, seed[(size_t)k],
+            seed[(size_t)k + 1], part[(size_t)k], ut[(size_t)k]); });
     for (auto &t : th) t.join();
     size_t total = 0;
     for (int k = 0; k < T; ++k) { if (!ok[(size_t)k]) return false; total += part[(size_t)k].size(); }
@@ -854,7 +864,8 @@ int lps_bgzf_deflate_host(lps_ctx *c, const uint8_t *bytes, int64_t n_bytes, int
     return 0;
 }
 
-static int write_tagged_bgzf(lps_ctx *c, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, const uint8_t *prefix, int64_t prefix_bytes, int64_t *out_bytes, int somatic_tags) {
+static int write_tagged_bgzf(lps_ctx *c, const uint8_t *status, const uint8_t *hp, const int32_t *ps, const int32_t *pq, const uint8_t *prefix, int64_t prefix_bytes,
+        int64_t *out_bytes, int somatic_tags) {
     if (!c || !out_bytes || prefix_bytes < 0 || (prefix_bytes && !prefix)) return -1;
     if (c->read_mode != 3 || c->cur_first < 0) return fail(c, "lps_haplotag_write_bgzf / lps_somatic_write_bgzf: needs exactly one lps_push_bam_resident in this chromosome");
     const size_t n = (size_t)c->cur_count;
@@ -1069,7 +1080,8 @@ static int run_late(lps_ctx *c, bool with_cnv) {
         c->cnv_flag.reserve(nR + 1); c->cnv_idx.reserve(nR + 1); c->cnv_list.reserve(nR + 1); c->cnv_nlist.reserve(4);
         c->cnv_fn.reserve(nR + 1); c->cnv_pre.reserve(nR + 1);
         CnvScratch W{c->cnv_flag.p, c->cnv_idx.p, c->cnv_list.p, c->cnv_nlist.p, c->cnv_fn.p, c->cnv_pre.p};
-        launch_cnv_filter(c->d_cnt, nR, nV, c->rows.p, c->deleted.p, c->obs.p, c->g_vpos, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, W, c->var_del2.p, c->temp.p, c->temp_bytes, s);
+        launch_cnv_filter(c->d_cnt, nR, nV, c->rows.p, c->deleted.p, c->obs.p, c->g_vpos, c->cnv_start.p, c->cnv_end.p, c->agg_sum.p, c->agg_cnt.p, c->miss.p, W,
+                c->var_del2.p, c->temp.p, c->temp_bytes, s);
     }
     // ---- a10 node set (numbered before the host looked at the counters when no CNV filter was expected), graph view of the rows, node-major lists,
     //      merged rows of reads with several alignments
@@ -1082,7 +1094,8 @@ static int run_late(lps_ctx *c, bool with_cnv) {
     launch_edges(G, c->m_bits, c->a_bits, c->key64, P.edge_weight, P.edge_threshold, s);
     // ---- a13 vote scan
     mark(c, ST_SCAN);
-    launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->g_vpos, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2, c->hp.p, c->block.p, c->bmulti.p, c->nX ? 2 : 1, s);
+    launch_vote_scan(c->d_cnt, nV, c->nodes.p, c->g_vpos, c->erec.p, A, P.distance, c->hp_v.p, c->blk_v.p, c->st_b.p, c->st_e.p, c->seg_i32.p, c->clip_stats.p + 2,
+            c->hp.p, c->block.p, c->bmulti.p, c->nX ? 2 : 1, s);
     // ---- a14/a15 read correction + export
     mark(c, ST_CORR);
     launch_correction(G, c->block.p, c->bmulti.p, c->hp.p, c->nstate.p, P.read_confidence, P.snp_confidence, c->cnt4.p, c->out_ps.p, c->out_gt.p, s);
@@ -1255,7 +1268,8 @@ static size_t enqueue_result_copy(lps_ctx *c) {
     const size_t span = (size_t)((uint8_t *)c->out_gt.p - (uint8_t *)c->out_ps.p) + (size_t)c->nG;
     const size_t n16 = (span + 15) / 16;                                   // the zero pool's slots are padded to 256 bytes: the rounded span stays inside it
     if (n16 * 16 > c->h_res_bytes) { if (c->h_res) HIP_TRY(hipHostFree(c->h_res)); c->h_res = nullptr; c->h_res_bytes = n16 * 16 + span / 4 + 4096; HIP_TRY(hipHostMalloc((void **)&c->h_res, c->h_res_bytes)); }
-    hipLaunchKernelGGL(k_result_out, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, (const uint4 *)c->out_ps.p, (uint4 *)c->h_res, n16, c->d_cnt, c->h_cnt_pin, c->clip_stats.p, c->h_stats_pin);
+    hipLaunchKernelGGL(k_result_out, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, (const uint4 *)c->out_ps.p, (uint4 *)c->h_res, n16, c->d_cnt,
+            c->h_cnt_pin, c->clip_stats.p, c->h_stats_pin);
     return span;
 }
 static void deliver_result(lps_ctx *c, lps_phase_result *out) {
@@ -1634,7 +1648,8 @@ int lps_somatic_extract_tumor(lps_ctx *c, lps_tumor_extract_result *out) {
         if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) return fail(c, "Alignment find unsupported CIGAR operation", -2);
         out->n_pairs = (int64_t)ctr[0]; out->n_windows = (int64_t)ctr[1];
         const size_t np_ = (size_t)std::min<int64_t>(out->n_pairs, out->pair_capacity), nw_ = (size_t)std::min<int64_t>(out->n_windows, out->win_capacity);
-        if (np_) { HIP_TRY(hipMemcpyAsync(out->pair_site, T.pair_site, np_ * 4, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->pair_read, T.pair_read, np_ * 4, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->pair_base_hp, T.pair_hp, np_, hipMemcpyDeviceToHost, s)); }
+        if (np_) { HIP_TRY(hipMemcpyAsync(out->pair_site, T.pair_site, np_ * 4, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->pair_read, T.pair_read, np_ * 4,
+                hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->pair_base_hp, T.pair_hp, np_, hipMemcpyDeviceToHost, s)); }
         if (nw_) { HIP_TRY(hipMemcpyAsync(out->win_site, T.win_site, nw_ * 4, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->win_allele, T.win_allele, nw_, hipMemcpyDeviceToHost, s));
                    HIP_TRY(hipMemcpyAsync(out->win_offset, T.win_offset, nw_ * 2, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->win_base, T.win_base, nw_, hipMemcpyDeviceToHost, s)); }
         HIP_TRY(hipEventRecord(c->ev_end, s));

@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(256) k_bam_core(BamView B, int n, int at, int3
     if (i == n) { cig_cnt[n] = 0; return; }
     const uint64_t ro = B.rec_off[i];
     unsigned e = 0;
-    if (ro < 4 || ro + 32 > B.push_bytes) { atomicOr(err, LPS_BAM_ERR_BOUNDS); cig_cnt[i] = 0; cig_src[i] = B.push_base; ref_start[at + i] = 0; l_qseq[at + i] = 0; flag[at + i] = 4; mapq[at + i] = 0; seq_off[at + i] = qual_off[at + i] = B.push_base; return; }
+    if (ro < 4 || ro + 32 > B.push_bytes) { atomicOr(err,
+            LPS_BAM_ERR_BOUNDS); cig_cnt[i] = 0; cig_src[i] = B.push_base; ref_start[at + i] = 0; l_qseq[at + i] = 0; flag[at + i] = 4; mapq[at + i] = 0; seq_off[at + i] = qual_off[at + i] = B.push_base; return; }
     const uint8_t *r = B.blob + B.push_base + ro;
     const uint32_t block_size = ld_u32_unaligned(r - 4);
     const int32_t pos = (int32_t)ld_u32_unaligned(r + 4);
@@ -271,8 +272,10 @@ __device__ __forceinline__ uint8_t som_tag_byte(uint32_t b, uint32_t hp, int32_t
     if (ps != -1) { if (b < 7u) return b == 0 ? (uint8_t)'P' : b == 1 ? (uint8_t)'S' : b == 2 ? (uint8_t)'i' : (uint8_t)((uint32_t)ps >> (8 * (b - 3u))); b -= 7u; }
     return b == 0 ? (uint8_t)'P' : b == 1 ? (uint8_t)'Q' : b == 2 ? (uint8_t)'i' : (uint8_t)((uint32_t)pq >> (8 * (b - 3u)));
 }
-__global__ void __launch_bounds__(256) k_tag_sizes(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, const int32_t *ps, int som, unsigned long long *new_len,
-                                                   uint2 *spans /* [n][4] (offset from refID, length), sorted by offset, length 0 = none; [3] = the CG field, re-appended at the end */, unsigned *err) {
+__global__ void __launch_bounds__(256) k_tag_sizes(const uint8_t *d, const uint64_t *rec, uint32_t n, const uint8_t *status, const uint8_t *hp, const int32_t *ps,
+        int som, unsigned long long *new_len,
+                                                   uint2 *spans /* [n][4] (offset from refID, length), sorted by offset, length 0 = none; [3] = the CG field,
+                                                           re-appended at the end */, unsigned *err) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i > n) return;
     if (i == n) { new_len[n] = 0; return; }
@@ -314,7 +317,12 @@ __global__ void __launch_bounds__(256) k_tag_write(const uint8_t *d, const uint6
             uint2 lo = {0xffffffffu, 0};                                  // the pass-th smallest offset among the spans in use
             const uint2 all[4] = {s0, s1, s2, cg};
             int taken = 0;
-            for (int a = 0; a < 4; ++a) if (all[a].y) { int before = 0; for (int b2 = 0; b2 < 4; ++b2) if (all[b2].y && (all[b2].x < all[a].x)) ++before; if (before == pass) { lo = all[a]; taken = 1; } }
+            for (int a = 0; a < 4; ++a) {
+                if (!all[a].y) continue;
+                int before = 0;
+                for (int b2 = 0; b2 < 4; ++b2) if (all[b2].y && all[b2].x < all[a].x) ++before;
+                if (before == pass) { lo = all[a]; taken = 1; }
+            }
             if (taken && src >= lo.x) src += lo.y;
         }
         o[4 + j] = d[r + src];

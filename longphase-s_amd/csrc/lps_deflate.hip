@@ -177,7 +177,8 @@ __global__ void __launch_bounds__(64) k_bgzf_deflate(const uint8_t *src, uint64_
                 const uint8_t v = qi[k]; acc |= (uint64_t)S.code[v] << nacc; nacc += S.len[v];
                 if (nacc >= 32) { if (first) { atomicOr(&w[wpos], (uint32_t)acc); first = false; } else w[wpos] = (uint32_t)acc; ++wpos; acc >>= 32; nacc -= 32; }
             }
-            if (lane == 63) { acc |= (uint64_t)S.code[256] << nacc; nacc += S.len[256]; if (nacc >= 32) { if (first) { atomicOr(&w[wpos], (uint32_t)acc); first = false; } else w[wpos] = (uint32_t)acc; ++wpos; acc >>= 32; nacc -= 32; } }
+            if (lane == 63) { acc |= (uint64_t)S.code[256] << nacc; nacc += S.len[256]; if (nacc >= 32) { if (first) { atomicOr(&w[wpos],
+                    (uint32_t)acc); first = false; } else w[wpos] = (uint32_t)acc; ++wpos; acc >>= 32; nacc -= 32; } }
             if (nacc) atomicOr(&w[wpos], (uint32_t)acc);
         }
         bitpos += header_bits + S.data_bits;                              // uniform: S.* were written before the barrier above

@@ -454,7 +454,8 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                         {
                             const bool i0 = lo < hi, i1 = lo + 1 < hi, i2 = lo + 2 < hi, ih = hi < end;
                             const uint32_t v0 = i0 ? X.mod_pack[lo] : 0u, v1 = i1 ? X.mod_pack[lo + 1] : 0u, v2 = i2 ? X.mod_pack[lo + 2] : 0u, vh = ih ? X.mod_pack[hi] : 0u;
-                            if (i0 && v0 >= key) { have = true; hit = v0; } else if (i1 && v1 >= key) { have = true; hit = v1; } else if (i2 && v2 >= key) { have = true; hit = v2; } else if (ih) { have = true; hit = vh; }
+                            if (i0 && v0 >= key) { have = true; hit = v0; } else if (i1 && v1 >= key) { have = true; hit = v1; } else if (i2 &&
+                                    v2 >= key) { have = true; hit = v2; } else if (ih) { have = true; hit = vh; }
                         }
                         if (have && (hit >> 2) == name) {
                             const unsigned f = hit & 3u;
@@ -537,7 +538,8 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                         out[og] = (ka < kb) ? A[i] : B[j];
                     }
                 }
-                if (l < 4 && SEL4(l, nB) > 0) { RowDesc d = O.rows[r0 + l]; d.off = (uint32_t)(arena_lo + off2 + (unsigned)SEL4(l, cm)); d.cnt = SEL4(l, nA) + SEL4(l, nB); d.flags = 0; O.rows[r0 + l] = d; }
+                if (l < 4 && SEL4(l, nB) > 0) { RowDesc d = O.rows[r0 + l]; d.off = (uint32_t)(arena_lo + off2 + (unsigned)SEL4(l, cm)); d.cnt = SEL4(l, nA) + SEL4(l,
+                        nB); d.flags = 0; O.rows[r0 + l] = d; }
             }
         }
         wave_sync();
@@ -545,7 +547,8 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
     if (l < nq && general) redo[atomicAdd(n_redo, 1u)] = (uint32_t)(r0 + l);   // (rare: one atomic per alignment that is left to the general walker)
 }
 
-void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int32_t *x0, uint32_t *redo, unsigned *n_redo, int mapping_quality, LpsCounters *cnt, hipStream_t s) {
+void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int32_t *x0, uint32_t *redo, unsigned *n_redo, int mapping_quality,
+        LpsCounters *cnt, hipStream_t s) {
     if (R.n <= 0) return;
     (void)hipMemsetAsync(n_redo, 0, sizeof(unsigned), s);
     hipLaunchKernelGGL(k_read_x0, dim3((R.n + 255) / 256), dim3(256), 0, s, X, R.ref_start, R.n, x0);

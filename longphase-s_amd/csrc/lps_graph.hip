@@ -298,7 +298,8 @@ __device__ __forceinline__ int cnv_obs_step(int ci, int K, int U, int j, bool ho
 // (rate >= 0.7) - nearly all - move the cursor exactly like passes 1/2 and erase nothing; the others replay the reference's loop on the
 // loaded values.
 template <bool ERASE>
-__global__ __launch_bounds__(256) void k_cnv_rows(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *pre, const RowDesc *rows, ObsRec *obs, const int32_t *vpos, const int32_t *cs, const int32_t *ce,
+__global__ __launch_bounds__(256) void k_cnv_rows(const LpsCounters *cnt, const uint32_t *list, const uint32_t *n_list, const uint8_t *pre, const RowDesc *rows,
+        ObsRec *obs, const int32_t *vpos, const int32_t *cs, const int32_t *ce,
                                                   const double *miss, uint8_t *fn, uint32_t *var_del2) {
     const int l = lane_id(), grp = l / ROW_G, sl = l % ROW_G;
     const unsigned k = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS_PER_WAVE + grp;
@@ -427,7 +428,8 @@ __global__ __launch_bounds__(VSCAN_B) void k_var_sums(int n_var, const uint32_t 
     const uint32_t a = wave_sum(x.nodes), b = wave_sum(x.cap), c = wave_sum(x.valid);
     if (lane_id() == 0) { s_a[w] = a; s_b[w] = b; s_c[w] = c; }
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t A = 0, B = 0, Cc = 0; for (int q = 0; q < VSCAN_B / 64; ++q) { A += s_a[q]; B += s_b[q]; Cc += s_c[q]; } bsum[3 * blockIdx.x] = A; bsum[3 * blockIdx.x + 1] = B; bsum[3 * blockIdx.x + 2] = Cc; }
+    if (threadIdx.x == 0) { uint32_t A = 0, B = 0,
+            Cc = 0; for (int q = 0; q < VSCAN_B / 64; ++q) { A += s_a[q]; B += s_b[q]; Cc += s_c[q]; } bsum[3 * blockIdx.x] = A; bsum[3 * blockIdx.x + 1] = B; bsum[3 * blockIdx.x + 2] = Cc; }
 }
 __global__ __launch_bounds__(VSCAN_B) void k_var_scan(int n_var, const uint32_t *var_cnt, const uint32_t *var_del, const uint32_t *var_del2, const uint32_t *bsum,
                                                       uint32_t *node_of, uint32_t *var_off, int32_t *nodes, uint32_t *node_off, uint32_t *node_cap, uint32_t *node_end, LpsCounters *cnt) {
@@ -687,7 +689,8 @@ void launch_debug_std_sort(int32_t *keys, uint8_t *payload, const long long *row
 
 template <bool KEY64>
 __global__ __launch_bounds__(256) void k_merge_multi(const LpsCounters *cnt, const uint32_t *mg_start, const uint32_t *mg_cnt, const uint32_t *mg_name, const uint32_t *mg_plan, const uint32_t *mm_r,
-                                                     const RowDesc *rows, const int32_t *g_cnt, uint32_t *g_pack, const uint32_t *g_rank, int32_t *t_node, uint8_t *t_flag, uint32_t *t_src, uint32_t tail_lo,
+                                                     const RowDesc *rows, const int32_t *g_cnt, uint32_t *g_pack, const uint32_t *g_rank, int32_t *t_node,
+                                                             uint8_t *t_flag, uint32_t *t_src, uint32_t tail_lo,
                                                      const uint32_t *mrow_off, const int32_t *nodes, const uint32_t *var_off, int a_bits, void *ukeys_v, uint32_t *uvals
                                                      ) {
     __shared__ int s_stk[4][192]; __shared__ int32_t s_k[4][STDSORT_LDS]; __shared__ uint8_t s_p[4][STDSORT_LDS]; __shared__ uint16_t s_a[4][STDSORT_LDS], s_b[4][STDSORT_LDS];
@@ -819,7 +822,8 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
     // the node's list: room for every observation counted at the extraction (cap), of which n_valid are left after the filters; the others are holes
     // (wave-uniform by construction - one node per wave -, but only readfirstlane tells the compiler: the loops over the list then run on the scalar unit
     // instead of under an exec mask, with the cells copied around every pass)
-    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)node_off[i]); const int cap = __builtin_amdgcn_readfirstlane((int)node_cap[i]), n_valid = __builtin_amdgcn_readfirstlane((int)node_end[i]);
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)node_off[i]); const int cap = __builtin_amdgcn_readfirstlane((int)node_cap[i]),
+            n_valid = __builtin_amdgcn_readfirstlane((int)node_end[i]);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     unsigned long long pairs = 0;
     const uint32_t m_mask = (uint32_t)((1ull << m_bits) - 1ull);
@@ -1490,7 +1494,8 @@ void launch_dense_names(int n_reads, const uint32_t *name_id, uint32_t name_max,
 void launch_names(const GraphView &G, const ClipView &C, unsigned long long *clip_keys, const unsigned long long *arena_ctr, unsigned long long arena_size, hipStream_t s) {
     if (!G.n_reads) return;
     const int nb_reads = (G.n_reads + NAMES_B - 1) / NAMES_B;
-    hipLaunchKernelGGL(k_name_link, dim3(nb_reads + 1 + std::min(512, nb_reads)), dim3(NAMES_B), 0, s, G.n_reads, G.name, G.rows, G.name_head, G.name_link, G.cnt, arena_ctr, arena_size, C, clip_keys, nb_reads);
+    hipLaunchKernelGGL(k_name_link, dim3(nb_reads + 1 + std::min(512, nb_reads)), dim3(NAMES_B), 0, s, G.n_reads, G.name, G.rows, G.name_head, G.name_link, G.cnt,
+            arena_ctr, arena_size, C, clip_keys, nb_reads);
 }
 
 void launch_groups(const GraphView &G, double overlap_threshold, bool counted, hipStream_t s) {
@@ -1511,13 +1516,17 @@ void launch_var_scan(const GraphView &G, hipStream_t s) {
 }
 void launch_graph_rows(const GraphView &G, int base_quality, int a_bits, bool key64, unsigned n_multi, hipStream_t s) {
     const int nb_reads = round_up8((G.n_reads + 15) / 16);                // workgroups of four extraction jobs (16 rows)
-    if (key64) hipLaunchKernelGGL(k_graph_rows<true>, dim3(nb_reads), dim3(256), 0, s, G.n_reads, G.rows, G.deleted, G.obs, G.name, G.name_head, G.name_link, G.node_of, G.var_off, base_quality, a_bits, G.g_pack, G.g_rank, G.g_cnt, G.mrow_off, G.mrow_cnt, G.ukeys, G.uvals, G.vtype_key, nb_reads);
-    else hipLaunchKernelGGL(k_graph_rows<false>, dim3(nb_reads), dim3(256), 0, s, G.n_reads, G.rows, G.deleted, G.obs, G.name, G.name_head, G.name_link, G.node_of, G.var_off, base_quality, a_bits, G.g_pack, G.g_rank, G.g_cnt, G.mrow_off, G.mrow_cnt, G.ukeys, G.uvals, G.vtype_key, nb_reads);
+    if (key64) hipLaunchKernelGGL(k_graph_rows<true>, dim3(nb_reads), dim3(256), 0, s, G.n_reads, G.rows, G.deleted, G.obs, G.name, G.name_head, G.name_link, G.node_of,
+            G.var_off, base_quality, a_bits, G.g_pack, G.g_rank, G.g_cnt, G.mrow_off, G.mrow_cnt, G.ukeys, G.uvals, G.vtype_key, nb_reads);
+    else hipLaunchKernelGGL(k_graph_rows<false>, dim3(nb_reads), dim3(256), 0, s, G.n_reads, G.rows, G.deleted, G.obs, G.name, G.name_head, G.name_link, G.node_of,
+            G.var_off, base_quality, a_bits, G.g_pack, G.g_rank, G.g_cnt, G.mrow_off, G.mrow_cnt, G.ukeys, G.uvals, G.vtype_key, nb_reads);
     if (!n_multi) return;                                                 // (known on the host since the overlap filter)
     hipLaunchKernelGGL(k_merge_plan, GRID(n_multi, 256), 0, s, G.cnt, G.mg_start, G.mg_cnt, G.mg_name, G.mm_r, G.rows, G.g_cnt, G.tail_lo, G.tail_size, G.mrow_off, G.mrow_cnt, G.mg_plan);
     const unsigned mb = std::min(1024u, (n_multi + 3) / 4);
-    if (key64) hipLaunchKernelGGL(k_merge_multi<true>, dim3(mb), dim3(256), 0, s, G.cnt, G.mg_start, G.mg_cnt, G.mg_name, G.mg_plan, G.mm_r, G.rows, G.g_cnt, G.g_pack, G.g_rank, G.t_node, G.t_flag, G.t_src, (uint32_t)G.tail_lo, G.mrow_off, G.nodes, G.var_off, a_bits, G.ukeys, G.uvals);
-    else hipLaunchKernelGGL(k_merge_multi<false>, dim3(mb), dim3(256), 0, s, G.cnt, G.mg_start, G.mg_cnt, G.mg_name, G.mg_plan, G.mm_r, G.rows, G.g_cnt, G.g_pack, G.g_rank, G.t_node, G.t_flag, G.t_src, (uint32_t)G.tail_lo, G.mrow_off, G.nodes, G.var_off, a_bits, G.ukeys, G.uvals);
+    if (key64) hipLaunchKernelGGL(k_merge_multi<true>, dim3(mb), dim3(256), 0, s, G.cnt, G.mg_start, G.mg_cnt, G.mg_name, G.mg_plan, G.mm_r, G.rows, G.g_cnt, G.g_pack,
+            G.g_rank, G.t_node, G.t_flag, G.t_src, (uint32_t)G.tail_lo, G.mrow_off, G.nodes, G.var_off, a_bits, G.ukeys, G.uvals);
+    else hipLaunchKernelGGL(k_merge_multi<false>, dim3(mb), dim3(256), 0, s, G.cnt, G.mg_start, G.mg_cnt, G.mg_name, G.mg_plan, G.mm_r, G.rows, G.g_cnt, G.g_pack,
+            G.g_rank, G.t_node, G.t_flag, G.t_src, (uint32_t)G.tail_lo, G.mrow_off, G.nodes, G.var_off, a_bits, G.ukeys, G.uvals);
 }
 
 void launch_edges(const GraphView &G, int m_bits, int a_bits, bool key64, double edge_weight, double edge_threshold, hipStream_t s) {
@@ -1550,7 +1559,8 @@ void launch_vote_scan(const LpsCounters *cnt, int n_var, const int32_t *nodes, c
     int4 *seg_bs = reinterpret_cast<int4 *>(seg_i32 + 4 * (((size_t)segs + 3) / 4 * 4));     // behind the four int arrays, 16-byte aligned
     hipLaunchKernelGGL(k_scan_match, dim3((segs + 3) / 4), dim3(256), 0, s, cnt, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs, seg_bs);
     if (const char *e = getenv("LPS_SCAN_FORCE_REPLAY")) { const int every = atoi(e); if (every > 0) hipLaunchKernelGGL(k_scan_break_matches, GRID(segs, 256), 0, s, seg_i32 + 3 * segs, segs, every); }
-    hipLaunchKernelGGL(k_scan_stitch, dim3(1), dim3(64), 0, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (const ScanState *)st_b, (const ScanState *)st_e, seg_i32 + 3 * segs, seg_bs, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, n_replayed);
+    hipLaunchKernelGGL(k_scan_stitch, dim3(1), dim3(64), 0, s, cnt, nodes, vpos, erec, A, distance, hp_v, blk_v, vstride, (const ScanState *)st_b,
+            (const ScanState *)st_e, seg_i32 + 3 * segs, seg_bs, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, n_replayed);
     hipLaunchKernelGGL(k_scan_finalize, GRID(n_var, 256), 0, s, cnt, hp_v, blk_v, vstride, seg_i32, seg_i32 + segs, seg_i32 + 2 * segs, hp, block, bmulti);
 }
 

@@ -252,7 +252,12 @@ __global__ void __launch_bounds__(INF_LANES) k_bgzf_inflate(const uint8_t *__res
                         if (!bad && !canon_tables(cc, s_dlim, s_dbase, lane, offs)) bad = true;
                         for (int s = 0; s < 19 && !bad; ++s) { const int l = (int)((clv >> (3 * s)) & 7u); if (l) { L(s_dsym, p16_get(offs, l)) = (uint8_t)s; p16_add(offs, l, 1); } }
                         int idx = 0, prev = 0; bool eob = false;
-                        auto put_len = [&](int v) __attribute__((always_inline)) { gl[idx * INF_LANES] = (uint8_t)v; if (idx < nlen) p16_add(cl, v, 1); else p16_add(cd, v, 1); if (idx == 256 && v) eob = true; prev = v; ++idx; };
+                        auto put_len = [&](int v) __attribute__((always_inline)) {
+                            gl[idx * INF_LANES] = (uint8_t)v;
+                            if (idx < nlen) p16_add(cl, v, 1); else p16_add(cd, v, 1);
+                            if (idx == 256 && v) eob = true;
+                            prev = v; ++idx;
+                        };
                         while (!bad && idx < nlen + ndist) {
                             refill_now(b, w_end);
                             uint32_t si; const int l = decode_limit(peek15(b), s_dlim, s_dbase, lane, si);
@@ -274,7 +279,8 @@ __global__ void __launch_bounds__(INF_LANES) k_bgzf_inflate(const uint8_t *__res
                         for (int k = 0; k < 36; ++k) L(s_lhi, k) = 0;
                         for (int s = 0; s < nlen; ++s) {
                             const int l = gl[s * INF_LANES];
-                            if (l) { const unsigned at = p16_get(offs, l); L(s_lsym8, at) = (uint8_t)s; if (s >> 8) s_lhi[(at >> 3) * INF_LANES + lane] |= (uint8_t)(1u << (at & 7u)); p16_add(offs, l, 1); }
+                            if (l) { const unsigned at = p16_get(offs, l); L(s_lsym8,
+                                    at) = (uint8_t)s; if (s >> 8) s_lhi[(at >> 3) * INF_LANES + lane] |= (uint8_t)(1u << (at & 7u)); p16_add(offs, l, 1); }
                         }
                     }
                     if (!bad && !canon_tables(cd, s_dlim, s_dbase, lane, offs)) bad = true;
@@ -341,7 +347,8 @@ __global__ void __launch_bounds__(256) k_bgzf_crc(const uint8_t *in, const Infla
     const uint32_t per = (((len + 63) / 64) + 31) & ~31u, s0 = min(len, per * lane), s1 = min(len, s0 + per), half = per / 2;   // per: multiple of 32 -> two 16-byte-multiple halves
     const uint32_t a0 = s0, a1 = min(s1, s0 + half), b0 = a1, b1 = s1;
     const uint32_t *o32 = reinterpret_cast<const uint32_t *>(out); const uint64_t base = B.out_off;
-    auto word = [&](uint32_t pos) -> uint32_t { const uint64_t a = base + pos; const uint32_t lo = o32[a >> 2], hi = o32[(a >> 2) + 1]; return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3)); };
+    auto word = [&](uint32_t pos) -> uint32_t { const uint64_t a = base + pos; const uint32_t lo = o32[a >> 2],
+            hi = o32[(a >> 2) + 1]; return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3)); };
     auto step4 = [&](uint32_t c, uint32_t w) -> uint32_t { c ^= w; return tab[3][c & 255u] ^ tab[2][(c >> 8) & 255u] ^ tab[1][(c >> 16) & 255u] ^ tab[0][c >> 24]; };
     uint32_t ca = lane == 0 ? 0xffffffffu : 0u, cb = 0u; uint32_t pa = a0, pb = b0;
     // 16 bytes of each half per trip: five dwords per half (one 16-byte load + one dword; `word` alone costs two loads per FOUR bytes, and every lane's

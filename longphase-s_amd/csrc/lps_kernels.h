@@ -99,7 +99,8 @@ struct ExtraView {
     const int4 *rec;           // per row {pos, info, u | kind << 30, position of the last SNP row before it}: one load for k_extra_find
     const uint32_t *mod_pack;  // mod_name << 2 | mod_flag: the search finds the flags with the name
 };
-void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int32_t *x0, uint32_t *redo, unsigned *n_redo, int mapping_quality, LpsCounters *cnt, hipStream_t s);
+void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int32_t *x0, uint32_t *redo, unsigned *n_redo, int mapping_quality,
+        LpsCounters *cnt, hipStream_t s);
 
 void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *rec, hipStream_t s);
 
@@ -114,7 +115,8 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 #define VREC_DERIVE(a) (((a) >> 24) & 3u) /* somaticReadDeriveByHP of role-1 rows */
 #define VREC_TKIND(a) (((a) >> 26) & 7u)  /* somatic extraction: TUMOR row kind at this position (0 none, 1 SNP, 2 INS, 3 DEL, 4 other) */
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,
-                          int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint32_t *var_cnt /* NULL: observations are counted later */, uint32_t *var_del, hipStream_t s);
+                          int mapping_quality, LpsCounters *cnt, uint32_t *redo_list, unsigned *n_redo, uint32_t *var_cnt /* NULL: observations are counted later */,
+                                  uint32_t *var_del, hipStream_t s);
 
 // ---- device helpers shared by the extraction (phase) and scoring (haplotag) kernels
 #ifdef __HIPCC__

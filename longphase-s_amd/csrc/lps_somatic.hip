@@ -176,7 +176,8 @@ __global__ __launch_bounds__(64) void k_tumor_extract(VarView V, ReadView R, Tum
                                         if (!r_record) atomicAdd(&sc[24], 1);
                                         else if (r_clean) {
                                             atomicAdd(&sc[25], 1);
-                                            if (r_h1 == 0 && r_h2 == 0) atomicAdd(&sc[28], 1); else if (r_h1 != 0 && r_h2 == 0) atomicAdd(&sc[26], 1); else if (r_h1 == 0 && r_h2 != 0) atomicAdd(&sc[27], 1);
+                                            if (r_h1 == 0 && r_h2 == 0) atomicAdd(&sc[28], 1); else if (r_h1 != 0 && r_h2 == 0) atomicAdd(&sc[26],
+                                                    1); else if (r_h1 == 0 && r_h2 != 0) atomicAdd(&sc[27], 1);
                                         } else atomicAdd(&sc[29], 1);
                                         atomicAdd(&sc[30 + r_hp], 1);
                                     }

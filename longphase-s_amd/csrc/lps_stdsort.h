@@ -56,7 +56,8 @@ template <class A> LPS_HD inline void stdsort_adjust_heap(A &v, int first, int h
 }
 template <class A> LPS_HD inline void stdsort_heapsort(A &v, int first, int last) {      // __partial_sort(first, last, last)
     const int len = last - first;
-    if (len >= 2) for (int parent = (len - 2) / 2;; --parent) { const int32_t vk = v.K(first + parent); const uint8_t vp = v.P(first + parent); stdsort_adjust_heap(v, first, parent, len, vk, vp); if (parent == 0) break; }
+    if (len >= 2) for (int parent = (len - 2) / 2;; --parent) { const int32_t vk = v.K(first + parent); const uint8_t vp = v.P(first + parent); stdsort_adjust_heap(v,
+            first, parent, len, vk, vp); if (parent == 0) break; }
     while (last - first > 1) { --last; const int32_t vk = v.K(last); const uint8_t vp = v.P(last); stdsort_move(v, last, first); stdsort_adjust_heap(v, first, 0, last - first, vk, vp); }
 }
 template <class A> LPS_HD inline void stdsort_unguarded_linear_insert(A &v, int last) {
