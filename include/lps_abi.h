@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 17
+#define LPS_ABI_VERSION 18
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -303,6 +303,12 @@ int lps_bgzf_load(lps_ctx *ctx, const uint8_t *bgzf, int64_t n_bytes, int64_t *i
 /* the same for bytes [offset, offset + n_bytes) of an open FILE: read with pread straight into the page-locked upload pieces, so that a multi-GB file
  * is never mapped (an 8 GB mapping costs 0.14 s to tear down when the process ends, and as many page-table entries to set up while it is copied) */
 int lps_bgzf_load_fd(lps_ctx *ctx, int fd, int64_t offset, int64_t n_bytes, int64_t *inflated_bytes);
+/* The header walk on its own, HOST ONLY (no GPU, no ctx - e.g. while the HIP runtime is still coming up): the table of the BGZF blocks in bytes
+ * [offset, offset + n_bytes) of the file, in_off relative to `offset`.  lps_bgzf_load_fd_blocks then takes the table instead of walking again. */
+typedef struct { uint64_t in_off, out_off; uint32_t in_len, out_len; } lps_bgzf_block;
+int lps_bgzf_walk_fd(int fd, int64_t offset, int64_t n_bytes, lps_bgzf_block **blocks, int64_t *n_blocks, int64_t *inflated_bytes);
+void lps_bgzf_blocks_free(lps_bgzf_block *blocks);
+int lps_bgzf_load_fd_blocks(lps_ctx *ctx, int fd, int64_t offset, int64_t n_bytes, const lps_bgzf_block *blocks, int64_t n_blocks, int64_t *inflated_bytes);
 int lps_bgzf_read(lps_ctx *ctx, int64_t offset, int64_t n, uint8_t *dst);
 int lps_bgzf_timings(lps_ctx *ctx, double *h2d_ms, double *inflate_ms);
 /* GPU BGZF writer (replaces bgzf_write/deflate behind sam_write1, src/haplotag/HaplotagParsingBam.cpp:124-134): bytes [offset, offset+n_bytes)

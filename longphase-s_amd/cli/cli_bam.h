@@ -203,13 +203,50 @@ struct GpuBam {
         }
         indexed = true;
     }
-    void close_file() { if (raw) munmap((void *)raw, fsz); if (fd >= 0) close(fd); raw = nullptr; fd = -1; }
+    void close_file() { if (ahead.th.joinable()) ahead.th.join(); if (raw) munmap((void *)raw, fsz); if (fd >= 0) close(fd); raw = nullptr; fd = -1; }
 
+    // The header walk of the next load made AHEAD, on a helper thread: it needs the file and the library's host code, not the GPU - the first one runs
+    // while the HIP runtime is still coming up (0.07 s of an 8 GB file's load), the next group's while the contigs of this one are phased.
+    ~GpuBam() { if (ahead.th.joinable()) ahead.th.join(); }            // (a walk nobody took: e.g. --gpus N, where every worker opens the file itself)
+    struct WalkAhead { uint64_t beg = 0, len = 0; lps_bgzf_block *blocks = nullptr; int64_t n = 0, inflated = 0; int rc = -1; std::thread th; bool pending = false; } ahead;
+    void walk_ahead(Lps &L, uint64_t beg, uint64_t len) {
+        drop_walk(L);
+        if (getenv("LPS_CLI_NO_WALK_AHEAD")) return;                    // (A/B switch)
+        ahead.beg = beg; ahead.len = len; ahead.pending = true; ahead.rc = -1;
+        WalkAhead *a = &ahead; Lps *lib = &L; const int f = fd;
+        ahead.th = std::thread([a, lib, f] {
+            for (int spin = 0; !lib->ready.load(std::memory_order_acquire) && spin < 20000; ++spin) usleep(500);   // (the library is being loaded by the thread that creates the context)
+            if (lib->ready.load(std::memory_order_acquire)) a->rc = lib->bgzf_walk_fd(f, (int64_t)a->beg, (int64_t)a->len, &a->blocks, &a->n, &a->inflated);
+        });
+    }
+    void drop_walk(Lps &L) { if (ahead.th.joinable()) ahead.th.join(); if (ahead.blocks) L.bgzf_blocks_free(ahead.blocks); ahead.blocks = nullptr; ahead.pending = false; }
+    // bytes [beg, beg + len) of the file onto the GPU, with the table walked ahead when it is the one for these bytes
+    void load_span(Lps &L, lps_ctx *ctx, uint64_t beg, uint64_t len) {
+        if (ahead.pending && ahead.th.joinable()) ahead.th.join();
+        const bool have = ahead.pending && ahead.rc == 0 && ahead.beg == beg && ahead.len == len;
+        const int rc = have ? L.bgzf_load_fd_blocks(ctx, fd, (int64_t)beg, (int64_t)len, ahead.blocks, ahead.n, &total) : L.bgzf_load_fd(ctx, fd, (int64_t)beg, (int64_t)len, &total);
+        drop_walk(L);
+        if (rc) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
+    }
+    // the compressed span of a group of consecutive contigs (first block of the first, last block of the last) as the index gives it
+    void group_span(const std::vector<std::string> &chrs, uint64_t &cbeg, uint64_t &stop, uint64_t &ubeg, uint64_t &uend, uint64_t &last_isize) const {
+        const size_t t0 = (size_t)tid_of(chrs.front()), t9 = (size_t)tid_of(chrs.back());
+        cbeg = voff[t0].first >> 16; ubeg = voff[t0].first & 0xffff; const uint64_t cend = voff[t9].second >> 16; uend = voff[t9].second & 0xffff;
+        stop = cend; last_isize = 0;
+        if (uend) { if (cend + 18 > fsz) die("ERROR: index of " + path + " points past the end of the file");
+            const uint64_t bsize = (uint64_t)(raw[cend + 16] | (raw[cend + 17] << 8)) + 1;
+            stop = cend + bsize;
+            if (stop > fsz) die("ERROR: truncated BGZF block in " + path);
+            last_isize = rd32(raw + stop - 4);
+            }
+        if (cbeg >= stop || stop > fsz) die("ERROR: index of " + path + " is inconsistent");
+    }
+    void walk_group_ahead(Lps &L, const std::vector<std::string> &chrs) { if (chrs.empty()) return; uint64_t cbeg, stop, ubeg, uend, li; group_span(chrs, cbeg, stop, ubeg, uend, li); walk_ahead(L, cbeg, stop - cbeg); }
     // whole-file mode: everything resident at once, one contiguous record range per contig
     void load_all(Lps &L, lps_ctx *ctx) {
         const double t1 = now();
         posix_fadvise(fd, 0, (off_t)fsz, POSIX_FADV_WILLNEED);
-        if (L.bgzf_load_fd(ctx, fd, 0, (int64_t)fsz, &total)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));      // (pread into the upload pieces: the mapping stays a few header pages)
+        load_span(L, ctx, 0, fsz);                                     // (pread into the upload pieces: the mapping stays a few header pages)
         const double t2 = now(); t_inflate += t2 - t1;
         int64_t n = 0;
         if (L.bam_scan(ctx, (int64_t)header.size(), (int32_t)ref_names.size(), &n)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
@@ -247,16 +284,9 @@ struct GpuBam {
         if (chrs.empty()) return;
         const size_t t0 = (size_t)tid_of(chrs.front()), t9 = (size_t)tid_of(chrs.back());
         const double t1 = now();
-        const uint64_t cbeg = voff[t0].first >> 16, ubeg = voff[t0].first & 0xffff, cend = voff[t9].second >> 16, uend = voff[t9].second & 0xffff;
-        uint64_t stop = cend; uint64_t last_isize = 0;
-        if (uend) { if (cend + 18 > fsz) die("ERROR: index of " + path + " points past the end of the file");
-            const uint64_t bsize = (uint64_t)(raw[cend + 16] | (raw[cend + 17] << 8)) + 1;
-            stop = cend + bsize;
-            if (stop > fsz) die("ERROR: truncated BGZF block in " + path);
-            last_isize = rd32(raw + stop - 4);
-            }
-        if (cbeg >= stop || stop > fsz) die("ERROR: index of " + path + " is inconsistent");
-        if (L.bgzf_load_fd(ctx, fd, (int64_t)cbeg, (int64_t)(stop - cbeg), &total)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
+        uint64_t cbeg, stop, ubeg, uend, last_isize;
+        group_span(chrs, cbeg, stop, ubeg, uend, last_isize);
+        load_span(L, ctx, cbeg, stop - cbeg);
         const int64_t end = uend ? total - (int64_t)last_isize + (int64_t)uend : total;
         const double t2 = now(); t_inflate += t2 - t1;
         int64_t n = 0;

@@ -70,9 +70,10 @@ struct Lps {
     decltype(&lps_somatic_tag_chromosome) somatic_tag_chromosome = nullptr;
     decltype(&lps_comm_create_all) comm_create_all = nullptr;
     decltype(&lps_comm_bcast) comm_bcast = nullptr; decltype(&lps_comm_bcast_to_device) comm_bcast_to_device = nullptr; decltype(&lps_set_variants_device) set_variants_device = nullptr;
-    decltype(&lps_somatic_write_bgzf) somatic_write_bgzf = nullptr; decltype(&lps_bgzf_load_fd) bgzf_load_fd = nullptr; decltype(&lps_dump_graph) dump_graph = nullptr; decltype(&lps_dump_votes) dump_votes = nullptr;
+    decltype(&lps_somatic_write_bgzf) somatic_write_bgzf = nullptr; decltype(&lps_bgzf_load_fd) bgzf_load_fd = nullptr; decltype(&lps_bgzf_walk_fd) bgzf_walk_fd = nullptr; decltype(&lps_bgzf_blocks_free) bgzf_blocks_free = nullptr; decltype(&lps_bgzf_load_fd_blocks) bgzf_load_fd_blocks = nullptr; decltype(&lps_dump_graph) dump_graph = nullptr; decltype(&lps_dump_votes) dump_votes = nullptr;
     decltype(&lps_comm_destroy) comm_destroy = nullptr;
     decltype(&lps_comm_size) comm_size = nullptr; decltype(&lps_comm_last_error) comm_last_error = nullptr;
+    std::atomic<bool> ready{false};                                     // the symbols are bound (load() has returned true): host-only entry points may be called
     std::string error;
     bool load() {
         char exe[4096]; const ssize_t k = readlink("/proc/self/exe", exe, sizeof exe - 1);
@@ -94,12 +95,13 @@ struct Lps {
                 lps_bam_record_offsets) LPS_SYM(bam_scan_range, lps_bam_scan_range) LPS_SYM(device_count, lps_device_count) LPS_SYM(set_stage_timing,
                 lps_set_stage_timing) LPS_SYM(haplotag_write_bgzf, lps_haplotag_write_bgzf) LPS_SYM(bgzf_deflate_fetch, lps_bgzf_deflate_fetch)
         LPS_SYM(somatic_extract_normal, lps_somatic_extract_normal) LPS_SYM(somatic_extract_tumor, lps_somatic_extract_tumor) LPS_SYM(somatic_tag_chromosome, lps_somatic_tag_chromosome)
-        LPS_SYM(somatic_write_bgzf, lps_somatic_write_bgzf) LPS_SYM(bgzf_load_fd, lps_bgzf_load_fd) LPS_SYM(dump_graph, lps_dump_graph) LPS_SYM(dump_votes, lps_dump_votes)
+        LPS_SYM(somatic_write_bgzf, lps_somatic_write_bgzf) LPS_SYM(bgzf_load_fd, lps_bgzf_load_fd) LPS_SYM(bgzf_walk_fd, lps_bgzf_walk_fd) LPS_SYM(bgzf_blocks_free, lps_bgzf_blocks_free) LPS_SYM(bgzf_load_fd_blocks, lps_bgzf_load_fd_blocks) LPS_SYM(dump_graph, lps_dump_graph) LPS_SYM(dump_votes, lps_dump_votes)
         LPS_SYM(comm_create_all, lps_comm_create_all) LPS_SYM(comm_bcast, lps_comm_bcast) LPS_SYM(comm_bcast_to_device,
                 lps_comm_bcast_to_device) LPS_SYM(set_variants_device, lps_set_variants_device) LPS_SYM(comm_destroy, lps_comm_destroy) LPS_SYM(comm_size,
                 lps_comm_size) LPS_SYM(comm_last_error, lps_comm_last_error)
 #undef LPS_SYM
         if (abi_version() != LPS_ABI_VERSION) { error = "liblps_hip.so has a different ABI version than this binary was built for"; return false; }
+        ready.store(true, std::memory_order_release);
         return true;
     }
 };

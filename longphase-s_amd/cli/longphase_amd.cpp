@@ -94,6 +94,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "--deepsomatic_output") deepsomatic = true;
         else if (a == "--indelQuality") indel_quality = std::stoi(val());
         else if (a == "--dot") dot = true;
+        else if (a == "--no-walk-ahead") setenv("LPS_CLI_NO_WALK_AHEAD", "1", 1);      // (A/B switch: the BGZF header walk inside the load, not ahead of it)
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kUsage; return 1; }
     }
     if (dot && (!sv_file.empty() || !mod_file.empty())) die("longphase_amd: --dot together with --sv-file / --mod-file is not supported by the GPU path; use the reference binary");
@@ -141,12 +142,24 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<BamFile> files(gpu_input ? 0 : bams.size());
     for (size_t b = 0; b < files.size(); ++b) files[b].load(bams[b], threads, want);
     const double t_bam = now();
+    // with a .bai next to the BAM only the blocks of one contig are resident at a time (any file size, per-contig sharding); without, the whole file.
+    // The BGZF header walk of the first load needs no GPU: it runs on a helper thread while the HIP runtime is still coming up
+    GpuBam gb;
+    if (gpu_input) {
+        gb.open_file(bams[0], !no_index);
+        if (!gb.indexed) gb.walk_ahead(L, 0, gb.fsz);
+        else if (n_gpus == 1 && workers_per_gpu == 1) {
+            std::vector<std::string> list; for (const std::string &c : chr_order) if (want.count(c)) list.push_back(c);
+            std::sort(list.begin(), list.end(), [&](const std::string &a, const std::string &b) { return gb.tid_of(a) < gb.tid_of(b); });
+            const auto groups = gb.plan_groups(list, group_bytes);
+            if (!groups.empty()) gb.walk_group_ahead(L, groups.front());
+        }
+    }
 
     gpu_init.join();
     if (!ctx) die("longphase_amd: " + L.error);
     const double t_ctx = now();
-    // with a .bai next to the BAM only the blocks of one contig are resident at a time (any file size, per-contig sharding); without, the whole file
-    GpuBam gb; if (gpu_input) { gb.open_file(bams[0], !no_index); if (!gb.indexed) gb.load_all(L, ctx); }
+    if (gpu_input && !gb.indexed) gb.load_all(L, ctx);
     const double t_gin = now();
     std::map<std::string, std::map<int32_t, Phased>> res; std::mutex res_mu;
     // packed SNP table of the whole genome (pos i32 | ref0 u8 | alt0 u8 | ref_len u16 | alt_len u16, contig after contig): worker 0 builds it from the parsed
@@ -315,8 +328,10 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         if (!gpu_input || !g.indexed) { for (const std::string &c : list) run_contig(cx, g, c, tab); return; }
         std::sort(list.begin(), list.end(), [&](const std::string &a, const std::string &b) { return g.tid_of(a) < g.tid_of(b); });
         // file order, so that neighbours share an upload
-        for (auto &grp : g.plan_groups(list, group_bytes)) {
+        const auto groups = g.plan_groups(list, group_bytes);
+        for (size_t gi = 0; gi < groups.size(); ++gi) { const auto &grp = groups[gi];
             g.load_group(L, cx, grp);
+            if (gi + 1 < groups.size()) g.walk_group_ahead(L, groups[gi + 1]);       // the next group's header walk beside this group's contigs
             if (files.empty()) {                                          // one BAM: all names of a contig are the GPU's
                 std::map<std::string, std::unique_ptr<NamesAhead>> mine;
                 for (const std::string &c : grp) { auto it = g.range.find(c); if (it == g.range.end() || !vars.count(c) || vars[c].pos.empty()) continue;
@@ -474,6 +489,12 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
     if (host_inflate) host_deflate = true;                             // the GPU writer works on the stream the GPU inflated
     const bool gpu_writer = !host_deflate;
     if (host_inflate) in.load(bam, threads, want);
+    std::vector<std::vector<std::string>> groups;
+    if (!host_inflate) {                                                // the first load's BGZF header walk runs while the HIP runtime comes up
+        gb.open_file(bam, !no_index);
+        if (!gb.indexed) gb.walk_ahead(L, 0, gb.fsz);
+        else { groups = gb.plan_groups(chr_vec, group_bytes); if (!groups.empty()) gb.walk_group_ahead(L, groups.front()); }
+    }
     const double t_bam = now();
     gpu_init.join();
     if (!ctx) die("longphase_amd: " + L.error);
@@ -494,7 +515,6 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         if (L.bgzf_read(ctx, 0, total, in.z.data)) die(std::string("ERROR: ") + L.last_error(ctx));
     };
     if (!host_inflate) {
-        gb.open_file(bam, !no_index);
         if (!gb.indexed) {
             gb.load_all(L, ctx);
             if (!gpu_writer) copy_back(gb.total);
@@ -653,15 +673,14 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         _exit(0);
     }
 
-    std::vector<std::vector<std::string>> groups;
-    if (!host_inflate && gb.indexed) groups = gb.plan_groups(chr_vec, group_bytes);
     // output order = chr_vec order; a group = a run of consecutive contigs in it
     for (const std::string &chr : chr_vec) {                          // contigs in VCF-header order (HaplotagProcess.cpp:94-97)
         if (!host_inflate && gb.indexed) {                              // indexed input: the group of consecutive contigs this one belongs to is loaded when its first member comes up
             const double tl = now();
             if (!gb.range.count(chr)) {
-                for (auto &grp : groups) if (!grp.empty() && grp.front() == chr) {
+                for (size_t gi = 0; gi < groups.size(); ++gi) if (!groups[gi].empty() && groups[gi].front() == chr) { auto &grp = groups[gi];
                     gb.load_group(L, ctx, grp);
+                    if (gi + 1 < groups.size()) gb.walk_group_ahead(L, groups[gi + 1]);   // the next group's header walk beside this group's contigs
                     if (!gpu_writer) copy_back(gb.total);
                     for (const std::string &m : grp) { auto it = gb.range.find(m);
                         if (it == gb.range.end()) continue;
@@ -949,19 +968,21 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     const bool n_gpu = !host_inflate && (gpu_inflate || file_bytes(nbam) >= kGpuInflateMinBytes), t_gpu = !host_inflate && (gpu_inflate || file_bytes(tbam) >= kGpuInflateMinBytes);
     if (!n_gpu) nin.load(nbam, threads, want);
     if (!t_gpu) tin.load(tbam, threads, want);
+    const bool resident = n_gpu && t_gpu && !host_deflate && n_gpus <= 1;
+    GpuBam ngb, tgb;
+    if (resident) { tgb.open_file(tbam, false); tgb.walk_ahead(L, 0, tgb.fsz); ngb.open_file(nbam, false); ngb.walk_ahead(L, 0, ngb.fsz); }   // header walks beside the GPU start-up
     gpu_init.join();
     if (!ctx) die("longphase_amd: " + L.error);
     // One worker and the GPU writer: both inflated streams STAY on the GPU (the tumor's in this context, the normal's in a second one that runs pass 1):
     // the passes take their records from there (lps_push_bam_resident), the tagged records are spliced and deflated there (lps_somatic_write_bgzf).
     // Otherwise (--gpus N, --host-deflate): the stream is copied back once and the contigs' records are pushed from host memory as before.
-    const bool resident = n_gpu && t_gpu && !host_deflate && n_gpus <= 1;
-    double t_gpu_inflate = 0; GpuBam ngb, tgb; lps_ctx *nctx = nullptr;
+    double t_gpu_inflate = 0; lps_ctx *nctx = nullptr;
     if (resident) {
-        tgb.open_file(tbam, false); tgb.load_all(L, ctx);
+        tgb.load_all(L, ctx);
         lps_params P; L.default_params(&P); for (auto &f : over) f(P);
         nctx = L.create(gpu, &P); if (!nctx) die("longphase_amd: cannot create the GPU context of the normal BAM");
         L.set_stage_timing(nctx, 0);
-        ngb.open_file(nbam, false); ngb.load_all(L, nctx);
+        ngb.load_all(L, nctx);
         t_gpu_inflate = tgb.t_inflate + tgb.t_scan + ngb.t_inflate + ngb.t_scan;
     } else {
         if (n_gpu) gpu_load_to_host(L, ctx, nbam, want, threads, nin, &t_gpu_inflate);
