@@ -517,10 +517,9 @@ def main():
 
         def k_steps(s):
             s["step_ms"] = []
-            for _ in range(a.steps):
-                t1 = time.perf_counter()
-                s["ctx"].run_phase(s["out"])      # synchronous: returns with the results in host memory (its stream drained)
-                s["step_ms"].append(round((time.perf_counter() - t1) * 1e3, 2))
+            # the K calls behind one entry of the library (lps_phase_chromosome_steps): each is synchronous and returns with its results in host
+            # memory; between them the thread does not come back to the interpreter, where it would wait for the other contexts' threads' lock
+            s["step_ms"] = [round(x, 2) for x in s["ctx"].run_phase_steps(s["out"], a.steps)]
         with quiet():
             dt = concurrent([(lambda s=s: k_steps(s)) for s in slots])
         elapsed += dt
@@ -563,8 +562,7 @@ def main():
         concurrent([(lambda s=s: s["ctx"].run_haplotag(s["hout"])) for s in slots])
 
         def k_tags(s):
-            for _ in range(a.steps):
-                s["ctx"].run_haplotag(s["hout"])
+            s["ctx"].run_haplotag_steps(s["hout"], a.steps)
         with quiet():
             hdt = concurrent([(lambda s=s: k_tags(s)) for s in slots])
         hap_elapsed += hdt

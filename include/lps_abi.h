@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 18
+#define LPS_ABI_VERSION 19
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -364,6 +364,10 @@ int lps_set_stage_timing(lps_ctx *ctx, int level);
 int lps_phase_chromosome(lps_ctx *ctx, lps_phase_result *out);
 /* haplotag: per-read scoring of the reads pushed so far against the phased table. */
 int lps_haplotag_chromosome(lps_ctx *ctx, lps_haplotag_result *out);
+/* k consecutive calls of the two entries above behind one call (every call does the full work; ms_each, k doubles or NULL, receives each call's wall
+ * time): for callers whose own loop would put an interpreter between the calls (bench.py's timed region) */
+int lps_phase_chromosome_steps(lps_ctx *ctx, lps_phase_result *out, int k, double *ms_each);
+int lps_haplotag_chromosome_steps(lps_ctx *ctx, lps_haplotag_result *out, int k, double *ms_each);
 /* judgeSVHap (src/haplotag/HaplotagStrategy.cpp:220-226), `haplotag --sv-file --mod-file`: the votes a read brings along from the phased SV / MOD
  * files - one per record that lists the read's name under RNAMES= / MR= (src/haplotag/HaplotagVcfParser.cpp:403-468), for the haplotype the
  * record's GT puts ALT on - are added to hpCount[H1] / hpCount[H2] of every scored alignment before judgeReadHap.  h1 / h2: one entry per pushed

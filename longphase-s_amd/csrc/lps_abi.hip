@@ -1458,6 +1458,27 @@ static const PqSmall &pq_small_table() {
     return tab;
 }
 
+// K consecutive calls behind ONE entry (bench.py's timed region: a caller written in Python re-enters the interpreter between calls, and with several
+// contexts driven from several threads a step then waits for the interpreter lock, not for the GPU).  ms_each (may be NULL): wall time of every call.
+int lps_phase_chromosome_steps(lps_ctx *c, lps_phase_result *out, int k, double *ms_each) {
+    for (int i = 0; i < k; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = lps_phase_chromosome(c, out);
+        if (ms_each) ms_each[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (rc) return rc;
+    }
+    return 0;
+}
+int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out);
+int lps_haplotag_chromosome_steps(lps_ctx *c, lps_haplotag_result *out, int k, double *ms_each) {
+    for (int i = 0; i < k; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = lps_haplotag_chromosome(c, out);
+        if (ms_each) ms_each[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (rc) return rc;
+    }
+    return 0;
+}
 int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
     if (!c || !out) return -1;
     try {

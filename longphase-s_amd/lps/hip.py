@@ -74,6 +74,8 @@ def load():
     L.lps_bam_names.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.lps_push_bam_resident.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     L.lps_phase_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.PhaseResult)]
+    L.lps_phase_chromosome_steps.argtypes = [C.c_void_p, C.POINTER(abi.PhaseResult), C.c_int, C.POINTER(C.c_double)]
+    L.lps_haplotag_chromosome_steps.argtypes = [C.c_void_p, C.POINTER(abi.HaplotagResult), C.c_int, C.POINTER(C.c_double)]
     L.lps_haplotag_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.HaplotagResult)]
     L.lps_somatic_tag_chromosome.argtypes = [C.c_void_p, C.POINTER(abi.SomaticTagResult)]
     L.lps_somatic_extract_normal.argtypes = [C.c_void_p, C.POINTER(abi.SiteCounters)]
@@ -259,6 +261,17 @@ class Context:
         out = out or abi.PhaseOut(self.n_var)
         self._check(self.L.lps_phase_chromosome(self.h, C.byref(out.c)), "lps_phase_chromosome")
         return out
+
+    def run_phase_steps(self, out, k):
+        """k consecutive lps_phase_chromosome calls without returning to Python in between; -> the calls' wall times in ms"""
+        ms = (C.c_double * k)()
+        self._check(self.L.lps_phase_chromosome_steps(self.h, C.byref(out.c), k, ms), "lps_phase_chromosome_steps")
+        return [float(x) for x in ms]
+
+    def run_haplotag_steps(self, out, k):
+        ms = (C.c_double * k)()
+        self._check(self.L.lps_haplotag_chromosome_steps(self.h, C.byref(out.c), k, ms), "lps_haplotag_chromosome_steps")
+        return [float(x) for x in ms]
 
     def phase(self, variants, ref, reads):
         self.load_chromosome(variants, ref, reads)
