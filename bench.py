@@ -8,9 +8,13 @@ library (lps_push_reads_device), and then
 
     a STEP = one pass of the hot path over the whole genome = one lps_phase_chromosome() per contig,
 
-everything from allele extraction to phased genotypes recomputed from the raw reads in HBM, results back in host memory.  K steps are run as K
-consecutive calls per contig while that contig is resident (inputs in HBM when its timed region starts); `value` = phased SNPs of all
-contigs x K / sum of the per-contig timed regions.  Nothing is cached between calls.
+everything from allele extraction to phased genotypes recomputed from the decoded reads as the push left them in HBM, results back in host
+memory.  K steps are run as K consecutive calls per contig while that contig is resident (inputs in HBM when its timed region starts); `value` =
+phased SNPs of all contigs x K / sum of the per-contig timed regions.  ONE-PASS CLOCK: the library keeps nothing between a push and a call or
+from one call to the next (ABI 20: no lps_prepare_reads, no re-laid copy of bases, qualities or CIGAR words; `prepare_ms` on the line is 0 by
+construction), so every timed call does what the first call on a freshly loaded chromosome does - the reference phases each chromosome once
+(src/phase/PhasingProcess.cpp:113-173).  What a first call additionally pays is the growth of the context's device buffers (hipMalloc); the
+line carries it as `first_call_pass_ms` (the un-warmed first call of every contig, contexts side by side like the timed ones).
 
   python bench.py --gpus N --steps K --warmup W
 N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling - the 24 contigs are dealt longest-first onto the ranks
@@ -224,6 +228,7 @@ def whole_node_baseline(dev, P, threads, seed, n_contigs=16, contig_mb=10):
     import numpy as np
     from lps import abi, hip
     from lps.synth_gpu import SynthGpu
+    n_contigs = max(2, min(24, n_contigs))
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "longphase-s-ref"); tv = os.path.join(ROOT, "oracle", "_ref", "test_view")
     if not (os.path.exists(ref_bin) and os.path.exists(tv)):
         return None
@@ -336,7 +341,7 @@ def whole_node_baseline(dev, P, threads, seed, n_contigs=16, contig_mb=10):
                        f"`longphase-s phase -t {threads} --ont` end to end, every thread with a contig of its own; best of 2 runs",
                 wall_s=round(min(ts), 2), runs_s=[round(x, 2) for x in ts], prepare_s=round(prep_s, 1), identical_to_gpu_result_all_contigs=bool(same),
                 p_clock=dict(value=float(gpu_p), unit="SNPs/s", wall_s=round(p_wall, 3), pinned_host_memory=all(c["pinned"] for c in contigs),
-                             note="decoded alignments in pinned host memory -> results in host memory: lps_set_variants + lps_set_reference + lps_push_reads (H2D) + lps_prepare_reads + "
+                             note="decoded alignments in pinned host memory -> results in host memory: lps_set_variants + lps_set_reference + lps_push_reads (H2D, CIGAR words lane-chunked as they arrive) + "
                                   "lps_phase_chromosome per contig, two contexts on one GPU so that one contig's load overlaps another's phase; PCIe-inclusive, never `value`"),
                 e_clock=e_clock,
                 vs_baseline=dict(p_clock_over_cpu=round(gpu_p / cpu, 2), note="clock P (what SURVEY.md 8d judges the >= 20x target by) over the whole-node reference rate on the same sample; "
@@ -371,11 +376,32 @@ def spawn_ranks(a):
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0]
+    # rank 0's line is read on a helper thread while the children are SUPERVISED: when one of them dies (a port taken between the probe above and
+    # the rendezvous, a rank that fails before init_process_group) the others are stopped instead of waiting for it in the rendezvous
+    out0 = []
+    rd = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True); rd.start()
+    bad = 0
+    while any(p.poll() is None for p in procs):
+        rcs = [p.poll() for p in procs]
+        failed = [rc for rc in rcs if rc not in (None, 0)]
+        if failed:
+            bad = failed[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode(errors="replace")); sys.stdout.flush()
-    bad = [rc for rc in rcs if rc != 0]
-    raise SystemExit(bad[0] if bad else 0)
+    rd.join(5)
+    sys.stdout.write(b"".join(out0).decode(errors="replace")); sys.stdout.flush()
+    bad = bad or next((rc for rc in rcs if rc != 0), 0)
+    raise SystemExit(bad)
 
 
 def main():
@@ -413,7 +439,8 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
 
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
     cpu_share = max(2, min(16, ncpu // world))
@@ -450,7 +477,7 @@ def main():
     elapsed = 0.0; hap_elapsed = 0.0; total_phased = 0; total_reads = 0; total_tagged = 0; total_bases = 0
     largest = None; cpu_pick = None; p_clock = None; port = None
     cpu_name = a.cpu_contig or min(contigs, key=lambda c: c["contig_len"])["name"]
-    gen_s = 0.0; push_s = 0.0; d2h_s = 0.0
+    gen_s = 0.0; push_s = 0.0; d2h_s = 0.0; first_call_s = 0.0
 
     def barrier():
         if dist is not None:
@@ -509,7 +536,10 @@ def main():
             else:
                 g.release_reads()
             slots.append(dict(ctx=ctx, spec=spec, g=g, V=V, ref=ref, host=host, out=abi.PhaseOut(V.n)))
-        for _ in range(a.warmup):
+        # the FIRST call on the freshly pushed contigs (un-warmed: device buffers may still grow), timed on its own; then the remaining warm-up calls
+        if a.warmup >= 1:
+            first_call_s += concurrent([(lambda s=s: s["ctx"].run_phase(s["out"])) for s in slots])
+        for _ in range(max(0, a.warmup - 1)):
             concurrent([(lambda s=s: s["ctx"].run_phase(s["out"])) for s in slots])
         # ---- timed region of the group: K steps per contig, the contexts running side by side
         for s in slots:
@@ -651,44 +681,59 @@ def main():
             "metric": "het SNPs phased/sec", "value": total_phased * a.steps / elapsed, "unit": "SNPs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if a.workload == "wgs_50x" else "weak", "vs_baseline": None, "dtype": "i32/f32", "data": "synthetic",
+            # ---- scalars first (a reader that truncates the line still sees them); the long per-contig arrays come last
+            "clock": "one-pass: every timed call starts from the decoded reads as the push left them; nothing prepared or cached (ABI 20)",
+            "prepare_ms": 0.0,
+            "first_call_pass_ms": round(first_call_s * 1e3, 3) if a.warmup >= 1 else None,
+            "parity_checked": bool(parity and parity["checked"]),
+            "whole_step_gbs": round(sum(sum(r["alg"].values()) for r in per_contig) * a.steps / my_elapsed / 1e9, 1),
+            "secondary_value": total_reads * a.steps / hap_elapsed, "secondary_unit": "reads haplotagged/s", "secondary_ms_per_step": hap_elapsed / a.steps * 1e3,
+            "host_nproc": ncpu,
             "config": {"workload": f"germline phase, {a.workload}: {len(contigs)} contig(s), {int(total_bases)/1e9:.1f} Gbases of synthetic ONT reads, {int(total_reads)} alignments, "
-                                   f"~{n_all} het SNP strata; streamed per contig, decoded reads resident in HBM during a contig's timed region; a step = one pass over all contigs",
+                                   f"~{n_all} het SNP strata; streamed per contig, decoded reads resident in HBM during a contig's timed region; a step = one pass over all contigs; "
+                                   "one-pass clock: a call recomputes everything from the pushed arrays (no layout pass outside the timed region: the library has none)",
                        "seed": a.seed, "phased_per_step": int(total_phased), "contigs": len(contigs), "parallelism": f"contigs dealt longest-first onto {world} rank(s); {C_CTX} context(s) per GPU, each with one contig resident, run side by side", "contexts_per_gpu": C_CTX,
                        "generation_s": round(gen_s, 2), "device_push_s": round(push_s, 2), "d2h_for_oracle_s": round(d2h_s, 2)},
-            "parity_checked": bool(parity and parity["checked"]), "parity": parity,
             "roofline": {"bound": "hbm", "kernel": dom, "at": f"{spec['name']} {spec['coverage']:.0f}x ({rec['alignments']} alignments, {rec['snps']} SNPs, {rec['obs']} observations)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes": int(alg.get(dom, 0)), "kernel_ms": stage_avg[dom], "solo_call_ms": rec.get("solo_ms_per_step"),
                          "note": "dominant stage by time at the largest contig, measured with that contig ALONE on the GPU: durations from hipEvents on the library's stream (extract: the two events around the kernel, live; the others: pass with every stage event recorded)"},
-            "stages_at_largest_contig": stages,
-            "whole_step_gbs": round(sum(sum(r["alg"].values()) for r in per_contig) * a.steps / my_elapsed / 1e9, 1),
-            "per_contig_rank0": [{k: v for k, v in r.items() if k != "alg"} for r in per_contig],
-            "rank_loads": rank_loads,
             "secondary": {"metric": "reads haplotagged/sec", "value": total_reads * a.steps / hap_elapsed, "unit": "reads/s", "ms_per_step": hap_elapsed / a.steps * 1e3,
                           "reads_tagged_per_step": int(total_tagged), "config": "germline haplotag, same resident 50x alignments (BASELINE.json configs[2]), table = this run's phased SNPs"},
             "p_clock": p_clock,
+            "parity": parity,
+            "stages_at_largest_contig": stages,
+            "rank_loads": rank_loads,
         }
         if rccl_info is not None:
             res["rccl"] = rccl_info
+        cpu_threads = a.cpu_threads or min(24, ncpu)          # the reference's compute parallelism is its chromosome loop: at most 24 threads compute on a genome (PhasingProcess.cpp:106,113)
         if not a.no_cpu_baseline and cpu_pick is not None:
             t0 = time.time()
-            res["cpu_baseline"] = cpu_baseline(cpu_pick[0], cpu_pick[1], a.cpu_threads or min(16, ncpu), port, cpu_pick[2])
+            one = cpu_baseline(cpu_pick[0], cpu_pick[1], cpu_threads, port, cpu_pick[2])
+            one["nproc"] = ncpu
             cpu_pick[0].close()
             log(f"cpu baseline (one contig) took {time.time()-t0:.1f}s")
+            res["cpu_baseline"] = one
             if a.workload == "wgs_50x" and not a.no_whole_node:
                 t0 = time.time()
                 for cx in ctxs:                                            # (their buffers are not needed any more: room for the sample's two contexts)
                     cx.close()
                 try:
-                    wn = whole_node_baseline(dev, P, a.cpu_threads or min(16, ncpu), a.seed)
+                    wn = whole_node_baseline(dev, P, cpu_threads, a.seed, n_contigs=cpu_threads)
                 except Exception as e:  # noqa: BLE001
                     log("whole-node baseline failed:", repr(e)[:300]); wn = None
                 if wn is not None:
+                    # the number that matters - every host thread with a contig of its own - is cpu_baseline.value; the one-contig run (one compute
+                    # thread, the others feed BGZF) stays beside it
                     wn["k_clock_over_cpu"] = round(res["value"] / wn["value"], 1)
-                    res["cpu_baseline"]["whole_node"] = wn
+                    wn["nproc"] = ncpu
+                    wn["one_contig"] = one
+                    res["cpu_baseline"] = wn
                 log(f"whole-node baseline took {time.time()-t0:.1f}s")
         elif port:
-            res["cpu_baseline"] = dict(port, kind="port", cores=1, sample=f"contig {cpu_name}, oracle restatement on decoded arrays, one thread")
+            res["cpu_baseline"] = dict(port, kind="port", cores=1, nproc=ncpu, sample=f"contig {cpu_name}, oracle restatement on decoded arrays, one thread")
+        res["per_contig_rank0"] = [{k: v for k, v in r.items() if k != "alg"} for r in per_contig]
         print(json.dumps(res), flush=True)
     for cx in ctxs:
         cx.close()

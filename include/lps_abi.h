@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 19
+#define LPS_ABI_VERSION 20
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -271,18 +271,14 @@ int lps_get_extra_result(lps_ctx *ctx, lps_phase_result *sv, lps_phase_result *m
 /* Reference bases of the chromosome; the library applies FastaParser's truncation to [0,lastVariant+5]
  * (src/phase/ParsingBam.cpp:47) itself.  May be shorter than the contig as long as it covers that prefix. */
 int lps_set_reference(lps_ctx *ctx, const char *seq, int64_t len);
-/* Append decoded alignments (H2D copy).  May be called repeatedly (batches / several BAM files). */
+/* Append decoded alignments (H2D copy).  May be called repeatedly (batches / several BAM files).  Every push leaves the alignments in the layout the
+ * kernels read - the CIGAR words go into lane-chunks of 8 as they are copied into the context (csrc/lps_reads.hip), bases and qualities stay in the BAM
+ * record's own encodings and are gathered in place: lps_phase_chromosome / lps_haplotag_chromosome start from the pushed arrays, nothing is prepared
+ * or cached between a push and a call (ABI 20 removed lps_prepare_reads). */
 int lps_push_reads(lps_ctx *ctx, const lps_read_batch *batch);
-/* After the last push of a chromosome (optional: lps_phase_chromosome does it itself when it has not been done for the resident alignments):
- * builds the layouts the hot kernels read (csrc/lps_reads.hip): bases and qualities of a base in ONE 128-byte line instead of two, because a random
- * byte costs a whole line of HBM traffic (one pass over SEQ + QUAL; *ms (optional) = its duration on the GPU, 0 if already built), and the CIGAR
- * words in lane-chunks - every alignment padded to a multiple of 8 words - which the stream walks of phase and haplotag take 8 words per lane
- * (lps_haplotag_chromosome builds the latter itself when needed).  Part of loading a chromosome (P and E clocks include it); pushing more
- * alignments invalidates both. */
-int lps_prepare_reads(lps_ctx *ctx, double *ms);
 /* Same as lps_push_reads for a batch that is already resident on the ctx's GPU: every pointer of `batch` is a DEVICE pointer
- * (e.g. the output of a GPU-side BAM decoder or generator).  The arrays are copied device-to-device; the caller may free them when the
- * call returns.  The operand checks of lps_push_reads (offsets, seq/qual lengths, coordinate order) run as a kernel. */
+ * (e.g. the output of a GPU-side BAM decoder or generator).  The arrays are copied device-to-device (the CIGAR words into lane-chunks as they are
+ * copied); the caller may free them when the call returns.  The operand checks of lps_push_reads (offsets, seq/qual lengths, coordinate order) run as a kernel. */
 int lps_push_reads_device(lps_ctx *ctx, const lps_read_batch *batch);
 /* Append alignments as RAW (inflated) BAM records - what `sam_itr_multi_next` fills into bam1_t in the loop of
  * direct_detect_alleles (src/phase/ParsingBam.cpp:1279) / processSingleChrom (src/haplotag/HaplotagParsingBam.cpp:453),
@@ -311,6 +307,9 @@ void lps_bgzf_blocks_free(lps_bgzf_block *blocks);
 int lps_bgzf_load_fd_blocks(lps_ctx *ctx, int fd, int64_t offset, int64_t n_bytes, const lps_bgzf_block *blocks, int64_t n_blocks, int64_t *inflated_bytes);
 int lps_bgzf_read(lps_ctx *ctx, int64_t offset, int64_t n, uint8_t *dst);
 int lps_bgzf_timings(lps_ctx *ctx, double *h2d_ms, double *inflate_ms);
+/* 1 when the last lps_bgzf_load* had to inflate a second time: the kernel launched beside the upload outran a slow source (its wavefronts wait a
+ * bounded time for their bytes) and the members were inflated again once the upload was complete.  The load itself succeeded either way. */
+int lps_bgzf_retried(lps_ctx *ctx);
 /* GPU BGZF writer (replaces bgzf_write/deflate behind sam_write1, src/haplotag/HaplotagParsingBam.cpp:124-134): bytes [offset, offset+n_bytes)
  * of the resident stream are cut into 0xff00-byte blocks, each deflated with a per-block dynamic Huffman code (no LZ77) and wrapped as a BGZF
  * member with CRC32/ISIZE; lps_bgzf_deflate leaves the blocks on the device and returns their total size, lps_bgzf_deflate_fetch copies them

@@ -189,8 +189,17 @@ static int phase_main(int argc, char **argv, const std::string &command) {
               al[o + i] = (uint16_t)cv.alt[i].size();
               } } }
     // names and name ranks of the contigs of a loaded group, made ahead of the contig loop: the names come off the GPU in one go per contig, the ranks
-    // (a sort of the contig's read names: 2.5 ms for 25 k) are computed by helper threads while the contigs before are phased
-    struct NamesAhead { std::vector<char> store; std::vector<uint32_t> off; std::vector<std::pair<const char *, size_t>> names; std::vector<uint32_t> id; std::thread ranker; };
+    // (a sort of the contig's read names: 2.5 ms for 25 k) are computed by a BOUNDED pool of helper threads (at most -t of them, whatever the
+    // number of contigs in the group: a genome with hundreds of decoy contigs does not start hundreds of sorts at once) that walks the group in contig
+    // order while the contigs before are phased
+    struct NamesAhead { std::vector<char> store; std::vector<uint32_t> off; std::vector<std::pair<const char *, size_t>> names; std::vector<uint32_t> id;
+                        std::mutex m; std::condition_variable cv; bool done = false;
+                        void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return done; }); } };
+    struct RankPool { std::vector<NamesAhead *> items; std::atomic<size_t> next{0}; std::vector<std::thread> th;
+                      void start(int n) { for (int k = 0; k < n; ++k) th.emplace_back([this] { for (;;) { const size_t i = next++; if (i >= items.size()) break;
+                              NamesAhead *a = items[i]; rank_names(a->names, a->id);
+                              std::lock_guard<std::mutex> lk(a->m); a->done = true; a->cv.notify_all(); } }); }     // (notified under the lock: the waiter may destroy *a as soon as it sees done)
+                      ~RankPool() { for (auto &t : th) if (t.joinable()) t.join(); } };                              // joins on every way out of the scope, an exception included
     std::map<lps_ctx *, std::map<std::string, std::unique_ptr<NamesAhead>>> ahead; std::mutex ahead_mu;
     static std::atomic<long long> ns_names{0}, ns_rank{0}, ns_setup{0}, ns_push{0}, ns_phase{0}, ns_merge{0};      // where a contig's host time goes (LPS_CLI_DEBUG)
     auto tick_ns = [] { return std::chrono::steady_clock::now(); };
@@ -211,7 +220,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         if (gpu_input) {
             { auto it = gb.range.find(chr); if (it == gb.range.end()) return; gr = it->second; }   // whole file, or the group loaded by the caller
             { std::lock_guard<std::mutex> lk(ahead_mu); auto a = ahead.find(ctx); if (a != ahead.end()) { auto b = a->second.find(chr); if (b != a->second.end()) { pre = std::move(b->second); a->second.erase(b); } } }
-            if (pre) { if (pre->ranker.joinable()) pre->ranker.join(); names.swap(pre->names); }
+            if (pre) { pre->wait(); names.swap(pre->names); }
             else gb.names(L, ctx, gr.first, gr.second, name_store, name_off, names);
         }
         tock_ns(ns_names, t_st);
@@ -332,17 +341,20 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         for (size_t gi = 0; gi < groups.size(); ++gi) { const auto &grp = groups[gi];
             g.load_group(L, cx, grp);
             if (gi + 1 < groups.size()) g.walk_group_ahead(L, groups[gi + 1]);       // the next group's header walk beside this group's contigs
+            RankPool pool;                                                // (declared before the contig loop: joined when the group is done or on a throw)
             if (files.empty()) {                                          // one BAM: all names of a contig are the GPU's
                 std::map<std::string, std::unique_ptr<NamesAhead>> mine;
                 for (const std::string &c : grp) { auto it = g.range.find(c); if (it == g.range.end() || !vars.count(c) || vars[c].pos.empty()) continue;
                     std::unique_ptr<NamesAhead> a(new NamesAhead());
                     g.names(L, cx, it->second.first, it->second.second, a->store, a->off, a->names);
-                    NamesAhead *ap = a.get(); a->ranker = std::thread([ap] { rank_names(ap->names, ap->id); });
+                    pool.items.push_back(a.get());
                     mine[c] = std::move(a); }
-                std::lock_guard<std::mutex> lk(ahead_mu); ahead[cx] = std::move(mine);
+                { std::lock_guard<std::mutex> lk(ahead_mu); ahead[cx] = std::move(mine); }
+                pool.start((int)std::min<size_t>((size_t)std::max(1, threads), pool.items.size()));
             }
             for (const std::string &c : grp) run_contig(cx, g, c, tab);
-            { std::lock_guard<std::mutex> lk(ahead_mu); for (auto &kv : ahead[cx]) if (kv.second && kv.second->ranker.joinable()) kv.second->ranker.join(); ahead.erase(cx); }
+            for (auto &t : pool.th) if (t.joinable()) t.join();            // (every item has been ranked: each contig waited for its own)
+            { std::lock_guard<std::mutex> lk(ahead_mu); ahead.erase(cx); }
         }
     };
     // the one collective: a communicator over the workers' GPUs (ncclCommInitAll); fails when two workers share a device (rehearsal on fewer GPUs

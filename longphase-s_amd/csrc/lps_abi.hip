@@ -3,10 +3,11 @@
 // HBM layout (one chromosome resident per ctx; all SoA, sized for 288 GB: a 50x human chr1 batch is ~25 GB):
 //   variants   pos i32 | ref0,alt0 u8 | ref_len,alt_len u16 | danger,hpoly,erased u8          (<= 16 B / variant)
 //   reference  chars [0, lastVariant+5]
-//   reads      ref_start,l_qseq i32 | flag u16 | mapq u8 | name_id u32 | 3 x u64 offsets | cigar u32[] | seq 4-bit | qual u8
+//   reads      ref_start,l_qseq i32 | flag u16 | mapq u8 | name_id u32 | seq/qual u64 offsets | cigar u32[] in lane-chunks of 8 (cp_off u32, cp_n i32) | seq 4-bit | qual u8
 //   obs rows   var i32 + aq u16 per observation, rows placed by atomic reservation; g_node i32 + g_flag u8 mirror them
 //   graph      node-major sorted (key u64, slot u32) list | edge f32[N][A][4] | vote records {f32 w,u32 flags}[N][A] | hp i8[N] | block i32[N]
-// Every lps_phase_chromosome() recomputes all stages from the resident raw reads.
+// Every lps_phase_chromosome() recomputes all stages from the resident reads as the pushes left them: nothing is prepared or cached between a push
+// and a call, or from one call to the next.
 #include <algorithm>
 #include <thread>
 #include <chrono>
@@ -50,13 +51,16 @@ struct lps_ctx {
     // reads
     int nR = 0; uint64_t n_cig = 0, n_seq = 0, n_qual = 0;
     DevBuf<int32_t> r_start, r_lq; DevBuf<uint16_t> r_flag; DevBuf<uint8_t> r_mapq; DevBuf<uint32_t> r_name;
-    DevBuf<uint64_t> r_coff, r_soff, r_qoff; DevBuf<uint32_t> cigar; DevBuf<uint8_t> seq, qual;
-    DevBuf<uint8_t> sq; DevBuf<uint32_t> r_sqblk, sq_cnt; DevBuf<int32_t> r_v0; DevBuf<uint32_t> cigp, cp_off, cp_cnt; DevBuf<int32_t> cp_n; int cp_reads = -1; int sq_reads = -1; int32_t last_start = 0;   /* start of the last alignment pushed (order across pushes) */ float sq_ms = 0;   // bases + qualities interleaved per 128-byte line (lps_reads.hip); sq_reads: alignments it covers (-1: not built)
+    DevBuf<uint64_t> r_soff, r_qoff; DevBuf<uint8_t> seq, qual;
+    // CIGAR words: ONE resident copy, in lane-chunks of 8 words (lps_reads.hip), written in that layout by every kind of push.  n_cig counts the real
+    // words (algorithmic bytes), n_chunks the chunks in place; cp_off[r] = first chunk of alignment r (nR + 1 entries), cp_n[r] = its words
+    DevBuf<uint32_t> cigar, cp_off, cp_cnt, cp_rel, cig_tmp; DevBuf<int32_t> cp_n; DevBuf<uint64_t> coff_tmp, chunk_off; DevBuf<unsigned long long> cig_words; uint64_t n_chunks = 0;
+    DevBuf<int32_t> r_v0; int32_t last_start = 0;   /* start of the last alignment pushed (order across pushes) */
     // raw BAM records (lps_push_bam_records): seq/qual are read in place from the blob
     DevBuf<uint8_t> blob; uint64_t n_blob = 0; int read_mode = 0;   // 0 none yet, 1 SoA batches, 2 BAM records
     DevBuf<uint64_t> rec_off, cig_src; DevBuf<unsigned long long> cig_cnt; DevBuf<unsigned> bam_err;
     // whole BAM file resident on the device (lps_bgzf_load): compressed bytes, block table, inflated stream; survives lps_begin_chromosome
-    DevBuf<uint8_t> zfile, file, zscratch; DevBuf<InflateBlock> zblk; uint64_t file_bytes = 0; float bgzf_h2d_ms = 0, bgzf_inflate_ms = 0;
+    DevBuf<uint8_t> zfile, file, zscratch; DevBuf<InflateBlock> zblk; uint64_t file_bytes = 0; float bgzf_h2d_ms = 0, bgzf_inflate_ms = 0; bool bgzf_retried = false;
     DevBuf<unsigned long long> tg_len, tg_off; DevBuf<uint2> tg_spans; DevBuf<uint8_t> tg_stream, tg_status, tg_hp; DevBuf<int32_t> tg_ps, tg_pq; int64_t cur_first = -1, cur_count = 0;
     uint8_t *stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; size_t stage_bytes = 0;   // pinned staging ring for large pageable uploads
     unsigned long long *up_mark = nullptr;   // upload watermark of lps_bgzf_load: a page-locked host word the inflate kernel polls
@@ -147,6 +151,7 @@ static void h2d_staged(lps_ctx *c, uint8_t *dst, const ZSource &src, size_t n, h
     for (size_t off = 0; off < n; off += CH, k ^= 1) {
         const size_t len = std::min(CH, n - off);
         if (used[k]) { HIP_TRY(hipEventSynchronize(c->stage_ev[k])); raise(end_of[k]); }       // (pieces complete in order: everything before end_of[k] is in place)
+        if (mark) { const char *thr = getenv("LPS_BGZF_TEST_THROTTLE_MS"); if (thr) usleep((useconds_t)(atof(thr) * 1000.0)); }   // test hook: a slow source (network storage, a cold page cache)
         const int nt = 4; std::thread th[nt]; const size_t part = (len + nt - 1) / nt; bool ok[nt];
         for (int t = 0; t < nt; ++t) th[t] = std::thread([&, t] { const size_t a = std::min(len, part * t), b = std::min(len, a + part); ok[t] = b <= a ||
                 src.read(off + a, b - a, c->stage[k] + a); });
@@ -260,8 +265,8 @@ void *lps_stream(lps_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int lps_begin_chromosome(lps_ctx *c) {
     if (!c) return -1;
-    c->nV = 0; c->last_pos = -1; c->ref_len = c->ref_len_eff = 0; c->nR = 0; c->n_cig = c->n_seq = c->n_qual = 0; c->n_blob = 0; c->read_mode = 0; c->cur_first = -1; c->cur_count = 0;
-    c->phase_valid = false; c->has_hap = false; c->h_vpos.clear(); c->vpos_on_device_only = false; c->name_max = 0; c->sq_reads = -1; c->cp_reads = -1;
+    c->nV = 0; c->last_pos = -1; c->ref_len = c->ref_len_eff = 0; c->nR = 0; c->n_cig = c->n_seq = c->n_qual = 0; c->n_chunks = 0; c->n_blob = 0; c->read_mode = 0; c->cur_first = -1; c->cur_count = 0;
+    c->phase_valid = false; c->has_hap = false; c->h_vpos.clear(); c->vpos_on_device_only = false; c->name_max = 0;
     c->nX = c->nSV = c->nMOD = 0; c->h_snp_u.clear(); c->h_sv_u.clear(); c->h_mod_u.clear(); c->votes_h1.clear(); c->votes_h2.clear();
     return 0;
 }
@@ -416,6 +421,30 @@ int lps_set_reference(lps_ctx *c, const char *seq, int64_t len) {
     return 0;
 }
 
+// CIGAR words of a batch - dense on the device: words [d_off[i], d_off[i + 1]) of d_src, offsets as the caller numbers them - appended to the resident
+// lane-chunk layout behind the chunks already there; fills cp_n[at + i] and cp_off[at .. at + n].  Synchronizes the stream.
+static int append_cigar_chunks(lps_ctx *c, size_t at, size_t n, const uint64_t *d_off, const uint32_t *d_src) {
+    hipStream_t s = c->stream;
+    c->cp_cnt.reserve(n + 2, s); c->cp_rel.reserve(n + 2, s);
+    c->cp_n.reserve(at + n + 1, s, true, at); c->cp_off.reserve(at + n + 2, s, true, at);
+    const size_t need = GraphTemp::need(n + 2);
+    if (need > c->temp_bytes) { c->temp.reserve(need, s); c->temp_bytes = need; }
+    unsigned *flag = reinterpret_cast<unsigned *>(c->cp_cnt.p + n + 1);
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, s));
+    launch_cp_count((int)n, d_off, c->cp_cnt.p, c->cp_n.p + at, flag, s);
+    exscan_u32(c->temp.p, c->temp_bytes, c->cp_cnt.p, c->cp_rel.p, n + 1, s);
+    uint32_t total = 0, bad = 0;
+    HIP_TRY(hipMemcpyAsync(&total, c->cp_rel.p + n, sizeof total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof bad, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (bad || c->n_chunks + (uint64_t)total > 0xffffffffull) return fail(c, "CIGAR arrays beyond 2^35 words per chromosome (or 2^31 per alignment) are not supported");
+    c->cigar.reserve(8 * (c->n_chunks + total) + 64, s, true, 8 * c->n_chunks);
+    launch_cp_pack((int)n, d_off, d_src, c->cp_rel.p, (uint32_t)c->n_chunks, c->cp_off.p + at, c->cigar.p, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    c->n_chunks += total;
+    return 0;
+}
+
 int lps_push_reads(lps_ctx *c, const lps_read_batch *b) {
     if (!c || !b) return -1;
     try {
@@ -439,12 +468,13 @@ int lps_push_reads(lps_ctx *c, const lps_read_batch *b) {
         upload(c, c->r_name, b->name_id, n, at, true);
         for (size_t i = 0; i < n; ++i) c->name_max = std::max(c->name_max, b->name_id[i]);
         std::vector<uint64_t> co(n + 1), so(n + 1), qo(n + 1);
-        for (size_t i = 0; i <= n; ++i) { co[i] = b->cigar_off[i] - b->cigar_off[0] + c->n_cig; so[i] = b->seq_off[i] - b->seq_off[0] + c->n_seq; qo[i] = b->qual_off[i] - b->qual_off[0] + c->n_qual; }
-        upload(c, c->r_coff, co.data(), n + 1, at, true); upload(c, c->r_soff, so.data(), n + 1, at, true); upload(c, c->r_qoff, qo.data(), n + 1, at, true);
-        upload(c, c->cigar, b->cigar + b->cigar_off[0], (size_t)nc, (size_t)c->n_cig, true);
+        for (size_t i = 0; i <= n; ++i) { co[i] = b->cigar_off[i] - b->cigar_off[0]; so[i] = b->seq_off[i] - b->seq_off[0] + c->n_seq; qo[i] = b->qual_off[i] - b->qual_off[0] + c->n_qual; }
+        upload(c, c->r_soff, so.data(), n + 1, at, true); upload(c, c->r_qoff, qo.data(), n + 1, at, true);
+        upload(c, c->coff_tmp, co.data(), n + 1); upload(c, c->cig_tmp, b->cigar + b->cigar_off[0], (size_t)nc);   // the batch's words as they come; they reach the resident layout below
         upload(c, c->seq, b->seq + b->seq_off[0], (size_t)ns, (size_t)c->n_seq, true);
         upload(c, c->qual, b->qual + b->qual_off[0], (size_t)nq, (size_t)c->n_qual, true);
-        HIP_TRY(hipStreamSynchronize(c->stream));          // co/so/qo are stack-owned
+        const int rc = append_cigar_chunks(c, at, n, c->coff_tmp.p, c->cig_tmp.p);     // (synchronizes: co/so/qo are stack-owned)
+        if (rc) return rc;
         c->nR += (int)n; c->n_cig += nc; c->n_seq += ns; c->n_qual += nq;
         c->phase_valid = false;
     } catch (std::string &e) { return fail(c, e); }
@@ -479,21 +509,25 @@ static int push_record_view(lps_ctx *c, const BamView &B, size_t n, const uint32
     upload(c, c->r_name, name_id, n, at, true);
     for (size_t i = 0; i < n; ++i) c->name_max = std::max(c->name_max, name_id[i]);
     c->r_start.reserve(at + n, s, true, at); c->r_lq.reserve(at + n, s, true, at); c->r_flag.reserve(at + n, s, true, at); c->r_mapq.reserve(at + n, s, true, at);
-    c->r_soff.reserve(at + n + 1, s, true, at); c->r_qoff.reserve(at + n + 1, s, true, at); c->r_coff.reserve(at + n + 1, s, true, at);
-    c->cig_cnt.reserve(n + 1); c->cig_src.reserve(n + 1); c->bam_err.reserve(1);
-    HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s));
-    launch_bam_core(B, (int)n, (int)at, c->r_start.p, c->r_lq.p, c->r_flag.p, c->r_mapq.p, c->r_soff.p, c->r_qoff.p, c->cig_cnt.p, c->cig_src.p, c->bam_err.p, s);
-    bam_cigar_offsets(c->temp, c->temp_bytes, c->cig_cnt.p, c->r_coff.p + at, (int)n, c->n_cig, s);
-    uint64_t total = 0; unsigned err = 0;
-    HIP_TRY(hipMemcpyAsync(&total, c->r_coff.p + at + n, sizeof total, hipMemcpyDeviceToHost, s));
+    c->r_soff.reserve(at + n + 1, s, true, at); c->r_qoff.reserve(at + n + 1, s, true, at);
+    c->cp_n.reserve(at + n + 1, s, true, at); c->cp_off.reserve(at + n + 2, s, true, at);
+    c->cig_cnt.reserve(n + 1); c->cig_src.reserve(n + 1); c->chunk_off.reserve(n + 2); c->bam_err.reserve(1); c->cig_words.reserve(1);
+    HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s)); HIP_TRY(hipMemsetAsync(c->cig_words.p, 0, sizeof(unsigned long long), s));
+    launch_bam_core(B, (int)n, (int)at, c->r_start.p, c->r_lq.p, c->r_flag.p, c->r_mapq.p, c->r_soff.p, c->r_qoff.p, c->cig_cnt.p, c->cp_n.p, c->cig_src.p, c->bam_err.p, s);
+    bam_cigar_offsets(c->temp, c->temp_bytes, c->cig_cnt.p, c->chunk_off.p, (int)n, c->n_chunks, s);       // lane-chunks: first chunk of every record, behind the chunks in place
+    launch_sum_i32(c->cp_n.p + at, (int)n, c->cig_words.p, s);
+    uint64_t total = 0; unsigned err = 0; unsigned long long words = 0;
+    HIP_TRY(hipMemcpyAsync(&total, c->chunk_off.p + n, sizeof total, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&err, c->bam_err.p, sizeof err, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&words, c->cig_words.p, sizeof words, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (err & LPS_BAM_ERR_BOUNDS) return fail(c, "BAM record does not fit the bytes handed over (truncated or corrupt record)");
     if (err & LPS_BAM_ERR_UNSORTED) return fail(c, "alignments must be coordinate-sorted");
-    c->cigar.reserve(total + 1, s, true, c->n_cig);
-    launch_bam_cigar(B, (int)n, c->r_coff.p + at, c->cig_src.p, c->cigar.p, s);
+    if (total > 0xffffffffull) return fail(c, "CIGAR arrays beyond 2^35 words per chromosome are not supported");
+    c->cigar.reserve(8 * total + 64, s, true, 8 * c->n_chunks);
+    launch_bam_cigar(B, (int)n, c->chunk_off.p, c->cp_n.p + at, c->cig_src.p, c->cigar.p, c->cp_off.p + at, s);   // the words re-aligned straight into their lane-chunks
     HIP_TRY(hipStreamSynchronize(s));
-    c->nR += (int)n; c->n_cig = total;
+    c->nR += (int)n; c->n_chunks = total; c->n_cig += words;
     c->phase_valid = false;
     return 0;
 }
@@ -555,15 +589,14 @@ int lps_push_reads_device(lps_ctx *c, const lps_read_batch *b) {
             if (cnt) HIP_TRY(hipMemcpyAsync(buf.p + where, src, cnt * sizeof(*src), hipMemcpyDeviceToDevice, s));
         };
         d2d(c->r_start, b->ref_start, n, at); d2d(c->r_lq, b->l_qseq, n, at); d2d(c->r_flag, b->flag, n, at); d2d(c->r_mapq, b->mapq, n, at); d2d(c->r_name, b->name_id, n, at);
-        c->r_coff.reserve(at + n + 1, s, true, at); c->r_soff.reserve(at + n + 1, s, true, at); c->r_qoff.reserve(at + n + 1, s, true, at);
+        c->r_soff.reserve(at + n + 1, s, true, at); c->r_qoff.reserve(at + n + 1, s, true, at);
         const dim3 g((unsigned)((n + 1 + 255) / 256)), bl(256);
-        hipLaunchKernelGGL(k_rebase_offsets, g, bl, 0, s, (long long)n + 1, b->cigar_off, c->n_cig, c->r_coff.p + at);
         hipLaunchKernelGGL(k_rebase_offsets, g, bl, 0, s, (long long)n + 1, b->seq_off, c->n_seq, c->r_soff.p + at);
         hipLaunchKernelGGL(k_rebase_offsets, g, bl, 0, s, (long long)n + 1, b->qual_off, c->n_qual, c->r_qoff.p + at);
-        d2d(c->cigar, b->cigar + ends[0], (size_t)nc, (size_t)c->n_cig);
         d2d(c->seq, b->seq + ends[2], (size_t)ns, (size_t)c->n_seq);
         d2d(c->qual, b->qual + ends[4], (size_t)nq, (size_t)c->n_qual);
-        HIP_TRY(hipStreamSynchronize(s));
+        const int rc = append_cigar_chunks(c, at, n, b->cigar_off, b->cigar);     // the words' copy into the context, lane-chunked as it is made (synchronizes)
+        if (rc) return rc;
         c->name_max = std::max(c->name_max, flags[1]);
         c->nR += (int)n; c->n_cig += nc; c->n_seq += ns; c->n_qual += nq;
         c->phase_valid = false;
@@ -779,7 +812,7 @@ static int bgzf_load_source(lps_ctx *c, const ZSource &src, int64_t n_bytes, int
         struct Events { hipEvent_t &a, &b, &c; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); if (c) (void)hipEventDestroy(c); } } ev_guard{e0, e1, e2};   // every early return below releases them
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
         c->zfile.reserve((uint64_t)n_bytes + 64, s);
-        if (!c->up_mark) HIP_TRY(hipHostMalloc((void **)&c->up_mark, 64, hipHostMallocDefault));
+        if (!c->up_mark) HIP_TRY(hipHostMalloc((void **)&c->up_mark, 64, hipHostMallocCoherent));   // coherent (uncached on the GPU side): the polling kernel sees the host's stores
         __atomic_store_n(c->up_mark, 0ull, __ATOMIC_RELEASE);
         HIP_TRY(hipStreamSynchronize(s));                                   // (the buffers exist before another stream writes them)
         HIP_TRY(hipMemsetAsync(c->zfile.p + n_bytes, 0, 64, cs));
@@ -821,11 +854,14 @@ static int bgzf_load_source(lps_ctx *c, const ZSource &src, int64_t n_bytes, int
             // The kernel is launched when the bytes of its FIRST round of wavefronts are in place (65 536 members are resident at a time: about 2 GB,
             // 50 ms of upload).  Launched earlier - the table may have been walked long before - every resident wavefront sits waiting, and the
             // upload beside them ran at half its rate (measured: 0.37 - 0.40 s instead of 0.20 s for 8.26 GB, on some boxes three times that).
-            const unsigned long long first_round = blks.size() > 65536 ? blks[65536].in_off : n;
+            const char *fr_env = getenv("LPS_BGZF_TEST_FIRST_ROUND");                      // test hook: members the launch waits for
+            const size_t fr = fr_env ? (size_t)std::max(1, atoi(fr_env)) : 65536;
+            const unsigned long long first_round = blks.size() > fr ? blks[fr].in_off : n;
             while (__atomic_load_n(c->up_mark, __ATOMIC_ACQUIRE) < first_round) usleep(200);
         }
         HIP_TRY(hipEventRecord(e2, s));
-        launch_bgzf_inflate(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, c->zscratch.p, s, serial ? nullptr : c->up_mark, n);
+        const char *to_env = getenv("LPS_BGZF_TEST_TIMEOUT_MS");                           // test hook: how long a wave waits for its bytes
+        launch_bgzf_inflate(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, c->zscratch.p, s, serial ? nullptr : c->up_mark, n, to_env ? atof(to_env) : 5000.0);
         launch_bgzf_crc(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, s);
         HIP_TRY(hipMemsetAsync(c->file.p + utot, 0, 64, s));
         hipEvent_t e3 = nullptr; HIP_TRY(hipEventCreate(&e3)); struct One { hipEvent_t &a; ~One() { if (a) (void)hipEventDestroy(a); } } e3_guard{e3};
@@ -835,11 +871,26 @@ static int bgzf_load_source(lps_ctx *c, const ZSource &src, int64_t n_bytes, int
         if (uploader.joinable()) uploader.join();
         HIP_TRY(hipStreamSynchronize(cs)); HIP_TRY(hipStreamSynchronize(s));
         if (!up_err.empty()) return fail(c, up_err);
+        c->bgzf_retried = false;
+        if (err & LPS_INF_ERR_TIMEOUT) {
+            // Some wavefront waited longer for its bytes than it is allowed to (a slow source: network storage, a file that fell out of the page cache,
+            // another worker's upload on the same link) and left.  The upload itself is complete now - the uploader has been joined, its stream
+            // synchronized - so the members are inflated again WITHOUT the watermark: slower than the overlap, never wrong, no failure for the caller.
+            HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s));
+            HIP_TRY(hipEventRecord(e2, s));
+            launch_bgzf_inflate(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, c->zscratch.p, s);
+            launch_bgzf_crc(c->zfile.p, c->zblk.p, (int)blks.size(), c->file.p, c->bam_err.p, s);
+            HIP_TRY(hipMemsetAsync(c->file.p + utot, 0, 64, s));
+            HIP_TRY(hipEventRecord(e3, s));
+            HIP_TRY(hipMemcpyAsync(&err, c->bam_err.p, sizeof err, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            c->bgzf_retried = true;
+            if (getenv("LPS_DEBUG")) fprintf(stderr, "[lps_bgzf_load] the inflate kernel outran the upload (timeout): inflated again after the upload\n");
+        }
         HIP_TRY(hipEventElapsedTime(&c->bgzf_h2d_ms, e0, e1)); HIP_TRY(hipEventElapsedTime(&c->bgzf_inflate_ms, e2, e3));
         if (getenv("LPS_DEBUG")) fprintf(stderr, "[lps_bgzf_load] %zu blocks: header walk %.1f ms | device buffers %.1f ms | upload %.1f ms beside inflate + crc %.1f ms (from its launch; it waits for its bytes) | host wall %.1f ms\n", blks.size(), th1 - th0, th2 - th1, c->bgzf_h2d_ms, c->bgzf_inflate_ms, tnow() - th0);
         c->file_bytes = 0; c->n_rec_all = 0; c->names_ready = false;
-        if (err) return fail(c, err & LPS_INF_ERR_TIMEOUT ? "lps_bgzf_load: the inflate kernel waited for the upload for more than five seconds"
-                               : err & LPS_INF_ERR_DATA ? "lps_bgzf_load: corrupt deflate stream" : err & (LPS_INF_ERR_SIZE | LPS_INF_ERR_OVERRUN) ? "lps_bgzf_load: a block does not inflate to its ISIZE"
+        if (err) return fail(c, err & LPS_INF_ERR_DATA ? "lps_bgzf_load: corrupt deflate stream" : err & (LPS_INF_ERR_SIZE | LPS_INF_ERR_OVERRUN) ? "lps_bgzf_load: a block does not inflate to its ISIZE"
                                                                 : "lps_bgzf_load: CRC32 mismatch in a BGZF block");
         c->file_bytes = utot;
         if (inflated_bytes) *inflated_bytes = (int64_t)utot;
@@ -948,6 +999,7 @@ int lps_bgzf_deflate_fetch_range(lps_ctx *c, int64_t offset, int64_t n, uint8_t 
 void *lps_host_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 void lps_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+int lps_bgzf_retried(lps_ctx *c) { return c ? (c->bgzf_retried ? 1 : 0) : -1; }
 int lps_bgzf_timings(lps_ctx *c, double *h2d_ms, double *inflate_ms) {
     if (!c) return -1;
     if (h2d_ms) *h2d_ms = c->bgzf_h2d_ms;
@@ -1027,60 +1079,12 @@ static VarView var_view(lps_ctx *c) {
     V.n_bucket = (int)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 1; V.bucket = c->v_bucket.p; V.rec = c->v_rec.p;
     return V;
 }
-// the interleaved base + quality blocks of the resident alignments (lps_prepare_reads; lps_phase_chromosome builds them itself when the caller did not)
-static int prepare_reads(lps_ctx *c) {
-    if (c->sq_reads == c->nR || c->nR == 0) return 0;
-    hipStream_t s = c->stream; const int n = c->nR;
-    ReadView R{}; R.n = n; R.l_qseq = c->r_lq.p; R.seq_off = c->r_soff.p; R.qual_off = c->r_qoff.p;
-    if (c->read_mode == 2) R.seq = R.qual = c->blob.p; else if (c->read_mode == 3) R.seq = R.qual = c->file.p; else { R.seq = c->seq.p; R.qual = c->qual.p; }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    struct Ev { hipEvent_t a, b; ~Ev() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } guard{e0, e1};
-    HIP_TRY(hipEventRecord(e0, s));
-    c->sq_cnt.reserve((size_t)n + 2); c->r_sqblk.reserve((size_t)n + 2);
-    launch_sq_count(n, c->r_lq.p, c->sq_cnt.p, s);
-    const size_t need = GraphTemp::need((size_t)n + 2);
-    if (need > c->temp_bytes) { c->temp.reserve(need); c->temp_bytes = need; }
-    exscan_u32(c->temp.p, c->temp_bytes, c->sq_cnt.p, c->r_sqblk.p, (size_t)n + 1, s);
-    uint32_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, c->r_sqblk.p + n, sizeof total, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    c->sq.reserve((size_t)total * 128 + 128);
-    launch_sq_pack(R, c->r_sqblk.p, c->sq.p, s);
-    HIP_TRY(hipEventRecord(e1, s)); HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipEventElapsedTime(&c->sq_ms, e0, e1));
-    c->sq_reads = n;
-    return 0;
-}
-
-// the CIGAR words in lane-chunks (lps_reads.hip): what the stream walks of phase and haplotag read
-static int prepare_cigar(lps_ctx *c) {
-    if (c->cp_reads == c->nR || c->nR == 0) return 0;
-    hipStream_t s = c->stream; const int n = c->nR;
-    c->cp_cnt.reserve((size_t)n + 2); c->cp_off.reserve((size_t)n + 2); c->cp_n.reserve((size_t)n + 2);
-    const size_t need = GraphTemp::need((size_t)n + 2);
-    if (need > c->temp_bytes) { c->temp.reserve(need); c->temp_bytes = need; }
-    unsigned *flag = reinterpret_cast<unsigned *>(c->cp_cnt.p + n + 1);
-    HIP_TRY(hipMemsetAsync(flag, 0, 4, s));
-    launch_cp_count(n, c->r_coff.p, c->cp_cnt.p, c->cp_n.p, flag, s);
-    exscan_u32(c->temp.p, c->temp_bytes, c->cp_cnt.p, c->cp_off.p, (size_t)n + 1, s);
-    uint32_t total = 0, bad = 0;
-    HIP_TRY(hipMemcpyAsync(&total, c->cp_off.p + n, sizeof total, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof bad, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (bad || (uint64_t)total * 8 < c->n_cig) return fail(c, "CIGAR arrays beyond 2^35 words per chromosome (or 2^31 per alignment) are not supported");
-    c->cigp.reserve((size_t)total * 8 + 64);
-    launch_cp_pack(n, c->r_coff.p, c->cigar.p, c->cp_off.p, c->cigp.p, s);
-    c->cp_reads = n;
-    return 0;
-}
-
 static ReadView read_view(lps_ctx *c) {
     ReadView R{};
     R.n = c->nR; R.ref_start = c->r_start.p; R.l_qseq = c->r_lq.p; R.flag = c->r_flag.p; R.mapq = c->r_mapq.p; R.name_id = c->r_name.p;
-    R.cigar_off = c->r_coff.p; R.seq_off = c->r_soff.p; R.qual_off = c->r_qoff.p; R.cigar = c->cigar.p;
+    R.seq_off = c->r_soff.p; R.qual_off = c->r_qoff.p;
     if (c->read_mode == 2) R.seq = R.qual = c->blob.p; else if (c->read_mode == 3) R.seq = R.qual = c->file.p; else { R.seq = c->seq.p; R.qual = c->qual.p; }
-    R.sq = c->sq.p; R.sq_blk = c->r_sqblk.p; R.v0 = c->r_v0.p; R.cigp = c->cigp.p; R.cp_off = c->cp_off.p; R.cp_n = c->cp_n.p;
+    R.v0 = c->r_v0.p; R.cigp = c->cigar.p; R.cp_off = c->cp_off.p; R.cp_n = c->cp_n.p;
     return R;
 }
 
@@ -1311,17 +1315,6 @@ static void deliver_result(lps_ctx *c, lps_phase_result *out) {
     for (int i = 0; i < c->nV; ++i) { out->phase_set[i] = ps[c->h_snp_u[i]]; out->gt[i] = gt[c->h_snp_u[i]]; }
 }
 
-int lps_prepare_reads(lps_ctx *c, double *ms) {
-    if (!c) return -1;
-    try {
-        HIP_TRY(hipSetDevice(c->device));
-        const bool had = c->sq_reads == c->nR;
-        if (prepare_reads(c) != 0 || prepare_cigar(c) != 0) return -1;
-        if (ms) *ms = had ? 0.0 : (double)c->sq_ms;
-    } catch (std::string &e) { return fail(c, e); }
-    return 0;
-}
-
 int lps_debug_set_obs_capacity(lps_ctx *c, int64_t slots) {
     if (!c || slots < 0) return -1;
     c->obs_capacity = (unsigned long long)slots;
@@ -1341,9 +1334,8 @@ int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
         if (out->n != c->nV) return fail(c, "lps_phase_result.n must equal the variant table size");
         memset(out->phase_set, 0, (size_t)out->n * sizeof(int32_t)); memset(out->gt, 0, (size_t)out->n);
         c->phase_valid = false; c->h_res_ps_u.clear(); c->h_res_gt_u.clear();
-        if (c->nV == 0 || c->nR == 0) { c->phase_valid = c->nV != 0; return 0; }
+        if (c->nV == 0 || c->nR == 0) { c->h_cnt = LpsCounters{}; memset(c->h_stats, 0, sizeof c->h_stats); c->h_cnv_start.clear(); c->h_cnv_end.clear(); c->phase_valid = c->nV != 0; return 0; }   // (the dump entries then report an empty graph, not the previous chromosome's)
         if (c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
-        if (prepare_reads(c) != 0 || prepare_cigar(c) != 0) return -1;
         c->in_phase = true;
         int rc = run_phase(c);
         c->in_phase = false;
@@ -1491,7 +1483,6 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
         const bool votes = !c->votes_h1.empty();
         if (votes && (int)c->votes_h1.size() != nR) return fail(c, "lps_set_read_votes was called for another set of alignments");
         hipStream_t s = c->stream;
-        if (prepare_cigar(c) != 0) return -1;
         // ---- one 16-byte record per read: votes, PS and the read-level decision (judgeReadHap, HaplotagStrategy.cpp:243-300) taken on the GPU
         c->hap_rec.reserve((size_t)nR + 1);
         const size_t span = (size_t)nR * sizeof(uint4);
@@ -1720,6 +1711,7 @@ int lps_get_timings(lps_ctx *c, lps_timings *t) { if (!c || !t) return -1; *t = 
 // ------------------------------------------------------------------------------------------------ dumps
 int64_t lps_dump_observations(lps_ctx *c, int32_t *obs_count, int32_t *var_index, int8_t *allele, int16_t *quality, int64_t capacity) {
     if (!c || !c->phase_valid) return -1;
+    if (c->nR == 0) return 0;                                            // nothing ran
     try {
         HIP_TRY(hipSetDevice(c->device));
         auto rows = download(c, c->rows.p, c->nR);

@@ -16,8 +16,9 @@ struct BamView {
 };
 
 void launch_bam_core(const BamView &B, int n, int at, int32_t *ref_start, int32_t *l_qseq, uint16_t *flag, uint8_t *mapq, uint64_t *seq_off,
-                     uint64_t *qual_off, unsigned long long *cig_cnt, uint64_t *cig_src, unsigned *err, hipStream_t s);
-void launch_bam_cigar(const BamView &B, int n, const uint64_t *cigar_off, const uint64_t *cig_src, uint32_t *cigar, hipStream_t s);
+                     uint64_t *qual_off, unsigned long long *cig_cnt /* [n+1] lane-chunks */, int32_t *cig_n /* [at + i] words */, uint64_t *cig_src, unsigned *err, hipStream_t s);
+// words of record i -> chunks [chunk_off[i], chunk_off[i+1]) of cigp (padded with 6u), cp_off[i] = (uint32_t)chunk_off[i] for i = 0..n
+void launch_bam_cigar(const BamView &B, int n, const uint64_t *chunk_off, const int32_t *cig_n, const uint64_t *cig_src, uint32_t *cigp, uint32_t *cp_off, hipStream_t s);
 void bam_cigar_offsets(DevBuf<char> &temp, size_t &temp_bytes, const unsigned long long *cig_cnt, uint64_t *cigar_off, int n, uint64_t init, hipStream_t s);
 // record discovery in a resident (GPU-inflated) BAM stream; returns 0, or <0: -2 stream too large, -3 no record found, -4 broken record chain
 int bam_scan_records(const uint8_t *d, uint64_t first_rec, uint64_t total, int32_t n_ref, DevBuf<uint64_t> &cand, DevBuf<uint32_t> &wg_cnt, DevBuf<uint32_t> &wg_off,

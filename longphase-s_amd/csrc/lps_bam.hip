@@ -4,7 +4,8 @@
 //                src/phase/ParsingBam.cpp:1282-1299,1303-1316) -> ref_start/flag/mapq/l_qseq, CIGAR op count,
 //                seq/qual byte offsets INTO the blob (4-bit seq and qual are used in place, no copy)
 //   k_bam_cigar  wave per record: the CIGAR words are at arbitrary byte alignment inside a record; they are re-packed
-//                into an aligned u32 array with two aligned dword loads + v_alignbyte per word
+//                with two aligned dword loads + v_alignbyte per word, straight into the resident lane-chunk layout
+//                (every alignment padded to a multiple of 8 words, lps_reads.hip)
 // Records are validated against the blob bounds before any kernel dereferences the offsets they imply.
 #include <hip/hip_runtime.h>
 
@@ -57,14 +58,15 @@ __device__ __forceinline__ uint32_t find_cg_field(const uint8_t *r, uint32_t blo
 
 
 __global__ void __launch_bounds__(256) k_bam_core(BamView B, int n, int at, int32_t *ref_start, int32_t *l_qseq, uint16_t *flag, uint8_t *mapq,
-                                                  uint64_t *seq_off, uint64_t *qual_off, unsigned long long *cig_cnt, uint64_t *cig_src, unsigned *err) {
+                                                  uint64_t *seq_off, uint64_t *qual_off, unsigned long long *cig_cnt /* lane-chunks of 8 words */, int32_t *cig_n /* words */,
+                                                  uint64_t *cig_src, unsigned *err) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i > n) return;
     if (i == n) { cig_cnt[n] = 0; return; }
     const uint64_t ro = B.rec_off[i];
     unsigned e = 0;
     if (ro < 4 || ro + 32 > B.push_bytes) { atomicOr(err,
-            LPS_BAM_ERR_BOUNDS); cig_cnt[i] = 0; cig_src[i] = B.push_base; ref_start[at + i] = 0; l_qseq[at + i] = 0; flag[at + i] = 4; mapq[at + i] = 0; seq_off[at + i] = qual_off[at + i] = B.push_base; return; }
+            LPS_BAM_ERR_BOUNDS); cig_cnt[i] = 0; cig_n[at + i] = 0; cig_src[i] = B.push_base; ref_start[at + i] = 0; l_qseq[at + i] = 0; flag[at + i] = 4; mapq[at + i] = 0; seq_off[at + i] = qual_off[at + i] = B.push_base; return; }
     const uint8_t *r = B.blob + B.push_base + ro;
     const uint32_t block_size = ld_u32_unaligned(r - 4);
     const int32_t pos = (int32_t)ld_u32_unaligned(r + 4);
@@ -84,29 +86,33 @@ __global__ void __launch_bounds__(256) k_bam_core(BamView B, int n, int at, int3
     if (e) atomicOr(err, e);
     const bool ok = (e & LPS_BAM_ERR_BOUNDS) == 0;
     ref_start[at + i] = pos; l_qseq[at + i] = ok ? (int32_t)l_seq : 0; flag[at + i] = (uint16_t)fl; mapq[at + i] = (uint8_t)mq;
-    cig_cnt[i] = ok ? n_real : 0; cig_src[i] = src;
+    cig_cnt[i] = ok ? (n_real + 7u) >> 3 : 0; cig_n[at + i] = ok ? (int32_t)n_real : 0; cig_src[i] = src;
     const uint64_t so = B.push_base + ro + 32 + l_name + 4ull * n_cig;
     seq_off[at + i] = ok ? so : B.push_base; qual_off[at + i] = ok ? so + (l_seq + 1ull) / 2 : B.push_base;
 }
 
-__global__ void __launch_bounds__(256) k_bam_cigar(BamView B, int n, const uint64_t *cigar_off /* [n+1], absolute */, const uint64_t *cig_src, uint32_t *cigar) {
+__global__ void __launch_bounds__(256) k_bam_cigar(BamView B, int n, const uint64_t *chunk_off /* [n+1], absolute */, const int32_t *cig_n, const uint64_t *cig_src,
+                                                   uint32_t *cigp, uint32_t *cp_off) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= n) return;
-    const uint64_t c0 = cigar_off[i]; const int n_cig = (int)(cigar_off[i + 1] - c0);
-    if (n_cig == 0) return;
+    if (i > n) return;
+    const uint64_t c0 = chunk_off[i];
+    if (lane == 0) cp_off[i] = (uint32_t)c0;
+    if (i == n) return;
+    const int n_cig = cig_n[i], n_pad = (int)(chunk_off[i + 1] - c0) * 8;
     const uint8_t *src = B.blob + cig_src[i];                            // behind the read name, or inside the CG field
-    for (int j = lane; j < n_cig; j += 64) cigar[c0 + j] = ld_u32_unaligned(src + 4ull * j);
+    uint32_t *dst = cigp + 8ull * c0;
+    for (int j = lane; j < n_pad; j += 64) dst[j] = j < n_cig ? ld_u32_unaligned(src + 4ull * j) : 6u;   // (6u: op P, length 0)
 }
 
 void launch_bam_core(const BamView &B, int n, int at, int32_t *ref_start, int32_t *l_qseq, uint16_t *flag, uint8_t *mapq, uint64_t *seq_off,
-                     uint64_t *qual_off, unsigned long long *cig_cnt, uint64_t *cig_src, unsigned *err, hipStream_t s) {
-    hipLaunchKernelGGL(k_bam_core, dim3((n + 1 + 255) / 256), dim3(256), 0, s, B, n, at, ref_start, l_qseq, flag, mapq, seq_off, qual_off, cig_cnt, cig_src, err);
+                     uint64_t *qual_off, unsigned long long *cig_cnt, int32_t *cig_n, uint64_t *cig_src, unsigned *err, hipStream_t s) {
+    hipLaunchKernelGGL(k_bam_core, dim3((n + 1 + 255) / 256), dim3(256), 0, s, B, n, at, ref_start, l_qseq, flag, mapq, seq_off, qual_off, cig_cnt, cig_n, cig_src, err);
 }
-void launch_bam_cigar(const BamView &B, int n, const uint64_t *cigar_off, const uint64_t *cig_src, uint32_t *cigar, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_bam_cigar, dim3((n + 3) / 4), dim3(256), 0, s, B, n, cigar_off, cig_src, cigar);
+void launch_bam_cigar(const BamView &B, int n, const uint64_t *chunk_off, const int32_t *cig_n, const uint64_t *cig_src, uint32_t *cigp, uint32_t *cp_off, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_bam_cigar, dim3((n + 1 + 3) / 4), dim3(256), 0, s, B, n, chunk_off, cig_n, cig_src, cigp, cp_off);
 }
 
-// cigar_off[at + i] = init + sum_{k<i} cig_cnt[k], i = 0..n  (cig_cnt[n] == 0)
+// cigar_off[i] = init + sum_{k<i} cig_cnt[k], i = 0..n  (cig_cnt[n] == 0); counts and offsets in lane-chunks
 void bam_cigar_offsets(DevBuf<char> &temp, size_t &temp_bytes, const unsigned long long *cig_cnt, uint64_t *cigar_off, int n, uint64_t init, hipStream_t s) {
     size_t need = 0;
     unsigned long long *out = reinterpret_cast<unsigned long long *>(cigar_off);

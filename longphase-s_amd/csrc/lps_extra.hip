@@ -50,8 +50,8 @@ __device__ void extra_merge_one(const int r, const int arena, const VarView &V, 
     const int start = R.ref_start[r], flag = R.flag[r];
     const bool live = !(R.mapq[r] < mapping_quality || (flag & 0x4) || (flag & 0x100) || (flag & 0x400) || start >= V.last_pos) && rd.fail == 0x7fffffff;
     if (!live) return;                                                  // filtered (:1282-1291) or get_snp returned early: the alignment has no row
-    const int n_cig = (int)(R.cigar_off[r + 1] - R.cigar_off[r]);
-    const uint32_t *cig = R.cigar + R.cigar_off[r];
+    const int n_cig = R.cp_n[r];
+    const uint32_t *cig = R.cig(r);
     const uint32_t name = R.name_id[r];
     const bool rev = (flag & 0x10) != 0;
 
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
         if (l < 4) {
             ExtHdr &h = s_hdr[l];
             h.crel = 8 * h_c0; h.ncig = h_walk ? h_n : 0; h.c0 = h_c0; h.nch = h_walk ? h_nch : 0;
-            h.lq = h_flag; h.blk0 = h_name;
+            h.lq = h_flag; h.soff = h_name;
         }
         // ---- walk: coordinates like stream_round (lps_kernels.h) + the running maximum of E, a segmented inclusive max-scan (heads = first chunks)
         int carry_r = 0, carry_e = (int)0x80000000; uint32_t big = 0; bool absurd = false;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64, 4) void k_extra_find(VarView V, ReadView R, Obs
                         }
                         emit = true; rec = ObsRec{xu, (uint32_t)pack_aq(allele, -1)};
                     } else {                                            // :1377-1392
-                        const uint32_t name = s_hdr[q].blk0; const bool rev = (hflag & 0x10) != 0;
+                        const uint32_t name = (uint32_t)s_hdr[q].soff; const bool rev = (hflag & 0x10) != 0;
                         uint32_t lo = m_lo, hi = m_hi; const uint32_t end = hi;
                         // first listed read with name >= this one: a 4-ary search over name << 2 | flags (three probes a trip: a site lists a read per fold of coverage)
                         const uint32_t key = name << 2;

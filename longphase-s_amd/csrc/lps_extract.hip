@@ -147,10 +147,10 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
     auto to_redo = [&]() __attribute__((always_inline)) { no_clips(); if (l == 0) redo_list[atomicAdd(n_redo, 1u)] = (uint32_t)job; };
 
     // ---- plan: headers, alignment q in lane q.  direct_detect_alleles filters (:1282-1291) + region "chr:1-<lastSNPPos>" (:1273)
-    int h_start = 0, h_lq = 0, h_v0 = 0, h_n = 0; bool h_live = false; unsigned h_cp = 0, h_blk = 0;
+    int h_start = 0, h_lq = 0, h_v0 = 0, h_n = 0; bool h_live = false; unsigned h_cp = 0; unsigned long long h_soff = 0, h_qoff = 0;
     if (l <= nq) h_cp = R.cp_off[r0 + l];
     if (l < nq) {
-        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_blk = R.sq_blk[r]; h_v0 = V.n ? R.v0[r] : 0; h_n = R.cp_n[r];
+        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r]; h_qoff = R.qual_off[r]; h_v0 = V.n ? R.v0[r] : 0; h_n = R.cp_n[r];
         const int flag = R.flag[r];
         h_live = !(R.mapq[r] < mapping_quality || (flag & 0x4) || (flag & 0x100) || (flag & 0x400) || h_start >= V.last_pos);
     }
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
         if (l < 4) {                                                      // (first half of the header)
             ExtHdr &h = s_hdr[l];
             h.crel = fast ? 8 * h_c0 : 0; h.ncig = h_walk ? h_n : 0; h.c0 = fast ? h_c0 : 0; h.nch = h_walk ? (int)(((unsigned)h_nch + (1u << shift) - 1u) >> shift) : 0;
-            h.lq = h_lq; h.blk0 = h_blk;
+            h.lq = h_lq; h.soff = h_soff; h.qoff = h_qoff;
         }
 
         // ---- walk.  FOUR rounds per trip, all four requested at its head: 8 KB of the stream in flight per wave, one exposed memory latency per
@@ -370,10 +370,11 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
                             else if (kind == 2) { allele = 1; qv = -4; }
                         }
                     }
-                    if (qi >= 0) {                                                // base and quality at the variant site: one 128-byte line holds both
+                    if (qi >= 0) {                                                // base and quality at the variant site, in place (the BAM record's own encodings)
                         const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
                         int code;
-                        sq_fetch(R.sq, s_hdr[q].blk0, qi, code, qv);
+                        const ulonglong2 sqo = *reinterpret_cast<const ulonglong2 *>(&s_hdr[q].soff);
+                        sq_fetch(R.seq, R.qual, sqo.x, sqo.y, qi, code, qv);
                         const char base_c = nt16_char(code);
                         if (base_c == ref_c) allele = 0; else if (base_c == alt_c) allele = 1;
                     }
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
     __shared__ __attribute__((aligned(16))) uint32_t s_cig[4][LPS_SEG + 4];
     __shared__ int s_bvar[4][REDO_CAP];
     __shared__ uint32_t s_baq[4][REDO_CAP];
-    enum { H_START, H_LQ, H_REL, H_V0, H_SOFF, H_QOFF = H_SOFF + 2, H_KIND = H_QOFF + 2, H_ROFF, H_RCNT, H_RFAIL, H_RFLAGS, H_WORDS };
+    enum { H_START, H_LQ, H_CP, H_NCIG, H_V0, H_SOFF, H_QOFF = H_SOFF + 2, H_KIND = H_QOFF + 2, H_ROFF, H_RCNT, H_RFAIL, H_RFLAGS, H_WORDS };
     enum { ROW_DEAD = 0, ROW_BUFFERED = 1, ROW_GLOBAL = 2 };
     __shared__ int s_hdr[4][EXT_RPW + 1][H_WORDS];
     const int w = threadIdx.x >> 6, l = lane_id();
@@ -473,17 +474,14 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
     const int nq = min(EXT_RPW, R.n - r0);
 
     // ---- plan: headers, alignment q in lane q.  direct_detect_alleles filters (:1282-1291) + region "chr:1-<lastSNPPos>" (:1273)
-    int h_start = 0, h_lq = 0, h_rel = 0; bool h_live = false; unsigned long long h_coff = 0; unsigned h_blk = 0;
-    if (l <= nq) h_coff = R.cigar_off[r0 + l];
+    int h_start = 0, h_lq = 0, h_n = 0; bool h_live = false; unsigned h_cp = 0; unsigned long long h_soff = 0, h_qoff = 0;
     if (l < nq) {
-        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_blk = R.sq_blk[r];
+        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r]; h_qoff = R.qual_off[r]; h_cp = R.cp_off[r]; h_n = R.cp_n[r];
         const int flag = R.flag[r];
         h_live = !(R.mapq[r] < mapping_quality || (flag & 0x4) || (flag & 0x100) || (flag & 0x400) || h_start >= V.last_pos);
     }
     const unsigned live_mask = (unsigned)__ballot(h_live) & 15u;
-    const unsigned long long c_lo = __shfl(h_coff, 0);
-    if (l <= nq) h_rel = (int)(h_coff - c_lo);                         // op index of alignment q's first op inside the wave's CIGAR range
-    const uint32_t *cg = R.cigar + c_lo;
+    const uint32_t *cg = R.cigp;                                       // alignment q's words: cg + 8 * (its first lane-chunk), cp_n of them
 
     // what was requested ahead for segment (pf_q, pf_seg): CIGAR words, op after the segment, candidate records, predecessor position
     uint32_t pw[8]; uint32_t pnext = 0xfu; uint2 pvr = make_uint2(0x7fffffffu, 0u); int ppv = -1;
@@ -492,7 +490,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
     for (int u = 0; u < 8; ++u) pw[u] = 6u;
     int q = live_mask ? __builtin_ctz(live_mask) : nq;
     if (q < nq) {                                                      // first segment of the first alignment: on its way while the bounds are searched
-        const int crel = __shfl(h_rel, q), ncq = __shfl(h_rel, q + 1) - crel;
+        const unsigned long long crel = 8ull * (unsigned)__shfl((int)h_cp, q); const int ncq = __shfl(h_n, q);
         if (ncq > 0) {
             const int nsegn = min(LPS_SEG, ncq);
             pnext = (nsegn < ncq) ? cg[crel + nsegn] : 0xfu;
@@ -505,10 +503,10 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
     if (l < 4 && h_live) h_v0 = lane_var_lower_bound(V, h_start);
     if (l <= 4) {
         int *h = s_hdr[w][l];
-        h[H_REL] = h_rel;
+        h[H_CP] = (int)h_cp; h[H_NCIG] = h_n;
         if (l < 4) {
             h[H_START] = h_start; h[H_LQ] = h_lq; h[H_V0] = h_v0;
-            h[H_SOFF] = (int)h_blk; h[H_SOFF + 1] = 0; h[H_QOFF] = 0; h[H_QOFF + 1] = 0;
+            h[H_SOFF] = (int)(unsigned)h_soff; h[H_SOFF + 1] = (int)(unsigned)(h_soff >> 32); h[H_QOFF] = (int)(unsigned)h_qoff; h[H_QOFF + 1] = (int)(unsigned)(h_qoff >> 32);
             h[H_KIND] = ROW_DEAD; h[H_ROFF] = 0; h[H_RCNT] = 0; h[H_RFAIL] = 0x7fffffff; h[H_RFLAGS] = 0;
         }
     }
@@ -523,15 +521,15 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
         const int r = r0 + q;
         int *h = hdr + q * H_WORDS;
 #define HU(i) __builtin_amdgcn_readfirstlane(h[i])
-        const int start = HU(H_START), lq = HU(H_LQ), crel = HU(H_REL), n_cig = HU(H_WORDS + H_REL) - crel;
-        const uint32_t *cig = cg + crel;
-        const unsigned blk0 = (unsigned)HU(H_SOFF);                      // first block of the read's interleaved bases + qualities
+        const int start = HU(H_START), lq = HU(H_LQ), n_cig = HU(H_NCIG);
+        const uint32_t *cig = cg + 8ull * (unsigned)HU(H_CP);
+        const unsigned long long soff = (unsigned)HU(H_SOFF) | ((unsigned long long)(unsigned)HU(H_SOFF + 1) << 32), qoff = (unsigned)HU(H_QOFF) | ((unsigned long long)(unsigned)HU(H_QOFF + 1) << 32);
         int vcur = HU(H_V0);
 #undef HU
         const unsigned rest = live_mask >> (q + 1);
         const int qn = rest ? q + 1 + __builtin_ctz(rest) : nq;                 // next alignment to walk
-        const int *hn = hdr + qn * H_WORDS;                                     // (row nq exists: only its H_REL is meaningful)
-        const int n_cig_n = qn < nq ? hn[H_WORDS + H_REL] - hn[H_REL] : 0;
+        const int *hn = hdr + qn * H_WORDS;                                     // (row nq exists; nothing of it is used)
+        const int n_cig_n = qn < nq ? hn[H_NCIG] : 0;
 
         int ref_pos = start, q_pos = 0, n_emit = 0, fail_op = 0x7fffffff;
         bool had_any = false, direct = false;
@@ -583,7 +581,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
             const bool same = seg0 + LPS_SEG < n_cig;
             const bool has_next = same || (qn < nq && n_cig_n > 0);
             if (has_next) {
-                const uint32_t *cign = same ? cig : cg + hn[H_REL];
+                const uint32_t *cign = same ? cig : cg + 8ull * (unsigned)hn[H_CP];
                 const int segn = same ? seg0 + LPS_SEG : 0, ncn = same ? n_cig : n_cig_n, nsegn = min(LPS_SEG, ncn - segn);
                 pnext = (segn + nsegn < ncn) ? cign[segn + nsegn] : 0xfu;
                 request_ops8(cign + segn, 8 * l, nsegn, pw);
@@ -631,7 +629,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
                                 if (qs + off + 1 > lq) fail = true;                           // :1453-1455
                                 else if (kind == 0) {
                                     const int qi = qs + off;
-                                    int code; sq_fetch(R.sq, blk0, qi, code, qv);
+                                    int code; sq_fetch(R.seq, R.qual, soff, qoff, qi, code, qv);
                                     const char base_c = nt16_char(code);
                                     if (base_c == ref_c) allele = 0; else if (base_c == alt_c) allele = 1;
                                     emit = allele != -1;
@@ -647,7 +645,7 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
                                 if (first_in && (at & VREC_HPOLY3)) {
                                     if (qs + 1 > lq) fail = true;                             // :1559-1561
                                     else if (kind == 0) {
-                                        int code; sq_fetch(R.sq, blk0, qs, code, qv);
+                                        int code; sq_fetch(R.seq, R.qual, soff, qoff, qs, code, qv);
                                         const char base_c = nt16_char(code);
                                         if (base_c == ref_c) allele = 0; else if (base_c == alt_c) allele = 1;
                                         emit = allele != -1;

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
     const int start = R.ref_start[r];
     const int flag = R.flag[r];
     // every field of the read's header in one round trip (the filter cascade below needs three of them; the others used to be a second trip)
-    const uint64_t coff = R.cigar_off[r], coff_end = R.cigar_off[r + 1], soff = R.seq_off[r];
+    const uint64_t soff = R.seq_off[r]; const unsigned cp0 = R.cp_off[r]; const int n_words = R.cp_n[r];
     const int lq = R.l_qseq[r];
     constexpr bool SOMATIC = MODE == 1;
     constexpr bool EXTRACT = MODE == 2 || MODE == 3;
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
     else if (!(start <= V.last_pos)) status = 6;
     int h1 = 0, h2 = 0, h3 = 0, d1 = 0, d2 = 0, ps_lo = 0x7fffffff, ps_hi = (int)0x80000000;
     if (status == 0) {
-        const int n_cig = (int)(coff_end - coff);
-        const uint32_t *cig = R.cigar + coff;
+        const int n_cig = n_words;
+        const uint32_t *cig = R.cigp + 8ull * cp0;
         const uint8_t *seq = R.seq + soff;
         uint32_t pw[8];                                              // the NEXT segment's words, requested while the current one is searched
         request_ops8(cig, 8 * l, min(LPS_SEG, n_cig), pw);            // (the first segment's: on their way while the first candidate is searched)
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
         if (l < 4) {
             ExtHdr &h = s_hdr[l];
             h.crel = fast ? 8 * h_c0 : 0; h.ncig = h_walk ? h_n : 0; h.c0 = fast ? h_c0 : 0; h.nch = h_walk ? (int)(((unsigned)h_nch + (1u << shift) - 1u) >> shift) : 0;
-            h.lq = h_lq; h.blk0 = (unsigned)h_soff; h.pad0 = (unsigned)(h_soff >> 32);
+            h.lq = h_lq; h.soff = h_soff;
         }
         // ---- walk: four rounds per trip, all four requested at its head (see k_extract_phase); it counts the words whose op the reference rejects
         int carry_r = 0, carry_q = 0; unsigned special = 0; uint32_t big = 0; bool absurd = false;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
                 if (ps < rs + len) {
                     const unsigned kind = VREC_KIND(at);
                     const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
-                    const uint8_t *seq = R.seq + ((unsigned long long)s_hdr[q].blk0 | ((unsigned long long)s_hdr[q].pad0 << 32));
+                    const uint8_t *seq = R.seq + s_hdr[q].soff;
                     if (op_is_match(op)) {                                        // judgeSnpHap (:20-130)
                         if (kind == 0) {
                             const int qi = qs + (ps - rs);

@@ -96,7 +96,7 @@ __device__ __forceinline__ bool canon_tables(const Pack16 &cnt, uint16_t *lim, u
 // cadence: few stores, so the in-order vmcnt queue does not stall the input prefetch behind them.
 #define INF_SCRATCH 320      // code lengths of one header per lane (<= 286 + 30), bytes; column layout [i][lane] per wavefront
 __global__ void __launch_bounds__(INF_LANES) k_bgzf_inflate(const uint8_t *__restrict__ in, const InflateBlock *__restrict__ blk, int n_blk, uint8_t *out, unsigned *err,
-                                                      uint8_t *scratch, const unsigned long long *uploaded, unsigned long long total_in) {
+                                                      uint8_t *scratch, const unsigned long long *uploaded, unsigned long long total_in, long long timeout_ticks) {
     __shared__ uint8_t s_lsym8[288 * INF_LANES];                                  // low byte of the (length, symbol)-sorted litlen symbols
     __shared__ uint8_t s_lhi[36 * INF_LANES];                                     // their ninth bit, 8 per byte
     __shared__ uint16_t s_llim[16 * INF_LANES], s_lbase[16 * INF_LANES];                 // litlen lengths 1..15
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(INF_LANES) k_bgzf_inflate(const uint8_t *__res
             if (have >= need) break;
             const unsigned long long naps = (need - have) >> 18;            // 3.4 us each (s_sleep 127 = 8 128 cycles): 256 KiB of upload take 6.5 us
             for (unsigned long long k = 0, n_k = naps < 1 ? 1 : naps > 4096 ? 4096 : naps; k < n_k; ++k) __builtin_amdgcn_s_sleep(127);
-            if (wall_clock64() - t0 > 500000000ll) { timed_out = true; break; }
+            if (wall_clock64() - t0 > timeout_ticks) { timed_out = true; break; }
         }
         if (timed_out) { if (lane == 0) atomicOr(err, (unsigned)LPS_INF_ERR_TIMEOUT); return; }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -388,6 +388,7 @@ void launch_bgzf_crc(const uint8_t *in, const InflateBlock *blk, int n_blk, cons
 
 size_t bgzf_inflate_scratch_bytes(int n_blk) { return (size_t)((n_blk + INF_LANES - 1) / INF_LANES) * INF_SCRATCH * INF_LANES; }
 void launch_bgzf_inflate(const uint8_t *in, const InflateBlock *blk, int n_blk, uint8_t *out, unsigned *err, uint8_t *scratch, hipStream_t s,
-                         const unsigned long long *uploaded, unsigned long long total_in) {
-    if (n_blk > 0) hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_blk + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), 0, s, in, blk, n_blk, out, err, scratch, uploaded, total_in);
+                         const unsigned long long *uploaded, unsigned long long total_in, double timeout_ms) {
+    const long long ticks = (long long)(timeout_ms * 1e5);               // wall_clock64 counts at 100 MHz
+    if (n_blk > 0) hipLaunchKernelGGL(k_bgzf_inflate, dim3((n_blk + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), 0, s, in, blk, n_blk, out, err, scratch, uploaded, total_in, ticks);
 }

@@ -29,27 +29,28 @@ struct ReadView {
     const uint16_t *flag;
     const uint8_t *mapq;
     const uint32_t *name_id;
-    const uint64_t *cigar_off, *seq_off, *qual_off;
-    const uint32_t *cigar;
+    const uint64_t *seq_off, *qual_off;   // byte offsets of a read's 4-bit bases / its qualities inside seq / qual (for BAM-record pushes both point into the record blob: used in place)
     const uint8_t *seq, *qual;
-    const uint8_t *sq;         // bases + qualities interleaved in 128-byte blocks of LPS_SQ_BASES bases (lps_reads.hip); read r starts at block sq_blk[r]
-    const uint32_t *sq_blk;
-    const uint32_t *cigp;      // the CIGAR words in lane-chunks of 8, every alignment padded to a whole number of them (lps_reads.hip): read r = chunks [cp_off[r], cp_off[r + 1]), cp_n[r] words
+    // The CIGAR words, resident in lane-chunks of 8 (lps_reads.hip): every alignment starts on a multiple of 8 words and is padded to one with op P,
+    // length 0.  Read r = chunks [cp_off[r], cp_off[r + 1]), cp_n[r] real words.  Written in this layout by whatever makes the alignments resident
+    // (lps_push_reads*, the BAM record decoder): there is no second copy and no pass between a push and the kernels.
+    const uint32_t *cigp;
     const uint32_t *cp_off;
     const int32_t *cp_n;
     const int32_t *v0;         // first variant at or after the alignment's start (k_read_v0: one thread per alignment, before the wave-per-job kernels)
-};
-#define LPS_SQ_BASES 84
-void launch_sq_count(int n, const int32_t *l_qseq, uint32_t *nblk, hipStream_t s);
-void launch_sq_pack(const ReadView &R, const uint32_t *blk, uint8_t *sq, hipStream_t s);
-void launch_cp_count(int n, const uint64_t *cigar_off, uint32_t *nch, int32_t *ncig, unsigned *too_long, hipStream_t s);
-void launch_cp_pack(int n, const uint64_t *cigar_off, const uint32_t *cigar, const uint32_t *cp_off, uint32_t *cigp, hipStream_t s);
 #ifdef __HIPCC__
-// base code (4 bits) and quality of query index qi of a read whose first block is at `blk0`: both from ONE 128-byte line
-__device__ __forceinline__ void sq_fetch(const uint8_t *__restrict__ sq, uint32_t blk0, int qi, int &code, int &qual) {
-    const int b = qi / LPS_SQ_BASES, t = qi - b * LPS_SQ_BASES;
-    const uint8_t *p = sq + ((size_t)blk0 + (unsigned)b) * 128;
-    code = (p[LPS_SQ_BASES + (t >> 1)] >> ((~t & 1) << 2)) & 15; qual = p[t];
+    __device__ __forceinline__ const uint32_t *cig(int r) const { return cigp + 8ull * cp_off[r]; }
+#endif
+};
+// lps_reads.hip: a pushed batch's CIGAR words (dense, cigar_off[i]..cigar_off[i+1]) into the resident lane-chunk layout
+void launch_cp_count(int n, const uint64_t *cigar_off, uint32_t *nch, int32_t *ncig, unsigned *too_long, hipStream_t s);
+void launch_cp_pack(int n, const uint64_t *cigar_off, const uint32_t *cigar, const uint32_t *rel_off, uint32_t chunk_base, uint32_t *cp_off, uint32_t *cigp, hipStream_t s);
+void launch_sum_i32(const int32_t *v, int n, unsigned long long *out, hipStream_t s);
+#ifdef __HIPCC__
+// base code (4 bits) and quality of query index qi of a read whose bases start at seq + soff and whose qualities start at qual + qoff (the BAM
+// record's own encodings, read in place: two lines of HBM per site)
+__device__ __forceinline__ void sq_fetch(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, unsigned long long soff, unsigned long long qoff, int qi, int &code, int &qv) {
+    code = (seq[soff + (unsigned)(qi >> 1)] >> ((~qi & 1) << 2)) & 15; qv = qual[qoff + (unsigned)qi];
 }
 #endif
 
@@ -238,7 +239,7 @@ __device__ __forceinline__ int lane_var_lower_bound(const VarView &V, int key) {
 struct __attribute__((aligned(16))) ExtHdr {
     int crel, ncig, c0, nch;               // first CIGAR word (relative to the job's first), CIGAR words, first chunk in the table, chunks it touches
     int vadj, lq, ds, dq;                  // variant of flattened candidate i = vadj + i; l_qseq; stream - true reference coordinate; stream query coordinate of the read's first base
-    unsigned blk0, pad0, pad1, pad2;       // first block of the read's interleaved bases + qualities (lps_reads.hip)
+    unsigned long long soff, qoff;         // where the read's bases / qualities start in ReadView::seq / qual
 };
 
 // waits for the loads into w[] (an empty asm that reads the registers): see the walk loop of k_extract_phase

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64) void k_tumor_extract(VarView V, ReadView R, Tum
     const int flag = R.flag[r];
     const bool mq_ok = R.mapq[r] >= mapping_quality;
     // every field of the read's header in one round trip (as in k_haplotag_score)
-    const uint64_t coff = R.cigar_off[r], coff_end = R.cigar_off[r + 1], soff = R.seq_off[r];
+    const uint64_t soff = R.seq_off[r]; const unsigned cp0 = R.cp_off[r]; const int n_words = R.cp_n[r];
     const int lq = R.l_qseq[r];
     int status = 0;                                                    // mappingQualityFilter == false in the extraction passes
     if (flag & 0x4) status = 2;
@@ -93,8 +93,8 @@ __global__ __launch_bounds__(64) void k_tumor_extract(VarView V, ReadView R, Tum
     int ref_pos = start, q_pos = 0;
     bool walked = false;
     if (status == 0) {
-        const int n_cig = (int)(coff_end - coff);
-        const uint32_t *cig = R.cigar + coff;
+        const int n_cig = n_words;
+        const uint32_t *cig = R.cigp + 8ull * cp0;
         const uint8_t *seq = R.seq + soff;
         int vcur = var_lower_bound(V, start);
         walked = vcur < V.n;                                           // parsingCigar returns at once when no variant is left (:555-557)

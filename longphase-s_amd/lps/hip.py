@@ -67,6 +67,7 @@ def load():
     L.lps_haplotag_write_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.lps_somatic_write_bgzf.argtypes = L.lps_haplotag_write_bgzf.argtypes
     L.lps_bgzf_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.lps_bgzf_retried.argtypes = [C.c_void_p]
     L.lps_bam_scan.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
     L.lps_bam_scan_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
     L.lps_bam_record_tids.argtypes = [C.c_void_p, C.c_void_p]
@@ -95,7 +96,6 @@ def load():
     L.lps_comm_bcast_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]
     L.lps_comm_bcast_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_double)]
     L.lps_set_variants_device.argtypes = [C.c_void_p, C.POINTER(abi.VariantTable)]
-    L.lps_prepare_reads.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.lps_comm_last_error.restype = C.c_char_p
     L.lps_debug_set_obs_capacity.argtypes = [C.c_void_p, C.c_int64]
     L.lps_stage_name.restype = C.c_char_p
@@ -150,9 +150,6 @@ class Context:
             else:
                 self._check(self.L.lps_push_reads(self.h, C.byref(r.c)), "lps_push_reads")
             self.n_reads += r.n_reads
-        ms = C.c_double(0)
-        self._check(self.L.lps_prepare_reads(self.h, C.byref(ms)), "lps_prepare_reads")
-        self.prepare_ms = ms.value
         self.n_var = variants.n
 
     def load_chromosome_device(self, variants, ref, batch, n_reads, table_dev=None):
@@ -170,9 +167,6 @@ class Context:
         ref = np.ascontiguousarray(ref, dtype=np.uint8)
         self._check(self.L.lps_set_reference(self.h, ref.ctypes.data, ref.size), "lps_set_reference")
         self._check(self.L.lps_push_reads_device(self.h, C.byref(batch)), "lps_push_reads_device")
-        ms = C.c_double(0)
-        self._check(self.L.lps_prepare_reads(self.h, C.byref(ms)), "lps_prepare_reads")      # loading includes the library's layout of bases + qualities
-        self.prepare_ms = ms.value
         self.n_reads = n_reads
         self.n_var = variants.n
 

@@ -263,3 +263,33 @@ def test_file_of_several_upload_pieces_read_with_pread(tmp_path):
             assert ctx.bgzf_load_fd(fd, 0, len(z)) == len(data)         # the context is still usable
     finally:
         os.close(fd)
+
+
+def test_slow_source_makes_the_inflate_kernel_time_out_and_the_load_still_succeeds(tmp_path, monkeypatch):
+    """The inflate kernel is launched beside the upload and its wavefronts wait a bounded time for their bytes.  A source slower than that bound
+    (network storage, a file that fell out of the page cache) used to fail the load; now the members are inflated again after the upload.  The hooks
+    make it happen on a 160 MB file: the launch waits for 64 members only, every 64-MiB piece of the upload is held back by 300 ms, a wavefront
+    gives up after 20 ms."""
+    import os
+    rng = np.random.default_rng(12)
+    parts, zs = [], []
+    for k in range(2700):
+        raw = rng.integers(0, 200, int(rng.integers(60_000, 65_280)), dtype=np.uint8).tobytes()
+        parts.append(raw); zs.append(bgzf(raw, 1 << 20, 1, eof=False))
+    z = b"".join(zs) + bgzf(b"", 1, 1)[:28]
+    data = b"".join(parts)
+    assert len(z) > 150_000_000
+    path = str(tmp_path / "slow.bgzf"); open(path, "wb").write(z)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        with hip.Context(0, abi.default_params()) as ctx:
+            monkeypatch.setenv("LPS_BGZF_TEST_THROTTLE_MS", "300"); monkeypatch.setenv("LPS_BGZF_TEST_FIRST_ROUND", "64"); monkeypatch.setenv("LPS_BGZF_TEST_TIMEOUT_MS", "20")
+            assert ctx.bgzf_load_fd(fd, 0, len(z)) == len(data)
+            assert ctx.L.lps_bgzf_retried(ctx.h) == 1                    # the path under test did run
+            for a in (0, 70_000_000, 140_000_000, len(data) - 9_000):
+                assert ctx.bgzf_read(a, 9_000).tobytes() == data[a:a + 9_000]
+            monkeypatch.delenv("LPS_BGZF_TEST_THROTTLE_MS"); monkeypatch.delenv("LPS_BGZF_TEST_FIRST_ROUND"); monkeypatch.delenv("LPS_BGZF_TEST_TIMEOUT_MS")
+            assert ctx.bgzf_load_fd(fd, 0, len(z)) == len(data) and ctx.L.lps_bgzf_retried(ctx.h) == 0
+            assert ctx.bgzf_read(123_456_789, 4_096).tobytes() == data[123_456_789:123_456_789 + 4_096]
+    finally:
+        os.close(fd)
