@@ -905,7 +905,7 @@ static const char *kSomUsage =
 static int somatic_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
     std::string snp, ref, nbam, tvcf, tbam, prefix = "result";
-    int threads = 1, gpu = 0, n_gpus = 1;
+    int threads = 1, gpu = 0, n_gpus = 1; uint64_t group_bytes = 8ull << 30; bool no_index = false;
     double purity = -1, pct = 0.6;
     bool enable_filter = true, write_log = false, write_sc_vcf = false; bool host_deflate = false, raw_started = false, host_inflate = false, gpu_inflate = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kSomUsage; exit(1); } return argv[++i]; };
@@ -937,6 +937,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         else if (a == "--host-deflate") host_deflate = true;
         else if (a == "--host-inflate") host_inflate = true;
         else if (a == "--gpu-inflate") gpu_inflate = true;
+        else if (a == "--group-bytes") group_bytes = (uint64_t)std::stoull(val());
+        else if (a == "--no-index") no_index = true;
         else if (a == "--help") { std::cout << kSomUsage; return 0; }
         else if (a == "--cram" || a == "--region" || a == "--log" || a == "--truth-vcf" || a == "--truth-bed" || a == "--benchmark-log") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
         else { std::cerr << "longphase_amd: unknown option " << a << "\n" << kSomUsage; return 1; }
@@ -982,7 +984,32 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     if (!t_gpu) tin.load(tbam, threads, want);
     const bool resident = n_gpu && t_gpu && !host_deflate && n_gpus <= 1;
     GpuBam ngb, tgb;
-    if (resident) { tgb.open_file(tbam, false); tgb.walk_ahead(L, 0, tgb.fsz); ngb.open_file(nbam, false); ngb.walk_ahead(L, 0, ngb.fsz); }   // header walks beside the GPU start-up
+    // GROUPED (both BAMs indexed): the pair is walked in groups of consecutive contigs, as the reference walks it chromosome by chromosome
+    // (src/somatic_haplotag/SomaticVarCaller.cpp:822, SomaticHaplotagProcess.cpp:54-109) - one group of the tumor BAM and the same contigs of the
+    // normal BAM are uploaded, inflated and scanned, their contigs go through the passes, the next group replaces them.  HBM then holds
+    // --group-bytes of the pair at a time instead of both whole files (a 50x / 25x whole-genome pair inflates to ~0.5 TB).
+    std::vector<std::vector<std::string>> som_groups; bool grouped = false;
+    if (resident) {
+        tgb.open_file(tbam, !no_index); ngb.open_file(nbam, !no_index);
+        grouped = tgb.indexed && ngb.indexed;
+        if (grouped) {
+            // a group is a run of chr_vec whose members are neighbours in BOTH files (contigs without records in a file do not break its run)
+            auto has = [](const GpuBam &g, int t) { return t >= 0 && g.voff[(size_t)t].second > g.voff[(size_t)t].first; };
+            auto span = [](const GpuBam &g, int t) -> uint64_t { return (g.voff[(size_t)t].second >> 16) - (g.voff[(size_t)t].first >> 16) + 65536; };
+            auto run_ok = [&](const GpuBam &g, int last, int t) { if (t <= last) return false; for (int k = last + 1; k < t; ++k) if (has(g, k)) return false; return true; };
+            int last_t = -2, last_n = -2; uint64_t bytes = 0;
+            for (const std::string &c : chr_vec) {
+                const int tt = tgb.tid_of(c), tn = ngb.tid_of(c);
+                if (!has(tgb, tt)) continue;                              // no tumor records: nothing is tagged or written for this contig
+                const bool hn = has(ngb, tn);
+                const uint64_t sz = span(tgb, tt) + (hn ? span(ngb, tn) : 0);
+                const bool ok = !som_groups.empty() && run_ok(tgb, last_t, tt) && (!hn || last_n == -2 || run_ok(ngb, last_n, tn)) && bytes + sz <= group_bytes;
+                if (!ok) { som_groups.emplace_back(); bytes = 0; last_n = -2; }
+                som_groups.back().push_back(c); bytes += sz; last_t = tt; if (hn) last_n = tn;
+            }
+            if (!som_groups.empty()) tgb.walk_group_ahead(L, som_groups.front());
+        } else { tgb.walk_ahead(L, 0, tgb.fsz); ngb.walk_ahead(L, 0, ngb.fsz); }   // header walks beside the GPU start-up
+    }
     gpu_init.join();
     if (!ctx) die("longphase_amd: " + L.error);
     // One worker and the GPU writer: both inflated streams STAY on the GPU (the tumor's in this context, the normal's in a second one that runs pass 1):
@@ -990,12 +1017,10 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     // Otherwise (--gpus N, --host-deflate): the stream is copied back once and the contigs' records are pushed from host memory as before.
     double t_gpu_inflate = 0; lps_ctx *nctx = nullptr;
     if (resident) {
-        tgb.load_all(L, ctx);
         lps_params P; L.default_params(&P); for (auto &f : over) f(P);
         nctx = L.create(gpu, &P); if (!nctx) die("longphase_amd: cannot create the GPU context of the normal BAM");
         L.set_stage_timing(nctx, 0);
-        ngb.load_all(L, nctx);
-        t_gpu_inflate = tgb.t_inflate + tgb.t_scan + ngb.t_inflate + ngb.t_scan;
+        if (!grouped) { tgb.load_all(L, ctx); ngb.load_all(L, nctx); t_gpu_inflate = tgb.t_inflate + tgb.t_scan + ngb.t_inflate + ngb.t_scan; }
     } else {
         if (n_gpu) gpu_load_to_host(L, ctx, nbam, want, threads, nin, &t_gpu_inflate);
         if (t_gpu) gpu_load_to_host(L, ctx, tbam, want, threads, tin, &t_gpu_inflate);
@@ -1443,6 +1468,25 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         } else { A.out = obp; A.out_bytes = (size_t)out_off[nt]; }
         std::cerr << "(" << chr << ")";
     };
+    // GROUPED: which group a contig belongs to, and the loader that makes a group's records resident (tumor in ctx, normal in nctx) when the
+    // contig loop reaches its first member
+    std::map<std::string, size_t> group_of; size_t group_loaded = (size_t)-1;
+    for (size_t g = 0; g < som_groups.size(); ++g) for (const std::string &c : som_groups[g]) group_of[c] = g;
+    auto enter_group = [&](const std::string &chr) {
+        if (!grouped) return;
+        auto it = group_of.find(chr);
+        if (it == group_of.end()) { tgb.range.erase(chr); ngb.range.erase(chr); return; }      // no tumor records
+        if (it->second == group_loaded) return;
+        const std::vector<std::string> &grp = som_groups[it->second];
+        tgb.load_group(L, ctx, grp);
+        std::vector<std::string> ngrp; for (const std::string &c : grp) { const int t = ngb.tid_of(c); if (t >= 0 && ngb.voff[(size_t)t].second > ngb.voff[(size_t)t].first) ngrp.push_back(c); }
+        ngb.load_group(L, nctx, ngrp);
+        group_loaded = it->second;
+        // the next group's header walk (host only) beside this group's passes; at the last group of the estimation phase: the first group's again
+        const size_t nxt = it->second + 1 < som_groups.size() ? it->second + 1 : 0;
+        if (som_groups.size() > 1) tgb.walk_group_ahead(L, som_groups[nxt]);
+        if (getenv("LPS_CLI_DEBUG")) fprintf(stderr, "[cli] somatic group %zu / %zu: %zu contig(s) from %s, %zu of them in the normal BAM\n", it->second + 1, som_groups.size(), grp.size(), grp.front().c_str(), ngrp.size());
+    };
     // contigs dealt longest-first (tumor records) onto the workers; worker 0 is this thread's context, the others create theirs
     const int n_dev = std::max(1, L.device_count());
     const int n_workers = std::max(1, std::min<int>(n_gpus, (int)chr_vec.size()));
@@ -1467,7 +1511,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         std::vector<std::thread> workers;
         if (n_workers > 1) for (int g = 0; g < n_workers; ++g) workers.emplace_back(run_share, g);
         for (size_t i = 0; i < chr_vec.size(); ++i) {                    // merge (and write) in contig order
-            if (n_workers == 1) do_contig(ctx, chr_vec[i], phase, acc[i]);
+            if (n_workers == 1) { enter_group(chr_vec[i]); do_contig(ctx, chr_vec[i], phase, acc[i]); }
             else { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return acc[i].ready; }); }
             ContigAcc &A = acc[i];
             pdata.insert(pdata.end(), A.pdata.begin(), A.pdata.end()); p_initial += A.p_initial; for (int k = 0; k < 5; ++k) lcvf[k] += A.lcvf[k];
@@ -1517,6 +1561,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     fprintf(stderr, "somatic variant count(Flag): %llu\n", n_somatic_flag);
     fprintf(stderr, "total alignment %llu | HP1 %llu HP2 %llu HP1-1 %llu HP2-1 %llu HP3 %llu | judged untagged %llu | low mapq %llu unmapped %llu secondary %llu supplementary %llu no variant %llu beyond last variant %llu\n",
             total, hp_hist[1], hp_hist[2], hp_hist[5], hp_hist[7], hp_hist[3], hp_hist[0], st_count[1], st_count[2], st_count[3], st_count[4], st_count[5], st_count[6]);
+    if (grouped) fprintf(stderr, "contig groups: %zu (both BAMs indexed, --group-bytes %llu): upload + gpu inflate %.3fs, record scan %.3fs, inside the passes' time\n", som_groups.size(), (unsigned long long)group_bytes,
+                         tgb.t_inflate + ngb.t_inflate, tgb.t_scan + ngb.t_scan);
     fprintf(stderr, "inputs %.3fs | passes + caller + writer %.3fs (table %.3f, normal pass %.3f, tumor pass %.3f, host stages %.3f, purity %.3f, tagging pass %.3f, tag splice %.3f, gpu deflate + copy out %.3f, %s %.3f + %.3f) | total %.3fs\n", t_in - t_begin, now() - t_in,
             ns_prep / 1e9, ns_p1 / 1e9, ns_p2 / 1e9, ns_host / 1e9, ns_purity / 1e9, ns_p3 / 1e9, ns_splice / 1e9, ns_gpu_deflate / 1e9, host_deflate ? "deflate + write" : "write", ns_append / 1e9, ns_finish / 1e9, now() - t_begin);
     fflush(stderr);
