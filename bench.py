@@ -348,6 +348,97 @@ def whole_node_baseline(dev, P, threads, seed, n_contigs=16, contig_mb=10):
                                  "the top-level vs_baseline stays null: BASELINE.md holds no published number"))
 
 
+def somatic_leg(dev, mb, steps, threads, seed=301, check=True):
+    """BASELINE.json configs[4] on one contig of `mb` Mb: a tumor / normal pair (50x / 25x, SNP + indel VCFs, 60 % simulated purity).  The normal sample
+    is phased on the GPU (prelude), then the THREE per-read passes of somatic_haplotag run from the decoded alignments resident in HBM - normal
+    extraction (a20, SomaticVarCaller.cpp:123-293), tumor extraction (a21, :334-759) and tagging (a22, SomaticHaplotagProcess.cpp:310-527) - each
+    timed as K consecutive calls that recompute everything (one-pass clock: nothing is kept between calls) and, with `check`, compared with the
+    oracle: every per-site counter, per-read count, list entry and tag.  Rate = tumor alignments / (the three passes' times)."""
+    import numpy as np
+    from lps import abi, hip
+    from lps.synth import Synth
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lps_oracle
+    total = sum(n for _, n in GRCH38)
+    L = int(mb * 1_000_000)
+    genome = dict(seed=seed, contig_len=L, n_snp=int(round(WGS_SNPS * L / total)), indel_var_frac=0.10, somatic_every=20000.0, n_threads=threads)
+    t0 = time.time()
+    N = Synth(**dict(genome, coverage=25.0, read_seed=seed * 10 + 1, tumor_purity=0.0))
+    T = Synth(**dict(genome, coverage=50.0, read_seed=seed * 10 + 2, tumor_purity=0.6))
+    RN, RT = abi.Reads.from_synth(N), abi.Reads.from_synth(T)
+    gen_s = time.time() - t0
+    P = abi.default_params(phase_indel=1)
+    V0 = abi.Variants(N.var_pos, N.var_ref, N.var_alt)
+    res = dict(contig_mb=mb, tumor_alignments=int(RT.n_reads), normal_alignments=int(RN.n_reads), germline_rows=int(V0.n), somatic_rows=int(N.n_somatic), generation_s=round(gen_s, 1))
+    with hip.Context(dev, P) as ctx:
+        ph = ctx.phase(V0, N.ref, RN)
+        keep = np.nonzero(ph.phase_set != 0)[0]
+        # the merged table as the command line builds it (cli/longphase_amd.cpp, MultiGenomeVar map of HaplotagType.h:146-162): the normal sample's phased
+        # het rows (role 0, no tumor row there) + the tumor VCF's rows, which hold the somatic sites only (SURVEY.md 8d) - role 2 with their tumor kind
+        # for the two extraction passes; for the tagging pass the rows the caller flagged (here: all of them) become role 1 with the haplotype they derive from
+        rows = [(int(N.var_pos[i]), N.var_ref[i], N.var_alt[i], int(ph.gt[i]), int(ph.phase_set[i]), 0, 0, 0) for i in keep]
+        kind_of = lambda r, a: 1 if len(r) == 1 and len(a) == 1 else (2 if len(r) == 1 else 3)  # noqa: E731
+        rows += [(int(p), bytes([r]), bytes([a]), 0, 0, 2, int(h) + 1, kind_of(bytes([r]), bytes([a]))) for p, r, a, h in zip(N.som_pos, N.som_ref, N.som_alt, N.som_hap)]
+        rows.sort()
+        rows = [r for k, r in enumerate(rows) if k == 0 or r[0] != rows[k - 1][0]]
+        cols = lambda tag: dict(hp1_is_alt=[r[3] for r in rows], phase_set=[r[4] for r in rows], somatic_role=[(1 if tag and r[5] == 2 else r[5]) for r in rows],  # noqa: E731
+                                derive_hp=[(r[6] if tag and r[5] == 2 else 0) for r in rows], tumor_kind=[r[7] for r in rows])
+        V = abi.Variants([r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows], **cols(False))
+        VT = abi.Variants([r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows], **cols(True))
+        res["merged_table_rows"] = int(V.n)
+        Lh = ctx.L
+        def timed(fn, k):
+            fn()                                                         # warm-up: buffers at their working size
+            t0 = time.perf_counter()
+            for _ in range(k):
+                fn()
+            return (time.perf_counter() - t0) / k * 1e3
+        # ---- pass 1: normal BAM
+        ctx.load_chromosome(V, N.ref, RN)
+        o1 = abi.SiteCountersOut(V.n, RN.n_reads)
+        def p1():
+            ctx._check(Lh.lps_somatic_extract_normal(ctx.h, C.byref(o1.c)), "lps_somatic_extract_normal")
+        ms1 = timed(p1, steps); k1 = ctx.timings()["stages"]["extract"]
+        # ---- pass 2: tumor BAM
+        ctx.load_chromosome(V, T.ref, RT)
+        pair_cap, win_cap = 64 * RT.n_reads + 1024, 256 * RT.n_reads + 1024
+        o2 = abi.TumorExtractOut(V.n, RT.n_reads, pair_cap, win_cap)
+        def p2():
+            ctx._check(Lh.lps_somatic_extract_tumor(ctx.h, C.byref(o2.c)), "lps_somatic_extract_tumor")
+        ms2 = timed(p2, steps); k2 = ctx.timings()["stages"]["extract"]
+        # ---- pass 3: tagging, tumor reads still resident; the table with the flagged rows
+        ctx.set_table(VT, T.ref)
+        o3 = abi.SomaticTagOut(RT.n_reads)
+        def p3():
+            ctx._check(Lh.lps_somatic_tag_chromosome(ctx.h, C.byref(o3.c)), "lps_somatic_tag_chromosome")
+        ms3 = timed(p3, steps); k3 = ctx.timings()["stages"]["extract"]
+    tot = ms1 + ms2 + ms3
+    n_cig_t = int(RT.cigar.size); n_cig_n = int(RN.cigar.size)
+    alg = {"normal_extract": 36 * RN.n_reads + 4 * n_cig_n, "tumor_extract": 36 * RT.n_reads + 4 * n_cig_t + 8 * int(o2.c.n_pairs) + 8 * int(o2.c.n_windows), "tag": 36 * RT.n_reads + 4 * n_cig_t + 16 * RT.n_reads}
+    kms = {"normal_extract": k1, "tumor_extract": k2, "tag": k3}
+    dom = max(kms, key=lambda k: kms[k])
+    res.update(metric="tumor reads through the three somatic_haplotag passes / s", value=RT.n_reads / (tot * 1e-3), unit="reads/s", steps=steps,
+               pass_ms=dict(normal_extract=round(ms1, 3), tumor_extract=round(ms2, 3), tag=round(ms3, 3)), kernel_ms={k: round(v, 4) for k, v in kms.items()},
+               pairs=int(o2.c.n_pairs), windows=int(o2.c.n_windows),
+               roofline=dict(bound="hbm", kernel=dom, achieved=alg[dom] / (kms[dom] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=alg[dom] / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             algorithmic_bytes=int(alg[dom]), note="SURVEY.md 8(d) closed form of the per-read passes: 36 B + 4 B x CIGAR words per alignment + what the pass writes per hit; the sites' bases are gathered in place"),
+               clock="one-pass: every call recomputes from the decoded alignments as the push left them; call = launch to results in host memory")
+    if check:
+        t0 = time.time()
+        ok = {}
+        w1 = lps_oracle.somatic_extract_normal(P, V, N.ref, RN)
+        ok["normal_extract"] = bool(np.array_equal(o1.read_hp, w1.read_hp) and np.array_equal(o1.counters, w1.counters))
+        w2 = lps_oracle.somatic_extract_tumor(P, V, T.ref, RT)
+        same = all(np.array_equal(getattr(o2, k), getattr(w2, k)) for k in ("status", "hp1", "hp2", "hp3", "hp", "ps_min", "end_pos", "read_len", "has_site"))
+        same = same and np.array_equal(o2.site, w2.site) and o2.c.n_pairs == w2.c.n_pairs and o2.c.n_windows == w2.c.n_windows
+        same = same and all(np.array_equal(a, b) for a, b in zip(o2.pairs(), w2.pairs())) and all(np.array_equal(a, b) for a, b in zip(o2.windows(), w2.windows()))
+        ok["tumor_extract"] = bool(same)
+        w3 = lps_oracle.somatic_tag(P, VT, RT)
+        ok["tag"] = bool(all(np.array_equal(getattr(o3, k), getattr(w3, k)) for k in ("status", "hp1", "hp2", "hp3", "derive_h1", "derive_h2", "ps_min", "hp", "pq", "ps")))
+        res.update(parity=ok, parity_checked=all(ok.values()), oracle_s=round(time.time() - t0, 1), tagged_somatic_reads=int((o3.hp >= 5).sum()), tagged_germline_reads=int(((o3.hp == 1) | (o3.hp == 2)).sum()))
+    return res
+
+
 def gpu_nodes():
     """GPUs of this machine from the KFD topology in sysfs - no HIP call (the parent of spawn_ranks must not touch the GPU).  None = unknown."""
     import glob
@@ -409,7 +500,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="wgs_50x", choices=["wgs_50x", "chr1_50x", "chr20_30x", "chr20_30x_pileups", "5mb_10x", "mini_wgs"])
+    ap.add_argument("--workload", default="wgs_50x", choices=["wgs_50x", "chr1_50x", "chr20_30x", "chr20_30x_pileups", "5mb_10x", "mini_wgs", "somatic_tn"])
+    ap.add_argument("--somatic-mb", type=float, default=0.0, help="contig length (Mb) of the tumor / normal leg: 160 for --workload somatic_tn, 16 for the sample inside the default run; 0 = those defaults")
+    ap.add_argument("--no-somatic", action="store_true", help="skip the tumor / normal sample of the default run (about half a minute)")
     ap.add_argument("--seed", type=int, default=201)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity", default="all", help="all | none | comma-separated contig names whose step-0 output is compared with the oracle")
@@ -419,6 +512,18 @@ def main():
     ap.add_argument("--ctx-per-gpu", type=int, default=4, help="contigs phased concurrently on one GPU, one context (stream, host thread) each")
     a = ap.parse_args()
 
+    if a.workload == "somatic_tn":          # BASELINE.json configs[4] on one GPU: its own line (a step = the three passes over the pair)
+        sys.path.insert(0, os.path.join(ROOT, "longphase-s_amd"))
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+        r = somatic_leg(int(os.environ.get("LOCAL_RANK", "0")), a.somatic_mb or 160.0, a.steps, min(16, ncpu), check=a.parity != "none")
+        line = {"metric": r.pop("metric"), "value": r.pop("value"), "unit": r.pop("unit"), "n_gpus": 1, "steps": a.steps, "warmup": 1, "ms_per_step": sum(r["pass_ms"].values()),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic", "parity_checked": r.get("parity_checked"),
+                "config": {"workload": f"somatic_haplotag passes, tumor 50x / normal 25x at 60 % purity, one contig of {r['contig_mb']:.0f} Mb, SNP + indel VCFs, decoded alignments resident in HBM"},
+                "roofline": r.pop("roofline"), "somatic_tn": r}
+        print(json.dumps(line), flush=True)
+        if line["parity_checked"] is False:
+            sys.exit(4)
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(a)                       # never returns: `python3 bench.py --gpus N` without a launcher starts its N ranks itself
     rank = int(os.environ.get("RANK", "0"))
@@ -477,7 +582,7 @@ def main():
     elapsed = 0.0; hap_elapsed = 0.0; total_phased = 0; total_reads = 0; total_tagged = 0; total_bases = 0
     largest = None; cpu_pick = None; p_clock = None; port = None
     cpu_name = a.cpu_contig or min(contigs, key=lambda c: c["contig_len"])["name"]
-    gen_s = 0.0; push_s = 0.0; d2h_s = 0.0; first_call_s = 0.0
+    gen_s = 0.0; push_s = 0.0; d2h_s = 0.0; first_call_s = 0.0; somatic_bad = False
 
     def barrier():
         if dist is not None:
@@ -707,6 +812,18 @@ def main():
         }
         if rccl_info is not None:
             res["rccl"] = rccl_info
+        if a.workload == "wgs_50x" and not a.no_somatic:
+            # config 5 inside the default line: a bounded sample of the tumor / normal leg (`--workload somatic_tn` runs it at 160 Mb)
+            try:
+                t0 = time.time()
+                sm = somatic_leg(dev, a.somatic_mb or 16.0, max(2, min(a.steps, 5)), min(16, ncpu), check=a.parity != "none")
+                res["somatic_tn_value"] = sm["value"]; res["somatic_tn_unit"] = sm["unit"]; res["somatic_tn_parity_checked"] = sm.get("parity_checked")
+                res["somatic_tn"] = sm
+                if sm.get("parity_checked") is False:
+                    somatic_bad = True
+                log(f"somatic tumor / normal sample took {time.time()-t0:.1f}s")
+            except Exception as e:  # noqa: BLE001
+                log("somatic sample failed:", repr(e)[:300]); res["somatic_tn"] = dict(failed=repr(e)[:200])
         cpu_threads = a.cpu_threads or min(24, ncpu)          # the reference's compute parallelism is its chromosome loop: at most 24 threads compute on a genome (PhasingProcess.cpp:106,113)
         if not a.no_cpu_baseline and cpu_pick is not None:
             t0 = time.time()
@@ -743,6 +860,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     rc = 0
+    if somatic_bad:
+        log(f"[rank {rank}] PARITY FAILED in the tumor / normal sample"); rc = 4
     if parity is not None and not parity["checked"]:
         log(f"[rank {rank}] PARITY FAILED: {parity}")
         rc = 4                                     # the JSON line above carries parity_checked false; the exit code says it too

@@ -249,3 +249,19 @@ def test_tumor_normal_pair_50x_25x_every_somatic_pass():
         for k in ("status", "hp1", "hp2", "hp3", "derive_h1", "derive_h2", "ps_min", "hp", "pq", "ps"):
             assert np.array_equal(getattr(out, k), getattr(want, k)), "tagging: " + k
         assert (out.hp >= 5).sum() > 1000 and (out.hp == 1).sum() > 5000
+
+
+def test_tumor_normal_pair_160mb_three_passes_as_the_command_line_runs_them():
+    """BASELINE configs[4] at scale: tumor 50x / normal 25x at 60 % purity on a 160 Mb contig (8 Gbases + 4 Gbases of alignments), the merged table as
+    `somatic_haplotag` builds it - the normal sample's phased rows plus the tumor VCF's somatic rows (role 2 for the extraction passes, role 1 with
+    their derived haplotype for the tagging pass).  bench.py's tumor / normal leg runs the three passes from the resident alignments and compares every
+    per-site counter, per-read count, (site, read, base HP) pair, difference window and tag with the oracle."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    r = bench.somatic_leg(0, 160.0, 1, min(16, ncpu), check=True)
+    assert r["parity"] == {"normal_extract": True, "tumor_extract": True, "tag": True}, r["parity"]
+    assert r["tumor_alignments"] > 380_000 and r["normal_alignments"] > 190_000 and r["somatic_rows"] > 5_000
+    assert r["pairs"] > 100_000 and r["windows"] > 100_000 and r["tagged_somatic_reads"] > 10_000 and r["tagged_germline_reads"] > 200_000
+    print({k: r[k] for k in ("value", "pass_ms", "kernel_ms", "pairs", "windows", "oracle_s", "generation_s")})
