@@ -101,7 +101,7 @@ struct lps_ctx {
     DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
     DevBuf<uint8_t> hap_status, hap_nps, v_role, v_derive, v_tkind, read_hp; DevBuf<int32_t> site, t_end, t_len, t_pair_site, t_pair_read,
             t_win_site; DevBuf<uint8_t> t_hp, t_has, t_pair_hp, t_win_allele,
-            t_win_base; DevBuf<int16_t> t_win_off; DevBuf<unsigned long long> t_ctr; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1,
+            t_win_base; DevBuf<int16_t> t_win_off; DevBuf<unsigned long long> t_ctr; DevBuf<int4> t_hits; DevBuf<int> t_hit_rp; DevBuf<uint32_t> t_win_cnt, t_win_at; size_t t_hit_cap = 0; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1,
             hap_d2; bool has_somatic = false;
     DevBuf<char> temp; size_t temp_bytes = 0;
     LpsCounters *d_cnt = nullptr; LpsCounters h_cnt{}; unsigned h_stats[4]{};
@@ -1654,27 +1654,47 @@ int lps_somatic_extract_tumor(lps_ctx *c, lps_tumor_extract_result *out) {
         const size_t pc = (size_t)std::max<int64_t>(out->pair_capacity, 1), wc = (size_t)std::max<int64_t>(out->win_capacity, 1);
         c->site.reserve((size_t)nV * LPS_TSITE_COUNTERS + 1);
         c->hap_status.reserve(nR); c->hap_h1.reserve(nR); c->hap_h2.reserve(nR); c->hap_h3.reserve(nR); c->hap_nps.reserve(nR); c->hap_psmin.reserve(nR);
-        c->t_hp.reserve(nR); c->t_has.reserve(nR); c->t_end.reserve(nR); c->t_len.reserve(nR); c->t_ctr.reserve(2);
+        c->t_hp.reserve(nR); c->t_has.reserve(nR); c->t_end.reserve(nR); c->t_len.reserve(nR); c->t_ctr.reserve(4);
         c->t_pair_site.reserve(pc); c->t_pair_read.reserve(pc); c->t_pair_hp.reserve(pc);
         c->t_win_site.reserve(wc); c->t_win_allele.reserve(wc); c->t_win_off.reserve(wc); c->t_win_base.reserve(wc);
         c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1);
-        HIP_TRY(hipEventRecord(c->ev_begin, s));
-        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
-        HIP_TRY(hipMemsetAsync(c->site.p, 0, ((size_t)nV * LPS_TSITE_COUNTERS + 1) * sizeof(int32_t), s));
-        HIP_TRY(hipMemsetAsync(c->t_ctr.p, 0, 2 * sizeof(unsigned long long), s));
-        VarView V = var_view(c); ReadView R = read_view(c);
-        for (auto &u : c->ev_used) u = false;
-        mark(c, ST_PREP);
-        if (nV) launch_variant_prep(V, 0, c->v_bucket.p, c->v_rec.p, s);
-        mark(c, ST_EXTRACT);
-        TumOut T{c->site.p, c->hap_status.p, c->hap_h1.p, c->hap_h2.p, c->hap_h3.p, c->t_hp.p, c->hap_nps.p, c->hap_psmin.p, c->t_end.p, c->t_len.p, c->t_has.p,
-                 c->t_ctr.p, (long long)out->pair_capacity, (long long)out->win_capacity, c->t_pair_site.p, c->t_pair_read.p, c->t_pair_hp.p,
-                 c->t_win_site.p, c->t_win_allele.p, c->t_win_off.p, c->t_win_base.p, c->P.percentage_threshold};
-        launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 0, c->d_cnt, s);
-        launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 1, c->d_cnt, s);
-        mark(c, ST_D2H);
-        unsigned long long ctr[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(ctr, c->t_ctr.p, sizeof ctr, hipMemcpyDeviceToHost, s));
+        // window hits (alignment x TUMOR row): about as many as (site, read) pairs; when the list turns out too short the pass runs again with what it needs
+        if (c->t_hit_cap < (size_t)out->pair_capacity + (size_t)nR + 1024) c->t_hit_cap = (size_t)out->pair_capacity + (size_t)nR + 1024;
+        unsigned long long ctr[3] = {0, 0, 0};
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            const size_t hc = c->t_hit_cap;
+            if (2 * hc + 1 > 0xfffffff0ull) return fail(c, "somatic extraction: more than 2^31 window hits");
+            c->t_hits.reserve(hc + 1); c->t_hit_rp.reserve(hc + 1); c->t_win_cnt.reserve(2 * hc + 2); c->t_win_at.reserve(2 * hc + 2);
+            { const size_t need = GraphTemp::need(2 * hc + 2); if (need > c->temp_bytes) { c->temp.reserve(need, s); c->temp_bytes = need; } }
+            HIP_TRY(hipEventRecord(c->ev_begin, s));
+            HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
+            HIP_TRY(hipMemsetAsync(c->site.p, 0, ((size_t)nV * LPS_TSITE_COUNTERS + 1) * sizeof(int32_t), s));
+            HIP_TRY(hipMemsetAsync(c->t_ctr.p, 0, 4 * sizeof(unsigned long long), s));
+            VarView V = var_view(c); ReadView R = read_view(c);
+            for (auto &u : c->ev_used) u = false;
+            mark(c, ST_PREP);
+            if (nV) launch_variant_prep(V, 0, c->v_bucket.p, c->v_rec.p, s);
+            mark(c, ST_EXTRACT);
+            TumOut T{c->site.p, c->hap_status.p, c->hap_h1.p, c->hap_h2.p, c->hap_h3.p, c->t_hp.p, c->hap_nps.p, c->hap_psmin.p, c->t_end.p, c->t_len.p, c->t_has.p,
+                     c->t_ctr.p, (long long)out->pair_capacity, (long long)out->win_capacity, c->t_pair_site.p, c->t_pair_read.p, c->t_pair_hp.p,
+                     c->t_win_site.p, c->t_win_allele.p, c->t_win_off.p, c->t_win_base.p, c->P.percentage_threshold,
+                     c->t_hits.p, c->t_hit_rp.p, (long long)hc, c->t_win_cnt.p, c->t_win_at.p};
+            launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 0, c->d_cnt, s);
+            launch_tumor_windows(V, R, T, c->temp.p, c->temp_bytes, s);
+            launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 1, c->d_cnt, s);
+            mark(c, ST_D2H);
+            uint32_t n_win = 0;
+            HIP_TRY(hipMemcpyAsync(ctr, c->t_ctr.p, sizeof ctr, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(&n_win, c->t_win_at.p + 2 * hc, sizeof n_win, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            ctr[1] = n_win;
+            if (ctr[2] <= hc) break;
+            c->t_hit_cap = (size_t)ctr[2] + (size_t)ctr[2] / 8 + 1024;   // the list was too short: again with room for every hit
+            if (attempt == 2) return fail(c, "somatic extraction: the window hit list kept overflowing");
+        }
+        TumOut T{}; T.status = c->hap_status.p; T.hp1 = c->hap_h1.p; T.hp2 = c->hap_h2.p; T.hp3 = c->hap_h3.p; T.hp = c->t_hp.p; T.n_ps = c->hap_nps.p; T.ps_min = c->hap_psmin.p;
+        T.end_pos = c->t_end.p; T.read_len = c->t_len.p; T.has_site = c->t_has.p; T.pair_site = c->t_pair_site.p; T.pair_read = c->t_pair_read.p; T.pair_hp = c->t_pair_hp.p;
+        T.win_site = c->t_win_site.p; T.win_allele = c->t_win_allele.p; T.win_offset = c->t_win_off.p; T.win_base = c->t_win_base.p;
         HIP_TRY(hipMemcpyAsync(out->site, c->site.p, (size_t)nV * LPS_TSITE_COUNTERS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(out->status, T.status, (size_t)nR, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(out->hp1, T.hp1, (size_t)nR * 4, hipMemcpyDeviceToHost, s));

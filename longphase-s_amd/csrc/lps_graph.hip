@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void k_count_ranks(int n_reads, const RowDesc 
 __global__ __launch_bounds__(256) void k_merge_plan(LpsCounters *cnt, const uint32_t *mg_start, const uint32_t *mg_cnt, const uint32_t *mg_name, const uint32_t *mm_r,
                              const RowDesc *rows, const int32_t *g_cnt, unsigned long long tail_lo, unsigned long long tail_size,
                              uint32_t *mrow_off, int32_t *mrow_cnt, uint32_t *mg_plan) {
-    __shared__ unsigned s_tot[4], s_n[4]; __shared__ unsigned long long s_base_t; __shared__ unsigned s_base_n;
+    __shared__ unsigned s_tot[4], s_n[4]; __shared__ unsigned long long s_base_t;
     const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
     const int w = threadIdx.x >> 6;
     bool multi = false; int total = 0; uint32_t id = 0;

@@ -267,11 +267,15 @@ void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int m
 struct TumOut {
     int32_t *site;                 // [nV][LPS_TSITE_COUNTERS]
     uint8_t *status; int32_t *hp1, *hp2, *hp3; uint8_t *hp; uint8_t *n_ps; int32_t *ps_min; int32_t *end_pos, *read_len; uint8_t *has_site;
-    unsigned long long *list_ctr;  // [0] pairs, [1] windows
+    unsigned long long *list_ctr;  // [0] pairs, [1] windows, [2] window hits (an alignment at a TUMOR row whose difference window has to be taken)
     long long pair_cap, win_cap;
     int32_t *pair_site, *pair_read; uint8_t *pair_hp;
     int32_t *win_site; uint8_t *win_allele; int16_t *win_offset; uint8_t *win_base;
     double pct_thr;
+    int4 *hits; int *hit_rp; long long hit_cap;   // the hits of pass 0: {row, alignment, CIGAR word index, offset inside the op | allele << 30} + the query position there
+    uint32_t *win_cnt, *win_at;                   // per (hit, direction): differences, and where they go in the window list
 };
+// the +-100 bp difference windows of the hits pass 0 listed (getWindowsDiffRef, SomaticVarCaller.cpp:654-710): ONE THREAD per (hit, direction)
+void launch_tumor_windows(const VarView &V, const ReadView &R, const TumOut &T, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_tumor_extract(const VarView &V, const ReadView &R, const TumOut &T, int mapping_quality, int tag_supplementary, int pass,
                           LpsCounters *cnt, hipStream_t s);

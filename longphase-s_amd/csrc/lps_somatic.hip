@@ -9,12 +9,13 @@
 //   SomaticJudgeHapStrategy::judgeSomaticReadHap (without PQ)        :452-602
 //
 // Two passes of the same wave-per-alignment walker (LDS-staged CIGAR prefixes, packed variant records):
-//   PASS 0  votes (H1/H2 at NORMAL rows, H3 at tumor-only rows), per-site base counters + alleleCount by atomics, the +-100 bp
-//           difference windows (count -> one reservation per wave chunk -> write), the read's haplotype and its per-read record;
+//   PASS 0  votes (H1/H2 at NORMAL rows, H3 at tumor-only rows), per-site base counters + alleleCount by atomics, the list of hits whose +-100 bp
+//           difference window has to be taken (k_tumor_windows: one thread per hit and direction), the read's haplotype and its per-read record;
 //   PASS 1  everything that needs the read's haplotype: base.ReadHpCount, classifyReadsByCase counters, somaticReadHpCount and the
 //           (site, read, base HP) pairs of tumorPosReadCorrBaseHP.
 // All per-site quantities are order-free integer counts, so atomics reproduce the reference exactly.
 #include "lps_kernels.h"
+#include "lps_graph.h"
 
 
 // processCigarOperation (:627-652).  The reference's own enum has CIGAR_N == 6 (HaplotagType.h:29).
@@ -190,24 +191,17 @@ __global__ __launch_bounds__(64) void k_tumor_extract(VarView V, ReadView R, Tum
                     }
                 }
                 if (PASS == 0) {
-                    // getWindowsDiffRef (:687-710): count, reserve once per wave chunk, write
-                    if (__ballot(want_win)) {
-                        int nw = 0, fwd = 0, rev = 0, len = 0, rp = 0;
+                    // getWindowsDiffRef (:687-710) walks up to 100 bases to either side of the site, one dependent pair of loads (read base, reference
+                    // base) per step: inside this kernel ONE lane did that while 63 waited - 21.7 of the pass's 22 ms at 160 Mb.  The hit is listed
+                    // instead (one reservation per round of the wave) and k_win_count / k_win_write take the walks one THREAD per (hit, direction).
+                    const unsigned long long wm = __ballot(want_win);
+                    if (wm) {
+                        unsigned long long hb = 0;
+                        if (l == 0) hb = atomicAdd(&T.list_ctr[2], (unsigned long long)__popcll(wm));
+                        hb = __shfl(hb, 0);
                         if (want_win) {
-                            len = (int)(cig[opj] >> 4); fwd = (len - win_off > 0) ? len - win_off : 0; rev = win_off > 0 ? win_off : 0;
-                            rp = sqry[opj - seg0] + win_off;
-                            nw = win_dir<false>(cig, opj, n_cig, seq, lq, V.ref, (int)V.ref_len_eff, rp, rev, p, -1, T, 0, 0, 0)
-                               + win_dir<false>(cig, opj, n_cig, seq, lq, V.ref, (int)V.ref_len_eff, rp, fwd, p, +1, T, 0, 0, 0);
-                        }
-                        const int incl = wave_incl_scan_dpp(nw);
-                        const int tot = __shfl(incl, 63);
-                        unsigned long long wb = 0;
-                        if (l == 0 && tot) wb = atomicAdd(&T.list_ctr[1], (unsigned long long)tot);
-                        wb = __shfl(wb, 0);
-                        if (want_win && nw) {
-                            const long long b0 = (long long)wb + incl - nw;
-                            const int k1 = win_dir<true>(cig, opj, n_cig, seq, lq, V.ref, (int)V.ref_len_eff, rp, rev, p, -1, T, b0, v, win_allele);
-                            win_dir<true>(cig, opj, n_cig, seq, lq, V.ref, (int)V.ref_len_eff, rp, fwd, p, +1, T, b0 + k1, v, win_allele);
+                            const long long slot = (long long)hb + __popcll(wm & lanemask_lt());
+                            if (slot < T.hit_cap) { T.hits[slot] = make_int4(v, r, opj, win_off | (win_allele << 30)); T.hit_rp[slot] = sqry[opj - seg0] + win_off; }
                         }
                     }
                 } else {
@@ -240,6 +234,30 @@ __global__ __launch_bounds__(64) void k_tumor_extract(VarView V, ReadView R, Tum
         T.read_len[r] = (status == 0 && walked) ? q_pos : 0;
         T.has_site[r] = n_site > 0;
     }
+}
+
+// thread t = (hit t >> 1, direction t & 1: 0 towards the read's start, 1 towards its end).  WRITE = false: cnt[t] = differences found;
+// WRITE = true: they are stored from slot at[t] on.  The walk itself is the reference's (win_dir above), untouched.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_tumor_windows(VarView V, ReadView R, TumOut T) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long n_hits = min(T.list_ctr[2], (unsigned long long)T.hit_cap);
+    if ((unsigned long long)(t >> 1) >= n_hits) { if (!WRITE && t < 2 * T.hit_cap + 1) T.win_cnt[t] = 0u; return; }
+    if (WRITE && T.win_cnt[t] == 0u) return;
+    const int4 h = T.hits[t >> 1]; const int dir = (t & 1) ? +1 : -1;
+    const int v = h.x, r = h.y, opj = h.z, win_off = h.w & 0x3fffffff, allele = (h.w >> 30) & 1, rp = T.hit_rp[t >> 1];
+    const uint32_t *cig = R.cig(r); const int n_cig = R.cp_n[r];
+    const int len = (int)(cig[opj] >> 4);
+    const int remaining = dir > 0 ? ((len - win_off > 0) ? len - win_off : 0) : (win_off > 0 ? win_off : 0);
+    const int n = win_dir<WRITE>(cig, opj, n_cig, R.seq + R.seq_off[r], R.l_qseq[r], V.ref, (int)V.ref_len_eff, rp, remaining, V.pos[v], dir, T, WRITE ? (long long)T.win_at[t] : 0, v, allele);
+    if (!WRITE) T.win_cnt[t] = (uint32_t)n;
+}
+void launch_tumor_windows(const VarView &V, const ReadView &R, const TumOut &T, void *temp, size_t temp_bytes, hipStream_t s) {
+    const size_t n = (size_t)(2 * T.hit_cap + 1);
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    hipLaunchKernelGGL(k_tumor_windows<false>, g, b, 0, s, V, R, T);
+    exscan_u32(temp, temp_bytes, T.win_cnt, T.win_at, n, s);              // win_at[2 * hit_cap] = all differences: the window count
+    hipLaunchKernelGGL(k_tumor_windows<true>, g, b, 0, s, V, R, T);
 }
 
 void launch_tumor_extract(const VarView &V, const ReadView &R, const TumOut &T, int mapping_quality, int tag_supplementary, int pass,
