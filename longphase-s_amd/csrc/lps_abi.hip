@@ -101,7 +101,7 @@ struct lps_ctx {
     DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
     DevBuf<uint8_t> hap_status, hap_nps, v_role, v_derive, v_tkind, read_hp; DevBuf<int32_t> site, t_end, t_len, t_pair_site, t_pair_read,
             t_win_site; DevBuf<uint8_t> t_hp, t_has, t_pair_hp, t_win_allele,
-            t_win_base; DevBuf<int16_t> t_win_off; DevBuf<unsigned long long> t_ctr; DevBuf<int4> t_hits; DevBuf<int> t_hit_rp; DevBuf<uint32_t> t_win_cnt, t_win_at; size_t t_hit_cap = 0; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1,
+            t_win_base; DevBuf<int16_t> t_win_off; DevBuf<unsigned long long> t_ctr; DevBuf<int4> t_hits; DevBuf<int> t_hit_rp; DevBuf<uint32_t> t_win_cnt, t_win_at; DevBuf<int32_t> t_apair_site, t_apair_read; DevBuf<uint8_t> t_apair_hp; size_t t_hit_arena = 0, t_pair_arena = 0; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1,
             hap_d2; bool has_somatic = false;
     DevBuf<char> temp; size_t temp_bytes = 0;
     LpsCounters *d_cnt = nullptr; LpsCounters h_cnt{}; unsigned h_stats[4]{};
@@ -1658,40 +1658,53 @@ int lps_somatic_extract_tumor(lps_ctx *c, lps_tumor_extract_result *out) {
         c->t_pair_site.reserve(pc); c->t_pair_read.reserve(pc); c->t_pair_hp.reserve(pc);
         c->t_win_site.reserve(wc); c->t_win_allele.reserve(wc); c->t_win_off.reserve(wc); c->t_win_base.reserve(wc);
         c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1);
-        // window hits (alignment x TUMOR row): about as many as (site, read) pairs; when the list turns out too short the pass runs again with what it needs
-        if (c->t_hit_cap < (size_t)out->pair_capacity + (size_t)nR + 1024) c->t_hit_cap = (size_t)out->pair_capacity + (size_t)nR + 1024;
-        unsigned long long ctr[3] = {0, 0, 0};
+        // The two lists the passes append to - (site, read, base HP) pairs and window hits (alignment x TUMOR row) - live in LPS_TARENAS arenas each
+        // (lps_kernels.h).  They start at two entries per alignment - a tumor VCF holds the somatic sites, an alignment meets one or none - and when
+        // an arena turns out too short the passes run again with what the fullest one needs; the size sticks to the context (the per-slot kernels
+        // behind the lists cost what the arenas hold, not what they could)
+        const size_t want = (2 * (size_t)nR + 4096 + LPS_TARENAS - 1) / LPS_TARENAS;
+        if (c->t_pair_arena < want) c->t_pair_arena = want;
+        if (c->t_hit_arena < want) c->t_hit_arena = want;
+        unsigned long long tot[4] = {0, 0, 0, 0}; uint32_t n_win = 0;
         for (int attempt = 0; attempt < 3; ++attempt) {
-            const size_t hc = c->t_hit_cap;
+            const size_t pa = c->t_pair_arena, ha = c->t_hit_arena, hc = ha * LPS_TARENAS, ipc = pa * LPS_TARENAS;
             if (2 * hc + 1 > 0xfffffff0ull) return fail(c, "somatic extraction: more than 2^31 window hits");
             c->t_hits.reserve(hc + 1); c->t_hit_rp.reserve(hc + 1); c->t_win_cnt.reserve(2 * hc + 2); c->t_win_at.reserve(2 * hc + 2);
+            c->t_apair_site.reserve(ipc + 1); c->t_apair_read.reserve(ipc + 1); c->t_apair_hp.reserve(ipc + 1);
+            c->t_ctr.reserve(2 * LPS_TARENAS * 16 + 8);
             { const size_t need = GraphTemp::need(2 * hc + 2); if (need > c->temp_bytes) { c->temp.reserve(need, s); c->temp_bytes = need; } }
             HIP_TRY(hipEventRecord(c->ev_begin, s));
             HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
             HIP_TRY(hipMemsetAsync(c->site.p, 0, ((size_t)nV * LPS_TSITE_COUNTERS + 1) * sizeof(int32_t), s));
-            HIP_TRY(hipMemsetAsync(c->t_ctr.p, 0, 4 * sizeof(unsigned long long), s));
+            HIP_TRY(hipMemsetAsync(c->t_ctr.p, 0, (2 * LPS_TARENAS * 16 + 8) * sizeof(unsigned long long), s));
             VarView V = var_view(c); ReadView R = read_view(c);
             for (auto &u : c->ev_used) u = false;
             mark(c, ST_PREP);
             if (nV) launch_variant_prep(V, 0, c->v_bucket.p, c->v_rec.p, s);
             mark(c, ST_EXTRACT);
-            TumOut T{c->site.p, c->hap_status.p, c->hap_h1.p, c->hap_h2.p, c->hap_h3.p, c->t_hp.p, c->hap_nps.p, c->hap_psmin.p, c->t_end.p, c->t_len.p, c->t_has.p,
-                     c->t_ctr.p, (long long)out->pair_capacity, (long long)out->win_capacity, c->t_pair_site.p, c->t_pair_read.p, c->t_pair_hp.p,
-                     c->t_win_site.p, c->t_win_allele.p, c->t_win_off.p, c->t_win_base.p, c->P.percentage_threshold,
-                     c->t_hits.p, c->t_hit_rp.p, (long long)hc, c->t_win_cnt.p, c->t_win_at.p};
+            TumOut T{};
+            T.site = c->site.p; T.status = c->hap_status.p; T.hp1 = c->hap_h1.p; T.hp2 = c->hap_h2.p; T.hp3 = c->hap_h3.p; T.hp = c->t_hp.p; T.n_ps = c->hap_nps.p; T.ps_min = c->hap_psmin.p;
+            T.end_pos = c->t_end.p; T.read_len = c->t_len.p; T.has_site = c->t_has.p;
+            T.pair_ctr = c->t_ctr.p; T.hit_ctr = c->t_ctr.p + LPS_TARENAS * 16; T.tot = c->t_ctr.p + 2 * LPS_TARENAS * 16;
+            T.pair_arena = (long long)pa; T.hit_arena = (long long)ha; T.apair_site = c->t_apair_site.p; T.apair_read = c->t_apair_read.p; T.apair_hp = c->t_apair_hp.p;
+            T.pair_cap = (long long)out->pair_capacity; T.win_cap = (long long)out->win_capacity;
+            T.pair_site = c->t_pair_site.p; T.pair_read = c->t_pair_read.p; T.pair_hp = c->t_pair_hp.p;
+            T.win_site = c->t_win_site.p; T.win_allele = c->t_win_allele.p; T.win_offset = c->t_win_off.p; T.win_base = c->t_win_base.p; T.pct_thr = c->P.percentage_threshold;
+            T.hits = c->t_hits.p; T.hit_rp = c->t_hit_rp.p; T.win_cnt = c->t_win_cnt.p; T.win_at = c->t_win_at.p;
             launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 0, c->d_cnt, s);
             launch_tumor_windows(V, R, T, c->temp.p, c->temp_bytes, s);
             launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 1, c->d_cnt, s);
+            launch_tumor_pairs_out(T, s);
             mark(c, ST_D2H);
-            uint32_t n_win = 0;
-            HIP_TRY(hipMemcpyAsync(ctr, c->t_ctr.p, sizeof ctr, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(tot, T.tot, sizeof tot, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(&n_win, c->t_win_at.p + 2 * hc, sizeof n_win, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            ctr[1] = n_win;
-            if (ctr[2] <= hc) break;
-            c->t_hit_cap = (size_t)ctr[2] + (size_t)ctr[2] / 8 + 1024;   // the list was too short: again with room for every hit
-            if (attempt == 2) return fail(c, "somatic extraction: the window hit list kept overflowing");
+            if (tot[1] <= pa && tot[3] <= ha) break;
+            if (tot[1] > pa) c->t_pair_arena = (size_t)tot[1] + (size_t)tot[1] / 8 + 1024;   // an arena was too short: again with room for the fullest one
+            if (tot[3] > ha) c->t_hit_arena = (size_t)tot[3] + (size_t)tot[3] / 8 + 1024;
+            if (attempt == 2) return fail(c, "somatic extraction: a list arena kept overflowing");
         }
+        const unsigned long long ctr[2] = {tot[0], n_win};
         TumOut T{}; T.status = c->hap_status.p; T.hp1 = c->hap_h1.p; T.hp2 = c->hap_h2.p; T.hp3 = c->hap_h3.p; T.hp = c->t_hp.p; T.n_ps = c->hap_nps.p; T.ps_min = c->hap_psmin.p;
         T.end_pos = c->t_end.p; T.read_len = c->t_len.p; T.has_site = c->t_has.p; T.pair_site = c->t_pair_site.p; T.pair_read = c->t_pair_read.p; T.pair_hp = c->t_pair_hp.p;
         T.win_site = c->t_win_site.p; T.win_allele = c->t_win_allele.p; T.win_offset = c->t_win_off.p; T.win_base = c->t_win_base.p;

@@ -7,19 +7,21 @@
 //   BamParser::direct_detect_alleles   src/phase/ParsingBam.cpp:1243-1301   -> k_extract_phase (filters)
 //   BamParser::get_snp / getClip       src/phase/ParsingBam.cpp:1303-1645   -> k_extract_phase
 //
-// Design (MI355X-first, not a translation of the reference's cursor walk):
-//   * a 64-lane wavefront takes FOUR consecutive alignments (planned together: one chain of dependent loads for the four); CIGAR words are
-//     staged 8 per lane, 512 per segment, turned into (reference start, query start) per op by one pair of DPP wave scans and kept in LDS;
-//   * instead of walking ops and advancing a variant cursor, the VARIANTS search the ops: the candidate variants of the segment (a contiguous
-//     slice of the position-sorted table, one packed 8-byte record per lane) find their op with a fixed, branch-free sequence of LDS probes;
-//   * what a candidate needs from the read is decided in two steps.  The search leaves a HIT (variant, query index or the finished call) in an
-//     LDS list - nothing else happens per segment, where only ~13 of 64 lanes hold a candidate.  When the wave's four alignments are through,
-//     the hits (~100) are resolved 64 at a time with every lane busy: base + quality gathered (seq/qual are touched only at variant sites),
-//     allele called, filterSNP's erasures applied, the survivors compacted in place;
-//   * the rows of all four alignments are reserved with ONE atomicAdd of their exact size and leave LDS as coalesced 8-byte records
-//     {variant, allele|quality}; the four 16-byte row descriptors are one 64-byte line; clip events go to a list (one reservation per wave
-//     that has any).  A wave whose hits do not fit the list (long reads over very dense variants) queues itself for k_extract_redo, which
-//     walks such alignments with the direct-to-memory path.
+// Design (MI355X-first, not a translation of the reference's cursor walk; the kernel's own comment below has the details):
+//   * a 64-lane wavefront (one per workgroup) takes a JOB of four consecutive alignments.  Their CIGAR words are resident in lane-chunks of 8, every
+//     alignment padded to a whole number of chunks (lps_reads.hip), so the job's words are ONE stream: 512 words per round, 8 per lane, four rounds
+//     requested together; one pair of DPP wave scans per round turns the lanes' advances into stream coordinates, 8 bytes per chunk kept in LDS;
+//   * clips (getClip) are read off the first two and last two words of each alignment; the walk only counts clip / rejected ops and sends the job to
+//     the general walker (k_extract_redo) when the count disagrees, as it does for absurd lengths;
+//   * instead of walking ops and advancing a variant cursor, the VARIANTS search the ops: the candidate variants of the four alignments (contiguous
+//     slices of the position-sorted table) are counted, ONE atomicAdd reserves that many observation slots, and the candidates are taken 64 at a time
+//     as one flattened list with every lane busy - binary search of the chunk table in LDS, the chunk's 8 words from the caches, an 8-step walk in
+//     registers, the reference's rule for the op, base and quality gathered IN PLACE from the BAM record's own encodings (two random lines of HBM
+//     per site: what bounds the kernel), allele called, filterSNP's erasure applied, the record written straight to its compacted place and counted
+//     in its variant's list (the rank the counting atomic returns travels with the record);
+//   * the four 16-byte row descriptors of a job are one 64-byte line; its clip events go to 16 slots the job owns (no list, no counter);
+//   * a job whose chunks do not fit the LDS table is walked in groups of alignments, an alignment that alone does not fit with a coarser table; a job in
+//     which get_snp's early return fires queues itself for k_extract_redo, the general per-op-prefix walker that takes any BAM record.
 #include <algorithm>
 
 #include "lps_kernels.h"
@@ -120,9 +122,9 @@ void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *r
 //     many observation slots, and the candidates are taken 64 at a time as one flattened list, every lane busy: binary search of the alignment's
 //     chunks for the last chunk that starts at or before the variant, the chunk's 8 words (+ the one after) from the caches, an 8-step walk in
 //     registers to the op that covers the variant, the reference's rules for that op (ParsingBam.cpp:1445-1607), base and quality gathered
-//     right there (one 128-byte line for both, lps_reads.hip), allele called, filterSNP's erasures applied, the observation counted (its rank
-//     in the variant's list) and the record written to its final, compacted place.  Every CIGAR word is fetched from memory ONCE and a base /
-//     quality pair costs one line.
+//     right there (in place: the BAM record's 4-bit bases and its qualities, two lines of HBM), allele called, filterSNP's erasures applied, the observation counted (its rank
+//     in the variant's list) and the record written to its final, compacted place.  Every CIGAR word is fetched from memory ONCE; a base /
+//     quality pair costs two random lines.
 // A job whose chunks do not fit the table (EXT_TAB) is walked in groups of alignments; an alignment that alone does not fit is walked with one
 // table entry per 1 << shift chunks and re-reads the words it needs (LONG mode: read lengths beyond ~100 kb).  A job in which get_snp's early
 // return fires (:1453-1455, :1559-1561: a record whose SEQ is shorter than its CIGAR) queues itself for k_extract_redo before it has written
@@ -444,8 +446,8 @@ __global__ __launch_bounds__(64, EXT_WAVES) void k_extract_phase(VarView V, Read
 }
 
 #define REDO_CAP 512    // observations buffered per wave of the redo kernel
-// The alignments of waves whose hits did not fit k_extract_phase's LDS list (long reads over very dense variants), one job (four alignments) per
-// wave: observations are called as their segment is searched and collected in an LDS buffer; when that fills up the wave reserves an upper bound
+// The general walker: jobs k_extract_phase queued (a clip in the middle of a CIGAR, an op the reference rejects, an op of 2^24 bases and more, a record
+// whose SEQ is shorter than its CIGAR says), one job (four alignments) per wave, per-op prefixes staged in LDS 512 ops at a time: observations are called as their segment is searched and collected in an LDS buffer; when that fills up the wave reserves an upper bound
 // for the row it is in - remaining reference span -> remaining candidates -, empties the buffer and writes the rest of that row directly.
 __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, ObsView O, ClipView C, int mapping_quality,
                                                       LpsCounters *cnt, const uint32_t *redo_list, const unsigned *n_redo, uint32_t *var_cnt, uint32_t *var_del) {

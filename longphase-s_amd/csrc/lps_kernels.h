@@ -267,15 +267,23 @@ void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int m
 struct TumOut {
     int32_t *site;                 // [nV][LPS_TSITE_COUNTERS]
     uint8_t *status; int32_t *hp1, *hp2, *hp3; uint8_t *hp; uint8_t *n_ps; int32_t *ps_min; int32_t *end_pos, *read_len; uint8_t *has_site;
-    unsigned long long *list_ctr;  // [0] pairs, [1] windows, [2] window hits (an alignment at a TUMOR row whose difference window has to be taken)
+    // Both lists of the passes - (site, read, base HP) pairs and window hits - are appended in LPS_TARENAS ARENAS, arena = workgroup % LPS_TARENAS,
+    // every arena with its own counter on its own 128-byte line: a returning atomic on ONE word is served one after the other, ~11 ns each
+    // (two lists x 370 k appending waves = 7 ms of the passes' 9 at 160 Mb), on 64 words they are served side by side.  tot[0..3] = pairs, the
+    // fullest pair arena, hits, the fullest hit arena (k_tumor_totals).
+    unsigned long long *pair_ctr, *hit_ctr, *tot;
+    long long pair_arena, hit_arena;              // slots per arena
+    int32_t *apair_site, *apair_read; uint8_t *apair_hp;   // the pairs in their arenas; compacted into pair_site / pair_read / pair_hp (k_tumor_pairs_out)
     long long pair_cap, win_cap;
     int32_t *pair_site, *pair_read; uint8_t *pair_hp;
     int32_t *win_site; uint8_t *win_allele; int16_t *win_offset; uint8_t *win_base;
     double pct_thr;
-    int4 *hits; int *hit_rp; long long hit_cap;   // the hits of pass 0: {row, alignment, CIGAR word index, offset inside the op | allele << 30} + the query position there
+    int4 *hits; int *hit_rp;                      // the hits of pass 0: {row, alignment, CIGAR word index, offset inside the op | allele << 30} + the query position there
     uint32_t *win_cnt, *win_at;                   // per (hit, direction): differences, and where they go in the window list
 };
 // the +-100 bp difference windows of the hits pass 0 listed (getWindowsDiffRef, SomaticVarCaller.cpp:654-710): ONE THREAD per (hit, direction)
 void launch_tumor_windows(const VarView &V, const ReadView &R, const TumOut &T, void *temp, size_t temp_bytes, hipStream_t s);
+void launch_tumor_pairs_out(const TumOut &T, hipStream_t s);     // after pass 1: totals + the pairs out of their arenas into the caller's list
+#define LPS_TARENAS 64
 void launch_tumor_extract(const VarView &V, const ReadView &R, const TumOut &T, int mapping_quality, int tag_supplementary, int pass,
                           LpsCounters *cnt, hipStream_t s);

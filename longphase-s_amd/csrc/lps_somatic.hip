@@ -196,23 +196,27 @@ __global__ __launch_bounds__(64) void k_tumor_extract(VarView V, ReadView R, Tum
                     // instead (one reservation per round of the wave) and k_win_count / k_win_write take the walks one THREAD per (hit, direction).
                     const unsigned long long wm = __ballot(want_win);
                     if (wm) {
+                        const int arena = (int)(blockIdx.x % LPS_TARENAS);
                         unsigned long long hb = 0;
-                        if (l == 0) hb = atomicAdd(&T.list_ctr[2], (unsigned long long)__popcll(wm));
+                        if (l == 0) hb = atomicAdd(&T.hit_ctr[arena * 16], (unsigned long long)__popcll(wm));
                         hb = __shfl(hb, 0);
                         if (want_win) {
-                            const long long slot = (long long)hb + __popcll(wm & lanemask_lt());
-                            if (slot < T.hit_cap) { T.hits[slot] = make_int4(v, r, opj, win_off | (win_allele << 30)); T.hit_rp[slot] = sqry[opj - seg0] + win_off; }
+                            const long long idx = (long long)hb + __popcll(wm & lanemask_lt());
+                            if (idx < T.hit_arena) { const long long slot = (long long)arena * T.hit_arena + idx;
+                                T.hits[slot] = make_int4(v, r, opj, win_off | (win_allele << 30)); T.hit_rp[slot] = sqry[opj - seg0] + win_off; }
                         }
                     }
                 } else {
                     const unsigned long long pm = __ballot(pair);
                     if (pm) {
+                        const int arena = (int)(blockIdx.x % LPS_TARENAS);
                         unsigned long long pb = 0;
-                        if (l == 0) pb = atomicAdd(&T.list_ctr[0], (unsigned long long)__popcll(pm));
+                        if (l == 0) pb = atomicAdd(&T.pair_ctr[arena * 16], (unsigned long long)__popcll(pm));
                         pb = __shfl(pb, 0);
                         if (pair) {
-                            const long long slot = (long long)pb + __popcll(pm & lanemask_lt());
-                            if (slot < T.pair_cap) { T.pair_site[slot] = v; T.pair_read[slot] = r; T.pair_hp[slot] = (uint8_t)base_hp; }
+                            const long long idx = (long long)pb + __popcll(pm & lanemask_lt());
+                            if (idx < T.pair_arena) { const long long slot = (long long)arena * T.pair_arena + idx;
+                                T.apair_site[slot] = v; T.apair_read[slot] = r; T.apair_hp[slot] = (uint8_t)base_hp; }
                         }
                     }
                 }
@@ -236,16 +240,19 @@ __global__ __launch_bounds__(64) void k_tumor_extract(VarView V, ReadView R, Tum
     }
 }
 
-// thread t = (hit t >> 1, direction t & 1: 0 towards the read's start, 1 towards its end).  WRITE = false: cnt[t] = differences found;
-// WRITE = true: they are stored from slot at[t] on.  The walk itself is the reference's (win_dir above), untouched.
+// thread t = (hit slot t >> 1, direction t & 1: 0 towards the read's start, 1 towards its end); a slot holds a hit when its index inside its arena is
+// below the arena's counter.  WRITE = false: cnt[t] = differences found; WRITE = true: they are stored from slot at[t] on.  The walk itself is the
+// reference's (win_dir above), untouched.
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_tumor_windows(VarView V, ReadView R, TumOut T) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const unsigned long long n_hits = min(T.list_ctr[2], (unsigned long long)T.hit_cap);
-    if ((unsigned long long)(t >> 1) >= n_hits) { if (!WRITE && t < 2 * T.hit_cap + 1) T.win_cnt[t] = 0u; return; }
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x, n_slots = (long long)LPS_TARENAS * T.hit_arena;
+    if (t > 2 * n_slots) return;
+    const long long hs = t >> 1, arena = hs / T.hit_arena, idx = hs - arena * T.hit_arena;
+    const bool live = hs < n_slots && (unsigned long long)idx < T.hit_ctr[arena * 16];
+    if (!live) { if (!WRITE) T.win_cnt[t] = 0u; return; }
     if (WRITE && T.win_cnt[t] == 0u) return;
-    const int4 h = T.hits[t >> 1]; const int dir = (t & 1) ? +1 : -1;
-    const int v = h.x, r = h.y, opj = h.z, win_off = h.w & 0x3fffffff, allele = (h.w >> 30) & 1, rp = T.hit_rp[t >> 1];
+    const int4 h = T.hits[hs]; const int dir = (t & 1) ? +1 : -1;
+    const int v = h.x, r = h.y, opj = h.z, win_off = h.w & 0x3fffffff, allele = (h.w >> 30) & 1, rp = T.hit_rp[hs];
     const uint32_t *cig = R.cig(r); const int n_cig = R.cp_n[r];
     const int len = (int)(cig[opj] >> 4);
     const int remaining = dir > 0 ? ((len - win_off > 0) ? len - win_off : 0) : (win_off > 0 ? win_off : 0);
@@ -253,11 +260,42 @@ __global__ __launch_bounds__(256) void k_tumor_windows(VarView V, ReadView R, Tu
     if (!WRITE) T.win_cnt[t] = (uint32_t)n;
 }
 void launch_tumor_windows(const VarView &V, const ReadView &R, const TumOut &T, void *temp, size_t temp_bytes, hipStream_t s) {
-    const size_t n = (size_t)(2 * T.hit_cap + 1);
+    const size_t n = (size_t)(2 * LPS_TARENAS * T.hit_arena + 1);
     const dim3 g((unsigned)((n + 255) / 256)), b(256);
     hipLaunchKernelGGL(k_tumor_windows<false>, g, b, 0, s, V, R, T);
-    exscan_u32(temp, temp_bytes, T.win_cnt, T.win_at, n, s);              // win_at[2 * hit_cap] = all differences: the window count
+    exscan_u32(temp, temp_bytes, T.win_cnt, T.win_at, n, s);              // win_at[n - 1] = all differences: the window count
     hipLaunchKernelGGL(k_tumor_windows<true>, g, b, 0, s, V, R, T);
+}
+
+// totals of both lists (one wave), then the pairs out of their arenas into the caller's contiguous list: arena a's entries go behind those of the arenas before it
+__global__ void k_tumor_totals(TumOut T) {
+    const int a = threadIdx.x;                                            // LPS_TARENAS == 64 == one wave
+    const unsigned long long p = T.pair_ctr[a * 16], h = T.hit_ctr[a * 16];
+    unsigned long long ps = p, pm = p, hs = h, hm = h;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { ps += __shfl_xor(ps, d); hs += __shfl_xor(hs, d); const unsigned long long x = __shfl_xor(pm, d), y = __shfl_xor(hm, d); pm = x > pm ? x : pm; hm = y > hm ? y : hm; }
+    if (a == 0) { T.tot[0] = ps; T.tot[1] = pm; T.tot[2] = hs; T.tot[3] = hm; }
+}
+__global__ __launch_bounds__(256) void k_tumor_pairs_out(TumOut T) {
+    static_assert(LPS_TARENAS == 64, "one wave reduces the arena counters");
+    __shared__ unsigned long long s_base;
+    const int a = blockIdx.y; const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long n_a = min(T.pair_ctr[a * 16], (unsigned long long)T.pair_arena);
+    if ((unsigned long long)blockIdx.x * 256ull >= n_a) return;
+    if (threadIdx.x < 64) {
+        unsigned long long b = threadIdx.x < a ? min(T.pair_ctr[threadIdx.x * 16], (unsigned long long)T.pair_arena) : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) b += __shfl_xor(b, d);
+        if (threadIdx.x == 0) s_base = b;
+    }
+    __syncthreads();
+    if ((unsigned long long)idx >= n_a) return;
+    const long long src = (long long)a * T.pair_arena + idx, dst = (long long)s_base + idx;
+    if (dst < T.pair_cap) { T.pair_site[dst] = T.apair_site[src]; T.pair_read[dst] = T.apair_read[src]; T.pair_hp[dst] = T.apair_hp[src]; }
+}
+void launch_tumor_pairs_out(const TumOut &T, hipStream_t s) {
+    hipLaunchKernelGGL(k_tumor_totals, dim3(1), dim3(64), 0, s, T);
+    hipLaunchKernelGGL(k_tumor_pairs_out, dim3((unsigned)((T.pair_arena + 255) / 256), LPS_TARENAS), dim3(256), 0, s, T);
 }
 
 void launch_tumor_extract(const VarView &V, const ReadView &R, const TumOut &T, int mapping_quality, int tag_supplementary, int pass,
