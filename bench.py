@@ -394,8 +394,11 @@ def somatic_leg(dev, mb, steps, threads, seed=301, check=True):
                 fn()
             return (time.perf_counter() - t0) / k * 1e3
         # ---- pass 1: normal BAM
+        def pin_all(o, names):                                           # results land in page-locked host memory (hipHostRegister), as a caller that cares would hold them
+            return all(pin(getattr(o, k)) for k in names)
         ctx.load_chromosome(V, N.ref, RN)
         o1 = abi.SiteCountersOut(V.n, RN.n_reads)
+        pinned = pin_all(o1, ("counters", "read_hp"))
         def p1():
             ctx._check(Lh.lps_somatic_extract_normal(ctx.h, C.byref(o1.c)), "lps_somatic_extract_normal")
         ms1 = timed(p1, steps); k1 = ctx.timings()["stages"]["extract"]
@@ -403,12 +406,15 @@ def somatic_leg(dev, mb, steps, threads, seed=301, check=True):
         ctx.load_chromosome(V, T.ref, RT)
         pair_cap, win_cap = 64 * RT.n_reads + 1024, 256 * RT.n_reads + 1024
         o2 = abi.TumorExtractOut(V.n, RT.n_reads, pair_cap, win_cap)
+        pinned = pin_all(o2, ("site", "hp1", "hp2", "hp3", "ps_min", "end_pos", "read_len", "status", "hp", "n_ps", "has_site", "pair_site", "pair_read", "pair_base_hp",
+                              "win_site", "win_allele", "win_offset", "win_base")) and pinned
         def p2():
             ctx._check(Lh.lps_somatic_extract_tumor(ctx.h, C.byref(o2.c)), "lps_somatic_extract_tumor")
         ms2 = timed(p2, steps); k2 = ctx.timings()["stages"]["extract"]
         # ---- pass 3: tagging, tumor reads still resident; the table with the flagged rows
         ctx.set_table(VT, T.ref)
         o3 = abi.SomaticTagOut(RT.n_reads)
+        pinned = pin_all(o3, abi.SomaticTagOut.I32 + abi.SomaticTagOut.U8) and pinned
         def p3():
             ctx._check(Lh.lps_somatic_tag_chromosome(ctx.h, C.byref(o3.c)), "lps_somatic_tag_chromosome")
         ms3 = timed(p3, steps); k3 = ctx.timings()["stages"]["extract"]
@@ -419,7 +425,7 @@ def somatic_leg(dev, mb, steps, threads, seed=301, check=True):
     dom = max(kms, key=lambda k: kms[k])
     res.update(metric="tumor reads through the three somatic_haplotag passes / s", value=RT.n_reads / (tot * 1e-3), unit="reads/s", steps=steps,
                pass_ms=dict(normal_extract=round(ms1, 3), tumor_extract=round(ms2, 3), tag=round(ms3, 3)), kernel_ms={k: round(v, 4) for k, v in kms.items()},
-               pairs=int(o2.c.n_pairs), windows=int(o2.c.n_windows),
+               pairs=int(o2.c.n_pairs), windows=int(o2.c.n_windows), results_in_pinned_host_memory=bool(pinned),
                roofline=dict(bound="hbm", kernel=dom, achieved=alg[dom] / (kms[dom] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=alg[dom] / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              algorithmic_bytes=int(alg[dom]), note="SURVEY.md 8(d) closed form of the per-read passes: 36 B + 4 B x CIGAR words per alignment + what the pass writes per hit; the sites' bases are gathered in place"),
                clock="one-pass: every call recomputes from the decoded alignments as the push left them; call = launch to results in host memory")

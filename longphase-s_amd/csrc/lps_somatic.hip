@@ -35,18 +35,32 @@ __device__ __forceinline__ bool win_next_op(const uint32_t *cig, int &idx, int e
 }
 
 // getOrderWindowsDiffRef (:654-685): WRITE=false counts the differences, WRITE=true stores them from slot `base`.
+// One THREAD walks a window (k_tumor_windows): its 64 neighbours in the wave walk 64 other reads, so every byte load of a step is 64 different lines
+// and the working set of a CU's waves (two lines per lane) is far beyond its L1 - every step went to L2 for a line to use ONE byte of it (1.1 ms per
+// launch at 160 Mb).  The walk therefore keeps the aligned 8 bytes around the last read base (16 bases) and reference base in registers and loads
+// again only when it leaves them: a sixteenth / an eighth of the loads.  (Both arrays are DevBuf allocations: 256-byte aligned, 64 bytes of slack.)
+struct ByteWindow {
+    const uint8_t *p; uintptr_t at = ~(uintptr_t)0; unsigned long long w = 0;
+    __device__ __forceinline__ explicit ByteWindow(const void *q) : p((const uint8_t *)q) {}
+    __device__ __forceinline__ unsigned operator[](long long i) {
+        const uintptr_t a = (uintptr_t)(p + i), b = a & ~(uintptr_t)7;
+        if (b != at) { w = *reinterpret_cast<const unsigned long long *>(b); at = b; }
+        return (unsigned)(w >> (8u * (unsigned)(a & 7))) & 0xffu;
+    }
+};
 template <bool WRITE>
 __device__ __forceinline__ int win_dir(const uint32_t *cig, int idx, int n_cig, const uint8_t *seq, int readLen, const char *ref, int refLen,
                                        int readPos, int remaining, int refPos, int dir, const TumOut &T, long long base, int site, int allele) {
     int op = cig[idx] & 15, n = 0;
+    ByteWindow sq(seq), rf(ref);
     for (int i = 1; i <= 100; ++i) {
         remaining--;
         if (remaining == 0 || remaining == -1) { if (!win_next_op(cig, idx, n_cig, dir, remaining, readPos, refPos, op)) return n; }
         if (op == 2 || op == 1 || op == 3 || op == 6 || op == 8) continue;
         readPos += dir; refPos += dir;
         if (readPos > readLen || refPos > refLen || readPos < 0 || refPos < 0) return n;
-        const char rb = readPos < readLen ? nt16_char(seq[readPos >> 1] >> ((~readPos & 1) << 2)) : '\0';
-        const char fb = refPos < refLen ? ref[refPos] : '\0';
+        const char rb = readPos < readLen ? nt16_char((int)(sq[readPos >> 1] >> ((~readPos & 1) << 2))) : '\0';
+        const char fb = refPos < refLen ? (char)rf[refPos] : '\0';
         if (rb != fb) {
             if (WRITE && base + n < T.win_cap) { T.win_site[base + n] = site; T.win_allele[base + n] = (uint8_t)allele; T.win_offset[base + n] = (int16_t)(i * dir); T.win_base[base + n] = (uint8_t)rb; }
             ++n;
