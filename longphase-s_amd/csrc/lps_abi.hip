@@ -1604,8 +1604,7 @@ int lps_somatic_extract_normal(lps_ctx *c, lps_site_counters *out) {
         const int nR = c->nR, nV = c->nV;
         if (out->n != nV) return fail(c, "lps_site_counters.n must equal the variant table size");
         if (out->read_hp && out->n_reads != nR) return fail(c, "lps_site_counters.n_reads must equal the number of pushed alignments");
-        memset(out->counters, 0, (size_t)nV * LPS_SITE_COUNTERS * sizeof(int32_t));
-        if (nR == 0 || nV == 0) return 0;
+        if (nR == 0 || nV == 0) { memset(out->counters, 0, (size_t)nV * LPS_SITE_COUNTERS * sizeof(int32_t)); return 0; }   // (otherwise every counter is overwritten by the copy below)
         if (!c->has_tkind) return fail(c, "somatic extraction needs hp1_is_alt, phase_set, somatic_role and tumor_kind in the variant table");
         if (c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
         hipStream_t s = c->stream;
@@ -1645,9 +1644,8 @@ int lps_somatic_extract_tumor(lps_ctx *c, lps_tumor_extract_result *out) {
         const int nR = c->nR, nV = c->nV;
         if (out->n != nV) return fail(c, "lps_tumor_extract_result.n must equal the variant table size");
         if (out->n_reads != nR) return fail(c, "lps_tumor_extract_result.n_reads must equal the number of pushed alignments");
-        memset(out->site, 0, (size_t)nV * LPS_TSITE_COUNTERS * sizeof(int32_t));
         out->n_pairs = 0; out->n_windows = 0;
-        if (nR == 0) return 0;
+        if (nR == 0) { memset(out->site, 0, (size_t)nV * LPS_TSITE_COUNTERS * sizeof(int32_t)); return 0; }   // (otherwise every counter is overwritten by the copy below)
         if (nV > 0 && !c->has_tkind) return fail(c, "somatic extraction needs hp1_is_alt, phase_set, somatic_role and tumor_kind in the variant table");
         if (nV > 0 && c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
         hipStream_t s = c->stream;
