@@ -142,6 +142,14 @@ def pin(arr):
     return hiprt.hipHostRegister(arr.ctypes.data, arr.nbytes, 0) == 0
 
 
+def unpin(arr):
+    """hipHostUnregister: a registered range must be released before its memory goes back to the allocator (a later array that reuses part of it
+    would make every copy from it fail)."""
+    hiprt = C.CDLL("libamdhip64.so")
+    hiprt.hipHostUnregister.argtypes = [C.c_void_p]
+    return hiprt.hipHostUnregister(arr.ctypes.data) == 0
+
+
 def cpu_baseline(g, spec, threads, port, gpu_result=None):
     """The reference binary (oracle/_ref/longphase-s-ref: BAM + VCF + FASTA in, phased VCF out, incl. BGZF/BAM decode) on ONE WHOLE contig
     of the benched workload; kind 'port' (the oracle restatement on decoded arrays, 1 thread) when the binary is not there."""
@@ -328,6 +336,9 @@ def whole_node_baseline(dev, P, threads, seed, n_contigs=16, contig_mb=10):
     p_wall = time.perf_counter() - t0
     for cx in ctxs:
         cx.close()
+    for c in contigs:
+        for x in (c["host"].qual, c["host"].seq, c["host"].cigar):
+            unpin(x)
     same = True; n_ph = 0; n_ref = 0
     for c in contigs:
         w = want.get(c["name"], {})
@@ -394,8 +405,16 @@ def somatic_leg(dev, mb, steps, threads, seed=301, check=True):
                 fn()
             return (time.perf_counter() - t0) / k * 1e3
         # ---- pass 1: normal BAM
+        pinned_arrays = []
         def pin_all(o, names):                                           # results land in page-locked host memory (hipHostRegister), as a caller that cares would hold them
-            return all(pin(getattr(o, k)) for k in names)
+            ok = True
+            for k in names:
+                a = getattr(o, k)
+                if pin(a):
+                    pinned_arrays.append(a)
+                else:
+                    ok = False
+            return ok
         ctx.load_chromosome(V, N.ref, RN)
         o1 = abi.SiteCountersOut(V.n, RN.n_reads)
         pinned = pin_all(o1, ("counters", "read_hp"))
@@ -418,6 +437,8 @@ def somatic_leg(dev, mb, steps, threads, seed=301, check=True):
         def p3():
             ctx._check(Lh.lps_somatic_tag_chromosome(ctx.h, C.byref(o3.c)), "lps_somatic_tag_chromosome")
         ms3 = timed(p3, steps); k3 = ctx.timings()["stages"]["extract"]
+        for a in pinned_arrays:
+            unpin(a)
     tot = ms1 + ms2 + ms3
     n_cig_t = int(RT.cigar.size); n_cig_n = int(RN.cigar.size)
     alg = {"normal_extract": 36 * RN.n_reads + 4 * n_cig_n, "tumor_extract": 36 * RT.n_reads + 4 * n_cig_t + 8 * int(o2.c.n_pairs) + 8 * int(o2.c.n_windows), "tag": 36 * RT.n_reads + 4 * n_cig_t + 16 * RT.n_reads}
@@ -724,6 +745,8 @@ def main():
                 t0 = time.perf_counter(); s["ctx"].run_phase(s["out"]); one = time.perf_counter() - t0
                 p_clock = dict(contig=cpu_name, h2d_s=round(h2d, 3), step_s=round(one, 4), value=s["n_ph"] / (h2d + one), unit="SNPs/s", pinned_host_memory=bool(pinned),
                                note="lps_set_variants + lps_set_reference + lps_push_reads (H2D of the decoded batch) + one lps_phase_chromosome; PCIe-inclusive, never `value`")
+                for x in (s["host"].qual, s["host"].seq, s["host"].cigar):
+                    unpin(x)
         for s in slots:
             per_contig.append(s["rec"])
             if cpu_pick is None or cpu_pick[0] is not s["g"]:

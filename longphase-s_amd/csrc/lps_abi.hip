@@ -79,7 +79,7 @@ struct lps_ctx {
     DevBuf<uint8_t> zpool;        // the zero-initialised arrays of a phase run (arena_ctr, out_ps/gt, deleted, is_node, vtype_key, mrow_cnt, node_end/cur, bsize, cnt4) are carved from it
     // clips / cnv
     DevBuf<ClipEv> clip_ev; size_t clip_capacity = 0;
-    DevBuf<unsigned long long> clip_keys, clip_keys_s;
+    DevBuf<unsigned long long> clip_keys, clip_keys_s; DevBuf<uint32_t> clip_tab; bool clips_sorted = false;
     DevBuf<int32_t> cnv_start, cnv_end;
     DevBuf<long long> agg_sum; DevBuf<int32_t> agg_cnt; DevBuf<double> miss;
     DevBuf<uint32_t> cnv_flag, cnv_idx, cnv_list, cnv_nlist; DevBuf<uint8_t> cnv_fn, cnv_pre;
@@ -1175,14 +1175,15 @@ static int run_phase(lps_ctx *c) {
         // everything that has to start a run as zeros sits in ONE allocation cleared by one fill (a dozen separate fills cost ~4 us each)
         size_t zbytes = 0;
         auto zslot = [&](size_t bytes) { const size_t at = zbytes; zbytes += (bytes + 255) & ~(size_t)255; return at; };
-        const size_t z_arena = zslot(LPS_ARENAS * 8 * sizeof(unsigned long long)), z_del = zslot((size_t)nR + 1), z_stats = zslot(4 * sizeof(unsigned)),
+        const size_t z_arena = zslot(LPS_ARENAS * 8 * sizeof(unsigned long long)), z_del = zslot((size_t)nR + 1), z_stats = zslot(4 * sizeof(unsigned)), z_ctab = zslot((size_t)(2u << LPS_CLIP_TAB_BITS) * 4),
                      z_vc = zslot(((size_t)nG + 1) * 4), z_vd = zslot(((size_t)nG + 1) * 4), z_nh = zslot((c->name_cap + 2) * 4),
                      z_ps = zslot(((size_t)nG + 1) * 4), z_gt = zslot((size_t)nG + 1), z_vd2 = zslot(((size_t)nG + 1) * 4), z_vtk = zslot(((size_t)nG + 1) * 4),
                      z_bm = zslot((size_t)nG + 1), z_c4 = zslot(((size_t)nG * 4 + 4) * 4);
+
         c->zpool.reserve(zbytes);
         c->z_late_off = z_ps; c->z_late_bytes = zbytes - z_ps;       // what the stages after the overlap filter need zeroed (see run_late)
         c->arena_ctr.carve(c->zpool.p + z_arena, LPS_ARENAS * 8); c->out_ps.carve(c->zpool.p + z_ps, (size_t)nG + 1); c->out_gt.carve(c->zpool.p + z_gt, (size_t)nG + 1);
-        c->deleted.carve(c->zpool.p + z_del, (size_t)nR + 1); c->clip_stats.carve(c->zpool.p + z_stats, 4);
+        c->deleted.carve(c->zpool.p + z_del, (size_t)nR + 1); c->clip_stats.carve(c->zpool.p + z_stats, 4); c->clip_tab.carve(c->zpool.p + z_ctab, (size_t)(2u << LPS_CLIP_TAB_BITS));
         c->var_cnt.carve(c->zpool.p + z_vc, (size_t)nG + 1); c->var_del.carve(c->zpool.p + z_vd, (size_t)nG + 1); c->name_head.carve(c->zpool.p + z_nh, c->name_cap + 2);
         c->var_del2.carve(c->zpool.p + z_vd2, (size_t)nG + 1); c->vtype_key.carve(c->zpool.p + z_vtk, (size_t)nG + 1);
         c->bmulti.carve(c->zpool.p + z_bm, (size_t)nG + 1); c->cnt4.carve(c->zpool.p + z_c4, (size_t)nG * 4 + 4);
@@ -1237,7 +1238,7 @@ static int run_phase(lps_ctx *c) {
         G.edge = c->edge.p; G.erec = c->erec.p; G.node_pairs = c->node_pairs.p; G.cnt = c->d_cnt;
         // ---- read names linked into lists, clip keys, reservation totals: one launch; then the groups of several alignments and their overlap filter (a8)
         mark(c, ST_GROUPS);
-        launch_names(G, C, c->clip_keys.p, c->arena_ctr.p, arena_size, s);
+        launch_names(G, C, c->clip_keys.p, c->arena_ctr.p, arena_size, c->clip_tab.p, s);
         mark(c, ST_OVERLAP);
         launch_groups(G, P.overlap_threshold, /*counted=*/!c->nX, s);
         if (c->nX) launch_count_ranks(G, s);
@@ -1264,17 +1265,26 @@ static int run_phase(lps_ctx *c) {
         G.ukeys = c->nkeys.p; G.skeys = c->nkeys_s.p; G.uvals = c->nvals.p; G.svals = c->nvals_s.p;
         // places in the lists that no row will ever fill (observations of a job that went to the general walker after they were counted: malformed records)
         if (c->h_cnt.n_abandoned) HIP_TRY(hipMemsetAsync(c->nkeys.p, 0xff, (size_t)c->late_n_keys * (c->key64 ? 8 : 4), s));
-        // ---- a7 clips -> CNV intervals: the keys are sorted here and travel to the host (pinned), which replays the state machine (replay_cnv)
+        // ---- a7 clips -> CNV intervals: the keys are sorted here and travel to the host (pinned), which replays the state machine (replay_cnv) -
+        //      unless no (position, front / back) key occurs five times (clip_mult, k_name_link's count-min bound): then no interval can be emitted
+        //      (replay_cnv's own first test) and the sort (nine launches), the copy and the replay are skipped
         mark(c, ST_CLIP);
-        launch_clip_sort(c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, s);
         const size_t nk = c->h_cnt.n_clips;
+        c->late_cap_main = cap_main; c->late_tail = tail_size;
+        c->h_ub_hazard = nk == 0 ? 1u : 0u;                               // reference: UB on an empty ClipCount (PhasingGraph.cpp:1134)
+        static const bool always_sort = getenv("LPS_CLIP_ALWAYS_SORT") != nullptr;       // (test hook: the sorted path on inputs that would skip it)
+        c->clips_sorted = false;
+        if (c->h_cnt.clip_mult < 5u && !always_sort) {
+            c->h_cnv_start.clear(); c->h_cnv_end.clear();
+            return run_late(c, false);
+        }
+        launch_clip_sort(c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, s);
+        c->clips_sorted = true;
         if (nk > c->h_clip_cap) { if (c->h_clip_keys) HIP_TRY(hipHostFree(c->h_clip_keys)); c->h_clip_keys = nullptr; c->h_clip_cap = nk + nk / 2 + 1024; HIP_TRY(hipHostMalloc((void **)&c->h_clip_keys, c->h_clip_cap * sizeof(unsigned long long))); }
         HIP_TRY(hipEventRecord(c->ev_sorted, s));
         HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_sorted, 0));      // the copy rides on its own stream: the late stages do not queue behind it
         if (nk) HIP_TRY(hipMemcpyAsync(c->h_clip_keys, c->clip_keys_s.p, nk * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->copy_stream));
         HIP_TRY(hipEventRecord(c->ev_clip, c->copy_stream));
-        c->late_cap_main = cap_main; c->late_tail = tail_size;
-        c->h_ub_hazard = nk == 0 ? 1u : 0u;                               // reference: UB on an empty ClipCount (PhasingGraph.cpp:1134)
         // ---- everything after.  Usually the clips give no CNV interval, so the late stages are enqueued on that guess and the host replays the state
         //      machine meanwhile; lps_phase_chromosome runs them again with the filter if the guess was wrong.  When the previous run of this ctx did
         //      have intervals the guess is not made: the host waits for the keys (a bubble of one small copy), replays, and the late stages run once.
@@ -1794,6 +1804,7 @@ int64_t lps_dump_clips(lps_ctx *c, int32_t *pos, uint8_t *front_back, int64_t ca
     try {
         HIP_TRY(hipSetDevice(c->device));
         const size_t n = c->h_cnt.n_clips;
+        if (!c->clips_sorted && n) { launch_clip_sort((unsigned)n, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, c->stream); c->clips_sorted = true; }   // (the run itself had no use for the order)
         auto k = download(c, c->clip_keys_s.p, n);
         int64_t m = 0;
         for (size_t i = 0; i < n; ++i) { if (k[i] == ~0ull) break; if (pos && m < capacity) { pos[m] = (int32_t)(k[i] >> 1); front_back[m] = (uint8_t)(k[i] & 1); } ++m; }

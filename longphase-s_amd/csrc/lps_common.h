@@ -67,7 +67,7 @@ struct LpsCounters {
     unsigned int ub_hazard;
     unsigned int n_nodes;
     unsigned int n_abandoned;       // observations counted at the extraction whose job then went to the general walker (their list places are holes)
-    unsigned int pad0;
+    unsigned int clip_mult;         // upper bound of the largest number of clip events with one key (position, front / back): count-min over two hashed tables (k_name_link)
     // ---- accumulated by the stages after the overlap filter (cleared when they run again with the CNV filter)
     unsigned long long n_pairs;
     unsigned long long n_obs_final; // observations of kept alignments after all filters

@@ -30,7 +30,8 @@ struct GraphView {
 void launch_clip_sort(unsigned n_clips, unsigned long long *keys, unsigned long long *keys_sorted, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_dense_names(int n_reads, const uint32_t *name_id, uint32_t name_max, unsigned long long *keys, unsigned long long *keys_s, uint32_t *head, uint32_t *gidx,
                         uint32_t *dense, void *temp, size_t temp_bytes, hipStream_t s);
-void launch_names(const GraphView &G, const ClipView &C, unsigned long long *clip_keys, const unsigned long long *arena_ctr, unsigned long long arena_size, hipStream_t s);
+#define LPS_CLIP_TAB_BITS 20   /* two tables of 2^20 counters each (8 MB, part of the zero pool): the count-min bound of the clip keys' multiplicity */
+void launch_names(const GraphView &G, const ClipView &C, unsigned long long *clip_keys, const unsigned long long *arena_ctr, unsigned long long arena_size, uint32_t *clip_tab, hipStream_t s);
 void launch_groups(const GraphView &G, double overlap_threshold, bool counted, hipStream_t s);
 void launch_count_ranks(const GraphView &G, hipStream_t s);
 struct CnvScratch { uint32_t *flag, *idx, *list, *n_list; uint8_t *fn, *pre; };

@@ -36,7 +36,7 @@
 #define NAMES_B 1024      // alignments (and clip slots per pass) of a workgroup: a quarter of the atomics on the counters' single words that 256 would make
 __global__ __launch_bounds__(NAMES_B) void k_name_link(int n_reads, const uint32_t *name, const RowDesc *rows, uint32_t *name_head, uint32_t *name_link,
                                                    LpsCounters *cnt, const unsigned long long *arena_ctr, unsigned long long arena_size,
-                                                   ClipView C, unsigned long long *keys, int nb_reads) {
+                                                   ClipView C, unsigned long long *keys, int nb_reads, uint32_t *clip_tab) {
     __shared__ unsigned s_wcnt[NAMES_B / 64], s_wmax[NAMES_B / 64], s_base;
     const int w = threadIdx.x >> 6;
     if ((int)blockIdx.x < nb_reads) {
@@ -88,7 +88,18 @@ __global__ __launch_bounds__(NAMES_B) void k_name_link(int n_reads, const uint32
     if (threadIdx.x == 0) { unsigned tot = 0; for (int q = 0; q < NAMES_B / 64; ++q) tot += s_wcnt[q]; s_base = tot ? atomicAdd(&cnt->n_clips, tot) : 0u; }
     __syncthreads();
     unsigned off = s_base + incl - mine; for (int q = 0; q < w; ++q) off += s_wcnt[q];
-    for (unsigned e = lo + threadIdx.x; e < hi; e += blockDim.x) if (key_of(e, key)) keys[off++] = key;
+    // Clip::getCNVInterval can only emit an interval when some position holds five or more front clips or five or more back clips (replay_cnv,
+    // lps_abi.hip) - nearly never.  Every key is counted in two hashed tables; the smaller of its two counts bounds the key's multiplicity from
+    // above (count-min), the largest such bound goes to the counters: below 5 the host skips the key sort, the copy and the replay altogether.
+    unsigned worst = 0;
+    for (unsigned e = lo + threadIdx.x; e < hi; e += blockDim.x) if (key_of(e, key)) {
+        keys[off++] = key;
+        const unsigned h1 = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> (64 - LPS_CLIP_TAB_BITS)), h2 = (unsigned)((key * 0xC2B2AE3D27D4EB4Full + 0x165667B19E3779F9ull) >> (64 - LPS_CLIP_TAB_BITS));
+        const unsigned a = atomicAdd(&clip_tab[h1], 1u) + 1u, b = atomicAdd(&clip_tab[(1u << LPS_CLIP_TAB_BITS) + h2], 1u) + 1u;
+        worst = max(worst, min(a, b));
+    }
+    worst = (unsigned)wave_max((int)worst);
+    if (lane_id() == 0 && worst > 1u) atomicMax(&cnt->clip_mult, worst);     // (1 is the floor whenever there is a clip: nothing to tell)
     if (cb == 0 && threadIdx.x == 0 && *C.n_ev > C.capacity - C.fixed) atomicOr(&cnt->err, (unsigned)LPS_ERR_CLIP_OVERFLOW);
 }
 
@@ -1491,11 +1502,11 @@ void launch_dense_names(int n_reads, const uint32_t *name_id, uint32_t name_max,
     hipLaunchKernelGGL(k_dense_ids, GRID(n_reads, 256), 0, s, keys_s, head, gidx, n_reads, dense);
 }
 
-void launch_names(const GraphView &G, const ClipView &C, unsigned long long *clip_keys, const unsigned long long *arena_ctr, unsigned long long arena_size, hipStream_t s) {
+void launch_names(const GraphView &G, const ClipView &C, unsigned long long *clip_keys, const unsigned long long *arena_ctr, unsigned long long arena_size, uint32_t *clip_tab, hipStream_t s) {
     if (!G.n_reads) return;
     const int nb_reads = (G.n_reads + NAMES_B - 1) / NAMES_B;
     hipLaunchKernelGGL(k_name_link, dim3(nb_reads + 1 + std::min(512, nb_reads)), dim3(NAMES_B), 0, s, G.n_reads, G.name, G.rows, G.name_head, G.name_link, G.cnt,
-            arena_ctr, arena_size, C, clip_keys, nb_reads);
+            arena_ctr, arena_size, C, clip_keys, nb_reads, clip_tab);
 }
 
 void launch_groups(const GraphView &G, double overlap_threshold, bool counted, hipStream_t s) {
