@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
                     if (op_is_match(op)) {                                        // judgeSnpHap (:20-130)
                         if (kind == 0) {
                             const int qi = qs + (ps - rs);
-                            const char base_c = qi < hlq ? nt16_char(seq[qi >> 1] >> ((~qi & 1) << 2)) : 'N';
+                            const char base_c = qi < hlq ? nt16_char(__builtin_nontemporal_load(seq + (qi >> 1)) >> ((~qi & 1) << 2)) : 'N';   // (a line touched once per launch: non-temporal)
                             if (base_c == ref_c) vote = 0; else if (base_c == alt_c) vote = 1;
                             count_ps = vote >= 0;
                         } else if ((kind == 1 || kind == 2) && opi + 1 < hncig) {
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
                         const bool first_in = (v == 0) || V.pos[v - 1] + hb.z < rs;
                         if (first_in && (at & VREC_HPOLY3)) {
                             if (kind == 0) {
-                                const char base_c = qs < hlq ? nt16_char(seq[qs >> 1] >> ((~qs & 1) << 2)) : 'N';
+                                const char base_c = qs < hlq ? nt16_char(__builtin_nontemporal_load(seq + (qs >> 1)) >> ((~qs & 1) << 2)) : 'N';
                                 if (base_c == ref_c) vote = 0; else if (base_c == alt_c) vote = 1;
                                 count_ps = true;
                             } else if (kind == 2) { vote = 0; count_ps = true; }
