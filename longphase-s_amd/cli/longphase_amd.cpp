@@ -1078,7 +1078,13 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     int n_workers_now = 1; uint8_t *pin[2] = {nullptr, nullptr};       // set once the workers are known (below); pin: page-locked pieces of the single-worker writer
     struct ContigAcc { std::vector<PurityDatum> pdata; size_t p_initial = 0; int lcvf[5] = {0, 0, 0, 0, 0}; std::ostringstream flog; std::set<int32_t> som;
                        unsigned long long n_flag = 0, hp_hist[9] = {0}, st_count[8] = {0}; uint8_t *out = nullptr; size_t out_bytes = 0; bool ready = false, deflated = false; };
-    auto do_contig = [&](lps_ctx *ctx, const std::string &chr, int phase, ContigAcc &A) {
+    // What passes 1 and 2 of a contig produced, kept from the estimation phase (0) for the calling phase (1): the reference, too, extracts once and
+    // holds the per-site data of every chromosome while it estimates the purity (SomaticVarCaller.cpp:822-905); the second phase then needs the tumor
+    // records only (tagging pass + writer) - the normal BAM is read once, the two extraction passes run once.
+    struct Saved { bool have = false; std::vector<int32_t> nsite, tsite, h1, h2, h3, psmin, endp, rlen, pr_site, pr_read, wn_site; std::vector<uint8_t> tstat, thp, tnps, has, pr_hp, wn_al, wn_base;
+                   std::vector<int16_t> wn_off; int64_t n_pairs = 0, n_windows = 0; };
+    std::vector<Saved> saved(chr_vec.size());
+    auto do_contig = [&](lps_ctx *ctx, const std::string &chr, int phase, ContigAcc &A, Saved &SV) {
         auto t_prep = tick();
         auto fail = [&]() { die(std::string("longphase_amd: ") + L.last_error(ctx)); };
         std::vector<PurityDatum> &pdata = A.pdata; size_t &p_initial = A.p_initial; int (&lcvf)[5] = A.lcvf; std::ostringstream &flog = A.flog;
@@ -1139,9 +1145,11 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             // ---- pass 1: normal BAM (ExtractNorDataBamParser)
             tock(ns_prep, t_prep);
             auto t_stage = tick();
-            std::vector<int32_t> nsite(nv * LPS_SITE_COUNTERS, 0);
+            const bool reuse = phase == 1 && SV.have;                       // passes 1 and 2 ran in the estimation phase
+            std::vector<int32_t> nsite; if (reuse) nsite.swap(SV.nsite); else nsite.assign(nv * LPS_SITE_COUNTERS, 0);
             auto ni = nin.contigs.find(chr);
-            if (resident) {
+            if (reuse) {}
+            else if (resident) {
                 if (n_range.second > 0) { std::vector<uint32_t> nid((size_t)n_range.second, 0);
                     lps_site_counters sc{(int64_t)nv, nsite.data(), 0, nullptr};
                     if (L.begin_chromosome(nctx) || L.set_variants(nctx, &vt) || L.set_reference(nctx, sq.data(), (int64_t)sq.size()) ||
@@ -1154,9 +1162,12 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             }
             tock(ns_p1, t_stage); t_stage = tick();
             // ---- pass 2: tumor BAM (ExtractTumDataBamParser)
-            std::vector<int32_t> tsite(nv * LPS_TSITE_COUNTERS, 0), h1(nt), h2(nt), h3(nt), psmin(nt), endp(nt), rlen(nt);
-            std::vector<uint8_t> tstat(nt), thp(nt), tnps(nt), has(nt);
+            std::vector<int32_t> tsite, h1, h2, h3, psmin, endp, rlen;
+            std::vector<uint8_t> tstat, thp, tnps, has;
             std::vector<int32_t> pr_site, pr_read, wn_site; std::vector<uint8_t> pr_hp, wn_al, wn_base; std::vector<int16_t> wn_off;
+            if (reuse) { tsite.swap(SV.tsite); h1.swap(SV.h1); h2.swap(SV.h2); h3.swap(SV.h3); psmin.swap(SV.psmin); endp.swap(SV.endp); rlen.swap(SV.rlen); tstat.swap(SV.tstat); thp.swap(SV.thp);
+                tnps.swap(SV.tnps); has.swap(SV.has); pr_site.swap(SV.pr_site); pr_read.swap(SV.pr_read); pr_hp.swap(SV.pr_hp); wn_site.swap(SV.wn_site); wn_al.swap(SV.wn_al); wn_base.swap(SV.wn_base); wn_off.swap(SV.wn_off); }
+            else { tsite.assign(nv * LPS_TSITE_COUNTERS, 0); h1.resize(nt); h2.resize(nt); h3.resize(nt); psmin.resize(nt); endp.resize(nt); rlen.resize(nt); tstat.resize(nt); thp.resize(nt); tnps.resize(nt); has.resize(nt); }
             lps_tumor_extract_result te{};
             te.n = (int64_t)nv;
             te.site = tsite.data();
@@ -1174,7 +1185,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
               tumor_pushed = true;
               }
             size_t pcap = nt * 4 + 1024, wcap = nt * 64 + 4096;
-            for (int attempt = 0;; ++attempt) {
+            if (reuse) { te.n_pairs = SV.n_pairs; te.n_windows = SV.n_windows; SV = Saved(); }
+            else for (int attempt = 0;; ++attempt) {
                 pr_site.resize(pcap);
                 pr_read.resize(pcap);
                 pr_hp.resize(pcap);
@@ -1214,6 +1226,13 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
                     else if (ncount <= 5) ++lcvf[3];
                     else if (npct <= 0.7f) ++lcvf[4];
                     else pdata.push_back(PurityDatum{tr_ratio, ncount}); }
+                // kept for the calling phase (a few bytes per alignment, a few hundred per touched site)
+                SV.have = true; SV.n_pairs = te.n_pairs; SV.n_windows = te.n_windows;
+                pr_site.resize((size_t)te.n_pairs); pr_read.resize((size_t)te.n_pairs); pr_hp.resize((size_t)te.n_pairs);
+                wn_site.resize((size_t)te.n_windows); wn_al.resize((size_t)te.n_windows); wn_off.resize((size_t)te.n_windows); wn_base.resize((size_t)te.n_windows);
+                pr_site.shrink_to_fit(); pr_read.shrink_to_fit(); pr_hp.shrink_to_fit(); wn_site.shrink_to_fit(); wn_al.shrink_to_fit(); wn_off.shrink_to_fit(); wn_base.shrink_to_fit();
+                SV.nsite.swap(nsite); SV.tsite.swap(tsite); SV.h1.swap(h1); SV.h2.swap(h2); SV.h3.swap(h3); SV.psmin.swap(psmin); SV.endp.swap(endp); SV.rlen.swap(rlen); SV.tstat.swap(tstat); SV.thp.swap(thp);
+                SV.tnps.swap(tnps); SV.has.swap(has); SV.pr_site.swap(pr_site); SV.pr_read.swap(pr_read); SV.pr_hp.swap(pr_hp); SV.wn_site.swap(wn_site); SV.wn_al.swap(wn_al); SV.wn_base.swap(wn_base); SV.wn_off.swap(wn_off);
                 return;
             }
             tock(ns_p2, t_stage); t_stage = tick();
@@ -1472,7 +1491,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     // contig loop reaches its first member
     std::map<std::string, size_t> group_of; size_t group_loaded = (size_t)-1;
     for (size_t g = 0; g < som_groups.size(); ++g) for (const std::string &c : som_groups[g]) group_of[c] = g;
-    auto enter_group = [&](const std::string &chr) {
+    auto enter_group = [&](const std::string &chr, int phase) {
         if (!grouped) return;
         auto it = group_of.find(chr);
         if (it == group_of.end()) { tgb.range.erase(chr); ngb.range.erase(chr); return; }      // no tumor records
@@ -1480,7 +1499,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         const std::vector<std::string> &grp = som_groups[it->second];
         tgb.load_group(L, ctx, grp);
         std::vector<std::string> ngrp; for (const std::string &c : grp) { const int t = ngb.tid_of(c); if (t >= 0 && ngb.voff[(size_t)t].second > ngb.voff[(size_t)t].first) ngrp.push_back(c); }
-        ngb.load_group(L, nctx, ngrp);
+        if (phase == 0 || !estimate) ngb.load_group(L, nctx, ngrp);        // (the calling phase behind an estimation phase reuses that phase's passes: it needs the tumor records only)
+        else ngb.range.clear();
         group_loaded = it->second;
         // the next group's header walk (host only) beside this group's passes; at the last group of the estimation phase: the first group's again
         const size_t nxt = it->second + 1 < som_groups.size() ? it->second + 1 : 0;
@@ -1507,11 +1527,11 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         if (phase == 1 && estimate) { auto tp = tick(); purity = estimate_purity(pdata, p_initial, lcvf, prefix); T = somatic_thresholds(purity); announce(); tock(ns_purity, tp); }
         std::vector<ContigAcc> acc(chr_vec.size()); std::mutex mu; std::condition_variable cv;
         auto run_share = [&](int g) { for (size_t i : share[(size_t)g]) { do_contig(wctx[(size_t)g], chr_vec[i], phase,
-                acc[i]); { std::lock_guard<std::mutex> lk(mu); acc[i].ready = true; } cv.notify_all(); } };
+                acc[i], saved[i]); { std::lock_guard<std::mutex> lk(mu); acc[i].ready = true; } cv.notify_all(); } };
         std::vector<std::thread> workers;
         if (n_workers > 1) for (int g = 0; g < n_workers; ++g) workers.emplace_back(run_share, g);
         for (size_t i = 0; i < chr_vec.size(); ++i) {                    // merge (and write) in contig order
-            if (n_workers == 1) { enter_group(chr_vec[i]); do_contig(ctx, chr_vec[i], phase, acc[i]); }
+            if (n_workers == 1) { enter_group(chr_vec[i], phase); do_contig(ctx, chr_vec[i], phase, acc[i], saved[i]); }
             else { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return acc[i].ready; }); }
             ContigAcc &A = acc[i];
             pdata.insert(pdata.end(), A.pdata.begin(), A.pdata.end()); p_initial += A.p_initial; for (int k = 0; k < 5; ++k) lcvf[k] += A.lcvf[k];

@@ -1406,7 +1406,7 @@ static int run_scorer(lps_ctx *c, bool somatic, uint8_t *status, int32_t *hp1, i
     c->hap_psmin.carve(c->hap_pool.p + o_pm, nR); c->hap_h3.carve(c->hap_pool.p + o_h3, nR); c->hap_d1.carve(c->hap_pool.p + o_d1, nR); c->hap_d2.carve(c->hap_pool.p + o_d2, nR);
     const size_t span = somatic ? hbytes : o_h3;
     if (span + 1024 > c->h_res_bytes) { if (c->h_res) HIP_TRY(hipHostFree(c->h_res)); c->h_res = nullptr; c->h_res_bytes = span + span / 4 + 4096; HIP_TRY(hipHostMalloc((void **)&c->h_res, c->h_res_bytes)); }
-    c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1);
+    c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1); c->r_v0.reserve((size_t)nR + 1);
     HIP_TRY(hipEventRecord(c->ev_begin, s));
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
     VarView V = var_view(c); ReadView R = read_view(c);
@@ -1414,14 +1414,20 @@ static int run_scorer(lps_ctx *c, bool somatic, uint8_t *status, int32_t *hp1, i
     mark(c, ST_PREP);
     launch_variant_prep(V, /*is_ont (filterSNP is a `phase` step)*/ 0, c->v_bucket.p, c->v_rec.p, s);
     mark(c, ST_EXTRACT);
+    if (somatic) launch_read_v0(V, R, c->r_v0.p, s);                     // (the stream walk starts every alignment at its first candidate row)
     HapOut H{c->hap_status.p, c->hap_h1.p, c->hap_h2.p, c->hap_nps.p, c->hap_psmin.p, c->hap_h3.p, c->hap_d1.p, c->hap_d2.p, nullptr, nullptr, 0.0};
-    launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, somatic ? 1 : 0, c->d_cnt, s);
-    mark(c, ST_D2H);
-    HIP_TRY(hipMemcpyAsync(c->h_res, c->hap_pool.p, span, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(c->h_cnt_pin, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(c->ev_end, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    c->h_cnt = *c->h_cnt_pin;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, somatic ? 1 : 0, c->d_cnt, s, /*general=*/attempt == 1);
+        if (attempt == 0) mark(c, ST_D2H);
+        HIP_TRY(hipMemcpyAsync(c->h_res, c->hap_pool.p, span, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(c->h_cnt_pin, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(c->ev_end, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        c->h_cnt = *c->h_cnt_pin;
+        // the stream walk (somatic tagging pass) met a record outside its arithmetic - an op of 2^24 bases, a job spanning 2^30: the per-op-prefix walker takes any record
+        if (!(c->h_cnt.err & LPS_ERR_KEY_RANGE) || attempt == 1) break;
+        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
+    }
     if (nR < 200000) {
         memcpy(status, c->h_res + o_st, (size_t)nR); memcpy(hp1, c->h_res + o_h1, (size_t)nR * 4); memcpy(hp2, c->h_res + o_h2, (size_t)nR * 4);
         memcpy(n_ps, c->h_res + o_np, (size_t)nR); memcpy(ps_min, c->h_res + o_pm, (size_t)nR * 4);

@@ -265,7 +265,9 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
 #ifndef HTG_TAB
 #define HTG_TAB 1024
 #endif
+template <int MODE>   // 0: germline haplotag; 1: the tagging pass of somatic_haplotag over the merged normal + tumor table (same rules as k_haplotag_score<1>)
 __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary, LpsCounters *cnt) {
+    constexpr bool SOM = MODE == 1;
     __shared__ __attribute__((aligned(16))) int2 s_tab[HTG_TAB + 1];
     __shared__ ExtHdr s_hdr[4];
     const int l = lane_id();
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
     const unsigned live_mask = (unsigned)__ballot(h_live) & 15u;
     const int h_nch = (int)(__shfl_down(h_cp, 1) - h_cp);                 // chunks of alignment q (lanes < nq)
     int vh1[4] = {0, 0, 0, 0}, vh2[4] = {0, 0, 0, 0}, plo[4], phi[4];      // per alignment: votes, smallest / largest phase set seen (wave-uniform)
+    int vh3[4] = {0, 0, 0, 0}, vd1[4] = {0, 0, 0, 0}, vd2[4] = {0, 0, 0, 0};   // SOM: H3 bases at somatic calls and which germline haplotype they derive from
 #pragma unroll
     for (int q = 0; q < 4; ++q) { plo[q] = 0x7fffffff; phi[q] = (int)0x80000000; }
     unsigned todo = live_mask;
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
         for (int i0 = 0; i0 < T; i0 += 64) {
             const int i = i0 + l;
             const bool in = i < T;
-            int vote = -1, ps_v = 0; bool count_ps = false, hp1alt = false;
+            int vote = -1, ps_v = 0; bool count_ps = false, hp1alt = false; int h3v = 0;      // h3v (SOM): 1 H3 base, 2 / 3 deriving from haplotype 1 / 2 as well
             const uint2 vr = pvr;
             pvr = V.rec[min(SELC(i + 64, cum, vadj) + i + 64, V.n - 1)];
             if (in) {
@@ -428,6 +431,24 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
                     const unsigned kind = VREC_KIND(at);
                     const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
                     const uint8_t *seq = R.seq + s_hdr[q].soff;
+                    if (SOM) {
+                        // SomaticHaplotagCigarParser (SomaticHaplotagProcess.cpp:557-579): deletions cast no vote; judgeNormalSnpHap (HaplotagStrategy.cpp:403-435)
+                        // at the normal sample's rows, the tumor ALT at a somatic call is an H3 base (:653-668)
+                        if (op_is_match(op)) {
+                            const int qi = qs + (ps - rs);
+                            const char base_c = qi < hlq ? nt16_char(__builtin_nontemporal_load(seq + (qi >> 1)) >> ((~qi & 1) << 2)) : 'N';
+                            bool is_alt = false;                                      // IsAltIndel (HaplotagParsingBam.cpp:650-670)
+                            if (kind == 0) is_alt = base_c == alt_c;
+                            else if ((kind == 1 || kind == 2) && opi + 1 < hncig) is_alt = (rs + len - 1 == ps) && (int)(wn & 15u) == ((kind == 1) ? 1 : 2);
+                            const unsigned role = VREC_ROLE(at);
+                            if (role == 0) {
+                                if (kind == 0) { if (base_c == ref_c || base_c == alt_c) { vote = is_alt; count_ps = true; } }
+                                else if (kind == 1 || kind == 2) { vote = is_alt; count_ps = true; }
+                            } else if (role == 1) {
+                                if ((kind == 0 || kind == 1 || kind == 2) && is_alt) { const unsigned dv = VREC_DERIVE(at); h3v = dv == 1 ? 2 : (dv == 2 ? 3 : 1); }
+                            }
+                        }
+                    } else
                     if (op_is_match(op)) {                                        // judgeSnpHap (:20-130)
                         if (kind == 0) {
                             const int qi = qs + (ps - rs);
@@ -457,12 +478,14 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
             //      carry ONE phase set (they nearly always do: blocks are long)
             const bool to1 = vote >= 0 && ((vote == 1) == hp1alt), to2 = vote >= 0 && !((vote == 1) == hp1alt);
             const unsigned long long m1 = __ballot(to1), m2 = __ballot(to2), mp = __ballot(count_ps);
+            const unsigned long long m3 = SOM ? __ballot(h3v != 0) : 0ull, md1 = SOM ? __ballot(h3v == 2) : 0ull, md2 = SOM ? __ballot(h3v == 3) : 0ull;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int a = max(cum[k] - i0, 0), b = min(cum[k + 1] - i0, 64);
                 if (b > a) {
                     const unsigned long long rm = ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << a) - 1ull);
                     vh1[k] += __popcll(m1 & rm); vh2[k] += __popcll(m2 & rm);
+                    if (SOM) { vh3[k] += __popcll(m3 & rm); vd1[k] += __popcll(md1 & rm); vd2[k] += __popcll(md2 & rm); }
                     const unsigned long long pk = mp & rm;
                     if (pk) {
                         const int first = __builtin_amdgcn_readlane(ps_v, __builtin_ctzll(pk));
@@ -477,6 +500,14 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
         wave_sync();                                                      // the table and the headers are reused by the next group
     }
     if (bad_cigar && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
+    if (SOM) {                                                            // the counts of the tagging pass: the caller applies judgeSomaticReadHap / inheritHaplotype
+        if (l < nq) {
+            const int r = r0 + l; const int lo = SEL4(l, plo), hi = SEL4(l, phi); const bool any = lo <= hi;
+            H.status[r] = (uint8_t)h_status; H.hp1[r] = SEL4(l, vh1); H.hp2[r] = SEL4(l, vh2); H.n_ps[r] = any ? (lo == hi ? 1 : 2) : 0; H.ps_min[r] = any ? lo : 0;
+            H.hp3[r] = SEL4(l, vh3); H.d1[r] = SEL4(l, vd1); H.d2[r] = SEL4(l, vd2);
+        }
+        return;
+    }
     // ---- judgeReadHap (:243-300) for the four alignments, one lane each; ONE 64-byte line of results per job
     if (l < nq) {
         const int r = r0 + l;
@@ -501,7 +532,11 @@ void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int m
                      int mode, LpsCounters *cnt, hipStream_t s, bool general) {
     if (R.n == 0) return;
     if (mode == 0 && H.rec && !general) {                                 // germline haplotag: the stream walk, four alignments per wave
-        hipLaunchKernelGGL(k_haplotag_stream, dim3(round_up8((R.n + 3) / 4)), dim3(64), 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
+        hipLaunchKernelGGL(k_haplotag_stream<0>, dim3(round_up8((R.n + 3) / 4)), dim3(64), 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
+        return;
+    }
+    if (mode == 1 && !general) {                                          // somatic tagging pass: the same walk (a record it cannot take sets LPS_ERR_KEY_RANGE: the caller runs the general walker)
+        hipLaunchKernelGGL(k_haplotag_stream<1>, dim3(round_up8((R.n + 3) / 4)), dim3(64), 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
         return;
     }
     const dim3 g(round_up8((R.n + HAP_WPB - 1) / HAP_WPB)), b(64 * HAP_WPB);   // a multiple of 8: the XCD-aware unit mapping
