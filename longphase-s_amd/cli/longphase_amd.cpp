@@ -982,15 +982,16 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     const bool n_gpu = !host_inflate && (gpu_inflate || file_bytes(nbam) >= kGpuInflateMinBytes), t_gpu = !host_inflate && (gpu_inflate || file_bytes(tbam) >= kGpuInflateMinBytes);
     if (!n_gpu) nin.load(nbam, threads, want);
     if (!t_gpu) tin.load(tbam, threads, want);
-    const bool resident = n_gpu && t_gpu && !host_deflate && n_gpus <= 1;
+    bool resident = n_gpu && t_gpu && !host_deflate;
     GpuBam ngb, tgb;
+    if (resident) { tgb.open_file(tbam, !no_index); ngb.open_file(nbam, !no_index);
+        if (n_gpus > 1 && !(tgb.indexed && ngb.indexed)) { resident = false; tgb.close_file(); ngb.close_file(); } }   // several workers need the groups an index gives; else: records pushed from host memory
     // GROUPED (both BAMs indexed): the pair is walked in groups of consecutive contigs, as the reference walks it chromosome by chromosome
     // (src/somatic_haplotag/SomaticVarCaller.cpp:822, SomaticHaplotagProcess.cpp:54-109) - one group of the tumor BAM and the same contigs of the
     // normal BAM are uploaded, inflated and scanned, their contigs go through the passes, the next group replaces them.  HBM then holds
     // --group-bytes of the pair at a time instead of both whole files (a 50x / 25x whole-genome pair inflates to ~0.5 TB).
     std::vector<std::vector<std::string>> som_groups; bool grouped = false;
     if (resident) {
-        tgb.open_file(tbam, !no_index); ngb.open_file(nbam, !no_index);
         grouped = tgb.indexed && ngb.indexed;
         if (grouped) {
             // a group is a run of chr_vec whose members are neighbours in BOTH files (contigs without records in a file do not break its run)
@@ -1081,10 +1082,13 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     // What passes 1 and 2 of a contig produced, kept from the estimation phase (0) for the calling phase (1): the reference, too, extracts once and
     // holds the per-site data of every chromosome while it estimates the purity (SomaticVarCaller.cpp:822-905); the second phase then needs the tumor
     // records only (tagging pass + writer) - the normal BAM is read once, the two extraction passes run once.
+    // a worker of the resident path: its context (tumor stream), the second context that holds the normal stream, its own views of the two files
+    struct SomWorker { lps_ctx *ctx = nullptr, *nctx = nullptr; GpuBam *tgb = nullptr, *ngb = nullptr; size_t group_loaded = (size_t)-1; };
     struct Saved { bool have = false; std::vector<int32_t> nsite, tsite, h1, h2, h3, psmin, endp, rlen, pr_site, pr_read, wn_site; std::vector<uint8_t> tstat, thp, tnps, has, pr_hp, wn_al, wn_base;
                    std::vector<int16_t> wn_off; int64_t n_pairs = 0, n_windows = 0; };
     std::vector<Saved> saved(chr_vec.size());
-    auto do_contig = [&](lps_ctx *ctx, const std::string &chr, int phase, ContigAcc &A, Saved &SV) {
+    auto do_contig = [&](SomWorker &W, const std::string &chr, int phase, ContigAcc &A, Saved &SV) {
+        lps_ctx *ctx = W.ctx, *nctx = W.nctx; GpuBam &tgb = *W.tgb, &ngb = *W.ngb;
         auto t_prep = tick();
         auto fail = [&]() { die(std::string("longphase_amd: ") + L.last_error(ctx)); };
         std::vector<PurityDatum> &pdata = A.pdata; size_t &p_initial = A.p_initial; int (&lcvf)[5] = A.lcvf; std::ostringstream &flog = A.flog;
@@ -1385,6 +1389,18 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
             if (L.somatic_write_bgzf(ctx, status.data(), hp.data(), psv.data(), pq.data(), nullptr, 0, &nb)) fail();
             tock(ns_splice, t_splice);
             auto td = tick();
+            if (n_workers_now > 1) {                                        // several workers: the merger writes the contigs' members in contig order
+                uint8_t *zb = (uint8_t *)malloc((size_t)nb + 64); if (!zb) die("ERROR: out of memory");
+                uint8_t *bounce = (uint8_t *)L.host_alloc(32u << 20); if (!bounce) die("longphase_amd: cannot allocate page-locked host memory");
+                for (int64_t off = 0; off < nb; off += (32ll << 20)) { const int64_t len = std::min<int64_t>(32ll << 20, nb - off);
+                    if (L.bgzf_deflate_fetch_range(ctx, off, len, bounce)) fail();
+                    memcpy(zb + off, bounce, (size_t)len); }
+                L.host_free(bounce);
+                A.out = zb; A.out_bytes = (size_t)nb; A.deflated = true;
+                tock(ns_gpu_deflate, td);
+                std::cerr << "(" << chr << ")";
+                return;
+            }
             if (!pin[0]) { pin[0] = (uint8_t *)L.host_alloc(64u << 20); pin[1] = (uint8_t *)L.host_alloc(64u << 20); if (!pin[0] || !pin[1]) die("longphase_amd: cannot allocate page-locked host memory"); }
             if (!raw_started) { w.flush_partial(); raw_started = true; }
             std::thread wr; int k = 0;
@@ -1489,29 +1505,38 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
     };
     // GROUPED: which group a contig belongs to, and the loader that makes a group's records resident (tumor in ctx, normal in nctx) when the
     // contig loop reaches its first member
-    std::map<std::string, size_t> group_of; size_t group_loaded = (size_t)-1;
+    std::map<std::string, size_t> group_of;
     for (size_t g = 0; g < som_groups.size(); ++g) for (const std::string &c : som_groups[g]) group_of[c] = g;
-    auto enter_group = [&](const std::string &chr, int phase) {
+    auto enter_group = [&](SomWorker &W, const std::string &chr, int phase) {
         if (!grouped) return;
+        GpuBam &tgb = *W.tgb, &ngb = *W.ngb;
         auto it = group_of.find(chr);
         if (it == group_of.end()) { tgb.range.erase(chr); ngb.range.erase(chr); return; }      // no tumor records
-        if (it->second == group_loaded) return;
+        if (it->second == W.group_loaded) return;
         const std::vector<std::string> &grp = som_groups[it->second];
-        tgb.load_group(L, ctx, grp);
+        tgb.load_group(L, W.ctx, grp);
         std::vector<std::string> ngrp; for (const std::string &c : grp) { const int t = ngb.tid_of(c); if (t >= 0 && ngb.voff[(size_t)t].second > ngb.voff[(size_t)t].first) ngrp.push_back(c); }
-        if (phase == 0 || !estimate) ngb.load_group(L, nctx, ngrp);        // (the calling phase behind an estimation phase reuses that phase's passes: it needs the tumor records only)
+        if (phase == 0 || !estimate) ngb.load_group(L, W.nctx, ngrp);      // (the calling phase behind an estimation phase reuses that phase's passes: it needs the tumor records only)
         else ngb.range.clear();
-        group_loaded = it->second;
-        // the next group's header walk (host only) beside this group's passes; at the last group of the estimation phase: the first group's again
-        const size_t nxt = it->second + 1 < som_groups.size() ? it->second + 1 : 0;
-        if (som_groups.size() > 1) tgb.walk_group_ahead(L, som_groups[nxt]);
+        W.group_loaded = it->second;
+        // one worker: the next group's header walk (host only) beside this group's passes; at the last group of the estimation phase the first group's again
+        if (n_workers_now == 1 && som_groups.size() > 1) tgb.walk_group_ahead(L, som_groups[it->second + 1 < som_groups.size() ? it->second + 1 : 0]);
         if (getenv("LPS_CLI_DEBUG")) fprintf(stderr, "[cli] somatic group %zu / %zu: %zu contig(s) from %s, %zu of them in the normal BAM\n", it->second + 1, som_groups.size(), grp.size(), grp.front().c_str(), ngrp.size());
     };
     // contigs dealt longest-first (tumor records) onto the workers; worker 0 is this thread's context, the others create theirs
     const int n_dev = std::max(1, L.device_count());
-    const int n_workers = std::max(1, std::min<int>(n_gpus, (int)chr_vec.size()));
+    const int n_workers = std::max(1, std::min<int>(n_gpus, grouped ? (int)std::max<size_t>(1, som_groups.size()) : (int)chr_vec.size()));
     std::vector<std::vector<size_t>> share((size_t)n_workers);
-    { std::vector<size_t> order(chr_vec.size()); for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    if (grouped && n_workers > 1) {
+        // whole GROUPS dealt longest-first (compressed bytes of the tumor BAM) onto the workers: a worker uploads and inflates only its own groups
+        std::vector<size_t> gorder(som_groups.size()), gbytes(som_groups.size(), 0), load((size_t)n_workers, 0);
+        for (size_t g = 0; g < som_groups.size(); ++g) { gorder[g] = g; for (const std::string &c : som_groups[g]) { const int t = tgb.tid_of(c); gbytes[g] += (size_t)((tgb.voff[(size_t)t].second >> 16) - (tgb.voff[(size_t)t].first >> 16)) + 1; } }
+        std::stable_sort(gorder.begin(), gorder.end(), [&](size_t a, size_t b) { return gbytes[a] > gbytes[b]; });
+        std::vector<int> worker_of_group(som_groups.size(), 0);
+        for (size_t g : gorder) { const size_t k = (size_t)(std::min_element(load.begin(), load.end()) - load.begin()); worker_of_group[g] = (int)k; load[k] += gbytes[g]; }
+        for (size_t i = 0; i < chr_vec.size(); ++i) { auto it = group_of.find(chr_vec[i]); share[it == group_of.end() ? 0 : (size_t)worker_of_group[it->second]].push_back(i); }
+    } else {
+      std::vector<size_t> order(chr_vec.size()); for (size_t i = 0; i < order.size(); ++i) order[i] = i;
       auto weight = [&](size_t i) -> size_t { if (resident) { auto a = tgb.range.find(chr_vec[i]); return a == tgb.range.end() ? 0 : (size_t)a->second.second; }
           auto it = tin.contigs.find(chr_vec[i]); return it == tin.contigs.end() ? 0 : it->second.rec_off.size(); };
       std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight(a) > weight(b); });
@@ -1519,19 +1544,27 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
       for (size_t i : order) { const size_t g = (size_t)(std::min_element(load.begin(), load.end()) - load.begin()); share[g].push_back(i); load[g] += weight(i) + 1; }
       for (auto &v : share) std::sort(v.begin(), v.end()); }
     n_workers_now = n_workers;
-    std::vector<lps_ctx *> wctx((size_t)n_workers, nullptr); wctx[0] = ctx;
+    std::vector<SomWorker> wk((size_t)n_workers); std::vector<std::unique_ptr<GpuBam>> wbams;
+    wk[0].ctx = ctx; wk[0].nctx = nctx; wk[0].tgb = &tgb; wk[0].ngb = &ngb;
     for (int g = 1; g < n_workers; ++g) { lps_params P; L.default_params(&P); for (auto &f : over) f(P);
-        wctx[(size_t)g] = L.create((gpu + g) % n_dev, &P); if (!wctx[(size_t)g]) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
-        L.set_stage_timing(wctx[(size_t)g], 0); }
+        SomWorker &W = wk[(size_t)g];
+        W.ctx = L.create((gpu + g) % n_dev, &P); if (!W.ctx) die("longphase_amd: cannot create a GPU context for worker " + std::to_string(g));
+        L.set_stage_timing(W.ctx, 0);
+        W.tgb = &tgb; W.ngb = &ngb;                                       // (host-record path: the files' records are in host memory, shared)
+        if (resident) {                                                   // grouped: its own second context and its own views of the two files
+            W.nctx = L.create((gpu + g) % n_dev, &P); if (!W.nctx) die("longphase_amd: cannot create the normal-BAM context of worker " + std::to_string(g));
+            L.set_stage_timing(W.nctx, 0);
+            wbams.emplace_back(new GpuBam()); wbams.back()->open_file(tbam, true); W.tgb = wbams.back().get();
+            wbams.emplace_back(new GpuBam()); wbams.back()->open_file(nbam, true); W.ngb = wbams.back().get(); } }
     for (int phase = estimate ? 0 : 1; phase < 2; ++phase) {
         if (phase == 1 && estimate) { auto tp = tick(); purity = estimate_purity(pdata, p_initial, lcvf, prefix); T = somatic_thresholds(purity); announce(); tock(ns_purity, tp); }
         std::vector<ContigAcc> acc(chr_vec.size()); std::mutex mu; std::condition_variable cv;
-        auto run_share = [&](int g) { for (size_t i : share[(size_t)g]) { do_contig(wctx[(size_t)g], chr_vec[i], phase,
+        auto run_share = [&](int g) { for (size_t i : share[(size_t)g]) { enter_group(wk[(size_t)g], chr_vec[i], phase); do_contig(wk[(size_t)g], chr_vec[i], phase,
                 acc[i], saved[i]); { std::lock_guard<std::mutex> lk(mu); acc[i].ready = true; } cv.notify_all(); } };
         std::vector<std::thread> workers;
         if (n_workers > 1) for (int g = 0; g < n_workers; ++g) workers.emplace_back(run_share, g);
         for (size_t i = 0; i < chr_vec.size(); ++i) {                    // merge (and write) in contig order
-            if (n_workers == 1) { enter_group(chr_vec[i], phase); do_contig(ctx, chr_vec[i], phase, acc[i], saved[i]); }
+            if (n_workers == 1) { enter_group(wk[0], chr_vec[i], phase); do_contig(wk[0], chr_vec[i], phase, acc[i], saved[i]); }
             else { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return acc[i].ready; }); }
             ContigAcc &A = acc[i];
             pdata.insert(pdata.end(), A.pdata.begin(), A.pdata.end()); p_initial += A.p_initial; for (int k = 0; k < 5; ++k) lcvf[k] += A.lcvf[k];
@@ -1544,7 +1577,8 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         }
         for (auto &x : workers) x.join();
     }
-    for (int g = 1; g < n_workers; ++g) L.destroy(wctx[(size_t)g]);
+    for (int g = 1; g < n_workers; ++g) { L.destroy(wk[(size_t)g].ctx); if (resident && wk[(size_t)g].nctx) L.destroy(wk[(size_t)g].nctx); }
+    if (grouped) for (int g = 1; g < n_workers; ++g) { tgb.t_inflate += wk[(size_t)g].tgb->t_inflate; tgb.t_scan += wk[(size_t)g].tgb->t_scan; ngb.t_inflate += wk[(size_t)g].ngb->t_inflate; ngb.t_scan += wk[(size_t)g].ngb->t_scan; }
     if (n_workers > 1) std::cerr << "\n" << n_workers << " workers (one GPU context each, contigs dealt by tumor record count)";
     std::cerr << "\n";
     { auto tf = tick(); w.finish(); tock(ns_finish, tf); }

@@ -114,11 +114,14 @@ def test_cli_somatic_gpus_equals_single_worker(tmp_path):
     # both BAMs indexed: the pair is walked in contig groups (one group of the tumor BAM + the same contigs of the normal BAM resident at a time, loaded
     # once per phase - the purity estimation walks all groups first), here one contig per group, all three in one group, and the indexes ignored
     util.write_bai(d + "/normal.bam"); util.write_bai(d + "/tumor.bam")
-    for tag, extra, n_groups in (("grp1", ["--gpu-inflate", "--group-bytes", "1"], 3), ("grp_all", ["--gpu-inflate"], 1), ("noidx", ["--gpu-inflate", "--no-index"], 0)):
+    # ... and the three groups dealt onto three workers (`--gpus 3`: each with two contexts and its own view of the two files, all on the one GPU of the box)
+    for tag, extra, n_groups in (("grp1", ["--gpu-inflate", "--group-bytes", "1"], 3), ("grp_all", ["--gpu-inflate"], 1), ("noidx", ["--gpu-inflate", "--no-index"], 0),
+                                 ("grp1_3w", ["--gpu-inflate", "--group-bytes", "1", "--gpus", "3"], 3)):
         r = subprocess.run([CLI, "somatic_haplotag", "-s", "normal_phased.vcf", "-b", "normal.bam", "--tumor-snv-file", "tumor.vcf", "--tumor-bam-file", "tumor.bam", "-r", "ref.fa",
                             "-t", "4", "-o", tag, "--somatic-calling-log", "--output-somatic-vcf", "--tagSupplementary"] + extra, cwd=d, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert (f"contig groups: {n_groups} " in r.stderr) == (n_groups > 0), r.stderr[-600:]
+        assert ("3 workers" in r.stderr) == (tag == "grp1_3w")
         text, refs, recs = util.bam_sections(os.path.join(d, tag + ".bam"))
         sc = [l for l in open(os.path.join(d, tag + "_sc.vcf")).read().split("\n") if not l.startswith("##commandline=")]
         got = (hashlib.sha256(recs).hexdigest(), len(recs), open(os.path.join(d, tag + "_somatic_filter.log")).read(), open(os.path.join(d, tag + "_purity.out")).read(), sc,
