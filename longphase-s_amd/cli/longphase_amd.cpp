@@ -905,7 +905,7 @@ static const char *kSomUsage =
 static int somatic_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
     std::string snp, ref, nbam, tvcf, tbam, prefix = "result";
-    int threads = 1, gpu = 0, n_gpus = 1; uint64_t group_bytes = 8ull << 30; bool no_index = false;
+    int threads = 1, gpu = 0, n_gpus = 1; uint64_t group_bytes = 24ull << 30; bool no_index = false;   // (a pair whose compressed bytes fit one group is loaded once; ~4x that inflated, of 288 GB)
     double purity = -1, pct = 0.6;
     bool enable_filter = true, write_log = false, write_sc_vcf = false; bool host_deflate = false, raw_started = false, host_inflate = false, gpu_inflate = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kSomUsage; exit(1); } return argv[++i]; };
