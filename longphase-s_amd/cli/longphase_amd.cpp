@@ -900,7 +900,10 @@ static const char *kSomUsage =
     "   --host-deflate   zlib (level 6, RLE) on the -t threads for the tagged BAM instead of the GPU's BGZF writer\n"
     "   --host-inflate   zlib on the -t threads for both BAMs instead of the GPU's BGZF inflate (the default for files below 256 MiB); --gpu-inflate forces the GPU\n"
     "   --gpus=N (deal the contigs onto N GPU contexts, devices --gpu, --gpu+1, ...: the three BAM passes of a contig run on its worker, purity is estimated\n"
-    "             over all contigs, logs and the tagged BAM are merged in contig order)\n";
+    "             over all contigs, logs and the tagged BAM are merged in contig order; with both BAMs indexed: contig GROUPS onto the workers)\n"
+    "   --group-bytes=N  both BAMs indexed (.bai): the pair is walked in groups of consecutive contigs of up to N compressed bytes, tumor + normal together\n"
+    "                    (24 GiB) - only one group's inflated records are on the GPU at a time, as the reference walks the pair chromosome by chromosome;\n"
+    "                    --no-index: ignore the indexes and keep both whole files on the GPU\n";
 
 static int somatic_main(int argc, char **argv, const std::string &command) {
     std::vector<std::function<void(lps_params &)>> over;
