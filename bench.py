@@ -46,7 +46,6 @@ GRCH38 = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4"
           ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189), ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285),
           ("chr19", 58617616), ("chr20", 64444167), ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
 WGS_SNPS = 4_000_000
-HAP_FIELDS = ("status", "hp1", "hp2", "n_ps", "ps_min", "hp", "pq", "ps")
 
 
 def wgs_contigs(seed, coverage=50.0):
@@ -722,8 +721,6 @@ def main():
             VT = abi.Variants.from_snps(V.pos[idx], V.ref0[idx], V.alt0[idx], hp1_is_alt=out.gt[idx], phase_set=out.phase_set[idx])
             s["ctx"].set_table(VT, s["ref"]); s["VT"] = VT
             s["hout"] = abi.HaplotagOut(s["g"].n_reads)
-            # the tags land in page-locked host memory: the library then fills the eight arrays by copies at the link's rate instead of unpacking on host threads
-            s["hout_pinned"] = all(pin(getattr(s["hout"], k)) for k in HAP_FIELDS)
         concurrent([(lambda s=s: s["ctx"].run_haplotag(s["hout"])) for s in slots])
 
         def k_tags(s):
@@ -732,8 +729,6 @@ def main():
             hdt = concurrent([(lambda s=s: k_tags(s)) for s in slots])
         hap_elapsed += hdt
         for s in slots:
-            for k in HAP_FIELDS:
-                unpin(getattr(s["hout"], k))
             s["rec"].update(group_haplotag_ms_per_step=hdt / a.steps * 1e3, haplotag_kernel_ms=s["ctx"].timings()["stages"]["extract"], tagged=int((s["hout"].hp != 0).sum()))
             total_tagged += s["rec"]["tagged"]
             if s["host"] is not None and s["spec"]["name"] in parity_set:      # oracle on host threads, outside every timed region: phase result + tags
@@ -838,8 +833,7 @@ def main():
                          "algorithmic_bytes": int(alg.get(dom, 0)), "kernel_ms": stage_avg[dom], "solo_call_ms": rec.get("solo_ms_per_step"),
                          "note": "dominant stage by time at the largest contig, measured with that contig ALONE on the GPU: durations from hipEvents on the library's stream (extract: the two events around the kernel, live; the others: pass with every stage event recorded)"},
             "secondary": {"metric": "reads haplotagged/sec", "value": total_reads * a.steps / hap_elapsed, "unit": "reads/s", "ms_per_step": hap_elapsed / a.steps * 1e3,
-                          "reads_tagged_per_step": int(total_tagged), "config": "germline haplotag, same resident 50x alignments (BASELINE.json configs[2]), table = this run's phased SNPs; "
-                                                                                          "tags (hp, pq, ps + the votes) into page-locked host arrays"},
+                          "reads_tagged_per_step": int(total_tagged), "config": "germline haplotag, same resident 50x alignments (BASELINE.json configs[2]), table = this run's phased SNPs"},
             "p_clock": p_clock,
             "parity": parity,
             "stages_at_largest_contig": stages,

@@ -1466,24 +1466,6 @@ static const PqSmall &pq_small_table() {
     return tab;
 }
 
-
-// The packed per-read records of the germline pass into the caller's eight arrays, on the GPU: when those arrays are page-locked host memory
-// (lps_host_alloc, hipHostRegister) they are then filled by eight copies at the link's rate instead of by host threads unpacking 16-byte records
-// (1.2 of the 2.1 ms of a chr1-50x call).  pq 255 (votes of 64 and more: the host's libm) is patched by the host afterwards.
-__global__ void k_hap_unpack(const uint4 *rec, int n, uint8_t *status, int32_t *hp1, int32_t *hp2, uint8_t *n_ps, int32_t *ps_min, uint8_t *hp, int32_t *pq, int32_t *ps) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const uint4 w = rec[r];
-    const unsigned h = (w.x >> 16) & 0xffu, nps = (w.x >> 8) & 0xffu;
-    status[r] = (uint8_t)(w.x & 0xffu); hp1[r] = (int32_t)w.y; hp2[r] = (int32_t)w.z; n_ps[r] = (uint8_t)nps; ps_min[r] = (int32_t)w.w;
-    hp[r] = (uint8_t)h; pq[r] = (int32_t)(w.x >> 24); ps[r] = (h && nps) ? (int32_t)w.w : 0;
-}
-static bool is_pinned_host(const void *p) {
-    hipPointerAttribute_t a{};
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
-}
-
 // K consecutive calls behind ONE entry (bench.py's timed region: a caller written in Python re-enters the interpreter between calls, and with several
 // contexts driven from several threads a step then waits for the interpreter lock, not for the GPU).  ms_each (may be NULL): wall time of every call.
 int lps_phase_chromosome_steps(lps_ctx *c, lps_phase_result *out, int k, double *ms_each) {
@@ -1534,27 +1516,9 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
         launch_read_v0(V, R, c->r_v0.p, s);
         HapOut H{};
         H.pct_thr = c->P.percentage_threshold; H.rec = c->hap_rec.p; H.pq_tab = c->pq_tab.p; H.votes1 = votes ? c->d_votes1.p : nullptr; H.votes2 = votes ? c->d_votes2.p : nullptr;
-        // results straight into the caller's arrays when all eight are page-locked host memory (see k_hap_unpack)
-        const bool direct = nR >= 4096 && is_pinned_host(out->status) && is_pinned_host(out->hp1) && is_pinned_host(out->hp2) && is_pinned_host(out->n_ps) &&
-                            is_pinned_host(out->ps_min) && is_pinned_host(out->hp) && is_pinned_host(out->pq) && is_pinned_host(out->ps);
-        uint8_t *d_status = nullptr, *d_nps = nullptr, *d_hp = nullptr; int32_t *d_h1 = nullptr, *d_h2 = nullptr, *d_psmin = nullptr, *d_pq = nullptr, *d_ps = nullptr;
-        if (direct) {                                                       // the eight arrays side by side in the per-read output pool
-            size_t hb = 0; auto slot = [&](size_t bytes) { const size_t at = hb; hb += (bytes + 255) & ~(size_t)255; return at; };
-            const size_t o0 = slot(nR), o1 = slot((size_t)nR * 4), o2 = slot((size_t)nR * 4), o3 = slot(nR), o4 = slot((size_t)nR * 4), o5 = slot(nR), o6 = slot((size_t)nR * 4), o7 = slot((size_t)nR * 4);
-            c->hap_pool.reserve(hb);
-            uint8_t *q = c->hap_pool.p;
-            d_status = q + o0; d_h1 = (int32_t *)(q + o1); d_h2 = (int32_t *)(q + o2); d_nps = q + o3; d_psmin = (int32_t *)(q + o4); d_hp = q + o5; d_pq = (int32_t *)(q + o6); d_ps = (int32_t *)(q + o7);
-        }
         for (int attempt = 0; attempt < 2; ++attempt) {
             launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 0, c->d_cnt, s, /*general=*/attempt == 1);
             if (attempt == 0) mark(c, ST_D2H);
-            if (direct) {
-                hipLaunchKernelGGL(k_hap_unpack, dim3((unsigned)((nR + 255) / 256)), dim3(256), 0, s, c->hap_rec.p, nR, d_status, d_h1, d_h2, d_nps, d_psmin, d_hp, d_pq, d_ps);
-                HIP_TRY(hipMemcpyAsync(out->status, d_status, (size_t)nR, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->hp1, d_h1, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipMemcpyAsync(out->hp2, d_h2, (size_t)nR * 4, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->n_ps, d_nps, (size_t)nR, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipMemcpyAsync(out->ps_min, d_psmin, (size_t)nR * 4, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->hp, d_hp, (size_t)nR, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipMemcpyAsync(out->pq, d_pq, (size_t)nR * 4, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(out->ps, d_ps, (size_t)nR * 4, hipMemcpyDeviceToHost, s));
-            } else
             HIP_TRY(hipMemcpyAsync(c->h_res, c->hap_rec.p, span, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(c->h_cnt_pin, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipEventRecord(c->ev_end, s));
@@ -1581,13 +1545,7 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
             return n_tagged;
         };
         int64_t tagged = 0;
-        if (direct) {                                                       // the arrays are in place: the host's libm for the few reads with 64 votes and more, the tag count
-            for (int r = 0; r < nR; ++r) {
-                if (out->pq[r] == 255) { const int a = out->hp1[r], b = out->hp2[r]; const double mn = a < b ? a : b, mx = a < b ? b : a; out->pq[r] = -10 * (std::log10(mn / double(mx + mn))); }
-                tagged += out->hp[r] != 0;
-            }
-        }
-        else if (nR < 200000) tagged = unpack(0, nR);
+        if (nR < 200000) tagged = unpack(0, nR);
         else {                                                            // a whole 50x chromosome: a few host threads share the copy-out
             const int nt = 4; std::thread th[nt]; int64_t part[nt] = {0, 0, 0, 0};
             for (int t = 0; t < nt; ++t) th[t] = std::thread([&, t] { part[t] = unpack((int)((int64_t)nR * t / nt), (int)((int64_t)nR * (t + 1) / nt)); });

@@ -90,37 +90,3 @@ def test_haplotag_empty_table_and_filters():
     P = abi.default_params()
     ref = lps_oracle.haplotag(P, empty, s.ref, R)
     assert set(np.unique(ref.status)) <= {1, 3, 4, 5}
-
-
-def test_haplotag_results_into_page_locked_arrays():
-    """When the caller's eight result arrays are page-locked host memory the library unpacks the per-read records on the GPU and fills the arrays by
-    copies (no host threads): same numbers as the pageable path, incl. the PQ of reads with 64 votes and more (the host's libm) - long reads over a
-    dense table so that such reads exist."""
-    import ctypes as C
-    from lps.synth import Synth
-    s = Synth(seed=77, contig_len=3_000_000, n_snp=30_000, coverage=40.0, n_threads=4)
-    V0 = abi.Variants(s.var_pos, s.var_ref, s.var_alt); R = abi.Reads.from_synth(s)
-    assert R.n_reads >= 4096
-    P = abi.default_params()
-    hiprt = C.CDLL("libamdhip64.so")
-    hiprt.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]; hiprt.hipHostUnregister.argtypes = [C.c_void_p]
-    fields = ("status", "hp1", "hp2", "n_ps", "ps_min", "hp", "pq", "ps")
-    with hip.Context(0, P) as ctx:
-        ph = ctx.phase(V0, s.ref, R)
-        keep = np.nonzero(ph.phase_set != 0)[0]
-        VT = abi.Variants.from_snps(V0.pos[keep], V0.ref0[keep], V0.alt0[keep], hp1_is_alt=ph.gt[keep], phase_set=ph.phase_set[keep])
-        ctx.set_table(VT, s.ref)
-        plain = ctx.run_haplotag()
-        pinned = abi.HaplotagOut(R.n_reads)
-        for k in fields:
-            a = getattr(pinned, k); assert hiprt.hipHostRegister(a.ctypes.data, a.nbytes, 0) == 0
-        try:
-            ctx.run_haplotag(pinned)
-            for k in fields:
-                assert np.array_equal(getattr(pinned, k), getattr(plain, k)), k
-        finally:
-            for k in fields:
-                hiprt.hipHostUnregister(getattr(pinned, k).ctypes.data)
-    want = lps_oracle.haplotag(P, VT, s.ref, R)
-    assert np.array_equal(plain.hp, want.hp) and np.array_equal(plain.pq, want.pq) and np.array_equal(plain.ps, want.ps)
-    assert ((plain.hp1 + plain.hp2) >= 64).sum() > 10 and (plain.hp != 0).sum() > 3000
