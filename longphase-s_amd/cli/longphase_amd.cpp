@@ -28,7 +28,7 @@ static const char *kUsage =
     "   --sv-file=NAME  --mod-file=NAME   co-phase structural variants / modcall records (outputs <prefix>_SV.vcf, <prefix>_mod.vcf)   -w svWindow(20)  -h svThreshold(0.1)\n"
     "   --host-inflate | --gpu-inflate   BGZF inflate with zlib on the -t host threads / on the GPU (default: GPU for one BAM of 256 MiB or more)\n"
     "   --no-index       ignore <bam>.bai: make the whole file resident on the GPU instead of one contig at a time\n"
-    "   --group-bytes=N  indexed input: consecutive contigs are uploaded and inflated together up to N compressed bytes (8 GiB)\n"
+    "   --group-bytes=N  indexed input: consecutive contigs are uploaded and inflated together up to N compressed bytes (phase: 16 GiB, haplotag: 8 GiB)\n"
     "   --workers-per-gpu=N  indexed input: contig groups in flight per GPU, each with its own context and stream (1)\n"
     "   --gpus=N         deal the contigs onto N GPUs (devices --gpu, --gpu+1, ... modulo the number present); needs the .bai index\n";
 
@@ -43,7 +43,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::string snp, ref, prefix = "result", sv_file, mod_file;
     std::vector<std::string> bams;
     int threads = 1, gpu = 0, n_gpus = 1, sv_window = 20, indel_quality = 0; double sv_threshold = 0.1;
-    uint64_t group_bytes = 8ull << 30; int workers_per_gpu = 1;        // indexed BAM: contigs are taken in groups of about this many compressed bytes, by this many concurrent workers per GPU
+    uint64_t group_bytes = 16ull << 30; int workers_per_gpu = 1;       // indexed BAM: contigs are taken in groups of about this many compressed bytes (16 GiB inflate to 50 - 60 GB of the 288; the 12.4 GB sample of bench.py as ONE group: 1.23 s against 1.53 s in two), by this many concurrent workers per GPU
     bool ont = false, pb = false, host_inflate = false, gpu_inflate = false, no_index = false, deepsomatic = false, dot = false;
     auto need = [&](int &i) -> std::string { if (i + 1 >= argc) { std::cerr << kUsage; exit(1); } return argv[++i]; };
     for (int i = 2; i < argc; ++i) {

@@ -10,6 +10,10 @@
 // and a call, or from one call to the next.
 #include <algorithm>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <chrono>
 #include <cmath>
 #include <climits>
@@ -28,6 +32,20 @@ static const char *kStageNames[LPS_MAX_STAGES] = {
     "edges", "vote_scan", "read_correction", "d2h", nullptr};
 // recorded in this order on the stream
 enum { ST_PREP, ST_EXTRACT, ST_GROUPS, ST_OVERLAP, ST_CLIP, ST_CNV, ST_NODES, ST_EDGES, ST_SCAN, ST_CORR, ST_D2H, ST_COUNT };
+
+// A few persistent host threads that fill the page-locked pieces of a large upload (h2d_staged): created once per context, woken per piece - a piece
+// of 64 MiB lasts 1.3 ms on the link, so the readers must deliver 50 GB/s and must not be created and joined per piece (round 3: four threads per
+// piece, 22 GB/s - as long as the inflate beside it).
+struct ReaderPool {
+    std::vector<std::thread> th; std::mutex m; std::condition_variable cv_go, cv_done;
+    std::function<void(int)> job; unsigned long long gen = 0; int pending = 0; bool stop = false;
+    explicit ReaderPool(int n) { for (int t = 0; t < n; ++t) th.emplace_back([this, t] { unsigned long long seen = 0;
+        for (;;) { std::unique_lock<std::mutex> lk(m); cv_go.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; auto f = job; lk.unlock();
+                   f(t); lk.lock(); if (--pending == 0) cv_done.notify_all(); } }); }
+    void run(const std::function<void(int)> &f) { std::unique_lock<std::mutex> lk(m); job = f; pending = (int)th.size(); ++gen; cv_go.notify_all(); cv_done.wait(lk, [&] { return pending == 0; }); }
+    int size() const { return (int)th.size(); }
+    ~ReaderPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv_go.notify_all(); for (auto &t : th) t.join(); }
+};
 
 struct lps_ctx {
     int device = 0;
@@ -62,7 +80,7 @@ struct lps_ctx {
     // whole BAM file resident on the device (lps_bgzf_load): compressed bytes, block table, inflated stream; survives lps_begin_chromosome
     DevBuf<uint8_t> zfile, file, zscratch; DevBuf<InflateBlock> zblk; uint64_t file_bytes = 0; float bgzf_h2d_ms = 0, bgzf_inflate_ms = 0; bool bgzf_retried = false;
     DevBuf<unsigned long long> tg_len, tg_off; DevBuf<uint2> tg_spans; DevBuf<uint8_t> tg_stream, tg_status, tg_hp; DevBuf<int32_t> tg_ps, tg_pq; int64_t cur_first = -1, cur_count = 0;
-    uint8_t *stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; size_t stage_bytes = 0;   // pinned staging ring for large pageable uploads
+    uint8_t *stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; size_t stage_bytes = 0; std::unique_ptr<ReaderPool> readers;   // pinned staging ring for large pageable uploads
     unsigned long long *up_mark = nullptr;   // upload watermark of lps_bgzf_load: a page-locked host word the inflate kernel polls
     DevBuf<uint8_t> dz_slots, dz_packed, dz_src; DevBuf<uint32_t> dz_bytes; DevBuf<unsigned long long> dz_tmp; DevBuf<uint64_t> dz_off; uint64_t dz_total = 0; float dz_ms = 0;
     DevBuf<uint64_t> rcand; uint64_t n_rec_all = 0; DevBuf<int32_t> r_tid_all; DevBuf<uint32_t> r_lname, r_nameoff, wg_cnt, wg_off, scan_nout; DevBuf<uint8_t> names_d; bool names_ready = false;
@@ -152,11 +170,10 @@ static void h2d_staged(lps_ctx *c, uint8_t *dst, const ZSource &src, size_t n, h
         const size_t len = std::min(CH, n - off);
         if (used[k]) { HIP_TRY(hipEventSynchronize(c->stage_ev[k])); raise(end_of[k]); }       // (pieces complete in order: everything before end_of[k] is in place)
         if (mark) { const char *thr = getenv("LPS_BGZF_TEST_THROTTLE_MS"); if (thr) usleep((useconds_t)(atof(thr) * 1000.0)); }   // test hook: a slow source (network storage, a cold page cache)
-        const int nt = 4; std::thread th[nt]; const size_t part = (len + nt - 1) / nt; bool ok[nt];
-        for (int t = 0; t < nt; ++t) th[t] = std::thread([&, t] { const size_t a = std::min(len, part * t), b = std::min(len, a + part); ok[t] = b <= a ||
-                src.read(off + a, b - a, c->stage[k] + a); });
-        for (int t = 0; t < nt; ++t) th[t].join();
-        for (int t = 0; t < nt; ++t) if (!ok[t]) throw std::string("cannot read the file");
+        if (!c->readers) { const char *e = getenv("LPS_UPLOAD_THREADS"); c->readers.reset(new ReaderPool(std::max(1, std::min(64, e ? atoi(e) : 12)))); }
+        const int nt = c->readers->size(); const size_t part = ((len + nt - 1) / nt + 4095) & ~(size_t)4095; std::vector<char> ok((size_t)nt, 1);
+        c->readers->run([&](int t) { const size_t a = std::min(len, part * (size_t)t), b = std::min(len, a + part); ok[(size_t)t] = b <= a || src.read(off + a, b - a, c->stage[k] + a); });
+        for (int t = 0; t < nt; ++t) if (!ok[(size_t)t]) throw std::string("cannot read the file");
         HIP_TRY(hipMemcpyAsync(dst + off, c->stage[k], len, hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(c->stage_ev[k], st)); used[k] = true; end_of[k] = off + len;
     }
@@ -1547,9 +1564,11 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
         int64_t tagged = 0;
         if (nR < 200000) tagged = unpack(0, nR);
         else {                                                            // a whole 50x chromosome: a few host threads share the copy-out
-            const int nt = 4; std::thread th[nt]; int64_t part[nt] = {0, 0, 0, 0};
-            for (int t = 0; t < nt; ++t) th[t] = std::thread([&, t] { part[t] = unpack((int)((int64_t)nR * t / nt), (int)((int64_t)nR * (t + 1) / nt)); });
-            for (int t = 0; t < nt; ++t) { th[t].join(); tagged += part[t]; }
+            const int NT = 8, nt = nR >= 400000 ? NT : 4; std::thread th[NT]; int64_t part[NT] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t = 1; t < nt; ++t) th[t] = std::thread([&, t] { part[t] = unpack((int)((int64_t)nR * t / nt), (int)((int64_t)nR * (t + 1) / nt)); });
+            part[0] = unpack(0, (int)((int64_t)nR / nt));                 // (the calling thread takes a share instead of waiting)
+            tagged += part[0];
+            for (int t = 1; t < nt; ++t) { th[t].join(); tagged += part[t]; }
         }
         lps_timings &t = c->tm; memset(&t, 0, sizeof t);
         t.n_stages = ST_COUNT;
