@@ -293,7 +293,7 @@ def whole_node_baseline(dev, P, threads, seed, n_contigs=16, contig_mb=10):
             try:
                 gcmd = [cli, "phase", "-s", "in.vcf", "-b", "reads.bam", "-r", "ref.fa", "-t", str(threads), "-o", "outg", "--ont", "--gpu", str(dev)]
                 es = []
-                for _ in range(4):      # (a second each; the first runs behind the reference's 16 threads and the BAM's write-back are often the slowest)
+                for _ in range(6):      # (a second each; on some boxes every other run behind the reference's threads and the BAM's write-back takes twice as long: best of six)
                     t0 = time.time(); r = subprocess.run(gcmd, cwd=d, capture_output=True); es.append(time.time() - t0)
                     assert r.returncode == 0, r.stderr[-500:]
                 body = lambda p: [ln for ln in open(p) if not ln.startswith("##commandline=") and not ln.startswith("##longphaseVersion=")]  # noqa: E731

@@ -86,6 +86,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
         else if (a == "--gpu") gpu = std::stoi(val());
         else if (a == "--gpus") n_gpus = std::max(1, std::stoi(val()));
         else if (a == "--group-bytes") group_bytes = (uint64_t)std::stoull(val());
+        else if (a == "--upload-threads") setenv("LPS_UPLOAD_THREADS", val().c_str(), 1);      // host threads that fill the upload's page-locked pieces (library default 12)
         else if (a == "--workers-per-gpu") workers_per_gpu = std::max(1, std::stoi(val()));
         else if (a == "--host-inflate") host_inflate = true;
         else if (a == "--gpu-inflate") gpu_inflate = true;
@@ -457,6 +458,7 @@ static int haplotag_main(int argc, char **argv, const std::string &command) {
         else if (a == "--no-index") no_index = true;
         else if (a == "--host-deflate") host_deflate = true;
         else if (a == "--group-bytes") group_bytes = (uint64_t)std::stoull(val());
+        else if (a == "--upload-threads") setenv("LPS_UPLOAD_THREADS", val().c_str(), 1);      // host threads that fill the upload's page-locked pieces (library default 12)
         else if (a == "--compress-level") level = std::stoi(val());
         else if (a == "--compress-strategy") { const std::string x = val();
             strategy = x == "default" ? Z_DEFAULT_STRATEGY : x == "rle" ? Z_RLE : x == "huffman" ? Z_HUFFMAN_ONLY : -1;
@@ -941,6 +943,7 @@ static int somatic_main(int argc, char **argv, const std::string &command) {
         else if (a == "--host-inflate") host_inflate = true;
         else if (a == "--gpu-inflate") gpu_inflate = true;
         else if (a == "--group-bytes") group_bytes = (uint64_t)std::stoull(val());
+        else if (a == "--upload-threads") setenv("LPS_UPLOAD_THREADS", val().c_str(), 1);      // host threads that fill the upload's page-locked pieces (library default 12)
         else if (a == "--no-index") no_index = true;
         else if (a == "--help") { std::cout << kSomUsage; return 0; }
         else if (a == "--cram" || a == "--region" || a == "--log" || a == "--truth-vcf" || a == "--truth-bed" || a == "--benchmark-log") die("longphase_amd: " + a + " is not supported by the GPU path; use the reference binary");
