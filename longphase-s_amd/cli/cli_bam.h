@@ -222,7 +222,9 @@ struct GpuBam {
     void drop_walk(Lps &L) { if (ahead.th.joinable()) ahead.th.join(); if (ahead.blocks) L.bgzf_blocks_free(ahead.blocks); ahead.blocks = nullptr; ahead.pending = false; }
     // bytes [beg, beg + len) of the file onto the GPU, with the table walked ahead when it is the one for these bytes
     void load_span(Lps &L, lps_ctx *ctx, uint64_t beg, uint64_t len) {
+        const double tj = now();
         if (ahead.pending && ahead.th.joinable()) ahead.th.join();
+        if (getenv("LPS_CLI_DEBUG")) fprintf(stderr, "[cli] waited %.3f s for the header walk made ahead\n", now() - tj);
         const bool have = ahead.pending && ahead.rc == 0 && ahead.beg == beg && ahead.len == len;
         const int rc = have ? L.bgzf_load_fd_blocks(ctx, fd, (int64_t)beg, (int64_t)len, ahead.blocks, ahead.n, &total) : L.bgzf_load_fd(ctx, fd, (int64_t)beg, (int64_t)len, &total);
         drop_walk(L);

@@ -755,7 +755,9 @@ static bool bgzf_walk_piece(const ZSource &z, uint64_t n, uint64_t from, uint64_
 // starts at the first position behind k * n / T where FOUR block headers follow one another; the piece before it must end exactly there, otherwise
 // (and whenever anything else looks wrong) the caller walks the file serially.
 static bool bgzf_walk_parallel(const ZSource &z, uint64_t n, std::vector<InflateBlock> &blks, uint64_t &utot) {
-    const int T = 8;
+    // pieces walked side by side: the walk is one small read per 20 - 30 KB block - latency, not bytes - and it runs beside the GPU start-up, which it
+    // must not outlast (8 pieces took 0.2 s for 12 GB: longer than the rest of the start-up)
+    const int T = (int)std::max(8u, std::min(32u, std::thread::hardware_concurrency() / 2u));
     if (n < (64ull << 20)) return false;
     std::vector<uint64_t> seed((size_t)T + 1, 0); seed[(size_t)T] = n;
     std::vector<uint8_t> win((1u << 20) + 64);
