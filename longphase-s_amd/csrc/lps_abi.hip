@@ -1597,8 +1597,9 @@ int lps_somatic_tag_chromosome(lps_ctx *c, lps_somatic_tag_result *out) {
         if (rc) return rc;
         // judgeSomaticReadHap (HaplotagStrategy.cpp:452-602) + inheritHaplotype (SomaticHaplotagProcess.cpp:461-527) + PS rule (:416-434)
         const double thr = c->P.percentage_threshold;
+        auto judge = [&](int r_lo, int r_hi) -> int64_t {
         int64_t tagged = 0;
-        for (int r = 0; r < nR; ++r) {
+        for (int r = r_lo; r < r_hi; ++r) {
             int hp = 0, pq = 0, ps = -1;
             if (out->status[r] == 0) {
                 const int h1 = out->hp1[r], h2 = out->hp2[r], h3 = out->hp3[r], h4 = 0;
@@ -1628,6 +1629,15 @@ int lps_somatic_tag_chromosome(lps_ctx *c, lps_somatic_tag_result *out) {
             }
             out->hp[r] = (uint8_t)hp; out->pq[r] = pq; out->ps[r] = ps;
             tagged += hp != 0;
+        }
+        return tagged; };
+        int64_t tagged = 0;
+        if (nR < 200000) tagged = judge(0, nR);
+        else {                                                            // a whole 50x chromosome: the reads are independent, a few host threads share them
+            const int nt = 8; std::thread th[nt]; int64_t part[nt] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t = 1; t < nt; ++t) th[t] = std::thread([&, t] { part[t] = judge((int)((int64_t)nR * t / nt), (int)((int64_t)nR * (t + 1) / nt)); });
+            tagged = judge(0, (int)((int64_t)nR / nt));
+            for (int t = 1; t < nt; ++t) { th[t].join(); tagged += part[t]; }
         }
         c->tm.n_reads_used = tagged;
     } catch (std::string &e) { return fail(c, e); }
