@@ -1297,6 +1297,7 @@ static int run_phase(lps_ctx *c) {
             c->h_cnv_start.clear(); c->h_cnv_end.clear();
             return run_late(c, false);
         }
+        { const size_t need_k = GraphTemp::need((size_t)c->h_cnt.n_clips + 1); if (need_k > c->temp_bytes) { c->temp.reserve(need_k, s); c->temp_bytes = need_k; } }   // (more clip events than alignments: every read clipped at both ends)
         launch_clip_sort(c->h_cnt.n_clips, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, s);
         c->clips_sorted = true;
         if (nk > c->h_clip_cap) { if (c->h_clip_keys) HIP_TRY(hipHostFree(c->h_clip_keys)); c->h_clip_keys = nullptr; c->h_clip_cap = nk + nk / 2 + 1024; HIP_TRY(hipHostMalloc((void **)&c->h_clip_keys, c->h_clip_cap * sizeof(unsigned long long))); }
@@ -1841,7 +1842,8 @@ int64_t lps_dump_clips(lps_ctx *c, int32_t *pos, uint8_t *front_back, int64_t ca
     try {
         HIP_TRY(hipSetDevice(c->device));
         const size_t n = c->h_cnt.n_clips;
-        if (!c->clips_sorted && n) { launch_clip_sort((unsigned)n, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, c->stream); c->clips_sorted = true; }   // (the run itself had no use for the order)
+        if (!c->clips_sorted && n) { const size_t need_k = GraphTemp::need(n + 1); if (need_k > c->temp_bytes) { c->temp.reserve(need_k, c->stream); c->temp_bytes = need_k; }
+            launch_clip_sort((unsigned)n, c->clip_keys.p, c->clip_keys_s.p, c->temp.p, c->temp_bytes, c->stream); c->clips_sorted = true; }   // (the run itself had no use for the order)
         auto k = download(c, c->clip_keys_s.p, n);
         int64_t m = 0;
         for (size_t i = 0; i < n; ++i) { if (k[i] == ~0ull) break; if (pos && m < capacity) { pos[m] = (int32_t)(k[i] >> 1); front_back[m] = (uint8_t)(k[i] & 1); } ++m; }
