@@ -1219,7 +1219,7 @@ static int run_phase(lps_ctx *c) {
         c->r_v0.reserve((size_t)nR + 1);
         VarView V = var_view(c); ReadView R = read_view(c);
         mark(c, ST_PREP);
-        launch_variant_prep(V, P.is_ont, c->v_bucket.p, c->v_rec.p, s);
+        launch_variant_prep(V, P.is_ont, c->v_bucket.p, c->v_rec.p, s, R.ref_start, R.n, c->r_v0.p);
         if (!dense) {
             c->name_keys.reserve(nR + 1); c->name_keys_s.reserve(nR + 1); c->head.reserve(nR + 1); c->gidx.reserve(nR + 1); c->name_dense.reserve(nR + 1);
             launch_dense_names(nR, c->r_name.p, c->name_max, c->name_keys.p, c->name_keys_s.p, c->head.p, c->gidx.p, c->name_dense.p, c->temp.p, c->temp_bytes, s);
@@ -1229,7 +1229,6 @@ static int run_phase(lps_ctx *c) {
         ObsView O{c->rows.p, c->obs.p, arena_size, c->arena_ctr.p, n_arenas, c->nX ? c->x_snp_u.p : nullptr};
         ClipView C{c->clip_ev.p, c->clip_stats.p, (unsigned)c->clip_capacity, (unsigned)(EXT_CLIPS * ((nR + 3) / 4))};            // clip_stats[0]: events appended by the general walker, [1]: jobs queued for it (zero pool)
         mark(c, ST_EXTRACT);
-        launch_read_v0(V, R, c->r_v0.p, s);
         launch_extract_phase(V, R, O, C, P.mapping_quality, c->d_cnt, c->redo_list.p, c->clip_stats.p + 1, c->nX ? nullptr : c->var_cnt.p, c->var_del.p, s);
         {   // diagnostic (profiles/extract_only.py: timing experiments on builds whose extraction is incomplete on purpose): stop here, rc 77
             static const bool extract_only = getenv("LPS_EXTRACT_ONLY") != nullptr;
@@ -1432,9 +1431,8 @@ static int run_scorer(lps_ctx *c, bool somatic, uint8_t *status, int32_t *hp1, i
     VarView V = var_view(c); ReadView R = read_view(c);
     for (auto &u : c->ev_used) u = false;
     mark(c, ST_PREP);
-    launch_variant_prep(V, /*is_ont (filterSNP is a `phase` step)*/ 0, c->v_bucket.p, c->v_rec.p, s);
+    launch_variant_prep(V, /*is_ont (filterSNP is a `phase` step)*/ 0, c->v_bucket.p, c->v_rec.p, s, R.ref_start, somatic ? R.n : 0, somatic ? c->r_v0.p : nullptr);   // (the stream walk starts every alignment at its first candidate row)
     mark(c, ST_EXTRACT);
-    if (somatic) launch_read_v0(V, R, c->r_v0.p, s);                     // (the stream walk starts every alignment at its first candidate row)
     HapOut H{c->hap_status.p, c->hap_h1.p, c->hap_h2.p, c->hap_nps.p, c->hap_psmin.p, c->hap_h3.p, c->hap_d1.p, c->hap_d2.p, nullptr, nullptr, 0.0};
     for (int attempt = 0; attempt < 2; ++attempt) {
         launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, somatic ? 1 : 0, c->d_cnt, s, /*general=*/attempt == 1);
@@ -1531,9 +1529,8 @@ int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
         VarView V = var_view(c); ReadView R = read_view(c);
         for (auto &u : c->ev_used) u = false;
         mark(c, ST_PREP);
-        launch_variant_prep(V, /*is_ont (filterSNP is a `phase` step)*/ 0, c->v_bucket.p, c->v_rec.p, s);
+        launch_variant_prep(V, /*is_ont (filterSNP is a `phase` step)*/ 0, c->v_bucket.p, c->v_rec.p, s, R.ref_start, R.n, c->r_v0.p);
         mark(c, ST_EXTRACT);
-        launch_read_v0(V, R, c->r_v0.p, s);
         HapOut H{};
         H.pct_thr = c->P.percentage_threshold; H.rec = c->hap_rec.p; H.pq_tab = c->pq_tab.p; H.votes1 = votes ? c->d_votes1.p : nullptr; H.votes2 = votes ? c->d_votes2.p : nullptr;
         for (int attempt = 0; attempt < 2; ++attempt) {

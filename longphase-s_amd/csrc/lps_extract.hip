@@ -1,9 +1,9 @@
 // lps_extract.hip — variant-table preparation and the read x variant allele extraction kernel (gfx950).
 //
 // Replaces (reference file:line, relative to /root/reference/):
-//   SnpParser::getVariants_markindel   src/phase/ParsingBam.cpp:378-417     -> k_variant_prep (danger flag)
-//   homopolymerLength                  src/shared/Util.cpp:21-54            -> k_variant_prep (hpoly)
-//   SnpParser::filterSNP               src/phase/ParsingBam.cpp:837-912     -> k_filter_snp (erased flag)
+//   SnpParser::getVariants_markindel   src/phase/ParsingBam.cpp:378-417     -> k_variant_table (danger flag)
+//   homopolymerLength                  src/shared/Util.cpp:21-54            -> k_variant_table (hpoly)
+//   SnpParser::filterSNP               src/phase/ParsingBam.cpp:837-912     -> k_variant_table (erased flag)
 //   BamParser::direct_detect_alleles   src/phase/ParsingBam.cpp:1243-1301   -> k_extract_phase (filters)
 //   BamParser::get_snp / getClip       src/phase/ParsingBam.cpp:1303-1645   -> k_extract_phase
 //
@@ -27,41 +27,28 @@
 #include "lps_kernels.h"
 
 // ------------------------------------------------------------------------------------------------ variants
-__global__ void k_variant_prep(VarView V) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V.n) return;
-    const long long L = V.ref_len_eff;
-    const long long p0 = V.pos[v];
-    auto at = [&](long long i) -> char { return (i >= 0 && i < L) ? V.ref[i] : '\0'; };
-    uint8_t danger = 0;
-    if (V.ref_len[v] > 1 || V.alt_len[v] > 1) {
-        long long p = p0; const char a = at(p + 1), b = at(p + 2); int i = 0;
-        while (i < 5) { if (a != at(p + 1) || b != at(p + 2)) break; p += 2; ++i; }
-        danger = (i == 5);
+// ONE launch makes everything the walkers read about the table (round 4: four dependent launches before - prep, filterSNP, pack + buckets, first
+// candidates - each a few microseconds of work behind a kernel boundary):
+//   * workgroups [0, nb_var): thread per variant - danger flag (getVariants_markindel), homopolymer length, filterSNP's erasure, the packed 8-byte
+//     record {pos, attr} so that a candidate costs ONE load in the walkers.  filterSNP (:837-912) relates only SNPs at most 2 bp apart: the table
+//     splits into independent chains at every larger gap, and a variant that is not its chain's head replays the reference's erase-while-iterating
+//     scan from the head down to itself (chains hold two or three rows; the homopolymer lengths on the way are recomputed, a few bytes of reference each);
+//   * the next workgroups: the coarse position index (bucket b = first variant at or beyond b << LPS_BUCKET_SHIFT), plain binary search;
+//   * the last workgroups (when asked for): first candidate row of every alignment, a binary search of the positions per alignment.
+__device__ __forceinline__ int var_hpoly(const VarView &V, int v) { return homopolymer_length(V.ref, V.ref_len_eff, (long long)V.pos[v]); }
+__global__ void k_variant_table(VarView V, int is_ont, uint2 *rec, int32_t *bucket, int nb_var, int nb_bucket, const int32_t *ref_start, int n_reads, int32_t *v0) {
+    const int blk = (int)blockIdx.x;
+    if (blk >= nb_var + nb_bucket) {                                       // ---- first candidate of every alignment (== lane_var_lower_bound)
+        const int r = (blk - nb_var - nb_bucket) * blockDim.x + threadIdx.x;
+        if (r >= n_reads) return;
+        const int key = ref_start[r];
+        int lo = 0, hi = V.n;
+        if (key >= 0) while (lo < hi) { const int m = (lo + hi) >> 1; if (V.pos[m] < key) lo = m + 1; else hi = m; } else lo = 0;
+        v0[r] = lo;
+        return;
     }
-    V.danger[v] = danger;
-    V.hpoly[v] = (uint8_t)homopolymer_length(V.ref, L, p0);
-    V.erased[v] = 0;
-}
-
-// filterSNP: the reference's erase-while-iterating pair scan only ever relates SNPs <= 2 bp apart, so the table
-// splits into independent chains at every gap > 2 bp; the head of each chain replays the scan for its chain.
-__global__ void k_filter_snp(VarView V) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V.n) return;
-    if (v != 0 && V.pos[v] - V.pos[v - 1] <= 2) return;   // not a chain head
-    int cur = v, nxt = v + 1;
-    while (nxt < V.n && V.pos[nxt] - V.pos[nxt - 1] <= 2) {
-        if (V.hpoly[cur] >= 3 && V.hpoly[nxt] >= 3 && V.pos[nxt] - V.pos[cur] <= 2) { V.erased[nxt] = 1; ++nxt; }
-        else { cur = nxt; ++nxt; }
-    }
-}
-
-// one 8-byte record per variant so that a candidate costs ONE gather in the extraction kernel
-// + (the workgroups after the variants') the coarse position index over the table: thread per bucket, plain binary search
-__global__ void k_variant_pack(VarView V, uint2 *rec, int32_t *bucket, int nb_pack) {
-    if ((int)blockIdx.x >= nb_pack) {
-        const int b = ((int)blockIdx.x - nb_pack) * blockDim.x + threadIdx.x;
+    if (blk >= nb_var) {                                                   // ---- bucket index
+        const int b = (blk - nb_var) * blockDim.x + threadIdx.x;
         if (b > V.n_bucket) return;
         const long long key = (long long)b << LPS_BUCKET_SHIFT;
         int lo = 0, hi = V.n;
@@ -69,24 +56,45 @@ __global__ void k_variant_pack(VarView V, uint2 *rec, int32_t *bucket, int nb_pa
         bucket[b] = lo;
         return;
     }
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blk * blockDim.x + threadIdx.x;
     if (v >= V.n) return;
+    const long long L = V.ref_len_eff;
+    const long long p0 = V.pos[v];
+    auto at = [&](long long i) -> char { return (i >= 0 && i < L) ? V.ref[i] : '\0'; };
     const int rl = V.ref_len[v], al = V.alt_len[v];
+    uint8_t danger = 0;
+    if (rl > 1 || al > 1) {                                               // getVariants_markindel (:391-406): the 2-mer behind the site repeats five times
+        long long p = p0; const char a = at(p + 1), b = at(p + 2); int i = 0;
+        while (i < 5) { if (a != at(p + 1) || b != at(p + 2)) break; p += 2; ++i; }
+        danger = (i == 5);
+    }
+    const int hp = var_hpoly(V, v);
+    uint8_t erased = 0;
+    if (is_ont && v != 0 && V.pos[v] - V.pos[v - 1] <= 2) {                // not a chain head: replay the chain's scan up to this row
+        int h = v - 1;
+        while (h > 0 && V.pos[h] - V.pos[h - 1] <= 2) --h;
+        int cur = h, hp_cur = var_hpoly(V, h);
+        for (int nxt = h + 1; nxt <= v; ++nxt) {
+            const int hp_nxt = nxt == v ? hp : var_hpoly(V, nxt);
+            const bool er = hp_cur >= 3 && hp_nxt >= 3 && V.pos[nxt] - V.pos[cur] <= 2;
+            if (nxt == v) erased = er;
+            if (!er) { cur = nxt; hp_cur = hp_nxt; }
+        }
+    }
+    V.danger[v] = danger; V.hpoly[v] = (uint8_t)hp; V.erased[v] = erased;
     const unsigned kind = (rl == 1 && al == 1) ? 0u : ((rl == 1 && al != 1) ? 1u : ((rl != 1 && al == 1) ? 2u : 3u));
-    const unsigned attr = (unsigned)V.ref0[v] | ((unsigned)V.alt0[v] << 8) | (kind << 16) | (V.danger[v] ? VREC_DANGER : 0u) |
-                          (V.erased[v] ? VREC_ERASED : 0u) | (V.hpoly[v] >= 3 ? VREC_HPOLY3 : 0u) |
+    const unsigned attr = (unsigned)V.ref0[v] | ((unsigned)V.alt0[v] << 8) | (kind << 16) | (danger ? VREC_DANGER : 0u) |
+                          (erased ? VREC_ERASED : 0u) | (hp >= 3 ? VREC_HPOLY3 : 0u) |
                           ((V.hp1_is_alt && V.hp1_is_alt[v]) ? VREC_HP1ALT : 0u) |
                           (V.somatic_role ? ((unsigned)(V.somatic_role[v] & 3) << 22) | ((unsigned)((V.derive_hp ? V.derive_hp[v] : 0) & 3) << 24) : 0u) |
                           (V.tumor_kind ? ((unsigned)(V.tumor_kind[v] & 7) << 26) : 0u);
     rec[v] = make_uint2((unsigned)V.pos[v], attr);
 }
 
-void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *rec, hipStream_t s) {
+void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *rec, hipStream_t s, const int32_t *ref_start, int n_reads, int32_t *v0) {
     if (V.n == 0) return;
-    const int b = 256, g = (V.n + b - 1) / b;
-    hipLaunchKernelGGL(k_variant_prep, dim3(g), dim3(b), 0, s, V);
-    if (is_ont) hipLaunchKernelGGL(k_filter_snp, dim3(g), dim3(b), 0, s, V);
-    hipLaunchKernelGGL(k_variant_pack, dim3(g + (V.n_bucket + 1 + b) / b), dim3(b), 0, s, V, rec, bucket, g);
+    const int b = 256, nb_var = (V.n + b - 1) / b, nb_bucket = (V.n_bucket + 1 + b) / b, nb_reads = (v0 && n_reads > 0) ? (n_reads + b - 1) / b : 0;
+    hipLaunchKernelGGL(k_variant_table, dim3(nb_var + nb_bucket + nb_reads), dim3(b), 0, s, V, is_ont, rec, bucket, nb_var, nb_bucket, ref_start, v0 ? n_reads : 0, v0);
 }
 
 // ------------------------------------------------------------------------------------------------ extraction
@@ -741,17 +749,6 @@ __global__ __launch_bounds__(256, 4) void k_extract_redo(VarView V, ReadView R, 
     }
     wave_sync();                                                         // the LDS buffers are reused by the wave's next job
     }
-}
-
-// first candidate of every alignment: the position-sorted table searched by one thread per alignment, all at once - inside the wave-per-job kernels
-// the same search was a chain of dependent loads at the head of every job
-__global__ void k_read_v0(VarView V, const int32_t *ref_start, int n, int32_t *v0) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) v0[r] = lane_var_lower_bound(V, ref_start[r]);
-}
-void launch_read_v0(const VarView &V, const ReadView &R, int32_t *v0, hipStream_t s) {
-    if (R.n == 0 || V.n == 0) return;
-    hipLaunchKernelGGL(k_read_v0, dim3((R.n + 255) / 256), dim3(256), 0, s, V, R.ref_start, R.n, v0);
 }
 
 void launch_extract_phase(const VarView &V, const ReadView &R, const ObsView &O, const ClipView &C,

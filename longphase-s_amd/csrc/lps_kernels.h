@@ -37,7 +37,7 @@ struct ReadView {
     const uint32_t *cigp;
     const uint32_t *cp_off;
     const int32_t *cp_n;
-    const int32_t *v0;         // first variant at or after the alignment's start (k_read_v0: one thread per alignment, before the wave-per-job kernels)
+    const int32_t *v0;         // first variant at or after the alignment's start (k_variant_table's last workgroups: one thread per alignment, before the wave-per-job kernels)
 #ifdef __HIPCC__
     __device__ __forceinline__ const uint32_t *cig(int r) const { return cigp + 8ull * cp_off[r]; }
 #endif
@@ -105,7 +105,8 @@ struct ExtraView {
 void launch_extra_merge(const VarView &V, const ReadView &R, const ObsView &O, const ExtraView &X, int32_t *x0, uint32_t *redo, unsigned *n_redo, int mapping_quality,
         LpsCounters *cnt, hipStream_t s);
 
-void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *rec, hipStream_t s);
+// one launch: derived columns + packed records, the bucket index and (v0 != NULL) the first candidate row of every alignment
+void launch_variant_prep(const VarView &V, int is_ont, int32_t *bucket, uint2 *rec, hipStream_t s, const int32_t *ref_start = nullptr, int n_reads = 0, int32_t *v0 = nullptr);
 
 // attr word of a packed variant record: bits 0-7 REF[0], 8-15 ALT[0], 16-17 kind (0 SNP, 1 insertion, 2 deletion,
 // 3 other), 18 danger, 19 erased by filterSNP, 20 homopolymerLength >= 3
@@ -259,7 +260,6 @@ struct HapOut { uint8_t *status; int32_t *hp1, *hp2; uint8_t *n_ps; int32_t *ps_
                 // germline haplotag (mode 0): ONE 16-byte record per read instead of five arrays, the read-level decision taken on the GPU:
                 //   word 0 = status | n_ps << 8 | HP << 16 | PQ << 24 (PQ 255: votes of 64 or more, the host computes it), hp1, hp2 (votes included), ps_min
                 uint4 *rec; const int *pq_tab /* [64][64]: PQ of (min, max) votes, built by the host's libm */; const int32_t *votes1, *votes2; };
-void launch_read_v0(const VarView &V, const ReadView &R, int32_t *v0, hipStream_t s);
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
                      int mode, LpsCounters *cnt, hipStream_t s, bool general = false);   // general: the per-op-prefix walker also for the germline pass (what the stream walk cannot take);   // mode 0 haplotag, 1 somatic tag, 2 normal extraction, 3 its read-HP pass
 
