@@ -663,7 +663,7 @@ def main():
             host = None
             if spec["name"] in parity_set or (rank == 0 and spec["name"] == cpu_name):
                 t0 = time.time(); host = g.to_host(); d2h_s += time.time() - t0
-            if rank == 0 and spec["name"] == cpu_name and not a.no_cpu_baseline:
+            if rank == 0 and world == 1 and spec["name"] == cpu_name and not a.no_cpu_baseline:      # (the CPU baseline is timed at N = 1 only)
                 cpu_pick = [g, spec, None]      # keeps its device arrays for the SAM writer; everything else is released below
             else:
                 g.release_reads()
@@ -841,7 +841,7 @@ def main():
         }
         if rccl_info is not None:
             res["rccl"] = rccl_info
-        if a.workload == "wgs_50x" and not a.no_somatic:
+        if a.workload == "wgs_50x" and not a.no_somatic and world == 1:
             # config 5 inside the default line: a bounded sample of the tumor / normal leg (`--workload somatic_tn` runs it at 160 Mb)
             try:
                 t0 = time.time()

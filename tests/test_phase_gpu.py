@@ -242,3 +242,20 @@ def test_config1_scale_matches_oracle():
         out = ctx.phase(V, s.ref, R)
     util.assert_phase_equal(out.phase_set, out.gt, ref_out.phase_set, ref_out.gt, "config1")
     assert (out.phase_set != 0).sum() > 4900
+
+
+def test_clip_sort_path_on_inputs_that_skip_it():
+    """Since round 4 the clip keys are only sorted (and the CNV state machine only replayed) when some (position, end) holds five clips - the
+    count-min bound k_name_link takes.  LPS_CLIP_ALWAYS_SORT=1 forces the sorted path on a fixture that skips it: same stages, same result.
+    (The variable is read once per process: a child process.)"""
+    import os, subprocess, sys
+    code = ("import sys; sys.path[:0] = [%r, %r, %r, %r]\n"
+            "import numpy as np, fixtures, util, lps_oracle\nfrom lps import abi, hip\n"
+            "kw, _, over = fixtures.PHASE_FIXTURES['snp_ont']\ns, V, R = util.make_case(kw)\nP = abi.default_params(**over)\n"
+            "want, d = lps_oracle.phase(P, V, s.ref, R, dump=True)\n"
+            "with hip.Context(0, P) as ctx:\n    out = ctx.phase(V, s.ref, R)\n    util.assert_stages_equal(ctx, d, 'always-sort')\n"
+            "util.assert_phase_equal(out.phase_set, out.gt, want.phase_set, want.gt, 'always-sort')\nprint('ok')\n") % (
+        os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"),
+        os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "longphase-s_amd"), os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LPS_CLIP_ALWAYS_SORT="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]
