@@ -1654,22 +1654,24 @@ int lps_somatic_extract_normal(lps_ctx *c, lps_site_counters *out) {
         if (c->ref_len_eff == 0) return fail(c, "lps_set_reference has not been called");
         hipStream_t s = c->stream;
         c->site.reserve((size_t)nV * LPS_SITE_COUNTERS); c->read_hp.reserve(nR);
-        c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1);
+        c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1); c->r_v0.reserve((size_t)nR + 1);
         HIP_TRY(hipEventRecord(c->ev_begin, s));
-        HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
-        HIP_TRY(hipMemsetAsync(c->site.p, 0, (size_t)nV * LPS_SITE_COUNTERS * sizeof(int32_t), s));
         VarView V = var_view(c); ReadView R = read_view(c);
         for (auto &u : c->ev_used) u = false;
-        mark(c, ST_PREP);
-        launch_variant_prep(V, 0, c->v_bucket.p, c->v_rec.p, s);
-        mark(c, ST_EXTRACT);
-        HapOut H{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c->site.p, c->read_hp.p, c->P.percentage_threshold};
-        launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 2, c->d_cnt, s);   // votes + base counters + read haplotype
-        launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 3, c->d_cnt, s);   // ReadHpCount of the touched sites
-        mark(c, ST_D2H);
+        for (int attempt = 0; attempt < 2; ++attempt) {                   // the stream walk; the per-op-prefix walker when it met a record outside its arithmetic
+            HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
+            HIP_TRY(hipMemsetAsync(c->site.p, 0, (size_t)nV * LPS_SITE_COUNTERS * sizeof(int32_t), s));
+            if (attempt == 0) { mark(c, ST_PREP); launch_variant_prep(V, 0, c->v_bucket.p, c->v_rec.p, s, R.ref_start, R.n, c->r_v0.p); mark(c, ST_EXTRACT); }
+            HapOut H{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c->site.p, c->read_hp.p, c->P.percentage_threshold};
+            launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 2, c->d_cnt, s, /*general=*/attempt == 1);   // votes + base counters + read haplotype
+            launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 3, c->d_cnt, s, /*general=*/attempt == 1);   // ReadHpCount of the touched sites
+            if (attempt == 0) mark(c, ST_D2H);
+            HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (!(c->h_cnt.err & LPS_ERR_KEY_RANGE)) break;
+        }
         HIP_TRY(hipMemcpyAsync(out->counters, c->site.p, (size_t)nV * LPS_SITE_COUNTERS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         if (out->read_hp) HIP_TRY(hipMemcpyAsync(out->read_hp, c->read_hp.p, (size_t)nR, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(c->ev_end, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (c->h_cnt.err & LPS_ERR_BAD_CIGAR) return fail(c, "Alignment find unsupported CIGAR operation", -2);

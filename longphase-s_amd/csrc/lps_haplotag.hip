@@ -265,9 +265,12 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
 #ifndef HTG_TAB
 #define HTG_TAB 1024
 #endif
-template <int MODE>   // 0: germline haplotag; 1: the tagging pass of somatic_haplotag over the merged normal + tumor table (same rules as k_haplotag_score<1>)
+// MODE 0: germline haplotag; 1: the tagging pass of somatic_haplotag over the merged normal + tumor table; 2 / 3: the normal-BAM extraction pass of
+// somatic_haplotag (votes gated by MAPQ + per-site base counters + the read's haplotype / ReadHpCount of the touched sites) - the rules of
+// k_haplotag_score<MODE>, which stays the general walker for records this walk's arithmetic cannot take
+template <int MODE>
 __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary, LpsCounters *cnt) {
-    constexpr bool SOM = MODE == 1;
+    constexpr bool SOM = MODE == 1, EXT = MODE == 2 || MODE == 3;
     __shared__ __attribute__((aligned(16))) int2 s_tab[HTG_TAB + 1];
     __shared__ ExtHdr s_hdr[4];
     const int l = lane_id();
@@ -275,12 +278,14 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
     if (r0 >= R.n) return;
     const int nq = min(4, R.n - r0);
     // ---- plan: headers, alignment q in lane q; the filter cascade of processSingleChrom (HaplotagParsingBam.cpp:453-486)
-    int h_start = 0, h_lq = 0, h_status = 0, h_v0 = 0, h_n = 0; unsigned h_cp = 0; unsigned long long h_soff = 0;
+    int h_start = 0, h_lq = 0, h_status = 0, h_v0 = 0, h_n = 0; unsigned h_cp = 0; unsigned long long h_soff = 0; bool h_mq = false; int h_myhp = 0;
     if (l <= nq) h_cp = R.cp_off[r0 + l];
     if (l < nq) {
         const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r]; h_v0 = V.n ? R.v0[r] : 0; h_n = R.cp_n[r];
         const int flag = R.flag[r];
-        if (R.mapq[r] < mapping_quality) h_status = 1;
+        h_mq = R.mapq[r] >= mapping_quality;
+        if (MODE == 3) h_myhp = (int)H.read_hp[r];
+        if (!EXT && !h_mq) h_status = 1;                                  // (the extraction passes run with mappingQualityFilter == false)
         else if (flag & 0x4) h_status = 2;
         else if (flag & 0x100) h_status = 3;
         else if ((flag & 0x800) && !tag_supplementary) h_status = 4;
@@ -290,6 +295,12 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
     const bool h_live = l < nq && h_status == 0;
     bool bad_cigar = false;
     const unsigned live_mask = (unsigned)__ballot(h_live) & 15u;
+    const unsigned mq_mask = (unsigned)__ballot(h_mq) & 15u;              // EXT: alignments whose votes count (MAPQ)
+    int myhp[4] = {0, 0, 0, 0}, judged[4] = {-1, -1, -1, -1};            // EXT: the read's haplotype of pass 2 (MODE 3); last D op whose once-per-op vote has been cast (MODE 2)
+    if (MODE == 3) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) myhp[q] = __builtin_amdgcn_readlane(h_myhp, q);
+    }
     const int h_nch = (int)(__shfl_down(h_cp, 1) - h_cp);                 // chunks of alignment q (lanes < nq)
     int vh1[4] = {0, 0, 0, 0}, vh2[4] = {0, 0, 0, 0}, plo[4], phi[4];      // per alignment: votes, smallest / largest phase set seen (wave-uniform)
     int vh3[4] = {0, 0, 0, 0}, vd1[4] = {0, 0, 0, 0}, vd2[4] = {0, 0, 0, 0};   // SOM: H3 bases at somatic calls and which germline haplotype they derive from
@@ -392,6 +403,7 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
             const int i = i0 + l;
             const bool in = i < T;
             int vote = -1, ps_v = 0; bool count_ps = false, hp1alt = false; int h3v = 0;      // h3v (SOM): 1 H3 base, 2 / 3 deriving from haplotype 1 / 2 as well
+            int del_key = -1, del_qs = 0; unsigned del_at = 0u;             // MODE 2: (alignment, D op) of a NORMAL row waiting for the op's one vote
             const uint2 vr = pvr;
             pvr = V.rec[min(SELC(i + 64, cum, vadj) + i + 64, V.n - 1)];
             if (in) {
@@ -431,6 +443,42 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
                     const unsigned kind = VREC_KIND(at);
                     const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
                     const uint8_t *seq = R.seq + s_hdr[q].soff;
+                    if (EXT) {
+                        // ExtractNorDataCigarParser (SomaticVarCaller.cpp:227-293): countBaseNucleotide at the tumor rows, the germline vote at the
+                        // normal sample's rows (MAPQ-gated), ReadHpCount of the touched sites in the second pass
+                        const unsigned tk = VREC_TKIND(at);
+                        const bool mq_ok = (mq_mask >> q) & 1u;
+                        int32_t *sc = H.site + (size_t)v * LPS_SITE_COUNTERS;
+                        if (op_is_match(op)) {
+                            const int qi = qs + (ps - rs);
+                            const char base_c = qi < hlq ? nt16_char(__builtin_nontemporal_load(seq + (qi >> 1)) >> ((~qi & 1) << 2)) : 'N';
+                            bool is_alt = false;
+                            const bool has_next = opi + 1 < hncig;
+                            if (kind == 0) is_alt = base_c == alt_c;
+                            else if ((kind == 1 || kind == 2) && has_next) is_alt = (rs + len - 1 == ps) && (int)(wn & 15u) == ((kind == 1) ? 1 : 2);
+                            if (tk >= 1 && tk <= 3) {                                 // countBaseNucleotide (HaplotagParsingBam.cpp:682-719)
+                                if (MODE == 3) atomicAdd(&sc[LPS_SC_READHP_UNTAG + SEL4(q, myhp)], 1);
+                                else {
+                                    const int bi = base_c == 'A' ? LPS_SC_A : base_c == 'C' ? LPS_SC_C : base_c == 'G' ? LPS_SC_G : base_c == 'T' ? LPS_SC_T : LPS_SC_UNKNOWN;
+                                    if (mq_ok) { atomicAdd(&sc[bi + (LPS_SC_MPQ_A - LPS_SC_A)], 1); if (is_alt) atomicAdd(&sc[LPS_SC_MPQ_ALT], 1); atomicAdd(&sc[LPS_SC_MPQ_DEPTH], 1); }
+                                    atomicAdd(&sc[bi], 1);
+                                    if (is_alt) { if (tk == 3) atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_ALT], 1); }
+                                    atomicAdd(&sc[LPS_SC_DEPTH], 1);
+                                }
+                            }
+                            if (MODE == 2 && mq_ok && VREC_ROLE(at) == 0) {           // germline judgeSnpHap on the NORMAL row
+                                if (kind == 0) { if (base_c == ref_c) vote = 0; else if (base_c == alt_c) vote = 1; count_ps = vote >= 0; }
+                                else if ((kind == 1 || kind == 2) && has_next) { vote = (kind == 1) ? (is_alt ? 1 : 0) : (is_alt ? 0 : 1); count_ps = true; }
+                            }
+                        } else if (op == 2) {
+                            if (tk != 0) {                                            // processDeletionOperation (:265-282)
+                                if (MODE == 3) atomicAdd(&sc[LPS_SC_READHP_UNTAG + SEL4(q, myhp)], 1);
+                                else if (tk == 1) { atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_DEPTH], 1); }
+                                else if (tk == 3) { atomicAdd(&sc[LPS_SC_ALT], 1); atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_DEPTH], 1); }
+                            }
+                            if (MODE == 2 && mq_ok && VREC_ROLE(at) == 0) { del_key = (q << 28) | opi; del_qs = qs; del_at = at; }   // the vote is cast below, once per D op
+                        }
+                    } else
                     if (SOM) {
                         // SomaticHaplotagCigarParser (SomaticHaplotagProcess.cpp:557-579): deletions cast no vote; judgeNormalSnpHap (HaplotagStrategy.cpp:403-435)
                         // at the normal sample's rows, the tumor ALT at a somatic call is an H3 base (:653-668)
@@ -476,6 +524,29 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
             }
             // ---- per alignment: votes by ballot; the phase-set range by two masked reductions, taken only when the alignment's variants do not all
             //      carry ONE phase set (they nearly always do: blocks are long)
+            if (MODE == 2) {
+                // once per D op: the FIRST normal row inside the deletion (the lowest lane: candidates are in position order) casts the judgeDeletionHap
+                // vote (:285-291), unless the op's vote was cast in an earlier round of this alignment
+                unsigned long long dtodo = __ballot(del_key >= 0);
+                while (dtodo) {
+                    const int leader = __builtin_ctzll(dtodo);
+                    const int k0 = __builtin_amdgcn_readlane(del_key, leader);
+                    const unsigned long long same = __ballot(del_key == k0);
+                    const int q0 = k0 >> 28;
+                    if (l == leader && k0 != SEL4(q0, judged) && (del_at & VREC_HPOLY3)) {
+                        const unsigned kind = VREC_KIND(del_at);
+                        if (kind == 0) {
+                            const uint8_t *seq = R.seq + s_hdr[q0].soff; const int hlq = s_hdr[q0].lq;
+                            const char base_c = del_qs < hlq ? nt16_char(__builtin_nontemporal_load(seq + (del_qs >> 1)) >> ((~del_qs & 1) << 2)) : 'N';
+                            if (base_c == (char)(del_at & 0xff)) vote = 0; else if (base_c == (char)((del_at >> 8) & 0xff)) vote = 1;
+                            count_ps = true;
+                        } else if (kind == 2) { vote = 0; count_ps = true; }
+                        if (count_ps) ps_v = V.phase_set[SELC(i, cum, vadj) + i];
+                    }
+                    judged[0] = q0 == 0 ? k0 : judged[0]; judged[1] = q0 == 1 ? k0 : judged[1]; judged[2] = q0 == 2 ? k0 : judged[2]; judged[3] = q0 == 3 ? k0 : judged[3];
+                    dtodo &= ~same;
+                }
+            }
             const bool to1 = vote >= 0 && ((vote == 1) == hp1alt), to2 = vote >= 0 && !((vote == 1) == hp1alt);
             const unsigned long long m1 = __ballot(to1), m2 = __ballot(to2), mp = __ballot(count_ps);
             const unsigned long long m3 = SOM ? __ballot(h3v != 0) : 0ull, md1 = SOM ? __ballot(h3v == 2) : 0ull, md2 = SOM ? __ballot(h3v == 3) : 0ull;
@@ -500,6 +571,18 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
         wave_sync();                                                      // the table and the headers are reused by the next group
     }
     if (bad_cigar && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
+    if (MODE == 3) return;
+    if (MODE == 2) {                                                      // judgeReadHap (HaplotagStrategy.cpp:243-300) without the PQ: the read's haplotype for the second pass
+        if (l < nq) {
+            const int h1 = SEL4(l, vh1), h2 = SEL4(l, vh2), lo = SEL4(l, plo), hi = SEL4(l, phi);
+            double mn, mx; int hp = 0;
+            if (h1 > h2) { mn = h2; mx = h1; } else { mn = h1; mx = h2; }
+            if (!(mx / (mx + mn) < H.pct_thr)) { if (h1 > h2) hp = 1; if (h1 < h2) hp = 2; }
+            if (lo <= hi && lo != hi) hp = 0;
+            H.read_hp[r0 + l] = (uint8_t)(h_status == 0 ? hp : 255);     // 255: read not processed by the pass
+        }
+        return;
+    }
     if (SOM) {                                                            // the counts of the tagging pass: the caller applies judgeSomaticReadHap / inheritHaplotype
         if (l < nq) {
             const int r = r0 + l; const int lo = SEL4(l, plo), hi = SEL4(l, phi); const bool any = lo <= hi;
@@ -535,8 +618,11 @@ void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int m
         hipLaunchKernelGGL(k_haplotag_stream<0>, dim3(round_up8((R.n + 3) / 4)), dim3(64), 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
         return;
     }
-    if (mode == 1 && !general) {                                          // somatic tagging pass: the same walk (a record it cannot take sets LPS_ERR_KEY_RANGE: the caller runs the general walker)
-        hipLaunchKernelGGL(k_haplotag_stream<1>, dim3(round_up8((R.n + 3) / 4)), dim3(64), 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
+    if (mode >= 1 && mode <= 3 && !general) {                             // the somatic passes on the same walk (a record it cannot take sets LPS_ERR_KEY_RANGE: the caller runs the general walker)
+        const dim3 gs(round_up8((R.n + 3) / 4)), bs(64);
+        if (mode == 1) hipLaunchKernelGGL(k_haplotag_stream<1>, gs, bs, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
+        else if (mode == 2) hipLaunchKernelGGL(k_haplotag_stream<2>, gs, bs, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
+        else hipLaunchKernelGGL(k_haplotag_stream<3>, gs, bs, 0, s, V, R, H, mapping_quality, tag_supplementary, cnt);
         return;
     }
     const dim3 g(round_up8((R.n + HAP_WPB - 1) / HAP_WPB)), b(64 * HAP_WPB);   // a multiple of 8: the XCD-aware unit mapping
