@@ -299,13 +299,18 @@ def whole_node_baseline(dev, P, threads, seed, n_contigs=16, contig_mb=10):
                 body = lambda p: [ln for ln in open(p) if not ln.startswith("##commandline=") and not ln.startswith("##longphaseVersion=")]  # noqa: E731
                 sweep = []                                               # (profiles/e2e_whole_node.py: other settings of the command line on the same files)
                 for extra in json.loads(os.environ.get("LPS_E2E_SWEEP", "[]")):
-                    xs = []
-                    for _ in range(2):
-                        t0 = time.time(); rx = subprocess.run(gcmd + list(extra), cwd=d, capture_output=True); xs.append(time.time() - t0); spawn = (round(t0, 3), round(time.time(), 3))
+                    xs = []; xenv = dict(os.environ); xargs = []          # (an item NAME=value sets the environment of the run instead of an argument)
+                    for x in extra:
+                        if "=" in x and not x.startswith("-"):
+                            xenv[x.split("=", 1)[0]] = x.split("=", 1)[1]
+                        else:
+                            xargs.append(x)
+                    for _ in range(3):
+                        t0 = time.time(); rx = subprocess.run(gcmd + xargs, cwd=d, capture_output=True, env=xenv); xs.append(time.time() - t0); spawn = (round(t0, 3), round(time.time(), 3))
                     err_lines = rx.stderr.decode(errors="replace").strip().splitlines()
-                    sweep.append(dict(args=extra, wall_s=round(min(xs), 3), rc=rx.returncode, last_run_spawned_and_reaped_at=spawn, stage_line=err_lines[-1][:400], debug=[ln[:400] for ln in err_lines if ln.startswith("[lps_") or ln.startswith("[cli]")]))
+                    sweep.append(dict(args=extra, wall_s=round(min(xs), 3), rc=rx.returncode, last_run_spawned_and_reaped_at=spawn, stage_line=([ln for ln in err_lines if "| total " in ln] or err_lines[-1:])[-1][:400], debug=[ln[ln.find("["):][:400] for ln in err_lines if "[lps_" in ln or "[cli]" in ln]))
                 e_clock = dict(sweep=sweep, wall_s=round(min(es), 3), runs_s=[round(x, 3) for x in es], vcf_identical_to_reference=body(d + "/out.vcf") == body(d + "/outg.vcf"),
-                               over_cpu=round(min(ts) / min(es), 2), stage_line=r.stderr.decode(errors="replace").strip().splitlines()[-1][:600],
+                               over_cpu=round(min(ts) / min(es), 2), stage_line=([ln for ln in r.stderr.decode(errors="replace").strip().splitlines() if "| total " in ln] or [""])[-1][:600],
                                note="`longphase_amd phase` end to end on the same BAM + VCF + FASTA (page cache warm, like the reference's best run): file -> phased VCF, GPU start-up included")
             except Exception as e:  # noqa: BLE001
                 log("whole-node sample: the command line run failed:", repr(e)[:300])

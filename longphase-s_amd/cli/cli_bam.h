@@ -1,6 +1,7 @@
 // cli_bam.h — BGZF / BAM input (host inflate, GPU-resident file with .bai ranges) and the BGZF writer of longphase_amd.
 #pragma once
 #include "cli_common.h"
+#include "../csrc/lps_bgzf_walk.h"
 
 // ------------------------------------------------------------------------------------------------ BGZF / BAM
 struct Bgzf {
@@ -203,14 +204,46 @@ struct GpuBam {
         }
         indexed = true;
     }
-    void close_file() { if (ahead.th.joinable()) ahead.th.join(); if (raw) munmap((void *)raw, fsz); if (fd >= 0) close(fd); raw = nullptr; fd = -1; }
+    void close_file() { if (whole.th.joinable()) whole.th.join(); if (ahead.th.joinable()) ahead.th.join(); if (raw) munmap((void *)raw, fsz); if (fd >= 0) close(fd); raw = nullptr; fd = -1; }
 
     // The header walk of the next load made AHEAD, on a helper thread: it needs the file and the library's host code, not the GPU - the first one runs
     // while the HIP runtime is still coming up (0.07 s of an 8 GB file's load), the next group's while the contigs of this one are phased.
-    ~GpuBam() { if (ahead.th.joinable()) ahead.th.join(); }            // (a walk nobody took: e.g. --gpus N, where every worker opens the file itself)
+    ~GpuBam() { if (whole.th.joinable()) whole.th.join(); if (ahead.th.joinable()) ahead.th.join(); }            // (a walk nobody took: e.g. --gpus N, where every worker opens the file itself)
     struct WalkAhead { uint64_t beg = 0, len = 0; lps_bgzf_block *blocks = nullptr; int64_t n = 0, inflated = 0; int rc = -1; std::thread th; bool pending = false; } ahead;
+    // The WHOLE file's table, walked from the moment the file is open - host-only code of csrc/lps_bgzf_walk.h compiled into this program, so it needs
+    // neither the GPU nor the library and runs beside the VCF parse and the HIP start-up; every later load takes its table as a slice of it.  For
+    // files that are one contig group anyway (the caller decides): a walk touches one page per block, which a load of the same bytes reads anyway.
+    struct WholeWalk { std::vector<lps_bgzf_block> blks; std::vector<uint64_t> ends; bool ok = false, started = false; std::thread th; } whole;
+    void walk_whole_file() {
+        if (whole.started || fd < 0 || getenv("LPS_CLI_NO_WALK_AHEAD")) return;
+        whole.started = true;
+        whole.th = std::thread([this] {
+            const ZSource z{nullptr, fd, 0}; uint64_t ut = 0;
+            bool ok = bgzf_walk_parallel(z, (uint64_t)fsz, whole.blks, ut);
+            if (!ok) { whole.blks.clear(); ut = 0; ok = bgzf_walk_piece(z, (uint64_t)fsz, 0, (uint64_t)fsz, whole.blks, ut) && !whole.blks.empty(); }
+            if (ok) { whole.ends.resize(whole.blks.size()); for (size_t k = 0; k < whole.blks.size(); ++k) whole.ends[k] = whole.blks[k].in_off + whole.blks[k].in_len + 8; }
+            whole.ok = ok;
+        });
+    }
+    // the blocks of bytes [beg, beg + len) out of the whole file's table, offsets relative to the span; false: the span does not begin and end on blocks of it
+    bool slice_whole(uint64_t beg, uint64_t len, std::vector<lps_bgzf_block> &out) {
+        if (!whole.started) return false;
+        if (whole.th.joinable()) whole.th.join();
+        if (!whole.ok || !len) return false;
+        size_t k0 = 0;
+        if (beg) { auto it = std::lower_bound(whole.ends.begin(), whole.ends.end(), beg); if (it == whole.ends.end() || *it != beg) return false; k0 = (size_t)(it - whole.ends.begin()) + 1; }
+        auto it9 = std::lower_bound(whole.ends.begin(), whole.ends.end(), beg + len);
+        if (it9 == whole.ends.end() || *it9 != beg + len) return false;
+        const size_t k9 = (size_t)(it9 - whole.ends.begin());
+        if (k9 < k0) return false;
+        out.assign(whole.blks.begin() + (ptrdiff_t)k0, whole.blks.begin() + (ptrdiff_t)k9 + 1);
+        const uint64_t o0 = out.front().out_off;
+        for (lps_bgzf_block &b : out) { b.in_off -= beg; b.out_off -= o0; }
+        return true;
+    }
     void walk_ahead(Lps &L, uint64_t beg, uint64_t len) {
         drop_walk(L);
+        if (whole.started) return;                                      // (the whole file's table is being made: load_span slices it)
         if (getenv("LPS_CLI_NO_WALK_AHEAD")) return;                    // (A/B switch)
         ahead.beg = beg; ahead.len = len; ahead.pending = true; ahead.rc = -1;
         WalkAhead *a = &ahead; Lps *lib = &L; const int f = fd;
@@ -223,6 +256,13 @@ struct GpuBam {
     // bytes [beg, beg + len) of the file onto the GPU, with the table walked ahead when it is the one for these bytes
     void load_span(Lps &L, lps_ctx *ctx, uint64_t beg, uint64_t len) {
         const double tj = now();
+        std::vector<lps_bgzf_block> part;
+        if (slice_whole(beg, len, part)) {
+            if (getenv("LPS_CLI_DEBUG")) fprintf(stderr, "[cli] waited %.3f s for the whole file's header walk; %zu of %zu blocks in this span\n", now() - tj, part.size(), whole.blks.size());
+            if (L.bgzf_load_fd_blocks(ctx, fd, (int64_t)beg, (int64_t)len, part.data(), (int64_t)part.size(), &total)) die(std::string("ERROR: ") + path + ": " + L.last_error(ctx));
+            drop_walk(L);
+            return;
+        }
         if (ahead.pending && ahead.th.joinable()) ahead.th.join();
         if (getenv("LPS_CLI_DEBUG")) fprintf(stderr, "[cli] waited %.3f s for the header walk made ahead\n", now() - tj);
         const bool have = ahead.pending && ahead.rc == 0 && ahead.beg == beg && ahead.len == len;

@@ -34,7 +34,7 @@ struct SvTable {
             if (f.size() < 10) continue;
             const int pos = std::stoi(f[1]) - 1; const std::string &c = f[0];
             bool filter = gt_is_hom(f[9], gt_value_start(f[8], f[9]));                                                   // :984-986
-            { auto sc = snps.find(c); if (sc != snps.end() && sc->second.rows.count(pos)) filter = true; }               // :988-990 the row sits on a SNP
+            { auto sc = snps.find(c); if (sc != snps.end() && sc->second.has(pos)) filter = true; }               // :988-990 the row sits on a SNP
             auto &d = dup[c]; auto di = d.find(pos);
             if (di == d.end()) d[pos] = false; else { di->second = true; filter = true; }                                // :992-999 second record at a position
             if (filter) continue;
@@ -62,7 +62,7 @@ struct ModTable {
             const int pos = std::stoi(f[1]) - 1; const std::string &c = f[0];
             if (up + 1 != pos) rep = pos;                               // :1709-1711 a run of consecutive positions is one row, at its first position
             if (gt_is_hom(f[9], gt_value_start(f[8], f[9]))) continue;  // :1725-1727
-            { auto sc = snps.find(c); if ((sc != snps.end() && sc->second.rows.count(pos)) || sv.find(c, pos)) continue; }   // :1730-1732 (findSV with the 0-based value)
+            { auto sc = snps.find(c); if ((sc != snps.end() && sc->second.has(pos)) || sv.find(c, pos)) continue; }   // :1730-1732 (findSV with the 0-based value)
             bool reverse;
             if (f[7].find("RS=P") != std::string::npos) reverse = false; else if (f[7].find("RS=N") != std::string::npos) reverse = true; else continue;
             auto list = [&](const char *key, bool modified) {           // :1748-1780

@@ -7,16 +7,19 @@
 static bool read_lines(const std::string &path, std::vector<std::string> &lines) {   // plain or gzip text
     gzFile f = gzopen(path.c_str(), "rb");
     if (!f) return false;
-    std::string cur; char buf[1 << 16]; int k;
-    while ((k = gzread(f, buf, sizeof buf)) > 0) {
-        for (int i = 0; i < k; ++i) { if (buf[i] == '\n') { lines.push_back(cur); cur.clear(); } else cur.push_back(buf[i]); }
-    }
-    if (!cur.empty()) lines.push_back(cur);
+    gzbuffer(f, 1u << 20);
+    std::string all; size_t have = 0; int k;                           // the whole text first: the lines are then cut with memchr, their count known before the first is made
+    for (;;) { if (all.size() - have < (1u << 22)) all.resize(std::max<size_t>(all.size() * 2, 1u << 24)); k = gzread(f, &all[have], (unsigned)std::min<size_t>(all.size() - have, 1u << 30)); if (k <= 0) break; have += (size_t)k; }
     gzclose(f);
+    const char *b = all.data(), *e = b + have; size_t n = 0;
+    for (const char *q = b; q < e;) { const char *nl = (const char *)memchr(q, '\n', (size_t)(e - q)); ++n; if (!nl) break; q = nl + 1; }
+    lines.reserve(lines.size() + n);
+    for (const char *q = b; q < e;) { const char *nl = (const char *)memchr(q, '\n', (size_t)(e - q)); lines.emplace_back(q, nl ? (size_t)(nl - q) : (size_t)(e - q)); if (!nl) break; q = nl + 1; }
     return true;
 }
 
-struct ChrVariants { std::map<int32_t, std::pair<std::string, std::string>> rows; std::vector<int32_t> pos; std::vector<std::string> ref, alt; };
+// rows of one contig, position-sorted, one per position (has(): is there a row at this 0-based position)
+struct ChrVariants { std::vector<int32_t> pos; std::vector<std::string> ref, alt; bool has(int32_t p) const { return std::binary_search(pos.begin(), pos.end(), p); } };
 
 static std::vector<std::string> split_tab(const std::string &s) {
     std::vector<std::string> f; size_t a = 0;
@@ -33,59 +36,92 @@ static std::vector<std::string> split_tab(const std::string &s) {
 // het bi-allelic record.  GT of the first sample must be 0/1, 1/0, 0|1 or 1|0.
 // --indelQuality N (with --indels; :229-235, 325-340): a het record that is not a SNP and whose QUAL is below N is dropped before anything else is
 // looked at, logged to <prefix>_removed_indels.log, and its FILTER reads INDEL_QUAL_FILTERED in the output VCF (IndelQual below).
+// A whole-genome VCF holds millions of lines and the GPU is idle until the table exists: the lines are parsed in slices on `threads` host threads
+// (no allocation per skipped line: fields are found in place), what the slices kept is applied in line order - first mention of a contig,
+// "the later record at one position wins", the log and the first error are what one thread walking the file would produce.
 struct IndelQual { int threshold = 0; std::ofstream log; std::map<std::string, std::set<int32_t>> filtered; };
-static void parse_vcf(const std::vector<std::string> &lines, bool indels, std::vector<std::string> &chr_order, std::map<std::string, ChrVariants> &out, IndelQual *iq = nullptr) {
-    for (const std::string &ln : lines) {
-        if (ln.empty()) continue;
-        if (ln[0] == '#') {
-            if (ln.compare(0, 13, "##contig=<ID=") == 0) { size_t e = ln.find_first_of(",>", 13);
-                std::string c = ln.substr(13, e - 13);
-                if (!out.count(c)) { out[c];
-                    chr_order.push_back(c);
-                    } }
-            continue;
-        }
-        std::vector<std::string> f = split_tab(ln);
-        if (f.size() < 10) continue;
-        const std::string &ref = f[3], &alt = f[4];
-        const bool unusable = alt.find(',') != std::string::npos || alt.empty() || alt[0] == '<' || alt == "." || alt == "*";
-        const bool is_snp = ref.size() == 1 && alt.size() == 1;
-        if (!(iq && iq->threshold > 0 && indels) && (unusable || (!is_snp && !indels))) continue;
-        if (unusable && alt.find(',') != std::string::npos) {              // all-single-base alleles: htslib calls it a SNP, the multi-allele check drops it
-            bool all1 = ref.size() == 1; size_t a = 0;
-            while (all1) { const size_t b = alt.find(',', a); if ((b == std::string::npos ? alt.size() : b) - a != 1) all1 = false; if (b == std::string::npos) break; a = b + 1; }
-            if (all1) continue;
-        }
-        if (!is_snp && !indels) continue;
-        // GT position inside FORMAT
-        std::vector<std::string> fmt, smp;
-        { std::stringstream a(f[8]), b(f[9]);
-            std::string x;
-            while (std::getline(a, x, ':')) fmt.push_back(x);
-            while (std::getline(b, x, ':')) smp.push_back(x);
-            }
-        size_t gi = std::find(fmt.begin(), fmt.end(), "GT") - fmt.begin();
-        if (gi >= fmt.size() || gi >= smp.size()) die("pos " + f[1] + " missing GT value");
-        const std::string &gt = smp[gi];
-        if (!(gt == "0/1" || gt == "1/0" || gt == "0|1" || gt == "1|0")) continue;
-        if (!is_snp && iq && iq->threshold > 0) {                          // :325-340, before the multi-allele check
-            float qual = 0.0f; bool missing = f[5] == ".";
-            if (!missing) { try { qual = std::stof(f[5]); } catch (...) { qual = 0.0f; missing = true; } }
-            if (qual < (float)iq->threshold) {
-                const std::string alt1 = alt.substr(0, alt.find(','));
-                if (iq->log.is_open()) iq->log << f[0] << "\t" << f[1] << "\t" << ref << "\t" << alt1 << "\t" << (missing ? std::string(".") : std::to_string(qual)) << "\n";
-                iq->filtered[f[0]].insert(std::stoi(f[1]) - 1);
-                continue;
-            }
-        }
-        if (unusable) continue;
-        if (!out.count(f[0])) { out[f[0]]; chr_order.push_back(f[0]); }
-        out[f[0]].rows[std::stoi(f[1]) - 1] = {ref, alt};           // map semantics: the later record at one position wins
+struct VcfKept { int kind = 0; std::string chr, ref, alt, text; int32_t pos = 0; };   // 1 ##contig line, 2 row, 3 row dropped by --indelQuality (text: its log line), 4 error (text)
+static void parse_vcf_line(const std::string &ln, bool indels, int iq_threshold, std::vector<VcfKept> &out) {
+    if (ln.empty()) return;
+    if (ln[0] == '#') {
+        if (ln.compare(0, 13, "##contig=<ID=") == 0) { const size_t e = ln.find_first_of(",>", 13); VcfKept k; k.kind = 1; k.chr = ln.substr(13, e - 13); out.push_back(std::move(k)); }
+        return;
     }
-    for (auto &kv : out) for (auto &r : kv.second.rows) { kv.second.pos.push_back(r.first);
-        kv.second.ref.push_back(r.second.first);
-        kv.second.alt.push_back(r.second.second);
+    // the first ten fields in place
+    const char *b = ln.data(), *e = b + ln.size(); const char *fs[10]; size_t fl[10]; int nf = 0;
+    for (const char *q = b; nf < 10;) { const char *t = (const char *)memchr(q, '\t', (size_t)(e - q)); fs[nf] = q; fl[nf] = (size_t)((t ? t : e) - q); ++nf; if (!t) break; q = t + 1; }
+    if (nf < 10) return;
+    auto has_comma = [](const char *p, size_t n) { return memchr(p, ',', n) != nullptr; };
+    const char *ref = fs[3], *alt = fs[4]; const size_t rl = fl[3], al = fl[4];
+    const bool iq_on = iq_threshold > 0 && indels;
+    const bool unusable = has_comma(alt, al) || al == 0 || alt[0] == '<' || (al == 1 && (alt[0] == '.' || alt[0] == '*'));
+    const bool is_snp = rl == 1 && al == 1;
+    if (!iq_on && (unusable || (!is_snp && !indels))) return;
+    if (unusable && has_comma(alt, al)) {                                  // all-single-base alleles: htslib calls it a SNP, the multi-allele check drops it
+        bool all1 = rl == 1; size_t a = 0;
+        while (all1) { const char *c = (const char *)memchr(alt + a, ',', al - a); const size_t bnd = c ? (size_t)(c - alt) : al; if (bnd - a != 1) all1 = false; if (!c) break; a = bnd + 1; }
+        if (all1) return;
+    }
+    if (!is_snp && !indels) return;
+    // GT position inside FORMAT; pieces as std::getline cuts them (a trailing empty piece does not exist)
+    auto piece = [](const char *p, size_t n, size_t want, const char *&q, size_t &ql) -> bool {      // piece number `want` of p[0, n) split at ':'
+        size_t idx = 0, a = 0;
+        for (;;) { const char *c = (const char *)memchr(p + a, ':', n - a); const size_t bnd = c ? (size_t)(c - p) : n;
+            if (!c && bnd == a) return false;                                 // (the empty piece behind a trailing ':' or of an empty string)
+            if (idx == want) { q = p + a; ql = bnd - a; return true; }
+            if (!c) return false;
+            ++idx; a = bnd + 1; }
+    };
+    size_t gi = 0; bool have_gt = false;
+    for (;; ++gi) { const char *q; size_t ql; if (!piece(fs[8], fl[8], gi, q, ql)) break; if (ql == 2 && q[0] == 'G' && q[1] == 'T') { have_gt = true; break; } }
+    const char *gt = nullptr; size_t gl = 0;
+    if (!have_gt || !piece(fs[9], fl[9], gi, gt, gl)) { VcfKept k; k.kind = 4; k.text = "pos " + std::string(fs[1], fl[1]) + " missing GT value"; out.push_back(std::move(k)); return; }
+    if (!(gl == 3 && (gt[1] == '/' || gt[1] == '|') && ((gt[0] == '0' && gt[2] == '1') || (gt[0] == '1' && gt[2] == '0')))) return;
+    VcfKept k; k.chr.assign(fs[0], fl[0]);
+    if (!is_snp && iq_threshold > 0) {                                     // :325-340, before the multi-allele check
+        const std::string qs(fs[5], fl[5]);
+        float qual = 0.0f; bool missing = qs == ".";
+        if (!missing) { try { qual = std::stof(qs); } catch (...) { qual = 0.0f; missing = true; } }
+        if (qual < (float)iq_threshold) {
+            const char *c = (const char *)memchr(alt, ',', al);
+            k.kind = 3; k.pos = std::stoi(std::string(fs[1], fl[1])) - 1;
+            k.text = k.chr + "\t" + std::string(fs[1], fl[1]) + "\t" + std::string(ref, rl) + "\t" + std::string(alt, c ? (size_t)(c - alt) : al) + "\t" + (missing ? std::string(".") : std::to_string(qual)) + "\n";
+            out.push_back(std::move(k));
+            return;
         }
+    }
+    if (unusable) return;
+    k.kind = 2; k.pos = std::stoi(std::string(fs[1], fl[1])) - 1; k.ref.assign(ref, rl); k.alt.assign(alt, al);
+    out.push_back(std::move(k));
+}
+static void parse_vcf(const std::vector<std::string> &lines, bool indels, std::vector<std::string> &chr_order, std::map<std::string, ChrVariants> &out, IndelQual *iq = nullptr, int threads = 1) {
+    const int iq_threshold = iq ? iq->threshold : 0;
+    const size_t n = lines.size();
+    const int T = (int)std::max<size_t>(1, std::min<size_t>({(size_t)std::max(1, threads), (size_t)16, n / 20000 + 1}));
+    std::vector<std::vector<VcfKept>> kept((size_t)T);
+    auto slice = [&](int t) { const size_t a = n * (size_t)t / (size_t)T, b = n * (size_t)(t + 1) / (size_t)T; kept[(size_t)t].reserve((b - a) / 2 + 16);
+        for (size_t i = a; i < b; ++i) parse_vcf_line(lines[i], indels, iq_threshold, kept[(size_t)t]); };
+    { std::vector<std::thread> th; for (int t = 1; t < T; ++t) th.emplace_back(slice, t); slice(0); for (auto &x : th) x.join(); }
+    // in line order: contigs in order of first mention, the rows of a contig with their line number (the later record at one position wins)
+    struct Row { int32_t pos; uint32_t seq; VcfKept *k; };
+    std::map<std::string, std::vector<Row>> rows; uint32_t seq = 0;
+    std::string last_chr; std::vector<Row> *last = nullptr;
+    for (auto &part : kept) for (VcfKept &k : part) {
+        if (k.kind == 4) die(k.text);
+        if (k.kind == 3) { if (iq->log.is_open()) iq->log << k.text; iq->filtered[k.chr].insert(k.pos); continue; }
+        if (!last || k.chr != last_chr) { if (!out.count(k.chr)) { out[k.chr]; chr_order.push_back(k.chr); } last = &rows[k.chr]; last_chr = k.chr; }
+        if (k.kind == 2) last->push_back(Row{k.pos, seq++, &k});
+    }
+    for (auto &kv : rows) {
+        std::vector<Row> &r = kv.second; ChrVariants &cv = out[kv.first];
+        if (!std::is_sorted(r.begin(), r.end(), [](const Row &a, const Row &b) { return a.pos < b.pos; }))
+            std::sort(r.begin(), r.end(), [](const Row &a, const Row &b) { return a.pos != b.pos ? a.pos < b.pos : a.seq < b.seq; });
+        cv.pos.reserve(r.size()); cv.ref.reserve(r.size()); cv.alt.reserve(r.size());
+        for (size_t i = 0; i < r.size(); ++i) {
+            if (i + 1 < r.size() && r[i + 1].pos == r[i].pos) continue;    // a later record at the same position replaces this one
+            cv.pos.push_back(r[i].pos); cv.ref.push_back(std::move(r[i].k->ref)); cv.alt.push_back(std::move(r[i].k->alt));
+        }
+    }
 }
 
 static void read_fasta(const std::string &path, const std::map<std::string, ChrVariants> &want, std::map<std::string, std::string> &seqs) {

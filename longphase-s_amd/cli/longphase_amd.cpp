@@ -108,10 +108,20 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     over.push_back([ont](lps_params &P) { P.is_ont = ont; });
 
     Lps L; lps_ctx *ctx = nullptr;
-    std::thread gpu_init([&] { if (!L.load()) return; lps_params P; L.default_params(&P); for (auto &f : over) f(P); ctx = L.create(gpu, &P); if (!ctx) L.error = "cannot create a GPU context (no CPU fallback)"; else L.set_stage_timing(ctx, 0); });
-    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{gpu_init};
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_begin = now();
+    const double t_begin = now(); double t_lib = 0, t_ctx_ready = 0;
+    std::thread gpu_init([&] { if (!L.load()) return; t_lib = now(); lps_params P; L.default_params(&P); for (auto &f : over) f(P); ctx = L.create(gpu, &P); if (!ctx) L.error = "cannot create a GPU context (no CPU fallback)"; else L.set_stage_timing(ctx, 0); t_ctx_ready = now(); });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{gpu_init};
+    // One BAM large enough for the GPU path is opened NOW: when the whole file is one contig group anyway (or has no index), its BGZF headers are
+    // walked on helper threads beside the VCF parse and the HIP start-up - host-only code compiled into this program (cli_bam.h, csrc/lps_bgzf_walk.h),
+    // so the walk waits neither for the library nor for the list of wanted contigs, and the first load finds its table made.
+    GpuBam gb;
+    if (!host_inflate && !gpu_inflate && bams.size() == 1) host_inflate = file_bytes(bams[0]) < kGpuInflateMinBytes;
+    // small file: zlib on the host overlaps the GPU start-up
+    if (bams.size() == 1 && !host_inflate) {
+        gb.open_file(bams[0], !no_index);
+        if (n_gpus == 1 && workers_per_gpu == 1 && (!gb.indexed || (uint64_t)gb.fsz <= group_bytes)) gb.walk_whole_file();
+    }
     std::vector<std::string> vcf_lines;
     if (!read_lines(snp, vcf_lines)) die("ERROR: Cannot open vcf file " + snp);
     if (deepsomatic) {                                                  // PhasingProcess.cpp:47-61: the filtered, re-genotyped copy IS the SNP file from here on
@@ -123,7 +133,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::vector<std::string> chr_order; std::map<std::string, ChrVariants> vars;
     IndelQual iq;
     if (indels && indel_quality > 0) { iq.threshold = indel_quality; iq.log.open(prefix + "_removed_indels.log"); if (iq.log.is_open()) iq.log << "#CHROM\tPOS\tREF\tALT\tQUAL\n"; }
-    parse_vcf(vcf_lines, indels, chr_order, vars, &iq);
+    parse_vcf(vcf_lines, indels, chr_order, vars, &iq, threads);
     if (iq.log.is_open()) iq.log.close();
     // SV rows, then MOD rows: each reader drops what sits on a row of the tables read before it (PhasingProcess.cpp:69-79)
     std::vector<std::string> sv_lines, mod_lines; SvTable svt; ModTable modt;
@@ -137,17 +147,13 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     std::once_flag fasta_once; auto need_fasta = [&] { std::call_once(fasta_once, [&] { fasta_thread.join(); }); };
     const double t_text = now();
     // one BAM: BGZF inflate, record discovery and record decode all run on the GPU; several BAMs (or --host-inflate): zlib on `-t` host threads
-    if (!host_inflate && !gpu_inflate && bams.size() == 1) host_inflate = file_bytes(bams[0]) < kGpuInflateMinBytes;
-    // small file: zlib on the host overlaps the GPU start-up
     const bool gpu_input = bams.size() == 1 && !host_inflate;
     std::vector<BamFile> files(gpu_input ? 0 : bams.size());
     for (size_t b = 0; b < files.size(); ++b) files[b].load(bams[b], threads, want);
     const double t_bam = now();
     // with a .bai next to the BAM only the blocks of one contig are resident at a time (any file size, per-contig sharding); without, the whole file.
     // The BGZF header walk of the first load needs no GPU: it runs on a helper thread while the HIP runtime is still coming up
-    GpuBam gb;
     if (gpu_input) {
-        gb.open_file(bams[0], !no_index);
         if (!gb.indexed) gb.walk_ahead(L, 0, gb.fsz);
         else if (n_gpus == 1 && workers_per_gpu == 1) {
             std::vector<std::string> list; for (const std::string &c : chr_order) if (want.count(c)) list.push_back(c);
@@ -202,7 +208,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
                               std::lock_guard<std::mutex> lk(a->m); a->done = true; a->cv.notify_all(); } }); }     // (notified under the lock: the waiter may destroy *a as soon as it sees done)
                       ~RankPool() { for (auto &t : th) if (t.joinable()) t.join(); } };                              // joins on every way out of the scope, an exception included
     std::map<lps_ctx *, std::map<std::string, std::unique_ptr<NamesAhead>>> ahead; std::mutex ahead_mu;
-    static std::atomic<long long> ns_names{0}, ns_rank{0}, ns_setup{0}, ns_push{0}, ns_phase{0}, ns_merge{0};      // where a contig's host time goes (LPS_CLI_DEBUG)
+    static std::atomic<long long> ns_names{0}, ns_rank{0}, ns_setup{0}, ns_push{0}, ns_phase{0}, ns_merge{0}, ns_result{0};      // where a contig's host time goes (LPS_CLI_DEBUG)
     auto tick_ns = [] { return std::chrono::steady_clock::now(); };
     auto tock_ns = [](std::atomic<long long> &acc,
             std::chrono::steady_clock::time_point t0) { acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
@@ -298,8 +304,9 @@ static int phase_main(int argc, char **argv, const std::string &command) {
                 d << "}\n";
             }
         }
+        tock_ns(ns_merge, t_st); t_st = tick_ns();                     // (ns_merge: --dot)
         std::map<int32_t, Phased> rc;
-        for (size_t i = 0; i < cv.pos.size(); ++i) if (ps[i]) rc[cv.pos[i]] = Phased{ps[i], gt[i] ? '1' : '0', gt[i] ? '0' : '1'};
+        for (size_t i = 0; i < cv.pos.size(); ++i) if (ps[i]) rc.emplace_hint(rc.end(), cv.pos[i], Phased{ps[i], gt[i] ? '1' : '0', gt[i] ? '0' : '1'});   // (positions ascend: appended)
         if (xr.any()) {                                              // the reference keeps ONE result map keyed by position for all three files
             std::vector<int32_t> sps(xr.sv_pos.size()), mps(xr.mod_pos.size()); std::vector<uint8_t> sgt(xr.sv_pos.size()), mgt(xr.mod_pos.size());
             lps_phase_result rs{(int64_t)sps.size(), sps.data(), sgt.data()}, rm{(int64_t)mps.size(), mps.data(), mgt.data()};
@@ -308,6 +315,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
             for (size_t i = 0; i < mps.size(); ++i) if (mps[i]) rc[xr.mod_pos[i]] = Phased{mps[i], mgt[i] ? '1' : '0', mgt[i] ? '0' : '1'};
         }
         { std::lock_guard<std::mutex> lk(res_mu); res[chr].swap(rc); std::cerr << "(" << chr << ")"; }
+        tock_ns(ns_result, t_st);
     };
     // contigs never interact: with --gpus N and an indexed BAM they are dealt longest-first onto N contexts, one host thread + one
     // GPU each, every worker uploading only the BGZF blocks of its own contigs.  No data-path collective; results meet in the VCF writer.
@@ -343,6 +351,7 @@ static int phase_main(int argc, char **argv, const std::string &command) {
             g.load_group(L, cx, grp);
             if (gi + 1 < groups.size()) g.walk_group_ahead(L, groups[gi + 1]);       // the next group's header walk beside this group's contigs
             RankPool pool;                                                // (declared before the contig loop: joined when the group is done or on a throw)
+            const double tn0 = now();
             if (files.empty()) {                                          // one BAM: all names of a contig are the GPU's
                 std::map<std::string, std::unique_ptr<NamesAhead>> mine;
                 for (const std::string &c : grp) { auto it = g.range.find(c); if (it == g.range.end() || !vars.count(c) || vars[c].pos.empty()) continue;
@@ -353,7 +362,9 @@ static int phase_main(int argc, char **argv, const std::string &command) {
                 { std::lock_guard<std::mutex> lk(ahead_mu); ahead[cx] = std::move(mine); }
                 pool.start((int)std::min<size_t>((size_t)std::max(1, threads), pool.items.size()));
             }
+            const double tn1 = now();
             for (const std::string &c : grp) run_contig(cx, g, c, tab);
+            if (getenv("LPS_CLI_DEBUG")) fprintf(stderr, "[cli] group of %zu contigs: names off the GPU %.3f s, contig loop %.3f s\n", grp.size(), tn1 - tn0, now() - tn1);
             for (auto &t : pool.th) if (t.joinable()) t.join();            // (every item has been ranked: each contig waited for its own)
             { std::lock_guard<std::mutex> lk(ahead_mu); ahead.erase(cx); }
         }
@@ -398,17 +409,22 @@ static int phase_main(int argc, char **argv, const std::string &command) {
     for (lps_comm *cm : comms) if (cm) L.comm_destroy(cm);
     std::cerr << "\n";
     need_fasta();
-    L.destroy(ctx);        // (25 ms.  Left to the process exit, the driver gives the device memory back from a work queue AFTER the exit - and the next process on the GPU pays for it)
+    // the context is given back beside the VCF writer (25 ms for the buffers of a 12 GB group.  Left to the process exit, the driver gives the device
+    // memory back from a work queue AFTER the exit - and the next process on the GPU pays for it)
+    std::thread destroyer([&] { L.destroy(ctx); });
+    struct JoinD { std::thread &t; ~JoinD() { if (t.joinable()) t.join(); } } join_destroyer{destroyer};
     const double t_gpu = now();
     write_vcf(vcf_lines, prefix + ".vcf", res, vars, command, &iq);
     if (!sv_file.empty()) write_sv_vcf(sv_lines, prefix + "_SV.vcf", res, svt, command);          // PhasingProcess.cpp:191-203
     if (!mod_file.empty()) write_mod_vcf(mod_lines, prefix + "_mod.vcf", res, modt, command);
+    destroyer.join();
     if (gpu_input) fprintf(stderr, "%s | vcf read (fasta beside the gpu start-up) %.3fs | wait for gpu context %.3fs | map bam+header%s %.3fs | upload+gpu inflate %.3fs | gpu record scan %.3fs | names+decode+phase %.3fs | write vcf %.3fs | total %.3fs\n",
-                           gb.indexed ? "contig groups (indexed)" : "whole file", t_text - t_begin, t_ctx - t_bam, gb.indexed ? "+index" : "", gb.t_map, gb.t_inflate, gb.t_scan,
+                           gb.indexed ? "contig groups (indexed)" : "whole file", t_text - t_begin - gb.t_map, t_ctx - t_bam, gb.indexed ? "+index" : "", gb.t_map, gb.t_inflate, gb.t_scan,
                            t_gpu - t_gin - (gb.indexed ? gb.t_inflate + gb.t_scan : 0.0), now() - t_gpu, now() - t_begin);
     else fprintf(stderr, "vcf+fasta read %.3fs | bam inflate+walk %.3fs | wait for gpu context %.3fs | upload+phase %.3fs | write vcf %.3fs | total %.3fs\n", t_text - t_begin,
                  t_bam - t_text, t_ctx - t_bam, t_gpu - t_ctx, now() - t_gpu, now() - t_begin);
-    if (getenv("LPS_CLI_DEBUG")) fprintf(stderr, "[cli] per-contig host time summed: names %.3fs, ranks %.3fs, table + reference %.3fs, push %.3fs, phase %.3fs\n", ns_names / 1e9, ns_rank / 1e9, ns_setup / 1e9, ns_push / 1e9, ns_phase / 1e9);
+    if (getenv("LPS_CLI_DEBUG")) fprintf(stderr, "[cli] per-contig host time summed: names %.3fs, ranks %.3fs, table + reference %.3fs, push %.3fs, phase %.3fs, result map %.3fs\n", ns_names / 1e9, ns_rank / 1e9, ns_setup / 1e9, ns_push / 1e9, ns_phase / 1e9, ns_result / 1e9);
+    if (getenv("LPS_CLI_DEBUG")) fprintf(stderr, "[cli] start-up: library loaded after %.3f s, gpu context ready after %.3f s, text inputs parsed after %.3f s\n", t_lib - t_begin, t_ctx_ready - t_begin, t_text - t_begin);
     if (getenv("LPS_CLI_DEBUG")) fprintf(stderr, "[cli] main entered at %.3f, left at %.3f (epoch seconds: what the caller's clock shows before and after is start-up and exit)\n", g_main_entered, epoch_now());
     fflush(stderr);
     if (getenv("LPS_CLI_NO_FAST_EXIT")) return 0;                       // e.g. under a profiler that writes its report from an exit handler
@@ -1654,6 +1670,21 @@ static int view_main(int argc, char **argv) {
     return 0;
 }
 
+// the SNP table `phase` makes of a VCF, as text (no GPU; tests/test_cli_cpu.py holds the threaded parser against a line-by-line restatement):
+//   longphase_amd vcf-table <in.vcf[.gz]> <threads> [--indels] [--indelQuality=N]
+static int vcf_table_main(int argc, char **argv) {
+    if (argc < 4) die("Usage: longphase_amd vcf-table <in.vcf> <threads> [--indels] [--indelQuality=N]");
+    bool indels = false; IndelQual iq;
+    for (int i = 4; i < argc; ++i) { const std::string a = argv[i]; if (a == "--indels") indels = true; else if (a.rfind("--indelQuality=", 0) == 0) iq.threshold = atoi(a.c_str() + 15); }
+    std::vector<std::string> lines; if (!read_lines(argv[2], lines)) die(std::string("ERROR: Cannot open vcf file ") + argv[2]);
+    std::vector<std::string> order; std::map<std::string, ChrVariants> vars;
+    parse_vcf(lines, indels, order, vars, &iq, atoi(argv[3]));
+    for (const std::string &c : order) { const ChrVariants &v = vars[c]; std::cout << "#" << c << "\t" << v.pos.size() << "\n";
+        for (size_t i = 0; i < v.pos.size(); ++i) std::cout << c << "\t" << v.pos[i] << "\t" << v.ref[i] << "\t" << v.alt[i] << "\n"; }
+    for (auto &kv : iq.filtered) for (int32_t p : kv.second) std::cout << "!" << kv.first << "\t" << p << "\n";
+    return 0;
+}
+
 int main(int argc, char **argv) {
     g_main_entered = epoch_now();
     std::string command; for (int i = 0; i < argc; ++i) { if (i) command += " "; command += argv[i]; }
@@ -1663,6 +1694,7 @@ int main(int argc, char **argv) {
     const std::string cmd = argv[1];
     if (cmd == "phase") return phase_main(argc, argv, command);
     if (cmd == "view") return view_main(argc, argv);
+    if (cmd == "vcf-table") return vcf_table_main(argc, argv);
     if (cmd == "haplotag") return haplotag_main(argc, argv, command);
     if (cmd == "somatic_haplotag") return somatic_main(argc, argv, command);
     std::cerr << "Unrecognized command: " << cmd << "\n"; return 1;

@@ -24,6 +24,7 @@
 #include "lps_graph.h"
 #include "lps_bam.h"
 #include "lps_inflate.h"
+#include "lps_bgzf_walk.h"
 #include "lps_deflate.h"
 #include "lps_stdsort.h"
 
@@ -138,19 +139,7 @@ static int fail(lps_ctx *c, const std::string &m, int code = -1) { if (c) c->err
 // pinned 2 x 64 MiB ring while the DMA engine drains the other half.
 // Where a large upload takes its bytes from: memory, or a file read with pread straight into the page-locked pieces (no mapping of the file: an 8 GB
 // mapping costs two million page-table entries to set up while it is copied and 0.14 s to tear down when the process ends).
-struct ZSource {
-    const uint8_t *mem = nullptr; int fd = -1; uint64_t base = 0;
-    bool read(uint64_t pos, size_t len, uint8_t *dst) const {
-        if (mem) { memcpy(dst, mem + pos, len); return true; }
-        while (len) {
-            const ssize_t r = pread(fd, dst, len, (off_t)(base + pos));
-            if (r < 0 && errno == EINTR) continue;
-            if (r <= 0) return false;
-            dst += r; pos += (uint64_t)r; len -= (size_t)r;
-        }
-        return true;
-    }
-};
+// (ZSource: lps_bgzf_walk.h)
 // `mark` (optional): a word in PAGE-LOCKED HOST memory that this (host) thread raises to the number of bytes known to be in place - after the event of
 // a piece has been waited for, i.e. two pieces late, and n at the end.  It is what a kernel launched beside the upload polls (k_bgzf_inflate): host
 // memory, because a word in device memory written by the copy engine would sit stale in the polling XCD's L2 until the next kernel boundary.
@@ -714,84 +703,7 @@ int lps_push_bam_resident(lps_ctx *c, int64_t first, int64_t count, const uint32
     return 0;
 }
 
-// One BGZF block header (18 bytes + extra subfields; RFC 1952 member with the BC subfield, SAM spec 4.1) in h[0, avail) = the file's bytes from p on
-// -> BSIZE; 0 when it is none; ~0 when the extra field reaches beyond `avail` (the caller reads more)
-static inline uint64_t bgzf_parse_header(const uint8_t *h, size_t avail, uint64_t p, uint64_t n, unsigned &xlen) {
-    if (avail < 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return 0;
-    xlen = h[10] | (h[11] << 8);
-    if (12ull + xlen > avail) return p + 12ull + xlen > n ? 0 : ~0ull;
-    uint64_t q = 12, bsize = 0;
-    while (q + 4 <= 12ull + xlen) {
-        const unsigned slen = h[q + 2] | (h[q + 3] << 8);
-        if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2 && q + 6 <= 12ull + xlen) bsize = (uint64_t)(h[q + 4] | (h[q + 5] << 8)) + 1;
-        q += 4 + slen;
-    }
-    if (!bsize || bsize < 12ull + xlen + 8 || p + bsize > n) return 0;
-    return bsize;
-}
-// The block table of [from, to): false when a header is bad, a block is larger than 64 KiB, the source cannot be read or the chain does not land on
-// `to` exactly.  out_off is relative to the piece's first block (utot = the piece's inflated size).  One read per block: the ISIZE at a block's end
-// and the header behind it come together.
-static bool bgzf_walk_piece(const ZSource &z, uint64_t n, uint64_t from, uint64_t to, std::vector<InflateBlock> &blks, uint64_t &utot, uint64_t *bad_at = nullptr) {
-    uint64_t p = from; utot = 0; uint8_t h[64], t[68]; size_t have = 0; std::vector<uint8_t> wide;
-    while (p < to) {
-        if (bad_at) *bad_at = p;
-        const size_t want = (size_t)std::min<uint64_t>(sizeof h, n - p);
-        if (have < want) { if (!z.read(p + have, want - have, h + have)) return false; have = want; }
-        unsigned xlen = 0; uint64_t bsize = bgzf_parse_header(h, have, p, n, xlen);
-        if (bsize == ~0ull) { wide.resize(12 + (size_t)xlen); if (!z.read(p, wide.size(), wide.data())) return false; bsize = bgzf_parse_header(wide.data(), wide.size(), p, n, xlen); }
-        if (!bsize || bsize == ~0ull) return false;
-        const size_t tl = (size_t)std::min<uint64_t>(sizeof t, n - (p + bsize - 4));
-        if (!z.read(p + bsize - 4, tl, t)) return false;
-        const uint64_t isize = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
-        if (isize > 65536) return false;
-        blks.push_back(InflateBlock{p + 12 + xlen, utot, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize});
-        utot += isize; p += bsize;
-        have = tl - 4; memcpy(h, t + 4, have);
-    }
-    return p == to;
-}
-// The header walk is latency, not bytes (one small read per 20 - 30 KB block; 0.2 s for 8 GB on one thread): T threads take a piece each.  A piece
-// starts at the first position behind k * n / T where FOUR block headers follow one another; the piece before it must end exactly there, otherwise
-// (and whenever anything else looks wrong) the caller walks the file serially.
-static bool bgzf_walk_parallel(const ZSource &z, uint64_t n, std::vector<InflateBlock> &blks, uint64_t &utot) {
-    // pieces walked side by side: the walk is one small read per 20 - 30 KB block - latency, not bytes - and it runs beside the GPU start-up, which it
-    // must not outlast (8 pieces took 0.2 s for 12 GB: longer than the rest of the start-up)
-    const int T = (int)std::max(8u, std::min(32u, std::thread::hardware_concurrency() / 2u));
-    if (n < (64ull << 20)) return false;
-    std::vector<uint64_t> seed((size_t)T + 1, 0); seed[(size_t)T] = n;
-    std::vector<uint8_t> win((1u << 20) + 64);
-    for (int k = 1; k < T; ++k) {
-        const uint64_t w0 = n * (uint64_t)k / T; const size_t wl = (size_t)std::min<uint64_t>(win.size(), n - w0);
-        if (!z.read(w0, wl, win.data())) return false;
-        uint64_t found = 0;
-        for (size_t i = 0; i + 18 <= wl && i < (1u << 20) && !found; ++i) {
-            if (win[i] != 31 || win[i + 1] != 139 || win[i + 2] != 8 || !(win[i + 3] & 4)) continue;
-            uint64_t q = w0 + i; int chain = 0; uint8_t h[64];
-            for (; chain < 4 && q < n; ++chain) {
-                const size_t hl = (size_t)std::min<uint64_t>(sizeof h, n - q); unsigned xl = 0;
-                if (!z.read(q, hl, h)) return false;
-                const uint64_t b = bgzf_parse_header(h, hl, q, n, xl);
-                if (!b || b == ~0ull) break;
-                q += b;
-            }
-            if (chain == 4 || (chain > 0 && q == n)) found = w0 + i;
-        }
-        if (!found) return false;
-        seed[(size_t)k] = found;
-    }
-    std::vector<std::vector<InflateBlock>> part((size_t)T); std::vector<uint64_t> ut((size_t)T, 0); std::vector<char> ok((size_t)T, 0); std::vector<std::thread> th;
-    for (int k = 0; k < T; ++k) th.emplace_back([&,
-            k] { part[(size_t)k].reserve((size_t)((seed[(size_t)k + 1] - seed[(size_t)k]) / 16384 + 16)); ok[(size_t)k] = bgzf_walk_piece(z, n, seed[(size_t)k],
-            seed[(size_t)k + 1], part[(size_t)k], ut[(size_t)k]); });
-    for (auto &t : th) t.join();
-    size_t total = 0;
-    for (int k = 0; k < T; ++k) { if (!ok[(size_t)k]) return false; total += part[(size_t)k].size(); }
-    blks.clear(); blks.reserve(total); utot = 0;
-    for (int k = 0; k < T; ++k) { for (InflateBlock b : part[(size_t)k]) { b.out_off += utot; blks.push_back(b); } utot += ut[(size_t)k]; }
-    return true;
-}
-
+// (the header walk itself - bgzf_parse_header, bgzf_walk_piece, bgzf_walk_parallel - is host-only code shared with the command line: lps_bgzf_walk.h)
 static int bgzf_load_source(lps_ctx *c, const ZSource &src, int64_t n_bytes, int64_t *inflated_bytes, const InflateBlock *table = nullptr, int64_t n_table = 0);
 static_assert(sizeof(lps_bgzf_block) == sizeof(InflateBlock) && offsetof(lps_bgzf_block, in_len) == offsetof(InflateBlock, in_len), "lps_bgzf_block is the kernel's block record");
 // host only: needs no GPU and no context (a caller can walk the file while the HIP runtime is still coming up)
@@ -874,7 +786,7 @@ static int bgzf_load_source(lps_ctx *c, const ZSource &src, int64_t n_bytes, int
             // 50 ms of upload).  Launched earlier - the table may have been walked long before - every resident wavefront sits waiting, and the
             // upload beside them ran at half its rate (measured: 0.37 - 0.40 s instead of 0.20 s for 8.26 GB, on some boxes three times that).
             const char *fr_env = getenv("LPS_BGZF_TEST_FIRST_ROUND");                      // test hook: members the launch waits for
-            const size_t fr = fr_env ? (size_t)std::max(1, atoi(fr_env)) : 65536;
+            const size_t fr = fr_env ? (size_t)std::max(1, atoi(fr_env)) : 16384;
             const unsigned long long first_round = blks.size() > fr ? blks[fr].in_off : n;
             while (__atomic_load_n(c->up_mark, __ATOMIC_ACQUIRE) < first_round) usleep(200);
         }

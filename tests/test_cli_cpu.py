@@ -69,3 +69,119 @@ def test_deepsomatic_preprocessing_matches_reference(tmp_path):
     subprocess.run([CLI, "phase", "-s", "ds.vcf", "-b", "r.bam", "-r", os.path.join(DATA, "tiny_snp.fa"), "-o", "o", "--ont", "--deepsomatic_output"],
                    cwd=d, capture_output=True, text=True, timeout=120)
     assert open(d + "/o_preprocessed.vcf").read() == gzip.open(os.path.join(DATA, "cli_deepsomatic.out_preprocessed.vcf.gz"), "rt").read()
+
+
+def _snp_table_by_the_book(text, indels, iq):
+    """The SNP table of `phase` restated line by line (SnpParser::SnpParser, src/phase/ParsingBam.cpp:222-359): het bi-allelic SNPs, with --indels every
+    other het bi-allelic record, the later record at one position wins, contigs in order of first mention (##contig lines count)."""
+    order, rows, dropped = [], {}, {}
+    for ln in text.split("\n"):
+        if not ln:
+            continue
+        if ln[0] == "#":
+            if ln.startswith("##contig=<ID="):
+                c = ln[13:].split(",")[0].split(">")[0]
+                if c not in rows:
+                    rows[c] = {}; order.append(c)
+            continue
+        f = ln.split("\t")
+        if len(f) < 10:
+            continue
+        ref, alt = f[3], f[4]
+        unusable = "," in alt or alt == "" or alt[0] == "<" or alt in (".", "*")
+        is_snp = len(ref) == 1 and len(alt) == 1
+        if not (iq > 0 and indels) and (unusable or (not is_snp and not indels)):
+            continue
+        if unusable and "," in alt and len(ref) == 1 and all(len(a) == 1 for a in alt.split(",")):
+            continue
+        if not is_snp and not indels:
+            continue
+        fmt, smp = f[8].split(":"), f[9].split(":")
+        if fmt and fmt[-1] == "":
+            fmt.pop()
+        if smp and smp[-1] == "":
+            smp.pop()
+        gi = fmt.index("GT") if "GT" in fmt else len(fmt)
+        if gi >= len(fmt) or gi >= len(smp):
+            return None
+        if smp[gi] not in ("0/1", "1/0", "0|1", "1|0"):
+            continue
+        if not is_snp and iq > 0:
+            try:
+                q = float(f[5]) if f[5] != "." else 0.0
+            except ValueError:
+                q = 0.0
+            if q < iq:
+                dropped.setdefault(f[0], set()).add(int(f[1]) - 1)
+                continue
+        if unusable:
+            continue
+        if f[0] not in rows:
+            rows[f[0]] = {}; order.append(f[0])
+        rows[f[0]][int(f[1]) - 1] = (ref, alt)
+    return order, rows, dropped
+
+
+@pytest.mark.parametrize("indels,iq", [(False, 0), (True, 0), (True, 20)])
+def test_threaded_vcf_parser_makes_the_table_one_thread_would(tmp_path, indels, iq):
+    """40 000 generated records over three contigs (one without a ##contig line, one listed and empty): SNPs, indels, multi-allelic rows, symbolic and
+    '*' alleles, homozygous and phased genotypes, GT not first in FORMAT, a trailing ':' in FORMAT, short lines, duplicate positions (the later record
+    wins), an unsorted stretch - parsed on 1, 3 and 16 threads; every table must be the line-by-line restatement's."""
+    import random
+    rng = random.Random(17)
+    head = ["##fileformat=VCFv4.2", "##contig=<ID=chrA,length=9000000>", "##contig=<ID=chrEmpty,length=5>", "##contig=<ID=chrB>", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS"]
+    body = []
+    for c in ("chrA", "chrB", "chrLate"):
+        pos = 100
+        for i in range(13_400):
+            pos += rng.choice([0, 1, 1, 7, 200, 900]) if i % 50 else -rng.randrange(0, 3000) * (i % 1000 == 0)
+            pos = max(pos, 1)
+            kind = rng.random()
+            ref = rng.choice("ACGT"); alt = rng.choice([b for b in "ACGT" if b != ref])
+            if kind < 0.15:
+                ref, alt = (ref + "ACG"[: rng.randrange(1, 4)], ref) if rng.random() < 0.5 else (ref, ref + "TTG"[: rng.randrange(1, 4)])
+            elif kind < 0.20:
+                alt = alt + "," + rng.choice(["A", "GT", "*"])
+            elif kind < 0.23:
+                alt = rng.choice(["<DEL>", ".", "*", ""])
+            gt = rng.choice(["0/1", "0/1", "1/0", "0|1", "1|0", "1/1", "0/0", "./.", "1|2", "0/1/1"])
+            fmt, smp = rng.choice([("GT:GQ", gt + ":30"), ("GQ:GT", "30:" + gt), ("GT", gt), ("GT:", gt + ":"), ("GT:AD:", gt + ":3,4")])
+            qual = rng.choice([".", "3", "19.99", "20", "55.5", "x"])
+            ln = f"{c}\t{pos}\t.\t{ref}\t{alt}\t{qual}\tPASS\t.\t{fmt}\t{smp}"
+            if rng.random() < 0.002:
+                ln = "\t".join(ln.split("\t")[:8])
+            body.append(ln)
+    text = "\n".join(head + body) + "\n"
+    p = tmp_path / "in.vcf"; p.write_text(text)
+    gz = tmp_path / "in.vcf.gz"
+    with gzip.open(gz, "wt") as f:
+        f.write(text)
+    want = _snp_table_by_the_book(text, indels, iq)
+    assert want is not None and sum(len(v) for v in want[1].values()) > 5000 and "chrEmpty" in want[0]
+    if indels and iq:
+        assert sum(len(v) for v in want[2].values()) > 100
+    outs = []
+    for path, threads in ((p, 1), (p, 3), (gz, 16)):
+        args = [CLI, "vcf-table", str(path), str(threads)] + (["--indels"] if indels else []) + ([f"--indelQuality={iq}"] if iq else [])
+        r = subprocess.run(args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-300:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == outs[2]
+    order, rows, dropped = [], {}, {}
+    for ln in outs[0].splitlines():
+        f = ln.split("\t")
+        if ln[0] == "#":
+            order.append(f[0][1:]); rows[f[0][1:]] = {}
+        elif ln[0] == "!":
+            dropped.setdefault(f[0][1:], set()).add(int(f[1]))
+        else:
+            assert int(f[1]) not in rows[f[0]] and (not rows[f[0]] or int(f[1]) > max(rows[f[0]]))      # one row per position, ascending
+            rows[f[0]][int(f[1])] = (f[2], f[3])
+    assert order == want[0] and rows == want[1] and dropped == want[2]
+
+
+def test_vcf_record_without_gt_stops_the_run(tmp_path):
+    p = tmp_path / "in.vcf"
+    p.write_text("##contig=<ID=c>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\nc\t5\t.\tA\tC\t.\t.\t.\tGQ\t30\n")
+    r = subprocess.run([CLI, "vcf-table", str(p), "2"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "pos 5 missing GT value" in r.stderr
