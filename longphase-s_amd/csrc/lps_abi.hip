@@ -1614,7 +1614,7 @@ int lps_somatic_extract_tumor(lps_ctx *c, lps_tumor_extract_result *out) {
         c->t_hp.reserve(nR); c->t_has.reserve(nR); c->t_end.reserve(nR); c->t_len.reserve(nR); c->t_ctr.reserve(4);
         c->t_pair_site.reserve(pc); c->t_pair_read.reserve(pc); c->t_pair_hp.reserve(pc);
         c->t_win_site.reserve(wc); c->t_win_allele.reserve(wc); c->t_win_off.reserve(wc); c->t_win_base.reserve(wc);
-        c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1);
+        c->v_bucket.reserve((size_t)(((long long)c->last_pos + 1) >> LPS_BUCKET_SHIFT) + 8); c->v_rec.reserve((size_t)nV + 1); c->r_v0.reserve((size_t)nR + 1);
         // The two lists the passes append to - (site, read, base HP) pairs and window hits (alignment x TUMOR row) - live in LPS_TARENAS arenas each
         // (lps_kernels.h).  They start at two entries per alignment - a tumor VCF holds the somatic sites, an alignment meets one or none - and when
         // an arena turns out too short the passes run again with what the fullest one needs; the size sticks to the context (the per-slot kernels
@@ -1623,6 +1623,7 @@ int lps_somatic_extract_tumor(lps_ctx *c, lps_tumor_extract_result *out) {
         if (c->t_pair_arena < want) c->t_pair_arena = want;
         if (c->t_hit_arena < want) c->t_hit_arena = want;
         unsigned long long tot[4] = {0, 0, 0, 0}; uint32_t n_win = 0;
+        bool general = false;                                             // the passes on the per-op-prefix walker: after the stream walk met a record outside its arithmetic
         for (int attempt = 0; attempt < 3; ++attempt) {
             const size_t pa = c->t_pair_arena, ha = c->t_hit_arena, hc = ha * LPS_TARENAS, ipc = pa * LPS_TARENAS;
             if (2 * hc + 1 > 0xfffffff0ull) return fail(c, "somatic extraction: more than 2^31 window hits");
@@ -1637,7 +1638,7 @@ int lps_somatic_extract_tumor(lps_ctx *c, lps_tumor_extract_result *out) {
             VarView V = var_view(c); ReadView R = read_view(c);
             for (auto &u : c->ev_used) u = false;
             mark(c, ST_PREP);
-            if (nV) launch_variant_prep(V, 0, c->v_bucket.p, c->v_rec.p, s);
+            if (nV) launch_variant_prep(V, 0, c->v_bucket.p, c->v_rec.p, s, R.ref_start, R.n, c->r_v0.p);
             mark(c, ST_EXTRACT);
             TumOut T{};
             T.site = c->site.p; T.status = c->hap_status.p; T.hp1 = c->hap_h1.p; T.hp2 = c->hap_h2.p; T.hp3 = c->hap_h3.p; T.hp = c->t_hp.p; T.n_ps = c->hap_nps.p; T.ps_min = c->hap_psmin.p;
@@ -1648,14 +1649,18 @@ int lps_somatic_extract_tumor(lps_ctx *c, lps_tumor_extract_result *out) {
             T.pair_site = c->t_pair_site.p; T.pair_read = c->t_pair_read.p; T.pair_hp = c->t_pair_hp.p;
             T.win_site = c->t_win_site.p; T.win_allele = c->t_win_allele.p; T.win_offset = c->t_win_off.p; T.win_base = c->t_win_base.p; T.pct_thr = c->P.percentage_threshold;
             T.hits = c->t_hits.p; T.hit_rp = c->t_hit_rp.p; T.win_cnt = c->t_win_cnt.p; T.win_at = c->t_win_at.p;
-            launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 0, c->d_cnt, s);
+            launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 0, c->d_cnt, s, general);
             launch_tumor_windows(V, R, T, c->temp.p, c->temp_bytes, s);
-            launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 1, c->d_cnt, s);
+            launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 1, c->d_cnt, s, general);
             launch_tumor_pairs_out(T, s);
             mark(c, ST_D2H);
+            unsigned walk_err = 0;
             HIP_TRY(hipMemcpyAsync(tot, T.tot, sizeof tot, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(&n_win, c->t_win_at.p + 2 * hc, sizeof n_win, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(&walk_err, &c->d_cnt->err, sizeof walk_err, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
+            // one CIGAR operation of 2^24 bases and more, or the alignments of a job spanning more than 2^30 bases: the passes again on the general walker
+            if (!general && (walk_err & LPS_ERR_KEY_RANGE)) { general = true; --attempt; continue; }
             if (tot[1] <= pa && tot[3] <= ha) break;
             if (tot[1] > pa) c->t_pair_arena = (size_t)tot[1] + (size_t)tot[1] / 8 + 1024;   // an arena was too short: again with room for the fullest one
             if (tot[3] > ha) c->t_hit_arena = (size_t)tot[3] + (size_t)tot[3] / 8 + 1024;

@@ -286,4 +286,4 @@ void launch_tumor_windows(const VarView &V, const ReadView &R, const TumOut &T, 
 void launch_tumor_pairs_out(const TumOut &T, hipStream_t s);     // after pass 1: totals + the pairs out of their arenas into the caller's list
 #define LPS_TARENAS 64
 void launch_tumor_extract(const VarView &V, const ReadView &R, const TumOut &T, int mapping_quality, int tag_supplementary, int pass,
-                          LpsCounters *cnt, hipStream_t s);
+                          LpsCounters *cnt, hipStream_t s, bool general = false);

@@ -254,6 +254,294 @@ __global__ __launch_bounds__(64) void k_tumor_extract(VarView V, ReadView R, Tum
     }
 }
 
+// ---- the two tumor passes as a STREAM walk (the design of k_extract_phase / k_haplotag_stream): a wave takes FOUR consecutive alignments, their CIGAR
+// words are one stream (lane-chunks, lps_reads.hip), one pair of DPP scans per round gives every chunk its stream coordinates, and the rows of the merged
+// table under the four alignments are taken 64 at a time as one flattened list, every lane busy: chunk search, the chunk's words, the 8-step walk to the
+// op that covers the row, then exactly the rules of k_tumor_extract<PASS> above (which stays the general walker for records this walk's arithmetic cannot
+// take: LPS_ERR_KEY_RANGE).  Votes, phase sets and the "met a tumor row" flag are reduced per alignment with ballots; one list reservation per ROUND of
+// 64 candidates of four alignments instead of one per alignment and round.
+#ifndef TUM_TAB
+#define TUM_TAB 1024
+#endif
+template <int PASS>
+__global__ __launch_bounds__(64, 4) void k_tumor_stream(VarView V, ReadView R, TumOut T, int mapping_quality, int tag_supplementary, LpsCounters *cnt) {
+    __shared__ __attribute__((aligned(16))) int2 s_tab[TUM_TAB + 1];
+    __shared__ ExtHdr s_hdr[4];
+    const int l = lane_id();
+    const int r0 = (int)blockIdx.x * 4;
+    if (r0 >= R.n) return;
+    const int nq = min(4, R.n - r0);
+    const int arena = (int)(blockIdx.x % LPS_TARENAS);
+    // ---- plan: headers, alignment q in lane q (mappingQualityFilter == false in the extraction passes: MAPQ only gates the votes)
+    int h_start = 0, h_lq = 0, h_status = 0, h_v0 = 0, h_n = 0; unsigned h_cp = 0; unsigned long long h_soff = 0; bool h_mq = false;
+    int h_rhp = 0, h_rh1 = 0, h_rh2 = 0; bool h_rec = true, h_clean = false;     // PASS 1: the read-level facts of PASS 0
+    if (l <= nq) h_cp = R.cp_off[r0 + l];
+    if (l < nq) {
+        const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r]; h_v0 = V.n ? R.v0[r] : 0; h_n = R.cp_n[r];
+        const int flag = R.flag[r];
+        h_mq = R.mapq[r] >= mapping_quality;
+        if (flag & 0x4) h_status = 2;
+        else if (flag & 0x100) h_status = 3;
+        else if ((flag & 0x800) && !tag_supplementary) h_status = 4;
+        else if (V.n == 0) h_status = 5;
+        else if (!(h_start <= V.last_pos)) h_status = 6;
+        if (PASS == 1) { h_rhp = T.hp[r]; h_rh1 = T.hp1[r]; h_rh2 = T.hp2[r]; h_rec = T.n_ps[r] <= 1; h_clean = (h_rh1 == 0 || h_rh2 == 0) && T.hp3[r] != 0; }
+    }
+    const bool h_walked = l < nq && h_status == 0 && h_v0 < V.n;         // parsingCigar returns at once when no variant is left (:555-557)
+    bool bad_cigar = false;
+    const unsigned live_mask = (unsigned)__ballot(h_walked) & 15u;
+    const unsigned mq_mask = (unsigned)__ballot(h_mq) & 15u;
+    int rhp[4] = {0, 0, 0, 0}, rh1[4] = {0, 0, 0, 0}, rh2[4] = {0, 0, 0, 0}; unsigned rec_mask = 15u, clean_mask = 0u;
+    if (PASS == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { rhp[q] = __builtin_amdgcn_readlane(h_rhp, q); rh1[q] = __builtin_amdgcn_readlane(h_rh1, q); rh2[q] = __builtin_amdgcn_readlane(h_rh2, q); }
+        rec_mask = (unsigned)__ballot(h_rec) & 15u; clean_mask = (unsigned)__ballot(h_clean) & 15u;
+    }
+    const int h_nch = (int)(__shfl_down(h_cp, 1) - h_cp);
+    int vh1[4] = {0, 0, 0, 0}, vh2[4] = {0, 0, 0, 0}, vh3[4] = {0, 0, 0, 0}, nsite[4] = {0, 0, 0, 0}, plo[4], phi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { plo[q] = 0x7fffffff; phi[q] = (int)0x80000000; }
+    int e_end = h_start, e_len = 0;                                       // lane q: where alignment q ends on the reference, bases of the read its CIGAR consumes
+    unsigned todo = live_mask;
+#pragma unroll 1
+    while (todo) {
+        const int qa = __builtin_ctz(todo);
+        const unsigned c_lo = __shfl(h_cp, qa);
+        int qb = qa; unsigned gm = 1u << qa;
+        for (int q = qa + 1; q < nq; ++q) {
+            if (!((todo >> q) & 1u)) continue;
+            if (__shfl(h_cp, q + 1) - c_lo > (unsigned)TUM_TAB) break;
+            gm |= 1u << q; qb = q;
+        }
+        todo &= ~gm;
+        int shift = 0;
+        { const unsigned n1 = __shfl(h_cp, qa + 1) - c_lo; while (((n1 + (1u << shift) - 1u) >> shift) > (unsigned)TUM_TAB) ++shift; }
+        const bool fast = shift == 0;
+        const bool h_in = l < 4 && ((gm >> l) & 1u);
+        const bool h_walk = h_in && h_n > 0;
+        const int h_c0 = (l <= nq) ? (int)(h_cp - c_lo) : 0;
+        const uint32_t *cg = R.cigp + 8ull * c_lo;
+        const int TC = __builtin_amdgcn_readlane(h_c0 + h_nch, qb);
+        auto request = [&](int cid, uint32_t (&w)[8]) __attribute__((always_inline)) {
+            const uint32_t *p = cg + 8 * min(cid, max(TC - 1, 0));
+            const uint4 a = *reinterpret_cast<const uint4 *>(p), b = *reinterpret_cast<const uint4 *>(p + 4);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        };
+        int v0q[4], pp[4]; bool walkq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v0q[q] = __builtin_amdgcn_readlane(h_v0, q); walkq[q] = (__ballot(h_walk) >> q) & 1ull; pp[q] = V.pos[min(v0q[q] + l, V.n - 1)]; }
+        if (l < 4) {
+            ExtHdr &h = s_hdr[l];
+            h.crel = fast ? 8 * h_c0 : 0; h.ncig = h_walk ? h_n : 0; h.c0 = fast ? h_c0 : 0; h.nch = h_walk ? (int)(((unsigned)h_nch + (1u << shift) - 1u) >> shift) : 0;
+            h.lq = h_lq; h.soff = h_soff;
+        }
+        int carry_r = 0, carry_q = 0; unsigned special = 0; uint32_t big = 0; bool absurd = false;
+#pragma unroll 1
+        for (int R0 = 0; R0 < TC; R0 += 256) {
+            uint32_t w0[8], w1[8], w2[8], w3[8];
+            request(R0 + l, w0); request(R0 + 64 + l, w1); request(R0 + 128 + l, w2); request(R0 + 192 + l, w3);
+            stream_round<LPS_BADMASK2>(w0, R0 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
+            stream_round<LPS_BADMASK2>(w1, R0 + 64 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
+            stream_round<LPS_BADMASK2>(w2, R0 + 128 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
+            stream_round<LPS_BADMASK2>(w3, R0 + 192 + l, TC, shift, s_tab, carry_r, carry_q, special, big);
+            absurd |= (unsigned)carry_r > 0x3fffffffu || (unsigned)carry_q > 0x3fffffffu;
+            if (absurd) break;
+        }
+        if (fast && l == 0) s_tab[TC] = make_int2(carry_r, carry_q);
+        if (absurd || __ballot(big >= 0x10000000u)) { if (l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_KEY_RANGE); break; }   // the host runs the pass again on k_tumor_extract
+        if (__ballot(special != 0u)) {                                    // an op code the reference rejects: in an alignment that is walked?
+            bool bad = false;
+            for (int cid = l; cid < TC; cid += 64) {
+                bool inq = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) inq |= s_hdr[q].ncig > 0 && (!fast || (cid >= s_hdr[q].c0 && 8 * (cid - s_hdr[q].c0) < s_hdr[q].ncig));
+                for (int k = 0; k < 8; ++k) bad |= inq && op_bit(LPS_BADMASK2, cg[8 * cid + k]) != 0u;
+            }
+            bad_cigar |= __ballot(bad) != 0ull;
+        }
+        wave_sync();
+        int b_sat = 0, b_qat = 0, b_rend = h_start;
+        if (h_walk) {
+            if (fast) { const int2 ts = s_tab[h_c0], te = s_tab[h_c0 + h_nch]; b_sat = ts.x; b_qat = ts.y; b_rend = h_start + te.x - ts.x; e_len = te.y - ts.y; }
+            else { b_rend = h_start + carry_r; e_len = carry_q; }
+            e_end = b_rend;
+        }
+        int ncand[4], rend[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rend[q] = __builtin_amdgcn_readlane(b_rend, q);
+            int n = __popcll(__ballot(walkq[q] && v0q[q] + l < V.n && pp[q] < rend[q]));
+            if (n == 64) {
+                for (;;) { int p2 = 0x7fffffff; if (v0q[q] + n + l < V.n) p2 = V.pos[v0q[q] + n + l]; const int m = __popcll(__ballot(p2 < rend[q])); n += m; if (m < 64) break; }
+            }
+            ncand[q] = n;
+        }
+        int cum[5]; cum[0] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cum[q + 1] = cum[q] + ncand[q];
+        const int TT = cum[4];
+        int vadj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vadj[q] = v0q[q] - cum[q];
+        if (l < 4) { ExtHdr &h = s_hdr[l]; h.vadj = SEL4(l, vadj); h.ds = b_sat - h_start; h.dq = b_qat; }
+        int maxnch = l < 4 ? s_hdr[l].nch : 0;
+        maxnch = max(max(__builtin_amdgcn_readlane(maxnch, 0), __builtin_amdgcn_readlane(maxnch, 1)), max(__builtin_amdgcn_readlane(maxnch, 2), __builtin_amdgcn_readlane(maxnch, 3)));
+        wave_sync();
+        const int step0 = maxnch > 1 ? 1 << (31 - __builtin_clz(maxnch - 1)) : 0;
+        uint2 pvr = V.rec[min(SELC(l, cum, vadj) + l, V.n - 1)];
+#pragma unroll 1
+        for (int i0 = 0; i0 < TT; i0 += 64) {
+            const int i = i0 + l;
+            const bool in = i < TT;
+            bool to1 = false, to2 = false, to3 = false, count_ps = false, pairf = false, want_win = false;
+            int ps_v = 0, base_hp = 0, win_allele = 0, win_off = 0, opi = 0, hit_q = 0, v = 0, q = 0;
+            const uint2 vr = pvr;
+            pvr = V.rec[min(SELC(i + 64, cum, vadj) + i + 64, V.n - 1)];
+            if (in) {
+                q = (i >= cum[1]) + (i >= cum[2]) + (i >= cum[3]);
+                const int4 ha = *reinterpret_cast<const int4 *>(&s_hdr[q].crel), hb = *reinterpret_cast<const int4 *>(&s_hdr[q].vadj);
+                const int hcrel = ha.x, hncig = ha.y, hc0 = ha.z, hnch = ha.w, hlq = hb.y;
+                v = hb.x + i;
+                const int p = (int)vr.x; const unsigned at = vr.y;
+                const int ps = p + hb.z;
+                int co = 0;
+                for (int step = step0; step >= 1; step >>= 1) { const int t = co + step; const int sv = s_tab[hc0 + min(t, hnch - 1)].x; co = (t < hnch && sv <= ps) ? t : co; }
+                const int2 base = s_tab[hc0 + co];
+                const int x0 = (8 * (hc0 + co)) << shift;
+                int rr = base.x, qq = base.y, jx = x0, rs = base.x, qs = base.y; uint32_t wj = 6u, wn = 6u;
+                auto walk8 = [&](const uint32_t (&w)[9], int xb) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool le = rr <= ps;
+                        jx = le ? xb + k : jx; rs = le ? rr : rs; qs = le ? qq : qs; wj = le ? w[k] : wj; wn = le ? w[k + 1] : wn;
+                        const unsigned len = w[k] >> 4;
+                        rr += (int)__umul24(len, op_bit(LPS_RMASK2, w[k])); qq += (int)__umul24(len, op_bit(LPS_QMASK2, w[k]));
+                    }
+                };
+                for (int u = 0; u < (1 << shift); ++u) {                  // (one trip unless the alignment is walked in LONG mode)
+                    const uint32_t *cw = cg + x0 + 8 * u;
+                    uint32_t w[9];
+                    const uint4 a = *reinterpret_cast<const uint4 *>(cw), b = *reinterpret_cast<const uint4 *>(cw + 4);
+                    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = cw[8];
+                    walk8(w, x0 + 8 * u);
+                    if (rr > ps || x0 + 8 * u + 8 >= hcrel + hncig) break;
+                }
+                const int op = wj & 15, len = (int)(wj >> 4);
+                opi = jx - hcrel;
+                qs -= hb.w;
+                if (ps < rs + len) {
+                    const unsigned kind = VREC_KIND(at), tk = VREC_TKIND(at), role = VREC_ROLE(at);
+                    const char ref_c = (char)(at & 0xff), alt_c = (char)((at >> 8) & 0xff);
+                    const bool hp1alt = (at & VREC_HP1ALT) != 0, mq_ok = (mq_mask >> q) & 1u;
+                    int32_t *sc = T.site + (size_t)v * LPS_TSITE_COUNTERS;
+                    if (op_is_match(op)) {
+                        const int qi = qs + (ps - rs);
+                        const uint8_t *seq = R.seq + s_hdr[q].soff;
+                        const char base_c = qi < hlq ? nt16_char(__builtin_nontemporal_load(seq + (qi >> 1)) >> ((~qi & 1) << 2)) : 'N';
+                        bool is_alt = false;
+                        if (kind == 0) is_alt = base_c == alt_c;
+                        else if ((kind == 1 || kind == 2) && opi + 1 < hncig) is_alt = (rs + len - 1 == ps) && (int)(wn & 15u) == ((kind == 1) ? 1 : 2);
+                        if (mq_ok) {                                                  // judgeSomaticSnpHap (:315-389)
+                            if (role == 0) {
+                                bool counted = false;
+                                if (kind == 0) counted = base_c == ref_c || base_c == alt_c;
+                                else if (kind == 1 || kind == 2) counted = true;         // base := isAlt ? Alt : Ref
+                                if (counted) { const bool h1v = hp1alt == is_alt; to1 = h1v; to2 = !h1v; base_hp = h1v ? 1 : 2; count_ps = true; ps_v = V.phase_set[v]; }
+                            } else if (tk != 0) {                                     // tumor-only row: H3 when the read shows the tumor ALT
+                                to3 = (kind == 0 || kind == 1 || kind == 2) && is_alt; base_hp = to3 ? 3 : base_hp;
+                            }
+                            pairf = tk != 0;                                          // tumorSnpPosVec (:722-724)
+                        }
+                        if (PASS == 0 && tk >= 1 && tk <= 3) {                        // :728-741
+                            if (tk != 1 || base_c == ref_c || base_c == alt_c) {
+                                atomicAdd(&sc[39 + (is_alt ? 1 : 0)], 1);
+                                want_win = true; win_allele = is_alt; win_off = ps - rs; hit_q = qs + win_off;
+                            }
+                            const int bi = base_c == 'A' ? LPS_SC_A : base_c == 'C' ? LPS_SC_C : base_c == 'G' ? LPS_SC_G : base_c == 'T' ? LPS_SC_T : LPS_SC_UNKNOWN;
+                            if (mq_ok) { atomicAdd(&sc[bi + (LPS_SC_MPQ_A - LPS_SC_A)], 1); if (is_alt) atomicAdd(&sc[LPS_SC_MPQ_ALT], 1); atomicAdd(&sc[LPS_SC_MPQ_DEPTH], 1); }
+                            atomicAdd(&sc[bi], 1);
+                            if (is_alt) { if (tk == 3) atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_ALT], 1); }
+                            atomicAdd(&sc[LPS_SC_DEPTH], 1);
+                        }
+                        if (PASS == 1 && pairf) {
+                            const int r_hp = SEL4(q, rhp), r_h1 = SEL4(q, rh1), r_h2 = SEL4(q, rh2);
+                            atomicAdd(&sc[15 + r_hp], 1);                             // base.ReadHpCount[hpResult] (:457)
+                            if (base_hp == 3) {                                       // classifyReadsByCase (:462-518) + somaticReadHpCount (:386-404)
+                                if (!((rec_mask >> q) & 1u)) atomicAdd(&sc[24], 1);
+                                else if ((clean_mask >> q) & 1u) {
+                                    atomicAdd(&sc[25], 1);
+                                    if (r_h1 == 0 && r_h2 == 0) atomicAdd(&sc[28], 1); else if (r_h1 != 0 && r_h2 == 0) atomicAdd(&sc[26], 1); else if (r_h1 == 0 && r_h2 != 0) atomicAdd(&sc[27], 1);
+                                } else atomicAdd(&sc[29], 1);
+                                atomicAdd(&sc[30 + r_hp], 1);
+                            }
+                        }
+                    } else if (op == 2 && PASS == 0) {                                // processDeletionOperation (:743-759)
+                        if (tk == 1) { atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_DEPTH], 1); }
+                        else if (tk == 3) { atomicAdd(&sc[LPS_SC_ALT], 1); atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_DEPTH], 1); }
+                    }
+                }
+            }
+            if (PASS == 0) {                                              // the hit is listed; k_tumor_windows walks the +-100 bases one thread per (hit, direction)
+                const unsigned long long wm = __ballot(want_win);
+                if (wm) {
+                    unsigned long long hb = 0;
+                    if (l == 0) hb = atomicAdd(&T.hit_ctr[arena * 16], (unsigned long long)__popcll(wm));
+                    hb = __shfl(hb, 0);
+                    if (want_win) {
+                        const long long idx = (long long)hb + __popcll(wm & lanemask_lt());
+                        if (idx < T.hit_arena) { const long long slot = (long long)arena * T.hit_arena + idx;
+                            T.hits[slot] = make_int4(v, r0 + q, opi, win_off | (win_allele << 30)); T.hit_rp[slot] = hit_q; }
+                    }
+                }
+            } else {
+                const unsigned long long pm = __ballot(pairf);
+                if (pm) {
+                    unsigned long long pb = 0;
+                    if (l == 0) pb = atomicAdd(&T.pair_ctr[arena * 16], (unsigned long long)__popcll(pm));
+                    pb = __shfl(pb, 0);
+                    if (pairf) {
+                        const long long idx = (long long)pb + __popcll(pm & lanemask_lt());
+                        if (idx < T.pair_arena) { const long long slot = (long long)arena * T.pair_arena + idx;
+                            T.apair_site[slot] = v; T.apair_read[slot] = r0 + q; T.apair_hp[slot] = (uint8_t)base_hp; }
+                    }
+                }
+            }
+            if (PASS == 0) {
+                const unsigned long long m1 = __ballot(to1), m2 = __ballot(to2), m3 = __ballot(to3), mp = __ballot(count_ps), ms = __ballot(pairf);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int a = max(cum[k] - i0, 0), b = min(cum[k + 1] - i0, 64);
+                    if (b > a) {
+                        const unsigned long long rm = ((b >= 64) ? ~0ull : ((1ull << b) - 1ull)) & ~((1ull << a) - 1ull);
+                        vh1[k] += __popcll(m1 & rm); vh2[k] += __popcll(m2 & rm); vh3[k] += __popcll(m3 & rm); nsite[k] += __popcll(ms & rm);
+                        const unsigned long long pk = mp & rm;
+                        if (pk) {
+                            const int first = __builtin_amdgcn_readlane(ps_v, __builtin_ctzll(pk));
+                            if (__ballot(count_ps && ps_v != first) & rm) {
+                                const bool mine = (pk >> l) & 1ull;
+                                plo[k] = min(plo[k], wave_min(mine ? ps_v : 0x7fffffff)); phi[k] = max(phi[k], wave_max(mine ? ps_v : (int)0x80000000));
+                            } else { plo[k] = min(plo[k], first); phi[k] = max(phi[k], first); }
+                        }
+                    }
+                }
+            }
+        }
+        wave_sync();                                                      // the table and the headers are reused by the next group
+    }
+    if (bad_cigar && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
+    if (PASS == 0 && l < nq) {
+        const int r = r0 + l;
+        const int h1 = SEL4(l, vh1), h2 = SEL4(l, vh2), h3 = SEL4(l, vh3), lo = SEL4(l, plo), hi = SEL4(l, phi);
+        const bool any = lo <= hi;
+        T.status[r] = (uint8_t)h_status; T.hp1[r] = h1; T.hp2[r] = h2; T.hp3[r] = h3;
+        T.n_ps[r] = any ? (lo == hi ? 1 : 2) : 0; T.ps_min[r] = any ? lo : 0;
+        T.hp[r] = (uint8_t)(h_status == 0 ? somatic_read_hp(h1, h2, h3, any && lo != hi, T.pct_thr) : 0);
+        T.end_pos[r] = h_walked ? e_end : (h_status == 0 ? h_start : 0);
+        T.read_len[r] = h_walked ? e_len : 0;
+        T.has_site[r] = SEL4(l, nsite) > 0;
+    }
+}
+
 // thread t = (hit slot t >> 1, direction t & 1: 0 towards the read's start, 1 towards its end); a slot holds a hit when its index inside its arena is
 // below the arena's counter.  WRITE = false: cnt[t] = differences found; WRITE = true: they are stored from slot at[t] on.  The walk itself is the
 // reference's (win_dir above), untouched.
@@ -312,9 +600,16 @@ void launch_tumor_pairs_out(const TumOut &T, hipStream_t s) {
     hipLaunchKernelGGL(k_tumor_pairs_out, dim3((unsigned)((T.pair_arena + 255) / 256), LPS_TARENAS), dim3(256), 0, s, T);
 }
 
+// general = false: the stream walk (R.v0 must hold every alignment's first row); true: the per-op-prefix walker, which takes any BAM record
 void launch_tumor_extract(const VarView &V, const ReadView &R, const TumOut &T, int mapping_quality, int tag_supplementary, int pass,
-                          LpsCounters *cnt, hipStream_t s) {
+                          LpsCounters *cnt, hipStream_t s, bool general) {
     if (R.n == 0) return;
+    if (!general) {
+        const dim3 g((R.n + 3) / 4), b(64);
+        if (pass == 0) hipLaunchKernelGGL(k_tumor_stream<0>, g, b, 0, s, V, R, T, mapping_quality, tag_supplementary, cnt);
+        else hipLaunchKernelGGL(k_tumor_stream<1>, g, b, 0, s, V, R, T, mapping_quality, tag_supplementary, cnt);
+        return;
+    }
     const dim3 g(R.n), b(64);
     if (pass == 0) hipLaunchKernelGGL(k_tumor_extract<0>, g, b, 0, s, V, R, T, mapping_quality, tag_supplementary, cnt);
     else hipLaunchKernelGGL(k_tumor_extract<1>, g, b, 0, s, V, R, T, mapping_quality, tag_supplementary, cnt);
