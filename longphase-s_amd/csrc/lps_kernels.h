@@ -280,6 +280,7 @@ struct TumOut {
     double pct_thr;
     int4 *hits; int *hit_rp;                      // the hits of pass 0: {row, alignment, CIGAR word index, offset inside the op | allele << 30} + the query position there
     uint32_t *win_cnt, *win_at;                   // per (hit, direction): differences, and where they go in the window list
+    unsigned long long *win_memo; uint32_t *win_codes;   // per (hit, direction): which steps differ (two words) and the read's base codes at the first eight (lps_somatic.hip: WinMemo)
 };
 // the +-100 bp difference windows of the hits pass 0 listed (getWindowsDiffRef, SomaticVarCaller.cpp:654-710): ONE THREAD per (hit, direction)
 void launch_tumor_windows(const VarView &V, const ReadView &R, const TumOut &T, void *temp, size_t temp_bytes, hipStream_t s);

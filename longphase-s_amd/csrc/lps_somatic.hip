@@ -48,25 +48,34 @@ struct ByteWindow {
         return (unsigned)(w >> (8u * (unsigned)(a & 7))) & 0xffu;
     }
 };
+// The counting walk also leaves a MEMO of what it found - which of the 100 steps differ (a bit each) and the read's base code at the first eight of them -
+// so that the writing pass stores a window of up to eight differences (nearly all of them) from 24 bytes instead of walking it again.
+struct WinMemo { unsigned long long lo, hi; };                             // bits 0-63 / 64-99: step i differs (bit i - 1); hi bit 63: the memo cannot stand for the walk
+#define WIN_MEMO_MAX 8
 template <bool WRITE>
 __device__ __forceinline__ int win_dir(const uint32_t *cig, int idx, int n_cig, const uint8_t *seq, int readLen, const char *ref, int refLen,
-                                       int readPos, int remaining, int refPos, int dir, const TumOut &T, long long base, int site, int allele) {
+                                       int readPos, int remaining, int refPos, int dir, const TumOut &T, long long base, int site, int allele,
+                                       WinMemo *memo = nullptr, uint32_t *codes = nullptr) {
     int op = cig[idx] & 15, n = 0;
     ByteWindow sq(seq), rf(ref);
+    unsigned long long mlo = 0, mhi = 0; uint32_t cd = 0; bool plain = true;
+    auto leave = [&]() __attribute__((always_inline)) { if (!WRITE) { memo->lo = mlo; memo->hi = mhi | ((plain && n <= WIN_MEMO_MAX) ? 0ull : (1ull << 63)); *codes = cd; } return n; };
     for (int i = 1; i <= 100; ++i) {
         remaining--;
-        if (remaining == 0 || remaining == -1) { if (!win_next_op(cig, idx, n_cig, dir, remaining, readPos, refPos, op)) return n; }
+        if (remaining == 0 || remaining == -1) { if (!win_next_op(cig, idx, n_cig, dir, remaining, readPos, refPos, op)) return leave(); }
         if (op == 2 || op == 1 || op == 3 || op == 6 || op == 8) continue;
         readPos += dir; refPos += dir;
-        if (readPos > readLen || refPos > refLen || readPos < 0 || refPos < 0) return n;
-        const char rb = readPos < readLen ? nt16_char((int)(sq[readPos >> 1] >> ((~readPos & 1) << 2))) : '\0';
+        if (readPos > readLen || refPos > refLen || readPos < 0 || refPos < 0) return leave();
+        const int code = readPos < readLen ? (int)((sq[readPos >> 1] >> ((~readPos & 1) << 2)) & 15u) : -1;
+        const char rb = code >= 0 ? nt16_char(code) : '\0';
         const char fb = refPos < refLen ? (char)rf[refPos] : '\0';
         if (rb != fb) {
             if (WRITE && base + n < T.win_cap) { T.win_site[base + n] = site; T.win_allele[base + n] = (uint8_t)allele; T.win_offset[base + n] = (int16_t)(i * dir); T.win_base[base + n] = (uint8_t)rb; }
+            if (!WRITE) { if (i <= 64) mlo |= 1ull << (i - 1); else mhi |= 1ull << (i - 65); plain = plain && code >= 0; if (n < WIN_MEMO_MAX) cd |= (uint32_t)(code & 15) << (4 * n); }
             ++n;
         }
     }
-    return n;
+    return leave();
 }
 
 // judgeSomaticReadHap (HaplotagStrategy.cpp:452-602) restricted to the haplotype decision (hpCount[4] is never incremented here)
@@ -555,11 +564,26 @@ __global__ __launch_bounds__(256) void k_tumor_windows(VarView V, ReadView R, Tu
     if (WRITE && T.win_cnt[t] == 0u) return;
     const int4 h = T.hits[hs]; const int dir = (t & 1) ? +1 : -1;
     const int v = h.x, r = h.y, opj = h.z, win_off = h.w & 0x3fffffff, allele = (h.w >> 30) & 1, rp = T.hit_rp[hs];
+    if (WRITE) {                                                          // from the counting walk's memo when it holds the whole window
+        const WinMemo m = reinterpret_cast<const WinMemo *>(T.win_memo)[t];
+        if (!(m.hi >> 63)) {
+            const uint32_t cd = T.win_codes[t]; long long at = (long long)T.win_at[t]; int k = 0;
+            unsigned long long lo = m.lo, hi = m.hi;
+            while (lo | hi) {
+                int i;
+                if (lo) { i = __builtin_ctzll(lo) + 1; lo &= lo - 1; } else { i = __builtin_ctzll(hi) + 65; hi &= hi - 1; }
+                if (at < T.win_cap) { T.win_site[at] = v; T.win_allele[at] = (uint8_t)allele; T.win_offset[at] = (int16_t)(i * dir); T.win_base[at] = (uint8_t)nt16_char((int)((cd >> (4 * k)) & 15u)); }
+                ++at; ++k;
+            }
+            return;
+        }
+    }
     const uint32_t *cig = R.cig(r); const int n_cig = R.cp_n[r];
     const int len = (int)(cig[opj] >> 4);
     const int remaining = dir > 0 ? ((len - win_off > 0) ? len - win_off : 0) : (win_off > 0 ? win_off : 0);
-    const int n = win_dir<WRITE>(cig, opj, n_cig, R.seq + R.seq_off[r], R.l_qseq[r], V.ref, (int)V.ref_len_eff, rp, remaining, V.pos[v], dir, T, WRITE ? (long long)T.win_at[t] : 0, v, allele);
-    if (!WRITE) T.win_cnt[t] = (uint32_t)n;
+    WinMemo memo{0, 0}; uint32_t codes = 0;
+    const int n = win_dir<WRITE>(cig, opj, n_cig, R.seq + R.seq_off[r], R.l_qseq[r], V.ref, (int)V.ref_len_eff, rp, remaining, V.pos[v], dir, T, WRITE ? (long long)T.win_at[t] : 0, v, allele, &memo, &codes);
+    if (!WRITE) { T.win_cnt[t] = (uint32_t)n; if (n) { reinterpret_cast<WinMemo *>(T.win_memo)[t] = memo; T.win_codes[t] = codes; } }
 }
 void launch_tumor_windows(const VarView &V, const ReadView &R, const TumOut &T, void *temp, size_t temp_bytes, hipStream_t s) {
     const size_t n = (size_t)(2 * LPS_TARENAS * T.hit_arena + 1);
