@@ -266,13 +266,13 @@ __global__ __launch_bounds__(64) void k_tumor_extract(VarView V, ReadView R, Tum
 // ---- the two tumor passes as a STREAM walk (the design of k_extract_phase / k_haplotag_stream): a wave takes FOUR consecutive alignments, their CIGAR
 // words are one stream (lane-chunks, lps_reads.hip), one pair of DPP scans per round gives every chunk its stream coordinates, and the rows of the merged
 // table under the four alignments are taken 64 at a time as one flattened list, every lane busy: chunk search, the chunk's words, the 8-step walk to the
-// op that covers the row, then exactly the rules of k_tumor_extract<PASS> above (which stays the general walker for records this walk's arithmetic cannot
-// take: LPS_ERR_KEY_RANGE).  Votes, phase sets and the "met a tumor row" flag are reduced per alignment with ballots; one list reservation per ROUND of
-// 64 candidates of four alignments instead of one per alignment and round.
+// op that covers the row, then exactly the rules of k_tumor_extract<0> above (which, with <1>, stays the general walker for records this walk's arithmetic
+// cannot take: LPS_ERR_KEY_RANGE).  Votes, phase sets and the "met a tumor row" flag are reduced per alignment with ballots; one list reservation per
+// ROUND of 64 candidates of four alignments instead of one per alignment and round.  ONE walk: it lists the (tumor row, alignment) pairs as well, and
+// what the reference's second loop over the alignments adds at a row (k_tumor_extract<1>) is done from that list by k_tumor_pair_sites.
 #ifndef TUM_TAB
 #define TUM_TAB 1024
 #endif
-template <int PASS>
 __global__ __launch_bounds__(64, 4) void k_tumor_stream(VarView V, ReadView R, TumOut T, int mapping_quality, int tag_supplementary, LpsCounters *cnt) {
     __shared__ __attribute__((aligned(16))) int2 s_tab[TUM_TAB + 1];
     __shared__ ExtHdr s_hdr[4];
@@ -283,7 +283,6 @@ __global__ __launch_bounds__(64, 4) void k_tumor_stream(VarView V, ReadView R, T
     const int arena = (int)(blockIdx.x % LPS_TARENAS);
     // ---- plan: headers, alignment q in lane q (mappingQualityFilter == false in the extraction passes: MAPQ only gates the votes)
     int h_start = 0, h_lq = 0, h_status = 0, h_v0 = 0, h_n = 0; unsigned h_cp = 0; unsigned long long h_soff = 0; bool h_mq = false;
-    int h_rhp = 0, h_rh1 = 0, h_rh2 = 0; bool h_rec = true, h_clean = false;     // PASS 1: the read-level facts of PASS 0
     if (l <= nq) h_cp = R.cp_off[r0 + l];
     if (l < nq) {
         const int r = r0 + l; h_start = R.ref_start[r]; h_lq = R.l_qseq[r]; h_soff = R.seq_off[r]; h_v0 = V.n ? R.v0[r] : 0; h_n = R.cp_n[r];
@@ -294,18 +293,11 @@ __global__ __launch_bounds__(64, 4) void k_tumor_stream(VarView V, ReadView R, T
         else if ((flag & 0x800) && !tag_supplementary) h_status = 4;
         else if (V.n == 0) h_status = 5;
         else if (!(h_start <= V.last_pos)) h_status = 6;
-        if (PASS == 1) { h_rhp = T.hp[r]; h_rh1 = T.hp1[r]; h_rh2 = T.hp2[r]; h_rec = T.n_ps[r] <= 1; h_clean = (h_rh1 == 0 || h_rh2 == 0) && T.hp3[r] != 0; }
     }
     const bool h_walked = l < nq && h_status == 0 && h_v0 < V.n;         // parsingCigar returns at once when no variant is left (:555-557)
     bool bad_cigar = false;
     const unsigned live_mask = (unsigned)__ballot(h_walked) & 15u;
     const unsigned mq_mask = (unsigned)__ballot(h_mq) & 15u;
-    int rhp[4] = {0, 0, 0, 0}, rh1[4] = {0, 0, 0, 0}, rh2[4] = {0, 0, 0, 0}; unsigned rec_mask = 15u, clean_mask = 0u;
-    if (PASS == 1) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { rhp[q] = __builtin_amdgcn_readlane(h_rhp, q); rh1[q] = __builtin_amdgcn_readlane(h_rh1, q); rh2[q] = __builtin_amdgcn_readlane(h_rh2, q); }
-        rec_mask = (unsigned)__ballot(h_rec) & 15u; clean_mask = (unsigned)__ballot(h_clean) & 15u;
-    }
     const int h_nch = (int)(__shfl_down(h_cp, 1) - h_cp);
     int vh1[4] = {0, 0, 0, 0}, vh2[4] = {0, 0, 0, 0}, vh3[4] = {0, 0, 0, 0}, nsite[4] = {0, 0, 0, 0}, plo[4], phi[4];
 #pragma unroll
@@ -461,7 +453,7 @@ __global__ __launch_bounds__(64, 4) void k_tumor_stream(VarView V, ReadView R, T
                             }
                             pairf = tk != 0;                                          // tumorSnpPosVec (:722-724)
                         }
-                        if (PASS == 0 && tk >= 1 && tk <= 3) {                        // :728-741
+                        if (tk >= 1 && tk <= 3) {                                     // :728-741
                             if (tk != 1 || base_c == ref_c || base_c == alt_c) {
                                 atomicAdd(&sc[39 + (is_alt ? 1 : 0)], 1);
                                 want_win = true; win_allele = is_alt; win_off = ps - rs; hit_q = qs + win_off;
@@ -472,25 +464,13 @@ __global__ __launch_bounds__(64, 4) void k_tumor_stream(VarView V, ReadView R, T
                             if (is_alt) { if (tk == 3) atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_ALT], 1); }
                             atomicAdd(&sc[LPS_SC_DEPTH], 1);
                         }
-                        if (PASS == 1 && pairf) {
-                            const int r_hp = SEL4(q, rhp), r_h1 = SEL4(q, rh1), r_h2 = SEL4(q, rh2);
-                            atomicAdd(&sc[15 + r_hp], 1);                             // base.ReadHpCount[hpResult] (:457)
-                            if (base_hp == 3) {                                       // classifyReadsByCase (:462-518) + somaticReadHpCount (:386-404)
-                                if (!((rec_mask >> q) & 1u)) atomicAdd(&sc[24], 1);
-                                else if ((clean_mask >> q) & 1u) {
-                                    atomicAdd(&sc[25], 1);
-                                    if (r_h1 == 0 && r_h2 == 0) atomicAdd(&sc[28], 1); else if (r_h1 != 0 && r_h2 == 0) atomicAdd(&sc[26], 1); else if (r_h1 == 0 && r_h2 != 0) atomicAdd(&sc[27], 1);
-                                } else atomicAdd(&sc[29], 1);
-                                atomicAdd(&sc[30 + r_hp], 1);
-                            }
-                        }
-                    } else if (op == 2 && PASS == 0) {                                // processDeletionOperation (:743-759)
+                    } else if (op == 2) {                                             // processDeletionOperation (:743-759)
                         if (tk == 1) { atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_DEPTH], 1); }
                         else if (tk == 3) { atomicAdd(&sc[LPS_SC_ALT], 1); atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_DEPTH], 1); }
                     }
                 }
             }
-            if (PASS == 0) {                                              // the hit is listed; k_tumor_windows walks the +-100 bases one thread per (hit, direction)
+            {                                                             // the hit is listed; k_tumor_windows walks the +-100 bases one thread per (hit, direction)
                 const unsigned long long wm = __ballot(want_win);
                 if (wm) {
                     unsigned long long hb = 0;
@@ -502,7 +482,8 @@ __global__ __launch_bounds__(64, 4) void k_tumor_stream(VarView V, ReadView R, T
                             T.hits[slot] = make_int4(v, r0 + q, opi, win_off | (win_allele << 30)); T.hit_rp[slot] = hit_q; }
                     }
                 }
-            } else {
+                // ... and so is the (tumor row, alignment, base haplotype) pair: what the reference's second loop over the alignments does at the row
+                // needs the read's FINAL haplotype and nothing else of the walk - k_tumor_pair_sites takes it from this list, no second walk
                 const unsigned long long pm = __ballot(pairf);
                 if (pm) {
                     unsigned long long pb = 0;
@@ -515,7 +496,7 @@ __global__ __launch_bounds__(64, 4) void k_tumor_stream(VarView V, ReadView R, T
                     }
                 }
             }
-            if (PASS == 0) {
+            {
                 const unsigned long long m1 = __ballot(to1), m2 = __ballot(to2), m3 = __ballot(to3), mp = __ballot(count_ps), ms = __ballot(pairf);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -538,7 +519,7 @@ __global__ __launch_bounds__(64, 4) void k_tumor_stream(VarView V, ReadView R, T
         wave_sync();                                                      // the table and the headers are reused by the next group
     }
     if (bad_cigar && l == 0) atomicOr(&cnt->err, (unsigned)LPS_ERR_BAD_CIGAR);
-    if (PASS == 0 && l < nq) {
+    if (l < nq) {
         const int r = r0 + l;
         const int h1 = SEL4(l, vh1), h2 = SEL4(l, vh2), h3 = SEL4(l, vh3), lo = SEL4(l, plo), hi = SEL4(l, phi);
         const bool any = lo <= hi;
@@ -548,6 +529,28 @@ __global__ __launch_bounds__(64, 4) void k_tumor_stream(VarView V, ReadView R, T
         T.end_pos[r] = h_walked ? e_end : (h_status == 0 ? h_start : 0);
         T.read_len[r] = h_walked ? e_len : 0;
         T.has_site[r] = SEL4(l, nsite) > 0;
+    }
+}
+
+// the second loop of the reference over the alignments (SomaticVarCaller.cpp:440-518), from the pair list of the stream walk: one thread per listed
+// (tumor row, alignment) - ReadHpCount of the row by the read's final haplotype, and for an H3 base the read's case (classifyReadsByCase :462-518,
+// somaticReadHpCount :386-404)
+__global__ __launch_bounds__(256) void k_tumor_pair_sites(TumOut T) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x, n_slots = (long long)LPS_TARENAS * T.pair_arena;
+    if (t >= n_slots) return;
+    const long long arena = t / T.pair_arena, idx = t - arena * T.pair_arena;
+    if ((unsigned long long)idx >= T.pair_ctr[arena * 16]) return;
+    const int v = T.apair_site[t], r = T.apair_read[t], base_hp = T.apair_hp[t];
+    const int r_hp = T.hp[r], r_h1 = T.hp1[r], r_h2 = T.hp2[r]; const bool r_record = T.n_ps[r] <= 1, r_clean = (r_h1 == 0 || r_h2 == 0) && T.hp3[r] != 0;
+    int32_t *sc = T.site + (size_t)v * LPS_TSITE_COUNTERS;
+    atomicAdd(&sc[15 + r_hp], 1);                                         // base.ReadHpCount[hpResult] (:457)
+    if (base_hp == 3) {
+        if (!r_record) atomicAdd(&sc[24], 1);
+        else if (r_clean) {
+            atomicAdd(&sc[25], 1);
+            if (r_h1 == 0 && r_h2 == 0) atomicAdd(&sc[28], 1); else if (r_h1 != 0 && r_h2 == 0) atomicAdd(&sc[26], 1); else if (r_h1 == 0 && r_h2 != 0) atomicAdd(&sc[27], 1);
+        } else atomicAdd(&sc[29], 1);
+        atomicAdd(&sc[30 + r_hp], 1);
     }
 }
 
@@ -629,9 +632,8 @@ void launch_tumor_extract(const VarView &V, const ReadView &R, const TumOut &T, 
                           LpsCounters *cnt, hipStream_t s, bool general) {
     if (R.n == 0) return;
     if (!general) {
-        const dim3 g((R.n + 3) / 4), b(64);
-        if (pass == 0) hipLaunchKernelGGL(k_tumor_stream<0>, g, b, 0, s, V, R, T, mapping_quality, tag_supplementary, cnt);
-        else hipLaunchKernelGGL(k_tumor_stream<1>, g, b, 0, s, V, R, T, mapping_quality, tag_supplementary, cnt);
+        if (pass == 0) hipLaunchKernelGGL(k_tumor_stream, dim3((R.n + 3) / 4), dim3(64), 0, s, V, R, T, mapping_quality, tag_supplementary, cnt);
+        else hipLaunchKernelGGL(k_tumor_pair_sites, dim3((unsigned)(((long long)LPS_TARENAS * T.pair_arena + 255) / 256)), dim3(256), 0, s, T);   // (the walk listed the pairs: no second one)
         return;
     }
     const dim3 g(R.n), b(64);
