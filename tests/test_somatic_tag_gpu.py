@@ -70,3 +70,35 @@ def test_tumor_extraction_matches_oracle_and_reference_logs(name):
     same = dense_alt_same_count(V, out)
     didx = np.searchsorted(V.pos, V.dense_pos)
     assert np.array_equal(same[didx], V.dense_cnt), "DenseAlt sameCount vs reference log"
+
+
+def test_an_operation_of_2_pow_24_bases_sends_every_somatic_pass_to_the_general_walker():
+    """The three passes run on the stream walker (k_haplotag_stream<1>, <2,3>, k_tumor_stream); one CIGAR operation of 2^24 bases and more is outside
+    its 24-bit sums: the chromosome is then taken again by the per-op-prefix walkers (k_haplotag_score<MODE>, k_tumor_extract<PASS>), same results."""
+    from test_cigar_shapes_gpu import with_cigars, op, M, N
+    name = sorted(fixtures.SOMATIC_FIXTURES)[0]
+    genome, nkw, tkw, cli, over = fixtures.SOMATIC_FIXTURES[name]
+    V, _, _, _ = util.load_golden_somatic(name)
+    P = abi.default_params(**over)
+    T, RT0 = util.make_tumor_reads(name)
+    Nn, RN0 = util.make_normal_reads(name)
+
+    def crafted(R):
+        lq = np.asarray(R.l_qseq)
+        r = int(np.nonzero(lq > 400)[0][R.n_reads // 3 % max(1, int((lq > 400).sum()))])
+        return with_cigars(R, {r: [op(M, 150), op(N, (1 << 24) + 3), op(M, int(lq[r]) - 150)]})
+    RT, RN = crafted(RT0), crafted(RN0)
+    with hip.Context(0, P) as ctx:
+        o1 = ctx.somatic_extract_normal(V, Nn.ref, RN)
+        o2 = ctx.somatic_extract_tumor(V, T.ref, RT)
+        o3 = ctx.somatic_tag(V, T.ref, RT)
+    w1 = lps_oracle.somatic_extract_normal(P, V, Nn.ref, RN)
+    assert np.array_equal(o1.read_hp, w1.read_hp) and np.array_equal(o1.counters, w1.counters)
+    w2 = lps_oracle.somatic_extract_tumor(P, V, T.ref, RT)
+    for k in ("status", "hp1", "hp2", "hp3", "hp", "ps_min", "end_pos", "read_len", "has_site"):
+        assert np.array_equal(getattr(o2, k), getattr(w2, k)), k
+    assert np.array_equal(o2.site, w2.site) and o2.c.n_pairs == w2.c.n_pairs and o2.c.n_windows == w2.c.n_windows
+    assert all(np.array_equal(a, b) for a, b in zip(o2.pairs(), w2.pairs())) and all(np.array_equal(a, b) for a, b in zip(o2.windows(), w2.windows()))
+    w3 = lps_oracle.somatic_tag(P, V, RT)
+    for k in ("status", "hp1", "hp2", "hp3", "derive_h1", "derive_h2", "ps_min", "hp", "pq", "ps"):
+        assert np.array_equal(getattr(o3, k), getattr(w3, k)), k
