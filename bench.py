@@ -11,7 +11,7 @@ library (lps_push_reads_device), and then
 everything from allele extraction to phased genotypes recomputed from the decoded reads as the push left them in HBM, results back in host
 memory.  K steps are run as K consecutive calls per contig while that contig is resident (inputs in HBM when its timed region starts); `value` =
 phased SNPs of all contigs x K / sum of the per-contig timed regions.  ONE-PASS CLOCK: the library keeps nothing between a push and a call or
-from one call to the next (ABI 20: no lps_prepare_reads, no re-laid copy of bases, qualities or CIGAR words; `prepare_ms` on the line is 0 by
+from one call to the next (since ABI 20: no lps_prepare_reads, no re-laid copy of bases, qualities or CIGAR words; `prepare_ms` on the line is 0 by
 construction), so every timed call does what the first call on a freshly loaded chromosome does - the reference phases each chromosome once
 (src/phase/PhasingProcess.cpp:113-173).  What a first call additionally pays is the growth of the context's device buffers (hipMalloc); the
 line carries it as `first_call_pass_ms` (the un-warmed first call of every contig, contexts side by side like the timed ones).
@@ -616,7 +616,7 @@ def main():
     elapsed = 0.0; hap_elapsed = 0.0; total_phased = 0; total_reads = 0; total_tagged = 0; total_bases = 0
     largest = None; cpu_pick = None; p_clock = None; port = None
     cpu_name = a.cpu_contig or min(contigs, key=lambda c: c["contig_len"])["name"]
-    gen_s = 0.0; push_s = 0.0; d2h_s = 0.0; first_call_s = 0.0; somatic_bad = False
+    gen_s = 0.0; push_s = 0.0; d2h_s = 0.0; first_call_s = 0.0; first_alloc_ms = 0.0; somatic_bad = False
 
     def barrier():
         if dist is not None:
@@ -678,6 +678,7 @@ def main():
         # the FIRST call on the freshly pushed contigs (un-warmed: device buffers may still grow), timed on its own; then the remaining warm-up calls
         if a.warmup >= 1:
             first_call_s += concurrent([(lambda s=s: s["ctx"].run_phase(s["out"])) for s in slots])
+            first_alloc_ms += max(float(s["ctx"].L.lps_alloc_ms(s["ctx"].h)) for s in slots)     # (the contexts run side by side: the longest of the group)
         for _ in range(max(0, a.warmup - 1)):
             concurrent([(lambda s=s: s["ctx"].run_phase(s["out"])) for s in slots])
         # ---- timed region of the group: K steps per contig, the contexts running side by side
@@ -823,9 +824,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if a.workload == "wgs_50x" else "weak", "vs_baseline": None, "dtype": "i32/f32", "data": "synthetic",
             # ---- scalars first (a reader that truncates the line still sees them); the long per-contig arrays come last
-            "clock": "one-pass: every timed call starts from the decoded reads as the push left them; nothing prepared or cached (ABI 20)",
+            "clock": "one-pass: every timed call starts from the decoded reads as the push left them; nothing prepared or cached (since ABI 20)",
             "prepare_ms": 0.0,
             "first_call_pass_ms": round(first_call_s * 1e3, 3) if a.warmup >= 1 else None,
+            "first_call_alloc_ms": round(first_alloc_ms, 3) if a.warmup >= 1 else None,     # of which: host time in hipMalloc / hipFree (the stage buffers are sized in the first call; varies 5 - 450 ms with the host)
             "parity_checked": bool(parity and parity["checked"]),
             "whole_step_gbs": round(sum(sum(r["alg"].values()) for r in per_contig) * a.steps / my_elapsed / 1e9, 1),
             "secondary_value": total_reads * a.steps / hap_elapsed, "secondary_unit": "reads haplotagged/s", "secondary_ms_per_step": hap_elapsed / a.steps * 1e3,

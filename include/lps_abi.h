@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LPS_ABI_VERSION 20
+#define LPS_ABI_VERSION 21
 #define LPS_MAX_ADJACENT 63 /* upper bound for lps_params.connect_adjacent (reference default 35) */
 
 typedef struct lps_ctx lps_ctx;
@@ -363,6 +363,9 @@ int lps_set_stage_timing(lps_ctx *ctx, int level);
 int lps_phase_chromosome(lps_ctx *ctx, lps_phase_result *out);
 /* haplotag: per-read scoring of the reads pushed so far against the phased table. */
 int lps_haplotag_chromosome(lps_ctx *ctx, lps_haplotag_result *out);
+/* host milliseconds the last lps_phase_chromosome / lps_haplotag_chromosome call spent growing device buffers (hipMalloc / hipFree): the FIRST call
+ * on a chromosome sizes the stage buffers, later calls find them in place - and on some hosts an allocation of a few GB takes hundreds of ms. */
+double lps_alloc_ms(lps_ctx *ctx);
 /* k consecutive calls of the two entries above behind one call (every call does the full work; ms_each, k doubles or NULL, receives each call's wall
  * time): for callers whose own loop would put an interpreter between the calls (bench.py's timed region) */
 int lps_phase_chromosome_steps(lps_ctx *ctx, lps_phase_result *out, int k, double *ms_each);

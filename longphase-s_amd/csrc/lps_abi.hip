@@ -74,6 +74,7 @@ struct lps_ctx {
     // CIGAR words: ONE resident copy, in lane-chunks of 8 words (lps_reads.hip), written in that layout by every kind of push.  n_cig counts the real
     // words (algorithmic bytes), n_chunks the chunks in place; cp_off[r] = first chunk of alignment r (nR + 1 entries), cp_n[r] = its words
     DevBuf<uint32_t> cigar, cp_off, cp_cnt, cp_rel, cig_tmp; DevBuf<int32_t> cp_n; DevBuf<uint64_t> coff_tmp, chunk_off; DevBuf<unsigned long long> cig_words; uint64_t n_chunks = 0;
+    double alloc_ms = 0.0;                       // lps_alloc_ms
     DevBuf<int32_t> r_v0; int32_t last_start = 0;   /* start of the last alignment pushed (order across pushes) */
     // raw BAM records (lps_push_bam_records): seq/qual are read in place from the blob
     DevBuf<uint8_t> blob; uint64_t n_blob = 0; int read_mode = 0;   // 0 none yet, 1 SoA batches, 2 BAM records
@@ -1268,8 +1269,12 @@ int lps_set_stage_timing(lps_ctx *c, int level) {
     return 0;
 }
 
+// what the call spent growing device buffers (host time; the first call on a chromosome sizes them, later calls find them in place)
+struct AllocScope { lps_ctx *c; double a0; explicit AllocScope(lps_ctx *x) : c(x), a0(g_lps_alloc_ms) {} ~AllocScope() { c->alloc_ms = g_lps_alloc_ms - a0; } };
+double lps_alloc_ms(lps_ctx *c) { return c ? c->alloc_ms : -1.0; }
 int lps_phase_chromosome(lps_ctx *c, lps_phase_result *out) {
     if (!c || !out) return -1;
+    AllocScope alloc_scope(c);
     try {
         HIP_TRY(hipSetDevice(c->device));
         if (out->n != c->nV) return fail(c, "lps_phase_result.n must equal the variant table size");
@@ -1419,6 +1424,7 @@ int lps_haplotag_chromosome_steps(lps_ctx *c, lps_haplotag_result *out, int k, d
 }
 int lps_haplotag_chromosome(lps_ctx *c, lps_haplotag_result *out) {
     if (!c || !out) return -1;
+    AllocScope alloc_scope(c);
     try {
         HIP_TRY(hipSetDevice(c->device));
         const int nR = c->nR, nV = c->nV;

@@ -1,5 +1,6 @@
 // lps_common.h — shared device/host helpers of liblps_hip.so (gfx950 only, wave64).
 #pragma once
+#include <chrono>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -22,6 +23,9 @@
 
 // ---------------------------------------------------------------- device memory
 // Growable device buffer.  grow() keeps contents only when keep=true (append buffers).
+// host time the calling thread spent growing device buffers (hipMalloc / hipFree and the synchronisation before a free): an entry point of the
+// library zeroes it when it starts and reports it with its timings - on some hosts an allocation of a few GB takes hundreds of milliseconds
+inline thread_local double g_lps_alloc_ms = 0.0;
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -38,9 +42,11 @@ struct DevBuf {
         size_t nc = cap ? cap : 256;
         while (nc < n) nc = nc + nc / 2 + 256;
         T *q = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         HIP_TRY(hipMalloc((void **)&q, nc * sizeof(T) + 64));      // 64 B of slack: kernels read whole 16-B vectors at the tail (CIGAR words)
         if (keep && p && used) HIP_TRY(hipMemcpyAsync(q, p, used * sizeof(T), hipMemcpyDeviceToDevice, s));
         if (p) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(p)); }
+        g_lps_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         p = q; cap = nc;
     }
 };

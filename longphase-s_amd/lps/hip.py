@@ -68,6 +68,7 @@ def load():
     L.lps_somatic_write_bgzf.argtypes = L.lps_haplotag_write_bgzf.argtypes
     L.lps_bgzf_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.lps_bgzf_retried.argtypes = [C.c_void_p]
+    L.lps_alloc_ms.argtypes = [C.c_void_p]; L.lps_alloc_ms.restype = C.c_double
     L.lps_bam_scan.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
     L.lps_bam_scan_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
     L.lps_bam_record_tids.argtypes = [C.c_void_p, C.c_void_p]
