@@ -1192,10 +1192,11 @@ static int run_phase(lps_ctx *c) {
         c->key64 = c->m_bits + c->a_bits > 31;
         if (c->m_bits + c->a_bits > 63) { c->err = "sort key overflow"; return -4; }
         c->late_n_keys = c->h_cnt.obs_total;
-        c->nkeys.reserve(c->late_n_keys / (c->key64 ? 1 : 2) + 2); c->nkeys_s.reserve(c->late_n_keys / (c->key64 ? 1 : 2) + 2); c->nvals.reserve(c->late_n_keys + 1); c->nvals_s.reserve(c->late_n_keys + 1);
+        // (32-bit keys: the unsorted lists are {key, slot} entries of 8 bytes, nvals is not used; the lists k_edges sorts keep keys and slots apart)
+        c->nkeys.reserve(c->late_n_keys + 2); c->nkeys_s.reserve(c->late_n_keys / (c->key64 ? 1 : 2) + 2); c->nvals.reserve(c->key64 ? c->late_n_keys + 1 : 1); c->nvals_s.reserve(c->late_n_keys + 1);
         G.ukeys = c->nkeys.p; G.skeys = c->nkeys_s.p; G.uvals = c->nvals.p; G.svals = c->nvals_s.p;
         // places in the lists that no row will ever fill (observations of a job that went to the general walker after they were counted: malformed records)
-        if (c->h_cnt.n_abandoned) HIP_TRY(hipMemsetAsync(c->nkeys.p, 0xff, (size_t)c->late_n_keys * (c->key64 ? 8 : 4), s));
+        if (c->h_cnt.n_abandoned) HIP_TRY(hipMemsetAsync(c->nkeys.p, 0xff, (size_t)c->late_n_keys * 8, s));
         // ---- a7 clips -> CNV intervals: the keys are sorted here and travel to the host (pinned), which replays the state machine (replay_cnv) -
         //      unless no (position, front / back) key occurs five times (clip_mult, k_name_link's count-min bound): then no interval can be emitted
         //      (replay_cnv's own first test) and the sort (nine launches), the copy and the replay are skipped

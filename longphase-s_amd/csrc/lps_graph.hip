@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void k_graph_rows(int n_reads, const RowDesc *
     const int l = lane_id();
     const int r0 = (xcd_unit((int)blockIdx.x, nb_reads) * 4 + (threadIdx.x >> 6)) * 4;
     if (r0 >= n_reads) return;
-    unsigned long long *ukeys64 = (unsigned long long *)ukeys_v; uint32_t *ukeys32 = (uint32_t *)ukeys_v;
+    unsigned long long *ukeys64 = (unsigned long long *)ukeys_v;
     int h_n = 0; uint32_t h_off = 0, h_name = 0; bool h_dead = true, h_single = false;
     if (l < 4 && r0 + l < n_reads) {
         const int r = r0 + l; const RowDesc d = rows[r]; h_n = max(d.cnt, 0); h_off = d.off;
@@ -542,11 +542,12 @@ __global__ __launch_bounds__(256) void k_graph_rows(int n_reads, const RowDesc *
                 }
                 if ((single >> j) & 1u) {
                     const uint32_t nmj = j == 0 ? nm[0] : (j == 1 ? nm[1] : (j == 2 ? nm[2] : nm[3]));
-                    if (KEY64) ukeys64[e] = ((unsigned long long)nmj << a_bits) | (unsigned)a; else ukeys32[e] = (nmj << a_bits) | (unsigned)a;
-                    uvals[e] = slot;
+                    // (32-bit keys: key and slot are ONE 8-byte entry - one scattered store per observation instead of two)
+                    if (KEY64) { ukeys64[e] = ((unsigned long long)nmj << a_bits) | (unsigned)a; uvals[e] = slot; }
+                    else reinterpret_cast<uint2 *>(ukeys_v)[e] = make_uint2((nmj << a_bits) | (unsigned)a, slot);
                 } else g_rank[slot] = rank;
             } else if (n[0] + n[1] + n[2] + n[3] > 0) {                   // a dropped observation: its place in the list stays a hole
-                if (KEY64) ukeys64[e] = ~0ull; else ukeys32[e] = 0xffffffffu;
+                if (KEY64) ukeys64[e] = ~0ull; else reinterpret_cast<uint2 *>(ukeys_v)[e] = make_uint2(0xffffffffu, 0u);
             }
         }
     }
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(256) void k_merge_multi(const LpsCounters *cnt, con
     __shared__ int s_stk[4][192]; __shared__ int32_t s_k[4][STDSORT_LDS]; __shared__ uint8_t s_p[4][STDSORT_LDS]; __shared__ uint16_t s_a[4][STDSORT_LDS], s_b[4][STDSORT_LDS];
     const int l = lane_id();
     const unsigned n_waves = gridDim.x * 4;
-    unsigned long long *ukeys64 = (unsigned long long *)ukeys_v; uint32_t *ukeys32 = (uint32_t *)ukeys_v;
+    unsigned long long *ukeys64 = (unsigned long long *)ukeys_v;
     for (unsigned q = blockIdx.x * 4 + (threadIdx.x >> 6); q < cnt->n_multi; q += n_waves) {
         const uint32_t plan = mg_plan[q];
         if ((plan & 3u) == 0u) continue;                                  // no observation left, or its tail reservation failed (the host grows the buffers and reruns)
@@ -715,8 +716,8 @@ __global__ __launch_bounds__(256) void k_merge_multi(const LpsCounters *cnt, con
         // entry of the node's list for element a of the read's merged row: (read name, a) at the rank of the observation it came from
         auto place = [&](int a, uint32_t slot, int nd, uint32_t src) __attribute__((always_inline)) {
             const uint32_t e = var_off[nodes[nd]] + g_rank[src];
-            if (KEY64) ukeys64[e] = ((unsigned long long)id << a_bits) | (unsigned)a; else ukeys32[e] = (id << a_bits) | (unsigned)a;
-            uvals[e] = slot;
+            if (KEY64) { ukeys64[e] = ((unsigned long long)id << a_bits) | (unsigned)a; uvals[e] = slot; }
+            else reinterpret_cast<uint2 *>(ukeys_v)[e] = make_uint2((id << a_bits) | (unsigned)a, slot);
         };
         if ((plan & 3u) == 1u) {                                          // one alignment left: its row is the merged row
             const uint32_t r = plan >> 2, off = rows[r].off; const int n = g_cnt[r];
@@ -823,6 +824,8 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
                                                double edge_threshold, const int32_t *nodes, const uint32_t *vtype_key, float *edge, uint8_t *erec, uint32_t *node_pairs) {
     typedef typename std::conditional<KEY64, unsigned long long, uint32_t>::type key_t;
     const key_t *ukeys = (const key_t *)ukeys_v; key_t *skeys = (key_t *)skeys_v;
+    const uint2 *uent = (const uint2 *)ukeys_v;                          // !KEY64: the unsorted lists hold {key, slot} entries (k_graph_rows)
+    auto ukey = [&](uint32_t e) __attribute__((always_inline)) -> key_t { if constexpr (KEY64) return ukeys[e]; else return (key_t)uent[e].x; };
     const key_t HOLE = (key_t)~(key_t)0;                                // a dropped observation's place in the list (k_graph_rows)
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2, and a row of packed words is wanted by the ~35 source nodes before it:
     // workgroup b takes node block (b % 8) * (blocks / 8) + b / 8, so that an XCD walks ONE contiguous eighth of the nodes and a row is fetched into
@@ -842,10 +845,10 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
     const bool short_list = cap <= 64;                                  // unsorted entries (ukeys/uvals): up to 64 are ordered in registers below
     if (!short_list) {                                                  // coverage above 64: rank sort through memory (rank = number of smaller keys; keys are unique, holes sort last)
         for (int a = l; a < cap; a += 64) {
-            const key_t k = ukeys[off + a];
+            const key_t k = ukey(off + a);
             int rank = 0;
-            for (int t = 0; t < cap; ++t) rank += ukeys[off + t] < k;  // wave-uniform address: one broadcast load per step
-            if (k != HOLE) { skeys[off + rank] = k; svals[off + rank] = uvals[off + a]; }
+            for (int t = 0; t < cap; ++t) rank += ukey(off + t) < k;   // wave-uniform address: one broadcast load per step
+            if (k != HOLE) { skeys[off + rank] = k; svals[off + rank] = KEY64 ? uvals[off + a] : uent[off + a].y; }
         }
         __threadfence_block(); wave_sync();
     }
@@ -854,11 +857,11 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
         int nb = __builtin_amdgcn_readfirstlane((int)min(64u, end - e0));      // wave-uniform: the loops over it run on the scalar unit
         uint32_t my_val = 0, my_end = 0;
         if (short_list) {
-            key_t key = HOLE; uint32_t v0 = 0, x0 = 0;
-            if (l < nb) key = ukeys[e0 + l];
+            key_t key = HOLE; uint32_t v0 = 0, x0 = 0, vslot = 0;
+            if (l < nb) { if constexpr (KEY64) { key = ukeys[e0 + l]; } else { const uint2 en = uent[e0 + l]; key = (key_t)en.x; vslot = en.y; } }
             if (key != HOLE) {
                 const uint32_t m = (uint32_t)(key >> a_bits) & m_mask;
-                v0 = uvals[e0 + l]; x0 = mrow_off[m] + (uint32_t)mrow_cnt[m];
+                v0 = KEY64 ? uvals[e0 + l] : vslot; x0 = mrow_off[m] + (uint32_t)mrow_cnt[m];
             }
             // rank = number of smaller keys (keys are unique): the read order of the reference (name rank, index in the merged read); holes rank last
             int rank = 0;
