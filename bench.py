@@ -678,7 +678,7 @@ def main():
         # the FIRST call on the freshly pushed contigs (un-warmed: device buffers may still grow), timed on its own; then the remaining warm-up calls
         if a.warmup >= 1:
             first_call_s += concurrent([(lambda s=s: s["ctx"].run_phase(s["out"])) for s in slots])
-            first_alloc_ms += max(float(s["ctx"].L.lps_alloc_ms(s["ctx"].h)) for s in slots)     # (the contexts run side by side: the longest of the group)
+            first_alloc_ms += max((float(s["ctx"].L.lps_alloc_ms(s["ctx"].h)) if hasattr(s["ctx"].L, "lps_alloc_ms") else 0.0) for s in slots)     # (the contexts run side by side: the longest of the group)
         for _ in range(max(0, a.warmup - 1)):
             concurrent([(lambda s=s: s["ctx"].run_phase(s["out"])) for s in slots])
         # ---- timed region of the group: K steps per contig, the contexts running side by side

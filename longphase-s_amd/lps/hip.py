@@ -34,8 +34,9 @@ def load():
         raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950). "
                            "The product path has no CPU fallback.")
     L = C.CDLL(LIB_PATH)
+    older = set(os.environ.get("LPS_AB_OLDER_BUILD", "").split(","))       # A/B runs only (profiles/ab*.sh): entries a build from an earlier commit lacks
     for sym in declared_symbols():
-        if not hasattr(L, sym):
+        if not hasattr(L, sym) and sym not in older:
             raise RuntimeError(f"liblps_hip.so does not export {sym} declared in include/lps_abi.h")
     L.lps_create.restype = C.c_void_p
     L.lps_create.argtypes = [C.c_int, C.POINTER(abi.Params)]
@@ -68,7 +69,8 @@ def load():
     L.lps_somatic_write_bgzf.argtypes = L.lps_haplotag_write_bgzf.argtypes
     L.lps_bgzf_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.lps_bgzf_retried.argtypes = [C.c_void_p]
-    L.lps_alloc_ms.argtypes = [C.c_void_p]; L.lps_alloc_ms.restype = C.c_double
+    if hasattr(L, "lps_alloc_ms"):                                   # (A/B runs load builds from before ABI 21 out of csrc/ab/)
+        L.lps_alloc_ms.argtypes = [C.c_void_p]; L.lps_alloc_ms.restype = C.c_double
     L.lps_bam_scan.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
     L.lps_bam_scan_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]
     L.lps_bam_record_tids.argtypes = [C.c_void_p, C.c_void_p]
