@@ -121,7 +121,7 @@ struct lps_ctx {
     DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
     DevBuf<uint8_t> hap_status, hap_nps, v_role, v_derive, v_tkind, read_hp; DevBuf<int32_t> site, t_end, t_len, t_pair_site, t_pair_read,
             t_win_site; DevBuf<uint8_t> t_hp, t_has, t_pair_hp, t_win_allele,
-            t_win_base; DevBuf<int16_t> t_win_off; DevBuf<unsigned long long> t_ctr; DevBuf<int4> t_hits; DevBuf<int> t_hit_rp; DevBuf<uint32_t> t_win_cnt, t_win_at, t_win_codes; DevBuf<unsigned long long> t_win_memo; DevBuf<int32_t> t_apair_site, t_apair_read; DevBuf<uint8_t> t_apair_hp; size_t t_hit_arena = 0, t_pair_arena = 0; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1,
+            t_win_base; DevBuf<int16_t> t_win_off; DevBuf<unsigned long long> t_ctr; DevBuf<int4> t_hits; DevBuf<int> t_hit_rp; DevBuf<uint32_t> t_win_cnt, t_win_at, t_win_codes; DevBuf<unsigned long long> t_win_memo; DevBuf<int32_t> t_apair_site, t_apair_read; DevBuf<uint8_t> t_apair_hp; size_t t_hit_arena = 0, t_pair_arena = 0, n_pair_arena = 0; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1,
             hap_d2; bool has_somatic = false;
     DevBuf<char> temp; size_t temp_bytes = 0;
     LpsCounters *d_cnt = nullptr; LpsCounters h_cnt{}; unsigned h_stats[4]{};
@@ -1577,17 +1577,32 @@ int lps_somatic_extract_normal(lps_ctx *c, lps_site_counters *out) {
         HIP_TRY(hipEventRecord(c->ev_begin, s));
         VarView V = var_view(c); ReadView R = read_view(c);
         for (auto &u : c->ev_used) u = false;
-        for (int attempt = 0; attempt < 2; ++attempt) {                   // the stream walk; the per-op-prefix walker when it met a record outside its arithmetic
+        // The stream walk (votes, base counters, the read's haplotype) lists the (tumor row, alignment) pairs it touches in LPS_TARENAS arenas; the rows'
+        // ReadHpCount comes from that list (no second walk).  An arena that turns out too short: again with room for the fullest one.  A record outside
+        // the stream walk's arithmetic (LPS_ERR_KEY_RANGE): both passes on the per-op-prefix walker, which takes any BAM record.
+        { const size_t want = (2 * (size_t)nR + 4096 + LPS_TARENAS - 1) / LPS_TARENAS; if (c->n_pair_arena < want) c->n_pair_arena = want; }
+        bool general = false;
+        for (int attempt = 0; attempt < 4; ++attempt) {
+            const size_t pa = c->n_pair_arena, ipc = pa * LPS_TARENAS;
+            c->t_apair_site.reserve(ipc + 1); c->t_apair_read.reserve(ipc + 1); c->t_ctr.reserve(2 * LPS_TARENAS * 16 + 8);
             HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
             HIP_TRY(hipMemsetAsync(c->site.p, 0, (size_t)nV * LPS_SITE_COUNTERS * sizeof(int32_t), s));
+            HIP_TRY(hipMemsetAsync(c->t_ctr.p, 0, (size_t)LPS_TARENAS * 16 * sizeof(unsigned long long), s));
             if (attempt == 0) { mark(c, ST_PREP); launch_variant_prep(V, 0, c->v_bucket.p, c->v_rec.p, s, R.ref_start, R.n, c->r_v0.p); mark(c, ST_EXTRACT); }
             HapOut H{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c->site.p, c->read_hp.p, c->P.percentage_threshold};
-            launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 2, c->d_cnt, s, /*general=*/attempt == 1);   // votes + base counters + read haplotype
-            launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 3, c->d_cnt, s, /*general=*/attempt == 1);   // ReadHpCount of the touched sites
+            if (!general) { H.pair_ctr = c->t_ctr.p; H.pair_arena = (long long)pa; H.apair_site = c->t_apair_site.p; H.apair_read = c->t_apair_read.p; }
+            launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 2, c->d_cnt, s, general);   // votes + base counters + read haplotype (+ the pair list)
+            if (!general) launch_normal_pair_sites(H, s);                                                      // ReadHpCount of the touched sites
+            else launch_haplotag(V, R, H, c->P.mapping_quality, c->P.tag_supplementary, 3, c->d_cnt, s, true);
             if (attempt == 0) mark(c, ST_D2H);
+            std::vector<unsigned long long> ctr((size_t)LPS_TARENAS * 16, 0ull);
             HIP_TRY(hipMemcpyAsync(&c->h_cnt, c->d_cnt, sizeof(LpsCounters), hipMemcpyDeviceToHost, s));
+            if (!general) HIP_TRY(hipMemcpyAsync(ctr.data(), c->t_ctr.p, ctr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            if (!(c->h_cnt.err & LPS_ERR_KEY_RANGE)) break;
+            if (!general && (c->h_cnt.err & LPS_ERR_KEY_RANGE)) { general = true; continue; }
+            unsigned long long fullest = 0; for (int a = 0; a < LPS_TARENAS; ++a) fullest = std::max(fullest, ctr[(size_t)a * 16]);
+            if (!general && fullest > pa) { if (attempt == 3) return fail(c, "somatic extraction: a list arena kept overflowing"); c->n_pair_arena = (size_t)fullest + (size_t)fullest / 8 + 1024; continue; }
+            break;
         }
         HIP_TRY(hipMemcpyAsync(out->counters, c->site.p, (size_t)nV * LPS_SITE_COUNTERS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         if (out->read_hp) HIP_TRY(hipMemcpyAsync(out->read_hp, c->read_hp.p, (size_t)nR, hipMemcpyDeviceToHost, s));

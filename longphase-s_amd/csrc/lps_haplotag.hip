@@ -404,6 +404,7 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
             const bool in = i < T;
             int vote = -1, ps_v = 0; bool count_ps = false, hp1alt = false; int h3v = 0;      // h3v (SOM): 1 H3 base, 2 / 3 deriving from haplotype 1 / 2 as well
             int del_key = -1, del_qs = 0; unsigned del_at = 0u;             // MODE 2: (alignment, D op) of a NORMAL row waiting for the op's one vote
+            bool pairf = false; int pair_v = 0, pair_r = 0;                 // MODE 2: a tumor row this alignment touches (its ReadHpCount is added from the pair list)
             const uint2 vr = pvr;
             pvr = V.rec[min(SELC(i + 64, cum, vadj) + i + 64, V.n - 1)];
             if (in) {
@@ -457,6 +458,7 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
                             if (kind == 0) is_alt = base_c == alt_c;
                             else if ((kind == 1 || kind == 2) && has_next) is_alt = (rs + len - 1 == ps) && (int)(wn & 15u) == ((kind == 1) ? 1 : 2);
                             if (tk >= 1 && tk <= 3) {                                 // countBaseNucleotide (HaplotagParsingBam.cpp:682-719)
+                                if (MODE == 2) { pairf = true; pair_v = v; pair_r = r0 + q; }
                                 if (MODE == 3) atomicAdd(&sc[LPS_SC_READHP_UNTAG + SEL4(q, myhp)], 1);
                                 else {
                                     const int bi = base_c == 'A' ? LPS_SC_A : base_c == 'C' ? LPS_SC_C : base_c == 'G' ? LPS_SC_G : base_c == 'T' ? LPS_SC_T : LPS_SC_UNKNOWN;
@@ -472,6 +474,7 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
                             }
                         } else if (op == 2) {
                             if (tk != 0) {                                            // processDeletionOperation (:265-282)
+                                if (MODE == 2) { pairf = true; pair_v = v; pair_r = r0 + q; }
                                 if (MODE == 3) atomicAdd(&sc[LPS_SC_READHP_UNTAG + SEL4(q, myhp)], 1);
                                 else if (tk == 1) { atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_DEPTH], 1); }
                                 else if (tk == 3) { atomicAdd(&sc[LPS_SC_ALT], 1); atomicAdd(&sc[LPS_SC_DEL], 1); atomicAdd(&sc[LPS_SC_DEPTH], 1); }
@@ -524,6 +527,19 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
             }
             // ---- per alignment: votes by ballot; the phase-set range by two masked reductions, taken only when the alignment's variants do not all
             //      carry ONE phase set (they nearly always do: blocks are long)
+            if (MODE == 2 && H.pair_ctr) {                                // the touched tumor rows of this round: one reservation in the job's arena
+                const unsigned long long pm = __ballot(pairf);
+                if (pm) {
+                    const int arena = (int)(blockIdx.x % LPS_TARENAS);
+                    unsigned long long pb = 0;
+                    if (l == 0) pb = atomicAdd(&H.pair_ctr[arena * 16], (unsigned long long)__popcll(pm));
+                    pb = __shfl(pb, 0);
+                    if (pairf) {
+                        const long long idx = (long long)pb + __popcll(pm & lanemask_lt());
+                        if (idx < H.pair_arena) { const long long slot = (long long)arena * H.pair_arena + idx; H.apair_site[slot] = pair_v; H.apair_read[slot] = pair_r; }
+                    }
+                }
+            }
             if (MODE == 2) {
                 // once per D op: the FIRST normal row inside the deletion (the lowest lane: candidates are in position order) casts the judgeDeletionHap
                 // vote (:285-291), unless the op's vote was cast in an earlier round of this alignment
@@ -611,6 +627,18 @@ __global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R
     }
 }
 
+// ReadHpCount of the tumor rows the normal sample's alignments touch (ExtractNorDataCigarParser's second pass, SomaticVarCaller.cpp:227-293): from the pair
+// list of k_haplotag_stream<2>, one thread per pair, with the read haplotype that walk decided
+__global__ __launch_bounds__(256) void k_normal_pair_sites(HapOut H) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x, n_slots = (long long)LPS_TARENAS * H.pair_arena;
+    if (t >= n_slots) return;
+    const long long arena = t / H.pair_arena, idx = t - arena * H.pair_arena;
+    if ((unsigned long long)idx >= H.pair_ctr[arena * 16]) return;
+    atomicAdd(&H.site[(size_t)H.apair_site[t] * LPS_SITE_COUNTERS + LPS_SC_READHP_UNTAG + (int)H.read_hp[H.apair_read[t]]], 1);
+}
+void launch_normal_pair_sites(const HapOut &H, hipStream_t s) {
+    hipLaunchKernelGGL(k_normal_pair_sites, dim3((unsigned)(((long long)LPS_TARENAS * H.pair_arena + 255) / 256)), dim3(256), 0, s, H);
+}
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
                      int mode, LpsCounters *cnt, hipStream_t s, bool general) {
     if (R.n == 0) return;

@@ -259,7 +259,11 @@ struct HapOut { uint8_t *status; int32_t *hp1, *hp2; uint8_t *n_ps; int32_t *ps_
                 int32_t *site; uint8_t *read_hp; double pct_thr;     // site counters [nV][LPS_SITE_COUNTERS], per-read hp of the pass
                 // germline haplotag (mode 0): ONE 16-byte record per read instead of five arrays, the read-level decision taken on the GPU:
                 //   word 0 = status | n_ps << 8 | HP << 16 | PQ << 24 (PQ 255: votes of 64 or more, the host computes it), hp1, hp2 (votes included), ps_min
-                uint4 *rec; const int *pq_tab /* [64][64]: PQ of (min, max) votes, built by the host's libm */; const int32_t *votes1, *votes2; };
+                uint4 *rec; const int *pq_tab /* [64][64]: PQ of (min, max) votes, built by the host's libm */; const int32_t *votes1, *votes2;
+                // normal-BAM extraction on the stream walker (mode 2): the (tumor row, alignment) pairs it touches, appended in LPS_TARENAS arenas like
+                // TumOut's lists - the rows' ReadHpCount needs the read's FINAL haplotype and is added from this list (launch_normal_pair_sites), no second walk
+                unsigned long long *pair_ctr; long long pair_arena; int32_t *apair_site, *apair_read; };
+void launch_normal_pair_sites(const HapOut &H, hipStream_t s);
 void launch_haplotag(const VarView &V, const ReadView &R, const HapOut &H, int mapping_quality, int tag_supplementary,
                      int mode, LpsCounters *cnt, hipStream_t s, bool general = false);   // general: the per-op-prefix walker also for the germline pass (what the stream walk cannot take);   // mode 0 haplotag, 1 somatic tag, 2 normal extraction, 3 its read-HP pass
 
