@@ -783,9 +783,11 @@ static int bgzf_load_source(lps_ctx *c, const ZSource &src, int64_t n_bytes, int
         HIP_TRY(hipMemcpyAsync(c->zblk.p, blks.data(), blks.size() * sizeof(InflateBlock), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(c->bam_err.p, 0, sizeof(unsigned), s));
         if (!serial) {
-            // The kernel is launched when the bytes of its FIRST round of wavefronts are in place (65 536 members are resident at a time: about 2 GB,
-            // 50 ms of upload).  Launched earlier - the table may have been walked long before - every resident wavefront sits waiting, and the
-            // upload beside them ran at half its rate (measured: 0.37 - 0.40 s instead of 0.20 s for 8.26 GB, on some boxes three times that).
+            // The kernel is launched when the bytes of its first 16 384 members are in place (a quarter of the 65 536 that are resident at a time: about
+            // 0.5 GB, 20 ms of upload).  Launched at once - the table may have been walked long before - every resident wavefront sits waiting, and the
+            // upload beside them ran at half its rate (measured: 0.37 - 0.40 s instead of 0.20 s for 8.26 GB, on some boxes three times that); launched
+            // after a whole round of 65 536 the kernel, which bounds the load at 35 GB/s, starts 60 ms later for nothing (12.4 GB: 0.70 against 0.66 s;
+            // 4 096: 0.70 s, the upload slows down again).
             const char *fr_env = getenv("LPS_BGZF_TEST_FIRST_ROUND");                      // test hook: members the launch waits for
             const size_t fr = fr_env ? (size_t)std::max(1, atoi(fr_env)) : 16384;
             const unsigned long long first_round = blks.size() > fr ? blks[fr].in_off : n;
