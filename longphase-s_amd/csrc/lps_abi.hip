@@ -121,7 +121,7 @@ struct lps_ctx {
     DevBuf<int32_t> out_ps; DevBuf<uint8_t> out_gt;
     DevBuf<uint8_t> hap_status, hap_nps, v_role, v_derive, v_tkind, read_hp; DevBuf<int32_t> site, t_end, t_len, t_pair_site, t_pair_read,
             t_win_site; DevBuf<uint8_t> t_hp, t_has, t_pair_hp, t_win_allele,
-            t_win_base; DevBuf<int16_t> t_win_off; DevBuf<unsigned long long> t_ctr; DevBuf<int4> t_hits; DevBuf<int> t_hit_rp; DevBuf<uint32_t> t_win_cnt, t_win_at, t_win_codes; DevBuf<unsigned long long> t_win_memo; DevBuf<int32_t> t_apair_site, t_apair_read; DevBuf<uint8_t> t_apair_hp; size_t t_hit_arena = 0, t_pair_arena = 0, n_pair_arena = 0; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1,
+            t_win_base; DevBuf<int16_t> t_win_off; DevBuf<unsigned long long> t_ctr; DevBuf<int4> t_hits; DevBuf<int> t_hit_rp;  DevBuf<int32_t> t_apair_site, t_apair_read; DevBuf<uint8_t> t_apair_hp; size_t t_hit_arena = 0, t_pair_arena = 0, n_pair_arena = 0; bool has_tkind = false; DevBuf<int32_t> hap_h1, hap_h2, hap_psmin, hap_h3, hap_d1,
             hap_d2; bool has_somatic = false;
     DevBuf<char> temp; size_t temp_bytes = 0;
     LpsCounters *d_cnt = nullptr; LpsCounters h_cnt{}; unsigned h_stats[4]{};
@@ -1646,15 +1646,14 @@ int lps_somatic_extract_tumor(lps_ctx *c, lps_tumor_extract_result *out) {
         const size_t want = (2 * (size_t)nR + 4096 + LPS_TARENAS - 1) / LPS_TARENAS;
         if (c->t_pair_arena < want) c->t_pair_arena = want;
         if (c->t_hit_arena < want) c->t_hit_arena = want;
-        unsigned long long tot[4] = {0, 0, 0, 0}; uint32_t n_win = 0;
+        unsigned long long tot[4] = {0, 0, 0, 0}, n_win = 0;
         bool general = false;                                             // the passes on the per-op-prefix walker: after the stream walk met a record outside its arithmetic
         for (int attempt = 0; attempt < 3; ++attempt) {
             const size_t pa = c->t_pair_arena, ha = c->t_hit_arena, hc = ha * LPS_TARENAS, ipc = pa * LPS_TARENAS;
             if (2 * hc + 1 > 0xfffffff0ull) return fail(c, "somatic extraction: more than 2^31 window hits");
-            c->t_hits.reserve(hc + 1); c->t_hit_rp.reserve(hc + 1); c->t_win_cnt.reserve(2 * hc + 2); c->t_win_at.reserve(2 * hc + 2); c->t_win_memo.reserve(2 * (2 * hc + 2)); c->t_win_codes.reserve(2 * hc + 2);
+            c->t_hits.reserve(hc + 1); c->t_hit_rp.reserve(hc + 1);
             c->t_apair_site.reserve(ipc + 1); c->t_apair_read.reserve(ipc + 1); c->t_apair_hp.reserve(ipc + 1);
             c->t_ctr.reserve(2 * LPS_TARENAS * 16 + 8);
-            { const size_t need = GraphTemp::need(2 * hc + 2); if (need > c->temp_bytes) { c->temp.reserve(need, s); c->temp_bytes = need; } }
             HIP_TRY(hipEventRecord(c->ev_begin, s));
             HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(LpsCounters), s));
             HIP_TRY(hipMemsetAsync(c->site.p, 0, ((size_t)nV * LPS_TSITE_COUNTERS + 1) * sizeof(int32_t), s));
@@ -1672,15 +1671,15 @@ int lps_somatic_extract_tumor(lps_ctx *c, lps_tumor_extract_result *out) {
             T.pair_cap = (long long)out->pair_capacity; T.win_cap = (long long)out->win_capacity;
             T.pair_site = c->t_pair_site.p; T.pair_read = c->t_pair_read.p; T.pair_hp = c->t_pair_hp.p;
             T.win_site = c->t_win_site.p; T.win_allele = c->t_win_allele.p; T.win_offset = c->t_win_off.p; T.win_base = c->t_win_base.p; T.pct_thr = c->P.percentage_threshold;
-            T.hits = c->t_hits.p; T.hit_rp = c->t_hit_rp.p; T.win_cnt = c->t_win_cnt.p; T.win_at = c->t_win_at.p; T.win_memo = c->t_win_memo.p; T.win_codes = c->t_win_codes.p;
+            T.hits = c->t_hits.p; T.hit_rp = c->t_hit_rp.p; T.win_total = T.tot + 4;
             launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 0, c->d_cnt, s, general);
-            launch_tumor_windows(V, R, T, c->temp.p, c->temp_bytes, s);
+            launch_tumor_windows(V, R, T, s);
             launch_tumor_extract(V, R, T, c->P.mapping_quality, c->P.tag_supplementary, 1, c->d_cnt, s, general);
             launch_tumor_pairs_out(T, s);
             mark(c, ST_D2H);
             unsigned walk_err = 0;
             HIP_TRY(hipMemcpyAsync(tot, T.tot, sizeof tot, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(&n_win, c->t_win_at.p + 2 * hc, sizeof n_win, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(&n_win, T.win_total, sizeof n_win, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(&walk_err, &c->d_cnt->err, sizeof walk_err, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             // one CIGAR operation of 2^24 bases and more, or the alignments of a job spanning more than 2^30 bases: the passes again on the general walker

@@ -283,11 +283,10 @@ struct TumOut {
     int32_t *win_site; uint8_t *win_allele; int16_t *win_offset; uint8_t *win_base;
     double pct_thr;
     int4 *hits; int *hit_rp;                      // the hits of pass 0: {row, alignment, CIGAR word index, offset inside the op | allele << 30} + the query position there
-    uint32_t *win_cnt, *win_at;                   // per (hit, direction): differences, and where they go in the window list
-    unsigned long long *win_memo; uint32_t *win_codes;   // per (hit, direction): which steps differ (two words) and the read's base codes at the first eight (lps_somatic.hip: WinMemo)
+    unsigned long long *win_total;                // entries of the window list so far (k_tumor_windows reserves a wave's stretch with one atomic)
 };
 // the +-100 bp difference windows of the hits pass 0 listed (getWindowsDiffRef, SomaticVarCaller.cpp:654-710): ONE THREAD per (hit, direction)
-void launch_tumor_windows(const VarView &V, const ReadView &R, const TumOut &T, void *temp, size_t temp_bytes, hipStream_t s);
+void launch_tumor_windows(const VarView &V, const ReadView &R, const TumOut &T, hipStream_t s);
 void launch_tumor_pairs_out(const TumOut &T, hipStream_t s);     // after pass 1: totals + the pairs out of their arenas into the caller's list
 #define LPS_TARENAS 64
 void launch_tumor_extract(const VarView &V, const ReadView &R, const TumOut &T, int mapping_quality, int tag_supplementary, int pass,

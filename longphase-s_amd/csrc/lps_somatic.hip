@@ -555,45 +555,45 @@ __global__ __launch_bounds__(256) void k_tumor_pair_sites(TumOut T) {
 }
 
 // thread t = (hit slot t >> 1, direction t & 1: 0 towards the read's start, 1 towards its end); a slot holds a hit when its index inside its arena is
-// below the arena's counter.  WRITE = false: cnt[t] = differences found; WRITE = true: they are stored from slot at[t] on.  The walk itself is the
-// reference's (win_dir above), untouched.
-template <bool WRITE>
+// below the arena's counter.  ONE launch: a thread walks its window once (the reference's walk, win_dir above, untouched) and keeps what it found in
+// registers (the memo); the wave sums its threads' counts, ONE atomic on the list's counter reserves the wave's stretch of the window list, and
+// every thread stores its differences from the memo - a window of more than eight differences (or one that runs past the read's last base) is walked a
+// second time, writing.  The list's order is that of the waves' reservations: it is a multiset (the reference keeps a map per site, the callers count).
 __global__ __launch_bounds__(256) void k_tumor_windows(VarView V, ReadView R, TumOut T) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x, n_slots = (long long)LPS_TARENAS * T.hit_arena;
-    if (t > 2 * n_slots) return;
-    const long long hs = t >> 1, arena = hs / T.hit_arena, idx = hs - arena * T.hit_arena;
+    const long long hs = t >> 1, arena = min(hs, n_slots - 1) / T.hit_arena, idx = hs - arena * T.hit_arena;
     const bool live = hs < n_slots && (unsigned long long)idx < T.hit_ctr[arena * 16];
-    if (!live) { if (!WRITE) T.win_cnt[t] = 0u; return; }
-    if (WRITE && T.win_cnt[t] == 0u) return;
-    const int4 h = T.hits[hs]; const int dir = (t & 1) ? +1 : -1;
-    const int v = h.x, r = h.y, opj = h.z, win_off = h.w & 0x3fffffff, allele = (h.w >> 30) & 1, rp = T.hit_rp[hs];
-    if (WRITE) {                                                          // from the counting walk's memo when it holds the whole window
-        const WinMemo m = reinterpret_cast<const WinMemo *>(T.win_memo)[t];
-        if (!(m.hi >> 63)) {
-            const uint32_t cd = T.win_codes[t]; long long at = (long long)T.win_at[t]; int k = 0;
-            unsigned long long lo = m.lo, hi = m.hi;
-            while (lo | hi) {
-                int i;
-                if (lo) { i = __builtin_ctzll(lo) + 1; lo &= lo - 1; } else { i = __builtin_ctzll(hi) + 65; hi &= hi - 1; }
-                if (at < T.win_cap) { T.win_site[at] = v; T.win_allele[at] = (uint8_t)allele; T.win_offset[at] = (int16_t)(i * dir); T.win_base[at] = (uint8_t)nt16_char((int)((cd >> (4 * k)) & 15u)); }
-                ++at; ++k;
-            }
-            return;
-        }
+    int n = 0, v = 0, r = 0, opj = 0, allele = 0, rp = 0, remaining = 0, dir = 1; WinMemo memo{0, 0}; uint32_t codes = 0;
+    if (live) {
+        const int4 h = T.hits[hs]; dir = (t & 1) ? +1 : -1;
+        v = h.x; r = h.y; opj = h.z; const int win_off = h.w & 0x3fffffff; allele = (h.w >> 30) & 1; rp = T.hit_rp[hs];
+        const uint32_t *cig = R.cig(r);
+        const int len = (int)(cig[opj] >> 4);
+        remaining = dir > 0 ? ((len - win_off > 0) ? len - win_off : 0) : (win_off > 0 ? win_off : 0);
+        n = win_dir<false>(cig, opj, R.cp_n[r], R.seq + R.seq_off[r], R.l_qseq[r], V.ref, (int)V.ref_len_eff, rp, remaining, V.pos[v], dir, T, 0, v, allele, &memo, &codes);
     }
-    const uint32_t *cig = R.cig(r); const int n_cig = R.cp_n[r];
-    const int len = (int)(cig[opj] >> 4);
-    const int remaining = dir > 0 ? ((len - win_off > 0) ? len - win_off : 0) : (win_off > 0 ? win_off : 0);
-    WinMemo memo{0, 0}; uint32_t codes = 0;
-    const int n = win_dir<WRITE>(cig, opj, n_cig, R.seq + R.seq_off[r], R.l_qseq[r], V.ref, (int)V.ref_len_eff, rp, remaining, V.pos[v], dir, T, WRITE ? (long long)T.win_at[t] : 0, v, allele, &memo, &codes);
-    if (!WRITE) { T.win_cnt[t] = (uint32_t)n; if (n) { reinterpret_cast<WinMemo *>(T.win_memo)[t] = memo; T.win_codes[t] = codes; } }
+    const int incl = wave_incl_scan_dpp(n), total = __builtin_amdgcn_readlane(incl, 63);
+    if (total == 0) return;
+    unsigned long long base = 0;
+    if (lane_id() == 0) base = atomicAdd(T.win_total, (unsigned long long)total);
+    base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (n == 0) return;
+    long long at = (long long)base + incl - n;
+    if (!(memo.hi >> 63)) {                                               // from the memo
+        int k = 0; unsigned long long lo = memo.lo, hi = memo.hi;
+        while (lo | hi) {
+            int i;
+            if (lo) { i = __builtin_ctzll(lo) + 1; lo &= lo - 1; } else { i = __builtin_ctzll(hi) + 65; hi &= hi - 1; }
+            if (at < T.win_cap) { T.win_site[at] = v; T.win_allele[at] = (uint8_t)allele; T.win_offset[at] = (int16_t)(i * dir); T.win_base[at] = (uint8_t)nt16_char((int)((codes >> (4 * k)) & 15u)); }
+            ++at; ++k;
+        }
+        return;
+    }
+    (void)win_dir<true>(R.cig(r), opj, R.cp_n[r], R.seq + R.seq_off[r], R.l_qseq[r], V.ref, (int)V.ref_len_eff, rp, remaining, V.pos[v], dir, T, at, v, allele);
 }
-void launch_tumor_windows(const VarView &V, const ReadView &R, const TumOut &T, void *temp, size_t temp_bytes, hipStream_t s) {
-    const size_t n = (size_t)(2 * LPS_TARENAS * T.hit_arena + 1);
-    const dim3 g((unsigned)((n + 255) / 256)), b(256);
-    hipLaunchKernelGGL(k_tumor_windows<false>, g, b, 0, s, V, R, T);
-    exscan_u32(temp, temp_bytes, T.win_cnt, T.win_at, n, s);              // win_at[n - 1] = all differences: the window count
-    hipLaunchKernelGGL(k_tumor_windows<true>, g, b, 0, s, V, R, T);
+void launch_tumor_windows(const VarView &V, const ReadView &R, const TumOut &T, hipStream_t s) {
+    const size_t n = (size_t)(2 * LPS_TARENAS * T.hit_arena);
+    hipLaunchKernelGGL(k_tumor_windows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, V, R, T);
 }
 
 // totals of both lists (one wave), then the pairs out of their arenas into the caller's contiguous list: arena a's entries go behind those of the arenas before it
