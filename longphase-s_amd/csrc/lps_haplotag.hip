@@ -262,6 +262,9 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
 // chunk search, the chunk's words, an 8-step walk to the op that covers the variant, judgeSnpHap / judgeDeletionHap (HaplotagStrategy.cpp:20-209),
 // votes and phase sets reduced per alignment with ballots.  judgeReadHap (:243-300) follows right there and the four 16-byte records of the job
 // leave as ONE 64-byte line.  A third of the vector instructions of k_haplotag_score<0>, which it replaces for the germline pass.
+#ifndef HTG_WAVES
+#define HTG_WAVES 4
+#endif
 #ifndef HTG_TAB
 #define HTG_TAB 1024
 #endif
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(64 * HAP_WPB, 6) void k_haplotag_score(VarView V, R
 // somatic_haplotag (votes gated by MAPQ + per-site base counters + the read's haplotype / ReadHpCount of the touched sites) - the rules of
 // k_haplotag_score<MODE>, which stays the general walker for records this walk's arithmetic cannot take
 template <int MODE>
-__global__ __launch_bounds__(64, 4) void k_haplotag_stream(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary, LpsCounters *cnt) {
+__global__ __launch_bounds__(64, HTG_WAVES) void k_haplotag_stream(VarView V, ReadView R, HapOut H, int mapping_quality, int tag_supplementary, LpsCounters *cnt) {
     constexpr bool SOM = MODE == 1, EXT = MODE == 2 || MODE == 3;
     __shared__ __attribute__((aligned(16))) int2 s_tab[HTG_TAB + 1];
     __shared__ ExtHdr s_hdr[4];
