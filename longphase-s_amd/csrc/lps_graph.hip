@@ -977,11 +977,19 @@ __global__ __launch_bounds__(256) void k_edges(const LpsCounters *cnt, const uin
             while (t < run_end) {
                 const unsigned long long rest = slow_mask >> t;
                 const int stop = min(run_end, rest ? t + (int)__builtin_ctzll(rest) : 64);
-                for (; t < stop; ++t) {
+                // two reads per trip, the request buffers taking turns: no copy of the word just requested into the register of the one just applied
+                for (; t + 1 < stop; t += 2) {
                     uint32_t w1; int m1;
                     request(t + 1, w1, m1);
                     plain_read(w0, m0, x0, x1);
-                    w0 = w1; m0 = m1;
+                    request(t + 2, w0, m0);
+                    plain_read(w1, m1, x0, x1);
+                }
+                if (t < stop) {
+                    uint32_t w1; int m1;
+                    request(t + 1, w1, m1);
+                    plain_read(w0, m0, x0, x1);
+                    w0 = w1; m0 = m1; ++t;
                 }
                 if (t < run_end) {
                     uint32_t w1; int m1;
